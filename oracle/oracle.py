@@ -1,0 +1,378 @@
+"""ctypes/numpy front-end of ``oracle/curobo_oracle.c`` (TEST INFRASTRUCTURE ONLY).
+
+All inputs are numpy arrays; outputs are freshly allocated numpy arrays unless the reference
+contract is stateful (self-collision gradient buffers, L-BFGS history, line-search state), in
+which case the caller's arrays are updated in place exactly like the reference kernels do.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libcurobo_oracle.so")
+_SRC = os.path.join(_HERE, "curobo_oracle.c")
+
+
+def build_oracle(force: bool = False) -> str:
+    """Compile the C oracle with gcc (``make -C oracle``) if missing or stale."""
+    stale = (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _SceneStruct(C.Structure):
+    _fields_ = [
+        ("cub_dims", C.c_void_p),
+        ("cub_inv_pose", C.c_void_p),
+        ("cub_enable", C.c_void_p),
+        ("cub_count", C.c_void_p),
+        ("max_cub", C.c_int),
+        ("vox_params", C.c_void_p),
+        ("vox_inv_pose", C.c_void_p),
+        ("vox_enable", C.c_void_p),
+        ("vox_count", C.c_void_p),
+        ("vox_features", C.c_void_p),
+        ("max_vox", C.c_int),
+        ("vox_n_voxels", C.c_int),
+        ("vox_max_distance", C.c_float),
+    ]
+
+
+class Oracle:
+    """Thin wrapper; one instance per process is enough (``load_oracle()``)."""
+
+    def __init__(self, path: Optional[str] = None):
+        self.lib = C.CDLL(path or build_oracle())
+        self.lib.orc_num_threads.restype = C.c_int
+        for name in (
+            "orc_kinematics_forward",
+            "orc_kinematics_backward",
+            "orc_self_collision",
+            "orc_scene_collision",
+            "orc_bspline_forward",
+            "orc_bspline_backward",
+            "orc_lbfgs_step",
+            "orc_line_search",
+            "orc_trajectory_cost_sum",
+            "orc_set_num_threads",
+        ):
+            getattr(self.lib, name).restype = None
+
+    # ------------------------------------------------------------------ threads
+    def num_threads(self) -> int:
+        return int(self.lib.orc_num_threads())
+
+    def set_num_threads(self, n: int) -> None:
+        self.lib.orc_set_num_threads(C.c_int(n))
+
+    # ------------------------------------------------------------------ FK
+    def kinematics_forward(
+        self,
+        q: np.ndarray,
+        model: Dict[str, np.ndarray],
+        horizon: int = 1,
+        env_query_idx: Optional[np.ndarray] = None,
+        compute_jacobian: bool = False,
+        compute_com: bool = False,
+        compute_spheres: bool = True,
+    ) -> Dict[str, np.ndarray]:
+        q = _f32(q).reshape(-1, q.shape[-1])
+        n, d = q.shape
+        L = model["link_map"].shape[0]
+        T = model["tool_frame_map"].shape[0]
+        spheres = _f32(model["link_spheres"])
+        num_envs = spheres.shape[0]
+        S = spheres.shape[1] if compute_spheres else 0
+        if env_query_idx is None:
+            env_query_idx = np.zeros(max(n // max(horizon, 1), 1), dtype=np.int32)
+        env_query_idx = np.ascontiguousarray(env_query_idx, dtype=np.int32)
+        out = {
+            "link_pos": np.zeros((n, T, 3), np.float32),
+            "link_quat": np.zeros((n, T, 4), np.float32),
+            "robot_spheres": np.zeros((n, max(S, 0), 4), np.float32),
+            "cumul_mat": np.zeros((n, L, 3, 4), np.float32),
+            "com": np.zeros((n, 4), np.float32) if compute_com else None,
+            "jacobian": np.zeros((n, T, 6, d), np.float32) if compute_jacobian else None,
+        }
+        jae = np.ascontiguousarray(model["joint_affects_endeffector"]).astype(np.uint8)
+        self.lib.orc_kinematics_forward(
+            _ptr(out["link_pos"]), _ptr(out["link_quat"]),
+            _ptr(out["robot_spheres"]) if S > 0 else None,
+            _ptr(out["com"]), _ptr(out["jacobian"]), _ptr(out["cumul_mat"]),
+            _ptr(q), _ptr(_f32(model["fixed_transforms"])), _ptr(spheres),
+            _ptr(_f32(model["link_masses_com"])),
+            _ptr(np.ascontiguousarray(model["joint_map_type"], np.int8)),
+            _ptr(np.ascontiguousarray(model["joint_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["tool_frame_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_sphere_idx_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_chain_data"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_chain_offsets"], np.int16)),
+            _ptr(np.ascontiguousarray(model["joint_links_data"], np.int16)),
+            _ptr(np.ascontiguousarray(model["joint_links_offsets"], np.int16)),
+            _ptr(jae), _ptr(_f32(model["joint_offset_map"])), _ptr(env_query_idx),
+            C.c_int(n), C.c_int(horizon), C.c_int(S), C.c_int(num_envs), C.c_int(L), C.c_int(d),
+            C.c_int(T),
+        )
+        return out
+
+    def kinematics_backward(
+        self,
+        model: Dict[str, np.ndarray],
+        cumul_mat: np.ndarray,
+        grad_spheres: Optional[np.ndarray],
+        grad_link_pos: Optional[np.ndarray] = None,
+        grad_link_quat: Optional[np.ndarray] = None,
+        grad_com: Optional[np.ndarray] = None,
+        batch_com: Optional[np.ndarray] = None,
+        horizon: int = 1,
+        env_query_idx: Optional[np.ndarray] = None,
+    ) -> np.ndarray:
+        L = model["link_map"].shape[0]
+        T = model["tool_frame_map"].shape[0]
+        cumul = _f32(cumul_mat).reshape(-1, L, 3, 4)
+        n = cumul.shape[0]
+        d = int(model["num_dof"])
+        spheres = _f32(model["link_spheres"])
+        num_envs, S = spheres.shape[0], spheres.shape[1]
+        if grad_spheres is None:
+            S = 0
+        else:
+            grad_spheres = _f32(grad_spheres).reshape(n, S, 4)
+        gp = _f32(grad_link_pos).reshape(n, T, 3) if grad_link_pos is not None else np.zeros((n, T, 3), np.float32)
+        gq = _f32(grad_link_quat).reshape(n, T, 4) if grad_link_quat is not None else np.zeros((n, T, 4), np.float32)
+        if env_query_idx is None:
+            env_query_idx = np.zeros(max(n // max(horizon, 1), 1), dtype=np.int32)
+        env_query_idx = np.ascontiguousarray(env_query_idx, dtype=np.int32)
+        out = np.zeros((n, d), np.float32)
+        compute_com = grad_com is not None and batch_com is not None
+        self.lib.orc_kinematics_backward(
+            _ptr(out), _ptr(gp), _ptr(gq), _ptr(grad_spheres),
+            _ptr(_f32(grad_com)) if compute_com else None,
+            _ptr(_f32(batch_com)) if compute_com else None,
+            _ptr(cumul), _ptr(spheres), _ptr(_f32(model["link_masses_com"])),
+            _ptr(np.ascontiguousarray(model["joint_map_type"], np.int8)),
+            _ptr(np.ascontiguousarray(model["joint_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["tool_frame_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_sphere_idx_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_chain_data"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_chain_offsets"], np.int16)),
+            _ptr(_f32(model["joint_offset_map"])), _ptr(env_query_idx),
+            C.c_int(n), C.c_int(horizon), C.c_int(S), C.c_int(num_envs), C.c_int(L), C.c_int(d),
+            C.c_int(T), C.c_int(1 if compute_com else 0),
+        )
+        return out
+
+    # ------------------------------------------------------------------ self collision
+    def self_collision(
+        self,
+        robot_spheres: np.ndarray,
+        sphere_padding: np.ndarray,
+        collision_pairs: np.ndarray,
+        weight: float,
+        out_gradient: Optional[np.ndarray] = None,
+        sparse_index: Optional[np.ndarray] = None,
+        store_pair_distance: bool = False,
+        write_grad: bool = True,
+    ) -> Dict[str, np.ndarray]:
+        rs = _f32(robot_spheres)
+        S = rs.shape[-2]
+        rs = rs.reshape(-1, S, 4)
+        n = rs.shape[0]
+        pairs = np.ascontiguousarray(collision_pairs, np.int16).reshape(-1, 2)
+        P = pairs.shape[0]
+        if out_gradient is None:
+            out_gradient = np.zeros((n, S, 4), np.float32)
+        if sparse_index is None:
+            sparse_index = np.zeros((n, S), np.uint8)
+        dist = np.zeros((n,), np.float32)
+        pair_idx = np.zeros((n, 2), np.int16)
+        pair_d = np.zeros((n, P), np.float32) if store_pair_distance else None
+        w = np.array([weight], np.float32)
+        self.lib.orc_self_collision(
+            _ptr(dist), _ptr(out_gradient), _ptr(pair_d), _ptr(sparse_index), _ptr(pair_idx),
+            _ptr(rs), _ptr(_f32(sphere_padding)), _ptr(w), _ptr(pairs),
+            C.c_int(n), C.c_int(S), C.c_int(P), C.c_int(int(store_pair_distance)),
+            C.c_int(int(write_grad)),
+        )
+        return {
+            "distance": dist,
+            "gradient": out_gradient,
+            "sparse_index": sparse_index,
+            "pair_idx": pair_idx,
+            "pair_distance": pair_d,
+        }
+
+    # ------------------------------------------------------------------ scene collision
+    def scene_collision(
+        self,
+        spheres: np.ndarray,
+        scene: Dict[str, np.ndarray],
+        weight: float,
+        activation_distance: float,
+        env_query_idx: Optional[np.ndarray] = None,
+        use_multi_env: bool = False,
+        sweep: bool = False,
+        enable_speed_metric: bool = False,
+        speed_dt: float = 0.02,
+    ) -> Dict[str, np.ndarray]:
+        sp = _f32(spheres)
+        assert sp.ndim == 4, "spheres must be [batch, horizon, num_spheres, 4]"
+        b, h, S, _ = sp.shape
+        st = _SceneStruct()
+        keep = []
+
+        def hold(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        if scene.get("cuboid_dims") is not None and scene["cuboid_dims"].size > 0:
+            dims = scene["cuboid_dims"]
+            st.max_cub = int(dims.shape[1])
+            st.cub_dims = hold(dims, np.float32)
+            st.cub_inv_pose = hold(scene["cuboid_inv_pose"], np.float32)
+            st.cub_enable = hold(scene["cuboid_enable"], np.uint8)
+            st.cub_count = hold(scene["cuboid_count"], np.int32)
+        else:
+            st.max_cub = 0
+        if scene.get("voxel_params") is not None and scene["voxel_params"].size > 0:
+            prm = scene["voxel_params"]
+            st.max_vox = int(prm.shape[1])
+            st.vox_params = hold(prm, np.float32)
+            st.vox_inv_pose = hold(scene["voxel_inv_pose"], np.float32)
+            st.vox_enable = hold(scene["voxel_enable"], np.uint8)
+            st.vox_count = hold(scene["voxel_count"], np.int32)
+            feats = np.ascontiguousarray(scene["voxel_features"], dtype=np.float16)
+            keep.append(feats)
+            st.vox_features = feats.view(np.uint16).ctypes.data
+            st.vox_n_voxels = int(feats.reshape(prm.shape[0], prm.shape[1], -1).shape[-1])
+            st.vox_max_distance = float(scene.get("voxel_max_distance", 10000.0))
+        else:
+            st.max_vox = 0
+        if env_query_idx is None:
+            env_query_idx = np.zeros((b,), np.int32)
+        env_query_idx = np.ascontiguousarray(env_query_idx, np.int32)
+        dist = np.zeros((b, h, S), np.float32)
+        grad = np.zeros((b, h, S, 4), np.float32)
+        w = np.array([weight], np.float32)
+        eta = np.array([activation_distance], np.float32)
+        dt = np.array([speed_dt], np.float32)
+        self.lib.orc_scene_collision(
+            _ptr(dist), _ptr(grad), _ptr(sp), C.byref(st), _ptr(w), _ptr(eta), _ptr(env_query_idx),
+            C.c_int(b), C.c_int(h), C.c_int(S), C.c_int(int(use_multi_env)),
+            C.c_int(3 if sweep else 0), C.c_int(int(enable_speed_metric)), _ptr(dt),
+        )
+        return {"distance": dist, "gradient": grad}
+
+    # ------------------------------------------------------------------ B-spline
+    def bspline_forward(self, u, start, goal, start_idx, goal_idx, traj_dt, use_implicit_goal,
+                        padded_horizon: int, degree: int = 3):
+        """start/goal: dict with position/velocity/acceleration/jerk arrays [n_states, dof]."""
+        u = _f32(u)
+        b, n_knots, dof = u.shape
+        outs = [np.zeros((b, padded_horizon, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros((b,), np.float32)
+        keys = ("position", "velocity", "acceleration", "jerk")
+        s = [_f32(start[k]) for k in keys]
+        g = [_f32(goal[k]) for k in keys]
+        self.lib.orc_bspline_forward(
+            *[_ptr(o) for o in outs], _ptr(out_dt), _ptr(u), *[_ptr(x) for x in s],
+            *[_ptr(x) for x in g], _ptr(np.ascontiguousarray(start_idx, np.int32)),
+            _ptr(np.ascontiguousarray(goal_idx, np.int32)), _ptr(_f32(traj_dt)),
+            _ptr(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+            C.c_int(b), C.c_int(padded_horizon), C.c_int(dof), C.c_int(n_knots), C.c_int(degree),
+        )
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2],
+                "jerk": outs[3], "dt": out_dt}
+
+    def bspline_backward(self, grad_p, grad_v, grad_a, grad_j, traj_dt, dt_idx, use_implicit_goal,
+                         n_knots: int, degree: int = 3):
+        gp = _f32(grad_p)
+        b, ph, dof = gp.shape
+        out = np.zeros((b, n_knots, dof), np.float32)
+        self.lib.orc_bspline_backward(
+            _ptr(out), _ptr(gp), _ptr(_f32(grad_v)), _ptr(_f32(grad_a)), _ptr(_f32(grad_j)),
+            _ptr(_f32(traj_dt)), _ptr(np.ascontiguousarray(dt_idx, np.int32)),
+            _ptr(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+            C.c_int(b), C.c_int(ph), C.c_int(dof), C.c_int(n_knots), C.c_int(degree),
+        )
+        return out
+
+    # ------------------------------------------------------------------ optimiser step
+    def lbfgs_step(self, step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0,
+                   epsilon: float, stable_mode: bool):
+        """In-place on (step_vec, rho/y/s buffers, x_0, grad_0); shapes as the reference."""
+        m = y_buffer.shape[0]
+        b = q.shape[0]
+        v = int(np.prod(q.shape[1:]))
+        for a in (step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        self.lib.orc_lbfgs_step(
+            _ptr(step_vec), _ptr(rho_buffer), _ptr(y_buffer), _ptr(s_buffer), _ptr(q), _ptr(grad_q),
+            _ptr(x_0), _ptr(grad_0), C.c_float(epsilon), C.c_int(b), C.c_int(m), C.c_int(v),
+            C.c_int(int(stable_mode)),
+        )
+        return step_vec
+
+    def line_search(self, state: Dict[str, np.ndarray], search_cost, search_action, search_gradient,
+                    step_direction, search_magnitudes, c_1: float, c_2: float, strong_wolfe: bool,
+                    approx_wolfe: bool, convergence_iteration: int, cost_delta_threshold: float,
+                    cost_relative_threshold: float):
+        """state keys (updated in place): best_cost, best_action, best_iteration,
+        current_iteration, converged, exploration_cost/action/gradient, cost, action, gradient,
+        exploration_idx, selected_idx."""
+        b, nls = search_cost.shape[0], search_cost.shape[1]
+        opt_dim = search_action.shape[-1]
+        self.lib.orc_line_search(
+            _ptr(state["best_cost"]), _ptr(state["best_action"]), _ptr(state["best_iteration"]),
+            _ptr(state["current_iteration"]), _ptr(state["converged"]),
+            C.c_int(convergence_iteration), C.c_float(cost_delta_threshold),
+            C.c_float(cost_relative_threshold), _ptr(state["exploration_cost"]),
+            _ptr(state["exploration_action"]), _ptr(state["exploration_gradient"]),
+            _ptr(state["exploration_idx"]), _ptr(state["cost"]), _ptr(state["action"]),
+            _ptr(state["gradient"]), _ptr(state["selected_idx"]), _ptr(_f32(search_cost)),
+            _ptr(_f32(search_action)), _ptr(_f32(search_gradient)), _ptr(_f32(step_direction)),
+            _ptr(_f32(search_magnitudes)), C.c_float(c_1), C.c_float(c_2),
+            C.c_int(int(strong_wolfe)), C.c_int(int(approx_wolfe)), C.c_int(nls), C.c_int(opt_dim),
+            C.c_int(b),
+        )
+        return state
+
+    def trajectory_cost_sum(self, self_cost, scene_cost):
+        sc = _f32(scene_cost)
+        b, h, S = sc.shape
+        out = np.zeros((b,), np.float32)
+        self.lib.orc_trajectory_cost_sum(
+            _ptr(out), _ptr(_f32(self_cost)) if self_cost is not None else None, _ptr(sc),
+            C.c_int(b), C.c_int(h), C.c_int(S),
+        )
+        return out
+
+
+_ORACLE: Optional[Oracle] = None
+
+
+def load_oracle() -> Oracle:
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
