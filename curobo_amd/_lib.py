@@ -1,0 +1,121 @@
+"""ctypes binding of ``libcurobo_hip.so`` (the C ABI declared in ``include/curobo_hip.h``).
+
+The product path fails loudly when the HIP library is missing: there is no CPU or eager-torch
+fallback behind these calls.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List, Optional
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libcurobo_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "curobo_hip.h")
+
+_lib: Optional[C.CDLL] = None
+
+
+class CuroboHipError(RuntimeError):
+    """Launch failure reported by the HIP backend (reference: log_and_raise after
+    cudaGetLastError, cuda_core_backend/launch_helper.py:17-19)."""
+
+
+class Scene(C.Structure):
+    """``curobo_hip_scene`` (see include/curobo_hip.h)."""
+
+    _fields_ = [
+        ("cuboid_dims", C.c_void_p), ("cuboid_inv_pose", C.c_void_p), ("cuboid_enable", C.c_void_p),
+        ("cuboid_count", C.c_void_p), ("max_cuboids", C.c_int32),
+        ("voxel_params", C.c_void_p), ("voxel_inv_pose", C.c_void_p), ("voxel_enable", C.c_void_p),
+        ("voxel_count", C.c_void_p), ("voxel_features", C.c_void_p), ("max_voxel_grids", C.c_int32),
+        ("voxel_n_voxels", C.c_int32), ("voxel_max_distance", C.c_float),
+    ]
+
+
+def declared_symbols(header: str = HEADER_PATH) -> List[str]:
+    """Every function name the public header declares."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(curobo_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def _ctype_of(tok: str):
+    tok = tok.strip()
+    if "*" in tok or tok.startswith("curobo_hip_stream_t"):
+        return C.c_void_p
+    if tok.startswith("float"):
+        return C.c_float
+    if tok.startswith("int") or tok.startswith("int32_t"):
+        return C.c_int
+    raise ValueError(f"unhandled C type in header: {tok!r}")
+
+
+def _signatures(header: str = HEADER_PATH) -> Dict[str, list]:
+    """Parse argument types from the header so Python and C cannot drift apart."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\bint\s+(curobo_hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if args in ("", "void"):
+            sigs[name] = []
+            continue
+        sigs[name] = [_ctype_of(a) for a in args.split(",")]
+    return sigs
+
+
+def library_available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load the shared library (after ``import torch`` so torch's HIP runtime is reused)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m curobo_amd.build` "
+            "(hipcc --offload-arch=gfx950). curobo_amd has no CPU fallback."
+        )
+    import torch  # noqa: F401  (loads libamdhip64 first; same SONAME is then shared)
+
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _signatures().items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    lib.curobo_hip_last_error.restype = C.c_char_p
+    lib.curobo_hip_last_error.argtypes = []
+    lib.curobo_hip_set_debug_sync.restype = None
+    lib.curobo_hip_set_debug_sync.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    """Convert a C status into the reference's exception types."""
+    if status == 0:
+        return
+    msg = load().curobo_hip_last_error().decode()
+    if status == 1:
+        raise ValueError(msg)
+    raise CuroboHipError(msg)
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(t) -> int:
+    """Raw hipStream_t of torch's current stream on the tensor's device.
+
+    Mandatory for correctness under stream-per-cost execution and graph capture (reference
+    cuda_core_backend/kinematics.py:50-51)."""
+    import torch
+
+    return torch.cuda.current_stream(t.device).cuda_stream

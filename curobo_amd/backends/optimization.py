@@ -1,0 +1,78 @@
+"""HIP backend for the optimiser-step kernels (reference
+``curobo/_src/curobolib/backends/cuda_core_backend/optimization.py:27-260``,
+``pybind/optimization_bindings.cpp:14-75``)."""
+
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from .._lib import check, current_stream, load, ptr
+
+
+def launch_line_search(
+    best_cost: torch.Tensor,
+    best_action: torch.Tensor,
+    best_iteration: torch.Tensor,
+    current_iteration: torch.Tensor,
+    converged_global: torch.Tensor,
+    convergence_iteration: int,
+    cost_delta_threshold: float,
+    cost_relative_threshold: float,
+    exploration_cost: torch.Tensor,
+    exploration_action: torch.Tensor,
+    exploration_gradient: torch.Tensor,
+    exploration_idx: torch.Tensor,
+    selected_cost: torch.Tensor,
+    selected_action: torch.Tensor,
+    selected_gradient: torch.Tensor,
+    selected_idx: torch.Tensor,
+    search_cost: torch.Tensor,
+    search_action: torch.Tensor,
+    search_gradient: torch.Tensor,
+    step_direction: torch.Tensor,
+    search_magnitudes: torch.Tensor,
+    armijo_threshold_c_1: float,
+    curvature_threshold_c_2: float,
+    strong_wolfe: bool,
+    approx_wolfe: bool,
+    n_linesearch: int,
+    opt_dim: int,
+    batchsize: int,
+):
+    check(load().curobo_hip_launch_line_search(
+        ptr(best_cost), ptr(best_action), ptr(best_iteration), ptr(current_iteration),
+        ptr(converged_global), convergence_iteration, cost_delta_threshold,
+        cost_relative_threshold, ptr(exploration_cost), ptr(exploration_action),
+        ptr(exploration_gradient), ptr(exploration_idx), ptr(selected_cost), ptr(selected_action),
+        ptr(selected_gradient), ptr(selected_idx), ptr(search_cost), ptr(search_action),
+        ptr(search_gradient), ptr(step_direction), ptr(search_magnitudes), armijo_threshold_c_1,
+        curvature_threshold_c_2, int(strong_wolfe), int(approx_wolfe), n_linesearch, opt_dim,
+        batchsize, current_stream(best_cost),
+    ))
+
+
+def launch_lbfgs_step(
+    step_vec: torch.Tensor,
+    rho_buffer: torch.Tensor,
+    y_buffer: torch.Tensor,
+    s_buffer: torch.Tensor,
+    q: torch.Tensor,
+    grad_q: torch.Tensor,
+    x_0: torch.Tensor,
+    grad_0: torch.Tensor,
+    epsilon: float,
+    batch_size: int,
+    history_m: int,
+    v_dim: int,
+    stable_mode: bool,
+    use_shared_buffers: bool,
+) -> List[torch.Tensor]:
+    """Returns ``[step_vec, rho_buffer, y_buffer, s_buffer, x_0, grad_0]`` like the reference."""
+    check(load().curobo_hip_launch_lbfgs_step(
+        ptr(step_vec), ptr(rho_buffer), ptr(y_buffer), ptr(s_buffer), ptr(q), ptr(grad_q),
+        ptr(x_0), ptr(grad_0), epsilon, batch_size, history_m, v_dim, int(stable_mode),
+        int(use_shared_buffers), current_stream(step_vec),
+    ))
+    return [step_vec, rho_buffer, y_buffer, s_buffer, x_0, grad_0]

@@ -1,0 +1,92 @@
+"""Build libcurobo_hip.so (the C-ABI kernel backend) with hipcc for gfx950.
+
+The shared object is built in-tree (``curobo_amd/lib/libcurobo_hip.so``) so that it travels with
+the source snapshot to the GPU box; hipcc cross-compiles for gfx950 without a GPU.
+Usage: ``python -m curobo_amd.build [--force]``.
+"""
+
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcurobo_hip.so")
+OBJ_DIR = os.path.join(_PKG, "build")
+ARCH = "gfx950"
+
+SOURCES = [
+    "runtime.cpp",
+    "kinematics.hip",
+    "self_collision.hip",
+    "scene_collision.hip",
+    "trajectory.hip",
+    "optimization.hip",
+]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP backend cannot be built on this machine")
+
+
+def _flags() -> List[str]:
+    return [
+        f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+        "-ffp-contract=fast", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+        f"-I{INCLUDE}", f"-I{CSRC}",
+    ]
+
+
+def _deps(src: str) -> List[str]:
+    return [src, os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "curobo_hip.h")]
+
+
+def _compile(src_name: str, force: bool) -> str:
+    src = os.path.join(CSRC, src_name)
+    obj = os.path.join(OBJ_DIR, src_name.rsplit(".", 1)[0] + ".o")
+    if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
+        return obj
+    cmd = [hipcc_path(), *_flags(), "-x", "hip", "-c", src, "-o", obj]
+    subprocess.check_call(cmd)
+    return obj
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"),
+                                                        os.path.join(INCLUDE, "curobo_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,109 @@
+// common.hpp -- shared host/device helpers for the gfx950 kernels (wave64 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "curobo_hip.h"
+
+#define CUROBO_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace curobo_hip {
+
+// joint types: reference kernels/kinematics/kinematics_constants.h:10-16
+enum : int { J_FIXED = -1, J_X_PRISM = 0, J_Y_PRISM = 1, J_Z_PRISM = 2, J_X_ROT = 3, J_Y_ROT = 4, J_Z_ROT = 5 };
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------- host side error plumbing
+int set_error(int code, const char *fmt, ...);
+int check_launch(const char *what, hipStream_t stream);
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline long ceil_div_l(long a, long b) { return (a + b - 1) / b; }
+
+#define CUROBO_REQUIRE(cond, ...)                                      \
+  do {                                                                 \
+    if (!(cond)) return set_error(CUROBO_HIP_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ---------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+
+// DPP quad broadcast: every lane receives the value of lane (4*(lane/4) + K).
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K,K,K,K]
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+
+// butterfly sum over groups of WIDTH consecutive lanes (WIDTH power of two <= 64)
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<kWave>(v); }
+
+struct f3 {
+  float x, y, z;
+};
+__device__ __forceinline__ f3 make_f3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// 3x4 row-major rigid transform applied to a point (reference kinematics_util.cuh:38-50)
+__device__ __forceinline__ float4 transform_sphere(const float *C, float4 s) {
+  float4 o;
+  o.x = C[0] * s.x + C[1] * s.y + C[2] * s.z + C[3];
+  o.y = C[4] * s.x + C[5] * s.y + C[6] * s.z + C[7];
+  o.z = C[8] * s.x + C[9] * s.y + C[10] * s.z + C[11];
+  o.w = s.w;
+  return o;
+}
+
+// rotation block of a row-major 3x4 -> unit quaternion (x,y,z,w), w >= 0.
+// reference common/quaternion_util.cuh:50-57,110-160 (4-branch form, then normalise).
+__device__ __forceinline__ float4 quat_from_transform(const float *T) {
+  const float t0 = T[0], t1 = T[1], t2 = T[2];
+  const float t3 = T[4], t4 = T[5], t5 = T[6];
+  const float t6 = T[8], t7 = T[9], t8 = T[10];
+  float x, y, z, w, n, ns;
+  if (t8 < 0.0f) {
+    if (t0 > t4) {
+      n = 1 + t0 - t4 - t8;
+      ns = 0.5f / sqrtf(n);
+      x = n * ns; y = (t1 + t3) * ns; z = (t6 + t2) * ns; w = -1 * (t5 - t7) * ns;
+    } else {
+      n = 1 - t0 + t4 - t8;
+      ns = 0.5f / sqrtf(n);
+      x = (t1 + t3) * ns; y = n * ns; z = (t5 + t7) * ns; w = -1 * (t6 - t2) * ns;
+    }
+  } else {
+    if (t0 < -1 * t4) {
+      n = 1 - t0 - t4 + t8;
+      ns = 0.5f / sqrtf(n);
+      x = (t6 + t2) * ns; y = (t5 + t7) * ns; z = n * ns; w = -1 * (t1 - t3) * ns;
+    } else {
+      n = 1 + t0 + t4 + t8;
+      ns = 0.5f / sqrtf(n);
+      x = (t5 - t7) * ns; y = (t6 - t2) * ns; z = (t1 - t3) * ns; w = -1 * n * ns;
+    }
+  }
+  float inv = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+  if (w < 0.0f) inv = -inv;
+  return make_float4(x * inv, y * inv, z * inv, w * inv);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace curobo_hip

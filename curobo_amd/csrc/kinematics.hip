@@ -1,0 +1,531 @@
+// kinematics.hip -- forward kinematics over the URDF tree (+ collision spheres, geometric
+// Jacobian, centre of mass) and its VJP, for gfx950 (wave64).
+//
+// What is computed follows the reference kernels
+//   curobolib/kernels/kinematics/kinematics_forward_kernel.cuh:20-433
+//   curobolib/kernels/kinematics/kinematics_forward_helper.cuh:45-600
+//   curobolib/kernels/kinematics/kinematics_backward_kernel.cuh:27-157
+//   curobolib/kernels/kinematics/kinematics_backward_helper.cuh:14-291
+// How it is computed is CDNA4-specific:
+//   * a point (one joint configuration) is owned by 16 consecutive lanes, 4 points per wave64;
+//     lane (4*r + c) of the group owns element (r, c) of the 3x4 link transform.  The serial
+//     chain  C_l = C_parent(l) * M_l  needs, per lane, the three rotation entries of ITS OWN row
+//     of the parent: they live in the same DPP quad, so each chain step is 4 quad broadcasts +
+//     one 16-byte LDS read of the local-transform column + 4 FMAs.  A lane only ever re-reads
+//     cumulative entries that it wrote itself, so the whole chain runs without any barrier
+//     (the reference needs a __syncwarp per link).
+//   * local joint transforms (the sincos) are computed once per (point, link) by all 256 lanes,
+//     column-major and padded to float4 so the chain reads them with ds_read_b128.
+//   * cumulative transforms are built directly in the [L][3][4] output layout in LDS and leave
+//     the CU as one contiguous float4 stream per block; spheres leave as 16 lanes x 16 B = 256 B
+//     contiguous segments per point.
+//   * the VJP accumulates per-lane partial joint gradients in LDS rows (ds_add_f32, no dynamic
+//     register indexing -> no scratch), then 16-lane reduces them.
+#include "common.hpp"
+
+namespace curobo_hip {
+
+constexpr int kFkLanes = 16;  // lanes per point
+
+// reference kinematics_forward_helper.cuh:316-393 / kinematics_util.cuh:62-74.
+// Writes the local 3x4 of one (point, link) column-major, each column padded to 4 floats.
+__device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst, const float *__restrict__ F,
+                                                        int j_type, float q_val, float off_mul,
+                                                        float off_add) {
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3];
+  const float f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7];
+  const float f8 = F[8], f9 = F[9], f10 = F[10], f11 = F[11];
+  float4 c0 = make_float4(f0, f4, f8, 0.0f);
+  float4 c1 = make_float4(f1, f5, f9, 0.0f);
+  float4 c2 = make_float4(f2, f6, f10, 0.0f);
+  float4 c3 = make_float4(f3, f7, f11, 0.0f);
+  if (j_type != J_FIXED) {
+    const float angle = off_mul * q_val + off_add;
+    if (j_type <= J_Z_PRISM) {
+      c3.x = f3 + (j_type == J_X_PRISM ? f0 : (j_type == J_Y_PRISM ? f1 : f2)) * angle;
+      c3.y = f7 + (j_type == J_X_PRISM ? f4 : (j_type == J_Y_PRISM ? f5 : f6)) * angle;
+      c3.z = f11 + (j_type == J_X_PRISM ? f8 : (j_type == J_Y_PRISM ? f9 : f10)) * angle;
+    } else {
+      float s, c;
+      sincosf(angle, &s, &c);
+      const int xyz = j_type - J_X_ROT;
+      const float is_x = xyz == 0 ? 1.0f : 0.0f;
+      const float is_y = xyz == 1 ? 1.0f : 0.0f;
+      const float is_z = xyz == 2 ? 1.0f : 0.0f;
+      const float s0 = is_x + c * (is_y + is_z);
+      const float s1 = is_y + c * (is_x + is_z);
+      const float s2 = is_z + c * (is_x + is_y);
+      c0 = make_float4(f0 * s0 + s * (is_z * f1 - is_y * f2), f4 * s0 + s * (is_z * f5 - is_y * f6),
+                       f8 * s0 + s * (is_z * f9 - is_y * f10), 0.0f);
+      c1 = make_float4(f1 * s1 + s * (is_x * f2 - is_z * f0), f5 * s1 + s * (is_x * f6 - is_z * f4),
+                       f9 * s1 + s * (is_x * f10 - is_z * f8), 0.0f);
+      c2 = make_float4(f2 * s2 + s * (is_y * f0 - is_x * f1), f6 * s2 + s * (is_y * f4 - is_x * f5),
+                       f10 * s2 + s * (is_y * f8 - is_x * f9), 0.0f);
+    }
+  }
+  float4 *d4 = reinterpret_cast<float4 *>(dst);
+  d4[0] = c0; d4[1] = c1; d4[2] = c2; d4[3] = c3;
+}
+
+struct FkArgs {
+  float *link_pos;
+  float *link_quat;
+  float *spheres_out;
+  float *com_out;
+  float *jacobian_out;
+  float *cumul_out;
+  const float *q;
+  const float *fixed_transform;
+  const float *robot_spheres;
+  const float *link_masses_com;
+  const int8_t *joint_map_type;
+  const int16_t *joint_map;
+  const int16_t *link_map;
+  const int16_t *tool_frame_map;
+  const int16_t *link_sphere_map;
+  const int16_t *link_chain_data;
+  const int16_t *link_chain_offsets;
+  const int16_t *joint_links_data;
+  const int16_t *joint_links_offsets;
+  const uint8_t *joint_affects_endeffector;
+  const float *joint_offset;
+  const int32_t *env_query_idx;
+  int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames;
+};
+
+template <bool SPHERES, bool JACOBIAN, bool COM, bool WRITE_CUMUL>
+__global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.nlinks;
+  const int pts = blockDim.x / kFkLanes;
+  float *cumul = smem;                  // [pts][L][12]   (row-major 3x4, the output layout)
+  float *local = smem + pts * L * 12;   // [pts][L][16]   (column-major, float4 per column)
+  int *s_parent = reinterpret_cast<int *>(local + pts * L * 16);  // [L]
+
+  const int tid = threadIdx.x;
+  const int pt0 = blockIdx.x * pts;
+  const int npts = min(pts, a.n_points - pt0);
+
+  for (int l = tid; l < L; l += blockDim.x) s_parent[l] = a.link_map[l];
+
+  // ---- phase 1: local transforms, one (point, link) item per lane
+  for (int e = tid; e < npts * L; e += blockDim.x) {
+    const int lp = e / L;
+    const int l = e - lp * L;
+    const int jt = a.joint_map_type[l];
+    float qv = 0.0f;
+    if (jt != J_FIXED) qv = a.q[(size_t)(pt0 + lp) * a.njoints + a.joint_map[l]];
+    local_transform_colmajor(local + (size_t)e * 16, a.fixed_transform + l * 12, jt, qv,
+                             a.joint_offset[2 * l], a.joint_offset[2 * l + 1]);
+  }
+  __syncthreads();
+
+  // ---- phase 2: serial chain, barrier free (see file header)
+  const int grp = tid / kFkLanes;
+  const int lane = tid % kFkLanes;
+  const bool active = grp < npts;
+  float *my_cumul = cumul + (size_t)grp * L * 12;
+  if (active) {
+    const int c = lane & 3;
+    const bool owner = lane < 12;
+    float cur = owner ? a.fixed_transform[lane] : 0.0f;  // base link: reference :467-485
+    if (owner) my_cumul[lane] = cur;
+    const float *my_local = local + (size_t)grp * L * 16 + c * 4;
+    for (int l = 1; l < L; l++) {
+      const int parent = s_parent[l];
+      float p = cur;
+      if (parent != l - 1) p = owner ? my_cumul[parent * 12 + lane] : 0.0f;
+      const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
+      const float4 m = *reinterpret_cast<const float4 *>(my_local + l * 16);
+      cur = a0 * m.x + a1 * m.y + a2 * m.z + (c == 3 ? a3 : 0.0f);
+      if (owner) my_cumul[l * 12 + lane] = cur;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3a: cumulative transforms -> HBM, one contiguous float4 stream per block
+  if (WRITE_CUMUL) {
+    const float4 *src = reinterpret_cast<const float4 *>(cumul);
+    float4 *dst = reinterpret_cast<float4 *>(a.cumul_out + (size_t)pt0 * L * 12);
+    for (int i = tid; i < npts * L * 3; i += blockDim.x) dst[i] = src[i];
+  }
+  if (!active) return;
+  const int n = pt0 + grp;
+
+  // ---- phase 3b: collision spheres (reference kinematics_forward_helper.cuh:218-254)
+  if (SPHERES) {
+    const int env = (a.num_envs > 1) ? a.env_query_idx[n / a.horizon] : 0;
+    const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * a.nspheres;
+    float4 *out = reinterpret_cast<float4 *>(a.spheres_out) + (size_t)n * a.nspheres;
+    for (int s = lane; s < a.nspheres; s += kFkLanes) {
+      const int link = a.link_sphere_map[s];
+      out[s] = transform_sphere(my_cumul + link * 12, rs[s]);
+    }
+  }
+  // ---- centre of mass (reference :538-600)
+  if (COM) {
+    float wx = 0.f, wy = 0.f, wz = 0.f, wm = 0.f;
+    for (int l = lane; l < L; l += kFkLanes) {
+      const float4 mc = reinterpret_cast<const float4 *>(a.link_masses_com)[l];
+      if (mc.w > 0.0f) {
+        const float4 cw = transform_sphere(my_cumul + l * 12, mc);
+        wx += mc.w * cw.x; wy += mc.w * cw.y; wz += mc.w * cw.z; wm += mc.w;
+      }
+    }
+    wx = group_sum<kFkLanes>(wx); wy = group_sum<kFkLanes>(wy);
+    wz = group_sum<kFkLanes>(wz); wm = group_sum<kFkLanes>(wm);
+    if (lane == 0) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wm > 0.0f) o = make_float4(wx / wm, wy / wm, wz / wm, wm);
+      reinterpret_cast<float4 *>(a.com_out)[n] = o;
+    }
+  }
+  // ---- tool-frame poses (reference :270-301), quaternion written wxyz
+  for (int t = lane; t < a.n_tool_frames; t += kFkLanes) {
+    const float *C = my_cumul + a.tool_frame_map[t] * 12;
+    const float4 qx = quat_from_transform(C);
+    reinterpret_cast<float4 *>(a.link_quat)[(size_t)n * a.n_tool_frames + t] = make_float4(qx.w, qx.x, qx.y, qx.z);
+    float *p = a.link_pos + ((size_t)n * a.n_tool_frames + t) * 3;
+    p[0] = C[3]; p[1] = C[7]; p[2] = C[11];
+  }
+  // ---- geometric Jacobian (reference :45-200), one joint column per lane, no atomics
+  if (JACOBIAN) {
+    const int D = a.njoints, T = a.n_tool_frames;
+    for (int t = 0; t < T; t++) {
+      const int tl = a.tool_frame_map[t];
+      const float *E = my_cumul + tl * 12;
+      const f3 ee = make_f3(E[3], E[7], E[11]);
+      const int cs = a.link_chain_offsets[tl], ce = a.link_chain_offsets[tl + 1];
+      float *J = a.jacobian_out + ((size_t)n * T + t) * 6 * D;
+      for (int j = lane; j < D; j += kFkLanes) {
+        float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.joint_affects_endeffector[j * T + t]) {
+          for (int jl = a.joint_links_offsets[j]; jl < a.joint_links_offsets[j + 1]; jl++) {
+            const int li = a.joint_links_data[jl];
+            if (li == 0) continue;
+            bool in_chain = false;
+            for (int ci = cs; ci < ce; ci++) in_chain |= (a.link_chain_data[ci] == li);
+            if (!in_chain) continue;
+            const float *C = my_cumul + li * 12;
+            const int jt = a.joint_map_type[li];
+            const float sign = a.joint_offset[li * 2];
+            if (jt >= J_X_ROT) {
+              const int ax = jt - J_X_ROT;
+              const f3 axis = sign * make_f3(C[ax], C[4 + ax], C[8 + ax]);
+              const f3 lin = cross(axis, ee - make_f3(C[3], C[7], C[11]));
+              col[0] += lin.x; col[1] += lin.y; col[2] += lin.z;
+              col[3] += axis.x; col[4] += axis.y; col[5] += axis.z;
+            } else if (jt >= J_X_PRISM) {
+              const int ax = jt - J_X_PRISM;
+              col[0] += sign * C[ax]; col[1] += sign * C[4 + ax]; col[2] += sign * C[8 + ax];
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) J[r * D + j] = col[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// VJP.  reference kinematics_backward_kernel.cuh:27-157 (+ helpers, see file header).
+// ------------------------------------------------------------------------------------------
+struct FkBwdArgs {
+  float *grad_q;
+  const float *grad_link_pos;
+  const float *grad_link_quat;
+  const float *grad_spheres;
+  const float *grad_spheres_b;
+  const float *grad_com;
+  const float *batch_com;
+  const float *cumul_in;
+  const float *robot_spheres;
+  const float *link_masses_com;
+  const int8_t *joint_map_type;
+  const int16_t *joint_map;
+  const int16_t *tool_frame_map;
+  const int16_t *link_sphere_map;
+  const int16_t *link_chain_data;
+  const int16_t *link_chain_offsets;
+  const float *joint_offset;
+  const int32_t *env_query_idx;
+  int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames, dpad;
+};
+
+// gradient of one world point p with cost gradient g, pushed down the chain of link `l`
+// (reference kinematics_backward_helper.cuh:62-98, kinematics_joint_util.cuh:13-66)
+__device__ __forceinline__ void chain_point_vjp(float *__restrict__ psum, const float *__restrict__ cumul,
+                                                const FkBwdArgs &a, int l, f3 p, f3 g) {
+  const int cs = a.link_chain_offsets[l];
+  for (int ci = a.link_chain_offsets[l + 1] - 1; ci >= cs; ci--) {
+    const int j = a.link_chain_data[ci];
+    const int jt = a.joint_map_type[j];
+    if (jt < J_X_PRISM) continue;
+    const float sign = a.joint_offset[j * 2];
+    const float *C = cumul + j * 12;
+    const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
+    const f3 axis = make_f3(C[ax], C[4 + ax], C[8 + ax]);
+    float r;
+    if (jt >= J_X_ROT) r = dot(sign * g, cross(axis, p - make_f3(C[3], C[7], C[11])));
+    else r = sign * dot(axis, g);
+    atomicAdd(&psum[a.joint_map[j]], r);  // own LDS row: ds_add_f32, never contended
+  }
+}
+
+template <bool COM>
+__global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.nlinks, D = a.njoints;
+  const int pts = blockDim.x / kFkLanes;
+  float *cumul = smem;                          // [pts][L][12]
+  float *psum_all = smem + pts * L * 12;        // [pts][16][dpad]
+  const int tid = threadIdx.x;
+  const int pt0 = blockIdx.x * pts;
+  const int npts = min(pts, a.n_points - pt0);
+
+  {  // saved cumulative transforms -> LDS, contiguous float4 stream
+    const float4 *src = reinterpret_cast<const float4 *>(a.cumul_in + (size_t)pt0 * L * 12);
+    float4 *dst = reinterpret_cast<float4 *>(cumul);
+    for (int i = tid; i < npts * L * 3; i += blockDim.x) dst[i] = src[i];
+  }
+  for (int i = tid; i < pts * kFkLanes * a.dpad; i += blockDim.x) psum_all[i] = 0.0f;
+  __syncthreads();
+
+  const int grp = tid / kFkLanes, lane = tid % kFkLanes;
+  if (grp >= npts) return;
+  const int n = pt0 + grp;
+  const float *my_cumul = cumul + (size_t)grp * L * 12;
+  float *psum = psum_all + ((size_t)grp * kFkLanes + lane) * a.dpad;
+
+  // ---- spheres (sparsity skip on zero gradient, reference :48-52)
+  if (a.nspheres > 0) {
+    const int env = (a.num_envs > 1) ? a.env_query_idx[n / a.horizon] : 0;
+    const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * a.nspheres;
+    const float4 *ga = reinterpret_cast<const float4 *>(a.grad_spheres) + (size_t)n * a.nspheres;
+    const float4 *gb = a.grad_spheres_b
+                           ? reinterpret_cast<const float4 *>(a.grad_spheres_b) + (size_t)n * a.nspheres
+                           : nullptr;
+    for (int s = lane; s < a.nspheres; s += kFkLanes) {
+      float4 g4 = ga[s];
+      if (gb) { const float4 h = gb[s]; g4.x += h.x; g4.y += h.y; g4.z += h.z; }
+      if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f) continue;
+      const int l = a.link_sphere_map[s];
+      const float4 pw = transform_sphere(my_cumul + l * 12, rs[s]);
+      chain_point_vjp(psum, my_cumul, a, l, make_f3(pw.x, pw.y, pw.z), make_f3(g4.x, g4.y, g4.z));
+    }
+  }
+  // ---- tool frames: position + orientation (reference :102-183), chain split across lanes
+  for (int t = 0; t < a.n_tool_frames; t++) {
+    const float *gp = a.grad_link_pos + ((size_t)n * a.n_tool_frames + t) * 3;
+    const float4 gq = reinterpret_cast<const float4 *>(a.grad_link_quat)[(size_t)n * a.n_tool_frames + t];
+    const f3 g = make_f3(gp[0], gp[1], gp[2]);
+    if (g.x == 0.f && g.y == 0.f && g.z == 0.f && gq.x == 0.f && gq.y == 0.f && gq.z == 0.f && gq.w == 0.f) continue;
+    const int l = a.tool_frame_map[t];
+    const float *C = my_cumul + l * 12;
+    const float4 qx = quat_from_transform(C);
+    const f3 pos = make_f3(C[3], C[7], C[11]);
+    // omega = 0.5 * E(q)^T g  (reference quaternion_util.cuh:86-102; q xyzw, g wxyz)
+    const float dqw = gq.x, dqx = gq.y, dqy = gq.z, dqz = gq.w;
+    const f3 om = make_f3(0.5f * (-qx.x * dqw + qx.w * dqx + qx.z * dqy - qx.y * dqz),
+                          0.5f * (-qx.y * dqw - qx.z * dqx + qx.w * dqy + qx.x * dqz),
+                          0.5f * (-qx.z * dqw + qx.y * dqx - qx.x * dqy + qx.w * dqz));
+    const int cs = a.link_chain_offsets[l], ce = a.link_chain_offsets[l + 1];
+    for (int ci = cs + lane; ci < ce; ci += kFkLanes) {
+      const int j = a.link_chain_data[ci];
+      const int jt = a.joint_map_type[j];
+      if (jt < J_X_PRISM) continue;
+      const float sign = a.joint_offset[j * 2];
+      const float *Cj = my_cumul + j * 12;
+      const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
+      const f3 axis = make_f3(Cj[ax], Cj[4 + ax], Cj[8 + ax]);
+      float r;
+      if (jt >= J_X_ROT)
+        r = dot(sign * g, cross(axis, pos - make_f3(Cj[3], Cj[7], Cj[11]))) + sign * dot(axis, om);
+      else
+        r = sign * dot(axis, g);
+      atomicAdd(&psum[a.joint_map[j]], r);
+    }
+  }
+  // ---- centre of mass (reference :186-291)
+  if (COM) {
+    const float total_mass = a.batch_com[(size_t)n * 4 + 3];
+    const float4 gc = reinterpret_cast<const float4 *>(a.grad_com)[n];
+    if (total_mass > 0.0f && !(gc.x == 0.f && gc.y == 0.f && gc.z == 0.f)) {
+      for (int l = lane; l < L; l += kFkLanes) {
+        const float4 mc = reinterpret_cast<const float4 *>(a.link_masses_com)[l];
+        if (mc.w <= 0.0f) continue;
+        const f3 g = make_f3(gc.x * mc.w / total_mass, gc.y * mc.w / total_mass, gc.z * mc.w / total_mass);
+        const float4 cw = transform_sphere(my_cumul + l * 12, mc);
+        chain_point_vjp(psum, my_cumul, a, l, make_f3(cw.x, cw.y, cw.z), g);
+      }
+    }
+  }
+  // ---- 16-lane reduction of the per-lane rows.  All 16 lanes of a point sit in one wave and
+  // DS operations of a wave complete in order, so a wave-level fence suffices.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float *rows = psum_all + (size_t)grp * kFkLanes * a.dpad;
+  for (int j = lane; j < D; j += kFkLanes) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kFkLanes; k++) acc += rows[k * a.dpad + j];
+    a.grad_q[(size_t)n * D + j] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- host launchers
+static int fk_points_per_block(int nlinks) {
+  // LDS per point: forward 28*L floats, backward 12*L + 16*dpad; keep a block <= ~48 KiB so that
+  // >= 3 blocks share a CU's 160 KiB.
+  if (nlinks <= 24) return 16;
+  if (nlinks <= 64) return 8;
+  return 4;
+}
+
+template <bool S, bool J, bool C>
+static void launch_fk(const FkArgs &a, bool write_cumul, int blocks, int threads, size_t lds, hipStream_t st) {
+  if (write_cumul) hipLaunchKernelGGL((fk_forward_kernel<S, J, C, true>), dim3(blocks), dim3(threads), lds, st, a);
+  else hipLaunchKernelGGL((fk_forward_kernel<S, J, C, false>), dim3(blocks), dim3(threads), lds, st, a);
+}
+
+static int fk_forward_dispatch(const FkArgs &a, bool spheres, bool jac, bool com, bool write_cumul,
+                               hipStream_t st, const char *what) {
+  CUROBO_REQUIRE(a.nlinks >= 1 && a.nlinks <= 128, "%s: num_links=%d out of range [1,128]", what, a.nlinks);
+  CUROBO_REQUIRE(a.n_points >= 0 && a.horizon >= 1, "%s: bad batch_size/horizon", what);
+  CUROBO_REQUIRE(a.njoints >= 1, "%s: n_joints must be >= 1", what);
+  if (a.n_points == 0) return CUROBO_HIP_OK;
+  const int pts = fk_points_per_block(a.nlinks);
+  const int threads = pts * kFkLanes;
+  const int blocks = ceil_div(a.n_points, pts);
+  const size_t lds = (size_t)pts * a.nlinks * 28 * sizeof(float) + (size_t)a.nlinks * sizeof(int);
+  const int key = (spheres ? 1 : 0) | (jac ? 2 : 0) | (com ? 4 : 0);
+  switch (key) {
+    case 0: launch_fk<false, false, false>(a, write_cumul, blocks, threads, lds, st); break;
+    case 1: launch_fk<true, false, false>(a, write_cumul, blocks, threads, lds, st); break;
+    case 2: launch_fk<false, true, false>(a, write_cumul, blocks, threads, lds, st); break;
+    case 3: launch_fk<true, true, false>(a, write_cumul, blocks, threads, lds, st); break;
+    case 4: launch_fk<false, false, true>(a, write_cumul, blocks, threads, lds, st); break;
+    case 5: launch_fk<true, false, true>(a, write_cumul, blocks, threads, lds, st); break;
+    case 6: launch_fk<false, true, true>(a, write_cumul, blocks, threads, lds, st); break;
+    default: launch_fk<true, true, true>(a, write_cumul, blocks, threads, lds, st); break;
+  }
+  return check_launch(what, st);
+}
+
+}  // namespace curobo_hip
+
+using namespace curobo_hip;
+
+CUROBO_EXPORT int curobo_hip_launch_kinematics_forward(
+    float *link_pos, float *link_quat, float *batch_center_of_mass, float *global_cumul_mat,
+    const float *joint_vec, const float *fixed_transform, const float *link_masses_com,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map,
+    const int16_t *tool_frame_map, const float *joint_offset_map, int batch_size, int horizon,
+    int n_joints, int num_links, int n_tool_frames, int compute_com, curobo_hip_stream_t stream) {
+  FkArgs a{};
+  a.link_pos = link_pos; a.link_quat = link_quat; a.com_out = batch_center_of_mass;
+  a.cumul_out = global_cumul_mat; a.q = joint_vec; a.fixed_transform = fixed_transform;
+  a.link_masses_com = link_masses_com; a.joint_map_type = joint_map_type; a.joint_map = joint_map;
+  a.link_map = link_map; a.tool_frame_map = tool_frame_map; a.joint_offset = joint_offset_map;
+  a.n_points = batch_size; a.horizon = horizon; a.nspheres = 0; a.num_envs = 1;
+  a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
+  return fk_forward_dispatch(a, false, false, compute_com != 0, global_cumul_mat != nullptr,
+                             (hipStream_t)stream, "launch_kinematics_forward");
+}
+
+CUROBO_EXPORT int curobo_hip_launch_kinematics_forward_spheres(
+    float *link_pos, float *link_quat, float *batch_robot_spheres, float *batch_center_of_mass,
+    float *global_cumul_mat, const float *joint_vec, const float *fixed_transform,
+    const float *robot_spheres, const float *link_masses_com, const int8_t *joint_map_type,
+    const int16_t *joint_map, const int16_t *link_map, const int16_t *tool_frame_map,
+    const int16_t *link_sphere_map, const float *joint_offset_map, const int32_t *env_query_idx,
+    int num_envs, int batch_size, int horizon, int n_joints, int num_spheres, int num_links,
+    int n_tool_frames, int write_global_cumul, int compute_com, curobo_hip_stream_t stream) {
+  FkArgs a{};
+  a.link_pos = link_pos; a.link_quat = link_quat; a.spheres_out = batch_robot_spheres;
+  a.com_out = batch_center_of_mass; a.cumul_out = global_cumul_mat; a.q = joint_vec;
+  a.fixed_transform = fixed_transform; a.robot_spheres = robot_spheres;
+  a.link_masses_com = link_masses_com; a.joint_map_type = joint_map_type; a.joint_map = joint_map;
+  a.link_map = link_map; a.tool_frame_map = tool_frame_map; a.link_sphere_map = link_sphere_map;
+  a.joint_offset = joint_offset_map; a.env_query_idx = env_query_idx;
+  a.n_points = batch_size; a.horizon = horizon; a.nspheres = num_spheres; a.num_envs = num_envs;
+  a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
+  return fk_forward_dispatch(a, num_spheres > 0, false, compute_com != 0, write_global_cumul != 0,
+                             (hipStream_t)stream, "launch_kinematics_forward_spheres");
+}
+
+CUROBO_EXPORT int curobo_hip_launch_kinematics_forward_spheres_jacobian(
+    float *link_pos, float *link_quat, float *batch_robot_spheres, float *batch_center_of_mass,
+    float *batch_jacobian, float *global_cumul_mat, const float *joint_vec,
+    const float *fixed_transform, const float *robot_spheres, const float *link_masses_com,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map,
+    const int16_t *tool_frame_map, const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const int16_t *joint_links_data,
+    const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
+    const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames,
+    int write_global_cumul, int compute_com, curobo_hip_stream_t stream) {
+  FkArgs a{};
+  a.link_pos = link_pos; a.link_quat = link_quat; a.spheres_out = batch_robot_spheres;
+  a.com_out = batch_center_of_mass; a.jacobian_out = batch_jacobian; a.cumul_out = global_cumul_mat;
+  a.q = joint_vec; a.fixed_transform = fixed_transform; a.robot_spheres = robot_spheres;
+  a.link_masses_com = link_masses_com; a.joint_map_type = joint_map_type; a.joint_map = joint_map;
+  a.link_map = link_map; a.tool_frame_map = tool_frame_map; a.link_sphere_map = link_sphere_map;
+  a.link_chain_data = link_chain_data; a.link_chain_offsets = link_chain_offsets;
+  a.joint_links_data = joint_links_data; a.joint_links_offsets = joint_links_offsets;
+  a.joint_affects_endeffector = joint_affects_endeffector; a.joint_offset = joint_offset_map;
+  a.env_query_idx = env_query_idx;
+  a.n_points = batch_size; a.horizon = horizon; a.nspheres = num_spheres; a.num_envs = num_envs;
+  a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
+  return fk_forward_dispatch(a, num_spheres > 0, true, compute_com != 0, write_global_cumul != 0,
+                             (hipStream_t)stream, "launch_kinematics_forward_spheres_jacobian");
+}
+
+CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
+    float *grad_out, const float *grad_nlinks_pos, const float *grad_nlinks_quat,
+    const float *grad_spheres, const float *grad_spheres_b, const float *grad_center_of_mass,
+    const float *batch_center_of_mass, const float *grad_jacobian, const float *global_cumul_mat,
+    const float *robot_spheres, const float *link_masses_com, const int16_t *link_map,
+    const int16_t *joint_map, const int8_t *joint_map_type, const int16_t *tool_frame_map,
+    const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const int16_t *joint_links_data,
+    const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
+    const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int compute_com,
+    int compute_jacobian_grad, curobo_hip_stream_t stream) {
+  (void)grad_jacobian; (void)link_map; (void)joint_links_data; (void)joint_links_offsets;
+  (void)joint_affects_endeffector;
+  const char *what = "launch_kinematics_backward";
+  CUROBO_REQUIRE(!compute_jacobian_grad, "%s: compute_jacobian_grad is not supported by the HIP backend yet", what);
+  CUROBO_REQUIRE(num_links >= 1 && num_links <= 128, "%s: num_links=%d out of range [1,128]", what, num_links);
+  CUROBO_REQUIRE(n_joints >= 1 && n_joints <= 1024, "%s: n_joints=%d out of range", what, n_joints);
+  CUROBO_REQUIRE(((uintptr_t)grad_nlinks_quat & 15) == 0, "%s: grad_nlinks_quat is not aligned to 16 bytes", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  FkBwdArgs a{};
+  a.grad_q = grad_out; a.grad_link_pos = grad_nlinks_pos; a.grad_link_quat = grad_nlinks_quat;
+  a.grad_spheres = grad_spheres; a.grad_spheres_b = grad_spheres_b; a.grad_com = grad_center_of_mass;
+  a.batch_com = batch_center_of_mass; a.cumul_in = global_cumul_mat; a.robot_spheres = robot_spheres;
+  a.link_masses_com = link_masses_com; a.joint_map_type = joint_map_type; a.joint_map = joint_map;
+  a.tool_frame_map = tool_frame_map; a.link_sphere_map = link_sphere_map;
+  a.link_chain_data = link_chain_data; a.link_chain_offsets = link_chain_offsets;
+  a.joint_offset = joint_offset_map; a.env_query_idx = env_query_idx;
+  a.n_points = batch_size; a.horizon = horizon; a.nspheres = grad_spheres ? num_spheres : 0;
+  a.num_envs = num_envs; a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
+  a.dpad = n_joints | 1;  // odd row stride: conflict-free column reads
+  int pts = fk_points_per_block(num_links);
+  size_t lds = 0;
+  for (;;) {
+    lds = ((size_t)pts * num_links * 12 + (size_t)pts * kFkLanes * a.dpad) * sizeof(float);
+    if (lds <= 60 * 1024 || pts == 4) break;
+    pts /= 2;
+  }
+  CUROBO_REQUIRE(lds <= 64 * 1024, "%s: robot too large for the LDS tiling (%zu bytes)", what, lds);
+  const int threads = pts * kFkLanes;
+  const int blocks = ceil_div(batch_size, threads / kFkLanes);
+  if (compute_com)
+    hipLaunchKernelGGL((fk_backward_kernel<true>), dim3(blocks), dim3(threads), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((fk_backward_kernel<false>), dim3(blocks), dim3(threads), lds, (hipStream_t)stream, a);
+  return check_launch(what, (hipStream_t)stream);
+}

@@ -1,0 +1,315 @@
+// optimization.hip -- fused L-BFGS direction update and Wolfe line search bookkeeping, plus the
+// per-trajectory cost reduction used by the rollout.
+// Reference: kernels/optimization/lbfgs/lbfgs_step_kernel.cuh:18-199 (+ lbfgs_step_helpers.cuh),
+// kernels/optimization/line_search/line_search_kernel.cuh:27-155 (+ line_search_helpers.cuh),
+// rollout/metrics.py:233-265 / util/tensor_util.py:104 (cat_sum).
+//
+// gfx950 design: the reference gives one problem to one CUDA block of V threads and pays
+// 2m+2 block-wide reductions (shared memory + __syncthreads each).  On CDNA4 a problem is owned
+// by ONE wavefront: each lane keeps ceil(V/64) components of the running vector in registers,
+// every dot product is a wave64 butterfly (no LDS, no barrier), and 4 problems share a
+// 256-thread workgroup so that 256 problems still fill 64 CUs.  History rows are streamed from
+// L2 in [m][B][V] order (coalesced 256 B per wave-instruction); the shift-by-one of the
+// history is done in the same pass that reads it, as in the reference.
+#include "common.hpp"
+
+namespace curobo_hip {
+
+constexpr int kMaxVPL = 16;  // components per lane -> v_dim <= 1024 (reference: V < 1024)
+
+struct LbfgsArgs {
+  float *step_vec, *rho_buffer, *y_buffer, *s_buffer;
+  const float *q, *grad_q;
+  float *x_0, *grad_0;
+  float epsilon;
+  int batch, m, v_dim, stable_mode;
+};
+
+template <int VPL>
+__global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= a.batch) return;  // whole wave exits together
+  const int V = a.v_dim, m = a.m, B = a.batch;
+  const size_t bv = (size_t)b * V;
+  const size_t hist_stride = (size_t)B * V;
+  float gq[VPL], y[VPL], s[VPL];
+  float part = 0.0f;
+  // ---- load state, form (y, s), update (x_0, grad_0): lbfgs_step_helpers.cuh:37-70
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    gq[e] = y[e] = s[e] = 0.0f;
+    if (v < V) {
+      const float g = a.grad_q[bv + v], x = a.q[bv + v];
+      y[e] = g - a.grad_0[bv + v];
+      s[e] = x - a.x_0[bv + v];
+      a.grad_0[bv + v] = g;
+      a.x_0[bv + v] = x;
+      gq[e] = g;
+      part += y[e] * s[e];
+    }
+  }
+  const float numerator = wave_sum(part);
+  // ---- shift history by one and append (y, s): :89-150; rho likewise: :213-240
+  for (int i = 0; i < m - 1; i++) {
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      if (v < V) {
+        a.y_buffer[i * hist_stride + bv + v] = a.y_buffer[(i + 1) * hist_stride + bv + v];
+        a.s_buffer[i * hist_stride + bv + v] = a.s_buffer[(i + 1) * hist_stride + bv + v];
+      }
+    }
+  }
+  if (m > 0) {
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      if (v < V) {
+        a.y_buffer[(size_t)(m - 1) * hist_stride + bv + v] = y[e];
+        a.s_buffer[(size_t)(m - 1) * hist_stride + bv + v] = s[e];
+      }
+    }
+  }
+  // rho: lanes 0..m-1 each own one history slot (m <= 31 < 64)
+  float rho_mine = 0.0f;
+  if (lane < m) {
+    if (lane < m - 1) rho_mine = a.rho_buffer[(size_t)(lane + 1) * B + b];
+    else {
+      rho_mine = 1.0f / numerator;
+      if (a.stable_mode && numerator <= 0.0f) rho_mine = 0.0f;
+    }
+    a.rho_buffer[(size_t)lane * B + b] = rho_mine;
+  }
+  // ---- two-loop recursion.  alpha_i lives in lane i.
+  float alpha_mine = 0.0f;
+  for (int i = m - 1; i >= 0; i--) {  // backward pass, :262-330
+    float d = 0.0f;
+    float yi[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      yi[e] = 0.0f;
+      if (v < V) {
+        d += gq[e] * a.s_buffer[i * hist_stride + bv + v];
+        yi[e] = a.y_buffer[i * hist_stride + bv + v];
+      }
+    }
+    d = wave_sum(d);
+    const float alpha = d * __shfl(rho_mine, i, kWave);
+    if (lane == i) alpha_mine = alpha;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * yi[e];
+  }
+  if (m > 0) {  // scaling gamma = relu(s.y / y.y), :346-373
+    float d = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) d += y[e] * y[e];
+    d = wave_sum(d);
+    float var1 = numerator / d;
+    if (a.stable_mode && (isinf(var1) || isnan(var1))) var1 = a.epsilon;
+    const float gamma = var1 < 0.0f ? 0.0f : var1;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) gq[e] = gamma * gq[e];
+  }
+  for (int i = 0; i < m; i++) {  // forward pass, :396-470
+    float d = 0.0f;
+    float si[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      si[e] = 0.0f;
+      if (v < V) {
+        d += gq[e] * a.y_buffer[i * hist_stride + bv + v];
+        si[e] = a.s_buffer[i * hist_stride + bv + v];
+      }
+    }
+    d = wave_sum(d);
+    const float beta = __shfl(alpha_mine, i, kWave) - d * __shfl(rho_mine, i, kWave);
+#pragma unroll
+    for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * si[e];
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    if (v < V) a.step_vec[bv + v] = -gq[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct LineSearchArgs {
+  float *best_cost, *best_action;
+  int16_t *best_iteration, *current_iteration;
+  uint8_t *converged;
+  int convergence_iteration;
+  float cost_delta_threshold, cost_relative_threshold;
+  float *exploration_cost, *exploration_action, *exploration_gradient;
+  int32_t *exploration_idx;
+  float *selected_cost, *selected_action, *selected_gradient;
+  int32_t *selected_idx;
+  const float *search_cost, *search_action, *search_gradient, *step_direction, *search_magnitudes;
+  float c_1, c_2;
+  int strong_wolfe, approx_wolfe, n_linesearch, opt_dim, batch;
+};
+
+__global__ void __launch_bounds__(256) line_search_kernel(const LineSearchArgs a) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= a.batch) return;
+  const int V = a.opt_dim, NLS = a.n_linesearch;
+  const float *dir = a.step_direction + (size_t)b * V;
+  // g_k . d for every candidate; lane k keeps the k-th value (NLS <= 64)
+  float gd_mine = 0.0f, gd0 = 0.0f;
+  for (int k = 0; k < NLS; k++) {
+    const float *g = a.search_gradient + ((size_t)b * NLS + k) * V;
+    float d = 0.0f;
+    for (int v = lane; v < V; v += kWave) d += g[v] * dir[v];
+    d = wave_sum(d);
+    if (k == 0) gd0 = d;
+    if (lane == k) gd_mine = d;
+  }
+  // evaluate_wolfe_conditions (line_search_helpers.cuh:262-312), one candidate per lane
+  bool w1 = false, wboth = false;
+  const float c0 = a.search_cost[(size_t)b * NLS];
+  if (lane < NLS) {
+    const float alpha = a.search_magnitudes[lane];
+    const float cv = a.search_cost[(size_t)b * NLS + lane];
+    w1 = cv <= (c0 + a.c_1 * alpha * gd0);
+    const bool w2 = a.strong_wolfe ? (fabsf(gd_mine) <= a.c_2 * fabsf(gd0)) : (gd_mine >= a.c_2 * gd0);
+    wboth = w1 && w2;
+  }
+  // compute_wolfe_indices (:62-95): LARGEST candidate index that passes, 0 if none.
+  // wave64 ballot + count-leading-zeros replaces the reference's 32-bit ballot/brev/ffs.
+  const unsigned long long m1 = __ballot(w1), mb = __ballot(wboth);
+  const int id1 = m1 ? 63 - __clzll((long long)m1) : 0;
+  const int id = mb ? 63 - __clzll((long long)mb) : 0;
+  const int sel = a.strong_wolfe ? id : (id == 0 ? id1 : id);  // get_linesearch_idx (:46-60)
+  const int expl = (a.approx_wolfe && !a.strong_wolfe && sel == 0) ? 1 : sel;
+  // update_costs_and_convergence (:97-150), computed redundantly by every lane (uniform)
+  const float sc = a.search_cost[(size_t)b * NLS + sel];
+  const float bc = a.best_cost[b];
+  const int cur = (int)a.current_iteration[b] + 1;
+  int bi = a.best_iteration[b];
+  const float delta = bc - sc;
+  const float rel = delta / (bc + 1e-6f);
+  const bool update_best = delta > a.cost_delta_threshold && rel > a.cost_relative_threshold;
+  if (update_best) bi = cur;
+  __builtin_amdgcn_wave_barrier();  // all lanes have read the old state before lane 0 rewrites it
+  if (lane == 0) {
+    a.exploration_cost[b] = a.search_cost[(size_t)b * NLS + expl];
+    a.selected_cost[b] = sc;
+    a.converged[b] = (bi + a.convergence_iteration < cur) ? 1 : 0;
+    a.best_iteration[b] = (int16_t)bi;
+    a.current_iteration[b] = (int16_t)cur;
+    if (update_best) a.best_cost[b] = sc;
+  }
+  // copy_action_gradient_results (:152-198)
+  const size_t es = ((size_t)b * NLS + expl) * V, ss = ((size_t)b * NLS + sel) * V, o = (size_t)b * V;
+  for (int v = lane; v < V; v += kWave) {
+    a.exploration_action[o + v] = a.search_action[es + v];
+    a.exploration_gradient[o + v] = a.search_gradient[es + v];
+    const float av = a.search_action[ss + v];
+    a.selected_action[o + v] = av;
+    a.selected_gradient[o + v] = a.search_gradient[ss + v];
+    if (update_best) a.best_action[o + v] = av;
+  }
+  if (lane < NLS) {
+    a.exploration_idx[(size_t)b * NLS + lane] = expl;
+    a.selected_idx[(size_t)b * NLS + lane] = sel;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-trajectory cost sum: one wavefront per trajectory, wave64 shuffle reduction.
+__global__ void __launch_bounds__(256) trajectory_cost_sum_kernel(float *out, const float *self_cost,
+                                                                  const float *scene_cost, int batch,
+                                                                  int horizon, int nspheres) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= batch) return;
+  float acc = 0.0f;
+  if (scene_cost) {
+    const size_t n = (size_t)horizon * nspheres;
+    const float *src = scene_cost + (size_t)b * n;
+    if ((n & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+      const float4 *s4 = reinterpret_cast<const float4 *>(src);
+      for (size_t i = lane; i < n / 4; i += kWave) {
+        const float4 v = s4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (size_t i = lane; i < n; i += kWave) acc += src[i];
+    }
+  }
+  if (self_cost)
+    for (int h = lane; h < horizon; h += kWave) acc += self_cost[(size_t)b * horizon + h];
+  acc = wave_sum(acc);
+  if (lane == 0) out[b] = acc;
+}
+
+}  // namespace curobo_hip
+
+using namespace curobo_hip;
+
+CUROBO_EXPORT int curobo_hip_launch_lbfgs_step(
+    float *step_vec, float *rho_buffer, float *y_buffer, float *s_buffer, const float *q,
+    const float *grad_q, float *x_0, float *grad_0, float epsilon, int batch_size, int history_m,
+    int v_dim, int stable_mode, int use_shared_buffers, curobo_hip_stream_t stream) {
+  (void)use_shared_buffers;
+  const char *what = "launch_lbfgs_step";
+  // reference cuda_core_backend/optimization.py:185-188 and optim/gradient/lbfgs.py:177
+  CUROBO_REQUIRE(history_m <= 31, "%s: History_m greater than 31 is not supported", what);
+  CUROBO_REQUIRE(history_m >= 0, "%s: History_m less than 0 is not supported", what);
+  CUROBO_REQUIRE(v_dim >= 1 && v_dim <= kWave * kMaxVPL, "%s: v_dim=%d out of range [1,%d]", what, v_dim, kWave * kMaxVPL);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  LbfgsArgs a{step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0,
+              epsilon, batch_size, history_m, v_dim, stable_mode};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)ceil_div(batch_size, 4)), block(256);
+  const int vpl = ceil_div(v_dim, kWave);
+  if (vpl <= 1) hipLaunchKernelGGL((lbfgs_step_kernel<1>), grid, block, 0, st, a);
+  else if (vpl <= 2) hipLaunchKernelGGL((lbfgs_step_kernel<2>), grid, block, 0, st, a);
+  else if (vpl <= 4) hipLaunchKernelGGL((lbfgs_step_kernel<4>), grid, block, 0, st, a);
+  else if (vpl <= 8) hipLaunchKernelGGL((lbfgs_step_kernel<8>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((lbfgs_step_kernel<16>), grid, block, 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_launch_line_search(
+    float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
+    uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
+    float cost_relative_threshold, float *exploration_cost, float *exploration_action,
+    float *exploration_gradient, int32_t *exploration_idx, float *selected_cost,
+    float *selected_action, float *selected_gradient, int32_t *selected_idx,
+    const float *search_cost, const float *search_action, const float *search_gradient,
+    const float *step_direction, const float *search_magnitudes, float armijo_threshold_c_1,
+    float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
+    int opt_dim, int batchsize, curobo_hip_stream_t stream) {
+  const char *what = "launch_line_search";
+  CUROBO_REQUIRE(n_linesearch >= 1 && n_linesearch <= kWave, "%s: n_linesearch=%d out of range [1,64]", what, n_linesearch);
+  CUROBO_REQUIRE(opt_dim >= 1, "%s: opt_dim must be >= 1", what);
+  if (batchsize == 0) return CUROBO_HIP_OK;
+  LineSearchArgs a{best_cost, best_action, best_iteration, current_iteration, converged_global,
+                   convergence_iteration, cost_delta_threshold, cost_relative_threshold,
+                   exploration_cost, exploration_action, exploration_gradient, exploration_idx,
+                   selected_cost, selected_action, selected_gradient, selected_idx,
+                   search_cost, search_action, search_gradient, step_direction, search_magnitudes,
+                   armijo_threshold_c_1, curvature_threshold_c_2, strong_wolfe, approx_wolfe,
+                   n_linesearch, opt_dim, batchsize};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(line_search_kernel, dim3((unsigned)ceil_div(batchsize, 4)), dim3(256), 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_trajectory_cost_sum(float *out_cost, const float *self_cost,
+                                                 const float *scene_cost, int batch_size, int horizon,
+                                                 int num_spheres, curobo_hip_stream_t stream) {
+  const char *what = "trajectory_cost_sum";
+  CUROBO_REQUIRE(horizon >= 1 && num_spheres >= 0, "%s: bad horizon/num_spheres", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(trajectory_cost_sum_kernel, dim3((unsigned)ceil_div(batch_size, 4)), dim3(256), 0, st,
+                     out_cost, self_cost, scene_cost, batch_size, horizon, num_spheres);
+  return check_launch(what, st);
+}

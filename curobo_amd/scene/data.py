@@ -1,0 +1,112 @@
+"""World obstacle stores in the layout the collision kernels read.
+
+Mirrors the tensor layouts of the reference's ``CuboidData`` (``curobo/_src/geom/data/data_cuboid.py``
+``:67-108``: ``dims [E,n,4]`` full extents, ``inv_pose [E,n,8]`` = x y z qw qx qy qz pad,
+``enable u8 [E,n]``, ``count i32 [E]``) and ``VoxelData`` (``geom/data/data_voxel.py:42-95``:
+``params [E,n,4]`` = nx ny nz voxel_size, ``features fp16 [E,n,nvox]``).  Arrays are built with
+numpy (shared by the oracle tests) and uploaded once; the hot path only reads them.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def _quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+    ])
+
+
+def _quat_rotate(q, v):
+    w, x, y, z = q
+    qv = np.array([x, y, z])
+    t = 2.0 * np.cross(qv, v)
+    return v + w * t + np.cross(qv, t)
+
+
+def inverse_pose7(pose7: Sequence[float]) -> np.ndarray:
+    """[x y z qw qx qy qz] -> inverse pose in the same layout (world->obstacle frame)."""
+    p = np.asarray(pose7[:3], dtype=np.float64)
+    q = np.asarray(pose7[3:7], dtype=np.float64)
+    q = q / np.linalg.norm(q)
+    qi = np.array([q[0], -q[1], -q[2], -q[3]])
+    pi = -_quat_rotate(qi, p)
+    return np.concatenate([pi, qi])
+
+
+def cuboid_scene_arrays(envs: List[List[Dict]], max_n: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """``envs[e]`` = list of ``{"dims": [x,y,z], "pose": [x,y,z,qw,qx,qy,qz], "enable": bool}``."""
+    E = len(envs)
+    n = max_n or max(1, max(len(e) for e in envs))
+    dims = np.zeros((E, n, 4), np.float32)
+    inv_pose = np.zeros((E, n, 8), np.float32)
+    inv_pose[..., 3] = 1.0
+    enable = np.zeros((E, n), np.uint8)
+    count = np.zeros((E,), np.int32)
+    for e, obs in enumerate(envs):
+        count[e] = len(obs)
+        for i, o in enumerate(obs):
+            dims[e, i, :3] = o["dims"]
+            inv_pose[e, i, :7] = inverse_pose7(o["pose"])
+            enable[e, i] = 1 if o.get("enable", True) else 0
+    return {"cuboid_dims": dims, "cuboid_inv_pose": inv_pose, "cuboid_enable": enable, "cuboid_count": count}
+
+
+def voxel_grid_from_sdf(sdf_fn: Callable[[np.ndarray], np.ndarray], grid_shape: Sequence[int],
+                        voxel_size: float, pose7: Sequence[float] = (0, 0, 0, 1, 0, 0, 0),
+                        max_distance: float = 10000.0) -> Dict[str, np.ndarray]:
+    """One fp16 ESDF grid sampled at voxel centres (align-corners convention of the reference:
+    voxel (i,j,k) centre = ((i,j,k) + 0.5 - n/2) * voxel_size in the grid frame)."""
+    nx, ny, nz = [int(v) for v in grid_shape]
+    ax = [(np.arange(n) + 0.5 - n / 2.0) * voxel_size for n in (nx, ny, nz)]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    pts_local = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    # the field is defined in world coordinates; grid frame -> world
+    q = np.asarray(pose7[3:7], dtype=np.float64)
+    q = q / np.linalg.norm(q)
+    pts_world = np.stack([_quat_rotate(q, p) for p in pts_local]) + np.asarray(pose7[:3]) \
+        if not np.allclose(q, [1, 0, 0, 0]) else pts_local + np.asarray(pose7[:3])
+    vals = sdf_fn(pts_world).astype(np.float16).reshape(1, 1, -1)
+    params = np.array([[[nx, ny, nz, voxel_size]]], np.float32)
+    inv_pose = np.zeros((1, 1, 8), np.float32)
+    inv_pose[0, 0, :7] = inverse_pose7(pose7)
+    return {
+        "voxel_params": params, "voxel_inv_pose": inv_pose, "voxel_enable": np.ones((1, 1), np.uint8),
+        "voxel_count": np.ones((1,), np.int32), "voxel_features": vals,
+        "voxel_max_distance": float(max_distance),
+    }
+
+
+@dataclass
+class SceneData:
+    """Device-resident scene; ``.struct`` is the ``curobo_hip_scene`` passed to the kernels."""
+
+    tensors: Dict[str, "object"]
+    struct: "object"
+    arrays: Dict[str, np.ndarray]
+
+    @staticmethod
+    def from_arrays(arrays: Dict[str, np.ndarray], device) -> "SceneData":
+        import torch
+
+        from ..backends.collision import make_scene
+
+        t = {}
+        for k, v in arrays.items():
+            if isinstance(v, np.ndarray):
+                t[k] = torch.as_tensor(v).to(device).contiguous()
+        struct = make_scene(
+            t.get("cuboid_dims"), t.get("cuboid_inv_pose"), t.get("cuboid_enable"), t.get("cuboid_count"),
+            t.get("voxel_params"), t.get("voxel_inv_pose"), t.get("voxel_enable"), t.get("voxel_count"),
+            t.get("voxel_features"), float(arrays.get("voxel_max_distance", 10000.0)),
+        )
+        return SceneData(tensors=t, struct=struct, arrays=arrays)

@@ -1,0 +1,200 @@
+/*
+ * curobo_hip.h -- C ABI of libcurobo_hip.so, the MI355X (gfx950) kernel backend for cuRobo's
+ * batched motion-generation hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one module-level launch function of
+ * the reference's kernel backend (curobo/_src/curobolib/backends/__init__.py:162-227; the two
+ * existing backends are cuda_core_backend/ (Python) and pybind/ (C++ bindings)).  Argument order and
+ * meaning follow the reference function that each entry point cites; torch.Tensor arguments
+ * become raw device pointers, and one trailing `stream` (hipStream_t, may be NULL = default
+ * stream) replaces the reference's implicit torch.cuda.current_stream() lookup
+ * (cuda_core_backend/kinematics.py:50-51).
+ *
+ * Contract (same as the reference):
+ *   - the caller owns all memory; every output is pre-allocated and mutated in place;
+ *   - no allocation, no host synchronisation and no host read of device data happens inside a
+ *     launch, so every entry point is hipGraph-capturable;
+ *   - tensors are contiguous, fp32 unless stated; index tables int16 / int8 / int32 / uint8;
+ *   - return value: 0 on success, non-zero on error; curobo_hip_last_error() returns a
+ *     thread-local message (the reference raises via log_and_raise; the Python shim in
+ *     curobo_amd/backends converts the status to the same exception types).
+ */
+#ifndef CUROBO_HIP_H
+#define CUROBO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *curobo_hip_stream_t; /* hipStream_t */
+
+#define CUROBO_HIP_OK 0
+#define CUROBO_HIP_ERR_INVALID 1 /* bad argument (reference: ValueError / RuntimeError) */
+#define CUROBO_HIP_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after a launch */
+
+const char *curobo_hip_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int curobo_hip_abi_version(void);
+/* when non-zero every launch is followed by hipStreamSynchronize + error check
+ * (reference runtime.debug, cuda_core_backend/launch_helper.py:13-19). */
+void curobo_hip_set_debug_sync(int enabled);
+
+/* ---------------------------------------------------------------- kinematics
+ * reference: cuda_core_backend/kinematics.py:21-379, pybind/kinematics_bindings.cpp:128-237
+ * kernels:   kernels/kinematics/kinematics_forward_kernel.cuh:20-433,
+ *            kernels/kinematics/kinematics_backward_kernel.cuh:27-157
+ * batch_size is the number of points N = batch * horizon (cuda_ops/kinematics.py:113).
+ */
+/* replaces launch_kinematics_forward (cuda_core_backend/kinematics.py:21-88) */
+int curobo_hip_launch_kinematics_forward(
+    float *link_pos, float *link_quat, float *batch_center_of_mass, float *global_cumul_mat,
+    const float *joint_vec, const float *fixed_transform, const float *link_masses_com,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map,
+    const int16_t *tool_frame_map, const float *joint_offset_map, int batch_size, int horizon,
+    int n_joints, int num_links, int n_tool_frames, int compute_com, curobo_hip_stream_t stream);
+
+/* replaces launch_kinematics_forward_spheres (cuda_core_backend/kinematics.py:91-190) */
+int curobo_hip_launch_kinematics_forward_spheres(
+    float *link_pos, float *link_quat, float *batch_robot_spheres, float *batch_center_of_mass,
+    float *global_cumul_mat, const float *joint_vec, const float *fixed_transform,
+    const float *robot_spheres, const float *link_masses_com, const int8_t *joint_map_type,
+    const int16_t *joint_map, const int16_t *link_map, const int16_t *tool_frame_map,
+    const int16_t *link_sphere_map, const float *joint_offset_map, const int32_t *env_query_idx,
+    int num_envs, int batch_size, int horizon, int n_joints, int num_spheres, int num_links,
+    int n_tool_frames, int write_global_cumul, int compute_com, curobo_hip_stream_t stream);
+
+/* replaces launch_kinematics_forward_spheres_jacobian (cuda_core_backend/kinematics.py:193-300) */
+int curobo_hip_launch_kinematics_forward_spheres_jacobian(
+    float *link_pos, float *link_quat, float *batch_robot_spheres, float *batch_center_of_mass,
+    float *batch_jacobian, float *global_cumul_mat, const float *joint_vec,
+    const float *fixed_transform, const float *robot_spheres, const float *link_masses_com,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map,
+    const int16_t *tool_frame_map, const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const int16_t *joint_links_data,
+    const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
+    const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames,
+    int write_global_cumul, int compute_com, curobo_hip_stream_t stream);
+
+/* replaces launch_kinematics_backward (cuda_core_backend/kinematics.py:303-379).
+ * grad_spheres_b (extension, may be NULL): a second sphere-gradient buffer that is added to
+ * grad_spheres on the fly, so the self-collision and scene-collision gradient buffers can be
+ * consumed without a separate elementwise add.  compute_jacobian_grad != 0 is rejected
+ * (CUROBO_HIP_ERR_INVALID): the dJ/dq term is a SURVEY section 8f-2 "next" row. */
+int curobo_hip_launch_kinematics_backward(
+    float *grad_out, const float *grad_nlinks_pos, const float *grad_nlinks_quat,
+    const float *grad_spheres, const float *grad_spheres_b, const float *grad_center_of_mass,
+    const float *batch_center_of_mass, const float *grad_jacobian, const float *global_cumul_mat,
+    const float *robot_spheres, const float *link_masses_com, const int16_t *link_map,
+    const int16_t *joint_map, const int8_t *joint_map_type, const int16_t *tool_frame_map,
+    const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const int16_t *joint_links_data,
+    const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
+    const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int compute_com,
+    int compute_jacobian_grad, curobo_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- geometry: self collision
+ * reference: cuda_core_backend/geometry.py:63-227, pybind/geometry_bindings.cpp:16-45
+ * kernels:   kernels/geometry/self_collision/self_collision_kernel.cuh:19-297
+ * num_blocks_per_batch / max_threads_per_block are accepted for signature parity; the HIP
+ * backend picks its own wave64 tiling (block_batch_max_* scratch is used when it splits the
+ * pair list across workgroups).
+ */
+int curobo_hip_self_collision_distance(
+    float *out_distance, float *out_vec, float *pair_distance, uint8_t *sparse_index,
+    const float *robot_spheres, const float *sphere_padding, const float *weight,
+    const int16_t *pair_locations, float *block_batch_max_value, int16_t *block_batch_max_index,
+    int num_blocks_per_batch, int max_threads_per_block, int batch_size, int horizon, int nspheres,
+    int num_collision_pairs, int store_pair_distance, int compute_grad,
+    curobo_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- collision: sphere vs scene
+ * The reference has NO backend hook here: these are NVIDIA Warp kernels launched from
+ * geom/collision/wp_autograd.py:37-249 (SphereObstacleCollision / SweptSphereObstacleCollision).
+ * The struct mirrors CuboidDataWarp (geom/data/data_cuboid.py:43-62) and VoxelDataWarp
+ * (geom/data/data_voxel.py:684-702).  One launch handles every obstacle type, sums the
+ * obstacles of a sphere in index order (deterministic; the reference uses float atomics) and
+ * fully rewrites distance/gradient (no separate zero_() pass).
+ */
+typedef struct curobo_hip_scene {
+  const float *cuboid_dims;       /* [num_envs, max_cuboids, 4] full extents */
+  const float *cuboid_inv_pose;   /* [num_envs, max_cuboids, 8] x y z qw qx qy qz pad */
+  const uint8_t *cuboid_enable;   /* [num_envs, max_cuboids] */
+  const int32_t *cuboid_count;    /* [num_envs] */
+  int32_t max_cuboids;
+  const float *voxel_params;      /* [num_envs, max_voxel_grids, 4] nx ny nz voxel_size */
+  const float *voxel_inv_pose;    /* [num_envs, max_voxel_grids, 8] */
+  const uint8_t *voxel_enable;    /* [num_envs, max_voxel_grids] */
+  const int32_t *voxel_count;     /* [num_envs] */
+  const uint16_t *voxel_features; /* fp16 ESDF [num_envs, max_voxel_grids, n_voxels] */
+  int32_t max_voxel_grids;
+  int32_t voxel_n_voxels;
+  float voxel_max_distance;
+} curobo_hip_scene;
+
+/* sweep_steps: 0 = SphereObstacleCollision, 3 = SweptSphereObstacleCollision (SWEEP_STEPS,
+ * wp_sweep_collision_kernel.py:66).  enable_speed_metric applies wp_speed_metric.py:10-93 in
+ * the same launch; speed_dt is the reference's 1-element device tensor (may be NULL if off). */
+int curobo_hip_sphere_obstacle_collision(
+    float *distance, float *gradient, const float *spheres, const curobo_hip_scene *scene,
+    const float *weight, const float *activation_distance, const int32_t *env_query_idx,
+    int batch_size, int horizon, int num_spheres, int use_multi_env, int sweep_steps,
+    int enable_speed_metric, const float *speed_dt, curobo_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- trajectory: B-spline
+ * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142
+ * kernels:   kernels/trajectory/bspline/bspline_kernel.cuh:81-151,332-380
+ * `horizon` of the forward launch is the padded horizon (out_position.shape[1]).
+ */
+int curobo_hip_launch_bspline_interpolation_forward_kernel(
+    float *out_position, float *out_velocity, float *out_acceleration, float *out_jerk,
+    float *out_dt, const float *u_position, const float *start_position,
+    const float *start_velocity, const float *start_acceleration, const float *start_jerk,
+    const float *goal_position, const float *goal_velocity, const float *goal_acceleration,
+    const float *goal_jerk, const int32_t *start_idx, const int32_t *goal_idx,
+    const float *traj_dt, const uint8_t *use_implicit_goal_state, int batch_size, int horizon,
+    int dof, int n_knots, int bspline_degree, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_bspline_interpolation_backward_kernel(
+    float *out_grad_position, const float *grad_position, const float *grad_velocity,
+    const float *grad_acceleration, const float *grad_jerk, const float *traj_dt,
+    const int32_t *dt_idx, const uint8_t *use_implicit_goal_state, int batch_size,
+    int padded_horizon, int dof, int n_knots, int bspline_degree, int use_direct_polynomial,
+    curobo_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- optimization
+ * reference: cuda_core_backend/optimization.py:27-260, pybind/optimization_bindings.cpp:14-75
+ * kernels:   kernels/optimization/lbfgs/lbfgs_step_kernel.cuh:18-199,
+ *            kernels/optimization/line_search/line_search_kernel.cuh:27-155
+ */
+int curobo_hip_launch_lbfgs_step(
+    float *step_vec, float *rho_buffer, float *y_buffer, float *s_buffer, const float *q,
+    const float *grad_q, float *x_0, float *grad_0, float epsilon, int batch_size, int history_m,
+    int v_dim, int stable_mode, int use_shared_buffers, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_line_search(
+    float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
+    uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
+    float cost_relative_threshold, float *exploration_cost, float *exploration_action,
+    float *exploration_gradient, int32_t *exploration_idx, float *selected_cost,
+    float *selected_action, float *selected_gradient, int32_t *selected_idx,
+    const float *search_cost, const float *search_action, const float *search_gradient,
+    const float *step_direction, const float *search_magnitudes, float armijo_threshold_c_1,
+    float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
+    int opt_dim, int batchsize, curobo_hip_stream_t stream);
+
+/* ---------------------------------------------------------------- rollout glue
+ * Per-trajectory cost sum (reference rollout/metrics.py:233-265 + util/tensor_util.py:104:
+ * torch cat + sum): out[b] = sum_h( self_cost[b,h] + sum_s scene_cost[b,h,s] ), one wavefront
+ * per trajectory with a wave64 shuffle reduction.  Either input may be NULL. */
+int curobo_hip_trajectory_cost_sum(float *out_cost, const float *self_cost,
+                                   const float *scene_cost, int batch_size, int horizon,
+                                   int num_spheres, curobo_hip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUROBO_HIP_H */

@@ -1,0 +1,345 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances: FK poses / spheres / costs 1e-5 abs (north_star), gradients
+1e-4 rel-to-scale (different fp32 summation order), integer outputs exact."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model, sample_q
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def _kp(model, device):
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+
+    return KinematicsParams.from_model(model, device)
+
+
+def _fk_gpu(kp, q, horizon=1, jac=False, com=False, env_query_idx=None):
+    from curobo_amd.backends import kinematics as K
+
+    dev = kp.device
+    n, d = q.shape
+    T, S, L = kp.num_pose_links, kp.num_spheres, kp.num_links
+    qd = torch.as_tensor(q, device=dev)
+    o = dict(
+        link_pos=torch.zeros(n, T, 3, device=dev), link_quat=torch.zeros(n, T, 4, device=dev),
+        spheres=torch.zeros(n, S, 4, device=dev), com=torch.zeros(n, 4, device=dev),
+        jac=torch.zeros(n, T, 6, d, device=dev), cumul=torch.zeros(n, L, 3, 4, device=dev),
+    )
+    env = torch.zeros(max(n // horizon, 1), dtype=torch.int32, device=dev) if env_query_idx is None \
+        else torch.as_tensor(env_query_idx, device=dev)
+    if jac:
+        K.launch_kinematics_forward_spheres_jacobian(
+            o["link_pos"], o["link_quat"], o["spheres"], o["com"], o["jac"], o["cumul"], qd,
+            kp.fixed_transforms, kp.link_spheres, kp.link_masses_com, kp.joint_map_type, kp.joint_map,
+            kp.link_map, kp.tool_frame_map, kp.link_sphere_idx_map, kp.link_chain_data,
+            kp.link_chain_offsets, kp.joint_links_data, kp.joint_links_offsets,
+            kp.joint_affects_endeffector, kp.joint_offset_map, env, kp.num_envs, n, horizon, d, S, 32,
+            True, com)
+    else:
+        K.launch_kinematics_forward_spheres(
+            o["link_pos"], o["link_quat"], o["spheres"], o["com"], o["cumul"], qd, kp.fixed_transforms,
+            kp.link_spheres, kp.link_masses_com, kp.joint_map_type, kp.joint_map, kp.link_map,
+            kp.tool_frame_map, kp.link_sphere_idx_map, kp.joint_offset_map, env, kp.num_envs, n,
+            horizon, d, S, 32, True, com)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+@pytest.mark.parametrize("robot", ["franka", "ur10e", "unitree_g1"])
+@pytest.mark.parametrize("n", [1, 17, 1000])
+def test_fk_forward(robot, n, oracle, device):
+    model = load_model(robot)
+    kp = _kp(model, device)
+    q = sample_q(model, n, seed=n)
+    ref = oracle.kinematics_forward(q, model.as_dict(), compute_jacobian=True, compute_com=True)
+    got = _fk_gpu(kp, q, jac=True, com=True)
+    np.testing.assert_allclose(got["link_pos"], ref["link_pos"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got["link_quat"], ref["link_quat"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got["spheres"], ref["robot_spheres"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got["cumul"], ref["cumul_mat"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got["com"], ref["com"], atol=2e-5, rtol=1e-6)
+    np.testing.assert_allclose(got["jac"], ref["jacobian"], atol=ATOL, rtol=0)
+    # non-jacobian variant must agree bit-for-bit with the jacobian variant
+    got2 = _fk_gpu(kp, q, jac=False, com=False)
+    assert np.array_equal(got2["spheres"], got["spheres"])
+    assert np.array_equal(got2["link_quat"], got["link_quat"])
+
+
+def test_fk_known_answer(device):
+    """reference curobo/tests/_src/robot/kinematics/test_kinematics.py:57-82"""
+    model = load_model("franka")
+    kp = _kp(model, device)
+    got = _fk_gpu(kp, np.array([[0, -1.2, 0, -2, 0, 1, 0]], np.float32))
+    np.testing.assert_allclose(got["link_pos"][0, 0], [6.0860e-02, -4.7547e-12, 7.6373e-01], atol=1e-5)
+    np.testing.assert_allclose(got["link_quat"][0, 0], [0.0382, 0.9193, 0.3808, 0.0922], atol=1e-4)
+
+
+@pytest.mark.parametrize("robot", ["franka", "ur10e", "unitree_g1"])
+def test_fk_backward(robot, oracle, device):
+    from curobo_amd.backends import kinematics as K
+
+    model = load_model(robot)
+    kp = _kp(model, device)
+    n = 257
+    q = sample_q(model, n, seed=3)
+    fwd = oracle.kinematics_forward(q, model.as_dict(), compute_com=True)
+    rng = np.random.default_rng(1)
+    S, T, L, d = model.num_spheres, len(model.tool_frames), model.num_links, model.num_dof
+    g_s = rng.normal(size=(n, S, 4)).astype(np.float32)
+    g_s[rng.uniform(size=(n, S)) < 0.6] = 0.0  # sparse, like collision gradients
+    g_b = rng.normal(size=(n, S, 4)).astype(np.float32)
+    g_b[rng.uniform(size=(n, S)) < 0.8] = 0.0
+    g_p = rng.normal(size=(n, T, 3)).astype(np.float32)
+    g_q = rng.normal(size=(n, T, 4)).astype(np.float32)
+    g_c = rng.normal(size=(n, 4)).astype(np.float32)
+    ref = oracle.kinematics_backward(model.as_dict(), fwd["cumul_mat"], g_s + g_b * np.array([1, 1, 1, 0], np.float32),
+                                     g_p, g_q, g_c, fwd["com"])
+    dev = device
+    out = torch.zeros(n, d, device=dev)
+    env = torch.zeros(n, dtype=torch.int32, device=dev)
+    t = lambda a: torch.as_tensor(a, device=dev)  # noqa: E731
+    K.launch_kinematics_backward(
+        out, t(g_p), t(g_q), t(g_s), t(g_c), t(fwd["com"]), t(g_p), t(fwd["cumul_mat"]), kp.link_spheres,
+        kp.link_masses_com, kp.link_map, kp.joint_map, kp.joint_map_type, kp.tool_frame_map,
+        kp.link_sphere_idx_map, kp.link_chain_data, kp.link_chain_offsets, kp.joint_links_data,
+        kp.joint_links_offsets, kp.joint_affects_endeffector, kp.joint_offset_map, env, kp.num_envs, n, 1,
+        d, S, True, False, grad_spheres_b=t(g_b))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, atol=1e-5 * max(scale, 1.0), rtol=1e-4)
+
+
+@pytest.mark.parametrize("robot,n", [("franka", 515), ("ur10e", 64), ("unitree_g1", 33)])
+def test_self_collision(robot, n, oracle, device):
+    from curobo_amd.backends import geometry as G
+
+    model = load_model(robot)
+    kp = _kp(model, device)
+    q = sample_q(model, n, seed=5)
+    sph = oracle.kinematics_forward(q, model.as_dict())["robot_spheres"]
+    S, P = model.num_spheres, model.collision_pairs.shape[0]
+    dev = device
+    # stale state from a "previous call": flagged rows must be zeroed
+    stale_grad = np.zeros((n, S, 4), np.float32)
+    stale_flag = np.zeros((n, S), np.uint8)
+    stale_grad[:, 3] = 7.0
+    stale_flag[:, 3] = 1
+    ref = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 2.5,
+                                out_gradient=stale_grad.copy(), sparse_index=stale_flag.copy(),
+                                store_pair_distance=True)
+    out_d = torch.full((n, 1), -1.0, device=dev)
+    out_g = torch.as_tensor(stale_grad, device=dev)
+    flags = torch.as_tensor(stale_flag, device=dev)
+    pd = torch.zeros(n, P, device=dev)
+    w = torch.tensor([2.5], device=dev)
+    G.self_collision_distance(
+        out_d, out_g, pd, flags, torch.as_tensor(sph, device=dev), kp.self_collision.sphere_padding, w,
+        kp.self_collision.collision_pairs, torch.zeros(1, device=dev), torch.zeros(2, dtype=torch.int16, device=dev),
+        1, 256, n, 1, S, P, True, True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_d.cpu().numpy()[:, 0], ref["distance"], atol=ATOL, rtol=1e-5)
+    assert np.array_equal(flags.cpu().numpy(), ref["sparse_index"]), "collision-pair indices must be exact"
+    np.testing.assert_allclose(out_g.cpu().numpy(), ref["gradient"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(pd.cpu().numpy(), ref["pair_distance"], atol=ATOL, rtol=1e-5)
+    assert (ref["distance"] > 0).any(), "test inputs must contain self collisions"
+
+
+def _scene_arrays():
+    from curobo_amd.scene import cuboid_scene_arrays
+
+    c, s = np.cos(0.4), np.sin(0.4)
+    return cuboid_scene_arrays([[
+        {"dims": [2.2, 2.2, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]},
+        {"dims": [0.1, 0.1, 1.5], "pose": [0.45, 0.0, 0.3, 1, 0, 0, 0]},
+        {"dims": [0.3, 0.4, 0.5], "pose": [0.3, 0.5, 0.4, c, 0, 0, s]},
+        {"dims": [0.2, 0.2, 0.2], "pose": [-0.4, -0.3, 0.6, c, s, 0, 0], "enable": False},
+        {"dims": [0.5, 0.1, 0.6], "pose": [0.1, -0.5, 0.5, c, 0, s, 0]},
+    ]])
+
+
+@pytest.mark.parametrize("sweep,speed", [(False, False), (True, False), (True, True)])
+def test_scene_collision_cuboids(sweep, speed, oracle, device):
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData
+
+    model = load_model("franka")
+    b, h = 24, 9
+    rng = np.random.default_rng(9)
+    q0 = sample_q(model, b, seed=11)[:, None, :]
+    q1 = sample_q(model, b, seed=12)[:, None, :]
+    tt = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    q = (q0 * (1 - tt) + q1 * tt).reshape(b * h, -1) * 0.6
+    sph = oracle.kinematics_forward(q, model.as_dict(), horizon=h)["robot_spheres"].reshape(b, h, -1, 4)
+    arrays = _scene_arrays()
+    ref = oracle.scene_collision(sph, arrays, 3.0, 0.03, sweep=sweep, enable_speed_metric=speed, speed_dt=0.05)
+    scene = SceneData.from_arrays(arrays, device)
+    S = sph.shape[2]
+    dist = torch.full((b, h, S), 5.0, device=device)
+    grad = torch.full((b, h, S, 4), 5.0, device=device)
+    Cn.sphere_obstacle_collision(
+        dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([3.0], device=device),
+        torch.tensor([0.03], device=device), torch.zeros(b, dtype=torch.int32, device=device), b, h, S,
+        False, 3 if sweep else 0, speed, torch.tensor([0.05], device=device))
+    torch.cuda.synchronize()
+    assert (ref["distance"] > 0).mean() > 0.02
+    np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref["gradient"], atol=2e-4, rtol=1e-3)
+
+
+def test_scene_collision_voxels(oracle, device):
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData, voxel_grid_from_sdf
+
+    def sdf(p):  # union of a box and a sphere
+        qb = np.abs(p - np.array([0.4, 0.0, 0.3])) - np.array([0.15, 0.3, 0.3])
+        box = np.linalg.norm(np.maximum(qb, 0), axis=-1) + np.minimum(qb.max(-1), 0)
+        sp = np.linalg.norm(p - np.array([-0.3, 0.4, 0.5]), axis=-1) - 0.2
+        return np.minimum(box, sp)
+
+    model = load_model("ur10e")
+    arrays = voxel_grid_from_sdf(sdf, (48, 40, 44), 0.04, pose7=(0.05, -0.02, 0.4, 1, 0, 0, 0), max_distance=100.0)
+    b, h = 16, 8
+    q = sample_q(model, b * h, seed=21)
+    sph = oracle.kinematics_forward(q, model.as_dict(), horizon=h)["robot_spheres"].reshape(b, h, -1, 4)
+    sph[0, 0, 0, :3] = [5.0, 5.0, 5.0]  # far outside the grid: boundary path
+    sph[0, 0, 1, :3] = [0.05 + 0.95, -0.02, 0.4]  # straddles the grid face
+    ref = oracle.scene_collision(sph, arrays, 1.0, 0.05, sweep=True)
+    scene = SceneData.from_arrays(arrays, device)
+    S = sph.shape[2]
+    dist = torch.zeros(b, h, S, device=device)
+    grad = torch.zeros(b, h, S, 4, device=device)
+    Cn.sphere_obstacle_collision(
+        dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([1.0], device=device),
+        torch.tensor([0.05], device=device), None, b, h, S, False, 3, False, None)
+    torch.cuda.synchronize()
+    assert (ref["distance"] > 0).mean() > 0.02
+    np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref["gradient"], atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+@pytest.mark.parametrize("implicit", [False, True])
+def test_bspline(degree, implicit, oracle, device):
+    from curobo_amd.backends import trajectory as Tr
+
+    rng = np.random.default_rng(degree)
+    b, nk, dof, interp = 19, 12, 7, 2
+    ph = (nk + degree + 1) * interp + 1
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda n: {k: rng.normal(size=(n, dof)).astype(np.float32) * 0.3  # noqa: E731
+                    for k in ("position", "velocity", "acceleration", "jerk")}
+    start, goal = mk(3), mk(2)
+    sidx = rng.integers(0, 3, size=b).astype(np.int32)
+    gidx = rng.integers(0, 2, size=b).astype(np.int32)
+    dt = np.array([0.05, 0.08], np.float32)
+    imp = np.array([implicit, implicit], np.uint8)
+    ref = oracle.bspline_forward(u, start, goal, sidx, gidx, dt, imp, ph, degree)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    outs = [torch.zeros(b, ph, dof, device=device) for _ in range(4)]
+    out_dt = torch.zeros(b, device=device)
+    keys = ("position", "velocity", "acceleration", "jerk")
+    Tr.launch_bspline_interpolation_forward_kernel(
+        *outs, out_dt, t(u), *[t(start[k]) for k in keys], *[t(goal[k]) for k in keys], t(sidx), t(gidx),
+        t(dt), t(imp), b, ph, dof, nk, degree)
+    torch.cuda.synchronize()
+    for o, k in zip(outs, keys):
+        scale = max(1.0, np.abs(ref[k]).max())
+        np.testing.assert_allclose(o.cpu().numpy(), ref[k], atol=1e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), ref["dt"])
+    g = [rng.normal(size=(b, ph, dof)).astype(np.float32) for _ in range(4)]
+    refb = oracle.bspline_backward(*g, dt, gidx, imp, nk, degree)
+    og = torch.zeros(b, nk, dof, device=device)
+    Tr.launch_bspline_interpolation_backward_kernel(og, *[t(x) for x in g], t(dt), t(gidx), t(imp), b, ph,
+                                                    dof, nk, degree, False)
+    torch.cuda.synchronize()
+    scale = max(1.0, np.abs(refb).max())
+    np.testing.assert_allclose(og.cpu().numpy(), refb, atol=1e-5 * scale, rtol=1e-4)
+
+
+@pytest.mark.parametrize("v_dim,m", [(7, 7), (84, 27), (84, 0), (300, 15), (1000, 5)])
+def test_lbfgs_step(v_dim, m, oracle, device):
+    from curobo_amd.backends import optimization as Op
+
+    rng = np.random.default_rng(v_dim + m)
+    b = 37
+    mk = lambda *s: rng.normal(size=s).astype(np.float32)  # noqa: E731
+    st = dict(step=np.zeros((b, v_dim), np.float32), rho=mk(m, b) * 0.1, y=mk(m, b, v_dim), s=mk(m, b, v_dim),
+              q=mk(b, v_dim), g=mk(b, v_dim), x0=mk(b, v_dim), g0=mk(b, v_dim))
+    st["rho"][:, 0] = 0.0
+    dv = {k: torch.as_tensor(v.copy(), device=device) for k, v in st.items()}
+    for it in range(3):  # several consecutive steps exercise the history roll
+        oracle.lbfgs_step(st["step"], st["rho"], st["y"], st["s"], st["q"], st["g"], st["x0"], st["g0"], 0.01, True)
+        Op.launch_lbfgs_step(dv["step"], dv["rho"], dv["y"], dv["s"], dv["q"], dv["g"], dv["x0"], dv["g0"],
+                             0.01, b, m, v_dim, True, True)
+        torch.cuda.synchronize()
+        for k in ("step", "rho", "y", "s", "x0", "g0"):
+            scale = max(1.0, float(np.abs(st[k]).max()))
+            np.testing.assert_allclose(dv[k].cpu().numpy(), st[k], atol=2e-5 * scale, rtol=2e-4, err_msg=f"{k} it{it}")
+        st["q"] = st["q"] + 0.1 * st["step"] / max(1.0, float(np.abs(st["step"]).max()))
+        st["g"] = mk(b, v_dim)
+        dv["q"] = torch.as_tensor(st["q"], device=device)
+        dv["g"] = torch.as_tensor(st["g"], device=device)
+
+
+@pytest.mark.parametrize("strong,approx", [(False, True), (True, False), (False, False)])
+def test_line_search(strong, approx, oracle, device):
+    from curobo_amd.backends import optimization as Op
+
+    rng = np.random.default_rng(4)
+    b, nls, v = 301, 4, 84
+    x = rng.normal(size=(b, 1, v)).astype(np.float32)
+    d = rng.normal(size=(b, 1, v)).astype(np.float32)
+    alphas = np.array([0.0, 0.1, 0.5, 1.0], np.float32)
+    sa = (x + alphas[None, :, None] * d).astype(np.float32)
+    # quadratic bowl with random curvature + noise so that all branches (none / armijo-only / both) occur
+    curv = rng.uniform(0.1, 3.0, size=(b, 1, v)).astype(np.float32)
+    sg = (curv * sa + 0.3 * rng.normal(size=sa.shape)).astype(np.float32)
+    scost = (0.5 * (curv * sa * sa).sum(-1, keepdims=True) + rng.normal(size=(b, nls, 1))).astype(np.float32)
+
+    def fresh():
+        return dict(
+            best_cost=np.full((b,), 1e3, np.float32) * rng.uniform(0, 1, size=b).astype(np.float32),
+            best_action=np.zeros((b, v), np.float32), best_iteration=np.zeros((b,), np.int16),
+            current_iteration=rng.integers(0, 30, size=b).astype(np.int16), converged=np.zeros((b,), np.uint8),
+            exploration_cost=np.zeros((b,), np.float32), exploration_action=np.zeros((b, v), np.float32),
+            exploration_gradient=np.zeros((b, v), np.float32), cost=np.zeros((b,), np.float32),
+            action=np.zeros((b, v), np.float32), gradient=np.zeros((b, v), np.float32),
+            exploration_idx=np.zeros((b, nls), np.int32), selected_idx=np.zeros((b, nls), np.int32))
+
+    st = fresh()
+    dv = {k: torch.as_tensor(a.copy(), device=device) for k, a in st.items()}
+    oracle.line_search(st, scost, sa, sg, d, alphas, 1e-5, 0.9, strong, approx, 5, 1e-4, 1e-3)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    Op.launch_line_search(
+        dv["best_cost"], dv["best_action"], dv["best_iteration"], dv["current_iteration"], dv["converged"], 5,
+        1e-4, 1e-3, dv["exploration_cost"], dv["exploration_action"], dv["exploration_gradient"],
+        dv["exploration_idx"], dv["cost"], dv["action"], dv["gradient"], dv["selected_idx"], t(scost), t(sa), t(sg),
+        t(d), t(alphas), 1e-5, 0.9, strong, approx, nls, v, b)
+    torch.cuda.synchronize()
+    sel = st["selected_idx"][:, 0]
+    assert len(np.unique(sel)) >= 3, "inputs should exercise several line-search outcomes"
+    for k in ("selected_idx", "exploration_idx", "best_iteration", "current_iteration", "converged"):
+        assert np.array_equal(dv[k].cpu().numpy(), st[k]), f"{k}: integer outputs must be exact"
+    for k in ("best_cost", "best_action", "exploration_cost", "exploration_action", "exploration_gradient",
+              "cost", "action", "gradient"):
+        np.testing.assert_array_equal(dv[k].cpu().numpy(), st[k], err_msg=k)
+
+
+def test_trajectory_cost_sum(oracle, device):
+    from curobo_amd.backends import collision as Cn
+
+    rng = np.random.default_rng(0)
+    b, h, S = 70, 33, 65
+    sc = rng.uniform(size=(b, h, S)).astype(np.float32)
+    se = rng.uniform(size=(b, h)).astype(np.float32)
+    out = torch.zeros(b, device=device)
+    Cn.trajectory_cost_sum(out, torch.as_tensor(se, device=device), torch.as_tensor(sc, device=device), b, h, S)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.trajectory_cost_sum(se, sc), rtol=2e-6)
