@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py -- trajopt rollouts/sec on MI355X (BASELINE.json metric, config C2).
+
+A *step* is one L-BFGS iteration of the reference's trajectory optimiser over one batch of
+synthetic seeds: generate the 4 line-search candidates per seed, evaluate cost
+AND gradient of every candidate trajectory (B-spline -> FK -> self + swept scene collision ->
+per-trajectory sum -> FK backward -> B-spline backward), run the Wolfe line search and the fused
+L-BFGS direction update.  Workload (per GPU): Franka Panda, 256 seeds x 4 line-search
+candidates = 1024 rollouts of 32 steps (padded 33) per step, 4-cuboid world.  Rollouts/s counts
+cost+gradient trajectory evaluations.  With --gpus N the seed axis shards (weak scaling: every
+rank owns 256 seeds of its own, no data-path collective); the only exchange is the RCCL
+all-gather arg-min over seeds at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel, live
+HIP-event timing) and `cpu_baseline` (the C oracle on the host cores, bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seeds", type=int, default=256, help="seeds per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--graph-iters", type=int, default=10, help="L-BFGS iterations per captured graph")
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters, torch):
+    """Average duration (us) of `fn` (one kernel launch on the current stream) with HIP events."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def cpu_baseline(model, scene_arrays, cfg, knots, start, budget_s):
+    """The CPU oracle (restatement of the reference kernels) on the host cores of this box."""
+    from oracle import load_oracle
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    orc = load_oracle()
+    cores = os.cpu_count() or 1
+    orc.set_num_threads(cores)
+    sample = knots[:64]
+    kw = dict(interpolation_steps=cfg.interpolation_steps, degree=cfg.bspline_degree, traj_dt=cfg.traj_dt,
+              self_collision_weight=cfg.self_collision_weight, scene_collision_weight=cfg.scene_collision_weight,
+              activation_distance=cfg.activation_distance, use_sweep=cfg.use_sweep,
+              use_speed_metric=cfg.use_speed_metric)
+    md = model.as_dict()
+    rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)
+        n += sample.shape[0]
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {
+        "value": n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
+        "sample": f"{sample.shape[0]} trajectories x {cfg.padded_horizon} points per pass, cost+grad, "
+                  f"{n // sample.shape[0]} passes in {el:.1f} s, OpenMP over points ({orc.num_threads()} threads)",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from curobo_amd import _lib
+    from curobo_amd.distributed import global_argmin
+    from curobo_amd.optim import LBFGSOpt, LBFGSOptCfg
+    from curobo_amd.robot import load_packaged_robot
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    model = load_packaged_robot("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene_arrays = cuboid_scene_arrays(c2_world())
+    scene = SceneData.from_arrays(scene_arrays, device)
+    cfg = CollisionRolloutCfg()
+    ocfg = LBFGSOptCfg(num_problems=args.seeds, inner_iters=args.graph_iters)
+    nls = len(ocfg.line_search_scale)
+    rollout = CollisionRollout(kin, scene, args.seeds * nls, cfg)
+    start = start_configuration(model)
+    rollout.update_start_state(torch.as_tensor(start, device=device))
+    bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+    opt = LBFGSOpt(ocfg, rollout.cost_and_gradient, cfg.n_knots, kin.num_dof, bounds, device,
+                   use_cuda_graph=not args.no_graph)
+    opt1 = None
+    knots = seed_knots(model, args.seeds, cfg.n_knots, seed=2, seed_offset=rank * args.seeds)
+    seed_t = torch.as_tensor(knots, device=device)
+    opt.reinitialize(seed_t)
+
+    G = args.graph_iters
+
+    def run_steps(k):
+        """exactly k optimiser iterations"""
+        nonlocal opt1
+        if args.no_graph:
+            for _ in range(k):
+                opt._opt_step()
+            return
+        for _ in range(k // G):
+            opt.run_inner()
+        if k % G:
+            for _ in range(k % G):
+                opt._opt_step()
+
+    run_steps(max(args.warmup, 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    # the one real exchange of the path: arg-min over the seeds of all ranks (1 problem)
+    best_c, best_i, best_x = global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, args.seeds, -1),
+                                           rank * args.seeds)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rollouts_per_step = args.seeds * nls * world
+    value = rollouts_per_step * args.steps / elapsed
+
+    # ---------------- per-kernel live timing (HIP events on the launch stream) -> roofline
+    out = None
+    if rank == 0:
+        B, H = rollout.batch_size, cfg.padded_horizon
+        N = B * H
+        D, T, L, S = kin.num_dof, kin.num_pose_links, kin.num_links, kin.num_spheres
+        act = opt.x_set.view(B, cfg.n_knots, D)
+        rollout.evaluate_action(act)
+        rollout.backward()
+        it = 200
+        kernels = {
+            "bspline_forward": (lambda: rollout.compute_state_from_action(act), B * (cfg.n_knots * D * 4 + 4 * H * D * 4)),
+            "fk_forward_spheres": (lambda: rollout.compute_kinematics(rollout.position), N * (4 * D + 28 * T + 16 * S + 48 * L)),
+            "self_collision": (lambda: rollout_self(rollout), N * (16 * S + 4)),
+            "scene_collision_swept": (lambda: rollout_scene(rollout), N * (36 * S)),
+            "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 16 * S + 28 * T + 4 * D)),
+        }
+        timings = {}
+        for name, (fn, nbytes) in kernels.items():
+            us = time_kernel(fn, it, torch)
+            timings[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes),
+                             "GBps": round(nbytes / us * 1e-3, 1)}
+        step_us = time_kernel(lambda: opt._opt_step(), 50, torch)
+        dom = max(timings, key=lambda k: timings[k]["us"])
+        ach = timings[dom]["GBps"]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": timings[dom]["us"], "algorithmic_bytes_per_launch": timings[dom]["algorithmic_bytes"]}
+        total_bytes = N * rollout.algorithmic_bytes_per_point()
+        out = {
+            "metric": "trajopt rollouts/sec (batch x horizon cost+grad)",
+            "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: Franka Panda trajopt, 256 seeds x 4 line-search candidates x 32-step horizon "
+                            "(padded 33), 4-cuboid world, swept scene collision + speed metric + self collision, "
+                            "one L-BFGS iteration (line search + two-loop) per step",
+                "robot": "franka", "seeds_per_gpu": args.seeds, "line_search_candidates": nls,
+                "horizon": cfg.horizon, "n_knots": cfg.n_knots, "rollouts_per_step_per_gpu": args.seeds * nls,
+                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "parallelism": f"seed-shard x{world}",
+            },
+            "roofline": roofline,
+            "kernels_us": {k: v["us"] for k, v in timings.items()},
+            "kernels_GBps": {k: v["GBps"] for k, v in timings.items()},
+            "eager_step_us": round(step_us, 1),
+            "stack_algorithmic_GBps": round(total_bytes / (elapsed / args.steps) * 1e-9, 1),
+            "best_cost": float(best_c[0].item()), "best_seed": int(best_i[0].item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def rollout_self(r):
+    from curobo_amd.backends import geometry as g
+
+    k, sc = r.kin, r.kin.self_collision
+    g.self_collision_distance(r.self_dist, r.self_grad, r._pair_distance, r.self_sparse, r.robot_spheres,
+                              sc.sphere_padding, r._w_self, sc.collision_pairs, r._bbmv, r._bbmi, 1, 256,
+                              r.batch_size, r.cfg.padded_horizon, k.num_spheres, sc.collision_pairs.shape[0],
+                              False, True)
+
+
+def rollout_scene(r):
+    from curobo_amd.backends import collision as c
+
+    c.sphere_obstacle_collision(r.scene_dist, r.scene_grad, r.robot_spheres, r.scene.struct, r._w_scene, r._eta,
+                                r.env_query_idx, r.batch_size, r.cfg.padded_horizon, r.kin.num_spheres, False,
+                                3 if r.cfg.use_sweep else 0, r.cfg.use_sweep and r.cfg.use_speed_metric, r._speed_dt)
+
+
+def rollout_bwd_fk(r):
+    from curobo_amd.backends import kinematics as kb
+
+    k = r.kin
+    kb.launch_kinematics_backward(
+        r.grad_q, r.grad_zero_pos, r.grad_zero_quat, r.self_grad, r.com, r.com, r.grad_zero_pos, r.cumul_mat,
+        k.link_spheres, k.link_masses_com, k.link_map, k.joint_map, k.joint_map_type, k.tool_frame_map,
+        k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets, k.joint_links_data, k.joint_links_offsets,
+        k.joint_affects_endeffector, k.joint_offset_map, r.env_query_idx, k.num_envs,
+        r.batch_size * r.cfg.padded_horizon, r.cfg.padded_horizon, r.action_dim, k.num_spheres, False, False,
+        grad_spheres_b=r.scene_grad)
+
+
+if __name__ == "__main__":
+    main()

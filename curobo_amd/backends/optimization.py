@@ -76,3 +76,25 @@ def launch_lbfgs_step(
         int(use_shared_buffers), current_stream(step_vec),
     ))
     return [step_vec, rho_buffer, y_buffer, s_buffer, x_0, grad_0]
+
+
+def prepare_search_points(
+    x_set: torch.Tensor,
+    step_direction_out: torch.Tensor,
+    x: torch.Tensor,
+    step_direction: torch.Tensor,
+    action_step_max: torch.Tensor,
+    search_magnitudes: torch.Tensor,
+    batchsize: int,
+    n_linesearch: int,
+    opt_dim: int,
+    action_dim: int,
+    apply_step_scale: bool,
+):
+    """Fused ``_prepare_search_points`` (reference optim/gradient/line_search_strategy.py:134-204):
+    step clamping + ``x + alpha_k * d`` for every line-search magnitude, one wavefront per problem."""
+    check(load().curobo_hip_prepare_search_points(
+        ptr(x_set), ptr(step_direction_out), ptr(x), ptr(step_direction), ptr(action_step_max),
+        ptr(search_magnitudes), batchsize, n_linesearch, opt_dim, action_dim, int(apply_step_scale),
+        current_stream(x_set),
+    ))

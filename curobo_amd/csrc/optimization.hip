@@ -248,6 +248,36 @@ __global__ void __launch_bounds__(256) trajectory_cost_sum_kernel(float *out, co
   if (lane == 0) out[b] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Line-search candidate generation, fused (reference optim/gradient/line_search_strategy.py:
+// 134-204 `_prepare_search_points` = scale_action (:301-325) + jit_get_x_set (:281-299), three to
+// four torch elementwise/reduction kernels).  One wavefront per problem:
+//   scale = max(1, max_v |d_v| / step_max[v % action_dim])   (only if step_scale not in {0,1})
+//   d_out = d / scale ;  x_set[b,k,:] = x[b,:] + alpha_k * d_out
+__global__ void __launch_bounds__(256) prepare_search_points_kernel(
+    float *x_set, float *d_out, const float *x, const float *d, const float *step_max,
+    const float *alphas, int batch, int nls, int opt_dim, int action_dim, int apply_scale) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= batch) return;
+  const size_t o = (size_t)b * opt_dim;
+  float scale = 1.0f;
+  if (apply_scale) {
+    float mx = 0.0f;
+    for (int v = lane; v < opt_dim; v += kWave) mx = fmaxf(mx, fabsf(d[o + v]) / step_max[v % action_dim]);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    scale = fmaxf(mx, 1.0f);
+  }
+  for (int v = lane; v < opt_dim; v += kWave) {
+    const float dv = d[o + v] / scale;
+    const float xv = x[o + v];
+    d_out[o + v] = dv;
+    for (int k = 0; k < nls; k++) x_set[((size_t)b * nls + k) * opt_dim + v] = xv + alphas[k] * dv;
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -311,5 +341,21 @@ CUROBO_EXPORT int curobo_hip_trajectory_cost_sum(float *out_cost, const float *s
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(trajectory_cost_sum_kernel, dim3((unsigned)ceil_div(batch_size, 4)), dim3(256), 0, st,
                      out_cost, self_cost, scene_cost, batch_size, horizon, num_spheres);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_prepare_search_points(float *x_set, float *step_direction_out, const float *x,
+                                                   const float *step_direction, const float *action_step_max,
+                                                   const float *search_magnitudes, int batchsize,
+                                                   int n_linesearch, int opt_dim, int action_dim,
+                                                   int apply_step_scale, curobo_hip_stream_t stream) {
+  const char *what = "prepare_search_points";
+  CUROBO_REQUIRE(n_linesearch >= 1 && opt_dim >= 1 && action_dim >= 1, "%s: bad dimensions", what);
+  CUROBO_REQUIRE(opt_dim % action_dim == 0, "%s: opt_dim must be a multiple of action_dim", what);
+  if (batchsize == 0) return CUROBO_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(prepare_search_points_kernel, dim3((unsigned)ceil_div(batchsize, 4)), dim3(256), 0, st,
+                     x_set, step_direction_out, x, step_direction, action_step_max, search_magnitudes,
+                     batchsize, n_linesearch, opt_dim, action_dim, apply_step_scale);
   return check_launch(what, st);
 }

@@ -1,0 +1,62 @@
+"""Seed-parallel multi-GPU layer: one process per GPU, seeds sharded, one tiny exchange.
+
+The reference is single-GPU (no NCCL/MPI anywhere).  Every (problem, seed)
+row is independent through transition, FK, costs, backward, L-BFGS and line search, so the seed
+axis shards with NO data-path collective; the only exchange is the arg-min over seeds at the end
+of a solve (reference single-GPU equivalent: ``solver/solver_ik.py:503-515`` top-k,
+``solver/solver_trajopt.py:469-484``).  That exchange is ~KBs -> latency-bound, so it is a single
+``all_gather`` (RCCL over xGMI; every peer is one hop away) of a packed
+``[cost, global_seed_index, payload...]`` row per problem, after which every rank computes the
+identical arg-min (ties -> lowest global seed index).
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_seeds: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous seed range [lo, hi) owned by ``rank`` (first ranks take the remainder)."""
+    base, rem = divmod(num_seeds, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_best(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int) -> torch.Tensor:
+    """cost[P, S_local], payload[P, S_local, V] -> packed [P, 2 + V] rows (cost, global idx, payload).
+
+    The seed index travels as fp32 (exact below 2^24 seeds)."""
+    c, i = torch.min(cost, dim=1)  # torch.min returns the first minimal index on ties
+    P = cost.shape[0]
+    row = torch.empty(P, 2 + payload.shape[-1], device=cost.device, dtype=torch.float32)
+    row[:, 0] = c
+    row[:, 1] = (i + seed_offset).to(torch.float32)
+    row[:, 2:] = payload[torch.arange(P, device=cost.device), i]
+    return row
+
+
+def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
+                  group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Best (cost[P], global_seed_idx[P], payload[P, V]) over the seeds of ALL ranks.
+
+    Works unchanged without an initialised process group (world size 1)."""
+    row = local_best(cost, payload, seed_offset)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        gathered = torch.empty(world, *row.shape, device=row.device, dtype=row.dtype)
+        dist.all_gather_into_tensor(gathered, row.contiguous(), group=group)
+    else:
+        gathered = row.unsqueeze(0)
+    costs = gathered[:, :, 0]  # [W, P]
+    idxs = gathered[:, :, 1]
+    # lexicographic (cost, global index) minimum -> identical on every rank
+    best_cost = costs.min(dim=0).values
+    is_best = costs == best_cost.unsqueeze(0)
+    idx_masked = torch.where(is_best, idxs, torch.full_like(idxs, float("inf")))
+    win_rank = idx_masked.argmin(dim=0)  # [P]
+    P = row.shape[0]
+    sel = gathered[win_rank, torch.arange(P, device=row.device)]
+    return sel[:, 0], sel[:, 1].to(torch.int64), sel[:, 2:]

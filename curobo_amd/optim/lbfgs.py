@@ -1,0 +1,193 @@
+"""L-BFGS with a parallel Wolfe line search over pre-evaluated step magnitudes.
+
+Mirrors the reference's ``LBFGSOpt`` / ``GradientOptCore`` iteration
+(``curobo/_src/optim/gradient/lbfgs.py:156-265``, ``optim/components/gradient_opt_core.py:255-480``,
+``optim/gradient/line_search_strategy.py:488-734``; call stack in SURVEY.md section 3.3):
+
+    for each iteration:
+        x_set = x_explore + alpha_k * clamp(d)          (prepare_search_points, fused HIP kernel)
+        cost, grad = rollout(x_set)                      (num_problems * n_linesearch rollouts)
+        selected / exploration / best / converged       (launch_line_search)
+        d = L-BFGS two-loop(x_explore, g_explore)        (launch_lbfgs_step)
+
+``inner_iters`` iterations are captured once into a hipGraph (``torch.cuda.CUDAGraph`` is
+hipGraph on ROCm) and replayed, like the reference's ``GraphExecutor`` around ``_opt_iters``
+(``util/cuda_graph_util.py:144-180``).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from ..backends import optimization as optimization_hip
+
+
+@dataclass
+class LBFGSOptCfg:
+    """Names and defaults follow ``content/configs/task/trajopt/lbfgs_bspline_trajopt.yml:3-40``."""
+
+    num_problems: int = 1
+    history: int = 27
+    inner_iters: int = 25
+    num_iters: int = 100
+    line_search_scale: List[float] = field(default_factory=lambda: [0.0, 0.1, 0.5, 1.0])
+    line_search_type: str = "approx_wolfe"  # approx_wolfe | wolfe | strong_wolfe
+    line_search_c_1: float = 1e-5
+    line_search_c_2: float = 0.9
+    epsilon: float = 0.01
+    stable_mode: bool = True
+    step_scale: float = 0.98
+    initial_step_scale: float = 0.001
+    cost_delta_threshold: float = 0.0
+    cost_relative_threshold: float = 0.001
+    convergence_iteration: int = 10
+
+
+class LBFGSOpt:
+    """``optimize(seed)`` runs ``num_iters`` iterations on ``num_problems`` independent problems.
+
+    ``cost_and_gradient(x[B*NLS, V]) -> (cost[B*NLS], grad[B*NLS, V])`` is the rollout; its
+    batch must be ``num_problems * n_linesearch``.  ``action_bounds`` = (low[D], high[D]).
+    """
+
+    def __init__(self, cfg: LBFGSOptCfg, cost_and_gradient: Callable, action_horizon: int, action_dim: int,
+                 action_bounds: Tuple[torch.Tensor, torch.Tensor], device, use_cuda_graph: bool = True):
+        self.cfg = cfg
+        self.rollout_fn = cost_and_gradient
+        self.action_horizon, self.action_dim = action_horizon, action_dim
+        self.opt_dim = action_horizon * action_dim
+        self.device = device
+        self.use_cuda_graph = use_cuda_graph
+        if self.opt_dim >= 1024:  # reference lbfgs.py:177
+            raise ValueError("opt_dim must be < 1024 for the fused L-BFGS step")
+        if cfg.history > 31:
+            raise ValueError("History_m greater than 31 is not supported")
+        self.history = min(cfg.history, self.opt_dim)  # reference lbfgs.py:189-191
+        lows, highs = action_bounds
+        self._step_max = (cfg.step_scale * torch.abs(highs - lows)).to(device=device, dtype=torch.float32).contiguous()
+        self._alphas = torch.tensor(cfg.line_search_scale, device=device, dtype=torch.float32)
+        self.n_linesearch = len(cfg.line_search_scale)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._alloc(cfg.num_problems)
+
+    # reference QuasiNewtonBuffers (optim/components/quasi_newton_buffers.py:23-142) and
+    # OptimizationIterationState (optim/components/...): all static, graph-safe.
+    def _alloc(self, B: int) -> None:
+        d, V, m, N = self.device, self.opt_dim, self.history, self.n_linesearch
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=d, dtype=dt)  # noqa: E731
+        self.num_problems = B
+        self.y, self.s, self.rho = z(m, B, V), z(m, B, V), z(m, B)
+        self.x_0, self.grad_0 = z(B, V), z(B, V)
+        self.step_direction = z(B, V)
+        self.step_scaled = z(B, V)
+        self.x_set = z(B, N, V)
+        self.search_cost = z(B, N, 1)
+        self.search_gradient = z(B, N, V)
+        self.action, self.gradient, self.cost = z(B, V), z(B, V), z(B)
+        self.exploration_action, self.exploration_gradient, self.exploration_cost = z(B, V), z(B, V), z(B)
+        self.best_action, self.best_cost = z(B, V), z(B)
+        self.best_iteration, self.current_iteration = z(B, dt=torch.int16), z(B, dt=torch.int16)
+        self.converged = z(B, dt=torch.uint8)
+        self.exploration_idx, self.selected_idx = z(B, N, dt=torch.int32), z(B, N, dt=torch.int32)
+        self._graph = None
+
+    # ------------------------------------------------------------------ one iteration
+    def _evaluate_search_points(self) -> None:
+        B, N, V = self.num_problems, self.n_linesearch, self.opt_dim
+        cost, grad = self.rollout_fn(self.x_set.view(B * N, V))
+        # The rollout returns its own static output buffers; alias them instead of copying
+        # (pointers are stable across calls, so this is also what the captured graph sees).
+        if cost.data_ptr() != self.search_cost.data_ptr():
+            self.search_cost = cost.view(B, N, 1)
+        if grad.data_ptr() != self.search_gradient.data_ptr():
+            self.search_gradient = grad.view(B, N, V)
+
+    def _opt_step(self) -> None:
+        cfg, B, N, V = self.cfg, self.num_problems, self.n_linesearch, self.opt_dim
+        apply_scale = cfg.step_scale != 0.0 and cfg.step_scale != 1.0
+        optimization_hip.prepare_search_points(
+            self.x_set, self.step_scaled, self.exploration_action, self.step_direction, self._step_max,
+            self._alphas, B, N, V, self.action_dim, apply_scale)
+        self._evaluate_search_points()
+        optimization_hip.launch_line_search(
+            self.best_cost, self.best_action, self.best_iteration, self.current_iteration, self.converged,
+            cfg.convergence_iteration, cfg.cost_delta_threshold, cfg.cost_relative_threshold,
+            self.exploration_cost, self.exploration_action, self.exploration_gradient,
+            self.exploration_idx.view(-1), self.cost, self.action, self.gradient, self.selected_idx.view(-1),
+            self.search_cost, self.x_set, self.search_gradient, self.step_scaled, self._alphas,
+            cfg.line_search_c_1, cfg.line_search_c_2, cfg.line_search_type == "strong_wolfe",
+            cfg.line_search_type == "approx_wolfe", N, V, B)
+        optimization_hip.launch_lbfgs_step(
+            self.step_direction, self.rho, self.y, self.s, self.exploration_action, self.exploration_gradient,
+            self.x_0, self.grad_0, cfg.epsilon, B, self.history, V, cfg.stable_mode, True)
+
+    def _opt_iters(self) -> None:
+        for _ in range(self.cfg.inner_iters):
+            self._opt_step()
+
+    # ------------------------------------------------------------------ lifecycle
+    def reinitialize(self, seed: torch.Tensor) -> None:
+        """reference GradientOptCore._prepare_initial_iteration_state (:402-441): evaluate the seed,
+        first direction = -initial_step_scale * gradient, L-BFGS reference point = the seed."""
+        B, V = self.num_problems, self.opt_dim
+        x = seed.reshape(B, V).to(self.device, torch.float32)
+        for t in (self.y, self.s, self.rho):
+            t.zero_()
+        self.best_cost.fill_(1e10)
+        self.best_iteration.zero_()
+        self.current_iteration.zero_()
+        self.converged.zero_()
+        self.exploration_action.copy_(x)
+        self.action.copy_(x)
+        self.best_action.copy_(x)
+        self.x_set.copy_(x.unsqueeze(1).expand(B, self.n_linesearch, V))
+        self._evaluate_search_points()
+        self.exploration_gradient.copy_(self.search_gradient[:, 0])
+        self.exploration_cost.copy_(self.search_cost[:, 0, 0])
+        self.gradient.copy_(self.exploration_gradient)
+        self.cost.copy_(self.exploration_cost)
+        self.best_cost.copy_(self.exploration_cost)
+        self.step_direction.copy_(-self.cfg.initial_step_scale * self.exploration_gradient)
+        self.x_0.copy_(self.exploration_action)
+        self.grad_0.copy_(self.exploration_gradient)
+
+    def capture(self) -> None:
+        """Warm up on a side stream, then record ``inner_iters`` iterations into one hipGraph."""
+        saved = [t.clone() for t in self._state_tensors()]
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._opt_step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._opt_iters()
+        for t, s in zip(self._state_tensors(), saved):
+            t.copy_(s)
+        torch.cuda.synchronize(self.device)
+
+    def _state_tensors(self):
+        return [self.y, self.s, self.rho, self.x_0, self.grad_0, self.step_direction, self.action,
+                self.gradient, self.cost, self.exploration_action, self.exploration_gradient,
+                self.exploration_cost, self.best_action, self.best_cost, self.best_iteration,
+                self.current_iteration, self.converged]
+
+    def run_inner(self) -> None:
+        """``inner_iters`` iterations (graph replay when enabled)."""
+        if self.use_cuda_graph:
+            if self._graph is None:
+                self.capture()
+            self._graph.replay()
+        else:
+            self._opt_iters()
+
+    def optimize(self, seed: torch.Tensor) -> torch.Tensor:
+        self.reinitialize(seed)
+        outer = max(1, self.cfg.num_iters // self.cfg.inner_iters)
+        for _ in range(outer):
+            self.run_inner()
+        return self.best_action.view(self.num_problems, self.action_horizon, self.action_dim)

@@ -127,8 +127,8 @@ class RobotModel:
             tool_frames=np.array(self.tool_frames), base_link=np.array(self.base_link),
             lock_joint_names=np.array(list(self.lock_joints.keys())),
             lock_joint_values=np.array(list(self.lock_joints.values()), dtype=np.float64),
-            cspace_max_acceleration=np.float64(self.cspace.get("max_acceleration", 10.0)),
-            cspace_max_jerk=np.float64(self.cspace.get("max_jerk", 500.0)),
+            cspace_max_acceleration=np.atleast_1d(np.asarray(self.cspace.get("max_acceleration", 10.0), dtype=np.float64)),
+            cspace_max_jerk=np.atleast_1d(np.asarray(self.cspace.get("max_jerk", 500.0), dtype=np.float64)),
             cspace_default_joint_position=np.array(
                 self.cspace.get("default_joint_position", [0.0] * self.num_dof), dtype=np.float64
             ),
@@ -148,8 +148,8 @@ class RobotModel:
             tool_frames=[str(x) for x in z["tool_frames"]],
             lock_joints=lock,
             cspace=dict(
-                max_acceleration=float(z["cspace_max_acceleration"]),
-                max_jerk=float(z["cspace_max_jerk"]),
+                max_acceleration=[float(x) for x in np.atleast_1d(z["cspace_max_acceleration"])],
+                max_jerk=[float(x) for x in np.atleast_1d(z["cspace_max_jerk"])],
                 default_joint_position=[float(x) for x in z["cspace_default_joint_position"]],
             ),
             base_link=str(z["base_link"]),

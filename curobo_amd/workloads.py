@@ -1,0 +1,51 @@
+"""Synthetic, deterministic workloads of the BASELINE configs.
+
+C2 "Franka Panda trajopt: 256 seeds x 32-step horizon, sphere+cuboid world": the cuboid world of
+the reference's kernel benchmark (``benchmark/cost_gradient_benchmark.py:486-497``: table
+[2.2,2.2,0.2]@[0,0,-0.1] and pillar [0.1,0.1,1.5]@[0.45,0,0.3]) plus two more cuboids.  The
+reference turns sphere primitives into meshes (``geom/types.py:1104-1124``), so cuboid
+equivalents are used for result parity.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+
+
+def c2_world() -> List[List[Dict]]:
+    c, s = math.cos(0.3), math.sin(0.3)
+    return [[
+        {"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]},
+        {"dims": [0.1, 0.1, 1.5], "pose": [0.45, 0.0, 0.3, 1, 0, 0, 0]},
+        {"dims": [0.3, 0.3, 0.3], "pose": [0.2, 0.55, 0.45, c, 0, 0, s]},
+        {"dims": [0.25, 0.25, 0.25], "pose": [-0.2, -0.5, 0.7, 1, 0, 0, 0]},
+    ]]
+
+
+def seed_knots(model, num_seeds: int, n_knots: int, seed: int = 2, seed_offset: int = 0,
+               spread: float = 0.35) -> np.ndarray:
+    """Deterministic per-seed knot sets: a straight line from the start configuration to a
+    per-seed goal plus a smooth per-seed perturbation.  Seed ``i`` depends only on its GLOBAL
+    index ``seed_offset + i`` so any sharding of the seed axis sees identical seeds."""
+    lo, hi = model.joint_limits_position
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    D = model.num_dof
+    out = np.zeros((num_seeds, n_knots, D), np.float32)
+    t = np.linspace(0.0, 1.0, n_knots)[:, None]
+    start = start_configuration(model)
+    for i in range(num_seeds):
+        rng = np.random.default_rng([seed, seed_offset + i])
+        goal = mid + half * 0.8 * rng.uniform(-1, 1, size=D)
+        bump = rng.normal(size=(1, D)) * spread * half * np.sin(np.pi * t)
+        out[i] = (start[None] * (1 - t) + goal[None] * t + bump).astype(np.float32)
+    return np.clip(out, lo + 1e-3, hi - 1e-3).astype(np.float32)
+
+
+def start_configuration(model) -> np.ndarray:
+    q = np.asarray(model.cspace.get("default_joint_position", [0.0] * model.num_dof), dtype=np.float64)
+    if q.shape[0] != model.num_dof:
+        q = 0.5 * (model.joint_limits_position[0] + model.joint_limits_position[1])
+    return q.astype(np.float32)

@@ -186,6 +186,15 @@ int curobo_hip_launch_line_search(
     float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
     int opt_dim, int batchsize, curobo_hip_stream_t stream);
 
+/* Line-search candidates, fused (extension; reference: torch ops in
+ * optim/gradient/line_search_strategy.py:134-204 `_prepare_search_points`, :281-325):
+ *   scale = max(1, max_v |d_v| / action_step_max[v % action_dim])  (if apply_step_scale)
+ *   step_direction_out = d / scale;  x_set[b,k,:] = x[b,:] + search_magnitudes[k] * d / scale */
+int curobo_hip_prepare_search_points(
+    float *x_set, float *step_direction_out, const float *x, const float *step_direction,
+    const float *action_step_max, const float *search_magnitudes, int batchsize, int n_linesearch,
+    int opt_dim, int action_dim, int apply_step_scale, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- rollout glue
  * Per-trajectory cost sum (reference rollout/metrics.py:233-265 + util/tensor_util.py:104:
  * torch cat + sum): out[b] = sum_h( self_cost[b,h] + sum_s scene_cost[b,h,s] ), one wavefront
