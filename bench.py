@@ -58,13 +58,25 @@ def time_kernel(fn, iters, torch):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model, scene_arrays, cfg, knots, start, budget_s):
     """The CPU oracle (restatement of the reference kernels) on the host cores of this box."""
     from oracle import load_oracle
     from oracle.rollout_ref import rollout_cost_and_gradient
 
     orc = load_oracle()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     orc.set_num_threads(cores)
     sample = knots[:64]
     kw = dict(interpolation_steps=cfg.interpolation_steps, degree=cfg.bspline_degree, traj_dt=cfg.traj_dt,
@@ -150,6 +162,8 @@ def main():
                 opt._opt_step()
 
     run_steps(max(args.warmup, 1))
+    # warm the exchange too (first use of the torch index/min kernels loads their code objects)
+    global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, args.seeds, -1), rank * args.seeds)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

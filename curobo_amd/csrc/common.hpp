@@ -47,7 +47,33 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) { return group_sum<kWave>(v); }
+// DPP helpers (gfx9 encodings): quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_zero_fill(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// wave64 all-reduce (sum), result uniform: the canonical GCN/CDNA DPP ladder -- 6 VALU adds with
+// DPP operand modifiers + one v_readlane; no LDS crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_zero_fill<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_zero_fill<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_zero_fill<0x141>(v);       // row_half_mirror: 8-lane sums
+  v += dpp_zero_fill<0x140>(v);       // row_mirror: every lane holds its row-of-16 sum
+  v += dpp_zero_fill<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_zero_fill<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over each group of 16 consecutive lanes (a DPP row); every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_zero_fill<0xB1>(v);
+  v += dpp_zero_fill<0x4E>(v);
+  v += dpp_zero_fill<0x141>(v);
+  v += dpp_zero_fill<0x140>(v);
+  return v;
+}
 
 struct f3 {
   float x, y, z;

@@ -137,6 +137,117 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
   }
 }
 
+// Register-resident variant for the common sizes (V <= 128, m <= 32: trajopt V=84/m=27, IK
+// V=7/m=7).  The whole (y, s) history of a problem is pulled into VGPRs with independent,
+// fully pipelined loads (VPL * 2 * 32 <= 128 registers), written back shifted by one, and both
+// loops of the recursion then run out of registers: the 2m dependent L2 round trips of the
+// streaming variant above disappear.  m is a run-time value; slots >= m are predicated off.
+template <int VPL>
+__global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) {
+  constexpr int MMAX = 32;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= a.batch) return;
+  const int V = a.v_dim, m = a.m, B = a.batch;
+  const size_t bv = (size_t)b * V;
+  const size_t hist_stride = (size_t)B * V;
+  float ys[MMAX][VPL], ss[MMAX][VPL];
+  // slot i <- old slot i+1 (shift), all loads independent
+#pragma unroll
+  for (int i = 0; i < MMAX; i++) {
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      const bool ld = (i < m - 1) && (v < V);
+      ys[i][e] = ld ? a.y_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
+      ss[i][e] = ld ? a.s_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
+    }
+  }
+  float rho_mine = (lane < m - 1) ? a.rho_buffer[(size_t)(lane + 1) * B + b] : 0.0f;
+  float gq[VPL], y[VPL], s[VPL];
+  float part = 0.0f;
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    gq[e] = y[e] = s[e] = 0.0f;
+    if (v < V) {
+      const float g = a.grad_q[bv + v], x = a.q[bv + v];
+      y[e] = g - a.grad_0[bv + v];
+      s[e] = x - a.x_0[bv + v];
+      a.grad_0[bv + v] = g;
+      a.x_0[bv + v] = x;
+      gq[e] = g;
+      part += y[e] * s[e];
+    }
+  }
+  const float numerator = wave_sum(part);
+  if (lane == m - 1) {
+    rho_mine = 1.0f / numerator;
+    if (a.stable_mode && numerator <= 0.0f) rho_mine = 0.0f;
+  }
+  if (lane < m) a.rho_buffer[(size_t)lane * B + b] = rho_mine;
+  // append the new pair at slot m-1, then write the shifted history back
+#pragma unroll
+  for (int i = 0; i < MMAX; i++) {
+    if (i == m - 1) {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) { ys[i][e] = y[e]; ss[i][e] = s[e]; }
+    }
+    if (i < m) {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) {
+        const int v = lane + e * kWave;
+        if (v < V) {
+          a.y_buffer[(size_t)i * hist_stride + bv + v] = ys[i][e];
+          a.s_buffer[(size_t)i * hist_stride + bv + v] = ss[i][e];
+        }
+      }
+    }
+  }
+  float alpha_mine = 0.0f;
+#pragma unroll
+  for (int i = MMAX - 1; i >= 0; i--) {
+    if (i < m) {
+      float d = 0.0f;
+#pragma unroll
+      for (int e = 0; e < VPL; e++) d += gq[e] * ss[i][e];
+      d = wave_sum(d);
+      const float alpha = d * __shfl(rho_mine, i, kWave);
+      if (lane == i) alpha_mine = alpha;
+#pragma unroll
+      for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * ys[i][e];
+    }
+  }
+  if (m > 0) {
+    float d = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) d += y[e] * y[e];
+    d = wave_sum(d);
+    float var1 = numerator / d;
+    if (a.stable_mode && (isinf(var1) || isnan(var1))) var1 = a.epsilon;
+    const float gamma = var1 < 0.0f ? 0.0f : var1;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) gq[e] = gamma * gq[e];
+  }
+#pragma unroll
+  for (int i = 0; i < MMAX; i++) {
+    if (i < m) {
+      float d = 0.0f;
+#pragma unroll
+      for (int e = 0; e < VPL; e++) d += gq[e] * ys[i][e];
+      d = wave_sum(d);
+      const float beta = __shfl(alpha_mine, i, kWave) - d * __shfl(rho_mine, i, kWave);
+#pragma unroll
+      for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * ss[i][e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    if (v < V) a.step_vec[bv + v] = -gq[e];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 struct LineSearchArgs {
   float *best_cost, *best_action;
@@ -221,33 +332,30 @@ __global__ void __launch_bounds__(256) line_search_kernel(const LineSearchArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// per-trajectory cost sum: one wavefront per trajectory, wave64 shuffle reduction.
+// per-trajectory cost sum: one 256-lane workgroup per trajectory; every lane owns a strided
+// slice (independent loads, all in flight at once), then wave64 DPP reduction and a fixed-order
+// 4-entry LDS combine (deterministic).
 __global__ void __launch_bounds__(256) trajectory_cost_sum_kernel(float *out, const float *self_cost,
                                                                   const float *scene_cost, int batch,
                                                                   int horizon, int nspheres) {
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
-  if (b >= batch) return;
-  float acc = 0.0f;
+  __shared__ float s_part[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid / kWave;
+  float acc0 = 0.0f, acc1 = 0.0f;
   if (scene_cost) {
-    const size_t n = (size_t)horizon * nspheres;
+    const int n = horizon * nspheres;
     const float *src = scene_cost + (size_t)b * n;
-    if ((n & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
-      const float4 *s4 = reinterpret_cast<const float4 *>(src);
-      for (size_t i = lane; i < n / 4; i += kWave) {
-        const float4 v = s4[i];
-        acc += (v.x + v.y) + (v.z + v.w);
-      }
-    } else {
-      for (size_t i = lane; i < n; i += kWave) acc += src[i];
-    }
+    int i = tid;
+    for (; i + 256 < n; i += 512) { acc0 += src[i]; acc1 += src[i + 256]; }
+    if (i < n) acc0 += src[i];
   }
   if (self_cost)
-    for (int h = lane; h < horizon; h += kWave) acc += self_cost[(size_t)b * horizon + h];
-  acc = wave_sum(acc);
-  if (lane == 0) out[b] = acc;
+    for (int h = tid; h < horizon; h += 256) acc1 += self_cost[(size_t)b * horizon + h];
+  const float w = wave_sum(acc0 + acc1);
+  if ((tid & (kWave - 1)) == 0) s_part[wave] = w;
+  __syncthreads();
+  if (tid == 0) out[b] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Line-search candidate generation, fused (reference optim/gradient/line_search_strategy.py:
@@ -298,8 +406,8 @@ CUROBO_EXPORT int curobo_hip_launch_lbfgs_step(
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)ceil_div(batch_size, 4)), block(256);
   const int vpl = ceil_div(v_dim, kWave);
-  if (vpl <= 1) hipLaunchKernelGGL((lbfgs_step_kernel<1>), grid, block, 0, st, a);
-  else if (vpl <= 2) hipLaunchKernelGGL((lbfgs_step_kernel<2>), grid, block, 0, st, a);
+  if (vpl <= 1) hipLaunchKernelGGL((lbfgs_step_reg_kernel<1>), grid, block, 0, st, a);
+  else if (vpl <= 2) hipLaunchKernelGGL((lbfgs_step_reg_kernel<2>), grid, block, 0, st, a);
   else if (vpl <= 4) hipLaunchKernelGGL((lbfgs_step_kernel<4>), grid, block, 0, st, a);
   else if (vpl <= 8) hipLaunchKernelGGL((lbfgs_step_kernel<8>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((lbfgs_step_kernel<16>), grid, block, 0, st, a);
@@ -339,7 +447,7 @@ CUROBO_EXPORT int curobo_hip_trajectory_cost_sum(float *out_cost, const float *s
   CUROBO_REQUIRE(horizon >= 1 && num_spheres >= 0, "%s: bad horizon/num_spheres", what);
   if (batch_size == 0) return CUROBO_HIP_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(trajectory_cost_sum_kernel, dim3((unsigned)ceil_div(batch_size, 4)), dim3(256), 0, st,
+  hipLaunchKernelGGL(trajectory_cost_sum_kernel, dim3((unsigned)batch_size), dim3(256), 0, st,
                      out_cost, self_cost, scene_cost, batch_size, horizon, num_spheres);
   return check_launch(what, st);
 }

@@ -191,9 +191,15 @@ __device__ __forceinline__ float eval_point(const SceneArgs &a, int flat, f3 lp,
   return pen;
 }
 
+// Sweep culling (result-preserving): every swept sample lies within half_dist of the current
+// centre (t in (0.5, 1]) and a signed distance field is 1-Lipschitz, so when the centre's
+// clearance  sdf - r_adj  exceeds half_dist (+ an interpolation slack for voxel grids) no sample
+// can penetrate and the whole sweep direction contributes exactly zero.
+// half_w* are the world-frame half segment lengths (rigid transforms preserve them).
 template <bool VOXEL, int SWEEP>
 __device__ __forceinline__ void obstacle_set(const SceneArgs &a, int env, int h, const float *sph_ptr, f3 center,
-                                             float r_adj, float eta, float w, float &dsum, f3 &gsum) {
+                                             float r_adj, float eta, float w, float half_w_prev, float half_w_next,
+                                             float &dsum, f3 &gsum) {
   const int max_n = VOXEL ? a.sc.max_voxel_grids : a.sc.max_cuboids;
   if (max_n <= 0) return;
   const int count = VOXEL ? a.sc.voxel_count[env] : a.sc.cuboid_count[env];
@@ -207,11 +213,20 @@ __device__ __forceinline__ void obstacle_set(const SceneArgs &a, int env, int h,
     const f3 lc = tf_point(t, center);
     float cost_sum = 0.0f;
     f3 grad_local = make_f3(0.f, 0.f, 0.f);
-    eval_point<VOXEL>(a, flat, lc, r_adj, eta, cost_sum, grad_local);
+    const float pen_c = eval_point<VOXEL>(a, flat, lc, r_adj, eta, cost_sum, grad_local);
     if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
+      // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
+      const float sdf_c = r_adj - pen_c;
+      const bool can_cull = VOXEL ? (sdf_c < a.sc.voxel_max_distance) : true;
+      // voxel slack: interpolated values are convex combinations of corner samples that sit within
+      // sqrt(3) voxels of the query, once at the centre and once at the sample, + fp16 rounding
+      const float slack = VOXEL ? 3.5f * a.sc.voxel_params[(size_t)flat * 4 + 3] + 0.002f * fabsf(sdf_c) : 0.0f;
+      const float clearance = -pen_c;
 #pragma unroll
       for (int dir = 0; dir < 2; dir++) {
-        if (dir == 0 ? (h > 0) : (h < a.horizon - 1)) {
+        const float half_w = dir == 0 ? half_w_prev : half_w_next;
+        const bool culled = can_cull && clearance > half_w * 1.0001f + slack + 1e-6f;
+        if ((dir == 0 ? (h > 0) : (h < a.horizon - 1)) && !culled) {
           const float4 ns = *reinterpret_cast<const float4 *>(dir == 0 ? sph_ptr - (size_t)a.nspheres * 4
                                                                         : sph_ptr + (size_t)a.nspheres * 4);
           const f3 ln = tf_point(t, make_f3(ns.x, ns.y, ns.z));
@@ -256,8 +271,21 @@ __global__ void __launch_bounds__(256) scene_collision_kernel(const SceneArgs a)
   f3 gsum = make_f3(0.f, 0.f, 0.f);
   if (s.w >= 0.0f) {
     const float r_adj = s.w + eta;
-    obstacle_set<false, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, dsum, gsum);
-    obstacle_set<true, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, dsum, gsum);
+    float half_w_prev = 0.0f, half_w_next = 0.0f;
+    if (SWEEP > 0) {
+      if (h > 0) {
+        const float4 ps = *reinterpret_cast<const float4 *>(sph_ptr - (size_t)a.nspheres * 4);
+        const f3 dd = make_f3(ps.x, ps.y, ps.z) - center;
+        half_w_prev = 0.5f * sqrtf(dot(dd, dd));
+      }
+      if (h < a.horizon - 1) {
+        const float4 ns = *reinterpret_cast<const float4 *>(sph_ptr + (size_t)a.nspheres * 4);
+        const f3 dd = make_f3(ns.x, ns.y, ns.z) - center;
+        half_w_next = 0.5f * sqrtf(dot(dd, dd));
+      }
+    }
+    obstacle_set<false, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum, gsum);
+    obstacle_set<true, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum, gsum);
   }
   // ---- speed metric, fused (wp_speed_metric.py:38-93)
   if (a.enable_speed_metric && h > 0 && h < a.horizon - 1 && dsum > 0.0f) {

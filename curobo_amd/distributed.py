@@ -46,8 +46,9 @@ def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
     row = local_best(cost, payload, seed_offset)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        gathered = torch.empty(world, *row.shape, device=row.device, dtype=row.dtype)
-        dist.all_gather_into_tensor(gathered, row.contiguous(), group=group)
+        flat = torch.empty(world * row.shape[0], row.shape[1], device=row.device, dtype=row.dtype)
+        dist.all_gather_into_tensor(flat, row.contiguous(), group=group)  # concatenated along dim 0
+        gathered = flat.view(world, *row.shape)
     else:
         gathered = row.unsqueeze(0)
     costs = gathered[:, :, 0]  # [W, P]

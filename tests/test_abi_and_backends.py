@@ -1,0 +1,90 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol the header declares;
+the Python backend modules expose the reference's function names with the reference's
+positional argument order (checked against the reference sources when they are present)."""
+
+import ast
+import ctypes
+import inspect
+import os
+
+import pytest
+
+from curobo_amd import _lib
+
+REF_BACKEND = "/root/reference/curobo/_src/curobolib/backends/cuda_core_backend"
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"libcurobo_hip.so does not export {n}"
+    assert lib.curobo_hip_abi_version() == 1
+    assert isinstance(lib.curobo_hip_last_error(), bytes)
+
+
+def test_header_signatures_are_plain_c():
+    sigs = _lib._signatures()
+    assert set(sigs) >= {"curobo_hip_launch_kinematics_forward_spheres", "curobo_hip_self_collision_distance",
+                         "curobo_hip_launch_lbfgs_step", "curobo_hip_launch_line_search"}
+    for name, args in sigs.items():
+        for a in args:
+            assert a in (ctypes.c_void_p, ctypes.c_int, ctypes.c_float), (name, a)
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """argument validation happens before any launch (reference raises ValueError/RuntimeError)"""
+    lib = _lib.load()
+    rc = lib.curobo_hip_launch_lbfgs_step(None, None, None, None, None, None, None, None, 0.01, 4, 32, 84, 1, 1, None)
+    assert rc == 1 and b"History_m greater than 31" in lib.curobo_hip_last_error()
+    with pytest.raises(ValueError, match="History_m"):
+        _lib.check(rc)
+    rc = lib.curobo_hip_launch_kinematics_backward(*([None] * 23), 1, 10, 1, 7, 65, 13, 1, 0, 1, None)
+    assert rc == 1 and b"compute_jacobian_grad" in lib.curobo_hip_last_error()
+
+
+EXPECTED = {
+    "kinematics": ["launch_kinematics_forward", "launch_kinematics_forward_spheres",
+                   "launch_kinematics_forward_spheres_jacobian", "launch_kinematics_backward"],
+    "geometry": ["self_collision_distance"],
+    "trajectory": ["launch_bspline_interpolation_forward_kernel", "launch_bspline_interpolation_backward_kernel"],
+    "optimization": ["launch_line_search", "launch_lbfgs_step"],
+}
+
+
+@pytest.mark.parametrize("module", sorted(EXPECTED))
+def test_backend_modules_export_reference_names(module):
+    import importlib
+
+    mod = importlib.import_module(f"curobo_amd.backends.{module}")
+    for fn in EXPECTED[module]:
+        assert callable(getattr(mod, fn))
+
+
+def _ref_signature(module, fn):
+    tree = ast.parse(open(os.path.join(REF_BACKEND, f"{module}.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == fn:
+            return [a.arg for a in node.args.args]
+    raise KeyError(fn)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_BACKEND), reason="reference checkout not present")
+@pytest.mark.parametrize("module,fn", [(m, f) for m in sorted(EXPECTED) for f in EXPECTED[m]])
+def test_positional_arguments_match_reference(module, fn):
+    import importlib
+
+    ours = list(inspect.signature(getattr(importlib.import_module(f"curobo_amd.backends.{module}"), fn)).parameters)
+    ref = _ref_signature(module, fn)
+    assert ours[: len(ref)] == ref, f"{module}.{fn}: positional arguments differ from the reference backend"
+    extra = ours[len(ref):]
+    assert all(inspect.signature(getattr(importlib.import_module(f"curobo_amd.backends.{module}"), fn)).parameters[e].default
+               is not inspect.Parameter.empty for e in extra), "extensions must be optional keywords"
+
+
+def test_get_backend_shape():
+    from curobo_amd.backends import get_backend
+
+    be = get_backend()
+    assert {"kinematics", "optimization", "trajectory", "geometry"} <= set(be)

@@ -280,7 +280,7 @@ def test_lbfgs_step(v_dim, m, oracle, device):
                              0.01, b, m, v_dim, True, True)
         torch.cuda.synchronize()
         for k in ("step", "rho", "y", "s", "x0", "g0"):
-            scale = max(1.0, float(np.abs(st[k]).max()))
+            scale = max(1.0, float(np.abs(st[k]).max())) if st[k].size else 1.0
             np.testing.assert_allclose(dv[k].cpu().numpy(), st[k], atol=2e-5 * scale, rtol=2e-4, err_msg=f"{k} it{it}")
         st["q"] = st["q"] + 0.1 * st["step"] / max(1.0, float(np.abs(st["step"]).max()))
         st["g"] = mk(b, v_dim)

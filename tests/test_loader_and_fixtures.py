@@ -1,0 +1,88 @@
+"""Host logic: URDF/YAML loader, packaged robot fixtures, scene stores, workloads."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_model
+
+REF_CONTENT = "/root/reference/curobo/content"
+
+
+def test_packaged_fixture_shapes(franka, ur10e, g1):
+    assert (franka.num_dof, franka.num_links, franka.num_spheres, franka.collision_pairs.shape[0]) == (7, 13, 65, 818)
+    assert (ur10e.num_dof, ur10e.num_spheres, ur10e.collision_pairs.shape[0]) == (6, 20, 83)
+    assert (g1.num_dof, g1.num_links, g1.num_spheres, len(g1.tool_frames)) == (49, 56, 674, 4)
+    assert g1.collision_pairs.shape[0] > 512 * 256  # the reference's map-reduce regime
+    for m in (franka, ur10e, g1):
+        assert (m.link_map[1:] < np.arange(1, m.num_links)).all(), "parents must precede children"
+        assert m.link_chain_offsets[-1] == len(m.link_chain_data)
+        assert m.joint_map.max() == m.num_dof - 1
+        assert m.collision_pairs.dtype == np.int16 and (m.collision_pairs[:, 0] < m.collision_pairs[:, 1]).all()
+        assert m.fixed_transforms.dtype == np.float32
+
+
+def test_franka_locked_fingers_are_fixed_links(franka):
+    lf, rf = franka.link_names.index("panda_leftfinger"), franka.link_names.index("panda_rightfinger")
+    assert franka.joint_map_type[lf] == -1 and franka.joint_map_type[rf] == -1
+    assert franka.lock_joints == {"panda_finger_joint1": 0.04, "panda_finger_joint2": 0.04}
+    # prismatic along +y / -y by 0.04 m from the hand frame
+    assert franka.fixed_transforms[lf, 1, 3] == pytest.approx(0.04, abs=1e-6)
+    assert franka.fixed_transforms[rf, 1, 3] == pytest.approx(-0.04, abs=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONTENT), reason="reference checkout not present")
+@pytest.mark.parametrize("name", ["franka", "ur10e"])
+def test_loader_reproduces_packaged_fixture(name):
+    from curobo_amd.robot import load_robot_model
+
+    fresh = load_robot_model(f"{REF_CONTENT}/configs/robot/{name}.yml", f"{REF_CONTENT}/assets")
+    packed = load_model(name)
+    for k, v in fresh.as_dict().items():
+        np.testing.assert_array_equal(v, packed.as_dict()[k], err_msg=k)
+    assert fresh.joint_names == packed.joint_names and fresh.link_names == packed.link_names
+
+
+def test_inverse_pose_roundtrip():
+    from curobo_amd.scene import inverse_pose7
+
+    p = [0.3, -0.2, 0.5, 0.8, 0.1, -0.5, 0.3]
+    pi = inverse_pose7(p)
+    back = inverse_pose7(pi)
+    q = np.asarray(p[3:]) / np.linalg.norm(p[3:])
+    np.testing.assert_allclose(back[:3], p[:3], atol=1e-12)
+    np.testing.assert_allclose(back[3:], q, atol=1e-12)
+
+
+def test_seed_knots_are_sharding_invariant(franka):
+    from curobo_amd.workloads import seed_knots
+
+    full = seed_knots(franka, 8, 12, seed=2)
+    lo, hi = seed_knots(franka, 4, 12, seed=2, seed_offset=0), seed_knots(franka, 4, 12, seed=2, seed_offset=4)
+    np.testing.assert_array_equal(full, np.concatenate([lo, hi]))
+    assert (full >= franka.joint_limits_position[0]).all() and (full <= franka.joint_limits_position[1]).all()
+
+
+def test_rollout_oracle_composition_runs(oracle, franka):
+    """the oracle pipeline used by smoke()/bench cpu_baseline: finite, positive costs, FD-consistent"""
+    from curobo_amd.scene import cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    arrays = cuboid_scene_arrays(c2_world())
+    knots = seed_knots(franka, 4, 12, seed=1)
+    start = start_configuration(franka)
+    kw = dict(use_sweep=False, use_speed_metric=False)  # smooth variant for the FD check
+    r = rollout_cost_and_gradient(oracle, franka.as_dict(), arrays, knots, start, **kw)
+    assert np.isfinite(r["cost"]).all() and (r["cost"] > 0).any()
+    b = int(np.argmax(r["cost"]))
+    g = r["grad_knots"][b]
+    k, d = np.unravel_index(np.argmax(np.abs(g)), g.shape)
+    eps = 2e-4
+    kp, km = knots.copy(), knots.copy()
+    kp[b, k, d] += eps
+    km[b, k, d] -= eps
+    fd = (rollout_cost_and_gradient(oracle, franka.as_dict(), arrays, kp, start, **kw)["cost"][b].astype(np.float64)
+          - rollout_cost_and_gradient(oracle, franka.as_dict(), arrays, km, start, **kw)["cost"][b]) / (2 * eps)
+    assert fd == pytest.approx(g[k, d], rel=0.15), (fd, g[k, d])

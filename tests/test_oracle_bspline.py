@@ -1,0 +1,94 @@
+"""Pins for the B-spline oracle: boundary conditions the reference documents
+(bspline_interpolation.cuh:110-124: start state fixes the first knots, the last knot is replicated
+to come to rest, implicit goal state enforces the goal) and VJP vs finite differences
+(reference curobo/tests/_src/transition/test_transition_gradients.py)."""
+
+import numpy as np
+import pytest
+
+
+def _case(oracle, degree, implicit, rng, b=3, nk=10, dof=4, interp=3, dt=0.07):
+    ph = (nk + degree + 1) * interp + 1
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda: {k: (rng.normal(size=(1, dof)) * s).astype(np.float32)  # noqa: E731
+                  for k, s in (("position", 1.0), ("velocity", 0.3), ("acceleration", 0.2), ("jerk", 0.1))}
+    start, goal = mk(), mk()
+    idx = np.zeros(b, np.int32)
+    out = oracle.bspline_forward(u, start, goal, idx, idx, np.array([dt], np.float32),
+                                 np.array([implicit], np.uint8), ph, degree)
+    return u, start, goal, out, ph, dt, interp
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_start_boundary_conditions(degree, oracle):
+    u, start, goal, out, ph, dt, interp = _case(oracle, degree, False, np.random.default_rng(degree))
+    np.testing.assert_allclose(out["position"][:, 0], np.broadcast_to(start["position"], out["position"][:, 0].shape), atol=2e-5)
+    np.testing.assert_allclose(out["velocity"][:, 0], np.broadcast_to(start["velocity"], out["velocity"][:, 0].shape), atol=2e-4)
+    np.testing.assert_allclose(out["acceleration"][:, 0], np.broadcast_to(start["acceleration"], out["acceleration"][:, 0].shape), atol=3e-3)
+    if degree >= 4:  # a cubic cannot control jerk (FixedKnotCoeffsData<3> jerk row is zero)
+        np.testing.assert_allclose(out["jerk"][:, 0], np.broadcast_to(start["jerk"], out["jerk"][:, 0].shape), atol=5e-2)
+    np.testing.assert_allclose(out["dt"], dt)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_replicated_goal_comes_to_rest_at_last_knot(degree, oracle):
+    u, start, goal, out, ph, dt, interp = _case(oracle, degree, False, np.random.default_rng(10 + degree))
+    np.testing.assert_allclose(out["position"][:, -1], u[:, -1], atol=1e-5)
+    np.testing.assert_allclose(out["velocity"][:, -1], 0.0, atol=1e-4)
+    np.testing.assert_allclose(out["acceleration"][:, -1], 0.0, atol=2e-3)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_implicit_goal_state_is_reached(degree, oracle):
+    """With an implicit goal the reference re-uses the START fixed-knot coefficients for the goal
+    side (bspline_boundary_constraint.cuh:330-367), so the goal state is met at the beginning of
+    the last knot interval (h = horizon - interpolation_steps); the remaining interval is the
+    constant-acceleration continuation of that state."""
+    u, start, goal, out, ph, dt, interp = _case(oracle, degree, True, np.random.default_rng(20 + degree))
+    h = ph - 1 - interp
+    bc = lambda a, ref: np.broadcast_to(ref, a.shape)  # noqa: E731
+    np.testing.assert_allclose(out["position"][:, h], bc(out["position"][:, h], goal["position"]), atol=3e-5)
+    np.testing.assert_allclose(out["velocity"][:, h], bc(out["velocity"][:, h], goal["velocity"]), atol=3e-4)
+    np.testing.assert_allclose(out["acceleration"][:, h], bc(out["acceleration"][:, h], goal["acceleration"]), atol=5e-3)
+    # the last free knot does not influence the trajectory (bspline_interpolation.cuh:186-205)
+    u2 = u.copy()
+    u2[:, -1] += 1.0
+    idx = np.zeros(u.shape[0], np.int32)
+    out2 = oracle.bspline_forward(u2, start, goal, idx, idx, np.array([dt], np.float32), np.array([1], np.uint8), ph, degree)
+    np.testing.assert_array_equal(out2["position"], out["position"])
+
+
+@pytest.mark.parametrize("degree", [3, 5])
+def test_derivatives_are_consistent(degree, oracle):
+    """velocity ~ d position / dt by central differences inside the spline"""
+    u, start, goal, out, ph, dt, interp = _case(oracle, degree, False, np.random.default_rng(30 + degree), interp=8, dt=0.01)
+    p, v = out["position"].astype(np.float64), out["velocity"].astype(np.float64)
+    fd = (p[:, 2:] - p[:, :-2]) / (2 * dt)
+    np.testing.assert_allclose(v[:, 1:-1][:, 5:-10], fd[:, 5:-10], atol=2e-2 * max(1.0, np.abs(fd).max()))
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+@pytest.mark.parametrize("implicit", [False, True])
+def test_backward_is_the_transpose_of_forward(degree, implicit, oracle):
+    """The map knots -> (p, v, a, j) is affine, so <J u, g> == <u, J^T g> exactly (up to fp32)
+    once the constant (start/goal) part is removed; this checks the VJP against the forward
+    oracle without finite-difference noise."""
+    rng = np.random.default_rng(40 + degree + int(implicit))
+    b, nk, dof, interp, dt = 2, 9, 3, 2, 0.05
+    ph = (nk + degree + 1) * interp + 1
+    z = {k: np.zeros((1, dof), np.float32) for k in ("position", "velocity", "acceleration", "jerk")}
+    idx = np.zeros(b, np.int32)
+    dts, imp = np.array([dt], np.float32), np.array([implicit], np.uint8)
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    f = oracle.bspline_forward(u, z, z, idx, idx, dts, imp, ph, degree)  # linear part only (zero boundary states)
+    g = [rng.normal(size=(b, ph, dof)).astype(np.float32) for _ in range(4)]
+    # scale derivative gradients so all four terms contribute comparably
+    g[1] *= dt * interp
+    g[2] *= (dt * interp) ** 2
+    g[3] *= (dt * interp) ** 3
+    gu = oracle.bspline_backward(*g, dts, idx, imp, nk, degree)
+    lhs = sum((f[k].astype(np.float64) * gg).sum() for k, gg in zip(("position", "velocity", "acceleration", "jerk"), g))
+    rhs = (u.astype(np.float64) * gu).sum()
+    assert lhs == pytest.approx(rhs, rel=2e-4, abs=1e-3)
+    if implicit:  # last knot is ignored with an implicit goal state: zero gradient
+        assert not gu[:, -1].any()
