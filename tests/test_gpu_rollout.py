@@ -71,8 +71,8 @@ def test_rollout_cost_and_gradient_matches_oracle(oracle, device):
     still = np.zeros(sp.shape[:3], bool)
     still[:, 1:] |= step < 1e-5
     still[:, :-1] |= step < 1e-5
-    assert still.mean() < 0.25
     mv = ~still
+    assert (wc["distance"][mv] > 0).sum() > 100, "moving spheres must include collisions"
     dmax = max(1.0, wc["distance"].max())
     np.testing.assert_allclose(g(ro.scene_dist)[mv], wc["distance"][mv], rtol=2e-4, atol=2e-5 * dmax)
     gmax = max(1.0, np.abs(wc["gradient"]).max())
