@@ -177,6 +177,6 @@ def launch_kinematics_backward(
         ptr(link_chain_data), ptr(link_chain_offsets), ptr(joint_links_data),
         ptr(joint_links_offsets), ptr(joint_affects_endeffector), ptr(joint_offset_map),
         ptr(env_query_idx), num_envs, batch_size, horizon, n_joints, num_spheres,
-        link_map.shape[0], tool_frame_map.shape[0], int(compute_com), int(compute_jacobian_grad),
-        current_stream(grad_out),
+        link_map.shape[0], tool_frame_map.shape[0], link_chain_data.shape[0], int(compute_com),
+        int(compute_jacobian_grad), current_stream(grad_out),
     ))

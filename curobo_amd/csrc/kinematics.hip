@@ -250,26 +250,36 @@ struct FkBwdArgs {
   const int16_t *link_chain_offsets;
   const float *joint_offset;
   const int32_t *env_query_idx;
-  int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames, dpad;
+  int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames, dpad, chain_len;
+};
+
+// Small robot tables staged in LDS once per workgroup (the chain walk is a pointer chase; from
+// global memory every step is a dependent L1/L2 round trip).
+struct BwdTables {
+  const int *chain;      // [C]   link indices, CSR data
+  const int *chain_off;  // [L+1] CSR offsets
+  const int *link_info;  // [L]   (joint_type + 1) | joint_index << 8   (joint_type in [-1,5])
+  const float *sign;     // [L]   joint_offset[2*l] (axis sign x mimic multiplier)
 };
 
 // gradient of one world point p with cost gradient g, pushed down the chain of link `l`
 // (reference kinematics_backward_helper.cuh:62-98, kinematics_joint_util.cuh:13-66)
 __device__ __forceinline__ void chain_point_vjp(float *__restrict__ psum, const float *__restrict__ cumul,
-                                                const FkBwdArgs &a, int l, f3 p, f3 g) {
-  const int cs = a.link_chain_offsets[l];
-  for (int ci = a.link_chain_offsets[l + 1] - 1; ci >= cs; ci--) {
-    const int j = a.link_chain_data[ci];
-    const int jt = a.joint_map_type[j];
+                                                const BwdTables &t, int l, f3 p, f3 g) {
+  const int cs = t.chain_off[l];
+  for (int ci = t.chain_off[l + 1] - 1; ci >= cs; ci--) {
+    const int j = t.chain[ci];
+    const int info = t.link_info[j];
+    const int jt = (info & 0xff) - 1;
     if (jt < J_X_PRISM) continue;
-    const float sign = a.joint_offset[j * 2];
+    const float sign = t.sign[j];
     const float *C = cumul + j * 12;
     const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
     const f3 axis = make_f3(C[ax], C[4 + ax], C[8 + ax]);
     float r;
     if (jt >= J_X_ROT) r = dot(sign * g, cross(axis, p - make_f3(C[3], C[7], C[11])));
     else r = sign * dot(axis, g);
-    atomicAdd(&psum[a.joint_map[j]], r);  // own LDS row: ds_add_f32, never contended
+    atomicAdd(&psum[info >> 8], r);  // own LDS row: ds_add_f32, never contended
   }
 }
 
@@ -280,6 +290,10 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   const int pts = blockDim.x / kFkLanes;
   float *cumul = smem;                          // [pts][L][12]
   float *psum_all = smem + pts * L * 12;        // [pts][16][dpad]
+  int *s_chain_off = reinterpret_cast<int *>(psum_all + pts * kFkLanes * a.dpad);  // [L+1]
+  int *s_link_info = s_chain_off + (L + 1);                                        // [L]
+  float *s_sign = reinterpret_cast<float *>(s_link_info + L);                      // [L]
+  int *s_chain = reinterpret_cast<int *>(s_sign + L);                              // [C]
   const int tid = threadIdx.x;
   const int pt0 = blockIdx.x * pts;
   const int npts = min(pts, a.n_points - pt0);
@@ -290,7 +304,14 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
     for (int i = tid; i < npts * L * 3; i += blockDim.x) dst[i] = src[i];
   }
   for (int i = tid; i < pts * kFkLanes * a.dpad; i += blockDim.x) psum_all[i] = 0.0f;
+  for (int l = tid; l <= L; l += blockDim.x) s_chain_off[l] = a.link_chain_offsets[l];
+  for (int l = tid; l < L; l += blockDim.x) {
+    s_link_info[l] = ((int)a.joint_map_type[l] + 1) | ((int)(a.joint_map[l] < 0 ? 0 : a.joint_map[l]) << 8);
+    s_sign[l] = a.joint_offset[2 * l];
+  }
+  for (int c = tid; c < a.chain_len; c += blockDim.x) s_chain[c] = a.link_chain_data[c];
   __syncthreads();
+  const BwdTables tb{s_chain, s_chain_off, s_link_info, s_sign};
 
   const int grp = tid / kFkLanes, lane = tid % kFkLanes;
   if (grp >= npts) return;
@@ -312,7 +333,7 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
       if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f) continue;
       const int l = a.link_sphere_map[s];
       const float4 pw = transform_sphere(my_cumul + l * 12, rs[s]);
-      chain_point_vjp(psum, my_cumul, a, l, make_f3(pw.x, pw.y, pw.z), make_f3(g4.x, g4.y, g4.z));
+      chain_point_vjp(psum, my_cumul, tb, l, make_f3(pw.x, pw.y, pw.z), make_f3(g4.x, g4.y, g4.z));
     }
   }
   // ---- tool frames: position + orientation (reference :102-183), chain split across lanes
@@ -330,12 +351,13 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
     const f3 om = make_f3(0.5f * (-qx.x * dqw + qx.w * dqx + qx.z * dqy - qx.y * dqz),
                           0.5f * (-qx.y * dqw - qx.z * dqx + qx.w * dqy + qx.x * dqz),
                           0.5f * (-qx.z * dqw + qx.y * dqx - qx.x * dqy + qx.w * dqz));
-    const int cs = a.link_chain_offsets[l], ce = a.link_chain_offsets[l + 1];
+    const int cs = s_chain_off[l], ce = s_chain_off[l + 1];
     for (int ci = cs + lane; ci < ce; ci += kFkLanes) {
-      const int j = a.link_chain_data[ci];
-      const int jt = a.joint_map_type[j];
+      const int j = s_chain[ci];
+      const int info = s_link_info[j];
+      const int jt = (info & 0xff) - 1;
       if (jt < J_X_PRISM) continue;
-      const float sign = a.joint_offset[j * 2];
+      const float sign = s_sign[j];
       const float *Cj = my_cumul + j * 12;
       const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
       const f3 axis = make_f3(Cj[ax], Cj[4 + ax], Cj[8 + ax]);
@@ -344,7 +366,7 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
         r = dot(sign * g, cross(axis, pos - make_f3(Cj[3], Cj[7], Cj[11]))) + sign * dot(axis, om);
       else
         r = sign * dot(axis, g);
-      atomicAdd(&psum[a.joint_map[j]], r);
+      atomicAdd(&psum[info >> 8], r);
     }
   }
   // ---- centre of mass (reference :186-291)
@@ -357,7 +379,7 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
         if (mc.w <= 0.0f) continue;
         const f3 g = make_f3(gc.x * mc.w / total_mass, gc.y * mc.w / total_mass, gc.z * mc.w / total_mass);
         const float4 cw = transform_sphere(my_cumul + l * 12, mc);
-        chain_point_vjp(psum, my_cumul, a, l, make_f3(cw.x, cw.y, cw.z), g);
+        chain_point_vjp(psum, my_cumul, tb, l, make_f3(cw.x, cw.y, cw.z), g);
       }
     }
   }
@@ -492,14 +514,15 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
     const int16_t *link_chain_offsets, const int16_t *joint_links_data,
     const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
     const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
-    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int compute_com,
-    int compute_jacobian_grad, curobo_hip_stream_t stream) {
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int link_chain_len,
+    int compute_com, int compute_jacobian_grad, curobo_hip_stream_t stream) {
   (void)grad_jacobian; (void)link_map; (void)joint_links_data; (void)joint_links_offsets;
   (void)joint_affects_endeffector;
   const char *what = "launch_kinematics_backward";
   CUROBO_REQUIRE(!compute_jacobian_grad, "%s: compute_jacobian_grad is not supported by the HIP backend yet", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128, "%s: num_links=%d out of range [1,128]", what, num_links);
   CUROBO_REQUIRE(n_joints >= 1 && n_joints <= 1024, "%s: n_joints=%d out of range", what, n_joints);
+  CUROBO_REQUIRE(link_chain_len >= 1 && link_chain_len <= 16384, "%s: link_chain_len=%d out of range", what, link_chain_len);
   CUROBO_REQUIRE(((uintptr_t)grad_nlinks_quat & 15) == 0, "%s: grad_nlinks_quat is not aligned to 16 bytes", what);
   if (batch_size == 0) return CUROBO_HIP_OK;
   FkBwdArgs a{};
@@ -513,10 +536,12 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
   a.n_points = batch_size; a.horizon = horizon; a.nspheres = grad_spheres ? num_spheres : 0;
   a.num_envs = num_envs; a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
   a.dpad = n_joints | 1;  // odd row stride: conflict-free column reads
+  a.chain_len = link_chain_len;
   int pts = fk_points_per_block(num_links);
   size_t lds = 0;
   for (;;) {
-    lds = ((size_t)pts * num_links * 12 + (size_t)pts * kFkLanes * a.dpad) * sizeof(float);
+    lds = ((size_t)pts * num_links * 12 + (size_t)pts * kFkLanes * a.dpad + 3 * (size_t)num_links + 1 +
+           (size_t)a.chain_len) * sizeof(float);
     if (lds <= 60 * 1024 || pts == 4) break;
     pts /= 2;
   }

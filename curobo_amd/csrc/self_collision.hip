@@ -2,13 +2,15 @@
 // on the arg-max pair only (reference kernels/geometry/self_collision/self_collision_kernel.cuh
 // :19-297, self_collision_helper.cuh:61-349, collision_pair.cuh:13-103).
 //
-// gfx950 design: one wavefront owns one point when the pair list is small (franka: 818 pairs =
-// 13 per lane) -- the point's spheres sit in LDS as float4, pair indices stream as packed
-// int16x2 dwords (coalesced, L2 resident), and the (value, pair-index) arg-max is a pure wave64
-// butterfly: no __syncthreads and no second kernel.  Large pair lists (humanoids: 1.6e5 pairs)
-// give the point to the 4 waves of a workgroup and finish with a 4-entry LDS reduction; the
-// reference's two-kernel map-reduce (self_collision_max_block_kernel + _max_reduce_kernel) and
-// its block_batch_max_* scratch are not needed.
+// gfx950 design: for arms (franka: 818 pairs) a point is owned by a 16-lane DPP row, 4 points per
+// wave64 and 16 per workgroup: the 16 points' spheres are one contiguous float4 run (coalesced),
+// the pair list (packed int16x2 dwords) is staged in LDS once per workgroup, each lane scans 4
+// pairs per iteration (the list is (i,j)-sorted: sph[i] is a broadcast, sph[j] a conflict-free
+// run), and the (value, pair-index) arg-max is 8 DPP row operations -- no __syncthreads after
+// the staging barrier, no second kernel.  Humanoids (1.6e5 pairs, 674 spheres) give a point to
+// a whole wave and stream the pair list through LDS in 4096-pair tiles shared by the 8 points
+// of a workgroup; the reference's two-kernel map-reduce (self_collision_max_block_kernel +
+// _max_reduce_kernel) and its block_batch_max_* scratch are not needed.
 // Canonical tie rule: equal maxima -> lowest index in pair_locations.
 #include "common.hpp"
 
@@ -33,81 +35,224 @@ __device__ __forceinline__ void argmax_merge(float &v, int &k, float ov, int ok)
   k = take ? ok : k;
 }
 
-template <int WAVES_PER_POINT>
-__global__ void __launch_bounds__(256) self_collision_kernel(const SelfCollArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kPointsPerBlock = 4 / WAVES_PER_POINT;
-  const int S = a.nspheres, P = a.npairs;
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int local_pt = wave / WAVES_PER_POINT;
-  const int sub = wave % WAVES_PER_POINT;  // which slice of the pair list this wave scans
-  const int n = blockIdx.x * kPointsPerBlock + local_pt;
-  float4 *sph = reinterpret_cast<float4 *>(smem) + (size_t)local_pt * S;
-  __shared__ float s_red_v[4];
-  __shared__ int s_red_k[4];
-  const bool valid_pt = n < a.n_points;
+// one pair evaluation (reference sphere_squared_distance_fused, self_collision_helper.cuh:61-71)
+__device__ __forceinline__ float pair_penetration(float4 s1, float4 s2) {
+  const float r = s1.w + s2.w;
+  const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  const float valid = (s1.w >= 0.0f && s2.w >= 0.0f) ? 1.0f : 0.0f;
+  return ((r * r) - d2) * valid;
+}
 
-  // ---- spheres (+ padding) -> LDS; zero the rows flagged by the previous call
-  //      (reference load_spheres_and_zero_gradients, self_collision_helper.cuh:151-192)
-  if (valid_pt) {
-    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
-    for (int s = sub * kWave + lane; s < S; s += kWave * WAVES_PER_POINT) {
-      float4 v = src[s];
-      v.w += a.offsets[s];
-      sph[s] = v;
-      if (a.sparse_index[(size_t)n * S + s]) {
-        reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        a.sparse_index[(size_t)n * S + s] = 0;
+// Scan pairs [k_begin, k_end) of the LDS-resident pair tile for the wave's point.  Four pairs per
+// lane are in flight per iteration (pair dwords first, then the 8 sphere reads) so the two
+// dependent LDS round trips overlap.  Consecutive lanes take consecutive pairs: the list is
+// (i, j)-sorted, so sph[i] is mostly a broadcast and sph[j] a conflict-free run.
+template <bool STORE>
+__device__ __forceinline__ void scan_pairs(const uint32_t *__restrict__ s_pairs, const float4 *__restrict__ sph,
+                                           int tile_base, int tile_count, int lane, float *pair_out,
+                                           float &best, int &best_k) {
+  constexpr int U = 4;
+  for (int k0 = lane; k0 < tile_count; k0 += kWave * U) {
+    uint32_t ij[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + u * kWave;
+      ij[u] = s_pairs[k < tile_count ? k : 0];
+    }
+    float f[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = (int)(int16_t)(ij[u] & 0xffffu), j = (int)(int16_t)(ij[u] >> 16);
+      f[u] = pair_penetration(sph[i], sph[j]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + u * kWave;
+      if (k < tile_count) {
+        if (STORE) pair_out[tile_base + k] = f[u];
+        if (f[u] > best) { best = f[u]; best_k = tile_base + k; }
       }
     }
   }
-  if (WAVES_PER_POINT > 1) __syncthreads();
-  else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+}
 
-  // ---- scan this wave's slice of the pair list
+// NWAVES waves per workgroup, one point per wave at a time, PPW points per wave in sequence.
+// The pair list is staged through LDS in tiles of `tile_pairs` dwords shared by all waves
+// (small robots: a single tile loaded once per workgroup; humanoids: 4096-pair tiles).
+template <int NWAVES, bool STORE>
+__global__ void __launch_bounds__(NWAVES * 64) self_collision_kernel(const SelfCollArgs a, int ppw, int tile_pairs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.nspheres, P = a.npairs;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  float4 *sph = reinterpret_cast<float4 *>(smem) + (size_t)wave * S;
+  uint32_t *s_pairs = reinterpret_cast<uint32_t *>(reinterpret_cast<float4 *>(smem) + (size_t)NWAVES * S);
+  const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pair_locations);
+  const bool single_tile = P <= tile_pairs;
+  if (single_tile) {
+    for (int k = threadIdx.x; k < P; k += NWAVES * kWave) s_pairs[k] = g_pairs[k];
+    __syncthreads();
+  }
+  const int pt_base = (blockIdx.x * NWAVES + wave) * ppw;
+  for (int it = 0; it < ppw; it++) {
+    const int n = pt_base + it;
+    const bool valid_pt = n < a.n_points;
+    // ---- spheres (+ padding) -> this wave's LDS slot; zero rows flagged by the previous call
+    //      (reference load_spheres_and_zero_gradients, self_collision_helper.cuh:151-192)
+    if (valid_pt) {
+      const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
+      for (int s = lane; s < S; s += kWave) {
+        float4 v = src[s];
+        v.w += a.offsets[s];
+        sph[s] = v;
+        if (a.sparse_index[(size_t)n * S + s]) {
+          reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a.sparse_index[(size_t)n * S + s] = 0;
+        }
+      }
+    }
+    float best = 0.0f;
+    int best_k = -1;
+    float *pair_out = STORE ? a.pair_distance + (size_t)(valid_pt ? n : 0) * P : nullptr;
+    if (single_tile) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (valid_pt) scan_pairs<STORE>(s_pairs, sph, 0, P, lane, pair_out, best, best_k);
+    } else {
+      for (int t0 = 0; t0 < P; t0 += tile_pairs) {
+        const int cnt = min(tile_pairs, P - t0);
+        __syncthreads();  // previous tile fully consumed (and sphere slots written)
+        for (int k = threadIdx.x; k < cnt; k += NWAVES * kWave) s_pairs[k] = g_pairs[t0 + k];
+        __syncthreads();
+        if (valid_pt) scan_pairs<STORE>(s_pairs, sph, t0, cnt, lane, pair_out, best, best_k);
+      }
+    }
+    // wave64 butterfly arg-max on (value, pair index); ties -> lowest pair index
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, kWave);
+      const int ok = __shfl_xor(best_k, off, kWave);
+      argmax_merge(best, best_k, ov, ok);
+    }
+    // ---- finalize (reference finalize_collision_results, self_collision_helper.cuh:277-349)
+    if (valid_pt && lane == 0) {
+      if (best_k < 0 || best <= 0.0f) {
+        a.out_distance[n] = 0.0f;
+      } else {
+        const float w = a.weight[0];
+        a.out_distance[n] = 0.5f * w * best;
+        if (a.write_grad) {
+          const int i = a.pair_locations[2 * best_k], j = a.pair_locations[2 * best_k + 1];
+          const float4 s1 = sph[i], s2 = sph[j];
+          const float vx = w * (s2.x - s1.x), vy = w * (s2.y - s1.y), vz = w * (s2.z - s1.z);
+          float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
+          g[i] = make_float4(vx, vy, vz, w * -1.0f);
+          g[j] = make_float4(-1.0f * vx, -1.0f * vy, -1.0f * vz, w * -1.0f);
+          a.sparse_index[(size_t)n * S + i] = 1;
+          a.sparse_index[(size_t)n * S + j] = 1;
+        }
+      }
+    }
+    // the sphere slot is rewritten by the next point: all lanes must be done reading it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- small pair lists (arms): 16 lanes per point, 4 points per wave, 16 points per workgroup.
+// Spheres of the 16 points are one contiguous float4 run in HBM (coalesced load), the pair list
+// is staged once per workgroup, and the (value, index) arg-max never leaves a 16-lane DPP row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, dpp_i<0xB1>(v));
+  v = min(v, dpp_i<0x4E>(v));
+  v = min(v, dpp_i<0x141>(v));
+  v = min(v, dpp_i<0x140>(v));
+  return v;
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256) self_collision_row16_kernel(const SelfCollArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kLanes = 16, kPts = 16, U = 4;
+  const int S = a.nspheres, P = a.npairs;
+  const int tid = threadIdx.x, grp = tid / kLanes, lane = tid % kLanes;
+  float4 *sph_all = reinterpret_cast<float4 *>(smem);                       // [16][S]
+  uint32_t *s_pairs = reinterpret_cast<uint32_t *>(sph_all + (size_t)kPts * S);  // [P]
+  const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pair_locations);
+  const int pt0 = blockIdx.x * kPts;
+  const int npts = min(kPts, a.n_points - pt0);
+  {  // spheres (+ padding) of the workgroup's points; zero rows flagged by the previous call
+    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)pt0 * S;
+    const size_t flat0 = (size_t)pt0 * S;
+    for (int i = tid; i < npts * S; i += 256) {
+      float4 v = src[i];
+      v.w += a.offsets[i % S];
+      sph_all[i] = v;
+      if (a.sparse_index[flat0 + i]) {
+        reinterpret_cast<float4 *>(a.out_gradient)[flat0 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.sparse_index[flat0 + i] = 0;
+      }
+    }
+    for (int k = tid; k < P; k += 256) s_pairs[k] = g_pairs[k];
+  }
+  __syncthreads();
+  const int n = pt0 + grp;
+  const bool valid_pt = grp < npts;
+  const float4 *sph = sph_all + (size_t)grp * S;
   float best = 0.0f;
-  int best_k = -1;
+  int best_k = 0x7fffffff;
   if (valid_pt) {
-    const uint32_t *pairs = reinterpret_cast<const uint32_t *>(a.pair_locations);
-    for (int k = sub * kWave + lane; k < P; k += kWave * WAVES_PER_POINT) {
-      const uint32_t ij = pairs[k];
-      const int i = (int)(int16_t)(ij & 0xffffu), j = (int)(int16_t)(ij >> 16);
-      const float4 s1 = sph[i], s2 = sph[j];
-      // reference sphere_squared_distance_fused, self_collision_helper.cuh:61-71
-      const float r = s1.w + s2.w;
-      const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      const float valid = (s1.w >= 0.0f && s2.w >= 0.0f) ? 1.0f : 0.0f;
-      const float f = ((r * r) - d2) * valid;
-      if (a.store_pair_distance) a.pair_distance[(size_t)n * P + k] = f;
-      if (f > best) { best = f; best_k = k; }
+    for (int k0 = lane; k0 < P; k0 += kLanes * U) {
+      uint32_t ij[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = k0 + u * kLanes;
+        ij[u] = s_pairs[k < P ? k : 0];
+      }
+      float f[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = (int)(int16_t)(ij[u] & 0xffffu), j = (int)(int16_t)(ij[u] >> 16);
+        f[u] = pair_penetration(sph[i], sph[j]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = k0 + u * kLanes;
+        if (k < P) {
+          if (STORE) a.pair_distance[(size_t)n * P + k] = f[u];
+          if (f[u] > best) { best = f[u]; best_k = k; }
+        }
+      }
     }
   }
-  // wave64 butterfly arg-max
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(best, off, kWave);
-    const int ok = __shfl_xor(best_k, off, kWave);
-    argmax_merge(best, best_k, ov, ok);
-  }
-  if (WAVES_PER_POINT > 1) {
-    if (lane == 0) { s_red_v[wave] = best; s_red_k[wave] = best_k; }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int w = 1; w < WAVES_PER_POINT; w++) argmax_merge(best, best_k, s_red_v[w], s_red_k[w]);
-  }
+  // arg-max inside the 16-lane row: max value, then the lowest pair index that attains it
+  const float m = row16_max(best);
+  const int kmin = row16_min((best == m && best > 0.0f) ? best_k : 0x7fffffff);
   if (!valid_pt || lane != 0) return;
-
-  // ---- finalize (reference finalize_collision_results, self_collision_helper.cuh:277-349)
-  if (best_k < 0 || best <= 0.0f) {
+  if (kmin == 0x7fffffff || m <= 0.0f) {
     a.out_distance[n] = 0.0f;
     return;
   }
   const float w = a.weight[0];
-  a.out_distance[n] = 0.5f * w * best;
+  a.out_distance[n] = 0.5f * w * m;
   if (a.write_grad) {
-    const int i = a.pair_locations[2 * best_k], j = a.pair_locations[2 * best_k + 1];
+    const uint32_t ij = s_pairs[kmin];
+    const int i = (int)(int16_t)(ij & 0xffffu), j = (int)(int16_t)(ij >> 16);
     const float4 s1 = sph[i], s2 = sph[j];
     const float vx = w * (s2.x - s1.x), vy = w * (s2.y - s1.y), vz = w * (s2.z - s1.z);
     float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
@@ -116,6 +261,14 @@ __global__ void __launch_bounds__(256) self_collision_kernel(const SelfCollArgs 
     a.sparse_index[(size_t)n * S + i] = 1;
     a.sparse_index[(size_t)n * S + j] = 1;
   }
+}
+
+template <int NWAVES>
+static void launch_self(const SelfCollArgs &a, int blocks, size_t lds, int ppw, int tile, hipStream_t st) {
+  if (a.store_pair_distance)
+    hipLaunchKernelGGL((self_collision_kernel<NWAVES, true>), dim3(blocks), dim3(NWAVES * 64), lds, st, a, ppw, tile);
+  else
+    hipLaunchKernelGGL((self_collision_kernel<NWAVES, false>), dim3(blocks), dim3(NWAVES * 64), lds, st, a, ppw, tile);
 }
 
 }  // namespace curobo_hip
@@ -132,7 +285,7 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
   (void)block_batch_max_value; (void)block_batch_max_index; (void)num_blocks_per_batch;
   (void)max_threads_per_block;
   const char *what = "self_collision_distance";
-  CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 2048, "%s: nspheres=%d out of range [1,2048]", what, nspheres);
+  CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 768, "%s: nspheres=%d out of range [1,768]", what, nspheres);
   CUROBO_REQUIRE(num_collision_pairs >= 0, "%s: negative num_collision_pairs", what);
   CUROBO_REQUIRE(((uintptr_t)pair_locations & 3) == 0, "%s: pair_locations must be 4-byte aligned", what);
   CUROBO_REQUIRE(!store_pair_distance || pair_distance, "%s: store_pair_distance needs pair_distance", what);
@@ -145,12 +298,24 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
   a.n_points = (int)n_points; a.nspheres = nspheres; a.npairs = num_collision_pairs;
   a.store_pair_distance = store_pair_distance; a.write_grad = compute_grad;
   hipStream_t st = (hipStream_t)stream;
-  if (num_collision_pairs > 4096) {
-    const size_t lds = (size_t)nspheres * 16;
-    hipLaunchKernelGGL((self_collision_kernel<4>), dim3((unsigned)n_points), dim3(256), lds, st, a);
+  const int P = num_collision_pairs;
+  const size_t lds16 = (size_t)16 * nspheres * 16 + (size_t)(P > 0 ? P : 1) * 4;
+  if (P <= 8192 && lds16 <= 60 * 1024) {
+    // arms: 16 lanes per point, 16 points per workgroup, whole pair list resident in LDS
+    const unsigned blocks = (unsigned)ceil_div_l(n_points, 16);
+    if (store_pair_distance)
+      hipLaunchKernelGGL((self_collision_row16_kernel<true>), dim3(blocks), dim3(256), lds16, st, a);
+    else
+      hipLaunchKernelGGL((self_collision_row16_kernel<false>), dim3(blocks), dim3(256), lds16, st, a);
+  } else if (P <= 8192) {
+    const size_t lds = (size_t)4 * nspheres * 16 + (size_t)(P > 0 ? P : 1) * 4;
+    launch_self<4>(a, (int)ceil_div_l(n_points, 4), lds, 1, P > 0 ? P : 1, st);
   } else {
-    const size_t lds = (size_t)nspheres * 16 * 4;
-    hipLaunchKernelGGL((self_collision_kernel<1>), dim3((unsigned)ceil_div_l(n_points, 4)), dim3(256), lds, st, a);
+    // humanoids: 4096-pair tiles shared by 8 (or 4) concurrent points of a workgroup
+    const int tile = 4096;
+    const size_t lds8 = (size_t)8 * nspheres * 16 + (size_t)tile * 4;
+    if (lds8 <= 64 * 1024) launch_self<8>(a, (int)ceil_div_l(n_points, 8), lds8, 1, tile, st);
+    else launch_self<4>(a, (int)ceil_div_l(n_points, 4), (size_t)4 * nspheres * 16 + (size_t)tile * 4, 1, tile, st);
   }
   return check_launch(what, st);
 }

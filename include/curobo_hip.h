@@ -81,7 +81,8 @@ int curobo_hip_launch_kinematics_forward_spheres_jacobian(
 /* replaces launch_kinematics_backward (cuda_core_backend/kinematics.py:303-379).
  * grad_spheres_b (extension, may be NULL): a second sphere-gradient buffer that is added to
  * grad_spheres on the fly, so the self-collision and scene-collision gradient buffers can be
- * consumed without a separate elementwise add.  compute_jacobian_grad != 0 is rejected
+ * consumed without a separate elementwise add.  link_chain_len = number of entries of
+ * link_chain_data (link_chain_data.shape[0] in the reference).  compute_jacobian_grad != 0 is rejected
  * (CUROBO_HIP_ERR_INVALID): the dJ/dq term is a SURVEY section 8f-2 "next" row. */
 int curobo_hip_launch_kinematics_backward(
     float *grad_out, const float *grad_nlinks_pos, const float *grad_nlinks_quat,
@@ -93,8 +94,8 @@ int curobo_hip_launch_kinematics_backward(
     const int16_t *link_chain_offsets, const int16_t *joint_links_data,
     const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
     const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
-    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int compute_com,
-    int compute_jacobian_grad, curobo_hip_stream_t stream);
+    int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int link_chain_len,
+    int compute_com, int compute_jacobian_grad, curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- geometry: self collision
  * reference: cuda_core_backend/geometry.py:63-227, pybind/geometry_bindings.cpp:16-45

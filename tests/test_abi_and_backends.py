@@ -40,7 +40,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert rc == 1 and b"History_m greater than 31" in lib.curobo_hip_last_error()
     with pytest.raises(ValueError, match="History_m"):
         _lib.check(rc)
-    rc = lib.curobo_hip_launch_kinematics_backward(*([None] * 23), 1, 10, 1, 7, 65, 13, 1, 0, 1, None)
+    rc = lib.curobo_hip_launch_kinematics_backward(*([None] * 23), 1, 10, 1, 7, 65, 13, 1, 88, 0, 1, None)
     assert rc == 1 and b"compute_jacobian_grad" in lib.curobo_hip_last_error()
 
 
