@@ -44,6 +44,10 @@ def _flags() -> List[str]:
     return [
         f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
         "-ffp-contract=fast", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+        # fp32 div/sqrt as single hardware ops (<= 2.5 ulp) instead of the IEEE fix-up sequences;
+        # the reference kernels are built the same way (--prec-div=false --prec-sqrt=false,
+        # cuda_core_backend/kernel_cache.py:208-218)
+        "-fno-hip-fp32-correctly-rounded-divide-sqrt",
         f"-I{INCLUDE}", f"-I{CSRC}",
     ]
 

@@ -89,8 +89,7 @@ __device__ __forceinline__ float cuboid_sdf(float4 dims, f3 lp, f3 &g) {
 }
 
 // data_voxel.py:781-1056 + :1164-1215; g = normalised minus-gradient, 0 when sdf >= max_dist
-__device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_idx, f3 lp, f3 &g) {
-  const float4 prm = reinterpret_cast<const float4 *>(sc.voxel_params)[flat_idx];
+__device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_idx, float4 prm, f3 lp, f3 &g) {
   const int nx = (int)prm.x, ny = (int)prm.y, nz = (int)prm.z;
   const float vs = prm.w, max_dist = sc.voxel_max_distance;
   const __half *feat = reinterpret_cast<const __half *>(sc.voxel_features) + (size_t)flat_idx * sc.voxel_n_voxels;
@@ -175,12 +174,12 @@ __device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_
 }
 
 template <bool VOXEL>
-__device__ __forceinline__ float eval_point(const SceneArgs &a, int flat, f3 lp, float r_adj, float eta,
+__device__ __forceinline__ float eval_point(const SceneArgs &a, int flat, float4 shape, f3 lp, float r_adj, float eta,
                                             float &cost_sum, f3 &grad_sum) {
   f3 g;
   float sdf;
-  if (VOXEL) sdf = voxel_sdf(a.sc, flat, lp, g);
-  else sdf = cuboid_sdf(reinterpret_cast<const float4 *>(a.sc.cuboid_dims)[flat], lp, g);
+  if (VOXEL) sdf = voxel_sdf(a.sc, flat, shape, lp, g);
+  else sdf = cuboid_sdf(shape, lp, g);
   const float pen = -sdf + r_adj;
   if (pen > 0.0f) {
     float c, gs;
@@ -191,36 +190,59 @@ __device__ __forceinline__ float eval_point(const SceneArgs &a, int flat, f3 lp,
   return pen;
 }
 
+// One obstacle record as the kernels consume it.  STAGED: the workgroup copies the records of
+// the (few) batch rows it touches into LDS once, so the obstacle loop reads them as LDS
+// broadcasts instead of a dependent global-memory round trip per field and obstacle.
+struct ObsRec {
+  float4 p;      // inverse position xyz, inverse quaternion w
+  float4 q;      // inverse quaternion xyz, enabled (1.0 / 0.0; already includes o < count)
+  float4 shape;  // cuboid: full extents xyz | voxel grid: nx ny nz voxel_size
+};
+
+template <bool VOXEL>
+__device__ __forceinline__ ObsRec load_rec_global(const SceneArgs &a, int env, int o) {
+  const int max_n = VOXEL ? a.sc.max_voxel_grids : a.sc.max_cuboids;
+  const int count = VOXEL ? a.sc.voxel_count[env] : a.sc.cuboid_count[env];
+  const uint8_t *enable = VOXEL ? a.sc.voxel_enable : a.sc.cuboid_enable;
+  const float *inv_pose = VOXEL ? a.sc.voxel_inv_pose : a.sc.cuboid_inv_pose;
+  const float *shape = VOXEL ? a.sc.voxel_params : a.sc.cuboid_dims;
+  const int flat = env * max_n + o;
+  ObsRec r;
+  r.p = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2];
+  r.q = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2 + 1];
+  r.shape = reinterpret_cast<const float4 *>(shape)[flat];
+  r.q.w = (o < count && enable[flat] == 1) ? 1.0f : 0.0f;  // is_obs_enabled, data_cuboid.py:467-485
+  return r;
+}
+
 // Sweep culling (result-preserving): every swept sample lies within half_dist of the current
 // centre (t in (0.5, 1]) and a signed distance field is 1-Lipschitz, so when the centre's
 // clearance  sdf - r_adj  exceeds half_dist (+ an interpolation slack for voxel grids) no sample
 // can penetrate and the whole sweep direction contributes exactly zero.
 // half_w* are the world-frame half segment lengths (rigid transforms preserve them).
-template <bool VOXEL, int SWEEP>
-__device__ __forceinline__ void obstacle_set(const SceneArgs &a, int env, int h, const float *sph_ptr, f3 center,
-                                             float r_adj, float eta, float w, float half_w_prev, float half_w_next,
-                                             float &dsum, f3 &gsum) {
+template <bool VOXEL, int SWEEP, bool STAGED>
+__device__ __forceinline__ void obstacle_set(const SceneArgs &a, const ObsRec *__restrict__ recs, int env, int h,
+                                             const float *sph_ptr, f3 center, float r_adj, float eta, float w,
+                                             float half_w_prev, float half_w_next, float &dsum, f3 &gsum) {
   const int max_n = VOXEL ? a.sc.max_voxel_grids : a.sc.max_cuboids;
-  if (max_n <= 0) return;
-  const int count = VOXEL ? a.sc.voxel_count[env] : a.sc.cuboid_count[env];
-  const uint8_t *enable = VOXEL ? a.sc.voxel_enable : a.sc.cuboid_enable;
-  const float *inv_pose = VOXEL ? a.sc.voxel_inv_pose : a.sc.cuboid_inv_pose;
-  const int n_obs = count < max_n ? count : max_n;
-  for (int o = 0; o < n_obs; o++) {
+  for (int o = 0; o < max_n; o++) {
+    const ObsRec rec = STAGED ? recs[o] : load_rec_global<VOXEL>(a, env, o);
+    if (rec.q.w == 0.0f) continue;
     const int flat = env * max_n + o;
-    if (enable[flat] != 1) continue;  // is_obs_enabled, data_cuboid.py:467-485
-    const Tf t = load_inv_tf(inv_pose + (size_t)flat * 8);
+    Tf t;
+    t.p = make_f3(rec.p.x, rec.p.y, rec.p.z);
+    t.qw = rec.p.w; t.qx = rec.q.x; t.qy = rec.q.y; t.qz = rec.q.z;
     const f3 lc = tf_point(t, center);
     float cost_sum = 0.0f;
     f3 grad_local = make_f3(0.f, 0.f, 0.f);
-    const float pen_c = eval_point<VOXEL>(a, flat, lc, r_adj, eta, cost_sum, grad_local);
+    const float pen_c = eval_point<VOXEL>(a, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
     if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
       // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
       const float sdf_c = r_adj - pen_c;
       const bool can_cull = VOXEL ? (sdf_c < a.sc.voxel_max_distance) : true;
       // voxel slack: interpolated values are convex combinations of corner samples that sit within
       // sqrt(3) voxels of the query, once at the centre and once at the sample, + fp16 rounding
-      const float slack = VOXEL ? 3.5f * a.sc.voxel_params[(size_t)flat * 4 + 3] + 0.002f * fabsf(sdf_c) : 0.0f;
+      const float slack = VOXEL ? 3.5f * rec.shape.w + 0.002f * fabsf(sdf_c) : 0.0f;
       const float clearance = -pen_c;
 #pragma unroll
       for (int dir = 0; dir < 2; dir++) {
@@ -238,7 +260,7 @@ __device__ __forceinline__ void obstacle_set(const SceneArgs &a, int env, int h,
             if (jump >= half_dist) break;
             const float tt = 1.0f - 0.5f * jump * inv_half;
             const f3 lp = tt * lc + (1.0f - tt) * ln;
-            const float p2 = eval_point<VOXEL>(a, flat, lp, r_adj, eta, cost_sum, grad_local);
+            const float p2 = eval_point<VOXEL>(a, flat, rec.shape, lp, r_adj, eta, cost_sum, grad_local);
             if (p2 > 0.0f) jump += p2;
             else if (-p2 >= 1000.0f) jump += r_adj;
             else jump += fmaxf(-p2, r_adj);
@@ -254,12 +276,30 @@ __device__ __forceinline__ void obstacle_set(const SceneArgs &a, int env, int h,
   }
 }
 
-template <int SWEEP>
+// KINDS: bit 0 = cuboids present, bit 1 = voxel grids present (separate instantiations keep the
+// cuboid-only kernel's register footprint free of the 8-corner voxel gather state)
+template <int SWEEP, bool STAGED, int KINDS>
 __global__ void __launch_bounds__(256) scene_collision_kernel(const SceneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const long total = (long)a.batch * a.horizon * a.nspheres;
-  const long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (sidx >= total) return;
+  const long sidx0 = (long)blockIdx.x * blockDim.x;
+  const long sidx = sidx0 + threadIdx.x;
   const int hs = a.horizon * a.nspheres;
+  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
+  const int b_first = (int)(sidx0 / hs);
+  ObsRec *recs = reinterpret_cast<ObsRec *>(smem);  // [batch rows touched by this workgroup][n_rec]
+  if (STAGED) {
+    const long last = (sidx0 + blockDim.x - 1 < total - 1) ? sidx0 + blockDim.x - 1 : total - 1;
+    const int nslots = (int)(last / hs) - b_first + 1;
+    for (int idx = threadIdx.x; idx < nslots * n_rec; idx += blockDim.x) {
+      const int slot = idx / n_rec, o = idx - slot * n_rec;
+      const int env = a.use_multi_env ? a.env_query_idx[b_first + slot] : 0;
+      recs[idx] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a, env, o)
+                                         : load_rec_global<true>(a, env, o - a.sc.max_cuboids);
+    }
+    __syncthreads();
+  }
+  if (sidx >= total) return;
   const int b = (int)(sidx / hs);
   const int h = (int)((sidx - (long)b * hs) / a.nspheres);
   const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
@@ -284,8 +324,13 @@ __global__ void __launch_bounds__(256) scene_collision_kernel(const SceneArgs a)
         half_w_next = 0.5f * sqrtf(dot(dd, dd));
       }
     }
-    obstacle_set<false, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum, gsum);
-    obstacle_set<true, SWEEP>(a, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum, gsum);
+    const ObsRec *my = recs + (size_t)(b - b_first) * n_rec;
+    if (KINDS & 1)
+      obstacle_set<false, SWEEP, STAGED>(a, my, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum,
+                                         gsum);
+    if (KINDS & 2)
+      obstacle_set<true, SWEEP, STAGED>(a, my + a.sc.max_cuboids, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev,
+                                        half_w_next, dsum, gsum);
   }
   // ---- speed metric, fused (wp_speed_metric.py:38-93)
   if (a.enable_speed_metric && h > 0 && h < a.horizon - 1 && dsum > 0.0f) {
@@ -335,7 +380,26 @@ CUROBO_EXPORT int curobo_hip_sphere_obstacle_collision(
   a.use_multi_env = use_multi_env; a.sweep_steps = sweep_steps; a.enable_speed_metric = enable_speed_metric;
   hipStream_t st = (hipStream_t)stream;
   const unsigned blocks = (unsigned)ceil_div_l(total, 256);
-  if (sweep_steps == 0) hipLaunchKernelGGL((scene_collision_kernel<0>), dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((scene_collision_kernel<3>), dim3(blocks), dim3(256), 0, st, a);
+  // obstacle records of every batch row a 256-sphere workgroup can touch, staged in LDS
+  const long hs = (long)horizon * num_spheres;
+  const long slots = (256 + hs - 1) / hs + 1;
+  const size_t lds = (size_t)slots * (scene->max_cuboids + scene->max_voxel_grids) * sizeof(ObsRec);
+  const bool staged = lds > 0 && lds <= 32 * 1024;
+  const int kinds = (scene->max_cuboids > 0 ? 1 : 0) | (scene->max_voxel_grids > 0 ? 2 : 0);
+#define CUROBO_SCENE_LAUNCH(SW, ST, KD) \
+  hipLaunchKernelGGL((scene_collision_kernel<SW, ST, KD>), dim3(blocks), dim3(256), (ST) ? lds : 0, st, a)
+#define CUROBO_SCENE_KINDS(SW, ST)                   \
+  do {                                               \
+    if (kinds == 1) CUROBO_SCENE_LAUNCH(SW, ST, 1);  \
+    else if (kinds == 2) CUROBO_SCENE_LAUNCH(SW, ST, 2); \
+    else CUROBO_SCENE_LAUNCH(SW, ST, 3);             \
+  } while (0)
+  if (sweep_steps == 0) {
+    if (staged) CUROBO_SCENE_KINDS(0, true); else CUROBO_SCENE_KINDS(0, false);
+  } else {
+    if (staged) CUROBO_SCENE_KINDS(3, true); else CUROBO_SCENE_KINDS(3, false);
+  }
+#undef CUROBO_SCENE_KINDS
+#undef CUROBO_SCENE_LAUNCH
   return check_launch(what, st);
 }
