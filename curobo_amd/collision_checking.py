@@ -1,0 +1,80 @@
+"""Public collision-checking API -- counterpart of ``curobo.collision_checking``
+(``RobotCollisionChecker`` = reference ``curobo/_src/collision/collision_robot_scene.py:26-541``):
+joint configurations -> (scene distance per sphere, self-collision distance per point)."""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .hip_ops.collision import CollisionBuffer, SphereObstacleCollision, SweptSphereObstacleCollision
+from .hip_ops.geometry import SelfCollisionDistance
+from .kinematics import Kinematics, KinematicsCfg
+from .scene.data import SceneData
+
+
+class RobotCollisionChecker:
+    def __init__(self, kinematics_cfg: KinematicsCfg, scene: Optional[SceneData], activation_distance: float = 0.0,
+                 scene_weight: float = 1.0, self_weight: float = 1.0):
+        self.kinematics = Kinematics(kinematics_cfg, compute_spheres=True)
+        self.scene = scene
+        d = kinematics_cfg.kinematics_config.device
+        self._w_scene = torch.tensor([scene_weight], device=d)
+        self._w_self = torch.tensor([self_weight], device=d)
+        self._eta = torch.tensor([activation_distance], device=d)
+        self._max_d = torch.tensor([10000.0], device=d)
+        self._shape = None
+
+    def update_world(self, scene: SceneData) -> None:
+        """reference :93 -- swap the obstacle store (tensors are replicated per GPU)"""
+        self.scene = scene
+
+    def _setup(self, b, h):
+        if self._shape == (b, h):
+            return
+        k = self.kinematics.kinematics_config
+        d, S = k.device, k.num_spheres
+        self._buf = CollisionBuffer.create(b, h, S, d)
+        self._self_d = torch.zeros(b, h, 1, device=d)
+        self._self_g = torch.zeros(b, h, S, 4, device=d)
+        self._sparse = torch.zeros(b, h, S, dtype=torch.uint8, device=d)
+        self._pd = torch.zeros(1, device=d)
+        self._bbmv = torch.zeros(1, device=d)
+        self._bbmi = torch.zeros(2, dtype=torch.int16, device=d)
+        self._env = torch.zeros(b, dtype=torch.int32, device=d)
+        self._speed_dt = torch.tensor([0.02], device=d)
+        self._shape = (b, h)
+
+    def get_scene_self_collision_distance_from_joints(
+            self, q: torch.Tensor, env_query_idx: Optional[torch.Tensor] = None,
+            sweep: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """q[B,H,D] -> (d_world[B,H,S], d_self[B,H,1]); reference :247-264.  Differentiable in q."""
+        if q.ndim == 2:
+            q = q.unsqueeze(1)
+        b, h, _ = q.shape
+        self._setup(b, h)
+        state = self.kinematics.compute_kinematics(q)
+        sph = state.robot_spheres
+        env = self._env if env_query_idx is None else env_query_idx
+        sc = self.kinematics.kinematics_config.self_collision
+        d_self = SelfCollisionDistance.apply(
+            sph, self._self_d, self._self_g, self._pd, self._sparse, self._w_self, sc.sphere_padding,
+            sc.collision_pairs, self._bbmv, self._bbmi, sc.num_blocks_per_batch, sc.max_threads_per_block,
+            False, True)
+        if self.scene is None:
+            d_world = torch.zeros(b, h, sph.shape[2], device=q.device)
+        elif sweep:
+            d_world = SweptSphereObstacleCollision.apply(
+                sph, self._buf, self.scene, self._w_scene, self._eta, self._max_d, self._speed_dt, False, env,
+                env_query_idx is not None, True)
+        else:
+            d_world = SphereObstacleCollision.apply(sph, self._buf, self.scene, self._w_scene, self._eta,
+                                                    self._max_d, env, env_query_idx is not None, True)
+        return d_world, d_self
+
+    def validate(self, q: torch.Tensor) -> torch.Tensor:
+        """True where the configuration is free of scene AND self collision (reference :341)."""
+        with torch.no_grad():
+            d_world, d_self = self.get_scene_self_collision_distance_from_joints(q)
+        return (d_world.sum(-1) <= 0.0) & (d_self[..., 0] <= 0.0)

@@ -1,0 +1,95 @@
+"""Public kinematics API -- counterpart of ``curobo.kinematics`` (reference
+``curobo/_src/robot/kinematics/kinematics.py:38-198``, ``kinematics_cfg.py:68-213``,
+``kinematics_state.py:15-35``): differentiable batched FK over the URDF tree with collision
+spheres, tool-frame poses, geometric Jacobian and centre of mass."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Union
+
+import torch
+
+from .hip_ops.kinematics import KinematicsFusedFunction
+from .robot import RobotModel, load_packaged_robot, load_robot_model
+from .robot.kinematics_params import KinematicsParams
+
+
+@dataclass
+class ToolPose:
+    """positions [B,H,T,3] and quaternions [B,H,T,4] (wxyz) of the tool frames."""
+
+    tool_frames: List[str]
+    position: torch.Tensor
+    quaternion: torch.Tensor
+
+
+@dataclass
+class KinematicsState:
+    tool_poses: ToolPose
+    tool_jacobians: Optional[torch.Tensor]  # [B,H,T,6,D]
+    robot_spheres: Optional[torch.Tensor]  # [B,H,S,4]
+    robot_com: Optional[torch.Tensor]  # [B,H,4]
+
+
+@dataclass
+class KinematicsCfg:
+    kinematics_config: KinematicsParams
+    model: RobotModel
+
+    @staticmethod
+    def from_robot_yaml_file(robot_yaml: str, assets_root: str, device="cuda:0", num_envs: int = 1) -> "KinematicsCfg":
+        model = load_robot_model(robot_yaml, assets_root, num_envs=num_envs)
+        return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)
+
+    @staticmethod
+    def from_packaged(name: str, device="cuda:0") -> "KinematicsCfg":
+        model = load_packaged_robot(name)
+        return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)
+
+
+class Kinematics:
+    def __init__(self, config: KinematicsCfg, compute_jacobian: bool = False, compute_spheres: bool = True,
+                 compute_com: bool = False):
+        self.config = config
+        self.kinematics_config = config.kinematics_config
+        self.compute_jacobian, self.compute_spheres, self.compute_com = compute_jacobian, compute_spheres, compute_com
+        self._shape = None
+        self._buffers = None
+        self._env_idx = None
+
+    @property
+    def joint_names(self):
+        return self.kinematics_config.joint_names
+
+    @property
+    def tool_frames(self):
+        return self.kinematics_config.tool_frames
+
+    def _setup(self, b: int, h: int):
+        if self._shape != (b, h):
+            self._buffers = KinematicsFusedFunction.create_buffers(b, h, self.kinematics_config)
+            self._env_idx = torch.zeros(b, dtype=torch.int32, device=self.kinematics_config.device)
+            self._shape = (b, h)
+
+    def compute_kinematics(self, joint_state: Union[torch.Tensor, object],
+                           idxs_env: Optional[torch.Tensor] = None) -> KinematicsState:
+        q = joint_state.position if hasattr(joint_state, "position") else joint_state
+        squeeze = q.ndim == 2
+        if squeeze:
+            q = q.unsqueeze(1)
+        b, h, _ = q.shape
+        self._setup(b, h)
+        bu = self._buffers
+        env = self._env_idx if idxs_env is None else idxs_env
+        pos, quat, spheres, com, jac = KinematicsFusedFunction.apply(
+            q.contiguous(), bu["batch_link_position"], bu["batch_link_quaternion"], bu["batch_robot_spheres"],
+            bu["batch_com"], bu["batch_jacobian"], bu["batch_cumul_mat"], self.kinematics_config, bu["grad_out_q"],
+            bu["grad_out_q_jacobian"], bu["grad_in_link_pos"], bu["grad_in_link_quat"],
+            bu["grad_in_robot_spheres"], bu["grad_in_com"], self.compute_jacobian, self.compute_spheres,
+            self.compute_com, env, h)
+        return KinematicsState(
+            tool_poses=ToolPose(self.tool_frames, pos, quat),
+            tool_jacobians=jac if self.compute_jacobian else None,
+            robot_spheres=spheres if self.compute_spheres else None,
+            robot_com=com if self.compute_com else None)

@@ -1,0 +1,127 @@
+"""Drop-in layer on the GPU: autograd wrappers (reference cuda_ops / Warp autograd contract) and
+the public Kinematics / RobotCollisionChecker API give the same numbers as the explicit rollout."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model, sample_q
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(device, name="franka"):
+    from curobo_amd.kinematics import KinematicsCfg
+
+    return KinematicsCfg.from_packaged(name, device)
+
+
+def test_kinematics_api_matches_oracle(oracle, device):
+    from curobo_amd.kinematics import Kinematics
+
+    cfg = _cfg(device)
+    kin = Kinematics(cfg, compute_jacobian=True, compute_spheres=True, compute_com=True)
+    q = sample_q(cfg.model, 12, seed=1).reshape(4, 3, 7)
+    st = kin.compute_kinematics(torch.as_tensor(q, device=device))
+    ref = oracle.kinematics_forward(q.reshape(12, 7), cfg.model.as_dict(), horizon=3, compute_jacobian=True,
+                                    compute_com=True)
+    np.testing.assert_allclose(st.tool_poses.position.cpu().numpy().reshape(12, 1, 3), ref["link_pos"], atol=1e-5)
+    np.testing.assert_allclose(st.tool_poses.quaternion.cpu().numpy().reshape(12, 1, 4), ref["link_quat"], atol=1e-5)
+    np.testing.assert_allclose(st.robot_spheres.cpu().numpy().reshape(12, 65, 4), ref["robot_spheres"], atol=1e-5)
+    np.testing.assert_allclose(st.tool_jacobians.cpu().numpy().reshape(12, 1, 6, 7), ref["jacobian"], atol=1e-5)
+    assert st.tool_poses.tool_frames == ["panda_hand"]
+
+
+def test_autograd_through_kinematics_matches_oracle_vjp(oracle, device):
+    from curobo_amd.kinematics import Kinematics
+
+    cfg = _cfg(device)
+    kin = Kinematics(cfg, compute_spheres=True)
+    rng = np.random.default_rng(0)
+    qn = sample_q(cfg.model, 10, seed=2).reshape(5, 2, 7)
+    q = torch.as_tensor(qn, device=device).requires_grad_(True)
+    st = kin.compute_kinematics(q)
+    gs = rng.normal(size=(5, 2, 65, 4)).astype(np.float32)
+    gp = rng.normal(size=(5, 2, 1, 3)).astype(np.float32)
+    loss = (st.robot_spheres * torch.as_tensor(gs, device=device)).sum() + \
+        (st.tool_poses.position * torch.as_tensor(gp, device=device)).sum()
+    loss.backward()
+    fwd = oracle.kinematics_forward(qn.reshape(10, 7), cfg.model.as_dict(), horizon=2)
+    ref = oracle.kinematics_backward(cfg.model.as_dict(), fwd["cumul_mat"], gs.reshape(10, 65, 4), gp.reshape(10, 1, 3),
+                                     horizon=2)
+    np.testing.assert_allclose(q.grad.cpu().numpy().reshape(10, 7), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_collision_checker_autograd_equals_explicit_rollout(device):
+    """cost.backward() through the autograd wrappers == the explicit VJP path of CollisionRollout"""
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    cfg = _cfg(device)
+    model = cfg.model
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    rcfg = CollisionRolloutCfg(use_sweep=False, use_speed_metric=False)
+    knots = seed_knots(model, 8, rcfg.n_knots, seed=5)
+    ro = CollisionRollout(cfg.kinematics_config, scene, 8, rcfg)
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+    cost, _ = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(8, -1))
+    q_traj = ro.position.clone()
+    grad_q_explicit = ro.grad_q.clone()
+    chk = RobotCollisionChecker(cfg, scene, activation_distance=rcfg.activation_distance,
+                                scene_weight=rcfg.scene_collision_weight, self_weight=rcfg.self_collision_weight)
+    q = q_traj.clone().requires_grad_(True)
+    d_world, d_self = chk.get_scene_self_collision_distance_from_joints(q)
+    total = d_world.sum((1, 2)) + d_self.sum((1, 2))
+    torch.testing.assert_close(total, cost, rtol=1e-5, atol=1e-3)
+    total.sum().backward()
+    torch.testing.assert_close(q.grad, grad_q_explicit, rtol=1e-4, atol=1e-5 * float(grad_q_explicit.abs().max()))
+    free = chk.validate(q_traj)
+    assert free.shape == (8, rcfg.padded_horizon) and free.any() and (~free).any()
+
+
+def test_bspline_and_lbfgs_autograd_wrappers(oracle, device):
+    from curobo_amd.hip_ops import BSplineIdxKernel, LBFGScu
+
+    rng = np.random.default_rng(1)
+    b, nk, dof, deg, interp = 6, 12, 7, 3, 2
+    ph = (nk + deg + 1) * interp + 1
+    t = lambda a, dt=torch.float32: torch.as_tensor(a, device=device).to(dt)  # noqa: E731
+    u = t(rng.normal(size=(b, nk, dof)).astype(np.float32)).requires_grad_(True)
+    z = lambda: torch.zeros(1, dof, device=device)  # noqa: E731
+    outs = [torch.zeros(b, ph, dof, device=device) for _ in range(4)]
+    idx = torch.zeros(b, dtype=torch.int32, device=device)
+    p, v, a_, j = BSplineIdxKernel.apply(u, z(), z(), z(), z(), z(), z(), z(), z(), idx, idx, *outs,
+                                         torch.zeros(b, device=device), t([0.05]), torch.zeros(1, dtype=torch.uint8, device=device),
+                                         torch.zeros(b, nk, dof, device=device), deg)
+    gp = rng.normal(size=(b, ph, dof)).astype(np.float32)
+    gv = rng.normal(size=(b, ph, dof)).astype(np.float32) * 0.1
+    (p * t(gp)).sum().add((v * t(gv)).sum()).backward()
+    zz = np.zeros_like(gp)
+    ref = oracle.bspline_backward(gp, gv, zz, zz, np.array([0.05], np.float32), np.zeros(b, np.int32),
+                                  np.zeros(1, np.uint8), nk, deg)
+    np.testing.assert_allclose(u.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+    # LBFGScu with the reference's QuasiNewtonBuffers shapes (m,B,V,1)/(m,B,1,1)/(B,V,1)
+    m, V = 5, 20
+    mk = lambda *s: rng.normal(size=s).astype(np.float32)  # noqa: E731
+    st = dict(step=np.zeros((b, V), np.float32), rho=np.abs(mk(m, b)) * 0.1, y=mk(m, b, V), s=mk(m, b, V),
+              q=mk(b, V), g=mk(b, V), x0=mk(b, V), g0=mk(b, V))
+    dv = {k: t(a.copy()) for k, a in st.items()}
+    out = LBFGScu.apply(dv["step"], dv["rho"].view(m, b, 1, 1), dv["y"].view(m, b, V, 1), dv["s"].view(m, b, V, 1),
+                        dv["q"], dv["g"].view(b, 1, V), dv["x0"].view(b, V, 1), dv["g0"].view(b, V, 1), 0.01, True, True)
+    oracle.lbfgs_step(st["step"], st["rho"], st["y"], st["s"], st["q"], st["g"], st["x0"], st["g0"], 0.01, True)
+    np.testing.assert_allclose(out.cpu().numpy(), st["step"], rtol=2e-4, atol=2e-5 * np.abs(st["step"]).max())
+
+
+def test_tensor_checks_reject_bad_inputs(device):
+    from curobo_amd.hip_ops.tensor_checks import check_float32_tensors
+
+    good = torch.zeros(4, 4, device=device)
+    check_float32_tensors(device, good=good)
+    with pytest.raises(ValueError, match="not contiguous"):
+        check_float32_tensors(device, bad=good.t())
+    with pytest.raises(ValueError, match="dtype"):
+        check_float32_tensors(device, bad=good.double())
+    with pytest.raises(ValueError, match="is on"):
+        check_float32_tensors(device, bad=torch.zeros(2))
