@@ -30,6 +30,7 @@ SOURCES = [
     "scene_collision.hip",
     "trajectory.hip",
     "optimization.hip",
+    "cost.hip",
 ]
 
 
@@ -53,7 +54,8 @@ def _flags() -> List[str]:
 
 
 def _deps(src: str) -> List[str]:
-    return [src, os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "curobo_hip.h")]
+    return [src, os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "cost_device.hpp"),
+            os.path.join(INCLUDE, "curobo_hip.h")]
 
 
 def _compile(src_name: str, force: bool) -> str:
@@ -71,6 +73,7 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"),
+                                                        os.path.join(CSRC, "cost_device.hpp"),
                                                         os.path.join(INCLUDE, "curobo_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -1,0 +1,138 @@
+// cost.hip -- goal-set tool-pose distance and c-space POSITION bound cost.
+// Reference (NVIDIA Warp, no backend hook): cost/wp_tool_pose.py:61-692 (ToolPoseDistance :698),
+// cost/wp_cspace_position.py:232-362, cost/warp_bound_util.py:9-100.
+//
+// Both are tiny elementwise maps (one lane per (batch, horizon, link) resp. (batch, horizon,
+// dof)); they exist as stand-alone entry points for the drop-in API and are also inlined into
+// the fused IK rollout kernel (rollout_fused.hip) where launch latency matters.
+#include "cost_device.hpp"
+
+namespace curobo_hip {
+
+__global__ void __launch_bounds__(256) tool_pose_distance_kernel(const ToolPoseArgs a) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.batch * a.horizon * a.num_links;
+  if (tid >= total) return;
+  const int hl = a.horizon * a.num_links;
+  const int b = (int)(tid / hl);
+  const int h = (int)((tid - (long)b * hl) / a.num_links);
+  const int l = (int)(tid - (long)b * hl - (long)h * a.num_links);
+  const float *cp = a.current_position + tid * 3;
+  const float4 cqw = reinterpret_cast<const float4 *>(a.current_quat)[tid];
+  const ToolPoseResult r = tool_pose_distance_point(a, b, h, l, make_f3(cp[0], cp[1], cp[2]), cqw);
+  a.out_distance[2 * tid] = r.position_cost;
+  a.out_distance[2 * tid + 1] = r.rotation_cost;
+  a.out_goalset_idx[tid] = r.goalset_idx;
+  a.out_position_distance[tid] = r.position_distance;
+  a.out_rotation_distance[tid] = r.rotation_distance;
+  float *pg = a.out_position_gradient + tid * 3;
+  pg[0] = r.position_gradient.x; pg[1] = r.position_gradient.y; pg[2] = r.position_gradient.z;
+  reinterpret_cast<float4 *>(a.out_rotation_gradient)[tid] = r.quat_rate_wxyz;
+}
+
+__global__ void __launch_bounds__(256) cspace_position_kernel(const CspacePosArgs a) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.batch * a.horizon * a.dof;
+  if (tid >= total) return;
+  const int b = (int)(tid / ((long)a.horizon * a.dof));
+  const int d = (int)(tid % a.dof);
+  float gp, gt;
+  const float c = cspace_position_point(a, b, d, a.pos[tid], a.effort ? a.effort[tid] : 0.0f, gp, gt);
+  a.out_cost[tid] = c;
+  if (a.write_grad) {
+    a.out_grad_p[tid] = gp;
+    if (a.out_grad_tau) a.out_grad_tau[tid] = gt;
+  }
+}
+
+
+// Per-row cost aggregation for teleport (horizon 1) rollouts such as IK: one 16-lane DPP row per
+// rollout row sums pose (2 per link), c-space (per dof), self-collision and scene (per sphere)
+// costs, and folds the c-space gradient into grad_q (the reference does this with torch cat/sum
+// and autograd accumulation: rollout/metrics.py:233-265).
+__global__ void __launch_bounds__(256) rollout_point_aggregate_kernel(
+    float *out_cost, float *grad_q, const float *pose_cost, const float *cspace_cost, const float *cspace_grad,
+    const float *self_cost, const float *scene_cost, int rows, int num_links, int dof, int nspheres) {
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / 16, lane = threadIdx.x % 16;
+  const bool valid = grp < rows;
+  float acc = 0.0f;
+  if (valid) {
+    if (pose_cost)
+      for (int i = lane; i < 2 * num_links; i += 16) acc += pose_cost[(size_t)grp * 2 * num_links + i];
+    if (cspace_cost)
+      for (int i = lane; i < dof; i += 16) acc += cspace_cost[(size_t)grp * dof + i];
+    if (scene_cost)
+      for (int i = lane; i < nspheres; i += 16) acc += scene_cost[(size_t)grp * nspheres + i];
+    if (self_cost && lane == 0) acc += self_cost[grp];
+    if (cspace_grad && grad_q)
+      for (int i = lane; i < dof; i += 16) grad_q[(size_t)grp * dof + i] += cspace_grad[(size_t)grp * dof + i];
+  }
+  acc = row16_sum(acc);
+  if (valid && lane == 0) out_cost[grp] = acc;
+}
+
+}  // namespace curobo_hip
+
+using namespace curobo_hip;
+
+CUROBO_EXPORT int curobo_hip_tool_pose_distance(
+    float *out_distance, float *out_position_distance, float *out_rotation_distance,
+    float *out_position_gradient, float *out_rotation_gradient, int32_t *out_goalset_idx,
+    const float *current_position, const float *current_quat, const float *goal_position,
+    const float *goal_quat, const int32_t *idxs_goal, const float *position_orientation_weight,
+    const float *terminal_pose_axes_weight_factor, const float *non_terminal_pose_axes_weight_factor,
+    const float *terminal_pose_convergence_tolerance, const float *non_terminal_pose_convergence_tolerance,
+    const uint8_t *project_distance_to_goal, int batch_size, int horizon, int num_links, int num_goalset,
+    int rotation_method, curobo_hip_stream_t stream) {
+  const char *what = "tool_pose_distance";
+  CUROBO_REQUIRE(rotation_method >= 0 && rotation_method <= 2, "%s: rotation_method must be 0, 1 or 2", what);
+  CUROBO_REQUIRE(num_goalset >= 1 && num_links >= 1 && horizon >= 1, "%s: bad dimensions", what);
+  CUROBO_REQUIRE(((uintptr_t)current_quat & 15) == 0 && ((uintptr_t)out_rotation_gradient & 15) == 0,
+                 "%s: quaternion buffers must be 16-byte aligned", what);
+  const long total = (long)batch_size * horizon * num_links;
+  if (total == 0) return CUROBO_HIP_OK;
+  ToolPoseArgs a{out_distance, out_position_distance, out_rotation_distance, out_position_gradient,
+                 out_rotation_gradient, out_goalset_idx, current_position, current_quat, goal_position, goal_quat,
+                 idxs_goal, position_orientation_weight, terminal_pose_axes_weight_factor,
+                 non_terminal_pose_axes_weight_factor, terminal_pose_convergence_tolerance,
+                 non_terminal_pose_convergence_tolerance, project_distance_to_goal, batch_size, horizon, num_links,
+                 num_goalset, rotation_method};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tool_pose_distance_kernel, dim3((unsigned)ceil_div_l(total, 256)), dim3(256), 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_cspace_position_cost(
+    float *out_cost, float *out_grad_p, float *out_grad_tau, const float *pos, const float *effort,
+    const float *cspace_target, const int32_t *cspace_target_idx, const float *p_b, const float *effort_b,
+    const float *weight, const float *activation_distance, const float *cspace_target_weight,
+    const float *cspace_target_dof_weight, const float *squared_l2_reg_weight, const float *current_position,
+    const float *current_velocity, const int32_t *idxs_current_state, const float *v_b, const float *state_dt,
+    int write_grad, int batch_size, int horizon, int dof, curobo_hip_stream_t stream) {
+  const char *what = "cspace_position_cost";
+  CUROBO_REQUIRE(dof >= 1 && horizon >= 1, "%s: bad dimensions", what);
+  const long total = (long)batch_size * horizon * dof;
+  if (total == 0) return CUROBO_HIP_OK;
+  CspacePosArgs a{out_cost, out_grad_p, out_grad_tau, pos, effort, cspace_target, cspace_target_idx, p_b, effort_b,
+                  weight, activation_distance, cspace_target_weight, cspace_target_dof_weight, squared_l2_reg_weight,
+                  current_position, current_velocity, idxs_current_state, v_b, state_dt, write_grad, batch_size,
+                  horizon, dof};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cspace_position_kernel, dim3((unsigned)ceil_div_l(total, 256)), dim3(256), 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_point_aggregate(float *out_cost, float *grad_q, const float *pose_cost,
+                                                     const float *cspace_cost, const float *cspace_grad,
+                                                     const float *self_cost, const float *scene_cost, int rows,
+                                                     int num_links, int dof, int num_spheres,
+                                                     curobo_hip_stream_t stream) {
+  const char *what = "rollout_point_aggregate";
+  CUROBO_REQUIRE(rows >= 0 && num_links >= 0 && dof >= 1 && num_spheres >= 0, "%s: bad dimensions", what);
+  if (rows == 0) return CUROBO_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rollout_point_aggregate_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, st, out_cost,
+                     grad_q, pose_cost, cspace_cost, cspace_grad, self_cost, scene_cost, rows, num_links, dof,
+                     num_spheres);
+  return check_launch(what, st);
+}

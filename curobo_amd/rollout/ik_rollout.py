@@ -1,0 +1,147 @@
+"""Teleport (horizon 1) rollout for inverse kinematics: q -> FK -> tool-pose + c-space bound +
+self + scene collision costs, and the analytic gradient back to q.
+
+Data path of the reference's ``RobotRollout`` with ``StateFromPositionTeleport``
+(``content/configs/task/ik/transition_ik.yml``) and the IK cost set
+(``content/configs/task/ik/lbfgs_ik.yml:3-36``); kernels cited in the backend modules.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+from ..backends import collision as collision_hip
+from ..backends import cost as cost_hip
+from ..backends import geometry as geometry_hip
+from ..backends import kinematics as kinematics_hip
+from ..robot.kinematics_params import KinematicsParams
+from ..scene.data import SceneData
+
+
+@dataclass
+class IKRolloutCfg:
+    """Defaults = reference ``lbfgs_ik.yml``."""
+
+    pose_weight: List[float] = field(default_factory=lambda: [10000.0, 500.0])
+    pose_convergence_tolerance: List[float] = field(default_factory=lambda: [1e-8, 1e-8])
+    rotation_method: int = 0  # use_lie_group: false
+    cspace_weight: List[float] = field(default_factory=lambda: [5000.0, 0.0])
+    cspace_activation_distance: List[float] = field(default_factory=lambda: [0.01, 0.01])
+    scene_collision_weight: float = 5000.0
+    scene_activation_distance: float = 0.0
+    self_collision_weight: float = 5000.0
+
+
+class IKRollout:
+    """cost[B] and d cost / d q [B, D] for B joint configurations against per-row goal poses."""
+
+    def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], batch_size: int,
+                 cfg: Optional[IKRolloutCfg] = None, num_goalset: int = 1):
+        self.kin, self.scene, self.cfg = kin, scene, cfg or IKRolloutCfg()
+        self.device = kin.device
+        self.action_horizon, self.action_dim = 1, kin.num_dof
+        self.num_goalset = num_goalset
+        d, T, D = self.device, kin.num_pose_links, kin.num_dof
+        c = self.cfg
+        f = lambda v: torch.tensor(v, device=d, dtype=torch.float32)  # noqa: E731
+        self._pose_w = f(c.pose_weight)
+        self._axes_w = torch.ones(T, 6, device=d)
+        self._tol = f([c.pose_convergence_tolerance] * T)
+        self._project = torch.zeros(T, dtype=torch.uint8, device=d)
+        self._cs_w, self._cs_eta = f(c.cspace_weight), f(c.cspace_activation_distance)
+        self._p_b = kin.joint_limits_position.contiguous()
+        self._effort_b = torch.stack([torch.full((D,), -1e9, device=d), torch.full((D,), 1e9, device=d)])
+        self._v_b = kin.joint_limits_velocity.contiguous()
+        self._zero1 = torch.zeros(1, device=d)
+        self._zeroD = torch.zeros(1, D, device=d)
+        self._onesD = torch.ones(D, device=d)
+        self._reg = torch.zeros(2, device=d)
+        self._w_scene, self._eta_scene = f([c.scene_collision_weight]), f([c.scene_activation_distance])
+        self._w_self = f([c.self_collision_weight])
+        self.batch_size = 0
+        self.update_batch_size(batch_size)
+
+    def update_batch_size(self, B: int) -> None:
+        if B == self.batch_size:
+            return
+        k, d = self.kin, self.device
+        T, S, L, D = k.num_pose_links, k.num_spheres, k.num_links, k.num_dof
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=d, dtype=dt)  # noqa: E731
+        self.batch_size = B
+        self.link_pos, self.link_quat = z(B, 1, T, 3), z(B, 1, T, 4)
+        self.robot_spheres, self.cumul_mat, self.com = z(B, 1, S, 4), z(B, 1, L, 3, 4), z(B, 1, 4)
+        self.env_query_idx = z(B, dt=torch.int32)
+        self.pose_cost, self.pose_pos_dist, self.pose_rot_dist = z(B, 1, 2 * T), z(B, 1, T), z(B, 1, T)
+        self.pose_grad_pos, self.pose_grad_quat = z(B, 1, T, 3), z(B, 1, T, 4)
+        self.goalset_idx = z(B, 1, T, dt=torch.int32)
+        self.cspace_cost, self.cspace_grad = z(B, 1, D), z(B, 1, D)
+        self.self_dist, self.self_grad = z(B, 1, 1), z(B, 1, S, 4)
+        self.self_sparse = z(B, 1, S, dt=torch.uint8)
+        self.scene_dist, self.scene_grad = z(B, 1, S), z(B, 1, S, 4)
+        self._pd, self._bbmv, self._bbmi = z(1), z(1), z(2, dt=torch.int16)
+        self.cost, self.grad_q = z(B), z(B, 1, D)
+        self.idxs_goal = z(B, dt=torch.int32)
+        self._idx0 = z(B, dt=torch.int32)
+        self.goal_position = z(1, T, self.num_goalset, 3)
+        self.goal_quat = z(1, T, self.num_goalset, 4)
+        self.goal_quat[..., 0] = 1.0
+
+    def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
+        """goal_position [G, T, num_goalset, 3], goal_quat (wxyz) [G, T, num_goalset, 4], idxs_goal [B]."""
+        assert goal_position.shape[1:3] == (self.kin.num_pose_links, self.num_goalset)
+        if goal_position.shape == self.goal_position.shape:
+            self.goal_position.copy_(goal_position)
+            self.goal_quat.copy_(goal_quat)
+        else:  # re-allocation invalidates captured graphs: callers re-capture after a shape change
+            self.goal_position = goal_position.to(self.device, torch.float32).contiguous().clone()
+            self.goal_quat = goal_quat.to(self.device, torch.float32).contiguous().clone()
+        self.idxs_goal.copy_(idxs_goal.to(torch.int32))
+
+    # ------------------------------------------------------------------ forward + backward
+    def evaluate(self, q: torch.Tensor, with_gradient: bool = True) -> torch.Tensor:
+        k, B, c = self.kin, self.batch_size, self.cfg
+        T, S, D = k.num_pose_links, k.num_spheres, k.num_dof
+        kinematics_hip.launch_kinematics_forward_spheres(
+            self.link_pos, self.link_quat, self.robot_spheres, self.com, self.cumul_mat, q, k.fixed_transforms,
+            k.link_spheres, k.link_masses_com, k.joint_map_type, k.joint_map, k.link_map, k.tool_frame_map,
+            k.link_sphere_idx_map, k.joint_offset_map, self.env_query_idx, k.num_envs, B, 1, D, S, 32, True, False)
+        cost_hip.tool_pose_distance(
+            self.pose_cost, self.pose_pos_dist, self.pose_rot_dist, self.pose_grad_pos, self.pose_grad_quat,
+            self.goalset_idx, self.link_pos, self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal,
+            self._pose_w, self._axes_w, self._axes_w, self._tol, self._tol, self._project, B, 1, T,
+            self.num_goalset, c.rotation_method)
+        cost_hip.cspace_position_cost(
+            self.cspace_cost, self.cspace_grad, None, q, None, self._zeroD, self._idx0, self._p_b, self._effort_b,
+            self._cs_w, self._cs_eta, self._zero1, self._onesD, self._reg, self._zeroD, self._zeroD, self._idx0,
+            self._v_b, self._zero1, True, B, 1, D)
+        sc = k.self_collision
+        geometry_hip.self_collision_distance(
+            self.self_dist, self.self_grad, self._pd, self.self_sparse, self.robot_spheres, sc.sphere_padding,
+            self._w_self, sc.collision_pairs, self._bbmv, self._bbmi, 1, 256, B, 1, S, sc.collision_pairs.shape[0],
+            False, True)
+        use_scene = self.scene is not None
+        if use_scene:
+            collision_hip.sphere_obstacle_collision(
+                self.scene_dist, self.scene_grad, self.robot_spheres, self.scene.struct, self._w_scene,
+                self._eta_scene, self.env_query_idx, B, 1, S, False, 0, False, None)
+        if with_gradient:
+            kinematics_hip.launch_kinematics_backward(
+                self.grad_q, self.pose_grad_pos, self.pose_grad_quat, self.self_grad, self.com, self.com,
+                self.pose_grad_pos, self.cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map,
+                k.joint_map_type, k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets,
+                k.joint_links_data, k.joint_links_offsets, k.joint_affects_endeffector, k.joint_offset_map,
+                self.env_query_idx, k.num_envs, B, 1, D, S, False, False,
+                grad_spheres_b=self.scene_grad if use_scene else None)
+        cost_hip.rollout_point_aggregate(
+            self.cost, self.grad_q if with_gradient else None, self.pose_cost, self.cspace_cost,
+            self.cspace_grad if with_gradient else None, self.self_dist, self.scene_dist if use_scene else None, B, T,
+            D, S)
+        return self.cost
+
+    def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x[B, D] -> (cost[B], grad[B, D]) in static buffers (graph friendly)."""
+        cost = self.evaluate(x.view(self.batch_size, 1, self.action_dim), with_gradient=True)
+        return cost, self.grad_q.view(self.batch_size, -1)

@@ -49,3 +49,14 @@ def start_configuration(model) -> np.ndarray:
     if q.shape[0] != model.num_dof:
         q = 0.5 * (model.joint_limits_position[0] + model.joint_limits_position[1])
     return q.astype(np.float32)
+
+
+def c1_world() -> List[List[Dict]]:
+    """C1 "4-primitive world" for IK: the reference's table (``collision_table.yml``: dims
+    [2.0, 2.0, 0.2] under the base) plus three boxes in the workspace."""
+    return [[
+        {"dims": [2.0, 2.0, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]},
+        {"dims": [0.2, 0.2, 0.6], "pose": [0.55, 0.35, 0.3, 1, 0, 0, 0]},
+        {"dims": [0.2, 0.2, 0.6], "pose": [0.55, -0.35, 0.3, 1, 0, 0, 0]},
+        {"dims": [0.3, 0.3, 0.05], "pose": [-0.5, 0.0, 0.6, 1, 0, 0, 0]},
+    ]]

@@ -145,6 +145,46 @@ int curobo_hip_sphere_obstacle_collision(
     int batch_size, int horizon, int num_spheres, int use_multi_env, int sweep_steps,
     int enable_speed_metric, const float *speed_dt, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- cost: tool pose + c-space
+ * The reference runs these as NVIDIA Warp kernels without a backend hook:
+ * ToolPoseDistance (cost/wp_tool_pose.py:698-914, kernel :456-692) and the POSITION c-space cost
+ * (cost/wp_cspace_position.py:232-362).  Argument order follows the Warp kernels' inputs.
+ * goal_position/goal_quat: [n_goals, num_links, num_goalset, 3|4] (quaternions wxyz);
+ * out_distance [b,h,2*num_links] = (position cost, rotation cost) per link; out_rotation_gradient
+ * is the quaternion rate q (x) (omega,0) (wxyz) that launch_kinematics_backward consumes.
+ * rotation_method: 0 axis-angle, 1 lie group, 2 lie group advanced. */
+int curobo_hip_tool_pose_distance(
+    float *out_distance, float *out_position_distance, float *out_rotation_distance,
+    float *out_position_gradient, float *out_rotation_gradient, int32_t *out_goalset_idx,
+    const float *current_position, const float *current_quat, const float *goal_position,
+    const float *goal_quat, const int32_t *idxs_goal, const float *position_orientation_weight,
+    const float *terminal_pose_axes_weight_factor, const float *non_terminal_pose_axes_weight_factor,
+    const float *terminal_pose_convergence_tolerance,
+    const float *non_terminal_pose_convergence_tolerance, const uint8_t *project_distance_to_goal,
+    int batch_size, int horizon, int num_links, int num_goalset, int rotation_method,
+    curobo_hip_stream_t stream);
+
+/* p_b/effort_b/v_b: [2, dof] lower then upper; weight/activation_distance: [2] (position,
+ * effort); squared_l2_reg_weight: [2] (velocity, acceleration); effort / out_grad_tau may be NULL. */
+int curobo_hip_cspace_position_cost(
+    float *out_cost, float *out_grad_p, float *out_grad_tau, const float *pos, const float *effort,
+    const float *cspace_target, const int32_t *cspace_target_idx, const float *p_b,
+    const float *effort_b, const float *weight, const float *activation_distance,
+    const float *cspace_target_weight, const float *cspace_target_dof_weight,
+    const float *squared_l2_reg_weight, const float *current_position,
+    const float *current_velocity, const int32_t *idxs_current_state, const float *v_b,
+    const float *state_dt, int write_grad, int batch_size, int horizon, int dof,
+    curobo_hip_stream_t stream);
+
+/* Per-row aggregation for horizon-1 (teleport / IK) rollouts (reference: torch cat+sum and autograd
+ * accumulation, rollout/metrics.py:233-265): out_cost[r] = sum(pose_cost[r,:2*num_links]) +
+ * sum(cspace_cost[r,:dof]) + self_cost[r] + sum(scene_cost[r,:num_spheres]);
+ * grad_q[r,:] += cspace_grad[r,:].  Any input may be NULL. */
+int curobo_hip_rollout_point_aggregate(
+    float *out_cost, float *grad_q, const float *pose_cost, const float *cspace_cost,
+    const float *cspace_grad, const float *self_cost, const float *scene_cost, int rows,
+    int num_links, int dof, int num_spheres, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- trajectory: B-spline
  * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142
  * kernels:   kernels/trajectory/bspline/bspline_kernel.cuh:81-151,332-380

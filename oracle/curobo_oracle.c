@@ -1186,3 +1186,209 @@ ORC_API void orc_trajectory_cost_sum(float *out, const float *self_cost, const f
     out[b] = (float)acc;
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * A9. goal-set tool-pose distance (Warp in the reference): cost/wp_tool_pose.py:61-435 (error
+ *     functions), :456-692 (kernel).  Quaternions are stored wxyz in memory and handled xyzw
+ *     inside, as in the reference.  rotation_method: 0 axis-angle, 1 lie group, 2 lie advanced.
+ *     The rotation gradient is emitted as a quaternion RATE  q (x) (omega, 0)  (wxyz), which the
+ *     FK backward turns back into omega/2 (quaternion_util.cuh:86-102).
+ * ---------------------------------------------------------------------------------------- */
+static void orc_qmul(const float *a, const float *b, float *o) { /* xyzw Hamilton product */
+  const float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+  o[0] = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+  o[1] = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+  o[2] = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+  o[3] = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+}
+
+static void orc_rotation_error(const float *cq, const float *gq, const float *wt, float rw, float tol,
+                               int method, float *dist, float *grad_w, float *angle_out) {
+  const float ginv[4] = {-gq[0], -gq[1], -gq[2], gq[3]};
+  float qd[4];
+  orc_qmul(cq, ginv, qd);
+  grad_w[0] = grad_w[1] = grad_w[2] = 0.0f;
+  if (method == 0) { /* wp_tool_pose.py:129-203 */
+    const float v[3] = {wt[0] * qd[0], wt[1] * qd[1], wt[2] * qd[2]};
+    const float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float angle = 2.0f * atan2f(len, fabsf(qd[3]));
+    if (rw == 0.0f) angle = 0.0f;
+    float ax[3] = {0, 0, 0};
+    if (!(len < 1e-15f)) { ax[0] = v[0] / len; ax[1] = v[1] / len; ax[2] = v[2] / len; }
+    const float om[3] = {angle * ax[0], angle * ax[1], angle * ax[2]};
+    float d = rw * (om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    if (d < tol) d = 0.0f;
+    else {
+      float sf = 2.0f;
+      if (qd[3] < 0.0f) sf = -1.0f * sf;
+      for (int k = 0; k < 3; k++) grad_w[k] = sf * rw * om[k];
+    }
+    *dist = d; *angle_out = angle;
+    return;
+  }
+  /* lie group (1) and lie group advanced (2) produce identical outputs: :206-383 */
+  if (qd[3] < 0.0f) { qd[0] = -qd[0]; qd[1] = -qd[1]; qd[2] = -qd[2]; qd[3] = -qd[3]; }
+  const float w = qd[3];
+  const float vn = sqrtf(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2]);
+  float half = atan2f(vn, fabsf(w));
+  if (rw == 0.0f) half = 0.0f;
+  const float geo = 2.0f * half;
+  float tv[3];
+  if (vn < 1e-10f) { for (int k = 0; k < 3; k++) tv[k] = 2.0f * qd[k]; }
+  else if (fabsf(half) < 1e-15f) {
+    const float corr = 1.0f + (vn * vn) / (6.0f * w * w);
+    for (int k = 0; k < 3; k++) tv[k] = 2.0f * qd[k] * corr;
+  } else {
+    const float sinc = geo / (2.0f * sinf(half));
+    for (int k = 0; k < 3; k++) tv[k] = sinc * qd[k];
+  }
+  const float wv[3] = {wt[0] * tv[0], wt[1] * tv[1], wt[2] * tv[2]};
+  const float n2 = wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2];
+  float d = rw * n2;
+  if (d < tol) d = 0.0f;
+  else for (int k = 0; k < 3; k++) grad_w[k] = 2.0f * rw * wv[k];
+  *dist = d; *angle_out = sqrtf(n2);
+}
+
+ORC_API void orc_tool_pose_distance(
+    float *out_distance, float *out_position_distance, float *out_rotation_distance,
+    float *out_position_gradient, float *out_rotation_gradient, int32_t *out_goalset_idx,
+    const float *current_position, const float *current_quat, const float *goal_position,
+    const float *goal_quat, const int32_t *idxs_goal, const float *position_orientation_weight,
+    const float *terminal_axes_weight, const float *non_terminal_axes_weight,
+    const float *terminal_tolerance, const float *non_terminal_tolerance,
+    const uint8_t *project_distance_to_goal, int batch, int horizon, int num_links, int num_goalset,
+    int rotation_method) {
+  const long total = (long)batch * horizon * num_links;
+#pragma omp parallel for schedule(static)
+  for (long tid = 0; tid < total; tid++) {
+    const int b = (int)(tid / ((long)horizon * num_links));
+    const int h = (int)((tid - (long)b * horizon * num_links) / num_links);
+    const int l = (int)(tid - (long)b * horizon * num_links - (long)h * num_links);
+    const int non_terminal = (h < horizon - 1) && horizon > 1;
+    const float *aw = (non_terminal ? non_terminal_axes_weight : terminal_axes_weight) + l * 6;
+    const float *tl = (non_terminal ? non_terminal_tolerance : terminal_tolerance) + l * 2;
+    const float pw = position_orientation_weight[0], rw = position_orientation_weight[1];
+    const float tol_p = tl[0] * tl[0], tol_r = tl[1] * tl[1];
+    const int gi = idxs_goal[b];
+    const int project = project_distance_to_goal[l];
+    const float *cp = current_position + tid * 3;
+    const float *cqw = current_quat + tid * 4;
+    const float cq[4] = {cqw[1], cqw[2], cqw[3], cqw[0]};
+    float best = -1.0f, best_pd = -1.0f, best_rd = -1.0f, best_angle = -1.0f;
+    float best_pg[3] = {0, 0, 0}, best_rg[3] = {0, 0, 0}, best_gq[4] = {0, 0, 0, 1};
+    int best_g = 0;
+    for (int g = 0; g < num_goalset; g++) {
+      const size_t ga = ((size_t)gi * num_links + l) * num_goalset + g;
+      const float *gp = goal_position + ga * 3;
+      const float *gqw = goal_quat + ga * 4;
+      const float gq[4] = {gqw[1], gqw[2], gqw[3], gqw[0]};
+      float cpf[3], cqf[4], gpf[3], gqf[4];
+      if (project == 1) { /* current pose expressed in the goal frame, goal = identity */
+        const float gi_q[4] = {-gq[0], -gq[1], -gq[2], gq[3]};
+        const float dpv[3] = {cp[0] - gp[0], cp[1] - gp[1], cp[2] - gp[2]};
+        orc_quat_rotate(gi_q, dpv, cpf);
+        orc_qmul(gi_q, cq, cqf);
+        gpf[0] = gpf[1] = gpf[2] = 0.0f;
+        gqf[0] = gqf[1] = gqf[2] = 0.0f; gqf[3] = 1.0f;
+      } else {
+        memcpy(cpf, cp, 12); memcpy(cqf, cq, 16); memcpy(gpf, gp, 12); memcpy(gqf, gq, 16);
+      }
+      /* compute_position_error: :61-104 */
+      const float dl[3] = {cpf[0] - gpf[0], cpf[1] - gpf[1], cpf[2] - gpf[2]};
+      const float wd[3] = {dl[0] * aw[0], dl[1] * aw[1], dl[2] * aw[2]};
+      float pd = 0.5f * pw * (wd[0] * wd[0] + wd[1] * wd[1] + wd[2] * wd[2]);
+      float pg[3] = {pw * aw[0] * aw[0] * dl[0], pw * aw[1] * aw[1] * dl[1], pw * aw[2] * aw[2] * dl[2]};
+      if (pd < tol_p) { pd = 0.0f; pg[0] = pg[1] = pg[2] = 0.0f; }
+      float rd, rg[3], angle;
+      orc_rotation_error(cqf, gqf, aw + 3, rw, tol_r, rotation_method, &rd, rg, &angle);
+      const float tot = pd + rd;
+      if (best < 0 || tot < best) {
+        best = tot; best_g = g; best_pd = pd; best_rd = rd; best_angle = angle;
+        memcpy(best_pg, pg, 12); memcpy(best_rg, rg, 12); memcpy(best_gq, gq, 16);
+      }
+    }
+    if (project == 1) { /* gradients back to the world frame */
+      float t3[3];
+      orc_quat_rotate(best_gq, best_pg, t3); memcpy(best_pg, t3, 12);
+      orc_quat_rotate(best_gq, best_rg, t3); memcpy(best_rg, t3, 12);
+    }
+    const float om[4] = {best_rg[0], best_rg[1], best_rg[2], 0.0f};
+    float qr[4];
+    orc_qmul(cq, om, qr); /* convert_angular_velocity_to_quaternion_rate: :107-126 */
+    out_distance[2 * tid] = best_pd;
+    out_distance[2 * tid + 1] = best_rd;
+    out_goalset_idx[tid] = best_g;
+    out_position_distance[tid] = pw > 0.0f ? sqrtf(2.0f * best_pd / pw) : 0.0f;
+    out_rotation_distance[tid] = best_angle;
+    memcpy(out_position_gradient + tid * 3, best_pg, 12);
+    out_rotation_gradient[tid * 4 + 0] = qr[3];
+    out_rotation_gradient[tid * 4 + 1] = qr[0];
+    out_rotation_gradient[tid * 4 + 2] = qr[1];
+    out_rotation_gradient[tid * 4 + 3] = qr[2];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A10. c-space POSITION cost (Warp): cost/wp_cspace_position.py:232-362, warp_bound_util.py:9-100.
+ *   Joint-limit (and optional effort-limit) hinge^2, optional target and implied
+ *   velocity/acceleration regularisation w.r.t. a current state.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_cspace_position_cost(
+    float *out_cost, float *out_grad_p, float *out_grad_tau, const float *pos, const float *effort,
+    const float *cspace_target, const int32_t *cspace_target_idx, const float *p_b,
+    const float *effort_b, const float *weight, const float *activation_distance,
+    const float *cspace_target_weight, const float *cspace_target_dof_weight,
+    const float *squared_l2_reg_weight, const float *current_position,
+    const float *current_velocity, const int32_t *idxs_current_state, const float *v_b,
+    const float *state_dt, int write_grad, int batch, int horizon, int dof) {
+  const long total = (long)batch * horizon * dof;
+#pragma omp parallel for schedule(static)
+  for (long tid = 0; tid < total; tid++) {
+    const int b = (int)(tid / ((long)horizon * dof));
+    const int d = (int)(tid % dof);
+    const float eta_p = activation_distance[0], eta_tau = activation_distance[1];
+    const float w = weight[0], tau_w = weight[1];
+    float tl = effort_b[d], tu = effort_b[dof + d];
+    { const float r = tu - tl; tl = tl + eta_tau * r; tu = tu - eta_tau * r; }
+    float pl = p_b[d], pu = p_b[dof + d];
+    { const float r = pu - pl; pl = pl + eta_p * r; pu = pu - eta_p * r; }
+    const int cur = idxs_current_state[b];
+    const float dt = state_dt[cur];
+    float cur_p = 0.0f;
+    if (dt > 0.0f) {
+      cur_p = current_position[(size_t)cur * dof + d];
+      pl = fmaxf(pl, cur_p + v_b[d] * dt);
+      pu = fminf(pu, cur_p + v_b[dof + d] * dt);
+    }
+    const float cp = pos[tid];
+    const float ctau = effort ? effort[tid] : 0.0f;
+    float c = 0.0f, gp = 0.0f, gt = 0.0f;
+    if (cp < pl || cp > pu) {
+      const float delta = cp < pl ? cp - pl : cp - pu;
+      const float wv = w * delta;
+      c += 0.5f * wv * delta; gp += wv;
+    }
+    if (tau_w > 0.0f && (ctau < tl || ctau > tu)) {
+      const float delta = ctau < tl ? ctau - tl : ctau - tu;
+      const float wv = tau_w * delta;
+      c += 0.5f * wv * delta; gt += wv;
+    }
+    const float tw = cspace_target_weight[0] * cspace_target_dof_weight[d];
+    if (tw > 0.0f) {
+      const float e = cp - cspace_target[(size_t)cspace_target_idx[b] * dof + d];
+      c += tw * e * e; gp += 2.0f * tw * e;
+    }
+    const float vw = squared_l2_reg_weight[0] * dt, aw = squared_l2_reg_weight[1] * dt * dt;
+    if (dt > 0.0f && (vw > 0.0f || aw > 0.0f)) {
+      const float vi = (cp - cur_p) / dt;
+      if (vw > 0.0f) { c += 0.5f * vw * vi * vi; gp += vw * vi / dt; }
+      if (aw > 0.0f) {
+        const float ai = (vi - current_velocity[(size_t)cur * dof + d]) / dt;
+        c += 0.5f * aw * ai * ai; gp += aw * ai / (dt * dt);
+      }
+    }
+    out_cost[tid] = c;
+    if (write_grad) { out_grad_p[tid] = gp; out_grad_tau[tid] = gt; }
+  }
+}

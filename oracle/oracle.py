@@ -72,6 +72,8 @@ class Oracle:
             "orc_lbfgs_step",
             "orc_line_search",
             "orc_trajectory_cost_sum",
+            "orc_tool_pose_distance",
+            "orc_cspace_position_cost",
             "orc_set_num_threads",
         ):
             getattr(self.lib, name).restype = None
@@ -356,6 +358,62 @@ class Oracle:
             C.c_int(b),
         )
         return state
+
+    # ------------------------------------------------------------------ costs
+    def tool_pose_distance(self, current_position, current_quat, goal_position, goal_quat, idxs_goal,
+                           position_orientation_weight, terminal_axes_weight, non_terminal_axes_weight,
+                           terminal_tolerance, non_terminal_tolerance, project_distance_to_goal,
+                           rotation_method: int = 0):
+        cp = _f32(current_position)
+        b, h, L, _ = cp.shape
+        gp = _f32(goal_position)
+        ng = gp.shape[-2]
+        out = {
+            "distance": np.zeros((b, h, 2 * L), np.float32),
+            "position_distance": np.zeros((b, h, L), np.float32),
+            "rotation_distance": np.zeros((b, h, L), np.float32),
+            "position_gradient": np.zeros((b, h, L, 3), np.float32),
+            "rotation_gradient": np.zeros((b, h, L, 4), np.float32),
+            "goalset_idx": np.zeros((b, h, L), np.int32),
+        }
+        self.lib.orc_tool_pose_distance(
+            _ptr(out["distance"]), _ptr(out["position_distance"]), _ptr(out["rotation_distance"]),
+            _ptr(out["position_gradient"]), _ptr(out["rotation_gradient"]), _ptr(out["goalset_idx"]),
+            _ptr(cp), _ptr(_f32(current_quat)), _ptr(gp), _ptr(_f32(goal_quat)),
+            _ptr(np.ascontiguousarray(idxs_goal, np.int32)), _ptr(_f32(position_orientation_weight)),
+            _ptr(_f32(terminal_axes_weight)), _ptr(_f32(non_terminal_axes_weight)),
+            _ptr(_f32(terminal_tolerance)), _ptr(_f32(non_terminal_tolerance)),
+            _ptr(np.ascontiguousarray(project_distance_to_goal, np.uint8)),
+            C.c_int(b), C.c_int(h), C.c_int(L), C.c_int(ng), C.c_int(rotation_method),
+        )
+        return out
+
+    def cspace_position_cost(self, pos, p_b, weight, activation_distance, effort=None, effort_b=None,
+                             cspace_target=None, cspace_target_idx=None, cspace_target_weight=0.0,
+                             cspace_target_dof_weight=None, squared_l2_reg_weight=(0.0, 0.0),
+                             current_position=None, current_velocity=None, idxs_current_state=None, v_b=None,
+                             state_dt=None):
+        p = _f32(pos)
+        b, h, d = p.shape
+        z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+        effort_b = _f32(effort_b) if effort_b is not None else np.stack([-1e9 * np.ones(d), 1e9 * np.ones(d)]).astype(np.float32)
+        out_c, out_gp, out_gt = z(b, h, d), z(b, h, d), z(b, h, d)
+        self.lib.orc_cspace_position_cost(
+            _ptr(out_c), _ptr(out_gp), _ptr(out_gt), _ptr(p), _ptr(_f32(effort)) if effort is not None else None,
+            _ptr(_f32(cspace_target) if cspace_target is not None else z(1, d)),
+            _ptr(np.ascontiguousarray(cspace_target_idx if cspace_target_idx is not None else np.zeros(b), np.int32)),
+            _ptr(_f32(p_b)), _ptr(effort_b), _ptr(_f32(weight)), _ptr(_f32(activation_distance)),
+            _ptr(np.array([cspace_target_weight], np.float32)),
+            _ptr(_f32(cspace_target_dof_weight) if cspace_target_dof_weight is not None else np.ones(d, np.float32)),
+            _ptr(_f32(squared_l2_reg_weight)),
+            _ptr(_f32(current_position) if current_position is not None else z(1, d)),
+            _ptr(_f32(current_velocity) if current_velocity is not None else z(1, d)),
+            _ptr(np.ascontiguousarray(idxs_current_state if idxs_current_state is not None else np.zeros(b), np.int32)),
+            _ptr(_f32(v_b) if v_b is not None else z(2, d)),
+            _ptr(_f32(state_dt) if state_dt is not None else z(1)),
+            C.c_int(1), C.c_int(b), C.c_int(h), C.c_int(d),
+        )
+        return {"cost": out_c, "grad_position": out_gp, "grad_effort": out_gt}
 
     def trajectory_cost_sum(self, self_cost, scene_cost):
         sc = _f32(scene_cost)

@@ -1,0 +1,161 @@
+"""Tool-pose / c-space cost kernels vs the oracle, the IK rollout vs the oracle composition, and
+the IK solver end to end."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model, sample_q
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("project", [0, 1])
+def test_tool_pose_distance_kernel(method, project, oracle, device):
+    from curobo_amd.backends import cost as Cs
+
+    rng = np.random.default_rng(method * 2 + project)
+    b, h, L, G, ngoal = 37, 3, 2, 3, 5
+
+    def rq(*s):
+        q = rng.normal(size=s + (4,)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        return q
+
+    cp, cq = rng.normal(size=(b, h, L, 3)).astype(np.float32), rq(b, h, L)
+    gp, gq = rng.normal(size=(ngoal, L, G, 3)).astype(np.float32), rq(ngoal, L, G)
+    gq[0, 0, 0] = cq[0, 0, 0]  # an exact match exercises the zero / tolerance branch
+    gp[0, 0, 0] = cp[0, 0, 0]
+    idx = rng.integers(0, ngoal, size=b).astype(np.int32)
+    idx[0] = 0
+    w = np.array([100.0, 30.0], np.float32)
+    ta, na = rng.uniform(0.5, 1.5, size=(L, 6)).astype(np.float32), rng.uniform(0.0, 1.0, size=(L, 6)).astype(np.float32)
+    tt, nt = np.full((L, 2), 1e-4, np.float32), np.full((L, 2), 1e-3, np.float32)
+    proj = np.full((L,), project, np.uint8)
+    ref = oracle.tool_pose_distance(cp, cq, gp, gq, idx, w, ta, na, tt, nt, proj, method)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    out = dict(distance=torch.zeros(b, h, 2 * L, device=device), position_distance=torch.zeros(b, h, L, device=device),
+               rotation_distance=torch.zeros(b, h, L, device=device), position_gradient=torch.zeros(b, h, L, 3, device=device),
+               rotation_gradient=torch.zeros(b, h, L, 4, device=device),
+               goalset_idx=torch.zeros(b, h, L, dtype=torch.int32, device=device))
+    Cs.tool_pose_distance(out["distance"], out["position_distance"], out["rotation_distance"], out["position_gradient"],
+                          out["rotation_gradient"], out["goalset_idx"], t(cp), t(cq), t(gp), t(gq), t(idx), t(w), t(ta),
+                          t(na), t(tt), t(nt), t(proj), b, h, L, G, method)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["goalset_idx"].cpu().numpy(), ref["goalset_idx"]), "goal-set indices must be exact"
+    for k in ("distance", "position_distance", "rotation_distance", "position_gradient", "rotation_gradient"):
+        scale = max(1.0, np.abs(ref[k]).max())
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], atol=1e-5 * scale, rtol=1e-4, err_msg=k)
+
+
+def test_cspace_position_kernel(oracle, device):
+    from curobo_amd.backends import cost as Cs
+
+    model = load_model("franka")
+    rng = np.random.default_rng(0)
+    b, h, d = 53, 2, 7
+    lo, hi = model.joint_limits_position.astype(np.float32)
+    pos = (sample_q(model, b * h, seed=1, scale=1.2)).reshape(b, h, d)
+    p_b = np.stack([lo, hi])
+    cur = sample_q(model, 3, seed=2)
+    curv = rng.normal(size=(3, d)).astype(np.float32)
+    tgt = sample_q(model, 4, seed=3)
+    kw = dict(cspace_target=tgt, cspace_target_idx=rng.integers(0, 4, size=b), cspace_target_weight=2.0,
+              cspace_target_dof_weight=rng.uniform(0, 1, size=d).astype(np.float32), squared_l2_reg_weight=(0.5, 0.2),
+              current_position=cur, current_velocity=curv, idxs_current_state=rng.integers(0, 3, size=b),
+              v_b=np.stack([-model.joint_limits_velocity[1], model.joint_limits_velocity[1]]).astype(np.float32) * 40,
+              state_dt=np.array([0.1, 0.0, 0.05], np.float32))
+    ref = oracle.cspace_position_cost(pos, p_b, np.array([5000.0, 0.0], np.float32), np.array([0.01, 0.01], np.float32), **kw)
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), device=device) if dt is None else torch.as_tensor(np.ascontiguousarray(a), device=device).to(dt)  # noqa: E731
+    oc, og = torch.zeros(b, h, d, device=device), torch.zeros(b, h, d, device=device)
+    eff_b = torch.stack([torch.full((d,), -1e9, device=device), torch.full((d,), 1e9, device=device)])
+    Cs.cspace_position_cost(oc, og, None, t(pos), None, t(tgt), t(kw["cspace_target_idx"], torch.int32), t(p_b), eff_b,
+                            t(np.array([5000.0, 0.0], np.float32)), t(np.array([0.01, 0.01], np.float32)),
+                            t(np.array([2.0], np.float32)), t(kw["cspace_target_dof_weight"]),
+                            t(np.array([0.5, 0.2], np.float32)), t(cur), t(curv),
+                            t(kw["idxs_current_state"], torch.int32), t(kw["v_b"]), t(kw["state_dt"]), True, b, h, d)
+    torch.cuda.synchronize()
+    assert (ref["cost"] > 0).mean() > 0.3
+    np.testing.assert_allclose(oc.cpu().numpy(), ref["cost"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(og.cpu().numpy(), ref["grad_position"], rtol=1e-4, atol=1e-3)
+
+
+def _ik_setup(device, P=6, S=16):
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c1_world
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays(c1_world())
+    scene = SceneData.from_arrays(arrays, device)
+    return model, kin, arrays, scene
+
+
+def test_ik_rollout_matches_oracle_composition(oracle, device):
+    from curobo_amd.rollout.ik_rollout import IKRollout
+
+    model, kin, arrays, scene = _ik_setup(device)
+    md = model.as_dict()
+    B = 40
+    q = sample_q(model, B, seed=5, scale=1.05)  # a few rows violate the joint limits
+    goals = oracle.kinematics_forward(sample_q(model, 4, seed=6, scale=0.7), md)
+    ro = IKRollout(kin, scene, B)
+    idx = np.arange(B, dtype=np.int32) % 4
+    ro.update_goals(torch.as_tensor(goals["link_pos"].reshape(4, 1, 1, 3)), torch.as_tensor(goals["link_quat"].reshape(4, 1, 1, 4)),
+                    torch.as_tensor(idx, device=device))
+    cost, grad = ro.cost_and_gradient(torch.as_tensor(q, device=device))
+    torch.cuda.synchronize()
+    c = ro.cfg
+    fk = oracle.kinematics_forward(q, md)
+    T = 1
+    pose = oracle.tool_pose_distance(fk["link_pos"].reshape(B, 1, T, 3), fk["link_quat"].reshape(B, 1, T, 4),
+                                     goals["link_pos"].reshape(4, 1, 1, 3), goals["link_quat"].reshape(4, 1, 1, 4), idx,
+                                     np.array(c.pose_weight, np.float32), np.ones((T, 6), np.float32), np.ones((T, 6), np.float32),
+                                     np.full((T, 2), 1e-8, np.float32), np.full((T, 2), 1e-8, np.float32), np.zeros(T, np.uint8), 0)
+    cs = oracle.cspace_position_cost(q.reshape(B, 1, 7), model.joint_limits_position.astype(np.float32),
+                                     np.array(c.cspace_weight, np.float32), np.array(c.cspace_activation_distance, np.float32))
+    sph = fk["robot_spheres"].reshape(B, 1, -1, 4)
+    sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, c.self_collision_weight)
+    wc = oracle.scene_collision(sph, arrays, c.scene_collision_weight, c.scene_activation_distance)
+    want = pose["distance"].sum((1, 2)) + cs["cost"].sum((1, 2)) + sc["distance"] + wc["distance"].sum((1, 2))
+    assert (sc["distance"] > 0).any() and (wc["distance"] > 0).any() and (cs["cost"] > 0).any()
+    np.testing.assert_allclose(cost.cpu().numpy(), want, rtol=1e-4, atol=1e-2)
+    gs = sc["gradient"].reshape(B, -1, 4) + wc["gradient"].reshape(B, -1, 4) * np.array([1, 1, 1, 0], np.float32)
+    gq = oracle.kinematics_backward(md, fk["cumul_mat"], gs, pose["position_gradient"].reshape(B, 1, 3),
+                                    pose["rotation_gradient"].reshape(B, 1, 4)) + cs["grad_position"].reshape(B, 7)
+    np.testing.assert_allclose(grad.cpu().numpy(), gq, rtol=2e-3, atol=2e-5 * np.abs(gq).max())
+
+
+def test_ik_solver_end_to_end(oracle, device):
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+
+    model, kin, arrays, scene = _ik_setup(device)
+    md = model.as_dict()
+    P = 12
+    # reachable, collision-free goals: FK of joint samples that the oracle finds collision free
+    cand = sample_q(model, 400, seed=11, scale=0.8)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(400, 1, -1, 4)
+    free = (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0) & \
+        (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0)
+    sel = np.nonzero(free)[0][:P]
+    assert len(sel) == P
+    gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32))
+    res = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq))
+    torch.cuda.synchronize()
+    succ = res.success.cpu().numpy()
+    assert succ.mean() >= 0.9, f"IK success rate {succ.mean():.2f}"
+    # verify the reported solutions with the oracle: pose reached, limits respected, collision free
+    qs = res.solution.cpu().numpy()[succ]
+    chk = oracle.kinematics_forward(qs, md)
+    np.testing.assert_allclose(chk["link_pos"][:, 0], gp[succ], atol=5e-3)
+    dotq = np.abs((chk["link_quat"][:, 0] * gq[succ]).sum(-1))
+    assert (2 * np.arccos(np.clip(dotq, 0, 1)) < 0.05).all()
+    lo, hi = model.joint_limits_position
+    assert (qs >= lo - 1e-4).all() and (qs <= hi + 1e-4).all()
+    s2 = chk["robot_spheres"].reshape(len(qs), 1, -1, 4)
+    assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
+    assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
