@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--graph-iters", type=int, default=10, help="L-BFGS iterations per captured graph")
+    ap.add_argument("--no-ik", action="store_true", help="skip the secondary IK solves/s measurement")
+    ap.add_argument("--ik-problems", type=int, default=100)
+    ap.add_argument("--ik-seeds", type=int, default=64)
     return ap.parse_args()
 
 
@@ -236,6 +239,8 @@ def main():
             "stack_algorithmic_GBps": round(total_bytes / (elapsed / args.steps) * 1e-9, 1),
             "best_cost": float(best_c[0].item()), "best_seed": int(best_i[0].item()),
         }
+        if world == 1 and not args.no_ik:
+            out["ik"] = ik_benchmark(args, model, kin, device, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -244,6 +249,38 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def ik_benchmark(args, model, kin, device, torch):
+    """Secondary metric of BASELINE.json: collision-free IK solves/s (config C1: Franka, 64 seeds
+    per problem, 4-cuboid world, 100 problems per batch as in the reference's ik_benchmark.py;
+    100 L-BFGS iterations of 4 line-search candidates each, hipGraph replay)."""
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+    from curobo_amd.workloads import c1_world, reachable_goals
+
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
+    P, S = args.ik_problems, args.ik_seeds
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S))
+    gp, gq = reachable_goals(kin, P, seed=7)
+    res = solver.solve_pose(gp, gq)  # warm-up + graph capture
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = solver.solve_pose(gp, gq)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ocfg = solver.cfg.optimizer
+    return {
+        "value": round(P / dt, 1), "unit": "IK solves/s", "ms_per_batch": round(dt * 1e3, 3), "problems": P,
+        "seeds_per_problem": S, "lbfgs_iterations": ocfg.num_iters,
+        "rollout_rows_per_s": round(P * S * len(ocfg.line_search_scale) * (ocfg.num_iters + 1) / dt, 1),
+        "success_rate": round(float(res.success.float().mean().item()), 4),
+        "median_position_error_m": float(res.position_error[res.success].median().item()) if bool(res.success.any()) else None,
+        "workload": "C1: Franka 7-DoF, 64 uniform seeds per problem, 4-cuboid world, pose + joint-limit + self + scene "
+                    "collision costs, goals = FK of random configurations",
+    }
 
 
 def rollout_self(r):

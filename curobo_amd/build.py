@@ -23,6 +23,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libcurobo_hip.so")
 OBJ_DIR = os.path.join(_PKG, "build")
 ARCH = "gfx950"
 
+HEADERS = ["common.hpp", "cost_device.hpp", "scene_device.hpp", "fk_device.hpp", "self_device.hpp",
+           "bspline_device.hpp"]
+
 SOURCES = [
     "runtime.cpp",
     "kinematics.hip",
@@ -54,8 +57,8 @@ def _flags() -> List[str]:
 
 
 def _deps(src: str) -> List[str]:
-    return [src, os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "cost_device.hpp"),
-            os.path.join(INCLUDE, "curobo_hip.h")]
+    return [src, os.path.join(INCLUDE, "curobo_hip.h")] + [os.path.join(CSRC, h) for h in HEADERS
+                                                          if os.path.exists(os.path.join(CSRC, h))]
 
 
 def _compile(src_name: str, force: bool) -> str:
@@ -72,9 +75,8 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.hpp"),
-                                                        os.path.join(CSRC, "cost_device.hpp"),
-                                                        os.path.join(INCLUDE, "curobo_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(INCLUDE, "curobo_hip.h")] + [
+        os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

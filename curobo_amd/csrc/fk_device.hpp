@@ -1,0 +1,104 @@
+// fk_device.hpp -- device functions of forward kinematics and its VJP shared by kinematics.hip
+// and the fused rollout kernels.  Reference: kernels/kinematics/kinematics_forward_helper.cuh
+// :316-512, kinematics_backward_helper.cuh:14-183, kinematics_joint_util.cuh:13-66.
+#pragma once
+#include "common.hpp"
+
+namespace curobo_hip {
+
+constexpr int kFkLanes = 16;  // lanes per point
+
+// reference kinematics_forward_helper.cuh:316-393 / kinematics_util.cuh:62-74.
+// Writes the local 3x4 of one (point, link) column-major, each column padded to 4 floats.
+__device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst, const float *__restrict__ F,
+                                                        int j_type, float q_val, float off_mul,
+                                                        float off_add) {
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3];
+  const float f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7];
+  const float f8 = F[8], f9 = F[9], f10 = F[10], f11 = F[11];
+  float4 c0 = make_float4(f0, f4, f8, 0.0f);
+  float4 c1 = make_float4(f1, f5, f9, 0.0f);
+  float4 c2 = make_float4(f2, f6, f10, 0.0f);
+  float4 c3 = make_float4(f3, f7, f11, 0.0f);
+  if (j_type != J_FIXED) {
+    const float angle = off_mul * q_val + off_add;
+    if (j_type <= J_Z_PRISM) {
+      c3.x = f3 + (j_type == J_X_PRISM ? f0 : (j_type == J_Y_PRISM ? f1 : f2)) * angle;
+      c3.y = f7 + (j_type == J_X_PRISM ? f4 : (j_type == J_Y_PRISM ? f5 : f6)) * angle;
+      c3.z = f11 + (j_type == J_X_PRISM ? f8 : (j_type == J_Y_PRISM ? f9 : f10)) * angle;
+    } else {
+      float s, c;
+      sincosf(angle, &s, &c);
+      const int xyz = j_type - J_X_ROT;
+      const float is_x = xyz == 0 ? 1.0f : 0.0f;
+      const float is_y = xyz == 1 ? 1.0f : 0.0f;
+      const float is_z = xyz == 2 ? 1.0f : 0.0f;
+      const float s0 = is_x + c * (is_y + is_z);
+      const float s1 = is_y + c * (is_x + is_z);
+      const float s2 = is_z + c * (is_x + is_y);
+      c0 = make_float4(f0 * s0 + s * (is_z * f1 - is_y * f2), f4 * s0 + s * (is_z * f5 - is_y * f6),
+                       f8 * s0 + s * (is_z * f9 - is_y * f10), 0.0f);
+      c1 = make_float4(f1 * s1 + s * (is_x * f2 - is_z * f0), f5 * s1 + s * (is_x * f6 - is_z * f4),
+                       f9 * s1 + s * (is_x * f10 - is_z * f8), 0.0f);
+      c2 = make_float4(f2 * s2 + s * (is_y * f0 - is_x * f1), f6 * s2 + s * (is_y * f4 - is_x * f5),
+                       f10 * s2 + s * (is_y * f8 - is_x * f9), 0.0f);
+    }
+  }
+  float4 *d4 = reinterpret_cast<float4 *>(dst);
+  d4[0] = c0; d4[1] = c1; d4[2] = c2; d4[3] = c3;
+}
+
+// Serial chain of ONE point, executed by its 16-lane group without any barrier (lane 4r+c owns
+// element (r, c) of every cumulative 3x4; a lane only re-reads entries it wrote itself, the three
+// rotation entries of its row come from its DPP quad).  `local` holds the point's column-major
+// padded local transforms [L][16], `cumul` receives [L][12] row-major, `parent` = link_map.
+__device__ __forceinline__ void fk_chain_16(float *__restrict__ cumul, const float *__restrict__ local,
+                                            const int *__restrict__ parent, const float *__restrict__ fixed_transform,
+                                            int L, int lane) {
+  const int c = lane & 3;
+  const bool owner = lane < 12;
+  float cur = owner ? fixed_transform[lane] : 0.0f;  // base link: reference :467-485
+  if (owner) cumul[lane] = cur;
+  const float *my_local = local + c * 4;
+  for (int l = 1; l < L; l++) {
+    const int par = parent[l];
+    float p = cur;
+    if (par != l - 1) p = owner ? cumul[par * 12 + lane] : 0.0f;
+    const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
+    const float4 m = *reinterpret_cast<const float4 *>(my_local + l * 16);
+    cur = a0 * m.x + a1 * m.y + a2 * m.z + (c == 3 ? a3 : 0.0f);
+    if (owner) cumul[l * 12 + lane] = cur;
+  }
+}
+
+// Small robot tables staged in LDS once per workgroup (the chain walk is a pointer chase; from
+// global memory every step is a dependent L1/L2 round trip).
+struct BwdTables {
+  const int *chain;      // [C]   link indices, CSR data
+  const int *chain_off;  // [L+1] CSR offsets
+  const int *link_info;  // [L]   (joint_type + 1) | joint_index << 8   (joint_type in [-1,5])
+  const float *sign;     // [L]   joint_offset[2*l] (axis sign x mimic multiplier)
+};
+
+// gradient of one world point p with cost gradient g, pushed down the chain of link `l`
+// (reference kinematics_backward_helper.cuh:62-98, kinematics_joint_util.cuh:13-66)
+__device__ __forceinline__ void chain_point_vjp(float *__restrict__ psum, const float *__restrict__ cumul,
+                                                const BwdTables &t, int l, f3 p, f3 g) {
+  const int cs = t.chain_off[l];
+  for (int ci = t.chain_off[l + 1] - 1; ci >= cs; ci--) {
+    const int j = t.chain[ci];
+    const int info = t.link_info[j];
+    const int jt = (info & 0xff) - 1;
+    if (jt < J_X_PRISM) continue;
+    const float sign = t.sign[j];
+    const float *C = cumul + j * 12;
+    const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
+    const f3 axis = make_f3(C[ax], C[4 + ax], C[8 + ax]);
+    float r;
+    if (jt >= J_X_ROT) r = dot(sign * g, cross(axis, p - make_f3(C[3], C[7], C[11])));
+    else r = sign * dot(axis, g);
+    atomicAdd(&psum[info >> 8], r);  // own LDS row: ds_add_f32, never contended
+  }
+}
+
+}  // namespace curobo_hip

@@ -15,9 +15,7 @@
 //     distance/gradient stores are 16 B per lane, fully coalesced along the sphere axis;
 //   * the 128^3 fp16 ESDF (4 MiB) stays L2/Infinity-Cache resident; the 8 corner gathers per
 //     query are the cost, not HBM.
-#include "common.hpp"
-
-#include <hip/hip_fp16.h>
+#include "scene_device.hpp"
 
 namespace curobo_hip {
 
@@ -32,249 +30,6 @@ struct SceneArgs {
   const float *speed_dt;
   int batch, horizon, nspheres, use_multi_env, sweep_steps, enable_speed_metric;
 };
-
-struct Tf {
-  f3 p;
-  float qx, qy, qz, qw;
-};
-
-// warp-lang quat_rotate(q, v) = v (2w^2 - 1) + 2w (q x v) + 2 q (q . v)
-__device__ __forceinline__ f3 quat_rotate(float x, float y, float z, float w, f3 v) {
-  const f3 qv = make_f3(x, y, z);
-  const f3 c = cross(qv, v);
-  const float d = dot(qv, v);
-  const float k = 2.0f * w * w - 1.0f;
-  return make_f3(v.x * k + c.x * w * 2.0f + x * d * 2.0f, v.y * k + c.y * w * 2.0f + y * d * 2.0f,
-                 v.z * k + c.z * w * 2.0f + z * d * 2.0f);
-}
-__device__ __forceinline__ Tf load_inv_tf(const float *inv_pose8) {
-  // helper_pose.py:28-90: [x y z qw qx qy qz pad]
-  const float4 a = reinterpret_cast<const float4 *>(inv_pose8)[0];
-  const float4 b = reinterpret_cast<const float4 *>(inv_pose8)[1];
-  Tf t;
-  t.p = make_f3(a.x, a.y, a.z);
-  t.qw = a.w; t.qx = b.x; t.qy = b.y; t.qz = b.z;
-  return t;
-}
-__device__ __forceinline__ f3 tf_point(const Tf &t, f3 v) { return quat_rotate(t.qx, t.qy, t.qz, t.qw, v) + t.p; }
-__device__ __forceinline__ f3 tf_inv_vector(const Tf &t, f3 v) { return quat_rotate(-t.qx, -t.qy, -t.qz, t.qw, v); }
-
-// wp_collision_common.py:11-38
-__device__ __forceinline__ void activation(float dist, float eta, float &cost, float &gscale) {
-  if (dist > eta) { cost = dist - 0.5f * eta; gscale = 1.0f; }
-  else { cost = 0.5f * dist * dist / eta; gscale = dist / eta; }
-}
-
-// data_cuboid.py:547-628; g = minus the SDF gradient
-__device__ __forceinline__ float cuboid_sdf(float4 dims, f3 lp, f3 &g) {
-  const float hx = dims.x * 0.5f, hy = dims.y * 0.5f, hz = dims.z * 0.5f;
-  const float qx = fabsf(lp.x) - hx, qy = fabsf(lp.y) - hy, qz = fabsf(lp.z) - hz;
-  const float cx = fmaxf(qx, 0.0f), cy = fmaxf(qy, 0.0f), cz = fmaxf(qz, 0.0f);
-  const float od = sqrtf(cx * cx + cy * cy + cz * cz);
-  const float mq = fmaxf(qx, fmaxf(qy, qz));
-  const float sdf = od + fminf(mq, 0.0f);
-  g = make_f3(0.f, 0.f, 0.f);
-  if (od > 1e-6f) {
-    const float inv = -1.0f / od;
-    g = make_f3(cx * inv, cy * inv, cz * inv);
-    if (lp.x < 0.0f) g.x = -g.x;
-    if (lp.y < 0.0f) g.y = -g.y;
-    if (lp.z < 0.0f) g.z = -g.z;
-  } else {
-    if (fabsf(qx - mq) < 1e-6f) g.x = (lp.x < 0.0f) ? 1.0f : -1.0f;
-    else if (fabsf(qy - mq) < 1e-6f) g.y = (lp.y < 0.0f) ? 1.0f : -1.0f;
-    else g.z = (lp.z < 0.0f) ? 1.0f : -1.0f;
-  }
-  return sdf;
-}
-
-// data_voxel.py:781-1056 + :1164-1215; g = normalised minus-gradient, 0 when sdf >= max_dist
-__device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_idx, float4 prm, f3 lp, f3 &g) {
-  const int nx = (int)prm.x, ny = (int)prm.y, nz = (int)prm.z;
-  const float vs = prm.w, max_dist = sc.voxel_max_distance;
-  const __half *feat = reinterpret_cast<const __half *>(sc.voxel_features) + (size_t)flat_idx * sc.voxel_n_voxels;
-  float sdf, gx = 0.f, gy = 0.f, gz = 0.f;
-  if (nx < 2 || ny < 2 || nz < 2) {
-    const int ix = (int)((lp.x + (float)nx * vs * 0.5f) / vs);
-    const int iy = (int)((lp.y + (float)ny * vs * 0.5f) / vs);
-    const int iz = (int)((lp.z + (float)nz * vs * 0.5f) / vs);
-    const bool ok = ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz;
-    sdf = ok ? __half2float(feat[ix * ny * nz + iy * nz + iz]) : max_dist;
-  } else {
-    const float inv_voxel = 1.0f / vs;
-    const float vx = lp.x * inv_voxel + (float)nx * 0.5f - 0.5f;
-    const float vy = lp.y * inv_voxel + (float)ny * 0.5f - 0.5f;
-    const float vz = lp.z * inv_voxel + (float)nz * 0.5f - 0.5f;
-    const int x0 = (int)floorf(vx), y0 = (int)floorf(vy), z0 = (int)floorf(vz);
-    const float fx = vx - (float)x0, fy = vy - (float)y0, fz = vz - (float)z0;
-    const float fx1 = 1.0f - fx, fy1 = 1.0f - fy, fz1 = 1.0f - fz;
-    const int sx = ny * nz, sy = nz;
-    const bool x0ok = x0 >= 0 && x0 < nx, x1ok = x0 + 1 >= 0 && x0 + 1 < nx;
-    const bool y0ok = y0 >= 0 && y0 < ny, y1ok = y0 + 1 >= 0 && y0 + 1 < ny;
-    const bool z0ok = z0 >= 0 && z0 < nz, z1ok = z0 + 1 >= 0 && z0 + 1 < nz;
-    const long base = (long)x0 * sx + (long)y0 * sy + z0;
-    const bool ok[8] = {x0ok && y0ok && z0ok, x0ok && y0ok && z1ok, x0ok && y1ok && z0ok, x0ok && y1ok && z1ok,
-                        x1ok && y0ok && z0ok, x1ok && y0ok && z1ok, x1ok && y1ok && z0ok, x1ok && y1ok && z1ok};
-    const int off[8] = {0, 1, sy, sy + 1, sx, sx + 1, sx + sy, sx + sy + 1};
-    float s[8];
-    bool all_valid = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      s[k] = ok[k] ? __half2float(feat[base + off[k]]) : max_dist;
-      all_valid = all_valid && ok[k];
-    }
-    if (all_valid) {
-      sdf = s[0] * fx1 * fy1 * fz1 + s[1] * fx1 * fy1 * fz + s[2] * fx1 * fy * fz1 + s[3] * fx1 * fy * fz +
-            s[4] * fx * fy1 * fz1 + s[5] * fx * fy1 * fz + s[6] * fx * fy * fz1 + s[7] * fx * fy * fz;
-      gx = ((s[4] - s[0]) * fy1 * fz1 + (s[5] - s[1]) * fy1 * fz + (s[6] - s[2]) * fy * fz1 + (s[7] - s[3]) * fy * fz) * inv_voxel;
-      gy = ((s[2] - s[0]) * fx1 * fz1 + (s[3] - s[1]) * fx1 * fz + (s[6] - s[4]) * fx * fz1 + (s[7] - s[5]) * fx * fz) * inv_voxel;
-      gz = ((s[1] - s[0]) * fx1 * fy1 + (s[3] - s[2]) * fx1 * fy + (s[5] - s[4]) * fx * fy1 + (s[7] - s[6]) * fx * fy) * inv_voxel;
-    } else {
-      const float wts[8] = {fx1 * fy1 * fz1, fx1 * fy1 * fz, fx1 * fy * fz1, fx1 * fy * fz,
-                            fx * fy1 * fz1,  fx * fy1 * fz,  fx * fy * fz1,  fx * fy * fz};
-      float wsum = 0.f, vsum = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const float v = ok[k] ? 1.0f : 0.0f;
-        vsum += s[k] * wts[k] * v;
-        wsum += wts[k] * v;
-      }
-      if (wsum <= 0.0f) {
-        sdf = max_dist;
-      } else {
-        sdf = vsum / wsum;
-        const float wx[4] = {fy1 * fz1, fy1 * fz, fy * fz1, fy * fz};
-        const float wy[4] = {fx1 * fz1, fx1 * fz, fx * fz1, fx * fz};
-        const float wz[4] = {fx1 * fy1, fx1 * fy, fx * fy1, fx * fy};
-        float gs = 0.f, gw = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; k++)  // pairs (k, k+4)
-          if (ok[k] && ok[k + 4]) { gs += (s[k + 4] - s[k]) * wx[k]; gw += wx[k]; }
-        gx = gw > 0.0f ? gs / gw * inv_voxel : 0.0f;
-        gs = gw = 0.f;
-        const int py[4] = {0, 1, 4, 5};
-#pragma unroll
-        for (int k = 0; k < 4; k++)  // pairs (p, p+2)
-          if (ok[py[k]] && ok[py[k] + 2]) { gs += (s[py[k] + 2] - s[py[k]]) * wy[k]; gw += wy[k]; }
-        gy = gw > 0.0f ? gs / gw * inv_voxel : 0.0f;
-        gs = gw = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; k++)  // pairs (2k, 2k+1)
-          if (ok[2 * k] && ok[2 * k + 1]) { gs += (s[2 * k + 1] - s[2 * k]) * wz[k]; gw += wz[k]; }
-        gz = gw > 0.0f ? gs / gw * inv_voxel : 0.0f;
-      }
-    }
-  }
-  g = make_f3(0.f, 0.f, 0.f);
-  if (sdf >= max_dist) return max_dist;
-  const f3 ng = make_f3(-gx, -gy, -gz);
-  const float len = sqrtf(dot(ng, ng));
-  if (len > 1e-6f) g = make_f3(ng.x / len, ng.y / len, ng.z / len);
-  return sdf;
-}
-
-template <bool VOXEL>
-__device__ __forceinline__ float eval_point(const SceneArgs &a, int flat, float4 shape, f3 lp, float r_adj, float eta,
-                                            float &cost_sum, f3 &grad_sum) {
-  f3 g;
-  float sdf;
-  if (VOXEL) sdf = voxel_sdf(a.sc, flat, shape, lp, g);
-  else sdf = cuboid_sdf(shape, lp, g);
-  const float pen = -sdf + r_adj;
-  if (pen > 0.0f) {
-    float c, gs;
-    activation(pen, eta, c, gs);
-    cost_sum += c;
-    grad_sum = grad_sum + gs * g;
-  }
-  return pen;
-}
-
-// One obstacle record as the kernels consume it.  STAGED: the workgroup copies the records of
-// the (few) batch rows it touches into LDS once, so the obstacle loop reads them as LDS
-// broadcasts instead of a dependent global-memory round trip per field and obstacle.
-struct ObsRec {
-  float4 p;      // inverse position xyz, inverse quaternion w
-  float4 q;      // inverse quaternion xyz, enabled (1.0 / 0.0; already includes o < count)
-  float4 shape;  // cuboid: full extents xyz | voxel grid: nx ny nz voxel_size
-};
-
-template <bool VOXEL>
-__device__ __forceinline__ ObsRec load_rec_global(const SceneArgs &a, int env, int o) {
-  const int max_n = VOXEL ? a.sc.max_voxel_grids : a.sc.max_cuboids;
-  const int count = VOXEL ? a.sc.voxel_count[env] : a.sc.cuboid_count[env];
-  const uint8_t *enable = VOXEL ? a.sc.voxel_enable : a.sc.cuboid_enable;
-  const float *inv_pose = VOXEL ? a.sc.voxel_inv_pose : a.sc.cuboid_inv_pose;
-  const float *shape = VOXEL ? a.sc.voxel_params : a.sc.cuboid_dims;
-  const int flat = env * max_n + o;
-  ObsRec r;
-  r.p = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2];
-  r.q = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2 + 1];
-  r.shape = reinterpret_cast<const float4 *>(shape)[flat];
-  r.q.w = (o < count && enable[flat] == 1) ? 1.0f : 0.0f;  // is_obs_enabled, data_cuboid.py:467-485
-  return r;
-}
-
-// Sweep culling (result-preserving): every swept sample lies within half_dist of the current
-// centre (t in (0.5, 1]) and a signed distance field is 1-Lipschitz, so when the centre's
-// clearance  sdf - r_adj  exceeds half_dist (+ an interpolation slack for voxel grids) no sample
-// can penetrate and the whole sweep direction contributes exactly zero.
-// half_w* are the world-frame half segment lengths (rigid transforms preserve them).
-template <bool VOXEL, int SWEEP, bool STAGED>
-__device__ __forceinline__ void obstacle_set(const SceneArgs &a, const ObsRec *__restrict__ recs, int env, int h,
-                                             const float *sph_ptr, f3 center, float r_adj, float eta, float w,
-                                             float half_w_prev, float half_w_next, float &dsum, f3 &gsum) {
-  const int max_n = VOXEL ? a.sc.max_voxel_grids : a.sc.max_cuboids;
-  for (int o = 0; o < max_n; o++) {
-    const ObsRec rec = STAGED ? recs[o] : load_rec_global<VOXEL>(a, env, o);
-    if (rec.q.w == 0.0f) continue;
-    const int flat = env * max_n + o;
-    Tf t;
-    t.p = make_f3(rec.p.x, rec.p.y, rec.p.z);
-    t.qw = rec.p.w; t.qx = rec.q.x; t.qy = rec.q.y; t.qz = rec.q.z;
-    const f3 lc = tf_point(t, center);
-    float cost_sum = 0.0f;
-    f3 grad_local = make_f3(0.f, 0.f, 0.f);
-    const float pen_c = eval_point<VOXEL>(a, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
-    if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
-      // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
-      const float sdf_c = r_adj - pen_c;
-      const bool can_cull = VOXEL ? (sdf_c < a.sc.voxel_max_distance) : true;
-      // voxel slack: interpolated values are convex combinations of corner samples that sit within
-      // sqrt(3) voxels of the query, once at the centre and once at the sample, + fp16 rounding
-      const float slack = VOXEL ? 3.5f * rec.shape.w + 0.002f * fabsf(sdf_c) : 0.0f;
-      const float clearance = -pen_c;
-#pragma unroll
-      for (int dir = 0; dir < 2; dir++) {
-        const float half_w = dir == 0 ? half_w_prev : half_w_next;
-        const bool culled = can_cull && clearance > half_w * 1.0001f + slack + 1e-6f;
-        if ((dir == 0 ? (h > 0) : (h < a.horizon - 1)) && !culled) {
-          const float4 ns = *reinterpret_cast<const float4 *>(dir == 0 ? sph_ptr - (size_t)a.nspheres * 4
-                                                                        : sph_ptr + (size_t)a.nspheres * 4);
-          const f3 ln = tf_point(t, make_f3(ns.x, ns.y, ns.z));
-          const f3 dd = ln - lc;
-          const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
-          const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
-          float jump = 0.0f;
-          for (int k = 0; k < SWEEP; k++) {
-            if (jump >= half_dist) break;
-            const float tt = 1.0f - 0.5f * jump * inv_half;
-            const f3 lp = tt * lc + (1.0f - tt) * ln;
-            const float p2 = eval_point<VOXEL>(a, flat, rec.shape, lp, r_adj, eta, cost_sum, grad_local);
-            if (p2 > 0.0f) jump += p2;
-            else if (-p2 >= 1000.0f) jump += r_adj;
-            else jump += fmaxf(-p2, r_adj);
-          }
-        }
-      }
-    }
-    if (cost_sum > 0.0f) {
-      const f3 gw = tf_inv_vector(t, grad_local);
-      dsum += w * cost_sum;
-      gsum = gsum + w * gw;
-    }
-  }
-}
 
 // KINDS: bit 0 = cuboids present, bit 1 = voxel grids present (separate instantiations keep the
 // cuboid-only kernel's register footprint free of the 8-corner voxel gather state)
@@ -294,8 +49,8 @@ __global__ void __launch_bounds__(256) scene_collision_kernel(const SceneArgs a)
     for (int idx = threadIdx.x; idx < nslots * n_rec; idx += blockDim.x) {
       const int slot = idx / n_rec, o = idx - slot * n_rec;
       const int env = a.use_multi_env ? a.env_query_idx[b_first + slot] : 0;
-      recs[idx] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a, env, o)
-                                         : load_rec_global<true>(a, env, o - a.sc.max_cuboids);
+      recs[idx] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a.sc, env, o)
+                                         : load_rec_global<true>(a.sc, env, o - a.sc.max_cuboids);
     }
     __syncthreads();
   }
@@ -303,55 +58,18 @@ __global__ void __launch_bounds__(256) scene_collision_kernel(const SceneArgs a)
   const int b = (int)(sidx / hs);
   const int h = (int)((sidx - (long)b * hs) / a.nspheres);
   const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
-  const float w = a.weight[0], eta = a.activation_distance[0];
   const float *sph_ptr = a.spheres + sidx * 4;
   const float4 s = *reinterpret_cast<const float4 *>(sph_ptr);
-  const f3 center = make_f3(s.x, s.y, s.z);
-  float dsum = 0.0f;
-  f3 gsum = make_f3(0.f, 0.f, 0.f);
-  if (s.w >= 0.0f) {
-    const float r_adj = s.w + eta;
-    float half_w_prev = 0.0f, half_w_next = 0.0f;
-    if (SWEEP > 0) {
-      if (h > 0) {
-        const float4 ps = *reinterpret_cast<const float4 *>(sph_ptr - (size_t)a.nspheres * 4);
-        const f3 dd = make_f3(ps.x, ps.y, ps.z) - center;
-        half_w_prev = 0.5f * sqrtf(dot(dd, dd));
-      }
-      if (h < a.horizon - 1) {
-        const float4 ns = *reinterpret_cast<const float4 *>(sph_ptr + (size_t)a.nspheres * 4);
-        const f3 dd = make_f3(ns.x, ns.y, ns.z) - center;
-        half_w_next = 0.5f * sqrtf(dot(dd, dd));
-      }
-    }
-    const ObsRec *my = recs + (size_t)(b - b_first) * n_rec;
-    if (KINDS & 1)
-      obstacle_set<false, SWEEP, STAGED>(a, my, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev, half_w_next, dsum,
-                                         gsum);
-    if (KINDS & 2)
-      obstacle_set<true, SWEEP, STAGED>(a, my + a.sc.max_cuboids, env, h, sph_ptr, center, r_adj, eta, w, half_w_prev,
-                                        half_w_next, dsum, gsum);
-  }
-  // ---- speed metric, fused (wp_speed_metric.py:38-93)
-  if (a.enable_speed_metric && h > 0 && h < a.horizon - 1 && dsum > 0.0f) {
-    float dt = a.speed_dt[0];
-    if (dt < 1e-6f) dt = 1e-6f;
-    const float4 ps = *reinterpret_cast<const float4 *>(sph_ptr - (size_t)a.nspheres * 4);
-    const float4 ns = *reinterpret_cast<const float4 *>(sph_ptr + (size_t)a.nspheres * 4);
-    const f3 pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
-    const f3 vel = (0.5f / dt) * (np - pp);
-    const float sv = sqrtf(dot(vel, vel));
-    if (sv >= 1e-3f) {
-      const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
-      const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
-      const float sv2 = sv * sv;
-      const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
-      const f3 og = gsum - dot(nv, gsum) * nv;
-      const f3 oc = curv - dot(nv, curv) * nv;
-      gsum = sv * (og - dsum * oc);
-      dsum = sv * dsum;
-    }
-  }
+  const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;  // neighbours feed the sweep and the speed metric
+  const bool has_prev = need_nb && h > 0, has_next = need_nb && h < a.horizon - 1;
+  float4 ps = s, ns = s;
+  if (has_prev) ps = *reinterpret_cast<const float4 *>(sph_ptr - (size_t)a.nspheres * 4);
+  if (has_next) ns = *reinterpret_cast<const float4 *>(sph_ptr + (size_t)a.nspheres * 4);
+  float dsum;
+  f3 gsum;
+  sphere_scene_cost<SWEEP, STAGED, KINDS>(a.sc, recs + (size_t)(b - b_first) * n_rec, env, s, has_prev, ps, has_next, ns,
+                                          a.activation_distance[0], a.weight[0], a.enable_speed_metric != 0,
+                                          a.enable_speed_metric ? a.speed_dt[0] : 0.0f, dsum, gsum);
   a.distance[sidx] = dsum;
   reinterpret_cast<float4 *>(a.gradient)[sidx] = make_float4(gsum.x, gsum.y, gsum.z, 0.0f);
 }

@@ -12,7 +12,7 @@
 // of a workgroup; the reference's two-kernel map-reduce (self_collision_max_block_kernel +
 // _max_reduce_kernel) and its block_batch_max_* scratch are not needed.
 // Canonical tie rule: equal maxima -> lowest index in pair_locations.
-#include "common.hpp"
+#include "self_device.hpp"
 
 namespace curobo_hip {
 
@@ -28,21 +28,6 @@ struct SelfCollArgs {
   int n_points, nspheres, npairs;
   int store_pair_distance, write_grad;
 };
-
-__device__ __forceinline__ void argmax_merge(float &v, int &k, float ov, int ok) {
-  const bool take = (ov > v) || (ov == v && ok < k);
-  v = take ? ov : v;
-  k = take ? ok : k;
-}
-
-// one pair evaluation (reference sphere_squared_distance_fused, self_collision_helper.cuh:61-71)
-__device__ __forceinline__ float pair_penetration(float4 s1, float4 s2) {
-  const float r = s1.w + s2.w;
-  const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
-  const float d2 = dx * dx + dy * dy + dz * dz;
-  const float valid = (s1.w >= 0.0f && s2.w >= 0.0f) ? 1.0f : 0.0f;
-  return ((r * r) - d2) * valid;
-}
 
 // Scan pairs [k_begin, k_end) of the LDS-resident pair tile for the wave's point.  Four pairs per
 // lane are in flight per iteration (pair dwords first, then the 8 sphere reads) so the two
@@ -162,29 +147,6 @@ __global__ void __launch_bounds__(NWAVES * 64) self_collision_kernel(const SelfC
 // ---- small pair lists (arms): 16 lanes per point, 4 points per wave, 16 points per workgroup.
 // Spheres of the 16 points are one contiguous float4 run in HBM (coalesced load), the pair list
 // is staged once per workgroup, and the (value, index) arg-max never leaves a 16-lane DPP row.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_f<0xB1>(v));
-  v = fmaxf(v, dpp_f<0x4E>(v));
-  v = fmaxf(v, dpp_f<0x141>(v));
-  v = fmaxf(v, dpp_f<0x140>(v));
-  return v;
-}
-__device__ __forceinline__ int row16_min(int v) {
-  v = min(v, dpp_i<0xB1>(v));
-  v = min(v, dpp_i<0x4E>(v));
-  v = min(v, dpp_i<0x141>(v));
-  v = min(v, dpp_i<0x140>(v));
-  return v;
-}
-
 template <bool STORE>
 __global__ void __launch_bounds__(256) self_collision_row16_kernel(const SelfCollArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

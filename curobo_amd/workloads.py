@@ -60,3 +60,19 @@ def c1_world() -> List[List[Dict]]:
         {"dims": [0.2, 0.2, 0.6], "pose": [0.55, -0.35, 0.3, 1, 0, 0, 0]},
         {"dims": [0.3, 0.3, 0.05], "pose": [-0.5, 0.0, 0.6, 1, 0, 0, 0]},
     ]]
+
+
+def reachable_goals(kin, num: int, seed: int = 0, scale: float = 0.8):
+    """Goal poses (position [num,3], quaternion wxyz [num,4]) = FK of random joint samples, so that
+    every goal is kinematically reachable (the reference's ik_benchmark.py:88-94 protocol)."""
+    import torch
+
+    from .kinematics import Kinematics, KinematicsCfg
+
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = kin.joint_limits_position[0].cpu(), kin.joint_limits_position[1].cpu()
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * scale
+    q = (mid + half * (2 * torch.rand(num, kin.num_dof, generator=g) - 1)).to(kin.device)
+    fk = Kinematics(KinematicsCfg(kin, None), compute_spheres=False)
+    st = fk.compute_kinematics(q)
+    return st.tool_poses.position[:, 0, 0].clone(), st.tool_poses.quaternion[:, 0, 0].clone()
