@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--graph-iters", type=int, default=10, help="L-BFGS iterations per captured graph")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="drop-in kernel sequence (7 launches per rollout) instead of the fused rollout kernel")
     ap.add_argument("--no-ik", action="store_true", help="skip the secondary IK solves/s measurement")
     ap.add_argument("--ik-problems", type=int, default=100)
     ap.add_argument("--ik-seeds", type=int, default=64)
@@ -135,7 +137,7 @@ def main():
     kin = KinematicsParams.from_model(model, device)
     scene_arrays = cuboid_scene_arrays(c2_world())
     scene = SceneData.from_arrays(scene_arrays, device)
-    cfg = CollisionRolloutCfg()
+    cfg = CollisionRolloutCfg(use_fused=not args.no_fused)
     ocfg = LBFGSOptCfg(num_problems=args.seeds, inner_iters=args.graph_iters)
     nls = len(ocfg.line_search_scale)
     rollout = CollisionRollout(kin, scene, args.seeds * nls, cfg)
@@ -206,13 +208,17 @@ def main():
             "scene_collision_swept": (lambda: rollout_scene(rollout), N * (36 * S)),
             "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 16 * S + 28 * T + 4 * D)),
         }
+        fused = cfg.use_fused and rollout.fused_available()
+        if fused:  # one launch does the work of the five kernels above + cost sum + B-spline VJP
+            kernels["rollout_trajectory_fused"] = (lambda: rollout.cost_and_gradient_fused(act),
+                                                   N * rollout.algorithmic_bytes_per_point())
         timings = {}
         for name, (fn, nbytes) in kernels.items():
             us = time_kernel(fn, it, torch)
             timings[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes),
                              "GBps": round(nbytes / us * 1e-3, 1)}
         step_us = time_kernel(lambda: opt._opt_step(), 50, torch)
-        dom = max(timings, key=lambda k: timings[k]["us"])
+        dom = "rollout_trajectory_fused" if fused else max(timings, key=lambda k: timings[k]["us"])
         ach = timings[dom]["GBps"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -230,7 +236,7 @@ def main():
                             "one L-BFGS iteration (line search + two-loop) per step",
                 "robot": "franka", "seeds_per_gpu": args.seeds, "line_search_candidates": nls,
                 "horizon": cfg.horizon, "n_knots": cfg.n_knots, "rollouts_per_step_per_gpu": args.seeds * nls,
-                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "parallelism": f"seed-shard x{world}",
+                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "fused_rollout_kernel": bool(fused), "parallelism": f"seed-shard x{world}",
             },
             "roofline": roofline,
             "kernels_us": {k: v["us"] for k, v in timings.items()},

@@ -5,17 +5,17 @@
 
 namespace curobo_hip {
 
-__device__ __constant__ float kB3[4][4] = {{-1.0f / 6.0f, 3.0f / 6.0f, -3.0f / 6.0f, 1.0f / 6.0f},
+static __device__ __constant__ float kB3[4][4] = {{-1.0f / 6.0f, 3.0f / 6.0f, -3.0f / 6.0f, 1.0f / 6.0f},
                                            {3.0f / 6.0f, -6.0f / 6.0f, 0.0f, 4.0f / 6.0f},
                                            {-3.0f / 6.0f, 3.0f / 6.0f, 3.0f / 6.0f, 1.0f / 6.0f},
                                            {1.0f / 6.0f, 0.0f, 0.0f, 0.0f}};
-__device__ __constant__ float kB4[5][5] = {
+static __device__ __constant__ float kB4[5][5] = {
     {1.0f / 24.0f, -4.0f / 24.0f, 6.0f / 24.0f, -4.0f / 24.0f, 1.0f / 24.0f},
     {-4.0f / 24.0f, 12.0f / 24.0f, -6.0f / 24.0f, -12.0f / 24.0f, 11.0f / 24.0f},
     {6.0f / 24.0f, -12.0f / 24.0f, -6.0f / 24.0f, 12.0f / 24.0f, 11.0f / 24.0f},
     {-4.0f / 24.0f, 4.0f / 24.0f, 6.0f / 24.0f, 4.0f / 24.0f, 1.0f / 24.0f},
     {1.0f / 24.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
-__device__ __constant__ float kB5[6][6] = {
+static __device__ __constant__ float kB5[6][6] = {
     {-1.0f / 120.0f, 5.0f / 120.0f, -10.0f / 120.0f, 10.0f / 120.0f, -5.0f / 120.0f, 1.0f / 120.0f},
     {5.0f / 120.0f, -20.0f / 120.0f, 20.0f / 120.0f, 20.0f / 120.0f, -50.0f / 120.0f, 26.0f / 120.0f},
     {-10.0f / 120.0f, 30.0f / 120.0f, -0.0f / 120.0f, -60.0f / 120.0f, 0.0f / 120.0f, 66.0f / 120.0f},
@@ -24,15 +24,15 @@ __device__ __constant__ float kB5[6][6] = {
     {1.0f / 120.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
 
 // start/goal boundary knot coefficients, bspline_boundary_constraint.cuh:52-92
-__device__ __constant__ float kFix3[4][4] = {{1.0f, 1.0f, 1.0f, 1.0f},
+static __device__ __constant__ float kFix3[4][4] = {{1.0f, 1.0f, 1.0f, 1.0f},
                                              {-1.0f, 0.0f, 1.0f, 2.0f},
                                              {1.0f / 3.0f, -1.0f / 6.0f, 1.0f / 3.0f, 11.0f / 6.0f},
                                              {0.0f, 0.0f, 0.0f, 0.0f}};
-__device__ __constant__ float kFix4[4][5] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0f},
+static __device__ __constant__ float kFix4[4][5] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0f},
                                              {-3.0f / 2.0f, -1.0f / 2.0f, 1.0f / 2.0f, 3.0f / 2.0f, 5.0f / 2.0f},
                                              {11.0f / 12.0f, -1.0f / 12.0f, -1.0f / 12.0f, 11.0f / 12.0f, 35.0f / 12.0f},
                                              {-3.0f / 12.0f, 1.0f / 12.0f, -1.0f / 12.0f, 3.0f / 12.0f, 25.0f / 12.0f}};
-__device__ __constant__ float kFix5[4][6] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f},
+static __device__ __constant__ float kFix5[4][6] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f},
                                              {-2.0f, -1.0f, 0.0f, 1.0f, 2.0f, 3.0f},
                                              {1.75f, 0.25f, -0.25f, 0.25f, 1.75f, 4.25f},
                                              {-0.833333f, 0.083333f, 0.0f, -0.083333f, 0.833333f, 3.75f}};

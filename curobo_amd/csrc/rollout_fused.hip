@@ -1,0 +1,564 @@
+// rollout_fused.hip -- the whole rollout of one trajectory in ONE kernel launch:
+//   knots -> B-spline -> FK -> collision spheres -> self collision + (swept) scene collision
+//         -> per-trajectory cost, and the VJP back through FK and the B-spline to the knots.
+//
+// This is the MI355X-first form of the hot path.  The reference (and the drop-in entry points of
+// this library) run 7 kernels that hand ~6.8 KB per trajectory point through HBM (joint angles,
+// 13 cumulative transforms, 65 spheres, two 65x4 gradient buffers, ...).  None of those tensors
+// is consumed by the optimiser: L-BFGS only needs cost[B] and d cost / d knots.  Here a
+// workgroup owns one trajectory; every intermediate lives in LDS (2.1 KB per point for a Franka,
+// two workgroups per CU), HBM traffic drops to ~0.7 KB per ROLLOUT (knots in, cost + gradient
+// out), and the six launch boundaries disappear.  Optional pointers materialise joint positions
+// and world spheres for callers that want them (metrics / visualisation).
+//
+// Arithmetic is shared with the stand-alone kernels through the *_device.hpp headers, so the
+// fused and unfused paths agree to fp32 summation order (tests/test_gpu_fused.py).
+//
+// Mapping: a trajectory point is owned by a 16-lane DPP row exactly as in kinematics.hip
+// (4 points per wave64); group g handles points g, g + n_groups, ... .  Phases (3 barriers):
+//   P0  all lanes: stage robot tables, pair list, obstacle records; B-spline samples -> q in LDS
+//   P1  per point: local transforms (one sincos per lane) -> barrier-free chain -> spheres
+//   P2  per point: self collision (row16 DPP arg-max), scene collision per sphere (neighbour
+//       spheres read from LDS for the sweep / speed metric), immediate chain VJP of every
+//       non-zero sphere gradient into per-lane LDS rows, row reduction -> grad_q, point cost
+//   P3  B-spline VJP to the knots, fixed-order sum of the point costs
+#include <cstdio>
+#include <cstdlib>
+
+#include "bspline_device.hpp"
+#include "cost_device.hpp"
+#include "fk_device.hpp"
+#include "scene_device.hpp"
+#include "self_device.hpp"
+
+namespace curobo_hip {
+
+struct FusedTrajArgs {
+  float *out_cost;        // [B]
+  float *out_grad_knots;  // [B, n_knots, D]
+  float *out_position;    // optional [B, H, D]
+  float *out_spheres;     // optional [B, H, S, 4]
+  BsFwdArgs bs;           // knots + start/goal states + dt (out_* members unused)
+  const float *fixed_transform, *robot_spheres, *joint_offset;
+  const int8_t *joint_map_type;
+  const int16_t *joint_map, *link_map, *link_sphere_map, *link_chain_data, *link_chain_offsets;
+  const float *sphere_padding, *w_self;
+  const int16_t *pairs;
+  curobo_hip_scene sc;
+  const float *w_scene, *eta, *speed_dt;
+  const int32_t *env_query_idx;
+  int batch, nlinks, nspheres, npairs, chain_len, dpad, num_envs, use_multi_env, enable_speed_metric;
+  int use_self, use_scene;
+  long long *prof;  // optional [B][8] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
+};
+
+// LDS carve (floats unless noted), per workgroup:
+//   q / grad_q [H][D] | cumul [H][L][12] | work [H][WS] (locals [L][16] then spheres [S][4])
+//   | wrench [H][L][7] | cost [H] | parent[L] chain_off[L+1] link_info[L] sign[L] chain[C]
+//   sphere_link[S] sphere_rad[S] (raw radius) | subtree masks [L][4] | joint-link masks [D][4]
+//   | leftover-point sphere gradients [S][4] + arg-max key | pairs [P] | obstacle records
+constexpr int kWrench = 7;  // per link: force xyz, torque xyz about the link origin, joint gradient
+
+struct FusedLayout {
+  int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, chain, sph_link, sph_rad, sub, jlinks, left,
+      key, pairs, recs, total;
+};
+__host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec) {
+  FusedLayout f;
+  int o = 0;
+  auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
+  f.q = take(H * D);
+  f.cumul = take(H * L * 12);
+  f.ws = ((L * 16 > S * 4 ? L * 16 : S * 4) + 3) & ~3;
+  f.work = take(H * f.ws);
+  f.wl = L * kWrench;
+  f.wrench = take(H * f.wl);
+  f.cost = take(H);
+  f.parent = take(L);
+  f.chain_off = take(L + 1);
+  f.link_info = take(L);
+  f.sign = take(L);
+  f.chain = take(C);
+  f.sph_link = take(S);
+  f.sph_rad = take(S);
+  f.sub = take(L * 4);
+  f.jlinks = take(D * 4);
+  f.left = take(S * 4);
+  f.key = take(4);
+  f.pairs = take(P);
+  f.recs = take(n_rec * kObsRecFloats);
+  f.total = o;
+  return f;
+}
+
+// LDS views + per-launch scalars shared by the phases
+struct FusedCtx {
+  float *q, *cumul, *work, *wrench, *cost, *sign, *sph_rad;
+  int *parent, *chain_off, *link_info, *chain, *sph_link;
+  uint32_t *sub, *jlinks, *pairs;
+  float4 *left;
+  unsigned long long *key;
+  const ObsRec *recs;
+  int H, D, L, S, P, ws, wl, env;
+  float w_self, w_scene, eta, speed_dt;
+  bool speed_metric;
+  __device__ __forceinline__ const float4 *spheres(int h) const { return reinterpret_cast<const float4 *>(work + (size_t)h * ws); }
+};
+
+// Adds the cost gradient g acting at world point p of a sphere on link l to that link's wrench
+// accumulator (force, torque about the link origin).  Called by ONE lane at a time (the callers
+// serialise the contributing lanes in lane order), so the fp32 sums are reproducible.
+__device__ __forceinline__ void wrench_add(float *__restrict__ wr, const float *__restrict__ cumul, int l, f3 p, f3 g) {
+  const float *C = cumul + l * 12;
+  const f3 t = cross(p - make_f3(C[3], C[7], C[11]), g);
+  float *w = wr + l * kWrench;
+  atomicAdd(w + 0, g.x); atomicAdd(w + 1, g.y); atomicAdd(w + 2, g.z);  // ds_add_f32, fire and forget
+  atomicAdd(w + 3, t.x); atomicAdd(w + 4, t.y); atomicAdd(w + 5, t.z);
+}
+
+// the lanes of the wave whose sphere gradient is non-zero add their wrench one at a time, in lane
+// order; returns whether the caller's 16-lane row had any
+__device__ __forceinline__ bool wrench_add_serialised(const FusedCtx &c, int h, int s, f3 p, f3 g, int lane64) {
+  unsigned long long m = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f);
+  const bool row_any = ((m >> (lane64 & 48)) & 0xffffull) != 0ull;
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (lane64 == src) wrench_add(c.wrench + (size_t)h * c.wl, c.cumul + (size_t)h * c.L * 12, c.sph_link[s], p, g);
+  }
+  return row_any;
+}
+
+__device__ __forceinline__ unsigned long long pair_key(float pen, int k) {  // max = largest pen, then lowest k
+  return ((unsigned long long)__float_as_uint(pen) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)k);
+}
+
+// the arg-max pair pushes its two spheres apart (reference self_collision_kernel.cuh:84-111)
+__device__ __forceinline__ float self_pair_apply(const FusedCtx &c, int h, float m, int k) {
+  const float4 *sph = c.spheres(h);
+  const uint32_t ij = c.pairs[k];
+  const int i = (int)(int16_t)(ij & 0xffffu), j = (int)(int16_t)(ij >> 16);
+  const float4 s1 = sph[i], s2 = sph[j];
+  const f3 g = make_f3(c.w_self * (s2.x - s1.x), c.w_self * (s2.y - s1.y), c.w_self * (s2.z - s1.z));
+  float *wr = c.wrench + (size_t)h * c.wl;
+  const float *cumul = c.cumul + (size_t)h * c.L * 12;
+  wrench_add(wr, cumul, c.sph_link[i], make_f3(s1.x, s1.y, s1.z), g);
+  wrench_add(wr, cumul, c.sph_link[j], make_f3(s2.x, s2.y, s2.z), -1.0f * g);
+  return 0.5f * c.w_self * m;
+}
+
+// scene cost + gradient of sphere s of point h (neighbour spheres from LDS for the sweep / speed metric)
+template <int SWEEP, int KINDS>
+__device__ __forceinline__ float4 scene_sphere(const FusedCtx &c, const curobo_hip_scene &sc, int h, int s, float &d, f3 &g) {
+  const bool need_nb = SWEEP > 0 || c.speed_metric;
+  const bool has_prev = need_nb && h > 0, has_next = need_nb && h < c.H - 1;
+  float4 c4 = c.spheres(h)[s];
+  c4.w = c.sph_rad[s];  // scene collision uses the raw radius
+  sphere_scene_cost<SWEEP, true, KINDS>(sc, c.recs, c.env, c4, has_prev, c.spheres(h > 0 ? h - 1 : h)[s], has_next,
+                                        c.spheres(h < c.H - 1 ? h + 1 : h)[s], c.eta, c.w_scene, c.speed_metric, c.speed_dt, d, g);
+  return c4;
+}
+
+// Second half of the VJP of point h, run by its 16-lane row after all wrenches are in: every
+// moving link sums the wrenches of its subtree about its own origin and projects them on its joint
+// axis; then every dof sums its links (mimic joints) in a fixed order.  The reference walks the
+// chain once per sphere (kinematics_backward_helper.cuh:62-98, kinematics_joint_util.cuh:13-66);
+// the sum is the same, factored through the link wrenches.
+__device__ __forceinline__ void point_vjp_gather(const FusedCtx &c, int h, bool any_grad, int lane) {
+  const float *cumul = c.cumul + (size_t)h * c.L * 12;
+  float *wr = c.wrench + (size_t)h * c.wl;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int l = lane; l < c.L; l += kFkLanes) {
+    float r = 0.0f;
+    const int info = c.link_info[l];
+    const int jt = (info & 0xff) - 1;
+    if (any_grad && jt >= J_X_PRISM) {
+      const float *C = cumul + l * 12;
+      const f3 o = make_f3(C[3], C[7], C[11]);
+      f3 F = make_f3(0.f, 0.f, 0.f), T = make_f3(0.f, 0.f, 0.f);
+      for (int wd = 0; wd < (c.L + 31) / 32; wd++) {
+        uint32_t mask = c.sub[l * 4 + wd];
+        while (mask) {
+          const int lp = wd * 32 + __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const float *w = wr + lp * kWrench;
+          const f3 f = make_f3(w[0], w[1], w[2]);
+          const float *Cp = cumul + lp * 12;
+          F = F + f;
+          T = T + make_f3(w[3], w[4], w[5]) + cross(make_f3(Cp[3], Cp[7], Cp[11]) - o, f);
+        }
+      }
+      const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
+      const f3 axis = make_f3(C[ax], C[4 + ax], C[8 + ax]);
+      r = c.sign[l] * (jt >= J_X_ROT ? dot(axis, T) : dot(axis, F));
+    }
+    wr[l * kWrench + 6] = r;  // slot 6 of link l: its joint gradient
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < c.D; d += kFkLanes) {
+    float acc = 0.0f;
+    for (int wd = 0; wd < (c.L + 31) / 32; wd++) {
+      uint32_t mask = c.jlinks[d * 4 + wd];
+      while (mask) {
+        const int l = wd * 32 + __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        acc += wr[l * kWrench + 6];
+      }
+    }
+    c.q[h * c.D + d] = acc;  // grad_q re-uses the q slots
+  }
+}
+
+// FK of point h by one 16-lane row: local transforms (one sincos per lane) -> barrier-free chain
+__device__ __forceinline__ void point_fk_chain(const FusedCtx &c, const FusedTrajArgs &a, int h, int lane) {
+  float *work = c.work + (size_t)h * c.ws;
+  float *cumul = c.cumul + (size_t)h * c.L * 12;
+  for (int l = lane; l < c.L; l += kFkLanes) {
+    const int info = c.link_info[l];
+    const int jt = (info & 0xff) - 1;
+    const float qv = jt != J_FIXED ? c.q[h * c.D + (info >> 8)] : 0.0f;
+    local_transform_colmajor(work + l * 16, a.fixed_transform + l * 12, jt, qv, c.sign[l], a.joint_offset[2 * l + 1]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  fk_chain_16(cumul, work, c.parent, a.fixed_transform, c.L, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// world sphere s of point h overwrites the (dead) local transforms; .w = radius + self-collision padding
+__device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajArgs &a, const float4 *rs, int b, int h, int s) {
+  float4 w4 = transform_sphere(c.cumul + ((size_t)h * c.L + c.sph_link[s]) * 12, rs[s]);
+  if (a.out_spheres) reinterpret_cast<float4 *>(a.out_spheres)[((size_t)b * c.H + h) * c.S + s] = w4;
+  w4.w += a.sphere_padding[s];
+  reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[s] = w4;
+}
+
+// Workgroups are at most 8 waves when two of them fit in a CU's LDS (<= 80 KB each): 2 x 8 waves =
+// 4 per SIMD is what 128 VGPRs allow, and the second workgroup hides the serial phases (table
+// loads, the FK chain, barriers) of the first.  (9-wave workgroups do not pair up on a CU even at
+// 5 waves/SIMD: measured with tools/probes/lds_occupancy_probe.hip + the profile hook.)
+// Points beyond the last full round of 16-lane rows (H = 33 on 32 rows) are "leftover" points:
+// instead of a round in which one row works and 31 wait, all threads share them (pairs and spheres
+// spread over the workgroup, gradients handed over through LDS, row 0 finishes the VJP).
+template <int DEG, int SWEEP, int KINDS>
+__global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const FusedTrajArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
+  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.x;
+  FusedCtx c;
+  c.q = smem + lay.q; c.cumul = smem + lay.cumul; c.work = smem + lay.work; c.wrench = smem + lay.wrench;
+  c.cost = smem + lay.cost; c.sign = smem + lay.sign; c.sph_rad = smem + lay.sph_rad;
+  c.parent = reinterpret_cast<int *>(smem + lay.parent);
+  c.chain_off = reinterpret_cast<int *>(smem + lay.chain_off);
+  c.link_info = reinterpret_cast<int *>(smem + lay.link_info);
+  c.chain = reinterpret_cast<int *>(smem + lay.chain);
+  c.sph_link = reinterpret_cast<int *>(smem + lay.sph_link);
+  c.sub = reinterpret_cast<uint32_t *>(smem + lay.sub);        // [L][4]: links in the subtree of l
+  c.jlinks = reinterpret_cast<uint32_t *>(smem + lay.jlinks);  // [D][4]: links driven by joint d
+  c.left = reinterpret_cast<float4 *>(smem + lay.left);
+  c.key = reinterpret_cast<unsigned long long *>(smem + lay.key);
+  c.pairs = reinterpret_cast<uint32_t *>(smem + lay.pairs);
+  ObsRec *s_recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
+  c.recs = s_recs;
+  c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
+  c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
+#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 8 + (i)] = wall_clock64(); } while (0)
+  CUROBO_STAMP(0);
+  const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
+  const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
+  c.w_self = a.use_self ? a.w_self[0] : 0.0f;
+  c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
+  c.eta = a.use_scene ? a.eta[0] : 0.0f;
+  c.speed_metric = a.enable_speed_metric != 0;
+  c.speed_dt = c.speed_metric ? a.speed_dt[0] : 0.0f;
+
+  // ---------------- P0: tables + B-spline samples
+  for (int i = tid; i < L * 4 + D * 4; i += nt) c.sub[i] = 0u;  // sub and jlinks are adjacent
+  for (int l = tid; l < L; l += nt) {
+    c.parent[l] = a.link_map[l];
+    c.link_info[l] = ((int)a.joint_map_type[l] + 1) | ((int)(a.joint_map[l] < 0 ? 0 : a.joint_map[l]) << 8);
+    c.sign[l] = a.joint_offset[2 * l];
+  }
+  for (int l = tid; l <= L; l += nt) c.chain_off[l] = a.link_chain_offsets[l];
+  for (int ci = tid; ci < a.chain_len; ci += nt) c.chain[ci] = a.link_chain_data[ci];
+  for (int s = tid; s < S; s += nt) {
+    c.sph_link[s] = a.link_sphere_map[s];
+    c.sph_rad[s] = rs[s].w;
+  }
+  if (a.use_self) {
+    const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pairs);
+    for (int k = tid; k < P; k += nt) c.pairs[k] = g_pairs[k];
+  }
+  if (a.use_scene)
+    for (int o = tid; o < n_rec; o += nt)
+      s_recs[o] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a.sc, c.env, o)
+                                         : load_rec_global<true>(a.sc, c.env, o - a.sc.max_cuboids);
+  for (int e = tid; e < H * D; e += nt) {
+    const int h = e / D, d = e - h * D;
+    float o4[4];
+    bspline_sample<DEG>(a.bs, b, h, d, o4);
+    c.q[e] = o4[0];
+    if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
+  }
+  for (int i = tid; i < H * lay.wl; i += nt) c.wrench[i] = 0.0f;
+  __syncthreads();
+  // transposed kinematic tables (integer atomics: order independent)
+  for (int l = tid; l < L; l += nt) {
+    for (int ci = c.chain_off[l]; ci < c.chain_off[l + 1]; ci++) atomicOr(&c.sub[c.chain[ci] * 4 + (l >> 5)], 1u << (l & 31));
+    const int info = c.link_info[l];
+    if ((info & 0xff) - 1 >= J_X_PRISM) atomicOr(&c.jlinks[(info >> 8) * 4 + (l >> 5)], 1u << (l & 31));
+  }
+  CUROBO_STAMP(1);
+
+  const int grp = tid / kFkLanes, lane = tid % kFkLanes, ngroups = nt / kFkLanes;
+  const int lane64 = tid & 63;
+  // leftover points are shared by the workgroup when they are few (else: one more ordinary round)
+  int n_left = H % ngroups;
+  if (n_left * 4 > ngroups) n_left = 0;
+  const int H_main = H - n_left;
+
+  // ---------------- P1: FK per point
+  for (int h = grp; h < H_main; h += ngroups) {
+    point_fk_chain(c, a, h, lane);
+    for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, rs, b, h, s);
+  }
+  if (n_left) {
+    if (grp < n_left) point_fk_chain(c, a, H_main + grp, lane);
+    __syncthreads();
+    for (int e = tid; e < n_left * S; e += nt) point_sphere(c, a, rs, b, H_main + e / S, e % S);
+  }
+  __syncthreads();
+  CUROBO_STAMP(2);
+
+  // ---------------- P2: costs + VJP per point
+  for (int h = grp; h < H_main; h += ngroups) {
+    const float4 *sph = c.spheres(h);
+    float cost_pt = 0.0f;
+    bool any_grad = false;  // uniform over the 16-lane row
+    if (a.use_self) {       // reference self_collision_kernel.cuh:19-111
+      constexpr int U = 4;
+      float best = 0.0f;
+      int best_k = 0x7fffffff;
+      for (int k0 = lane; k0 < P; k0 += kFkLanes * U) {
+        uint32_t ij[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int k = k0 + u * kFkLanes;
+          ij[u] = c.pairs[k < P ? k : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int k = k0 + u * kFkLanes;
+          const int i = (int)(int16_t)(ij[u] & 0xffffu), j = (int)(int16_t)(ij[u] >> 16);
+          const float f = pair_penetration(sph[i], sph[j]);
+          if (k < P && f > best) { best = f; best_k = k; }
+        }
+      }
+      const float m = row16_max(best);
+      const int kmin = row16_min((best == m && best > 0.0f) ? best_k : 0x7fffffff);
+      if (kmin != 0x7fffffff && m > 0.0f) {
+        any_grad = true;
+        if (lane == 0) cost_pt += self_pair_apply(c, h, m, kmin);
+      }
+    }
+    const bool stamp_pt = a.prof && lane == 0 && h == (b % H);
+    if (stamp_pt) a.prof[(size_t)b * 8 + 5] = wall_clock64();
+    if (a.use_scene) {
+      for (int s0 = 0; s0 < S; s0 += kFkLanes) {
+        const int s = s0 + lane;
+        float d = 0.0f;
+        f3 g = make_f3(0.f, 0.f, 0.f);
+        float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (s < S) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g);
+        cost_pt += d;
+        any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_grad;
+      }
+    }
+    if (stamp_pt) a.prof[(size_t)b * 8 + 6] = wall_clock64();
+    cost_pt = row16_sum(cost_pt);
+    if (lane == 0) c.cost[h] = cost_pt;
+    point_vjp_gather(c, h, any_grad, lane);
+    if (stamp_pt) a.prof[(size_t)b * 8 + 7] = wall_clock64();
+  }
+  for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
+    if (tid == 0) *c.key = 0ull;
+    __syncthreads();
+    if (a.use_self) {
+      const float4 *sph = c.spheres(h);
+      float best = 0.0f;
+      int best_k = 0x7fffffff;
+      for (int k = tid; k < P; k += nt) {
+        const uint32_t ij = c.pairs[k];
+        const float f = pair_penetration(sph[(int)(int16_t)(ij & 0xffffu)], sph[(int)(int16_t)(ij >> 16)]);
+        if (f > best) { best = f; best_k = k; }
+      }
+      if (best > 0.0f) atomicMax(c.key, pair_key(best, best_k));  // integer max: order independent
+    }
+    if (a.use_scene)
+      for (int s = tid; s < S; s += nt) {
+        float d;
+        f3 g;
+        scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g);
+        c.left[s] = make_float4(g.x, g.y, g.z, d);
+      }
+    __syncthreads();
+    if (grp == 0) {  // row 0 folds the handed-over results in the same order as an ordinary point
+      float cost_pt = 0.0f;
+      bool any_grad = false;
+      const unsigned long long key = *c.key;
+      if (key != 0ull) {
+        any_grad = true;
+        if (lane == 0) cost_pt += self_pair_apply(c, h, __uint_as_float((uint32_t)(key >> 32)), (int)(0x7fffffffu - (uint32_t)key));
+      }
+      if (a.use_scene) {
+        const float4 *sph = c.spheres(h);
+        for (int s0 = 0; s0 < S; s0 += kFkLanes) {
+          const int s = s0 + lane;
+          float4 gd = make_float4(0.f, 0.f, 0.f, 0.f), c4 = gd;
+          if (s < S) { gd = c.left[s]; c4 = sph[s]; }
+          cost_pt += gd.w;
+          any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), make_f3(gd.x, gd.y, gd.z), lane64) || any_grad;
+        }
+      }
+      cost_pt = row16_sum(cost_pt);
+      if (lane == 0) c.cost[h] = cost_pt;
+      point_vjp_gather(c, h, any_grad, lane);
+    }
+  }
+  __syncthreads();
+  CUROBO_STAMP(3);
+
+  // ---------------- P3: B-spline VJP + trajectory cost
+  const int nk = a.bs.n_knots;
+  const int go = a.bs.goal_idx[b];
+  const float traj_dt = a.bs.traj_dt[go];
+  const bool use_goal = a.bs.use_implicit_goal[go] != 0;
+  const float *gin[4] = {c.q, nullptr, nullptr, nullptr};
+  for (int e = tid; e < nk * D; e += nt) {
+    const int k = e / D, d = e - k * D;
+    a.out_grad_knots[(size_t)b * nk * D + e] = bspline_knot_grad<DEG>(gin, (size_t)d, D, k, nk, H, traj_dt, use_goal);
+  }
+  if (tid == 0) {
+    float acc = 0.0f;
+    for (int h = 0; h < H; h++) acc += c.cost[h];
+    a.out_cost[b] = acc;
+  }
+  CUROBO_STAMP(4);
+#undef CUROBO_STAMP
+}
+
+}  // namespace curobo_hip
+
+using namespace curobo_hip;
+
+static long long *g_fused_prof = nullptr;
+
+// development hook (not part of the drop-in surface): device buffer [batch][8] of int64 that
+// receives 100 MHz wall-clock stamps at the phase boundaries of every fused launch; NULL = off
+CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_buffer) {
+  g_fused_prof = (long long *)device_buffer;
+  return CUROBO_HIP_OK;
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horizon, int dof, int num_links,
+                                                                   int num_spheres, int num_collision_pairs,
+                                                                   int link_chain_len, int num_obstacles) {
+  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
+                                       num_obstacles);
+  return lay.total * (int)sizeof(float);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
+    float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres, const float *u_position,
+    const float *start_position, const float *start_velocity, const float *start_acceleration, const float *start_jerk,
+    const float *goal_position, const float *goal_velocity, const float *goal_acceleration, const float *goal_jerk,
+    const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt, const uint8_t *use_implicit_goal_state,
+    const float *fixed_transform, const float *robot_spheres, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const float *joint_offset_map, const float *sphere_padding,
+    const float *self_collision_weight, const int16_t *pair_locations, const curobo_hip_scene *scene,
+    const float *scene_collision_weight, const float *activation_distance, const float *speed_dt,
+    const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof,
+    int n_knots, int bspline_degree, int num_links, int num_spheres, int num_collision_pairs, int link_chain_len,
+    int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream) {
+  const char *what = "rollout_trajectory_fused";
+  CUROBO_REQUIRE(bspline_degree >= 3 && bspline_degree <= 5, "%s: bspline_degree must be 3, 4 or 5", what);
+  CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3", what);
+  CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && padded_horizon >= 2 && n_knots >= 1,
+                 "%s: bad dimensions", what);
+  CUROBO_REQUIRE(link_chain_len >= 1, "%s: link_chain_len must be >= 1", what);
+  CUROBO_REQUIRE(((uintptr_t)pair_locations & 3) == 0, "%s: pair_locations must be 4-byte aligned", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  FusedTrajArgs a{};
+  a.out_cost = out_cost; a.out_grad_knots = out_grad_knots; a.out_position = out_position;
+  a.out_spheres = out_robot_spheres;
+  a.bs.u = u_position;
+  a.bs.start[0] = start_position; a.bs.start[1] = start_velocity; a.bs.start[2] = start_acceleration; a.bs.start[3] = start_jerk;
+  a.bs.goal[0] = goal_position; a.bs.goal[1] = goal_velocity; a.bs.goal[2] = goal_acceleration; a.bs.goal[3] = goal_jerk;
+  a.bs.start_idx = start_idx; a.bs.goal_idx = goal_idx; a.bs.traj_dt = traj_dt; a.bs.use_implicit_goal = use_implicit_goal_state;
+  a.bs.batch = batch_size; a.bs.padded_horizon = padded_horizon; a.bs.dof = dof; a.bs.n_knots = n_knots;
+  a.fixed_transform = fixed_transform; a.robot_spheres = robot_spheres; a.joint_offset = joint_offset_map;
+  a.joint_map_type = joint_map_type; a.joint_map = joint_map; a.link_map = link_map; a.link_sphere_map = link_sphere_map;
+  a.link_chain_data = link_chain_data; a.link_chain_offsets = link_chain_offsets;
+  a.sphere_padding = sphere_padding; a.w_self = self_collision_weight; a.pairs = pair_locations;
+  a.use_self = (pair_locations && self_collision_weight && num_collision_pairs > 0) ? 1 : 0;
+  a.use_scene = (scene && scene_collision_weight) ? 1 : 0;
+  if (scene) a.sc = *scene;
+  a.w_scene = scene_collision_weight; a.eta = activation_distance; a.speed_dt = speed_dt; a.env_query_idx = env_query_idx;
+  a.batch = batch_size; a.nlinks = num_links; a.nspheres = num_spheres; a.npairs = a.use_self ? num_collision_pairs : 0;
+  a.chain_len = link_chain_len; a.dpad = dof | 1; a.num_envs = num_envs; a.use_multi_env = use_multi_env;
+  a.enable_speed_metric = (a.use_scene && enable_speed_metric) ? 1 : 0;
+  a.prof = g_fused_prof;
+  CUROBO_REQUIRE(!a.enable_speed_metric || speed_dt, "%s: speed metric needs speed_dt", what);
+  const int n_rec = a.use_scene ? a.sc.max_cuboids + a.sc.max_voxel_grids : 0;
+  if (!a.use_scene) { a.sc.max_cuboids = 0; a.sc.max_voxel_grids = 0; }
+  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec);
+  const size_t lds = (size_t)lay.total * sizeof(float);
+  CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
+  int threads = ((padded_horizon * kFkLanes + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  static const int force_threads = [] { const char *e = getenv("CUROBO_HIP_FUSED_THREADS"); return e ? atoi(e) : 0; }();
+  if (threads > 512 && lds <= 80 * 1024) threads = 512;  // two workgroups per CU, see the kernel's header
+  if (force_threads >= 64 && force_threads <= 1024) threads = force_threads & ~63;  // tuning knob
+  const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+#define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
+  do {                                                                                                         \
+    auto kfn = rollout_trajectory_fused_kernel<DG, SW, KD>;                                                    \
+    if (lds > 64 * 1024) {                                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(e)); \
+    }                                                                                                          \
+    static const bool dbg = getenv("CUROBO_HIP_FUSED_DEBUG") != nullptr;                                      \
+    if (dbg) {                                                                                                 \
+      int nb = -1;                                                                                             \
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kfn, threads, lds);                      \
+      fprintf(stderr, "[curobo_hip] fused: threads %d lds %zu -> %d workgroups/CU\n", threads, lds, nb); \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)batch_size), dim3(threads), lds, st, a);                            \
+  } while (0)
+#define CUROBO_FUSED_KINDS(DG, SW)                         \
+  do {                                                     \
+    if (kinds == 2) CUROBO_FUSED_LAUNCH(DG, SW, 2);        \
+    else if (kinds == 3) CUROBO_FUSED_LAUNCH(DG, SW, 3);   \
+    else CUROBO_FUSED_LAUNCH(DG, SW, 1);                   \
+  } while (0)
+#define CUROBO_FUSED_SWEEP(DG)                             \
+  do {                                                     \
+    if (sweep_steps == 0) CUROBO_FUSED_KINDS(DG, 0);       \
+    else CUROBO_FUSED_KINDS(DG, 3);                        \
+  } while (0)
+  if (bspline_degree == 3) CUROBO_FUSED_SWEEP(3);
+  else if (bspline_degree == 4) CUROBO_FUSED_SWEEP(4);
+  else CUROBO_FUSED_SWEEP(5);
+#undef CUROBO_FUSED_SWEEP
+#undef CUROBO_FUSED_KINDS
+#undef CUROBO_FUSED_LAUNCH
+  return check_launch(what, st);
+}

@@ -10,31 +10,25 @@
 
 namespace curobo_hip {
 
-struct Tf {
-  f3 p;
-  float qx, qy, qz, qw;
+// warp-lang quat_rotate(q, v) = v (2w^2 - 1) + 2w (q x v) + 2 q (q . v), written out as the 3x3
+// matrix it is: R = (2w^2 - 1) I + 2w [q]x + 2 q q^T (also for non-unit q).  The obstacle records
+// carry R | t of the INVERSE obstacle pose (helper_pose.py:28-90: [x y z qw qx qy qz pad]), built
+// once per workgroup, so a sphere-obstacle test starts with 9 FMAs instead of the quaternion form.
+struct ObsRec {
+  float4 r0, r1, r2;  // rows of R, .w = translation component: local = R world + t
+  float4 shape;       // cuboid: HALF extents xyz | voxel grid: nx ny nz voxel_size
+  float4 meta;        // .x = enabled (1.0 / 0.0; already includes o < count)
 };
+constexpr int kObsRecFloats = sizeof(ObsRec) / sizeof(float);
 
-// warp-lang quat_rotate(q, v) = v (2w^2 - 1) + 2w (q x v) + 2 q (q . v)
-__device__ __forceinline__ f3 quat_rotate(float x, float y, float z, float w, f3 v) {
-  const f3 qv = make_f3(x, y, z);
-  const f3 c = cross(qv, v);
-  const float d = dot(qv, v);
-  const float k = 2.0f * w * w - 1.0f;
-  return make_f3(v.x * k + c.x * w * 2.0f + x * d * 2.0f, v.y * k + c.y * w * 2.0f + y * d * 2.0f,
-                 v.z * k + c.z * w * 2.0f + z * d * 2.0f);
+__device__ __forceinline__ f3 to_local(const ObsRec &r, f3 v) {
+  return make_f3(r.r0.x * v.x + r.r0.y * v.y + r.r0.z * v.z + r.r0.w, r.r1.x * v.x + r.r1.y * v.y + r.r1.z * v.z + r.r1.w,
+                 r.r2.x * v.x + r.r2.y * v.y + r.r2.z * v.z + r.r2.w);
 }
-__device__ __forceinline__ Tf load_inv_tf(const float *inv_pose8) {
-  // helper_pose.py:28-90: [x y z qw qx qy qz pad]
-  const float4 a = reinterpret_cast<const float4 *>(inv_pose8)[0];
-  const float4 b = reinterpret_cast<const float4 *>(inv_pose8)[1];
-  Tf t;
-  t.p = make_f3(a.x, a.y, a.z);
-  t.qw = a.w; t.qx = b.x; t.qy = b.y; t.qz = b.z;
-  return t;
+__device__ __forceinline__ f3 to_world_vector(const ObsRec &r, f3 v) {  // R^T v
+  return make_f3(r.r0.x * v.x + r.r1.x * v.y + r.r2.x * v.z, r.r0.y * v.x + r.r1.y * v.y + r.r2.y * v.z,
+                 r.r0.z * v.x + r.r1.z * v.y + r.r2.z * v.z);
 }
-__device__ __forceinline__ f3 tf_point(const Tf &t, f3 v) { return quat_rotate(t.qx, t.qy, t.qz, t.qw, v) + t.p; }
-__device__ __forceinline__ f3 tf_inv_vector(const Tf &t, f3 v) { return quat_rotate(-t.qx, -t.qy, -t.qz, t.qw, v); }
 
 // wp_collision_common.py:11-38
 __device__ __forceinline__ void activation(float dist, float eta, float &cost, float &gscale) {
@@ -43,14 +37,15 @@ __device__ __forceinline__ void activation(float dist, float eta, float &cost, f
 }
 
 // data_cuboid.py:547-628; g = minus the SDF gradient
-__device__ __forceinline__ float cuboid_sdf(float4 dims, f3 lp, f3 &g) {
-  const float hx = dims.x * 0.5f, hy = dims.y * 0.5f, hz = dims.z * 0.5f;
-  const float qx = fabsf(lp.x) - hx, qy = fabsf(lp.y) - hy, qz = fabsf(lp.z) - hz;
+// (half = half extents; the gradient is only worked out by the caller's penetrating lanes)
+__device__ __forceinline__ float cuboid_sdf(float4 half, f3 lp, bool want_grad, float r_adj, f3 &g) {
+  const float qx = fabsf(lp.x) - half.x, qy = fabsf(lp.y) - half.y, qz = fabsf(lp.z) - half.z;
   const float cx = fmaxf(qx, 0.0f), cy = fmaxf(qy, 0.0f), cz = fmaxf(qz, 0.0f);
   const float od = sqrtf(cx * cx + cy * cy + cz * cz);
   const float mq = fmaxf(qx, fmaxf(qy, qz));
   const float sdf = od + fminf(mq, 0.0f);
   g = make_f3(0.f, 0.f, 0.f);
+  if (!(want_grad && r_adj - sdf > 0.0f)) return sdf;
   if (od > 1e-6f) {
     const float inv = -1.0f / od;
     g = make_f3(cx * inv, cy * inv, cz * inv);
@@ -156,7 +151,7 @@ __device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat
   f3 g;
   float sdf;
   if (VOXEL) sdf = voxel_sdf(sc, flat, shape, lp, g);
-  else sdf = cuboid_sdf(shape, lp, g);
+  else sdf = cuboid_sdf(shape, lp, true, r_adj, g);
   const float pen = -sdf + r_adj;
   if (pen > 0.0f) {
     float c, gs;
@@ -167,15 +162,9 @@ __device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat
   return pen;
 }
 
-// One obstacle record as the kernels consume it.  STAGED: the workgroup copies the records of
-// the (few) batch rows it touches into LDS once, so the obstacle loop reads them as LDS
-// broadcasts instead of a dependent global-memory round trip per field and obstacle.
-struct ObsRec {
-  float4 p;      // inverse position xyz, inverse quaternion w
-  float4 q;      // inverse quaternion xyz, enabled (1.0 / 0.0; already includes o < count)
-  float4 shape;  // cuboid: full extents xyz | voxel grid: nx ny nz voxel_size
-};
-
+// One obstacle record as the kernels consume it.  STAGED: the workgroup builds the records of the
+// (few) batch rows it touches in LDS once, so the obstacle loop reads them as LDS broadcasts instead
+// of a dependent global-memory round trip (and a quaternion expansion) per obstacle and sphere.
 template <bool VOXEL>
 __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, int env, int o) {
   const int max_n = VOXEL ? sc.max_voxel_grids : sc.max_cuboids;
@@ -184,11 +173,17 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   const float *inv_pose = VOXEL ? sc.voxel_inv_pose : sc.cuboid_inv_pose;
   const float *shape = VOXEL ? sc.voxel_params : sc.cuboid_dims;
   const int flat = env * max_n + o;
+  const float4 p = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2];      // x y z qw
+  const float4 q = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2 + 1];  // qx qy qz pad
+  const float x = q.x, y = q.y, z = q.z, w = p.w;
+  const float k = 2.0f * w * w - 1.0f;
   ObsRec r;
-  r.p = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2];
-  r.q = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2 + 1];
+  r.r0 = make_float4(k + 2.0f * x * x, 2.0f * x * y - 2.0f * w * z, 2.0f * x * z + 2.0f * w * y, p.x);
+  r.r1 = make_float4(2.0f * x * y + 2.0f * w * z, k + 2.0f * y * y, 2.0f * y * z - 2.0f * w * x, p.y);
+  r.r2 = make_float4(2.0f * x * z - 2.0f * w * y, 2.0f * y * z + 2.0f * w * x, k + 2.0f * z * z, p.z);
   r.shape = reinterpret_cast<const float4 *>(shape)[flat];
-  r.q.w = (o < count && enable[flat] == 1) ? 1.0f : 0.0f;  // is_obs_enabled, data_cuboid.py:467-485
+  if (!VOXEL) r.shape = make_float4(r.shape.x * 0.5f, r.shape.y * 0.5f, r.shape.z * 0.5f, 0.0f);
+  r.meta = make_float4((o < count && enable[flat] == 1) ? 1.0f : 0.0f, 0.f, 0.f, 0.f);  // is_obs_enabled, data_cuboid.py:467-485
   return r;
 }
 
@@ -197,20 +192,36 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
 // clearance  sdf - r_adj  exceeds half_dist (+ an interpolation slack for voxel grids) no sample
 // can penetrate and the whole sweep direction contributes exactly zero.
 // half_w* are the world-frame half segment lengths (rigid transforms preserve them).
+// Early reject (result-preserving as well): thr2 = (r_adj + max half sweep length + margin)^2.  A
+// cuboid whose squared outside distance exceeds it is clear of the centre by more than any sweep
+// can reach: no penetration, both sweep directions culled -> exactly zero, without sqrt, gradient
+// or sweep bookkeeping.  A voxel grid is skipped when the centre is so far outside its box (sweep
+// reach + one voxel) that every sample reads the constant max_distance.
 template <bool VOXEL, int SWEEP, bool STAGED>
 __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs, int env,
                                              bool has_prev, bool has_next, f3 prev_c, f3 next_c, f3 center, float r_adj,
                                              float eta, float w, float half_w_prev, float half_w_next, float &dsum,
                                              f3 &gsum) {
   const int max_n = VOXEL ? sc.max_voxel_grids : sc.max_cuboids;
+  const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
+  const float thr_c = r_adj + reach;
+  const float thr2_c = thr_c * thr_c * 1.00001f;
   for (int o = 0; o < max_n; o++) {
     const ObsRec rec = STAGED ? recs[o] : load_rec_global<VOXEL>(sc, env, o);
-    if (rec.q.w == 0.0f) continue;
+    if (rec.meta.x == 0.0f) continue;
     const int flat = env * max_n + o;
-    Tf t;
-    t.p = make_f3(rec.p.x, rec.p.y, rec.p.z);
-    t.qw = rec.p.w; t.qx = rec.q.x; t.qy = rec.q.y; t.qz = rec.q.z;
-    const f3 lc = tf_point(t, center);
+    const f3 lc = to_local(rec, center);
+    if (!VOXEL) {
+      const float cx = fmaxf(fabsf(lc.x) - rec.shape.x, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y, 0.0f),
+                  cz = fmaxf(fabsf(lc.z) - rec.shape.z, 0.0f);
+      if (cx * cx + cy * cy + cz * cz > thr2_c) continue;
+    } else if (r_adj < sc.voxel_max_distance) {
+      const float vs = rec.shape.w;
+      const float cx = fmaxf(fabsf(lc.x) - rec.shape.x * vs * 0.5f, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y * vs * 0.5f, 0.0f),
+                  cz = fmaxf(fabsf(lc.z) - rec.shape.z * vs * 0.5f, 0.0f);
+      const float thr_v = reach + vs;
+      if (cx * cx + cy * cy + cz * cz > thr_v * thr_v * 1.00001f) continue;
+    }
     float cost_sum = 0.0f;
     f3 grad_local = make_f3(0.f, 0.f, 0.f);
     const float pen_c = eval_point<VOXEL>(sc, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
@@ -227,7 +238,7 @@ __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const O
         const float half_w = dir == 0 ? half_w_prev : half_w_next;
         const bool culled = can_cull && clearance > half_w * 1.0001f + slack + 1e-6f;
         if ((dir == 0 ? has_prev : has_next) && !culled) {
-          const f3 ln = tf_point(t, dir == 0 ? prev_c : next_c);
+          const f3 ln = to_local(rec, dir == 0 ? prev_c : next_c);
           const f3 dd = ln - lc;
           const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
           const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
@@ -245,7 +256,7 @@ __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const O
       }
     }
     if (cost_sum > 0.0f) {
-      const f3 gw = tf_inv_vector(t, grad_local);
+      const f3 gw = to_world_vector(rec, grad_local);
       dsum += w * cost_sum;
       gsum = gsum + w * gw;
     }

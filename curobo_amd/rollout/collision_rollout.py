@@ -25,6 +25,7 @@ import torch
 from ..backends import collision as collision_hip
 from ..backends import geometry as geometry_hip
 from ..backends import kinematics as kinematics_hip
+from ..backends import rollout as rollout_hip
 from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
 from ..scene.data import SceneData
@@ -47,6 +48,12 @@ class CollisionRolloutCfg:
     use_speed_metric: bool = True
     use_self_collision: bool = True
     use_scene_collision: bool = True
+    #: one fused launch (csrc/rollout_fused.hip) instead of the 7-kernel sequence whenever one
+    #: trajectory fits in LDS; False forces the drop-in kernel sequence (and materialises every
+    #: intermediate tensor, which the fused path only does on request)
+    use_fused: bool = True
+    #: fused path: also write position[B,H,D] and robot_spheres[B,H,S,4] to HBM
+    fused_materialize: bool = False
 
     @property
     def horizon(self) -> int:
@@ -69,6 +76,7 @@ class CollisionRollout:
         self.action_horizon = self.cfg.n_knots
         self.action_dim = kin.num_dof
         self.batch_size = 0
+        self._fused_ok: Optional[bool] = None
         d = self.device
         self._w_self = torch.tensor([self.cfg.self_collision_weight], device=d)
         self._w_scene = torch.tensor([self.cfg.scene_collision_weight], device=d)
@@ -197,9 +205,46 @@ class CollisionRollout:
             cfg.bspline_degree, False)
         return self.grad_knots
 
+    # ------------------------------------------------------------------ fused
+    def fused_available(self) -> bool:
+        cfg, k = self.cfg, self.kin
+        use_scene = cfg.use_scene_collision and self.scene is not None
+        n_obs = (self.scene.struct.max_cuboids + self.scene.struct.max_voxel_grids) if use_scene else 0
+        n_pairs = k.self_collision.collision_pairs.shape[0] if cfg.use_self_collision else 0
+        need = rollout_hip.rollout_trajectory_fused_lds_bytes(
+            cfg.padded_horizon, self.action_dim, k.num_links, k.num_spheres, n_pairs,
+            int(k.link_chain_data.shape[0]), n_obs)
+        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128
+
+    def cost_and_gradient_fused(self, act_seq: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Same numbers as ``evaluate_action`` + ``backward`` from one kernel launch."""
+        cfg, k, B = self.cfg, self.kin, self.batch_size
+        use_scene = cfg.use_scene_collision and self.scene is not None
+        sc = k.self_collision
+        mat = cfg.fused_materialize
+        rollout_hip.rollout_trajectory_fused(
+            self.cost, self.grad_knots, self.position if mat else None, self.robot_spheres if mat else None,
+            act_seq, self.start_pos, self.start_vel, self.start_acc, self.start_jerk, self.goal_pos,
+            self.goal_vel, self.goal_acc, self.goal_jerk, self.start_idx, self.goal_idx, self._traj_dt,
+            self._implicit_goal, k.fixed_transforms, k.link_spheres, k.joint_map_type, k.joint_map, k.link_map,
+            k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets, k.joint_offset_map,
+            sc.sphere_padding, self._w_self if cfg.use_self_collision else None,
+            sc.collision_pairs if cfg.use_self_collision else None,
+            self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
+            self._eta, self._speed_dt, self.env_query_idx, k.num_envs, False, B, cfg.padded_horizon,
+            self.action_dim, cfg.n_knots, cfg.bspline_degree, 3 if cfg.use_sweep else 0,
+            cfg.use_sweep and cfg.use_speed_metric)
+        return self.cost, self.grad_knots
+
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x[B, n_knots*D] -> (cost[B], grad[B, n_knots*D]); buffers are reused every call."""
         act = x.view(self.batch_size, self.cfg.n_knots, self.action_dim)
+        if self.cfg.use_fused:
+            if self._fused_ok is None:
+                self._fused_ok = self.fused_available()
+            if self._fused_ok:
+                cost, grad = self.cost_and_gradient_fused(act)
+                return cost, grad.view(self.batch_size, -1)
         cost = self.evaluate_action(act)
         grad = self.backward()
         return cost, grad.view(self.batch_size, -1)

@@ -185,6 +185,48 @@ int curobo_hip_rollout_point_aggregate(
     const float *cspace_grad, const float *self_cost, const float *scene_cost, int rows,
     int num_links, int dof, int num_spheres, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- fused rollout
+ * One launch for the data path of RobotRollout.evaluate_action + cost.backward
+ * (reference rollout/rollout_robot.py:252-263,537-587, optim/components/gradient_opt_core.py
+ * :445-480): B-spline knots -> joint positions -> FK -> collision spheres -> self collision +
+ * (swept) scene collision -> out_cost[b] (sum over the padded horizon) and
+ * out_grad_knots[b, n_knots, dof] = d out_cost / d knots.  It replaces the launch sequence
+ * bspline forward, kinematics forward, self collision, sphere-obstacle collision, cost sum,
+ * kinematics backward, bspline backward of the entry points above with identical arithmetic; all
+ * intermediates stay in LDS.  out_position [b, h, dof] and out_robot_spheres [b, h, s, 4] are
+ * optional (NULL = not materialised).  pair_locations / self_collision_weight NULL = no self
+ * collision term; scene / scene_collision_weight NULL = no scene term.  Returns
+ * CUROBO_HIP_ERR_ARG when one trajectory's working set does not fit in 160 KB of LDS (use the
+ * unfused entry points then). */
+int curobo_hip_rollout_trajectory_fused(
+    float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres,
+    const float *u_position, const float *start_position, const float *start_velocity,
+    const float *start_acceleration, const float *start_jerk, const float *goal_position,
+    const float *goal_velocity, const float *goal_acceleration, const float *goal_jerk,
+    const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt,
+    const uint8_t *use_implicit_goal_state, const float *fixed_transform,
+    const float *robot_spheres, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const float *joint_offset_map, const float *sphere_padding,
+    const float *self_collision_weight, const int16_t *pair_locations,
+    const curobo_hip_scene *scene, const float *scene_collision_weight,
+    const float *activation_distance, const float *speed_dt, const int32_t *env_query_idx,
+    int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
+    int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
+    int link_chain_len, int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream);
+
+/* LDS bytes one trajectory needs in curobo_hip_rollout_trajectory_fused (host-side query, no GPU
+ * work); the fused entry point is usable when this is <= 163840.  num_obstacles = max_cuboids +
+ * max_voxel_grids of the scene (0 without a scene term). */
+int curobo_hip_rollout_trajectory_fused_lds_bytes(
+    int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
+    int link_chain_len, int num_obstacles);
+
+/* Development hook: device buffer [batch, 8] (int64) that receives 100 MHz wall-clock stamps at
+ * the phase boundaries (start, tables+spline, FK, costs+VJP, end) of every fused launch; NULL
+ * (default) turns it off.  Used by tools/profile_fused.py. */
+int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_buffer);
+
 /* ---------------------------------------------------------------- trajectory: B-spline
  * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142
  * kernels:   kernels/trajectory/bspline/bspline_kernel.cuh:81-151,332-380

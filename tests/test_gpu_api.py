@@ -62,7 +62,7 @@ def test_collision_checker_autograd_equals_explicit_rollout(device):
     cfg = _cfg(device)
     model = cfg.model
     scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
-    rcfg = CollisionRolloutCfg(use_sweep=False, use_speed_metric=False)
+    rcfg = CollisionRolloutCfg(use_sweep=False, use_speed_metric=False, use_fused=False)
     knots = seed_knots(model, 8, rcfg.n_knots, seed=5)
     ro = CollisionRollout(cfg.kinematics_config, scene, 8, rcfg)
     ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))

@@ -1,0 +1,143 @@
+"""Parity of the fused rollout kernel (csrc/rollout_fused.hip) against the drop-in kernel
+sequence (same device functions, different summation order) and against the oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(device, robot="franka", seeds=24, world=None, voxel=False, **cfg_kw):
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model(robot)
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays(world if world is not None else c2_world())
+    if voxel:  # cuboids + one ESDF grid (a sphere obstacle) in the same scene
+        from curobo_amd.scene import voxel_grid_from_sdf
+
+        def sdf(p):
+            return np.linalg.norm(p - np.array([0.35, -0.3, 0.5]), axis=-1) - 0.18
+
+        arrays = {**arrays, **voxel_grid_from_sdf(sdf, (40, 40, 40), 0.04, pose7=(0.1, -0.1, 0.5, 1, 0, 0, 0),
+                                                  max_distance=100.0)}
+    scene = SceneData.from_arrays(arrays, device)
+    knots = seed_knots(model, seeds, cfg_kw.get("n_knots", 12), seed=11)
+    start = start_configuration(model)
+    ros = []
+    for fused in (False, True):
+        cfg = CollisionRolloutCfg(use_fused=fused, fused_materialize=True, **cfg_kw)
+        ro = CollisionRollout(kin, scene, seeds, cfg)
+        ro.update_start_state(torch.as_tensor(start, device=device))
+        ros.append(ro)
+    return model, arrays, knots, start, ros[0], ros[1]
+
+
+def _compare(ro_ref, ro_fused, knots, device, moving_only=False):
+    b = knots.shape[0]
+    x = torch.as_tensor(knots, device=device).reshape(b, -1)
+    assert ro_fused.fused_available()
+    c1, g1 = [t.clone() for t in ro_fused.cost_and_gradient(x)]
+    act = x.view(b, ro_ref.cfg.n_knots, -1)
+    ro_ref.compute_kinematics(ro_ref.compute_state_from_action(act))
+    torch.cuda.synchronize()
+    # the two paths are compiled separately, so FMA contraction may differ in the last bit
+    torch.testing.assert_close(ro_fused.position, ro_ref.position, rtol=0, atol=1e-6)
+    torch.testing.assert_close(ro_fused.robot_spheres, ro_ref.robot_spheres, rtol=0, atol=1e-6)
+    # The swept cost is discontinuous in the sphere positions at zero motion (see
+    # test_gpu_rollout.py), so the kernel sequence is evaluated on the fused kernel's own
+    # materialised spheres: identical inputs -> identical branches -> only summation order differs.
+    ro_ref.robot_spheres.copy_(ro_fused.robot_spheres)
+    c0 = ro_ref.compute_costs().clone()
+    g0 = ro_ref.backward().clone().view(b, -1)
+    torch.cuda.synchronize()
+    assert float(c0.max()) > 0.0
+    return c0.cpu().numpy(), g0.cpu().numpy(), c1.cpu().numpy(), g1.cpu().numpy()
+
+
+@pytest.mark.parametrize("sweep,speed", [(False, False), (True, False), (True, True)])
+def test_fused_equals_kernel_sequence_franka(device, sweep, speed):
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, use_sweep=sweep, use_speed_metric=speed)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    # identical sphere positions -> identical branches; only fp32 summation order differs
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+@pytest.mark.parametrize("use_self,use_scene", [(True, False), (False, True)])
+def test_fused_single_cost_terms(device, use_self, use_scene):
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, use_self_collision=use_self, use_scene_collision=use_scene)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+@pytest.mark.parametrize("degree,n_knots,interp", [(4, 10, 2), (5, 8, 3), (3, 4, 8)])
+def test_fused_bspline_degrees_and_horizons(device, degree, n_knots, interp):
+    """padded horizons 31, 43 and 65: more points than 16-lane groups exercises the group loop"""
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, seeds=9, n_knots=n_knots, interpolation_steps=interp,
+                                             bspline_degree=degree)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+def test_fused_cuboids_and_voxel_grid(device):
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, voxel=True)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+def test_fused_ur10e(device):
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, robot="ur10e", seeds=7)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+def test_fused_matches_oracle_discrete(oracle, device):
+    """strict end-to-end check against the all-oracle pipeline (continuous, non-swept cost)"""
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    model, arrays, knots, start, _, ro = _pair(device, use_sweep=False, use_speed_metric=False)
+    ref = rollout_cost_and_gradient(oracle, model.as_dict(), arrays, knots, start, use_sweep=False,
+                                    use_speed_metric=False)
+    cost, grad = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(knots.shape[0], -1))
+    torch.cuda.synchronize()
+    assert (ref["cost"] > 0).mean() > 0.5
+    np.testing.assert_allclose(cost.cpu().numpy(), ref["cost"], rtol=1e-4, atol=1e-2)
+    gk = ref["grad_knots"].reshape(knots.shape[0], -1)
+    np.testing.assert_allclose(grad.cpu().numpy(), gk, rtol=2e-3, atol=2e-5 * np.abs(gk).max())
+
+
+def test_fused_is_deterministic_and_stateless(device):
+    _, _, knots, _, _, ro = _pair(device)
+    x = torch.as_tensor(knots, device=device).reshape(knots.shape[0], -1)
+    c1, g1 = [t.clone() for t in ro.cost_and_gradient(x)]
+    ro.cost_and_gradient(x * 0.5)
+    c2, g2 = ro.cost_and_gradient(x)
+    assert torch.equal(c1, c2) and torch.equal(g1, g2)
+
+
+def test_fused_rejects_what_does_not_fit(device):
+    """G1 humanoid (674 spheres, 162k pairs) exceeds the per-trajectory LDS budget: the entry point
+    must say so (ValueError, like every argument error) and the rollout must fall back."""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+
+    model = load_model("unitree_g1")
+    kin = KinematicsParams.from_model(model, device)
+    ro = CollisionRollout(kin, None, 2, CollisionRolloutCfg(use_fused=True))
+    assert not ro.fused_available()
+    with pytest.raises(ValueError, match="LDS"):
+        ro.cost_and_gradient_fused(torch.zeros(2, 12, kin.num_dof, device=device))
+    cost, grad = ro.cost_and_gradient(torch.zeros(2, 12 * kin.num_dof, device=device))  # falls back
+    torch.cuda.synchronize()
+    assert torch.isfinite(cost).all() and torch.isfinite(grad).all()

@@ -9,7 +9,7 @@ from conftest import load_model
 pytestmark = pytest.mark.gpu
 
 
-def _setup(device, seeds=24):
+def _setup(device, seeds=24, fused=False):
     from curobo_amd.robot.kinematics_params import KinematicsParams
     from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
     from curobo_amd.scene import SceneData, cuboid_scene_arrays
@@ -19,7 +19,7 @@ def _setup(device, seeds=24):
     kin = KinematicsParams.from_model(model, device)
     arrays = cuboid_scene_arrays(c2_world())
     scene = SceneData.from_arrays(arrays, device)
-    cfg = CollisionRolloutCfg()
+    cfg = CollisionRolloutCfg(use_fused=fused)
     knots = seed_knots(model, seeds, cfg.n_knots, seed=7)
     start = start_configuration(model)
     ro = CollisionRollout(kin, scene, seeds, cfg)
