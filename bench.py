@@ -220,8 +220,9 @@ def main():
         step_us = time_kernel(lambda: opt._opt_step(), 50, torch)
         dom = "rollout_trajectory_fused" if fused else max(timings, key=lambda k: timings[k]["us"])
         ach = timings[dom]["GBps"]
+        traffic, traffic_src = measured_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": timings[dom]["us"], "algorithmic_bytes_per_launch": timings[dom]["algorithmic_bytes"]}
         total_bytes = N * rollout.algorithmic_bytes_per_point()
         out = {
@@ -255,6 +256,25 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, see profiles/*_pmc_fused.json);
+    counters cannot be collected from inside the timed process, so the figure is read back from
+    the newest matching profile (None if there is none for this kernel)."""
+    import glob
+
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_*.json"))):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if kernel in str(rec.get("kernel", "")) and rec.get("hbm_bytes_per_launch"):
+            best = (int(rec["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(path))
+    return best
 
 
 def ik_benchmark(args, model, kin, device, torch):

@@ -98,3 +98,26 @@ def prepare_search_points(
         ptr(search_magnitudes), batchsize, n_linesearch, opt_dim, action_dim, int(apply_step_scale),
         current_stream(x_set),
     ))
+
+
+def launch_lbfgs_iteration_tail(
+    best_cost, best_action, best_iteration, current_iteration, converged_global, convergence_iteration: int,
+    cost_delta_threshold: float, cost_relative_threshold: float, exploration_cost, exploration_action,
+    exploration_gradient, exploration_idx, selected_cost, selected_action, selected_gradient, selected_idx,
+    search_cost, search_action, search_gradient, step_direction_scaled, search_magnitudes,
+    armijo_threshold_c_1: float, curvature_threshold_c_2: float, strong_wolfe: bool, approx_wolfe: bool,
+    n_linesearch: int, opt_dim: int, batchsize: int, step_vec, rho_buffer, y_buffer, s_buffer, x_0, grad_0,
+    epsilon: float, history_m: int, stable_mode: bool, action_step_max, action_dim: int, apply_step_scale: bool,
+):
+    """``launch_line_search`` + ``launch_lbfgs_step`` + ``prepare_search_points`` (next iteration) in
+    one launch; argument groups in that order, same meaning as in the three functions above."""
+    check(load().curobo_hip_launch_lbfgs_iteration_tail(
+        ptr(best_cost), ptr(best_action), ptr(best_iteration), ptr(current_iteration), ptr(converged_global),
+        convergence_iteration, cost_delta_threshold, cost_relative_threshold, ptr(exploration_cost),
+        ptr(exploration_action), ptr(exploration_gradient), ptr(exploration_idx), ptr(selected_cost),
+        ptr(selected_action), ptr(selected_gradient), ptr(selected_idx), ptr(search_cost), ptr(search_action),
+        ptr(search_gradient), ptr(step_direction_scaled), ptr(search_magnitudes), armijo_threshold_c_1,
+        curvature_threshold_c_2, int(strong_wolfe), int(approx_wolfe), n_linesearch, opt_dim, batchsize,
+        ptr(step_vec), ptr(rho_buffer), ptr(y_buffer), ptr(s_buffer), ptr(x_0), ptr(grad_0), epsilon, history_m,
+        int(stable_mode), ptr(action_step_max), action_dim, int(apply_step_scale), current_stream(best_cost),
+    ))

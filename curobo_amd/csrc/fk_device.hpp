@@ -71,6 +71,51 @@ __device__ __forceinline__ void fk_chain_16(float *__restrict__ cumul, const flo
   }
 }
 
+// The same chain for N independent points in one instruction stream, software-pipelined: the walk
+// is a string of dependent steps, so everything that does not depend on the previous link (the
+// local transforms and parent indices of the next UNROLL links) is fetched up front and the
+// dependent part of a step is 4 DPP broadcasts + 3 FMAs; a second point rides in the first one's
+// latency shadow.
+template <int N, int UNROLL = 4>
+__device__ __forceinline__ void fk_chain_16_multi(float *const (&cumul)[N], const float *const (&local)[N],
+                                                  const int *__restrict__ parent, const float *__restrict__ fixed_transform,
+                                                  int L, int lane) {
+  const int c = lane & 3;
+  const bool owner = lane < 12;
+  float cur[N];
+  const float base = owner ? fixed_transform[lane] : 0.0f;
+#pragma unroll
+  for (int n = 0; n < N; n++) {
+    cur[n] = base;
+    if (owner) cumul[n][lane] = base;
+  }
+  for (int l0 = 1; l0 < L; l0 += UNROLL) {
+    float4 m[UNROLL][N];
+    int par[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int l = l0 + u < L ? l0 + u : L - 1;
+      par[u] = parent[l];
+#pragma unroll
+      for (int n = 0; n < N; n++) m[u][n] = *reinterpret_cast<const float4 *>(local[n] + c * 4 + l * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int l = l0 + u;
+      if (l < L) {
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+          float p = cur[n];
+          if (par[u] != l - 1) p = owner ? cumul[n][par[u] * 12 + lane] : 0.0f;
+          const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
+          cur[n] = a0 * m[u][n].x + a1 * m[u][n].y + a2 * m[u][n].z + (c == 3 ? a3 : 0.0f);
+          if (owner) cumul[n][l * 12 + lane] = cur[n];
+        }
+      }
+    }
+  }
+}
+
 // Small robot tables staged in LDS once per workgroup (the chain walk is a pointer chase; from
 // global memory every step is a dependent L1/L2 round trip).
 struct BwdTables {

@@ -142,12 +142,16 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
 // fully pipelined loads (VPL * 2 * 32 <= 128 registers), written back shifted by one, and both
 // loops of the recursion then run out of registers: the 2m dependent L2 round trips of the
 // streaming variant above disappear.  m is a run-time value; slots >= m are predicated off.
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+// body for one problem b on one wavefront; g_in / x_in = current gradient / iterate of the lane's
+// elements (v = lane + e * 64), dir_out = the new step direction (also stored to a.step_vec)
 template <int VPL>
-__global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) {
+__device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, int lane, const float (&g_in)[VPL],
+                                                    const float (&x_in)[VPL], float (&dir_out)[VPL]) {
   constexpr int MMAX = 32;
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
-  if (b >= a.batch) return;
   const int V = a.v_dim, m = a.m, B = a.batch;
   const size_t bv = (size_t)b * V;
   const size_t hist_stride = (size_t)B * V;
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) 
     const int v = lane + e * kWave;
     gq[e] = y[e] = s[e] = 0.0f;
     if (v < V) {
-      const float g = a.grad_q[bv + v], x = a.q[bv + v];
+      const float g = g_in[e], x = x_in[e];
       y[e] = g - a.grad_0[bv + v];
       s[e] = x - a.x_0[bv + v];
       a.grad_0[bv + v] = g;
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) 
 #pragma unroll
       for (int e = 0; e < VPL; e++) d += gq[e] * ss[i][e];
       d = wave_sum(d);
-      const float alpha = d * __shfl(rho_mine, i, kWave);
+      const float alpha = d * lane_bcast(rho_mine, i);  // i is a constant after unrolling: v_readlane
       if (lane == i) alpha_mine = alpha;
 #pragma unroll
       for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * ys[i][e];
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) 
 #pragma unroll
       for (int e = 0; e < VPL; e++) d += gq[e] * ys[i][e];
       d = wave_sum(d);
-      const float beta = __shfl(alpha_mine, i, kWave) - d * __shfl(rho_mine, i, kWave);
+      const float beta = lane_bcast(alpha_mine, i) - d * lane_bcast(rho_mine, i);
 #pragma unroll
       for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * ss[i][e];
     }
@@ -244,8 +248,24 @@ __global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) 
 #pragma unroll
   for (int e = 0; e < VPL; e++) {
     const int v = lane + e * kWave;
+    dir_out[e] = -gq[e];
     if (v < V) a.step_vec[bv + v] = -gq[e];
   }
+}
+
+template <int VPL>
+__global__ void __launch_bounds__(256) lbfgs_step_reg_kernel(const LbfgsArgs a) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= a.batch) return;
+  float g[VPL], x[VPL], dir[VPL];
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    g[e] = v < a.v_dim ? a.grad_q[(size_t)b * a.v_dim + v] : 0.0f;
+    x[e] = v < a.v_dim ? a.q[(size_t)b * a.v_dim + v] : 0.0f;
+  }
+  lbfgs_step_reg_body<VPL>(a, b, lane, g, x, dir);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,10 +284,8 @@ struct LineSearchArgs {
   int strong_wolfe, approx_wolfe, n_linesearch, opt_dim, batch;
 };
 
-__global__ void __launch_bounds__(256) line_search_kernel(const LineSearchArgs a) {
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
-  if (b >= a.batch) return;
+// body for one problem b on one wavefront; returns the exploration candidate index
+__device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, int lane) {
   const int V = a.opt_dim, NLS = a.n_linesearch;
   const float *dir = a.step_direction + (size_t)b * V;
   // g_k . d for every candidate; lane k keeps the k-th value (NLS <= 64)
@@ -329,6 +347,14 @@ __global__ void __launch_bounds__(256) line_search_kernel(const LineSearchArgs a
     a.exploration_idx[(size_t)b * NLS + lane] = expl;
     a.selected_idx[(size_t)b * NLS + lane] = sel;
   }
+  return expl;
+}
+
+__global__ void __launch_bounds__(256) line_search_kernel(const LineSearchArgs a) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= a.batch) return;
+  line_search_body(a, b, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -383,6 +409,59 @@ __global__ void __launch_bounds__(256) prepare_search_points_kernel(
     const float xv = x[o + v];
     d_out[o + v] = dv;
     for (int k = 0; k < nls; k++) x_set[((size_t)b * nls + k) * opt_dim + v] = xv + alphas[k] * dv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The optimiser side of one L-BFGS iteration in ONE launch: line search over the evaluated
+// candidates -> L-BFGS two-loop from the chosen exploration point -> the next iteration's
+// candidates.  Same arithmetic as line_search_kernel + lbfgs_step_reg_kernel +
+// prepare_search_points_kernel run back to back (those are the device functions above); the
+// exploration point and the new direction are handed over in registers, so the three dependent
+// launches (each a chain of global round trips on one wavefront per problem) become one.
+struct PrepareArgs {
+  float *x_set, *d_out;
+  const float *step_max, *alphas;
+  int action_dim, apply_scale;
+};
+
+template <int VPL>
+__global__ void __launch_bounds__(256) lbfgs_iteration_tail_kernel(const LineSearchArgs ls, const LbfgsArgs lb,
+                                                                   const PrepareArgs pr) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (b >= ls.batch) return;
+  const int V = ls.opt_dim, NLS = ls.n_linesearch;
+  const int expl = line_search_body(ls, b, lane);
+  float g[VPL], x[VPL], dir[VPL];
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {  // the values line_search_body just copied to the exploration buffers
+    const int v = lane + e * kWave;
+    const size_t src = ((size_t)b * NLS + expl) * V + v;
+    g[e] = v < V ? ls.search_gradient[src] : 0.0f;
+    x[e] = v < V ? ls.search_action[src] : 0.0f;
+  }
+  lbfgs_step_reg_body<VPL>(lb, b, lane, g, x, dir);
+  float scale = 1.0f;
+  if (pr.apply_scale) {
+    float mx = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * kWave;
+      if (v < V) mx = fmaxf(mx, fabsf(dir[e]) / pr.step_max[v % pr.action_dim]);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    scale = fmaxf(mx, 1.0f);
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * kWave;
+    if (v < V) {
+      const float dv = dir[e] / scale;
+      pr.d_out[(size_t)b * V + v] = dv;
+      for (int k = 0; k < NLS; k++) pr.x_set[((size_t)b * NLS + k) * V + v] = x[e] + pr.alphas[k] * dv;
+    }
   }
 }
 
@@ -465,5 +544,42 @@ CUROBO_EXPORT int curobo_hip_prepare_search_points(float *x_set, float *step_dir
   hipLaunchKernelGGL(prepare_search_points_kernel, dim3((unsigned)ceil_div(batchsize, 4)), dim3(256), 0, st,
                      x_set, step_direction_out, x, step_direction, action_step_max, search_magnitudes,
                      batchsize, n_linesearch, opt_dim, action_dim, apply_step_scale);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_launch_lbfgs_iteration_tail(
+    float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
+    uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
+    float cost_relative_threshold, float *exploration_cost, float *exploration_action,
+    float *exploration_gradient, int32_t *exploration_idx, float *selected_cost,
+    float *selected_action, float *selected_gradient, int32_t *selected_idx,
+    const float *search_cost, float *search_action, const float *search_gradient,
+    float *step_direction_scaled, const float *search_magnitudes, float armijo_threshold_c_1,
+    float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
+    int opt_dim, int batchsize, float *step_vec, float *rho_buffer, float *y_buffer, float *s_buffer,
+    float *x_0, float *grad_0, float epsilon, int history_m, int stable_mode,
+    const float *action_step_max, int action_dim, int apply_step_scale, curobo_hip_stream_t stream) {
+  const char *what = "launch_lbfgs_iteration_tail";
+  CUROBO_REQUIRE(n_linesearch >= 1 && n_linesearch <= kWave, "%s: n_linesearch=%d out of range [1,64]", what, n_linesearch);
+  CUROBO_REQUIRE(history_m <= 31, "%s: History_m greater than 31 is not supported", what);
+  CUROBO_REQUIRE(history_m >= 0, "%s: History_m less than 0 is not supported", what);
+  CUROBO_REQUIRE(opt_dim >= 1 && opt_dim <= 2 * kWave, "%s: opt_dim=%d out of range [1,%d] (use the three separate launches)",
+                 what, opt_dim, 2 * kWave);
+  CUROBO_REQUIRE(action_dim >= 1 && opt_dim % action_dim == 0, "%s: opt_dim must be a multiple of action_dim", what);
+  if (batchsize == 0) return CUROBO_HIP_OK;
+  LineSearchArgs ls{best_cost, best_action, best_iteration, current_iteration, converged_global,
+                    convergence_iteration, cost_delta_threshold, cost_relative_threshold,
+                    exploration_cost, exploration_action, exploration_gradient, exploration_idx,
+                    selected_cost, selected_action, selected_gradient, selected_idx,
+                    search_cost, search_action, search_gradient, step_direction_scaled, search_magnitudes,
+                    armijo_threshold_c_1, curvature_threshold_c_2, strong_wolfe, approx_wolfe,
+                    n_linesearch, opt_dim, batchsize};
+  LbfgsArgs lb{step_vec, rho_buffer, y_buffer, s_buffer, exploration_action, exploration_gradient, x_0, grad_0,
+               epsilon, batchsize, history_m, opt_dim, stable_mode};
+  PrepareArgs pr{search_action, step_direction_scaled, action_step_max, search_magnitudes, action_dim, apply_step_scale};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)ceil_div(batchsize, 4)), block(256);
+  if (opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1>), grid, block, 0, st, ls, lb, pr);
+  else hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<2>), grid, block, 0, st, ls, lb, pr);
   return check_launch(what, st);
 }

@@ -49,19 +49,20 @@ struct FusedTrajArgs {
   const int32_t *env_query_idx;
   int batch, nlinks, nspheres, npairs, chain_len, dpad, num_envs, use_multi_env, enable_speed_metric;
   int use_self, use_scene;
-  long long *prof;  // optional [B][8] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
+  long long *prof;  // optional [B][16] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
 };
 
 // LDS carve (floats unless noted), per workgroup:
 //   q / grad_q [H][D] | cumul [H][L][12] | work [H][WS] (locals [L][16] then spheres [S][4])
 //   | wrench [H][L][7] | cost [H] | parent[L] chain_off[L+1] link_info[L] sign[L] chain[C]
-//   sphere_link[S] sphere_rad[S] (raw radius) | subtree masks [L][4] | joint-link masks [D][4]
+//   offset_add[L] fixed_transform[L][12] sphere_link[S] sphere_rad[S] (raw radius) sphere_pad[S]
+//   link-frame spheres [S][4] | link bounding boxes [L][8] (ordered-int keys) | subtree masks [L][4] | joint-link masks [D][4]
 //   | leftover-point sphere gradients [S][4] + arg-max key | pairs [P] | obstacle records
 constexpr int kWrench = 7;  // per link: force xyz, torque xyz about the link origin, joint gradient
 
 struct FusedLayout {
-  int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, chain, sph_link, sph_rad, sub, jlinks, left,
-      key, pairs, recs, total;
+  int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, off_add, fixed, chain, sph_link, sph_rad,
+      sph_pad, rs, lbound, sub, jlinks, left, key, pairs, recs, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec) {
   FusedLayout f;
@@ -78,9 +79,14 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.chain_off = take(L + 1);
   f.link_info = take(L);
   f.sign = take(L);
+  f.off_add = take(L);
+  f.fixed = take(L * 12);
   f.chain = take(C);
   f.sph_link = take(S);
   f.sph_rad = take(S);
+  f.sph_pad = take(S);
+  f.rs = take(S * 4);
+  f.lbound = take(L * 8);
   f.sub = take(L * 4);
   f.jlinks = take(D * 4);
   f.left = take(S * 4);
@@ -93,7 +99,9 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
 
 // LDS views + per-launch scalars shared by the phases
 struct FusedCtx {
-  float *q, *cumul, *work, *wrench, *cost, *sign, *sph_rad;
+  float *q, *cumul, *work, *wrench, *cost, *sign, *off_add, *fixed, *sph_rad, *sph_pad;
+  const float4 *rs;      // link-frame spheres of this trajectory's robot instance
+  const int *lbound;     // per link: box (link frame) around its collision spheres: lo xyz, hi xyz as ordered-int keys
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
   float4 *left;
@@ -129,6 +137,16 @@ __device__ __forceinline__ bool wrench_add_serialised(const FusedCtx &c, int h, 
   return row_any;
 }
 
+// squared-distance penetration of one staged pair (reference sphere_squared_distance_fused,
+// self_collision_helper.cuh:61-71); ij = byte offsets of the two spheres, NaN when either is disabled
+__device__ __forceinline__ float staged_pair_penetration(const float4 *sph, uint32_t ij) {
+  const float4 s1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij & 0xffffu));
+  const float4 s2 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij >> 16));
+  const float r = s1.w + s2.w;
+  const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
+  return (r * r) - (dx * dx + dy * dy + dz * dz);
+}
+
 __device__ __forceinline__ unsigned long long pair_key(float pen, int k) {  // max = largest pen, then lowest k
   return ((unsigned long long)__float_as_uint(pen) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)k);
 }
@@ -137,7 +155,7 @@ __device__ __forceinline__ unsigned long long pair_key(float pen, int k) {  // m
 __device__ __forceinline__ float self_pair_apply(const FusedCtx &c, int h, float m, int k) {
   const float4 *sph = c.spheres(h);
   const uint32_t ij = c.pairs[k];
-  const int i = (int)(int16_t)(ij & 0xffffu), j = (int)(int16_t)(ij >> 16);
+  const int i = (int)((ij & 0xffffu) >> 4), j = (int)(ij >> 20);
   const float4 s1 = sph[i], s2 = sph[j];
   const f3 g = make_f3(c.w_self * (s2.x - s1.x), c.w_self * (s2.y - s1.y), c.w_self * (s2.z - s1.z));
   float *wr = c.wrench + (size_t)h * c.wl;
@@ -147,15 +165,67 @@ __device__ __forceinline__ float self_pair_apply(const FusedCtx &c, int h, float
   return 0.5f * c.w_self * m;
 }
 
+// order-preserving float <-> int map (its own inverse) so that integer atomic min/max order floats
+__device__ __forceinline__ int float_key(float f) { const int k = __float_as_int(f); return k >= 0 ? k : k ^ 0x7fffffff; }
+__device__ __forceinline__ float key_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// Obstacle mask of every link of point h (lanes = links): the link's bounding ball against the
+// obstacles, with the sweep reach bounded through the link's own motion,
+//   |c_s(h+-1) - c_s(h)| <= |C(h+-1) - C(h)| + ||R(h+-1) - R(h)||_F |x_s - x_centre|.
+// The mask is parked in the link's (not yet used) joint-gradient slot of the wrench table.
+template <int SWEEP, int KINDS>
+__device__ __forceinline__ void point_link_masks(const FusedCtx &c, const curobo_hip_scene &sc, int h, int lane) {
+  float *wr = c.wrench + (size_t)h * c.wl;
+  for (int l = lane; l < c.L; l += kFkLanes) {
+    // ball around the link's box of collision spheres: centre, half diagonal (+ rounding margin)
+    const int *bx = c.lbound + l * 8;
+    const f3 lo = make_f3(key_float(bx[0]), key_float(bx[1]), key_float(bx[2]));
+    const f3 hi = make_f3(key_float(bx[4]), key_float(bx[5]), key_float(bx[6]));
+    const f3 hd = 0.5f * (hi - lo);
+    const float4 lb = make_float4(0.5f * (hi.x + lo.x), 0.5f * (hi.y + lo.y), 0.5f * (hi.z + lo.z),
+                                  lo.x <= hi.x ? sqrtf(dot(hd, hd)) * 1.0001f + 1e-6f : -1.0f);
+    uint32_t mask = 0u;
+    if (lb.w >= 0.0f) {
+      const float *M = c.cumul + ((size_t)h * c.L + l) * 12;
+      const float4 C4 = transform_sphere(M, lb);
+      const f3 C = make_f3(C4.x, C4.y, C4.z);
+      float reach = 0.0f;
+      if (SWEEP > 0) {
+#pragma unroll
+        for (int dir = 0; dir < 2; dir++) {
+          const int hn = dir == 0 ? h - 1 : h + 1;
+          if (hn >= 0 && hn < c.H) {
+            const float *N = c.cumul + ((size_t)hn * c.L + l) * 12;
+            const float4 Cn = transform_sphere(N, lb);
+            const f3 dC = make_f3(Cn.x - C.x, Cn.y - C.y, Cn.z - C.z);
+            float fr = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int k = 0; k < 3; k++) { const float dr = N[r * 4 + k] - M[r * 4 + k]; fr += dr * dr; }
+            reach = fmaxf(reach, 0.5f * (sqrtf(dot(dC, dC)) + sqrtf(fr) * lb.w));
+          }
+        }
+        reach = reach * 1.001f + 1e-5f;
+      }
+      mask = bounding_ball_obstacle_mask<KINDS>(sc, c.recs, C, lb.w, c.eta, reach);
+    }
+    wr[l * kWrench + 6] = __uint_as_float(mask);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // scene cost + gradient of sphere s of point h (neighbour spheres from LDS for the sweep / speed metric)
 template <int SWEEP, int KINDS>
-__device__ __forceinline__ float4 scene_sphere(const FusedCtx &c, const curobo_hip_scene &sc, int h, int s, float &d, f3 &g) {
+__device__ __forceinline__ float4 scene_sphere(const FusedCtx &c, const curobo_hip_scene &sc, int h, int s, float &d, f3 &g,
+                                               uint32_t mask = 0xffffffffu) {
   const bool need_nb = SWEEP > 0 || c.speed_metric;
   const bool has_prev = need_nb && h > 0, has_next = need_nb && h < c.H - 1;
   float4 c4 = c.spheres(h)[s];
   c4.w = c.sph_rad[s];  // scene collision uses the raw radius
   sphere_scene_cost<SWEEP, true, KINDS>(sc, c.recs, c.env, c4, has_prev, c.spheres(h > 0 ? h - 1 : h)[s], has_next,
-                                        c.spheres(h < c.H - 1 ? h + 1 : h)[s], c.eta, c.w_scene, c.speed_metric, c.speed_dt, d, g);
+                                        c.spheres(h < c.H - 1 ? h + 1 : h)[s], c.eta, c.w_scene, c.speed_metric, c.speed_dt, d, g, mask);
   return c4;
 }
 
@@ -211,28 +281,23 @@ __device__ __forceinline__ void point_vjp_gather(const FusedCtx &c, int h, bool 
   }
 }
 
-// FK of point h by one 16-lane row: local transforms (one sincos per lane) -> barrier-free chain
-__device__ __forceinline__ void point_fk_chain(const FusedCtx &c, const FusedTrajArgs &a, int h, int lane) {
+// local transforms of point h by one 16-lane row (one sincos per lane)
+__device__ __forceinline__ void point_fk_locals(const FusedCtx &c, int h, int lane) {
   float *work = c.work + (size_t)h * c.ws;
-  float *cumul = c.cumul + (size_t)h * c.L * 12;
   for (int l = lane; l < c.L; l += kFkLanes) {
     const int info = c.link_info[l];
     const int jt = (info & 0xff) - 1;
     const float qv = jt != J_FIXED ? c.q[h * c.D + (info >> 8)] : 0.0f;
-    local_transform_colmajor(work + l * 16, a.fixed_transform + l * 12, jt, qv, c.sign[l], a.joint_offset[2 * l + 1]);
+    local_transform_colmajor(work + l * 16, c.fixed + l * 12, jt, qv, c.sign[l], c.off_add[l]);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  fk_chain_16(cumul, work, c.parent, a.fixed_transform, c.L, lane);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 }
 
 // world sphere s of point h overwrites the (dead) local transforms; .w = radius + self-collision padding
-__device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajArgs &a, const float4 *rs, int b, int h, int s) {
-  float4 w4 = transform_sphere(c.cumul + ((size_t)h * c.L + c.sph_link[s]) * 12, rs[s]);
+__device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int s) {
+  float4 w4 = transform_sphere(c.cumul + ((size_t)h * c.L + c.sph_link[s]) * 12, c.rs[s]);
   if (a.out_spheres) reinterpret_cast<float4 *>(a.out_spheres)[((size_t)b * c.H + h) * c.S + s] = w4;
-  w4.w += a.sphere_padding[s];
+  // disabled spheres (negative radius) carry NaN: every pair test against them compares false
+  w4.w = (w4.w + c.sph_pad[s]) >= 0.0f ? w4.w + c.sph_pad[s] : __builtin_nanf("");
   reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[s] = w4;
 }
 
@@ -254,6 +319,11 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   FusedCtx c;
   c.q = smem + lay.q; c.cumul = smem + lay.cumul; c.work = smem + lay.work; c.wrench = smem + lay.wrench;
   c.cost = smem + lay.cost; c.sign = smem + lay.sign; c.sph_rad = smem + lay.sph_rad;
+  c.off_add = smem + lay.off_add; c.fixed = smem + lay.fixed; c.sph_pad = smem + lay.sph_pad;
+  float4 *s_rs = reinterpret_cast<float4 *>(smem + lay.rs);
+  c.rs = s_rs;
+  int *s_lbound = reinterpret_cast<int *>(smem + lay.lbound);
+  c.lbound = s_lbound;
   c.parent = reinterpret_cast<int *>(smem + lay.parent);
   c.chain_off = reinterpret_cast<int *>(smem + lay.chain_off);
   c.link_info = reinterpret_cast<int *>(smem + lay.link_info);
@@ -268,7 +338,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   c.recs = s_recs;
   c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
   c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
-#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 8 + (i)] = wall_clock64(); } while (0)
+#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
   CUROBO_STAMP(0);
   const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
   const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
@@ -279,40 +349,87 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   c.speed_dt = c.speed_metric ? a.speed_dt[0] : 0.0f;
 
   // ---------------- P0: tables + B-spline samples
+  // Every global read of the kernel happens here.  Loads are clamped instead of predicated so each
+  // loop body is one basic block (all loads issued back to back, one wait), and the independent
+  // jobs start on different waves (rotated thread index) so their latencies overlap.
+  const auto rot = [&](int first_wave) { const int t = tid - (first_wave * 64) % nt; return t < 0 ? t + nt : t; };
+  const int nwaves = nt >> 6;
   for (int i = tid; i < L * 4 + D * 4; i += nt) c.sub[i] = 0u;  // sub and jlinks are adjacent
-  for (int l = tid; l < L; l += nt) {
-    c.parent[l] = a.link_map[l];
-    c.link_info[l] = ((int)a.joint_map_type[l] + 1) | ((int)(a.joint_map[l] < 0 ? 0 : a.joint_map[l]) << 8);
-    c.sign[l] = a.joint_offset[2 * l];
+  for (int i = tid; i < H * lay.wl; i += nt) c.wrench[i] = 0.0f;
+  for (int i = tid; i < L * 8; i += nt) s_lbound[i] = (i & 4) ? float_key(-3.0e38f) : float_key(3.0e38f);  // empty boxes
+  {
+    const int C = a.chain_len;
+    int n_tab = L * 12;
+    n_tab = n_tab > C ? n_tab : C;
+    n_tab = n_tab > S ? n_tab : S;
+    for (int i = rot(0); i < n_tab; i += nt) {
+      const int il = i < L ? i : L - 1, ic = i < C ? i : C - 1, is = i < S ? i : (S > 0 ? S - 1 : 0);
+      const int io = i <= L ? i : L, ix = i < L * 12 ? i : L * 12 - 1;
+      const int v_parent = a.link_map[il], v_type = a.joint_map_type[il], v_joint = a.joint_map[il];
+      const float v_sign = a.joint_offset[2 * il], v_add = a.joint_offset[2 * il + 1];
+      const int v_off = a.link_chain_offsets[io], v_chain = a.link_chain_data[ic];
+      const float v_fixed = a.fixed_transform[ix];
+      float4 v_rs = make_float4(0.f, 0.f, 0.f, -1.f);
+      int v_slink = 0;
+      float v_pad = 0.0f;
+      if (S > 0) {
+        v_rs = rs[is];
+        v_slink = a.link_sphere_map[is];
+        v_pad = a.sphere_padding ? a.sphere_padding[is] : 0.0f;
+      }
+      if (i < L) {
+        c.parent[i] = v_parent;
+        c.link_info[i] = (v_type + 1) | ((v_joint < 0 ? 0 : v_joint) << 8);
+        c.sign[i] = v_sign;
+        c.off_add[i] = v_add;
+      }
+      if (i <= L) c.chain_off[i] = v_off;
+      if (i < C) c.chain[i] = v_chain;
+      if (i < L * 12) c.fixed[i] = v_fixed;
+      if (i < S) {
+        c.sph_link[i] = v_slink;
+        c.sph_rad[i] = v_rs.w;
+        c.sph_pad[i] = v_pad;
+        s_rs[i] = v_rs;
+      }
+    }
   }
-  for (int l = tid; l <= L; l += nt) c.chain_off[l] = a.link_chain_offsets[l];
-  for (int ci = tid; ci < a.chain_len; ci += nt) c.chain[ci] = a.link_chain_data[ci];
-  for (int s = tid; s < S; s += nt) {
-    c.sph_link[s] = a.link_sphere_map[s];
-    c.sph_rad[s] = rs[s].w;
-  }
-  if (a.use_self) {
+  if (a.use_self) {  // (i, j) -> byte offsets of the float4 spheres; two loads in flight per thread
     const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pairs);
-    for (int k = tid; k < P; k += nt) c.pairs[k] = g_pairs[k];
+    for (int k = tid; k < P; k += 2 * nt) {
+      const int k1 = k + nt < P ? k + nt : k;
+      const uint32_t v0 = g_pairs[k], v1 = g_pairs[k1];
+      c.pairs[k] = v0 << 4;
+      c.pairs[k1] = v1 << 4;
+    }
   }
   if (a.use_scene)
-    for (int o = tid; o < n_rec; o += nt)
+    for (int o = rot(nwaves - 1); o < n_rec; o += nt)
       s_recs[o] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a.sc, c.env, o)
                                          : load_rec_global<true>(a.sc, c.env, o - a.sc.max_cuboids);
-  for (int e = tid; e < H * D; e += nt) {
+  for (int e = rot(nwaves / 2); e < H * D; e += nt) {
     const int h = e / D, d = e - h * D;
     float o4[4];
     bspline_sample<DEG>(a.bs, b, h, d, o4);
     c.q[e] = o4[0];
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
   }
-  for (int i = tid; i < H * lay.wl; i += nt) c.wrench[i] = 0.0f;
   __syncthreads();
-  // transposed kinematic tables (integer atomics: order independent)
-  for (int l = tid; l < L; l += nt) {
+  // derived tables, on the last wave (the first one carries the leftover points): transposed
+  // kinematic tables (integer atomics: order independent)
+  for (int l = rot(nwaves - 1); l < L; l += nt) {
     for (int ci = c.chain_off[l]; ci < c.chain_off[l + 1]; ci++) atomicOr(&c.sub[c.chain[ci] * 4 + (l >> 5)], 1u << (l & 31));
     const int info = c.link_info[l];
     if ((info & 0xff) - 1 >= J_X_PRISM) atomicOr(&c.jlinks[(info >> 8) * 4 + (l >> 5)], 1u << (l & 31));
+  }
+  // box per link around its collision spheres (link frame), by integer atomic min / max
+  for (int sidx = rot(nwaves > 1 ? nwaves - 2 : 0); sidx < S; sidx += nt) {
+    const float4 v = s_rs[sidx];
+    if (v.w >= 0.0f) {
+      int *bx = s_lbound + c.sph_link[sidx] * 8;
+      atomicMin(bx + 0, float_key(v.x - v.w)); atomicMin(bx + 1, float_key(v.y - v.w)); atomicMin(bx + 2, float_key(v.z - v.w));
+      atomicMax(bx + 4, float_key(v.x + v.w)); atomicMax(bx + 5, float_key(v.y + v.w)); atomicMax(bx + 6, float_key(v.z + v.w));
+    }
   }
   CUROBO_STAMP(1);
 
@@ -320,19 +437,41 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int lane64 = tid & 63;
   // leftover points are shared by the workgroup when they are few (else: one more ordinary round)
   int n_left = H % ngroups;
-  if (n_left * 4 > ngroups) n_left = 0;
+  if (n_left * 4 > ngroups || H < ngroups) n_left = 0;
   const int H_main = H - n_left;
 
-  // ---------------- P1: FK per point
+  // ---------------- P1: FK per point.  Row g < n_left also walks the chain of leftover point g in
+  // the same instruction stream; that point's spheres are then shared by the lanes of its wave.
   for (int h = grp; h < H_main; h += ngroups) {
-    point_fk_chain(c, a, h, lane);
-    for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, rs, b, h, s);
+    const bool extra = n_left > 0 && h == grp && grp < n_left;
+    const int hx = H_main + grp;
+    point_fk_locals(c, h, lane);
+    if (extra) point_fk_locals(c, hx, lane);
+    CUROBO_STAMP(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (extra) {
+      float *const cm[2] = {c.cumul + (size_t)h * L * 12, c.cumul + (size_t)hx * L * 12};
+      const float *const lc[2] = {c.work + (size_t)h * c.ws, c.work + (size_t)hx * c.ws};
+      fk_chain_16_multi<2>(cm, lc, c.parent, c.fixed, L, lane);
+    } else {
+      float *const cm[1] = {c.cumul + (size_t)h * L * 12};
+      const float *const lc[1] = {c.work + (size_t)h * c.ws};
+      fk_chain_16_multi<1>(cm, lc, c.parent, c.fixed, L, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    CUROBO_STAMP(9);
+    for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, b, h, s);
+    CUROBO_STAMP(10);
   }
-  if (n_left) {
-    if (grp < n_left) point_fk_chain(c, a, H_main + grp, lane);
-    __syncthreads();
-    for (int e = tid; e < n_left * S; e += nt) point_sphere(c, a, rs, b, H_main + e / S, e % S);
+  if (n_left > 0 && (tid >> 6) * 4 < n_left) {  // leftover points whose chains this wave walked
+    const int lo = (tid >> 6) * 4, cnt = (n_left - lo < 4 ? n_left - lo : 4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane64; e < cnt * S; e += 64) point_sphere(c, a, b, H_main + lo + e / S, e % S);
   }
+  CUROBO_STAMP(11);
   __syncthreads();
   CUROBO_STAMP(2);
 
@@ -355,8 +494,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int k = k0 + u * kFkLanes;
-          const int i = (int)(int16_t)(ij[u] & 0xffffu), j = (int)(int16_t)(ij[u] >> 16);
-          const float f = pair_penetration(sph[i], sph[j]);
+          const float f = staged_pair_penetration(sph, ij[u]);
           if (k < P && f > best) { best = f; best_k = k; }
         }
       }
@@ -368,23 +506,26 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       }
     }
     const bool stamp_pt = a.prof && lane == 0 && h == (b % H);
-    if (stamp_pt) a.prof[(size_t)b * 8 + 5] = wall_clock64();
+    if (stamp_pt) a.prof[(size_t)b * 16 + 5] = wall_clock64();
     if (a.use_scene) {
+      point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
+      const float *wr = c.wrench + (size_t)h * c.wl;
       for (int s0 = 0; s0 < S; s0 += kFkLanes) {
         const int s = s0 + lane;
         float d = 0.0f;
         f3 g = make_f3(0.f, 0.f, 0.f);
         float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (s < S) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g);
+        const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+        if (mask != 0u) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
         cost_pt += d;
         any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_grad;
       }
     }
-    if (stamp_pt) a.prof[(size_t)b * 8 + 6] = wall_clock64();
+    if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
     cost_pt = row16_sum(cost_pt);
     if (lane == 0) c.cost[h] = cost_pt;
     point_vjp_gather(c, h, any_grad, lane);
-    if (stamp_pt) a.prof[(size_t)b * 8 + 7] = wall_clock64();
+    if (stamp_pt) a.prof[(size_t)b * 16 + 7] = wall_clock64();
   }
   for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
     if (tid == 0) *c.key = 0ull;
@@ -394,8 +535,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       float best = 0.0f;
       int best_k = 0x7fffffff;
       for (int k = tid; k < P; k += nt) {
-        const uint32_t ij = c.pairs[k];
-        const float f = pair_penetration(sph[(int)(int16_t)(ij & 0xffffu)], sph[(int)(int16_t)(ij >> 16)]);
+        const float f = staged_pair_penetration(sph, c.pairs[k]);
         if (f > best) { best = f; best_k = k; }
       }
       if (best > 0.0f) atomicMax(c.key, pair_key(best, best_k));  // integer max: order independent
@@ -492,6 +632,7 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
   CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && padded_horizon >= 2 && n_knots >= 1,
                  "%s: bad dimensions", what);
+  CUROBO_REQUIRE(num_spheres < 4096, "%s: at most 4095 spheres", what);
   CUROBO_REQUIRE(link_chain_len >= 1, "%s: link_chain_len must be >= 1", what);
   CUROBO_REQUIRE(((uintptr_t)pair_locations & 3) == 0, "%s: pair_locations must be 4-byte aligned", what);
   if (batch_size == 0) return CUROBO_HIP_OK;

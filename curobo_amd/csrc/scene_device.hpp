@@ -200,13 +200,15 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
 template <bool VOXEL, int SWEEP, bool STAGED>
 __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs, int env,
                                              bool has_prev, bool has_next, f3 prev_c, f3 next_c, f3 center, float r_adj,
-                                             float eta, float w, float half_w_prev, float half_w_next, float &dsum,
-                                             f3 &gsum) {
+                                             float eta, float w, float half_w_prev, float half_w_next, uint32_t mask,
+                                             float &dsum, f3 &gsum) {
   const int max_n = VOXEL ? sc.max_voxel_grids : sc.max_cuboids;
+  const int bit0 = VOXEL ? sc.max_cuboids : 0;
   const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
   const float thr_c = r_adj + reach;
   const float thr2_c = thr_c * thr_c * 1.00001f;
   for (int o = 0; o < max_n; o++) {
+    if (bit0 + o < 32 && !((mask >> (bit0 + o)) & 1u)) continue;  // culled by the caller's bounding volume
     const ObsRec rec = STAGED ? recs[o] : load_rec_global<VOXEL>(sc, env, o);
     if (rec.meta.x == 0.0f) continue;
     const int flat = env * max_n + o;
@@ -263,13 +265,47 @@ __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const O
   }
 }
 
+// Which of the first 32 obstacles can touch ANY sphere inside a bounding ball (world centre C,
+// radius R >= |c_s - C| + r_s for every contained sphere) whose spheres sweep at most `reach`
+// (>= the half sweep length of each of them)?  A signed distance field is 1-Lipschitz, so
+// sdf(c_s) - r_s >= sdf(C) - R; when that exceeds eta + reach the per-sphere test above would
+// reject the obstacle for every contained sphere, i.e. clearing its bit is result-preserving.
+// Voxel grids: cleared when the ball (+ reach + one voxel) lies outside the grid box, where every
+// sample reads the constant max_distance.  Obstacles >= 32 are never culled.
+template <int KINDS>
+__device__ __forceinline__ uint32_t bounding_ball_obstacle_mask(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs,
+                                                                f3 C, float R, float eta, float reach) {
+  uint32_t mask = 0u;
+  const float thr = (R + eta + reach) * 1.0001f + 4e-6f;
+  const float thr2 = thr * thr * 1.00001f;
+  const int n_c = (KINDS & 1) ? sc.max_cuboids : 0, n_v = (KINDS & 2) ? sc.max_voxel_grids : 0;
+  for (int o = 0; o < n_c + n_v && o < 32; o++) {
+    const ObsRec rec = recs[o < n_c ? o : sc.max_cuboids + (o - n_c)];
+    const int bit = o < n_c ? o : sc.max_cuboids + (o - n_c);
+    if (bit >= 32) break;
+    if (rec.meta.x == 0.0f) continue;
+    const f3 lc = to_local(rec, C);
+    float hx = rec.shape.x, hy = rec.shape.y, hz = rec.shape.z, t2 = thr2;
+    if (o >= n_c) {  // voxel grid: box half extents, one voxel of margin, only when no radius reaches max_distance
+      const float vs = rec.shape.w;
+      hx *= vs * 0.5f; hy *= vs * 0.5f; hz *= vs * 0.5f;
+      const float tv = (R + reach + vs) * 1.0001f + 4e-6f;
+      t2 = (R + eta < sc.voxel_max_distance) ? tv * tv * 1.00001f : 3.0e38f;
+    }
+    const float cx = fmaxf(fabsf(lc.x) - hx, 0.0f), cy = fmaxf(fabsf(lc.y) - hy, 0.0f), cz = fmaxf(fabsf(lc.z) - hz, 0.0f);
+    if (!(cx * cx + cy * cy + cz * cz > t2)) mask |= 1u << bit;
+  }
+  return mask;
+}
+
 // Full scene cost of ONE sphere of one trajectory point: every enabled obstacle (cuboids, then voxel
 // grids, in index order), optional sweep towards the previous / next point and the fused speed
 // metric (wp_speed_metric.py:38-93).  KINDS: bit 0 = cuboids present, bit 1 = voxel grids.
 template <int SWEEP, bool STAGED, int KINDS>
 __device__ __forceinline__ void sphere_scene_cost(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs, int env,
                                                   float4 s, bool has_prev, float4 ps, bool has_next, float4 ns, float eta,
-                                                  float w, bool speed_metric, float speed_dt, float &dsum, f3 &gsum) {
+                                                  float w, bool speed_metric, float speed_dt, float &dsum, f3 &gsum,
+                                                  uint32_t mask = 0xffffffffu) {
   dsum = 0.0f;
   gsum = make_f3(0.f, 0.f, 0.f);
   const f3 center = make_f3(s.x, s.y, s.z);
@@ -283,10 +319,10 @@ __device__ __forceinline__ void sphere_scene_cost(const curobo_hip_scene &sc, co
     }
     if (KINDS & 1)
       obstacle_set<false, SWEEP, STAGED>(sc, recs, env, has_prev, has_next, pp, np, center, r_adj, eta, w, half_w_prev,
-                                         half_w_next, dsum, gsum);
+                                         half_w_next, mask, dsum, gsum);
     if (KINDS & 2)
       obstacle_set<true, SWEEP, STAGED>(sc, recs + sc.max_cuboids, env, has_prev, has_next, pp, np, center, r_adj, eta, w,
-                                        half_w_prev, half_w_next, dsum, gsum);
+                                        half_w_prev, half_w_next, mask, dsum, gsum);
   }
   if (speed_metric && has_prev && has_next && dsum > 0.0f) {
     float dt = speed_dt;

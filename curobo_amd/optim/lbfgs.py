@@ -44,6 +44,9 @@ class LBFGSOptCfg:
     cost_delta_threshold: float = 0.0
     cost_relative_threshold: float = 0.001
     convergence_iteration: int = 10
+    #: line search + two-loop + next candidates in one launch (opt_dim <= 128); False = the three
+    #: drop-in launches of the reference's iteration
+    fused_tail: bool = True
 
 
 class LBFGSOpt:
@@ -105,9 +108,35 @@ class LBFGSOpt:
         if grad.data_ptr() != self.search_gradient.data_ptr():
             self.search_gradient = grad.view(B, N, V)
 
+    @property
+    def _use_fused_tail(self) -> bool:
+        return self.cfg.fused_tail and self.opt_dim <= 128
+
+    def _prepare_search_points(self) -> None:
+        cfg, B, N, V = self.cfg, self.num_problems, self.n_linesearch, self.opt_dim
+        apply_scale = cfg.step_scale != 0.0 and cfg.step_scale != 1.0
+        optimization_hip.prepare_search_points(
+            self.x_set, self.step_scaled, self.exploration_action, self.step_direction, self._step_max,
+            self._alphas, B, N, V, self.action_dim, apply_scale)
+
     def _opt_step(self) -> None:
         cfg, B, N, V = self.cfg, self.num_problems, self.n_linesearch, self.opt_dim
         apply_scale = cfg.step_scale != 0.0 and cfg.step_scale != 1.0
+        if self._use_fused_tail:
+            # x_set / step_scaled of this iteration were produced by the previous tail (or by
+            # reinitialize): rollout, then one launch for everything on the optimiser side
+            self._evaluate_search_points()
+            optimization_hip.launch_lbfgs_iteration_tail(
+                self.best_cost, self.best_action, self.best_iteration, self.current_iteration, self.converged,
+                cfg.convergence_iteration, cfg.cost_delta_threshold, cfg.cost_relative_threshold,
+                self.exploration_cost, self.exploration_action, self.exploration_gradient,
+                self.exploration_idx.view(-1), self.cost, self.action, self.gradient, self.selected_idx.view(-1),
+                self.search_cost, self.x_set, self.search_gradient, self.step_scaled, self._alphas,
+                cfg.line_search_c_1, cfg.line_search_c_2, cfg.line_search_type == "strong_wolfe",
+                cfg.line_search_type == "approx_wolfe", N, V, B, self.step_direction, self.rho, self.y, self.s,
+                self.x_0, self.grad_0, cfg.epsilon, self.history, cfg.stable_mode, self._step_max,
+                self.action_dim, apply_scale)
+            return
         optimization_hip.prepare_search_points(
             self.x_set, self.step_scaled, self.exploration_action, self.step_direction, self._step_max,
             self._alphas, B, N, V, self.action_dim, apply_scale)
@@ -153,6 +182,8 @@ class LBFGSOpt:
         self.step_direction.copy_(-self.cfg.initial_step_scale * self.exploration_gradient)
         self.x_0.copy_(self.exploration_action)
         self.grad_0.copy_(self.exploration_gradient)
+        if self._use_fused_tail:  # candidates of the first iteration (later ones come from the tail)
+            self._prepare_search_points()
 
     def capture(self) -> None:
         """Warm up on a side stream, then record ``inner_iters`` iterations into one hipGraph."""
@@ -174,7 +205,7 @@ class LBFGSOpt:
         return [self.y, self.s, self.rho, self.x_0, self.grad_0, self.step_direction, self.action,
                 self.gradient, self.cost, self.exploration_action, self.exploration_gradient,
                 self.exploration_cost, self.best_action, self.best_cost, self.best_iteration,
-                self.current_iteration, self.converged]
+                self.current_iteration, self.converged, self.x_set, self.step_scaled]
 
     def run_inner(self) -> None:
         """``inner_iters`` iterations (graph replay when enabled)."""

@@ -222,7 +222,7 @@ int curobo_hip_rollout_trajectory_fused_lds_bytes(
     int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int num_obstacles);
 
-/* Development hook: device buffer [batch, 8] (int64) that receives 100 MHz wall-clock stamps at
+/* Development hook: device buffer [batch, 16] (int64) that receives 100 MHz wall-clock stamps at
  * the phase boundaries (start, tables+spline, FK, costs+VJP, end) of every fused launch; NULL
  * (default) turns it off.  Used by tools/profile_fused.py. */
 int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_buffer);
@@ -277,6 +277,27 @@ int curobo_hip_prepare_search_points(
     float *x_set, float *step_direction_out, const float *x, const float *step_direction,
     const float *action_step_max, const float *search_magnitudes, int batchsize, int n_linesearch,
     int opt_dim, int action_dim, int apply_step_scale, curobo_hip_stream_t stream);
+
+/* The optimiser side of one L-BFGS iteration in ONE launch (opt_dim <= 128): launch_line_search,
+ * then launch_lbfgs_step from the chosen exploration point, then prepare_search_points for the
+ * next iteration -- the same arithmetic as the three entry points above run back to back
+ * (reference optim/gradient/lbfgs.py:156-265, gradient_opt_core.py:255-480), with the exploration
+ * point and the new direction handed over in registers.  search_action (the candidate set x_set)
+ * and step_direction_scaled are read by the line search and then overwritten with the next
+ * iteration's candidates / scaled direction.  step_vec receives the unscaled direction. */
+int curobo_hip_launch_lbfgs_iteration_tail(
+    float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
+    uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
+    float cost_relative_threshold, float *exploration_cost, float *exploration_action,
+    float *exploration_gradient, int32_t *exploration_idx, float *selected_cost,
+    float *selected_action, float *selected_gradient, int32_t *selected_idx,
+    const float *search_cost, float *search_action, const float *search_gradient,
+    float *step_direction_scaled, const float *search_magnitudes, float armijo_threshold_c_1,
+    float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
+    int opt_dim, int batchsize, float *step_vec, float *rho_buffer, float *y_buffer,
+    float *s_buffer, float *x_0, float *grad_0, float epsilon, int history_m, int stable_mode,
+    const float *action_step_max, int action_dim, int apply_step_scale,
+    curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- rollout glue
  * Per-trajectory cost sum (reference rollout/metrics.py:233-265 + util/tensor_util.py:104:

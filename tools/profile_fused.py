@@ -47,7 +47,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print(f"fused launch: {e0.elapsed_time(e1) * 1e3 / args.reps:.1f} us for {B} trajectories")
-    prof = torch.zeros(B, 8, dtype=torch.int64, device=dev)
+    prof = torch.zeros(B, 16, dtype=torch.int64, device=dev)
     lib = load()
     lib.curobo_hip_rollout_fused_set_profile_buffer(prof.data_ptr())
     ro.cost_and_gradient(x)
@@ -58,8 +58,11 @@ def main():
     for i, n in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
-    for lo, hi, n in ((2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (6, 7, "  P2: gather")):
+    for lo, hi, n in ((1, 8, "  P1: locals (row 0)"), (8, 9, "  P1: chain x2"), (9, 10, "  P1: spheres"),
+                      (10, 11, "  P1: left spheres"), (11, 2, "  P1: barrier wait"),
+                      (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (6, 7, "  P2: gather")):
         d = t[:, hi] - t[:, lo]
+        d = d[np.abs(d) < 1e6]  # rows whose stamped point was a leftover point carry no inner stamps
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
     first_end = t[:, 4].min()
     print(f"  workgroups started before the first one finished: {(t[:, 0] < first_end).sum()}")
