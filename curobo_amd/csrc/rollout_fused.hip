@@ -70,7 +70,7 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
   f.q = take(H * D);
   f.cumul = take(H * L * 12);
-  f.ws = ((L * 16 > S * 4 ? L * 16 : S * 4) + 3) & ~3;
+  f.ws = ((L * 16 > (S + 1) * 4 ? L * 16 : (S + 1) * 4) + 3) & ~3;  // + one all-NaN sphere behind the last one
   f.work = take(H * f.ws);
   f.wl = L * kWrench;
   f.wrench = take(H * f.wl);
@@ -91,7 +91,7 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.jlinks = take(D * 4);
   f.left = take(S * 4);
   f.key = take(4);
-  f.pairs = take(P);
+  f.pairs = take((P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
   f.recs = take(n_rec * kObsRecFloats);
   f.total = o;
   return f;
@@ -402,6 +402,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       c.pairs[k] = v0 << 4;
       c.pairs[k1] = v1 << 4;
     }
+    for (int k = P + tid; k < ((P + 63) & ~63); k += nt) c.pairs[k] = (uint32_t)(S * 16) | ((uint32_t)(S * 16) << 16);
   }
   if (a.use_scene)
     for (int o = rot(nwaves - 1); o < n_rec; o += nt)
@@ -463,6 +464,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     __builtin_amdgcn_wave_barrier();
     CUROBO_STAMP(9);
     for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, b, h, s);
+    if (lane == 0) reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
     CUROBO_STAMP(10);
   }
   if (n_left > 0 && (tid >> 6) * 4 < n_left) {  // leftover points whose chains this wave walked
@@ -470,6 +472,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int e = lane64; e < cnt * S; e += 64) point_sphere(c, a, b, H_main + lo + e / S, e % S);
+    if (lane64 < cnt) reinterpret_cast<float4 *>(c.work + (size_t)(H_main + lo + lane64) * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
   }
   CUROBO_STAMP(11);
   __syncthreads();
@@ -481,25 +484,40 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     float cost_pt = 0.0f;
     bool any_grad = false;  // uniform over the 16-lane row
     if (a.use_self) {       // reference self_collision_kernel.cuh:19-111
+      // One pass over the padded pair list (no bounds checks; disabled / padding spheres are NaN and
+      // lose every max).  Per pair only a v_max; the arg-max is tracked per group of U pairs (one
+      // compare per group) and resolved inside the winning group afterwards.
       constexpr int U = 4;
+      const int P_pad = (P + 63) & ~63;
       float best = 0.0f;
-      int best_k = 0x7fffffff;
-      for (int k0 = lane; k0 < P; k0 += kFkLanes * U) {
+      int best_k0 = 0x7fffffff;
+      for (int k0 = lane; k0 < P_pad; k0 += kFkLanes * U) {
         uint32_t ij[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int k = k0 + u * kFkLanes;
-          ij[u] = c.pairs[k < P ? k : 0];
-        }
+        for (int u = 0; u < U; u++) ij[u] = c.pairs[k0 + u * kFkLanes];
+        float gmax = staged_pair_penetration(sph, ij[0]);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int k = k0 + u * kFkLanes;
-          const float f = staged_pair_penetration(sph, ij[u]);
-          if (k < P && f > best) { best = f; best_k = k; }
-        }
+        for (int u = 1; u < U; u++) gmax = fmaxf(gmax, staged_pair_penetration(sph, ij[u]));
+        if (gmax > best) { best = gmax; best_k0 = k0; }
       }
-      const float m = row16_max(best);
-      const int kmin = row16_min((best == m && best > 0.0f) ? best_k : 0x7fffffff);
+      float m = row16_max(best);
+      int kmin = 0x7fffffff;
+      if (m > 0.0f) {  // rows in self collision: lowest pair index of the largest penetration
+        int best_k = 0x7fffffff;
+        if (best == m) {
+          float f_best = 0.0f;
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const float f = staged_pair_penetration(sph, c.pairs[best_k0 + u * kFkLanes]);
+            if (f > f_best) { f_best = f; best_k = best_k0 + u * kFkLanes; }
+          }
+          best = f_best;
+        } else {
+          best = 0.0f;
+        }
+        m = row16_max(best);
+        kmin = row16_min((best == m && best > 0.0f) ? best_k : 0x7fffffff);
+      }
       if (kmin != 0x7fffffff && m > 0.0f) {
         any_grad = true;
         if (lane == 0) cost_pt += self_pair_apply(c, h, m, kmin);
