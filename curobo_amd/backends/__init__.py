@@ -20,4 +20,5 @@ def get_backend():
         "geometry": geometry,
         "collision": collision,
         "cost": cost,
+        "rollout": rollout,
     }
