@@ -97,12 +97,14 @@ struct BsBwdArgs {
 
 // one (b, h, d) sample of the spline and its first three derivatives -> o[4]
 // (reference bspline_interpolation.cuh:95-297); returns the interpolation dt of the trajectory
+// (ph = padded horizon of THIS trajectory and interpolated_dt are explicit so that the single-dt
+// re-interpolation, bspline_kernel.cuh:221-270, shares the code)
 template <int DEG>
-__device__ __forceinline__ float bspline_sample(const BsFwdArgs &a, int b, int h, int d, float *o) {
+__device__ __forceinline__ float bspline_sample_at(const BsFwdArgs &a, int b, int h, int d, int ph, float interpolated_dt,
+                                                   float *o) {
   constexpr int SUP = DEG + 1;
-  const int dof = a.dof, ph = a.padded_horizon;
+  const int dof = a.dof;
   const int bo = a.start_idx[b], go = a.goal_idx[b];
-  const float interpolated_dt = a.traj_dt[go];
   const bool implicit_goal = a.use_implicit_goal[go] != 0;
   const int horizon = ph - 1;
   const int padded_n_knots = a.n_knots + SUP;
@@ -179,6 +181,11 @@ __device__ __forceinline__ float bspline_sample(const BsFwdArgs &a, int b, int h
   for (int i = 0; i < SUP; i++) o[3] += knots[i] * bs[i];
   o[3] = o[3] / dt3;
   return interpolated_dt;
+}
+
+template <int DEG>
+__device__ __forceinline__ float bspline_sample(const BsFwdArgs &a, int b, int h, int d, float *o) {
+  return bspline_sample_at<DEG>(a, b, h, d, a.padded_horizon, a.traj_dt[a.goal_idx[b]], o);
 }
 
 // gradient of one knot (k) of one (trajectory, dof): sum over the interpolation steps of the

@@ -248,6 +248,48 @@ int curobo_hip_launch_bspline_interpolation_backward_kernel(
     int padded_horizon, int dof, int n_knots, int bspline_degree, int use_direct_polynomial,
     curobo_hip_stream_t stream);
 
+/* reference: cuda_core_backend/trajectory.py:207-306, kernel bspline_kernel.cuh:221-270.
+ * One interpolation_dt[1] for all trajectories, interpolation_horizon[b] per trajectory; outputs
+ * are [batch, max_out_tsteps, dof]; points past a trajectory's horizon repeat its last sample.
+ * knot_dt is accepted and ignored, as in the reference kernel. */
+int curobo_hip_launch_bspline_interpolation_single_dt_kernel(
+    float *out_position, float *out_velocity, float *out_acceleration, float *out_jerk,
+    float *out_dt, const float *knots, const float *knot_dt, const float *start_position,
+    const float *start_velocity, const float *start_acceleration, const float *start_jerk,
+    const float *goal_position, const float *goal_velocity, const float *goal_acceleration,
+    const float *goal_jerk, const int32_t *start_idx, const int32_t *goal_idx,
+    const float *interpolation_dt, const uint8_t *use_implicit_goal_state,
+    const int32_t *interpolation_horizon, int batch_size, int max_out_tsteps, int dof,
+    int n_knots, int bspline_degree, curobo_hip_stream_t stream);
+
+/* Legacy control spaces (reference cuda_core_backend/trajectory.py:309-556; kernels
+ * kernels/trajectory/legacy/differentiation_position_kernel.cuh:15-370 with use_stencil = true,
+ * legacy/integration_acceleration_kernel.cuh:8-135).
+ * POSITION: u_position [batch, horizon-4, dof] -> position/velocity/acceleration/jerk
+ * [batch, horizon, dof] by five-point stencils over the start-extrapolated, goal-replicated
+ * position sequence; horizon >= 9.  goal_velocity / goal_acceleration are accepted and unused.
+ * ACCELERATION: u_acc [batch, horizon, dof], traj_dt [horizon] (indexed by step); use_rk2 selects
+ * nothing (both reference kernels run the same recursion). */
+int curobo_hip_launch_differentiation_position_forward_kernel(
+    float *out_position, float *out_velocity, float *out_acceleration, float *out_jerk,
+    float *out_dt, const float *u_position, const float *start_position,
+    const float *start_velocity, const float *start_acceleration, const float *goal_position,
+    const float *goal_velocity, const float *goal_acceleration, const int32_t *start_idx,
+    const int32_t *goal_idx, const float *traj_dt, const uint8_t *use_implicit_goal_state,
+    int batch_size, int horizon, int dof, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_differentiation_position_backward_kernel(
+    float *out_grad_position, const float *grad_position, const float *grad_velocity,
+    const float *grad_acceleration, const float *grad_jerk, const float *traj_dt,
+    const int32_t *dt_idx, const uint8_t *use_implicit_goal_state, int batch_size, int horizon,
+    int dof, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_integration_acceleration_kernel(
+    float *out_position, float *out_velocity, float *out_acceleration, float *out_jerk,
+    const float *u_acc, const float *start_position, const float *start_velocity,
+    const float *start_acceleration, const int32_t *start_idx, const float *traj_dt,
+    int batch_size, int horizon, int dof, int use_rk2, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- optimization
  * reference: cuda_core_backend/optimization.py:27-260, pybind/optimization_bindings.cpp:14-75
  * kernels:   kernels/optimization/lbfgs/lbfgs_step_kernel.cuh:18-199,

@@ -960,6 +960,38 @@ ORC_API void orc_bspline_forward(float *out_pos, float *out_vel, float *out_acc,
   }
 }
 
+/* interpolate_bspline_single_dt_kernel: bspline_kernel.cuh:221-270 (one dt, per-trajectory horizon,
+ * output stride max_out; h runs over max_out and clamps to the last knot past the horizon) */
+ORC_API void orc_bspline_single_dt(float *out_pos, float *out_vel, float *out_acc, float *out_jerk,
+                                   float *out_dt, const float *knots, const float *start_pos,
+                                   const float *start_vel, const float *start_acc,
+                                   const float *start_jerk, const float *goal_pos,
+                                   const float *goal_vel, const float *goal_acc,
+                                   const float *goal_jerk, const int32_t *start_idx,
+                                   const int32_t *goal_idx, const float *interpolation_dt,
+                                   const uint8_t *use_implicit_goal_state,
+                                   const int32_t *interpolation_horizon, int batch, int max_out,
+                                   int dof, int n_knots, int degree) {
+  const float *s4[4] = {start_pos, start_vel, start_acc, start_jerk};
+  const float *g4[4] = {goal_pos, goal_vel, goal_acc, goal_jerk};
+  const float dt = interpolation_dt[0];
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    const int bo = start_idx[b], go = goal_idx[b];
+    int nh = interpolation_horizon[b];
+    if (nh > max_out - 1) nh = max_out - 1;
+    for (int h = 0; h < max_out; h++)
+      for (int d = 0; d < dof; d++) {
+        float o[4];
+        orc_bspline_sample(o, knots, s4, g4, dt, use_implicit_goal_state[go], nh + 1, dof, b, h, d, bo,
+                           go, n_knots, degree);
+        const size_t a = ((size_t)b * max_out + h) * dof + d;
+        out_pos[a] = o[0]; out_vel[a] = o[1]; out_acc[a] = o[2]; out_jerk[a] = o[3];
+      }
+    out_dt[b] = dt;
+  }
+}
+
 /* bspline_backward_kernel: bspline_kernel.cuh:332-380 with load_gradients
  * (bspline_gradient_util.cuh:141-227) and compute_backward_grad_from_basis
  * (bspline_context.cuh:133-170).  grad_* are [batch, padded_horizon, dof]. */
@@ -1019,6 +1051,127 @@ ORC_API void orc_bspline_backward(float *out_grad_knots, const float *grad_pos,
         out_grad_knots[((size_t)b * n_knots + k) * dof + d] = total;
       }
   }
+}
+
+
+/* ------------------------------------------------------------------------------------------
+ * A5b. Legacy position-clique transition (differentiation_position_kernel.cuh) and acceleration
+ *      integration (integration_acceleration_kernel.cuh).
+ *
+ * Forward (compute_central_difference :15-232, use_stencil = true as the launcher fixes it,
+ * cuda_core_backend/trajectory.py:343): the branch table there is a 5-point window sliding over
+ * ONE extended position sequence
+ *   P = [e(-3), e(-2), e(-1), x0, u_0 .. u_{A-1}, u_{A-1} x4],   A = horizon - 4,
+ * with e(.) the constant-acceleration back-extrapolation of the start state and u_{A-1} replaced
+ * by the goal position when use_implicit_goal_state; window of point h = P[h .. h+4].
+ * (identical to the reference's branches for horizon >= 9, where they do not overlap) */
+static float orc_clique_P(int j, const float *u, int A, int dof, int d, float x0, float v0, float a0,
+                          float dt, int use_goal, float goal) {
+  const float fixed_jerk = 0.0f;
+  if (j == 0) return (3.0f / 2) * (-1 * a0 * (dt * dt) - (dt * dt * dt) * fixed_jerk) - 3.0f * dt * v0 + x0;
+  if (j == 1) return -2.0f * a0 * dt * dt - (4.0f / 3) * dt * dt * dt * fixed_jerk - 2.0f * dt * v0 + x0;
+  if (j == 2) return -(3.0f / 2) * a0 * dt * dt - (7.0f / 6) * dt * dt * dt * fixed_jerk - dt * v0 + x0;
+  if (j == 3) return x0;
+  int i = j - 4;
+  if (i >= A - 1) return use_goal ? goal : u[(size_t)(A - 1) * dof + d];
+  return u[(size_t)i * dof + d];
+}
+
+ORC_API void orc_differentiation_position_forward(
+    float *out_pos, float *out_vel, float *out_acc, float *out_jerk, float *out_dt, const float *u_position,
+    const float *start_pos, const float *start_vel, const float *start_acc, const float *goal_pos,
+    const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt,
+    const uint8_t *use_implicit_goal_state, int batch, int horizon, int dof) {
+  const int A = horizon - 4;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    const int bo = start_idx[b], go = goal_idx[b];
+    const float dt = traj_dt[go], dt_inv = 1.0f / dt;
+    const int use_goal = use_implicit_goal_state[go];
+    const float *u = u_position + (size_t)b * A * dof;
+    for (int h = 0; h < horizon; h++)
+      for (int d = 0; d < dof; d++) {
+        const float x0 = start_pos[bo * dof + d], v0 = start_vel[bo * dof + d], a0 = start_acc[bo * dof + d];
+        const float goal = use_goal ? goal_pos[go * dof + d] : 0.0f;
+        float p[5];
+        for (int i = 0; i < 5; i++) p[i] = orc_clique_P(h + i, u, A, dof, d, x0, v0, a0, dt, use_goal, goal);
+        const size_t a = ((size_t)b * horizon + h) * dof + d;
+        out_pos[a] = p[2];
+        out_vel[a] = ((0.083333333f) * p[0] - (0.666666667f) * p[1] + (0.666666667f) * p[3] + (-0.083333333f) * p[4]) * dt_inv;
+        out_acc[a] = ((-0.083333333f) * p[0] + (1.333333333f) * p[1] + (-2.5f) * p[2] + (1.333333333f) * p[3] +
+                      (-0.083333333f) * p[4]) * dt_inv * dt_inv;
+        out_jerk[a] = ((-(1.0f / 2.0f)) * p[0] + p[1] - p[3] + ((1.0f / 2.0f)) * p[4]) * (dt_inv * dt_inv * dt_inv);
+      }
+    out_dt[b] = dt;
+  }
+}
+
+/* position_clique_loop_idx_bwd_kernel :234-370 (stencil variant) */
+ORC_API void orc_differentiation_position_backward(
+    float *out_grad, const float *grad_pos, const float *grad_vel, const float *grad_acc, const float *grad_jerk,
+    const float *traj_dt, const int32_t *dt_idx, const uint8_t *use_implicit_goal_state, int batch, int horizon,
+    int dof) {
+  const int A = horizon - 4;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    const int dto = dt_idx[b];
+    const float dt_inv = 1.0f / traj_dt[dto];
+    const int use_goal = use_implicit_goal_state[dto];
+    const float i1 = dt_inv, i2 = dt_inv * dt_inv, i3 = dt_inv * dt_inv * dt_inv;
+    for (int ah = 0; ah < A; ah++)
+      for (int d = 0; d < dof; d++) {
+        const size_t base = (size_t)b * horizon * dof + d;
+        float gv[5], ga[5], gj[5];
+        for (int i = 0; i < 5; i++) {
+          gv[i] = grad_vel[base + (size_t)(ah + i) * dof];
+          ga[i] = grad_acc[base + (size_t)(ah + i) * dof];
+          gj[i] = grad_jerk[base + (size_t)(ah + i) * dof];
+        }
+        float g = grad_pos[base + (size_t)(ah + 2) * dof];
+        if (ah == A - 1) {
+          if (use_goal) g = 0.0f;
+          else g += grad_pos[base + (size_t)(ah + 3) * dof] + grad_pos[base + (size_t)(ah + 4) * dof];
+        }
+        float o = g;
+        if (ah < A - 1) {
+          o += (float)((-0.083333333 * gv[0] + 0.666666667 * gv[1] - 0.666666667 * gv[3] + 0.083333333 * gv[4]) * i1);
+          o += (float)((-0.083333333 * ga[0] + 1.333333333 * ga[1] + (-2.5) * ga[2] + 1.333333333 * ga[3] + (-0.083333333) * ga[4]) * i2);
+          o += (0.5f * gj[0] - 1.0f * gj[1] + 1.0f * gj[3] - 0.5f * gj[4]) * i3;
+        } else if (use_goal) {
+          o = (float)(-0.083333333 * gv[0] * i1 + -0.083333333 * ga[0] * i2 + 0.5 * gj[0] * i3);
+        } else {
+          o += (float)((-0.083333333 * gv[0] + 0.583333334 * gv[1] + 0.583333334 * gv[2] - 0.083333333 * gv[3]) * i1);
+          o += (float)((-0.083333333 * ga[0] + 1.25 * ga[1] + (-1.25) * ga[2] + 0.083333333 * ga[3]) * i2);
+          o += (float)((0.5 * gj[0] - 0.5 * gj[1] - 0.5 * gj[2] + 0.5 * gj[3]) * i3);
+        }
+        out_grad[((size_t)b * A + ah) * dof + d] = o;
+      }
+  }
+}
+
+/* acceleration_loop_idx(_rk2)_kernel: integration_acceleration_kernel.cuh:8-135 (both variants
+ * run the same semi-implicit Euler recursion); traj_dt is indexed by the step h */
+ORC_API void orc_integration_acceleration(float *out_pos, float *out_vel, float *out_acc, float *out_jerk,
+                                          const float *u_acc, const float *start_pos, const float *start_vel,
+                                          const float *start_acc, const int32_t *start_idx, const float *traj_dt,
+                                          int batch, int horizon, int dof) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++)
+    for (int d = 0; d < dof; d++) {
+      const int bo = start_idx[b];
+      float pos = start_pos[bo * dof + d], vel = start_vel[bo * dof + d], acc = start_acc[bo * dof + d];
+      size_t a = (size_t)b * horizon * dof + d;
+      out_pos[a] = pos; out_vel[a] = vel; out_acc[a] = acc; out_jerk[a] = 0.0f;
+      for (int h = 1; h < horizon; h++) {
+        const float dt = traj_dt[h];
+        const float acc_n = u_acc[(size_t)b * horizon * dof + (size_t)(h - 1) * dof + d];
+        vel = vel + acc_n * dt;
+        pos = pos + vel * dt;
+        a = ((size_t)b * horizon + h) * dof + d;
+        out_acc[a] = acc_n; out_vel[a] = vel; out_pos[a] = pos; out_jerk[a] = (acc_n - acc) / dt;
+        acc = acc_n;
+      }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

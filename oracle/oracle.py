@@ -69,6 +69,10 @@ class Oracle:
             "orc_scene_collision",
             "orc_bspline_forward",
             "orc_bspline_backward",
+            "orc_bspline_single_dt",
+            "orc_differentiation_position_forward",
+            "orc_differentiation_position_backward",
+            "orc_integration_acceleration",
             "orc_lbfgs_step",
             "orc_line_search",
             "orc_trajectory_cost_sum",
@@ -306,6 +310,25 @@ class Oracle:
         return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2],
                 "jerk": outs[3], "dt": out_dt}
 
+    def bspline_single_dt(self, knots, start, goal, start_idx, goal_idx, interpolation_dt, use_implicit_goal,
+                          interpolation_horizon, max_out_tsteps: int, degree: int = 3):
+        """reference launch_bspline_interpolation_single_dt_kernel: one dt, per-trajectory horizons."""
+        u = _f32(knots)
+        b, n_knots, dof = u.shape
+        outs = [np.zeros((b, max_out_tsteps, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros((b,), np.float32)
+        keys = ("position", "velocity", "acceleration", "jerk")
+        s = [_f32(start[k]) for k in keys]
+        g = [_f32(goal[k]) for k in keys]
+        self.lib.orc_bspline_single_dt(
+            *[_ptr(o) for o in outs], _ptr(out_dt), _ptr(u), *[_ptr(x) for x in s], *[_ptr(x) for x in g],
+            _ptr(np.ascontiguousarray(start_idx, np.int32)), _ptr(np.ascontiguousarray(goal_idx, np.int32)),
+            _ptr(_f32(interpolation_dt)), _ptr(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+            _ptr(np.ascontiguousarray(interpolation_horizon, np.int32)),
+            C.c_int(b), C.c_int(max_out_tsteps), C.c_int(dof), C.c_int(n_knots), C.c_int(degree),
+        )
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3], "dt": out_dt}
+
     def bspline_backward(self, grad_p, grad_v, grad_a, grad_j, traj_dt, dt_idx, use_implicit_goal,
                          n_knots: int, degree: int = 3):
         gp = _f32(grad_p)
@@ -318,6 +341,42 @@ class Oracle:
             C.c_int(b), C.c_int(ph), C.c_int(dof), C.c_int(n_knots), C.c_int(degree),
         )
         return out
+
+    # ------------------------------------------------------------------ legacy transitions
+    def differentiation_position_forward(self, u_position, start, goal_position, start_idx, goal_idx, traj_dt,
+                                         use_implicit_goal):
+        """reference launch_differentiation_position_forward_kernel; u [b, horizon-4, dof] -> 4 x [b, horizon, dof]."""
+        u = _f32(u_position)
+        b, ah, dof = u.shape
+        horizon = ah + 4
+        outs = [np.zeros((b, horizon, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros((b,), np.float32)
+        self.lib.orc_differentiation_position_forward(
+            *[_ptr(o) for o in outs], _ptr(out_dt), _ptr(u), _ptr(_f32(start["position"])), _ptr(_f32(start["velocity"])),
+            _ptr(_f32(start["acceleration"])), _ptr(_f32(goal_position)), _ptr(np.ascontiguousarray(start_idx, np.int32)),
+            _ptr(np.ascontiguousarray(goal_idx, np.int32)), _ptr(_f32(traj_dt)),
+            _ptr(np.ascontiguousarray(use_implicit_goal, np.uint8)), C.c_int(b), C.c_int(horizon), C.c_int(dof))
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3], "dt": out_dt}
+
+    def differentiation_position_backward(self, grad_p, grad_v, grad_a, grad_j, traj_dt, dt_idx, use_implicit_goal):
+        gp = _f32(grad_p)
+        b, horizon, dof = gp.shape
+        out = np.zeros((b, horizon - 4, dof), np.float32)
+        self.lib.orc_differentiation_position_backward(
+            _ptr(out), _ptr(gp), _ptr(_f32(grad_v)), _ptr(_f32(grad_a)), _ptr(_f32(grad_j)), _ptr(_f32(traj_dt)),
+            _ptr(np.ascontiguousarray(dt_idx, np.int32)), _ptr(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+            C.c_int(b), C.c_int(horizon), C.c_int(dof))
+        return out
+
+    def integration_acceleration(self, u_acc, start, start_idx, traj_dt):
+        u = _f32(u_acc)
+        b, horizon, dof = u.shape
+        outs = [np.zeros((b, horizon, dof), np.float32) for _ in range(4)]
+        self.lib.orc_integration_acceleration(
+            *[_ptr(o) for o in outs], _ptr(u), _ptr(_f32(start["position"])), _ptr(_f32(start["velocity"])),
+            _ptr(_f32(start["acceleration"])), _ptr(np.ascontiguousarray(start_idx, np.int32)), _ptr(_f32(traj_dt)),
+            C.c_int(b), C.c_int(horizon), C.c_int(dof))
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3]}
 
     # ------------------------------------------------------------------ optimiser step
     def lbfgs_step(self, step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0,

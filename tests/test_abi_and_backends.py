@@ -48,7 +48,9 @@ EXPECTED = {
     "kinematics": ["launch_kinematics_forward", "launch_kinematics_forward_spheres",
                    "launch_kinematics_forward_spheres_jacobian", "launch_kinematics_backward"],
     "geometry": ["self_collision_distance"],
-    "trajectory": ["launch_bspline_interpolation_forward_kernel", "launch_bspline_interpolation_backward_kernel"],
+    "trajectory": ["launch_bspline_interpolation_forward_kernel", "launch_bspline_interpolation_backward_kernel",
+                   "launch_bspline_interpolation_single_dt_kernel", "launch_differentiation_position_forward_kernel",
+                   "launch_differentiation_position_backward_kernel", "launch_integration_acceleration_kernel"],
     "optimization": ["launch_line_search", "launch_lbfgs_step"],
 }
 

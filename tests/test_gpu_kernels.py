@@ -343,3 +343,89 @@ def test_trajectory_cost_sum(oracle, device):
     Cn.trajectory_cost_sum(out, torch.as_tensor(se, device=device), torch.as_tensor(sc, device=device), b, h, S)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), oracle.trajectory_cost_sum(se, sc), rtol=2e-6)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_bspline_single_dt(degree, oracle, device):
+    from curobo_amd.backends import trajectory as Tr
+
+    rng = np.random.default_rng(40 + degree)
+    b, nk, dof, max_out = 9, 12, 7, 150
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda n: {k: rng.normal(size=(n, dof)).astype(np.float32) * 0.3  # noqa: E731
+                    for k in ("position", "velocity", "acceleration", "jerk")}
+    start, goal = mk(3), mk(2)
+    sidx = rng.integers(0, 3, size=b).astype(np.int32)
+    gidx = rng.integers(0, 2, size=b).astype(np.int32)
+    horizons = rng.integers(20, 200, size=b).astype(np.int32)  # some beyond max_out: clamped
+    dt = np.array([0.02], np.float32)
+    imp = np.array([0, 1], np.uint8)
+    ref = oracle.bspline_single_dt(u, start, goal, sidx, gidx, dt, imp, horizons, max_out, degree)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    outs = [torch.zeros(b, max_out, dof, device=device) for _ in range(4)]
+    out_dt = torch.zeros(b, device=device)
+    keys = ("position", "velocity", "acceleration", "jerk")
+    Tr.launch_bspline_interpolation_single_dt_kernel(
+        *outs, out_dt, t(u), torch.zeros(b, nk - 1, device=device), *[t(start[k]) for k in keys],
+        *[t(goal[k]) for k in keys], t(sidx), t(gidx), t(dt), t(imp), t(horizons), b, max_out, dof, nk, degree)
+    torch.cuda.synchronize()
+    for o, k in zip(outs, keys):
+        scale = max(1.0, np.abs(ref[k]).max())
+        np.testing.assert_allclose(o.cpu().numpy(), ref[k], atol=2e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), ref["dt"])
+
+
+@pytest.mark.parametrize("use_goal", [0, 1])
+def test_legacy_position_transition(use_goal, oracle, device):
+    from curobo_amd.backends import trajectory as Tr
+
+    rng = np.random.default_rng(50 + use_goal)
+    b, horizon, dof = 11, 30, 7
+    u = rng.normal(size=(b, horizon - 4, dof)).astype(np.float32)
+    start = {k: rng.normal(size=(3, dof)).astype(np.float32) * 0.3 for k in ("position", "velocity", "acceleration")}
+    goal = rng.normal(size=(2, dof)).astype(np.float32)
+    sidx = rng.integers(0, 3, size=b).astype(np.int32)
+    gidx = rng.integers(0, 2, size=b).astype(np.int32)
+    dt = np.array([0.05, 0.08], np.float32)
+    imp = np.array([use_goal, use_goal], np.uint8)
+    ref = oracle.differentiation_position_forward(u, start, goal, sidx, gidx, dt, imp)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    outs = [torch.zeros(b, horizon, dof, device=device) for _ in range(4)]
+    out_dt = torch.zeros(b, device=device)
+    Tr.launch_differentiation_position_forward_kernel(
+        *outs, out_dt, t(u), t(start["position"]), t(start["velocity"]), t(start["acceleration"]), t(goal),
+        torch.zeros(2, dof, device=device), torch.zeros(2, dof, device=device), t(sidx), t(gidx), t(dt), t(imp),
+        b, horizon, dof)
+    torch.cuda.synchronize()
+    for o, k in zip(outs, ("position", "velocity", "acceleration", "jerk")):
+        scale = max(1.0, np.abs(ref[k]).max())
+        np.testing.assert_allclose(o.cpu().numpy(), ref[k], atol=2e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), ref["dt"])
+    g = [rng.normal(size=(b, horizon, dof)).astype(np.float32) for _ in range(4)]
+    refb = oracle.differentiation_position_backward(*g, dt, gidx, imp)
+    og = torch.zeros(b, horizon - 4, dof, device=device)
+    Tr.launch_differentiation_position_backward_kernel(og, *[t(x) for x in g], t(dt), t(gidx), t(imp), b, horizon, dof)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(og.cpu().numpy(), refb, rtol=2e-5, atol=2e-5 * np.abs(refb).max())
+    with pytest.raises(ValueError, match="horizon"):
+        Tr.launch_differentiation_position_backward_kernel(og, *[t(x) for x in g], t(dt), t(gidx), t(imp), b, 8, dof)
+
+
+def test_legacy_acceleration_integration(oracle, device):
+    from curobo_amd.backends import trajectory as Tr
+
+    rng = np.random.default_rng(60)
+    b, horizon, dof = 13, 41, 6
+    u = rng.normal(size=(b, horizon, dof)).astype(np.float32)
+    start = {k: rng.normal(size=(2, dof)).astype(np.float32) for k in ("position", "velocity", "acceleration")}
+    sidx = rng.integers(0, 2, size=b).astype(np.int32)
+    dt = rng.uniform(0.01, 0.1, size=horizon).astype(np.float32)
+    ref = oracle.integration_acceleration(u, start, sidx, dt)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    outs = [torch.zeros(b, horizon, dof, device=device) for _ in range(4)]
+    Tr.launch_integration_acceleration_kernel(*outs, t(u), t(start["position"]), t(start["velocity"]),
+                                              t(start["acceleration"]), t(sidx), t(dt), b, horizon, dof)
+    torch.cuda.synchronize()
+    for o, k in zip(outs, ("position", "velocity", "acceleration", "jerk")):
+        scale = max(1.0, np.abs(ref[k]).max())
+        np.testing.assert_allclose(o.cpu().numpy(), ref[k], atol=1e-5 * scale, rtol=1e-5)

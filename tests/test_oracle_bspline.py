@@ -92,3 +92,34 @@ def test_backward_is_the_transpose_of_forward(degree, implicit, oracle):
     assert lhs == pytest.approx(rhs, rel=2e-4, abs=1e-3)
     if implicit:  # last knot is ignored with an implicit goal state: zero gradient
         assert not gu[:, -1].any()
+
+
+@pytest.mark.parametrize("degree", [3, 5])
+def test_single_dt_reinterpolation_matches_forward_per_trajectory(degree, oracle):
+    """The single-dt kernel is the forward interpolation with interpolation_dt[0] and a
+    per-trajectory horizon (bspline_kernel.cuh:221-270): every trajectory must equal the plain
+    forward kernel run at its own horizon, and points past its horizon repeat the last sample."""
+    rng = np.random.default_rng(degree)
+    b, nk, dof, max_out = 4, 8, 3, 80
+    sup = degree + 1
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda n: {k: (rng.normal(size=(n, dof)) * 0.2).astype(np.float32)  # noqa: E731
+                    for k in ("position", "velocity", "acceleration", "jerk")}
+    start, goal = mk(2), mk(2)
+    sidx = np.array([0, 1, 1, 0], np.int32)
+    gidx = np.array([1, 0, 1, 0], np.int32)
+    horizons = np.array([(nk + sup) * 2, (nk + sup) * 4, (nk + sup) * 3, 500], np.int32)  # last one is clamped
+    dt = np.array([0.03], np.float32)
+    imp = np.zeros(2, np.uint8)
+    out = oracle.bspline_single_dt(u, start, goal, sidx, gidx, dt, imp, horizons, max_out, degree)
+    np.testing.assert_allclose(out["dt"], 0.03)
+    for i in range(b):
+        nh = min(int(horizons[i]), max_out - 1)
+        ref = oracle.bspline_forward(u[i:i + 1], start, goal, sidx[i:i + 1], gidx[i:i + 1], np.array([0.03, 0.03], np.float32),
+                                     imp, nh + 1, degree)
+        for k in ("position", "velocity", "acceleration", "jerk"):
+            np.testing.assert_array_equal(out[k][i, :nh + 1], ref[k][0])
+            if nh + 1 < max_out:  # clamped tail = the sample at t = 1 of the last knot interval
+                np.testing.assert_array_equal(out[k][i, nh + 1:], np.broadcast_to(out[k][i, nh + 1], out[k][i, nh + 1:].shape))
+        if nh + 1 < max_out and (nh % (nk + sup)) == 0:
+            np.testing.assert_allclose(out["position"][i, nh + 1], out["position"][i, nh], atol=1e-5)
