@@ -1,0 +1,101 @@
+"""HIP backend for the RNEA inverse-dynamics kernels.
+
+Drop-in for ``curobo/_src/curobolib/backends/cuda_core_backend/dynamics.py`` (same function names
+and positional argument order: ``launch_rnea_forward`` :24-131, ``launch_rnea_backward`` :134-260).
+``forward_cache`` is the reference's opaque per-element scratch ``[batch, num_links*20]``; only its
+size is part of the contract, the HIP kernels use a ``[link][20][batch]`` layout inside it.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .._lib import check, current_stream, load, ptr
+
+_workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, n_floats: int) -> torch.Tensor:
+    """Adjoint scratch of the backward kernel (f_bar, a_bar, v_bar per link and element).  The
+    reference keeps these in shared memory; here they are a per-device tensor that only ever grows.
+    The first backward call at a new size allocates, so warm up once before hipGraph capture."""
+    key = (str(device), 0)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < n_floats:
+        ws = torch.empty(n_floats, device=device, dtype=torch.float32)
+        _workspaces[key] = ws
+    return ws
+
+
+def launch_rnea_forward(
+    tau: torch.Tensor,
+    q: torch.Tensor,
+    qd: torch.Tensor,
+    qdd: torch.Tensor,
+    fixed_transforms: torch.Tensor,
+    link_masses_com: torch.Tensor,
+    link_inertias: torch.Tensor,
+    joint_map_type: torch.Tensor,
+    joint_map: torch.Tensor,
+    link_map: torch.Tensor,
+    joint_offset_map: torch.Tensor,
+    gravity: torch.Tensor,
+    level_starts: torch.Tensor,
+    level_links: torch.Tensor,
+    forward_cache: torch.Tensor,
+    batch_size: int,
+    num_links: int,
+    num_dof: int,
+    n_levels: int,
+    threads_per_batch: int = 1,
+    f_ext: Optional[torch.Tensor] = None,
+):
+    if forward_cache.numel() < batch_size * num_links * 20:
+        raise ValueError("forward_cache must hold batch_size * num_links * 20 floats")
+    check(load().curobo_hip_launch_rnea_forward(
+        ptr(tau), ptr(q), ptr(qd), ptr(qdd), ptr(fixed_transforms), ptr(link_masses_com), ptr(link_inertias),
+        ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(joint_offset_map), ptr(gravity), ptr(level_starts),
+        ptr(level_links), ptr(forward_cache), batch_size, num_links, num_dof, n_levels, threads_per_batch,
+        ptr(f_ext), current_stream(tau),
+    ))
+
+
+def launch_rnea_backward(
+    grad_q: torch.Tensor,
+    grad_qd: torch.Tensor,
+    grad_qdd: torch.Tensor,
+    grad_tau: torch.Tensor,
+    q: torch.Tensor,
+    qd: torch.Tensor,
+    fixed_transforms: torch.Tensor,
+    link_masses_com: torch.Tensor,
+    link_inertias: torch.Tensor,
+    joint_map_type: torch.Tensor,
+    joint_map: torch.Tensor,
+    link_map: torch.Tensor,
+    joint_offset_map: torch.Tensor,
+    gravity: torch.Tensor,
+    level_starts: torch.Tensor,
+    level_links: torch.Tensor,
+    forward_cache: torch.Tensor,
+    batch_size: int,
+    num_links: int,
+    num_dof: int,
+    n_levels: int,
+    threads_per_batch: int = 1,
+    grad_f_ext: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+):
+    """Gradient buffers are fully rewritten (no ``zero_()`` needed), as in the reference."""
+    need = batch_size * num_links * 18
+    ws = workspace if workspace is not None else _workspace(grad_q.device, need)
+    if ws.numel() < need:
+        raise ValueError("workspace must hold batch_size * num_links * 18 floats")
+    check(load().curobo_hip_launch_rnea_backward(
+        ptr(grad_q), ptr(grad_qd), ptr(grad_qdd), ptr(grad_tau), ptr(q), ptr(qd), ptr(fixed_transforms),
+        ptr(link_masses_com), ptr(link_inertias), ptr(joint_map_type), ptr(joint_map), ptr(link_map),
+        ptr(joint_offset_map), ptr(gravity), ptr(level_starts), ptr(level_links), ptr(forward_cache), batch_size,
+        num_links, num_dof, n_levels, threads_per_batch, ptr(grad_f_ext), ptr(ws), current_stream(grad_q),
+    ))

@@ -52,6 +52,14 @@ class KinematicsParams:
     joint_limits_position: torch.Tensor
     joint_limits_velocity: torch.Tensor
     self_collision: Optional[SelfCollisionKinematicsCfg] = None
+    #: links sorted by tree depth + CSR offsets per level (reference :147-152, _compute_link_levels :255-290)
+    link_level_data: Optional[torch.Tensor] = None
+    link_level_offsets: Optional[torch.Tensor] = None
+    max_level_width: int = 1
+
+    @property
+    def n_tree_levels(self) -> int:
+        return 0 if self.link_level_offsets is None else int(self.link_level_offsets.shape[0]) - 1
 
     @property
     def num_links(self) -> int:
@@ -86,7 +94,19 @@ class KinematicsParams:
             sphere_padding=up(model.sphere_padding, torch.float32),
             collision_pairs=up(model.collision_pairs, torch.int16),
         )
+        depth, levels = [], {}
+        for k, par in enumerate([int(x) for x in model.link_map]):
+            d = 0 if (par < 0 or par == k) else depth[par] + 1
+            depth.append(d)
+            levels.setdefault(d, []).append(k)
+        level_data = [k for d in sorted(levels) for k in levels[d]]
+        level_offsets = [0]
+        for d in sorted(levels):
+            level_offsets.append(level_offsets[-1] + len(levels[d]))
         return KinematicsParams(
+            link_level_data=up(level_data, torch.int16),
+            link_level_offsets=up(level_offsets, torch.int16),
+            max_level_width=max(len(v) for v in levels.values()),
             fixed_transforms=up(model.fixed_transforms, torch.float32),
             link_map=up(model.link_map, torch.int16),
             joint_map=up(model.joint_map, torch.int16),

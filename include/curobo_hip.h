@@ -185,6 +185,33 @@ int curobo_hip_rollout_point_aggregate(
     const float *cspace_grad, const float *self_cost, const float *scene_cost, int rows,
     int num_links, int dof, int num_spheres, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- dynamics: RNEA
+ * reference: cuda_core_backend/dynamics.py:24-131,134-260
+ * kernels:   kernels/dynamics/rnea_forward_kernel.cuh:53-292, rnea_backward_kernel.cuh:65-468
+ * tau[b, num_dof] = RNEA(q, qd, qdd, f_ext); spatial vectors are [angular; linear], gravity[6] is
+ * the spatial base acceleration (0,0,0,0,0,+9.81 for z-up gravity).  forward_cache is the
+ * reference's opaque [batch, num_links*20] scratch handed from forward to backward (internal
+ * layout here: [link][20][batch]).  level_starts / n_levels / threads_per_batch are accepted for
+ * signature parity; links are visited in level_links order.  f_ext / grad_f_ext [b, links, 6]
+ * may be NULL.  The backward needs a caller-owned workspace of num_links*18*batch floats (the
+ * Python shim keeps one per device). */
+int curobo_hip_launch_rnea_forward(
+    float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
+    const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type,
+    const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
+    const float *gravity, const int16_t *level_starts, const int16_t *level_links,
+    float *forward_cache, int batch_size, int num_links, int num_dof, int n_levels,
+    int threads_per_batch, const float *f_ext, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_rnea_backward(
+    float *grad_q, float *grad_qd, float *grad_qdd, const float *grad_tau, const float *q,
+    const float *qd, const float *fixed_transforms, const float *link_masses_com,
+    const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const float *joint_offset_map, const float *gravity,
+    const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
+    int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch,
+    float *grad_f_ext, float *workspace, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- fused rollout
  * One launch for the data path of RobotRollout.evaluate_action + cost.backward
  * (reference rollout/rollout_robot.py:252-263,537-587, optim/components/gradient_opt_core.py

@@ -1174,6 +1174,267 @@ ORC_API void orc_integration_acceleration(float *out_pos, float *out_vel, float 
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * A8. Inverse dynamics: body-frame RNEA and its VJP (config 4).
+ *     kernels/dynamics/rnea_forward_kernel.cuh:53-292, rnea_backward_kernel.cuh:65-468,
+ *     spatial_algebra.cuh, rnea_helpers.cuh; same algorithm as the reference's in-tree NumPy
+ *     oracle curobo/tests/_src/robot/dynamics/rnea_numpy_reference.py (which pins this file
+ *     through tests/golden/rnea_golden.npz).
+ *     Spatial vectors are [angular(3); linear(3)].  Links are visited in level_links order
+ *     (parents before children); cache per (element, link) = v[6] a[6] f[6] 0 0
+ *     (dynamics_constants.h:37-39).
+ * ------------------------------------------------------------------------------------------ */
+static void orc_local_Rp(const float *F, int jt, float q, float *R, float *p) {
+  /* compute_local_Rp: R = R_fixed * R_joint(q), p = p_fixed (+ R_fixed * d for prismatic) */
+  float Rf[9] = {F[0], F[1], F[2], F[4], F[5], F[6], F[8], F[9], F[10]};
+  p[0] = F[3]; p[1] = F[7]; p[2] = F[11];
+  for (int i = 0; i < 9; i++) R[i] = Rf[i];
+  if (jt == J_FIXED) return;
+  if (jt >= J_X_ROT) {
+    const float c = cosf(q), s = sinf(q);
+    const int ax = jt - J_X_ROT, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    /* rotation about axis ax: columns a1, a2 mix: col a1' = c col a1 + s col a2; col a2' = -s col a1 + c col a2 */
+    for (int r = 0; r < 3; r++) {
+      const float u = Rf[r * 3 + a1], w = Rf[r * 3 + a2];
+      R[r * 3 + a1] = c * u + s * w;
+      R[r * 3 + a2] = -s * u + c * w;
+    }
+  } else {
+    const int ax = jt - J_X_PRISM;
+    for (int r = 0; r < 3; r++) p[r] += Rf[r * 3 + ax] * q;
+  }
+}
+static void orc_cross3(const float *a, const float *b, float *o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* X v = [E w; E (v + w x p)], E = R^T */
+static void orc_Xv(const float *R, const float *p, const float *v, float *o) {
+  float t[3], c[3];
+  orc_cross3(v, p, c);
+  for (int i = 0; i < 3; i++) t[i] = v[3 + i] + c[i];
+  for (int i = 0; i < 3; i++) {
+    o[i] = R[0 * 3 + i] * v[0] + R[1 * 3 + i] * v[1] + R[2 * 3 + i] * v[2];
+    o[3 + i] = R[0 * 3 + i] * t[0] + R[1 * 3 + i] * t[1] + R[2 * 3 + i] * t[2];
+  }
+}
+/* X^T f = [R n + p x (R f); R f] */
+static void orc_XTf(const float *R, const float *p, const float *f, float *o) {
+  float Rf[3], Rn[3], c[3];
+  for (int i = 0; i < 3; i++) {
+    Rn[i] = R[i * 3 + 0] * f[0] + R[i * 3 + 1] * f[1] + R[i * 3 + 2] * f[2];
+    Rf[i] = R[i * 3 + 0] * f[3] + R[i * 3 + 1] * f[4] + R[i * 3 + 2] * f[5];
+  }
+  orc_cross3(p, Rf, c);
+  for (int i = 0; i < 3; i++) { o[i] = Rn[i] + c[i]; o[3 + i] = Rf[i]; }
+}
+/* I v with mc = [com xyz, mass], inertia = [ixx iyy izz ixy ixz iyz ..] at the CoM */
+static void orc_Iv(const float *mc, const float *in, const float *v, float *o) {
+  float h[3], c[3], ch[3];
+  orc_cross3(v, mc, c);
+  for (int i = 0; i < 3; i++) h[i] = v[3 + i] + c[i];
+  orc_cross3(mc, h, ch);
+  const float m = mc[3];
+  o[0] = in[0] * v[0] + in[3] * v[1] + in[4] * v[2] + m * ch[0];
+  o[1] = in[3] * v[0] + in[1] * v[1] + in[5] * v[2] + m * ch[1];
+  o[2] = in[4] * v[0] + in[5] * v[1] + in[2] * v[2] + m * ch[2];
+  for (int i = 0; i < 3; i++) o[3 + i] = m * h[i];
+}
+/* crf(v) f = [w x n + v x f; w x f] */
+static void orc_crf(const float *v, const float *f, float *o) {
+  float a[3], b[3], c[3];
+  orc_cross3(v, f, a); orc_cross3(v + 3, f + 3, b); orc_cross3(v, f + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+/* crm(v1) v2 = [w1 x w2; v1 x w2 + w1 x v2] */
+static void orc_crm(const float *v1, const float *v2, float *o) {
+  float a[3], b[3], c[3];
+  orc_cross3(v1, v2, a); orc_cross3(v1 + 3, v2, b); orc_cross3(v1, v2 + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+static int orc_s_index(int jt) { return jt >= J_X_ROT ? jt - J_X_ROT : 3 + jt - J_X_PRISM; }
+
+ORC_API void orc_rnea_forward(float *tau, float *forward_cache, const float *q, const float *qd, const float *qdd,
+                              const float *fixed_transforms, const float *link_masses_com,
+                              const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
+                              const int16_t *link_map, const float *joint_offset_map, const float *gravity,
+                              const int16_t *level_links, const float *f_ext, int batch, int num_links, int num_dof) {
+  const int L = num_links, D = num_dof;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    float *cache = forward_cache + (size_t)b * L * 20;
+    float *v = (float *)malloc(sizeof(float) * L * 12), *a = v + L * 6;
+    float *t = tau + (size_t)b * D;
+    for (int j = 0; j < D; j++) t[j] = 0.0f;
+    for (int idx = 0; idx < L; idx++) {
+      const int k = level_links[idx];
+      const int jt = joint_map_type[k], ji = joint_map[k], par = link_map[k];
+      const int is_root = par < 0 || par == k;
+      float qe = 0.f, qde = 0.f, qdde = 0.f;
+      if (jt != J_FIXED && ji >= 0) {
+        const float mul = joint_offset_map[2 * k];
+        qe = mul * q[(size_t)b * D + ji] + joint_offset_map[2 * k + 1];
+        qde = mul * qd[(size_t)b * D + ji];
+        qdde = mul * qdd[(size_t)b * D + ji];
+      }
+      float R[9], p[3];
+      orc_local_Rp(fixed_transforms + k * 12, jt, qe, R, p);
+      float *vk = v + k * 6, *ak = a + k * 6;
+      if (is_root) {
+        for (int i = 0; i < 6; i++) vk[i] = 0.0f;
+        orc_Xv(R, p, gravity, ak);
+      } else {
+        orc_Xv(R, p, v + par * 6, vk);
+        orc_Xv(R, p, a + par * 6, ak);
+      }
+      if (jt != J_FIXED) {
+        const int si = orc_s_index(jt);
+        vk[si] += qde;
+        ak[si] += qdde;
+        float S[6] = {0, 0, 0, 0, 0, 0}, cor[6];
+        S[si] = qde;
+        orc_crm(vk, S, cor);
+        for (int i = 0; i < 6; i++) ak[i] += cor[i];
+      }
+    }
+    for (int k = 0; k < L; k++) {
+      float *c = cache + k * 20;
+      for (int i = 0; i < 6; i++) { c[i] = v[k * 6 + i]; c[6 + i] = a[k * 6 + i]; }
+      float Ia[6], Ivv[6], x[6];
+      orc_Iv(link_masses_com + k * 4, link_inertias + k * 8, a + k * 6, Ia);
+      orc_Iv(link_masses_com + k * 4, link_inertias + k * 8, v + k * 6, Ivv);
+      orc_crf(v + k * 6, Ivv, x);
+      for (int i = 0; i < 6; i++)
+        a[k * 6 + i] = Ia[i] + x[i] - (f_ext ? f_ext[((size_t)b * L + k) * 6 + i] : 0.0f); /* a now holds f */
+    }
+    for (int idx = L - 1; idx >= 0; idx--) {
+      const int k = level_links[idx];
+      const int jt = joint_map_type[k], ji = joint_map[k], par = link_map[k];
+      const float *fk = a + k * 6;
+      if (jt != J_FIXED && ji >= 0) t[ji] += joint_offset_map[2 * k] * fk[orc_s_index(jt)];
+      if (!(par < 0 || par == k)) {
+        float qe = 0.f;
+        if (jt != J_FIXED && ji >= 0) qe = joint_offset_map[2 * k] * q[(size_t)b * D + ji] + joint_offset_map[2 * k + 1];
+        float R[9], p[3], fc[6];
+        orc_local_Rp(fixed_transforms + k * 12, jt, qe, R, p);
+        orc_XTf(R, p, fk, fc);
+        for (int i = 0; i < 6; i++) a[par * 6 + i] += fc[i];
+      }
+    }
+    for (int k = 0; k < L; k++) {
+      float *c = cache + k * 20 + 12;
+      for (int i = 0; i < 6; i++) c[i] = a[k * 6 + i];
+      c[6] = c[7] = 0.0f;
+    }
+    free(v);
+  }
+}
+
+ORC_API void orc_rnea_backward(float *grad_q, float *grad_qd, float *grad_qdd, float *grad_f_ext,
+                               const float *grad_tau, const float *q, const float *qd, const float *fixed_transforms,
+                               const float *link_masses_com, const float *link_inertias,
+                               const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map,
+                               const float *joint_offset_map, const float *gravity, const int16_t *level_links,
+                               const float *forward_cache, int batch, int num_links, int num_dof) {
+  const int L = num_links, D = num_dof;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    const float *cache = forward_cache + (size_t)b * L * 20;
+    float *w = (float *)calloc((size_t)L * 18, sizeof(float));
+    float *fb = w, *ab = w + L * 6, *vb = w + L * 12;
+    float *gq = grad_q + (size_t)b * D, *gqd = grad_qd + (size_t)b * D, *gqdd = grad_qdd + (size_t)b * D;
+    for (int j = 0; j < D; j++) gq[j] = gqd[j] = gqdd[j] = 0.0f;
+    /* pass 1 (root -> leaves): adjoint of the force propagation */
+    for (int idx = 0; idx < L; idx++) {
+      const int k = level_links[idx];
+      const int jt = joint_map_type[k], ji = joint_map[k], par = link_map[k];
+      const int mov = jt != J_FIXED && ji >= 0;
+      const float mul = mov ? joint_offset_map[2 * k] : 1.0f;
+      float *fbk = fb + k * 6;
+      if (mov) fbk[orc_s_index(jt)] += mul * grad_tau[(size_t)b * D + ji];
+      if (!(par < 0 || par == k)) {
+        const float qe = mov ? mul * q[(size_t)b * D + ji] + joint_offset_map[2 * k + 1] : 0.0f;
+        float R[9], p[3], X[6];
+        orc_local_Rp(fixed_transforms + k * 12, jt, qe, R, p);
+        orc_Xv(R, p, fb + par * 6, X);
+        for (int i = 0; i < 6; i++) fbk[i] += X[i];
+        if (mov) { /* X_fbar_parent . crf(S) f_k */
+          float S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
+          S[orc_s_index(jt)] = 1.0f;
+          orc_crf(S, cache + k * 20 + 12, cf);
+          float d = 0.0f;
+          for (int i = 0; i < 6; i++) d += X[i] * cf[i];
+          gq[ji] += mul * d;
+        }
+      }
+    }
+    if (grad_f_ext)
+      for (int k = 0; k < L; k++)
+        for (int i = 0; i < 6; i++) grad_f_ext[((size_t)b * L + k) * 6 + i] = -fb[k * 6 + i];
+    /* pass 2 (leaves -> root): adjoint of the velocity / acceleration propagation */
+    for (int idx = L - 1; idx >= 0; idx--) {
+      const int k = level_links[idx];
+      const int jt = joint_map_type[k], ji = joint_map[k], par = link_map[k];
+      const int is_root = par < 0 || par == k;
+      const int mov = jt != J_FIXED && ji >= 0;
+      const float mul = mov ? joint_offset_map[2 * k] : 1.0f;
+      const float *mc = link_masses_com + k * 4, *in = link_inertias + k * 8;
+      const float *vk = cache + k * 20;
+      float *abk = ab + k * 6, *vbk = vb + k * 6, *fbk = fb + k * 6;
+      float t1[6], t2[6];
+      orc_Iv(mc, in, fbk, t1);
+      for (int i = 0; i < 6; i++) abk[i] += t1[i];
+      orc_Iv(mc, in, vk, t1);
+      orc_crf(fbk, t1, t2);
+      for (int i = 0; i < 6; i++) vbk[i] -= t2[i];
+      orc_crm(vk, fbk, t1);
+      orc_Iv(mc, in, t1, t2);
+      for (int i = 0; i < 6; i++) vbk[i] -= t2[i];
+      const int si = mov ? orc_s_index(jt) : 0;
+      if (mov) {
+        const float qdk = mul * qd[(size_t)b * D + ji];
+        gqdd[ji] += mul * abk[si];
+        orc_crf(vk, abk, t1);
+        gqd[ji] -= mul * t1[si];
+        float S[6] = {0, 0, 0, 0, 0, 0};
+        S[si] = qdk;
+        orc_crf(S, abk, t1);
+        for (int i = 0; i < 6; i++) vbk[i] += t1[i];
+      }
+      const float qe = mov ? mul * q[(size_t)b * D + ji] + joint_offset_map[2 * k + 1] : 0.0f;
+      float R[9], p[3], S1[6] = {0, 0, 0, 0, 0, 0};
+      orc_local_Rp(fixed_transforms + k * 12, jt, qe, R, p);
+      S1[si] = 1.0f;
+      if (!is_root) {
+        orc_XTf(R, p, abk, t1);
+        for (int i = 0; i < 6; i++) ab[par * 6 + i] += t1[i];
+      }
+      if (mov) { /* dX/dq on the acceleration path: parent acceleration, or gravity at the root */
+        float Xa[6], cm[6];
+        orc_Xv(R, p, is_root ? gravity : cache + par * 20 + 6, Xa);
+        orc_crm(S1, Xa, cm);
+        float d = 0.0f;
+        for (int i = 0; i < 6; i++) d += abk[i] * cm[i];
+        gq[ji] -= mul * d;
+        gqd[ji] += mul * vbk[si];
+      }
+      if (!is_root) {
+        orc_XTf(R, p, vbk, t1);
+        for (int i = 0; i < 6; i++) vb[par * 6 + i] += t1[i];
+        if (mov) {
+          float Xv[6], cm[6];
+          orc_Xv(R, p, cache + par * 20, Xv);
+          orc_crm(S1, Xv, cm);
+          float d = 0.0f;
+          for (int i = 0; i < 6; i++) d += vbk[i] * cm[i];
+          gq[ji] -= mul * d;
+        }
+      }
+    }
+    free(w);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * A6. L-BFGS step (lbfgs_step_kernel.cuh:18-90, lbfgs_step_helpers.cuh:37-470)
  *   Buffers: y_buffer, s_buffer [m, B, V]; rho_buffer [m, B]; x_0, grad_0, q, grad_q, step [B, V].

@@ -73,6 +73,8 @@ class Oracle:
             "orc_differentiation_position_forward",
             "orc_differentiation_position_backward",
             "orc_integration_acceleration",
+            "orc_rnea_forward",
+            "orc_rnea_backward",
             "orc_lbfgs_step",
             "orc_line_search",
             "orc_trajectory_cost_sum",
@@ -377,6 +379,53 @@ class Oracle:
             _ptr(_f32(start["acceleration"])), _ptr(np.ascontiguousarray(start_idx, np.int32)), _ptr(_f32(traj_dt)),
             C.c_int(b), C.c_int(horizon), C.c_int(dof))
         return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3]}
+
+    # ------------------------------------------------------------------ inverse dynamics
+    @staticmethod
+    def tree_levels(link_map):
+        """(level_starts, level_links): links grouped by tree depth, reference
+        KinematicsParams._compute_link_levels (robot/types/kinematics_params.py:255-290)."""
+        link_map = np.asarray(link_map)
+        n = len(link_map)
+        depth = np.zeros(n, np.int64)
+        for k in range(n):
+            p = int(link_map[k])
+            depth[k] = 0 if (p < 0 or p == k) else depth[p] + 1
+        order = np.argsort(depth, kind="stable")
+        starts = np.searchsorted(depth[order], np.arange(depth.max() + 2))
+        return starts.astype(np.int16), order.astype(np.int16)
+
+    def rnea_forward(self, q, qd, qdd, model, gravity=(0, 0, 0, 0, 0, 9.81), f_ext=None):
+        """tau[b, dof], cache[b, L, 20] = (v6, a6, f6, 0, 0) per link."""
+        q, qd, qdd = _f32(q), _f32(qd), _f32(qdd)
+        b, dof = q.shape
+        L = model["fixed_transforms"].shape[0]
+        tau = np.zeros((b, dof), np.float32)
+        cache = np.zeros((b, L, 20), np.float32)
+        _, level_links = self.tree_levels(model["link_map"])
+        fe = None if f_ext is None else _f32(f_ext)
+        self.lib.orc_rnea_forward(
+            _ptr(tau), _ptr(cache), _ptr(q), _ptr(qd), _ptr(qdd), _ptr(_f32(model["fixed_transforms"])),
+            _ptr(_f32(model["link_masses_com"])), _ptr(_f32(model["link_inertias"])),
+            _ptr(np.ascontiguousarray(model["joint_map_type"], np.int8)), _ptr(np.ascontiguousarray(model["joint_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_map"], np.int16)), _ptr(_f32(model["joint_offset_map"])),
+            _ptr(_f32(gravity)), _ptr(level_links), None if fe is None else _ptr(fe), C.c_int(b), C.c_int(L), C.c_int(dof))
+        return tau, cache
+
+    def rnea_backward(self, grad_tau, q, qd, cache, model, gravity=(0, 0, 0, 0, 0, 9.81), want_f_ext_grad=False):
+        q, qd, gt = _f32(q), _f32(qd), _f32(grad_tau)
+        b, dof = q.shape
+        L = model["fixed_transforms"].shape[0]
+        g = [np.zeros((b, dof), np.float32) for _ in range(3)]
+        gf = np.zeros((b, L, 6), np.float32) if want_f_ext_grad else None
+        _, level_links = self.tree_levels(model["link_map"])
+        self.lib.orc_rnea_backward(
+            _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), None if gf is None else _ptr(gf), _ptr(gt), _ptr(q), _ptr(qd),
+            _ptr(_f32(model["fixed_transforms"])), _ptr(_f32(model["link_masses_com"])), _ptr(_f32(model["link_inertias"])),
+            _ptr(np.ascontiguousarray(model["joint_map_type"], np.int8)), _ptr(np.ascontiguousarray(model["joint_map"], np.int16)),
+            _ptr(np.ascontiguousarray(model["link_map"], np.int16)), _ptr(_f32(model["joint_offset_map"])),
+            _ptr(_f32(gravity)), _ptr(level_links), _ptr(_f32(cache)), C.c_int(b), C.c_int(L), C.c_int(dof))
+        return (g[0], g[1], g[2], gf) if want_f_ext_grad else (g[0], g[1], g[2])
 
     # ------------------------------------------------------------------ optimiser step
     def lbfgs_step(self, step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0,

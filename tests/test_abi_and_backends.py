@@ -52,6 +52,7 @@ EXPECTED = {
                    "launch_bspline_interpolation_single_dt_kernel", "launch_differentiation_position_forward_kernel",
                    "launch_differentiation_position_backward_kernel", "launch_integration_acceleration_kernel"],
     "optimization": ["launch_line_search", "launch_lbfgs_step"],
+    "dynamics": ["launch_rnea_forward", "launch_rnea_backward"],
 }
 
 
