@@ -8,7 +8,7 @@ modules here export the same function names with the same positional argument or
 reference runs scene collision through NVIDIA Warp and has no backend hook for it.
 """
 
-from . import collision, cost, dynamics, geometry, kinematics, optimization, rollout, trajectory  # noqa: F401
+from . import collision, cost, dynamics, geometry, kinematics, linalg, optimization, rollout, trajectory  # noqa: F401
 
 
 def get_backend():
@@ -22,4 +22,5 @@ def get_backend():
         "cost": cost,
         "rollout": rollout,
         "dynamics": dynamics,
+        "linalg": linalg,
     }

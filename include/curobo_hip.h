@@ -212,6 +212,17 @@ int curobo_hip_launch_rnea_backward(
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch,
     float *grad_f_ext, float *workspace, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- linalg: Levenberg-Marquardt step
+ * reference: optim/util/levenberg_marquardt_step.py:96-199 (Warp tile kernel, no backend hook).
+ * Per problem: delta = -(J^T J + lambda I)^-1 jTerror; joint_position_out = joint_position_in +
+ * delta; pred_reduction = 0.5 * delta . (lambda * delta - jTerror).
+ * jacobian [batch, n_residuals, action_dim], action_dim <= 64.  J^T J runs on the matrix cores
+ * (v_mfma_f32_16x16x4_f32, exact fp32), the Cholesky solve in LDS, one wavefront per problem. */
+int curobo_hip_levenberg_marquardt_step(
+    float *joint_position_out, float *pred_reduction, const float *jacobian, const float *jTerror,
+    const float *lambda_damping, const float *joint_position_in, int batch_size, int n_residuals,
+    int action_dim, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- fused rollout
  * One launch for the data path of RobotRollout.evaluate_action + cost.backward
  * (reference rollout/rollout_robot.py:252-263,537-587, optim/components/gradient_opt_core.py

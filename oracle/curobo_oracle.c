@@ -1435,6 +1435,51 @@ ORC_API void orc_rnea_backward(float *grad_q, float *grad_qd, float *grad_qdd, f
   }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * A9. Levenberg-Marquardt step (optim/util/levenberg_marquardt_step.py:146-199, a Warp tile
+ *     kernel: tile_matmul, tile_cholesky, tile_cholesky_solve).  fp32 throughout like the
+ *     reference; pinned against numpy.linalg.solve in float64 (the Warp kernel cannot run).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_lm_step(float *q_out, float *pred, const float *jac, const float *jtr, const float *lam,
+                         const float *q_in, int batch, int n_res, int dof) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; b++) {
+    const float *J = jac + (size_t)b * n_res * dof;
+    float *A = (float *)malloc(sizeof(float) * dof * dof), *y = (float *)malloc(sizeof(float) * dof);
+    for (int i = 0; i < dof; i++)
+      for (int j = 0; j < dof; j++) {
+        float s = 0.0f;
+        for (int k = 0; k < n_res; k++) s += J[k * dof + i] * J[k * dof + j];
+        A[i * dof + j] = s + (i == j ? lam[b] : 0.0f);
+      }
+    for (int j = 0; j < dof; j++) { /* Cholesky, lower triangle in place */
+      for (int i = j; i < dof; i++) {
+        float s = A[i * dof + j];
+        for (int k = 0; k < j; k++) s -= A[i * dof + k] * A[j * dof + k];
+        A[i * dof + j] = (i == j) ? sqrtf(s) : s / A[j * dof + j];
+      }
+    }
+    for (int i = 0; i < dof; i++) {
+      float s = -jtr[(size_t)b * dof + i];
+      for (int k = 0; k < i; k++) s -= A[i * dof + k] * y[k];
+      y[i] = s / A[i * dof + i];
+    }
+    for (int i = dof - 1; i >= 0; i--) {
+      float s = y[i];
+      for (int k = i + 1; k < dof; k++) s -= A[k * dof + i] * y[k];
+      y[i] = s / A[i * dof + i];
+    }
+    float red = 0.0f;
+    for (int i = 0; i < dof; i++) {
+      q_out[(size_t)b * dof + i] = q_in[(size_t)b * dof + i] + y[i];
+      red += y[i] * (lam[b] * y[i] - jtr[(size_t)b * dof + i]);
+    }
+    pred[b] = 0.5f * red;
+    free(A); free(y);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * A6. L-BFGS step (lbfgs_step_kernel.cuh:18-90, lbfgs_step_helpers.cuh:37-470)
  *   Buffers: y_buffer, s_buffer [m, B, V]; rho_buffer [m, B]; x_0, grad_0, q, grad_q, step [B, V].

@@ -75,6 +75,7 @@ class Oracle:
             "orc_integration_acceleration",
             "orc_rnea_forward",
             "orc_rnea_backward",
+            "orc_lm_step",
             "orc_lbfgs_step",
             "orc_line_search",
             "orc_trajectory_cost_sum",
@@ -426,6 +427,17 @@ class Oracle:
             _ptr(np.ascontiguousarray(model["link_map"], np.int16)), _ptr(_f32(model["joint_offset_map"])),
             _ptr(_f32(gravity)), _ptr(level_links), _ptr(_f32(cache)), C.c_int(b), C.c_int(L), C.c_int(dof))
         return (g[0], g[1], g[2], gf) if want_f_ext_grad else (g[0], g[1], g[2])
+
+    # ------------------------------------------------------------------ Levenberg-Marquardt
+    def lm_step(self, jacobian, jTerror, lambda_damping, joint_position_in):
+        """(joint_position_out[b, d], pred_reduction[b]) of the reference's LevenbergMarquardtStep."""
+        J = _f32(jacobian)
+        b, r, d = J.shape
+        q_out = np.zeros((b, d), np.float32)
+        pred = np.zeros((b,), np.float32)
+        self.lib.orc_lm_step(_ptr(q_out), _ptr(pred), _ptr(J), _ptr(_f32(jTerror)), _ptr(_f32(lambda_damping)),
+                             _ptr(_f32(joint_position_in)), C.c_int(b), C.c_int(r), C.c_int(d))
+        return q_out, pred
 
     # ------------------------------------------------------------------ optimiser step
     def lbfgs_step(self, step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0,

@@ -429,3 +429,30 @@ def test_legacy_acceleration_integration(oracle, device):
     for o, k in zip(outs, ("position", "velocity", "acceleration", "jerk")):
         scale = max(1.0, np.abs(ref[k]).max())
         np.testing.assert_allclose(o.cpu().numpy(), ref[k], atol=1e-5 * scale, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dof,n_res", [(7, 13), (6, 12), (16, 16), (17, 30), (33, 40), (49, 73), (64, 70)])
+def test_levenberg_marquardt_step_mfma(dof, n_res, oracle, device):
+    """J^T J on the matrix cores + in-LDS Cholesky vs the oracle (itself checked against
+    numpy.linalg.solve); every tile configuration (1..4 tiles per side, ragged edges)"""
+    from curobo_amd.backends import linalg as La
+
+    rng = np.random.default_rng(dof)
+    b = 37
+    J = rng.normal(size=(b, n_res, dof)).astype(np.float32)
+    g = np.einsum("brd,br->bd", J, rng.normal(size=(b, n_res))).astype(np.float32)
+    lam = rng.uniform(1e-2, 1.0, size=b).astype(np.float32)
+    q = rng.normal(size=(b, dof)).astype(np.float32)
+    q_ref, pred_ref = oracle.lm_step(J, g, lam, q)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    q_out = torch.zeros(b, dof, device=device)
+    pred = torch.zeros(b, device=device)
+    La.levenberg_marquardt_step(q_out, pred, t(J), t(g), t(lam), t(q))
+    torch.cuda.synchronize()
+    d_ref = q_ref - q
+    np.testing.assert_allclose(q_out.cpu().numpy() - q, d_ref, rtol=2e-3, atol=5e-4 * np.abs(d_ref).max())
+    np.testing.assert_allclose(pred.cpu().numpy(), pred_ref, rtol=2e-3, atol=1e-4 * np.abs(pred_ref).max())
+    J64, g64 = J.astype(np.float64), g.astype(np.float64)
+    A = np.einsum("brd,bre->bde", J64, J64) + lam[:, None, None].astype(np.float64) * np.eye(dof)
+    delta = np.linalg.solve(A, -g64[..., None])[..., 0]
+    np.testing.assert_allclose(q_out.cpu().numpy() - q, delta, rtol=5e-3, atol=1e-3 * np.abs(delta).max())
