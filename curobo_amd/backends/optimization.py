@@ -121,3 +121,20 @@ def launch_lbfgs_iteration_tail(
         ptr(step_vec), ptr(rho_buffer), ptr(y_buffer), ptr(s_buffer), ptr(x_0), ptr(grad_0), epsilon, history_m,
         int(stable_mode), ptr(action_step_max), action_dim, int(apply_step_scale), current_stream(best_cost),
     ))
+
+
+def mppi_update_distribution(
+    new_mean, new_cov, new_scale_tril, best_traj, weights, costs, gamma_seq, actions, mean, cov,
+    beta: float, step_size_mean: float, step_size_cov: float, kappa: float,
+):
+    """One launch for ``MPPI._update_distribution`` (reference optim/particle/mppi.py:201-313,
+    DIAG_A covariance): softmax weights, blended mean, blended diagonal covariance + its square
+    root, best sample.  ``costs`` [problems, particles, cost_horizon]; ``actions``
+    [problems, particles, action_horizon, action_dim]; ``best_traj`` / ``weights`` may be None."""
+    nb, npart, hc = costs.shape
+    ha, d = actions.shape[-2], actions.shape[-1]
+    check(load().curobo_hip_mppi_update_distribution(
+        ptr(new_mean), ptr(new_cov), ptr(new_scale_tril), ptr(best_traj), ptr(weights), ptr(costs), ptr(gamma_seq),
+        ptr(actions), ptr(mean), ptr(cov), nb, npart, hc, ha, d, float(beta), float(step_size_mean),
+        float(step_size_cov), float(kappa), current_stream(new_mean),
+    ))

@@ -1,0 +1,128 @@
+"""MPPI: sampling-based optimiser with softmax-weighted distribution updates.
+
+Mirrors the reference's ``MPPI`` / ``ParticleOptCore`` iteration
+(``curobo/_src/optim/particle/mppi.py:173-313``, ``optim/components/particle_opt_core.py:283-470``):
+
+    for each iteration:
+        actions = squash(mean + noise * scale_tril)  (+ negated-mean and null particles)
+        costs   = rollout(actions)                   (num_problems * particles rollouts, cost only)
+        mean, cov, scale_tril, best <- softmax-weighted moments of the particles
+
+The distribution update is one HIP launch (``backends.optimization.mppi_update_distribution``)
+instead of the reference's chain of torch kernels; sampling uses a per-optimiser
+``torch.Generator`` (Gaussian; the reference's Halton/stomp sample library is a sampling policy,
+not part of the update arithmetic).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from ..backends import optimization as optimization_hip
+
+
+@dataclass
+class MPPICfg:
+    """Names and defaults follow ``MPPICfg`` (``optim/particle/mppi.py:64-140``)."""
+
+    num_problems: int = 1
+    num_particles: int = 256
+    num_iters: int = 100
+    inner_iters: int = 1
+    gamma: float = 1.0
+    beta: float = 0.1
+    init_cov: float = 0.5
+    step_size_mean: float = 0.9
+    step_size_cov: float = 0.1
+    kappa: float = 0.01
+    null_act_frac: float = 0.0
+    update_cov: bool = True
+    sample_mode: str = "MEAN"  # MEAN | BEST
+    seed: int = 0
+
+
+class MPPI:
+    """``optimize(seed[num_problems, action_horizon, action_dim])`` -> action of the fitted distribution.
+
+    ``cost_fn(actions[num_problems * num_particles, action_horizon * action_dim])`` returns either
+    total costs ``[N]`` or per-step costs ``[N, horizon]`` (discounted with ``gamma``).
+    """
+
+    def __init__(self, cfg: MPPICfg, cost_fn: Callable[[torch.Tensor], torch.Tensor], action_horizon: int,
+                 action_dim: int, action_bounds: Tuple[torch.Tensor, torch.Tensor], device):
+        self.cfg, self.cost_fn = cfg, cost_fn
+        self.action_horizon, self.action_dim, self.device = action_horizon, action_dim, device
+        B, P, Ha, D = cfg.num_problems, cfg.num_particles, action_horizon, action_dim
+        lows, highs = action_bounds
+        self._low = lows.to(device=device, dtype=torch.float32).view(1, 1, 1, D)
+        self._high = highs.to(device=device, dtype=torch.float32).view(1, 1, 1, D)
+        # particle layout of the reference (particle_opt_core.py:190-216): sampled, then one
+        # negated-mean particle and the null (zero-action) particles
+        self.null_per_problem = int(round(cfg.null_act_frac * P))
+        self.neg_per_problem = 1 if self.null_per_problem > 0 else 0
+        self.sampled_per_problem = P - self.null_per_problem - self.neg_per_problem
+        z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)  # noqa: E731
+        self.mean, self.cov, self.scale_tril = z(B, Ha, D), z(B, 1, D), z(B, 1, D)
+        self._new_mean, self._new_cov, self._new_tril = z(B, Ha, D), z(B, 1, D), z(B, 1, D)
+        self.best_traj, self.weights = z(B, Ha, D), z(B, P)
+        self.actions = z(B, P, Ha, D)
+        self._gen = torch.Generator(device=device)
+        self._gamma_seq: Optional[torch.Tensor] = None
+        self.reset_distribution()
+
+    def reset_distribution(self) -> None:
+        self.mean.zero_()
+        self.cov.fill_(self.cfg.init_cov)
+        self.scale_tril.copy_(torch.sqrt(self.cov))
+        self._gen.manual_seed(self.cfg.seed)
+
+    # reference ParticleOptCore.sample_actions (:393-442), CLAMP squash
+    @torch.no_grad()
+    def sample_actions(self) -> torch.Tensor:
+        B, Ha, D = self.cfg.num_problems, self.action_horizon, self.action_dim
+        n = self.sampled_per_problem
+        noise = torch.randn(B, n, Ha, D, device=self.device, generator=self._gen)
+        self.actions[:, :n] = self.mean.unsqueeze(1) + noise * self.scale_tril.unsqueeze(1)
+        if self.neg_per_problem:
+            self.actions[:, n:n + 1] = -self.mean.unsqueeze(1)
+        if self.null_per_problem:
+            self.actions[:, n + self.neg_per_problem:] = 0.0
+        torch.maximum(self.actions, self._low, out=self.actions)
+        torch.minimum(self.actions, self._high, out=self.actions)
+        return self.actions
+
+    @torch.no_grad()
+    def update_distribution(self, costs: torch.Tensor) -> None:
+        """reference MPPI._update_distribution (:201-262); ``costs`` [B*P] or [B*P, horizon]"""
+        cfg, B, P = self.cfg, self.cfg.num_problems, self.cfg.num_particles
+        costs = costs.reshape(B, P, -1).contiguous()
+        hc = costs.shape[-1]
+        if self._gamma_seq is None or self._gamma_seq.shape[0] != hc:
+            self._gamma_seq = torch.cumprod(torch.full((hc,), cfg.gamma, device=self.device), 0) / cfg.gamma
+        optimization_hip.mppi_update_distribution(
+            self._new_mean, self._new_cov, self._new_tril, self.best_traj, self.weights, costs, self._gamma_seq,
+            self.actions, self.mean, self.cov, cfg.beta, cfg.step_size_mean, cfg.step_size_cov if cfg.update_cov else 0.0,
+            cfg.kappa if cfg.update_cov else 0.0)
+        self.mean, self._new_mean = self._new_mean, self.mean
+        if cfg.update_cov:
+            self.cov, self._new_cov = self._new_cov, self.cov
+            self.scale_tril, self._new_tril = self._new_tril, self.scale_tril
+
+    def _opt_step(self) -> torch.Tensor:
+        acts = self.sample_actions()
+        costs = self.cost_fn(acts.view(-1, self.action_horizon * self.action_dim))
+        self.update_distribution(costs)
+        return costs
+
+    @torch.no_grad()
+    def optimize(self, seed_action: torch.Tensor) -> torch.Tensor:
+        """reference ParticleOptCore.optimize (:283-312): seed the mean, iterate, return the action"""
+        self.mean.copy_(seed_action.reshape(self.mean.shape))
+        costs = None
+        for _ in range(self.cfg.num_iters):
+            costs = self._opt_step()
+        self.last_costs = costs
+        return (self.best_traj if self.cfg.sample_mode == "BEST" else self.mean).clone()

@@ -223,6 +223,21 @@ int curobo_hip_levenberg_marquardt_step(
     const float *lambda_damping, const float *joint_position_in, int batch_size, int n_residuals,
     int action_dim, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- optimization: MPPI update
+ * reference: optim/particle/mppi.py:201-313 + jit helpers :615-757 (pure torch, DIAG_A
+ * covariance).  costs [problems, particles, cost_horizon] (cost_horizon may be 1 for totals),
+ * gamma_seq [cost_horizon], actions [problems, particles, action_horizon, action_dim],
+ * mean [problems, action_horizon, action_dim], cov / new_cov / new_scale_tril
+ * [problems, 1, action_dim].  w = softmax(-(sum_h gamma_h cost_h / gamma_0) / beta);
+ * best_traj (optional) = the action sequence of arg-max w (first index); weights (optional)
+ * [problems, particles]. */
+int curobo_hip_mppi_update_distribution(
+    float *new_mean, float *new_cov, float *new_scale_tril, float *best_traj, float *weights,
+    const float *costs, const float *gamma_seq, const float *actions, const float *mean,
+    const float *cov, int num_problems, int num_particles, int cost_horizon, int action_horizon,
+    int action_dim, float beta, float step_size_mean, float step_size_cov, float kappa,
+    curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- fused rollout
  * One launch for the data path of RobotRollout.evaluate_action + cost.backward
  * (reference rollout/rollout_robot.py:252-263,537-587, optim/components/gradient_opt_core.py
