@@ -61,3 +61,42 @@ def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
     P = row.shape[0]
     sel = gathered[win_rank, torch.arange(P, device=row.device)]
     return sel[:, 0], sel[:, 1].to(torch.int64), sel[:, 2:]
+
+
+def local_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: int) -> torch.Tensor:
+    """cost[P, S_local], payload[P, S_local, V] -> packed [P, k, 2 + V] rows, best first.
+
+    The reference ranks seeds with ``torch.topk(largest=False)`` (``solver/solver_ik.py:503-515``,
+    ``util/tensor_util.py:178-179``), whose order among equal costs is unspecified; here ties are
+    resolved towards the lowest seed index (stable sort), so the result does not depend on the
+    sharding.  ``k`` is clamped to the local seed count (missing rows carry cost +inf)."""
+    P, S = cost.shape
+    order = torch.sort(cost, dim=1, stable=True).indices[:, : min(k, S)]  # [P, k']
+    rows = torch.full((P, k, 2 + payload.shape[-1]), float("inf"), device=cost.device, dtype=torch.float32)
+    ar = torch.arange(P, device=cost.device).unsqueeze(1)
+    kk = order.shape[1]
+    rows[:, :kk, 0] = cost[ar, order]
+    rows[:, :kk, 1] = (order + seed_offset).to(torch.float32)
+    rows[:, :kk, 2:] = payload[ar, order]
+    return rows
+
+
+def global_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: int,
+                group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The k best (cost[P, k], global_seed_idx[P, k], payload[P, k, V]) over the seeds of ALL ranks,
+    ordered by (cost, global seed index): every rank sends its local top-k (k rows per problem, one
+    ``all_gather`` over RCCL), then ranks the W*k candidates identically."""
+    rows = local_topk(cost, payload, seed_offset, k)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * rows.shape[0], *rows.shape[1:], device=rows.device, dtype=rows.dtype)
+        dist.all_gather_into_tensor(flat, rows.contiguous(), group=group)
+        cand = flat.view(world, *rows.shape).permute(1, 0, 2, 3).reshape(rows.shape[0], world * k, -1)
+    else:
+        cand = rows
+    # lexicographic (cost, global index): sort by index first, then stably by cost
+    by_idx = torch.sort(cand[:, :, 1], dim=1, stable=True).indices
+    cand = torch.gather(cand, 1, by_idx.unsqueeze(-1).expand_as(cand))
+    by_cost = torch.sort(cand[:, :, 0], dim=1, stable=True).indices[:, :k]
+    best = torch.gather(cand, 1, by_cost.unsqueeze(-1).expand(-1, -1, cand.shape[-1]))
+    return best[:, :, 0], best[:, :, 1].to(torch.int64), best[:, :, 2:]

@@ -76,6 +76,7 @@ class CollisionRollout:
         self.action_horizon = self.cfg.n_knots
         self.action_dim = kin.num_dof
         self.batch_size = 0
+        self.use_multi_env = False
         self._fused_ok: Optional[bool] = None
         d = self.device
         self._w_self = torch.tensor([self.cfg.self_collision_weight], device=d)
@@ -125,6 +126,17 @@ class CollisionRollout:
         self.grad_zero_state = z(B, H, D)
         self.grad_knots = z(B, self.cfg.n_knots, D)
 
+    def update_env_query_idx(self, env_query_idx: Optional[torch.Tensor]) -> None:
+        """Scene environment of every trajectory (reference ``idxs_env`` / ``use_multi_env`` of the
+        collision costs, cost/cost_scene_collision.py:58-198): trajectory b collides against the
+        obstacles of environment ``env_query_idx[b]``; ``None`` = every trajectory uses env 0."""
+        if env_query_idx is None:
+            self.use_multi_env = False
+            self.env_query_idx.zero_()
+            return
+        self.use_multi_env = True
+        self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
+
     def update_start_state(self, start_position: Optional[torch.Tensor]) -> None:
         """One shared start state (position; zero velocity/acceleration/jerk)."""
         D, d = self.action_dim, self.device
@@ -172,7 +184,7 @@ class CollisionRollout:
         if cfg.use_scene_collision and self.scene is not None:
             collision_hip.sphere_obstacle_collision(
                 self.scene_dist, self.scene_grad, self.robot_spheres, self.scene.struct, self._w_scene,
-                self._eta, self.env_query_idx, B, H, S, False, 3 if cfg.use_sweep else 0,
+                self._eta, self.env_query_idx, B, H, S, self.use_multi_env, 3 if cfg.use_sweep else 0,
                 cfg.use_sweep and cfg.use_speed_metric, self._speed_dt)
         collision_hip.trajectory_cost_sum(
             self.cost, self.self_dist if cfg.use_self_collision else None,
@@ -231,7 +243,7 @@ class CollisionRollout:
             sc.sphere_padding, self._w_self if cfg.use_self_collision else None,
             sc.collision_pairs if cfg.use_self_collision else None,
             self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
-            self._eta, self._speed_dt, self.env_query_idx, k.num_envs, False, B, cfg.padded_horizon,
+            self._eta, self._speed_dt, self.env_query_idx, k.num_envs, self.use_multi_env, B, cfg.padded_horizon,
             self.action_dim, cfg.n_knots, cfg.bspline_degree, 3 if cfg.use_sweep else 0,
             cfg.use_sweep and cfg.use_speed_metric)
         return self.cost, self.grad_knots

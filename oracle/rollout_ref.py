@@ -29,6 +29,7 @@ def rollout_cost_and_gradient(
     activation_distance: float = 0.0025,
     use_sweep: bool = True,
     use_speed_metric: bool = True,
+    env_query_idx: Optional[np.ndarray] = None,
 ) -> Dict[str, np.ndarray]:
     b, nk, d = knots.shape
     ph = (nk + degree + 1) * interpolation_steps + 1
@@ -50,7 +51,8 @@ def rollout_cost_and_gradient(
     scene_cost = np.zeros((b, ph, S), np.float32)
     if scene is not None:
         wc = orc.scene_collision(sph, scene, scene_collision_weight, activation_distance, sweep=use_sweep,
-                                 enable_speed_metric=use_sweep and use_speed_metric, speed_dt=traj_dt)
+                                 enable_speed_metric=use_sweep and use_speed_metric, speed_dt=traj_dt,
+                                 env_query_idx=env_query_idx, use_multi_env=env_query_idx is not None)
         scene_cost = wc["distance"]
         grad_sph[..., :3] += wc["gradient"][..., :3]
     cost = orc.trajectory_cost_sum(self_cost, scene_cost)

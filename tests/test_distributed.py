@@ -61,3 +61,43 @@ def test_global_argmin_world_size_2_gloo(tmp_path):
     mp.spawn(_worker, args=(world, port, 64, str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     np.testing.assert_array_equal(a, b)  # every rank holds the identical winner
+
+
+def test_global_topk_single_process_orders_by_cost_then_index():
+    from curobo_amd.distributed import global_topk
+
+    cost = torch.tensor([[3.0, 1.0, 1.0, 5.0, 0.5], [2.0, 2.0, 2.0, 2.0, 2.0]])
+    payload = torch.arange(2 * 5 * 2, dtype=torch.float32).view(2, 5, 2)
+    c, i, p = global_topk(cost, payload, seed_offset=10, k=3)
+    assert c[0].tolist() == [0.5, 1.0, 1.0] and i[0].tolist() == [14, 11, 12]
+    assert i[1].tolist() == [10, 11, 12]  # all equal: lowest indices, in order
+    assert torch.equal(p[0, 0], payload[0, 4])
+    # k larger than the seed count pads with +inf rows
+    c2, i2, _ = global_topk(cost[:, :2].contiguous(), payload[:, :2].contiguous(), 0, k=3)
+    assert torch.isinf(c2[:, 2]).all()
+
+
+def _topk_worker(rank, world, port, total_seeds, k):
+    from curobo_amd.distributed import global_topk
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1)
+    cost = torch.rand(4, total_seeds, generator=g)
+    cost[2, 3] = cost[2, 50] = cost[2, 20] = -1.0  # ties across ranks
+    payload = torch.rand(4, total_seeds, 5, generator=g)
+    lo, hi = shard_range(total_seeds, rank, world)
+    c, i, p = global_topk(cost[:, lo:hi].contiguous(), payload[:, lo:hi].contiguous(), lo, k)
+    ref = torch.sort(cost, dim=1, stable=True)
+    assert torch.equal(i, ref.indices[:, :k]), (rank, i, ref.indices[:, :k])
+    assert torch.equal(c, ref.values[:, :k])
+    assert torch.equal(p, payload[torch.arange(4).unsqueeze(1), ref.indices[:, :k]])
+    assert i[2, :3].tolist() == [3, 20, 50]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_global_topk_world_size_2_gloo():
+    world, port = 2, _free_port()
+    mp.spawn(_topk_worker, args=(world, port, 64, 5), nprocs=world, join=True)

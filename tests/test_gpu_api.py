@@ -125,3 +125,39 @@ def test_tensor_checks_reject_bad_inputs(device):
         check_float32_tensors(device, bad=good.double())
     with pytest.raises(ValueError, match="is on"):
         check_float32_tensors(device, bad=torch.zeros(2))
+
+
+def test_c3_ur10e_voxel_world_collision_checking_path(oracle, device):
+    """BASELINE config 3: UR10e + one nvblox-style ESDF voxel grid (128^3 at 0.02 m = 2.56 m cube,
+    fp16), 512 seeds through the collision_checking SDF path
+    (RobotCollisionChecker.get_scene_self_collision_distance_from_joints) vs the oracle."""
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.scene import SceneData, voxel_grid_from_sdf
+
+    def sdf(p):  # union of a box and a sphere, like the reference's analytic voxel suites
+        qb = np.abs(p - np.array([0.5, 0.0, 0.35])) - np.array([0.2, 0.4, 0.35])
+        box = np.linalg.norm(np.maximum(qb, 0), axis=-1) + np.minimum(qb.max(-1), 0)
+        sp = np.linalg.norm(p - np.array([-0.35, 0.45, 0.6]), axis=-1) - 0.25
+        return np.minimum(box, sp)
+
+    cfg = KinematicsCfg.from_packaged("ur10e", device=device)
+    model = cfg.model
+    arrays = voxel_grid_from_sdf(sdf, (128, 128, 128), 0.02, pose7=(0.0, 0.0, 0.6, 1, 0, 0, 0), max_distance=10.0)
+    assert arrays["voxel_features"].shape[-1] == 128 ** 3 and arrays["voxel_features"].dtype == np.float16
+    scene = SceneData.from_arrays(arrays, device)
+    seeds, horizon = 512, 4
+    q = sample_q(model, seeds * horizon, seed=33).astype(np.float32).reshape(seeds, horizon, -1)
+    chk = RobotCollisionChecker(cfg, scene, activation_distance=0.02, scene_weight=1.0, self_weight=1.0)
+    d_world, d_self = chk.get_scene_self_collision_distance_from_joints(torch.as_tensor(q, device=device))
+    torch.cuda.synchronize()
+    assert d_world.shape == (seeds, horizon, model.num_spheres) and d_self.shape == (seeds, horizon, 1)
+    fk = oracle.kinematics_forward(q.reshape(-1, q.shape[-1]), model.as_dict(), horizon=horizon)
+    sph = fk["robot_spheres"].reshape(seeds, horizon, -1, 4)
+    ref_w = oracle.scene_collision(sph, arrays, 1.0, 0.02)
+    ref_s = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)
+    assert (ref_w["distance"] > 0).mean() > 0.02, "the synthetic world must produce hits"
+    np.testing.assert_allclose(d_world.cpu().numpy(), ref_w["distance"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(d_self.cpu().numpy().reshape(-1), ref_s["distance"], rtol=1e-5, atol=1e-6)
+    # bit-exact collision-hit indices (north_star): which spheres are in collision
+    assert np.array_equal(d_world.cpu().numpy() > 0, ref_w["distance"] > 0)

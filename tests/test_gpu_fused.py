@@ -141,3 +141,56 @@ def test_fused_rejects_what_does_not_fit(device):
     cost, grad = ro.cost_and_gradient(torch.zeros(2, 12 * kin.num_dof, device=device))  # falls back
     torch.cuda.synchronize()
     assert torch.isfinite(cost).all() and torch.isfinite(grad).all()
+
+
+def test_c5_shape_multi_env_horizon_64(oracle, device):
+    """BASELINE config 5 in miniature: 16 problems, each with its OWN world (num_envs = 16,
+    env_query_idx per trajectory; cuboids everywhere, one environment also carries an ESDF grid...
+    here cuboid-only per env with different layouts), horizon 64 (12 knots x 4 interpolation
+    steps, padded 65 -> 1024-thread workgroups with a leftover point).  Fused kernel vs the kernel
+    sequence vs the all-oracle pipeline (non-swept for the strict end-to-end check)."""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import seed_knots, start_configuration
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    rng = np.random.default_rng(5)
+    envs = []
+    for e in range(16):
+        obs = [{"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}]
+        for _ in range(1 + e % 3):
+            p = rng.uniform([-0.6, -0.6, 0.2], [0.6, 0.6, 0.9])
+            obs.append({"dims": list(rng.uniform(0.1, 0.35, size=3)), "pose": [*p, 1, 0, 0, 0], "enable": True})
+        envs.append(obs)
+    arrays = cuboid_scene_arrays(envs)
+    scene = SceneData.from_arrays(arrays, device)
+    seeds_per_problem, n_prob = 3, 16
+    B = n_prob * seeds_per_problem
+    env_idx = np.repeat(np.arange(n_prob, dtype=np.int32), seeds_per_problem)
+    knots = seed_knots(model, B, 12, seed=21)
+    start = start_configuration(model)
+    outs = []
+    for fused in (False, True):
+        cfg = CollisionRolloutCfg(interpolation_steps=4, use_sweep=False, use_speed_metric=False, use_fused=fused)
+        ro = CollisionRollout(kin, scene, B, cfg)
+        ro.update_start_state(torch.as_tensor(start, device=device))
+        ro.update_env_query_idx(torch.as_tensor(env_idx, device=device))
+        if fused:
+            assert ro.fused_available() and cfg.padded_horizon == 65
+        c, g = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(B, -1))
+        torch.cuda.synchronize()
+        outs.append((c.cpu().numpy().copy(), g.cpu().numpy().copy()))
+    ref = rollout_cost_and_gradient(oracle, model.as_dict(), arrays, knots, start, interpolation_steps=4,
+                                    use_sweep=False, use_speed_metric=False, env_query_idx=env_idx)
+    assert (ref["cost"] > 0).mean() > 0.5
+    # different worlds must matter: the same seeds against env 0 only give a different answer
+    ref0 = rollout_cost_and_gradient(oracle, model.as_dict(), arrays, knots, start, interpolation_steps=4,
+                                     use_sweep=False, use_speed_metric=False)
+    assert np.abs(ref0["cost"] - ref["cost"]).max() > 1.0
+    gk = ref["grad_knots"].reshape(B, -1)
+    for c, g in outs:
+        np.testing.assert_allclose(c, ref["cost"], rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(g, gk, rtol=2e-3, atol=2e-5 * np.abs(gk).max())
