@@ -11,6 +11,8 @@
 // 256-thread workgroup so that 256 problems still fill 64 CUs.  History rows are streamed from
 // L2 in [m][B][V] order (coalesced 256 B per wave-instruction); the shift-by-one of the
 // history is done in the same pass that reads it, as in the reference.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace curobo_hip {
@@ -146,12 +148,25 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
-// body for one problem b on one wavefront; g_in / x_in = current gradient / iterate of the lane's
+// A problem is owned by a lane GROUP: the whole wavefront (G = 64), or one 16-lane DPP row (G = 16,
+// four problems per wavefront) for small problems such as IK (opt_dim 7): the reductions of a row
+// are the first four steps of the wavefront ladder, so both group sizes produce the same bits.
+template <int G>
+__device__ __forceinline__ float gsum(float v) { return G == kWave ? wave_sum(v) : row16_sum(v); }
+template <int G>
+__device__ __forceinline__ float gbcast(float v, int i) { return G == kWave ? lane_bcast(v, i) : __shfl(v, i, G); }
+template <int G>
+__device__ __forceinline__ unsigned long long gballot(bool p) {
+  const unsigned long long m = __ballot(p);
+  return G == kWave ? m : (m >> (__lane_id() & 48)) & 0xffffull;
+}
+
+// body for one problem b on one lane group; g_in / x_in = current gradient / iterate of the lane's
 // elements (v = lane + e * 64), dir_out = the new step direction (also stored to a.step_vec)
-template <int VPL>
+template <int VPL, int G = kWave>
 __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, int lane, const float (&g_in)[VPL],
                                                     const float (&x_in)[VPL], float (&dir_out)[VPL]) {
-  constexpr int MMAX = 32;
+  constexpr int MMAX = G == kWave ? 32 : 16;
   const int V = a.v_dim, m = a.m, B = a.batch;
   const size_t bv = (size_t)b * V;
   const size_t hist_stride = (size_t)B * V;
@@ -161,7 +176,7 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
   for (int i = 0; i < MMAX; i++) {
 #pragma unroll
     for (int e = 0; e < VPL; e++) {
-      const int v = lane + e * kWave;
+      const int v = lane + e * G;
       const bool ld = (i < m - 1) && (v < V);
       ys[i][e] = ld ? a.y_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
       ss[i][e] = ld ? a.s_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
@@ -172,7 +187,7 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
   float part = 0.0f;
 #pragma unroll
   for (int e = 0; e < VPL; e++) {
-    const int v = lane + e * kWave;
+    const int v = lane + e * G;
     gq[e] = y[e] = s[e] = 0.0f;
     if (v < V) {
       const float g = g_in[e], x = x_in[e];
@@ -184,7 +199,7 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
       part += y[e] * s[e];
     }
   }
-  const float numerator = wave_sum(part);
+  const float numerator = gsum<G>(part);
   if (lane == m - 1) {
     rho_mine = 1.0f / numerator;
     if (a.stable_mode && numerator <= 0.0f) rho_mine = 0.0f;
@@ -200,7 +215,7 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     if (i < m) {
 #pragma unroll
       for (int e = 0; e < VPL; e++) {
-        const int v = lane + e * kWave;
+        const int v = lane + e * G;
         if (v < V) {
           a.y_buffer[(size_t)i * hist_stride + bv + v] = ys[i][e];
           a.s_buffer[(size_t)i * hist_stride + bv + v] = ss[i][e];
@@ -215,8 +230,8 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
       float d = 0.0f;
 #pragma unroll
       for (int e = 0; e < VPL; e++) d += gq[e] * ss[i][e];
-      d = wave_sum(d);
-      const float alpha = d * lane_bcast(rho_mine, i);  // i is a constant after unrolling: v_readlane
+      d = gsum<G>(d);
+      const float alpha = d * gbcast<G>(rho_mine, i);  // i is a constant after unrolling: v_readlane (G = 64)
       if (lane == i) alpha_mine = alpha;
 #pragma unroll
       for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * ys[i][e];
@@ -226,7 +241,7 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     float d = 0.0f;
 #pragma unroll
     for (int e = 0; e < VPL; e++) d += y[e] * y[e];
-    d = wave_sum(d);
+    d = gsum<G>(d);
     float var1 = numerator / d;
     if (a.stable_mode && (isinf(var1) || isnan(var1))) var1 = a.epsilon;
     const float gamma = var1 < 0.0f ? 0.0f : var1;
@@ -239,15 +254,15 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
       float d = 0.0f;
 #pragma unroll
       for (int e = 0; e < VPL; e++) d += gq[e] * ys[i][e];
-      d = wave_sum(d);
-      const float beta = lane_bcast(alpha_mine, i) - d * lane_bcast(rho_mine, i);
+      d = gsum<G>(d);
+      const float beta = gbcast<G>(alpha_mine, i) - d * gbcast<G>(rho_mine, i);
 #pragma unroll
       for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * ss[i][e];
     }
   }
 #pragma unroll
   for (int e = 0; e < VPL; e++) {
-    const int v = lane + e * kWave;
+    const int v = lane + e * G;
     dir_out[e] = -gq[e];
     if (v < V) a.step_vec[bv + v] = -gq[e];
   }
@@ -285,6 +300,7 @@ struct LineSearchArgs {
 };
 
 // body for one problem b on one wavefront; returns the exploration candidate index
+template <int G = kWave>
 __device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, int lane) {
   const int V = a.opt_dim, NLS = a.n_linesearch;
   const float *dir = a.step_direction + (size_t)b * V;
@@ -293,8 +309,8 @@ __device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, 
   for (int k = 0; k < NLS; k++) {
     const float *g = a.search_gradient + ((size_t)b * NLS + k) * V;
     float d = 0.0f;
-    for (int v = lane; v < V; v += kWave) d += g[v] * dir[v];
-    d = wave_sum(d);
+    for (int v = lane; v < V; v += G) d += g[v] * dir[v];
+    d = gsum<G>(d);
     if (k == 0) gd0 = d;
     if (lane == k) gd_mine = d;
   }
@@ -310,7 +326,7 @@ __device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, 
   }
   // compute_wolfe_indices (:62-95): LARGEST candidate index that passes, 0 if none.
   // wave64 ballot + count-leading-zeros replaces the reference's 32-bit ballot/brev/ffs.
-  const unsigned long long m1 = __ballot(w1), mb = __ballot(wboth);
+  const unsigned long long m1 = gballot<G>(w1), mb = gballot<G>(wboth);
   const int id1 = m1 ? 63 - __clzll((long long)m1) : 0;
   const int id = mb ? 63 - __clzll((long long)mb) : 0;
   const int sel = a.strong_wolfe ? id : (id == 0 ? id1 : id);  // get_linesearch_idx (:46-60)
@@ -335,7 +351,7 @@ __device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, 
   }
   // copy_action_gradient_results (:152-198)
   const size_t es = ((size_t)b * NLS + expl) * V, ss = ((size_t)b * NLS + sel) * V, o = (size_t)b * V;
-  for (int v = lane; v < V; v += kWave) {
+  for (int v = lane; v < V; v += G) {
     a.exploration_action[o + v] = a.search_action[es + v];
     a.exploration_gradient[o + v] = a.search_gradient[es + v];
     const float av = a.search_action[ss + v];
@@ -425,38 +441,38 @@ struct PrepareArgs {
   int action_dim, apply_scale;
 };
 
-template <int VPL>
+template <int VPL, int G = kWave>
 __global__ void __launch_bounds__(256) lbfgs_iteration_tail_kernel(const LineSearchArgs ls, const LbfgsArgs lb,
                                                                    const PrepareArgs pr) {
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int b = blockIdx.x * (blockDim.x / kWave) + wave;
-  if (b >= ls.batch) return;
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int b = blockIdx.x * (blockDim.x / G) + grp;
+  if (b >= ls.batch) return;  // (groups of a wavefront exit together or run the same control flow)
   const int V = ls.opt_dim, NLS = ls.n_linesearch;
-  const int expl = line_search_body(ls, b, lane);
+  const int expl = line_search_body<G>(ls, b, lane);
   float g[VPL], x[VPL], dir[VPL];
 #pragma unroll
   for (int e = 0; e < VPL; e++) {  // the values line_search_body just copied to the exploration buffers
-    const int v = lane + e * kWave;
+    const int v = lane + e * G;
     const size_t src = ((size_t)b * NLS + expl) * V + v;
     g[e] = v < V ? ls.search_gradient[src] : 0.0f;
     x[e] = v < V ? ls.search_action[src] : 0.0f;
   }
-  lbfgs_step_reg_body<VPL>(lb, b, lane, g, x, dir);
+  lbfgs_step_reg_body<VPL, G>(lb, b, lane, g, x, dir);
   float scale = 1.0f;
   if (pr.apply_scale) {
     float mx = 0.0f;
 #pragma unroll
     for (int e = 0; e < VPL; e++) {
-      const int v = lane + e * kWave;
+      const int v = lane + e * G;
       if (v < V) mx = fmaxf(mx, fabsf(dir[e]) / pr.step_max[v % pr.action_dim]);
     }
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    for (int off = G / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, G));
     scale = fmaxf(mx, 1.0f);
   }
 #pragma unroll
   for (int e = 0; e < VPL; e++) {
-    const int v = lane + e * kWave;
+    const int v = lane + e * G;
     if (v < V) {
       const float dv = dir[e] / scale;
       pr.d_out[(size_t)b * V + v] = dv;
@@ -579,7 +595,10 @@ CUROBO_EXPORT int curobo_hip_launch_lbfgs_iteration_tail(
   PrepareArgs pr{search_action, step_direction_scaled, action_step_max, search_magnitudes, action_dim, apply_step_scale};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)ceil_div(batchsize, 4)), block(256);
-  if (opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1>), grid, block, 0, st, ls, lb, pr);
+  static const bool no_row16 = getenv("CUROBO_HIP_NO_ROW16") != nullptr;
+  if (!no_row16 && opt_dim <= 16 && history_m <= 16 && n_linesearch <= 16)  // IK-sized problems: one 16-lane row each
+    hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1, 16>), dim3((unsigned)ceil_div(batchsize, 16)), block, 0, st, ls, lb, pr);
+  else if (opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1>), grid, block, 0, st, ls, lb, pr);
   else hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<2>), grid, block, 0, st, ls, lb, pr);
   return check_launch(what, st);
 }
