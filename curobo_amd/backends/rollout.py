@@ -87,3 +87,36 @@ def rollout_trajectory_fused_lds_bytes(padded_horizon: int, dof: int, num_links:
     """LDS bytes one trajectory needs in the fused kernel (usable when <= FUSED_LDS_LIMIT)."""
     return int(load().curobo_hip_rollout_trajectory_fused_lds_bytes(
         padded_horizon, dof, num_links, num_spheres, num_collision_pairs, link_chain_len, num_obstacles))
+
+
+def rollout_ik_fused(
+    out_cost, out_grad_q, out_pose_distance, out_position_distance, out_rotation_distance, out_goalset_idx,
+    out_link_pos, out_link_quat, out_robot_spheres, out_cspace_cost, q, goal_position, goal_quat, idxs_goal,
+    position_orientation_weight, terminal_pose_axes_weight_factor, terminal_pose_convergence_tolerance,
+    project_distance_to_goal, num_goalset: int, rotation_method: int, p_b, cspace_weight, cspace_activation_distance,
+    fixed_transform, robot_spheres, joint_map_type, joint_map, link_map, tool_frame_map, link_sphere_map,
+    link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight, pair_locations,
+    scene: Optional[Scene], scene_collision_weight, activation_distance, batch_size: int, dof: int,
+):
+    """cost[b], d cost / d q [b, dof] of ``batch_size`` joint configurations against per-row goal
+    poses in one launch (see ``curobo_hip_rollout_ik_fused`` in the header); optional outputs may be None."""
+    num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
+    check(load().curobo_hip_rollout_ik_fused(
+        ptr(out_cost), ptr(out_grad_q), ptr(out_pose_distance), ptr(out_position_distance), ptr(out_rotation_distance),
+        ptr(out_goalset_idx), ptr(out_link_pos), ptr(out_link_quat), ptr(out_robot_spheres), ptr(out_cspace_cost),
+        ptr(q), ptr(goal_position), ptr(goal_quat), ptr(idxs_goal), ptr(position_orientation_weight),
+        ptr(terminal_pose_axes_weight_factor), ptr(terminal_pose_convergence_tolerance), ptr(project_distance_to_goal),
+        num_goalset, rotation_method, ptr(p_b), ptr(cspace_weight), ptr(cspace_activation_distance), ptr(fixed_transform),
+        ptr(robot_spheres), ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(tool_frame_map), ptr(link_sphere_map),
+        ptr(link_chain_data), ptr(link_chain_offsets), ptr(joint_offset_map), ptr(sphere_padding),
+        ptr(self_collision_weight), ptr(pair_locations), None if scene is None else C.addressof(scene),
+        ptr(scene_collision_weight), ptr(activation_distance), batch_size, dof, int(fixed_transform.shape[0]),
+        int(tool_frame_map.shape[0]), int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]),
+        current_stream(out_cost),
+    ))
+
+
+def rollout_ik_fused_lds_bytes(dof: int, num_links: int, num_spheres: int, num_collision_pairs: int,
+                               link_chain_len: int, num_obstacles: int) -> int:
+    return int(load().curobo_hip_rollout_ik_fused_lds_bytes(dof, num_links, num_spheres, num_collision_pairs,
+                                                            link_chain_len, num_obstacles))

@@ -156,6 +156,19 @@ struct CspacePosArgs {
   int write_grad, batch, horizon, dof;
 };
 
+// joint-limit term of the c-space cost for one dof (wp_cspace_position.py:268-300): limits shrunk
+// by eta * range, quadratic outside; returns the cost, g = d cost / d position
+__device__ __forceinline__ float cspace_bound_term(float cp, float pl, float pu, float w, float &g) {
+  g = 0.0f;
+  if (cp < pl || cp > pu) {
+    const float delta = cp < pl ? cp - pl : cp - pu;
+    const float wv = w * delta;
+    g = wv;
+    return 0.5f * wv * delta;
+  }
+  return 0.0f;
+}
+
 // one (batch, horizon, dof) entry, wp_cspace_position.py:232-362
 __device__ __forceinline__ float cspace_position_point(const CspacePosArgs &a, int b, int d, float cp, float ctau,
                                                        float &gp, float &gt) {
@@ -175,14 +188,8 @@ __device__ __forceinline__ float cspace_position_point(const CspacePosArgs &a, i
     pu = fminf(pu, cur_p + a.v_b[dof + d] * dt);
   }
   float c = 0.0f;
-  gp = 0.0f;
   gt = 0.0f;
-  if (cp < pl || cp > pu) {
-    const float delta = cp < pl ? cp - pl : cp - pu;
-    const float wv = w * delta;
-    c += 0.5f * wv * delta;
-    gp += wv;
-  }
+  c += cspace_bound_term(cp, pl, pu, w, gp);
   if (tau_w > 0.0f && (ctau < tl || ctau > tu)) {
     const float delta = ctau < tl ? ctau - tl : ctau - tu;
     const float wv = tau_w * delta;

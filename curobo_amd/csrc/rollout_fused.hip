@@ -100,13 +100,13 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
 // LDS views + per-launch scalars shared by the phases
 struct FusedCtx {
   float *q, *cumul, *work, *wrench, *cost, *sign, *off_add, *fixed, *sph_rad, *sph_pad;
-  const float4 *rs;      // link-frame spheres of this trajectory's robot instance
-  const int *lbound;     // per link: box (link frame) around its collision spheres: lo xyz, hi xyz as ordered-int keys
+  float4 *rs;            // link-frame spheres of this workgroup's robot instance
+  int *lbound;           // per link: box (link frame) around its collision spheres: lo xyz, hi xyz as ordered-int keys
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
   float4 *left;
   unsigned long long *key;
-  const ObsRec *recs;
+  ObsRec *recs;
   int H, D, L, S, P, ws, wl, env;
   float w_self, w_scene, eta, speed_dt;
   bool speed_metric;
@@ -301,29 +301,14 @@ __device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajA
   reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[s] = w4;
 }
 
-// Workgroups are at most 8 waves when two of them fit in a CU's LDS (<= 80 KB each): 2 x 8 waves =
-// 4 per SIMD is what 128 VGPRs allow, and the second workgroup hides the serial phases (table
-// loads, the FK chain, barriers) of the first.  (9-wave workgroups do not pair up on a CU even at
-// 5 waves/SIMD: measured with tools/probes/lds_occupancy_probe.hip + the profile hook.)
-// Points beyond the last full round of 16-lane rows (H = 33 on 32 rows) are "leftover" points:
-// instead of a round in which one row works and 31 wait, all threads share them (pairs and spheres
-// spread over the workgroup, gradients handed over through LDS, row 0 finishes the VJP).
-template <int DEG, int SWEEP, int KINDS>
-__global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const FusedTrajArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
-  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int b = blockIdx.x;
-  FusedCtx c;
+// LDS views of a workgroup (H = points held by the workgroup)
+__device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const FusedLayout &lay, int H, int D, int L, int S,
+                                                int P) {
   c.q = smem + lay.q; c.cumul = smem + lay.cumul; c.work = smem + lay.work; c.wrench = smem + lay.wrench;
   c.cost = smem + lay.cost; c.sign = smem + lay.sign; c.sph_rad = smem + lay.sph_rad;
   c.off_add = smem + lay.off_add; c.fixed = smem + lay.fixed; c.sph_pad = smem + lay.sph_pad;
-  float4 *s_rs = reinterpret_cast<float4 *>(smem + lay.rs);
-  c.rs = s_rs;
-  int *s_lbound = reinterpret_cast<int *>(smem + lay.lbound);
-  c.lbound = s_lbound;
+  c.rs = reinterpret_cast<float4 *>(smem + lay.rs);
+  c.lbound = reinterpret_cast<int *>(smem + lay.lbound);
   c.parent = reinterpret_cast<int *>(smem + lay.parent);
   c.chain_off = reinterpret_cast<int *>(smem + lay.chain_off);
   c.link_info = reinterpret_cast<int *>(smem + lay.link_info);
@@ -334,35 +319,31 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   c.left = reinterpret_cast<float4 *>(smem + lay.left);
   c.key = reinterpret_cast<unsigned long long *>(smem + lay.key);
   c.pairs = reinterpret_cast<uint32_t *>(smem + lay.pairs);
-  ObsRec *s_recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
-  c.recs = s_recs;
+  c.recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
   c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
-  c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
-#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
-  CUROBO_STAMP(0);
-  const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
-  const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
-  c.w_self = a.use_self ? a.w_self[0] : 0.0f;
-  c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
-  c.eta = a.use_scene ? a.eta[0] : 0.0f;
-  c.speed_metric = a.enable_speed_metric != 0;
-  c.speed_dt = c.speed_metric ? a.speed_dt[0] : 0.0f;
+}
 
-  // ---------------- P0: tables + B-spline samples
-  // Every global read of the kernel happens here.  Loads are clamped instead of predicated so each
-  // loop body is one basic block (all loads issued back to back, one wait), and the independent
-  // jobs start on different waves (rotated thread index) so their latencies overlap.
-  const auto rot = [&](int first_wave) { const int t = tid - (first_wave * 64) % nt; return t < 0 ? t + nt : t; };
-  const int nwaves = nt >> 6;
+__device__ __forceinline__ int rotated_tid(int first_wave) {  // jobs start on different waves
+  const int nt = blockDim.x, t = (int)threadIdx.x - (first_wave * 64) % nt;
+  return t < 0 ? t + nt : t;
+}
+
+// Every global read of the robot / scene constants happens here (before the first barrier).  Loads
+// are clamped instead of predicated so each loop body is one basic block (all loads issued back to
+// back, one wait), and the independent jobs start on different waves so their latencies overlap.
+__device__ __forceinline__ void fused_stage_tables(const FusedCtx &c, const FusedTrajArgs &a, const FusedLayout &lay,
+                                                   const float4 *rs, int n_rec) {
+  const int tid = threadIdx.x, nt = blockDim.x, nwaves = nt >> 6;
+  const int H = c.H, D = c.D, L = c.L, S = c.S, P = c.P;
   for (int i = tid; i < L * 4 + D * 4; i += nt) c.sub[i] = 0u;  // sub and jlinks are adjacent
   for (int i = tid; i < H * lay.wl; i += nt) c.wrench[i] = 0.0f;
-  for (int i = tid; i < L * 8; i += nt) s_lbound[i] = (i & 4) ? float_key(-3.0e38f) : float_key(3.0e38f);  // empty boxes
+  for (int i = tid; i < L * 8; i += nt) c.lbound[i] = (i & 4) ? float_key(-3.0e38f) : float_key(3.0e38f);  // empty boxes
   {
     const int C = a.chain_len;
     int n_tab = L * 12;
     n_tab = n_tab > C ? n_tab : C;
     n_tab = n_tab > S ? n_tab : S;
-    for (int i = rot(0); i < n_tab; i += nt) {
+    for (int i = rotated_tid(0); i < n_tab; i += nt) {
       const int il = i < L ? i : L - 1, ic = i < C ? i : C - 1, is = i < S ? i : (S > 0 ? S - 1 : 0);
       const int io = i <= L ? i : L, ix = i < L * 12 ? i : L * 12 - 1;
       const int v_parent = a.link_map[il], v_type = a.joint_map_type[il], v_joint = a.joint_map[il];
@@ -390,7 +371,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
         c.sph_link[i] = v_slink;
         c.sph_rad[i] = v_rs.w;
         c.sph_pad[i] = v_pad;
-        s_rs[i] = v_rs;
+        c.rs[i] = v_rs;
       }
     }
   }
@@ -405,10 +386,63 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     for (int k = P + tid; k < ((P + 63) & ~63); k += nt) c.pairs[k] = (uint32_t)(S * 16) | ((uint32_t)(S * 16) << 16);
   }
   if (a.use_scene)
-    for (int o = rot(nwaves - 1); o < n_rec; o += nt)
-      s_recs[o] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a.sc, c.env, o)
+    for (int o = rotated_tid(nwaves - 1); o < n_rec; o += nt)
+      c.recs[o] = (o < a.sc.max_cuboids) ? load_rec_global<false>(a.sc, c.env, o)
                                          : load_rec_global<true>(a.sc, c.env, o - a.sc.max_cuboids);
-  for (int e = rot(nwaves / 2); e < H * D; e += nt) {
+}
+
+// Derived tables (after the first barrier), on the last waves (the first one carries leftover
+// points): transposed kinematic tables and a box per link around its collision spheres (link
+// frame), both by integer atomics (order independent).
+__device__ __forceinline__ void fused_derive_tables(const FusedCtx &c) {
+  const int nt = blockDim.x, nwaves = nt >> 6;
+  for (int l = rotated_tid(nwaves - 1); l < c.L; l += nt) {
+    for (int ci = c.chain_off[l]; ci < c.chain_off[l + 1]; ci++) atomicOr(&c.sub[c.chain[ci] * 4 + (l >> 5)], 1u << (l & 31));
+    const int info = c.link_info[l];
+    if ((info & 0xff) - 1 >= J_X_PRISM) atomicOr(&c.jlinks[(info >> 8) * 4 + (l >> 5)], 1u << (l & 31));
+  }
+  for (int sidx = rotated_tid(nwaves > 1 ? nwaves - 2 : 0); sidx < c.S; sidx += nt) {
+    const float4 v = c.rs[sidx];
+    if (v.w >= 0.0f) {
+      int *bx = c.lbound + c.sph_link[sidx] * 8;
+      atomicMin(bx + 0, float_key(v.x - v.w)); atomicMin(bx + 1, float_key(v.y - v.w)); atomicMin(bx + 2, float_key(v.z - v.w));
+      atomicMax(bx + 4, float_key(v.x + v.w)); atomicMax(bx + 5, float_key(v.y + v.w)); atomicMax(bx + 6, float_key(v.z + v.w));
+    }
+  }
+}
+
+// Workgroups are at most 8 waves when two of them fit in a CU's LDS (<= 80 KB each): 2 x 8 waves =
+// 4 per SIMD is what 128 VGPRs allow, and the second workgroup hides the serial phases (table
+// loads, the FK chain, barriers) of the first.  (9-wave workgroups do not pair up on a CU even at
+// 5 waves/SIMD: measured with tools/probes/lds_occupancy_probe.hip + the profile hook.)
+// Points beyond the last full round of 16-lane rows (H = 33 on 32 rows) are "leftover" points:
+// instead of a round in which one row works and 31 wait, all threads share them (pairs and spheres
+// spread over the workgroup, gradients handed over through LDS, row 0 finishes the VJP).
+template <int DEG, int SWEEP, int KINDS>
+__global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const FusedTrajArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
+  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.x;
+  FusedCtx c;
+  fused_ctx_carve(c, smem, lay, H, D, L, S, P);
+  c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
+#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
+  CUROBO_STAMP(0);
+  const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
+  const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
+  c.w_self = a.use_self ? a.w_self[0] : 0.0f;
+  c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
+  c.eta = a.use_scene ? a.eta[0] : 0.0f;
+  c.speed_metric = a.enable_speed_metric != 0;
+  c.speed_dt = c.speed_metric ? a.speed_dt[0] : 0.0f;
+
+  // ---------------- P0: tables + B-spline samples
+  const int nwaves = nt >> 6;
+  fused_stage_tables(c, a, lay, rs, n_rec);
+  for (int e = rotated_tid(nwaves / 2); e < H * D; e += nt) {
     const int h = e / D, d = e - h * D;
     float o4[4];
     bspline_sample<DEG>(a.bs, b, h, d, o4);
@@ -416,22 +450,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
   }
   __syncthreads();
-  // derived tables, on the last wave (the first one carries the leftover points): transposed
-  // kinematic tables (integer atomics: order independent)
-  for (int l = rot(nwaves - 1); l < L; l += nt) {
-    for (int ci = c.chain_off[l]; ci < c.chain_off[l + 1]; ci++) atomicOr(&c.sub[c.chain[ci] * 4 + (l >> 5)], 1u << (l & 31));
-    const int info = c.link_info[l];
-    if ((info & 0xff) - 1 >= J_X_PRISM) atomicOr(&c.jlinks[(info >> 8) * 4 + (l >> 5)], 1u << (l & 31));
-  }
-  // box per link around its collision spheres (link frame), by integer atomic min / max
-  for (int sidx = rot(nwaves > 1 ? nwaves - 2 : 0); sidx < S; sidx += nt) {
-    const float4 v = s_rs[sidx];
-    if (v.w >= 0.0f) {
-      int *bx = s_lbound + c.sph_link[sidx] * 8;
-      atomicMin(bx + 0, float_key(v.x - v.w)); atomicMin(bx + 1, float_key(v.y - v.w)); atomicMin(bx + 2, float_key(v.z - v.w));
-      atomicMax(bx + 4, float_key(v.x + v.w)); atomicMax(bx + 5, float_key(v.y + v.w)); atomicMax(bx + 6, float_key(v.z + v.w));
-    }
-  }
+  fused_derive_tables(c);
   CUROBO_STAMP(1);
 
   const int grp = tid / kFkLanes, lane = tid % kFkLanes, ngroups = nt / kFkLanes;
@@ -611,6 +630,193 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
 #undef CUROBO_STAMP
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Horizon-1 ("teleport") rollout of the IK solver in one launch: q -> FK -> tool-pose goal-set
+// cost + c-space bound cost + self + scene collision -> cost[b] and d cost / d q[b].  Replaces
+// the seven launches of curobo_amd/rollout/ik_rollout.py (reference RobotRollout with
+// StateFromPositionTeleport and the cost set of content/configs/task/ik/lbfgs_ik.yml); same
+// device functions, intermediates in LDS.  16 configurations per 256-thread workgroup (one
+// 16-lane row each) share the staged robot / scene tables.  The tool-pose gradient enters the
+// link-wrench VJP as a force at the tool link's origin plus the free torque omega = 1/2 E(q)^T g
+// (reference kinematics_backward_helper.cuh:102-183, quaternion_util.cuh:86-102).
+struct FusedIkArgs {
+  FusedTrajArgs r;  // robot / self / scene members, out_cost, out_position (= nothing), out_spheres
+  const float *x;   // [n_points, dof]
+  float *out_grad_q;
+  ToolPoseArgs tp;  // current_position / current_quat unused (computed here); out_* optional
+  const float *p_b, *cs_weight, *cs_eta;  // c-space bound term: limits [2, dof], weight[>=1], activation[>=1]
+  float *out_cspace_cost;                 // optional [n_points, dof]
+  const int16_t *tool_frame_map;
+  float *out_link_pos, *out_link_quat;  // optional [n_points, T, 3|4]
+  int n_tool_frames, n_points;
+};
+
+constexpr int kIkPoints = 16;
+
+template <int KINDS>
+__global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkArgs ia) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const FusedTrajArgs &a = ia.r;
+  const int H = kIkPoints, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs, T = ia.n_tool_frames;
+  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int pt0 = blockIdx.x * kIkPoints;
+  const int npts = min(kIkPoints, ia.n_points - pt0);
+  FusedCtx c;
+  fused_ctx_carve(c, smem, lay, H, D, L, S, P);
+  c.env = 0;
+  c.w_self = a.use_self ? a.w_self[0] : 0.0f;
+  c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
+  c.eta = a.use_scene ? a.eta[0] : 0.0f;
+  c.speed_metric = false;
+  c.speed_dt = 0.0f;
+  fused_stage_tables(c, a, lay, reinterpret_cast<const float4 *>(a.robot_spheres), n_rec);
+  for (int e = rotated_tid((nt >> 6) / 2); e < npts * D; e += nt) c.q[e] = ia.x[(size_t)pt0 * D + e];
+  __syncthreads();
+  fused_derive_tables(c);
+
+  const int h = tid / kFkLanes, lane = tid % kFkLanes, lane64 = tid & 63;
+  const bool live = h < npts;
+  const int n = pt0 + h;
+  // ---- FK
+  if (live) {
+    point_fk_locals(c, h, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *const cm[1] = {c.cumul + (size_t)h * L * 12};
+    const float *const lc[1] = {c.work + (size_t)h * c.ws};
+    fk_chain_16_multi<1>(cm, lc, c.parent, c.fixed, L, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, blockIdx.x, h, s);
+    if (lane == 0) reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
+  }
+  __syncthreads();  // derived tables (other waves) + this row's spheres
+  if (!live) return;
+
+  // ---- costs + wrenches
+  const float4 *sph = c.spheres(h);
+  const float *cumul = c.cumul + (size_t)h * L * 12;
+  float *wr = c.wrench + (size_t)h * c.wl;
+  float cost_pt = 0.0f;
+  bool any_grad = false;
+  if (a.use_self) {  // reference self_collision_kernel.cuh:19-111 (same loop as the trajectory kernel)
+    constexpr int U = 4;
+    const int P_pad = (P + 63) & ~63;
+    float best = 0.0f;
+    int best_k0 = 0x7fffffff;
+    for (int k0 = lane; k0 < P_pad; k0 += kFkLanes * U) {
+      uint32_t ij[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) ij[u] = c.pairs[k0 + u * kFkLanes];
+      float gmax = staged_pair_penetration(sph, ij[0]);
+#pragma unroll
+      for (int u = 1; u < U; u++) gmax = fmaxf(gmax, staged_pair_penetration(sph, ij[u]));
+      if (gmax > best) { best = gmax; best_k0 = k0; }
+    }
+    float m = row16_max(best);
+    if (m > 0.0f) {
+      int best_k = 0x7fffffff;
+      if (best == m) {
+        float f_best = 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float f = staged_pair_penetration(sph, c.pairs[best_k0 + u * kFkLanes]);
+          if (f > f_best) { f_best = f; best_k = best_k0 + u * kFkLanes; }
+        }
+        best = f_best;
+      } else {
+        best = 0.0f;
+      }
+      m = row16_max(best);
+      const int kmin = row16_min((best == m && best > 0.0f) ? best_k : 0x7fffffff);
+      if (kmin != 0x7fffffff && m > 0.0f) {
+        any_grad = true;
+        if (lane == 0) cost_pt += self_pair_apply(c, h, m, kmin);
+      }
+    }
+  }
+  if (a.use_scene) {
+    point_link_masks<0, KINDS>(c, a.sc, h, lane);
+    for (int s0 = 0; s0 < S; s0 += kFkLanes) {
+      const int s = s0 + lane;
+      float d = 0.0f;
+      f3 g = make_f3(0.f, 0.f, 0.f);
+      float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
+      const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+      if (mask != 0u) c4 = scene_sphere<0, KINDS>(c, a.sc, h, s, d, g, mask);
+      cost_pt += d;
+      any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_grad;
+    }
+  }
+  // tool-pose goal-set cost (wp_tool_pose.py:456-692), one tool frame per lane
+  for (int t0 = 0; t0 < T; t0 += kFkLanes) {
+    const int t = t0 + lane;
+    f3 gp = make_f3(0.f, 0.f, 0.f), om = gp, pos = gp;
+    int l = 0;
+    if (t < T) {
+      l = ia.tool_frame_map[t];
+      const float *C = cumul + l * 12;
+      const float4 qx = quat_from_transform(C);
+      pos = make_f3(C[3], C[7], C[11]);
+      const ToolPoseResult res = tool_pose_distance_point(ia.tp, n, 0, t, pos, make_float4(qx.w, qx.x, qx.y, qx.z));
+      cost_pt += res.position_cost + res.rotation_cost;
+      gp = res.position_gradient;
+      // omega = 0.5 * E(q)^T g  (reference quaternion_util.cuh:86-102; q xyzw, g wxyz)
+      const float dqw = res.quat_rate_wxyz.x, dqx = res.quat_rate_wxyz.y, dqy = res.quat_rate_wxyz.z, dqz = res.quat_rate_wxyz.w;
+      om = make_f3(0.5f * (-qx.x * dqw + qx.w * dqx + qx.z * dqy - qx.y * dqz),
+                   0.5f * (-qx.y * dqw - qx.z * dqx + qx.w * dqy + qx.x * dqz),
+                   0.5f * (-qx.z * dqw + qx.y * dqx - qx.x * dqy + qx.w * dqz));
+      const size_t o = (size_t)n * T + t;
+      if (ia.tp.out_distance) { ia.tp.out_distance[2 * o] = res.position_cost; ia.tp.out_distance[2 * o + 1] = res.rotation_cost; }
+      if (ia.tp.out_position_distance) ia.tp.out_position_distance[o] = res.position_distance;
+      if (ia.tp.out_rotation_distance) ia.tp.out_rotation_distance[o] = res.rotation_distance;
+      if (ia.tp.out_goalset_idx) ia.tp.out_goalset_idx[o] = res.goalset_idx;
+      if (ia.out_link_pos) { float *lp = ia.out_link_pos + o * 3; lp[0] = pos.x; lp[1] = pos.y; lp[2] = pos.z; }
+      if (ia.out_link_quat) reinterpret_cast<float4 *>(ia.out_link_quat)[o] = make_float4(qx.w, qx.x, qx.y, qx.z);
+    }
+    // force at the tool link's origin + free torque, one contributing lane at a time (lane order)
+    unsigned long long mk = __ballot(gp.x != 0.f || gp.y != 0.f || gp.z != 0.f || om.x != 0.f || om.y != 0.f || om.z != 0.f);
+    any_grad = any_grad || ((mk >> (lane64 & 48)) & 0xffffull) != 0ull;
+    while (mk) {
+      const int src = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      if (lane64 == src) {
+        wrench_add(wr, cumul, l, pos, gp);
+        float *w = wr + l * kWrench;
+        atomicAdd(w + 3, om.x); atomicAdd(w + 4, om.y); atomicAdd(w + 5, om.z);
+      }
+    }
+  }
+  // c-space bound cost (wp_cspace_position.py:232-362): its gradient is already in joint space
+  float gp_joint[(64 + kFkLanes - 1) / kFkLanes];
+#pragma unroll
+  for (int it = 0; it < (64 + kFkLanes - 1) / kFkLanes; it++) {
+    const int d = it * kFkLanes + lane;
+    float g = 0.0f;
+    if (d < D) {
+      float pl = ia.p_b[d], pu = ia.p_b[D + d];
+      { const float r = pu - pl, eta_p = ia.cs_eta[0]; pl = pl + eta_p * r; pu = pu - eta_p * r; }
+      const float cc = cspace_bound_term(c.q[h * D + d], pl, pu, ia.cs_weight[0], g);
+      cost_pt += cc;
+      if (ia.out_cspace_cost) ia.out_cspace_cost[(size_t)n * D + d] = cc;
+    }
+    gp_joint[it] = g;
+  }
+  cost_pt = row16_sum(cost_pt);
+  if (lane == 0) a.out_cost[n] = cost_pt;
+  point_vjp_gather(c, h, any_grad, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < (64 + kFkLanes - 1) / kFkLanes; it++) {
+    const int d = it * kFkLanes + lane;
+    if (d < D) ia.out_grad_q[(size_t)n * D + d] = c.q[h * D + d] + gp_joint[it];
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -719,5 +925,84 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
 #undef CUROBO_FUSED_SWEEP
 #undef CUROBO_FUSED_KINDS
 #undef CUROBO_FUSED_LAUNCH
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres, int num_collision_pairs,
+                                                        int link_chain_len, int num_obstacles) {
+  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, num_collision_pairs, num_obstacles);
+  return lay.total * (int)sizeof(float);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
+    float *out_cost, float *out_grad_q, float *out_pose_distance, float *out_position_distance,
+    float *out_rotation_distance, int32_t *out_goalset_idx, float *out_link_pos, float *out_link_quat,
+    float *out_robot_spheres, float *out_cspace_cost, const float *q, const float *goal_position, const float *goal_quat,
+    const int32_t *idxs_goal, const float *position_orientation_weight, const float *terminal_pose_axes_weight_factor,
+    const float *terminal_pose_convergence_tolerance, const uint8_t *project_distance_to_goal, int num_goalset,
+    int rotation_method, const float *p_b, const float *cspace_weight, const float *cspace_activation_distance,
+    const float *fixed_transform, const float *robot_spheres, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *tool_frame_map, const int16_t *link_sphere_map,
+    const int16_t *link_chain_data, const int16_t *link_chain_offsets, const float *joint_offset_map,
+    const float *sphere_padding, const float *self_collision_weight, const int16_t *pair_locations,
+    const curobo_hip_scene *scene, const float *scene_collision_weight, const float *activation_distance,
+    int batch_size, int dof, int num_links, int n_tool_frames, int num_spheres, int num_collision_pairs,
+    int link_chain_len, curobo_hip_stream_t stream) {
+  const char *what = "rollout_ik_fused";
+  CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && dof <= 64, "%s: bad dimensions", what);
+  CUROBO_REQUIRE(n_tool_frames >= 1 && num_goalset >= 1, "%s: need at least one tool frame / goal", what);
+  CUROBO_REQUIRE(link_chain_len >= 1, "%s: link_chain_len must be >= 1", what);
+  CUROBO_REQUIRE(num_spheres < 4096, "%s: at most 4095 spheres", what);
+  CUROBO_REQUIRE(((uintptr_t)pair_locations & 3) == 0, "%s: pair_locations must be 4-byte aligned", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  FusedIkArgs ia{};
+  FusedTrajArgs &a = ia.r;
+  a.out_cost = out_cost; a.out_spheres = out_robot_spheres;
+  a.bs.dof = dof;
+  a.fixed_transform = fixed_transform; a.robot_spheres = robot_spheres; a.joint_offset = joint_offset_map;
+  a.joint_map_type = joint_map_type; a.joint_map = joint_map; a.link_map = link_map; a.link_sphere_map = link_sphere_map;
+  a.link_chain_data = link_chain_data; a.link_chain_offsets = link_chain_offsets;
+  a.sphere_padding = sphere_padding; a.w_self = self_collision_weight; a.pairs = pair_locations;
+  a.use_self = (pair_locations && self_collision_weight && num_collision_pairs > 0) ? 1 : 0;
+  a.use_scene = (scene && scene_collision_weight) ? 1 : 0;
+  if (scene) a.sc = *scene;
+  if (!a.use_scene) { a.sc.max_cuboids = 0; a.sc.max_voxel_grids = 0; }
+  a.w_scene = scene_collision_weight; a.eta = activation_distance;
+  a.batch = batch_size; a.nlinks = num_links; a.nspheres = num_spheres; a.npairs = a.use_self ? num_collision_pairs : 0;
+  a.chain_len = link_chain_len; a.num_envs = 1; a.use_multi_env = 0;
+  ia.x = q; ia.out_grad_q = out_grad_q; ia.tool_frame_map = tool_frame_map; ia.n_tool_frames = n_tool_frames;
+  ia.n_points = batch_size; ia.out_link_pos = out_link_pos; ia.out_link_quat = out_link_quat;
+  ToolPoseArgs &tp = ia.tp;
+  tp.out_distance = out_pose_distance; tp.out_position_distance = out_position_distance;
+  tp.out_rotation_distance = out_rotation_distance; tp.out_goalset_idx = out_goalset_idx;
+  tp.goal_position = goal_position; tp.goal_quat = goal_quat; tp.idxs_goal = idxs_goal;
+  tp.position_orientation_weight = position_orientation_weight;
+  tp.terminal_axes_weight = terminal_pose_axes_weight_factor; tp.non_terminal_axes_weight = terminal_pose_axes_weight_factor;
+  tp.terminal_tolerance = terminal_pose_convergence_tolerance; tp.non_terminal_tolerance = terminal_pose_convergence_tolerance;
+  tp.project_distance_to_goal = project_distance_to_goal;
+  tp.batch = batch_size; tp.horizon = 1; tp.num_links = n_tool_frames; tp.num_goalset = num_goalset; tp.rotation_method = rotation_method;
+  CUROBO_REQUIRE(rotation_method >= 0 && rotation_method <= 2, "%s: rotation_method must be 0, 1 or 2", what);
+  // c-space bound term only (no effort, target or velocity-limited bounds in the IK cost set)
+  ia.p_b = p_b; ia.cs_weight = cspace_weight; ia.cs_eta = cspace_activation_distance; ia.out_cspace_cost = out_cspace_cost;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
+  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec);
+  const size_t lds = (size_t)lay.total * sizeof(float);
+  CUROBO_REQUIRE(lds <= 160 * 1024, "%s: 16 configurations do not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
+  const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
+  const dim3 grid((unsigned)ceil_div(batch_size, kIkPoints)), block(kIkPoints * kFkLanes);
+#define CUROBO_IK_LAUNCH(KD)                                                                                    \
+  do {                                                                                                          \
+    auto kfn = rollout_ik_fused_kernel<KD>;                                                                     \
+    if (lds > 64 * 1024) {                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(e)); \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kfn, grid, block, lds, st, ia);                                                          \
+  } while (0)
+  if (kinds == 2) CUROBO_IK_LAUNCH(2);
+  else if (kinds == 3) CUROBO_IK_LAUNCH(3);
+  else CUROBO_IK_LAUNCH(1);
+#undef CUROBO_IK_LAUNCH
   return check_launch(what, st);
 }

@@ -17,6 +17,7 @@ from ..backends import collision as collision_hip
 from ..backends import cost as cost_hip
 from ..backends import geometry as geometry_hip
 from ..backends import kinematics as kinematics_hip
+from ..backends import rollout as rollout_hip
 from ..robot.kinematics_params import KinematicsParams
 from ..scene.data import SceneData
 
@@ -33,6 +34,9 @@ class IKRolloutCfg:
     scene_collision_weight: float = 5000.0
     scene_activation_distance: float = 0.0
     self_collision_weight: float = 5000.0
+    #: one fused launch (csrc/rollout_fused.hip, rollout_ik_fused_kernel) for cost + gradient when 16
+    #: configurations fit in LDS; False = the seven drop-in launches
+    use_fused: bool = True
 
 
 class IKRollout:
@@ -62,6 +66,7 @@ class IKRollout:
         self._w_scene, self._eta_scene = f([c.scene_collision_weight]), f([c.scene_activation_distance])
         self._w_self = f([c.self_collision_weight])
         self.batch_size = 0
+        self._fused_ok: Optional[bool] = None
         self.update_batch_size(batch_size)
 
     def update_batch_size(self, B: int) -> None:
@@ -141,7 +146,38 @@ class IKRollout:
             D, S)
         return self.cost
 
+    # ------------------------------------------------------------------ fused
+    def fused_available(self) -> bool:
+        k = self.kin
+        n_obs = (self.scene.struct.max_cuboids + self.scene.struct.max_voxel_grids) if self.scene is not None else 0
+        need = rollout_hip.rollout_ik_fused_lds_bytes(
+            k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
+            int(k.link_chain_data.shape[0]), n_obs)
+        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64 and k.num_envs == 1
+
+    def cost_and_gradient_fused(self, q: torch.Tensor, with_metrics: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Same numbers as ``evaluate`` from one launch; ``with_metrics`` also fills the pose-error,
+        link-pose and sphere buffers the solver's metrics read."""
+        k, B, c = self.kin, self.batch_size, self.cfg
+        sc = k.self_collision
+        m = with_metrics
+        rollout_hip.rollout_ik_fused(
+            self.cost, self.grad_q, self.pose_cost if m else None, self.pose_pos_dist if m else None,
+            self.pose_rot_dist if m else None, self.goalset_idx if m else None, self.link_pos if m else None,
+            self.link_quat if m else None, self.robot_spheres if m else None, self.cspace_cost if m else None,
+            q, self.goal_position, self.goal_quat, self.idxs_goal, self._pose_w, self._axes_w, self._tol, self._project,
+            self.num_goalset, c.rotation_method, self._p_b, self._cs_w, self._cs_eta, k.fixed_transforms, k.link_spheres,
+            k.joint_map_type, k.joint_map, k.link_map, k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data,
+            k.link_chain_offsets, k.joint_offset_map, sc.sphere_padding, self._w_self, sc.collision_pairs,
+            self.scene.struct if self.scene is not None else None, self._w_scene, self._eta_scene, B, k.num_dof)
+        return self.cost, self.grad_q.view(B, -1)
+
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x[B, D] -> (cost[B], grad[B, D]) in static buffers (graph friendly)."""
+        if self.cfg.use_fused:
+            if self._fused_ok is None:
+                self._fused_ok = self.fused_available()
+            if self._fused_ok:
+                return self.cost_and_gradient_fused(x.view(self.batch_size, self.action_dim).contiguous())
         cost = self.evaluate(x.view(self.batch_size, 1, self.action_dim), with_gradient=True)
         return cost, self.grad_q.view(self.batch_size, -1)

@@ -275,6 +275,39 @@ int curobo_hip_rollout_trajectory_fused_lds_bytes(
     int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int num_obstacles);
 
+/* Horizon-1 (IK / teleport) rollout in one launch: q[b, dof] -> FK -> tool-pose goal-set cost
+ * (curobo_hip_tool_pose_distance semantics, terminal weights) + joint-limit term of the c-space
+ * cost (weight[0], activation_distance[0], limits p_b[2, dof]) + self collision + scene collision
+ * (no sweep) -> out_cost[b] and out_grad_q[b, dof].  Replaces the launch sequence kinematics
+ * forward, tool_pose_distance, cspace_position_cost, self_collision_distance,
+ * sphere_obstacle_collision, kinematics backward, rollout_point_aggregate (reference: RobotRollout
+ * with StateFromPositionTeleport and content/configs/task/ik/lbfgs_ik.yml).  Optional outputs
+ * (NULL = skip): out_pose_distance [b, T, 2], out_position_distance / out_rotation_distance /
+ * out_goalset_idx [b, T], out_link_pos [b, T, 3], out_link_quat [b, T, 4] (wxyz),
+ * out_robot_spheres [b, S, 4], out_cspace_cost [b, dof].  Single scene environment. */
+int curobo_hip_rollout_ik_fused(
+    float *out_cost, float *out_grad_q, float *out_pose_distance, float *out_position_distance,
+    float *out_rotation_distance, int32_t *out_goalset_idx, float *out_link_pos,
+    float *out_link_quat, float *out_robot_spheres, float *out_cspace_cost, const float *q,
+    const float *goal_position, const float *goal_quat, const int32_t *idxs_goal,
+    const float *position_orientation_weight, const float *terminal_pose_axes_weight_factor,
+    const float *terminal_pose_convergence_tolerance, const uint8_t *project_distance_to_goal,
+    int num_goalset, int rotation_method, const float *p_b, const float *cspace_weight,
+    const float *cspace_activation_distance, const float *fixed_transform,
+    const float *robot_spheres, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *tool_frame_map, const int16_t *link_sphere_map,
+    const int16_t *link_chain_data, const int16_t *link_chain_offsets,
+    const float *joint_offset_map, const float *sphere_padding,
+    const float *self_collision_weight, const int16_t *pair_locations,
+    const curobo_hip_scene *scene, const float *scene_collision_weight,
+    const float *activation_distance, int batch_size, int dof, int num_links, int n_tool_frames,
+    int num_spheres, int num_collision_pairs, int link_chain_len, curobo_hip_stream_t stream);
+
+/* LDS bytes of one 16-configuration workgroup of curobo_hip_rollout_ik_fused (usable when <= 163840) */
+int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres,
+                                          int num_collision_pairs, int link_chain_len,
+                                          int num_obstacles);
+
 /* Development hook: device buffer [batch, 16] (int64) that receives 100 MHz wall-clock stamps at
  * the phase boundaries (start, tables+spline, FK, costs+VJP, end) of every fused launch; NULL
  * (default) turns it off.  Used by tools/profile_fused.py. */

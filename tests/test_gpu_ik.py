@@ -93,15 +93,17 @@ def _ik_setup(device, P=6, S=16):
     return model, kin, arrays, scene
 
 
-def test_ik_rollout_matches_oracle_composition(oracle, device):
-    from curobo_amd.rollout.ik_rollout import IKRollout
+@pytest.mark.parametrize("fused", [False, True])
+def test_ik_rollout_matches_oracle_composition(fused, oracle, device):
+    from curobo_amd.rollout.ik_rollout import IKRollout, IKRolloutCfg
 
     model, kin, arrays, scene = _ik_setup(device)
     md = model.as_dict()
     B = 40
     q = sample_q(model, B, seed=5, scale=1.05)  # a few rows violate the joint limits
     goals = oracle.kinematics_forward(sample_q(model, 4, seed=6, scale=0.7), md)
-    ro = IKRollout(kin, scene, B)
+    ro = IKRollout(kin, scene, B, IKRolloutCfg(use_fused=fused))
+    assert ro.fused_available()
     idx = np.arange(B, dtype=np.int32) % 4
     ro.update_goals(torch.as_tensor(goals["link_pos"].reshape(4, 1, 1, 3)), torch.as_tensor(goals["link_quat"].reshape(4, 1, 1, 4)),
                     torch.as_tensor(idx, device=device))
@@ -126,6 +128,48 @@ def test_ik_rollout_matches_oracle_composition(oracle, device):
     gq = oracle.kinematics_backward(md, fk["cumul_mat"], gs, pose["position_gradient"].reshape(B, 1, 3),
                                     pose["rotation_gradient"].reshape(B, 1, 4)) + cs["grad_position"].reshape(B, 7)
     np.testing.assert_allclose(grad.cpu().numpy(), gq, rtol=2e-3, atol=2e-5 * np.abs(gq).max())
+
+
+@pytest.mark.parametrize("robot,method", [("franka", 0), ("franka", 2), ("unitree_g1", 1)])
+def test_ik_fused_equals_kernel_sequence(robot, method, device):
+    """one-launch IK rollout vs the seven drop-in launches: cost, gradient and every metric buffer
+    (G1: 4 tool frames, 49 dof, goal sets of 3; the tiled self-collision kernel on the other side)"""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout.ik_rollout import IKRollout, IKRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c1_world
+
+    model = load_model(robot)
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
+    B, T, G, NG = 53, kin.num_pose_links, 3, 5
+    rng = np.random.default_rng(9)
+    q = torch.as_tensor(sample_q(model, B, seed=5, scale=1.05), device=device)
+    gpos = torch.as_tensor(rng.normal(size=(NG, T, G, 3)).astype(np.float32) * 0.5, device=device)
+    gq = rng.normal(size=(NG, T, G, 4)).astype(np.float32)
+    gq /= np.linalg.norm(gq, axis=-1, keepdims=True)
+    idx = torch.as_tensor(rng.integers(0, NG, size=B).astype(np.int32), device=device)
+    outs = []
+    for fused in (False, True):
+        ro = IKRollout(kin, scene, B, IKRolloutCfg(use_fused=fused, rotation_method=method), num_goalset=G)
+        ro.update_goals(gpos, torch.as_tensor(gq, device=device), idx)
+        if fused:
+            if not ro.fused_available():
+                pytest.skip("16 configurations of this robot do not fit in LDS")
+            cost, grad = ro.cost_and_gradient_fused(q, with_metrics=True)
+        else:
+            cost, grad = ro.cost_and_gradient(q)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (cost, grad, ro.pose_cost, ro.pose_pos_dist, ro.pose_rot_dist, ro.goalset_idx,
+                                         ro.link_pos, ro.link_quat, ro.robot_spheres, ro.cspace_cost)])
+    ref, got = outs
+    assert torch.equal(ref[5], got[5]), "goal-set indices must be exact"
+    assert float(ref[0].max()) > 0
+    for i, (a_, b_) in enumerate(zip(ref, got)):
+        if i == 5:
+            continue
+        tol = dict(rtol=2e-3, atol=2e-5 * float(a_.abs().max())) if i == 1 else dict(rtol=2e-5, atol=2e-5 * max(1.0, float(a_.abs().max())))
+        torch.testing.assert_close(b_.reshape(a_.shape), a_, **tol)
 
 
 def test_ik_solver_end_to_end(oracle, device):
