@@ -102,3 +102,22 @@ def rollout_point_aggregate(
         ptr(out_cost), ptr(grad_q), ptr(pose_cost), ptr(cspace_cost), ptr(cspace_grad), ptr(self_cost),
         ptr(scene_cost), rows, num_links, dof, num_spheres, current_stream(out_cost),
     ))
+
+
+def cspace_state_cost(
+    out_cost, out_grad_p, out_grad_v, out_grad_a, out_grad_j, out_grad_tau, pos, vel, acc, jerk, effort, state_dt,
+    target_joint_position, idxs_target_joint_position, p_b, v_b, a_b, j_b, effort_b, weight, activation_distance,
+    squared_l2_regularization_weights, cspace_target_weight, cspace_non_terminal_weight_factor,
+    cspace_target_dof_weight, write_grad: bool, batch_size: int, horizon: int, dof: int,
+    retime_weights: bool = False, retime_regularization_weights: bool = False,
+):
+    """reference ``forward_cspace_state_warp`` (``cost/wp_cspace_state.py:20-287``), argument order =
+    the Warp kernel's inputs then outputs-first like the other backends."""
+    check(load().curobo_hip_cspace_state_cost(
+        ptr(out_cost), ptr(out_grad_p), ptr(out_grad_v), ptr(out_grad_a), ptr(out_grad_j), ptr(out_grad_tau), ptr(pos),
+        ptr(vel), ptr(acc), ptr(jerk), ptr(effort), ptr(state_dt), ptr(target_joint_position),
+        ptr(idxs_target_joint_position), ptr(p_b), ptr(v_b), ptr(a_b), ptr(j_b), ptr(effort_b), ptr(weight),
+        ptr(activation_distance), ptr(squared_l2_regularization_weights), ptr(cspace_target_weight),
+        ptr(cspace_non_terminal_weight_factor), ptr(cspace_target_dof_weight), int(write_grad), batch_size, horizon, dof,
+        int(retime_weights), int(retime_regularization_weights), current_stream(out_cost),
+    ))

@@ -71,6 +71,22 @@ __global__ void __launch_bounds__(256) rollout_point_aggregate_kernel(
   if (valid && lane == 0) out_cost[grp] = acc;
 }
 
+__global__ void __launch_bounds__(256) cspace_state_kernel(const CspaceStateArgs a) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.batch * a.horizon * a.dof;
+  if (tid >= total) return;
+  const int b = (int)(tid / ((long)a.horizon * a.dof));
+  const int h = (int)((tid - (long)b * a.horizon * a.dof) / a.dof);
+  const int d = (int)(tid % a.dof);
+  const float x[5] = {a.pos[tid], a.vel[tid], a.acc[tid], a.jerk[tid], a.effort ? a.effort[tid] : 0.0f};
+  float g[5];
+  a.out_cost[tid] = cspace_state_point(a, b, h, d, x, g);
+  if (a.write_grad) {
+    a.out_gp[tid] = g[0]; a.out_gv[tid] = g[1]; a.out_ga[tid] = g[2]; a.out_gj[tid] = g[3];
+    if (a.out_gtau) a.out_gtau[tid] = g[4];
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -134,5 +150,28 @@ CUROBO_EXPORT int curobo_hip_rollout_point_aggregate(float *out_cost, float *gra
   hipLaunchKernelGGL(rollout_point_aggregate_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, st, out_cost,
                      grad_q, pose_cost, cspace_cost, cspace_grad, self_cost, scene_cost, rows, num_links, dof,
                      num_spheres);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_cspace_state_cost(
+    float *out_cost, float *out_grad_p, float *out_grad_v, float *out_grad_a, float *out_grad_j, float *out_grad_tau,
+    const float *pos, const float *vel, const float *acc, const float *jerk, const float *effort, const float *state_dt,
+    const float *target_joint_position, const int32_t *idxs_target_joint_position, const float *p_b, const float *v_b,
+    const float *a_b, const float *j_b, const float *effort_b, const float *weight, const float *activation_distance,
+    const float *squared_l2_regularization_weights, const float *cspace_target_weight,
+    const float *cspace_non_terminal_weight_factor, const float *cspace_target_dof_weight, int write_grad,
+    int batch_size, int horizon, int dof, int retime_weights, int retime_regularization_weights,
+    curobo_hip_stream_t stream) {
+  const char *what = "cspace_state_cost";
+  CUROBO_REQUIRE(horizon >= 1 && dof >= 1, "%s: bad dimensions", what);
+  CUROBO_REQUIRE(!write_grad || (out_grad_p && out_grad_v && out_grad_a && out_grad_j), "%s: gradient buffers are NULL", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  CspaceStateArgs a{out_cost, out_grad_p, out_grad_v, out_grad_a, out_grad_j, out_grad_tau, pos, vel, acc, jerk, effort,
+                    state_dt, target_joint_position, idxs_target_joint_position, p_b, v_b, a_b, j_b, effort_b, weight,
+                    activation_distance, squared_l2_regularization_weights, cspace_target_weight,
+                    cspace_non_terminal_weight_factor, cspace_target_dof_weight, write_grad, batch_size, horizon, dof,
+                    retime_weights, retime_regularization_weights};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cspace_state_kernel, dim3((unsigned)ceil_div_l((long)batch_size * horizon * dof, 256)), dim3(256), 0, st, a);
   return check_launch(what, st);
 }

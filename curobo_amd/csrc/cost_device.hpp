@@ -215,4 +215,65 @@ __device__ __forceinline__ float cspace_position_point(const CspacePosArgs &a, i
   return c;
 }
 
+// ------------------------------------------------------------------------------------------
+// c-space STATE cost (curobo/_src/cost/wp_cspace_state.py:20-287, cost/warp_bound_util.py)
+struct CspaceStateArgs {
+  float *out_cost, *out_gp, *out_gv, *out_ga, *out_gj, *out_gtau;
+  const float *pos, *vel, *acc, *jerk, *effort, *state_dt, *target;
+  const int32_t *idxs_target;
+  const float *p_b, *v_b, *a_b, *j_b, *effort_b, *weight, *activation_distance, *sql2_weights;
+  const float *target_weight, *non_terminal_factor, *target_dof_weight;
+  int write_grad, batch, horizon, dof, retime_weights, retime_reg_weights;
+};
+
+__device__ __forceinline__ void squared_l2_term(float x, float w, float &c, float &g) {
+  const float wv = w * x;
+  c += 0.5f * wv * x;
+  g += wv;
+}
+__device__ __forceinline__ void bound_term(float x, const float *lim, int dof, int d, float eta, float w, float &c, float &g) {
+  float lo = lim[d], hi = lim[dof + d];
+  const float r = hi - lo;
+  lo = lo + eta * r;
+  hi = hi - eta * r;
+  if (x < lo) squared_l2_term(x - lo, w, c, g);
+  else if (x > hi) squared_l2_term(x - hi, w, c, g);
+}
+
+// one (batch, horizon, dof) entry: x = (position, velocity, acceleration, jerk, effort) -> cost, g[5]
+__device__ __forceinline__ float cspace_state_point(const CspaceStateArgs &a, int b, int h, int d, const float (&x)[5],
+                                                    float (&g)[5]) {
+  const float dt = a.state_dt[b];
+  float wb[5], wr[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) { wb[i] = a.weight[i]; wr[i] = a.sql2_weights[i]; g[i] = 0.0f; }
+  if (a.retime_weights) { wb[1] = dt * wb[1]; wb[2] = powf(dt, 2.0f) * wb[2]; wb[3] = powf(dt, 3.0f) * wb[3]; }
+  if (a.retime_reg_weights) { wr[0] = dt * wr[0]; wr[1] = powf(dt, 2.0f) * wr[1]; wr[2] = powf(dt, 3.0f) * wr[2]; wr[4] = dt * wr[4]; }
+  float c = 0.0f;
+  bound_term(x[0], a.p_b, a.dof, d, a.activation_distance[0], wb[0], c, g[0]);
+  bound_term(x[1], a.v_b, a.dof, d, a.activation_distance[1], wb[1], c, g[1]);
+  bound_term(x[2], a.a_b, a.dof, d, a.activation_distance[2], wb[2], c, g[2]);
+  bound_term(x[3], a.j_b, a.dof, d, a.activation_distance[3], wb[3], c, g[3]);
+  bound_term(x[4], a.effort_b, a.dof, d, a.activation_distance[4], wb[4], c, g[4]);
+  float tw = a.target_weight[0];
+  if (h < a.horizon - 1) tw *= a.non_terminal_factor[0];
+  if (tw > 0.0f) {
+    tw *= a.target_dof_weight[d];
+    const float e = x[0] - a.target[(size_t)a.idxs_target[b] * a.dof + d];
+    c += tw * e * e;
+    g[0] += 2.0f * tw * e;
+  }
+  squared_l2_term(x[1], wr[0], c, g[1]);
+  squared_l2_term(x[2], wr[1], c, g[2]);
+  squared_l2_term(x[3], wr[2], c, g[3]);
+  squared_l2_term(x[4], wr[3], c, g[4]);
+  if (wr[4] > 0.0f) {  // aggregate_energy_regularization
+    const float e = x[4] * x[1] * dt;
+    c += wr[4] * e * e;
+    g[4] += 2.0f * wr[4] * e * x[1] * dt;
+    g[1] += 2.0f * wr[4] * e * x[4] * dt;
+  }
+  return c;
+}
+
 }  // namespace curobo_hip

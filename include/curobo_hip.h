@@ -176,6 +176,21 @@ int curobo_hip_cspace_position_cost(
     const float *state_dt, int write_grad, int batch_size, int horizon, int dof,
     curobo_hip_stream_t stream);
 
+/* c-space STATE cost (reference cost/wp_cspace_state.py:20-287, a Warp kernel): bound costs on
+ * position / velocity / acceleration / jerk / effort, optional joint target, squared-L2 and
+ * energy regularisation.  weight, activation_distance, squared_l2_regularization_weights: [5];
+ * limits [2, dof] each; state_dt [batch]; effort / out_grad_tau may be NULL. */
+int curobo_hip_cspace_state_cost(
+    float *out_cost, float *out_grad_p, float *out_grad_v, float *out_grad_a, float *out_grad_j,
+    float *out_grad_tau, const float *pos, const float *vel, const float *acc, const float *jerk,
+    const float *effort, const float *state_dt, const float *target_joint_position,
+    const int32_t *idxs_target_joint_position, const float *p_b, const float *v_b,
+    const float *a_b, const float *j_b, const float *effort_b, const float *weight,
+    const float *activation_distance, const float *squared_l2_regularization_weights,
+    const float *cspace_target_weight, const float *cspace_non_terminal_weight_factor,
+    const float *cspace_target_dof_weight, int write_grad, int batch_size, int horizon, int dof,
+    int retime_weights, int retime_regularization_weights, curobo_hip_stream_t stream);
+
 /* Per-row aggregation for horizon-1 (teleport / IK) rollouts (reference: torch cat+sum and autograd
  * accumulation, rollout/metrics.py:233-265): out_cost[r] = sum(pose_cost[r,:2*num_links]) +
  * sum(cspace_cost[r,:dof]) + self_cost[r] + sum(scene_cost[r,:num_spheres]);

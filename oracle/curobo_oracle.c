@@ -1175,6 +1175,81 @@ ORC_API void orc_integration_acceleration(float *out_pos, float *out_vel, float 
 }
 
 
+
+/* c-space STATE cost (curobo/_src/cost/wp_cspace_state.py:20-287, helpers cost/warp_bound_util.py):
+ * per (batch, horizon, dof): hinge^2 bound costs on position / velocity / acceleration / jerk /
+ * effort (limits shrunk by activation_distance * range), optional joint-position target (scaled by
+ * the non-terminal factor before the last step), squared-L2 regularisation of velocity /
+ * acceleration / jerk / effort and the energy term (tau qd dt)^2.  weight, activation_distance and
+ * squared_l2_regularization_weights have 5 entries; state_dt is per trajectory. */
+static void orc_bound(float x, float lo, float hi, float w, float *cost, float *grad) {
+  float delta;
+  if (x < lo) delta = x - lo;
+  else if (x > hi) delta = x - hi;
+  else return;
+  const float wv = w * delta;
+  *cost += 0.5f * wv * delta;
+  *grad += wv;
+}
+static void orc_sql2(float x, float w, float *cost, float *grad) {
+  const float wv = w * x;
+  *cost += 0.5f * wv * x;
+  *grad += wv;
+}
+ORC_API void orc_cspace_state_cost(
+    float *out_cost, float *out_gp, float *out_gv, float *out_ga, float *out_gj, float *out_gtau, const float *pos,
+    const float *vel, const float *acc, const float *jerk, const float *effort, const float *state_dt,
+    const float *target, const int32_t *idxs_target, const float *p_b, const float *v_b, const float *a_b,
+    const float *j_b, const float *effort_b, const float *weight, const float *activation_distance,
+    const float *sql2_weights, const float *target_weight, const float *non_terminal_factor,
+    const float *target_dof_weight, int write_grad, int batch, int horizon, int dof, int retime_weights,
+    int retime_regularization_weights) {
+  const long total = (long)batch * horizon * dof;
+#pragma omp parallel for schedule(static)
+  for (long tid = 0; tid < total; tid++) {
+    const int b = (int)(tid / ((long)horizon * dof));
+    const int h = (int)((tid - (long)b * horizon * dof) / dof);
+    const int d = (int)(tid % dof);
+    const float dt = state_dt[b];
+    float tw = target_weight[0];
+    if (h < horizon - 1) tw *= non_terminal_factor[0];
+    float wb[5], wr[5];
+    for (int i = 0; i < 5; i++) { wb[i] = weight[i]; wr[i] = sql2_weights[i]; }
+    if (retime_weights) { wb[1] = dt * wb[1]; wb[2] = powf(dt, 2.0f) * wb[2]; wb[3] = powf(dt, 3.0f) * wb[3]; }
+    if (retime_regularization_weights) {
+      wr[0] = dt * wr[0]; wr[1] = powf(dt, 2.0f) * wr[1]; wr[2] = powf(dt, 3.0f) * wr[2]; wr[4] = dt * wr[4];
+    }
+    const float x[5] = {pos[tid], vel[tid], acc[tid], jerk[tid], effort ? effort[tid] : 0.0f};
+    const float *lim[5] = {p_b, v_b, a_b, j_b, effort_b};
+    float c = 0.0f, g[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; i++) {
+      float lo = lim[i][d], hi = lim[i][dof + d];
+      const float r = hi - lo;
+      lo = lo + activation_distance[i] * r;
+      hi = hi - activation_distance[i] * r;
+      orc_bound(x[i], lo, hi, wb[i], &c, &g[i]);
+    }
+    if (tw > 0.0f) {
+      tw *= target_dof_weight[d];
+      const float e = x[0] - target[(size_t)idxs_target[b] * dof + d];
+      c += tw * e * e;
+      g[0] += 2.0f * tw * e;
+    }
+    orc_sql2(x[1], wr[0], &c, &g[1]);
+    orc_sql2(x[2], wr[1], &c, &g[2]);
+    orc_sql2(x[3], wr[2], &c, &g[3]);
+    orc_sql2(x[4], wr[3], &c, &g[4]);
+    if (wr[4] > 0.0f) { /* aggregate_energy_regularization */
+      const float e = x[4] * x[1] * dt;
+      c += wr[4] * e * e;
+      g[4] += 2.0f * wr[4] * e * x[1] * dt;
+      g[1] += 2.0f * wr[4] * e * x[4] * dt;
+    }
+    out_cost[tid] = c;
+    if (write_grad) { out_gp[tid] = g[0]; out_gv[tid] = g[1]; out_ga[tid] = g[2]; out_gj[tid] = g[3]; out_gtau[tid] = g[4]; }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * A8. Inverse dynamics: body-frame RNEA and its VJP (config 4).
  *     kernels/dynamics/rnea_forward_kernel.cuh:53-292, rnea_backward_kernel.cuh:65-468,

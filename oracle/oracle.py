@@ -81,6 +81,7 @@ class Oracle:
             "orc_trajectory_cost_sum",
             "orc_tool_pose_distance",
             "orc_cspace_position_cost",
+            "orc_cspace_state_cost",
             "orc_set_num_threads",
         ):
             getattr(self.lib, name).restype = None
@@ -534,6 +535,29 @@ class Oracle:
             C.c_int(1), C.c_int(b), C.c_int(h), C.c_int(d),
         )
         return {"cost": out_c, "grad_position": out_gp, "grad_effort": out_gt}
+
+    def cspace_state_cost(self, pos, vel, acc, jerk, state_dt, limits, weight, activation_distance, sql2_weights,
+                          effort=None, target=None, idxs_target=None, target_weight=0.0, non_terminal_factor=1.0,
+                          target_dof_weight=None, retime_weights=False, retime_regularization_weights=False):
+        """reference CSpaceStateCost kernel; ``limits`` = dict position/velocity/acceleration/jerk/effort -> [2, dof]."""
+        p = _f32(pos)
+        b, h, d = p.shape
+        z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+        big = np.stack([-1e9 * np.ones(d), 1e9 * np.ones(d)]).astype(np.float32)
+        lim = [_f32(limits.get(k, big)) for k in ("position", "velocity", "acceleration", "jerk", "effort")]
+        outs = [z(b, h, d) for _ in range(6)]
+        self.lib.orc_cspace_state_cost(
+            *[_ptr(o) for o in outs], _ptr(p), _ptr(_f32(vel)), _ptr(_f32(acc)), _ptr(_f32(jerk)),
+            _ptr(_f32(effort)) if effort is not None else None, _ptr(_f32(state_dt)),
+            _ptr(_f32(target) if target is not None else z(1, d)),
+            _ptr(np.ascontiguousarray(idxs_target if idxs_target is not None else np.zeros(b), np.int32)),
+            *[_ptr(x) for x in lim], _ptr(_f32(weight)), _ptr(_f32(activation_distance)), _ptr(_f32(sql2_weights)),
+            _ptr(np.array([target_weight], np.float32)), _ptr(np.array([non_terminal_factor], np.float32)),
+            _ptr(_f32(target_dof_weight) if target_dof_weight is not None else np.ones(d, np.float32)),
+            C.c_int(1), C.c_int(b), C.c_int(h), C.c_int(d), C.c_int(int(retime_weights)),
+            C.c_int(int(retime_regularization_weights)))
+        keys = ("cost", "grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")
+        return dict(zip(keys, outs))
 
     def trajectory_cost_sum(self, self_cost, scene_cost):
         sc = _f32(scene_cost)

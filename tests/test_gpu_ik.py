@@ -203,3 +203,32 @@ def test_ik_solver_end_to_end(oracle, device):
     s2 = chk["robot_spheres"].reshape(len(qs), 1, -1, 4)
     assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
     assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
+
+
+@pytest.mark.parametrize("retime", [False, True])
+def test_cspace_state_kernel(retime, oracle, device):
+    from curobo_amd.backends import cost as Cs
+
+    rng = np.random.default_rng(3)
+    b, h, d = 41, 9, 7
+    x = {k: rng.normal(size=(b, h, d)).astype(np.float32) * s for k, s in
+         (("pos", 2.0), ("vel", 3.0), ("acc", 8.0), ("jerk", 30.0), ("effort", 40.0))}
+    lim = {k: np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * s for k, s in
+           (("position", 1.5), ("velocity", 2.0), ("acceleration", 6.0), ("jerk", 25.0), ("effort", 30.0))}
+    dt = rng.uniform(0.02, 0.1, size=b).astype(np.float32)
+    tgt = rng.normal(size=(3, d)).astype(np.float32)
+    tidx = rng.integers(0, 3, size=b).astype(np.int32)
+    dofw = rng.uniform(0.5, 1, size=d).astype(np.float32)
+    w, eta, reg = [50.0, 20.0, 5.0, 1.0, 2.0], [0.05, 0.1, 0.1, 0.1, 0.1], [0.3, 0.2, 0.1, 0.05, 0.4]
+    ref = oracle.cspace_state_cost(x["pos"], x["vel"], x["acc"], x["jerk"], dt, lim, w, eta, reg, effort=x["effort"], target=tgt,
+                                   idxs_target=tidx, target_weight=3.0, non_terminal_factor=0.25, target_dof_weight=dofw,
+                                   retime_weights=retime, retime_regularization_weights=retime)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32 if np.asarray(a).dtype.kind == "f" else None), device=device)  # noqa: E731
+    outs = [torch.zeros(b, h, d, device=device) for _ in range(6)]
+    Cs.cspace_state_cost(*outs, t(x["pos"]), t(x["vel"]), t(x["acc"]), t(x["jerk"]), t(x["effort"]), t(dt), t(tgt), t(tidx),
+                         t(lim["position"]), t(lim["velocity"]), t(lim["acceleration"]), t(lim["jerk"]), t(lim["effort"]),
+                         t(np.array(w, np.float32)), t(np.array(eta, np.float32)), t(np.array(reg, np.float32)),
+                         t(np.array([3.0], np.float32)), t(np.array([0.25], np.float32)), t(dofw), True, b, h, d, retime, retime)
+    torch.cuda.synchronize()
+    for o, k in zip(outs, ("cost", "grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")):
+        np.testing.assert_allclose(o.cpu().numpy(), ref[k], rtol=2e-5, atol=2e-5 * max(1.0, np.abs(ref[k]).max()), err_msg=k)

@@ -122,3 +122,71 @@ def test_cspace_position_regularisers(oracle):
     np.testing.assert_allclose(out["cost"][0, 0], want, rtol=1e-5)
     wantg = 8.0 * pos[0, 0] + (2.0 * dt) * v / dt + (3.0 * dt * dt) * a / (dt * dt)
     np.testing.assert_allclose(out["grad_position"][0, 0], wantg, rtol=1e-5)
+
+
+def _state_case(rng, b=5, h=6, d=4):
+    x = {k: rng.normal(size=(b, h, d)).astype(np.float32) * s for k, s in
+         (("pos", 2.0), ("vel", 3.0), ("acc", 8.0), ("jerk", 30.0), ("effort", 40.0))}
+    lim = {"position": np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * 1.5,
+           "velocity": np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * 2.0,
+           "acceleration": np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * 6.0,
+           "jerk": np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * 25.0,
+           "effort": np.stack([-np.ones(d), np.ones(d)]).astype(np.float32) * 30.0}
+    return x, lim
+
+
+def test_cspace_state_cost_gradients_are_exact_derivatives(oracle):
+    """every term is a piecewise quadratic of its own input (wp_cspace_state.py:170-260): the
+    returned gradients must be the central finite differences of the summed cost"""
+    rng = np.random.default_rng(0)
+    x, lim = _state_case(rng)
+    b, h, d = x["pos"].shape
+    kw = dict(state_dt=np.full(b, 0.05, np.float32), limits=lim, weight=[50.0, 20.0, 5.0, 1.0, 2.0],
+              activation_distance=[0.05, 0.1, 0.1, 0.1, 0.1], sql2_weights=[0.3, 0.2, 0.1, 0.05, 0.4],
+              target=rng.normal(size=(2, d)).astype(np.float32), idxs_target=rng.integers(0, 2, size=b),
+              target_weight=3.0, non_terminal_factor=0.25, target_dof_weight=rng.uniform(0.5, 1, size=d).astype(np.float32))
+    ref = oracle.cspace_state_cost(x["pos"], x["vel"], x["acc"], x["jerk"], effort=x["effort"], **kw)
+    assert (ref["cost"] > 0).all()
+    eps = 1e-2
+    names = (("pos", "grad_position"), ("vel", "grad_velocity"), ("acc", "grad_acceleration"), ("jerk", "grad_jerk"),
+             ("effort", "grad_effort"))
+    for key, gname in names:
+        xp, xm = dict(x), dict(x)
+        xp[key] = x[key] + eps
+        xm[key] = x[key] - eps
+        cp = oracle.cspace_state_cost(xp["pos"], xp["vel"], xp["acc"], xp["jerk"], effort=xp["effort"], **kw)["cost"]
+        cm = oracle.cspace_state_cost(xm["pos"], xm["vel"], xm["acc"], xm["jerk"], effort=xm["effort"], **kw)["cost"]
+        fd = (cp.astype(np.float64) - cm) / (2 * eps)
+        # a bound kink inside [x - eps, x + eps] makes the FD a blend: compare away from kinks
+        g = ref[gname]
+        ok = np.abs(fd - g) <= 2e-2 * np.maximum(1.0, np.abs(g))
+        assert ok.mean() > 0.9, (key, ok.mean())
+
+
+def test_cspace_state_cost_semantics(oracle):
+    rng = np.random.default_rng(1)
+    x, lim = _state_case(rng)
+    b, h, d = x["pos"].shape
+    z5 = [0.0] * 5
+    base = dict(state_dt=np.full(b, 0.1, np.float32), limits=lim, activation_distance=z5)
+    # inside all limits and without regularisation the cost is zero
+    small = {k: v * 0.0 for k, v in x.items()}
+    r0 = oracle.cspace_state_cost(small["pos"], small["vel"], small["acc"], small["jerk"], weight=[1.0] * 5, sql2_weights=z5, **base)
+    assert np.all(r0["cost"] == 0.0)
+    # position bound only: 0.5 w (x - limit)^2 outside, limits shrunk by eta * range
+    r1 = oracle.cspace_state_cost(x["pos"], small["vel"], small["acc"], small["jerk"], weight=[10.0, 0, 0, 0, 0], sql2_weights=z5,
+                                  state_dt=base["state_dt"], limits=lim, activation_distance=[0.1, 0, 0, 0, 0])
+    lo, hi = -1.5 + 0.1 * 3.0, 1.5 - 0.1 * 3.0
+    delta = np.where(x["pos"] < lo, x["pos"] - lo, np.where(x["pos"] > hi, x["pos"] - hi, 0.0))
+    np.testing.assert_allclose(r1["cost"], 0.5 * 10.0 * delta ** 2, rtol=1e-5, atol=1e-6)
+    # retimed weights scale with dt, dt^2, dt^3
+    r2 = oracle.cspace_state_cost(small["pos"], x["vel"], x["acc"], x["jerk"], weight=z5, sql2_weights=[1.0, 1.0, 1.0, 0, 0],
+                                  retime_regularization_weights=True, **base)
+    want = 0.5 * (0.1 * x["vel"] ** 2 + 0.1 ** 2 * x["acc"] ** 2 + 0.1 ** 3 * x["jerk"] ** 2)
+    np.testing.assert_allclose(r2["cost"], want, rtol=2e-5, atol=1e-5)
+    # the joint target is down-weighted before the last step
+    tgt = np.zeros((1, d), np.float32)
+    r3 = oracle.cspace_state_cost(x["pos"], small["vel"], small["acc"], small["jerk"], weight=z5, sql2_weights=z5, target=tgt,
+                                  target_weight=2.0, non_terminal_factor=0.5, **base)
+    np.testing.assert_allclose(r3["cost"][:, -1], 2.0 * x["pos"][:, -1] ** 2, rtol=1e-5)
+    np.testing.assert_allclose(r3["cost"][:, 0], 1.0 * x["pos"][:, 0] ** 2, rtol=1e-5)
