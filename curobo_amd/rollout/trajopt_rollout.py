@@ -1,0 +1,221 @@
+"""The full trajectory-optimisation rollout: B-spline knots -> (q, qd, qdd, qddd) -> FK -> tool-pose
+goal cost + c-space STATE cost (bounds, smoothness) + self + swept scene collision, and the analytic
+gradient back to the knots.
+
+Cost set and weights = the reference trajopt task ``content/configs/task/trajopt/
+lbfgs_bspline_trajopt.yml:38-100`` (``RobotRollout`` with ``StateFromBSplineKnot``; call stack in
+SURVEY.md section 3.2).  Like ``CollisionRollout`` the data path is a straight line of launches on
+static buffers (no autograd graph, hipGraph capturable); the pose / c-space kernels are the ones of
+the IK rollout, evaluated over the whole horizon (the pose cost only acts on the last point: the
+non-terminal axes weights are zero, as in the reference config).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+from ..backends import collision as collision_hip
+from ..backends import cost as cost_hip
+from ..backends import geometry as geometry_hip
+from ..backends import kinematics as kinematics_hip
+from ..backends import trajectory as trajectory_hip
+from ..robot.kinematics_params import KinematicsParams
+from ..scene.data import SceneData
+
+
+@dataclass
+class TrajOptRolloutCfg:
+    n_knots: int = 12
+    interpolation_steps: int = 2
+    bspline_degree: int = 3
+    traj_dt: float = 0.05
+    # constraint_cfg
+    self_collision_weight: float = 10000.0
+    scene_collision_weight: float = 100000.0
+    scene_activation_distance: float = 0.0025
+    use_sweep: bool = True
+    use_speed_metric: bool = True
+    # cost_cfg.tool_pose_cfg
+    pose_weight: List[float] = field(default_factory=lambda: [1000000.0, 100000.0])
+    pose_convergence_tolerance: List[float] = field(default_factory=lambda: [1e-8, 1e-8])
+    rotation_method: int = 0
+    # cost_cfg.cspace_cfg (cost_type STATE)
+    cspace_weight: List[float] = field(default_factory=lambda: [10000.0, 10000.0, 100.0, 50.0, 100.0])
+    cspace_activation_distance: List[float] = field(default_factory=lambda: [0.01] * 5)
+    cspace_regularization: List[float] = field(default_factory=lambda: [1000.0, 10000.0, 5.0, 0.0, 10000.0])
+    retime_weights: bool = True
+    retime_regularization_weights: bool = True
+    max_acceleration: float = 15.0  # content/configs/robot/franka.yml:48-49
+    max_jerk: float = 500.0
+
+    @property
+    def horizon(self) -> int:
+        return (self.n_knots + self.bspline_degree + 1) * self.interpolation_steps
+
+    @property
+    def padded_horizon(self) -> int:
+        return self.horizon + 1
+
+
+class TrajOptRollout:
+    """cost[B] and d cost / d knots [B, n_knots * D] of B trajectories from one shared start state
+    towards per-row goal poses (goal joint state = implicit rest at the last knot)."""
+
+    def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], batch_size: int,
+                 cfg: Optional[TrajOptRolloutCfg] = None):
+        self.kin, self.scene, self.cfg = kin, scene, cfg or TrajOptRolloutCfg()
+        self.device = kin.device
+        self.action_horizon, self.action_dim = self.cfg.n_knots, kin.num_dof
+        d, T, D, c = self.device, kin.num_pose_links, kin.num_dof, self.cfg
+        f = lambda v: torch.tensor(v, device=d, dtype=torch.float32)  # noqa: E731
+        self._w_self, self._w_scene = f([c.self_collision_weight]), f([c.scene_collision_weight])
+        self._eta_scene, self._speed_dt = f([c.scene_activation_distance]), f([c.traj_dt])
+        self._traj_dt, self._implicit_goal = f([c.traj_dt]), torch.zeros(1, dtype=torch.uint8, device=d)
+        self._pose_w = f(c.pose_weight)
+        self._axes_w, self._axes_w0 = torch.ones(T, 6, device=d), torch.zeros(T, 6, device=d)
+        self._tol = f([c.pose_convergence_tolerance] * T)
+        self._project = torch.zeros(T, dtype=torch.uint8, device=d)
+        self._cs_w, self._cs_eta, self._cs_reg = f(c.cspace_weight), f(c.cspace_activation_distance), f(c.cspace_regularization)
+        self._p_b, self._v_b = kin.joint_limits_position.contiguous(), kin.joint_limits_velocity.contiguous()
+        ones = torch.ones(D, device=d)
+        self._a_b = torch.stack([-c.max_acceleration * ones, c.max_acceleration * ones])
+        self._j_b = torch.stack([-c.max_jerk * ones, c.max_jerk * ones])
+        self._effort_b = torch.stack([-1e9 * ones, 1e9 * ones])
+        self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
+        self.batch_size = 0
+        self.update_batch_size(batch_size)
+        self.update_start_state(None)
+
+    def update_batch_size(self, B: int) -> None:
+        if B == self.batch_size:
+            return
+        k, d, c = self.kin, self.device, self.cfg
+        H, D, S, L, T = c.padded_horizon, k.num_dof, k.num_spheres, k.num_links, k.num_pose_links
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=d, dtype=dt)  # noqa: E731
+        self.batch_size = B
+        self.position, self.velocity, self.acceleration, self.jerk = z(B, H, D), z(B, H, D), z(B, H, D), z(B, H, D)
+        self.out_dt, self.state_dt = z(B), torch.full((B,), c.traj_dt, device=d)
+        self.start_idx, self.goal_idx, self.env_query_idx = z(B, dt=torch.int32), z(B, dt=torch.int32), z(B, dt=torch.int32)
+        self.link_pos, self.link_quat = z(B, H, T, 3), z(B, H, T, 4)
+        self.robot_spheres, self.cumul_mat, self.com = z(B, H, S, 4), z(B, H, L, 3, 4), z(B, H, 4)
+        self.pose_cost, self.pose_pos_dist, self.pose_rot_dist = z(B, H, 2 * T), z(B, H, T), z(B, H, T)
+        self.pose_grad_pos, self.pose_grad_quat = z(B, H, T, 3), z(B, H, T, 4)
+        self.goalset_idx = z(B, H, T, dt=torch.int32)
+        self.cspace_cost = z(B, H, D)
+        self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj = z(B, H, D), z(B, H, D), z(B, H, D), z(B, H, D)
+        self.self_dist, self.self_grad, self.self_sparse = z(B, H, 1), z(B, H, S, 4), z(B, H, S, dt=torch.uint8)
+        self.scene_dist, self.scene_grad = z(B, H, S), z(B, H, S, 4)
+        self._pd, self._bbmv, self._bbmi = z(1), z(1), z(2, dt=torch.int16)
+        self.point_cost, self.cost = z(B, H, 1), z(B)
+        self.grad_q, self.grad_knots = z(B, H, D), z(B, c.n_knots, D)
+        self.idxs_goal, self._idx0 = z(B, dt=torch.int32), z(B, dt=torch.int32)
+        self.goal_position, self.goal_quat = z(1, T, 1, 3), z(1, T, 1, 4)
+        self.goal_quat[..., 0] = 1.0
+
+    def update_start_state(self, start_position: Optional[torch.Tensor]) -> None:
+        D, d = self.action_dim, self.device
+        if start_position is None:
+            start_position = torch.zeros(1, D, device=d)
+        sp = start_position.to(d, torch.float32).reshape(-1, D).contiguous()
+        if getattr(self, "start_pos", None) is not None and self.start_pos.shape == sp.shape:
+            self.start_pos.copy_(sp)  # keep the pointers a captured hipGraph holds
+            return
+        self.start_pos = sp.clone()
+        n = self.start_pos.shape[0]
+        self.start_vel, self.start_acc, self.start_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
+        if getattr(self, "goal_pos", None) is None:
+            self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(1, D, device=d) for _ in range(4))
+
+    def update_goal_state(self, goal_joint_position: Optional[torch.Tensor], goal_idx: Optional[torch.Tensor] = None) -> None:
+        """Implicit goal state (reference ``use_implicit_goal_state``, bspline_interpolation.cuh:
+        110-124): trajectory b ends at rest in joint configuration ``goal_joint_position[goal_idx[b]]``
+        (enforced by the spline's goal boundary knots, not by a cost).  ``None`` = free end point that
+        only comes to rest (replicated last knot)."""
+        D, d = self.action_dim, self.device
+        if goal_joint_position is None:
+            self.goal_pos = torch.zeros(1, D, device=d)
+            self.goal_idx.zero_()
+            self._implicit_goal = torch.zeros(1, dtype=torch.uint8, device=d)
+            self._traj_dt = torch.full((1,), self.cfg.traj_dt, device=d)
+            n = 1
+        else:
+            g = goal_joint_position.to(d, torch.float32).reshape(-1, D).contiguous()
+            n = g.shape[0]
+            self.goal_idx.copy_(goal_idx.to(torch.int32) if goal_idx is not None else torch.zeros_like(self.goal_idx))
+            if self.goal_pos.shape == g.shape and self._implicit_goal.shape[0] == n and bool(self._implicit_goal[0]):
+                self.goal_pos.copy_(g)  # same shape: keep the pointers a captured hipGraph holds
+                return
+            self.goal_pos = g.clone()
+            self._implicit_goal = torch.ones(n, dtype=torch.uint8, device=d)
+            self._traj_dt = torch.full((n,), self.cfg.traj_dt, device=d)
+        self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
+
+    def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
+        """goal_position [G, T, 1, 3], goal_quat (wxyz) [G, T, 1, 4], idxs_goal [B]."""
+        if goal_position.shape == self.goal_position.shape:
+            self.goal_position.copy_(goal_position)
+            self.goal_quat.copy_(goal_quat)
+        else:
+            self.goal_position = goal_position.to(self.device, torch.float32).contiguous().clone()
+            self.goal_quat = goal_quat.to(self.device, torch.float32).contiguous().clone()
+        self.idxs_goal.copy_(idxs_goal.to(torch.int32))
+
+    # ------------------------------------------------------------------ forward + backward
+    def evaluate_action(self, act_seq: torch.Tensor, with_gradient: bool = True) -> torch.Tensor:
+        k, c, B = self.kin, self.cfg, self.batch_size
+        H, D, S, T = c.padded_horizon, k.num_dof, k.num_spheres, k.num_pose_links
+        trajectory_hip.launch_bspline_interpolation_forward_kernel(
+            self.position, self.velocity, self.acceleration, self.jerk, self.out_dt, act_seq, self.start_pos,
+            self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk,
+            self.start_idx, self.goal_idx, self._traj_dt, self._implicit_goal, B, H, D, c.n_knots, c.bspline_degree)
+        kinematics_hip.launch_kinematics_forward_spheres(
+            self.link_pos, self.link_quat, self.robot_spheres, self.com, self.cumul_mat, self.position,
+            k.fixed_transforms, k.link_spheres, k.link_masses_com, k.joint_map_type, k.joint_map, k.link_map,
+            k.tool_frame_map, k.link_sphere_idx_map, k.joint_offset_map, self.env_query_idx, k.num_envs, B * H, H, D, S,
+            32, True, False)
+        cost_hip.tool_pose_distance(
+            self.pose_cost, self.pose_pos_dist, self.pose_rot_dist, self.pose_grad_pos, self.pose_grad_quat,
+            self.goalset_idx, self.link_pos, self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal,
+            self._pose_w, self._axes_w, self._axes_w0, self._tol, self._tol, self._project, B, H, T, 1, c.rotation_method)
+        cost_hip.cspace_state_cost(
+            self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, None, self.position, self.velocity,
+            self.acceleration, self.jerk, None, self.state_dt, self._zeroD, self._idx0, self._p_b, self._v_b, self._a_b,
+            self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg, self._zero1, self._zero1, self._onesD,
+            True, B, H, D, c.retime_weights, c.retime_regularization_weights)
+        sc = k.self_collision
+        geometry_hip.self_collision_distance(
+            self.self_dist, self.self_grad, self._pd, self.self_sparse, self.robot_spheres, sc.sphere_padding,
+            self._w_self, sc.collision_pairs, self._bbmv, self._bbmi, 1, 256, B, H, S, sc.collision_pairs.shape[0],
+            False, True)
+        use_scene = self.scene is not None
+        if use_scene:
+            collision_hip.sphere_obstacle_collision(
+                self.scene_dist, self.scene_grad, self.robot_spheres, self.scene.struct, self._w_scene, self._eta_scene,
+                self.env_query_idx, B, H, S, False, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric,
+                self._speed_dt)
+        if with_gradient:
+            kinematics_hip.launch_kinematics_backward(
+                self.grad_q, self.pose_grad_pos, self.pose_grad_quat, self.self_grad, self.com, self.com,
+                self.pose_grad_pos, self.cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map,
+                k.joint_map_type, k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets,
+                k.joint_links_data, k.joint_links_offsets, k.joint_affects_endeffector, k.joint_offset_map,
+                self.env_query_idx, k.num_envs, B * H, H, D, S, False, False,
+                grad_spheres_b=self.scene_grad if use_scene else None)
+        # per-point totals (+ the c-space position gradient into grad_q), then the sum over the horizon
+        cost_hip.rollout_point_aggregate(
+            self.point_cost, self.grad_q if with_gradient else None, self.pose_cost, self.cspace_cost,
+            self.cs_gp if with_gradient else None, self.self_dist, self.scene_dist if use_scene else None, B * H, T, D, S)
+        collision_hip.trajectory_cost_sum(self.cost, None, self.point_cost, B, H, 1)
+        if with_gradient:
+            trajectory_hip.launch_bspline_interpolation_backward_kernel(
+                self.grad_knots, self.grad_q, self.cs_gv, self.cs_ga, self.cs_gj, self._traj_dt, self.goal_idx,
+                self._implicit_goal, B, H, D, c.n_knots, c.bspline_degree, False)
+        return self.cost
+
+    def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        act = x.view(self.batch_size, self.cfg.n_knots, self.action_dim)
+        cost = self.evaluate_action(act, with_gradient=True)
+        return cost, self.grad_knots.view(self.batch_size, -1)

@@ -1,1 +1,2 @@
 from .ik import IKResult, IKSolver, IKSolverCfg  # noqa: F401
+from .trajopt import TrajOptResult, TrajOptSolver, TrajOptSolverCfg  # noqa: F401

@@ -1,0 +1,120 @@
+"""Collision-free trajectory optimisation to a goal pose: IK for the goal configuration, B-spline
+seeds from the start to the IK solutions, L-BFGS on the full trajopt rollout of every seed in
+parallel, best successful seed per problem.
+
+Mirrors the flow of the reference ``TrajOptSolver._solve_impl`` (``curobo/_src/solver/
+solver_trajopt.py:331-520``: goal IK -> linear seeds in joint space -> ``optimizer.optimize`` ->
+metrics rollout -> success mask -> ranking, :469-484) for the ``lbfgs_bspline_trajopt.yml`` task.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from ..distributed import global_argmin
+from ..optim import LBFGSOpt, LBFGSOptCfg
+from ..robot.kinematics_params import KinematicsParams
+from ..rollout.trajopt_rollout import TrajOptRollout, TrajOptRolloutCfg
+from ..scene.data import SceneData
+from .ik import IKSolver, IKSolverCfg
+
+
+@dataclass
+class TrajOptSolverCfg:
+    num_seeds: int = 4
+    position_threshold: float = 0.005
+    rotation_threshold: float = 0.05
+    seed_bump: float = 0.15  # relative mid-trajectory perturbation of seeds 1..S-1
+    #: traj_dt 0.15 s: the reference optimises at its ``maximum_trajectory_dt`` and retimes afterwards
+    rollout: TrajOptRolloutCfg = field(default_factory=lambda: TrajOptRolloutCfg(traj_dt=0.15))
+    optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=27, inner_iters=25, num_iters=100))
+    ik: IKSolverCfg = field(default_factory=lambda: IKSolverCfg(num_seeds=32))
+    seed: int = 0
+
+
+@dataclass
+class TrajOptResult:
+    success: torch.Tensor  # [P] bool
+    knots: torch.Tensor  # [P, n_knots, D]
+    position: torch.Tensor  # [P, H, D] interpolated joint trajectory of the winner
+    position_error: torch.Tensor  # [P] at the last point
+    rotation_error: torch.Tensor  # [P]
+    cost: torch.Tensor  # [P]
+    seed_index: torch.Tensor  # [P]
+    goal_config: torch.Tensor  # [P, D] IK solution the seeds aim at
+    ik_success: torch.Tensor  # [P]
+
+
+class TrajOptSolver:
+    def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int,
+                 cfg: Optional[TrajOptSolverCfg] = None, use_cuda_graph: bool = True):
+        self.kin, self.scene, self.cfg = kin, scene, cfg or TrajOptSolverCfg()
+        self.P, self.S, self.device = num_problems, self.cfg.num_seeds, kin.device
+        ocfg = self.cfg.optimizer
+        ocfg.num_problems = self.P * self.S
+        self.nls = len(ocfg.line_search_scale)
+        rc = self.cfg.rollout
+        self.ik = IKSolver(kin, scene, num_problems, self.cfg.ik, use_cuda_graph=use_cuda_graph)
+        self.rollout = TrajOptRollout(kin, scene, self.P * self.S * self.nls, rc)
+        self.metrics_rollout = TrajOptRollout(kin, scene, self.P * self.S, rc)
+        for r in (self.rollout, self.metrics_rollout):  # allocate the goal-state buffers before any graph capture
+            r.update_goal_state(torch.zeros(self.P, kin.num_dof, device=self.device), None)
+        bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+        self.optimizer = LBFGSOpt(ocfg, self.rollout.cost_and_gradient, rc.n_knots, kin.num_dof, bounds, self.device,
+                                  use_cuda_graph=use_cuda_graph)
+        rows = torch.arange(self.P * self.S * self.nls, device=self.device)
+        self._row_goal = (rows // (self.S * self.nls)).to(torch.int32)
+        self._mrow_goal = (torch.arange(self.P * self.S, device=self.device) // self.S).to(torch.int32)
+
+    def seed_knots(self, start: torch.Tensor, goal_config: torch.Tensor) -> torch.Tensor:
+        """[P, S, n_knots, D]: straight joint-space lines start -> goal configuration (reference
+        seed generation, solver_trajopt.py:390-420); seeds 1.. add a smooth mid-trajectory bump."""
+        rc, D = self.cfg.rollout, self.kin.num_dof
+        t = torch.linspace(0.0, 1.0, rc.n_knots + 2, device=self.device)[1:-1].view(1, 1, -1, 1)
+        line = start.view(1, 1, 1, D) * (1 - t) + goal_config.view(self.P, 1, 1, D) * t
+        gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
+        half = 0.5 * (self.kin.joint_limits_position[1] - self.kin.joint_limits_position[0])
+        bump = torch.randn(self.P, self.S, 1, D, generator=gen).to(self.device) * self.cfg.seed_bump * half
+        bump[:, 0] = 0.0
+        knots = line + bump * torch.sin(torch.pi * t)
+        lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
+        return torch.minimum(torch.maximum(knots, lo + 1e-3), hi - 1e-3).contiguous()
+
+    def solve_pose(self, start_position: torch.Tensor, goal_position: torch.Tensor, goal_quat: torch.Tensor) -> TrajOptResult:
+        """One shared start configuration [D]; goal_position [P, 3], goal_quat [P, 4] (wxyz)."""
+        P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
+        rc = self.cfg.rollout
+        start = start_position.to(self.device, torch.float32).view(1, D)
+        ikr = self.ik.solve_pose(goal_position, goal_quat)
+        gp = goal_position.to(self.device, torch.float32).view(P, 1, 1, 3).expand(P, T, 1, 3).contiguous()
+        gq = goal_quat.to(self.device, torch.float32).view(P, 1, 1, 4).expand(P, T, 1, 4).contiguous()
+        for r, rows in ((self.rollout, self._row_goal), (self.metrics_rollout, self._mrow_goal)):
+            r.update_start_state(start)
+            r.update_goals(gp, gq, rows)
+            r.update_goal_state(ikr.solution, rows)  # end at rest in the IK solution (implicit goal state)
+        seeds = self.seed_knots(start, ikr.solution)
+        best = self.optimizer.optimize(seeds.view(P * S, rc.n_knots, D))
+        knots = best.reshape(P * S, rc.n_knots * D).contiguous()
+        m = self.metrics_rollout
+        cost = m.evaluate_action(knots.view(P * S, rc.n_knots, D), with_gradient=False)
+        pos_err = m.pose_pos_dist.view(P, S, -1, T)[:, :, -1, 0]
+        rot_err = m.pose_rot_dist.view(P, S, -1, T)[:, :, -1, 0]
+        lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
+        q = m.position.view(P, S, -1, D)
+        feasible = ((q >= lo - 1e-4) & (q <= hi + 1e-4)).all(-1).all(-1)
+        feasible &= m.self_dist.view(P, S, -1).sum(-1) <= 0.0
+        if self.scene is not None:
+            feasible &= m.scene_dist.view(P, S, -1).sum(-1) <= 0.0
+        ok = feasible & (pos_err < self.cfg.position_threshold) & (rot_err < self.cfg.rotation_threshold)
+        ranked = cost.view(P, S) + 1e16 * (~ok).float()  # reference solver_trajopt.py:469-484
+        payload = torch.cat([knots.view(P, S, -1), pos_err.unsqueeze(-1), rot_err.unsqueeze(-1), ok.float().unsqueeze(-1),
+                             cost.view(P, S, 1)], dim=-1)
+        _, idx, win = global_argmin(ranked, payload, 0)
+        V = rc.n_knots * D
+        traj = q[torch.arange(P, device=self.device), idx.clamp(0, S - 1)]
+        return TrajOptResult(success=win[:, V + 2] > 0.5, knots=win[:, :V].view(P, rc.n_knots, D), position=traj,
+                             position_error=win[:, V], rotation_error=win[:, V + 1], cost=win[:, V + 3], seed_index=idx,
+                             goal_config=ikr.solution, ik_success=ikr.success)

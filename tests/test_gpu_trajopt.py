@@ -1,0 +1,118 @@
+"""The full trajopt rollout (pose + c-space STATE + self + swept scene collision) vs the oracle
+composition, and the TrajOptSolver end to end (trajectory verified with the oracle)."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model, sample_q
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(device):
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c1_world
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays(c1_world())
+    return model, kin, arrays, SceneData.from_arrays(arrays, device)
+
+
+def test_trajopt_rollout_matches_oracle_composition(oracle, device):
+    """non-swept scene term for the strict comparison (the sweep has the documented zero-motion
+    discontinuity); every cost term of the reference trajopt task is active"""
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()
+    cfg = TrajOptRolloutCfg(use_sweep=False, use_speed_metric=False)
+    B, nk, D, H = 10, cfg.n_knots, kin.num_dof, cfg.padded_horizon
+    knots = seed_knots(model, B, nk, seed=4, spread=0.6)
+    start = start_configuration(model)
+    goals = oracle.kinematics_forward(sample_q(model, 3, seed=6, scale=0.7), md)
+    idx = np.arange(B, dtype=np.int32) % 3
+    ro = TrajOptRollout(kin, scene, B, cfg)
+    ro.update_start_state(torch.as_tensor(start, device=device))
+    ro.update_goals(torch.as_tensor(goals["link_pos"].reshape(3, 1, 1, 3)), torch.as_tensor(goals["link_quat"].reshape(3, 1, 1, 4)),
+                    torch.as_tensor(idx, device=device))
+    cost, grad = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(B, -1))
+    torch.cuda.synchronize()
+    # ---- oracle composition
+    zeros = np.zeros((1, D), np.float32)
+    st = {"position": start.reshape(1, D).astype(np.float32), "velocity": zeros, "acceleration": zeros, "jerk": zeros}
+    gl = {k: zeros for k in st}
+    i0 = np.zeros(B, np.int32)
+    dt = np.array([cfg.traj_dt], np.float32)
+    imp = np.zeros(1, np.uint8)
+    s = oracle.bspline_forward(knots, st, gl, i0, i0, dt, imp, H, cfg.bspline_degree)
+    fk = oracle.kinematics_forward(s["position"].reshape(B * H, D), md, horizon=H)
+    T = 1
+    pose = oracle.tool_pose_distance(fk["link_pos"].reshape(B, H, T, 3), fk["link_quat"].reshape(B, H, T, 4),
+                                     goals["link_pos"].reshape(3, 1, 1, 3), goals["link_quat"].reshape(3, 1, 1, 4), idx,
+                                     np.array(cfg.pose_weight, np.float32), np.ones((T, 6), np.float32), np.zeros((T, 6), np.float32),
+                                     np.full((T, 2), 1e-8, np.float32), np.full((T, 2), 1e-8, np.float32), np.zeros(T, np.uint8), 0)
+    ones = np.ones(D, np.float32)
+    lim = {"position": model.joint_limits_position.astype(np.float32), "velocity": model.joint_limits_velocity.astype(np.float32),
+           "acceleration": np.stack([-cfg.max_acceleration * ones, cfg.max_acceleration * ones]),
+           "jerk": np.stack([-cfg.max_jerk * ones, cfg.max_jerk * ones])}
+    cs = oracle.cspace_state_cost(s["position"], s["velocity"], s["acceleration"], s["jerk"], np.full(B, cfg.traj_dt, np.float32),
+                                  lim, cfg.cspace_weight, cfg.cspace_activation_distance, cfg.cspace_regularization,
+                                  retime_weights=True, retime_regularization_weights=True)
+    sph = fk["robot_spheres"].reshape(B, H, -1, 4)
+    sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, cfg.self_collision_weight)
+    wc = oracle.scene_collision(sph, arrays, cfg.scene_collision_weight, cfg.scene_activation_distance)
+    want = pose["distance"].sum((1, 2)) + cs["cost"].sum((1, 2)) + sc["distance"].reshape(B, H).sum(1) + wc["distance"].sum((1, 2))
+    assert pose["distance"][:, -1].sum() > 0 and (pose["distance"][:, :-1] == 0).all(), "pose cost acts on the last point only"
+    assert (cs["cost"] > 0).any() and (wc["distance"] > 0).any()
+    np.testing.assert_allclose(cost.cpu().numpy(), want, rtol=2e-4, atol=1e-1)
+    gs = sc["gradient"].reshape(B * H, -1, 4) + wc["gradient"].reshape(B * H, -1, 4) * np.array([1, 1, 1, 0], np.float32)
+    gq = oracle.kinematics_backward(md, fk["cumul_mat"], gs, pose["position_gradient"].reshape(B * H, 1, 3),
+                                    pose["rotation_gradient"].reshape(B * H, 1, 4), horizon=H).reshape(B, H, D)
+    gk = oracle.bspline_backward(gq + cs["grad_position"], cs["grad_velocity"], cs["grad_acceleration"], cs["grad_jerk"], dt, i0,
+                                 imp, nk, cfg.bspline_degree)
+    np.testing.assert_allclose(grad.cpu().numpy().reshape(gk.shape), gk, rtol=3e-3, atol=3e-5 * np.abs(gk).max())
+
+
+def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
+    from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()
+    P = 6
+    cand = sample_q(model, 400, seed=12, scale=0.6)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(400, 1, -1, 4)
+    free = (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0) & \
+        (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0)
+    sel = np.nonzero(free)[0][:P]
+    gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
+    start = start_configuration(model)
+    solver = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=4))
+    res = solver.solve_pose(torch.as_tensor(start), torch.as_tensor(gp), torch.as_tensor(gq))
+    torch.cuda.synchronize()
+    succ = res.success.cpu().numpy()
+    assert res.ik_success.cpu().numpy().mean() >= 0.8
+    assert succ.mean() >= 0.8, f"trajopt success rate {succ.mean():.2f}"
+    # a second solve re-uses the captured hipGraph (goal / start buffers are updated in place)
+    res2 = solver.solve_pose(torch.as_tensor(start), torch.as_tensor(gp[::-1].copy()), torch.as_tensor(gq[::-1].copy()))
+    torch.cuda.synchronize()
+    assert res2.success.cpu().numpy().mean() >= 0.8
+    np.testing.assert_allclose(res2.position_error.cpu().numpy()[::-1], res.position_error.cpu().numpy(), atol=1e-3)
+    traj = res.position.cpu().numpy()[succ]  # [n, H, D]
+    n, H, D = traj.shape
+    np.testing.assert_allclose(traj[:, 0], np.broadcast_to(start, (n, D)), atol=1e-4)  # starts at the start state
+    chk = oracle.kinematics_forward(traj.reshape(n * H, D), md, horizon=H)
+    np.testing.assert_allclose(chk["link_pos"].reshape(n, H, 3)[:, -1], gp[succ], atol=5e-3)
+    assert np.abs(traj[:, -1] - traj[:, -2]).max() < 1e-3, "the trajectory must end at rest"
+    lo, hi = model.joint_limits_position
+    assert (traj >= lo - 1e-3).all() and (traj <= hi + 1e-3).all()
+    s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
+    assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
+    assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
+    vel = np.diff(traj, axis=1) / 0.15
+    assert np.abs(vel).max() <= np.abs(model.joint_limits_velocity).max() * 1.05
