@@ -35,6 +35,26 @@ class Scene(C.Structure):
     ]
 
 
+class TrajOptTerms(C.Structure):
+    """``curobo_hip_trajopt_terms`` (see include/curobo_hip.h): optional tool-pose / c-space STATE
+    terms of the fused trajopt rollout.  Field order and types mirror the C struct."""
+
+    _P, _I = C.c_void_p, C.c_int32
+    _fields_ = [
+        ("out_pose_distance", _P), ("out_position_distance", _P), ("out_rotation_distance", _P), ("out_goalset_idx", _P),
+        ("goal_position", _P), ("goal_quat", _P), ("idxs_goal", _P), ("position_orientation_weight", _P),
+        ("terminal_pose_axes_weight_factor", _P), ("non_terminal_pose_axes_weight_factor", _P),
+        ("terminal_pose_convergence_tolerance", _P), ("non_terminal_pose_convergence_tolerance", _P),
+        ("project_distance_to_goal", _P), ("tool_frame_map", _P),
+        ("n_tool_frames", _I), ("num_goalset", _I), ("rotation_method", _I),
+        ("out_cspace_cost", _P), ("state_dt", _P), ("target_joint_position", _P), ("idxs_target_joint_position", _P),
+        ("p_b", _P), ("v_b", _P), ("a_b", _P), ("j_b", _P), ("effort_b", _P),
+        ("cspace_weight", _P), ("cspace_activation_distance", _P), ("squared_l2_regularization_weights", _P),
+        ("cspace_target_weight", _P), ("cspace_non_terminal_weight_factor", _P), ("cspace_target_dof_weight", _P),
+        ("retime_weights", _I), ("retime_regularization_weights", _I),
+    ]
+
+
 def declared_symbols(header: str = HEADER_PATH) -> List[str]:
     """Every function name the public header declares."""
     text = open(header).read()

@@ -14,7 +14,71 @@ from typing import Optional
 
 import torch
 
-from .._lib import Scene, check, current_stream, load, ptr
+from .._lib import Scene, TrajOptTerms, check, current_stream, load, ptr
+
+
+def _rollout_trajectory(fn, terms, with_terms,
+
+    out_cost: torch.Tensor,
+    out_grad_knots: torch.Tensor,
+    out_position: Optional[torch.Tensor],
+    out_robot_spheres: Optional[torch.Tensor],
+    u_position: torch.Tensor,
+    start_position: torch.Tensor,
+    start_velocity: torch.Tensor,
+    start_acceleration: torch.Tensor,
+    start_jerk: torch.Tensor,
+    goal_position: torch.Tensor,
+    goal_velocity: torch.Tensor,
+    goal_acceleration: torch.Tensor,
+    goal_jerk: torch.Tensor,
+    start_idx: torch.Tensor,
+    goal_idx: torch.Tensor,
+    traj_dt: torch.Tensor,
+    use_implicit_goal_state: torch.Tensor,
+    fixed_transform: torch.Tensor,
+    robot_spheres: torch.Tensor,
+    joint_map_type: torch.Tensor,
+    joint_map: torch.Tensor,
+    link_map: torch.Tensor,
+    link_sphere_map: torch.Tensor,
+    link_chain_data: torch.Tensor,
+    link_chain_offsets: torch.Tensor,
+    joint_offset_map: torch.Tensor,
+    sphere_padding: Optional[torch.Tensor],
+    self_collision_weight: Optional[torch.Tensor],
+    pair_locations: Optional[torch.Tensor],
+    scene: Optional[Scene],
+    scene_collision_weight: Optional[torch.Tensor],
+    activation_distance: Optional[torch.Tensor],
+    speed_dt: Optional[torch.Tensor],
+    env_query_idx: torch.Tensor,
+    num_envs: int,
+    use_multi_env: bool,
+    batch_size: int,
+    padded_horizon: int,
+    dof: int,
+    n_knots: int,
+    bspline_degree: int,
+    sweep_steps: int = 0,
+    enable_speed_metric: bool = False,
+):
+    num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
+    extra = ((None if terms is None else C.addressof(terms)),) if with_terms else ()
+    check(fn(
+        ptr(out_cost), ptr(out_grad_knots), ptr(out_position), ptr(out_robot_spheres), ptr(u_position),
+        ptr(start_position), ptr(start_velocity), ptr(start_acceleration), ptr(start_jerk),
+        ptr(goal_position), ptr(goal_velocity), ptr(goal_acceleration), ptr(goal_jerk), ptr(start_idx),
+        ptr(goal_idx), ptr(traj_dt), ptr(use_implicit_goal_state), ptr(fixed_transform), ptr(robot_spheres),
+        ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(link_sphere_map), ptr(link_chain_data),
+        ptr(link_chain_offsets), ptr(joint_offset_map), ptr(sphere_padding), ptr(self_collision_weight),
+        ptr(pair_locations), None if scene is None else C.addressof(scene), ptr(scene_collision_weight),
+        ptr(activation_distance), ptr(speed_dt), ptr(env_query_idx), num_envs, int(use_multi_env),
+        batch_size, padded_horizon, dof, n_knots, bspline_degree, int(fixed_transform.shape[0]),
+        int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]), sweep_steps,
+        int(enable_speed_metric), *extra, current_stream(out_cost),
+    ))
+
 
 
 def rollout_trajectory_fused(
@@ -63,20 +127,7 @@ def rollout_trajectory_fused(
     enable_speed_metric: bool = False,
 ):
     """cost[b], grad_knots[b, n_knots, dof] of ``batch_size`` B-spline trajectories in one launch."""
-    num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
-    check(load().curobo_hip_rollout_trajectory_fused(
-        ptr(out_cost), ptr(out_grad_knots), ptr(out_position), ptr(out_robot_spheres), ptr(u_position),
-        ptr(start_position), ptr(start_velocity), ptr(start_acceleration), ptr(start_jerk),
-        ptr(goal_position), ptr(goal_velocity), ptr(goal_acceleration), ptr(goal_jerk), ptr(start_idx),
-        ptr(goal_idx), ptr(traj_dt), ptr(use_implicit_goal_state), ptr(fixed_transform), ptr(robot_spheres),
-        ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(link_sphere_map), ptr(link_chain_data),
-        ptr(link_chain_offsets), ptr(joint_offset_map), ptr(sphere_padding), ptr(self_collision_weight),
-        ptr(pair_locations), None if scene is None else C.addressof(scene), ptr(scene_collision_weight),
-        ptr(activation_distance), ptr(speed_dt), ptr(env_query_idx), num_envs, int(use_multi_env),
-        batch_size, padded_horizon, dof, n_knots, bspline_degree, int(fixed_transform.shape[0]),
-        int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]), sweep_steps,
-        int(enable_speed_metric), current_stream(out_cost),
-    ))
+    return _rollout_trajectory(load().curobo_hip_rollout_trajectory_fused, None, False, out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity, start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, traj_dt, use_implicit_goal_state, fixed_transform, robot_spheres, joint_map_type, joint_map, link_map, link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight, pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs, use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, sweep_steps, enable_speed_metric)
 
 
 FUSED_LDS_LIMIT = 160 * 1024
@@ -120,3 +171,27 @@ def rollout_ik_fused_lds_bytes(dof: int, num_links: int, num_spheres: int, num_c
                                link_chain_len: int, num_obstacles: int) -> int:
     return int(load().curobo_hip_rollout_ik_fused_lds_bytes(dof, num_links, num_spheres, num_collision_pairs,
                                                             link_chain_len, num_obstacles))
+
+
+def make_trajopt_terms(**tensors) -> TrajOptTerms:
+    """Pack device tensors / ints into ``curobo_hip_trajopt_terms`` (field names of the header; the
+    caller keeps the tensors alive).  Omitted fields stay NULL / 0."""
+    t = TrajOptTerms()
+    for name, value in tensors.items():
+        setattr(t, name, int(value) if isinstance(value, (int, bool)) else ptr(value))
+    return t
+
+
+def rollout_trajopt_fused(terms: Optional[TrajOptTerms], *args, **kwargs):
+    """``rollout_trajectory_fused`` plus the optional tool-pose and c-space STATE terms of the
+    reference trajopt task in the same launch (``curobo_hip_rollout_trajopt_fused``).  Positional
+    arguments after ``terms`` are those of :func:`rollout_trajectory_fused`."""
+    return _rollout_trajectory(load().curobo_hip_rollout_trajopt_fused, terms, True, *args, **kwargs)
+
+
+def rollout_trajopt_fused_lds_bytes(padded_horizon: int, dof: int, num_links: int, num_spheres: int,
+                                    num_collision_pairs: int, link_chain_len: int, num_obstacles: int,
+                                    with_cspace_terms: bool) -> int:
+    return int(load().curobo_hip_rollout_trajopt_fused_lds_bytes(
+        padded_horizon, dof, num_links, num_spheres, num_collision_pairs, link_chain_len, num_obstacles,
+        int(with_cspace_terms)))

@@ -49,6 +49,12 @@ struct FusedTrajArgs {
   const int32_t *env_query_idx;
   int batch, nlinks, nspheres, npairs, chain_len, dpad, num_envs, use_multi_env, enable_speed_metric;
   int use_self, use_scene;
+  // optional cost terms of the full trajopt task (lbfgs_bspline_trajopt.yml): tool-pose goal cost
+  // over the horizon (terminal / non-terminal weights) and the c-space STATE cost
+  ToolPoseArgs tp;        // current_position / current_quat unused; out_* optional [B, H, T, .]
+  CspaceStateArgs cs;     // pos/vel/acc/jerk unused (LDS); out_cost optional [B, H, D]; out_g* unused
+  const int16_t *tool_frame_map;
+  int n_tool_frames, use_pose, use_cspace;
   long long *prof;  // optional [B][16] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
 };
 
@@ -62,9 +68,9 @@ constexpr int kWrench = 7;  // per link: force xyz, torque xyz about the link or
 
 struct FusedLayout {
   int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, off_add, fixed, chain, sph_link, sph_rad,
-      sph_pad, rs, lbound, sub, jlinks, left, key, pairs, recs, total;
+      sph_pad, rs, lbound, sub, jlinks, left, key, dyn, pairs, recs, total;
 };
-__host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec) {
+__host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0) {
   FusedLayout f;
   int o = 0;
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
@@ -91,6 +97,7 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.jlinks = take(D * 4);
   f.left = take(S * 4);
   f.key = take(4);
+  f.dyn = take(n_dyn);  // velocity / acceleration / jerk [3][H][D] when the c-space STATE cost is on
   f.pairs = take((P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
   f.recs = take(n_rec * kObsRecFloats);
   f.total = o;
@@ -105,6 +112,7 @@ struct FusedCtx {
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
   float4 *left;
+  float *dyn;  // [3][H][D] velocity / acceleration / jerk, later their cost gradients
   unsigned long long *key;
   ObsRec *recs;
   int H, D, L, S, P, ws, wl, env;
@@ -301,6 +309,80 @@ __device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajA
   reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[s] = w4;
 }
 
+// Tool-pose goal-set cost of point h (batch row n, horizon position hh of tp.horizon) for every
+// tool frame (one per lane): cost -> cost_pt, gradient -> the link wrench as a force at the tool
+// link's origin plus the free torque omega = 1/2 E(q)^T g (reference wp_tool_pose.py:456-692,
+// kinematics_backward_helper.cuh:102-183, quaternion_util.cuh:86-102).  out_index0 = flat index of
+// (n, hh, tool frame 0) in the optional metric outputs.
+__device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPoseArgs &tp, const int16_t *tool_frame_map,
+                                                int T, int n, int hh, int h, size_t out_index0, float *out_link_pos,
+                                                float *out_link_quat, int lane, int lane64, float &cost_pt, bool &any_grad) {
+  const float *cumul = c.cumul + (size_t)h * c.L * 12;
+  float *wr = c.wrench + (size_t)h * c.wl;
+  for (int t0 = 0; t0 < T; t0 += kFkLanes) {
+    const int t = t0 + lane;
+    f3 gp = make_f3(0.f, 0.f, 0.f), om = gp, pos = gp;
+    int l = 0;
+    if (t < T) {
+      l = tool_frame_map[t];
+      const float *C = cumul + l * 12;
+      const float4 qx = quat_from_transform(C);
+      pos = make_f3(C[3], C[7], C[11]);
+      const ToolPoseResult res = tool_pose_distance_point(tp, n, hh, t, pos, make_float4(qx.w, qx.x, qx.y, qx.z));
+      cost_pt += res.position_cost + res.rotation_cost;
+      gp = res.position_gradient;
+      // omega = 0.5 * E(q)^T g  (q xyzw, g wxyz)
+      const float dqw = res.quat_rate_wxyz.x, dqx = res.quat_rate_wxyz.y, dqy = res.quat_rate_wxyz.z, dqz = res.quat_rate_wxyz.w;
+      om = make_f3(0.5f * (-qx.x * dqw + qx.w * dqx + qx.z * dqy - qx.y * dqz),
+                   0.5f * (-qx.y * dqw - qx.z * dqx + qx.w * dqy + qx.x * dqz),
+                   0.5f * (-qx.z * dqw + qx.y * dqx - qx.x * dqy + qx.w * dqz));
+      const size_t o = out_index0 + t;
+      if (tp.out_distance) { tp.out_distance[2 * o] = res.position_cost; tp.out_distance[2 * o + 1] = res.rotation_cost; }
+      if (tp.out_position_distance) tp.out_position_distance[o] = res.position_distance;
+      if (tp.out_rotation_distance) tp.out_rotation_distance[o] = res.rotation_distance;
+      if (tp.out_goalset_idx) tp.out_goalset_idx[o] = res.goalset_idx;
+      if (out_link_pos) { float *lp = out_link_pos + o * 3; lp[0] = pos.x; lp[1] = pos.y; lp[2] = pos.z; }
+      if (out_link_quat) reinterpret_cast<float4 *>(out_link_quat)[o] = make_float4(qx.w, qx.x, qx.y, qx.z);
+    }
+    // one contributing lane at a time (lane order): reproducible fp32 sums
+    unsigned long long mk = __ballot(gp.x != 0.f || gp.y != 0.f || gp.z != 0.f || om.x != 0.f || om.y != 0.f || om.z != 0.f);
+    any_grad = any_grad || ((mk >> (lane64 & 48)) & 0xffffull) != 0ull;
+    while (mk) {
+      const int src = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      if (lane64 == src) {
+        wrench_add(wr, cumul, l, pos, gp);
+        float *w = wr + l * kWrench;
+        atomicAdd(w + 3, om.x); atomicAdd(w + 4, om.y); atomicAdd(w + 5, om.z);
+      }
+    }
+  }
+}
+
+// c-space STATE cost of point h (wp_cspace_state.py:20-287), one dof per lane.  The position
+// gradient is returned per lane (added to grad_q after the wrench gather, it is already in joint
+// space); the velocity / acceleration / jerk gradients replace the values in c.dyn in place.
+constexpr int kDofIters = (64 + kFkLanes - 1) / kFkLanes;
+__device__ __forceinline__ void point_cspace_state(const FusedCtx &c, const CspaceStateArgs &cs, int b, int h, int lane,
+                                                   float &cost_pt, float (&gp_joint)[kDofIters]) {
+  const int HD = c.H * c.D;
+#pragma unroll
+  for (int it = 0; it < kDofIters; it++) {
+    const int d = it * kFkLanes + lane;
+    gp_joint[it] = 0.0f;
+    if (d < c.D) {
+      const int e = h * c.D + d;
+      const float x[5] = {c.q[e], c.dyn[e], c.dyn[HD + e], c.dyn[2 * HD + e], 0.0f};
+      float g[5];
+      const float cc = cspace_state_point(cs, b, h, d, x, g);
+      cost_pt += cc;
+      gp_joint[it] = g[0];
+      c.dyn[e] = g[1]; c.dyn[HD + e] = g[2]; c.dyn[2 * HD + e] = g[3];
+      if (cs.out_cost) cs.out_cost[((size_t)b * c.H + h) * c.D + d] = cc;
+    }
+  }
+}
+
 // LDS views of a workgroup (H = points held by the workgroup)
 __device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const FusedLayout &lay, int H, int D, int L, int S,
                                                 int P) {
@@ -318,6 +400,7 @@ __device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const 
   c.jlinks = reinterpret_cast<uint32_t *>(smem + lay.jlinks);  // [D][4]: links driven by joint d
   c.left = reinterpret_cast<float4 *>(smem + lay.left);
   c.key = reinterpret_cast<unsigned long long *>(smem + lay.key);
+  c.dyn = smem + lay.dyn;
   c.pairs = reinterpret_cast<uint32_t *>(smem + lay.pairs);
   c.recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
   c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
@@ -423,7 +506,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, a.use_cspace ? 3 * H * D : 0);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.x;
   FusedCtx c;
@@ -447,6 +530,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     float o4[4];
     bspline_sample<DEG>(a.bs, b, h, d, o4);
     c.q[e] = o4[0];
+    if (a.use_cspace) { c.dyn[e] = o4[1]; c.dyn[H * D + e] = o4[2]; c.dyn[2 * H * D + e] = o4[3]; }
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
   }
   __syncthreads();
@@ -559,9 +643,21 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       }
     }
     if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
+    float gp_joint[kDofIters];
+    if (a.use_pose)
+      point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * H + h) * a.n_tool_frames, nullptr,
+                      nullptr, lane, lane64, cost_pt, any_grad);
+    if (a.use_cspace) point_cspace_state(c, a.cs, b, h, lane, cost_pt, gp_joint);
     cost_pt = row16_sum(cost_pt);
     if (lane == 0) c.cost[h] = cost_pt;
     point_vjp_gather(c, h, any_grad, lane);
+    if (a.use_cspace) {
+#pragma unroll
+      for (int it = 0; it < kDofIters; it++) {
+        const int d = it * kFkLanes + lane;
+        if (d < D) c.q[h * D + d] += gp_joint[it];  // same lane wrote it in the gather
+      }
+    }
     if (stamp_pt) a.prof[(size_t)b * 16 + 7] = wall_clock64();
   }
   for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
@@ -603,9 +699,21 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
           any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), make_f3(gd.x, gd.y, gd.z), lane64) || any_grad;
         }
       }
+      float gp_joint[kDofIters];
+      if (a.use_pose)
+        point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * H + h) * a.n_tool_frames, nullptr,
+                        nullptr, lane, lane64, cost_pt, any_grad);
+      if (a.use_cspace) point_cspace_state(c, a.cs, b, h, lane, cost_pt, gp_joint);
       cost_pt = row16_sum(cost_pt);
       if (lane == 0) c.cost[h] = cost_pt;
       point_vjp_gather(c, h, any_grad, lane);
+      if (a.use_cspace) {
+#pragma unroll
+        for (int it = 0; it < kDofIters; it++) {
+          const int d = it * kFkLanes + lane;
+          if (d < D) c.q[h * D + d] += gp_joint[it];
+        }
+      }
     }
   }
   __syncthreads();
@@ -616,7 +724,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int go = a.bs.goal_idx[b];
   const float traj_dt = a.bs.traj_dt[go];
   const bool use_goal = a.bs.use_implicit_goal[go] != 0;
-  const float *gin[4] = {c.q, nullptr, nullptr, nullptr};
+  const float *gin[4] = {c.q, a.use_cspace ? c.dyn : nullptr, a.use_cspace ? c.dyn + H * D : nullptr,
+                         a.use_cspace ? c.dyn + 2 * H * D : nullptr};
   for (int e = tid; e < nk * D; e += nt) {
     const int k = e / D, d = e - k * D;
     a.out_grad_knots[(size_t)b * nk * D + e] = bspline_knot_grad<DEG>(gin, (size_t)d, D, k, nk, H, traj_dt, use_goal);
@@ -752,48 +861,12 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
     }
   }
   // tool-pose goal-set cost (wp_tool_pose.py:456-692), one tool frame per lane
-  for (int t0 = 0; t0 < T; t0 += kFkLanes) {
-    const int t = t0 + lane;
-    f3 gp = make_f3(0.f, 0.f, 0.f), om = gp, pos = gp;
-    int l = 0;
-    if (t < T) {
-      l = ia.tool_frame_map[t];
-      const float *C = cumul + l * 12;
-      const float4 qx = quat_from_transform(C);
-      pos = make_f3(C[3], C[7], C[11]);
-      const ToolPoseResult res = tool_pose_distance_point(ia.tp, n, 0, t, pos, make_float4(qx.w, qx.x, qx.y, qx.z));
-      cost_pt += res.position_cost + res.rotation_cost;
-      gp = res.position_gradient;
-      // omega = 0.5 * E(q)^T g  (reference quaternion_util.cuh:86-102; q xyzw, g wxyz)
-      const float dqw = res.quat_rate_wxyz.x, dqx = res.quat_rate_wxyz.y, dqy = res.quat_rate_wxyz.z, dqz = res.quat_rate_wxyz.w;
-      om = make_f3(0.5f * (-qx.x * dqw + qx.w * dqx + qx.z * dqy - qx.y * dqz),
-                   0.5f * (-qx.y * dqw - qx.z * dqx + qx.w * dqy + qx.x * dqz),
-                   0.5f * (-qx.z * dqw + qx.y * dqx - qx.x * dqy + qx.w * dqz));
-      const size_t o = (size_t)n * T + t;
-      if (ia.tp.out_distance) { ia.tp.out_distance[2 * o] = res.position_cost; ia.tp.out_distance[2 * o + 1] = res.rotation_cost; }
-      if (ia.tp.out_position_distance) ia.tp.out_position_distance[o] = res.position_distance;
-      if (ia.tp.out_rotation_distance) ia.tp.out_rotation_distance[o] = res.rotation_distance;
-      if (ia.tp.out_goalset_idx) ia.tp.out_goalset_idx[o] = res.goalset_idx;
-      if (ia.out_link_pos) { float *lp = ia.out_link_pos + o * 3; lp[0] = pos.x; lp[1] = pos.y; lp[2] = pos.z; }
-      if (ia.out_link_quat) reinterpret_cast<float4 *>(ia.out_link_quat)[o] = make_float4(qx.w, qx.x, qx.y, qx.z);
-    }
-    // force at the tool link's origin + free torque, one contributing lane at a time (lane order)
-    unsigned long long mk = __ballot(gp.x != 0.f || gp.y != 0.f || gp.z != 0.f || om.x != 0.f || om.y != 0.f || om.z != 0.f);
-    any_grad = any_grad || ((mk >> (lane64 & 48)) & 0xffffull) != 0ull;
-    while (mk) {
-      const int src = __ffsll((long long)mk) - 1;
-      mk &= mk - 1;
-      if (lane64 == src) {
-        wrench_add(wr, cumul, l, pos, gp);
-        float *w = wr + l * kWrench;
-        atomicAdd(w + 3, om.x); atomicAdd(w + 4, om.y); atomicAdd(w + 5, om.z);
-      }
-    }
-  }
+  point_tool_pose(c, ia.tp, ia.tool_frame_map, T, n, 0, h, (size_t)n * T, ia.out_link_pos, ia.out_link_quat, lane, lane64,
+                  cost_pt, any_grad);
   // c-space bound cost (wp_cspace_position.py:232-362): its gradient is already in joint space
-  float gp_joint[(64 + kFkLanes - 1) / kFkLanes];
+  float gp_joint[kDofIters];
 #pragma unroll
-  for (int it = 0; it < (64 + kFkLanes - 1) / kFkLanes; it++) {
+  for (int it = 0; it < kDofIters; it++) {
     const int d = it * kFkLanes + lane;
     float g = 0.0f;
     if (d < D) {
@@ -811,7 +884,7 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int it = 0; it < (64 + kFkLanes - 1) / kFkLanes; it++) {
+  for (int it = 0; it < kDofIters; it++) {
     const int d = it * kFkLanes + lane;
     if (d < D) ia.out_grad_q[(size_t)n * D + d] = c.q[h * D + d] + gp_joint[it];
   }
@@ -838,7 +911,8 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horiz
   return lay.total * (int)sizeof(float);
 }
 
-CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
+static int rollout_trajectory_fused_impl(
+    const char *what, const curobo_hip_trajopt_terms *terms,
     float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres, const float *u_position,
     const float *start_position, const float *start_velocity, const float *start_acceleration, const float *start_jerk,
     const float *goal_position, const float *goal_velocity, const float *goal_acceleration, const float *goal_jerk,
@@ -851,7 +925,6 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
     const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof,
     int n_knots, int bspline_degree, int num_links, int num_spheres, int num_collision_pairs, int link_chain_len,
     int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream) {
-  const char *what = "rollout_trajectory_fused";
   CUROBO_REQUIRE(bspline_degree >= 3 && bspline_degree <= 5, "%s: bspline_degree must be 3, 4 or 5", what);
   CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && padded_horizon >= 2 && n_knots >= 1,
@@ -883,7 +956,50 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
   CUROBO_REQUIRE(!a.enable_speed_metric || speed_dt, "%s: speed metric needs speed_dt", what);
   const int n_rec = a.use_scene ? a.sc.max_cuboids + a.sc.max_voxel_grids : 0;
   if (!a.use_scene) { a.sc.max_cuboids = 0; a.sc.max_voxel_grids = 0; }
-  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec);
+  if (terms) {
+    const curobo_hip_trajopt_terms &t = *terms;
+    a.use_pose = (t.n_tool_frames > 0 && t.goal_position) ? 1 : 0;
+    a.use_cspace = t.cspace_weight ? 1 : 0;
+    if (a.use_pose) {
+      CUROBO_REQUIRE(t.tool_frame_map && t.goal_quat && t.idxs_goal && t.position_orientation_weight &&
+                         t.terminal_pose_axes_weight_factor && t.non_terminal_pose_axes_weight_factor &&
+                         t.terminal_pose_convergence_tolerance && t.non_terminal_pose_convergence_tolerance &&
+                         t.project_distance_to_goal && t.num_goalset >= 1,
+                     "%s: incomplete tool-pose terms", what);
+      CUROBO_REQUIRE(t.rotation_method >= 0 && t.rotation_method <= 2, "%s: rotation_method must be 0, 1 or 2", what);
+      ToolPoseArgs &tp = a.tp;
+      tp.out_distance = t.out_pose_distance; tp.out_position_distance = t.out_position_distance;
+      tp.out_rotation_distance = t.out_rotation_distance; tp.out_goalset_idx = t.out_goalset_idx;
+      tp.goal_position = t.goal_position; tp.goal_quat = t.goal_quat; tp.idxs_goal = t.idxs_goal;
+      tp.position_orientation_weight = t.position_orientation_weight;
+      tp.terminal_axes_weight = t.terminal_pose_axes_weight_factor;
+      tp.non_terminal_axes_weight = t.non_terminal_pose_axes_weight_factor;
+      tp.terminal_tolerance = t.terminal_pose_convergence_tolerance;
+      tp.non_terminal_tolerance = t.non_terminal_pose_convergence_tolerance;
+      tp.project_distance_to_goal = t.project_distance_to_goal;
+      tp.batch = batch_size; tp.horizon = padded_horizon; tp.num_links = t.n_tool_frames; tp.num_goalset = t.num_goalset;
+      tp.rotation_method = t.rotation_method;
+      a.tool_frame_map = t.tool_frame_map; a.n_tool_frames = t.n_tool_frames;
+    }
+    if (a.use_cspace) {
+      CUROBO_REQUIRE(t.state_dt && t.p_b && t.v_b && t.a_b && t.j_b && t.effort_b && t.cspace_activation_distance &&
+                         t.squared_l2_regularization_weights && t.cspace_target_weight &&
+                         t.cspace_non_terminal_weight_factor && t.cspace_target_dof_weight && t.target_joint_position &&
+                         t.idxs_target_joint_position,
+                     "%s: incomplete c-space terms", what);
+      CUROBO_REQUIRE(dof <= 64, "%s: c-space term supports dof <= 64", what);
+      CspaceStateArgs &cs = a.cs;
+      cs.out_cost = t.out_cspace_cost; cs.state_dt = t.state_dt; cs.target = t.target_joint_position;
+      cs.idxs_target = t.idxs_target_joint_position; cs.p_b = t.p_b; cs.v_b = t.v_b; cs.a_b = t.a_b; cs.j_b = t.j_b;
+      cs.effort_b = t.effort_b; cs.weight = t.cspace_weight; cs.activation_distance = t.cspace_activation_distance;
+      cs.sql2_weights = t.squared_l2_regularization_weights; cs.target_weight = t.cspace_target_weight;
+      cs.non_terminal_factor = t.cspace_non_terminal_weight_factor; cs.target_dof_weight = t.cspace_target_dof_weight;
+      cs.write_grad = 1; cs.batch = batch_size; cs.horizon = padded_horizon; cs.dof = dof;
+      cs.retime_weights = t.retime_weights; cs.retime_reg_weights = t.retime_regularization_weights;
+    }
+  }
+  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
+                                       a.use_cspace ? 3 * padded_horizon * dof : 0);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   int threads = ((padded_horizon * kFkLanes + 63) / 64) * 64;
@@ -926,6 +1042,47 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(
 #undef CUROBO_FUSED_KINDS
 #undef CUROBO_FUSED_LAUNCH
   return check_launch(what, st);
+}
+
+#define CUROBO_TRAJ_PARAMS                                                                                          \
+  float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres, const float *u_position,     \
+      const float *start_position, const float *start_velocity, const float *start_acceleration,                      \
+      const float *start_jerk, const float *goal_position, const float *goal_velocity, const float *goal_acceleration, \
+      const float *goal_jerk, const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt,                \
+      const uint8_t *use_implicit_goal_state, const float *fixed_transform, const float *robot_spheres,               \
+      const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const int16_t *link_sphere_map, \
+      const int16_t *link_chain_data, const int16_t *link_chain_offsets, const float *joint_offset_map,               \
+      const float *sphere_padding, const float *self_collision_weight, const int16_t *pair_locations,                 \
+      const curobo_hip_scene *scene, const float *scene_collision_weight, const float *activation_distance,           \
+      const float *speed_dt, const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size,           \
+      int padded_horizon, int dof, int n_knots, int bspline_degree, int num_links, int num_spheres,                   \
+      int num_collision_pairs, int link_chain_len, int sweep_steps, int enable_speed_metric
+#define CUROBO_TRAJ_ARGS                                                                                              \
+  out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity,             \
+      start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, \
+      traj_dt, use_implicit_goal_state, fixed_transform, robot_spheres, joint_map_type, joint_map, link_map,          \
+      link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight,  \
+      pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs,          \
+      use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, num_links, num_spheres,                \
+      num_collision_pairs, link_chain_len, sweep_steps, enable_speed_metric
+
+CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(CUROBO_TRAJ_PARAMS, curobo_hip_stream_t stream) {
+  return rollout_trajectory_fused_impl("rollout_trajectory_fused", nullptr, CUROBO_TRAJ_ARGS, stream);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused(CUROBO_TRAJ_PARAMS, const curobo_hip_trajopt_terms *terms,
+                                                   curobo_hip_stream_t stream) {
+  return rollout_trajectory_fused_impl("rollout_trajopt_fused", terms, CUROBO_TRAJ_ARGS, stream);
+}
+#undef CUROBO_TRAJ_PARAMS
+#undef CUROBO_TRAJ_ARGS
+
+CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_lds_bytes(int padded_horizon, int dof, int num_links, int num_spheres,
+                                                             int num_collision_pairs, int link_chain_len,
+                                                             int num_obstacles, int with_cspace_terms) {
+  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
+                                       num_obstacles, with_cspace_terms ? 3 * padded_horizon * dof : 0);
+  return lay.total * (int)sizeof(float);
 }
 
 CUROBO_EXPORT int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres, int num_collision_pairs,

@@ -21,6 +21,7 @@ from ..backends import collision as collision_hip
 from ..backends import cost as cost_hip
 from ..backends import geometry as geometry_hip
 from ..backends import kinematics as kinematics_hip
+from ..backends import rollout as rollout_hip
 from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
 from ..scene.data import SceneData
@@ -50,6 +51,8 @@ class TrajOptRolloutCfg:
     retime_regularization_weights: bool = True
     max_acceleration: float = 15.0  # content/configs/robot/franka.yml:48-49
     max_jerk: float = 500.0
+    #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
+    use_fused: bool = True
 
     @property
     def horizon(self) -> int:
@@ -86,6 +89,8 @@ class TrajOptRollout:
         self._effort_b = torch.stack([-1e9 * ones, 1e9 * ones])
         self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
         self.batch_size = 0
+        self._fused_ok: Optional[bool] = None
+        self._terms = None
         self.update_batch_size(batch_size)
         self.update_start_state(None)
 
@@ -215,7 +220,53 @@ class TrajOptRollout:
                 self._implicit_goal, B, H, D, c.n_knots, c.bspline_degree, False)
         return self.cost
 
+    # ------------------------------------------------------------------ fused
+    def fused_available(self) -> bool:
+        k, c = self.kin, self.cfg
+        n_obs = (self.scene.struct.max_cuboids + self.scene.struct.max_voxel_grids) if self.scene is not None else 0
+        need = rollout_hip.rollout_trajopt_fused_lds_bytes(
+            c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
+            int(k.link_chain_data.shape[0]), n_obs, True)
+        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
+
+    def cost_and_gradient_fused(self, act_seq: torch.Tensor, with_metrics: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Same numbers as ``evaluate_action`` from one launch (the struct of optional terms is
+        rebuilt per call: it only holds pointers of the static buffers)."""
+        k, c, B = self.kin, self.cfg, self.batch_size
+        sc, m = k.self_collision, with_metrics
+        use_scene = self.scene is not None
+        self._terms = rollout_hip.make_trajopt_terms(
+            out_pose_distance=self.pose_cost if m else None, out_position_distance=self.pose_pos_dist if m else None,
+            out_rotation_distance=self.pose_rot_dist if m else None, out_goalset_idx=self.goalset_idx if m else None,
+            goal_position=self.goal_position, goal_quat=self.goal_quat, idxs_goal=self.idxs_goal,
+            position_orientation_weight=self._pose_w, terminal_pose_axes_weight_factor=self._axes_w,
+            non_terminal_pose_axes_weight_factor=self._axes_w0, terminal_pose_convergence_tolerance=self._tol,
+            non_terminal_pose_convergence_tolerance=self._tol, project_distance_to_goal=self._project,
+            tool_frame_map=k.tool_frame_map, n_tool_frames=k.num_pose_links, num_goalset=1,
+            rotation_method=c.rotation_method, out_cspace_cost=self.cspace_cost if m else None, state_dt=self.state_dt,
+            target_joint_position=self._zeroD, idxs_target_joint_position=self._idx0, p_b=self._p_b, v_b=self._v_b,
+            a_b=self._a_b, j_b=self._j_b, effort_b=self._effort_b, cspace_weight=self._cs_w,
+            cspace_activation_distance=self._cs_eta, squared_l2_regularization_weights=self._cs_reg,
+            cspace_target_weight=self._zero1, cspace_non_terminal_weight_factor=self._zero1,
+            cspace_target_dof_weight=self._onesD, retime_weights=c.retime_weights,
+            retime_regularization_weights=c.retime_regularization_weights)
+        rollout_hip.rollout_trajopt_fused(
+            self._terms, self.cost, self.grad_knots, self.position if m else None, self.robot_spheres if m else None,
+            act_seq, self.start_pos, self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel,
+            self.goal_acc, self.goal_jerk, self.start_idx, self.goal_idx, self._traj_dt, self._implicit_goal,
+            k.fixed_transforms, k.link_spheres, k.joint_map_type, k.joint_map, k.link_map, k.link_sphere_idx_map,
+            k.link_chain_data, k.link_chain_offsets, k.joint_offset_map, sc.sphere_padding, self._w_self,
+            sc.collision_pairs, self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
+            self._eta_scene, self._speed_dt, self.env_query_idx, k.num_envs, False, B, c.padded_horizon, self.action_dim,
+            c.n_knots, c.bspline_degree, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric)
+        return self.cost, self.grad_knots.view(B, -1)
+
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         act = x.view(self.batch_size, self.cfg.n_knots, self.action_dim)
+        if self.cfg.use_fused:
+            if self._fused_ok is None:
+                self._fused_ok = self.fused_available()
+            if self._fused_ok:
+                return self.cost_and_gradient_fused(act)
         cost = self.evaluate_action(act, with_gradient=True)
         return cost, self.grad_knots.view(self.batch_size, -1)

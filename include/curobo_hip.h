@@ -283,6 +283,58 @@ int curobo_hip_rollout_trajectory_fused(
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream);
 
+/* Optional cost terms of the full trajopt task (reference content/configs/task/trajopt/
+ * lbfgs_bspline_trajopt.yml: tool_pose_cfg + cspace_cfg with cost_type STATE) for
+ * curobo_hip_rollout_trajopt_fused.  Pointer meaning = curobo_hip_tool_pose_distance and
+ * curobo_hip_cspace_state_cost.  Set n_tool_frames = 0 / cspace_weight = NULL to switch a term off.
+ * Optional metric outputs (NULL = skip): out_pose_distance [b, h, T, 2], out_position_distance,
+ * out_rotation_distance, out_goalset_idx [b, h, T], out_cspace_cost [b, h, dof]. */
+typedef struct curobo_hip_trajopt_terms {
+  float *out_pose_distance, *out_position_distance, *out_rotation_distance;
+  int32_t *out_goalset_idx;
+  const float *goal_position, *goal_quat;
+  const int32_t *idxs_goal;
+  const float *position_orientation_weight;
+  const float *terminal_pose_axes_weight_factor, *non_terminal_pose_axes_weight_factor;
+  const float *terminal_pose_convergence_tolerance, *non_terminal_pose_convergence_tolerance;
+  const uint8_t *project_distance_to_goal;
+  const int16_t *tool_frame_map;
+  int32_t n_tool_frames, num_goalset, rotation_method;
+  float *out_cspace_cost;
+  const float *state_dt, *target_joint_position;
+  const int32_t *idxs_target_joint_position;
+  const float *p_b, *v_b, *a_b, *j_b, *effort_b;
+  const float *cspace_weight, *cspace_activation_distance, *squared_l2_regularization_weights;
+  const float *cspace_target_weight, *cspace_non_terminal_weight_factor, *cspace_target_dof_weight;
+  int32_t retime_weights, retime_regularization_weights;
+} curobo_hip_trajopt_terms;
+
+/* curobo_hip_rollout_trajectory_fused plus the optional terms above: the whole reference trajopt
+ * rollout (B-spline -> FK -> tool pose + c-space STATE + self + swept scene collision -> cost and
+ * gradient to the knots) in one launch; the velocity / acceleration / jerk samples and their
+ * gradients live in LDS as well.  terms may be NULL (then identical to the function above). */
+int curobo_hip_rollout_trajopt_fused(
+    float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres,
+    const float *u_position, const float *start_position, const float *start_velocity,
+    const float *start_acceleration, const float *start_jerk, const float *goal_position,
+    const float *goal_velocity, const float *goal_acceleration, const float *goal_jerk,
+    const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt,
+    const uint8_t *use_implicit_goal_state, const float *fixed_transform,
+    const float *robot_spheres, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *link_sphere_map, const int16_t *link_chain_data,
+    const int16_t *link_chain_offsets, const float *joint_offset_map, const float *sphere_padding,
+    const float *self_collision_weight, const int16_t *pair_locations,
+    const curobo_hip_scene *scene, const float *scene_collision_weight,
+    const float *activation_distance, const float *speed_dt, const int32_t *env_query_idx,
+    int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
+    int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
+    int link_chain_len, int sweep_steps, int enable_speed_metric,
+    const curobo_hip_trajopt_terms *terms, curobo_hip_stream_t stream);
+
+int curobo_hip_rollout_trajopt_fused_lds_bytes(
+    int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
+    int link_chain_len, int num_obstacles, int with_cspace_terms);
+
 /* LDS bytes one trajectory needs in curobo_hip_rollout_trajectory_fused (host-side query, no GPU
  * work); the fused entry point is usable when this is <= 163840.  num_obstacles = max_cuboids +
  * max_voxel_grids of the scene (0 without a scene term). */

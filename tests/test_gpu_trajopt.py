@@ -21,7 +21,8 @@ def _setup(device):
     return model, kin, arrays, SceneData.from_arrays(arrays, device)
 
 
-def test_trajopt_rollout_matches_oracle_composition(oracle, device):
+@pytest.mark.parametrize("fused", [False, True])
+def test_trajopt_rollout_matches_oracle_composition(fused, oracle, device):
     """non-swept scene term for the strict comparison (the sweep has the documented zero-motion
     discontinuity); every cost term of the reference trajopt task is active"""
     from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
@@ -29,7 +30,7 @@ def test_trajopt_rollout_matches_oracle_composition(oracle, device):
 
     model, kin, arrays, scene = _setup(device)
     md = model.as_dict()
-    cfg = TrajOptRolloutCfg(use_sweep=False, use_speed_metric=False)
+    cfg = TrajOptRolloutCfg(use_sweep=False, use_speed_metric=False, use_fused=fused)
     B, nk, D, H = 10, cfg.n_knots, kin.num_dof, cfg.padded_horizon
     knots = seed_knots(model, B, nk, seed=4, spread=0.6)
     start = start_configuration(model)
@@ -75,6 +76,50 @@ def test_trajopt_rollout_matches_oracle_composition(oracle, device):
     gk = oracle.bspline_backward(gq + cs["grad_position"], cs["grad_velocity"], cs["grad_acceleration"], cs["grad_jerk"], dt, i0,
                                  imp, nk, cfg.bspline_degree)
     np.testing.assert_allclose(grad.cpu().numpy().reshape(gk.shape), gk, rtol=3e-3, atol=3e-5 * np.abs(gk).max())
+
+
+@pytest.mark.parametrize("implicit_goal", [False, True])
+def test_trajopt_fused_equals_kernel_sequence(implicit_goal, device):
+    """one launch vs the ten-launch sequence of TrajOptRollout.evaluate_action, swept scene term
+    included (evaluated on the fused kernel's own materialised spheres, see test_gpu_fused.py),
+    with and without an implicit goal joint state; metric buffers too"""
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    B = 12
+    rng = np.random.default_rng(2)
+    knots = torch.as_tensor(seed_knots(model, B, 12, seed=8, spread=0.6), device=device)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    gpos = torch.as_tensor(rng.normal(size=(3, 1, 1, 3)).astype(np.float32) * 0.4, device=device)
+    gq = rng.normal(size=(3, 1, 1, 4)).astype(np.float32)
+    gq /= np.linalg.norm(gq, axis=-1, keepdims=True)
+    idx = torch.as_tensor(rng.integers(0, 3, size=B).astype(np.int32), device=device)
+    goal_q = torch.as_tensor(sample_q(model, 3, seed=4, scale=0.5), device=device)
+    ros = []
+    for fused in (False, True):
+        ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(use_fused=fused, traj_dt=0.1))
+        ro.update_start_state(start)
+        ro.update_goals(gpos, torch.as_tensor(gq, device=device), idx)
+        if implicit_goal:
+            ro.update_goal_state(goal_q, idx)
+        ros.append(ro)
+    ref, fz = ros
+    assert fz.fused_available()
+    c1, g1 = [t.clone() for t in fz.cost_and_gradient_fused(knots, with_metrics=True)]
+    torch.cuda.synchronize()
+    # kernel sequence on the fused kernel's materialised spheres (identical sweep branches)
+    c0 = ref.evaluate_action(knots, with_gradient=True)  # fills ref.position / spheres from its own FK
+    torch.testing.assert_close(fz.position, ref.position, rtol=0, atol=2e-6)
+    torch.testing.assert_close(fz.robot_spheres, ref.robot_spheres, rtol=0, atol=2e-6)
+    assert float(c0.max()) > 0
+    torch.testing.assert_close(fz.pose_cost, ref.pose_cost, rtol=2e-4, atol=2e-5 * float(ref.pose_cost.abs().max()))
+    torch.testing.assert_close(fz.cspace_cost, ref.cspace_cost, rtol=2e-4, atol=2e-5 * float(ref.cspace_cost.abs().max()))
+    still = (ref.robot_spheres[:, 1:, :, :3] - ref.robot_spheres[:, :-1, :, :3]).norm(dim=-1).min() < 1e-5
+    tol = dict(rtol=5e-2, atol=5e-2 * float(c0.abs().max())) if bool(still) else dict(rtol=2e-4, atol=1e-1)
+    torch.testing.assert_close(c1, c0, **tol)
+    g0 = ref.grad_knots.view(B, -1)
+    torch.testing.assert_close(g1, g0, rtol=5e-2 if bool(still) else 2e-3, atol=(5e-2 if bool(still) else 5e-5) * float(g0.abs().max()))
 
 
 def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
