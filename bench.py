@@ -254,6 +254,7 @@ def main():
         }
         if world == 1 and not args.no_ik:
             out["ik"] = ik_benchmark(args, model, kin, device, torch)
+            out["full_trajopt_rollout"] = full_trajopt_benchmark(args, model, kin, scene, device, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -281,6 +282,32 @@ def measured_traffic(kernel: str):
         if kernel in str(rec.get("kernel", "")) and rec.get("hbm_bytes_per_launch"):
             best = (int(rec["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(path))
     return best
+
+
+def full_trajopt_benchmark(args, model, kin, scene, device, torch):
+    """Secondary: the FULL reference trajopt cost set (tool pose + c-space STATE + self + swept
+    scene collision, lbfgs_bspline_trajopt.yml) on the C2 shapes: one fused launch vs the
+    ten-launch kernel sequence, cost + gradient of 1024 trajectories."""
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    B = args.seeds * 4
+    res = {}
+    knots = torch.as_tensor(seed_knots(model, B, 12, seed=2), device=device)
+    for name, fused in (("fused_us", True), ("kernel_sequence_us", False)):
+        ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(use_fused=fused))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        x = knots.reshape(B, -1)
+        ro.cost_and_gradient(x)
+        torch.cuda.synchronize()
+        g, reps = torch.cuda.CUDAGraph(), 10  # hipGraph replay: device time, not Python launch overhead
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                ro.cost_and_gradient(x)
+        res[name] = round(time_kernel(g.replay, 20, torch) / reps, 1)
+    res["rollouts_per_s_fused"] = round(B / res["fused_us"] * 1e6, 1)
+    res["workload"] = "C2 shapes, full trajopt cost set (pose + c-space state + self + swept scene), cost+grad"
+    return res
 
 
 def ik_benchmark(args, model, kin, device, torch):

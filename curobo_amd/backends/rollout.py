@@ -62,8 +62,10 @@ def _rollout_trajectory(fn, terms, with_terms,
     bspline_degree: int,
     sweep_steps: int = 0,
     enable_speed_metric: bool = False,
+    dispatch: Optional["DispatchOrder"] = None,
 ):
     num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
+    ws, phase = (None, 0) if dispatch is None else dispatch.next(batch_size)
     extra = ((None if terms is None else C.addressof(terms)),) if with_terms else ()
     check(fn(
         ptr(out_cost), ptr(out_grad_knots), ptr(out_position), ptr(out_robot_spheres), ptr(u_position),
@@ -76,7 +78,7 @@ def _rollout_trajectory(fn, terms, with_terms,
         ptr(activation_distance), ptr(speed_dt), ptr(env_query_idx), num_envs, int(use_multi_env),
         batch_size, padded_horizon, dof, n_knots, bspline_degree, int(fixed_transform.shape[0]),
         int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]), sweep_steps,
-        int(enable_speed_metric), *extra, current_stream(out_cost),
+        int(enable_speed_metric), ptr(ws), phase, *extra, current_stream(out_cost),
     ))
 
 
@@ -125,12 +127,34 @@ def rollout_trajectory_fused(
     bspline_degree: int,
     sweep_steps: int = 0,
     enable_speed_metric: bool = False,
+    dispatch: Optional["DispatchOrder"] = None,
 ):
     """cost[b], grad_knots[b, n_knots, dof] of ``batch_size`` B-spline trajectories in one launch."""
-    return _rollout_trajectory(load().curobo_hip_rollout_trajectory_fused, None, False, out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity, start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, traj_dt, use_implicit_goal_state, fixed_transform, robot_spheres, joint_map_type, joint_map, link_map, link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight, pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs, use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, sweep_steps, enable_speed_metric)
+    return _rollout_trajectory(load().curobo_hip_rollout_trajectory_fused, None, False, out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity, start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, traj_dt, use_implicit_goal_state, fixed_transform, robot_spheres, joint_map_type, joint_map, link_map, link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight, pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs, use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, sweep_steps, enable_speed_metric, dispatch)
 
 
 FUSED_LDS_LIMIT = 160 * 1024
+
+
+class DispatchOrder:
+    """Longest-first dispatch workspace of the fused trajectory kernels (``dispatch_ws`` /
+    ``dispatch_phase`` of the header): one per rollout instance, i.e. per sequence of launches on the
+    same batch of optimisation variables.  ``next`` hands out the workspace with alternating phase
+    (also under graph capture: the captured launches keep the phase they were captured with; any
+    phase sequence is safe, alternation just keeps the duration estimates one launch old)."""
+
+    def __init__(self, batch_size: int, device: torch.device):
+        lib = load()
+        self.batch_size = batch_size
+        self.ws = torch.empty(int(lib.curobo_hip_rollout_dispatch_ws_size(batch_size)), dtype=torch.int32, device=device)
+        check(lib.curobo_hip_rollout_dispatch_ws_init(ptr(self.ws), batch_size, current_stream(self.ws)))
+        self._phase = 1
+
+    def next(self, batch_size: int):
+        if batch_size != self.batch_size:
+            raise ValueError(f"dispatch workspace was made for batch {self.batch_size}, launch has {batch_size}")
+        self._phase ^= 1
+        return self.ws, self._phase
 
 
 def rollout_trajectory_fused_lds_bytes(padded_horizon: int, dof: int, num_links: int, num_spheres: int,

@@ -53,6 +53,8 @@ def _flags() -> List[str]:
         # cuda_core_backend/kernel_cache.py:208-218)
         "-fno-hip-fp32-correctly-rounded-divide-sqrt",
         f"-I{INCLUDE}", f"-I{CSRC}",
+        # diagnostic builds only (e.g. CUROBO_HIP_EXTRA_FLAGS=-DCUROBO_FUSED_STAMP_TERMS with force=True)
+        *os.environ.get("CUROBO_HIP_EXTRA_FLAGS", "").split(),
     ]
 
 

@@ -247,8 +247,11 @@ __device__ __forceinline__ float cspace_state_point(const CspaceStateArgs &a, in
   float wb[5], wr[5];
 #pragma unroll
   for (int i = 0; i < 5; i++) { wb[i] = a.weight[i]; wr[i] = a.sql2_weights[i]; g[i] = 0.0f; }
-  if (a.retime_weights) { wb[1] = dt * wb[1]; wb[2] = powf(dt, 2.0f) * wb[2]; wb[3] = powf(dt, 3.0f) * wb[3]; }
-  if (a.retime_reg_weights) { wr[0] = dt * wr[0]; wr[1] = powf(dt, 2.0f) * wr[1]; wr[2] = powf(dt, 3.0f) * wr[2]; wr[4] = dt * wr[4]; }
+  // (the reference writes wp.pow(dt, 2.0) / wp.pow(dt, 3.0); plain products are within an ulp and keep
+  // the generic pow expansion out of the fused kernel's register budget)
+  const float dt2 = dt * dt, dt3 = dt * dt * dt;
+  if (a.retime_weights) { wb[1] = dt * wb[1]; wb[2] = dt2 * wb[2]; wb[3] = dt3 * wb[3]; }
+  if (a.retime_reg_weights) { wr[0] = dt * wr[0]; wr[1] = dt2 * wr[1]; wr[2] = dt3 * wr[2]; wr[4] = dt * wr[4]; }
   float c = 0.0f;
   bound_term(x[0], a.p_b, a.dof, d, a.activation_distance[0], wb[0], c, g[0]);
   bound_term(x[1], a.v_b, a.dof, d, a.activation_distance[1], wb[1], c, g[1]);

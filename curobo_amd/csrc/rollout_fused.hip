@@ -55,6 +55,9 @@ struct FusedTrajArgs {
   CspaceStateArgs cs;     // pos/vel/acc/jerk unused (LDS); out_cost optional [B, H, D]; out_g* unused
   const int16_t *tool_frame_map;
   int n_tool_frames, use_pose, use_cspace;
+  // optional longest-first dispatch (see rebuild_dispatch_order): int32 [4][B] = order[2][B], ticks[2][B]
+  int32_t *dispatch_ws;
+  int dispatch_phase;
   long long *prof;  // optional [B][16] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
 };
 
@@ -68,7 +71,7 @@ constexpr int kWrench = 7;  // per link: force xyz, torque xyz about the link or
 
 struct FusedLayout {
   int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, off_add, fixed, chain, sph_link, sph_rad,
-      sph_pad, rs, lbound, sub, jlinks, left, key, dyn, pairs, recs, total;
+      sph_pad, rs, lbound, sub, jlinks, left, key, flag, dyn, cstab, pairs, recs, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0) {
   FusedLayout f;
@@ -97,7 +100,9 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.jlinks = take(D * 4);
   f.left = take(S * 4);
   f.key = take(4);
-  f.dyn = take(n_dyn);  // velocity / acceleration / jerk [3][H][D] when the c-space STATE cost is on
+  f.flag = take(H);  // per point: any wrench written
+  f.dyn = take(n_dyn);  // velocity / acceleration / jerk (+ joint-space position gradient) [4][H][D] when the c-space STATE cost is on
+  f.cstab = take(n_dyn ? 8 * D + 12 : 0);  // c-space limits (shrunk) [8][D] + 10 retimed weights + dt
   f.pairs = take((P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
   f.recs = take(n_rec * kObsRecFloats);
   f.total = o;
@@ -112,7 +117,9 @@ struct FusedCtx {
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
   float4 *left;
+  int *flag;   // [H] point has gradients (set by the cost pass, read by the VJP pass)
   float *dyn;  // [3][H][D] velocity / acceleration / jerk, later their cost gradients
+  float *cstab;  // c-space STATE constants staged once per workgroup: limits [8][D], weights [10], dt
   unsigned long long *key;
   ObsRec *recs;
   int H, D, L, S, P, ws, wl, env;
@@ -319,8 +326,10 @@ __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPos
                                                 float *out_link_quat, int lane, int lane64, float &cost_pt, bool &any_grad) {
   const float *cumul = c.cumul + (size_t)h * c.L * 12;
   float *wr = c.wrench + (size_t)h * c.wl;
+  int lane_o = lane;
+  asm volatile("" : "+v"(lane_o));  // keeps the per-lane output addresses out of the caller's loop-invariant set
   for (int t0 = 0; t0 < T; t0 += kFkLanes) {
-    const int t = t0 + lane;
+    const int t = t0 + lane_o;
     f3 gp = make_f3(0.f, 0.f, 0.f), om = gp, pos = gp;
     int l = 0;
     if (t < T) {
@@ -359,27 +368,78 @@ __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPos
   }
 }
 
-// c-space STATE cost of point h (wp_cspace_state.py:20-287), one dof per lane.  The position
-// gradient is returned per lane (added to grad_q after the wrench gather, it is already in joint
-// space); the velocity / acceleration / jerk gradients replace the values in c.dyn in place.
+// c-space STATE constants of this trajectory -> LDS (wp_cspace_state.py:92-160): limits shrunk by
+// activation_distance * range, bound / regularisation weights retimed with the trajectory's dt.
+// Keeps the ~20 global pointers of the term out of the per-point code (register budget).
+__device__ __forceinline__ void stage_cspace_tables(const FusedCtx &c, const CspaceStateArgs &cs, int b) {
+  const int D = c.D;
+  for (int i = threadIdx.x; i < 8 * D + 11; i += blockDim.x) {
+    float v;
+    if (i < 8 * D) {
+      const int q = i / (2 * D), side = (i / D) & 1, d = i % D;  // quantity 0..3 (pos, vel, acc, jerk), lower / upper
+      const float *lim = q == 0 ? cs.p_b : q == 1 ? cs.v_b : q == 2 ? cs.a_b : cs.j_b;
+      const float lo = lim[d], hi = lim[D + d], r = hi - lo, eta = cs.activation_distance[q];
+      v = side == 0 ? lo + eta * r : hi - eta * r;
+    } else {
+      const int k = i - 8 * D;
+      const float dt = cs.state_dt[b], dt2 = dt * dt, dt3 = dt * dt * dt;
+      if (k < 5) {
+        v = cs.weight[k];
+        if (cs.retime_weights) v = k == 1 ? dt * v : k == 2 ? dt2 * v : k == 3 ? dt3 * v : v;
+      } else if (k < 10) {
+        const int j = k - 5;
+        v = cs.sql2_weights[j];
+        if (cs.retime_reg_weights) v = j == 0 ? dt * v : j == 1 ? dt2 * v : j == 2 ? dt3 * v : j == 4 ? dt * v : v;
+      } else {
+        v = dt;
+      }
+    }
+    c.cstab[i] = v;
+  }
+}
+
+// c-space STATE cost of point h (wp_cspace_state.py:20-287), one dof per lane, constants from LDS.
+// The position gradient is returned per lane (added to grad_q after the wrench gather: it is already
+// in joint space); the velocity / acceleration / jerk gradients replace the values in c.dyn.
+// Effort terms are off in the fused kernel (no dynamics in the loop): tau = 0 contributes nothing.
 constexpr int kDofIters = (64 + kFkLanes - 1) / kFkLanes;
 __device__ __forceinline__ void point_cspace_state(const FusedCtx &c, const CspaceStateArgs &cs, int b, int h, int lane,
-                                                   float &cost_pt, float (&gp_joint)[kDofIters]) {
-  const int HD = c.H * c.D;
-#pragma unroll
-  for (int it = 0; it < kDofIters; it++) {
-    const int d = it * kFkLanes + lane;
-    gp_joint[it] = 0.0f;
-    if (d < c.D) {
-      const int e = h * c.D + d;
-      const float x[5] = {c.q[e], c.dyn[e], c.dyn[HD + e], c.dyn[2 * HD + e], 0.0f};
-      float g[5];
-      const float cc = cspace_state_point(cs, b, h, d, x, g);
-      cost_pt += cc;
-      gp_joint[it] = g[0];
-      c.dyn[e] = g[1]; c.dyn[HD + e] = g[2]; c.dyn[2 * HD + e] = g[3];
-      if (cs.out_cost) cs.out_cost[((size_t)b * c.H + h) * c.D + d] = cc;
+                                                   float &cost_pt) {
+  const int D = c.D, HD = c.H * c.D;
+  const float *w = c.cstab + 8 * D;
+  // opaque to the optimiser: otherwise the per-lane addresses of the ~12 table / stream slots are
+  // hoisted out of the caller's point loop and held in VGPRs across the pose term and the gather
+  int d0 = lane;
+  asm volatile("" : "+v"(d0));
+#pragma unroll 1
+  for (int d = d0; d < D; d += kFkLanes) {
+    const int e = h * D + d;
+    float cc = 0.0f, g0 = 0.0f;
+    {
+      const float x = c.q[e], lo = c.cstab[d], hi = c.cstab[D + d];
+      if (x < lo) squared_l2_term(x - lo, w[0], cc, g0);
+      else if (x > hi) squared_l2_term(x - hi, w[0], cc, g0);
+      float tw = cs.target_weight[0];
+      if (h < c.H - 1) tw *= cs.non_terminal_factor[0];
+      if (tw > 0.0f) {
+        tw *= cs.target_dof_weight[d];
+        const float err = x - cs.target[(size_t)cs.idxs_target[b] * D + d];
+        cc += tw * err * err;
+        g0 += 2.0f * tw * err;
+      }
     }
+#pragma unroll
+    for (int q = 1; q < 4; q++) {  // velocity, acceleration, jerk: bound + squared-L2 regularisation
+      const float x = c.dyn[(q - 1) * HD + e], lo = c.cstab[2 * q * D + d], hi = c.cstab[(2 * q + 1) * D + d];
+      float g = 0.0f;
+      if (x < lo) squared_l2_term(x - lo, w[q], cc, g);
+      else if (x > hi) squared_l2_term(x - hi, w[q], cc, g);
+      squared_l2_term(x, w[5 + q - 1], cc, g);
+      c.dyn[(q - 1) * HD + e] = g;
+    }
+    cost_pt += cc;
+    c.dyn[3 * HD + e] = g0;  // joint-space position gradient, added to grad_q after the wrench gather
+    if (cs.out_cost) cs.out_cost[((size_t)b * c.H + h) * D + d] = cc;
   }
 }
 
@@ -400,7 +460,9 @@ __device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const 
   c.jlinks = reinterpret_cast<uint32_t *>(smem + lay.jlinks);  // [D][4]: links driven by joint d
   c.left = reinterpret_cast<float4 *>(smem + lay.left);
   c.key = reinterpret_cast<unsigned long long *>(smem + lay.key);
+  c.flag = reinterpret_cast<int *>(smem + lay.flag);
   c.dyn = smem + lay.dyn;
+  c.cstab = smem + lay.cstab;
   c.pairs = reinterpret_cast<uint32_t *>(smem + lay.pairs);
   c.recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
   c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
@@ -501,18 +563,90 @@ __device__ __forceinline__ void fused_derive_tables(const FusedCtx &c) {
 // Points beyond the last full round of 16-lane rows (H = 33 on 32 rows) are "leftover" points:
 // instead of a round in which one row works and 31 wait, all threads share them (pairs and spheres
 // spread over the workgroup, gradients handed over through LDS, row 0 finishes the VJP).
-template <int DEG, int SWEEP, int KINDS>
+// Optional terms of a point, each in its own loop over the row's points (the register sets of the
+// tool-pose distance, the c-space STATE term and the wrench gather then do not add up):
+// tool pose -> cost, wrench and gradient flag; c-space STATE -> cost and stream gradients.
+__device__ __forceinline__ void point_pose_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane, int lane64) {
+  bool any_grad = c.flag[h] != 0;
+  float cost2 = 0.0f;
+  point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * c.H + h) * a.n_tool_frames, nullptr, nullptr,
+                  lane, lane64, cost2, any_grad);
+  cost2 = row16_sum(cost2);
+  if (lane == 0) { c.cost[h] += cost2; c.flag[h] = any_grad ? 1 : 0; }
+}
+__device__ __forceinline__ void point_cspace_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane) {
+  float cost2 = 0.0f;
+  point_cspace_state(c, a.cs, b, h, lane, cost2);
+  cost2 = row16_sum(cost2);
+  if (lane == 0) c.cost[h] += cost2;
+}
+
+// Longest-first dispatch of the trajectory workgroups.  A launch is two rounds of workgroups on the
+// chip (1024 trajectories, 2 x 256 resident) and their durations differ by 3x (trajectories deep in
+// collision do many more signed-distance evaluations), so the launch ends with a few CUs finishing
+// long workgroups that started late.  Workgroups are dispatched in blockIdx order: mapping blockIdx
+// through a longest-first permutation starts the long ones in the first round.  The durations of an
+// optimiser's candidates change little between iterations, so the previous launch's measurements
+// are the estimate: every workgroup records its wall-clock ticks in ticks[phase][b]; one workgroup
+// of the launch turns ticks[1 - phase] (complete: written by an earlier launch) into
+// order[1 - phase] for the next launch, which the caller runs with the other phase.  A launch reads
+// order[phase] and writes order[1 - phase] / ticks[phase], so no array is read and written by the
+// same launch, whatever sequence of phases the caller uses; every order[] is a permutation, the
+// outputs do not depend on it.  Bucket sort (64 buckets of max/64 ticks) with LDS atomics.
+__device__ __forceinline__ void rebuild_dispatch_order(int32_t *ws, int B, int phase, int *lds, int tid, int nt) {
+  constexpr int NB = 64;
+  const int32_t *ticks = ws + (size_t)(2 + (1 - phase)) * B;
+  int32_t *order = ws + (size_t)(1 - phase) * B;
+  for (int i = tid; i <= 2 * NB; i += nt) lds[i] = 0;
+  __syncthreads();
+  int m = 0;
+  for (int i = tid; i < B; i += nt) m = max(m, ticks[i]);
+  if (m > 0) atomicMax(&lds[2 * NB], m);
+  __syncthreads();
+  const long long mx = lds[2 * NB];
+  for (int i = tid; i < B; i += nt) {
+    const int t = max(ticks[i], 0);
+    atomicAdd(&lds[NB - 1 - (int)((long long)t * NB / (mx + 1))], 1);  // bucket 0 = longest
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NB; k++) { lds[NB + k] = acc; acc += lds[k]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += nt) {
+    const int t = max(ticks[i], 0);
+    order[atomicAdd(&lds[NB + NB - 1 - (int)((long long)t * NB / (mx + 1))], 1)] = i;
+  }
+}
+
+#ifdef CUROBO_FUSED_STAMP_TERMS
+constexpr bool kStampTerms = true;  // diagnostic builds only: the stamps cost the TERMS variant registers
+#else
+constexpr bool kStampTerms = false;
+#endif
+
+// TERMS: the optional tool-pose / c-space STATE terms are compiled in (separate instantiation so the
+// collision-only kernel keeps its register budget: with them inlined it spilled 232 B per lane)
+template <int DEG, int SWEEP, int KINDS, bool TERMS>
 __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const FusedTrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, a.use_cspace ? 3 * H * D : 0);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int b = blockIdx.x;
+  const bool use_pose = TERMS && a.use_pose != 0, use_cspace = TERMS && a.use_cspace != 0;
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0);
+  const int tid = threadIdx.x;
+  const int wave_idx = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockDim.x;
+  // trajectory of this workgroup: blockIdx.x itself, or the entry of the longest-first order that the
+  // previous launches built from the measured workgroup durations (same results, shorter tail)
+  const bool reorder = a.dispatch_ws != nullptr;
+  const int b = reorder ? a.dispatch_ws[(size_t)a.dispatch_phase * a.batch + blockIdx.x] : (int)blockIdx.x;
+  const long long t_begin = reorder ? wall_clock64() : 0ll;
   FusedCtx c;
   fused_ctx_carve(c, smem, lay, H, D, L, S, P);
   c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
-#define CUROBO_STAMP(i) do { if (a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
+#define CUROBO_STAMP(i) do { if ((!TERMS || kStampTerms) && a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
   CUROBO_STAMP(0);
   const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
   const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
@@ -525,12 +659,13 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   // ---------------- P0: tables + B-spline samples
   const int nwaves = nt >> 6;
   fused_stage_tables(c, a, lay, rs, n_rec);
+  if (use_cspace) stage_cspace_tables(c, a.cs, b);
   for (int e = rotated_tid(nwaves / 2); e < H * D; e += nt) {
     const int h = e / D, d = e - h * D;
     float o4[4];
     bspline_sample<DEG>(a.bs, b, h, d, o4);
     c.q[e] = o4[0];
-    if (a.use_cspace) { c.dyn[e] = o4[1]; c.dyn[H * D + e] = o4[2]; c.dyn[2 * H * D + e] = o4[3]; }
+    if (use_cspace) { c.dyn[e] = o4[1]; c.dyn[H * D + e] = o4[2]; c.dyn[2 * H * D + e] = o4[3]; }
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
   }
   __syncthreads();
@@ -626,7 +761,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
         if (lane == 0) cost_pt += self_pair_apply(c, h, m, kmin);
       }
     }
-    const bool stamp_pt = a.prof && lane == 0 && h == (b % H);
+    const bool stamp_pt = (!TERMS || kStampTerms) && a.prof && lane == 0 && h == (b % H);
     if (stamp_pt) a.prof[(size_t)b * 16 + 5] = wall_clock64();
     if (a.use_scene) {
       point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
@@ -643,22 +778,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       }
     }
     if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
-    float gp_joint[kDofIters];
-    if (a.use_pose)
-      point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * H + h) * a.n_tool_frames, nullptr,
-                      nullptr, lane, lane64, cost_pt, any_grad);
-    if (a.use_cspace) point_cspace_state(c, a.cs, b, h, lane, cost_pt, gp_joint);
     cost_pt = row16_sum(cost_pt);
-    if (lane == 0) c.cost[h] = cost_pt;
-    point_vjp_gather(c, h, any_grad, lane);
-    if (a.use_cspace) {
-#pragma unroll
-      for (int it = 0; it < kDofIters; it++) {
-        const int d = it * kFkLanes + lane;
-        if (d < D) c.q[h * D + d] += gp_joint[it];  // same lane wrote it in the gather
-      }
-    }
-    if (stamp_pt) a.prof[(size_t)b * 16 + 7] = wall_clock64();
+    if (lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
   }
   for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
     if (tid == 0) *c.key = 0ull;
@@ -699,22 +820,32 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
           any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), make_f3(gd.x, gd.y, gd.z), lane64) || any_grad;
         }
       }
-      float gp_joint[kDofIters];
-      if (a.use_pose)
-        point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * H + h) * a.n_tool_frames, nullptr,
-                        nullptr, lane, lane64, cost_pt, any_grad);
-      if (a.use_cspace) point_cspace_state(c, a.cs, b, h, lane, cost_pt, gp_joint);
       cost_pt = row16_sum(cost_pt);
-      if (lane == 0) c.cost[h] = cost_pt;
-      point_vjp_gather(c, h, any_grad, lane);
-      if (a.use_cspace) {
-#pragma unroll
-        for (int it = 0; it < kDofIters; it++) {
-          const int d = it * kFkLanes + lane;
-          if (d < D) c.q[h * D + d] += gp_joint[it];
-        }
-      }
+      if (lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
     }
+  }
+  if (n_left > 0) __syncthreads();
+  // further passes over all points, leftover ones included (their own loops so that the register
+  // allocation of the collision pass above is not shared with the optional terms, and so that those
+  // are instantiated once): tool pose, c-space STATE, then the VJP gather
+  CUROBO_STAMP(12);
+  if (TERMS && use_pose)
+    for (int h = grp; h < H; h += ngroups) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      point_pose_term(c, a, b, h, lane, lane64);
+    }
+  CUROBO_STAMP(13);
+  if (TERMS && use_cspace)
+    for (int h = grp; h < H; h += ngroups) point_cspace_term(c, a, b, h, lane);
+  CUROBO_STAMP(14);
+  for (int h = grp; h < H; h += ngroups) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    point_vjp_gather(c, h, c.flag[h] != 0, lane);
+    // joint-space part of the c-space gradient: added after the gather (same lane wrote the slot)
+    if (TERMS && use_cspace)
+      for (int d = lane; d < D; d += kFkLanes) c.q[h * D + d] += c.dyn[3 * H * D + h * D + d];
   }
   __syncthreads();
   CUROBO_STAMP(3);
@@ -724,19 +855,34 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int go = a.bs.goal_idx[b];
   const float traj_dt = a.bs.traj_dt[go];
   const bool use_goal = a.bs.use_implicit_goal[go] != 0;
-  const float *gin[4] = {c.q, a.use_cspace ? c.dyn : nullptr, a.use_cspace ? c.dyn + H * D : nullptr,
-                         a.use_cspace ? c.dyn + 2 * H * D : nullptr};
-  for (int e = tid; e < nk * D; e += nt) {
+  const float *gin[4] = {c.q, use_cspace ? c.dyn : nullptr, use_cspace ? c.dyn + H * D : nullptr,
+                         use_cspace ? c.dyn + 2 * H * D : nullptr};
+  // TERMS variant: the thread id is recomputed here (uniform wave index * 64 + mbcnt, opaque to CSE)
+  // instead of being carried in a VGPR from the top: it was the one value that variant spilled
+  int tid3 = tid;
+  if (TERMS) {
+    int l64;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l64));
+    tid3 = wave_idx * 64 + l64;
+  }
+  for (int e = tid3; e < nk * D; e += nt) {
     const int k = e / D, d = e - k * D;
     a.out_grad_knots[(size_t)b * nk * D + e] = bspline_knot_grad<DEG>(gin, (size_t)d, D, k, nk, H, traj_dt, use_goal);
   }
-  if (tid == 0) {
+  if (tid3 == 0) {
     float acc = 0.0f;
     for (int h = 0; h < H; h++) acc += c.cost[h];
     a.out_cost[b] = acc;
   }
   CUROBO_STAMP(4);
 #undef CUROBO_STAMP
+  if (reorder) {
+    if (tid3 == 0) a.dispatch_ws[(size_t)(2 + a.dispatch_phase) * a.batch + b] = (int)(wall_clock64() - t_begin);
+    if (blockIdx.x == (gridDim.x - 1) / 2) {
+      __syncthreads();
+      rebuild_dispatch_order(a.dispatch_ws, a.batch, a.dispatch_phase, reinterpret_cast<int *>(smem), tid3, nt);
+    }
+  }
 }
 
 
@@ -924,7 +1070,7 @@ static int rollout_trajectory_fused_impl(
     const float *scene_collision_weight, const float *activation_distance, const float *speed_dt,
     const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof,
     int n_knots, int bspline_degree, int num_links, int num_spheres, int num_collision_pairs, int link_chain_len,
-    int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream) {
+    int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws, int dispatch_phase, curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(bspline_degree >= 3 && bspline_degree <= 5, "%s: bspline_degree must be 3, 4 or 5", what);
   CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && padded_horizon >= 2 && n_knots >= 1,
@@ -953,6 +1099,8 @@ static int rollout_trajectory_fused_impl(
   a.chain_len = link_chain_len; a.dpad = dof | 1; a.num_envs = num_envs; a.use_multi_env = use_multi_env;
   a.enable_speed_metric = (a.use_scene && enable_speed_metric) ? 1 : 0;
   a.prof = g_fused_prof;
+  a.dispatch_ws = dispatch_ws; a.dispatch_phase = dispatch_phase;
+  CUROBO_REQUIRE(!dispatch_ws || dispatch_phase == 0 || dispatch_phase == 1, "%s: dispatch_phase must be 0 or 1", what);
   CUROBO_REQUIRE(!a.enable_speed_metric || speed_dt, "%s: speed metric needs speed_dt", what);
   const int n_rec = a.use_scene ? a.sc.max_cuboids + a.sc.max_voxel_grids : 0;
   if (!a.use_scene) { a.sc.max_cuboids = 0; a.sc.max_voxel_grids = 0; }
@@ -960,6 +1108,10 @@ static int rollout_trajectory_fused_impl(
     const curobo_hip_trajopt_terms &t = *terms;
     a.use_pose = (t.n_tool_frames > 0 && t.goal_position) ? 1 : 0;
     a.use_cspace = t.cspace_weight ? 1 : 0;
+    // development knob (timing by elimination): CUROBO_HIP_TERMS_MASK bit 0 = tool pose, bit 1 = c-space STATE
+    static const int terms_mask = [] { const char *e = getenv("CUROBO_HIP_TERMS_MASK"); return e ? atoi(e) : 3; }();
+    if (!(terms_mask & 1)) a.use_pose = 0;
+    if (!(terms_mask & 2)) a.use_cspace = 0;
     if (a.use_pose) {
       CUROBO_REQUIRE(t.tool_frame_map && t.goal_quat && t.idxs_goal && t.position_orientation_weight &&
                          t.terminal_pose_axes_weight_factor && t.non_terminal_pose_axes_weight_factor &&
@@ -999,7 +1151,7 @@ static int rollout_trajectory_fused_impl(
     }
   }
   const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                       a.use_cspace ? 3 * padded_horizon * dof : 0);
+                                       a.use_cspace ? 4 * padded_horizon * dof : 0);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   int threads = ((padded_horizon * kFkLanes + 63) / 64) * 64;
@@ -1011,7 +1163,9 @@ static int rollout_trajectory_fused_impl(
   hipStream_t st = (hipStream_t)stream;
 #define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
   do {                                                                                                         \
-    auto kfn = rollout_trajectory_fused_kernel<DG, SW, KD>;                                                    \
+    static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;                              \
+    auto kfn = (a.use_pose || a.use_cspace || force_terms) ? rollout_trajectory_fused_kernel<DG, SW, KD, true>                     \
+                                            : rollout_trajectory_fused_kernel<DG, SW, KD, false>;                                                    \
     if (lds > 64 * 1024) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(e)); \
@@ -1044,6 +1198,20 @@ static int rollout_trajectory_fused_impl(
   return check_launch(what, st);
 }
 
+__global__ void dispatch_ws_init_kernel(int32_t *ws, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { ws[i] = i; ws[B + i] = i; ws[2 * B + i] = 0; ws[3 * B + i] = 0; }
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_dispatch_ws_size(int batch_size) { return batch_size > 0 ? 4 * batch_size : 0; }
+
+CUROBO_EXPORT int curobo_hip_rollout_dispatch_ws_init(int32_t *dispatch_ws, int batch_size, curobo_hip_stream_t stream) {
+  CUROBO_REQUIRE(dispatch_ws && batch_size > 0, "rollout_dispatch_ws_init: NULL workspace or empty batch%s", "");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dispatch_ws_init_kernel, dim3((batch_size + 255) / 256), dim3(256), 0, st, dispatch_ws, batch_size);
+  return check_launch("rollout_dispatch_ws_init", st);
+}
+
 #define CUROBO_TRAJ_PARAMS                                                                                          \
   float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres, const float *u_position,     \
       const float *start_position, const float *start_velocity, const float *start_acceleration,                      \
@@ -1056,7 +1224,8 @@ static int rollout_trajectory_fused_impl(
       const curobo_hip_scene *scene, const float *scene_collision_weight, const float *activation_distance,           \
       const float *speed_dt, const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size,           \
       int padded_horizon, int dof, int n_knots, int bspline_degree, int num_links, int num_spheres,                   \
-      int num_collision_pairs, int link_chain_len, int sweep_steps, int enable_speed_metric
+      int num_collision_pairs, int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,    \
+      int dispatch_phase
 #define CUROBO_TRAJ_ARGS                                                                                              \
   out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity,             \
       start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, \
@@ -1064,7 +1233,7 @@ static int rollout_trajectory_fused_impl(
       link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight,  \
       pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs,          \
       use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, num_links, num_spheres,                \
-      num_collision_pairs, link_chain_len, sweep_steps, enable_speed_metric
+      num_collision_pairs, link_chain_len, sweep_steps, enable_speed_metric, dispatch_ws, dispatch_phase
 
 CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(CUROBO_TRAJ_PARAMS, curobo_hip_stream_t stream) {
   return rollout_trajectory_fused_impl("rollout_trajectory_fused", nullptr, CUROBO_TRAJ_ARGS, stream);
@@ -1081,7 +1250,7 @@ CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_lds_bytes(int padded_horizon,
                                                              int num_collision_pairs, int link_chain_len,
                                                              int num_obstacles, int with_cspace_terms) {
   const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
-                                       num_obstacles, with_cspace_terms ? 3 * padded_horizon * dof : 0);
+                                       num_obstacles, with_cspace_terms ? 4 * padded_horizon * dof : 0);
   return lay.total * (int)sizeof(float);
 }
 

@@ -52,6 +52,9 @@ class CollisionRolloutCfg:
     #: trajectory fits in LDS; False forces the drop-in kernel sequence (and materialises every
     #: intermediate tensor, which the fused path only does on request)
     use_fused: bool = True
+    # fused launches map workgroups to trajectories longest-first (durations measured by the previous
+    # launch; same outputs, shorter launch tail when trajectories differ in collision work)
+    longest_first_dispatch: bool = True
     #: fused path: also write position[B,H,D] and robot_spheres[B,H,S,4] to HBM
     fused_materialize: bool = False
 
@@ -78,6 +81,7 @@ class CollisionRollout:
         self.batch_size = 0
         self.use_multi_env = False
         self._fused_ok: Optional[bool] = None
+        self._dispatch = None
         d = self.device
         self._w_self = torch.tensor([self.cfg.self_collision_weight], device=d)
         self._w_scene = torch.tensor([self.cfg.scene_collision_weight], device=d)
@@ -228,6 +232,14 @@ class CollisionRollout:
             int(k.link_chain_data.shape[0]), n_obs)
         return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128
 
+    def _dispatch_order(self):
+        """longest-first dispatch workspace of this rollout's fused launches (cfg.longest_first_dispatch)"""
+        if not self.cfg.longest_first_dispatch:
+            return None
+        if self._dispatch is None:
+            self._dispatch = rollout_hip.DispatchOrder(self.batch_size, self.cost.device)
+        return self._dispatch
+
     def cost_and_gradient_fused(self, act_seq: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Same numbers as ``evaluate_action`` + ``backward`` from one kernel launch."""
         cfg, k, B = self.cfg, self.kin, self.batch_size
@@ -245,7 +257,7 @@ class CollisionRollout:
             self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
             self._eta, self._speed_dt, self.env_query_idx, k.num_envs, self.use_multi_env, B, cfg.padded_horizon,
             self.action_dim, cfg.n_knots, cfg.bspline_degree, 3 if cfg.use_sweep else 0,
-            cfg.use_sweep and cfg.use_speed_metric)
+            cfg.use_sweep and cfg.use_speed_metric, self._dispatch_order())
         return self.cost, self.grad_knots
 
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

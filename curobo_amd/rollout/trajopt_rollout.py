@@ -53,6 +53,7 @@ class TrajOptRolloutCfg:
     max_jerk: float = 500.0
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
+    longest_first_dispatch: bool = True  # see CollisionRolloutCfg
 
     @property
     def horizon(self) -> int:
@@ -90,6 +91,7 @@ class TrajOptRollout:
         self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
         self.batch_size = 0
         self._fused_ok: Optional[bool] = None
+        self._dispatch = None
         self._terms = None
         self.update_batch_size(batch_size)
         self.update_start_state(None)
@@ -229,6 +231,13 @@ class TrajOptRollout:
             int(k.link_chain_data.shape[0]), n_obs, True)
         return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
 
+    def _dispatch_order(self):
+        if not self.cfg.longest_first_dispatch:
+            return None
+        if self._dispatch is None:
+            self._dispatch = rollout_hip.DispatchOrder(self.batch_size, self.cost.device)
+        return self._dispatch
+
     def cost_and_gradient_fused(self, act_seq: torch.Tensor, with_metrics: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """Same numbers as ``evaluate_action`` from one launch (the struct of optional terms is
         rebuilt per call: it only holds pointers of the static buffers)."""
@@ -258,7 +267,8 @@ class TrajOptRollout:
             k.link_chain_data, k.link_chain_offsets, k.joint_offset_map, sc.sphere_padding, self._w_self,
             sc.collision_pairs, self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
             self._eta_scene, self._speed_dt, self.env_query_idx, k.num_envs, False, B, c.padded_horizon, self.action_dim,
-            c.n_knots, c.bspline_degree, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric)
+            c.n_knots, c.bspline_degree, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric,
+            dispatch=self._dispatch_order())
         return self.cost, self.grad_knots.view(B, -1)
 
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

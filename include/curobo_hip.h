@@ -281,7 +281,18 @@ int curobo_hip_rollout_trajectory_fused(
     const float *activation_distance, const float *speed_dt, const int32_t *env_query_idx,
     int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
-    int link_chain_len, int sweep_steps, int enable_speed_metric, curobo_hip_stream_t stream);
+    int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,
+    int dispatch_phase, curobo_hip_stream_t stream);
+
+/* Longest-first dispatch workspace of the fused trajectory kernels (optional; no reference
+ * counterpart: the reference launches one thread per sphere, its work per thread block is
+ * uniform).  dispatch_ws = device int32 [curobo_hip_rollout_dispatch_ws_size(batch)], set up once by
+ * curobo_hip_rollout_dispatch_ws_init; the caller alternates dispatch_phase 0, 1, 0, ... between
+ * consecutive launches on the same batch (each launch measures its workgroup durations and one
+ * workgroup sorts the previous launch's into the order the next launch uses).  Outputs are
+ * identical with and without it (NULL = blockIdx order); only the tail of the launch shortens. */
+int curobo_hip_rollout_dispatch_ws_size(int batch_size);
+int curobo_hip_rollout_dispatch_ws_init(int32_t *dispatch_ws, int batch_size, curobo_hip_stream_t stream);
 
 /* Optional cost terms of the full trajopt task (reference content/configs/task/trajopt/
  * lbfgs_bspline_trajopt.yml: tool_pose_cfg + cspace_cfg with cost_type STATE) for
@@ -328,8 +339,8 @@ int curobo_hip_rollout_trajopt_fused(
     const float *activation_distance, const float *speed_dt, const int32_t *env_query_idx,
     int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
-    int link_chain_len, int sweep_steps, int enable_speed_metric,
-    const curobo_hip_trajopt_terms *terms, curobo_hip_stream_t stream);
+    int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,
+    int dispatch_phase, const curobo_hip_trajopt_terms *terms, curobo_hip_stream_t stream);
 
 int curobo_hip_rollout_trajopt_fused_lds_bytes(
     int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,

@@ -126,6 +126,45 @@ def test_fused_is_deterministic_and_stateless(device):
     assert torch.equal(c1, c2) and torch.equal(g1, g2)
 
 
+def test_longest_first_dispatch_changes_only_the_order(device):
+    """The dispatch workspace maps workgroups to trajectories longest-first from measured durations:
+    outputs stay bit-identical to blockIdx order over a sequence of launches, both order arrays stay
+    permutations, and after a few launches the order follows the measured ticks (descending buckets)."""
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    B = 700  # more workgroups than fit on the chip at once, not a multiple of anything
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=5), device=device).reshape(B, -1)
+    ros = []
+    for lf in (False, True):
+        ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(use_sweep=True, use_speed_metric=True,
+                                                                 longest_first_dispatch=lf))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        ros.append(ro)
+    for it in range(5):
+        xi = x * (1.0 - 0.02 * it)
+        c0, g0 = [t.clone() for t in ros[0].cost_and_gradient(xi)]
+        c1, g1 = ros[1].cost_and_gradient(xi)
+        assert torch.equal(c0, c1) and torch.equal(g0, g1), f"launch {it}"
+        ws = ros[1]._dispatch.ws.view(4, B).cpu().numpy()
+        for p in (0, 1):
+            assert np.array_equal(np.sort(ws[p]), np.arange(B)), f"order[{p}] is not a permutation after launch {it}"
+    assert ros[0]._dispatch is None
+    ticks = ws[2:4]
+    assert (ticks > 0).all()  # every workgroup measured itself in both phases
+    # the order built last was sorted from the other phase's ticks: bucket index (64 buckets) non-increasing
+    last_phase = ros[1]._dispatch._phase
+    src = ticks[1 - last_phase].astype(np.int64)
+    order = ws[1 - last_phase]
+    buckets = src[order] * 64 // (src.max() + 1)
+    assert (np.diff(buckets) <= 0).all()
+
+
 def test_fused_rejects_what_does_not_fit(device):
     """G1 humanoid (674 spheres, 162k pairs) exceeds the per-trajectory LDS budget: the entry point
     must say so (ValueError, like every argument error) and the rollout must fall back."""

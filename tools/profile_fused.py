@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--trajopt", action="store_true",
+                    help="full trajopt cost set (pose + c-space STATE terms); needs a library built with "
+                         "CUROBO_HIP_EXTRA_FLAGS=-DCUROBO_FUSED_STAMP_TERMS")
     args = ap.parse_args()
     from curobo_amd._lib import load
     from curobo_amd.robot import load_packaged_robot
@@ -34,7 +37,12 @@ def main():
     scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), dev)
     cfg = CollisionRolloutCfg(use_sweep=not args.no_sweep, use_speed_metric=not args.no_sweep)
     B = args.batch
-    ro = CollisionRollout(kin, scene, B, cfg)
+    if args.trajopt:
+        from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+        cfg = TrajOptRolloutCfg(use_fused=True)
+        ro = TrajOptRollout(kin, scene, B, cfg)
+    else:
+        ro = CollisionRollout(kin, scene, B, cfg)
     ro.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
     x = torch.as_tensor(seed_knots(model, B, cfg.n_knots, seed=2), device=dev).reshape(B, -1)
     for _ in range(3):
@@ -60,7 +68,8 @@ def main():
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
     for lo, hi, n in ((1, 8, "  P1: locals (row 0)"), (8, 9, "  P1: chain x2"), (9, 10, "  P1: spheres"),
                       (10, 11, "  P1: left spheres"), (11, 2, "  P1: barrier wait"),
-                      (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (6, 7, "  P2: gather")):
+                      (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (2, 12, "  P2: collision pass"),
+                      (12, 13, "  P2: pose pass"), (13, 14, "  P2: c-space pass"), (14, 3, "  P2: gather pass")):
         d = t[:, hi] - t[:, lo]
         d = d[np.abs(d) < 1e6]  # rows whose stamped point was a leftover point carry no inner stamps
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
@@ -69,6 +78,18 @@ def main():
     st = np.sort(t[:, 0] - t[:, 0].min())
     print("  start-time deciles (us):", np.round(st[:: max(1, len(st) // 10)], 1))
     tot = t[:, 4] - t[:, 0]
+    # what a different dispatch order could buy: greedy list scheduling of the measured workgroup
+    # durations on the slots that were concurrently busy (2 per CU), in index order vs longest first
+    import heapq
+
+    def makespan(durs, slots=512):
+        heap = [0.0] * slots
+        for d in durs:
+            heapq.heappush(heap, heapq.heappop(heap) + d)
+        return max(heap)
+    print(f"  list-schedule makespan on 512 slots: index order {makespan(tot):.1f} us, longest-first "
+          f"{makespan(np.sort(tot)[::-1]):.1f} us, lower bound {tot.sum() / 512:.1f} us; "
+          f"duration deciles {np.round(np.percentile(tot, [10, 50, 90, 99, 100]), 1)}")
     print(f"  workgroup total    mean {tot.mean():7.2f} us; kernel span {t[:, 4].max() - t[:, 0].min():.1f} us; "
           f"concurrent workgroups ~{tot.sum() / (t[:, 4].max() - t[:, 0].min()):.0f}")
 
