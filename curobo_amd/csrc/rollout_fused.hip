@@ -58,6 +58,7 @@ struct FusedTrajArgs {
   // optional longest-first dispatch (see rebuild_dispatch_order): int32 [4][B] = order[2][B], ticks[2][B]
   int32_t *dispatch_ws;
   int dispatch_phase;
+  int scene_rows;  // development knob: one sphere per lane in the scene pass (CUROBO_HIP_SCENE_ROWS)
   long long *prof;  // optional [B][16] wall-clock ticks (100 MHz) at the phase boundaries, see set_profile_buffer
 };
 
@@ -68,12 +69,14 @@ struct FusedTrajArgs {
 //   link-frame spheres [S][4] | link bounding boxes [L][8] (ordered-int keys) | subtree masks [L][4] | joint-link masks [D][4]
 //   | leftover-point sphere gradients [S][4] + arg-max key | pairs [P] | obstacle records
 constexpr int kWrench = 7;  // per link: force xyz, torque xyz about the link origin, joint gradient
+constexpr int kSceneListEntries = 128;  // ring of active (row, sphere) entries per wave: < 64 pending + <= 64 appended
 
 struct FusedLayout {
-  int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, off_add, fixed, chain, sph_link, sph_rad,
+  int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, lists, off_add, fixed, chain, sph_link, sph_rad,
       sph_pad, rs, lbound, sub, jlinks, left, key, flag, dyn, cstab, pairs, recs, total;
 };
-__host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0) {
+__host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0,
+                                                    int n_waves = 0) {
   FusedLayout f;
   int o = 0;
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
@@ -88,13 +91,17 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.chain_off = take(L + 1);
   f.link_info = take(L);
   f.sign = take(L);
+  // tables that are dead after P1 (staging + FK) share their bytes with the per-wave lists of active
+  // scene spheres of P2 (kSceneListEntries uint16 per wave)
+  f.lists = o;
   f.off_add = take(L);
   f.fixed = take(L * 12);
   f.chain = take(C);
-  f.sph_link = take(S);
-  f.sph_rad = take(S);
   f.sph_pad = take(S);
   f.rs = take(S * 4);
+  if (o - f.lists < n_waves * kSceneListEntries / 2) o = f.lists + n_waves * kSceneListEntries / 2;
+  f.sph_link = take(S);
+  f.sph_rad = take(S);
   f.lbound = take(L * 8);
   f.sub = take(L * 4);
   f.jlinks = take(D * 4);
@@ -109,6 +116,10 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   return f;
 }
 
+__device__ __forceinline__ float uniform_f(float v) {  // wave-uniform value -> SGPR
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 // LDS views + per-launch scalars shared by the phases
 struct FusedCtx {
   float *q, *cumul, *work, *wrench, *cost, *sign, *off_add, *fixed, *sph_rad, *sph_pad;
@@ -117,6 +128,7 @@ struct FusedCtx {
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
   float4 *left;
+  uint16_t *lists;  // [waves][kSceneListEntries], overlays the P1-only tables
   int *flag;   // [H] point has gradients (set by the cost pass, read by the VJP pass)
   float *dyn;  // [3][H][D] velocity / acceleration / jerk, later their cost gradients
   float *cstab;  // c-space STATE constants staged once per workgroup: limits [8][D], weights [10], dt
@@ -140,14 +152,26 @@ __device__ __forceinline__ void wrench_add(float *__restrict__ wr, const float *
 }
 
 // the lanes of the wave whose sphere gradient is non-zero add their wrench one at a time, in lane
-// order; returns whether the caller's 16-lane row had any
+// order; returns whether the caller's 16-lane row had any.  Everything that needs a wait (link
+// origin from LDS, the torque) is computed by all lanes before the serial section: that section is
+// the tail of points deep in collision (one turn per contributing sphere), so it only issues the
+// six ds_add_f32.
 __device__ __forceinline__ bool wrench_add_serialised(const FusedCtx &c, int h, int s, f3 p, f3 g, int lane64) {
   unsigned long long m = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f);
   const bool row_any = ((m >> (lane64 & 48)) & 0xffffull) != 0ull;
-  while (m) {
-    const int src = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (lane64 == src) wrench_add(c.wrench + (size_t)h * c.wl, c.cumul + (size_t)h * c.L * 12, c.sph_link[s], p, g);
+  if (m) {
+    const int l = c.sph_link[s < c.S ? s : 0];
+    const float *C = c.cumul + (size_t)h * c.L * 12 + l * 12;
+    const f3 t = cross(p - make_f3(C[3], C[7], C[11]), g);
+    float *w = c.wrench + (size_t)h * c.wl + l * kWrench;
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (lane64 == src) {
+        atomicAdd(w + 0, g.x); atomicAdd(w + 1, g.y); atomicAdd(w + 2, g.z);  // ds_add_f32, fire and forget
+        atomicAdd(w + 3, t.x); atomicAdd(w + 4, t.y); atomicAdd(w + 5, t.z);
+      }
+    }
   }
   return row_any;
 }
@@ -244,6 +268,149 @@ __device__ __forceinline__ float4 scene_sphere(const FusedCtx &c, const curobo_h
   return c4;
 }
 
+// OR over the 64 lanes of the wave (uniform result)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+  int x = (int)v;
+  x |= dpp_i<0xB1>(x);
+  x |= dpp_i<0x4E>(x);
+  x |= dpp_i<0x141>(x);
+  x |= dpp_i<0x140>(x);
+  return (uint32_t)(__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) | __builtin_amdgcn_readlane(x, 32) |
+                    __builtin_amdgcn_readlane(x, 48));
+}
+
+// Scene pass of the (up to) four points of a wave.  Only spheres on links whose bounding ball
+// reaches an obstacle's activation shell do any work (a quarter of them on the C2 workload), few of
+// those get past the per-obstacle early reject, and the ones that do cost up to 1 + 2 * SWEEP
+// signed-distance evaluations per obstacle: with one sphere per lane, a row waits for its one lane
+// that sweeps through several obstacles.  The unit of work is therefore a (sphere, obstacle) pair
+// that passed the early reject.  The wave packs those of its rows into a ring in LDS (ballot + mbcnt
+// compaction) and evaluates them 64 at a time, whichever row they belong to.  Costs and link
+// wrenches are then added by one lane at a time in ring order (per point: sphere block, obstacle,
+// sphere), so the fp32 sums are reproducible.  The speed metric is linear in (cost, gradient) and is
+// applied per pair.  Entry = sphere (9 bits) | row (2) | obstacle record (5): S <= 512, <= 32 records.
+constexpr int kScenePassMaxSpheres = 512, kScenePassMaxRecords = 32;
+template <int SWEEP, int KINDS>
+__device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_hip_scene &sc, int h, bool valid, int lane,
+                                                int lane64, uint16_t *ring, int fill_to = 64) {
+  const int row = lane64 >> 4;
+  const int n_rec = sc.max_cuboids + sc.max_voxel_grids;
+  const bool need_nb = SWEEP > 0 || c.speed_metric;
+  const float *wr = c.wrench + (size_t)(valid ? h : 0) * c.wl;
+  // geometry of sphere s of point hh shared by the reject test and the evaluation
+  struct Geo { f3 center, pp, np; float r_adj, half_prev, half_next; bool has_prev, has_next, enabled = false; };
+  auto geometry = [&](int hh, int s) {
+    Geo q;
+    const float4 c4 = c.spheres(hh)[s];
+    const float r = c.sph_rad[s];  // scene collision uses the raw radius
+    q.enabled = r >= 0.0f;
+    q.center = make_f3(c4.x, c4.y, c4.z);
+    q.r_adj = r + c.eta;
+    q.has_prev = need_nb && hh > 0;
+    q.has_next = need_nb && hh < c.H - 1;
+    const float4 p4 = c.spheres(hh > 0 ? hh - 1 : hh)[s], n4 = c.spheres(hh < c.H - 1 ? hh + 1 : hh)[s];
+    q.pp = make_f3(p4.x, p4.y, p4.z);
+    q.np = make_f3(n4.x, n4.y, n4.z);
+    q.half_prev = q.half_next = 0.0f;
+    if (SWEEP > 0) {
+      if (q.has_prev) { const f3 dd = q.pp - q.center; q.half_prev = 0.5f * sqrtf(dot(dd, dd)); }
+      if (q.has_next) { const f3 dd = q.np - q.center; q.half_next = 0.5f * sqrtf(dot(dd, dd)); }
+    }
+    return q;
+  };
+  int head = 0, pending = 0, s0 = 0;  // uniform: ring state, cursor over the sphere blocks ...
+  uint32_t done = 0u;                 // ... and the records of block s0 already looked at
+  for (;;) {
+    while (pending < fill_to && s0 < c.S) {  // fill
+      const int s = s0 + lane;
+      const bool in = valid && s < c.S;
+      const uint32_t lmask = in ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+      uint32_t todo = wave_or(lmask) & ~done;  // records some lane of the wave still has to test
+      if (todo != 0u) {
+        Geo q;
+        float reach = 0.0f, thr2 = 0.0f;
+        if (lmask != 0u) {
+          q = geometry(h, s);
+          reach = SWEEP > 0 ? fmaxf(q.half_prev, q.half_next) * 1.0001f + 2e-6f : 2e-6f;
+          thr2 = (q.r_adj + reach) * (q.r_adj + reach) * 1.00001f;
+        }
+        while (todo != 0u && pending < fill_to) {
+          const int j = __ffs((int)todo) - 1;
+          todo &= todo - 1u;
+          done |= 1u << j;
+          bool pass = false;
+          if (((lmask >> j) & 1u) && q.enabled) {
+            const ObsRec rec = c.recs[j];
+            if (rec.meta.x != 0.0f) {
+              const f3 lc = to_local(rec, q.center);
+              const bool vox = (KINDS & 2) && (!(KINDS & 1) || j >= sc.max_cuboids);
+              pass = vox ? !obstacle_early_reject<true>(sc, rec, lc, q.r_adj, reach, thr2)
+                         : !obstacle_early_reject<false>(sc, rec, lc, q.r_adj, reach, thr2);
+            }
+          }
+          const unsigned long long ball = __ballot(pass);
+          if (pass) {
+            const int at = head + pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
+            ring[at & (kSceneListEntries - 1)] = (uint16_t)(s | (row << 9) | (j << 11));
+          }
+          pending += __builtin_popcountll(ball);
+        }
+      }
+      if (todo == 0u) { s0 += kFkLanes; done = 0u; }
+    }
+    if (pending == 0) break;
+    const int count = pending < 64 ? pending : 64;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float d = 0.0f;
+    f3 g = make_f3(0.f, 0.f, 0.f), center = g;
+    int he = 0, se = 0;
+    if (lane64 < count) {
+      const unsigned e = ring[(head + lane64) & (kSceneListEntries - 1)];
+      se = (int)(e & 511u);
+      he = h + (int)((e >> 9) & 3u) - row;
+      const int je = (int)(e >> 11);
+      const ObsRec rec = c.recs[je];
+      const Geo q = geometry(he, se);
+      center = q.center;
+      const f3 lc = to_local(rec, q.center);
+      float cost_sum = 0.0f;
+      f3 grad_local = make_f3(0.f, 0.f, 0.f);
+      const bool vox = (KINDS & 2) && (!(KINDS & 1) || je >= sc.max_cuboids);
+      if (vox)
+        obstacle_contribution<true, SWEEP>(sc, rec, c.env * sc.max_voxel_grids + je - sc.max_cuboids, lc, q.has_prev, q.has_next,
+                                           q.pp, q.np, q.r_adj, c.eta, q.half_prev, q.half_next, cost_sum, grad_local);
+      else
+        obstacle_contribution<false, SWEEP>(sc, rec, c.env * sc.max_cuboids + je, lc, q.has_prev, q.has_next, q.pp, q.np, q.r_adj,
+                                            c.eta, q.half_prev, q.half_next, cost_sum, grad_local);
+      if (cost_sum > 0.0f) {
+        d = c.w_scene * cost_sum;
+        g = c.w_scene * to_world_vector(rec, grad_local);
+        if (c.speed_metric && q.has_prev && q.has_next) speed_metric_apply(q.center, q.pp, q.np, c.speed_dt, d, g);
+      }
+    }
+    unsigned long long m = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || d != 0.0f);
+    if (m) {  // waits (link origin, torque) before the serial section, which only issues LDS atomics
+      const int l = c.sph_link[se];
+      const float *C = c.cumul + (size_t)he * c.L * 12 + l * 12;
+      const f3 t = cross(center - make_f3(C[3], C[7], C[11]), g);
+      float *w = c.wrench + (size_t)he * c.wl + l * kWrench;
+      while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (lane64 == src) {
+          atomicAdd(w + 0, g.x); atomicAdd(w + 1, g.y); atomicAdd(w + 2, g.z);
+          atomicAdd(w + 3, t.x); atomicAdd(w + 4, t.y); atomicAdd(w + 5, t.z);
+          atomicAdd(&c.cost[he], d);
+          c.flag[he] = 1;
+        }
+      }
+    }
+    head += count;
+    pending -= count;
+  }
+}
+
 // Second half of the VJP of point h, run by its 16-lane row after all wrenches are in: every
 // moving link sums the wrenches of its subtree about its own origin and projects them on its joint
 // axis; then every dof sums its links (mimic joints) in a fixed order.  The reference walks the
@@ -328,6 +495,7 @@ __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPos
   float *wr = c.wrench + (size_t)h * c.wl;
   int lane_o = lane;
   asm volatile("" : "+v"(lane_o));  // keeps the per-lane output addresses out of the caller's loop-invariant set
+  asm volatile("" : "+v"(lane64));  // ... and values derived from the lane id out of registers held since P0
   for (int t0 = 0; t0 < T; t0 += kFkLanes) {
     const int t = t0 + lane_o;
     f3 gp = make_f3(0.f, 0.f, 0.f), om = gp, pos = gp;
@@ -459,6 +627,7 @@ __device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const 
   c.sub = reinterpret_cast<uint32_t *>(smem + lay.sub);        // [L][4]: links in the subtree of l
   c.jlinks = reinterpret_cast<uint32_t *>(smem + lay.jlinks);  // [D][4]: links driven by joint d
   c.left = reinterpret_cast<float4 *>(smem + lay.left);
+  c.lists = reinterpret_cast<uint16_t *>(smem + lay.lists);
   c.key = reinterpret_cast<unsigned long long *>(smem + lay.key);
   c.flag = reinterpret_cast<int *>(smem + lay.flag);
   c.dyn = smem + lay.dyn;
@@ -634,7 +803,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
   const bool use_pose = TERMS && a.use_pose != 0, use_cspace = TERMS && a.use_cspace != 0;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0);
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6);
   const int tid = threadIdx.x;
   const int wave_idx = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockDim.x;
@@ -650,11 +819,13 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   CUROBO_STAMP(0);
   const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
   const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
-  c.w_self = a.use_self ? a.w_self[0] : 0.0f;
-  c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
-  c.eta = a.use_scene ? a.eta[0] : 0.0f;
+  // launch-wide scalars: loaded through the vector path, moved to SGPRs (else each occupies a VGPR
+  // for the whole kernel)
+  c.w_self = uniform_f(a.use_self ? a.w_self[0] : 0.0f);
+  c.w_scene = uniform_f(a.use_scene ? a.w_scene[0] : 0.0f);
+  c.eta = uniform_f(a.use_scene ? a.eta[0] : 0.0f);
   c.speed_metric = a.enable_speed_metric != 0;
-  c.speed_dt = c.speed_metric ? a.speed_dt[0] : 0.0f;
+  c.speed_dt = uniform_f(c.speed_metric ? a.speed_dt[0] : 0.0f);
 
   // ---------------- P0: tables + B-spline samples
   const int nwaves = nt >> 6;
@@ -716,12 +887,15 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   __syncthreads();
   CUROBO_STAMP(2);
 
-  // ---------------- P2: costs + VJP per point
-  for (int h = grp; h < H_main; h += ngroups) {
-    const float4 *sph = c.spheres(h);
+  // ---------------- P2: costs + VJP per point.  The waves stay converged over the rounds (rows
+  // without a point in the last round are masked), because the scene pass is a wave-level job.
+  for (int h0 = 0; h0 < H_main; h0 += ngroups) {
+    const int h = h0 + grp;
+    const bool valid = h < H_main;
+    const float4 *sph = c.spheres(valid ? h : 0);
     float cost_pt = 0.0f;
     bool any_grad = false;  // uniform over the 16-lane row
-    if (a.use_self) {       // reference self_collision_kernel.cuh:19-111
+    if (a.use_self && valid) {  // reference self_collision_kernel.cuh:19-111
       // One pass over the padded pair list (no bounds checks; disabled / padding spheres are NaN and
       // lose every max).  Per pair only a v_max; the arg-max is tracked per group of U pairs (one
       // compare per group) and resolved inside the winning group afterwards.
@@ -763,23 +937,30 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     }
     const bool stamp_pt = (!TERMS || kStampTerms) && a.prof && lane == 0 && h == (b % H);
     if (stamp_pt) a.prof[(size_t)b * 16 + 5] = wall_clock64();
+    if (valid && lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
     if (a.use_scene) {
-      point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
-      const float *wr = c.wrench + (size_t)h * c.wl;
-      for (int s0 = 0; s0 < S; s0 += kFkLanes) {
-        const int s = s0 + lane;
-        float d = 0.0f;
-        f3 g = make_f3(0.f, 0.f, 0.f);
-        float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
-        const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
-        if (mask != 0u) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
-        cost_pt += d;
-        any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_grad;
+      if (valid) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
+      if (S <= kScenePassMaxSpheres && n_rec <= kScenePassMaxRecords && a.scene_rows != 1) {
+        wave_scene_pass<SWEEP, KINDS>(c, a.sc, h, valid, lane, lane64, c.lists + (tid >> 6) * kSceneListEntries, a.scene_rows == 2 ? 1 : 64);
+      } else if (valid) {  // beyond the ring's entry format: one sphere per lane, all its obstacles
+        const float *wr = c.wrench + (size_t)h * c.wl;
+        float cost_scene = 0.0f;
+        bool any_scene = false;
+        for (int s0 = 0; s0 < S; s0 += kFkLanes) {
+          const int s = s0 + lane;
+          float d = 0.0f;
+          f3 g = make_f3(0.f, 0.f, 0.f);
+          float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
+          const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+          if (mask != 0u) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
+          cost_scene += d;
+          any_scene = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_scene;
+        }
+        cost_scene = row16_sum(cost_scene);
+        if (lane == 0) { c.cost[h] += cost_scene; if (any_scene) c.flag[h] = 1; }
       }
     }
     if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
-    cost_pt = row16_sum(cost_pt);
-    if (lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
   }
   for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
     if (tid == 0) *c.key = 0ull;
@@ -1049,11 +1230,25 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_bu
   return CUROBO_HIP_OK;
 }
 
+// workgroup size and LDS layout of the trajectory kernels (the layout depends on the number of waves
+// through the per-wave scene lists): 8 waves when two workgroups then fit in a CU's LDS, see the
+// kernel's header; else one row per point up to 16 waves
+static FusedLayout trajectory_launch_shape(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn, int *threads_out) {
+  int threads = ((H * kFkLanes + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  if (threads > 512 && (size_t)fused_layout(H, D, L, S, C, P, n_rec, n_dyn, 8).total * sizeof(float) <= 80 * 1024) threads = 512;
+  static const int force_threads = [] { const char *e = getenv("CUROBO_HIP_FUSED_THREADS"); return e ? atoi(e) : 0; }();
+  if (force_threads >= 64 && force_threads <= 1024) threads = force_threads & ~63;  // tuning knob
+  *threads_out = threads;
+  return fused_layout(H, D, L, S, C, P, n_rec, n_dyn, threads >> 6);
+}
+
 CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horizon, int dof, int num_links,
                                                                    int num_spheres, int num_collision_pairs,
                                                                    int link_chain_len, int num_obstacles) {
-  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
-                                       num_obstacles);
+  int threads;
+  const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len,
+                                                  num_collision_pairs, num_obstacles, 0, &threads);
   return lay.total * (int)sizeof(float);
 }
 
@@ -1100,6 +1295,8 @@ static int rollout_trajectory_fused_impl(
   a.enable_speed_metric = (a.use_scene && enable_speed_metric) ? 1 : 0;
   a.prof = g_fused_prof;
   a.dispatch_ws = dispatch_ws; a.dispatch_phase = dispatch_phase;
+  static const int scene_rows = [] { const char *e = getenv("CUROBO_HIP_SCENE_ROWS"); return e ? atoi(e) : 0; }();
+  a.scene_rows = scene_rows;
   CUROBO_REQUIRE(!dispatch_ws || dispatch_phase == 0 || dispatch_phase == 1, "%s: dispatch_phase must be 0 or 1", what);
   CUROBO_REQUIRE(!a.enable_speed_metric || speed_dt, "%s: speed metric needs speed_dt", what);
   const int n_rec = a.use_scene ? a.sc.max_cuboids + a.sc.max_voxel_grids : 0;
@@ -1150,15 +1347,11 @@ static int rollout_trajectory_fused_impl(
       cs.retime_weights = t.retime_weights; cs.retime_reg_weights = t.retime_regularization_weights;
     }
   }
-  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                       a.use_cspace ? 4 * padded_horizon * dof : 0);
+  int threads;
+  const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
+                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
-  int threads = ((padded_horizon * kFkLanes + 63) / 64) * 64;
-  if (threads > 1024) threads = 1024;
-  static const int force_threads = [] { const char *e = getenv("CUROBO_HIP_FUSED_THREADS"); return e ? atoi(e) : 0; }();
-  if (threads > 512 && lds <= 80 * 1024) threads = 512;  // two workgroups per CU, see the kernel's header
-  if (force_threads >= 64 && force_threads <= 1024) threads = force_threads & ~63;  // tuning knob
   const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
   hipStream_t st = (hipStream_t)stream;
 #define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
@@ -1249,8 +1442,9 @@ CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused(CUROBO_TRAJ_PARAMS, const cur
 CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_lds_bytes(int padded_horizon, int dof, int num_links, int num_spheres,
                                                              int num_collision_pairs, int link_chain_len,
                                                              int num_obstacles, int with_cspace_terms) {
-  const FusedLayout lay = fused_layout(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
-                                       num_obstacles, with_cspace_terms ? 4 * padded_horizon * dof : 0);
+  int threads;
+  const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
+                                                  num_obstacles, with_cspace_terms ? 4 * padded_horizon * dof : 0, &threads);
   return lay.total * (int)sizeof(float);
 }
 

@@ -21,9 +21,14 @@ struct ObsRec {
 };
 constexpr int kObsRecFloats = sizeof(ObsRec) / sizeof(float);
 
+// Explicit fma chain: the same bits in every kernel and inlining context.  The swept cost is
+// discontinuous where two consecutive sphere positions coincide in the obstacle frame (zero sweep
+// length -> no sweep samples), so two code paths only agree on such points when this transform
+// rounds identically in both (with -ffp-contract=fast the compiler picks the fusion per context).
 __device__ __forceinline__ f3 to_local(const ObsRec &r, f3 v) {
-  return make_f3(r.r0.x * v.x + r.r0.y * v.y + r.r0.z * v.z + r.r0.w, r.r1.x * v.x + r.r1.y * v.y + r.r1.z * v.z + r.r1.w,
-                 r.r2.x * v.x + r.r2.y * v.y + r.r2.z * v.z + r.r2.w);
+  return make_f3(__builtin_fmaf(r.r0.x, v.x, __builtin_fmaf(r.r0.y, v.y, __builtin_fmaf(r.r0.z, v.z, r.r0.w))),
+                 __builtin_fmaf(r.r1.x, v.x, __builtin_fmaf(r.r1.y, v.y, __builtin_fmaf(r.r1.z, v.z, r.r1.w))),
+                 __builtin_fmaf(r.r2.x, v.x, __builtin_fmaf(r.r2.y, v.y, __builtin_fmaf(r.r2.z, v.z, r.r2.w))));
 }
 __device__ __forceinline__ f3 to_world_vector(const ObsRec &r, f3 v) {  // R^T v
   return make_f3(r.r0.x * v.x + r.r1.x * v.y + r.r2.x * v.z, r.r0.y * v.x + r.r1.y * v.y + r.r2.y * v.z,
@@ -187,6 +192,65 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   return r;
 }
 
+// Cost and obstacle-frame gradient of ONE sphere against ONE obstacle that passed the early reject:
+// the centre sample plus the sweep towards the previous / next point (the body of obstacle_set's
+// loop; also the unit of work of the fused kernel's scene pass).  lc = centre in the obstacle frame.
+template <bool VOXEL, int SWEEP>
+__device__ __forceinline__ void obstacle_contribution(const curobo_hip_scene &sc, const ObsRec &rec, int flat, f3 lc,
+                                                      bool has_prev, bool has_next, f3 prev_c, f3 next_c, float r_adj, float eta,
+                                                      float half_w_prev, float half_w_next, float &cost_sum, f3 &grad_local) {
+  const float pen_c = eval_point<VOXEL>(sc, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
+  if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
+    // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
+    const float sdf_c = r_adj - pen_c;
+    const bool can_cull = VOXEL ? (sdf_c < sc.voxel_max_distance) : true;
+    // voxel slack: interpolated values are convex combinations of corner samples that sit within
+    // sqrt(3) voxels of the query, once at the centre and once at the sample, + fp16 rounding
+    const float slack = VOXEL ? 3.5f * rec.shape.w + 0.002f * fabsf(sdf_c) : 0.0f;
+    const float clearance = -pen_c;
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+      const float half_w = dir == 0 ? half_w_prev : half_w_next;
+      const bool culled = can_cull && clearance > half_w * 1.0001f + slack + 1e-6f;
+      if ((dir == 0 ? has_prev : has_next) && !culled) {
+        const f3 ln = to_local(rec, dir == 0 ? prev_c : next_c);
+        const f3 dd = ln - lc;
+        const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
+        const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
+        float jump = 0.0f;
+        for (int k = 0; k < SWEEP; k++) {
+          if (jump >= half_dist) break;
+          const float tt = 1.0f - 0.5f * jump * inv_half;
+          const f3 lp = tt * lc + (1.0f - tt) * ln;
+          const float p2 = eval_point<VOXEL>(sc, flat, rec.shape, lp, r_adj, eta, cost_sum, grad_local);
+          if (p2 > 0.0f) jump += p2;
+          else if (-p2 >= 1000.0f) jump += r_adj;
+          else jump += fmaxf(-p2, r_adj);
+        }
+      }
+    }
+  }
+}
+
+// Early reject of one obstacle for one sphere (see obstacle_set): true = contributes exactly zero.
+// reach = max half sweep length * 1.0001 + 2e-6 (2e-6 without sweep), thr2_c = ((r_adj + reach)^2) * 1.00001.
+template <bool VOXEL>
+__device__ __forceinline__ bool obstacle_early_reject(const curobo_hip_scene &sc, const ObsRec &rec, f3 lc, float r_adj,
+                                                      float reach, float thr2_c) {
+  if (!VOXEL) {
+    const float cx = fmaxf(fabsf(lc.x) - rec.shape.x, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y, 0.0f),
+                cz = fmaxf(fabsf(lc.z) - rec.shape.z, 0.0f);
+    return cx * cx + cy * cy + cz * cz > thr2_c;
+  } else if (r_adj < sc.voxel_max_distance) {
+    const float vs = rec.shape.w;
+    const float cx = fmaxf(fabsf(lc.x) - rec.shape.x * vs * 0.5f, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y * vs * 0.5f, 0.0f),
+                cz = fmaxf(fabsf(lc.z) - rec.shape.z * vs * 0.5f, 0.0f);
+    const float thr_v = reach + vs;
+    return cx * cx + cy * cy + cz * cz > thr_v * thr_v * 1.00001f;
+  }
+  return false;
+}
+
 // Sweep culling (result-preserving): every swept sample lies within half_dist of the current
 // centre (t in (0.5, 1]) and a signed distance field is 1-Lipschitz, so when the centre's
 // clearance  sdf - r_adj  exceeds half_dist (+ an interpolation slack for voxel grids) no sample
@@ -213,50 +277,11 @@ __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const O
     if (rec.meta.x == 0.0f) continue;
     const int flat = env * max_n + o;
     const f3 lc = to_local(rec, center);
-    if (!VOXEL) {
-      const float cx = fmaxf(fabsf(lc.x) - rec.shape.x, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y, 0.0f),
-                  cz = fmaxf(fabsf(lc.z) - rec.shape.z, 0.0f);
-      if (cx * cx + cy * cy + cz * cz > thr2_c) continue;
-    } else if (r_adj < sc.voxel_max_distance) {
-      const float vs = rec.shape.w;
-      const float cx = fmaxf(fabsf(lc.x) - rec.shape.x * vs * 0.5f, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y * vs * 0.5f, 0.0f),
-                  cz = fmaxf(fabsf(lc.z) - rec.shape.z * vs * 0.5f, 0.0f);
-      const float thr_v = reach + vs;
-      if (cx * cx + cy * cy + cz * cz > thr_v * thr_v * 1.00001f) continue;
-    }
+    if (obstacle_early_reject<VOXEL>(sc, rec, lc, r_adj, reach, thr2_c)) continue;
     float cost_sum = 0.0f;
     f3 grad_local = make_f3(0.f, 0.f, 0.f);
-    const float pen_c = eval_point<VOXEL>(sc, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
-    if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
-      // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
-      const float sdf_c = r_adj - pen_c;
-      const bool can_cull = VOXEL ? (sdf_c < sc.voxel_max_distance) : true;
-      // voxel slack: interpolated values are convex combinations of corner samples that sit within
-      // sqrt(3) voxels of the query, once at the centre and once at the sample, + fp16 rounding
-      const float slack = VOXEL ? 3.5f * rec.shape.w + 0.002f * fabsf(sdf_c) : 0.0f;
-      const float clearance = -pen_c;
-#pragma unroll
-      for (int dir = 0; dir < 2; dir++) {
-        const float half_w = dir == 0 ? half_w_prev : half_w_next;
-        const bool culled = can_cull && clearance > half_w * 1.0001f + slack + 1e-6f;
-        if ((dir == 0 ? has_prev : has_next) && !culled) {
-          const f3 ln = to_local(rec, dir == 0 ? prev_c : next_c);
-          const f3 dd = ln - lc;
-          const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
-          const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
-          float jump = 0.0f;
-          for (int k = 0; k < SWEEP; k++) {
-            if (jump >= half_dist) break;
-            const float tt = 1.0f - 0.5f * jump * inv_half;
-            const f3 lp = tt * lc + (1.0f - tt) * ln;
-            const float p2 = eval_point<VOXEL>(sc, flat, rec.shape, lp, r_adj, eta, cost_sum, grad_local);
-            if (p2 > 0.0f) jump += p2;
-            else if (-p2 >= 1000.0f) jump += r_adj;
-            else jump += fmaxf(-p2, r_adj);
-          }
-        }
-      }
-    }
+    obstacle_contribution<VOXEL, SWEEP>(sc, rec, flat, lc, has_prev, has_next, prev_c, next_c, r_adj, eta, half_w_prev,
+                                        half_w_next, cost_sum, grad_local);
     if (cost_sum > 0.0f) {
       const f3 gw = to_world_vector(rec, grad_local);
       dsum += w * cost_sum;
@@ -298,6 +323,26 @@ __device__ __forceinline__ uint32_t bounding_ball_obstacle_mask(const curobo_hip
   return mask;
 }
 
+// Speed metric (wp_speed_metric.py:38-93) of a sphere with both neighbours: cost and gradient are
+// scaled by the sphere's speed and the gradient is projected off the velocity direction (minus the
+// curvature term).  The map is linear in (dsum, gsum), so it may be applied per obstacle contribution.
+__device__ __forceinline__ void speed_metric_apply(f3 center, f3 pp, f3 np, float speed_dt, float &dsum, f3 &gsum) {
+  float dt = speed_dt;
+  if (dt < 1e-6f) dt = 1e-6f;
+  const f3 vel = (0.5f / dt) * (np - pp);
+  const float sv = sqrtf(dot(vel, vel));
+  if (sv >= 1e-3f) {
+    const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
+    const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
+    const float sv2 = sv * sv;
+    const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
+    const f3 og = gsum - dot(nv, gsum) * nv;
+    const f3 oc = curv - dot(nv, curv) * nv;
+    gsum = sv * (og - dsum * oc);
+    dsum = sv * dsum;
+  }
+}
+
 // Full scene cost of ONE sphere of one trajectory point: every enabled obstacle (cuboids, then voxel
 // grids, in index order), optional sweep towards the previous / next point and the fused speed
 // metric (wp_speed_metric.py:38-93).  KINDS: bit 0 = cuboids present, bit 1 = voxel grids.
@@ -324,22 +369,7 @@ __device__ __forceinline__ void sphere_scene_cost(const curobo_hip_scene &sc, co
       obstacle_set<true, SWEEP, STAGED>(sc, recs + sc.max_cuboids, env, has_prev, has_next, pp, np, center, r_adj, eta, w,
                                         half_w_prev, half_w_next, mask, dsum, gsum);
   }
-  if (speed_metric && has_prev && has_next && dsum > 0.0f) {
-    float dt = speed_dt;
-    if (dt < 1e-6f) dt = 1e-6f;
-    const f3 vel = (0.5f / dt) * (np - pp);
-    const float sv = sqrtf(dot(vel, vel));
-    if (sv >= 1e-3f) {
-      const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
-      const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
-      const float sv2 = sv * sv;
-      const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
-      const f3 og = gsum - dot(nv, gsum) * nv;
-      const f3 oc = curv - dot(nv, curv) * nv;
-      gsum = sv * (og - dsum * oc);
-      dsum = sv * dsum;
-    }
-  }
+  if (speed_metric && has_prev && has_next && dsum > 0.0f) speed_metric_apply(center, pp, np, speed_dt, dsum, gsum);
 }
 
 }  // namespace curobo_hip

@@ -73,6 +73,11 @@ def main():
         d = t[:, hi] - t[:, lo]
         d = d[np.abs(d) < 1e6]  # rows whose stamped point was a leftover point carry no inner stamps
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
+    diag = prof.cpu().numpy()[:, 15]
+    if diag.any():  # library built with -DCUROBO_FUSED_DIAG: active scene spheres / 16-lane iterations that had any
+        act, its = (diag & 0xffffffff).astype(np.float64), (diag >> 32).astype(np.float64)
+        print(f"  scene spheres past the link mask per trajectory: mean {act.mean():.0f} of {33 * 65}; row iterations with "
+              f"any: mean {its.mean():.1f} of {33 * 5}; dense packing would need {np.ceil(act / 16).mean():.1f}+")
     first_end = t[:, 4].min()
     print(f"  workgroups started before the first one finished: {(t[:, 0] < first_end).sum()}")
     st = np.sort(t[:, 0] - t[:, 0].min())
