@@ -292,7 +292,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 constexpr int kScenePassMaxSpheres = 512, kScenePassMaxRecords = 32;
 template <int SWEEP, int KINDS>
 __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_hip_scene &sc, int h, bool valid, int lane,
-                                                int lane64, uint16_t *ring, int fill_to = 64) {
+                                                int lane64, uint16_t *ring, int row_stride, int fill_to = 64) {
   const int row = lane64 >> 4;
   const int n_rec = sc.max_cuboids + sc.max_voxel_grids;
   const bool need_nb = SWEEP > 0 || c.speed_metric;
@@ -368,7 +368,7 @@ __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_
     if (lane64 < count) {
       const unsigned e = ring[(head + lane64) & (kSceneListEntries - 1)];
       se = (int)(e & 511u);
-      he = h + (int)((e >> 9) & 3u) - row;
+      he = h + ((int)((e >> 9) & 3u) - row) * row_stride;
       const int je = (int)(e >> 11);
       const ObsRec rec = c.recs[je];
       const Geo q = geometry(he, se);
@@ -889,8 +889,11 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
 
   // ---------------- P2: costs + VJP per point.  The waves stay converged over the rounds (rows
   // without a point in the last round are masked), because the scene pass is a wave-level job.
+  // Row r of wave w takes point w + r * nwaves of the round (not 4 * w + r): points deep in collision
+  // come in runs along the trajectory, and a wave is as slow as the sum of its rows' scene work.
+  const int row_stride = ngroups >> 2;
   for (int h0 = 0; h0 < H_main; h0 += ngroups) {
-    const int h = h0 + grp;
+    const int h = h0 + (grp & 3) * row_stride + (grp >> 2);
     const bool valid = h < H_main;
     const float4 *sph = c.spheres(valid ? h : 0);
     float cost_pt = 0.0f;
@@ -941,7 +944,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     if (a.use_scene) {
       if (valid) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
       if (S <= kScenePassMaxSpheres && n_rec <= kScenePassMaxRecords && a.scene_rows != 1) {
-        wave_scene_pass<SWEEP, KINDS>(c, a.sc, h, valid, lane, lane64, c.lists + (tid >> 6) * kSceneListEntries, a.scene_rows == 2 ? 1 : 64);
+        wave_scene_pass<SWEEP, KINDS>(c, a.sc, h, valid, lane, lane64, c.lists + (tid >> 6) * kSceneListEntries, row_stride, a.scene_rows == 2 ? 1 : 64);
       } else if (valid) {  // beyond the ring's entry format: one sphere per lane, all its obstacles
         const float *wr = c.wrench + (size_t)h * c.wl;
         float cost_scene = 0.0f;
@@ -965,6 +968,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
     if (tid == 0) *c.key = 0ull;
     __syncthreads();
+    if (h == H_main) CUROBO_STAMP(7);
     if (a.use_self) {
       const float4 *sph = c.spheres(h);
       float best = 0.0f;
@@ -1005,7 +1009,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       if (lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
     }
   }
-  if (n_left > 0) __syncthreads();
+  __syncthreads();  // the passes below take point h on row h % rows: another wave than the cost pass above
+  CUROBO_STAMP(15);
   // further passes over all points, leftover ones included (their own loops so that the register
   // allocation of the collision pass above is not shared with the optional terms, and so that those
   // are instantiated once): tool pose, c-space STATE, then the VJP gather

@@ -68,16 +68,11 @@ def main():
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
     for lo, hi, n in ((1, 8, "  P1: locals (row 0)"), (8, 9, "  P1: chain x2"), (9, 10, "  P1: spheres"),
                       (10, 11, "  P1: left spheres"), (11, 2, "  P1: barrier wait"),
-                      (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (2, 12, "  P2: collision pass"),
+                      (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (2, 7, "  P2: rows (slowest)"), (7, 15, "  P2: leftover point"), (2, 12, "  P2: collision pass"),
                       (12, 13, "  P2: pose pass"), (13, 14, "  P2: c-space pass"), (14, 3, "  P2: gather pass")):
         d = t[:, hi] - t[:, lo]
         d = d[np.abs(d) < 1e6]  # rows whose stamped point was a leftover point carry no inner stamps
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
-    diag = prof.cpu().numpy()[:, 15]
-    if diag.any():  # library built with -DCUROBO_FUSED_DIAG: active scene spheres / 16-lane iterations that had any
-        act, its = (diag & 0xffffffff).astype(np.float64), (diag >> 32).astype(np.float64)
-        print(f"  scene spheres past the link mask per trajectory: mean {act.mean():.0f} of {33 * 65}; row iterations with "
-              f"any: mean {its.mean():.1f} of {33 * 5}; dense packing would need {np.ceil(act / 16).mean():.1f}+")
     first_end = t[:, 4].min()
     print(f"  workgroups started before the first one finished: {(t[:, 0] < first_end).sum()}")
     st = np.sort(t[:, 0] - t[:, 0].min())
