@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--graph-iters", type=int, default=10, help="L-BFGS iterations per captured graph")
     ap.add_argument("--no-fused", action="store_true",
                     help="drop-in kernel sequence (7 launches per rollout) instead of the fused rollout kernel")
+    ap.add_argument("--shards", type=int, default=4,
+                    help="seed shards of the optimiser on separate HIP streams of the GPU (1 = one batch, one stream)")
     ap.add_argument("--no-ik", action="store_true", help="skip the secondary IK solves/s measurement")
     ap.add_argument("--ik-problems", type=int, default=100)
     ap.add_argument("--ik-seeds", type=int, default=64)
@@ -150,8 +152,21 @@ def main():
     start = start_configuration(model)
     rollout.update_start_state(torch.as_tensor(start, device=device))
     bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
-    opt = LBFGSOpt(ocfg, rollout.cost_and_gradient, cfg.n_knots, kin.num_dof, bounds, device,
-                   use_cuda_graph=not args.no_graph)
+    start_t = torch.as_tensor(start, device=device)
+    if args.shards > 1:
+        # the seeds are independent problems: shard them over HIP streams so that the optimiser-side
+        # kernel of one shard overlaps the rollout workgroups of the others (optim/pipelined.py)
+        from curobo_amd.optim import PipelinedLBFGS
+
+        def shard_rollout(batch):
+            ro = CollisionRollout(kin, scene, batch, cfg)
+            ro.update_start_state(start_t)
+            return ro.cost_and_gradient
+        opt = PipelinedLBFGS(ocfg, shard_rollout, cfg.n_knots, kin.num_dof, bounds, device, n_shards=args.shards,
+                             use_cuda_graph=not args.no_graph)
+    else:
+        opt = LBFGSOpt(ocfg, rollout.cost_and_gradient, cfg.n_knots, kin.num_dof, bounds, device,
+                       use_cuda_graph=not args.no_graph)
     opt1 = None
     knots = seed_knots(model, args.seeds, cfg.n_knots, seed=2, seed_offset=rank * args.seeds)
     seed_t = torch.as_tensor(knots, device=device)
@@ -162,15 +177,16 @@ def main():
     def run_steps(k):
         """exactly k optimiser iterations"""
         nonlocal opt1
+        one = opt.step if args.shards > 1 else opt._opt_step
         if args.no_graph:
             for _ in range(k):
-                opt._opt_step()
+                one()
             return
         for _ in range(k // G):
             opt.run_inner()
         if k % G:
             for _ in range(k % G):
-                opt._opt_step()
+                one()
 
     run_steps(max(args.warmup, 1))
     # warm the exchange too (first use of the torch index/min kernels loads their code objects)
@@ -223,7 +239,7 @@ def main():
             us = time_kernel(fn, it, torch)
             timings[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes),
                              "GBps": round(nbytes / us * 1e-3, 1)}
-        step_us = time_kernel(lambda: opt._opt_step(), 50, torch)
+        step_us = time_kernel(opt.step if args.shards > 1 else opt._opt_step, 50, torch)
         dom = "rollout_trajectory_fused" if fused else max(timings, key=lambda k: timings[k]["us"])
         ach = timings[dom]["GBps"]
         traffic, traffic_src = measured_traffic(dom)
@@ -243,7 +259,8 @@ def main():
                             "one L-BFGS iteration (line search + two-loop) per step",
                 "robot": "franka", "seeds_per_gpu": args.seeds, "line_search_candidates": nls,
                 "horizon": cfg.horizon, "n_knots": cfg.n_knots, "rollouts_per_step_per_gpu": args.seeds * nls,
-                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "fused_rollout_kernel": bool(fused), "parallelism": f"seed-shard x{world}",
+                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "fused_rollout_kernel": bool(fused), "streams_per_gpu": args.shards,
+                "parallelism": f"seed-shard x{world} GPUs x{args.shards} streams",
             },
             "roofline": roofline,
             "kernels_us": {k: v["us"] for k, v in timings.items()},

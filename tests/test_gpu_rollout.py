@@ -228,3 +228,40 @@ def test_fused_iteration_tail_row16_matches_three_launches(device, V, hist):
     for a_, b_ in zip(state[0][:7], state[1][:7]):
         torch.testing.assert_close(a_, b_, rtol=2e-3, atol=2e-4 * float(a_.abs().max()))
     assert torch.equal(state[0][7], state[1][7]) and torch.equal(state[0][8], state[1][8])
+
+
+def test_pipelined_lbfgs_matches_single_batch(device):
+    """Seed shards on separate HIP streams (optim/pipelined.py) take exactly the iterates of the
+    one-batch optimiser: same best cost / action per seed after a graph replay of 6 iterations."""
+    from curobo_amd.optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    cfg = CollisionRolloutCfg()
+    seeds = 12
+    ocfg = LBFGSOptCfg(num_problems=seeds, inner_iters=6, num_iters=12)
+    nls = len(ocfg.line_search_scale)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+
+    def make(batch):
+        ro = CollisionRollout(kin, scene, batch, cfg)
+        ro.update_start_state(start)
+        return ro.cost_and_gradient
+
+    x0 = torch.as_tensor(seed_knots(model, seeds, cfg.n_knots, seed=4), device=device)
+    one = LBFGSOpt(ocfg, make(seeds * nls), cfg.n_knots, kin.num_dof, bounds, device)
+    ref = one.optimize(x0).clone()
+    ref_cost = one.best_cost.clone()
+    for shards in (2, 3, 4):
+        pipe = PipelinedLBFGS(ocfg, make, cfg.n_knots, kin.num_dof, bounds, device, n_shards=shards)
+        got = pipe.optimize(x0)
+        torch.cuda.synchronize()
+        assert torch.equal(pipe.best_cost, ref_cost), shards
+        assert torch.equal(got, ref), shards
+    assert float(ref_cost.min()) < 1e9
