@@ -1235,6 +1235,19 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_bu
   return CUROBO_HIP_OK;
 }
 
+// Same hook for a SEQUENCE of launches (e.g. the launches recorded into a hipGraph): launch k after
+// this call stamps into block k = device_buffer + k * block_rows * 16 (launches beyond n_blocks, or
+// with more than block_rows trajectories, are not stamped).  NULL / 0 ends the sequence.
+static long long *g_fused_prof_seq = nullptr;
+static int g_fused_prof_blocks = 0, g_fused_prof_rows = 0, g_fused_prof_next = 0;
+CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_buffer, int n_blocks, int block_rows) {
+  g_fused_prof_seq = (long long *)device_buffer;
+  g_fused_prof_blocks = device_buffer ? n_blocks : 0;
+  g_fused_prof_rows = block_rows;
+  g_fused_prof_next = 0;
+  return CUROBO_HIP_OK;
+}
+
 // workgroup size and LDS layout of the trajectory kernels (the layout depends on the number of waves
 // through the per-wave scene lists): 8 waves when two workgroups then fit in a CU's LDS, see the
 // kernel's header; else one row per point up to 16 waves
@@ -1299,6 +1312,8 @@ static int rollout_trajectory_fused_impl(
   a.chain_len = link_chain_len; a.dpad = dof | 1; a.num_envs = num_envs; a.use_multi_env = use_multi_env;
   a.enable_speed_metric = (a.use_scene && enable_speed_metric) ? 1 : 0;
   a.prof = g_fused_prof;
+  if (g_fused_prof_seq && g_fused_prof_next < g_fused_prof_blocks && batch_size <= g_fused_prof_rows)
+    a.prof = g_fused_prof_seq + (size_t)g_fused_prof_next++ * g_fused_prof_rows * 16;
   a.dispatch_ws = dispatch_ws; a.dispatch_phase = dispatch_phase;
   static const int scene_rows = [] { const char *e = getenv("CUROBO_HIP_SCENE_ROWS"); return e ? atoi(e) : 0; }();
   a.scene_rows = scene_rows;

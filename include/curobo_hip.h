@@ -390,6 +390,11 @@ int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_sphere
  * the phase boundaries (start, tables+spline, FK, costs+VJP, end) of every fused launch; NULL
  * (default) turns it off.  Used by tools/profile_fused.py. */
 int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_buffer);
+/* Same hook for a sequence of launches (e.g. those recorded into a hipGraph): launch k after this
+ * call stamps into block k = device_buffer + k * block_rows * 16; launches beyond n_blocks (or with
+ * more than block_rows trajectories) are not stamped.  NULL ends the sequence.  bench.py uses it to
+ * time the rollout launches inside the replayed graph (stamp 0 = workgroup start, 4 = end). */
+int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_buffer, int n_blocks, int block_rows);
 
 /* ---------------------------------------------------------------- trajectory: B-spline
  * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142
