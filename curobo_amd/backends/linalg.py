@@ -25,3 +25,26 @@ def levenberg_marquardt_step(
         ptr(joint_position_out), ptr(pred_reduction), ptr(jacobian), ptr(jTerror), ptr(lambda_damping),
         ptr(joint_position_in), b, r, d, current_stream(joint_position_out),
     ))
+
+
+def seed_ik_update_state(
+    joint_position, jacobian, jTerror, error_norm, position_error, orientation_error, lambda_damping, success,
+    improvement, candidate_joint_position, candidate_pose_jacobian, candidate_pose_jTerror, candidate_pose_cost,
+    candidate_position_distance, candidate_rotation_distance, predicted_reduction, action_min, action_max,
+    current_position, dt, velocity_limits, joint_limit_weight: float, rho_min: float, lambda_factor: float,
+    lambda_min: float, lambda_max: float, convergence_position_tolerance: float,
+    convergence_orientation_tolerance: float, convergence_joint_limit_weight: float, initial: bool,
+):
+    """One launch for the torch glue of a seed-IK LM iteration (``curobo_hip_seed_ik_update_state``):
+    joint-limit residual rows + trust ratio + acceptance + damping + state selection + convergence."""
+    n, d = candidate_joint_position.shape
+    t = candidate_position_distance.shape[-1]
+    check(load().curobo_hip_seed_ik_update_state(
+        ptr(joint_position), ptr(jacobian), ptr(jTerror), ptr(error_norm), ptr(position_error), ptr(orientation_error),
+        ptr(lambda_damping), ptr(success), ptr(improvement), ptr(candidate_joint_position), ptr(candidate_pose_jacobian),
+        ptr(candidate_pose_jTerror), ptr(candidate_pose_cost), ptr(candidate_position_distance),
+        ptr(candidate_rotation_distance), ptr(predicted_reduction), ptr(action_min), ptr(action_max), ptr(current_position),
+        ptr(dt), ptr(velocity_limits), float(joint_limit_weight), float(rho_min), float(lambda_factor), float(lambda_min),
+        float(lambda_max), float(convergence_position_tolerance), float(convergence_orientation_tolerance),
+        float(convergence_joint_limit_weight), n, d, t, int(initial), current_stream(joint_position),
+    ))

@@ -1,0 +1,253 @@
+"""Levenberg-Marquardt seed-IK solver on the HIP kernels.
+
+Mirrors the reference's ``SeedIKSolver`` (``curobo/_src/solver/seed_ik/seed_ik_solver.py:48-824``,
+``seed_ik_error_calculator.py``, ``seed_iteration_state_manager.py``, ``seed_ik_solver_cfg.py``):
+fast approximate IK solutions from Halton seeds that seed the L-BFGS IK solver.  One LM iteration
+is five launches here (the reference: a Warp tile kernel, two CUDA kernels, a Warp cost kernel and
+~25 torch elementwise kernels under a CUDA graph):
+
+    lm_step (J^T J on the matrix cores + Cholesky solve)   csrc/linalg.hip
+    FK + geometric tool Jacobian of the candidate          csrc/kinematics.hip
+    tool-pose cost, its position / quaternion gradients    csrc/cost.hip
+    FK VJP of those gradients = pose J^T e                 csrc/kinematics.hip
+    joint-limit rows + trust ratio + accept / damping /
+    selection / convergence flags                          csrc/seed_ik.hip
+
+``inner_iterations`` iterations are captured into one hipGraph; the early-exit test between
+replays is the reference's (`_calculate_exit_condition`).  Velocity / acceleration residuals
+(``velocity_weight``, ``acceleration_weight``, default 0 in the reference) are not implemented.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ..backends import cost as cost_hip
+from ..backends import kinematics as kinematics_hip
+from ..backends import linalg as linalg_hip
+from ..robot.kinematics_params import KinematicsParams
+
+
+@dataclass
+class SeedIKSolverCfg:
+    """Names and defaults of ``solver/seed_ik/seed_ik_solver_cfg.py:25-94``."""
+
+    max_iterations: int = 16
+    inner_iterations: int = 4
+    position_tolerance: float = 0.005
+    orientation_tolerance: float = 0.05
+    convergence_position_tolerance: float = 0.00001
+    convergence_orientation_tolerance: float = 0.00001
+    convergence_joint_limit_weight: float = 1.0
+    lambda_initial: float = 0.2
+    lambda_factor: float = 2.0
+    lambda_max: float = 1.0e10
+    lambda_min: float = 1e-5
+    joint_limit_margin: float = 0.001
+    batch_success_threshold: float = 1.0
+    num_seeds: int = 1
+    joint_limit_weight: float = 1.0
+    use_cuda_graph: bool = True
+    rho_min: float = 1e-3
+    sampler_seed: int = 451
+    start_cspace_dist_weight: float = 0.01
+    position_weight: float = 1.0
+    orientation_weight: float = 1.0
+
+    def __post_init__(self):
+        if self.max_iterations < self.inner_iterations or self.max_iterations % self.inner_iterations != 0:
+            raise ValueError(f"max_iterations: {self.max_iterations} must be a positive multiple of inner_iterations: "
+                             f"{self.inner_iterations}")
+
+
+@dataclass
+class SeedIKResult:  # the fields of IKSolverResult the seed solver fills (solver_ik_result.py)
+    success: torch.Tensor         # [P, return_seeds] bool
+    solution: torch.Tensor        # [P, return_seeds, D]
+    position_error: torch.Tensor  # [P, return_seeds]
+    rotation_error: torch.Tensor  # [P, return_seeds]
+    iterations: int
+
+
+class HaltonSeeds:
+    """The reference's ``SampleBuffer.create_halton_sample_buffer`` (``util/sampling/sample_buffer.py``
+    :60-157,253-279 over ``sequencer_halton.py``: scipy's scrambled Halton sequence): 2000 points are
+    generated once, then ``get_samples(n)`` draws n of them by random index.  The index stream comes
+    from a CPU ``torch.Generator`` here (the reference's lives on its device, so it is device specific)."""
+
+    def __init__(self, ndims: int, low: torch.Tensor, high: torch.Tensor, seed: int = 123, store_buffer: int = 2000):
+        from scipy.stats.qmc import Halton
+
+        self.low, self.range = low, high - low
+        self._qmc_args = (ndims, seed)
+        self.buffer = torch.as_tensor(Halton(d=ndims, seed=seed, scramble=True).random(store_buffer), dtype=torch.float32,
+                                      device=low.device)
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)
+        self._state0 = self._gen.get_state().clone()
+
+    def reset(self) -> None:
+        self._gen.set_state(self._state0)
+
+    def get_samples(self, n: int, bounded: bool = True) -> torch.Tensor:
+        idx = torch.randint(0, self.buffer.shape[0], (n,), generator=self._gen).to(self.buffer.device)
+        s = self.buffer[idx]
+        return s * self.range + self.low if bounded else s
+
+
+class SeedIKSolver:
+    """``solve_batch(goal_position[P, T, 3], goal_quat[P, T, 4] (wxyz))`` -> best ``return_seeds``
+    configurations per problem out of ``num_seeds`` LM runs."""
+
+    def __init__(self, kin: KinematicsParams, num_problems: int, cfg: Optional[SeedIKSolverCfg] = None,
+                 default_joint_position: Optional[torch.Tensor] = None):
+        self.kin, self.cfg = kin, cfg or SeedIKSolverCfg()
+        c, dev = self.cfg, kin.fixed_transforms.device
+        self.device = dev
+        self.P, self.S = num_problems, c.num_seeds
+        self.n = n = self.P * self.S
+        D, T, L, Sp = kin.num_dof, kin.num_pose_links, kin.num_links, kin.num_spheres
+        self.D, self.T, self.R = D, T, 6 * T + D
+        lo, hi = kin.joint_limits_position[0], kin.joint_limits_position[1]
+        margin = (hi - lo) * c.joint_limit_margin
+        self.action_min, self.action_max = (lo + margin).contiguous(), (hi - margin).contiguous()
+        self._limits = (lo, hi)
+        self.default_joint_position = (default_joint_position if default_joint_position is not None
+                                       else 0.5 * (lo + hi)).to(dev, torch.float32)
+        self.sampler = HaltonSeeds(D, self.action_min, self.action_max, seed=c.sampler_seed)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)  # noqa: E731
+        # iteration state (reference SeedIKState)
+        self.q, self.jacobian, self.jTerror = z(n, D), z(n, self.R, D), z(n, D)
+        self.error_norm, self.position_error, self.orientation_error = z(n), z(n), z(n)
+        self.lambda_damping = z(n)
+        self.success, self.improvement = z(n, dt=torch.uint8), z(n, dt=torch.uint8)
+        # candidate evaluation
+        self.q_new, self.pred_reduction = z(n, D), z(n)
+        self.link_pos, self.link_quat = z(n, T, 3), z(n, T, 4)
+        self.pose_jacobian, self.cumul_mat = z(n, T, 6, D), z(n, L, 3, 4)
+        self.robot_spheres, self.com = z(n, max(Sp, 1), 4), z(n, 4)
+        self.pose_cost, self.pos_dist, self.rot_dist = z(n, T, 2), z(n, T), z(n, T)
+        self.grad_pos, self.grad_quat = z(n, T, 3), z(n, T, 4)
+        self.goalset_idx = z(n, T, dt=torch.int32)
+        self.pose_jTerror = z(n, D)
+        self.env_query_idx = z(n, dt=torch.int32)
+        self.idxs_goal = (torch.arange(n, device=dev) // self.S).to(torch.int32)
+        self.goal_position, self.goal_quat = z(self.P, T, 1, 3), z(self.P, T, 1, 4)
+        self.goal_quat[..., 0] = 1.0
+        self._pose_w = torch.tensor([c.position_weight, c.orientation_weight], device=dev)
+        self._axes_w = torch.ones(T * 6, device=dev)
+        self._tol = z(T * 2)
+        self._project = z(T, dt=torch.uint8)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+
+    # ------------------------------------------------------------------ one evaluation / iteration
+    def _evaluate_candidate(self, q: torch.Tensor, initial: bool) -> None:
+        """reference SeedIKErrorCalculator.compute_error_and_jacobian + (unless ``initial``)
+        SeedIterationStateManager.update_iteration_state"""
+        k, c, n, D, T = self.kin, self.cfg, self.n, self.D, self.T
+        kinematics_hip.launch_kinematics_forward_spheres_jacobian(
+            self.link_pos, self.link_quat, self.robot_spheres, self.com, self.pose_jacobian, self.cumul_mat, q,
+            k.fixed_transforms, k.link_spheres, k.link_masses_com, k.joint_map_type, k.joint_map, k.link_map,
+            k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets, k.joint_links_data,
+            k.joint_links_offsets, k.joint_affects_endeffector, k.joint_offset_map, self.env_query_idx, k.num_envs,
+            n, 1, D, k.num_spheres, 32, True, False)
+        cost_hip.tool_pose_distance(
+            self.pose_cost, self.pos_dist, self.rot_dist, self.grad_pos, self.grad_quat, self.goalset_idx, self.link_pos,
+            self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal, self._pose_w, self._axes_w, self._axes_w,
+            self._tol, self._tol, self._project, n, 1, T, 1, 0)
+        kinematics_hip.launch_kinematics_backward(
+            self.pose_jTerror, self.grad_pos, self.grad_quat, self.robot_spheres, self.com, self.com, self.grad_pos,
+            self.cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map, k.joint_map_type,
+            k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data, k.link_chain_offsets, k.joint_links_data,
+            k.joint_links_offsets, k.joint_affects_endeffector, k.joint_offset_map, self.env_query_idx, k.num_envs,
+            n, 1, D, 0, False, False)
+        linalg_hip.seed_ik_update_state(
+            self.q, self.jacobian, self.jTerror, self.error_norm, self.position_error, self.orientation_error,
+            self.lambda_damping, self.success, self.improvement, q, self.pose_jacobian.view(n, 6 * T, D),
+            self.pose_jTerror, self.pose_cost, self.pos_dist, self.rot_dist, self.pred_reduction, self.action_min,
+            self.action_max, None, None, None, c.joint_limit_weight, c.rho_min, c.lambda_factor, c.lambda_min,
+            c.lambda_max, c.convergence_position_tolerance, c.convergence_orientation_tolerance,
+            c.convergence_joint_limit_weight, initial)
+
+    def _lm_iteration(self) -> None:
+        linalg_hip.levenberg_marquardt_step(self.q_new, self.pred_reduction, self.jacobian, self.jTerror,
+                                            self.lambda_damping, self.q)
+        self._evaluate_candidate(self.q_new, initial=False)
+
+    def _inner_iterations(self) -> None:
+        for _ in range(self.cfg.inner_iterations):
+            self._lm_iteration()
+
+    def _run_inner(self) -> None:
+        if not self.cfg.use_cuda_graph:
+            self._inner_iterations()
+            return
+        if self._graph is None:
+            saved = [t.clone() for t in self._state()]
+            self._lm_iteration()  # warm-up outside the capture
+            torch.cuda.synchronize(self.device)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._inner_iterations()
+            for t, s in zip(self._state(), saved):
+                t.copy_(s)
+        self._graph.replay()
+
+    def _state(self):
+        return [self.q, self.jacobian, self.jTerror, self.error_norm, self.position_error, self.orientation_error,
+                self.lambda_damping, self.success, self.improvement]
+
+    # ------------------------------------------------------------------ seeds, solve
+    def generate_seeds(self, seed_config: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference _generate_seed_configs (:470-520): the same Halton seeds for every problem, the
+        last one replaced by the default joint position; given seeds come first."""
+        P, S, D = self.P, self.S, self.D
+        if seed_config is not None:
+            seed_config = seed_config.to(self.device, torch.float32).view(P, -1, D)
+            if seed_config.shape[1] > S:
+                raise ValueError(f"seed_config has {seed_config.shape[1]} seeds, but only {S} are needed")
+            if seed_config.shape[1] == S:
+                return seed_config
+            extra = self.sampler.get_samples(P * (S - seed_config.shape[1])).view(P, -1, D)
+            return torch.cat([seed_config, extra], dim=1)
+        seeds = self.sampler.get_samples(S).view(1, S, D).repeat(P, 1, 1)
+        seeds[:, -1, :] = self.default_joint_position.view(1, -1)
+        return seeds
+
+    def solve_batch(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, seed_config: Optional[torch.Tensor] = None,
+                    return_seeds: int = 1, current_position: Optional[torch.Tensor] = None) -> SeedIKResult:
+        P, S, D, T, c = self.P, self.S, self.D, self.T, self.cfg
+        self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, 1, 3))
+        self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, 1, 4))
+        if seed_config is None and current_position is not None:
+            seed_config = current_position.view(P, 1, D)
+        seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
+        self.lambda_damping.fill_(c.lambda_initial)
+        self.success.zero_()
+        self._evaluate_candidate(seeds, initial=True)
+        outer = c.max_iterations // c.inner_iterations
+        it = 0
+        for it in range(outer):
+            self._run_inner()
+            if it < outer - 1:  # reference _calculate_exit_condition (:452-468)
+                solved = (self.success.view(P, S).sum(-1) >= 1).sum()
+                if int(solved) >= c.batch_success_threshold * P:
+                    break
+        pos, ori = self.position_error.view(P, S), self.orientation_error.view(P, S)
+        q = self.q.view(P, S, D)
+        ok = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)
+        if c.joint_limit_weight > 0:
+            ok &= ((q > self._limits[0]) & (q < self._limits[1])).all(-1)
+        # reference _select_top_solutions (:522-572)
+        costs = pos + ori
+        if c.start_cspace_dist_weight > 0 and current_position is not None:
+            costs = costs + c.start_cspace_dist_weight * torch.norm(q - current_position.view(P, 1, D), dim=-1)
+        costs = costs + 1e10 * (~ok).float()
+        top = torch.topk(costs, k=return_seeds, dim=-1, largest=False).indices
+        g = lambda t: torch.gather(t, 1, top)  # noqa: E731
+        sol = torch.gather(q, 1, top.unsqueeze(-1).expand(P, return_seeds, D))
+        return SeedIKResult(success=g(ok), solution=sol, position_error=g(pos), rotation_error=g(ori),
+                            iterations=(it + 1) * c.inner_iterations)

@@ -238,6 +238,33 @@ int curobo_hip_levenberg_marquardt_step(
     const float *lambda_damping, const float *joint_position_in, int batch_size, int n_residuals,
     int action_dim, curobo_hip_stream_t stream);
 
+/* ---------------------------------------------------------------- seed IK: iteration-state update
+ * reference (torch elementwise ops, ~25 launches per iteration):
+ *   solver/seed_ik/seed_ik_error_calculator.py:292-305,338-387,464-495 (pose-error reduction,
+ *   joint-limit residual rows, combination) and solver/seed_ik/seed_iteration_state_manager.py:74-260
+ *   (trust ratio rho = (old - new) / (pred + 1e-8), accept rho >= rho_min, lambda /= or *= factor
+ *   clamped, candidate-or-current selection, convergence flags).
+ * State [n, ...] is updated in place from the candidate evaluation: candidate_pose_jacobian
+ * [n, 6T, dof] (FK Jacobian kernel), candidate_pose_jTerror [n, dof] (FK VJP of the pose cost),
+ * candidate_pose_cost [n, T, 2], candidate_{position,rotation}_distance [n, T] (tool-pose kernel),
+ * predicted_reduction [n] (LM step).  jacobian [n, 6T + dof, dof] gets the pose rows and the
+ * diagonal joint-limit rows; error_norm always takes the candidate's value (as the reference does).
+ * initial != 0: the candidate becomes the state unconditionally (lambda is left as set by the
+ * caller).  current_position / dt / velocity_limits [2, dof] (optional, all or none) tighten the
+ * limits for velocity-aware IK. */
+int curobo_hip_seed_ik_update_state(
+    float *joint_position, float *jacobian, float *jTerror, float *error_norm, float *position_error,
+    float *orientation_error, float *lambda_damping, uint8_t *success, uint8_t *improvement,
+    const float *candidate_joint_position, const float *candidate_pose_jacobian,
+    const float *candidate_pose_jTerror, const float *candidate_pose_cost,
+    const float *candidate_position_distance, const float *candidate_rotation_distance,
+    const float *predicted_reduction, const float *action_min, const float *action_max,
+    const float *current_position, const float *dt, const float *velocity_limits,
+    float joint_limit_weight, float rho_min, float lambda_factor, float lambda_min, float lambda_max,
+    float convergence_position_tolerance, float convergence_orientation_tolerance,
+    float convergence_joint_limit_weight, int num_problems, int dof, int num_tool_frames,
+    int initial, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- optimization: MPPI update
  * reference: optim/particle/mppi.py:201-313 + jit helpers :615-757 (pure torch, DIAG_A
  * covariance).  costs [problems, particles, cost_horizon] (cost_horizon may be 1 for totals),

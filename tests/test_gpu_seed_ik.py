@@ -1,0 +1,150 @@
+"""Seed-IK (Levenberg-Marquardt) solver on the HIP kernels against the CPU restatement of the
+reference's iteration (oracle/seed_ik_ref.py): state-update kernel, one evaluation, the first
+iterations, and the solve statistics."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(oracle, model, P, S, seed=0):
+    md = model.as_dict()
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    qg = (lo + (hi - lo) * rng.random((P, lo.shape[0]))).astype(np.float32)
+    fk = oracle.kinematics_forward(qg, md, compute_spheres=False)
+    T = md["tool_frame_map"].shape[0]
+    seeds = (lo + (hi - lo) * rng.random((P * S, lo.shape[0]))).astype(np.float32)
+    return md, fk["link_pos"].reshape(P, T, 1, 3), fk["link_quat"].reshape(P, T, 1, 4), seeds, np.repeat(np.arange(P, dtype=np.int32), S)
+
+
+def _solver(device, P, S, **kw):
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.solver.seed_ik import SeedIKSolver, SeedIKSolverCfg
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    return model, SeedIKSolver(kin, P, SeedIKSolverCfg(num_seeds=S, **kw))
+
+
+def test_update_state_kernel_matches_reference_logic(device):
+    from curobo_amd.backends import linalg
+    from oracle import seed_ik_ref as R
+
+    rng = np.random.default_rng(3)
+    n, D, T = 203, 7, 2
+    Rr = 6 * T + D
+    cfg = R.SeedIKRefCfg()
+    lo, hi = -np.ones(D, np.float32), np.ones(D, np.float32)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    cur = {"joint_position": 0.7 * f(n, D), "jacobian": f(n, Rr, D), "jTerror": f(n, D), "error_norm": np.abs(f(n)) + 0.5,
+           "position_errors": np.abs(f(n)) * 1e-5, "orientation_errors": np.abs(f(n)) * 1e-5,
+           "lambda_damping": np.abs(f(n)) + 0.01}
+    cq = 0.8 * f(n, D)
+    pose_jac, pose_jte = f(n, 6 * T, D), f(n, D)
+    pose_cost, pd, rd = np.abs(f(n, T, 2)) * 0.5, np.abs(f(n, T)) * 1e-5, np.abs(f(n, T)) * 1e-5
+    pred = f(n) * 0.5
+    pred[:5] = 0.0
+    # candidate in the reference's form
+    uv, lv = np.maximum(cq - hi, 0), np.maximum(lo - cq, 0)
+    jl = cfg.joint_limit_weight * (lv + uv)
+    diag = cfg.joint_limit_weight * (np.where(lv > 0, -1.0, 0.0) + np.where(uv > 0, 1.0, 0.0)).astype(np.float32)
+    J = np.zeros((n, Rr, D), np.float32)
+    J[:, :6 * T] = pose_jac
+    J[:, 6 * T + np.arange(D), np.arange(D)] = diag
+    cand = {"joint_position": cq, "jacobian": J, "jTerror": pose_jte + diag * jl,
+            "error_norm": pose_cost.reshape(n, -1).sum(-1) + jl.sum(-1), "position_errors": pd.max(-1), "orientation_errors": rd.max(-1)}
+    ref = R.update_state(cur, cand, pred, lo, hi, cfg)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dt)  # noqa: E731
+    st = {k: t(v) for k, v in cur.items()}
+    succ, imp = torch.zeros(n, dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.uint8, device=device)
+    linalg.seed_ik_update_state(
+        st["joint_position"], st["jacobian"], st["jTerror"], st["error_norm"], st["position_errors"], st["orientation_errors"],
+        st["lambda_damping"], succ, imp, t(cq), t(pose_jac), t(pose_jte), t(pose_cost), t(pd), t(rd), t(pred), t(lo), t(hi),
+        None, None, None, cfg.joint_limit_weight, cfg.rho_min, cfg.lambda_factor, cfg.lambda_min, cfg.lambda_max,
+        cfg.convergence_position_tolerance, cfg.convergence_orientation_tolerance, cfg.convergence_joint_limit_weight, False)
+    torch.cuda.synchronize()
+    # decisions: exact, except where the trust ratio sits within rounding of the threshold
+    rho = (cur["error_norm"] - cand["error_norm"]) / (pred + np.float32(1e-8))
+    clear = np.abs(rho - cfg.rho_min) > 1e-4 * (1 + np.abs(rho))
+    assert np.array_equal(imp.cpu().numpy().astype(bool)[clear], ref["improvement"][clear])
+    m = clear
+    assert np.array_equal(succ.cpu().numpy().astype(bool)[m], ref["success"][m])
+    for k in ("joint_position", "jacobian", "jTerror", "position_errors", "orientation_errors", "lambda_damping"):
+        np.testing.assert_allclose(st[k].cpu().numpy()[m], ref[k][m], rtol=1e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(st["error_norm"].cpu().numpy(), ref["error_norm"], rtol=1e-5, atol=1e-6)
+    assert ref["improvement"].any() and (~ref["improvement"]).any() and ref["success"].any()
+
+
+def test_evaluation_and_first_iterations_match_oracle(oracle, device):
+    from oracle import seed_ik_ref as R
+
+    P, S = 12, 6
+    model, solver = _solver(device, P, S, use_cuda_graph=False, max_iterations=4, inner_iterations=1, batch_success_threshold=2.0)
+    md, gp, gq, seeds, idx = _problem(oracle, model, P, S)
+    cfg = R.SeedIKRefCfg(max_iterations=2)
+    ref0 = R.evaluate(oracle, md, cfg, seeds, gp, gq, idx)
+    solver.goal_position.copy_(torch.as_tensor(gp, device=device))
+    solver.goal_quat.copy_(torch.as_tensor(gq, device=device))
+    solver.lambda_damping.fill_(cfg.lambda_initial)
+    solver._evaluate_candidate(torch.as_tensor(seeds, device=device), initial=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(solver.jacobian.cpu().numpy(), ref0["jacobian"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(solver.jTerror.cpu().numpy(), ref0["jTerror"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(solver.error_norm.cpu().numpy(), ref0["error_norm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(solver.position_error.cpu().numpy(), ref0["position_errors"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(solver.orientation_error.cpu().numpy(), ref0["orientation_errors"], rtol=1e-4, atol=1e-5)
+    # two LM iterations (accept / reject decisions can only differ on knife-edge trust ratios)
+    ref = R.solve(oracle, md, cfg, seeds, gp, gq, idx)
+    solver._lm_iteration()
+    solver._lm_iteration()
+    torch.cuda.synchronize()
+    q = solver.q.cpu().numpy()
+    close = np.abs(q - ref["joint_position"]).max(-1) < 2e-4
+    assert close.mean() > 0.95, close.mean()
+    np.testing.assert_allclose(solver.lambda_damping.cpu().numpy()[close], ref["lambda_damping"][close], rtol=1e-5)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_seed_ik_solves_reachable_goals(oracle, device, graph):
+    from oracle import seed_ik_ref as R
+
+    P, S = 40, 16
+    model, solver = _solver(device, P, S, use_cuda_graph=graph, batch_success_threshold=2.0)
+    md, gp, gq, seeds, idx = _problem(oracle, model, P, S, seed=5)
+    ref = R.solve(oracle, md, R.SeedIKRefCfg(), seeds, gp, gq, idx)
+    res = solver.solve_batch(torch.as_tensor(gp[:, :, 0]), torch.as_tensor(gq[:, :, 0]),
+                             seed_config=torch.as_tensor(seeds).view(P, S, -1))
+    torch.cuda.synchronize()
+    assert res.iterations == 16
+    ok_ref = ref["final_success"].reshape(P, S).any(-1)
+    ok = res.success[:, 0].cpu().numpy()
+    assert abs(ok.mean() - ok_ref.mean()) <= 0.05 and ok.mean() > 0.8, (ok.mean(), ok_ref.mean())
+    # reported solutions really reach the goals (checked with the oracle's FK) and respect the limits
+    sol = res.solution[:, 0].cpu().numpy()
+    fk = oracle.kinematics_forward(sol, md, compute_spheres=False)
+    err = np.linalg.norm(fk["link_pos"][:, 0] - gp[:, 0, 0], axis=-1)
+    assert (err[ok] < 0.005 + 1e-5).all()
+    np.testing.assert_allclose(err[ok], res.position_error[:, 0].cpu().numpy()[ok], atol=1e-5)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    assert ((sol[ok] > lo) & (sol[ok] < hi)).all()
+    # per-seed agreement with the CPU iteration: most seeds end at the same configuration
+    same = np.abs(solver.q.cpu().numpy() - ref["joint_position"]).max(-1) < 1e-3
+    assert same.mean() > 0.7, same.mean()
+
+
+def test_early_exit_and_sampled_seeds(oracle, device):
+    P, S = 16, 32
+    model, solver = _solver(device, P, S)
+    md, gp, gq, _, _ = _problem(oracle, model, P, S, seed=9)
+    res = solver.solve_batch(torch.as_tensor(gp[:, :, 0]), torch.as_tensor(gq[:, :, 0]), return_seeds=3)
+    assert res.solution.shape == (P, 3, 7) and res.success.shape == (P, 3)
+    assert res.success[:, 0].float().mean() > 0.9
+    assert res.iterations in (4, 8, 12, 16)
+    # ranked: successful solutions first, ascending error
+    e = (res.position_error + res.rotation_error + 1e10 * (~res.success).float()).cpu().numpy()
+    assert (np.diff(e, axis=1) >= 0).all()
