@@ -1,0 +1,65 @@
+"""Host-side obstacle fields (curobo_amd/scene/primitives.py): the mesh signed distance equals the
+closed-form field of the same solid, primitives obey their defining properties, and a baked ESDF
+reproduces the field within the grid's interpolation error through the oracle's voxel lookup."""
+
+import numpy as np
+
+from curobo_amd.scene import bake_esdf, box_mesh, capsule_sdf, cuboid_sdf, cylinder_sdf, mesh_sdf, sphere_sdf, union_sdf
+
+
+def test_box_mesh_sdf_equals_cuboid_sdf():
+    rng = np.random.default_rng(0)
+    dims = (0.6, 0.4, 0.25)
+    pose = (0.3, -0.2, 0.5, 0.9238795, 0.0, 0.3826834, 0.0)
+    v, f = box_mesh(dims)
+    p = rng.uniform(-0.5, 0.5, (4000, 3)) + np.array(pose[:3])
+    got, want = mesh_sdf(v, f, pose)(p), cuboid_sdf(dims, pose)(p)
+    np.testing.assert_allclose(got, want, atol=1e-9)
+    assert (want < 0).sum() > 50  # inside samples were tested too
+    # points exactly on faces, edges and vertices of the box: distance 0, no sign flips nearby
+    on = np.array([[0.3, 0.0, 0.0], [0.3, 0.2, 0.0], [0.3, 0.2, 0.125]])
+    local = mesh_sdf(v, f)
+    np.testing.assert_allclose(local(on), 0.0, atol=1e-12)
+    assert (local(on * 1.001) > 0).all() and (local(on * 0.999) < 0).all()
+
+
+def test_primitive_fields():
+    rng = np.random.default_rng(1)
+    p = rng.uniform(-1, 1, (2000, 3))
+    s = sphere_sdf(0.3, (0.1, 0.2, -0.1, 1, 0, 0, 0))
+    np.testing.assert_allclose(s(p), np.linalg.norm(p - [0.1, 0.2, -0.1], axis=-1) - 0.3)
+    # a capsule with base == tip is a sphere; a long thin capsule contains its axis
+    c0 = capsule_sdf(0.3, (0, 0, 0), (0, 0, 0), (0.1, 0.2, -0.1, 1, 0, 0, 0))
+    np.testing.assert_allclose(c0(p), s(p), atol=1e-12)
+    c = capsule_sdf(0.05, (0, 0, 0), (0, 0, 0.5))
+    axis = np.stack([np.zeros(11), np.zeros(11), np.linspace(0, 0.5, 11)], -1)
+    np.testing.assert_allclose(c(axis), -0.05, atol=1e-12)
+    np.testing.assert_allclose(c(np.array([[0.0, 0.0, 0.7]])), 0.15, atol=1e-12)
+    # cylinder: radial and axial distances, corner distance
+    cy = cylinder_sdf(0.2, 0.6)
+    np.testing.assert_allclose(cy(np.array([[0.5, 0, 0], [0, 0, 0.5], [0, 0, 0], [0.5, 0, 0.7]])),
+                               [0.3, 0.2, -0.2, np.hypot(0.3, 0.4)], atol=1e-12)
+    # every field is 1-Lipschitz (the culling in the kernels relies on it)
+    q = p + rng.normal(0, 0.05, p.shape)
+    for fld in (s, c, cy, cuboid_sdf((0.3, 0.2, 0.5), (0, 0.1, 0, 0.7071068, 0.7071068, 0, 0)), union_sdf(s, cy)):
+        assert (np.abs(fld(p) - fld(q)) <= np.linalg.norm(p - q, axis=-1) + 1e-12).all()
+
+
+def test_baked_esdf_reproduces_the_field_through_the_oracle(oracle):
+    field = union_sdf(sphere_sdf(0.15, (0.4, 0.0, 0.3, 1, 0, 0, 0)), capsule_sdf(0.05, (0, 0, 0), (0, 0, 0.4), (0.2, 0.3, 0.1, 1, 0, 0, 0)))
+    vs = 0.02
+    grid = bake_esdf(field, (-0.1, -0.3, -0.1), (0.7, 0.6, 0.7), vs)
+    assert grid["voxel_features"].dtype == np.float16
+    rng = np.random.default_rng(2)
+    pts = rng.uniform([0.0, -0.2, 0.0], [0.6, 0.5, 0.6], (3000, 3)).astype(np.float32)
+    radius = np.float32(0.03)
+    spheres = np.concatenate([pts, np.full((len(pts), 1), radius, np.float32)], -1).reshape(len(pts), 1, 1, 4)
+    eta = 0.02
+    out = oracle.scene_collision(spheres, grid, weight=1.0, activation_distance=eta)
+    d = field(pts.astype(np.float64))
+    pen = radius + eta - d
+    want = np.where(pen <= 0, 0.0, np.where(pen > eta, pen - 0.5 * eta, 0.5 * pen * pen / eta))
+    got = out["distance"].reshape(-1)
+    # trilinear interpolation of a 1-Lipschitz field on a 2 cm grid + fp16 storage
+    np.testing.assert_allclose(got, want, atol=0.6 * vs)
+    assert (want > 0).sum() > 100 and (want == 0).sum() > 100
