@@ -397,7 +397,8 @@ def ik_benchmark(args, model, kin, device, torch):
 
     scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
     P, S = args.ik_problems, args.ik_seeds
-    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S))
+    shards = 4 if P % 4 == 0 else 1  # problem shards on HIP streams (optim/pipelined.py)
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=shards))
     gp, gq = reachable_goals(kin, P, seed=7)
     res = solver.solve_pose(gp, gq)  # warm-up + graph capture
     torch.cuda.synchronize()
@@ -414,8 +415,10 @@ def ik_benchmark(args, model, kin, device, torch):
         "rollout_rows_per_s": round(P * S * len(ocfg.line_search_scale) * (ocfg.num_iters + 1) / dt, 1),
         "success_rate": round(float(res.success.float().mean().item()), 4),
         "median_position_error_m": float(res.position_error[res.success].median().item()) if bool(res.success.any()) else None,
-        "workload": "C1: Franka 7-DoF, 64 uniform seeds per problem, 4-cuboid world, pose + joint-limit + self + scene "
-                    "collision costs, goals = FK of random configurations",
+        "lm_seed_solver": bool(solver.cfg.use_lm_seed), "stream_shards": shards,
+        "workload": "C1: Franka 7-DoF, 64 seeds per problem (best 64 of 128 Levenberg-Marquardt seed-IK runs, as the "
+                    "reference's use_lm_seed), 4-cuboid world, pose + joint-limit + self + scene collision costs, "
+                    "goals = FK of random configurations (some of them in collision: unreachable collision-free)",
     }
 
 

@@ -24,8 +24,8 @@ from .lbfgs import LBFGSOpt, LBFGSOptCfg
 
 
 class PipelinedLBFGS:
-    """``rollout_factory(batch) -> cost_and_gradient`` builds one rollout per shard (batch =
-    seeds of the shard x line-search candidates).  The interface follows :class:`LBFGSOpt`."""
+    """``rollout_factory(batch[, shard_index]) -> cost_and_gradient`` builds one rollout per shard
+    (batch = seeds of the shard x line-search candidates).  The interface follows :class:`LBFGSOpt`."""
 
     def __init__(self, cfg: LBFGSOptCfg, rollout_factory: Callable[[int], Callable], action_horizon: int,
                  action_dim: int, action_bounds: Tuple[torch.Tensor, torch.Tensor], device, n_shards: int = 2,
@@ -37,10 +37,13 @@ class PipelinedLBFGS:
         self.shard_problems = cfg.num_problems // n_shards
         sub = dataclasses.replace(cfg, num_problems=self.shard_problems)
         nls = len(cfg.line_search_scale)
+        import inspect
+
+        takes_index = len(inspect.signature(rollout_factory).parameters) >= 2  # factory(batch, shard_index)
         self.opts: List[LBFGSOpt] = [
-            LBFGSOpt(sub, rollout_factory(self.shard_problems * nls), action_horizon, action_dim, action_bounds, device,
-                     use_cuda_graph=False)
-            for _ in range(n_shards)]
+            LBFGSOpt(sub, rollout_factory(self.shard_problems * nls, k) if takes_index else rollout_factory(self.shard_problems * nls),
+                     action_horizon, action_dim, action_bounds, device, use_cuda_graph=False)
+            for k in range(n_shards)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_shards)]
         self.action_horizon, self.action_dim = action_horizon, action_dim
         self._graph: Optional[torch.cuda.CUDAGraph] = None

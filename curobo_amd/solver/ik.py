@@ -3,8 +3,10 @@ seed in parallel, best successful seed per problem.
 
 Mirrors the flow of the reference ``IKSolver._solve_impl`` (``curobo/_src/solver/solver_ik.py:363-586``):
 seeds -> ``optimizer.optimize`` -> metrics rollout -> success mask -> ``cost + 1e16 * fail`` ->
-top-1 over seeds.  Seeding is uniform within the joint limits (the reference's LM seed solver is a
-SURVEY section 8f-2 "next" row).  With ``torch.distributed`` initialised the seed axis is sharded and the
+top-1 over seeds.  Seeds come from the Levenberg-Marquardt seed solver (``use_lm_seed``, reference
+``solver_ik.py:707-722``: the best ``num_seeds`` of ``seed_solver_num_seeds`` LM runs) or are uniform
+within the joint limits.  ``stream_shards`` > 1 splits the problems over L-BFGS instances on their own
+HIP streams inside one graph (``optim/pipelined.py``).  With ``torch.distributed`` initialised the seed axis is sharded and the
 winner found with one RCCL all-gather (``curobo_amd.distributed.global_argmin``).
 """
 
@@ -16,10 +18,11 @@ from typing import Optional
 import torch
 
 from ..distributed import global_argmin
-from ..optim import LBFGSOpt, LBFGSOptCfg
+from ..optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
 from ..robot.kinematics_params import KinematicsParams
 from ..rollout.ik_rollout import IKRollout, IKRolloutCfg
 from ..scene.data import SceneData
+from .seed_ik import SeedIKSolver, SeedIKSolverCfg
 
 
 @dataclass
@@ -32,6 +35,12 @@ class IKSolverCfg:
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(
         history=7, inner_iters=20, num_iters=100, cost_relative_threshold=0.01))
     seed: int = 0
+    #: seeds of the optimiser = best ``num_seeds`` solutions of the LM seed solver (reference
+    #: solver_ik_cfg.py:71,93; solver_ik.py:131-141: at least 2 x num_seeds LM runs)
+    use_lm_seed: bool = True
+    seed_solver_num_seeds: int = 32
+    #: problem shards of the optimiser on separate HIP streams (1 = one batch, one stream)
+    stream_shards: int = 1
 
 
 @dataclass
@@ -54,14 +63,34 @@ class IKSolver:
         ocfg = self.cfg.optimizer
         ocfg.num_problems = self.P * self.S
         self.nls = len(ocfg.line_search_scale)
-        self.rollout = IKRollout(kin, scene, self.P * self.S * self.nls, self.cfg.rollout)
         self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, self.cfg.rollout)
         bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
-        self.optimizer = LBFGSOpt(ocfg, self.rollout.cost_and_gradient, 1, kin.num_dof, bounds, self.device,
-                                  use_cuda_graph=use_cuda_graph)
-        rows = torch.arange(self.P * self.S * self.nls, device=self.device)
-        self._row_goal = (rows // (self.S * self.nls)).to(torch.int32)
+        K = self.cfg.stream_shards
+        if K > 1 and self.P % K != 0:
+            raise ValueError(f"num_problems ({self.P}) must be a multiple of stream_shards ({K})")
+        rows_per_problem = self.S * self.nls
+        self.rollouts = []
+
+        def make_rollout(batch, k=0):
+            ro = IKRollout(kin, scene, batch, self.cfg.rollout)
+            ro._first_problem = k * (self.P // K)  # rows of shard k belong to problems [first, first + P/K)
+            self.rollouts.append(ro)
+            return ro.cost_and_gradient
+        if K > 1:
+            self.optimizer = PipelinedLBFGS(ocfg, make_rollout, 1, kin.num_dof, bounds, self.device, n_shards=K,
+                                            use_cuda_graph=use_cuda_graph)
+        else:
+            self.optimizer = LBFGSOpt(ocfg, make_rollout(self.P * rows_per_problem), 1, kin.num_dof, bounds, self.device,
+                                      use_cuda_graph=use_cuda_graph)
+        self.rollout = self.rollouts[0]
+        self._row_goals = [(ro._first_problem + torch.arange(ro.batch_size, device=self.device) // rows_per_problem).to(torch.int32)
+                           for ro in self.rollouts]
         self._mrow_goal = (torch.arange(self.P * self.S, device=self.device) // self.S).to(torch.int32)
+        self.seed_solver = None
+        if self.cfg.use_lm_seed:
+            n_lm = max(self.cfg.seed_solver_num_seeds, 2 * self.S)
+            self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=n_lm, use_cuda_graph=use_cuda_graph,
+                                                                         sampler_seed=451 + self.cfg.seed))
         self._gen = torch.Generator(device="cpu")
 
     def sample_seeds(self) -> torch.Tensor:
@@ -80,10 +109,14 @@ class IKSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         gp = goal_position.to(self.device, torch.float32).view(P, 1, 1, 3).expand(P, T, 1, 3).contiguous()
         gq = goal_quat.to(self.device, torch.float32).view(P, 1, 1, 4).expand(P, T, 1, 4).contiguous()
-        self.rollout.update_goals(gp, gq, self._row_goal)
+        for ro, rows in zip(self.rollouts, self._row_goals):
+            ro.update_goals(gp, gq, rows)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
         if seeds is None:
-            seeds = self.sample_seeds()
+            if self.seed_solver is not None:
+                seeds = self.seed_solver.solve_batch(gp[:, :, 0], gq[:, :, 0], return_seeds=S).solution
+            else:
+                seeds = self.sample_seeds()
         best = self.optimizer.optimize(seeds.reshape(P * S, 1, D))
         q = best.reshape(P * S, D).contiguous()
         m = self.metrics_rollout

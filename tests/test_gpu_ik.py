@@ -232,3 +232,28 @@ def test_cspace_state_kernel(retime, oracle, device):
     torch.cuda.synchronize()
     for o, k in zip(outs, ("cost", "grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")):
         np.testing.assert_allclose(o.cpu().numpy(), ref[k], rtol=2e-5, atol=2e-5 * max(1.0, np.abs(ref[k]).max()), err_msg=k)
+
+
+def test_ik_solver_stream_shards_give_the_same_solutions(device):
+    """Problem shards on separate HIP streams (IKSolverCfg.stream_shards) are the same optimisation:
+    identical winners and errors as the one-stream solver from the same seeds."""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+    from curobo_amd.workloads import c1_world, reachable_goals
+
+    kin = KinematicsParams.from_model(load_model("franka"), device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
+    P, S = 8, 16
+    gp, gq = reachable_goals(kin, P, seed=3)
+    ref = None
+    for shards in (1, 2, 4):
+        solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=shards, use_lm_seed=False))
+        res = solver.solve_pose(gp, gq, seeds=solver.sample_seeds())
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = res
+            assert res.success.float().mean() > 0.5
+        else:
+            assert torch.equal(res.success, ref.success) and torch.equal(res.seed_index, ref.seed_index)
+            assert torch.equal(res.solution, ref.solution)
