@@ -79,3 +79,34 @@ def test_mppi_on_collision_rollout_reduces_cost(device):
     torch.cuda.synchronize()
     assert (c0 > 0).any()
     assert (c1 <= c0 + 1e-3).all() and float(c1.sum()) < 0.7 * float(c0.sum())
+
+
+def test_multi_stage_mppi_then_lbfgs(device):
+    """reference MultiStageOptimizer: a particle stage seeds the gradient stage; the chain ends at
+    least as low as either stage alone started, and a disabled stage is skipped."""
+    from curobo_amd.optim import MPPI, LBFGSOpt, LBFGSOptCfg, MPPICfg, MultiStageOptimizer
+
+    B, Ha, D = 4, 6, 3
+    V = Ha * D
+    target = torch.linspace(-0.6, 0.6, V, device=device).view(1, V)
+    lo, hi = -torch.ones(D, device=device), torch.ones(D, device=device)
+    cost = lambda a: ((a - target) ** 2).sum(-1)  # noqa: E731
+    mppi = MPPI(MPPICfg(num_problems=B, num_particles=256, num_iters=10, beta=1.0, init_cov=0.3), cost, Ha, D, (lo, hi), device)
+    ocfg = LBFGSOptCfg(num_problems=B, num_iters=20, inner_iters=10, history=5)
+    nls = len(ocfg.line_search_scale)
+
+    def cost_grad(x):
+        return cost(x).clone(), (2.0 * (x - target)).contiguous()
+    lb = LBFGSOpt(ocfg, cost_grad, Ha, D, (lo, hi), device, use_cuda_graph=False)
+    assert nls == 4
+    chain = MultiStageOptimizer([mppi, lb])
+    assert chain.solver_names == ["MPPI", "LBFGSOpt"] and chain.action_horizon == Ha and chain.opt_dim == V
+    x0 = torch.zeros(B, Ha, D, device=device)
+    after_mppi = mppi.optimize(x0).clone()
+    mppi.reset_distribution()
+    out = chain.optimize(x0)
+    torch.cuda.synchronize()
+    c_m, c_out = cost(after_mppi.view(B, V)), cost(out.view(B, V))
+    assert float(c_out.max()) < 1e-3 and bool((c_out <= c_m + 1e-6).all())
+    chain.enable_stage(0, False)  # gradient stage alone from the same seed: also converges here
+    assert float(cost(chain.optimize(x0).view(B, V)).max()) < 1e-3
