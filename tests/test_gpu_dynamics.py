@@ -77,3 +77,88 @@ def test_dynamics_front_end_autograd(oracle, device):
     z = torch.zeros(4, 7, device=device)
     tg = dyn.compute_inverse_dynamics(torch.as_tensor(q[:4], device=device), z, z)
     assert float(tg[:, 0].abs().max()) < 1e-4 and float(tg.abs().max()) > 1.0
+
+
+def test_c4_shape_humanoid_self_collision_plus_inverse_dynamics_cost(oracle, device):
+    """BASELINE config 4 in small: Unitree G1 whole body (the in-tree stand-in for the 38-DoF
+    humanoid), map-reduce-sized self collision (162 k sphere pairs, tiled kernel) + an
+    inverse-dynamics cost (joint-torque limits and torque regularisation on RNEA's tau, through the
+    c-space STATE cost) and the complete VJP chain back to (q, qd, qdd) -- HIP kernels vs the oracle
+    composition of the same stages."""
+    from curobo_amd.backends import cost as Cs
+    from curobo_amd.backends import dynamics as Dy
+    from curobo_amd.backends import geometry as G
+    from curobo_amd.backends import kinematics as K
+
+    B, H = 4, 6
+    n = B * H
+    model, kin, q, qd, qdd, rng = _setup("unitree_g1", device, n, 11)
+    md = model.as_dict()
+    L, D, S, T = kin.num_links, kin.num_dof, kin.num_spheres, kin.num_pose_links
+    P = model.collision_pairs.shape[0]
+    assert P > 100000 and D >= 29
+    qd, qdd = 0.5 * qd, 0.5 * qdd
+    grav = np.array([0, 0, 0, 0, 0, 9.81], np.float32)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dt)  # noqa: E731
+    z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
+    w_self = 3.0
+    # ---------------- oracle
+    fk = oracle.kinematics_forward(q, md)
+    sc = oracle.self_collision(fk["robot_spheres"], model.sphere_padding, model.collision_pairs, w_self)
+    tau_ref, cache_ref = oracle.rnea_forward(q, qd, qdd, md, gravity=grav)
+    # torque limits chosen so that about half of the joint torques violate them (the robot file's
+    # limits are placeholders for the virtual base joints)
+    cap = np.float32(np.median(np.abs(tau_ref)) + 1e-3)
+    eff_b = np.stack([-cap * np.ones(D, np.float32), cap * np.ones(D, np.float32)])
+    lim = {"position": np.asarray(md["joint_limits_position"], np.float32), "effort": eff_b.astype(np.float32)}
+    weight = np.array([50.0, 1.0, 1.0, 1.0, 7.0], np.float32)          # position, velocity, acceleration, jerk, effort bounds
+    eta = np.array([0.05, 0.0, 0.0, 0.0, 0.05], np.float32)
+    sql2 = np.array([0.01, 0.02, 0.0, 0.003, 0.0], np.float32)           # vel, acc, jerk, effort regularisation, (dt)
+    dt = np.full(B, 0.1, np.float32)
+    shp = (B, H, D)
+    cs = oracle.cspace_state_cost(q.reshape(shp), qd.reshape(shp), qdd.reshape(shp), np.zeros(shp, np.float32), dt, lim,
+                                  weight, eta, sql2, effort=tau_ref.reshape(shp))
+    g_q1 = oracle.kinematics_backward(md, fk["cumul_mat"], sc["gradient"])
+    g_rnea = oracle.rnea_backward(cs["grad_effort"].reshape(n, D), q, qd, cache_ref, md, gravity=grav)
+    ref_cost = sc["distance"].reshape(B, H).sum(-1) + cs["cost"].reshape(B, -1).sum(-1)
+    ref_gq = g_q1 + g_rnea[0] + cs["grad_position"].reshape(n, D)
+    ref_gqd = g_rnea[1] + cs["grad_velocity"].reshape(n, D)
+    ref_gqdd = g_rnea[2] + cs["grad_acceleration"].reshape(n, D)
+    assert (sc["distance"] > 0).any() and (np.abs(cs["grad_effort"]) > 0).any()
+    # ---------------- HIP
+    tq, tqd, tqdd = t(q), t(qd), t(qdd)
+    link_pos, link_quat, spheres, com, cumul = z(n, T, 3), z(n, T, 4), z(n, S, 4), z(n, 4), z(n, L, 3, 4)
+    env = torch.zeros(n, dtype=torch.int32, device=device)
+    K.launch_kinematics_forward_spheres(link_pos, link_quat, spheres, com, cumul, tq, kin.fixed_transforms, kin.link_spheres,
+                                        kin.link_masses_com, kin.joint_map_type, kin.joint_map, kin.link_map, kin.tool_frame_map,
+                                        kin.link_sphere_idx_map, kin.joint_offset_map, env, kin.num_envs, n, 1, D, S, 32, True, False)
+    self_d, self_g, flags = z(n, 1), z(n, S, 4), torch.zeros(n, S, dtype=torch.uint8, device=device)
+    scp = kin.self_collision
+    G.self_collision_distance(self_d, self_g, z(1), flags, spheres, scp.sphere_padding, torch.tensor([w_self], device=device),
+                              scp.collision_pairs, z(1), torch.zeros(2, dtype=torch.int16, device=device), 1, 256, n, 1, S, P,
+                              False, True)
+    tau, cache = z(n, D), z(n, L * 20)
+    rargs = (kin.fixed_transforms, kin.link_masses_com, kin.link_inertias, kin.joint_map_type, kin.joint_map, kin.link_map,
+             kin.joint_offset_map, t(grav), kin.link_level_offsets, kin.link_level_data)
+    Dy.launch_rnea_forward(tau, tq, tqd, tqdd, *rargs, cache, n, L, D, kin.n_tree_levels, 1, None)
+    big = np.stack([-1e9 * np.ones(D), 1e9 * np.ones(D)]).astype(np.float32)
+    c_cost, gp, gv, ga, gj, gtau = [z(B, H, D) for _ in range(6)]
+    Cs.cspace_state_cost(c_cost, gp, gv, ga, gj, gtau, tq.view(shp), tqd.view(shp), tqdd.view(shp), z(*shp), tau.view(shp), t(dt),
+                         z(1, D), torch.zeros(B, dtype=torch.int32, device=device), t(lim["position"]), t(big), t(big), t(big),
+                         t(lim["effort"]), t(weight), t(eta), t(sql2), z(1), torch.ones(1, device=device), torch.ones(D, device=device),
+                         True, B, H, D)
+    g1 = z(n, D)
+    K.launch_kinematics_backward(g1, z(n, T, 3), z(n, T, 4), self_g, com, com, z(n, T, 3), cumul, kin.link_spheres,
+                                 kin.link_masses_com, kin.link_map, kin.joint_map, kin.joint_map_type, kin.tool_frame_map,
+                                 kin.link_sphere_idx_map, kin.link_chain_data, kin.link_chain_offsets, kin.joint_links_data,
+                                 kin.joint_links_offsets, kin.joint_affects_endeffector, kin.joint_offset_map, env, kin.num_envs,
+                                 n, 1, D, S, False, False)
+    g2 = [z(n, D) for _ in range(3)]
+    Dy.launch_rnea_backward(*g2, gtau.view(n, D), tq, tqd, *rargs, cache, n, L, D, kin.n_tree_levels, 1, None)
+    torch.cuda.synchronize()
+    cost = self_d.view(B, H).sum(-1) + c_cost.view(B, -1).sum(-1)
+    np.testing.assert_allclose(tau.cpu().numpy(), tau_ref, rtol=1e-4, atol=1e-4 * np.abs(tau_ref).max())
+    assert np.array_equal(flags.cpu().numpy(), sc["sparse_index"]), "colliding sphere pair must be identical"
+    np.testing.assert_allclose(cost.cpu().numpy(), ref_cost, rtol=2e-4, atol=1e-4 * np.abs(ref_cost).max())
+    for got, ref in (((g1 + g2[0] + gp.view(n, D)), ref_gq), ((g2[1] + gv.view(n, D)), ref_gqd), ((g2[2] + ga.view(n, D)), ref_gqdd)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
