@@ -10,7 +10,9 @@ Follows, with the oracle's FK / Jacobian / FK-VJP / tool-pose / LM-step restatem
       :464-495  combination
   curobo/_src/solver/seed_ik/seed_iteration_state_manager.py:74-260  state update
   curobo/_src/solver/seed_ik/seed_ik_solver.py:291-330,384-437     iteration / solve loop
-Parity of the pieces is pinned where they are defined (oracle/curobo_oracle.c); the LM step itself is
+The state update is pinned bit-exactly by the reference's own SeedIterationStateManager run on CPU
+(tests/golden/seed_ik_update_golden.npz, tests/golden/make_seed_ik_golden.py).  Parity of the other
+pieces is pinned where they are defined (oracle/curobo_oracle.c); the LM step itself is
 "parity unpinned" against the reference (Warp tile kernel, no numeric test upstream) and pinned
 against numpy.linalg.solve in tests/test_oracle_linalg.py.
 """

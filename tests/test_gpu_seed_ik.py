@@ -148,3 +148,46 @@ def test_early_exit_and_sampled_seeds(oracle, device):
     # ranked: successful solutions first, ascending error
     e = (res.position_error + res.rotation_error + 1e10 * (~res.success).float()).cpu().numpy()
     assert (np.diff(e, axis=1) >= 0).all()
+
+
+def test_update_state_kernel_matches_reference_golden(device):
+    """the HIP state-update kernel against the reference's own SeedIterationStateManager outputs
+    (tests/golden/seed_ik_update_golden.npz).  The kernel also builds the joint-limit rows; here
+    the candidate lies inside the limits' violation-free region or not as drawn, so the golden
+    candidate Jacobian / J^T e are fed through weight 0 rows: pose block = the golden candidate."""
+    import os
+
+    from curobo_amd.backends import linalg
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seed_ik_update_golden.npz"))
+    pick = lambda pre: {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(pre + "/")}  # noqa: E731
+    c, cur, cand, out = pick("cfg"), pick("cur"), pick("cand"), pick("out")
+    n, D = cand["joint_position"].shape
+    R = cand["jacobian"].shape[1]
+    T = (R - D) // 6
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dt)  # noqa: E731
+    st = {k: t(v) for k, v in cur.items()}
+    succ, imp = torch.zeros(n, dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.uint8, device=device)
+    # joint_limit_weight = 0: no joint-limit contribution, so error norm / J^T e are the pose block's;
+    # the pose cost is fed as one number per problem (its sum is what the kernel uses)
+    pose_cost = np.zeros((n, T, 2), np.float32)
+    pose_cost[:, 0, 0] = cand["error_norm"]
+    pd = np.repeat(cand["position_errors"][:, None], T, 1)
+    rd = np.repeat(cand["orientation_errors"][:, None], T, 1)
+    linalg.seed_ik_update_state(
+        st["joint_position"], st["jacobian"], st["jTerror"], st["error_norm"], st["position_errors"], st["orientation_errors"],
+        st["lambda_damping"], succ, imp, t(cand["joint_position"]), t(cand["jacobian"][:, :6 * T]), t(cand["jTerror"]), t(pose_cost),
+        t(pd), t(rd), t(g["pred"]), t(g["lo"]), t(g["hi"]), None, None, None, 0.0, float(c["rho_min"]), float(c["lambda_factor"]),
+        float(c["lambda_min"]), float(c["lambda_max"]), float(c["convergence_position_tolerance"]),
+        float(c["convergence_orientation_tolerance"]), float(c["convergence_joint_limit_weight"]), False)
+    torch.cuda.synchronize()
+    assert np.array_equal(imp.cpu().numpy().astype(bool), out["improvement"])
+    assert np.array_equal(succ.cpu().numpy().astype(bool), out["success"])
+    acc = out["improvement"]
+    for k in ("joint_position", "jTerror", "position_errors", "orientation_errors", "error_norm"):
+        np.testing.assert_array_equal(st[k].cpu().numpy(), out[k], err_msg=k)
+    np.testing.assert_allclose(st["lambda_damping"].cpu().numpy(), out["lambda_damping"], rtol=1e-6)
+    J = st["jacobian"].cpu().numpy()
+    np.testing.assert_array_equal(J[:, :6 * T], out["jacobian"][:, :6 * T])        # pose rows: candidate where accepted, else kept
+    np.testing.assert_array_equal(J[~acc, 6 * T:], cur["jacobian"][~acc, 6 * T:])   # rejected: joint-limit rows untouched
+    assert (J[acc, 6 * T:] == 0).all()                                               # accepted: rebuilt (weight 0 -> zero rows)

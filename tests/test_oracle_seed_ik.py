@@ -57,3 +57,27 @@ def test_halton_seed_buffer_is_scipys_scrambled_halton():
         finally:
             sys.path.remove(ref_root)
         np.testing.assert_allclose(s.buffer.numpy(), HaltonSequencer(ndims=3, seed=451).random(2000).astype(np.float32))
+
+
+def _golden():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seed_ik_update_golden.npz"))
+    pick = lambda pre: {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(pre + "/")}  # noqa: E731
+    return g, pick("cfg"), pick("cur"), pick("cand"), pick("out")
+
+
+def test_state_update_restatement_matches_reference_golden():
+    """oracle/seed_ik_ref.update_state against the outputs of the reference's own
+    SeedIterationStateManager.update_iteration_state (tests/golden/make_seed_ik_golden.py)"""
+    from oracle import seed_ik_ref as R
+
+    g, c, cur, cand, out = _golden()
+    cfg = R.SeedIKRefCfg(rho_min=float(c["rho_min"]), lambda_factor=float(c["lambda_factor"]), lambda_min=float(c["lambda_min"]),
+                         lambda_max=float(c["lambda_max"]), convergence_position_tolerance=float(c["convergence_position_tolerance"]),
+                         convergence_orientation_tolerance=float(c["convergence_orientation_tolerance"]),
+                         convergence_joint_limit_weight=float(c["convergence_joint_limit_weight"]))
+    got = R.update_state(cur, cand, g["pred"], g["lo"], g["hi"], cfg)
+    assert np.array_equal(got["improvement"], out["improvement"]) and np.array_equal(got["success"], out["success"])
+    for k in ("joint_position", "jacobian", "jTerror", "error_norm", "position_errors", "orientation_errors"):
+        np.testing.assert_array_equal(got[k], out[k], err_msg=k)
+    np.testing.assert_allclose(got["lambda_damping"], out["lambda_damping"], rtol=1e-6)
+    assert 0 < out["improvement"].sum() < len(out["improvement"]) and out["success"].any()
