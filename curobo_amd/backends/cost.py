@@ -121,3 +121,12 @@ def cspace_state_cost(
         ptr(cspace_non_terminal_weight_factor), ptr(cspace_target_dof_weight), int(write_grad), batch_size, horizon, dof,
         int(retime_weights), int(retime_regularization_weights), current_stream(out_cost),
     ))
+
+
+def cspace_l2_distance(out_cost, out_grad_p, pos, target, target_idx, weight, terminal_dof_weight,
+                       non_terminal_dof_weight, write_grad: bool, batch_size: int, horizon: int, dof: int):
+    """reference ``forward_l2_warp`` (``cost/wp_torch_cspace_dist.py:12-78``; outputs first)."""
+    check(load().curobo_hip_cspace_l2_distance(
+        ptr(out_cost), ptr(out_grad_p), ptr(pos), ptr(target), ptr(target_idx), ptr(weight), ptr(terminal_dof_weight),
+        ptr(non_terminal_dof_weight), int(write_grad), batch_size, horizon, dof, current_stream(out_cost),
+    ))

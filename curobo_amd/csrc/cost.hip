@@ -87,6 +87,31 @@ __global__ void __launch_bounds__(256) cspace_state_kernel(const CspaceStateArgs
   }
 }
 
+// c-space L2 distance to a target configuration (reference forward_l2_warp,
+// cost/wp_torch_cspace_dist.py:12-78): cost = w * r_d * (q - target)^2 per (batch, horizon, dof) with the
+// per-dof weight r_d taken from the terminal / non-terminal table; entries of zero weight are NOT
+// written (the reference returns before its stores), so the caller's buffers keep their content there.
+struct CspaceL2Args {
+  float *out_cost, *out_gp;
+  const float *pos, *target, *weight, *terminal_dof_weight, *non_terminal_dof_weight;
+  const int32_t *target_idx;
+  int write_grad, batch, horizon, dof;
+};
+
+__global__ void __launch_bounds__(256) cspace_l2_kernel(const CspaceL2Args a) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.batch * a.horizon * a.dof;
+  if (tid >= total) return;
+  const int b = (int)(tid / ((long)a.horizon * a.dof));
+  const int h = (int)((tid - (long)b * a.horizon * a.dof) / a.dof);
+  const int d = (int)(tid % a.dof);
+  const float w = (h < a.horizon - 1 ? a.non_terminal_dof_weight[d] : a.terminal_dof_weight[d]) * a.weight[0];
+  if (w == 0.0f) return;
+  const float err = a.pos[tid] - a.target[(size_t)a.target_idx[b] * a.dof + d];
+  a.out_cost[tid] = w * err * err;
+  if (a.write_grad) a.out_gp[tid] = 2.0f * w * err;
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -173,5 +198,23 @@ CUROBO_EXPORT int curobo_hip_cspace_state_cost(
                     retime_weights, retime_regularization_weights};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cspace_state_kernel, dim3((unsigned)ceil_div_l((long)batch_size * horizon * dof, 256)), dim3(256), 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_cspace_l2_distance(float *out_cost, float *out_grad_p, const float *pos, const float *target,
+                                                const int32_t *target_idx, const float *weight,
+                                                const float *terminal_dof_weight, const float *non_terminal_dof_weight,
+                                                int write_grad, int batch_size, int horizon, int dof,
+                                                curobo_hip_stream_t stream) {
+  const char *what = "cspace_l2_distance";
+  CUROBO_REQUIRE(batch_size >= 0 && horizon >= 1 && dof >= 1, "%s: bad sizes", what);
+  CUROBO_REQUIRE(out_cost && pos && target && target_idx && weight && terminal_dof_weight && non_terminal_dof_weight,
+                 "%s: NULL argument", what);
+  CUROBO_REQUIRE(!write_grad || out_grad_p, "%s: write_grad without a gradient buffer", what);
+  if (batch_size == 0) return CUROBO_HIP_OK;
+  CspaceL2Args a{out_cost, out_grad_p, pos, target, weight, terminal_dof_weight, non_terminal_dof_weight, target_idx,
+                 write_grad, batch_size, horizon, dof};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cspace_l2_kernel, dim3((unsigned)ceil_div_l((long)batch_size * horizon * dof, 256)), dim3(256), 0, st, a);
   return check_launch(what, st);
 }

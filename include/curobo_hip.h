@@ -238,6 +238,16 @@ int curobo_hip_levenberg_marquardt_step(
     const float *lambda_damping, const float *joint_position_in, int batch_size, int n_residuals,
     int action_dim, curobo_hip_stream_t stream);
 
+/* c-space L2 distance cost (reference forward_l2_warp / L2DistFunction,
+ * cost/wp_torch_cspace_dist.py:12-158): out_cost[b, h, d] = weight[0] * r[d] * (pos - target[target_idx[b]])^2
+ * with r = terminal_dof_weight at h == horizon - 1, else non_terminal_dof_weight [dof]; out_grad_p =
+ * 2 w err.  Entries of zero weight are left untouched, as in the reference. */
+int curobo_hip_cspace_l2_distance(float *out_cost, float *out_grad_p, const float *pos, const float *target,
+                                  const int32_t *target_idx, const float *weight,
+                                  const float *terminal_dof_weight, const float *non_terminal_dof_weight,
+                                  int write_grad, int batch_size, int horizon, int dof,
+                                  curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- seed IK: iteration-state update
  * reference (torch elementwise ops, ~25 launches per iteration):
  *   solver/seed_ik/seed_ik_error_calculator.py:292-305,338-387,464-495 (pose-error reduction,

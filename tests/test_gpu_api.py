@@ -161,3 +161,35 @@ def test_c3_ur10e_voxel_world_collision_checking_path(oracle, device):
     np.testing.assert_allclose(d_self.cpu().numpy().reshape(-1), ref_s["distance"], rtol=1e-5, atol=1e-6)
     # bit-exact collision-hit indices (north_star): which spheres are in collision
     assert np.array_equal(d_world.cpu().numpy() > 0, ref_w["distance"] > 0)
+
+
+def test_cspace_l2_distance_autograd(device):
+    """reference L2DistFunction (cost/wp_torch_cspace_dist.py): cost / gradient vs the closed form,
+    zero-weight entries untouched, gradient scaling through use_grad_input"""
+    from curobo_amd.hip_ops import L2DistFunction
+
+    torch.manual_seed(0)
+    B, H, D = 5, 4, 7
+    pos = torch.randn(B, H, D, device=device, requires_grad=True)
+    target = torch.randn(3, D, device=device)
+    tidx = torch.tensor([2, 0, 1, 1, 0], dtype=torch.int32, device=device)
+    w = torch.tensor([3.0], device=device)
+    term = torch.rand(D, device=device) + 0.5
+    nonterm = torch.rand(D, device=device)
+    nonterm[2] = 0.0  # untouched entries
+    out_c = torch.full((B, H, D), -7.0, device=device)
+    out_g = torch.full((B, H, D), -7.0, device=device)
+    cost = L2DistFunction.apply(pos, target, tidx, w, term, nonterm, out_c, out_g, True)
+    r = nonterm.view(1, 1, D).expand(B, H, D).clone()
+    r[:, -1] = term
+    err = pos.detach() - target[tidx.long()].view(B, 1, D)
+    ref = 3.0 * r * err * err
+    mask = (r != 0)
+    torch.testing.assert_close(out_c[mask], ref[mask], rtol=1e-6, atol=1e-6)
+    assert bool((out_c[~mask] == -7.0).all()) and bool((out_g[~mask] == -7.0).all())
+    out_c[~mask] = 0.0
+    out_g[~mask] = 0.0
+    scale = torch.rand(B, H, device=device)
+    cost = L2DistFunction.apply(pos, target, tidx, w, term, nonterm, out_c, out_g, True)
+    (cost * scale).sum().backward()
+    torch.testing.assert_close(pos.grad, 6.0 * r * err * scale.unsqueeze(-1), rtol=1e-5, atol=1e-6)
