@@ -955,7 +955,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
           f3 g = make_f3(0.f, 0.f, 0.f);
           float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
           const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
-          if (mask != 0u) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
+          // records beyond the 32 mask bits are never culled: the sphere is evaluated whatever its link mask says
+          if (s < S && (mask != 0u || n_rec > 32)) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
           cost_scene += d;
           any_scene = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_scene;
         }
@@ -1187,7 +1188,7 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
       f3 g = make_f3(0.f, 0.f, 0.f);
       float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
       const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
-      if (mask != 0u) c4 = scene_sphere<0, KINDS>(c, a.sc, h, s, d, g, mask);
+      if (s < S && (mask != 0u || n_rec > 32)) c4 = scene_sphere<0, KINDS>(c, a.sc, h, s, d, g, mask);
       cost_pt += d;
       any_grad = wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64) || any_grad;
     }

@@ -233,3 +233,23 @@ def test_c5_shape_multi_env_horizon_64(oracle, device):
     for c, g in outs:
         np.testing.assert_allclose(c, ref["cost"], rtol=1e-4, atol=1e-2)
         np.testing.assert_allclose(g, gk, rtol=2e-3, atol=2e-5 * np.abs(gk).max())
+
+
+def test_fused_many_obstacles_uses_the_row_pass(device):
+    """More than 32 obstacle records do not fit the packed scene pass's entry format (and the link
+    masks only cover 32): the kernel falls back to one sphere per lane; same numbers as the sequence."""
+    from curobo_amd.workloads import c2_world
+
+    rng = np.random.default_rng(4)
+    world = c2_world()[0]
+    for _ in range(33):  # small boxes scattered through the workspace
+        p = rng.uniform([-0.6, -0.6, 0.1], [0.7, 0.7, 0.9])
+        world.append({"dims": rng.uniform(0.04, 0.12, 3).tolist(), "pose": [*p.tolist(), 1, 0, 0, 0]})
+    assert len(world) == 37
+    # discrete collision: with ~9x the (sphere, obstacle) sweep evaluations of the C2 world, the swept cost's
+    # zero-motion discontinuity (DESIGN.md section 2) would make two separately compiled paths disagree on
+    # the odd trajectory; the fallback pass itself is the same code for both modes
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, seeds=12, world=[world], use_sweep=False, use_speed_metric=False)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())

@@ -130,8 +130,8 @@ def test_ik_rollout_matches_oracle_composition(fused, oracle, device):
     np.testing.assert_allclose(grad.cpu().numpy(), gq, rtol=2e-3, atol=2e-5 * np.abs(gq).max())
 
 
-@pytest.mark.parametrize("robot,method", [("franka", 0), ("franka", 2), ("unitree_g1", 1)])
-def test_ik_fused_equals_kernel_sequence(robot, method, device):
+@pytest.mark.parametrize("robot,method,n_extra", [("franka", 0, 0), ("franka", 2, 0), ("unitree_g1", 1, 0), ("franka", 0, 33)])
+def test_ik_fused_equals_kernel_sequence(robot, method, n_extra, device):
     """one-launch IK rollout vs the seven drop-in launches: cost, gradient and every metric buffer
     (G1: 4 tool frames, 49 dof, goal sets of 3; the tiled self-collision kernel on the other side)"""
     from curobo_amd.robot.kinematics_params import KinematicsParams
@@ -141,9 +141,13 @@ def test_ik_fused_equals_kernel_sequence(robot, method, device):
 
     model = load_model(robot)
     kin = KinematicsParams.from_model(model, device)
-    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
-    B, T, G, NG = 53, kin.num_pose_links, 3, 5
     rng = np.random.default_rng(9)
+    world = c1_world()
+    for _ in range(n_extra):  # > 32 obstacle records: beyond the 32-bit link masks (never culled)
+        p = rng.uniform([-0.6, -0.6, 0.1], [0.7, 0.7, 0.9])
+        world[0].append({"dims": rng.uniform(0.04, 0.12, 3).tolist(), "pose": [*p.tolist(), 1, 0, 0, 0]})
+    scene = SceneData.from_arrays(cuboid_scene_arrays(world), device)
+    B, T, G, NG = 53, kin.num_pose_links, 3, 5
     q = torch.as_tensor(sample_q(model, B, seed=5, scale=1.05), device=device)
     gpos = torch.as_tensor(rng.normal(size=(NG, T, G, 3)).astype(np.float32) * 0.5, device=device)
     gq = rng.normal(size=(NG, T, G, 4)).astype(np.float32)
