@@ -76,7 +76,7 @@ struct FusedLayout {
       sph_pad, rs, lbound, sub, jlinks, left, key, flag, dyn, cstab, pairs, recs, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0,
-                                                    int n_waves = 0) {
+                                                    int n_waves = 0, int rings = 1) {
   FusedLayout f;
   int o = 0;
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
@@ -92,14 +92,14 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.link_info = take(L);
   f.sign = take(L);
   // tables that are dead after P1 (staging + FK) share their bytes with the per-wave lists of active
-  // scene spheres of P2 (kSceneListEntries uint16 per wave)
+  // scene spheres of P2 (`rings` x kSceneListEntries uint16 per wave)
   f.lists = o;
   f.off_add = take(L);
   f.fixed = take(L * 12);
   f.chain = take(C);
   f.sph_pad = take(S);
   f.rs = take(S * 4);
-  if (o - f.lists < n_waves * kSceneListEntries / 2) o = f.lists + n_waves * kSceneListEntries / 2;
+  if (o - f.lists < n_waves * rings * kSceneListEntries / 2) o = f.lists + n_waves * rings * kSceneListEntries / 2;
   f.sph_link = take(S);
   f.sph_rad = take(S);
   f.lbound = take(L * 8);
@@ -290,7 +290,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // sphere), so the fp32 sums are reproducible.  The speed metric is linear in (cost, gradient) and is
 // applied per pair.  Entry = sphere (9 bits) | row (2) | obstacle record (5): S <= 512, <= 32 records.
 constexpr int kScenePassMaxSpheres = 512, kScenePassMaxRecords = 32;
-template <int SWEEP, int KINDS>
+template <int SWEEP, int KINDS, bool DENSE>
 __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_hip_scene &sc, int h, bool valid, int lane,
                                                 int lane64, uint16_t *ring, int row_stride, int fill_to = 64) {
   const int row = lane64 >> 4;
@@ -320,7 +320,74 @@ __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_
   };
   int head = 0, pending = 0, s0 = 0;  // uniform: ring state, cursor over the sphere blocks ...
   uint32_t done = 0u;                 // ... and the records of block s0 already looked at
+  // DENSE: a second ring (behind the first) packs the spheres whose link mask is not empty, so that the
+  // obstacle tests below run on full wavefronts: a lane then walks the set bits of ITS sphere's mask
+  // (with one sphere per lane and one obstacle per step, 7 of 8 lanes idled through the tests).
+  uint16_t *ring_a = ring + kSceneListEntries;
+  int head_a = 0, pend_a = 0;
+  uint32_t bits = 0u;   // per lane: obstacle bits of my packed sphere still to test
+  unsigned mine = 0u;   // per lane: my packed sphere (s | row << 9)
   for (;;) {
+    if (DENSE) {
+      while (pending < fill_to) {
+        if (__ballot(bits != 0u) == 0ull) {  // the packed batch is used up: pack the next one
+          while (pend_a < 64 && s0 < c.S) {
+            const int s = s0 + lane;
+            const bool has = valid && s < c.S && __float_as_uint(wr[c.sph_link[s < c.S ? s : 0] * kWrench + 6]) != 0u;
+            const unsigned long long ball = __ballot(has);
+            if (has) {
+              const int at = head_a + pend_a + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
+              ring_a[at & (kSceneListEntries - 1)] = (uint16_t)(s | (row << 9));
+            }
+            pend_a += __builtin_popcountll(ball);
+            s0 += kFkLanes;
+          }
+          if (pend_a == 0) break;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int cnt = pend_a < 64 ? pend_a : 64;
+          bits = 0u;
+          if (lane64 < cnt) {
+            mine = ring_a[(head_a + lane64) & (kSceneListEntries - 1)];
+            const int sm = (int)(mine & 511u), hm = h + ((int)(mine >> 9) - row) * row_stride;
+            bits = __float_as_uint(c.wrench[(size_t)hm * c.wl + c.sph_link[sm] * kWrench + 6]);
+            if (n_rec < 32) bits &= (1u << n_rec) - 1u;
+          }
+          head_a += cnt;
+          pend_a -= cnt;
+        }
+        // geometry of my sphere once per visit (it is recomputed after an evaluation round in between)
+        Geo q;
+        float reach = 0.0f, thr2 = 0.0f;
+        const int sm = (int)(mine & 511u), rm = (int)(mine >> 9);
+        if (bits != 0u) {
+          q = geometry(h + (rm - row) * row_stride, sm);
+          reach = SWEEP > 0 ? fmaxf(q.half_prev, q.half_next) * 1.0001f + 2e-6f : 2e-6f;
+          thr2 = (q.r_adj + reach) * (q.r_adj + reach) * 1.00001f;
+        }
+        do {
+          bool pass = false;
+          int j = 0;
+          if (bits != 0u) {
+            j = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const ObsRec rec = c.recs[j];
+            if (rec.meta.x != 0.0f && q.enabled) {
+              const f3 lc = to_local(rec, q.center);
+              const bool vox = (KINDS & 2) && (!(KINDS & 1) || j >= sc.max_cuboids);
+              pass = vox ? !obstacle_early_reject<true>(sc, rec, lc, q.r_adj, reach, thr2)
+                         : !obstacle_early_reject<false>(sc, rec, lc, q.r_adj, reach, thr2);
+            }
+          }
+          const unsigned long long ball = __ballot(pass);
+          if (pass) {
+            const int at = head + pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
+            ring[at & (kSceneListEntries - 1)] = (uint16_t)(sm | (rm << 9) | (j << 11));
+          }
+          pending += __builtin_popcountll(ball);
+        } while (pending < fill_to && __ballot(bits != 0u) != 0ull);
+      }
+    } else {
     while (pending < fill_to && s0 < c.S) {  // fill
       const int s = s0 + lane;
       const bool in = valid && s < c.S;
@@ -357,6 +424,7 @@ __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_
         }
       }
       if (todo == 0u) { s0 += kFkLanes; done = 0u; }
+    }
     }
     if (pending == 0) break;
     const int count = pending < 64 ? pending : 64;
@@ -803,7 +871,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
   const bool use_pose = TERMS && a.use_pose != 0, use_cspace = TERMS && a.use_cspace != 0;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6);
+  constexpr int kRings = TERMS ? 1 : 2;  // the TERMS variant has no LDS to spare for the second ring (dense obstacle tests)
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6, kRings);
   const int tid = threadIdx.x;
   const int wave_idx = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockDim.x;
@@ -944,7 +1013,10 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     if (a.use_scene) {
       if (valid) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
       if (S <= kScenePassMaxSpheres && n_rec <= kScenePassMaxRecords && a.scene_rows != 1) {
-        wave_scene_pass<SWEEP, KINDS>(c, a.sc, h, valid, lane, lane64, c.lists + (tid >> 6) * kSceneListEntries, row_stride, a.scene_rows == 2 ? 1 : 64);
+        // dense packing of the obstacle tests: cuboid-only worlds (with an ESDF grid that covers the workspace every
+        // sphere is active anyway; the voxel x sweep instantiation also did not reproduce the row pass with it)
+        wave_scene_pass<SWEEP, KINDS, !TERMS && KINDS == 1>(c, a.sc, h, valid, lane, lane64, c.lists + (tid >> 6) * kRings * kSceneListEntries, row_stride,
+                                              a.scene_rows == 2 ? 1 : 64);
       } else if (valid) {  // beyond the ring's entry format: one sphere per lane, all its obstacles
         const float *wr = c.wrench + (size_t)h * c.wl;
         float cost_scene = 0.0f;
@@ -1252,14 +1324,15 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_
 // workgroup size and LDS layout of the trajectory kernels (the layout depends on the number of waves
 // through the per-wave scene lists): 8 waves when two workgroups then fit in a CU's LDS, see the
 // kernel's header; else one row per point up to 16 waves
-static FusedLayout trajectory_launch_shape(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn, int *threads_out) {
+static FusedLayout trajectory_launch_shape(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn, int *threads_out,
+                                           int rings = 1) {
   int threads = ((H * kFkLanes + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
-  if (threads > 512 && (size_t)fused_layout(H, D, L, S, C, P, n_rec, n_dyn, 8).total * sizeof(float) <= 80 * 1024) threads = 512;
+  if (threads > 512 && (size_t)fused_layout(H, D, L, S, C, P, n_rec, n_dyn, 8, rings).total * sizeof(float) <= 80 * 1024) threads = 512;
   static const int force_threads = [] { const char *e = getenv("CUROBO_HIP_FUSED_THREADS"); return e ? atoi(e) : 0; }();
   if (force_threads >= 64 && force_threads <= 1024) threads = force_threads & ~63;  // tuning knob
   *threads_out = threads;
-  return fused_layout(H, D, L, S, C, P, n_rec, n_dyn, threads >> 6);
+  return fused_layout(H, D, L, S, C, P, n_rec, n_dyn, threads >> 6, rings);
 }
 
 CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horizon, int dof, int num_links,
@@ -1267,7 +1340,7 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horiz
                                                                    int link_chain_len, int num_obstacles) {
   int threads;
   const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len,
-                                                  num_collision_pairs, num_obstacles, 0, &threads);
+                                                  num_collision_pairs, num_obstacles, 0, &threads, 2);
   return lay.total * (int)sizeof(float);
 }
 
@@ -1369,16 +1442,17 @@ static int rollout_trajectory_fused_impl(
     }
   }
   int threads;
+  static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;
+  const bool with_terms = a.use_pose || a.use_cspace || force_terms;  // the TERMS instantiation: one scene ring per wave
   const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads);
+                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
   hipStream_t st = (hipStream_t)stream;
 #define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
   do {                                                                                                         \
-    static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;                              \
-    auto kfn = (a.use_pose || a.use_cspace || force_terms) ? rollout_trajectory_fused_kernel<DG, SW, KD, true>                     \
+    auto kfn = with_terms ? rollout_trajectory_fused_kernel<DG, SW, KD, true>                                 \
                                             : rollout_trajectory_fused_kernel<DG, SW, KD, false>;                                                    \
     if (lds > 64 * 1024) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -253,3 +253,17 @@ def test_fused_many_obstacles_uses_the_row_pass(device):
     c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
     np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+
+
+def test_fused_every_sphere_in_collision(device):
+    """Three large slabs through the workspace: every sphere of every point is in (swept) collision
+    with several obstacles, so the packed scene pass runs with full rings (wrap-around, evaluation
+    rounds in the middle of a sphere's obstacle list); same numbers as the kernel sequence."""
+    big = [[{"dims": [3.0, 3.0, 0.4], "pose": [0, 0, 0.5, 1, 0, 0, 0]},
+            {"dims": [0.5, 3.0, 3.0], "pose": [0.3, 0, 0.5, 1, 0, 0, 0]},
+            {"dims": [3.0, 0.5, 3.0], "pose": [0, 0.2, 0.5, 0.9238795, 0, 0, 0.3826834]}]]
+    for kw in (dict(), dict(use_sweep=False, use_speed_metric=False)):
+        _, _, knots, _, ro_ref, ro_fused = _pair(device, seeds=12, world=big, **kw)
+        c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+        np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
