@@ -54,6 +54,13 @@ EXPECTED = {
     "optimization": ["launch_line_search", "launch_lbfgs_step"],
     "dynamics": ["launch_rnea_forward", "launch_rnea_backward"],
 }
+# HIP-side extensions (no reference backend module of that name): exported and callable
+EXTENSIONS = {
+    "cost": ["tool_pose_distance", "cspace_position_cost", "cspace_state_cost", "cspace_l2_distance", "rollout_point_aggregate"],
+    "linalg": ["levenberg_marquardt_step", "seed_ik_update_state"],
+    "rollout": ["rollout_trajectory_fused", "rollout_trajopt_fused", "rollout_ik_fused", "make_trajopt_terms", "DispatchOrder"],
+    "optimization": ["launch_lbfgs_iteration_tail", "prepare_search_points", "mppi_update_distribution"],
+}
 
 
 @pytest.mark.parametrize("module", sorted(EXPECTED))
@@ -63,6 +70,15 @@ def test_backend_modules_export_reference_names(module):
     mod = importlib.import_module(f"curobo_amd.backends.{module}")
     for fn in EXPECTED[module]:
         assert callable(getattr(mod, fn))
+
+
+@pytest.mark.parametrize("module", sorted(EXTENSIONS))
+def test_extension_backend_modules(module):
+    import importlib
+
+    mod = importlib.import_module(f"curobo_amd.backends.{module}")
+    for fn in EXTENSIONS[module]:
+        assert callable(getattr(mod, fn)), f"{module}.{fn}"
 
 
 def _ref_signature(module, fn):
