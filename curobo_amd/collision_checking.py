@@ -73,8 +73,68 @@ class RobotCollisionChecker:
                                                     self._max_d, env, env_query_idx is not None, True)
         return d_world, d_self
 
-    def validate(self, q: torch.Tensor) -> torch.Tensor:
-        """True where the configuration is free of scene AND self collision (reference :341)."""
+    def get_scene_self_collision_distance_from_joint_trajectory(
+            self, q: torch.Tensor, env_query_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """reference :266-284 (the same evaluation: every trajectory point is checked on its own)"""
+        return self.get_scene_self_collision_distance_from_joints(q, env_query_idx)
+
+    def get_bound(self, q: torch.Tensor) -> torch.Tensor:
+        """joint-limit violation cost [B,H,D] (reference :286-312, the c-space POSITION cost with unit
+        weight, no activation margin)"""
+        from .backends import cost as cost_hip
+
+        if q.ndim != 3:
+            raise ValueError(f"q must have shape [batch, horizon, dof], got {tuple(q.shape)}")
+        b, h, dof = q.shape
+        k = self.kinematics.kinematics_config
+        d = q.device
+        z1, zd = torch.zeros(1, device=d), torch.zeros(dof, device=d)
+        big = torch.stack([torch.full((dof,), -1e9, device=d), torch.full((dof,), 1e9, device=d)])
+        cost = torch.zeros(b, h, dof, device=d)
+        idx0 = torch.zeros(b, dtype=torch.int32, device=d)
+        cost_hip.cspace_position_cost(
+            cost, None, None, q.detach().contiguous(), None, zd, idx0, k.joint_limits_position.contiguous(), big,
+            torch.tensor([1.0, 0.0], device=d), torch.zeros(2, device=d), z1, torch.ones(dof, device=d),
+            torch.zeros(2, device=d), zd, zd, idx0, big, z1, False, b, h, dof)
+        return cost
+
+    def validate(self, q: torch.Tensor, env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B,H] True where the configuration is inside the joint limits and free of scene and self
+        collision (reference :341-372: the three violation sums are exactly zero)."""
+        if q.ndim == 2:
+            q = q.unsqueeze(1)
         with torch.no_grad():
-            d_world, d_self = self.get_scene_self_collision_distance_from_joints(q)
-        return (d_world.sum(-1) <= 0.0) & (d_self[..., 0] <= 0.0)
+            d_world, d_self = self.get_scene_self_collision_distance_from_joints(q, env_query_idx)
+            d_bound = self.get_bound(q)
+        return (d_world.sum(-1) + d_self[..., 0] + d_bound.sum(-1)) == 0.0
+
+    def validate_trajectory(self, q: torch.Tensor, env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.validate(q, env_query_idx)  # reference :404-417
+
+    # ------------------------------------------------------------------ sampling (reference :314-402)
+    rejection_ratio = 10
+
+    def _sampler(self):
+        if getattr(self, "_halton", None) is None:
+            from .solver.seed_ik import HaltonSeeds
+
+            lim = self.kinematics.kinematics_config.joint_limits_position
+            self._halton = HaltonSeeds(lim.shape[1], lim[0].contiguous(), lim[1].contiguous(), seed=1312)
+        return self._halton
+
+    def sample(self, n: int, mask_valid: bool = True, env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """n joint configurations [n, dof] (Halton points in the joint limits), collision-free when
+        ``mask_valid`` -- fewer than n come back when the rejection sampling runs short, as in the reference."""
+        q = self._sampler().get_samples(n * self.rejection_ratio if mask_valid else n, bounded=True)
+        if mask_valid:
+            q = q[self.validate(q.unsqueeze(1), env_query_idx).view(-1)][:n]
+        return q
+
+    def sample_trajectory(self, batch: int, horizon: int, mask_valid: bool = True,
+                          env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        sh = horizon * self.rejection_ratio if mask_valid else horizon
+        q = self._sampler().get_samples(batch * sh, bounded=True).reshape(batch, sh, -1)
+        if mask_valid:
+            ok = self.validate_trajectory(q, env_query_idx)
+            q = torch.cat([q[i][ok[i]][:horizon].unsqueeze(0) for i in range(batch)])
+        return q

@@ -193,3 +193,40 @@ def test_cspace_l2_distance_autograd(device):
     cost = L2DistFunction.apply(pos, target, tidx, w, term, nonterm, out_c, out_g, True)
     (cost * scale).sum().backward()
     torch.testing.assert_close(pos.grad, 6.0 * r * err * scale.unsqueeze(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_collision_checker_validate_sample_and_bounds(oracle, device):
+    """RobotCollisionChecker.validate / validate_trajectory / get_bound / sample / sample_trajectory
+    (reference collision_robot_scene.py:286-417) against the oracle's distances."""
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world
+
+    model = load_model("franka")
+    md = model.as_dict()
+    arrays = cuboid_scene_arrays(c2_world())
+    chk = RobotCollisionChecker(KinematicsCfg.from_packaged("franka", device=device), SceneData.from_arrays(arrays, device))
+    B, H = 6, 5
+    q = sample_q(model, B * H, seed=12, scale=1.08).reshape(B, H, 7)  # some rows beyond the limits
+    tq = torch.as_tensor(q, device=device)
+    ok = chk.validate(tq).cpu().numpy()
+    assert ok.shape == (B, H) and np.array_equal(ok, chk.validate_trajectory(tq).cpu().numpy())
+    fk = oracle.kinematics_forward(q.reshape(-1, 7), md)
+    sph = fk["robot_spheres"].reshape(B, H, -1, 4)
+    d_self = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"].reshape(B, H)
+    d_world = oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].reshape(B, H, -1).sum(-1)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    inside = ((q >= lo) & (q <= hi)).all(-1)
+    want = (d_self == 0) & (d_world == 0) & inside
+    assert np.array_equal(ok, want) and want.any() and (~want).any()
+    bound = chk.get_bound(tq).cpu().numpy()
+    viol = np.maximum(q - hi, 0) + np.maximum(lo - q, 0)
+    np.testing.assert_allclose(bound, 0.5 * viol * viol, rtol=1e-5, atol=1e-7)
+    # sampling: Halton points in the limits; with mask_valid every returned configuration validates
+    qs = chk.sample(32, mask_valid=True)
+    assert 0 < qs.shape[0] <= 32 and qs.shape[1] == 7 and bool(chk.validate(qs.unsqueeze(1)).all())
+    raw = chk.sample(64, mask_valid=False)
+    assert raw.shape == (64, 7) and bool(((raw >= torch.as_tensor(lo, device=device)) & (raw <= torch.as_tensor(hi, device=device))).all())
+    traj = chk.sample_trajectory(3, 4, mask_valid=True)
+    assert traj.shape == (3, 4, 7) and bool(chk.validate_trajectory(traj).all())
