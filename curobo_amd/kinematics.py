@@ -43,6 +43,31 @@ class KinematicsCfg:
         return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)
 
     @staticmethod
+    def from_data_dict(data_dict: dict, assets_root: str = "", tool_frames: Optional[list] = None, device="cuda:0",
+                       num_envs: int = 1) -> "KinematicsCfg":
+        """reference KinematicsCfg.from_data_dict (robot/kinematics/kinematics_cfg.py:186-211): the
+        ``kinematics`` section of a robot configuration as a dictionary (``urdf_path`` relative to
+        ``assets_root``, or absolute)."""
+        import copy
+        import os
+
+        from .robot.loader import build_robot_model
+        from .robot.urdf import load_urdf
+
+        cfg = copy.deepcopy(data_dict.get("robot_cfg", data_dict))
+        cfg = cfg.get("kinematics", cfg)
+        if tool_frames is not None:
+            cfg["tool_frames"] = list(tool_frames)
+        model = build_robot_model(cfg, load_urdf(os.path.join(assets_root, cfg["urdf_path"])), num_envs=num_envs)
+        return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)
+
+    @staticmethod
+    def from_basic_urdf(urdf_path: str, base_link: str, tool_frames: list, device="cuda:0") -> "KinematicsCfg":
+        """reference KinematicsCfg.from_basic_urdf (:68-88): kinematics only (no collision spheres)."""
+        return KinematicsCfg.from_data_dict({"urdf_path": urdf_path, "base_link": base_link, "tool_frames": list(tool_frames)},
+                                            device=device)
+
+    @staticmethod
     def from_packaged(name: str, device="cuda:0") -> "KinematicsCfg":
         model = load_packaged_robot(name)
         return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)

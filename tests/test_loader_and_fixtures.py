@@ -86,3 +86,36 @@ def test_rollout_oracle_composition_runs(oracle, franka):
     fd = (rollout_cost_and_gradient(oracle, franka.as_dict(), arrays, kp, start, **kw)["cost"][b].astype(np.float64)
           - rollout_cost_and_gradient(oracle, franka.as_dict(), arrays, km, start, **kw)["cost"][b]) / (2 * eps)
     assert fd == pytest.approx(g[k, d], rel=0.15), (fd, g[k, d])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONTENT), reason="reference checkout not present")
+def test_kinematics_cfg_constructors(oracle, franka):
+    """KinematicsCfg.from_data_dict / from_basic_urdf (reference kinematics_cfg.py:68-88,186-211):
+    the dictionary route reproduces the packaged tensors; the URDF-only route gives the same tool pose."""
+    import numpy as np
+    import yaml
+
+    from curobo_amd.kinematics import KinematicsCfg
+
+    with open(f"{REF_CONTENT}/configs/robot/franka.yml") as fh:
+        data = yaml.safe_load(fh)
+    cfg = KinematicsCfg.from_data_dict(data, assets_root=f"{REF_CONTENT}/assets", device="cpu")
+    for k in ("fixed_transforms", "link_map", "joint_map", "link_sphere_idx_map", "collision_pairs"):
+        np.testing.assert_array_equal(np.asarray(getattr(cfg.model, k)), np.asarray(getattr(franka, k)), err_msg=k)
+    kin = data["robot_cfg"]["kinematics"]
+    urdf = os.path.join(f"{REF_CONTENT}/assets", kin["urdf_path"])
+    basic = KinematicsCfg.from_basic_urdf(urdf, kin["base_link"], kin["tool_frames"], device="cpu")
+    assert basic.model.num_spheres == 0
+    # the URDF-only model keeps the finger joints free (no lock_joints): compare the arm chain at the locked values
+    q7 = np.array([[0.1, -0.6, 0.3, -2.0, 0.2, 1.5, 0.7]], np.float32)
+    pose_full = oracle.kinematics_forward(q7, franka.as_dict(), compute_spheres=False)
+    names = list(basic.model.joint_names)
+    qb = np.zeros((1, basic.model.num_dof), np.float32)
+    for i, n in enumerate(franka.joint_names):
+        qb[0, names.index(n)] = q7[0, i]
+    for n, v in (kin.get("lock_joints") or {}).items():
+        if n in names:
+            qb[0, names.index(n)] = v
+    pose_basic = oracle.kinematics_forward(qb, basic.model.as_dict(), compute_spheres=False)
+    np.testing.assert_allclose(pose_basic["link_pos"], pose_full["link_pos"], atol=1e-6)
+    np.testing.assert_allclose(np.abs(pose_basic["link_quat"]), np.abs(pose_full["link_quat"]), atol=1e-6)
