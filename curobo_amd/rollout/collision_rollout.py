@@ -200,6 +200,57 @@ class CollisionRollout:
         self.compute_kinematics(self.compute_state_from_action(act_seq))
         return self.compute_costs()
 
+    # ------------------------------------------------------------------ reference Rollout protocol
+    # (curobo/_src/rollout/rollout_protocol.py:46-174): the members solvers and optimisers rely on
+    @property
+    def action_bound_lows(self) -> torch.Tensor:
+        return self.kin.joint_limits_position[0]
+
+    @property
+    def action_bound_highs(self) -> torch.Tensor:
+        return self.kin.joint_limits_position[1]
+
+    @property
+    def dt(self) -> float:
+        return self.cfg.traj_dt
+
+    @property
+    def sum_horizon(self) -> bool:
+        return True  # costs are returned summed over the horizon, one value per trajectory
+
+    def compute_metrics_from_action(self, act_seq: torch.Tensor) -> dict:
+        """reference :107-121: evaluate through the kernel sequence (materialised state) and report
+        per-trajectory metrics: cost, worst self / scene collision terms, feasibility."""
+        with torch.no_grad():
+            cost = self.evaluate_action(act_seq.view(self.batch_size, self.cfg.n_knots, self.action_dim)).clone()
+        B = self.batch_size
+        self_c = self.self_dist.view(B, -1).sum(-1) if self.cfg.use_self_collision else torch.zeros_like(cost)
+        scene_on = self.cfg.use_scene_collision and self.scene is not None
+        scene_c = self.scene_dist.view(B, -1).sum(-1) if scene_on else torch.zeros_like(cost)
+        return {"cost": cost, "self_collision_cost": self_c.clone(), "scene_collision_cost": scene_c.clone(),
+                "feasible": (self_c + scene_c) == 0.0, "position": self.position}
+
+    def update_params(self, start_position: Optional[torch.Tensor] = None, scene: Optional[SceneData] = None,
+                      env_query_idx: Optional[torch.Tensor] = None) -> bool:
+        """reference :123-129 (goal / start / world updates between solves, buffers stay in place)"""
+        if start_position is not None:
+            self.update_start_state(start_position)
+        if scene is not None:
+            self.scene = scene
+            self._fused_ok = None
+        if env_query_idx is not None:
+            self.update_env_query_idx(env_query_idx)
+        return True
+
+    def reset(self, **kwargs) -> bool:
+        return True
+
+    def reset_shape(self) -> bool:
+        return True
+
+    def reset_seed(self) -> None:
+        return None
+
     # ------------------------------------------------------------------ backward
     def backward(self) -> torch.Tensor:
         """d(sum cost)/d(knots) of the last ``evaluate_action`` (grad_output = 1 per trajectory,

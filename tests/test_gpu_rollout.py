@@ -265,3 +265,40 @@ def test_pipelined_lbfgs_matches_single_batch(device):
         assert torch.equal(pipe.best_cost, ref_cost), shards
         assert torch.equal(got, ref), shards
     assert float(ref_cost.min()) < 1e9
+
+
+def test_rollout_protocol_members(device):
+    """reference Rollout protocol (rollout_protocol.py): bounds, dt, metrics from an action,
+    parameter updates that keep captured buffers valid"""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    B = 16
+    ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg())
+    assert ro.action_dim == 7 and ro.action_horizon == 12 and ro.sum_horizon and ro.dt == ro.cfg.traj_dt
+    assert torch.equal(ro.action_bound_lows, kin.joint_limits_position[0])
+    start = torch.as_tensor(start_configuration(model), device=device)
+    assert ro.update_params(start_position=start)
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=2), device=device)
+    m = ro.compute_metrics_from_action(x)
+    assert float(m["scene_collision_cost"].max()) > 0.0
+    cost = ro.cost_and_gradient(x.reshape(B, -1))[0].clone()
+    # kernel sequence (metrics) vs fused launch: equal up to summation order, except on trajectories with
+    # stationary points where the swept cost is discontinuous (DESIGN.md section 2)
+    close = (m["cost"] - cost).abs() <= 2e-5 * cost.abs() + 1e-3
+    assert float(close.float().mean()) >= 0.75, (m["cost"], cost)
+    torch.testing.assert_close(m["self_collision_cost"] + m["scene_collision_cost"], m["cost"], rtol=1e-5, atol=1e-3)
+    assert m["feasible"].dtype == torch.bool and bool((m["feasible"] == (m["cost"] == 0)).all()) and m["position"].shape == (B, 33, 7)
+    # a moved world changes the costs without new buffers
+    arrays = cuboid_scene_arrays([[{"dims": [0.2, 0.2, 0.2], "pose": [3.0, 3.0, 3.0, 1, 0, 0, 0]}] * 4])
+    ptr = ro.cost.data_ptr()
+    ro.update_params(scene=SceneData.from_arrays(arrays, device))
+    c2, _ = ro.cost_and_gradient(x.reshape(B, -1))
+    assert ro.cost.data_ptr() == ptr
+    torch.testing.assert_close(c2, m["self_collision_cost"], rtol=2e-5, atol=1e-3)  # only self collision is left
+    assert float(ro.compute_metrics_from_action(x)["scene_collision_cost"].abs().max()) == 0.0
