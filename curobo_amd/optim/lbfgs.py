@@ -201,6 +201,20 @@ class LBFGSOpt:
             t.copy_(s)
         torch.cuda.synchronize(self.device)
 
+    def make_graph(self, n_iters: int) -> "torch.cuda.CUDAGraph":
+        """a hipGraph of ``n_iters`` iterations (optimiser state is restored after the capture)"""
+        saved = [t.clone() for t in self._state_tensors()]
+        self._opt_step()  # warm-up outside the capture
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n_iters):
+                self._opt_step()
+        for t, s in zip(self._state_tensors(), saved):
+            t.copy_(s)
+        torch.cuda.synchronize(self.device)
+        return g
+
     def _state_tensors(self):
         return [self.y, self.s, self.rho, self.x_0, self.grad_0, self.step_direction, self.action,
                 self.gradient, self.cost, self.exploration_action, self.exploration_gradient,

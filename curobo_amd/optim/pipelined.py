@@ -79,6 +79,20 @@ class PipelinedLBFGS:
                 t.copy_(s)
         torch.cuda.synchronize(self.device)
 
+    def make_graph(self, n_iters: int) -> "torch.cuda.CUDAGraph":
+        """a hipGraph of ``n_iters`` iterations of every shard (state is restored after the capture)"""
+        saved = [[t.clone() for t in o._state_tensors()] for o in self.opts]
+        self.step()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._forked(lambda o: [o._opt_step() for _ in range(n_iters)])
+        for o, sv in zip(self.opts, saved):
+            for t, s in zip(o._state_tensors(), sv):
+                t.copy_(s)
+        torch.cuda.synchronize(self.device)
+        return g
+
     def run_inner(self) -> None:
         if self.use_cuda_graph:
             if self._graph is None:
