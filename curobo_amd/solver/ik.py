@@ -89,8 +89,10 @@ class IKSolver:
         self.seed_solver = None
         if self.cfg.use_lm_seed:
             n_lm = max(self.cfg.seed_solver_num_seeds, 2 * self.S)
+            # seed shards (ranks) draw different Halton points: the shard index enters the sampler seed
+            shard = seed_offset // max(self.S, 1)
             self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=n_lm, use_cuda_graph=use_cuda_graph,
-                                                                         sampler_seed=451 + self.cfg.seed))
+                                                                         sampler_seed=451 + self.cfg.seed + 7919 * shard))
         self._gen = torch.Generator(device="cpu")
 
     def sample_seeds(self) -> torch.Tensor:
