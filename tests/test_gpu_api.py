@@ -230,3 +230,51 @@ def test_collision_checker_validate_sample_and_bounds(oracle, device):
     assert raw.shape == (64, 7) and bool(((raw >= torch.as_tensor(lo, device=device)) & (raw <= torch.as_tensor(hi, device=device))).all())
     traj = chk.sample_trajectory(3, 4, mask_valid=True)
     assert traj.shape == (3, 4, 7) and bool(chk.validate_trajectory(traj).all())
+
+
+def test_cost_modules_match_oracle_and_backpropagate(oracle, device):
+    """SelfCollisionCost / SceneCollisionCost (reference cost/cost_self_collision.py, cost_scene_collision.py):
+    forward values vs the oracle, sum / max / binary variants, gradients through the kinematics."""
+    from curobo_amd.cost import SceneCollisionCost, SceneCollisionCostCfg, SelfCollisionCost, SelfCollisionCostCfg
+    from curobo_amd.kinematics import Kinematics, KinematicsCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world
+
+    model = load_model("franka")
+    md = model.as_dict()
+    cfg = KinematicsCfg.from_packaged("franka", device=device)
+    kin = Kinematics(cfg, compute_spheres=True)
+    arrays = cuboid_scene_arrays(c2_world())
+    scene = SceneData.from_arrays(arrays, device)
+    B, H = 5, 4
+    q = sample_q(model, B * H, seed=21).reshape(B, H, 7)
+    tq = torch.as_tensor(q, device=device).requires_grad_(True)
+    sph = kin.compute_kinematics(tq).robot_spheres
+    S = sph.shape[2]
+    self_cost = SelfCollisionCost(SelfCollisionCostCfg(cfg.kinematics_config.self_collision, weight=3.0), device)
+    with pytest.raises(ValueError):
+        self_cost.forward(sph)  # buffers not set up
+    self_cost.setup_batch_tensors(B, H)
+    scene_cost = SceneCollisionCost(SceneCollisionCostCfg(scene, S, weight=2.0, activation_distance=0.02), device)
+    scene_cost.setup_batch_tensors(B, H)
+    cs, cw = self_cost(sph), scene_cost(sph)
+    assert cs.shape == (B, H) and cw.shape == (B, H)
+    fk = oracle.kinematics_forward(q.reshape(-1, 7), md)
+    ref_s = oracle.self_collision(fk["robot_spheres"].reshape(B, H, S, 4), model.sphere_padding, model.collision_pairs, 3.0)
+    ref_w = oracle.scene_collision(fk["robot_spheres"].reshape(B, H, S, 4), arrays, 2.0, 0.02)
+    np.testing.assert_allclose(cs.detach().cpu().numpy(), ref_s["distance"].reshape(B, H), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cw.detach().cpu().numpy(), ref_w["distance"].reshape(B, H, S).sum(-1), rtol=1e-5, atol=1e-5)
+    (cs.sum() + cw.sum()).backward()
+    gs = ref_s["gradient"].reshape(B * H, S, 4) + ref_w["gradient"].reshape(B * H, S, 4) * np.array([1, 1, 1, 0], np.float32)
+    ref_g = oracle.kinematics_backward(md, fk["cumul_mat"], gs)
+    np.testing.assert_allclose(tq.grad.cpu().numpy().reshape(-1, 7), ref_g, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref_g).max()))
+    assert (ref_s["distance"] > 0).any() and (ref_w["distance"] > 0).any()
+    # variants: worst sphere instead of the sum, binary flags
+    mx = SceneCollisionCost(SceneCollisionCostCfg(scene, S, weight=2.0, activation_distance=0.02, sum_distance=False), device)
+    mx.setup_batch_tensors(B, H)
+    np.testing.assert_allclose(mx(sph.detach()).cpu().numpy(), ref_w["distance"].reshape(B, H, S).max(-1), rtol=1e-5, atol=1e-5)
+    bn = SelfCollisionCost(SelfCollisionCostCfg(cfg.kinematics_config.self_collision, weight=3.0, convert_to_binary=True), device)
+    bn.setup_batch_tensors(B, H)
+    b = bn(sph.detach()).cpu().numpy()
+    want = np.minimum(ref_s["distance"].reshape(B, H), 1.0)
+    np.testing.assert_allclose(b, np.where(want > 0, want + 1.0, want), rtol=1e-5, atol=1e-5)
