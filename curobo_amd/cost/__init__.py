@@ -3,3 +3,4 @@
 ``setup_batch_tensors``, weights as device tensors so they can change under a captured graph)."""
 
 from .collision import SceneCollisionCost, SceneCollisionCostCfg, SelfCollisionCost, SelfCollisionCostCfg  # noqa: F401
+from .tool_pose import ToolPoseCost, ToolPoseCostCfg  # noqa: F401

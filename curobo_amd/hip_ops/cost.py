@@ -31,3 +31,41 @@ class L2DistFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             p_g = p_grad * grad_out_cost.unsqueeze(-1) if ctx.use_grad_input else p_grad
         return p_g, None, None, None, None, None, None, None, None
+
+
+class ToolPoseDistance(torch.autograd.Function):
+    """reference ``ToolPoseDistance`` (``curobo/_src/cost/wp_tool_pose.py:696-914``): same argument
+    order without the Warp kernel handle (``num_goalset`` / ``rotation_method`` are plain arguments
+    here); gradients flow to ``current_position`` / ``current_quat`` only, from the buffers the
+    forward launch wrote; ``out_distance`` interleaves (position cost, rotation cost) per link."""
+
+    @staticmethod
+    def forward(ctx, current_position, current_quat, goal_position, goal_quat, idxs_goal, position_orientation_weight,
+                terminal_pose_axes_weight_factor, non_terminal_pose_axes_weight_factor,
+                terminal_pose_convergence_tolerance, non_terminal_pose_convergence_tolerance, project_distance_to_goal,
+                out_distance, out_position_distance, out_rotation_distance, out_position_gradient, out_rotation_gradient,
+                out_goalset_idx, use_grad_input: bool, num_goalset: int = 1, rotation_method: int = 0):
+        b, h, num_links, _ = current_position.shape
+        cp, cq = current_position.detach().contiguous(), current_quat.detach().contiguous()
+        check_float32_tensors(cp.device, current_position=cp, current_quat=cq, goal_position=goal_position, goal_quat=goal_quat)
+        cost_hip.tool_pose_distance(
+            out_distance, out_position_distance, out_rotation_distance, out_position_gradient, out_rotation_gradient,
+            out_goalset_idx, cp, cq, goal_position, goal_quat, idxs_goal, position_orientation_weight,
+            terminal_pose_axes_weight_factor, non_terminal_pose_axes_weight_factor, terminal_pose_convergence_tolerance,
+            non_terminal_pose_convergence_tolerance, project_distance_to_goal, b, h, num_links, num_goalset, rotation_method)
+        ctx.use_grad_input = use_grad_input
+        ctx.mark_non_differentiable(out_position_distance, out_rotation_distance, out_goalset_idx)
+        ctx.save_for_backward(out_position_gradient, out_rotation_gradient)
+        return out_distance, out_position_distance, out_rotation_distance, out_goalset_idx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_distance, grad_position_distance, grad_rotation_distance, grad_goalset_idx):
+        pos_grad = quat_grad = None
+        if grad_distance is not None:
+            gp, gr = ctx.saved_tensors
+            if ctx.needs_input_grad[0]:
+                pos_grad = gp * grad_distance[:, :, 0::2].unsqueeze(-1) if ctx.use_grad_input else gp
+            if ctx.needs_input_grad[1]:
+                quat_grad = gr * grad_distance[:, :, 1::2].unsqueeze(-1) if ctx.use_grad_input else gr
+        return (pos_grad, quat_grad) + (None,) * 18

@@ -278,3 +278,39 @@ def test_cost_modules_match_oracle_and_backpropagate(oracle, device):
     b = bn(sph.detach()).cpu().numpy()
     want = np.minimum(ref_s["distance"].reshape(B, H), 1.0)
     np.testing.assert_allclose(b, np.where(want > 0, want + 1.0, want), rtol=1e-5, atol=1e-5)
+
+
+def test_tool_pose_cost_module_autograd(oracle, device):
+    """ToolPoseCost / ToolPoseDistance (reference cost_tool_pose.py, wp_tool_pose.py:696-914): values vs the
+    oracle, gradient to the joint angles through the kinematics vs the oracle's FK VJP of the pose gradients."""
+    from curobo_amd.cost import ToolPoseCost, ToolPoseCostCfg
+    from curobo_amd.kinematics import Kinematics, KinematicsCfg
+
+    model = load_model("franka")
+    md = model.as_dict()
+    kin = Kinematics(KinematicsCfg.from_packaged("franka", device=device), compute_spheres=False)
+    B, H, T, G = 6, 3, 1, 2
+    q = sample_q(model, B * H, seed=31).reshape(B, H, 7)
+    goals = oracle.kinematics_forward(sample_q(model, 4 * G, seed=32), md, compute_spheres=False)
+    gp = goals["link_pos"].reshape(4, T, G, 3)
+    gq = goals["link_quat"].reshape(4, T, G, 4)
+    idx = np.array([0, 3, 1, 2, 2, 0], np.int32)
+    cost = ToolPoseCost(ToolPoseCostCfg(num_links=T, weight=[20.0, 5.0], non_terminal_pose_axes_weight_factor=[0.5] * 6), device)
+    cost.setup_batch_tensors(B, H)
+    tq = torch.as_tensor(q, device=device).requires_grad_(True)
+    st = kin.compute_kinematics(tq)
+    pos, quat = st.tool_poses.position.view(B, H, T, 3), st.tool_poses.quaternion.view(B, H, T, 4)
+    c, lin, ang, gidx = cost(pos, quat, torch.as_tensor(gp, device=device), torch.as_tensor(gq, device=device),
+                             torch.as_tensor(idx, device=device))
+    fk = oracle.kinematics_forward(q.reshape(-1, 7), md, compute_spheres=False)
+    ref = oracle.tool_pose_distance(fk["link_pos"].reshape(B, H, T, 3), fk["link_quat"].reshape(B, H, T, 4), gp, gq, idx,
+                                    np.array([20.0, 5.0], np.float32), np.ones(6 * T, np.float32), np.full(6 * T, 0.5, np.float32),
+                                    np.zeros(2 * T, np.float32), np.zeros(2 * T, np.float32), np.zeros(T, np.uint8), 0)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), ref["distance"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lin.cpu().numpy(), ref["position_distance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ang.cpu().numpy(), ref["rotation_distance"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(gidx.cpu().numpy(), ref["goalset_idx"]) and set(np.unique(ref["goalset_idx"])) == {0, 1}
+    c.sum().backward()
+    ref_g = oracle.kinematics_backward(md, fk["cumul_mat"], None, ref["position_gradient"].reshape(B * H, T, 3),
+                                       ref["rotation_gradient"].reshape(B * H, T, 4))
+    np.testing.assert_allclose(tq.grad.cpu().numpy().reshape(-1, 7), ref_g, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref_g).max()))
