@@ -10,4 +10,4 @@ from .geometry import SelfCollisionDistance  # noqa: F401
 from .kinematics import KinematicsFusedFunction  # noqa: F401
 from .optimization import LBFGScu, wolfe_line_search  # noqa: F401
 from .trajectory import BSplineIdxKernel  # noqa: F401
-from .cost import L2DistFunction, ToolPoseDistance  # noqa: F401
+from .cost import L2DistFunction, StateCSpaceFunction, ToolPoseDistance  # noqa: F401

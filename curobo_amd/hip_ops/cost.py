@@ -69,3 +69,37 @@ class ToolPoseDistance(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 quat_grad = gr * grad_distance[:, :, 1::2].unsqueeze(-1) if ctx.use_grad_input else gr
         return (pos_grad, quat_grad) + (None,) * 18
+
+
+class StateCSpaceFunction(torch.autograd.Function):
+    """reference ``StateCSpaceFunction`` (``curobo/_src/cost/wp_cspace_state.py:288-680``), same argument
+    order: joint-limit / velocity / acceleration / jerk / effort bounds, squared-L2 regularisation and
+    the optional configuration target in one launch; returns ``out_cost[B,H,D]``; gradients to
+    position, velocity, acceleration, jerk and effort from the buffers written by the forward launch."""
+
+    @staticmethod
+    def forward(ctx, pos, vel, acc, jerk, effort, state_dt, target_joint_position, idxs_target_joint_position, p_b, v_b,
+                a_b, j_b, effort_b, weight, activation_distance, squared_l2_regularization_weight, cspace_target_weight,
+                cspace_non_terminal_weight_factor, cspace_target_dof_weight, out_cost, out_gp, out_gv, out_ga, out_gj,
+                out_gtau, retime_weights: bool, retime_regularization_weights: bool, use_grad_input: bool):
+        b, h, dof = pos.shape
+        det = lambda t: None if t is None else t.detach().contiguous()  # noqa: E731
+        cost_hip.cspace_state_cost(
+            out_cost, out_gp, out_gv, out_ga, out_gj, out_gtau, det(pos), det(vel), det(acc), det(jerk), det(effort), state_dt,
+            target_joint_position, idxs_target_joint_position, p_b, v_b, a_b, j_b, effort_b, weight, activation_distance,
+            squared_l2_regularization_weight, cspace_target_weight, cspace_non_terminal_weight_factor,
+            cspace_target_dof_weight, True, b, h, dof, retime_weights, retime_regularization_weights)
+        ctx.use_grad_input = use_grad_input
+        ctx.has_effort = effort is not None
+        ctx.save_for_backward(out_gp, out_gv, out_ga, out_gj, out_gtau)
+        return out_cost
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out_cost):
+        grads = [None] * 5
+        if grad_out_cost is not None:
+            for i, g in enumerate(ctx.saved_tensors):
+                if ctx.needs_input_grad[i] and (i < 4 or ctx.has_effort):
+                    grads[i] = g * grad_out_cost if ctx.use_grad_input else g
+        return tuple(grads) + (None,) * 23

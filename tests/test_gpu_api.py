@@ -314,3 +314,39 @@ def test_tool_pose_cost_module_autograd(oracle, device):
     ref_g = oracle.kinematics_backward(md, fk["cumul_mat"], None, ref["position_gradient"].reshape(B * H, T, 3),
                                        ref["rotation_gradient"].reshape(B * H, T, 4))
     np.testing.assert_allclose(tq.grad.cpu().numpy().reshape(-1, 7), ref_g, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref_g).max()))
+
+
+def test_state_cspace_function_autograd(oracle, device):
+    """StateCSpaceFunction (reference wp_cspace_state.py:288-680): cost vs the oracle and gradients to all
+    five state streams, scaled by the incoming gradient (use_grad_input)."""
+    from curobo_amd.hip_ops import StateCSpaceFunction
+
+    rng = np.random.default_rng(5)
+    B, H, D = 4, 6, 7
+    model = load_model("franka")
+    lim_p = np.asarray(model.joint_limits_position, np.float32)
+    f = lambda s: rng.normal(size=(B, H, D)).astype(np.float32) * s  # noqa: E731
+    pos, vel, acc, jerk, tau = f(2.0), f(2.0), f(8.0), f(200.0), f(30.0)
+    lim = {"position": lim_p, "velocity": np.stack([-np.ones(D), np.ones(D)]).astype(np.float32) * 2.0,
+           "acceleration": np.stack([-np.ones(D), np.ones(D)]).astype(np.float32) * 10.0,
+           "jerk": np.stack([-np.ones(D), np.ones(D)]).astype(np.float32) * 300.0,
+           "effort": np.stack([-np.ones(D), np.ones(D)]).astype(np.float32) * 40.0}
+    weight = np.array([100.0, 10.0, 5.0, 1.0, 3.0], np.float32)
+    eta = np.array([0.05, 0.0, 0.0, 0.0, 0.1], np.float32)
+    sql2 = np.array([0.1, 0.05, 0.01, 0.02, 0.0], np.float32)
+    dt = np.full(B, 0.05, np.float32)
+    ref = oracle.cspace_state_cost(pos, vel, acc, jerk, dt, lim, weight, eta, sql2, effort=tau)
+    t = lambda a, dt_=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dt_)  # noqa: E731
+    z = lambda: torch.zeros(B, H, D, device=device)  # noqa: E731
+    ins = [t(x).requires_grad_(True) for x in (pos, vel, acc, jerk, tau)]
+    cost = StateCSpaceFunction.apply(
+        *ins, t(dt), torch.zeros(1, D, device=device), torch.zeros(B, dtype=torch.int32, device=device), t(lim["position"]),
+        t(lim["velocity"]), t(lim["acceleration"]), t(lim["jerk"]), t(lim["effort"]), t(weight), t(eta), t(sql2),
+        torch.zeros(1, device=device), torch.ones(1, device=device), torch.ones(D, device=device), z(), z(), z(), z(), z(), z(),
+        False, False, True)
+    np.testing.assert_allclose(cost.detach().cpu().numpy(), ref["cost"], rtol=1e-5, atol=1e-5)
+    scale = torch.rand(B, H, D, device=device) + 0.5
+    (cost * scale).sum().backward()
+    for x, k in zip(ins, ("grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")):
+        np.testing.assert_allclose(x.grad.cpu().numpy(), ref[k] * scale.cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref[k]).max()), err_msg=k)
+        assert np.abs(ref[k]).max() > 0
