@@ -6,22 +6,28 @@
 // this library) run 7 kernels that hand ~6.8 KB per trajectory point through HBM (joint angles,
 // 13 cumulative transforms, 65 spheres, two 65x4 gradient buffers, ...).  None of those tensors
 // is consumed by the optimiser: L-BFGS only needs cost[B] and d cost / d knots.  Here a
-// workgroup owns one trajectory; every intermediate lives in LDS (2.1 KB per point for a Franka,
-// two workgroups per CU), HBM traffic drops to ~0.7 KB per ROLLOUT (knots in, cost + gradient
-// out), and the six launch boundaries disappear.  Optional pointers materialise joint positions
+// workgroup owns one trajectory; every intermediate lives in LDS (2.3 KB per point for a Franka,
+// two workgroups per CU), HBM traffic drops to ~1.8 KB per ROLLOUT (measured: knots in, cost +
+// gradient out, tables from L2), and the six launch boundaries disappear.  Optional pointers materialise joint positions
 // and world spheres for callers that want them (metrics / visualisation).
 //
 // Arithmetic is shared with the stand-alone kernels through the *_device.hpp headers, so the
 // fused and unfused paths agree to fp32 summation order (tests/test_gpu_fused.py).
 //
 // Mapping: a trajectory point is owned by a 16-lane DPP row exactly as in kinematics.hip
-// (4 points per wave64); group g handles points g, g + n_groups, ... .  Phases (3 barriers):
+// (4 points per wave64).  Phases (workgroup barriers between them):
 //   P0  all lanes: stage robot tables, pair list, obstacle records; B-spline samples -> q in LDS
 //   P1  per point: local transforms (one sincos per lane) -> barrier-free chain -> spheres
-//   P2  per point: self collision (row16 DPP arg-max), scene collision per sphere (neighbour
-//       spheres read from LDS for the sweep / speed metric), immediate chain VJP of every
-//       non-zero sphere gradient into per-lane LDS rows, row reduction -> grad_q, point cost
-//   P3  B-spline VJP to the knots, fixed-order sum of the point costs
+//   P2  self collision per row (DPP arg-max over the padded pair list); per-link obstacle masks; the
+//       scene pass of a wave packs its rows' (sphere, obstacle) pairs into LDS rings and evaluates
+//       them 64 at a time (wave_scene_pass); sphere gradients go into per-link wrenches in a fixed
+//       order; then, per point, every moving link gathers the wrenches of its subtree -> grad_q.
+//       Rows of a wave take points strided along the trajectory; a 33rd ("leftover") point is shared
+//       by the whole workgroup.  Optional passes (TERMS): tool pose, c-space STATE.
+//   P3  B-spline VJP to the knots (four streams with TERMS), fixed-order sum of the point costs
+// Workgroups take their trajectory through an optional longest-first permutation that the previous
+// launches built from measured workgroup durations (rebuild_dispatch_order).  DESIGN.md section 4.1
+// has the measurements behind each of these choices.
 #include <cstdio>
 #include <cstdlib>
 
