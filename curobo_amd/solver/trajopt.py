@@ -33,6 +33,11 @@ class TrajOptSolverCfg:
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=27, inner_iters=25, num_iters=100))
     ik: IKSolverCfg = field(default_factory=lambda: IKSolverCfg(num_seeds=32))
     seed: int = 0
+    # retiming / re-interpolation of the winner (reference TrajOptSolverCfg: interpolation_dt,
+    # minimum_trajectory_dt, maximum_trajectory_dt; solver_trajopt.py:579-680)
+    interpolation_dt: float = 0.02
+    minimum_trajectory_dt: float = 0.01
+    maximum_trajectory_dt: float = 0.15
 
 
 @dataclass
@@ -118,3 +123,54 @@ class TrajOptSolver:
         return TrajOptResult(success=win[:, V + 2] > 0.5, knots=win[:, :V].view(P, rc.n_knots, D), position=traj,
                              position_error=win[:, V], rotation_error=win[:, V + 1], cost=win[:, V + 3], seed_index=idx,
                              goal_config=ikr.solution, ik_success=ikr.success)
+
+    # ------------------------------------------------------------------ retiming
+    def compute_trajectory_dt(self, velocity: torch.Tensor, acceleration: torch.Tensor, jerk: torch.Tensor,
+                              dt: Optional[torch.Tensor] = None, epsilon: float = 1e-3) -> torch.Tensor:
+        """reference TrajOptSolver.compute_trajectory_dt (:636-677): the dt at which the trajectory just
+        respects the velocity / acceleration / jerk limits, clamped to [minimum, maximum]_trajectory_dt;
+        inputs [B, H, D] sampled at ``dt`` [B] (or scalar ``cfg.rollout.traj_dt``)."""
+        from ..util.trajectory import calculate_dt_no_clamp
+
+        rc, D = self.cfg.rollout, self.kin.num_dof
+        ones = torch.ones(D, device=self.device)
+        vmax = self.kin.joint_limits_velocity[1].abs()
+        score = calculate_dt_no_clamp(velocity, acceleration, jerk, vmax, rc.max_acceleration * ones, rc.max_jerk * ones, epsilon)
+        base = dt if dt is not None else torch.full_like(score, rc.traj_dt)
+        return torch.clamp(score * base, min=self.cfg.minimum_trajectory_dt, max=self.cfg.maximum_trajectory_dt)
+
+    def get_interpolated_trajectory(self, knots: torch.Tensor, start_position: torch.Tensor,
+                                    goal_config: Optional[torch.Tensor] = None, retime: bool = True):
+        """Winner knots [P, n_knots, D] -> (position, velocity, acceleration, jerk) [P, steps, D] at
+        ``cfg.interpolation_dt`` and the last valid step per trajectory (reference
+        get_interpolated_trajectory, :579-634, BSPLINE_KNOTS_CUDA branch), after rescaling the
+        trajectory's dt to the fastest one that respects the joint limits when ``retime``."""
+        from ..backends import trajectory as trajectory_hip
+        from ..util.trajectory import interpolate_bspline_knots
+
+        rc, D = self.cfg.rollout, self.kin.num_dof
+        P = knots.shape[0]
+        dev = self.device
+        z = torch.zeros(1, D, device=dev)
+        start = (start_position.to(dev, torch.float32).view(1, D), z, z, z)
+        goal = None
+        implicit = None
+        if goal_config is not None:  # end at rest in the goal configuration (the optimiser's implicit goal state)
+            zP = torch.zeros(P, D, device=dev)
+            goal = (goal_config.to(dev, torch.float32).view(P, D), zP, zP, zP)
+            implicit = torch.ones(P, dtype=torch.uint8, device=dev)
+        traj_dt = torch.full((P,), rc.traj_dt, device=dev)
+        if retime:
+            H = rc.padded_horizon
+            st = [torch.zeros(P, H, D, device=dev) for _ in range(4)]
+            g = start if goal is None else goal
+            sidx = torch.zeros(P, dtype=torch.int32, device=dev)
+            gidx = sidx if goal is None else torch.arange(P, dtype=torch.int32, device=dev)
+            imp = implicit if implicit is not None else torch.zeros(1, dtype=torch.uint8, device=dev)
+            trajectory_hip.launch_bspline_interpolation_forward_kernel(
+                *st, torch.zeros(P, device=dev), knots.contiguous(), *start, *g, sidx, gidx, traj_dt, imp, P, H, D, rc.n_knots,
+                rc.bspline_degree)
+            traj_dt = self.compute_trajectory_dt(st[1], st[2], st[3], traj_dt)
+        knot_dt = traj_dt * rc.interpolation_steps
+        out, last = interpolate_bspline_knots(knots, knot_dt, self.cfg.interpolation_dt, start, goal, implicit, rc.bspline_degree)
+        return out, last, traj_dt

@@ -161,3 +161,51 @@ def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
     assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
     vel = np.diff(traj, axis=1) / 0.15
     assert np.abs(vel).max() <= np.abs(model.joint_limits_velocity).max() * 1.05
+
+
+def test_trajopt_retime_and_interpolate(device):
+    """TrajOptSolver.get_interpolated_trajectory (reference solver_trajopt.py:579-677): the winner's knots
+    re-sampled at interpolation_dt; without retiming the samples on the optimiser's grid are the
+    optimiser's own trajectory; with retiming the fastest dt that respects the joint limits is used."""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import c1_world, reachable_goals, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
+    P = 4
+    cfg = TrajOptSolverCfg(interpolation_dt=0.05)  # a third of the optimiser's traj_dt (0.15)
+    solver = TrajOptSolver(kin, scene, P, cfg)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    gp, gq = reachable_goals(kin, P, seed=4)
+    res = solver.solve_pose(start, gp, gq)
+    assert res.success.float().mean() >= 0.5
+    rc = cfg.rollout
+    (pos, vel, acc, jerk), last, dt = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=False)
+    torch.cuda.synchronize()
+    assert torch.allclose(dt, torch.full_like(dt, rc.traj_dt))
+    # both samplings hit the knot boundaries of the same spline: every `per`-th re-interpolated sample
+    # (per = samples per knot interval, reference calculate_traj_steps with nearest_int) is every
+    # interpolation_steps-th point of the optimiser's own trajectory
+    total = rc.n_knots + rc.bspline_degree + 1
+    per = (int(last[0]) - 1) // total
+    assert per >= 6 and (int(last[0]) - 1) % total == 0 and bool((last == last[0]).all())
+    torch.testing.assert_close(pos[:, 0:total * per + 1:per], res.position[:, 0:total * rc.interpolation_steps + 1:rc.interpolation_steps],
+                               rtol=0, atol=2e-5)
+    torch.testing.assert_close(pos[:, 0], start.view(1, -1).expand(P, -1), rtol=0, atol=1e-6)
+    # retimed: dt within the configured range, limits respected at the new dt, same path end point
+    (pos2, vel2, acc2, jerk2), last2, dt2 = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=True)
+    torch.cuda.synchronize()
+    assert bool(((dt2 >= cfg.minimum_trajectory_dt - 1e-7) & (dt2 <= cfg.maximum_trajectory_dt + 1e-7)).all())
+    vmax = kin.joint_limits_velocity[1].abs()
+    free = dt2 < cfg.maximum_trajectory_dt - 1e-6  # not clamped: the limit is met with the 0.1 % margin
+    for p in range(P):
+        sl = slice(0, int(last2[p]))
+        if bool(free[p]) and float(dt2[p]) > cfg.minimum_trajectory_dt + 1e-6:
+            assert float((vel2[p, sl].abs() / vmax).max()) <= 1.0 + 5e-3
+            assert float(acc2[p, sl].abs().max()) <= rc.max_acceleration * (1.0 + 5e-3)
+            assert float(jerk2[p, sl].abs().max()) <= rc.max_jerk * (1.0 + 5e-3)
+        end = pos2[p, int(last2[p]) - 1]
+        assert float((end - res.goal_config[p]).abs().max()) < 5e-3

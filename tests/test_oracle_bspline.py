@@ -123,3 +123,26 @@ def test_single_dt_reinterpolation_matches_forward_per_trajectory(degree, oracle
                 np.testing.assert_array_equal(out[k][i, nh + 1:], np.broadcast_to(out[k][i, nh + 1], out[k][i, nh + 1:].shape))
         if nh + 1 < max_out and (nh % (nk + sup)) == 0:
             np.testing.assert_allclose(out["position"][i, nh + 1], out["position"][i, nh], atol=1e-5)
+
+
+def test_retiming_helpers_match_reference_golden():
+    """calculate_dt_no_clamp / calculate_traj_steps (curobo_amd/util/trajectory.py) against the outputs of the
+    reference's own functions (tests/golden/make_retime_golden.py)"""
+    import os
+
+    import torch
+
+    from curobo_amd.util.trajectory import calculate_dt_no_clamp, calculate_traj_steps
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "retime_golden.npz"))
+    t = lambda k: torch.as_tensor(g[k])  # noqa: E731
+    score = calculate_dt_no_clamp(t("vel"), t("acc"), t("jerk"), t("max_vel"), t("max_acc"), t("max_jerk"), epsilon=1e-3)
+    np.testing.assert_allclose(score.numpy(), g["score"], rtol=1e-6)
+    for ni in (0, 1):
+        steps, smax = calculate_traj_steps(t("dt"), t("idt"), 17, nearest_int=bool(ni))
+        assert np.array_equal(steps.numpy(), g[f"steps_{ni}"]) and int(smax) == int(g[f"steps_max_{ni}"])
+    # scaling property: a trajectory slowed down by the score meets its tightest limit exactly
+    s = score.view(-1, 1, 1) / (1.0 + 1e-3)
+    worst = torch.maximum(torch.maximum((t("vel") / s).abs().amax(1) / t("max_vel"), (t("acc") / s ** 2).abs().amax(1) / t("max_acc")),
+                          (t("jerk") / s ** 3).abs().amax(1) / t("max_jerk")).amax(-1)
+    np.testing.assert_allclose(worst.numpy(), 1.0, rtol=1e-5)
