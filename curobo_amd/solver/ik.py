@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from ..distributed import global_argmin
+from ..distributed import global_argmin, global_topk
 from ..optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
 from ..robot.kinematics_params import KinematicsParams
 from ..rollout.ik_rollout import IKRollout, IKRolloutCfg
@@ -106,8 +106,10 @@ class IKSolver:
         return out.to(self.device)
 
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
-                   seeds: Optional[torch.Tensor] = None) -> IKResult:
-        """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame."""
+                   seeds: Optional[torch.Tensor] = None, return_seeds: int = 1) -> IKResult:
+        """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame.  ``return_seeds`` k > 1
+        returns the k best seeds per problem, best first (reference IKSolver.solve_pose
+        ``return_seeds``, solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result."""
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         gp = goal_position.to(self.device, torch.float32).view(P, 1, 1, 3).expand(P, T, 1, 3).contiguous()
         gq = goal_quat.to(self.device, torch.float32).view(P, 1, 1, 4).expand(P, T, 1, 4).contiguous()
@@ -132,6 +134,10 @@ class IKSolver:
         ranked = cost.view(P, S) + 1e16 * (~ok).float()  # reference solver_ik.py:503-509
         payload = torch.cat([q.view(P, S, D), pos_err.unsqueeze(-1), rot_err.unsqueeze(-1), ok.float().unsqueeze(-1),
                              cost.view(P, S, 1)], dim=-1)
+        if return_seeds > 1:
+            _, idx, win = global_topk(ranked, payload, self.seed_offset, return_seeds)
+            return IKResult(success=win[..., D + 2] > 0.5, solution=win[..., :D], position_error=win[..., D],
+                            rotation_error=win[..., D + 1], cost=win[..., D + 3], seed_index=idx)
         _, idx, win = global_argmin(ranked, payload, self.seed_offset)
         return IKResult(success=win[:, D + 2] > 0.5, solution=win[:, :D], position_error=win[:, D],
                         rotation_error=win[:, D + 1], cost=win[:, D + 3], seed_index=idx)

@@ -27,7 +27,13 @@ class TrajOptSolverCfg:
     num_seeds: int = 4
     position_threshold: float = 0.005
     rotation_threshold: float = 0.05
-    seed_bump: float = 0.15  # relative mid-trajectory perturbation of seeds 1..S-1
+    seed_bump: float = 0.15  # relative mid-trajectory perturbation of the seeds that repeat a goal configuration
+    #: distinct IK solutions the seeds aim at (reference: every trajopt seed gets its own IK solution,
+    #: solver_trajopt.py:390-420 / trajectory_seed_generator.py:122-170).  Seed s ends in solution
+    #: s % num_ik_goals (the best one when that solution failed); 0 = num_seeds (the reference's
+    #: behaviour), 1 = all seeds share the best solution.  Measured (tools/trajopt_goal_diversity.py,
+    #: 32 goals, 4 / 8 seeds): success 0.78 -> 0.875 (C1 world), 0.69 -> 0.78 (C2 world), same time.
+    num_ik_goals: int = 0
     #: traj_dt 0.15 s: the reference optimises at its ``maximum_trajectory_dt`` and retimes afterwards
     rollout: TrajOptRolloutCfg = field(default_factory=lambda: TrajOptRolloutCfg(traj_dt=0.15))
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=27, inner_iters=25, num_iters=100))
@@ -65,8 +71,9 @@ class TrajOptSolver:
         self.ik = IKSolver(kin, scene, num_problems, self.cfg.ik, use_cuda_graph=use_cuda_graph)
         self.rollout = TrajOptRollout(kin, scene, self.P * self.S * self.nls, rc)
         self.metrics_rollout = TrajOptRollout(kin, scene, self.P * self.S, rc)
+        self.K = max(1, min(self.cfg.num_ik_goals or self.S, self.S, self.cfg.ik.num_seeds))
         for r in (self.rollout, self.metrics_rollout):  # allocate the goal-state buffers before any graph capture
-            r.update_goal_state(torch.zeros(self.P, kin.num_dof, device=self.device), None)
+            r.update_goal_state(torch.zeros(self.P * self.K, kin.num_dof, device=self.device), None)
         bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
         self.optimizer = LBFGSOpt(ocfg, self.rollout.cost_and_gradient, rc.n_knots, kin.num_dof, bounds, self.device,
                                   use_cuda_graph=use_cuda_graph)
@@ -74,16 +81,32 @@ class TrajOptSolver:
         self._row_goal = (rows // (self.S * self.nls)).to(torch.int32)
         self._mrow_goal = (torch.arange(self.P * self.S, device=self.device) // self.S).to(torch.int32)
 
-    def seed_knots(self, start: torch.Tensor, goal_config: torch.Tensor) -> torch.Tensor:
-        """[P, S, n_knots, D]: straight joint-space lines start -> goal configuration (reference
-        seed generation, solver_trajopt.py:390-420); seeds 1.. add a smooth mid-trajectory bump."""
-        rc, D = self.cfg.rollout, self.kin.num_dof
+    def seed_goal_choice(self, ik_success: torch.Tensor) -> torch.Tensor:
+        """[P, S] index (0..K-1) of the IK solution seed s of problem p ends in: s % K when that
+        solution passed the IK checks, else the best one (solutions are ranked best first)."""
+        s_goal = (torch.arange(self.S, device=self.device) % self.K).view(1, self.S).expand(self.P, self.S)
+        ok = torch.gather(ik_success.view(self.P, self.K), 1, s_goal)
+        return torch.where(ok, s_goal, torch.zeros_like(s_goal))
+
+    def seed_knots(self, start: torch.Tensor, goal_config: torch.Tensor, choice: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[P, S, n_knots, D]: straight joint-space lines start -> the seed's goal configuration
+        (reference seed generation, solver_trajopt.py:390-420; linspace weights as
+        trajectory_seed_generator.py:150-170).  ``goal_config`` [P, K, D] (or [P, D]), ``choice``
+        [P, S] from ``seed_goal_choice``; a seed that repeats an earlier seed's goal adds a smooth
+        mid-trajectory bump so that the seeds stay distinct."""
+        rc, D, P, S = self.cfg.rollout, self.kin.num_dof, self.P, self.S
+        goal_config = goal_config.reshape(P, -1, D)
+        if choice is None:
+            choice = torch.zeros(P, S, dtype=torch.int64, device=self.device)
+        goal = torch.gather(goal_config, 1, choice.unsqueeze(-1).expand(P, S, D))  # [P, S, D]
         t = torch.linspace(0.0, 1.0, rc.n_knots + 2, device=self.device)[1:-1].view(1, 1, -1, 1)
-        line = start.view(1, 1, 1, D) * (1 - t) + goal_config.view(self.P, 1, 1, D) * t
+        line = start.view(1, 1, 1, D) * (1 - t) + goal.view(P, S, 1, D) * t
         gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
         half = 0.5 * (self.kin.joint_limits_position[1] - self.kin.joint_limits_position[0])
-        bump = torch.randn(self.P, self.S, 1, D, generator=gen).to(self.device) * self.cfg.seed_bump * half
-        bump[:, 0] = 0.0
+        bump = torch.randn(P, S, 1, D, generator=gen).to(self.device) * self.cfg.seed_bump * half
+        sidx = torch.arange(S, device=self.device).view(1, S)
+        first_use = (choice == sidx) & (sidx < goal_config.shape[1])  # seed s is the first one aimed at goal s
+        bump = bump * (~first_use).view(P, S, 1, 1)
         knots = line + bump * torch.sin(torch.pi * t)
         lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
         return torch.minimum(torch.maximum(knots, lo + 1e-3), hi - 1e-3).contiguous()
@@ -93,14 +116,20 @@ class TrajOptSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         rc = self.cfg.rollout
         start = start_position.to(self.device, torch.float32).view(1, D)
-        ikr = self.ik.solve_pose(goal_position, goal_quat)
+        K = self.K
+        ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K)
+        ik_ok = ikr.success.view(P, K)
+        ik_q = ikr.solution.reshape(P, K, D).contiguous()
+        choice = self.seed_goal_choice(ik_ok)  # [P, S]
+        goal_row = torch.arange(P, device=self.device).view(P, 1) * K + choice  # row of ik_q.view(P*K, D) per (p, s)
         gp = goal_position.to(self.device, torch.float32).view(P, 1, 1, 3).expand(P, T, 1, 3).contiguous()
         gq = goal_quat.to(self.device, torch.float32).view(P, 1, 1, 4).expand(P, T, 1, 4).contiguous()
-        for r, rows in ((self.rollout, self._row_goal), (self.metrics_rollout, self._mrow_goal)):
+        grows = (goal_row.view(P, S, 1).expand(P, S, self.nls).reshape(-1), goal_row.reshape(-1))
+        for r, rows, gr in ((self.rollout, self._row_goal, grows[0]), (self.metrics_rollout, self._mrow_goal, grows[1])):
             r.update_start_state(start)
             r.update_goals(gp, gq, rows)
-            r.update_goal_state(ikr.solution, rows)  # end at rest in the IK solution (implicit goal state)
-        seeds = self.seed_knots(start, ikr.solution)
+            r.update_goal_state(ik_q.view(P * K, D), gr)  # end at rest in the seed's IK solution (implicit goal state)
+        seeds = self.seed_knots(start, ik_q, choice)
         best = self.optimizer.optimize(seeds.view(P * S, rc.n_knots, D))
         knots = best.reshape(P * S, rc.n_knots * D).contiguous()
         m = self.metrics_rollout
@@ -119,10 +148,13 @@ class TrajOptSolver:
                              cost.view(P, S, 1)], dim=-1)
         _, idx, win = global_argmin(ranked, payload, 0)
         V = rc.n_knots * D
-        traj = q[torch.arange(P, device=self.device), idx.clamp(0, S - 1)]
+        ar = torch.arange(P, device=self.device)
+        widx = idx.clamp(0, S - 1)
+        traj = q[ar, widx]
+        win_goal = ik_q[ar, choice[ar, widx]]  # the IK solution the winning seed ends in
         return TrajOptResult(success=win[:, V + 2] > 0.5, knots=win[:, :V].view(P, rc.n_knots, D), position=traj,
                              position_error=win[:, V], rotation_error=win[:, V + 1], cost=win[:, V + 3], seed_index=idx,
-                             goal_config=ikr.solution, ik_success=ikr.success)
+                             goal_config=win_goal, ik_success=ik_ok[:, 0])
 
     # ------------------------------------------------------------------ retiming
     def compute_trajectory_dt(self, velocity: torch.Tensor, acceleration: torch.Tensor, jerk: torch.Tensor,

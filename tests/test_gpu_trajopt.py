@@ -122,7 +122,8 @@ def test_trajopt_fused_equals_kernel_sequence(implicit_goal, device):
     torch.testing.assert_close(g1, g0, rtol=5e-2 if bool(still) else 2e-3, atol=(5e-2 if bool(still) else 5e-5) * float(g0.abs().max()))
 
 
-def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
+@pytest.mark.parametrize("num_ik_goals", [1, 4])
+def test_trajopt_solver_reaches_goal_collision_free(num_ik_goals, oracle, device):
     from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
     from curobo_amd.workloads import start_configuration
 
@@ -137,7 +138,7 @@ def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
     sel = np.nonzero(free)[0][:P]
     gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
     start = start_configuration(model)
-    solver = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=4))
+    solver = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=4, num_ik_goals=num_ik_goals))
     res = solver.solve_pose(torch.as_tensor(start), torch.as_tensor(gp), torch.as_tensor(gq))
     torch.cuda.synchronize()
     succ = res.success.cpu().numpy()
@@ -151,6 +152,8 @@ def test_trajopt_solver_reaches_goal_collision_free(oracle, device):
     traj = res.position.cpu().numpy()[succ]  # [n, H, D]
     n, H, D = traj.shape
     np.testing.assert_allclose(traj[:, 0], np.broadcast_to(start, (n, D)), atol=1e-4)  # starts at the start state
+    # ... and ends in the IK solution its winning seed aimed at (one of num_ik_goals per problem)
+    np.testing.assert_allclose(traj[:, -1], res.goal_config.cpu().numpy()[succ], atol=1e-4)
     chk = oracle.kinematics_forward(traj.reshape(n * H, D), md, horizon=H)
     np.testing.assert_allclose(chk["link_pos"].reshape(n, H, 3)[:, -1], gp[succ], atol=5e-3)
     assert np.abs(traj[:, -1] - traj[:, -2]).max() < 1e-3, "the trajectory must end at rest"

@@ -119,3 +119,46 @@ def test_kinematics_cfg_constructors(oracle, franka):
     pose_basic = oracle.kinematics_forward(qb, basic.model.as_dict(), compute_spheres=False)
     np.testing.assert_allclose(pose_basic["link_pos"], pose_full["link_pos"], atol=1e-6)
     np.testing.assert_allclose(np.abs(pose_basic["link_quat"]), np.abs(pose_full["link_quat"]), atol=1e-6)
+
+
+def test_trajopt_seed_generation_host_logic():
+    """TrajOptSolver.seed_goal_choice / seed_knots (pure torch; reference trajectory_seed_generator.py:
+    122-170 linear interpolation start -> per-seed IK goal): checked without building any rollout."""
+    import types
+
+    import torch
+
+    from curobo_amd.solver.trajopt import TrajOptSolver, TrajOptSolverCfg
+
+    P, S, K, D, nk = 3, 6, 4, 5, 8
+    slv = TrajOptSolver.__new__(TrajOptSolver)
+    slv.P, slv.S, slv.K, slv.device = P, S, K, torch.device("cpu")
+    slv.cfg = TrajOptSolverCfg(num_seeds=S, num_ik_goals=K)
+    slv.cfg.rollout.n_knots = nk
+    lim = torch.stack([-3.0 * torch.ones(D), 3.0 * torch.ones(D)])
+    slv.kin = types.SimpleNamespace(num_dof=D, joint_limits_position=lim)
+    ok = torch.tensor([[1, 1, 1, 1], [1, 0, 1, 0], [0, 0, 0, 0]], dtype=torch.bool)
+    choice = slv.seed_goal_choice(ok)
+    assert choice.tolist() == [[0, 1, 2, 3, 0, 1], [0, 0, 2, 0, 0, 0], [0, 0, 0, 0, 0, 0]]
+    g = torch.Generator().manual_seed(0)
+    goals = torch.rand(P, K, D, generator=g) * 2 - 1
+    start = torch.rand(1, D, generator=g) - 0.5
+    knots = slv.seed_knots(start, goals, choice)
+    assert knots.shape == (P, S, nk, D)
+    t = torch.linspace(0, 1, nk + 2)[1:-1].view(1, 1, nk, 1)
+    sel = torch.gather(goals, 1, choice.unsqueeze(-1).expand(P, S, D))
+    line = start.view(1, 1, 1, D) * (1 - t) + sel.view(P, S, 1, D) * t
+    first = torch.tensor([[1, 1, 1, 1, 0, 0], [1, 0, 1, 0, 0, 0], [1, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    dev = (knots - line).abs().amax((-1, -2))
+    assert (dev[first] < 1e-6).all(), "the first seed aimed at a goal is the straight line"
+    assert (dev[~first] > 1e-3).all(), "seeds that repeat a goal are perturbed"
+    # every seed of a problem is distinct
+    flat = knots.view(P, S, -1)
+    for p in range(P):
+        assert torch.cdist(flat[p], flat[p]).fill_diagonal_(1.0).min() > 1e-3
+    # one shared goal (K = 1): seed 0 straight, the others bumped -- the original behaviour
+    slv.K = 1
+    c1 = slv.seed_goal_choice(ok[:, :1])
+    assert int(c1.abs().sum()) == 0
+    k1 = slv.seed_knots(start, goals[:, 0], c1)
+    torch.testing.assert_close(k1[:, 0], (start.view(1, 1, D) * (1 - t[0]) + goals[:, 0].view(P, 1, D) * t[0]))
