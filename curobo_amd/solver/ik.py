@@ -41,6 +41,8 @@ class IKSolverCfg:
     seed_solver_num_seeds: int = 32
     #: problem shards of the optimiser on separate HIP streams (1 = one batch, one stream)
     stream_shards: int = 1
+    #: alternative goal poses per problem (reference IKSolverCfg.max_goalset): a solution may reach any one
+    num_goalset: int = 1
 
 
 @dataclass
@@ -51,6 +53,7 @@ class IKResult:
     rotation_error: torch.Tensor  # [P]
     cost: torch.Tensor  # [P]
     seed_index: torch.Tensor  # [P] global seed index of the winner
+    goalset_index: Optional[torch.Tensor] = None  # [P] member of the goal set the solution reaches
 
 
 class IKSolver:
@@ -63,7 +66,8 @@ class IKSolver:
         ocfg = self.cfg.optimizer
         ocfg.num_problems = self.P * self.S
         self.nls = len(ocfg.line_search_scale)
-        self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, self.cfg.rollout)
+        self.G = self.cfg.num_goalset
+        self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, self.cfg.rollout, num_goalset=self.G)
         bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
         K = self.cfg.stream_shards
         if K > 1 and self.P % K != 0:
@@ -72,7 +76,7 @@ class IKSolver:
         self.rollouts = []
 
         def make_rollout(batch, k=0):
-            ro = IKRollout(kin, scene, batch, self.cfg.rollout)
+            ro = IKRollout(kin, scene, batch, self.cfg.rollout, num_goalset=self.G)
             ro._first_problem = k * (self.P // K)  # rows of shard k belong to problems [first, first + P/K)
             self.rollouts.append(ro)
             return ro.cost_and_gradient
@@ -92,7 +96,8 @@ class IKSolver:
             # seed shards (ranks) draw different Halton points: the shard index enters the sampler seed
             shard = seed_offset // max(self.S, 1)
             self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=n_lm, use_cuda_graph=use_cuda_graph,
-                                                                         sampler_seed=451 + self.cfg.seed + 7919 * shard))
+                                                                         sampler_seed=451 + self.cfg.seed + 7919 * shard),
+                                            num_goalset=self.G)
         self._gen = torch.Generator(device="cpu")
 
     def sample_seeds(self) -> torch.Tensor:
@@ -107,18 +112,23 @@ class IKSolver:
 
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
                    seeds: Optional[torch.Tensor] = None, return_seeds: int = 1) -> IKResult:
-        """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame.  ``return_seeds`` k > 1
+        """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame -- or [P, G, 3] / [P, G, 4]
+        with ``cfg.num_goalset`` = G alternatives per problem (reference solve_pose with a goal set,
+        solver_ik.py:660-700; the result names the member reached).  ``return_seeds`` k > 1
         returns the k best seeds per problem, best first (reference IKSolver.solve_pose
         ``return_seeds``, solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result."""
-        P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
-        gp = goal_position.to(self.device, torch.float32).view(P, 1, 1, 3).expand(P, T, 1, 3).contiguous()
-        gq = goal_quat.to(self.device, torch.float32).view(P, 1, 1, 4).expand(P, T, 1, 4).contiguous()
+        P, S, D, T, G = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links, self.G
+        if goal_position.numel() != P * G * 3 or goal_quat.numel() != P * G * 4:
+            raise ValueError(f"solve_pose: expected {P} problems x {G} goal-set members, got position "
+                             f"{tuple(goal_position.shape)}, quaternion {tuple(goal_quat.shape)}")
+        gp = goal_position.to(self.device, torch.float32).view(P, 1, G, 3).expand(P, T, G, 3).contiguous()
+        gq = goal_quat.to(self.device, torch.float32).view(P, 1, G, 4).expand(P, T, G, 4).contiguous()
         for ro, rows in zip(self.rollouts, self._row_goals):
             ro.update_goals(gp, gq, rows)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
         if seeds is None:
             if self.seed_solver is not None:
-                seeds = self.seed_solver.solve_batch(gp[:, :, 0], gq[:, :, 0], return_seeds=S).solution
+                seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=S).solution
             else:
                 seeds = self.sample_seeds()
         best = self.optimizer.optimize(seeds.reshape(P * S, 1, D))
@@ -132,12 +142,15 @@ class IKSolver:
             feasible &= m.scene_dist.view(P, S, -1).sum(-1) <= 0.0
         ok = feasible & (pos_err < self.cfg.position_threshold) & (rot_err < self.cfg.rotation_threshold)
         ranked = cost.view(P, S) + 1e16 * (~ok).float()  # reference solver_ik.py:503-509
+        gidx = m.goalset_idx.view(P, S, T)[..., 0].float()
         payload = torch.cat([q.view(P, S, D), pos_err.unsqueeze(-1), rot_err.unsqueeze(-1), ok.float().unsqueeze(-1),
-                             cost.view(P, S, 1)], dim=-1)
+                             cost.view(P, S, 1), gidx.unsqueeze(-1)], dim=-1)
         if return_seeds > 1:
             _, idx, win = global_topk(ranked, payload, self.seed_offset, return_seeds)
             return IKResult(success=win[..., D + 2] > 0.5, solution=win[..., :D], position_error=win[..., D],
-                            rotation_error=win[..., D + 1], cost=win[..., D + 3], seed_index=idx)
+                            rotation_error=win[..., D + 1], cost=win[..., D + 3], seed_index=idx,
+                            goalset_index=win[..., D + 4].long())
         _, idx, win = global_argmin(ranked, payload, self.seed_offset)
         return IKResult(success=win[:, D + 2] > 0.5, solution=win[:, :D], position_error=win[:, D],
-                        rotation_error=win[:, D + 1], cost=win[:, D + 3], seed_index=idx)
+                        rotation_error=win[:, D + 1], cost=win[:, D + 3], seed_index=idx,
+                        goalset_index=win[:, D + 4].long())

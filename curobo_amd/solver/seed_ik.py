@@ -103,8 +103,12 @@ class SeedIKSolver:
     configurations per problem out of ``num_seeds`` LM runs."""
 
     def __init__(self, kin: KinematicsParams, num_problems: int, cfg: Optional[SeedIKSolverCfg] = None,
-                 default_joint_position: Optional[torch.Tensor] = None):
+                 default_joint_position: Optional[torch.Tensor] = None, num_goalset: int = 1):
+        """``num_goalset`` G > 1: every problem has G alternative goal poses per tool frame and each seed
+        is pulled to the member its pose error is smallest for (reference SeedIKSolver goal-set
+        buffer, seed_ik_solver.py:340-365; the arg-min is the pose kernel's)."""
         self.kin, self.cfg = kin, cfg or SeedIKSolverCfg()
+        self.G = num_goalset
         c, dev = self.cfg, kin.fixed_transforms.device
         self.device = dev
         self.P, self.S = num_problems, c.num_seeds
@@ -135,7 +139,7 @@ class SeedIKSolver:
         self.pose_jTerror = z(n, D)
         self.env_query_idx = z(n, dt=torch.int32)
         self.idxs_goal = (torch.arange(n, device=dev) // self.S).to(torch.int32)
-        self.goal_position, self.goal_quat = z(self.P, T, 1, 3), z(self.P, T, 1, 4)
+        self.goal_position, self.goal_quat = z(self.P, T, self.G, 3), z(self.P, T, self.G, 4)
         self.goal_quat[..., 0] = 1.0
         self._pose_w = torch.tensor([c.position_weight, c.orientation_weight], device=dev)
         self._axes_w = torch.ones(T * 6, device=dev)
@@ -157,7 +161,7 @@ class SeedIKSolver:
         cost_hip.tool_pose_distance(
             self.pose_cost, self.pos_dist, self.rot_dist, self.grad_pos, self.grad_quat, self.goalset_idx, self.link_pos,
             self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal, self._pose_w, self._axes_w, self._axes_w,
-            self._tol, self._tol, self._project, n, 1, T, 1, 0)
+            self._tol, self._tol, self._project, n, 1, T, self.G, 0)
         kinematics_hip.launch_kinematics_backward(
             self.pose_jTerror, self.grad_pos, self.grad_quat, self.robot_spheres, self.com, self.com, self.grad_pos,
             self.cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map, k.joint_map_type,
@@ -220,8 +224,8 @@ class SeedIKSolver:
     def solve_batch(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, seed_config: Optional[torch.Tensor] = None,
                     return_seeds: int = 1, current_position: Optional[torch.Tensor] = None) -> SeedIKResult:
         P, S, D, T, c = self.P, self.S, self.D, self.T, self.cfg
-        self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, 1, 3))
-        self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, 1, 4))
+        self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, self.G, 3))
+        self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, self.G, 4))
         if seed_config is None and current_position is not None:
             seed_config = current_position.view(P, 1, D)
         seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()

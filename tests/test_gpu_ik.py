@@ -209,6 +209,51 @@ def test_ik_solver_end_to_end(oracle, device):
     assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
 
 
+def test_ik_solver_goalset(oracle, device):
+    """Goal sets (reference solve_pose with num_goalset > 1): member 0 of every problem is out of
+    reach, so a solution has to pick one of the two reachable members and say which."""
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+
+    model, kin, arrays, scene = _ik_setup(device)
+    md = model.as_dict()
+    P, G = 8, 3
+    cand = sample_q(model, 600, seed=21, scale=0.8)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(600, 1, -1, 4)
+    free = (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0) & \
+        (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0)
+    sel = np.nonzero(free)[0][:P * (G - 1)]
+    assert len(sel) == P * (G - 1)
+    gp = np.zeros((P, G, 3), np.float32)
+    gq = np.zeros((P, G, 4), np.float32)
+    gp[:, 0] = [3.0, 0.0, 0.5]  # 3 m away: unreachable
+    gq[:, 0] = [1, 0, 0, 0]
+    gp[:, 1:] = fk["link_pos"][sel, 0].reshape(P, G - 1, 3)
+    gq[:, 1:] = fk["link_quat"][sel, 0].reshape(P, G - 1, 4)
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32, num_goalset=G))
+    res = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq))
+    torch.cuda.synchronize()
+    succ = res.success.cpu().numpy()
+    assert succ.mean() >= 0.85, f"goal-set IK success rate {succ.mean():.2f}"
+    member = res.goalset_index.cpu().numpy()
+    assert set(np.unique(member[succ])) <= {1, 2}
+    qs = res.solution.cpu().numpy()[succ]
+    chk = oracle.kinematics_forward(qs, md)
+    reached_p = gp[np.arange(P), member][succ]
+    reached_q = gq[np.arange(P), member][succ]
+    np.testing.assert_allclose(chk["link_pos"][:, 0], reached_p, atol=5e-3)
+    dotq = np.abs((chk["link_quat"][:, 0] * reached_q).sum(-1))
+    assert (2 * np.arccos(np.clip(dotq, 0, 1)) < 0.05).all()
+    # the top-k interface returns distinct ranked seeds per problem, best first
+    top = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq), return_seeds=4)
+    assert top.solution.shape == (P, 4, kin.num_dof) and top.goalset_index.shape == (P, 4)
+    c = top.cost.cpu().numpy() + 1e16 * (~top.success.cpu().numpy())
+    assert (np.diff(c, axis=1) >= 0).all()
+    assert top.success[:, 0].float().mean().item() >= 0.85  # (the seed sampler advances between solves: not the same seeds)
+    with pytest.raises(ValueError, match="goal-set members"):
+        solver.solve_pose(torch.as_tensor(gp[:, 0]), torch.as_tensor(gq[:, 0]))
+
+
 @pytest.mark.parametrize("retime", [False, True])
 def test_cspace_state_kernel(retime, oracle, device):
     from curobo_amd.backends import cost as Cs
