@@ -413,13 +413,13 @@ def ik_benchmark(args, model, kin, device, torch):
     100 L-BFGS iterations of 4 line-search candidates each, hipGraph replay)."""
     from curobo_amd.scene import SceneData, cuboid_scene_arrays
     from curobo_amd.solver import IKSolver, IKSolverCfg
-    from curobo_amd.workloads import c1_world, reachable_goals
+    from curobo_amd.workloads import c1_world, feasible_goals
 
     scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), device)
     P, S = args.ik_problems, args.ik_seeds
     shards = 4 if P % 4 == 0 else 1  # problem shards on HIP streams (optim/pipelined.py)
     solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=shards))
-    gp, gq = reachable_goals(kin, P, seed=7)
+    gp, gq = feasible_goals(kin, scene, P)
     res = solver.solve_pose(gp, gq)  # warm-up + graph capture
     torch.cuda.synchronize()
     reps = 5
@@ -438,7 +438,7 @@ def ik_benchmark(args, model, kin, device, torch):
         "lm_seed_solver": bool(solver.cfg.use_lm_seed), "stream_shards": shards,
         "workload": "C1: Franka 7-DoF, 64 seeds per problem (best 64 of 128 Levenberg-Marquardt seed-IK runs, as the "
                     "reference's use_lm_seed), 4-cuboid world, pose + joint-limit + self + scene collision costs, "
-                    "goals = FK of random configurations (some of them in collision: unreachable collision-free)",
+                    "goals = FK of rejection-sampled collision-free configurations (the reference's ik_benchmark.py protocol)",
     }
 
 

@@ -76,3 +76,19 @@ def reachable_goals(kin, num: int, seed: int = 0, scale: float = 0.8):
     fk = Kinematics(KinematicsCfg(kin, None), compute_spheres=False)
     st = fk.compute_kinematics(q)
     return st.tool_poses.position[:, 0, 0].clone(), st.tool_poses.quaternion[:, 0, 0].clone()
+
+
+def feasible_goals(kin, scene, num: int):
+    """Goal poses = FK of COLLISION-FREE joint samples (the reference's ik_benchmark.py:92-101 protocol:
+    ``ik_solver.sample_configs`` rejection-samples feasible configurations, then takes their tool
+    poses), so that every goal has at least one collision-free solution.  Uses the product collision
+    checker (HIP kernels), not the oracle."""
+    from .collision_checking import RobotCollisionChecker
+    from .kinematics import Kinematics, KinematicsCfg
+
+    cfg = KinematicsCfg(kin, None)
+    q = RobotCollisionChecker(cfg, scene).sample(num, mask_valid=True)
+    if q.shape[0] < num:
+        raise RuntimeError(f"rejection sampling found only {q.shape[0]} of {num} collision-free configurations")
+    st = Kinematics(cfg, compute_spheres=False).compute_kinematics(q.contiguous())
+    return st.tool_poses.position[:, 0, 0].clone(), st.tool_poses.quaternion[:, 0, 0].clone()
