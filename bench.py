@@ -420,25 +420,38 @@ def ik_benchmark(args, model, kin, device, torch):
     shards = 4 if P % 4 == 0 else 1  # problem shards on HIP streams (optim/pipelined.py)
     solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=shards))
     gp, gq = feasible_goals(kin, scene, P)
-    res = solver.solve_pose(gp, gq)  # warm-up + graph capture
-    torch.cuda.synchronize()
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        res = solver.solve_pose(gp, gq)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    def timed(exit_early, reps=5):
+        res = solver.solve_pose(gp, gq, exit_early=exit_early)  # warm-up (+ graph capture the first time)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ran = 0
+        for _ in range(reps):
+            res = solver.solve_pose(gp, gq, exit_early=exit_early)
+            ran += int(solver.optimizer_ran)
+        torch.cuda.synchronize()
+        return res, (time.perf_counter() - t0) / reps, ran
+
+    res_full, dt_full, _ = timed(False)  # every solve runs the 100 L-BFGS iterations
+    res, dt, ran = timed(True)  # the reference's benchmark setting (ik_benchmark.py: config.exit_early = True)
     ocfg = solver.cfg.optimizer
+    stat = lambda r: {  # noqa: E731
+        "success_rate": round(float(r.success.float().mean().item()), 4),
+        "median_position_error_m": float(r.position_error[r.success].median().item()) if bool(r.success.any()) else None}
     return {
         "value": round(P / dt, 1), "unit": "IK solves/s", "ms_per_batch": round(dt * 1e3, 3), "problems": P,
-        "seeds_per_problem": S, "lbfgs_iterations": ocfg.num_iters,
-        "rollout_rows_per_s": round(P * S * len(ocfg.line_search_scale) * (ocfg.num_iters + 1) / dt, 1),
-        "success_rate": round(float(res.success.float().mean().item()), 4),
-        "median_position_error_m": float(res.position_error[res.success].median().item()) if bool(res.success.any()) else None,
+        "seeds_per_problem": S, **stat(res), "exit_early": True, "solves_that_ran_lbfgs": f"{ran}/5",
+        "full_optimizer": {"value": round(P / dt_full, 1), "ms_per_batch": round(dt_full * 1e3, 3),
+                           "lbfgs_iterations": ocfg.num_iters,
+                           "rollout_rows_per_s": round(P * S * len(ocfg.line_search_scale) * (ocfg.num_iters + 1) / dt_full, 1),
+                           **stat(res_full)},
         "lm_seed_solver": bool(solver.cfg.use_lm_seed), "stream_shards": shards,
+        "reference_published": {"ms_per_batch": 2.726, "success_rate": 1.0, "hardware": "an NVIDIA GPU the page does not name",
+                                "source": "reference docs/reference/benchmarks.rst:62-72 (franka.yml, batch 100, collision-free IK)"},
         "workload": "C1: Franka 7-DoF, 64 seeds per problem (best 64 of 128 Levenberg-Marquardt seed-IK runs, as the "
-                    "reference's use_lm_seed), 4-cuboid world, pose + joint-limit + self + scene collision costs, "
-                    "goals = FK of rejection-sampled collision-free configurations (the reference's ik_benchmark.py protocol)",
+                    "reference's use_lm_seed), 4-cuboid world, pose + joint-limit + self + scene collision checks, "
+                    "goals = FK of rejection-sampled collision-free configurations, exit_early as in the reference's "
+                    "ik_benchmark.py (L-BFGS is skipped when the seed-IK solutions pass every check for all problems); "
+                    "full_optimizer = the same solve with the 100 L-BFGS iterations (4 line-search candidates each) forced",
     }
 
 

@@ -43,6 +43,12 @@ class IKSolverCfg:
     stream_shards: int = 1
     #: alternative goal poses per problem (reference IKSolverCfg.max_goalset): a solution may reach any one
     num_goalset: int = 1
+    #: reference IKSolverCfg.exit_early / exit_early_batch_success_threshold (solver_ik_cfg.py:74-77,
+    #: solver_ik.py:395-404): when the seed-IK solutions already pass every check (pose error, joint
+    #: limits, self and scene collision) for at least this fraction of the problems, they are returned
+    #: and the L-BFGS stage is skipped.  Costs one device->host read of the success count, as there.
+    exit_early: bool = True
+    exit_early_batch_success_threshold: float = 1.0
 
 
 @dataclass
@@ -111,7 +117,8 @@ class IKSolver:
         return out.to(self.device)
 
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
-                   seeds: Optional[torch.Tensor] = None, return_seeds: int = 1) -> IKResult:
+                   seeds: Optional[torch.Tensor] = None, return_seeds: int = 1,
+                   exit_early: Optional[bool] = None) -> IKResult:
         """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame -- or [P, G, 3] / [P, G, 4]
         with ``cfg.num_goalset`` = G alternatives per problem (reference solve_pose with a goal set,
         solver_ik.py:660-700; the result names the member reached).  ``return_seeds`` k > 1
@@ -131,8 +138,20 @@ class IKSolver:
                 seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=S).solution
             else:
                 seeds = self.sample_seeds()
+        self.optimizer_ran = True
+        if self.cfg.exit_early if exit_early is None else exit_early:
+            early = self._get_result(seeds.reshape(P * S, D).contiguous(), return_seeds)
+            solved = early.success if return_seeds == 1 else early.success[:, 0]
+            if float(solved.float().mean()) >= self.cfg.exit_early_batch_success_threshold:
+                self.optimizer_ran = False
+                return early
         best = self.optimizer.optimize(seeds.reshape(P * S, 1, D))
-        q = best.reshape(P * S, D).contiguous()
+        return self._get_result(best.reshape(P * S, D).contiguous(), return_seeds)
+
+    def _get_result(self, q: torch.Tensor, return_seeds: int) -> IKResult:
+        """Metrics of P*S joint configurations, feasibility checks and the ranked winner(s) per problem
+        (reference IKSolver._get_result, solver_ik.py:440-580)."""
+        P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         m = self.metrics_rollout
         cost = m.evaluate(q.view(P * S, 1, D), with_gradient=False)
         pos_err = m.pose_pos_dist.view(P, S, T)[..., 0]

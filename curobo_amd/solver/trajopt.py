@@ -117,7 +117,9 @@ class TrajOptSolver:
         rc = self.cfg.rollout
         start = start_position.to(self.device, torch.float32).view(1, D)
         K = self.K
-        ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K)
+        # the L-BFGS stage always runs here: the goal configurations should be converged, not just inside the IK
+        # tolerances (the reference's motion planner switches exit_early off as well, motion_planner.py:143-144)
+        ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K, exit_early=False)
         ik_ok = ikr.success.view(P, K)
         ik_q = ikr.solution.reshape(P, K, D).contiguous()
         choice = self.seed_goal_choice(ik_ok)  # [P, S]

@@ -176,7 +176,8 @@ def test_ik_fused_equals_kernel_sequence(robot, method, n_extra, device):
         torch.testing.assert_close(b_.reshape(a_.shape), a_, **tol)
 
 
-def test_ik_solver_end_to_end(oracle, device):
+@pytest.mark.parametrize("exit_early", [False, True])
+def test_ik_solver_end_to_end(exit_early, oracle, device):
     from curobo_amd.solver import IKSolver, IKSolverCfg
 
     model, kin, arrays, scene = _ik_setup(device)
@@ -191,11 +192,17 @@ def test_ik_solver_end_to_end(oracle, device):
     sel = np.nonzero(free)[0][:P]
     assert len(sel) == P
     gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
-    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32))
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32, exit_early=exit_early))
     res = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq))
     torch.cuda.synchronize()
     succ = res.success.cpu().numpy()
     assert succ.mean() >= 0.9, f"IK success rate {succ.mean():.2f}"
+    # reference exit_early (solver_ik.py:395-404): the L-BFGS stage is skipped exactly when the seed-IK
+    # solutions already solve every problem; the checks below hold for either kind of solution
+    if not exit_early:
+        assert solver.optimizer_ran
+    elif not solver.optimizer_ran:
+        assert succ.all()
     # verify the reported solutions with the oracle: pose reached, limits respected, collision free
     qs = res.solution.cpu().numpy()[succ]
     chk = oracle.kinematics_forward(qs, md)
