@@ -17,7 +17,7 @@ def main():
     from curobo_amd.robot.kinematics_params import KinematicsParams
     from curobo_amd.scene import SceneData, cuboid_scene_arrays
     from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
-    from curobo_amd.workloads import c1_world, c2_world, reachable_goals, start_configuration
+    from curobo_amd.workloads import c1_world, c2_world, feasible_goals, start_configuration
 
     dev = torch.device("cuda:0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,7 @@ def main():
     P = int(os.environ.get("P", 32))
     for wname, world in (("c1", c1_world()), ("c2", c2_world())):
         scene = SceneData.from_arrays(cuboid_scene_arrays(world), dev)
-        gp, gq = reachable_goals(kin, P, seed=5, scale=0.7)
+        gp, gq = feasible_goals(kin, scene, P)  # FK of collision-free configurations (reference benchmark protocol)
         start = torch.as_tensor(start_configuration(model))
         for S, K in ((4, 1), (4, 4), (8, 1), (8, 8)):
             slv = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=S, num_ik_goals=K))
