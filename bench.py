@@ -309,6 +309,7 @@ def main():
         if world == 1 and not args.no_ik:
             guarded("ik", lambda: ik_benchmark(args, model, kin, device, torch))
             guarded("full_trajopt_rollout", lambda: full_trajopt_benchmark(args, model, kin, scene, device, torch))
+            guarded("trajopt_solve", lambda: trajopt_solve_benchmark(model, kin, scene, device, torch))
         if world == 1 and not args.no_cpu_baseline:
             guarded("cpu_baseline", lambda: cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds))
             if "value" in out["cpu_baseline"]:
@@ -404,6 +405,35 @@ def full_trajopt_benchmark(args, model, kin, scene, device, torch):
         res[name] = round(time_kernel(g.replay, 20, torch) / reps, 1)
     res["rollouts_per_s_fused"] = round(B / res["fused_us"] * 1e6, 1)
     res["workload"] = "C2 shapes, full trajopt cost set (pose + c-space state + self + swept scene), cost+grad"
+    return res
+
+
+def trajopt_solve_benchmark(model, kin, scene, device, torch):
+    """Secondary: pose-to-pose trajectory optimisation end to end (TrajOptSolver: collision-free IK with
+    ranked goal configurations -> one B-spline seed per IK solution -> 100 L-BFGS iterations on the full
+    trajopt cost set -> metrics and winner), C2 world, goals = FK of collision-free configurations."""
+    from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import feasible_goals, start_configuration
+
+    start = torch.as_tensor(start_configuration(model))
+    res = {}
+    for P, S in ((1, 8), (64, 4)):
+        slv = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=S))
+        gp, gq = feasible_goals(kin, scene, 64)
+        gp, gq = gp[:P].contiguous(), gq[:P].contiguous()
+        r = slv.solve_pose(start, gp, gq)  # warm-up + graph capture
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = slv.solve_pose(start, gp, gq)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[f"{P}_problems_x_{S}_seeds"] = {"ms_per_batch": round(dt * 1e3, 2), "success_rate": round(float(r.success.float().mean()), 3),
+                                            "lbfgs_iterations": slv.cfg.optimizer.num_iters}
+    res["workload"] = ("Franka, C2 world, 32-step horizon, pose goal; IK (64 seeds, 100 iterations) + trajopt (100 iterations, "
+                       "pose + c-space state + self + swept scene collision) + metrics; context only: the reference "
+                       "publishes 31 ms mean solve time for its full motion planner on an RTX 6000 Ada")
     return res
 
 
