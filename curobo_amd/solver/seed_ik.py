@@ -14,8 +14,11 @@ is five launches here (the reference: a Warp tile kernel, two CUDA kernels, a Wa
     selection / convergence flags                          csrc/seed_ik.hip
 
 ``inner_iterations`` iterations are captured into one hipGraph; the early-exit test between
-replays is the reference's (`_calculate_exit_condition`).  Velocity / acceleration residuals
-(``velocity_weight``, ``acceleration_weight``, default 0 in the reference) are not implemented.
+replays is the reference's (`_calculate_exit_condition`).  ``solve_batch(current_position=, dt=)``
+tightens the joint-limit bounds to what one step of ``dt`` can reach from the current position
+(velocity clamping, seed_ik_error_calculator.py:355-363, seed_ik_solver.py:601-615).  The velocity /
+acceleration residual rows (``velocity_weight``, ``acceleration_weight``, default 0 in the
+reference) are not implemented.
 """
 
 from __future__ import annotations
@@ -145,7 +148,11 @@ class SeedIKSolver:
         self._axes_w = torch.ones(T * 6, device=dev)
         self._tol = z(T * 2)
         self._project = z(T, dt=torch.uint8)
-        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        # velocity clamping of the bounds: buffers with stable addresses (captured graphs), one graph per mode
+        self._vel_current, self._vel_dt = z(n, D), torch.ones(n, device=dev)
+        self._vel_limits = kin.joint_limits_velocity.to(dev, torch.float32).contiguous()
+        self._vel_active = False
+        self._graphs = {}
 
     # ------------------------------------------------------------------ one evaluation / iteration
     def _evaluate_candidate(self, q: torch.Tensor, initial: bool) -> None:
@@ -172,7 +179,8 @@ class SeedIKSolver:
             self.q, self.jacobian, self.jTerror, self.error_norm, self.position_error, self.orientation_error,
             self.lambda_damping, self.success, self.improvement, q, self.pose_jacobian.view(n, 6 * T, D),
             self.pose_jTerror, self.pose_cost, self.pos_dist, self.rot_dist, self.pred_reduction, self.action_min,
-            self.action_max, None, None, None, c.joint_limit_weight, c.rho_min, c.lambda_factor, c.lambda_min,
+            self.action_max, *((self._vel_current, self._vel_dt, self._vel_limits) if self._vel_active else (None, None, None)),
+            c.joint_limit_weight, c.rho_min, c.lambda_factor, c.lambda_min,
             c.lambda_max, c.convergence_position_tolerance, c.convergence_orientation_tolerance,
             c.convergence_joint_limit_weight, initial)
 
@@ -189,16 +197,17 @@ class SeedIKSolver:
         if not self.cfg.use_cuda_graph:
             self._inner_iterations()
             return
-        if self._graph is None:
+        if self._vel_active not in self._graphs:
             saved = [t.clone() for t in self._state()]
             self._lm_iteration()  # warm-up outside the capture
             torch.cuda.synchronize(self.device)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 self._inner_iterations()
             for t, s in zip(self._state(), saved):
                 t.copy_(s)
-        self._graph.replay()
+            self._graphs[self._vel_active] = graph
+        self._graphs[self._vel_active].replay()
 
     def _state(self):
         return [self.q, self.jacobian, self.jTerror, self.error_norm, self.position_error, self.orientation_error,
@@ -222,8 +231,16 @@ class SeedIKSolver:
         return seeds
 
     def solve_batch(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, seed_config: Optional[torch.Tensor] = None,
-                    return_seeds: int = 1, current_position: Optional[torch.Tensor] = None) -> SeedIKResult:
+                    return_seeds: int = 1, current_position: Optional[torch.Tensor] = None,
+                    dt: Optional[torch.Tensor] = None) -> SeedIKResult:
+        """``current_position`` [P, D]: first seed of every problem and the c-space distance term of the
+        ranking; together with ``dt`` (scalar or [P]) it also switches velocity clamping on: a solution
+        has to lie within ``velocity_limits * dt`` of the current position (reference: ``current_state.dt``)."""
         P, S, D, T, c = self.P, self.S, self.D, self.T, self.cfg
+        self._vel_active = current_position is not None and dt is not None
+        if self._vel_active:
+            self._vel_current.view(P, S, D).copy_(current_position.to(self.device, torch.float32).view(P, 1, D).expand(P, S, D))
+            self._vel_dt.view(P, S).copy_(torch.as_tensor(dt, dtype=torch.float32, device=self.device).reshape(-1, 1).expand(P, S))
         self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, self.G, 3))
         self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, self.G, 4))
         if seed_config is None and current_position is not None:

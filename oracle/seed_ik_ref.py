@@ -11,7 +11,9 @@ Follows, with the oracle's FK / Jacobian / FK-VJP / tool-pose / LM-step restatem
   curobo/_src/solver/seed_ik/seed_iteration_state_manager.py:74-260  state update
   curobo/_src/solver/seed_ik/seed_ik_solver.py:291-330,384-437     iteration / solve loop
 The state update is pinned bit-exactly by the reference's own SeedIterationStateManager run on CPU
-(tests/golden/seed_ik_update_golden.npz, tests/golden/make_seed_ik_golden.py).  Parity of the other
+(tests/golden/seed_ik_update_golden.npz, tests/golden/make_seed_ik_golden.py), the joint-limit block
+(with and without velocity clamping of the bounds) by the reference's own
+SeedIKErrorCalculator._compute_joint_limit_errors (tests/golden/seed_ik_limits_golden.npz).  Parity of the other
 pieces is pinned where they are defined (oracle/curobo_oracle.c); the LM step itself is
 "parity unpinned" against the reference (Warp tile kernel, no numeric test upstream) and pinned
 against numpy.linalg.solve in tests/test_oracle_linalg.py.
@@ -51,8 +53,29 @@ def action_bounds(model: Dict[str, np.ndarray], cfg: SeedIKRefCfg):
     return (lo + margin).astype(np.float32), (hi - margin).astype(np.float32)
 
 
-def evaluate(orc, model, cfg: SeedIKRefCfg, q, goal_position, goal_quat, idxs_goal):
-    """error + Jacobian of configurations q[n, D] against goals [P, T, G, 3|4] (seed_ik_error_calculator.py:128-231)"""
+def joint_limit_block(q, lo, hi, weight, current_position=None, dt=None, velocity_limits=None):
+    """seed_ik_error_calculator.py:338-387: (J^T e contribution [n, D], Jacobian diagonal [n, D], summed
+    error [n]).  With ``current_position`` [n, D], ``dt`` [n] and ``velocity_limits`` [2, D] (lower row
+    negative) the bounds are tightened to what one step of ``dt`` can reach (:355-363)."""
+    q = np.asarray(q, np.float32)
+    lo = np.broadcast_to(np.asarray(lo, np.float32), q.shape)
+    hi = np.broadcast_to(np.asarray(hi, np.float32), q.shape)
+    if current_position is not None and dt is not None:
+        v = np.asarray(velocity_limits, np.float32)
+        dtc = np.asarray(dt, np.float32).reshape(-1, 1)
+        cp = np.asarray(current_position, np.float32)
+        lo = np.maximum(lo, cp + v[0] * dtc)
+        hi = np.minimum(hi, cp + v[1] * dtc)
+    uv, lv = np.maximum(q - hi, np.float32(0)), np.maximum(lo - q, np.float32(0))
+    w = np.float32(weight)
+    err = w * (lv + uv)
+    diag = w * (np.where(lv > 0, -1.0, 0.0) + np.where(uv > 0, 1.0, 0.0)).astype(np.float32)
+    return (diag * err).astype(np.float32), diag, err.sum(-1).astype(np.float32)
+
+
+def evaluate(orc, model, cfg: SeedIKRefCfg, q, goal_position, goal_quat, idxs_goal, current_position=None, dt=None):
+    """error + Jacobian of configurations q[n, D] against goals [P, T, G, 3|4] (seed_ik_error_calculator.py:128-231);
+    ``current_position`` / ``dt``: velocity clamping of the joint-limit bounds with the model's velocity limits"""
     q = np.ascontiguousarray(q, np.float32)
     n, D = q.shape
     T = model["tool_frame_map"].shape[0]
@@ -65,18 +88,16 @@ def evaluate(orc, model, cfg: SeedIKRefCfg, q, goal_position, goal_quat, idxs_go
     pose_jte = orc.kinematics_backward(model, fk["cumul_mat"], None, tp["position_gradient"].reshape(n, T, 3),
                                        tp["rotation_gradient"].reshape(n, T, 4))
     lo, hi = action_bounds(model, cfg)
-    uv, lv = np.maximum(q - hi, 0.0), np.maximum(lo - q, 0.0)
-    w = np.float32(cfg.joint_limit_weight)
-    jl_err = w * (lv + uv)
-    diag = w * (np.where(lv > 0, -1.0, 0.0) + np.where(uv > 0, 1.0, 0.0)).astype(np.float32)
+    jl_jte, diag, jl_sum = joint_limit_block(q, lo, hi, cfg.joint_limit_weight, current_position, dt,
+                                             model.get("joint_limits_velocity"))
     J = np.zeros((n, 6 * T + D, D), np.float32)
     J[:, : 6 * T] = fk["jacobian"].reshape(n, 6 * T, D)
     J[:, 6 * T + np.arange(D), np.arange(D)] = diag
     return {
         "joint_position": q,
         "jacobian": J,
-        "jTerror": (pose_jte + diag * jl_err).astype(np.float32),
-        "error_norm": (tp["distance"].reshape(n, -1).sum(-1) + jl_err.sum(-1)).astype(np.float32),
+        "jTerror": (pose_jte + jl_jte).astype(np.float32),
+        "error_norm": (tp["distance"].reshape(n, -1).sum(-1) + jl_sum).astype(np.float32),
         "position_errors": tp["position_distance"].reshape(n, T).max(-1),
         "orientation_errors": tp["rotation_distance"].reshape(n, T).max(-1),
         "pose_jacobian": fk["jacobian"].reshape(n, 6 * T, D), "pose_jTerror": pose_jte,

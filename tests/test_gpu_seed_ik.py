@@ -191,3 +191,70 @@ def test_update_state_kernel_matches_reference_golden(device):
     np.testing.assert_array_equal(J[:, :6 * T], out["jacobian"][:, :6 * T])        # pose rows: candidate where accepted, else kept
     np.testing.assert_array_equal(J[~acc, 6 * T:], cur["jacobian"][~acc, 6 * T:])   # rejected: joint-limit rows untouched
     assert (J[acc, 6 * T:] == 0).all()                                               # accepted: rebuilt (weight 0 -> zero rows)
+
+
+def test_velocity_clamped_bounds_kernel_and_solver(oracle, device):
+    """``current_position`` + ``dt``: the joint-limit rows use the bounds one step can reach
+    (reference seed_ik_error_calculator.py:355-363).  (1) the state-update kernel's joint-limit block
+    against the reference's own outputs (tests/golden/seed_ik_limits_golden.npz); (2) one solver
+    evaluation against the oracle; (3) a solve stays within ``velocity_limits * dt`` of the start."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from curobo_amd.backends import linalg
+    from oracle import seed_ik_ref as R
+
+    g = np.load(os.path.join(GOLDEN_DIR, "seed_ik_limits_golden.npz"))
+    n, D = g["q"].shape
+    T = 1
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dt)  # noqa: E731
+    z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
+    for name, clamp in (("plain", False), ("clamped", True)):
+        st = dict(q=z(n, D), J=z(n, 6 * T + D, D), jte=z(n, D), en=z(n), pe=z(n), oe=z(n), lam=torch.ones(n, device=device))
+        succ, imp = torch.zeros(n, dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.uint8, device=device)
+        extra = (t(g["current_position"]), t(g["dt"]), t(g["velocity_limits"])) if clamp else (None, None, None)
+        linalg.seed_ik_update_state(st["q"], st["J"], st["jte"], st["en"], st["pe"], st["oe"], st["lam"], succ, imp, t(g["q"]),
+                                    z(n, 6 * T, D), z(n, D), z(n, T, 2), z(n, T), z(n, T), None, t(g["lo"]), t(g["hi"]), *extra,
+                                    float(g["weight"]), 1e-3, 2.0, 1e-5, 1e10, 1e-5, 1e-5, 1.0, True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(st["jte"].cpu().numpy(), g[f"{name}/jTerror"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(st["J"].cpu().numpy()[:, 6 * T:], g[f"{name}/jacobian"])
+        np.testing.assert_allclose(st["en"].cpu().numpy(), g[f"{name}/error"], rtol=1e-6, atol=1e-7)
+
+    P, S = 10, 8
+    model, solver = _solver(device, P, S, use_cuda_graph=True, batch_success_threshold=2.0)
+    md = model.as_dict()
+    rng = np.random.default_rng(4)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    vmax = np.asarray(md["joint_limits_velocity"], np.float32)[1]
+    dt = 0.2
+    cur = (lo + (hi - lo) * (0.25 + 0.5 * rng.random((P, 7)))).astype(np.float32)
+    target = cur + (0.5 * vmax * dt * (2 * rng.random((P, 7)) - 1)).astype(np.float32)
+    fk = oracle.kinematics_forward(target, md, compute_spheres=False)
+    gp, gq = fk["link_pos"].reshape(P, 1, 1, 3), fk["link_quat"].reshape(P, 1, 1, 4)
+    # (2) one evaluation with clamped bounds == the oracle's
+    seeds = (lo + (hi - lo) * rng.random((P * S, 7))).astype(np.float32)
+    idx = np.repeat(np.arange(P, dtype=np.int32), S)
+    ref0 = R.evaluate(oracle, md, R.SeedIKRefCfg(), seeds, gp, gq, idx, current_position=np.repeat(cur, S, axis=0),
+                      dt=np.full(P * S, dt, np.float32))
+    plain = R.evaluate(oracle, md, R.SeedIKRefCfg(), seeds, gp, gq, idx)
+    assert np.abs(ref0["error_norm"] - plain["error_norm"]).max() > 0.1  # the clamping matters for random seeds
+    solver.goal_position.copy_(t(gp))
+    solver.goal_quat.copy_(t(gq))
+    solver._vel_active = True
+    solver._vel_current.copy_(t(np.repeat(cur, S, axis=0)))
+    solver._vel_dt.fill_(dt)
+    solver._evaluate_candidate(t(seeds), initial=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(solver.error_norm.cpu().numpy(), ref0["error_norm"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(solver.jTerror.cpu().numpy(), ref0["jTerror"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(solver.jacobian.cpu().numpy(), ref0["jacobian"], rtol=1e-4, atol=2e-6)
+    # (3) solve from the current position: reaches the goal without leaving the one-step box
+    res = solver.solve_batch(t(gp[:, :, 0]), t(gq[:, :, 0]), current_position=t(cur), dt=dt)
+    ok = res.success[:, 0].cpu().numpy()
+    assert ok.mean() >= 0.9
+    step = np.abs(res.solution[:, 0].cpu().numpy() - cur)
+    assert (step[ok] <= vmax * dt + 2e-3).all(), step[ok].max(0)
+    # without dt the same call is unconstrained (separate captured graph), still solves
+    res2 = solver.solve_batch(t(gp[:, :, 0]), t(gq[:, :, 0]), current_position=t(cur))
+    assert res2.success[:, 0].float().mean().item() >= 0.9

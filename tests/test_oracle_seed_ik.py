@@ -35,6 +35,22 @@ def test_seed_ik_restatement_converges(oracle):
     assert st["lambda_damping"].min() < 0.2 < st["lambda_damping"].max()
 
 
+def test_joint_limit_block_matches_reference_golden():
+    """oracle.seed_ik_ref.joint_limit_block == the reference's own _compute_joint_limit_errors
+    (tests/golden/make_seed_ik_limits_golden.py), plain and with velocity-clamped bounds"""
+    from conftest import GOLDEN_DIR
+    from oracle import seed_ik_ref as R
+
+    g = np.load(os.path.join(GOLDEN_DIR, "seed_ik_limits_golden.npz"))
+    for name, kw in (("plain", {}), ("clamped", dict(current_position=g["current_position"], dt=g["dt"],
+                                                      velocity_limits=g["velocity_limits"]))):
+        jte, diag, err = R.joint_limit_block(g["q"], g["lo"], g["hi"], float(g["weight"]), **kw)
+        np.testing.assert_array_equal(jte, g[f"{name}/jTerror"])
+        np.testing.assert_array_equal(diag, np.diagonal(g[f"{name}/jacobian"], axis1=-2, axis2=-1))
+        np.testing.assert_allclose(err, g[f"{name}/error"], rtol=1e-6)
+    assert (g["clamped/jTerror"] != g["plain/jTerror"]).any()
+
+
 def test_halton_seed_buffer_is_scipys_scrambled_halton():
     from scipy.stats.qmc import Halton
 
