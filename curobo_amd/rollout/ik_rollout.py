@@ -94,6 +94,19 @@ class IKRollout:
         self.goal_quat = z(1, T, self.num_goalset, 4)
         self.goal_quat[..., 0] = 1.0
 
+    use_multi_env = False
+
+    def update_env_query_idx(self, env_query_idx: Optional[torch.Tensor]) -> None:
+        """Scene environment of every configuration (reference ``idxs_env`` / ``use_multi_env``,
+        cost/cost_scene_collision.py:58-198): row b collides with the obstacles of environment
+        ``env_query_idx[b]``; ``None`` = env 0.  Multi-env rows run on the kernel sequence (the fused IK
+        launch reads one environment); switching modes changes the launches: re-capture graphs."""
+        self.use_multi_env = env_query_idx is not None
+        if env_query_idx is None:
+            self.env_query_idx.zero_()
+        else:
+            self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
+
     def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
         """goal_position [G, T, num_goalset, 3], goal_quat (wxyz) [G, T, num_goalset, 4], idxs_goal [B]."""
         assert goal_position.shape[1:3] == (self.kin.num_pose_links, self.num_goalset)
@@ -131,7 +144,7 @@ class IKRollout:
         if use_scene:
             collision_hip.sphere_obstacle_collision(
                 self.scene_dist, self.scene_grad, self.robot_spheres, self.scene.struct, self._w_scene,
-                self._eta_scene, self.env_query_idx, B, 1, S, False, 0, False, None)
+                self._eta_scene, self.env_query_idx, B, 1, S, self.use_multi_env, 0, False, None)
         if with_gradient:
             kinematics_hip.launch_kinematics_backward(
                 self.grad_q, self.pose_grad_pos, self.pose_grad_quat, self.self_grad, self.com, self.com,
@@ -174,7 +187,7 @@ class IKRollout:
 
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x[B, D] -> (cost[B], grad[B, D]) in static buffers (graph friendly)."""
-        if self.cfg.use_fused:
+        if self.cfg.use_fused and not self.use_multi_env:
             if self._fused_ok is None:
                 self._fused_ok = self.fused_available()
             if self._fused_ok:

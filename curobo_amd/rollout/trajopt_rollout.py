@@ -160,6 +160,19 @@ class TrajOptRollout:
             self._traj_dt = torch.full((n,), self.cfg.traj_dt, device=d)
         self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
 
+    use_multi_env = False
+
+    def update_env_query_idx(self, env_query_idx: Optional[torch.Tensor]) -> None:
+        """Scene environment of every trajectory (reference ``idxs_env`` / ``use_multi_env``,
+        cost/cost_scene_collision.py:58-198; batch-env planning, motion_planner_batch.py):
+        trajectory b collides with the obstacles of environment ``env_query_idx[b]``; ``None`` = env 0.
+        Switching between ``None`` and indices changes a kernel argument: re-capture graphs after it."""
+        self.use_multi_env = env_query_idx is not None
+        if env_query_idx is None:
+            self.env_query_idx.zero_()
+        else:
+            self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
+
     def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
         """goal_position [G, T, 1, 3], goal_quat (wxyz) [G, T, 1, 4], idxs_goal [B]."""
         if goal_position.shape == self.goal_position.shape:
@@ -201,7 +214,7 @@ class TrajOptRollout:
         if use_scene:
             collision_hip.sphere_obstacle_collision(
                 self.scene_dist, self.scene_grad, self.robot_spheres, self.scene.struct, self._w_scene, self._eta_scene,
-                self.env_query_idx, B, H, S, False, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric,
+                self.env_query_idx, B, H, S, self.use_multi_env, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric,
                 self._speed_dt)
         if with_gradient:
             kinematics_hip.launch_kinematics_backward(
@@ -266,7 +279,7 @@ class TrajOptRollout:
             k.fixed_transforms, k.link_spheres, k.joint_map_type, k.joint_map, k.link_map, k.link_sphere_idx_map,
             k.link_chain_data, k.link_chain_offsets, k.joint_offset_map, sc.sphere_padding, self._w_self,
             sc.collision_pairs, self.scene.struct if use_scene else None, self._w_scene if use_scene else None,
-            self._eta_scene, self._speed_dt, self.env_query_idx, k.num_envs, False, B, c.padded_horizon, self.action_dim,
+            self._eta_scene, self._speed_dt, self.env_query_idx, k.num_envs, self.use_multi_env, B, c.padded_horizon, self.action_dim,
             c.n_knots, c.bspline_degree, 3 if c.use_sweep else 0, c.use_sweep and c.use_speed_metric,
             dispatch=self._dispatch_order())
         return self.cost, self.grad_knots.view(B, -1)

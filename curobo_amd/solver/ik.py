@@ -118,7 +118,7 @@ class IKSolver:
 
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
                    seeds: Optional[torch.Tensor] = None, return_seeds: int = 1,
-                   exit_early: Optional[bool] = None) -> IKResult:
+                   exit_early: Optional[bool] = None, env_idx: Optional[torch.Tensor] = None) -> IKResult:
         """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame -- or [P, G, 3] / [P, G, 4]
         with ``cfg.num_goalset`` = G alternatives per problem (reference solve_pose with a goal set,
         solver_ik.py:660-700; the result names the member reached).  ``return_seeds`` k > 1
@@ -130,6 +130,7 @@ class IKSolver:
                              f"{tuple(goal_position.shape)}, quaternion {tuple(goal_quat.shape)}")
         gp = goal_position.to(self.device, torch.float32).view(P, 1, G, 3).expand(P, T, G, 3).contiguous()
         gq = goal_quat.to(self.device, torch.float32).view(P, 1, G, 4).expand(P, T, G, 4).contiguous()
+        self._set_envs(env_idx)
         for ro, rows in zip(self.rollouts, self._row_goals):
             ro.update_goals(gp, gq, rows)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
@@ -147,6 +148,17 @@ class IKSolver:
                 return early
         best = self.optimizer.optimize(seeds.reshape(P * S, 1, D))
         return self._get_result(best.reshape(P * S, D).contiguous(), return_seeds)
+
+    def _set_envs(self, env_idx: Optional[torch.Tensor]) -> None:
+        """``env_idx`` [P]: problem p is checked against scene environment env_idx[p] (reference batch-env
+        IK, ``idxs_env`` / ``use_multi_env``); every rollout row takes the environment of its problem."""
+        mode = env_idx is not None
+        if mode != getattr(self, "_env_mode", False):
+            self.optimizer._graph = None  # the launches differ between the two modes: capture again
+        self._env_mode = mode
+        env = env_idx.to(self.device).long().view(self.P) if mode else None
+        for ro, rows in zip(self.rollouts + [self.metrics_rollout], self._row_goals + [self._mrow_goal]):
+            ro.update_env_query_idx(env[rows.long()] if mode else None)
 
     def _get_result(self, q: torch.Tensor, return_seeds: int) -> IKResult:
         """Metrics of P*S joint configurations, feasibility checks and the ranked winner(s) per problem

@@ -111,15 +111,23 @@ class TrajOptSolver:
         lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
         return torch.minimum(torch.maximum(knots, lo + 1e-3), hi - 1e-3).contiguous()
 
-    def solve_pose(self, start_position: torch.Tensor, goal_position: torch.Tensor, goal_quat: torch.Tensor) -> TrajOptResult:
-        """One shared start configuration [D]; goal_position [P, 3], goal_quat [P, 4] (wxyz)."""
+    def solve_pose(self, start_position: torch.Tensor, goal_position: torch.Tensor, goal_quat: torch.Tensor,
+                   env_idx: Optional[torch.Tensor] = None) -> TrajOptResult:
+        """One shared start configuration [D]; goal_position [P, 3], goal_quat [P, 4] (wxyz); ``env_idx``
+        [P]: problem p plans in scene environment env_idx[p] (reference batch-env planning,
+        motion_planner_batch.py; ``idxs_env`` / ``use_multi_env`` of the collision costs)."""
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         rc = self.cfg.rollout
         start = start_position.to(self.device, torch.float32).view(1, D)
         K = self.K
         # the L-BFGS stage always runs here: the goal configurations should be converged, not just inside the IK
         # tolerances (the reference's motion planner switches exit_early off as well, motion_planner.py:143-144)
-        ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K, exit_early=False)
+        ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K, exit_early=False, env_idx=env_idx)
+        mode = env_idx is not None
+        if mode != getattr(self, "_env_mode", False):
+            self.optimizer._graph = None  # the multi-env flag is a kernel argument: capture again
+        self._env_mode = mode
+        env = env_idx.to(self.device).long().view(P) if mode else None
         ik_ok = ikr.success.view(P, K)
         ik_q = ikr.solution.reshape(P, K, D).contiguous()
         choice = self.seed_goal_choice(ik_ok)  # [P, S]
@@ -129,6 +137,7 @@ class TrajOptSolver:
         grows = (goal_row.view(P, S, 1).expand(P, S, self.nls).reshape(-1), goal_row.reshape(-1))
         for r, rows, gr in ((self.rollout, self._row_goal, grows[0]), (self.metrics_rollout, self._mrow_goal, grows[1])):
             r.update_start_state(start)
+            r.update_env_query_idx(env[rows.long()] if mode else None)
             r.update_goals(gp, gq, rows)
             r.update_goal_state(ik_q.view(P * K, D), gr)  # end at rest in the seed's IK solution (implicit goal state)
         seeds = self.seed_knots(start, ik_q, choice)

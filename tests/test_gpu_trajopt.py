@@ -212,3 +212,77 @@ def test_trajopt_retime_and_interpolate(device):
             assert float(jerk2[p, sl].abs().max()) <= rc.max_jerk * (1.0 + 5e-3)
         end = pos2[p, int(last2[p]) - 1]
         assert float((end - res.goal_config[p]).abs().max()) < 5e-3
+
+
+def test_batch_env_ik_and_trajopt(oracle, device):
+    """Batch-env solving (BASELINE config 5 at solver level; reference motion_planner_batch.py /
+    ``idxs_env``): problem p is solved in ITS scene environment.  Two worlds with the obstacles in
+    different places; the solutions are verified with the oracle against the right world, and the
+    multi-env fused trajopt launch equals the kernel sequence."""
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import IKSolver, IKSolverCfg, TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import c1_world, c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    md = model.as_dict()
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays([c1_world()[0], c2_world()[0]])
+    scene = SceneData.from_arrays(arrays, device)
+    P = 6
+    env = np.array([0, 1, 0, 1, 1, 0], np.int32)
+
+    # (1) rollout: fused == sequence with per-trajectory environments, and the environment matters
+    B = 8
+    knots = torch.as_tensor(seed_knots(model, B, 12, seed=3, spread=0.6), device=device)
+    envB = torch.as_tensor(np.arange(B) % 2, device=device)
+    res = []
+    for fused, e in ((False, envB), (True, envB), (True, None)):
+        ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(use_fused=fused))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        ro.update_env_query_idx(e)
+        c, g = ro.cost_and_gradient(knots.reshape(B, -1))
+        torch.cuda.synchronize()
+        res.append((c.clone(), g.clone()))
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=2e-3, atol=2e-5 * float(res[0][1].abs().max()))
+    assert float((res[2][0] - res[1][0]).abs().max()) > 1e-2
+
+    # (2) goals that are collision free in their own world
+    cand = sample_q(model, 600, seed=31, scale=0.6)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(600, 1, -1, 4)
+    free_self = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0
+    sel = []
+    for p in range(P):
+        e = np.full(600, env[p], np.int32)
+        free = free_self & (oracle.scene_collision(sph, arrays, 1.0, 0.0, env_query_idx=e, use_multi_env=True)["distance"].sum((1, 2)) == 0)
+        sel.append([i for i in np.nonzero(free)[0] if i not in sel][0])
+    gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
+    t_env = torch.as_tensor(env)
+
+    def in_collision(q, e):  # q [n, H, D] in world e[n]
+        n, H, _ = q.shape
+        chk = oracle.kinematics_forward(q.reshape(n * H, -1), md, horizon=H)
+        s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
+        d = oracle.scene_collision(s2, arrays, 1.0, 0.0, env_query_idx=e.astype(np.int32), use_multi_env=True)["distance"]
+        return d.sum((1, 2)) > 0
+
+    ik = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32))
+    r = ik.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq), env_idx=t_env)
+    torch.cuda.synchronize()
+    ok = r.success.cpu().numpy()
+    assert ok.mean() >= 0.8
+    assert not in_collision(r.solution.cpu().numpy()[ok][:, None], env[ok]).any()
+
+    solver = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=4))
+    start = start_configuration(model)
+    out = solver.solve_pose(torch.as_tensor(start), torch.as_tensor(gp), torch.as_tensor(gq), env_idx=t_env)
+    torch.cuda.synchronize()
+    succ = out.success.cpu().numpy()
+    assert succ.mean() >= 0.8, succ
+    traj = out.position.cpu().numpy()[succ]
+    assert not in_collision(traj, env[succ]).any()
+    # the worlds differ where it matters: some winning trajectory collides in the OTHER world
+    assert in_collision(traj, 1 - env[succ]).any()
