@@ -56,6 +56,7 @@ class KinematicsParams:
     link_level_data: Optional[torch.Tensor] = None
     link_level_offsets: Optional[torch.Tensor] = None
     max_level_width: int = 1
+    joint_limits_effort: Optional[torch.Tensor] = None  # [D] max |torque| per joint (URDF effort limits)
 
     @property
     def n_tree_levels(self) -> int:
@@ -128,4 +129,5 @@ class KinematicsParams:
             joint_limits_position=up(model.joint_limits_position, torch.float32),
             joint_limits_velocity=up(model.joint_limits_velocity, torch.float32),
             self_collision=sc,
+            joint_limits_effort=up(model.joint_limits_effort, torch.float32) if getattr(model, "joint_limits_effort", None) is not None else None,
         )

@@ -19,6 +19,7 @@ import torch
 
 from ..backends import collision as collision_hip
 from ..backends import cost as cost_hip
+from ..backends import dynamics as dynamics_hip
 from ..backends import geometry as geometry_hip
 from ..backends import kinematics as kinematics_hip
 from ..backends import rollout as rollout_hip
@@ -51,6 +52,14 @@ class TrajOptRolloutCfg:
     retime_regularization_weights: bool = True
     max_acceleration: float = 15.0  # content/configs/robot/franka.yml:48-49
     max_jerk: float = 500.0
+    #: joint-torque limits (reference: the c-space STATE cost's effort bound on inverse-dynamics torques,
+    #: cost/wp_cspace_state.py + cuda_ops/dynamics.py RNEA; "motion generation with torque limits",
+    #: docs/reference/benchmarks.rst:32-42): tau = RNEA(q, qd, qdd) per point, bound cost with
+    #: cspace_weight[4] / activation[4], squared regularisation cspace_regularization[3]; the VJP goes back
+    #: through the RNEA backward kernel.  Runs on the kernel sequence (the fused launch has no RNEA).
+    use_torque_limits: bool = False
+    effort_limit: Optional[List[float]] = None  # per joint max |tau|; None = the robot's URDF effort limits
+    gravity: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 0.0, 0.0, 9.81])  # spatial base acceleration
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
     longest_first_dispatch: bool = True  # see CollisionRolloutCfg
@@ -88,6 +97,12 @@ class TrajOptRollout:
         self._a_b = torch.stack([-c.max_acceleration * ones, c.max_acceleration * ones])
         self._j_b = torch.stack([-c.max_jerk * ones, c.max_jerk * ones])
         self._effort_b = torch.stack([-1e9 * ones, 1e9 * ones])
+        if c.use_torque_limits:
+            lim = f(c.effort_limit) if c.effort_limit is not None else kin.joint_limits_effort
+            if lim is None:
+                raise ValueError("use_torque_limits needs effort_limit (the robot model carries no effort limits)")
+            self._effort_b = torch.stack([-lim.abs(), lim.abs()]).contiguous()
+            self._gravity = f(c.gravity)
         self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
         self.batch_size = 0
         self._fused_ok: Optional[bool] = None
@@ -200,11 +215,29 @@ class TrajOptRollout:
             self.pose_cost, self.pose_pos_dist, self.pose_rot_dist, self.pose_grad_pos, self.pose_grad_quat,
             self.goalset_idx, self.link_pos, self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal,
             self._pose_w, self._axes_w, self._axes_w0, self._tol, self._tol, self._project, B, H, T, 1, c.rotation_method)
+        tq = c.use_torque_limits
+        if tq:  # inverse dynamics of every trajectory point (reference cuda_ops/dynamics.py, RNEA forward)
+            n, L = B * H, k.num_links
+            if getattr(self, "_tau", None) is None or self._tau.shape[0] != n:
+                z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
+                self._tau, self._rnea_cache, self._rnea_ws = z(n, D), z(n, L * 20), z(n, L * 18)
+                self._cs_gtau, self._rnea_g = z(B, H, D), [z(n, D) for _ in range(3)]
+            rargs = (k.fixed_transforms, k.link_masses_com, k.link_inertias, k.joint_map_type, k.joint_map, k.link_map,
+                     k.joint_offset_map, self._gravity, k.link_level_offsets, k.link_level_data)
+            dynamics_hip.launch_rnea_forward(self._tau, self.position.view(n, D), self.velocity.view(n, D),
+                                             self.acceleration.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1, None)
         cost_hip.cspace_state_cost(
-            self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, None, self.position, self.velocity,
-            self.acceleration, self.jerk, None, self.state_dt, self._zeroD, self._idx0, self._p_b, self._v_b, self._a_b,
-            self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg, self._zero1, self._zero1, self._onesD,
-            True, B, H, D, c.retime_weights, c.retime_regularization_weights)
+            self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, self._cs_gtau if tq else None, self.position,
+            self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._zeroD,
+            self._idx0, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
+            self._zero1, self._zero1, self._onesD, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
+        if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
+            dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
+                                              self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
+                                              None, self._rnea_ws)
+            self.cs_gp.view(n, D).add_(self._rnea_g[0])
+            self.cs_gv.view(n, D).add_(self._rnea_g[1])
+            self.cs_ga.view(n, D).add_(self._rnea_g[2])
         sc = k.self_collision
         geometry_hip.self_collision_distance(
             self.self_dist, self.self_grad, self._pd, self.self_sparse, self.robot_spheres, sc.sphere_padding,
@@ -242,7 +275,7 @@ class TrajOptRollout:
         need = rollout_hip.rollout_trajopt_fused_lds_bytes(
             c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
             int(k.link_chain_data.shape[0]), n_obs, True)
-        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
+        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64 and not c.use_torque_limits
 
     def _dispatch_order(self):
         if not self.cfg.longest_first_dispatch:

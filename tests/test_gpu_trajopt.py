@@ -21,16 +21,22 @@ def _setup(device):
     return model, kin, arrays, SceneData.from_arrays(arrays, device)
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_trajopt_rollout_matches_oracle_composition(fused, oracle, device):
+@pytest.mark.parametrize("fused,torque", [(False, False), (True, False), (False, True)])
+def test_trajopt_rollout_matches_oracle_composition(fused, torque, oracle, device):
     """non-swept scene term for the strict comparison (the sweep has the documented zero-motion
-    discontinuity); every cost term of the reference trajopt task is active"""
+    discontinuity); every cost term of the reference trajopt task is active.  ``torque``: plus the
+    joint-torque limits on the inverse-dynamics torques (RNEA forward, effort bound + regularisation in
+    the c-space STATE cost, RNEA VJP) -- the reference's torque-limited motion generation."""
     from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
     from curobo_amd.workloads import seed_knots, start_configuration
 
     model, kin, arrays, scene = _setup(device)
     md = model.as_dict()
     cfg = TrajOptRolloutCfg(use_sweep=False, use_speed_metric=False, use_fused=fused)
+    if torque:  # limits low enough that a good part of the torques violate them; effort regularisation on
+        cfg.use_torque_limits, cfg.effort_limit = True, [12.0, 25.0, 10.0, 10.0, 2.0, 1.5, 0.5]
+        cfg.cspace_weight = [10000.0, 10000.0, 100.0, 50.0, 30.0]
+        cfg.cspace_regularization = [1000.0, 10000.0, 5.0, 0.02, 10000.0]
     B, nk, D, H = 10, cfg.n_knots, kin.num_dof, cfg.padded_horizon
     knots = seed_knots(model, B, nk, seed=4, spread=0.6)
     start = start_configuration(model)
@@ -60,9 +66,23 @@ def test_trajopt_rollout_matches_oracle_composition(fused, oracle, device):
     lim = {"position": model.joint_limits_position.astype(np.float32), "velocity": model.joint_limits_velocity.astype(np.float32),
            "acceleration": np.stack([-cfg.max_acceleration * ones, cfg.max_acceleration * ones]),
            "jerk": np.stack([-cfg.max_jerk * ones, cfg.max_jerk * ones])}
+    extra = {}
+    if torque:
+        grav = np.array(cfg.gravity, np.float32)
+        flat = lambda a: np.ascontiguousarray(a.reshape(B * H, D))  # noqa: E731
+        tau, cache = oracle.rnea_forward(flat(s["position"]), flat(s["velocity"]), flat(s["acceleration"]), md, gravity=grav)
+        cap = np.array(cfg.effort_limit, np.float32)
+        lim["effort"] = np.stack([-cap, cap])
+        extra["effort"] = tau.reshape(B, H, D)
+        assert 0.05 < (np.abs(tau) > cap).mean() < 0.95
     cs = oracle.cspace_state_cost(s["position"], s["velocity"], s["acceleration"], s["jerk"], np.full(B, cfg.traj_dt, np.float32),
                                   lim, cfg.cspace_weight, cfg.cspace_activation_distance, cfg.cspace_regularization,
-                                  retime_weights=True, retime_regularization_weights=True)
+                                  retime_weights=True, retime_regularization_weights=True, **extra)
+    if torque:  # d cost / d tau through the RNEA VJP
+        gr = oracle.rnea_backward(flat(cs["grad_effort"]), flat(s["position"]), flat(s["velocity"]), cache, md, gravity=grav)
+        assert np.abs(gr[0]).max() > 0
+        for key, g in zip(("grad_position", "grad_velocity", "grad_acceleration"), gr):
+            cs[key] = cs[key] + g.reshape(B, H, D)
     sph = fk["robot_spheres"].reshape(B, H, -1, 4)
     sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, cfg.self_collision_weight)
     wc = oracle.scene_collision(sph, arrays, cfg.scene_collision_weight, cfg.scene_activation_distance)
