@@ -153,6 +153,8 @@ class TrajOptSolver:
         feasible &= m.self_dist.view(P, S, -1).sum(-1) <= 0.0
         if self.scene is not None:
             feasible &= m.scene_dist.view(P, S, -1).sum(-1) <= 0.0
+        if rc.use_torque_limits:  # inverse-dynamics torques of the whole trajectory inside the effort limits
+            feasible &= (m._tau.view(P, S, -1, D).abs() <= m._effort_b[1] * (1.0 + 1e-3) + 1e-3).all(-1).all(-1)
         ok = feasible & (pos_err < self.cfg.position_threshold) & (rot_err < self.cfg.rotation_threshold)
         ranked = cost.view(P, S) + 1e16 * (~ok).float()  # reference solver_trajopt.py:469-484
         payload = torch.cat([knots.view(P, S, -1), pos_err.unsqueeze(-1), rot_err.unsqueeze(-1), ok.float().unsqueeze(-1),

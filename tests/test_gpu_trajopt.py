@@ -306,3 +306,45 @@ def test_batch_env_ik_and_trajopt(oracle, device):
     assert not in_collision(traj, env[succ]).any()
     # the worlds differ where it matters: some winning trajectory collides in the OTHER world
     assert in_collision(traj, 1 - env[succ]).any()
+
+
+def test_trajopt_solver_with_torque_limits(oracle, device):
+    """pose-to-pose trajectory optimisation under joint-torque limits (reference: motion generation with
+    torque limits) on the kernel sequence under hipGraph: the winners' inverse-dynamics torques, recomputed
+    with the oracle's B-spline + RNEA, respect the (tightened) limits."""
+    from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import feasible_goals, start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()
+    P = 4
+    gp, gq = feasible_goals(kin, scene, P)
+    start = torch.as_tensor(start_configuration(model))
+    grav = np.array([0, 0, 0, 0, 0, 9.81], np.float32)
+
+    lim_cfg = TrajOptSolverCfg(num_seeds=4)
+    lim_cfg.rollout.use_torque_limits = True
+    eff = np.asarray(model.joint_limits_effort, np.float32)
+    lim_cfg.rollout.effort_limit = [float(v) for v in 0.6 * eff]  # tighter than the URDF's so that the limits bind
+    lim_cfg.rollout.cspace_weight = [10000.0, 10000.0, 100.0, 50.0, 1000.0]
+    slv = TrajOptSolver(kin, scene, P, lim_cfg)
+    assert not slv.rollout.fused_available()
+    r1 = slv.solve_pose(start, gp, gq)
+    torch.cuda.synchronize()
+    ok = r1.success.cpu().numpy()
+    assert ok.mean() >= 0.75, ok
+    # torques of the winners from the oracle's B-spline + RNEA
+    rc = lim_cfg.rollout
+    D, H = kin.num_dof, rc.padded_horizon
+    zeros = np.zeros((1, D), np.float32)
+    st = {"position": start.numpy().reshape(1, D).astype(np.float32), "velocity": zeros, "acceleration": zeros, "jerk": zeros}
+    gl = {"position": r1.goal_config.cpu().numpy().astype(np.float32), "velocity": np.zeros((P, D), np.float32),
+          "acceleration": np.zeros((P, D), np.float32), "jerk": np.zeros((P, D), np.float32)}
+    i0, gi = np.zeros(P, np.int32), np.arange(P, dtype=np.int32)
+    s = oracle.bspline_forward(r1.knots.cpu().numpy(), st, gl, i0, gi, np.full(P, rc.traj_dt, np.float32), np.ones(P, np.uint8), H,
+                               rc.bspline_degree)
+    flat = lambda a: np.ascontiguousarray(a.reshape(P * H, D))  # noqa: E731
+    tau, _ = oracle.rnea_forward(flat(s["position"]), flat(s["velocity"]), flat(s["acceleration"]), md, gravity=grav)
+    tau = np.abs(tau.reshape(P, H, D))[ok]
+    assert (tau <= 0.6 * eff * 1.002 + 2e-3).all(), (tau / (0.6 * eff)).max((0, 1))
+    np.testing.assert_allclose(s["position"][ok], r1.position.cpu().numpy()[ok], atol=1e-4)
