@@ -107,3 +107,38 @@ def test_get_backend_shape():
 
     be = get_backend()
     assert {"kinematics", "optimization", "trajectory", "geometry"} <= set(be)
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under curobo_amd/ may import it (statically checked on
+    every module's AST, so a lazily imported fallback would be caught as well)."""
+    root = os.path.dirname(os.path.abspath(_lib.__file__))
+    bad = []
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            for node in ast.walk(ast.parse(open(path).read(), path)):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    bad.append(os.path.relpath(path, root))
+    assert not bad, f"product modules import the oracle: {bad}"
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """no silent CPU / eager fallback: without the built HIP library every entry point raises"""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "no_such_library.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    from curobo_amd.backends import kinematics
+
+    n_args = len([p for p in inspect.signature(kinematics.launch_kinematics_forward).parameters.values()
+                  if p.default is inspect.Parameter.empty])
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        kinematics.launch_kinematics_forward(*([None] * n_args))
