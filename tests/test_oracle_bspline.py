@@ -146,3 +146,25 @@ def test_retiming_helpers_match_reference_golden():
     worst = torch.maximum(torch.maximum((t("vel") / s).abs().amax(1) / t("max_vel"), (t("acc") / s ** 2).abs().amax(1) / t("max_acc")),
                           (t("jerk") / s ** 3).abs().amax(1) / t("max_jerk")).amax(-1)
     np.testing.assert_allclose(worst.numpy(), 1.0, rtol=1e-5)
+
+
+def test_trajectory_seed_generator_matches_reference_golden():
+    """curobo_amd.util.trajectory_seed_generator == the reference's TrajectorySeedGenerator
+    (tests/golden/make_trajectory_seed_golden.py)"""
+    import os
+
+    import torch
+
+    from conftest import GOLDEN_DIR
+    from curobo_amd.util.trajectory_seed_generator import TrajectorySeedGenerator
+
+    g = np.load(os.path.join(GOLDEN_DIR, "trajectory_seed_golden.npz"))
+    B, S, H, D = g["interpolated"].shape
+    gen = TrajectorySeedGenerator(H, D)
+    out = gen.generate_interpolated_seeds(torch.as_tensor(g["start"]), torch.as_tensor(g["goal"]), S)
+    np.testing.assert_array_equal(out.numpy(), g["interpolated"])
+    np.testing.assert_array_equal(gen.generate_constant_seeds(torch.as_tensor(g["start"]), S).numpy(), g["constant"])
+    np.testing.assert_array_equal(out[:, :, 0].numpy(), np.broadcast_to(g["start"][:, None], (B, S, D)))
+    np.testing.assert_allclose(out[:, :, -1].numpy(), g["goal"], atol=1e-7)
+    with pytest.raises(ValueError):
+        gen.generate_interpolated_seeds(torch.as_tensor(g["start"]), torch.as_tensor(g["goal"][:, :2]), S)
