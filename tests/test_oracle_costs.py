@@ -190,3 +190,27 @@ def test_cspace_state_cost_semantics(oracle):
                                   target_weight=2.0, non_terminal_factor=0.5, **base)
     np.testing.assert_allclose(r3["cost"][:, -1], 2.0 * x["pos"][:, -1] ** 2, rtol=1e-5)
     np.testing.assert_allclose(r3["cost"][:, 0], 1.0 * x["pos"][:, 0] ** 2, rtol=1e-5)
+
+
+def test_rotation_distance_matches_reference_metrics_golden(oracle):
+    """the tool-pose cost's rotation distance: method 0 = rotation angle of the relative rotation
+    (reference geom/quaternion.py angular_distance_axis_angle), method 1 = acos|<q1, q2>| (= phi3 * pi/2)
+    -- against outputs of the reference's own torch functions (tests/golden/make_rotation_metric_golden.py)"""
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    g = np.load(os.path.join(GOLDEN_DIR, "rotation_metric_golden.npz"))
+    cur, goal = g["current_quat"], g["goal_quat"]
+    n = cur.shape[0]
+    p = np.zeros((n, 1, 1, 3), np.float32)
+    one6, z2 = np.ones((1, 6), np.float32), np.zeros((1, 2), np.float32)
+    for method, want in ((0, g["axis_angle"]), (1, g["phi3"] * np.float32(np.pi / 2))):
+        out = oracle.tool_pose_distance(p, cur.reshape(n, 1, 1, 4), p, goal.reshape(n, 1, 1, 4), np.arange(n, dtype=np.int32),
+                                        np.array([1.0, 1.0], np.float32), one6, one6, z2, z2, np.zeros(1, np.uint8), method)
+        got = out["rotation_distance"].reshape(n)
+        # acos / atan2 near |dot| = 1 lose digits: 1e-3 rad absolute there, 1e-6 elsewhere
+        near = want < 1e-2
+        np.testing.assert_allclose(got[~near], want[~near], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(got[near], want[near], atol=1e-3)
+    assert (g["axis_angle"][:16] < 1e-3).all() and (g["axis_angle"][16:24] > 1e-4).all()
