@@ -162,3 +162,30 @@ def test_trajopt_seed_generation_host_logic():
     assert int(c1.abs().sum()) == 0
     k1 = slv.seed_knots(start, goals[:, 0], c1)
     torch.testing.assert_close(k1[:, 0], (start.view(1, 1, D) * (1 - t[0]) + goals[:, 0].view(P, 1, D) * t[0]))
+
+
+@pytest.mark.parametrize("robot", ["franka", "ur10e", "unitree_g1"])
+def test_kinematics_params_from_model_on_cpu(robot):
+    """RobotModel -> KinematicsParams (host tensors on the CPU device): every table the kernels read is
+    there with the documented dtype / shape, including the effort limits of the torque-limit cost and the
+    tree levels of RNEA"""
+    import torch
+
+    from conftest import load_model
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+
+    model = load_model(robot)
+    kin = KinematicsParams.from_model(model, torch.device("cpu"))
+    D, L = kin.num_dof, kin.num_links
+    assert kin.fixed_transforms.shape == (L, 3, 4) and kin.fixed_transforms.dtype == torch.float32
+    assert kin.joint_limits_position.shape == (2, D) and kin.joint_limits_velocity.shape == (2, D)
+    assert kin.joint_limits_effort is not None and kin.joint_limits_effort.shape == (D,) and bool((kin.joint_limits_effort > 0).all())
+    assert kin.link_map.dtype == torch.int16 and kin.joint_map_type.dtype == torch.int8
+    # parents precede children (the FK chain composes in index order), levels partition the links
+    lm = kin.link_map.long()
+    assert bool((lm[1:] < torch.arange(1, L)).all())
+    lv = kin.link_level_offsets.long()
+    assert int(lv[0]) == 0 and int(lv[-1]) == L and kin.n_tree_levels == lv.numel() - 1
+    assert sorted(kin.link_level_data.long().tolist()) == list(range(L))
+    pairs = kin.self_collision.collision_pairs
+    assert pairs.shape[1] == 2 and int(pairs.max()) < kin.num_spheres
