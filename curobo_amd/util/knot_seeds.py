@@ -24,7 +24,8 @@ class TrajectorySeedGenerator:
         """constant_position [B, D] -> [B, num_seeds, action_horizon, D], every knot equal to it"""
         if constant_position.ndim != 2 or constant_position.shape[-1] != self.action_dim:
             raise ValueError(f"constant_position must be [batch, {self.action_dim}], got {tuple(constant_position.shape)}")
-        return constant_position.unsqueeze(1).unsqueeze(2).repeat(1, num_seeds, self.action_horizon, 1)
+        B, D = constant_position.shape
+        return constant_position.view(B, 1, 1, D).expand(B, num_seeds, self.action_horizon, D).contiguous()
 
     def generate_interpolated_seeds(self, start_position: torch.Tensor, goal_position: torch.Tensor, num_seeds: int) -> torch.Tensor:
         """start_position [B, D], goal_position [B, num_seeds, D] -> [B, num_seeds, action_horizon, D]"""
@@ -32,7 +33,6 @@ class TrajectorySeedGenerator:
         if D != self.action_dim or goal_position.shape != (B, num_seeds, D):
             raise ValueError(f"expected start [batch, {self.action_dim}] and goal [batch, {num_seeds}, {self.action_dim}], got "
                              f"{tuple(start_position.shape)} and {tuple(goal_position.shape)}")
-        start = start_position.unsqueeze(1).repeat(1, num_seeds, 1).reshape(B * num_seeds, 1, D)
-        goal = goal_position.reshape(B * num_seeds, 1, D)
-        w = self._interpolation_weights
-        return (w[:, :, 0, :] * start + w[:, :, 1, :] * goal).view(B, num_seeds, self.action_horizon, D)
+        w_start, w_goal = self._interpolation_weights[0, :, 0, :], self._interpolation_weights[0, :, 1, :]  # [H, 1] each
+        # start-weighted term first, then the goal-weighted one: the same two roundings as the reference's expression
+        return w_start * start_position.view(B, 1, 1, D) + w_goal * goal_position.view(B, num_seeds, 1, D)

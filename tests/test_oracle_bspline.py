@@ -149,14 +149,14 @@ def test_retiming_helpers_match_reference_golden():
 
 
 def test_trajectory_seed_generator_matches_reference_golden():
-    """curobo_amd.util.trajectory_seed_generator == the reference's TrajectorySeedGenerator
+    """curobo_amd.util.knot_seeds == the reference's TrajectorySeedGenerator
     (tests/golden/make_trajectory_seed_golden.py)"""
     import os
 
     import torch
 
     from conftest import GOLDEN_DIR
-    from curobo_amd.util.trajectory_seed_generator import TrajectorySeedGenerator
+    from curobo_amd.util.knot_seeds import TrajectorySeedGenerator
 
     g = np.load(os.path.join(GOLDEN_DIR, "trajectory_seed_golden.npz"))
     B, S, H, D = g["interpolated"].shape
