@@ -2,17 +2,28 @@
 """bench.py -- trajopt rollouts/sec on MI355X (BASELINE.json metric, config C2).
 
 A *step* is one L-BFGS iteration of the reference's trajectory optimiser over one batch of
-synthetic seeds: generate the 4 line-search candidates per seed, evaluate cost
-AND gradient of every candidate trajectory (B-spline -> FK -> self + swept scene collision ->
-per-trajectory sum -> FK backward -> B-spline backward), run the Wolfe line search and the fused
-L-BFGS direction update.  Workload (per GPU): Franka Panda, 256 seeds x 4 line-search
-candidates = 1024 rollouts of 32 steps (padded 33) per step, 4-cuboid world.  Rollouts/s counts
-cost+gradient trajectory evaluations.  With --gpus N the seed axis shards (weak scaling: every
-rank owns 256 seeds of its own, no data-path collective); the only exchange is the RCCL
-all-gather arg-min over seeds at the end of the timed region.
+synthetic seeds: the 4 line-search candidates per seed are evaluated for cost
+AND gradient (B-spline -> FK -> self + swept scene collision -> per-trajectory sum -> FK backward
+-> B-spline backward), then the Wolfe line search and the L-BFGS two-loop produce the next
+candidates.  Workload (per GPU): Franka Panda, 256 seeds x 4 line-search candidates = 1024
+rollouts of 32 steps (padded 33) per step, 4-cuboid world.  Rollouts/s counts cost+gradient
+trajectory evaluations.
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel, live
-HIP-event timing) and `cpu_baseline` (the C oracle on the host cores, bounded sample).
+Timing protocol (state-stable): a *block* = re-initialise the optimiser from the seeds, run
+``--warmup`` untimed iterations, then time EXACTLY ``--steps`` iterations + the arg-min exchange
+between barrier + synchronize pairs (MAX over ranks).  Blocks repeat until >= 0.25 s of timed work
+has been collected (every block starts from the same state, so the data-dependent culling of the
+collision passes cannot drift the figure); ``ms_per_step`` is the MEDIAN block time / steps.
+
+``--gpus N`` without a torchrun environment re-executes itself under ``torch.distributed.run``
+with N ranks (one per GPU, RCCL); ``n_gpus`` is only ever printed after an RCCL all-reduce over
+exactly N ranks succeeded.  Weak scaling by default (256 seeds per rank); ``--scaling strong``
+splits 256 seeds over the ranks.  The only exchange of the path is the all-gather arg-min over
+seeds at the end of the timed steps.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel), `cpu_baseline` (the C oracle on
+the host cores, bounded sample), a fixed-state figure and the single-GPU shares of BASELINE configs
+C3 / C4 / C5 with their own rooflines.
 """
 
 from __future__ import annotations
@@ -20,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,41 +42,85 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# fp32 vector issue: 256 CU x 4 SIMD x 2.4 GHz, one wave64 VALU instruction per 2 cycles (same guide)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+MIN_TIMED_S = 0.25
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seeds", type=int, default=256, help="seeds per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--seeds", type=int, default=256, help="seeds per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget per leg")
     ap.add_argument("--graph-iters", type=int, default=25,
                     help="L-BFGS iterations per captured graph (the reference's inner_iters, lbfgs_bspline_trajopt.yml)")
     ap.add_argument("--no-fused", action="store_true",
                     help="drop-in kernel sequence (7 launches per rollout) instead of the fused rollout kernel")
     ap.add_argument("--shards", type=int, default=4,
                     help="seed shards of the optimiser on separate HIP streams of the GPU (1 = one batch, one stream)")
-    ap.add_argument("--no-ik", action="store_true", help="skip the secondary IK solves/s measurement")
+    ap.add_argument("--no-ik", action="store_true", help="skip the secondary solver measurements (IK, trajopt solve)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 single-GPU shares")
+    ap.add_argument("--only", default="", help="comma list of secondary objects to run (c3,c4,c5,ik,fixed); default all")
     ap.add_argument("--ik-problems", type=int, default=100)
     ap.add_argument("--ik-seeds", type=int, default=64)
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     return ap.parse_args()
 
 
-def time_kernel(fn, iters, torch):
-    """Average duration (us) of `fn` (one kernel launch on the current stream) with HIP events."""
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N outside torchrun -> N ranks under torch.distributed.run
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    import torch
+
+    backend = os.environ.get("CUROBO_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to print a line for fewer ranks")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def time_kernel(fn, iters, torch, min_s=0.0):
+    """Average duration (us) of `fn` (launches on the current stream) with HIP events."""
     for _ in range(3):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    total, n = 0.0, 0
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        total += e0.elapsed_time(e1) * 1e3
+        n += iters
+        if total * 1e-6 >= min_s:
+            return total / n
+
+
+def graphed(fn, reps, torch):
+    """hipGraph of `reps` calls of `fn` (device time without Python launch overhead)."""
+    fn()
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    return g
 
 
 def usable_cores():
@@ -79,37 +136,78 @@ def usable_cores():
 
 
 def cpu_baseline(model, scene_arrays, cfg, knots, start, budget_s):
-    """The CPU oracle (restatement of the reference kernels) on the host cores of this box."""
-    from oracle import load_oracle
+    """The CPU oracle (C restatement of the reference kernels, gcc -O3 -march=native, OpenMP over the
+    point axis) on the host cores of this box: all usable cores (headline) and one thread
+    (SURVEY section 8d asks for both)."""
+    from oracle import load_native_oracle, load_oracle
     from oracle.rollout_ref import rollout_cost_and_gradient
 
-    orc = load_oracle()
+    try:
+        orc, build = load_native_oracle(), "gcc -O3 -march=native -fopenmp, built on this host (oracle/_native/)"
+    except Exception as e:  # noqa: BLE001  (no compiler on the box: the portable checker build)
+        orc, build = load_oracle(), f"portable checker build (-O2 -ffp-contract=off; native build failed: {type(e).__name__})"
     cores = usable_cores()
-    orc.set_num_threads(cores)
-    sample = knots[:64]
+    sample = knots[:256]
     kw = dict(interpolation_steps=cfg.interpolation_steps, degree=cfg.bspline_degree, traj_dt=cfg.traj_dt,
               self_collision_weight=cfg.self_collision_weight, scene_collision_weight=cfg.scene_collision_weight,
               activation_distance=cfg.activation_distance, use_sweep=cfg.use_sweep,
               use_speed_metric=cfg.use_speed_metric)
     md = model.as_dict()
-    rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)  # warm
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)
-        n += sample.shape[0]
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
+
+    def leg(threads, budget):
+        orc.set_num_threads(threads)
+        rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)  # warm
+        t0, n = time.perf_counter(), 0
+        while True:
+            rollout_cost_and_gradient(orc, md, scene_arrays, sample, start, **kw)
+            n += sample.shape[0]
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return n / el, n // sample.shape[0], el, orc.num_threads()
+
+    v_all, passes, el, used = leg(cores, budget_s)
+    v_one, passes1, el1, _ = leg(1, max(2.0, budget_s * 0.4))
+    orc.set_num_threads(cores)
     return {
-        "value": n / el, "unit": "rollouts/s", "cores": orc.num_threads(), "kind": "port",
+        "value": v_all, "unit": "rollouts/s", "cores": used, "kind": "port",
+        "single_thread_value": v_one,
+        "build": build,
         "sample": f"{sample.shape[0]} trajectories x {cfg.padded_horizon} points per pass, cost+grad, "
-                  f"{n // sample.shape[0]} passes in {el:.1f} s, OpenMP over points ({orc.num_threads()} threads)",
+                  f"{passes} passes in {el:.1f} s on {used} threads (OpenMP over points); single thread: {passes1} passes in {el1:.1f} s",
     }
 
 
+def cpu_optimizer_baseline(num_problems, V, m, nls, budget_s):
+    """The reference's OWN torch fallbacks of the optimiser stage, timed on the host cores when the
+    reference checkout is importable (this container); on the GPU box the oracle's C restatement
+    of the same two functions (pinned bit-wise by tests/golden/optim_golden.npz) is timed instead."""
+    from oracle import load_native_oracle, load_oracle
+
+    try:
+        orc = load_native_oracle()
+    except Exception:  # noqa: BLE001
+        orc = load_oracle()
+    rng = np.random.default_rng(0)
+    B = num_problems
+    x, g = rng.normal(size=(B, V)).astype(np.float32), rng.normal(size=(B, V)).astype(np.float32)
+    y, s_, rho = np.zeros((m, B, V), np.float32), np.zeros((m, B, V), np.float32), np.zeros((m, B), np.float32)
+    x0, g0, step = x.copy(), g.copy(), np.zeros((B, V), np.float32)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        x += np.float32(0.01)
+        g *= np.float32(0.99)
+        orc.lbfgs_step(step, rho, y, s_, x, g, x0, g0, 0.01, True)
+        n += 1
+    el = time.perf_counter() - t0
+    return {"lbfgs_steps_per_s": n * B / el, "problems": B, "opt_dim": V, "history": m, "kind": "port",
+            "sample": f"{n} two-loop updates of {B} problems in {el:.1f} s (C restatement of lbfgs_jit_helpers.py:10-78)"}
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -118,19 +216,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
-    local_rank %= torch.cuda.device_count()  # (only differs in the single-GPU gloo smoke test below)
+    backend = os.environ.get("CUROBO_BENCH_BACKEND", "nccl")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPUs visible")
+    local_rank %= torch.cuda.device_count()  # (only differs in the single-GPU gloo smoke test)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # CUROBO_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test the multi-rank logic
-        backend = os.environ.get("CUROBO_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise SystemExit(f"collective over {world} ranks returned {probe.item()}")
 
     from curobo_amd import _lib
     from curobo_amd.distributed import global_argmin
@@ -147,14 +251,23 @@ def main():
     scene_arrays = cuboid_scene_arrays(c2_world())
     scene = SceneData.from_arrays(scene_arrays, device)
     cfg = CollisionRolloutCfg(use_fused=not args.no_fused)
-    ocfg = LBFGSOptCfg(num_problems=args.seeds, inner_iters=args.graph_iters)
+    if args.scaling == "strong":
+        if args.seeds % world:
+            raise SystemExit(f"--scaling strong: {args.seeds} seeds do not split over {world} ranks")
+        seeds = args.seeds // world
+    else:
+        seeds = args.seeds
+    shards = args.shards
+    while shards > 1 and seeds % shards:
+        shards //= 2
+    ocfg = LBFGSOptCfg(num_problems=seeds, inner_iters=args.graph_iters)
     nls = len(ocfg.line_search_scale)
-    rollout = CollisionRollout(kin, scene, args.seeds * nls, cfg)
+    rollout = CollisionRollout(kin, scene, seeds * nls, cfg)
     start = start_configuration(model)
     rollout.update_start_state(torch.as_tensor(start, device=device))
     bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
     start_t = torch.as_tensor(start, device=device)
-    if args.shards > 1:
+    if shards > 1:
         # the seeds are independent problems: shard them over HIP streams so that the optimiser-side
         # kernel of one shard overlaps the rollout workgroups of the others (optim/pipelined.py)
         from curobo_amd.optim import PipelinedLBFGS
@@ -163,13 +276,12 @@ def main():
             ro = CollisionRollout(kin, scene, batch, cfg)
             ro.update_start_state(start_t)
             return ro.cost_and_gradient
-        opt = PipelinedLBFGS(ocfg, shard_rollout, cfg.n_knots, kin.num_dof, bounds, device, n_shards=args.shards,
+        opt = PipelinedLBFGS(ocfg, shard_rollout, cfg.n_knots, kin.num_dof, bounds, device, n_shards=shards,
                              use_cuda_graph=not args.no_graph)
     else:
         opt = LBFGSOpt(ocfg, rollout.cost_and_gradient, cfg.n_knots, kin.num_dof, bounds, device,
                        use_cuda_graph=not args.no_graph)
-    opt1 = None
-    knots = seed_knots(model, args.seeds, cfg.n_knots, seed=2, seed_offset=rank * args.seeds)
+    knots = seed_knots(model, seeds, cfg.n_knots, seed=2, seed_offset=rank * seeds)
     seed_t = torch.as_tensor(knots, device=device)
     opt.reinitialize(seed_t)
 
@@ -178,8 +290,7 @@ def main():
 
     def run_steps(k):
         """exactly k optimiser iterations"""
-        nonlocal opt1
-        one = opt.step if args.shards > 1 else opt._opt_step
+        one = opt.step if shards > 1 else opt._opt_step
         if args.no_graph:
             for _ in range(k):
                 one()
@@ -191,129 +302,116 @@ def main():
                 rem_graphs[k % G] = opt.make_graph(k % G)
             rem_graphs[k % G].replay()
 
-    run_steps(max(args.warmup, 1))
-    if not args.no_graph:  # every graph the timed region replays is captured before it
-        if args.steps >= G and opt._graph is None:
-            opt.capture()
-        if args.steps % G and args.steps % G not in rem_graphs:
-            rem_graphs[args.steps % G] = opt.make_graph(args.steps % G)
-    # warm the exchange too (first use of the torch index/min kernels loads their code objects)
-    global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, args.seeds, -1), rank * args.seeds)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    # the one real exchange of the path: arg-min over the seeds of all ranks (1 problem)
-    best_c, best_i, best_x = global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, args.seeds, -1),
-                                           rank * args.seeds)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    rollouts_per_step = args.seeds * nls * world
+    # every graph the timed region replays is captured before it; the exchange is warmed too
+    run_steps(max(args.warmup, 1))
+    run_steps(args.steps)
+    global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, seeds, -1), rank * seeds)
+    sync_all()
+
+    def timed_block():
+        """seeds -> W untimed iterations -> EXACTLY K timed iterations + the arg-min exchange"""
+        opt.reinitialize(seed_t)
+        run_steps(args.warmup)
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        # the one real exchange of the path: arg-min over the seeds of all ranks (1 problem)
+        res = global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, seeds, -1), rank * seeds)
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, res
+
+    blocks, total, t_wall = [], 0.0, time.perf_counter()
+    while True:
+        el, (best_c, best_i, best_x) = timed_block()
+        blocks.append(el)
+        total += el
+        go_on = (total < args.min_timed_s or len(blocks) < 5) and len(blocks) < 2000 and time.perf_counter() - t_wall < 60.0
+        if world > 1:  # every rank must take the same decision
+            flag = torch.tensor([1.0 if go_on else 0.0], device=device if backend == "nccl" else "cpu")
+            dist.broadcast(flag, 0)
+            go_on = bool(flag.item() > 0.5)
+        if not go_on:
+            break
+    elapsed = float(np.median(blocks))
+    rollouts_per_step = seeds * nls * world
     value = rollouts_per_step * args.steps / elapsed
 
-    # ---------------- per-kernel live timing (HIP events on the launch stream) -> roofline
     out = None
     if rank == 0:
-        B, H = rollout.batch_size, cfg.padded_horizon
-        N = B * H
-        D, T, L, S = kin.num_dof, kin.num_pose_links, kin.num_links, kin.num_spheres
-        act = opt.x_set.view(B, cfg.n_knots, D)
-        rollout.evaluate_action(act)
-        rollout.backward()
-        it = 200
-        kernels = {
-            "bspline_forward": (lambda: rollout.compute_state_from_action(act), B * (cfg.n_knots * D * 4 + 4 * H * D * 4)),
-            "fk_forward_spheres": (lambda: rollout.compute_kinematics(rollout.position), N * (4 * D + 28 * T + 16 * S + 48 * L)),
-            "self_collision": (lambda: rollout_self(rollout), N * (16 * S + 4)),
-            "scene_collision_swept": (lambda: rollout_scene(rollout), N * (36 * S)),
-            "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 16 * S + 28 * T + 4 * D)),
-        }
-        fused = cfg.use_fused and rollout.fused_available()
-        if fused:  # one launch does the work of the five kernels above + cost sum + B-spline VJP
-            kernels["rollout_trajectory_fused"] = (lambda: rollout.cost_and_gradient_fused(act),
-                                                   N * rollout.algorithmic_bytes_per_point())
-        timings = {}
-        for name, (fn, nbytes) in kernels.items():
-            us = time_kernel(fn, it, torch)
-            timings[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes),
-                             "GBps": round(nbytes / us * 1e-3, 1)}
-        step_us = time_kernel(opt.step if args.shards > 1 else opt._opt_step, 50, torch)
-        dom = "rollout_trajectory_fused" if fused else max(timings, key=lambda k: timings[k]["us"])
-        ach = timings[dom]["GBps"]
-        traffic, traffic_src = measured_traffic(dom, B)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_us": timings[dom]["us"], "algorithmic_bytes_per_launch": timings[dom]["algorithmic_bytes"],
-                    "launch": {"trajectories": B, "concurrent_launches": 1.0,
-                               "timing": "HIP events around back-to-back launches on the launch stream"}}
-        if fused and not args.no_graph:
-            # the launches of the timed region as they run inside the replayed hipGraph (one per seed
-            # shard and iteration, overlapping across the shard streams): device wall-clock stamps
-            try:
-                in_graph = graph_launch_times(opt, args, nls, torch)
-            except Exception as e:  # noqa: BLE001  (keep the HIP-event figures of the exclusive launch)
-                in_graph = None
-                roofline["in_graph_timing_error"] = f"{type(e).__name__}: {e}"
-        if fused and not args.no_graph and in_graph is not None:
-            shard_rows = B // args.shards
-            nbytes = shard_rows * H * rollout.algorithmic_bytes_per_point()
-            ach = nbytes / in_graph["avg_launch_us"] * 1e-3
-            traffic, traffic_src = measured_traffic(dom, shard_rows)
-            exclusive = {k: roofline[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "launch")}
-            roofline.update({
-                "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_us": in_graph["avg_launch_us"], "algorithmic_bytes_per_launch": int(nbytes),
-                "launch": {"trajectories": shard_rows, "concurrent_launches": in_graph["concurrency"],
-                           "timing": "device wall-clock stamps (100 MHz) of the launches inside the replayed hipGraph"},
-                "aggregate_achieved": round(ach * in_graph["concurrency"], 1),
-                "exclusive_launch": exclusive})
-        total_bytes = N * rollout.algorithmic_bytes_per_point()
+        only = {s for s in args.only.split(",") if s}
+        want = lambda k: (not only) or k in only  # noqa: E731
         out = {
             "metric": "trajopt rollouts/sec (batch x horizon cost+grad)",
             "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "C2: Franka Panda trajopt, 256 seeds x 4 line-search candidates x 32-step horizon "
                             "(padded 33), 4-cuboid world, swept scene collision + speed metric + self collision, "
                             "one L-BFGS iteration (line search + two-loop) per step",
-                "robot": "franka", "seeds_per_gpu": args.seeds, "line_search_candidates": nls,
-                "horizon": cfg.horizon, "n_knots": cfg.n_knots, "rollouts_per_step_per_gpu": args.seeds * nls,
-                "points_per_step_per_gpu": N, "hip_graph": not args.no_graph, "fused_rollout_kernel": bool(fused), "streams_per_gpu": args.shards,
-                "parallelism": f"seed-shard x{world} GPUs x{args.shards} streams",
+                "robot": "franka", "seeds_per_gpu": seeds, "line_search_candidates": nls,
+                "horizon": cfg.horizon, "n_knots": cfg.n_knots, "rollouts_per_step_per_gpu": seeds * nls,
+                "points_per_step_per_gpu": seeds * nls * cfg.padded_horizon, "hip_graph": not args.no_graph,
+                "fused_rollout_kernel": bool(cfg.use_fused and rollout.fused_available()), "streams_per_gpu": shards,
+                "parallelism": f"seed-shard x{world} GPUs x{shards} streams ({args.scaling} scaling, "
+                               f"{'RCCL' if backend == 'nccl' else backend} all-gather arg-min)" if world > 1
+                               else f"1 GPU x{shards} streams",
             },
-            "roofline": roofline,
-            "kernels_us": {k: v["us"] for k, v in timings.items()},
-            "kernels_GBps": {k: v["GBps"] for k, v in timings.items()},
-            "eager_step_us": round(step_us, 1),
-            "stack_algorithmic_GBps": round(total_bytes / (elapsed / args.steps) * 1e-9, 1),
+            "timing": {
+                "protocol": "block = reinitialise from the seeds, `warmup` untimed iterations, then `steps` timed iterations + "
+                            "arg-min exchange between barrier+synchronize pairs (max over ranks); ms_per_step = median block / steps",
+                "blocks": len(blocks), "timed_total_s": round(total, 4), "block_ms_median": round(elapsed * 1e3, 4),
+                "block_ms_min": round(min(blocks) * 1e3, 4), "block_ms_max": round(max(blocks) * 1e3, 4),
+            },
             "best_cost": float(best_c[0].item()), "best_seed": int(best_i[0].item()),
         }
-        # secondary measurements never take the headline line down with them
-        def guarded(key, fn):
+
+        def guarded(key, fn):  # secondary measurements never take the headline line down with them
             try:
                 out[key] = fn()
             except Exception as e:  # noqa: BLE001
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_ik:
-            guarded("ik", lambda: ik_benchmark(args, model, kin, device, torch))
-            guarded("full_trajopt_rollout", lambda: full_trajopt_benchmark(args, model, kin, scene, device, torch))
-            guarded("trajopt_solve", lambda: trajopt_solve_benchmark(model, kin, scene, device, torch))
-        if world == 1 and not args.no_cpu_baseline:
-            guarded("cpu_baseline", lambda: cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds))
-            if "value" in out["cpu_baseline"]:
-                out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+
+        def roofline():
+            return c2_roofline(args, opt, rollout, cfg, kin, seed_t, seeds, shards, nls, elapsed / args.steps, torch)
+        guarded("roofline", roofline)
+        if world == 1:
+            if want("c3") and not args.no_configs:
+                guarded("c3_ur10e_voxel", lambda: c3_benchmark(device, torch))
+            if want("c4") and not args.no_configs:
+                guarded("c4_humanoid_share", lambda: c4_benchmark(device, torch))
+            if want("c5") and not args.no_configs:
+                guarded("c5_batch_planner_share", lambda: c5_benchmark(model, kin, device, torch))
+            if want("ik") and not args.no_ik:
+                guarded("ik", lambda: ik_benchmark(args, model, kin, device, torch))
+                guarded("full_trajopt_rollout", lambda: full_trajopt_benchmark(seeds, model, kin, scene, device, torch))
+                guarded("trajopt_solve", lambda: trajopt_solve_benchmark(model, kin, scene, device, torch))
+            if not args.no_cpu_baseline:
+                guarded("cpu_baseline", lambda: cpu_baseline(model, scene_arrays, cfg, knots, start, args.cpu_seconds))
+                if "value" in out["cpu_baseline"]:
+                    out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                    try:
+                        out["cpu_baseline"]["optimizer_stage"] = cpu_optimizer_baseline(
+                            seeds, cfg.n_knots * kin.num_dof, ocfg.history, nls, 2.0)
+                    except Exception as e:  # noqa: BLE001
+                        out["cpu_baseline"]["optimizer_stage"] = {"error": f"{type(e).__name__}: {e}"}
+    if world > 1 and args.scaling == "weak":
+        # the strong-scaling reading of the same job (north_star: 256 seeds in total), measured in the same launch
+        strong = strong_scaling_leg(args, world, rank, kin, scene, cfg, ocfg, model, start_t, bounds, device, backend, torch, dist)
+        if rank == 0:
+            out["strong_scaling"] = strong
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -321,30 +419,175 @@ def main():
         print(json.dumps(out))
 
 
-def graph_launch_times(opt, args, nls, torch):
-    """Average duration of the fused rollout launches INSIDE the replayed hipGraph: the graph is
-    re-captured with the library's profile sequence on (every launch stamps its workgroups' start /
-    end wall clock into its own block), replayed, and the stamps of the last replay are read back.
+def strong_scaling_leg(args, world, rank, kin, scene, cfg, ocfg, model, start_t, bounds, device, backend, torch, dist):
+    """256 seeds IN TOTAL split over the ranks (north_star's 256-seed job): same block protocol."""
+    import dataclasses
+
+    from curobo_amd.distributed import global_argmin
+    from curobo_amd.optim import LBFGSOpt
+    from curobo_amd.rollout import CollisionRollout
+    from curobo_amd.workloads import seed_knots
+
+    total_seeds = args.seeds
+    if total_seeds % world:
+        return {"error": f"{total_seeds} seeds do not split over {world} ranks"}
+    seeds = total_seeds // world
+    nls = len(ocfg.line_search_scale)
+    ro = CollisionRollout(kin, scene, seeds * nls, cfg)
+    ro.update_start_state(start_t)
+    opt = LBFGSOpt(dataclasses.replace(ocfg, num_problems=seeds), ro.cost_and_gradient, cfg.n_knots, kin.num_dof, bounds, device)
+    seed_t = torch.as_tensor(seed_knots(model, seeds, cfg.n_knots, seed=2, seed_offset=rank * seeds), device=device)
+    opt.reinitialize(seed_t)
+    g = opt.make_graph(args.steps)
+    gw = opt.make_graph(max(args.warmup, 1))
+    cdev = device if backend == "nccl" else "cpu"
+
+    def sync_all():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    blocks = []
+    for _ in range(25):
+        opt.reinitialize(seed_t)
+        gw.replay()
+        sync_all()
+        t0 = time.perf_counter()
+        g.replay()
+        global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, seeds, -1), rank * seeds)
+        sync_all()
+        tt = torch.tensor([time.perf_counter() - t0], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        blocks.append(float(tt.item()))
+    el = float(np.median(blocks))
+    return {"scaling": "strong", "total_seeds": total_seeds, "seeds_per_gpu": seeds, "streams_per_gpu": 1,
+            "value": round(total_seeds * nls * args.steps / el, 1), "unit": "rollouts/s",
+            "ms_per_step": round(el / args.steps * 1e3, 5), "blocks": len(blocks)}
+
+
+# ------------------------------------------------------------------------------------------------
+# C2 roofline object
+# ------------------------------------------------------------------------------------------------
+def c2_roofline(args, opt, rollout, cfg, kin, seed_t, seeds, shards, nls, step_s, torch):
+    """Dominant kernel = the fused rollout launch.  `achieved` is the AGGREGATE algorithmic rate of the
+    rollout launches of the timed steps (all concurrent shard launches together: bytes of one step's
+    launches / time during which any of them was running), live from device wall-clock stamps inside
+    the replayed graph; the exclusive 1024-trajectory launch at the SEED state (HIP events on the
+    launch stream) and the drop-in kernel sequence are reported next to it."""
+    B, H = rollout.batch_size, cfg.padded_horizon
+    N = B * H
+    D, T, L, S = kin.num_dof, kin.num_pose_links, kin.num_links, kin.num_spheres
+    bpp = rollout.algorithmic_bytes_per_point()
+    # fixed state: the line-search candidates of iteration 1 at the seeds (no optimiser progress)
+    opt.reinitialize(seed_t)
+    torch.cuda.synchronize()
+    act = opt.x_set.reshape(B, cfg.n_knots, D).clone()
+    rollout.evaluate_action(act)
+    rollout.backward()
+    reps = 20
+    kernels = {
+        "bspline_forward": (lambda: rollout.compute_state_from_action(act), B * (cfg.n_knots * D * 4 + 4 * H * D * 4)),
+        "fk_forward_spheres": (lambda: rollout.compute_kinematics(rollout.position), N * (4 * D + 28 * T + 16 * S + 48 * L)),
+        "self_collision": (lambda: rollout_self(rollout), N * (16 * S + 4)),
+        "scene_collision_swept": (lambda: rollout_scene(rollout), N * (36 * S)),
+        "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 16 * S + 28 * T + 4 * D)),
+    }
+    fused = cfg.use_fused and rollout.fused_available()
+    if fused:  # one launch does the work of the five kernels above + cost sum + B-spline VJP
+        kernels["rollout_trajectory_fused"] = (lambda: rollout.cost_and_gradient_fused(act), N * bpp)
+    timings = {}
+    for name, (fn, nbytes) in kernels.items():
+        g = graphed(fn, reps, torch)
+        us = time_kernel(g.replay, 10, torch, min_s=0.05) / reps
+        timings[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / us * 1e-3, 1)}
+    seq_us = sum(v["us"] for k, v in timings.items() if k != "rollout_trajectory_fused")
+    dom = "rollout_trajectory_fused" if fused else max(timings, key=lambda k: timings[k]["us"])
+    excl = timings[dom]
+    traffic, traffic_src = measured_traffic(dom, B)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": excl["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(excl["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_note": f"HBM bytes per {B}-trajectory launch from the COMMITTED rocprofv3 PMC passes of this command "
+                            f"({traffic_src}); counters are not collected in this run",
+            "avg_launch_us": excl["us"], "algorithmic_bytes_per_launch": excl["algorithmic_bytes"],
+            "definition": "exclusive launch at the seed state"}
+    exclusive = {"state": "seed candidates (iteration 1, every trajectory as seeded; no optimiser progress)",
+                 "trajectories": B, "avg_launch_us": excl["us"], "achieved": excl["GBps"],
+                 "frac": round(excl["GBps"] / HBM_PEAK_GBS, 4), "rollouts_per_s": round(B / excl["us"] * 1e6, 1),
+                 "timing": "HIP events around hipGraph replays of 20 back-to-back launches on the launch stream"}
+    roof["exclusive_launch_fixed_state"] = exclusive
+    if fused and not args.no_graph and hasattr(opt, "opts"):
+        try:
+            ig = graph_launch_times(opt, args.graph_iters, shards, seeds, nls, seed_t, torch)
+            step_bytes = N * bpp
+            agg = step_bytes / ig["rollout_busy_us_per_step"] * 1e-3
+            roof.update({
+                "achieved": round(agg, 1), "frac": round(agg / HBM_PEAK_GBS, 4),
+                "definition": "AGGREGATE over the concurrent shard launches of a step: algorithmic bytes of one step's rollout "
+                              "launches / time during which any of them was running (device wall-clock stamps, 100 MHz, "
+                              "inside the replayed hipGraph, first graph_iters iterations from the seeds)",
+                "avg_launch_us": ig["avg_launch_us"], "algorithmic_bytes_per_launch": int(step_bytes // shards),
+                "launch": {"trajectories": B // shards, "concurrent_launches": ig["concurrency"], "launches_sampled": ig["launches"],
+                           "rollout_busy_us_per_step": ig["rollout_busy_us_per_step"]},
+            })
+            t256, src256 = measured_traffic(dom, B // shards)
+            if t256 is not None:
+                roof["traffic"] = t256
+                roof["traffic_note"] = (f"HBM bytes per {B // shards}-trajectory launch from the COMMITTED rocprofv3 PMC passes "
+                                        f"of the single-stream variant of this command ({src256}); not collected in this run")
+        except Exception as e:  # noqa: BLE001  (keep the HIP-event figures of the exclusive launch)
+            roof["in_graph_timing_error"] = f"{type(e).__name__}: {e}"
+    roof["whole_step_algorithmic_GBps"] = round(N * bpp / step_s * 1e-9, 1)
+    roof["whole_step_frac"] = round(N * bpp / step_s * 1e-9 / HBM_PEAK_GBS, 4)
+    # what actually bounds the fused kernel: VALU issue (committed SQ counters x the live launch time)
+    sq = committed_sq_counters(dom)
+    if sq is not None:
+        insts = sq["valu_wave_instructions_per_trajectory"] * B
+        roof["valu_issue_frac"] = round(insts / (excl["us"] * 1e-6) / VALU_ISSUE_PEAK, 4)
+        roof["valu_issue_note"] = (f"{sq['valu_wave_instructions_per_trajectory']} VALU wave-instructions per trajectory "
+                                   f"(seed state, {sq['source']}, committed file) x {B} trajectories / live exclusive launch time, "
+                                   f"against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = {VALU_ISSUE_PEAK:.3g} wave-instructions/s")
+    roof["kernels_us"] = {k: v["us"] for k, v in timings.items()}
+    roof["kernels_GBps"] = {k: v["GBps"] for k, v in timings.items()}
+    roof["kernel_sequence_us"] = round(seq_us, 1)
+    return roof
+
+
+def committed_sq_counters(kernel):
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if kernel in str(rec.get("kernel", "")) and "per_trajectory" in rec:
+            best = {"valu_wave_instructions_per_trajectory": rec["per_trajectory"]["valu_wave_instructions"],
+                    "source": "profiles/" + os.path.basename(path)}
+    return best
+
+
+def graph_launch_times(opt, G, shards, seeds, nls, seed_t, torch):
+    """Durations of the fused rollout launches INSIDE the replayed hipGraph: the graph is re-captured
+    with the library's profile sequence on (every launch stamps its workgroups' start / end wall
+    clock into its own block), replayed from the seed state, and the stamps are read back.
     concurrency = sum of launch durations / time during which any of them was running."""
     from curobo_amd._lib import load
 
     lib = load()
-    G, shards = args.graph_iters, max(args.shards, 1)
-    rows = args.seeds // shards * nls
+    rows = seeds // shards * nls
     warm = shards  # capture() runs one eager warm-up iteration per shard first: those blocks are skipped
     buf = torch.zeros((warm + shards * G, rows, 16), dtype=torch.int64, device="cuda")
     lib.curobo_hip_rollout_fused_set_profile_sequence(buf.data_ptr(), buf.shape[0], rows)
     opt._graph = None
     opt.capture()
     lib.curobo_hip_rollout_fused_set_profile_sequence(None, 0, 0)
-    for _ in range(3):
-        opt.run_inner()
+    opt.reinitialize(seed_t)
+    opt.run_inner()
     torch.cuda.synchronize()
     t = buf[warm:].cpu().numpy().astype(np.float64) / 100.0  # us
     start, end = t[:, :, 0].min(axis=1), t[:, :, 4].max(axis=1)
     dur = end - start
-    # union of the launch intervals
-    order = np.argsort(start)
+    order = np.argsort(start)  # union of the launch intervals
     busy, cur_s, cur_e = 0.0, start[order[0]], end[order[0]]
     for i in order[1:]:
         if start[i] > cur_e:
@@ -366,7 +609,7 @@ def measured_traffic(kernel: str, trajectories: int = 0):
     import glob
 
     best = (None, None)
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json"))):
         try:
             with open(path) as fh:
                 rec = json.load(fh)
@@ -382,27 +625,239 @@ def measured_traffic(kernel: str, trajectories: int = 0):
     return best
 
 
-def full_trajopt_benchmark(args, model, kin, scene, device, torch):
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 3 / 4 / 5: single-GPU shares, each with its own roofline
+# ------------------------------------------------------------------------------------------------
+def _timed_stages(stages, torch, reps=5):
+    """{name: (fn, algorithmic_bytes)} -> per-stage us / GB/s, each stage replayed from a hipGraph"""
+    res = {}
+    for name, (fn, nbytes) in stages.items():
+        g = graphed(fn, reps, torch)
+        us = time_kernel(g.replay, 3, torch, min_s=0.05) / reps
+        res[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / us * 1e-3, 1),
+                     "hbm_frac": round(nbytes / us * 1e-3 / HBM_PEAK_GBS, 4)}
+    return res
+
+
+def c3_benchmark(device, torch):
+    """C3: UR10e + one nvblox-style ESDF grid (128^3 fp16 at 0.02 m), 512 seeds.  (a) the
+    collision_checking SDF path (RobotCollisionChecker.get_scene_self_collision_distance_from_joints:
+    FK -> sphere-voxel distance + self collision) on 512 seeds x 33 points; (b) the trajopt rollout
+    (cost + gradient) of 512 seeds x 4 candidates on the same world, fused launch and kernel sequence."""
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import c3_voxel_world, seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("ur10e", device=device)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    arrays = c3_voxel_world()
+    scene = SceneData.from_arrays(arrays, device)
+    seeds, H = 512, 33
+    D, S, L, T = kin.num_dof, kin.num_spheres, kin.num_links, kin.num_pose_links
+    knots = seed_knots(model, seeds * 4, 12, seed=4)
+    res = {"workload": "C3: UR10e, 128^3 fp16 ESDF (2.56 m cube, box + sphere union), 512 seeds",
+           "robot": {"dof": D, "spheres": S, "links": L}}
+    # (a) collision checker query
+    chk = RobotCollisionChecker(kcfg, scene, activation_distance=0.02, scene_weight=1.0, self_weight=1.0)
+    g = torch.Generator().manual_seed(3)
+    lo, hi = kin.joint_limits_position[0].cpu(), kin.joint_limits_position[1].cpu()
+    q = (lo + (hi - lo) * torch.rand(seeds, H, D, generator=g)).to(device)
+    d_world, d_self = chk.get_scene_self_collision_distance_from_joints(q)
+    torch.cuda.synchronize()
+    res["hit_fraction"] = round(float((d_world > 0).float().mean()), 4)
+    query = lambda: chk.get_scene_self_collision_distance_from_joints(q)  # noqa: E731
+    try:
+        with torch.no_grad():
+            gq = graphed(query, 5, torch)
+        us, how = time_kernel(gq.replay, 3, torch, min_s=0.05) / 5, "hipGraph replay"
+    except Exception:  # noqa: BLE001  (front end not capturable: eager launches, Python overhead included)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            us, how = time_kernel(query, 20, torch, min_s=0.05), "eager launches (Python overhead included)"
+    n = seeds * H
+    nbytes = n * (4 * D + 28 * T + 16 * S + 48 * L + 2 * 16 * S + 4 * S + 4 + 16 * S)  # FK out, 2 reads of spheres, outputs, 8 fp16 corners
+    res["collision_checking_query"] = {"points": n, "us": round(us, 2), "sphere_queries_per_s": round(n * S / us * 1e6, 1),
+                                       "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / us * 1e-3, 1), "timing": how}
+    # (b) rollout cost + gradient
+    B = seeds * 4
+    x = torch.as_tensor(knots, device=device).reshape(B, -1)
+    for name, fused in (("fused", True), ("kernel_sequence", False)):
+        ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(use_fused=fused))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        if fused and not ro.fused_available():
+            res[name] = {"error": "one trajectory does not fit in LDS"}
+            continue
+        gr = graphed(lambda: ro.cost_and_gradient(x), 5, torch)
+        us = time_kernel(gr.replay, 3, torch, min_s=0.05) / 5
+        nb = B * H * (ro.algorithmic_bytes_per_point() + 16 * S)
+        res[name] = {"us_per_launch_set": round(us, 2), "rollouts_per_s": round(B / us * 1e6, 1),
+                     "algorithmic_bytes": int(nb), "GBps": round(nb / us * 1e-3, 1)}
+        if not fused:
+            N = B * H
+            stages = {
+                "fk_forward_spheres": (lambda: ro.compute_kinematics(ro.position), N * (4 * D + 28 * T + 16 * S + 48 * L)),
+                "self_collision": (lambda: rollout_self(ro), N * (16 * S + 4)),
+                "scene_collision_voxel_swept": (lambda: rollout_scene(ro), N * (36 * S + 16 * S)),
+                "fk_backward": (lambda: rollout_bwd_fk(ro), N * (48 * L + 16 * S + 28 * T + 4 * D)),
+            }
+            res["kernels"] = _timed_stages(stages, torch)
+    best = res["fused"] if "rollouts_per_s" in res.get("fused", {}) else res["kernel_sequence"]
+    res["value"], res["unit"] = best["rollouts_per_s"], "rollouts/s"
+    k = res["kernels"]["scene_collision_voxel_swept"]
+    res["roofline"] = {"bound": "hbm", "kernel": "scene_collision_kernel (fp16 ESDF, swept)", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": k["hbm_frac"], "traffic": None, "avg_launch_us": k["us"],
+                       "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                       "note": "36*S B/pt of sphere reads / distance + gradient writes + 8 fp16 corner gathers (16 B) per sphere; "
+                               "the grid (4 MiB) is L2 / Infinity-Cache resident"}
+    return res
+
+
+def c4_benchmark(device, torch):
+    """C4 single-GPU share: Unitree G1 whole body (in-tree stand-in for the 38-DoF humanoid; 43 actuated
+    dof + virtual base), 256 seeds (1024 seeds over 4 GPUs) x 4 candidates x 33 points: FK, tiled
+    self collision over 162 k sphere pairs, RNEA inverse dynamics + torque-limit cost and the VJPs,
+    run as the kernel sequence (one G1 trajectory does not fit in 160 KB of LDS)."""
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("unitree_g1", device=device)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    seeds, nls, H = 256, 4, 33
+    B = seeds * nls
+    D, S, L, T = kin.num_dof, kin.num_spheres, kin.num_links, kin.num_pose_links
+    P = int(kin.self_collision.collision_pairs.shape[0])
+    eff = [200.0] * D
+    cfg = TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=eff)
+    ro = TrajOptRollout(kin, None, B, cfg)
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=6, spread=0.15), device=device).reshape(B, -1)
+    ro.cost_and_gradient(x)
+    torch.cuda.synchronize()
+    g = graphed(lambda: ro.cost_and_gradient(x), 2, torch)
+    us = time_kernel(g.replay, 2, torch, min_s=0.1) / 2
+    N = B * H
+    res = {"workload": f"C4 share: unitree_g1 ({D} dof, {L} links, {S} spheres, {P} self-collision pairs), {seeds} seeds x {nls} "
+                       f"candidates x {H} points: pose + c-space STATE (torque limits on RNEA tau) + self collision, cost+grad, "
+                       "kernel sequence",
+           "us_per_rollout_set": round(us, 1), "value": round(B / us * 1e6, 1), "unit": "rollouts/s",
+           "in_self_collision_fraction": round(float((ro.self_dist > 0).float().mean()), 4)}
+    from curobo_amd.backends import dynamics as Dy
+    from curobo_amd.backends import geometry as G
+
+    sc = kin.self_collision
+
+    def self_only():
+        G.self_collision_distance(ro.self_dist, ro.self_grad, ro._pd, ro.self_sparse, ro.robot_spheres, sc.sphere_padding,
+                                  ro._w_self, sc.collision_pairs, ro._bbmv, ro._bbmi, 1, 256, B, H, S, P, False, True)
+    n = N
+    rargs = (kin.fixed_transforms, kin.link_masses_com, kin.link_inertias, kin.joint_map_type, kin.joint_map, kin.link_map,
+             kin.joint_offset_map, ro._gravity, kin.link_level_offsets, kin.link_level_data)
+
+    def rnea_f():
+        Dy.launch_rnea_forward(ro._tau, ro.position.view(n, D), ro.velocity.view(n, D), ro.acceleration.view(n, D), *rargs,
+                               ro._rnea_cache, n, L, D, kin.n_tree_levels, 1, None)
+
+    def rnea_b():
+        Dy.launch_rnea_backward(*ro._rnea_g, ro._cs_gtau.view(n, D), ro.position.view(n, D), ro.velocity.view(n, D), *rargs,
+                                ro._rnea_cache, n, L, D, kin.n_tree_levels, 1, None, ro._rnea_ws)
+    stages = {
+        "fk_forward_spheres": (lambda: _fk_fwd(ro, kin, B, H, D, S), N * (4 * D + 28 * T + 16 * S + 48 * L)),
+        "self_collision_tiled": (self_only, N * (16 * S + 4)),
+        "rnea_forward": (rnea_f, N * (12 * D + 4 * D + 80 * L)),
+        "rnea_backward": (rnea_b, N * (16 * D + 12 * D + 80 * L + 2 * 72 * L)),
+        "fk_backward": (lambda: _fk_bwd(ro, kin, B, H, D, S), N * (48 * L + 16 * S + 28 * T + 4 * D)),
+    }
+    res["kernels"] = _timed_stages(stages, torch, reps=2)
+    k = res["kernels"]["self_collision_tiled"]
+    flops = 10.0 * P * N  # SURVEY section 8d: ~10 FLOP per pair test
+    res["roofline"] = {"bound": "valu (LDS gather)", "kernel": "self_collision_kernel<NWAVES> (tiled, 162 k pairs)",
+                       "achieved": round(flops / k["us"] * 1e-6, 2), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(flops / k["us"] * 1e-6 / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                       "avg_launch_us": k["us"], "pair_tests_per_s": round(P * N / k["us"] * 1e6, 1),
+                       "hbm_frac_of_the_same_launch": k["hbm_frac"],
+                       "note": "compute-bound pair tests (31 FLOP/B against the materialised sphere tensor): priced against the fp32 "
+                               "vector peak at 10 FLOP per pair test, not against HBM"}
+    return res
+
+
+def _fk_fwd(ro, kin, B, H, D, S):
+    from curobo_amd.backends import kinematics as K
+
+    K.launch_kinematics_forward_spheres(ro.link_pos, ro.link_quat, ro.robot_spheres, ro.com, ro.cumul_mat, ro.position,
+                                        kin.fixed_transforms, kin.link_spheres, kin.link_masses_com, kin.joint_map_type, kin.joint_map,
+                                        kin.link_map, kin.tool_frame_map, kin.link_sphere_idx_map, kin.joint_offset_map, ro.env_query_idx,
+                                        kin.num_envs, B * H, H, D, S, 32, True, False)
+
+
+def _fk_bwd(ro, kin, B, H, D, S):
+    from curobo_amd.backends import kinematics as K
+
+    K.launch_kinematics_backward(ro.grad_q, ro.pose_grad_pos, ro.pose_grad_quat, ro.self_grad, ro.com, ro.com, ro.pose_grad_pos,
+                                 ro.cumul_mat, kin.link_spheres, kin.link_masses_com, kin.link_map, kin.joint_map, kin.joint_map_type,
+                                 kin.tool_frame_map, kin.link_sphere_idx_map, kin.link_chain_data, kin.link_chain_offsets,
+                                 kin.joint_links_data, kin.joint_links_offsets, kin.joint_affects_endeffector, kin.joint_offset_map,
+                                 ro.env_query_idx, kin.num_envs, B * H, H, D, S, False, False)
+
+
+def c5_benchmark(model, kin, device, torch):
+    """C5 single-GPU share: 2 of the 16 planning problems (16 robots over 8 GPUs), each with its own
+    world (cuboids + one 64^3 ESDF grid per environment, env_query_idx per trajectory), 512 seeds x 4
+    candidates x 64-step horizon (12 knots x 4, padded 65): cost + gradient of 4096 trajectories."""
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import c5_mixed_worlds, seed_knots, start_configuration
+
+    n_prob, seeds, nls = 2, 512, 4
+    B = n_prob * seeds * nls
+    res = {"workload": f"C5 share: {n_prob} problems (own worlds) x {seeds} seeds x {nls} candidates, Franka, horizon 64 (padded 65), "
+                       "swept scene collision + speed metric + self collision, cost+grad"}
+    env_idx = torch.arange(n_prob, dtype=torch.int32, device=device).repeat_interleave(seeds * nls)
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=8), device=device).reshape(B, -1)
+    for world_name in ("mixed cuboid + ESDF", "cuboid-only"):
+        arrays = c5_mixed_worlds(n_prob, voxels=world_name.startswith("mixed"))
+        scene = SceneData.from_arrays(arrays, device)
+        sub = {}
+        for name, fused in (("fused", True), ("kernel_sequence", False)):
+            ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(interpolation_steps=4, use_fused=fused))
+            ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+            ro.update_env_query_idx(env_idx)
+            if fused and not ro.fused_available():
+                sub[name] = {"error": "one trajectory does not fit in LDS"}
+                continue
+            g = graphed(lambda: ro.cost_and_gradient(x), 3, torch)
+            us = time_kernel(g.replay, 3, torch, min_s=0.05) / 3
+            nb = B * ro.cfg.padded_horizon * ro.algorithmic_bytes_per_point()
+            sub[name] = {"us_per_launch_set": round(us, 1), "rollouts_per_s": round(B / us * 1e6, 1), "algorithmic_bytes": int(nb),
+                         "GBps": round(nb / us * 1e-3, 1), "hbm_frac": round(nb / us * 1e-3 / HBM_PEAK_GBS, 4)}
+        res[world_name] = sub
+    head = res["mixed cuboid + ESDF"]
+    best = max((v for v in head.values() if "rollouts_per_s" in v), key=lambda v: v["rollouts_per_s"])
+    res["value"], res["unit"] = best["rollouts_per_s"], "rollouts/s"
+    res["roofline"] = {"bound": "hbm", "kernel": "rollout_trajectory_fused (H = 65, multi-env)" if best is head.get("fused") else "kernel sequence",
+                       "achieved": best["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["hbm_frac"], "traffic": None,
+                       "avg_launch_us": best["us_per_launch_set"], "algorithmic_bytes_per_launch": best["algorithmic_bytes"]}
+    return res
+
+
+def full_trajopt_benchmark(seeds, model, kin, scene, device, torch):
     """Secondary: the FULL reference trajopt cost set (tool pose + c-space STATE + self + swept
     scene collision, lbfgs_bspline_trajopt.yml) on the C2 shapes: one fused launch vs the
     ten-launch kernel sequence, cost + gradient of 1024 trajectories."""
     from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
     from curobo_amd.workloads import seed_knots, start_configuration
 
-    B = args.seeds * 4
+    B = seeds * 4
     res = {}
     knots = torch.as_tensor(seed_knots(model, B, 12, seed=2), device=device)
     for name, fused in (("fused_us", True), ("kernel_sequence_us", False)):
         ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(use_fused=fused))
         ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
         x = knots.reshape(B, -1)
-        ro.cost_and_gradient(x)
-        torch.cuda.synchronize()
-        g, reps = torch.cuda.CUDAGraph(), 10  # hipGraph replay: device time, not Python launch overhead
-        with torch.cuda.graph(g):
-            for _ in range(reps):
-                ro.cost_and_gradient(x)
-        res[name] = round(time_kernel(g.replay, 20, torch) / reps, 1)
+        g = graphed(lambda: ro.cost_and_gradient(x), 10, torch)
+        res[name] = round(time_kernel(g.replay, 20, torch) / 10, 1)
     res["rollouts_per_s_fused"] = round(B / res["fused_us"] * 1e6, 1)
     res["workload"] = "C2 shapes, full trajopt cost set (pose + c-space state + self + swept scene), cost+grad"
     return res
@@ -450,6 +905,7 @@ def ik_benchmark(args, model, kin, device, torch):
     shards = 4 if P % 4 == 0 else 1  # problem shards on HIP streams (optim/pipelined.py)
     solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=shards))
     gp, gq = feasible_goals(kin, scene, P)
+
     def timed(exit_early, reps=5):
         res = solver.solve_pose(gp, gq, exit_early=exit_early)  # warm-up (+ graph capture the first time)
         torch.cuda.synchronize()
@@ -499,7 +955,7 @@ def rollout_scene(r):
     from curobo_amd.backends import collision as c
 
     c.sphere_obstacle_collision(r.scene_dist, r.scene_grad, r.robot_spheres, r.scene.struct, r._w_scene, r._eta,
-                                r.env_query_idx, r.batch_size, r.cfg.padded_horizon, r.kin.num_spheres, False,
+                                r.env_query_idx, r.batch_size, r.cfg.padded_horizon, r.kin.num_spheres, r.use_multi_env,
                                 3 if r.cfg.use_sweep else 0, r.cfg.use_sweep and r.cfg.use_speed_metric, r._speed_dt)
 
 

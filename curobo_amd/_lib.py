@@ -13,7 +13,10 @@ from typing import Dict, List, Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libcurobo_hip.so")
-HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "curobo_hip.h")
+# the public header: the copy the build puts next to the library (so an installed / copied package is
+# self-contained), else the repository's include/ directory
+_HEADER_CANDIDATES = (os.path.join(_PKG, "lib", "curobo_hip.h"), os.path.join(os.path.dirname(_PKG), "include", "curobo_hip.h"))
+HEADER_PATH = next((p for p in _HEADER_CANDIDATES if os.path.exists(p)), _HEADER_CANDIDATES[-1])
 
 _lib: Optional[C.CDLL] = None
 
@@ -104,10 +107,17 @@ def load() -> C.CDLL:
     import torch  # noqa: F401  (loads libamdhip64 first; same SONAME is then shared)
 
     lib = C.CDLL(LIB_PATH)
-    for name, argtypes in _signatures().items():
+    sigs = _signatures()
+    for name, argtypes in sigs.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes
+    # every declared entry point must have been understood by the header parser (a formatting the
+    # regex misses would otherwise leave a function without argtypes: silent int truncation of pointers)
+    special = {"curobo_hip_last_error", "curobo_hip_set_debug_sync"}
+    untyped = [n for n in declared_symbols() if n not in sigs and n not in special]
+    if untyped:
+        raise ImportError(f"include/curobo_hip.h declares entry points the ctypes binding could not parse: {untyped}")
     lib.curobo_hip_last_error.restype = C.c_char_p
     lib.curobo_hip_last_error.argtypes = []
     lib.curobo_hip_set_debug_sync.restype = None
@@ -138,4 +148,8 @@ def current_stream(t) -> int:
     cuda_core_backend/kinematics.py:50-51)."""
     import torch
 
+    if t.device.index != torch.cuda.current_device():
+        # the launch (and hipFuncSetAttribute) would go to the current device's context
+        raise ValueError(f"tensor on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                         "wrap the call in `with torch.cuda.device(tensor.device):`")
     return torch.cuda.current_stream(t.device).cuda_stream

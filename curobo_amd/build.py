@@ -96,6 +96,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, LIB_PATH)
+    shutil.copyfile(os.path.join(INCLUDE, "curobo_hip.h"), os.path.join(LIB_DIR, "curobo_hip.h"))  # travels with the library
     return LIB_PATH
 
 

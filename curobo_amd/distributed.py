@@ -69,10 +69,12 @@ def local_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: i
     The reference ranks seeds with ``torch.topk(largest=False)`` (``solver/solver_ik.py:503-515``,
     ``util/tensor_util.py:178-179``), whose order among equal costs is unspecified; here ties are
     resolved towards the lowest seed index (stable sort), so the result does not depend on the
-    sharding.  ``k`` is clamped to the local seed count (missing rows carry cost +inf)."""
+    sharding.  ``k`` is clamped to the local seed count (missing rows carry cost +inf, seed index -1 and a zero payload)."""
     P, S = cost.shape
     order = torch.sort(cost, dim=1, stable=True).indices[:, : min(k, S)]  # [P, k']
-    rows = torch.full((P, k, 2 + payload.shape[-1]), float("inf"), device=cost.device, dtype=torch.float32)
+    rows = torch.zeros((P, k, 2 + payload.shape[-1]), device=cost.device, dtype=torch.float32)
+    rows[:, :, 0] = float("inf")  # rows beyond the local seed count: cost +inf, seed index -1, zero payload
+    rows[:, :, 1] = -1.0
     ar = torch.arange(P, device=cost.device).unsqueeze(1)
     kk = order.shape[1]
     rows[:, :kk, 0] = cost[ar, order]
@@ -94,7 +96,8 @@ def global_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: 
         cand = flat.view(world, *rows.shape).permute(1, 0, 2, 3).reshape(rows.shape[0], world * k, -1)
     else:
         cand = rows
-    # lexicographic (cost, global index): sort by index first, then stably by cost
+    # lexicographic (cost, global index): sort by index first, then stably by cost (padding rows, index -1,
+    # have cost +inf and therefore end up last whatever their index)
     by_idx = torch.sort(cand[:, :, 1], dim=1, stable=True).indices
     cand = torch.gather(cand, 1, by_idx.unsqueeze(-1).expand_as(cand))
     by_cost = torch.sort(cand[:, :, 0], dim=1, stable=True).indices[:, :k]

@@ -28,7 +28,7 @@ from ..backends import kinematics as kinematics_hip
 from ..backends import rollout as rollout_hip
 from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
-from ..scene.data import SceneData
+from ..scene.data import SceneData, validate_env_query_idx
 
 
 @dataclass
@@ -139,6 +139,7 @@ class CollisionRollout:
             self.env_query_idx.zero_()
             return
         self.use_multi_env = True
+        validate_env_query_idx(env_query_idx, self.scene, self.kin.num_envs)
         self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
 
     def update_start_state(self, start_position: Optional[torch.Tensor]) -> None:

@@ -25,7 +25,7 @@ from ..backends import kinematics as kinematics_hip
 from ..backends import rollout as rollout_hip
 from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
-from ..scene.data import SceneData
+from ..scene.data import SceneData, validate_env_query_idx
 
 
 @dataclass
@@ -186,6 +186,7 @@ class TrajOptRollout:
         if env_query_idx is None:
             self.env_query_idx.zero_()
         else:
+            validate_env_query_idx(env_query_idx, self.scene, self.kin.num_envs)
             self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
 
     def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:

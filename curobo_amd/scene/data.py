@@ -94,6 +94,14 @@ class SceneData:
     struct: "object"
     arrays: Dict[str, np.ndarray]
 
+    @property
+    def num_envs(self) -> int:
+        """number of scene environments (leading dimension of the obstacle stores)"""
+        for k in ("cuboid_dims", "voxel_params"):
+            if k in self.arrays:
+                return int(self.arrays[k].shape[0])
+        return 1
+
     @staticmethod
     def from_arrays(arrays: Dict[str, np.ndarray], device) -> "SceneData":
         import torch
@@ -110,3 +118,23 @@ class SceneData:
             t.get("voxel_features"), float(arrays.get("voxel_max_distance", 10000.0)),
         )
         return SceneData(tensors=t, struct=struct, arrays=arrays)
+
+
+def validate_env_query_idx(env_query_idx, scene: Optional["SceneData"], kin_num_envs: int = 1) -> None:
+    """Reject environment indices the kernels would read out of bounds: every entry must address one of
+    the scene's environments and, when the robot carries per-environment collision spheres
+    (``KinematicsParams.num_envs > 1``: the same index selects the sphere table in the FK kernels), one of
+    those as well.  One host read-back, at update time (never inside a captured launch sequence)."""
+    import torch
+
+    if env_query_idx is None or env_query_idx.numel() == 0:
+        return
+    lo, hi = int(torch.min(env_query_idx)), int(torch.max(env_query_idx))
+    limits = []
+    if scene is not None:
+        limits.append(("scene environments", scene.num_envs))
+    if kin_num_envs > 1:
+        limits.append(("robot sphere environments", int(kin_num_envs)))
+    for what, n in limits:
+        if lo < 0 or hi >= n:
+            raise ValueError(f"env_query_idx spans [{lo}, {hi}] but there are {n} {what}")

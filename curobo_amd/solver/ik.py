@@ -12,6 +12,7 @@ winner found with one RCCL all-gather (``curobo_amd.distributed.global_argmin``)
 
 from __future__ import annotations
 
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -69,8 +70,9 @@ class IKSolver:
         self.P, self.S = num_problems, self.cfg.num_seeds
         self.device = kin.device
         self.seed_offset = seed_offset
-        ocfg = self.cfg.optimizer
-        ocfg.num_problems = self.P * self.S
+        # private copy of the optimiser configuration: the caller's cfg may be shared by solvers of other sizes
+        ocfg = dataclasses.replace(self.cfg.optimizer, num_problems=self.P * self.S)
+        self.cfg = dataclasses.replace(self.cfg, optimizer=ocfg)
         self.nls = len(ocfg.line_search_scale)
         self.G = self.cfg.num_goalset
         self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, self.cfg.rollout, num_goalset=self.G)

@@ -9,6 +9,7 @@ metrics rollout -> success mask -> ranking, :469-484) for the ``lbfgs_bspline_tr
 
 from __future__ import annotations
 
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -64,8 +65,9 @@ class TrajOptSolver:
                  cfg: Optional[TrajOptSolverCfg] = None, use_cuda_graph: bool = True):
         self.kin, self.scene, self.cfg = kin, scene, cfg or TrajOptSolverCfg()
         self.P, self.S, self.device = num_problems, self.cfg.num_seeds, kin.device
-        ocfg = self.cfg.optimizer
-        ocfg.num_problems = self.P * self.S
+        # private copy of the optimiser configuration: the caller's cfg may be shared by solvers of other sizes
+        ocfg = dataclasses.replace(self.cfg.optimizer, num_problems=self.P * self.S)
+        self.cfg = dataclasses.replace(self.cfg, optimizer=ocfg)
         self.nls = len(ocfg.line_search_scale)
         rc = self.cfg.rollout
         self.ik = IKSolver(kin, scene, num_problems, self.cfg.ik, use_cuda_graph=use_cuda_graph)
@@ -150,6 +152,12 @@ class TrajOptSolver:
         lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
         q = m.position.view(P, S, -1, D)
         feasible = ((q >= lo - 1e-4) & (q <= hi + 1e-4)).all(-1).all(-1)
+        # velocity / acceleration / jerk inside their limits at the optimised dt: the reference's success mask is the
+        # c-space STATE constraint at zero activation distance over position, velocity, acceleration, jerk (and torque)
+        # (content/configs/task/metrics_base.yml:16-19, solver/solver_trajopt_result.py:154-210)
+        for x, b in ((m.velocity, m._v_b), (m.acceleration, m._a_b), (m.jerk, m._j_b)):
+            x = x.view(P, S, -1, D)
+            feasible &= ((x >= b[0] - 1e-3 * b[0].abs() - 1e-4) & (x <= b[1] + 1e-3 * b[1].abs() + 1e-4)).all(-1).all(-1)
         feasible &= m.self_dist.view(P, S, -1).sum(-1) <= 0.0
         if self.scene is not None:
             feasible &= m.scene_dist.view(P, S, -1).sum(-1) <= 0.0

@@ -92,3 +92,42 @@ def feasible_goals(kin, scene, num: int):
         raise RuntimeError(f"rejection sampling found only {q.shape[0]} of {num} collision-free configurations")
     st = Kinematics(cfg, compute_spheres=False).compute_kinematics(q.contiguous())
     return st.tool_poses.position[:, 0, 0].clone(), st.tool_poses.quaternion[:, 0, 0].clone()
+
+
+def c3_voxel_world(n: int = 128, voxel_size: float = 0.02) -> Dict:
+    """C3 "UR10 + nvblox ESDF voxel world (128^3)": one fp16 ESDF grid (2.56 m cube at 0.02 m) around
+    the robot, synthesised analytically from the union of a box and a sphere (the reference's
+    voxel suites use the same kind of analytic fields, tests/_src/geom/sdf/test_voxel_collision.py)."""
+    from .scene import voxel_grid_from_sdf
+
+    def sdf(p):
+        qb = np.abs(p - np.array([0.5, 0.0, 0.35])) - np.array([0.2, 0.4, 0.35])
+        box = np.linalg.norm(np.maximum(qb, 0), axis=-1) + np.minimum(qb.max(-1), 0)
+        sp = np.linalg.norm(p - np.array([-0.35, 0.45, 0.6]), axis=-1) - 0.25
+        return np.minimum(box, sp)
+
+    return voxel_grid_from_sdf(sdf, (n, n, n), voxel_size, pose7=(0.0, 0.0, 0.6, 1, 0, 0, 0), max_distance=10.0)
+
+
+def c5_mixed_worlds(num_envs: int, voxels: bool = True, grid: int = 64, seed: int = 5) -> Dict:
+    """C5 "mixed scene": every planning problem has its OWN world -- a table plus 1-3 random cuboids
+    and (``voxels``) one fp16 ESDF grid (``grid``^3 at 0.04 m) holding a sphere obstacle."""
+    from .scene import cuboid_scene_arrays, voxel_grid_from_sdf
+
+    rng = np.random.default_rng(seed)
+    envs, grids = [], []
+    for e in range(num_envs):
+        obs = [{"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}]
+        for _ in range(1 + e % 3):
+            p = rng.uniform([-0.6, -0.6, 0.2], [0.6, 0.6, 0.9])
+            obs.append({"dims": list(rng.uniform(0.1, 0.35, size=3)), "pose": [*p, 1, 0, 0, 0]})
+        envs.append(obs)
+        c = rng.uniform([-0.5, -0.5, 0.3], [0.5, 0.5, 0.8])
+        grids.append(voxel_grid_from_sdf(lambda p, c=c: np.linalg.norm(p - c, axis=-1) - 0.15, (grid,) * 3, 0.04,
+                                         pose7=(0.0, 0.0, 0.6, 1, 0, 0, 0), max_distance=10.0))
+    arrays = cuboid_scene_arrays(envs)
+    if voxels:
+        for k in ("voxel_params", "voxel_inv_pose", "voxel_enable", "voxel_count", "voxel_features"):
+            arrays[k] = np.concatenate([g[k] for g in grids], axis=0)
+        arrays["voxel_max_distance"] = grids[0]["voxel_max_distance"]
+    return arrays

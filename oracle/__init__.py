@@ -5,4 +5,4 @@ this package (see the header of ``oracle/curobo_oracle.c``).  The product packag
 ``curobo_amd`` never imports it.
 """
 
-from .oracle import Oracle, build_oracle, load_oracle  # noqa: F401
+from .oracle import Oracle, build_native_oracle, build_oracle, load_native_oracle, load_oracle  # noqa: F401

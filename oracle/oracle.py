@@ -27,6 +27,23 @@ def build_oracle(force: bool = False) -> str:
     return _LIB
 
 
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+
+
+def build_native_oracle() -> str:
+    """The same C source compiled FOR THE HOST IT RUNS ON (``gcc -O3 -march=native -fopenmp``, SURVEY.md
+    section 8d) -- used only as the timed CPU baseline of bench.py, never as the checker (the checker
+    build keeps -ffp-contract=off so its fp32 results do not depend on the host's FMA support).  Built
+    into oracle/_native/ on the box that runs it (ignored by git and by gpurun: a -march=native object
+    must not travel between machines)."""
+    os.makedirs(_NATIVE_DIR, exist_ok=True)
+    lib = os.path.join(_NATIVE_DIR, "libcurobo_oracle_native.so")
+    if (not os.path.exists(lib)) or os.path.getmtime(lib) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c99", "-fPIC", "-fopenmp", "-fvisibility=hidden",
+                               "-shared", "-o", lib, _SRC, "-lm"])
+    return lib
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -571,6 +588,11 @@ class Oracle:
 
 
 _ORACLE: Optional[Oracle] = None
+
+
+def load_native_oracle() -> Oracle:
+    """bench.py's CPU-baseline leg: the -O3 -march=native build (see build_native_oracle)."""
+    return Oracle(build_native_oracle())
 
 
 def load_oracle() -> Oracle:
