@@ -51,6 +51,7 @@ class KinematicsFusedFunction(Function):
         n_joints = joint_seq.shape[-1]
         ctx.set_materialize_grads(False)
         device = joint_seq.device
+        k.validate_shapes()  # reference :155
         check_float32_tensors(
             device, joint_seq=joint_seq, batch_link_position=batch_link_position,
             batch_link_quaternion=batch_link_quaternion, batch_robot_spheres=batch_robot_spheres,

@@ -82,6 +82,20 @@ class KinematicsParams:
     def device(self):
         return self.fixed_transforms.device
 
+    def validate_shapes(self) -> None:
+        """Cross-field consistency of the CSR tables (reference ``KinematicsParams.validate_shapes``,
+        robot/types/kinematics_params.py:212-248; the reference's ``KinematicsFusedFunction.forward`` calls
+        it before every launch, cuda_ops/kinematics.py:155): sizes of ``link_chain_offsets``,
+        ``joint_links_offsets`` and ``joint_affects_endeffector`` against the link / dof / tool-frame counts."""
+        L, D, T = int(self.fixed_transforms.shape[0]), int(self.num_dof), len(self.tool_frames)
+        if self.link_chain_offsets is not None and self.link_chain_offsets.shape[0] != L + 1:
+            raise ValueError(f"link_chain_offsets.size(0) = {self.link_chain_offsets.shape[0]}, expected num_links + 1 = {L + 1}")
+        if self.joint_links_offsets is not None and self.joint_links_offsets.shape[0] != D + 1:
+            raise ValueError(f"joint_links_offsets.size(0) = {self.joint_links_offsets.shape[0]}, expected num_dof + 1 = {D + 1}")
+        if self.joint_affects_endeffector is not None and self.joint_affects_endeffector.numel() != D * T:
+            raise ValueError(f"joint_affects_endeffector.numel() = {self.joint_affects_endeffector.numel()}, expected "
+                             f"num_dof * n_tool_frames = {D} * {T} = {D * T}")
+
     @staticmethod
     def from_model(model: RobotModel, device) -> "KinematicsParams":
         def up(a, dtype=None):

@@ -189,3 +189,22 @@ def test_kinematics_params_from_model_on_cpu(robot):
     assert sorted(kin.link_level_data.long().tolist()) == list(range(L))
     pairs = kin.self_collision.collision_pairs
     assert pairs.shape[1] == 2 and int(pairs.max()) < kin.num_spheres
+
+
+def test_kinematics_params_validate_shapes():
+    """reference KinematicsParams.validate_shapes (robot/types/kinematics_params.py:212-248)"""
+    import dataclasses
+
+    import torch
+
+    from curobo_amd.robot import load_packaged_robot
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+
+    k = KinematicsParams.from_model(load_packaged_robot("franka"), torch.device("cpu"))
+    k.validate_shapes()
+    with pytest.raises(ValueError, match="link_chain_offsets"):
+        dataclasses.replace(k, link_chain_offsets=k.link_chain_offsets[:-1]).validate_shapes()
+    with pytest.raises(ValueError, match="joint_links_offsets"):
+        dataclasses.replace(k, joint_links_offsets=k.joint_links_offsets[:-1]).validate_shapes()
+    with pytest.raises(ValueError, match="joint_affects_endeffector"):
+        dataclasses.replace(k, joint_affects_endeffector=k.joint_affects_endeffector.reshape(-1)[:-1]).validate_shapes()

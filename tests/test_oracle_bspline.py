@@ -168,3 +168,92 @@ def test_trajectory_seed_generator_matches_reference_golden():
     np.testing.assert_allclose(out[:, :, -1].numpy(), g["goal"], atol=1e-7)
     with pytest.raises(ValueError):
         gen.generate_interpolated_seeds(torch.as_tensor(g["start"]), torch.as_tensor(g["goal"][:, :2]), S)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pins from outside the repository (tests/golden/make_bspline_golden.py): the reference's own
+# derivation script for the fixed-knot coefficients + scipy.interpolate.BSpline for the basis.
+# ---------------------------------------------------------------------------------------------
+def _bspline_golden():
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    return np.load(os.path.join(GOLDEN_DIR, "bspline_golden.npz"))
+
+
+def _table_from_source(path, name_regex, rows, cols):
+    """the float table `name` of a C / HIP source as an array (entries are literals like -3.0f / 2.0f)"""
+    import re
+
+    text = open(path).read()
+    m = re.search(name_regex + r"[^=]*=\s*\{(.*?)\};", text, flags=re.S)
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", m.group(1))
+    vals = [eval(tok.replace("f", "")) for tok in re.findall(r"-?[0-9.]+f(?:\s*/\s*[0-9.]+f)?", body)]  # noqa: S307
+    return np.array(vals, np.float64).reshape(rows, cols)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_fixed_knot_tables_equal_the_reference_derivation(degree):
+    """kFix3/4/5 (HIP) and c3/c4/c5 (oracle) == the coefficients the reference's derivation script
+    produces (bspline_boundary_coefficients.py, run by the golden generator); the cubic's jerk row is
+    zero in the reference table (bspline_boundary_constraint.cuh:61) although derivable."""
+    import os
+
+    from conftest import ROOT
+
+    gold = _bspline_golden()
+    want = gold[f"coeffs_table_{degree}"]
+    hip = _table_from_source(os.path.join(ROOT, "curobo_amd", "csrc", "bspline_device.hpp"), rf"kFix{degree}\[4\]\[{degree + 1}\]", 4, degree + 1)
+    orc = _table_from_source(os.path.join(ROOT, "oracle", "curobo_oracle.c"), rf"c{degree}\[4\]\[{degree + 1}\]", 4, degree + 1)
+    np.testing.assert_allclose(hip, want, atol=5e-7)  # -0.833333f is the reference's own truncation of -5/6
+    np.testing.assert_allclose(orc, want, atol=5e-7)
+    if degree == 3:
+        np.testing.assert_allclose(gold["coeffs_3"][3], [0, 0, 0, 1], atol=1e-12)
+
+
+@pytest.mark.parametrize("implicit", [0, 1])
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_whole_trajectory_matches_scipy_bspline(degree, implicit, oracle):
+    """position / velocity / acceleration / jerk at EVERY sample vs scipy.interpolate.BSpline on the
+    control sequence [fixed start knots | free knots | replicated last knot or fixed goal knots]
+    (float64; fixed knots from the reference-derived coefficients)."""
+    gold = _bspline_golden()
+    key = f"d{degree}_g{implicit}"
+    n, dof, interp, dt, H = gold[key + "_meta"]
+    n, dof, interp, H = int(n), int(dof), int(interp), int(H)
+    u = gold[key + "_u"].astype(np.float32)
+    names = ("position", "velocity", "acceleration", "jerk")
+    start = {k: gold[key + "_start"][i][None].astype(np.float32) for i, k in enumerate(names)}
+    goal = {k: gold[key + "_goal"][i][None].astype(np.float32) for i, k in enumerate(names)}
+    idx = np.zeros(u.shape[0], np.int32)
+    out = oracle.bspline_forward(u, start, goal, idx, idx, np.array([dt], np.float32), np.array([implicit], np.uint8), H, degree)
+    want = gold[key + "_out"]
+    for i, k in enumerate(names):
+        scale = max(1.0, np.abs(want[i]).max())
+        np.testing.assert_allclose(out[k], want[i], atol=2e-5 * scale * (10.0 ** i), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_basis_functions_match_scipy(degree, oracle):
+    """interior segments (no boundary knots involved): samples = sum_i u[seg - support + i] N_i(t) with
+    scipy's N_i and its derivatives"""
+    gold = _bspline_golden()
+    basis, ts = gold[f"basis_{degree}"], gold["basis_t"]
+    sup, interp, dt = degree + 1, 8, 0.05
+    n = 3 * sup
+    rng = np.random.default_rng(degree)
+    u = rng.normal(size=(1, n, 2)).astype(np.float32)
+    z = {k: np.zeros((1, 2), np.float32) for k in ("position", "velocity", "acceleration", "jerk")}
+    idx = np.zeros(1, np.int32)
+    H = (n + sup) * interp + 1
+    out = oracle.bspline_forward(u, z, z, idx, idx, np.array([dt], np.float32), np.array([0], np.uint8), H, degree)
+    knot_dt = dt * interp
+    for seg in range(sup, n):  # segments whose support lies inside the free knots
+        for ti in range(interp):
+            h = seg * interp + ti
+            assert abs(ts[ti] - ti / interp) < 1e-12
+            ctrl = u[0, seg - sup:seg].astype(np.float64)  # [support, dof]
+            for der, k in enumerate(("position", "velocity", "acceleration", "jerk")):
+                want = basis[der, ti] @ ctrl / knot_dt ** der
+                np.testing.assert_allclose(out[k][0, h], want, atol=1e-5 * max(1.0, np.abs(want).max()) * 3.0 ** der)
