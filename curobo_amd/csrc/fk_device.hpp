@@ -48,6 +48,15 @@ __device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst
   d4[0] = c0; d4[1] = c1; d4[2] = c2; d4[3] = c3;
 }
 
+// ds_read_b32 + wait as one opaque unit (LDS operations of a wave execute in issue order, so the read sees
+// every earlier ds_write of the wave)
+__device__ __forceinline__ float lds_read_f32_now(const float *p) {
+  float v;
+  const uint32_t a = (uint32_t)(uintptr_t)p;  // LDS pointers: the low 32 bits are the LDS byte address
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+
 // Serial chain of ONE point, executed by its 16-lane group without any barrier (lane 4r+c owns
 // element (r, c) of every cumulative 3x4; a lane only re-reads entries it wrote itself, the three
 // rotation entries of its row come from its DPP quad).  `local` holds the point's column-major
@@ -61,9 +70,10 @@ __device__ __forceinline__ void fk_chain_16(float *__restrict__ cumul, const flo
   if (owner) cumul[lane] = cur;
   const float *my_local = local + c * 4;
   for (int l = 1; l < L; l++) {
-    const int par = parent[l];
+    const int par = __builtin_amdgcn_readfirstlane(parent[l]);
     float p = cur;
-    if (par != l - 1) p = owner ? cumul[par * 12 + lane] : 0.0f;
+    if (par != l - 1) p = lds_read_f32_now(cumul + par * 12 + lane);  // see fk_chain_16_multi
+    p = owner ? p : 0.0f;
     const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
     const float4 m = *reinterpret_cast<const float4 *>(my_local + l * 16);
     cur = a0 * m.x + a1 * m.y + a2 * m.z + (c == 3 ? a3 : 0.0f);
@@ -95,7 +105,9 @@ __device__ __forceinline__ void fk_chain_16_multi(float *const (&cumul)[N], cons
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const int l = l0 + u < L ? l0 + u : L - 1;
-      par[u] = parent[l];
+      // the parent table is the same for every lane: a scalar value makes `par != l - 1` a scalar branch
+      // (no exec-mask round trip, no VGPR compare on the dependent path of the chain)
+      par[u] = __builtin_amdgcn_readfirstlane(parent[l]);
 #pragma unroll
       for (int n = 0; n < N; n++) m[u][n] = *reinterpret_cast<const float4 *>(local[n] + c * 4 + l * 16);
     }
@@ -106,7 +118,13 @@ __device__ __forceinline__ void fk_chain_16_multi(float *const (&cumul)[N], cons
 #pragma unroll
         for (int n = 0; n < N; n++) {
           float p = cur[n];
-          if (par[u] != l - 1) p = owner ? cumul[n][par[u] * 12 + lane] : 0.0f;
+          // A parent that is not the previous link (tree branches) is re-read from LDS.  The read sits in an
+          // opaque asm block with its own wait so that it stays behind a real scalar branch: as plain C++ the
+          // compiler if-converts it into an exec-masked load followed by an UNCONDITIONAL s_waitcnt
+          // lgkmcnt(0), and every step of the chain then also waits for the previous step's ds_write
+          // (LDS returns in order) -- a full LDS round trip per link on the dependent path.
+          if (par[u] != l - 1) p = lds_read_f32_now(cumul[n] + par[u] * 12 + lane);
+          p = owner ? p : 0.0f;
           const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
           cur[n] = a0 * m[u][n].x + a1 * m[u][n].y + a2 * m[u][n].z + (c == 3 ? a3 : 0.0f);
           if (owner) cumul[n][l * 12 + lane] = cur[n];

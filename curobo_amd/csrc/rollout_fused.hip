@@ -929,13 +929,17 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   // the same instruction stream; that point's spheres are then shared by the lanes of its wave.
   for (int h = grp; h < H_main; h += ngroups) {
     const bool extra = n_left > 0 && h == grp && grp < n_left;
-    const int hx = H_main + grp;
+    // uniform over the wave: a wave with a leftover row walks two chains in ALL its rows (the other rows
+    // repeat their own point: same values to the same slots) -- with a per-row branch the wave executed the
+    // two-chain stream for row 0 and then the one-chain stream for rows 1-3, back to back
+    const bool wave_extra = n_left > 0 && h < ngroups && (grp & ~3) < n_left;
+    const int hx = extra ? H_main + grp : h;
     point_fk_locals(c, h, lane);
     if (extra) point_fk_locals(c, hx, lane);
     CUROBO_STAMP(8);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (extra) {
+    if (wave_extra) {
       float *const cm[2] = {c.cumul + (size_t)h * L * 12, c.cumul + (size_t)hx * L * 12};
       const float *const lc[2] = {c.work + (size_t)h * c.ws, c.work + (size_t)hx * c.ws};
       fk_chain_16_multi<2>(cm, lc, c.parent, c.fixed, L, lane);
@@ -959,6 +963,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     if (lane64 < cnt) reinterpret_cast<float4 *>(c.work + (size_t)(H_main + lo + lane64) * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
   }
   CUROBO_STAMP(11);
+  if (tid == 0) *c.key = 0ull;
   __syncthreads();
   CUROBO_STAMP(2);
 
@@ -967,6 +972,10 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   // Row r of wave w takes point w + r * nwaves of the round (not 4 * w + r): points deep in collision
   // come in runs along the trajectory, and a wave is as slow as the sum of its rows' scene work.
   const int row_stride = ngroups >> 2;
+  // A single leftover point (H = 33 / 65 on 32 / 64 rows) is folded into the main round instead of a
+  // barrier - all threads - barrier - fold section: its pair list is sliced over the rows, its scene cost is
+  // evaluated by row 0 with the link-mask culling of an ordinary point, nothing is handed over through LDS.
+  const bool fold_left = n_left == 1;
   for (int h0 = 0; h0 < H_main; h0 += ngroups) {
     const int h = h0 + (grp & 3) * row_stride + (grp >> 2);
     const bool valid = h < H_main;
@@ -1013,6 +1022,18 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
         if (lane == 0) cost_pt += self_pair_apply(c, h, m, kmin);
       }
     }
+    if (fold_left && a.use_self && h0 == 0) {
+      // this row's slice of the ONE leftover point's pair list; the arg-max meets in c.key (integer max of
+      // (penetration, lowest pair index): order independent) and is applied by row 0 after the barrier
+      const float4 *sphl = c.spheres(H_main);
+      float bl = 0.0f;
+      int kl = 0x7fffffff;
+      for (int k = grp * kFkLanes + lane; k < P; k += ngroups * kFkLanes) {
+        const float f = staged_pair_penetration(sphl, c.pairs[k]);
+        if (f > bl) { bl = f; kl = k; }
+      }
+      if (bl > 0.0f) atomicMax(c.key, pair_key(bl, kl));
+    }
     const bool stamp_pt = (!TERMS || kStampTerms) && a.prof && lane == 0 && h == (b % H);
     if (stamp_pt) a.prof[(size_t)b * 16 + 5] = wall_clock64();
     if (valid && lane == 0) { c.cost[h] = cost_pt; c.flag[h] = any_grad ? 1 : 0; }
@@ -1044,7 +1065,52 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     }
     if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
   }
-  for (int h = H_main; h < H; h++) {  // leftover points, all threads on one point
+  if (fold_left) {
+    CUROBO_STAMP(7);
+    const int h = H_main;
+    if (a.use_scene && (tid >> 6) == 0) {  // wave 0 stays converged for the wave-level fences; row 0 works
+      const bool mine = grp == 0;
+      if (mine) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
+      if (mine) {
+        const float *wr = c.wrench + (size_t)h * c.wl;
+        float cost_scene = 0.0f;
+        bool any_scene = false;
+        for (int s0 = 0; s0 < S; s0 += kFkLanes) {
+          const int s = s0 + lane;
+          float d = 0.0f;
+          f3 g = make_f3(0.f, 0.f, 0.f);
+          float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
+          const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+          if (s < S && (mask != 0u || n_rec > 32)) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
+          cost_scene += d;
+          // serialised over the contributing lanes of THIS row (lanes of the other rows contribute nothing)
+          unsigned long long m = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f) & 0xffffull;
+          any_scene = any_scene || m != 0ull;
+          if (m) {
+            const int l = c.sph_link[s < S ? s : 0];
+            const float *C = c.cumul + (size_t)h * c.L * 12 + l * 12;
+            const f3 t = cross(make_f3(c4.x, c4.y, c4.z) - make_f3(C[3], C[7], C[11]), g);
+            float *w = c.wrench + (size_t)h * c.wl + l * kWrench;
+            while (m) {
+              const int src = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              if (lane64 == src) {
+                atomicAdd(w + 0, g.x); atomicAdd(w + 1, g.y); atomicAdd(w + 2, g.z);
+                atomicAdd(w + 3, t.x); atomicAdd(w + 4, t.y); atomicAdd(w + 5, t.z);
+              }
+            }
+          }
+        }
+        cost_scene = row16_sum(cost_scene);
+        if (lane == 0) { c.cost[h] = cost_scene; c.flag[h] = any_scene ? 1 : 0; }
+      }
+    } else if (tid == 0) {
+      c.cost[h] = 0.0f;
+      c.flag[h] = 0;
+    }
+    if (!a.use_scene && tid == 0) { c.cost[h] = 0.0f; c.flag[h] = 0; }
+  }
+  for (int h = H_main; h < H && !fold_left; h++) {  // several leftover points: all threads on one point at a time
     if (tid == 0) *c.key = 0ull;
     __syncthreads();
     if (h == H_main) CUROBO_STAMP(7);
@@ -1089,6 +1155,13 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     }
   }
   __syncthreads();  // the passes below take point h on row h % rows: another wave than the cost pass above
+  if (fold_left && a.use_self && grp == 0) {
+    const unsigned long long key = *c.key;
+    if (key != 0ull && lane == 0) {
+      c.cost[H_main] += self_pair_apply(c, H_main, __uint_as_float((uint32_t)(key >> 32)), (int)(0x7fffffffu - (uint32_t)key));
+      c.flag[H_main] = 1;
+    }
+  }
   CUROBO_STAMP(15);
   // further passes over all points, leftover ones included (their own loops so that the register
   // allocation of the collision pass above is not shared with the optional terms, and so that those
