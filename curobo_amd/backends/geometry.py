@@ -4,9 +4,38 @@
 
 from __future__ import annotations
 
+from typing import Dict, Optional, Tuple
+
+import numpy as np
 import torch
 
 from .._lib import check, current_stream, load, ptr
+
+#: pair lists at least this long AND at least this dense (enabled / possible pairs) run on the register-tiled
+#: bitmap kernel (humanoids); arms keep the LDS pair-list kernels
+DENSE_MIN_PAIRS, DENSE_MIN_DENSITY = 8192, 0.25
+_bitmap_cache: Dict[Tuple[int, int, int, str], Optional[Tuple[torch.Tensor, int]]] = {}
+
+
+def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[torch.Tensor, int]]:
+    """(bitmap uint32 [2 * nslots, nslots * 64] on the pairs' device, nslots) for
+    ``curobo_hip_self_collision_distance_dense`` -- bit jj of bitmap[jb, i] <-> pair (i, 32 * jb + jj) -- or ``None``
+    when the list is not (i, j)-sorted with i < j (then "lowest pair index" is not the lexicographic order the
+    dense kernel resolves ties by).  Built once per pair tensor (one host read-back: call outside graph capture)."""
+    key = (pair_locations.data_ptr(), int(pair_locations.shape[0]), int(nspheres), str(pair_locations.device))
+    if key in _bitmap_cache:
+        return _bitmap_cache[key]
+    p = pair_locations.detach().cpu().numpy().astype(np.int64).reshape(-1, 2)
+    i, j = p[:, 0], p[:, 1]
+    ok = bool((i < j).all() and (i >= 0).all() and (j < nspheres).all() and (np.diff(i * 65536 + j) > 0).all())
+    res = None
+    if ok:
+        nslots = 4 * ((nspheres + 255) // 256)
+        bm = np.zeros((2 * nslots, nslots * 64), np.uint32)
+        np.bitwise_or.at(bm, (j // 32, i), (np.uint32(1) << (j % 32).astype(np.uint32)))
+        res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots)
+    _bitmap_cache[key] = res
+    return res
 
 
 def self_collision_distance(
@@ -30,6 +59,14 @@ def self_collision_distance(
     compute_grad: bool,
 ):
     """Max sphere-pair penetration per point; modifies the output tensors in place."""
+    if (not store_pair_distance and num_collision_pairs >= DENSE_MIN_PAIRS and nspheres <= 1024
+            and num_collision_pairs >= DENSE_MIN_DENSITY * 0.5 * nspheres * (nspheres - 1)):
+        bm = pair_bitmap(pair_locations, nspheres)
+        if bm is not None:
+            check(load().curobo_hip_self_collision_distance_dense(
+                ptr(out_distance), ptr(out_vec), ptr(sparse_index), ptr(robot_spheres), ptr(sphere_padding), ptr(weight),
+                ptr(bm[0]), batch_size, horizon, nspheres, bm[1], int(compute_grad), current_stream(out_distance)))
+            return
     check(load().curobo_hip_self_collision_distance(
         ptr(out_distance), ptr(out_vec), ptr(pair_distance), ptr(sparse_index), ptr(robot_spheres),
         ptr(sphere_padding), ptr(weight), ptr(pair_locations), ptr(block_batch_max_value),

@@ -225,6 +225,157 @@ __global__ void __launch_bounds__(256) self_collision_row16_kernel(const SelfCol
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Dense pair sets (humanoids: Unitree G1 has 162 k of the 227 k possible pairs of its 674 spheres).
+// A pair LIST costs two 16-byte LDS gathers + an index per pair test; here the pair set is a BITMAP
+// over the (i, j) matrix and the test is register tiled: a wave owns one point, lane l holds
+// spheres i = 64 * slot + l of a group of G slots in registers, sphere j is ONE broadcast LDS read
+// shared by G x 64 pair tests, and bit (i, j) masks the result (a disabled pair contributes +0,
+// which never beats the running maximum >= 0).  Upper triangle only: a slot group starts at the
+// first 32-sphere block that can hold a j above its smallest i.  Packed fp32 arithmetic on slot
+// pairs.  The arg-max is tracked per (slot, 32-block) and resolved to the lexicographically first
+// (i, j) among equal maxima -- the lowest index of the (i, j)-sorted pair_locations, i.e. the same
+// tie rule as the list kernels.  bitmap[jb][i] (uint32, bit jj <-> pair (i, 32 jb + jj)) is built
+// once per robot by the caller (curobo_amd/backends/geometry.py, from pair_locations).
+struct SelfDenseArgs {
+  float *out_distance;
+  float *out_gradient;
+  uint8_t *sparse_index;
+  const float *robot_spheres;
+  const float *offsets;
+  const float *weight;
+  const uint32_t *bitmap;  // [2 * nslots][nslots * 64]
+  int n_points, nspheres, nslots, write_grad;
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// penetration of spheres (a, b) of two slots against sphere j, masked by bit jj of the slots' words
+__device__ __forceinline__ v2f dense_pair2(v2f x, v2f y, v2f z, v2f r, float4 sj) {
+  const v2f dx = x - sj.x, dy = y - sj.y, dz = z - sj.z, rr = r + sj.w;
+  return rr * rr - (dx * dx + dy * dy + dz * dz);
+}
+__device__ __forceinline__ float mask_f(float v, uint32_t word, int jj) {  // v if bit jj of word else +0
+  const int m = __builtin_amdgcn_sbfe((int)word, jj, 1);  // 0 or -1
+  return __int_as_float(__float_as_int(v) & m);
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) self_collision_dense_kernel(const SelfDenseArgs a) {
+  static_assert(G == 4, "slot groups of four (two packed pairs)");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.nspheres, NS = a.nslots, SL = NS * 64, NB = NS * 2;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  float4 *sph = reinterpret_cast<float4 *>(smem) + (size_t)wave * SL;
+  const int n = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (n >= a.n_points) return;  // waves are independent: only wave-level fences below
+  const float qnan = __builtin_nanf("");
+  {  // spheres (+ padding) -> this wave's LDS slot; disabled / padding spheres carry a NaN radius (lose every max)
+    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
+    for (int s = lane; s < SL; s += kWave) {
+      float4 v = make_float4(0.f, 0.f, 0.f, qnan);
+      if (s < S) {
+        v = src[s];
+        v.w += a.offsets[s];
+        if (!(v.w >= 0.0f)) v.w = qnan;  // pair_penetration: pairs with a negative (padded) radius contribute 0
+        if (a.sparse_index[(size_t)n * S + s]) {
+          reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a.sparse_index[(size_t)n * S + s] = 0;
+        }
+      }
+      sph[s] = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float best = 0.0f;
+  int best_code = -1;  // slot * NB + jb of the first (slot-major, then block) 32-block that attains `best`
+  for (int g0 = 0; g0 < NS; g0 += G) {
+    float4 own[G];
+#pragma unroll
+    for (int t = 0; t < G; t++) own[t] = g0 + t < NS ? sph[(g0 + t) * 64 + lane] : make_float4(0.f, 0.f, 0.f, qnan);
+    const v2f x01 = {own[0].x, own[1].x}, y01 = {own[0].y, own[1].y}, z01 = {own[0].z, own[1].z}, r01 = {own[0].w, own[1].w};
+    const v2f x23 = {own[2].x, own[3].x}, y23 = {own[2].y, own[3].y}, z23 = {own[2].z, own[3].z}, r23 = {own[2].w, own[3].w};
+    float gbest[G] = {0.f, 0.f, 0.f, 0.f};
+    int gjb[G] = {0, 0, 0, 0};
+    for (int jb = 2 * g0; jb < NB; jb++) {
+      uint32_t w[G];
+#pragma unroll
+      for (int t = 0; t < G; t++) w[t] = g0 + t < NS ? a.bitmap[(size_t)jb * SL + (g0 + t) * 64 + lane] : 0u;
+      if (__ballot((w[0] | w[1] | w[2] | w[3]) != 0u) == 0ull) continue;  // no enabled pair in this tile (uniform)
+      const float4 *sj = sph + jb * 32;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (__ballot((w[0] & w[1] & w[2] & w[3]) != 0xffffffffu) == 0ull) {
+        // every pair of the tile is enabled (spheres of links far apart in the tree): no mask arithmetic
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++) {
+          const float4 s = sj[jj];
+          const v2f p01 = dense_pair2(x01, y01, z01, r01, s), p23 = dense_pair2(x23, y23, z23, r23, s);
+          b0 = fmaxf(b0, p01.x);
+          b1 = fmaxf(b1, p01.y);
+          b2 = fmaxf(b2, p23.x);
+          b3 = fmaxf(b3, p23.y);
+        }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++) {
+          const float4 s = sj[jj];
+          const v2f p01 = dense_pair2(x01, y01, z01, r01, s), p23 = dense_pair2(x23, y23, z23, r23, s);
+          b0 = fmaxf(b0, mask_f(p01.x, w[0], jj));
+          b1 = fmaxf(b1, mask_f(p01.y, w[1], jj));
+          b2 = fmaxf(b2, mask_f(p23.x, w[2], jj));
+          b3 = fmaxf(b3, mask_f(p23.y, w[3], jj));
+        }
+      }
+      const float bb[G] = {b0, b1, b2, b3};
+#pragma unroll
+      for (int t = 0; t < G; t++)
+        if (bb[t] > gbest[t]) { gbest[t] = bb[t]; gjb[t] = jb; }  // strict: the first block of a slot wins ties
+    }
+#pragma unroll
+    for (int t = 0; t < G; t++)
+      if (gbest[t] > best) { best = gbest[t]; best_code = (g0 + t) * NB + gjb[t]; }  // strict: the lowest slot wins ties
+  }
+  // ---- arg-max over the wave; lanes that attain it look up the first j of their winning block
+  float m = best;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  int key = 0x7fffffff;
+  if (m > 0.0f && best == m) {
+    const int slot = best_code / NB, jb = best_code - slot * NB;
+    const float4 o = sph[slot * 64 + lane];
+    const uint32_t word = a.bitmap[(size_t)jb * SL + slot * 64 + lane];
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, orr = {o.w, o.w};
+    float bv = 0.0f;
+    int bj = -1;
+    for (int jj = 0; jj < 32; jj++) {
+      const float v = mask_f(dense_pair2(ox, oy, oz, orr, sph[jb * 32 + jj]).x, word, jj);
+      if (v > bv) { bv = v; bj = jb * 32 + jj; }
+    }
+    if (bj >= 0) key = ((slot * 64 + lane) << 10) | bj;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, kWave));
+  if (lane != 0) return;
+  if (!(m > 0.0f) || key == 0x7fffffff) {
+    a.out_distance[n] = 0.0f;
+    return;
+  }
+  const float wgt = a.weight[0];
+  a.out_distance[n] = 0.5f * wgt * m;
+  if (a.write_grad) {
+    const int i = key >> 10, j = key & 1023;
+    const float4 s1 = sph[i], s2 = sph[j];
+    const float vx = wgt * (s2.x - s1.x), vy = wgt * (s2.y - s1.y), vz = wgt * (s2.z - s1.z);
+    float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
+    g[i] = make_float4(vx, vy, vz, wgt * -1.0f);
+    g[j] = make_float4(-1.0f * vx, -1.0f * vy, -1.0f * vz, wgt * -1.0f);
+    a.sparse_index[(size_t)n * S + i] = 1;
+    a.sparse_index[(size_t)n * S + j] = 1;
+  }
+}
+
 template <int NWAVES>
 static void launch_self(const SelfCollArgs &a, int blocks, size_t lds, int ppw, int tile, hipStream_t st) {
   if (a.store_pair_distance)
@@ -279,5 +430,34 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
     if (lds8 <= 64 * 1024) launch_self<8>(a, (int)ceil_div_l(n_points, 8), lds8, 1, tile, st);
     else launch_self<4>(a, (int)ceil_div_l(n_points, 4), (size_t)4 * nspheres * 16 + (size_t)tile * 4, 1, tile, st);
   }
+  return check_launch(what, st);
+}
+
+
+CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
+    float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
+    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, int batch_size, int horizon,
+    int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream) {
+  const char *what = "self_collision_distance_dense";
+  CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 1024, "%s: nspheres=%d out of range [1,1024]", what, nspheres);
+  CUROBO_REQUIRE(nslots >= 1 && nslots * 64 >= nspheres && nslots % 4 == 0 && nslots <= 16,
+                 "%s: nslots=%d must be a multiple of 4 with nslots * 64 >= nspheres (<= 16)", what, nslots);
+  CUROBO_REQUIRE(pair_bitmap != nullptr, "%s: pair_bitmap is NULL", what);
+  const long n_points = (long)batch_size * horizon;
+  if (n_points == 0) return CUROBO_HIP_OK;
+  SelfDenseArgs a{};
+  a.out_distance = out_distance; a.out_gradient = out_vec; a.sparse_index = sparse_index;
+  a.robot_spheres = robot_spheres; a.offsets = sphere_padding; a.weight = weight; a.bitmap = pair_bitmap;
+  a.n_points = (int)n_points; a.nspheres = nspheres; a.nslots = nslots; a.write_grad = compute_grad;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds_wave = (size_t)nslots * 64 * 16;
+  const int waves = lds_wave * 4 <= 64 * 1024 ? 4 : (lds_wave * 2 <= 64 * 1024 ? 2 : 1);
+  const size_t lds = lds_wave * waves;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((self_collision_dense_kernel<4>), dim3((unsigned)ceil_div_l(n_points, waves)), dim3(waves * 64), lds, st, a);
   return check_launch(what, st);
 }

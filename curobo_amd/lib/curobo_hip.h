@@ -112,6 +112,18 @@ int curobo_hip_self_collision_distance(
     int num_collision_pairs, int store_pair_distance, int compute_grad,
     curobo_hip_stream_t stream);
 
+/* Dense pair sets (humanoids: most of the S (S - 1) / 2 sphere pairs are enabled): the same result as
+ * curobo_hip_self_collision_distance without store_pair_distance, from a register-tiled all-pairs pass masked by a
+ * bitmap of the pair set instead of a gather per listed pair.  pair_bitmap: uint32 [2 * nslots][nslots * 64], bit jj
+ * of pair_bitmap[jb][i] <-> pair (i, 32 * jb + jj) of pair_locations (i < j; the list must be (i, j)-sorted so
+ * that "lowest pair index" = lexicographically first pair); nslots = multiple of 4 with nslots * 64 >= nspheres.
+ * reference: self_collision_max_block_kernel + _max_reduce_kernel, self_collision_kernel.cuh:113-297.
+ */
+int curobo_hip_self_collision_distance_dense(
+    float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
+    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, int batch_size, int horizon,
+    int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- collision: sphere vs scene
  * The reference has NO backend hook here: these are NVIDIA Warp kernels launched from
  * geom/collision/wp_autograd.py:37-249 (SphereObstacleCollision / SweptSphereObstacleCollision).

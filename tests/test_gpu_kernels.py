@@ -456,3 +456,53 @@ def test_levenberg_marquardt_step_mfma(dof, n_res, oracle, device):
     A = np.einsum("brd,bre->bde", J64, J64) + lam[:, None, None].astype(np.float64) * np.eye(dof)
     delta = np.linalg.solve(A, -g64[..., None])[..., 0]
     np.testing.assert_allclose(q_out.cpu().numpy() - q, delta, rtol=5e-3, atol=1e-3 * np.abs(delta).max())
+
+
+def test_self_collision_dense_bitmap_kernel_c4_size(oracle, device):
+    """BASELINE config 4 at full size: Unitree G1 (674 spheres, 162 111 pairs), 1024 seeds x 8 points through the
+    register-tiled bitmap kernel (the drop-in entry point picks it for dense pair sets) vs the oracle and vs the
+    LDS pair-list kernel: exact colliding-sphere flags, stale gradient rows cleared, disabled spheres ignored."""
+    from curobo_amd._lib import check, current_stream, load, ptr
+    from curobo_amd.backends import geometry as G
+
+    model = load_model("unitree_g1")
+    kp = _kp(model, device)
+    B, H = 1024, 8
+    n = B * H
+    S, P = model.num_spheres, model.collision_pairs.shape[0]
+    q = sample_q(model, n, seed=17, scale=0.6)
+    sph = oracle.kinematics_forward(q, model.as_dict())["robot_spheres"].copy()
+    sph[5, 100, 3] = -0.5   # a disabled sphere (negative radius): its pairs must not count
+    sph[6, 0:40, 3] = -1.0
+    stale_grad = np.zeros((n, S, 4), np.float32)
+    stale_flag = np.zeros((n, S), np.uint8)
+    stale_grad[::7, 11] = 3.0
+    stale_flag[::7, 11] = 1
+    ref = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 2.5, out_gradient=stale_grad.copy(),
+                                sparse_index=stale_flag.copy())
+    assert 0.05 < (ref["distance"] > 0).mean() < 0.95
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    w = torch.tensor([2.5], device=device)
+    sc = kp.self_collision
+    assert G.pair_bitmap(sc.collision_pairs, S) is not None
+
+    def run(dense):
+        out_d, out_g, flags = torch.full((n, 1), -1.0, device=device), t(stale_grad.copy()), t(stale_flag.copy())
+        if dense:  # the drop-in signature (dispatches to curobo_hip_self_collision_distance_dense)
+            G.self_collision_distance(out_d, out_g, torch.zeros(1, device=device), flags, t(sph), sc.sphere_padding, w, sc.collision_pairs,
+                                      torch.zeros(1, device=device), torch.zeros(2, dtype=torch.int16, device=device), 1, 256, B, H, S, P,
+                                      False, True)
+        else:
+            check(load().curobo_hip_self_collision_distance(
+                ptr(out_d), ptr(out_g), None, ptr(flags), ptr(t(sph)), ptr(sc.sphere_padding), ptr(w), ptr(sc.collision_pairs), None, None,
+                1, 256, B, H, S, P, 0, 1, current_stream(out_d)))
+        torch.cuda.synchronize()
+        return out_d.cpu().numpy()[:, 0], out_g.cpu().numpy(), flags.cpu().numpy()
+
+    d1, g1, f1 = run(True)
+    d0, g0, f0 = run(False)
+    assert np.array_equal(f1, ref["sparse_index"]) and np.array_equal(f0, f1), "collision-pair indices must be exact"
+    np.testing.assert_allclose(d1, ref["distance"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(g1, ref["gradient"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(d1, d0, atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(g1, g0, atol=1e-6, rtol=1e-6)
