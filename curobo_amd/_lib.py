@@ -35,6 +35,8 @@ class Scene(C.Structure):
         ("voxel_params", C.c_void_p), ("voxel_inv_pose", C.c_void_p), ("voxel_enable", C.c_void_p),
         ("voxel_count", C.c_void_p), ("voxel_features", C.c_void_p), ("max_voxel_grids", C.c_int32),
         ("voxel_n_voxels", C.c_int32), ("voxel_max_distance", C.c_float),
+        ("voxel_coarse_min", C.c_void_p), ("voxel_coarse_block", C.c_int32), ("voxel_coarse_dilate", C.c_int32),
+        ("voxel_n_coarse", C.c_int32),
     ]
 
 

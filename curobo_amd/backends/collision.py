@@ -27,6 +27,9 @@ def make_scene(
     voxel_count: Optional[torch.Tensor] = None,
     voxel_features: Optional[torch.Tensor] = None,
     voxel_max_distance: float = 10000.0,
+    voxel_coarse_min: Optional[torch.Tensor] = None,
+    voxel_coarse_block: int = 0,
+    voxel_coarse_dilate: int = 0,
 ) -> Scene:
     """Pack device tensors into the ``curobo_hip_scene`` struct (host side, plain pointers).
 
@@ -51,7 +54,42 @@ def make_scene(
         s.max_voxel_grids = voxel_params.shape[1]
         s.voxel_n_voxels = voxel_features.numel() // (voxel_params.shape[0] * voxel_params.shape[1])
         s.voxel_max_distance = float(voxel_max_distance)
+        if voxel_coarse_min is not None:  # optional culling aid, see build_voxel_coarse_min
+            assert voxel_coarse_min.dtype == torch.float16 and voxel_coarse_block >= 1 and voxel_coarse_dilate >= 1
+            s.voxel_coarse_min = ptr(voxel_coarse_min)
+            s.voxel_coarse_block, s.voxel_coarse_dilate = int(voxel_coarse_block), int(voxel_coarse_dilate)
+            s.voxel_n_coarse = voxel_coarse_min.numel() // (voxel_params.shape[0] * voxel_params.shape[1])
     return s
+
+
+def build_voxel_coarse_min(voxel_features: torch.Tensor, voxel_params, block: int = 4, dilate: int = 3) -> torch.Tensor:
+    """fp16 [E, n, n_coarse]: per grid the ESDF minimum over every ``block``^3 block of voxels dilated by ``dilate``
+    voxels (``curobo_hip_scene.voxel_coarse_min``).  ``voxel_params`` [E, n, 4] = (nx, ny, nz, voxel_size) on the
+    host.  A min-pool on the device (scene upload time, not the hot path); fp16 minima of fp16 values are exact."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    prm = np.asarray(voxel_params, np.float32)
+    E, n = prm.shape[0], prm.shape[1]
+    feats = voxel_features.reshape(E, n, -1)
+    grids, n_coarse = [], 1
+    for e in range(E):
+        row = []
+        for g in range(n):
+            nx, ny, nz = (int(v) for v in prm[e, g, :3])
+            x = feats[e, g, : nx * ny * nz].reshape(1, 1, nx, ny, nz).float()
+            c = -F.max_pool3d(-x, kernel_size=block + 2 * dilate, stride=block, padding=dilate, ceil_mode=True)
+            cx, cy, cz = -(-nx // block), -(-ny // block), -(-nz // block)
+            c = c[0, 0, :cx, :cy, :cz].contiguous()
+            assert c.shape == (cx, cy, cz)
+            row.append(c.reshape(-1).half())
+            n_coarse = max(n_coarse, cx * cy * cz)
+        grids.append(row)
+    out = torch.full((E, n, n_coarse), -65504.0, dtype=torch.float16, device=voxel_features.device)  # padding never culls
+    for e in range(E):
+        for g in range(n):
+            out[e, g, : grids[e][g].numel()] = grids[e][g]
+    return out
 
 
 def sphere_obstacle_collision(

@@ -188,7 +188,8 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   r.r2 = make_float4(2.0f * x * z - 2.0f * w * y, 2.0f * y * z + 2.0f * w * x, k + 2.0f * z * z, p.z);
   r.shape = reinterpret_cast<const float4 *>(shape)[flat];
   if (!VOXEL) r.shape = make_float4(r.shape.x * 0.5f, r.shape.y * 0.5f, r.shape.z * 0.5f, 0.0f);
-  r.meta = make_float4((o < count && enable[flat] == 1) ? 1.0f : 0.0f, 0.f, 0.f, 0.f);  // is_obs_enabled, data_cuboid.py:467-485
+  // .x = is_obs_enabled (data_cuboid.py:467-485), .y = flat obstacle index env * max_n + o (integer bits)
+  r.meta = make_float4((o < count && enable[flat] == 1) ? 1.0f : 0.0f, __int_as_float(flat), 0.f, 0.f);
   return r;
 }
 
@@ -246,7 +247,23 @@ __device__ __forceinline__ bool obstacle_early_reject(const curobo_hip_scene &sc
     const float cx = fmaxf(fabsf(lc.x) - rec.shape.x * vs * 0.5f, 0.0f), cy = fmaxf(fabsf(lc.y) - rec.shape.y * vs * 0.5f, 0.0f),
                 cz = fmaxf(fabsf(lc.z) - rec.shape.z * vs * 0.5f, 0.0f);
     const float thr_v = reach + vs;
-    return cx * cx + cy * cy + cz * cz > thr_v * thr_v * 1.00001f;
+    if (cx * cx + cy * cy + cz * cz > thr_v * thr_v * 1.00001f) return true;
+    // Coarse minimum (scene upload, optional): every sample of this sphere -- centre and sweep -- interpolates
+    // corner voxels within ceil(reach / vs) + 1 voxels of the centre's voxel, a convex combination of values
+    // >= the dilated block minimum m (out-of-grid corners read max_distance >= m as well).  m > r_adj
+    // therefore means penetration = r_adj - sdf < 0 at every sample: exactly zero cost and gradient.
+    if (sc.voxel_coarse_min != nullptr && reach <= (float)(sc.voxel_coarse_dilate - 1) * vs) {
+      const int nx = (int)rec.shape.x, ny = (int)rec.shape.y, nz = (int)rec.shape.z, blk = sc.voxel_coarse_block;
+      const float inv = 1.0f / vs;
+      const int ix = (int)floorf(lc.x * inv + (float)nx * 0.5f), iy = (int)floorf(lc.y * inv + (float)ny * 0.5f),
+                iz = (int)floorf(lc.z * inv + (float)nz * 0.5f);
+      if (ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz) {
+        const int cy = (ny + blk - 1) / blk, cz = (nz + blk - 1) / blk;
+        const size_t at = (size_t)__float_as_int(rec.meta.y) * sc.voxel_n_coarse + ((size_t)(ix / blk) * cy + iy / blk) * cz + iz / blk;
+        const float m = __half2float(reinterpret_cast<const __half *>(sc.voxel_coarse_min)[at]);
+        if (m * 0.9999f > r_adj + 1e-6f) return true;
+      }
+    }
   }
   return false;
 }

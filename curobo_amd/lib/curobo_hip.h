@@ -146,6 +146,16 @@ typedef struct curobo_hip_scene {
   int32_t max_voxel_grids;
   int32_t voxel_n_voxels;
   float voxel_max_distance;
+  /* optional culling aid built at scene upload (NULL = none; results are identical with and without it):
+   * fp16 [num_envs, max_voxel_grids, voxel_n_coarse], cell (cx, cy, cz) of a grid = the MINIMUM of its ESDF over
+   * the block of voxel_coarse_block^3 voxels starting at (cx, cy, cz) * voxel_coarse_block, dilated by
+   * voxel_coarse_dilate voxels on every side; row-major over (ceil(nx / block), ceil(ny / block), ceil(nz / block)).
+   * A sphere whose whole sweep stays (voxel_coarse_dilate - 1) voxels around its centre's voxel and whose radius +
+   * activation distance is below that minimum cannot touch the grid: its 8-corner lookups are skipped. */
+  const uint16_t *voxel_coarse_min;
+  int32_t voxel_coarse_block;
+  int32_t voxel_coarse_dilate;
+  int32_t voxel_n_coarse;
 } curobo_hip_scene;
 
 /* sweep_steps: 0 = SphereObstacleCollision, 3 = SweptSphereObstacleCollision (SWEEP_STEPS,

@@ -103,19 +103,26 @@ class SceneData:
         return 1
 
     @staticmethod
-    def from_arrays(arrays: Dict[str, np.ndarray], device) -> "SceneData":
+    def from_arrays(arrays: Dict[str, np.ndarray], device, coarse_culling: bool = True) -> "SceneData":
+        """``coarse_culling``: also build the min-pooled ESDF the voxel kernels use to skip spheres that are far from
+        every surface (``curobo_hip_scene.voxel_coarse_min``; results are identical with and without it)."""
         import torch
 
-        from ..backends.collision import make_scene
+        from ..backends.collision import build_voxel_coarse_min, make_scene
 
         t = {}
         for k, v in arrays.items():
             if isinstance(v, np.ndarray):
                 t[k] = torch.as_tensor(v).to(device).contiguous()
+        coarse, block, dilate = None, 0, 0
+        if coarse_culling and t.get("voxel_features") is not None and t["voxel_features"].numel() > 0:
+            block, dilate = 4, 3  # culls spheres whose sweep stays within 2 voxels of the centre's voxel
+            coarse = t["voxel_coarse_min"] = build_voxel_coarse_min(t["voxel_features"], arrays["voxel_params"], block, dilate)
         struct = make_scene(
             t.get("cuboid_dims"), t.get("cuboid_inv_pose"), t.get("cuboid_enable"), t.get("cuboid_count"),
             t.get("voxel_params"), t.get("voxel_inv_pose"), t.get("voxel_enable"), t.get("voxel_count"),
             t.get("voxel_features"), float(arrays.get("voxel_max_distance", 10000.0)),
+            voxel_coarse_min=coarse, voxel_coarse_block=block, voxel_coarse_dilate=dilate,
         )
         return SceneData(tensors=t, struct=struct, arrays=arrays)
 

@@ -506,3 +506,35 @@ def test_self_collision_dense_bitmap_kernel_c4_size(oracle, device):
     np.testing.assert_allclose(g1, ref["gradient"], atol=ATOL, rtol=1e-5)
     np.testing.assert_allclose(d1, d0, atol=1e-6, rtol=1e-6)
     np.testing.assert_allclose(g1, g0, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("sweep", [False, True])
+def test_voxel_coarse_culling_changes_nothing(sweep, oracle, device):
+    """the min-pooled ESDF (curobo_hip_scene.voxel_coarse_min) only skips spheres that provably contribute zero:
+    distance and gradient are BIT-identical with and without it (UR10e trajectories through the C3 world)"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import c3_voxel_world
+
+    model = load_model("ur10e")
+    arrays = c3_voxel_world(64, 0.04)
+    b, h = 64, 17
+    q0, q1 = sample_q(model, b, seed=3)[:, None], sample_q(model, b, seed=4)[:, None]
+    tt = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    q = (q0 * (1 - tt) + q1 * tt).reshape(b * h, -1)
+    sph = oracle.kinematics_forward(q, model.as_dict(), horizon=h)["robot_spheres"].reshape(b, h, -1, 4)
+    S = sph.shape[2]
+    outs = []
+    for coarse in (False, True):
+        scene = SceneData.from_arrays(arrays, device, coarse_culling=coarse)
+        assert (scene.struct.voxel_coarse_min is not None) == coarse
+        dist, grad = torch.full((b, h, S), 3.0, device=device), torch.full((b, h, S, 4), 3.0, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([1.0], device=device),
+                                     torch.tensor([0.02], device=device), None, b, h, S, False, 3 if sweep else 0, sweep,
+                                     torch.tensor([0.05], device=device) if sweep else None)
+        torch.cuda.synchronize()
+        outs.append((dist.cpu().numpy(), grad.cpu().numpy()))
+    assert 0.02 < (outs[0][0] > 0).mean() < 0.9
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ref = oracle.scene_collision(sph, arrays, 1.0, 0.02, sweep=sweep, enable_speed_metric=sweep, speed_dt=0.05)
+    assert np.array_equal(outs[1][0] > 0, ref["distance"] > 0)

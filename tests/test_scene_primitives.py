@@ -63,3 +63,34 @@ def test_baked_esdf_reproduces_the_field_through_the_oracle(oracle):
     # trilinear interpolation of a 1-Lipschitz field on a 2 cm grid + fp16 storage
     np.testing.assert_allclose(got, want, atol=0.6 * vs)
     assert (want > 0).sum() > 100 and (want == 0).sum() > 100
+
+
+def test_voxel_coarse_min_is_a_lower_bound_of_every_interpolated_value():
+    """curobo_hip_scene.voxel_coarse_min (backends.collision.build_voxel_coarse_min, CPU tensors here): for every
+    fine voxel, the coarse cell that contains it holds a value <= the ESDF at every voxel within `dilate` voxels
+    (the corners any trilinear sample within (dilate - 1) voxels of it can touch)."""
+    import torch
+
+    from curobo_amd.backends.collision import build_voxel_coarse_min
+
+    rng = np.random.default_rng(0)
+    nx, ny, nz, block, dilate = 13, 10, 9, 4, 3
+    f = rng.normal(size=(nx, ny, nz)).astype(np.float16)
+    prm = np.array([[[nx, ny, nz, 0.02]]], np.float32)
+    c = build_voxel_coarse_min(torch.as_tensor(f.reshape(1, 1, -1)), prm, block, dilate).numpy()[0, 0]
+    cx, cy, cz = -(-nx // block), -(-ny // block), -(-nz // block)
+    c = c[: cx * cy * cz].reshape(cx, cy, cz).astype(np.float32)
+    ff = f.astype(np.float32)
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                lo = [max(0, v - dilate) for v in (i, j, k)]
+                hi = [min(n, v + dilate + 1) for v, n in ((i, nx), (j, ny), (k, nz))]
+                assert c[i // block, j // block, k // block] <= ff[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].min()
+    # and it is tight: the cell minimum is attained inside its dilated block
+    for a in range(cx):
+        for b in range(cy):
+            for d in range(cz):
+                lo = [max(0, v * block - dilate) for v in (a, b, d)]
+                hi = [min(n, v * block + block + dilate) for v, n in ((a, nx), (b, ny), (d, nz))]
+                assert c[a, b, d] == ff[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].min()
