@@ -36,7 +36,7 @@ class Scene(C.Structure):
         ("voxel_count", C.c_void_p), ("voxel_features", C.c_void_p), ("max_voxel_grids", C.c_int32),
         ("voxel_n_voxels", C.c_int32), ("voxel_max_distance", C.c_float),
         ("voxel_coarse_min", C.c_void_p), ("voxel_coarse_block", C.c_int32), ("voxel_coarse_dilate", C.c_int32),
-        ("voxel_n_coarse", C.c_int32),
+        ("voxel_n_coarse", C.c_int32), ("cuboid_has_primitives", C.c_int32),
     ]
 
 

@@ -45,6 +45,7 @@ def make_scene(
         s.cuboid_dims, s.cuboid_inv_pose = ptr(cuboid_dims), ptr(cuboid_inv_pose)
         s.cuboid_enable, s.cuboid_count = ptr(cuboid_enable), ptr(cuboid_count)
         s.max_cuboids = cuboid_dims.shape[1]
+        s.cuboid_has_primitives = int(bool((cuboid_dims[..., 3] != 0).any()))  # host read-back at scene build
     if voxel_params is not None and voxel_params.numel() > 0:
         assert voxel_params.dtype == torch.float32 and voxel_features.dtype == torch.float16
         assert voxel_enable.dtype == torch.uint8 and voxel_count.dtype == torch.int32

@@ -455,7 +455,7 @@ __device__ __forceinline__ void wave_scene_pass(const FusedCtx &c, const curobo_
         obstacle_contribution<true, SWEEP>(sc, rec, c.env * sc.max_voxel_grids + je - sc.max_cuboids, lc, q.has_prev, q.has_next,
                                            q.pp, q.np, q.r_adj, c.eta, q.half_prev, q.half_next, cost_sum, grad_local);
       else
-        obstacle_contribution<false, SWEEP>(sc, rec, c.env * sc.max_cuboids + je, lc, q.has_prev, q.has_next, q.pp, q.np, q.r_adj,
+        obstacle_contribution<false, SWEEP, (KINDS & 4) != 0>(sc, rec, c.env * sc.max_cuboids + je, lc, q.has_prev, q.has_next, q.pp, q.np, q.r_adj,
                                             c.eta, q.half_prev, q.half_next, cost_sum, grad_local);
       if (cost_sum > 0.0f) {
         d = c.w_scene * cost_sum;
@@ -1527,7 +1527,8 @@ static int rollout_trajectory_fused_impl(
                                                   a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
-  const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
+  // scenes with analytic primitives in the cuboid store run the one instantiation that tests the tag (KINDS = 7)
+  const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
   hipStream_t st = (hipStream_t)stream;
 #define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
   do {                                                                                                         \
@@ -1549,6 +1550,7 @@ static int rollout_trajectory_fused_impl(
   do {                                                     \
     if (kinds == 2) CUROBO_FUSED_LAUNCH(DG, SW, 2);        \
     else if (kinds == 3) CUROBO_FUSED_LAUNCH(DG, SW, 3);   \
+    else if (kinds == 7) CUROBO_FUSED_LAUNCH(DG, SW, 7);   \
     else CUROBO_FUSED_LAUNCH(DG, SW, 1);                   \
   } while (0)
 #define CUROBO_FUSED_SWEEP(DG)                             \
@@ -1683,7 +1685,7 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
   const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: 16 configurations do not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
-  const int kinds = (a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0);
+  const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
   const dim3 grid((unsigned)ceil_div(batch_size, kIkPoints)), block(kIkPoints * kFkLanes);
 #define CUROBO_IK_LAUNCH(KD)                                                                                    \
   do {                                                                                                          \
@@ -1696,6 +1698,7 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
   } while (0)
   if (kinds == 2) CUROBO_IK_LAUNCH(2);
   else if (kinds == 3) CUROBO_IK_LAUNCH(3);
+  else if (kinds == 7) CUROBO_IK_LAUNCH(7);
   else CUROBO_IK_LAUNCH(1);
 #undef CUROBO_IK_LAUNCH
   return check_launch(what, st);

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) scene_collision_packed_kernel(const Scene
         obstacle_contribution<true, SWEEP>(a.sc, rec, env * a.sc.max_voxel_grids + o - a.sc.max_cuboids, lc, hp, hn, pp, np, r_adj, eta,
                                            half_w_prev, half_w_next, cost_sum, grad_local);
       else
-        obstacle_contribution<false, SWEEP>(a.sc, rec, env * a.sc.max_cuboids + o, lc, hp, hn, pp, np, r_adj, eta, half_w_prev,
+        obstacle_contribution<false, SWEEP, (KINDS & 4) != 0>(a.sc, rec, env * a.sc.max_cuboids + o, lc, hp, hn, pp, np, r_adj, eta, half_w_prev,
                                             half_w_next, cost_sum, grad_local);
       if (cost_sum > 0.0f) {
         const f3 gw = to_world_vector(rec, grad_local);
@@ -254,13 +254,16 @@ CUROBO_EXPORT int curobo_hip_sphere_obstacle_collision(
   const long slots = (256 + hs - 1) / hs + 1;
   const size_t lds = (size_t)slots * (scene->max_cuboids + scene->max_voxel_grids) * sizeof(ObsRec);
   const bool staged = lds > 0 && lds <= 32 * 1024;
-  const int kinds = (scene->max_cuboids > 0 ? 1 : 0) | (scene->max_voxel_grids > 0 ? 2 : 0);
+  const int kinds = (scene->max_cuboids > 0 ? 1 : 0) | (scene->max_voxel_grids > 0 ? 2 : 0) |
+                    ((scene->max_cuboids > 0 && scene->cuboid_has_primitives) ? 4 : 0);
 #define CUROBO_SCENE_LAUNCH(SW, ST, KD) \
   hipLaunchKernelGGL((scene_collision_kernel<SW, ST, KD>), dim3(blocks), dim3(256), (ST) ? lds : 0, st, a)
 #define CUROBO_SCENE_KINDS(SW, ST)                   \
   do {                                               \
     if (kinds == 1) CUROBO_SCENE_LAUNCH(SW, ST, 1);  \
     else if (kinds == 2) CUROBO_SCENE_LAUNCH(SW, ST, 2); \
+    else if (kinds == 5) CUROBO_SCENE_LAUNCH(SW, ST, 5); \
+    else if (kinds == 7) CUROBO_SCENE_LAUNCH(SW, ST, 7); \
     else CUROBO_SCENE_LAUNCH(SW, ST, 3);             \
   } while (0)
   const int n_rec = scene->max_cuboids + scene->max_voxel_grids;
@@ -271,6 +274,7 @@ CUROBO_EXPORT int curobo_hip_sphere_obstacle_collision(
   do {                                                                                                                       \
     if (kinds == 1) hipLaunchKernelGGL((scene_collision_packed_kernel<SW, 1>), dim3(blocks), dim3(256), lds_packed, st, a);      \
     else if (kinds == 2) hipLaunchKernelGGL((scene_collision_packed_kernel<SW, 2>), dim3(blocks), dim3(256), lds_packed, st, a); \
+    else if (kinds == 7) hipLaunchKernelGGL((scene_collision_packed_kernel<SW, 7>), dim3(blocks), dim3(256), lds_packed, st, a); \
     else hipLaunchKernelGGL((scene_collision_packed_kernel<SW, 3>), dim3(blocks), dim3(256), lds_packed, st, a);                 \
   } while (0)
     if (sweep_steps == 0) CUROBO_SCENE_PACKED(0); else CUROBO_SCENE_PACKED(3);

@@ -16,8 +16,10 @@ namespace curobo_hip {
 // once per workgroup, so a sphere-obstacle test starts with 9 FMAs instead of the quaternion form.
 struct ObsRec {
   float4 r0, r1, r2;  // rows of R, .w = translation component: local = R world + t
-  float4 shape;       // cuboid: HALF extents xyz | voxel grid: nx ny nz voxel_size
-  float4 meta;        // .x = enabled (1.0 / 0.0; already includes o < count)
+  float4 shape;       // cuboid store: HALF extents xyz of the (bounding) box, .w = primitive tag (0 cuboid, 1 sphere,
+                      // 2 capsule, 3 cylinder) | voxel grid: nx ny nz voxel_size
+  float4 meta;        // .x = enabled (1.0 / 0.0; already includes o < count), .y = flat obstacle index (int bits),
+                      // .z / .w = primitive radius / half length (capsule: half segment; cylinder: half height)
 };
 constexpr int kObsRecFloats = sizeof(ObsRec) / sizeof(float);
 
@@ -62,6 +64,41 @@ __device__ __forceinline__ float cuboid_sdf(float4 half, f3 lp, bool want_grad, 
     else if (fabsf(qy - mq) < 1e-6f) g.y = (lp.y < 0.0f) ? 1.0f : -1.0f;
     else g.z = (lp.z < 0.0f) ? 1.0f : -1.0f;
   }
+  return sdf;
+}
+
+// Analytic primitives in the cuboid store (tag in dims.w, see include/curobo_hip.h): the reference turns Sphere /
+// Capsule / Cylinder obstacles into triangle meshes and queries them through Warp's BVH (geom/types.py:290-450,
+// :1104-1124, geom/data/data_mesh.py:555-700); here they are their closed forms in the obstacle frame (axis = local
+// z, centred at the origin: the trimesh.creation conventions the reference's get_trimesh_mesh uses).  g = minus the
+// SDF gradient, as for cuboid_sdf; the same host-side fields are curobo_amd/scene/primitives.py.
+__device__ __forceinline__ float primitive_sdf(const ObsRec &rec, f3 lp, bool want_grad, float r_adj, f3 &g) {
+  const int tag = (int)rec.shape.w;
+  const float r = rec.meta.z, hl = rec.meta.w;
+  g = make_f3(0.f, 0.f, 0.f);
+  if (tag == 3) {  // cylinder: radius r, half height hl
+    const float rho = sqrtf(lp.x * lp.x + lp.y * lp.y);
+    const float dr = rho - r, dz = fabsf(lp.z) - hl;
+    const float cr = fmaxf(dr, 0.0f), cz = fmaxf(dz, 0.0f);
+    const float od = sqrtf(cr * cr + cz * cz);
+    const float sdf = od + fminf(fmaxf(dr, dz), 0.0f);
+    if (!(want_grad && r_adj - sdf > 0.0f)) return sdf;
+    const float ir = rho > 1e-6f ? 1.0f / rho : 0.0f;
+    const f3 er = rho > 1e-6f ? make_f3(lp.x * ir, lp.y * ir, 0.0f) : make_f3(1.0f, 0.0f, 0.0f);
+    const float sz = lp.z < 0.0f ? -1.0f : 1.0f;
+    if (od > 1e-6f) g = make_f3(-er.x * cr / od, -er.y * cr / od, -sz * cz / od);
+    else if (dr > dz) g = make_f3(-er.x, -er.y, 0.0f);
+    else g = make_f3(0.0f, 0.0f, -sz);
+    return sdf;
+  }
+  // sphere (hl = 0) and capsule: distance to the segment [-hl, hl] on the local z axis, minus r
+  const float t = fminf(fmaxf(lp.z, -hl), hl);
+  const f3 v = make_f3(lp.x, lp.y, lp.z - t);
+  const float d = sqrtf(dot(v, v));
+  const float sdf = d - r;
+  if (!(want_grad && r_adj - sdf > 0.0f)) return sdf;
+  if (d > 1e-6f) g = make_f3(-v.x / d, -v.y / d, -v.z / d);
+  else g = make_f3(0.0f, 0.0f, -1.0f);
   return sdf;
 }
 
@@ -150,13 +187,14 @@ __device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_
   return sdf;
 }
 
-template <bool VOXEL>
-__device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat, float4 shape, f3 lp, float r_adj,
+template <bool VOXEL, bool PRIMS = false>
+__device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat, const ObsRec &rec, f3 lp, float r_adj,
                                             float eta, float &cost_sum, f3 &grad_sum) {
   f3 g;
   float sdf;
-  if (VOXEL) sdf = voxel_sdf(sc, flat, shape, lp, g);
-  else sdf = cuboid_sdf(shape, lp, true, r_adj, g);
+  if (VOXEL) sdf = voxel_sdf(sc, flat, rec.shape, lp, g);
+  else if (PRIMS && rec.shape.w != 0.0f) sdf = primitive_sdf(rec, lp, true, r_adj, g);
+  else sdf = cuboid_sdf(rec.shape, lp, true, r_adj, g);
   const float pen = -sdf + r_adj;
   if (pen > 0.0f) {
     float c, gs;
@@ -187,20 +225,31 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   r.r1 = make_float4(2.0f * x * y + 2.0f * w * z, k + 2.0f * y * y, 2.0f * y * z - 2.0f * w * x, p.y);
   r.r2 = make_float4(2.0f * x * z - 2.0f * w * y, 2.0f * y * z + 2.0f * w * x, k + 2.0f * z * z, p.z);
   r.shape = reinterpret_cast<const float4 *>(shape)[flat];
-  if (!VOXEL) r.shape = make_float4(r.shape.x * 0.5f, r.shape.y * 0.5f, r.shape.z * 0.5f, 0.0f);
+  float prim_r = 0.0f, prim_hl = 0.0f;
+  if (!VOXEL) {
+    const float4 d = r.shape;
+    const int tag = (int)d.w;  // 0 = cuboid (the reference's dims[..., 3] padding is zero)
+    if (tag == 0) {
+      r.shape = make_float4(d.x * 0.5f, d.y * 0.5f, d.z * 0.5f, 0.0f);
+    } else {  // primitive: (radius, half length, -, tag); .xyz becomes its bounding box for the early rejects
+      prim_r = d.x;
+      prim_hl = tag == 1 ? 0.0f : d.y;
+      r.shape = make_float4(d.x, d.x, tag == 1 ? d.x : (tag == 2 ? d.y + d.x : d.y), (float)tag);
+    }
+  }
   // .x = is_obs_enabled (data_cuboid.py:467-485), .y = flat obstacle index env * max_n + o (integer bits)
-  r.meta = make_float4((o < count && enable[flat] == 1) ? 1.0f : 0.0f, __int_as_float(flat), 0.f, 0.f);
+  r.meta = make_float4((o < count && enable[flat] == 1) ? 1.0f : 0.0f, __int_as_float(flat), prim_r, prim_hl);
   return r;
 }
 
 // Cost and obstacle-frame gradient of ONE sphere against ONE obstacle that passed the early reject:
 // the centre sample plus the sweep towards the previous / next point (the body of obstacle_set's
 // loop; also the unit of work of the fused kernel's scene pass).  lc = centre in the obstacle frame.
-template <bool VOXEL, int SWEEP>
+template <bool VOXEL, int SWEEP, bool PRIMS = false>
 __device__ __forceinline__ void obstacle_contribution(const curobo_hip_scene &sc, const ObsRec &rec, int flat, f3 lc,
                                                       bool has_prev, bool has_next, f3 prev_c, f3 next_c, float r_adj, float eta,
                                                       float half_w_prev, float half_w_next, float &cost_sum, f3 &grad_local) {
-  const float pen_c = eval_point<VOXEL>(sc, flat, rec.shape, lc, r_adj, eta, cost_sum, grad_local);
+  const float pen_c = eval_point<VOXEL, PRIMS>(sc, flat, rec, lc, r_adj, eta, cost_sum, grad_local);
   if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
     // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
     const float sdf_c = r_adj - pen_c;
@@ -223,7 +272,7 @@ __device__ __forceinline__ void obstacle_contribution(const curobo_hip_scene &sc
           if (jump >= half_dist) break;
           const float tt = 1.0f - 0.5f * jump * inv_half;
           const f3 lp = tt * lc + (1.0f - tt) * ln;
-          const float p2 = eval_point<VOXEL>(sc, flat, rec.shape, lp, r_adj, eta, cost_sum, grad_local);
+          const float p2 = eval_point<VOXEL, PRIMS>(sc, flat, rec, lp, r_adj, eta, cost_sum, grad_local);
           if (p2 > 0.0f) jump += p2;
           else if (-p2 >= 1000.0f) jump += r_adj;
           else jump += fmaxf(-p2, r_adj);
@@ -278,7 +327,7 @@ __device__ __forceinline__ bool obstacle_early_reject(const curobo_hip_scene &sc
 // can reach: no penetration, both sweep directions culled -> exactly zero, without sqrt, gradient
 // or sweep bookkeeping.  A voxel grid is skipped when the centre is so far outside its box (sweep
 // reach + one voxel) that every sample reads the constant max_distance.
-template <bool VOXEL, int SWEEP, bool STAGED>
+template <bool VOXEL, int SWEEP, bool STAGED, bool PRIMS = false>
 __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs, int env,
                                              bool has_prev, bool has_next, f3 prev_c, f3 next_c, f3 center, float r_adj,
                                              float eta, float w, float half_w_prev, float half_w_next, uint32_t mask,
@@ -297,8 +346,8 @@ __device__ __forceinline__ void obstacle_set(const curobo_hip_scene &sc, const O
     if (obstacle_early_reject<VOXEL>(sc, rec, lc, r_adj, reach, thr2_c)) continue;
     float cost_sum = 0.0f;
     f3 grad_local = make_f3(0.f, 0.f, 0.f);
-    obstacle_contribution<VOXEL, SWEEP>(sc, rec, flat, lc, has_prev, has_next, prev_c, next_c, r_adj, eta, half_w_prev,
-                                        half_w_next, cost_sum, grad_local);
+    obstacle_contribution<VOXEL, SWEEP, PRIMS>(sc, rec, flat, lc, has_prev, has_next, prev_c, next_c, r_adj, eta, half_w_prev,
+                                               half_w_next, cost_sum, grad_local);
     if (cost_sum > 0.0f) {
       const f3 gw = to_world_vector(rec, grad_local);
       dsum += w * cost_sum;
@@ -362,7 +411,8 @@ __device__ __forceinline__ void speed_metric_apply(f3 center, f3 pp, f3 np, floa
 
 // Full scene cost of ONE sphere of one trajectory point: every enabled obstacle (cuboids, then voxel
 // grids, in index order), optional sweep towards the previous / next point and the fused speed
-// metric (wp_speed_metric.py:38-93).  KINDS: bit 0 = cuboids present, bit 1 = voxel grids.
+// metric (wp_speed_metric.py:38-93).  KINDS: bit 0 = cuboid store present, bit 1 = voxel grids, bit 2 = the cuboid
+// store may hold analytic primitives (sphere / capsule / cylinder tags).
 template <int SWEEP, bool STAGED, int KINDS>
 __device__ __forceinline__ void sphere_scene_cost(const curobo_hip_scene &sc, const ObsRec *__restrict__ recs, int env,
                                                   float4 s, bool has_prev, float4 ps, bool has_next, float4 ns, float eta,
@@ -380,8 +430,8 @@ __device__ __forceinline__ void sphere_scene_cost(const curobo_hip_scene &sc, co
       if (has_next) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
     }
     if (KINDS & 1)
-      obstacle_set<false, SWEEP, STAGED>(sc, recs, env, has_prev, has_next, pp, np, center, r_adj, eta, w, half_w_prev,
-                                         half_w_next, mask, dsum, gsum);
+      obstacle_set<false, SWEEP, STAGED, (KINDS & 4) != 0>(sc, recs, env, has_prev, has_next, pp, np, center, r_adj, eta, w,
+                                                           half_w_prev, half_w_next, mask, dsum, gsum);
     if (KINDS & 2)
       obstacle_set<true, SWEEP, STAGED>(sc, recs + sc.max_cuboids, env, has_prev, has_next, pp, np, center, r_adj, eta, w,
                                         half_w_prev, half_w_next, mask, dsum, gsum);

@@ -156,6 +156,12 @@ typedef struct curobo_hip_scene {
   int32_t voxel_coarse_block;
   int32_t voxel_coarse_dilate;
   int32_t voxel_n_coarse;
+  /* Analytic primitives (beyond the reference, which turns Sphere / Capsule / Cylinder obstacles into meshes,
+   * geom/types.py:1104-1124): a record of the cuboid store is a primitive when cuboid_dims[..., 3] (the reference's
+   * zero padding) holds a tag: 1 sphere (dims = radius, -, -), 2 capsule (radius, half length of the segment on the
+   * local z axis, -), 3 cylinder (radius, half height along local z, -); pose / enable / count as for cuboids.  Set
+   * cuboid_has_primitives when any tag is non-zero (selects the kernel instantiations that test the tag). */
+  int32_t cuboid_has_primitives;
 } curobo_hip_scene;
 
 /* sweep_steps: 0 = SphereObstacleCollision, 3 = SweptSphereObstacleCollision (SWEEP_STEPS,

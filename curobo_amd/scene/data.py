@@ -44,7 +44,12 @@ def inverse_pose7(pose7: Sequence[float]) -> np.ndarray:
 
 
 def cuboid_scene_arrays(envs: List[List[Dict]], max_n: Optional[int] = None) -> Dict[str, np.ndarray]:
-    """``envs[e]`` = list of ``{"dims": [x,y,z], "pose": [x,y,z,qw,qx,qy,qz], "enable": bool}``."""
+    """``envs[e]`` = list of ``{"dims": [x,y,z], "pose": [x,y,z,qw,qx,qy,qz], "enable": bool}`` cuboids and / or analytic
+    primitives (reference ``Sphere`` / ``Capsule`` / ``Cylinder``, geom/types.py:290-450; evaluated in closed form on
+    the device instead of through a mesh): ``{"type": "sphere", "radius": r, "pose": ...}``, ``{"type": "capsule",
+    "radius": r, "base": [0,0,z0], "tip": [0,0,z1], "pose": ...}`` (segment on the local z axis, as the reference
+    requires for its capsule mesh) and ``{"type": "cylinder", "radius": r, "height": h, "pose": ...}`` (axis = local z,
+    centred).  They live in the cuboid store with a tag in ``dims[..., 3]`` (see include/curobo_hip.h)."""
     E = len(envs)
     n = max_n or max(1, max(len(e) for e in envs))
     dims = np.zeros((E, n, 4), np.float32)
@@ -55,8 +60,24 @@ def cuboid_scene_arrays(envs: List[List[Dict]], max_n: Optional[int] = None) -> 
     for e, obs in enumerate(envs):
         count[e] = len(obs)
         for i, o in enumerate(obs):
-            dims[e, i, :3] = o["dims"]
-            inv_pose[e, i, :7] = inverse_pose7(o["pose"])
+            kind, pose = o.get("type", "cuboid"), list(o["pose"])
+            if kind == "cuboid":
+                dims[e, i, :3] = o["dims"]
+            elif kind == "sphere":
+                dims[e, i] = [o["radius"], 0.0, 0.0, 1.0]
+            elif kind == "cylinder":
+                dims[e, i] = [o["radius"], 0.5 * o["height"], 0.0, 3.0]
+            elif kind == "capsule":
+                base, tip = np.asarray(o.get("base", [0, 0, 0]), np.float64), np.asarray(o.get("tip", [0, 0, 0]), np.float64)
+                if abs(base[0]) + abs(base[1]) + abs(tip[0]) + abs(tip[1]) > 0 or tip[2] < base[2]:
+                    raise ValueError("capsule base / tip must lie on the local z axis with tip above base (as in the reference)")
+                dims[e, i] = [o["radius"], 0.5 * (tip[2] - base[2]), 0.0, 2.0]
+                # the stored frame is centred on the segment: shift the pose along the obstacle's own z axis
+                q = np.asarray(pose[3:7], np.float64)
+                pose[:3] = list(np.asarray(pose[:3], np.float64) + _quat_rotate(q / np.linalg.norm(q), np.array([0, 0, 0.5 * (base[2] + tip[2])])))
+            else:
+                raise ValueError(f"unknown obstacle type {kind!r}")
+            inv_pose[e, i, :7] = inverse_pose7(pose)
             enable[e, i] = 1 if o.get("enable", True) else 0
     return {"cuboid_dims": dims, "cuboid_inv_pose": inv_pose, "cuboid_enable": enable, "cuboid_count": count}
 

@@ -509,8 +509,37 @@ static void orc_activation(float dist, float eta, float *cost, float *gscale) {
   else { *cost = 0.5f * dist * dist / eta; *gscale = dist / eta; }
 }
 
+/* Analytic primitives of the cuboid store (an extension over the reference, which meshes them: geom/types.py
+ * :290-450, :1104-1124): dims[3] = 1 sphere (dims[0] = radius), 2 capsule (radius, half segment length on local z),
+ * 3 cylinder (radius, half height on local z).  Closed forms; g = minus the SDF gradient. */
+static float orc_primitive_sdf(const float *dims, const float *lp, float *g) {
+  const int tag = (int)dims[3];
+  const float r = dims[0], hl = tag == 1 ? 0.0f : dims[1];
+  g[0] = g[1] = g[2] = 0.0f;
+  if (tag == 3) {
+    const float rho = sqrtf(lp[0] * lp[0] + lp[1] * lp[1]);
+    const float dr = rho - r, dz = fabsf(lp[2]) - hl;
+    const float cr = fmaxf(dr, 0.0f), cz = fmaxf(dz, 0.0f);
+    const float od = sqrtf(cr * cr + cz * cz);
+    const float sdf = od + fminf(fmaxf(dr, dz), 0.0f);
+    const float ex = rho > 1e-6f ? lp[0] / rho : 1.0f, ey = rho > 1e-6f ? lp[1] / rho : 0.0f;
+    const float sz = lp[2] < 0.0f ? -1.0f : 1.0f;
+    if (od > 1e-6f) { g[0] = -ex * cr / od; g[1] = -ey * cr / od; g[2] = -sz * cz / od; }
+    else if (dr > dz) { g[0] = -ex; g[1] = -ey; }
+    else g[2] = -sz;
+    return sdf;
+  }
+  const float t = fminf(fmaxf(lp[2], -hl), hl);
+  const float vx = lp[0], vy = lp[1], vz = lp[2] - t;
+  const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+  if (d > 1e-6f) { g[0] = -vx / d; g[1] = -vy / d; g[2] = -vz / d; }
+  else g[2] = -1.0f;
+  return d - r;
+}
+
 /* data_cuboid.py:547-628; returns sdf, g = minus the SDF gradient (cost gradient direction) */
 static float orc_cuboid_sdf(const float *dims, const float *lp, float *g) {
+  if (dims[3] != 0.0f) return orc_primitive_sdf(dims, lp, g);
   const float hx = dims[0] * 0.5f, hy = dims[1] * 0.5f, hz = dims[2] * 0.5f;
   const float qx = fabsf(lp[0]) - hx, qy = fabsf(lp[1]) - hy, qz = fabsf(lp[2]) - hz;
   const float cx = fmaxf(qx, 0.0f), cy = fmaxf(qy, 0.0f), cz = fmaxf(qz, 0.0f);

@@ -348,3 +348,24 @@ def test_fused_swept_matches_oracle_at_c2_size(oracle, device):
     gkr = ref["grad_knots"].reshape(B, nk, D)
     gerr = np.abs(grad - gkr).reshape(B, -1).max(-1) / np.abs(gkr).max()
     assert np.quantile(gerr[clean], 0.99) < 2e-3, np.sort(gerr[clean])[-5:]
+
+
+def test_fused_world_with_analytic_primitives(oracle, device):
+    """BASELINE config 2 says "sphere + cuboid world": sphere / capsule / cylinder obstacles as analytic records of
+    the cuboid store, fused launch vs the kernel sequence and vs the all-oracle pipeline (non-swept: continuous)."""
+    from test_scene_primitives import PRIM_WORLD
+
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, world=PRIM_WORLD)
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
+    model, arrays, knots, start, _, ro = _pair(device, world=PRIM_WORLD, use_sweep=False, use_speed_metric=False)
+    ref = rollout_cost_and_gradient(oracle, model.as_dict(), arrays, knots, start, use_sweep=False, use_speed_metric=False)
+    cost, grad = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(knots.shape[0], -1))
+    torch.cuda.synchronize()
+    assert (ref["scene_cost"] > 0).mean() > 0.01
+    np.testing.assert_allclose(cost.cpu().numpy(), ref["cost"], rtol=1e-4, atol=1e-2)
+    gk = ref["grad_knots"].reshape(knots.shape[0], -1)
+    np.testing.assert_allclose(grad.cpu().numpy(), gk, rtol=2e-3, atol=2e-5 * np.abs(gk).max())

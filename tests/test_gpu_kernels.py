@@ -538,3 +538,37 @@ def test_voxel_coarse_culling_changes_nothing(sweep, oracle, device):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     ref = oracle.scene_collision(sph, arrays, 1.0, 0.02, sweep=sweep, enable_speed_metric=sweep, speed_dt=0.05)
     assert np.array_equal(outs[1][0] > 0, ref["distance"] > 0)
+
+
+@pytest.mark.parametrize("sweep,voxel", [(False, False), (True, False), (True, True)])
+def test_scene_collision_analytic_primitives(sweep, voxel, oracle, device):
+    """sphere / capsule / cylinder records of the cuboid store (closed forms on the device; the reference meshes
+    them) next to a cuboid [and an ESDF grid]: HIP kernel vs the oracle, exact hit set"""
+    from test_scene_primitives import PRIM_WORLD
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c3_voxel_world
+
+    model = load_model("franka")
+    arrays = cuboid_scene_arrays(PRIM_WORLD)
+    if voxel:
+        arrays = {**arrays, **c3_voxel_world(64, 0.04)}
+    b, h = 32, 9
+    q0, q1 = sample_q(model, b, seed=11)[:, None], sample_q(model, b, seed=12)[:, None]
+    tt = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    sph = oracle.kinematics_forward((q0 * (1 - tt) + q1 * tt).reshape(b * h, -1) * 0.7, model.as_dict(), horizon=h)["robot_spheres"]
+    sph = sph.reshape(b, h, -1, 4)
+    S = sph.shape[2]
+    ref = oracle.scene_collision(sph, arrays, 3.0, 0.02, sweep=sweep, enable_speed_metric=sweep, speed_dt=0.05)
+    scene = SceneData.from_arrays(arrays, device)
+    assert scene.struct.cuboid_has_primitives == 1
+    dist, grad = torch.full((b, h, S), 5.0, device=device), torch.full((b, h, S, 4), 5.0, device=device)
+    Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([3.0], device=device),
+                                 torch.tensor([0.02], device=device), None, b, h, S, False, 3 if sweep else 0, sweep,
+                                 torch.tensor([0.05], device=device))
+    torch.cuda.synchronize()
+    assert (ref["distance"] > 0).mean() > 0.03
+    assert np.array_equal(dist.cpu().numpy() > 0, ref["distance"] > 0)
+    np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref["gradient"], atol=2e-4, rtol=1e-3)

@@ -94,3 +94,60 @@ def test_voxel_coarse_min_is_a_lower_bound_of_every_interpolated_value():
                 lo = [max(0, v * block - dilate) for v in (a, b, d)]
                 hi = [min(n, v * block + block + dilate) for v, n in ((a, nx), (b, ny), (d, nz))]
                 assert c[a, b, d] == ff[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].min()
+
+
+PRIM_WORLD = [[
+    {"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]},
+    {"type": "sphere", "radius": 0.18, "pose": [0.45, 0.1, 0.45, 1, 0, 0, 0]},
+    {"type": "capsule", "radius": 0.07, "base": [0, 0, 0.0], "tip": [0, 0, 0.5], "pose": [0.1, 0.5, 0.2, 0.9238795, 0.3826834, 0, 0]},
+    {"type": "cylinder", "radius": 0.12, "height": 0.6, "pose": [-0.35, -0.35, 0.4, 0.9659258, 0, 0.2588190, 0]},
+]]
+
+
+def test_device_primitive_records_match_the_closed_forms(oracle):
+    """Analytic sphere / capsule / cylinder records of the cuboid store (oracle restatement of the device code) vs
+    the independent NumPy closed forms of scene/primitives.py: hit set and cost of random probe spheres (weight 1,
+    activation 0: cost = penetration depth r - sdf), gradient vs central finite differences."""
+    from curobo_amd.scene import capsule_sdf, cuboid_scene_arrays, cylinder_sdf, sphere_sdf
+
+    arrays = cuboid_scene_arrays(PRIM_WORLD)
+    assert arrays["cuboid_dims"][0, :, 3].tolist() == [0.0, 1.0, 2.0, 3.0]
+    rng = np.random.default_rng(0)
+    n = 4000
+    pts = rng.uniform([-0.7, -0.7, 0.05], [0.8, 0.9, 0.9], size=(n, 3))
+    rad = rng.uniform(0.01, 0.06, size=n)
+    sph = np.concatenate([pts, rad[:, None]], -1).astype(np.float32).reshape(1, 1, n, 4)
+    fields = [sphere_sdf(0.18, PRIM_WORLD[0][1]["pose"]),
+              capsule_sdf(0.07, [0, 0, 0.0], [0, 0, 0.5], PRIM_WORLD[0][2]["pose"]),
+              cylinder_sdf(0.12, 0.6, PRIM_WORLD[0][3]["pose"])]
+    for k, f in enumerate(fields):
+        only = cuboid_scene_arrays([[dict(o, enable=(i == k + 1)) for i, o in enumerate(PRIM_WORLD[0])]])
+        r = oracle.scene_collision(sph, only, 1.0, 0.0)
+        sdf = f(pts.astype(np.float32).astype(np.float64))
+        pen = rad.astype(np.float32).astype(np.float64) - sdf
+        clear = np.abs(pen) > 1e-5
+        assert np.array_equal((r["distance"][0, 0] > 0)[clear], (pen > 0)[clear]), k
+        hit = (pen > 1e-4)
+        assert hit.sum() > 20
+        np.testing.assert_allclose(r["distance"][0, 0][hit], pen[hit], rtol=2e-4, atol=2e-6)
+        # gradient of the cost wrt the sphere centre = -grad sdf: central differences of the closed form
+        idx = np.where(hit)[0][:64]
+        eps = 1e-4
+        for a in range(3):
+            dp = np.zeros(3); dp[a] = eps
+            fd = -(f(pts[idx].astype(np.float32) + dp) - f(pts[idx].astype(np.float32) - dp)) / (2 * eps)
+            np.testing.assert_allclose(r["gradient"][0, 0][idx, a], fd, atol=2e-2)
+
+
+def test_primitive_world_costs_add_up(oracle):
+    """all four records together = the sum of the single-record scenes (obstacle-index order)"""
+    from curobo_amd.scene import cuboid_scene_arrays
+
+    rng = np.random.default_rng(1)
+    sph = np.concatenate([rng.uniform([-0.7, -0.7, 0.0], [0.8, 0.9, 0.9], size=(2, 5, 40, 3)), rng.uniform(0.02, 0.08, size=(2, 5, 40, 1))],
+                         -1).astype(np.float32)
+    full = oracle.scene_collision(sph, cuboid_scene_arrays(PRIM_WORLD), 3.0, 0.01, sweep=True)
+    parts = [oracle.scene_collision(sph, cuboid_scene_arrays([[dict(o, enable=(i == k)) for i, o in enumerate(PRIM_WORLD[0])]]), 3.0, 0.01,
+                                    sweep=True) for k in range(4)]
+    np.testing.assert_allclose(full["distance"], sum(p["distance"] for p in parts), rtol=1e-5, atol=1e-6)
+    assert all((p["distance"] > 0).any() for p in parts)
