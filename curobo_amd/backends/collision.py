@@ -132,3 +132,20 @@ def trajectory_cost_sum(
         ptr(out_cost), ptr(self_cost), ptr(scene_cost), batch_size, horizon, num_spheres,
         current_stream(out_cost),
     ))
+
+
+
+def mesh_esdf_bake(out_esdf: torch.Tensor, vertices: torch.Tensor, faces: torch.Tensor, grid_shape, voxel_size: float,
+                   grid_to_mesh_3x4, max_distance: float = 100.0) -> torch.Tensor:
+    """Closed triangle mesh -> fp16 ESDF grid on the device (``curobo_hip_mesh_esdf_bake``; the reference queries
+    meshes through Warp's BVH, geom/data/data_mesh.py:555-700).  ``out_esdf`` fp16 [nx * ny * nz] (pre-allocated),
+    ``vertices`` f32 [V, 3] in the mesh frame, ``faces`` i32 [F, 3], ``grid_to_mesh_3x4`` 12 floats (host)."""
+    assert out_esdf.dtype == torch.float16 and vertices.dtype == torch.float32 and faces.dtype == torch.int32
+    assert vertices.is_contiguous() and faces.is_contiguous() and out_esdf.is_contiguous()
+    nx, ny, nz = (int(v) for v in grid_shape)
+    assert out_esdf.numel() == nx * ny * nz
+    xf = (C.c_float * 12)(*[float(v) for v in grid_to_mesh_3x4])
+    check(load().curobo_hip_mesh_esdf_bake(ptr(out_esdf), ptr(vertices), ptr(faces), int(vertices.shape[0]), int(faces.shape[0]),
+                                           nx, ny, nz, float(voxel_size), float(max_distance), C.cast(xf, C.c_void_p),
+                                           current_stream(out_esdf)))
+    return out_esdf

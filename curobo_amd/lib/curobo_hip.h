@@ -173,6 +173,17 @@ int curobo_hip_sphere_obstacle_collision(
     int batch_size, int horizon, int num_spheres, int use_multi_env, int sweep_steps,
     int enable_speed_metric, const float *speed_dt, curobo_hip_stream_t stream);
 
+/* Mesh obstacles -> one more ESDF grid of the voxel store (scene-upload time, not the hot path).  The reference
+ * queries meshes through NVIDIA Warp's BVH (geom/data/data_mesh.py:555-700, wp.mesh_query_point); here a closed,
+ * consistently oriented triangle mesh is baked into an fp16 grid [nx, ny, nz] (voxel centres
+ * (i + 0.5 - n / 2) * voxel_size in the grid frame, the layout of geom/data/data_voxel.py:42-95): exact
+ * point-triangle distance, sign from the generalised winding number, clamped to +-max_distance.
+ * vertices [n_vertices, 3] (mesh frame) and faces int32 [n_faces, 3] are device pointers; grid_to_mesh_3x4_host is a
+ * HOST pointer to the row-major 3x4 transform grid frame -> mesh frame. */
+int curobo_hip_mesh_esdf_bake(uint16_t *out_esdf_fp16, const float *vertices, const int32_t *faces, int n_vertices,
+                              int n_faces, int nx, int ny, int nz, float voxel_size, float max_distance,
+                              const float *grid_to_mesh_3x4_host, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- cost: tool pose + c-space
  * The reference runs these as NVIDIA Warp kernels without a backend hook:
  * ToolPoseDistance (cost/wp_tool_pose.py:698-914, kernel :456-692) and the POSITION c-space cost

@@ -135,6 +135,8 @@ class SceneData:
         for k, v in arrays.items():
             if isinstance(v, np.ndarray):
                 t[k] = torch.as_tensor(v).to(device).contiguous()
+            elif torch.is_tensor(v):  # e.g. an ESDF grid baked on the device (bake_mesh_esdf_device)
+                t[k] = v.to(device).contiguous()
         coarse, block, dilate = None, 0, 0
         if coarse_culling and t.get("voxel_features") is not None and t["voxel_features"].numel() > 0:
             block, dilate = 4, 3  # culls spheres whose sweep stays within 2 voxels of the centre's voxel

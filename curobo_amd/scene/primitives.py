@@ -157,3 +157,37 @@ def bake_esdf(field: SDF, bounds_min: Sequence[float], bounds_max: Sequence[floa
     centre = 0.5 * (lo + hi)
     return voxel_grid_from_sdf(lambda p: np.clip(field(p), -max_distance, max_distance), tuple(int(s) for s in shape),
                                voxel_size, pose7=(*centre, 1, 0, 0, 0), max_distance=max_distance)
+
+
+def bake_mesh_esdf_device(vertices, faces, mesh_pose7: Sequence[float], bounds_min: Sequence[float], bounds_max: Sequence[float],
+                          voxel_size: float, device, max_distance: float = 100.0) -> Dict[str, object]:
+    """A closed triangle mesh (``vertices`` [V, 3] in the mesh frame, ``faces`` [F, 3], world pose ``mesh_pose7``) baked
+    ON THE DEVICE into an axis-aligned fp16 ESDF grid covering [bounds_min, bounds_max] (world frame): the device
+    counterpart of ``bake_esdf(mesh_sdf(...))`` (same algorithm: exact point-triangle distance + winding-number sign,
+    csrc/mesh_bake.hip).  Returns the voxel arrays for ``SceneData.from_arrays`` (``voxel_features`` is a device tensor)."""
+    import torch
+
+    from ..backends.collision import mesh_esdf_bake
+
+    lo, hi = np.asarray(bounds_min, np.float64), np.asarray(bounds_max, np.float64)
+    shape = tuple(int(v) for v in np.maximum(np.ceil((hi - lo) / voxel_size).astype(int), 2))
+    centre = 0.5 * (lo + hi)
+    # grid frame (axis aligned, origin at the grid centre) -> world -> mesh frame
+    inv = np.asarray(inverse_pose7(mesh_pose7), np.float64)
+    w, x, y, z = inv[3:7]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    t = R @ centre + inv[:3]
+    g2m = np.concatenate([R, t[:, None]], axis=1).reshape(-1)
+    dev = torch.device(device)
+    out = torch.empty(shape[0] * shape[1] * shape[2], dtype=torch.float16, device=dev)
+    v = torch.as_tensor(np.ascontiguousarray(vertices, dtype=np.float32), device=dev)
+    f = torch.as_tensor(np.ascontiguousarray(faces, dtype=np.int32), device=dev)
+    with torch.cuda.device(dev):
+        mesh_esdf_bake(out, v, f, shape, voxel_size, g2m, max_distance)
+    inv_pose = np.zeros((1, 1, 8), np.float32)
+    inv_pose[0, 0, :7] = inverse_pose7((*centre, 1, 0, 0, 0))
+    return {"voxel_params": np.array([[[shape[0], shape[1], shape[2], voxel_size]]], np.float32), "voxel_inv_pose": inv_pose,
+            "voxel_enable": np.ones((1, 1), np.uint8), "voxel_count": np.ones((1,), np.int32),
+            "voxel_features": out.view(1, 1, -1), "voxel_max_distance": float(max_distance)}

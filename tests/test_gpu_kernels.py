@@ -572,3 +572,37 @@ def test_scene_collision_analytic_primitives(sweep, voxel, oracle, device):
     assert np.array_equal(dist.cpu().numpy() > 0, ref["distance"] > 0)
     np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(grad.cpu().numpy(), ref["gradient"], atol=2e-4, rtol=1e-3)
+
+
+def test_mesh_esdf_bake_on_device(oracle, device):
+    """mesh -> ESDF on the device (csrc/mesh_bake.hip) vs the NumPy mesh signed distance (same algorithm) and vs the
+    closed form of the shape the mesh represents (a rotated box); then the baked grid through the collision kernel"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData, bake_esdf, bake_mesh_esdf_device, box_mesh, cuboid_sdf, mesh_sdf
+
+    dims, pose = [0.3, 0.5, 0.2], [0.1, -0.05, 0.4, 0.9238795, 0, 0.3826834, 0]
+    v, f = box_mesh(dims)
+    lo, hi, vs = [-0.4, -0.5, 0.0], [0.6, 0.4, 0.8], 0.025
+    grid = bake_mesh_esdf_device(v, f, pose, lo, hi, vs, device, max_distance=10.0)
+    torch.cuda.synchronize()
+    host = bake_esdf(mesh_sdf(v, f, pose), lo, hi, vs, max_distance=10.0)
+    got = grid["voxel_features"].cpu().numpy().astype(np.float32).reshape(-1)
+    want = host["voxel_features"].astype(np.float32).reshape(-1)
+    assert np.array_equal(grid["voxel_params"], host["voxel_params"])
+    np.testing.assert_allclose(got, want, atol=2e-3)  # fp16 grid, f32 vs f64 arithmetic
+    assert np.array_equal(np.sign(got)[np.abs(want) > 2e-3], np.sign(want)[np.abs(want) > 2e-3])
+    exact = bake_esdf(cuboid_sdf(dims, pose), lo, hi, vs, max_distance=10.0)["voxel_features"].astype(np.float32).reshape(-1)
+    np.testing.assert_allclose(got, exact, atol=2e-3)
+    # the device-baked grid as an obstacle: same cost as the host-baked grid
+    scene_d, scene_h = SceneData.from_arrays(grid, device), SceneData.from_arrays(host, device)
+    rng = np.random.default_rng(0)
+    sph = np.concatenate([rng.uniform(lo, hi, size=(4, 3, 50, 3)), rng.uniform(0.02, 0.06, size=(4, 3, 50, 1))], -1).astype(np.float32)
+    outs = []
+    for scene in (scene_d, scene_h):
+        dist, grad = torch.zeros(4, 3, 50, device=device), torch.zeros(4, 3, 50, 4, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([1.0], device=device),
+                                     torch.tensor([0.01], device=device), None, 4, 3, 50, False, 0, False, None)
+        torch.cuda.synchronize()
+        outs.append(dist.cpu().numpy())
+    assert (outs[1] > 0).mean() > 0.02
+    np.testing.assert_allclose(outs[0], outs[1], atol=3e-3)
