@@ -4,6 +4,7 @@ joint configurations -> (scene distance per sphere, self-collision distance per 
 
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import torch
@@ -14,9 +15,45 @@ from .kinematics import Kinematics, KinematicsCfg
 from .scene.data import SceneData
 
 
+@dataclass
+class RobotCollisionCheckerCfg:
+    """reference RobotCollisionCheckerCfg (collision/collision_robot_scene.py): robot + world + activation distance"""
+
+    kinematics: KinematicsCfg
+    scene: Optional[SceneData] = None
+    collision_activation_distance: float = 0.0
+    scene_weight: float = 1.0
+    self_weight: float = 1.0
+
+    @staticmethod
+    def load_from_config(robot_config, scene_model=None, collision_activation_distance: float = 0.0, device="cuda:0",
+                         assets_root: str = "", **unused) -> "RobotCollisionCheckerCfg":
+        """``robot_config``: packaged name (``"franka.yml"``), yaml path or dictionary; ``scene_model``: the reference's
+        scene format (``curobo_amd.scene.config``)."""
+        import os
+
+        from .scene.config import scene_arrays_from_config
+
+        if isinstance(robot_config, dict):
+            kin = KinematicsCfg.from_data_dict(robot_config, assets_root=assets_root, device=device)
+        elif os.path.exists(str(robot_config)):
+            kin = KinematicsCfg.from_robot_yaml_file(robot_config, assets_root or os.path.dirname(os.path.abspath(robot_config)), device=device)
+        else:
+            kin = KinematicsCfg.from_packaged(str(robot_config).replace(".yml", "").replace(".yaml", ""), device=device)
+        arrays = scene_arrays_from_config(scene_model)
+        scene = SceneData.from_arrays(arrays, device) if arrays is not None else None
+        return RobotCollisionCheckerCfg(kin, scene, collision_activation_distance)
+
+
 class RobotCollisionChecker:
-    def __init__(self, kinematics_cfg: KinematicsCfg, scene: Optional[SceneData], activation_distance: float = 0.0,
+    def __init__(self, kinematics_cfg, scene: Optional[SceneData] = None, activation_distance: float = 0.0,
                  scene_weight: float = 1.0, self_weight: float = 1.0):
+        """``RobotCollisionChecker(config: RobotCollisionCheckerCfg)`` (the reference's constructor) or the explicit
+        ``(kinematics_cfg, scene, activation_distance, ...)`` form."""
+        if isinstance(kinematics_cfg, RobotCollisionCheckerCfg):
+            c = kinematics_cfg
+            kinematics_cfg, scene, activation_distance = c.kinematics, c.scene, c.collision_activation_distance
+            scene_weight, self_weight = c.scene_weight, c.self_weight
         self.kinematics = Kinematics(kinematics_cfg, compute_spheres=True)
         self.scene = scene
         d = kinematics_cfg.kinematics_config.device

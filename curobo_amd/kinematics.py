@@ -23,6 +23,14 @@ class ToolPose:
     position: torch.Tensor
     quaternion: torch.Tensor
 
+    def as_goal(self):
+        """the poses as goals for the solvers (reference ToolPose.as_goal, _src/types/tool_pose.py): the last point
+        of every trajectory, one goal per batch row -> GoalToolPose [batch, T, 1, 3 | 4]"""
+        from .types import GoalToolPose
+
+        p, q = self.position.detach(), self.quaternion.detach()
+        return GoalToolPose(list(self.tool_frames), p[:, -1].unsqueeze(2).contiguous(), q[:, -1].unsqueeze(2).contiguous())
+
 
 @dataclass
 class KinematicsState:

@@ -1,0 +1,167 @@
+"""``InverseKinematics`` / ``InverseKinematicsCfg``: the reference's IK front end (``curobo.inverse_kinematics``:
+``IKSolver`` / ``IKSolverCfg.create`` / ``IKSolverResult``, reference ``curobo/_src/solver/solver_ik.py:60-760``,
+``solver_ik_cfg.py:30-330``) over ``curobo_amd.solver.IKSolver``.  The call sequence of the reference's
+``benchmark/ik_benchmark.py:55-142`` runs unchanged: ``create(robot=..., scene_model=..., num_seeds=...)`` ->
+``sample_configs`` -> ``compute_kinematics(JointState)`` -> ``tool_poses.as_goal()`` -> ``solve_pose(goal_tool_poses=...)``."""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from ..collision_checking import RobotCollisionChecker
+from ..kinematics import Kinematics, KinematicsCfg, KinematicsState
+from ..scene import SceneData
+from ..scene.config import scene_arrays_from_config
+from ..types import DeviceCfg, GoalToolPose, JointState
+from .ik import IKSolver, IKSolverCfg
+
+
+@dataclass
+class InverseKinematicsResult:
+    """reference IKSolverResult / BaseSolverResult fields (solver_ik_result.py, solver_result.py)"""
+
+    success: torch.Tensor            # [batch, return_seeds] bool
+    solution: torch.Tensor           # [batch, return_seeds, dof]
+    js_solution: JointState
+    position_error: torch.Tensor     # [batch, return_seeds] metres
+    rotation_error: torch.Tensor     # [batch, return_seeds] radians
+    goalset_index: Optional[torch.Tensor] = None
+    solve_time: float = 0.0
+    debug_info: Optional[dict] = None
+
+
+@dataclass
+class InverseKinematicsCfg:
+    kinematics: KinematicsCfg = None
+    scene: Optional[SceneData] = None
+    device_cfg: DeviceCfg = field(default_factory=DeviceCfg)
+    num_seeds: int = 32
+    position_tolerance: float = 0.005
+    orientation_tolerance: float = 0.05
+    use_cuda_graph: bool = True
+    self_collision_check: bool = True
+    optimizer_collision_activation_distance: float = 0.0025
+    exit_early: bool = True
+    seed_solver_num_seeds: int = 64
+    use_lm_seed: bool = True
+    max_batch_size: int = 0
+    max_goalset: int = 1
+    stream_shards: int = 1
+
+    @staticmethod
+    def create(robot: Union[str, Dict], scene_model: Union[str, Dict, List, None] = None, num_seeds: int = 32,
+               position_tolerance: float = 0.005, orientation_tolerance: float = 0.05, use_cuda_graph: bool = True,
+               self_collision_check: bool = True, optimizer_collision_activation_distance: float = 0.0025,
+               device_cfg: Optional[DeviceCfg] = None, seed_solver_num_seeds: Optional[int] = None, max_batch_size: int = 0,
+               max_goalset: int = 1, use_lm_seed: bool = True, exit_early: bool = True, assets_root: str = "", **unused
+               ) -> "InverseKinematicsCfg":
+        """``robot``: packaged name (``"franka.yml"``), a robot yaml path or its dictionary.  ``scene_model``: the
+        reference's scene format (see ``curobo_amd.scene.config``).  Keyword arguments of the reference this backend has
+        no use for (``optimizer_configs``, ``metrics_rollout``, ``transition_model``, ...) are accepted and ignored: the
+        cost set and optimiser settings of ``content/configs/task/ik/lbfgs_ik.yml`` are built in."""
+        import os
+
+        device_cfg = device_cfg or DeviceCfg()
+        dev = device_cfg.device
+        if isinstance(robot, dict):
+            kin = KinematicsCfg.from_data_dict(robot, assets_root=assets_root, device=dev)
+        elif os.path.exists(str(robot)):
+            kin = KinematicsCfg.from_robot_yaml_file(robot, assets_root or os.path.dirname(os.path.abspath(robot)), device=dev)
+        else:
+            kin = KinematicsCfg.from_packaged(str(robot).replace(".yml", "").replace(".yaml", ""), device=dev)
+        arrays = scene_arrays_from_config(scene_model)
+        scene = SceneData.from_arrays(arrays, dev) if arrays is not None else None
+        return InverseKinematicsCfg(
+            kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,
+            orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,
+            optimizer_collision_activation_distance=optimizer_collision_activation_distance, exit_early=exit_early,
+            seed_solver_num_seeds=seed_solver_num_seeds or max(32, 2 * num_seeds), use_lm_seed=use_lm_seed,
+            max_batch_size=max_batch_size, max_goalset=max_goalset)
+
+
+class InverseKinematics:
+    def __init__(self, config: InverseKinematicsCfg):
+        self.config = config
+        self.kinematics = Kinematics(config.kinematics, compute_spheres=True)
+        self._checker: Optional[RobotCollisionChecker] = None
+        self._solvers: Dict[int, IKSolver] = {}
+        self.solve_time = 0.0
+
+    # ---- reference members used by benchmarks / planners
+    @property
+    def joint_names(self) -> List[str]:
+        return self.kinematics.joint_names
+
+    @property
+    def tool_frames(self) -> List[str]:
+        return self.kinematics.tool_frames
+
+    @property
+    def dof(self) -> int:
+        return self.config.kinematics.kinematics_config.num_dof
+
+    def compute_kinematics(self, joint_state: Union[JointState, torch.Tensor]) -> KinematicsState:
+        return self.kinematics.compute_kinematics(joint_state)
+
+    def _collision_checker(self) -> RobotCollisionChecker:
+        if self._checker is None:
+            self._checker = RobotCollisionChecker(self.config.kinematics, self.config.scene)
+        return self._checker
+
+    def sample_configs(self, num_samples: int, rejection_ratio: int = 10) -> torch.Tensor:
+        """collision-free joint configurations [<= num_samples, dof] (reference IKSolver.sample_configs)"""
+        chk = self._collision_checker()
+        chk.rejection_ratio = rejection_ratio
+        return chk.sample(num_samples, mask_valid=True)
+
+    def reset_seed(self) -> None:
+        for s in self._solvers.values():
+            s._gen.manual_seed(s.cfg.seed)
+            if s.seed_solver is not None and hasattr(s.seed_solver, "reset_seed"):
+                s.seed_solver.reset_seed()
+
+    def update_world(self, scene: SceneData) -> None:
+        self.config.scene = scene
+        self._solvers.clear()
+        self._checker = None
+
+    def _solver(self, batch: int) -> IKSolver:
+        if batch not in self._solvers:
+            c = self.config
+            cfg = IKSolverCfg(num_seeds=c.num_seeds, position_threshold=c.position_tolerance, rotation_threshold=c.orientation_tolerance,
+                              use_lm_seed=c.use_lm_seed, seed_solver_num_seeds=c.seed_solver_num_seeds, num_goalset=c.max_goalset,
+                              stream_shards=c.stream_shards if batch % max(c.stream_shards, 1) == 0 else 1)
+            cfg.rollout.scene_activation_distance = c.optimizer_collision_activation_distance
+            if not c.self_collision_check:
+                cfg.rollout.self_collision_weight = 0.0
+            self._solvers[batch] = IKSolver(c.kinematics.kinematics_config, c.scene, batch, cfg, use_cuda_graph=c.use_cuda_graph)
+        return self._solvers[batch]
+
+    def solve_pose(self, goal_tool_poses: GoalToolPose, seed_config: Optional[torch.Tensor] = None, return_seeds: int = 1,
+                   **unused) -> InverseKinematicsResult:
+        """``goal_tool_poses``: GoalToolPose [batch, T, num_goalset, 3 | 4] (first tool frame is the goal frame);
+        ``seed_config`` [batch, num_seeds, dof] optional warm starts."""
+        t0 = time.perf_counter()
+        gp, gq = goal_tool_poses.position, goal_tool_poses.quaternion
+        B, G = int(gp.shape[0]), int(gp.shape[2])
+        if G != self.config.max_goalset:
+            self.config.max_goalset = G
+            self._solvers.clear()
+        slv = self._solver(B)
+        pos, quat = gp[:, 0].reshape(B, G, 3), gq[:, 0].reshape(B, G, 4)
+        if G == 1:
+            pos, quat = pos[:, 0], quat[:, 0]
+        r = slv.solve_pose(pos, quat, seeds=seed_config, return_seeds=return_seeds, exit_early=self.config.exit_early)
+        torch.cuda.synchronize(pos.device) if pos.is_cuda else None
+        self.solve_time = time.perf_counter() - t0
+        k = return_seeds
+        sol = r.solution.reshape(B, k, -1)
+        return InverseKinematicsResult(
+            success=r.success.reshape(B, k), solution=sol, js_solution=JointState.from_position(sol, joint_names=self.joint_names),
+            position_error=r.position_error.reshape(B, k), rotation_error=r.rotation_error.reshape(B, k),
+            goalset_index=None if r.goalset_index is None else r.goalset_index.reshape(B, k), solve_time=self.solve_time,
+            debug_info={"optimizer_ran": bool(getattr(slv, "optimizer_ran", True))})

@@ -1,0 +1,133 @@
+"""The reference's public names (curobo.kinematics / collision_checking / rollout / optim / types /
+inverse_kinematics) resolve in this repository's ``curobo`` namespace, and the call sequences of the reference's
+own benchmark / tests run on them (GPU)."""
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_reference_public_names_resolve():
+    from curobo import InverseKinematics, InverseKinematicsCfg  # noqa: F401  (reference: curobo/__init__.py)
+    from curobo.collision_checking import RobotCollisionChecker, RobotCollisionCheckerCfg  # noqa: F401
+    from curobo.kinematics import Kinematics, KinematicsCfg, KinematicsState  # noqa: F401
+    from curobo.optim import MPPI, LBFGSOpt, LBFGSOptCfg, MPPICfg, MultiStageOptimizer  # noqa: F401
+    from curobo.rollout import RosenbrockCfg, RosenbrockRollout  # noqa: F401
+    from curobo.types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPose  # noqa: F401
+    import inspect
+
+    # constructor shapes of the reference: LBFGSOpt(config, rollout_list, use_cuda_graph) (optim/gradient/lbfgs.py:156),
+    # Kinematics(config, compute_jacobian, compute_spheres, compute_com) (robot/kinematics/kinematics.py:49),
+    # compute_kinematics(joint_state, idxs_env) (:138)
+    assert list(inspect.signature(LBFGSOpt.__init__).parameters)[1:4] == ["config", "rollout_list", "use_cuda_graph"]
+    assert list(inspect.signature(Kinematics.__init__).parameters)[1:5] == ["config", "compute_jacobian", "compute_spheres", "compute_com"]
+    assert list(inspect.signature(Kinematics.compute_kinematics).parameters)[1:3] == ["joint_state", "idxs_env"]
+    for f in ("num_problems", "num_iters", "history", "step_scale", "use_cuda_kernel_step_direction", "use_cuda_kernel_shared_buffers",
+              "use_cuda_kernel_line_search", "stable_mode", "solver_type", "line_search_scale"):
+        assert f in LBFGSOptCfg.__dataclass_fields__, f  # the fields tests/_src/optim/gradient/test_lbfgs.py:249-261 sets
+
+
+def test_rosenbrock_rollout_and_cost_containers():
+    from curobo.rollout import Rollout, RosenbrockCfg, RosenbrockRollout
+    from curobo.types import DeviceCfg
+
+    ro = RosenbrockRollout(RosenbrockCfg(device_cfg=DeviceCfg("cpu"), dimensions=3))
+    assert isinstance(ro, Rollout) and ro.action_dim == 3 and ro.action_horizon == 1
+    x = torch.tensor([[[1.0, 1.0, 1.0]], [[0.0, 0.0, 0.0]], [[-1.0, 2.0, 0.5]]])
+    c = ro.evaluate_action(x).costs_and_constraints.get_sum_cost_and_constraint(sum_horizon=True)
+    want = [(1 - a) ** 2 + 100 * (b - a * a) ** 2 + (1 - b) ** 2 + 100 * (cc - b * b) ** 2 for a, b, cc in x[:, 0].tolist()]
+    np.testing.assert_allclose(c.numpy(), want, rtol=1e-6)
+    m = ro.compute_metrics_from_action(x)
+    assert m.feasible.all() and m.convergence.shape == (3, 1)
+    assert ro.get_initial_action(use_random=True).shape == (3, 1, 3)
+
+
+def test_scene_config_in_the_reference_format():
+    from curobo.scene import load_scene_config, scene_arrays_from_config
+
+    cfg = {"cuboid": {"table": {"dims": [2.0, 2.0, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}},
+           "sphere": {"ball": {"radius": 0.1, "pose": [0.4, 0, 0.4, 1, 0, 0, 0]}},
+           "cylinder": {"post": {"radius": 0.05, "height": 0.8, "pose": [0.3, 0.3, 0.4, 1, 0, 0, 0]}},
+           "capsule": {"bar": {"radius": 0.04, "base": [0, 0, 0], "tip": [0, 0, 0.4], "pose": [-0.3, 0.2, 0.3, 1, 0, 0, 0]}}}
+    arr = scene_arrays_from_config(cfg)
+    assert arr["cuboid_dims"].shape == (1, 4, 4) and arr["cuboid_dims"][0, :, 3].tolist() == [0.0, 1.0, 2.0, 3.0]
+    np.testing.assert_allclose(arr["cuboid_dims"][0, 2], [0.04, 0.2, 0.0, 2.0])  # capsule: radius, half length
+    np.testing.assert_allclose(arr["cuboid_inv_pose"][0, 2, :3], [0.3, -0.2, -0.5], atol=1e-6)  # centred on the segment
+    assert load_scene_config("collision_table.yml")[0][0]["dims"] == [4.0, 4.0, 0.2]
+    assert load_scene_config(None) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_cuda_graph", [False, True])
+def test_reference_shaped_lbfgs_on_rollout_protocol_objects(use_cuda_graph, device):
+    """the call sequence of the reference's tests/_src/optim/gradient/test_lbfgs.py:236-270 (create_optimizer,
+    reinitialize, optimize) on a Rollout-protocol object written in torch (gradient through autograd), kernels = HIP"""
+    from curobo.optim import LBFGSOpt, LBFGSOptCfg
+    from curobo.rollout import CostsAndConstraints, RolloutResult, RosenbrockCfg, RosenbrockRollout
+    from curobo.types import DeviceCfg
+
+    class QuadraticRollout(RosenbrockRollout):  # the reference test's cost: sum (10 - x)^2 (MockRollout, :52-191)
+        def __init__(self, dof, horizon):
+            super().__init__(RosenbrockCfg(device_cfg=DeviceCfg(device), dimensions=dof, time_action_horizon=horizon, time_horizon=horizon))
+            self._lows, self._highs = -torch.ones(dof, device=device), torch.ones(dof, device=device)
+
+        def evaluate_action(self, act_seq, **kw):
+            cc = CostsAndConstraints()
+            cc.costs.add(((10.0 - act_seq) ** 2).sum(-1, keepdim=True), "cost")
+            return RolloutResult(act_seq, None, cc)
+
+    ro = QuadraticRollout(7, 4)
+    cfg = LBFGSOptCfg(num_problems=4, num_iters=50, history=10, step_scale=0.98, use_cuda_kernel_step_direction=True,
+                      use_cuda_kernel_shared_buffers=True, use_cuda_kernel_line_search=True, stable_mode=True, solver_type="lbfgs",
+                      line_search_scale=[0, 0.1, 0.5, 1.0], inner_iters=25)
+    opt = LBFGSOpt(cfg, [ro, ro], use_cuda_graph=use_cuda_graph)
+    opt.update_num_problems(4)
+    torch.manual_seed(0)
+    x0 = torch.randn(4, 4, 7, device=device) * 10.0
+    opt.reinitialize(x0.clone())
+    out = opt.optimize(x0.clone()).clone()
+    assert float(((10.0 - out) ** 2).sum(-1).mean()) < 1e-5  # the reference test's bar (:320)
+    # Rosenbrock (curobo.rollout) from the bounds' corner
+    rr = RosenbrockRollout(RosenbrockCfg(device_cfg=DeviceCfg(device), dimensions=2))
+    opt2 = LBFGSOpt(LBFGSOptCfg(num_problems=8, num_iters=400, history=7, inner_iters=25), [rr], use_cuda_graph=use_cuda_graph)
+    x = rr.get_initial_action(use_random=True)
+    rr.update_batch_size(8)
+    x = torch.linspace(-1.2, 1.5, 16, device=device).view(8, 1, 2)
+    best = opt2.optimize(x)
+    assert float((best.view(8, 2) - 1.0).abs().max()) < 2e-2 and opt2.solve_time > 0.0
+
+
+@pytest.mark.gpu
+def test_ik_benchmark_call_sequence(device):
+    """reference benchmark/ik_benchmark.py:55-165, line for line on the curobo namespace of this repository"""
+    from curobo.inverse_kinematics import InverseKinematics as IKSolver
+    from curobo.inverse_kinematics import InverseKinematicsCfg as IKSolverCfg
+    from curobo.types import DeviceCfg, JointState
+
+    batch_size, num_seeds = 100, 8
+    device_cfg = DeviceCfg()
+    config = IKSolverCfg.create(
+        robot="franka.yml", optimizer_configs=["ik/lbfgs_ik.yml"], metrics_rollout="metrics_base.yml",
+        transition_model="ik/transition_ik.yml", scene_model="collision_table.yml", use_cuda_graph=True, num_seeds=num_seeds,
+        position_tolerance=0.005, optimizer_collision_activation_distance=0.0025, self_collision_check=True, device_cfg=device_cfg,
+        override_iters_for_multi_link_ik=None, seed_solver_num_seeds=max(32, num_seeds * 2), max_batch_size=batch_size)
+    ik_solver = IKSolver(config)
+    q_sample = ik_solver.sample_configs(batch_size, rejection_ratio=10)
+    assert q_sample.shape == (batch_size, 7)
+    ik_solver.config.exit_early = False
+    results = []
+    for exit_early in (False, True):
+        ik_solver.config.exit_early = exit_early
+        ik_solver.reset_seed()
+        kin_state = ik_solver.compute_kinematics(JointState.from_position(q_sample))
+        goal_tool_poses = kin_state.tool_poses.as_goal()
+        result = ik_solver.solve_pose(goal_tool_poses=goal_tool_poses, seed_config=None)
+        success = 100.0 * torch.count_nonzero(result.success).item() / len(q_sample)
+        p_err = np.percentile(result.position_error[result.success.view(-1)].cpu().numpy(), 90).item()
+        q_err = np.percentile(result.rotation_error[result.success.view(-1)].cpu().numpy(), 90).item()
+        results.append((success, p_err, q_err, result.solve_time))
+        assert success >= 95.0 and p_err < 0.005 and q_err < 0.05, results
+        # the solutions really solve the problem: FK of the solution reaches the goal
+        st = ik_solver.compute_kinematics(result.js_solution[:, 0])
+        err = (st.tool_poses.position[:, 0, 0] - goal_tool_poses.position[:, 0, 0]).norm(dim=-1)
+        assert float(err[result.success.view(-1)].max()) < 0.005
