@@ -29,7 +29,8 @@ class ToolPose:
         from .types import GoalToolPose
 
         p, q = self.position.detach(), self.quaternion.detach()
-        return GoalToolPose(list(self.tool_frames), p[:, -1].unsqueeze(2).contiguous(), q[:, -1].unsqueeze(2).contiguous())
+        # copies: the kinematics front end re-uses its output buffers on the next call
+        return GoalToolPose(list(self.tool_frames), p[:, -1].unsqueeze(2).clone(), q[:, -1].unsqueeze(2).clone())
 
 
 @dataclass

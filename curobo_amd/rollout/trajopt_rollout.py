@@ -44,6 +44,10 @@ class TrajOptRolloutCfg:
     pose_weight: List[float] = field(default_factory=lambda: [1000000.0, 100000.0])
     pose_convergence_tolerance: List[float] = field(default_factory=lambda: [1e-8, 1e-8])
     rotation_method: int = 0
+    #: pose-cost weight factor of the NON-terminal points (0 = the pose goal only acts on the last point, as in the
+    #: reference trajopt task; > 0 = tracking along the whole horizon, the reference's MPC task
+    #: content/configs/task/mpc/: non_terminal_pose_axes_weight_factor)
+    non_terminal_pose_factor: float = 0.0
     # cost_cfg.cspace_cfg (cost_type STATE)
     cspace_weight: List[float] = field(default_factory=lambda: [10000.0, 10000.0, 100.0, 50.0, 100.0])
     cspace_activation_distance: List[float] = field(default_factory=lambda: [0.01] * 5)
@@ -88,7 +92,7 @@ class TrajOptRollout:
         self._eta_scene, self._speed_dt = f([c.scene_activation_distance]), f([c.traj_dt])
         self._traj_dt, self._implicit_goal = f([c.traj_dt]), torch.zeros(1, dtype=torch.uint8, device=d)
         self._pose_w = f(c.pose_weight)
-        self._axes_w, self._axes_w0 = torch.ones(T, 6, device=d), torch.zeros(T, 6, device=d)
+        self._axes_w, self._axes_w0 = torch.ones(T, 6, device=d), torch.full((T, 6), float(c.non_terminal_pose_factor), device=d)
         self._tol = f([c.pose_convergence_tolerance] * T)
         self._project = torch.zeros(T, dtype=torch.uint8, device=d)
         self._cs_w, self._cs_eta, self._cs_reg = f(c.cspace_weight), f(c.cspace_activation_distance), f(c.cspace_regularization)
@@ -137,17 +141,29 @@ class TrajOptRollout:
         self.goal_position, self.goal_quat = z(1, T, 1, 3), z(1, T, 1, 4)
         self.goal_quat[..., 0] = 1.0
 
-    def update_start_state(self, start_position: Optional[torch.Tensor]) -> None:
+    def update_start_state(self, start_position: Optional[torch.Tensor], start_velocity: Optional[torch.Tensor] = None,
+                           start_acceleration: Optional[torch.Tensor] = None, start_idx: Optional[torch.Tensor] = None) -> None:
+        """Start state(s) of the trajectories: position [n, D] (+ velocity / acceleration for a robot in motion: the
+        B-spline's fixed knots reproduce them, bspline_boundary_constraint.cuh:330-367); ``start_idx`` [B] picks the
+        start state of every trajectory (reference ``idxs_start``; default: state 0)."""
         D, d = self.action_dim, self.device
         if start_position is None:
             start_position = torch.zeros(1, D, device=d)
         sp = start_position.to(d, torch.float32).reshape(-1, D).contiguous()
+        if start_idx is not None:
+            self.start_idx.copy_(start_idx.to(device=d, dtype=torch.int32).reshape(-1))
         if getattr(self, "start_pos", None) is not None and self.start_pos.shape == sp.shape:
             self.start_pos.copy_(sp)  # keep the pointers a captured hipGraph holds
+            self.start_vel.copy_(start_velocity.to(d, torch.float32).reshape(-1, D)) if start_velocity is not None else self.start_vel.zero_()
+            self.start_acc.copy_(start_acceleration.to(d, torch.float32).reshape(-1, D)) if start_acceleration is not None else self.start_acc.zero_()
             return
         self.start_pos = sp.clone()
         n = self.start_pos.shape[0]
         self.start_vel, self.start_acc, self.start_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
+        if start_velocity is not None:
+            self.start_vel.copy_(start_velocity.to(d, torch.float32).reshape(-1, D))
+        if start_acceleration is not None:
+            self.start_acc.copy_(start_acceleration.to(d, torch.float32).reshape(-1, D))
         if getattr(self, "goal_pos", None) is None:
             self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(1, D, device=d) for _ in range(4))
 

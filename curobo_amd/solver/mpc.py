@@ -1,0 +1,199 @@
+"""Model-predictive control on the trajectory-optimisation rollout.
+
+Counterpart of the reference's ``MPCSolver`` (``curobo/_src/solver/solver_mpc.py:33-878``; configuration
+``solver_mpc_cfg.py:30-287``: ``optimization_dt``, ``interpolation_steps``, ``cold_start_optimization_num_iters``,
+``warm_start_optimization_num_iters``): a receding-horizon loop over B-spline knots.
+
+    setup(current_state, goal)              goals (tool pose and / or joint configuration), batch of robots
+    optimize_next_action(current_state)     first call: COLD start (more iterations, from a hold-still seed);
+                                            then, whenever the command buffer of the current knot interval is used up:
+                                            shift the knots by one interval, re-anchor the spline's start state at the
+                                            robot's CURRENT position / velocity / acceleration and WARM-start L-BFGS
+                                            (fewer iterations) -- solver_mpc.py:533-700
+    -> MPCSolverResult.next_action          the next interpolated state (position, velocity, acceleration)
+
+The optimiser iterations are the same hipGraph-captured HIP kernels as trajectory optimisation (fused rollout: pose
+tracking along the horizon + c-space STATE limits + self + swept scene collision; line search + two-loop)."""
+
+from __future__ import annotations
+
+import dataclasses
+import time
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from ..optim import LBFGSOpt, LBFGSOptCfg
+from ..robot.kinematics_params import KinematicsParams
+from ..rollout.trajopt_rollout import TrajOptRollout, TrajOptRolloutCfg
+from ..scene.data import SceneData
+from ..types import GoalToolPose, JointState
+
+
+@dataclass
+class MPCSolverCfg:
+    optimization_dt: float = 0.02          # duration of one knot interval (reference default, solver_mpc_cfg.py:71)
+    interpolation_steps: int = 4           # commands per knot interval: command_dt = optimization_dt / interpolation_steps
+    n_knots: int = 16
+    #: False (the reference): commands are the plan's SECOND knot interval and the plan is renewed every interval from the
+    #: robot's measured state -- the command stream then steps by about velocity x optimization_dt at every renewal (the
+    #: first interval, which only extrapolates the start state, is skipped).  True: the first TWO intervals of every plan
+    #: are executed from sample 1 on, so consecutive plans join with continuous position / velocity / acceleration, at
+    #: half the re-planning rate.
+    continuous_commands: bool = True
+    cold_start_optimization_num_iters: int = 100
+    warm_start_optimization_num_iters: int = 25
+    #: tracking along the whole horizon; pose weights far below the trajopt task's (1e6 / 1e5: a terminal goal there) so
+    #: that the velocity / acceleration bounds of the c-space STATE cost shape the motion at a 5 ms command step
+    rollout: TrajOptRolloutCfg = field(default_factory=lambda: TrajOptRolloutCfg(
+        non_terminal_pose_factor=1.0, pose_weight=[2000.0, 200.0], cspace_weight=[10000.0, 10000.0, 2000.0, 100.0, 100.0],
+        cspace_regularization=[10.0, 100.0, 1.0, 0.0, 10.0]))
+    optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=15, inner_iters=25))
+    use_cuda_graph: bool = True
+
+
+@dataclass
+class MPCSolverResult:
+    """reference MPCSolverResult (solver_mpc_result.py)"""
+
+    next_action: Optional[JointState] = None
+    action_sequence: Optional[JointState] = None   # the remaining planned states [B, steps, D]
+    action_buffer: Optional[torch.Tensor] = None   # knots [B, n_knots, D]
+    action_dt: float = 0.0
+    solve_time: float = 0.0
+    position_error: Optional[torch.Tensor] = None  # [B] tool position error of the plan's end point
+    rotation_error: Optional[torch.Tensor] = None
+    feasible: Optional[torch.Tensor] = None        # [B] no collision / limit violation over the next two knot intervals
+    reoptimized: bool = False
+
+
+class MPCSolver:
+    def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], num_robots: int = 1, cfg: Optional[MPCSolverCfg] = None):
+        self.kin, self.scene, self.B = kin, scene, num_robots
+        self.cfg = cfg or MPCSolverCfg()
+        c = self.cfg
+        self.device = kin.device
+        rc = dataclasses.replace(c.rollout, n_knots=c.n_knots, interpolation_steps=c.interpolation_steps,
+                                 traj_dt=c.optimization_dt / c.interpolation_steps)
+        self.rollout_cfg = rc
+        ocfg = dataclasses.replace(c.optimizer, num_problems=num_robots, num_iters=c.cold_start_optimization_num_iters)
+        self.nls = len(ocfg.line_search_scale)
+        self.rollout = TrajOptRollout(kin, scene, num_robots * self.nls, rc)
+        self.metrics_rollout = TrajOptRollout(kin, scene, num_robots, dataclasses.replace(rc, use_fused=False))
+        bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+        self.optimizer = LBFGSOpt(ocfg, self.rollout.cost_and_gradient, rc.n_knots, kin.num_dof, bounds, self.device,
+                                  use_cuda_graph=c.use_cuda_graph)
+        self._rows = torch.arange(num_robots * self.nls, device=self.device, dtype=torch.int32) // self.nls
+        self._mrows = torch.arange(num_robots, device=self.device, dtype=torch.int32)
+        self._knots: Optional[torch.Tensor] = None
+        self._cmd = None       # (position, velocity, acceleration) [B, H, D] of the current plan
+        self._cursor = 0
+        self._setup_done = False
+        self._warm = False
+
+    # ------------------------------------------------------------------ problem definition
+    @property
+    def command_dt(self) -> float:
+        return self.cfg.optimization_dt / self.cfg.interpolation_steps
+
+    def setup(self, current_state: JointState, goal_tool_poses: Optional[GoalToolPose] = None) -> None:
+        """first state + goals (reference MPCSolver.setup, solver_mpc.py:261-330)"""
+        if goal_tool_poses is not None:
+            self.update_goal_tool_poses(goal_tool_poses)
+        self.update_current_state(current_state)
+        self._setup_done, self._warm = True, False
+        self._knots = None
+
+    def update_goal_tool_poses(self, goal_tool_poses: GoalToolPose) -> None:
+        """tracked tool poses [B, T, 1, 3 | 4]; may change between control steps (reference :365-438)"""
+        gp = goal_tool_poses.position.to(self.device, torch.float32).contiguous()
+        gq = goal_tool_poses.quaternion.to(self.device, torch.float32).contiguous()
+        T = self.kin.num_pose_links
+        if gp.shape[1] != T:
+            gp, gq = gp[:, :1].expand(-1, T, -1, -1).contiguous(), gq[:, :1].expand(-1, T, -1, -1).contiguous()
+        self.rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._rows)
+        self.metrics_rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._mrows)
+
+    def update_current_state(self, current_state: JointState) -> None:
+        """the spline starts at the robot's current position / velocity / acceleration (reference :476-497)"""
+        D = self.kin.num_dof
+        p = current_state.position.to(self.device, torch.float32).reshape(self.B, D)
+        v = None if current_state.velocity is None else current_state.velocity.reshape(self.B, D)
+        a = None if current_state.acceleration is None else current_state.acceleration.reshape(self.B, D)
+        self.rollout.update_start_state(p, v, a, start_idx=self._rows)
+        self.metrics_rollout.update_start_state(p, v, a, start_idx=self._mrows)
+        self._current = p.clone()
+
+    def reset_robot(self, current_state: JointState) -> None:
+        self.update_current_state(current_state)
+        self._warm, self._knots = False, None
+
+    # ------------------------------------------------------------------ solves
+    def _solve(self, seed_knots: torch.Tensor, iters: int) -> None:
+        o = self.optimizer
+        o.cfg.num_iters = iters
+        best = o.optimize(seed_knots)
+        self._knots = best.reshape(self.B, self.rollout_cfg.n_knots, self.kin.num_dof).clone()
+        m = self.metrics_rollout
+        m.evaluate_action(self._knots, with_gradient=False)
+        self._cmd = (m.position.clone(), m.velocity.clone(), m.acceleration.clone())
+        # Commands come from the SECOND knot interval (reference: command_start_idx = interpolation_steps for B-spline
+        # control spaces, solver_mpc.py:44-55): the first one is spanned by the start state's fixed knots alone (it only
+        # extrapolates the current position / velocity / acceleration), the free knots act from the second one on.
+        self._cursor = 1 if self.cfg.continuous_commands else self.cfg.interpolation_steps
+        H, T = self.rollout_cfg.padded_horizon, self.kin.num_pose_links
+        self._pos_err = m.pose_pos_dist.view(self.B, H, T)[:, -1, 0].clone()
+        self._rot_err = m.pose_rot_dist.view(self.B, H, T)[:, -1, 0].clone()
+        near = 2 * self.cfg.interpolation_steps + 1
+        ok = m.self_dist.view(self.B, H)[:, :near].sum(-1) <= 0.0
+        if self.scene is not None:
+            ok &= m.scene_dist.view(self.B, H, -1)[:, :near].sum((-1, -2)) <= 0.0
+        self._feasible = ok
+
+    def cold_start_solve(self, current_state: JointState) -> None:
+        """hold-still seed, ``cold_start_optimization_num_iters`` iterations (reference :626-642)"""
+        self.update_current_state(current_state)
+        seed = self._current.view(self.B, 1, -1).expand(-1, self.rollout_cfg.n_knots, -1).contiguous()
+        self._solve(seed, self.cfg.cold_start_optimization_num_iters)
+
+    def warm_start_solve(self, current_state: JointState) -> None:
+        """previous knots shifted by one interval (last knot repeated), ``warm_start_optimization_num_iters`` iterations
+        (reference :643-700: trajectory_execution_manager.get_shifted action buffer + optimizer.shift)"""
+        self.update_current_state(current_state)
+        seed = torch.cat([self._knots[:, 1:], self._knots[:, -1:]], dim=1).contiguous()
+        self._solve(seed, self.cfg.warm_start_optimization_num_iters)
+
+    def optimize_next_action(self, current_state: JointState) -> MPCSolverResult:
+        if not self._setup_done:
+            raise RuntimeError("MPC problem not setup, call setup first")
+        t0 = time.perf_counter()
+        reopt = False
+        if not self._warm:
+            self.cold_start_solve(current_state)
+            self._warm, reopt = True, True
+        elif self._cursor >= 2 * self.cfg.interpolation_steps + (1 if self.cfg.continuous_commands else 0):  # commands used up
+            self.warm_start_solve(current_state)
+            reopt = True
+        p, v, a = (x[:, self._cursor] for x in self._cmd)
+        rest = slice(self._cursor, None)
+        self._cursor += 1
+        if p.is_cuda:
+            torch.cuda.synchronize(p.device)
+        return MPCSolverResult(
+            next_action=JointState(position=p.clone(), velocity=v.clone(), acceleration=a.clone(), joint_names=self.kin.joint_names),
+            action_sequence=JointState(position=self._cmd[0][:, rest], velocity=self._cmd[1][:, rest], acceleration=self._cmd[2][:, rest]),
+            action_buffer=self._knots, action_dt=self.command_dt, solve_time=time.perf_counter() - t0, position_error=self._pos_err,
+            rotation_error=self._rot_err, feasible=self._feasible, reoptimized=reopt)
+
+    def optimize_action_sequence(self, current_state: JointState) -> MPCSolverResult:
+        """always re-optimise and return the whole planned sequence (reference :581-624)"""
+        if not self._setup_done:
+            raise RuntimeError("MPC problem not setup, call setup first")
+        t0 = time.perf_counter()
+        (self.warm_start_solve if self._warm else self.cold_start_solve)(current_state)
+        self._warm = True
+        return MPCSolverResult(action_sequence=JointState(position=self._cmd[0][:, self.cfg.interpolation_steps:], velocity=self._cmd[1][:, self.cfg.interpolation_steps:],
+                                                          acceleration=self._cmd[2][:, self.cfg.interpolation_steps:]),
+                               action_buffer=self._knots, action_dt=self.command_dt, solve_time=time.perf_counter() - t0,
+                               position_error=self._pos_err, rotation_error=self._rot_err, feasible=self._feasible, reoptimized=True)

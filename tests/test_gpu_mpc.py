@@ -1,0 +1,70 @@
+"""Model-predictive control loop (reference solver/solver_mpc.py): closed-loop tracking of a
+tool-pose goal with warm-started re-optimisation, and re-planning when the goal moves."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("continuous", [False, True])
+def test_mpc_tracks_a_pose_goal_in_closed_loop(continuous, oracle, device):
+    from curobo_amd.kinematics import Kinematics, KinematicsCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import MPCSolver, MPCSolverCfg
+    from curobo_amd.types import JointState
+    from curobo_amd.workloads import c1_world, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("franka", device=device)
+    kin = kcfg.kinematics_config
+    arrays = cuboid_scene_arrays(c1_world())
+    scene = SceneData.from_arrays(arrays, device)
+    B = 2
+    fk = Kinematics(kcfg, compute_spheres=True)
+    q0 = torch.as_tensor(start_configuration(kcfg.model), device=device).repeat(B, 1)
+    # goals = FK of collision-free configurations near the start (reachable without crossing an obstacle)
+    dq = torch.tensor([[0.5, 0.2, -0.3, 0.3, 0.2, -0.2, 0.3], [-0.5, 0.1, 0.3, 0.2, -0.3, 0.3, -0.2]], device=device)
+    goal = fk.compute_kinematics(JointState.from_position((q0 + dq).unsqueeze(1))).tool_poses.as_goal()
+    mpc = MPCSolver(kin, scene, B, MPCSolverCfg(continuous_commands=continuous))
+    state = JointState(position=q0.clone(), velocity=torch.zeros_like(q0), acceleration=torch.zeros_like(q0))
+    with pytest.raises(RuntimeError, match="setup"):
+        mpc.optimize_next_action(state)
+    mpc.setup(state, goal)
+    times, reopt, errs = [], 0, []
+    vmax = float(kin.joint_limits_velocity[1].abs().max())
+    per_plan = 8 if continuous else 4
+    for step in range(400):
+        res = mpc.optimize_next_action(state)
+        reopt += int(res.reoptimized)
+        times.append((res.reoptimized, res.solve_time))
+        a = res.next_action
+        # continuity of the command stream: the next command is close to the current state (command_dt * max velocity)
+        # continuity of the command stream: one command step (5 ms) of motion; the reference's scheme additionally steps by
+        # about velocity x optimization_dt when a plan is renewed, the continuous scheme must not
+        step_bound = vmax * mpc.command_dt * 1.1 + 1e-4 + (0.0 if continuous or not res.reoptimized else 0.06)
+        assert float((a.position - state.position).abs().max()) < step_bound
+        state = JointState(position=a.position, velocity=a.velocity, acceleration=a.acceleration)  # perfect tracking
+        st = fk.compute_kinematics(JointState.from_position(state.position.unsqueeze(1)))
+        errs.append((st.tool_poses.position[:, 0, 0] - goal.position[:, 0, 0]).norm(dim=-1).max().item())
+        assert bool(res.feasible.all())
+    assert reopt == 400 // per_plan, reopt  # one re-optimisation per knot interval (two in the continuous scheme)
+    assert errs[-1] < 0.005 and errs[-1] < 0.05 * errs[0], (errs[0], errs[-1])
+    # the robot never touched the world on the way (oracle check of the executed states is done on the last one)
+    sph = st.robot_spheres.cpu().numpy()
+    assert float(oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum()) == 0.0
+    cold = [t for r, t in times[:1]][0]
+    warm = np.median([t for r, t in times[1:] if r])
+    assert warm < cold, (warm, cold)
+    # moving goal: swap the two robots' goals, the loop re-plans and converges again
+    from curobo_amd.types import GoalToolPose
+
+    goal2 = GoalToolPose(goal.tool_frames, goal.position.flip(0).contiguous(), goal.quaternion.flip(0).contiguous())
+    mpc.update_goal_tool_poses(goal2)
+    for step in range(1000):
+        a = mpc.optimize_next_action(state).next_action
+        state = JointState(position=a.position, velocity=a.velocity, acceleration=a.acceleration)
+    st = fk.compute_kinematics(JointState.from_position(state.position.unsqueeze(1)))
+    assert float((st.tool_poses.position[:, 0, 0] - goal2.position[:, 0, 0]).norm(dim=-1).max()) < 0.01
+    seq = mpc.optimize_action_sequence(state)
+    assert seq.action_sequence.position.shape[0] == B and seq.action_buffer.shape == (B, 16, 7)
