@@ -2,9 +2,28 @@
 inverse_kinematics) resolve in this repository's ``curobo`` namespace, and the call sequences of the reference's
 own benchmark / tests run on them (GPU)."""
 
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(autouse=True)
+def _this_repos_curobo_namespace():
+    """Other tests of the CPU suite import the REFERENCE's ``curobo`` package (live comparisons, /root/reference on
+    sys.path): make ``import curobo`` resolve to this repository's namespace for the tests of this file."""
+    stale = [m for m in sys.modules if (m == "curobo" or m.startswith("curobo.")) and not str(getattr(sys.modules[m], "__file__", "")).startswith(ROOT)]
+    saved = {m: sys.modules.pop(m) for m in stale}
+    path = list(sys.path)
+    sys.path[:] = [ROOT] + [p for p in sys.path if p != ROOT]
+    yield
+    sys.path[:] = path
+    for m in [m for m in sys.modules if m == "curobo" or m.startswith("curobo.")]:
+        sys.modules.pop(m)
+    sys.modules.update(saved)
 
 
 def test_reference_public_names_resolve():
