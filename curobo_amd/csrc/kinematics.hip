@@ -181,6 +181,7 @@ struct FkBwdArgs {
   const float *grad_spheres;
   const float *grad_spheres_b;
   const float *grad_com;
+  const float *grad_jacobian;  // optional [n_points, n_tool_frames, 6, njoints]: VJP of the Jacobian output (dJ/dq)
   const float *batch_com;
   const float *cumul_in;
   const float *robot_spheres;
@@ -280,6 +281,65 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
       else
         r = sign * dot(axis, g);
       atomicAdd(&psum[info >> 8], r);
+    }
+  }
+  // ---- geometric-Jacobian output: grad_q[i] += sum_k <grad_J[:, k], dJ[:, k] / dq_i> (reference JAC_GRAD,
+  // kinematics_jacobian_backward_helper.cuh:19-300).  Column k of tool frame t is (a_k x (p_ee - p_k), a_k) for a
+  // revolute link k of the tool's chain (a = signed world axis) and (a_k, 0) for a prismatic one.  A joint i EARLIER in
+  // the chain rotates / translates everything after it, one at or after k only moves the tool point:
+  //   k rev, i rev,   i before k:  d a_k = a_i x a_k,  d Jv = (a_i x a_k) x (p_ee - p_k) + a_k x (a_i x (p_ee - p_k))
+  //   k rev, i rev,   otherwise :  d Jv = a_k x (a_i x (p_ee - p_i))
+  //   k rev, i prism, i after k :  d Jv = a_k x a_i          (before k: p_ee - p_k does not change)
+  //   k prism, i rev, i before k:  d Jv = a_i x a_k
+  // One chain position i per lane; every link of a (mimic) joint contributes, as in the forward Jacobian.
+  if (a.grad_jacobian != nullptr) {
+    for (int t = 0; t < a.n_tool_frames; t++) {
+      const int tl = a.tool_frame_map[t];
+      const float *E = my_cumul + tl * 12;
+      const f3 pe = make_f3(E[3], E[7], E[11]);
+      const int cs = s_chain_off[tl], ce = s_chain_off[tl + 1];
+      const float *gJ = a.grad_jacobian + ((size_t)n * a.n_tool_frames + t) * 6 * D;
+      for (int pi = cs + lane; pi < ce; pi += kFkLanes) {
+        const int li = s_chain[pi];
+        const int info_i = s_link_info[li];
+        const int jt_i = (info_i & 0xff) - 1;
+        if (jt_i < J_X_PRISM || li == 0) continue;
+        const float *Ci = my_cumul + li * 12;
+        const int ax_i = jt_i >= J_X_ROT ? jt_i - J_X_ROT : jt_i;
+        const f3 a_i = s_sign[li] * make_f3(Ci[ax_i], Ci[4 + ax_i], Ci[8 + ax_i]);
+        const f3 p_i = make_f3(Ci[3], Ci[7], Ci[11]);
+        float r = 0.0f;
+        for (int pk = cs; pk < ce; pk++) {
+          const int lk = s_chain[pk];
+          const int info_k = s_link_info[lk];
+          const int jt_k = (info_k & 0xff) - 1;
+          if (jt_k < J_X_PRISM || lk == 0) continue;
+          const int k = info_k >> 8;
+          const f3 gv = make_f3(gJ[0 * D + k], gJ[1 * D + k], gJ[2 * D + k]);
+          const f3 gw = make_f3(gJ[3 * D + k], gJ[4 * D + k], gJ[5 * D + k]);
+          if (gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gw.x == 0.f && gw.y == 0.f && gw.z == 0.f) continue;
+          const float *Ck = my_cumul + lk * 12;
+          const int ax_k = jt_k >= J_X_ROT ? jt_k - J_X_ROT : jt_k;
+          const f3 a_k = s_sign[lk] * make_f3(Ck[ax_k], Ck[4 + ax_k], Ck[8 + ax_k]);
+          const bool before = pi < pk;
+          if (jt_k >= J_X_ROT) {
+            const f3 p_k = make_f3(Ck[3], Ck[7], Ck[11]);
+            if (jt_i >= J_X_ROT) {
+              if (before) {
+                const f3 dw = cross(a_i, a_k), ek = pe - p_k;
+                r += dot(gw, dw) + dot(gv, cross(dw, ek) + cross(a_k, cross(a_i, ek)));
+              } else {
+                r += dot(gv, cross(a_k, cross(a_i, pe - p_i)));
+              }
+            } else if (!before) {
+              r += dot(gv, cross(a_k, a_i));
+            }
+          } else if (jt_i >= J_X_ROT && before) {
+            r += dot(gv, cross(a_i, a_k));
+          }
+        }
+        if (r != 0.0f) atomicAdd(&psum[info_i >> 8], r);
+      }
     }
   }
   // ---- centre of mass (reference :186-291)
@@ -429,10 +489,9 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
     const float *joint_offset_map, const int32_t *env_query_idx, int num_envs, int batch_size,
     int horizon, int n_joints, int num_spheres, int num_links, int n_tool_frames, int link_chain_len,
     int compute_com, int compute_jacobian_grad, curobo_hip_stream_t stream) {
-  (void)grad_jacobian; (void)link_map; (void)joint_links_data; (void)joint_links_offsets;
-  (void)joint_affects_endeffector;
+  (void)link_map; (void)joint_links_data; (void)joint_links_offsets; (void)joint_affects_endeffector;
   const char *what = "launch_kinematics_backward";
-  CUROBO_REQUIRE(!compute_jacobian_grad, "%s: compute_jacobian_grad is not supported by the HIP backend yet", what);
+  CUROBO_REQUIRE(!compute_jacobian_grad || grad_jacobian, "%s: compute_jacobian_grad needs grad_jacobian", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128, "%s: num_links=%d out of range [1,128]", what, num_links);
   CUROBO_REQUIRE(n_joints >= 1 && n_joints <= 1024, "%s: n_joints=%d out of range", what, n_joints);
   CUROBO_REQUIRE(link_chain_len >= 1 && link_chain_len <= 16384, "%s: link_chain_len=%d out of range", what, link_chain_len);
@@ -441,6 +500,7 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
   FkBwdArgs a{};
   a.grad_q = grad_out; a.grad_link_pos = grad_nlinks_pos; a.grad_link_quat = grad_nlinks_quat;
   a.grad_spheres = grad_spheres; a.grad_spheres_b = grad_spheres_b; a.grad_com = grad_center_of_mass;
+  a.grad_jacobian = compute_jacobian_grad ? grad_jacobian : nullptr;
   a.batch_com = batch_center_of_mass; a.cumul_in = global_cumul_mat; a.robot_spheres = robot_spheres;
   a.link_masses_com = link_masses_com; a.joint_map_type = joint_map_type; a.joint_map = joint_map;
   a.tool_frame_map = tool_frame_map; a.link_sphere_map = link_sphere_map;

@@ -116,16 +116,17 @@ class KinematicsFusedFunction(Function):
                 batch_cumul_mat=batch_cumul_mat, batch_com=batch_com, grad_in_com=grad_in_com)
             if grad_in_link_quat.data_ptr() % 16 != 0:
                 raise ValueError("grad_in_link_quat is not aligned to 16 bytes")
-            if ctx.compute_jacobian and grad_in_link_jacobian is not None:
-                raise NotImplementedError(
-                    "gradient through the Jacobian output (dJ/dq) is not supported by the HIP backend yet")
+            jac_grad = ctx.compute_jacobian and grad_in_link_jacobian is not None  # dJ/dq (reference JAC_GRAD, :268-378)
+            if jac_grad:
+                grad_in_link_jacobian = grad_in_link_jacobian.contiguous()
+                check_float32_tensors(joint_seq.device, grad_in_link_jacobian=grad_in_link_jacobian)
             b_size = joint_seq.shape[0] * joint_seq.shape[1]
             kinematics_hip.launch_kinematics_backward(
                 grad_out, grad_in_link_pos, grad_in_link_quat, grad_in_spheres, grad_in_com, batch_com,
-                grad_in_link_pos, batch_cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map,
+                grad_in_link_jacobian if jac_grad else grad_in_link_pos, batch_cumul_mat, k.link_spheres, k.link_masses_com, k.link_map, k.joint_map,
                 k.joint_map_type, k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data,
                 k.link_chain_offsets, k.joint_links_data, k.joint_links_offsets, k.joint_affects_endeffector,
                 k.joint_offset_map, ctx.env_query_idx, k.num_envs, b_size, ctx.horizon, joint_seq.shape[-1],
-                num_spheres, ctx.compute_com, False)
+                num_spheres, ctx.compute_com, jac_grad)
             grad_joint = grad_out
         return (grad_joint,) + (None,) * 18

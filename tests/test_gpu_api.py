@@ -350,3 +350,41 @@ def test_state_cspace_function_autograd(oracle, device):
     for x, k in zip(ins, ("grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")):
         np.testing.assert_allclose(x.grad.cpu().numpy(), ref[k] * scale.cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref[k]).max()), err_msg=k)
         assert np.abs(ref[k]).max() > 0
+
+
+@pytest.mark.parametrize("robot", ["franka", "ur10e", "unitree_g1"])
+def test_jacobian_output_is_differentiable(robot, device):
+    """dJ/dq: gradient THROUGH the geometric-Jacobian output (reference JAC_GRAD, kinematics_backward_kernel.cuh:27-157,
+    kinematics_jacobian_backward_helper.cuh) vs central finite differences of the Jacobian itself (the reference's
+    tests/_src/robot/kinematics/test_jacobian_gradcheck.py style), serial arm, and a humanoid tree with four tool frames"""
+    from curobo_amd.kinematics import Kinematics, KinematicsCfg
+
+    cfg = KinematicsCfg.from_packaged(robot, device=device)
+    kin = Kinematics(cfg, compute_jacobian=True, compute_spheres=False)
+    D, T = cfg.kinematics_config.num_dof, cfg.kinematics_config.num_pose_links
+    rng = np.random.default_rng(3)
+    qn = sample_q(cfg.model, 6, seed=9, scale=0.7).reshape(3, 2, D)
+    w = torch.as_tensor(rng.normal(size=(3, 2, T, 6, D)).astype(np.float32), device=device)
+    q = torch.as_tensor(qn, device=device).requires_grad_(True)
+    st = kin.compute_kinematics(q)
+    (st.tool_jacobians * w).sum().backward()
+    got = q.grad.cpu().numpy().astype(np.float64)
+    assert np.abs(got).max() > 1e-3
+    eps = 1e-3
+    fd = np.zeros_like(got)
+    with torch.no_grad():
+        for d in range(D):
+            dq = torch.zeros(3, 2, D, device=device)
+            dq[..., d] = eps
+            jp = kin.compute_kinematics(torch.as_tensor(qn, device=device) + dq).tool_jacobians.double().clone()
+            jm = kin.compute_kinematics(torch.as_tensor(qn, device=device) - dq).tool_jacobians.double().clone()
+            fd[..., d] = (((jp - jm) / (2 * eps)) * w.double()).sum(dim=(2, 3, 4)).cpu().numpy()
+    np.testing.assert_allclose(got, fd, rtol=2e-2, atol=2e-2 * np.abs(fd).max())
+    # and together with a pose gradient: the two VJPs add up
+    q2 = torch.as_tensor(qn, device=device).requires_grad_(True)
+    st2 = kin.compute_kinematics(q2)
+    wp = torch.as_tensor(rng.normal(size=(3, 2, T, 3)).astype(np.float32), device=device)
+    ((st2.tool_jacobians * w).sum() + (st2.tool_poses.position * wp).sum()).backward()
+    q3 = torch.as_tensor(qn, device=device).requires_grad_(True)
+    (kin.compute_kinematics(q3).tool_poses.position * wp).sum().backward()
+    torch.testing.assert_close(q2.grad, q.grad + q3.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()))
