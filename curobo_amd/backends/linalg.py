@@ -34,6 +34,7 @@ def seed_ik_update_state(
     current_position, dt, velocity_limits, joint_limit_weight: float, rho_min: float, lambda_factor: float,
     lambda_min: float, lambda_max: float, convergence_position_tolerance: float,
     convergence_orientation_tolerance: float, convergence_joint_limit_weight: float, initial: bool,
+    current_velocity=None, velocity_weight: float = 0.0, acceleration_weight: float = 0.0,
 ):
     """One launch for the torch glue of a seed-IK LM iteration (``curobo_hip_seed_ik_update_state``):
     joint-limit residual rows + trust ratio + acceptance + damping + state selection + convergence."""
@@ -44,7 +45,8 @@ def seed_ik_update_state(
         ptr(lambda_damping), ptr(success), ptr(improvement), ptr(candidate_joint_position), ptr(candidate_pose_jacobian),
         ptr(candidate_pose_jTerror), ptr(candidate_pose_cost), ptr(candidate_position_distance),
         ptr(candidate_rotation_distance), ptr(predicted_reduction), ptr(action_min), ptr(action_max), ptr(current_position),
-        ptr(dt), ptr(velocity_limits), float(joint_limit_weight), float(rho_min), float(lambda_factor), float(lambda_min),
+        ptr(dt), ptr(velocity_limits), ptr(current_velocity), float(velocity_weight), float(acceleration_weight),
+        float(joint_limit_weight), float(rho_min), float(lambda_factor), float(lambda_min),
         float(lambda_max), float(convergence_position_tolerance), float(convergence_orientation_tolerance),
         float(convergence_joint_limit_weight), n, d, t, int(initial), current_stream(joint_position),
     ))

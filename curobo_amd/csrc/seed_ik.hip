@@ -25,11 +25,34 @@ struct SeedIkUpdateArgs {
   const float *action_min, *action_max;
   // optional velocity clamping of the limits (seed_ik_error_calculator.py:355-363)
   const float *current_position, *dt, *velocity_limits;
+  // optional velocity / acceleration regularisation rows (seed_ik_error_calculator.py:389-456): with
+  // v = (q - current_position) / dt,  r_v = sqrt(w_v dt) v  and  r_a = sqrt(w_a) (v - current_velocity); both blocks are
+  // DIAGONAL in q, like the joint-limit block, and the LM step only sees J^T J and J^T r, so the three diagonal rows of a
+  // dof are stored as ONE row of magnitude sqrt(sum of squares) (same normal equations, same predicted reduction)
+  const float *current_velocity;
+  float velocity_weight, acceleration_weight;
   float joint_limit_weight, rho_min, lambda_factor, lambda_min, lambda_max, conv_pos_tol, conv_ori_tol, conv_jl_weight;
   int n, D, T, initial;
 };
 
 constexpr int kRow = 16;
+
+// velocity / acceleration residuals of dof d: squared Jacobian diagonal, J^T r and squared error
+__device__ __forceinline__ void vel_acc_rows(const SeedIkUpdateArgs &a, int p, int d, float x, float &diag2, float &jtr, float &err2) {
+  diag2 = jtr = err2 = 0.0f;
+  if (a.current_position == nullptr || a.dt == nullptr || !(a.dt[p] > 0.0f)) return;
+  if (a.velocity_weight <= 0.0f && a.acceleration_weight <= 0.0f) return;
+  const float dt = fmaxf(a.dt[p], 1e-10f), inv_dt = 1.0f / dt;
+  const float v = (x - a.current_position[(size_t)p * a.D + d]) * inv_dt;
+  if (a.velocity_weight > 0.0f) {
+    const float sw = sqrtf(a.velocity_weight * dt), e = sw * v, jd = sw * inv_dt;
+    diag2 += jd * jd; jtr += jd * e; err2 += e * e;
+  }
+  if (a.acceleration_weight > 0.0f && a.current_velocity != nullptr) {
+    const float sw = sqrtf(a.acceleration_weight), e = sw * (v - a.current_velocity[(size_t)p * a.D + d]), jd = sw * inv_dt;
+    diag2 += jd * jd; jtr += jd * e; err2 += e * e;
+  }
+}
 
 __device__ __forceinline__ float row16_maxf(float v) { return row16_max(v); }
 
@@ -46,7 +69,7 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
   bool inside = true;  // strictly inside [action_min, action_max] (convergence check on the SELECTED q, below)
   for (int d = lane; d < D; d += kRow) {
     float lo = a.action_min[d], hi = a.action_max[d];
-    if (a.current_position) {
+    if (a.current_position && a.velocity_limits) {
       const float cp = a.current_position[(size_t)p * D + d], dt = a.dt[p];
       lo = fmaxf(lo, cp + a.velocity_limits[d] * dt);
       hi = fminf(hi, cp + a.velocity_limits[D + d] * dt);
@@ -54,6 +77,9 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
     const float x = cq[d];
     const float uv = fmaxf(x - hi, 0.0f), lv = fmaxf(lo - x, 0.0f);
     jl_sum += a.joint_limit_weight * (lv + uv);
+    float d2, jt, e2;
+    vel_acc_rows(a, p, d, x, d2, jt, e2);
+    jl_sum += e2;  // error norms of the velocity / acceleration blocks (_combine_errors, :464-495)
   }
   jl_sum = row16_sum(jl_sum);
 
@@ -91,7 +117,7 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
     }
     for (int d = lane; d < D; d += kRow) {
       float lo = a.action_min[d], hi = a.action_max[d];
-      if (a.current_position) {
+      if (a.current_position && a.velocity_limits) {
         const float cp = a.current_position[(size_t)p * D + d], dt = a.dt[p];
         lo = fmaxf(lo, cp + a.velocity_limits[d] * dt);
         hi = fminf(hi, cp + a.velocity_limits[D + d] * dt);
@@ -100,9 +126,11 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
       const float uv = fmaxf(x - hi, 0.0f), lv = fmaxf(lo - x, 0.0f);
       const float err = a.joint_limit_weight * (lv + uv);
       const float diag = a.joint_limit_weight * ((lv > 0.0f ? -1.0f : 0.0f) + (uv > 0.0f ? 1.0f : 0.0f));
+      float d2, jt, e2;
+      vel_acc_rows(a, p, d, x, d2, jt, e2);
       if (live) {
         a.q[(size_t)p * D + d] = x;
-        a.jTerror[(size_t)p * D + d] = a.cand_pose_jTerror[(size_t)p * D + d] + diag * err;
+        a.jTerror[(size_t)p * D + d] = a.cand_pose_jTerror[(size_t)p * D + d] + diag * err + jt;
       }
     }
     // the zero fill above and the diagonal below touch the same elements from different lanes
@@ -110,7 +138,7 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
     __builtin_amdgcn_wave_barrier();
     for (int d = lane; d < D; d += kRow) {
       float lo = a.action_min[d], hi = a.action_max[d];
-      if (a.current_position) {
+      if (a.current_position && a.velocity_limits) {
         const float cp = a.current_position[(size_t)p * D + d], dt = a.dt[p];
         lo = fmaxf(lo, cp + a.velocity_limits[d] * dt);
         hi = fminf(hi, cp + a.velocity_limits[D + d] * dt);
@@ -118,7 +146,9 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
       const float x = cq[d];
       const float uv = fmaxf(x - hi, 0.0f), lv = fmaxf(lo - x, 0.0f);
       const float diag = a.joint_limit_weight * ((lv > 0.0f ? -1.0f : 0.0f) + (uv > 0.0f ? 1.0f : 0.0f));
-      if (live) J[(size_t)(6 * T + d) * D + d] = diag;
+      float d2, jt, e2;
+      vel_acc_rows(a, p, d, x, d2, jt, e2);
+      if (live) J[(size_t)(6 * T + d) * D + d] = d2 > 0.0f ? sqrtf(diag * diag + d2) : diag;
     }
   } else {
     pos_e = a.position_error[p];
@@ -154,14 +184,15 @@ CUROBO_EXPORT int curobo_hip_seed_ik_update_state(
     const float *candidate_joint_position, const float *candidate_pose_jacobian, const float *candidate_pose_jTerror,
     const float *candidate_pose_cost, const float *candidate_position_distance, const float *candidate_rotation_distance,
     const float *predicted_reduction, const float *action_min, const float *action_max, const float *current_position,
-    const float *dt, const float *velocity_limits, float joint_limit_weight, float rho_min, float lambda_factor,
+    const float *dt, const float *velocity_limits, const float *current_velocity, float velocity_weight,
+    float acceleration_weight, float joint_limit_weight, float rho_min, float lambda_factor,
     float lambda_min, float lambda_max, float convergence_position_tolerance, float convergence_orientation_tolerance,
     float convergence_joint_limit_weight, int num_problems, int dof, int num_tool_frames, int initial,
     curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(num_problems >= 0 && dof >= 1 && num_tool_frames >= 1, "seed_ik_update_state: bad sizes (n=%d, dof=%d, T=%d)",
                  num_problems, dof, num_tool_frames);
   CUROBO_REQUIRE(initial || predicted_reduction, "seed_ik_update_state: predicted_reduction is NULL%s", "");
-  CUROBO_REQUIRE(!current_position || (dt && velocity_limits), "seed_ik_update_state: velocity clamping needs dt and velocity_limits%s", "");
+  CUROBO_REQUIRE(!current_position || dt, "seed_ik_update_state: current_position needs dt%s", "");
   if (num_problems == 0) return CUROBO_HIP_OK;
   SeedIkUpdateArgs a;
   a.q = joint_position; a.jacobian = jacobian; a.jTerror = jTerror; a.error_norm = error_norm;
@@ -172,6 +203,7 @@ CUROBO_EXPORT int curobo_hip_seed_ik_update_state(
   a.cand_rotation_distance = candidate_rotation_distance; a.pred_reduction = predicted_reduction;
   a.action_min = action_min; a.action_max = action_max; a.current_position = current_position; a.dt = dt;
   a.velocity_limits = velocity_limits;
+  a.current_velocity = current_velocity; a.velocity_weight = velocity_weight; a.acceleration_weight = acceleration_weight;
   a.joint_limit_weight = joint_limit_weight; a.rho_min = rho_min; a.lambda_factor = lambda_factor; a.lambda_min = lambda_min;
   a.lambda_max = lambda_max; a.conv_pos_tol = convergence_position_tolerance; a.conv_ori_tol = convergence_orientation_tolerance;
   a.conv_jl_weight = convergence_joint_limit_weight;

@@ -300,7 +300,10 @@ int curobo_hip_cspace_l2_distance(float *out_cost, float *out_grad_p, const floa
  * diagonal joint-limit rows; error_norm always takes the candidate's value (as the reference does).
  * initial != 0: the candidate becomes the state unconditionally (lambda is left as set by the
  * caller).  current_position / dt / velocity_limits [2, dof] (optional, all or none) tighten the
- * limits for velocity-aware IK. */
+ * limits for velocity-aware IK.  * velocity / acceleration regularisation rows (seed_ik_error_calculator.py:389-456): with current_position + dt given,
+ * velocity_weight > 0 adds r_v = sqrt(w dt) (q - current_position) / dt and acceleration_weight > 0 (current_velocity
+ * given) r_a = sqrt(w) ((q - current_position) / dt - current_velocity); velocity_limits may be NULL (no clamping).
+ */
 int curobo_hip_seed_ik_update_state(
     float *joint_position, float *jacobian, float *jTerror, float *error_norm, float *position_error,
     float *orientation_error, float *lambda_damping, uint8_t *success, uint8_t *improvement,
@@ -309,6 +312,7 @@ int curobo_hip_seed_ik_update_state(
     const float *candidate_position_distance, const float *candidate_rotation_distance,
     const float *predicted_reduction, const float *action_min, const float *action_max,
     const float *current_position, const float *dt, const float *velocity_limits,
+    const float *current_velocity, float velocity_weight, float acceleration_weight,
     float joint_limit_weight, float rho_min, float lambda_factor, float lambda_min, float lambda_max,
     float convergence_position_tolerance, float convergence_orientation_tolerance,
     float convergence_joint_limit_weight, int num_problems, int dof, int num_tool_frames,

@@ -17,8 +17,9 @@ is five launches here (the reference: a Warp tile kernel, two CUDA kernels, a Wa
 replays is the reference's (`_calculate_exit_condition`).  ``solve_batch(current_position=, dt=)``
 tightens the joint-limit bounds to what one step of ``dt`` can reach from the current position
 (velocity clamping, seed_ik_error_calculator.py:355-363, seed_ik_solver.py:601-615).  The velocity /
-acceleration residual rows (``velocity_weight``, ``acceleration_weight``, default 0 in the
-reference) are not implemented.
+acceleration residual rows (``cfg.velocity_weight``, ``cfg.acceleration_weight``, default 0 as in the reference;
+seed_ik_error_calculator.py:389-456) are diagonal blocks like the joint-limit rows and are folded into them in the
+state-update kernel (``solve_batch(..., current_velocity=)`` for the acceleration rows).
 """
 
 from __future__ import annotations
@@ -60,6 +61,10 @@ class SeedIKSolverCfg:
     start_cspace_dist_weight: float = 0.01
     position_weight: float = 1.0
     orientation_weight: float = 1.0
+    #: velocity / acceleration regularisation rows (reference SeedIKSolverCfg.velocity_weight / acceleration_weight,
+    #: seed_ik_error_calculator.py:389-456): active with ``solve_batch(current_position=, dt=[, current_velocity=])``
+    velocity_weight: float = 0.0
+    acceleration_weight: float = 0.0
 
     def __post_init__(self):
         if self.max_iterations < self.inner_iterations or self.max_iterations % self.inner_iterations != 0:
@@ -151,6 +156,7 @@ class SeedIKSolver:
         # velocity clamping of the bounds: buffers with stable addresses (captured graphs), one graph per mode
         self._vel_current, self._vel_dt = z(n, D), torch.ones(n, device=dev)
         self._vel_limits = kin.joint_limits_velocity.to(dev, torch.float32).contiguous()
+        self._vel_velocity = z(n, D)  # current joint velocity (acceleration rows)
         self._vel_active = False
         self._graphs = {}
 
@@ -182,7 +188,10 @@ class SeedIKSolver:
             self.action_max, *((self._vel_current, self._vel_dt, self._vel_limits) if self._vel_active else (None, None, None)),
             c.joint_limit_weight, c.rho_min, c.lambda_factor, c.lambda_min,
             c.lambda_max, c.convergence_position_tolerance, c.convergence_orientation_tolerance,
-            c.convergence_joint_limit_weight, initial)
+            c.convergence_joint_limit_weight, initial,
+            current_velocity=self._vel_velocity if (self._vel_active and c.acceleration_weight > 0) else None,
+            velocity_weight=c.velocity_weight if self._vel_active else 0.0,
+            acceleration_weight=c.acceleration_weight if self._vel_active else 0.0)
 
     def _lm_iteration(self) -> None:
         linalg_hip.levenberg_marquardt_step(self.q_new, self.pred_reduction, self.jacobian, self.jTerror,
@@ -232,7 +241,7 @@ class SeedIKSolver:
 
     def solve_batch(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, seed_config: Optional[torch.Tensor] = None,
                     return_seeds: int = 1, current_position: Optional[torch.Tensor] = None,
-                    dt: Optional[torch.Tensor] = None) -> SeedIKResult:
+                    dt: Optional[torch.Tensor] = None, current_velocity: Optional[torch.Tensor] = None) -> SeedIKResult:
         """``current_position`` [P, D]: first seed of every problem and the c-space distance term of the
         ranking; together with ``dt`` (scalar or [P]) it also switches velocity clamping on: a solution
         has to lie within ``velocity_limits * dt`` of the current position (reference: ``current_state.dt``)."""
@@ -241,6 +250,10 @@ class SeedIKSolver:
         if self._vel_active:
             self._vel_current.view(P, S, D).copy_(current_position.to(self.device, torch.float32).view(P, 1, D).expand(P, S, D))
             self._vel_dt.view(P, S).copy_(torch.as_tensor(dt, dtype=torch.float32, device=self.device).reshape(-1, 1).expand(P, S))
+            if current_velocity is not None:  # acceleration rows (cfg.acceleration_weight): [P, D]
+                self._vel_velocity.view(P, S, D).copy_(current_velocity.to(self.device, torch.float32).view(P, 1, D).expand(P, S, D))
+            else:
+                self._vel_velocity.zero_()
         self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, self.G, 3))
         self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, self.G, 4))
         if seed_config is None and current_position is not None:

@@ -258,3 +258,56 @@ def test_velocity_clamped_bounds_kernel_and_solver(oracle, device):
     # without dt the same call is unconstrained (separate captured graph), still solves
     res2 = solver.solve_batch(t(gp[:, :, 0]), t(gq[:, :, 0]), current_position=t(cur))
     assert res2.success[:, 0].float().mean().item() >= 0.9
+
+
+def test_velocity_and_acceleration_residual_rows(oracle, device):
+    """velocity / acceleration regularisation blocks of the seed-IK error (cfg.velocity_weight / acceleration_weight):
+    (1) the state-update kernel vs the reference's own _compute_velocity_errors / _compute_acceleration_errors
+    (tests/golden/seed_ik_velacc_golden.npz): J^T r, error norm, and the folded diagonal row sqrt(jv^2 + ja^2);
+    (2) a solve with the rows on stays closer to the current position than one without."""
+    import os
+
+    from curobo_amd.backends import linalg
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seed_ik_velacc_golden.npz"))
+    q, cur, vel, dt = g["q"], g["current_position"], g["current_velocity"], g["dt"]
+    n, D = q.shape
+    T, R = 1, 6 + D
+    t = lambda a, dtp=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dtp)  # noqa: E731
+    z = lambda *s: torch.zeros(*s, device=device)  # noqa: E731
+    for wv, wa in ((float(g["velocity_weight"]), 0.0), (0.0, float(g["acceleration_weight"])),
+                   (float(g["velocity_weight"]), float(g["acceleration_weight"]))):
+        st_q, J, jTe, en, pe, oe, lam = z(n, D), z(n, R, D), z(n, D), z(n), z(n), z(n), torch.full((n,), 0.2, device=device)
+        succ, imp = torch.zeros(n, dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.uint8, device=device)
+        big = np.full(D, 1e6, np.float32)
+        linalg.seed_ik_update_state(st_q, J, jTe, en, pe, oe, lam, succ, imp, t(q), z(n, 6, D), z(n, D), z(n, T, 2), z(n, T), z(n, T), None,
+                                    t(-big), t(big), t(cur), t(dt), None, 1.0, 1e-3, 2.0, 1e-5, 1e10, 1e-5, 1e-5, 0.0, True,
+                                    current_velocity=t(vel), velocity_weight=wv, acceleration_weight=wa)
+        torch.cuda.synchronize()
+        want_jt = (g["vel_jTerror"] if wv > 0 else 0) + (g["acc_jTerror"] if wa > 0 else 0)
+        want_en = (g["vel_error"] if wv > 0 else 0) + (g["acc_error"] if wa > 0 else 0)
+        want_d2 = (g["vel_jacobian_diag"] ** 2 if wv > 0 else 0) + (g["acc_jacobian_diag"] ** 2 if wa > 0 else 0)
+        np.testing.assert_allclose(jTe.cpu().numpy(), want_jt, rtol=2e-5, atol=1e-5 * np.abs(want_jt).max())
+        np.testing.assert_allclose(en.cpu().numpy(), want_en, rtol=2e-5)
+        Jn = J.cpu().numpy()
+        diag = Jn[:, 6 + np.arange(D), np.arange(D)]
+        np.testing.assert_allclose(diag ** 2, want_d2, rtol=5e-5)
+        off = Jn[:, 6:].copy()
+        off[:, np.arange(D), np.arange(D)] = 0
+        assert (off == 0).all() and (Jn[:, :6] == 0).all()
+    # ---- (2) the rows pull the solution towards the current state
+    P, S = 12, 8
+    md, gp, gq, _, _ = _problem(oracle, load_model("franka"), P, S, seed=4)
+    rng = np.random.default_rng(5)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    qc = torch.as_tensor((0.5 * (lo + hi) + 0.2 * (hi - lo) * rng.uniform(-1, 1, size=(P, lo.shape[0]))).astype(np.float32), device=device)
+    dist = {}
+    for w in (0.0, 0.5):
+        _, sol = _solver(device, P, S, velocity_weight=w, acceleration_weight=0.01 * w, batch_success_threshold=2.0)
+        r = sol.solve_batch(torch.as_tensor(gp, device=device), torch.as_tensor(gq, device=device), current_position=qc, dt=10.0,
+                            current_velocity=torch.zeros_like(qc))
+        # a soft regulariser trades pose accuracy for staying close: best seed by pose error, whatever the tolerance says
+        dist[w] = float((r.solution[:, 0] - qc).norm(dim=-1).mean())
+        if w == 0.0:
+            assert float(r.success[:, 0].float().mean()) >= 0.6
+    assert dist[0.5] < 0.9 * dist[0.0], dist
