@@ -17,6 +17,9 @@
 
 namespace curobo_hip {
 
+// Every multiply-add of the reductions and updates below is an explicit fma: left to -ffp-contract the same
+// source line becomes v_fma in one kernel and v_pk_mul + v_add in another (the vectoriser decides per context),
+// and the one-launch and three-launch forms of an iteration would then differ in the last bit.
 constexpr int kMaxVPL = 16;  // components per lane -> v_dim <= 1024 (reference: V < 1024)
 
 struct LbfgsArgs {
@@ -49,7 +52,7 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
       a.grad_0[bv + v] = g;
       a.x_0[bv + v] = x;
       gq[e] = g;
-      part += y[e] * s[e];
+      part = __builtin_fmaf(y[e], s[e], part);
     }
   }
   const float numerator = wave_sum(part);
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
       const int v = lane + e * kWave;
       yi[e] = 0.0f;
       if (v < V) {
-        d += gq[e] * a.s_buffer[i * hist_stride + bv + v];
+        d = __builtin_fmaf(gq[e], a.s_buffer[i * hist_stride + bv + v], d);
         yi[e] = a.y_buffer[i * hist_stride + bv + v];
       }
     }
@@ -102,12 +105,12 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
     const float alpha = d * __shfl(rho_mine, i, kWave);
     if (lane == i) alpha_mine = alpha;
 #pragma unroll
-    for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * yi[e];
+    for (int e = 0; e < VPL; e++) gq[e] = __builtin_fmaf(-alpha, yi[e], gq[e]);
   }
   if (m > 0) {  // scaling gamma = relu(s.y / y.y), :346-373
     float d = 0.0f;
 #pragma unroll
-    for (int e = 0; e < VPL; e++) d += y[e] * y[e];
+    for (int e = 0; e < VPL; e++) d = __builtin_fmaf(y[e], y[e], d);
     d = wave_sum(d);
     float var1 = numerator / d;
     if (a.stable_mode && (isinf(var1) || isnan(var1))) var1 = a.epsilon;
@@ -123,14 +126,14 @@ __global__ void __launch_bounds__(256) lbfgs_step_kernel(const LbfgsArgs a) {
       const int v = lane + e * kWave;
       si[e] = 0.0f;
       if (v < V) {
-        d += gq[e] * a.y_buffer[i * hist_stride + bv + v];
+        d = __builtin_fmaf(gq[e], a.y_buffer[i * hist_stride + bv + v], d);
         si[e] = a.s_buffer[i * hist_stride + bv + v];
       }
     }
     d = wave_sum(d);
-    const float beta = __shfl(alpha_mine, i, kWave) - d * __shfl(rho_mine, i, kWave);
+    const float beta = __builtin_fmaf(-d, __shfl(rho_mine, i, kWave), __shfl(alpha_mine, i, kWave));
 #pragma unroll
-    for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * si[e];
+    for (int e = 0; e < VPL; e++) gq[e] = __builtin_fmaf(beta, si[e], gq[e]);
   }
 #pragma unroll
   for (int e = 0; e < VPL; e++) {
@@ -161,28 +164,86 @@ __device__ __forceinline__ unsigned long long gballot(bool p) {
   return G == kWave ? m : (m >> (__lane_id() & 48)) & 0xffffull;
 }
 
-// body for one problem b on one lane group; g_in / x_in = current gradient / iterate of the lane's
-// elements (v = lane + e * 64), dir_out = the new step direction (also stored to a.step_vec)
-template <int VPL, int G = kWave>
-__device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, int lane, const float (&g_in)[VPL],
-                                                    const float (&x_in)[VPL], float (&dir_out)[VPL]) {
-  constexpr int MMAX = G == kWave ? 32 : 16;
+// The (y, s, rho) history of one problem plus its previous iterate, as one lane group holds it in VGPRs
+// (separate arrays, not a struct: a struct this size stays an alloca and lands in scratch).
+template <int G>
+struct LbfgsLimits {
+  static constexpr int MMAX = G == kWave ? 32 : 16;
+};
+#define LBFGS_HISTORY_DECL(VPL, G) \
+  float h_ys[LbfgsLimits<G>::MMAX][VPL], h_ss[LbfgsLimits<G>::MMAX][VPL], h_g0[VPL], h_x0[VPL], h_rho
+#define LBFGS_HISTORY_PARAMS(VPL, G)                                                                             \
+  float (&h_ys)[LbfgsLimits<G>::MMAX][VPL], float (&h_ss)[LbfgsLimits<G>::MMAX][VPL], float (&h_g0)[VPL], \
+      float (&h_x0)[VPL], float &h_rho
+#define LBFGS_HISTORY_ARGS h_ys, h_ss, h_g0, h_x0, h_rho
+
+// v & mask with a mask the optimiser cannot see through.  Out-of-range lanes load from a clamped address and
+// are zeroed with this: written as `in_range ? load : 0` the compiler moves each load under its own branch
+// (an exec-mask region per load, or worse a wait per load), and ~4 m loads that should leave as one burst
+// trickle out between branches.
+__device__ __forceinline__ int opaque_lane_mask(bool in_range) {
+  int mk = in_range ? -1 : 0;
+  asm volatile("" : "+v"(mk));
+  return mk;
+}
+__device__ __forceinline__ float and_mask(float v, int mk) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & mk);
+}
+
+// slot i <- old slot i+1 (the shift of the reference), every load independent of every other
+template <int VPL, int G>
+__device__ __forceinline__ void lbfgs_history_load(const LbfgsArgs &a, int b, int lane, LBFGS_HISTORY_PARAMS(VPL, G)) {
+  constexpr int MMAX = LbfgsLimits<G>::MMAX;
   const int V = a.v_dim, m = a.m, B = a.batch;
   const size_t bv = (size_t)b * V;
   const size_t hist_stride = (size_t)B * V;
-  float ys[MMAX][VPL], ss[MMAX][VPL];
-  // slot i <- old slot i+1 (shift), all loads independent
+  // Unconditional loads at clamped addresses: lanes past V are zeroed with the opaque mask; slots >= m-1 receive
+  // a copy of the newest old slot, which nothing reads (slot m-1 is overwritten by the append, the recursion
+  // stops at m).
+  int mk[VPL];
 #pragma unroll
-  for (int i = 0; i < MMAX; i++) {
-#pragma unroll
-    for (int e = 0; e < VPL; e++) {
-      const int v = lane + e * G;
-      const bool ld = (i < m - 1) && (v < V);
-      ys[i][e] = ld ? a.y_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
-      ss[i][e] = ld ? a.s_buffer[(size_t)(i + 1) * hist_stride + bv + v] : 0.0f;
-    }
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * G, vc = v < V ? v : V - 1;
+    mk[e] = opaque_lane_mask(v < V);
+    h_g0[e] = and_mask(a.grad_0[bv + vc], mk[e]);
+    h_x0[e] = and_mask(a.x_0[bv + vc], mk[e]);
   }
-  float rho_mine = (lane < m - 1) ? a.rho_buffer[(size_t)(lane + 1) * B + b] : 0.0f;
+  if (m > 0) {
+#pragma unroll
+    for (int i = MMAX - 1; i >= 0; i--) {  // newest first: the order the recursion consumes them in
+      const int slot = i + 1 < m ? i + 1 : m - 1;
+#pragma unroll
+      for (int e = 0; e < VPL; e++) {
+        const int v = lane + e * G, vc = v < V ? v : V - 1;
+        h_ys[i][e] = and_mask(a.y_buffer[(size_t)slot * hist_stride + bv + vc], mk[e]);
+        h_ss[i][e] = and_mask(a.s_buffer[(size_t)slot * hist_stride + bv + vc], mk[e]);
+      }
+    }
+    const int rl = lane + 1 < m ? lane + 1 : m - 1;
+    h_rho = and_mask(a.rho_buffer[(size_t)rl * B + b], opaque_lane_mask(lane < m - 1));
+  } else {
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) h_ys[i][e] = h_ss[i][e] = 0.0f;
+    }
+    h_rho = 0.0f;
+  }
+}
+
+// body for one problem b on one lane group; g_in / x_in = current gradient / iterate of the lane's
+// elements (v = lane + e * G), dir_out = the new step direction (also stored to a.step_vec)
+template <int VPL, int G, bool STORE_SHIFTED>
+__device__ __forceinline__ void lbfgs_step_from_history(const LbfgsArgs &a, int b, int lane, const float (&g_in)[VPL],
+                                                        const float (&x_in)[VPL], LBFGS_HISTORY_PARAMS(VPL, G),
+                                                        float (&dir_out)[VPL]) {
+  constexpr int MMAX = LbfgsLimits<G>::MMAX;
+  const int V = a.v_dim, m = a.m, B = a.batch;
+  const size_t bv = (size_t)b * V;
+  const size_t hist_stride = (size_t)B * V;
+  float (&ys)[MMAX][VPL] = h_ys;
+  float (&ss)[MMAX][VPL] = h_ss;
+  float rho_mine = h_rho;
   float gq[VPL], y[VPL], s[VPL];
   float part = 0.0f;
 #pragma unroll
@@ -191,12 +252,12 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     gq[e] = y[e] = s[e] = 0.0f;
     if (v < V) {
       const float g = g_in[e], x = x_in[e];
-      y[e] = g - a.grad_0[bv + v];
-      s[e] = x - a.x_0[bv + v];
+      y[e] = g - h_g0[e];
+      s[e] = x - h_x0[e];
       a.grad_0[bv + v] = g;
       a.x_0[bv + v] = x;
       gq[e] = g;
-      part += y[e] * s[e];
+      part = __builtin_fmaf(y[e], s[e], part);
     }
   }
   const float numerator = gsum<G>(part);
@@ -205,42 +266,30 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     if (a.stable_mode && numerator <= 0.0f) rho_mine = 0.0f;
   }
   if (lane < m) a.rho_buffer[(size_t)lane * B + b] = rho_mine;
-  // append the new pair at slot m-1, then write the shifted history back
-#pragma unroll
-  for (int i = 0; i < MMAX; i++) {
-    if (i == m - 1) {
-#pragma unroll
-      for (int e = 0; e < VPL; e++) { ys[i][e] = y[e]; ss[i][e] = s[e]; }
-    }
-    if (i < m) {
-#pragma unroll
-      for (int e = 0; e < VPL; e++) {
-        const int v = lane + e * G;
-        if (v < V) {
-          a.y_buffer[(size_t)i * hist_stride + bv + v] = ys[i][e];
-          a.s_buffer[(size_t)i * hist_stride + bv + v] = ss[i][e];
-        }
-      }
-    }
-  }
-  float alpha_mine = 0.0f;
+  float alpha_of[MMAX];  // alpha_i, the same value in every lane of the group (static indices: registers)
 #pragma unroll
   for (int i = MMAX - 1; i >= 0; i--) {
+    alpha_of[i] = 0.0f;
     if (i < m) {
+      if (i == m - 1) {  // append the new pair at slot m-1 (kept inside this loop: as a loop of its own it
+                         // becomes one dynamically indexed store and the history falls out of registers)
+#pragma unroll
+        for (int e = 0; e < VPL; e++) { ys[i][e] = y[e]; ss[i][e] = s[e]; }
+      }
       float d = 0.0f;
 #pragma unroll
-      for (int e = 0; e < VPL; e++) d += gq[e] * ss[i][e];
+      for (int e = 0; e < VPL; e++) d = __builtin_fmaf(gq[e], ss[i][e], d);
       d = gsum<G>(d);
       const float alpha = d * gbcast<G>(rho_mine, i);  // i is a constant after unrolling: v_readlane (G = 64)
-      if (lane == i) alpha_mine = alpha;
+      alpha_of[i] = alpha;
 #pragma unroll
-      for (int e = 0; e < VPL; e++) gq[e] = gq[e] - alpha * ys[i][e];
+      for (int e = 0; e < VPL; e++) gq[e] = __builtin_fmaf(-alpha, ys[i][e], gq[e]);
     }
   }
   if (m > 0) {
     float d = 0.0f;
 #pragma unroll
-    for (int e = 0; e < VPL; e++) d += y[e] * y[e];
+    for (int e = 0; e < VPL; e++) d = __builtin_fmaf(y[e], y[e], d);
     d = gsum<G>(d);
     float var1 = numerator / d;
     if (a.stable_mode && (isinf(var1) || isnan(var1))) var1 = a.epsilon;
@@ -253,11 +302,11 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     if (i < m) {
       float d = 0.0f;
 #pragma unroll
-      for (int e = 0; e < VPL; e++) d += gq[e] * ys[i][e];
+      for (int e = 0; e < VPL; e++) d = __builtin_fmaf(gq[e], ys[i][e], d);
       d = gsum<G>(d);
-      const float beta = gbcast<G>(alpha_mine, i) - d * gbcast<G>(rho_mine, i);
+      const float beta = __builtin_fmaf(-d, gbcast<G>(rho_mine, i), alpha_of[i]);
 #pragma unroll
-      for (int e = 0; e < VPL; e++) gq[e] = gq[e] + beta * ss[i][e];
+      for (int e = 0; e < VPL; e++) gq[e] = __builtin_fmaf(beta, ss[i][e], gq[e]);
     }
   }
 #pragma unroll
@@ -266,6 +315,29 @@ __device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, i
     dir_out[e] = -gq[e];
     if (v < V) a.step_vec[bv + v] = -gq[e];
   }
+  // the shifted history goes back to memory last: 4 m stores per lane that nothing in this launch waits for
+  // (!STORE_SHIFTED: only the appended pair, somebody else moves the rest)
+#pragma unroll
+  for (int i = 0; i < MMAX; i++) {
+    if (i < m && (STORE_SHIFTED || i == m - 1)) {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) {
+        const int v = lane + e * G;
+        if (v < V) {
+          a.y_buffer[(size_t)i * hist_stride + bv + v] = ys[i][e];
+          a.s_buffer[(size_t)i * hist_stride + bv + v] = ss[i][e];
+        }
+      }
+    }
+  }
+}
+
+template <int VPL, int G = kWave>
+__device__ __forceinline__ void lbfgs_step_reg_body(const LbfgsArgs &a, int b, int lane, const float (&g_in)[VPL],
+                                                    const float (&x_in)[VPL], float (&dir_out)[VPL]) {
+  LBFGS_HISTORY_DECL(VPL, G);
+  lbfgs_history_load<VPL, G>(a, b, lane, LBFGS_HISTORY_ARGS);
+  lbfgs_step_from_history<VPL, G, true>(a, b, lane, g_in, x_in, LBFGS_HISTORY_ARGS, dir_out);
 }
 
 template <int VPL>
@@ -309,7 +381,7 @@ __device__ __forceinline__ int line_search_body(const LineSearchArgs &a, int b, 
   for (int k = 0; k < NLS; k++) {
     const float *g = a.search_gradient + ((size_t)b * NLS + k) * V;
     float d = 0.0f;
-    for (int v = lane; v < V; v += G) d += g[v] * dir[v];
+    for (int v = lane; v < V; v += G) d = __builtin_fmaf(g[v], dir[v], d);
     d = gsum<G>(d);
     if (k == 0) gd0 = d;
     if (lane == k) gd_mine = d;
@@ -424,7 +496,7 @@ __global__ void __launch_bounds__(256) prepare_search_points_kernel(
     const float dv = d[o + v] / scale;
     const float xv = x[o + v];
     d_out[o + v] = dv;
-    for (int k = 0; k < nls; k++) x_set[((size_t)b * nls + k) * opt_dim + v] = xv + alphas[k] * dv;
+    for (int k = 0; k < nls; k++) x_set[((size_t)b * nls + k) * opt_dim + v] = __builtin_fmaf(alphas[k], dv, xv);
   }
 }
 
@@ -476,7 +548,304 @@ __global__ void __launch_bounds__(256) lbfgs_iteration_tail_kernel(const LineSea
     if (v < V) {
       const float dv = dir[e] / scale;
       pr.d_out[(size_t)b * V + v] = dv;
-      for (int k = 0; k < NLS; k++) pr.x_set[((size_t)b * NLS + k) * V + v] = x[e] + pr.alphas[k] * dv;
+      for (int k = 0; k < NLS; k++) pr.x_set[((size_t)b * NLS + k) * V + v] = __builtin_fmaf(pr.alphas[k], dv, x[e]);
+    }
+  }
+}
+
+// ---- the same launch, restructured around memory latency -------------------------------------------------
+// The kernel above is a string of ~a dozen DEPENDENT global round trips on one wavefront per problem (dot
+// products candidate by candidate, then the chosen costs, then the chosen rows, then the history ...).  The two
+// kernels below issue every load that does not depend on the line-search decision up front (all candidates'
+// actions and gradients, the step direction, the previous iterate, the whole history, the scalars), take the
+// decision in registers and pick the chosen rows with selects.  Same arithmetic in the same order => same bits.
+// NLS <= NLSMAX (the reference uses 4 candidates).
+
+// The ~350 B of arguments span six 64 B lines of the kernarg segment and the compiler fetches a field where it is
+// first needed: up to six dependent scalar-cache misses strung along the kernel.  One dword of every line is
+// requested here, back to back, so that all later s_loads hit the scalar cache.
+__device__ __forceinline__ void touch_kernarg_lines() {
+  const uint32_t *ka = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+  // (+ 1: the line the hidden launch-size arguments begin in)
+  constexpr int kLines = (int)((sizeof(LineSearchArgs) + sizeof(LbfgsArgs) + sizeof(PrepareArgs)) / 64) + 1;
+  uint32_t touch = 0;
+#pragma unroll
+  for (int i = 0; i < kLines; i++) touch |= ka[i * 16];
+  asm volatile("" ::"s"(touch));
+}
+
+// the inputs of the line search of problem b as one lane group holds them
+#define TAIL_INPUTS_DECL(VPL, NLSMAX) \
+  float t_sg[NLSMAX][VPL], t_sa[NLSMAX][VPL], t_dir[VPL], t_smax[VPL], t_cost, t_mag, t_bc; \
+  int t_cur, t_bi
+#define TAIL_INPUTS_PARAMS(VPL, NLSMAX)                                                                         \
+  float (&t_sg)[NLSMAX][VPL], float (&t_sa)[NLSMAX][VPL], float (&t_dir)[VPL], float (&t_smax)[VPL], float &t_cost, \
+      float &t_mag, float &t_bc, int &t_cur, int &t_bi
+#define TAIL_INPUTS_ARGS t_sg, t_sa, t_dir, t_smax, t_cost, t_mag, t_bc, t_cur, t_bi
+
+template <int VPL, int G, int NLSMAX>
+__device__ __forceinline__ void tail_inputs_load(const LineSearchArgs &ls, const PrepareArgs &pr, int b, int lane,
+                                                 TAIL_INPUTS_PARAMS(VPL, NLSMAX)) {
+  const int V = ls.opt_dim, NLS = ls.n_linesearch;
+  const size_t o = (size_t)b * V;
+  const int ln = lane < NLS ? lane : NLS - 1;
+  const int lane_is_cand = opaque_lane_mask(lane < NLS);
+  t_cost = and_mask(ls.search_cost[(size_t)b * NLS + ln], lane_is_cand);
+  t_mag = and_mask(ls.search_magnitudes[ln], lane_is_cand);
+  t_bc = ls.best_cost[b];
+  t_cur = (int)ls.current_iteration[b] + 1;
+  t_bi = ls.best_iteration[b];
+  // clamped unconditional loads (see lbfgs_history_load); candidates k >= NLS are copies of candidate NLS-1,
+  // which go through the arithmetic but can never be chosen
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * G, vc = v < V ? v : V - 1;
+    const int mk = opaque_lane_mask(v < V);
+    t_dir[e] = and_mask(ls.step_direction[o + vc], mk);
+#pragma unroll
+    for (int k = 0; k < NLSMAX; k++) {
+      const int kc = k < NLS ? k : NLS - 1;
+      t_sg[k][e] = and_mask(ls.search_gradient[((size_t)b * NLS + kc) * V + vc], mk);
+      t_sa[k][e] = and_mask(ls.search_action[((size_t)b * NLS + kc) * V + vc], mk);
+    }
+    t_smax[e] = pr.step_max[vc % pr.action_dim];
+  }
+}
+
+// line_search_body from registers; g / x = gradient / iterate of the exploration candidate
+template <int VPL, int G, int NLSMAX>
+__device__ __forceinline__ void tail_line_search(const LineSearchArgs &ls, int b, int lane, TAIL_INPUTS_PARAMS(VPL, NLSMAX),
+                                                 float (&g)[VPL], float (&x)[VPL]) {
+  const int V = ls.opt_dim, NLS = ls.n_linesearch;
+  const size_t o = (size_t)b * V;
+  float gd_mine = 0.0f, gd0 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NLSMAX; k++) {
+    float d = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) d = __builtin_fmaf(t_sg[k][e], t_dir[e], d);
+    d = gsum<G>(d);
+    if (k == 0) gd0 = d;
+    if (lane == k) gd_mine = d;
+  }
+  bool w1 = false, wboth = false;
+  const float c0 = gbcast<G>(t_cost, 0);
+  if (lane < NLS) {
+    w1 = t_cost <= (c0 + ls.c_1 * t_mag * gd0);
+    const bool w2 = ls.strong_wolfe ? (fabsf(gd_mine) <= ls.c_2 * fabsf(gd0)) : (gd_mine >= ls.c_2 * gd0);
+    wboth = w1 && w2;
+  }
+  const unsigned long long m1 = gballot<G>(w1), mb = gballot<G>(wboth);
+  const int id1 = m1 ? 63 - __clzll((long long)m1) : 0;
+  const int id = mb ? 63 - __clzll((long long)mb) : 0;
+  const int sel = ls.strong_wolfe ? id : (id == 0 ? id1 : id);
+  const int expl = (ls.approx_wolfe && !ls.strong_wolfe && sel == 0) ? 1 : sel;
+  float sc = 0.0f, ec = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NLSMAX; k++) {
+    const float ck = gbcast<G>(t_cost, k);
+    if (k == sel) sc = ck;
+    if (k == expl) ec = ck;
+  }
+  const float delta = t_bc - sc;
+  const float rel = delta / (t_bc + 1e-6f);
+  const bool update_best = delta > ls.cost_delta_threshold && rel > ls.cost_relative_threshold;
+  const int bi = update_best ? t_cur : t_bi;
+  if (lane == 0) {
+    ls.exploration_cost[b] = ec;
+    ls.selected_cost[b] = sc;
+    ls.converged[b] = (bi + ls.convergence_iteration < t_cur) ? 1 : 0;
+    ls.best_iteration[b] = (int16_t)bi;
+    ls.current_iteration[b] = (int16_t)t_cur;
+    if (update_best) ls.best_cost[b] = sc;
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * G;
+    float gs = 0.0f, xs = 0.0f;
+    g[e] = x[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NLSMAX; k++) {
+      if (k == expl) { g[e] = t_sg[k][e]; x[e] = t_sa[k][e]; }
+      if (k == sel) { gs = t_sg[k][e]; xs = t_sa[k][e]; }
+    }
+    if (v < V) {
+      ls.exploration_action[o + v] = x[e];
+      ls.exploration_gradient[o + v] = g[e];
+      ls.selected_action[o + v] = xs;
+      ls.selected_gradient[o + v] = gs;
+      if (update_best) ls.best_action[o + v] = xs;
+    }
+  }
+  if (lane < NLS) {
+    ls.exploration_idx[(size_t)b * NLS + lane] = expl;
+    ls.selected_idx[(size_t)b * NLS + lane] = sel;
+  }
+}
+
+// prepare_search_points_kernel from registers
+template <int VPL, int G, int NLSMAX>
+__device__ __forceinline__ void tail_next_candidates(const PrepareArgs &pr, int b, int lane, int V, int NLS,
+                                                     const float (&x)[VPL], const float (&dir)[VPL],
+                                                     const float (&smax)[VPL], float mag_mine) {
+  const size_t o = (size_t)b * V;
+  float scale = 1.0f;
+  if (pr.apply_scale) {
+    float mx = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * G;
+      if (v < V) mx = fmaxf(mx, fabsf(dir[e]) / smax[e]);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, G));
+    scale = fmaxf(mx, 1.0f);
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; e++) {
+    const int v = lane + e * G;
+    const float dv = dir[e] / scale;
+    if (v < V) pr.d_out[o + v] = dv;
+#pragma unroll
+    for (int k = 0; k < NLSMAX; k++) {
+      const float ak = gbcast<G>(mag_mine, k);
+      if (k < NLS && v < V) pr.x_set[((size_t)b * NLS + k) * V + v] = __builtin_fmaf(ak, dv, x[e]);
+    }
+  }
+}
+
+// (a) one lane group per problem: everything in one burst of loads.  Used for the 16-lane-row problems (IK).
+template <int VPL, int G, int NLSMAX>
+__global__ void __launch_bounds__(256) lbfgs_iteration_tail_prefetch_kernel(const LineSearchArgs ls, const LbfgsArgs lb,
+                                                                            const PrepareArgs pr) {
+  touch_kernarg_lines();
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int b = blockIdx.x * (blockDim.x / G) + grp;
+  if (b >= ls.batch) return;
+  TAIL_INPUTS_DECL(VPL, NLSMAX);
+  tail_inputs_load<VPL, G, NLSMAX>(ls, pr, b, lane, TAIL_INPUTS_ARGS);
+  LBFGS_HISTORY_DECL(VPL, G);
+  lbfgs_history_load<VPL, G>(lb, b, lane, LBFGS_HISTORY_ARGS);
+  float g[VPL], x[VPL], dir[VPL];
+  tail_line_search<VPL, G, NLSMAX>(ls, b, lane, TAIL_INPUTS_ARGS, g, x);
+  lbfgs_step_from_history<VPL, G, true>(lb, b, lane, g, x, LBFGS_HISTORY_ARGS, dir);
+  tail_next_candidates<VPL, G, NLSMAX>(pr, b, lane, ls.opt_dim, ls.n_linesearch, x, dir, t_smax, t_mag);
+}
+
+// (b) one 256-lane workgroup per problem, for wavefront-sized problems (trajectory optimisation: V = 84, m = 27).
+// A lone wavefront needs ~4 m + 25 loads per lane for such a problem: the address arithmetic alone is ~3 us of
+// issue time on a wavefront that has its SIMD to itself, and the 64-entry vmcnt queue turns the burst into three
+// round trips.  Here wavefronts 1..3 move the history: 192 lanes stage old slots 1..m-1 into LDS (coalesced, ~2 m V /
+// 192 loads per lane, one round trip) while wavefront 0 loads the line-search inputs and decides; after ONE
+// barrier wavefront 0 pulls the history from LDS into registers (transposed there: 8 float4 reads per array and
+// element instead of 4 m dword loads) and runs the two-loop recursion, and wavefronts
+// 1..3 write the shifted history back from the registers they staged it through -- off the critical path.
+constexpr int kStageLanes = 192;
+constexpr int kHistRow = 36;
+template <int VPL, int NLSMAX, int RMAX>
+__global__ void __launch_bounds__(256) lbfgs_iteration_tail_wg_kernel(const LineSearchArgs ls, const LbfgsArgs lb,
+                                                                      const PrepareArgs pr) {
+  // y then s, each [V + 1][kHistRow]: row v = the slots 0..m-2 (new numbering) of element v, so that the lane that
+  // owns v fetches them with float4 reads; row V is zero (lanes past V).  36 floats per row: 16 B aligned and the
+  // float4 reads of 16 consecutive lanes fall into distinct banks.
+  extern __shared__ float s_hist[];
+  constexpr int G = kWave;
+  const int s_off = (lb.v_dim + 1) * kHistRow;
+  touch_kernarg_lines();
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int V = lb.v_dim, m = lb.m;
+  const int n = m > 0 ? (m - 1) * V : 0;  // floats per array that move
+  const size_t hist_stride = (size_t)lb.batch * V;
+  float g[VPL], x[VPL];
+  TAIL_INPUTS_DECL(VPL, NLSMAX);
+  LBFGS_HISTORY_DECL(VPL, G);
+  float stage_y[RMAX], stage_s[RMAX];
+  if (tid < kWave) {
+    tail_inputs_load<VPL, G, NLSMAX>(ls, pr, b, lane, TAIL_INPUTS_ARGS);
+    int mk[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; e++) {
+      const int v = lane + e * G, vc = v < V ? v : V - 1;
+      mk[e] = opaque_lane_mask(v < V);
+      h_g0[e] = and_mask(lb.grad_0[(size_t)b * V + vc], mk[e]);
+      h_x0[e] = and_mask(lb.x_0[(size_t)b * V + vc], mk[e]);
+    }
+    const int rl = lane + 1 < m ? lane + 1 : (m > 0 ? m - 1 : 0);
+    h_rho = m > 0 ? and_mask(lb.rho_buffer[(size_t)rl * lb.batch + b], opaque_lane_mask(lane < m - 1)) : 0.0f;
+    tail_line_search<VPL, G, NLSMAX>(ls, b, lane, TAIL_INPUTS_ARGS, g, x);
+  } else if (n > 0) {
+    // element idx = i * V + v of the new numbering comes from old slot i + 1; idx advances by 192 per round:
+    // (i, v) are stepped, not divided
+    const int t = tid - kWave;
+    const int step_i = kStageLanes / V, step_v = kStageLanes % V;
+    int i = t / V, v = t % V;
+    const float *ysrc = lb.y_buffer + (size_t)b * V + hist_stride;  // old slot 1
+    const float *ssrc = lb.s_buffer + (size_t)b * V + hist_stride;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      const int idx = t + r * kStageLanes;
+      // past the end: re-read the last element (and re-write it below), no predication
+      const int ic = idx < n ? i : m - 2, vc = idx < n ? v : V - 1;
+      stage_y[r] = ysrc[(size_t)ic * hist_stride + vc];
+      stage_s[r] = ssrc[(size_t)ic * hist_stride + vc];
+      v += step_v; i += step_i;
+      if (v >= V) { v -= V; i++; }
+    }
+    {
+      int i2 = t / V, v2 = t % V;
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) {
+        const int idx = t + r * kStageLanes;
+        const int at = idx < n ? v2 * kHistRow + i2 : (V - 1) * kHistRow + m - 2;
+        s_hist[at] = stage_y[r];
+        s_hist[s_off + at] = stage_s[r];
+        v2 += step_v; i2 += step_i;
+        if (v2 >= V) { v2 -= V; i2++; }
+      }
+    }
+    if (t < 32) s_hist[V * kHistRow + t] = s_hist[s_off + V * kHistRow + t] = 0.0f;  // the row lanes past V read
+  }
+  __syncthreads();  // every old slot has been read: the shifted write-back cannot overtake a read
+  if (tid < kWave) {
+    if (n > 0) {
+#pragma unroll
+      for (int e = 0; e < VPL; e++) {
+        const int v = lane + e * G;
+        const float4 *ry = reinterpret_cast<const float4 *>(s_hist + (v < V ? v : V) * kHistRow);
+        const float4 *rs = reinterpret_cast<const float4 *>(s_hist + s_off + (v < V ? v : V) * kHistRow);
+#pragma unroll
+        for (int j = 0; j < LbfgsLimits<G>::MMAX / 4; j++) {  // (slots >= m-1 of a row: never written, never used)
+          const float4 qy = ry[j], qs = rs[j];
+          h_ys[4 * j][e] = qy.x; h_ys[4 * j + 1][e] = qy.y; h_ys[4 * j + 2][e] = qy.z; h_ys[4 * j + 3][e] = qy.w;
+          h_ss[4 * j][e] = qs.x; h_ss[4 * j + 1][e] = qs.y; h_ss[4 * j + 2][e] = qs.z; h_ss[4 * j + 3][e] = qs.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LbfgsLimits<G>::MMAX; i++) {
+#pragma unroll
+        for (int e = 0; e < VPL; e++) h_ys[i][e] = h_ss[i][e] = 0.0f;
+      }
+    }
+    float dir[VPL];
+    lbfgs_step_from_history<VPL, G, false>(lb, b, lane, g, x, LBFGS_HISTORY_ARGS, dir);
+    tail_next_candidates<VPL, G, NLSMAX>(pr, b, lane, V, ls.n_linesearch, x, dir, t_smax, t_mag);
+  } else if (n > 0) {
+    const int t = tid - kWave;
+    const int step_i = kStageLanes / V, step_v = kStageLanes % V;
+    int i = t / V, v = t % V;
+    float *ydst = lb.y_buffer + (size_t)b * V;  // new slot 0
+    float *sdst = lb.s_buffer + (size_t)b * V;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      const int idx = t + r * kStageLanes;
+      if (idx < n) {
+        ydst[(size_t)i * hist_stride + v] = stage_y[r];
+        sdst[(size_t)i * hist_stride + v] = stage_s[r];
+      }
+      v += step_v; i += step_i;
+      if (v >= V) { v -= V; i++; }
     }
   }
 }
@@ -594,10 +963,30 @@ CUROBO_EXPORT int curobo_hip_launch_lbfgs_iteration_tail(
                epsilon, batchsize, history_m, opt_dim, stable_mode};
   PrepareArgs pr{search_action, step_direction_scaled, action_step_max, search_magnitudes, action_dim, apply_step_scale};
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)ceil_div(batchsize, 4)), block(256);
+  static const bool wg64 = getenv("CUROBO_HIP_TAIL_WG64") != nullptr;
+  const dim3 grid((unsigned)ceil_div(batchsize, wg64 ? 1 : 4)), block(wg64 ? 64 : 256);
   static const bool no_row16 = getenv("CUROBO_HIP_NO_ROW16") != nullptr;
-  if (!no_row16 && opt_dim <= 16 && history_m <= 16 && n_linesearch <= 16)  // IK-sized problems: one 16-lane row each
-    hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1, 16>), dim3((unsigned)ceil_div(batchsize, 16)), block, 0, st, ls, lb, pr);
+  static const bool no_prefetch = getenv("CUROBO_HIP_TAIL_NO_PREFETCH") != nullptr;
+  const bool row16 = !no_row16 && opt_dim <= 16 && history_m <= 16 && n_linesearch <= 16;
+  const dim3 grid16((unsigned)ceil_div(batchsize, 16));
+  if (n_linesearch <= 4 && !no_prefetch) {
+    // a workgroup per problem pays while the problems do not fill the chip (64 / 256: 9.0 / 10.1 us against 12.3 /
+    // 12.9 us for a wavefront per problem); at 1024 problems the extra wavefronts cost more than they hide (19 vs 15)
+    static const bool no_wg_env = getenv("CUROBO_HIP_TAIL_NO_WG") != nullptr;
+    const bool no_wg = no_wg_env || batchsize > 512;
+    const int n_move = history_m > 0 ? (history_m - 1) * opt_dim : 0;
+    const int rounds = ceil_div(n_move, kStageLanes);
+    const size_t lds = (size_t)2 * (opt_dim + 1) * kHistRow * sizeof(float);
+    const dim3 grid_wg((unsigned)batchsize);
+    if (row16) hipLaunchKernelGGL((lbfgs_iteration_tail_prefetch_kernel<1, 16, 4>), grid16, block, 0, st, ls, lb, pr);
+    else if (no_wg && opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_prefetch_kernel<1, kWave, 4>), grid, block, 0, st, ls, lb, pr);
+    else if (no_wg) hipLaunchKernelGGL((lbfgs_iteration_tail_prefetch_kernel<2, kWave, 4>), grid, block, 0, st, ls, lb, pr);
+    else if (opt_dim <= kWave && rounds <= 12) hipLaunchKernelGGL((lbfgs_iteration_tail_wg_kernel<1, 4, 12>), grid_wg, block, lds, st, ls, lb, pr);
+    else if (opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_wg_kernel<1, 4, 20>), grid_wg, block, lds, st, ls, lb, pr);
+    else if (rounds <= 12) hipLaunchKernelGGL((lbfgs_iteration_tail_wg_kernel<2, 4, 12>), grid_wg, block, lds, st, ls, lb, pr);
+    else hipLaunchKernelGGL((lbfgs_iteration_tail_wg_kernel<2, 4, 20>), grid_wg, block, lds, st, ls, lb, pr);
+  } else if (row16)  // IK-sized problems: one 16-lane row each
+    hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1, 16>), grid16, block, 0, st, ls, lb, pr);
   else if (opt_dim <= kWave) hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<1>), grid, block, 0, st, ls, lb, pr);
   else hipLaunchKernelGGL((lbfgs_iteration_tail_kernel<2>), grid, block, 0, st, ls, lb, pr);
   return check_launch(what, st);
