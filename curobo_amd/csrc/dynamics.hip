@@ -111,7 +111,7 @@ __device__ __forceinline__ Rp local_Rp(const float *F, int jt, float q) {
   t.p = make_f3(F[3], F[7], F[11]);
   if (jt >= J_X_ROT) {
     float s, c;
-    sincosf(q, &s, &c);
+    sincos_bounded(q, &s, &c);
     const int ax = jt - J_X_ROT, a1 = ax == 2 ? 0 : ax + 1, a2 = ax == 0 ? 2 : ax - 1;
 #pragma unroll
     for (int r = 0; r < 3; r++) {

@@ -8,11 +8,21 @@ namespace curobo_hip {
 
 constexpr int kFkLanes = 16;  // lanes per point
 
-// reference kinematics_forward_helper.cuh:316-393 / kinematics_util.cuh:62-74.
-// Writes the local 3x4 of one (point, link) column-major, each column padded to 4 floats.
-__device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst, const float *__restrict__ F,
-                                                        int j_type, float q_val, float off_mul,
-                                                        float off_add) {
+// reference kinematics_forward_helper.cuh:316-393 / kinematics_util.cuh:62-74, in two steps so that the
+// transcendental can be computed by other lanes than the ones that build the matrix:
+//   joint_sincos: (s, c) of the joint angle (revolute), or s = the displacement (prismatic)
+//   local_transform_from_sincos: the local 3x4 of one (point, link) column-major, each column padded to 4 floats
+__device__ __forceinline__ void joint_sincos(int j_type, float q_val, float off_mul, float off_add, float *s, float *c) {
+  *s = 0.0f; *c = 1.0f;
+  if (j_type != J_FIXED) {
+    const float angle = off_mul * q_val + off_add;
+    if (j_type <= J_Z_PRISM) *s = angle;
+    else sincos_bounded(angle, s, c);
+  }
+}
+
+__device__ __forceinline__ void local_transform_from_sincos(float *__restrict__ dst, const float *__restrict__ F,
+                                                            int j_type, float s, float c) {
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3];
   const float f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7];
   const float f8 = F[8], f9 = F[9], f10 = F[10], f11 = F[11];
@@ -21,14 +31,12 @@ __device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst
   float4 c2 = make_float4(f2, f6, f10, 0.0f);
   float4 c3 = make_float4(f3, f7, f11, 0.0f);
   if (j_type != J_FIXED) {
-    const float angle = off_mul * q_val + off_add;
     if (j_type <= J_Z_PRISM) {
+      const float angle = s;
       c3.x = f3 + (j_type == J_X_PRISM ? f0 : (j_type == J_Y_PRISM ? f1 : f2)) * angle;
       c3.y = f7 + (j_type == J_X_PRISM ? f4 : (j_type == J_Y_PRISM ? f5 : f6)) * angle;
       c3.z = f11 + (j_type == J_X_PRISM ? f8 : (j_type == J_Y_PRISM ? f9 : f10)) * angle;
     } else {
-      float s, c;
-      sincosf(angle, &s, &c);
       const int xyz = j_type - J_X_ROT;
       const float is_x = xyz == 0 ? 1.0f : 0.0f;
       const float is_y = xyz == 1 ? 1.0f : 0.0f;
@@ -46,6 +54,14 @@ __device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst
   }
   float4 *d4 = reinterpret_cast<float4 *>(dst);
   d4[0] = c0; d4[1] = c1; d4[2] = c2; d4[3] = c3;
+}
+
+__device__ __forceinline__ void local_transform_colmajor(float *__restrict__ dst, const float *__restrict__ F,
+                                                        int j_type, float q_val, float off_mul,
+                                                        float off_add) {
+  float s, c;
+  joint_sincos(j_type, q_val, off_mul, off_add, &s, &c);
+  local_transform_from_sincos(dst, F, j_type, s, c);
 }
 
 // ds_read_b32 + wait as one opaque unit (LDS operations of a wave execute in issue order, so the read sees
@@ -78,6 +94,29 @@ __device__ __forceinline__ void fk_chain_16(float *__restrict__ cumul, const flo
     const float4 m = *reinterpret_cast<const float4 *>(my_local + l * 16);
     cur = a0 * m.x + a1 * m.y + a2 * m.z + (c == 3 ? a3 : 0.0f);
     if (owner) cumul[l * 12 + lane] = cur;
+  }
+}
+
+// fk_chain_16 with the cumulative transform of link l written OVER the local transform of link l (both at
+// buf + l * 16; the 3x4 takes the first 12 floats).  Every lane of the group has read its column of local[l]
+// before any lane writes cumul[l] (one wavefront, LDS operations execute in issue order), and nothing reads
+// local[l] again: the kernel needs 16 instead of 28 floats of LDS per (point, link).  No __restrict__ here: the
+// read of local[l] must stay ahead of the write to the same words.
+__device__ __forceinline__ void fk_chain_16_inplace(float *buf, const int *__restrict__ parent,
+                                                    const float *__restrict__ fixed_transform, int L, int lane) {
+  const int c = lane & 3;
+  const bool owner = lane < 12;
+  float cur = owner ? fixed_transform[lane] : 0.0f;
+  if (owner) buf[lane] = cur;
+  for (int l = 1; l < L; l++) {
+    const int par = __builtin_amdgcn_readfirstlane(parent[l]);
+    const float4 m = *reinterpret_cast<const float4 *>(buf + l * 16 + c * 4);
+    float p = cur;
+    if (par != l - 1) p = lds_read_f32_now(buf + par * 16 + lane);
+    p = owner ? p : 0.0f;
+    const float a0 = quad_bcast<0>(p), a1 = quad_bcast<1>(p), a2 = quad_bcast<2>(p), a3 = quad_bcast<3>(p);
+    cur = a0 * m.x + a1 * m.y + a2 * m.z + (c == 3 ? a3 : 0.0f);
+    if (owner) buf[l * 16 + lane] = cur;
   }
 }
 

@@ -21,6 +21,8 @@
 //     contiguous segments per point.
 //   * the VJP accumulates per-lane partial joint gradients in LDS rows (ds_add_f32, no dynamic
 //     register indexing -> no scratch), then 16-lane reduces them.
+#include <cstdlib>
+
 #include "fk_device.hpp"
 
 namespace curobo_hip {
@@ -51,20 +53,33 @@ struct FkArgs {
   int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames;
 };
 
+constexpr int kFkLinkStride = 16;  // floats of LDS per (point, link): the local 3x4 column-major padded, then the
+                                   // cumulative 3x4 row-major over it (fk_chain_16_inplace)
+
 template <bool SPHERES, bool JACOBIAN, bool COM, bool WRITE_CUMUL>
 __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.nlinks;
   const int pts = blockDim.x / kFkLanes;
-  float *cumul = smem;                  // [pts][L][12]   (row-major 3x4, the output layout)
-  float *local = smem + pts * L * 12;   // [pts][L][16]   (column-major, float4 per column)
-  int *s_parent = reinterpret_cast<int *>(local + pts * L * 16);  // [L]
+  float *cumul = smem;                                                    // [pts][L][16]
+  float4 *s_sph = reinterpret_cast<float4 *>(smem + pts * L * kFkLinkStride);  // [S] robot spheres (one env)
+  int *s_sph_link = reinterpret_cast<int *>(s_sph + (SPHERES ? a.nspheres : 0));  // [S]
+  int *s_parent = s_sph_link + (SPHERES ? a.nspheres : 0);                // [L]
 
   const int tid = threadIdx.x;
   const int pt0 = blockIdx.x * pts;
   const int npts = min(pts, a.n_points - pt0);
 
   for (int l = tid; l < L; l += blockDim.x) s_parent[l] = a.link_map[l];
+  // one set of robot spheres: the table goes to LDS with the first loads of the block, and the sphere pass
+  // below is LDS -> registers -> HBM with no global load on its path
+  const bool spheres_staged = SPHERES && a.num_envs <= 1;
+  if (spheres_staged) {
+    for (int s = tid; s < a.nspheres; s += blockDim.x) {
+      s_sph[s] = reinterpret_cast<const float4 *>(a.robot_spheres)[s];
+      s_sph_link[s] = a.link_sphere_map[s];
+    }
+  }
 
   // ---- phase 1: local transforms, one (point, link) item per lane
   for (int e = tid; e < npts * L; e += blockDim.x) {
@@ -73,7 +88,7 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
     const int jt = a.joint_map_type[l];
     float qv = 0.0f;
     if (jt != J_FIXED) qv = a.q[(size_t)(pt0 + lp) * a.njoints + a.joint_map[l]];
-    local_transform_colmajor(local + (size_t)e * 16, a.fixed_transform + l * 12, jt, qv,
+    local_transform_colmajor(cumul + (size_t)e * kFkLinkStride, a.fixed_transform + l * 12, jt, qv,
                              a.joint_offset[2 * l], a.joint_offset[2 * l + 1]);
   }
   __syncthreads();
@@ -82,27 +97,33 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
   const int grp = tid / kFkLanes;
   const int lane = tid % kFkLanes;
   const bool active = grp < npts;
-  float *my_cumul = cumul + (size_t)grp * L * 12;
-  if (active) fk_chain_16(my_cumul, local + (size_t)grp * L * 16, s_parent, a.fixed_transform, L, lane);
+  float *my_cumul = cumul + (size_t)grp * L * kFkLinkStride;
+  if (active) fk_chain_16_inplace(my_cumul, s_parent, a.fixed_transform, L, lane);
   __syncthreads();
 
-  // ---- phase 3a: cumulative transforms -> HBM, one contiguous float4 stream per block
+  // ---- phase 3a: cumulative transforms -> HBM as [L][3][4], one contiguous float4 stream per block
   if (WRITE_CUMUL) {
     const float4 *src = reinterpret_cast<const float4 *>(cumul);
     float4 *dst = reinterpret_cast<float4 *>(a.cumul_out + (size_t)pt0 * L * 12);
-    for (int i = tid; i < npts * L * 3; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < npts * L * 3; i += blockDim.x) {
+      const int link = i / 3;
+      store_float4_streaming(dst + i, src[link * 4 + (i - link * 3)]);
+    }
   }
   if (!active) return;
   const int n = pt0 + grp;
 
   // ---- phase 3b: collision spheres (reference kinematics_forward_helper.cuh:218-254)
   if (SPHERES) {
-    const int env = (a.num_envs > 1) ? a.env_query_idx[n / a.horizon] : 0;
-    const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * a.nspheres;
     float4 *out = reinterpret_cast<float4 *>(a.spheres_out) + (size_t)n * a.nspheres;
-    for (int s = lane; s < a.nspheres; s += kFkLanes) {
-      const int link = a.link_sphere_map[s];
-      out[s] = transform_sphere(my_cumul + link * 12, rs[s]);
+    if (spheres_staged) {
+      for (int s = lane; s < a.nspheres; s += kFkLanes)
+        store_float4_streaming(out + s, transform_sphere(my_cumul + s_sph_link[s] * kFkLinkStride, s_sph[s]));
+    } else {
+      const int env = a.env_query_idx[n / a.horizon];
+      const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * a.nspheres;
+      for (int s = lane; s < a.nspheres; s += kFkLanes)
+        out[s] = transform_sphere(my_cumul + a.link_sphere_map[s] * kFkLinkStride, rs[s]);
     }
   }
   // ---- centre of mass (reference :538-600)
@@ -111,7 +132,7 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
     for (int l = lane; l < L; l += kFkLanes) {
       const float4 mc = reinterpret_cast<const float4 *>(a.link_masses_com)[l];
       if (mc.w > 0.0f) {
-        const float4 cw = transform_sphere(my_cumul + l * 12, mc);
+        const float4 cw = transform_sphere(my_cumul + l * kFkLinkStride, mc);
         wx += mc.w * cw.x; wy += mc.w * cw.y; wz += mc.w * cw.z; wm += mc.w;
       }
     }
@@ -125,7 +146,7 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
   }
   // ---- tool-frame poses (reference :270-301), quaternion written wxyz
   for (int t = lane; t < a.n_tool_frames; t += kFkLanes) {
-    const float *C = my_cumul + a.tool_frame_map[t] * 12;
+    const float *C = my_cumul + a.tool_frame_map[t] * kFkLinkStride;
     const float4 qx = quat_from_transform(C);
     reinterpret_cast<float4 *>(a.link_quat)[(size_t)n * a.n_tool_frames + t] = make_float4(qx.w, qx.x, qx.y, qx.z);
     float *p = a.link_pos + ((size_t)n * a.n_tool_frames + t) * 3;
@@ -136,7 +157,7 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
     const int D = a.njoints, T = a.n_tool_frames;
     for (int t = 0; t < T; t++) {
       const int tl = a.tool_frame_map[t];
-      const float *E = my_cumul + tl * 12;
+      const float *E = my_cumul + tl * kFkLinkStride;
       const f3 ee = make_f3(E[3], E[7], E[11]);
       const int cs = a.link_chain_offsets[tl], ce = a.link_chain_offsets[tl + 1];
       float *J = a.jacobian_out + ((size_t)n * T + t) * 6 * D;
@@ -149,7 +170,7 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
             bool in_chain = false;
             for (int ci = cs; ci < ce; ci++) in_chain |= (a.link_chain_data[ci] == li);
             if (!in_chain) continue;
-            const float *C = my_cumul + li * 12;
+            const float *C = my_cumul + li * kFkLinkStride;
             const int jt = a.joint_map_type[li];
             const float sign = a.joint_offset[li * 2];
             if (jt >= J_X_ROT) {
@@ -168,6 +189,170 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
         for (int r = 0; r < 6; r++) J[r * D + j] = col[r];
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward kinematics with FOUR LANES PER POINT for the chain (the outputs the rollouts use: tool poses,
+// spheres, cumulative transforms; the Jacobian / centre-of-mass outputs stay on the kernel above).
+//
+// What bounds this launch is not the 57 MB it writes but the serial work in front of the first store: every
+// workgroup of the grid is resident at once, so the launch is (everything before the stores) + (the store
+// stream at the rate of a plain fill, ~9 us), and a wavefront that has its SIMD to itself issues one
+// instruction per ~7.5 cycles.  So the chain is laid out for the FEWEST INSTRUCTIONS PER LINK on the critical
+// wavefront: lane c of a quad owns column c of the cumulative 3x4 (three registers).  A joint's local transform
+// is F with two columns mixed (rotation about a coordinate axis) or one column added to the last (translation),
+// i.e. column c of it is alpha * F[:,c] + beta * F[:,c'] with (alpha, beta, c') a function of (joint type, c)
+// that is tabulated per link in LDS; column c of parent * local is then three FMAs per row whose parent
+// operands come from the quad through DPP (fused into the FMA) -- ~30 instructions per link against ~110 for a
+// lane that owns the whole matrix and ~30 for the 16-lane form above, which however keeps 4 of every 16 lanes
+// idle and carries 4x the wavefronts.  sin/cos of the (point, joint) pairs are computed beforehand by all lanes
+// (only the links that have a joint), and every global read of the block happens in one round trip up front.
+constexpr int kFkPts = 64;  // points per workgroup (4 lanes each)
+
+// what column c of the local transform of a joint of type jt is made of (see above): bit 0: alpha = cos (else
+// 1); bit 1: beta != 0; bit 2: beta negative; bits 3..4: c'
+__device__ __forceinline__ int local_column_code(int jt, int c) {
+  switch (jt) {
+    case J_X_PRISM: return c == 3 ? (2 | (0 << 3)) : 0;
+    case J_Y_PRISM: return c == 3 ? (2 | (1 << 3)) : 0;
+    case J_Z_PRISM: return c == 3 ? (2 | (2 << 3)) : 0;
+    case J_X_ROT: return c == 1 ? (1 | 2 | (2 << 3)) : (c == 2 ? (1 | 2 | 4 | (1 << 3)) : 0);
+    case J_Y_ROT: return c == 0 ? (1 | 2 | 4 | (2 << 3)) : (c == 2 ? (1 | 2 | (0 << 3)) : 0);
+    case J_Z_ROT: return c == 0 ? (1 | 2 | (1 << 3)) : (c == 1 ? (1 | 2 | 4 | (0 << 3)) : 0);
+    default: return 0;
+  }
+}
+
+template <bool SPHERES, bool WRITE_CUMUL>
+__global__ void __launch_bounds__(256) fk_forward_points_kernel(const FkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.nlinks, S = SPHERES ? a.nspheres : 0, D = a.njoints, T = a.n_tool_frames;
+  float *cumul = smem;                                                 // [kFkPts][L][12]
+  float2 *s_sc = reinterpret_cast<float2 *>(cumul + kFkPts * L * 12);  // [kFkPts][L] (sin, cos) | displacement
+  float4 *s_col = reinterpret_cast<float4 *>(s_sc + kFkPts * L);       // [L][4][2] column tables (see above)
+  float4 *s_sph = s_col + L * 8;                                       // [S]
+  int *s_sph_link = reinterpret_cast<int *>(s_sph + S);                // [S]
+  int4 *s_link = reinterpret_cast<int4 *>(s_sph_link + S + ((4 - (S & 3)) & 3));  // [L] (type, parent, joint, -)
+  float2 *s_off = reinterpret_cast<float2 *>(s_link + L);              // [L] joint_offset (multiplier, bias)
+  int *s_jointed = reinterpret_cast<int *>(s_off + L);                 // [L + 1] links with a joint, then their count
+  float *s_q = reinterpret_cast<float *>(s_jointed + L + 1 + ((L + 1) & 1));  // [kFkPts][D]
+  const int tid = threadIdx.x;
+  const int pt0 = blockIdx.x * kFkPts;
+  const int npts = min(kFkPts, a.n_points - pt0);
+  const bool spheres_staged = SPHERES && a.num_envs <= 1;
+  // ---- phase 0: everything the block reads from memory, in one round trip
+  for (int i = tid; i < npts * D; i += blockDim.x) s_q[i] = a.q[(size_t)pt0 * D + i];
+  for (int i = tid; i < L * 4; i += blockDim.x) {
+    const int l = i >> 2, c = i & 3;
+    const int code = local_column_code(a.joint_map_type[l], c);
+    const float *F = a.fixed_transform + l * 12;
+    const int c2 = code >> 3;
+    s_col[i * 2] = make_float4(F[c], F[4 + c], F[8 + c], __builtin_bit_cast(float, code));
+    s_col[i * 2 + 1] = make_float4(F[c2], F[4 + c2], F[8 + c2], 0.0f);
+    if (c == 0) {
+      s_link[l] = make_int4(a.joint_map_type[l], a.link_map[l], a.joint_map[l], 0);
+      s_off[l] = make_float2(a.joint_offset[2 * l], a.joint_offset[2 * l + 1]);
+    }
+  }
+  if (tid < kWave) {  // the links that have a joint, compacted (L <= 64 here: the LDS budget caps it lower)
+    const bool jointed = tid < L && a.joint_map_type[tid < L ? tid : 0] != J_FIXED;
+    const unsigned long long mask = __ballot(jointed);
+    if (jointed) s_jointed[__popcll(mask & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) s_jointed[L] = __popcll(mask);
+  }
+  if (spheres_staged) {
+    for (int s = tid; s < S; s += blockDim.x) {
+      s_sph[s] = reinterpret_cast<const float4 *>(a.robot_spheres)[s];
+      s_sph_link[s] = a.link_sphere_map[s];
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: sin/cos of every (point, jointed link), all lanes, LDS to LDS
+  {
+    const int nj = s_jointed[L];
+    for (int e = tid; e < npts * nj; e += blockDim.x) {
+      const int lp = e / nj;
+      const int l = s_jointed[e - lp * nj];
+      const int4 tab = s_link[l];
+      const float2 off = s_off[l];
+      float sn, cs;
+      joint_sincos(tab.x, s_q[lp * D + tab.z], off.x, off.y, &sn, &cs);
+      s_sc[lp * L + l] = make_float2(sn, cs);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the chain, one quad per point
+  {
+    const int c = tid & 3;
+    const int me = (tid >> 2) < npts ? (tid >> 2) : 0;  // (idle quads shadow point 0: identical stores)
+    float *mine = cumul + (size_t)me * L * 12 + c;
+    float P0 = s_col[c * 2].x, P1 = s_col[c * 2].y, P2 = s_col[c * 2].z;  // base link: reference :467-485
+    mine[0] = P0; mine[4] = P1; mine[8] = P2;
+    const float last = c == 3 ? 1.0f : 0.0f;
+    const int l1 = L > 1 ? 1 : 0;
+    float4 An = s_col[(l1 * 4 + c) * 2], Bn = s_col[(l1 * 4 + c) * 2 + 1];
+    float2 sc_n = s_sc[me * L + l1];
+    int par_n = s_link[l1].y;
+    for (int l = 1; l < L; l++) {
+      const float4 A = An, B = Bn;
+      const float sn = sc_n.x, cs = sc_n.y;
+      const int par = __builtin_amdgcn_readfirstlane(par_n);
+      const int ln = l + 1 < L ? l + 1 : l;  // the next link's operands are requested before this link's arithmetic
+      An = s_col[(ln * 4 + c) * 2]; Bn = s_col[(ln * 4 + c) * 2 + 1];
+      sc_n = s_sc[me * L + ln];
+      par_n = s_link[ln].y;
+      const int code = __builtin_bit_cast(int, A.w);
+      const float alpha = (code & 1) ? cs : 1.0f;
+      const float beta = (code & 2) ? ((code & 4) ? -sn : sn) : 0.0f;
+      const float M0 = A.x * alpha + beta * B.x, M1 = A.y * alpha + beta * B.y, M2 = A.z * alpha + beta * B.z;
+      if (par != l - 1) {  // a branch of the tree: the quad's own earlier result (LDS operations stay in order)
+        P0 = mine[par * 12]; P1 = mine[par * 12 + 4]; P2 = mine[par * 12 + 8];
+      }
+      const float C0 = quad_bcast<0>(P0) * M0 + quad_bcast<1>(P0) * M1 + quad_bcast<2>(P0) * M2 + last * quad_bcast<3>(P0);
+      const float C1 = quad_bcast<0>(P1) * M0 + quad_bcast<1>(P1) * M1 + quad_bcast<2>(P1) * M2 + last * quad_bcast<3>(P1);
+      const float C2 = quad_bcast<0>(P2) * M0 + quad_bcast<1>(P2) * M1 + quad_bcast<2>(P2) * M2 + last * quad_bcast<3>(P2);
+      mine[l * 12] = C0; mine[l * 12 + 4] = C1; mine[l * 12 + 8] = C2;
+      P0 = C0; P1 = C1; P2 = C2;
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: outputs, all lanes, every stream contiguous over the workgroup's points
+  if (WRITE_CUMUL) {
+    const float4 *src = reinterpret_cast<const float4 *>(cumul);
+    float4 *dst = reinterpret_cast<float4 *>(a.cumul_out + (size_t)pt0 * L * 12);
+    for (int i = tid; i < npts * L * 3; i += blockDim.x) store_float4_streaming(dst + i, src[i]);
+  }
+  if (SPHERES) {
+    // item e = (point, sphere) flat = the offset into the block's slice of the output; (point, sphere) are
+    // stepped by 256 per round instead of divided
+    float4 *out = reinterpret_cast<float4 *>(a.spheres_out) + (size_t)pt0 * S;
+    const int step_p = (int)blockDim.x / S, step_s = (int)blockDim.x % S;
+    int pt = tid / S, sp = tid - (tid / S) * S;
+    for (int e = tid; e < npts * S; e += blockDim.x) {
+      float4 rs;
+      int link;
+      if (spheres_staged) {
+        rs = s_sph[sp];
+        link = s_sph_link[sp];
+      } else {
+        const int env = a.env_query_idx[(pt0 + pt) / a.horizon];
+        rs = reinterpret_cast<const float4 *>(a.robot_spheres)[(size_t)env * S + sp];
+        link = a.link_sphere_map[sp];
+      }
+      store_float4_streaming(out + e, transform_sphere(cumul + ((size_t)pt * L + link) * 12, rs));
+      sp += step_s; pt += step_p;
+      if (sp >= S) { sp -= S; pt++; }
+    }
+  }
+  // tool-frame poses (reference :270-301), quaternion written wxyz
+  for (int e = tid; e < npts * T; e += blockDim.x) {
+    const int pt = e / T, t = e - pt * T;
+    const float *Cm = cumul + ((size_t)pt * L + a.tool_frame_map[t]) * 12;
+    const float4 qx = quat_from_transform(Cm);
+    reinterpret_cast<float4 *>(a.link_quat)[(size_t)pt0 * T + e] = make_float4(qx.w, qx.x, qx.y, qx.z);
+    float *p = a.link_pos + ((size_t)pt0 * T + e) * 3;
+    p[0] = Cm[3]; p[1] = Cm[7]; p[2] = Cm[11];
   }
 }
 
@@ -390,10 +575,24 @@ static int fk_forward_dispatch(const FkArgs &a, bool spheres, bool jac, bool com
   CUROBO_REQUIRE(a.n_points >= 0 && a.horizon >= 1, "%s: bad batch_size/horizon", what);
   CUROBO_REQUIRE(a.njoints >= 1, "%s: n_joints must be >= 1", what);
   if (a.n_points == 0) return CUROBO_HIP_OK;
+  static const bool grouped_only = getenv("CUROBO_HIP_FK_GROUPED") != nullptr;
+  const size_t lds_pts = (size_t)kFkPts * a.nlinks * (12 * sizeof(float) + sizeof(float2)) +
+                         (size_t)a.nlinks * (8 * sizeof(float4) + sizeof(int4) + sizeof(float2) + sizeof(int)) + 16 +
+                         (size_t)kFkPts * a.njoints * sizeof(float) +
+                         (spheres ? (size_t)(a.nspheres + 4) * (sizeof(float4) + sizeof(int)) : 0);
+  if (!jac && !com && !grouped_only && lds_pts <= 80 * 1024 && a.nlinks <= kWave) {  // (two workgroups per CU)
+    const int nblk = ceil_div(a.n_points, kFkPts);
+    if (spheres && write_cumul) hipLaunchKernelGGL((fk_forward_points_kernel<true, true>), dim3(nblk), dim3(256), lds_pts, st, a);
+    else if (spheres) hipLaunchKernelGGL((fk_forward_points_kernel<true, false>), dim3(nblk), dim3(256), lds_pts, st, a);
+    else if (write_cumul) hipLaunchKernelGGL((fk_forward_points_kernel<false, true>), dim3(nblk), dim3(256), lds_pts, st, a);
+    else hipLaunchKernelGGL((fk_forward_points_kernel<false, false>), dim3(nblk), dim3(256), lds_pts, st, a);
+    return check_launch(what, st);
+  }
   const int pts = fk_points_per_block(a.nlinks);
   const int threads = pts * kFkLanes;
   const int blocks = ceil_div(a.n_points, pts);
-  const size_t lds = (size_t)pts * a.nlinks * 28 * sizeof(float) + (size_t)a.nlinks * sizeof(int);
+  const size_t lds = (size_t)pts * a.nlinks * kFkLinkStride * sizeof(float) + (size_t)a.nlinks * sizeof(int) +
+                     (spheres ? (size_t)a.nspheres * (sizeof(float4) + sizeof(int)) : 0);
   const int key = (spheres ? 1 : 0) | (jac ? 2 : 0) | (com ? 4 : 0);
   switch (key) {
     case 0: launch_fk<false, false, false>(a, write_cumul, blocks, threads, lds, st); break;

@@ -65,10 +65,12 @@ def test_fk_forward(robot, n, oracle, device):
     np.testing.assert_allclose(got["cumul"], ref["cumul_mat"], atol=ATOL, rtol=0)
     np.testing.assert_allclose(got["com"], ref["com"], atol=2e-5, rtol=1e-6)
     np.testing.assert_allclose(got["jac"], ref["jacobian"], atol=ATOL, rtol=0)
-    # non-jacobian variant must agree bit-for-bit with the jacobian variant
+    # the spheres-only entry point runs the one-lane-per-point kernel (a different order of the same products):
+    # held to the oracle like the Jacobian variant, and to the Jacobian variant within a few ulp
     got2 = _fk_gpu(kp, q, jac=False, com=False)
-    assert np.array_equal(got2["spheres"], got["spheres"])
-    assert np.array_equal(got2["link_quat"], got["link_quat"])
+    for k, rk in (("link_pos", "link_pos"), ("link_quat", "link_quat"), ("spheres", "robot_spheres"), ("cumul", "cumul_mat")):
+        np.testing.assert_allclose(got2[k], ref[rk], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got2["spheres"], got["spheres"], atol=2e-6, rtol=0)
 
 
 def test_fk_known_answer(device):
