@@ -489,7 +489,7 @@ def c2_roofline(args, opt, rollout, cfg, kin, seed_t, seeds, shards, nls, step_s
         "fk_forward_spheres": (lambda: rollout.compute_kinematics(rollout.position), N * (4 * D + 28 * T + 16 * S + 48 * L)),
         "self_collision": (lambda: rollout_self(rollout), N * (16 * S + 4)),
         "scene_collision_swept": (lambda: rollout_scene(rollout), N * (36 * S)),
-        "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 16 * S + 28 * T + 4 * D)),
+        "fk_backward": (lambda: rollout_bwd_fk(rollout), N * (48 * L + 2 * 16 * S + 28 * T + 4 * D)),  # two gradient streams in (self, scene)
     }
     fused = cfg.use_fused and rollout.fused_available()
     if fused:  # one launch does the work of the five kernels above + cost sum + B-spline VJP

@@ -127,6 +127,33 @@ __device__ __forceinline__ void store_float4_streaming(float4 *p, float4 v) {
 #endif
 }
 
+// Flat float4 copy global -> LDS by the whole workgroup with U loads per lane in flight at once (a plain
+// `for (i = tid; i < n; i += nt) dst[i] = src[i]` with a run-time trip count is one global round trip PER
+// ITERATION: the loop is not unrolled, the store of an iteration waits for its load).  Optional second source
+// whose xyz are added (two gradient streams into one).
+template <int U>
+__device__ __forceinline__ void stage_float4(float4 *dst, const float4 *__restrict__ src, const float4 *__restrict__ src_b,
+                                             int n, int tid, int nt) {
+  if (n <= 0) return;
+  for (int base = 0; base < n; base += U * nt) {
+    // lanes past the end re-copy element n-1 (same value to the same word): no predicate anywhere, so the
+    // compiler has nothing to hang a branch + wait per load on
+    float4 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = min(base + u * nt + tid, n - 1);
+      v[u] = src[i];
+      if (src_b) w[u] = src_b[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = min(base + u * nt + tid, n - 1);
+      if (src_b) { v[u].x += w[u].x; v[u].y += w[u].y; v[u].z += w[u].z; }
+      dst[i] = v[u];
+    }
+  }
+}
+
 // 3x4 row-major rigid transform applied to a point (reference kinematics_util.cuh:38-50)
 __device__ __forceinline__ float4 transform_sphere(const float *C, float4 s) {
   float4 o;

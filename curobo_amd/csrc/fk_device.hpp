@@ -203,4 +203,26 @@ __device__ __forceinline__ void chain_point_vjp(float *__restrict__ psum, const 
   }
 }
 
+// the same for a WRENCH on link `l`: force F and torque T about the world origin (the sum of g and of p x g over
+// points p rigidly attached to the link).  sum_p <sign g, axis x (p - o)> = sign <axis, T - o x F>: one walk per
+// link instead of one per point.
+__device__ __forceinline__ void chain_wrench_vjp(float *__restrict__ psum, const float *__restrict__ cumul,
+                                                 const BwdTables &t, int l, f3 F, f3 T) {
+  const int cs = t.chain_off[l];
+  for (int ci = t.chain_off[l + 1] - 1; ci >= cs; ci--) {
+    const int j = t.chain[ci];
+    const int info = t.link_info[j];
+    const int jt = (info & 0xff) - 1;
+    if (jt < J_X_PRISM) continue;
+    const float sign = t.sign[j];
+    const float *C = cumul + j * 12;
+    const int ax = jt >= J_X_ROT ? jt - J_X_ROT : jt;
+    const f3 axis = make_f3(C[ax], C[4 + ax], C[8 + ax]);
+    float r;
+    if (jt >= J_X_ROT) r = sign * dot(axis, T - cross(make_f3(C[3], C[7], C[11]), F));
+    else r = sign * dot(axis, F);
+    atomicAdd(&psum[info >> 8], r);
+  }
+}
+
 }  // namespace curobo_hip

@@ -380,6 +380,7 @@ struct FkBwdArgs {
   const float *joint_offset;
   const int32_t *env_query_idx;
   int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames, dpad, chain_len;
+  int stage_spheres;  // LDS was sized for the per-link form of the sphere pass
 };
 
 template <bool COM>
@@ -393,22 +394,98 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   int *s_link_info = s_chain_off + (L + 1);                                        // [L]
   float *s_sign = reinterpret_cast<float *>(s_link_info + L);                      // [L]
   int *s_chain = reinterpret_cast<int *>(s_sign + L);                              // [C]
+  // per-link form of the sphere pass (see below)
+  const int S = a.nspheres;
+  int *s_start = s_chain + a.chain_len;                                            // [L+1] first sphere of link l
+  int *s_units = s_start + (L + 1);                                                // [kFkLanes + L] work units
+  int *s_meta = s_units + (kFkLanes + L);                                          // [0] #units  [1] unsorted flag
+  float4 *s_rs = reinterpret_cast<float4 *>(smem + (((s_meta + 2) - reinterpret_cast<int *>(smem) + 3) & ~3));  // [S]
+  float4 *s_g = s_rs + S;                                                          // [pts][S] sphere gradients
+  int *s_sph_link = reinterpret_cast<int *>(s_g + (size_t)pts * S);                // [S]
   const int tid = threadIdx.x;
   const int pt0 = blockIdx.x * pts;
   const int npts = min(pts, a.n_points - pt0);
+  const bool staged = a.stage_spheres && S > 0;
 
-  {  // saved cumulative transforms -> LDS, contiguous float4 stream
-    const float4 *src = reinterpret_cast<const float4 *>(a.cumul_in + (size_t)pt0 * L * 12);
-    float4 *dst = reinterpret_cast<float4 *>(cumul);
-    for (int i = tid; i < npts * L * 3; i += blockDim.x) dst[i] = src[i];
+  // ---- everything the block reads, requested in ONE burst: first the first round of every small table into
+  // registers (clamped indices, so that no load hangs on a predicate), then the two big contiguous streams --
+  // the saved cumulative transforms and (per-link form) the block's sphere gradients, both gradient streams
+  // summed; the LDS stores follow.  Written as independent loops each table costs a dependent round trip.
+  const int nt = blockDim.x;
+  const int iL = min(tid, L - 1), iL1 = min(tid, L), iC = min(tid, a.chain_len - 1), iS = min(tid, S > 0 ? S - 1 : 0);
+  const int r_off = a.link_chain_offsets[iL1];
+  const int r_jt = a.joint_map_type[iL], r_jm = a.joint_map[iL];
+  const float r_sign = a.joint_offset[2 * iL];
+  const int r_chain = a.link_chain_data[iC];
+  int r_lsm = 0;
+  float4 r_rs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (staged) {
+    r_lsm = a.link_sphere_map[iS];
+    if (a.num_envs <= 1) r_rs = reinterpret_cast<const float4 *>(a.robot_spheres)[iS];
   }
-  for (int i = tid; i < pts * kFkLanes * a.dpad; i += blockDim.x) psum_all[i] = 0.0f;
-  for (int l = tid; l <= L; l += blockDim.x) s_chain_off[l] = a.link_chain_offsets[l];
-  for (int l = tid; l < L; l += blockDim.x) {
+  stage_float4<4>(reinterpret_cast<float4 *>(cumul), reinterpret_cast<const float4 *>(a.cumul_in + (size_t)pt0 * L * 12),
+                  nullptr, npts * L * 3, tid, nt);
+  if (staged)
+    stage_float4<6>(s_g, reinterpret_cast<const float4 *>(a.grad_spheres) + (size_t)pt0 * S,
+                    a.grad_spheres_b ? reinterpret_cast<const float4 *>(a.grad_spheres_b) + (size_t)pt0 * S : nullptr,
+                    npts * S, tid, nt);
+  s_chain_off[iL1] = r_off;
+  s_link_info[iL] = (r_jt + 1) | ((r_jm < 0 ? 0 : r_jm) << 8);
+  s_sign[iL] = r_sign;
+  s_chain[iC] = r_chain;
+  if (staged) {
+    s_sph_link[iS] = r_lsm;
+    if (a.num_envs <= 1) s_rs[iS] = r_rs;
+    if (tid == 0) s_meta[1] = 0;
+  }
+  // (tables longer than the workgroup: the remaining rounds)
+  for (int l = tid + nt; l <= L; l += nt) s_chain_off[l] = a.link_chain_offsets[l];
+  for (int l = tid + nt; l < L; l += nt) {
     s_link_info[l] = ((int)a.joint_map_type[l] + 1) | ((int)(a.joint_map[l] < 0 ? 0 : a.joint_map[l]) << 8);
     s_sign[l] = a.joint_offset[2 * l];
   }
-  for (int c = tid; c < a.chain_len; c += blockDim.x) s_chain[c] = a.link_chain_data[c];
+  for (int c = tid + nt; c < a.chain_len; c += nt) s_chain[c] = a.link_chain_data[c];
+  if (staged)
+    for (int sp = tid + nt; sp < S; sp += nt) {
+      s_sph_link[sp] = a.link_sphere_map[sp];
+      if (a.num_envs <= 1) s_rs[sp] = reinterpret_cast<const float4 *>(a.robot_spheres)[sp];
+    }
+  for (int i = tid; i < pts * kFkLanes * a.dpad; i += nt) psum_all[i] = 0.0f;
+  __syncthreads();
+  // ---- work units of the per-link sphere pass.  With the spheres grouped by link (the order every robot file
+  // lists them in) link l owns the run [start[l], start[l+1]); a run is cut into units of at most `cs` spheres so
+  // that a point's 16 lanes get about one unit each whatever the distribution over the links (franka: 18 of 65 on
+  // the hand).  A table that is not grouped by link takes the per-sphere form.
+  if (staged) {
+    for (int s = tid; s < S; s += blockDim.x) {
+      const int lk = s_sph_link[s], prev = s > 0 ? s_sph_link[s - 1] : -1;
+      if (lk < prev) s_meta[1] = 1;
+      for (int l = prev + 1; l <= lk; l++) s_start[l] = s;
+      if (s == S - 1)
+        for (int l = lk + 1; l <= L; l++) s_start[l] = S;
+    }
+  }
+  __syncthreads();
+  const bool per_link = staged && s_meta[1] == 0;
+  if (per_link && tid < kWave) {
+    const int cs = (S + 11) / 12;
+    int carry = 0;
+    for (int l0 = 0; l0 < L; l0 += kWave) {  // (one pass unless the robot has more than 64 links)
+      const int l = l0 + tid;
+      const int b = l < L ? s_start[l] : 0, e = l < L ? s_start[l + 1] : 0;
+      const int nu = (e - b + cs - 1) / cs;
+      int incl = nu;  // inclusive scan over the wavefront
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if (tid >= off) incl += up;
+      }
+      const int at = carry + incl - nu;
+      for (int k = 0; k < nu; k++) s_units[at + k] = l | ((b + k * cs) << 8) | (min(b + (k + 1) * cs, e) << 20);
+      carry += __shfl(incl, kWave - 1, kWave);
+    }
+    if (tid == 0) s_meta[0] = carry;
+  }
   __syncthreads();
   const BwdTables tb{s_chain, s_chain_off, s_link_info, s_sign};
 
@@ -419,7 +496,31 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   float *psum = psum_all + ((size_t)grp * kFkLanes + lane) * a.dpad;
 
   // ---- spheres (sparsity skip on zero gradient, reference :48-52)
-  if (a.nspheres > 0) {
+  if (per_link) {
+    // The reference pushes every sphere's gradient down the chain of its link (kinematics_backward_helper.cuh:
+    // 62-98): S walks of ~depth joints per point.  The sum factors through the link: a lane adds up force and
+    // torque of its unit's spheres (registers, no atomics) and walks the chain ONCE with the wrench.
+    const int env = (a.num_envs > 1) ? a.env_query_idx[n / a.horizon] : 0;
+    const float4 *rs_env = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * S;
+    const float4 *g_pt = s_g + (size_t)grp * S;
+    const int U = s_meta[0];
+    for (int u = lane; u < U; u += kFkLanes) {
+      const int unit = s_units[u];
+      const int l = unit & 0xff, sb = (unit >> 8) & 0xfff, se = (unit >> 20) & 0xfff;
+      const float *C = my_cumul + l * 12;
+      f3 F = make_f3(0.f, 0.f, 0.f), T = make_f3(0.f, 0.f, 0.f);
+      for (int sp = sb; sp < se; sp++) {
+        const float4 g4 = g_pt[sp];
+        if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f) continue;
+        const float4 pw = transform_sphere(C, a.num_envs > 1 ? rs_env[sp] : s_rs[sp]);
+        const f3 g = make_f3(g4.x, g4.y, g4.z);
+        F = F + g;
+        T = T + cross(make_f3(pw.x, pw.y, pw.z), g);
+      }
+      if (F.x != 0.0f || F.y != 0.0f || F.z != 0.0f || T.x != 0.0f || T.y != 0.0f || T.z != 0.0f)
+        chain_wrench_vjp(psum, my_cumul, tb, l, F, T);
+    }
+  } else if (a.nspheres > 0) {
     const int env = (a.num_envs > 1) ? a.env_query_idx[n / a.horizon] : 0;
     const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)env * a.nspheres;
     const float4 *ga = reinterpret_cast<const float4 *>(a.grad_spheres) + (size_t)n * a.nspheres;
@@ -709,7 +810,9 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
   a.num_envs = num_envs; a.nlinks = num_links; a.njoints = n_joints; a.n_tool_frames = n_tool_frames;
   a.dpad = n_joints | 1;  // odd row stride: conflict-free column reads
   a.chain_len = link_chain_len;
-  int pts = fk_points_per_block(num_links);
+  // 8 points per workgroup where 16 would fit: twice the workgroups, whose load and arithmetic phases then overlap
+  // a little more (24.6 -> 23.5 us at 32 k points)
+  int pts = max(4, fk_points_per_block(num_links) / 2);
   size_t lds = 0;
   for (;;) {
     lds = ((size_t)pts * num_links * 12 + (size_t)pts * kFkLanes * a.dpad + 3 * (size_t)num_links + 1 +
@@ -717,6 +820,15 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
     if (lds <= 60 * 1024 || pts == 4) break;
     pts /= 2;
   }
+  {  // + the tables and the gradient slab of the per-link sphere pass, when they leave >= 3 workgroups per CU
+    const size_t S = (size_t)a.nspheres;
+    const size_t extra = ((size_t)2 * num_links + kFkLanes + 8) * sizeof(int) + (S + 4) * (sizeof(int) + sizeof(float4)) +
+                         (size_t)pts * S * sizeof(float4) + 16;
+    a.stage_spheres = S > 0 && S < 4096 && num_links < 256 && lds + extra <= 48 * 1024;
+    if (a.stage_spheres) lds += extra;
+  }
+  static const bool per_sphere_only = getenv("CUROBO_HIP_FK_BWD_PER_SPHERE") != nullptr;
+  if (per_sphere_only) a.stage_spheres = 0;
   CUROBO_REQUIRE(lds <= 64 * 1024, "%s: robot too large for the LDS tiling (%zu bytes)", what, lds);
   const int threads = pts * kFkLanes;
   const int blocks = ceil_div(batch_size, threads / kFkLanes);
