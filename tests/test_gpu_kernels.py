@@ -118,6 +118,63 @@ def test_fk_backward(robot, oracle, device):
     np.testing.assert_allclose(got, ref, atol=1e-5 * max(scale, 1.0), rtol=1e-4)
 
 
+@pytest.mark.parametrize("robot", ["franka", "unitree_g1"])
+def test_fk_sphere_sets_per_environment(robot, oracle, device):
+    """two sets of robot spheres selected per batch row through env_query_idx (reference
+    kinematics_forward_helper.cuh:218-254 / kinematics_backward_kernel.cuh:48-52: attached objects differ per
+    environment): forward spheres (both entry points) and the sphere VJP against the oracle run once per set"""
+    import dataclasses
+
+    from curobo_amd.backends import kinematics as K
+
+    model = load_model(robot)
+    kp = _kp(model, device)
+    rng = np.random.default_rng(11)
+    S, d = model.num_spheres, model.num_dof
+    base = np.asarray(model.as_dict()["link_spheres"], np.float32).reshape(-1, S, 4)[0]
+    sph2 = np.array(base, copy=True)
+    sph2[:, :3] += rng.normal(scale=0.02, size=(S, 3)).astype(np.float32)
+    sph2[:, 3] = np.abs(sph2[:, 3]) * 1.5
+    both = np.stack([base, sph2])
+    kp2 = dataclasses.replace(kp, link_spheres=torch.as_tensor(both, device=device))
+    batch, horizon = 70, 3  # 210 points: not a multiple of the 64-point workgroup, rows of both sets in one workgroup
+    n = batch * horizon
+    q = sample_q(model, n, seed=5)
+    env = (np.arange(batch) % 2).astype(np.int32)
+    refs = []
+    for e in range(2):
+        md = dict(model.as_dict())
+        md["link_spheres"] = both[e:e + 1]
+        refs.append(oracle.kinematics_forward(q, md))
+    row_env = np.repeat(env, horizon)
+    want = np.where(row_env[:, None, None] == 0, refs[0]["robot_spheres"], refs[1]["robot_spheres"])
+    for jac in (False, True):
+        got = _fk_gpu(kp2, q, horizon=horizon, jac=jac, com=False, env_query_idx=env)
+        np.testing.assert_allclose(got["spheres"], want, atol=ATOL, rtol=0)
+    # VJP: the sphere centres in world frame depend on the set
+    g_s = rng.normal(size=(n, S, 4)).astype(np.float32)
+    g_s[rng.uniform(size=(n, S)) < 0.5] = 0.0
+    T = len(model.tool_frames)
+    zp, zq, zc = np.zeros((n, T, 3), np.float32), np.zeros((n, T, 4), np.float32), np.zeros((n, 4), np.float32)
+    ref_g = []
+    for e in range(2):
+        md = dict(model.as_dict())
+        md["link_spheres"] = both[e:e + 1]
+        ref_g.append(oracle.kinematics_backward(md, refs[e]["cumul_mat"], g_s, zp, zq))
+    want_g = np.where(row_env[:, None] == 0, ref_g[0], ref_g[1])
+    out = torch.zeros(n, d, device=device)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    K.launch_kinematics_backward(
+        out, t(zp), t(zq), t(g_s), t(zc), t(zc), t(zp), t(refs[0]["cumul_mat"]), kp2.link_spheres,
+        kp2.link_masses_com, kp2.link_map, kp2.joint_map, kp2.joint_map_type, kp2.tool_frame_map,
+        kp2.link_sphere_idx_map, kp2.link_chain_data, kp2.link_chain_offsets, kp2.joint_links_data,
+        kp2.joint_links_offsets, kp2.joint_affects_endeffector, kp2.joint_offset_map, t(env), 2, n, horizon,
+        d, S, False, False)
+    torch.cuda.synchronize()
+    scale = max(np.abs(want_g).max(), 1.0)
+    np.testing.assert_allclose(out.cpu().numpy(), want_g, atol=1e-5 * scale, rtol=1e-4)
+
+
 @pytest.mark.parametrize("robot,n", [("franka", 515), ("ur10e", 64), ("unitree_g1", 33)])
 def test_self_collision(robot, n, oracle, device):
     from curobo_amd.backends import geometry as G
