@@ -118,8 +118,10 @@ def run_reference_tests(report):
 
 def compare_wrappers(report):
     """the reference's autograd wrappers vs curobo_amd.hip_ops on identical inputs, bit for bit"""
-    sys.path.insert(0, STAGE)
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, STAGE)  # the staged reference package must win over this repository's `curobo/` shim package
+    for name in [m for m in sys.modules if m == "curobo" or m.startswith("curobo.")]:
+        del sys.modules[name]
     import numpy as np
     import torch
 
