@@ -120,6 +120,81 @@ __device__ __forceinline__ void fk_chain_16_inplace(float *buf, const int *__res
   }
 }
 
+// what column c of the local transform of a joint of type jt is made of (fk_chain_quad): bit 0: alpha = cos (else
+// 1); bit 1: beta != 0; bit 2: beta negative; bits 3..4: c'
+__device__ __forceinline__ int local_column_code(int jt, int c) {
+  switch (jt) {
+    case J_X_PRISM: return c == 3 ? (2 | (0 << 3)) : 0;
+    case J_Y_PRISM: return c == 3 ? (2 | (1 << 3)) : 0;
+    case J_Z_PRISM: return c == 3 ? (2 | (2 << 3)) : 0;
+    case J_X_ROT: return c == 1 ? (1 | 2 | (2 << 3)) : (c == 2 ? (1 | 2 | 4 | (1 << 3)) : 0);
+    case J_Y_ROT: return c == 0 ? (1 | 2 | 4 | (2 << 3)) : (c == 2 ? (1 | 2 | (0 << 3)) : 0);
+    case J_Z_ROT: return c == 0 ? (1 | 2 | (1 << 3)) : (c == 1 ? (1 | 2 | 4 | (0 << 3)) : 0);
+    default: return 0;
+  }
+}
+
+// Serial chain of ONE point on ONE QUAD: lane c owns column c of the cumulative 3x4 (three registers).  A joint's
+// local transform is F with two columns mixed (rotation about a coordinate axis) or one column added to the last
+// (translation), i.e. column c of it is alpha * F[:,c] + beta * F[:,c'] with (alpha, beta, c') a function of
+// (joint type, c): col_tab[(l * 4 + c) * 2] = (F[:,c], code as bits), [.. + 1] = (F[:,c'], -).  Column c of
+// parent * local is three FMAs per row whose parent operands come from the quad through DPP: ~30 instructions
+// per link.  `cumul_pt` = the point's [L][12] row-major output, (sin, cos) of link l at sc[l * sc_stride]
+// (may alias cumul_pt[l * 12]: read one link ahead of the write), parent of link l at parent[l * pstride].
+template <int UNROLL = 4>
+__device__ __forceinline__ void fk_chain_quad(float *cumul_pt, const float4 *__restrict__ col_tab, const int *__restrict__ parent,
+                                              int pstride, int L, int c, const float *sc, int sc_stride) {
+  float *mine = cumul_pt + c;
+  float P0 = col_tab[c * 2].x, P1 = col_tab[c * 2].y, P2 = col_tab[c * 2].z;  // base link: reference :467-485
+  const float last = c == 3 ? 1.0f : 0.0f;
+  mine[0] = P0; mine[4] = P1; mine[8] = P2;
+  // UNROLL links per round: their operands (two table rows, sin / cos, parent) are requested together, so a round
+  // costs ONE LDS round trip plus its arithmetic.  Link by link every step is a dependent round trip -- cheap on an
+  // idle CU, several hundred cycles when a co-resident workgroup is hammering the LDS.
+  for (int l0 = 1; l0 < L; l0 += UNROLL) {
+    float4 A[UNROLL], B[UNROLL];
+    float2 sc_l[UNROLL];
+    int par[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int l = l0 + u < L ? l0 + u : L - 1;
+      A[u] = col_tab[(l * 4 + c) * 2]; B[u] = col_tab[(l * 4 + c) * 2 + 1];
+      sc_l[u] = *reinterpret_cast<const float2 *>(sc + l * sc_stride);
+      par[u] = parent[l * pstride];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int l = l0 + u;
+      if (l < L) {
+        const int code = __builtin_bit_cast(int, A[u].w);
+        const float alpha = (code & 1) ? sc_l[u].y : 1.0f;
+        const float beta = (code & 2) ? ((code & 4) ? -sc_l[u].x : sc_l[u].x) : 0.0f;
+        const float M0 = A[u].x * alpha + beta * B[u].x, M1 = A[u].y * alpha + beta * B[u].y, M2 = A[u].z * alpha + beta * B[u].z;
+        const int pl = __builtin_amdgcn_readfirstlane(par[u]);
+        if (pl != l - 1) {  // a branch of the tree: the quad's own earlier result (LDS operations stay in order)
+          P0 = mine[pl * 12]; P1 = mine[pl * 12 + 4]; P2 = mine[pl * 12 + 8];
+        }
+        const float C0 = quad_bcast<0>(P0) * M0 + quad_bcast<1>(P0) * M1 + quad_bcast<2>(P0) * M2 + last * quad_bcast<3>(P0);
+        const float C1 = quad_bcast<0>(P1) * M0 + quad_bcast<1>(P1) * M1 + quad_bcast<2>(P1) * M2 + last * quad_bcast<3>(P1);
+        const float C2 = quad_bcast<0>(P2) * M0 + quad_bcast<1>(P2) * M1 + quad_bcast<2>(P2) * M2 + last * quad_bcast<3>(P2);
+        mine[l * 12] = C0; mine[l * 12 + 4] = C1; mine[l * 12 + 8] = C2;
+        P0 = C0; P1 = C1; P2 = C2;
+      }
+    }
+  }
+}
+
+// the column table of fk_chain_quad from the global robot tables: entry i = (link i / 4, column i % 4)
+__device__ __forceinline__ void fk_column_table_entry(float4 *col_tab, int i, const int8_t *joint_map_type,
+                                                      const float *fixed_transform) {
+  const int l = i >> 2, c = i & 3;
+  const int code = local_column_code(joint_map_type[l], c);
+  const float *F = fixed_transform + l * 12;
+  const int c2 = code >> 3;
+  col_tab[i * 2] = make_float4(F[c], F[4 + c], F[8 + c], __builtin_bit_cast(float, code));
+  col_tab[i * 2 + 1] = make_float4(F[c2], F[4 + c2], F[8 + c2], 0.0f);
+}
+
 // The same chain for N independent points in one instruction stream, software-pipelined: the walk
 // is a string of dependent steps, so everything that does not depend on the previous link (the
 // local transforms and parent indices of the next UNROLL links) is fetched up front and the

@@ -210,20 +210,6 @@ __global__ void __launch_bounds__(256) fk_forward_kernel(const FkArgs a) {
 // (only the links that have a joint), and every global read of the block happens in one round trip up front.
 constexpr int kFkPts = 64;  // points per workgroup (4 lanes each)
 
-// what column c of the local transform of a joint of type jt is made of (see above): bit 0: alpha = cos (else
-// 1); bit 1: beta != 0; bit 2: beta negative; bits 3..4: c'
-__device__ __forceinline__ int local_column_code(int jt, int c) {
-  switch (jt) {
-    case J_X_PRISM: return c == 3 ? (2 | (0 << 3)) : 0;
-    case J_Y_PRISM: return c == 3 ? (2 | (1 << 3)) : 0;
-    case J_Z_PRISM: return c == 3 ? (2 | (2 << 3)) : 0;
-    case J_X_ROT: return c == 1 ? (1 | 2 | (2 << 3)) : (c == 2 ? (1 | 2 | 4 | (1 << 3)) : 0);
-    case J_Y_ROT: return c == 0 ? (1 | 2 | 4 | (2 << 3)) : (c == 2 ? (1 | 2 | (0 << 3)) : 0);
-    case J_Z_ROT: return c == 0 ? (1 | 2 | (1 << 3)) : (c == 1 ? (1 | 2 | 4 | (0 << 3)) : 0);
-    default: return 0;
-  }
-}
-
 template <bool SPHERES, bool WRITE_CUMUL>
 __global__ void __launch_bounds__(256) fk_forward_points_kernel(const FkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -245,11 +231,7 @@ __global__ void __launch_bounds__(256) fk_forward_points_kernel(const FkArgs a) 
   for (int i = tid; i < npts * D; i += blockDim.x) s_q[i] = a.q[(size_t)pt0 * D + i];
   for (int i = tid; i < L * 4; i += blockDim.x) {
     const int l = i >> 2, c = i & 3;
-    const int code = local_column_code(a.joint_map_type[l], c);
-    const float *F = a.fixed_transform + l * 12;
-    const int c2 = code >> 3;
-    s_col[i * 2] = make_float4(F[c], F[4 + c], F[8 + c], __builtin_bit_cast(float, code));
-    s_col[i * 2 + 1] = make_float4(F[c2], F[4 + c2], F[8 + c2], 0.0f);
+    fk_column_table_entry(s_col, i, a.joint_map_type, a.fixed_transform);
     if (c == 0) {
       s_link[l] = make_int4(a.joint_map_type[l], a.link_map[l], a.joint_map[l], 0);
       s_off[l] = make_float2(a.joint_offset[2 * l], a.joint_offset[2 * l + 1]);
@@ -286,35 +268,8 @@ __global__ void __launch_bounds__(256) fk_forward_points_kernel(const FkArgs a) 
   {
     const int c = tid & 3;
     const int me = (tid >> 2) < npts ? (tid >> 2) : 0;  // (idle quads shadow point 0: identical stores)
-    float *mine = cumul + (size_t)me * L * 12 + c;
-    float P0 = s_col[c * 2].x, P1 = s_col[c * 2].y, P2 = s_col[c * 2].z;  // base link: reference :467-485
-    mine[0] = P0; mine[4] = P1; mine[8] = P2;
-    const float last = c == 3 ? 1.0f : 0.0f;
-    const int l1 = L > 1 ? 1 : 0;
-    float4 An = s_col[(l1 * 4 + c) * 2], Bn = s_col[(l1 * 4 + c) * 2 + 1];
-    float2 sc_n = s_sc[me * L + l1];
-    int par_n = s_link[l1].y;
-    for (int l = 1; l < L; l++) {
-      const float4 A = An, B = Bn;
-      const float sn = sc_n.x, cs = sc_n.y;
-      const int par = __builtin_amdgcn_readfirstlane(par_n);
-      const int ln = l + 1 < L ? l + 1 : l;  // the next link's operands are requested before this link's arithmetic
-      An = s_col[(ln * 4 + c) * 2]; Bn = s_col[(ln * 4 + c) * 2 + 1];
-      sc_n = s_sc[me * L + ln];
-      par_n = s_link[ln].y;
-      const int code = __builtin_bit_cast(int, A.w);
-      const float alpha = (code & 1) ? cs : 1.0f;
-      const float beta = (code & 2) ? ((code & 4) ? -sn : sn) : 0.0f;
-      const float M0 = A.x * alpha + beta * B.x, M1 = A.y * alpha + beta * B.y, M2 = A.z * alpha + beta * B.z;
-      if (par != l - 1) {  // a branch of the tree: the quad's own earlier result (LDS operations stay in order)
-        P0 = mine[par * 12]; P1 = mine[par * 12 + 4]; P2 = mine[par * 12 + 8];
-      }
-      const float C0 = quad_bcast<0>(P0) * M0 + quad_bcast<1>(P0) * M1 + quad_bcast<2>(P0) * M2 + last * quad_bcast<3>(P0);
-      const float C1 = quad_bcast<0>(P1) * M0 + quad_bcast<1>(P1) * M1 + quad_bcast<2>(P1) * M2 + last * quad_bcast<3>(P1);
-      const float C2 = quad_bcast<0>(P2) * M0 + quad_bcast<1>(P2) * M1 + quad_bcast<2>(P2) * M2 + last * quad_bcast<3>(P2);
-      mine[l * 12] = C0; mine[l * 12 + 4] = C1; mine[l * 12 + 8] = C2;
-      P0 = C0; P1 = C1; P2 = C2;
-    }
+    fk_chain_quad(cumul + (size_t)me * L * 12, s_col, reinterpret_cast<const int *>(s_link) + 1, 4, L, c,
+                  reinterpret_cast<const float *>(s_sc + me * L), 2);
   }
   __syncthreads();
   // ---- phase 3: outputs, all lanes, every stream contiguous over the workgroup's points

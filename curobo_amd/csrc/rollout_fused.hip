@@ -763,6 +763,9 @@ __device__ __forceinline__ void fused_stage_tables(const FusedCtx &c, const Fuse
       }
     }
   }
+  // column table of the quad chain of P1 (fk_chain_quad), in the work area (dead until P1 writes the spheres)
+  for (int i = rotated_tid(nwaves > 2 ? 2 : 0); i < L * 4; i += nt)
+    fk_column_table_entry(reinterpret_cast<float4 *>(c.work), i, a.joint_map_type, a.fixed_transform);
   if (a.use_self) {  // (i, j) -> byte offsets of the float4 spheres; two loads in flight per thread
     const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pairs);
     for (int k = tid; k < P; k += 2 * nt) {
@@ -915,7 +918,6 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
   }
   __syncthreads();
-  fused_derive_tables(c);
   CUROBO_STAMP(1);
 
   const int grp = tid / kFkLanes, lane = tid % kFkLanes, ngroups = nt / kFkLanes;
@@ -925,44 +927,46 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   if (n_left * 4 > ngroups || H < ngroups) n_left = 0;
   const int H_main = H - n_left;
 
-  // ---------------- P1: FK per point.  Row g < n_left also walks the chain of leftover point g in
-  // the same instruction stream; that point's spheres are then shared by the lanes of its wave.
-  for (int h = grp; h < H_main; h += ngroups) {
-    const bool extra = n_left > 0 && h == grp && grp < n_left;
-    // uniform over the wave: a wave with a leftover row walks two chains in ALL its rows (the other rows
-    // repeat their own point: same values to the same slots) -- with a per-row branch the wave executed the
-    // two-chain stream for row 0 and then the one-chain stream for rows 1-3, back to back
-    const bool wave_extra = n_left > 0 && h < ngroups && (grp & ~3) < n_left;
-    const int hx = extra ? H_main + grp : h;
-    point_fk_locals(c, h, lane);
-    if (extra) point_fk_locals(c, hx, lane);
-    CUROBO_STAMP(8);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (wave_extra) {
-      float *const cm[2] = {c.cumul + (size_t)h * L * 12, c.cumul + (size_t)hx * L * 12};
-      const float *const lc[2] = {c.work + (size_t)h * c.ws, c.work + (size_t)hx * c.ws};
-      fk_chain_16_multi<2>(cm, lc, c.parent, c.fixed, L, lane);
-    } else {
-      float *const cm[1] = {c.cumul + (size_t)h * L * 12};
-      const float *const lc[1] = {c.work + (size_t)h * c.ws};
-      fk_chain_16_multi<1>(cm, lc, c.parent, c.fixed, L, lane);
+  // ---------------- P1: FK.  (1) sin / cos of every (point, jointed link) on all lanes, parked in the first
+  // two floats of that link's (not yet written) cumulative slot; (2) the chain of every point on ONE QUAD
+  // (fk_chain_quad: ~30 instructions per link on the critical path; 4 H lanes, the other wavefronts derive the
+  // transposed tables meanwhile); (3) the world spheres of every (point, sphere) on all lanes.  Every point is
+  // treated alike here; the row / leftover split only concerns the cost passes of P2.
+  for (int e = tid; e < H * L; e += nt) {
+    const int h = e / L, l = e - h * L;
+    const int info = c.link_info[l];
+    const int jt = (info & 0xff) - 1;
+    if (jt != J_FIXED) {
+      float sn, cs;
+      joint_sincos(jt, c.q[h * D + (info >> 8)], c.sign[l], c.off_add[l], &sn, &cs);
+      *reinterpret_cast<float2 *>(c.cumul + ((size_t)h * L + l) * 12) = make_float2(sn, cs);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    CUROBO_STAMP(9);
-    for (int s = lane; s < S; s += kFkLanes) point_sphere(c, a, b, h, s);
-    if (lane == 0) reinterpret_cast<float4 *>(c.work + (size_t)h * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
-    CUROBO_STAMP(10);
   }
-  if (n_left > 0 && (tid >> 6) * 4 < n_left) {  // leftover points whose chains this wave walked
-    const int lo = (tid >> 6) * 4, cnt = (n_left - lo < 4 ? n_left - lo : 4);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane64; e < cnt * S; e += 64) point_sphere(c, a, b, H_main + lo + e / S, e % S);
-    if (lane64 < cnt) reinterpret_cast<float4 *>(c.work + (size_t)(H_main + lo + lane64) * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
+  CUROBO_STAMP(8);
+  __syncthreads();
+  // the chains are the serial part the whole workgroup waits for, on wavefronts that share their SIMDs with the
+  // co-resident workgroup's cost passes: they run at raised issue priority
+  __builtin_amdgcn_s_setprio(3);
+  for (int pt = tid >> 2; pt < H; pt += nt >> 2) {
+    float *cm = c.cumul + (size_t)pt * L * 12;
+    fk_chain_quad(cm, reinterpret_cast<const float4 *>(c.work), c.parent, 1, L, tid & 3, cm, 12);
   }
-  CUROBO_STAMP(11);
+  __builtin_amdgcn_s_setprio(0);
+  fused_derive_tables(c);  // (on the last wavefronts: next to the chains, not after them)
+  CUROBO_STAMP(9);
+  __syncthreads();
+  {
+    const int step_h = nt / S, step_s = nt % S;
+    int h = tid / S, sp = tid - (tid / S) * S;
+    for (int e = tid; e < H * S; e += nt) {
+      point_sphere(c, a, b, h, sp);
+      sp += step_s; h += step_h;
+      if (sp >= S) { sp -= S; h++; }
+    }
+    for (int hh = tid; hh < H; hh += nt)
+      reinterpret_cast<float4 *>(c.work + (size_t)hh * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
+  }
+  CUROBO_STAMP(10);
   if (tid == 0) *c.key = 0ull;
   __syncthreads();
   CUROBO_STAMP(2);

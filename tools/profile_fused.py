@@ -66,8 +66,8 @@ def main():
     for i, n in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"  {n:18s} mean {d.mean():7.2f} us  median {np.median(d):7.2f}  max {d.max():7.2f}")
-    for lo, hi, n in ((1, 8, "  P1: locals (row 0)"), (8, 9, "  P1: chain x2"), (9, 10, "  P1: spheres"),
-                      (10, 11, "  P1: left spheres"), (11, 2, "  P1: barrier wait"),
+    for lo, hi, n in ((1, 8, "  P1: sin/cos     "), (8, 9, "  P1: barrier + quad chains"), (9, 10, "  P1: barrier + spheres"),
+                      (10, 2, "  P1: barrier wait"),
                       (2, 5, "  P2: self (pt b%H)"), (5, 6, "  P2: scene"), (2, 7, "  P2: rows (slowest)"), (7, 15, "  P2: leftover point"), (2, 12, "  P2: collision pass"),
                       (12, 13, "  P2: pose pass"), (13, 14, "  P2: c-space pass"), (14, 3, "  P2: gather pass")):
         d = t[:, hi] - t[:, lo]
