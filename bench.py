@@ -545,6 +545,12 @@ def c2_roofline(args, opt, rollout, cfg, kin, seed_t, seeds, shards, nls, step_s
         roof["valu_issue_note"] = (f"{sq['valu_wave_instructions_per_trajectory']} VALU wave-instructions per trajectory "
                                    f"(seed state, {sq['source']}, committed file) x {B} trajectories / live exclusive launch time, "
                                    f"against 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = {VALU_ISSUE_PEAK:.3g} wave-instructions/s")
+        if sq.get("active_inst_valu_quad_cycles_per_launch"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a VALU instruction of a wavefront is executing, summed over
+            # the wavefronts: x 4 cycles / (SIMDs x launch time x clock).  An upper bound on VALU occupancy: the counter
+            # cannot resolve less than one quad-cycle per instruction.
+            roof["valu_active_frac_upper_bound"] = round(
+                sq["active_inst_valu_quad_cycles_per_launch"] * 4.0 / (256 * 4 * excl["us"] * 1e-6 * 2.4e9), 4)
     roof["kernels_us"] = {k: v["us"] for k, v in timings.items()}
     roof["kernels_GBps"] = {k: v["GBps"] for k, v in timings.items()}
     roof["kernel_sequence_us"] = round(seq_us, 1)
@@ -562,6 +568,7 @@ def committed_sq_counters(kernel):
             continue
         if kernel in str(rec.get("kernel", "")) and "per_trajectory" in rec:
             best = {"valu_wave_instructions_per_trajectory": rec["per_trajectory"]["valu_wave_instructions"],
+                    "active_inst_valu_quad_cycles_per_launch": rec.get("SQ_ACTIVE_INST_VALU"),
                     "source": "profiles/" + os.path.basename(path)}
     return best
 
