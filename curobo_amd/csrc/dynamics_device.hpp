@@ -1,0 +1,286 @@
+// dynamics_device.hpp -- inverse dynamics (body-frame RNEA) and its VJP for ONE batch element per lane, shared by
+// dynamics.hip (global SoA cache) and the fused rollout kernel (the same code over LDS).
+// Reference: kernels/dynamics/rnea_forward_kernel.cuh:53-292, rnea_backward_kernel.cuh:65-468, spatial_algebra.cuh,
+// rnea_helpers.cuh.
+#pragma once
+#include "common.hpp"
+
+namespace curobo_hip {
+
+struct RneaArgs {
+  float *tau;                 // fwd out [B, D]
+  float *grad_q, *grad_qd, *grad_qdd, *grad_f_ext;  // bwd out
+  const float *grad_tau;      // bwd in
+  const float *q, *qd, *qdd;
+  const float *fixed_transforms, *link_masses_com, *link_inertias;
+  const int8_t *joint_map_type;
+  const int16_t *joint_map, *link_map;
+  const float *joint_offset_map, *gravity;
+  const int16_t *level_links;
+  float *cache;      // [L][20][B]
+  float *ws_fbar, *ws_abar, *ws_vbar;  // bwd adjoints, each [L][6][B] (three bases: the fused rollout kernel places them in
+                                       // different LDS regions)
+  const float *f_ext;
+  int batch, num_links, num_dof;
+};
+
+// per-link constants in LDS: 12 fixed transform + 4 mass/com + 6 inertia + multiplier, offset = 24 floats,
+// + (joint type, joint index, parent) as ints
+constexpr int kLinkFloats = 24;
+
+struct LinkConst {
+  const float *F, *mc, *in;
+  float mul, off;
+  int jt, ji, par;
+};
+
+__device__ __forceinline__ LinkConst link_const(const float *s_f, const int *s_i, int k) {
+  LinkConst c;
+  c.F = s_f + k * kLinkFloats;
+  c.mc = c.F + 12;
+  c.in = c.F + 16;
+  c.mul = c.F[22];
+  c.off = c.F[23];
+  c.jt = s_i[k * 3];
+  c.ji = s_i[k * 3 + 1];
+  c.par = s_i[k * 3 + 2];
+  return c;
+}
+
+__device__ __forceinline__ void stage_links(const RneaArgs &a, float *s_f, int *s_i) {
+  const int L = a.num_links;
+  for (int i = threadIdx.x; i < L * kLinkFloats; i += blockDim.x) {
+    const int k = i / kLinkFloats, c = i - k * kLinkFloats;
+    float v;
+    if (c < 12) v = a.fixed_transforms[k * 12 + c];
+    else if (c < 16) v = a.link_masses_com[k * 4 + (c - 12)];
+    else if (c < 22) v = a.link_inertias[k * 8 + (c - 16)];
+    else v = a.joint_offset_map[k * 2 + (c - 22)];
+    s_f[i] = v;
+  }
+  for (int k = threadIdx.x; k < L; k += blockDim.x) {
+    s_i[k * 3] = a.joint_map_type[k];
+    s_i[k * 3 + 1] = a.joint_map[k];
+    s_i[k * 3 + 2] = a.link_map[k];
+  }
+  for (int k = threadIdx.x; k < L; k += blockDim.x) s_i[L * 3 + k] = a.level_links[k];
+  __syncthreads();
+}
+
+struct Sv {  // spatial vector [angular; linear]
+  f3 w, v;
+};
+__device__ __forceinline__ Sv sv_zero() { return Sv{make_f3(0.f, 0.f, 0.f), make_f3(0.f, 0.f, 0.f)}; }
+__device__ __forceinline__ Sv operator+(Sv a, Sv b) { return Sv{a.w + b.w, a.v + b.v}; }
+__device__ __forceinline__ Sv operator-(Sv a, Sv b) { return Sv{a.w - b.w, a.v - b.v}; }
+__device__ __forceinline__ float sv_dot(Sv a, Sv b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+__device__ __forceinline__ float sv_get(const Sv &s, int i) {
+  return i == 0 ? s.w.x : i == 1 ? s.w.y : i == 2 ? s.w.z : i == 3 ? s.v.x : i == 4 ? s.v.y : s.v.z;
+}
+__device__ __forceinline__ void sv_add_at(Sv &s, int i, float x) {
+  s.w.x += i == 0 ? x : 0.f; s.w.y += i == 1 ? x : 0.f; s.w.z += i == 2 ? x : 0.f;
+  s.v.x += i == 3 ? x : 0.f; s.v.y += i == 4 ? x : 0.f; s.v.z += i == 5 ? x : 0.f;
+}
+__device__ __forceinline__ Sv sv_unit(int i, float x) {
+  Sv s = sv_zero();
+  sv_add_at(s, i, x);
+  return s;
+}
+
+struct Rp {  // local transform: R rotates child -> parent (row-major), p = child origin in the parent frame
+  float R[9];
+  f3 p;
+};
+// compute_local_Rp (rnea_helpers.cuh): R = R_fixed R_joint(q), p = p_fixed (+ R_fixed d for prismatic)
+__device__ __forceinline__ Rp local_Rp(const float *F, int jt, float q) {
+  Rp t;
+  t.R[0] = F[0]; t.R[1] = F[1]; t.R[2] = F[2];
+  t.R[3] = F[4]; t.R[4] = F[5]; t.R[5] = F[6];
+  t.R[6] = F[8]; t.R[7] = F[9]; t.R[8] = F[10];
+  t.p = make_f3(F[3], F[7], F[11]);
+  if (jt >= J_X_ROT) {
+    float s, c;
+    sincos_bounded(q, &s, &c);
+    const int ax = jt - J_X_ROT, a1 = ax == 2 ? 0 : ax + 1, a2 = ax == 0 ? 2 : ax - 1;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float u = a1 == 0 ? t.R[r * 3] : a1 == 1 ? t.R[r * 3 + 1] : t.R[r * 3 + 2];
+      const float w = a2 == 0 ? t.R[r * 3] : a2 == 1 ? t.R[r * 3 + 1] : t.R[r * 3 + 2];
+      const float n1 = c * u + s * w, n2 = -s * u + c * w;
+      if (a1 == 0) t.R[r * 3] = n1; else if (a1 == 1) t.R[r * 3 + 1] = n1; else t.R[r * 3 + 2] = n1;
+      if (a2 == 0) t.R[r * 3] = n2; else if (a2 == 1) t.R[r * 3 + 1] = n2; else t.R[r * 3 + 2] = n2;
+    }
+  } else if (jt >= J_X_PRISM) {
+    const int ax = jt - J_X_PRISM;
+    t.p.x += (ax == 0 ? F[0] : ax == 1 ? F[1] : F[2]) * q;
+    t.p.y += (ax == 0 ? F[4] : ax == 1 ? F[5] : F[6]) * q;
+    t.p.z += (ax == 0 ? F[8] : ax == 1 ? F[9] : F[10]) * q;
+  }
+  return t;
+}
+__device__ __forceinline__ f3 rot_T(const float *R, f3 v) {  // R^T v
+  return make_f3(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z,
+                 R[2] * v.x + R[5] * v.y + R[8] * v.z);
+}
+__device__ __forceinline__ f3 rot(const float *R, f3 v) {
+  return make_f3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z,
+                 R[6] * v.x + R[7] * v.y + R[8] * v.z);
+}
+// X m = [E w; E (v + w x p)], E = R^T          (spatial_Xv)
+__device__ __forceinline__ Sv X_motion(const Rp &t, Sv m) { return Sv{rot_T(t.R, m.w), rot_T(t.R, m.v + cross(m.w, t.p))}; }
+// X^T f = [R n + p x (R f); R f]               (spatial_XTf)
+__device__ __forceinline__ Sv XT_force(const Rp &t, Sv f) {
+  const f3 Rf = rot(t.R, f.v);
+  return Sv{rot(t.R, f.w) + cross(t.p, Rf), Rf};
+}
+// I m (spatial_inertia_times_vec): mc = [com, mass], in = [ixx iyy izz ixy ixz iyz] at the CoM
+__device__ __forceinline__ Sv inertia_mul(const float *mc, const float *in, Sv m) {
+  const f3 c = make_f3(mc[0], mc[1], mc[2]);
+  const float mass = mc[3];
+  const f3 h = m.v + cross(m.w, c);
+  const f3 ch = cross(c, h);
+  return Sv{make_f3(in[0] * m.w.x + in[3] * m.w.y + in[4] * m.w.z + mass * ch.x,
+                    in[3] * m.w.x + in[1] * m.w.y + in[5] * m.w.z + mass * ch.y,
+                    in[4] * m.w.x + in[5] * m.w.y + in[2] * m.w.z + mass * ch.z),
+            mass * h};
+}
+__device__ __forceinline__ Sv crf(Sv v, Sv f) { return Sv{cross(v.w, f.w) + cross(v.v, f.v), cross(v.w, f.v)}; }  // v x* f
+__device__ __forceinline__ Sv crm(Sv a, Sv b) { return Sv{cross(a.w, b.w), cross(a.v, b.w) + cross(a.w, b.v)}; }  // a x b
+__device__ __forceinline__ int s_index(int jt) { return jt >= J_X_ROT ? jt - J_X_ROT : 3 + jt - J_X_PRISM; }
+
+// SoA slots: slot(k, c)[b]
+__device__ __forceinline__ Sv load_sv(const float *base, size_t B, int slot, size_t b) {
+  const float *p = base + (size_t)slot * B + b;
+  return Sv{make_f3(p[0], p[B], p[2 * B]), make_f3(p[3 * B], p[4 * B], p[5 * B])};
+}
+__device__ __forceinline__ void store_sv(float *base, size_t B, int slot, size_t b, Sv s) {
+  float *p = base + (size_t)slot * B + b;
+  p[0] = s.w.x; p[B] = s.w.y; p[2 * B] = s.w.z; p[3 * B] = s.v.x; p[4 * B] = s.v.y; p[5 * B] = s.v.z;
+}
+
+// One element b of a batch of B (SoA slots with element stride B): the forward sweeps.  `order` = links in level order.
+template <bool HAS_FEXT>
+__device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
+                                                     size_t b, size_t B) {
+  const int L = a.num_links, D = a.num_dof;
+  const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
+  for (int j = 0; j < D; j++) a.tau[b * D + j] = 0.0f;
+  // sweep 1, root -> leaves: velocities and accelerations (rnea_forward_kernel.cuh:118-188)
+  for (int idx = 0; idx < L; idx++) {
+    const int k = order[idx];
+    const LinkConst c = link_const(s_f, s_i, k);
+    const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    float qe = 0.f, qde = 0.f, qdde = 0.f;
+    if (moving) {
+      qe = c.mul * a.q[b * D + c.ji] + c.off;
+      qde = c.mul * a.qd[b * D + c.ji];
+      qdde = c.mul * a.qdd[b * D + c.ji];
+    }
+    const Rp t = local_Rp(c.F, c.jt, qe);
+    Sv v = sv_zero(), acc;
+    if (is_root) {
+      acc = X_motion(t, grav);
+    } else {
+      v = X_motion(t, load_sv(a.cache, B, c.par * 20, b));
+      acc = X_motion(t, load_sv(a.cache, B, c.par * 20 + 6, b));
+    }
+    if (c.jt != J_FIXED) {
+      const int si = s_index(c.jt);
+      sv_add_at(v, si, qde);
+      sv_add_at(acc, si, qdde);
+      acc = acc + crm(v, sv_unit(si, qde));  // Coriolis
+    }
+    store_sv(a.cache, B, k * 20, b, v);
+    store_sv(a.cache, B, k * 20 + 6, b, acc);
+    store_sv(a.cache, B, k * 20 + 12, b, sv_zero());  // children accumulate their X^T f here
+  }
+  // sweep 2, leaves -> root: f = I a + v x* I v (- f_ext) + children; tau = S^T f (:190-283)
+  for (int idx = L - 1; idx >= 0; idx--) {
+    const int k = order[idx];
+    const LinkConst c = link_const(s_f, s_i, k);
+    const Sv v = load_sv(a.cache, B, k * 20, b), acc = load_sv(a.cache, B, k * 20 + 6, b);
+    Sv f = inertia_mul(c.mc, c.in, acc) + crf(v, inertia_mul(c.mc, c.in, v));
+    if (HAS_FEXT) {
+      const float *fe = a.f_ext + (b * L + k) * 6;
+      f = f - Sv{make_f3(fe[0], fe[1], fe[2]), make_f3(fe[3], fe[4], fe[5])};
+    }
+    f = f + load_sv(a.cache, B, k * 20 + 12, b);
+    store_sv(a.cache, B, k * 20 + 12, b, f);
+    const bool moving = c.jt != J_FIXED && c.ji >= 0;
+    if (moving) a.tau[b * D + c.ji] += c.mul * sv_get(f, s_index(c.jt));
+    if (!(c.par < 0 || c.par == k)) {
+      const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+      const Sv up = XT_force(local_Rp(c.F, c.jt, qe), f);
+      store_sv(a.cache, B, c.par * 20 + 12, b, load_sv(a.cache, B, c.par * 20 + 12, b) + up);
+    }
+  }
+}
+
+// ... and the VJP.  ACCUMULATE: add to grad_q / grad_qd / grad_qdd instead of overwriting them.
+template <bool HAS_FEXT, bool ACCUMULATE = false>
+__device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
+                                                      size_t b, size_t B) {
+  const int L = a.num_links, D = a.num_dof;
+  const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
+  if (!ACCUMULATE)
+    for (int j = 0; j < D; j++) { a.grad_q[b * D + j] = 0.0f; a.grad_qd[b * D + j] = 0.0f; a.grad_qdd[b * D + j] = 0.0f; }
+  // pass 1, root -> leaves: adjoint of the force propagation (rnea_backward_kernel.cuh:151-208)
+  for (int idx = 0; idx < L; idx++) {
+    const int k = order[idx];
+    const LinkConst c = link_const(s_f, s_i, k);
+    const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    Sv fb = sv_zero();
+    const int si = moving ? s_index(c.jt) : 0;
+    if (moving) sv_add_at(fb, si, c.mul * a.grad_tau[b * D + c.ji]);
+    if (!is_root) {
+      const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+      const Sv X = X_motion(local_Rp(c.F, c.jt, qe), load_sv(a.ws_fbar, B, c.par * 6, b));
+      fb = fb + X;
+      if (moving) a.grad_q[b * D + c.ji] += c.mul * sv_dot(X, crf(sv_unit(si, 1.0f), load_sv(a.cache, B, k * 20 + 12, b)));
+    }
+    store_sv(a.ws_fbar, B, k * 6, b, fb);
+    store_sv(a.ws_abar, B, k * 6, b, sv_zero());
+    store_sv(a.ws_vbar, B, k * 6, b, sv_zero());
+    if (HAS_FEXT) {
+      float *g = a.grad_f_ext + (b * L + k) * 6;
+      g[0] = -fb.w.x; g[1] = -fb.w.y; g[2] = -fb.w.z; g[3] = -fb.v.x; g[4] = -fb.v.y; g[5] = -fb.v.z;
+    }
+  }
+  // pass 2, leaves -> root: adjoint of the velocity / acceleration propagation (:236-465)
+  for (int idx = L - 1; idx >= 0; idx--) {
+    const int k = order[idx];
+    const LinkConst c = link_const(s_f, s_i, k);
+    const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    const Sv v = load_sv(a.cache, B, k * 20, b);
+    const Sv fb = load_sv(a.ws_fbar, B, k * 6, b);
+    Sv ab = load_sv(a.ws_abar, B, k * 6, b) + inertia_mul(c.mc, c.in, fb);
+    Sv vb = load_sv(a.ws_vbar, B, k * 6, b) - crf(fb, inertia_mul(c.mc, c.in, v)) - inertia_mul(c.mc, c.in, crm(v, fb));
+    const int si = moving ? s_index(c.jt) : 0;
+    float gq = 0.0f, gqd = 0.0f;
+    if (moving) {
+      const float qdk = c.mul * a.qd[b * D + c.ji];
+      a.grad_qdd[b * D + c.ji] += c.mul * sv_get(ab, si);
+      gqd -= c.mul * sv_get(crf(v, ab), si);
+      vb = vb + crf(sv_unit(si, qdk), ab);
+    }
+    const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+    const Rp t = local_Rp(c.F, c.jt, qe);
+    const Sv S1 = sv_unit(si, 1.0f);
+    if (!is_root) store_sv(a.ws_abar, B, c.par * 6, b, load_sv(a.ws_abar, B, c.par * 6, b) + XT_force(t, ab));
+    if (moving) {  // dX/dq on the acceleration path: the parent's acceleration, or gravity at the root
+      const Sv Xa = X_motion(t, is_root ? grav : load_sv(a.cache, B, c.par * 20 + 6, b));
+      gq -= c.mul * sv_dot(ab, crm(S1, Xa));
+      gqd += c.mul * sv_get(vb, si);
+    }
+    if (!is_root) {
+      store_sv(a.ws_vbar, B, c.par * 6, b, load_sv(a.ws_vbar, B, c.par * 6, b) + XT_force(t, vb));
+      if (moving) gq -= c.mul * sv_dot(vb, crm(S1, X_motion(t, load_sv(a.cache, B, c.par * 20, b))));
+    }
+    if (moving) {
+      a.grad_q[b * D + c.ji] += gq;
+      a.grad_qd[b * D + c.ji] += gqd;
+    }
+  }
+}
+
+}  // namespace curobo_hip
