@@ -57,6 +57,7 @@ class TrajOptTerms(C.Structure):
         ("cspace_weight", _P), ("cspace_activation_distance", _P), ("squared_l2_regularization_weights", _P),
         ("cspace_target_weight", _P), ("cspace_non_terminal_weight_factor", _P), ("cspace_target_dof_weight", _P),
         ("retime_weights", _I), ("retime_regularization_weights", _I),
+        ("link_masses_com", _P), ("link_inertias", _P), ("gravity", _P), ("level_links", _P), ("use_torque_limits", _I),
     ]
 
 

@@ -213,6 +213,13 @@ def rollout_trajopt_fused(terms: Optional[TrajOptTerms], *args, **kwargs):
     return _rollout_trajectory(load().curobo_hip_rollout_trajopt_fused, terms, True, *args, **kwargs)
 
 
+def rollout_trajopt_fused_torque_fits(padded_horizon: int, dof: int, num_links: int, num_spheres: int,
+                                      num_collision_pairs: int, link_chain_len: int, num_obstacles: int) -> bool:
+    """whether the torque-limit terms (RNEA forward / VJP inside the launch) fit the LDS regions they borrow"""
+    return bool(load().curobo_hip_rollout_trajopt_fused_torque_fits(
+        padded_horizon, dof, num_links, num_spheres, num_collision_pairs, link_chain_len, num_obstacles))
+
+
 def rollout_trajopt_fused_lds_bytes(padded_horizon: int, dof: int, num_links: int, num_spheres: int,
                                     num_collision_pairs: int, link_chain_len: int, num_obstacles: int,
                                     with_cspace_terms: bool) -> int:

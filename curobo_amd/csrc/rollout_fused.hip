@@ -33,6 +33,7 @@
 
 #include "bspline_device.hpp"
 #include "cost_device.hpp"
+#include "dynamics_device.hpp"
 #include "fk_device.hpp"
 #include "scene_device.hpp"
 #include "self_device.hpp"
@@ -61,6 +62,11 @@ struct FusedTrajArgs {
   CspaceStateArgs cs;     // pos/vel/acc/jerk unused (LDS); out_cost optional [B, H, D]; out_g* unused
   const int16_t *tool_frame_map;
   int n_tool_frames, use_pose, use_cspace;
+  // optional joint-torque limits (c-space STATE effort terms on tau = RNEA(q, qd, qdd)): inverse dynamics and its VJP
+  // run inside the launch on LDS regions that are dead by then (see fused_torque_fits)
+  const float *link_masses_com, *link_inertias, *gravity;
+  const int16_t *level_links;
+  int use_torque;
   // optional longest-first dispatch (see rebuild_dispatch_order): int32 [4][B] = order[2][B], ticks[2][B]
   int32_t *dispatch_ws;
   int dispatch_phase;
@@ -115,11 +121,24 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.key = take(4);
   f.flag = take(H);  // per point: any wrench written
   f.dyn = take(n_dyn);  // velocity / acceleration / jerk (+ joint-space position gradient) [4][H][D] when the c-space STATE cost is on
-  f.cstab = take(n_dyn ? 8 * D + 12 : 0);  // c-space limits (shrunk) [8][D] + 10 retimed weights + dt
+  f.cstab = take(n_dyn ? 10 * D + 12 : 0);  // c-space limits (shrunk) [10][D] (pos, vel, acc, jerk, effort) + 10 retimed weights + dt
   f.pairs = take((P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
   f.recs = take(n_rec * kObsRecFloats);
   f.total = o;
   return f;
+}
+
+// Inverse dynamics inside the launch (torque limits) borrows LDS that is dead when it runs:
+//   link constants [L][24 + 4]        <- the P1-only tables / scene rings (lists .. sph_link)
+//   q, qd, qdd copies [3][H][D]       <- the pair list (dead after the collision pass)
+//   tau [H][D]                        <- the leftover-point buffer `left`
+//   d cost / d tau [H][D]             <- sph_link + sph_rad + lbound
+//   forward cache [L][20][H]          <- the sphere rows `work` (dead after the collision pass)
+//   adjoints f, a [2][L][6][H]        <- cumul (dead after the wrench gather: exactly H L 12 floats)
+//   adjoint v [L][6][H]               <- wrench (dead after the gather)
+__host__ __device__ inline bool fused_torque_fits(const FusedLayout &f, int H, int D, int L, int S) {
+  return L * (kLinkFloats + 4) <= f.sph_link - f.lists && 3 * H * D <= f.recs - f.pairs && H * D <= S * 4 &&
+         H * D <= f.sub - f.sph_link && L * 20 <= f.ws && L * 6 <= L * kWrench;
 }
 
 __device__ __forceinline__ float uniform_f(float v) {  // wave-uniform value -> SGPR
@@ -615,15 +634,15 @@ __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPos
 // Keeps the ~20 global pointers of the term out of the per-point code (register budget).
 __device__ __forceinline__ void stage_cspace_tables(const FusedCtx &c, const CspaceStateArgs &cs, int b) {
   const int D = c.D;
-  for (int i = threadIdx.x; i < 8 * D + 11; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 10 * D + 11; i += blockDim.x) {
     float v;
-    if (i < 8 * D) {
-      const int q = i / (2 * D), side = (i / D) & 1, d = i % D;  // quantity 0..3 (pos, vel, acc, jerk), lower / upper
-      const float *lim = q == 0 ? cs.p_b : q == 1 ? cs.v_b : q == 2 ? cs.a_b : cs.j_b;
+    if (i < 10 * D) {
+      const int q = i / (2 * D), side = (i / D) & 1, d = i % D;  // quantity 0..4 (pos, vel, acc, jerk, effort), lower / upper
+      const float *lim = q == 0 ? cs.p_b : q == 1 ? cs.v_b : q == 2 ? cs.a_b : q == 3 ? cs.j_b : cs.effort_b;
       const float lo = lim[d], hi = lim[D + d], r = hi - lo, eta = cs.activation_distance[q];
       v = side == 0 ? lo + eta * r : hi - eta * r;
     } else {
-      const int k = i - 8 * D;
+      const int k = i - 10 * D;
       const float dt = cs.state_dt[b], dt2 = dt * dt, dt3 = dt * dt * dt;
       if (k < 5) {
         v = cs.weight[k];
@@ -643,12 +662,13 @@ __device__ __forceinline__ void stage_cspace_tables(const FusedCtx &c, const Csp
 // c-space STATE cost of point h (wp_cspace_state.py:20-287), one dof per lane, constants from LDS.
 // The position gradient is returned per lane (added to grad_q after the wrench gather: it is already
 // in joint space); the velocity / acceleration / jerk gradients replace the values in c.dyn.
-// Effort terms are off in the fused kernel (no dynamics in the loop): tau = 0 contributes nothing.
+// Effort terms: tau = nullptr (no dynamics in the launch) contributes nothing; else tau [H][D] are the inverse-dynamics
+// torques of the launch and d cost / d tau goes to gtau [H][D].
 constexpr int kDofIters = (64 + kFkLanes - 1) / kFkLanes;
 __device__ __forceinline__ void point_cspace_state(const FusedCtx &c, const CspaceStateArgs &cs, int b, int h, int lane,
-                                                   float &cost_pt) {
+                                                   float &cost_pt, const float *tau = nullptr, float *gtau = nullptr) {
   const int D = c.D, HD = c.H * c.D;
-  const float *w = c.cstab + 8 * D;
+  const float *w = c.cstab + 10 * D;
   // opaque to the optimiser: otherwise the per-lane addresses of the ~12 table / stream slots are
   // hoisted out of the caller's point loop and held in VGPRs across the pose term and the gather
   int d0 = lane;
@@ -670,6 +690,7 @@ __device__ __forceinline__ void point_cspace_state(const FusedCtx &c, const Cspa
         g0 += 2.0f * tw * err;
       }
     }
+    const float vel0 = tau != nullptr ? c.dyn[e] : 0.0f;  // (the loop below replaces the values by their gradients)
 #pragma unroll
     for (int q = 1; q < 4; q++) {  // velocity, acceleration, jerk: bound + squared-L2 regularisation
       const float x = c.dyn[(q - 1) * HD + e], lo = c.cstab[2 * q * D + d], hi = c.cstab[(2 * q + 1) * D + d];
@@ -677,7 +698,24 @@ __device__ __forceinline__ void point_cspace_state(const FusedCtx &c, const Cspa
       if (x < lo) squared_l2_term(x - lo, w[q], cc, g);
       else if (x > hi) squared_l2_term(x - hi, w[q], cc, g);
       squared_l2_term(x, w[5 + q - 1], cc, g);
+      if (q == 1 && tau != nullptr && w[9] > 0.0f) {  // aggregate_energy_regularization, velocity side
+        const float dt = c.cstab[10 * D + 10], en = tau[e] * x * dt;
+        g += 2.0f * w[9] * en * tau[e] * dt;
+      }
       c.dyn[(q - 1) * HD + e] = g;
+    }
+    if (tau != nullptr) {  // effort: bound + squared-L2 regularisation + energy (cspace_state_point, x[4])
+      const float x = tau[e], lo = c.cstab[8 * D + d], hi = c.cstab[9 * D + d];
+      float g = 0.0f;
+      if (x < lo) squared_l2_term(x - lo, w[4], cc, g);
+      else if (x > hi) squared_l2_term(x - hi, w[4], cc, g);
+      squared_l2_term(x, w[8], cc, g);
+      if (w[9] > 0.0f) {
+        const float dt = c.cstab[10 * D + 10], vel = vel0, en = x * vel * dt;
+        cc += w[9] * en * en;
+        g += 2.0f * w[9] * en * vel * dt;
+      }
+      gtau[e] = g;
     }
     cost_pt += cc;
     c.dyn[3 * HD + e] = g0;  // joint-space position gradient, added to grad_q after the wrench gather
@@ -820,9 +858,10 @@ __device__ __forceinline__ void point_pose_term(const FusedCtx &c, const FusedTr
   cost2 = row16_sum(cost2);
   if (lane == 0) { c.cost[h] += cost2; c.flag[h] = any_grad ? 1 : 0; }
 }
-__device__ __forceinline__ void point_cspace_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane) {
+__device__ __forceinline__ void point_cspace_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane,
+                                                  const float *tau, float *gtau) {
   float cost2 = 0.0f;
-  point_cspace_state(c, a.cs, b, h, lane, cost2);
+  point_cspace_state(c, a.cs, b, h, lane, cost2, tau, gtau);
   cost2 = row16_sum(cost2);
   if (lane == 0) c.cost[h] += cost2;
 }
@@ -1166,6 +1205,29 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       c.flag[H_main] = 1;
     }
   }
+  // ---- inverse dynamics of every point (torque limits), one lane per point: see fused_torque_fits for where its
+  // state lives.  Forward sweeps here (the c-space pass below needs tau), the VJP after the wrench gather.
+  const bool use_torque = TERMS && use_cspace && a.use_torque != 0;
+  float *tq_f = smem + lay.lists;
+  int *tq_i = reinterpret_cast<int *>(tq_f + L * kLinkFloats);
+  float *tq_q = smem + lay.pairs, *tq_tau = reinterpret_cast<float *>(c.left), *tq_gtau = smem + lay.sph_link;
+  RneaArgs rn{};
+  if (use_torque) {
+    __syncthreads();  // row 0 has applied the leftover point's self-collision pair: pair list, spheres and rings are dead
+    rn.fixed_transforms = a.fixed_transform; rn.link_masses_com = a.link_masses_com; rn.link_inertias = a.link_inertias;
+    rn.joint_map_type = a.joint_map_type; rn.joint_map = a.joint_map; rn.link_map = a.link_map;
+    rn.joint_offset_map = a.joint_offset; rn.gravity = a.gravity; rn.level_links = a.level_links;
+    rn.num_links = L; rn.num_dof = D; rn.batch = H;
+    rn.q = tq_q; rn.qd = tq_q + H * D; rn.qdd = tq_q + 2 * H * D; rn.tau = tq_tau; rn.cache = c.work;
+    for (int e = tid; e < H * D; e += nt) {
+      tq_q[e] = c.q[e];
+      tq_q[H * D + e] = c.dyn[e];
+      tq_q[2 * H * D + e] = c.dyn[H * D + e];
+    }
+    stage_links(rn, tq_f, tq_i);  // (ends with a workgroup barrier)
+    if (tid < H) rnea_forward_element<false>(rn, tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
+    __syncthreads();
+  }
   CUROBO_STAMP(15);
   // further passes over all points, leftover ones included (their own loops so that the register
   // allocation of the collision pass above is not shared with the optional terms, and so that those
@@ -1179,7 +1241,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     }
   CUROBO_STAMP(13);
   if (TERMS && use_cspace)
-    for (int h = grp; h < H; h += ngroups) point_cspace_term(c, a, b, h, lane);
+    for (int h = grp; h < H; h += ngroups) point_cspace_term(c, a, b, h, lane, use_torque ? tq_tau : nullptr, tq_gtau);
   CUROBO_STAMP(14);
   for (int h = grp; h < H; h += ngroups) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1190,6 +1252,12 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       for (int d = lane; d < D; d += kFkLanes) c.q[h * D + d] += c.dyn[3 * H * D + h * D + d];
   }
   __syncthreads();
+  if (use_torque) {  // VJP of the inverse dynamics: d cost / d tau -> added to the joint-space gradient streams
+    rn.grad_q = c.q; rn.grad_qd = c.dyn; rn.grad_qdd = c.dyn + H * D; rn.grad_tau = tq_gtau;
+    rn.ws_fbar = c.cumul; rn.ws_abar = c.cumul + (size_t)L * 6 * H; rn.ws_vbar = c.wrench;
+    if (tid < H) rnea_backward_element<false, true>(rn, tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
+    __syncthreads();
+  }
   CUROBO_STAMP(3);
 
   // ---------------- P3: B-spline VJP + trajectory cost
@@ -1522,6 +1590,12 @@ static int rollout_trajectory_fused_impl(
       cs.non_terminal_factor = t.cspace_non_terminal_weight_factor; cs.target_dof_weight = t.cspace_target_dof_weight;
       cs.write_grad = 1; cs.batch = batch_size; cs.horizon = padded_horizon; cs.dof = dof;
       cs.retime_weights = t.retime_weights; cs.retime_reg_weights = t.retime_regularization_weights;
+      if (t.use_torque_limits) {
+        CUROBO_REQUIRE(t.link_masses_com && t.link_inertias && t.gravity && t.level_links,
+                       "%s: torque limits need link_masses_com, link_inertias, gravity, level_links", what);
+        a.link_masses_com = t.link_masses_com; a.link_inertias = t.link_inertias; a.gravity = t.gravity;
+        a.level_links = t.level_links; a.use_torque = 1;
+      }
     }
   }
   int threads;
@@ -1531,6 +1605,9 @@ static int rollout_trajectory_fused_impl(
                                                   a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
+  CUROBO_REQUIRE(!a.use_torque || fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres),
+                 "%s: the inverse-dynamics state of this robot does not fit the LDS regions it borrows; run the torque "
+                 "limits on the kernel sequence (curobo_hip_rollout_trajopt_fused_torque_fits)", what);
   // scenes with analytic primitives in the cuboid store run the one instantiation that tests the tag (KINDS = 7)
   const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
   hipStream_t st = (hipStream_t)stream;
@@ -1626,6 +1703,14 @@ CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_lds_bytes(int padded_horizon,
   const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
                                                   num_obstacles, with_cspace_terms ? 4 * padded_horizon * dof : 0, &threads);
   return lay.total * (int)sizeof(float);
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_torque_fits(int padded_horizon, int dof, int num_links, int num_spheres,
+                                                               int num_collision_pairs, int link_chain_len, int num_obstacles) {
+  int threads;
+  const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, num_collision_pairs,
+                                                  num_obstacles, 4 * padded_horizon * dof, &threads, 1);
+  return (size_t)lay.total * sizeof(float) <= 160 * 1024 && fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres) ? 1 : 0;
 }
 
 CUROBO_EXPORT int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres, int num_collision_pairs,

@@ -398,6 +398,12 @@ typedef struct curobo_hip_trajopt_terms {
   const float *cspace_weight, *cspace_activation_distance, *squared_l2_regularization_weights;
   const float *cspace_target_weight, *cspace_non_terminal_weight_factor, *cspace_target_dof_weight;
   int32_t retime_weights, retime_regularization_weights;
+  /* joint-torque limits: the effort terms of the c-space STATE cost on tau = RNEA(q, qd, qdd) (reference
+   * cost/wp_cspace_state.py + kernels/dynamics/rnea_*_kernel.cuh), inverse dynamics and its VJP inside the launch.
+   * Pointers as in curobo_hip_launch_rnea_forward; needs curobo_hip_rollout_trajopt_fused_torque_fits(...) != 0 */
+  const float *link_masses_com, *link_inertias, *gravity;
+  const int16_t *level_links;
+  int32_t use_torque_limits;
 } curobo_hip_trajopt_terms;
 
 /* curobo_hip_rollout_trajectory_fused plus the optional terms above: the whole reference trajopt
@@ -421,6 +427,11 @@ int curobo_hip_rollout_trajopt_fused(
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,
     int dispatch_phase, const curobo_hip_trajopt_terms *terms, curobo_hip_stream_t stream);
+
+/* 1 if the torque-limit terms fit (they borrow LDS regions that are dead when the inverse dynamics runs) */
+int curobo_hip_rollout_trajopt_fused_torque_fits(
+    int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
+    int link_chain_len, int num_obstacles);
 
 int curobo_hip_rollout_trajopt_fused_lds_bytes(
     int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,

@@ -292,7 +292,12 @@ class TrajOptRollout:
         need = rollout_hip.rollout_trajopt_fused_lds_bytes(
             c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
             int(k.link_chain_data.shape[0]), n_obs, True)
-        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64 and not c.use_torque_limits
+        ok = need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
+        if ok and c.use_torque_limits:  # inverse dynamics inside the launch borrows LDS regions that are dead by then
+            ok = rollout_hip.rollout_trajopt_fused_torque_fits(
+                c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
+                int(k.link_chain_data.shape[0]), n_obs)
+        return ok
 
     def _dispatch_order(self):
         if not self.cfg.longest_first_dispatch:
@@ -321,7 +326,9 @@ class TrajOptRollout:
             cspace_activation_distance=self._cs_eta, squared_l2_regularization_weights=self._cs_reg,
             cspace_target_weight=self._zero1, cspace_non_terminal_weight_factor=self._zero1,
             cspace_target_dof_weight=self._onesD, retime_weights=c.retime_weights,
-            retime_regularization_weights=c.retime_regularization_weights)
+            retime_regularization_weights=c.retime_regularization_weights,
+            **(dict(link_masses_com=k.link_masses_com, link_inertias=k.link_inertias, gravity=self._gravity,
+                    level_links=k.link_level_data, use_torque_limits=1) if c.use_torque_limits else {}))
         rollout_hip.rollout_trajopt_fused(
             self._terms, self.cost, self.grad_knots, self.position if m else None, self.robot_spheres if m else None,
             act_seq, self.start_pos, self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel,

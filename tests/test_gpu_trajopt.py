@@ -21,7 +21,7 @@ def _setup(device):
     return model, kin, arrays, SceneData.from_arrays(arrays, device)
 
 
-@pytest.mark.parametrize("fused,torque", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("fused,torque", [(False, False), (True, False), (False, True), (True, True)])
 def test_trajopt_rollout_matches_oracle_composition(fused, torque, oracle, device):
     """non-swept scene term for the strict comparison (the sweep has the documented zero-motion
     discontinuity); every cost term of the reference trajopt task is active.  ``torque``: plus the
@@ -310,8 +310,8 @@ def test_batch_env_ik_and_trajopt(oracle, device):
 
 def test_trajopt_solver_with_torque_limits(oracle, device):
     """pose-to-pose trajectory optimisation under joint-torque limits (reference: motion generation with
-    torque limits) on the kernel sequence under hipGraph: the winners' inverse-dynamics torques, recomputed
-    with the oracle's B-spline + RNEA, respect the (tightened) limits."""
+    torque limits) under hipGraph, inverse dynamics and its VJP inside the fused rollout launch: the winners'
+    inverse-dynamics torques, recomputed with the oracle's B-spline + RNEA, respect the (tightened) limits."""
     from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
     from curobo_amd.workloads import feasible_goals, start_configuration
 
@@ -328,7 +328,7 @@ def test_trajopt_solver_with_torque_limits(oracle, device):
     lim_cfg.rollout.effort_limit = [float(v) for v in 0.6 * eff]  # tighter than the URDF's so that the limits bind
     lim_cfg.rollout.cspace_weight = [10000.0, 10000.0, 100.0, 50.0, 1000.0]
     slv = TrajOptSolver(kin, scene, P, lim_cfg)
-    assert not slv.rollout.fused_available()
+    assert slv.rollout.fused_available()  # (Franka: the RNEA state fits the LDS regions it borrows)
     r1 = slv.solve_pose(start, gp, gq)
     torch.cuda.synchronize()
     ok = r1.success.cpu().numpy()
