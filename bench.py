@@ -867,6 +867,17 @@ def full_trajopt_benchmark(seeds, model, kin, scene, device, torch):
         res[name] = round(time_kernel(g.replay, 20, torch) / 10, 1)
     res["rollouts_per_s_fused"] = round(B / res["fused_us"] * 1e6, 1)
     res["workload"] = "C2 shapes, full trajopt cost set (pose + c-space state + self + swept scene), cost+grad"
+    # the same with joint-torque limits (inverse dynamics + its VJP per point: inside the fused launch / two more launches)
+    tq = {}
+    for name, fused in (("fused_us", True), ("kernel_sequence_us", False)):
+        cfg = TrajOptRolloutCfg(use_fused=fused)
+        cfg.use_torque_limits = True
+        ro = TrajOptRollout(kin, scene, B, cfg)
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        x = knots.reshape(B, -1)
+        g = graphed(lambda: ro.cost_and_gradient(x), 10, torch)
+        tq[name] = round(time_kernel(g.replay, 20, torch) / 10, 1)
+    res["with_torque_limits"] = tq
     return res
 
 

@@ -50,3 +50,39 @@ def seed_ik_update_state(
         float(lambda_max), float(convergence_position_tolerance), float(convergence_orientation_tolerance),
         float(convergence_joint_limit_weight), n, d, t, int(initial), current_stream(joint_position),
     ))
+
+
+def seed_ik_iterate(
+    joint_position, jacobian, jTerror, error_norm, position_error, orientation_error, lambda_damping, success, improvement,
+    seed_joint_position, goal_position, goal_quat, idxs_goal, position_orientation_weight, pose_axes_weight_factor,
+    pose_convergence_tolerance, project_distance_to_goal, num_goalset: int, rotation_method: int, fixed_transform,
+    joint_map_type, joint_map, link_map, tool_frame_map, link_chain_data, link_chain_offsets, joint_links_data,
+    joint_links_offsets, joint_affects_endeffector, joint_offset_map, action_min, action_max, current_position, dt,
+    velocity_limits, joint_limit_weight: float, rho_min: float, lambda_factor: float, lambda_min: float, lambda_max: float,
+    convergence_position_tolerance: float, convergence_orientation_tolerance: float, convergence_joint_limit_weight: float,
+    iterations: int, initial: bool, current_velocity=None, velocity_weight: float = 0.0, acceleration_weight: float = 0.0,
+    stop_flag=None, blocks_run=None,
+):
+    """``iterations`` whole LM iterations of the seed-IK solver (plus the initial evaluation of ``seed_joint_position``
+    when ``initial``) in one launch (``curobo_hip_seed_ik_iterate``); state buffers as in :func:`seed_ik_update_state`."""
+    n, d = joint_position.shape
+    t = int(tool_frame_map.shape[0])
+    check(load().curobo_hip_seed_ik_iterate(
+        ptr(joint_position), ptr(jacobian), ptr(jTerror), ptr(error_norm), ptr(position_error), ptr(orientation_error),
+        ptr(lambda_damping), ptr(success), ptr(improvement), ptr(seed_joint_position), ptr(goal_position), ptr(goal_quat),
+        ptr(idxs_goal), ptr(position_orientation_weight), ptr(pose_axes_weight_factor), ptr(pose_convergence_tolerance),
+        ptr(project_distance_to_goal), int(num_goalset), int(rotation_method), ptr(fixed_transform), ptr(joint_map_type),
+        ptr(joint_map), ptr(link_map), ptr(tool_frame_map), ptr(link_chain_data), ptr(link_chain_offsets),
+        ptr(joint_links_data), ptr(joint_links_offsets), ptr(joint_affects_endeffector), ptr(joint_offset_map),
+        ptr(action_min), ptr(action_max), ptr(current_position), ptr(dt), ptr(velocity_limits), ptr(current_velocity),
+        float(velocity_weight), float(acceleration_weight), float(joint_limit_weight), float(rho_min), float(lambda_factor),
+        float(lambda_min), float(lambda_max), float(convergence_position_tolerance), float(convergence_orientation_tolerance),
+        float(convergence_joint_limit_weight), n, d, int(link_map.shape[0]), t, int(link_chain_data.shape[0]), int(iterations),
+        int(initial), ptr(stop_flag), ptr(blocks_run), current_stream(joint_position),
+    ))
+
+
+def seed_ik_batch_status(success, num_problems: int, num_seeds: int, needed: int, stop_flag):
+    """device-side exit test of the seed-IK solver (``curobo_hip_seed_ik_batch_status``)"""
+    check(load().curobo_hip_seed_ik_batch_status(ptr(success), int(num_problems), int(num_seeds), int(needed), ptr(stop_flag),
+                                                 current_stream(success)))

@@ -318,6 +318,36 @@ int curobo_hip_seed_ik_update_state(
     float convergence_joint_limit_weight, int num_problems, int dof, int num_tool_frames,
     int initial, curobo_hip_stream_t stream);
 
+/* `iterations` whole Levenberg-Marquardt iterations of the seed-IK solver (LM step -> FK + tool-frame Jacobian ->
+ * tool-pose error -> J^T e -> curobo_hip_seed_ik_update_state) in ONE launch, preceded by the initial evaluation of
+ * seed_joint_position when `initial` != 0: a problem lives on one 16-lane row with its state in LDS, global memory sees
+ * the state (the buffers of curobo_hip_seed_ik_update_state) on the way in and on the way out.  Replaces
+ * 5 x iterations launches of curobo_hip_levenberg_marquardt_step, curobo_hip_launch_kinematics_forward_spheres_jacobian,
+ * curobo_hip_tool_pose_distance, curobo_hip_launch_kinematics_backward, curobo_hip_seed_ik_update_state (reference:
+ * solver/seed_ik/seed_ik_solver.py:48-824, one torch graph per inner loop).  dof <= 16.  Goal / weight pointers as in
+ * curobo_hip_tool_pose_distance (horizon 1: terminal weights and tolerances). */
+int curobo_hip_seed_ik_iterate(
+    float *joint_position, float *jacobian, float *jTerror, float *error_norm, float *position_error,
+    float *orientation_error, float *lambda_damping, uint8_t *success, uint8_t *improvement, const float *seed_joint_position,
+    const float *goal_position, const float *goal_quat, const int32_t *idxs_goal, const float *position_orientation_weight,
+    const float *pose_axes_weight_factor, const float *pose_convergence_tolerance, const uint8_t *project_distance_to_goal,
+    int num_goalset, int rotation_method, const float *fixed_transform, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const int16_t *tool_frame_map, const int16_t *link_chain_data, const int16_t *link_chain_offsets,
+    const int16_t *joint_links_data, const int16_t *joint_links_offsets, const uint8_t *joint_affects_endeffector,
+    const float *joint_offset_map, const float *action_min, const float *action_max, const float *current_position,
+    const float *dt, const float *velocity_limits, const float *current_velocity, float velocity_weight,
+    float acceleration_weight, float joint_limit_weight, float rho_min, float lambda_factor, float lambda_min,
+    float lambda_max, float convergence_position_tolerance, float convergence_orientation_tolerance,
+    float convergence_joint_limit_weight, int num_problems, int dof, int num_links, int num_tool_frames, int link_chain_len,
+    int iterations, int initial, const int32_t *stop_flag, int32_t *blocks_run, curobo_hip_stream_t stream);
+
+/* Device-side early exit of the seed-IK solver (reference _calculate_exit_condition, seed_ik_solver.py:452-468): sets
+ * *stop_flag = 1 when at least `needed` of the num_problems problems have a converged seed in success [P, S].  Launches of
+ * curobo_hip_seed_ik_iterate that are given the flag (optional, NULL = always run) return at once when it is set and count
+ * themselves in *blocks_run otherwise, so the host can enqueue every block of iterations without a round trip. */
+int curobo_hip_seed_ik_batch_status(const uint8_t *success, int num_problems, int num_seeds, int needed,
+                                    int32_t *stop_flag, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- optimization: MPPI update
  * reference: optim/particle/mppi.py:201-313 + jit helpers :615-757 (pure torch, DIAG_A
  * covariance).  costs [problems, particles, cost_horizon] (cost_horizon may be 1 for totals),

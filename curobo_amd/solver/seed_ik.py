@@ -28,6 +28,8 @@ from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
+import math
+
 import torch
 
 from ..backends import cost as cost_hip
@@ -65,6 +67,10 @@ class SeedIKSolverCfg:
     #: seed_ik_error_calculator.py:389-456): active with ``solve_batch(current_position=, dt=[, current_velocity=])``
     velocity_weight: float = 0.0
     acceleration_weight: float = 0.0
+    #: every inner block of LM iterations (and the initial evaluation) as ONE launch with the per-problem state in LDS
+    #: (``curobo_hip_seed_ik_iterate``) instead of five launches per iteration; same per-stage arithmetic except
+    #: J^T J (fp32 FMAs on the row instead of the matrix-core contraction of the stand-alone LM step)
+    fused_iterations: bool = True
 
     def __post_init__(self):
         if self.max_iterations < self.inner_iterations or self.max_iterations % self.inner_iterations != 0:
@@ -159,6 +165,8 @@ class SeedIKSolver:
         self._vel_velocity = z(n, D)  # current joint velocity (acceleration rows)
         self._vel_active = False
         self._graphs = {}
+        self._stop_flag = z(1, dt=torch.int32)
+        self._blocks_run = z(1, dt=torch.int32)
 
     # ------------------------------------------------------------------ one evaluation / iteration
     def _evaluate_candidate(self, q: torch.Tensor, initial: bool) -> None:
@@ -192,6 +200,26 @@ class SeedIKSolver:
             current_velocity=self._vel_velocity if (self._vel_active and c.acceleration_weight > 0) else None,
             velocity_weight=c.velocity_weight if self._vel_active else 0.0,
             acceleration_weight=c.acceleration_weight if self._vel_active else 0.0)
+
+    def _fused_ok(self) -> bool:
+        return bool(self.cfg.fused_iterations) and self.D <= 16
+
+    def _iterate_fused(self, iterations: int, seeds: Optional[torch.Tensor] = None) -> None:
+        """``iterations`` LM iterations (after the initial evaluation of ``seeds`` when given) in one launch"""
+        k, c = self.kin, self.cfg
+        vel = self._vel_active
+        linalg_hip.seed_ik_iterate(
+            self.q, self.jacobian, self.jTerror, self.error_norm, self.position_error, self.orientation_error,
+            self.lambda_damping, self.success, self.improvement, seeds, self.goal_position, self.goal_quat, self.idxs_goal,
+            self._pose_w, self._axes_w, self._tol, self._project, self.G, 0, k.fixed_transforms, k.joint_map_type, k.joint_map,
+            k.link_map, k.tool_frame_map, k.link_chain_data, k.link_chain_offsets, k.joint_links_data, k.joint_links_offsets,
+            k.joint_affects_endeffector, k.joint_offset_map, self.action_min, self.action_max,
+            *((self._vel_current, self._vel_dt, self._vel_limits) if vel else (None, None, None)),
+            c.joint_limit_weight, c.rho_min, c.lambda_factor, c.lambda_min, c.lambda_max, c.convergence_position_tolerance,
+            c.convergence_orientation_tolerance, c.convergence_joint_limit_weight, iterations, seeds is not None,
+            current_velocity=self._vel_velocity if (vel and c.acceleration_weight > 0) else None,
+            velocity_weight=c.velocity_weight if vel else 0.0, acceleration_weight=c.acceleration_weight if vel else 0.0,
+            stop_flag=None if seeds is not None else self._stop_flag, blocks_run=None if seeds is not None else self._blocks_run)
 
     def _lm_iteration(self) -> None:
         linalg_hip.levenberg_marquardt_step(self.q_new, self.pred_reduction, self.jacobian, self.jTerror,
@@ -261,10 +289,23 @@ class SeedIKSolver:
         seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
         self.lambda_damping.fill_(c.lambda_initial)
         self.success.zero_()
-        self._evaluate_candidate(seeds, initial=True)
+        fused = self._fused_ok()
         outer = c.max_iterations // c.inner_iterations
+        if fused:
+            # every block of iterations is enqueued at once: the exit test between blocks runs on the device and the
+            # remaining launches return immediately once the batch is solved (no host round trip per block)
+            self._iterate_fused(0, seeds)
+            self._stop_flag.zero_()
+            self._blocks_run.zero_()
+            needed = int(math.ceil(c.batch_success_threshold * P))
+            for it in range(outer):
+                self._iterate_fused(c.inner_iterations)
+                if it < outer - 1:
+                    linalg_hip.seed_ik_batch_status(self.success, P, S, needed, self._stop_flag)
+        else:
+            self._evaluate_candidate(seeds, initial=True)
         it = 0
-        for it in range(outer):
+        for it in range(outer if not fused else 0):
             self._run_inner()
             if it < outer - 1:  # reference _calculate_exit_condition (:452-468)
                 solved = (self.success.view(P, S).sum(-1) >= 1).sum()
@@ -283,5 +324,5 @@ class SeedIKSolver:
         top = torch.topk(costs, k=return_seeds, dim=-1, largest=False).indices
         g = lambda t: torch.gather(t, 1, top)  # noqa: E731
         sol = torch.gather(q, 1, top.unsqueeze(-1).expand(P, return_seeds, D))
-        return SeedIKResult(success=g(ok), solution=sol, position_error=g(pos), rotation_error=g(ori),
-                            iterations=(it + 1) * c.inner_iterations)
+        n_it = int(self._blocks_run.item()) * c.inner_iterations if fused else (it + 1) * c.inner_iterations
+        return SeedIKResult(success=g(ok), solution=sol, position_error=g(pos), rotation_error=g(ori), iterations=n_it)
