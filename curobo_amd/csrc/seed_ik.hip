@@ -502,11 +502,16 @@ __global__ void __launch_bounds__(256) seed_ik_batch_status_kernel(const uint8_t
   __shared__ int s_count;
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
+  // one 16-lane row per problem and round, lanes stride over its seeds (coalesced byte loads), row-level OR
+  const int rowi = threadIdx.x / kRow, lane = threadIdx.x % kRow, rows = blockDim.x / kRow;
   int mine = 0;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    bool any = false;
-    for (int k = 0; k < S; k++) any = any || success[(size_t)p * S + k] != 0;
-    mine += any ? 1 : 0;
+  for (int p0 = 0; p0 < P; p0 += rows) {
+    const int p = p0 + rowi;
+    float any = 0.0f;
+    if (p < P)
+      for (int k = lane; k < S; k += kRow) any = fmaxf(any, success[(size_t)p * S + k] != 0 ? 1.0f : 0.0f);
+    any = row16_max(any);
+    if (lane == 0 && any > 0.0f) mine++;
   }
   if (mine) atomicAdd(&s_count, mine);
   __syncthreads();

@@ -67,6 +67,7 @@ class IKSolver:
     def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int,
                  cfg: Optional[IKSolverCfg] = None, seed_offset: int = 0, use_cuda_graph: bool = True):
         self.kin, self.scene, self.cfg = kin, scene, cfg or IKSolverCfg()
+        self._use_graph, self._result_graphs = use_cuda_graph, {}
         self.P, self.S = num_problems, self.cfg.num_seeds
         self.device = kin.device
         self.seed_offset = seed_offset
@@ -133,9 +134,15 @@ class IKSolver:
         gp = goal_position.to(self.device, torch.float32).view(P, 1, G, 3).expand(P, T, G, 3).contiguous()
         gq = goal_quat.to(self.device, torch.float32).view(P, 1, G, 4).expand(P, T, G, 4).contiguous()
         self._set_envs(env_idx)
-        for ro, rows in zip(self.rollouts, self._row_goals):
-            ro.update_goals(gp, gq, rows)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
+        optimizer_goals_set = False
+
+        def set_optimizer_goals():  # (only when the L-BFGS stage runs: with exit_early the seed solutions usually suffice)
+            nonlocal optimizer_goals_set
+            if not optimizer_goals_set:
+                for ro, rows in zip(self.rollouts, self._row_goals):
+                    ro.update_goals(gp, gq, rows)
+                optimizer_goals_set = True
         if seeds is None:
             if self.seed_solver is not None:
                 seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=S).solution
@@ -148,6 +155,7 @@ class IKSolver:
             if float(solved.float().mean()) >= self.cfg.exit_early_batch_success_threshold:
                 self.optimizer_ran = False
                 return early
+        set_optimizer_goals()
         best = self.optimizer.optimize(seeds.reshape(P * S, 1, D))
         return self._get_result(best.reshape(P * S, D).contiguous(), return_seeds)
 
@@ -163,6 +171,31 @@ class IKSolver:
             ro.update_env_query_idx(env[rows.long()] if mode else None)
 
     def _get_result(self, q: torch.Tensor, return_seeds: int) -> IKResult:
+        """``_get_result_eager`` replayed from a hipGraph when the process is alone (the ~25 small launches of the
+        metrics + ranking are then one submission; with ``torch.distributed`` initialised the winner exchange is a
+        collective and the eager path runs).  Results are copies: the next call does not overwrite them."""
+        import torch.distributed as dist
+
+        if not self._use_graph or (dist.is_available() and dist.is_initialized()):
+            return self._get_result_eager(q, return_seeds)
+        key = (return_seeds, bool(getattr(self, "_env_mode", False)))
+        if key not in self._result_graphs:
+            q_static = torch.empty_like(q)
+            q_static.copy_(q)
+            self._get_result_eager(q_static, return_seeds)  # warm-up outside the capture
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._get_result_eager(q_static, return_seeds)
+            self._result_graphs[key] = (graph, q_static, out)
+        graph, q_static, out = self._result_graphs[key]
+        q_static.copy_(q)
+        graph.replay()
+        return IKResult(**{f: (getattr(out, f).clone() if getattr(out, f) is not None else None)
+                           for f in ("success", "solution", "position_error", "rotation_error", "cost", "seed_index",
+                                     "goalset_index")})
+
+    def _get_result_eager(self, q: torch.Tensor, return_seeds: int) -> IKResult:
         """Metrics of P*S joint configurations, feasibility checks and the ranked winner(s) per problem
         (reference IKSolver._get_result, solver_ik.py:440-580)."""
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links

@@ -166,6 +166,7 @@ class SeedIKSolver:
         self._vel_active = False
         self._graphs = {}
         self._stop_flag = z(1, dt=torch.int32)
+        self._solve_graphs, self._last_outer = {}, 0
         self._blocks_run = z(1, dt=torch.int32)
 
     # ------------------------------------------------------------------ one evaluation / iteration
@@ -287,6 +288,33 @@ class SeedIKSolver:
         if seed_config is None and current_position is not None:
             seed_config = current_position.view(P, 1, D)
         seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
+        fused = self._fused_ok()
+        if fused and c.use_cuda_graph and not self._vel_active and current_position is None:
+            # the whole solve after the seeds (initial evaluation, every block of iterations with the device-side exit
+            # test, the ranking) replayed from ONE hipGraph: ~35 small submissions become one
+            if return_seeds not in self._solve_graphs:
+                self._seeds_static = torch.empty_like(seeds)
+                self._seeds_static.copy_(seeds)
+                self._solve_from_seeds(self._seeds_static, return_seeds, None)  # warm-up outside the capture
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._solve_from_seeds(self._seeds_static, return_seeds, None)
+                self._solve_graphs[return_seeds] = (graph, out)
+            graph, out = self._solve_graphs[return_seeds]
+            self._seeds_static.copy_(seeds)
+            graph.replay()
+            ok_t, sol, pos_t, ori_t = (t.clone() for t in out)
+            it = 0
+        else:
+            ok_t, sol, pos_t, ori_t = self._solve_from_seeds(seeds, return_seeds, current_position)
+            it = self._last_outer
+        n_it = int(self._blocks_run.item()) * c.inner_iterations if fused else (it + 1) * c.inner_iterations
+        return SeedIKResult(success=ok_t, solution=sol, position_error=pos_t, rotation_error=ori_t, iterations=n_it)
+
+    def _solve_from_seeds(self, seeds: torch.Tensor, return_seeds: int, current_position: Optional[torch.Tensor]):
+        """initial evaluation -> blocks of LM iterations (exit test between blocks) -> ranked top ``return_seeds``"""
+        P, S, D, c = self.P, self.S, self.D, self.cfg
         self.lambda_damping.fill_(c.lambda_initial)
         self.success.zero_()
         fused = self._fused_ok()
@@ -311,6 +339,7 @@ class SeedIKSolver:
                 solved = (self.success.view(P, S).sum(-1) >= 1).sum()
                 if int(solved) >= c.batch_success_threshold * P:
                     break
+        self._last_outer = it
         pos, ori = self.position_error.view(P, S), self.orientation_error.view(P, S)
         q = self.q.view(P, S, D)
         ok = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)
@@ -324,5 +353,4 @@ class SeedIKSolver:
         top = torch.topk(costs, k=return_seeds, dim=-1, largest=False).indices
         g = lambda t: torch.gather(t, 1, top)  # noqa: E731
         sol = torch.gather(q, 1, top.unsqueeze(-1).expand(P, return_seeds, D))
-        n_it = int(self._blocks_run.item()) * c.inner_iterations if fused else (it + 1) * c.inner_iterations
-        return SeedIKResult(success=g(ok), solution=sol, position_error=g(pos), rotation_error=g(ori), iterations=n_it)
+        return g(ok), sol, g(pos), g(ori)

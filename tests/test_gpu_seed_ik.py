@@ -109,12 +109,14 @@ def test_evaluation_and_first_iterations_match_oracle(oracle, device):
     np.testing.assert_allclose(solver.lambda_damping.cpu().numpy()[close], ref["lambda_damping"][close], rtol=1e-5)
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_seed_ik_solves_reachable_goals(oracle, device, graph):
+@pytest.mark.parametrize("graph,fused", [(False, False), (True, False), (False, True)])
+def test_seed_ik_solves_reachable_goals(oracle, device, graph, fused):
+    """``fused``: every block of LM iterations as one launch (curobo_hip_seed_ik_iterate, state in LDS) instead of
+    five launches per iteration"""
     from oracle import seed_ik_ref as R
 
     P, S = 40, 16
-    model, solver = _solver(device, P, S, use_cuda_graph=graph, batch_success_threshold=2.0)
+    model, solver = _solver(device, P, S, use_cuda_graph=graph, batch_success_threshold=2.0, fused_iterations=fused)
     md, gp, gq, seeds, idx = _problem(oracle, model, P, S, seed=5)
     ref = R.solve(oracle, md, R.SeedIKRefCfg(), seeds, gp, gq, idx)
     res = solver.solve_batch(torch.as_tensor(gp[:, :, 0]), torch.as_tensor(gq[:, :, 0]),
@@ -137,9 +139,11 @@ def test_seed_ik_solves_reachable_goals(oracle, device, graph):
     assert same.mean() > 0.7, same.mean()
 
 
-def test_early_exit_and_sampled_seeds(oracle, device):
+@pytest.mark.parametrize("fused", [False, True])
+def test_early_exit_and_sampled_seeds(oracle, device, fused):
+    """``fused``: the exit test between blocks runs on the device (curobo_hip_seed_ik_batch_status)"""
     P, S = 16, 32
-    model, solver = _solver(device, P, S)
+    model, solver = _solver(device, P, S, fused_iterations=fused)
     md, gp, gq, _, _ = _problem(oracle, model, P, S, seed=9)
     res = solver.solve_batch(torch.as_tensor(gp[:, :, 0]), torch.as_tensor(gq[:, :, 0]), return_seeds=3)
     assert res.solution.shape == (P, 3, 7) and res.success.shape == (P, 3)
