@@ -86,3 +86,31 @@ def seed_ik_batch_status(success, num_problems: int, num_seeds: int, needed: int
     """device-side exit test of the seed-IK solver (``curobo_hip_seed_ik_batch_status``)"""
     check(load().curobo_hip_seed_ik_batch_status(ptr(success), int(num_problems), int(num_seeds), int(needed), ptr(stop_flag),
                                                  current_stream(success)))
+
+
+def seed_ik_select(out_success, out_solution, out_position_error, out_orientation_error, joint_position, position_error,
+                   orientation_error, limit_lower, limit_upper, current_position, position_tolerance: float,
+                   orientation_tolerance: float, start_cspace_dist_weight: float, check_limits: bool, return_seeds: int):
+    """the ``return_seeds`` best seeds of every problem, best first (``curobo_hip_seed_ik_select``)"""
+    p, s, d = joint_position.shape
+    check(load().curobo_hip_seed_ik_select(
+        ptr(out_success), ptr(out_solution), ptr(out_position_error), ptr(out_orientation_error), ptr(joint_position),
+        ptr(position_error), ptr(orientation_error), ptr(limit_lower), ptr(limit_upper), ptr(current_position),
+        float(position_tolerance), float(orientation_tolerance), float(start_cspace_dist_weight), int(check_limits), p, s, d,
+        int(return_seeds), current_stream(joint_position)))
+
+
+def ik_rank(out_success, out_solution, out_position_error, out_rotation_error, out_cost, out_seed_index, out_goalset_index,
+            joint_position, cost, position_distance, rotation_distance, self_collision_distance, cspace_cost, scene_distance,
+            goalset_idx, position_threshold: float, rotation_threshold: float, num_problems: int, num_seeds: int,
+            return_seeds: int, seed_offset: int):
+    """feasibility, success and the ranked winners of an IK batch in one launch (``curobo_hip_ik_rank``)"""
+    d = joint_position.shape[-1]
+    t = position_distance.shape[-1]
+    n_scene = 0 if scene_distance is None else scene_distance.numel() // (num_problems * num_seeds)
+    check(load().curobo_hip_ik_rank(
+        ptr(out_success), ptr(out_solution), ptr(out_position_error), ptr(out_rotation_error), ptr(out_cost),
+        ptr(out_seed_index), ptr(out_goalset_index), ptr(joint_position), ptr(cost), ptr(position_distance),
+        ptr(rotation_distance), ptr(self_collision_distance), ptr(cspace_cost), ptr(scene_distance), ptr(goalset_idx),
+        float(position_threshold), float(rotation_threshold), int(num_problems), int(num_seeds), d, t, int(n_scene),
+        int(return_seeds), int(seed_offset), current_stream(joint_position)))

@@ -518,6 +518,114 @@ __global__ void __launch_bounds__(256) seed_ik_batch_status_kernel(const uint8_t
   if (threadIdx.x == 0 && s_count >= needed) *stop_flag = 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ranking of the seeds of a problem in ONE launch (the reference does it with ~20 torch kernels: comparisons,
+// masks, a top-k, gathers).  One workgroup per problem: every seed's cost goes to LDS, a thread finds the rank of
+// its seed by counting the seeds that beat it (cost, then lower index: the order of a stable sort, independent of
+// anything but the values), and the k best are written out in rank order with what the caller wants of them.
+constexpr int kRankMaxSeeds = 1024;
+
+__device__ __forceinline__ int rank_of(const float *s_cost, int S, int i) {
+  const float ci = s_cost[i];
+  int r = 0;
+  for (int j = 0; j < S; j++) {
+    const float cj = s_cost[j];
+    r += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+  }
+  return r;
+}
+
+struct SeedSelectArgs {
+  uint8_t *out_success;
+  float *out_solution, *out_pos, *out_ori;
+  const float *q, *pos_err, *ori_err, *lim_lo, *lim_hi, *current_position;
+  float pos_tol, ori_tol, cspace_w;
+  int P, S, D, k, check_limits;
+};
+
+// reference SeedIKSolver._select_top_solutions (seed_ik_solver.py:522-572)
+__global__ void __launch_bounds__(256) seed_ik_select_kernel(const SeedSelectArgs a) {
+  __shared__ float s_cost[kRankMaxSeeds];
+  __shared__ uint8_t s_ok[kRankMaxSeeds];
+  const int p = blockIdx.x, S = a.S, D = a.D;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const size_t e = (size_t)p * S + i;
+    const float pe = a.pos_err[e], oe = a.ori_err[e];
+    bool ok = pe < a.pos_tol && oe < a.ori_tol;
+    float dist2 = 0.0f;
+    for (int d = 0; d < D; d++) {
+      const float x = a.q[e * D + d];
+      if (a.check_limits) ok = ok && x > a.lim_lo[d] && x < a.lim_hi[d];
+      if (a.current_position) { const float df = x - a.current_position[(size_t)p * D + d]; dist2 += df * df; }
+    }
+    float c = pe + oe;
+    if (a.current_position && a.cspace_w > 0.0f) c = c + a.cspace_w * sqrtf(dist2);
+    c = c + 1e10f * (ok ? 0.0f : 1.0f);
+    s_cost[i] = c == c ? c : __builtin_inff();
+    s_ok[i] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const int r = rank_of(s_cost, S, i);
+    if (r < a.k) {
+      const size_t e = (size_t)p * S + i, o = (size_t)p * a.k + r;
+      a.out_success[o] = s_ok[i];
+      a.out_pos[o] = a.pos_err[e];
+      a.out_ori[o] = a.ori_err[e];
+      for (int d = 0; d < D; d++) a.out_solution[o * D + d] = a.q[e * D + d];
+    }
+  }
+}
+
+struct IkRankArgs {
+  uint8_t *out_success;
+  float *out_solution, *out_pos, *out_rot, *out_cost;
+  int64_t *out_seed, *out_goalset;
+  const float *q, *cost, *pos_dist, *rot_dist, *self_dist, *cspace_cost, *scene_dist;
+  const int32_t *goalset_idx;
+  float pos_thr, rot_thr;
+  int P, S, D, T, n_scene, k;
+  int64_t seed_offset;
+};
+
+// reference IKSolver._get_result ranking (solver_ik.py:440-580): feasible = no self collision, no joint-limit
+// cost, no scene collision; success = feasible and within the pose thresholds; ranked by cost + 1e16 (not success)
+__global__ void __launch_bounds__(256) ik_rank_kernel(const IkRankArgs a) {
+  __shared__ float s_cost[kRankMaxSeeds];
+  __shared__ uint8_t s_ok[kRankMaxSeeds];
+  const int p = blockIdx.x, S = a.S, D = a.D, T = a.T;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const size_t e = (size_t)p * S + i;
+    float cs = 0.0f;
+    for (int d = 0; d < D; d++) cs += a.cspace_cost[e * D + d];
+    bool ok = a.self_dist[e] <= 0.0f && cs <= 0.0f;
+    if (a.scene_dist) {
+      float sc = 0.0f;
+      for (int j = 0; j < a.n_scene; j++) sc += a.scene_dist[e * a.n_scene + j];
+      ok = ok && sc <= 0.0f;
+    }
+    ok = ok && a.pos_dist[e * T] < a.pos_thr && a.rot_dist[e * T] < a.rot_thr;
+    const float c = a.cost[e] + 1e16f * (ok ? 0.0f : 1.0f);
+    s_cost[i] = c == c ? c : __builtin_inff();
+    s_ok[i] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const int r = rank_of(s_cost, S, i);
+    if (r < a.k) {
+      const size_t e = (size_t)p * S + i, o = (size_t)p * a.k + r;
+      a.out_success[o] = s_ok[i];
+      a.out_pos[o] = a.pos_dist[e * T];
+      a.out_rot[o] = a.rot_dist[e * T];
+      a.out_cost[o] = a.cost[e];
+      a.out_seed[o] = a.seed_offset + i;
+      a.out_goalset[o] = a.goalset_idx ? (int64_t)a.goalset_idx[e * T] : 0;
+      for (int d = 0; d < D; d++) a.out_solution[o * D + d] = a.q[e * D + d];
+    }
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -622,4 +730,44 @@ CUROBO_EXPORT int curobo_hip_seed_ik_batch_status(const uint8_t *success, int nu
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(seed_ik_batch_status_kernel, dim3(1), dim3(256), 0, st, success, num_problems, num_seeds, needed, stop_flag);
   return check_launch("seed_ik_batch_status", st);
+}
+
+CUROBO_EXPORT int curobo_hip_seed_ik_select(
+    uint8_t *out_success, float *out_solution, float *out_position_error, float *out_orientation_error,
+    const float *joint_position, const float *position_error, const float *orientation_error, const float *limit_lower,
+    const float *limit_upper, const float *current_position, float position_tolerance, float orientation_tolerance,
+    float start_cspace_dist_weight, int check_limits, int num_problems, int num_seeds, int dof, int return_seeds,
+    curobo_hip_stream_t stream) {
+  const char *what = "seed_ik_select";
+  CUROBO_REQUIRE(num_problems >= 0 && num_seeds >= 1 && num_seeds <= kRankMaxSeeds && dof >= 1 && return_seeds >= 1 &&
+                     return_seeds <= num_seeds, "%s: bad sizes (P=%d, S=%d (<= 1024), D=%d, k=%d)", what, num_problems, num_seeds, dof, return_seeds);
+  CUROBO_REQUIRE(!check_limits || (limit_lower && limit_upper), "%s: check_limits needs the limits", what);
+  if (num_problems == 0) return CUROBO_HIP_OK;
+  SeedSelectArgs a{out_success, out_solution, out_position_error, out_orientation_error, joint_position, position_error,
+                   orientation_error, limit_lower, limit_upper, current_position, position_tolerance, orientation_tolerance,
+                   start_cspace_dist_weight, num_problems, num_seeds, dof, return_seeds, check_limits};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(seed_ik_select_kernel, dim3(num_problems), dim3(256), 0, st, a);
+  return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_ik_rank(
+    uint8_t *out_success, float *out_solution, float *out_position_error, float *out_rotation_error, float *out_cost,
+    int64_t *out_seed_index, int64_t *out_goalset_index, const float *joint_position, const float *cost,
+    const float *position_distance, const float *rotation_distance, const float *self_collision_distance,
+    const float *cspace_cost, const float *scene_distance, const int32_t *goalset_idx, float position_threshold,
+    float rotation_threshold, int num_problems, int num_seeds, int dof, int num_tool_frames, int num_scene_columns,
+    int return_seeds, int seed_offset, curobo_hip_stream_t stream) {
+  const char *what = "ik_rank";
+  CUROBO_REQUIRE(num_problems >= 0 && num_seeds >= 1 && num_seeds <= kRankMaxSeeds && dof >= 1 && num_tool_frames >= 1 &&
+                     return_seeds >= 1 && return_seeds <= num_seeds,
+                 "%s: bad sizes (P=%d, S=%d (<= 1024), D=%d, T=%d, k=%d)", what, num_problems, num_seeds, dof, num_tool_frames, return_seeds);
+  if (num_problems == 0) return CUROBO_HIP_OK;
+  IkRankArgs a{out_success, out_solution, out_position_error, out_rotation_error, out_cost, out_seed_index, out_goalset_index,
+               joint_position, cost, position_distance, rotation_distance, self_collision_distance, cspace_cost,
+               scene_distance, goalset_idx, position_threshold, rotation_threshold, num_problems, num_seeds, dof,
+               num_tool_frames, num_scene_columns, return_seeds, seed_offset};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ik_rank_kernel, dim3(num_problems), dim3(256), 0, st, a);
+  return check_launch(what, st);
 }

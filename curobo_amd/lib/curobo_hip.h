@@ -348,6 +348,27 @@ int curobo_hip_seed_ik_iterate(
 int curobo_hip_seed_ik_batch_status(const uint8_t *success, int num_problems, int num_seeds, int needed,
                                     int32_t *stop_flag, curobo_hip_stream_t stream);
 
+/* Ranking of the seeds of every problem in one launch (ties -> lower seed index: the order of a stable sort).
+ * curobo_hip_seed_ik_select: reference SeedIKSolver._select_top_solutions (seed_ik_solver.py:522-572): success =
+ * position / orientation error under the tolerances (and strictly inside the limits), cost = position + orientation
+ * error (+ start_cspace_dist_weight |q - current_position|) + 1e10 for failures; the return_seeds best, best first.
+ * curobo_hip_ik_rank: reference IKSolver._get_result (solver_ik.py:440-580): feasible = no self collision, no
+ * joint-limit cost, no scene collision (scene_distance [P, S, num_scene_columns], NULL = no scene), success = feasible
+ * and first tool frame within the thresholds, ranked by cost + 1e16 for failures.  num_seeds <= 1024. */
+int curobo_hip_seed_ik_select(
+    uint8_t *out_success, float *out_solution, float *out_position_error, float *out_orientation_error,
+    const float *joint_position, const float *position_error, const float *orientation_error, const float *limit_lower,
+    const float *limit_upper, const float *current_position, float position_tolerance, float orientation_tolerance,
+    float start_cspace_dist_weight, int check_limits, int num_problems, int num_seeds, int dof, int return_seeds,
+    curobo_hip_stream_t stream);
+int curobo_hip_ik_rank(
+    uint8_t *out_success, float *out_solution, float *out_position_error, float *out_rotation_error, float *out_cost,
+    int64_t *out_seed_index, int64_t *out_goalset_index, const float *joint_position, const float *cost,
+    const float *position_distance, const float *rotation_distance, const float *self_collision_distance,
+    const float *cspace_cost, const float *scene_distance, const int32_t *goalset_idx, float position_threshold,
+    float rotation_threshold, int num_problems, int num_seeds, int dof, int num_tool_frames, int num_scene_columns,
+    int return_seeds, int seed_offset, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- optimization: MPPI update
  * reference: optim/particle/mppi.py:201-313 + jit helpers :615-757 (pure torch, DIAG_A
  * covariance).  costs [problems, particles, cost_horizon] (cost_horizon may be 1 for totals),

@@ -201,6 +201,25 @@ class IKSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         m = self.metrics_rollout
         cost = m.evaluate(q.view(P * S, 1, D), with_gradient=False)
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) and S <= 1024 and return_seeds <= S:
+            # alone in the process: feasibility, success and the ranked winners in one launch (the winner exchange
+            # below is only needed across ranks)
+            from ..backends import linalg as linalg_hip
+
+            k, dev = return_seeds, self.device
+            ok_o = torch.empty(P, k, dtype=torch.uint8, device=dev)
+            sol_o = torch.empty(P, k, D, device=dev)
+            pe_o, re_o, c_o = (torch.empty(P, k, device=dev) for _ in range(3))
+            si_o, gi_o = (torch.empty(P, k, dtype=torch.int64, device=dev) for _ in range(2))
+            linalg_hip.ik_rank(ok_o, sol_o, pe_o, re_o, c_o, si_o, gi_o, q.view(P * S, D), cost.view(P * S), m.pose_pos_dist.view(P * S, T),
+                               m.pose_rot_dist.view(P * S, T), m.self_dist.view(P * S), m.cspace_cost.view(P * S, D),
+                               m.scene_dist if self.scene is not None else None, m.goalset_idx.view(P * S, T),
+                               self.cfg.position_threshold, self.cfg.rotation_threshold, P, S, k, self.seed_offset)
+            sq = (lambda x: x) if k > 1 else (lambda x: x[:, 0])  # noqa: E731
+            return IKResult(success=sq(ok_o.bool()), solution=sq(sol_o), position_error=sq(pe_o), rotation_error=sq(re_o),
+                            cost=sq(c_o), seed_index=sq(si_o), goalset_index=sq(gi_o))
         pos_err = m.pose_pos_dist.view(P, S, T)[..., 0]
         rot_err = m.pose_rot_dist.view(P, S, T)[..., 0]
         feasible = (m.self_dist.view(P, S) <= 0.0) & (m.cspace_cost.view(P, S, D).sum(-1) <= 0.0)

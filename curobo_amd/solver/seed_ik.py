@@ -340,6 +340,18 @@ class SeedIKSolver:
                 if int(solved) >= c.batch_success_threshold * P:
                     break
         self._last_outer = it
+        if S <= 1024 and return_seeds <= S:  # one launch instead of ~20 torch kernels (masks, top-k, gathers)
+            dev = self.device
+            ok_o = torch.empty(P, return_seeds, dtype=torch.uint8, device=dev)
+            sol_o = torch.empty(P, return_seeds, D, device=dev)
+            pos_o, ori_o = torch.empty(P, return_seeds, device=dev), torch.empty(P, return_seeds, device=dev)
+            cur = None
+            if c.start_cspace_dist_weight > 0 and current_position is not None:
+                cur = current_position.to(dev, torch.float32).reshape(P, D).contiguous()
+            linalg_hip.seed_ik_select(ok_o, sol_o, pos_o, ori_o, self.q.view(P, S, D), self.position_error, self.orientation_error,
+                                      self._limits[0], self._limits[1], cur, c.position_tolerance, c.orientation_tolerance,
+                                      c.start_cspace_dist_weight, c.joint_limit_weight > 0, return_seeds)
+            return ok_o.bool(), sol_o, pos_o, ori_o
         pos, ori = self.position_error.view(P, S), self.orientation_error.view(P, S)
         q = self.q.view(P, S, D)
         ok = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)
