@@ -69,9 +69,10 @@ struct SeedIkRow {
 
 // The update of problem p by its 16-lane row.  Rows beyond n keep running (DPP row reductions need all lanes of a
 // wave) with p clamped and live = false: no stores.
+template <int DT = 0, int TT = 0>
 __device__ __forceinline__ void seed_ik_update_row(const SeedIkUpdateArgs &a, const SeedIkRow &v, int p, bool live, int lane,
                                                    bool initial) {
-  const int D = a.D, T = a.T;
+  const int D = DT > 0 ? DT : a.D, T = TT > 0 ? TT : a.T;
   const float *cq = v.cq;
 
   // ---- joint-limit residual of the candidate: error, diagonal Jacobian, J^T e contribution
@@ -404,38 +405,34 @@ __global__ void __launch_bounds__(256, 4) seed_ik_solve_kernel(const SeedIkSolve
       fk_chain_16_multi<1>(cm, lc, s_parent, a.fixed_transform, L, lane);  // (four links' operands per LDS round trip)
     }
     SEED_ROW_SYNC();
-    // ---- tool-frame Jacobian columns (kinematics_forward_kernel.cuh:45-200), one joint per lane
+    // ---- tool-frame Jacobian columns (kinematics_forward_kernel.cuh:45-200): column j = sum over the links of joint j
+    // that lie on the tool's chain (link 0 excluded), so a lane takes a chain entry and adds to its joint's column
+    for (int i = lane; i < 6 * T * D; i += kRow) scJ[i] = 0.0f;
+    SEED_ROW_SYNC();
     for (int t = 0; t < T; t++) {
       const int tl = a.tool_frame_map[t];
       const float *E = cumul + tl * 12;
       const f3 ee = make_f3(E[3], E[7], E[11]);
-      const int cs = a.link_chain_offsets[tl], ce = a.link_chain_offsets[tl + 1];
-      for (int j = lane; j < D; j += kRow) {
-        float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (a.joint_affects_endeffector[j * T + t]) {
-          for (int jl = a.joint_links_offsets[j]; jl < a.joint_links_offsets[j + 1]; jl++) {
-            const int li = a.joint_links_data[jl];
-            if (li == 0) continue;
-            bool in_chain = false;
-            for (int ci = cs; ci < ce; ci++) in_chain |= (a.link_chain_data[ci] == li);
-            if (!in_chain) continue;
-            const float *C = cumul + li * 12;
-            const int jt = a.joint_map_type[li];
-            const float sign = a.joint_offset[li * 2];
-            if (jt >= J_X_ROT) {
-              const int ax = jt - J_X_ROT;
-              const f3 axis = sign * make_f3(C[ax], C[4 + ax], C[8 + ax]);
-              const f3 lin = cross(axis, ee - make_f3(C[3], C[7], C[11]));
-              col[0] += lin.x; col[1] += lin.y; col[2] += lin.z;
-              col[3] += axis.x; col[4] += axis.y; col[5] += axis.z;
-            } else if (jt >= J_X_PRISM) {
-              const int ax = jt - J_X_PRISM;
-              col[0] += sign * C[ax]; col[1] += sign * C[4 + ax]; col[2] += sign * C[8 + ax];
-            }
-          }
+      const int cs = s_choff[tl], ce = s_choff[tl + 1];
+      for (int ci = cs + lane; ci < ce; ci += kRow) {
+        const int li = s_chain[ci];
+        const int info = s_info[li];
+        const int jt = (info & 0xff) - 1;
+        if (li == 0 || jt < J_X_PRISM) continue;
+        const int j = info >> 8;
+        const float *C = cumul + li * 12;
+        const float sign = s_sign[li];
+        float *col = scJ + (t * 6) * D + j;
+        if (jt >= J_X_ROT) {
+          const int ax = jt - J_X_ROT;
+          const f3 axis = sign * make_f3(C[ax], C[4 + ax], C[8 + ax]);
+          const f3 lin = cross(axis, ee - make_f3(C[3], C[7], C[11]));
+          atomicAdd(col, lin.x); atomicAdd(col + D, lin.y); atomicAdd(col + 2 * D, lin.z);
+          atomicAdd(col + 3 * D, axis.x); atomicAdd(col + 4 * D, axis.y); atomicAdd(col + 5 * D, axis.z);
+        } else {
+          const int ax = jt - J_X_PRISM;
+          atomicAdd(col, sign * C[ax]); atomicAdd(col + D, sign * C[4 + ax]); atomicAdd(col + 2 * D, sign * C[8 + ax]);
         }
-#pragma unroll
-        for (int r = 0; r < 6; r++) scJ[(t * 6 + r) * D + j] = col[r];
       }
     }
     // ---- tool-pose error (wp_tool_pose.py:456-692), one tool frame per lane
@@ -480,7 +477,7 @@ __global__ void __launch_bounds__(256, 4) seed_ik_solve_kernel(const SeedIkSolve
     }
     SEED_ROW_SYNC();
     // ---- trust ratio, acceptance, damping, state selection, convergence (seed_iteration_state_manager.py:74-260)
-    seed_ik_update_row(u, v, p, true, lane, initial);
+    seed_ik_update_row<DT, TT>(u, v, p, true, lane, initial);
     SEED_ROW_SYNC();
   }
   // ---- state out
