@@ -40,6 +40,7 @@ struct SeedIkUpdateArgs {
 };
 
 constexpr int kRow = 16;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // velocity / acceleration residuals of dof d: squared Jacobian diagonal, J^T r and squared error
 __device__ __forceinline__ void vel_acc_rows(const SeedIkUpdateArgs &a, int p, int d, float x, float &diag2, float &jtr, float &err2) {
@@ -213,8 +214,8 @@ __global__ void __launch_bounds__(256) seed_ik_update_kernel(const SeedIkUpdateA
 // accepted Jacobian [6T + D][D], the normal matrix, q, J^T e, the 13 link transforms of the candidate -- and
 // the row runs `iterations` iterations back to back; global memory sees the state once on the way in and once
 // on the way out.  Same arithmetic per stage as the stand-alone kernels (shared device functions:
-// fk_chain_16, tool_pose_distance_point, seed_ik_update_row), except J^T J, which the stand-alone LM step
-// contracts on the matrix cores (one wavefront per problem) and a row contracts with 13 FMAs per entry.
+// fk_chain_16, tool_pose_distance_point, seed_ik_update_row); J^T J is contracted on the matrix cores here too
+// (a wavefront takes the Jacobians of its four rows in turn), the D x D system is then solved in registers.
 struct SeedIkSolveArgs {
   SeedIkUpdateArgs u;  // state pointers and parameters (u.cand_q = the seeds when u.initial; other u.cand_* unused)
   ToolPoseArgs tp;     // goal set, weights (current_* / out_* unused)
@@ -296,15 +297,30 @@ __global__ void __launch_bounds__(256, 4) seed_ik_solve_kernel(const SeedIkSolve
     } else {
       // ---- LM step: A = J^T J + lambda I, Cholesky, two triangular solves (levenberg_marquardt_step.py:146-199)
       const float lam = scal[3];
+      // J^T J on the matrix cores, as in the stand-alone LM step (linalg.hip): the wavefront contracts the Jacobians of
+      // its four rows one after the other with v_mfma_f32_16x16x4_f32 (A and B operand are the same register: both are
+      // 4 rows of J), lane (kk, col) feeding J[k0 + kk][col]; the D x D corner of the 16 x 16 result goes to that
+      // row's normal matrix.  Same accumulation order as the stand-alone kernel: identical J^T J.
+      {
+        const int lane64 = tid & 63, kk = lane64 >> 4, col = lane64 & 15;
+        const size_t row_stride = (size_t)((seed_ik_row_floats(D, T, L) + 3) & ~3);
+        float *wave_base = base - (size_t)(rowi & 3) * row_stride;  // row 0 of this wavefront
 #pragma unroll
-      for (int e = lane; e < D * D; e += kRow) {  // J^T J, entries spread over the lanes
-        const int i = e / D, j = e - i * D;
-        float acc = 0.0f;
+        for (int rr = 0; rr < 4; rr++) {
+          const float *Jr = wave_base + rr * row_stride;
+          float *Ar = wave_base + rr * row_stride + R * D;
+          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+          for (int k0 = 0; k0 < R; k0 += 4) {
+            const int r = k0 + kk;
+            const float x = (r < R && col < D) ? Jr[r * D + col] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, acc, 0, 0, 0);
+          }
 #pragma unroll
-        for (int r = 0; r < (DT > 0 && TT > 0 ? 6 * TT + DT : 1); r++) acc = __builtin_fmaf(sJ[r * D + i], sJ[r * D + j], acc);
-        if (!(DT > 0 && TT > 0))
-          for (int r = 1; r < R; r++) acc = __builtin_fmaf(sJ[r * D + i], sJ[r * D + j], acc);
-        sA[i * LD + j] = acc;
+          for (int reg = 0; reg < 4; reg++) {  // C layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+            const int ri = kk * 4 + reg;
+            if (ri < D && col < D) Ar[ri * LD + col] = acc[reg];
+          }
+        }
       }
       SEED_ROW_SYNC();
       const int i = lane;
