@@ -315,3 +315,62 @@ def test_velocity_and_acceleration_residual_rows(oracle, device):
         if w == 0.0:
             assert float(r.success[:, 0].float().mean()) >= 0.6
     assert dist[0.5] < 0.9 * dist[0.0], dist
+
+
+def test_seed_selection_and_ik_ranking_kernels(device):
+    """curobo_hip_seed_ik_select / curobo_hip_ik_rank against the torch formulation of the reference's selection
+    (seed_ik_solver.py:522-572, solver_ik.py:440-580) on random data with ties: exact indices (ties -> lower index)"""
+    from curobo_amd.backends import linalg
+
+    rng = np.random.default_rng(5)
+    P, S, D, T, k = 37, 96, 7, 2, 11
+    lo, hi = -np.ones(D, np.float32), np.ones(D, np.float32)
+    q = rng.uniform(-1.1, 1.1, size=(P, S, D)).astype(np.float32)
+    pos = rng.choice([0.001, 0.002, 0.004, 0.02], size=(P, S)).astype(np.float32)  # few distinct values: many ties
+    ori = rng.choice([0.01, 0.03, 0.2], size=(P, S)).astype(np.float32)
+    cur = rng.uniform(-1, 1, size=(P, D)).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    for use_cur in (False, True):
+        ok = (pos < 0.005) & (ori < 0.05) & ((q > lo) & (q < hi)).all(-1)
+        cost = pos + ori
+        if use_cur:
+            cost = cost + np.float32(0.01) * np.linalg.norm(q - cur[:, None], axis=-1).astype(np.float32)
+        cost = cost + np.float32(1e10) * (~ok).astype(np.float32)
+        order = np.argsort(cost, axis=1, kind="stable")[:, :k]
+        o_ok = torch.zeros(P, k, dtype=torch.uint8, device=device)
+        o_sol, o_pos, o_ori = torch.zeros(P, k, D, device=device), torch.zeros(P, k, device=device), torch.zeros(P, k, device=device)
+        linalg.seed_ik_select(o_ok, o_sol, o_pos, o_ori, t(q), t(pos), t(ori), t(lo), t(hi), t(cur) if use_cur else None,
+                              0.005, 0.05, 0.01, True, k)
+        torch.cuda.synchronize()
+        ar = np.arange(P)[:, None]
+        if not use_cur:  # (with the distance term the costs are distinct up to rounding of the norm: compare values)
+            np.testing.assert_array_equal(o_sol.cpu().numpy(), q[ar, order])
+        np.testing.assert_array_equal(o_ok.cpu().numpy().astype(bool), ok[ar, order])
+        np.testing.assert_array_equal(o_pos.cpu().numpy(), pos[ar, order])
+    # ---- IK ranking
+    n_sc = 9
+    cst = rng.choice([1.0, 2.0, 3.5], size=(P, S)).astype(np.float32)
+    pd = np.repeat(pos[..., None], T, -1).copy()
+    rd = np.repeat(ori[..., None], T, -1).copy()
+    selfd = (rng.random((P, S)) < 0.1).astype(np.float32) * 0.3
+    csp = (rng.random((P, S, D)) < 0.02).astype(np.float32)
+    scd = (rng.random((P, S, n_sc)) < 0.01).astype(np.float32) * 0.1
+    gidx = rng.integers(0, 3, size=(P, S, T)).astype(np.int32)
+    ok = (selfd <= 0) & (csp.sum(-1) <= 0) & (scd.sum(-1) <= 0) & (pos < 0.005) & (ori < 0.05)
+    ranked = cst + np.float32(1e16) * (~ok).astype(np.float32)
+    order = np.argsort(ranked, axis=1, kind="stable")[:, :k]
+    o_ok = torch.zeros(P, k, dtype=torch.uint8, device=device)
+    o_sol = torch.zeros(P, k, D, device=device)
+    o_pe, o_re, o_c = (torch.zeros(P, k, device=device) for _ in range(3))
+    o_si, o_gi = (torch.zeros(P, k, dtype=torch.int64, device=device) for _ in range(2))
+    linalg.ik_rank(o_ok, o_sol, o_pe, o_re, o_c, o_si, o_gi, t(q).view(P * S, D), t(cst).view(-1), t(pd).view(P * S, T),
+                   t(rd).view(P * S, T), t(selfd).view(-1), t(csp).view(P * S, D), t(scd), t(gidx).view(P * S, T), 0.005, 0.05,
+                   P, S, k, 1000)
+    torch.cuda.synchronize()
+    ar = np.arange(P)[:, None]
+    np.testing.assert_array_equal(o_si.cpu().numpy(), order + 1000)
+    np.testing.assert_array_equal(o_ok.cpu().numpy().astype(bool), ok[ar, order])
+    np.testing.assert_array_equal(o_sol.cpu().numpy(), q[ar, order])
+    np.testing.assert_array_equal(o_c.cpu().numpy(), cst[ar, order])
+    np.testing.assert_array_equal(o_gi.cpu().numpy(), gidx[ar, order, 0])
+    assert ok.any(1).mean() > 0.5 and (~ok).any()
