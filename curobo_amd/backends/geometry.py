@@ -17,8 +17,8 @@ DENSE_MIN_PAIRS, DENSE_MIN_DENSITY = 8192, 0.25
 _bitmap_cache: Dict[Tuple[int, int, int, str], Optional[Tuple[torch.Tensor, int]]] = {}
 
 
-def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[torch.Tensor, int]]:
-    """(bitmap uint32 [2 * nslots, nslots * 64] on the pairs' device, nslots) for
+def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[torch.Tensor, int, torch.Tensor]]:
+    """(bitmap uint32 [2 * nslots, nslots * 64] on the pairs' device, nslots, tile list int32) for
     ``curobo_hip_self_collision_distance_dense`` -- bit jj of bitmap[jb, i] <-> pair (i, 32 * jb + jj) -- or ``None``
     when the list is not (i, j)-sorted with i < j (then "lowest pair index" is not the lexicographic order the
     dense kernel resolves ties by).  Built once per pair tensor (one host read-back: call outside graph capture)."""
@@ -33,7 +33,11 @@ def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[t
         nslots = 4 * ((nspheres + 255) // 256)
         bm = np.zeros((2 * nslots, nslots * 64), np.uint32)
         np.bitwise_or.at(bm, (j // 32, i), (np.uint32(1) << (j % 32).astype(np.uint32)))
-        res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots)
+        # the 16 x 16 tiles of the pair matrix that hold an enabled pair, (i / 16) | (j / 16) << 8, in (ib, jb) order
+        tkey = np.unique((i // 16) * 256 + (j // 16))
+        tiles = ((tkey // 256) | ((tkey % 256) << 8)).astype(np.int32)
+        res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots,
+               torch.as_tensor(tiles).to(pair_locations.device).contiguous())
     _bitmap_cache[key] = res
     return res
 
@@ -65,7 +69,8 @@ def self_collision_distance(
         if bm is not None:
             check(load().curobo_hip_self_collision_distance_dense(
                 ptr(out_distance), ptr(out_vec), ptr(sparse_index), ptr(robot_spheres), ptr(sphere_padding), ptr(weight),
-                ptr(bm[0]), batch_size, horizon, nspheres, bm[1], int(compute_grad), current_stream(out_distance)))
+                ptr(bm[0]), ptr(bm[2]), int(bm[2].shape[0]), batch_size, horizon, nspheres, bm[1], int(compute_grad),
+                current_stream(out_distance)))
             return
     check(load().curobo_hip_self_collision_distance(
         ptr(out_distance), ptr(out_vec), ptr(pair_distance), ptr(sparse_index), ptr(robot_spheres),

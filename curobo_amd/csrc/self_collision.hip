@@ -376,6 +376,143 @@ __global__ void __launch_bounds__(256) self_collision_dense_kernel(const SelfDen
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same pair set with a BROAD PHASE in front.  The spheres of a robot file come link by link, so 16 consecutive
+// spheres sit close together: per point, every 16-sphere block gets an axis-aligned box (centres +- radii), and a
+// 16 x 16 tile of the pair matrix is only evaluated when the boxes of its two blocks overlap -- otherwise no pair of
+// it can penetrate, and only positive penetrations count (result preserving).  For a humanoid in a typical pose one
+// in seven of the tiles that hold enabled pairs survives (Unitree G1: 107 of 763; 32 x 32 tiles: 63 of 224 = twice
+// the pair tests).  `tiles` = the (ib | jb << 8) list of tiles with at least one enabled pair (built once per robot
+// next to the bitmap).  A wavefront owns a point; the surviving tiles are compacted and taken four at a time, one per
+// 16-lane row: lane (row, li) keeps sphere i = 16 ib + li in registers and streams the 16 spheres of block jb from LDS.
+constexpr int kTile = 16;
+struct SelfTilesArgs {
+  SelfDenseArgs d;
+  const int32_t *tiles;
+  int n_tiles;
+};
+
+__device__ __forceinline__ float pair_pen(float4 o, float4 sj) {
+  const float dx = o.x - sj.x, dy = o.y - sj.y, dz = o.z - sj.z, rr = o.w + sj.w;
+  return rr * rr - (dx * dx + dy * dy + dz * dz);
+}
+
+__global__ void __launch_bounds__(256) self_collision_tiles_kernel(const SelfTilesArgs t) {
+  const SelfDenseArgs &a = t.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.nspheres, NS = a.nslots, SL = NS * 64, NB = SL / kTile;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const size_t wave_floats = (size_t)SL * 4 + (size_t)NB * 8 + (size_t)((t.n_tiles + 3) & ~3);
+  float4 *sph = reinterpret_cast<float4 *>(smem + wave * wave_floats);
+  float *box = reinterpret_cast<float *>(sph + SL);       // [NB][8]: lo xyz, -, hi xyz, -
+  int *kept = reinterpret_cast<int *>(box + NB * 8);      // surviving tiles
+  const int n = blockIdx.x * (blockDim.x / kWave) + wave;
+  if (n >= a.n_points) return;  // waves are independent: only wave-level fences below
+  const float qnan = __builtin_nanf("");
+  const int row = lane >> 4, li = lane & 15;
+  {  // spheres (+ padding) -> LDS, stale gradient rows cleared (as the other kernels), block boxes on the way
+    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
+    for (int sl = 0; sl < NS; sl++) {
+      const int s = sl * 64 + lane;
+      float4 v = make_float4(0.f, 0.f, 0.f, qnan);
+      if (s < S) {
+        v = src[s];
+        v.w += a.offsets[s];
+        if (!(v.w >= 0.0f)) v.w = qnan;
+        if (a.sparse_index[(size_t)n * S + s]) {
+          reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a.sparse_index[(size_t)n * S + s] = 0;
+        }
+      }
+      sph[s] = v;
+      const bool on = v.w == v.w;  // disabled / padding spheres: an empty box
+      const float big = 3.0e38f;
+      const float lx = -row16_max(on ? v.w - v.x : -big), ly = -row16_max(on ? v.w - v.y : -big), lz = -row16_max(on ? v.w - v.z : -big);
+      const float hx = row16_max(on ? v.x + v.w : -big), hy = row16_max(on ? v.y + v.w : -big), hz = row16_max(on ? v.z + v.w : -big);
+      if (li == 0) {
+        float *b = box + (sl * 4 + row) * 8;
+        b[0] = lx; b[1] = ly; b[2] = lz; b[4] = hx; b[5] = hy; b[6] = hz;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- broad phase: tiles whose block boxes overlap, compacted in list order
+  int count = 0;
+  for (int c0 = 0; c0 < t.n_tiles; c0 += kWave) {
+    const int c = c0 + lane;
+    bool keep = false;
+    int tl = 0;
+    if (c < t.n_tiles) {
+      tl = t.tiles[c];
+      const float *bi = box + (tl & 0xff) * 8, *bj = box + (tl >> 8) * 8;
+      keep = bi[0] <= bj[4] && bj[0] <= bi[4] && bi[1] <= bj[5] && bj[1] <= bi[5] && bi[2] <= bj[6] && bj[2] <= bi[6];
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) kept[count + __popcll(m & ((1ull << lane) - 1ull))] = tl;
+    count += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- narrow phase: four tiles per round, one per 16-lane row
+  float bv = 0.0f;
+  int bkey = 0x7fffffff;
+  for (int t0 = 0; t0 < count; t0 += 4) {
+    const bool has = t0 + row < count;
+    const int tl = kept[has ? t0 + row : t0];
+    const int ib = tl & 0xff, jb = tl >> 8;
+    const int i = ib * kTile + li;
+    const float4 own = sph[i];
+    // bit jj of bitmap[j / 32][i] <-> pair (i, j): the 16 bits of this tile's j block
+    const uint32_t word = has ? (a.bitmap[(size_t)(jb >> 1) * SL + i] >> ((jb & 1) * 16)) & 0xffffu : 0u;
+    if (__ballot(word != 0u) == 0ull) continue;
+    const float4 *sj = sph + jb * kTile;
+    float tm = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < kTile; jj++) tm = fmaxf(tm, mask_f(pair_pen(own, sj[jj]), word, jj));
+    if (tm > 0.0f && tm >= bv) {  // the lane's best so far, or a tie with it: the first j of this tile that attains the
+      // maximum.  Value and index come from THIS loop (the unrolled loop above may contract the products differently,
+      // so an equality test against its maximum can fail by an ulp)
+      float tv = 0.0f;
+      int jf = 0;
+#pragma unroll 1
+      for (int jj = 0; jj < kTile; jj++) {
+        const float v = mask_f(pair_pen(own, sj[jj]), word, jj);
+        if (v > tv) { tv = v; jf = jj; }
+      }
+      if (tv > 0.0f && tv >= bv) {
+        const int key = (i << 10) | (jb * kTile + jf);
+        if (tv > bv || key < bkey) bkey = key;
+        bv = tv;
+      }
+    }
+  }
+  // ---- arg-max over the wave: largest penetration, then the lexicographically first (i, j)
+  float m = bv;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  int key = (m > 0.0f && bv == m) ? bkey : 0x7fffffff;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, kWave));
+  if (lane != 0) return;
+  if (!(m > 0.0f) || key == 0x7fffffff) {
+    a.out_distance[n] = 0.0f;
+    return;
+  }
+  const float wgt = a.weight[0];
+  a.out_distance[n] = 0.5f * wgt * m;
+  if (a.write_grad) {
+    const int i = key >> 10, j = key & 1023;
+    const float4 s1 = sph[i], s2 = sph[j];
+    const float vx = wgt * (s2.x - s1.x), vy = wgt * (s2.y - s1.y), vz = wgt * (s2.z - s1.z);
+    float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
+    g[i] = make_float4(vx, vy, vz, wgt * -1.0f);
+    g[j] = make_float4(-1.0f * vx, -1.0f * vy, -1.0f * vz, wgt * -1.0f);
+    a.sparse_index[(size_t)n * S + i] = 1;
+    a.sparse_index[(size_t)n * S + j] = 1;
+  }
+}
+
 template <int NWAVES>
 static void launch_self(const SelfCollArgs &a, int blocks, size_t lds, int ppw, int tile, hipStream_t st) {
   if (a.store_pair_distance)
@@ -436,8 +573,8 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
 
 CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
     float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
-    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, int batch_size, int horizon,
-    int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream) {
+    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, const int32_t *tile_list, int num_tiles,
+    int batch_size, int horizon, int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream) {
   const char *what = "self_collision_distance_dense";
   CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 1024, "%s: nspheres=%d out of range [1,1024]", what, nspheres);
   CUROBO_REQUIRE(nslots >= 1 && nslots * 64 >= nspheres && nslots % 4 == 0 && nslots <= 16,
@@ -450,6 +587,22 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
   a.robot_spheres = robot_spheres; a.offsets = sphere_padding; a.weight = weight; a.bitmap = pair_bitmap;
   a.n_points = (int)n_points; a.nspheres = nspheres; a.nslots = nslots; a.write_grad = compute_grad;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_tiles = getenv("CUROBO_HIP_SELF_NO_BROAD_PHASE") != nullptr;
+  if (tile_list != nullptr && num_tiles > 0 && !no_tiles) {  // broad phase over 16 x 16 tiles
+    const size_t wave_bytes = ((size_t)nslots * 64 * 4 + (size_t)nslots * 4 * 8 + (size_t)((num_tiles + 3) & ~3)) * sizeof(float);
+    // one wavefront per workgroup for big robots: the CU then holds as many wavefronts as its LDS allows (G1: 9), not a
+    // multiple of a workgroup's
+    const int wv = wave_bytes >= 8 * 1024 ? 1 : 4;
+    CUROBO_REQUIRE(wave_bytes <= 64 * 1024, "%s: too many tiles / spheres for the LDS tiling", what);
+    SelfTilesArgs ta{a, tile_list, num_tiles};
+    static bool attr2 = false;
+    if (!attr2) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(self_collision_tiles_kernel, dim3((unsigned)ceil_div_l(n_points, wv)), dim3(wv * 64), wave_bytes * wv, st, ta);
+    return check_launch(what, st);
+  }
   const size_t lds_wave = (size_t)nslots * 64 * 16;
   const int waves = lds_wave * 4 <= 64 * 1024 ? 4 : (lds_wave * 2 <= 64 * 1024 ? 2 : 1);
   const size_t lds = lds_wave * waves;

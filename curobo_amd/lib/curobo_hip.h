@@ -118,11 +118,14 @@ int curobo_hip_self_collision_distance(
  * of pair_bitmap[jb][i] <-> pair (i, 32 * jb + jj) of pair_locations (i < j; the list must be (i, j)-sorted so
  * that "lowest pair index" = lexicographically first pair); nslots = multiple of 4 with nslots * 64 >= nspheres.
  * reference: self_collision_max_block_kernel + _max_reduce_kernel, self_collision_kernel.cuh:113-297.
+ * tile_list (optional, NULL = evaluate every tile): the 16 x 16 tiles of the pair matrix that hold an enabled pair, as
+ * (i / 16) | (j / 16) << 8; with it a tile is only evaluated when the bounding boxes of its two 16-sphere blocks overlap
+ * (result preserving: only positive penetrations count).
  */
 int curobo_hip_self_collision_distance_dense(
     float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
-    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, int batch_size, int horizon,
-    int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream);
+    const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, const int32_t *tile_list, int num_tiles,
+    int batch_size, int horizon, int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- collision: sphere vs scene
  * The reference has NO backend hook here: these are NVIDIA Warp kernels launched from
