@@ -67,7 +67,10 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   a.level_links = level_links; a.cache = forward_cache; a.f_ext = f_ext;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)ceil_div(batch_size, 256)), block(256);
+  // one element per lane and a strictly serial walk: the launch is latency bound, so small batches are spread one
+  // wavefront per workgroup over as many CUs as possible
+  const int bt = batch_size <= 128 * 1024 ? 64 : 256;
+  const dim3 grid((unsigned)ceil_div(batch_size, bt)), block(bt);
   if (f_ext) hipLaunchKernelGGL((rnea_forward_kernel<true>), grid, block, rnea_lds(num_links), st, a);
   else hipLaunchKernelGGL((rnea_forward_kernel<false>), grid, block, rnea_lds(num_links), st, a);
   return check_launch(what, st);
@@ -97,7 +100,8 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   a.ws_vbar = workspace + (size_t)num_links * 12 * batch_size;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)ceil_div(batch_size, 256)), block(256);
+  const int bt = batch_size <= 128 * 1024 ? 64 : 256;
+  const dim3 grid((unsigned)ceil_div(batch_size, bt)), block(bt);
   if (grad_f_ext) hipLaunchKernelGGL((rnea_backward_kernel<true>), grid, block, rnea_lds(num_links), st, a);
   else hipLaunchKernelGGL((rnea_backward_kernel<false>), grid, block, rnea_lds(num_links), st, a);
   return check_launch(what, st);
