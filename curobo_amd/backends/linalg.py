@@ -114,3 +114,10 @@ def ik_rank(out_success, out_solution, out_position_error, out_rotation_error, o
         ptr(rotation_distance), ptr(self_collision_distance), ptr(cspace_cost), ptr(scene_distance), ptr(goalset_idx),
         float(position_threshold), float(rotation_threshold), int(num_problems), int(num_seeds), d, t, int(n_scene),
         int(return_seeds), int(seed_offset), current_stream(joint_position)))
+
+
+def argmin_rows(out_rows, cost, payload, seed_offset: int):
+    """(min cost, global index of the first seed that attains it, its payload row) per problem (``curobo_hip_argmin_rows``)"""
+    p, s = cost.shape
+    check(load().curobo_hip_argmin_rows(ptr(out_rows), ptr(cost), ptr(payload), p, s, int(payload.shape[-1]), int(seed_offset),
+                                        current_stream(cost)))

@@ -639,6 +639,39 @@ __global__ void __launch_bounds__(256) ik_rank_kernel(const IkRankArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Arg-min over the seeds of a problem with its payload row, one launch: row[p] = (min cost, seed_offset + first index
+// that attains it, payload[p, index, :]).  The local stage of the seed-parallel arg-min exchange (reference single-GPU
+// equivalent: solver_ik.py:503-515, solver_trajopt.py:469-484); torch needs ~8 small kernels for it.
+__global__ void __launch_bounds__(256) argmin_rows_kernel(float *row, const float *cost, const float *payload, int S, int V,
+                                                          float seed_offset) {
+  __shared__ float s_c[4];
+  __shared__ int s_i[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  float bc = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int i = tid; i < S; i += blockDim.x) {
+    const float c = cost[(size_t)p * S + i];
+    if (c < bc || (c == bc && i < bi)) { bc = c; bi = i; }  // (NaN never wins; all-NaN rows fall through to index 0 below)
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const float oc = __shfl_xor(bc, off, kWave);
+    const int oi = __shfl_xor(bi, off, kWave);
+    if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+  }
+  if ((tid & (kWave - 1)) == 0) { s_c[tid / kWave] = bc; s_i[tid / kWave] = bi; }
+  __syncthreads();
+  bc = s_c[0]; bi = s_i[0];
+  for (int w = 1; w < (int)(blockDim.x / kWave); w++)
+    if (s_c[w] < bc || (s_c[w] == bc && s_i[w] < bi)) { bc = s_c[w]; bi = s_i[w]; }
+  if (bi == 0x7fffffff) { bi = 0; bc = cost[(size_t)p * S]; }
+  float *out = row + (size_t)p * (2 + V);
+  if (tid == 0) { out[0] = bc; out[1] = seed_offset + (float)bi; }
+  for (int v = tid; v < V; v += blockDim.x) out[2 + v] = payload[((size_t)p * S + bi) * V + v];
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
@@ -783,4 +816,15 @@ CUROBO_EXPORT int curobo_hip_ik_rank(
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ik_rank_kernel, dim3(num_problems), dim3(256), 0, st, a);
   return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_argmin_rows(float *out_rows, const float *cost, const float *payload, int num_problems, int num_seeds,
+                                         int payload_width, int seed_offset, curobo_hip_stream_t stream) {
+  CUROBO_REQUIRE(out_rows && cost && (payload || payload_width == 0) && num_problems >= 0 && num_seeds >= 1 && payload_width >= 0,
+                 "argmin_rows: bad arguments (P=%d, S=%d, V=%d)", num_problems, num_seeds, payload_width);
+  if (num_problems == 0) return CUROBO_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(argmin_rows_kernel, dim3(num_problems), dim3(256), 0, st, out_rows, cost, payload, num_seeds, payload_width,
+                     (float)seed_offset);
+  return check_launch("argmin_rows", st);
 }

@@ -29,6 +29,12 @@ def local_best(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int) -> t
     """cost[P, S_local], payload[P, S_local, V] -> packed [P, 2 + V] rows (cost, global idx, payload).
 
     The seed index travels as fp32 (exact below 2^24 seeds)."""
+    if cost.is_cuda and cost.dtype == torch.float32 and payload.dtype == torch.float32:  # one launch instead of ~8
+        from .backends import linalg as linalg_hip
+
+        row = torch.empty(cost.shape[0], 2 + payload.shape[-1], device=cost.device, dtype=torch.float32)
+        linalg_hip.argmin_rows(row, cost.contiguous(), payload.contiguous(), seed_offset)
+        return row
     c, i = torch.min(cost, dim=1)  # torch.min returns the first minimal index on ties
     P = cost.shape[0]
     row = torch.empty(P, 2 + payload.shape[-1], device=cost.device, dtype=torch.float32)
@@ -44,6 +50,8 @@ def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
 
     Works unchanged without an initialised process group (world size 1)."""
     row = local_best(cost, payload, seed_offset)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return row[:, 0], row[:, 1].to(torch.int64), row[:, 2:]  # alone: the local best is the answer
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         flat = torch.empty(world * row.shape[0], row.shape[1], device=row.device, dtype=row.dtype)

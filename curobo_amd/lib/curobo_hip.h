@@ -372,6 +372,12 @@ int curobo_hip_ik_rank(
     float rotation_threshold, int num_problems, int num_seeds, int dof, int num_tool_frames, int num_scene_columns,
     int return_seeds, int seed_offset, curobo_hip_stream_t stream);
 
+/* Local stage of the seed-parallel arg-min exchange in one launch: out_rows[p] = (min over the seeds of cost[p, :], seed_offset
+ * + the first index that attains it (as fp32), payload[p, index, :]), [num_problems, 2 + payload_width].  Reference
+ * single-GPU equivalent: solver_ik.py:503-515, solver_trajopt.py:469-484. */
+int curobo_hip_argmin_rows(float *out_rows, const float *cost, const float *payload, int num_problems, int num_seeds,
+                           int payload_width, int seed_offset, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- optimization: MPPI update
  * reference: optim/particle/mppi.py:201-313 + jit helpers :615-757 (pure torch, DIAG_A
  * covariance).  costs [problems, particles, cost_horizon] (cost_horizon may be 1 for totals),

@@ -374,3 +374,21 @@ def test_seed_selection_and_ik_ranking_kernels(device):
     np.testing.assert_array_equal(o_c.cpu().numpy(), cst[ar, order])
     np.testing.assert_array_equal(o_gi.cpu().numpy(), gidx[ar, order, 0])
     assert ok.any(1).mean() > 0.5 and (~ok).any()
+
+
+def test_argmin_rows_kernel_matches_torch(device):
+    """curobo_hip_argmin_rows (the local stage of the arg-min exchange) == torch.min + gather, ties -> first index"""
+    from curobo_amd.distributed import global_argmin
+
+    rng = np.random.default_rng(2)
+    P, S, V = 19, 300, 84
+    cost = rng.choice([0.5, 1.0, 2.0, 7.0], size=(P, S)).astype(np.float32)  # many ties
+    cost[3] = np.nan
+    cost[4, :10] = np.nan
+    pay = rng.normal(size=(P, S, V)).astype(np.float32)
+    c, i, x = global_argmin(torch.as_tensor(cost, device=device), torch.as_tensor(pay, device=device), 1000)
+    torch.cuda.synchronize()
+    ref_i = np.array([int(np.nanargmin(r)) if not np.isnan(r).all() else 0 for r in cost])
+    np.testing.assert_array_equal(i.cpu().numpy(), ref_i + 1000)
+    np.testing.assert_array_equal(x.cpu().numpy(), pay[np.arange(P), ref_i])
+    np.testing.assert_array_equal(c.cpu().numpy()[np.arange(P) != 3], cost[np.arange(P), ref_i][np.arange(P) != 3])
