@@ -133,9 +133,20 @@ __device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_
     float s[8];
     bool all_valid = true;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      s[k] = ok[k] ? __half2float(feat[base + off[k]]) : max_dist;
-      all_valid = all_valid && ok[k];
+    for (int k = 0; k < 8; k++) all_valid = all_valid && ok[k];
+    if (all_valid) {
+      // interior: z is the fastest index, so the corners come as four (z0, z0 + 1) pairs = four 4-byte loads (2-byte
+      // aligned: global memory takes unaligned dwords) instead of eight predicated 2-byte loads
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t w;
+        __builtin_memcpy(&w, feat + base + off[2 * k], 4);
+        s[2 * k] = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
+        s[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = ok[k] ? __half2float(feat[base + off[k]]) : max_dist;
     }
     if (all_valid) {
       sdf = s[0] * fx1 * fy1 * fz1 + s[1] * fx1 * fy1 * fz + s[2] * fx1 * fy * fz1 + s[3] * fx1 * fy * fz +
