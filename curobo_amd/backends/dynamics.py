@@ -15,6 +15,37 @@ import torch
 from .._lib import check, current_stream, load, ptr
 
 _workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
+_dfs_orders: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tensor:
+    """Depth-first (parents first) order of the links as int16, cached per link table.  The kernels walk the tree
+    serially per element; any parents-first order is correct, and in depth-first order the parent of a link is mostly
+    the link just processed, whose state the kernels then keep in registers instead of re-reading it from the cache.
+    One host read-back per robot: call once outside graph capture (the first, warm-up call does)."""
+    key = (link_map.data_ptr(), int(link_map.numel()), str(link_map.device))
+    order = _dfs_orders.get(key)
+    if order is None:
+        par = link_map.detach().cpu().numpy().astype(int)
+        n = par.shape[0]
+        kids = [[] for _ in range(n)]
+        roots = []
+        for k in range(n):
+            if par[k] < 0 or par[k] == k:
+                roots.append(k)
+            else:
+                kids[par[k]].append(k)
+        out, stack = [], roots[::-1]
+        while stack:
+            k = stack.pop()
+            out.append(k)
+            stack.extend(kids[k][::-1])
+        if len(out) != n:  # not a forest rooted as expected: keep the caller's level order
+            order = level_links
+        else:
+            order = torch.as_tensor(out, dtype=level_links.dtype).to(level_links.device)
+        _dfs_orders[key] = order
+    return order
 
 
 def _workspace(device: torch.device, n_floats: int) -> torch.Tensor:
@@ -57,7 +88,7 @@ def launch_rnea_forward(
     check(load().curobo_hip_launch_rnea_forward(
         ptr(tau), ptr(q), ptr(qd), ptr(qdd), ptr(fixed_transforms), ptr(link_masses_com), ptr(link_inertias),
         ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(joint_offset_map), ptr(gravity), ptr(level_starts),
-        ptr(level_links), ptr(forward_cache), batch_size, num_links, num_dof, n_levels, threads_per_batch,
+        ptr(_walk_order(link_map, level_links)), ptr(forward_cache), batch_size, num_links, num_dof, n_levels, threads_per_batch,
         ptr(f_ext), current_stream(tau),
     ))
 
@@ -96,6 +127,6 @@ def launch_rnea_backward(
     check(load().curobo_hip_launch_rnea_backward(
         ptr(grad_q), ptr(grad_qd), ptr(grad_qdd), ptr(grad_tau), ptr(q), ptr(qd), ptr(fixed_transforms),
         ptr(link_masses_com), ptr(link_inertias), ptr(joint_map_type), ptr(joint_map), ptr(link_map),
-        ptr(joint_offset_map), ptr(gravity), ptr(level_starts), ptr(level_links), ptr(forward_cache), batch_size,
+        ptr(joint_offset_map), ptr(gravity), ptr(level_starts), ptr(_walk_order(link_map, level_links)), ptr(forward_cache), batch_size,
         num_links, num_dof, n_levels, threads_per_batch, ptr(grad_f_ext), ptr(ws), current_stream(grad_q),
     ))

@@ -166,6 +166,12 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
   const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
   for (int j = 0; j < D; j++) a.tau[b * D + j] = 0.0f;
   // sweep 1, root -> leaves: velocities and accelerations (rnea_forward_kernel.cuh:118-188)
+  // The walk is a chain of dependent steps whose operands travel through the cache (HBM / L2: a round trip per link).
+  // When the links come in depth-first order the parent of a link is mostly the link just processed: its state is then
+  // taken from registers and the round trip leaves the dependent path (any parents-first order is correct; the
+  // backends pass a depth-first one).
+  int prev_k = -1;
+  Sv prev_v = sv_zero(), prev_a = sv_zero();
   for (int idx = 0; idx < L; idx++) {
     const int k = order[idx];
     const LinkConst c = link_const(s_f, s_i, k);
@@ -180,6 +186,9 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
     Sv v = sv_zero(), acc;
     if (is_root) {
       acc = X_motion(t, grav);
+    } else if (c.par == prev_k) {
+      v = X_motion(t, prev_v);
+      acc = X_motion(t, prev_a);
     } else {
       v = X_motion(t, load_sv(a.cache, B, c.par * 20, b));
       acc = X_motion(t, load_sv(a.cache, B, c.par * 20 + 6, b));
@@ -193,8 +202,13 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
     store_sv(a.cache, B, k * 20, b, v);
     store_sv(a.cache, B, k * 20 + 6, b, acc);
     store_sv(a.cache, B, k * 20 + 12, b, sv_zero());  // children accumulate their X^T f here
+    prev_k = k; prev_v = v; prev_a = acc;
   }
   // sweep 2, leaves -> root: f = I a + v x* I v (- f_ext) + children; tau = S^T f (:190-283)
+  // (a link's contribution to its parent stays in registers when the parent is the next link of the walk -- in
+  // reversed depth-first order it usually is -- instead of a store the parent's load would have to wait for)
+  int pend_par = -1;
+  Sv pend = sv_zero();
   for (int idx = L - 1; idx >= 0; idx--) {
     const int k = order[idx];
     const LinkConst c = link_const(s_f, s_i, k);
@@ -205,13 +219,16 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
       f = f - Sv{make_f3(fe[0], fe[1], fe[2]), make_f3(fe[3], fe[4], fe[5])};
     }
     f = f + load_sv(a.cache, B, k * 20 + 12, b);
+    if (pend_par == k) f = f + pend;
+    pend_par = -1;
     store_sv(a.cache, B, k * 20 + 12, b, f);
     const bool moving = c.jt != J_FIXED && c.ji >= 0;
     if (moving) a.tau[b * D + c.ji] += c.mul * sv_get(f, s_index(c.jt));
     if (!(c.par < 0 || c.par == k)) {
       const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
       const Sv up = XT_force(local_Rp(c.F, c.jt, qe), f);
-      store_sv(a.cache, B, c.par * 20 + 12, b, load_sv(a.cache, B, c.par * 20 + 12, b) + up);
+      if (idx > 0 && order[idx - 1] == c.par) { pend = up; pend_par = c.par; }
+      else store_sv(a.cache, B, c.par * 20 + 12, b, load_sv(a.cache, B, c.par * 20 + 12, b) + up);
     }
   }
 }
@@ -225,6 +242,8 @@ __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const f
   if (!ACCUMULATE)
     for (int j = 0; j < D; j++) { a.grad_q[b * D + j] = 0.0f; a.grad_qd[b * D + j] = 0.0f; a.grad_qdd[b * D + j] = 0.0f; }
   // pass 1, root -> leaves: adjoint of the force propagation (rnea_backward_kernel.cuh:151-208)
+  int prev_k = -1;
+  Sv prev_fb = sv_zero();
   for (int idx = 0; idx < L; idx++) {
     const int k = order[idx];
     const LinkConst c = link_const(s_f, s_i, k);
@@ -234,27 +253,33 @@ __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const f
     if (moving) sv_add_at(fb, si, c.mul * a.grad_tau[b * D + c.ji]);
     if (!is_root) {
       const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
-      const Sv X = X_motion(local_Rp(c.F, c.jt, qe), load_sv(a.ws_fbar, B, c.par * 6, b));
+      const Sv X = X_motion(local_Rp(c.F, c.jt, qe), c.par == prev_k ? prev_fb : load_sv(a.ws_fbar, B, c.par * 6, b));
       fb = fb + X;
       if (moving) a.grad_q[b * D + c.ji] += c.mul * sv_dot(X, crf(sv_unit(si, 1.0f), load_sv(a.cache, B, k * 20 + 12, b)));
     }
     store_sv(a.ws_fbar, B, k * 6, b, fb);
     store_sv(a.ws_abar, B, k * 6, b, sv_zero());
     store_sv(a.ws_vbar, B, k * 6, b, sv_zero());
+    prev_k = k; prev_fb = fb;
     if (HAS_FEXT) {
       float *g = a.grad_f_ext + (b * L + k) * 6;
       g[0] = -fb.w.x; g[1] = -fb.w.y; g[2] = -fb.w.z; g[3] = -fb.v.x; g[4] = -fb.v.y; g[5] = -fb.v.z;
     }
   }
   // pass 2, leaves -> root: adjoint of the velocity / acceleration propagation (:236-465)
+  int pend_par = -1;
+  Sv pend_a = sv_zero(), pend_v = sv_zero();
   for (int idx = L - 1; idx >= 0; idx--) {
     const int k = order[idx];
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    const bool par_next = !is_root && idx > 0 && order[idx - 1] == c.par;  // this link's pushes stay in registers
     const Sv v = load_sv(a.cache, B, k * 20, b);
     const Sv fb = load_sv(a.ws_fbar, B, k * 6, b);
     Sv ab = load_sv(a.ws_abar, B, k * 6, b) + inertia_mul(c.mc, c.in, fb);
     Sv vb = load_sv(a.ws_vbar, B, k * 6, b) - crf(fb, inertia_mul(c.mc, c.in, v)) - inertia_mul(c.mc, c.in, crm(v, fb));
+    if (pend_par == k) { ab = ab + pend_a; vb = vb + pend_v; }
+    pend_par = -1;
     const int si = moving ? s_index(c.jt) : 0;
     float gq = 0.0f, gqd = 0.0f;
     if (moving) {
@@ -266,14 +291,20 @@ __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const f
     const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
     const Rp t = local_Rp(c.F, c.jt, qe);
     const Sv S1 = sv_unit(si, 1.0f);
-    if (!is_root) store_sv(a.ws_abar, B, c.par * 6, b, load_sv(a.ws_abar, B, c.par * 6, b) + XT_force(t, ab));
+    if (!is_root) {
+      const Sv up = XT_force(t, ab);
+      if (par_next) pend_a = up;
+      else store_sv(a.ws_abar, B, c.par * 6, b, load_sv(a.ws_abar, B, c.par * 6, b) + up);
+    }
     if (moving) {  // dX/dq on the acceleration path: the parent's acceleration, or gravity at the root
       const Sv Xa = X_motion(t, is_root ? grav : load_sv(a.cache, B, c.par * 20 + 6, b));
       gq -= c.mul * sv_dot(ab, crm(S1, Xa));
       gqd += c.mul * sv_get(vb, si);
     }
     if (!is_root) {
-      store_sv(a.ws_vbar, B, c.par * 6, b, load_sv(a.ws_vbar, B, c.par * 6, b) + XT_force(t, vb));
+      const Sv upv = XT_force(t, vb);
+      if (par_next) { pend_v = upv; pend_par = c.par; }
+      else store_sv(a.ws_vbar, B, c.par * 6, b, load_sv(a.ws_vbar, B, c.par * 6, b) + upv);
       if (moving) gq -= c.mul * sv_dot(vb, crm(S1, X_motion(t, load_sv(a.cache, B, c.par * 20, b))));
     }
     if (moving) {

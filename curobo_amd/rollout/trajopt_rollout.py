@@ -328,7 +328,8 @@ class TrajOptRollout:
             cspace_target_dof_weight=self._onesD, retime_weights=c.retime_weights,
             retime_regularization_weights=c.retime_regularization_weights,
             **(dict(link_masses_com=k.link_masses_com, link_inertias=k.link_inertias, gravity=self._gravity,
-                    level_links=k.link_level_data, use_torque_limits=1) if c.use_torque_limits else {}))
+                    level_links=dynamics_hip._walk_order(k.link_map, k.link_level_data), use_torque_limits=1)
+               if c.use_torque_limits else {}))
         rollout_hip.rollout_trajopt_fused(
             self._terms, self.cost, self.grad_knots, self.position if m else None, self.robot_spheres if m else None,
             act_seq, self.start_pos, self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel,
