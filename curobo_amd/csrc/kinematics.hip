@@ -482,13 +482,25 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
     const float4 *gb = a.grad_spheres_b
                            ? reinterpret_cast<const float4 *>(a.grad_spheres_b) + (size_t)n * a.nspheres
                            : nullptr;
-    for (int s = lane; s < a.nspheres; s += kFkLanes) {
-      float4 g4 = ga[s];
-      if (gb) { const float4 h = gb[s]; g4.x += h.x; g4.y += h.y; g4.z += h.z; }
-      if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f) continue;
-      const int l = a.link_sphere_map[s];
-      const float4 pw = transform_sphere(my_cumul + l * 12, rs[s]);
-      chain_point_vjp(psum, my_cumul, tb, l, make_f3(pw.x, pw.y, pw.z), make_f3(g4.x, g4.y, g4.z));
+    // four spheres per lane and round: their gradient loads are requested together (clamped, unpredicated), so a
+    // round is one memory round trip instead of four
+    constexpr int U = 4;
+    for (int s0 = lane; s0 < a.nspheres; s0 += kFkLanes * U) {
+      float4 g4[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int sc = min(s0 + u * kFkLanes, a.nspheres - 1);
+        g4[u] = ga[sc];
+        if (gb) { const float4 h = gb[sc]; g4[u].x += h.x; g4[u].y += h.y; g4[u].z += h.z; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int sidx = s0 + u * kFkLanes;
+        if (sidx >= a.nspheres || (g4[u].x == 0.0f && g4[u].y == 0.0f && g4[u].z == 0.0f)) continue;
+        const int l = a.link_sphere_map[sidx];
+        const float4 pw = transform_sphere(my_cumul + l * 12, rs[sidx]);
+        chain_point_vjp(psum, my_cumul, tb, l, make_f3(pw.x, pw.y, pw.z), make_f3(g4[u].x, g4[u].y, g4[u].z));
+      }
     }
   }
   // ---- tool frames: position + orientation (reference :102-183), chain split across lanes
