@@ -100,12 +100,23 @@ struct BsBwdArgs {
 // (ph = padded horizon of THIS trajectory and interpolated_dt are explicit so that the single-dt
 // re-interpolation, bspline_kernel.cuh:221-270, shares the code)
 template <int DEG>
+__device__ __forceinline__ float bspline_sample_pre(const BsFwdArgs &a, int b, int h, int d, int ph, float interpolated_dt,
+                                                    int bo, int go, bool implicit_goal, float *o);
+
+template <int DEG>
 __device__ __forceinline__ float bspline_sample_at(const BsFwdArgs &a, int b, int h, int d, int ph, float interpolated_dt,
                                                    float *o) {
+  const int bo = a.start_idx[b], go = a.goal_idx[b];
+  return bspline_sample_pre<DEG>(a, b, h, d, ph, interpolated_dt, bo, go, a.use_implicit_goal[go] != 0, o);
+}
+
+// the same with the trajectory's indices and goal mode already in registers (a caller that samples many points of ONE
+// trajectory loads them once, ahead of its other memory traffic, instead of at the head of every sample's chain)
+template <int DEG>
+__device__ __forceinline__ float bspline_sample_pre(const BsFwdArgs &a, int b, int h, int d, int ph, float interpolated_dt,
+                                                    int bo, int go, bool implicit_goal, float *o) {
   constexpr int SUP = DEG + 1;
   const int dof = a.dof;
-  const int bo = a.start_idx[b], go = a.goal_idx[b];
-  const bool implicit_goal = a.use_implicit_goal[go] != 0;
   const int horizon = ph - 1;
   const int padded_n_knots = a.n_knots + SUP;
   const int interp = horizon / padded_n_knots;
@@ -118,7 +129,9 @@ __device__ __forceinline__ float bspline_sample_at(const BsFwdArgs &a, int b, in
 #pragma unroll
   for (int i = 0; i < SUP; i++) {
     const int src = start_knot + i;
-    knots[i] = (src < a.n_knots && src >= 0) ? a.u[((size_t)b * a.n_knots + src) * dof + d] : 0.0f;
+    const int sc = src < 0 ? 0 : (src < a.n_knots ? src : a.n_knots - 1);  // (clamped, unpredicated: all SUP loads in flight)
+    const float kv = a.u[((size_t)b * a.n_knots + sc) * dof + d];
+    knots[i] = (src < a.n_knots && src >= 0) ? kv : 0.0f;
   }
   const bool req_start = knot_idx < SUP;
   const bool req_goal = implicit_goal ? (knot_idx > a.n_knots - 1) : (knot_idx > a.n_knots);

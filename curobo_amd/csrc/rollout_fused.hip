@@ -946,12 +946,16 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
 
   // ---------------- P0: tables + B-spline samples
   const int nwaves = nt >> 6;
+  // (the trajectory's state indices, dt and goal mode: requested here, ahead of the table loads, used by the samples)
+  const int bs_bo = a.bs.start_idx[b], bs_go = a.bs.goal_idx[b];
+  const float bs_dt = a.bs.traj_dt[bs_go];
+  const bool bs_implicit = a.bs.use_implicit_goal[bs_go] != 0;
   fused_stage_tables(c, a, lay, rs, n_rec);
   if (use_cspace) stage_cspace_tables(c, a.cs, b);
   for (int e = rotated_tid(nwaves / 2); e < H * D; e += nt) {
     const int h = e / D, d = e - h * D;
     float o4[4];
-    bspline_sample<DEG>(a.bs, b, h, d, o4);
+    bspline_sample_pre<DEG>(a.bs, b, h, d, a.bs.padded_horizon, bs_dt, bs_bo, bs_go, bs_implicit, o4);
     c.q[e] = o4[0];
     if (use_cspace) { c.dyn[e] = o4[1]; c.dyn[H * D + e] = o4[2]; c.dyn[2 * H * D + e] = o4[3]; }
     if (a.out_position) a.out_position[(size_t)b * H * D + e] = o4[0];
