@@ -1021,7 +1021,8 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int row_stride = ngroups >> 2;
   // A single leftover point (H = 33 / 65 on 32 / 64 rows) is folded into the main round instead of a
   // barrier - all threads - barrier - fold section: its pair list is sliced over the rows, its scene cost is
-  // evaluated by row 0 with the link-mask culling of an ordinary point, nothing is handed over through LDS.
+  // evaluated by wave 0 (one sphere per lane) with the link-mask culling of an ordinary point, nothing is handed
+  // over through LDS.
   const bool fold_left = n_left == 1;
   for (int h0 = 0; h0 < H_main; h0 += ngroups) {
     const int h = h0 + (grp & 3) * row_stride + (grp >> 2);
@@ -1115,42 +1116,34 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   if (fold_left) {
     CUROBO_STAMP(7);
     const int h = H_main;
-    if (a.use_scene && (tid >> 6) == 0) {  // wave 0 stays converged for the wave-level fences; row 0 works
-      const bool mine = grp == 0;
-      if (mine) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
-      if (mine) {
-        const float *wr = c.wrench + (size_t)h * c.wl;
-        float cost_scene = 0.0f;
-        bool any_scene = false;
-        for (int s0 = 0; s0 < S; s0 += kFkLanes) {
-          const int s = s0 + lane;
-          float d = 0.0f;
-          f3 g = make_f3(0.f, 0.f, 0.f);
-          float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
-          const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
-          if (s < S && (mask != 0u || n_rec > 32)) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
-          cost_scene += d;
-          // serialised over the contributing lanes of THIS row (lanes of the other rows contribute nothing)
-          unsigned long long m = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f) & 0xffffull;
-          any_scene = any_scene || m != 0ull;
-          if (m) {
-            const int l = c.sph_link[s < S ? s : 0];
-            const float *C = c.cumul + (size_t)h * c.L * 12 + l * 12;
-            const f3 t = cross(make_f3(c4.x, c4.y, c4.z) - make_f3(C[3], C[7], C[11]), g);
-            float *w = c.wrench + (size_t)h * c.wl + l * kWrench;
-            while (m) {
-              const int src = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              if (lane64 == src) {
-                atomicAdd(w + 0, g.x); atomicAdd(w + 1, g.y); atomicAdd(w + 2, g.z);
-                atomicAdd(w + 3, t.x); atomicAdd(w + 4, t.y); atomicAdd(w + 5, t.z);
-              }
-            }
-          }
-        }
-        cost_scene = row16_sum(cost_scene);
-        if (lane == 0) { c.cost[h] = cost_scene; c.flag[h] = any_scene ? 1 : 0; }
+    if (a.use_scene && (tid >> 6) == 0) {
+      // wave 0, all 64 lanes on this ONE point (one sphere per lane: the rest of the workgroup waits at the barrier
+      // below for exactly this section); row 0 computes the link masks first
+      if (grp == 0) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const float *wr = c.wrench + (size_t)h * c.wl;
+      float cost_scene = 0.0f;
+      bool any_scene = false;
+      for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane64;
+        float d = 0.0f;
+        f3 g = make_f3(0.f, 0.f, 0.f);
+        float4 c4 = make_float4(0.f, 0.f, 0.f, -1.f);
+        const uint32_t mask = s < S ? __float_as_uint(wr[c.sph_link[s] * kWrench + 6]) : 0u;
+        if (s < S && (mask != 0u || n_rec > 32)) c4 = scene_sphere<SWEEP, KINDS>(c, a.sc, h, s, d, g, mask);
+        cost_scene += d;
+        any_scene = __ballot(g.x != 0.0f || g.y != 0.0f || g.z != 0.0f) != 0ull || any_scene;
+        // (one turn per contributing lane, ascending sphere index: the order a single row would have used)
+        wrench_add_serialised(c, h, s, make_f3(c4.x, c4.y, c4.z), g, lane64);
       }
+      // sum in the order of a 16-lane row striding over the spheres (lane l: s = l, 16 + l, ...), then across the row
+      float x = __shfl(cost_scene, lane, 64);
+      x += __shfl(cost_scene, lane + 16, 64);
+      x += __shfl(cost_scene, lane + 32, 64);
+      x += __shfl(cost_scene, lane + 48, 64);
+      cost_scene = row16_sum(x);
+      if (tid == 0) { c.cost[h] = cost_scene; c.flag[h] = any_scene ? 1 : 0; }
     } else if (tid == 0) {
       c.cost[h] = 0.0f;
       c.flag[h] = 0;
