@@ -59,9 +59,11 @@ def _flags() -> List[str]:
 
 
 # The SLP vectoriser packs independent fp32 products into v_pk_* pairs; on gfx950 a packed fp32 instruction issues at
-# half rate and every pair costs register shuffles (v_mov / v_pk_mov), so for the serial chain of kinematics.hip it
-# turns ~110 instructions per link into ~150 on the one wavefront a workgroup waits for.
-PER_SOURCE_FLAGS = {"kinematics.hip": ["-fno-slp-vectorize"]}
+# half rate and every pair costs register shuffles (v_mov / v_pk_mov): ~110 instructions per link become ~150 on the
+# serial chain of kinematics.hip, and rollout_fused.hip's main instantiation needs 125 instead of 95 VGPRs (its
+# SWEEP x voxel instantiations spill 54-60 registers with it, 2-4 without).  Off for every source.
+PER_SOURCE_FLAGS: dict = {}
+NO_SLP = ["-fno-slp-vectorize"]
 
 
 def _deps(src: str) -> List[str]:
@@ -74,7 +76,7 @@ def _compile(src_name: str, force: bool) -> str:
     obj = os.path.join(OBJ_DIR, src_name.rsplit(".", 1)[0] + ".o")
     if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
         return obj
-    cmd = [hipcc_path(), *_flags(), *PER_SOURCE_FLAGS.get(src_name, []), "-x", "hip", "-c", src, "-o", obj]
+    cmd = [hipcc_path(), *_flags(), *NO_SLP, *PER_SOURCE_FLAGS.get(src_name, []), "-x", "hip", "-c", src, "-o", obj]
     subprocess.check_call(cmd)
     return obj
 
