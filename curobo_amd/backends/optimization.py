@@ -108,9 +108,12 @@ def launch_lbfgs_iteration_tail(
     armijo_threshold_c_1: float, curvature_threshold_c_2: float, strong_wolfe: bool, approx_wolfe: bool,
     n_linesearch: int, opt_dim: int, batchsize: int, step_vec, rho_buffer, y_buffer, s_buffer, x_0, grad_0,
     epsilon: float, history_m: int, stable_mode: bool, action_step_max, action_dim: int, apply_step_scale: bool,
+    overlapped: bool = False,
 ):
     """``launch_line_search`` + ``launch_lbfgs_step`` + ``prepare_search_points`` (next iteration) in
-    one launch; argument groups in that order, same meaning as in the three functions above."""
+    one launch; argument groups in that order, same meaning as in the three functions above.
+    ``overlapped``: the launch runs next to other kernels (seed shards on their own streams): one wavefront and no
+    LDS per problem instead of a workgroup (see the header)."""
     check(load().curobo_hip_launch_lbfgs_iteration_tail(
         ptr(best_cost), ptr(best_action), ptr(best_iteration), ptr(current_iteration), ptr(converged_global),
         convergence_iteration, cost_delta_threshold, cost_relative_threshold, ptr(exploration_cost),
@@ -119,7 +122,8 @@ def launch_lbfgs_iteration_tail(
         ptr(search_gradient), ptr(step_direction_scaled), ptr(search_magnitudes), armijo_threshold_c_1,
         curvature_threshold_c_2, int(strong_wolfe), int(approx_wolfe), n_linesearch, opt_dim, batchsize,
         ptr(step_vec), ptr(rho_buffer), ptr(y_buffer), ptr(s_buffer), ptr(x_0), ptr(grad_0), epsilon, history_m,
-        int(stable_mode), ptr(action_step_max), action_dim, int(apply_step_scale), current_stream(best_cost),
+        int(stable_mode), ptr(action_step_max), action_dim, int(apply_step_scale), int(overlapped),
+        current_stream(best_cost),
     ))
 
 

@@ -714,10 +714,18 @@ __device__ __forceinline__ void tail_next_candidates(const PrepareArgs &pr, int 
   }
 }
 
+// The tail is one dependent chain per problem (54 reductions) that shares its SIMD with the rollout wavefronts of the
+// other seed shards (optim/pipelined.py): at equal priority it gets one issue slot in five.  Highest wave priority for
+// the whole kernel; it issues an instruction every ~8 cycles, so the rollouts hardly notice.
+__device__ __forceinline__ void tail_raise_priority() {
+  __builtin_amdgcn_s_setprio(3);
+}
+
 // (a) one lane group per problem: everything in one burst of loads.  Used for the 16-lane-row problems (IK).
 template <int VPL, int G, int NLSMAX>
 __global__ void __launch_bounds__(256) lbfgs_iteration_tail_prefetch_kernel(const LineSearchArgs ls, const LbfgsArgs lb,
                                                                             const PrepareArgs pr) {
+  tail_raise_priority();
   touch_kernarg_lines();
   const int grp = threadIdx.x / G, lane = threadIdx.x % G;
   const int b = blockIdx.x * (blockDim.x / G) + grp;
@@ -751,6 +759,7 @@ __global__ void __launch_bounds__(256) lbfgs_iteration_tail_wg_kernel(const Line
   extern __shared__ float s_hist[];
   constexpr int G = kWave;
   const int s_off = (lb.v_dim + 1) * kHistRow;
+  tail_raise_priority();
   touch_kernarg_lines();
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid % kWave;
@@ -943,7 +952,7 @@ CUROBO_EXPORT int curobo_hip_launch_lbfgs_iteration_tail(
     float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
     int opt_dim, int batchsize, float *step_vec, float *rho_buffer, float *y_buffer, float *s_buffer,
     float *x_0, float *grad_0, float epsilon, int history_m, int stable_mode,
-    const float *action_step_max, int action_dim, int apply_step_scale, curobo_hip_stream_t stream) {
+    const float *action_step_max, int action_dim, int apply_step_scale, int overlapped, curobo_hip_stream_t stream) {
   const char *what = "launch_lbfgs_iteration_tail";
   CUROBO_REQUIRE(n_linesearch >= 1 && n_linesearch <= kWave, "%s: n_linesearch=%d out of range [1,64]", what, n_linesearch);
   CUROBO_REQUIRE(history_m <= 31, "%s: History_m greater than 31 is not supported", what);
@@ -971,9 +980,13 @@ CUROBO_EXPORT int curobo_hip_launch_lbfgs_iteration_tail(
   const dim3 grid16((unsigned)ceil_div(batchsize, 16));
   if (n_linesearch <= 4 && !no_prefetch) {
     // a workgroup per problem pays while the problems do not fill the chip (64 / 256: 9.0 / 10.1 us against 12.3 /
-    // 12.9 us for a wavefront per problem); at 1024 problems the extra wavefronts cost more than they hide (19 vs 15)
+    // 12.9 us for a wavefront per problem); at 1024 problems the extra wavefronts cost more than they hide (19 vs 15).
+    // Between the rollout workgroups of other seed shards (`overlapped`) it is the other way round: the workgroup form
+    // needs 24 KB of LDS and four 179-VGPR wavefronts per problem on CUs that the rollouts fill to 151 of 160 KB and
+    // 384 of 512 VGPRs per SIMD (C2, 100-iteration blocks: 65.1 us per iteration with it, 60.4 us without)
     static const bool no_wg_env = getenv("CUROBO_HIP_TAIL_NO_WG") != nullptr;
-    const bool no_wg = no_wg_env || batchsize > 512;
+    static const bool wg_env = getenv("CUROBO_HIP_TAIL_WG") != nullptr;  // (tuning knobs: force either form)
+    const bool no_wg = !wg_env && (no_wg_env || overlapped != 0 || batchsize > 512);
     const int n_move = history_m > 0 ? (history_m - 1) * opt_dim : 0;
     const int rounds = ceil_div(n_move, kStageLanes);
     const size_t lds = (size_t)2 * (opt_dim + 1) * kHistRow * sizeof(float);

@@ -646,7 +646,11 @@ int curobo_hip_prepare_search_points(
  * (reference optim/gradient/lbfgs.py:156-265, gradient_opt_core.py:255-480), with the exploration
  * point and the new direction handed over in registers.  search_action (the candidate set x_set)
  * and step_direction_scaled are read by the line search and then overwritten with the next
- * iteration's candidates / scaled direction.  step_vec receives the unscaled direction. */
+ * iteration's candidates / scaled direction.  step_vec receives the unscaled direction.
+ * overlapped != 0: the launch shares the GPU with other work (the seed shards of optim/pipelined.py run their rollouts
+ * next to it): wavefront-sized problems then take ONE wavefront and no LDS each instead of a 256-lane workgroup with
+ * the history staged through LDS -- 1 us more on an idle GPU, 5 us less per iteration between busy rollout
+ * workgroups, whose LDS and registers the workgroup form has to wait for.  Same results bit for bit. */
 int curobo_hip_launch_lbfgs_iteration_tail(
     float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
     uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
@@ -658,7 +662,7 @@ int curobo_hip_launch_lbfgs_iteration_tail(
     float curvature_threshold_c_2, int strong_wolfe, int approx_wolfe, int n_linesearch,
     int opt_dim, int batchsize, float *step_vec, float *rho_buffer, float *y_buffer,
     float *s_buffer, float *x_0, float *grad_0, float epsilon, int history_m, int stable_mode,
-    const float *action_step_max, int action_dim, int apply_step_scale,
+    const float *action_step_max, int action_dim, int apply_step_scale, int overlapped,
     curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- rollout glue

@@ -64,6 +64,9 @@ class LBFGSOpt:
         self.opt_dim = action_horizon * action_dim
         self.device = device
         self.use_cuda_graph = use_cuda_graph
+        # set by PipelinedLBFGS: this optimiser's launches run next to the rollouts of other seed shards, so its
+        # iteration tail takes the form that does not wait for their LDS / registers (one wavefront per problem)
+        self.overlapped = False
         if self.opt_dim >= 1024:  # reference lbfgs.py:177
             raise ValueError("opt_dim must be < 1024 for the fused L-BFGS step")
         if cfg.history > 31:
@@ -135,7 +138,7 @@ class LBFGSOpt:
                 cfg.line_search_c_1, cfg.line_search_c_2, cfg.line_search_type == "strong_wolfe",
                 cfg.line_search_type == "approx_wolfe", N, V, B, self.step_direction, self.rho, self.y, self.s,
                 self.x_0, self.grad_0, cfg.epsilon, self.history, cfg.stable_mode, self._step_max,
-                self.action_dim, apply_scale)
+                self.action_dim, apply_scale, overlapped=self.overlapped)
             return
         optimization_hip.prepare_search_points(
             self.x_set, self.step_scaled, self.exploration_action, self.step_direction, self._step_max,

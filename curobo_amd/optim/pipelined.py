@@ -44,6 +44,8 @@ class PipelinedLBFGS:
             LBFGSOpt(sub, rollout_factory(self.shard_problems * nls, k) if takes_index else rollout_factory(self.shard_problems * nls),
                      action_horizon, action_dim, action_bounds, device, use_cuda_graph=False)
             for k in range(n_shards)]
+        for o in self.opts:
+            o.overlapped = n_shards > 1
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_shards)]
         self.action_horizon, self.action_dim = action_horizon, action_dim
         self._graph: Optional[torch.cuda.CUDAGraph] = None

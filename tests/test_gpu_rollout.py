@@ -163,18 +163,21 @@ def test_fused_iteration_tail_equals_three_launches(device, fused_rollout):
     seeds = 16
     model, kin, arrays, cfg, knots, start, _ = _setup(device, seeds, fused=fused_rollout)
     state = []
-    for fused_tail in (False, True):
+    # (fused tail, overlapped): the workgroup-per-problem form and the wavefront-per-problem form the stream shards use
+    for fused_tail, overlapped in ((False, False), (True, False), (True, True)):
         ocfg = LBFGSOptCfg(num_problems=seeds, inner_iters=4, num_iters=12, fused_tail=fused_tail)
         ro = CollisionRollout(kin, _scene(arrays, device), seeds * 4, cfg)
         ro.update_start_state(torch.as_tensor(start, device=device))
         opt = LBFGSOpt(ocfg, ro.cost_and_gradient, cfg.n_knots, kin.num_dof,
                        (kin.joint_limits_position[0], kin.joint_limits_position[1]), device, use_cuda_graph=False)
+        opt.overlapped = overlapped
         best = opt.optimize(torch.as_tensor(knots, device=device))
         torch.cuda.synchronize()
         state.append([t.clone() for t in (best, opt.best_cost, opt.exploration_action, opt.exploration_gradient,
                                           opt.step_direction, opt.rho, opt.y, opt.s, opt.best_iteration)])
-    for a_, b_ in zip(*state):
-        assert torch.equal(a_, b_)
+    for other in state[1:]:
+        for a_, b_ in zip(state[0], other):
+            assert torch.equal(a_, b_)
 
 
 def _scene(arrays, device):
