@@ -35,7 +35,9 @@ typedef void *curobo_hip_stream_t; /* hipStream_t */
 #define CUROBO_HIP_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after a launch */
 
 const char *curobo_hip_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change.  2 = round 2 (new arguments on the extension entry
+ * points: fused rollouts, seed IK, dense self collision, the L-BFGS iteration tail; the reference-shaped entry points are
+ * unchanged). */
 int curobo_hip_abi_version(void);
 /* when non-zero every launch is followed by hipStreamSynchronize + error check
  * (reference runtime.debug, cuda_core_backend/launch_helper.py:13-19). */
