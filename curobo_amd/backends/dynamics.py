@@ -8,6 +8,8 @@ size is part of the contract, the HIP kernels use a ``[link][20][batch]`` layout
 
 from __future__ import annotations
 
+import weakref
+
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -15,7 +17,7 @@ import torch
 from .._lib import check, current_stream, load, ptr
 
 _workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
-_dfs_orders: Dict[Tuple[int, int, str], torch.Tensor] = {}
+_dfs_orders: Dict[Tuple[int, int, str], Tuple["weakref.ref", torch.Tensor]] = {}
 
 
 def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tensor:
@@ -24,7 +26,10 @@ def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tens
     the link just processed, whose state the kernels then keep in registers instead of re-reading it from the cache.
     One host read-back per robot: call once outside graph capture (the first, warm-up call does)."""
     key = (link_map.data_ptr(), int(link_map.numel()), str(link_map.device))
-    order = _dfs_orders.get(key)
+    hit = _dfs_orders.get(key)
+    # an entry only counts while the tensor it was made from is alive: the caching allocator hands a freed address
+    # to the next table of the same size (another robot), and a stale order need not be parents-first for it
+    order = hit[1] if hit is not None and hit[0]() is not None else None
     if order is None:
         par = link_map.detach().cpu().numpy().astype(int)
         n = par.shape[0]
@@ -44,7 +49,7 @@ def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tens
             order = level_links
         else:
             order = torch.as_tensor(out, dtype=level_links.dtype).to(level_links.device)
-        _dfs_orders[key] = order
+        _dfs_orders[key] = (weakref.ref(link_map), order)
     return order
 
 

@@ -4,6 +4,8 @@
 
 from __future__ import annotations
 
+import weakref
+
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -23,8 +25,9 @@ def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[t
     when the list is not (i, j)-sorted with i < j (then "lowest pair index" is not the lexicographic order the
     dense kernel resolves ties by).  Built once per pair tensor (one host read-back: call outside graph capture)."""
     key = (pair_locations.data_ptr(), int(pair_locations.shape[0]), int(nspheres), str(pair_locations.device))
-    if key in _bitmap_cache:
-        return _bitmap_cache[key]
+    hit = _bitmap_cache.get(key)
+    if hit is not None and hit[0]() is not None:  # (valid while the tensor it was built from lives: addresses are reused)
+        return hit[1]
     p = pair_locations.detach().cpu().numpy().astype(np.int64).reshape(-1, 2)
     i, j = p[:, 0], p[:, 1]
     ok = bool((i < j).all() and (i >= 0).all() and (j < nspheres).all() and (np.diff(i * 65536 + j) > 0).all())
@@ -38,7 +41,7 @@ def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[t
         tiles = ((tkey // 256) | ((tkey % 256) << 8)).astype(np.int32)
         res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots,
                torch.as_tensor(tiles).to(pair_locations.device).contiguous())
-    _bitmap_cache[key] = res
+    _bitmap_cache[key] = (weakref.ref(pair_locations), res)
     return res
 
 

@@ -142,3 +142,67 @@ def test_missing_library_fails_loudly(monkeypatch):
                   if p.default is inspect.Parameter.empty])
     with pytest.raises(ImportError, match="no CPU fallback"):
         kinematics.launch_kinematics_forward(*([None] * n_args))
+
+
+def test_rnea_walk_order_is_depth_first_and_survives_address_reuse():
+    """backends/dynamics._walk_order: parents before children, a child right after its parent wherever the tree allows
+    (what the kernels' register forwarding relies on), cached per link table, and a cache entry whose tensor died is
+    not trusted (the allocator hands the address to the next robot's table of the same size)."""
+    import gc
+    import weakref
+
+    import torch
+
+    from curobo_amd.backends import dynamics as D
+
+    #        0
+    #      /   \
+    #     1     4
+    #    / \     \
+    #   2   3     5
+    parent = torch.tensor([-1, 0, 1, 1, 0, 4], dtype=torch.int16)
+    level = torch.tensor([0, 1, 4, 2, 3, 5], dtype=torch.int16)  # breadth-first, what the loader produces
+    order = D._walk_order(parent, level).tolist()
+    assert sorted(order) == list(range(6))
+    pos = {k: i for i, k in enumerate(order)}
+    for k, p in enumerate(parent.tolist()):
+        assert p < 0 or pos[p] < pos[k]
+    assert order == [0, 1, 2, 3, 4, 5]
+    assert D._walk_order(parent, level) is D._walk_order(parent, level)  # cached
+    # the same key with a dead owner: recomputed from the tensor that is passed in
+    key = (parent.data_ptr(), int(parent.numel()), str(parent.device))
+    ghost = torch.zeros(1)
+    D._dfs_orders[key] = (weakref.ref(ghost), torch.tensor([5, 4, 3, 2, 1, 0], dtype=torch.int16))
+    del ghost
+    gc.collect()
+    assert D._walk_order(parent, level).tolist() == [0, 1, 2, 3, 4, 5]
+    # not a forest (a cycle): the caller's level order is kept
+    cyc = torch.tensor([1, 0, 1], dtype=torch.int16)
+    lv = torch.tensor([0, 1, 2], dtype=torch.int16)
+    assert D._walk_order(cyc, lv) is lv
+
+
+def test_pair_bitmap_and_tile_list_of_the_dense_self_collision_entry():
+    """backends/geometry.pair_bitmap: bit (j % 32) of word [j / 32, i] per listed pair, the 16 x 16 tiles that hold a
+    pair as (i / 16) | (j / 16) << 8, None for lists the dense kernel's tie rule does not cover."""
+    import numpy as np
+    import torch
+
+    from curobo_amd.backends import geometry as G
+
+    S = 70
+    pairs = [(0, 1), (0, 33), (2, 69), (17, 40), (40, 41)]
+    t = torch.tensor(pairs, dtype=torch.int16)
+    bm, nslots, tiles = G.pair_bitmap(t, S)
+    assert nslots == 4 and tuple(bm.shape) == (8, 256)
+    words = bm.numpy().view(np.uint32)
+    want = np.zeros_like(words)
+    for i, j in pairs:
+        want[j // 32, i] |= np.uint32(1) << np.uint32(j % 32)
+    assert np.array_equal(words, want)
+    assert sorted(tiles.tolist()) == sorted({(i // 16) | ((j // 16) << 8) for i, j in pairs})
+    assert G.pair_bitmap(t, S) is G.pair_bitmap(t, S)
+    unsorted = torch.tensor([(0, 33), (0, 1)], dtype=torch.int16)
+    assert G.pair_bitmap(unsorted, S) is None
+    swapped = torch.tensor([(5, 2)], dtype=torch.int16)
+    assert G.pair_bitmap(swapped, S) is None
