@@ -182,6 +182,7 @@ class quat(_Vec):  # (x, y, z, w)
 
 
 quatf = quat
+quaternion = quat
 
 
 class transform:
@@ -225,6 +226,20 @@ def length_sq(a):
 def normalize(a):
     n = length(a)
     return a / n if n > 0 else type(a)()
+
+
+def mul(a, b):
+    return a * b
+
+
+_generic_vecs = {}
+
+
+def vector(*vals, length=None, dtype=None):
+    """``wp.vector(a, b, ...)``: a float vector of as many components as arguments"""
+    n = len(vals) if vals else int(length)
+    cls = _generic_vecs.get(n) or _generic_vecs.setdefault(n, {2: vec2, 3: vec3, 4: vec4}.get(n) or _vec_type(f"vec{n}", n))
+    return cls(*vals) if vals else cls()
 
 
 def cw_mul(a, b):
@@ -506,6 +521,8 @@ def func(f=None, *, name=None, module=None, **kw):
     if f is None:
         return lambda g: func(g, name=name, module=module, **kw)
     base = f.name if isinstance(f, Function) else f.__name__
+    if module == "unique":  # (Warp: a module of its own per function, never an overload of an earlier one)
+        return Function(name or base).add(f)
     key = (module or getattr(f, "__module__", None), name or base)
     reg = _functions.get(key)
     if reg is None:
@@ -530,7 +547,7 @@ def kernel(f=None, **kw):
 def launch(kernel, dim, inputs=(), outputs=(), device=None, stream=None, **kw):  # noqa: A002
     """Every thread in index order, one after the other (a legal schedule of the GPU launch; outputs that the reference
     accumulates with float atomics therefore come out in thread-index order)."""
-    args = list(inputs) + list(outputs)
+    args = [int32(a) if type(a) is int else (_F(a) if type(a) is float else a) for a in list(inputs) + list(outputs)]
     fn = kernel.fn if isinstance(kernel, Kernel) else kernel
     if isinstance(dim, (tuple, list)) and len(dim) > 1:
         import itertools

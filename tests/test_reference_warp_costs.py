@@ -1,0 +1,152 @@
+"""Tool-pose and c-space costs against the REFERENCE's own Warp kernels.
+
+``tests/golden/tool_pose_warp_golden.npz`` / ``cspace_warp_golden.npz``: inputs and outputs of the reference's unmodified
+``goalset_pose_distance`` kernel (rotation methods 0 / 1 / 2, goal sets, goal-frame projection, tolerances),
+``forward_cspace_state_warp`` and ``forward_cspace_position_warp`` (+ ``warp_bound_util``), executed on the CPU through
+the Warp stand-in of ``tests/golden/warp_emulator`` (generator: ``tests/golden/make_cost_warp_golden.py``).
+
+CPU: the C oracle reproduces them (c-space: to the last bit but for pow(dt, 3); tool pose: ~2e-7 relative); GPU: the HIP
+cost kernels through the C ABI at the path's 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSE_KEYS = ("distance", "position_distance", "rotation_distance", "position_gradient", "rotation_gradient")
+STATE_KEYS = ("cost", "grad_position", "grad_velocity", "grad_acceleration", "grad_jerk", "grad_effort")
+LIMITS = ("position", "velocity", "acceleration", "jerk", "effort")
+
+
+def _close(got, want, tol, what):
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol * max(1.0, float(np.abs(want).max())), err_msg=what)
+
+
+# ---------------------------------------------------------------- tool pose
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_oracle_reproduces_the_reference_tool_pose_kernel(method, oracle):
+    g = np.load(os.path.join(GOLD, "tool_pose_warp_golden.npz"))
+    r = oracle.tool_pose_distance(g["current_position"], g["current_quat"], g["goal_position"], g["goal_quat"], g["idxs_goal"].reshape(-1),
+                                  g["position_orientation_weight"], g["terminal_axes_weight"], g["non_terminal_axes_weight"],
+                                  g["terminal_tolerance"], g["non_terminal_tolerance"], g["project_distance_to_goal"].reshape(-1),
+                                  rotation_method=method)
+    k = f"method{method}/"
+    assert np.array_equal(r["goalset_idx"], g[k + "goalset_idx"])
+    want = g[k + "distance"]
+    assert 5 <= (want == 0).sum() < want.size // 2  # poses inside the tolerance are in the set, most are not
+    assert np.array_equal(np.abs(r["distance"]) <= 1e-9, want == 0)  # (an exact match is 0 there and 1e-16 here: product order)
+    for key in POSE_KEYS:
+        _close(r[key], g[k + key], 1e-6, f"method {method} {key}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_hip_reproduces_the_reference_tool_pose_kernel(method, device):
+    import torch
+
+    from curobo_amd.backends import cost as Cs
+
+    g = np.load(os.path.join(GOLD, "tool_pose_warp_golden.npz"))
+    b, h, L, _ = g["current_position"].shape
+    ng = g["goal_position"].shape[-2]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)  # noqa: E731
+    out = dict(distance=torch.zeros(b, h, 2 * L, device=device), position_distance=torch.zeros(b, h, L, device=device),
+               rotation_distance=torch.zeros(b, h, L, device=device), position_gradient=torch.zeros(b, h, L, 3, device=device),
+               rotation_gradient=torch.zeros(b, h, L, 4, device=device),
+               goalset_idx=torch.zeros(b, h, L, dtype=torch.int32, device=device))
+    Cs.tool_pose_distance(out["distance"], out["position_distance"], out["rotation_distance"], out["position_gradient"],
+                          out["rotation_gradient"], out["goalset_idx"], t(g["current_position"]), t(g["current_quat"]),
+                          t(g["goal_position"]), t(g["goal_quat"]), t(g["idxs_goal"].reshape(-1)), t(g["position_orientation_weight"]),
+                          t(g["terminal_axes_weight"]), t(g["non_terminal_axes_weight"]), t(g["terminal_tolerance"]),
+                          t(g["non_terminal_tolerance"]), t(g["project_distance_to_goal"].reshape(-1)), b, h, L, ng, method)
+    torch.cuda.synchronize()
+    k = f"method{method}/"
+    assert np.array_equal(out["goalset_idx"].cpu().numpy(), g[k + "goalset_idx"])
+    for key in POSE_KEYS:
+        _close(out[key].cpu().numpy(), g[k + key], 1e-5, f"method {method} {key}")
+
+
+# ---------------------------------------------------------------- c-space
+def _state_cases():
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    for name, prm in zip([str(x) for x in g["state_case_names"]], g["state_case_params"]):
+        yield name, prm[0:5], prm[5:10], prm[10:15], float(prm[15]), float(prm[16]), bool(prm[17]), bool(prm[18])
+
+
+def _position_cases():
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    for name, prm in zip([str(x) for x in g["position_case_names"]], g["position_case_params"]):
+        yield name, prm[0:2], prm[2:4], float(prm[4]), prm[5:7], prm[7:9]
+
+
+STATE_CASES, POSITION_CASES = list(_state_cases()), list(_position_cases())
+
+
+@pytest.mark.parametrize("case", STATE_CASES, ids=[c[0] for c in STATE_CASES])
+def test_oracle_reproduces_the_reference_cspace_state_kernel(case, oracle):
+    name, w, act, reg, tw, ntf, rt, rtr = case
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    lim = {k: g["limit_" + k] for k in LIMITS}
+    r = oracle.cspace_state_cost(g["pos"], g["vel"], g["acc"], g["jerk"], g["state_dt"], lim, w, act, reg, effort=g["effort"],
+                                 target=g["target"], idxs_target=g["idxs_target"], target_weight=tw, non_terminal_factor=ntf,
+                                 target_dof_weight=g["target_dof_weight"], retime_weights=rt, retime_regularization_weights=rtr)
+    assert (g[name + "/cost"] != 0).sum() > 100
+    for key in STATE_KEYS:
+        _close(r[key], g[f"{name}/{key}"], 1e-6, f"{name} {key}")
+
+
+@pytest.mark.parametrize("case", POSITION_CASES, ids=[c[0] for c in POSITION_CASES])
+def test_oracle_reproduces_the_reference_cspace_position_kernel(case, oracle):
+    name, w, act, tw, reg, dts = case
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    r = oracle.cspace_position_cost(g["position_pos"], g["limit_position"], w, act, effort=g["effort"], effort_b=g["limit_effort"],
+                                    cspace_target=g["target"], cspace_target_idx=g["idxs_target"], cspace_target_weight=tw,
+                                    cspace_target_dof_weight=g["target_dof_weight"], squared_l2_reg_weight=reg,
+                                    current_position=g["position_current_position"], current_velocity=g["position_current_velocity"],
+                                    idxs_current_state=g["position_idxs_current_state"], v_b=g["limit_velocity"], state_dt=dts)
+    assert (g[name + "/cost"] != 0).sum() > 20
+    for key in ("cost", "grad_position", "grad_effort"):
+        _close(r[key], g[f"{name}/{key}"], 1e-6, f"{name} {key}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", STATE_CASES, ids=[c[0] for c in STATE_CASES])
+def test_hip_reproduces_the_reference_cspace_state_kernel(case, device):
+    import torch
+
+    from curobo_amd.backends import cost as Cs
+
+    name, w, act, reg, tw, ntf, rt, rtr = case
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    b, h, d = g["pos"].shape
+    f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)  # noqa: E731
+    outs = [torch.zeros(b, h, d, device=device) for _ in range(6)]
+    Cs.cspace_state_cost(*outs, f(g["pos"]), f(g["vel"]), f(g["acc"]), f(g["jerk"]), f(g["effort"]), f(g["state_dt"]), f(g["target"]),
+                         torch.as_tensor(g["idxs_target"].astype(np.int32), device=device), *[f(g["limit_" + k]) for k in LIMITS],
+                         f(w), f(act), f(reg), f([tw]), f([ntf]), f(g["target_dof_weight"]), True, b, h, d, rt, rtr)
+    torch.cuda.synchronize()
+    for o, key in zip(outs, STATE_KEYS):
+        _close(o.cpu().numpy(), g[f"{name}/{key}"], 1e-5, f"{name} {key}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", POSITION_CASES, ids=[c[0] for c in POSITION_CASES])
+def test_hip_reproduces_the_reference_cspace_position_kernel(case, device):
+    import torch
+
+    from curobo_amd.backends import cost as Cs
+
+    name, w, act, tw, reg, dts = case
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    b, h, d = g["position_pos"].shape
+    f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)  # noqa: E731
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)  # noqa: E731
+    oc, og, ot = (torch.zeros(b, h, d, device=device) for _ in range(3))
+    Cs.cspace_position_cost(oc, og, ot, f(g["position_pos"]), f(g["effort"]), f(g["target"]), i32(g["idxs_target"]), f(g["limit_position"]),
+                            f(g["limit_effort"]), f(w), f(act), f([tw]), f(g["target_dof_weight"]), f(reg), f(g["position_current_position"]),
+                            f(g["position_current_velocity"]), i32(g["position_idxs_current_state"]), f(g["limit_velocity"]), f(dts),
+                            True, b, h, d)
+    torch.cuda.synchronize()
+    for o, key in zip((oc, og, ot), ("cost", "grad_position", "grad_effort")):
+        _close(o.cpu().numpy(), g[f"{name}/{key}"], 1e-5, f"{name} {key}")
