@@ -397,7 +397,10 @@ class array:
         return d(int(x))
 
     def __getitem__(self, idx):
-        return self._wrap(self.a[idx])
+        x = self.a[idx]
+        if isinstance(x, np.ndarray) and x.ndim > (1 if self.vec else 0):  # a row / slab of a 2-d / 3-d array
+            return array(x, dtype=self.dtype)
+        return self._wrap(x)
 
     def __setitem__(self, idx, val):
         if self.vec:
@@ -467,6 +470,140 @@ def atomic_min(arr, *args):
     old = arr[idx]
     arr[idx] = min(old, val)
     return old
+
+
+# ----------------------------------------------------------------------------- tiles (the block-cooperative API)
+class Tile:
+    """a block-wide register tile: here just an fp32 numpy array"""
+
+    __array_ufunc__ = None
+
+    def __init__(self, a):
+        self.a = np.array(a, dtype=np.float32)
+
+    shape = property(lambda s: s.a.shape)
+
+    def __getitem__(self, i):
+        x = self.a[i]
+        return Tile(x) if isinstance(x, np.ndarray) and x.ndim else _F(x)
+
+    def __setitem__(self, i, v):
+        self.a[i] = v.a if isinstance(v, Tile) else v
+
+
+def _shape(shape):
+    return tuple(int(x) for x in shape) if hasattr(shape, "__len__") else (int(shape),)
+
+
+def tile_load(arr, shape=None, offset=None, **kw):
+    a = arr.a if isinstance(arr, array) else np.asarray(arr)
+    shp = _shape(shape)
+    if offset is not None:
+        a = a[tuple(slice(int(o), int(o) + n) for o, n in zip(_shape(offset), shp))]
+    return Tile(np.asarray(a, np.float32).reshape(shp))
+
+
+def tile_store(arr, t, offset=None, **kw):
+    dst = arr.a if isinstance(arr, array) else arr
+    if offset is not None:
+        dst = dst[tuple(slice(int(o), int(o) + n) for o, n in zip(_shape(offset), t.a.shape))]
+    dst[...] = t.a.reshape(dst.shape)
+
+
+def tile_zeros(shape=None, dtype=None, **kw):
+    return Tile(np.zeros(_shape(shape), np.float32))
+
+
+def tile_ones(shape=None, dtype=None, **kw):
+    return Tile(np.ones(_shape(shape), np.float32))
+
+
+def tile_transpose(t):
+    return Tile(t.a.T.copy())
+
+
+def tile_matmul(a, b, out=None):
+    """out += a b, every product and sum rounded to fp32 in index order"""
+    A, B = a.a, b.a
+    C = np.zeros((A.shape[0], B.shape[1]), np.float32) if out is None else out.a
+    for i in range(A.shape[0]):
+        for j in range(B.shape[1]):
+            acc = _F(C[i, j])
+            for k in range(A.shape[1]):
+                acc = _F(acc + _F(A[i, k] * B[k, j]))
+            C[i, j] = acc
+    return Tile(C) if out is None else out
+
+
+def tile_diag_add(a, d):
+    r = a.a.copy()
+    r[np.arange(r.shape[0]), np.arange(r.shape[0])] += d.a
+    return Tile(r)
+
+
+def tile_map(op, *tiles):
+    out = np.empty_like(tiles[0].a)
+    flat = [t.a.reshape(-1) for t in tiles]
+    o = out.reshape(-1)
+    for i in range(o.size):
+        o[i] = op(*[_F(f[i]) for f in flat])
+    return Tile(out)
+
+
+def tile_sum(t):
+    acc = _F(0.0)
+    for x in t.a.reshape(-1):
+        acc = _F(acc + x)
+    return Tile(np.array([acc], np.float32))
+
+
+def tile_cholesky(A):
+    """lower factor, row by row (Cholesky-Banachiewicz), fp32"""
+    a = A.a
+    n = a.shape[0]
+    L = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in range(i + 1):
+            acc = _F(a[i, j])
+            for k in range(j):
+                acc = _F(acc - _F(L[i, k] * L[j, k]))
+            L[i, j] = _F(np.sqrt(acc)) if i == j else _F(acc / L[j, j])
+    return Tile(L)
+
+
+def tile_cholesky_solve(L, y):
+    """solve L L^T x = y"""
+    l, b = L.a, y.a.reshape(-1)
+    n = l.shape[0]
+    z = np.zeros(n, np.float32)
+    for i in range(n):
+        acc = _F(b[i])
+        for k in range(i):
+            acc = _F(acc - _F(l[i, k] * z[k]))
+        z[i] = _F(acc / l[i, i])
+    x = np.zeros(n, np.float32)
+    for i in range(n - 1, -1, -1):
+        acc = _F(z[i])
+        for k in range(i + 1, n):
+            acc = _F(acc - _F(l[k, i] * x[k]))
+        x[i] = _F(acc / l[i, i])
+    return Tile(x.reshape(y.a.shape))
+
+
+def neg(a):
+    return -a
+
+
+def add(a, b):
+    return a + b
+
+
+def sub(a, b):
+    return a - b
+
+
+def launch_tiled(kernel, dim, inputs=(), outputs=(), block_dim=None, **kw):
+    return launch(kernel, dim, inputs=inputs, outputs=outputs)
 
 
 # ----------------------------------------------------------------------------- functions, kernels, structs

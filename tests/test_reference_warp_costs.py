@@ -150,3 +150,38 @@ def test_hip_reproduces_the_reference_cspace_position_kernel(case, device):
     torch.cuda.synchronize()
     for o, key in zip((oc, og, ot), ("cost", "grad_position", "grad_effort")):
         _close(o.cpu().numpy(), g[f"{name}/{key}"], 1e-5, f"{name} {key}")
+
+
+# ---------------------------------------------------------------- Levenberg-Marquardt step (Warp tile kernel)
+LM_TAGS = ("ik13x7", "r20x6")
+
+
+@pytest.mark.parametrize("tag", LM_TAGS)
+def test_oracle_reproduces_the_reference_lm_tile_kernel(tag, oracle):
+    """``LevenbergMarquardtStep.create_lm_warp_kernel`` run through the stand-in's tile API (generator
+    ``tests/golden/make_lm_warp_golden.py``): the step, q_out = q_in + delta, and the predicted reduction
+    0.5 * delta . (lambda delta - J^T e) -- same fp32 arithmetic in index order, so the oracle agrees to the last bit"""
+    g = np.load(os.path.join(GOLD, "lm_warp_golden.npz"))
+    q, pred = oracle.lm_step(g[tag + "/jacobian"], g[tag + "/jTerror"], g[tag + "/lambda"], g[tag + "/joint_position_in"])
+    _close(q, g[tag + "/joint_position_out"], 1e-6, tag + " joint_position_out")
+    _close(pred, g[tag + "/pred_reduction"], 1e-6, tag + " pred_reduction")
+    assert np.all(g[tag + "/pred_reduction"] > 0)  # a descent step of the damped model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", LM_TAGS)
+def test_hip_reproduces_the_reference_lm_tile_kernel(tag, device):
+    """the MFMA kernel sums J^T J in tile order, not index order: same tolerances as its test against the oracle"""
+    import torch
+
+    from curobo_amd.backends import linalg as La
+
+    g = np.load(os.path.join(GOLD, "lm_warp_golden.npz"))
+    J, jte, lam, q = (g[f"{tag}/{k}"] for k in ("jacobian", "jTerror", "lambda", "joint_position_in"))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)  # noqa: E731
+    q_out, pred = torch.zeros(q.shape, device=device), torch.zeros(q.shape[0], device=device)
+    La.levenberg_marquardt_step(q_out, pred, t(J), t(jte), t(lam), t(q))
+    torch.cuda.synchronize()
+    d_ref = g[tag + "/joint_position_out"] - q
+    np.testing.assert_allclose(q_out.cpu().numpy() - q, d_ref, rtol=2e-3, atol=5e-4 * np.abs(d_ref).max())
+    np.testing.assert_allclose(pred.cpu().numpy(), g[tag + "/pred_reduction"], rtol=2e-3, atol=1e-4 * np.abs(g[tag + "/pred_reduction"]).max())
