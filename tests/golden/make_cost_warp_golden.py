@@ -36,6 +36,7 @@ import warp as wp  # noqa: E402
 from curobo._src.cost.wp_cspace_position import forward_cspace_position_warp  # noqa: E402
 from curobo._src.cost.wp_cspace_state import forward_cspace_state_warp  # noqa: E402
 from curobo._src.cost.wp_tool_pose import create_goalset_pose_distance_kernel_with_constants  # noqa: E402
+from curobo._src.cost.wp_torch_cspace_dist import forward_l2_warp  # noqa: E402
 
 
 def unit(q):
@@ -160,6 +161,16 @@ def cspace():
         print(name, "nonzero", int((o[0] > 0).sum()), "of", n, "max cost", float(o[0].max()))
     out["position_case_names"] = np.array([m[0] for m in meta])
     out["position_case_params"] = np.array([m[1:] for m in meta], np.float64)  # weight[2], activation[2], target_w, sql2[2], state_dt[2]
+    # ---- joint-space L2 distance to a target (cost/wp_torch_cspace_dist.py: forward_l2_warp, as L2DistFunction.forward)
+    term_w = np.array([1.0, 0.5, 2.0, 0.0, 1.0, 1.0, 0.25], np.float32)
+    nonterm_w = np.array([0.1, 0.0, 0.2, 0.3, 0.0, 0.1, 0.05], np.float32)
+    o = [np.full(n, -7.0, np.float32) for _ in range(2)]  # entries of zero weight are not written
+    f = lambda a: wp.array(np.ascontiguousarray(a, np.float32).reshape(-1))  # noqa: E731
+    wp.launch(kernel=forward_l2_warp, dim=n, inputs=[f(pos), f(target), wp.array(idxs_target, dtype=wp.int32), f([3.5]), f(term_w), f(nonterm_w),
+                                                      wp.array(o[0]), wp.array(o[1]), wp.uint8(1), B, H, D])
+    out.update(l2_terminal_dof_weight=term_w, l2_non_terminal_dof_weight=nonterm_w, l2_weight=np.float32(3.5),
+               **{"l2/cost": o[0].reshape(B, H, D), "l2/grad_position": o[1].reshape(B, H, D)})
+    print("l2 untouched entries", int((o[0] == -7.0).sum()), "of", n)
     path = os.path.join(HERE, "cspace_warp_golden.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path))

@@ -152,6 +152,38 @@ def test_hip_reproduces_the_reference_cspace_position_kernel(case, device):
         _close(o.cpu().numpy(), g[f"{name}/{key}"], 1e-5, f"{name} {key}")
 
 
+def test_reference_l2_distance_kernel_golden_is_the_closed_form():
+    """``forward_l2_warp`` (cost/wp_torch_cspace_dist.py) through the stand-in: w r_d (q - target)^2 with the terminal
+    weights on the last point, entries of zero weight left untouched"""
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    b, h, d = g["pos"].shape
+    r = np.broadcast_to(g["l2_non_terminal_dof_weight"], (b, h, d)).copy()
+    r[:, -1] = g["l2_terminal_dof_weight"]
+    w = np.float32(g["l2_weight"]) * r
+    err = g["pos"] - g["target"][g["idxs_target"]][:, None, :]
+    assert np.array_equal(g["l2/cost"] == -7.0, w == 0) and np.array_equal(g["l2/grad_position"] == -7.0, w == 0)
+    m = w != 0
+    np.testing.assert_allclose(g["l2/cost"][m], (w * err * err)[m], rtol=1e-6)
+    np.testing.assert_allclose(g["l2/grad_position"][m], (2 * w * err)[m], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_reference_l2_distance_kernel(device):
+    import torch
+
+    from curobo_amd.backends import cost as Cs
+
+    g = np.load(os.path.join(GOLD, "cspace_warp_golden.npz"))
+    b, h, d = g["pos"].shape
+    f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)  # noqa: E731
+    oc, og = torch.full((b, h, d), -7.0, device=device), torch.full((b, h, d), -7.0, device=device)
+    Cs.cspace_l2_distance(oc, og, f(g["pos"]), f(g["target"]), torch.as_tensor(g["idxs_target"].astype(np.int32), device=device),
+                          f([g["l2_weight"]]), f(g["l2_terminal_dof_weight"]), f(g["l2_non_terminal_dof_weight"]), True, b, h, d)
+    torch.cuda.synchronize()
+    _close(oc.cpu().numpy(), g["l2/cost"], 1e-6, "l2 cost")
+    _close(og.cpu().numpy(), g["l2/grad_position"], 1e-6, "l2 grad")
+
+
 # ---------------------------------------------------------------- Levenberg-Marquardt step (Warp tile kernel)
 LM_TAGS = ("ik13x7", "r20x6")
 
