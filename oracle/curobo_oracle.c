@@ -468,8 +468,10 @@ ORC_API void orc_self_collision(float *out_distance, float *out_gradient, float 
  *   geom/collision/wp_collision_kernel.py:70-166, wp_sweep_collision_kernel.py:83-260,
  *   wp_collision_common.py:11-38, geom/data/data_cuboid.py:547-628, data_voxel.py:709-1215,
  *   geom/data/helper_pose.py:13-90.  Warp intrinsics (transform_point, quat_rotate,
- *   transform_inverse) are restated from their definitions (warp-lang, unpinned
+ *   transform_inverse) are restated from their definitions (warp-lang is not in the tree,
  *   pyproject.toml:38): quat_rotate(q,v) = v(2w^2-1) + 2w(q x v) + 2q(q.v).
+ *   Pinned by the reference's own kernel sources run on the CPU through the Warp stand-in of
+ *   tests/golden/warp_emulator (tests/golden/scene_warp_golden.npz: bit-equal distances).
  *   Obstacle sums are accumulated in obstacle-index order (the reference uses float atomics
  *   whose order is undefined), cuboids first then voxel grids.
  * ---------------------------------------------------------------------------------------- */

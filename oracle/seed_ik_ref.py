@@ -14,9 +14,9 @@ The state update is pinned bit-exactly by the reference's own SeedIterationState
 (tests/golden/seed_ik_update_golden.npz, tests/golden/make_seed_ik_golden.py), the joint-limit block
 (with and without velocity clamping of the bounds) by the reference's own
 SeedIKErrorCalculator._compute_joint_limit_errors (tests/golden/seed_ik_limits_golden.npz).  Parity of the other
-pieces is pinned where they are defined (oracle/curobo_oracle.c); the LM step itself is
-"parity unpinned" against the reference (Warp tile kernel, no numeric test upstream) and pinned
-against numpy.linalg.solve in tests/test_oracle_linalg.py.
+pieces is pinned where they are defined (oracle/curobo_oracle.c); the LM step is pinned by the reference's own Warp
+tile kernel run on the CPU through the stand-in of tests/golden/warp_emulator (tests/golden/lm_warp_golden.npz,
+bit-equal) and against numpy.linalg.solve in tests/test_oracle_linalg.py.
 """
 
 from __future__ import annotations
