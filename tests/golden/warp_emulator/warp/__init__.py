@@ -737,7 +737,8 @@ class _Config(types.SimpleNamespace):
     pass
 
 
-config = _Config(quiet=True, mode="release", verify_cuda=False, enable_backward=False, kernel_cache_dir=None)
+config = _Config(quiet=True, mode="release", verify_cuda=False, enable_backward=False, kernel_cache_dir=None,
+                 version="1.9.0")  # (the reference only compares it against minimum versions)
 
 
 class _Anything:
