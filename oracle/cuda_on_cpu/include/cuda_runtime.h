@@ -34,6 +34,10 @@ CUOC_VEC(float, float2, float3, float4)
 CUOC_VEC(int, int2, int3, int4)
 CUOC_VEC(unsigned, uint2, uint3_, uint4)
 CUOC_VEC(double, double2, double3, double4)
+CUOC_VEC(short, short2, short3, short4)
+CUOC_VEC(unsigned short, ushort2, ushort3, ushort4)
+CUOC_VEC(signed char, char2, char3, char4)
+CUOC_VEC(unsigned char, uchar2, uchar3, uchar4)
 inline uint3 make_uint3(unsigned x, unsigned y, unsigned z) { return uint3{x, y, z}; }
 
 namespace cuoc {
@@ -58,12 +62,13 @@ inline unsigned __ballot_sync(unsigned mask, int pred) { return cuoc::ballot(mas
 inline unsigned __activemask() { return 0xffffffffu; }
 template <typename T>
 inline T cuoc_shfl(unsigned mask, T v, int src_lane) {
-  static_assert(sizeof(T) == 4, "32-bit shuffles only");
-  uint32_t b;
-  std::memcpy(&b, &v, 4);
-  b = cuoc::shfl_bits(mask, b, src_lane);
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- and 64-bit shuffles only");
+  uint32_t b[2] = {0, 0};
+  std::memcpy(b, &v, sizeof(T));
+  b[0] = cuoc::shfl_bits(mask, b[0], src_lane);
+  if (sizeof(T) == 8) b[1] = cuoc::shfl_bits(mask, b[1], src_lane);  // (as the hardware does: two 32-bit exchanges)
   T r;
-  std::memcpy(&r, &b, 4);
+  std::memcpy(&r, b, sizeof(T));
   return r;
 }
 inline int cuoc_lane() { return (int)((threadIdx.x + threadIdx.y * blockDim.x + threadIdx.z * blockDim.x * blockDim.y) & 31u); }

@@ -5,6 +5,9 @@
 #include "simt.hpp"
 
 #include "kinematics/kinematics_forward_kernel.cuh"
+#include "geometry/self_collision/self_collision_kernel.cuh"
+#include "kinematics/kinematics_backward_kernel.cuh"
+#include "trajectory/bspline/bspline_kernel.cuh"
 
 using namespace curobo::kinematics;
 
@@ -85,5 +88,108 @@ extern "C" int ref_kinematics_forward_spheres(
     }
   };
   cuoc::launch(grid, block, smem, body);
+  return 0;
+}
+
+// self_collision_max_distance_kernel<false> (one block per point), reference launch: cuda_core_backend/geometry.py:98-144
+extern "C" int ref_self_collision_distance(float *out_distance, float *out_vec, float *pair_distance, uint8_t *sparse_index,
+                                           const float *robot_spheres, const float *sphere_padding, const float *weight,
+                                           int16_t *pair_locations, int batch_size, int horizon, int nspheres, int num_collision_pairs,
+                                           int max_threads_per_block, int compute_grad) {
+  int threads = std::min(max_threads_per_block, num_collision_pairs);
+  threads = std::min(((threads + 31) / 32) * 32, max_threads_per_block);
+  const dim3 grid(batch_size * horizon), block(threads);
+  auto body = [&] {
+    curobo::geometry::self_collision::self_collision_max_distance_kernel<false>(
+        out_distance, out_vec, pair_distance, sparse_index, robot_spheres, sphere_padding, weight, pair_locations, batch_size, horizon,
+        nspheres, num_collision_pairs, compute_grad != 0);
+  };
+  cuoc::launch(grid, block, (size_t)16 * nspheres, body);
+  return 0;
+}
+
+// kinematics_backward_kernel<float, float, MAX_JOINTS, true (warp reduce), COM, false>, reference launch:
+// cuda_core_backend/kinematics.py:293-379, geometry of kinematics_config.py:94-175 (num_spheres < 5000 branch)
+template <int16_t MAXJ>
+static void backward_launch(dim3 grid, dim3 block, size_t smem, bool com, float *grad_q, const float *g_pos, const float *g_quat,
+                            const float *g_sph, const float *g_com, const float *b_com, const float *g_jac, const float *cumul,
+                            const float *robot_spheres, const float *masses, const int8_t *jtype, const int16_t *jmap,
+                            const int16_t *lmap, const int16_t *tmap, const int16_t *smap, const int32_t *env, const int16_t *lcd,
+                            const int16_t *lco, const int16_t *jld, const int16_t *jlo, const bool *jae, const float *joff, int B, int H,
+                            int S, int L, int J, int T, int E, int tpb) {
+  auto body = [&] {
+    if (com)
+      kinematics_backward_kernel<float, float, MAXJ, true, true, false>(grad_q, g_pos, g_quat, g_sph, g_com, b_com, g_jac, cumul,
+          robot_spheres, masses, jtype, jmap, lmap, tmap, smap, env, lcd, lco, jld, jlo, jae, joff, B, H, S, L, J, T, E, tpb);
+    else
+      kinematics_backward_kernel<float, float, MAXJ, true, false, false>(grad_q, g_pos, g_quat, g_sph, g_com, b_com, g_jac, cumul,
+          robot_spheres, masses, jtype, jmap, lmap, tmap, smap, env, lcd, lco, jld, jlo, jae, joff, B, H, S, L, J, T, E, tpb);
+  };
+  cuoc::launch(grid, block, smem, body);
+}
+
+extern "C" int ref_kinematics_backward(
+    float *grad_q, const float *grad_link_pos, const float *grad_link_quat, const float *grad_spheres, const float *grad_com,
+    const float *batch_com, const float *global_cumul, const float *robot_spheres, const float *link_masses_com,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const int16_t *tool_frame_map,
+    const int16_t *link_sphere_map, const int32_t *env_query_idx, const int16_t *link_chain_data, const int16_t *link_chain_offsets,
+    const int16_t *joint_links_data, const int16_t *joint_links_offsets, const bool *joint_affects_endeffector, const float *joint_offset,
+    int batch_size, int horizon, int nspheres, int num_links, int n_joints, int n_tool_frames, int num_envs, int compute_com) {
+  const int max_threads = 128, tpb = 32;
+  int bpb = std::min(MAX_BW_BATCH_PER_BLOCK, (48 * 1024) / (num_links * 12 * 4));
+  if (bpb * tpb > max_threads) bpb = max_threads / tpb;
+  bpb = std::max(1, std::min(bpb, batch_size));
+  const dim3 block(bpb * tpb), grid((batch_size * tpb + bpb * tpb - 1) / (bpb * tpb));
+  const size_t smem = (size_t)bpb * num_links * 12 * 4;
+#define CUOC_BW(MAXJ) backward_launch<MAXJ>(grid, block, smem, compute_com != 0, grad_q, grad_link_pos, grad_link_quat, grad_spheres, grad_com, \
+    batch_com, nullptr, global_cumul, robot_spheres, link_masses_com, joint_map_type, joint_map, link_map, tool_frame_map, link_sphere_map,   \
+    env_query_idx, link_chain_data, link_chain_offsets, joint_links_data, joint_links_offsets, joint_affects_endeffector, joint_offset,       \
+    batch_size, horizon, nspheres, num_links, n_joints, n_tool_frames, num_envs, tpb)
+  if (n_joints < 16) CUOC_BW(16);
+  else if (n_joints < 64) CUOC_BW(64);
+  else CUOC_BW(128);
+#undef CUOC_BW
+  return 0;
+}
+
+// interpolate_bspline_kernel<float, Degree, MATRIX> and bspline_backward_kernel<Degree, float, MATRIX>; reference launch:
+// cuda_core_backend/trajectory.py:21-207, geometry of trajectory_config.py:124-174
+namespace bs = curobo::trajectory::bspline;
+template <int DEG>
+static void bspline_fwd(float *p, float *v, float *a, float *j, float *out_dt, const float *u, const float *sp, const float *sv,
+                        const float *sa, const float *sj, const float *gp, const float *gv, const float *ga, const float *gj,
+                        const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt, const uint8_t *implicit, int B, int PH,
+                        int D, int K) {
+  const int k_size = B * D * PH, threads = std::min(k_size, 128);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    bs::interpolate_bspline_kernel<float, DEG, bs::BasisBackend::MATRIX>(p, v, a, j, out_dt, u, sp, sv, sa, sj, gp, gv, ga, gj, start_idx,
+                                                                        goal_idx, traj_dt, implicit, B, PH, D, K);
+  });
+}
+template <int DEG>
+static void bspline_bwd(float *out, const float *gp, const float *gv, const float *ga, const float *gj, const float *traj_dt,
+                        const int32_t *dt_idx, const uint8_t *implicit, int B, int H, int D, int K) {
+  const bs::BSplineBackwardLayout layout = bs::compute_bspline_backward_layout<DEG>(H, D, K);
+  const int k_size = B * D * layout.threads_for_n_knots, threads = std::min(k_size, 128);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    bs::bspline_backward_kernel<DEG, float, bs::BasisBackend::MATRIX>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
+  });
+}
+extern "C" int ref_bspline_forward(float *p, float *v, float *a, float *j, float *out_dt, const float *u, const float *sp, const float *sv,
+                                   const float *sa, const float *sj, const float *gp, const float *gv, const float *ga, const float *gj,
+                                   const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt, const uint8_t *implicit, int B,
+                                   int PH, int D, int K, int degree) {
+  if (degree == 3) bspline_fwd<3>(p, v, a, j, out_dt, u, sp, sv, sa, sj, gp, gv, ga, gj, start_idx, goal_idx, traj_dt, implicit, B, PH, D, K);
+  else if (degree == 4) bspline_fwd<4>(p, v, a, j, out_dt, u, sp, sv, sa, sj, gp, gv, ga, gj, start_idx, goal_idx, traj_dt, implicit, B, PH, D, K);
+  else if (degree == 5) bspline_fwd<5>(p, v, a, j, out_dt, u, sp, sv, sa, sj, gp, gv, ga, gj, start_idx, goal_idx, traj_dt, implicit, B, PH, D, K);
+  else return 1;
+  return 0;
+}
+extern "C" int ref_bspline_backward(float *out, const float *gp, const float *gv, const float *ga, const float *gj, const float *traj_dt,
+                                    const int32_t *dt_idx, const uint8_t *implicit, int B, int H, int D, int K, int degree) {
+  if (degree == 3) bspline_bwd<3>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
+  else if (degree == 4) bspline_bwd<4>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
+  else if (degree == 5) bspline_bwd<5>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
+  else return 1;
   return 0;
 }
