@@ -1,0 +1,139 @@
+"""ctypes wrapper of ``oracle/_ref/libcurobo_ref.so``: THE REFERENCE'S OWN CUDA KERNELS, run on the CPU.
+
+Test infrastructure (like everything under ``oracle/``).  The library is built by ``make -C oracle/cuda_on_cpu`` (called
+from ``__graft_entry__.build()`` when ``/root/reference`` exists) from the reference's kernel sources where they lie, with
+g++, over a CUDA-on-CPU shim: a CUDA block is a group of std::threads, ``__syncthreads`` / ``__syncwarp`` /
+``__shfl_*_sync`` / ``__ballot_sync`` / shared memory behave as on the GPU (``oracle/cuda_on_cpu/simt.cpp``).  Kernels:
+
+    kinematics_forward_kernel, kinematics_forward_spheres_kernel, kinematics_forward_spheres_jacobian_kernel
+    kinematics_backward_kernel                              (kernels/kinematics/*.cuh)
+    self_collision_max_distance_kernel                      (kernels/geometry/self_collision/*.cuh)
+    interpolate_bspline_kernel, bspline_backward_kernel     (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
+
+The methods mirror ``oracle.Oracle`` (same arguments, same result dictionaries) so that a test can put the two side by
+side.  ``available()`` is False where the library was not built (no reference checkout and no prebuilt copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libcurobo_ref.so")
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+class ReferenceKernels:
+    def __init__(self, path: str = LIB_PATH):
+        self.lib = C.CDLL(path)
+
+    # ------------------------------------------------------------------ kinematics
+    def _tables(self, model):
+        return dict(fixed=_f32(model["fixed_transforms"]), spheres=_f32(model["link_spheres"]), masses=_f32(model["link_masses_com"]),
+                    jtype=np.ascontiguousarray(model["joint_map_type"], np.int8), jmap=_i16(model["joint_map"]), lmap=_i16(model["link_map"]),
+                    tmap=_i16(model["tool_frame_map"]), smap=_i16(model["link_sphere_idx_map"]), lcd=_i16(model["link_chain_data"]),
+                    lco=_i16(model["link_chain_offsets"]), jld=_i16(model["joint_links_data"]), jlo=_i16(model["joint_links_offsets"]),
+                    jae=np.ascontiguousarray(model["joint_affects_endeffector"]).astype(np.bool_), joff=_f32(model["joint_offset_map"]))
+
+    def kinematics_forward(self, q, model: Dict[str, np.ndarray], horizon: int = 1, env_query_idx: Optional[np.ndarray] = None,
+                           compute_jacobian: bool = False, compute_com: bool = False, compute_spheres: bool = True):
+        q = _f32(q).reshape(-1, q.shape[-1])
+        n, d = q.shape
+        t = self._tables(model)
+        L, T = t["lmap"].shape[0], t["tmap"].shape[0]
+        E, S = t["spheres"].shape[:2]
+        env = np.ascontiguousarray(env_query_idx if env_query_idx is not None else np.zeros(max(n // max(horizon, 1), 1)), np.int32)
+        out = {"link_pos": np.zeros((n, T, 3), np.float32), "link_quat": np.zeros((n, T, 4), np.float32),
+               "cumul_mat": np.zeros((n, L, 3, 4), np.float32), "com": np.zeros((n, 4), np.float32) if compute_com else None,
+               "robot_spheres": np.zeros((n, S if compute_spheres else 0, 4), np.float32),
+               "jacobian": np.zeros((n, T, 6, d), np.float32) if compute_jacobian else None}
+        com = out["com"] if compute_com else np.zeros((n, 4), np.float32)
+        if not compute_spheres and not compute_jacobian:
+            self.lib.ref_kinematics_forward(_p(out["link_pos"]), _p(out["link_quat"]), _p(com), _p(out["cumul_mat"]), _p(q), _p(t["fixed"]),
+                                            _p(t["masses"]), _p(t["jtype"]), _p(t["jmap"]), _p(t["lmap"]), _p(t["tmap"]), _p(t["joff"]), n,
+                                            horizon, L, d, T, int(compute_com))
+            return out
+        sph_out = out["robot_spheres"] if compute_spheres else np.zeros((n, S, 4), np.float32)
+        self.lib.ref_kinematics_forward_spheres(
+            _p(out["link_pos"]), _p(out["link_quat"]), _p(sph_out), _p(com), _p(out["jacobian"]), _p(out["cumul_mat"]), _p(q), _p(t["fixed"]),
+            _p(t["spheres"]), _p(t["masses"]), _p(t["jtype"]), _p(t["jmap"]), _p(t["lmap"]), _p(t["tmap"]), _p(t["smap"]), _p(t["lcd"]),
+            _p(t["lco"]), _p(t["jld"]), _p(t["jlo"]), _p(t["jae"]), _p(t["joff"]), _p(env), n, horizon, S, E, L, d, T, int(compute_com))
+        return out
+
+    def kinematics_backward(self, model, cumul_mat, grad_spheres, grad_link_pos=None, grad_link_quat=None, grad_com=None, batch_com=None,
+                            horizon: int = 1, env_query_idx: Optional[np.ndarray] = None):
+        t = self._tables(model)
+        L, T = t["lmap"].shape[0], t["tmap"].shape[0]
+        E, S = t["spheres"].shape[:2]
+        cumul = _f32(cumul_mat).reshape(-1, L, 3, 4)
+        n, d = cumul.shape[0], int(model["num_dof"])
+        gs = _f32(grad_spheres).reshape(n, S, 4) if grad_spheres is not None else np.zeros((n, S, 4), np.float32)
+        gp = _f32(grad_link_pos).reshape(n, T, 3) if grad_link_pos is not None else np.zeros((n, T, 3), np.float32)
+        gq = _f32(grad_link_quat).reshape(n, T, 4) if grad_link_quat is not None else np.zeros((n, T, 4), np.float32)
+        use_com = grad_com is not None and batch_com is not None
+        gc = _f32(grad_com) if use_com else np.zeros((n, 4), np.float32)
+        bc = _f32(batch_com) if use_com else np.zeros((n, 4), np.float32)
+        env = np.ascontiguousarray(env_query_idx if env_query_idx is not None else np.zeros(max(n // max(horizon, 1), 1)), np.int32)
+        out = np.zeros((n, d), np.float32)
+        self.lib.ref_kinematics_backward(_p(out), _p(gp), _p(gq), _p(gs), _p(gc), _p(bc), _p(cumul), _p(t["spheres"]), _p(t["masses"]),
+                                         _p(t["jtype"]), _p(t["jmap"]), _p(t["lmap"]), _p(t["tmap"]), _p(t["smap"]), _p(env), _p(t["lcd"]),
+                                         _p(t["lco"]), _p(t["jld"]), _p(t["jlo"]), _p(t["jae"]), _p(t["joff"]), n, horizon, S, L, d, T, E,
+                                         int(use_com))
+        return out
+
+    # ------------------------------------------------------------------ self collision
+    def self_collision(self, robot_spheres, sphere_padding, collision_pairs, weight: float, max_threads_per_block: int = 512,
+                       write_grad: bool = True):
+        rs = _f32(robot_spheres)
+        S = rs.shape[-2]
+        rs = rs.reshape(-1, S, 4)
+        n = rs.shape[0]
+        pairs = _i16(collision_pairs).reshape(-1, 2).copy()
+        dist, grad = np.zeros(n, np.float32), np.zeros((n, S, 4), np.float32)
+        flags, pd = np.zeros((n, S), np.uint8), np.zeros(1, np.float32)
+        self.lib.ref_self_collision_distance(_p(dist), _p(grad), _p(pd), _p(flags), _p(rs), _p(_f32(sphere_padding)),
+                                             _p(np.array([weight], np.float32)), _p(pairs), n, 1, S, pairs.shape[0], max_threads_per_block,
+                                             int(write_grad))
+        return {"distance": dist, "gradient": grad, "sparse_index": flags}
+
+    # ------------------------------------------------------------------ B-spline
+    def bspline_forward(self, u, start, goal, start_idx, goal_idx, traj_dt, use_implicit_goal, padded_horizon: int, degree: int = 3):
+        u = _f32(u)
+        b, n_knots, dof = u.shape
+        keys = ("position", "velocity", "acceleration", "jerk")
+        outs = [np.zeros((b, padded_horizon, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros(b, np.float32)
+        s, g = [_f32(start[k]) for k in keys], [_f32(goal[k]) for k in keys]
+        rc = self.lib.ref_bspline_forward(*[_p(o) for o in outs], _p(out_dt), _p(u), *[_p(x) for x in s], *[_p(x) for x in g],
+                                          _p(np.ascontiguousarray(start_idx, np.int32)), _p(np.ascontiguousarray(goal_idx, np.int32)),
+                                          _p(_f32(traj_dt)), _p(np.ascontiguousarray(use_implicit_goal, np.uint8)), b, padded_horizon, dof,
+                                          n_knots, degree)
+        assert rc == 0
+        return {**dict(zip(keys, outs)), "dt": out_dt}
+
+    def bspline_backward(self, grad_p, grad_v, grad_a, grad_j, traj_dt, dt_idx, use_implicit_goal, n_knots: int, degree: int = 3):
+        gp = _f32(grad_p)
+        b, ph, dof = gp.shape
+        out = np.zeros((b, n_knots, dof), np.float32)
+        rc = self.lib.ref_bspline_backward(_p(out), _p(gp), _p(_f32(grad_v)), _p(_f32(grad_a)), _p(_f32(grad_j)), _p(_f32(traj_dt)),
+                                           _p(np.ascontiguousarray(dt_idx, np.int32)), _p(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+                                           b, ph - 1, dof, n_knots, degree)
+        assert rc == 0
+        return out

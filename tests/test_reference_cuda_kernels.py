@@ -1,0 +1,124 @@
+"""The oracle against THE REFERENCE'S OWN CUDA KERNELS, executed on the CPU (``oracle/_ref/libcurobo_ref.so``).
+
+The reference's kinematics, self-collision and B-spline kernels are CUDA C++; ``oracle/cuda_on_cpu`` compiles their
+unmodified sources with g++ over a CUDA-on-CPU shim (a block = std::threads; barriers, warp shuffles, ballots and shared
+memory as on the GPU) and ``oracle/ref_kernels.py`` launches them with the reference's launch geometry.  These tests put
+the C oracle next to them on the same inputs: FK poses / spheres / Jacobian, B-spline and self collision agree TO THE LAST
+BIT; the FK VJP and the centre of mass to a few ulp (the kernels sum over threads in tree order).
+
+The library is built by ``__graft_entry__.build()`` where ``/root/reference`` exists and travels to the GPU box as a
+prebuilt file; the tests skip where it is absent.  ``tests/golden/cuda_kernels_golden.npz`` keeps a set of these outputs
+for places without the library (generator: ``tests/golden/make_cuda_kernels_golden.py``).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_model, sample_q
+
+from oracle import ref_kernels
+
+needs_ref = pytest.mark.skipif(not ref_kernels.available(), reason="oracle/_ref/libcurobo_ref.so not built (no /root/reference here)")
+ROBOTS = ["franka", "ur10e", "unitree_g1"]
+KEYS = ("position", "velocity", "acceleration", "jerk")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cuda_kernels_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return ref_kernels.ReferenceKernels()
+
+
+@needs_ref
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_fk_forward_kernels_bit_identical(robot, oracle, ref):
+    model = load_model(robot)
+    md = model.as_dict()
+    q = sample_q(model, 21, seed=11)
+    a = oracle.kinematics_forward(q, md, compute_jacobian=True, compute_com=True)
+    b = ref.kinematics_forward(q, md, compute_jacobian=True, compute_com=True)           # spheres + Jacobian kernel
+    c = ref.kinematics_forward(q, md, compute_spheres=False, compute_com=True)           # pose-only kernel
+    for k in ("link_pos", "link_quat", "cumul_mat", "robot_spheres", "jacobian"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("link_pos", "link_quat", "cumul_mat"):
+        assert np.array_equal(a[k], c[k]), k
+    for other in (b, c):  # centre of mass: a 16- / 32-lane shuffle tree there, a loop here
+        np.testing.assert_allclose(other["com"], a["com"], rtol=2e-6, atol=1e-6)
+
+
+@needs_ref
+@pytest.mark.parametrize("robot", ROBOTS)
+@pytest.mark.parametrize("with_com", [False, True])
+def test_fk_backward_kernel(robot, with_com, oracle, ref):
+    model = load_model(robot)
+    md = model.as_dict()
+    rng = np.random.default_rng(3)
+    n = 9
+    fk = oracle.kinematics_forward(sample_q(model, n, seed=12), md, compute_com=True)
+    S, T = fk["robot_spheres"].shape[1], fk["link_pos"].shape[1]
+    gs = rng.standard_normal((n, S, 4)).astype(np.float32)
+    gs[..., 3] = 0
+    gs[rng.random((n, S)) < 0.5] = 0
+    gp, gq = rng.standard_normal((n, T, 3)).astype(np.float32), rng.standard_normal((n, T, 4)).astype(np.float32)
+    gc = rng.standard_normal((n, 4)).astype(np.float32)
+    args = (md, fk["cumul_mat"], gs, gp, gq) + ((gc, fk["com"]) if with_com else ())
+    a, b = oracle.kinematics_backward(*args), ref.kinematics_backward(*args)
+    np.testing.assert_allclose(b, a, rtol=0, atol=2e-6 * np.abs(a).max())
+
+
+@needs_ref
+@pytest.mark.parametrize("robot", ["franka", "ur10e"])
+def test_self_collision_kernel_bit_identical(robot, oracle, ref):
+    model = load_model(robot)
+    sph = oracle.kinematics_forward(sample_q(model, 24, seed=13, scale=1.3), model.as_dict())["robot_spheres"]
+    a = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.5)
+    b = ref.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.5)
+    assert (a["distance"] > 0).sum() >= 3
+    assert np.array_equal(a["distance"], b["distance"]) and np.array_equal(a["gradient"], b["gradient"])
+    assert np.array_equal(a["sparse_index"], b["sparse_index"])
+
+
+def _bspline_case(degree, implicit):
+    rng = np.random.default_rng(degree)
+    b, nk, dof, interp = 7, 12, 7, 2
+    ph = (nk + degree + 1) * interp + 1
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda n: {k: (rng.normal(size=(n, dof)) * 0.3).astype(np.float32) for k in KEYS}  # noqa: E731
+    start, goal = mk(3), mk(2)
+    sidx, gidx = rng.integers(0, 3, size=b).astype(np.int32), rng.integers(0, 2, size=b).astype(np.int32)
+    dt, imp = np.array([0.05, 0.08], np.float32), np.array([implicit, implicit], np.uint8)
+    g = [rng.normal(size=(b, ph, dof)).astype(np.float32) for _ in range(4)]
+    return (u, start, goal, sidx, gidx, dt, imp, ph, degree), (*g, dt, gidx, imp, nk, degree)
+
+
+@needs_ref
+@pytest.mark.parametrize("degree", [3, 4, 5])
+@pytest.mark.parametrize("implicit", [0, 1])
+def test_bspline_kernels_bit_identical(degree, implicit, oracle, ref):
+    fwd, bwd = _bspline_case(degree, implicit)
+    a, b = oracle.bspline_forward(*fwd), ref.bspline_forward(*fwd)
+    for k in KEYS + ("dt",):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(oracle.bspline_backward(*bwd), ref.bspline_backward(*bwd))
+
+
+def test_oracle_against_the_committed_outputs_of_the_reference_kernels(oracle):
+    """the same comparison from a file, for machines without the library"""
+    g = np.load(GOLD)
+    model = load_model("franka")
+    md = model.as_dict()
+    a = oracle.kinematics_forward(g["fk/q"], md, compute_jacobian=True, compute_com=True)
+    for k in ("link_pos", "link_quat", "cumul_mat", "robot_spheres", "jacobian"):
+        assert np.array_equal(a[k], g["fk/" + k]), k
+    np.testing.assert_allclose(a["com"], g["fk/com"], rtol=2e-6, atol=1e-6)
+    vjp = oracle.kinematics_backward(md, g["fk/cumul_mat"], g["bwd/grad_spheres"], g["bwd/grad_link_pos"], g["bwd/grad_link_quat"])
+    np.testing.assert_allclose(vjp, g["bwd/grad_q"], rtol=0, atol=2e-6 * np.abs(g["bwd/grad_q"]).max())
+    sc = oracle.self_collision(g["self/spheres"], model.sphere_padding, model.collision_pairs, 1.5)
+    assert np.array_equal(sc["distance"], g["self/distance"]) and np.array_equal(sc["gradient"], g["self/gradient"])
+    assert np.array_equal(sc["sparse_index"], g["self/sparse_index"])
+    fwd, bwd = _bspline_case(3, 1)
+    bs = oracle.bspline_forward(*fwd)
+    for k in KEYS:
+        assert np.array_equal(bs[k], g["bspline/" + k]), k
+    assert np.array_equal(oracle.bspline_backward(*bwd), g["bspline/grad_knots"])
