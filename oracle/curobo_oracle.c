@@ -6,16 +6,16 @@
  * may load it.  The product path (curobo_amd) never links, imports or calls it.
  *
  * Every function cites the reference file:line (relative to NVlabs/curobo v0.8.0,
- * /root/reference) whose arithmetic it follows.  The reference kernels are CUDA/Warp and
- * cannot run in this container, so the oracle is pinned instead by (tests/test_oracle_*.py):
- *   - the reference's FK known-answer vector (curobo/tests/_src/robot/kinematics/
- *     test_kinematics.py:57-82),
- *   - the reference's own importable torch twins for L-BFGS and the Wolfe line search
- *     (curobo/_src/optim/gradient/lbfgs_jit_helpers.py:10-78,
- *      curobo/_src/optim/gradient/line_search_strategy.py:587-672),
- *   - central finite differences for every VJP (the reference's own test style,
- *     curobo/tests/_src/robot/kinematics/test_jacobian_gradcheck.py),
- *   - analytic SDF expectations for cuboids / voxel grids.
+ * /root/reference) whose arithmetic it follows.  The reference kernels are CUDA / Warp; both are
+ * run here FROM THEIR OWN SOURCES to pin this file:
+ *   - the CUDA kernels (FK, FK VJP, self collision, B-spline) on the CPU through the CUDA-on-CPU shim
+ *     of oracle/cuda_on_cpu -> oracle/_ref/libcurobo_ref.so: bit-identical outputs but for the
+ *     tree-ordered sums of the VJP / centre of mass (tests/test_reference_cuda_kernels.py),
+ *   - the Warp kernels (scene collision, sweep, speed metric, voxel lookup, tool pose, c-space, LM
+ *     step) through the Warp stand-in of tests/golden/warp_emulator (tests/test_reference_warp_*.py),
+ *   - the reference's own importable torch / NumPy twins for L-BFGS, the Wolfe line searches, MPPI,
+ *     RNEA and seed IK (tests/golden/*.npz), its FK known-answer vector, and central finite
+ *     differences for every VJP (the reference's own test style).
  *
  * Index tie rule (canonical): when several self-collision pairs share the
  * maximum penetration value the pair with the LOWEST index in pair_locations wins.  The
