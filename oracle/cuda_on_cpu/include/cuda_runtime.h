@@ -1,6 +1,6 @@
 // cuda_runtime.h of oracle/cuda_on_cpu: just enough of the CUDA C++ dialect for the reference's kernels
-// (/root/reference/curobo/_src/curobolib/kernels/**) to compile with g++ and run on the CPU, one std::thread per CUDA
-// thread, one block at a time (see simt.hpp).  TEST INFRASTRUCTURE: the reference's .cuh files are included where they
+// (/root/reference/curobo/_src/curobolib/kernels/**) to compile with g++ and run on the CPU, one fiber per CUDA thread,
+// one block at a time (see simt.hpp).  TEST INFRASTRUCTURE: the reference's .cuh files are included where they
 // lie, at build time, in the build container only; the products go to oracle/_ref/ (git-ignored).
 #pragma once
 #include <cmath>
@@ -41,8 +41,8 @@ CUOC_VEC(unsigned char, uchar2, uchar3, uchar4)
 inline uint3 make_uint3(unsigned x, unsigned y, unsigned z) { return uint3{x, y, z}; }
 
 namespace cuoc {
-extern thread_local uint3 t_threadIdx, t_blockIdx;
-extern thread_local dim3 t_blockDim, t_gridDim;
+extern uint3 t_threadIdx, t_blockIdx;   // of the fiber that is running
+extern dim3 t_blockDim, t_gridDim;
 void syncthreads();
 void syncwarp(unsigned mask);
 unsigned ballot(unsigned mask, int pred);
@@ -111,3 +111,8 @@ inline float __cosf(float a) { return std::cos(a); }
 inline void __sincosf(float a, float *s, float *c) { *s = std::sin(a); *c = std::cos(a); }
 inline void sincosf_(float a, float *s, float *c) { *s = std::sin(a); *c = std::cos(a); }
 template <typename T> inline T __ldg(const T *p) { return *p; }
+namespace cuoc { inline unsigned shl1(int n) { return n >= 32 || n < 0 ? 0u : 1u << n; } }  // 1 << n with the GPU's clamped shift
+inline unsigned __brev(unsigned x) { unsigned r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+inline int __ffs(int x) { return __builtin_ffs(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

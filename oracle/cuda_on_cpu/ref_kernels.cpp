@@ -8,6 +8,7 @@
 #include "geometry/self_collision/self_collision_kernel.cuh"
 #include "kinematics/kinematics_backward_kernel.cuh"
 #include "trajectory/bspline/bspline_kernel.cuh"
+#include "optimization/line_search/line_search_kernel.cuh"
 
 using namespace curobo::kinematics;
 
@@ -191,5 +192,26 @@ extern "C" int ref_bspline_backward(float *out, const float *gp, const float *gv
   else if (degree == 4) bspline_bwd<4>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
   else if (degree == 5) bspline_bwd<5>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D, K);
   else return 1;
+  return 0;
+}
+
+// kernel_line_search<float, -1> (one block per problem, opt_dim threads); reference launch: cuda_core_backend/optimization.py:21-110.
+// (kernel_lbfgs_step is NOT run here: it shifts and extends the rho history in warp 0 and reads it in every warp without a
+// barrier in between -- correct only under lock-step warps and favourable timing, which a cooperative schedule does not
+// reproduce.  The L-BFGS step is pinned by the reference's torch twin instead, tests/golden/optim_golden.npz.)
+extern "C" int ref_line_search(float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
+                               uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
+                               float cost_relative_threshold, float *exploration_cost, float *exploration_action,
+                               float *exploration_gradient, int32_t *exploration_idx, float *selected_cost, float *selected_action,
+                               float *selected_gradient, int32_t *selected_idx, const float *search_cost, const float *search_action,
+                               const float *search_gradient, const float *step_direction, const float *search_magnitudes, float c_1,
+                               float c_2, int strong_wolfe, int approx_wolfe, int n_linesearch, int opt_dim, int batchsize) {
+  cuoc::launch(dim3(batchsize), dim3(opt_dim), 0, [&] {
+    curobo::optimization::line_search::kernel_line_search<float, -1>(
+        best_cost, best_action, best_iteration, current_iteration, converged_global, convergence_iteration, cost_delta_threshold,
+        cost_relative_threshold, exploration_cost, exploration_action, exploration_gradient, exploration_idx, selected_cost,
+        selected_action, selected_gradient, selected_idx, search_cost, search_action, search_gradient, step_direction,
+        search_magnitudes, c_1, c_2, strong_wolfe != 0, approx_wolfe != 0, n_linesearch, opt_dim, batchsize);
+  });
   return 0;
 }

@@ -1,14 +1,25 @@
 // simt.cpp -- see simt.hpp (oracle/cuda_on_cpu, TEST INFRASTRUCTURE)
+//
+// Cooperative scheduling: the CUDA threads of a block are fibers (ucontext) that run ONE AT A TIME, in thread-index order,
+// each until it reaches a synchronisation point (__syncthreads, __syncwarp, a shuffle, a ballot) or returns; then the next
+// one runs.  That is a legal SIMT schedule, it is deterministic, and it keeps the warp-synchronous idioms of the sources
+// correct (e.g. "every lane reads its right neighbour's slot, then writes its own" without a barrier in between: lanes in
+// ascending order do exactly what lock-step lanes do).
 #include "simt.hpp"
 
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <map>
+#include <memory>
 
 namespace cuoc {
 
-thread_local uint3 t_threadIdx, t_blockIdx;
-thread_local dim3 t_blockDim, t_gridDim;
-thread_local BlockState *t_block = nullptr;
-thread_local int t_linear_tid = 0;
+uint3 t_threadIdx, t_blockIdx;
+dim3 t_blockDim, t_gridDim;
+BlockState *t_block = nullptr;
+int t_linear_tid = 0;
 
 namespace {
 
@@ -17,16 +28,35 @@ struct Rendezvous {
   unsigned long generation = 0;
   uint32_t slot[32] = {0}, snapshot[32] = {0};
   unsigned pred_bits = 0, pred_snapshot = 0;
-  unsigned participants = 0;  // the lanes that took part in the completed round (a lane may exit right after it)
+  unsigned participants = 0;  // the lanes that took part in the completed round (a lane may return right after it)
 };
 struct WarpSync {
-  std::mutex m;
-  std::condition_variable cv;
   unsigned exited = 0;
   std::map<unsigned, Rendezvous> by_mask;
 };
-thread_local WarpSync *t_warp = nullptr;
-std::mutex g_atomic;
+struct Fiber {
+  ucontext_t ctx;
+  std::unique_ptr<char[]> stack;
+  uint3 tid;
+  int linear = 0;
+  bool done = false;
+};
+struct Scheduler {
+  ucontext_t main_ctx;
+  std::vector<Fiber> fibers;
+  std::vector<WarpSync> warps;
+  int current = -1;
+  const std::function<void()> *body = nullptr;
+};
+Scheduler *g_sched = nullptr;
+constexpr size_t kStackBytes = 256 * 1024;
+
+inline WarpSync &my_warp() { return g_sched->warps[t_linear_tid >> 5]; }
+
+void yield() {  // back to the scheduler; it resumes this fiber on its next turn
+  Fiber &f = g_sched->fibers[g_sched->current];
+  swapcontext(&f.ctx, &g_sched->main_ctx);
+}
 
 inline void complete(Rendezvous &r, unsigned need) {
   for (int i = 0; i < 32; i++) r.snapshot[i] = r.slot[i];
@@ -38,8 +68,8 @@ inline void complete(Rendezvous &r, unsigned need) {
 }
 
 // every lane of `mask` that is still running meets here; returns once all have arrived
-Rendezvous &meet(unsigned mask, uint32_t value, int pred, std::unique_lock<std::mutex> &lk) {
-  WarpSync &w = *t_warp;
+Rendezvous &meet(unsigned mask, uint32_t value, int pred) {
+  WarpSync &w = my_warp();
   const int lane = t_linear_tid & 31;
   Rendezvous &r = w.by_mask[mask];
   r.slot[lane] = value;
@@ -47,55 +77,62 @@ Rendezvous &meet(unsigned mask, uint32_t value, int pred, std::unique_lock<std::
   r.arrived |= 1u << lane;
   const unsigned long gen = r.generation;
   const unsigned need = mask & ~w.exited;
-  if ((r.arrived & need) == need) {
-    complete(r, need);
-    w.cv.notify_all();
-  } else {
-    w.cv.wait(lk, [&] { return r.generation != gen; });
-  }
+  if ((r.arrived & need) == need) complete(r, need);
+  while (r.generation == gen) yield();
   return r;
+}
+
+void fiber_entry() {
+  Scheduler &s = *g_sched;
+  (*s.body)();
+  Fiber &f = s.fibers[s.current];
+  f.done = true;
+  {  // this thread is gone: nobody waits for it any more
+    WarpSync &w = s.warps[f.linear >> 5];
+    w.exited |= 1u << (f.linear & 31);
+    for (auto &kv : w.by_mask) {
+      Rendezvous &r = kv.second;
+      const unsigned need = kv.first & ~w.exited;
+      if (r.arrived != 0 && (r.arrived & need) == need) complete(r, need);
+    }
+  }
+  BlockState *b = t_block;
+  b->alive--;
+  if (b->alive > 0 && b->waiting == b->alive) {
+    b->waiting = 0;
+    b->generation++;
+  }
+  swapcontext(&f.ctx, &s.main_ctx);  // never resumed
 }
 
 }  // namespace
 
 void syncthreads() {
   BlockState *b = t_block;
-  std::unique_lock<std::mutex> lk(b->m);
   const unsigned long gen = b->generation;
   if (++b->waiting == b->alive) {
     b->waiting = 0;
     b->generation++;
-    b->cv.notify_all();
-  } else {
-    b->cv.wait(lk, [&] { return b->generation != gen; });
   }
+  while (b->generation == gen) yield();
 }
 
-void syncwarp(unsigned mask) {
-  std::unique_lock<std::mutex> lk(t_warp->m);
-  meet(mask, 0u, 0, lk);
-}
+void syncwarp(unsigned mask) { meet(mask, 0u, 0); }
 
-unsigned ballot(unsigned mask, int pred) {
-  std::unique_lock<std::mutex> lk(t_warp->m);
-  return meet(mask, 0u, pred, lk).pred_snapshot;
-}
+unsigned ballot(unsigned mask, int pred) { return meet(mask, 0u, pred).pred_snapshot; }
 
 uint32_t shfl_bits(unsigned mask, uint32_t v, int src_lane) {
-  std::unique_lock<std::mutex> lk(t_warp->m);
-  Rendezvous &r = meet(mask, v, 0, lk);
+  Rendezvous &r = meet(mask, v, 0);
   const bool valid = src_lane >= 0 && src_lane < 32 && ((r.participants >> src_lane) & 1u);
   return valid ? r.snapshot[src_lane] : v;
 }
 
 float atomic_add(float *p, float v) {
-  std::lock_guard<std::mutex> g(g_atomic);
   const float old = *p;
   *p = old + v;
   return old;
 }
 int atomic_add(int *p, int v) {
-  std::lock_guard<std::mutex> g(g_atomic);
   const int old = *p;
   *p = old + v;
   return old;
@@ -106,47 +143,43 @@ void run_block(dim3 grid, dim3 block, uint3 bidx, size_t shared_bytes, const std
   BlockState bs;
   bs.alive = n;
   bs.dyn_shared.assign(shared_bytes + 64, 0);
-  std::vector<WarpSync> warps((n + 31) / 32);
-  for (size_t w = 0; w < warps.size(); w++) {  // lanes beyond the block size never run
-    const int first = (int)w * 32;
+  Scheduler s;
+  s.body = &body;
+  s.fibers.resize(n);
+  s.warps.resize((n + 31) / 32);
+  for (size_t w = 0; w < s.warps.size(); w++)  // lanes beyond the block size never run
     for (int l = 0; l < 32; l++)
-      if (first + l >= n) warps[w].exited |= 1u << l;
-  }
-  std::vector<std::thread> threads;
-  threads.reserve(n);
+      if ((int)w * 32 + l >= n) s.warps[w].exited |= 1u << l;
   for (int t = 0; t < n; t++) {
-    threads.emplace_back([&, t] {
-      t_block = &bs;
-      t_linear_tid = t;
-      t_warp = &warps[t >> 5];
-      t_blockDim = block;
-      t_gridDim = grid;
-      t_blockIdx = bidx;
-      t_threadIdx = uint3{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
-      body();
-      {  // this thread is gone: nobody waits for it any more
-        WarpSync &w = *t_warp;
-        std::lock_guard<std::mutex> g(w.m);
-        w.exited |= 1u << (t & 31);
-        for (auto &kv : w.by_mask) {
-          Rendezvous &r = kv.second;
-          const unsigned need = kv.first & ~w.exited;
-          if (r.arrived != 0 && (r.arrived & need) == need) complete(r, need);
-        }
-        w.cv.notify_all();
-      }
-      {
-        std::lock_guard<std::mutex> g(bs.m);
-        bs.alive--;
-        if (bs.alive > 0 && bs.waiting == bs.alive) {
-          bs.waiting = 0;
-          bs.generation++;
-          bs.cv.notify_all();
-        }
-      }
-    });
+    Fiber &f = s.fibers[t];
+    f.linear = t;
+    f.tid = uint3{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+    f.stack.reset(new char[kStackBytes]);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.get();
+    f.ctx.uc_stack.ss_size = kStackBytes;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
   }
-  for (auto &th : threads) th.join();
+  Scheduler *outer = g_sched;
+  g_sched = &s;
+  t_block = &bs;
+  t_blockDim = block;
+  t_gridDim = grid;
+  t_blockIdx = bidx;
+  unsigned long rounds = 0;
+  while (bs.alive > 0) {
+    if (++rounds > 50000000ul) { std::fprintf(stderr, "cuoc: no progress in block (%u, %u, %u): a barrier that not every thread reaches?\n", bidx.x, bidx.y, bidx.z); std::abort(); }
+    for (int t = 0; t < n; t++) {
+      Fiber &f = s.fibers[t];
+      if (f.done) continue;
+      s.current = t;
+      t_linear_tid = t;
+      t_threadIdx = f.tid;
+      swapcontext(&s.main_ctx, &f.ctx);
+    }
+  }
+  g_sched = outer;
 }
 
 }  // namespace cuoc

@@ -1,18 +1,15 @@
-// simt.hpp -- a CUDA block as a group of std::threads (oracle/cuda_on_cpu, TEST INFRASTRUCTURE).
+// simt.hpp -- a CUDA block as a group of cooperatively scheduled fibers (oracle/cuda_on_cpu, TEST INFRASTRUCTURE).
 //
 // The reference's kernels (/root/reference/curobo/_src/curobolib/kernels) are CUDA C++.  There is no nvcc / NVRTC and no
 // NVIDIA GPU here, but the kernels only use a small part of the execution model: threadIdx / blockIdx / blockDim,
 // __syncthreads, __syncwarp(mask), __shfl_*_sync, __ballot_sync, atomicAdd, static and dynamic shared memory.  This
 // runtime gives them exactly that on the CPU: launch() runs the blocks of a grid one after the other; every CUDA thread
-// of a block is a std::thread; __syncthreads is a barrier over the threads of the block that have not returned yet;
-// warp-level primitives meet on a per-warp rendezvous keyed by the mask.  Exited threads never block a barrier (as on
-// the GPU).  Slow (thread creation per block) and meant for a few hundred blocks.
+// of a block is a fiber; fibers run one at a time in thread-index order, each up to its next synchronisation point;
+// __syncthreads is a barrier over the threads of the block that have not returned yet; warp-level primitives meet on a
+// per-warp rendezvous keyed by the mask.  Returned threads never block a barrier (as on the GPU).  Deterministic.
 #pragma once
-#include <condition_variable>
 #include <cstdint>
 #include <functional>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #include "cuda_runtime.h"
@@ -20,15 +17,13 @@
 namespace cuoc {
 
 struct BlockState {
-  std::mutex m;
-  std::condition_variable cv;
   int alive = 0, waiting = 0;
   unsigned long generation = 0;
   std::vector<unsigned char> dyn_shared;
 };
 
-extern thread_local BlockState *t_block;
-extern thread_local int t_linear_tid;
+extern BlockState *t_block;
+extern int t_linear_tid;
 
 // dynamic shared memory of the running block (`extern __shared__ T name[]` in the sources is rewritten to
 // `T *name = cuoc::dyn_shared<T>();` by the build recipe: C++ has no array of unknown bound with static storage)

@@ -2,13 +2,14 @@
 
 Test infrastructure (like everything under ``oracle/``).  The library is built by ``make -C oracle/cuda_on_cpu`` (called
 from ``__graft_entry__.build()`` when ``/root/reference`` exists) from the reference's kernel sources where they lie, with
-g++, over a CUDA-on-CPU shim: a CUDA block is a group of std::threads, ``__syncthreads`` / ``__syncwarp`` /
+g++, over a CUDA-on-CPU shim: a CUDA block is a group of cooperatively scheduled fibers, ``__syncthreads`` / ``__syncwarp`` /
 ``__shfl_*_sync`` / ``__ballot_sync`` / shared memory behave as on the GPU (``oracle/cuda_on_cpu/simt.cpp``).  Kernels:
 
     kinematics_forward_kernel, kinematics_forward_spheres_kernel, kinematics_forward_spheres_jacobian_kernel
     kinematics_backward_kernel                              (kernels/kinematics/*.cuh)
     self_collision_max_distance_kernel                      (kernels/geometry/self_collision/*.cuh)
     interpolate_bspline_kernel, bspline_backward_kernel     (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
+    kernel_line_search                                      (kernels/optimization/line_search/*.cuh)
 
 The methods mirror ``oracle.Oracle`` (same arguments, same result dictionaries) so that a test can put the two side by
 side.  ``available()`` is False where the library was not built (no reference checkout and no prebuilt copy).
@@ -137,3 +138,20 @@ class ReferenceKernels:
                                            b, ph - 1, dof, n_knots, degree)
         assert rc == 0
         return out
+
+    # ------------------------------------------------------------------ optimiser
+    def line_search(self, state, search_cost, search_action, search_gradient, step_direction, search_magnitudes, c_1: float, c_2: float,
+                    strong_wolfe: bool, approx_wolfe: bool, convergence_iteration: int, cost_delta_threshold: float,
+                    cost_relative_threshold: float):
+        """in place on ``state``, like ``Oracle.line_search`` (kernel_line_search<float, -1>)"""
+        b, nls = search_cost.shape[0], search_cost.shape[1]
+        opt_dim = search_action.shape[-1]
+        s = state
+        self.lib.ref_line_search(_p(s["best_cost"]), _p(s["best_action"]), _p(s["best_iteration"]), _p(s["current_iteration"]),
+                                 _p(s["converged"]), convergence_iteration, C.c_float(cost_delta_threshold),
+                                 C.c_float(cost_relative_threshold), _p(s["exploration_cost"]), _p(s["exploration_action"]),
+                                 _p(s["exploration_gradient"]), _p(s["exploration_idx"]), _p(s["cost"]), _p(s["action"]), _p(s["gradient"]),
+                                 _p(s["selected_idx"]), _p(_f32(search_cost)), _p(_f32(search_action)), _p(_f32(search_gradient)),
+                                 _p(_f32(step_direction)), _p(_f32(search_magnitudes)), C.c_float(c_1), C.c_float(c_2), int(strong_wolfe),
+                                 int(approx_wolfe), nls, opt_dim, b)
+        return state

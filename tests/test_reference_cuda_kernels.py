@@ -103,6 +103,37 @@ def test_bspline_kernels_bit_identical(degree, implicit, oracle, ref):
     assert np.array_equal(oracle.bspline_backward(*bwd), ref.bspline_backward(*bwd))
 
 
+def _ls_state(b, v, nls):
+    z = np.zeros
+    return dict(best_cost=np.full((b,), 1e9, np.float32), best_action=z((b, v), np.float32), best_iteration=z((b,), np.int16),
+                current_iteration=z((b,), np.int16), converged=z((b,), np.uint8), exploration_cost=z((b,), np.float32),
+                exploration_action=z((b, v), np.float32), exploration_gradient=z((b, v), np.float32), cost=z((b,), np.float32),
+                action=z((b, v), np.float32), gradient=z((b, v), np.float32), exploration_idx=z((b, nls), np.int32),
+                selected_idx=z((b, nls), np.int32))
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", ["wolfe", "strong_wolfe", "approx_wolfe"])
+def test_line_search_kernel_identical_state(kind, oracle, ref):
+    """four rounds of candidates through kernel_line_search and through the oracle: every state array identical (selected
+    and exploration indices, best cost / action / iteration, the convergence flag)"""
+    rng = np.random.default_rng(5)
+    b, nls, v = 24, 4, 84
+    sa, sb = _ls_state(b, v, nls), _ls_state(b, v, nls)
+    picks = set()
+    for _ in range(4):
+        x, d = rng.normal(size=(b, nls, v)).astype(np.float32), rng.normal(size=(b, v)).astype(np.float32)
+        c = (rng.random((b, nls)) * np.array([1, 0.8, 1.2, 2.0])).astype(np.float32)
+        gx = (rng.normal(size=(b, nls, v)) * 0.3).astype(np.float32)
+        al = np.array([0.0, 0.25, 0.5, 1.0], np.float32)
+        for impl, st in ((oracle, sa), (ref, sb)):
+            impl.line_search(st, c, x, gx, d, al, 1e-5, 0.9, kind == "strong_wolfe", kind == "approx_wolfe", 5, 0.0, 0.001)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+        picks |= set(sa["selected_idx"][:, 0].tolist())
+    assert len(picks) >= 3
+
+
 def test_oracle_against_the_committed_outputs_of_the_reference_kernels(oracle):
     """the same comparison from a file, for machines without the library"""
     g = np.load(GOLD)
