@@ -153,6 +153,28 @@ extern "C" int ref_kinematics_backward(
   return 0;
 }
 
+// the two-kernel form for long pair lists (Unitree G1: 162 k pairs): self_collision_max_block_kernel<false> over
+// batch x horizon x num_blocks_per_batch blocks, then self_collision_max_reduce_kernel; cuda_core_backend/geometry.py:146-226.
+// block_batch_max_value [n * num_blocks_per_batch] floats and block_batch_max_index [2 * n * num_blocks_per_batch] int16 are scratch.
+extern "C" int ref_self_collision_distance_blocks(float *out_distance, float *out_vec, float *pair_distance, uint8_t *sparse_index,
+                                                  const float *robot_spheres, const float *sphere_padding, const float *weight,
+                                                  int16_t *pair_locations, float *block_batch_max_value, int16_t *block_batch_max_index,
+                                                  int num_blocks_per_batch, int batch_size, int horizon, int nspheres,
+                                                  int num_collision_pairs, int max_threads_per_block, int compute_grad) {
+  namespace sc = curobo::geometry::self_collision;
+  cuoc::launch(dim3(batch_size * horizon * num_blocks_per_batch), dim3(max_threads_per_block), (size_t)16 * nspheres, [&] {
+    sc::self_collision_max_block_kernel<false>(out_vec, pair_distance, sparse_index, robot_spheres, sphere_padding, pair_locations,
+                                               block_batch_max_value, block_batch_max_index, num_blocks_per_batch, batch_size, horizon,
+                                               nspheres, num_collision_pairs);
+  });
+  cuoc::launch(dim3(batch_size * horizon), dim3(std::min(512, num_blocks_per_batch)), 0, [&] {
+    sc::self_collision_max_reduce_kernel(out_distance, out_vec, pair_distance, sparse_index, robot_spheres, sphere_padding, weight,
+                                         pair_locations, block_batch_max_value, block_batch_max_index, num_blocks_per_batch, batch_size,
+                                         horizon, nspheres, num_collision_pairs, compute_grad != 0);
+  });
+  return 0;
+}
+
 // interpolate_bspline_kernel<float, Degree, MATRIX> and bspline_backward_kernel<Degree, float, MATRIX>; reference launch:
 // cuda_core_backend/trajectory.py:21-207, geometry of trajectory_config.py:124-174
 namespace bs = curobo::trajectory::bspline;

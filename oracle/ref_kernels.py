@@ -7,7 +7,8 @@ g++, over a CUDA-on-CPU shim: a CUDA block is a group of cooperatively scheduled
 
     kinematics_forward_kernel, kinematics_forward_spheres_kernel, kinematics_forward_spheres_jacobian_kernel
     kinematics_backward_kernel                              (kernels/kinematics/*.cuh)
-    self_collision_max_distance_kernel                      (kernels/geometry/self_collision/*.cuh)
+    self_collision_max_distance_kernel, self_collision_max_block_kernel + self_collision_max_reduce_kernel
+                                                            (kernels/geometry/self_collision/*.cuh)
     interpolate_bspline_kernel, bspline_backward_kernel     (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
     kernel_line_search                                      (kernels/optimization/line_search/*.cuh)
 
@@ -112,6 +113,22 @@ class ReferenceKernels:
         self.lib.ref_self_collision_distance(_p(dist), _p(grad), _p(pd), _p(flags), _p(rs), _p(_f32(sphere_padding)),
                                              _p(np.array([weight], np.float32)), _p(pairs), n, 1, S, pairs.shape[0], max_threads_per_block,
                                              int(write_grad))
+        return {"distance": dist, "gradient": grad, "sparse_index": flags}
+
+    def self_collision_blocks(self, robot_spheres, sphere_padding, collision_pairs, weight: float, num_blocks_per_batch: int,
+                              max_threads_per_block: int = 512, write_grad: bool = True):
+        """the two-kernel form the reference takes for long pair lists (max per block, then reduce)"""
+        rs = _f32(robot_spheres)
+        S = rs.shape[-2]
+        rs = rs.reshape(-1, S, 4)
+        n = rs.shape[0]
+        pairs = _i16(collision_pairs).reshape(-1, 2).copy()
+        dist, grad = np.zeros(n, np.float32), np.zeros((n, S, 4), np.float32)
+        flags, pd = np.zeros((n, S), np.uint8), np.zeros(1, np.float32)
+        bmv, bmi = np.zeros(n * num_blocks_per_batch, np.float32), np.zeros(2 * n * num_blocks_per_batch, np.int16)
+        self.lib.ref_self_collision_distance_blocks(_p(dist), _p(grad), _p(pd), _p(flags), _p(rs), _p(_f32(sphere_padding)),
+                                                    _p(np.array([weight], np.float32)), _p(pairs), _p(bmv), _p(bmi), num_blocks_per_batch,
+                                                    n, 1, S, pairs.shape[0], max_threads_per_block, int(write_grad))
         return {"distance": dist, "gradient": grad, "sparse_index": flags}
 
     # ------------------------------------------------------------------ B-spline

@@ -79,6 +79,19 @@ def test_self_collision_kernel_bit_identical(robot, oracle, ref):
     assert np.array_equal(a["sparse_index"], b["sparse_index"])
 
 
+@needs_ref
+def test_self_collision_two_kernel_form_on_the_humanoid_pair_list(oracle, ref):
+    """Unitree G1, 162 111 pairs: the reference splits them over blocks (self_collision_max_block_kernel) and reduces
+    (self_collision_max_reduce_kernel); same distance, gradient and flags as the oracle"""
+    model = load_model("unitree_g1")
+    sph = oracle.kinematics_forward(sample_q(model, 4, seed=13, scale=1.2), model.as_dict())["robot_spheres"]
+    a = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.5)
+    b = ref.self_collision_blocks(sph, model.sphere_padding, model.collision_pairs, 1.5, num_blocks_per_batch=10)
+    assert model.collision_pairs.shape[0] > 160000 and (a["distance"] > 0).sum() >= 2
+    assert np.array_equal(a["distance"], b["distance"]) and np.array_equal(a["gradient"], b["gradient"])
+    assert np.array_equal(a["sparse_index"], b["sparse_index"])
+
+
 def _bspline_case(degree, implicit):
     rng = np.random.default_rng(degree)
     b, nk, dof, interp = 7, 12, 7, 2
