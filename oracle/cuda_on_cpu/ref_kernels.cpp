@@ -9,6 +9,8 @@
 #include "kinematics/kinematics_backward_kernel.cuh"
 #include "trajectory/bspline/bspline_kernel.cuh"
 #include "optimization/line_search/line_search_kernel.cuh"
+#include "dynamics/rnea_forward_kernel.cuh"
+#include "dynamics/rnea_backward_kernel.cuh"
 
 using namespace curobo::kinematics;
 
@@ -236,4 +238,56 @@ extern "C" int ref_line_search(float *best_cost, float *best_action, int16_t *be
         search_magnitudes, c_1, c_2, strong_wolfe != 0, approx_wolfe != 0, n_linesearch, opt_dim, batchsize);
   });
   return 0;
+}
+
+// With one thread per element the kernels return early in threads past the batch, BEFORE the block loads the link constants
+// cooperatively -- a partial last block then misses some links.  Every block is therefore full here: the block size is the
+// largest divisor of the batch size up to 32.
+static int full_block_size(int B) {
+  for (int b = std::min(B, 32); b > 1; b--)
+    if (B % b == 0) return b;
+  return 1;
+}
+
+// rnea_forward_kernel<N_LINKS, N_DOF, 1, false> / rnea_backward_kernel<N_LINKS, N_DOF, 1, false> (one thread per element; the
+// link and dof counts are template parameters there: franka 13 / 7 and unitree_g1 56 / 49 are instantiated);
+// cuda_core_backend/dynamics.py:24-260.  forward_cache is the reference's own [batch, links * 20] scratch.
+template <int L, int D>
+static int rnea_fwd(float *tau, const float *q, const float *qd, const float *qdd, const float *fixed, const float *masses,
+                    const float *inertias, const int8_t *jtype, const int16_t *jmap, const int16_t *lmap, const float *joff,
+                    const float *gravity, const int16_t *level_starts, const int16_t *level_links, float *cache, int B, int n_levels) {
+  const int bpb = full_block_size(B);
+  cuoc::launch(dim3(B / bpb), dim3(bpb), (size_t)1 << 20, [&] {
+    curobo::dynamics::rnea_forward_kernel<L, D, 1, false>(tau, q, qd, qdd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity,
+                                                         level_starts, level_links, cache, nullptr, B, n_levels);
+  });
+  return 0;
+}
+template <int L, int D>
+static int rnea_bwd(float *gq, float *gqd, float *gqdd, const float *gtau, const float *q, const float *qd, const float *fixed,
+                    const float *masses, const float *inertias, const int8_t *jtype, const int16_t *jmap, const int16_t *lmap,
+                    const float *joff, const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *cache,
+                    int B, int n_levels) {
+  const int bpb = full_block_size(B);
+  cuoc::launch(dim3(B / bpb), dim3(bpb), (size_t)1 << 20, [&] {
+    curobo::dynamics::rnea_backward_kernel<L, D, 1, false>(gq, gqd, gqdd, nullptr, gtau, q, qd, fixed, masses, inertias, jtype, jmap,
+                                                          lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
+  });
+  return 0;
+}
+extern "C" int ref_rnea_forward(float *tau, const float *q, const float *qd, const float *qdd, const float *fixed, const float *masses,
+                                const float *inertias, const int8_t *jtype, const int16_t *jmap, const int16_t *lmap, const float *joff,
+                                const float *gravity, const int16_t *level_starts, const int16_t *level_links, float *cache, int B,
+                                int n_levels, int num_links, int num_dof) {
+  if (num_links == 13 && num_dof == 7) return rnea_fwd<13, 7>(tau, q, qd, qdd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
+  if (num_links == 56 && num_dof == 49) return rnea_fwd<56, 49>(tau, q, qd, qdd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
+  return 1;
+}
+extern "C" int ref_rnea_backward(float *gq, float *gqd, float *gqdd, const float *gtau, const float *q, const float *qd, const float *fixed,
+                                 const float *masses, const float *inertias, const int8_t *jtype, const int16_t *jmap, const int16_t *lmap,
+                                 const float *joff, const float *gravity, const int16_t *level_starts, const int16_t *level_links,
+                                 const float *cache, int B, int n_levels, int num_links, int num_dof) {
+  if (num_links == 13 && num_dof == 7) return rnea_bwd<13, 7>(gq, gqd, gqdd, gtau, q, qd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
+  if (num_links == 56 && num_dof == 49) return rnea_bwd<56, 49>(gq, gqd, gqdd, gtau, q, qd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
+  return 1;
 }

@@ -11,6 +11,7 @@ g++, over a CUDA-on-CPU shim: a CUDA block is a group of cooperatively scheduled
                                                             (kernels/geometry/self_collision/*.cuh)
     interpolate_bspline_kernel, bspline_backward_kernel     (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
     kernel_line_search                                      (kernels/optimization/line_search/*.cuh)
+    rnea_forward_kernel, rnea_backward_kernel               (kernels/dynamics/*.cuh; franka and unitree_g1 instantiations)
 
 The methods mirror ``oracle.Oracle`` (same arguments, same result dictionaries) so that a test can put the two side by
 side.  ``available()`` is False where the library was not built (no reference checkout and no prebuilt copy).
@@ -172,3 +173,39 @@ class ReferenceKernels:
                                  _p(_f32(step_direction)), _p(_f32(search_magnitudes)), C.c_float(c_1), C.c_float(c_2), int(strong_wolfe),
                                  int(approx_wolfe), nls, opt_dim, b)
         return state
+
+    # ------------------------------------------------------------------ inverse dynamics
+    def _rnea_tables(self, model):
+        from .oracle import Oracle
+
+        level_starts, level_links = Oracle.tree_levels(model["link_map"])
+        return dict(fixed=_f32(model["fixed_transforms"]), masses=_f32(model["link_masses_com"]), inertias=_f32(model["link_inertias"]),
+                    jtype=np.ascontiguousarray(model["joint_map_type"], np.int8), jmap=_i16(model["joint_map"]), lmap=_i16(model["link_map"]),
+                    joff=_f32(model["joint_offset_map"]), starts=_i16(level_starts), links=_i16(level_links))
+
+    def rnea_forward(self, q, qd, qdd, model, gravity=(0, 0, 0, 0, 0, 9.81)):
+        """(tau [b, dof], the reference's opaque forward cache [b, links * 20]); rnea_forward_kernel<L, D, 1, false>"""
+        q, qd, qdd = _f32(q), _f32(qd), _f32(qdd)
+        b, dof = q.shape
+        t = self._rnea_tables(model)
+        L = t["fixed"].shape[0]
+        tau, cache = np.zeros((b, dof), np.float32), np.zeros((b, L * 20), np.float32)
+        rc = self.lib.ref_rnea_forward(_p(tau), _p(q), _p(qd), _p(qdd), _p(t["fixed"]), _p(t["masses"]), _p(t["inertias"]), _p(t["jtype"]),
+                                       _p(t["jmap"]), _p(t["lmap"]), _p(t["joff"]), _p(_f32(gravity)), _p(t["starts"]), _p(t["links"]),
+                                       _p(cache), b, len(t["starts"]) - 1, L, dof)
+        if rc != 0:
+            raise ValueError(f"rnea kernels are instantiated for franka (13 links / 7 dof) and unitree_g1 (56 / 49), not {L} / {dof}")
+        return tau, cache
+
+    def rnea_backward(self, grad_tau, q, qd, cache, model, gravity=(0, 0, 0, 0, 0, 9.81)):
+        q, qd, gt = _f32(q), _f32(qd), _f32(grad_tau)
+        b, dof = q.shape
+        t = self._rnea_tables(model)
+        L = t["fixed"].shape[0]
+        g = [np.zeros((b, dof), np.float32) for _ in range(3)]
+        rc = self.lib.ref_rnea_backward(_p(g[0]), _p(g[1]), _p(g[2]), _p(gt), _p(q), _p(qd), _p(t["fixed"]), _p(t["masses"]),
+                                        _p(t["inertias"]), _p(t["jtype"]), _p(t["jmap"]), _p(t["lmap"]), _p(t["joff"]), _p(_f32(gravity)),
+                                        _p(t["starts"]), _p(t["links"]), _p(_f32(cache)), b, len(t["starts"]) - 1, L, dof)
+        if rc != 0:
+            raise ValueError(f"rnea kernels are instantiated for franka and unitree_g1, not {L} / {dof}")
+        return tuple(g)

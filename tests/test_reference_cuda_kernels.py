@@ -92,6 +92,24 @@ def test_self_collision_two_kernel_form_on_the_humanoid_pair_list(oracle, ref):
     assert np.array_equal(a["sparse_index"], b["sparse_index"])
 
 
+@needs_ref
+@pytest.mark.parametrize("robot", ["franka", "unitree_g1"])
+def test_rnea_kernels(robot, oracle, ref):
+    """rnea_forward_kernel / rnea_backward_kernel (one thread per element): torques, the forward cache (same layout as the
+    oracle's: v, a, f per link) and the VJP w.r.t. q, qd, qdd"""
+    model = load_model(robot)
+    md = model.as_dict()
+    rng = np.random.default_rng(7)
+    q = sample_q(model, 12, seed=14)
+    qd, qdd, gt = (rng.standard_normal(q.shape).astype(np.float32) for _ in range(3))
+    ta, ca = oracle.rnea_forward(q, qd, qdd, md)
+    tb, cb = ref.rnea_forward(q, qd, qdd, md)
+    np.testing.assert_allclose(tb, ta, rtol=0, atol=1e-6 * np.abs(ta).max())
+    np.testing.assert_allclose(cb, ca.reshape(q.shape[0], -1), rtol=0, atol=1e-6 * np.abs(ca).max())
+    for a, b in zip(oracle.rnea_backward(gt, q, qd, ca, md), ref.rnea_backward(gt, q, qd, cb, md)):
+        np.testing.assert_allclose(b, a, rtol=0, atol=3e-6 * np.abs(a).max())
+
+
 def _bspline_case(degree, implicit):
     rng = np.random.default_rng(degree)
     b, nk, dof, interp = 7, 12, 7, 2
