@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) differentiation_position_backward_kernel(
     o += (-0.083333333f * ga[0] + 1.333333333f * ga[1] + (-2.5f) * ga[2] + 1.333333333f * ga[3] + (-0.083333333f) * ga[4]) * i2;
     o += (0.5f * gj[0] - 1.0f * gj[1] + 1.0f * gj[3] - 0.5f * gj[4]) * i3;
   } else if (use_goal) {
-    o = -0.083333333f * gv[0] * i1 + -0.083333333f * ga[0] * i2 + 0.5f * gj[0] * i3;
+    o = 0.0f;  // the forward pass replaces the last action by the goal (reference differentiation_position_kernel.cuh:352-361)
   } else {
     o += (-0.083333333f * gv[0] + 0.583333334f * gv[1] + 0.583333334f * gv[2] - 0.083333333f * gv[3]) * i1;
     o += (-0.083333333f * ga[0] + 1.25f * ga[1] + (-1.25f) * ga[2] + 0.083333333f * ga[3]) * i2;

@@ -9,6 +9,7 @@
 #include "kinematics/kinematics_backward_kernel.cuh"
 #include "trajectory/bspline/bspline_kernel.cuh"
 #include "optimization/line_search/line_search_kernel.cuh"
+#include "trajectory/legacy/differentiation_position_kernel.cuh"
 #include "dynamics/rnea_forward_kernel.cuh"
 #include "dynamics/rnea_backward_kernel.cuh"
 
@@ -290,4 +291,54 @@ extern "C" int ref_rnea_backward(float *gq, float *gqd, float *gqdd, const float
   if (num_links == 13 && num_dof == 7) return rnea_bwd<13, 7>(gq, gqd, gqdd, gtau, q, qd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
   if (num_links == 56 && num_dof == 49) return rnea_bwd<56, 49>(gq, gqd, gqdd, gtau, q, qd, fixed, masses, inertias, jtype, jmap, lmap, joff, gravity, level_starts, level_links, cache, B, n_levels);
   return 1;
+}
+
+// interpolate_bspline_single_dt_kernel<float, Degree, MATRIX>; cuda_core_backend/trajectory.py:207-301 (256 threads per block)
+template <int DEG>
+static void bspline_single_dt(float *p, float *v, float *a, float *j, float *out_dt, const float *u, const float *knot_dt, const float *sp,
+                              const float *sv, const float *sa, const float *sj, const float *gp, const float *gv, const float *ga,
+                              const float *gj, const int32_t *start_idx, const int32_t *goal_idx, const float *interp_dt,
+                              const uint8_t *implicit, const int32_t *interp_horizon, int B, int max_out, int D, int K) {
+  const int k_size = B * D * max_out, threads = std::min(k_size, 256);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    bs::interpolate_bspline_single_dt_kernel<float, DEG, bs::BasisBackend::MATRIX>(p, v, a, j, out_dt, u, knot_dt, sp, sv, sa, sj, gp, gv,
+                                                                                  ga, gj, start_idx, goal_idx, interp_dt, implicit,
+                                                                                  interp_horizon, B, max_out, D, K);
+  });
+}
+extern "C" int ref_bspline_single_dt(float *p, float *v, float *a, float *j, float *out_dt, const float *u, const float *knot_dt,
+                                     const float *sp, const float *sv, const float *sa, const float *sj, const float *gp, const float *gv,
+                                     const float *ga, const float *gj, const int32_t *start_idx, const int32_t *goal_idx,
+                                     const float *interp_dt, const uint8_t *implicit, const int32_t *interp_horizon, int B, int max_out,
+                                     int D, int K, int degree) {
+#define CUOC_SDT(DEG) bspline_single_dt<DEG>(p, v, a, j, out_dt, u, knot_dt, sp, sv, sa, sj, gp, gv, ga, gj, start_idx, goal_idx, interp_dt, implicit, interp_horizon, B, max_out, D, K)
+  if (degree == 3) CUOC_SDT(3);
+  else if (degree == 4) CUOC_SDT(4);
+  else if (degree == 5) CUOC_SDT(5);
+  else return 1;
+#undef CUOC_SDT
+  return 0;
+}
+
+// legacy POSITION control space: position_clique_loop_idx_fwd_kernel<float, true> / ..._bwd_kernel<float, true> (five-point
+// stencils); cuda_core_backend/trajectory.py:304-465 (128 threads per block)
+extern "C" int ref_differentiation_position_forward(float *p, float *v, float *a, float *j, float *out_dt, const float *u, const float *sp,
+                                                    const float *sv, const float *sa, const float *gp, const float *gv, const float *ga,
+                                                    const int32_t *start_idx, const int32_t *goal_idx, const float *traj_dt,
+                                                    const uint8_t *implicit, int B, int H, int D) {
+  const int k_size = B * D * H, threads = std::min(k_size, 128);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    curobo::trajectory::legacy::position_clique_loop_idx_fwd_kernel<float, true>(p, v, a, j, out_dt, u, sp, sv, sa, gp, gv, ga, start_idx,
+                                                                                goal_idx, traj_dt, implicit, B, H, D);
+  });
+  return 0;
+}
+extern "C" int ref_differentiation_position_backward(float *out, const float *gp, const float *gv, const float *ga, const float *gj,
+                                                     const float *traj_dt, const int32_t *dt_idx, const uint8_t *implicit, int B, int H,
+                                                     int D) {
+  const int k_size = B * D * (H - 4), threads = std::min(k_size, 128);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    curobo::trajectory::legacy::position_clique_loop_idx_bwd_kernel<float, true>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D);
+  });
+  return 0;
 }

@@ -1169,7 +1169,9 @@ ORC_API void orc_differentiation_position_backward(
           o += (float)((-0.083333333 * ga[0] + 1.333333333 * ga[1] + (-2.5) * ga[2] + 1.333333333 * ga[3] + (-0.083333333) * ga[4]) * i2);
           o += (0.5f * gj[0] - 1.0f * gj[1] + 1.0f * gj[3] - 0.5f * gj[4]) * i3;
         } else if (use_goal) {
-          o = (float)(-0.083333333 * gv[0] * i1 + -0.083333333 * ga[0] * i2 + 0.5 * gj[0] * i3);
+          /* the last action is replaced by the goal in the forward pass: no gradient (differentiation_position_kernel.cuh:
+           * 352-361 -- the stencil expression next to it there is commented out; found by running that kernel, oracle/_ref) */
+          o = 0.0f;
         } else {
           o += (float)((-0.083333333 * gv[0] + 0.583333334 * gv[1] + 0.583333334 * gv[2] - 0.083333333 * gv[3]) * i1);
           o += (float)((-0.083333333 * ga[0] + 1.25 * ga[1] + (-1.25) * ga[2] + 0.083333333 * ga[3]) * i2);

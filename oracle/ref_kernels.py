@@ -9,7 +9,9 @@ g++, over a CUDA-on-CPU shim: a CUDA block is a group of cooperatively scheduled
     kinematics_backward_kernel                              (kernels/kinematics/*.cuh)
     self_collision_max_distance_kernel, self_collision_max_block_kernel + self_collision_max_reduce_kernel
                                                             (kernels/geometry/self_collision/*.cuh)
-    interpolate_bspline_kernel, bspline_backward_kernel     (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
+    interpolate_bspline_kernel, bspline_backward_kernel, interpolate_bspline_single_dt_kernel
+                                                            (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
+    position_clique_loop_idx_fwd_kernel / _bwd_kernel       (kernels/trajectory/legacy/*.cuh)
     kernel_line_search                                      (kernels/optimization/line_search/*.cuh)
     rnea_forward_kernel, rnea_backward_kernel               (kernels/dynamics/*.cuh; franka and unitree_g1 instantiations)
 
@@ -155,6 +157,47 @@ class ReferenceKernels:
                                            _p(np.ascontiguousarray(dt_idx, np.int32)), _p(np.ascontiguousarray(use_implicit_goal, np.uint8)),
                                            b, ph - 1, dof, n_knots, degree)
         assert rc == 0
+        return out
+
+    def bspline_single_dt(self, knots, start, goal, start_idx, goal_idx, interpolation_dt, use_implicit_goal, interpolation_horizon,
+                          max_out_tsteps: int, degree: int = 3):
+        u = _f32(knots)
+        b, n_knots, dof = u.shape
+        keys = ("position", "velocity", "acceleration", "jerk")
+        outs = [np.zeros((b, max_out_tsteps, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros(b, np.float32)
+        s, g = [_f32(start[k]) for k in keys], [_f32(goal[k]) for k in keys]
+        rc = self.lib.ref_bspline_single_dt(*[_p(o) for o in outs], _p(out_dt), _p(u), _p(np.zeros((b, max(n_knots - 1, 1)), np.float32)),
+                                            *[_p(x) for x in s], *[_p(x) for x in g], _p(np.ascontiguousarray(start_idx, np.int32)),
+                                            _p(np.ascontiguousarray(goal_idx, np.int32)), _p(_f32(interpolation_dt)),
+                                            _p(np.ascontiguousarray(use_implicit_goal, np.uint8)),
+                                            _p(np.ascontiguousarray(interpolation_horizon, np.int32)), b, max_out_tsteps, dof, n_knots, degree)
+        assert rc == 0
+        return {**dict(zip(keys, outs)), "dt": out_dt}
+
+    # ------------------------------------------------------------------ legacy POSITION control space
+    def differentiation_position_forward(self, u_position, start, goal, start_idx, goal_idx, traj_dt, use_implicit_goal):
+        """``goal``: dict with position / velocity / acceleration (the oracle's wrapper takes the goal position only: the kernel reads the
+        other two only under the implicit goal, where they are zero by definition)"""
+        u = _f32(u_position)
+        b, ah, dof = u.shape
+        horizon = ah + 4
+        outs = [np.zeros((b, horizon, dof), np.float32) for _ in range(4)]
+        out_dt = np.zeros(b, np.float32)
+        self.lib.ref_differentiation_position_forward(
+            *[_p(o) for o in outs], _p(out_dt), _p(u), _p(_f32(start["position"])), _p(_f32(start["velocity"])),
+            _p(_f32(start["acceleration"])), _p(_f32(goal["position"])), _p(_f32(goal["velocity"])), _p(_f32(goal["acceleration"])),
+            _p(np.ascontiguousarray(start_idx, np.int32)), _p(np.ascontiguousarray(goal_idx, np.int32)), _p(_f32(traj_dt)),
+            _p(np.ascontiguousarray(use_implicit_goal, np.uint8)), b, horizon, dof)
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3], "dt": out_dt}
+
+    def differentiation_position_backward(self, grad_p, grad_v, grad_a, grad_j, traj_dt, dt_idx, use_implicit_goal):
+        gp = _f32(grad_p)
+        b, horizon, dof = gp.shape
+        out = np.zeros((b, horizon - 4, dof), np.float32)
+        self.lib.ref_differentiation_position_backward(_p(out), _p(gp), _p(_f32(grad_v)), _p(_f32(grad_a)), _p(_f32(grad_j)),
+                                                       _p(_f32(traj_dt)), _p(np.ascontiguousarray(dt_idx, np.int32)),
+                                                       _p(np.ascontiguousarray(use_implicit_goal, np.uint8)), b, horizon, dof)
         return out
 
     # ------------------------------------------------------------------ optimiser

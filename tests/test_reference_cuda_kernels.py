@@ -134,6 +134,51 @@ def test_bspline_kernels_bit_identical(degree, implicit, oracle, ref):
     assert np.array_equal(oracle.bspline_backward(*bwd), ref.bspline_backward(*bwd))
 
 
+@needs_ref
+@pytest.mark.parametrize("degree", [3, 4, 5])
+def test_bspline_single_dt_kernel(degree, oracle, ref):
+    """interpolate_bspline_single_dt_kernel (re-interpolation of solved knots at one dt, per-trajectory horizons, some beyond the
+    output buffer): positions and dt identical, the derivatives to a few ulp of their range"""
+    rng = np.random.default_rng(40 + degree)
+    b, nk, dof, max_out = 6, 12, 7, 150
+    u = rng.normal(size=(b, nk, dof)).astype(np.float32)
+    mk = lambda n: {k: (rng.normal(size=(n, dof)) * 0.3).astype(np.float32) for k in KEYS}  # noqa: E731
+    start, goal = mk(3), mk(2)
+    sidx, gidx = rng.integers(0, 3, size=b).astype(np.int32), rng.integers(0, 2, size=b).astype(np.int32)
+    horizons = rng.integers(20, 200, size=b).astype(np.int32)
+    args = (u, start, goal, sidx, gidx, np.array([0.02], np.float32), np.array([0, 1], np.uint8), horizons, max_out, degree)
+    a, c = oracle.bspline_single_dt(*args), ref.bspline_single_dt(*args)
+    assert np.array_equal(a["position"], c["position"]) and np.array_equal(a["dt"], c["dt"])
+    for k in KEYS[1:]:
+        np.testing.assert_allclose(c[k], a[k], rtol=0, atol=2e-6 * max(1.0, np.abs(a[k]).max()), err_msg=k)
+
+
+@needs_ref
+@pytest.mark.parametrize("implicit_goal", [0, 1])
+def test_legacy_position_kernels(implicit_goal, oracle, ref):
+    """position_clique_loop_idx_fwd_kernel / _bwd_kernel (five-point stencils).  Under the implicit goal the forward pass replaces
+    the last action by the goal, so its gradient is zero -- running the reference's kernel is what exposed a stencil expression
+    the oracle (and the HIP kernel) had restated from a commented-out block there."""
+    rng = np.random.default_rng(41)
+    b, ah, dof = 7, 28, 7
+    u = rng.normal(size=(b, ah, dof)).astype(np.float32)
+    start = {k: (rng.normal(size=(3, dof)) * 0.3).astype(np.float32) for k in KEYS}
+    goal = {"position": (rng.normal(size=(2, dof)) * 0.3).astype(np.float32), "velocity": np.zeros((2, dof), np.float32),
+            "acceleration": np.zeros((2, dof), np.float32)}
+    sidx, gidx = rng.integers(0, 3, size=b).astype(np.int32), rng.integers(0, 2, size=b).astype(np.int32)
+    dt, imp = np.array([0.05, 0.08], np.float32), np.array([implicit_goal] * 2, np.uint8)
+    a = oracle.differentiation_position_forward(u, start, goal["position"], sidx, gidx, dt, imp)
+    c = ref.differentiation_position_forward(u, start, goal, sidx, gidx, dt, imp)
+    assert np.array_equal(a["position"], c["position"]) and np.array_equal(a["dt"], c["dt"])
+    for k in KEYS[1:]:
+        np.testing.assert_allclose(c[k], a[k], rtol=0, atol=1e-6 * max(1.0, np.abs(a[k]).max()), err_msg=k)
+    g = [rng.normal(size=(b, ah + 4, dof)).astype(np.float32) for _ in range(4)]
+    ga, gc = oracle.differentiation_position_backward(*g, dt, gidx, imp), ref.differentiation_position_backward(*g, dt, gidx, imp)
+    np.testing.assert_allclose(gc, ga, rtol=0, atol=1e-6 * np.abs(ga).max())
+    if implicit_goal:
+        assert np.all(ga[:, -1] == 0) and np.all(gc[:, -1] == 0)
+
+
 def _ls_state(b, v, nls):
     z = np.zeros
     return dict(best_cost=np.full((b,), 1e9, np.float32), best_action=z((b, v), np.float32), best_iteration=z((b,), np.int16),
