@@ -3,7 +3,8 @@
 restatement is pinned by what the kernels are by construction: five-point finite-difference
 stencils (exact for quartic / cubic / quartic polynomials), the constant-acceleration
 back-extrapolation of the start state, goal replication, the backward pass being the transpose of
-the forward stencils for interior actions, and semi-implicit Euler integration."""
+the forward stencils for interior actions, and semi-implicit Euler integration.  (Since round 2 the reference's own
+kernels run on the CPU next to the oracle as well: tests/test_reference_cuda_kernels.py.)"""
 
 import numpy as np
 import pytest
@@ -95,6 +96,25 @@ def test_backward_is_transpose_of_forward_for_interior_actions(oracle):
         pert = _forward(oracle, u + du, start, goal, 0)
         lhs = sum(((pert[k].astype(np.float64) - base[k]) * gg).sum(axis=(1,)) for k, gg in zip(keys, g))  # [B, DOF]
         np.testing.assert_allclose(gu[:, ah, :], lhs, rtol=2e-3, atol=2e-3 * np.abs(lhs).max())
+
+
+def test_backward_last_action_under_the_implicit_goal_is_the_true_transpose(oracle):
+    """with the implicit goal the forward pass replaces the last action by the goal, so that action gets NO gradient
+    (reference differentiation_position_kernel.cuh:352-361; the stencil expression next to it there is commented out) --
+    checked as a transpose: perturbing the last action changes nothing"""
+    rng = np.random.default_rng(4)
+    u = rng.normal(size=(B, H - 4, DOF)).astype(np.float32)
+    start = {k: (rng.normal(size=(1, DOF)) * 0.2).astype(np.float32) for k in ("position", "velocity", "acceleration")}
+    goal = (rng.normal(size=(1, DOF)) * 0.2).astype(np.float32)
+    g = [rng.normal(size=(B, H, DOF)).astype(np.float32) * s for s in (1.0, DT, DT ** 2, DT ** 3)]
+    gu = oracle.differentiation_position_backward(*g, np.array([DT], np.float32), np.zeros(B, np.int32), np.ones(1, np.uint8))
+    base = _forward(oracle, u, start, goal, 1)
+    du = np.zeros_like(u)
+    du[:, -1, :] = 0.7
+    pert = _forward(oracle, u + du, start, goal, 1)
+    for k in ("position", "velocity", "acceleration", "jerk"):
+        assert np.array_equal(pert[k], base[k]), k
+    assert np.all(gu[:, -1, :] == 0.0)
 
 
 def test_backward_goal_state_masks_last_action_position_gradient(oracle):
