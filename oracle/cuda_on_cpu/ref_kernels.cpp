@@ -10,6 +10,7 @@
 #include "trajectory/bspline/bspline_kernel.cuh"
 #include "optimization/line_search/line_search_kernel.cuh"
 #include "trajectory/legacy/differentiation_position_kernel.cuh"
+#include "trajectory/legacy/integration_acceleration_kernel.cuh"
 #include "dynamics/rnea_forward_kernel.cuh"
 #include "dynamics/rnea_backward_kernel.cuh"
 
@@ -340,5 +341,26 @@ extern "C" int ref_differentiation_position_backward(float *out, const float *gp
   cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
     curobo::trajectory::legacy::position_clique_loop_idx_bwd_kernel<float, true>(out, gp, gv, ga, gj, traj_dt, dt_idx, implicit, B, H, D);
   });
+  return 0;
+}
+
+// legacy ACCELERATION control space: acceleration_loop_idx_kernel<float, H> / acceleration_loop_idx_rk2_kernel<float, H> (the horizon
+// is a template parameter there; 32 and 64 are instantiated, the call takes the smallest that holds `horizon`);
+// cuda_core_backend/trajectory.py:468-544
+template <int MAXH>
+static void accel_launch(bool rk2, float *p, float *v, float *a, float *j, const float *u, const float *sp, const float *sv, const float *sa,
+                         const int32_t *start_idx, const float *traj_dt, int B, int H, int D) {
+  const int k_size = B * D, threads = std::min(k_size, 512);
+  cuoc::launch(dim3((k_size + threads - 1) / threads), dim3(threads), 0, [&] {
+    if (rk2) curobo::trajectory::legacy::acceleration_loop_idx_rk2_kernel<float, MAXH>(p, v, a, j, u, sp, sv, sa, start_idx, traj_dt, B, H, D);
+    else curobo::trajectory::legacy::acceleration_loop_idx_kernel<float, MAXH>(p, v, a, j, u, sp, sv, sa, start_idx, traj_dt, B, H, D);
+  });
+}
+extern "C" int ref_integration_acceleration(float *p, float *v, float *a, float *j, const float *u, const float *sp, const float *sv,
+                                            const float *sa, const int32_t *start_idx, const float *traj_dt, int B, int H, int D,
+                                            int use_rk2) {
+  if (H <= 32) accel_launch<32>(use_rk2 != 0, p, v, a, j, u, sp, sv, sa, start_idx, traj_dt, B, H, D);
+  else if (H <= 64) accel_launch<64>(use_rk2 != 0, p, v, a, j, u, sp, sv, sa, start_idx, traj_dt, B, H, D);
+  else return 1;
   return 0;
 }

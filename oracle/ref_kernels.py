@@ -11,7 +11,8 @@ g++, over a CUDA-on-CPU shim: a CUDA block is a group of cooperatively scheduled
                                                             (kernels/geometry/self_collision/*.cuh)
     interpolate_bspline_kernel, bspline_backward_kernel, interpolate_bspline_single_dt_kernel
                                                             (kernels/trajectory/bspline/*.cuh, degrees 3 / 4 / 5)
-    position_clique_loop_idx_fwd_kernel / _bwd_kernel       (kernels/trajectory/legacy/*.cuh)
+    position_clique_loop_idx_fwd_kernel / _bwd_kernel, acceleration_loop_idx_kernel / _rk2_kernel
+                                                            (kernels/trajectory/legacy/*.cuh)
     kernel_line_search                                      (kernels/optimization/line_search/*.cuh)
     rnea_forward_kernel, rnea_backward_kernel               (kernels/dynamics/*.cuh; franka and unitree_g1 instantiations)
 
@@ -199,6 +200,16 @@ class ReferenceKernels:
                                                        _p(_f32(traj_dt)), _p(np.ascontiguousarray(dt_idx, np.int32)),
                                                        _p(np.ascontiguousarray(use_implicit_goal, np.uint8)), b, horizon, dof)
         return out
+
+    def integration_acceleration(self, u_acc, start, start_idx, traj_dt, use_rk2: bool = True):
+        u = _f32(u_acc)
+        b, horizon, dof = u.shape
+        outs = [np.zeros((b, horizon, dof), np.float32) for _ in range(4)]
+        rc = self.lib.ref_integration_acceleration(*[_p(o) for o in outs], _p(u), _p(_f32(start["position"])), _p(_f32(start["velocity"])),
+                                                   _p(_f32(start["acceleration"])), _p(np.ascontiguousarray(start_idx, np.int32)),
+                                                   _p(_f32(traj_dt)), b, horizon, dof, int(use_rk2))
+        assert rc == 0, "horizon > 64 is not instantiated"
+        return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3]}
 
     # ------------------------------------------------------------------ optimiser
     def line_search(self, state, search_cost, search_action, search_gradient, step_direction, search_magnitudes, c_1: float, c_2: float,

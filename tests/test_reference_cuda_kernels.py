@@ -179,6 +179,21 @@ def test_legacy_position_kernels(implicit_goal, oracle, ref):
         assert np.all(ga[:, -1] == 0) and np.all(gc[:, -1] == 0)
 
 
+@needs_ref
+@pytest.mark.parametrize("use_rk2", [False, True])
+def test_legacy_acceleration_kernels_bit_identical(use_rk2, oracle, ref):
+    """acceleration_loop_idx_kernel and acceleration_loop_idx_rk2_kernel run the same semi-implicit Euler recursion (which is why
+    the HIP entry point ignores use_rk2): both identical to the oracle"""
+    rng = np.random.default_rng(9)
+    b, H, dof = 5, 30, 7
+    u = rng.normal(size=(b, H, dof)).astype(np.float32)
+    start = {k: (rng.normal(size=(3, dof)) * 0.3).astype(np.float32) for k in ("position", "velocity", "acceleration")}
+    sidx, dt = rng.integers(0, 3, size=b).astype(np.int32), (0.02 + 0.05 * rng.random(H)).astype(np.float32)
+    a, c = oracle.integration_acceleration(u, start, sidx, dt), ref.integration_acceleration(u, start, sidx, dt, use_rk2=use_rk2)
+    for k in a:
+        assert np.array_equal(a[k], c[k]), k
+
+
 def _ls_state(b, v, nls):
     z = np.zeros
     return dict(best_cost=np.full((b,), 1e9, np.float32), best_action=z((b, v), np.float32), best_iteration=z((b,), np.int16),
