@@ -1,6 +1,7 @@
 // ref_kernels.cpp -- C entry points that LAUNCH THE REFERENCE'S OWN CUDA KERNELS on the CPU (oracle/cuda_on_cpu,
 // TEST INFRASTRUCTURE).  The kernel sources are included from /root/reference/curobo/_src/curobolib/kernels at build time
-// (the three files with `extern __shared__` arrays through a one-line sed rewrite into oracle/_ref/gen, see the Makefile);
+// (the files with `extern __shared__` arrays and the warp reduction through two one-line sed rewrites into a temporary
+// directory, see the Makefile);
 // launch geometry as in curobolib/backends/cuda_core_backend/kinematics_config.py:53-92 (geometry does not change results).
 #include "simt.hpp"
 
