@@ -48,6 +48,25 @@ def test_fk_forward_kernels_bit_identical(robot, oracle, ref):
 
 
 @needs_ref
+def test_fk_sphere_sets_per_environment_bit_identical(oracle, ref):
+    """two sphere sets (link_spheres [2, S, 4]) selected per trajectory through env_query_idx, horizon 3"""
+    model = load_model("franka")
+    md = dict(model.as_dict())
+    rng = np.random.default_rng(8)
+    base = np.asarray(md["link_spheres"], np.float32).reshape(-1, 4)
+    other = base.copy()
+    other[:, :3] += 0.01 * rng.standard_normal((base.shape[0], 3)).astype(np.float32)
+    other[:, 3] = np.where(base[:, 3] > 0, base[:, 3] * 1.2, base[:, 3])
+    md["link_spheres"] = np.stack([base, other])
+    horizon, env = 3, np.array([1, 0, 0, 1], np.int32)
+    q = sample_q(model, 4 * horizon, seed=15)
+    a = oracle.kinematics_forward(q, md, horizon=horizon, env_query_idx=env)
+    b = ref.kinematics_forward(q, md, horizon=horizon, env_query_idx=env)
+    assert np.array_equal(a["robot_spheres"], b["robot_spheres"])
+    assert not np.array_equal(a["robot_spheres"][0], oracle.kinematics_forward(q[:1], model.as_dict())["robot_spheres"][0])
+
+
+@needs_ref
 @pytest.mark.parametrize("robot", ROBOTS)
 @pytest.mark.parametrize("with_com", [False, True])
 def test_fk_backward_kernel(robot, with_com, oracle, ref):
