@@ -5,6 +5,8 @@
 // launch geometry as in curobolib/backends/cuda_core_backend/kinematics_config.py:53-92 (geometry does not change results).
 #include "simt.hpp"
 
+#include <type_traits>
+
 #include "kinematics/kinematics_forward_kernel.cuh"
 #include "geometry/self_collision/self_collision_kernel.cuh"
 #include "kinematics/kinematics_backward_kernel.cuh"
@@ -132,6 +134,37 @@ static void backward_launch(dim3 grid, dim3 block, size_t smem, bool com, float 
           robot_spheres, masses, jtype, jmap, lmap, tmap, smap, env, lcd, lco, jld, jlo, jae, joff, B, H, S, L, J, T, E, tpb);
   };
   cuoc::launch(grid, block, smem, body);
+}
+
+// the same launch with the Jacobian-gradient branch compiled in (COMPUTE_JACOBIAN_GRAD = true): d/dq of <grad_jacobian, J(q)>
+// is added to the pose / sphere terms
+extern "C" int ref_kinematics_backward_jacobian(
+    float *grad_q, const float *grad_link_pos, const float *grad_link_quat, const float *grad_spheres, const float *grad_jacobian,
+    const float *global_cumul, const float *robot_spheres, const float *link_masses_com, const int8_t *joint_map_type,
+    const int16_t *joint_map, const int16_t *link_map, const int16_t *tool_frame_map, const int16_t *link_sphere_map,
+    const int32_t *env_query_idx, const int16_t *link_chain_data, const int16_t *link_chain_offsets, const int16_t *joint_links_data,
+    const int16_t *joint_links_offsets, const bool *joint_affects_endeffector, const float *joint_offset, int batch_size, int horizon,
+    int nspheres, int num_links, int n_joints, int n_tool_frames, int num_envs) {
+  const int max_threads = 128, tpb = 32;
+  int bpb = std::min(MAX_BW_BATCH_PER_BLOCK, (48 * 1024) / (num_links * 12 * 4));
+  if (bpb * tpb > max_threads) bpb = max_threads / tpb;
+  bpb = std::max(1, std::min(bpb, batch_size));
+  const dim3 block(bpb * tpb), grid((batch_size * tpb + bpb * tpb - 1) / (bpb * tpb));
+  const size_t smem = (size_t)bpb * num_links * 12 * 4;
+  auto run = [&](auto maxj) {
+    constexpr int16_t MAXJ = decltype(maxj)::value;
+    cuoc::launch(grid, block, smem, [&] {
+      kinematics_backward_kernel<float, float, MAXJ, true, false, true>(
+          grad_q, grad_link_pos, grad_link_quat, grad_spheres, nullptr, nullptr, grad_jacobian, global_cumul, robot_spheres,
+          link_masses_com, joint_map_type, joint_map, link_map, tool_frame_map, link_sphere_map, env_query_idx, link_chain_data,
+          link_chain_offsets, joint_links_data, joint_links_offsets, joint_affects_endeffector, joint_offset, batch_size, horizon,
+          nspheres, num_links, n_joints, n_tool_frames, num_envs, tpb);
+    });
+  };
+  if (n_joints < 16) run(std::integral_constant<int16_t, 16>{});
+  else if (n_joints < 64) run(std::integral_constant<int16_t, 64>{});
+  else run(std::integral_constant<int16_t, 128>{});
+  return 0;
 }
 
 extern "C" int ref_kinematics_backward(

@@ -104,6 +104,26 @@ class ReferenceKernels:
                                          int(use_com))
         return out
 
+    def kinematics_backward_jacobian(self, model, cumul_mat, grad_jacobian, grad_link_pos=None, grad_link_quat=None, grad_spheres=None,
+                                     horizon: int = 1):
+        """d/dq of <grad_jacobian, J(q)> (+ the pose / sphere terms when given): the COMPUTE_JACOBIAN_GRAD instantiation"""
+        t = self._tables(model)
+        L, T = t["lmap"].shape[0], t["tmap"].shape[0]
+        E, S = t["spheres"].shape[:2]
+        cumul = _f32(cumul_mat).reshape(-1, L, 3, 4)
+        n, d = cumul.shape[0], int(model["num_dof"])
+        gj = _f32(grad_jacobian).reshape(n, T, 6, d)
+        gs = _f32(grad_spheres).reshape(n, S, 4) if grad_spheres is not None else np.zeros((n, S, 4), np.float32)
+        gp = _f32(grad_link_pos).reshape(n, T, 3) if grad_link_pos is not None else np.zeros((n, T, 3), np.float32)
+        gq = _f32(grad_link_quat).reshape(n, T, 4) if grad_link_quat is not None else np.zeros((n, T, 4), np.float32)
+        env = np.zeros(max(n // max(horizon, 1), 1), np.int32)
+        out = np.zeros((n, d), np.float32)
+        self.lib.ref_kinematics_backward_jacobian(_p(out), _p(gp), _p(gq), _p(gs), _p(gj), _p(cumul), _p(t["spheres"]), _p(t["masses"]),
+                                                  _p(t["jtype"]), _p(t["jmap"]), _p(t["lmap"]), _p(t["tmap"]), _p(t["smap"]), _p(env),
+                                                  _p(t["lcd"]), _p(t["lco"]), _p(t["jld"]), _p(t["jlo"]), _p(t["jae"]), _p(t["joff"]), n,
+                                                  horizon, S, L, d, T, E)
+        return out
+
     # ------------------------------------------------------------------ self collision
     def self_collision(self, robot_spheres, sphere_padding, collision_pairs, weight: float, max_threads_per_block: int = 512,
                        write_grad: bool = True):
