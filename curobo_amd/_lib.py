@@ -13,10 +13,20 @@ from typing import Dict, List, Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libcurobo_hip.so")
-# the public header: the copy the build puts next to the library (so an installed / copied package is
-# self-contained), else the repository's include/ directory
-_HEADER_CANDIDATES = (os.path.join(_PKG, "lib", "curobo_hip.h"), os.path.join(os.path.dirname(_PKG), "include", "curobo_hip.h"))
-HEADER_PATH = next((p for p in _HEADER_CANDIDATES if os.path.exists(p)), _HEADER_CANDIDATES[-1])
+# the public header: the repository's include/ directory, else the copy the build puts next to the library (a build
+# output, untracked: it makes a copied / installed package self-contained).  load() refuses a library whose header copy
+# differs from include/curobo_hip.h: the argtypes below are parsed from the header and must describe the loaded .so.
+_HEADER_CANDIDATES = (os.path.join(os.path.dirname(_PKG), "include", "curobo_hip.h"), os.path.join(_PKG, "lib", "curobo_hip.h"))
+HEADER_PATH = next((p for p in _HEADER_CANDIDATES if os.path.exists(p)), _HEADER_CANDIDATES[0])
+
+
+def _header_is_stale() -> bool:
+    """include/curobo_hip.h was edited after the library (and its header copy) were built"""
+    a, b = _HEADER_CANDIDATES
+    if not (os.path.exists(a) and os.path.exists(b)):
+        return False
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        return fa.read() != fb.read()
 
 _lib: Optional[C.CDLL] = None
 
@@ -107,6 +117,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m curobo_amd.build` "
             "(hipcc --offload-arch=gfx950). curobo_amd has no CPU fallback."
         )
+    if _header_is_stale():
+        raise ImportError(
+            f"{_HEADER_CANDIDATES[0]} differs from the header {LIB_PATH} was built with ({_HEADER_CANDIDATES[1]}): "
+            "rebuild with `python -m curobo_amd.build` so that the ctypes argument types match the library")
     import torch  # noqa: F401  (loads libamdhip64 first; same SONAME is then shared)
 
     lib = C.CDLL(LIB_PATH)

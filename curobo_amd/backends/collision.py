@@ -78,6 +78,9 @@ def build_voxel_coarse_min(voxel_features: torch.Tensor, voxel_params, block: in
         row = []
         for g in range(n):
             nx, ny, nz = (int(v) for v in prm[e, g, :3])
+            if nx * ny * nz == 0:  # padding slot (environments with fewer grids): its coarse row stays "never culls"
+                row.append(None)
+                continue
             x = feats[e, g, : nx * ny * nz].reshape(1, 1, nx, ny, nz).float()
             c = -F.max_pool3d(-x, kernel_size=block + 2 * dilate, stride=block, padding=dilate, ceil_mode=True)
             cx, cy, cz = -(-nx // block), -(-ny // block), -(-nz // block)
@@ -89,7 +92,8 @@ def build_voxel_coarse_min(voxel_features: torch.Tensor, voxel_params, block: in
     out = torch.full((E, n, n_coarse), -65504.0, dtype=torch.float16, device=voxel_features.device)  # padding never culls
     for e in range(E):
         for g in range(n):
-            out[e, g, : grids[e][g].numel()] = grids[e][g]
+            if grids[e][g] is not None:
+                out[e, g, : grids[e][g].numel()] = grids[e][g]
     return out
 
 

@@ -82,6 +82,11 @@ def seed_ik_iterate(
     ))
 
 
+def seed_ik_iterate_fits(dof: int, num_links: int, num_tool_frames: int, link_chain_len: int) -> bool:
+    """whether :func:`seed_ik_iterate` can hold 16 problems' state in its 64 KB of LDS (``curobo_hip_seed_ik_iterate_fits``)"""
+    return bool(load().curobo_hip_seed_ik_iterate_fits(int(dof), int(num_links), int(num_tool_frames), int(link_chain_len)))
+
+
 def seed_ik_batch_status(success, num_problems: int, num_seeds: int, needed: int, stop_flag):
     """device-side exit test of the seed-IK solver (``curobo_hip_seed_ik_batch_status``)"""
     check(load().curobo_hip_seed_ik_batch_status(ptr(success), int(num_problems), int(num_seeds), int(needed), ptr(stop_flag),

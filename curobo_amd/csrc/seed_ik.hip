@@ -236,6 +236,13 @@ __host__ __device__ inline int seed_ik_row_floats(int D, int T, int L) {
   return R * D + D * (D + 1) + 4 * D + 6 * T * D + L * 12 + L * 16 + 11 * T + 8 + 16;
 }
 
+// dynamic LDS of one 256-thread workgroup of seed_ik_solve_kernel: the shared robot tables + 16 rows of per-problem state
+constexpr int kSeedIkLdsLimit = 64 * 1024;
+__host__ inline size_t seed_ik_iterate_lds(int D, int T, int L, int chain_len) {
+  const int rows = 256 / kRow;
+  return ((size_t)((4 * L + 1 + chain_len + 3) & ~3) + (size_t)rows * ((seed_ik_row_floats(D, T, L) + 3) & ~3)) * sizeof(float);
+}
+
 #define SEED_ROW_SYNC()                                         \
   do {                                                          \
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      \
@@ -758,15 +765,19 @@ CUROBO_EXPORT int curobo_hip_seed_ik_iterate(
   a.joint_affects_endeffector = joint_affects_endeffector; a.L = num_links; a.iterations = iterations;
   a.chain_len = link_chain_len; a.stop_flag = stop_flag; a.blocks_run = blocks_run;
   const int rows = 256 / kRow;
-  const size_t lds = ((size_t)((4 * num_links + 1 + link_chain_len + 3) & ~3) +
-                      (size_t)rows * ((seed_ik_row_floats(dof, num_tool_frames, num_links) + 3) & ~3)) * sizeof(float);
-  CUROBO_REQUIRE(lds <= 64 * 1024, "%s: the per-problem state does not fit in LDS (%zu bytes); use the launch sequence", what, lds);
+  const size_t lds = seed_ik_iterate_lds(dof, num_tool_frames, num_links, link_chain_len);
+  CUROBO_REQUIRE(lds <= (size_t)kSeedIkLdsLimit, "%s: the per-problem state does not fit in LDS (%zu bytes); use the launch sequence", what, lds);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ceil_div(num_problems, rows)), block(256);
   if (dof == 7 && num_tool_frames == 1) hipLaunchKernelGGL((seed_ik_solve_kernel<7, 1>), grid, block, lds, st, a);
   else if (dof == 6 && num_tool_frames == 1) hipLaunchKernelGGL((seed_ik_solve_kernel<6, 1>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((seed_ik_solve_kernel<0, 0>), grid, block, lds, st, a);
   return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_seed_ik_iterate_fits(int dof, int num_links, int num_tool_frames, int link_chain_len) {
+  if (dof < 1 || dof > 16 || num_links < 1 || num_tool_frames < 1 || link_chain_len < 0) return 0;
+  return seed_ik_iterate_lds(dof, num_tool_frames, num_links, link_chain_len) <= (size_t)kSeedIkLdsLimit ? 1 : 0;
 }
 
 CUROBO_EXPORT int curobo_hip_seed_ik_batch_status(const uint8_t *success, int num_problems, int num_seeds, int needed,

@@ -346,6 +346,12 @@ int curobo_hip_seed_ik_iterate(
     float convergence_joint_limit_weight, int num_problems, int dof, int num_links, int num_tool_frames, int link_chain_len,
     int iterations, int initial, const int32_t *stop_flag, int32_t *blocks_run, curobo_hip_stream_t stream);
 
+/* 1 when the per-problem state of curobo_hip_seed_ik_iterate (16 problems per workgroup: accepted / candidate Jacobian,
+ * normal matrix, the candidate's link transforms, pose scratch) fits the launch's 64 KB of LDS and dof <= 16, else 0: the
+ * caller then runs the five-launch iteration (curobo_hip_levenberg_marquardt_step ... curobo_hip_seed_ik_update_state).
+ * Returns the answer itself, not a status (like curobo_hip_rollout_trajopt_fused_torque_fits). */
+int curobo_hip_seed_ik_iterate_fits(int dof, int num_links, int num_tool_frames, int link_chain_len);
+
 /* Device-side early exit of the seed-IK solver (reference _calculate_exit_condition, seed_ik_solver.py:452-468): sets
  * *stop_flag = 1 when at least `needed` of the num_problems problems have a converged seed in success [P, S].  Launches of
  * curobo_hip_seed_ik_iterate that are given the flag (optional, NULL = always run) return at once when it is set and count

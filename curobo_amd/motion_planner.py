@@ -1,0 +1,550 @@
+"""``TrajectoryOptimizer``, ``MotionPlanner`` and ``BatchMotionPlanner``: the reference's planning front ends
+over the HIP solvers.
+
+* ``TrajectoryOptimizer`` / ``TrajectoryOptimizerCfg`` / ``TrajectoryOptimizerResult`` = the reference's
+  ``curobo.trajectory_optimizer`` (``TrajOptSolver`` / ``TrajOptSolverCfg.create`` / ``TrajOptSolverResult``,
+  ``curobo/_src/solver/solver_trajopt.py``, ``solver_trajopt_cfg.py:118-240``) with ``JointState`` /
+  ``GoalToolPose`` arguments.
+* ``MotionPlanner.plan_pose`` = ``curobo/_src/motion/motion_planner.py:207-296``: per attempt, collision-free
+  IK with ``return_seeds = num_trajopt_seeds`` -> failed solutions replaced by the first good one -> trajectory
+  optimisation seeded with straight lines to those solutions, implicit goal state, one time-optimal finetune
+  pass (dt scale 0.55) -> stop at the first attempt with a successful seed.  ``plan_cspace`` (:329-396): joint-space
+  goal, three finetune passes at 0.75.  The PRM graph planner that seeds later attempts in the reference
+  (``_get_graph_seed_trajectories``) is out of scope (graph search), so every attempt is the
+  IK-seeded one; ``plan_grasp`` and the attachment manager are likewise not mirrored.
+* ``BatchMotionPlanner.plan_pose`` / ``plan_cspace`` = ``motion_planner_batch.py:139-289``: ``max_batch_size``
+  problems in one IK + trajopt pass, per-problem start states, first-success-wins over the attempts, optional
+  one-world-per-problem (``multi_env``: problem p collides with scene environment p).
+
+With ``torch.distributed`` initialised the solvers shard their seeds over the ranks (``IKSolver.sharded`` /
+``TrajOptSolver.sharded``); the planners' host decisions use results that are identical on every rank.
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from .kinematics import Kinematics, KinematicsCfg, KinematicsState
+from .scene import SceneData
+from .scene.config import scene_arrays_from_config
+from .solver.ik import IKSolver, IKSolverCfg
+from .solver.trajopt import TrajOptResult, TrajOptSolver, TrajOptSolverCfg
+from .types import DeviceCfg, GoalToolPose, JointState
+
+
+def _load_kinematics(robot, device, assets_root: str = "", num_envs: int = 1) -> KinematicsCfg:
+    import os
+
+    if isinstance(robot, KinematicsCfg):
+        return robot
+    if isinstance(robot, dict):
+        return KinematicsCfg.from_data_dict(robot, assets_root=assets_root, device=device, num_envs=num_envs)
+    if os.path.exists(str(robot)):
+        return KinematicsCfg.from_robot_yaml_file(robot, assets_root or os.path.dirname(os.path.abspath(robot)), device=device,
+                                                  num_envs=num_envs)
+    return KinematicsCfg.from_packaged(str(robot).replace(".yml", "").replace(".yaml", ""), device=device)
+
+
+@dataclass
+class TrajectoryOptimizerResult:
+    """reference TrajOptSolverResult fields (solver_trajopt_result.py:27-60): one row per problem and returned seed"""
+
+    success: torch.Tensor                 # [batch, return_seeds] bool
+    solution: torch.Tensor                # [batch, return_seeds, n_knots, dof] optimised knots
+    js_solution: JointState               # [batch, return_seeds, horizon, dof] with velocity / acceleration / jerk and dt [batch, return_seeds]
+    position_error: torch.Tensor          # [batch, return_seeds]
+    rotation_error: torch.Tensor
+    interpolated_trajectory: Optional[JointState] = None   # [batch, return_seeds, steps, dof] at interpolation_dt
+    interpolated_last_tstep: Optional[torch.Tensor] = None  # [batch, return_seeds]
+    seed_cost: Optional[torch.Tensor] = None
+    goalset_index: Optional[torch.Tensor] = None
+    solve_time: float = 0.0
+    total_time: float = 0.0
+    debug_info: Optional[dict] = None
+
+    @property
+    def motion_time(self) -> torch.Tensor:
+        """(horizon - 1) x dt per returned trajectory"""
+        return (self.js_solution.position.shape[-2] - 1) * self.js_solution.dt
+
+    def get_interpolated_plan(self) -> JointState:
+        """the best trajectory of a single-problem result, trimmed to its last step (reference :133-141)"""
+        if self.interpolated_trajectory is None:
+            raise ValueError("the result carries no interpolated trajectory")
+        if self.interpolated_last_tstep.numel() > 1 and self.interpolated_last_tstep.shape[0] > 1:
+            raise ValueError("only single result is supported")
+        n = int(self.interpolated_last_tstep.reshape(-1)[0])
+        t = self.interpolated_trajectory
+        g = lambda x: None if x is None else x.reshape(-1, x.shape[-2], x.shape[-1])[0, :n]  # noqa: E731
+        return JointState(g(t.position), g(t.velocity), g(t.acceleration), g(t.jerk), t.joint_names, t.dt)
+
+    def copy_at_batch_indices(self, other: "TrajectoryOptimizerResult", mask: torch.Tensor) -> None:
+        """rows of ``other`` where ``mask`` [batch] is set replace this result's (reference copy_at_batch_indices)"""
+        def put(a, b):
+            if a is None or b is None:
+                return a
+            if a.shape != b.shape:  # interpolation buffers of different lengths: pad the shorter one with its last sample
+                n = max(a.shape[2], b.shape[2])
+                pad = lambda x: torch.cat([x, x[:, :, -1:].expand(-1, -1, n - x.shape[2], -1)], 2) if x.shape[2] < n else x  # noqa: E731
+                a, b = pad(a), pad(b)
+            m = mask.view(-1, *([1] * (a.ndim - 1)))
+            return torch.where(m, b, a)
+        for name in ("success", "solution", "position_error", "rotation_error", "seed_cost", "interpolated_last_tstep"):
+            setattr(self, name, put(getattr(self, name), getattr(other, name)))
+        for js_name in ("js_solution", "interpolated_trajectory"):
+            a, b = getattr(self, js_name), getattr(other, js_name)
+            if a is None or b is None:
+                continue
+            for f in ("position", "velocity", "acceleration", "jerk", "dt"):
+                setattr(a, f, put(getattr(a, f), getattr(b, f)))
+
+
+@dataclass
+class TrajectoryOptimizerCfg:
+    kinematics: KinematicsCfg = None
+    scene: Optional[SceneData] = None
+    device_cfg: DeviceCfg = field(default_factory=DeviceCfg)
+    num_seeds: int = 4
+    position_tolerance: float = 0.005
+    orientation_tolerance: float = 0.05
+    use_cuda_graph: bool = True
+    self_collision_check: bool = True
+    optimizer_collision_activation_distance: float = 0.01
+    interpolation_dt: float = 0.025
+    minimum_trajectory_dt: float = 0.002
+    maximum_trajectory_dt: float = 0.2
+    max_batch_size: int = 1
+    multi_env: bool = False
+    random_seed: int = 123
+    num_ik_seeds: int = 32
+    #: spline of the optimiser: content/configs/task/trajopt/transition_bspline_trajopt.yml:9-11 in the reference
+    #: (n_knots 16, interpolation_steps 4); this backend's default is the C2 shape, 12 knots x 2 = 32 + 1 points
+    n_knots: int = 12
+    interpolation_steps: int = 2
+
+    @staticmethod
+    def create(robot: Union[str, Dict, KinematicsCfg], scene_model: Union[str, Dict, List, None] = None, num_seeds: int = 4,
+               position_tolerance: float = 0.005, orientation_tolerance: float = 0.05, use_cuda_graph: bool = True,
+               self_collision_check: bool = True, optimizer_collision_activation_distance: float = 0.01,
+               device_cfg: Optional[DeviceCfg] = None, interpolation_dt: float = 0.025, minimum_trajectory_dt: float = 0.002,
+               maximum_trajectory_dt: float = 0.2, max_batch_size: int = 1, multi_env: bool = False, random_seed: int = 123,
+               num_ik_seeds: int = 32, assets_root: str = "", n_knots: int = 12, interpolation_steps: int = 2, **unused
+               ) -> "TrajectoryOptimizerCfg":
+        """Arguments of the reference's ``TrajOptSolverCfg.create`` (solver_trajopt_cfg.py:118-240).  ``robot``: packaged
+        name (``"franka.yml"``), a robot yaml path, its dictionary or a ``KinematicsCfg``; ``scene_model``: the
+        reference's scene format (a list = one world per environment).  Keyword arguments this backend has no use
+        for (``optimizer_configs``, ``transition_model``, ``metrics_rollout``, ...) are accepted and ignored: the cost set
+        and optimiser settings of ``content/configs/task/trajopt/lbfgs_bspline_trajopt.yml`` are built in."""
+        device_cfg = device_cfg or DeviceCfg()
+        dev = device_cfg.device
+        arrays = scene_arrays_from_config(scene_model)
+        scene = SceneData.from_arrays(arrays, dev) if arrays is not None else None
+        kin = _load_kinematics(robot, dev, assets_root)
+        return TrajectoryOptimizerCfg(
+            kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,
+            orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,
+            optimizer_collision_activation_distance=optimizer_collision_activation_distance, interpolation_dt=interpolation_dt,
+            minimum_trajectory_dt=minimum_trajectory_dt, maximum_trajectory_dt=maximum_trajectory_dt,
+            max_batch_size=max_batch_size, multi_env=multi_env, random_seed=random_seed, num_ik_seeds=num_ik_seeds,
+            n_knots=n_knots, interpolation_steps=interpolation_steps)
+
+    def solver_cfg(self) -> TrajOptSolverCfg:
+        c = TrajOptSolverCfg(num_seeds=self.num_seeds, position_threshold=self.position_tolerance,
+                             rotation_threshold=self.orientation_tolerance, seed=self.random_seed,
+                             interpolation_dt=self.interpolation_dt, minimum_trajectory_dt=self.minimum_trajectory_dt,
+                             maximum_trajectory_dt=self.maximum_trajectory_dt)
+        c.rollout.n_knots, c.rollout.interpolation_steps = self.n_knots, self.interpolation_steps
+        c.rollout.scene_activation_distance = self.optimizer_collision_activation_distance
+        if not self.self_collision_check:
+            c.rollout.self_collision_weight = 0.0
+        c.ik = IKSolverCfg(num_seeds=self.num_ik_seeds, position_threshold=self.position_tolerance,
+                           rotation_threshold=self.orientation_tolerance, seed=self.random_seed)
+        c.ik.rollout.scene_activation_distance = self.optimizer_collision_activation_distance
+        return c
+
+
+class TrajectoryOptimizer:
+    """the reference's ``TrajOptSolver`` call surface: ``solve_pose(goal_tool_poses, current_state, ...)`` and
+    ``solve_cspace(goal_state, current_state, ...)`` on ``max_batch_size`` problems (smaller batches are padded with
+    their first problem, as the reference does, :759-775)"""
+
+    def __init__(self, config: TrajectoryOptimizerCfg):
+        self.config = config
+        self.kinematics = Kinematics(config.kinematics, compute_spheres=True)
+        self._solver: Optional[TrajOptSolver] = None
+        self.solve_time = 0.0
+
+    # ---- reference members
+    @property
+    def joint_names(self) -> List[str]:
+        return self.kinematics.joint_names
+
+    @property
+    def tool_frames(self) -> List[str]:
+        return self.kinematics.tool_frames
+
+    @property
+    def action_dim(self) -> int:
+        return self.config.kinematics.kinematics_config.num_dof
+
+    @property
+    def action_horizon(self) -> int:
+        return self.config.n_knots
+
+    @property
+    def interpolation_steps(self) -> int:
+        return self.config.interpolation_steps
+
+    @property
+    def default_joint_state(self) -> JointState:
+        from .workloads import start_configuration
+
+        q = torch.as_tensor(start_configuration(self.config.kinematics.model), device=self.config.device_cfg.device)
+        return JointState.from_position(q, joint_names=self.joint_names)
+
+    def compute_kinematics(self, state: Union[JointState, torch.Tensor]) -> KinematicsState:
+        return self.kinematics.compute_kinematics(state)
+
+    def update_world(self, scene: SceneData) -> None:
+        self.config.scene = scene
+        self._solver = None
+
+    def reset_seed(self) -> None:
+        pass  # seeds are a function of (config.random_seed, global seed index): nothing drifts between solves
+
+    @property
+    def solver(self) -> TrajOptSolver:
+        if self._solver is None:
+            c = self.config
+            self._solver = TrajOptSolver.sharded(c.kinematics.kinematics_config, c.scene, c.max_batch_size, c.solver_cfg(),
+                                                 use_cuda_graph=c.use_cuda_graph)
+        return self._solver
+
+    def _pad(self, x: Optional[torch.Tensor], batch: int) -> Optional[torch.Tensor]:
+        n = self.config.max_batch_size
+        if x is None or batch == n:
+            return x
+        return torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], dim=0)
+
+    def _env_idx(self) -> Optional[torch.Tensor]:
+        if not self.config.multi_env:
+            return None
+        return torch.arange(self.config.max_batch_size, device=self.config.device_cfg.device, dtype=torch.int32)
+
+    def _wrap(self, r: TrajOptResult, batch: int, k: int, t0: float, start: torch.Tensor) -> TrajectoryOptimizerResult:
+        slv, dev = self.solver, self.config.device_cfg.device
+        n = self.config.max_batch_size
+        D = self.action_dim
+        v = lambda x, *s: x.reshape(n, k, *s)[:batch]  # noqa: E731
+        H = r.position.shape[-2]
+        js = JointState(v(r.position, H, D), v(r.velocity, H, D), v(r.acceleration, H, D), v(r.jerk, H, D), self.joint_names,
+                        v(r.traj_dt))
+        # the returned seeds re-sampled at interpolation_dt (reference interpolated_trajectory / interpolated_last_tstep)
+        knots = r.knots.reshape(n * k, -1, D)
+        st = start.expand(n, D).repeat_interleave(k, dim=0) if start.shape[0] != 1 else start
+        goal = r.goal_config.reshape(n * k, D) if r.implicit_goal else None
+        (ip, iv, ia, ij), last, _ = slv.get_interpolated_trajectory(knots, st, goal, retime=False, traj_dt=r.traj_dt.reshape(n * k))
+        steps = ip.shape[1]
+        w = lambda x: x.reshape(n, k, steps, D)[:batch]  # noqa: E731
+        interp = JointState(w(ip), w(iv), w(ia), w(ij), self.joint_names,
+                            torch.full((batch, k), self.config.interpolation_dt, device=dev))
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        total = time.perf_counter() - t0
+        self.solve_time = total
+        return TrajectoryOptimizerResult(
+            success=v(r.success), solution=v(r.knots, self.config.n_knots, D), js_solution=js, position_error=v(r.position_error),
+            rotation_error=v(r.rotation_error), interpolated_trajectory=interp, interpolated_last_tstep=last.reshape(n, k)[:batch],
+            seed_cost=v(r.cost), solve_time=total, total_time=total,
+            debug_info={"finetune_passes": r.finetune_passes, "seed_index": v(r.seed_index)})
+
+    def solve_pose(self, goal_tool_poses: GoalToolPose, current_state: JointState, seed_config: Optional[torch.Tensor] = None,
+                   seed_traj: Optional[torch.Tensor] = None, return_seeds: int = 1, num_seeds: Optional[int] = None,
+                   dt: Optional[torch.Tensor] = None, use_implicit_goal: bool = False, finetune_attempts: int = 1,
+                   goal_state: Optional[JointState] = None, initial_iters: Optional[int] = None,
+                   time_optimal_iters: Optional[int] = None, finetune_iters: Optional[int] = None,
+                   finetune_dt_scale: float = 0.55) -> TrajectoryOptimizerResult:
+        """reference ``TrajOptSolver.solve_pose`` (:679-829).  ``goal_tool_poses`` [batch, T, 1, 3 | 4];
+        ``current_state.position`` [batch, dof]; ``seed_config`` [batch, n >= num_seeds, dof]; ``seed_traj`` [batch, n,
+        n_knots, dof].  Without seeds and with ``use_implicit_goal=False`` the reference optimises from constant seeds at
+        the current position; so does this."""
+        t0 = time.perf_counter()
+        if num_seeds is not None and num_seeds != self.config.num_seeds:
+            raise ValueError(f"num_seeds is fixed at construction ({self.config.num_seeds}); got {num_seeds}")
+        gp, gq = goal_tool_poses.position, goal_tool_poses.quaternion
+        batch = int(gp.shape[0])
+        if goal_tool_poses.num_goalset != 1:
+            raise ValueError("goal sets are not supported by the trajectory optimiser of this backend (num_goalset must be 1)")
+        if batch > self.config.max_batch_size:
+            raise ValueError(f"solve_pose: batch_size={batch} exceeds config.max_batch_size={self.config.max_batch_size}.")
+        dev = self.config.device_cfg.device
+        start = current_state.position.to(dev, torch.float32).reshape(batch, -1)
+        T = gp.shape[1]
+        pad = lambda x: self._pad(x, batch)  # noqa: E731
+        if seed_config is None and seed_traj is None:  # constant seeds at the current position (solver_core.py:206-210)
+            seed_config = start.view(batch, 1, -1).expand(batch, self.config.num_seeds, start.shape[-1])
+            if use_implicit_goal and goal_state is None:
+                raise ValueError("use_implicit_goal needs seed_config, seed_traj or goal_state")
+        r = self.solver.solve_pose(
+            pad(start), pad(gp.reshape(batch, T, 3).to(dev)), pad(gq.reshape(batch, T, 4).to(dev)), env_idx=self._env_idx(),
+            seed_config=pad(seed_config), seed_traj=pad(seed_traj), return_seeds=return_seeds, dt=pad(dt),
+            use_implicit_goal=use_implicit_goal, finetune_attempts=finetune_attempts,
+            goal_state=pad(goal_state.position.reshape(batch, -1)) if goal_state is not None else None, initial_iters=initial_iters,
+            time_optimal_iters=time_optimal_iters, finetune_iters=finetune_iters, finetune_dt_scale=finetune_dt_scale)
+        return self._wrap(r, batch, return_seeds, t0, pad(start))
+
+    def solve_cspace(self, goal_state: JointState, current_state: JointState, seed_traj: Optional[torch.Tensor] = None,
+                     return_seeds: int = 1, num_seeds: Optional[int] = None, dt: Optional[torch.Tensor] = None,
+                     finetune_attempts: int = 1, initial_iters: Optional[int] = None, time_optimal_iters: Optional[int] = None,
+                     finetune_iters: Optional[int] = None, finetune_dt_scale: float = 0.55) -> TrajectoryOptimizerResult:
+        """reference ``TrajOptSolver.solve_cspace`` (:831-971)"""
+        t0 = time.perf_counter()
+        dev = self.config.device_cfg.device
+        batch = int(current_state.position.reshape(-1, self.action_dim).shape[0])
+        if batch > self.config.max_batch_size:
+            raise ValueError(f"solve_cspace: batch_size={batch} exceeds config.max_batch_size={self.config.max_batch_size}.")
+        start = current_state.position.to(dev, torch.float32).reshape(batch, -1)
+        goal = goal_state.position.to(dev, torch.float32).reshape(batch, -1)
+        pad = lambda x: self._pad(x, batch)  # noqa: E731
+        r = self.solver.solve_cspace(pad(start), pad(goal), env_idx=self._env_idx(), seed_traj=pad(seed_traj),
+                                     return_seeds=return_seeds, dt=pad(dt), finetune_attempts=finetune_attempts,
+                                     initial_iters=initial_iters, time_optimal_iters=time_optimal_iters,
+                                     finetune_iters=finetune_iters, finetune_dt_scale=finetune_dt_scale)
+        return self._wrap(r, batch, return_seeds, t0, pad(start))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MotionPlannerCfg:
+    """reference MotionPlannerCfg (motion/motion_planner_cfg.py:28-261): the IK and trajectory-optimisation
+    configurations of one robot in one (set of) world(s); no graph planner here"""
+
+    trajopt_solver_config: TrajectoryOptimizerCfg = None
+    num_ik_seeds: int = 32
+    device_cfg: DeviceCfg = field(default_factory=DeviceCfg)
+
+    @staticmethod
+    def create(robot: Union[str, Dict, KinematicsCfg], scene_model: Union[str, Dict, List, None] = None,
+               self_collision_check: bool = True, device_cfg: Optional[DeviceCfg] = None, num_ik_seeds: int = 32,
+               num_trajopt_seeds: int = 4, position_tolerance: float = 0.005, orientation_tolerance: float = 0.05,
+               use_cuda_graph: bool = True, random_seed: int = 123, optimizer_collision_activation_distance: float = 0.01,
+               max_batch_size: int = 1, multi_env: bool = False, max_goalset: int = 1, assets_root: str = "", **unused
+               ) -> "MotionPlannerCfg":
+        """Arguments of the reference's ``MotionPlannerCfg.create`` (:37-66); task / graph-planner yaml arguments are
+        accepted and ignored.  ``multi_env``: ``scene_model`` is a list of ``max_batch_size`` worlds, problem p of a batch
+        plans in world p."""
+        if max_goalset != 1:
+            raise ValueError("goal sets are not supported by the planners of this backend (max_goalset must be 1)")
+        device_cfg = device_cfg or DeviceCfg()
+        to = TrajectoryOptimizerCfg.create(
+            robot, scene_model, num_seeds=num_trajopt_seeds, position_tolerance=position_tolerance,
+            orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,
+            optimizer_collision_activation_distance=optimizer_collision_activation_distance, device_cfg=device_cfg,
+            max_batch_size=max_batch_size, multi_env=multi_env, random_seed=random_seed, num_ik_seeds=num_ik_seeds,
+            assets_root=assets_root, **{k: v for k, v in unused.items() if k in ("n_knots", "interpolation_steps", "interpolation_dt",
+                                                                                  "minimum_trajectory_dt", "maximum_trajectory_dt")})
+        if multi_env and (to.scene is None or to.scene.num_envs < max_batch_size):
+            raise ValueError(f"multi_env needs a list of {max_batch_size} scene models (one world per problem)")
+        return MotionPlannerCfg(trajopt_solver_config=to, num_ik_seeds=num_ik_seeds, device_cfg=device_cfg)
+
+
+class _PlannerBase:
+    def __init__(self, config: MotionPlannerCfg):
+        self.config = config
+        self.device_cfg = config.device_cfg
+        self.trajopt_solver = TrajectoryOptimizer(config.trajopt_solver_config)
+        self._ik: Optional[IKSolver] = None
+
+    @property
+    def batch_size(self) -> int:
+        return self.config.trajopt_solver_config.max_batch_size
+
+    @property
+    def ik_solver(self) -> IKSolver:
+        if self._ik is None:
+            c = self.config.trajopt_solver_config
+            self._ik = IKSolver.sharded(c.kinematics.kinematics_config, c.scene, c.max_batch_size, c.solver_cfg().ik,
+                                        use_cuda_graph=c.use_cuda_graph)
+        return self._ik
+
+    # ---- reference properties (motion_planner.py:107-130)
+    @property
+    def joint_names(self) -> List[str]:
+        return self.trajopt_solver.joint_names
+
+    @property
+    def action_dim(self) -> int:
+        return self.trajopt_solver.action_dim
+
+    @property
+    def tool_frames(self) -> List[str]:
+        return self.trajopt_solver.tool_frames
+
+    @property
+    def default_joint_state(self) -> JointState:
+        return self.trajopt_solver.default_joint_state
+
+    @property
+    def kinematics(self) -> Kinematics:
+        return self.trajopt_solver.kinematics
+
+    def compute_kinematics(self, state: Union[JointState, torch.Tensor]) -> KinematicsState:
+        return self.trajopt_solver.compute_kinematics(state)
+
+    def update_world(self, scene: SceneData) -> None:
+        self.trajopt_solver.update_world(scene)
+        self._ik = None
+
+    def reset_seed(self) -> None:
+        self.trajopt_solver.reset_seed()
+
+    def destroy(self) -> None:
+        self._ik = None
+        self.trajopt_solver._solver = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+        return False
+
+    def _ik_seed_configs(self, goal_tool_poses: GoalToolPose, batch: int):
+        """IK with ``return_seeds = num_trajopt_seeds`` (L-BFGS stage always on: motion_planner.py:143-144) ->
+        (success [batch, k], solution [batch, k, dof]); the batch is padded to ``max_batch_size`` with its first problem"""
+        c = self.config.trajopt_solver_config
+        n, k, dev = c.max_batch_size, c.num_seeds, self.device_cfg.device
+        T = goal_tool_poses.position.shape[1]
+        gp = goal_tool_poses.position.to(dev, torch.float32).reshape(batch, T, 3)[:, 0]
+        gq = goal_tool_poses.quaternion.to(dev, torch.float32).reshape(batch, T, 4)[:, 0]
+        pad = lambda x: x if batch == n else torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], 0)  # noqa: E731
+        env = torch.arange(n, device=dev, dtype=torch.int32) if c.multi_env else None
+        r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, exit_early=False, env_idx=env)
+        return r.success.reshape(n, k)[:batch], r.solution.reshape(n, k, -1)[:batch]
+
+
+class MotionPlanner(_PlannerBase):
+    """single-problem planner with retries (reference ``MotionPlanner``, motion/motion_planner.py:38-396)"""
+
+    def __init__(self, config: MotionPlannerCfg):
+        if config.trajopt_solver_config.max_batch_size != 1:
+            raise ValueError("MotionPlanner plans one problem at a time (max_batch_size must be 1); use BatchMotionPlanner")
+        super().__init__(config)
+
+    def warmup(self, enable_graph: bool = True, warmup_joint_index: int = 0, warmup_joint_delta: float = 0.2,
+               num_warmup_iterations: int = 2) -> bool:
+        """a few plans to a pose near the default configuration: builds the solvers and captures their graphs"""
+        for _ in range(num_warmup_iterations):
+            cur = JointState.from_position(self.default_joint_state.position.view(1, -1).clone(), self.joint_names)
+            goal = cur.clone()
+            goal.position[..., warmup_joint_index] += warmup_joint_delta
+            self.plan_pose(self.compute_kinematics(goal).tool_poses.as_goal(), cur, max_attempts=1)
+        return True
+
+    def plan_pose(self, goal_tool_poses: GoalToolPose, current_state: JointState, use_implicit_goal: bool = True,
+                  max_attempts: int = 5, enable_graph_attempt: int = 1) -> Optional[TrajectoryOptimizerResult]:
+        """reference ``plan_pose`` / ``_plan_pose_single`` (:207-296).  Returns None when IK never found a solution."""
+        if current_state.position.ndim > 2:
+            raise ValueError(f"current_state must be a 2D tensor, got shape: {tuple(current_state.position.shape)}")
+        t0 = time.perf_counter()
+        result = None
+        solve_time = 0.0
+        for _ in range(max_attempts):
+            ok, seed_config = self._ik_seed_configs(goal_tool_poses, 1)
+            if int(ok.sum()) == 0:
+                continue
+            if int(ok.sum()) < ok.shape[1]:  # failed solutions are replaced by the first good one (:265-267)
+                good = seed_config[ok][0:1]
+                seed_config = torch.where(ok.unsqueeze(-1), seed_config, good.view(1, 1, -1))
+            result = self.trajopt_solver.solve_pose(goal_tool_poses, current_state, seed_config=seed_config,
+                                                    use_implicit_goal=True, finetune_attempts=1, finetune_dt_scale=0.55)
+            solve_time += result.solve_time
+            if int(result.success.sum()) > 0:
+                break
+        if result is not None:
+            result.solve_time, result.total_time = solve_time, time.perf_counter() - t0
+        return result
+
+    def plan_cspace(self, goal_state: JointState, current_state: JointState, max_attempts: int = 5,
+                    enable_graph_attempt: int = 1) -> Optional[TrajectoryOptimizerResult]:
+        """reference ``plan_cspace`` (:329-396): three finetune passes at a dt scale of 0.75"""
+        if current_state.position.ndim > 2 or goal_state.position.ndim > 2:
+            raise ValueError("current_state and goal_state must be 2D tensors")
+        t0 = time.perf_counter()
+        result, solve_time = None, 0.0
+        for _ in range(max_attempts):
+            result = self.trajopt_solver.solve_cspace(goal_state, current_state, finetune_attempts=3, finetune_dt_scale=0.75)
+            solve_time += result.solve_time
+            if int(result.success.sum()) > 0:
+                break
+        if result is not None:
+            result.solve_time, result.total_time = solve_time, time.perf_counter() - t0
+        return result
+
+
+class BatchMotionPlanner(_PlannerBase):
+    """``max_batch_size`` independent problems per pass (reference ``BatchMotionPlanner``, motion_planner_batch.py:38-289)"""
+
+    def warmup(self, enable_graph: bool = True, num_warmup_iterations: int = 2) -> bool:
+        n = self.batch_size
+        for _ in range(num_warmup_iterations):
+            cur = JointState.from_position(self.default_joint_state.position.view(1, -1).repeat(n, 1), self.joint_names)
+            goal = cur.clone()
+            goal.position[..., 0] += 0.2
+            self.plan_cspace(goal, cur)
+        return True
+
+    def plan_pose(self, goal_tool_poses: GoalToolPose, current_state: JointState, use_implicit_goal: bool = True,
+                  max_attempts: int = 1, success_ratio: float = 1.0, enable_graph_attempt: int = 0
+                  ) -> Optional[TrajectoryOptimizerResult]:
+        """reference ``plan_pose`` (:139-221): up to ``max_attempts`` IK -> trajopt passes over the whole batch, a
+        problem keeps the result of the first pass that solved it; stops when ``success_ratio`` of the batch is solved.
+        Returns None when IK never found a solution."""
+        t0 = time.perf_counter()
+        batch = goal_tool_poses.batch_size
+        best: Optional[TrajectoryOptimizerResult] = None
+        solved = torch.zeros(batch, dtype=torch.bool, device=self.device_cfg.device)
+        for _ in range(max_attempts):
+            ok, seed_config = self._ik_seed_configs(goal_tool_poses, batch)
+            if int(ok.sum()) == 0:
+                continue
+            r = self.trajopt_solver.solve_pose(goal_tool_poses, current_state, seed_config=seed_config,
+                                               use_implicit_goal=use_implicit_goal)
+            if best is None:
+                best, solved = r, r.success.any(dim=-1)
+            else:
+                newly = r.success.any(dim=-1) & ~solved
+                if bool(newly.any()):
+                    best.copy_at_batch_indices(r, newly)
+                    solved = solved | newly
+            if float(solved.float().mean()) >= success_ratio:
+                break
+        if best is not None:
+            best.total_time = time.perf_counter() - t0
+        return best
+
+    def plan_cspace(self, goal_states: JointState, current_state: JointState, max_attempts: int = 1,
+                    success_ratio: float = 1.0, enable_graph_attempt: int = 0) -> Optional[TrajectoryOptimizerResult]:
+        """reference ``plan_cspace`` (:223-289)"""
+        t0 = time.perf_counter()
+        batch = int(current_state.position.shape[0])
+        best: Optional[TrajectoryOptimizerResult] = None
+        solved = torch.zeros(batch, dtype=torch.bool, device=self.device_cfg.device)
+        for _ in range(max_attempts):
+            r = self.trajopt_solver.solve_cspace(goal_states, current_state)
+            if best is None:
+                best, solved = r, r.success.any(dim=-1)
+            else:
+                newly = r.success.any(dim=-1) & ~solved
+                if bool(newly.any()):
+                    best.copy_at_batch_indices(r, newly)
+                    solved = solved | newly
+            if float(solved.float().mean()) >= success_ratio:
+                break
+        if best is not None:
+            best.total_time = time.perf_counter() - t0
+        return best

@@ -233,9 +233,16 @@ class LBFGSOpt:
         else:
             self._opt_iters()
 
-    def optimize(self, seed: torch.Tensor) -> torch.Tensor:
+    def optimize(self, seed: torch.Tensor, num_iters: Optional[int] = None) -> torch.Tensor:
+        """``num_iters`` overrides ``cfg.num_iters`` for this call (reference ``update_niters``, used by the trajopt
+        solver's finetune passes): whole blocks of ``inner_iters`` replay the graph, a remainder runs eagerly."""
         self.reinitialize(seed)
-        outer = max(1, self.cfg.num_iters // self.cfg.inner_iters)
+        if num_iters is None:
+            outer, rest = max(1, self.cfg.num_iters // self.cfg.inner_iters), 0
+        else:
+            outer, rest = divmod(int(num_iters), self.cfg.inner_iters)
         for _ in range(outer):
             self.run_inner()
+        for _ in range(rest):
+            self._opt_step()
         return self.best_action.view(self.num_problems, self.action_horizon, self.action_dim)

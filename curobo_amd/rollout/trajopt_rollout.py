@@ -167,11 +167,13 @@ class TrajOptRollout:
         if getattr(self, "goal_pos", None) is None:
             self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(1, D, device=d) for _ in range(4))
 
-    def update_goal_state(self, goal_joint_position: Optional[torch.Tensor], goal_idx: Optional[torch.Tensor] = None) -> None:
+    def update_goal_state(self, goal_joint_position: Optional[torch.Tensor], goal_idx: Optional[torch.Tensor] = None,
+                          implicit: bool = True) -> None:
         """Implicit goal state (reference ``use_implicit_goal_state``, bspline_interpolation.cuh:
         110-124): trajectory b ends at rest in joint configuration ``goal_joint_position[goal_idx[b]]``
         (enforced by the spline's goal boundary knots, not by a cost).  ``None`` = free end point that
-        only comes to rest (replicated last knot)."""
+        only comes to rest (replicated last knot); ``implicit=False`` keeps the goal rows (and their dt, which the
+        kernels index with ``goal_idx`` like the reference's ``seed_goal_js.dt``) but leaves the end point free."""
         D, d = self.action_dim, self.device
         if goal_joint_position is None:
             self.goal_pos = torch.zeros(1, D, device=d)
@@ -183,13 +185,38 @@ class TrajOptRollout:
             g = goal_joint_position.to(d, torch.float32).reshape(-1, D).contiguous()
             n = g.shape[0]
             self.goal_idx.copy_(goal_idx.to(torch.int32) if goal_idx is not None else torch.zeros_like(self.goal_idx))
-            if self.goal_pos.shape == g.shape and self._implicit_goal.shape[0] == n and bool(self._implicit_goal[0]):
+            if self.goal_pos.shape == g.shape and self._implicit_goal.shape[0] == n and self._traj_dt.shape[0] == n:
                 self.goal_pos.copy_(g)  # same shape: keep the pointers a captured hipGraph holds
+                self._implicit_goal.fill_(1 if implicit else 0)
                 return
             self.goal_pos = g.clone()
-            self._implicit_goal = torch.ones(n, dtype=torch.uint8, device=d)
+            self._implicit_goal = torch.full((n,), 1 if implicit else 0, dtype=torch.uint8, device=d)
             self._traj_dt = torch.full((n,), self.cfg.traj_dt, device=d)
         self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
+
+    def update_traj_dt(self, dt) -> None:
+        """Time step of the trajectories (reference ``RobotRollout.update_goal_dt``, ``seed_goal_js.dt``): a scalar or one
+        value per goal-state row (``update_goal_state``); trajectory b runs at ``dt[goal_idx[b]]``.  In place (captured
+        graphs keep their pointers): the B-spline's dt, the c-space cost's per-trajectory dt and the speed metric's dt --
+        which is element 0 of the per-trajectory vector, as the reference's kernel reads it (wp_speed_metric.py:54)."""
+        if torch.is_tensor(dt):
+            self._traj_dt.copy_(dt.to(self.device, torch.float32).reshape(-1))
+        else:
+            self._traj_dt.fill_(float(dt))
+        if self._traj_dt.shape[0] == 1:
+            self.state_dt.copy_(self._traj_dt.expand(self.batch_size))
+        else:
+            torch.index_select(self._traj_dt, 0, self.goal_idx.long(), out=self.state_dt)
+        self._speed_dt.copy_(self.state_dt[:1])
+
+    def compute_state_from_action(self, act_seq: torch.Tensor) -> None:
+        """knots -> position / velocity / acceleration / jerk buffers only (reference ``compute_state_from_action``)"""
+        c, B = self.cfg, self.batch_size
+        trajectory_hip.launch_bspline_interpolation_forward_kernel(
+            self.position, self.velocity, self.acceleration, self.jerk, self.out_dt, act_seq, self.start_pos,
+            self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk,
+            self.start_idx, self.goal_idx, self._traj_dt, self._implicit_goal, B, c.padded_horizon, self.action_dim, c.n_knots,
+            c.bspline_degree)
 
     use_multi_env = False
 

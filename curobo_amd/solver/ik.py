@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from ..distributed import global_argmin, global_topk
+from ..distributed import global_argmin, global_topk, shard_range
 from ..optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
 from ..robot.kinematics_params import KinematicsParams
 from ..rollout.ik_rollout import IKRollout, IKRolloutCfg
@@ -65,12 +65,17 @@ class IKResult:
 
 class IKSolver:
     def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int,
-                 cfg: Optional[IKSolverCfg] = None, seed_offset: int = 0, use_cuda_graph: bool = True):
+                 cfg: Optional[IKSolverCfg] = None, seed_offset: int = 0, use_cuda_graph: bool = True,
+                 global_num_seeds: Optional[int] = None):
+        """``cfg.num_seeds`` seeds per problem run in this process: seeds ``[seed_offset, seed_offset + num_seeds)`` of
+        ``global_num_seeds`` when the seed axis is sharded over ranks (default: all of them; ``IKSolver.sharded``
+        derives the shard of this rank from ``torch.distributed``)."""
         self.kin, self.scene, self.cfg = kin, scene, cfg or IKSolverCfg()
         self._use_graph, self._result_graphs = use_cuda_graph, {}
         self.P, self.S = num_problems, self.cfg.num_seeds
         self.device = kin.device
         self.seed_offset = seed_offset
+        self.S_global = int(global_num_seeds) if global_num_seeds is not None else self.S
         # private copy of the optimiser configuration: the caller's cfg may be shared by solvers of other sizes
         ocfg = dataclasses.replace(self.cfg.optimizer, num_problems=self.P * self.S)
         self.cfg = dataclasses.replace(self.cfg, optimizer=ocfg)
@@ -101,13 +106,42 @@ class IKSolver:
         self._mrow_goal = (torch.arange(self.P * self.S, device=self.device) // self.S).to(torch.int32)
         self.seed_solver = None
         if self.cfg.use_lm_seed:
-            n_lm = max(self.cfg.seed_solver_num_seeds, 2 * self.S)
-            # seed shards (ranks) draw different Halton points: the shard index enters the sampler seed
-            shard = seed_offset // max(self.S, 1)
-            self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=n_lm, use_cuda_graph=use_cuda_graph,
-                                                                         sampler_seed=451 + self.cfg.seed + 7919 * shard),
-                                            num_goalset=self.G)
+            # the LM seed stage works on ONE global Halton set whatever the world size (W = 1 and
+            # W = 8 draw the same seeds): max(seed_solver_num_seeds, 2 x global seeds) LM runs per problem, this rank
+            # takes a contiguous slice of them, all ranks rank them together and the optimiser seeds of this rank are
+            # rows [seed_offset, seed_offset + num_seeds) of that ranking
+            n_lm = max(self.cfg.seed_solver_num_seeds, 2 * self.S_global)
+            lm_lo, lm_hi = 0, n_lm
+            if self.S_global != self.S:
+                import torch.distributed as dist
+
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise ValueError("a seed shard (global_num_seeds != num_seeds) needs torch.distributed initialised")
+                rank, world = dist.get_rank(), dist.get_world_size()
+                if shard_range(self.S_global, rank, world) != (seed_offset, seed_offset + self.S):
+                    raise ValueError(f"seed shard [{seed_offset}, {seed_offset + self.S}) of {self.S_global} is not rank {rank}'s "
+                                     f"contiguous shard {shard_range(self.S_global, rank, world)} (world size {world})")
+                lm_lo, lm_hi = shard_range(n_lm, rank, world)
+            self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=lm_hi - lm_lo, use_cuda_graph=use_cuda_graph,
+                                                                         sampler_seed=451 + self.cfg.seed),
+                                            num_goalset=self.G, seed_offset=lm_lo, global_num_seeds=n_lm)
         self._gen = torch.Generator(device="cpu")
+
+    @classmethod
+    def sharded(cls, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int, cfg: Optional[IKSolverCfg] = None,
+                use_cuda_graph: bool = True) -> "IKSolver":
+        """``cfg.num_seeds`` is the GLOBAL seed count; the solver of this rank runs its contiguous shard of it
+        (``distributed.shard_range``).  Alone in the process this is the plain solver."""
+        import torch.distributed as dist
+
+        cfg = cfg or IKSolverCfg()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return cls(kin, scene, num_problems, cfg, use_cuda_graph=use_cuda_graph)
+        lo, hi = shard_range(cfg.num_seeds, dist.get_rank(), dist.get_world_size())
+        if hi == lo:
+            raise ValueError(f"{cfg.num_seeds} seeds cannot be sharded over {dist.get_world_size()} ranks")
+        return cls(kin, scene, num_problems, dataclasses.replace(cfg, num_seeds=hi - lo), seed_offset=lo,
+                   use_cuda_graph=use_cuda_graph, global_num_seeds=cfg.num_seeds)
 
     def sample_seeds(self) -> torch.Tensor:
         """[P, S, D] uniform in the joint limits; seed s of problem p depends only on its GLOBAL
@@ -145,7 +179,10 @@ class IKSolver:
                 optimizer_goals_set = True
         if seeds is None:
             if self.seed_solver is not None:
-                seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=S).solution
+                # the S_global best LM runs over all ranks, identical everywhere; this rank optimises its rows of them
+                seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=self.S_global).solution
+                if self.S_global != S:
+                    seeds = seeds[:, self.seed_offset:self.seed_offset + S].contiguous()
             else:
                 seeds = self.sample_seeds()
         self.optimizer_ran = True

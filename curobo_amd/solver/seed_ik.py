@@ -117,15 +117,26 @@ class SeedIKSolver:
     configurations per problem out of ``num_seeds`` LM runs."""
 
     def __init__(self, kin: KinematicsParams, num_problems: int, cfg: Optional[SeedIKSolverCfg] = None,
-                 default_joint_position: Optional[torch.Tensor] = None, num_goalset: int = 1):
+                 default_joint_position: Optional[torch.Tensor] = None, num_goalset: int = 1,
+                 seed_offset: int = 0, global_num_seeds: Optional[int] = None):
         """``num_goalset`` G > 1: every problem has G alternative goal poses per tool frame and each seed
         is pulled to the member its pose error is smallest for (reference SeedIKSolver goal-set
-        buffer, seed_ik_solver.py:340-365; the arg-min is the pose kernel's)."""
+        buffer, seed_ik_solver.py:340-365; the arg-min is the pose kernel's).
+
+        Seed shards (one process per GPU): this instance runs seeds
+        ``[seed_offset, seed_offset + cfg.num_seeds)`` of a set of ``global_num_seeds`` that every rank
+        generates identically (same sampler seed, same index stream) and slices, so any world size
+        works on the same seeds; ``solve_batch`` then ranks the runs of ALL ranks (one all-gather)."""
         self.kin, self.cfg = kin, cfg or SeedIKSolverCfg()
         self.G = num_goalset
         c, dev = self.cfg, kin.fixed_transforms.device
         self.device = dev
         self.P, self.S = num_problems, c.num_seeds
+        self.seed_offset = int(seed_offset)
+        self.S_global = int(global_num_seeds) if global_num_seeds is not None else self.S
+        if not (0 <= self.seed_offset and self.seed_offset + self.S <= self.S_global):
+            raise ValueError(f"seed shard [{self.seed_offset}, {self.seed_offset + self.S}) is not inside the global seed "
+                             f"set of {self.S_global}")
         self.n = n = self.P * self.S
         D, T, L, Sp = kin.num_dof, kin.num_pose_links, kin.num_links, kin.num_spheres
         self.D, self.T, self.R = D, T, 6 * T + D
@@ -168,6 +179,7 @@ class SeedIKSolver:
         self._stop_flag = z(1, dt=torch.int32)
         self._solve_graphs, self._last_outer = {}, 0
         self._blocks_run = z(1, dt=torch.int32)
+        self._fused_fits: Optional[bool] = None
 
     # ------------------------------------------------------------------ one evaluation / iteration
     def _evaluate_candidate(self, q: torch.Tensor, initial: bool) -> None:
@@ -203,7 +215,13 @@ class SeedIKSolver:
             acceleration_weight=c.acceleration_weight if self._vel_active else 0.0)
 
     def _fused_ok(self) -> bool:
-        return bool(self.cfg.fused_iterations) and self.D <= 16
+        """the one-launch iteration needs dof <= 16 and 16 problems' state in 64 KB of LDS (a 7-dof arm with more than
+        ~27 links, or a dual arm with two tool frames, does not fit): otherwise the five-launch iteration runs"""
+        if self._fused_fits is None:
+            k = self.kin
+            self._fused_fits = bool(self.cfg.fused_iterations) and self.D <= 16 and linalg_hip.seed_ik_iterate_fits(
+                self.D, k.num_links, self.T, int(k.link_chain_data.shape[0]))
+        return self._fused_fits
 
     def _iterate_fused(self, iterations: int, seeds: Optional[torch.Tensor] = None) -> None:
         """``iterations`` LM iterations (after the initial evaluation of ``seeds`` when given) in one launch"""
@@ -254,19 +272,25 @@ class SeedIKSolver:
     # ------------------------------------------------------------------ seeds, solve
     def generate_seeds(self, seed_config: Optional[torch.Tensor] = None) -> torch.Tensor:
         """reference _generate_seed_configs (:470-520): the same Halton seeds for every problem, the
-        last one replaced by the default joint position; given seeds come first."""
-        P, S, D = self.P, self.S, self.D
+        last one replaced by the default joint position; given seeds come first.  A seed shard builds the
+        global set and keeps its slice (the index stream is a host generator: every rank draws the same)."""
+        P, S, D, SG, lo = self.P, self.S, self.D, self.S_global, self.seed_offset
         if seed_config is not None:
             seed_config = seed_config.to(self.device, torch.float32).view(P, -1, D)
-            if seed_config.shape[1] > S:
-                raise ValueError(f"seed_config has {seed_config.shape[1]} seeds, but only {S} are needed")
-            if seed_config.shape[1] == S:
-                return seed_config
-            extra = self.sampler.get_samples(P * (S - seed_config.shape[1])).view(P, -1, D)
-            return torch.cat([seed_config, extra], dim=1)
-        seeds = self.sampler.get_samples(S).view(1, S, D).repeat(P, 1, 1)
+            if seed_config.shape[1] > SG:
+                raise ValueError(f"seed_config has {seed_config.shape[1]} seeds, but only {SG} are needed")
+            if seed_config.shape[1] == SG:
+                return seed_config[:, lo:lo + S].contiguous()
+            extra = self.sampler.get_samples(P * (SG - seed_config.shape[1])).view(P, -1, D)
+            return torch.cat([seed_config, extra], dim=1)[:, lo:lo + S].contiguous()
+        seeds = self.sampler.get_samples(SG).view(1, SG, D).repeat(P, 1, 1)
         seeds[:, -1, :] = self.default_joint_position.view(1, -1)
-        return seeds
+        return seeds[:, lo:lo + S].contiguous()
+
+    def _sharded(self) -> bool:
+        import torch.distributed as dist
+
+        return self.S_global != self.S and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def solve_batch(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, seed_config: Optional[torch.Tensor] = None,
                     return_seeds: int = 1, current_position: Optional[torch.Tensor] = None,
@@ -289,7 +313,7 @@ class SeedIKSolver:
             seed_config = current_position.view(P, 1, D)
         seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
         fused = self._fused_ok()
-        if fused and c.use_cuda_graph and not self._vel_active and current_position is None:
+        if fused and c.use_cuda_graph and not self._vel_active and current_position is None and not self._sharded():
             # the whole solve after the seeds (initial evaluation, every block of iterations with the device-side exit
             # test, the ranking) replayed from ONE hipGraph: ~35 small submissions become one
             if return_seeds not in self._solve_graphs:
@@ -329,17 +353,27 @@ class SeedIKSolver:
             for it in range(outer):
                 self._iterate_fused(c.inner_iterations)
                 if it < outer - 1:
-                    linalg_hip.seed_ik_batch_status(self.success, P, S, needed, self._stop_flag)
+                    if self._sharded():
+                        self._global_batch_status(needed)
+                    else:
+                        linalg_hip.seed_ik_batch_status(self.success, P, S, needed, self._stop_flag)
         else:
             self._evaluate_candidate(seeds, initial=True)
         it = 0
         for it in range(outer if not fused else 0):
             self._run_inner()
             if it < outer - 1:  # reference _calculate_exit_condition (:452-468)
-                solved = (self.success.view(P, S).sum(-1) >= 1).sum()
-                if int(solved) >= c.batch_success_threshold * P:
+                solved = (self.success.view(P, S).sum(-1) >= 1)
+                if self._sharded():  # a problem counts as solved when ANY rank holds a converged seed of it
+                    import torch.distributed as dist
+
+                    solved = solved.to(torch.int32)
+                    dist.all_reduce(solved, op=dist.ReduceOp.MAX)
+                if int(solved.sum()) >= c.batch_success_threshold * P:
                     break
         self._last_outer = it
+        if self._sharded():
+            return self._rank_over_all_shards(return_seeds, current_position)
         if S <= 1024 and return_seeds <= S:  # one launch instead of ~20 torch kernels (masks, top-k, gathers)
             dev = self.device
             ok_o = torch.empty(P, return_seeds, dtype=torch.uint8, device=dev)
@@ -366,3 +400,33 @@ class SeedIKSolver:
         g = lambda t: torch.gather(t, 1, top)  # noqa: E731
         sol = torch.gather(q, 1, top.unsqueeze(-1).expand(P, return_seeds, D))
         return g(ok), sol, g(pos), g(ori)
+
+    # ------------------------------------------------------------------ seed shards (one process per GPU)
+    def _global_batch_status(self, needed: int) -> None:
+        """the exit test of the fused path over ALL seed shards: one all-reduce (MAX) of the per-problem "has a converged
+        seed" byte vector, enqueued on the stream like the launches around it (no host round trip); the flag is sticky,
+        as in ``curobo_hip_seed_ik_batch_status``"""
+        import torch.distributed as dist
+
+        solved = self.success.view(self.P, self.S).amax(dim=1).to(torch.int32)
+        dist.all_reduce(solved, op=dist.ReduceOp.MAX)
+        self._stop_flag.copy_(torch.maximum(self._stop_flag, (solved.sum() >= needed).to(torch.int32).view(1)))
+
+    def _rank_over_all_shards(self, return_seeds: int, current_position: Optional[torch.Tensor]):
+        """reference _select_top_solutions (:522-572) over the LM runs of every rank: the ``return_seeds`` best of the
+        global seed set, ordered by (cost, global seed index) -- identical on every rank and for every world size"""
+        from ..distributed import global_topk
+
+        P, S, D, c = self.P, self.S, self.D, self.cfg
+        pos, ori = self.position_error.view(P, S), self.orientation_error.view(P, S)
+        q = self.q.view(P, S, D)
+        ok = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)
+        if c.joint_limit_weight > 0:
+            ok &= ((q > self._limits[0]) & (q < self._limits[1])).all(-1)
+        costs = pos + ori
+        if c.start_cspace_dist_weight > 0 and current_position is not None:
+            costs = costs + c.start_cspace_dist_weight * torch.norm(q - current_position.to(self.device).view(P, 1, D), dim=-1)
+        costs = costs + 1e10 * (~ok).float()
+        payload = torch.cat([q, pos.unsqueeze(-1), ori.unsqueeze(-1), ok.float().unsqueeze(-1)], dim=-1)
+        _, _, best = global_topk(costs, payload, self.seed_offset, return_seeds)
+        return best[..., D + 2] > 0.5, best[..., :D].contiguous(), best[..., D], best[..., D + 1]

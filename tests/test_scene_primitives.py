@@ -96,6 +96,27 @@ def test_voxel_coarse_min_is_a_lower_bound_of_every_interpolated_value():
                 assert c[a, b, d] == ff[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].min()
 
 
+def test_voxel_coarse_min_skips_empty_grid_slots():
+    """Environments with different grid counts pad the [E, n] grid table with all-zero slots: those rows keep the
+    'never culls' padding (-65504) and the real slots are unchanged (a zero-sized slot used to reach max_pool3d)."""
+    import torch
+
+    from curobo_amd.backends.collision import build_voxel_coarse_min
+
+    rng = np.random.default_rng(1)
+    nx, ny, nz = 9, 8, 6
+    f = np.zeros((2, 2, nx * ny * nz), np.float16)
+    f[0, 0] = rng.normal(size=nx * ny * nz).astype(np.float16)
+    f[0, 1] = rng.normal(size=nx * ny * nz).astype(np.float16)
+    f[1, 0] = rng.normal(size=nx * ny * nz).astype(np.float16)
+    prm = np.zeros((2, 2, 4), np.float32)
+    prm[0, 0] = prm[0, 1] = prm[1, 0] = (nx, ny, nz, 0.02)  # env 1 has one grid: slot [1, 1] is padding
+    c = build_voxel_coarse_min(torch.as_tensor(f), prm, 4, 3).numpy()
+    assert (c[1, 1] == np.float16(-65504.0)).all()
+    one = build_voxel_coarse_min(torch.as_tensor(f[1:2, 0:1]), prm[1:2, 0:1], 4, 3).numpy()
+    np.testing.assert_array_equal(c[1, 0, : one.shape[-1]], one[0, 0])
+
+
 PRIM_WORLD = [[
     {"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]},
     {"type": "sphere", "radius": 0.18, "pose": [0.45, 0.1, 0.45, 1, 0, 0, 0]},
