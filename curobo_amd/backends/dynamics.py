@@ -24,7 +24,9 @@ def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tens
     """Depth-first (parents first) order of the links as int16, cached per link table.  The kernels walk the tree
     serially per element; any parents-first order is correct, and in depth-first order the parent of a link is mostly
     the link just processed, whose state the kernels then keep in registers instead of re-reading it from the cache.
-    One host read-back per robot: call once outside graph capture (the first, warm-up call does)."""
+    One host read-back per robot: call once outside graph capture (the first, warm-up call does).  The entry lives as
+    long as ``link_map`` does: pass the robot's own table (``KinematicsParams.link_map``), not a temporary copy, and keep
+    the returned tensor referenced while a struct holds its raw pointer (the fused trajopt terms)."""
     key = (link_map.data_ptr(), int(link_map.numel()), str(link_map.device))
     hit = _dfs_orders.get(key)
     # an entry only counts while the tensor it was made from is alive: the caching allocator hands a freed address
@@ -50,6 +52,9 @@ def _walk_order(link_map: torch.Tensor, level_links: torch.Tensor) -> torch.Tens
         else:
             order = torch.as_tensor(out, dtype=level_links.dtype).to(level_links.device)
         _dfs_orders[key] = (weakref.ref(link_map), order)
+        from .geometry import _evict_dead
+
+        weakref.finalize(link_map, _evict_dead, _dfs_orders, key)  # no dead entries (and their device tensors) pile up
     return order
 
 

@@ -42,7 +42,16 @@ def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[t
         res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots,
                torch.as_tensor(tiles).to(pair_locations.device).contiguous())
     _bitmap_cache[key] = (weakref.ref(pair_locations), res)
+    weakref.finalize(pair_locations, _evict_dead, _bitmap_cache, key)  # the device tensors of an entry go with the pair tensor
     return res
+
+
+def _evict_dead(cache: dict, key) -> None:
+    """drop ``cache[key]`` when the tensor it was built from is gone (a live entry under the same key -- the address was
+    reused by a new tensor that has been cached since -- stays)"""
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is None:
+        cache.pop(key, None)
 
 
 def self_collision_distance(

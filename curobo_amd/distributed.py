@@ -25,6 +25,43 @@ def shard_range(num_seeds: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_gather_rows(flat: torch.Tensor, row: torch.Tensor, group: Optional[dist.ProcessGroup]) -> None:
+    """``all_gather_into_tensor`` (RCCL over xGMI in production).  The gloo backend -- world-size-2 tests on CPU, or two
+    ranks sharing one GPU -- has no device all-gather: device tensors are staged through the host there."""
+    if row.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(flat.shape, dtype=flat.dtype)
+        dist.all_gather_into_tensor(host, row.cpu().contiguous(), group=group)
+        flat.copy_(host)
+    else:
+        dist.all_gather_into_tensor(flat, row.contiguous(), group=group)
+
+
+def all_reduce_max(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """in-place MAX over the ranks (no-op alone); device tensors go through the host on the gloo backend"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return x
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        host = x.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        x.copy_(host)
+    else:
+        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
+    return x
+
+
+def broadcast_from_rank0(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """in-place broadcast of rank 0's ``x`` (no-op alone); device tensors go through the host on the gloo backend"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return x
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        host = x.cpu()
+        dist.broadcast(host, src=0, group=group)
+        x.copy_(host)
+    else:
+        dist.broadcast(x, src=0, group=group)
+    return x
+
+
 def local_best(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int) -> torch.Tensor:
     """cost[P, S_local], payload[P, S_local, V] -> packed [P, 2 + V] rows (cost, global idx, payload).
 
@@ -55,7 +92,7 @@ def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         flat = torch.empty(world * row.shape[0], row.shape[1], device=row.device, dtype=row.dtype)
-        dist.all_gather_into_tensor(flat, row.contiguous(), group=group)  # concatenated along dim 0
+        _all_gather_rows(flat, row, group)  # concatenated along dim 0
         gathered = flat.view(world, *row.shape)
     else:
         gathered = row.unsqueeze(0)
@@ -100,7 +137,7 @@ def global_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         flat = torch.empty(world * rows.shape[0], *rows.shape[1:], device=rows.device, dtype=rows.dtype)
-        dist.all_gather_into_tensor(flat, rows.contiguous(), group=group)
+        _all_gather_rows(flat, rows, group)
         cand = flat.view(world, *rows.shape).permute(1, 0, 2, 3).reshape(rows.shape[0], world * k, -1)
     else:
         cand = rows

@@ -194,7 +194,7 @@ class TrajOptRollout:
             self._traj_dt = torch.full((n,), self.cfg.traj_dt, device=d)
         self.goal_vel, self.goal_acc, self.goal_jerk = (torch.zeros(n, D, device=d) for _ in range(3))
 
-    def update_traj_dt(self, dt) -> None:
+    def update_traj_dt(self, dt, speed_dt: Optional[torch.Tensor] = None) -> None:
         """Time step of the trajectories (reference ``RobotRollout.update_goal_dt``, ``seed_goal_js.dt``): a scalar or one
         value per goal-state row (``update_goal_state``); trajectory b runs at ``dt[goal_idx[b]]``.  In place (captured
         graphs keep their pointers): the B-spline's dt, the c-space cost's per-trajectory dt and the speed metric's dt --
@@ -207,7 +207,9 @@ class TrajOptRollout:
             self.state_dt.copy_(self._traj_dt.expand(self.batch_size))
         else:
             torch.index_select(self._traj_dt, 0, self.goal_idx.long(), out=self.state_dt)
-        self._speed_dt.copy_(self.state_dt[:1])
+        # (a seed shard passes the dt of GLOBAL trajectory 0, which lives on rank 0, so that every world size computes
+        # the speed metric the single-process solve does)
+        self._speed_dt.copy_(self.state_dt[:1] if speed_dt is None else speed_dt.reshape(1))
 
     def compute_state_from_action(self, act_seq: torch.Tensor) -> None:
         """knots -> position / velocity / acceleration / jerk buffers only (reference ``compute_state_from_action``)"""
@@ -339,6 +341,8 @@ class TrajOptRollout:
         k, c, B = self.kin, self.cfg, self.batch_size
         sc, m = k.self_collision, with_metrics
         use_scene = self.scene is not None
+        if c.use_torque_limits:  # the terms struct holds the raw pointer of the walk order: keep the tensor referenced
+            self._level_links = dynamics_hip._walk_order(k.link_map, k.link_level_data)
         self._terms = rollout_hip.make_trajopt_terms(
             out_pose_distance=self.pose_cost if m else None, out_position_distance=self.pose_pos_dist if m else None,
             out_rotation_distance=self.pose_rot_dist if m else None, out_goalset_idx=self.goalset_idx if m else None,
@@ -355,7 +359,7 @@ class TrajOptRollout:
             cspace_target_dof_weight=self._onesD, retime_weights=c.retime_weights,
             retime_regularization_weights=c.retime_regularization_weights,
             **(dict(link_masses_com=k.link_masses_com, link_inertias=k.link_inertias, gravity=self._gravity,
-                    level_links=dynamics_hip._walk_order(k.link_map, k.link_level_data), use_torque_limits=1)
+                    level_links=self._level_links, use_torque_limits=1)
                if c.use_torque_limits else {}))
         rollout_hip.rollout_trajopt_fused(
             self._terms, self.cost, self.grad_knots, self.position if m else None, self.robot_spheres if m else None,

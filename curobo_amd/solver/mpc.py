@@ -158,10 +158,14 @@ class MPCSolver:
         self._solve(seed, self.cfg.cold_start_optimization_num_iters)
 
     def warm_start_solve(self, current_state: JointState) -> None:
-        """previous knots shifted by one interval (last knot repeated), ``warm_start_optimization_num_iters`` iterations
+        """previous knots shifted by the executed intervals (last knot repeated), ``warm_start_optimization_num_iters`` iterations
         (reference :643-700: trajectory_execution_manager.get_shifted action buffer + optimizer.shift)"""
         self.update_current_state(current_state)
-        seed = torch.cat([self._knots[:, 1:], self._knots[:, -1:]], dim=1).contiguous()
+        # shift by the knot intervals the robot actually executed since the last solve: two in continuous mode (the plan is
+        # followed from point 1 up to point 2 * interpolation_steps), one otherwise; at least one
+        start = 1 if self.cfg.continuous_commands else self.cfg.interpolation_steps
+        n = max(1, min((self._cursor - start) // self.cfg.interpolation_steps, self._knots.shape[1] - 1))
+        seed = torch.cat([self._knots[:, n:], self._knots[:, -1:].expand(-1, n, -1)], dim=1).contiguous()
         self._solve(seed, self.cfg.warm_start_optimization_num_iters)
 
     def optimize_next_action(self, current_state: JointState) -> MPCSolverResult:

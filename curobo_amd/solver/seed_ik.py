@@ -365,10 +365,9 @@ class SeedIKSolver:
             if it < outer - 1:  # reference _calculate_exit_condition (:452-468)
                 solved = (self.success.view(P, S).sum(-1) >= 1)
                 if self._sharded():  # a problem counts as solved when ANY rank holds a converged seed of it
-                    import torch.distributed as dist
+                    from ..distributed import all_reduce_max
 
-                    solved = solved.to(torch.int32)
-                    dist.all_reduce(solved, op=dist.ReduceOp.MAX)
+                    solved = all_reduce_max(solved.to(torch.int32))
                 if int(solved.sum()) >= c.batch_success_threshold * P:
                     break
         self._last_outer = it
@@ -406,10 +405,9 @@ class SeedIKSolver:
         """the exit test of the fused path over ALL seed shards: one all-reduce (MAX) of the per-problem "has a converged
         seed" byte vector, enqueued on the stream like the launches around it (no host round trip); the flag is sticky,
         as in ``curobo_hip_seed_ik_batch_status``"""
-        import torch.distributed as dist
+        from ..distributed import all_reduce_max
 
-        solved = self.success.view(self.P, self.S).amax(dim=1).to(torch.int32)
-        dist.all_reduce(solved, op=dist.ReduceOp.MAX)
+        solved = all_reduce_max(self.success.view(self.P, self.S).amax(dim=1).to(torch.int32))
         self._stop_flag.copy_(torch.maximum(self._stop_flag, (solved.sum() >= needed).to(torch.int32).view(1)))
 
     def _rank_over_all_shards(self, return_seeds: int, current_position: Optional[torch.Tensor]):

@@ -239,8 +239,13 @@ class TrajOptSolver:
 
     def _set_dt(self, dt: torch.Tensor) -> None:
         """dt [P * S] of every (problem, seed) into both rollouts (reference _update_trajectory_dt, :560-577)"""
-        self.rollout.update_traj_dt(dt)
-        self.metrics_rollout.update_traj_dt(dt)
+        speed = None
+        if self.S_global != self.S:  # the speed metric reads the dt of global trajectory 0 (wp_speed_metric.py:54): rank 0's
+            from ..distributed import broadcast_from_rank0
+
+            speed = broadcast_from_rank0(dt[:1].clone())
+        self.rollout.update_traj_dt(dt, speed)
+        self.metrics_rollout.update_traj_dt(dt, speed)
 
     # ------------------------------------------------------------------ solve
     def solve_pose(self, start_position: torch.Tensor, goal_position: torch.Tensor, goal_quat: torch.Tensor,
@@ -392,12 +397,9 @@ class TrajOptSolver:
     def _any(mask: torch.Tensor) -> bool:
         """``mask.any()`` over the seeds of ALL ranks (the host decisions of the finetune loop, reference :441-450, are taken
         on the global seed set so that every world size runs the same passes)"""
-        import torch.distributed as dist
+        from ..distributed import all_reduce_max
 
-        flag = mask.any().to(torch.int32)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        return bool(flag.item())
+        return bool(all_reduce_max(mask.any().to(torch.int32).view(1)).item())
 
     def _seed_metrics(self, knots, dt, start, seed_goal, use_implicit_goal) -> dict:
         """metrics rollout of P * S optimised seeds at their dt: success = feasible over the horizon (and on the

@@ -101,3 +101,93 @@ def _topk_worker(rank, world, port, total_seeds, k):
 def test_global_topk_world_size_2_gloo():
     world, port = 2, _free_port()
     mp.spawn(_topk_worker, args=(world, port, 64, 5), nprocs=world, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Seed shards draw ONE global seed set ("W = 1 and W = 8 produce identical seed sets")
+def _cpu_seed_solver(num_problems, num_seeds, seed_offset=0, global_num_seeds=None, **cfg_kw):
+    from conftest import load_model
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.solver.seed_ik import SeedIKSolver, SeedIKSolverCfg
+
+    kin = KinematicsParams.from_model(load_model("franka"), torch.device("cpu"))
+    return SeedIKSolver(kin, num_problems, SeedIKSolverCfg(num_seeds=num_seeds, use_cuda_graph=False, **cfg_kw),
+                        seed_offset=seed_offset, global_num_seeds=global_num_seeds)
+
+
+def test_halton_seed_shards_are_slices_of_the_global_set():
+    P, SG = 3, 24
+    whole = _cpu_seed_solver(P, SG).generate_seeds()
+    assert whole.shape == (P, SG, 7)
+    for world in (2, 3, 8):
+        parts = []
+        for rank in range(world):
+            lo, hi = shard_range(SG, rank, world)
+            parts.append(_cpu_seed_solver(P, hi - lo, seed_offset=lo, global_num_seeds=SG).generate_seeds())
+        assert torch.equal(torch.cat(parts, dim=1), whole), f"world size {world}"
+    # the default joint position is the LAST seed of the global set, wherever that lands
+    s = _cpu_seed_solver(P, 4, seed_offset=20, global_num_seeds=SG)
+    assert torch.equal(s.generate_seeds()[:, -1], s.default_joint_position.view(1, -1).expand(P, -1))
+    assert not torch.equal(_cpu_seed_solver(P, 4, seed_offset=0, global_num_seeds=SG).generate_seeds()[:, -1],
+                           s.default_joint_position.view(1, -1).expand(P, -1))
+    # caller seeds come first in the global set
+    given = torch.rand(P, 2, 7)
+    g0 = _cpu_seed_solver(P, 12, 0, SG).generate_seeds(given)
+    g1 = _cpu_seed_solver(P, 12, 12, SG).generate_seeds(given)
+    assert torch.equal(g0[:, :2], given) and torch.equal(torch.cat([g0, g1], 1), _cpu_seed_solver(P, SG).generate_seeds(given))
+    with pytest.raises(ValueError, match="not inside the global seed"):
+        _cpu_seed_solver(P, 8, seed_offset=20, global_num_seeds=SG)
+
+
+def _lm_rank_worker(rank, world, port, out_dir):
+    """every rank holds the LM results of its seed shard; the ranking over all shards (SeedIKSolver._rank_over_all_shards: one
+    all-gather) must equal the single-process ranking of the whole seed set, on every rank"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, SG, k = 3, 20, 6
+    g = torch.Generator().manual_seed(7)
+    from conftest import load_model
+
+    lim = torch.as_tensor(np.asarray(load_model("franka").joint_limits_position), dtype=torch.float32)
+    q = 0.5 * (lim[0] + lim[1]) + 0.2 * (torch.rand(P, SG, 7, generator=g) - 0.5)  # inside the Franka limits
+    pos_fail = (1, 7)  # one seed outside the tolerances: ranked last
+    pos, ori = torch.rand(P, SG, generator=g) * 0.01, torch.rand(P, SG, generator=g) * 0.1
+    pos[1, 4] = pos[1, 15] = 0.001
+    ori[1, 4] = ori[1, 15] = 0.001  # a tie across the ranks: the lower global index wins
+    pos[pos_fail] = 0.5
+    lo, hi = shard_range(SG, rank, world)
+    s = _cpu_seed_solver(P, hi - lo, seed_offset=lo, global_num_seeds=SG)
+    assert s._sharded()
+    s.q.view(P, hi - lo, 7).copy_(q[:, lo:hi])
+    s.position_error.view(P, hi - lo).copy_(pos[:, lo:hi])
+    s.orientation_error.view(P, hi - lo).copy_(ori[:, lo:hi])
+    ok, sol, pe, oe = s._rank_over_all_shards(k, None)
+    c = s.cfg
+    good = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)
+    cost = pos + ori + 1e10 * (~good).float()
+    order = torch.sort(cost, dim=1, stable=True).indices[:, :k]
+    ar = torch.arange(P).unsqueeze(1)
+    assert torch.equal(sol, q[ar, order]) and torch.equal(pe, pos[ar, order]) and torch.equal(ok, good[ar, order])
+    assert order[1, :2].tolist() == [4, 15]
+    # the exit test over all shards: a problem counts as solved when ANY rank holds a converged seed of it
+    s.success.zero_()
+    if rank == 1:
+        s.success.view(P, hi - lo)[0, 0] = 1
+        s.success.view(P, hi - lo)[2, 1] = 1
+    s._stop_flag.zero_()
+    s._global_batch_status(needed=3)
+    assert int(s._stop_flag) == 0
+    if rank == 0:
+        s.success.view(P, hi - lo)[1, 3] = 1
+    s._global_batch_status(needed=3)
+    assert int(s._stop_flag) == 1
+    np.save(os.path.join(out_dir, f"lm{rank}.npy"), sol.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_lm_seed_ranking_over_shards_world_size_2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_lm_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "lm0.npy"), np.load(tmp_path / "lm1.npy"))

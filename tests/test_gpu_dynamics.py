@@ -79,18 +79,18 @@ def test_dynamics_front_end_autograd(oracle, device):
     assert float(tg[:, 0].abs().max()) < 1e-4 and float(tg.abs().max()) > 1.0
 
 
-def test_c4_shape_humanoid_self_collision_plus_inverse_dynamics_cost(oracle, device):
-    """BASELINE config 4 in small: Unitree G1 whole body (the in-tree stand-in for the 38-DoF
-    humanoid), map-reduce-sized self collision (162 k sphere pairs, tiled kernel) + an
-    inverse-dynamics cost (joint-torque limits and torque regularisation on RNEA's tau, through the
-    c-space STATE cost) and the complete VJP chain back to (q, qd, qdd) -- HIP kernels vs the oracle
+@pytest.mark.parametrize("B,H", [(4, 6), (256, 33)])
+def test_c4_shape_humanoid_self_collision_plus_inverse_dynamics_cost(B, H, oracle, device):
+    """BASELINE config 4, in small and at the size of one GPU's share of the benchmark (256 seeds x 33 points): Unitree G1
+    whole body (the in-tree stand-in for the 38-DoF humanoid), map-reduce-sized self collision (162 k sphere pairs, dense
+    bitmap + broad-phase tiles) + an inverse-dynamics cost (joint-torque limits and torque regularisation on RNEA's tau,
+    through the c-space STATE cost) and the complete VJP chain back to (q, qd, qdd) -- HIP kernels vs the oracle
     composition of the same stages."""
     from curobo_amd.backends import cost as Cs
     from curobo_amd.backends import dynamics as Dy
     from curobo_amd.backends import geometry as G
     from curobo_amd.backends import kinematics as K
 
-    B, H = 4, 6
     n = B * H
     model, kin, q, qd, qdd, rng = _setup("unitree_g1", device, n, 11)
     md = model.as_dict()

@@ -182,8 +182,11 @@ def test_trajopt_solver_reaches_goal_collision_free(num_ik_goals, oracle, device
     s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
     assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
     assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
-    vel = np.diff(traj, axis=1) / 0.15
+    dt = res.traj_dt.cpu().numpy()[succ]  # every winner was retimed to the fastest dt its limits allow
+    assert (dt >= solver.cfg.minimum_trajectory_dt - 1e-7).all() and (dt <= solver.cfg.maximum_trajectory_dt + 1e-7).all()
+    vel = np.diff(traj, axis=1) / dt[:, None, None]
     assert np.abs(vel).max() <= np.abs(model.joint_limits_velocity).max() * 1.05
+    np.testing.assert_allclose(res.motion_time.cpu().numpy()[succ], (H - 1) * dt, rtol=1e-6)
 
 
 def test_trajopt_retime_and_interpolate(device):
@@ -206,7 +209,8 @@ def test_trajopt_retime_and_interpolate(device):
     res = solver.solve_pose(start, gp, gq)
     assert res.success.float().mean() >= 0.5
     rc = cfg.rollout
-    (pos, vel, acc, jerk), last, dt = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=False)
+    fixed = torch.full((P,), rc.traj_dt, device=device)  # (positions do not depend on dt: the grids coincide at this one)
+    (pos, vel, acc, jerk), last, dt = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=False, traj_dt=fixed)
     torch.cuda.synchronize()
     assert torch.allclose(dt, torch.full_like(dt, rc.traj_dt))
     # both samplings hit the knot boundaries of the same spline: every `per`-th re-interpolated sample
@@ -219,7 +223,7 @@ def test_trajopt_retime_and_interpolate(device):
                                rtol=0, atol=2e-5)
     torch.testing.assert_close(pos[:, 0], start.view(1, -1).expand(P, -1), rtol=0, atol=1e-6)
     # retimed: dt within the configured range, limits respected at the new dt, same path end point
-    (pos2, vel2, acc2, jerk2), last2, dt2 = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=True)
+    (pos2, vel2, acc2, jerk2), last2, dt2 = solver.get_interpolated_trajectory(res.knots, start, res.goal_config, retime=True, traj_dt=fixed)
     torch.cuda.synchronize()
     assert bool(((dt2 >= cfg.minimum_trajectory_dt - 1e-7) & (dt2 <= cfg.maximum_trajectory_dt + 1e-7)).all())
     vmax = kin.joint_limits_velocity[1].abs()
@@ -341,7 +345,7 @@ def test_trajopt_solver_with_torque_limits(oracle, device):
     gl = {"position": r1.goal_config.cpu().numpy().astype(np.float32), "velocity": np.zeros((P, D), np.float32),
           "acceleration": np.zeros((P, D), np.float32), "jerk": np.zeros((P, D), np.float32)}
     i0, gi = np.zeros(P, np.int32), np.arange(P, dtype=np.int32)
-    s = oracle.bspline_forward(r1.knots.cpu().numpy(), st, gl, i0, gi, np.full(P, rc.traj_dt, np.float32), np.ones(P, np.uint8), H,
+    s = oracle.bspline_forward(r1.knots.cpu().numpy(), st, gl, i0, gi, r1.traj_dt.cpu().numpy().astype(np.float32), np.ones(P, np.uint8), H,
                                rc.bspline_degree)
     flat = lambda a: np.ascontiguousarray(a.reshape(P * H, D))  # noqa: E731
     tau, _ = oracle.rnea_forward(flat(s["position"]), flat(s["velocity"]), flat(s["acceleration"]), md, gravity=grav)
