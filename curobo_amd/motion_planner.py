@@ -214,7 +214,8 @@ class TrajectoryOptimizer:
         self._solver = None
 
     def reset_seed(self) -> None:
-        pass  # seeds are a function of (config.random_seed, global seed index): nothing drifts between solves
+        if self._solver is not None:
+            self._solver.reset_seed()
 
     @property
     def solver(self) -> TrajOptSolver:
@@ -401,6 +402,8 @@ class _PlannerBase:
 
     def reset_seed(self) -> None:
         self.trajopt_solver.reset_seed()
+        if self._ik is not None:
+            self._ik.reset_seed()
 
     def destroy(self) -> None:
         self._ik = None

@@ -143,6 +143,12 @@ class IKSolver:
         return cls(kin, scene, num_problems, dataclasses.replace(cfg, num_seeds=hi - lo), seed_offset=lo,
                    use_cuda_graph=use_cuda_graph, global_num_seeds=cfg.num_seeds)
 
+    def reset_seed(self) -> None:
+        """reference ``reset_seed``: rewind the Halton index stream of the LM seed stage, so that the next solve starts from
+        the seeds the first solve started from"""
+        if self.seed_solver is not None:
+            self.seed_solver.reset_seed()
+
     def sample_seeds(self) -> torch.Tensor:
         """[P, S, D] uniform in the joint limits; seed s of problem p depends only on its GLOBAL
         seed index so any sharding of the seed axis draws the same set."""

@@ -121,8 +121,7 @@ class InverseKinematics:
     def reset_seed(self) -> None:
         for s in self._solvers.values():
             s._gen.manual_seed(s.cfg.seed)
-            if s.seed_solver is not None and hasattr(s.seed_solver, "reset_seed"):
-                s.seed_solver.reset_seed()
+            s.reset_seed()
 
     def update_world(self, scene: SceneData) -> None:
         self.config.scene = scene

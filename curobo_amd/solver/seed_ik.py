@@ -287,6 +287,9 @@ class SeedIKSolver:
         seeds[:, -1, :] = self.default_joint_position.view(1, -1)
         return seeds[:, lo:lo + S].contiguous()
 
+    def reset_seed(self) -> None:
+        self.sampler.reset()
+
     def _sharded(self) -> bool:
         import torch.distributed as dist
 

@@ -118,7 +118,11 @@ class TrajOptSolver:
         self._use_graph = use_cuda_graph
         self._ik: Optional[IKSolver] = None  # built on first use: callers that bring seed_config never need it
         self.rollout = TrajOptRollout(kin, scene, self.P * self.S * self.nls, rc)
-        self.metrics_rollout = TrajOptRollout(kin, scene, self.P * self.S, rc)
+        # the metrics rollout checks feasibility the way the reference's does (content/configs/task/metrics_base.yml:8-19):
+        # discrete scene collision at zero activation distance (a seed fails when a sphere penetrates, not when it enters
+        # the optimiser's 2.5 mm activation shell), kernel sequence (it materialises the per-point terms the checks read)
+        self.metrics_rollout = TrajOptRollout(kin, scene, self.P * self.S, dataclasses.replace(
+            rc, use_sweep=False, use_speed_metric=False, scene_activation_distance=0.0, use_fused=False))
         self.K = max(1, min(self.cfg.num_ik_goals or self.S_global, self.S_global, self.cfg.ik.num_seeds))
         D, PS = kin.num_dof, self.P * self.S
         rows = torch.arange(PS * self.nls, device=self.device)
@@ -157,6 +161,12 @@ class TrajOptSolver:
         if self._ik is None:
             self._ik = IKSolver.sharded(self.kin, self.scene, self.P, self.cfg.ik, use_cuda_graph=self._use_graph)
         return self._ik
+
+    def reset_seed(self) -> None:
+        """reference ``reset_seed``: the next solve draws the seeds the first one drew (the LM seed stage of the IK samples
+        its Halton points from a stream that otherwise runs on from solve to solve)"""
+        if self._ik is not None:
+            self._ik.reset_seed()
 
     # ------------------------------------------------------------------ seeds
     def seed_goal_choice(self, ik_success: torch.Tensor) -> torch.Tensor:
@@ -365,6 +375,7 @@ class TrajOptSolver:
             best_dt = self._local(torch.as_tensor(dt, dtype=torch.float32, device=self.device).reshape(P, -1).expand(P, self.S_global)).reshape(P * S).clone()
         best = None
         passes = 0
+        self.last_pass_trace = [dict(seed_dt=best_dt.view(P, S).clone())]  # per pass: dt it ran at, dt after retiming, successes
         for i in range(finetune_attempts + 1):
             cur_dt = torch.clamp(best_dt * scale, min=cfg.minimum_trajectory_dt, max=cfg.maximum_trajectory_dt)
             self._set_dt(cur_dt)
@@ -378,6 +389,8 @@ class TrajOptSolver:
             new_dt = self.compute_trajectory_dt(m.velocity, m.acceleration, m.jerk, cur_dt)
             self._set_dt(new_dt)
             r = self._seed_metrics(knots, new_dt, start, seed_goal, use_implicit_goal)
+            self.last_pass_trace.append(dict(run_dt=cur_dt.view(P, S).clone(), retimed_dt=new_dt.view(P, S).clone(),
+                                             success=r["success"].view(P, S).clone()))
             if best is None:
                 best, best_dt = r, new_dt.clone()
             else:
@@ -419,16 +432,19 @@ class TrajOptSolver:
         # (content/configs/task/metrics_base.yml:16-19, solver/solver_trajopt_result.py:154-210)
         for x, b in ((m.velocity, m._v_b), (m.acceleration, m._a_b), (m.jerk, m._j_b)):
             feasible &= ((x >= b[0] - 1e-3 * b[0].abs() - 1e-4) & (x <= b[1] + 1e-3 * b[1].abs() + 1e-4)).all(-1).all(-1)
-        feasible &= m.self_dist.view(P * S, -1).sum(-1) <= 0.0
-        if self.scene is not None:
-            feasible &= m.scene_dist.view(P * S, -1).sum(-1) <= 0.0
+        in_limits = feasible.clone()
+        no_self = m.self_dist.view(P * S, -1).sum(-1) <= 0.0
+        no_scene = (m.scene_dist.view(P * S, -1).sum(-1) <= 0.0) if self.scene is not None else torch.ones_like(no_self)
+        feasible = feasible & no_self & no_scene
         if rc.use_torque_limits:  # inverse-dynamics torques of the whole trajectory inside the effort limits
             feasible &= (m._tau.view(P * S, -1, D).abs() <= m._effort_b[1] * (1.0 + 1e-3) + 1e-3).all(-1).all(-1)
+        ok_rollout = feasible.clone()
         if self._check is not None:
             env = m.env_query_idx if m.use_multi_env else None
             feasible &= self._check.feasible(knots, dt, start.expand(P, D).contiguous(), self._mrow_problem, seed_goal.reshape(P * S, D),
                                              use_implicit_goal, cfg.interpolation_dt, env)
-        ok = feasible & (pos_err < cfg.position_threshold) & (rot_err < cfg.rotation_threshold)
+        converged = (pos_err < cfg.position_threshold) & (rot_err < cfg.rotation_threshold)
+        ok = feasible & converged
         H = q.shape[1]
         st, en = (8, H - 8) if H > 17 else (0, H)
         mean_jerk = m.jerk.abs().mean(-1)[:, st:en].mean(-1)
@@ -436,7 +452,8 @@ class TrajOptSolver:
         rank = pos_err + rot_err + 0.001 * mean_jerk + 0.01 * mean_acc + 1000.0 * dt
         return dict(knots=knots.clone(), dt=dt.clone(), success=ok, pos_err=pos_err.clone(), rot_err=rot_err.clone(),
                     rank=rank, position=q.clone(), velocity=m.velocity.clone(), acceleration=m.acceleration.clone(),
-                    jerk=m.jerk.clone())
+                    jerk=m.jerk.clone(), feasible_rollout=ok_rollout, feasible_interpolated=feasible.clone(), converged=converged,
+                    in_limits=in_limits, no_self_collision=no_self, no_scene_collision=no_scene)
 
     def _rank(self, best: dict, seed_goal: torch.Tensor, k: int, passes: int) -> TrajOptResult:
         """the k best seeds per problem over ALL ranks: one all-gather of (rank cost, global seed index, payload)"""
@@ -459,7 +476,14 @@ class TrajOptSolver:
             goal_config=sq(goal), traj_dt=sq(dt[..., 0]), velocity=sq(vel.reshape(*lead, H, D)),
             acceleration=sq(acc.reshape(*lead, H, D)), jerk=sq(jerk.reshape(*lead, H, D)), finetune_passes=passes,
             all_seeds=dict(success=best["success"].view(P, S), traj_dt=best["dt"].view(P, S),
-                           knots=best["knots"].view(P, S, nk, D), cost=ranked))
+                           knots=best["knots"].view(P, S, nk, D), cost=ranked,
+                           # why a seed failed: limits / collision over the optimiser's points, the same on the
+                           # interpolated trajectory, pose error at the last point
+                           feasible_rollout=best["feasible_rollout"].view(P, S), in_limits=best["in_limits"].view(P, S),
+                           no_self_collision=best["no_self_collision"].view(P, S),
+                           no_scene_collision=best["no_scene_collision"].view(P, S),
+                           feasible_interpolated=best["feasible_interpolated"].view(P, S), converged=best["converged"].view(P, S),
+                           position_error=best["pos_err"].view(P, S), rotation_error=best["rot_err"].view(P, S)))
 
     # ------------------------------------------------------------------ retiming
     def get_interpolated_trajectory(self, knots: torch.Tensor, start_position: torch.Tensor,
