@@ -148,3 +148,36 @@ def global_topk(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int, k: 
     by_cost = torch.sort(cand[:, :, 0], dim=1, stable=True).indices[:, :k]
     best = torch.gather(cand, 1, by_cost.unsqueeze(-1).expand(-1, -1, cand.shape[-1]))
     return best[:, :, 0], best[:, :, 1].to(torch.int64), best[:, :, 2:]
+
+
+
+def gather_problem_winners(cost: torch.Tensor, payload: torch.Tensor, problem_offset: int, num_problems: int,
+                           group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """PROBLEM shard (BASELINE config 5; SURVEY.md section 8e: "for the particle stage shard by problem"): this rank holds
+    every seed of problems ``[problem_offset, problem_offset + P_local)``.  cost [P_local, S], payload [P_local, S, V] ->
+    (best cost [num_problems], best seed index [num_problems], payload [num_problems, V]) on every rank: the local arg-min
+    per problem, then ONE all-gather of the winners' packed rows (equal shards: num_problems divisible by the world size)."""
+    row = local_best(cost, payload, 0)  # [P_local, 2 + V]
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        if row.shape[0] != num_problems:
+            raise ValueError(f"alone in the process this rank must hold all {num_problems} problems, got {row.shape[0]}")
+        return row[:, 0], row[:, 1].to(torch.int64), row[:, 2:]
+    world = dist.get_world_size(group)
+    if row.shape[0] * world != num_problems:
+        raise ValueError(f"{num_problems} problems over {world} ranks need {num_problems // world} per rank, got {row.shape[0]}")
+    flat = torch.empty(num_problems, row.shape[1], device=row.device, dtype=row.dtype)
+    _all_gather_rows(flat, row, group)  # rank r's rows land at [r * P_local, (r + 1) * P_local): the problem order
+    return flat[:, 0], flat[:, 1].to(torch.int64), flat[:, 2:]
+
+
+def all_gather_problems(x: torch.Tensor, num_problems: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """problem shard: this rank's rows ``x [P_local, ...]`` -> the job's ``[num_problems, ...]`` on every rank (ranks own
+    equal, contiguous problem ranges in rank order; identity alone in the process)"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return x
+    world = dist.get_world_size(group)
+    if x.shape[0] * world != num_problems:
+        raise ValueError(f"{num_problems} problems over {world} ranks need {num_problems // world} per rank, got {x.shape[0]}")
+    flat = torch.empty(num_problems, *x.shape[1:], device=x.device, dtype=x.dtype)
+    _all_gather_rows(flat, x, group)
+    return flat

@@ -52,8 +52,20 @@ class MPPI:
     """
 
     def __init__(self, cfg: MPPICfg, cost_fn: Callable[[torch.Tensor], torch.Tensor], action_horizon: int,
-                 action_dim: int, action_bounds: Tuple[torch.Tensor, torch.Tensor], device):
+                 action_dim: int, action_bounds: Tuple[torch.Tensor, torch.Tensor], device, problem_offset: int = 0,
+                 global_num_problems: Optional[int] = None):
+        """PROBLEM shard (one process per GPU; SURVEY.md section 8e: the softmax couples the particles of a problem, so the
+        particle stage shards by problem): this instance optimises problems ``[problem_offset, problem_offset +
+        cfg.num_problems)`` of ``global_num_problems``.  The particle noise of a problem depends on its GLOBAL index only
+        (every rank draws the global noise tensor from the same generator state and keeps its rows), so any world size
+        samples the same particles; results are assembled with ``distributed.all_gather_problems``.  No collective inside
+        the iteration."""
         self.cfg, self.cost_fn = cfg, cost_fn
+        self.problem_offset = int(problem_offset)
+        self.global_num_problems = int(global_num_problems) if global_num_problems is not None else cfg.num_problems
+        if not (0 <= self.problem_offset and self.problem_offset + cfg.num_problems <= self.global_num_problems):
+            raise ValueError(f"problem shard [{self.problem_offset}, {self.problem_offset + cfg.num_problems}) is not inside "
+                             f"the {self.global_num_problems} problems of the job")
         self.action_horizon, self.action_dim, self.device = action_horizon, action_dim, device
         B, P, Ha, D = cfg.num_problems, cfg.num_particles, action_horizon, action_dim
         lows, highs = action_bounds
@@ -84,7 +96,11 @@ class MPPI:
     def sample_actions(self) -> torch.Tensor:
         B, Ha, D = self.cfg.num_problems, self.action_horizon, self.action_dim
         n = self.sampled_per_problem
-        noise = torch.randn(B, n, Ha, D, device=self.device, generator=self._gen)
+        if self.global_num_problems == B:
+            noise = torch.randn(B, n, Ha, D, device=self.device, generator=self._gen)
+        else:  # a problem shard: the job's noise tensor, this rank's problems of it
+            noise = torch.randn(self.global_num_problems, n, Ha, D, device=self.device, generator=self._gen)
+            noise = noise[self.problem_offset:self.problem_offset + B]
         self.actions[:, :n] = self.mean.unsqueeze(1) + noise * self.scale_tril.unsqueeze(1)
         if self.neg_per_problem:
             self.actions[:, n:n + 1] = -self.mean.unsqueeze(1)

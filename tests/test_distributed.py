@@ -191,3 +191,60 @@ def test_lm_seed_ranking_over_shards_world_size_2_gloo(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_lm_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     np.testing.assert_array_equal(np.load(tmp_path / "lm0.npy"), np.load(tmp_path / "lm1.npy"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PROBLEM shards (BASELINE config 5, the MPPI particle stage)
+def test_mppi_problem_shards_sample_the_jobs_particles():
+    """a problem's particle noise depends on its global index only: the shards' samples concatenate to the single-process ones"""
+    from curobo_amd.optim.mppi import MPPI, MPPICfg
+
+    PG, n_part, Ha, D = 6, 16, 5, 3
+    lo_b, hi_b = -2.0 * torch.ones(D), 2.0 * torch.ones(D)
+    mean = torch.rand(PG, Ha, D)
+    whole = MPPI(MPPICfg(num_problems=PG, num_particles=n_part, null_act_frac=0.125), lambda a: a.sum(-1), Ha, D, (lo_b, hi_b), "cpu")
+    whole.mean.copy_(mean)
+    want = [whole.sample_actions().clone() for _ in range(2)]  # two iterations: the generator state advances alike
+    for world in (2, 3):
+        parts = [[], []]
+        for rank in range(world):
+            lo, hi = shard_range(PG, rank, world)
+            m = MPPI(MPPICfg(num_problems=hi - lo, num_particles=n_part, null_act_frac=0.125), lambda a: a.sum(-1), Ha, D, (lo_b, hi_b),
+                     "cpu", problem_offset=lo, global_num_problems=PG)
+            m.mean.copy_(mean[lo:hi])
+            for it in range(2):
+                parts[it].append(m.sample_actions().clone())
+        for it in range(2):
+            assert torch.equal(torch.cat(parts[it], 0), want[it]), (world, it)
+    with pytest.raises(ValueError, match="problem shard"):
+        MPPI(MPPICfg(num_problems=4), lambda a: a, Ha, D, (lo_b, hi_b), "cpu", problem_offset=4, global_num_problems=6)
+
+
+def _problem_worker(rank, world, port):
+    from curobo_amd.distributed import all_gather_problems, gather_problem_winners
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    PG, S, V = 8, 10, 4
+    g = torch.Generator().manual_seed(3)
+    cost, payload = torch.rand(PG, S, generator=g), torch.rand(PG, S, V, generator=g)
+    cost[5, 2] = cost[5, 7] = -1.0  # a tie inside a problem: the lower seed index
+    lo, hi = shard_range(PG, rank, world)
+    c, i, p = gather_problem_winners(cost[lo:hi].contiguous(), payload[lo:hi].contiguous(), lo, PG)
+    ref = cost.argmin(1)
+    assert torch.equal(i, ref) and i[5].item() == 2
+    assert torch.equal(c, cost[torch.arange(PG), ref]) and torch.equal(p, payload[torch.arange(PG), ref])
+    full = all_gather_problems(payload[lo:hi].contiguous(), PG)
+    assert torch.equal(full, payload)
+    try:
+        gather_problem_winners(cost[:3].contiguous(), payload[:3].contiguous(), 0, PG)
+        raise AssertionError("unequal problem shards must be refused")
+    except ValueError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_problem_shard_exchange_world_size_2_gloo():
+    mp.spawn(_problem_worker, args=(2, _free_port()), nprocs=2, join=True)

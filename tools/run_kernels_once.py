@@ -1,0 +1,126 @@
+"""Every kernel the BASELINE configs launch, a few plain launches each on one stream (no hipGraph, no side streams): the
+target of the rocprofv3 counter passes of tools/collect_profiles_r03.sh.  Workloads and shapes are bench.py's:
+
+  c2   Franka, 256 seeds x 4 candidates x 33 points, 4-cuboid world: the drop-in kernel sequence, the fused launch
+       (1024 and 256 trajectories), the optimiser's iteration tail (workgroup and wavefront form)
+  c3   UR10e, 512 x 4 x 33, 128^3 fp16 ESDF: FK, self, scene_collision_packed_kernel, FK VJP, the fused launch
+  c4   Unitree G1, 256 x 4 x 33: FK, self_collision_tiles_kernel, RNEA forward / backward, c-space cost, FK VJP
+  c5   Franka, 2 worlds (cuboids + 64^3 ESDF) x 512 x 4 x 65: the fused multi-env launch, the swept scene kernel
+
+Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [--reps N]
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B_  # noqa: E402  (the stage helpers of bench.py: rollout_self / rollout_scene / rollout_bwd_fk / _fk_fwd / _fk_bwd)
+
+dev = torch.device("cuda:0")
+REPS = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 5
+
+
+def run(fn, reps=None):
+    for _ in range(reps or REPS):
+        fn()
+    torch.cuda.synchronize()
+
+
+def collision_rollout(robot, scene_arrays, batch, **cfg_kw):
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import start_configuration
+
+    kcfg = KinematicsCfg.from_packaged(robot, device=dev)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    scene = SceneData.from_arrays(scene_arrays, dev) if scene_arrays is not None else None
+    out = []
+    for fused in (False, True):
+        ro = CollisionRollout(kin, scene, batch, CollisionRolloutCfg(use_fused=fused, **cfg_kw))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
+        out.append(ro)
+    return model, kin, out[0], out[1]
+
+
+def sequence_and_fused(model, seq, fused, seed, env_idx=None):
+    from curobo_amd.workloads import seed_knots
+
+    B = seq.batch_size
+    x = torch.as_tensor(seed_knots(model, B, seq.cfg.n_knots, seed=seed), device=dev).reshape(B, -1)
+    act = x.view(B, seq.cfg.n_knots, -1)
+    for ro in (seq, fused):
+        ro.update_env_query_idx(env_idx)
+    seq.evaluate_action(act)
+    seq.backward()
+    torch.cuda.synchronize()
+    run(lambda: seq.compute_state_from_action(act))
+    run(lambda: seq.compute_kinematics(seq.position))
+    run(lambda: B_.rollout_self(seq))
+    run(lambda: B_.rollout_scene(seq))
+    run(lambda: B_.rollout_bwd_fk(seq))
+    run(seq.backward)  # (FK VJP + B-spline VJP)
+    if fused.fused_available():
+        run(lambda: fused.cost_and_gradient(x))
+    return x
+
+
+def c2():
+    from curobo_amd.optim import LBFGSOpt, LBFGSOptCfg
+    from curobo_amd.rollout import CollisionRollout
+    from curobo_amd.scene import cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model, kin, seq, fused = collision_rollout("franka", cuboid_scene_arrays(c2_world()), 1024)
+    sequence_and_fused(model, seq, fused, 2)
+    small = CollisionRollout(kin, fused.scene, 256, fused.cfg)  # one seed shard of the default command
+    small.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
+    xs = torch.as_tensor(seed_knots(model, 256, 12, seed=2), device=dev).reshape(256, -1)
+    run(lambda: small.cost_and_gradient(xs))
+    bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+    for problems, ro, overlapped in ((256, fused, False), (64, small, False), (64, small, True)):
+        opt = LBFGSOpt(LBFGSOptCfg(num_problems=problems), ro.cost_and_gradient, 12, kin.num_dof, bounds, dev, use_cuda_graph=False)
+        opt.overlapped = overlapped
+        opt.reinitialize(torch.as_tensor(seed_knots(model, problems, 12, seed=2), device=dev))
+        run(opt._opt_step)
+
+
+def c3():
+    from curobo_amd.workloads import c3_voxel_world
+
+    model, kin, seq, fused = collision_rollout("ur10e", c3_voxel_world(), 2048)
+    sequence_and_fused(model, seq, fused, 4)
+
+
+def c4():
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("unitree_g1", device=dev)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    B, H = 1024, 33
+    D, S = kin.num_dof, kin.num_spheres
+    ro = TrajOptRollout(kin, None, B, TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=[200.0] * D))
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=6, spread=0.15), device=dev).reshape(B, -1)
+    run(lambda: ro.cost_and_gradient(x), 3)  # the whole launch set (every kernel of the C4 rollout)
+
+
+def c5():
+    from curobo_amd.workloads import c5_mixed_worlds
+
+    n_prob, seeds, nls = 2, 512, 4
+    B = n_prob * seeds * nls
+    env = torch.arange(n_prob, dtype=torch.int32, device=dev).repeat_interleave(seeds * nls)
+    model, kin, seq, fused = collision_rollout("franka", c5_mixed_worlds(n_prob, voxels=True), B, interpolation_steps=4)
+    sequence_and_fused(model, seq, fused, 8, env)
+
+
+if __name__ == "__main__":
+    want = [a for a in sys.argv[1:] if a in ("c2", "c3", "c4", "c5")] or ["c2", "c3", "c4", "c5"]
+    for w in want:
+        globals()[w]()
+    print("ran", want)
