@@ -86,6 +86,23 @@ def stage():
     assert a1 in s and a2 in s
     s = s.replace(a1, HOOK_FN.lstrip("\n") + "\n" + a1, 1).replace(a2, a2 + HOOK_SELECT, 1)
     open(init, "w").write(s)
+    # ---- the Warp side: `warp` = the pure-Python stand-in of tests/golden/warp_emulator + the device shim,
+    # `yourdfpy` = the xml.etree stand-in, the pytest plugin that installs the hooks of INTEGRATION.md at run time
+    stubs = os.path.join(STAGE, "_stubs")
+    src = os.path.join(ROOT, "tools", "refstage_stubs")
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "warp_emulator", "warp"), os.path.join(stubs, "warp"),
+                    ignore=shutil.ignore_patterns("__pycache__"))
+    with open(os.path.join(stubs, "warp", "__init__.py"), "a") as fh:
+        fh.write(open(os.path.join(src, "warp_device_shim.py")).read())
+    shutil.copytree(os.path.join(src, "yourdfpy"), os.path.join(stubs, "yourdfpy"))
+    for f in ("hip_hooks.py", "refstage_plugin.py"):
+        shutil.copy(os.path.join(src, f), os.path.join(stubs, f))
+    # robot assets: the URDFs (text) of the robots the tests load; meshes are not needed (collision spheres come from the yaml)
+    for robot in ("franka_description", "ur_description"):
+        a = os.path.join(REF, "content", "assets", "robot", robot)
+        if os.path.isdir(a):
+            shutil.copytree(a, os.path.join(STAGE, "curobo", "content", "assets", "robot", robot),
+                            ignore=lambda d, names: [n for n in names if os.path.isfile(os.path.join(d, n)) and not n.endswith((".urdf", ".xacro", ".yml"))])
     n = sum(len(f) for _, _, f in os.walk(STAGE))
     print(f"staged {n} files under {STAGE} (untracked scratch; `clean` removes it)")
 
@@ -114,6 +131,52 @@ def run_reference_tests(report):
         res[t] = {"rc": rc, "summary": summary.strip()}
         print(t, "->", res[t])
     report["reference_pytest"] = res
+
+
+WARP_SIDE_TESTS = [
+    "tests/_src/cost/test_cost_scene_collision.py",
+    "tests/_src/cost/test_cost_tool_pose.py",
+    "tests/_src/cost/test_cost_cspace.py",
+    "tests/_src/solver/test_solver_ik.py",
+    "tests/_src/solver/seed_ik/test_seed_ik_solver.py",
+    "tests/_src/rollout/test_rollout_robot.py",
+    "tests/_src/collision/test_collision_robot_scene.py",
+    "tests/_src/solver/test_solver_trajopt.py",
+    "tests/_src/robot/kinematics/test_kinematics.py",
+    "tests/_src/cost/test_cost_self_collision.py",
+]
+
+
+def run_warp_side_tests(report, tests=None):
+    """the reference's own tests of its Warp-backed costs and of the IK solver, on the MI355X: `warp` is the stand-in
+    (names + host emulation of set-up kernels), the hot-path autograd functions end in libcurobo_hip.so (hip_hooks.py)"""
+    env = dict(os.environ)
+    stubs = os.path.join(STAGE, "_stubs")
+    env["PYTHONPATH"] = os.pathsep.join([stubs, STAGE, ROOT, env.get("PYTHONPATH", "")])
+    res = {}
+    for t in tests or WARP_SIDE_TESTS:
+        path = os.path.join(STAGE, "curobo", t)
+        tag = t.replace("/", "_")
+        log = os.path.join(OUT, tag + ".log")
+        env["REFSTAGE_REPORT"] = os.path.join(OUT, tag + ".hooks.json")
+        cmd = [sys.executable, "-m", "pytest", path, "-q", "-p", "refstage_plugin", "-p", "no:cacheprovider", "--no-header", "-rf"] + (["-x"] if os.environ.get("REFSTAGE_X") else [])
+        try:
+            p = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=1500)
+            out, rc, stdout = p.stdout + "\n---- stderr ----\n" + p.stderr[-6000:], p.returncode, p.stdout
+        except subprocess.TimeoutExpired as e:
+            out, rc, stdout = f"TIMEOUT\n{e.stdout}", -9, str(e.stdout)
+        open(log, "w").write(out)
+        tail = [ln for ln in stdout.splitlines() if ln.strip()]
+        summary = next((ln for ln in reversed(tail) if " passed" in ln or " failed" in ln or " error" in ln), tail[-1] if tail else "")
+        failed = [ln[len("FAILED "):].split(" - ")[0] for ln in tail if ln.startswith("FAILED ")]
+        hooks = {}
+        try:
+            hooks = json.load(open(env["REFSTAGE_REPORT"]))
+        except (OSError, ValueError):
+            pass
+        res[t] = {"rc": rc, "summary": summary.strip("= "), "failed": failed, **hooks}
+        print(t, "->", res[t]["summary"], "| HIP entry points:", hooks.get("hip_entry_points_reached"))
+    report["reference_warp_side_pytest"] = res
 
 
 def compare_wrappers(report):
@@ -221,7 +284,12 @@ def run():
     if not os.path.isdir(os.path.join(STAGE, "curobo")):
         raise SystemExit(".refstage/ is missing: run `python tools/reference_on_hip.py stage` in the container first")
     report = {"what": "the reference's unmodified Python callers over curobo_amd.backends (libcurobo_hip.so) on MI355X"}
+    if "warp" in sys.argv[2:]:  # only the Warp-side part (iterating on the hooks)
+        run_warp_side_tests(report, [a for a in sys.argv[3:] if a.endswith(".py")] or None)
+        json.dump(report, open(os.path.join(OUT, "report_warp_side.json"), "w"), indent=1)
+        return
     run_reference_tests(report)
+    run_warp_side_tests(report)
     try:
         compare_wrappers(report)
     except Exception as e:  # noqa: BLE001
