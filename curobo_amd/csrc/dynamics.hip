@@ -15,6 +15,7 @@
 // [link][20][batch].  The adjoints live in a caller-provided workspace [link][18][batch].
 // Robot constants are staged once per workgroup in LDS; any tree shape / link count works with
 // one compiled kernel (links are visited in level_links order, parents before children).
+#include <cstdlib>
 #include "dynamics_device.hpp"
 
 namespace curobo_hip {
@@ -43,9 +44,91 @@ __global__ void __launch_bounds__(256) rnea_backward_kernel(const RneaArgs a) {
   rnea_backward_element<HAS_FEXT>(a, s_f, s_i, s_i + L * 3, b, B);
 }
 
+// ---- the same walks with the element's joint-space vectors staged through LDS (RneaStagedIO): one wavefront of 64
+// elements per workgroup; q / qd / qdd (grad_tau) arrive with coalesced loads (the outputs are written as before).  The walk itself is unchanged (same device functions, same arithmetic order: results are bit-identical
+// to the unstaged kernels); what goes away are the per-link gathers of 64 scattered rows.
+constexpr int kStagedLanes = 64;
+
+__device__ __forceinline__ void stage_in(float *dst, const float *src, size_t b0, int n_here, int D) {
+  const float *g = src + b0 * (size_t)D;
+  for (int i = threadIdx.x; i < n_here * D; i += kStagedLanes) {
+    const int e = i / D, j = i - e * D;
+    dst[j * kRneaStageStride + e] = g[i];
+  }
+}
+
+template <bool HAS_FEXT>
+__global__ void __launch_bounds__(kStagedLanes) rnea_forward_staged_kernel(const RneaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.num_links, D = a.num_dof;
+  float *s_f = smem;
+  int *s_i = reinterpret_cast<int *>(smem + L * kLinkFloats);
+  float *st = smem + L * (kLinkFloats + 4);
+  const size_t B = (size_t)a.batch, b0 = (size_t)blockIdx.x * kStagedLanes;
+  const int n_here = (int)(B - b0 < (size_t)kStagedLanes ? B - b0 : (size_t)kStagedLanes);
+  const int sz = D * kRneaStageStride;
+  stage_in(st, a.q, b0, n_here, D);
+  stage_in(st + sz, a.qd, b0, n_here, D);
+  stage_in(st + 2 * sz, a.qdd, b0, n_here, D);
+  stage_links(a, s_f, s_i);  // (ends with the workgroup barrier)
+  if ((int)threadIdx.x < n_here) {
+    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + threadIdx.x), (int)threadIdx.x};
+    rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b0 + threadIdx.x, B);
+  }
+}
+
+template <bool HAS_FEXT>
+__global__ void __launch_bounds__(kStagedLanes) rnea_backward_staged_kernel(const RneaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.num_links, D = a.num_dof;
+  float *s_f = smem;
+  int *s_i = reinterpret_cast<int *>(smem + L * kLinkFloats);
+  float *st = smem + L * (kLinkFloats + 4);
+  const size_t B = (size_t)a.batch, b0 = (size_t)blockIdx.x * kStagedLanes;
+  const int n_here = (int)(B - b0 < (size_t)kStagedLanes ? B - b0 : (size_t)kStagedLanes);
+  const int sz = D * kRneaStageStride;
+  stage_in(st, a.q, b0, n_here, D);
+  stage_in(st + sz, a.qd, b0, n_here, D);
+  stage_in(st + 2 * sz, a.grad_tau, b0, n_here, D);
+  stage_links(a, s_f, s_i);
+  if ((int)threadIdx.x < n_here) {
+    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + threadIdx.x), (int)threadIdx.x};
+    rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b0 + threadIdx.x, B);
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
+
+// LDS of the staged kernels: link constants + three joint-space input vectors [dof][65]
+static size_t rnea_staged_lds(int num_links, int num_dof, int vectors) {
+  return ((size_t)num_links * (kLinkFloats + 4) + (size_t)vectors * num_dof * kRneaStageStride) * sizeof(float);
+}
+constexpr size_t kRneaStagedLdsLimit = 80 * 1024;  // two workgroups per CU
+
+template <class K>
+static int raise_lds(K kfn, size_t lds, const char *what) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(e));
+  }
+  return CUROBO_HIP_OK;
+}
+
+// elements per workgroup (= active lanes of its one wavefront below 64): EXPERIMENT knob CUROBO_RNEA_LANES
+static int rnea_block(int batch_size) {
+  static int forced = -1;
+  if (forced < 0) { const char *e = getenv("CUROBO_RNEA_LANES"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
+  return batch_size <= 128 * 1024 ? 64 : 256;
+}
+
+static bool rnea_staged() {  // EXPERIMENT knob: CUROBO_RNEA_STAGED=0 runs the unstaged kernels
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("CUROBO_RNEA_STAGED"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 
 static size_t rnea_lds(int num_links) { return (size_t)num_links * (kLinkFloats + 4) * sizeof(float); }
 
@@ -69,7 +152,19 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   hipStream_t st = (hipStream_t)stream;
   // one element per lane and a strictly serial walk: the launch is latency bound, so small batches are spread one
   // wavefront per workgroup over as many CUs as possible
-  const int bt = batch_size <= 128 * 1024 ? 64 : 256;
+  const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
+  if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
+    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(kStagedLanes);
+    if (f_ext) {
+      if (int rc = raise_lds(rnea_forward_staged_kernel<true>, slds, what)) return rc;
+      hipLaunchKernelGGL((rnea_forward_staged_kernel<true>), grid, block, slds, st, a);
+    } else {
+      if (int rc = raise_lds(rnea_forward_staged_kernel<false>, slds, what)) return rc;
+      hipLaunchKernelGGL((rnea_forward_staged_kernel<false>), grid, block, slds, st, a);
+    }
+    return check_launch(what, st);
+  }
+  const int bt = rnea_block(batch_size);
   const dim3 grid((unsigned)ceil_div(batch_size, bt)), block(bt);
   if (f_ext) hipLaunchKernelGGL((rnea_forward_kernel<true>), grid, block, rnea_lds(num_links), st, a);
   else hipLaunchKernelGGL((rnea_forward_kernel<false>), grid, block, rnea_lds(num_links), st, a);
@@ -100,7 +195,19 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   a.ws_vbar = workspace + (size_t)num_links * 12 * batch_size;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
-  const int bt = batch_size <= 128 * 1024 ? 64 : 256;
+  const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
+  if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
+    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(kStagedLanes);
+    if (grad_f_ext) {
+      if (int rc = raise_lds(rnea_backward_staged_kernel<true>, slds, what)) return rc;
+      hipLaunchKernelGGL((rnea_backward_staged_kernel<true>), grid, block, slds, st, a);
+    } else {
+      if (int rc = raise_lds(rnea_backward_staged_kernel<false>, slds, what)) return rc;
+      hipLaunchKernelGGL((rnea_backward_staged_kernel<false>), grid, block, slds, st, a);
+    }
+    return check_launch(what, st);
+  }
+  const int bt = rnea_block(batch_size);
   const dim3 grid((unsigned)ceil_div(batch_size, bt)), block(bt);
   if (grad_f_ext) hipLaunchKernelGGL((rnea_backward_kernel<true>), grid, block, rnea_lds(num_links), st, a);
   else hipLaunchKernelGGL((rnea_backward_kernel<false>), grid, block, rnea_lds(num_links), st, a);

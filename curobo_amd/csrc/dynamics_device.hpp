@@ -65,7 +65,27 @@ __device__ __forceinline__ void stage_links(const RneaArgs &a, float *s_f, int *
   }
   for (int k = threadIdx.x; k < L; k += blockDim.x) s_i[L * 3 + k] = a.level_links[k];
   __syncthreads();
+  // Bit 16 of an order entry: the link needs its accumulator slot in memory.  In the leaves -> root sweeps a link hands its
+  // contribution to its parent in registers when the parent is the next link of the walk; only a parent with a child
+  // elsewhere in the order (a branch point of the tree) receives contributions through memory.  Every other link neither
+  // zeroes nor re-reads the slot (a third of the cache traffic of the forward kernel on a humanoid).
+  int *order = s_i + L * 3;
+  int flag[4] = {0, 0, 0, 0};  // (L <= 4 * blockDim.x: checked by the callers' LDS limits, 64-thread blocks walk <= 256 links)
+  int n = 0;
+  for (int idx = threadIdx.x; idx < L && n < 4; idx += blockDim.x, n++) {
+    const int k = order[idx];
+    for (int p = 0; p < L; p++) {
+      const int c = order[p];
+      if (c != k && s_i[c * 3 + 2] == k && p != idx + 1) flag[n] = 1;
+    }
+  }
+  __syncthreads();
+  n = 0;
+  for (int idx = threadIdx.x; idx < L && n < 4; idx += blockDim.x, n++) order[idx] |= flag[n] << 16;
+  __syncthreads();
 }
+__device__ __forceinline__ int order_link(int e) { return e & 0xffff; }
+__device__ __forceinline__ bool order_needs_slot(int e) { return (e >> 16) != 0; }
 
 struct Sv {  // spatial vector [angular; linear]
   f3 w, v;
@@ -158,13 +178,65 @@ __device__ __forceinline__ void store_sv(float *base, size_t B, int slot, size_t
   p[0] = s.w.x; p[B] = s.w.y; p[2 * B] = s.w.z; p[3 * B] = s.v.x; p[4 * B] = s.v.y; p[5 * B] = s.v.z;
 }
 
+// Where an element's joint-space vectors live.  RneaGlobalIO: the caller's row-major [batch, dof] tensors, element b at
+// b * D (a wavefront's access is a gather of 64 rows: one cache line per lane).  RneaStagedIO: copies in LDS, [joint][65]
+// with the element (= lane) fastest, staged in and out by the kernel with coalesced transfers -- the walk then issues no
+// uncoalesced global access at all (dynamics.hip; measured on the Unitree G1 at the C4 size: those gathers were 60 % of the
+// L2 traffic of both kernels).
+struct RneaGlobalIO {
+  const RneaArgs &a;
+  size_t o;  // b * D
+  __device__ __forceinline__ RneaGlobalIO(const RneaArgs &a_, size_t b) : a(a_), o(b * (size_t)a_.num_dof) {}
+  __device__ __forceinline__ float q(int j) const { return a.q[o + j]; }
+  __device__ __forceinline__ float qd(int j) const { return a.qd[o + j]; }
+  __device__ __forceinline__ float qdd(int j) const { return a.qdd[o + j]; }
+  __device__ __forceinline__ float grad_tau(int j) const { return a.grad_tau[o + j]; }
+  __device__ __forceinline__ void tau_zero(int D) const { for (int j = 0; j < D; j++) a.tau[o + j] = 0.0f; }
+  __device__ __forceinline__ void tau_add(int j, float x) const { a.tau[o + j] += x; }
+  __device__ __forceinline__ void grads_zero(int D) const {
+    for (int j = 0; j < D; j++) { a.grad_q[o + j] = 0.0f; a.grad_qd[o + j] = 0.0f; a.grad_qdd[o + j] = 0.0f; }
+  }
+  __device__ __forceinline__ void grad_q_add(int j, float x) const { a.grad_q[o + j] += x; }
+  __device__ __forceinline__ void grad_qd_add(int j, float x) const { a.grad_qd[o + j] += x; }
+  __device__ __forceinline__ void grad_qdd_add(int j, float x) const { a.grad_qdd[o + j] += x; }
+};
+
+constexpr int kRneaStageStride = 65;  // [joint][65]: lane e of joint j sits in bank (j + e) mod 32
+struct RneaStagedIO {
+  // INPUTS from LDS (read-only during the walk): forward in0 = q, in1 = qd, in2 = qdd; backward in0 = q, in1 = qd,
+  // in2 = grad_tau.  OUTPUTS go to the caller's tensors as in RneaGlobalIO: their read-modify-writes are off the walk's
+  // dependent chain, and LDS stores in the walk would alias the link constants (both LDS: the compiler then re-reads the
+  // constants after every store -- measured: the forward kernel 50 % slower).
+  const float *in0, *in1, *in2;
+  RneaGlobalIO out;
+  int e;  // element of the workgroup = lane
+  __device__ __forceinline__ float q(int j) const { return in0[j * kRneaStageStride + e]; }
+  __device__ __forceinline__ float qd(int j) const { return in1[j * kRneaStageStride + e]; }
+  __device__ __forceinline__ float qdd(int j) const { return in2[j * kRneaStageStride + e]; }
+  __device__ __forceinline__ float grad_tau(int j) const { return in2[j * kRneaStageStride + e]; }
+  __device__ __forceinline__ void tau_zero(int D) const { out.tau_zero(D); }
+  __device__ __forceinline__ void tau_add(int j, float x) const { out.tau_add(j, x); }
+  __device__ __forceinline__ void grads_zero(int D) const { out.grads_zero(D); }
+  __device__ __forceinline__ void grad_q_add(int j, float x) const { out.grad_q_add(j, x); }
+  __device__ __forceinline__ void grad_qd_add(int j, float x) const { out.grad_qd_add(j, x); }
+  __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out.grad_qdd_add(j, x); }
+};
+
 // One element b of a batch of B (SoA slots with element stride B): the forward sweeps.  `order` = links in level order.
+template <bool HAS_FEXT, class IO>
+__device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
+                                                        const int *order, size_t b, size_t B);
 template <bool HAS_FEXT>
 __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
                                                      size_t b, size_t B) {
+  rnea_forward_element_io<HAS_FEXT>(a, RneaGlobalIO(a, b), s_f, s_i, order, b, B);
+}
+template <bool HAS_FEXT, class IO>
+__device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
+                                                        const int *order, size_t b, size_t B) {
   const int L = a.num_links, D = a.num_dof;
   const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
-  for (int j = 0; j < D; j++) a.tau[b * D + j] = 0.0f;
+  io.tau_zero(D);
   // sweep 1, root -> leaves: velocities and accelerations (rnea_forward_kernel.cuh:118-188)
   // The walk is a chain of dependent steps whose operands travel through the cache (HBM / L2: a round trip per link).
   // When the links come in depth-first order the parent of a link is mostly the link just processed: its state is then
@@ -173,14 +245,14 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
   int prev_k = -1;
   Sv prev_v = sv_zero(), prev_a = sv_zero();
   for (int idx = 0; idx < L; idx++) {
-    const int k = order[idx];
+    const int k = order_link(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     float qe = 0.f, qde = 0.f, qdde = 0.f;
     if (moving) {
-      qe = c.mul * a.q[b * D + c.ji] + c.off;
-      qde = c.mul * a.qd[b * D + c.ji];
-      qdde = c.mul * a.qdd[b * D + c.ji];
+      qe = c.mul * io.q(c.ji) + c.off;
+      qde = c.mul * io.qd(c.ji);
+      qdde = c.mul * io.qdd(c.ji);
     }
     const Rp t = local_Rp(c.F, c.jt, qe);
     Sv v = sv_zero(), acc;
@@ -201,7 +273,7 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
     }
     store_sv(a.cache, B, k * 20, b, v);
     store_sv(a.cache, B, k * 20 + 6, b, acc);
-    store_sv(a.cache, B, k * 20 + 12, b, sv_zero());  // children accumulate their X^T f here
+    if (order_needs_slot(order[idx])) store_sv(a.cache, B, k * 20 + 12, b, sv_zero());  // children accumulate their X^T f here
     prev_k = k; prev_v = v; prev_a = acc;
   }
   // sweep 2, leaves -> root: f = I a + v x* I v (- f_ext) + children; tau = S^T f (:190-283)
@@ -210,7 +282,7 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
   int pend_par = -1;
   Sv pend = sv_zero();
   for (int idx = L - 1; idx >= 0; idx--) {
-    const int k = order[idx];
+    const int k = order_link(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const Sv v = load_sv(a.cache, B, k * 20, b), acc = load_sv(a.cache, B, k * 20 + 6, b);
     Sv f = inertia_mul(c.mc, c.in, acc) + crf(v, inertia_mul(c.mc, c.in, v));
@@ -218,48 +290,59 @@ __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const fl
       const float *fe = a.f_ext + (b * L + k) * 6;
       f = f - Sv{make_f3(fe[0], fe[1], fe[2]), make_f3(fe[3], fe[4], fe[5])};
     }
-    f = f + load_sv(a.cache, B, k * 20 + 12, b);
+    if (order_needs_slot(order[idx])) f = f + load_sv(a.cache, B, k * 20 + 12, b);
+    else f = f + sv_zero();  // (-0 + 0 = +0, as the stored zero gave)
     if (pend_par == k) f = f + pend;
     pend_par = -1;
     store_sv(a.cache, B, k * 20 + 12, b, f);
     const bool moving = c.jt != J_FIXED && c.ji >= 0;
-    if (moving) a.tau[b * D + c.ji] += c.mul * sv_get(f, s_index(c.jt));
+    if (moving) io.tau_add(c.ji, c.mul * sv_get(f, s_index(c.jt)));
     if (!(c.par < 0 || c.par == k)) {
-      const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+      const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
       const Sv up = XT_force(local_Rp(c.F, c.jt, qe), f);
-      if (idx > 0 && order[idx - 1] == c.par) { pend = up; pend_par = c.par; }
+      if (idx > 0 && order_link(order[idx - 1]) == c.par) { pend = up; pend_par = c.par; }
       else store_sv(a.cache, B, c.par * 20 + 12, b, load_sv(a.cache, B, c.par * 20 + 12, b) + up);
     }
   }
 }
 
 // ... and the VJP.  ACCUMULATE: add to grad_q / grad_qd / grad_qdd instead of overwriting them.
+template <bool HAS_FEXT, bool ACCUMULATE, class IO>
+__device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
+                                                         const int *order, size_t b, size_t B);
 template <bool HAS_FEXT, bool ACCUMULATE = false>
 __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
                                                       size_t b, size_t B) {
+  rnea_backward_element_io<HAS_FEXT, ACCUMULATE>(a, RneaGlobalIO(a, b), s_f, s_i, order, b, B);
+}
+template <bool HAS_FEXT, bool ACCUMULATE, class IO>
+__device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
+                                                         const int *order, size_t b, size_t B) {
   const int L = a.num_links, D = a.num_dof;
   const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
-  if (!ACCUMULATE)
-    for (int j = 0; j < D; j++) { a.grad_q[b * D + j] = 0.0f; a.grad_qd[b * D + j] = 0.0f; a.grad_qdd[b * D + j] = 0.0f; }
+  if (!ACCUMULATE) io.grads_zero(D);
   // pass 1, root -> leaves: adjoint of the force propagation (rnea_backward_kernel.cuh:151-208)
   int prev_k = -1;
   Sv prev_fb = sv_zero();
   for (int idx = 0; idx < L; idx++) {
-    const int k = order[idx];
+    const int k = order_link(order[idx]);
+    const bool slot = order_needs_slot(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     Sv fb = sv_zero();
     const int si = moving ? s_index(c.jt) : 0;
-    if (moving) sv_add_at(fb, si, c.mul * a.grad_tau[b * D + c.ji]);
+    if (moving) sv_add_at(fb, si, c.mul * io.grad_tau(c.ji));
     if (!is_root) {
-      const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+      const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
       const Sv X = X_motion(local_Rp(c.F, c.jt, qe), c.par == prev_k ? prev_fb : load_sv(a.ws_fbar, B, c.par * 6, b));
       fb = fb + X;
-      if (moving) a.grad_q[b * D + c.ji] += c.mul * sv_dot(X, crf(sv_unit(si, 1.0f), load_sv(a.cache, B, k * 20 + 12, b)));
+      if (moving) io.grad_q_add(c.ji, c.mul * sv_dot(X, crf(sv_unit(si, 1.0f), load_sv(a.cache, B, k * 20 + 12, b))));
     }
     store_sv(a.ws_fbar, B, k * 6, b, fb);
-    store_sv(a.ws_abar, B, k * 6, b, sv_zero());
-    store_sv(a.ws_vbar, B, k * 6, b, sv_zero());
+    if (slot) {
+      store_sv(a.ws_abar, B, k * 6, b, sv_zero());
+      store_sv(a.ws_vbar, B, k * 6, b, sv_zero());
+    }
     prev_k = k; prev_fb = fb;
     if (HAS_FEXT) {
       float *g = a.grad_f_ext + (b * L + k) * 6;
@@ -270,25 +353,31 @@ __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const f
   int pend_par = -1;
   Sv pend_a = sv_zero(), pend_v = sv_zero();
   for (int idx = L - 1; idx >= 0; idx--) {
-    const int k = order[idx];
+    const int k = order_link(order[idx]);
+    const bool slot = order_needs_slot(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
-    const bool par_next = !is_root && idx > 0 && order[idx - 1] == c.par;  // this link's pushes stay in registers
+    const bool par_next = !is_root && idx > 0 && order_link(order[idx - 1]) == c.par;  // this link's pushes stay in registers
     const Sv v = load_sv(a.cache, B, k * 20, b);
     const Sv fb = load_sv(a.ws_fbar, B, k * 6, b);
-    Sv ab = load_sv(a.ws_abar, B, k * 6, b) + inertia_mul(c.mc, c.in, fb);
-    Sv vb = load_sv(a.ws_vbar, B, k * 6, b) - crf(fb, inertia_mul(c.mc, c.in, v)) - inertia_mul(c.mc, c.in, crm(v, fb));
+    Sv ab = sv_zero(), vb = sv_zero();  // (what a link without children elsewhere would read back from its slot)
+    if (slot) {
+      ab = load_sv(a.ws_abar, B, k * 6, b);
+      vb = load_sv(a.ws_vbar, B, k * 6, b);
+    }
+    ab = ab + inertia_mul(c.mc, c.in, fb);
+    vb = vb - crf(fb, inertia_mul(c.mc, c.in, v)) - inertia_mul(c.mc, c.in, crm(v, fb));
     if (pend_par == k) { ab = ab + pend_a; vb = vb + pend_v; }
     pend_par = -1;
     const int si = moving ? s_index(c.jt) : 0;
     float gq = 0.0f, gqd = 0.0f;
     if (moving) {
-      const float qdk = c.mul * a.qd[b * D + c.ji];
-      a.grad_qdd[b * D + c.ji] += c.mul * sv_get(ab, si);
+      const float qdk = c.mul * io.qd(c.ji);
+      io.grad_qdd_add(c.ji, c.mul * sv_get(ab, si));
       gqd -= c.mul * sv_get(crf(v, ab), si);
       vb = vb + crf(sv_unit(si, qdk), ab);
     }
-    const float qe = moving ? c.mul * a.q[b * D + c.ji] + c.off : 0.0f;
+    const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
     const Rp t = local_Rp(c.F, c.jt, qe);
     const Sv S1 = sv_unit(si, 1.0f);
     if (!is_root) {
@@ -308,8 +397,8 @@ __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const f
       if (moving) gq -= c.mul * sv_dot(vb, crm(S1, X_motion(t, load_sv(a.cache, B, c.par * 20, b))));
     }
     if (moving) {
-      a.grad_q[b * D + c.ji] += gq;
-      a.grad_qd[b * D + c.ji] += gqd;
+      io.grad_q_add(c.ji, gq);
+      io.grad_qd_add(c.ji, gqd);
     }
   }
 }
