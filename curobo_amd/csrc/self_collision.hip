@@ -513,6 +513,226 @@ __global__ void __launch_bounds__(256) self_collision_tiles_kernel(const SelfTil
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// TWO-LEVEL broad phase.  Measured on the Unitree G1 (tools: broad-phase statistics in DESIGN.md): of the 763 tiles of
+// 16 x 16 pairs that hold listed pairs ~100 survive the block-box test -- 25.7 k pair tests per point -- but only ~29 listed
+// pairs really penetrate.  Boxes of FOUR consecutive spheres are four times tighter: testing the 16 sub-tiles of every
+// surviving tile against them leaves ~260 sub-tiles of 4 x 4 = 4.2 k pair tests per point.  The sub-tile boxes cost
+// nothing extra (the second step of the 16-lane DPP maximum is the 4-lane maximum).  Narrow phase: the surviving sub-tiles
+// are compacted, four per round, lane (t, pi, pj) tests ONE pair (i = 4 ib4 + pi, j = 4 jb4 + pj) with its bit of the pair
+// bitmap; arg-max with the list's tie rule, (i, j) lexicographic.  Same pair_pen as the one-level kernel: same values.
+constexpr int kT2Waves = 4;   // wavefronts that share one point (its spheres and boxes in LDS)
+constexpr int kT2Ring = 512;  // sub-tiles a wavefront collects before it runs its narrow phase (a trip of four rounds adds <= 256)
+__host__ __device__ inline size_t tiles2_kept_cap(int n_tiles) { return (size_t)((n_tiles + kT2Waves * 64 - 1) / (kT2Waves * 64)) * 64; }
+__host__ __device__ inline size_t tiles2_lds_floats(int nslots, int n_tiles) {
+  const size_t SL = (size_t)nslots * 64;
+  return SL * 4 + (SL / kTile) * 8 + (SL / 4) * 8 + kT2Waves * (tiles2_kept_cap(n_tiles) + kT2Ring) + 2 * kT2Waves;
+}
+
+// One POINT per workgroup of four wavefronts.  A wavefront per point is latency bound (a dependent chain of LDS and
+// L2 round trips) and a CU only holds as many points as their spheres fit in its LDS (G1: 6-9): the SIMDs idle.  Four
+// wavefronts that share the point's staged spheres and boxes split the staging, the tile list and the narrow phase, so a CU
+// holds the same number of points with four times the wavefronts, and a point takes a quarter of the time.
+__global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(const SelfTilesArgs t) {
+  const SelfDenseArgs &a = t.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.nspheres, NS = a.nslots, SL = NS * 64, NB = SL / kTile, NB4 = SL / 4;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int kept_cap = (int)tiles2_kept_cap(t.n_tiles);
+  float4 *sph = reinterpret_cast<float4 *>(smem);
+  float *box = reinterpret_cast<float *>(sph + SL);       // [NB][8]: lo xyz, -, hi xyz, -
+  float *box4 = box + NB * 8;                             // [NB4][8]
+  int *kept = reinterpret_cast<int *>(box4 + NB4 * 8) + wave * (kept_cap + kT2Ring);  // this wavefront's surviving 16 x 16 tiles
+  int *ring = kept + kept_cap;                            // ... and its surviving 4 x 4 sub-tiles
+  float *red = box4 + NB4 * 8 + kT2Waves * (kept_cap + kT2Ring);  // [kT2Waves] (penetration, key) per wavefront
+  const int n = blockIdx.x;
+  const float qnan = __builtin_nanf("");
+  const int row = lane >> 4, li = lane & 15;
+  // this wavefront's tiles of the level-1 list: requested now, used after the staging (the list is 3 KB: L2)
+  constexpr int kMaxTileTrips = 8;  // <= 8 * 256 = 2048 listed tiles (64 x 64 blocks of 16 spheres hold 2080)
+  int my_tiles[kMaxTileTrips];
+#pragma unroll
+  for (int u = 0; u < kMaxTileTrips; u++) {
+    const int c = (u * kT2Waves + wave) * kWave + lane;
+    my_tiles[u] = c < t.n_tiles ? t.tiles[c] : -1;
+  }
+  {  // spheres (+ padding) -> LDS, stale gradient rows cleared, boxes of 4 and of 16 consecutive spheres on the way
+    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
+    constexpr int kMaxSlots = 4;  // nslots <= 16, four wavefronts
+    float4 sv[kMaxSlots];
+    float off[kMaxSlots];
+    uint8_t dirty[kMaxSlots];
+#pragma unroll
+    for (int u = 0; u < kMaxSlots; u++) {  // every load of the wavefront in flight before the first use
+      const int s = (u * kT2Waves + wave) * 64 + lane;
+      const bool in = u * kT2Waves + wave < NS && s < S;
+      sv[u] = in ? src[s] : make_float4(0.f, 0.f, 0.f, qnan);
+      off[u] = in ? a.offsets[s] : 0.0f;
+      dirty[u] = in ? a.sparse_index[(size_t)n * S + s] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxSlots; u++) {
+      const int sl = u * kT2Waves + wave;
+      if (sl >= NS) break;
+      const int s = sl * 64 + lane;
+      float4 v = sv[u];
+      if (s < S) {
+        v.w += off[u];
+        if (!(v.w >= 0.0f)) v.w = qnan;
+        if (dirty[u]) {
+          reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a.sparse_index[(size_t)n * S + s] = 0;
+        }
+      }
+      sph[s] = v;
+      const bool on = v.w == v.w;  // disabled / padding spheres: an empty box
+      const float big = 3.0e38f;
+      float e[6] = {on ? v.w - v.x : -big, on ? v.w - v.y : -big, on ? v.w - v.z : -big,
+                    on ? v.x + v.w : -big, on ? v.y + v.w : -big, on ? v.z + v.w : -big};
+#pragma unroll
+      for (int c = 0; c < 6; c++) {  // quad maximum, then the row's
+        e[c] = fmaxf(e[c], dpp_f<0xB1>(e[c]));
+        e[c] = fmaxf(e[c], dpp_f<0x4E>(e[c]));
+      }
+      if ((lane & 3) == 0) {
+        float *b = box4 + (size_t)(s >> 2) * 8;
+        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[4] = e[3]; b[5] = e[4]; b[6] = e[5];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        e[c] = fmaxf(e[c], dpp_f<0x141>(e[c]));
+        e[c] = fmaxf(e[c], dpp_f<0x140>(e[c]));
+      }
+      if (li == 0) {
+        float *b = box + (sl * 4 + row) * 8;
+        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[4] = e[3]; b[5] = e[4]; b[6] = e[5];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- level 1: this wavefront's share of the tiles whose block boxes overlap, compacted in list order
+  int count = 0;
+#pragma unroll
+  for (int u = 0; u < kMaxTileTrips; u++) {
+    if ((u * kT2Waves + wave) * kWave >= t.n_tiles) break;
+    const int tl = my_tiles[u];
+    bool keep = false;
+    if (tl >= 0) {
+      const float *bi = box + (tl & 0xff) * 8, *bj = box + (tl >> 8) * 8;
+      keep = bi[0] <= bj[4] && bj[0] <= bi[4] && bi[1] <= bj[5] && bj[1] <= bi[5] && bi[2] <= bj[6] && bj[2] <= bi[6];
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) kept[count + __popcll(m & ((1ull << lane) - 1ull))] = tl;
+    count += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- level 2: four tiles = 64 sub-tiles per round, one per lane.  A surviving sub-tile fetches its 16 bits of the pair
+  // bitmap (one 16-byte load: the words of its four spheres i) -- sub-tiles without a listed pair drop out here and the
+  // narrow phase needs no memory access besides LDS.  Ring entry: ib4 | jb4 << 8 | bits << 16.
+  float bv = 0.0f;
+  int bkey = 0x7fffffff;
+  int n4 = 0;  // sub-tiles in the ring (uniform)
+  const int sub_t = lane >> 4, pi = (lane >> 2) & 3, pj = lane & 3;
+  auto narrow = [&](int first) {  // ring entries first .. first + 3 (entries beyond n4 are skipped by `has`)
+    const bool has = first + sub_t < n4;
+    const uint32_t e = (uint32_t)ring[has ? first + sub_t : 0];
+    const int i = (int)(e & 0xffu) * 4 + pi, j = (int)((e >> 8) & 0xffu) * 4 + pj;
+    const float v = mask_f(pair_pen(sph[i], sph[j]), has ? e : 0u, 16 + pi * 4 + pj);
+    const int key = (i << 10) | j;
+    if (v > 0.0f && (v > bv || (v == bv && key < bkey))) { bv = v; bkey = key; }
+  };
+  auto drain = [&](bool all) {  // the narrow phase over the ring; `all`: also the last, incomplete group
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int first = 0;
+    for (; first + 16 <= n4; first += 16) {  // four independent groups per trip: their LDS reads go out together
+      narrow(first); narrow(first + 4); narrow(first + 8); narrow(first + 12);
+    }
+    for (; first + 4 <= n4; first += 4) narrow(first);
+    if (all && first < n4) { narrow(first); first = n4; }
+    const int left = n4 - first;
+    int keep_e = 0;
+    if (left > 0 && first > 0) {  // move the < 4 leftovers to the front
+      if (lane < left) keep_e = ring[first + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < left) ring[lane] = keep_e;
+    }
+    n4 = left;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  constexpr int kRounds = 4;  // rounds per trip: their bitmap loads are in flight together
+  for (int t0 = 0; t0 < count; t0 += 4 * kRounds) {
+    bool keep[kRounds];
+    int ib4[kRounds], jb4[kRounds];
+    uint4 w[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      const int ti = t0 + r * 4 + sub_t;
+      const bool has = ti < count;
+      const int tl = kept[has ? ti : 0];
+      ib4[r] = (tl & 0xff) * 4 + pi;
+      jb4[r] = (tl >> 8) * 4 + pj;
+      const float *bi = box4 + (size_t)ib4[r] * 8, *bj = box4 + (size_t)jb4[r] * 8;
+      // (the diagonal tiles list pairs i < j only: a sub-tile strictly below the diagonal holds none of them)
+      keep[r] = has && ib4[r] <= jb4[r] && bi[0] <= bj[4] && bj[0] <= bi[4] && bi[1] <= bj[5] && bj[1] <= bi[5] &&
+                bi[2] <= bj[6] && bj[2] <= bi[6];
+      // bit (jb4 * 4 + pj') & 31 of bitmap[(jb4 * 4) >> 5][ib4 * 4 + pi'] for the 4 x 4 pairs of the sub-tile
+      w[r] = keep[r] ? *reinterpret_cast<const uint4 *>(a.bitmap + (size_t)(jb4[r] >> 3) * SL + ib4[r] * 4) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      const int sh = (jb4[r] & 7) * 4;
+      const uint32_t bits = ((w[r].x >> sh) & 0xfu) | (((w[r].y >> sh) & 0xfu) << 4) | (((w[r].z >> sh) & 0xfu) << 8) |
+                            (((w[r].w >> sh) & 0xfu) << 12);
+      const bool k2 = keep[r] && bits != 0u;
+      const unsigned long long m = __ballot(k2);
+      if (k2) ring[n4 + __popcll(m & ((1ull << lane) - 1ull))] = (int)((uint32_t)ib4[r] | ((uint32_t)jb4[r] << 8) | (bits << 16));
+      n4 += __popcll(m);
+    }
+    if (n4 + 64 * kRounds > kT2Ring) drain(false);
+  }
+  drain(true);
+  // ---- arg-max: largest penetration, then the lexicographically first (i, j); over the wavefront, then over the four
+  float m = bv;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  int key = (m > 0.0f && bv == m) ? bkey : 0x7fffffff;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, kWave));
+  if (lane == 0) {
+    red[wave * 2] = m;
+    reinterpret_cast<int *>(red)[wave * 2 + 1] = key;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  m = 0.0f;
+  key = 0x7fffffff;
+  for (int w = 0; w < kT2Waves; w++) {
+    const float mw = red[w * 2];
+    const int kw = reinterpret_cast<const int *>(red)[w * 2 + 1];
+    if (mw > m || (mw == m && kw < key)) { m = mw; key = kw; }
+  }
+  if (!(m > 0.0f) || key == 0x7fffffff) {
+    a.out_distance[n] = 0.0f;
+    return;
+  }
+  const float wgt = a.weight[0];
+  a.out_distance[n] = 0.5f * wgt * m;
+  if (a.write_grad) {
+    const int i = key >> 10, j = key & 1023;
+    const float4 s1 = sph[i], s2 = sph[j];
+    const float vx = wgt * (s2.x - s1.x), vy = wgt * (s2.y - s1.y), vz = wgt * (s2.z - s1.z);
+    float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
+    g[i] = make_float4(vx, vy, vz, wgt * -1.0f);
+    g[j] = make_float4(-1.0f * vx, -1.0f * vy, -1.0f * vz, wgt * -1.0f);
+    a.sparse_index[(size_t)n * S + i] = 1;
+    a.sparse_index[(size_t)n * S + j] = 1;
+  }
+}
+
 template <int NWAVES>
 static void launch_self(const SelfCollArgs &a, int blocks, size_t lds, int ppw, int tile, hipStream_t st) {
   if (a.store_pair_distance)
@@ -589,17 +809,25 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
   hipStream_t st = (hipStream_t)stream;
   static const bool no_tiles = getenv("CUROBO_HIP_SELF_NO_BROAD_PHASE") != nullptr;
   if (tile_list != nullptr && num_tiles > 0 && !no_tiles) {  // broad phase over 16 x 16 tiles
-    const size_t wave_bytes = ((size_t)nslots * 64 * 4 + (size_t)nslots * 4 * 8 + (size_t)((num_tiles + 3) & ~3)) * sizeof(float);
-    // one wavefront per workgroup for big robots: the CU then holds as many wavefronts as its LDS allows (G1: 9), not a
-    // multiple of a workgroup's
-    const int wv = wave_bytes >= 8 * 1024 ? 1 : 4;
-    CUROBO_REQUIRE(wave_bytes <= 64 * 1024, "%s: too many tiles / spheres for the LDS tiling", what);
+    static const bool one_level = getenv("CUROBO_HIP_SELF_ONE_LEVEL") != nullptr;  // (A/B knob: the round-2 kernel)
     SelfTilesArgs ta{a, tile_list, num_tiles};
     static bool attr2 = false;
     if (!attr2) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr2 = true;
     }
+    if (!one_level) {  // two-level broad phase, four wavefronts per point
+      const size_t lds = tiles2_lds_floats(nslots, num_tiles) * sizeof(float);
+      CUROBO_REQUIRE(lds <= 64 * 1024 && num_tiles <= 2048 && nslots <= 16, "%s: too many tiles / spheres for the LDS tiling", what);
+      hipLaunchKernelGGL(self_collision_tiles2_kernel, dim3((unsigned)n_points), dim3(kT2Waves * 64), lds, st, ta);
+      return check_launch(what, st);
+    }
+    const size_t wave_bytes = ((size_t)nslots * 64 * 4 + (size_t)nslots * 4 * 8 + (size_t)((num_tiles + 3) & ~3)) * sizeof(float);
+    // one wavefront per workgroup for big robots: the CU then holds as many wavefronts as its LDS allows, not a
+    // multiple of a workgroup's
+    const int wv = wave_bytes >= 8 * 1024 ? 1 : 4;
+    CUROBO_REQUIRE(wave_bytes * wv <= 64 * 1024, "%s: too many tiles / spheres for the LDS tiling", what);
     hipLaunchKernelGGL(self_collision_tiles_kernel, dim3((unsigned)ceil_div_l(n_points, wv)), dim3(wv * 64), wave_bytes * wv, st, ta);
     return check_launch(what, st);
   }
@@ -608,7 +836,7 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
   const size_t lds = lds_wave * waves;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL((self_collision_dense_kernel<4>), dim3((unsigned)ceil_div_l(n_points, waves)), dim3(waves * 64), lds, st, a);
