@@ -114,13 +114,23 @@ def sphere_obstacle_collision(
     speed_dt: Optional[torch.Tensor] = None,
 ):
     """distance[b,h,s], gradient[b,h,s,4] <- activation-shaped penetration of every sphere
-    against every enabled obstacle (buffers are fully rewritten, no zero_() needed)."""
-    check(load().curobo_hip_sphere_obstacle_collision(
-        ptr(distance), ptr(gradient), ptr(spheres), C.addressof(scene), ptr(weight),
-        ptr(activation_distance), ptr(env_query_idx), batch_size, horizon, num_spheres,
-        int(use_multi_env), sweep_steps, int(enable_speed_metric), ptr(speed_dt),
-        current_stream(distance),
-    ))
+    against every enabled obstacle (buffers are fully rewritten, no zero_() needed).  Mesh obstacles (``scene.mesh_set``,
+    attached by ``SceneData.from_arrays(..., meshes=)``) are a second launch that adds its share, as the reference launches
+    its kernel once per obstacle kind into the same buffers (wp_autograd.py:85-99)."""
+    mesh_set = getattr(scene, "mesh_set", None)
+    others = scene.max_cuboids > 0 or scene.max_voxel_grids > 0
+    if others or mesh_set is None:
+        check(load().curobo_hip_sphere_obstacle_collision(
+            ptr(distance), ptr(gradient), ptr(spheres), C.addressof(scene), ptr(weight),
+            ptr(activation_distance), ptr(env_query_idx), batch_size, horizon, num_spheres,
+            int(use_multi_env), sweep_steps, int(enable_speed_metric), ptr(speed_dt),
+            current_stream(distance),
+        ))
+    if mesh_set is not None:
+        from .mesh import sphere_mesh_collision
+
+        sphere_mesh_collision(distance, gradient, spheres, mesh_set, weight, activation_distance, env_query_idx, batch_size, horizon,
+                              num_spheres, use_multi_env, sweep_steps, enable_speed_metric, speed_dt, accumulate=others)
 
 
 def trajectory_cost_sum(

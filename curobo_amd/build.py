@@ -33,7 +33,7 @@ SOURCES = [
     "scene_collision.hip",
     "trajectory.hip",
     "optimization.hip",
-    "cost.hip", "rollout_fused.hip", "dynamics.hip", "linalg.hip", "mppi.hip", "seed_ik.hip", "mesh_bake.hip",
+    "cost.hip", "rollout_fused.hip", "dynamics.hip", "linalg.hip", "mppi.hip", "seed_ik.hip", "mesh_bake.hip", "mesh_bvh.hip",
 ]
 
 

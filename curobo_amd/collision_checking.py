@@ -32,7 +32,7 @@ class RobotCollisionCheckerCfg:
         scene format (``curobo_amd.scene.config``)."""
         import os
 
-        from .scene.config import scene_arrays_from_config
+        from .scene.config import scene_from_config
 
         if isinstance(robot_config, dict):
             kin = KinematicsCfg.from_data_dict(robot_config, assets_root=assets_root, device=device)
@@ -40,8 +40,7 @@ class RobotCollisionCheckerCfg:
             kin = KinematicsCfg.from_robot_yaml_file(robot_config, assets_root or os.path.dirname(os.path.abspath(robot_config)), device=device)
         else:
             kin = KinematicsCfg.from_packaged(str(robot_config).replace(".yml", "").replace(".yaml", ""), device=device)
-        arrays = scene_arrays_from_config(scene_model)
-        scene = SceneData.from_arrays(arrays, device) if arrays is not None else None
+        scene = scene_from_config(scene_model, device)
         return RobotCollisionCheckerCfg(kin, scene, collision_activation_distance)
 
 

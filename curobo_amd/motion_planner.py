@@ -30,7 +30,7 @@ import torch
 
 from .kinematics import Kinematics, KinematicsCfg, KinematicsState
 from .scene import SceneData
-from .scene.config import scene_arrays_from_config
+from .scene.config import scene_from_config
 from .solver.ik import IKSolver, IKSolverCfg
 from .solver.trajopt import TrajOptResult, TrajOptSolver, TrajOptSolverCfg
 from .types import DeviceCfg, GoalToolPose, JointState
@@ -141,8 +141,7 @@ class TrajectoryOptimizerCfg:
         and optimiser settings of ``content/configs/task/trajopt/lbfgs_bspline_trajopt.yml`` are built in."""
         device_cfg = device_cfg or DeviceCfg()
         dev = device_cfg.device
-        arrays = scene_arrays_from_config(scene_model)
-        scene = SceneData.from_arrays(arrays, dev) if arrays is not None else None
+        scene = scene_from_config(scene_model, dev)
         kin = _load_kinematics(robot, dev, assets_root)
         return TrajectoryOptimizerCfg(
             kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,

@@ -282,6 +282,8 @@ class CollisionRollout:
         need = rollout_hip.rollout_trajectory_fused_lds_bytes(
             cfg.padded_horizon, self.action_dim, k.num_links, k.num_spheres, n_pairs,
             int(k.link_chain_data.shape[0]), n_obs)
+        if use_scene and getattr(self.scene.struct, "mesh_set", None) is not None:
+            return False  # mesh obstacles are queried by their own launch (BVH): the kernel sequence runs
         return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128
 
     def _dispatch_order(self):

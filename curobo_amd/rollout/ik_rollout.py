@@ -167,6 +167,8 @@ class IKRollout:
         need = rollout_hip.rollout_ik_fused_lds_bytes(
             k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
             int(k.link_chain_data.shape[0]), n_obs)
+        if self.scene is not None and getattr(self.scene.struct, "mesh_set", None) is not None:
+            return False  # mesh obstacles are queried by their own launch (BVH): the kernel sequence runs
         return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64 and k.num_envs == 1
 
     def cost_and_gradient_fused(self, q: torch.Tensor, with_metrics: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

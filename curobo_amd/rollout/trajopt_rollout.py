@@ -322,6 +322,8 @@ class TrajOptRollout:
             c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),
             int(k.link_chain_data.shape[0]), n_obs, True)
         ok = need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
+        if self.scene is not None and getattr(self.scene.struct, "mesh_set", None) is not None:
+            ok = False  # mesh obstacles are queried by their own launch (BVH): the kernel sequence runs
         if ok and c.use_torque_limits:  # inverse dynamics inside the launch borrows LDS regions that are dead by then
             ok = rollout_hip.rollout_trajopt_fused_torque_fits(
                 c.padded_horizon, k.num_dof, k.num_links, k.num_spheres, int(k.self_collision.collision_pairs.shape[0]),

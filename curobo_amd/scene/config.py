@@ -33,9 +33,28 @@ def _one_env(cfg: Dict) -> List[Dict]:
     for name, c in (cfg.get("cylinder") or {}).items():
         obs.append({"type": "cylinder", "radius": float(c["radius"]), "height": float(c["height"]), "pose": list(c["pose"]),
                     "enable": c.get("enable", True), "name": name})
-    if cfg.get("mesh"):
-        raise ValueError("mesh obstacles: bake them into an ESDF grid with curobo_amd.scene.bake_mesh_esdf_device")
     return obs
+
+
+def mesh_envs_from_config(scene_model) -> Optional[List[List[Dict]]]:
+    """the ``mesh`` entries of a scene description, per environment, in the form ``scene.mesh.MeshStore`` takes: ``{"mesh":
+    {name: {"file_path": *.obj | "vertices": ..., "faces": ..., "pose": [...], "scale": [...]}}}`` (reference ``Mesh``,
+    geom/types.py); ``None`` when no environment has one"""
+    if scene_model is None:
+        return None
+    models = scene_model if isinstance(scene_model, (list, tuple)) else [scene_model]
+    envs = []
+    for m in models:
+        if isinstance(m, str):
+            if m in PACKAGED_SCENES:
+                m = PACKAGED_SCENES[m]
+            else:
+                import yaml
+
+                with open(m) as fh:
+                    m = yaml.safe_load(fh)
+        envs.append([dict(c, name=name) for name, c in ((m.get("mesh") if isinstance(m, dict) else None) or {}).items()])
+    return envs if any(envs) else None
 
 
 def load_scene_config(scene_model: Union[str, Dict, List, None]) -> Optional[List[List[Dict]]]:
@@ -59,3 +78,18 @@ def load_scene_config(scene_model: Union[str, Dict, List, None]) -> Optional[Lis
 def scene_arrays_from_config(scene_model) -> Optional[Dict[str, np.ndarray]]:
     envs = load_scene_config(scene_model)
     return None if envs is None else cuboid_scene_arrays(envs)
+
+
+def scene_from_config(scene_model, device, gradient_mode: int = 0):
+    """scene description -> ``SceneData`` on ``device`` with every obstacle kind it names (cuboids and analytic primitives in the
+    cuboid store, ``mesh`` entries behind their BVHs); ``None`` for no world.  What ``SceneCollision.from_config`` does with a
+    ``SceneCfg`` in the reference (geom/collision/collision_scene.py)."""
+    from .data import SceneData
+    from .mesh import MeshStore
+
+    arrays = scene_arrays_from_config(scene_model)
+    if arrays is None:
+        return None
+    meshes = mesh_envs_from_config(scene_model)
+    store = MeshStore(meshes, device, gradient_mode=gradient_mode) if meshes is not None else None
+    return SceneData.from_arrays(arrays, device, meshes=store)

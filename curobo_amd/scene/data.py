@@ -114,6 +114,9 @@ class SceneData:
     tensors: Dict[str, "object"]
     struct: "object"
     arrays: Dict[str, np.ndarray]
+    #: mesh obstacles (``scene.mesh.MeshStore``): queried through their BVHs by a launch of its own after the scene launch
+    #: (``backends.collision.sphere_obstacle_collision`` runs it when ``struct.mesh_set`` is set)
+    meshes: Optional["object"] = None
 
     @property
     def num_envs(self) -> int:
@@ -124,9 +127,11 @@ class SceneData:
         return 1
 
     @staticmethod
-    def from_arrays(arrays: Dict[str, np.ndarray], device, coarse_culling: bool = True) -> "SceneData":
+    def from_arrays(arrays: Optional[Dict[str, np.ndarray]], device, coarse_culling: bool = True, meshes=None) -> "SceneData":
         """``coarse_culling``: also build the min-pooled ESDF the voxel kernels use to skip spheres that are far from
-        every surface (``curobo_hip_scene.voxel_coarse_min``; results are identical with and without it)."""
+        every surface (``curobo_hip_scene.voxel_coarse_min``; results are identical with and without it).  ``meshes``:
+        per environment a list of mesh obstacles (see ``scene.mesh.MeshStore``), or a ready ``MeshStore``."""
+        arrays = arrays if arrays is not None else {}
         import torch
 
         from ..backends.collision import build_voxel_coarse_min, make_scene
@@ -147,7 +152,13 @@ class SceneData:
             t.get("voxel_features"), float(arrays.get("voxel_max_distance", 10000.0)),
             voxel_coarse_min=coarse, voxel_coarse_block=block, voxel_coarse_dilate=dilate,
         )
-        return SceneData(tensors=t, struct=struct, arrays=arrays)
+        store = None
+        if meshes is not None:
+            from .mesh import MeshStore
+
+            store = meshes if isinstance(meshes, MeshStore) else MeshStore(meshes, device)
+            struct.mesh_set = store.struct  # (a Python attribute of the ctypes struct: the launch wrappers look for it)
+        return SceneData(tensors=t, struct=struct, arrays=arrays, meshes=store)
 
 
 def validate_env_query_idx(env_query_idx, scene: Optional["SceneData"], kin_num_envs: int = 1) -> None:

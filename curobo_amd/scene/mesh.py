@@ -1,0 +1,101 @@
+"""Mesh obstacles of a scene: the device-side store the mesh collision kernel reads.
+
+Counterpart of the reference's ``MeshData`` (``curobo/_src/geom/data/data_mesh.py:60-440``: a cache of loaded meshes, and
+per environment slot a mesh handle, inverse pose, bounding-box dims, enable flag; ``Mesh`` obstacles of a ``SceneCfg``,
+``geom/types.py``).  A mesh is loaded once (``build_mesh_bvh``: linear BVH on the device) and may be placed any number of
+times; poses and enable flags are updated in place.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..backends.mesh import DeviceMesh, Mesh, MeshSet, build_mesh_bvh
+from .data import inverse_pose7
+
+
+def load_obj(path: str):
+    """(vertices [V, 3], faces [F, 3]) of a Wavefront OBJ file (v / f records; polygons are fan-triangulated)"""
+    v, f = [], []
+    with open(path) as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                v.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(x.split("/")[0]) for x in t[1:]]
+                idx = [i - 1 if i > 0 else len(v) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    f.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(v, np.float32), np.asarray(f, np.int32)
+
+
+class MeshStore:
+    """``envs[e]`` = list of ``{"name": str, "vertices": [V, 3], "faces": [F, 3] (or "file_path": *.obj), "pose": [x, y, z,
+    qw, qx, qy, qz], "scale": [sx, sy, sz] (optional), "enable": bool}``; meshes that share a name share one BVH."""
+
+    #: 0 = the local gradient as the reference's mesh query returns it (data_mesh.py:693-697: away from the surface for a centre
+    #: outside it -- the opposite of what its cuboid and voxel queries return there); 1 = toward the obstacle on both sides
+    REFERENCE_GRADIENT, CONSISTENT_GRADIENT = 0, 1
+
+    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 4, gradient_mode: int = 0):
+        self.device = torch.device(device)
+        E = len(envs)
+        n = max_n or max(1, max(len(e) for e in envs))
+        self.cache: Dict[str, int] = {}
+        self.meshes: List[DeviceMesh] = []
+        mesh_id = np.zeros((E, n), np.int32)
+        dims = np.zeros((E, n, 4), np.float32)
+        inv_pose = np.zeros((E, n, 8), np.float32)
+        inv_pose[..., 3] = 1.0
+        enable = np.zeros((E, n), np.uint8)
+        count = np.zeros((E,), np.int32)
+        self.names: List[List[Optional[str]]] = [[None] * n for _ in range(E)]
+        for e, obs in enumerate(envs):
+            count[e] = len(obs)
+            for i, o in enumerate(obs):
+                name = o.get("name", f"mesh_{e}_{i}")
+                key = o.get("mesh_name", name)
+                if key not in self.cache:
+                    if "vertices" in o:
+                        v, f = np.asarray(o["vertices"], np.float32), np.asarray(o["faces"], np.int32)
+                    else:
+                        v, f = load_obj(o["file_path"])
+                    if o.get("scale") is not None:
+                        v = v * np.asarray(o["scale"], np.float32).reshape(1, 3)
+                    self.cache[key] = len(self.meshes)
+                    self.meshes.append(build_mesh_bvh(v, f, self.device, leaf_size))
+                mid = self.cache[key]
+                mesh_id[e, i] = mid
+                dims[e, i, :3] = self.meshes[mid].dims
+                inv_pose[e, i, :7] = inverse_pose7(o["pose"])
+                enable[e, i] = 1 if o.get("enable", True) else 0
+                self.names[e][i] = name
+        t = lambda a: torch.as_tensor(a).to(self.device).contiguous()  # noqa: E731
+        self.mesh_id, self.dims, self.inv_pose, self.enable, self.count = t(mesh_id), t(dims), t(inv_pose), t(enable), t(count)
+        raw = b"".join(bytes(m.struct) for m in self.meshes)
+        self._mesh_structs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device).contiguous()
+        self.max_n, self.num_envs = n, E
+        self.struct = MeshSet(self._mesh_structs.data_ptr(), self.mesh_id.data_ptr(), self.dims.data_ptr(), self.inv_pose.data_ptr(),
+                              self.enable.data_ptr(), self.count.data_ptr(), n, int(gradient_mode))
+        self.envs = envs
+
+    def _slot(self, name: str, env_idx: int) -> int:
+        try:
+            return self.names[env_idx].index(name)
+        except ValueError:
+            raise ValueError(f"Mesh with name '{name}' not found in environment {env_idx}") from None
+
+    def update_pose(self, name: str, pose7: Sequence[float], env_idx: int = 0) -> None:
+        """reference MeshData.update_pose: the obstacle moves, the BVH (mesh frame) stays"""
+        i = self._slot(name, env_idx)
+        self.inv_pose[env_idx, i, :7] = torch.as_tensor(inverse_pose7(pose7), dtype=torch.float32, device=self.device)
+
+    def set_enabled(self, name: str, enabled: bool, env_idx: int = 0) -> None:
+        self.enable[env_idx, self._slot(name, env_idx)] = int(enabled)

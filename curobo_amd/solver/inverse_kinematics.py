@@ -15,7 +15,7 @@ import torch
 from ..collision_checking import RobotCollisionChecker
 from ..kinematics import Kinematics, KinematicsCfg, KinematicsState
 from ..scene import SceneData
-from ..scene.config import scene_arrays_from_config
+from ..scene.config import scene_from_config
 from ..types import DeviceCfg, GoalToolPose, JointState
 from .ik import IKSolver, IKSolverCfg
 
@@ -73,8 +73,7 @@ class InverseKinematicsCfg:
             kin = KinematicsCfg.from_robot_yaml_file(robot, assets_root or os.path.dirname(os.path.abspath(robot)), device=dev)
         else:
             kin = KinematicsCfg.from_packaged(str(robot).replace(".yml", "").replace(".yaml", ""), device=dev)
-        arrays = scene_arrays_from_config(scene_model)
-        scene = SceneData.from_arrays(arrays, dev) if arrays is not None else None
+        scene = scene_from_config(scene_model, dev)
         return InverseKinematicsCfg(
             kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,
             orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,

@@ -189,6 +189,64 @@ int curobo_hip_mesh_esdf_bake(uint16_t *out_esdf_fp16, const float *vertices, co
                               int n_faces, int nx, int ny, int nz, float voxel_size, float max_distance,
                               const float *grid_to_mesh_3x4_host, curobo_hip_stream_t stream);
 
+/* Triangle-mesh obstacles queried directly (the reference: geom/data/data_mesh.py:555-700, wp.mesh_query_point per query
+ * sphere through NVIDIA Warp's BVH).  A mesh is a linear BVH in heap layout: triangles sorted by the Morton code of their
+ * centroids, `leaf_size` consecutive triangles per leaf, `n_leaves` (a power of two) leaves, node k has the children 2k and
+ * 2k + 1, the leaves are the nodes n_leaves .. 2 n_leaves - 1.  tri: [n_tri][12] floats = (a, b - a, c - a) as float4 each,
+ * in sorted order; node_box: [2 * n_leaves][8] floats = (lo xyz, -, hi xyz, -), node 0 unused.  All device pointers. */
+typedef struct curobo_hip_mesh {
+  const float *tri;
+  const float *node_box;
+  int32_t n_tri, n_leaves, leaf_size, _pad;
+} curobo_hip_mesh;
+
+/* The mesh obstacles of a scene (layout of the reference's MeshData, data_mesh.py:60-120): meshes = DEVICE array of
+ * curobo_hip_mesh (the cache of loaded meshes), mesh_id [num_envs, max_n] picks one per obstacle slot, dims [num_envs,
+ * max_n, 4] = bounding-box extents (the query's max_distance is half their diagonal), inv_pose / enable / count as for
+ * cuboids.  gradient_mode 0: the local gradient exactly as data_mesh.py:693-697 computes it, (p - closest) / |p - closest|
+ * on either side of the surface; 1: that vector negated for centres outside the surface, i.e. minus the gradient of the
+ * signed distance everywhere, which is what the cuboid (data_cuboid.py:596-626) and voxel kinds hand to the same kernel. */
+typedef struct curobo_hip_mesh_set {
+  const curobo_hip_mesh *meshes;
+  const int32_t *mesh_id;
+  const float *dims;
+  const float *inv_pose;
+  const uint8_t *enable;
+  const int32_t *count;
+  int32_t max_n, gradient_mode;
+} curobo_hip_mesh_set;
+
+/* Build: (1) Morton keys of the triangle centroids inside bounds_lo_hi_host (HOST pointer, 6 floats: the mesh's bounding
+ * box) -> out_codes [n_faces] int64 = code << 32 | triangle index; (2) the caller sorts the keys (any sort: they are
+ * unique); (3) triangles in sorted order + leaf boxes + one launch per level of the tree for the inner boxes.  out_tri
+ * [n_faces * 12], out_node_box [2 * n_leaves * 8] floats. */
+int curobo_hip_mesh_morton_codes(int64_t *out_codes, const float *vertices, const int32_t *faces, int n_faces,
+                                 const float *bounds_lo_hi_host, curobo_hip_stream_t stream);
+int curobo_hip_mesh_bvh_build(float *out_tri, float *out_node_box, const float *vertices, const int32_t *faces,
+                              const int64_t *sorted_codes, int n_faces, int n_leaves, int leaf_size,
+                              curobo_hip_stream_t stream);
+
+/* compute_local_sdf_with_grad of data_mesh.py:630-700 for points [n, 3] in the mesh frame: out_sdf [n] = signed distance
+ * (negative inside; max_distance when no surface lies within max_distance), out_grad [n, 3] (may be NULL) = (point -
+ * closest point) / distance.  Exact point-triangle distances; the sign is the parity of ray crossings (closed meshes). */
+int curobo_hip_mesh_query(float *out_sdf, float *out_grad, const float *points, const curobo_hip_mesh *mesh,
+                          float max_distance, int n_points, curobo_hip_stream_t stream);
+
+/* curobo_hip_mesh_esdf_bake through the BVH: O(voxels x log triangles) instead of O(voxels x triangles). */
+int curobo_hip_mesh_esdf_bake_bvh(uint16_t *out_esdf_fp16, const curobo_hip_mesh *mesh, int nx, int ny, int nz,
+                                  float voxel_size, float max_distance, const float *grid_to_mesh_3x4_host,
+                                  curobo_hip_stream_t stream);
+
+/* Sphere-vs-mesh collision: the mesh share of SphereObstacleCollision / SweptSphereObstacleCollision.forward
+ * (geom/collision/wp_autograd.py:37-249 launches its kernel once per obstacle kind into the same buffers; this is the
+ * launch for the mesh kind).  accumulate != 0: add to distance / gradient as written by curobo_hip_sphere_obstacle_collision
+ * for the other kinds (the speed metric is applied to this share: it is linear); 0: overwrite them. */
+int curobo_hip_sphere_mesh_collision(
+    float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
+    const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres,
+    int use_multi_env, int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate,
+    curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- cost: tool pose + c-space
  * The reference runs these as NVIDIA Warp kernels without a backend hook:
  * ToolPoseDistance (cost/wp_tool_pose.py:698-914, kernel :456-692) and the POSITION c-space cost

@@ -600,7 +600,93 @@ typedef struct {
   int max_vox;
   int vox_n_voxels;           /* per-grid feature stride */
   float vox_max_distance;
+  /* meshes: data_mesh.py:60-120 (MeshData); the triangles of every loaded mesh, concatenated.  No BVH here: the oracle
+   * walks all triangles of a mesh for every query (exact by construction). */
+  const float *mesh_dims;       /* [num_envs, max_mesh, 4] bounding-box extents */
+  const float *mesh_inv_pose;   /* [num_envs, max_mesh, 8] */
+  const uint8_t *mesh_enable;   /* [num_envs, max_mesh] */
+  const int32_t *mesh_count;    /* [num_envs] */
+  const int32_t *mesh_id;       /* [num_envs, max_mesh] index of the loaded mesh */
+  const float *mesh_vertices;   /* [sum V, 3] */
+  const int32_t *mesh_faces;    /* [sum F, 3], indices local to the mesh */
+  const int32_t *mesh_vert_offset, *mesh_face_offset; /* [n_meshes + 1] */
+  int max_mesh;
 } orc_scene;
+
+/* ---- triangle meshes: data_mesh.py:630-700 (compute_local_sdf_with_grad) with the closest point found by brute force
+ * (Ericson, Real-Time Collision Detection 5.1.5) and the sign from the generalised winding number (van Oosterom-Strackee
+ * solid angles summed in double precision): |w| > 0.5 = inside.  Warp's mesh_query_point is outside the reference tree;
+ * this restates its contract for closed, consistently oriented meshes. */
+static void orc_closest_on_triangle(const float *p, const float *a, const float *b, const float *c, float *out) {
+  float ab[3], ac[3], ap[3];
+  for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+#define ORC_DOT(x, y) ((x)[0] * (y)[0] + (x)[1] * (y)[1] + (x)[2] * (y)[2])
+  const float d1 = ORC_DOT(ab, ap), d2 = ORC_DOT(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { for (int i = 0; i < 3; i++) out[i] = a[i]; return; }
+  float bp[3];
+  for (int i = 0; i < 3; i++) bp[i] = p[i] - b[i];
+  const float d3 = ORC_DOT(ab, bp), d4 = ORC_DOT(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { for (int i = 0; i < 3; i++) out[i] = b[i]; return; }
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    const float v = d1 / (d1 - d3);
+    for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i];
+    return;
+  }
+  float cp[3];
+  for (int i = 0; i < 3; i++) cp[i] = p[i] - c[i];
+  const float d5 = ORC_DOT(ab, cp), d6 = ORC_DOT(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { for (int i = 0; i < 3; i++) out[i] = c[i]; return; }
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    const float w = d2 / (d2 - d6);
+    for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i];
+    return;
+  }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]);
+    return;
+  }
+  const float den = 1.0f / (va + vb + vc);
+  for (int i = 0; i < 3; i++) out[i] = a[i] + (vb * den) * ab[i] + (vc * den) * ac[i];
+}
+
+/* signed distance (negative inside) and gradient (p - closest) / |p - closest| of one mesh; max_distance when no surface
+ * lies within max_distance (data_mesh.py:670-672) */
+static float orc_mesh_sdf_raw(const float *verts, const int32_t *faces, int n_faces, const float *lp, float max_distance, float *g) {
+  g[0] = g[1] = g[2] = 0.0f;
+  float best2 = max_distance * max_distance, cl[3] = {0, 0, 0};
+  int found = 0;
+  double solid = 0.0;
+  for (int f = 0; f < n_faces; f++) {
+    const float *a = verts + (size_t)faces[f * 3] * 3, *b = verts + (size_t)faces[f * 3 + 1] * 3, *c = verts + (size_t)faces[f * 3 + 2] * 3;
+    float q[3];
+    orc_closest_on_triangle(lp, a, b, c, q);
+    const float dx = lp[0] - q[0], dy = lp[1] - q[1], dz = lp[2] - q[2];
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 <= best2) { best2 = d2; cl[0] = q[0]; cl[1] = q[1]; cl[2] = q[2]; found = 1; }
+    double ra[3], rb[3], rc[3];
+    for (int i = 0; i < 3; i++) { ra[i] = (double)a[i] - lp[i]; rb[i] = (double)b[i] - lp[i]; rc[i] = (double)c[i] - lp[i]; }
+    const double la = sqrt(ORC_DOT(ra, ra)), lb = sqrt(ORC_DOT(rb, rb)), lc = sqrt(ORC_DOT(rc, rc));
+    const double cr[3] = {rb[1] * rc[2] - rb[2] * rc[1], rb[2] * rc[0] - rb[0] * rc[2], rb[0] * rc[1] - rb[1] * rc[0]};
+    const double num = ORC_DOT(ra, cr);
+    const double den = la * lb * lc + ORC_DOT(ra, rb) * lc + ORC_DOT(rb, rc) * la + ORC_DOT(rc, ra) * lb;
+    solid += 2.0 * atan2(num, den);
+  }
+#undef ORC_DOT
+  if (!found) return max_distance;
+  const float d = sqrtf(best2);
+  if (d > 1e-6f) { g[0] = (lp[0] - cl[0]) / d; g[1] = (lp[1] - cl[1]) / d; g[2] = (lp[2] - cl[2]) / d; }
+  return fabs(solid) > 6.283185307179586 ? -d : d;
+}
+
+ORC_API void orc_mesh_query(float *out_sdf, float *out_grad, const float *points, const float *vertices, const int32_t *faces,
+                            int n_faces, float max_distance, int n_points) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_points; i++) out_sdf[i] = orc_mesh_sdf_raw(vertices, faces, n_faces, points + (size_t)i * 3, max_distance, out_grad + (size_t)i * 3);
+}
 
 /* Voxel ESDF lookup, restating data_voxel.py (trilinear, align-corners, analytic gradient).
  * See orc_voxel_sdf() below -- defined after the helper for clarity. */
@@ -612,11 +698,19 @@ static void orc_scene_eval_point(const orc_scene *sc, int env, int is_voxel, int
                                  float *grad_sum, float *pen_out) {
   float g[3];
   float sdf;
-  if (!is_voxel) {
+  if (is_voxel == 0) {
     sdf = orc_cuboid_sdf(sc->cub_dims + ((size_t)env * sc->max_cub + o) * 4, lp, g);
-  } else {
+  } else if (is_voxel == 1) {
     int valid = 1;
     sdf = orc_voxel_sdf(sc, env * sc->max_vox + o, lp, g, &valid);
+  } else {  /* mesh: data_mesh.py:630-700; max_distance = max(half the bounding-box diagonal, the query distance) */
+    const size_t flat = (size_t)env * sc->max_mesh + o;
+    const float *dm = sc->mesh_dims + flat * 4;
+    float max_distance = 0.5f * sqrtf(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]);
+    if (r_adj > max_distance) max_distance = r_adj;
+    const int m = sc->mesh_id[flat];
+    sdf = orc_mesh_sdf_raw(sc->mesh_vertices + (size_t)sc->mesh_vert_offset[m] * 3, sc->mesh_faces + (size_t)sc->mesh_face_offset[m] * 3,
+                           sc->mesh_face_offset[m + 1] - sc->mesh_face_offset[m], lp, max_distance, g);
   }
   const float pen = -sdf + r_adj;
   *pen_out = pen;
@@ -652,12 +746,14 @@ ORC_API void orc_scene_collision(float *distance, float *gradient, const float *
     float dsum = 0.0f, gsum[3] = {0, 0, 0};
     if (s[3] >= 0.0f) {
       const float r_adj = s[3] + eta;
-      for (int kind = 0; kind < 2; kind++) {
-        const int max_n = kind == 0 ? sc->max_cub : sc->max_vox;
+      /* the reference launches its kernel once per obstacle kind: cuboids, meshes, voxels (data_scene.py:72-81); sums of
+       * floats: the kinds are visited cuboids, voxels, meshes here and in the HIP path alike */
+      for (int kind = 0; kind < 3; kind++) {
+        const int max_n = kind == 0 ? sc->max_cub : (kind == 1 ? sc->max_vox : sc->max_mesh);
         if (max_n <= 0) continue;
-        const int32_t *count = kind == 0 ? sc->cub_count : sc->vox_count;
-        const uint8_t *enable = kind == 0 ? sc->cub_enable : sc->vox_enable;
-        const float *inv_pose = kind == 0 ? sc->cub_inv_pose : sc->vox_inv_pose;
+        const int32_t *count = kind == 0 ? sc->cub_count : (kind == 1 ? sc->vox_count : sc->mesh_count);
+        const uint8_t *enable = kind == 0 ? sc->cub_enable : (kind == 1 ? sc->vox_enable : sc->mesh_enable);
+        const float *inv_pose = kind == 0 ? sc->cub_inv_pose : (kind == 1 ? sc->vox_inv_pose : sc->mesh_inv_pose);
         for (int o = 0; o < max_n; o++) {
           /* is_obs_enabled: data_cuboid.py:467-485 */
           if (o >= count[env]) continue;

@@ -70,7 +70,49 @@ class _SceneStruct(C.Structure):
         ("max_vox", C.c_int),
         ("vox_n_voxels", C.c_int),
         ("vox_max_distance", C.c_float),
+        ("mesh_dims", C.c_void_p), ("mesh_inv_pose", C.c_void_p), ("mesh_enable", C.c_void_p), ("mesh_count", C.c_void_p),
+        ("mesh_id", C.c_void_p), ("mesh_vertices", C.c_void_p), ("mesh_faces", C.c_void_p), ("mesh_vert_offset", C.c_void_p),
+        ("mesh_face_offset", C.c_void_p), ("max_mesh", C.c_int),
     ]
+
+
+def mesh_scene_arrays(envs) -> Dict[str, np.ndarray]:
+    """``envs[e]`` = list of mesh obstacles as ``curobo_amd.scene.mesh.MeshStore`` takes them (name, vertices, faces, pose,
+    scale, enable) -> the ``mesh_*`` arrays of the oracle's scene dictionary (pure numpy; no BVH)"""
+    E = len(envs)
+    n = max(1, max(len(e) for e in envs))
+    cache, verts, faces, voff, foff = {}, [], [], [0], [0]
+    mesh_id, dims = np.zeros((E, n), np.int32), np.zeros((E, n, 4), np.float32)
+    inv_pose = np.zeros((E, n, 8), np.float32)
+    inv_pose[..., 3] = 1.0
+    enable, count = np.zeros((E, n), np.uint8), np.zeros((E,), np.int32)
+    for e, obs in enumerate(envs):
+        count[e] = len(obs)
+        for i, o in enumerate(obs):
+            key = o.get("mesh_name", o.get("name", f"mesh_{e}_{i}"))
+            if key not in cache:
+                v, f = np.asarray(o["vertices"], np.float32), np.asarray(o["faces"], np.int32)
+                if o.get("scale") is not None:
+                    v = v * np.asarray(o["scale"], np.float32).reshape(1, 3)
+                cache[key] = len(voff) - 1
+                verts.append(v)
+                faces.append(f)
+                voff.append(voff[-1] + len(v))
+                foff.append(foff[-1] + len(f))
+            m = cache[key]
+            used = verts[m][faces[m].reshape(-1)]
+            mesh_id[e, i] = m
+            dims[e, i, :3] = used.max(0) - used.min(0)
+            p = np.asarray(o["pose"], np.float64)
+            q = p[3:7] / np.linalg.norm(p[3:7])
+            qi = np.array([q[0], -q[1], -q[2], -q[3]])
+            t = 2.0 * np.cross(qi[1:], p[:3])
+            inv_pose[e, i, :3] = -(p[:3] + qi[0] * t + np.cross(qi[1:], t))
+            inv_pose[e, i, 3:7] = qi
+            enable[e, i] = 1 if o.get("enable", True) else 0
+    return {"mesh_id": mesh_id, "mesh_dims": dims, "mesh_inv_pose": inv_pose, "mesh_enable": enable, "mesh_count": count,
+            "mesh_vertices": np.concatenate(verts).astype(np.float32), "mesh_faces": np.concatenate(faces).astype(np.int32),
+            "mesh_vert_offset": np.asarray(voff, np.int32), "mesh_face_offset": np.asarray(foff, np.int32)}
 
 
 class Oracle:
@@ -295,6 +337,19 @@ class Oracle:
             st.vox_max_distance = float(scene.get("voxel_max_distance", 10000.0))
         else:
             st.max_vox = 0
+        if scene.get("mesh_id") is not None and scene["mesh_id"].size > 0:
+            st.max_mesh = int(scene["mesh_id"].shape[1])
+            st.mesh_id = hold(scene["mesh_id"], np.int32)
+            st.mesh_dims = hold(scene["mesh_dims"], np.float32)
+            st.mesh_inv_pose = hold(scene["mesh_inv_pose"], np.float32)
+            st.mesh_enable = hold(scene["mesh_enable"], np.uint8)
+            st.mesh_count = hold(scene["mesh_count"], np.int32)
+            st.mesh_vertices = hold(scene["mesh_vertices"], np.float32)
+            st.mesh_faces = hold(scene["mesh_faces"], np.int32)
+            st.mesh_vert_offset = hold(scene["mesh_vert_offset"], np.int32)
+            st.mesh_face_offset = hold(scene["mesh_face_offset"], np.int32)
+        else:
+            st.max_mesh = 0
         if env_query_idx is None:
             env_query_idx = np.zeros((b,), np.int32)
         env_query_idx = np.ascontiguousarray(env_query_idx, np.int32)
@@ -309,6 +364,15 @@ class Oracle:
             C.c_int(3 if sweep else 0), C.c_int(int(enable_speed_metric)), _ptr(dt),
         )
         return {"distance": dist, "gradient": grad}
+
+    def mesh_query(self, points, vertices, faces, max_distance: float):
+        """points [n, 3] in the mesh frame -> (sdf [n], gradient [n, 3]): brute force over every triangle, winding-number sign"""
+        p = _f32(points).reshape(-1, 3)
+        v, f = _f32(vertices), np.ascontiguousarray(faces, np.int32)
+        sdf, grad = np.zeros(p.shape[0], np.float32), np.zeros((p.shape[0], 3), np.float32)
+        self.lib.orc_mesh_query(_ptr(sdf), _ptr(grad), _ptr(p), _ptr(v), _ptr(f), C.c_int(f.shape[0]), C.c_float(max_distance),
+                                C.c_int(p.shape[0]))
+        return sdf, grad
 
     # ------------------------------------------------------------------ B-spline
     def bspline_forward(self, u, start, goal, start_idx, goal_idx, traj_dt, use_implicit_goal,

@@ -1,0 +1,299 @@
+"""Triangle-mesh obstacles on the device (csrc/mesh_bvh.hip: linear BVH build, closest point + sign, sphere-vs-mesh collision,
+ESDF bake through the BVH) against the oracle's brute force over every triangle (oracle/curobo_oracle.c orc_mesh_sdf_raw).
+
+The reference walks meshes with NVIDIA Warp's ``wp.mesh_query_point`` (data_mesh.py:630-700), which is neither in /root/reference
+nor buildable for ROCm: the BVH walk itself is unpinned against Warp.  What is pinned: the same contract on the same inputs --
+exact closest point (a BVH changes the order triangles are visited in, not the minimum), the sign of closed meshes, the
+``max_distance`` rule -- and the reference's own regression case (tests/_src/collision/test_mesh_collision_sdf.py)."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model, sample_q
+from test_oracle_mesh import box_shape, ell_shape, mesh_world, small_cube_case, sphere_shape, torus_shape
+
+pytestmark = pytest.mark.gpu
+
+
+SHAPES = {
+    "box": lambda: box_shape([0.3, 0.5, 0.2], 3),            # 768 triangles, many coplanar: ties between triangles
+    "sphere": lambda: sphere_shape(0.2, 32, 64),            # 3968
+    "torus": lambda: torus_shape(0.22, 0.06, 64, 32),       # 4096, genus 1
+    "ell": lambda: ell_shape(3),                            # non-convex polyhedron
+    "tiny": lambda: box_shape([0.05, 0.05, 0.05], 0),       # 12 triangles: fewer than one wavefront, 4 leaves
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+@pytest.mark.parametrize("leaf_size", [1, 4])
+def test_bvh_query_is_the_brute_force_query(shape, leaf_size, oracle, device):
+    from curobo_amd.backends.mesh import build_mesh_bvh, mesh_query
+
+    v, f = SHAPES[shape]()
+    mesh = build_mesh_bvh(v, f, device, leaf_size=leaf_size)
+    assert mesh.n_tri == len(f)
+    # the build keeps every triangle exactly once (sorted order): same multiset of (a, b - a, c - a)
+    tri = mesh.tri.cpu().numpy().reshape(-1, 3, 4)[:, :, :3]
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    want = np.stack([a, b - a, c - a], 1).reshape(len(f), 9)
+    got = tri.reshape(len(f), 9)
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    # every node box holds its triangles; the root box is the mesh's bounding box
+    box = mesh.node_box.cpu().numpy()
+    np.testing.assert_array_equal(box[1, :3], v[f.reshape(-1)].min(0))
+    np.testing.assert_array_equal(box[1, 4:7], v[f.reshape(-1)].max(0))
+    rng = np.random.default_rng(5)
+    ext = np.abs(v).max(0) + 0.15
+    p = rng.uniform(-ext, ext, size=(6000, 3)).astype(np.float32)
+    p[:200] = (v[f[rng.integers(0, len(f), 200), 0]] + rng.normal(size=(200, 3)) * 1e-3).astype(np.float32)  # hugging the surface
+    for max_distance in (10.0, 0.08):
+        ref_sdf, ref_grad = oracle.mesh_query(p, v, f, max_distance)
+        sdf, grad = mesh_query(mesh, torch.as_tensor(p, device=device), max_distance)
+        torch.cuda.synchronize()
+        sdf, grad = sdf.cpu().numpy(), grad.cpu().numpy()
+        # |distance|: same minimum over the same triangles (float rounding of the per-triangle distance only)
+        np.testing.assert_allclose(np.abs(sdf), np.abs(ref_sdf), atol=2e-6, rtol=1e-5)
+        # sign: ray-crossing parity on the device, winding number in the oracle: agree off the surface
+        off = np.abs(ref_sdf) > 1e-5
+        assert np.array_equal((sdf < 0)[off], (ref_sdf < 0)[off])
+        assert (ref_sdf < 0).sum() > 20 or shape == "tiny"
+        # cut-off: same set of points reports "nothing within max_distance"
+        edge = np.abs(np.abs(ref_sdf) - max_distance) < 1e-5
+        assert np.array_equal((sdf == np.float32(max_distance))[~edge], (ref_sdf == np.float32(max_distance))[~edge])
+        # gradient: same closest point, except where two triangles are equally close up to rounding (medial axis)
+        found = (ref_sdf != np.float32(max_distance)) & ~edge & (np.abs(ref_sdf) > 1e-4)
+        err = np.abs(grad - ref_grad).max(-1)[found]
+        assert (err > 1e-3).mean() < 0.01, (err > 1e-3).mean()
+        assert np.median(err) < 1e-5
+
+
+def test_reference_regression_small_mesh_cost_matches_cuboid(device):
+    """the reference's own mesh regression test on the device: a 5 cm cube as mesh and as cuboid give the same costs -- first
+    probe in collision, the other three exactly zero (two of them beyond half the bounding-box diagonal: the
+    ``max(max_distance, query_distance)`` rule of data_mesh.py:668)"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+
+    v, f, sph = small_cube_case()
+    pose = [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+    out = []
+    for scene in (SceneData.from_arrays(None, device, meshes=[[{"name": "box", "vertices": v, "faces": f, "pose": pose}]]),
+                  SceneData.from_arrays(cuboid_scene_arrays([[{"dims": [0.05] * 3, "pose": pose}]]), device)):
+        dist, grad = torch.full((1, 1, 4), 7.0, device=device), torch.full((1, 1, 4, 4), 7.0, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([1.0], device=device),
+                                     torch.tensor([0.01], device=device), None, 1, 1, 4, False)
+        torch.cuda.synchronize()
+        out.append(dist.cpu().numpy().reshape(-1))
+    assert np.allclose(out[0], out[1])
+    assert out[0][0] > 0.0 and (out[0][1:] == 0.0).all()
+
+
+def _trajectory_spheres(oracle, b, h, scale=0.7):
+    model = load_model("franka")
+    q0, q1 = sample_q(model, b, seed=11)[:, None], sample_q(model, b, seed=12)[:, None]
+    tt = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    sph = oracle.kinematics_forward((q0 * (1 - tt) + q1 * tt).reshape(b * h, -1) * scale, model.as_dict(), horizon=h)["robot_spheres"]
+    return sph.reshape(b, h, -1, 4)
+
+
+@pytest.mark.parametrize("sweep,speed", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("with_cuboids", [False, True])
+def test_sphere_mesh_collision_matches_the_oracle(sweep, speed, with_cuboids, oracle, device):
+    """robot spheres along trajectories against a mesh world (table, ball, torus, L prism; one disabled slot that shares a
+    BVH): cost and gradient per sphere vs the oracle's scene restatement with the mesh kind; alone and on top of cuboids"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+
+    world = mesh_world()
+    sph = _trajectory_spheres(oracle, 24, 9)
+    b, h, S, _ = sph.shape
+    arrays = cuboid_scene_arrays([[{"dims": [0.1, 0.1, 1.5], "pose": [0.45, -0.3, 0.3, 1, 0, 0, 0]},
+                                   {"type": "capsule", "radius": 0.07, "base": [0, 0, 0.0], "tip": [0, 0, 0.5],
+                                    "pose": [-0.3, 0.5, 0.2, 0.9238795, 0.3826834, 0, 0]}]]) if with_cuboids else {}
+    ref = oracle.scene_collision(sph, {**arrays, **mesh_scene_arrays(world)}, 3.0, 0.02, sweep=sweep, enable_speed_metric=speed, speed_dt=0.05)
+    scene = SceneData.from_arrays(arrays or None, device, meshes=world)
+    assert len(scene.meshes.meshes) == 4 and scene.meshes.max_n == 5
+    dist, grad = torch.full((b, h, S), 5.0, device=device), torch.full((b, h, S, 4), 5.0, device=device)
+    Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([3.0], device=device),
+                                 torch.tensor([0.02], device=device), None, b, h, S, False, 3 if sweep else 0, speed,
+                                 torch.tensor([0.05], device=device))
+    torch.cuda.synchronize()
+    d, g = dist.cpu().numpy(), grad.cpu().numpy()
+    assert 0.03 < (ref["distance"] > 0).mean() < 0.9
+    # hit set: exact except where a sphere grazes a surface within rounding
+    graze = np.abs(d - ref["distance"]) < 2e-5
+    assert np.array_equal((d > 0)[~graze], (ref["distance"] > 0)[~graze])
+    scale = 20.0 if speed else 1.0  # the speed metric multiplies cost and gradient by the sphere speed (up to ~10 m/s here)
+    np.testing.assert_allclose(d, ref["distance"], atol=2e-5 * scale, rtol=1e-4)
+    bad = np.abs(g - ref["gradient"]).max(-1) > (2e-4 * scale + 1e-3 * np.abs(ref["gradient"]).max(-1))
+    assert bad.mean() < 2e-3, bad.mean()  # (closest-point ties on coplanar triangles / the medial axis)
+
+
+def test_mesh_slots_per_environment_pose_updates_and_enable(oracle, device):
+    """two environments with different mesh sets, ``env_query_idx`` per trajectory; then move a mesh and switch one off:
+    the BVH stays, the store's pose / enable rows change (reference MeshData.update_pose / enable_obstacle)"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData
+
+    w0 = mesh_world()[0]
+    envs = [[w0[0], w0[1]], [dict(w0[2]), dict(w0[3]), dict(w0[1], name="ball_b", mesh_name="ball")]]
+    sph = _trajectory_spheres(oracle, 16, 7)
+    b, h, S, _ = sph.shape
+    idx = (np.arange(b) % 2).astype(np.int32)
+    scene = SceneData.from_arrays(None, device, meshes=envs)
+    assert len(scene.meshes.meshes) == 4  # "ball" is built once and used in both environments
+
+    def run():
+        dist, grad = torch.zeros(b, h, S, device=device), torch.zeros(b, h, S, 4, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([2.0], device=device),
+                                     torch.tensor([0.02], device=device), torch.as_tensor(idx, device=device), b, h, S, True, 3, False, None)
+        torch.cuda.synchronize()
+        return dist.cpu().numpy()
+
+    ref = oracle.scene_collision(sph, mesh_scene_arrays(envs), 2.0, 0.02, env_query_idx=idx, use_multi_env=True, sweep=True)["distance"]
+    np.testing.assert_allclose(run(), ref, atol=2e-5, rtol=1e-4)
+    assert (ref[0::2] > 0).any() and (ref[1::2] > 0).any()
+    envs[1][0]["pose"] = [0.3, 0.0, 0.5, 1, 0, 0, 0]
+    envs[1][1]["enable"] = False
+    scene.meshes.update_pose("ring", envs[1][0]["pose"], env_idx=1)
+    scene.meshes.set_enabled("ell", False, env_idx=1)
+    ref2 = oracle.scene_collision(sph, mesh_scene_arrays(envs), 2.0, 0.02, env_query_idx=idx, use_multi_env=True, sweep=True)["distance"]
+    assert np.abs(ref2 - ref).max() > 1e-3
+    np.testing.assert_allclose(run(), ref2, atol=2e-5, rtol=1e-4)
+    with pytest.raises(ValueError, match="not found"):
+        scene.meshes.update_pose("ring", envs[1][0]["pose"], env_idx=0)
+
+
+def test_consistent_gradient_mode_points_out_of_the_mesh_on_both_sides(oracle, device):
+    """``MeshStore(gradient_mode=CONSISTENT_GRADIENT)``: the cost gradient of a box mesh equals the analytic cuboid's for centres
+    outside the box as well (the reference's mesh query returns the opposite vector there, see scene/mesh.py); costs are the
+    same in both modes"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import MeshStore, SceneData, cuboid_scene_arrays
+
+    dims, pose = [0.3, 0.4, 0.5], [0.3, 0.1, 0.4, np.cos(0.4), 0, 0, np.sin(0.4)]
+    v, f = box_shape(dims)
+    rng = np.random.default_rng(7)
+    n = 4096
+    sph = np.concatenate([rng.uniform([-0.1, -0.3, 0.0], [0.7, 0.5, 0.8], size=(n, 3)), rng.uniform(0.02, 0.08, size=(n, 1))], -1)
+    sph = sph.astype(np.float32).reshape(1, 1, n, 4)
+    out = {}
+    for key, scene in (
+            ("cuboid", SceneData.from_arrays(cuboid_scene_arrays([[{"dims": dims, "pose": pose}]]), device)),
+            ("reference", SceneData.from_arrays(None, device, meshes=[[{"name": "b", "vertices": v, "faces": f, "pose": pose}]])),
+            ("consistent", SceneData.from_arrays(None, device, meshes=MeshStore([[{"name": "b", "vertices": v, "faces": f, "pose": pose}]], device,
+                                                                                gradient_mode=MeshStore.CONSISTENT_GRADIENT)))):
+        dist, grad = torch.zeros(1, 1, n, device=device), torch.zeros(1, 1, n, 4, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([1.0], device=device),
+                                     torch.tensor([0.02], device=device), None, 1, 1, n, False)
+        torch.cuda.synchronize()
+        out[key] = (dist.cpu().numpy().reshape(-1), grad.cpu().numpy().reshape(n, 4)[:, :3])
+    hit = out["cuboid"][0] > 1e-4
+    assert hit.sum() > 300
+    np.testing.assert_allclose(out["reference"][0], out["cuboid"][0], atol=2e-6, rtol=1e-4)
+    assert np.array_equal(out["reference"][0], out["consistent"][0])
+    # off the medial axis (where the closest face is unique) the consistent mode is the cuboid's gradient
+    agree = np.abs(out["consistent"][1] - out["cuboid"][1]).max(-1) < 1e-3
+    assert agree[hit].mean() > 0.9
+    # the reference's vector: the cuboid's for centres inside the box, its opposite for centres outside
+    flipped = np.abs(out["reference"][1] + out["cuboid"][1]).max(-1) < 1e-3
+    same = np.abs(out["reference"][1] - out["cuboid"][1]).max(-1) < 1e-3
+    sel = hit & agree & (np.abs(out["cuboid"][1]).max(-1) > 1e-2)
+    assert (flipped & sel).sum() > 100 and (same & sel).sum() > 100
+    assert ((flipped ^ same) | ~sel).all()
+
+
+def test_esdf_bake_through_the_bvh_equals_the_all_triangles_bake(device):
+    """mesh -> fp16 ESDF grid: the BVH bake and the bake that visits every triangle per voxel (csrc/mesh_bake.hip, pinned against
+    the NumPy mesh signed distance in test_gpu_kernels.py) fill the same grid"""
+    from curobo_amd.backends.collision import mesh_esdf_bake
+    from curobo_amd.backends.mesh import build_mesh_bvh, mesh_esdf_bake_bvh
+
+    v, f = torus_shape(0.22, 0.06, 64, 32)
+    nx, ny, nz, vs = 48, 48, 24, 0.0125
+    xf = [1, 0, 0, 0.01, 0, 1, 0, -0.02, 0, 0, 1, 0.005]
+    a = torch.zeros(nx * ny * nz, dtype=torch.float16, device=device)
+    b = torch.zeros_like(a)
+    mesh_esdf_bake(a, torch.as_tensor(v, device=device), torch.as_tensor(f, device=device), (nx, ny, nz), vs, xf, max_distance=0.1)
+    mesh_esdf_bake_bvh(b, build_mesh_bvh(v, f, device), (nx, ny, nz), vs, xf, max_distance=0.1)
+    torch.cuda.synchronize()
+    a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+    assert (a < 0).sum() > 500 and (a == np.float32(np.float16(0.1))).sum() > 500
+    assert np.abs(a - b).max() <= 2.0 ** -11 * 0.1 * 2  # one fp16 ulp at the largest magnitude
+    assert (a != b).mean() < 0.01
+
+
+def test_rollout_with_a_mesh_scene_uses_the_kernel_sequence(oracle, device):
+    """a mesh world through the collision rollout (the fused kernel does not walk meshes: ``fused_available`` is off and the
+    launch sequence with the mesh pass runs): the scene cost of the rollout's own spheres equals the oracle's, the gradient
+    reaches the knots"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays(c2_world())
+    scene = SceneData.from_arrays(arrays, device, meshes=mesh_world())
+    B = 16
+    ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(use_self_collision=False))
+    assert not ro.fused_available()
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=11), device=device).reshape(B, -1)
+    cost, grad = [t.clone() for t in ro.cost_and_gradient(x)]
+    torch.cuda.synchronize()
+    sph = ro.robot_spheres.cpu().numpy()
+    cfg = ro.cfg
+    ref = oracle.scene_collision(sph, {**arrays, **mesh_scene_arrays(mesh_world())}, cfg.scene_collision_weight, cfg.activation_distance,
+                                 sweep=True, enable_speed_metric=True, speed_dt=cfg.traj_dt)
+    only_cub = oracle.scene_collision(sph, arrays, cfg.scene_collision_weight, cfg.activation_distance, sweep=True, enable_speed_metric=True,
+                                      speed_dt=cfg.traj_dt)
+    want = ref["distance"].reshape(B, -1).astype(np.float64).sum(-1)
+    assert (want > only_cub["distance"].reshape(B, -1).sum(-1) * 1.01 + 1.0).any(), "the meshes must matter"
+    # per sphere: equal up to rounding, except the few whose sweep takes a different branch (the swept cost jumps where a
+    # sample's penetration crosses zero: test_gpu_rollout.py discusses it); the trajectory sums follow
+    d = ro.scene_dist.cpu().numpy()
+    bad = np.abs(d - ref["distance"]) > 2e-5 * cfg.scene_collision_weight * 20 + 1e-3 * np.abs(ref["distance"])
+    assert bad.mean() < 1e-3, bad.mean()
+    np.testing.assert_allclose(cost.cpu().numpy(), want, rtol=2e-2)
+    assert (np.abs(cost.cpu().numpy() - want) < 2e-3 * want + 1e-2).mean() > 0.8
+    assert float(grad.abs().max()) > 0.0
+
+
+def test_collision_checker_from_a_scene_config_with_a_mesh_file(tmp_path, oracle, device):
+    """``scene_model={"cuboid": ..., "mesh": {name: {"file_path": *.obj, "pose", "scale"}}}`` (the reference's SceneCfg format)
+    through ``RobotCollisionChecker``: the OBJ is read, scaled, placed; robot-vs-scene distances equal the oracle's"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.collision_checking import RobotCollisionChecker, RobotCollisionCheckerCfg
+    from curobo_amd.scene import cuboid_scene_arrays
+
+    v, f = torus_shape(0.11, 0.03)
+    path = tmp_path / "ring.obj"
+    with open(path, "w") as fh:
+        fh.write("# ring\n" + "".join(f"v {a:.7f} {b:.7f} {c:.7f}\n" for a, b, c in v) + "".join(f"f {a + 1} {b + 1}/1 {c + 1}//2\n" for a, b, c in f))
+    pose = [0.4, 0.0, 0.45, 0.9238795, 0.3826834, 0, 0]
+    cfg = {"cuboid": {"table": {"dims": [2.2, 2.2, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}},
+           "mesh": {"ring": {"file_path": str(path), "pose": pose, "scale": [2.0, 2.0, 2.0]}}}
+    chk = RobotCollisionChecker(RobotCollisionCheckerCfg.load_from_config("franka.yml", cfg, 0.02, device=device))
+    assert chk.scene.meshes is not None and chk.scene.meshes.meshes[0].n_tri == len(f)
+    model = load_model("franka")
+    q = sample_q(model, 256, seed=4, scale=0.7)
+    sph = oracle.kinematics_forward(q, model.as_dict(), horizon=1)["robot_spheres"].reshape(256, 1, -1, 4)
+    v2 = np.loadtxt([ln[2:] for ln in open(path) if ln.startswith("v ")], dtype=np.float32) * 2.0
+    arrays = {**cuboid_scene_arrays([[{"dims": [2.2, 2.2, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}]]),
+              **mesh_scene_arrays([[{"name": "ring", "vertices": v2, "faces": f, "pose": pose}]])}
+    ref = oracle.scene_collision(sph, arrays, 1.0, 0.02)["distance"].reshape(256, -1)
+    only_table = oracle.scene_collision(sph, cuboid_scene_arrays([[{"dims": [2.2, 2.2, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}]]), 1.0, 0.02)
+    assert (ref.sum(-1) > only_table["distance"].reshape(256, -1).sum(-1) + 1e-3).sum() > 5
+    d_scene, _ = chk.get_scene_self_collision_distance_from_joints(torch.as_tensor(q, device=device))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d_scene.detach().cpu().numpy().reshape(256, -1), ref, atol=2e-5, rtol=1e-4)
