@@ -65,6 +65,7 @@ def _rollout_trajectory(fn, terms, with_terms,
     dispatch: Optional["DispatchOrder"] = None,
 ):
     num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
+    lanes = getattr(pair_locations, "_self_lane_lists", None)
     ws, phase = (None, 0) if dispatch is None else dispatch.next(batch_size)
     extra = ((None if terms is None else C.addressof(terms)),) if with_terms else ()
     check(fn(
@@ -78,8 +79,29 @@ def _rollout_trajectory(fn, terms, with_terms,
         ptr(activation_distance), ptr(speed_dt), ptr(env_query_idx), num_envs, int(use_multi_env),
         batch_size, padded_horizon, dof, n_knots, bspline_degree, int(fixed_transform.shape[0]),
         int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]), sweep_steps,
-        int(enable_speed_metric), ptr(ws), phase, *extra, current_stream(out_cost),
+        int(enable_speed_metric), ptr(ws), phase, ptr(lanes[0]) if lanes else None, lanes[1] if lanes else 0, *extra,
+        current_stream(out_cost),
     ))
+
+
+def attach_self_lane_lists(pair_locations: Optional[torch.Tensor], num_spheres: int) -> None:
+    """Deal the robot's collision pairs to lanes once (``curobo_hip_self_lane_lists_host``) and hang the device copy on the
+    pair tensor itself: the fused trajectory launches find it there (``_self_lane_lists``) and run the lane = sphere form of
+    the self-collision pass; a pair tensor without it (a copy, a slice) runs the row form.  One device -> host read of the
+    pair list: call at set-up time, never inside a captured launch sequence."""
+    if pair_locations is None or pair_locations.numel() == 0 or getattr(pair_locations, "_self_lane_lists", None) is not None:
+        return
+    host = pair_locations.detach().to("cpu", torch.int16).contiguous()
+    n_pairs = int(host.shape[0])
+    cap = 64 * (n_pairs // 64 + 2) * (2 if num_spheres > 64 else 1) + 64 * 64
+    out = torch.zeros(cap, dtype=torch.int32)
+    code = int(load().curobo_hip_self_lane_lists_host(out.data_ptr(), cap, host.data_ptr(), n_pairs, int(num_spheres)))
+    if code < 0:
+        check(code)
+    if code == 0:
+        return
+    n = ((code & 0xffff) + (code >> 16)) * 64
+    pair_locations._self_lane_lists = (out[:n].to(pair_locations.device).contiguous(), code)
 
 
 

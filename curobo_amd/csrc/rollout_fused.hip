@@ -28,8 +28,11 @@
 // Workgroups take their trajectory through an optional longest-first permutation that the previous
 // launches built from measured workgroup durations (rebuild_dispatch_order).  DESIGN.md section 4.1
 // has the measurements behind each of these choices.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <vector>
 
 #include "bspline_device.hpp"
 #include "cost_device.hpp"
@@ -51,6 +54,8 @@ struct FusedTrajArgs {
   const int16_t *joint_map, *link_map, *link_sphere_map, *link_chain_data, *link_chain_offsets;
   const float *sphere_padding, *w_self;
   const int16_t *pairs;
+  const uint32_t *lane_lists;  // optional: the pair list re-ordered for lane = sphere (curobo_hip_self_lane_lists_host)
+  int lane_len0, lane_len1;    // list entries per lane of pass 0 (spheres 0..63) and pass 1 (64..127)
   curobo_hip_scene sc;
   const float *w_scene, *eta, *speed_dt;
   const int32_t *env_query_idx;
@@ -85,10 +90,11 @@ constexpr int kSceneListEntries = 128;  // ring of active (row, sphere) entries 
 
 struct FusedLayout {
   int q, cumul, work, ws, wrench, wl, cost, parent, chain_off, link_info, sign, lists, off_add, fixed, chain, sph_link, sph_rad,
-      sph_pad, rs, lbound, sub, jlinks, left, key, flag, dyn, cstab, pairs, recs, total;
+      sph_pad, rs, lbound, sub, jlinks, left, key, flag, dyn, cstab, pairs, lanel, recs, total;
 };
+// n_lane > 0: the lane = sphere form of the pair list (n_lane words) is staged INSTEAD of the (i, j) offsets
 __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0,
-                                                    int n_waves = 0, int rings = 1) {
+                                                    int n_waves = 0, int rings = 1, int n_lane = 0) {
   FusedLayout f;
   int o = 0;
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
@@ -122,7 +128,8 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.flag = take(H);  // per point: any wrench written
   f.dyn = take(n_dyn);  // velocity / acceleration / jerk (+ joint-space position gradient) [4][H][D] when the c-space STATE cost is on
   f.cstab = take(n_dyn ? 10 * D + 12 : 0);  // c-space limits (shrunk) [10][D] (pos, vel, acc, jerk, effort) + 10 retimed weights + dt
-  f.pairs = take((P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
+  f.pairs = take(n_lane > 0 ? 0 : (P + 63) & ~63);  // padded with (NaN sphere, NaN sphere) pairs: loops need no bounds checks
+  f.lanel = take(n_lane);
   f.recs = take(n_rec * kObsRecFloats);
   f.total = o;
   return f;
@@ -152,6 +159,9 @@ struct FusedCtx {
   int *lbound;           // per link: box (link frame) around its collision spheres: lo xyz, hi xyz as ordered-int keys
   int *parent, *chain_off, *link_info, *chain, *sph_link;
   uint32_t *sub, *jlinks, *pairs;
+  const uint32_t *lanel;  // [lane_len0 + lane_len1][64]: partner byte offset | pair index << 16
+  const uint32_t *g_pairs;  // the (i, j) list in global memory (read for the one winning pair when lanel is in use)
+  int lane_len0, lane_len1;
   float4 *left;
   uint16_t *lists;  // [waves][kSceneListEntries], overlays the P1-only tables
   int *flag;   // [H] point has gradients (set by the cost pass, read by the VJP pass)
@@ -203,12 +213,38 @@ __device__ __forceinline__ bool wrench_add_serialised(const FusedCtx &c, int h, 
 
 // squared-distance penetration of one staged pair (reference sphere_squared_distance_fused,
 // self_collision_helper.cuh:61-71); ij = byte offsets of the two spheres, NaN when either is disabled
-__device__ __forceinline__ float staged_pair_penetration(const float4 *sph, uint32_t ij) {
-  const float4 s1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij & 0xffffu));
-  const float4 s2 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij >> 16));
+__device__ __forceinline__ float sphere_pair_penetration(float4 s1, float4 s2) {  // the same bits whichever sphere comes first
   const float r = s1.w + s2.w;
   const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
   return (r * r) - (dx * dx + dy * dy + dz * dz);
+}
+__device__ __forceinline__ float staged_pair_penetration(const float4 *sph, uint32_t ij) {
+  const float4 s1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij & 0xffffu));
+  const float4 s2 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sph) + (ij >> 16));
+  return sphere_pair_penetration(s1, s2);
+}
+// max of two values that are never signalling NaNs (v_max_f32 returns the other operand for a quiet NaN): without the
+// v_max x, x canonicalisation the compiler puts in front of every fmaxf whose operand it cannot prove quiet
+__device__ __forceinline__ float max_quiet(float a, float b) {
+  float o;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+// wave64 reductions to a scalar: the row, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lane 63 holds
+// the result (no LDS round trip, the result is in an SGPR: branches on it are scalar)
+__device__ __forceinline__ float wave64_max(float v) {
+  v = row16_max(v);
+  int x = __builtin_bit_cast(int, v);
+  x = __builtin_bit_cast(int, fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false))));
+  v = __builtin_bit_cast(float, x);
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false)));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave64_min(int v) {
+  v = row16_min(v);
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ unsigned long long pair_key(float pen, int k) {  // max = largest pen, then lowest k
@@ -218,7 +254,7 @@ __device__ __forceinline__ unsigned long long pair_key(float pen, int k) {  // m
 // the arg-max pair pushes its two spheres apart (reference self_collision_kernel.cuh:84-111)
 __device__ __forceinline__ float self_pair_apply(const FusedCtx &c, int h, float m, int k) {
   const float4 *sph = c.spheres(h);
-  const uint32_t ij = c.pairs[k];
+  const uint32_t ij = c.g_pairs ? (c.g_pairs[k] << 4) : c.pairs[k];
   const int i = (int)((ij & 0xffffu) >> 4), j = (int)(ij >> 20);
   const float4 s1 = sph[i], s2 = sph[j];
   const f3 g = make_f3(c.w_self * (s2.x - s1.x), c.w_self * (s2.y - s1.y), c.w_self * (s2.z - s1.z));
@@ -745,6 +781,8 @@ __device__ __forceinline__ void fused_ctx_carve(FusedCtx &c, float *smem, const 
   c.dyn = smem + lay.dyn;
   c.cstab = smem + lay.cstab;
   c.pairs = reinterpret_cast<uint32_t *>(smem + lay.pairs);
+  c.lanel = reinterpret_cast<const uint32_t *>(smem + lay.lanel);
+  c.g_pairs = nullptr; c.lane_len0 = 0; c.lane_len1 = 0;
   c.recs = reinterpret_cast<ObsRec *>(smem + lay.recs);
   c.H = H; c.D = D; c.L = L; c.S = S; c.P = P; c.ws = lay.ws; c.wl = lay.wl;
 }
@@ -804,7 +842,11 @@ __device__ __forceinline__ void fused_stage_tables(const FusedCtx &c, const Fuse
   // column table of the quad chain of P1 (fk_chain_quad), in the work area (dead until P1 writes the spheres)
   for (int i = rotated_tid(nwaves > 2 ? 2 : 0); i < L * 4; i += nt)
     fk_column_table_entry(reinterpret_cast<float4 *>(c.work), i, a.joint_map_type, a.fixed_transform);
-  if (a.use_self) {  // (i, j) -> byte offsets of the float4 spheres; two loads in flight per thread
+  if (a.use_self && a.lane_lists) {  // lane = sphere form: a straight copy
+    const int n = (a.lane_len0 + a.lane_len1) * 64;
+    uint32_t *dst = const_cast<uint32_t *>(c.lanel);
+    for (int k = tid; k < n; k += nt) dst[k] = a.lane_lists[k];
+  } else if (a.use_self) {  // (i, j) -> byte offsets of the float4 spheres; two loads in flight per thread
     const uint32_t *g_pairs = reinterpret_cast<const uint32_t *>(a.pairs);
     for (int k = tid; k < P; k += 2 * nt) {
       const int k1 = k + nt < P ? k + nt : k;
@@ -920,7 +962,9 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
   const bool use_pose = TERMS && a.use_pose != 0, use_cspace = TERMS && a.use_cspace != 0;
   constexpr int kRings = TERMS ? 1 : 2;  // the TERMS variant has no LDS to spare for the second ring (dense obstacle tests)
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6, kRings);
+  const bool use_lanes = a.lane_lists != nullptr && a.use_self;
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6, kRings,
+                                       use_lanes ? (a.lane_len0 + a.lane_len1) * 64 : 0);
   const int tid = threadIdx.x;
   const int wave_idx = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockDim.x;
@@ -931,6 +975,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const long long t_begin = reorder ? wall_clock64() : 0ll;
   FusedCtx c;
   fused_ctx_carve(c, smem, lay, H, D, L, S, P);
+  if (use_lanes) { c.g_pairs = reinterpret_cast<const uint32_t *>(a.pairs); c.lane_len0 = a.lane_len0; c.lane_len1 = a.lane_len1; }
   c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
 #define CUROBO_STAMP(i) do { if ((!TERMS || kStampTerms) && a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
   CUROBO_STAMP(0);
@@ -1010,7 +1055,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       reinterpret_cast<float4 *>(c.work + (size_t)hh * c.ws)[S] = make_float4(0.f, 0.f, 0.f, __builtin_nanf(""));
   }
   CUROBO_STAMP(10);
-  if (tid == 0) *c.key = 0ull;
+  if (tid == 0) { c.key[0] = 0ull; c.key[1] = 0ull; }  // leftover point: arg-max key of its pair list, ticket for its scene pass
   __syncthreads();
   CUROBO_STAMP(2);
 
@@ -1030,7 +1075,68 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     const float4 *sph = c.spheres(valid ? h : 0);
     float cost_pt = 0.0f;
     bool any_grad = false;  // uniform over the 16-lane row
-    if (a.use_self && valid) {  // reference self_collision_kernel.cuh:19-111
+    if (use_lanes) {
+      // Lane = sphere (reference self_collision_kernel.cuh:19-111, same arg-max).  The wavefront takes its four points
+      // together: a lane keeps its OWN sphere of each point in registers and walks the partners that
+      // curobo_hip_self_lane_lists_host dealt to it -- every pair sits in the list of exactly one of its two spheres,
+      // the lists are balanced (818 Franka pairs: 13 or 14 per lane) -- so a pair costs one ds_read_b128 instead of
+      // two plus its index: this pass was bound by LDS bandwidth.  Only the maximum is tracked; the pair index is
+      // looked for afterwards, and only by points that are in self collision.
+      const int wv = grp >> 2;
+      const char *sp[4];
+      bool ok[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int hr = h0 + r * row_stride + wv;
+        ok[r] = hr < H_main;
+        sp[r] = reinterpret_cast<const char *>(c.spheres(ok[r] ? hr : 0));
+      }
+      float bm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      const uint32_t *ll = c.lanel + lane64;
+      for (int pass = 0; pass < 2; pass++) {
+        const int len = pass == 0 ? c.lane_len0 : c.lane_len1;
+        if (len == 0) continue;
+        const int own_i = pass * 64 + lane64;
+        const int own_off = (own_i < S ? own_i : S) * 16;
+        float4 own[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) own[r] = *reinterpret_cast<const float4 *>(sp[r] + own_off);
+        for (int e = 0; e < len; e++) {
+          const uint32_t off = ll[e * 64] & 0xffffu;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            bm[r] = max_quiet(bm[r], sphere_pair_penetration(own[r], *reinterpret_cast<const float4 *>(sp[r] + off)));
+        }
+        ll += len * 64;
+      }
+      float m_row = 0.0f;
+      int k_row = 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float m = wave64_max(bm[r]);
+        if (m > 0.0f && ok[r]) {  // (wave-uniform) in self collision: lowest pair index of the largest penetration
+          int kb = 0x7fffffff;
+          const uint32_t *l2 = c.lanel + lane64;
+          for (int pass = 0; pass < 2; pass++) {
+            const int len = pass == 0 ? c.lane_len0 : c.lane_len1;
+            const int own_i = pass * 64 + lane64;
+            const float4 own1 = *reinterpret_cast<const float4 *>(sp[r] + (own_i < S ? own_i : S) * 16);
+            for (int e = 0; e < len; e++) {
+              const uint32_t ent = l2[e * 64];
+              const float f = sphere_pair_penetration(own1, *reinterpret_cast<const float4 *>(sp[r] + (ent & 0xffffu)));
+              if (f == m) kb = min(kb, (int)(ent >> 16));
+            }
+            l2 += len * 64;
+          }
+          kb = wave64_min(kb);
+          if ((grp & 3) == r) { m_row = m; k_row = kb; }
+        }
+      }
+      if (valid && k_row != 0x7fffffff && m_row > 0.0f) {
+        any_grad = true;
+        if (lane == 0) cost_pt += self_pair_apply(c, h, m_row, k_row);
+      }
+    } else if (a.use_self && valid) {  // reference self_collision_kernel.cuh:19-111
       // One pass over the padded pair list (no bounds checks; disabled / padding spheres are NaN and
       // lose every max).  Per pair only a v_max; the arg-max is tracked per group of U pairs (one
       // compare per group) and resolved inside the winning group afterwards.
@@ -1076,9 +1182,26 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       const float4 *sphl = c.spheres(H_main);
       float bl = 0.0f;
       int kl = 0x7fffffff;
-      for (int k = grp * kFkLanes + lane; k < P; k += ngroups * kFkLanes) {
-        const float f = staged_pair_penetration(sphl, c.pairs[k]);
-        if (f > bl) { bl = f; kl = k; }
+      if (use_lanes) {  // the list entries of a lane are dealt over the wavefronts
+        const char *spl = reinterpret_cast<const char *>(sphl);
+        const uint32_t *ll = c.lanel + lane64;
+        for (int pass = 0; pass < 2; pass++) {
+          const int len = pass == 0 ? c.lane_len0 : c.lane_len1;
+          const int own_i = pass * 64 + lane64;
+          const float4 own1 = *reinterpret_cast<const float4 *>(spl + (own_i < S ? own_i : S) * 16);
+          for (int e = (grp >> 2); e < len; e += nwaves) {
+            const uint32_t ent = ll[e * 64];
+            const float f = sphere_pair_penetration(own1, *reinterpret_cast<const float4 *>(spl + (ent & 0xffffu)));
+            const int k = (int)(ent >> 16);
+            if (f > bl || (f == bl && f > 0.0f && k < kl)) { bl = f; kl = k; }
+          }
+          ll += len * 64;
+        }
+      } else {
+        for (int k = grp * kFkLanes + lane; k < P; k += ngroups * kFkLanes) {
+          const float f = staged_pair_penetration(sphl, c.pairs[k]);
+          if (f > bl) { bl = f; kl = k; }
+        }
       }
       if (bl > 0.0f) atomicMax(c.key, pair_key(bl, kl));
     }
@@ -1116,10 +1239,19 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   if (fold_left) {
     CUROBO_STAMP(7);
     const int h = H_main;
-    if (a.use_scene && (tid >> 6) == 0) {
-      // wave 0, all 64 lanes on this ONE point (one sphere per lane: the rest of the workgroup waits at the barrier
-      // below for exactly this section); row 0 computes the link masks first
-      if (grp == 0) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
+    // The wavefront that leaves the main round FIRST takes this point (a ticket in LDS), all 64 lanes on it, one
+    // sphere per lane.  The rest of the workgroup waits at the barrier below for the slowest wavefront of the main
+    // round anyway; with a fixed wavefront (it used to be wave 0) that wavefront's rows + this section were the
+    // critical path whenever wave 0 was not among the early ones.  Which wavefront runs it does not change a bit
+    // of the result: it reads and writes this point's slots only.
+    int ticket = 1;
+    if (a.use_scene) {
+      if (lane64 == 0) ticket = atomicAdd(reinterpret_cast<int *>(c.key) + 2, 1);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+    }
+    if (a.use_scene && ticket == 0) {
+      // the wave's first row computes the link masks
+      if ((grp & 3) == 0) point_link_masks<SWEEP, KINDS>(c, a.sc, h, lane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const float *wr = c.wrench + (size_t)h * c.wl;
@@ -1143,10 +1275,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       x += __shfl(cost_scene, lane + 32, 64);
       x += __shfl(cost_scene, lane + 48, 64);
       cost_scene = row16_sum(x);
-      if (tid == 0) { c.cost[h] = cost_scene; c.flag[h] = any_scene ? 1 : 0; }
-    } else if (tid == 0) {
-      c.cost[h] = 0.0f;
-      c.flag[h] = 0;
+      if (lane64 == 0) { c.cost[h] = cost_scene; c.flag[h] = any_scene ? 1 : 0; }
     }
     if (!a.use_scene && tid == 0) { c.cost[h] = 0.0f; c.flag[h] = 0; }
   }
@@ -1159,7 +1288,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       float best = 0.0f;
       int best_k = 0x7fffffff;
       for (int k = tid; k < P; k += nt) {
-        const float f = staged_pair_penetration(sph, c.pairs[k]);
+        const float f = staged_pair_penetration(sph, c.g_pairs ? (c.g_pairs[k] << 4) : c.pairs[k]);
         if (f > best) { best = f; best_k = k; }
       }
       if (best > 0.0f) atomicMax(c.key, pair_key(best, best_k));  // integer max: order independent
@@ -1473,14 +1602,14 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_
 // through the per-wave scene lists): 8 waves when two workgroups then fit in a CU's LDS, see the
 // kernel's header; else one row per point up to 16 waves
 static FusedLayout trajectory_launch_shape(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn, int *threads_out,
-                                           int rings = 1) {
+                                           int rings = 1, int n_lane = 0) {
   int threads = ((H * kFkLanes + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
-  if (threads > 512 && (size_t)fused_layout(H, D, L, S, C, P, n_rec, n_dyn, 8, rings).total * sizeof(float) <= 80 * 1024) threads = 512;
+  if (threads > 512 && (size_t)fused_layout(H, D, L, S, C, P, n_rec, n_dyn, 8, rings, n_lane).total * sizeof(float) <= 80 * 1024) threads = 512;
   static const int force_threads = [] { const char *e = getenv("CUROBO_HIP_FUSED_THREADS"); return e ? atoi(e) : 0; }();
   if (force_threads >= 64 && force_threads <= 1024) threads = force_threads & ~63;  // tuning knob
   *threads_out = threads;
-  return fused_layout(H, D, L, S, C, P, n_rec, n_dyn, threads >> 6, rings);
+  return fused_layout(H, D, L, S, C, P, n_rec, n_dyn, threads >> 6, rings, n_lane);
 }
 
 CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horizon, int dof, int num_links,
@@ -1505,7 +1634,8 @@ static int rollout_trajectory_fused_impl(
     const float *scene_collision_weight, const float *activation_distance, const float *speed_dt,
     const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof,
     int n_knots, int bspline_degree, int num_links, int num_spheres, int num_collision_pairs, int link_chain_len,
-    int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws, int dispatch_phase, curobo_hip_stream_t stream) {
+    int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws, int dispatch_phase, const uint32_t *self_lane_lists,
+    int self_lane_len, curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(bspline_degree >= 3 && bspline_degree <= 5, "%s: bspline_degree must be 3, 4 or 5", what);
   CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && padded_horizon >= 2 && n_knots >= 1,
@@ -1537,6 +1667,12 @@ static int rollout_trajectory_fused_impl(
   if (g_fused_prof_seq && g_fused_prof_next < g_fused_prof_blocks && batch_size <= g_fused_prof_rows)
     a.prof = g_fused_prof_seq + (size_t)g_fused_prof_next++ * g_fused_prof_rows * 16;
   a.dispatch_ws = dispatch_ws; a.dispatch_phase = dispatch_phase;
+  static const bool no_lanes = getenv("CUROBO_HIP_SELF_ROWS") != nullptr;  // development knob: the row form of the pair pass
+  if (self_lane_lists && a.use_self && !no_lanes) {
+    a.lane_lists = self_lane_lists; a.lane_len0 = self_lane_len & 0xffff; a.lane_len1 = (self_lane_len >> 16) & 0xffff;
+    CUROBO_REQUIRE(a.lane_len0 + a.lane_len1 > 0 && num_spheres <= 128 && num_collision_pairs < 65535,
+                   "%s: self_lane_lists does not describe this robot (curobo_hip_self_lane_lists_host)", what);
+  }
   static const int scene_rows = [] { const char *e = getenv("CUROBO_HIP_SCENE_ROWS"); return e ? atoi(e) : 0; }();
   a.scene_rows = scene_rows;
   CUROBO_REQUIRE(!dispatch_ws || dispatch_phase == 0 || dispatch_phase == 1, "%s: dispatch_phase must be 0 or 1", what);
@@ -1599,7 +1735,8 @@ static int rollout_trajectory_fused_impl(
   static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;
   const bool with_terms = a.use_pose || a.use_cspace || force_terms;  // the TERMS instantiation: one scene ring per wave
   const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2);
+                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2,
+                                                  a.lane_lists ? (a.lane_len0 + a.lane_len1) * 64 : 0);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   CUROBO_REQUIRE(!a.use_torque || fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres),
@@ -1672,7 +1809,7 @@ CUROBO_EXPORT int curobo_hip_rollout_dispatch_ws_init(int32_t *dispatch_ws, int 
       const float *speed_dt, const int32_t *env_query_idx, int num_envs, int use_multi_env, int batch_size,           \
       int padded_horizon, int dof, int n_knots, int bspline_degree, int num_links, int num_spheres,                   \
       int num_collision_pairs, int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,    \
-      int dispatch_phase
+      int dispatch_phase, const uint32_t *self_lane_lists, int self_lane_len
 #define CUROBO_TRAJ_ARGS                                                                                              \
   out_cost, out_grad_knots, out_position, out_robot_spheres, u_position, start_position, start_velocity,             \
       start_acceleration, start_jerk, goal_position, goal_velocity, goal_acceleration, goal_jerk, start_idx, goal_idx, \
@@ -1680,7 +1817,88 @@ CUROBO_EXPORT int curobo_hip_rollout_dispatch_ws_init(int32_t *dispatch_ws, int 
       link_sphere_map, link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight,  \
       pair_locations, scene, scene_collision_weight, activation_distance, speed_dt, env_query_idx, num_envs,          \
       use_multi_env, batch_size, padded_horizon, dof, n_knots, bspline_degree, num_links, num_spheres,                \
-      num_collision_pairs, link_chain_len, sweep_steps, enable_speed_metric, dispatch_ws, dispatch_phase
+      num_collision_pairs, link_chain_len, sweep_steps, enable_speed_metric, dispatch_ws, dispatch_phase, self_lane_lists,   \
+      self_lane_len
+
+// The pair list dealt to lanes (lane = sphere form of the self-collision pass of the fused kernels): every pair (i, j)
+// is given to ONE of its two spheres so that the longest list is as short as possible (a b-matching, found with
+// augmenting paths); sphere s is owned by lane s % 64 of pass s / 64.  out_lists_host [(len0 + len1) * 64] words,
+// word (e, lane) = partner byte offset (16 j) | pair index << 16, lists in ascending pair index, padded with the NaN
+// sphere behind the last one (16 S) | 0xffff << 16.  Returns len0 | len1 << 16 (pass the value on as self_lane_len),
+// 0 when this robot is outside the form (more than 128 spheres, 65535 pairs or `capacity_words`), < 0 on bad arguments.
+// HOST pointers: call once per robot, copy out_lists_host to the device.
+CUROBO_EXPORT int curobo_hip_self_lane_lists_host(uint32_t *out_lists_host, int capacity_words, const int16_t *pair_locations_host,
+                                                  int num_collision_pairs, int num_spheres) {
+  const char *what = "self_lane_lists_host";
+  if (!out_lists_host || !pair_locations_host || num_collision_pairs <= 0 || num_spheres <= 0) {
+    set_error(CUROBO_HIP_ERR_INVALID, "%s: bad arguments", what);
+    return -1;
+  }
+  const int P = num_collision_pairs, S = num_spheres;
+  if (S > 128 || P >= 65535 || P > 16384) return 0;
+  for (int k = 0; k < P; k++) {
+    const int i = pair_locations_host[2 * k], j = pair_locations_host[2 * k + 1];
+    if (i < 0 || j < 0 || i >= S || j >= S) { set_error(CUROBO_HIP_ERR_INVALID, "%s: pair %d out of range", what, k); return -1; }
+  }
+  std::vector<int> owner(P), load(S), cap(S), seen(S);
+  std::vector<std::vector<int>> owned(S);
+  auto other = [&](int k, int x) { const int i = pair_locations_host[2 * k], j = pair_locations_host[2 * k + 1]; return x == i ? j : i; };
+  // free one slot of sphere x by moving one of its pairs to that pair's other sphere (recursively)
+  std::function<bool(int)> make_room = [&](int x) -> bool {
+    for (size_t n = 0; n < owned[x].size(); n++) {
+      const int k2 = owned[x][n], y = other(k2, x);
+      if (y == x || seen[y]) continue;
+      seen[y] = 1;
+      if (load[y] < cap[y] || make_room(y)) {
+        owned[x].erase(owned[x].begin() + (long)n);
+        load[x]--;
+        owned[y].push_back(k2);
+        load[y]++;
+        owner[k2] = y;
+        return true;
+      }
+    }
+    return false;
+  };
+  auto feasible = [&](int c0, int c1) -> bool {
+    for (int x = 0; x < S; x++) { cap[x] = x < 64 ? c0 : c1; load[x] = 0; owned[x].clear(); }
+    for (int k = 0; k < P; k++) {
+      const int e[2] = {pair_locations_host[2 * k], pair_locations_host[2 * k + 1]};
+      int x = -1;
+      // the emptier of the two spheres when it has room, else make room at either
+      const int a0 = load[e[0]] <= load[e[1]] ? e[0] : e[1], a1 = a0 == e[0] ? e[1] : e[0];
+      if (load[a0] < cap[a0]) x = a0;
+      else if (load[a1] < cap[a1]) x = a1;
+      else {
+        for (int t = 0; t < 2 && x < 0; t++) {
+          std::fill(seen.begin(), seen.end(), 0);
+          seen[e[0]] = seen[e[1]] = 1;
+          if (cap[e[t]] > 0 && make_room(e[t])) x = e[t];
+        }
+      }
+      if (x < 0) return false;
+      owned[x].push_back(k);
+      load[x]++;
+      owner[k] = x;
+    }
+    return true;
+  };
+  int len0 = -1, len1 = -1;
+  const int lower = (P + 63) / 64;
+  for (int total = lower; total <= P && len0 < 0; total++)
+    for (int c1 = 0; c1 <= (S > 64 ? total : 0) && len0 < 0; c1++)
+      if (feasible(total - c1, c1)) { len0 = total - c1; len1 = c1; }
+  if (len0 < 0 || len0 > 0xffff || len1 > 0xffff || (len0 + len1) * 64 > capacity_words) return 0;
+  const uint32_t pad = (uint32_t)(S * 16) | (0xffffu << 16);
+  for (int w = 0; w < (len0 + len1) * 64; w++) out_lists_host[w] = pad;
+  for (int x = 0; x < S; x++) {
+    std::sort(owned[x].begin(), owned[x].end());
+    const int base = x < 64 ? 0 : len0, lane = x & 63;
+    for (size_t n = 0; n < owned[x].size(); n++)
+      out_lists_host[(size_t)(base + (int)n) * 64 + lane] = (uint32_t)(other(owned[x][n], x) * 16) | ((uint32_t)owned[x][n] << 16);
+  }
+  return len0 | (len1 << 16);
+}
 
 CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused(CUROBO_TRAJ_PARAMS, curobo_hip_stream_t stream) {
   return rollout_trajectory_fused_impl("rollout_trajectory_fused", nullptr, CUROBO_TRAJ_ARGS, stream);

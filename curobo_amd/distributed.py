@@ -86,7 +86,13 @@ def global_argmin(cost: torch.Tensor, payload: torch.Tensor, seed_offset: int,
     """Best (cost[P], global_seed_idx[P], payload[P, V]) over the seeds of ALL ranks.
 
     Works unchanged without an initialised process group (world size 1)."""
-    row = local_best(cost, payload, seed_offset)
+    return global_argmin_of_rows(local_best(cost, payload, seed_offset), group)
+
+
+def global_argmin_of_rows(row: torch.Tensor, group: Optional[dist.ProcessGroup] = None
+                          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """the exchange stage of ``global_argmin`` for callers that ran ``local_best`` themselves (e.g. captured behind the
+    optimiser iterations in one hipGraph): packed rows [P, 2 + V] of this rank -> the winner over all ranks"""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return row[:, 0], row[:, 1].to(torch.int64), row[:, 2:]  # alone: the local best is the answer
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -204,15 +204,20 @@ class LBFGSOpt:
             t.copy_(s)
         torch.cuda.synchronize(self.device)
 
-    def make_graph(self, n_iters: int) -> "torch.cuda.CUDAGraph":
-        """a hipGraph of ``n_iters`` iterations (optimiser state is restored after the capture)"""
+    def make_graph(self, n_iters: int, after=None) -> "torch.cuda.CUDAGraph":
+        """a hipGraph of ``n_iters`` iterations (optimiser state is restored after the capture); ``after`` (optional callable)
+        is captured behind them"""
         saved = [t.clone() for t in self._state_tensors()]
         self._opt_step()  # warm-up outside the capture
+        if after is not None:
+            after()
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(n_iters):
                 self._opt_step()
+            if after is not None:
+                after()
         for t, s in zip(self._state_tensors(), saved):
             t.copy_(s)
         torch.cuda.synchronize(self.device)

@@ -81,14 +81,19 @@ class PipelinedLBFGS:
                 t.copy_(s)
         torch.cuda.synchronize(self.device)
 
-    def make_graph(self, n_iters: int) -> "torch.cuda.CUDAGraph":
-        """a hipGraph of ``n_iters`` iterations of every shard (state is restored after the capture)"""
+    def make_graph(self, n_iters: int, after: Optional[Callable[[], None]] = None) -> "torch.cuda.CUDAGraph":
+        """a hipGraph of ``n_iters`` iterations of every shard (state is restored after the capture); ``after`` is captured
+        behind the join of the shards (e.g. the local stage of an arg-min exchange: one replay = iterations + reduction)"""
         saved = [[t.clone() for t in o._state_tensors()] for o in self.opts]
         self.step()
+        if after is not None:
+            after()  # warm-up outside the capture
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._forked(lambda o: [o._opt_step() for _ in range(n_iters)])
+            if after is not None:
+                after()
         for o, sv in zip(self.opts, saved):
             for t, s in zip(o._state_tensors(), sv):
                 t.copy_(s)

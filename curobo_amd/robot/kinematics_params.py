@@ -109,6 +109,9 @@ class KinematicsParams:
             sphere_padding=up(model.sphere_padding, torch.float32),
             collision_pairs=up(model.collision_pairs, torch.int16),
         )
+        from ..backends.rollout import attach_self_lane_lists
+
+        attach_self_lane_lists(sc.collision_pairs, model.num_spheres)  # (host work, once per robot: see the function)
         depth, levels = [], {}
         for k, par in enumerate([int(x) for x in model.link_map]):
             d = 0 if (par < 0 or par == k) else depth[par] + 1

@@ -470,7 +470,7 @@ int curobo_hip_mppi_update_distribution(
  * intermediates stay in LDS.  out_position [b, h, dof] and out_robot_spheres [b, h, s, 4] are
  * optional (NULL = not materialised).  pair_locations / self_collision_weight NULL = no self
  * collision term; scene / scene_collision_weight NULL = no scene term.  Returns
- * CUROBO_HIP_ERR_ARG when one trajectory's working set does not fit in 160 KB of LDS (use the
+ * CUROBO_HIP_ERR_INVALID when one trajectory's working set does not fit in 160 KB of LDS (use the
  * unfused entry points then). */
 int curobo_hip_rollout_trajectory_fused(
     float *out_cost, float *out_grad_knots, float *out_position, float *out_robot_spheres,
@@ -488,7 +488,17 @@ int curobo_hip_rollout_trajectory_fused(
     int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,
-    int dispatch_phase, curobo_hip_stream_t stream);
+    int dispatch_phase, const uint32_t *self_lane_lists, int self_lane_len, curobo_hip_stream_t stream);
+
+/* The pair list of a robot dealt to lanes, for the self-collision pass of the fused trajectory kernels (optional:
+ * self_lane_lists NULL = the pass walks pair_locations as the reference kernel does, self_collision_kernel.cuh:19-111).
+ * Every pair is given to one of its two spheres so that the longest per-sphere list is as short as possible; a lane
+ * then keeps its own sphere in registers and reads one partner per pair.  Same arg-max, same bits.  HOST pointers in,
+ * HOST words out ((len0 + len1) * 64 of them; 64 * (num_collision_pairs / 64 + 2) words of capacity always suffice for
+ * robots of up to 64 spheres); the return value (len0 | len1 << 16) is the self_lane_len argument; 0 = this robot is
+ * outside the form (pass NULL); < 0 = bad arguments.  Copy the words to the device once per robot. */
+int curobo_hip_self_lane_lists_host(uint32_t *out_lists_host, int capacity_words, const int16_t *pair_locations_host,
+                                    int num_collision_pairs, int num_spheres);
 
 /* Longest-first dispatch workspace of the fused trajectory kernels (optional; no reference
  * counterpart: the reference launches one thread per sphere, its work per thread block is
@@ -552,7 +562,8 @@ int curobo_hip_rollout_trajopt_fused(
     int num_envs, int use_multi_env, int batch_size, int padded_horizon, int dof, int n_knots,
     int bspline_degree, int num_links, int num_spheres, int num_collision_pairs,
     int link_chain_len, int sweep_steps, int enable_speed_metric, int32_t *dispatch_ws,
-    int dispatch_phase, const curobo_hip_trajopt_terms *terms, curobo_hip_stream_t stream);
+    int dispatch_phase, const uint32_t *self_lane_lists, int self_lane_len, const curobo_hip_trajopt_terms *terms,
+    curobo_hip_stream_t stream);
 
 /* 1 if the torque-limit terms fit (they borrow LDS regions that are dead when the inverse dynamics runs) */
 int curobo_hip_rollout_trajopt_fused_torque_fits(

@@ -206,3 +206,37 @@ def test_pair_bitmap_and_tile_list_of_the_dense_self_collision_entry():
     assert G.pair_bitmap(unsorted, S) is None
     swapped = torch.tensor([(5, 2)], dtype=torch.int16)
     assert G.pair_bitmap(swapped, S) is None
+
+
+def test_self_lane_lists_host_deals_every_pair_once():
+    """curobo_hip_self_lane_lists_host (pure host code): every pair of the packaged robots lands in the list of exactly one of
+    its two spheres, lists are as short as a perfect balance allows (+1), padding points at the NaN sphere; robots
+    outside the form return 0"""
+    import numpy as np
+    import torch
+
+    from curobo_amd.backends.rollout import attach_self_lane_lists
+    from curobo_amd.robot import load_packaged_robot
+
+    for name, expect in (("franka", True), ("ur10e", True), ("unitree_g1", False)):
+        m = load_packaged_robot(name)
+        pairs = torch.as_tensor(np.asarray(m.collision_pairs)).to(torch.int16).contiguous()
+        attach_self_lane_lists(pairs, m.num_spheres)
+        got = getattr(pairs, "_self_lane_lists", None)
+        assert (got is not None) == expect, name
+        if got is None:
+            continue
+        words, code = got
+        len0, len1 = code & 0xffff, code >> 16
+        S, P = m.num_spheres, pairs.shape[0]
+        owners = min(S, 64)
+        assert len1 == 0 and len0 <= -(-P // owners) + 1
+        w = words.numpy().astype(np.uint32).reshape(len0 + len1, 64)
+        pad = np.uint32((S * 16) | (0xffff << 16))
+        live = w != pad
+        k = (w >> 16)[live]
+        assert np.array_equal(np.sort(k), np.arange(P))
+        lane = np.broadcast_to(np.arange(64), w.shape)[live]
+        partner = ((w & 0xffff) // 16)[live]
+        pn = pairs.numpy()
+        assert all({int(a), int(b)} == {int(pn[kk, 0]), int(pn[kk, 1])} for a, b, kk in zip(lane, partner, k))

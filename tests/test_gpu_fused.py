@@ -369,3 +369,29 @@ def test_fused_world_with_analytic_primitives(oracle, device):
     np.testing.assert_allclose(cost.cpu().numpy(), ref["cost"], rtol=1e-4, atol=1e-2)
     gk = ref["grad_knots"].reshape(knots.shape[0], -1)
     np.testing.assert_allclose(grad.cpu().numpy(), gk, rtol=2e-3, atol=2e-5 * np.abs(gk).max())
+
+
+@pytest.mark.parametrize("robot,n_left", [("franka", 1), ("ur10e", 1), ("franka", 0)])
+def test_self_collision_lane_lists_change_no_bit(device, robot, n_left):
+    """the lane = sphere form of the self-collision pass (pair list dealt to lanes, curobo_hip_self_lane_lists_host) against
+    the row form that walks pair_locations: same maxima, same arg-max pair -> bit-identical cost and gradient; with and
+    without a leftover point (padded horizon 33 on 32 rows; 31 on 32 rows)"""
+    kw = dict(use_scene_collision=False) if n_left else dict(use_scene_collision=False, n_knots=10, interpolation_steps=2, bspline_degree=4)
+    model, _, knots, _, _, ro = _pair(device, robot=robot, seeds=24, **kw)
+    pairs = ro.kin.self_collision.collision_pairs
+    lanes = getattr(pairs, "_self_lane_lists", None)
+    assert lanes is not None, "KinematicsParams.from_model deals the pair list to lanes"
+    code = lanes[1]
+    assert ((code & 0xffff) + (code >> 16)) * 64 == lanes[0].numel()
+    x = torch.as_tensor(knots, device=device).reshape(knots.shape[0], -1)
+    # push the arm into itself so that many points are in self collision
+    x = x * 1.6
+    c1, g1 = [t.clone() for t in ro.cost_and_gradient(x)]
+    del pairs._self_lane_lists
+    try:
+        c0, g0 = [t.clone() for t in ro.cost_and_gradient(x)]
+    finally:
+        pairs._self_lane_lists = lanes
+    torch.cuda.synchronize()
+    assert float((c0 > 0).float().mean()) > 0.3
+    assert torch.equal(c0, c1) and torch.equal(g0, g1)
