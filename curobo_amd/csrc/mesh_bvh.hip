@@ -261,15 +261,21 @@ __device__ __forceinline__ void activation_m(float dist, float eta, float &cost,
   else { cost = 0.5f * dist * dist / eta; gscale = dist / eta; }
 }
 
-__device__ __forceinline__ float mesh_eval_point(const curobo_hip_mesh &m, f3 lp, float max_distance, float r_adj, float eta,
-                                                 float &cost_sum, f3 &grad_sum, int gradient_mode) {
-  f3 g;
+__device__ __forceinline__ float mesh_point_terms(const curobo_hip_mesh &m, f3 lp, float max_distance, float r_adj, float eta,
+                                                  float &c, float &gs, f3 &g, int gradient_mode) {
   const float sdf = mesh_sdf_with_grad(m, lp, max_distance, g);
   if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
   const float pen = -sdf + r_adj;
+  c = 0.0f; gs = 0.0f;
+  if (pen > 0.0f) activation_m(pen, eta, c, gs);
+  return pen;
+}
+__device__ __forceinline__ float mesh_eval_point(const curobo_hip_mesh &m, f3 lp, float max_distance, float r_adj, float eta,
+                                                 float &cost_sum, f3 &grad_sum, int gradient_mode) {
+  f3 g;
+  float c, gs;
+  const float pen = mesh_point_terms(m, lp, max_distance, r_adj, eta, c, gs, g, gradient_mode);
   if (pen > 0.0f) {
-    float c, gs;
-    activation_m(pen, eta, c, gs);
     cost_sum += c;
     grad_sum = grad_sum + gs * g;
   }
@@ -318,7 +324,10 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
       const f3 lc = quat_rot(qw, qx, qy, qz, center) + t;
       float cost_sum = 0.0f;
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
-      mesh_eval_point(m, lc, max_distance, r_adj, eta, cost_sum, grad_local, ms.gradient_mode);
+      f3 g_c;
+      float c_c, gs_c;
+      const float pen_c = mesh_point_terms(m, lc, max_distance, r_adj, eta, c_c, gs_c, g_c, ms.gradient_mode);
+      if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; }
       if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
 #pragma unroll 1
         for (int dir = 0; dir < 2; dir++) {
@@ -328,7 +337,12 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
           const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
           const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
           float jump = 0.0f;
-          for (int k = 0; k < SWEEP; k++) {
+          if (jump >= half_dist) continue;
+          // k = 0 of the reference's loop samples t = 1, the centre itself: its terms are added again, not walked again
+          if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; jump += pen_c; }
+          else if (-pen_c >= 1000.0f) jump += r_adj;
+          else jump += fmaxf(-pen_c, r_adj);
+          for (int k = 1; k < SWEEP; k++) {
             if (jump >= half_dist) break;
             const float tt = 1.0f - 0.5f * jump * inv_half;
             const f3 lp = tt * lc + (1.0f - tt) * ln;

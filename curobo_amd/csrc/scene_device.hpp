@@ -198,18 +198,27 @@ __device__ __forceinline__ float voxel_sdf(const curobo_hip_scene &sc, int flat_
   return sdf;
 }
 
+// penetration of one sample + its cost c and gradient scale gs * direction g (both 0 when it does not penetrate)
 template <bool VOXEL, bool PRIMS = false>
-__device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat, const ObsRec &rec, f3 lp, float r_adj,
-                                            float eta, float &cost_sum, f3 &grad_sum) {
-  f3 g;
+__device__ __forceinline__ float point_terms(const curobo_hip_scene &sc, int flat, const ObsRec &rec, f3 lp, float r_adj,
+                                             float eta, float &c, float &gs, f3 &g) {
   float sdf;
   if (VOXEL) sdf = voxel_sdf(sc, flat, rec.shape, lp, g);
   else if (PRIMS && rec.shape.w != 0.0f) sdf = primitive_sdf(rec, lp, true, r_adj, g);
   else sdf = cuboid_sdf(rec.shape, lp, true, r_adj, g);
   const float pen = -sdf + r_adj;
+  c = 0.0f; gs = 0.0f;
+  if (pen > 0.0f) activation(pen, eta, c, gs);
+  return pen;
+}
+
+template <bool VOXEL, bool PRIMS = false>
+__device__ __forceinline__ float eval_point(const curobo_hip_scene &sc, int flat, const ObsRec &rec, f3 lp, float r_adj,
+                                            float eta, float &cost_sum, f3 &grad_sum) {
+  f3 g;
+  float c, gs;
+  const float pen = point_terms<VOXEL, PRIMS>(sc, flat, rec, lp, r_adj, eta, c, gs, g);
   if (pen > 0.0f) {
-    float c, gs;
-    activation(pen, eta, c, gs);
     cost_sum += c;
     grad_sum = grad_sum + gs * g;
   }
@@ -260,7 +269,13 @@ template <bool VOXEL, int SWEEP, bool PRIMS = false>
 __device__ __forceinline__ void obstacle_contribution(const curobo_hip_scene &sc, const ObsRec &rec, int flat, f3 lc,
                                                       bool has_prev, bool has_next, f3 prev_c, f3 next_c, float r_adj, float eta,
                                                       float half_w_prev, float half_w_next, float &cost_sum, f3 &grad_local) {
-  const float pen_c = eval_point<VOXEL, PRIMS>(sc, flat, rec, lc, r_adj, eta, cost_sum, grad_local);
+  f3 g_c;
+  float c_c, gs_c;
+  const float pen_c = point_terms<VOXEL, PRIMS>(sc, flat, rec, lc, r_adj, eta, c_c, gs_c, g_c);
+  if (pen_c > 0.0f) {
+    cost_sum += c_c;
+    grad_local = grad_local + gs_c * g_c;
+  }
   if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
     // outside a voxel grid the SDF is the constant max_dist: no bound across the grid face
     const float sdf_c = r_adj - pen_c;
@@ -279,14 +294,26 @@ __device__ __forceinline__ void obstacle_contribution(const curobo_hip_scene &sc
         const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
         const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
         float jump = 0.0f;
-        for (int k = 0; k < SWEEP; k++) {
-          if (jump >= half_dist) break;
-          const float tt = 1.0f - 0.5f * jump * inv_half;
-          const f3 lp = tt * lc + (1.0f - tt) * ln;
-          const float p2 = eval_point<VOXEL, PRIMS>(sc, flat, rec, lp, r_adj, eta, cost_sum, grad_local);
-          if (p2 > 0.0f) jump += p2;
-          else if (-p2 >= 1000.0f) jump += r_adj;
-          else jump += fmaxf(-p2, r_adj);
+        // The reference's first sample of a direction (k = 0) sits at jump = 0, i.e. t = 1: the centre itself
+        // (lp = 1 * lc + 0 * ln).  Its signed distance, cost and gradient are the centre sample's, bit for bit, so they
+        // are added again instead of being evaluated again (for an ESDF: eight gathers fewer, per direction, at the
+        // head of the serial chain of the sweep).
+        if (!(jump >= half_dist)) {
+          if (pen_c > 0.0f) {
+            cost_sum += c_c;
+            grad_local = grad_local + gs_c * g_c;
+            jump += pen_c;
+          } else if (-pen_c >= 1000.0f) jump += r_adj;
+          else jump += fmaxf(-pen_c, r_adj);
+          for (int k = 1; k < SWEEP; k++) {
+            if (jump >= half_dist) break;
+            const float tt = 1.0f - 0.5f * jump * inv_half;
+            const f3 lp = tt * lc + (1.0f - tt) * ln;
+            const float p2 = eval_point<VOXEL, PRIMS>(sc, flat, rec, lp, r_adj, eta, cost_sum, grad_local);
+            if (p2 > 0.0f) jump += p2;
+            else if (-p2 >= 1000.0f) jump += r_adj;
+            else jump += fmaxf(-p2, r_adj);
+          }
         }
       }
     }
