@@ -1033,8 +1033,8 @@ def c4_benchmark(device, torch):
     }
     res["kernels"] = _timed_stages(stages, torch, reps=2)
     k = res["kernels"]["self_collision_tiled"]
-    cr = counter_roofline("self_collision_tiles_kernel", 0, k["us"], units=N)
-    res["roofline"] = {"bound": "hbm", "kernel": "self_collision_tiles_kernel (pair bitmap, broad phase over 16 x 16 tiles, 162 k pairs)",
+    cr = counter_roofline("self_collision_tiles", 0, k["us"], units=N)
+    res["roofline"] = {"bound": "hbm", "kernel": "self_collision_tiles2_kernel (pair bitmap, two-level broad phase: 16- and 4-sphere boxes, 4 waves per point, 162 k pairs)",
                        "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["hbm_frac"], "traffic": cr.get("traffic"),
                        "avg_launch_us": k["us"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
                        "listed_pair_tests_per_s": round(P * N / k["us"] * 1e6, 1),
@@ -1045,8 +1045,8 @@ def c4_benchmark(device, torch):
                        **({"primary_bound": cr["valu"], "counters_source": cr["counters_source"], "l2_hit_rate": cr.get("l2_hit_rate")}
                           if "valu" in cr else {})}
     res["kernel_counters"] = _stage_counters(res["kernels"], {
-        "fk_forward_spheres": "fk_forward_kernel", "self_collision_tiled": "self_collision_tiles_kernel", "rnea_forward": "rnea_forward_kernel",
-        "rnea_backward": "rnea_backward_kernel", "fk_backward": "fk_backward_kernel"}, N)
+        "fk_forward_spheres": "fk_forward_kernel", "self_collision_tiled": "self_collision_tiles", "rnea_forward": "rnea_forward",
+        "rnea_backward": "rnea_backward", "fk_backward": "fk_backward_kernel"}, N)
     return res
 
 

@@ -4,7 +4,7 @@ target of the rocprofv3 counter passes of tools/collect_profiles_r03.sh.  Worklo
   c2   Franka, 256 seeds x 4 candidates x 33 points, 4-cuboid world: the drop-in kernel sequence, the fused launch
        (1024 and 256 trajectories), the optimiser's iteration tail (workgroup and wavefront form)
   c3   UR10e, 512 x 4 x 33, 128^3 fp16 ESDF: FK, self, scene_collision_packed_kernel, FK VJP, the fused launch
-  c4   Unitree G1, 256 x 4 x 33: FK, self_collision_tiles_kernel, RNEA forward / backward, c-space cost, FK VJP
+  c4   Unitree G1, 256 x 4 x 33: FK, self_collision_tiles2_kernel, RNEA forward (staged kernels) / backward, c-space cost, FK VJP
   c5   Franka, 2 worlds (cuboids + 64^3 ESDF) x 512 x 4 x 65: the fused multi-env launch, the swept scene kernel
 
 Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [--reps N]
