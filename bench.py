@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget per leg")
     ap.add_argument("--graph-iters", type=int, default=25,
                     help="L-BFGS iterations per captured graph (the reference's inner_iters, lbfgs_bspline_trajopt.yml)")
+    ap.add_argument("--graph-lead", type=int, default=5,
+                    help="iterations of the short first graph of a run of steps (0 = none): see step_chunks()")
     ap.add_argument("--no-fused", action="store_true",
                     help="drop-in kernel sequence (7 launches per rollout) instead of the fused rollout kernel")
     ap.add_argument("--shards", type=int, default=4,
@@ -289,6 +291,22 @@ def main():
     G = args.graph_iters
     rem_graphs = {}
 
+    def step_chunks(k):
+        """how k iterations are enqueued: a SHORT first graph, then graphs of up to --graph-iters iterations.  The launch of
+        a four-branch graph costs host time in proportion to its nodes before its first kernel runs (~250 us for the 160
+        nodes of 20 iterations: measured by fitting T(K) = K s + F); behind a 5-iteration lead-in that time is spent while
+        the GPU already works, and only the lead-in's own launch is exposed.  More, smaller graphs lose again (every replay
+        adds a fork / join of the four streams): measured 71.4 us per step for [20], 65.9 for [5, 15], 68.9 for [5, 5, 10],
+        70.7 for [1, 2, 4, 13] at the driver's command."""
+        lead = min(args.graph_lead, k // 4) if k > args.graph_lead else 0
+        out = [lead] if lead > 0 else []
+        k -= lead
+        while k > 0:
+            n = min(G, k)
+            out.append(n)
+            k -= n
+        return out
+
     def run_steps(k):
         """exactly k optimiser iterations"""
         one = opt.step if shards > 1 else opt._opt_step
@@ -296,12 +314,13 @@ def main():
             for _ in range(k):
                 one()
             return
-        for _ in range(k // G):
-            opt.run_inner()
-        if k % G:  # remainder: its own (cached) graph, so any step count runs at replay speed
-            if k % G not in rem_graphs:
-                rem_graphs[k % G] = opt.make_graph(k % G)
-            rem_graphs[k % G].replay()
+        for n in step_chunks(k):
+            if n == G:
+                opt.run_inner()
+                continue
+            if n not in rem_graphs:  # its own (cached) graph, so any step count runs at replay speed
+                rem_graphs[n] = opt.make_graph(n)
+            rem_graphs[n].replay()
 
     def sync_all():
         torch.cuda.synchronize()
