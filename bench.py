@@ -68,7 +68,7 @@ def parse_args():
                     help="seed shards of the optimiser on separate HIP streams of the GPU (1 = one batch, one stream)")
     ap.add_argument("--no-ik", action="store_true", help="skip the secondary solver measurements (IK, trajopt solve)")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 single-GPU shares")
-    ap.add_argument("--only", default="", help="comma list of secondary objects to run (c3,c4,c5,ik,fixed); default all")
+    ap.add_argument("--only", default="", help="comma list of secondary objects to run (c3,c4,c5,mesh,ik,fixed); default all")
     ap.add_argument("--ik-problems", type=int, default=100)
     ap.add_argument("--ik-seeds", type=int, default=64)
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
@@ -424,6 +424,8 @@ def main():
                 guarded("c4_humanoid_share", lambda: c4_benchmark(device, torch))
             if want("c5") and not args.no_configs:
                 guarded("c5_batch_planner_share", lambda: c5_benchmark(model, kin, device, torch))
+            if want("mesh") and not args.no_configs:
+                guarded("mesh_world", lambda: mesh_benchmark(model, kin, device, torch))
             if want("ik") and not args.no_ik:
                 guarded("ik", lambda: ik_benchmark(args, model, kin, device, torch))
                 guarded("full_trajopt_rollout", lambda: full_trajopt_benchmark(seeds, model, kin, scene, device, torch))
@@ -879,6 +881,88 @@ def _timed_stages(stages, torch, reps=5):
         res[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / us * 1e-3, 1),
                      "hbm_frac": round(nbytes / us * 1e-3 / HBM_PEAK_GBS, 4)}
     return res
+
+
+def mesh_benchmark(model, kin, device, torch):
+    """Mesh obstacles: the C2 world with every cuboid handed over as a triangle mesh (12 288 triangles in all:
+    each box face subdivided) + a torus, 1024 trajectories x 33 points of robot spheres: the mesh launch
+    (curobo_hip_sphere_mesh_collision, BVH walk per sphere and sweep sample) next to the cuboid kernel on the same boxes,
+    BVH build time, and the ESDF bake through the BVH against the all-triangles bake."""
+    import numpy as np
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.backends.mesh import build_mesh_bvh, mesh_esdf_bake_bvh
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, box_mesh, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    def subdivide(v, f, times):
+        v = [tuple(x) for x in np.asarray(v, np.float64)]
+        f = np.asarray(f, np.int64)
+        for _ in range(times):
+            cache, out = {}, []
+
+            def mid(a, b):
+                key = (min(a, b), max(a, b))
+                if key not in cache:
+                    cache[key] = len(v)
+                    v.append(tuple((np.asarray(v[a]) + np.asarray(v[b])) * 0.5))
+                return cache[key]
+            for a, b, c in f:
+                ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+                out += [[a, ab, ca], [ab, b, bc], [ca, bc, c], [ab, bc, ca]]
+            f = np.asarray(out, np.int64)
+        return np.asarray(v, np.float32), f.astype(np.int32)
+
+    world = c2_world()
+    meshes = [[dict(name=f"box{i}", pose=o["pose"], **dict(zip(("vertices", "faces"), subdivide(*box_mesh(o["dims"]), 4))))
+               for i, o in enumerate(world[0])]]
+    n_tri = sum(len(m["faces"]) for m in meshes[0])
+    B, H = 1024, 33
+    cfg = CollisionRolloutCfg(use_fused=False)
+    out = {"workload": f"C2 shapes (1024 x 33 points x {kin.num_spheres} spheres), the {len(world[0])} cuboids of the C2 world as triangle "
+                       f"meshes ({n_tri} triangles), swept + speed metric", "triangles": n_tri}
+    x = torch.as_tensor(seed_knots(model, B, cfg.n_knots, seed=2), device=device).reshape(B, -1)
+    times = {}
+    for key, scene in (("cuboid_kernel", SceneData.from_arrays(cuboid_scene_arrays(world), device)),
+                       ("mesh_launch", SceneData.from_arrays(None, device, meshes=meshes))):
+        ro = CollisionRollout(kin, scene, B, cfg)
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        ro.compute_kinematics(ro.compute_state_from_action(x.view(B, cfg.n_knots, -1)))
+        S = kin.num_spheres
+
+        def scene_pass(ro=ro, scene=scene):
+            Cn.sphere_obstacle_collision(ro.scene_dist, ro.scene_grad, ro.robot_spheres, scene.struct, ro._w_scene, ro._eta, ro.env_query_idx,
+                                         B, cfg.padded_horizon, S, False, 3, True, ro._speed_dt)
+        scene_pass()
+        torch.cuda.synchronize()
+        g = graphed(scene_pass, 5, torch)
+        times[key] = time_kernel(g.replay, 3, torch, min_s=0.05) / 5
+        out[key] = {"us": round(times[key], 2), "cost_sum": float(ro.scene_dist.sum())}
+    alg = B * H * kin.num_spheres * 36
+    out["mesh_launch"].update({"algorithmic_bytes": alg, "GBps": round(alg / times["mesh_launch"] * 1e-3, 1),
+                               "hbm_frac": round(alg / times["mesh_launch"] * 1e-3 / HBM_PEAK_GBS, 4),
+                               "cost_relative_to_cuboids": round(out["mesh_launch"]["cost_sum"] / max(out["cuboid_kernel"]["cost_sum"], 1e-9), 6),
+                               "slowdown_vs_cuboid_kernel": round(times["mesh_launch"] / times["cuboid_kernel"], 2)})
+    # BVH build and the two bakes of one mesh (torus-free: the table box, 3 072 triangles) into a 96^3 grid
+    v, f = meshes[0][0]["vertices"], meshes[0][0]["faces"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        bvh = build_mesh_bvh(v, f, device)
+    torch.cuda.synchronize()
+    out["bvh_build"] = {"triangles": int(len(f)), "ms": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                        "note": "Morton keys + torch.sort + one launch per tree level; host-driven, per loaded mesh, once"}
+    n = 96
+    grid_a = torch.zeros(n ** 3, dtype=torch.float16, device=device)
+    grid_b = torch.zeros_like(grid_a)
+    xf = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+    vt, ft = torch.as_tensor(v, device=device), torch.as_tensor(f, device=device)
+    us_all = time_kernel(lambda: Cn.mesh_esdf_bake(grid_a, vt, ft, (n, n, n), 0.05, xf, max_distance=1.0), 3, torch, min_s=0.05)
+    us_bvh = time_kernel(lambda: mesh_esdf_bake_bvh(grid_b, bvh, (n, n, n), 0.05, xf, max_distance=1.0), 3, torch, min_s=0.05)
+    out["esdf_bake_96^3"] = {"all_triangles_us": round(us_all, 1), "through_bvh_us": round(us_bvh, 1), "speedup": round(us_all / us_bvh, 1),
+                             "max_abs_difference": float((grid_a.float() - grid_b.float()).abs().max())}
+    return out
 
 
 def c3_benchmark(device, torch):

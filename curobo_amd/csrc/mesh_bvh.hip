@@ -20,6 +20,7 @@
 
 namespace curobo_hip {
 
+
 constexpr int kMeshStack = 64;
 
 struct TriRec {  // 48 bytes
@@ -33,7 +34,8 @@ __device__ __forceinline__ float box_dist2(const float4 lo, const float4 hi, f3 
 }
 
 // closest point of triangle (a, a + ab, a + ac) to p (Ericson, Real-Time Collision Detection 5.1.5)
-__device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac) {
+__device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac, bool &interior) {
+  interior = false;
   const f3 ap = p - a;
   const float d1 = dot(ab, ap), d2 = dot(ac, ap);
   if (d1 <= 0.0f && d2 <= 0.0f) return a;
@@ -50,11 +52,15 @@ __device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac) {
   const float va = d3 * d6 - d5 * d4;
   if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
   const float den = 1.0f / (va + vb + vc);
+  interior = true;  // the face region: the closest point is the projection on the triangle's plane
   return a + (vb * den) * ab + (vc * den) * ac;
 }
 
 // closest surface point within sqrt(best_d2) of p; returns false when there is none
-__device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp) {
+// side: +1 / -1 = p is on the outer / inner side of the FACE its closest point lies in (then that is the sign of the
+// signed distance of a closed mesh), 0 = the closest point lies on an edge or a vertex (no verdict: count crossings)
+__device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp, int &side) {
+  side = 0;
   const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
   const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
   int stack[kMeshStack];
@@ -68,10 +74,19 @@ __device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 
       const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
       for (int t = t0; t < t1; t++) {
         const TriRec r = tri[t];
-        const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z));
+        bool interior;
+        const f3 ab = make_f3(r.ab.x, r.ab.y, r.ab.z), ac = make_f3(r.ac.x, r.ac.y, r.ac.z);
+        const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), ab, ac, interior);
         const f3 d = p - c;
         const float d2 = dot(d, d);
-        if (d2 <= best_d2) { best_d2 = d2; cp = c; found = true; }
+        if (d2 <= best_d2) {
+          // (a tie between a face and an edge / vertex of a neighbour keeps whichever came last; a face verdict is only
+          // trusted when the point is clearly off the plane)
+          const float sd = dot(d, cross(ab, ac));
+          side = (interior && d2 > 1e-12f && sd != 0.0f) ? (sd > 0.0f ? 1 : -1) : 0;
+          if (d2 == best_d2 && found) side = 0;
+          best_d2 = d2; cp = c; found = true;
+        }
       }
     } else {
       const int c0 = node * 2, c1 = c0 + 1;
@@ -147,11 +162,14 @@ __device__ __forceinline__ float mesh_sdf_with_grad(const curobo_hip_mesh &m, f3
   g = make_f3(0.f, 0.f, 0.f);
   float d2 = max_distance * max_distance;
   f3 cp = lp;
-  if (!mesh_closest_point(m, lp, d2, cp)) return max_distance;
+  int side;
+  if (!mesh_closest_point(m, lp, d2, cp, side)) return max_distance;
   const float d = sqrtf(d2);
   const f3 delta = lp - cp;
   if (d > 1e-6f) g = (1.0f / d) * delta;
-  return mesh_inside(m, lp) ? -d : d;
+  // the face the closest point lies in says which side the point is on; on an edge or a vertex the crossings are counted
+  const bool inside = side != 0 ? side < 0 : mesh_inside(m, lp);
+  return inside ? -d : d;
 }
 
 // ------------------------------------------------------------------------------------------------ build
@@ -241,9 +259,11 @@ __global__ void __launch_bounds__(256) mesh_esdf_bake_bvh_kernel(const MeshBakeB
   // the field is clamped to +-max_distance anyway: nothing farther needs a closest point, only a side
   float d2 = a.max_distance * a.max_distance;
   f3 cp = p;
-  const bool found = mesh_closest_point(a.m, p, d2, cp);
+  int side;
+  const bool found = mesh_closest_point(a.m, p, d2, cp, side);
   const float d = found ? sqrtf(d2) : a.max_distance;
-  a.out[v] = __float2half(mesh_inside(a.m, p) ? -d : d);
+  const bool inside = (found && side != 0) ? side < 0 : mesh_inside(a.m, p);
+  a.out[v] = __float2half(inside ? -d : d);
 }
 
 // ------------------------------------------------------------------------------------------------ sphere vs meshes
@@ -309,6 +329,12 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
   const f3 center = make_f3(s.x, s.y, s.z), pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
   if (s.w >= 0.0f) {
     const float r_adj = s.w + eta;
+    float half_w_prev = 0.0f, half_w_next = 0.0f;
+    if (SWEEP > 0) {
+      if (has_prev) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+      if (has_next) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+    }
+    const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
     const curobo_hip_mesh_set &ms = a.set;
     const int count = ms.count[env];
     for (int o = 0; o < ms.max_n; o++) {
@@ -322,16 +348,31 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
       // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
       const float max_distance = fmaxf(0.5f * sqrtf(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]), r_adj);
       const f3 lc = quat_rot(qw, qx, qy, qz, center) + t;
+      // Early reject (result preserving): the surface lies inside the mesh's bounding box (root of the tree), so the
+      // signed distance of a point outside the box is at least its distance to the box; when that exceeds
+      // r_adj + the half sweep length (+ rounding) neither the centre nor any sweep sample can penetrate.
+      {
+        const float *rb = m.node_box + 8;
+        const float ex = fmaxf(fmaxf(rb[0] - lc.x, lc.x - rb[4]), 0.0f), ey = fmaxf(fmaxf(rb[1] - lc.y, lc.y - rb[5]), 0.0f),
+                    ez = fmaxf(fmaxf(rb[2] - lc.z, lc.z - rb[6]), 0.0f);
+        const float thr = r_adj + reach;
+        if (ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f) continue;
+      }
       float cost_sum = 0.0f;
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
       f3 g_c;
       float c_c, gs_c;
       const float pen_c = mesh_point_terms(m, lc, max_distance, r_adj, eta, c_c, gs_c, g_c, ms.gradient_mode);
       if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; }
+      const float sdf_c = r_adj - pen_c;
       if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
 #pragma unroll 1
         for (int dir = 0; dir < 2; dir++) {
           if (!(dir == 0 ? has_prev : has_next)) continue;
+          // sweep culling (result preserving, as for cuboids: scene_device.hpp): every sample lies within the half
+          // segment length of the centre and the signed distance is 1-Lipschitz, so a centre that is clear by more
+          // than that cannot have a penetrating sample (no bound when the centre found no surface within max_distance)
+          if (sdf_c < max_distance && -pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + 2e-6f + 1e-6f * max_distance) continue;
           const f3 ln = quat_rot(qw, qx, qy, qz, dir == 0 ? pp : np) + t;
           const f3 dd = ln - lc;
           const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
