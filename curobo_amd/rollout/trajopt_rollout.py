@@ -12,6 +12,8 @@ non-terminal axes weights are zero, as in the reference config).
 
 from __future__ import annotations
 
+import contextlib
+
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -63,6 +65,9 @@ class TrajOptRolloutCfg:
     #: through the RNEA backward kernel.  Runs on the kernel sequence (the fused launch has no RNEA).
     use_torque_limits: bool = False
     effort_limit: Optional[List[float]] = None  # per joint max |tau|; None = the robot's URDF effort limits
+    #: kernel sequence with torque limits: run the joint-space chain (RNEA -> c-space STATE -> RNEA VJP) on a side stream
+    #: next to the task-space chain (FK -> costs -> FK VJP); same kernels, same numbers (evaluate_action)
+    overlap_dynamics: bool = True
     gravity: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 0.0, 0.0, 9.81])  # spatial base acceleration
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
@@ -252,6 +257,46 @@ class TrajOptRollout:
             self.position, self.velocity, self.acceleration, self.jerk, self.out_dt, act_seq, self.start_pos,
             self.start_vel, self.start_acc, self.start_jerk, self.goal_pos, self.goal_vel, self.goal_acc, self.goal_jerk,
             self.start_idx, self.goal_idx, self._traj_dt, self._implicit_goal, B, H, D, c.n_knots, c.bspline_degree)
+        tq = c.use_torque_limits
+        # The joint-space chain (inverse dynamics -> c-space STATE cost -> RNEA VJP) reads the B-spline samples only, the
+        # task-space chain (FK -> tool pose -> self / scene collision -> FK VJP) the joint positions only: with torque
+        # limits on, the first runs on a side stream next to the second and the two meet at the per-point aggregate.  The
+        # serial tree walks of RNEA occupy half a wavefront per SIMD (528 wavefronts for 33 792 elements) and leave the
+        # chip to the collision kernels; one after the other they cost the sum (Unitree G1, C4 shapes: 1 428 us).
+        side = None
+        if tq and c.overlap_dynamics and self.position.is_cuda:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            if getattr(self, "_tau", None) is None or self._tau.shape[0] != B * H:
+                side = None  # first call: the buffers below are allocated on the calling stream
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            if tq:  # inverse dynamics of every trajectory point (reference cuda_ops/dynamics.py, RNEA forward)
+                n, L = B * H, k.num_links
+                if getattr(self, "_tau", None) is None or self._tau.shape[0] != n:
+                    z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
+                    self._tau, self._rnea_cache, self._rnea_ws = z(n, D), z(n, L * 20), z(n, L * 18)
+                    self._cs_gtau, self._rnea_g = z(B, H, D), [z(n, D) for _ in range(3)]
+                rargs = (k.fixed_transforms, k.link_masses_com, k.link_inertias, k.joint_map_type, k.joint_map, k.link_map,
+                         k.joint_offset_map, self._gravity, k.link_level_offsets, k.link_level_data)
+                dynamics_hip.launch_rnea_forward(self._tau, self.position.view(n, D), self.velocity.view(n, D),
+                                                 self.acceleration.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1, None)
+            cost_hip.cspace_state_cost(
+                self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, self._cs_gtau if tq else None, self.position,
+                self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._zeroD,
+                self._idx0, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
+                self._zero1, self._zero1, self._onesD, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
+            if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
+                dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
+                                                  self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
+                                                  None, self._rnea_ws)
+                self.cs_gp.view(n, D).add_(self._rnea_g[0])
+                self.cs_gv.view(n, D).add_(self._rnea_g[1])
+                self.cs_ga.view(n, D).add_(self._rnea_g[2])
+        # (the task-space chain is enqueued AFTER the joint-space chain: the few, long-running workgroups of the tree walks
+        # take their slots on an empty chip; started behind the collision kernels they wait for LDS that those keep taking)
         kinematics_hip.launch_kinematics_forward_spheres(
             self.link_pos, self.link_quat, self.robot_spheres, self.com, self.cumul_mat, self.position,
             k.fixed_transforms, k.link_spheres, k.link_masses_com, k.joint_map_type, k.joint_map, k.link_map,
@@ -261,29 +306,6 @@ class TrajOptRollout:
             self.pose_cost, self.pose_pos_dist, self.pose_rot_dist, self.pose_grad_pos, self.pose_grad_quat,
             self.goalset_idx, self.link_pos, self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal,
             self._pose_w, self._axes_w, self._axes_w0, self._tol, self._tol, self._project, B, H, T, 1, c.rotation_method)
-        tq = c.use_torque_limits
-        if tq:  # inverse dynamics of every trajectory point (reference cuda_ops/dynamics.py, RNEA forward)
-            n, L = B * H, k.num_links
-            if getattr(self, "_tau", None) is None or self._tau.shape[0] != n:
-                z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
-                self._tau, self._rnea_cache, self._rnea_ws = z(n, D), z(n, L * 20), z(n, L * 18)
-                self._cs_gtau, self._rnea_g = z(B, H, D), [z(n, D) for _ in range(3)]
-            rargs = (k.fixed_transforms, k.link_masses_com, k.link_inertias, k.joint_map_type, k.joint_map, k.link_map,
-                     k.joint_offset_map, self._gravity, k.link_level_offsets, k.link_level_data)
-            dynamics_hip.launch_rnea_forward(self._tau, self.position.view(n, D), self.velocity.view(n, D),
-                                             self.acceleration.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1, None)
-        cost_hip.cspace_state_cost(
-            self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, self._cs_gtau if tq else None, self.position,
-            self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._zeroD,
-            self._idx0, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
-            self._zero1, self._zero1, self._onesD, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
-        if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
-            dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
-                                              self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
-                                              None, self._rnea_ws)
-            self.cs_gp.view(n, D).add_(self._rnea_g[0])
-            self.cs_gv.view(n, D).add_(self._rnea_g[1])
-            self.cs_ga.view(n, D).add_(self._rnea_g[2])
         sc = k.self_collision
         geometry_hip.self_collision_distance(
             self.self_dist, self.self_grad, self._pd, self.self_sparse, self.robot_spheres, sc.sphere_padding,
@@ -303,6 +325,8 @@ class TrajOptRollout:
                 k.joint_links_data, k.joint_links_offsets, k.joint_affects_endeffector, k.joint_offset_map,
                 self.env_query_idx, k.num_envs, B * H, H, D, S, False, False,
                 grad_spheres_b=self.scene_grad if use_scene else None)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
         # per-point totals (+ the c-space position gradient into grad_q), then the sum over the horizon
         cost_hip.rollout_point_aggregate(
             self.point_cost, self.grad_q if with_gradient else None, self.pose_cost, self.cspace_cost,
