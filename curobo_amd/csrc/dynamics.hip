@@ -51,14 +51,16 @@ constexpr int kStagedLanes = 64;
 
 __device__ __forceinline__ void stage_in(float *dst, const float *src, size_t b0, int n_here, int D) {
   const float *g = src + b0 * (size_t)D;
-  for (int i = threadIdx.x; i < n_here * D; i += kStagedLanes) {
+  for (int i = threadIdx.x; i < n_here * D; i += blockDim.x) {
     const int e = i / D, j = i - e * D;
     dst[j * kRneaStageStride + e] = g[i];
   }
 }
 
-template <bool HAS_FEXT>
-__global__ void __launch_bounds__(kStagedLanes) rnea_forward_staged_kernel(const RneaArgs a) {
+// QUAD: the 64 elements of the workgroup on 64 quads (256 threads, QuadAlg: a spatial vector's components over the lanes
+// of the quad) instead of on the 64 lanes of one wavefront.  Same cache / workspace layout: the two forms can be mixed.
+template <bool HAS_FEXT, bool QUAD>
+__global__ void __launch_bounds__(256) rnea_forward_staged_kernel(const RneaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.num_links, D = a.num_dof;
   float *s_f = smem;
@@ -71,14 +73,20 @@ __global__ void __launch_bounds__(kStagedLanes) rnea_forward_staged_kernel(const
   stage_in(st + sz, a.qd, b0, n_here, D);
   stage_in(st + 2 * sz, a.qdd, b0, n_here, D);
   stage_links(a, s_f, s_i);  // (ends with the workgroup barrier)
-  if ((int)threadIdx.x < n_here) {
-    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + threadIdx.x), (int)threadIdx.x};
-    rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b0 + threadIdx.x, B);
+  const int e = QUAD ? (int)threadIdx.x >> 2 : (int)threadIdx.x;
+  if (e < n_here) {
+    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + e), e};
+    if (QUAD) {
+      const int c = (int)threadIdx.x & 3;
+      rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b0 + e, B, QuadAlg{c < 3 ? c : 2});
+    } else {
+      rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b0 + e, B);
+    }
   }
 }
 
-template <bool HAS_FEXT>
-__global__ void __launch_bounds__(kStagedLanes) rnea_backward_staged_kernel(const RneaArgs a) {
+template <bool HAS_FEXT, bool QUAD>
+__global__ void __launch_bounds__(256) rnea_backward_staged_kernel(const RneaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.num_links, D = a.num_dof;
   float *s_f = smem;
@@ -91,9 +99,15 @@ __global__ void __launch_bounds__(kStagedLanes) rnea_backward_staged_kernel(cons
   stage_in(st + sz, a.qd, b0, n_here, D);
   stage_in(st + 2 * sz, a.grad_tau, b0, n_here, D);
   stage_links(a, s_f, s_i);
-  if ((int)threadIdx.x < n_here) {
-    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + threadIdx.x), (int)threadIdx.x};
-    rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b0 + threadIdx.x, B);
+  const int e = QUAD ? (int)threadIdx.x >> 2 : (int)threadIdx.x;
+  if (e < n_here) {
+    RneaStagedIO io{st, st + sz, st + 2 * sz, RneaGlobalIO(a, b0 + e), e};
+    if (QUAD) {
+      const int c = (int)threadIdx.x & 3;
+      rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b0 + e, B, QuadAlg{c < 3 ? c : 2});
+    } else {
+      rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b0 + e, B);
+    }
   }
 }
 
@@ -130,6 +144,12 @@ static bool rnea_staged() {  // EXPERIMENT knob: CUROBO_RNEA_STAGED=0 runs the u
   return v != 0;
 }
 
+static bool rnea_quad() {  // EXPERIMENT knob: CUROBO_RNEA_QUAD=0 keeps an element on one lane
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("CUROBO_RNEA_QUAD"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 static size_t rnea_lds(int num_links) { return (size_t)num_links * (kLinkFloats + 4) * sizeof(float); }
 
 CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
@@ -154,14 +174,16 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   // wavefront per workgroup over as many CUs as possible
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
   if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
-    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(kStagedLanes);
-    if (f_ext) {
-      if (int rc = raise_lds(rnea_forward_staged_kernel<true>, slds, what)) return rc;
-      hipLaunchKernelGGL((rnea_forward_staged_kernel<true>), grid, block, slds, st, a);
-    } else {
-      if (int rc = raise_lds(rnea_forward_staged_kernel<false>, slds, what)) return rc;
-      hipLaunchKernelGGL((rnea_forward_staged_kernel<false>), grid, block, slds, st, a);
-    }
+    const bool quad = rnea_quad();
+    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
+#define CUROBO_RNEA_LAUNCH(FE, QD)                                                                        \
+  do {                                                                                                    \
+    if (int rc = raise_lds(rnea_forward_staged_kernel<FE, QD>, slds, what)) return rc;                      \
+    hipLaunchKernelGGL((rnea_forward_staged_kernel<FE, QD>), grid, block, slds, st, a);                     \
+  } while (0)
+    if (f_ext) { if (quad) CUROBO_RNEA_LAUNCH(true, true); else CUROBO_RNEA_LAUNCH(true, false); }
+    else { if (quad) CUROBO_RNEA_LAUNCH(false, true); else CUROBO_RNEA_LAUNCH(false, false); }
+#undef CUROBO_RNEA_LAUNCH
     return check_launch(what, st);
   }
   const int bt = rnea_block(batch_size);
@@ -197,14 +219,16 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   hipStream_t st = (hipStream_t)stream;
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
   if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
-    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(kStagedLanes);
-    if (grad_f_ext) {
-      if (int rc = raise_lds(rnea_backward_staged_kernel<true>, slds, what)) return rc;
-      hipLaunchKernelGGL((rnea_backward_staged_kernel<true>), grid, block, slds, st, a);
-    } else {
-      if (int rc = raise_lds(rnea_backward_staged_kernel<false>, slds, what)) return rc;
-      hipLaunchKernelGGL((rnea_backward_staged_kernel<false>), grid, block, slds, st, a);
-    }
+    const bool quad = rnea_quad();
+    const dim3 grid((unsigned)ceil_div(batch_size, kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
+#define CUROBO_RNEA_LAUNCH(FE, QD)                                                                        \
+  do {                                                                                                    \
+    if (int rc = raise_lds(rnea_backward_staged_kernel<FE, QD>, slds, what)) return rc;                      \
+    hipLaunchKernelGGL((rnea_backward_staged_kernel<FE, QD>), grid, block, slds, st, a);                     \
+  } while (0)
+    if (grad_f_ext) { if (quad) CUROBO_RNEA_LAUNCH(true, true); else CUROBO_RNEA_LAUNCH(true, false); }
+    else { if (quad) CUROBO_RNEA_LAUNCH(false, true); else CUROBO_RNEA_LAUNCH(false, false); }
+#undef CUROBO_RNEA_LAUNCH
     return check_launch(what, st);
   }
   const int bt = rnea_block(batch_size);

@@ -178,6 +178,124 @@ __device__ __forceinline__ void store_sv(float *base, size_t B, int slot, size_t
   p[0] = s.w.x; p[B] = s.w.y; p[2 * B] = s.w.z; p[3 * B] = s.v.x; p[4 * B] = s.v.y; p[5 * B] = s.v.z;
 }
 
+// ---- the spatial algebra of the walks as a policy.  LaneAlg: one element per lane, a spatial vector is six registers
+// (everything above).  QuadAlg: one element per QUAD -- lane c of the quad (c = 0, 1, 2; lane 3 rides along) holds
+// component c of the angular and of the linear part, rotations take the other components through DPP quad broadcasts,
+// cross products through the two quad rotations.  A link is then ~230 instead of ~535 dependent VALU instructions and a
+// batch four times the wavefronts: the walks are bound by exactly that dependent stream (30 k instructions per
+// wavefront at half a wavefront per SIMD).
+struct LaneAlg {
+  using SvT = Sv;
+  using Xf = Rp;
+  __device__ __forceinline__ bool writer() const { return true; }
+  __device__ __forceinline__ SvT zero() const { return sv_zero(); }
+  __device__ __forceinline__ Xf xform(const float *F, int jt, float q) const { return local_Rp(F, jt, q); }
+  __device__ __forceinline__ SvT motion(const Xf &t, SvT m) const { return X_motion(t, m); }
+  __device__ __forceinline__ SvT force_T(const Xf &t, SvT f) const { return XT_force(t, f); }
+  __device__ __forceinline__ SvT inertia(const float *mc, const float *in, SvT m) const { return inertia_mul(mc, in, m); }
+  __device__ __forceinline__ SvT cross_f(SvT v, SvT f) const { return crf(v, f); }
+  __device__ __forceinline__ SvT cross_m(SvT a, SvT b) const { return crm(a, b); }
+  __device__ __forceinline__ float dot6(SvT a, SvT b) const { return sv_dot(a, b); }
+  __device__ __forceinline__ float get(const SvT &s, int i) const { return sv_get(s, i); }
+  __device__ __forceinline__ void add_at(SvT &s, int i, float x) const { sv_add_at(s, i, x); }
+  __device__ __forceinline__ SvT unit(int i, float x) const { return sv_unit(i, x); }
+  __device__ __forceinline__ SvT load(const float *base, size_t B, int slot, size_t b) const { return load_sv(base, B, slot, b); }
+  __device__ __forceinline__ void store(float *base, size_t B, int slot, size_t b, SvT s) const { store_sv(base, B, slot, b, s); }
+  __device__ __forceinline__ SvT load6(const float *p) const { return Sv{make_f3(p[0], p[1], p[2]), make_f3(p[3], p[4], p[5])}; }
+  __device__ __forceinline__ void store6_neg(float *g, SvT s) const {
+    g[0] = -s.w.x; g[1] = -s.w.y; g[2] = -s.w.z; g[3] = -s.v.x; g[4] = -s.v.y; g[5] = -s.v.z;
+  }
+};
+
+struct SvQ {  // component c (the lane's) of [angular; linear]
+  float w, v;
+};
+__device__ __forceinline__ SvQ operator+(SvQ a, SvQ b) { return SvQ{a.w + b.w, a.v + b.v}; }
+__device__ __forceinline__ SvQ operator-(SvQ a, SvQ b) { return SvQ{a.w - b.w, a.v - b.v}; }
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// quad_perm selectors: lane i of the quad reads lane sel_i, ctrl = sel_0 | sel_1 << 2 | sel_2 << 4 | sel_3 << 6
+__device__ __forceinline__ float q_bc0(float x) { return quad_perm<0x00>(x); }
+__device__ __forceinline__ float q_bc1(float x) { return quad_perm<0x55>(x); }
+__device__ __forceinline__ float q_bc2(float x) { return quad_perm<0xAA>(x); }
+__device__ __forceinline__ float q_next(float x) { return quad_perm<0xC9>(x); }   // [1, 2, 0, 3]: component c + 1
+__device__ __forceinline__ float q_next2(float x) { return quad_perm<0xD2>(x); }  // [2, 0, 1, 3]: component c + 2
+__device__ __forceinline__ float q_cross(float a, float b) {  // (a x b)_c = a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
+  return q_next(a) * q_next2(b) - q_next2(a) * q_next(b);
+}
+__device__ __forceinline__ float q_sum3(float x) { return x + q_next(x) + q_next2(x); }
+
+struct XfQ {
+  float col[3];  // R[0][c], R[1][c], R[2][c]: column c (for R^T v)
+  float row[3];  // R[c][0], R[c][1], R[c][2]: row c (for R v)
+  float p;       // component c of the child origin in the parent frame
+};
+
+struct QuadAlg {
+  int c;  // 0, 1, 2 (lane 3 of the quad computes as lane 2 and never writes)
+  using SvT = SvQ;
+  using Xf = XfQ;
+  __device__ __forceinline__ float pick(float x, float y, float z) const { return c == 0 ? x : c == 1 ? y : z; }
+  __device__ __forceinline__ bool writer() const { return c == 0 && (threadIdx.x & 3) == 0; }
+  __device__ __forceinline__ SvT zero() const { return SvQ{0.f, 0.f}; }
+  __device__ __forceinline__ Xf xform(const float *F, int jt, float q) const {
+    const Rp t = local_Rp(F, jt, q);  // (every lane builds the whole 3 x 3: the same instructions, no exchange)
+    XfQ x;
+    x.col[0] = pick(t.R[0], t.R[1], t.R[2]); x.col[1] = pick(t.R[3], t.R[4], t.R[5]); x.col[2] = pick(t.R[6], t.R[7], t.R[8]);
+    x.row[0] = pick(t.R[0], t.R[3], t.R[6]); x.row[1] = pick(t.R[1], t.R[4], t.R[7]); x.row[2] = pick(t.R[2], t.R[5], t.R[8]);
+    x.p = pick(t.p.x, t.p.y, t.p.z);
+    return x;
+  }
+  __device__ __forceinline__ float rot_T(const Xf &t, float v) const { return t.col[0] * q_bc0(v) + t.col[1] * q_bc1(v) + t.col[2] * q_bc2(v); }
+  __device__ __forceinline__ float rot(const Xf &t, float v) const { return t.row[0] * q_bc0(v) + t.row[1] * q_bc1(v) + t.row[2] * q_bc2(v); }
+  __device__ __forceinline__ SvT motion(const Xf &t, SvT m) const { return SvQ{rot_T(t, m.w), rot_T(t, m.v + q_cross(m.w, t.p))}; }
+  __device__ __forceinline__ SvT force_T(const Xf &t, SvT f) const {
+    const float Rf = rot(t, f.v);
+    return SvQ{rot(t, f.w) + q_cross(t.p, Rf), Rf};
+  }
+  __device__ __forceinline__ SvT inertia(const float *mc, const float *in, SvT m) const {
+    const float com = pick(mc[0], mc[1], mc[2]), mass = mc[3];
+    const float h = m.v + q_cross(m.w, com);
+    const float ch = q_cross(com, h);
+    // row c of the inertia at the centre of mass: (ixx ixy ixz), (ixy iyy iyz), (ixz iyz izz)
+    const float i0 = pick(in[0], in[3], in[4]), i1 = pick(in[3], in[1], in[5]), i2 = pick(in[4], in[5], in[2]);
+    return SvQ{i0 * q_bc0(m.w) + i1 * q_bc1(m.w) + i2 * q_bc2(m.w) + mass * ch, mass * h};
+  }
+  __device__ __forceinline__ SvT cross_f(SvT v, SvT f) const { return SvQ{q_cross(v.w, f.w) + q_cross(v.v, f.v), q_cross(v.w, f.v)}; }
+  __device__ __forceinline__ SvT cross_m(SvT a, SvT b) const { return SvQ{q_cross(a.w, b.w), q_cross(a.v, b.w) + q_cross(a.w, b.v)}; }
+  __device__ __forceinline__ float dot6(SvT a, SvT b) const { return q_sum3(c < 3 ? a.w * b.w + a.v * b.v : 0.0f); }
+  __device__ __forceinline__ float get(const SvT &s, int i) const {
+    const float x = i < 3 ? s.w : s.v;
+    const int k = i < 3 ? i : i - 3;
+    return k == 0 ? q_bc0(x) : k == 1 ? q_bc1(x) : q_bc2(x);
+  }
+  __device__ __forceinline__ void add_at(SvT &s, int i, float x) const {
+    s.w += (i == c) ? x : 0.f;
+    s.v += (i == c + 3) ? x : 0.f;
+  }
+  __device__ __forceinline__ SvT unit(int i, float x) const {
+    SvQ s{0.f, 0.f};
+    add_at(s, i, x);
+    return s;
+  }
+  __device__ __forceinline__ SvT load(const float *base, size_t B, int slot, size_t b) const {
+    const float *p = base + (size_t)(slot + c) * B + b;
+    return SvQ{p[0], p[3 * B]};
+  }
+  __device__ __forceinline__ void store(float *base, size_t B, int slot, size_t b, SvT s) const {
+    if ((threadIdx.x & 3) == 3) return;
+    float *p = base + (size_t)(slot + c) * B + b;
+    p[0] = s.w; p[3 * B] = s.v;
+  }
+  __device__ __forceinline__ SvT load6(const float *p) const { return SvQ{p[c], p[3 + c]}; }
+  __device__ __forceinline__ void store6_neg(float *g, SvT s) const {
+    if ((threadIdx.x & 3) == 3) return;
+    g[c] = -s.w; g[3 + c] = -s.v;
+  }
+};
+
 // Where an element's joint-space vectors live.  RneaGlobalIO: the caller's row-major [batch, dof] tensors, element b at
 // b * D (a wavefront's access is a gather of 64 rows: one cache line per lane).  RneaStagedIO: copies in LDS, [joint][65]
 // with the element (= lane) fastest, staged in and out by the kernel with coalesced transfers -- the walk then issues no
@@ -223,27 +341,29 @@ struct RneaStagedIO {
 };
 
 // One element b of a batch of B (SoA slots with element stride B): the forward sweeps.  `order` = links in level order.
-template <bool HAS_FEXT, class IO>
+// IO = where the joint-space vectors live, V = the spatial algebra (LaneAlg: the element on one lane; QuadAlg: on a quad).
+template <bool HAS_FEXT, class IO, class V = LaneAlg>
 __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
-                                                        const int *order, size_t b, size_t B);
+                                                        const int *order, size_t b, size_t B, const V &alg = V());
 template <bool HAS_FEXT>
 __device__ __forceinline__ void rnea_forward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
                                                      size_t b, size_t B) {
   rnea_forward_element_io<HAS_FEXT>(a, RneaGlobalIO(a, b), s_f, s_i, order, b, B);
 }
-template <bool HAS_FEXT, class IO>
+template <bool HAS_FEXT, class IO, class V>
 __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
-                                                        const int *order, size_t b, size_t B) {
+                                                        const int *order, size_t b, size_t B, const V &alg) {
+  using SvT = typename V::SvT;
   const int L = a.num_links, D = a.num_dof;
-  const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
-  io.tau_zero(D);
+  const SvT grav = alg.load6(a.gravity);
+  if (alg.writer()) io.tau_zero(D);
   // sweep 1, root -> leaves: velocities and accelerations (rnea_forward_kernel.cuh:118-188)
   // The walk is a chain of dependent steps whose operands travel through the cache (HBM / L2: a round trip per link).
   // When the links come in depth-first order the parent of a link is mostly the link just processed: its state is then
   // taken from registers and the round trip leaves the dependent path (any parents-first order is correct; the
   // backends pass a depth-first one).
   int prev_k = -1;
-  Sv prev_v = sv_zero(), prev_a = sv_zero();
+  SvT prev_v = alg.zero(), prev_a = alg.zero();
   for (int idx = 0; idx < L; idx++) {
     const int k = order_link(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
@@ -254,149 +374,151 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
       qde = c.mul * io.qd(c.ji);
       qdde = c.mul * io.qdd(c.ji);
     }
-    const Rp t = local_Rp(c.F, c.jt, qe);
-    Sv v = sv_zero(), acc;
+    const typename V::Xf t = alg.xform(c.F, c.jt, qe);
+    SvT v = alg.zero(), acc;
     if (is_root) {
-      acc = X_motion(t, grav);
+      acc = alg.motion(t, grav);
     } else if (c.par == prev_k) {
-      v = X_motion(t, prev_v);
-      acc = X_motion(t, prev_a);
+      v = alg.motion(t, prev_v);
+      acc = alg.motion(t, prev_a);
     } else {
-      v = X_motion(t, load_sv(a.cache, B, c.par * 20, b));
-      acc = X_motion(t, load_sv(a.cache, B, c.par * 20 + 6, b));
+      v = alg.motion(t, alg.load(a.cache, B, c.par * 20, b));
+      acc = alg.motion(t, alg.load(a.cache, B, c.par * 20 + 6, b));
     }
     if (c.jt != J_FIXED) {
       const int si = s_index(c.jt);
-      sv_add_at(v, si, qde);
-      sv_add_at(acc, si, qdde);
-      acc = acc + crm(v, sv_unit(si, qde));  // Coriolis
+      alg.add_at(v, si, qde);
+      alg.add_at(acc, si, qdde);
+      acc = acc + alg.cross_m(v, alg.unit(si, qde));  // Coriolis
     }
-    store_sv(a.cache, B, k * 20, b, v);
-    store_sv(a.cache, B, k * 20 + 6, b, acc);
-    if (order_needs_slot(order[idx])) store_sv(a.cache, B, k * 20 + 12, b, sv_zero());  // children accumulate their X^T f here
+    alg.store(a.cache, B, k * 20, b, v);
+    alg.store(a.cache, B, k * 20 + 6, b, acc);
+    if (order_needs_slot(order[idx])) alg.store(a.cache, B, k * 20 + 12, b, alg.zero());  // children accumulate their X^T f here
     prev_k = k; prev_v = v; prev_a = acc;
   }
   // sweep 2, leaves -> root: f = I a + v x* I v (- f_ext) + children; tau = S^T f (:190-283)
   // (a link's contribution to its parent stays in registers when the parent is the next link of the walk -- in
   // reversed depth-first order it usually is -- instead of a store the parent's load would have to wait for)
   int pend_par = -1;
-  Sv pend = sv_zero();
+  SvT pend = alg.zero();
   for (int idx = L - 1; idx >= 0; idx--) {
     const int k = order_link(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
-    const Sv v = load_sv(a.cache, B, k * 20, b), acc = load_sv(a.cache, B, k * 20 + 6, b);
-    Sv f = inertia_mul(c.mc, c.in, acc) + crf(v, inertia_mul(c.mc, c.in, v));
-    if (HAS_FEXT) {
-      const float *fe = a.f_ext + (b * L + k) * 6;
-      f = f - Sv{make_f3(fe[0], fe[1], fe[2]), make_f3(fe[3], fe[4], fe[5])};
-    }
-    if (order_needs_slot(order[idx])) f = f + load_sv(a.cache, B, k * 20 + 12, b);
-    else f = f + sv_zero();  // (-0 + 0 = +0, as the stored zero gave)
+    const SvT v = alg.load(a.cache, B, k * 20, b), acc = alg.load(a.cache, B, k * 20 + 6, b);
+    SvT f = alg.inertia(c.mc, c.in, acc) + alg.cross_f(v, alg.inertia(c.mc, c.in, v));
+    if (HAS_FEXT) f = f - alg.load6(a.f_ext + (b * L + k) * 6);
+    if (order_needs_slot(order[idx])) f = f + alg.load(a.cache, B, k * 20 + 12, b);
+    else f = f + alg.zero();  // (-0 + 0 = +0, as the stored zero gave)
     if (pend_par == k) f = f + pend;
     pend_par = -1;
-    store_sv(a.cache, B, k * 20 + 12, b, f);
+    alg.store(a.cache, B, k * 20 + 12, b, f);
     const bool moving = c.jt != J_FIXED && c.ji >= 0;
-    if (moving) io.tau_add(c.ji, c.mul * sv_get(f, s_index(c.jt)));
+    if (moving) {
+      const float tj = c.mul * alg.get(f, s_index(c.jt));
+      if (alg.writer()) io.tau_add(c.ji, tj);
+    }
     if (!(c.par < 0 || c.par == k)) {
       const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
-      const Sv up = XT_force(local_Rp(c.F, c.jt, qe), f);
+      const SvT up = alg.force_T(alg.xform(c.F, c.jt, qe), f);
       if (idx > 0 && order_link(order[idx - 1]) == c.par) { pend = up; pend_par = c.par; }
-      else store_sv(a.cache, B, c.par * 20 + 12, b, load_sv(a.cache, B, c.par * 20 + 12, b) + up);
+      else alg.store(a.cache, B, c.par * 20 + 12, b, alg.load(a.cache, B, c.par * 20 + 12, b) + up);
     }
   }
 }
 
 // ... and the VJP.  ACCUMULATE: add to grad_q / grad_qd / grad_qdd instead of overwriting them.
-template <bool HAS_FEXT, bool ACCUMULATE, class IO>
+template <bool HAS_FEXT, bool ACCUMULATE, class IO, class V = LaneAlg>
 __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
-                                                         const int *order, size_t b, size_t B);
+                                                         const int *order, size_t b, size_t B, const V &alg = V());
 template <bool HAS_FEXT, bool ACCUMULATE = false>
 __device__ __forceinline__ void rnea_backward_element(const RneaArgs &a, const float *s_f, const int *s_i, const int *order,
                                                       size_t b, size_t B) {
   rnea_backward_element_io<HAS_FEXT, ACCUMULATE>(a, RneaGlobalIO(a, b), s_f, s_i, order, b, B);
 }
-template <bool HAS_FEXT, bool ACCUMULATE, class IO>
+template <bool HAS_FEXT, bool ACCUMULATE, class IO, class V>
 __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, const IO &io, const float *s_f, const int *s_i,
-                                                         const int *order, size_t b, size_t B) {
+                                                         const int *order, size_t b, size_t B, const V &alg) {
+  using SvT = typename V::SvT;
   const int L = a.num_links, D = a.num_dof;
-  const Sv grav = Sv{make_f3(a.gravity[0], a.gravity[1], a.gravity[2]), make_f3(a.gravity[3], a.gravity[4], a.gravity[5])};
-  if (!ACCUMULATE) io.grads_zero(D);
+  const SvT grav = alg.load6(a.gravity);
+  if (!ACCUMULATE && alg.writer()) io.grads_zero(D);
   // pass 1, root -> leaves: adjoint of the force propagation (rnea_backward_kernel.cuh:151-208)
   int prev_k = -1;
-  Sv prev_fb = sv_zero();
+  SvT prev_fb = alg.zero();
   for (int idx = 0; idx < L; idx++) {
     const int k = order_link(order[idx]);
     const bool slot = order_needs_slot(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
-    Sv fb = sv_zero();
+    SvT fb = alg.zero();
     const int si = moving ? s_index(c.jt) : 0;
-    if (moving) sv_add_at(fb, si, c.mul * io.grad_tau(c.ji));
+    if (moving) alg.add_at(fb, si, c.mul * io.grad_tau(c.ji));
     if (!is_root) {
       const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
-      const Sv X = X_motion(local_Rp(c.F, c.jt, qe), c.par == prev_k ? prev_fb : load_sv(a.ws_fbar, B, c.par * 6, b));
+      const SvT X = alg.motion(alg.xform(c.F, c.jt, qe), c.par == prev_k ? prev_fb : alg.load(a.ws_fbar, B, c.par * 6, b));
       fb = fb + X;
-      if (moving) io.grad_q_add(c.ji, c.mul * sv_dot(X, crf(sv_unit(si, 1.0f), load_sv(a.cache, B, k * 20 + 12, b))));
+      if (moving) {
+        const float g = c.mul * alg.dot6(X, alg.cross_f(alg.unit(si, 1.0f), alg.load(a.cache, B, k * 20 + 12, b)));
+        if (alg.writer()) io.grad_q_add(c.ji, g);
+      }
     }
-    store_sv(a.ws_fbar, B, k * 6, b, fb);
+    alg.store(a.ws_fbar, B, k * 6, b, fb);
     if (slot) {
-      store_sv(a.ws_abar, B, k * 6, b, sv_zero());
-      store_sv(a.ws_vbar, B, k * 6, b, sv_zero());
+      alg.store(a.ws_abar, B, k * 6, b, alg.zero());
+      alg.store(a.ws_vbar, B, k * 6, b, alg.zero());
     }
     prev_k = k; prev_fb = fb;
-    if (HAS_FEXT) {
-      float *g = a.grad_f_ext + (b * L + k) * 6;
-      g[0] = -fb.w.x; g[1] = -fb.w.y; g[2] = -fb.w.z; g[3] = -fb.v.x; g[4] = -fb.v.y; g[5] = -fb.v.z;
-    }
+    if (HAS_FEXT) alg.store6_neg(a.grad_f_ext + (b * L + k) * 6, fb);
   }
   // pass 2, leaves -> root: adjoint of the velocity / acceleration propagation (:236-465)
   int pend_par = -1;
-  Sv pend_a = sv_zero(), pend_v = sv_zero();
+  SvT pend_a = alg.zero(), pend_v = alg.zero();
   for (int idx = L - 1; idx >= 0; idx--) {
     const int k = order_link(order[idx]);
     const bool slot = order_needs_slot(order[idx]);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     const bool par_next = !is_root && idx > 0 && order_link(order[idx - 1]) == c.par;  // this link's pushes stay in registers
-    const Sv v = load_sv(a.cache, B, k * 20, b);
-    const Sv fb = load_sv(a.ws_fbar, B, k * 6, b);
-    Sv ab = sv_zero(), vb = sv_zero();  // (what a link without children elsewhere would read back from its slot)
+    const SvT v = alg.load(a.cache, B, k * 20, b);
+    const SvT fb = alg.load(a.ws_fbar, B, k * 6, b);
+    SvT ab = alg.zero(), vb = alg.zero();  // (what a link without children elsewhere would read back from its slot)
     if (slot) {
-      ab = load_sv(a.ws_abar, B, k * 6, b);
-      vb = load_sv(a.ws_vbar, B, k * 6, b);
+      ab = alg.load(a.ws_abar, B, k * 6, b);
+      vb = alg.load(a.ws_vbar, B, k * 6, b);
     }
-    ab = ab + inertia_mul(c.mc, c.in, fb);
-    vb = vb - crf(fb, inertia_mul(c.mc, c.in, v)) - inertia_mul(c.mc, c.in, crm(v, fb));
+    ab = ab + alg.inertia(c.mc, c.in, fb);
+    vb = vb - alg.cross_f(fb, alg.inertia(c.mc, c.in, v)) - alg.inertia(c.mc, c.in, alg.cross_m(v, fb));
     if (pend_par == k) { ab = ab + pend_a; vb = vb + pend_v; }
     pend_par = -1;
     const int si = moving ? s_index(c.jt) : 0;
     float gq = 0.0f, gqd = 0.0f;
     if (moving) {
       const float qdk = c.mul * io.qd(c.ji);
-      io.grad_qdd_add(c.ji, c.mul * sv_get(ab, si));
-      gqd -= c.mul * sv_get(crf(v, ab), si);
-      vb = vb + crf(sv_unit(si, qdk), ab);
+      const float gdd = c.mul * alg.get(ab, si);
+      if (alg.writer()) io.grad_qdd_add(c.ji, gdd);
+      gqd -= c.mul * alg.get(alg.cross_f(v, ab), si);
+      vb = vb + alg.cross_f(alg.unit(si, qdk), ab);
     }
     const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
-    const Rp t = local_Rp(c.F, c.jt, qe);
-    const Sv S1 = sv_unit(si, 1.0f);
+    const typename V::Xf t = alg.xform(c.F, c.jt, qe);
+    const SvT S1 = alg.unit(si, 1.0f);
     if (!is_root) {
-      const Sv up = XT_force(t, ab);
+      const SvT up = alg.force_T(t, ab);
       if (par_next) pend_a = up;
-      else store_sv(a.ws_abar, B, c.par * 6, b, load_sv(a.ws_abar, B, c.par * 6, b) + up);
+      else alg.store(a.ws_abar, B, c.par * 6, b, alg.load(a.ws_abar, B, c.par * 6, b) + up);
     }
     if (moving) {  // dX/dq on the acceleration path: the parent's acceleration, or gravity at the root
-      const Sv Xa = X_motion(t, is_root ? grav : load_sv(a.cache, B, c.par * 20 + 6, b));
-      gq -= c.mul * sv_dot(ab, crm(S1, Xa));
-      gqd += c.mul * sv_get(vb, si);
+      const SvT Xa = alg.motion(t, is_root ? grav : alg.load(a.cache, B, c.par * 20 + 6, b));
+      gq -= c.mul * alg.dot6(ab, alg.cross_m(S1, Xa));
+      gqd += c.mul * alg.get(vb, si);
     }
     if (!is_root) {
-      const Sv upv = XT_force(t, vb);
+      const SvT upv = alg.force_T(t, vb);
       if (par_next) { pend_v = upv; pend_par = c.par; }
-      else store_sv(a.ws_vbar, B, c.par * 6, b, load_sv(a.ws_vbar, B, c.par * 6, b) + upv);
-      if (moving) gq -= c.mul * sv_dot(vb, crm(S1, X_motion(t, load_sv(a.cache, B, c.par * 20, b))));
+      else alg.store(a.ws_vbar, B, c.par * 6, b, alg.load(a.ws_vbar, B, c.par * 6, b) + upv);
+      if (moving) gq -= c.mul * alg.dot6(vb, alg.cross_m(S1, alg.motion(t, alg.load(a.cache, B, c.par * 20, b))));
     }
-    if (moving) {
+    if (moving && alg.writer()) {
       io.grad_q_add(c.ji, gq);
       io.grad_qd_add(c.ji, gqd);
     }
