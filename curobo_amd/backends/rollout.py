@@ -194,9 +194,12 @@ def rollout_ik_fused(
     fixed_transform, robot_spheres, joint_map_type, joint_map, link_map, tool_frame_map, link_sphere_map,
     link_chain_data, link_chain_offsets, joint_offset_map, sphere_padding, self_collision_weight, pair_locations,
     scene: Optional[Scene], scene_collision_weight, activation_distance, batch_size: int, dof: int,
+    env_query_idx=None, num_envs: int = 1, use_multi_env: bool = False,
 ):
     """cost[b], d cost / d q [b, dof] of ``batch_size`` joint configurations against per-row goal
-    poses in one launch (see ``curobo_hip_rollout_ik_fused`` in the header); optional outputs may be None."""
+    poses in one launch (see ``curobo_hip_rollout_ik_fused`` in the header); optional outputs may be None.
+    ``env_query_idx`` [b] (scene environment with ``use_multi_env``, sphere set with ``num_envs`` > 1) must be constant
+    over aligned runs of 16 configurations."""
     num_pairs = 0 if pair_locations is None else int(pair_locations.shape[0])
     check(load().curobo_hip_rollout_ik_fused(
         ptr(out_cost), ptr(out_grad_q), ptr(out_pose_distance), ptr(out_position_distance), ptr(out_rotation_distance),
@@ -209,7 +212,7 @@ def rollout_ik_fused(
         ptr(self_collision_weight), ptr(pair_locations), None if scene is None else C.addressof(scene),
         ptr(scene_collision_weight), ptr(activation_distance), batch_size, dof, int(fixed_transform.shape[0]),
         int(tool_frame_map.shape[0]), int(link_sphere_map.shape[0]), num_pairs, int(link_chain_data.shape[0]),
-        current_stream(out_cost),
+        ptr(env_query_idx), int(num_envs), int(use_multi_env), current_stream(out_cost),
     ))
 
 

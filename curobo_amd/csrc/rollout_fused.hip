@@ -1457,13 +1457,16 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
   const int npts = min(kIkPoints, ia.n_points - pt0);
   FusedCtx c;
   fused_ctx_carve(c, smem, lay, H, D, L, S, P);
-  c.env = 0;
+  // the 16 configurations of a workgroup share ONE environment (scene and sphere set): that of its first configuration.
+  // The caller checks that env_query_idx is constant over aligned runs of 16 (seeds of one problem: IkRollout).
+  const int wg_env = (a.use_multi_env || a.num_envs > 1) ? a.env_query_idx[pt0] : 0;
+  c.env = a.use_multi_env ? wg_env : 0;
   c.w_self = a.use_self ? a.w_self[0] : 0.0f;
   c.w_scene = a.use_scene ? a.w_scene[0] : 0.0f;
   c.eta = a.use_scene ? a.eta[0] : 0.0f;
   c.speed_metric = false;
   c.speed_dt = 0.0f;
-  fused_stage_tables(c, a, lay, reinterpret_cast<const float4 *>(a.robot_spheres), n_rec);
+  fused_stage_tables(c, a, lay, reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)(a.num_envs > 1 ? wg_env : 0) * S, n_rec);
   for (int e = rotated_tid((nt >> 6) / 2); e < npts * D; e += nt) c.q[e] = ia.x[(size_t)pt0 * D + e];
   __syncthreads();
   fused_derive_tables(c);
@@ -1947,8 +1950,9 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
     const float *sphere_padding, const float *self_collision_weight, const int16_t *pair_locations,
     const curobo_hip_scene *scene, const float *scene_collision_weight, const float *activation_distance,
     int batch_size, int dof, int num_links, int n_tool_frames, int num_spheres, int num_collision_pairs,
-    int link_chain_len, curobo_hip_stream_t stream) {
+    int link_chain_len, const int32_t *env_query_idx, int num_envs, int use_multi_env, curobo_hip_stream_t stream) {
   const char *what = "rollout_ik_fused";
+  CUROBO_REQUIRE((!use_multi_env && num_envs <= 1) || env_query_idx, "%s: per-environment scenes / sphere sets need env_query_idx", what);
   CUROBO_REQUIRE(num_links >= 1 && num_links <= 128 && dof >= 1 && dof <= 64, "%s: bad dimensions", what);
   CUROBO_REQUIRE(n_tool_frames >= 1 && num_goalset >= 1, "%s: need at least one tool frame / goal", what);
   CUROBO_REQUIRE(link_chain_len >= 1, "%s: link_chain_len must be >= 1", what);
@@ -1969,7 +1973,8 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
   if (!a.use_scene) { a.sc.max_cuboids = 0; a.sc.max_voxel_grids = 0; }
   a.w_scene = scene_collision_weight; a.eta = activation_distance;
   a.batch = batch_size; a.nlinks = num_links; a.nspheres = num_spheres; a.npairs = a.use_self ? num_collision_pairs : 0;
-  a.chain_len = link_chain_len; a.num_envs = 1; a.use_multi_env = 0;
+  a.chain_len = link_chain_len; a.num_envs = num_envs > 1 ? num_envs : 1; a.use_multi_env = use_multi_env ? 1 : 0;
+  a.env_query_idx = env_query_idx;
   ia.x = q; ia.out_grad_q = out_grad_q; ia.tool_frame_map = tool_frame_map; ia.n_tool_frames = n_tool_frames;
   ia.n_points = batch_size; ia.out_link_pos = out_link_pos; ia.out_link_quat = out_link_quat;
   ToolPoseArgs &tp = ia.tp;

@@ -67,6 +67,7 @@ class IKRollout:
         self._w_self = f([c.self_collision_weight])
         self.batch_size = 0
         self._fused_ok: Optional[bool] = None
+        self._env_runs_ok = True  # env_query_idx constant over aligned runs of 16 rows (update_env_query_idx)
         self.update_batch_size(batch_size)
 
     def update_batch_size(self, B: int) -> None:
@@ -99,14 +100,21 @@ class IKRollout:
     def update_env_query_idx(self, env_query_idx: Optional[torch.Tensor]) -> None:
         """Scene environment of every configuration (reference ``idxs_env`` / ``use_multi_env``,
         cost/cost_scene_collision.py:58-198): row b collides with the obstacles of environment
-        ``env_query_idx[b]``; ``None`` = env 0.  Multi-env rows run on the kernel sequence (the fused IK
-        launch reads one environment); switching modes changes the launches: re-capture graphs."""
+        ``env_query_idx[b]``; ``None`` = env 0.  The fused IK launch serves 16 configurations per workgroup from one
+        staged scene / sphere set: it runs when the index is constant over aligned runs of 16 rows (the seeds of one
+        problem; checked here, one host read-back, never inside a captured launch sequence), else the kernel
+        sequence does.  Switching modes changes the launches: re-capture graphs."""
         self.use_multi_env = env_query_idx is not None
         if env_query_idx is None:
             self.env_query_idx.zero_()
+            self._env_runs_ok = True
         else:
             validate_env_query_idx(env_query_idx, self.scene, self.kin.num_envs)
             self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
+            idx = self.env_query_idx
+            n = idx.numel()
+            first = idx[(torch.arange(n, device=idx.device) // 16) * 16]
+            self._env_runs_ok = bool((idx == first).all())
 
     def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
         """goal_position [G, T, num_goalset, 3], goal_quat (wxyz) [G, T, num_goalset, 4], idxs_goal [B]."""
@@ -169,7 +177,7 @@ class IKRollout:
             int(k.link_chain_data.shape[0]), n_obs)
         if self.scene is not None and getattr(self.scene.struct, "mesh_set", None) is not None:
             return False  # mesh obstacles are queried by their own launch (BVH): the kernel sequence runs
-        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64 and k.num_envs == 1
+        return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128 and k.num_dof <= 64
 
     def cost_and_gradient_fused(self, q: torch.Tensor, with_metrics: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """Same numbers as ``evaluate`` from one launch; ``with_metrics`` also fills the pose-error,
@@ -185,12 +193,13 @@ class IKRollout:
             self.num_goalset, c.rotation_method, self._p_b, self._cs_w, self._cs_eta, k.fixed_transforms, k.link_spheres,
             k.joint_map_type, k.joint_map, k.link_map, k.tool_frame_map, k.link_sphere_idx_map, k.link_chain_data,
             k.link_chain_offsets, k.joint_offset_map, sc.sphere_padding, self._w_self, sc.collision_pairs,
-            self.scene.struct if self.scene is not None else None, self._w_scene, self._eta_scene, B, k.num_dof)
+            self.scene.struct if self.scene is not None else None, self._w_scene, self._eta_scene, B, k.num_dof,
+            self.env_query_idx, k.num_envs, self.use_multi_env)
         return self.cost, self.grad_q.view(B, -1)
 
     def cost_and_gradient(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x[B, D] -> (cost[B], grad[B, D]) in static buffers (graph friendly)."""
-        if self.cfg.use_fused and not self.use_multi_env:
+        if self.cfg.use_fused and (self._env_runs_ok or not (self.use_multi_env or self.kin.num_envs > 1)):
             if self._fused_ok is None:
                 self._fused_ok = self.fused_available()
             if self._fused_ok:

@@ -590,7 +590,9 @@ int curobo_hip_rollout_trajectory_fused_lds_bytes(
  * with StateFromPositionTeleport and content/configs/task/ik/lbfgs_ik.yml).  Optional outputs
  * (NULL = skip): out_pose_distance [b, T, 2], out_position_distance / out_rotation_distance /
  * out_goalset_idx [b, T], out_link_pos [b, T, 3], out_link_quat [b, T, 4] (wxyz),
- * out_robot_spheres [b, S, 4], out_cspace_cost [b, dof].  Single scene environment. */
+ * out_robot_spheres [b, S, 4], out_cspace_cost [b, dof].  env_query_idx [b] (use_multi_env: scene environment; num_envs > 1:
+ * sphere set) must be constant over aligned runs of 16 configurations -- the seeds of one problem -- which share a
+ * workgroup and its staged tables; NULL / 1 / 0 = one environment. */
 int curobo_hip_rollout_ik_fused(
     float *out_cost, float *out_grad_q, float *out_pose_distance, float *out_position_distance,
     float *out_rotation_distance, int32_t *out_goalset_idx, float *out_link_pos,
@@ -607,7 +609,8 @@ int curobo_hip_rollout_ik_fused(
     const float *self_collision_weight, const int16_t *pair_locations,
     const curobo_hip_scene *scene, const float *scene_collision_weight,
     const float *activation_distance, int batch_size, int dof, int num_links, int n_tool_frames,
-    int num_spheres, int num_collision_pairs, int link_chain_len, curobo_hip_stream_t stream);
+    int num_spheres, int num_collision_pairs, int link_chain_len, const int32_t *env_query_idx, int num_envs,
+    int use_multi_env, curobo_hip_stream_t stream);
 
 /* LDS bytes of one 16-configuration workgroup of curobo_hip_rollout_ik_fused (usable when <= 163840) */
 int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres,

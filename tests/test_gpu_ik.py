@@ -313,3 +313,57 @@ def test_ik_solver_stream_shards_give_the_same_solutions(device):
         else:
             assert torch.equal(res.success, ref.success) and torch.equal(res.seed_index, ref.seed_index)
             assert torch.equal(res.solution, ref.solution)
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_ik_fused_multi_env_equals_kernel_sequence(aligned, device):
+    """batch-env IK rollout: every problem has its own world (cuboids + an ESDF grid) and its own collision-sphere set; the
+    one-launch form serves a workgroup's 16 configurations from one staged environment, so it runs when ``env_query_idx``
+    is constant over aligned runs of 16 rows (seeds of one problem) and hands over to the kernel sequence when it is not"""
+    import dataclasses
+
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout.ik_rollout import IKRollout, IKRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import c5_mixed_worlds
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    n_env = 3
+    sph = kin.link_spheres.repeat(n_env, 1, 1).clone()  # per-environment sphere sets: radii differ
+    sph[1, :, 3] = torch.where(sph[1, :, 3] > 0, sph[1, :, 3] * 1.3, sph[1, :, 3])
+    sph[2, :, :3] += 0.01
+    kin = dataclasses.replace(kin, link_spheres=sph.contiguous())
+    assert kin.num_envs == n_env
+    scene = SceneData.from_arrays(c5_mixed_worlds(n_env, grid=32), device)
+    seeds = 32 if aligned else 20  # 20 seeds per problem: runs of 16 rows straddle two problems
+    B = n_env * seeds
+    env = torch.arange(n_env, dtype=torch.int32, device=device).repeat_interleave(seeds)
+    rng = np.random.default_rng(3)
+    q = torch.as_tensor(sample_q(model, B, seed=8, scale=0.9), device=device)
+    T = kin.num_pose_links
+    gpos = torch.as_tensor(rng.normal(size=(n_env, T, 1, 3)).astype(np.float32) * 0.4, device=device)
+    gq = rng.normal(size=(n_env, T, 1, 4)).astype(np.float32)
+    gq /= np.linalg.norm(gq, axis=-1, keepdims=True)
+    idx = env.clone()
+    outs = []
+    for fused in (False, True):
+        ro = IKRollout(kin, scene, B, IKRolloutCfg(use_fused=fused), num_goalset=1)
+        ro.update_goals(gpos, torch.as_tensor(gq, device=device), idx)
+        ro.update_env_query_idx(env)
+        assert ro._env_runs_ok == aligned
+        cost, grad = ro.cost_and_gradient(q)
+        torch.cuda.synchronize()
+        outs.append((cost.clone(), grad.clone(), ro))
+    (c0, g0, _), (c1, g1, ro1) = outs
+    assert ro1.fused_available()
+    assert float(c0.max()) > 0 and float((c0 > 0).float().mean()) > 0.3
+    torch.testing.assert_close(c1, c0, rtol=2e-5, atol=1e-3)
+    torch.testing.assert_close(g1, g0, rtol=1e-3, atol=2e-5 * float(g0.abs().max()))
+    # the environments matter: the same rows against environment 0 only cost something else
+    ro0 = IKRollout(kin, scene, B, IKRolloutCfg(use_fused=False), num_goalset=1)
+    ro0.update_goals(gpos, torch.as_tensor(gq, device=device), idx)
+    ro0.update_env_query_idx(torch.zeros_like(env))
+    cz, _ = ro0.cost_and_gradient(q)
+    torch.cuda.synchronize()
+    assert float((cz - c0).abs().max()) > 1e-3
