@@ -977,7 +977,11 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   fused_ctx_carve(c, smem, lay, H, D, L, S, P);
   if (use_lanes) { c.g_pairs = reinterpret_cast<const uint32_t *>(a.pairs); c.lane_len0 = a.lane_len0; c.lane_len1 = a.lane_len1; }
   c.env = a.use_multi_env ? a.env_query_idx[b] : 0;
+#ifdef CUROBO_FUSED_WAVE_STAMPS
+#define CUROBO_STAMP(i) do { if ((i) < 8 && (!TERMS || kStampTerms) && a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
+#else
 #define CUROBO_STAMP(i) do { if ((!TERMS || kStampTerms) && a.prof && tid == 0) a.prof[(size_t)b * 16 + (i)] = wall_clock64(); } while (0)
+#endif
   CUROBO_STAMP(0);
   const int sph_env = a.num_envs > 1 ? a.env_query_idx[b] : 0;
   const float4 *rs = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)sph_env * S;
@@ -1236,6 +1240,9 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     }
     if (stamp_pt) a.prof[(size_t)b * 16 + 6] = wall_clock64();
   }
+#ifdef CUROBO_FUSED_WAVE_STAMPS  // diagnostic build: when each wavefront leaves the main round (slots 8..15 of the profile row)
+  if (a.prof && !TERMS && lane64 == 0) a.prof[(size_t)b * 16 + 8 + (tid >> 6)] = wall_clock64();
+#endif
   if (fold_left) {
     CUROBO_STAMP(7);
     const int h = H_main;
