@@ -202,8 +202,32 @@ def cpu_optimizer_baseline(num_problems, V, m, nls, budget_s):
         orc.lbfgs_step(step, rho, y, s_, x, g, x0, g0, 0.01, True)
         n += 1
     el = time.perf_counter() - t0
-    return {"lbfgs_steps_per_s": n * B / el, "problems": B, "opt_dim": V, "history": m, "kind": "port",
-            "sample": f"{n} two-loop updates of {B} problems in {el:.1f} s (C restatement of lbfgs_jit_helpers.py:10-78)"}
+    out = {"lbfgs_steps_per_s": n * B / el, "problems": B, "opt_dim": V, "history": m, "kind": "port",
+           "sample": f"{n} two-loop updates of {B} problems in {el:.1f} s (C restatement of lbfgs_jit_helpers.py:10-78)"}
+    # the optimiser stage as torch on the host cores (the reference's torch fallbacks cannot travel to the
+    # GPU box: oracle/lbfgs_torch.py is their twin, pinned by the golden those functions produced)
+    try:
+        import torch
+
+        from oracle.lbfgs_torch import lbfgs_step
+
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        tx, tg = torch.as_tensor(x).clone(), torch.as_tensor(g).clone()
+        ty, ts, tr = torch.zeros(m, B, V), torch.zeros(m, B, V), torch.zeros(m, B)
+        tx0, tg0 = tx.clone(), tg.clone()
+        t1, k = time.perf_counter(), 0
+        while time.perf_counter() - t1 < budget_s:
+            tx += 0.01
+            tg *= 0.99
+            lbfgs_step(tr, ty, ts, tx, tg, tx0, tg0, 0.01, True)
+            k += 1
+        e2 = time.perf_counter() - t1
+        out["torch_twin"] = {"lbfgs_steps_per_s": k * B / e2, "threads": threads, "kind": "port",
+                             "sample": f"{k} updates of {B} problems in {e2:.1f} s (torch on the CPU, oracle/lbfgs_torch.py)"}
+    except Exception as e:  # noqa: BLE001
+        out["torch_twin"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -100,3 +100,25 @@ def test_lbfgs_stable_mode_negative_curvature(oracle):
     assert (rho[-1] == 0).all()
     np.testing.assert_array_equal(step, np.zeros_like(step))
     assert np.array_equal(x0, q) and np.array_equal(g0, g)
+
+
+@pytest.mark.parametrize("name", ["ik", "trajopt"])
+def test_torch_twin_of_the_optimiser_stage_matches_the_reference_golden(name, gold):
+    """oracle/lbfgs_torch.py (what bench.py times as the optimiser stage's torch CPU baseline) against the vectors the
+    reference's own jit_lbfgs_update_buffers + jit_lbfgs_compute_step_direction produced"""
+    import torch
+
+    from oracle.lbfgs_torch import lbfgs_step
+
+    q, g, step_ref = gold[f"lbfgs_{name}_q"], gold[f"lbfgs_{name}_g"], gold[f"lbfgs_{name}_step"]
+    iters, b, v = q.shape
+    m = gold[f"lbfgs_{name}_y"].shape[0]
+    y, s, rho = torch.zeros(m, b, v), torch.zeros(m, b, v), torch.zeros(m, b)
+    x0, g0 = torch.tensor(gold[f"lbfgs_{name}_init_x0"]).float(), torch.tensor(gold[f"lbfgs_{name}_init_g0"]).float()
+    for it in range(iters):
+        step = lbfgs_step(rho, y, s, torch.tensor(q[it]), torch.tensor(g[it]), x0, g0, 0.01, True)
+        scale = np.abs(step_ref[it]).max()
+        np.testing.assert_allclose(step.numpy(), step_ref[it], atol=2e-4 * scale, rtol=2e-3, err_msg=f"iteration {it}")
+    np.testing.assert_allclose(y.numpy(), gold[f"lbfgs_{name}_y"], atol=1e-6)
+    np.testing.assert_allclose(s.numpy(), gold[f"lbfgs_{name}_s"], atol=1e-6)
+    np.testing.assert_allclose(rho.numpy(), gold[f"lbfgs_{name}_rho"], rtol=1e-4, atol=1e-6)
