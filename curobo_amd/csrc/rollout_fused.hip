@@ -1744,9 +1744,22 @@ static int rollout_trajectory_fused_impl(
   int threads;
   static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;
   const bool with_terms = a.use_pose || a.use_cspace || force_terms;  // the TERMS instantiation: one scene ring per wave
-  const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                                  a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2,
-                                                  a.lane_lists ? (a.lane_len0 + a.lane_len1) * 64 : 0);
+  FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
+                                            a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2,
+                                            a.lane_lists ? (a.lane_len0 + a.lane_len1) * 64 : 0);
+  if (a.lane_lists) {
+    // the lane form must not cost a workgroup slot: where its lists (64 words per entry, whatever the sphere count) push
+    // the trajectory over 160 KB, or over the 80 KB that let two workgroups share a CU, the pass walks pair_locations
+    int threads0;
+    const FusedLayout lay0 = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
+                                                     a.use_cspace ? 4 * padded_horizon * dof : 0, &threads0, with_terms ? 1 : 2, 0);
+    const size_t l1 = (size_t)lay.total * sizeof(float), l0 = (size_t)lay0.total * sizeof(float);
+    if (l1 > 160 * 1024 || (l1 > 80 * 1024 && l0 <= 80 * 1024) || (a.use_torque && !fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres))) {
+      a.lane_lists = nullptr; a.lane_len0 = 0; a.lane_len1 = 0;
+      lay = lay0;
+      threads = threads0;
+    }
+  }
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   CUROBO_REQUIRE(!a.use_torque || fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres),
