@@ -23,14 +23,17 @@ class ToolPose:
     position: torch.Tensor
     quaternion: torch.Tensor
 
-    def as_goal(self):
-        """the poses as goals for the solvers (reference ToolPose.as_goal, _src/types/tool_pose.py): the last point
-        of every trajectory, one goal per batch row -> GoalToolPose [batch, T, 1, 3 | 4]"""
+    def as_goal(self, ordered_tool_frames: Optional[List[str]] = None):
+        """the poses as goals for the solvers (reference ToolPose.as_goal, _src/types/tool_pose.py:165-179): a goal-set
+        axis of one is added -> GoalToolPose [batch, horizon, T, 1, 3 | 4]"""
         from .types import GoalToolPose
 
-        p, q = self.position.detach(), self.quaternion.detach()
+        p, q, frames = self.position.detach(), self.quaternion.detach(), list(self.tool_frames)
+        if ordered_tool_frames:
+            order = [frames.index(f) for f in ordered_tool_frames]
+            p, q, frames = p[:, :, order], q[:, :, order], list(ordered_tool_frames)
         # copies: the kinematics front end re-uses its output buffers on the next call
-        return GoalToolPose(list(self.tool_frames), p[:, -1].unsqueeze(2).clone(), q[:, -1].unsqueeze(2).clone())
+        return GoalToolPose(frames, p.unsqueeze(3).clone(), q.unsqueeze(3).clone())
 
 
 @dataclass

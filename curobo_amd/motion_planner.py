@@ -11,7 +11,9 @@ over the HIP solvers.
   pass (dt scale 0.55) -> stop at the first attempt with a successful seed.  ``plan_cspace`` (:329-396): joint-space
   goal, three finetune passes at 0.75.  The PRM graph planner that seeds later attempts in the reference
   (``_get_graph_seed_trajectories``) is out of scope (graph search), so every attempt is the
-  IK-seeded one; ``plan_grasp`` and the attachment manager are likewise not mirrored.
+  IK-seeded one.  ``plan_grasp`` (:419-588): goal-set plan to the grasp candidates -> approach pose -> straight-line motion
+  to the chosen grasp -> straight-line lift, with the grasp-contact links' collision spheres switched off where the
+  reference switches them off.  The attachment manager is not mirrored.
 * ``BatchMotionPlanner.plan_pose`` / ``plan_cspace`` = ``motion_planner_batch.py:139-289``: ``max_batch_size``
   problems in one IK + trajopt pass, per-problem start states, first-success-wins over the attempts, optional
   one-world-per-problem (``multi_env``: problem p collides with scene environment p).
@@ -33,7 +35,7 @@ from .scene import SceneData
 from .scene.config import scene_from_config
 from .solver.ik import IKSolver, IKSolverCfg
 from .solver.trajopt import TrajOptResult, TrajOptSolver, TrajOptSolverCfg
-from .types import DeviceCfg, GoalToolPose, JointState
+from .types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPoseCriteria
 
 
 def _load_kinematics(robot, device, assets_root: str = "", num_envs: int = 1) -> KinematicsCfg:
@@ -104,6 +106,38 @@ class TrajectoryOptimizerResult:
 
 
 @dataclass
+class GraspPlanResult:
+    """reference GraspPlanResult (motion/motion_planner_result.py): the three legs of a grasp plan"""
+
+    success: Optional[torch.Tensor] = None
+    approach_success: Optional[torch.Tensor] = None
+    grasp_success: Optional[torch.Tensor] = None
+    lift_success: Optional[torch.Tensor] = None
+    status: Optional[str] = None
+    goalset_result: Optional[TrajectoryOptimizerResult] = None
+    goalset_index: Optional[torch.Tensor] = None
+    approach_result: Optional[TrajectoryOptimizerResult] = None
+    approach_trajectory: Optional[JointState] = None
+    approach_trajectory_dt: Optional[torch.Tensor] = None
+    approach_interpolated_trajectory: Optional[JointState] = None
+    approach_interpolated_last_tstep: Optional[torch.Tensor] = None
+    grasp_trajectory: Optional[JointState] = None
+    grasp_trajectory_dt: Optional[torch.Tensor] = None
+    grasp_interpolated_trajectory: Optional[JointState] = None
+    grasp_interpolated_last_tstep: Optional[torch.Tensor] = None
+    lift_trajectory: Optional[JointState] = None
+    lift_trajectory_dt: Optional[torch.Tensor] = None
+    lift_interpolated_trajectory: Optional[JointState] = None
+    lift_interpolated_last_tstep: Optional[torch.Tensor] = None
+
+
+def _axis_offset_pose(axis: str, offset: float) -> Pose:
+    if axis not in ("x", "y", "z"):
+        raise ValueError(f"Invalid axis: {axis}, must be 'x', 'y', or 'z'")
+    return Pose.from_list([offset * (axis == a) for a in ("x", "y", "z")] + [1.0, 0.0, 0.0, 0.0])
+
+
+@dataclass
 class TrajectoryOptimizerCfg:
     kinematics: KinematicsCfg = None
     scene: Optional[SceneData] = None
@@ -125,6 +159,8 @@ class TrajectoryOptimizerCfg:
     #: (n_knots 16, interpolation_steps 4); this backend's default is the C2 shape, 12 knots x 2 = 32 + 1 points
     n_knots: int = 12
     interpolation_steps: int = 2
+    #: goal poses per problem the solvers are built for (reference ``max_goalset``); smaller sets are padded
+    max_goalset: int = 1
 
     @staticmethod
     def create(robot: Union[str, Dict, KinematicsCfg], scene_model: Union[str, Dict, List, None] = None, num_seeds: int = 4,
@@ -132,8 +168,8 @@ class TrajectoryOptimizerCfg:
                self_collision_check: bool = True, optimizer_collision_activation_distance: float = 0.01,
                device_cfg: Optional[DeviceCfg] = None, interpolation_dt: float = 0.025, minimum_trajectory_dt: float = 0.002,
                maximum_trajectory_dt: float = 0.2, max_batch_size: int = 1, multi_env: bool = False, random_seed: int = 123,
-               num_ik_seeds: int = 32, assets_root: str = "", n_knots: int = 12, interpolation_steps: int = 2, **unused
-               ) -> "TrajectoryOptimizerCfg":
+               num_ik_seeds: int = 32, assets_root: str = "", n_knots: int = 12, interpolation_steps: int = 2,
+               max_goalset: int = 1, **unused) -> "TrajectoryOptimizerCfg":
         """Arguments of the reference's ``TrajOptSolverCfg.create`` (solver_trajopt_cfg.py:118-240).  ``robot``: packaged
         name (``"franka.yml"``), a robot yaml path, its dictionary or a ``KinematicsCfg``; ``scene_model``: the
         reference's scene format (a list = one world per environment).  Keyword arguments this backend has no use
@@ -149,19 +185,19 @@ class TrajectoryOptimizerCfg:
             optimizer_collision_activation_distance=optimizer_collision_activation_distance, interpolation_dt=interpolation_dt,
             minimum_trajectory_dt=minimum_trajectory_dt, maximum_trajectory_dt=maximum_trajectory_dt,
             max_batch_size=max_batch_size, multi_env=multi_env, random_seed=random_seed, num_ik_seeds=num_ik_seeds,
-            n_knots=n_knots, interpolation_steps=interpolation_steps)
+            n_knots=n_knots, interpolation_steps=interpolation_steps, max_goalset=max_goalset)
 
     def solver_cfg(self) -> TrajOptSolverCfg:
         c = TrajOptSolverCfg(num_seeds=self.num_seeds, position_threshold=self.position_tolerance,
                              rotation_threshold=self.orientation_tolerance, seed=self.random_seed,
                              interpolation_dt=self.interpolation_dt, minimum_trajectory_dt=self.minimum_trajectory_dt,
-                             maximum_trajectory_dt=self.maximum_trajectory_dt)
+                             maximum_trajectory_dt=self.maximum_trajectory_dt, num_goalset=self.max_goalset)
         c.rollout.n_knots, c.rollout.interpolation_steps = self.n_knots, self.interpolation_steps
         c.rollout.scene_activation_distance = self.optimizer_collision_activation_distance
         if not self.self_collision_check:
             c.rollout.self_collision_weight = 0.0
         c.ik = IKSolverCfg(num_seeds=self.num_ik_seeds, position_threshold=self.position_tolerance,
-                           rotation_threshold=self.orientation_tolerance, seed=self.random_seed)
+                           rotation_threshold=self.orientation_tolerance, seed=self.random_seed, num_goalset=self.max_goalset)
         c.ik.rollout.scene_activation_distance = self.optimizer_collision_activation_distance
         return c
 
@@ -216,12 +252,25 @@ class TrajectoryOptimizer:
         if self._solver is not None:
             self._solver.reset_seed()
 
+    def update_tool_pose_criteria(self, tool_pose_criteria: Dict[str, ToolPoseCriteria]) -> None:
+        self._criteria = dict(tool_pose_criteria)
+        if self._solver is not None:
+            self._solver.update_tool_pose_criteria(tool_pose_criteria)
+
+    def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
+        self.config.kinematics.kinematics_config.update_link_inertial(link_name, mass, com, inertia)
+
+    def update_links_inertial(self, link_properties: Dict) -> None:
+        self.config.kinematics.kinematics_config.update_links_inertial(link_properties)
+
     @property
     def solver(self) -> TrajOptSolver:
         if self._solver is None:
             c = self.config
             self._solver = TrajOptSolver.sharded(c.kinematics.kinematics_config, c.scene, c.max_batch_size, c.solver_cfg(),
                                                  use_cuda_graph=c.use_cuda_graph)
+            if getattr(self, "_criteria", None):
+                self._solver.update_tool_pose_criteria(self._criteria)
         return self._solver
 
     def _pad(self, x: Optional[torch.Tensor], batch: int) -> Optional[torch.Tensor]:
@@ -260,6 +309,7 @@ class TrajectoryOptimizer:
             success=v(r.success), solution=v(r.knots, self.config.n_knots, D), js_solution=js, position_error=v(r.position_error),
             rotation_error=v(r.rotation_error), interpolated_trajectory=interp, interpolated_last_tstep=last.reshape(n, k)[:batch],
             seed_cost=v(r.cost), solve_time=total, total_time=total,
+            goalset_index=None if r.goalset_index is None else v(r.goalset_index),
             debug_info={"finetune_passes": r.finetune_passes, "seed_index": v(r.seed_index)})
 
     def solve_pose(self, goal_tool_poses: GoalToolPose, current_state: JointState, seed_config: Optional[torch.Tensor] = None,
@@ -268,29 +318,29 @@ class TrajectoryOptimizer:
                    goal_state: Optional[JointState] = None, initial_iters: Optional[int] = None,
                    time_optimal_iters: Optional[int] = None, finetune_iters: Optional[int] = None,
                    finetune_dt_scale: float = 0.55) -> TrajectoryOptimizerResult:
-        """reference ``TrajOptSolver.solve_pose`` (:679-829).  ``goal_tool_poses`` [batch, T, 1, 3 | 4];
+        """reference ``TrajOptSolver.solve_pose`` (:679-829).  ``goal_tool_poses`` [batch, 1, T, g <= max_goalset, 3 | 4];
         ``current_state.position`` [batch, dof]; ``seed_config`` [batch, n >= num_seeds, dof]; ``seed_traj`` [batch, n,
         n_knots, dof].  Without seeds and with ``use_implicit_goal=False`` the reference optimises from constant seeds at
         the current position; so does this."""
         t0 = time.perf_counter()
         if num_seeds is not None and num_seeds != self.config.num_seeds:
             raise ValueError(f"num_seeds is fixed at construction ({self.config.num_seeds}); got {num_seeds}")
-        gp, gq = goal_tool_poses.position, goal_tool_poses.quaternion
+        gp, gq = goal_tool_poses.static_goals()  # [batch, T, g, 3 | 4]
         batch = int(gp.shape[0])
-        if goal_tool_poses.num_goalset != 1:
-            raise ValueError("goal sets are not supported by the trajectory optimiser of this backend (num_goalset must be 1)")
+        if goal_tool_poses.num_goalset > self.config.max_goalset:
+            raise ValueError(f"solve_pose: goal set of {goal_tool_poses.num_goalset} poses exceeds config.max_goalset="
+                             f"{self.config.max_goalset}")
         if batch > self.config.max_batch_size:
             raise ValueError(f"solve_pose: batch_size={batch} exceeds config.max_batch_size={self.config.max_batch_size}.")
         dev = self.config.device_cfg.device
         start = current_state.position.to(dev, torch.float32).reshape(batch, -1)
-        T = gp.shape[1]
         pad = lambda x: self._pad(x, batch)  # noqa: E731
         if seed_config is None and seed_traj is None:  # constant seeds at the current position (solver_core.py:206-210)
             seed_config = start.view(batch, 1, -1).expand(batch, self.config.num_seeds, start.shape[-1])
             if use_implicit_goal and goal_state is None:
                 raise ValueError("use_implicit_goal needs seed_config, seed_traj or goal_state")
         r = self.solver.solve_pose(
-            pad(start), pad(gp.reshape(batch, T, 3).to(dev)), pad(gq.reshape(batch, T, 4).to(dev)), env_idx=self._env_idx(),
+            pad(start), pad(gp.to(dev)), pad(gq.to(dev)), env_idx=self._env_idx(),
             seed_config=pad(seed_config), seed_traj=pad(seed_traj), return_seeds=return_seeds, dt=pad(dt),
             use_implicit_goal=use_implicit_goal, finetune_attempts=finetune_attempts,
             goal_state=pad(goal_state.position.reshape(batch, -1)) if goal_state is not None else None, initial_iters=initial_iters,
@@ -337,15 +387,13 @@ class MotionPlannerCfg:
         """Arguments of the reference's ``MotionPlannerCfg.create`` (:37-66); task / graph-planner yaml arguments are
         accepted and ignored.  ``multi_env``: ``scene_model`` is a list of ``max_batch_size`` worlds, problem p of a batch
         plans in world p."""
-        if max_goalset != 1:
-            raise ValueError("goal sets are not supported by the planners of this backend (max_goalset must be 1)")
         device_cfg = device_cfg or DeviceCfg()
         to = TrajectoryOptimizerCfg.create(
             robot, scene_model, num_seeds=num_trajopt_seeds, position_tolerance=position_tolerance,
             orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,
             optimizer_collision_activation_distance=optimizer_collision_activation_distance, device_cfg=device_cfg,
             max_batch_size=max_batch_size, multi_env=multi_env, random_seed=random_seed, num_ik_seeds=num_ik_seeds,
-            assets_root=assets_root, **{k: v for k, v in unused.items() if k in ("n_knots", "interpolation_steps", "interpolation_dt",
+            assets_root=assets_root, max_goalset=max_goalset, **{k: v for k, v in unused.items() if k in ("n_knots", "interpolation_steps", "interpolation_dt",
                                                                                   "minimum_trajectory_dt", "maximum_trajectory_dt")})
         if multi_env and (to.scene is None or to.scene.num_envs < max_batch_size):
             raise ValueError(f"multi_env needs a list of {max_batch_size} scene models (one world per problem)")
@@ -369,6 +417,8 @@ class _PlannerBase:
             c = self.config.trajopt_solver_config
             self._ik = IKSolver.sharded(c.kinematics.kinematics_config, c.scene, c.max_batch_size, c.solver_cfg().ik,
                                         use_cuda_graph=c.use_cuda_graph)
+            if getattr(self, "_criteria", None):
+                self._ik.update_tool_pose_criteria(self._criteria)
         return self._ik
 
     # ---- reference properties (motion_planner.py:107-130)
@@ -404,6 +454,34 @@ class _PlannerBase:
         if self._ik is not None:
             self._ik.reset_seed()
 
+    def clear_scene_cache(self) -> None:
+        """reference ``clear_scene_cache`` (:606-609): the obstacle buffers are emptied; here the solvers are rebuilt
+        without a scene on their next use"""
+        self.update_world(None)
+
+    # ---- robot model edits (reference :590-640); all in place on tensors the captured graphs read
+    def enable_link_collision(self, enable_collision_links: List[str]) -> None:
+        for name in enable_collision_links:
+            self.kinematics.config.kinematics_config.enable_link_spheres(name)
+
+    def disable_link_collision(self, disable_collision_links: List[str]) -> None:
+        for name in disable_collision_links:
+            self.kinematics.config.kinematics_config.disable_link_spheres(name)
+
+    def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
+        self.kinematics.config.kinematics_config.update_link_inertial(link_name, mass, com, inertia)
+
+    def update_links_inertial(self, link_properties: Dict) -> None:
+        self.kinematics.config.kinematics_config.update_links_inertial(link_properties)
+
+    def update_tool_pose_criteria(self, tool_pose_criteria: Dict[str, ToolPoseCriteria]) -> None:
+        """reference ``update_tool_pose_criteria`` (:638-640): IK and trajectory optimisation score the tool frames with
+        these per-axis factors from the next call on"""
+        self._criteria = dict(tool_pose_criteria)
+        if self._ik is not None:
+            self._ik.update_tool_pose_criteria(tool_pose_criteria)
+        self.trajopt_solver.update_tool_pose_criteria(tool_pose_criteria)
+
     def destroy(self) -> None:
         self._ik = None
         self.trajopt_solver._solver = None
@@ -417,12 +495,20 @@ class _PlannerBase:
 
     def _ik_seed_configs(self, goal_tool_poses: GoalToolPose, batch: int):
         """IK with ``return_seeds = num_trajopt_seeds`` (L-BFGS stage always on: motion_planner.py:143-144) ->
-        (success [batch, k], solution [batch, k, dof]); the batch is padded to ``max_batch_size`` with its first problem"""
+        (success [batch, k], solution [batch, k, dof]); the batch is padded to ``max_batch_size`` with its first problem,
+        a goal set to ``max_goalset`` with its last pose"""
         c = self.config.trajopt_solver_config
-        n, k, dev = c.max_batch_size, c.num_seeds, self.device_cfg.device
-        T = goal_tool_poses.position.shape[1]
-        gp = goal_tool_poses.position.to(dev, torch.float32).reshape(batch, T, 3)[:, 0]
-        gq = goal_tool_poses.quaternion.to(dev, torch.float32).reshape(batch, T, 4)[:, 0]
+        n, k, dev, G = c.max_batch_size, c.num_seeds, self.device_cfg.device, c.max_goalset
+        gp, gq = goal_tool_poses.static_goals()
+        gp, gq = gp.to(dev, torch.float32)[:, 0], gq.to(dev, torch.float32)[:, 0]  # first tool frame: [batch, g, 3 | 4]
+        g = gp.shape[1]
+        if g > G:
+            raise ValueError(f"goal set of {g} poses exceeds max_goalset={G}")
+        if g < G:
+            gp = torch.cat([gp, gp[:, -1:].expand(batch, G - g, 3)], 1)
+            gq = torch.cat([gq, gq[:, -1:].expand(batch, G - g, 4)], 1)
+        if G == 1:
+            gp, gq = gp[:, 0], gq[:, 0]
         pad = lambda x: x if batch == n else torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], 0)  # noqa: E731
         env = torch.arange(n, device=dev, dtype=torch.int32) if c.multi_env else None
         r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, exit_early=False, env_idx=env)
@@ -469,6 +555,111 @@ class MotionPlanner(_PlannerBase):
                 break
         if result is not None:
             result.solve_time, result.total_time = solve_time, time.perf_counter() - t0
+        return result
+
+    def plan_grasp(self, grasp_poses: GoalToolPose, current_state: JointState, grasp_approach_axis: str = "z",
+                   grasp_approach_offset: float = -0.15, grasp_approach_in_tool_frame: bool = True, grasp_lift_axis: str = "z",
+                   grasp_lift_offset: float = -0.15, grasp_lift_in_tool_frame: bool = True, plan_approach_to_grasp: bool = True,
+                   plan_grasp_to_lift: bool = True, disable_collision_links: Optional[List[str]] = None) -> GraspPlanResult:
+        """reference ``plan_grasp`` (:419-588).  ``grasp_poses`` holds ``num_goalset <= max_goalset`` candidate grasps per
+        tool frame.  (1) plan to the candidate set with the grasp-contact links' spheres off: finds a reachable grasp;
+        (2) plan from the current state to the approach pose, the chosen grasp shifted by ``grasp_approach_offset`` along
+        ``grasp_approach_axis`` (of the tool frame, or of the world); (3) from the end of that plan to the grasp under the
+        linear-motion criteria (every point held on the approach line and at the grasp orientation), contact spheres off;
+        (4) from the grasp to the lift pose the same way."""
+        kp = self.kinematics.config.kinematics_config
+        if disable_collision_links is None:
+            disable_collision_links = kp.grasp_contact_link_names or []
+        disable_collision_links = [n for n in disable_collision_links if n in (kp.link_names or [])]
+        dev = current_state.position.device
+        f = lambda: torch.tensor([False], device=dev)  # noqa: E731
+        result = GraspPlanResult(success=f(), approach_success=f(), grasp_success=f(), lift_success=f())
+        frames = list(grasp_poses.tool_frames)
+        standard = {k: ToolPoseCriteria() for k in frames}
+
+        def last_state(r: TrajectoryOptimizerResult) -> JointState:
+            return JointState.from_position(r.js_solution.position[:, 0, -1].reshape(1, -1).clone(), joint_names=self.joint_names)
+
+        def leg(goal: GoalToolPose, start: JointState, criteria=None, contacts_off: bool = False):
+            if criteria is not None:
+                self.update_tool_pose_criteria({k: criteria for k in frames})
+            if contacts_off:
+                self.disable_link_collision(disable_collision_links)
+            try:
+                return self.plan_pose(goal, start)
+            finally:
+                if contacts_off:
+                    self.enable_link_collision(disable_collision_links)
+                if criteria is not None:
+                    self.update_tool_pose_criteria(standard)
+
+        # 1: one of the grasp poses
+        goalset_result = leg(grasp_poses, current_state, contacts_off=True)
+        if goalset_result is None:
+            result.status = "Goalset planning returned None."
+            return result
+        result.success = torch.zeros_like(goalset_result.success)
+        result.goalset_result = goalset_result
+        if not bool(goalset_result.success.any()):
+            result.status = "No grasp in goal set was reachable."
+            return result
+        result.goalset_index = goalset_result.goalset_index.clone()
+        goal_index = int(goalset_result.goalset_index.view(-1)[0].item())
+        grasp = {fr: Pose(grasp_poses.position[:, 0, i, goal_index, :], grasp_poses.quaternion[:, 0, i, goal_index, :])
+                 for i, fr in enumerate(frames)}
+
+        def shifted(axis: str, offset: float, in_tool_frame: bool) -> GoalToolPose:
+            off = _axis_offset_pose(axis, offset).to(dev)
+            d = {fr: (p.to(dev).multiply(off) if in_tool_frame else off.multiply(p.to(dev))) for fr, p in grasp.items()}
+            return GoalToolPose.from_poses(d, ordered_tool_frames=frames, num_goalset=1)
+
+        # 2: the approach pose
+        approach = leg(shifted(grasp_approach_axis, grasp_approach_offset, grasp_approach_in_tool_frame), current_state)
+        result.approach_result = approach
+        if approach is None or not bool(approach.success.any()):
+            result.status = "Planning to approach pose failed."
+            return result
+        result.approach_success = approach.success.clone()
+        result.approach_trajectory, result.approach_trajectory_dt = approach.js_solution, approach.js_solution.dt
+        result.approach_interpolated_trajectory = approach.interpolated_trajectory
+        result.approach_interpolated_last_tstep = approach.interpolated_last_tstep
+        result.status = "Planning to approach pose succeeded."
+        if not plan_approach_to_grasp:
+            result.success = torch.ones_like(result.success)
+            return result
+
+        # 3: straight line from the approach pose to the grasp
+        grasp_goal = GoalToolPose.from_poses({fr: p.to(dev) for fr, p in grasp.items()}, ordered_tool_frames=frames, num_goalset=1)
+        line = ToolPoseCriteria.linear_motion(axis=grasp_approach_axis, non_terminal_scale=1.0,
+                                              project_distance_to_goal=grasp_approach_in_tool_frame)
+        grasp_result = leg(grasp_goal, last_state(approach), criteria=line, contacts_off=True)
+        if grasp_result is None or not bool(grasp_result.success.any()):
+            result.status = "Planning to grasp pose failed."
+            return result
+        result.grasp_trajectory, result.grasp_trajectory_dt = grasp_result.js_solution, grasp_result.js_solution.dt
+        result.grasp_interpolated_trajectory = grasp_result.interpolated_trajectory
+        result.grasp_interpolated_last_tstep = grasp_result.interpolated_last_tstep
+        result.success = grasp_result.success.clone()
+        result.grasp_success = grasp_result.success.clone()
+        result.status = "Planning to grasp pose succeeded."
+        if not plan_grasp_to_lift:
+            return result
+
+        # 4: straight line from the grasp to the lift pose
+        lift_line = ToolPoseCriteria.linear_motion(axis=grasp_lift_axis, non_terminal_scale=1.0,
+                                                   project_distance_to_goal=grasp_lift_in_tool_frame)
+        lift = leg(shifted(grasp_lift_axis, grasp_lift_offset, grasp_lift_in_tool_frame), last_state(grasp_result),
+                   criteria=lift_line, contacts_off=True)
+        if lift is None or not bool(lift.success.any()):
+            result.status = "Planning to lift pose failed."
+            result.success = torch.zeros_like(result.success)
+            return result
+        result.lift_trajectory, result.lift_trajectory_dt = lift.js_solution, lift.js_solution.dt
+        result.lift_interpolated_trajectory = lift.interpolated_trajectory
+        result.lift_interpolated_last_tstep = lift.interpolated_last_tstep
+        result.success = lift.success.clone()
+        result.lift_success = lift.success.clone()
+        result.status = "Planning to lift pose succeeded."
         return result
 
     def plan_cspace(self, goal_state: JointState, current_state: JointState, max_attempts: int = 5,

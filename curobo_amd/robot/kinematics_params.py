@@ -57,6 +57,9 @@ class KinematicsParams:
     link_level_offsets: Optional[torch.Tensor] = None
     max_level_width: int = 1
     joint_limits_effort: Optional[torch.Tensor] = None  # [D] max |torque| per joint (URDF effort limits)
+    link_names: Optional[List[str]] = None  # name of link k (index into fixed_transforms / link_sphere_idx_map values)
+    reference_link_spheres: Optional[torch.Tensor] = None  # the spheres as loaded: what enable / reset restore
+    grasp_contact_link_names: Optional[List[str]] = None
 
     @property
     def n_tree_levels(self) -> int:
@@ -95,6 +98,52 @@ class KinematicsParams:
         if self.joint_affects_endeffector is not None and self.joint_affects_endeffector.numel() != D * T:
             raise ValueError(f"joint_affects_endeffector.numel() = {self.joint_affects_endeffector.numel()}, expected "
                              f"num_dof * n_tool_frames = {D} * {T} = {D * T}")
+
+    # ---- collision spheres of a link on / off, inertial parameters: in place, so captured graphs (which hold the pointers of
+    # ``link_spheres`` / ``link_masses_com`` / ``link_inertias``) see the change on their next replay
+    def _link_index(self, link_name: str) -> int:
+        if self.link_names is None or link_name not in self.link_names:
+            raise ValueError(f"{link_name} not found in the links of the robot")
+        return self.link_names.index(link_name)
+
+    def get_sphere_index_from_link_name(self, link_name: str) -> torch.Tensor:
+        """indices of the spheres attached to ``link_name`` (reference kinematics_params.py:get_sphere_index_from_link_name)"""
+        return torch.nonzero(self.link_sphere_idx_map.to(torch.int64) == self._link_index(link_name)).view(-1)
+
+    def disable_link_spheres(self, link_name: str) -> None:
+        """radius -100 in every sphere set: the collision kernels skip spheres with a negative radius (reference :558-567)"""
+        self.link_spheres[:, self.get_sphere_index_from_link_name(link_name), 3] = -100.0
+
+    def enable_link_spheres(self, link_name: str) -> None:
+        """radii back from the loaded spheres; positions stay (reference :569-582)"""
+        idx = self.get_sphere_index_from_link_name(link_name)
+        self.link_spheres[:, idx, 3] = self.reference_link_spheres[:, idx, 3]
+
+    def reset_link_spheres(self, link_name: str) -> None:
+        idx = self.get_sphere_index_from_link_name(link_name)
+        self.link_spheres[:, idx, :] = self.reference_link_spheres[:, idx, :]
+
+    def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
+        """mass [kg], centre of mass [3] in the link frame, inertia [ixx, iyy, izz, ixy, ixz, iyz] of one link (reference
+        robot/dynamics/dynamics.py:401-428)"""
+        if mass is None and com is None and inertia is None:
+            raise ValueError("At least one property (mass, com, or inertia) must be provided")
+        k = self._link_index(link_name)
+        f = lambda v: torch.as_tensor(v, dtype=torch.float32).reshape(-1).to(self.device)  # noqa: E731
+        if mass is not None:
+            self.link_masses_com[k, 3] = float(mass)
+        if com is not None:
+            self.link_masses_com[k, :3] = f(com)[:3]
+        if inertia is not None:
+            self.link_inertias[k, :6] = f(inertia)[:6]
+
+    def update_links_inertial(self, link_properties) -> None:
+        if not link_properties:
+            raise ValueError("link_properties dictionary cannot be empty")
+        for name, props in link_properties.items():
+            if not props:
+                raise ValueError(f"No properties specified for link '{name}'")
+            self.update_link_inertial(name, mass=props.get("mass"), com=props.get("com"), inertia=props.get("inertia"))
 
     @staticmethod
     def from_model(model: RobotModel, device) -> "KinematicsParams":
@@ -147,4 +196,7 @@ class KinematicsParams:
             joint_limits_velocity=up(model.joint_limits_velocity, torch.float32),
             self_collision=sc,
             joint_limits_effort=up(model.joint_limits_effort, torch.float32) if getattr(model, "joint_limits_effort", None) is not None else None,
+            link_names=list(model.link_names),
+            reference_link_spheres=up(model.link_spheres, torch.float32).clone(),
+            grasp_contact_link_names=None if getattr(model, "grasp_contact_link_names", None) is None else list(model.grasp_contact_link_names),
         )

@@ -99,6 +99,9 @@ class RobotModel:
     lock_joints: Dict[str, float]
     cspace: Dict
     base_link: str
+    #: links in contact with a grasped object (robot yaml ``grasp_contact_link_names``; the grasp planner switches their
+    #: collision spheres off for the final approach and the lift, reference motion_planner.py:437-440)
+    grasp_contact_link_names: Optional[List[str]] = None
 
     @property
     def num_links(self) -> int:
@@ -133,6 +136,8 @@ class RobotModel:
                 self.cspace.get("default_joint_position", [0.0] * self.num_dof), dtype=np.float64
             ),
         )
+        if self.grasp_contact_link_names is not None:
+            meta["grasp_contact_link_names"] = np.array(list(self.grasp_contact_link_names), dtype=str)
         np.savez_compressed(path, **self.as_dict(), **meta)
 
     @staticmethod
@@ -153,6 +158,7 @@ class RobotModel:
                 default_joint_position=[float(x) for x in z["cspace_default_joint_position"]],
             ),
             base_link=str(z["base_link"]),
+            grasp_contact_link_names=[str(x) for x in z["grasp_contact_link_names"]] if "grasp_contact_link_names" in z.files else None,
         )
 
 
@@ -494,4 +500,5 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
         joint_limits_position=pos_lim, joint_limits_velocity=vel_lim, joint_limits_effort=eff_lim,
         num_dof=D, joint_names=joint_names, link_names=list(chain_names),
         tool_frames=tool_frames, lock_joints=locked, cspace=cspace, base_link=base_link,
+        grasp_contact_link_names=list(cfg["grasp_contact_link_names"]) if cfg.get("grasp_contact_link_names") else None,
     )

@@ -127,6 +127,17 @@ class IKRollout:
             self.goal_quat = goal_quat.to(self.device, torch.float32).contiguous().clone()
         self.idxs_goal.copy_(idxs_goal.to(torch.int32))
 
+    def update_tool_pose_criteria(self, criteria) -> None:
+        """``{tool frame: ToolPoseCriteria}``: an IK rollout has one point per row, so only the terminal factors, the
+        terminal tolerance and the projection flag apply (reference ToolPoseCost.update_tool_pose_criteria); in place"""
+        for name, c in criteria.items():
+            if name not in self.kin.tool_frames:
+                raise ValueError(f"tool frame {name} not in {self.kin.tool_frames}")
+            i, f = self.kin.tool_frames.index(name), lambda v: torch.tensor(v, device=self.device, dtype=torch.float32)  # noqa: E731
+            self._axes_w[i].copy_(f(c.terminal_pose_axes_weight_factor))
+            self._tol[i].copy_(f(c.terminal_pose_convergence_tolerance))
+            self._project[i] = int(bool(c.project_distance_to_goal))
+
     # ------------------------------------------------------------------ forward + backward
     def evaluate(self, q: torch.Tensor, with_gradient: bool = True) -> torch.Tensor:
         k, B, c = self.kin, self.batch_size, self.cfg

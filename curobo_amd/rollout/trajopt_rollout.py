@@ -99,6 +99,7 @@ class TrajOptRollout:
         self._pose_w = f(c.pose_weight)
         self._axes_w, self._axes_w0 = torch.ones(T, 6, device=d), torch.full((T, 6), float(c.non_terminal_pose_factor), device=d)
         self._tol = f([c.pose_convergence_tolerance] * T)
+        self._tol0 = self._tol.clone()
         self._project = torch.zeros(T, dtype=torch.uint8, device=d)
         self._cs_w, self._cs_eta, self._cs_reg = f(c.cspace_weight), f(c.cspace_activation_distance), f(c.cspace_regularization)
         self._p_b, self._v_b = kin.joint_limits_position.contiguous(), kin.joint_limits_velocity.contiguous()
@@ -240,14 +241,29 @@ class TrajOptRollout:
             self.env_query_idx.copy_(env_query_idx.to(device=self.device, dtype=torch.int32).reshape(-1))
 
     def update_goals(self, goal_position: torch.Tensor, goal_quat: torch.Tensor, idxs_goal: torch.Tensor) -> None:
-        """goal_position [G, T, 1, 3], goal_quat (wxyz) [G, T, 1, 4], idxs_goal [B]."""
+        """goal_position [G, T, num_goalset, 3], goal_quat (wxyz) [G, T, num_goalset, 4], idxs_goal [B]: every point is
+        scored against the closest member of its row's goal set (reference goal sets, cost/tool_pose kernels)."""
         if goal_position.shape == self.goal_position.shape:
             self.goal_position.copy_(goal_position)
             self.goal_quat.copy_(goal_quat)
-        else:
+        else:  # new buffers (and a new goal-set size): the fused launch's argument block is rebuilt on the next evaluation
             self.goal_position = goal_position.to(self.device, torch.float32).contiguous().clone()
             self.goal_quat = goal_quat.to(self.device, torch.float32).contiguous().clone()
+            self._terms = None
         self.idxs_goal.copy_(idxs_goal.to(torch.int32))
+
+    def update_tool_pose_criteria(self, criteria) -> None:
+        """``{tool frame: ToolPoseCriteria}`` -> the per-frame factor / tolerance / projection rows the pose cost reads
+        (reference ToolPoseCost.update_tool_pose_criteria); written in place, so captured graphs see the new values"""
+        for name, c in criteria.items():
+            if name not in self.kin.tool_frames:
+                raise ValueError(f"tool frame {name} not in {self.kin.tool_frames}")
+            i, f = self.kin.tool_frames.index(name), lambda v: torch.tensor(v, device=self.device, dtype=torch.float32)  # noqa: E731
+            self._axes_w[i].copy_(f(c.terminal_pose_axes_weight_factor))
+            self._axes_w0[i].copy_(f(c.non_terminal_pose_axes_weight_factor))
+            self._tol[i].copy_(f(c.terminal_pose_convergence_tolerance))
+            self._tol0[i].copy_(f(c.non_terminal_pose_convergence_tolerance))
+            self._project[i] = int(bool(c.project_distance_to_goal))
 
     # ------------------------------------------------------------------ forward + backward
     def evaluate_action(self, act_seq: torch.Tensor, with_gradient: bool = True) -> torch.Tensor:
@@ -305,7 +321,8 @@ class TrajOptRollout:
         cost_hip.tool_pose_distance(
             self.pose_cost, self.pose_pos_dist, self.pose_rot_dist, self.pose_grad_pos, self.pose_grad_quat,
             self.goalset_idx, self.link_pos, self.link_quat, self.goal_position, self.goal_quat, self.idxs_goal,
-            self._pose_w, self._axes_w, self._axes_w0, self._tol, self._tol, self._project, B, H, T, 1, c.rotation_method)
+            self._pose_w, self._axes_w, self._axes_w0, self._tol, self._tol0, self._project, B, H, T, int(self.goal_position.shape[2]),
+            c.rotation_method)
         sc = k.self_collision
         geometry_hip.self_collision_distance(
             self.self_dist, self.self_grad, self._pd, self.self_sparse, self.robot_spheres, sc.sphere_padding,
@@ -375,8 +392,8 @@ class TrajOptRollout:
             goal_position=self.goal_position, goal_quat=self.goal_quat, idxs_goal=self.idxs_goal,
             position_orientation_weight=self._pose_w, terminal_pose_axes_weight_factor=self._axes_w,
             non_terminal_pose_axes_weight_factor=self._axes_w0, terminal_pose_convergence_tolerance=self._tol,
-            non_terminal_pose_convergence_tolerance=self._tol, project_distance_to_goal=self._project,
-            tool_frame_map=k.tool_frame_map, n_tool_frames=k.num_pose_links, num_goalset=1,
+            non_terminal_pose_convergence_tolerance=self._tol0, project_distance_to_goal=self._project,
+            tool_frame_map=k.tool_frame_map, n_tool_frames=k.num_pose_links, num_goalset=int(self.goal_position.shape[2]),
             rotation_method=c.rotation_method, out_cspace_cost=self.cspace_cost if m else None, state_dt=self.state_dt,
             target_joint_position=self._zeroD, idxs_target_joint_position=self._idx0, p_b=self._p_b, v_b=self._v_b,
             a_b=self._a_b, j_b=self._j_b, effort_b=self._effort_b, cspace_weight=self._cs_w,

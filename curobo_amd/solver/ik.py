@@ -149,6 +149,12 @@ class IKSolver:
         if self.seed_solver is not None:
             self.seed_solver.reset_seed()
 
+    def update_tool_pose_criteria(self, criteria) -> None:
+        """``{tool frame: ToolPoseCriteria}`` for the L-BFGS stage and the success metrics (reference IKSolver.
+        update_tool_pose_criteria); the LM seed stage keeps solving for the full pose -- its solutions are only seeds"""
+        for ro in self.rollouts + [self.metrics_rollout]:
+            ro.update_tool_pose_criteria(criteria)
+
     def sample_seeds(self) -> torch.Tensor:
         """[P, S, D] uniform in the joint limits; seed s of problem p depends only on its GLOBAL
         seed index so any sharding of the seed axis draws the same set."""

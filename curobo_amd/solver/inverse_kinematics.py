@@ -141,17 +141,22 @@ class InverseKinematics:
 
     def solve_pose(self, goal_tool_poses: GoalToolPose, seed_config: Optional[torch.Tensor] = None, return_seeds: int = 1,
                    **unused) -> InverseKinematicsResult:
-        """``goal_tool_poses``: GoalToolPose [batch, T, num_goalset, 3 | 4] (first tool frame is the goal frame);
+        """``goal_tool_poses``: GoalToolPose [batch, 1, T, num_goalset, 3 | 4] (first tool frame is the goal frame; a goal
+        set smaller than ``config.max_goalset`` is padded with its last pose, a larger one rebuilds the solvers);
         ``seed_config`` [batch, num_seeds, dof] optional warm starts."""
         t0 = time.perf_counter()
-        gp, gq = goal_tool_poses.position, goal_tool_poses.quaternion
+        gp, gq = goal_tool_poses.static_goals()
         B, G = int(gp.shape[0]), int(gp.shape[2])
-        if G != self.config.max_goalset:
+        if G > self.config.max_goalset:
             self.config.max_goalset = G
             self._solvers.clear()
+        M = self.config.max_goalset
         slv = self._solver(B)
         pos, quat = gp[:, 0].reshape(B, G, 3), gq[:, 0].reshape(B, G, 4)
-        if G == 1:
+        if G < M:
+            pos = torch.cat([pos, pos[:, -1:].expand(B, M - G, 3)], 1)
+            quat = torch.cat([quat, quat[:, -1:].expand(B, M - G, 4)], 1)
+        if M == 1:
             pos, quat = pos[:, 0], quat[:, 0]
         r = slv.solve_pose(pos, quat, seeds=seed_config, return_seeds=return_seeds, exit_early=self.config.exit_early)
         torch.cuda.synchronize(pos.device) if pos.is_cuda else None

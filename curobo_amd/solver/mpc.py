@@ -106,9 +106,9 @@ class MPCSolver:
         self._knots = None
 
     def update_goal_tool_poses(self, goal_tool_poses: GoalToolPose) -> None:
-        """tracked tool poses [B, T, 1, 3 | 4]; may change between control steps (reference :365-438)"""
-        gp = goal_tool_poses.position.to(self.device, torch.float32).contiguous()
-        gq = goal_tool_poses.quaternion.to(self.device, torch.float32).contiguous()
+        """tracked tool poses [B, 1, T, 1, 3 | 4]; may change between control steps (reference :365-438)"""
+        gp, gq = goal_tool_poses.static_goals()
+        gp, gq = gp.to(self.device, torch.float32).contiguous(), gq.to(self.device, torch.float32).contiguous()
         T = self.kin.num_pose_links
         if gp.shape[1] != T:
             gp, gq = gp[:, :1].expand(-1, T, -1, -1).contiguous(), gq[:, :1].expand(-1, T, -1, -1).contiguous()

@@ -55,6 +55,9 @@ class TrajOptSolverCfg:
     #: behaviour), 1 = all seeds share the best solution.  Measured (tools/trajopt_goal_diversity.py,
     #: 64 feasible goals, 8 seeds): success 0.95 -> 1.00 (C1 world), 0.89 -> 1.00 (C2 world), same time.
     num_ik_goals: int = 0
+    #: goal poses per problem (reference ``max_goalset``): every seed is scored against the closest member of the set, the
+    #: result reports which member the winner reached; smaller sets are padded with their last member
+    num_goalset: int = 1
     #: ``rollout.traj_dt`` only initialises the dt buffers: every solve sets a dt per seed
     rollout: TrajOptRolloutCfg = field(default_factory=lambda: TrajOptRolloutCfg(traj_dt=0.15))
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=27, inner_iters=25, num_iters=100))
@@ -91,6 +94,7 @@ class TrajOptResult:
     jerk: Optional[torch.Tensor] = None
     finetune_passes: int = 0  # optimisation passes that ran (1 = no finetune pass)
     implicit_goal: bool = True  # the trajectories end exactly in ``goal_config`` (spline boundary knots)
+    goalset_index: Optional[torch.Tensor] = None  # member of the goal set the last point is closest to (first tool frame)
     #: every local seed before ranking: dict(success [P, S], traj_dt [P, S], knots [P, S, n_knots, D], cost [P, S])
     all_seeds: Optional[dict] = None
 
@@ -159,7 +163,10 @@ class TrajOptSolver:
     @property
     def ik(self) -> IKSolver:
         if self._ik is None:
-            self._ik = IKSolver.sharded(self.kin, self.scene, self.P, self.cfg.ik, use_cuda_graph=self._use_graph)
+            self._ik = IKSolver.sharded(self.kin, self.scene, self.P, dataclasses.replace(self.cfg.ik, num_goalset=self.cfg.num_goalset),
+                                        use_cuda_graph=self._use_graph)
+            if getattr(self, "_criteria", None):
+                self._ik.update_tool_pose_criteria(self._criteria)
         return self._ik
 
     def reset_seed(self) -> None:
@@ -167,6 +174,15 @@ class TrajOptSolver:
         its Halton points from a stream that otherwise runs on from solve to solve)"""
         if self._ik is not None:
             self._ik.reset_seed()
+
+    def update_tool_pose_criteria(self, criteria) -> None:
+        """``{tool frame: ToolPoseCriteria}`` (reference TrajOptSolver.update_tool_pose_criteria): the optimiser's and the
+        metrics rollout's pose-cost rows are rewritten in place (captured graphs read the new values)"""
+        self._criteria = dict(criteria)
+        for r in (self.rollout, self.metrics_rollout):
+            r.update_tool_pose_criteria(criteria)
+        if self._ik is not None:
+            self._ik.update_tool_pose_criteria(criteria)
 
     # ------------------------------------------------------------------ seeds
     def seed_goal_choice(self, ik_success: torch.Tensor) -> torch.Tensor:
@@ -265,7 +281,8 @@ class TrajOptSolver:
                    goal_state: Optional[torch.Tensor] = None, initial_iters: Optional[int] = None,
                    time_optimal_iters: Optional[int] = None, finetune_iters: Optional[int] = None,
                    finetune_dt_scale: Optional[float] = None) -> TrajOptResult:
-        """``start_position`` [D] (shared) or [P, D]; goal_position [P, 3], goal_quat [P, 4] (wxyz); ``env_idx``
+        """``start_position`` [D] (shared) or [P, D]; goal_position [P, 3], goal_quat [P, 4] (wxyz) -- or [P, T, 3 | 4] per
+        tool frame, or [P, T, g, 3 | 4] with a goal set of g <= ``cfg.num_goalset`` poses per frame; ``env_idx``
         [P]: problem p plans in scene environment env_idx[p] (reference batch-env planning,
         motion_planner_batch.py; ``idxs_env`` / ``use_multi_env`` of the collision costs).  ``seed_config``
         [P, n >= num_seeds, D]: goal configurations of the seeds (reference: the IK solutions the planner passes,
@@ -280,7 +297,8 @@ class TrajOptSolver:
             # the L-BFGS stage of the IK always runs here: the goal configurations should be converged, not just inside the
             # IK tolerances (the reference's motion planner switches exit_early off as well, motion_planner.py:143-144)
             K = self.K
-            ikr = self.ik.solve_pose(goal_position, goal_quat, return_seeds=K, exit_early=False, env_idx=env_idx)
+            gp_ik, gq_ik = self._goal_sets(goal_position, goal_quat)
+            ikr = self.ik.solve_pose(gp_ik[:, 0], gq_ik[:, 0], return_seeds=K, exit_early=False, env_idx=env_idx)
             ik_ok = ikr.success.view(P, K)
             ik_q = ikr.solution.reshape(P, K, D).contiguous()
             choice = self.seed_goal_choice(ik_ok)  # [P, S_global]
@@ -333,6 +351,26 @@ class TrajOptSolver:
             k.num_dof, S, 32, True, False)
         return pos.view(n, T, 3), quat.view(n, T, 4)
 
+    def _goal_sets(self, goal_position: torch.Tensor, goal_quat: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[P, 3] | [P, T, 3] | [P, T, g, 3] (and the quaternions) -> [P, T, cfg.num_goalset, 3 | 4]; a set smaller than the
+        solver's is padded with its last member (the closest-member search then never prefers the padding: ties go to the
+        lower index)"""
+        P, T, G = self.P, self.kin.num_pose_links, self.cfg.num_goalset
+        out = []
+        for x, w in ((goal_position, 3), (goal_quat, 4)):
+            x = x.to(self.device, torch.float32)
+            if x.ndim <= 2 or x.numel() == P * w:
+                x = x.reshape(P, 1, 1, w).expand(P, T, 1, w)
+            elif x.ndim == 3:
+                x = x.reshape(P, T, 1, w)
+            g = x.shape[2]
+            if g > G:
+                raise ValueError(f"goal set of {g} poses exceeds the solver's num_goalset ({G})")
+            if g < G:
+                x = torch.cat([x, x[:, :, -1:].expand(P, T, G - g, w)], 2)
+            out.append(x.contiguous())
+        return out[0], out[1]
+
     def _set_problem(self, start, goal_position, goal_quat, env_idx, seed_goal, use_implicit_goal) -> None:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         mode = env_idx is not None
@@ -340,10 +378,7 @@ class TrajOptSolver:
             self.optimizer._graph = None  # the multi-env flag is a kernel argument: capture again
         self._env_mode = mode
         env = env_idx.to(self.device).long().view(P) if mode else None
-        gp = goal_position.to(self.device, torch.float32)
-        gq = goal_quat.to(self.device, torch.float32)
-        gp = (gp.view(P, 1, 1, 3).expand(P, T, 1, 3) if gp.numel() == P * 3 else gp.view(P, T, 1, 3)).contiguous()
-        gq = (gq.view(P, 1, 1, 4).expand(P, T, 1, 4) if gq.numel() == P * 4 else gq.view(P, T, 1, 4)).contiguous()
+        gp, gq = self._goal_sets(goal_position, goal_quat)
         startP = start.expand(P, D).contiguous()
         for r, seed_rows, prob_rows in ((self.rollout, self._row_seed, self._row_problem),
                                         (self.metrics_rollout, self._mrow_seed, self._mrow_problem)):
@@ -424,6 +459,7 @@ class TrajOptSolver:
         m.evaluate_action(knots, with_gradient=False)
         pos_err = m.pose_pos_dist.view(P * S, -1, T)[:, -1].amax(-1)
         rot_err = m.pose_rot_dist.view(P * S, -1, T)[:, -1].amax(-1)
+        goalset_index = m.goalset_idx.view(P * S, -1, T)[:, -1, 0].clone()
         lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
         q = m.position
         feasible = ((q >= lo - 1e-4) & (q <= hi + 1e-4)).all(-1).all(-1)
@@ -453,7 +489,7 @@ class TrajOptSolver:
         return dict(knots=knots.clone(), dt=dt.clone(), success=ok, pos_err=pos_err.clone(), rot_err=rot_err.clone(),
                     rank=rank, position=q.clone(), velocity=m.velocity.clone(), acceleration=m.acceleration.clone(),
                     jerk=m.jerk.clone(), feasible_rollout=ok_rollout, feasible_interpolated=feasible.clone(), converged=converged,
-                    in_limits=in_limits, no_self_collision=no_self, no_scene_collision=no_scene)
+                    in_limits=in_limits, no_self_collision=no_self, no_scene_collision=no_scene, goalset_index=goalset_index)
 
     def _rank(self, best: dict, seed_goal: torch.Tensor, k: int, passes: int) -> TrajOptResult:
         """the k best seeds per problem over ALL ranks: one all-gather of (rank cost, global seed index, payload)"""
@@ -463,11 +499,12 @@ class TrajOptSolver:
         ranked = (best["rank"] + 1e16 * (~best["success"]).float()).view(P, S)
         f = lambda x: x.reshape(P, S, -1)  # noqa: E731
         parts = [f(best["knots"]), f(best["position"]), f(best["velocity"]), f(best["acceleration"]), f(best["jerk"]),
-                 f(seed_goal), f(best["pos_err"]), f(best["rot_err"]), f(best["success"].float()), f(best["dt"])]
+                 f(seed_goal), f(best["pos_err"]), f(best["rot_err"]), f(best["success"].float()), f(best["dt"]),
+                 f(best["goalset_index"].float())]
         payload = torch.cat(parts, dim=-1)
         cost, idx, win = global_topk(ranked, payload, self.seed_offset, k)
         sizes = [p.shape[-1] for p in parts]
-        kn, pos, vel, acc, jerk, goal, pe, re, ok, dt = torch.split(win, sizes, dim=-1)
+        kn, pos, vel, acc, jerk, goal, pe, re, ok, dt, gsi = torch.split(win, sizes, dim=-1)
         sq = (lambda x: x) if k > 1 else (lambda x: x[:, 0])  # noqa: E731
         lead = (P, k)
         return TrajOptResult(
@@ -475,6 +512,7 @@ class TrajOptSolver:
             position_error=sq(pe[..., 0]), rotation_error=sq(re[..., 0]), cost=sq(cost), seed_index=sq(idx),
             goal_config=sq(goal), traj_dt=sq(dt[..., 0]), velocity=sq(vel.reshape(*lead, H, D)),
             acceleration=sq(acc.reshape(*lead, H, D)), jerk=sq(jerk.reshape(*lead, H, D)), finetune_passes=passes,
+            goalset_index=sq(gsi[..., 0].round().long()),
             all_seeds=dict(success=best["success"].view(P, S), traj_dt=best["dt"].view(P, S),
                            knots=best["knots"].view(P, S, nk, D), cost=ranked,
                            # why a seed failed: limits / collision over the optimiser's points, the same on the

@@ -71,12 +71,26 @@ class JointState:
         return int(self.position.shape[0])
 
 
+def _quat_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+
+
+def _quat_rotate(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    w, u = q[..., :1], q[..., 1:]
+    t = 2.0 * torch.cross(u, v, dim=-1)
+    return v + w * t + torch.cross(u, t, dim=-1)
+
+
 @dataclass
 class Pose:
-    """position [..., 3] and quaternion [..., 4] (w, x, y, z)"""
+    """position [..., 3] and quaternion [..., 4] (w, x, y, z) (reference _src/types/pose.py: the members the planners use)"""
 
     position: torch.Tensor
     quaternion: torch.Tensor
+    name: Optional[str] = None
 
     def __post_init__(self):
         if not torch.is_tensor(self.position):
@@ -84,29 +98,171 @@ class Pose:
         if not torch.is_tensor(self.quaternion):
             self.quaternion = torch.as_tensor(self.quaternion, dtype=torch.float32)
 
+    @staticmethod
+    def from_list(pose: Sequence[float], device_cfg: Optional[DeviceCfg] = None) -> "Pose":
+        """[x, y, z, qw, qx, qy, qz] -> Pose with a batch of one (reference Pose.from_list)"""
+        dev = device_cfg.device if device_cfg is not None else None
+        t = torch.as_tensor([float(x) for x in pose], dtype=torch.float32, device=dev)
+        return Pose(t[:3].view(1, 3).clone(), t[3:7].view(1, 4).clone())
+
+    def to(self, device) -> "Pose":
+        return Pose(self.position.to(device), self.quaternion.to(device), self.name)
+
+    def clone(self) -> "Pose":
+        return Pose(self.position.clone(), self.quaternion.clone(), self.name)
+
+    def multiply(self, other: "Pose") -> "Pose":
+        """self * other: ``other`` is expressed in the frame of ``self`` (reference Pose.multiply)"""
+        q1, p1 = self.quaternion, self.position
+        q2, p2 = other.quaternion.to(q1.device), other.position.to(p1.device)
+        return Pose(p1 + _quat_rotate(q1, p2.expand_as(p1) if p2.shape[0] == 1 else p2), _quat_mul(q1, q2))
+
+    def inverse(self) -> "Pose":
+        qi = self.quaternion * self.quaternion.new_tensor([1.0, -1.0, -1.0, -1.0])
+        return Pose(-_quat_rotate(qi, self.position), qi)
+
 
 @dataclass
 class GoalToolPose:
-    """goal poses per tool frame: position [batch, T, num_goalset, 3], quaternion [batch, T, num_goalset, 4] (wxyz)
-    (reference GoalToolPose, _src/types/tool_pose.py)"""
+    """goal poses per tool frame (reference GoalToolPose, _src/types/tool_pose.py:182-340): position [batch, horizon,
+    num_links, num_goalset, 3], quaternion [batch, horizon, num_links, num_goalset, 4] (wxyz).  The solvers of this package
+    take static goals: with horizon > 1 they read the last entry."""
 
     tool_frames: List[str]
     position: torch.Tensor
     quaternion: torch.Tensor
+
+    def __post_init__(self):
+        if self.position.ndim != 5:
+            raise ValueError(f"GoalToolPose position must be 5D [B,H,L,G,3], got {tuple(self.position.shape)}")
+        if self.quaternion.ndim != 5:
+            raise ValueError(f"GoalToolPose quaternion must be 5D [B,H,L,G,4], got {tuple(self.quaternion.shape)}")
+        if self.position.shape[2] != len(self.tool_frames):
+            raise ValueError(f"num_links dim ({self.position.shape[2]}) != len(tool_frames) ({len(self.tool_frames)})")
 
     @property
     def batch_size(self) -> int:
         return int(self.position.shape[0])
 
     @property
-    def num_goalset(self) -> int:
+    def horizon(self) -> int:
+        return int(self.position.shape[1])
+
+    @property
+    def num_links(self) -> int:
         return int(self.position.shape[2])
+
+    @property
+    def num_goalset(self) -> int:
+        return int(self.position.shape[3])
+
+    @property
+    def shape(self):
+        return self.position.shape
+
+    @property
+    def device(self):
+        return self.position.device
+
+    def static_goals(self):
+        """(position [batch, num_links, num_goalset, 3], quaternion [batch, num_links, num_goalset, 4]): what the solvers read"""
+        return self.position[:, -1], self.quaternion[:, -1]
+
+    @classmethod
+    def from_poses(cls, pose_dict, ordered_tool_frames: Optional[List[str]] = None, num_goalset: int = 1) -> "GoalToolPose":
+        """per-frame ``Pose`` objects with position [batch * num_goalset, 3] -> GoalToolPose [batch, 1, num_links,
+        num_goalset, 3 | 4] (reference from_poses, :242-277)"""
+        if not pose_dict:
+            raise ValueError("pose_dict cannot be empty")
+        frames = list(ordered_tool_frames) if ordered_tool_frames else list(pose_dict.keys())
+        missing = set(frames) - set(pose_dict.keys())
+        if missing:
+            raise ValueError(f"Missing poses for links: {missing}")
+        batch = pose_dict[frames[0]].position.shape[0] // num_goalset
+        pos = torch.stack([pose_dict[f].position.reshape(batch, num_goalset, 3) for f in frames], dim=1)
+        quat = torch.stack([pose_dict[f].quaternion.reshape(batch, num_goalset, 4) for f in frames], dim=1)
+        return cls(frames, pos.unsqueeze(1), quat.unsqueeze(1))
+
+    def get_link_pose(self, link_name: str) -> Pose:
+        if link_name not in self.tool_frames:
+            raise ValueError(f"Link {link_name} not found in {self.tool_frames}")
+        li = self.tool_frames.index(link_name)
+        return Pose(self.position[:, :, li].reshape(-1, 3), self.quaternion[:, :, li].reshape(-1, 4), link_name)
+
+    def to_dict(self):
+        return {n: self.get_link_pose(n) for n in self.tool_frames}
+
+    def clone(self) -> "GoalToolPose":
+        return GoalToolPose(list(self.tool_frames), self.position.clone(), self.quaternion.clone())
+
+    def __len__(self) -> int:
+        return len(self.tool_frames)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, str):
+            return self.get_link_pose(idx)
+        if isinstance(idx, int):
+            return GoalToolPose(self.tool_frames, self.position[idx].unsqueeze(0), self.quaternion[idx].unsqueeze(0))
+        return GoalToolPose(self.tool_frames, self.position[idx], self.quaternion[idx])
 
 
 @dataclass
 class ToolPoseCriteria:
-    """per-axis weights of the pose cost (reference _src/cost/tool_pose_criteria.py): terminal / non-terminal
-    position + rotation axis factors"""
+    """how the pose cost of one tool frame is weighted (reference _src/cost/tool_pose_criteria.py:17-200): factors on the
+    (x, y, z, roll, pitch, yaw) terms at the last point of a trajectory and at the points before it, convergence tolerances
+    (position [m], rotation [rad]) and whether the error is measured in the goal frame"""
 
-    terminal_pose_axes_weight_factor: List[float] = field(default_factory=lambda: [1.0] * 6)
-    non_terminal_pose_axes_weight_factor: List[float] = field(default_factory=lambda: [0.0] * 6)
+    terminal_pose_axes_weight_factor: Optional[Sequence[float]] = None
+    non_terminal_pose_axes_weight_factor: Optional[Sequence[float]] = None
+    terminal_pose_convergence_tolerance: Optional[Sequence[float]] = None
+    non_terminal_pose_convergence_tolerance: Optional[Sequence[float]] = None
+    project_distance_to_goal: bool = False
+
+    def __post_init__(self):
+        def vec(x, n, default, what):
+            x = [default] * n if x is None else [float(v) for v in (x.tolist() if torch.is_tensor(x) else x)]
+            if len(x) != n:
+                raise ValueError(f"{what} must be a list of {n} floats, got {x}")
+            return x
+
+        self.terminal_pose_axes_weight_factor = vec(self.terminal_pose_axes_weight_factor, 6, 1.0, "terminal_pose_axes_weight_factor")
+        self.non_terminal_pose_axes_weight_factor = vec(self.non_terminal_pose_axes_weight_factor, 6, 0.0,
+                                                        "non_terminal_pose_axes_weight_factor")
+        self.terminal_pose_convergence_tolerance = vec(self.terminal_pose_convergence_tolerance, 2, 0.0,
+                                                       "terminal_pose_convergence_tolerance")
+        self.non_terminal_pose_convergence_tolerance = vec(self.non_terminal_pose_convergence_tolerance, 2, 0.0,
+                                                           "non_terminal_pose_convergence_tolerance")
+        if torch.is_tensor(self.project_distance_to_goal):
+            self.project_distance_to_goal = bool(self.project_distance_to_goal.reshape(-1)[0].item())
+        if not isinstance(self.project_distance_to_goal, bool):
+            raise ValueError(f"project_distance_to_goal must be a bool, got {self.project_distance_to_goal}")
+
+    def clone(self) -> "ToolPoseCriteria":
+        return ToolPoseCriteria(list(self.terminal_pose_axes_weight_factor), list(self.non_terminal_pose_axes_weight_factor),
+                                list(self.terminal_pose_convergence_tolerance), list(self.non_terminal_pose_convergence_tolerance),
+                                self.project_distance_to_goal)
+
+    @staticmethod
+    def track_position(xyz: Sequence[float] = (1.0, 1.0, 1.0)) -> "ToolPoseCriteria":
+        w = [xyz[0], xyz[1], xyz[2], 0.0, 0.0, 0.0]
+        return ToolPoseCriteria(w, list(w))
+
+    @staticmethod
+    def track_orientation(rpy: Sequence[float] = (0.001, 0.001, 0.001), non_terminal_scale: float = 1.0) -> "ToolPoseCriteria":
+        return ToolPoseCriteria([0.0, 0.0, 0.0, rpy[0], rpy[1], rpy[2]], [0.0, 0.0, 0.0] + [non_terminal_scale * r for r in rpy])
+
+    @staticmethod
+    def track_position_and_orientation(xyz: Sequence[float] = (1.0, 1.0, 1.0), rpy: Sequence[float] = (1.0, 1.0, 1.0),
+                                       non_terminal_scale: float = 0.1) -> "ToolPoseCriteria":
+        w = [xyz[0], xyz[1], xyz[2], rpy[0], rpy[1], rpy[2]]
+        return ToolPoseCriteria(w, [non_terminal_scale * v for v in w])
+
+    @staticmethod
+    def linear_motion(axis: str = "z", non_terminal_scale: float = 1.0, project_distance_to_goal: bool = True) -> "ToolPoseCriteria":
+        """keep the tool on the line along ``axis`` through the goal (and at the goal's orientation) on the way there: the
+        points before the last one are held on the other two axes and on all three rotations"""
+        if axis not in ("x", "y", "z"):
+            raise ValueError(f"Invalid axis: {axis}, must be 'x', 'y', or 'z'")
+        free = [1.0 if axis == a else 0.0 for a in ("x", "y", "z")]
+        return ToolPoseCriteria([1.0] * 6, [non_terminal_scale * (1.0 - f) for f in free] + [non_terminal_scale] * 3,
+                                project_distance_to_goal=project_distance_to_goal)

@@ -46,7 +46,7 @@ def test_mpc_tracks_a_pose_goal_in_closed_loop(continuous, oracle, device):
         assert float((a.position - state.position).abs().max()) < step_bound
         state = JointState(position=a.position, velocity=a.velocity, acceleration=a.acceleration)  # perfect tracking
         st = fk.compute_kinematics(JointState.from_position(state.position.unsqueeze(1)))
-        errs.append((st.tool_poses.position[:, 0, 0] - goal.position[:, 0, 0]).norm(dim=-1).max().item())
+        errs.append((st.tool_poses.position[:, 0, 0] - goal.position[:, 0, 0, 0]).norm(dim=-1).max().item())
         assert bool(res.feasible.all())
     assert reopt == 400 // per_plan, reopt  # one re-optimisation per knot interval (two in the continuous scheme)
     assert errs[-1] < 0.005 and errs[-1] < 0.05 * errs[0], (errs[0], errs[-1])
@@ -65,6 +65,6 @@ def test_mpc_tracks_a_pose_goal_in_closed_loop(continuous, oracle, device):
         a = mpc.optimize_next_action(state).next_action
         state = JointState(position=a.position, velocity=a.velocity, acceleration=a.acceleration)
     st = fk.compute_kinematics(JointState.from_position(state.position.unsqueeze(1)))
-    assert float((st.tool_poses.position[:, 0, 0] - goal2.position[:, 0, 0]).norm(dim=-1).max()) < 0.01
+    assert float((st.tool_poses.position[:, 0, 0] - goal2.position[:, 0, 0, 0]).norm(dim=-1).max()) < 0.01
     seq = mpc.optimize_action_sequence(state)
     assert seq.action_sequence.position.shape[0] == B and seq.action_buffer.shape == (B, 16, 7)

@@ -195,7 +195,7 @@ def test_motion_planner_plan_pose_and_plan_cspace(oracle, device, this_repos_cur
     traj = res.js_solution.position[0].cpu().numpy()
     chk = _verify_with_oracle(oracle, model, arrays, traj, res.js_solution.dt[0].cpu().numpy(), cur.position[0].cpu().numpy(),
                               config.trajopt_solver_config.solver_cfg().rollout)
-    np.testing.assert_allclose(chk["link_pos"].reshape(1, 33, 3)[0, -1], goal.position[0, 0, 0].cpu().numpy(), atol=5e-3)
+    np.testing.assert_allclose(chk["link_pos"].reshape(1, 33, 3)[0, -1], goal.position[0, 0, 0, 0].cpu().numpy(), atol=5e-3)
     # the interpolated plan: interpolation_dt samples of the same spline, trimmed to the last step
     plan = res.get_interpolated_plan()
     n = plan.position.shape[0]
@@ -254,7 +254,7 @@ def test_batch_motion_planner_one_world_per_problem(oracle, device, this_repos_c
     s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
     d = oracle.scene_collision(s2, arrays, 1.0, 0.0, env_query_idx=env[ok].astype(np.int32), use_multi_env=True)["distance"]
     assert (d.sum((1, 2)) == 0).all()
-    np.testing.assert_allclose(chk["link_pos"].reshape(n, H, 3)[:, -1], goal.position[:, 0, 0].cpu().numpy()[ok], atol=5e-3)
+    np.testing.assert_allclose(chk["link_pos"].reshape(n, H, 3)[:, -1], goal.position[:, 0, 0, 0].cpu().numpy()[ok], atol=5e-3)
     res_c = planner.plan_cspace(goal_js, cur)
     okc = res_c.success[:, 0].cpu().numpy()
     assert okc.mean() >= 0.75

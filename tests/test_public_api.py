@@ -148,5 +148,90 @@ def test_ik_benchmark_call_sequence(device):
         assert success >= 95.0 and p_err < 0.005 and q_err < 0.05, results
         # the solutions really solve the problem: FK of the solution reaches the goal
         st = ik_solver.compute_kinematics(result.js_solution[:, 0])
-        err = (st.tool_poses.position[:, 0, 0] - goal_tool_poses.position[:, 0, 0]).norm(dim=-1)
+        err = (st.tool_poses.position[:, 0, 0] - goal_tool_poses.position[:, 0, 0, 0]).norm(dim=-1)
         assert float(err[result.success.view(-1)].max()) < 0.005
+
+
+def test_pose_goal_tool_pose_and_criteria_types():
+    """reference shapes and factories: Pose.from_list / multiply (_src/types/pose.py), GoalToolPose [batch, horizon, links,
+    goalset, 3 | 4] with from_poses (_src/types/tool_pose.py:182-277), ToolPoseCriteria factories
+    (_src/cost/tool_pose_criteria.py:143-200)"""
+    from scipy.spatial.transform import Rotation as R
+
+    from curobo.types import GoalToolPose, Pose, ToolPoseCriteria
+
+    rng = np.random.default_rng(0)
+    qa, qb = R.random(5, random_state=1), R.random(5, random_state=2)
+    pa, pb = rng.normal(size=(5, 3)), rng.normal(size=(5, 3))
+    wxyz = lambda r: torch.as_tensor(np.roll(r.as_quat(), 1, axis=-1), dtype=torch.float32)  # noqa: E731
+    a = Pose(torch.as_tensor(pa, dtype=torch.float32), wxyz(qa))
+    b = Pose(torch.as_tensor(pb, dtype=torch.float32), wxyz(qb))
+    ab = a.multiply(b)
+    np.testing.assert_allclose(ab.position.numpy(), pa + qa.apply(pb), atol=1e-5)
+    want_q = np.roll((qa * qb).as_quat(), 1, axis=-1)
+    got_q = ab.quaternion.numpy()
+    assert np.minimum(np.abs(got_q - want_q).max(1), np.abs(got_q + want_q).max(1)).max() < 1e-5
+    ident = a.multiply(a.inverse())
+    np.testing.assert_allclose(ident.position.numpy(), 0.0, atol=1e-5)
+    np.testing.assert_allclose(ident.quaternion.abs().numpy(), [[1, 0, 0, 0]] * 5, atol=1e-5)
+    off = Pose.from_list([0, 0, -0.15, 1, 0, 0, 0])
+    assert off.position.shape == (1, 3) and off.quaternion.shape == (1, 4)
+    np.testing.assert_allclose(a.multiply(off).position.numpy(), pa + qa.apply([0, 0, -0.15]), atol=1e-5)  # in the tool frame
+    np.testing.assert_allclose(off.multiply(a).position.numpy(), pa + [0, 0, -0.15], atol=1e-5)  # in the world frame
+
+    g = GoalToolPose.from_poses({"tool": Pose(torch.arange(18.0).view(6, 3), torch.tensor([[1.0, 0, 0, 0]]).repeat(6, 1))}, num_goalset=3)
+    assert g.position.shape == (2, 1, 1, 3, 3) and g.quaternion.shape == (2, 1, 1, 3, 4)
+    assert (g.batch_size, g.horizon, g.num_links, g.num_goalset) == (2, 1, 1, 3) and len(g) == 1
+    assert g.position[1, 0, 0, 2].tolist() == [15.0, 16.0, 17.0]
+    p, q = g.static_goals()
+    assert p.shape == (2, 1, 3, 3) and q.shape == (2, 1, 3, 4)
+    assert g["tool"].position.shape == (6, 3) and g[1].position.shape == (1, 1, 1, 3, 3)
+    two = GoalToolPose.from_poses({"a": Pose(torch.zeros(2, 3), torch.zeros(2, 4)), "b": Pose(torch.ones(2, 3), torch.ones(2, 4))},
+                                  ordered_tool_frames=["b", "a"])
+    assert two.tool_frames == ["b", "a"] and float(two.position[0, 0, 0, 0, 0]) == 1.0
+    with pytest.raises(ValueError, match="5D"):
+        GoalToolPose(["tool"], torch.zeros(2, 1, 1, 3), torch.zeros(2, 1, 1, 4))
+    with pytest.raises(ValueError, match="num_links"):
+        GoalToolPose(["a", "b"], torch.zeros(2, 1, 1, 1, 3), torch.zeros(2, 1, 1, 1, 4))
+    with pytest.raises(ValueError, match="Missing poses"):
+        GoalToolPose.from_poses({"a": off}, ordered_tool_frames=["a", "b"])
+
+    c = ToolPoseCriteria()
+    assert c.terminal_pose_axes_weight_factor == [1.0] * 6 and c.non_terminal_pose_axes_weight_factor == [0.0] * 6
+    assert c.terminal_pose_convergence_tolerance == [0.0, 0.0] and c.project_distance_to_goal is False
+    lm = ToolPoseCriteria.linear_motion("y", non_terminal_scale=2.0)
+    assert lm.non_terminal_pose_axes_weight_factor == [2.0, 0.0, 2.0, 2.0, 2.0, 2.0] and lm.project_distance_to_goal is True
+    assert lm.terminal_pose_axes_weight_factor == [1.0] * 6
+    assert ToolPoseCriteria.track_position([1, 2, 3]).non_terminal_pose_axes_weight_factor == [1.0, 2.0, 3.0, 0.0, 0.0, 0.0]
+    assert ToolPoseCriteria.track_orientation([1, 1, 1], 0.5).non_terminal_pose_axes_weight_factor == [0.0, 0.0, 0.0, 0.5, 0.5, 0.5]
+    assert ToolPoseCriteria.track_position_and_orientation().non_terminal_pose_axes_weight_factor == [0.1] * 6
+    with pytest.raises(ValueError, match="6 floats"):
+        ToolPoseCriteria(terminal_pose_axes_weight_factor=[1.0, 1.0])
+    with pytest.raises(ValueError, match="Invalid axis"):
+        ToolPoseCriteria.linear_motion("w")
+    assert lm.clone() == lm
+
+
+def test_link_sphere_toggles_and_grasp_links_from_the_robot_file():
+    """reference KinematicsParams.disable_link_spheres / enable_link_spheres / reset_link_spheres (robot/types/
+    kinematics_params.py:558-595) and ``grasp_contact_link_names`` of the robot yaml (franka.yml:6-10)"""
+    from curobo.kinematics import KinematicsCfg
+
+    cfg = KinematicsCfg.from_packaged("franka", device="cpu")
+    kp = cfg.kinematics_config
+    assert kp.grasp_contact_link_names == ["panda_hand", "panda_leftfinger", "panda_rightfinger", "attached_object"]
+    idx = kp.get_sphere_index_from_link_name("panda_leftfinger")
+    assert idx.numel() > 0 and (kp.link_sphere_idx_map[idx].long() == kp.link_names.index("panda_leftfinger")).all()
+    before = kp.link_spheres.clone()
+    kp.disable_link_spheres("panda_leftfinger")
+    assert (kp.link_spheres[:, idx, 3] == -100.0).all()
+    other = torch.ones(kp.num_spheres, dtype=torch.bool)
+    other[idx] = False
+    assert torch.equal(kp.link_spheres[:, other], before[:, other]) and torch.equal(kp.link_spheres[:, idx, :3], before[:, idx, :3])
+    kp.link_spheres[:, idx, :3] += 0.01
+    kp.enable_link_spheres("panda_leftfinger")  # radius only
+    assert torch.equal(kp.link_spheres[:, idx, 3], before[:, idx, 3]) and not torch.equal(kp.link_spheres[:, idx, :3], before[:, idx, :3])
+    kp.reset_link_spheres("panda_leftfinger")
+    assert torch.equal(kp.link_spheres, before)
+    with pytest.raises(ValueError, match="not found"):
+        kp.enable_link_spheres("nope")
