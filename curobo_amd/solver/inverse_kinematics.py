@@ -127,6 +127,38 @@ class InverseKinematics:
         self._solvers.clear()
         self._checker = None
 
+    # ---- reference solver_ik.py:184-216, 253-257, 293-296
+    @property
+    def action_dim(self) -> int:
+        return self.dof
+
+    @property
+    def action_horizon(self) -> int:
+        return 1
+
+    @property
+    def default_joint_state(self) -> JointState:
+        from ..workloads import start_configuration
+
+        q = torch.as_tensor(start_configuration(self.config.kinematics.model), device=self.config.kinematics.kinematics_config.device)
+        return JointState.from_position(q, joint_names=self.joint_names)
+
+    def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
+        self.config.kinematics.kinematics_config.update_link_inertial(link_name, mass, com, inertia)
+
+    def update_links_inertial(self, link_properties: Dict) -> None:
+        self.config.kinematics.kinematics_config.update_links_inertial(link_properties)
+
+    def update_tool_pose_criteria(self, tool_pose_criteria: Dict) -> None:
+        """``{tool frame: ToolPoseCriteria}``: in place on the solvers that exist, and kept for the ones built later"""
+        self._criteria = dict(tool_pose_criteria)
+        for s in self._solvers.values():
+            s.update_tool_pose_criteria(tool_pose_criteria)
+
+    def destroy(self) -> None:
+        self._solvers.clear()
+        self._checker = None
+
     def _solver(self, batch: int) -> IKSolver:
         if batch not in self._solvers:
             c = self.config
@@ -137,6 +169,8 @@ class InverseKinematics:
             if not c.self_collision_check:
                 cfg.rollout.self_collision_weight = 0.0
             self._solvers[batch] = IKSolver(c.kinematics.kinematics_config, c.scene, batch, cfg, use_cuda_graph=c.use_cuda_graph)
+            if getattr(self, "_criteria", None):
+                self._solvers[batch].update_tool_pose_criteria(self._criteria)
         return self._solvers[batch]
 
     def solve_pose(self, goal_tool_poses: GoalToolPose, seed_config: Optional[torch.Tensor] = None, return_seeds: int = 1,

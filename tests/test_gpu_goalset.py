@@ -287,3 +287,42 @@ def test_planner_goal_set_and_plan_grasp(oracle, device, this_repos_curobo):  # 
     far = GoalToolPose(grasps.tool_frames, grasps.position + torch.tensor([3.0, 0, 0], device=device), grasps.quaternion.clone())
     g3 = planner.plan_grasp(far, cur)
     assert not bool(g3.success.any()) and g3.status in ("Goalset planning returned None.", "No grasp in goal set was reachable.")
+
+
+def test_ik_position_only_criteria(oracle, device, this_repos_curobo):  # noqa: F811
+    """``InverseKinematics.update_tool_pose_criteria`` with ``ToolPoseCriteria.track_position``: the orientation of the goal is
+    ignored (it is a rotation the arm cannot take there: the goal orientation flipped), the position is reached; the
+    standard criteria then make the same goals fail on rotation"""
+    from curobo.inverse_kinematics import InverseKinematics, InverseKinematicsCfg
+    from curobo.types import GoalToolPose, JointState, ToolPoseCriteria
+
+    n = 16
+    config = InverseKinematicsCfg.create(robot="franka.yml", scene_model="collision_table.yml", num_seeds=16, max_batch_size=n)
+    ik = InverseKinematics(config)
+    model = config.kinematics.model
+    frame = ik.tool_frames[0]
+    q = ik.sample_configs(n)
+    goal = ik.compute_kinematics(JointState.from_position(q)).tool_poses.as_goal()
+    # same positions, orientations of OTHER samples: mostly unreachable as a full pose
+    mixed = GoalToolPose(goal.tool_frames, goal.position.clone(), goal.quaternion.flip(0).contiguous())
+    full = ik.solve_pose(mixed)
+    ik.update_tool_pose_criteria({frame: ToolPoseCriteria.track_position()})
+    ik.reset_seed()
+    pos_only = ik.solve_pose(mixed)
+    assert int(pos_only.success.sum()) == n and int(pos_only.success.sum()) >= int(full.success.sum())
+    sol = pos_only.solution[:, 0].cpu().numpy()
+    p, qn = _tool_pose(oracle, model, sol)
+    np.testing.assert_allclose(p, mixed.position[:, 0, 0, 0].cpu().numpy(), atol=5e-3)
+    gq = mixed.quaternion[:, 0, 0, 0].cpu().numpy()
+    off = np.minimum(np.linalg.norm(qn - gq, axis=1), np.linalg.norm(qn + gq, axis=1))
+    assert (off > 0.05).sum() >= n // 2, "the orientation was free"
+    fk = oracle.kinematics_forward(sol, model.as_dict())
+    sph = fk["robot_spheres"].reshape(n, 1, -1, 4)
+    assert (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
+    # back to the standard criteria: a solver built before and one built after the call both see them
+    ik.update_tool_pose_criteria({frame: ToolPoseCriteria()})
+    ik.reset_seed()
+    again = ik.solve_pose(mixed)
+    ok = again.success[:, 0].cpu().numpy()
+    assert (again.rotation_error[:, 0].cpu().numpy()[ok] < 0.05).all()
+    np.testing.assert_array_equal(ok, full.success[:, 0].cpu().numpy())
