@@ -162,6 +162,8 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   const char *what = "launch_rnea_forward";
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
+  CUROBO_REQUIRE((long long)batch_size * (num_dof > 4 ? num_dof : 4) < (1ll << 30), "%s: batch too large for 32-bit row offsets (%d x %d)",
+                 what, batch_size, num_dof);
   if (batch_size == 0) return CUROBO_HIP_OK;
   RneaArgs a{};
   a.tau = tau; a.q = q; a.qd = qd; a.qdd = qdd; a.fixed_transforms = fixed_transforms;
@@ -204,6 +206,8 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   const char *what = "launch_rnea_backward";
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
+  CUROBO_REQUIRE((long long)batch_size * (num_dof > 4 ? num_dof : 4) < (1ll << 30), "%s: batch too large for 32-bit row offsets (%d x %d)",
+                 what, batch_size, num_dof);
   CUROBO_REQUIRE(workspace != nullptr || batch_size == 0, "%s: workspace [num_links * 18 * batch_size] floats is required", what);
   if (batch_size == 0) return CUROBO_HIP_OK;
   RneaArgs a{};

@@ -41,11 +41,15 @@ __device__ __forceinline__ LinkConst link_const(const float *s_f, const int *s_i
   c.in = c.F + 16;
   c.mul = c.F[22];
   c.off = c.F[23];
-  c.jt = s_i[k * 3];
-  c.ji = s_i[k * 3 + 1];
-  c.par = s_i[k * 3 + 2];
+  // every lane of a wavefront walks the same link: joint type, joint index and parent go to scalar registers, so that
+  // what depends on them is scalar control flow (no exec-mask traffic, no per-lane selects) and the rows they address
+  // have scalar base addresses
+  c.jt = __builtin_amdgcn_readfirstlane(s_i[k * 3]);
+  c.ji = __builtin_amdgcn_readfirstlane(s_i[k * 3 + 1]);
+  c.par = __builtin_amdgcn_readfirstlane(s_i[k * 3 + 2]);
   return c;
 }
+__device__ __forceinline__ int order_entry(const int *order, int idx) { return __builtin_amdgcn_readfirstlane(order[idx]); }
 
 __device__ __forceinline__ void stage_links(const RneaArgs &a, float *s_f, int *s_i) {
   const int L = a.num_links;
@@ -94,12 +98,27 @@ __device__ __forceinline__ Sv sv_zero() { return Sv{make_f3(0.f, 0.f, 0.f), make
 __device__ __forceinline__ Sv operator+(Sv a, Sv b) { return Sv{a.w + b.w, a.v + b.v}; }
 __device__ __forceinline__ Sv operator-(Sv a, Sv b) { return Sv{a.w - b.w, a.v - b.v}; }
 __device__ __forceinline__ float sv_dot(Sv a, Sv b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+// (the component index is the joint's axis: the same for the whole wavefront, so these are scalar branches)
 __device__ __forceinline__ float sv_get(const Sv &s, int i) {
-  return i == 0 ? s.w.x : i == 1 ? s.w.y : i == 2 ? s.w.z : i == 3 ? s.v.x : i == 4 ? s.v.y : s.v.z;
+  switch (i) {
+    case 0: return s.w.x;
+    case 1: return s.w.y;
+    case 2: return s.w.z;
+    case 3: return s.v.x;
+    case 4: return s.v.y;
+    default: return s.v.z;
+  }
 }
 __device__ __forceinline__ void sv_add_at(Sv &s, int i, float x) {
-  s.w.x += i == 0 ? x : 0.f; s.w.y += i == 1 ? x : 0.f; s.w.z += i == 2 ? x : 0.f;
-  s.v.x += i == 3 ? x : 0.f; s.v.y += i == 4 ? x : 0.f; s.v.z += i == 5 ? x : 0.f;
+  switch (i) {
+    case 0: s.w.x += x; break;
+    case 1: s.w.y += x; break;
+    case 2: s.w.z += x; break;
+    case 3: s.v.x += x; break;
+    case 4: s.v.y += x; break;
+    case 5: s.v.z += x; break;
+    default: break;
+  }
 }
 __device__ __forceinline__ Sv sv_unit(int i, float x) {
   Sv s = sv_zero();
@@ -111,6 +130,15 @@ struct Rp {  // local transform: R rotates child -> parent (row-major), p = chil
   float R[9];
   f3 p;
 };
+template <int A1, int A2>
+__device__ __forceinline__ void rotate_columns(float *R, float s, float c) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const float u = R[r * 3 + A1], w = R[r * 3 + A2];
+    R[r * 3 + A1] = c * u + s * w;
+    R[r * 3 + A2] = -s * u + c * w;
+  }
+}
 // compute_local_Rp (rnea_helpers.cuh): R = R_fixed R_joint(q), p = p_fixed (+ R_fixed d for prismatic)
 __device__ __forceinline__ Rp local_Rp(const float *F, int jt, float q) {
   Rp t;
@@ -121,20 +149,17 @@ __device__ __forceinline__ Rp local_Rp(const float *F, int jt, float q) {
   if (jt >= J_X_ROT) {
     float s, c;
     sincos_bounded(q, &s, &c);
-    const int ax = jt - J_X_ROT, a1 = ax == 2 ? 0 : ax + 1, a2 = ax == 0 ? 2 : ax - 1;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const float u = a1 == 0 ? t.R[r * 3] : a1 == 1 ? t.R[r * 3 + 1] : t.R[r * 3 + 2];
-      const float w = a2 == 0 ? t.R[r * 3] : a2 == 1 ? t.R[r * 3 + 1] : t.R[r * 3 + 2];
-      const float n1 = c * u + s * w, n2 = -s * u + c * w;
-      if (a1 == 0) t.R[r * 3] = n1; else if (a1 == 1) t.R[r * 3 + 1] = n1; else t.R[r * 3 + 2] = n1;
-      if (a2 == 0) t.R[r * 3] = n2; else if (a2 == 1) t.R[r * 3 + 1] = n2; else t.R[r * 3 + 2] = n2;
+    switch (jt - J_X_ROT) {  // columns a1 = axis + 1, a2 = axis + 2 of every row: (u, w) -> (c u + s w, -s u + c w)
+      case 0: rotate_columns<1, 2>(t.R, s, c); break;
+      case 1: rotate_columns<2, 0>(t.R, s, c); break;
+      default: rotate_columns<0, 1>(t.R, s, c); break;
     }
   } else if (jt >= J_X_PRISM) {
-    const int ax = jt - J_X_PRISM;
-    t.p.x += (ax == 0 ? F[0] : ax == 1 ? F[1] : F[2]) * q;
-    t.p.y += (ax == 0 ? F[4] : ax == 1 ? F[5] : F[6]) * q;
-    t.p.z += (ax == 0 ? F[8] : ax == 1 ? F[9] : F[10]) * q;
+    switch (jt - J_X_PRISM) {
+      case 0: t.p.x += F[0] * q; t.p.y += F[4] * q; t.p.z += F[8] * q; break;
+      case 1: t.p.x += F[1] * q; t.p.y += F[5] * q; t.p.z += F[9] * q; break;
+      default: t.p.x += F[2] * q; t.p.y += F[6] * q; t.p.z += F[10] * q; break;
+    }
   }
   return t;
 }
@@ -169,13 +194,23 @@ __device__ __forceinline__ Sv crm(Sv a, Sv b) { return Sv{cross(a.w, b.w), cross
 __device__ __forceinline__ int s_index(int jt) { return jt >= J_X_ROT ? jt - J_X_ROT : 3 + jt - J_X_PRISM; }
 
 // SoA slots: slot(k, c)[b]
+// The slot is the same for the whole wavefront (the link being walked): a row address is a scalar base plus the lane's
+// 32-bit byte offset -- scalar arithmetic per row instead of a 64-bit vector multiply-add per access.
+__device__ __forceinline__ const float *row_at(const float *base, size_t B, int slot, uint32_t byte_off) {
+  return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base + (size_t)slot * B) + byte_off);
+}
+__device__ __forceinline__ float *row_at(float *base, size_t B, int slot, uint32_t byte_off) {
+  return reinterpret_cast<float *>(reinterpret_cast<char *>(base + (size_t)slot * B) + byte_off);
+}
 __device__ __forceinline__ Sv load_sv(const float *base, size_t B, int slot, size_t b) {
-  const float *p = base + (size_t)slot * B + b;
-  return Sv{make_f3(p[0], p[B], p[2 * B]), make_f3(p[3 * B], p[4 * B], p[5 * B])};
+  const uint32_t o = (uint32_t)b * 4u;
+  return Sv{make_f3(*row_at(base, B, slot, o), *row_at(base, B, slot + 1, o), *row_at(base, B, slot + 2, o)),
+            make_f3(*row_at(base, B, slot + 3, o), *row_at(base, B, slot + 4, o), *row_at(base, B, slot + 5, o))};
 }
 __device__ __forceinline__ void store_sv(float *base, size_t B, int slot, size_t b, Sv s) {
-  float *p = base + (size_t)slot * B + b;
-  p[0] = s.w.x; p[B] = s.w.y; p[2 * B] = s.w.z; p[3 * B] = s.v.x; p[4 * B] = s.v.y; p[5 * B] = s.v.z;
+  const uint32_t o = (uint32_t)b * 4u;
+  *row_at(base, B, slot, o) = s.w.x; *row_at(base, B, slot + 1, o) = s.w.y; *row_at(base, B, slot + 2, o) = s.w.z;
+  *row_at(base, B, slot + 3, o) = s.v.x; *row_at(base, B, slot + 4, o) = s.v.y; *row_at(base, B, slot + 5, o) = s.v.z;
 }
 
 // ---- the spatial algebra of the walks as a policy.  LaneAlg: one element per lane, a spatial vector is six registers
@@ -281,13 +316,13 @@ struct QuadAlg {
     return s;
   }
   __device__ __forceinline__ SvT load(const float *base, size_t B, int slot, size_t b) const {
-    const float *p = base + (size_t)(slot + c) * B + b;
-    return SvQ{p[0], p[3 * B]};
+    const uint32_t o = ((uint32_t)c * (uint32_t)B + (uint32_t)b) * 4u;  // row slot + c, element b
+    return SvQ{*row_at(base, B, slot, o), *row_at(base, B, slot + 3, o)};
   }
   __device__ __forceinline__ void store(float *base, size_t B, int slot, size_t b, SvT s) const {
     if ((threadIdx.x & 3) == 3) return;
-    float *p = base + (size_t)(slot + c) * B + b;
-    p[0] = s.w; p[3 * B] = s.v;
+    const uint32_t o = ((uint32_t)c * (uint32_t)B + (uint32_t)b) * 4u;
+    *row_at(base, B, slot, o) = s.w; *row_at(base, B, slot + 3, o) = s.v;
   }
   __device__ __forceinline__ SvT load6(const float *p) const { return SvQ{p[c], p[3 + c]}; }
   __device__ __forceinline__ void store6_neg(float *g, SvT s) const {
@@ -303,20 +338,25 @@ struct QuadAlg {
 // L2 traffic of both kernels).
 struct RneaGlobalIO {
   const RneaArgs &a;
-  size_t o;  // b * D
-  __device__ __forceinline__ RneaGlobalIO(const RneaArgs &a_, size_t b) : a(a_), o(b * (size_t)a_.num_dof) {}
-  __device__ __forceinline__ float q(int j) const { return a.q[o + j]; }
-  __device__ __forceinline__ float qd(int j) const { return a.qd[o + j]; }
-  __device__ __forceinline__ float qdd(int j) const { return a.qdd[o + j]; }
-  __device__ __forceinline__ float grad_tau(int j) const { return a.grad_tau[o + j]; }
-  __device__ __forceinline__ void tau_zero(int D) const { for (int j = 0; j < D; j++) a.tau[o + j] = 0.0f; }
-  __device__ __forceinline__ void tau_add(int j, float x) const { a.tau[o + j] += x; }
-  __device__ __forceinline__ void grads_zero(int D) const {
-    for (int j = 0; j < D; j++) { a.grad_q[o + j] = 0.0f; a.grad_qd[o + j] = 0.0f; a.grad_qdd[o + j] = 0.0f; }
+  uint32_t o;  // byte offset of row b: b * D * 4 (the launchers check batch * dof < 2^30); the joint index is the same for
+               // the whole wavefront, so an access is (scalar tensor base + joint) + this one 32-bit lane offset
+  __device__ __forceinline__ RneaGlobalIO(const RneaArgs &a_, size_t b) : a(a_), o((uint32_t)b * (uint32_t)a_.num_dof * 4u) {}
+  __device__ __forceinline__ const float &in(const float *t, int j) const {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t + j) + o);
   }
-  __device__ __forceinline__ void grad_q_add(int j, float x) const { a.grad_q[o + j] += x; }
-  __device__ __forceinline__ void grad_qd_add(int j, float x) const { a.grad_qd[o + j] += x; }
-  __device__ __forceinline__ void grad_qdd_add(int j, float x) const { a.grad_qdd[o + j] += x; }
+  __device__ __forceinline__ float &out(float *t, int j) const { return *reinterpret_cast<float *>(reinterpret_cast<char *>(t + j) + o); }
+  __device__ __forceinline__ float q(int j) const { return in(a.q, j); }
+  __device__ __forceinline__ float qd(int j) const { return in(a.qd, j); }
+  __device__ __forceinline__ float qdd(int j) const { return in(a.qdd, j); }
+  __device__ __forceinline__ float grad_tau(int j) const { return in(a.grad_tau, j); }
+  __device__ __forceinline__ void tau_zero(int D) const { for (int j = 0; j < D; j++) out(a.tau, j) = 0.0f; }
+  __device__ __forceinline__ void tau_add(int j, float x) const { out(a.tau, j) += x; }
+  __device__ __forceinline__ void grads_zero(int D) const {
+    for (int j = 0; j < D; j++) { out(a.grad_q, j) = 0.0f; out(a.grad_qd, j) = 0.0f; out(a.grad_qdd, j) = 0.0f; }
+  }
+  __device__ __forceinline__ void grad_q_add(int j, float x) const { out(a.grad_q, j) += x; }
+  __device__ __forceinline__ void grad_qd_add(int j, float x) const { out(a.grad_qd, j) += x; }
+  __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out(a.grad_qdd, j) += x; }
 };
 
 constexpr int kRneaStageStride = 65;  // [joint][65]: lane e of joint j sits in bank (j + e) mod 32
@@ -365,7 +405,8 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
   int prev_k = -1;
   SvT prev_v = alg.zero(), prev_a = alg.zero();
   for (int idx = 0; idx < L; idx++) {
-    const int k = order_link(order[idx]);
+    const int oe = order_entry(order, idx);
+    const int k = order_link(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     float qe = 0.f, qde = 0.f, qdde = 0.f;
@@ -393,7 +434,7 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
     }
     alg.store(a.cache, B, k * 20, b, v);
     alg.store(a.cache, B, k * 20 + 6, b, acc);
-    if (order_needs_slot(order[idx])) alg.store(a.cache, B, k * 20 + 12, b, alg.zero());  // children accumulate their X^T f here
+    if (order_needs_slot(oe)) alg.store(a.cache, B, k * 20 + 12, b, alg.zero());  // children accumulate their X^T f here
     prev_k = k; prev_v = v; prev_a = acc;
   }
   // sweep 2, leaves -> root: f = I a + v x* I v (- f_ext) + children; tau = S^T f (:190-283)
@@ -402,12 +443,13 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
   int pend_par = -1;
   SvT pend = alg.zero();
   for (int idx = L - 1; idx >= 0; idx--) {
-    const int k = order_link(order[idx]);
+    const int oe = order_entry(order, idx);
+    const int k = order_link(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const SvT v = alg.load(a.cache, B, k * 20, b), acc = alg.load(a.cache, B, k * 20 + 6, b);
     SvT f = alg.inertia(c.mc, c.in, acc) + alg.cross_f(v, alg.inertia(c.mc, c.in, v));
     if (HAS_FEXT) f = f - alg.load6(a.f_ext + (b * L + k) * 6);
-    if (order_needs_slot(order[idx])) f = f + alg.load(a.cache, B, k * 20 + 12, b);
+    if (order_needs_slot(oe)) f = f + alg.load(a.cache, B, k * 20 + 12, b);
     else f = f + alg.zero();  // (-0 + 0 = +0, as the stored zero gave)
     if (pend_par == k) f = f + pend;
     pend_par = -1;
@@ -420,7 +462,7 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
     if (!(c.par < 0 || c.par == k)) {
       const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
       const SvT up = alg.force_T(alg.xform(c.F, c.jt, qe), f);
-      if (idx > 0 && order_link(order[idx - 1]) == c.par) { pend = up; pend_par = c.par; }
+      if (idx > 0 && order_link(order_entry(order, idx - 1)) == c.par) { pend = up; pend_par = c.par; }
       else alg.store(a.cache, B, c.par * 20 + 12, b, alg.load(a.cache, B, c.par * 20 + 12, b) + up);
     }
   }
@@ -446,8 +488,9 @@ __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, cons
   int prev_k = -1;
   SvT prev_fb = alg.zero();
   for (int idx = 0; idx < L; idx++) {
-    const int k = order_link(order[idx]);
-    const bool slot = order_needs_slot(order[idx]);
+    const int oe = order_entry(order, idx);
+    const int k = order_link(oe);
+    const bool slot = order_needs_slot(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     SvT fb = alg.zero();
@@ -474,11 +517,12 @@ __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, cons
   int pend_par = -1;
   SvT pend_a = alg.zero(), pend_v = alg.zero();
   for (int idx = L - 1; idx >= 0; idx--) {
-    const int k = order_link(order[idx]);
-    const bool slot = order_needs_slot(order[idx]);
+    const int oe = order_entry(order, idx);
+    const int k = order_link(oe);
+    const bool slot = order_needs_slot(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
-    const bool par_next = !is_root && idx > 0 && order_link(order[idx - 1]) == c.par;  // this link's pushes stay in registers
+    const bool par_next = !is_root && idx > 0 && order_link(order_entry(order, idx - 1)) == c.par;  // this link's pushes stay in registers
     const SvT v = alg.load(a.cache, B, k * 20, b);
     const SvT fb = alg.load(a.ws_fbar, B, k * 6, b);
     SvT ab = alg.zero(), vb = alg.zero();  // (what a link without children elsewhere would read back from its slot)

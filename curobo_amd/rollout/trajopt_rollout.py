@@ -68,6 +68,10 @@ class TrajOptRolloutCfg:
     #: kernel sequence with torque limits: run the joint-space chain (RNEA -> c-space STATE -> RNEA VJP) on a side stream
     #: next to the task-space chain (FK -> costs -> FK VJP); same kernels, same numbers (evaluate_action)
     overlap_dynamics: bool = True
+    #: with torque limits the fused launch carries the inverse dynamics of 33 points on 33 lanes of each workgroup: it wins
+    #: while the batch fits one round of workgroups (two per CU: 512 rollouts, ~103 us) and loses to the kernel sequence with
+    #: its side stream beyond (1024 rollouts: 201 vs 181 us, 4096: 759 vs 548 us; tools/probes/torque_rollout_time.py)
+    fused_torque_max_batch: int = 768
     gravity: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 0.0, 0.0, 9.81])  # spatial base acceleration
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
@@ -128,6 +132,7 @@ class TrajOptRollout:
         H, D, S, L, T = c.padded_horizon, k.num_dof, k.num_spheres, k.num_links, k.num_pose_links
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=d, dtype=dt)  # noqa: E731
         self.batch_size = B
+        self._fused_ok = None  # (the choice between the fused launch and the kernel sequence depends on the batch)
         self.position, self.velocity, self.acceleration, self.jerk = z(B, H, D), z(B, H, D), z(B, H, D), z(B, H, D)
         self.out_dt, self.state_dt = z(B), torch.full((B,), c.traj_dt, device=d)
         self.start_idx, self.goal_idx, self.env_query_idx = z(B, dt=torch.int32), z(B, dt=torch.int32), z(B, dt=torch.int32)
@@ -420,7 +425,9 @@ class TrajOptRollout:
         act = x.view(self.batch_size, self.cfg.n_knots, self.action_dim)
         if self.cfg.use_fused:
             if self._fused_ok is None:
-                self._fused_ok = self.fused_available()
+                c = self.cfg
+                too_big = c.use_torque_limits and c.overlap_dynamics and self.batch_size > c.fused_torque_max_batch
+                self._fused_ok = self.fused_available() and not too_big
             if self._fused_ok:
                 return self.cost_and_gradient_fused(act)
         cost = self.evaluate_action(act, with_gradient=True)
