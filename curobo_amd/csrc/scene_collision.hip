@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) scene_collision_packed_kernel(const Scene
   const int b_first = (int)(sidx0 / hs);
   const long last = (sidx0 + NT - 1 < total - 1) ? sidx0 + NT - 1 : total - 1;
   const int nslots = (int)(last / hs) - b_first + 1;
-  // LDS: records | sphere stash [3][256] float4 | results [256] float4 | queue [256 * 32] u16 | prefix [256 + 4] int
+  // LDS: records | sphere stash [3][256] float4 | results [256] float4 | prefix [256 + 8] int | queue [256 * n_rec] u16
   ObsRec *recs = reinterpret_cast<ObsRec *>(smem);
   float4 *stash = reinterpret_cast<float4 *>(recs + (size_t)nslots * n_rec);
   float4 *res = stash + 3 * NT;
@@ -267,7 +267,9 @@ CUROBO_EXPORT int curobo_hip_sphere_obstacle_collision(
     else CUROBO_SCENE_LAUNCH(SW, ST, 3);             \
   } while (0)
   const int n_rec = scene->max_cuboids + scene->max_voxel_grids;
-  const size_t lds_packed = lds + (size_t)(3 + 1) * 256 * 16 + (256 + 8) * 4 + (size_t)256 * 32 * 2;
+  // (the queue holds at most one item per sphere and obstacle record: sized by the scene, not by the 32-record limit --
+  // LDS per workgroup is occupancy)
+  const size_t lds_packed = lds + (size_t)(3 + 1) * 256 * 16 + (256 + 8) * 4 + (((size_t)256 * n_rec * 2 + 15) & ~(size_t)15);
   static const bool no_packed = getenv("CUROBO_HIP_SCENE_UNPACKED") != nullptr;  // development knob: the in-lane obstacle loop
   if (staged && (kinds & 2) && n_rec <= 32 && lds_packed <= 64 * 1024 && !no_packed) {  // ESDF grids: see the kernel's header
 #define CUROBO_SCENE_PACKED(SW)                                                                                              \

@@ -522,11 +522,16 @@ __global__ void __launch_bounds__(256) self_collision_tiles_kernel(const SelfTil
 // are compacted, four per round, lane (t, pi, pj) tests ONE pair (i = 4 ib4 + pi, j = 4 jb4 + pj) with its bit of the pair
 // bitmap; arg-max with the list's tie rule, (i, j) lexicographic.  Same pair_pen as the one-level kernel: same values.
 constexpr int kT2Waves = 4;   // wavefronts that share one point (its spheres and boxes in LDS)
-constexpr int kT2Ring = 512;  // sub-tiles a wavefront collects before it runs its narrow phase (a trip of four rounds adds <= 256)
+#ifndef CUROBO_T2_RING
+#define CUROBO_T2_RING 72
+#endif
+constexpr int kT2Ring = CUROBO_T2_RING;  // sub-tiles a wavefront may hold before its narrow phase runs: < 4 left over + <= 64 of a trip.  (A 512-entry
+                                         // ring drained after four trips was 25 % slower: 8 KB of LDS per point are two points per CU)
+constexpr int kT2Box = 6;    // floats per box: lo xyz, hi xyz (every byte of LDS per point is occupancy: eight points per CU at 20 KB)
 __host__ __device__ inline size_t tiles2_kept_cap(int n_tiles) { return (size_t)((n_tiles + kT2Waves * 64 - 1) / (kT2Waves * 64)) * 64; }
 __host__ __device__ inline size_t tiles2_lds_floats(int nslots, int n_tiles) {
   const size_t SL = (size_t)nslots * 64;
-  return SL * 4 + (SL / kTile) * 8 + (SL / 4) * 8 + kT2Waves * (tiles2_kept_cap(n_tiles) + kT2Ring) + 2 * kT2Waves;
+  return SL * 4 + (SL / kTile) * kT2Box + (SL / 4) * kT2Box + kT2Waves * (tiles2_kept_cap(n_tiles) + kT2Ring) + 2 * kT2Waves;
 }
 
 // One POINT per workgroup of four wavefronts.  A wavefront per point is latency bound (a dependent chain of LDS and
@@ -540,11 +545,11 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int kept_cap = (int)tiles2_kept_cap(t.n_tiles);
   float4 *sph = reinterpret_cast<float4 *>(smem);
-  float *box = reinterpret_cast<float *>(sph + SL);       // [NB][8]: lo xyz, -, hi xyz, -
-  float *box4 = box + NB * 8;                             // [NB4][8]
-  int *kept = reinterpret_cast<int *>(box4 + NB4 * 8) + wave * (kept_cap + kT2Ring);  // this wavefront's surviving 16 x 16 tiles
+  float *box = reinterpret_cast<float *>(sph + SL);       // [NB][6]: lo xyz, hi xyz
+  float *box4 = box + NB * kT2Box;                        // [NB4][6]
+  int *kept = reinterpret_cast<int *>(box4 + NB4 * kT2Box) + wave * (kept_cap + kT2Ring);  // this wavefront's surviving 16 x 16 tiles
   int *ring = kept + kept_cap;                            // ... and its surviving 4 x 4 sub-tiles
-  float *red = box4 + NB4 * 8 + kT2Waves * (kept_cap + kT2Ring);  // [kT2Waves] (penetration, key) per wavefront
+  float *red = box4 + NB4 * kT2Box + kT2Waves * (kept_cap + kT2Ring);  // [kT2Waves] (penetration, key) per wavefront
   const int n = blockIdx.x;
   const float qnan = __builtin_nanf("");
   const int row = lane >> 4, li = lane & 15;
@@ -595,8 +600,8 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
         e[c] = fmaxf(e[c], dpp_f<0x4E>(e[c]));
       }
       if ((lane & 3) == 0) {
-        float *b = box4 + (size_t)(s >> 2) * 8;
-        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[4] = e[3]; b[5] = e[4]; b[6] = e[5];
+        float *b = box4 + (size_t)(s >> 2) * kT2Box;
+        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[3] = e[3]; b[4] = e[4]; b[5] = e[5];
       }
 #pragma unroll
       for (int c = 0; c < 6; c++) {
@@ -604,8 +609,8 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
         e[c] = fmaxf(e[c], dpp_f<0x140>(e[c]));
       }
       if (li == 0) {
-        float *b = box + (sl * 4 + row) * 8;
-        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[4] = e[3]; b[5] = e[4]; b[6] = e[5];
+        float *b = box + (sl * 4 + row) * kT2Box;
+        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[3] = e[3]; b[4] = e[4]; b[5] = e[5];
       }
     }
   }
@@ -618,8 +623,8 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
     const int tl = my_tiles[u];
     bool keep = false;
     if (tl >= 0) {
-      const float *bi = box + (tl & 0xff) * 8, *bj = box + (tl >> 8) * 8;
-      keep = bi[0] <= bj[4] && bj[0] <= bi[4] && bi[1] <= bj[5] && bj[1] <= bi[5] && bi[2] <= bj[6] && bj[2] <= bi[6];
+      const float *bi = box + (tl & 0xff) * kT2Box, *bj = box + (tl >> 8) * kT2Box;
+      keep = bi[0] <= bj[3] && bj[0] <= bi[3] && bi[1] <= bj[4] && bj[1] <= bi[4] && bi[2] <= bj[5] && bj[2] <= bi[5];
     }
     const unsigned long long m = __ballot(keep);
     if (keep) kept[count + __popcll(m & ((1ull << lane) - 1ull))] = tl;
@@ -663,36 +668,36 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  constexpr int kRounds = 4;  // rounds per trip: their bitmap loads are in flight together
-  for (int t0 = 0; t0 < count; t0 += 4 * kRounds) {
-    bool keep[kRounds];
-    int ib4[kRounds], jb4[kRounds];
-    uint4 w[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; r++) {
-      const int ti = t0 + r * 4 + sub_t;
-      const bool has = ti < count;
-      const int tl = kept[has ? ti : 0];
-      ib4[r] = (tl & 0xff) * 4 + pi;
-      jb4[r] = (tl >> 8) * 4 + pj;
-      const float *bi = box4 + (size_t)ib4[r] * 8, *bj = box4 + (size_t)jb4[r] * 8;
-      // (the diagonal tiles list pairs i < j only: a sub-tile strictly below the diagonal holds none of them)
-      keep[r] = has && ib4[r] <= jb4[r] && bi[0] <= bj[4] && bj[0] <= bi[4] && bi[1] <= bj[5] && bj[1] <= bi[5] &&
-                bi[2] <= bj[6] && bj[2] <= bi[6];
-      // bit (jb4 * 4 + pj') & 31 of bitmap[(jb4 * 4) >> 5][ib4 * 4 + pi'] for the 4 x 4 pairs of the sub-tile
-      w[r] = keep[r] ? *reinterpret_cast<const uint4 *>(a.bitmap + (size_t)(jb4[r] >> 3) * SL + ib4[r] * 4) : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; r++) {
-      const int sh = (jb4[r] & 7) * 4;
-      const uint32_t bits = ((w[r].x >> sh) & 0xfu) | (((w[r].y >> sh) & 0xfu) << 4) | (((w[r].z >> sh) & 0xfu) << 8) |
-                            (((w[r].w >> sh) & 0xfu) << 12);
-      const bool k2 = keep[r] && bits != 0u;
-      const unsigned long long m = __ballot(k2);
-      if (k2) ring[n4 + __popcll(m & ((1ull << lane) - 1ull))] = (int)((uint32_t)ib4[r] | ((uint32_t)jb4[r] << 8) | (bits << 16));
-      n4 += __popcll(m);
-    }
-    if (n4 + 64 * kRounds > kT2Ring) drain(false);
+  // One trip = four kept tiles = 64 sub-tiles, one per lane.  The next trip's box tests and bitmap loads are issued before
+  // this trip's survivors go through the ring and the narrow phase: the L2 round trip of the words overlaps LDS-only work.
+  struct Trip { bool keep; int ib4, jb4; uint4 w; };
+  auto fetch = [&](int t0) {
+    Trip tr;
+    const int ti = t0 + sub_t;
+    const bool has = ti < count;
+    const int tl = kept[has ? ti : 0];
+    tr.ib4 = (tl & 0xff) * 4 + pi;
+    tr.jb4 = (tl >> 8) * 4 + pj;
+    const float *bi = box4 + (size_t)tr.ib4 * kT2Box, *bj = box4 + (size_t)tr.jb4 * kT2Box;
+    // (the diagonal tiles list pairs i < j only: a sub-tile strictly below the diagonal holds none of them)
+    tr.keep = has && tr.ib4 <= tr.jb4 && bi[0] <= bj[3] && bj[0] <= bi[3] && bi[1] <= bj[4] && bj[1] <= bi[4] &&
+              bi[2] <= bj[5] && bj[2] <= bi[5];
+    // bit (jb4 * 4 + pj') & 31 of bitmap[(jb4 * 4) >> 5][ib4 * 4 + pi'] for the 4 x 4 pairs of the sub-tile
+    tr.w = tr.keep ? *reinterpret_cast<const uint4 *>(a.bitmap + (size_t)(tr.jb4 >> 3) * SL + tr.ib4 * 4) : make_uint4(0u, 0u, 0u, 0u);
+    return tr;
+  };
+  Trip nxt = fetch(0);
+  for (int t0 = 0; t0 < count; t0 += 4) {
+    const Trip cur = nxt;
+    if (t0 + 4 < count) nxt = fetch(t0 + 4);
+    const int sh = (cur.jb4 & 7) * 4;
+    const uint32_t bits = ((cur.w.x >> sh) & 0xfu) | (((cur.w.y >> sh) & 0xfu) << 4) | (((cur.w.z >> sh) & 0xfu) << 8) |
+                          (((cur.w.w >> sh) & 0xfu) << 12);
+    const bool k2 = cur.keep && bits != 0u;
+    const unsigned long long m = __ballot(k2);
+    if (k2) ring[n4 + __popcll(m & ((1ull << lane) - 1ull))] = (int)((uint32_t)cur.ib4 | ((uint32_t)cur.jb4 << 8) | (bits << 16));
+    n4 += __popcll(m);
+    if (n4 + 64 > kT2Ring) drain(false);
   }
   drain(true);
   // ---- arg-max: largest penetration, then the lexicographically first (i, j); over the wavefront, then over the four

@@ -1,4 +1,4 @@
-"""development / profiling target: the dense-bitmap self-collision kernel at C4 size (Unitree G1, 8448 points)"""
+"""development / profiling target: the dense-bitmap self-collision kernel at C4 size (Unitree G1; B x 33 points, B = argv[1], default 256)"""
 import os, sys
 import numpy as np
 import torch
@@ -11,7 +11,7 @@ from curobo_amd.robot.kinematics_params import KinematicsParams
 dev = torch.device("cuda:0")
 model = load_packaged_robot("unitree_g1")
 kp = KinematicsParams.from_model(model, dev)
-B, H = 256, 33
+B, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 33
 n = B * H
 S, P = model.num_spheres, int(kp.self_collision.collision_pairs.shape[0])
 rng = np.random.default_rng(0)
