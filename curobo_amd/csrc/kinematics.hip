@@ -336,6 +336,7 @@ struct FkBwdArgs {
   const int32_t *env_query_idx;
   int n_points, horizon, nspheres, num_envs, nlinks, njoints, n_tool_frames, dpad, chain_len;
   int stage_spheres;  // LDS was sized for the per-link form of the sphere pass
+  int psum_rows;      // joint-gradient rows per point in LDS (16 = one per lane; fewer: lanes share rows through ds_add_f32)
 };
 
 template <bool COM>
@@ -344,8 +345,9 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   const int L = a.nlinks, D = a.njoints;
   const int pts = blockDim.x / kFkLanes;
   float *cumul = smem;                          // [pts][L][12]
-  float *psum_all = smem + pts * L * 12;        // [pts][16][dpad]
-  int *s_chain_off = reinterpret_cast<int *>(psum_all + pts * kFkLanes * a.dpad);  // [L+1]
+  const int R = a.psum_rows;
+  float *psum_all = smem + pts * L * 12;        // [pts][R][dpad]
+  int *s_chain_off = reinterpret_cast<int *>(psum_all + pts * R * a.dpad);  // [L+1]
   int *s_link_info = s_chain_off + (L + 1);                                        // [L]
   float *s_sign = reinterpret_cast<float *>(s_link_info + L);                      // [L]
   int *s_chain = reinterpret_cast<int *>(s_sign + L);                              // [C]
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
       s_sph_link[sp] = a.link_sphere_map[sp];
       if (a.num_envs <= 1) s_rs[sp] = reinterpret_cast<const float4 *>(a.robot_spheres)[sp];
     }
-  for (int i = tid; i < pts * kFkLanes * a.dpad; i += nt) psum_all[i] = 0.0f;
+  for (int i = tid; i < pts * R * a.dpad; i += nt) psum_all[i] = 0.0f;
   __syncthreads();
   // ---- work units of the per-link sphere pass.  With the spheres grouped by link (the order every robot file
   // lists them in) link l owns the run [start[l], start[l+1]); a run is cut into units of at most `cs` spheres so
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   if (grp >= npts) return;
   const int n = pt0 + grp;
   const float *my_cumul = cumul + (size_t)grp * L * 12;
-  float *psum = psum_all + ((size_t)grp * kFkLanes + lane) * a.dpad;
+  float *psum = psum_all + ((size_t)grp * R + (lane & (R - 1))) * a.dpad;
 
   // ---- spheres (sparsity skip on zero gradient, reference :48-52)
   if (per_link) {
@@ -613,11 +615,10 @@ __global__ void __launch_bounds__(256) fk_backward_kernel(const FkBwdArgs a) {
   // DS operations of a wave complete in order, so a wave-level fence suffices.
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const float *rows = psum_all + (size_t)grp * kFkLanes * a.dpad;
+  const float *rows = psum_all + (size_t)grp * R * a.dpad;
   for (int j = lane; j < D; j += kFkLanes) {
     float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kFkLanes; k++) acc += rows[k * a.dpad + j];
+    for (int k = 0; k < R; k++) acc += rows[k * a.dpad + j];
     a.grad_q[(size_t)n * D + j] = acc;
   }
 }
@@ -656,11 +657,19 @@ static int fk_forward_dispatch(const FkArgs &a, bool spheres, bool jac, bool com
     else hipLaunchKernelGGL((fk_forward_points_kernel<false, false>), dim3(nblk), dim3(256), lds_pts, st, a);
     return check_launch(what, st);
   }
-  const int pts = fk_points_per_block(a.nlinks);
+  static const int env_pts = getenv("CUROBO_FK_FWD_PTS") ? atoi(getenv("CUROBO_FK_FWD_PTS")) : 0;
+  auto lds_for = [&](int p) {
+    return (size_t)p * a.nlinks * kFkLinkStride * sizeof(float) + (size_t)a.nlinks * sizeof(int) +
+           (spheres ? (size_t)a.nspheres * (sizeof(float4) + sizeof(int)) : 0);
+  };
+  int pts = fk_points_per_block(a.nlinks);
+  // every workgroup stages the sphere table: with many spheres (G1: 13.5 KB) twice the points per workgroup hold more
+  // wavefronts per CU in the same LDS (two workgroups of 16 points instead of three of 8: 151 -> 145 us at the C4 size)
+  if (spheres && pts == 8 && lds_for(16) <= 80 * 1024) pts = 16;
+  if (env_pts > 0) pts = env_pts;
   const int threads = pts * kFkLanes;
   const int blocks = ceil_div(a.n_points, pts);
-  const size_t lds = (size_t)pts * a.nlinks * kFkLinkStride * sizeof(float) + (size_t)a.nlinks * sizeof(int) +
-                     (spheres ? (size_t)a.nspheres * (sizeof(float4) + sizeof(int)) : 0);
+  const size_t lds = lds_for(pts);
   const int key = (spheres ? 1 : 0) | (jac ? 2 : 0) | (com ? 4 : 0);
   switch (key) {
     case 0: launch_fk<false, false, false>(a, write_cumul, blocks, threads, lds, st); break;
@@ -780,9 +789,18 @@ CUROBO_EXPORT int curobo_hip_launch_kinematics_backward(
   // 8 points per workgroup where 16 would fit: twice the workgroups, whose load and arithmetic phases then overlap
   // a little more (24.6 -> 23.5 us at 32 k points)
   int pts = max(4, fk_points_per_block(num_links) / 2);
+  static const int env_rows = getenv("CUROBO_FK_BWD_ROWS") ? atoi(getenv("CUROBO_FK_BWD_ROWS")) : 0;
+  static const int env_pts = getenv("CUROBO_FK_BWD_PTS") ? atoi(getenv("CUROBO_FK_BWD_PTS")) : 0;
+  // One gradient row per lane costs 16 * dof floats of LDS per point: with many joints that, not the wavefront slots, is what
+  // limits the points a CU holds (Unitree G1, 49 joints: 6.1 KB per point = 6.5 wavefronts per CU).  Four rows shared by the
+  // lanes through ds_add_f32 make it 3.5 KB (G1 at the C4 size, sparse sphere gradient + four tool frames: 314 -> 194 us);
+  // robots with few joints keep a private row per lane (no LDS pressure, no shared-address adds).
+  a.psum_rows = env_rows > 0 ? env_rows : (a.dpad > 16 ? 4 : kFkLanes);
+  if (a.psum_rows < kFkLanes) pts = fk_points_per_block(num_links);
+  if (env_pts > 0) pts = env_pts;
   size_t lds = 0;
   for (;;) {
-    lds = ((size_t)pts * num_links * 12 + (size_t)pts * kFkLanes * a.dpad + 3 * (size_t)num_links + 1 +
+    lds = ((size_t)pts * num_links * 12 + (size_t)pts * a.psum_rows * a.dpad + 3 * (size_t)num_links + 1 +
            (size_t)a.chain_len) * sizeof(float);
     if (lds <= 60 * 1024 || pts == 4) break;
     pts /= 2;
