@@ -95,7 +95,7 @@ class TrajectoryOptimizerResult:
                 a, b = pad(a), pad(b)
             m = mask.view(-1, *([1] * (a.ndim - 1)))
             return torch.where(m, b, a)
-        for name in ("success", "solution", "position_error", "rotation_error", "seed_cost", "interpolated_last_tstep"):
+        for name in ("success", "solution", "position_error", "rotation_error", "seed_cost", "interpolated_last_tstep", "goalset_index"):
             setattr(self, name, put(getattr(self, name), getattr(other, name)))
         for js_name in ("js_solution", "interpolated_trajectory"):
             a, b = getattr(self, js_name), getattr(other, js_name)
@@ -719,6 +719,125 @@ class BatchMotionPlanner(_PlannerBase):
         if best is not None:
             best.total_time = time.perf_counter() - t0
         return best
+
+    def plan_grasp(self, grasp_poses: GoalToolPose, current_state: JointState, grasp_approach_axis: str = "z",
+                   grasp_approach_offset: float = -0.15, grasp_approach_in_tool_frame: bool = True, grasp_lift_axis: str = "z",
+                   grasp_lift_offset: float = -0.15, grasp_lift_in_tool_frame: bool = True, plan_approach_to_grasp: bool = True,
+                   plan_grasp_to_lift: bool = True, disable_collision_links: Optional[List[str]] = None) -> GraspPlanResult:
+        """reference batch ``plan_grasp`` (motion_planner_batch.py:291-472): the four stages of ``MotionPlanner.plan_grasp`` for
+        every problem of the batch at once.  Every problem is planned at every stage (fixed shapes); a problem that failed a
+        stage gets the pose it is already in as the goal of the next ones, and its success flags stay off."""
+        kp = self.kinematics.config.kinematics_config
+        if disable_collision_links is None:
+            disable_collision_links = kp.grasp_contact_link_names or []
+        disable_collision_links = [n for n in disable_collision_links if n in (kp.link_names or [])]
+        batch, dev = grasp_poses.batch_size, current_state.position.device
+        frames = list(grasp_poses.tool_frames)
+        f = lambda: torch.zeros(batch, dtype=torch.bool, device=dev)  # noqa: E731
+        result = GraspPlanResult(success=f(), approach_success=f(), grasp_success=f(), lift_success=f())
+        standard = {k: ToolPoseCriteria() for k in frames}
+
+        def leg(goal: GoalToolPose, start: JointState, criteria=None, contacts_off: bool = False):
+            if criteria is not None:
+                self.update_tool_pose_criteria({k: criteria for k in frames})
+            if contacts_off:
+                self.disable_link_collision(disable_collision_links)
+            try:
+                return self.plan_pose(goal, start)
+            finally:
+                if contacts_off:
+                    self.enable_link_collision(disable_collision_links)
+                if criteria is not None:
+                    self.update_tool_pose_criteria(standard)
+
+        def last_state(r: TrajectoryOptimizerResult) -> JointState:
+            return JointState.from_position(r.js_solution.position[:, 0, -1].clone(), joint_names=self.joint_names)
+
+        def stay_where_failed(goal: GoalToolPose, state: JointState, failed: torch.Tensor) -> None:
+            if not bool(failed.any()):
+                return
+            here = self.compute_kinematics(state).tool_poses  # [batch, 1, T, 3 | 4]
+            for i, fr in enumerate(goal.tool_frames):
+                j = list(here.tool_frames).index(fr)
+                goal.position[failed, :, i, :, :] = here.position[failed, 0, j][:, None, None, :]
+                goal.quaternion[failed, :, i, :, :] = here.quaternion[failed, 0, j][:, None, None, :]
+
+        # 1: a reachable grasp per problem
+        goalset_result = leg(grasp_poses, current_state, contacts_off=True)
+        if goalset_result is None:
+            result.status = "Goalset planning returned None."
+            return result
+        goalset_ok = goalset_result.success.any(dim=-1)
+        result.goalset_result = goalset_result
+        if not bool(goalset_ok.any()):
+            result.status = "No grasp in goal set was reachable."
+            return result
+        result.goalset_index = goalset_result.goalset_index.clone()
+        idx = goalset_result.goalset_index[:, 0].long().clone()
+        idx[~goalset_ok] = 0
+        rows = torch.arange(batch, device=dev)
+        grasp = {fr: Pose(grasp_poses.position[:, 0, i].to(dev)[rows, idx], grasp_poses.quaternion[:, 0, i].to(dev)[rows, idx])
+                 for i, fr in enumerate(frames)}
+
+        def shifted(axis: str, offset: float, in_tool_frame: bool) -> GoalToolPose:
+            off = _axis_offset_pose(axis, offset).to(dev)
+            d = {fr: (p.multiply(off) if in_tool_frame else off.multiply(p)) for fr, p in grasp.items()}
+            return GoalToolPose.from_poses(d, ordered_tool_frames=frames, num_goalset=1)
+
+        # 2: the approach poses
+        approach = leg(shifted(grasp_approach_axis, grasp_approach_offset, grasp_approach_in_tool_frame), current_state)
+        result.approach_result = approach
+        if approach is None:
+            result.status = "Planning to approach pose failed."
+            return result
+        approach_ok = goalset_ok & approach.success.any(dim=-1)
+        result.approach_success = approach_ok.clone()
+        result.approach_trajectory, result.approach_trajectory_dt = approach.js_solution, approach.js_solution.dt
+        result.approach_interpolated_trajectory = approach.interpolated_trajectory
+        result.approach_interpolated_last_tstep = approach.interpolated_last_tstep
+        if not plan_approach_to_grasp:
+            result.success = approach_ok.clone()
+            result.status = "Planning to approach pose completed."
+            return result
+
+        # 3: straight lines from the approach poses to the grasps
+        approach_end = last_state(approach)
+        grasp_goal = GoalToolPose.from_poses({fr: p.clone() for fr, p in grasp.items()}, ordered_tool_frames=frames, num_goalset=1)
+        stay_where_failed(grasp_goal, approach_end, ~approach_ok)
+        line = ToolPoseCriteria.linear_motion(axis=grasp_approach_axis, non_terminal_scale=1.0,
+                                              project_distance_to_goal=grasp_approach_in_tool_frame)
+        grasp_result = leg(grasp_goal, approach_end, criteria=line, contacts_off=True)
+        if grasp_result is None:
+            result.status = "Planning to grasp pose failed."
+            return result
+        grasp_ok = approach_ok & grasp_result.success.any(dim=-1)
+        result.grasp_success = grasp_ok.clone()
+        result.grasp_trajectory, result.grasp_trajectory_dt = grasp_result.js_solution, grasp_result.js_solution.dt
+        result.grasp_interpolated_trajectory = grasp_result.interpolated_trajectory
+        result.grasp_interpolated_last_tstep = grasp_result.interpolated_last_tstep
+        if not plan_grasp_to_lift:
+            result.success = grasp_ok.clone()
+            result.status = "Planning to grasp pose completed."
+            return result
+
+        # 4: lift
+        lift_start = last_state(grasp_result)
+        lift_goal = shifted(grasp_lift_axis, grasp_lift_offset, grasp_lift_in_tool_frame)
+        stay_where_failed(lift_goal, lift_start, ~grasp_ok)
+        lift_line = ToolPoseCriteria.linear_motion(axis=grasp_lift_axis, non_terminal_scale=1.0,
+                                                   project_distance_to_goal=grasp_lift_in_tool_frame)
+        lift = leg(lift_goal, lift_start, criteria=lift_line, contacts_off=True)
+        if lift is None:
+            result.status = "Planning to lift pose failed."
+            return result
+        lift_ok = grasp_ok & lift.success.any(dim=-1)
+        result.lift_success = lift_ok.clone()
+        result.lift_trajectory, result.lift_trajectory_dt = lift.js_solution, lift.js_solution.dt
+        result.lift_interpolated_trajectory = lift.interpolated_trajectory
+        result.lift_interpolated_last_tstep = lift.interpolated_last_tstep
+        result.success = lift_ok.clone()
+        result.status = "Grasp planning completed."
+        return result
 
     def plan_cspace(self, goal_states: JointState, current_state: JointState, max_attempts: int = 1,
                     success_ratio: float = 1.0, enable_graph_attempt: int = 0) -> Optional[TrajectoryOptimizerResult]:

@@ -326,3 +326,63 @@ def test_ik_position_only_criteria(oracle, device, this_repos_curobo):  # noqa: 
     ok = again.success[:, 0].cpu().numpy()
     assert (again.rotation_error[:, 0].cpu().numpy()[ok] < 0.05).all()
     np.testing.assert_array_equal(ok, full.success[:, 0].cpu().numpy())
+
+
+def test_batch_planner_plan_grasp(oracle, device, this_repos_curobo):  # noqa: F811
+    """``BatchMotionPlanner.plan_grasp`` (reference motion_planner_batch.py:291-472): three problems with their own grasp sets,
+    one of them out of reach -- its flags stay off and the others' legs are verified with the oracle like the single planner's"""
+    from curobo.batch_motion_planner import BatchMotionPlanner, MotionPlannerCfg
+    from curobo.types import GoalToolPose, JointState, Pose
+    from curobo_amd.scene import cuboid_scene_arrays
+
+    world = [{"dims": [2.0, 2.0, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}]
+    n, G = 3, 2
+    config = MotionPlannerCfg.create(robot="franka.yml", scene_model=_scene_cfg(world), num_ik_seeds=32, num_trajopt_seeds=4,
+                                     max_batch_size=n, max_goalset=G)
+    planner = BatchMotionPlanner(config)
+    model = config.trajopt_solver_config.kinematics.model
+    kp = config.trajopt_solver_config.kinematics.kinematics_config
+    arrays = cuboid_scene_arrays([world])
+    rc = config.trajopt_solver_config.solver_cfg().rollout
+    q0 = planner.default_joint_state.position.view(1, -1).repeat(n, 1)
+    cur = JointState.from_position(q0.clone(), planner.joint_names)
+    q0n = q0.cpu().numpy()
+    frame = planner.tool_frames[0]
+    dq = np.array([[0.5, 0.25, 0, -0.2, 0, 0.3, 0], [-0.4, 0.3, 0, -0.1, 0, 0.2, 0.3], [0.1, 0.4, 0.2, 0.1, 0, 0.4, -0.3],
+                   [0.3, 0.1, -0.2, 0.2, 0, 0.1, 0.2]], np.float32)
+    p, q = _tool_pose(oracle, model, q0n[:1] + dq)
+    cand_p = np.stack([p[[0, 1]], p[[2, 3]], p[[0, 1]] + np.array([3.0, 0, 0], np.float32)]).astype(np.float32)  # [n, G, 3]
+    cand_q = np.stack([q[[0, 1]], q[[2, 3]], q[[0, 1]]]).astype(np.float32)
+    grasps = GoalToolPose.from_poses({frame: Pose(torch.as_tensor(cand_p.reshape(n * G, 3), device=device),
+                                                  torch.as_tensor(cand_q.reshape(n * G, 4), device=device))}, num_goalset=G)
+    assert grasps.position.shape == (n, 1, 1, G, 3)
+    offset = -0.10
+    g = planner.plan_grasp(grasps, cur, grasp_approach_offset=offset, grasp_lift_offset=offset)
+    assert g.status == "Grasp planning completed."
+    want = [True, True, False]
+    for flags in (g.success, g.approach_success, g.grasp_success, g.lift_success):
+        assert flags.cpu().tolist() == want, (g.status, flags)
+    assert torch.equal(kp.link_spheres, kp.reference_link_spheres)
+    contacts_off = dataclasses.replace(model, link_spheres=np.where(
+        np.isin(model.link_sphere_idx_map, [model.link_names.index(x) for x in kp.grasp_contact_link_names if x in model.link_names])[None, :, None]
+        & (np.arange(4) == 3)[None, None, :], np.float32(-100.0), model.link_spheres))
+    for b in (0, 1):
+        gi = int(g.goalset_index[b, 0])
+        gp, gq = cand_p[b, gi], cand_q[b, gi]
+        axis = _quat_rotate_np(gq, np.array([0.0, 0.0, 1.0], np.float32))
+        legs = [(g.approach_trajectory, q0n[b], gp + offset * axis, model, False), (g.grasp_trajectory, None, gp, contacts_off, True),
+                (g.lift_trajectory, None, gp + offset * axis, contacts_off, True)]
+        prev = None
+        for js, start, goal_p, m2, linear in legs:
+            traj = js.position[b].cpu().numpy()  # [1, H, D]
+            _verify_with_oracle(oracle, m2, arrays, traj, js.dt[b].cpu().numpy(), prev if start is None else start, rc)
+            pp, qq = _tool_pose(oracle, model, traj[0])
+            np.testing.assert_allclose(pp[-1], goal_p, atol=5e-3)
+            if linear:
+                d = pp - gp
+                assert np.linalg.norm(d - (d @ axis)[:, None] * axis, axis=1).max() < 0.01
+                assert np.minimum(np.linalg.norm(qq - gq, axis=1), np.linalg.norm(qq + gq, axis=1)).max() < 0.05
+            prev = traj[0, -1]
+    # approach only
+    g2 = planner.plan_grasp(grasps, cur, grasp_approach_offset=offset, plan_approach_to_grasp=False)
+    assert g2.success.cpu().tolist() == want and g2.grasp_trajectory is None and g2.status == "Planning to approach pose completed."
