@@ -244,8 +244,9 @@ class TrajectoryOptimizer:
     def compute_kinematics(self, state: Union[JointState, torch.Tensor]) -> KinematicsState:
         return self.kinematics.compute_kinematics(state)
 
-    def update_world(self, scene: SceneData) -> None:
-        self.config.scene = scene
+    def update_world(self, scene) -> None:
+        """``SceneData``, or a scene description (``curobo.scene.Scene``, dictionary, yaml path, list per environment)"""
+        self.config.scene = scene if (scene is None or isinstance(scene, SceneData)) else scene_from_config(scene, self.config.device_cfg.device)
         self._solver = None
 
     def reset_seed(self) -> None:
@@ -445,7 +446,8 @@ class _PlannerBase:
     def compute_kinematics(self, state: Union[JointState, torch.Tensor]) -> KinematicsState:
         return self.trajopt_solver.compute_kinematics(state)
 
-    def update_world(self, scene: SceneData) -> None:
+    def update_world(self, scene) -> None:
+        """reference ``update_world(scene_cfg)`` (:605-608): a ``SceneData`` or a scene description"""
         self.trajopt_solver.update_world(scene)
         self._ik = None
 

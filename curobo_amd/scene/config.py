@@ -3,7 +3,8 @@
 Counterpart of ``SceneCfg.create`` (reference ``curobo/_src/geom/types.py:919-1010``; yaml files under
 ``content/configs/scene/``): a dictionary ``{"cuboid": {name: {"dims": [x, y, z], "pose": [x, y, z, qw, qx, qy, qz]}},
 "sphere": {name: {"radius": r, "pose": [...]}}, "capsule": {name: {"radius", "base", "tip", "pose"}}, "cylinder":
-{name: {"radius", "height", "pose"}}}``, a path to such a yaml file, or a list of such (one per environment)."""
+{name: {"radius", "height", "pose"}}, "mesh": {...}, "voxel": {...}}``, a path to such a yaml file, a ``SceneCfg`` (scene/types.py:
+``curobo.scene.Scene`` built from ``Cuboid`` / ``Sphere`` / ... objects), or a list of such (one per environment)."""
 
 from __future__ import annotations
 
@@ -36,14 +37,21 @@ def _one_env(cfg: Dict) -> List[Dict]:
     return obs
 
 
-def mesh_envs_from_config(scene_model) -> Optional[List[List[Dict]]]:
-    """the ``mesh`` entries of a scene description, per environment, in the form ``scene.mesh.MeshStore`` takes: ``{"mesh":
-    {name: {"file_path": *.obj | "vertices": ..., "faces": ..., "pose": [...], "scale": [...]}}}`` (reference ``Mesh``,
-    geom/types.py); ``None`` when no environment has one"""
-    if scene_model is None:
-        return None
+def _plain(scene_model):
+    """``SceneCfg`` objects (scene/types.py; one, or a list with one per environment) -> their dictionary form"""
+    from .types import SceneCfg
+
+    if isinstance(scene_model, SceneCfg):
+        return scene_model.to_config()
+    if isinstance(scene_model, (list, tuple)):
+        return [m.to_config() if isinstance(m, SceneCfg) else m for m in scene_model]
+    return scene_model
+
+
+def _load_dicts(scene_model) -> List[Optional[Dict]]:
+    """per environment the scene dictionary (yaml files read), ``None`` where the entry is already an obstacle list"""
     models = scene_model if isinstance(scene_model, (list, tuple)) else [scene_model]
-    envs = []
+    out = []
     for m in models:
         if isinstance(m, str):
             if m in PACKAGED_SCENES:
@@ -53,12 +61,60 @@ def mesh_envs_from_config(scene_model) -> Optional[List[List[Dict]]]:
 
                 with open(m) as fh:
                     m = yaml.safe_load(fh)
-        envs.append([dict(c, name=name) for name, c in ((m.get("mesh") if isinstance(m, dict) else None) or {}).items()])
+        out.append(m if isinstance(m, dict) else None)
+    return out
+
+
+def voxel_arrays_from_config(scene_model) -> Optional[Dict[str, np.ndarray]]:
+    """the ``voxel`` entries (reference ``VoxelGrid``: ``dims``, ``voxel_size``, ``feature_tensor`` = the ESDF, ``pose``) of
+    every environment -> the voxel arrays of ``SceneData.from_arrays``: fp16 features padded to the largest grid"""
+    from .data import inverse_pose7
+
+    scene_model = _plain(scene_model)
+    if scene_model is None:
+        return None
+    envs = [list((m.get("voxel") or {}).items()) if m is not None else [] for m in _load_dicts(scene_model)]
+    n = max(len(e) for e in envs)
+    if n == 0:
+        return None
+    E = len(envs)
+    shape = lambda c: [int(round(float(x) / float(c.get("voxel_size", 0.02)))) for x in c["dims"]]  # noqa: E731
+    cells = max(int(np.prod(shape(c))) for e in envs for _, c in e)
+    params, inv = np.zeros((E, n, 4), np.float32), np.zeros((E, n, 8), np.float32)
+    inv[..., 3] = 1.0
+    enable, count = np.zeros((E, n), np.uint8), np.zeros((E,), np.int32)
+    feats = np.full((E, n, cells), -65504.0, np.float16)
+    for e, grids in enumerate(envs):
+        count[e] = len(grids)
+        for g, (name, c) in enumerate(grids):
+            nx, ny, nz = shape(c)
+            f = c.get("feature_tensor")
+            if f is None:
+                raise ValueError(f"voxel grid '{name}' has no feature_tensor (the ESDF)")
+            f = f.detach().cpu().numpy() if hasattr(f, "detach") else np.asarray(f)
+            if f.size != nx * ny * nz:
+                raise ValueError(f"voxel grid '{name}': feature_tensor has {f.size} values, dims / voxel_size give {nx} x {ny} x {nz}")
+            params[e, g] = [nx, ny, nz, float(c.get("voxel_size", 0.02))]
+            inv[e, g, :7] = inverse_pose7(c.get("pose") or [0, 0, 0, 1, 0, 0, 0])
+            enable[e, g] = 1 if c.get("enable", True) else 0
+            feats[e, g, : nx * ny * nz] = f.reshape(-1).astype(np.float16)
+    return {"voxel_params": params, "voxel_inv_pose": inv, "voxel_enable": enable, "voxel_count": count, "voxel_features": feats}
+
+
+def mesh_envs_from_config(scene_model) -> Optional[List[List[Dict]]]:
+    """the ``mesh`` entries of a scene description, per environment, in the form ``scene.mesh.MeshStore`` takes: ``{"mesh":
+    {name: {"file_path": *.obj | "vertices": ..., "faces": ..., "pose": [...], "scale": [...]}}}`` (reference ``Mesh``,
+    geom/types.py); ``None`` when no environment has one"""
+    scene_model = _plain(scene_model)
+    if scene_model is None:
+        return None
+    envs = [[dict(c, name=name) for name, c in ((m.get("mesh") if m is not None else None) or {}).items()] for m in _load_dicts(scene_model)]
     return envs if any(envs) else None
 
 
 def load_scene_config(scene_model: Union[str, Dict, List, None]) -> Optional[List[List[Dict]]]:
     """-> obstacle lists per environment (input of ``cuboid_scene_arrays``), or ``None`` for no world"""
+    scene_model = _plain(scene_model)
     if scene_model is None:
         return None
     if isinstance(scene_model, (list, tuple)):
@@ -87,9 +143,13 @@ def scene_from_config(scene_model, device, gradient_mode: int = 0):
     from .data import SceneData
     from .mesh import MeshStore
 
+    scene_model = _plain(scene_model)
     arrays = scene_arrays_from_config(scene_model)
     if arrays is None:
         return None
+    voxels = voxel_arrays_from_config(scene_model)
+    if voxels is not None:
+        arrays = dict(arrays, **voxels)
     meshes = mesh_envs_from_config(scene_model)
     store = MeshStore(meshes, device, gradient_mode=gradient_mode) if meshes is not None else None
     return SceneData.from_arrays(arrays, device, meshes=store)

@@ -122,7 +122,12 @@ class InverseKinematics:
             s._gen.manual_seed(s.cfg.seed)
             s.reset_seed()
 
-    def update_world(self, scene: SceneData) -> None:
+    def update_world(self, scene) -> None:
+        """``SceneData``, or a scene description (``curobo.scene.Scene``, dictionary, yaml path)"""
+        if scene is not None and not isinstance(scene, SceneData):
+            from ..scene.config import scene_from_config
+
+            scene = scene_from_config(scene, self.config.kinematics.kinematics_config.device)
         self.config.scene = scene
         self._solvers.clear()
         self._checker = None

@@ -386,3 +386,48 @@ def test_batch_planner_plan_grasp(oracle, device, this_repos_curobo):  # noqa: F
     # approach only
     g2 = planner.plan_grasp(grasps, cur, grasp_approach_offset=offset, plan_approach_to_grasp=False)
     assert g2.success.cpu().tolist() == want and g2.grasp_trajectory is None and g2.status == "Planning to approach pose completed."
+
+
+def test_scene_objects_reach_the_kernels(oracle, device, this_repos_curobo):  # noqa: F811
+    """a world built from ``curobo.scene`` objects (cuboid + sphere + an ESDF ``VoxelGrid``) gives the collision costs of the
+    oracle on the same obstacles, through ``scene_from_config`` and through a planner's ``update_world``"""
+    from curobo.scene import Cuboid, Scene, Sphere, VoxelGrid, scene_from_config
+    from curobo_amd.backends import collision as collision_hip
+    from curobo_amd.scene import cuboid_scene_arrays, voxel_grid_from_sdf
+
+    model = load_model("franka")
+    md = model.as_dict()
+    box = {"dims": [0.3, 0.3, 0.3], "pose": [0.5, 0.0, 0.4, 1, 0, 0, 0]}
+    ball = {"type": "sphere", "radius": 0.15, "pose": [0.2, 0.4, 0.5, 1, 0, 0, 0]}
+    centre, half = np.array([0.3, -0.3, 0.4]), np.array([0.1, 0.15, 0.2])
+
+    def sdf(p):  # positive inside a box (the ESDF convention of the voxel store)
+        d = np.abs(p - centre) - half
+        return -(np.linalg.norm(np.maximum(d, 0), axis=1) + np.minimum(d.max(1), 0))
+
+    n, vs = 32, 0.025
+    grid_arrays = voxel_grid_from_sdf(sdf, (n, n, n), vs, (0.3, -0.3, 0.4, 1, 0, 0, 0))
+    esdf = torch.as_tensor(grid_arrays["voxel_features"].reshape(n, n, n).astype(np.float32))
+    scene = Scene(cuboid=[Cuboid(name="box", **box)], sphere=[Sphere(name="ball", radius=0.15, pose=ball["pose"])],
+                  voxel=[VoxelGrid(name="esdf", dims=[n * vs] * 3, voxel_size=vs, feature_tensor=esdf, pose=[0.3, -0.3, 0.4, 1, 0, 0, 0])])
+    data = scene_from_config(scene, device)
+    arrays = dict(cuboid_scene_arrays([[box, ball]]), **grid_arrays)
+    q = sample_q(model, 64, seed=2, scale=0.6)
+    sph = oracle.kinematics_forward(q, md)["robot_spheres"].reshape(64, 1, -1, 4)
+    want = oracle.scene_collision(sph, arrays, 1.0, 0.02)
+    S = sph.shape[2]
+    dist, grad = torch.zeros(64, 1, S, device=device), torch.zeros(64, 1, S, 4, device=device)
+    w, eta = torch.tensor([1.0], device=device), torch.tensor([0.02], device=device)
+    env = torch.zeros(64, dtype=torch.int32, device=device)
+    collision_hip.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), data.struct, w, eta, env, 64, 1, S, False, 0, False, w)
+    torch.cuda.synchronize()
+    assert (want["distance"] > 0).mean() > 0.02
+    np.testing.assert_allclose(dist.cpu().numpy(), want["distance"], rtol=1e-4, atol=1e-5)
+    # the same description through a planner
+    from curobo.motion_planner import MotionPlanner, MotionPlannerCfg
+
+    planner = MotionPlanner(MotionPlannerCfg.create(robot="franka.yml", scene_model=None))
+    assert planner.trajopt_solver.config.scene is None
+    planner.update_world(scene)
+    st = planner.trajopt_solver.config.scene.struct
+    assert st.max_cuboids == 2 and st.max_voxel_grids == 1

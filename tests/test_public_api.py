@@ -235,3 +235,61 @@ def test_link_sphere_toggles_and_grasp_links_from_the_robot_file():
     assert torch.equal(kp.link_spheres, before)
     with pytest.raises(ValueError, match="not found"):
         kp.enable_link_spheres("nope")
+
+
+def test_scene_types_build_the_same_stores_as_the_dictionary_format():
+    """reference ``curobo.scene``: ``Scene`` (SceneCfg, geom/types.py:918-1292) of ``Cuboid`` / ``Sphere`` / ``Capsule`` / ``Cylinder`` /
+    ``Mesh`` / ``VoxelGrid`` objects; ``create`` from the yaml dictionary, add / get / remove, box approximation"""
+    from curobo.scene import Capsule, Cuboid, Cylinder, Mesh, Scene, Sphere, VoxelGrid, scene_arrays_from_config
+    from curobo_amd.scene.config import mesh_envs_from_config, voxel_arrays_from_config
+
+    cfg = {"cuboid": {"table": {"dims": [2.0, 2.0, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}},
+           "sphere": {"ball": {"radius": 0.1, "pose": [0.4, 0, 0.4, 1, 0, 0, 0]}},
+           "cylinder": {"post": {"radius": 0.05, "height": 0.8, "pose": [0.3, 0.3, 0.4, 1, 0, 0, 0]}},
+           "capsule": {"bar": {"radius": 0.04, "base": [0, 0, 0], "tip": [0, 0, 0.4], "pose": [-0.3, 0.2, 0.3, 0.7071068, 0.7071068, 0, 0]}}}
+    scene = Scene(cuboid=[Cuboid(name="table", dims=[2.0, 2.0, 0.2], pose=[0, 0, -0.1, 1, 0, 0, 0])],
+                  sphere=[Sphere(name="ball", radius=0.1, pose=[0.4, 0, 0.4, 1, 0, 0, 0])])
+    scene.add_obstacle(Cylinder(name="post", radius=0.05, height=0.8, pose=[0.3, 0.3, 0.4, 1, 0, 0, 0]))
+    scene.add_obstacle(Capsule(name="bar", radius=0.04, base=[0, 0, 0], tip=[0, 0, 0.4], pose=[-0.3, 0.2, 0.3, 0.7071068, 0.7071068, 0, 0]))
+    assert len(scene) == 4 and [o.name for o in scene] == ["ball", "table", "post", "bar"] and scene.get_cache_dict() == {"obb": 1, "mesh": 0}
+    want, got, made = scene_arrays_from_config(cfg), scene_arrays_from_config(scene), scene_arrays_from_config(Scene.create(cfg))
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+        np.testing.assert_array_equal(made[k], want[k], err_msg=k)
+    assert scene.get_obstacle("post").height == 0.8 and scene.get_obstacle("nope") is None
+    scene.remove_obstacle("ball")
+    assert len(scene) == 3 and scene.sphere == [] and int(scene_arrays_from_config(scene)["cuboid_count"][0]) == 3
+    two = scene_arrays_from_config([scene, Scene.create(cfg)])  # one world per environment
+    assert two["cuboid_count"].tolist() == [3, 4]
+    with pytest.raises(ValueError, match="requires a pose"):
+        Cuboid(name="x", dims=[1, 1, 1])
+    assert Sphere(name="s", radius=0.2, position=[1, 2, 3]).pose == [1, 2, 3, 1, 0, 0, 0]
+
+    # boxes around the analytic kinds: every point of the obstacle is inside its box
+    boxes = Scene.create(cfg).get_obb_world()
+    assert len(boxes.cuboid) == 4 and len(boxes) == 4
+    bar = [b for b in boxes.cuboid if b.name == "bar"][0]
+    np.testing.assert_allclose(bar.dims, [0.08, 0.08, 0.48], atol=1e-6)
+    np.testing.assert_allclose(bar.pose[:3], [-0.3, 0.2 - 0.2, 0.3], atol=1e-6)  # the axis (local z) lies along world -y... rotated 90 deg about x
+    ball = [b for b in boxes.cuboid if b.name == "ball"][0]
+    assert ball.dims == [0.2, 0.2, 0.2]
+
+    # meshes and voxel grids
+    v = [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    f = [[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]]
+    m = Mesh(name="tet", vertices=v, faces=f, scale=[0.5, 0.5, 2.0], pose=[0.1, 0, 0, 1, 0, 0, 0])
+    assert m.scale is None and np.allclose(m.vertices[3], [0, 0, 2.0])
+    np.testing.assert_allclose(m.get_cuboid().dims, [0.5, 0.5, 2.0])
+    s2 = Scene(mesh=[m], cuboid=[Cuboid(name="floor", dims=[1, 1, 0.1], pose=[0, 0, -0.05, 1, 0, 0, 0])])
+    envs = mesh_envs_from_config(s2)
+    assert len(envs) == 1 and envs[0][0]["name"] == "tet" and np.asarray(envs[0][0]["vertices"]).shape == (4, 3)
+    esdf = np.linspace(-1, 1, 4 * 3 * 2).astype(np.float32)
+    grid = VoxelGrid(name="g", dims=[0.4, 0.3, 0.2], voxel_size=0.1, feature_tensor=torch.as_tensor(esdf).view(4, 3, 2), pose=[0, 0, 0.5, 1, 0, 0, 0])
+    assert grid.get_grid_shape()[0] == [4, 3, 2]
+    s2.add_obstacle(grid)
+    va = voxel_arrays_from_config([s2, Scene()])
+    assert va["voxel_count"].tolist() == [1, 0] and va["voxel_params"][0, 0].tolist() == [4.0, 3.0, 2.0, np.float32(0.1)]
+    np.testing.assert_array_equal(va["voxel_features"][0, 0], esdf.astype(np.float16))
+    np.testing.assert_allclose(va["voxel_inv_pose"][0, 0, :7], [0, 0, -0.5, 1, 0, 0, 0])
+    with pytest.raises(ValueError, match="feature_tensor has"):
+        voxel_arrays_from_config(Scene(voxel=[VoxelGrid(name="bad", dims=[0.4, 0.4, 0.4], voxel_size=0.1, feature_tensor=esdf, pose=[0, 0, 0, 1, 0, 0, 0])]))
