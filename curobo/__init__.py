@@ -5,12 +5,14 @@
 ``from curobo.trajectory_optimizer import TrajectoryOptimizer``, ``from curobo.motion_planner import MotionPlanner``,
 ``from curobo.batch_motion_planner import BatchMotionPlanner`` and
 ``from curobo.types import JointState`` resolve to the classes documented in ``curobo_amd`` (each cites the reference
-file it mirrors).  Only the motion-generation hot path is covered: graph search, grasp planning, perception, viewers are out of scope."""
+file it mirrors).  Only the motion-generation hot path is covered: graph search, perception, viewers are out of scope."""
 
 from curobo_amd import __version__  # noqa: F401
 from curobo_amd.motion_planner import (BatchMotionPlanner, MotionPlanner, MotionPlannerCfg,  # noqa: F401
                                        TrajectoryOptimizer, TrajectoryOptimizerCfg)
+from curobo_amd.kinematics import Kinematics, KinematicsCfg  # noqa: F401
+from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg  # noqa: F401
 from curobo_amd.solver.inverse_kinematics import InverseKinematics, InverseKinematicsCfg  # noqa: F401
 
 __all__ = ["InverseKinematics", "InverseKinematicsCfg", "TrajectoryOptimizer", "TrajectoryOptimizerCfg", "MotionPlanner",
-           "MotionPlannerCfg", "BatchMotionPlanner"]
+           "MotionPlannerCfg", "BatchMotionPlanner", "ModelPredictiveControl", "ModelPredictiveControlCfg", "Kinematics", "KinematicsCfg"]

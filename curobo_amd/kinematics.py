@@ -37,6 +37,16 @@ class ToolPose:
 
 
 @dataclass
+class JointLimits:
+    """reference JointLimits (robot/types/joint_limits.py): position / velocity [2, dof] (lower, upper), effort [dof]"""
+
+    joint_names: List[str]
+    position: torch.Tensor
+    velocity: torch.Tensor
+    effort: Optional[torch.Tensor] = None
+
+
+@dataclass
 class KinematicsState:
     tool_poses: ToolPose
     tool_jacobians: Optional[torch.Tensor]  # [B,H,T,6,D]
@@ -102,6 +112,91 @@ class Kinematics:
     @property
     def tool_frames(self):
         return self.kinematics_config.tool_frames
+
+    # ---- reference members (robot/kinematics/kinematics.py:200-420): sizes, defaults, limits, joint-state bookkeeping
+    @property
+    def dof(self) -> int:
+        return self.kinematics_config.num_dof
+
+    def get_dof(self) -> int:
+        return self.dof
+
+    @property
+    def base_link(self) -> str:
+        return self.config.model.base_link
+
+    @property
+    def total_spheres(self) -> int:
+        return self.kinematics_config.num_spheres
+
+    @property
+    def default_joint_position(self) -> torch.Tensor:
+        from .workloads import start_configuration
+
+        return torch.as_tensor(start_configuration(self.config.model), dtype=torch.float32, device=self.kinematics_config.device)
+
+    @property
+    def default_joint_state(self):
+        from .types import JointState
+
+        return JointState.from_position(self.default_joint_position, joint_names=self.joint_names)
+
+    @property
+    def lock_jointstate(self):
+        """the joints the robot file locks, at their locked values (reference ``lock_jointstate``)"""
+        from .types import JointState
+
+        lock = self.config.model.lock_joints or {}
+        return JointState.from_position(torch.tensor(list(lock.values()), dtype=torch.float32, device=self.kinematics_config.device),
+                                        joint_names=list(lock.keys()))
+
+    def get_joint_limits(self) -> "JointLimits":
+        k = self.kinematics_config
+        return JointLimits(list(self.joint_names), k.joint_limits_position, k.joint_limits_velocity, k.joint_limits_effort)
+
+    def get_self_collision_config(self):
+        return self.kinematics_config.self_collision
+
+    def get_active_js(self, full_js):
+        """the active (optimised) joints of a joint state that may carry more -- or differently ordered -- joints, selected by
+        name (reference ``get_active_js``); a state without names is taken to be in the active order already"""
+        names = getattr(full_js, "joint_names", None)
+        if not names or list(names) == list(self.joint_names):
+            return full_js
+        missing = [n for n in self.joint_names if n not in names]
+        if missing:
+            raise ValueError(f"joint state lacks the active joints {missing}")
+        idx = torch.as_tensor([list(names).index(n) for n in self.joint_names], device=full_js.position.device)
+        from .types import JointState
+
+        g = lambda t: None if t is None else t.index_select(-1, idx)  # noqa: E731
+        return JointState(g(full_js.position), g(full_js.velocity), g(full_js.acceleration), g(full_js.jerk), list(self.joint_names), full_js.dt)
+
+    def get_full_js(self, active_js):
+        """active joints + the locked ones at their locked values (zero velocity / acceleration / jerk), reference ``get_full_js``"""
+        lock = self.lock_jointstate
+        if not lock.joint_names:
+            return active_js
+        from .types import JointState
+
+        p = active_js.position
+        lp = lock.position.to(p.device).expand(*p.shape[:-1], -1)
+        cat = lambda t, fill: None if t is None else torch.cat([t, fill], -1)  # noqa: E731
+        z = torch.zeros_like(lp)
+        return JointState(cat(p, lp), cat(active_js.velocity, z), cat(active_js.acceleration, z), cat(active_js.jerk, z),
+                          list(active_js.joint_names or self.joint_names) + list(lock.joint_names), active_js.dt)
+
+    def get_robot_as_spheres(self, q: torch.Tensor, filter_valid: bool = True):
+        """per configuration the robot's collision spheres as ``curobo.scene.Sphere`` objects (reference ``get_robot_as_spheres``);
+        ``filter_valid`` drops the disabled ones (radius <= 0)"""
+        from .scene.types import Sphere
+
+        sph = self.compute_kinematics(q.reshape(-1, self.dof)).robot_spheres[:, 0].detach().cpu().numpy()
+        out = []
+        for b in range(sph.shape[0]):
+            out.append([Sphere(name=f"robot_sphere_{b}_{i}", pose=[float(x), float(y), float(z), 1, 0, 0, 0], radius=float(r))
+                        for i, (x, y, z, r) in enumerate(sph[b]) if not filter_valid or r > 0.0])
+        return out
 
     def _setup(self, b: int, h: int):
         if self._shape != (b, h):

@@ -258,6 +258,54 @@ class TrajectoryOptimizer:
         if self._solver is not None:
             self._solver.update_tool_pose_criteria(tool_pose_criteria)
 
+    # ---- further reference members (solver_trajopt.py:121-215, solver_core.py)
+    @property
+    def device_cfg(self) -> DeviceCfg:
+        return self.config.device_cfg
+
+    @property
+    def default_joint_position(self) -> torch.Tensor:
+        return self.kinematics.default_joint_position
+
+    @property
+    def horizon(self) -> int:
+        """points of an optimised trajectory"""
+        return self.config.solver_cfg().rollout.padded_horizon
+
+    @property
+    def opt_dim(self) -> int:
+        return self.action_horizon * self.action_dim
+
+    @property
+    def problem_batch_size(self) -> int:
+        return int(self.config.max_batch_size)
+
+    def get_active_js(self, full_js: JointState) -> JointState:
+        return self.kinematics.get_active_js(full_js)
+
+    def get_full_js(self, active_js: JointState) -> JointState:
+        return self.kinematics.get_full_js(active_js)
+
+    def compute_trajectory_dt(self, velocity: torch.Tensor, acceleration: torch.Tensor, jerk: torch.Tensor, dt: torch.Tensor) -> torch.Tensor:
+        """the fastest time step at which a trajectory sampled at ``dt`` stays inside the velocity / acceleration / jerk limits
+        (reference ``compute_trajectory_dt``; see ``TrajOptSolver.compute_trajectory_dt``)"""
+        return self.solver.compute_trajectory_dt(velocity, acceleration, jerk, dt)
+
+    def get_interpolated_trajectory(self, knots: torch.Tensor, start_position: torch.Tensor, goal_config: Optional[torch.Tensor] = None,
+                                    retime: bool = True, traj_dt: Optional[torch.Tensor] = None):
+        """knots [P, n_knots, dof] -> the trajectory sampled at ``interpolation_dt`` (reference ``get_interpolated_trajectory``,
+        :579-634; ``TrajOptSolver.get_interpolated_trajectory``)"""
+        return self.solver.get_interpolated_trajectory(knots, start_position, goal_config, retime, traj_dt)
+
+    def reset_shape(self) -> None:
+        self._solver = None
+
+    def reset_cuda_graph(self) -> None:
+        self._solver = None
+
+    def destroy(self) -> None:
+        self._solver = None
+
     def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
         self.config.kinematics.kinematics_config.update_link_inertial(link_name, mass, com, inertia)
 

@@ -33,6 +33,18 @@ class InverseKinematicsResult:
     solve_time: float = 0.0
     debug_info: Optional[dict] = None
 
+    def get_unique_solution(self, roundoff_decimals: int = 2) -> torch.Tensor:
+        """the successful solutions, one representative per configuration after rounding to ``roundoff_decimals`` (reference
+        ``get_unique_solution``, solver_ik_result.py) -> [num_unique, dof]"""
+        sol = self.solution[self.success]
+        if sol.ndim != 2:
+            raise ValueError("Solution shape is not of length 2")
+        rounded = torch.round(sol, decimals=roundoff_decimals)
+        uniq, inverse = torch.unique(rounded, dim=-2, return_inverse=True)
+        first = torch.full((uniq.shape[0],), sol.shape[0], dtype=torch.long, device=sol.device)
+        first.scatter_reduce_(0, inverse, torch.arange(sol.shape[0], device=sol.device), reduce="amin")
+        return sol[first]
+
 
 @dataclass
 class InverseKinematicsCfg:
@@ -147,6 +159,31 @@ class InverseKinematics:
 
         q = torch.as_tensor(start_configuration(self.config.kinematics.model), device=self.config.kinematics.kinematics_config.device)
         return JointState.from_position(q, joint_names=self.joint_names)
+
+    @property
+    def device_cfg(self) -> DeviceCfg:
+        return self.config.device_cfg
+
+    @property
+    def default_joint_position(self) -> torch.Tensor:
+        return self.kinematics.default_joint_position
+
+    @property
+    def problem_batch_size(self) -> int:
+        return max(self._solvers) if self._solvers else int(self.config.max_batch_size)
+
+    def get_active_js(self, full_js: JointState) -> JointState:
+        return self.kinematics.get_active_js(full_js)
+
+    def get_full_js(self, active_js: JointState) -> JointState:
+        return self.kinematics.get_full_js(active_js)
+
+    def reset_shape(self) -> None:
+        """reference ``reset_shape``: the solvers (and their captured graphs) are rebuilt on the next solve"""
+        self._solvers.clear()
+
+    def reset_cuda_graph(self) -> None:
+        self._solvers.clear()
 
     def update_link_inertial(self, link_name: str, mass: Optional[float] = None, com=None, inertia=None) -> None:
         self.config.kinematics.kinematics_config.update_link_inertial(link_name, mass, com, inertia)

@@ -68,3 +68,62 @@ def test_mpc_tracks_a_pose_goal_in_closed_loop(continuous, oracle, device):
     assert float((st.tool_poses.position[:, 0, 0] - goal2.position[:, 0, 0, 0]).norm(dim=-1).max()) < 0.01
     seq = mpc.optimize_action_sequence(state)
     assert seq.action_sequence.position.shape[0] == B and seq.action_buffer.shape == (B, 16, 7)
+
+
+def test_model_predictive_control_front_end(oracle, device):
+    """the reference's usage (curobo/model_predictive_control.py docstring): ModelPredictiveControlCfg.create(robot=..., scene_model=...) ->
+    ModelPredictiveControl -> setup(current_state) -> update_goal_tool_poses -> optimize_next_action in a loop; per-robot goal updates
+    through ``robot_ids``; a goal given as ``{tool frame: Pose}``"""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg
+    from curobo_amd.scene.types import Cuboid, SceneCfg
+    from curobo_amd.types import JointState, Pose
+
+    scene = SceneCfg(cuboid=[Cuboid(name="table", dims=[2.0, 2.0, 0.2], pose=[0, 0, -0.1, 1, 0, 0, 0])])
+    B = 2
+    config = ModelPredictiveControlCfg.create(robot="franka.yml", scene_model=scene, optimization_dt=0.02, interpolation_steps=4,
+                                              max_batch_size=B, optimizer_configs=["mpc/lbfgs_mpc.yml"])  # (accepted, ignored)
+    mpc = ModelPredictiveControl(config)
+    assert mpc.action_dim == 7 and mpc.action_horizon == 16 and abs(mpc.command_dt - 0.005) < 1e-12 and mpc.problem_batch_size == B
+    q0 = mpc.default_joint_state.position.view(1, -1).repeat(B, 1)
+    state = JointState(position=q0.clone(), velocity=torch.zeros_like(q0), acceleration=torch.zeros_like(q0), joint_names=mpc.joint_names)
+    with pytest.raises(RuntimeError, match="setup"):
+        mpc.optimize_next_action(state)
+    mpc.setup(state)  # holds the current tool pose
+    hold = mpc.optimize_next_action(state)
+    assert float((hold.next_action.position - q0).abs().max()) < 2e-3
+    dq = torch.tensor([[0.4, 0.2, -0.3, 0.3, 0.2, -0.2, 0.3], [-0.4, 0.1, 0.3, 0.2, -0.3, 0.3, -0.2]], device=device)
+    goal = mpc.compute_kinematics(JointState.from_position(q0 + dq)).tool_poses.as_goal()
+    assert mpc.update_goal_tool_poses(goal)
+
+    def run(steps):
+        nonlocal state
+        for _ in range(steps):
+            r = mpc.optimize_next_action(state)
+            state = JointState(position=r.next_action.position.clone(), velocity=r.next_action.velocity.clone(),
+                               acceleration=r.next_action.acceleration.clone(), joint_names=mpc.joint_names)
+        st = mpc.compute_kinematics(JointState.from_position(state.position))
+        return st.tool_poses.position[:, 0, 0]
+
+    p = run(400)
+    assert float((p - goal.position[:, 0, 0, 0]).norm(dim=-1).max()) < 0.01
+    # robot 1 alone gets a new goal (robot_ids); robot 0 keeps its own
+    back = mpc.compute_kinematics(JointState.from_position(q0)).tool_poses.as_goal()
+    mpc.update_goal_tool_poses(back, robot_ids=torch.tensor([1], device=device))
+    p = run(400)
+    assert float((p[0] - goal.position[0, 0, 0, 0]).norm()) < 0.01 and float((p[1] - back.position[1, 0, 0, 0]).norm()) < 0.01
+    # a dictionary of poses: both robots to the start pose again; the plans stay clear of the table (oracle)
+    frame = mpc.tool_frames[0]
+    mpc.update_goal_tool_poses({frame: Pose(back.position[:, 0, 0, 0], back.quaternion[:, 0, 0, 0])})
+    p = run(400)
+    assert float((p - back.position[:, 0, 0, 0]).norm(dim=-1).max()) < 0.01
+    model = config.kinematics.model
+    sph = oracle.kinematics_forward(state.position.cpu().numpy(), model.as_dict())["robot_spheres"].reshape(B, 1, -1, 4)
+    from curobo_amd.scene import cuboid_scene_arrays
+    arrays = cuboid_scene_arrays([[{"dims": [2.0, 2.0, 0.2], "pose": [0, 0, -0.1, 1, 0, 0, 0]}]])
+    assert (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"] == 0).all()
+    seq = mpc.optimize_action_sequence(state)
+    assert seq.action_sequence.position.shape[0] == B and seq.action_sequence.position.shape[-1] == 7

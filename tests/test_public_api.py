@@ -293,3 +293,45 @@ def test_scene_types_build_the_same_stores_as_the_dictionary_format():
     np.testing.assert_allclose(va["voxel_inv_pose"][0, 0, :7], [0, 0, -0.5, 1, 0, 0, 0])
     with pytest.raises(ValueError, match="feature_tensor has"):
         voxel_arrays_from_config(Scene(voxel=[VoxelGrid(name="bad", dims=[0.4, 0.4, 0.4], voxel_size=0.1, feature_tensor=esdf, pose=[0, 0, 0, 1, 0, 0, 0])]))
+
+
+def test_kinematics_accessors_and_result_helpers():
+    """reference ``Kinematics`` members (robot/kinematics/kinematics.py): sizes, defaults, limits, active / full joint states with the
+    robot file's locked joints; ``IKSolverResult.get_unique_solution``; the front ends' class surfaces"""
+    from curobo import ModelPredictiveControl, ModelPredictiveControlCfg, TrajectoryOptimizer  # noqa: F401
+    from curobo.inverse_kinematics import InverseKinematics
+    from curobo.kinematics import Kinematics, KinematicsCfg
+    from curobo.types import JointState
+    from curobo_amd.solver.inverse_kinematics import InverseKinematicsResult
+
+    k = Kinematics(KinematicsCfg.from_packaged("franka", device="cpu"))
+    assert (k.dof, k.get_dof(), k.base_link, k.total_spheres) == (7, 7, "panda_link0", 65)
+    np.testing.assert_allclose(k.default_joint_position.numpy(), [0.0, -1.3, 0.0, -2.5, 0.0, 1.5, 0.8], atol=1e-6)
+    assert k.default_joint_state.joint_names == k.joint_names
+    lim = k.get_joint_limits()
+    assert lim.position.shape == (2, 7) and lim.velocity.shape == (2, 7) and lim.effort.shape == (7,) and lim.joint_names == k.joint_names
+    lock = k.lock_jointstate
+    assert lock.joint_names == ["panda_finger_joint1", "panda_finger_joint2"] and lock.position.tolist() == pytest.approx([0.04, 0.04])
+    full = k.get_full_js(JointState.from_position(torch.arange(14.0).view(2, 7), joint_names=k.joint_names))
+    assert full.position.shape == (2, 9) and full.joint_names[-2:] == lock.joint_names and full.position[1, -1].item() == pytest.approx(0.04)
+    shuffled = JointState.from_position(full.position.flip(-1), joint_names=list(reversed(full.joint_names)))
+    act = k.get_active_js(shuffled)
+    assert act.joint_names == k.joint_names and torch.equal(act.position, torch.arange(14.0).view(2, 7))
+    with pytest.raises(ValueError, match="lacks the active joints"):
+        k.get_active_js(JointState.from_position(torch.zeros(1, 2), joint_names=["a", "b"]))
+    assert k.get_self_collision_config().collision_pairs.shape[0] == 818
+
+    sol = torch.tensor([[[0.10, 0.2], [0.101, 0.2], [0.5, 0.5], [0.9, 0.9]]])
+    res = InverseKinematicsResult(success=torch.tensor([[True, True, True, False]]), solution=sol, js_solution=None,
+                                  position_error=torch.zeros(1, 4), rotation_error=torch.zeros(1, 4))
+    uniq = res.get_unique_solution(roundoff_decimals=2)
+    assert uniq.shape == (2, 2) and sorted(uniq[:, 0].tolist()) == pytest.approx([0.10, 0.5])
+    for cls, names in ((InverseKinematics, ("solve_pose", "sample_configs", "update_world", "update_tool_pose_criteria", "update_link_inertial",
+                                            "get_active_js", "get_full_js", "reset_seed", "reset_shape", "destroy", "default_joint_state")),
+                       (TrajectoryOptimizer, ("solve_pose", "solve_cspace", "compute_trajectory_dt", "get_interpolated_trajectory",
+                                              "update_tool_pose_criteria", "reset_seed", "destroy", "horizon", "opt_dim")),
+                       (ModelPredictiveControl, ("setup", "update_goal_tool_poses", "update_current_state", "optimize_next_action",
+                                                 "optimize_action_sequence", "reset_robot", "update_world", "update_tool_pose_criteria"))):
+        for n in names:
+            assert hasattr(cls, n), (cls.__name__, n)
+    assert hasattr(ModelPredictiveControlCfg, "create")
