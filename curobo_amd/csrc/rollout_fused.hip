@@ -94,7 +94,7 @@ struct FusedLayout {
 };
 // n_lane > 0: the lane = sphere form of the pair list (n_lane words) is staged INSTEAD of the (i, j) offsets
 __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, int C, int P, int n_rec, int n_dyn = 0,
-                                                    int n_waves = 0, int rings = 1, int n_lane = 0) {
+                                                    int n_waves = 0, int rings = 1, int n_lane = 0, bool with_left = true) {
   FusedLayout f;
   int o = 0;
   auto take = [&](int n) { const int at = o; o += (n + 3) & ~3; return at; };  // 16-byte granules
@@ -123,7 +123,8 @@ __host__ __device__ inline FusedLayout fused_layout(int H, int D, int L, int S, 
   f.lbound = take(L * 8);
   f.sub = take(L * 4);
   f.jlinks = take(D * 4);
-  f.left = take(S * 4);
+  f.left = take(with_left ? S * 4 : 0);  // (the trajectory kernel's leftover-point buffer: the IK launch has none, and its 1 KB is
+                                         // the difference between three and four workgroups per CU there)
   f.key = take(4);
   f.flag = take(H);  // per point: any wrench written
   f.dyn = take(n_dyn);  // velocity / acceleration / jerk (+ joint-space position gradient) [4][H][D] when the c-space STATE cost is on
@@ -1458,7 +1459,7 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
   const FusedTrajArgs &a = ia.r;
   const int H = kIkPoints, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs, T = ia.n_tool_frames;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
-  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec);
+  const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, 0, 0, 1, 0, false);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int pt0 = blockIdx.x * kIkPoints;
   const int npts = min(kIkPoints, ia.n_points - pt0);
@@ -1953,7 +1954,7 @@ CUROBO_EXPORT int curobo_hip_rollout_trajopt_fused_torque_fits(int padded_horizo
 
 CUROBO_EXPORT int curobo_hip_rollout_ik_fused_lds_bytes(int dof, int num_links, int num_spheres, int num_collision_pairs,
                                                         int link_chain_len, int num_obstacles) {
-  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, num_collision_pairs, num_obstacles);
+  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, num_collision_pairs, num_obstacles, 0, 0, 1, 0, false);
   return lay.total * (int)sizeof(float);
 }
 
@@ -2011,7 +2012,7 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
   ia.p_b = p_b; ia.cs_weight = cspace_weight; ia.cs_eta = cspace_activation_distance; ia.out_cspace_cost = out_cspace_cost;
   hipStream_t st = (hipStream_t)stream;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
-  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec);
+  const FusedLayout lay = fused_layout(kIkPoints, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec, 0, 0, 1, 0, false);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: 16 configurations do not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
