@@ -1264,11 +1264,13 @@ def full_trajopt_benchmark(seeds, model, kin, scene, device, torch):
     for name, fused in (("fused_us", True), ("kernel_sequence_us", False)):
         cfg = TrajOptRolloutCfg(use_fused=fused)
         cfg.use_torque_limits = True
+        cfg.fused_torque_max_batch = 1 << 30 if fused else 0  # (measure both forms at this batch; the rollout's own choice is below)
         ro = TrajOptRollout(kin, scene, B, cfg)
         ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
         x = knots.reshape(B, -1)
         g = graphed(lambda: ro.cost_and_gradient(x), 10, torch)
         tq[name] = round(time_kernel(g.replay, 20, torch) / 10, 1)
+    tq["rollout_picks"] = "kernel_sequence" if B > TrajOptRolloutCfg().fused_torque_max_batch else "fused"
     res["with_torque_limits"] = tq
     return res
 
