@@ -1159,6 +1159,10 @@ def c4_benchmark(device, torch):
         "fk_backward": (lambda: _fk_bwd(ro, kin, B, H, D, S), N * (48 * L + 16 * S + 28 * T + 4 * D)),
     }
     res["kernels"] = _timed_stages(stages, torch, reps=2)
+    res["kernels_note"] = ("every kernel timed ALONE (plain launches); in the rollout set the joint-space chain (RNEA -> c-space -> RNEA VJP) "
+                           "runs on a side stream next to the task-space chain, and its RNEA launches read their inputs from a transposed "
+                           "scratch instead of LDS (curobo_hip_launch_rnea_*_scratch: 180 / 350 us alone, but the self-collision kernel "
+                           "keeps its eight points per CU next to them)")
     k = res["kernels"]["self_collision_tiled"]
     cr = counter_roofline("self_collision_tiles", 0, k["us"], units=N)
     res["roofline"] = {"bound": "hbm", "kernel": "self_collision_tiles2_kernel (pair bitmap, two-level broad phase: 16- and 4-sphere boxes, 4 waves per point, 162 k pairs)",

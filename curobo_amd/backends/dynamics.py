@@ -92,9 +92,22 @@ def launch_rnea_forward(
     n_levels: int,
     threads_per_batch: int = 1,
     f_ext: Optional[torch.Tensor] = None,
+    scratch: Optional[torch.Tensor] = None,
 ):
+    """``scratch`` (extension, 3 * num_dof * batch_size floats): the launch transposes its inputs into it and the walk reads them
+    from there instead of staging them through LDS (``curobo_hip_launch_rnea_forward_scratch``: same values)"""
     if forward_cache.numel() < batch_size * num_links * 20:
         raise ValueError("forward_cache must hold batch_size * num_links * 20 floats")
+    if scratch is not None:
+        if scratch.numel() < 3 * num_dof * batch_size:
+            raise ValueError("scratch must hold 3 * num_dof * batch_size floats")
+        check(load().curobo_hip_launch_rnea_forward_scratch(
+            ptr(tau), ptr(q), ptr(qd), ptr(qdd), ptr(fixed_transforms), ptr(link_masses_com), ptr(link_inertias),
+            ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(joint_offset_map), ptr(gravity), ptr(level_starts),
+            ptr(_walk_order(link_map, level_links)), ptr(forward_cache), batch_size, num_links, num_dof, n_levels, threads_per_batch,
+            ptr(f_ext), ptr(scratch), current_stream(tau),
+        ))
+        return
     check(load().curobo_hip_launch_rnea_forward(
         ptr(tau), ptr(q), ptr(qd), ptr(qdd), ptr(fixed_transforms), ptr(link_masses_com), ptr(link_inertias),
         ptr(joint_map_type), ptr(joint_map), ptr(link_map), ptr(joint_offset_map), ptr(gravity), ptr(level_starts),
@@ -128,12 +141,23 @@ def launch_rnea_backward(
     threads_per_batch: int = 1,
     grad_f_ext: Optional[torch.Tensor] = None,
     workspace: Optional[torch.Tensor] = None,
+    scratch: Optional[torch.Tensor] = None,
 ):
-    """Gradient buffers are fully rewritten (no ``zero_()`` needed), as in the reference."""
+    """Gradient buffers are fully rewritten (no ``zero_()`` needed), as in the reference.  ``scratch``: see ``launch_rnea_forward``."""
     need = batch_size * num_links * 18
     ws = workspace if workspace is not None else _workspace(grad_q.device, need)
     if ws.numel() < need:
         raise ValueError("workspace must hold batch_size * num_links * 18 floats")
+    if scratch is not None:
+        if scratch.numel() < 3 * num_dof * batch_size:
+            raise ValueError("scratch must hold 3 * num_dof * batch_size floats")
+        check(load().curobo_hip_launch_rnea_backward_scratch(
+            ptr(grad_q), ptr(grad_qd), ptr(grad_qdd), ptr(grad_tau), ptr(q), ptr(qd), ptr(fixed_transforms),
+            ptr(link_masses_com), ptr(link_inertias), ptr(joint_map_type), ptr(joint_map), ptr(link_map),
+            ptr(joint_offset_map), ptr(gravity), ptr(level_starts), ptr(_walk_order(link_map, level_links)), ptr(forward_cache), batch_size,
+            num_links, num_dof, n_levels, threads_per_batch, ptr(grad_f_ext), ptr(ws), ptr(scratch), current_stream(grad_q),
+        ))
+        return
     check(load().curobo_hip_launch_rnea_backward(
         ptr(grad_q), ptr(grad_qd), ptr(grad_qdd), ptr(grad_tau), ptr(q), ptr(qd), ptr(fixed_transforms),
         ptr(link_masses_com), ptr(link_inertias), ptr(joint_map_type), ptr(joint_map), ptr(link_map),

@@ -111,9 +111,64 @@ __global__ void __launch_bounds__(256) rnea_backward_staged_kernel(const RneaArg
   }
 }
 
+// ---- the walks over inputs transposed into a scratch (RneaTransposedIO): link constants are the only LDS
+__global__ void __launch_bounds__(256) rnea_transpose_kernel(const float *in0, const float *in1, const float *in2, float *out, int B, int D) {
+  // [B][D] -> [D][B] for three tensors (blockIdx.z), 32 x 32 tiles through LDS: coalesced on both sides
+  __shared__ float tile[32][33];
+  const float *in = blockIdx.z == 0 ? in0 : blockIdx.z == 1 ? in1 : in2;
+  float *o = out + (size_t)blockIdx.z * D * B;
+  const int b0 = blockIdx.x * 32, j0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int b = b0 + r, j = j0 + tx;
+    tile[r][tx] = (b < B && j < D) ? in[(size_t)b * D + j] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + r, b = b0 + tx;
+    if (j < D && b < B) o[(size_t)j * B + b] = tile[tx][r];
+  }
+}
+
+template <bool HAS_FEXT, bool QUAD, bool BACKWARD>
+__global__ void __launch_bounds__(256) rnea_scratch_kernel(const RneaArgs a, const float *scratch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.num_links, D = a.num_dof;
+  float *s_f = smem;
+  int *s_i = reinterpret_cast<int *>(smem + L * kLinkFloats);
+  stage_links(a, s_f, s_i);  // (ends with the workgroup barrier)
+  const size_t B = (size_t)a.batch;
+  const size_t b = (size_t)blockIdx.x * kStagedLanes + (QUAD ? threadIdx.x >> 2 : threadIdx.x);
+  if (b >= B) return;
+  const RneaTransposedIO io{scratch, scratch + (size_t)D * B, scratch + 2 * (size_t)D * B, B, (uint32_t)b * 4u, RneaGlobalIO(a, b)};
+  if (QUAD) {
+    const int c = (int)threadIdx.x & 3;
+    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b, B, QuadAlg{c < 3 ? c : 2});
+    else rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b, B, QuadAlg{c < 3 ? c : 2});
+  } else {
+    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b, B);
+    else rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b, B);
+  }
+}
+
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
+
+// the scratch form of a launch: transposition, then the walk
+template <bool BACKWARD>
+static int launch_rnea_scratch(const RneaArgs &a, const float *in0, const float *in1, const float *in2, float *scratch, bool fext,
+                               hipStream_t st, const char *what) {
+  const int B = a.batch, D = a.num_dof;
+  hipLaunchKernelGGL(rnea_transpose_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32), 3), dim3(256), 0, st, in0, in1, in2, scratch, B, D);
+  static const bool quad = [] { const char *e = getenv("CUROBO_RNEA_QUAD"); return e ? atoi(e) != 0 : true; }();
+  const dim3 grid((unsigned)((B + kStagedLanes - 1) / kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
+  const size_t lds = (size_t)a.num_links * (kLinkFloats + 4) * sizeof(float);
+  if (fext) { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<true, true, BACKWARD>), grid, block, lds, st, a, scratch);
+              else hipLaunchKernelGGL((rnea_scratch_kernel<true, false, BACKWARD>), grid, block, lds, st, a, scratch); }
+  else { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<false, true, BACKWARD>), grid, block, lds, st, a, scratch);
+         else hipLaunchKernelGGL((rnea_scratch_kernel<false, false, BACKWARD>), grid, block, lds, st, a, scratch); }
+  return check_launch(what, st);
+}
 
 // LDS of the staged kernels: link constants + three joint-space input vectors [dof][65]
 static size_t rnea_staged_lds(int num_links, int num_dof, int vectors) {
@@ -152,14 +207,13 @@ static bool rnea_quad() {  // EXPERIMENT knob: CUROBO_RNEA_QUAD=0 keeps an eleme
 
 static size_t rnea_lds(int num_links) { return (size_t)num_links * (kLinkFloats + 4) * sizeof(float); }
 
-CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
+static int rnea_forward_impl(
     float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
     const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
     const int16_t *link_map, const float *joint_offset_map, const float *gravity, const int16_t *level_starts,
     const int16_t *level_links, float *forward_cache, int batch_size, int num_links, int num_dof, int n_levels,
-    int threads_per_batch, const float *f_ext, curobo_hip_stream_t stream) {
+    int threads_per_batch, const float *f_ext, float *scratch, curobo_hip_stream_t stream, const char *what) {
   (void)level_starts; (void)n_levels; (void)threads_per_batch;  // one lane per element: level order is all that is needed
-  const char *what = "launch_rnea_forward";
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
   CUROBO_REQUIRE((long long)batch_size * (num_dof > 4 ? num_dof : 4) < (1ll << 30), "%s: batch too large for 32-bit row offsets (%d x %d)",
@@ -172,6 +226,7 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   a.level_links = level_links; a.cache = forward_cache; a.f_ext = f_ext;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
+  if (scratch != nullptr) return launch_rnea_scratch<false>(a, q, qd, qdd, scratch, f_ext != nullptr, st, what);
   // one element per lane and a strictly serial walk: the launch is latency bound, so small batches are spread one
   // wavefront per workgroup over as many CUs as possible
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
@@ -195,15 +250,37 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
   return check_launch(what, st);
 }
 
-CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
+CUROBO_EXPORT int curobo_hip_launch_rnea_forward(
+    float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
+    const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const float *joint_offset_map, const float *gravity, const int16_t *level_starts,
+    const int16_t *level_links, float *forward_cache, int batch_size, int num_links, int num_dof, int n_levels,
+    int threads_per_batch, const float *f_ext, curobo_hip_stream_t stream) {
+  return rnea_forward_impl(tau, q, qd, qdd, fixed_transforms, link_masses_com, link_inertias, joint_map_type, joint_map, link_map,
+                           joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links, num_dof, n_levels,
+                           threads_per_batch, f_ext, nullptr, stream, "launch_rnea_forward");
+}
+
+CUROBO_EXPORT int curobo_hip_launch_rnea_forward_scratch(
+    float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
+    const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const float *joint_offset_map, const float *gravity, const int16_t *level_starts,
+    const int16_t *level_links, float *forward_cache, int batch_size, int num_links, int num_dof, int n_levels,
+    int threads_per_batch, const float *f_ext, float *scratch, curobo_hip_stream_t stream) {
+  CUROBO_REQUIRE(scratch != nullptr || batch_size == 0, "launch_rnea_forward_scratch: scratch [3 * num_dof * batch_size] floats is required");
+  return rnea_forward_impl(tau, q, qd, qdd, fixed_transforms, link_masses_com, link_inertias, joint_map_type, joint_map, link_map,
+                           joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links, num_dof, n_levels,
+                           threads_per_batch, f_ext, scratch, stream, "launch_rnea_forward_scratch");
+}
+
+static int rnea_backward_impl(
     float *grad_q, float *grad_qd, float *grad_qdd, const float *grad_tau, const float *q, const float *qd,
     const float *fixed_transforms, const float *link_masses_com, const float *link_inertias,
     const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
     const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
-    float *workspace, curobo_hip_stream_t stream) {
+    float *workspace, float *scratch, curobo_hip_stream_t stream, const char *what) {
   (void)level_starts; (void)n_levels; (void)threads_per_batch;
-  const char *what = "launch_rnea_backward";
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
   CUROBO_REQUIRE((long long)batch_size * (num_dof > 4 ? num_dof : 4) < (1ll << 30), "%s: batch too large for 32-bit row offsets (%d x %d)",
@@ -221,6 +298,7 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   a.ws_vbar = workspace + (size_t)num_links * 12 * batch_size;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
+  if (scratch != nullptr) return launch_rnea_scratch<true>(a, q, qd, grad_tau, scratch, grad_f_ext != nullptr, st, what);
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
   if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
     const bool quad = rnea_quad();
@@ -240,4 +318,29 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
   if (grad_f_ext) hipLaunchKernelGGL((rnea_backward_kernel<true>), grid, block, rnea_lds(num_links), st, a);
   else hipLaunchKernelGGL((rnea_backward_kernel<false>), grid, block, rnea_lds(num_links), st, a);
   return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
+    float *grad_q, float *grad_qd, float *grad_qdd, const float *grad_tau, const float *q, const float *qd,
+    const float *fixed_transforms, const float *link_masses_com, const float *link_inertias,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
+    const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
+    int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
+    float *workspace, curobo_hip_stream_t stream) {
+  return rnea_backward_impl(grad_q, grad_qd, grad_qdd, grad_tau, q, qd, fixed_transforms, link_masses_com, link_inertias, joint_map_type,
+                            joint_map, link_map, joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links,
+                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, nullptr, stream, "launch_rnea_backward");
+}
+
+CUROBO_EXPORT int curobo_hip_launch_rnea_backward_scratch(
+    float *grad_q, float *grad_qd, float *grad_qdd, const float *grad_tau, const float *q, const float *qd,
+    const float *fixed_transforms, const float *link_masses_com, const float *link_inertias,
+    const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
+    const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
+    int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
+    float *workspace, float *scratch, curobo_hip_stream_t stream) {
+  CUROBO_REQUIRE(scratch != nullptr || batch_size == 0, "launch_rnea_backward_scratch: scratch [3 * num_dof * batch_size] floats is required");
+  return rnea_backward_impl(grad_q, grad_qd, grad_qdd, grad_tau, q, qd, fixed_transforms, link_masses_com, link_inertias, joint_map_type,
+                            joint_map, link_map, joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links,
+                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, scratch, stream, "launch_rnea_backward_scratch");
 }

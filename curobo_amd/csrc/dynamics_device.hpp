@@ -359,6 +359,29 @@ struct RneaGlobalIO {
   __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out(a.grad_qdd, j) += x; }
 };
 
+// RneaTransposedIO: the inputs in [dof][batch] order in global memory (a scratch the launch fills with a coalesced
+// transposition): joint j of a wavefront's elements is one contiguous run -- coalesced without any LDS, which matters when the
+// walks share the CUs with a kernel that lives on LDS (the C4 rollout: the self-collision kernel next to the RNEA VJP).
+struct RneaTransposedIO {
+  const float *in0, *in1, *in2;  // forward: q, qd, qdd; backward: q, qd, grad_tau -- each [dof][batch]
+  size_t B;
+  uint32_t ob;  // element b as a byte offset
+  RneaGlobalIO out;
+  __device__ __forceinline__ float at(const float *t, int j) const {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t + (size_t)j * B) + ob);
+  }
+  __device__ __forceinline__ float q(int j) const { return at(in0, j); }
+  __device__ __forceinline__ float qd(int j) const { return at(in1, j); }
+  __device__ __forceinline__ float qdd(int j) const { return at(in2, j); }
+  __device__ __forceinline__ float grad_tau(int j) const { return at(in2, j); }
+  __device__ __forceinline__ void tau_zero(int D) const { out.tau_zero(D); }
+  __device__ __forceinline__ void tau_add(int j, float x) const { out.tau_add(j, x); }
+  __device__ __forceinline__ void grads_zero(int D) const { out.grads_zero(D); }
+  __device__ __forceinline__ void grad_q_add(int j, float x) const { out.grad_q_add(j, x); }
+  __device__ __forceinline__ void grad_qd_add(int j, float x) const { out.grad_qd_add(j, x); }
+  __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out.grad_qdd_add(j, x); }
+};
+
 constexpr int kRneaStageStride = 65;  // [joint][65]: lane e of joint j sits in bank (j + e) mod 32
 struct RneaStagedIO {
   // INPUTS from LDS (read-only during the walk): forward in0 = q, in1 = qd, in2 = qdd; backward in0 = q, in1 = qd,

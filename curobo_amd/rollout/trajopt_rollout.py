@@ -300,10 +300,14 @@ class TrajOptRollout:
                     z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
                     self._tau, self._rnea_cache, self._rnea_ws = z(n, D), z(n, L * 20), z(n, L * 18)
                     self._cs_gtau, self._rnea_g = z(B, H, D), [z(n, D) for _ in range(3)]
+                    # with the joint-space chain on the side stream the walks read their inputs from a transposed scratch
+                    # instead of staging them through LDS: the CU's LDS stays with the collision kernels they run next to
+                    self._rnea_scratch = z(3 * n * D) if (c.overlap_dynamics and self.position.is_cuda) else None
                 rargs = (k.fixed_transforms, k.link_masses_com, k.link_inertias, k.joint_map_type, k.joint_map, k.link_map,
                          k.joint_offset_map, self._gravity, k.link_level_offsets, k.link_level_data)
                 dynamics_hip.launch_rnea_forward(self._tau, self.position.view(n, D), self.velocity.view(n, D),
-                                                 self.acceleration.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1, None)
+                                                 self.acceleration.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1, None,
+                                                 scratch=self._rnea_scratch)
             cost_hip.cspace_state_cost(
                 self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, self._cs_gtau if tq else None, self.position,
                 self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._zeroD,
@@ -312,7 +316,7 @@ class TrajOptRollout:
             if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
                 dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
                                                   self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
-                                                  None, self._rnea_ws)
+                                                  None, self._rnea_ws, scratch=self._rnea_scratch)
                 self.cs_gp.view(n, D).add_(self._rnea_g[0])
                 self.cs_gv.view(n, D).add_(self._rnea_g[1])
                 self.cs_ga.view(n, D).add_(self._rnea_g[2])

@@ -329,6 +329,28 @@ int curobo_hip_launch_rnea_backward(
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch,
     float *grad_f_ext, float *workspace, curobo_hip_stream_t stream);
 
+/* Extensions: the same two launches with a caller-provided scratch of 3 * num_dof * batch_size floats.  The launch first
+ * transposes its joint-space inputs (q, qd, qdd | grad_tau) into it, [dof][batch], and the walks read them from there:
+ * coalesced without staging them through LDS (38 KB per workgroup for a 49-dof humanoid).  Same values as the launches
+ * above; meant for rollouts that run the walks NEXT TO a kernel that lives on LDS (C4: the self-collision kernel holds
+ * eight points per CU in 160 KB, and three while the staged walks share the CU). */
+int curobo_hip_launch_rnea_forward_scratch(
+    float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
+    const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type,
+    const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
+    const float *gravity, const int16_t *level_starts, const int16_t *level_links,
+    float *forward_cache, int batch_size, int num_links, int num_dof, int n_levels,
+    int threads_per_batch, const float *f_ext, float *scratch, curobo_hip_stream_t stream);
+
+int curobo_hip_launch_rnea_backward_scratch(
+    float *grad_q, float *grad_qd, float *grad_qdd, const float *grad_tau, const float *q,
+    const float *qd, const float *fixed_transforms, const float *link_masses_com,
+    const float *link_inertias, const int8_t *joint_map_type, const int16_t *joint_map,
+    const int16_t *link_map, const float *joint_offset_map, const float *gravity,
+    const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
+    int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch,
+    float *grad_f_ext, float *workspace, float *scratch, curobo_hip_stream_t stream);
+
 /* ---------------------------------------------------------------- linalg: Levenberg-Marquardt step
  * reference: optim/util/levenberg_marquardt_step.py:96-199 (Warp tile kernel, no backend hook).
  * Per problem: delta = -(J^T J + lambda I)^-1 jTerror; joint_position_out = joint_position_in +

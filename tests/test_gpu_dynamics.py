@@ -162,3 +162,34 @@ def test_c4_shape_humanoid_self_collision_plus_inverse_dynamics_cost(B, H, oracl
     np.testing.assert_allclose(cost.cpu().numpy(), ref_cost, rtol=2e-4, atol=1e-4 * np.abs(ref_cost).max())
     for got, ref in (((g1 + g2[0] + gp.view(n, D)), ref_gq), ((g2[1] + gv.view(n, D)), ref_gqd), ((g2[2] + ga.view(n, D)), ref_gqdd)):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("robot,n", [("franka", 1000), ("unitree_g1", 300)])
+def test_rnea_scratch_launches_equal_the_staged_ones(robot, n, oracle, device):
+    """``curobo_hip_launch_rnea_forward_scratch`` / ``_backward_scratch`` (inputs transposed into a caller's scratch, no LDS staging):
+    torques, cache and gradients bit-identical to the staged launches -- same walk, same arithmetic -- and equal to the oracle"""
+    from curobo_amd.backends import dynamics as Dy
+
+    model, kin, q, qd, qdd, rng = _setup(robot, device, n, 5)
+    L, D = kin.num_links, kin.num_dof
+    grav = np.array([0, 0, 0, 0, 0, 9.81], np.float32)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    args = (kin.fixed_transforms, kin.link_masses_com, kin.link_inertias, kin.joint_map_type, kin.joint_map, kin.link_map,
+            kin.joint_offset_map, t(grav), kin.link_level_offsets, kin.link_level_data)
+    w = rng.normal(size=(n, D)).astype(np.float32)
+    out = []
+    for scratch in (None, torch.full((3 * n * D,), float("nan"), device=device)):
+        tau, cache = torch.zeros(n, D, device=device), torch.zeros(n, L * 20, device=device)
+        Dy.launch_rnea_forward(tau, t(q), t(qd), t(qdd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch)
+        g = [torch.full((n, D), 7.0, device=device) for _ in range(3)]
+        Dy.launch_rnea_backward(*g, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch)
+        torch.cuda.synchronize()
+        out.append((tau, cache, g))
+    (tau0, cache0, g0), (tau1, cache1, g1) = out
+    assert torch.equal(tau0, tau1) and torch.equal(cache0, cache1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    tau_ref, _ = oracle.rnea_forward(q, qd, qdd, model.as_dict(), gravity=grav)
+    np.testing.assert_allclose(tau1.cpu().numpy(), tau_ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(tau_ref).max()))
+    with pytest.raises(ValueError, match="scratch must hold"):
+        Dy.launch_rnea_forward(tau, t(q), t(qd), t(qdd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=torch.zeros(8, device=device))
