@@ -1161,7 +1161,7 @@ def c4_benchmark(device, torch):
     res["kernels"] = _timed_stages(stages, torch, reps=2)
     res["kernels_note"] = ("every kernel timed ALONE (plain launches); in the rollout set the joint-space chain (RNEA -> c-space -> RNEA VJP) "
                            "runs on a side stream next to the task-space chain, and its RNEA launches read their inputs from a transposed "
-                           "scratch instead of LDS (curobo_hip_launch_rnea_*_scratch: 180 / 350 us alone, but the self-collision kernel "
+                           "scratch instead of LDS (curobo_hip_launch_rnea_*_scratch: 177 / 325 us alone, but the self-collision kernel "
                            "keeps its eight points per CU next to them)")
     k = res["kernels"]["self_collision_tiled"]
     cr = counter_roofline("self_collision_tiles", 0, k["us"], units=N)

@@ -337,6 +337,7 @@ struct QuadAlg {
 // uncoalesced global access at all (dynamics.hip; measured on the Unitree G1 at the C4 size: those gathers were 60 % of the
 // L2 traffic of both kernels).
 struct RneaGlobalIO {
+  static constexpr bool kPrefetch = true;  // inputs from global memory: requested one link ahead (link_inputs)
   const RneaArgs &a;
   uint32_t o;  // byte offset of row b: b * D * 4 (the launchers check batch * dof < 2^30); the joint index is the same for
                // the whole wavefront, so an access is (scalar tensor base + joint) + this one 32-bit lane offset
@@ -359,10 +360,17 @@ struct RneaGlobalIO {
   __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out(a.grad_qdd, j) += x; }
 };
 
+// the same accessors where the "tensors" are LDS regions (the fused rollout kernel): no read-ahead
+struct RneaLdsIO : RneaGlobalIO {
+  static constexpr bool kPrefetch = false;
+  __device__ __forceinline__ RneaLdsIO(const RneaArgs &a_, size_t b) : RneaGlobalIO(a_, b) {}
+};
+
 // RneaTransposedIO: the inputs in [dof][batch] order in global memory (a scratch the launch fills with a coalesced
 // transposition): joint j of a wavefront's elements is one contiguous run -- coalesced without any LDS, which matters when the
 // walks share the CUs with a kernel that lives on LDS (the C4 rollout: the self-collision kernel next to the RNEA VJP).
 struct RneaTransposedIO {
+  static constexpr bool kPrefetch = true;
   const float *in0, *in1, *in2;  // forward: q, qd, qdd; backward: q, qd, grad_tau -- each [dof][batch]
   size_t B;
   uint32_t ob;  // element b as a byte offset
@@ -384,6 +392,7 @@ struct RneaTransposedIO {
 
 constexpr int kRneaStageStride = 65;  // [joint][65]: lane e of joint j sits in bank (j + e) mod 32
 struct RneaStagedIO {
+  static constexpr bool kPrefetch = false;  // LDS: read where they are used (carrying them a link ahead costs more than it hides)
   // INPUTS from LDS (read-only during the walk): forward in0 = q, in1 = qd, in2 = qdd; backward in0 = q, in1 = qd,
   // in2 = grad_tau.  OUTPUTS go to the caller's tensors as in RneaGlobalIO: their read-modify-writes are off the walk's
   // dependent chain, and LDS stores in the walk would alias the link constants (both LDS: the compiler then re-reads the
@@ -402,6 +411,26 @@ struct RneaStagedIO {
   __device__ __forceinline__ void grad_qd_add(int j, float x) const { out.grad_qd_add(j, x); }
   __device__ __forceinline__ void grad_qdd_add(int j, float x) const { out.grad_qdd_add(j, x); }
 };
+
+// The joint-space inputs of the link at position idx of the walk, requested one link AHEAD of their use: they do not depend on
+// the walk, and where they come from global memory (RneaTransposedIO / RneaGlobalIO) their round trip then leaves the walk's
+// dependent chain.  x0, x1, x2 = the IO's three input vectors at the link's joint (0 for a link without a moving joint).
+struct LinkInputs {
+  float x0, x1, x2;
+};
+template <bool W0, bool W1, int W2, class IO>  // W2: 0 none, 1 = qdd, 2 = grad_tau (the backward IO's third vector)
+__device__ __forceinline__ LinkInputs link_inputs(const IO &io, const int *s_i, const int *order, int idx) {
+  const int k = order_link(order_entry(order, idx));
+  const int jt = __builtin_amdgcn_readfirstlane(s_i[k * 3]), ji = __builtin_amdgcn_readfirstlane(s_i[k * 3 + 1]);
+  LinkInputs in{0.0f, 0.0f, 0.0f};
+  if (jt != J_FIXED && ji >= 0) {
+    if (W0) in.x0 = io.q(ji);
+    if (W1) in.x1 = io.qd(ji);
+    if (W2 == 1) in.x2 = io.qdd(ji);
+    if (W2 == 2) in.x2 = io.grad_tau(ji);
+  }
+  return in;
+}
 
 // One element b of a batch of B (SoA slots with element stride B): the forward sweeps.  `order` = links in level order.
 // IO = where the joint-space vectors live, V = the spatial algebra (LaneAlg: the element on one lane; QuadAlg: on a quad).
@@ -427,16 +456,20 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
   // backends pass a depth-first one).
   int prev_k = -1;
   SvT prev_v = alg.zero(), prev_a = alg.zero();
+  LinkInputs nxt{0.0f, 0.0f, 0.0f};
+  if (IO::kPrefetch) nxt = link_inputs<true, true, 1>(io, s_i, order, 0);
   for (int idx = 0; idx < L; idx++) {
     const int oe = order_entry(order, idx);
     const int k = order_link(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    const LinkInputs in = IO::kPrefetch ? nxt : link_inputs<true, true, 1>(io, s_i, order, idx);
+    if (IO::kPrefetch && idx + 1 < L) nxt = link_inputs<true, true, 1>(io, s_i, order, idx + 1);
     float qe = 0.f, qde = 0.f, qdde = 0.f;
     if (moving) {
-      qe = c.mul * io.q(c.ji) + c.off;
-      qde = c.mul * io.qd(c.ji);
-      qdde = c.mul * io.qdd(c.ji);
+      qe = c.mul * in.x0 + c.off;
+      qde = c.mul * in.x1;
+      qdde = c.mul * in.x2;
     }
     const typename V::Xf t = alg.xform(c.F, c.jt, qe);
     SvT v = alg.zero(), acc;
@@ -465,10 +498,13 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
   // reversed depth-first order it usually is -- instead of a store the parent's load would have to wait for)
   int pend_par = -1;
   SvT pend = alg.zero();
+  if (IO::kPrefetch) nxt = link_inputs<true, false, 0>(io, s_i, order, L - 1);
   for (int idx = L - 1; idx >= 0; idx--) {
     const int oe = order_entry(order, idx);
     const int k = order_link(oe);
     const LinkConst c = link_const(s_f, s_i, k);
+    const LinkInputs in = IO::kPrefetch ? nxt : link_inputs<true, false, 0>(io, s_i, order, idx);
+    if (IO::kPrefetch && idx > 0) nxt = link_inputs<true, false, 0>(io, s_i, order, idx - 1);
     const SvT v = alg.load(a.cache, B, k * 20, b), acc = alg.load(a.cache, B, k * 20 + 6, b);
     SvT f = alg.inertia(c.mc, c.in, acc) + alg.cross_f(v, alg.inertia(c.mc, c.in, v));
     if (HAS_FEXT) f = f - alg.load6(a.f_ext + (b * L + k) * 6);
@@ -483,7 +519,7 @@ __device__ __forceinline__ void rnea_forward_element_io(const RneaArgs &a, const
       if (alg.writer()) io.tau_add(c.ji, tj);
     }
     if (!(c.par < 0 || c.par == k)) {
-      const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
+      const float qe = moving ? c.mul * in.x0 + c.off : 0.0f;
       const SvT up = alg.force_T(alg.xform(c.F, c.jt, qe), f);
       if (idx > 0 && order_link(order_entry(order, idx - 1)) == c.par) { pend = up; pend_par = c.par; }
       else alg.store(a.cache, B, c.par * 20 + 12, b, alg.load(a.cache, B, c.par * 20 + 12, b) + up);
@@ -510,17 +546,21 @@ __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, cons
   // pass 1, root -> leaves: adjoint of the force propagation (rnea_backward_kernel.cuh:151-208)
   int prev_k = -1;
   SvT prev_fb = alg.zero();
+  LinkInputs nxt{0.0f, 0.0f, 0.0f};
+  if (IO::kPrefetch) nxt = link_inputs<true, false, 2>(io, s_i, order, 0);
   for (int idx = 0; idx < L; idx++) {
     const int oe = order_entry(order, idx);
     const int k = order_link(oe);
     const bool slot = order_needs_slot(oe);
     const LinkConst c = link_const(s_f, s_i, k);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
+    const LinkInputs in = IO::kPrefetch ? nxt : link_inputs<true, false, 2>(io, s_i, order, idx);
+    if (IO::kPrefetch && idx + 1 < L) nxt = link_inputs<true, false, 2>(io, s_i, order, idx + 1);
     SvT fb = alg.zero();
     const int si = moving ? s_index(c.jt) : 0;
-    if (moving) alg.add_at(fb, si, c.mul * io.grad_tau(c.ji));
+    if (moving) alg.add_at(fb, si, c.mul * in.x2);
     if (!is_root) {
-      const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
+      const float qe = moving ? c.mul * in.x0 + c.off : 0.0f;
       const SvT X = alg.motion(alg.xform(c.F, c.jt, qe), c.par == prev_k ? prev_fb : alg.load(a.ws_fbar, B, c.par * 6, b));
       fb = fb + X;
       if (moving) {
@@ -539,11 +579,14 @@ __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, cons
   // pass 2, leaves -> root: adjoint of the velocity / acceleration propagation (:236-465)
   int pend_par = -1;
   SvT pend_a = alg.zero(), pend_v = alg.zero();
+  if (IO::kPrefetch) nxt = link_inputs<true, true, 0>(io, s_i, order, L - 1);
   for (int idx = L - 1; idx >= 0; idx--) {
     const int oe = order_entry(order, idx);
     const int k = order_link(oe);
     const bool slot = order_needs_slot(oe);
     const LinkConst c = link_const(s_f, s_i, k);
+    const LinkInputs in = IO::kPrefetch ? nxt : link_inputs<true, true, 0>(io, s_i, order, idx);
+    if (IO::kPrefetch && idx > 0) nxt = link_inputs<true, true, 0>(io, s_i, order, idx - 1);
     const bool is_root = c.par < 0 || c.par == k, moving = c.jt != J_FIXED && c.ji >= 0;
     const bool par_next = !is_root && idx > 0 && order_link(order_entry(order, idx - 1)) == c.par;  // this link's pushes stay in registers
     const SvT v = alg.load(a.cache, B, k * 20, b);
@@ -560,13 +603,13 @@ __device__ __forceinline__ void rnea_backward_element_io(const RneaArgs &a, cons
     const int si = moving ? s_index(c.jt) : 0;
     float gq = 0.0f, gqd = 0.0f;
     if (moving) {
-      const float qdk = c.mul * io.qd(c.ji);
+      const float qdk = c.mul * in.x1;
       const float gdd = c.mul * alg.get(ab, si);
       if (alg.writer()) io.grad_qdd_add(c.ji, gdd);
       gqd -= c.mul * alg.get(alg.cross_f(v, ab), si);
       vb = vb + alg.cross_f(alg.unit(si, qdk), ab);
     }
-    const float qe = moving ? c.mul * io.q(c.ji) + c.off : 0.0f;
+    const float qe = moving ? c.mul * in.x0 + c.off : 0.0f;
     const typename V::Xf t = alg.xform(c.F, c.jt, qe);
     const SvT S1 = alg.unit(si, 1.0f);
     if (!is_root) {

@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       tq_q[2 * H * D + e] = c.dyn[H * D + e];
     }
     stage_links(rn, tq_f, tq_i);  // (ends with a workgroup barrier)
-    if (tid < H) rnea_forward_element<false>(rn, tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
+    if (tid < H) rnea_forward_element_io<false>(rn, RneaLdsIO(rn, (size_t)tid), tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
     __syncthreads();
   }
   CUROBO_STAMP(15);
@@ -1389,7 +1389,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   if (use_torque) {  // VJP of the inverse dynamics: d cost / d tau -> added to the joint-space gradient streams
     rn.grad_q = c.q; rn.grad_qd = c.dyn; rn.grad_qdd = c.dyn + H * D; rn.grad_tau = tq_gtau;
     rn.ws_fbar = c.cumul; rn.ws_abar = c.cumul + (size_t)L * 6 * H; rn.ws_vbar = c.wrench;
-    if (tid < H) rnea_backward_element<false, true>(rn, tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
+    if (tid < H) rnea_backward_element_io<false, true>(rn, RneaLdsIO(rn, (size_t)tid), tq_f, tq_i, tq_i + L * 3, (size_t)tid, (size_t)H);
     __syncthreads();
   }
   CUROBO_STAMP(3);
