@@ -112,11 +112,13 @@ __global__ void __launch_bounds__(256) rnea_backward_staged_kernel(const RneaArg
 }
 
 // ---- the walks over inputs transposed into a scratch (RneaTransposedIO): link constants are the only LDS
-__global__ void __launch_bounds__(256) rnea_transpose_kernel(const float *in0, const float *in1, const float *in2, float *out, int B, int D) {
-  // [B][D] -> [D][B] for three tensors (blockIdx.z), 32 x 32 tiles through LDS: coalesced on both sides
+__global__ void __launch_bounds__(256) rnea_transpose_kernel(const float *in0, const float *in1, const float *in2, float *out, int B, int D,
+                                                             int first) {
+  // [B][D] -> [D][B] for the tensors first .. 2 (blockIdx.z), 32 x 32 tiles through LDS: coalesced on both sides
   __shared__ float tile[32][33];
-  const float *in = blockIdx.z == 0 ? in0 : blockIdx.z == 1 ? in1 : in2;
-  float *o = out + (size_t)blockIdx.z * D * B;
+  const int which = first + (int)blockIdx.z;
+  const float *in = which == 0 ? in0 : which == 1 ? in1 : in2;
+  float *o = out + (size_t)which * D * B;
   const int b0 = blockIdx.x * 32, j0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
   for (int r = ty; r < 32; r += 8) {
     const int b = b0 + r, j = j0 + tx;
@@ -157,9 +159,10 @@ using namespace curobo_hip;
 // the scratch form of a launch: transposition, then the walk
 template <bool BACKWARD>
 static int launch_rnea_scratch(const RneaArgs &a, const float *in0, const float *in1, const float *in2, float *scratch, bool fext,
-                               hipStream_t st, const char *what) {
+                               hipStream_t st, const char *what, int first = 0) {
   const int B = a.batch, D = a.num_dof;
-  hipLaunchKernelGGL(rnea_transpose_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32), 3), dim3(256), 0, st, in0, in1, in2, scratch, B, D);
+  hipLaunchKernelGGL(rnea_transpose_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)(3 - first)), dim3(256), 0, st, in0,
+                     in1, in2, scratch, B, D, first);
   static const bool quad = [] { const char *e = getenv("CUROBO_RNEA_QUAD"); return e ? atoi(e) != 0 : true; }();
   const dim3 grid((unsigned)((B + kStagedLanes - 1) / kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
   const size_t lds = (size_t)a.num_links * (kLinkFloats + 4) * sizeof(float);
@@ -279,7 +282,7 @@ static int rnea_backward_impl(
     const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
     const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
-    float *workspace, float *scratch, curobo_hip_stream_t stream, const char *what) {
+    float *workspace, float *scratch, int scratch_holds_q_qd, curobo_hip_stream_t stream, const char *what) {
   (void)level_starts; (void)n_levels; (void)threads_per_batch;
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
@@ -298,7 +301,7 @@ static int rnea_backward_impl(
   a.ws_vbar = workspace + (size_t)num_links * 12 * batch_size;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
-  if (scratch != nullptr) return launch_rnea_scratch<true>(a, q, qd, grad_tau, scratch, grad_f_ext != nullptr, st, what);
+  if (scratch != nullptr) return launch_rnea_scratch<true>(a, q, qd, grad_tau, scratch, grad_f_ext != nullptr, st, what, scratch_holds_q_qd ? 2 : 0);
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
   if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
     const bool quad = rnea_quad();
@@ -329,7 +332,7 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward(
     float *workspace, curobo_hip_stream_t stream) {
   return rnea_backward_impl(grad_q, grad_qd, grad_qdd, grad_tau, q, qd, fixed_transforms, link_masses_com, link_inertias, joint_map_type,
                             joint_map, link_map, joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links,
-                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, nullptr, stream, "launch_rnea_backward");
+                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, nullptr, 0, stream, "launch_rnea_backward");
 }
 
 CUROBO_EXPORT int curobo_hip_launch_rnea_backward_scratch(
@@ -338,9 +341,10 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward_scratch(
     const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
     const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
-    float *workspace, float *scratch, curobo_hip_stream_t stream) {
+    float *workspace, float *scratch, int scratch_holds_q_qd, curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(scratch != nullptr || batch_size == 0, "launch_rnea_backward_scratch: scratch [3 * num_dof * batch_size] floats is required");
   return rnea_backward_impl(grad_q, grad_qd, grad_qdd, grad_tau, q, qd, fixed_transforms, link_masses_com, link_inertias, joint_map_type,
                             joint_map, link_map, joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links,
-                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, scratch, stream, "launch_rnea_backward_scratch");
+                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, scratch, scratch_holds_q_qd, stream,
+                            "launch_rnea_backward_scratch");
 }

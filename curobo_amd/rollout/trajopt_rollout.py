@@ -317,7 +317,8 @@ class TrajOptRollout:
             if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
                 dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
                                                   self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
-                                                  None, self._rnea_ws, scratch=self._rnea_scratch)
+                                                  None, self._rnea_ws, scratch=self._rnea_scratch,
+                                                  scratch_holds_q_qd=self._rnea_scratch is not None)
                 self.cs_gp.view(n, D).add_(self._rnea_g[0])
                 self.cs_gv.view(n, D).add_(self._rnea_g[1])
                 self.cs_ga.view(n, D).add_(self._rnea_g[2])

@@ -187,6 +187,14 @@ def test_rnea_scratch_launches_equal_the_staged_ones(robot, n, oracle, device):
         Dy.launch_rnea_backward(*g, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch)
         torch.cuda.synchronize()
         out.append((tau, cache, g))
+        if scratch is not None:  # q and qd of the forward launch are still in the scratch: only grad_tau is transposed again
+            g2 = [torch.full((n, D), 7.0, device=device) for _ in range(3)]
+            Dy.launch_rnea_forward(tau, t(q), t(qd), t(qdd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch)
+            Dy.launch_rnea_backward(*g2, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch,
+                                    scratch_holds_q_qd=True)
+            torch.cuda.synchronize()
+            for a, b in zip(g, g2):
+                assert torch.equal(a, b)
     (tau0, cache0, g0), (tau1, cache1, g1) = out
     if os.environ.get("CUROBO_RNEA_STAGED", "1") != "0" and os.environ.get("CUROBO_RNEA_QUAD", "1") != "0":  # (both on quads: bit for bit)
         assert torch.equal(tau0, tau1) and torch.equal(cache0, cache1)
