@@ -143,13 +143,17 @@ def launch_rnea_backward(
     workspace: Optional[torch.Tensor] = None,
     scratch: Optional[torch.Tensor] = None,
     scratch_holds_q_qd: bool = False,
+    accumulate: bool = False,
 ):
     """Gradient buffers are fully rewritten (no ``zero_()`` needed), as in the reference.  ``scratch``: see ``launch_rnea_forward``;
-    ``scratch_holds_q_qd``: it still holds q and qd of the forward launch on the same inputs (only grad_tau is transposed)."""
+    ``scratch_holds_q_qd``: it still holds q and qd of the forward launch on the same inputs (only grad_tau is transposed);
+    ``accumulate`` (scratch launches only): add to the gradient buffers instead of rewriting them."""
     need = batch_size * num_links * 18
     ws = workspace if workspace is not None else _workspace(grad_q.device, need)
     if ws.numel() < need:
         raise ValueError("workspace must hold batch_size * num_links * 18 floats")
+    if accumulate and scratch is None:
+        raise ValueError("accumulate needs the scratch form of the launch")
     if scratch is not None:
         if scratch.numel() < 3 * num_dof * batch_size:
             raise ValueError("scratch must hold 3 * num_dof * batch_size floats")
@@ -157,7 +161,7 @@ def launch_rnea_backward(
             ptr(grad_q), ptr(grad_qd), ptr(grad_qdd), ptr(grad_tau), ptr(q), ptr(qd), ptr(fixed_transforms),
             ptr(link_masses_com), ptr(link_inertias), ptr(joint_map_type), ptr(joint_map), ptr(link_map),
             ptr(joint_offset_map), ptr(gravity), ptr(level_starts), ptr(_walk_order(link_map, level_links)), ptr(forward_cache), batch_size,
-            num_links, num_dof, n_levels, threads_per_batch, ptr(grad_f_ext), ptr(ws), ptr(scratch), int(bool(scratch_holds_q_qd)),
+            num_links, num_dof, n_levels, threads_per_batch, ptr(grad_f_ext), ptr(ws), ptr(scratch), int(bool(scratch_holds_q_qd)) | (2 if accumulate else 0),
             current_stream(grad_q),
         ))
         return

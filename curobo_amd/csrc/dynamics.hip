@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) rnea_transpose_kernel(const float *in0, c
   }
 }
 
-template <bool HAS_FEXT, bool QUAD, bool BACKWARD>
+template <bool HAS_FEXT, bool QUAD, bool BACKWARD, bool ACC = false>
 __global__ void __launch_bounds__(256) rnea_scratch_kernel(const RneaArgs a, const float *scratch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = a.num_links, D = a.num_dof;
@@ -144,10 +144,10 @@ __global__ void __launch_bounds__(256) rnea_scratch_kernel(const RneaArgs a, con
   const RneaTransposedIO io{scratch, scratch + (size_t)D * B, scratch + 2 * (size_t)D * B, B, (uint32_t)b * 4u, RneaGlobalIO(a, b)};
   if (QUAD) {
     const int c = (int)threadIdx.x & 3;
-    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b, B, QuadAlg{c < 3 ? c : 2});
+    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, ACC>(a, io, s_f, s_i, s_i + L * 3, b, B, QuadAlg{c < 3 ? c : 2});
     else rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b, B, QuadAlg{c < 3 ? c : 2});
   } else {
-    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, false>(a, io, s_f, s_i, s_i + L * 3, b, B);
+    if (BACKWARD) rnea_backward_element_io<HAS_FEXT, ACC>(a, io, s_f, s_i, s_i + L * 3, b, B);
     else rnea_forward_element_io<HAS_FEXT>(a, io, s_f, s_i, s_i + L * 3, b, B);
   }
 }
@@ -159,13 +159,20 @@ using namespace curobo_hip;
 // the scratch form of a launch: transposition, then the walk
 template <bool BACKWARD>
 static int launch_rnea_scratch(const RneaArgs &a, const float *in0, const float *in1, const float *in2, float *scratch, bool fext,
-                               hipStream_t st, const char *what, int first = 0) {
+                               hipStream_t st, const char *what, int first = 0, bool accumulate = false) {
   const int B = a.batch, D = a.num_dof;
   hipLaunchKernelGGL(rnea_transpose_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)(3 - first)), dim3(256), 0, st, in0,
                      in1, in2, scratch, B, D, first);
   static const bool quad = [] { const char *e = getenv("CUROBO_RNEA_QUAD"); return e ? atoi(e) != 0 : true; }();
   const dim3 grid((unsigned)((B + kStagedLanes - 1) / kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
   const size_t lds = (size_t)a.num_links * (kLinkFloats + 4) * sizeof(float);
+  if (BACKWARD && accumulate) {  // gradients ADDED to the output tensors (the caller's running joint-space gradients)
+    if (fext) { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<true, true, BACKWARD, true>), grid, block, lds, st, a, scratch);
+                else hipLaunchKernelGGL((rnea_scratch_kernel<true, false, BACKWARD, true>), grid, block, lds, st, a, scratch); }
+    else { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<false, true, BACKWARD, true>), grid, block, lds, st, a, scratch);
+           else hipLaunchKernelGGL((rnea_scratch_kernel<false, false, BACKWARD, true>), grid, block, lds, st, a, scratch); }
+    return check_launch(what, st);
+  }
   if (fext) { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<true, true, BACKWARD>), grid, block, lds, st, a, scratch);
               else hipLaunchKernelGGL((rnea_scratch_kernel<true, false, BACKWARD>), grid, block, lds, st, a, scratch); }
   else { if (quad) hipLaunchKernelGGL((rnea_scratch_kernel<false, true, BACKWARD>), grid, block, lds, st, a, scratch);
@@ -282,7 +289,7 @@ static int rnea_backward_impl(
     const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
     const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
-    float *workspace, float *scratch, int scratch_holds_q_qd, curobo_hip_stream_t stream, const char *what) {
+    float *workspace, float *scratch, int flags, curobo_hip_stream_t stream, const char *what) {
   (void)level_starts; (void)n_levels; (void)threads_per_batch;
   CUROBO_REQUIRE(num_links >= 1 && num_dof >= 1, "%s: bad dimensions", what);
   CUROBO_REQUIRE(rnea_lds(num_links) <= 64 * 1024, "%s: too many links (%d)", what, num_links);
@@ -301,7 +308,7 @@ static int rnea_backward_impl(
   a.ws_vbar = workspace + (size_t)num_links * 12 * batch_size;
   a.batch = batch_size; a.num_links = num_links; a.num_dof = num_dof;
   hipStream_t st = (hipStream_t)stream;
-  if (scratch != nullptr) return launch_rnea_scratch<true>(a, q, qd, grad_tau, scratch, grad_f_ext != nullptr, st, what, scratch_holds_q_qd ? 2 : 0);
+  if (scratch != nullptr) return launch_rnea_scratch<true>(a, q, qd, grad_tau, scratch, grad_f_ext != nullptr, st, what, (flags & 1) ? 2 : 0, (flags & 2) != 0);
   const size_t slds = rnea_staged_lds(num_links, num_dof, 3);
   if (slds <= kRneaStagedLdsLimit && rnea_staged()) {
     const bool quad = rnea_quad();
@@ -341,10 +348,10 @@ CUROBO_EXPORT int curobo_hip_launch_rnea_backward_scratch(
     const int8_t *joint_map_type, const int16_t *joint_map, const int16_t *link_map, const float *joint_offset_map,
     const float *gravity, const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch, float *grad_f_ext,
-    float *workspace, float *scratch, int scratch_holds_q_qd, curobo_hip_stream_t stream) {
+    float *workspace, float *scratch, int flags, curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(scratch != nullptr || batch_size == 0, "launch_rnea_backward_scratch: scratch [3 * num_dof * batch_size] floats is required");
   return rnea_backward_impl(grad_q, grad_qd, grad_qdd, grad_tau, q, qd, fixed_transforms, link_masses_com, link_inertias, joint_map_type,
                             joint_map, link_map, joint_offset_map, gravity, level_starts, level_links, forward_cache, batch_size, num_links,
-                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, scratch, scratch_holds_q_qd, stream,
+                            num_dof, n_levels, threads_per_batch, grad_f_ext, workspace, scratch, flags, stream,
                             "launch_rnea_backward_scratch");
 }

@@ -315,13 +315,18 @@ class TrajOptRollout:
                 self._idx0, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
                 self._zero1, self._zero1, self._onesD, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
             if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
-                dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
-                                                  self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
-                                                  None, self._rnea_ws, scratch=self._rnea_scratch,
-                                                  scratch_holds_q_qd=self._rnea_scratch is not None)
-                self.cs_gp.view(n, D).add_(self._rnea_g[0])
-                self.cs_gv.view(n, D).add_(self._rnea_g[1])
-                self.cs_ga.view(n, D).add_(self._rnea_g[2])
+                if self._rnea_scratch is not None:  # straight into the c-space gradients (no separate buffers, no adds)
+                    dynamics_hip.launch_rnea_backward(self.cs_gp.view(n, D), self.cs_gv.view(n, D), self.cs_ga.view(n, D),
+                                                      self._cs_gtau.view(n, D), self.position.view(n, D), self.velocity.view(n, D), *rargs,
+                                                      self._rnea_cache, n, L, D, k.n_tree_levels, 1, None, self._rnea_ws,
+                                                      scratch=self._rnea_scratch, scratch_holds_q_qd=True, accumulate=True)
+                else:
+                    dynamics_hip.launch_rnea_backward(*self._rnea_g, self._cs_gtau.view(n, D), self.position.view(n, D),
+                                                      self.velocity.view(n, D), *rargs, self._rnea_cache, n, L, D, k.n_tree_levels, 1,
+                                                      None, self._rnea_ws)
+                    self.cs_gp.view(n, D).add_(self._rnea_g[0])
+                    self.cs_gv.view(n, D).add_(self._rnea_g[1])
+                    self.cs_ga.view(n, D).add_(self._rnea_g[2])
         # (the task-space chain is enqueued AFTER the joint-space chain: the few, long-running workgroups of the tree walks
         # take their slots on an empty chip; started behind the collision kernels they wait for LDS that those keep taking)
         kinematics_hip.launch_kinematics_forward_spheres(

@@ -333,8 +333,9 @@ int curobo_hip_launch_rnea_backward(
  * transposes its joint-space inputs (q, qd, qdd | grad_tau) into it, [dof][batch], and the walks read them from there:
  * coalesced without staging them through LDS (38 KB per workgroup for a 49-dof humanoid).  Same values as the launches
  * above; meant for rollouts that run the walks NEXT TO a kernel that lives on LDS (C4: the self-collision kernel holds
- * eight points per CU in 160 KB, and three while the staged walks share the CU).  scratch_holds_q_qd != 0: the scratch still
- * holds q and qd of a forward launch on the same inputs (its first two thirds): only grad_tau is transposed. */
+ * eight points per CU in 160 KB, and three while the staged walks share the CU).  flags bit 0: the scratch still holds q and qd of a
+ * forward launch on the same inputs (its first two thirds): only grad_tau is transposed; bit 1: the gradients are ADDED to
+ * grad_q / grad_qd / grad_qdd (the caller's running joint-space gradients) instead of overwriting them. */
 int curobo_hip_launch_rnea_forward_scratch(
     float *tau, const float *q, const float *qd, const float *qdd, const float *fixed_transforms,
     const float *link_masses_com, const float *link_inertias, const int8_t *joint_map_type,
@@ -350,7 +351,7 @@ int curobo_hip_launch_rnea_backward_scratch(
     const int16_t *link_map, const float *joint_offset_map, const float *gravity,
     const int16_t *level_starts, const int16_t *level_links, const float *forward_cache,
     int batch_size, int num_links, int num_dof, int n_levels, int threads_per_batch,
-    float *grad_f_ext, float *workspace, float *scratch, int scratch_holds_q_qd, curobo_hip_stream_t stream);
+    float *grad_f_ext, float *workspace, float *scratch, int flags, curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- linalg: Levenberg-Marquardt step
  * reference: optim/util/levenberg_marquardt_step.py:96-199 (Warp tile kernel, no backend hook).

@@ -195,6 +195,15 @@ def test_rnea_scratch_launches_equal_the_staged_ones(robot, n, oracle, device):
             torch.cuda.synchronize()
             for a, b in zip(g, g2):
                 assert torch.equal(a, b)
+            # accumulate: added to what the buffers hold
+            g3 = [torch.full((n, D), 0.5, device=device) for _ in range(3)]
+            Dy.launch_rnea_backward(*g3, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, scratch=scratch,
+                                    scratch_holds_q_qd=True, accumulate=True)
+            torch.cuda.synchronize()
+            for a, b in zip(g, g3):
+                torch.testing.assert_close(b, a + 0.5, rtol=1e-6, atol=1e-6 * float(a.abs().max()))
+            with pytest.raises(ValueError, match="accumulate needs"):
+                Dy.launch_rnea_backward(*g3, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, accumulate=True)
     (tau0, cache0, g0), (tau1, cache1, g1) = out
     if os.environ.get("CUROBO_RNEA_STAGED", "1") != "0" and os.environ.get("CUROBO_RNEA_QUAD", "1") != "0":  # (both on quads: bit for bit)
         assert torch.equal(tau0, tau1) and torch.equal(cache0, cache1)

@@ -354,3 +354,31 @@ def test_trajopt_solver_with_torque_limits(oracle, device):
     tau = np.abs(tau.reshape(P, H, D))[ok]
     assert (tau <= 0.6 * eff * 1.002 + 2e-3).all(), (tau / (0.6 * eff)).max((0, 1))
     np.testing.assert_allclose(s["position"][ok], r1.position.cpu().numpy()[ok], atol=1e-4)
+
+
+def test_humanoid_rollout_side_stream_scratch_walks_equal_the_single_stream_sequence(device):
+    """C4 shape in small: Unitree G1 with torque limits on the kernel sequence.  ``overlap_dynamics`` runs the joint-space chain on a
+    side stream with the RNEA launches in their scratch form (inputs transposed, VJP accumulated straight into the c-space gradients);
+    one stream runs the staged launches and adds their gradients afterwards: same cost, same gradient (summation order only)"""
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("unitree_g1", device=device)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    B = 24
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=6, spread=0.15), device=device).reshape(B, -1)
+    out = []
+    for overlap in (False, True):
+        ro = TrajOptRollout(kin, None, B, TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=[40.0] * kin.num_dof,
+                                                            overlap_dynamics=overlap))
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+        ro.cost_and_gradient(x)  # (first call allocates on the calling stream)
+        c, g = ro.cost_and_gradient(x)
+        torch.cuda.synchronize()
+        assert (ro._rnea_scratch is not None) == overlap
+        out.append((c.clone(), g.clone(), float(ro._tau.abs().max())))
+    (c0, g0, t0), (c1, g1, t1) = out
+    assert t0 > 40.0, "the effort limit is active"
+    torch.testing.assert_close(c1, c0, rtol=1e-5, atol=1e-5 * float(c0.abs().max()))
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5 * float(g0.abs().max()))
