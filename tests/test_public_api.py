@@ -32,7 +32,13 @@ def test_reference_public_names_resolve():
     from curobo.kinematics import Kinematics, KinematicsCfg, KinematicsState  # noqa: F401
     from curobo.optim import MPPI, LBFGSOpt, LBFGSOptCfg, MPPICfg, MultiStageOptimizer  # noqa: F401
     from curobo.rollout import RosenbrockCfg, RosenbrockRollout  # noqa: F401
-    from curobo.types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPose  # noqa: F401
+    from curobo.types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPose, ToolPoseCriteria  # noqa: F401
+    from curobo.scene import Capsule, Cuboid, Cylinder, Mesh, Obstacle, Scene, SceneData, Sphere, VoxelGrid  # noqa: F401  (reference: curobo/scene.py)
+    from curobo.motion_planner import GraspPlanResult, MotionPlanner, MotionPlannerCfg  # noqa: F401
+    from curobo.batch_motion_planner import BatchMotionPlanner  # noqa: F401
+    from curobo.trajectory_optimizer import TrajectoryOptimizer, TrajectoryOptimizerCfg  # noqa: F401
+    from curobo.model_predictive_control import (ModelPredictiveControl, ModelPredictiveControlCfg,  # noqa: F401
+                                                 ModelPredictiveControlResult)
     import inspect
 
     # constructor shapes of the reference: LBFGSOpt(config, rollout_list, use_cuda_graph) (optim/gradient/lbfgs.py:156),
