@@ -163,7 +163,11 @@ static int launch_rnea_scratch(const RneaArgs &a, const float *in0, const float 
   const int B = a.batch, D = a.num_dof;
   hipLaunchKernelGGL(rnea_transpose_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)(3 - first)), dim3(256), 0, st, in0,
                      in1, in2, scratch, B, D, first);
-  static const bool quad = [] { const char *e = getenv("CUROBO_RNEA_QUAD"); return e ? atoi(e) != 0 : true; }();
+  // element per LANE by default here: these launches exist to run next to LDS- and wavefront-hungry kernels, and a lane walk
+  // occupies a quarter of the wavefront slots of the quad walk (C4 rollout set: 900 us with lanes, 945 us with quads; alone the
+  // quad walk is the faster one).  CUROBO_RNEA_SCRATCH_QUAD: 1 = quads, 2 = quads forward only, 3 = quads backward only.
+  static const int quad_mode = [] { const char *e = getenv("CUROBO_RNEA_SCRATCH_QUAD"); return e ? atoi(e) : 0; }();
+  const bool quad = quad_mode == 1 || (quad_mode == 2 && !BACKWARD) || (quad_mode == 3 && BACKWARD);
   const dim3 grid((unsigned)((B + kStagedLanes - 1) / kStagedLanes)), block(quad ? 4 * kStagedLanes : kStagedLanes);
   const size_t lds = (size_t)a.num_links * (kLinkFloats + 4) * sizeof(float);
   if (BACKWARD && accumulate) {  // gradients ADDED to the output tensors (the caller's running joint-space gradients)

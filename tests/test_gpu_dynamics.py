@@ -169,7 +169,8 @@ def test_c4_shape_humanoid_self_collision_plus_inverse_dynamics_cost(B, H, oracl
 @pytest.mark.parametrize("robot,n", [("franka", 1000), ("unitree_g1", 300)])
 def test_rnea_scratch_launches_equal_the_staged_ones(robot, n, oracle, device):
     """``curobo_hip_launch_rnea_forward_scratch`` / ``_backward_scratch`` (inputs transposed into a caller's scratch, no LDS staging):
-    torques, cache and gradients bit-identical to the staged launches -- same walk, same arithmetic -- and equal to the oracle"""
+    torques and gradients equal to the staged launches' (same walk; lanes instead of quads) and to the oracle; the variants of the
+    scratch VJP (q / qd re-used from the forward's scratch, accumulation) bit-identical among themselves"""
     from curobo_amd.backends import dynamics as Dy
 
     model, kin, q, qd, qdd, rng = _setup(robot, device, n, 5)
@@ -205,12 +206,10 @@ def test_rnea_scratch_launches_equal_the_staged_ones(robot, n, oracle, device):
             with pytest.raises(ValueError, match="accumulate needs"):
                 Dy.launch_rnea_backward(*g3, t(w), t(q), t(qd), *args, cache, n, L, D, kin.n_tree_levels, 1, None, accumulate=True)
     (tau0, cache0, g0), (tau1, cache1, g1) = out
-    if os.environ.get("CUROBO_RNEA_STAGED", "1") != "0" and os.environ.get("CUROBO_RNEA_QUAD", "1") != "0":  # (both on quads: bit for bit)
-        assert torch.equal(tau0, tau1) and torch.equal(cache0, cache1)
-        for a, b in zip(g0, g1):
-            assert torch.equal(a, b)
-    else:
-        torch.testing.assert_close(tau0, tau1, rtol=1e-5, atol=1e-5 * float(tau0.abs().max()))
+    # (the staged launches walk on quads, the scratch launches on lanes by default: same arithmetic, another summation order)
+    torch.testing.assert_close(tau0, tau1, rtol=1e-5, atol=1e-5 * float(tau0.abs().max()))
+    for a, b in zip(g0, g1):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
     tau_ref, _ = oracle.rnea_forward(q, qd, qdd, model.as_dict(), gravity=grav)
     np.testing.assert_allclose(tau1.cpu().numpy(), tau_ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(tau_ref).max()))
     with pytest.raises(ValueError, match="scratch must hold"):
