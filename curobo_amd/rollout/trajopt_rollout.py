@@ -302,8 +302,10 @@ class TrajOptRollout:
                     self._cs_gtau, self._rnea_g = z(B, H, D), [z(n, D) for _ in range(3)]
                     # with the joint-space chain on the side stream the walks read their inputs from a transposed scratch
                     # instead of staging them through LDS: the CU's LDS stays with the collision kernels they run next to
-                    # (worth it where staging is big -- the G1's 49 joints are 38 KB per workgroup -- not for a 7-dof arm's 5 KB)
-                    self._rnea_scratch = z(3 * n * D) if (c.overlap_dynamics and self.position.is_cuda and D > 20) else None
+                    # (they walk with an element per lane, a quarter of the staged quad walk's wavefronts: next to other kernels that
+                    # wins for a 7-dof arm as well -- Franka, 1024 / 4096 rollouts: 160 / 488 us against 177 / 543)
+                    # (below ~24 k points the two extra transposition launches cost more than the walks gain: 512 rollouts 139 / 130 us)
+                    self._rnea_scratch = z(3 * n * D) if (c.overlap_dynamics and self.position.is_cuda and (D > 20 or n >= 24576)) else None
                 rargs = (k.fixed_transforms, k.link_masses_com, k.link_inertias, k.joint_map_type, k.joint_map, k.link_map,
                          k.joint_offset_map, self._gravity, k.link_level_offsets, k.link_level_data)
                 dynamics_hip.launch_rnea_forward(self._tau, self.position.view(n, D), self.velocity.view(n, D),
