@@ -125,7 +125,11 @@ class IKRollout:
         else:  # re-allocation invalidates captured graphs: callers re-capture after a shape change
             self.goal_position = goal_position.to(self.device, torch.float32).contiguous().clone()
             self.goal_quat = goal_quat.to(self.device, torch.float32).contiguous().clone()
-        self.idxs_goal.copy_(idxs_goal.to(torch.int32))
+        key = (idxs_goal, idxs_goal._version)  # (solvers pass the same, unmodified row -> goal map every solve: no copy then)
+        last = getattr(self, "_idxs_src", None)
+        if last is None or last[0] is not key[0] or last[1] != key[1]:
+            self.idxs_goal.copy_(idxs_goal.to(torch.int32))
+            self._idxs_src = key
 
     def update_tool_pose_criteria(self, criteria) -> None:
         """``{tool frame: ToolPoseCriteria}``: an IK rollout has one point per row, so only the terminal factors, the

@@ -212,6 +212,8 @@ class IKSolver:
         """``env_idx`` [P]: problem p is checked against scene environment env_idx[p] (reference batch-env
         IK, ``idxs_env`` / ``use_multi_env``); every rollout row takes the environment of its problem."""
         mode = env_idx is not None
+        if not mode and getattr(self, "_env_mode", None) is False:
+            return  # still "every row in environment 0": the index buffers are zero already (five fill launches per solve otherwise)
         if mode != getattr(self, "_env_mode", False):
             self.optimizer._graph = None  # the launches differ between the two modes: capture again
         self._env_mode = mode
