@@ -124,6 +124,8 @@ class SceneData:
         for k in ("cuboid_dims", "voxel_params"):
             if k in self.arrays:
                 return int(self.arrays[k].shape[0])
+        if self.meshes is not None:  # a mesh-only scene: the mesh store carries the environment count
+            return int(self.meshes.num_envs)
         return 1
 
     @staticmethod
@@ -157,6 +159,12 @@ class SceneData:
             from .mesh import MeshStore
 
             store = meshes if isinstance(meshes, MeshStore) else MeshStore(meshes, device)
+            # the mesh launch indexes its per-environment tables (count, mesh_id, inv_pose, enable) with the SAME
+            # env_query_idx as the cuboid / voxel stores: a store with fewer environments would be read out of bounds
+            n_arr = [int(arrays[k].shape[0]) for k in ("cuboid_dims", "voxel_params") if k in arrays]
+            if n_arr and any(n != int(store.num_envs) for n in n_arr):
+                raise ValueError(f"meshes describe {store.num_envs} environment(s) but the obstacle arrays {n_arr[0]}: "
+                                 "every obstacle store of a scene must cover the same environments")
             struct.mesh_set = store.struct  # (a Python attribute of the ctypes struct: the launch wrappers look for it)
         return SceneData(tensors=t, struct=struct, arrays=arrays, meshes=store)
 

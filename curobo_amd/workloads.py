@@ -109,18 +109,25 @@ def c3_voxel_world(n: int = 128, voxel_size: float = 0.02) -> Dict:
     return voxel_grid_from_sdf(sdf, (n, n, n), voxel_size, pose7=(0.0, 0.0, 0.6, 1, 0, 0, 0), max_distance=10.0)
 
 
-def c5_mixed_worlds(num_envs: int, voxels: bool = True, grid: int = 64, seed: int = 5) -> Dict:
+def c5_mixed_worlds(num_envs: int, voxels: bool = True, grid: int = 64, seed: int = 5, rotated: bool = False) -> Dict:
     """C5 "mixed scene": every planning problem has its OWN world -- a table plus 1-3 random cuboids
-    and (``voxels``) one fp16 ESDF grid (``grid``^3 at 0.04 m) holding a sphere obstacle."""
+    and (``voxels``) one fp16 ESDF grid (``grid``^3 at 0.04 m) holding a sphere obstacle.  ``rotated``: the random
+    cuboids are turned about two axes (parity tests: in a rotated obstacle frame the swept cost's stationary-sphere
+    branch depends on rounding); the benchmark's worlds are axis aligned."""
     from .scene import cuboid_scene_arrays, voxel_grid_from_sdf
 
     rng = np.random.default_rng(seed)
     envs, grids = [], []
     for e in range(num_envs):
         obs = [{"dims": [2.2, 2.2, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}]
-        for _ in range(1 + e % 3):
+        for k in range(1 + e % 3):
             p = rng.uniform([-0.6, -0.6, 0.2], [0.6, 0.6, 0.9])
-            obs.append({"dims": list(rng.uniform(0.1, 0.35, size=3)), "pose": [*p, 1, 0, 0, 0]})
+            quat = [1, 0, 0, 0]
+            if rotated:
+                a, b = 0.3 + 0.4 * k + 0.2 * e, 0.2 + 0.1 * k
+                qz, qx = np.array([np.cos(a / 2), 0, 0, np.sin(a / 2)]), np.array([np.cos(b / 2), np.sin(b / 2), 0, 0])
+                quat = [qz[0] * qx[0] - qz[3] * 0, qz[0] * qx[1], qz[3] * qx[1], qz[3] * qx[0]]  # qz (x) qx, wxyz
+            obs.append({"dims": list(rng.uniform(0.1, 0.35, size=3)), "pose": [*p, *quat]})
         envs.append(obs)
         c = rng.uniform([-0.5, -0.5, 0.3], [0.5, 0.5, 0.8])
         grids.append(voxel_grid_from_sdf(lambda p, c=c: np.linalg.norm(p - c, axis=-1) - 0.15, (grid,) * 3, 0.04,

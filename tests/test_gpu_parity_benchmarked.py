@@ -179,3 +179,140 @@ def test_c3_size_sweep_x_voxel_fused_and_packed_kernel_match_oracle(oracle, devi
     np.testing.assert_allclose(d[rest], wc["distance"][rest], rtol=1e-4, atol=2e-5 * w)  # axis-aligned grid: no 1x / 2x / 3x split
     # per trajectory the scene cost agrees to the 1e-5 of the fused comparison
     np.testing.assert_allclose(d.sum((1, 2)), wc["distance"].sum((1, 2)), rtol=1e-5, atol=1e-7 * w)
+
+
+def _per_obstacle_centre_terms(oracle, sph, arrays, w, eta, env_idx, speed_dt):
+    """Centre-sample cost / gradient of every sphere against every obstacle ALONE (sweep off, speed metric on: the map is
+    linear in (cost, gradient), so this is the term a duplicated centre sample adds): lists over the obstacles."""
+    out = []
+    n_c = arrays["cuboid_dims"].shape[1] if arrays.get("cuboid_dims") is not None else 0
+    n_v = arrays["voxel_params"].shape[1] if arrays.get("voxel_params") is not None else 0
+    for kind, n, key in (("cuboid", n_c, "cuboid_enable"), ("voxel", n_v, "voxel_enable")):
+        for o in range(n):
+            part = dict(arrays)
+            for k2 in ("cuboid_enable", "voxel_enable"):
+                if part.get(k2) is not None:
+                    part[k2] = np.zeros_like(arrays[k2])
+            part[key] = np.zeros_like(arrays[key])
+            part[key][:, o] = arrays[key][:, o]
+            r = oracle.scene_collision(sph, part, w, eta, sweep=False, enable_speed_metric=True, speed_dt=speed_dt,
+                                       env_query_idx=env_idx, use_multi_env=True)
+            out.append((r["distance"], r["gradient"][..., :3]))
+    return out
+
+
+@pytest.mark.parametrize("rotated", [False, True], ids=["bench_worlds", "rotated_cuboids"])
+def test_c5_bench_size_per_sphere_sweep_allowance(rotated, oracle, device):
+    """C5 at the SIZE ``bench.py`` runs per GPU share (2 problems x 512 seeds x 4 candidates = 4096 trajectories x 65
+    points x 65 spheres), held to the oracle PER SPHERE.
+
+    The reference's swept kernel duplicates the centre sample of a direction iff the half sweep length in the obstacle
+    frame is > 0 (wp_sweep_collision_kernel.py:186-203): for a sphere that is stationary up to rounding, two
+    implementations may land on different sides.  The allowance is therefore per (sphere, obstacle, direction): a sphere
+    with n stationary neighbours may differ from the oracle by k_o centre-sample terms of obstacle o, |k_o| <= n, and by
+    nothing else; every other sphere of the same trajectory is compared tightly.  (1) the kernel sequence's swept scene
+    kernel on the fused launch's own spheres, per sphere; (2) the fused launch's per-trajectory cost against the sum of
+    the oracle's per-sphere costs corrected by exactly those k_o terms, 1e-5.  ``bench_worlds`` are what ``bench.py``
+    launches (axis-aligned obstacle frames: the transform into them is exact and no sphere needs the allowance --
+    measured: 58 130 stationary colliding spheres, 0 whole-term corrections); ``rotated_cuboids`` turns the random cuboids
+    so that the allowance is exercised at the same size."""
+    import itertools
+
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import c5_mixed_worlds, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    n_prob, seeds, nls = 2, 512, 4
+    B = n_prob * seeds * nls
+    arrays = c5_mixed_worlds(n_prob, voxels=True, rotated=rotated)
+    scene = SceneData.from_arrays(arrays, device)
+    cfg = CollisionRolloutCfg(interpolation_steps=4, use_fused=True, fused_materialize=True)
+    ro = CollisionRollout(kin, scene, B, cfg)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    ro.update_start_state(start)
+    env_idx = np.repeat(np.arange(n_prob, dtype=np.int32), seeds * nls)
+    ro.update_env_query_idx(torch.as_tensor(env_idx, device=device))
+    assert ro.fused_available() and ro.use_multi_env and cfg.padded_horizon == 65
+    knots = _candidates(model, n_prob * seeds, nls, cfg.n_knots, seed=8)
+    x = torch.as_tensor(knots, device=device).reshape(B, -1)
+    cost, _ = ro.cost_and_gradient(x)
+    torch.cuda.synchronize()
+    cost = cost.cpu().numpy().astype(np.float64)
+    sph = ro.robot_spheres.cpu().numpy()
+    # (1) the kernel sequence's scene kernel on the SAME spheres
+    seq = CollisionRollout(kin, scene, B, CollisionRolloutCfg(interpolation_steps=4, use_fused=False))
+    seq.update_start_state(start)
+    seq.update_env_query_idx(torch.as_tensor(env_idx, device=device))
+    seq.compute_kinematics(seq.compute_state_from_action(x.view(B, cfg.n_knots, -1)))
+    seq.robot_spheres.copy_(ro.robot_spheres)
+    seq.compute_costs()
+    torch.cuda.synchronize()
+    d, g = seq.scene_dist.cpu().numpy(), seq.scene_grad.cpu().numpy()[..., :3]
+    w, eta = cfg.scene_collision_weight, cfg.activation_distance
+    wc = oracle.scene_collision(sph, arrays, w, eta, sweep=True, enable_speed_metric=True, speed_dt=cfg.traj_dt,
+                                env_query_idx=env_idx, use_multi_env=True)
+    sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, cfg.self_collision_weight)
+    d_ref, g_ref = wc["distance"], wc["gradient"][..., :3]
+    # stationary neighbours per sphere (world frame, up to rounding)
+    p = sph[..., :3]
+    stepn = np.linalg.norm(np.diff(p, axis=1), axis=-1)
+    n_still = np.zeros(p.shape[:3], np.int32)
+    n_still[:, 1:] += stepn < 1e-5
+    n_still[:, :-1] += stepn < 1e-5
+    amb = (n_still > 0) & ((d > 0) | (d_ref > 0))
+    frac_amb = float(amb.mean())
+    in_col = (d_ref > 0)
+    assert in_col.sum() > 100000, "the workload must collide"
+    assert np.array_equal((d > 0) & ~amb, in_col & ~amb), "which moving spheres collide must be identical"
+    tight = ~amb
+    e_d = np.abs(d[tight] - d_ref[tight])
+    # per sphere: 1e-5 relative + 5e-6 m of penetration (measured: 1.05e-6 m at most -- up to seven fp32 trilinear ESDF
+    # samples of fp16 data per sphere; the C3 test's bound for the same kernel is 2e-5 m)
+    tol_d = 1e-5 * np.abs(d_ref[tight]) + 5e-6 * w
+    e_g = np.abs(g[tight] - g_ref[tight])
+    tol_g = 1e-3 * np.abs(g_ref[tight]) + 2e-4 * w
+    print(f"\n[c5 per sphere] {B} trajectories, {int(in_col.sum())} colliding spheres, ambiguous (stationary and in collision) "
+          f"{int(amb.sum())} = {frac_amb:.2e} of all spheres; tight spheres: max cost error {float((e_d / tol_d).max()):.3f} of the "
+          f"bound ({float(e_d.max() / w):.2e} m), gradient {float((e_g / tol_g).max()):.3f} of the bound")
+    assert (e_d <= tol_d).all(), f"tight spheres: {(e_d > tol_d).sum()} beyond the bound; ambiguous fraction {frac_amb:.2e}"
+    assert (e_g > tol_g).mean() < 1e-5 and (e_g <= 30 * tol_g).all(), (int((e_g > tol_g).sum()), float((e_g / tol_g).max()))
+    # ambiguous spheres: the difference is a combination of whole centre-sample terms, |k_o| <= number of stationary neighbours
+    corr = np.zeros_like(d_ref, dtype=np.float64)  # what the HIP branches add to the oracle's per-sphere cost
+    if amb.any():
+        terms = _per_obstacle_centre_terms(oracle, sph, arrays, w, eta, env_idx, cfg.traj_dt)
+        ia = np.nonzero(amb)
+        diff = (d[ia] - d_ref[ia]).astype(np.float64)
+        c1 = np.stack([t[0][ia] for t in terms], axis=1).astype(np.float64)  # [n_amb, n_obs]
+        nmax = n_still[ia]
+        best = np.full(diff.shape, np.inf)
+        best_k = np.zeros_like(c1)
+        # (fewest whole terms first: an obstacle the sphere does not touch has c1 = 0 and must not collect a k)
+        for ks in sorted(itertools.product(range(-2, 3), repeat=c1.shape[1]), key=lambda k: sum(abs(v) for v in k)):
+            kv = np.asarray(ks, np.float64)
+            ok = (np.abs(kv)[None, :] <= nmax[:, None]).all(1)
+            r = np.where(ok, np.abs(diff - c1 @ kv), np.inf)
+            better = r < best - 1e-12
+            best = np.where(better, r, best)
+            best_k[better] = kv
+        tol_a = 1e-5 * (np.abs(d_ref[ia]) + np.abs(c1).sum(1)) + 5e-6 * w
+        assert (best <= tol_a).all(), (f"{int((best > tol_a).sum())} of {amb.sum()} ambiguous spheres differ from the oracle by more than "
+                                      f"whole centre-sample terms (ambiguous fraction {frac_amb:.2e})")
+        corr[ia] = (c1 * best_k).sum(1)
+        print(f"[c5 per sphere] ambiguous spheres: {int(amb.sum())}, of which the HIP kernel and the oracle took different sweep "
+              f"branches (a non-zero whole-term correction): {int((np.abs(c1 * best_k).sum(1) > 0).sum())}; largest residual "
+              f"{float((best / tol_a).max()):.3f} of the bound")
+    # (2) the fused launch, per trajectory: oracle per-sphere costs + exactly the allowed corrections + self collision
+    want = d_ref.astype(np.float64).sum((1, 2)) + corr.sum((1, 2)) + sc["distance"].reshape(B, -1).astype(np.float64).sum(1)
+    # (the criterion of _check_against_oracle_on_same_inputs: 1e-5 relative + 1e-7 m of penetration)
+    e_c = np.abs(cost - want) / (np.abs(want) + 1e-2 * w)
+    seq_sum = d.astype(np.float64).sum((1, 2)) + seq.self_dist.cpu().numpy().reshape(B, -1).astype(np.float64).sum(1)
+    e_hip = np.abs(cost - seq_sum) / (np.abs(seq_sum) + 1e-2 * w)
+    iw = int(np.argmax(e_c))
+    print(f"[c5 per sphere] fused launch vs oracle per trajectory: max relative cost error {float(e_c.max()):.2e} "
+          f"({int((e_c > 1e-5).sum())} of {B} beyond 1e-5); fused vs the kernel sequence's own per-sphere sum {float(e_hip.max()):.2e}; "
+          f"worst trajectory {iw}: fused {cost[iw]:.4f}, oracle + corrections {want[iw]:.4f}, kernel sequence {seq_sum[iw]:.4f}, "
+          f"colliding spheres {int((d_ref[iw] > 0).sum())}, |corrections| {float(np.abs(corr[iw]).sum()):.4f}")
+    assert (e_c <= 1e-5).all(), f"{int((e_c > 1e-5).sum())} trajectories beyond 1e-5 (ambiguous sphere fraction {frac_amb:.2e})"

@@ -356,10 +356,13 @@ def test_trajopt_solver_with_torque_limits(oracle, device):
     np.testing.assert_allclose(s["position"][ok], r1.position.cpu().numpy()[ok], atol=1e-4)
 
 
-def test_humanoid_rollout_side_stream_scratch_walks_equal_the_single_stream_sequence(device):
+def test_humanoid_rollout_side_stream_scratch_walks_equal_the_single_stream_sequence(oracle, device):
     """C4 shape in small: Unitree G1 with torque limits on the kernel sequence.  ``overlap_dynamics`` runs the joint-space chain on a
     side stream with the RNEA launches in their scratch form (inputs transposed, VJP accumulated straight into the c-space gradients);
-    one stream runs the staged launches and adds their gradients afterwards: same cost, same gradient (summation order only)"""
+    one stream runs the staged launches and adds their gradients afterwards: same cost, same gradient (summation order only) -- and
+    BOTH are held to the oracle composition of the same stages (tests/oracle_compose.py: B-spline, FK, tool pose, RNEA, c-space
+    STATE with effort bounds, RNEA VJP, self collision, FK VJP, B-spline VJP): cost 1e-5 relative, gradient 5e-4 of its scale."""
+    from oracle_compose import trajopt_cost_and_gradient
     from curobo_amd.kinematics import KinematicsCfg
     from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
     from curobo_amd.workloads import seed_knots, start_configuration
@@ -370,15 +373,26 @@ def test_humanoid_rollout_side_stream_scratch_walks_equal_the_single_stream_sequ
     x = torch.as_tensor(seed_knots(model, B, 12, seed=6, spread=0.15), device=device).reshape(B, -1)
     out = []
     for overlap in (False, True):
-        ro = TrajOptRollout(kin, None, B, TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=[40.0] * kin.num_dof,
-                                                            overlap_dynamics=overlap))
+        cfg = TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=[40.0] * kin.num_dof, overlap_dynamics=overlap)
+        ro = TrajOptRollout(kin, None, B, cfg)
         ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
         ro.cost_and_gradient(x)  # (first call allocates on the calling stream)
         c, g = ro.cost_and_gradient(x)
         torch.cuda.synchronize()
         assert (ro._rnea_scratch is not None) == overlap
-        out.append((c.clone(), g.clone(), float(ro._tau.abs().max())))
-    (c0, g0, t0), (c1, g1, t1) = out
+        out.append((c.clone(), g.clone(), float(ro._tau.abs().max()), ro._tau.clone()))
+    (c0, g0, t0, tau0), (c1, g1, t1, tau1) = out
     assert t0 > 40.0, "the effort limit is active"
     torch.testing.assert_close(c1, c0, rtol=1e-5, atol=1e-5 * float(c0.abs().max()))
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5 * float(g0.abs().max()))
+    # the oracle's composition of the same stages
+    ref = trajopt_cost_and_gradient(oracle, model, cfg, x.cpu().numpy().reshape(B, 12, -1), start_configuration(model))
+    gk = ref["grad_knots"].reshape(B, -1)
+    for name, c, g, tau in (("one stream, staged walks", c0, g0, tau0), ("side stream, scratch walks", c1, g1, tau1)):
+        e_tau = float(np.abs(tau.cpu().numpy() - ref["tau"]).max() / np.abs(ref["tau"]).max())
+        e_c = float(np.abs(c.cpu().numpy().astype(np.float64) - ref["cost"]).max() / np.abs(ref["cost"]).max())
+        e_g = float(np.abs(g.cpu().numpy() - gk).max() / np.abs(gk).max())
+        print(f"\n[g1 rollout parity] {name}: tau {e_tau:.2e}, cost {e_c:.2e}, grad_knots {e_g:.2e} (fractions of the largest entry)")
+        np.testing.assert_allclose(tau.cpu().numpy(), ref["tau"], rtol=1e-5, atol=1e-5 * np.abs(ref["tau"]).max())
+        np.testing.assert_allclose(c.cpu().numpy(), ref["cost"], rtol=1e-5, atol=1e-6 * np.abs(ref["cost"]).max())
+        np.testing.assert_allclose(g.cpu().numpy(), gk, rtol=5e-4, atol=5e-4 * np.abs(gk).max())
