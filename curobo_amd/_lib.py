@@ -84,6 +84,10 @@ def _ctype_of(tok: str):
         return C.c_void_p
     if tok.startswith("float"):
         return C.c_float
+    if tok.startswith("size_t"):
+        return C.c_size_t
+    if tok.startswith("int64_t"):
+        return C.c_int64
     if tok.startswith("int") or tok.startswith("int32_t"):
         return C.c_int
     raise ValueError(f"unhandled C type in header: {tok!r}")

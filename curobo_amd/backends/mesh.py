@@ -21,7 +21,7 @@ from .._lib import check, current_stream, load, ptr
 class Mesh(C.Structure):
     """``curobo_hip_mesh``"""
 
-    _fields_ = [("tri", C.c_void_p), ("node_box", C.c_void_p), ("n_tri", C.c_int32), ("n_leaves", C.c_int32),
+    _fields_ = [("tri", C.c_void_p), ("node_box", C.c_void_p), ("tri_pn", C.c_void_p), ("n_tri", C.c_int32), ("n_leaves", C.c_int32),
                 ("leaf_size", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -29,7 +29,8 @@ class MeshSet(C.Structure):
     """``curobo_hip_mesh_set``"""
 
     _fields_ = [("meshes", C.c_void_p), ("mesh_id", C.c_void_p), ("dims", C.c_void_p), ("inv_pose", C.c_void_p),
-                ("enable", C.c_void_p), ("count", C.c_void_p), ("max_n", C.c_int32), ("gradient_mode", C.c_int32)]
+                ("enable", C.c_void_p), ("count", C.c_void_p), ("max_n", C.c_int32), ("gradient_mode", C.c_int32),
+                ("num_envs", C.c_int32), ("_pad", C.c_int32)]
 
 
 @dataclass
@@ -38,6 +39,7 @@ class DeviceMesh:
 
     tri: torch.Tensor
     node_box: torch.Tensor
+    tri_pn: torch.Tensor
     struct: Mesh
     bounds: np.ndarray  # [2, 3] lo / hi in the mesh frame
     n_tri: int
@@ -47,9 +49,51 @@ class DeviceMesh:
         return (self.bounds[1] - self.bounds[0]).astype(np.float32)
 
 
+def feature_pseudonormals(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """[F, 6, 4] float32: per triangle the angle-weighted pseudonormals of its vertices a, b, c and the pseudonormals of its
+    edges ab, bc, ca (sum of the unit normals of the faces sharing the edge) -- Baerentzen & Aanaes, "Signed distance
+    computation using the angle weighted pseudonormal" (2005): for a closed, consistently oriented surface the sign of
+    (p - closest point) . pseudonormal of the feature the closest point lies on is the sign of the signed distance.  Vertices
+    are welded by position first (faces of a mesh file often do not share indices along creases).  Scene-upload plumbing,
+    once per loaded mesh; a feature whose pseudonormal degenerates (|n| ~ 0) is left zero: the kernels then count crossings."""
+    v = np.asarray(vertices, np.float64)
+    f = np.asarray(faces, np.int64)
+    span = float(np.ptp(v, axis=0).max()) or 1.0
+    key = np.round((v - v.min(0)) / (span * 1e-7)).astype(np.int64)
+    _, weld = np.unique(key, axis=0, return_inverse=True)
+    weld = weld.reshape(-1)
+    fw = weld[f]                                     # faces over welded vertex ids
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    n = np.cross(b - a, c - a)
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-300), 0.0)
+
+    def angle(p, q, r):  # angle at p
+        u, w = q - p, r - p
+        cu = np.einsum("ij,ij->i", u, w) / np.maximum(np.linalg.norm(u, axis=1) * np.linalg.norm(w, axis=1), 1e-300)
+        return np.arccos(np.clip(cu, -1.0, 1.0))
+    ang = np.stack([angle(a, b, c), angle(b, c, a), angle(c, a, b)], axis=1)           # [F, 3]
+    nv = np.zeros((int(weld.max()) + 1, 3))
+    for k in range(3):
+        np.add.at(nv, fw[:, k], ang[:, k:k + 1] * n)
+    out = np.zeros((f.shape[0], 6, 4), np.float32)
+    out[:, 0:3, :3] = nv[fw]                                                            # vertices a, b, c
+    # edges ab, bc, ca: undirected key over welded ids
+    e0 = np.stack([fw[:, [0, 1]], fw[:, [1, 2]], fw[:, [2, 0]]], axis=1)                # [F, 3, 2]
+    ek = np.sort(e0.reshape(-1, 2), axis=1)
+    _, inv = np.unique(ek, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    ne = np.zeros((int(inv.max()) + 1, 3))
+    np.add.at(ne, inv, np.repeat(n, 3, axis=0))
+    out[:, 3:6, :3] = ne[inv].reshape(-1, 3, 3)
+    return out
+
+
 def build_mesh_bvh(vertices, faces, device, leaf_size: int = 4) -> DeviceMesh:
     """vertices [V, 3] (mesh frame), faces [F, 3] -> the linear BVH on ``device``: Morton keys of the centroids (HIP), the
     sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level)"""
+    import os
+    leaf_size = int(os.environ.get("CUROBO_MESH_LEAF_SIZE", leaf_size))  # development knob
     v = torch.as_tensor(np.ascontiguousarray(vertices, np.float32)).to(device).contiguous()
     f = torch.as_tensor(np.ascontiguousarray(faces, np.int32)).to(device).contiguous()
     if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3 or f.shape[0] == 0:
@@ -69,8 +113,11 @@ def build_mesh_bvh(vertices, faces, device, leaf_size: int = 4) -> DeviceMesh:
     tri = torch.zeros(n, 12, device=device)
     box = torch.zeros(2 * n_leaves, 8, device=device)
     check(load().curobo_hip_mesh_bvh_build(ptr(tri), ptr(box), ptr(v), ptr(f), ptr(codes), n, n_leaves, leaf_size, current_stream(v)))
-    s = Mesh(ptr(tri), ptr(box), n, n_leaves, leaf_size, 0)
-    return DeviceMesh(tri, box, s, bounds, n)
+    # pseudonormals of the triangle features, in the sorted order of the triangles (the low half of a key is the index)
+    pn = torch.as_tensor(feature_pseudonormals(np.asarray(vertices, np.float32), np.asarray(faces, np.int64))).to(device)
+    tri_pn = pn[(codes & 0xFFFFFFFF).long()].contiguous()
+    s = Mesh(ptr(tri), ptr(box), ptr(tri_pn), n, n_leaves, leaf_size, 0)
+    return DeviceMesh(tri, box, tri_pn, s, bounds, n)
 
 
 def mesh_query(mesh: DeviceMesh, points: torch.Tensor, max_distance: float, want_grad: bool = True
@@ -97,9 +144,29 @@ def mesh_esdf_bake_bvh(out_esdf: torch.Tensor, mesh: DeviceMesh, grid_shape, vox
 
 def sphere_mesh_collision(distance, gradient, spheres, mesh_set: MeshSet, weight, activation_distance, env_query_idx, batch_size: int,
                           horizon: int, num_spheres: int, use_multi_env: bool, sweep_steps: int = 0, enable_speed_metric: bool = False,
-                          speed_dt=None, accumulate: bool = True):
-    """the mesh share of the scene-collision forward (``curobo_hip_sphere_mesh_collision``)"""
-    check(load().curobo_hip_sphere_mesh_collision(
+                          speed_dt=None, accumulate: bool = True, workspace=None):
+    """the mesh share of the scene-collision forward (``curobo_hip_sphere_mesh_collision_ws``: survivors of the bounding-box
+    reject queued launch-wide, see include/curobo_hip.h; ``workspace=False`` runs the one-kernel form).  The workspace is kept
+    per (device, size): launches on one stream are ordered, and a captured graph keeps its pointer alive through this cache."""
+    lib = load()
+    if workspace is False:
+        check(lib.curobo_hip_sphere_mesh_collision(
+            ptr(distance), ptr(gradient), ptr(spheres), C.addressof(mesh_set), ptr(weight), ptr(activation_distance), ptr(env_query_idx),
+            batch_size, horizon, num_spheres, int(use_multi_env), sweep_steps, int(enable_speed_metric), ptr(speed_dt), int(accumulate),
+            current_stream(distance)))
+        return
+    nbytes = C.c_int64(0)
+    check(lib.curobo_hip_sphere_mesh_collision_ws_bytes(batch_size, horizon, num_spheres, C.cast(C.pointer(nbytes), C.c_void_p)))
+    need = int(nbytes.value)
+    if workspace is None:
+        key = (distance.device, need)
+        workspace = _WORKSPACES.get(key)
+        if workspace is None:
+            workspace = _WORKSPACES[key] = torch.empty(need, dtype=torch.uint8, device=distance.device)
+    check(lib.curobo_hip_sphere_mesh_collision_ws(
         ptr(distance), ptr(gradient), ptr(spheres), C.addressof(mesh_set), ptr(weight), ptr(activation_distance), ptr(env_query_idx),
         batch_size, horizon, num_spheres, int(use_multi_env), sweep_steps, int(enable_speed_metric), ptr(speed_dt), int(accumulate),
-        current_stream(distance)))
+        ptr(workspace), int(workspace.numel()), current_stream(distance)))
+
+
+_WORKSPACES: dict = {}

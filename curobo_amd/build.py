@@ -24,7 +24,7 @@ OBJ_DIR = os.path.join(_PKG, "build")
 ARCH = "gfx950"
 
 HEADERS = ["common.hpp", "cost_device.hpp", "scene_device.hpp", "fk_device.hpp", "self_device.hpp",
-           "bspline_device.hpp", "dynamics_device.hpp"]
+           "bspline_device.hpp", "dynamics_device.hpp", "mesh_device.hpp"]
 
 SOURCES = [
     "runtime.cpp",

@@ -11,166 +11,18 @@
 // a kernel here, the sort is the caller's -- torch.sort, plumbing), `leaf_size` consecutive triangles form a leaf, the
 // leaf count is padded to a power of two and node k has the children 2k and 2k + 1: no pointers, no build-time atomics,
 // the boxes of a level are one launch.  Triangles are stored in sorted order as (a, b - a, c - a) float4 triples so that
-// a leaf is one contiguous run.  The query is a per-lane stack traversal (nearer child first, prune by the best squared
-// distance so far); the sign is the parity of ray crossings, majority of three rays through the same BVH (closed meshes;
-// the oracle uses the generalised winding number instead: two independent methods that must agree).
-#include "common.hpp"
+// a leaf is one contiguous run.  The query (mesh_device.hpp) is a per-lane STACKLESS traversal -- the heap index is the
+// path; nearer child first, prune by the best squared distance so far --; the sign is the parity of ray crossings,
+// majority of three rays through the same BVH (closed meshes; the oracle uses the generalised winding number instead:
+// two independent methods that must agree).  The collision launch packs the (sphere, mesh) items that survive the
+// bounding-box reject and searches each sample only as far as its distance can matter (mesh_sdf_within).
+#include <algorithm>
+
+#include "mesh_device.hpp"
 
 #include <hip/hip_fp16.h>
 
 namespace curobo_hip {
-
-
-constexpr int kMeshStack = 64;
-
-struct TriRec {  // 48 bytes
-  float4 a, ab, ac;
-};
-
-__device__ __forceinline__ float box_dist2(const float4 lo, const float4 hi, f3 p) {
-  const float dx = fmaxf(fmaxf(lo.x - p.x, p.x - hi.x), 0.0f), dy = fmaxf(fmaxf(lo.y - p.y, p.y - hi.y), 0.0f),
-              dz = fmaxf(fmaxf(lo.z - p.z, p.z - hi.z), 0.0f);
-  return dx * dx + dy * dy + dz * dz;
-}
-
-// closest point of triangle (a, a + ab, a + ac) to p (Ericson, Real-Time Collision Detection 5.1.5)
-__device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac, bool &interior) {
-  interior = false;
-  const f3 ap = p - a;
-  const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-  if (d1 <= 0.0f && d2 <= 0.0f) return a;
-  const f3 b = a + ab, bp = p - b;
-  const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-  if (d3 >= 0.0f && d4 <= d3) return b;
-  const float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + (d1 / (d1 - d3)) * ab;
-  const f3 c = a + ac, cp = p - c;
-  const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-  if (d6 >= 0.0f && d5 <= d6) return c;
-  const float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + (d2 / (d2 - d6)) * ac;
-  const float va = d3 * d6 - d5 * d4;
-  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
-  const float den = 1.0f / (va + vb + vc);
-  interior = true;  // the face region: the closest point is the projection on the triangle's plane
-  return a + (vb * den) * ab + (vc * den) * ac;
-}
-
-// closest surface point within sqrt(best_d2) of p; returns false when there is none
-// side: +1 / -1 = p is on the outer / inner side of the FACE its closest point lies in (then that is the sign of the
-// signed distance of a closed mesh), 0 = the closest point lies on an edge or a vertex (no verdict: count crossings)
-__device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp, int &side) {
-  side = 0;
-  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
-  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
-  int stack[kMeshStack];
-  int sp = 0;
-  bool found = false;
-  if (box_dist2(box[2], box[3], p) <= best_d2) stack[sp++] = 1;
-  while (sp > 0) {
-    const int node = stack[--sp];
-    if (box_dist2(box[node * 2], box[node * 2 + 1], p) > best_d2) continue;  // the best may have shrunk since the push
-    if (node >= m.n_leaves) {
-      const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
-      for (int t = t0; t < t1; t++) {
-        const TriRec r = tri[t];
-        bool interior;
-        const f3 ab = make_f3(r.ab.x, r.ab.y, r.ab.z), ac = make_f3(r.ac.x, r.ac.y, r.ac.z);
-        const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), ab, ac, interior);
-        const f3 d = p - c;
-        const float d2 = dot(d, d);
-        if (d2 <= best_d2) {
-          // (a tie between a face and an edge / vertex of a neighbour keeps whichever came last; a face verdict is only
-          // trusted when the point is clearly off the plane)
-          const float sd = dot(d, cross(ab, ac));
-          side = (interior && d2 > 1e-12f && sd != 0.0f) ? (sd > 0.0f ? 1 : -1) : 0;
-          if (d2 == best_d2 && found) side = 0;
-          best_d2 = d2; cp = c; found = true;
-        }
-      }
-    } else {
-      const int c0 = node * 2, c1 = c0 + 1;
-      const float d0 = box_dist2(box[c0 * 2], box[c0 * 2 + 1], p), d1 = box_dist2(box[c1 * 2], box[c1 * 2 + 1], p);
-      // the farther child first: the nearer one is popped next
-      if (d0 <= d1) {
-        if (d1 <= best_d2 && sp < kMeshStack) stack[sp++] = c1;
-        if (d0 <= best_d2 && sp < kMeshStack) stack[sp++] = c0;
-      } else {
-        if (d0 <= best_d2 && sp < kMeshStack) stack[sp++] = c0;
-        if (d1 <= best_d2 && sp < kMeshStack) stack[sp++] = c1;
-      }
-    }
-  }
-  return found;
-}
-
-// crossings of the ray p + t d (t > 0) with the surface
-__device__ __forceinline__ int mesh_ray_crossings(const curobo_hip_mesh &m, f3 p, f3 d) {
-  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
-  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
-  const f3 inv = make_f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  int stack[kMeshStack];
-  int sp = 0, hits = 0;
-  stack[sp++] = 1;
-  while (sp > 0) {
-    const int node = stack[--sp];
-    const float4 lo = box[node * 2], hi = box[node * 2 + 1];
-    // slab test (an empty padding box has lo > hi: t_enter > t_exit)
-    const float tx0 = (lo.x - p.x) * inv.x, tx1 = (hi.x - p.x) * inv.x, ty0 = (lo.y - p.y) * inv.y, ty1 = (hi.y - p.y) * inv.y,
-                tz0 = (lo.z - p.z) * inv.z, tz1 = (hi.z - p.z) * inv.z;
-    const float t_in = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-    const float t_out = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-    if (!(t_in <= t_out) || lo.x > hi.x) continue;
-    if (node >= m.n_leaves) {
-      const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
-      for (int t = t0; t < t1; t++) {  // Moeller-Trumbore
-        const TriRec r = tri[t];
-        const f3 ab = make_f3(r.ab.x, r.ab.y, r.ab.z), ac = make_f3(r.ac.x, r.ac.y, r.ac.z);
-        const f3 pv = cross(d, ac);
-        const float det = dot(ab, pv);
-        if (fabsf(det) < 1e-20f) continue;
-        const float idet = 1.0f / det;
-        const f3 tv = p - make_f3(r.a.x, r.a.y, r.a.z);
-        const float u = dot(tv, pv) * idet;
-        if (u < 0.0f || u > 1.0f) continue;
-        const f3 qv = cross(tv, ab);
-        const float v = dot(d, qv) * idet;
-        if (v < 0.0f || u + v > 1.0f) continue;
-        if (dot(ac, qv) * idet > 0.0f) hits++;
-      }
-    } else if (sp + 2 <= kMeshStack) {
-      stack[sp++] = node * 2;
-      stack[sp++] = node * 2 + 1;
-    }
-  }
-  return hits;
-}
-
-// inside a closed mesh: the parity of surface crossings, majority of three rays in generic directions (a ray that
-// grazes an edge or a vertex may count a crossing twice or not at all; three unrelated directions do not all do)
-__device__ __forceinline__ bool mesh_inside(const curobo_hip_mesh &m, f3 p) {
-  const int a = mesh_ray_crossings(m, p, make_f3(1.0f, 0.0713f, 0.0291f)) & 1;
-  const int b = mesh_ray_crossings(m, p, make_f3(-0.0517f, 1.0f, 0.0839f)) & 1;
-  if (a == b) return a != 0;
-  return (mesh_ray_crossings(m, p, make_f3(0.0331f, -0.0617f, -1.0f)) & 1) != 0;
-}
-
-// data_mesh.py:630-700 compute_local_sdf_with_grad: signed distance (negative inside) and the local gradient
-// (p - closest) / |p - closest| -- as the reference returns it, whatever side p is on.  No surface within max_distance:
-// (max_distance, 0).
-__device__ __forceinline__ float mesh_sdf_with_grad(const curobo_hip_mesh &m, f3 lp, float max_distance, f3 &g) {
-  g = make_f3(0.f, 0.f, 0.f);
-  float d2 = max_distance * max_distance;
-  f3 cp = lp;
-  int side;
-  if (!mesh_closest_point(m, lp, d2, cp, side)) return max_distance;
-  const float d = sqrtf(d2);
-  const f3 delta = lp - cp;
-  if (d > 1e-6f) g = (1.0f / d) * delta;
-  // the face the closest point lies in says which side the point is on; on an edge or a vertex the crossings are counted
-  const bool inside = side != 0 ? side < 0 : mesh_inside(m, lp);
-  return inside ? -d : d;
-}
 
 // ------------------------------------------------------------------------------------------------ build
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
@@ -274,185 +126,320 @@ struct MeshCollArgs {
   const float *weight, *eta, *speed_dt;
   const int32_t *env_query_idx;
   int batch, horizon, nspheres, use_multi_env, enable_speed_metric, accumulate;
+  int slot0, nslots;  // the obstacle slots [slot0, slot0 + nslots) of every environment are handled by this launch (<= 32)
 };
 
-__device__ __forceinline__ void activation_m(float dist, float eta, float &cost, float &gscale) {  // wp_collision_common.py:11-38
-  if (dist > eta) { cost = dist - 0.5f * eta; gscale = 1.0f; }
-  else { cost = 0.5f * dist * dist / eta; gscale = dist / eta; }
-}
+constexpr int kMeshSlotsPerLaunch = 32;
 
-__device__ __forceinline__ float mesh_point_terms(const curobo_hip_mesh &m, f3 lp, float max_distance, float r_adj, float eta,
-                                                  float &c, float &gs, f3 &g, int gradient_mode) {
-  const float sdf = mesh_sdf_with_grad(m, lp, max_distance, g);
-  if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
-  const float pen = -sdf + r_adj;
-  c = 0.0f; gs = 0.0f;
-  if (pen > 0.0f) activation_m(pen, eta, c, gs);
-  return pen;
-}
-__device__ __forceinline__ float mesh_eval_point(const curobo_hip_mesh &m, f3 lp, float max_distance, float r_adj, float eta,
-                                                 float &cost_sum, f3 &grad_sum, int gradient_mode) {
-  f3 g;
-  float c, gs;
-  const float pen = mesh_point_terms(m, lp, max_distance, r_adj, eta, c, gs, g, gradient_mode);
-  if (pen > 0.0f) {
-    cost_sum += c;
-    grad_sum = grad_sum + gs * g;
+// wp_speed_metric.py:38-93 on this kind's share (the map is linear in (cost, gradient))
+__device__ __forceinline__ void mesh_speed_metric(f3 center, f3 pp, f3 np, float dt, float &dsum, f3 &gsum) {
+  if (dt < 1e-6f) dt = 1e-6f;
+  const f3 vel = (0.5f / dt) * (np - pp);
+  const float sv = sqrtf(dot(vel, vel));
+  if (sv >= 1e-3f) {
+    const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
+    const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
+    const float sv2 = sv * sv;
+    const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
+    const f3 og = gsum - dot(nv, gsum) * nv;
+    const f3 oc = curv - dot(nv, curv) * nv;
+    gsum = sv * (og - dsum * oc);
+    dsum = sv * dsum;
   }
-  return pen;
 }
 
-__device__ __forceinline__ f3 quat_rot(float qw, float qx, float qy, float qz, f3 v) {  // warp quat_rotate
-  const f3 q = make_f3(qx, qy, qz);
-  const float c = 2.0f * qw * qw - 1.0f, d = 2.0f * dot(q, v);
-  const f3 cr = cross(q, v);
-  return make_f3(v.x * c + q.x * d + cr.x * 2.0f * qw, v.y * c + q.y * d + cr.y * 2.0f * qw, v.z * c + q.z * d + cr.z * 2.0f * qw);
-}
-
+// The mesh share of the scene cost, packed like scene_collision_packed_kernel: every lane first runs the cheap part for
+// ITS sphere -- transform into each mesh's frame + the result-preserving bounding-box reject -- , the workgroup compacts
+// the surviving (sphere, mesh slot) items into an LDS queue (sphere-major, slot ascending) and evaluates the queue
+// densely, 256 items per round (one tree walk per lane, whichever sphere it belongs to); every sphere then adds ITS items
+// in queue order, i.e. in slot order: the same sums as a per-sphere loop over the slots, no atomics.  With one sphere per
+// lane and the slot loop in-lane (the first version) a wavefront walked trees as long as ANY of its 64 spheres was near
+// any mesh, one sample after the other: 1 859 us per C2-size batch.
 template <int SWEEP>
 __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCollArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 256;
   const long total = (long)a.batch * a.horizon * a.nspheres;
-  const long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (sidx >= total) return;
-  const int b = (int)(sidx / ((long)a.horizon * a.nspheres));
-  const int h = (int)((sidx - (long)b * a.horizon * a.nspheres) / a.nspheres);
-  const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
+  const long sidx0 = (long)blockIdx.x * NT;
+  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
+  const long sidx = sidx0 + tid;
+  const int hs = a.horizon * a.nspheres;
+  // LDS: sphere stash [3][256] float4 | results [256] float4 | prefix [256 + 8] int | queue [256 * nslots] u16
+  float4 *stash = reinterpret_cast<float4 *>(smem);
+  float4 *res = stash + 3 * NT;
+  int *prefix = reinterpret_cast<int *>(res + NT);
+  uint16_t *queue = reinterpret_cast<uint16_t *>(prefix + NT + 8);
+  const bool in = sidx < total;
+  const int b = in ? (int)(sidx / hs) : 0;
+  const int h = in ? (int)((sidx - (long)b * hs) / a.nspheres) : 0;
+  const int env = (in && a.use_multi_env) ? a.env_query_idx[b] : 0;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
-  const float4 s = sph[sidx];
-  const float w = a.weight[0], eta = a.eta[0];
-  float dsum = 0.0f;
-  f3 gsum = make_f3(0.f, 0.f, 0.f);
   const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;  // neighbours feed the sweep and the speed metric
-  const bool nb_prev = need_nb && h > 0, nb_next = need_nb && h < a.horizon - 1;
-  const bool has_prev = SWEEP > 0 && nb_prev, has_next = SWEEP > 0 && nb_next;
-  const float4 ps = nb_prev ? sph[sidx - a.nspheres] : s, ns = nb_next ? sph[sidx + a.nspheres] : s;
-  const f3 center = make_f3(s.x, s.y, s.z), pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
-  if (s.w >= 0.0f) {
+  const bool nb_prev = in && need_nb && h > 0, nb_next = in && need_nb && h < a.horizon - 1;
+  float4 s = make_float4(0.f, 0.f, 0.f, -1.f), ps, ns;
+  if (in) s = sph[sidx];
+  ps = ns = s;
+  if (nb_prev) ps = sph[sidx - a.nspheres];
+  if (nb_next) ns = sph[sidx + a.nspheres];
+  stash[tid] = s; stash[NT + tid] = ps; stash[2 * NT + tid] = ns;
+  const float w = a.weight[0], eta = a.eta[0];
+  const curobo_hip_mesh_set &ms = a.set;
+  // ---- phase 1: which slots survive the bounding-box reject for my sphere
+  uint32_t live = 0u;
+  if (in && s.w >= 0.0f) {
+    const f3 center = make_f3(s.x, s.y, s.z);
     const float r_adj = s.w + eta;
     float half_w_prev = 0.0f, half_w_next = 0.0f;
     if (SWEEP > 0) {
-      if (has_prev) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
-      if (has_next) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+      if (nb_prev) { const f3 dd = make_f3(ps.x, ps.y, ps.z) - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+      if (nb_next) { const f3 dd = make_f3(ns.x, ns.y, ns.z) - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
     }
     const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
-    const curobo_hip_mesh_set &ms = a.set;
-    const int count = ms.count[env];
-    for (int o = 0; o < ms.max_n; o++) {
-      const int flat = env * ms.max_n + o;
-      if (o >= count || ms.enable[flat] != 1) continue;  // is_obs_enabled (data_mesh.py:555-575)
-      const curobo_hip_mesh m = ms.meshes[ms.mesh_id[flat]];
-      const float *ip = ms.inv_pose + (size_t)flat * 8;  // x y z qw qx qy qz pad: world -> mesh frame
-      const f3 t = make_f3(ip[0], ip[1], ip[2]);
-      const float qw = ip[3], qx = ip[4], qy = ip[5], qz = ip[6];
-      const float *dm = ms.dims + (size_t)flat * 4;
-      // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
-      const float max_distance = fmaxf(0.5f * sqrtf(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]), r_adj);
-      const f3 lc = quat_rot(qw, qx, qy, qz, center) + t;
-      // Early reject (result preserving): the surface lies inside the mesh's bounding box (root of the tree), so the
-      // signed distance of a point outside the box is at least its distance to the box; when that exceeds
-      // r_adj + the half sweep length (+ rounding) neither the centre nor any sweep sample can penetrate.
-      {
-        const float *rb = m.node_box + 8;
-        const float ex = fmaxf(fmaxf(rb[0] - lc.x, lc.x - rb[4]), 0.0f), ey = fmaxf(fmaxf(rb[1] - lc.y, lc.y - rb[5]), 0.0f),
-                    ez = fmaxf(fmaxf(rb[2] - lc.z, lc.z - rb[6]), 0.0f);
-        const float thr = r_adj + reach;
-        if (ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f) continue;
-      }
-      float cost_sum = 0.0f;
-      f3 grad_local = make_f3(0.f, 0.f, 0.f);
-      f3 g_c;
-      float c_c, gs_c;
-      const float pen_c = mesh_point_terms(m, lc, max_distance, r_adj, eta, c_c, gs_c, g_c, ms.gradient_mode);
-      if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; }
-      const float sdf_c = r_adj - pen_c;
-      if (SWEEP > 0) {  // wp_sweep_collision_kernel.py:176-254
-#pragma unroll 1
-        for (int dir = 0; dir < 2; dir++) {
-          if (!(dir == 0 ? has_prev : has_next)) continue;
-          // sweep culling (result preserving, as for cuboids: scene_device.hpp): every sample lies within the half
-          // segment length of the centre and the signed distance is 1-Lipschitz, so a centre that is clear by more
-          // than that cannot have a penetrating sample (no bound when the centre found no surface within max_distance)
-          if (sdf_c < max_distance && -pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + 2e-6f + 1e-6f * max_distance) continue;
-          const f3 ln = quat_rot(qw, qx, qy, qz, dir == 0 ? pp : np) + t;
-          const f3 dd = ln - lc;
-          const float half_dist = sqrtf(dot(dd, dd)) * 0.5f;
-          const float inv_half = 1.0f / fmaxf(half_dist, 0.001f);
-          float jump = 0.0f;
-          if (jump >= half_dist) continue;
-          // k = 0 of the reference's loop samples t = 1, the centre itself: its terms are added again, not walked again
-          if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; jump += pen_c; }
-          else if (-pen_c >= 1000.0f) jump += r_adj;
-          else jump += fmaxf(-pen_c, r_adj);
-          for (int k = 1; k < SWEEP; k++) {
-            if (jump >= half_dist) break;
-            const float tt = 1.0f - 0.5f * jump * inv_half;
-            const f3 lp = tt * lc + (1.0f - tt) * ln;
-            const float p2 = mesh_eval_point(m, lp, max_distance, r_adj, eta, cost_sum, grad_local, ms.gradient_mode);
-            if (p2 > 0.0f) jump += p2;
-            else if (-p2 >= 1000.0f) jump += r_adj;
-            else jump += fmaxf(-p2, r_adj);
-          }
-        }
-      }
-      if (cost_sum > 0.0f) {
-        const f3 gw = quat_rot(qw, -qx, -qy, -qz, grad_local);  // transform_vector(transform_inverse(inv_t), .)
-        dsum += w * cost_sum;
-        gsum = gsum + w * gw;
-      }
+    for (int k = 0; k < a.nslots; k++) {
+      const MeshSlot slot = load_mesh_slot(ms, env, a.slot0 + k);
+      if (!slot.enabled) continue;
+      if (!mesh_early_reject(slot, mesh_to_local(slot, center), r_adj, reach)) live |= 1u << k;
     }
   }
+  // ---- exclusive prefix of the item counts over the workgroup
+  const int cnt = __builtin_popcount(live);
+  int inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(inc, off, 64);
+    if (lane64 >= off) inc += v;
+  }
+  if (lane64 == 63) prefix[NT + wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int wv = 0; wv < wave; wv++) base += prefix[NT + wv];
+  const int n_items = prefix[NT] + prefix[NT + 1] + prefix[NT + 2] + prefix[NT + 3];
+  const int my_first = base + inc - cnt;
+  {
+    uint32_t m = live;
+    int at = my_first;
+    while (m) {
+      const int k = __ffs((int)m) - 1;
+      m &= m - 1;
+      queue[at++] = (uint16_t)(tid | (k << 8));
+    }
+  }
+  float dsum = 0.0f;
+  f3 gsum = make_f3(0.f, 0.f, 0.f);
+  // ---- phase 2: dense evaluation, 256 items per round; owners add their items of the round in queue order
+  for (int q0 = 0; q0 < n_items; q0 += NT) {
+    __syncthreads();  // queue complete (first round) / results of the previous round consumed
+    const int q = q0 + tid;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < n_items) {
+      CUROBO_MESH_COUNT(6, 1);
+      const unsigned e = queue[q];
+      const int owner = (int)(e & 255u), k = (int)(e >> 8);
+      const long osidx = sidx0 + owner;
+      const int ob = (int)(osidx / hs);
+      const int oh = (int)((osidx - (long)ob * hs) / a.nspheres);
+      const int oenv = a.use_multi_env ? a.env_query_idx[ob] : 0;
+      const float4 cs = stash[owner], cp = stash[NT + owner], cn = stash[2 * NT + owner];
+      const MeshSlot slot = load_mesh_slot(ms, oenv, a.slot0 + k);
+      const f3 center = make_f3(cs.x, cs.y, cs.z), pp = make_f3(cp.x, cp.y, cp.z), np = make_f3(cn.x, cn.y, cn.z);
+      const bool hp = SWEEP > 0 && oh > 0, hn = SWEEP > 0 && oh < a.horizon - 1;
+      const float r_adj = cs.w + eta;
+      float half_w_prev = 0.0f, half_w_next = 0.0f;
+      if (SWEEP > 0) {
+        if (hp) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+        if (hn) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+      }
+      const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
+      float cost_sum = 0.0f;
+      f3 grad_local = make_f3(0.f, 0.f, 0.f);
+      mesh_contribution<SWEEP>(slot, ms.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
+                               half_w_next, reach, cost_sum, grad_local);
+      if (cost_sum > 0.0f) {
+        const f3 gw = mesh_to_world_vector(slot, grad_local);
+        r4 = make_float4(w * gw.x, w * gw.y, w * gw.z, w * cost_sum);
+      }
+    }
+    res[tid] = r4;
+    __syncthreads();
+    const int lo = my_first > q0 ? my_first : q0, hi = (my_first + cnt) < (q0 + NT) ? (my_first + cnt) : (q0 + NT);
+    for (int k = lo; k < hi; k++) {
+      const float4 v = res[k - q0];
+      if (v.w > 0.0f) { dsum += v.w; gsum = gsum + make_f3(v.x, v.y, v.z); }
+    }
+  }
+  if (!in) return;
+  // the speed metric is linear in (cost, gradient): scaling this kind's share on its own and adding it to what the scene
+  // launch wrote (accumulate) gives the same sums as the reference's one scaling pass over all kinds (wp_autograd.py:
+  // 213-231) -- except for its `cost > 0` guard, which the sum passes whenever a share does
+  if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f)
+    mesh_speed_metric(make_f3(s.x, s.y, s.z), make_f3(ps.x, ps.y, ps.z), make_f3(ns.x, ns.y, ns.z), a.speed_dt[0], dsum, gsum);
   float4 *grad = reinterpret_cast<float4 *>(a.gradient);
   if (a.accumulate) {
-    // the other obstacle kinds were written (and, when on, speed scaled) by the scene launch before this one: the speed
-    // metric is linear in (cost, gradient), so scaling this kind's share on its own and adding gives the same sums as the
-    // reference's one scaling pass over all kinds (wp_autograd.py:213-231) -- except for its `cost > 0` guard, which the
-    // sum passes whenever a share does
     if (dsum > 0.0f) {
-      if (a.enable_speed_metric && h > 0 && h < a.horizon - 1) {
-        float dt = a.speed_dt[0];
-        if (dt < 1e-6f) dt = 1e-6f;
-        const f3 vel = (0.5f / dt) * (np - pp);
-        const float sv = sqrtf(dot(vel, vel));
-        if (sv >= 1e-3f) {
-          const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
-          const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
-          const float sv2 = sv * sv;
-          const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
-          const f3 og = gsum - dot(nv, gsum) * nv;
-          const f3 oc = curv - dot(nv, curv) * nv;
-          gsum = sv * (og - dsum * oc);
-          dsum = sv * dsum;
-        }
-      }
       a.distance[sidx] += dsum;
       const float4 g0 = grad[sidx];
       grad[sidx] = make_float4(g0.x + gsum.x, g0.y + gsum.y, g0.z + gsum.z, g0.w);
     }
     return;
   }
-  if (a.enable_speed_metric && h > 0 && h < a.horizon - 1 && dsum > 0.0f) {
-    float dt = a.speed_dt[0];
-    if (dt < 1e-6f) dt = 1e-6f;
-    const f3 vel = (0.5f / dt) * (np - pp);
-    const float sv = sqrtf(dot(vel, vel));
-    if (sv >= 1e-3f) {
-      const f3 acc = (1.0f / (dt * dt)) * (pp + np - 2.0f * center);
-      const f3 nv = make_f3(vel.x / sv, vel.y / sv, vel.z / sv);
-      const float sv2 = sv * sv;
-      const f3 curv = make_f3(acc.x / sv2, acc.y / sv2, acc.z / sv2);
-      const f3 og = gsum - dot(nv, gsum) * nv;
-      const f3 oc = curv - dot(nv, curv) * nv;
-      gsum = sv * (og - dsum * oc);
-      dsum = sv * dsum;
-    }
-  }
   a.distance[sidx] = dsum;
   grad[sidx] = make_float4(gsum.x, gsum.y, gsum.z, 0.0f);
+}
+
+// The same launch split in two (curobo_hip_sphere_mesh_collision_ws): spheres that survive the bounding-box reject for ANY
+// slot are rare -- 0.06 of them on the C2 shapes -- and sit in a few places of the batch (the links near an obstacle), so
+// even the workgroup-level packing above leaves most workgroups idle while a few walk trees for hundreds of
+// microseconds.  (1) select: the cheap part for every sphere; survivors go to ONE queue of the launch (a workgroup
+// reserves its run with one atomic: order inside a run = sphere order), the others get their zeros; (2) walk: the queue
+// evaluated densely by a grid sized for the chip, one live sphere per lane, its slots in ascending order in-lane (the sums
+// of the one-launch form), outputs written by that lane.  The queue holds at most one entry per sphere: it cannot
+// overflow.
+struct MeshQueueArgs {
+  MeshCollArgs c;
+  uint32_t *counter;  // workspace word 0
+  uint2 *queue;       // workspace + 16 bytes: (sphere index, live slot mask)
+};
+
+template <int SWEEP>
+__global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueueArgs qa) {
+  __shared__ int wave_cnt[4];
+  __shared__ uint32_t run_base;
+  const MeshCollArgs &a = qa.c;
+  const long total = (long)a.batch * a.horizon * a.nspheres;
+  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
+  const long sidx = (long)blockIdx.x * 256 + tid;
+  const int hs = a.horizon * a.nspheres;
+  const bool in = sidx < total;
+  const int b = in ? (int)(sidx / hs) : 0;
+  const int h = in ? (int)((sidx - (long)b * hs) / a.nspheres) : 0;
+  const int env = (in && a.use_multi_env) ? a.env_query_idx[b] : 0;
+  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
+  uint32_t live = 0u;
+  if (in) {
+    const float4 s = sph[sidx];
+    if (s.w >= 0.0f) {
+      const f3 center = make_f3(s.x, s.y, s.z);
+      const float r_adj = s.w + a.eta[0];
+      float reach = 2e-6f;
+      if (SWEEP > 0) {
+        float half_w_prev = 0.0f, half_w_next = 0.0f;
+        if (h > 0) { const float4 ps = sph[sidx - a.nspheres]; const f3 dd = make_f3(ps.x, ps.y, ps.z) - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+        if (h < a.horizon - 1) { const float4 ns = sph[sidx + a.nspheres]; const f3 dd = make_f3(ns.x, ns.y, ns.z) - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+        reach = fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f;
+      }
+      for (int k = 0; k < a.nslots; k++) {
+        const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
+        if (!slot.enabled) continue;
+        if (!mesh_early_reject(slot, mesh_to_local(slot, center), r_adj, reach)) live |= 1u << k;
+      }
+    }
+    if (live == 0u && !a.accumulate) {
+      a.distance[sidx] = 0.0f;
+      reinterpret_cast<float4 *>(a.gradient)[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const unsigned long long ball = __ballot(live != 0u);
+  const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
+  if (lane64 == 0) wave_cnt[wave] = __builtin_popcountll(ball);
+  __syncthreads();
+  if (tid == 0) {
+    const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    run_base = n ? atomicAdd(qa.counter, (uint32_t)n) : 0u;
+  }
+  __syncthreads();
+  if (live != 0u) {
+    int at = before;
+    for (int wv = 0; wv < wave; wv++) at += wave_cnt[wv];
+    qa.queue[run_base + (uint32_t)at] = make_uint2((uint32_t)sidx, live);
+  }
+}
+
+// ---- the walk kernel: one live sphere per lane, its slots in ascending order in-lane, every sample of a slot through the
+// one query site of mesh_contribution.  (Measured and dropped: the same work as ONE loop in which every lane runs its own
+// program -- an explicit state machine around a walker shared by the closest-point and the ray mode, leaves one triangle per
+// iteration, lanes refilled from the queue.  It keeps every lane busy, and executes the union of all states' code in every
+// iteration: 334 M VALU + 233 M SALU wave-instructions per launch for 8 M node visits, 2.3 - 2.6 ms.  What the nested form
+// needs instead is few, tight loops: one walk site, no sign rays -- mesh_device.hpp.)
+template <int SWEEP>
+__global__ void __launch_bounds__(256) sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
+  const MeshCollArgs &a = qa.c;
+  const uint32_t n = qa.counter[0];
+  const int hs = a.horizon * a.nspheres;
+  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
+  const float w = a.weight[0], eta = a.eta[0];
+  for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n; q += gridDim.x * 256u) {
+    const uint2 e = qa.queue[q];
+    const long sidx = (long)e.x;
+    const int b = (int)(sidx / hs);
+    const int h = (int)((sidx - (long)b * hs) / a.nspheres);
+    const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
+    const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;
+    const bool nb_prev = need_nb && h > 0, nb_next = need_nb && h < a.horizon - 1;
+    const float4 s = sph[sidx];
+    const float4 ps = nb_prev ? sph[sidx - a.nspheres] : s, ns = nb_next ? sph[sidx + a.nspheres] : s;
+    const f3 center = make_f3(s.x, s.y, s.z), pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
+    const bool hp = SWEEP > 0 && nb_prev, hn = SWEEP > 0 && nb_next;
+    const float r_adj = s.w + eta;
+    float half_w_prev = 0.0f, half_w_next = 0.0f;
+    if (SWEEP > 0) {
+      if (hp) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+      if (hn) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+    }
+    const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
+    float dsum = 0.0f;
+    f3 gsum = make_f3(0.f, 0.f, 0.f);
+    uint32_t m = e.y;
+#pragma unroll 1
+    while (m) {
+      const int k = __ffs((int)m) - 1;
+      m &= m - 1;
+      const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
+      float cost_sum = 0.0f;
+      f3 grad_local = make_f3(0.f, 0.f, 0.f);
+      mesh_contribution<SWEEP>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev, half_w_next,
+                               reach, cost_sum, grad_local);
+      if (cost_sum > 0.0f) {
+        const f3 gw = mesh_to_world_vector(slot, grad_local);
+        dsum += w * cost_sum;
+        gsum = gsum + w * gw;
+      }
+    }
+    if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f) mesh_speed_metric(center, pp, np, a.speed_dt[0], dsum, gsum);
+    float4 *grad = reinterpret_cast<float4 *>(a.gradient);
+    if (a.accumulate) {
+      if (dsum > 0.0f) {
+        a.distance[sidx] += dsum;
+        const float4 g0 = grad[sidx];
+        grad[sidx] = make_float4(g0.x + gsum.x, g0.y + gsum.y, g0.z + gsum.z, g0.w);
+      }
+    } else {
+      a.distance[sidx] = dsum;
+      grad[sidx] = make_float4(gsum.x, gsum.y, gsum.z, 0.0f);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) mesh_zero_outputs_kernel(float *distance, float4 *gradient, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) { distance[i] = 0.0f; gradient[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
 }
 
 }  // namespace curobo_hip
 
 using namespace curobo_hip;
+
+#ifdef CUROBO_MESH_STATS
+CUROBO_EXPORT int curobo_hip_mesh_stats(unsigned long long *out_host8, int reset) {
+  if (out_host8 && hipMemcpyFromSymbol(out_host8, HIP_SYMBOL(g_mesh_stats), 64) != hipSuccess) return CUROBO_HIP_ERR_LAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_stats), z, 64) != hipSuccess) return CUROBO_HIP_ERR_LAUNCH; }
+  return CUROBO_HIP_OK;
+}
+CUROBO_EXPORT int curobo_hip_mesh_lane_stats(unsigned int *out_host, int reset) {  // [1 << 18]
+  if (out_host && hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_mesh_lane), sizeof(unsigned int) << 18) != hipSuccess) return CUROBO_HIP_ERR_LAUNCH;
+  if (reset) { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_mesh_lane)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned int) << 18) != hipSuccess) return CUROBO_HIP_ERR_LAUNCH; }
+  return CUROBO_HIP_OK;
+}
+#endif
 
 CUROBO_EXPORT int curobo_hip_mesh_morton_codes(int64_t *out_codes, const float *vertices, const int32_t *faces, int n_faces,
                                                const float *bounds_lo_hi_host, curobo_hip_stream_t stream) {
@@ -484,7 +471,7 @@ CUROBO_EXPORT int curobo_hip_mesh_bvh_build(float *out_tri, float *out_node_box,
 
 static int check_mesh(const curobo_hip_mesh *m, const char *what) {
   CUROBO_REQUIRE(m && m->tri && m->node_box && m->n_tri > 0 && m->n_leaves >= 1 && m->leaf_size >= 1, "%s: incomplete mesh", what);
-  // stack: the traversal pushes at most two nodes per level
+  // the stackless walks keep one bit per tree level in two 32-bit trails (mesh_device.hpp): depth <= 24 here
   CUROBO_REQUIRE(m->n_leaves <= (1 << 24), "%s: mesh too large", what);
   return CUROBO_HIP_OK;
 }
@@ -516,11 +503,11 @@ CUROBO_EXPORT int curobo_hip_mesh_esdf_bake_bvh(uint16_t *out_esdf_fp16, const c
   return check_launch(what, (hipStream_t)stream);
 }
 
-CUROBO_EXPORT int curobo_hip_sphere_mesh_collision(
-    float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
+static int sphere_mesh_collision_impl(
+    const char *what, float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
     const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres, int use_multi_env,
-    int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate, curobo_hip_stream_t stream) {
-  const char *what = "sphere_mesh_collision";
+    int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate, void *workspace, size_t workspace_bytes,
+    curobo_hip_stream_t stream) {
   CUROBO_REQUIRE(distance && gradient && spheres && meshes && weight && activation_distance, "%s: NULL argument", what);
   CUROBO_REQUIRE(sweep_steps == 0 || sweep_steps == 3, "%s: sweep_steps must be 0 or 3 (reference SWEEP_STEPS)", what);
   CUROBO_REQUIRE(!use_multi_env || env_query_idx, "%s: use_multi_env needs env_query_idx", what);
@@ -528,14 +515,74 @@ CUROBO_EXPORT int curobo_hip_sphere_mesh_collision(
   CUROBO_REQUIRE(meshes->max_n == 0 || (meshes->meshes && meshes->mesh_id && meshes->inv_pose && meshes->dims && meshes->enable && meshes->count),
                  "%s: incomplete mesh set", what);
   const long total = (long)batch_size * horizon * num_spheres;
-  if (total == 0 || meshes->max_n == 0) return CUROBO_HIP_OK;
+  if (total == 0) return CUROBO_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)ceil_div_l(total, 256)), block(256);
+  if (meshes->max_n == 0) {  // no mesh slots: this kind's share is zero -- which an overwriting launch still has to write
+    if (!accumulate) hipLaunchKernelGGL(mesh_zero_outputs_kernel, grid, block, 0, st, distance, reinterpret_cast<float4 *>(gradient), total);
+    return check_launch(what, st);
+  }
   MeshCollArgs a{};
   a.distance = distance; a.gradient = gradient; a.spheres = spheres; a.set = *meshes; a.weight = weight; a.eta = activation_distance;
   a.speed_dt = speed_dt; a.env_query_idx = env_query_idx; a.batch = batch_size; a.horizon = horizon; a.nspheres = num_spheres;
-  a.use_multi_env = use_multi_env; a.enable_speed_metric = enable_speed_metric; a.accumulate = accumulate;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)ceil_div_l(total, 256)), block(256);
-  if (sweep_steps > 0) hipLaunchKernelGGL((sphere_mesh_collision_kernel<3>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((sphere_mesh_collision_kernel<0>), grid, block, 0, st, a);
+  a.use_multi_env = use_multi_env; a.enable_speed_metric = enable_speed_metric;
+  const bool queued = workspace != nullptr;
+  if (queued) {
+    CUROBO_REQUIRE(total < (1l << 31), "%s: the queued form indexes spheres with 32 bits", what);
+    CUROBO_REQUIRE(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 16 + (size_t)total * sizeof(uint2),
+                   "%s: workspace too small or misaligned (curobo_hip_sphere_mesh_collision_ws_bytes)", what);
+  }
+  // 32 obstacle slots per launch (the live mask of a sphere); further groups add to the first one's output
+  for (int slot0 = 0; slot0 < meshes->max_n; slot0 += kMeshSlotsPerLaunch) {
+    a.slot0 = slot0;
+    a.nslots = std::min(kMeshSlotsPerLaunch, meshes->max_n - slot0);
+    a.accumulate = (accumulate || slot0 > 0) ? 1 : 0;
+    if (queued) {
+      MeshQueueArgs qa{};
+      qa.c = a; qa.counter = reinterpret_cast<uint32_t *>(workspace);
+      qa.queue = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(workspace) + 16);
+      if (hipMemsetAsync(workspace, 0, 16, st) != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot clear the queue counter", what);
+      // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
+      const unsigned walk_blocks = (unsigned)std::min<long>(1024, ceil_div_l(total, 256));
+      if (sweep_steps > 0) {
+        hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), grid, block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), block, 0, st, qa);
+      } else {
+        hipLaunchKernelGGL((sphere_mesh_select_kernel<0>), grid, block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), block, 0, st, qa);
+      }
+      continue;
+    }
+    const size_t lds = (size_t)(3 + 1) * 256 * 16 + (256 + 8) * 4 + (((size_t)256 * a.nslots * 2 + 15) & ~(size_t)15);
+    if (sweep_steps > 0) hipLaunchKernelGGL((sphere_mesh_collision_kernel<3>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((sphere_mesh_collision_kernel<0>), grid, block, lds, st, a);
+  }
   return check_launch(what, st);
+}
+
+CUROBO_EXPORT int curobo_hip_sphere_mesh_collision(
+    float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
+    const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres, int use_multi_env,
+    int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate, curobo_hip_stream_t stream) {
+  return sphere_mesh_collision_impl("sphere_mesh_collision", distance, gradient, spheres, meshes, weight, activation_distance, env_query_idx,
+                                    batch_size, horizon, num_spheres, use_multi_env, sweep_steps, enable_speed_metric, speed_dt, accumulate,
+                                    nullptr, 0, stream);
+}
+
+CUROBO_EXPORT int curobo_hip_sphere_mesh_collision_ws_bytes(int batch_size, int horizon, int num_spheres, int64_t *out_bytes_host) {
+  CUROBO_REQUIRE(out_bytes_host && batch_size >= 0 && horizon >= 0 && num_spheres >= 0, "sphere_mesh_collision_ws_bytes: bad arguments%s", "");
+  *out_bytes_host = 16 + (int64_t)batch_size * horizon * num_spheres * (int64_t)sizeof(uint2);
+  return CUROBO_HIP_OK;
+}
+
+CUROBO_EXPORT int curobo_hip_sphere_mesh_collision_ws(
+    float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
+    const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres, int use_multi_env,
+    int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate, void *workspace, size_t workspace_bytes,
+    curobo_hip_stream_t stream) {
+  const char *what = "sphere_mesh_collision_ws";
+  CUROBO_REQUIRE(workspace, "%s: NULL workspace", what);
+  return sphere_mesh_collision_impl(what, distance, gradient, spheres, meshes, weight, activation_distance, env_query_idx, batch_size, horizon,
+                                    num_spheres, use_multi_env, sweep_steps, enable_speed_metric, speed_dt, accumulate, workspace,
+                                    workspace_bytes, stream);
 }

@@ -1,0 +1,391 @@
+// mesh_device.hpp -- device functions of the triangle-mesh obstacle kind: the closest-point / sign query through the
+// linear BVH of mesh_bvh.hip and the cost of one sphere against one mesh (centre + sweep), shared by the mesh launch
+// (mesh_bvh.hip) and the fused rollout kernels (rollout_fused.hip).
+//
+// Reference: curobo/_src/geom/data/data_mesh.py:555-700 (wp.mesh_query_point per query sphere: closest surface point,
+// signed distance, unit vector to the point) and geom/collision/wp_sweep_collision_kernel.py:176-254 (the sweep).  What
+// is restated is the published contract of mesh_query_point, not Warp's BVH.
+//
+// Traversal.  The tree is a complete binary tree in heap layout (node k -> 2k, 2k + 1; mesh_bvh.hip), so a walk needs
+// no stack: the path is the node index itself.  A lane keeps two bit trails indexed by depth -- which child of a node
+// it entered first (the nearer one) and whether the other child is still owed a visit -- and finds the next node by
+// shifting the index.  Everything lives in a handful of VGPRs: the private `int stack[64]` of the first version was
+// 256 B of scratch per lane and the reason the launch ran at 0.005 of the HBM roofline.
+#pragma once
+#include "common.hpp"
+
+namespace curobo_hip {
+
+#ifdef CUROBO_MESH_STATS  // diagnostic builds only (tools/r04/mesh_stats.py): work counters of the walks
+__device__ unsigned long long g_mesh_stats[8];  // closest calls, nodes tested, triangles, ray walks, ray nodes, full queries, items
+__device__ unsigned int g_mesh_lane[1 << 18];   // per lane of the launch: nodes tested (closest + ray walks)
+#define CUROBO_MESH_COUNT(i, n)                                                                          \
+  do {                                                                                                   \
+    atomicAdd(&g_mesh_stats[i], (unsigned long long)(n));                                                \
+    if ((i) == 1 || (i) == 4) g_mesh_lane[(blockIdx.x * blockDim.x + threadIdx.x) & ((1 << 18) - 1)] += (n); \
+  } while (0)
+#else
+#define CUROBO_MESH_COUNT(i, n) do {} while (0)
+#endif
+
+struct TriRec {  // 48 bytes
+  float4 a, ab, ac;
+};
+
+__device__ __forceinline__ float box_dist2(const float4 lo, const float4 hi, f3 p) {
+  const float dx = fmaxf(fmaxf(lo.x - p.x, p.x - hi.x), 0.0f), dy = fmaxf(fmaxf(lo.y - p.y, p.y - hi.y), 0.0f),
+              dz = fmaxf(fmaxf(lo.z - p.z, p.z - hi.z), 0.0f);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// closest point of triangle (a, a + ab, a + ac) to p (Ericson, Real-Time Collision Detection 5.1.5)
+// region: 0 = the face, 1 / 2 / 3 = vertex a / b / c, 4 / 5 / 6 = edge ab / bc / ca (the order of curobo_hip_mesh.tri_pn, + 1)
+__device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac, int &region) {
+  const f3 ap = p - a;
+  const float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { region = 1; return a; }
+  const f3 b = a + ab, bp = p - b;
+  const float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { region = 2; return b; }
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) { region = 4; return a + (d1 / (d1 - d3)) * ab; }
+  const f3 c = a + ac, cp = p - c;
+  const float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { region = 3; return c; }
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) { region = 6; return a + (d2 / (d2 - d6)) * ac; }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) { region = 5; return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b); }
+  const float den = 1.0f / (va + vb + vc);
+  region = 0;  // the face region: the closest point is the projection on the triangle's plane
+  return a + (vb * den) * ab + (vc * den) * ac;
+}
+
+// ---- the closest-point walk: nearer child first, no stack.  The tree is complete and in heap layout, so the node index IS
+// the path; two bit trails indexed by depth record which child of a node was entered first and whether the other one is
+// still owed a visit.  (A walk over four grandchildren per step -- half the depth, four independent box loads -- tested
+// fewer nodes, 5.0 M instead of 7.4 M on the C2 mesh world, and was slower: the step's selection logic costs more than
+// the loads it saves.)
+__device__ __forceinline__ int mesh_walk_next(int node, uint32_t first, uint32_t &owed) {
+  while (node > 1) {
+    const int parent = node >> 1;
+    const uint32_t bit = 1u << (30 - __builtin_clz(node));  // depth of the parent
+    const int entered_first = (parent << 1) | ((first & bit) ? 1 : 0);
+    if (node == entered_first && (owed & bit)) {
+      owed &= ~bit;
+      return node ^ 1;
+    }
+    node = parent;
+  }
+  return 0;
+}
+
+// closest surface point within sqrt(best_d2) of p; returns false when there is none
+// side: +1 / -1 = p is on the outer / inner side of the surface as the feature the closest point lies on says (the face's
+// normal, or the pseudonormal of the edge / vertex when the mesh carries them), 0 = no verdict (count crossings)
+//
+// "while-while" form: every lane first walks inner nodes until it holds a leaf (or is done), THEN the leaves are tested --
+// the wavefront runs the long triangle code once per round with most lanes active, instead of in every iteration in
+// which any of its 64 lanes happened to reach a leaf.
+__device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp, int &side) {
+  side = 0;
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  bool found = false, tie = false;
+  int best_t = 0, best_region = 0;
+  uint32_t first = 0u, owed = 0u;
+  int node = 1;
+  CUROBO_MESH_COUNT(0, 1);
+  bool check_own = true;  // the node was reached as the root or as a sibling: its own box is still to be tested
+  for (;;) {
+    int leaf = -1;
+    while (node != 0 && leaf < 0) {
+      CUROBO_MESH_COUNT(1, 1);
+      if (check_own && box_dist2(box[node * 2], box[node * 2 + 1], p) > best_d2) {
+        node = mesh_walk_next(node, first, owed);
+        continue;
+      }
+      if (node >= m.n_leaves) {
+        leaf = node;
+        node = mesh_walk_next(node, first, owed);  // (its own box is tested when it is reached: the leaf may shrink the distance)
+        check_own = true;
+        continue;
+      }
+      // both children's boxes are one 64-byte line: test them here, enter the nearer one, owe the other a visit
+      const int c0 = node * 2;
+      const float4 lo0 = box[c0 * 2], hi0 = box[c0 * 2 + 1], lo1 = box[c0 * 2 + 2], hi1 = box[c0 * 2 + 3];
+      const float d0 = box_dist2(lo0, hi0, p), d1 = box_dist2(lo1, hi1, p);
+      const bool in0 = d0 <= best_d2, in1 = d1 <= best_d2;
+      if (!(in0 || in1)) {
+        node = mesh_walk_next(node, first, owed);
+        check_own = true;
+        continue;
+      }
+      const uint32_t bit = 1u << (31 - __builtin_clz(node));  // depth of this node
+      // nearer box first; a point INSIDE both boxes (every query from inside the surface, near the root) has distance
+      // zero to both: then the box whose centre is nearer (a blind choice finds a far triangle first and prunes nothing)
+      bool right_first = in1 && (!in0 || d1 < d0);
+      if (in0 && in1 && d0 == d1) {
+        const f3 c0v = make_f3(lo0.x + hi0.x, lo0.y + hi0.y, lo0.z + hi0.z) - 2.0f * p;
+        const f3 c1v = make_f3(lo1.x + hi1.x, lo1.y + hi1.y, lo1.z + hi1.z) - 2.0f * p;
+        right_first = dot(c1v, c1v) < dot(c0v, c0v);
+      }
+      first = right_first ? (first | bit) : (first & ~bit);
+      owed = (in0 && in1) ? (owed | bit) : (owed & ~bit);
+      node = c0 + (right_first ? 1 : 0);
+      check_own = false;  // just tested
+    }
+    if (leaf < 0) break;
+    const int t0 = (leaf - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+    CUROBO_MESH_COUNT(2, t1 - t0);
+    for (int t = t0; t < t1; t++) {
+      const TriRec r = tri[t];
+      int region;
+      const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+      const f3 d = p - c;
+      const float d2 = dot(d, d);
+      if (d2 <= best_d2) {
+        // (the same distance from two triangles: the closest point lies on a feature they share -- or on two separate
+        // ones; a face verdict is then not trusted)
+        tie = found && d2 == best_d2;
+        best_d2 = d2; cp = c; found = true; best_t = t; best_region = region;
+      }
+    }
+  }
+  if (found) {
+    const f3 d = p - cp;
+    const TriRec r = tri[best_t];
+    if (best_region == 0 && !tie) {
+      // the face the closest point lies in: only trusted when the point is clearly off its plane
+      const float sd = dot(d, cross(make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z)));
+      side = (best_d2 > 1e-12f && sd != 0.0f) ? (sd > 0.0f ? 1 : -1) : 0;
+    } else if (m.tri_pn != nullptr && best_region != 0 && best_d2 > 1e-12f) {
+      // an edge or a vertex: its pseudonormal (for a closed, consistently oriented surface the sign of d . n is the sign of
+      // the distance whatever the dihedral angles); a degenerate pseudonormal gives no verdict
+      const float4 n4 = reinterpret_cast<const float4 *>(m.tri_pn)[(size_t)best_t * 6 + (best_region - 1)];
+      const f3 n = make_f3(n4.x, n4.y, n4.z);
+      const float sd = dot(d, n), scale = sqrtf(dot(n, n) * best_d2);
+      side = fabsf(sd) > 1e-4f * scale ? (sd > 0.0f ? 1 : -1) : 0;
+    }
+  }
+  return found;
+}
+
+// crossings of the ray p + t d (t > 0) with the surface (fixed-order stackless walk: the order does not matter here)
+__device__ __forceinline__ int mesh_ray_crossings(const curobo_hip_mesh &m, f3 p, f3 d) {
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  const f3 inv = make_f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int hits = 0;
+  unsigned node = 1u;
+  CUROBO_MESH_COUNT(3, 1);
+  while (node != 0u) {
+    CUROBO_MESH_COUNT(4, 1);
+    const float4 lo = box[node * 2], hi = box[node * 2 + 1];
+    // slab test (an empty padding box has lo > hi: t_enter > t_exit)
+    const float tx0 = (lo.x - p.x) * inv.x, tx1 = (hi.x - p.x) * inv.x, ty0 = (lo.y - p.y) * inv.y, ty1 = (hi.y - p.y) * inv.y,
+                tz0 = (lo.z - p.z) * inv.z, tz1 = (hi.z - p.z) * inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    const bool hit = (t_in <= t_out) && !(lo.x > hi.x);
+    if (hit && node < (unsigned)m.n_leaves) { node = node * 2u; continue; }
+    if (hit) {
+      const int t0 = ((int)node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+      for (int t = t0; t < t1; t++) {  // Moeller-Trumbore
+        const TriRec r = tri[t];
+        const f3 ab = make_f3(r.ab.x, r.ab.y, r.ab.z), ac = make_f3(r.ac.x, r.ac.y, r.ac.z);
+        const f3 pv = cross(d, ac);
+        const float det = dot(ab, pv);
+        if (fabsf(det) < 1e-20f) continue;
+        const float idet = 1.0f / det;
+        const f3 tv = p - make_f3(r.a.x, r.a.y, r.a.z);
+        const float u = dot(tv, pv) * idet;
+        if (u < 0.0f || u > 1.0f) continue;
+        const f3 qv = cross(tv, ab);
+        const float v = dot(d, qv) * idet;
+        if (v < 0.0f || u + v > 1.0f) continue;
+        if (dot(ac, qv) * idet > 0.0f) hits++;
+      }
+    }
+    // next node in pre-order: leave every subtree this node is the right end of, then step to the sibling
+    node >>= __builtin_ctz(~node);
+    node = node ? (node | 1u) : 0u;
+  }
+  return hits;
+}
+
+// inside a closed mesh: the parity of surface crossings, majority of three rays in generic directions (a ray that
+// grazes an edge or a vertex may count a crossing twice or not at all; three unrelated directions do not all do)
+__device__ __forceinline__ bool mesh_inside(const curobo_hip_mesh &m, f3 p) {
+  const int a = mesh_ray_crossings(m, p, make_f3(1.0f, 0.0713f, 0.0291f)) & 1;
+  const int b = mesh_ray_crossings(m, p, make_f3(-0.0517f, 1.0f, 0.0839f)) & 1;
+  if (a == b) return a != 0;
+  return (mesh_ray_crossings(m, p, make_f3(0.0331f, -0.0617f, -1.0f)) & 1) != 0;
+}
+
+// The same signed distance, searched only as far as the caller can use it.  The cost of a sample needs the distance when
+// it is below r_adj; the sweep's step needs it when it is below r_adj + what is left of the half segment -- beyond that
+// the sample contributes nothing and the walk along the segment ends, whatever the exact value (result preserving).  So
+// the closest point is looked for within `radius` only: the traversal then prunes almost every node for a sphere that is
+// merely near the mesh's bounding box.  Nothing within `radius` means "outside, farther than radius" (returns
+// max_distance) unless the point may lie INSIDE the surface deeper than `radius`: may_be_inside (the caller knows the
+// point is not -- e.g. a sweep sample within half_dist of a centre that is outside) and the root box gate a second walk
+// without a radius, whose closest feature then says which side the point is on.  ONE walk site (a retry loop): inlined
+// copies of the walk are what the register count of the callers is made of.
+__device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp, float radius, float max_distance, bool may_be_inside,
+                                                 f3 &g) {
+  g = make_f3(0.f, 0.f, 0.f);
+  bool full = !(radius < max_distance);
+  float d2 = 0.0f;
+  f3 cp = lp;
+  int side = 0;
+  bool found = false;
+#pragma unroll 1
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const float r = full ? max_distance : radius;
+    d2 = r * r;
+    found = mesh_closest_point(m, lp, d2, cp, side);
+    if (found || full || !may_be_inside) break;
+    const float *rb = m.node_box + 8;  // root box: a point outside it is outside the (closed) surface
+    if (lp.x < rb[0] || lp.y < rb[1] || lp.z < rb[2] || lp.x > rb[4] || lp.y > rb[5] || lp.z > rb[6]) break;
+    full = true;  // inside the box, nothing within the radius: far outside in a concavity -- or deep inside
+  }
+  if (!found) return max_distance;
+  const float d = sqrtf(d2);
+  const f3 delta = lp - cp;
+  if (d > 1e-6f) g = (1.0f / d) * delta;
+  // the feature the closest point lies on says which side the point is on; without a verdict the crossings are counted
+  const bool inside = side != 0 ? side < 0 : mesh_inside(m, lp);
+  return inside ? -d : d;
+}
+
+// data_mesh.py:630-700 compute_local_sdf_with_grad: signed distance (negative inside) and the local gradient
+// (p - closest) / |p - closest| -- as the reference returns it, whatever side p is on.  No surface within max_distance:
+// (max_distance, 0).
+__device__ __forceinline__ float mesh_sdf_with_grad(const curobo_hip_mesh &m, f3 lp, float max_distance, f3 &g) {
+  return mesh_sdf_within(m, lp, max_distance, max_distance, false, g);
+}
+
+__device__ __forceinline__ void activation_m(float dist, float eta, float &cost, float &gscale) {  // wp_collision_common.py:11-38
+  if (dist > eta) { cost = dist - 0.5f * eta; gscale = 1.0f; }
+  else { cost = 0.5f * dist * dist / eta; gscale = dist / eta; }
+}
+
+__device__ __forceinline__ f3 quat_rot(float qw, float qx, float qy, float qz, f3 v) {  // warp quat_rotate
+  const f3 q = make_f3(qx, qy, qz);
+  const float c = 2.0f * qw * qw - 1.0f, d = 2.0f * dot(q, v);
+  const f3 cr = cross(q, v);
+  return make_f3(v.x * c + q.x * d + cr.x * 2.0f * qw, v.y * c + q.y * d + cr.y * 2.0f * qw, v.z * c + q.z * d + cr.z * 2.0f * qw);
+}
+
+// one obstacle slot of a mesh set as the kernels consume it
+struct MeshSlot {
+  curobo_hip_mesh m;
+  f3 t;
+  float qw, qx, qy, qz, max_half_diag;
+  bool enabled;
+};
+__device__ __forceinline__ MeshSlot load_mesh_slot(const curobo_hip_mesh_set &ms, int env, int o) {
+  MeshSlot s;
+  const int flat = env * ms.max_n + o;
+  s.enabled = o < ms.count[env] && ms.enable[flat] == 1;  // is_obs_enabled (data_mesh.py:555-575)
+  s.m = ms.meshes[s.enabled ? ms.mesh_id[flat] : 0];
+  const float *ip = ms.inv_pose + (size_t)flat * 8;  // x y z qw qx qy qz pad: world -> mesh frame
+  s.t = make_f3(ip[0], ip[1], ip[2]);
+  s.qw = ip[3]; s.qx = ip[4]; s.qy = ip[5]; s.qz = ip[6];
+  const float *dm = ms.dims + (size_t)flat * 4;
+  s.max_half_diag = 0.5f * sqrtf(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]);
+  return s;
+}
+__device__ __forceinline__ f3 mesh_to_local(const MeshSlot &s, f3 v) { return quat_rot(s.qw, s.qx, s.qy, s.qz, v) + s.t; }
+
+// Early reject (result preserving): the surface lies inside the mesh's bounding box (root of the tree), so the signed
+// distance of a point outside the box is at least its distance to the box; when that exceeds r_adj + the half sweep
+// length (+ rounding) neither the centre nor any sweep sample can penetrate.
+__device__ __forceinline__ bool mesh_early_reject(const MeshSlot &s, f3 lc, float r_adj, float reach) {
+  const float *rb = s.m.node_box + 8;
+  const float ex = fmaxf(fmaxf(rb[0] - lc.x, lc.x - rb[4]), 0.0f), ey = fmaxf(fmaxf(rb[1] - lc.y, lc.y - rb[5]), 0.0f),
+              ez = fmaxf(fmaxf(rb[2] - lc.z, lc.z - rb[6]), 0.0f);
+  const float thr = r_adj + reach;
+  return ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f;
+}
+
+// Cost and mesh-frame gradient of ONE sphere against ONE mesh that passed the early reject: the centre sample plus the
+// sweep towards the previous / next point (wp_sweep_collision_kernel.py:176-254; the mesh twin of
+// scene_device.hpp::obstacle_contribution).  lc = centre in the mesh frame, reach as for mesh_early_reject.
+template <int SWEEP>
+__device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
+                                                  f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
+                                                  float reach, float &cost_sum, f3 &grad_local) {
+  // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
+  const float max_distance = fmaxf(s.max_half_diag, r_adj);
+  // how far the centre's distance matters: its cost below r_adj, the sweep culling below r_adj + the half segment
+  const float cull_slack = 2e-6f + 1e-6f * max_distance;
+  // The samples of an item -- the centre, then up to SWEEP - 1 per direction -- are queried by ONE loop (one inlined copy of
+  // the walk; in a wavefront the lanes' i-th queries run together).  dir = -1: the centre.
+  f3 g_c = make_f3(0.f, 0.f, 0.f), ln = lc, qp = lc;
+  float sdf_c = 0.0f, pen_c = 0.0f, c_c = 0.0f, gs_c = 0.0f, half_dist = 0.0f, inv_half = 0.0f, jump = 0.0f;
+  float q_radius = (r_adj + reach + cull_slack) * 1.0001f + 1e-6f;
+  bool q_may_in = true;
+  int dir = -1, k = 0;
+#pragma unroll 1
+  for (;;) {
+    f3 g;
+    const float sdf = mesh_sdf_within(s.m, qp, q_radius, max_distance, q_may_in, g);
+    if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
+    const float pen = -sdf + r_adj;
+    float c = 0.0f, gs = 0.0f;
+    if (pen > 0.0f) {
+      activation_m(pen, eta, c, gs);
+      cost_sum += c;
+      grad_local = grad_local + gs * g;
+    }
+    if (dir < 0) { sdf_c = sdf; pen_c = pen; c_c = c; gs_c = gs; g_c = g; }
+    else {  // a sweep sample: the step along the segment (wp_sweep_collision_kernel.py:204-212)
+      if (pen > 0.0f) jump += pen;
+      else if (-pen >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen, r_adj);
+      k++;
+    }
+    if (SWEEP == 0) break;
+    // ---- the next sample to query, if any
+    bool have = false;
+#pragma unroll 1
+    while (!have) {
+      if (dir >= 0 && k < SWEEP && !(jump >= half_dist)) { have = true; break; }
+      dir++;
+      if (dir >= 2) break;
+      if (!(dir == 0 ? has_prev : has_next)) continue;
+      // sweep culling (result preserving, as for cuboids: scene_device.hpp): every sample lies within the half segment
+      // length of the centre and the signed distance is 1-Lipschitz, so a centre that is clear by more than that cannot
+      // have a penetrating sample.  (A centre that found no surface within its search radius is clear by more than any
+      // half segment -- or beyond max_distance, where the samples find nothing either.)
+      if (-pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
+      ln = mesh_to_local(s, dir == 0 ? prev_c : next_c);
+      const f3 dd = ln - lc;
+      half_dist = sqrtf(dot(dd, dd)) * 0.5f;
+      inv_half = 1.0f / fmaxf(half_dist, 0.001f);
+      jump = 0.0f;
+      k = SWEEP;  // (no sample unless the direction is entered below)
+      if (jump >= half_dist) continue;
+      // k = 0 of the reference's loop samples t = 1, the centre itself: its terms are added again, not walked again
+      if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; jump += pen_c; }
+      else if (-pen_c >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen_c, r_adj);
+      k = 1;
+    }
+    if (!have) break;
+    const float tt = 1.0f - 0.5f * jump * inv_half;
+    qp = tt * lc + (1.0f - tt) * ln;
+    // the sample's distance matters below r_adj (cost) and below r_adj + the rest of the half segment (next step);
+    // it lies within half_dist of the centre, so it can only be deep inside when the centre is inside
+    q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
+    q_may_in = sdf_c < half_dist;
+  }
+}
+
+__device__ __forceinline__ f3 mesh_to_world_vector(const MeshSlot &s, f3 v) {  // transform_vector(transform_inverse(inv_t), .)
+  return quat_rot(s.qw, -s.qx, -s.qy, -s.qz, v);
+}
+
+}  // namespace curobo_hip

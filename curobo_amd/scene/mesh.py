@@ -83,7 +83,7 @@ class MeshStore:
         self._mesh_structs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device).contiguous()
         self.max_n, self.num_envs = n, E
         self.struct = MeshSet(self._mesh_structs.data_ptr(), self.mesh_id.data_ptr(), self.dims.data_ptr(), self.inv_pose.data_ptr(),
-                              self.enable.data_ptr(), self.count.data_ptr(), n, int(gradient_mode))
+                              self.enable.data_ptr(), self.count.data_ptr(), n, int(gradient_mode), E, 0)
         self.envs = envs
 
     def _slot(self, name: str, env_idx: int) -> int:

@@ -197,6 +197,11 @@ int curobo_hip_mesh_esdf_bake(uint16_t *out_esdf_fp16, const float *vertices, co
 typedef struct curobo_hip_mesh {
   const float *tri;
   const float *node_box;
+  /* optional (ABI 5): [n_tri][6][4] floats in the sorted triangle order = the angle-weighted pseudonormals of the triangle's
+   * vertices a, b, c and the edge pseudonormals of ab, bc, ca (sum of the normals of the faces that share the feature;
+   * Baerentzen & Aanaes 2005).  The sign of a query whose closest point lies on an edge or a vertex is the sign of
+   * (point - closest) . pseudonormal; NULL = count ray crossings instead (three tree walks per such query). */
+  const float *tri_pn;
   int32_t n_tri, n_leaves, leaf_size, _pad;
 } curobo_hip_mesh;
 
@@ -214,6 +219,7 @@ typedef struct curobo_hip_mesh_set {
   const uint8_t *enable;
   const int32_t *count;
   int32_t max_n, gradient_mode;
+  int32_t num_envs, _pad;  /* leading dimension of mesh_id / dims / inv_pose / enable / count (ABI 5) */
 } curobo_hip_mesh_set;
 
 /* Build: (1) Morton keys of the triangle centroids inside bounds_lo_hi_host (HOST pointer, 6 floats: the mesh's bounding
@@ -246,6 +252,18 @@ int curobo_hip_sphere_mesh_collision(
     const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres,
     int use_multi_env, int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate,
     curobo_hip_stream_t stream);
+
+/* The same launch with a caller-owned device workspace (>= curobo_hip_sphere_mesh_collision_ws_bytes(...) bytes, 16-byte
+ * aligned, contents irrelevant; the size is written to the HOST pointer out_bytes_host): the spheres that survive the bounding-box reject of any mesh -- few, and clustered in the
+ * batch -- are queued launch-wide and their tree walks run on a grid that covers the chip once, instead of inside the
+ * workgroups that happen to hold them.  Same results (per sphere the slots are summed in ascending order in both forms);
+ * two kernels + one 16-byte memset on `stream`, graph-capturable. */
+int curobo_hip_sphere_mesh_collision_ws_bytes(int batch_size, int horizon, int num_spheres, int64_t *out_bytes_host);
+int curobo_hip_sphere_mesh_collision_ws(
+    float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
+    const float *activation_distance, const int32_t *env_query_idx, int batch_size, int horizon, int num_spheres,
+    int use_multi_env, int sweep_steps, int enable_speed_metric, const float *speed_dt, int accumulate, void *workspace,
+    size_t workspace_bytes, curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- cost: tool pose + c-space
  * The reference runs these as NVIDIA Warp kernels without a backend hook:

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), f"libcurobo_hip.so does not export {n}"
-    assert lib.curobo_hip_abi_version() == 4
+    assert lib.curobo_hip_abi_version() == 5
     assert isinstance(lib.curobo_hip_last_error(), bytes)
 
 
@@ -30,7 +30,8 @@ def test_header_signatures_are_plain_c():
                          "curobo_hip_launch_lbfgs_step", "curobo_hip_launch_line_search"}
     for name, args in sigs.items():
         for a in args:
-            assert a in (ctypes.c_void_p, ctypes.c_int, ctypes.c_float), (name, a)
+            # plain pointers, ints, floats and sizes (size_t / int64_t byte counts): nothing a C FFI cannot bind
+            assert a in (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64), (name, a)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04_call8; mkdir -p $O
+cp curobo_amd/lib/variants/libcurobo_hip_meshstats.so curobo_amd/lib/libcurobo_hip.so
+python tools/r04/mesh_stats.py 2>&1 | grep -v amdgpu.ids | tee -a $O/mesh_stats.txt

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04_call9; mkdir -p $O
+python -m pytest tests/test_gpu_mesh.py -q -m gpu > $O/mesh_tests.log 2>&1; tail -3 $O/mesh_tests.log
+python tools/r04/mesh_stats.py 2>&1 | grep -v amdgpu.ids | tee $O/mesh_stats.txt
+cp curobo_amd/lib/variants/libcurobo_hip_meshstats.so curobo_amd/lib/libcurobo_hip.so
+python tools/r04/mesh_stats.py 2>&1 | grep "closest\|per lane" | tee -a $O/mesh_stats.txt
