@@ -73,6 +73,11 @@ def parse_args():
     ap.add_argument("--ik-seeds", type=int, default=64)
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     ap.add_argument("--legs", action="store_true", help="also run the sharded C4 / C5 legs with one rank (they always run with --gpus > 1)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="multi-rank plumbing only: init -> all-reduce -> one global arg-min -> destroy; prints the rank count the "
+                         "collective saw, so that an RCCL / xGMI problem is told apart from a kernel problem")
+    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("CUROBO_BENCH_DIST_TIMEOUT_S", "180")),
+                    help="seconds a rank waits in a collective before it gives up (a rank that died must not hang the job)")
     return ap.parse_args()
 
 
@@ -254,14 +259,28 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # CUROBO_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test the multi-rank logic
+        import datetime
+
+        # a collective that a peer never joins raises after --dist-timeout instead of waiting forever (gloo: RuntimeError in
+        # the waiting rank; RCCL: the watchdog aborts the communicator and the rank exits)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
+        t_init = time.perf_counter()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        t_init = time.perf_counter() - t_init
         probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        t_ar = time.perf_counter()
         dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter() - t_ar
         if int(probe.item()) != world:
             raise SystemExit(f"collective over {world} ranks returned {probe.item()}")
+    if args.selftest:
+        raise SystemExit(selftest(args, world, rank, device, backend, torch, dist,
+                                  {"init_process_group_s": round(t_init, 3), "first_all_reduce_ms": round(t_ar * 1e3, 3)} if world > 1 else {}))
 
     from curobo_amd import _lib
     from curobo_amd.distributed import global_argmin
@@ -463,26 +482,98 @@ def main():
                             seeds, cfg.n_knots * kin.num_dof, ocfg.history, nls, 2.0)
                     except Exception as e:  # noqa: BLE001
                         out["cpu_baseline"]["optimizer_stage"] = {"error": f"{type(e).__name__}: {e}"}
+    world_alive = True
     if world > 1 and args.scaling == "weak":
         # the strong-scaling reading of the same job (north_star: 256 seeds in total), measured in the same launch
-        strong = strong_scaling_leg(args, world, rank, kin, scene, cfg, ocfg, model, start_t, bounds, device, backend, torch, dist)
+        strong = run_leg_on_all_ranks(
+            "strong_scaling", lambda a, w, r, d, b, t, di: strong_scaling_leg(a, w, r, kin, scene, cfg, ocfg, model, start_t, bounds, d, b, t, di),
+            args, world, rank, device, backend, torch, dist)
+        world_alive = not strong.get("fatal", False)
         if rank == 0:
             out["strong_scaling"] = strong
-    if (world > 1 or args.legs) and not args.no_configs:
+    if (world > 1 or args.legs) and not args.no_configs and world_alive:
         # BASELINE configs 4 and 5 are multi-GPU jobs: their sharded legs (every rank runs them; rank 0 reports)
         legs = {}
         for key, fn in (("c4_humanoid_seed_shard", c4_sharded_leg), ("c5_batch_planner_problem_shard", c5_sharded_leg)):
-            try:
-                legs[key] = fn(args, world, rank, device, backend, torch, dist)
-            except Exception as e:  # noqa: BLE001  (every rank fails alike: shapes do not depend on the rank)
-                legs[key] = {"error": f"{type(e).__name__}: {e}"}
+            legs[key] = run_leg_on_all_ranks(key, fn, args, world, rank, device, backend, torch, dist)
+            if legs[key].get("fatal"):  # the process group is gone: no further collective may be entered
+                world_alive = False
+                break
         if rank == 0:
             out["multi_gpu_legs"] = legs
+    if rank == 0:  # the line goes out BEFORE the last barrier: a peer that died must not take the measured headline with it
+        print(json.dumps(out), flush=True)
+    if world > 1 and world_alive:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: teardown: {type(e).__name__}: {e}", file=sys.stderr)
+
+
+def run_leg_on_all_ranks(key, fn, args, world, rank, device, backend, torch, dist):
+    """One sharded leg on every rank, with the outcome AGREED over the ranks.  A per-rank try / except alone can deadlock: a
+    rank that fails (an RCCL / HSA error, an out-of-memory) leaves its peers inside the leg's next collective.  Here every
+    collective carries the process group's timeout (``--dist-timeout``), so the peers of a failed rank come back with an
+    error of their own; then all ranks all-reduce an error flag and report the leg as failed together.  If even that
+    all-reduce fails the group is unusable: ``fatal`` tells the caller to enter no further collective."""
+    err = None
+    res = None
+    try:
+        if os.environ.get("CUROBO_BENCH_FAIL_LEG") == f"{key}:{rank}":  # test hook: this rank fails before its first collective
+            raise RuntimeError(f"injected failure of {key} on rank {rank}")
+        res = fn(args, world, rank, device, backend, torch, dist)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if world == 1:
+        return res if err is None else {"error": err}
+    try:
+        flag = torch.tensor([0.0 if err is None else 1.0, float(rank) if err is not None else -1.0],
+                            device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed, who = bool(flag[0].item() > 0.5), int(flag[1].item())
+    except Exception as e:  # noqa: BLE001
+        return {"error": err or f"{type(e).__name__}: {e}", "fatal": True,
+                "note": "the error flag could not be exchanged: the process group is unusable, remaining legs skipped"}
+    if failed:
+        return {"error": err or f"a peer failed (highest failing rank: {who})", "failed_rank": who}
+    return res
+
+
+def selftest(args, world, rank, device, backend, torch, dist, timings):
+    """``--selftest``: the multi-rank plumbing without any benchmark kernel: init (done by the caller) -> all-reduce ->
+    one ``global_argmin`` (the path's one exchange: an all-gather of a packed row per rank) -> barrier -> destroy."""
+    from curobo_amd.distributed import global_argmin
+
+    out = {"selftest": True, "backend": "RCCL (torch 'nccl')" if backend == "nccl" else backend, "world_size_env": world,
+           "devices_visible": torch.cuda.device_count(), **timings}
     if world > 1:
+        cdev = device if backend == "nccl" else "cpu"
+        ones = torch.ones(1, device=cdev)
+        dist.all_reduce(ones)
+        out["ranks_counted_by_all_reduce"] = int(ones.item())
+        # rank r offers cost 10 - r for its second seed: the winner must be the last rank's seed 1, global index 2 (W - 1) + 1
+        cost = torch.tensor([[20.0, 10.0 - rank]], device=device)
+        payload = torch.full((1, 2, 3), float(rank), device=device)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            c, i, x = global_argmin(cost, payload, rank * 2)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        ok = int(i[0].item()) == 2 * (world - 1) + 1 and abs(float(c[0].item()) - (10.0 - (world - 1))) < 1e-6 and \
+            float(x[0, 0].item()) == float(world - 1)
+        out["global_argmin_ok"] = bool(ok)
+        out["global_argmin_ms_median"] = round(float(np.median(lat)) * 1e3, 4)
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        out["ranks_counted_by_all_reduce"] = 1
+        out["global_argmin_ok"] = True
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    return 0 if out["global_argmin_ok"] and out["ranks_counted_by_all_reduce"] == world else 1
 
 
 def _timed_sharded(step, exchange, steps, warmup, world, device, backend, torch, dist, blocks=7):
@@ -640,9 +731,23 @@ def strong_scaling_leg(args, world, rank, kin, scene, cfg, ocfg, model, start_t,
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         blocks.append(float(tt.item()))
     el = float(np.median(blocks))
-    return {"scaling": "strong", "total_seeds": total_seeds, "seeds_per_gpu": seeds, "streams_per_gpu": 1,
+    # the exchange alone (local best row + all-gather + arg-min): what a solve pays once, whatever its iteration count
+    ex = []
+    for _ in range(25):
+        sync_all()
+        t0 = time.perf_counter()
+        global_argmin(opt.best_cost.view(1, -1), opt.best_action.view(1, seeds, -1), rank * seeds)
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ex.append(float(tt.item()))
+    return {"scaling": "strong", "total_seeds": total_seeds, "seeds_per_gpu": seeds, "streams_per_gpu": 1, "n_gpus": world,
             "value": round(total_seeds * nls * args.steps / el, 1), "unit": "rollouts/s",
-            "ms_per_step": round(el / args.steps * 1e3, 5), "blocks": len(blocks)}
+            "ms_per_step": round(el / args.steps * 1e3, 5), "blocks": len(blocks),
+            "exchange_ms_per_solve": round(float(np.median(ex)) * 1e3, 4),
+            "exchange": "one all_gather_into_tensor of a packed [cost, global seed index, knots] row per rank, arg-min on every rank",
+            "note": "256 seeds IN TOTAL over the ranks (north_star's >= 6x target is this value at --gpus 8 over the same field at --gpus 1: "
+                    "run `bench.py --gpus 1 --scaling strong` for the denominator); one optimiser stream per GPU"}
 
 
 # ------------------------------------------------------------------------------------------------
