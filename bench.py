@@ -856,7 +856,7 @@ def c2_roofline(args, opt, rollout, cfg, kin, seed_t, seeds, shards, nls, step_s
                                          note="the binding limit of the fused launch: it keeps every intermediate in LDS and moves "
                                               "~1 % of its algorithmic bytes through HBM, so the HBM fraction above is notional")
     # what actually bounds the fused kernel: VALU issue (committed SQ counters x the live launch time)
-    sq = committed_sq_counters(dom)
+    sq = committed_sq_counters(dom, B)
     if sq is not None:
         insts = sq["valu_wave_instructions_per_trajectory"] * B
         roof["valu_issue_frac"] = round(insts / (excl["us"] * 1e-6) / VALU_ISSUE_PEAK, 4)
@@ -920,20 +920,16 @@ def counter_roofline(kernel: str, workgroups: int, live_us: float, units: int = 
     return out
 
 
-def committed_sq_counters(kernel):
-    import glob
-
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json"))):
-        try:
-            rec = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        if kernel in str(rec.get("kernel", "")) and "per_trajectory" in rec:
-            best = {"valu_wave_instructions_per_trajectory": rec["per_trajectory"]["valu_wave_instructions"],
-                    "active_inst_valu_quad_cycles_per_launch": rec.get("SQ_ACTIVE_INST_VALU"),
-                    "source": "profiles/" + os.path.basename(path)}
-    return best
+def committed_sq_counters(kernel, workgroups=0):
+    """VALU wave-instructions per trajectory (workgroup) of a fused launch from the NEWEST committed
+    ``profiles/*_counters_by_kernel.json`` (the same file every other counter figure of the line comes from)."""
+    e = committed_counters(kernel, workgroups)
+    if e is None or not e.get("counters", {}).get("SQ_INSTS_VALU") or not e.get("workgroups"):
+        return None
+    c = e["counters"]
+    return {"valu_wave_instructions_per_trajectory": round(c["SQ_INSTS_VALU"] / e["workgroups"], 1),
+            "active_inst_valu_quad_cycles_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
+            "counter_launch_workgroups": e["workgroups"], "source": e["source"]}
 
 
 def graph_launch_times(opt, G, shards, seeds, nls, seed_t, torch):
@@ -1017,13 +1013,31 @@ def mesh_benchmark(model, kin, device, torch):
     each box face subdivided) + a torus, 1024 trajectories x 33 points of robot spheres: the mesh launch
     (curobo_hip_sphere_mesh_collision, BVH walk per sphere and sweep sample) next to the cuboid kernel on the same boxes,
     BVH build time, and the ESDF bake through the BVH against the all-triangles bake."""
-    import numpy as np
-
     from curobo_amd.backends import collision as Cn
     from curobo_amd.backends.mesh import build_mesh_bvh, mesh_esdf_bake_bvh
     from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
-    from curobo_amd.scene import SceneData, box_mesh, cuboid_scene_arrays
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
     from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    world = c2_world()
+    meshes = c2_world_as_meshes()
+    n_tri = sum(len(m["faces"]) for m in meshes[0])
+    B, H = 1024, 33
+    cfg = CollisionRolloutCfg(use_fused=False)
+    out = {"workload": f"C2 shapes (1024 x 33 points x {kin.num_spheres} spheres), the {len(world[0])} cuboids of the C2 world as triangle "
+                       f"meshes ({n_tri} triangles), swept + speed metric", "triangles": n_tri}
+    x = torch.as_tensor(seed_knots(model, B, cfg.n_knots, seed=2), device=device).reshape(B, -1)
+    times = {}
+    return _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, out, x, times, Cn, build_mesh_bvh, mesh_esdf_bake_bvh,
+                                CollisionRollout, SceneData, cuboid_scene_arrays, start_configuration)
+
+
+def c2_world_as_meshes():
+    """the four cuboids of the C2 world as triangle meshes, every box face subdivided four times (3 072 triangles per box)"""
+    import numpy as np
+
+    from curobo_amd.scene import box_mesh
+    from curobo_amd.workloads import c2_world
 
     def subdivide(v, f, times):
         v = [tuple(x) for x in np.asarray(v, np.float64)]
@@ -1044,15 +1058,12 @@ def mesh_benchmark(model, kin, device, torch):
         return np.asarray(v, np.float32), f.astype(np.int32)
 
     world = c2_world()
-    meshes = [[dict(name=f"box{i}", pose=o["pose"], **dict(zip(("vertices", "faces"), subdivide(*box_mesh(o["dims"]), 4))))
-               for i, o in enumerate(world[0])]]
-    n_tri = sum(len(m["faces"]) for m in meshes[0])
-    B, H = 1024, 33
-    cfg = CollisionRolloutCfg(use_fused=False)
-    out = {"workload": f"C2 shapes (1024 x 33 points x {kin.num_spheres} spheres), the {len(world[0])} cuboids of the C2 world as triangle "
-                       f"meshes ({n_tri} triangles), swept + speed metric", "triangles": n_tri}
-    x = torch.as_tensor(seed_knots(model, B, cfg.n_knots, seed=2), device=device).reshape(B, -1)
-    times = {}
+    return [[dict(name=f"box{i}", pose=o["pose"], **dict(zip(("vertices", "faces"), subdivide(*box_mesh(o["dims"]), 4))))
+             for i, o in enumerate(world[0])]]
+
+
+def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, out, x, times, Cn, build_mesh_bvh, mesh_esdf_bake_bvh,
+                         CollisionRollout, SceneData, cuboid_scene_arrays, start_configuration):
     for key, scene in (("cuboid_kernel", SceneData.from_arrays(cuboid_scene_arrays(world), device)),
                        ("mesh_launch", SceneData.from_arrays(None, device, meshes=meshes))):
         ro = CollisionRollout(kin, scene, B, cfg)
@@ -1073,6 +1084,12 @@ def mesh_benchmark(model, kin, device, torch):
                                "hbm_frac": round(alg / times["mesh_launch"] * 1e-3 / HBM_PEAK_GBS, 4),
                                "cost_relative_to_cuboids": round(out["mesh_launch"]["cost_sum"] / max(out["cuboid_kernel"]["cost_sum"], 1e-9), 6),
                                "slowdown_vs_cuboid_kernel": round(times["mesh_launch"] / times["cuboid_kernel"], 2)})
+    out["mesh_launch"]["kernels"] = "curobo_hip_sphere_mesh_collision_ws: sphere_mesh_select_kernel<3> (bounding-box reject, queue) + sphere_mesh_walk_kernel<3>"
+    out["mesh_launch"]["kernel_counters"] = {
+        k2: (lambda e: None if e is None else {"mean_us": e.get("mean_us"), "hbm_bytes": e.get("hbm_bytes"), "valu_issue_frac": e.get("valu_issue_frac"),
+                                               "SQ_INSTS_VALU": e["counters"].get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": e["counters"].get("SQ_INSTS_SALU"),
+                                               "source": e["source"]})(committed_counters(k2))
+        for k2 in ("sphere_mesh_select_kernel", "sphere_mesh_walk_kernel")}
     # BVH build and the two bakes of one mesh (torus-free: the table box, 3 072 triangles) into a 96^3 grid
     v, f = meshes[0][0]["vertices"], meshes[0][0]["faces"]
     torch.cuda.synchronize()
@@ -1283,6 +1300,16 @@ def c4_benchmark(device, torch):
     res["kernel_counters"] = _stage_counters(res["kernels"], {
         "fk_forward_spheres": "fk_forward_kernel", "self_collision_tiled": "self_collision_tiles", "rnea_forward": "rnea_forward",
         "rnea_backward": "rnea_backward", "fk_backward": "fk_backward_kernel"}, N)
+    # the whole rollout set against the same roofline: the algorithmic bytes of its five dominant stages (the per-point
+    # figures above) / the measured time of one set (both chains, as the rollout runs them)
+    set_bytes = int(sum(v["algorithmic_bytes"] for v in res["kernels"].values()))
+    res["roofline_whole_set"] = {"bound": "hbm", "algorithmic_bytes_per_set": set_bytes, "us_per_rollout_set": res["us_per_rollout_set"],
+                                 "achieved": round(set_bytes / us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(set_bytes / us * 1e-3 / HBM_PEAK_GBS, 4),
+                                 "stages": {k2: v["algorithmic_bytes"] for k2, v in res["kernels"].items()},
+                                 "note": "sum of the stages' algorithmic bytes (SURVEY 8d per-point figures x 33 792 points) over the time "
+                                         "of one rollout set; the small stages (B-spline, tool pose, c-space STATE, aggregates) add time but "
+                                         "no bytes here"}
     return res
 
 

@@ -7,7 +7,9 @@ target of the rocprofv3 counter passes of tools/collect_profiles_r03.sh.  Worklo
   c4   Unitree G1, 256 x 4 x 33: FK, self_collision_tiles2_kernel, RNEA forward (staged kernels) / backward, c-space cost, FK VJP
   c5   Franka, 2 worlds (cuboids + 64^3 ESDF) x 512 x 4 x 65: the fused multi-env launch, the swept scene kernel
 
-Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [--reps N]
+  mesh bench.py's mesh world (the C2 cuboids as 12 288 triangles): sphere_mesh_select_kernel + sphere_mesh_walk_kernel
+
+Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [mesh] [--reps N]
 """
 import os
 import sys
@@ -119,8 +121,29 @@ def c5():
     sequence_and_fused(model, seq, fused, 8, env)
 
 
+def mesh():
+    """bench.py's mesh world: the C2 cuboids as four triangle meshes (12 288 triangles), C2 shapes, swept + speed metric"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("franka", device=dev)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    scene = SceneData.from_arrays(None, dev, meshes=B_.c2_world_as_meshes())
+    B = 1024
+    cfg = CollisionRolloutCfg(use_fused=False)
+    ro = CollisionRollout(kin, scene, B, cfg)
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
+    x = torch.as_tensor(seed_knots(model, B, cfg.n_knots, seed=2), device=dev).reshape(B, -1)
+    ro.compute_kinematics(ro.compute_state_from_action(x.view(B, cfg.n_knots, -1)))
+    run(lambda: Cn.sphere_obstacle_collision(ro.scene_dist, ro.scene_grad, ro.robot_spheres, scene.struct, ro._w_scene, ro._eta,
+                                             ro.env_query_idx, B, cfg.padded_horizon, kin.num_spheres, False, 3, True, ro._speed_dt))
+
+
 if __name__ == "__main__":
-    want = [a for a in sys.argv[1:] if a in ("c2", "c3", "c4", "c5")] or ["c2", "c3", "c4", "c5"]
+    want = [a for a in sys.argv[1:] if a in ("c2", "c3", "c4", "c5", "mesh")] or ["c2", "c3", "c4", "c5", "mesh"]
     for w in want:
         globals()[w]()
     print("ran", want)
