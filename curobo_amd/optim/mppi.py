@@ -9,9 +9,11 @@ Mirrors the reference's ``MPPI`` / ``ParticleOptCore`` iteration
         mean, cov, scale_tril, best <- softmax-weighted moments of the particles
 
 The distribution update is one HIP launch (``backends.optimization.mppi_update_distribution``)
-instead of the reference's chain of torch kernels; sampling uses a per-optimiser
-``torch.Generator`` (Gaussian; the reference's Halton/stomp sample library is a sampling policy,
-not part of the update arithmetic).
+instead of the reference's chain of torch kernels.  The particle noise is the reference's sample library
+(``optim/particle_samples.py``: scrambled Halton points through the 2000-row buffer, erfinv, three-tap filter; optional
+STOMP share), generated once per optimiser for the GLOBAL problem set and cycled as
+``GaussianDistribution.get_samples`` cycles it: the same seed gives the reference's particle set
+(``tests/test_mppi_samples.py``).  ``noise="torch"`` draws fresh Gaussian noise from a ``torch.Generator`` instead.
 """
 
 from __future__ import annotations
@@ -42,6 +44,12 @@ class MPPICfg:
     update_cov: bool = True
     sample_mode: str = "MEAN"  # MEAN | BEST
     seed: int = 0
+    # sample_params (reference ParticleSamplerCfg, sample_strategies/particle_sampler_cfg.py:18-44)
+    noise: str = "sample_lib"  # "sample_lib" = the reference's library (below) | "torch" = fresh Gaussian noise every iteration
+    sample_ratio: Optional[dict] = None  # default {"halton": 1.0}; e.g. {"halton": 0.5, "stomp": 0.5}
+    filter_coeffs: Optional[Tuple[float, float, float]] = (0.3, 0.3, 0.4)
+    fixed_samples: bool = True      # one noise set for every iteration (else num_iters sets, cycled)
+    sample_per_problem: bool = True  # every problem its own particles (else one set repeated over the problems)
 
 
 class MPPI:
@@ -83,6 +91,18 @@ class MPPI:
         self.actions = z(B, P, Ha, D)
         self._gen = torch.Generator(device=device)
         self._gamma_seq: Optional[torch.Tensor] = None
+        self._sample_set: Optional[torch.Tensor] = None
+        self._sample_iter = 0
+        if cfg.noise not in ("sample_lib", "torch"):
+            raise ValueError(f"MPPICfg.noise must be 'sample_lib' or 'torch', got {cfg.noise!r}")
+        if cfg.noise == "sample_lib" and self.sampled_per_problem > 0:
+            from .particle_samples import ParticleSampleLib, sample_set
+
+            # the job's set (global problem count), this shard's problems of it: any world size samples the same particles
+            lib = ParticleSampleLib(Ha, D, seed=cfg.seed, sample_ratio=cfg.sample_ratio, filter_coeffs=cfg.filter_coeffs)
+            full = sample_set(lib, self.global_num_problems, self.sampled_per_problem, 1 if cfg.fixed_samples else cfg.num_iters,
+                              cfg.sample_per_problem)
+            self._sample_set = full[:, self.problem_offset:self.problem_offset + B].to(device).contiguous()
         self.reset_distribution()
 
     def reset_distribution(self) -> None:
@@ -90,13 +110,17 @@ class MPPI:
         self.cov.fill_(self.cfg.init_cov)
         self.scale_tril.copy_(torch.sqrt(self.cov))
         self._gen.manual_seed(self.cfg.seed)
+        self._sample_iter = 0
 
     # reference ParticleOptCore.sample_actions (:393-442), CLAMP squash
     @torch.no_grad()
     def sample_actions(self) -> torch.Tensor:
         B, Ha, D = self.cfg.num_problems, self.action_horizon, self.action_dim
         n = self.sampled_per_problem
-        if self.global_num_problems == B:
+        if self._sample_set is not None:  # reference GaussianDistribution.get_samples (:243-256)
+            noise = self._sample_set[self._sample_iter]
+            self._sample_iter = (self._sample_iter + 1) % self._sample_set.shape[0]
+        elif self.global_num_problems == B:
             noise = torch.randn(B, n, Ha, D, device=self.device, generator=self._gen)
         else:  # a problem shard: the job's noise tensor, this rank's problems of it
             noise = torch.randn(self.global_num_problems, n, Ha, D, device=self.device, generator=self._gen)

@@ -195,16 +195,27 @@ def test_lm_seed_ranking_over_shards_world_size_2_gloo(tmp_path):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # PROBLEM shards (BASELINE config 5, the MPPI particle stage)
-def test_mppi_problem_shards_sample_the_jobs_particles():
-    """a problem's particle noise depends on its global index only: the shards' samples concatenate to the single-process ones"""
-    from curobo_amd.optim.mppi import MPPI, MPPICfg
+@pytest.mark.parametrize("noise_kw", [dict(), dict(fixed_samples=False, num_iters=3), dict(sample_ratio={"halton": 0.5, "stomp": 0.5}),
+                                      dict(noise="torch")], ids=["halton_fixed", "halton_per_iteration", "halton_stomp", "torch"])
+def test_mppi_problem_shards_sample_the_jobs_particles(noise_kw):
+    """a problem's particle noise depends on its global index only: the shards' samples concatenate to the single-process ones
+    (the reference's sample library, fixed or per iteration, with a STOMP share; and the torch.Generator noise)"""
+    import functools
 
+    from curobo_amd.optim.mppi import MPPI
+    from curobo_amd.optim.mppi import MPPICfg as _Cfg
+
+    MPPICfg = functools.partial(_Cfg, **noise_kw)
     PG, n_part, Ha, D = 6, 16, 5, 3
     lo_b, hi_b = -2.0 * torch.ones(D), 2.0 * torch.ones(D)
     mean = torch.rand(PG, Ha, D)
     whole = MPPI(MPPICfg(num_problems=PG, num_particles=n_part, null_act_frac=0.125), lambda a: a.sum(-1), Ha, D, (lo_b, hi_b), "cpu")
     whole.mean.copy_(mean)
     want = [whole.sample_actions().clone() for _ in range(2)]  # two iterations: the generator state advances alike
+    if noise_kw.get("fixed_samples", True) and noise_kw.get("noise") != "torch":
+        assert torch.equal(want[0], want[1])  # fixed samples: one noise set for every iteration (reference default)
+    else:
+        assert not torch.equal(want[0], want[1])
     for world in (2, 3):
         parts = [[], []]
         for rank in range(world):
