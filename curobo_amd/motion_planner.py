@@ -550,7 +550,12 @@ class _PlannerBase:
         c = self.config.trajopt_solver_config
         n, k, dev, G = c.max_batch_size, c.num_seeds, self.device_cfg.device, c.max_goalset
         gp, gq = goal_tool_poses.static_goals()
-        gp, gq = gp.to(dev, torch.float32)[:, 0], gq.to(dev, torch.float32)[:, 0]  # first tool frame: [batch, g, 3 | 4]
+        if gp.shape[1] != 1:
+            # the reference hands every tool frame's goal to its IK solver (motion_planner.py:249); the IK stage here scores
+            # ONE frame, so seeds for a multi-frame goal would silently ignore the other frames' goals
+            raise ValueError(f"the planner's IK stage takes one tool frame, the goal has {gp.shape[1]}: plan multi-frame robots "
+                             "with TrajOptSolver.solve_pose and caller-provided seed configurations")
+        gp, gq = gp.to(dev, torch.float32)[:, 0], gq.to(dev, torch.float32)[:, 0]  # the tool frame: [batch, g, 3 | 4]
         g = gp.shape[1]
         if g > G:
             raise ValueError(f"goal set of {g} poses exceeds max_goalset={G}")
@@ -755,6 +760,10 @@ class BatchMotionPlanner(_PlannerBase):
             ok, seed_config = self._ik_seed_configs(goal_tool_poses, batch)
             if int(ok.sum()) == 0:
                 continue
+            # per problem, failed IK solutions are replaced by that problem's first good one (reference :265-267, per row)
+            first_good = torch.argmax(ok.to(torch.int8), dim=1)
+            good = seed_config[torch.arange(batch, device=seed_config.device), first_good]
+            seed_config = torch.where((ok | ~ok.any(dim=1, keepdim=True)).unsqueeze(-1), seed_config, good.unsqueeze(1))
             r = self.trajopt_solver.solve_pose(goal_tool_poses, current_state, seed_config=seed_config,
                                                use_implicit_goal=use_implicit_goal)
             if best is None:

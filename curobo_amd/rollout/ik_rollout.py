@@ -90,6 +90,7 @@ class IKRollout:
         self._pd, self._bbmv, self._bbmi = z(1), z(1), z(2, dt=torch.int16)
         self.cost, self.grad_q = z(B), z(B, 1, D)
         self.idxs_goal = z(B, dt=torch.int32)
+        self._idxs_src = None  # (the row -> goal map was reallocated: the next update_goals must copy, whatever tensor it is handed)
         self._idx0 = z(B, dt=torch.int32)
         self.goal_position = z(1, T, self.num_goalset, 3)
         self.goal_quat = z(1, T, self.num_goalset, 4)

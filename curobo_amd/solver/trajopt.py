@@ -264,7 +264,10 @@ class TrajOptSolver:
         return torch.clamp(score * base, min=self.cfg.minimum_trajectory_dt, max=self.cfg.maximum_trajectory_dt)
 
     def _set_dt(self, dt: torch.Tensor) -> None:
-        """dt [P * S] of every (problem, seed) into both rollouts (reference _update_trajectory_dt, :560-577)"""
+        """dt [P * S] of every (problem, seed) into both rollouts (reference _update_trajectory_dt, :560-577).  On a seed shard
+        this is a COLLECTIVE (rank 0's dt of global trajectory 0 is broadcast): every rank must reach it the same number of
+        times, i.e. solve arguments that steer the host-side control flow (dt given or not, finetune_attempts, iteration counts)
+        must be identical on all ranks -- as must the decisions taken through ``_any``, which are all-reduced for that reason."""
         speed = None
         if self.S_global != self.S:  # the speed metric reads the dt of global trajectory 0 (wp_speed_metric.py:54): rank 0's
             from ..distributed import broadcast_from_rank0
