@@ -47,6 +47,7 @@ void syncthreads();
 void syncwarp(unsigned mask);
 unsigned ballot(unsigned mask, int pred);
 uint32_t shfl_bits(unsigned mask, uint32_t v, int src_lane_of_me);  // value of lane `src` (lane index inside the warp)
+inline void warp0_published() { syncthreads(); }  // see the Makefile: kernel_lbfgs_step's rho hand-over from warp 0 to the block
 float atomic_add(float *p, float v);
 int atomic_add(int *p, int v);
 }  // namespace cuoc

@@ -16,6 +16,7 @@
 #include "trajectory/legacy/integration_acceleration_kernel.cuh"
 #include "dynamics/rnea_forward_kernel.cuh"
 #include "dynamics/rnea_backward_kernel.cuh"
+#include "optimization/lbfgs/lbfgs_step_kernel.cuh"
 
 using namespace curobo::kinematics;
 
@@ -255,10 +256,29 @@ extern "C" int ref_bspline_backward(float *out, const float *gp, const float *gv
   return 0;
 }
 
+// kernel_lbfgs_step<float, false, -1> and kernel_lbfgs_step_shared_memory<float, false, -1> (one block per problem, v_dim threads;
+// reference launch: cuda_core_backend/optimization.py:138-260, LBFGSLaunchCfg: dynamic shared memory = history * 4 bytes for the
+// alpha buffer, or (2 history v_dim + 2 history + 33) floats for the shared-memory form).  The first kernel hands its rho history
+// from warp 0 to the whole block without a barrier; the build recipe spells that rendezvous out (Makefile).
+extern "C" int ref_lbfgs_step(float *step_vec, float *rho_buffer, float *y_buffer, float *s_buffer, float *q, float *x_0, float *grad_0,
+                              const float *grad_q, float epsilon, int batchsize, int m, int v_dim, int stable_mode, int shared_buffers) {
+  if (m < 1 || m > 31 || v_dim < 1 || v_dim > 1024) return 1;
+  if (shared_buffers) {
+    const size_t smem = (size_t)(2 * m * v_dim + 2 * m + 32 + 1) * sizeof(float);
+    cuoc::launch(dim3(batchsize), dim3(v_dim), smem, [&] {
+      curobo::optimization::kernel_lbfgs_step_shared_memory<float, false, -1>(step_vec, rho_buffer, y_buffer, s_buffer, q, x_0, grad_0, grad_q,
+                                                                              epsilon, batchsize, m, v_dim, stable_mode != 0);
+    });
+  } else {
+    cuoc::launch(dim3(batchsize), dim3(v_dim), (size_t)m * sizeof(float), [&] {
+      curobo::optimization::kernel_lbfgs_step<float, false, -1>(step_vec, rho_buffer, y_buffer, s_buffer, q, x_0, grad_0, grad_q, epsilon,
+                                                                batchsize, m, v_dim, stable_mode != 0);
+    });
+  }
+  return 0;
+}
+
 // kernel_line_search<float, -1> (one block per problem, opt_dim threads); reference launch: cuda_core_backend/optimization.py:21-110.
-// (kernel_lbfgs_step is NOT run here: it shifts and extends the rho history in warp 0 and reads it in every warp without a
-// barrier in between -- correct only under lock-step warps and favourable timing, which a cooperative schedule does not
-// reproduce.  The L-BFGS step is pinned by the reference's torch twin instead, tests/golden/optim_golden.npz.)
 extern "C" int ref_line_search(float *best_cost, float *best_action, int16_t *best_iteration, int16_t *current_iteration,
                                uint8_t *converged_global, int convergence_iteration, float cost_delta_threshold,
                                float cost_relative_threshold, float *exploration_cost, float *exploration_action,

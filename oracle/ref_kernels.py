@@ -232,6 +232,18 @@ class ReferenceKernels:
         return {"position": outs[0], "velocity": outs[1], "acceleration": outs[2], "jerk": outs[3]}
 
     # ------------------------------------------------------------------ optimiser
+    def lbfgs_step(self, step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0, epsilon: float, stable_mode: bool,
+                   shared_buffers: bool = False):
+        """in place like ``Oracle.lbfgs_step``: kernel_lbfgs_step<float, false, -1> (or its shared-memory form)"""
+        m, b = y_buffer.shape[0], q.shape[0]
+        v = int(np.prod(q.shape[1:]))
+        for a in (step_vec, rho_buffer, y_buffer, s_buffer, q, grad_q, x_0, grad_0):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        rc = self.lib.ref_lbfgs_step(_p(step_vec), _p(rho_buffer), _p(y_buffer), _p(s_buffer), _p(q), _p(x_0), _p(grad_0), _p(grad_q),
+                                     C.c_float(epsilon), b, m, v, int(stable_mode), int(shared_buffers))
+        assert rc == 0, "history must be 1..31 and the optimisation dimension <= 1024 (one thread each)"
+        return step_vec
+
     def line_search(self, state, search_cost, search_action, search_gradient, step_direction, search_magnitudes, c_1: float, c_2: float,
                     strong_wolfe: bool, approx_wolfe: bool, convergence_iteration: int, cost_delta_threshold: float,
                     cost_relative_threshold: float):

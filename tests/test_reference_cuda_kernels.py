@@ -223,6 +223,57 @@ def _ls_state(b, v, nls):
 
 
 @needs_ref
+@pytest.mark.parametrize("shared_buffers", [False, True], ids=["kernel_lbfgs_step", "kernel_lbfgs_step_shared_memory"])
+@pytest.mark.parametrize("b,v,m,stable", [(5, 84, 15, True), (3, 7, 5, True), (2, 175, 27, False)])
+def test_lbfgs_step_kernels(b, v, m, stable, shared_buffers, oracle, ref):
+    """kernel_lbfgs_step / kernel_lbfgs_step_shared_memory (lbfgs_step_kernel.cuh:18-199), run on the CPU, next to the oracle over
+    m + 3 iterations of one optimiser state (the history fills up and rolls): history buffers identical, rho and the step to
+    the rounding of the block reductions (the kernels sum the dot products over warps, the oracle in index order).  The first
+    kernel's rho hand-over from warp 0 is spelled out by the build recipe (oracle/cuda_on_cpu/Makefile); v = 84 and 175 span
+    several warps, v = 7 sits inside one."""
+    rng = np.random.default_rng(b * 1000 + v)
+    z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+    A = dict(step=z(b, v), rho=z(m, b), y=z(m, b, v), s=z(m, b, v), x0=z(b, v), g0=z(b, v))
+    B = {k: a.copy() for k, a in A.items()}
+    x = rng.normal(size=(b, v)).astype(np.float32)
+    for it in range(m + 3):
+        x = (x + 0.05 * rng.normal(size=(b, v))).astype(np.float32)
+        g = (2.0 * x + 0.1 * rng.normal(size=(b, v))).astype(np.float32)  # gradient of a noisy bowl: y . s > 0 mostly
+        if it == 4:
+            g[0] = A["g0"][0] - (x[0] - A["x0"][0])  # one problem with y . s < 0: the stable-mode branches (rho = 0, gamma clamped)
+        oracle.lbfgs_step(A["step"], A["rho"], A["y"], A["s"], x, g, A["x0"], A["g0"], 0.01, stable)
+        ref.lbfgs_step(B["step"], B["rho"], B["y"], B["s"], x, g, B["x0"], B["g0"], 0.01, stable, shared_buffers=shared_buffers)
+        for k in ("y", "s", "x0", "g0"):
+            assert np.array_equal(A[k], B[k]), (it, k)
+        np.testing.assert_allclose(B["rho"], A["rho"], rtol=2e-5, atol=1e-7 * np.abs(A["rho"]).max(), err_msg=f"iteration {it}")
+        fin = np.isfinite(A["step"])
+        assert np.array_equal(fin, np.isfinite(B["step"])), it
+        scale = np.abs(A["step"][fin]).max()
+        np.testing.assert_allclose(B["step"][fin], A["step"][fin], rtol=1e-3, atol=2e-5 * scale, err_msg=f"iteration {it}")
+    assert np.abs(A["step"][np.isfinite(A["step"])]).max() > 0
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["ik", "trajopt"])
+def test_lbfgs_step_kernel_against_the_reference_torch_twin(name, ref):
+    """the CUDA kernel on the CPU against the golden of the reference's OWN torch twin (tests/golden/optim_golden.npz): the two
+    reference implementations of the step agree here as they must on the GPU"""
+    gold = np.load(os.path.join(os.path.dirname(GOLD), "optim_golden.npz"))
+    q, g, step_ref = gold[f"lbfgs_{name}_q"], gold[f"lbfgs_{name}_g"], gold[f"lbfgs_{name}_step"]
+    iters, b, v = q.shape
+    m = gold[f"lbfgs_{name}_y"].shape[0]
+    y, s, rho = np.zeros((m, b, v), np.float32), np.zeros((m, b, v), np.float32), np.zeros((m, b), np.float32)
+    x0, g0 = gold[f"lbfgs_{name}_init_x0"].astype(np.float32).copy(), gold[f"lbfgs_{name}_init_g0"].astype(np.float32).copy()
+    step = np.zeros((b, v), np.float32)
+    for it in range(iters):
+        ref.lbfgs_step(step, rho, y, s, np.ascontiguousarray(q[it]), np.ascontiguousarray(g[it]), x0, g0, 0.01, True)
+        scale = np.abs(step_ref[it]).max()
+        np.testing.assert_allclose(step, step_ref[it], atol=2e-4 * scale, rtol=2e-3, err_msg=f"iteration {it}")
+    np.testing.assert_allclose(y, gold[f"lbfgs_{name}_y"], atol=1e-6)
+    np.testing.assert_allclose(rho, gold[f"lbfgs_{name}_rho"], rtol=1e-4, atol=1e-6)
+
+
+@needs_ref
 @pytest.mark.parametrize("kind", ["wolfe", "strong_wolfe", "approx_wolfe"])
 def test_line_search_kernel_identical_state(kind, oracle, ref):
     """four rounds of candidates through kernel_line_search and through the oracle: every state array identical (selected
