@@ -49,6 +49,19 @@ def all_reduce_max(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -
     return x
 
 
+def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """in-place SUM over the ranks (no-op alone); device tensors go through the host on the gloo backend"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return x
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        host = x.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        x.copy_(host)
+    else:
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+    return x
+
+
 def broadcast_from_rank0(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """in-place broadcast of rank 0's ``x`` (no-op alone); device tensors go through the host on the gloo backend"""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):

@@ -44,6 +44,12 @@ class LBFGSOptCfg:
     cost_delta_threshold: float = 0.0
     cost_relative_threshold: float = 0.001
     convergence_iteration: int = 10
+    #: reference LBFGSOptCfg.fixed_iters / converged_ratio (optim/gradient/lbfgs.py:61-62, gradient_opt_core.py:305-314):
+    #: False = between blocks of ``inner_iters`` iterations the optimiser stops once more than ``converged_ratio`` of the
+    #: problems carry the line-search kernel's convergence flag (best cost not improved for ``convergence_iteration``
+    #: iterations).  One host read-back per block.  The reference's task configs keep it True.
+    fixed_iters: bool = True
+    converged_ratio: float = 0.8
     #: line search + two-loop + next candidates in one launch (opt_dim <= 128); False = the three
     #: drop-in launches of the reference's iteration
     fused_tail: bool = True
@@ -223,6 +229,20 @@ class LBFGSOpt:
         torch.cuda.synchronize(self.device)
         return g
 
+    def _enough_converged(self) -> bool:
+        """reference BestTracker.check_convergence (optim/components/best_tracker.py:109-118); on a seed shard the count is
+        taken over all ranks so that every rank stops after the same block"""
+        n = torch.count_nonzero(self.converged).to(torch.float32).reshape(1)
+        total = float(self.converged.numel())
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from ..distributed import all_reduce_sum
+
+            both = all_reduce_sum(torch.cat([n, torch.tensor([total], device=n.device)]))
+            n, total = both[:1], float(both[1])
+        return float(n.item()) > total * self.cfg.converged_ratio
+
     def _state_tensors(self):
         return [self.y, self.s, self.rho, self.x_0, self.grad_0, self.step_direction, self.action,
                 self.gradient, self.cost, self.exploration_action, self.exploration_gradient,
@@ -246,8 +266,13 @@ class LBFGSOpt:
             outer, rest = max(1, self.cfg.num_iters // self.cfg.inner_iters), 0
         else:
             outer, rest = divmod(int(num_iters), self.cfg.inner_iters)
+        self.iterations_run = 0
         for _ in range(outer):
             self.run_inner()
+            self.iterations_run += self.cfg.inner_iters
+            if not self.cfg.fixed_iters and self._enough_converged():
+                return self.best_action.view(self.num_problems, self.action_horizon, self.action_dim)
         for _ in range(rest):
             self._opt_step()
+        self.iterations_run += rest
         return self.best_action.view(self.num_problems, self.action_horizon, self.action_dim)

@@ -44,6 +44,8 @@ class LBFGSOptCfg:
     cost_relative_threshold: float = 0.001
     cost_convergence: float = 0.0
     convergence_iteration: int = 10
+    fixed_iters: bool = True       # reference optim/gradient/lbfgs.py:61-62
+    converged_ratio: float = 0.8
     solver_type: str = "lbfgs"
     # the reference's kernel switches: the HIP backend has no torch fallback, the flags are accepted and ignored
     use_cuda_kernel_step_direction: bool = True
@@ -59,7 +61,7 @@ class LBFGSOptCfg:
             line_search_c_1=self.line_search_c_1, line_search_c_2=self.line_search_c_2, epsilon=self.epsilon,
             stable_mode=self.stable_mode, step_scale=self.step_scale, initial_step_scale=self.initial_step_scale,
             cost_delta_threshold=self.cost_delta_threshold, cost_relative_threshold=self.cost_relative_threshold,
-            convergence_iteration=self.convergence_iteration)
+            convergence_iteration=self.convergence_iteration, fixed_iters=self.fixed_iters, converged_ratio=self.converged_ratio)
 
 
 class LBFGSOpt:

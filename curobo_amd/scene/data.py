@@ -147,6 +147,9 @@ class SceneData:
         coarse, block, dilate = None, 0, 0
         if coarse_culling and t.get("voxel_features") is not None and t["voxel_features"].numel() > 0:
             block, dilate = 4, 3  # culls spheres whose sweep stays within 2 voxels of the centre's voxel
+            import os
+            if os.environ.get("CUROBO_VOXEL_COARSE"):  # development knob: "block,dilate"
+                block, dilate = (int(v) for v in os.environ["CUROBO_VOXEL_COARSE"].split(","))
             coarse = t["voxel_coarse_min"] = build_voxel_coarse_min(t["voxel_features"], arrays["voxel_params"], block, dilate)
         struct = make_scene(
             t.get("cuboid_dims"), t.get("cuboid_inv_pose"), t.get("cuboid_enable"), t.get("cuboid_count"),

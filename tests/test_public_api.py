@@ -112,6 +112,13 @@ def test_reference_shaped_lbfgs_on_rollout_protocol_objects(use_cuda_graph, devi
     opt.reinitialize(x0.clone())
     out = opt.optimize(x0.clone()).clone()
     assert float(((10.0 - out) ** 2).sum(-1).mean()) < 1e-5  # the reference test's bar (:320)
+    # the reference's optional convergence exit (fixed_iters = False): the same quadratic, 400 iterations allowed, stops once
+    # more than 80 % of the problems carry the line-search kernel's convergence flag -- same answer, far fewer iterations
+    cfg_e = LBFGSOptCfg(num_problems=4, num_iters=400, history=10, line_search_scale=[0, 0.1, 0.5, 1.0], inner_iters=25, fixed_iters=False)
+    opt_e = LBFGSOpt(cfg_e, [ro], use_cuda_graph=use_cuda_graph)
+    out_e = opt_e.optimize(x0.clone()).clone()
+    assert float(((10.0 - out_e) ** 2).sum(-1).mean()) < 1e-5
+    assert 25 <= opt_e._opt.iterations_run < 400, opt_e._opt.iterations_run
     # Rosenbrock (curobo.rollout) from the bounds' corner
     rr = RosenbrockRollout(RosenbrockCfg(device_cfg=DeviceCfg(device), dimensions=2))
     opt2 = LBFGSOpt(LBFGSOptCfg(num_problems=8, num_iters=400, history=7, inner_iters=25), [rr], use_cuda_graph=use_cuda_graph)
