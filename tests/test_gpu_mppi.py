@@ -34,19 +34,22 @@ def test_mppi_update_kernel_matches_reference_torch(case, device):
     np.testing.assert_array_equal(best.cpu().numpy(), ref_best)
 
 
-def test_mppi_minimises_a_quadratic_and_a_collision_rollout(device):
+@pytest.mark.parametrize("noise,bar", [("torch", 0.4), ("sample_lib", 1.2)])
+def test_mppi_minimises_a_quadratic_and_a_collision_rollout(noise, bar, device):
     from curobo_amd.optim import MPPI, MPPICfg
 
     torch.manual_seed(0)
     B, Ha, D = 3, 8, 5
     target = torch.linspace(-0.5, 0.5, Ha * D, device=device).view(1, Ha * D)
     lo, hi = -torch.ones(D, device=device), torch.ones(D, device=device)
-    cfg = MPPICfg(num_problems=B, num_particles=512, num_iters=40, beta=1.0, init_cov=0.3)
+    cfg = MPPICfg(num_problems=B, num_particles=512, num_iters=40, beta=1.0, init_cov=0.3, noise=noise)
     opt = MPPI(cfg, lambda a: ((a - target) ** 2).sum(-1), Ha, D, (lo, hi), device)
     out = opt.optimize(torch.zeros(B, Ha, D, device=device))
     torch.cuda.synchronize()
-    # start: |target|^2 = 3.5; the softmax-weighted mean walks to the optimum (40-dim problem, beta 1)
-    assert float(((out.view(B, -1) - target) ** 2).sum(-1).max()) < 0.4
+    # start: |target|^2 = 3.5; the softmax-weighted mean walks to the optimum (40-dim problem, beta 1).  Fresh white noise every
+    # iteration gets below 0.4; the reference's sample library -- ONE set of 512 Halton particles for all iterations, smoothed
+    # in time by its three-tap filter -- explores this synthetic ramp target more slowly (measured 0.95)
+    assert float(((out.view(B, -1) - target) ** 2).sum(-1).max()) < bar
     assert float(opt.cov.max()) < 0.3 + 1e-6
     # deterministic given the seed
     opt2 = MPPI(cfg, lambda a: ((a - target) ** 2).sum(-1), Ha, D, (lo, hi), device)
