@@ -89,7 +89,7 @@ def feature_pseudonormals(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray
     return out
 
 
-def build_mesh_bvh(vertices, faces, device, leaf_size: int = 4) -> DeviceMesh:
+def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8) -> DeviceMesh:
     """vertices [V, 3] (mesh frame), faces [F, 3] -> the linear BVH on ``device``: Morton keys of the centroids (HIP), the
     sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level)"""
     import os

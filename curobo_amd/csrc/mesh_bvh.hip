@@ -354,21 +354,43 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
   }
 }
 
-// ---- the walk kernel: one live sphere per lane, its slots in ascending order in-lane, every sample of a slot through the
-// one query site of mesh_contribution.  (Measured and dropped: the same work as ONE loop in which every lane runs its own
-// program -- an explicit state machine around a walker shared by the closest-point and the ray mode, leaves one triangle per
-// iteration, lanes refilled from the queue.  It keeps every lane busy, and executes the union of all states' code in every
-// iteration: 334 M VALU + 233 M SALU wave-instructions per launch for 8 M node visits, 2.3 - 2.6 ms.  What the nested form
-// needs instead is few, tight loops: one walk site, no sign rays -- mesh_device.hpp.)
+// ---- the walk kernel: EIGHT LANES per live sphere (queue entry).  All eight run the sphere's scalar program (its slots in
+// ascending order, every sample of a slot through the one query site of mesh_contribution) on the same values; only the
+// tree walks split the work (mesh_device.hpp::mesh_closest_point_group: three tree levels per step, one descendant box or
+// one leaf triangle per lane, sibling keys kept in LDS).  Measured on the bench's mesh world (tools/r04/mesh_stats.py: 1024 x 33 points x 65
+// spheres, the C2 world's 4 cuboids as meshes of 3072 triangles each, sweep 3), launch = select + walk:
+//    one sphere per lane, binary walk            1430 us   (112 M VALU + 106 M SALU wave-instructions, ~150 of 8192
+//                                                           wavefront slots busy on average: a few long walks per
+//                                                           wavefront hold the other lanes)
+//    eight lanes per sphere, leaves of 4 / of 8   801 / 677 us
+//    + four wavefronts a SIMD (128 registers)      577 us
+//    + sibling keys in LDS, nearest sibling next   460 us   (no box is fetched twice; half the dependent loads)
+//    sixteen lanes per sphere, leaves of 16        698 us   (before the last two steps; wider groups idle more lanes)
+// (Measured and dropped before that: the same work as ONE loop in which every lane runs its own program -- an explicit state
+// machine around a walker shared by the closest-point and the ray mode, leaves one triangle per iteration, lanes refilled
+// from the queue.  It keeps every lane busy, and executes the union of all states' code in every iteration: 334 M VALU +
+// 233 M SALU wave-instructions per launch for 8 M node visits, 2.3 - 2.6 ms.)
+#ifndef MESH_WALK_GROUP
+#define MESH_WALK_GROUP 8
+#endif
+#ifndef MESH_WALK_ATTR
+#define MESH_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // 128 registers: four wavefronts a SIMD, nothing spilled
+#endif
 template <int SWEEP>
-__global__ void __launch_bounds__(256) sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
+__global__ void __launch_bounds__(256) MESH_WALK_ATTR sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
   const MeshCollArgs &a = qa.c;
   const uint32_t n = qa.counter[0];
   const int hs = a.horizon * a.nspheres;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
   const float w = a.weight[0], eta = a.eta[0];
-  for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n; q += gridDim.x * 256u) {
-    const uint2 e = qa.queue[q];
+  // lane 0 of a group writes
+  constexpr unsigned G = MESH_WALK_GROUP, PER_WG = 256u / G;
+  __shared__ float group_keys[MESH_GROUP_LEVELS * 256];
+  for (uint32_t q0 = blockIdx.x * PER_WG; q0 < n; q0 += gridDim.x * PER_WG) {
+    const uint32_t q = q0 + threadIdx.x / G;
+    // (a group beyond the end of the queue repeats the last entry so that ballots and shuffles stay whole; it writes nothing)
+    const bool live_group = q < n;
+    const uint2 e = qa.queue[live_group ? q : n - 1];
     const long sidx = (long)e.x;
     const int b = (int)(sidx / hs);
     const int h = (int)((sidx - (long)b * hs) / a.nspheres);
@@ -396,8 +418,8 @@ __global__ void __launch_bounds__(256) sphere_mesh_walk_kernel(const MeshQueueAr
       const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
       float cost_sum = 0.0f;
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
-      mesh_contribution<SWEEP>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev, half_w_next,
-                               reach, cost_sum, grad_local);
+      mesh_contribution<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
+                                     half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, 256);
       if (cost_sum > 0.0f) {
         const f3 gw = mesh_to_world_vector(slot, grad_local);
         dsum += w * cost_sum;
@@ -405,6 +427,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_walk_kernel(const MeshQueueAr
       }
     }
     if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f) mesh_speed_metric(center, pp, np, a.speed_dt[0], dsum, gsum);
+    if (!live_group || (threadIdx.x & (G - 1u)) != 0) continue;
     float4 *grad = reinterpret_cast<float4 *>(a.gradient);
     if (a.accumulate) {
       if (dsum > 0.0f) {
@@ -543,7 +566,7 @@ static int sphere_mesh_collision_impl(
       qa.queue = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(workspace) + 16);
       if (hipMemsetAsync(workspace, 0, 16, st) != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot clear the queue counter", what);
       // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
-      const unsigned walk_blocks = (unsigned)std::min<long>(1024, ceil_div_l(total, 256));
+      const unsigned walk_blocks = (unsigned)std::min<long>(4096, ceil_div_l(total, 256 / MESH_WALK_GROUP));
       if (sweep_steps > 0) {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), grid, block, 0, st, qa);
         hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), block, 0, st, qa);

@@ -13,6 +13,7 @@
 // 256 B of scratch per lane and the reason the launch ran at 0.005 of the HBM roofline.
 #pragma once
 #include "common.hpp"
+#include "self_device.hpp"
 
 namespace curobo_hip {
 
@@ -78,6 +79,27 @@ __device__ __forceinline__ int mesh_walk_next(int node, uint32_t first, uint32_t
     node = parent;
   }
   return 0;
+}
+
+// which side of the surface p is on, judged by the feature its closest point lies on (see mesh_closest_point)
+__device__ __forceinline__ int mesh_feature_side(const curobo_hip_mesh &m, f3 p, f3 cp, float best_d2, int best_t, int best_region, bool tie) {
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  int side = 0;
+  const f3 d = p - cp;
+  const TriRec r = tri[best_t];
+  if (best_region == 0 && !tie) {
+    // the face the closest point lies in: only trusted when the point is clearly off its plane
+    const float sd = dot(d, cross(make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z)));
+    side = (best_d2 > 1e-12f && sd != 0.0f) ? (sd > 0.0f ? 1 : -1) : 0;
+  } else if (m.tri_pn != nullptr && best_region != 0 && best_d2 > 1e-12f) {
+    // an edge or a vertex: its pseudonormal (for a closed, consistently oriented surface the sign of d . n is the sign of
+    // the distance whatever the dihedral angles); a degenerate pseudonormal gives no verdict
+    const float4 n4 = reinterpret_cast<const float4 *>(m.tri_pn)[(size_t)best_t * 6 + (best_region - 1)];
+    const f3 n = make_f3(n4.x, n4.y, n4.z);
+    const float sd = dot(d, n), scale = sqrtf(dot(n, n) * best_d2);
+    side = fabsf(sd) > 1e-4f * scale ? (sd > 0.0f ? 1 : -1) : 0;
+  }
+  return side;
 }
 
 // closest surface point within sqrt(best_d2) of p; returns false when there is none
@@ -152,22 +174,128 @@ __device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 
       }
     }
   }
-  if (found) {
-    const f3 d = p - cp;
-    const TriRec r = tri[best_t];
-    if (best_region == 0 && !tie) {
-      // the face the closest point lies in: only trusted when the point is clearly off its plane
-      const float sd = dot(d, cross(make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z)));
-      side = (best_d2 > 1e-12f && sd != 0.0f) ? (sd > 0.0f ? 1 : -1) : 0;
-    } else if (m.tri_pn != nullptr && best_region != 0 && best_d2 > 1e-12f) {
-      // an edge or a vertex: its pseudonormal (for a closed, consistently oriented surface the sign of d . n is the sign of
-      // the distance whatever the dihedral angles); a degenerate pseudonormal gives no verdict
-      const float4 n4 = reinterpret_cast<const float4 *>(m.tri_pn)[(size_t)best_t * 6 + (best_region - 1)];
-      const f3 n = make_f3(n4.x, n4.y, n4.z);
-      const float sd = dot(d, n), scale = sqrtf(dot(n, n) * best_d2);
-      side = fabsf(sd) > 1e-4f * scale ? (sd > 0.0f ? 1 : -1) : 0;
+  if (found) side = mesh_feature_side(m, p, cp, best_d2, best_t, best_region, tie);
+  return found;
+}
+
+// ---- the same walk by EIGHT LANES per query (an aligned group of a wavefront; all eight hold the same query and leave with
+// the same result).  A step covers three tree levels: the eight great-grandchildren of a node are adjacent in the heap
+// layout (one 256-byte run of boxes), lane j tests descendant j, the group's in-range mask is a slice of the wavefront
+// ballot, the nearest one is entered first and the others are owed a visit (eight bits per step level in a 64-bit trail);
+// at a leaf lane j tests triangles j, j + 8, ...  One query per lane is bound by the instruction stream of 64 walkers of
+// very different lengths sharing a wavefront (107 k instructions per wavefront for queries that need ~70 node visits,
+// sphere_mesh_walk_kernel); eight lanes per query give eight times the wavefronts for the same items and walks a third as
+// deep.  A leaf node here is any node >= n_leaves; the tree depth need not be a multiple of three (the last step is
+// narrower).
+template <int G>
+__device__ __forceinline__ float group_min(float v) {
+  v = fminf(v, dpp_f<0xB1>(v));
+  v = fminf(v, dpp_f<0x4E>(v));
+  v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror: lane i <-> 7 - i of its group of eight
+  if (G == 16) v = fminf(v, dpp_f<0x140>(v));  // row_mirror: i <-> 15 - i
+  return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned group_ballot(bool pred) {
+  return (unsigned)(__ballot(pred) >> (threadIdx.x & (64u - G))) & ((1u << G) - 1u);
+}
+// ``keys``: the calling lane's column of a [MESH_GROUP_LEVELS][blockDim.x] float table in LDS (the ordering key of this
+// lane's descendant at every step level: siblings are revisited nearest first and re-judged against the distance found
+// since, without fetching their boxes again).
+#define MESH_GROUP_LEVELS 8
+template <int G>
+__device__ __forceinline__ bool mesh_closest_point_group(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp, int &side, float *keys,
+                                                         int key_stride) {
+  side = 0;
+  constexpr int LV = G == 16 ? 4 : 3;  // tree levels per step
+  constexpr unsigned GM = (1u << G) - 1u;
+  constexpr float FAR = 3.0e38f;
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  const int g = threadIdx.x & (G - 1), gbase = threadIdx.x & (64 - G);
+  const int depth_leaves = 31 - __builtin_clz(m.n_leaves);
+  bool found = false, tie = false;
+  int best_t = 0, best_region = 0;
+  if (box_dist2(box[2], box[3], p) > best_d2) return false;
+  unsigned long long owed = 0ull;  // G bits per step level: the descendants still to visit
+  int node = 1, gl = 0;            // the node being visited sits at step level gl = depth min(gl * LV, depth_leaves)
+  while (true) {
+    const int d0 = min(gl * LV, depth_leaves);
+    if (d0 == depth_leaves) {
+      // ---- a leaf: lane j tests triangles j, j + G, ...
+      const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+      float l_d2 = FAR;
+      f3 l_c = p;
+      int l_t = 0, l_region = 0;
+      bool l_tie = false;
+      for (int t = t0 + g; t < t1; t += G) {
+        const TriRec r = tri[t];
+        int region;
+        const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+        const f3 d = p - c;
+        const float d2 = dot(d, d);
+        if (d2 <= l_d2) { l_tie = d2 == l_d2; l_d2 = d2; l_c = c; l_t = t; l_region = region; }
+      }
+      const float dmin = group_min<G>(l_d2);
+      if (dmin <= best_d2) {
+        const unsigned win = group_ballot<G>(l_d2 == dmin);
+        const int src = gbase | (__ffs((int)win) - 1);
+        // (the same distance from several triangles -- here, or equal to the best so far: a face verdict is not trusted)
+        tie = (__builtin_popcount(win) > 1) || (found && dmin == best_d2) || (__shfl((int)l_tie, src, 64) != 0);
+        cp = make_f3(__shfl(l_c.x, src, 64), __shfl(l_c.y, src, 64), __shfl(l_c.z, src, 64));
+        best_t = __shfl(l_t, src, 64);
+        best_region = __shfl(l_region, src, 64);
+        best_d2 = dmin;
+        found = true;
+      }
+    } else {
+      // ---- an interior node: its 2^s descendants s levels down, one per lane
+      const int s = min(LV, depth_leaves - d0), cnt = 1 << s;
+      const int child = (node << s) + (g < cnt ? g : 0);
+      const float4 lo = box[child * 2], hi = box[child * 2 + 1];
+      const float dist = g < cnt ? box_dist2(lo, hi, p) : FAR;
+      // nearest first; boxes the point is inside of (distance zero to each) order by the distance to their centres: one key,
+      // negative for those (-1 / (1 + centre distance^2))
+      const f3 cv = make_f3(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z) - 2.0f * p;
+      const float key = dist > 0.0f ? dist : -__frcp_rn(1.0f + dot(cv, cv));
+      keys[gl * key_stride] = key;
+      const bool in = key <= best_d2;
+      const unsigned mask = group_ballot<G>(in);
+      if (mask != 0u) {
+        const float kmin = group_min<G>(in ? key : FAR);
+        const int j0 = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
+        owed = (owed & ~((unsigned long long)GM << (G * gl))) | ((unsigned long long)(mask & ~(1u << j0)) << (G * gl));
+        node = (node << s) + j0;
+        ++gl;
+        continue;
+      }
     }
+    // ---- the next node: the nearest sibling still owed a visit and still in range, else up
+    bool more = false;
+    while (gl > 0) {
+      const int lvl = gl - 1, dp = lvl * LV, sp = min(LV, depth_leaves - dp);
+      const int parent = node >> sp;
+      const unsigned rest = (unsigned)(owed >> (G * lvl)) & GM;
+      if (rest != 0u) {
+        const float key = keys[lvl * key_stride];
+        const bool in = ((rest >> g) & 1u) != 0u && key <= best_d2;
+        const unsigned mask = group_ballot<G>(in);
+        if (mask != 0u) {
+          const float kmin = group_min<G>(in ? key : FAR);
+          const int j = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
+          owed = (owed & ~((unsigned long long)GM << (G * lvl))) | ((unsigned long long)(mask & ~(1u << j)) << (G * lvl));
+          node = (parent << sp) + j;
+          more = true;
+          break;
+        }
+        owed &= ~((unsigned long long)GM << (G * lvl));
+      }
+      node = parent;
+      gl = lvl;
+    }
+    if (!more) break;
   }
+  if (found) side = mesh_feature_side(m, p, cp, best_d2, best_t, best_region, tie);
   return found;
 }
 
@@ -232,8 +360,9 @@ __device__ __forceinline__ bool mesh_inside(const curobo_hip_mesh &m, f3 p) {
 // point is not -- e.g. a sweep sample within half_dist of a centre that is outside) and the root box gate a second walk
 // without a radius, whose closest feature then says which side the point is on.  ONE walk site (a retry loop): inlined
 // copies of the walk are what the register count of the callers is made of.
+template <int COOP = 0>
 __device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp, float radius, float max_distance, bool may_be_inside,
-                                                 f3 &g) {
+                                                 f3 &g, float *keys = nullptr, int key_stride = 0) {
   g = make_f3(0.f, 0.f, 0.f);
   bool full = !(radius < max_distance);
   float d2 = 0.0f;
@@ -244,7 +373,7 @@ __device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp
   for (int attempt = 0; attempt < 2; attempt++) {
     const float r = full ? max_distance : radius;
     d2 = r * r;
-    found = mesh_closest_point(m, lp, d2, cp, side);
+    found = COOP ? mesh_closest_point_group<COOP ? COOP : 8>(m, lp, d2, cp, side, keys, key_stride) : mesh_closest_point(m, lp, d2, cp, side);
     if (found || full || !may_be_inside) break;
     const float *rb = m.node_box + 8;  // root box: a point outside it is outside the (closed) surface
     if (lp.x < rb[0] || lp.y < rb[1] || lp.z < rb[2] || lp.x > rb[4] || lp.y > rb[5] || lp.z > rb[6]) break;
@@ -313,10 +442,10 @@ __device__ __forceinline__ bool mesh_early_reject(const MeshSlot &s, f3 lc, floa
 // Cost and mesh-frame gradient of ONE sphere against ONE mesh that passed the early reject: the centre sample plus the
 // sweep towards the previous / next point (wp_sweep_collision_kernel.py:176-254; the mesh twin of
 // scene_device.hpp::obstacle_contribution).  lc = centre in the mesh frame, reach as for mesh_early_reject.
-template <int SWEEP>
+template <int SWEEP, int COOP = 0>
 __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
                                                   f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
-                                                  float reach, float &cost_sum, f3 &grad_local) {
+                                                  float reach, float &cost_sum, f3 &grad_local, float *keys = nullptr, int key_stride = 0) {
   // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
   const float max_distance = fmaxf(s.max_half_diag, r_adj);
   // how far the centre's distance matters: its cost below r_adj, the sweep culling below r_adj + the half segment
@@ -331,7 +460,7 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
 #pragma unroll 1
   for (;;) {
     f3 g;
-    const float sdf = mesh_sdf_within(s.m, qp, q_radius, max_distance, q_may_in, g);
+    const float sdf = mesh_sdf_within<COOP>(s.m, qp, q_radius, max_distance, q_may_in, g, keys, key_stride);
     if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
     const float pen = -sdf + r_adj;
     float c = 0.0f, gs = 0.0f;

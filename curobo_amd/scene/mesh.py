@@ -44,7 +44,7 @@ class MeshStore:
     #: outside it -- the opposite of what its cuboid and voxel queries return there); 1 = toward the obstacle on both sides
     REFERENCE_GRADIENT, CONSISTENT_GRADIENT = 0, 1
 
-    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 4, gradient_mode: int = 0):
+    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 8, gradient_mode: int = 0):
         self.device = torch.device(device)
         E = len(envs)
         n = max_n or max(1, max(len(e) for e in envs))
