@@ -366,6 +366,12 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 //    + four wavefronts a SIMD (128 registers)      577 us
 //    + sibling keys in LDS, nearest sibling next   460 us   (no box is fetched twice; half the dependent loads)
 //    sixteen lanes per sphere, leaves of 16        698 us   (before the last two steps; wider groups idle more lanes)
+// Work of that launch: 129 k of the 2.2 M spheres pass the select kernel, 332 k closest-point queries, 1.66 M interior steps,
+// 0.57 M leaves (17 moves per sphere); the walk kernel is bound by instruction issue (182 M VALU + 102 M SALU wave-
+// instructions: the eight spheres of a wavefront are each somewhere else in the program), not by the latency of the box
+// fetches: more wavefronts per SIMD (96 / 80 registers, some spilled) change nothing, and neither does the while-while form
+// (all eight move through interior nodes until each is at a leaf, then the leaves together: 531 us -- waiting costs what
+// the shared leaf code saves).
 // (Measured and dropped before that: the same work as ONE loop in which every lane runs its own program -- an explicit state
 // machine around a walker shared by the closest-point and the ray mode, leaves one triangle per iteration, lanes refilled
 // from the queue.  It keeps every lane busy, and executes the union of all states' code in every iteration: 334 M VALU +
@@ -391,6 +397,7 @@ __global__ void __launch_bounds__(256) MESH_WALK_ATTR sphere_mesh_walk_kernel(co
     // (a group beyond the end of the queue repeats the last entry so that ballots and shuffles stay whole; it writes nothing)
     const bool live_group = q < n;
     const uint2 e = qa.queue[live_group ? q : n - 1];
+    if (live_group && (threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(6, 1);
     const long sidx = (long)e.x;
     const int b = (int)(sidx / hs);
     const int h = (int)((sidx - (long)b * hs) / a.nspheres);
@@ -418,6 +425,7 @@ __global__ void __launch_bounds__(256) MESH_WALK_ATTR sphere_mesh_walk_kernel(co
       const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
       float cost_sum = 0.0f;
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
+      if ((threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(7, 1);
       mesh_contribution<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
                                      half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, 256);
       if (cost_sum > 0.0f) {

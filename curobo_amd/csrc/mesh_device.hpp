@@ -216,6 +216,7 @@ __device__ __forceinline__ bool mesh_closest_point_group(const curobo_hip_mesh &
   const int depth_leaves = 31 - __builtin_clz(m.n_leaves);
   bool found = false, tie = false;
   int best_t = 0, best_region = 0;
+  if (g == 0) CUROBO_MESH_COUNT(0, 1);
   if (box_dist2(box[2], box[3], p) > best_d2) return false;
   unsigned long long owed = 0ull;  // G bits per step level: the descendants still to visit
   int node = 1, gl = 0;            // the node being visited sits at step level gl = depth min(gl * LV, depth_leaves)
@@ -223,6 +224,7 @@ __device__ __forceinline__ bool mesh_closest_point_group(const curobo_hip_mesh &
     const int d0 = min(gl * LV, depth_leaves);
     if (d0 == depth_leaves) {
       // ---- a leaf: lane j tests triangles j, j + G, ...
+      if (g == 0) CUROBO_MESH_COUNT(2, 1);
       const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
       float l_d2 = FAR;
       f3 l_c = p;
@@ -250,6 +252,7 @@ __device__ __forceinline__ bool mesh_closest_point_group(const curobo_hip_mesh &
       }
     } else {
       // ---- an interior node: its 2^s descendants s levels down, one per lane
+      if (g == 0) CUROBO_MESH_COUNT(1, 1);
       const int s = min(LV, depth_leaves - d0), cnt = 1 << s;
       const int child = (node << s) + (g < cnt ? g : 0);
       const float4 lo = box[child * 2], hi = box[child * 2 + 1];
