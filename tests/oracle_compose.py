@@ -7,9 +7,11 @@ import numpy as np
 
 
 def trajopt_cost_and_gradient(oracle, model, cfg, knots, start, *, goal_position=None, goal_quat=None, idxs_goal=None,
-                              scene_arrays=None, effort_limit=None, sweep=None):
+                              scene_arrays=None, effort_limit=None, sweep=None, scene_spheres=None):
     """``cfg``: a ``TrajOptRolloutCfg``.  Goals default to what a fresh ``TrajOptRollout`` holds (origin, identity
-    quaternion, one goal).  Returns dict(cost [B], grad_knots [B, nk, D], tau [B*H, D] or None, parts)."""
+    quaternion, one goal).  ``scene_spheres`` [B, H, S, 4]: evaluate the scene stage on these (the device's own FK output) instead
+    of the oracle's -- the swept cost is discontinuous in the sphere positions (a sphere that does not move counts its centre
+    up to three times, wp_sweep_collision_kernel.py:197-203), so the last bit of an FK decides.  Returns dict(cost [B], grad_knots [B, nk, D], tau [B*H, D] or None, parts)."""
     md = model.as_dict()
     B, nk, D = knots.shape
     H = cfg.padded_horizon
@@ -59,7 +61,7 @@ def trajopt_cost_and_gradient(oracle, model, cfg, knots, start, *, goal_position
     wc = None
     if scene_arrays is not None:
         use_sweep = cfg.use_sweep if sweep is None else sweep
-        wc = oracle.scene_collision(sph, scene_arrays, cfg.scene_collision_weight, cfg.scene_activation_distance, sweep=use_sweep,
+        wc = oracle.scene_collision(sph if scene_spheres is None else np.asarray(scene_spheres, np.float32).reshape(sph.shape), scene_arrays, cfg.scene_collision_weight, cfg.scene_activation_distance, sweep=use_sweep,
                                     enable_speed_metric=use_sweep and cfg.use_speed_metric, speed_dt=cfg.traj_dt)
         cost = cost + wc["distance"].sum((1, 2))
         gs = gs + wc["gradient"].reshape(B * H, -1, 4) * np.array([1, 1, 1, 0], np.float32)

@@ -268,6 +268,70 @@ def test_rollout_with_a_mesh_scene_uses_the_kernel_sequence(oracle, device):
     assert float(grad.abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("with_cuboids", [True, False], ids=["cuboids+meshes", "meshes only"])
+def test_trajopt_rollout_in_a_mesh_world_against_the_oracle_composition(with_cuboids, oracle, device):
+    """The full trajopt rollout (tool pose + c-space + self collision + scene) in a world with meshes.  ``fused_available`` is
+    off (the fused launch does not walk meshes) and the kernel sequence runs with the mesh launch adding its share to the
+    cuboid kernel's: cost and d cost / d knots against the oracle's composition of the stages with the mesh kind in its scene
+    restatement, and replayed from a hipGraph.
+    (Measured and not kept: the fused launch for every other term + the meshes' share by its own chain on a side stream --
+    B-spline samples -> FK -> BVH walk -> FK VJP -> B-spline VJP, added to the fused result; equal to this sequence to 2e-7
+    and SLOWER, 575 us against 540 us per 1024 rollouts in the bench's mesh world: FK -> mesh walk (447 us) -> FK VJP is the
+    critical path of both, and the fused launch next to it only competes for the CUs.)"""
+    from oracle.oracle import mesh_scene_arrays
+    from oracle_compose import trajopt_cost_and_gradient
+
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    arrays = cuboid_scene_arrays(c2_world()) if with_cuboids else {}
+    B = 32
+    x = torch.as_tensor(seed_knots(model, B, 12, seed=11), device=device).reshape(B, -1)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    fused_ro = ro = TrajOptRollout(kin, SceneData.from_arrays(arrays or None, device, meshes=mesh_world()), B, TrajOptRolloutCfg())
+    assert not ro.fused_available()
+    ro.update_start_state(start)
+    ro.cost_and_gradient(x)
+    cf, gf = [t.clone() for t in ro.cost_and_gradient(x)]
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cg, gg = ro.cost_and_gradient(x)
+    cg.zero_(), gg.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cg, cf) and torch.equal(gg, gf), "hipGraph replay == eager"
+    only = TrajOptRollout(kin, SceneData.from_arrays(arrays, device) if with_cuboids else None, B, TrajOptRolloutCfg())
+    only.update_start_state(start)
+    assert bool((cf > only.cost_and_gradient(x)[0] * 1.01 + 1.0).any()), "the meshes must matter"
+    # The oracle's composition of the stages.  Its scene stage is evaluated on the spheres the device computed: the swept cost
+    # of a sphere that does not move counts its centre once, twice or three times depending on whether its neighbours are
+    # EXACTLY where it is (wp_sweep_collision_kernel.py:197-203), and the link next to the base sits still over the first
+    # points -- the last bit of its FK decides (test_gpu_parity_benchmarked.py holds that rule per sphere).
+    cfg = ro.cfg
+    sph = fused_ro.robot_spheres.cpu().numpy()
+    ref = trajopt_cost_and_gradient(oracle, model, cfg, x.cpu().numpy().reshape(B, 12, -1), start_configuration(model),
+                                    scene_arrays={**arrays, **mesh_scene_arrays(mesh_world())}, scene_spheres=sph)
+    kw = dict(sweep=cfg.use_sweep, enable_speed_metric=cfg.use_sweep and cfg.use_speed_metric, speed_dt=cfg.traj_dt)
+    mesh_ref = oracle.scene_collision(sph, mesh_scene_arrays(mesh_world()), cfg.scene_collision_weight, cfg.scene_activation_distance, **kw)
+    if not with_cuboids:  # (scene_dist holds the meshes' share alone)
+        d = fused_ro.scene_dist.cpu().numpy()
+        bad = np.abs(d - mesh_ref["distance"]) > 2e-5 * cfg.scene_collision_weight * 20 + 1e-3 * np.abs(mesh_ref["distance"])
+        assert bad.mean() < 1e-3, bad.mean()
+    want, got = ref["cost"], cf.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=2e-2)
+    # trajectories in which no sweep sample took another branch (a sample's penetration crossing zero within rounding):
+    # cost to 1e-5, gradient to 5e-4 of its scale
+    close = np.abs(got - want) < 1e-5 * np.abs(want)
+    print(f"[mesh world] vs the oracle: {int(close.sum())} of {B} trajectories to 1e-5, worst {float((np.abs(got - want) / np.abs(want)).max()):.2e}")
+    assert close.mean() >= 0.75
+    gk = ref["grad_knots"].reshape(B, -1)
+    np.testing.assert_allclose(gf.cpu().numpy()[close], gk[close], rtol=5e-4, atol=5e-4 * np.abs(gk[close]).max())
+
+
 def test_collision_checker_from_a_scene_config_with_a_mesh_file(tmp_path, oracle, device):
     """``scene_model={"cuboid": ..., "mesh": {name: {"file_path": *.obj, "pose", "scale"}}}`` (the reference's SceneCfg format)
     through ``RobotCollisionChecker``: the OBJ is read, scaled, placed; robot-vs-scene distances equal the oracle's"""
