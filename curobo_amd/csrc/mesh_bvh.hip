@@ -365,7 +365,12 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 //    eight lanes per sphere, leaves of 4 / of 8   801 / 677 us
 //    + four wavefronts a SIMD (128 registers)      577 us
 //    + sibling keys in LDS, nearest sibling next   460 us   (no box is fetched twice; half the dependent loads)
-//    sixteen lanes per sphere, leaves of 16        698 us   (before the last two steps; wider groups idle more lanes)
+//    + one wavefront a workgroup                   420 us   (a wavefront's slot is free when ITS eight spheres are done,
+//                                                           not when the slowest of 32 is; wavefront lifetimes: mean 67 us,
+//                                                           the longest three times that)
+//    sixteen lanes per sphere, leaves of 16        698 us   (before the last three steps; wider groups idle more lanes)
+// Without effect: the closest-point-on-triangle test without branches (459 us against 460), five wavefronts a SIMD (421),
+// a cap on the grid (the workgroups beyond the queue's end return at once).
 // Work of that launch: 129 k of the 2.2 M spheres pass the select kernel, 332 k closest-point queries, 1.66 M interior steps,
 // 0.57 M leaves (17 moves per sphere); the walk kernel is bound by instruction issue (182 M VALU + 102 M SALU wave-
 // instructions: the eight spheres of a wavefront are each somewhere else in the program), not by the latency of the box
@@ -379,19 +384,25 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 #ifndef MESH_WALK_GROUP
 #define MESH_WALK_GROUP 8
 #endif
+#ifndef MESH_WALK_THREADS
+#define MESH_WALK_THREADS 64  // one wavefront a workgroup: its slot is free again when ITS eight spheres are done
+#endif
+#ifndef MESH_WALK_MAX_BLOCKS
+#define MESH_WALK_MAX_BLOCKS (1 << 20)
+#endif
 #ifndef MESH_WALK_ATTR
 #define MESH_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // 128 registers: four wavefronts a SIMD, nothing spilled
 #endif
 template <int SWEEP>
-__global__ void __launch_bounds__(256) MESH_WALK_ATTR sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
+__global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
   const MeshCollArgs &a = qa.c;
   const uint32_t n = qa.counter[0];
   const int hs = a.horizon * a.nspheres;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
   const float w = a.weight[0], eta = a.eta[0];
   // lane 0 of a group writes
-  constexpr unsigned G = MESH_WALK_GROUP, PER_WG = 256u / G;
-  __shared__ float group_keys[MESH_GROUP_LEVELS * 256];
+  constexpr unsigned G = MESH_WALK_GROUP, PER_WG = MESH_WALK_THREADS / G;
+  __shared__ float group_keys[MESH_GROUP_LEVELS * MESH_WALK_THREADS];
   for (uint32_t q0 = blockIdx.x * PER_WG; q0 < n; q0 += gridDim.x * PER_WG) {
     const uint32_t q = q0 + threadIdx.x / G;
     // (a group beyond the end of the queue repeats the last entry so that ballots and shuffles stay whole; it writes nothing)
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(256) MESH_WALK_ATTR sphere_mesh_walk_kernel(co
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
       if ((threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(7, 1);
       mesh_contribution<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
-                                     half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, 256);
+                                     half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, MESH_WALK_THREADS);
       if (cost_sum > 0.0f) {
         const f3 gw = mesh_to_world_vector(slot, grad_local);
         dsum += w * cost_sum;
@@ -574,13 +585,13 @@ static int sphere_mesh_collision_impl(
       qa.queue = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(workspace) + 16);
       if (hipMemsetAsync(workspace, 0, 16, st) != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot clear the queue counter", what);
       // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
-      const unsigned walk_blocks = (unsigned)std::min<long>(4096, ceil_div_l(total, 256 / MESH_WALK_GROUP));
+      const unsigned walk_blocks = (unsigned)std::min<long>(MESH_WALK_MAX_BLOCKS, ceil_div_l(total, MESH_WALK_THREADS / MESH_WALK_GROUP));
       if (sweep_steps > 0) {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), grid, block, 0, st, qa);
-        hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
       } else {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<0>), grid, block, 0, st, qa);
-        hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
       }
       continue;
     }

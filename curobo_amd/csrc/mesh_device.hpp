@@ -41,25 +41,36 @@ __device__ __forceinline__ float box_dist2(const float4 lo, const float4 hi, f3 
 
 // closest point of triangle (a, a + ab, a + ac) to p (Ericson, Real-Time Collision Detection 5.1.5)
 // region: 0 = the face, 1 / 2 / 3 = vertex a / b / c, 4 / 5 / 6 = edge ab / bc / ca (the order of curobo_hip_mesh.tri_pn, + 1)
+// Without branches: the lanes of a wavefront meet different regions, and a chain of early returns is executed as the union of
+// its paths with the exec-mask bookkeeping of every test.  Every region's test is evaluated, the first that holds in
+// Ericson's order (a, b, ab, c, ca, bc, face) is taken, the three edge cases share one division.
 __device__ __forceinline__ f3 closest_on_triangle(f3 p, f3 a, f3 ab, f3 ac, int &region) {
   const f3 ap = p - a;
   const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-  if (d1 <= 0.0f && d2 <= 0.0f) { region = 1; return a; }
   const f3 b = a + ab, bp = p - b;
   const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-  if (d3 >= 0.0f && d4 <= d3) { region = 2; return b; }
-  const float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) { region = 4; return a + (d1 / (d1 - d3)) * ab; }
   const f3 c = a + ac, cp = p - c;
   const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-  if (d6 >= 0.0f && d5 <= d6) { region = 3; return c; }
-  const float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) { region = 6; return a + (d2 / (d2 - d6)) * ac; }
-  const float va = d3 * d6 - d5 * d4;
-  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) { region = 5; return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b); }
-  const float den = 1.0f / (va + vb + vc);
-  region = 0;  // the face region: the closest point is the projection on the triangle's plane
-  return a + (vb * den) * ab + (vc * den) * ac;
+  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  const float e43 = d4 - d3, e56 = d5 - d6;
+  const bool at_a = d1 <= 0.0f && d2 <= 0.0f;
+  const bool at_b = d3 >= 0.0f && d4 <= d3;
+  const bool on_ab = vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f;
+  const bool at_c = d6 >= 0.0f && d5 <= d6;
+  const bool on_ca = vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f;
+  const bool on_bc = va <= 0.0f && e43 >= 0.0f && e56 >= 0.0f;
+  region = at_a ? 1 : at_b ? 2 : on_ab ? 4 : at_c ? 3 : on_ca ? 6 : on_bc ? 5 : 0;
+  // the edge point: base + (num / den) dir
+  const float num = on_ab ? d1 : on_ca ? d2 : e43;
+  const float den = on_ab ? d1 - d3 : on_ca ? d2 - d6 : e43 + e56;
+  const bool from_a = on_ab || on_ca;
+  const f3 dir = on_ab ? ab : on_ca ? ac : c - b;
+  const f3 edge = (from_a ? a : b) + (num / den) * dir;
+  const float inv = 1.0f / (va + vb + vc);
+  const f3 face = a + (vb * inv) * ab + (vc * inv) * ac;  // the projection on the triangle's plane
+  const f3 vert = at_a ? a : at_b ? b : c;
+  const bool is_vert = region >= 1 && region <= 3, is_face = region == 0;
+  return is_vert ? vert : is_face ? face : edge;
 }
 
 // ---- the closest-point walk: nearer child first, no stack.  The tree is complete and in heap layout, so the node index IS
