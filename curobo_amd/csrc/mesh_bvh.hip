@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 
 // ---- the walk kernel: EIGHT LANES per live sphere (queue entry).  All eight run the sphere's scalar program (its slots in
 // ascending order, every sample of a slot through the one query site of mesh_contribution) on the same values; only the
-// tree walks split the work (mesh_device.hpp::mesh_closest_point_group: three tree levels per step, one descendant box or
+// tree walks split the work (mesh_device.hpp::mesh_contribution_group: three tree levels per step, one descendant box or
 // one leaf triangle per lane, sibling keys kept in LDS).  Measured on the bench's mesh world (tools/r04/mesh_stats.py: 1024 x 33 points x 65
 // spheres, the C2 world's 4 cuboids as meshes of 3072 triangles each, sweep 3), launch = select + walk:
 //    one sphere per lane, binary walk            1430 us   (112 M VALU + 106 M SALU wave-instructions, ~150 of 8192
@@ -369,6 +369,11 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 //                                                           not when the slowest of 32 is; wavefront lifetimes: mean 67 us,
 //                                                           the longest three times that)
 //    sixteen lanes per sphere, leaves of 16        698 us   (before the last three steps; wider groups idle more lanes)
+//    + every query of a sphere in ONE loop (a group settles a query and starts its next one while the others walk;
+//      the lanes keep their own best triangle, the closest point is settled once per query)      402 us
+// The walk kernel then makes 687 k passes through its loop (a wavefront: 43) for 2.64 M group moves and transitions: 3.85
+// of a wavefront's eight groups are busy in a pass; ~310 instructions per pass, 4.1 SIMD cycles per instruction -- the
+// rate every issue-bound kernel of this library runs at (2.9 - 4.4, profiles/r04_b_counters_by_kernel.json).
 // Without effect: the closest-point-on-triangle test without branches (459 us against 460), five wavefronts a SIMD (421),
 // a cap on the grid (the workgroups beyond the queue's end return at once).
 // Work of that launch: 129 k of the 2.2 M spheres pass the select kernel, 332 k closest-point queries, 1.66 M interior steps,
@@ -437,7 +442,7 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
       float cost_sum = 0.0f;
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
       if ((threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(7, 1);
-      mesh_contribution<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
+      mesh_contribution_group<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
                                      half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, MESH_WALK_THREADS);
       if (cost_sum > 0.0f) {
         const f3 gw = mesh_to_world_vector(slot, grad_local);

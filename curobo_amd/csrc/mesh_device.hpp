@@ -189,8 +189,8 @@ __device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 
   return found;
 }
 
-// ---- the same walk by EIGHT LANES per query (an aligned group of a wavefront; all eight hold the same query and leave with
-// the same result).  A step covers three tree levels: the eight great-grandchildren of a node are adjacent in the heap
+// ---- the same walk by EIGHT LANES per query (mesh_contribution_group below: an aligned group of a wavefront; all eight hold
+// the same query and leave with the same result).  A step covers three tree levels: the eight great-grandchildren of a node are adjacent in the heap
 // layout (one 256-byte run of boxes), lane j tests descendant j, the group's in-range mask is a slice of the wavefront
 // ballot, the nearest one is entered first and the others are owed a visit (eight bits per step level in a 64-bit trail);
 // at a leaf lane j tests triangles j, j + 8, ...  One query per lane is bound by the instruction stream of 64 walkers of
@@ -210,108 +210,10 @@ template <int G>
 __device__ __forceinline__ unsigned group_ballot(bool pred) {
   return (unsigned)(__ballot(pred) >> (threadIdx.x & (64u - G))) & ((1u << G) - 1u);
 }
-// ``keys``: the calling lane's column of a [MESH_GROUP_LEVELS][blockDim.x] float table in LDS (the ordering key of this
-// lane's descendant at every step level: siblings are revisited nearest first and re-judged against the distance found
-// since, without fetching their boxes again).
+// ``keys`` (mesh_contribution_group): the calling lane's column of a [MESH_GROUP_LEVELS][blockDim.x] float table in LDS (the
+// ordering key of this lane's descendant at every step level: siblings are revisited nearest first and re-judged against the
+// distance found since, without fetching their boxes again).
 #define MESH_GROUP_LEVELS 8
-template <int G>
-__device__ __forceinline__ bool mesh_closest_point_group(const curobo_hip_mesh &m, f3 p, float &best_d2, f3 &cp, int &side, float *keys,
-                                                         int key_stride) {
-  side = 0;
-  constexpr int LV = G == 16 ? 4 : 3;  // tree levels per step
-  constexpr unsigned GM = (1u << G) - 1u;
-  constexpr float FAR = 3.0e38f;
-  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
-  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
-  const int g = threadIdx.x & (G - 1), gbase = threadIdx.x & (64 - G);
-  const int depth_leaves = 31 - __builtin_clz(m.n_leaves);
-  bool found = false, tie = false;
-  int best_t = 0, best_region = 0;
-  if (g == 0) CUROBO_MESH_COUNT(0, 1);
-  if (box_dist2(box[2], box[3], p) > best_d2) return false;
-  unsigned long long owed = 0ull;  // G bits per step level: the descendants still to visit
-  int node = 1, gl = 0;            // the node being visited sits at step level gl = depth min(gl * LV, depth_leaves)
-  while (true) {
-    const int d0 = min(gl * LV, depth_leaves);
-    if (d0 == depth_leaves) {
-      // ---- a leaf: lane j tests triangles j, j + G, ...
-      if (g == 0) CUROBO_MESH_COUNT(2, 1);
-      const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
-      float l_d2 = FAR;
-      f3 l_c = p;
-      int l_t = 0, l_region = 0;
-      bool l_tie = false;
-      for (int t = t0 + g; t < t1; t += G) {
-        const TriRec r = tri[t];
-        int region;
-        const f3 c = closest_on_triangle(p, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
-        const f3 d = p - c;
-        const float d2 = dot(d, d);
-        if (d2 <= l_d2) { l_tie = d2 == l_d2; l_d2 = d2; l_c = c; l_t = t; l_region = region; }
-      }
-      const float dmin = group_min<G>(l_d2);
-      if (dmin <= best_d2) {
-        const unsigned win = group_ballot<G>(l_d2 == dmin);
-        const int src = gbase | (__ffs((int)win) - 1);
-        // (the same distance from several triangles -- here, or equal to the best so far: a face verdict is not trusted)
-        tie = (__builtin_popcount(win) > 1) || (found && dmin == best_d2) || (__shfl((int)l_tie, src, 64) != 0);
-        cp = make_f3(__shfl(l_c.x, src, 64), __shfl(l_c.y, src, 64), __shfl(l_c.z, src, 64));
-        best_t = __shfl(l_t, src, 64);
-        best_region = __shfl(l_region, src, 64);
-        best_d2 = dmin;
-        found = true;
-      }
-    } else {
-      // ---- an interior node: its 2^s descendants s levels down, one per lane
-      if (g == 0) CUROBO_MESH_COUNT(1, 1);
-      const int s = min(LV, depth_leaves - d0), cnt = 1 << s;
-      const int child = (node << s) + (g < cnt ? g : 0);
-      const float4 lo = box[child * 2], hi = box[child * 2 + 1];
-      const float dist = g < cnt ? box_dist2(lo, hi, p) : FAR;
-      // nearest first; boxes the point is inside of (distance zero to each) order by the distance to their centres: one key,
-      // negative for those (-1 / (1 + centre distance^2))
-      const f3 cv = make_f3(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z) - 2.0f * p;
-      const float key = dist > 0.0f ? dist : -__frcp_rn(1.0f + dot(cv, cv));
-      keys[gl * key_stride] = key;
-      const bool in = key <= best_d2;
-      const unsigned mask = group_ballot<G>(in);
-      if (mask != 0u) {
-        const float kmin = group_min<G>(in ? key : FAR);
-        const int j0 = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
-        owed = (owed & ~((unsigned long long)GM << (G * gl))) | ((unsigned long long)(mask & ~(1u << j0)) << (G * gl));
-        node = (node << s) + j0;
-        ++gl;
-        continue;
-      }
-    }
-    // ---- the next node: the nearest sibling still owed a visit and still in range, else up
-    bool more = false;
-    while (gl > 0) {
-      const int lvl = gl - 1, dp = lvl * LV, sp = min(LV, depth_leaves - dp);
-      const int parent = node >> sp;
-      const unsigned rest = (unsigned)(owed >> (G * lvl)) & GM;
-      if (rest != 0u) {
-        const float key = keys[lvl * key_stride];
-        const bool in = ((rest >> g) & 1u) != 0u && key <= best_d2;
-        const unsigned mask = group_ballot<G>(in);
-        if (mask != 0u) {
-          const float kmin = group_min<G>(in ? key : FAR);
-          const int j = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
-          owed = (owed & ~((unsigned long long)GM << (G * lvl))) | ((unsigned long long)(mask & ~(1u << j)) << (G * lvl));
-          node = (parent << sp) + j;
-          more = true;
-          break;
-        }
-        owed &= ~((unsigned long long)GM << (G * lvl));
-      }
-      node = parent;
-      gl = lvl;
-    }
-    if (!more) break;
-  }
-  if (found) side = mesh_feature_side(m, p, cp, best_d2, best_t, best_region, tie);
-  return found;
-}
 
 // crossings of the ray p + t d (t > 0) with the surface (fixed-order stackless walk: the order does not matter here)
 __device__ __forceinline__ int mesh_ray_crossings(const curobo_hip_mesh &m, f3 p, f3 d) {
@@ -374,9 +276,8 @@ __device__ __forceinline__ bool mesh_inside(const curobo_hip_mesh &m, f3 p) {
 // point is not -- e.g. a sweep sample within half_dist of a centre that is outside) and the root box gate a second walk
 // without a radius, whose closest feature then says which side the point is on.  ONE walk site (a retry loop): inlined
 // copies of the walk are what the register count of the callers is made of.
-template <int COOP = 0>
 __device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp, float radius, float max_distance, bool may_be_inside,
-                                                 f3 &g, float *keys = nullptr, int key_stride = 0) {
+                                                 f3 &g) {
   g = make_f3(0.f, 0.f, 0.f);
   bool full = !(radius < max_distance);
   float d2 = 0.0f;
@@ -387,7 +288,7 @@ __device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp
   for (int attempt = 0; attempt < 2; attempt++) {
     const float r = full ? max_distance : radius;
     d2 = r * r;
-    found = COOP ? mesh_closest_point_group<COOP ? COOP : 8>(m, lp, d2, cp, side, keys, key_stride) : mesh_closest_point(m, lp, d2, cp, side);
+    found = mesh_closest_point(m, lp, d2, cp, side);
     if (found || full || !may_be_inside) break;
     const float *rb = m.node_box + 8;  // root box: a point outside it is outside the (closed) surface
     if (lp.x < rb[0] || lp.y < rb[1] || lp.z < rb[2] || lp.x > rb[4] || lp.y > rb[5] || lp.z > rb[6]) break;
@@ -456,10 +357,10 @@ __device__ __forceinline__ bool mesh_early_reject(const MeshSlot &s, f3 lc, floa
 // Cost and mesh-frame gradient of ONE sphere against ONE mesh that passed the early reject: the centre sample plus the
 // sweep towards the previous / next point (wp_sweep_collision_kernel.py:176-254; the mesh twin of
 // scene_device.hpp::obstacle_contribution).  lc = centre in the mesh frame, reach as for mesh_early_reject.
-template <int SWEEP, int COOP = 0>
+template <int SWEEP>
 __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
                                                   f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
-                                                  float reach, float &cost_sum, f3 &grad_local, float *keys = nullptr, int key_stride = 0) {
+                                                  float reach, float &cost_sum, f3 &grad_local) {
   // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
   const float max_distance = fmaxf(s.max_half_diag, r_adj);
   // how far the centre's distance matters: its cost below r_adj, the sweep culling below r_adj + the half segment
@@ -474,7 +375,7 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
 #pragma unroll 1
   for (;;) {
     f3 g;
-    const float sdf = mesh_sdf_within<COOP>(s.m, qp, q_radius, max_distance, q_may_in, g, keys, key_stride);
+    const float sdf = mesh_sdf_within(s.m, qp, q_radius, max_distance, q_may_in, g);
     if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
     const float pen = -sdf + r_adj;
     float c = 0.0f, gs = 0.0f;
@@ -524,6 +425,195 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
     // it lies within half_dist of the centre, so it can only be deep inside when the centre is inside
     q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
     q_may_in = sdf_c < half_dist;
+  }
+}
+
+// ---- the same contribution by a GROUP of G lanes (sphere_mesh_walk_kernel), every query of the item in ONE loop.
+// With the queries as an outer loop around a group walk (a function of its own through most of round 4) the groups of a
+// wavefront meet again after every query: the wavefront makes (sum over its query rounds of the LONGEST walk of the round) passes through the loop body --
+// 74 on the bench's mesh world where a sphere needs 17 moves.  Here a group that has finished a query settles it and
+// starts its next one while the others are still walking; the wavefront's pass count is the longest TOTAL of its groups.
+// Per pass every group makes one move (down into the nearest descendant / to the nearest sibling still owed / a leaf's
+// triangles) or one transition between queries.
+template <int SWEEP, int G>
+__device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
+                                                        f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
+                                                        float reach, float &cost_sum, f3 &grad_local, float *keys, int key_stride) {
+  constexpr int LV = G == 16 ? 4 : 3;  // tree levels per step
+  constexpr unsigned GM = (1u << G) - 1u;
+  constexpr float FAR = 3.0e38f;
+  const curobo_hip_mesh &m = s.m;
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  const int g = threadIdx.x & (G - 1), gbase = threadIdx.x & (64 - G);
+  const int depth_leaves = 31 - __builtin_clz(m.n_leaves);
+  const float max_distance = fmaxf(s.max_half_diag, r_adj);      // (mesh_contribution)
+  const float cull_slack = 2e-6f + 1e-6f * max_distance;
+  // the item's sweep state (mesh_contribution)
+  f3 g_c = make_f3(0.f, 0.f, 0.f), ln = lc, qp = lc;
+  float sdf_c = 0.0f, pen_c = 0.0f, c_c = 0.0f, gs_c = 0.0f, half_dist = 0.0f, inv_half = 0.0f, jump = 0.0f;
+  float q_radius = (r_adj + reach + cull_slack) * 1.0001f + 1e-6f;
+  bool q_may_in = true;
+  int dir = -1, k = 0;
+  // the running query (mesh_sdf_within + the walk): every lane keeps the best of ITS triangles, only the
+  // distance is shared while walking (it prunes); which lane holds the closest point is settled when the walk is over
+  bool full = !(q_radius < max_distance);
+  float best_d2 = 0.0f, limit_d2 = 0.0f, l_d2 = FAR;
+  f3 l_c = lc;
+  int l_t = 0, l_region = 0, node = 0, gl = 0;
+  bool l_tie = false;
+  unsigned long long owed = 0ull;
+  auto begin_query = [&]() {
+    if (g == 0) CUROBO_MESH_COUNT(0, 1);
+    const float r = full ? max_distance : q_radius;
+    limit_d2 = best_d2 = r * r;
+    l_d2 = FAR;
+    l_tie = false;
+    owed = 0ull;
+    gl = 0;
+    node = box_dist2(box[2], box[3], qp) > best_d2 ? 0 : 1;
+  };
+  begin_query();
+#pragma unroll 1
+  for (;;) {
+#ifdef CUROBO_MESH_STATS
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) CUROBO_MESH_COUNT(3, 1);  // passes of the wavefront
+    if (g == 0 && node == 0) CUROBO_MESH_COUNT(4, 1);                                               // transitions
+#endif
+    if (node != 0) {
+      // ================= one move of the walk
+      const int d0 = min(gl * LV, depth_leaves);
+      bool descended = false;
+      if (d0 == depth_leaves) {  // a leaf: lane j tests triangles j, j + G, ...
+        if (g == 0) CUROBO_MESH_COUNT(2, 1);
+        const int t0 = (node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+        for (int t = t0 + g; t < t1; t += G) {
+          const TriRec r = tri[t];
+          int region;
+          const f3 c = closest_on_triangle(qp, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+          const f3 d = qp - c;
+          const float d2 = dot(d, d);
+          if (d2 <= l_d2) { l_tie = d2 == l_d2; l_d2 = d2; l_c = c; l_t = t; l_region = region; }
+        }
+        best_d2 = fminf(best_d2, group_min<G>(l_d2));
+      } else {  // an interior node: its 2^sl descendants sl levels down, one per lane
+        if (g == 0) CUROBO_MESH_COUNT(1, 1);
+        const int sl = min(LV, depth_leaves - d0), cnt = 1 << sl;
+        const int child = (node << sl) + (g < cnt ? g : 0);
+        const float4 lo = box[child * 2], hi = box[child * 2 + 1];
+        const float dist = g < cnt ? box_dist2(lo, hi, qp) : FAR;
+        // nearest first; boxes the point is inside of order by the distance to their centres: one key, negative for those
+        const f3 cv = make_f3(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z) - 2.0f * qp;
+        const float key = dist > 0.0f ? dist : -__frcp_rn(1.0f + dot(cv, cv));
+        keys[gl * key_stride] = key;
+        const bool in = key <= best_d2;
+        const unsigned mask = group_ballot<G>(in);
+        if (mask != 0u) {
+          const float kmin = group_min<G>(in ? key : FAR);
+          const int j0 = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
+          owed = (owed & ~((unsigned long long)GM << (G * gl))) | ((unsigned long long)(mask & ~(1u << j0)) << (G * gl));
+          node = (node << sl) + j0;
+          ++gl;
+          descended = true;
+        }
+      }
+      if (!descended) {  // the nearest sibling still owed a visit and still in range, else up
+        bool more = false;
+        while (gl > 0) {
+          const int lvl = gl - 1, sp = min(LV, depth_leaves - lvl * LV);
+          const int parent = node >> sp;
+          const unsigned rest = (unsigned)(owed >> (G * lvl)) & GM;
+          if (rest != 0u) {
+            const float key = keys[lvl * key_stride];
+            const bool in = ((rest >> g) & 1u) != 0u && key <= best_d2;
+            const unsigned mask = group_ballot<G>(in);
+            if (mask != 0u) {
+              const float kmin = group_min<G>(in ? key : FAR);
+              const int j = __ffs((int)group_ballot<G>(in && key == kmin)) - 1;
+              owed = (owed & ~((unsigned long long)GM << (G * lvl))) | ((unsigned long long)(mask & ~(1u << j)) << (G * lvl));
+              node = (parent << sp) + j;
+              more = true;
+              break;
+            }
+            owed &= ~((unsigned long long)GM << (G * lvl));
+          }
+          node = parent;
+          gl = lvl;
+        }
+        if (!more) node = 0;
+      }
+      continue;
+    }
+    // ================= the walk of a query is over: settle it (mesh_sdf_within)
+    const float dmin = group_min<G>(l_d2);
+    const bool found = dmin <= limit_d2;
+    if (!found && !full && q_may_in) {
+      const float *rb = m.node_box + 8;  // root box: a point outside it is outside the (closed) surface
+      if (!(qp.x < rb[0] || qp.y < rb[1] || qp.z < rb[2] || qp.x > rb[4] || qp.y > rb[5] || qp.z > rb[6])) {
+        full = true;  // inside the box, nothing within the radius: far outside in a concavity -- or deep inside
+        begin_query();
+        continue;
+      }
+    }
+    float sdf = max_distance;
+    f3 gq = make_f3(0.f, 0.f, 0.f);
+    if (found) {
+      const unsigned win = group_ballot<G>(l_d2 == dmin);
+      const int src = gbase | (__ffs((int)win) - 1);
+      // (the same distance from several triangles: the closest point lies on a feature they share -- or on two separate
+      // ones; a face verdict is then not trusted)
+      const bool tie = (__builtin_popcount(win) > 1) || (__shfl((int)l_tie, src, 64) != 0);
+      const f3 cp = make_f3(__shfl(l_c.x, src, 64), __shfl(l_c.y, src, 64), __shfl(l_c.z, src, 64));
+      const int side = mesh_feature_side(m, qp, cp, dmin, __shfl(l_t, src, 64), __shfl(l_region, src, 64), tie);
+      const float d = sqrtf(dmin);
+      if (d > 1e-6f) gq = (1.0f / d) * (qp - cp);
+      const bool inside = side != 0 ? side < 0 : mesh_inside(m, qp);
+      sdf = inside ? -d : d;
+    }
+    // ================= its terms, and the next sample (mesh_contribution)
+    if (gradient_mode == 1 && sdf > 0.0f) gq = -1.0f * gq;
+    const float pen = -sdf + r_adj;
+    float c = 0.0f, gs = 0.0f;
+    if (pen > 0.0f) {
+      activation_m(pen, eta, c, gs);
+      cost_sum += c;
+      grad_local = grad_local + gs * gq;
+    }
+    if (dir < 0) { sdf_c = sdf; pen_c = pen; c_c = c; gs_c = gs; g_c = gq; }
+    else {
+      if (pen > 0.0f) jump += pen;
+      else if (-pen >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen, r_adj);
+      k++;
+    }
+    if (SWEEP == 0) break;
+    bool have = false;
+#pragma unroll 1
+    while (!have) {
+      if (dir >= 0 && k < SWEEP && !(jump >= half_dist)) { have = true; break; }
+      dir++;
+      if (dir >= 2) break;
+      if (!(dir == 0 ? has_prev : has_next)) continue;
+      if (-pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
+      ln = mesh_to_local(s, dir == 0 ? prev_c : next_c);
+      const f3 dd = ln - lc;
+      half_dist = sqrtf(dot(dd, dd)) * 0.5f;
+      inv_half = 1.0f / fmaxf(half_dist, 0.001f);
+      jump = 0.0f;
+      k = SWEEP;
+      if (jump >= half_dist) continue;
+      if (pen_c > 0.0f) { cost_sum += c_c; grad_local = grad_local + gs_c * g_c; jump += pen_c; }
+      else if (-pen_c >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen_c, r_adj);
+      k = 1;
+    }
+    if (!have) break;
+    const float tt = 1.0f - 0.5f * jump * inv_half;
+    qp = tt * lc + (1.0f - tt) * ln;
+    q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
+    q_may_in = sdf_c < half_dist;
+    full = !(q_radius < max_distance);
+    begin_query();
   }
 }
 

@@ -79,7 +79,7 @@ for sweep in (3, 0):
         print(f"  per lane nodes: n {live.size} mean {live.mean():.1f} median {np.median(live):.0f} p90 {np.percentile(live, 90):.0f} "
               f"p99 {np.percentile(live, 99):.0f} max {live.max()};  per wavefront (max over lanes): n {w64.size} mean {w64.mean():.0f} "
               f"median {np.median(w64):.0f} p90 {np.percentile(w64, 90):.0f} max {w64.max()}")
-        names = ["closest calls", "steps", "leaf visits", "ray walks", "ray nodes", "full queries", "items", "item-slots"]
+        names = ["closest calls", "steps", "leaf visits", "wave passes", "transitions", "full queries", "items", "item-slots"]
         print(f"sweep {sweep}: spheres {B * H * S}", {n: int(v) for n, v in zip(names, buf)})
     t0 = time.perf_counter()
     for _ in range(5):
