@@ -898,6 +898,9 @@ def committed_counters(kernel: str, workgroups: int = 0):
     return best
 
 
+ISSUE_FLOOR_CYCLES = 2.9  # SIMD-cycles per wave-instruction of the best issue-bound kernel measured (self_collision_row16_kernel, r04_b)
+
+
 def counter_roofline(kernel: str, workgroups: int, live_us: float, units: int = 0) -> dict:
     """{traffic, valu / salu / lds instruction counts, VALU issue fraction at the LIVE launch time} of one kernel from the
     committed counters; {} when there are none.  ``units`` (trajectories or points per launch) adds per-unit counts."""
@@ -917,6 +920,18 @@ def counter_roofline(kernel: str, workgroups: int, live_us: float, units: int = 
         if units:
             out["valu"]["per_unit"] = {n: round(k[m] / units, 1) for n, m in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"),
                                                                                ("lds", "SQ_INSTS_LDS")) if m in k}
+        # Every instruction type against the issue rate: SIMD-cycles the launch had (1024 SIMDs x live time x 2.4 GHz) per
+        # wave-instruction it executed.  Across this library's kernels that run at four or more wavefronts per SIMD the figure
+        # sits between 2.9 (self_collision_row16_kernel, 78 % VALU) and 4.4 whatever their VALU share
+        # (profiles/r04_b_counters_by_kernel.json): that is the issue rate such kernels run at, and the
+        # fraction of it is the honest "how far from the machine" for a kernel that moves ~1 % of its bytes through HBM.
+        total = sum(k.get(m, 0.0) or 0.0 for m in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
+                                                   "SQ_INSTS_VMEM_WR"))
+        if total > 0:
+            cyc = live_us * 1e-6 * 2.4e9 * 1024 / total
+            out["valu"]["issue"] = {"wave_instructions_per_launch_all_types": round(total, 1), "simd_cycles_per_instruction": round(cyc, 2),
+                                    "best_rate_measured_in_this_library": ISSUE_FLOOR_CYCLES,
+                                    "frac_of_that_rate": round(ISSUE_FLOOR_CYCLES / cyc, 4)}
     return out
 
 

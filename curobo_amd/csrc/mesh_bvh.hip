@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
       f3 grad_local = make_f3(0.f, 0.f, 0.f);
       if ((threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(7, 1);
       mesh_contribution_group<SWEEP, (int)G>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev,
-                                     half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, MESH_WALK_THREADS);
+                                     half_w_next, reach, cost_sum, grad_local, group_keys + threadIdx.x, MESH_WALK_THREADS, q);
       if (cost_sum > 0.0f) {
         const f3 gw = mesh_to_world_vector(slot, grad_local);
         dsum += w * cost_sum;

@@ -19,11 +19,10 @@ namespace curobo_hip {
 
 #ifdef CUROBO_MESH_STATS  // diagnostic builds only (tools/r04/mesh_stats.py): work counters of the walks
 __device__ unsigned long long g_mesh_stats[8];  // closest calls, nodes tested, triangles, ray walks, ray nodes, full queries, items
-__device__ unsigned int g_mesh_lane[1 << 18];   // per lane of the launch: nodes tested (closest + ray walks)
+__device__ unsigned int g_mesh_lane[1 << 18];   // per queue entry: moves [0, 2^17), transitions [2^17, 2^18)
 #define CUROBO_MESH_COUNT(i, n)                                                                          \
   do {                                                                                                   \
     atomicAdd(&g_mesh_stats[i], (unsigned long long)(n));                                                \
-    if ((i) == 1 || (i) == 4) g_mesh_lane[(blockIdx.x * blockDim.x + threadIdx.x) & ((1 << 18) - 1)] += (n); \
   } while (0)
 #else
 #define CUROBO_MESH_COUNT(i, n) do {} while (0)
@@ -438,7 +437,7 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
 template <int SWEEP, int G>
 __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
                                                         f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
-                                                        float reach, float &cost_sum, f3 &grad_local, float *keys, int key_stride) {
+                                                        float reach, float &cost_sum, f3 &grad_local, float *keys, int key_stride, unsigned stat_q = 0u) {
   constexpr int LV = G == 16 ? 4 : 3;  // tree levels per step
   constexpr unsigned GM = (1u << G) - 1u;
   constexpr float FAR = 3.0e38f;
@@ -479,6 +478,7 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
 #ifdef CUROBO_MESH_STATS
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) CUROBO_MESH_COUNT(3, 1);  // passes of the wavefront
     if (g == 0 && node == 0) CUROBO_MESH_COUNT(4, 1);                                               // transitions
+    if (g == 0) g_mesh_lane[(stat_q & 0x1ffffu) + (node == 0 ? 0x20000u : 0u)] += 1;               // per item: moves | transitions
 #endif
     if (node != 0) {
       // ================= one move of the walk

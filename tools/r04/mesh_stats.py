@@ -73,12 +73,15 @@ for sweep in (3, 0):
         torch.cuda.synchronize()
         lib.curobo_hip_mesh_stats(buf, 1)
         lib.curobo_hip_mesh_lane_stats(lanes.ctypes.data_as(C.c_void_p), 1)
-        live = lanes[lanes > 0]
-        w64 = lanes.reshape(-1, 64).max(1)
-        w64 = w64[w64 > 0]
-        print(f"  per lane nodes: n {live.size} mean {live.mean():.1f} median {np.median(live):.0f} p90 {np.percentile(live, 90):.0f} "
-              f"p99 {np.percentile(live, 99):.0f} max {live.max()};  per wavefront (max over lanes): n {w64.size} mean {w64.mean():.0f} "
-              f"median {np.median(w64):.0f} p90 {np.percentile(w64, 90):.0f} max {w64.max()}")
+        moves, trans = lanes[:1 << 17].astype(np.int64), lanes[1 << 17:].astype(np.int64)
+        live = moves + trans
+        live = live[live > 0]
+        per_wave = (moves + trans)[: (live.size + 7) // 8 * 8].reshape(-1, 8).max(1)
+        print(f"  per item passes (moves + transitions): n {live.size} mean {live.mean():.1f} median {np.median(live):.0f} p90 {np.percentile(live, 90):.0f} "
+              f"p99 {np.percentile(live, 99):.0f} p99.9 {np.percentile(live, 99.9):.0f} max {live.max()};  per wavefront (max of 8 consecutive items): mean {per_wave.mean():.1f} "
+              f"p90 {np.percentile(per_wave, 90):.0f} p99 {np.percentile(per_wave, 99):.0f} max {per_wave.max()}")
+        top = np.argsort(moves + trans)[::-1][:5]
+        print("  heaviest items: passes", (moves + trans)[top], "queries+1", trans[top])
         names = ["closest calls", "steps", "leaf visits", "wave passes", "transitions", "full queries", "items", "item-slots"]
         print(f"sweep {sweep}: spheres {B * H * S}", {n: int(v) for n, v in zip(names, buf)})
     t0 = time.perf_counter()
