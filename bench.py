@@ -920,18 +920,24 @@ def counter_roofline(kernel: str, workgroups: int, live_us: float, units: int = 
         if units:
             out["valu"]["per_unit"] = {n: round(k[m] / units, 1) for n, m in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"),
                                                                                ("lds", "SQ_INSTS_LDS")) if m in k}
-        # Every instruction type against the issue rate: SIMD-cycles the launch had (1024 SIMDs x live time x 2.4 GHz) per
-        # wave-instruction it executed.  Across this library's kernels that run at four or more wavefronts per SIMD the figure
-        # sits between 2.9 (self_collision_row16_kernel, 78 % VALU) and 4.4 whatever their VALU share
-        # (profiles/r04_b_counters_by_kernel.json): that is the issue rate such kernels run at, and the
-        # fraction of it is the honest "how far from the machine" for a kernel that moves ~1 % of its bytes through HBM.
+        # Every instruction type: SIMD-cycles the launch had (1024 SIMDs x live time x 2.4 GHz) per wave-instruction it
+        # executed.  Across this library's kernels that run at four or more wavefronts per SIMD the figure sits between 2.9
+        # (self_collision_row16_kernel, 78 % VALU) and 4.4 whatever their VALU share (profiles/r04_b_counters_by_kernel.json,
+        # DESIGN.md section 5); tools/probes/valu_issue_probe.hip: independent VALU streams saturate at 2.1 - 2.6 cycles per
+        # instruction, and the scalar unit issues one instruction per cycle per CU (a SIMD's share: four cycles).
         total = sum(k.get(m, 0.0) or 0.0 for m in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
                                                    "SQ_INSTS_VMEM_WR"))
         if total > 0:
             cyc = live_us * 1e-6 * 2.4e9 * 1024 / total
+            simd_cycles = live_us * 1e-6 * 2.4e9
+            valu_c, salu_c = k.get("SQ_INSTS_VALU", 0.0) * 2.3 / 1024, (k.get("SQ_INSTS_SALU", 0.0) or 0.0) / 256
             out["valu"]["issue"] = {"wave_instructions_per_launch_all_types": round(total, 1), "simd_cycles_per_instruction": round(cyc, 2),
                                     "best_rate_measured_in_this_library": ISSUE_FLOOR_CYCLES,
-                                    "frac_of_that_rate": round(ISSUE_FLOOR_CYCLES / cyc, 4)}
+                                    "frac_of_that_rate": round(ISSUE_FLOOR_CYCLES / cyc, 4),
+                                    "valu_issue_share_of_launch": round(valu_c / simd_cycles, 4),
+                                    "scalar_issue_share_of_launch": round(salu_c / simd_cycles, 4),
+                                    "pricing": "VALU 2.3 SIMD-cycles per wave-instruction, scalar unit 1 instruction per cycle per CU "
+                                               "(tools/probes/valu_issue_probe.hip)"}
     return out
 
 
