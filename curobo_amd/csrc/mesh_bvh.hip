@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
 // evaluated densely by a grid sized for the chip, one live sphere per lane, its slots in ascending order in-lane (the sums
 // of the one-launch form), outputs written by that lane.  The queue holds at most one entry per sphere: it cannot
 // overflow.
+#ifndef MESH_HEAVY_FIRST
+#define MESH_HEAVY_FIRST 1
+#endif
 struct MeshQueueArgs {
   MeshCollArgs c;
   uint32_t *counter;  // workspace word 0
@@ -302,8 +305,8 @@ struct MeshQueueArgs {
 
 template <int SWEEP>
 __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueueArgs qa) {
-  __shared__ int wave_cnt[4];
-  __shared__ uint32_t run_base;
+  __shared__ int wave_cnt[2][4];
+  __shared__ uint32_t run_base[2];
   const MeshCollArgs &a = qa.c;
   const long total = (long)a.batch * a.horizon * a.nspheres;
   const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
@@ -315,6 +318,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
   const int env = (in && a.use_multi_env) ? a.env_query_idx[b] : 0;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
   uint32_t live = 0u;
+  bool heavy = false;  // the centre lies inside the bounding box of a live slot's mesh: long walks (front of the queue)
   if (in) {
     const float4 s = sph[sidx];
     if (s.w >= 0.0f) {
@@ -330,7 +334,12 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
       for (int k = 0; k < a.nslots; k++) {
         const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
         if (!slot.enabled) continue;
-        if (!mesh_early_reject(slot, mesh_to_local(slot, center), r_adj, reach)) live |= 1u << k;
+        const f3 lc = mesh_to_local(slot, center);
+        if (!mesh_early_reject(slot, lc, r_adj, reach)) {
+          live |= 1u << k;
+          const float *rb = slot.m.node_box + 8;
+          if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]);
+        }
       }
     }
     if (live == 0u && !a.accumulate) {
@@ -338,19 +347,25 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
       reinterpret_cast<float4 *>(a.gradient)[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const unsigned long long ball = __ballot(live != 0u);
+  // two classes: the heavy entries fill the queue from its head (counter word 0), the others from its tail backwards
+  // (counter word 2): the walk takes the head first, so the launch's longest chains start when the launch does
+  const bool is_h = live != 0u && heavy, is_l = live != 0u && !heavy;
+  const unsigned long long ball_h = __ballot(is_h), ball_l = __ballot(is_l);
+  const unsigned long long ball = is_h ? ball_h : ball_l;
   const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
-  if (lane64 == 0) wave_cnt[wave] = __builtin_popcountll(ball);
+  if (lane64 == 0) { wave_cnt[0][wave] = __builtin_popcountll(ball_h); wave_cnt[1][wave] = __builtin_popcountll(ball_l); }
   __syncthreads();
-  if (tid == 0) {
-    const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    run_base = n ? atomicAdd(qa.counter, (uint32_t)n) : 0u;
+  if (tid < 2) {
+    const int n = wave_cnt[tid][0] + wave_cnt[tid][1] + wave_cnt[tid][2] + wave_cnt[tid][3];
+    run_base[tid] = n ? atomicAdd(qa.counter + 2 * tid, (uint32_t)n) : 0u;
   }
   __syncthreads();
   if (live != 0u) {
+    const int cls = is_h ? 0 : 1;
     int at = before;
-    for (int wv = 0; wv < wave; wv++) at += wave_cnt[wv];
-    qa.queue[run_base + (uint32_t)at] = make_uint2((uint32_t)sidx, live);
+    for (int wv = 0; wv < wave; wv++) at += wave_cnt[cls][wv];
+    const uint32_t pos = run_base[cls] + (uint32_t)at;
+    qa.queue[is_h ? pos : (uint32_t)(total - 1) - pos] = make_uint2((uint32_t)sidx, live);
   }
 }
 
@@ -401,7 +416,8 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 template <int SWEEP>
 __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
   const MeshCollArgs &a = qa.c;
-  const uint32_t n = qa.counter[0];
+  const uint32_t n_front = qa.counter[0], n = n_front + qa.counter[2];  // heavy entries from the head, the others from the tail
+  const uint32_t q_last = (uint32_t)((long)a.batch * a.horizon * a.nspheres - 1);
   const int hs = a.horizon * a.nspheres;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
   const float w = a.weight[0], eta = a.eta[0];
@@ -412,7 +428,8 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
     const uint32_t q = q0 + threadIdx.x / G;
     // (a group beyond the end of the queue repeats the last entry so that ballots and shuffles stay whole; it writes nothing)
     const bool live_group = q < n;
-    const uint2 e = qa.queue[live_group ? q : n - 1];
+    const uint32_t qq = live_group ? q : n - 1;
+    const uint2 e = qa.queue[qq < n_front ? qq : q_last - (qq - n_front)];
     if (live_group && (threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(6, 1);
     const long sidx = (long)e.x;
     const int b = (int)(sidx / hs);

@@ -213,6 +213,9 @@ __device__ __forceinline__ unsigned group_ballot(bool pred) {
 // ordering key of this lane's descendant at every step level: siblings are revisited nearest first and re-judged against the
 // distance found since, without fetching their boxes again).
 #define MESH_GROUP_LEVELS 8
+#ifndef MESH_PREV_BOUND
+#define MESH_PREV_BOUND 1
+#endif
 
 // crossings of the ray p + t d (t > 0) with the surface (fixed-order stackless walk: the order does not matter here)
 __device__ __forceinline__ int mesh_ray_crossings(const curobo_hip_mesh &m, f3 p, f3 d) {
@@ -462,10 +465,23 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
   int l_t = 0, l_region = 0, node = 0, gl = 0;
   bool l_tie = false;
   unsigned long long owed = 0ull;
+  // The closest point found by an earlier sample of this item bounds the distance of the next one (triangle inequality:
+  // |q' - c| <= |q' - q| + |q - c|): the walk of a sweep sample then prunes with the sample's step, not with the search
+  // radius -- for a sphere deep inside a mesh (nothing within the radius: every sample is searched at the full range, and
+  // the seven samples of such a sphere are the longest chain of the launch) that is centimetres instead of the mesh's
+  // half diagonal.  Only the pruning bound shrinks (never below the true distance): the same closest point is found.
+  bool have_prev = false;
+  float prev_d = 0.0f;
+  f3 prev_qp = lc;
   auto begin_query = [&]() {
     if (g == 0) CUROBO_MESH_COUNT(0, 1);
     const float r = full ? max_distance : q_radius;
     limit_d2 = best_d2 = r * r;
+    if (MESH_PREV_BOUND && have_prev) {
+      const f3 dq = qp - prev_qp;
+      const float ub = (prev_d + sqrtf(dot(dq, dq))) * 1.00001f + 1e-6f;
+      best_d2 = fminf(best_d2, ub * ub);
+    }
     l_d2 = FAR;
     l_tie = false;
     owed = 0ull;
@@ -569,6 +585,7 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
       if (d > 1e-6f) gq = (1.0f / d) * (qp - cp);
       const bool inside = side != 0 ? side < 0 : mesh_inside(m, qp);
       sdf = inside ? -d : d;
+      have_prev = true; prev_d = d; prev_qp = qp;
     }
     // ================= its terms, and the next sample (mesh_contribution)
     if (gradient_mode == 1 && sdf > 0.0f) gq = -1.0f * gq;
