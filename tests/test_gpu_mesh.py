@@ -132,6 +132,37 @@ def test_sphere_mesh_collision_matches_the_oracle(sweep, speed, with_cuboids, or
     assert bad.mean() < 2e-3, bad.mean()  # (closest-point ties on coplanar triangles / the medial axis)
 
 
+@pytest.mark.parametrize("sweep", [False, True])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_queued_mesh_launch_equals_the_one_kernel_launch(sweep, accumulate, oracle, device):
+    """the launch-wide queue of the mesh launch (select + walk kernels: spheres inside a live mesh's bounding box queued from the
+    head, the others from the tail; eight lanes per sphere) against the one-kernel form (a tree walk per lane) on the same
+    buffers: the same spheres are live, costs agree to rounding, gradients except on closest-point ties"""
+    from curobo_amd.backends import mesh as M
+    from curobo_amd.scene import SceneData
+
+    world = mesh_world()
+    sph = torch.as_tensor(_trajectory_spheres(oracle, 24, 9), device=device)
+    b, h, S, _ = sph.shape
+    scene = SceneData.from_arrays(None, device, meshes=world)
+    w, eta, dt = torch.tensor([3.0], device=device), torch.tensor([0.02], device=device), torch.tensor([0.05], device=device)
+    outs = []
+    for workspace in (None, False):
+        dist, grad = torch.full((b, h, S), 0.25, device=device), torch.full((b, h, S, 4), 0.5, device=device)
+        M.sphere_mesh_collision(dist, grad, sph, scene.struct.mesh_set, w, eta, None, b, h, S, False, 3 if sweep else 0, sweep, dt,
+                                accumulate=accumulate, workspace=workspace)
+        torch.cuda.synchronize()
+        outs.append((dist.cpu().numpy(), grad.cpu().numpy()))
+    (dq, gq), (d1, g1) = outs
+    base = 0.25 if accumulate else 0.0
+    live = d1 != base
+    assert 0.03 < live.mean() < 0.9
+    assert np.array_equal(dq != base, live)
+    np.testing.assert_allclose(dq, d1, rtol=2e-5, atol=2e-6)
+    bad = np.abs(gq - g1).max(-1) > 1e-4 + 1e-3 * np.abs(g1).max(-1)
+    assert bad.mean() < 2e-3, bad.mean()
+
+
 def test_mesh_slots_per_environment_pose_updates_and_enable(oracle, device):
     """two environments with different mesh sets, ``env_query_idx`` per trajectory; then move a mesh and switch one off:
     the BVH stays, the store's pose / enable rows change (reference MeshData.update_pose / enable_obstacle)"""
