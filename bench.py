@@ -41,6 +41,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP runtime settings this path was measured with, made explicit (both are this ROCm's defaults; set before the runtime loads):
+# kernel arguments in device memory -- with HIP_FORCE_DEV_KERNARG=0 every launch of the replayed graphs fetches its arguments
+# from host memory and the C2 step takes 69.9 instead of 58.9 us (profiles r04, tools/r04/call57.sh) -- and the default four
+# hardware queues (GPU_MAX_HW_QUEUES=8 / 16: 113 / 153 us per step, tools/r04/call56.sh).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # fp32 vector issue: 256 CU x 4 SIMD x 2.4 GHz, one wave64 VALU instruction per 2 cycles (same guide)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
