@@ -763,9 +763,9 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
   CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 768, "%s: nspheres=%d out of range [1,768]", what, nspheres);
   CUROBO_REQUIRE(num_collision_pairs >= 0, "%s: negative num_collision_pairs", what);
   CUROBO_REQUIRE(((uintptr_t)pair_locations & 3) == 0, "%s: pair_locations must be 4-byte aligned", what);
-  CUROBO_REQUIRE(!store_pair_distance || pair_distance, "%s: store_pair_distance needs pair_distance", what);
   const long n_points = (long)batch_size * horizon;
-  if (n_points == 0) return CUROBO_HIP_OK;
+  if (n_points == 0) return CUROBO_HIP_OK;  // (an empty batch has no buffers: nothing below may ask for them)
+  CUROBO_REQUIRE(!store_pair_distance || pair_distance, "%s: store_pair_distance needs pair_distance", what);
   SelfCollArgs a{};
   a.out_distance = out_distance; a.out_gradient = out_vec; a.pair_distance = pair_distance;
   a.sparse_index = sparse_index; a.robot_spheres = robot_spheres; a.offsets = sphere_padding;

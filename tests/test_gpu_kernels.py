@@ -665,3 +665,58 @@ def test_mesh_esdf_bake_on_device(oracle, device):
         outs.append(dist.cpu().numpy())
     assert (outs[1] > 0).mean() > 0.02
     np.testing.assert_allclose(outs[0], outs[1], atol=3e-3)
+
+
+def test_empty_batches_are_no_ops(device):
+    """zero trajectories / points through the entry points of the path: status OK, nothing launched that reads or writes
+    (the reference's wrappers are called with whatever batch the planner has left after its filters -- an empty one included)"""
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.backends import geometry as G
+    from curobo_amd.backends import kinematics as K
+    from curobo_amd.backends import trajectory as Tr
+    from curobo_amd.scene import SceneData
+
+    model = load_model("franka")
+    kp = _kp(model, device)
+    d, S, L, T = model.num_dof, model.num_spheres, model.num_links, kp.num_pose_links
+    P = model.collision_pairs.shape[0]
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
+    env0 = z(0, dt=torch.int32)
+    # forward kinematics + spheres, and its VJP
+    K.launch_kinematics_forward_spheres(z(0, 1, T, 3), z(0, 1, T, 4), z(0, 1, S, 4), z(0, 1, 4), z(0, 1, L, 3, 4), z(0, d),
+                                        kp.fixed_transforms, kp.link_spheres, kp.link_masses_com, kp.joint_map_type, kp.joint_map,
+                                        kp.link_map, kp.tool_frame_map, kp.link_sphere_idx_map, kp.joint_offset_map, env0, kp.num_envs,
+                                        0, 1, d, S, 32, True, False)
+    K.launch_kinematics_backward(z(0, d), z(0, T, 3), z(0, T, 4), z(0, S, 4), z(0, 4), z(0, 4), z(0, T, 3), z(0, L, 3, 4),
+                                 kp.link_spheres, kp.link_masses_com, kp.link_map, kp.joint_map, kp.joint_map_type, kp.tool_frame_map,
+                                 kp.link_sphere_idx_map, kp.link_chain_data, kp.link_chain_offsets, kp.joint_links_data,
+                                 kp.joint_links_offsets, kp.joint_affects_endeffector, kp.joint_offset_map, env0, 1, 0, 1, d, S, False,
+                                 False)
+    # self collision, scene collision (cuboids)
+    G.self_collision_distance(z(0, 1), z(0, S, 4), z(0, P), z(0, S, dt=torch.uint8), z(0, S, 4), kp.self_collision.sphere_padding,
+                              torch.tensor([2.5], device=device), kp.self_collision.collision_pairs, z(1), z(2, dt=torch.int16), 1, 256,
+                              0, 1, S, P, True, True)
+    scene = SceneData.from_arrays(_scene_arrays(), device)
+    Cn.sphere_obstacle_collision(z(0, 3, S), z(0, 3, S, 4), z(0, 3, S, 4), scene.struct, torch.tensor([3.0], device=device),
+                                 torch.tensor([0.03], device=device), env0, 0, 3, S, False, 3, True, torch.tensor([0.05], device=device))
+    # B-spline forward / VJP
+    nk, degree, interp = 12, 3, 2
+    ph = (nk + degree + 1) * interp + 1
+    st = [z(1, d) for _ in range(8)]
+    Tr.launch_bspline_interpolation_forward_kernel(z(0, ph, d), z(0, ph, d), z(0, ph, d), z(0, ph, d), z(0), z(0, nk, d), *st,
+                                                   env0, env0, torch.tensor([0.05], device=device), z(1, dt=torch.uint8), 0, ph, d, nk,
+                                                   degree)
+    Tr.launch_bspline_interpolation_backward_kernel(z(0, nk, d), z(0, ph, d), z(0, ph, d), z(0, ph, d), z(0, ph, d),
+                                                    torch.tensor([0.05], device=device), env0, z(1, dt=torch.uint8), 0, ph, d, nk, degree,
+                                                    False)
+    # optimiser side: L-BFGS step, line search, per-trajectory cost sum
+    from curobo_amd.backends import optimization as Op
+
+    v, m, nls = 84, 5, 4
+    Op.launch_lbfgs_step(z(0, v), z(m, 0), z(m, 0, v), z(m, 0, v), z(0, v), z(0, v), z(0, v), z(0, v), 0.01, 0, m, v, True, True)
+    i16 = lambda *s: z(*s, dt=torch.int16)  # noqa: E731
+    Op.launch_line_search(z(0), z(0, v), i16(0), i16(0), z(0, dt=torch.uint8), 5, 1e-4, 1e-3, z(0), z(0, v), z(0, v),
+                          z(0, nls, dt=torch.int32), z(0), z(0, v), z(0, v), z(0, nls, dt=torch.int32), z(0, nls, 1), z(0, nls, v),
+                          z(0, nls, v), z(0, 1, v), torch.tensor([0.0, 0.1, 0.5, 1.0], device=device), 1e-5, 0.9, False, True, nls, v, 0)
+    Cn.trajectory_cost_sum(z(0), z(0, 3), z(0, 3, S), 0, 3, S)
+    torch.cuda.synchronize()
