@@ -239,11 +239,19 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   const float4 p = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2];      // x y z qw
   const float4 q = reinterpret_cast<const float4 *>(inv_pose)[(size_t)flat * 2 + 1];  // qx qy qz pad
   const float x = q.x, y = q.y, z = q.z, w = p.w;
-  const float k = 2.0f * w * w - 1.0f;
+  // The rotation as EXPLICIT fused multiply-adds over single products.  Written with * and +, every kernel that inlines this
+  // function contracts the nine expressions its own way (-ffp-contract=fast), and two kernels then hold rotations that differ
+  // in the last bit: enough for a sphere that is stationary up to rounding to coincide with its neighbour in one kernel's
+  // obstacle frame and not in the other's -- the sweep's duplicate centre sample (half_dist > 0) then exists in one of them
+  // only (found by tools/r04/fuzz_fused.py on randomly rotated cuboids: 19 of 1 496 such trajectories differed between
+  // the fused launch and the kernel sequence on identical spheres).
+  const float x2 = 2.0f * x, y2 = 2.0f * y, w2 = 2.0f * w;  // (exact)
+  const float k = __builtin_fmaf(w2, w, -1.0f);
+  const float wz = w2 * z, wy = w2 * y, wx = w2 * x;  // one rounding each, consumed by an fma below: nothing left to contract
   ObsRec r;
-  r.r0 = make_float4(k + 2.0f * x * x, 2.0f * x * y - 2.0f * w * z, 2.0f * x * z + 2.0f * w * y, p.x);
-  r.r1 = make_float4(2.0f * x * y + 2.0f * w * z, k + 2.0f * y * y, 2.0f * y * z - 2.0f * w * x, p.y);
-  r.r2 = make_float4(2.0f * x * z - 2.0f * w * y, 2.0f * y * z + 2.0f * w * x, k + 2.0f * z * z, p.z);
+  r.r0 = make_float4(__builtin_fmaf(x2, x, k), __builtin_fmaf(x2, y, -wz), __builtin_fmaf(x2, z, wy), p.x);
+  r.r1 = make_float4(__builtin_fmaf(x2, y, wz), __builtin_fmaf(y2, y, k), __builtin_fmaf(y2, z, -wx), p.y);
+  r.r2 = make_float4(__builtin_fmaf(x2, z, -wy), __builtin_fmaf(y2, z, wx), __builtin_fmaf(2.0f * z, z, k), p.z);
   r.shape = reinterpret_cast<const float4 *>(shape)[flat];
   float prim_r = 0.0f, prim_hl = 0.0f;
   if (!VOXEL) {

@@ -395,3 +395,26 @@ def test_self_collision_lane_lists_change_no_bit(device, robot, n_left):
     torch.cuda.synchronize()
     assert float((c0 > 0).float().mean()) > 0.3
     assert torch.equal(c0, c1) and torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fused_equals_the_sequence_on_randomly_rotated_cuboids(device, seed):
+    """Random worlds of 3 .. 10 cuboids with random rotations (the fixed worlds of this file rotate about one axis: their
+    rotation matrices are built from exact products).  The two paths must hold the SAME obstacle-frame rotation, bit for bit:
+    a sphere that rests in collision up to rounding otherwise gets the sweep's duplicate centre sample in one path only
+    (scene_device.hpp::load_rec_global; found by tools/r04/fuzz_fused.py).  Every trajectory is compared, the resting ones too."""
+    rng = np.random.default_rng(seed)
+    world = []
+    for _ in range(int(rng.integers(3, 11))):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        world.append({"dims": [float(v) for v in rng.uniform(0.05, 0.6, size=3)],
+                      "pose": [float(v) for v in rng.uniform([-0.7, -0.7, -0.2], [0.7, 0.7, 1.0])] + [float(v) for v in q]})
+    _, _, knots, _, ro_ref, ro_fused = _pair(device, seeds=48, world=[world])
+    c0, g0, c1, g1 = _compare(ro_ref, ro_fused, knots, device)
+    p = ro_fused.robot_spheres.cpu().numpy()[..., :3]
+    still = np.linalg.norm(np.diff(p, axis=1), axis=-1) < 1e-5
+    resting = (still & (ro_ref.scene_dist.cpu().numpy().reshape(p.shape[:3])[:, 1:] > 0)).any(axis=(1, 2))
+    assert resting.sum() >= 5, "the inputs must contain trajectories with a sphere that rests in collision"
+    np.testing.assert_allclose(c1, c0, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g1, g0, rtol=1e-3, atol=2e-5 * np.abs(g0).max())
