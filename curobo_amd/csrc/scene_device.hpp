@@ -243,7 +243,7 @@ __device__ __forceinline__ ObsRec load_rec_global(const curobo_hip_scene &sc, in
   // function contracts the nine expressions its own way (-ffp-contract=fast), and two kernels then hold rotations that differ
   // in the last bit: enough for a sphere that is stationary up to rounding to coincide with its neighbour in one kernel's
   // obstacle frame and not in the other's -- the sweep's duplicate centre sample (half_dist > 0) then exists in one of them
-  // only (found by tools/r04/fuzz_fused.py on randomly rotated cuboids: 19 of 1 496 such trajectories differed between
+  // only (found by tests/randomised/fuzz_fused.py on randomly rotated cuboids: 19 of 1 496 such trajectories differed between
   // the fused launch and the kernel sequence on identical spheres).
   const float x2 = 2.0f * x, y2 = 2.0f * y, w2 = 2.0f * w;  // (exact)
   const float k = __builtin_fmaf(w2, w, -1.0f);

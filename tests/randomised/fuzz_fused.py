@@ -1,7 +1,7 @@
 """Randomised parity sweep of the fused rollout launch against the kernel sequence (the harness of tests/test_gpu_fused.py on
 random worlds and shapes): robots, batch sizes, spline degrees / knots / interpolation steps (horizons 9 .. 65), 0 .. 12
 cuboids with random poses (disabled slots among them), an ESDF grid, sweep / speed metric / self / scene on and off.
-    python tools/r04/fuzz_fused.py [cases] [seed]"""
+    python tests/randomised/fuzz_fused.py [cases] [seed]"""
 import os
 import sys
 import traceback

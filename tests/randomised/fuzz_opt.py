@@ -1,6 +1,6 @@
 """Optimiser-side kernels against the oracle on random and degenerate inputs: the L-BFGS step (zero / tiny / huge curvature
 pairs, empty history, first iterations) and the Wolfe line search (ties between candidates, flat and rising costs): integer
-outputs exact.   python tools/r04/fuzz_opt.py [cases] [seed]"""
+outputs exact.   python tests/randomised/fuzz_opt.py [cases] [seed]"""
 import os
 import sys
 

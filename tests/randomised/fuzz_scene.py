@@ -1,6 +1,6 @@
 """The scene-collision kernel against the oracle on random worlds: rotated cuboids, analytic primitives, disabled slots, an
 optional ESDF grid, random activation distances; discrete (tight everywhere) and swept + speed metric (spheres that are
-stationary up to rounding excluded: the reference's duplicate-sample discontinuity).   python tools/r04/fuzz_scene.py [cases] [seed]"""
+stationary up to rounding excluded: the reference's duplicate-sample discontinuity).   python tests/randomised/fuzz_scene.py [cases] [seed]"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """Self collision at scale against the oracle: many random configurations per robot (inside, at and beyond the joint limits),
-the arg-max pair (flags) exact, distance and gradient to rounding.   python tools/r04/fuzz_self.py [seed]"""
+the arg-max pair (flags) exact, distance and gradient to rounding.   python tests/randomised/fuzz_self.py [seed]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the fused trajopt launch (pose + c-space STATE [+ torque limits] + self + scene) against the
 kernel sequence: random worlds (rotated cuboids), goals, spline shapes, dt, implicit goal state, sweep, torque limits,
-non-terminal pose factor.   python tools/r04/fuzz_trajopt.py [cases] [seed]"""
+non-terminal pose factor.   python tests/randomised/fuzz_trajopt.py [cases] [seed]"""
 import os
 import sys
 import traceback

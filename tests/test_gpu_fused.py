@@ -402,7 +402,7 @@ def test_fused_equals_the_sequence_on_randomly_rotated_cuboids(device, seed):
     """Random worlds of 3 .. 10 cuboids with random rotations (the fixed worlds of this file rotate about one axis: their
     rotation matrices are built from exact products).  The two paths must hold the SAME obstacle-frame rotation, bit for bit:
     a sphere that rests in collision up to rounding otherwise gets the sweep's duplicate centre sample in one path only
-    (scene_device.hpp::load_rec_global; found by tools/r04/fuzz_fused.py).  Every trajectory is compared, the resting ones too."""
+    (scene_device.hpp::load_rec_global; found by tests/randomised/fuzz_fused.py).  Every trajectory is compared, the resting ones too."""
     rng = np.random.default_rng(seed)
     world = []
     for _ in range(int(rng.integers(3, 11))):

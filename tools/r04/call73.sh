@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 800 python tools/r04/fuzz_scene.py 80 1 2>&1 | grep -v amdgpu.ids | cut -c1-500 | tail -24
+timeout 800 python tests/randomised/fuzz_scene.py 80 1 2>&1 | grep -v amdgpu.ids | cut -c1-500 | tail -24
