@@ -1,0 +1,90 @@
+"""The mesh launch (select + group walk) against the oracle's brute force on random mesh worlds: boxes (thin slabs and pillars
+among them), spheres, tori, L prisms at random poses and sizes, disabled slots, discrete / swept / speed metric, random
+activation distance.   python tests/randomised/fuzz_mesh.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_model, sample_q  # noqa: E402
+from test_oracle_mesh import box_shape, ell_shape, sphere_shape, torus_shape  # noqa: E402
+
+from curobo_amd.backends import collision as Cn  # noqa: E402
+from curobo_amd.scene import SceneData  # noqa: E402
+from oracle.oracle import Oracle, mesh_scene_arrays  # noqa: E402
+
+dev = torch.device("cuda:0")
+oracle = Oracle()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+model = load_model("franka")
+
+
+def rq():
+    q = rng.normal(size=4)
+    return [float(v) for v in q / np.linalg.norm(q)]
+
+
+def random_mesh(i):
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        v, f = box_shape([float(x) for x in rng.uniform(0.05, 0.6, size=3)], int(rng.integers(0, 4)))
+    elif kind == 1:  # a thin pillar / slab: the long walks of the bench's mesh world
+        d = [0.1, 0.1, 0.1]
+        d[int(rng.integers(3))] = float(rng.uniform(0.8, 1.6))
+        v, f = box_shape(d, int(rng.integers(2, 5)))
+    elif kind == 2:
+        v, f = sphere_shape(float(rng.uniform(0.05, 0.3)), int(rng.choice([6, 12, 24])), int(rng.choice([8, 24, 48])))
+    elif kind == 3:
+        v, f = torus_shape(float(rng.uniform(0.15, 0.3)), float(rng.uniform(0.03, 0.08)), int(rng.choice([16, 48])), int(rng.choice([8, 24])))
+    else:
+        v, f = ell_shape(int(rng.integers(1, 3)))
+    o = {"name": f"m{i}", "vertices": v, "faces": f, "pose": [float(x) for x in rng.uniform([-0.6, -0.6, -0.1], [0.6, 0.6, 0.9])] + rq()}
+    if rng.random() < 0.15:
+        o["enable"] = False
+    return o
+
+
+bad = 0
+for case in range(n_cases):
+    sweep = bool(rng.random() < 0.5)
+    speed = sweep and bool(rng.random() < 0.6)
+    eta = float(rng.choice([0.0, 0.0025, 0.02, 0.08]))
+    world = [[random_mesh(i) for i in range(int(rng.integers(1, 7)))]]
+    b, h = int(rng.integers(1, 24)), int(rng.integers(2, 12))
+    q0, q1 = sample_q(model, b, seed=int(rng.integers(1000)))[:, None], sample_q(model, b, seed=int(rng.integers(1000)))[:, None]
+    tt = np.linspace(0, 1, h, dtype=np.float32)[None, :, None]
+    sph = oracle.kinematics_forward((q0 * (1 - tt) + q1 * tt).reshape(b * h, -1) * float(rng.uniform(0.3, 1.0)), model.as_dict(), horizon=h)["robot_spheres"]
+    sph = sph.reshape(b, h, -1, 4)
+    S = sph.shape[2]
+    try:
+        ref = oracle.scene_collision(sph, mesh_scene_arrays(world), 3.0, eta, sweep=sweep, enable_speed_metric=speed, speed_dt=0.05)
+        scene = SceneData.from_arrays(None, dev, meshes=world)
+        dist, grad = torch.full((b, h, S), 5.0, device=dev), torch.full((b, h, S, 4), 5.0, device=dev)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=dev), scene.struct, torch.tensor([3.0], device=dev),
+                                     torch.tensor([eta], device=dev), None, b, h, S, False, 3 if sweep else 0, speed, torch.tensor([0.05], device=dev))
+        torch.cuda.synchronize()
+        d, g = dist.cpu().numpy(), grad.cpu().numpy()
+        dr, gr = ref["distance"], ref["gradient"]
+        ok = np.ones(d.shape, bool)
+        if sweep:
+            stepn = np.linalg.norm(np.diff(sph[..., :3], axis=1), axis=-1)
+            ok[:, 1:] &= stepn >= 1e-5
+            ok[:, :-1] &= stepn >= 1e-5
+        sc = 20.0 if speed else 1.0
+        graze = np.abs(d - dr) < 3e-5 * sc
+        assert np.array_equal((d > 0)[ok & ~graze], (dr > 0)[ok & ~graze]), "hit set differs"
+        e, tol = np.abs(d - dr)[ok], 3e-5 * sc + 2e-4 * np.abs(dr)[ok]
+        n_off = int((e > tol).sum())
+        allowed = (2 + int(2e-4 * (dr > 0).sum())) if sweep else 0
+        assert n_off <= allowed, f"{n_off} spheres beyond the cost bound (allowed {allowed}), worst {float((e / tol).max()):.1f} x; colliding {int((dr > 0).sum())}"
+        badg = np.abs(g - gr).max(-1)[ok] > (3e-4 * sc + 2e-3 * np.abs(gr).max(-1)[ok])
+        assert badg.mean() < 3e-3, f"gradient: {float(badg.mean()):.2e} of the spheres off (closest-point ties aside)"
+    except AssertionError as ex:
+        bad += 1
+        print(f"FAILED case {case}: meshes {[(m['name'], len(m['faces'])) for m in world[0]]} sweep {sweep} speed {speed} eta {eta} b {b} h {h}: {str(ex)[:300]}")
+print(f"{n_cases} cases, {bad} failed")
