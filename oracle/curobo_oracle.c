@@ -1142,6 +1142,7 @@ ORC_API void orc_bspline_backward(float *out_grad_knots, const float *grad_pos,
     for (int k = 0; k < n_knots; k++)
       for (int d = 0; d < dof; d++) {
         float total = 0.0f;
+        float part[64]; /* the interpolation points' shares, summed below in the reference's order */
         for (int ii = 0; ii < interp; ii++) {
           float g[4][6];
           memset(g, 0, sizeof(g));
@@ -1173,7 +1174,20 @@ ORC_API void orc_bspline_backward(float *out_grad_knots, const float *grad_pos,
             for (int i = 0; i < support; i++) acc += g[der][i] * basis[support - 1 - i];
             sums[der] = acc;
           }
-          total += sums[0] + (sums[1] / scale[1]) + (sums[2] / scale[2]) + (sums[3] / scale[3]);
+          const float share = sums[0] + (sums[1] / scale[1]) + (sums[2] / scale[2]) + (sums[3] / scale[3]);
+          if (ii < 64) part[ii] = share;
+          total += share;
+        }
+        /* The reference adds the shares of a knot with a warp-segmented shuffle tree (bspline_gradient_util.cuh:83-105,
+         * lane = interpolation index * knots_per_warp + knot): strides interp/2, interp/4, .., 1 -- e.g. (v0 + v2) + (v1 + v3)
+         * for its default of four interpolation steps.  That tree is only a sum of the RIGHT lanes when the step count
+         * divides the warp (a power of two): for 3, 5, 6, .. steps knots_per_warp * interp != 32 and the kernel pairs lanes of
+         * different knots (run on the CPU it differs from the sum by O(1), tests/randomised/sweep_reference_kernels.py).  The
+         * oracle follows the tree bit for bit where the reference is well defined and keeps the plain sum elsewhere. */
+        if (interp >= 2 && interp <= 32 && (interp & (interp - 1)) == 0) {
+          for (int stride = interp / 2; stride >= 1; stride /= 2)
+            for (int i = 0; i < stride; i++) part[i] += part[i + stride];
+          total = part[0];
         }
         out_grad_knots[((size_t)b * n_knots + k) * dof + d] = total;
       }
