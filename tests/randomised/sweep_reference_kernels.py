@@ -69,6 +69,34 @@ for case in range(n_cases):
             assert np.array_equal(fa[k], fb[k]), f"B-spline forward {k} not bit-identical (degree {degree}, knots {nk}, dof {dof}, interp {interp})"
         g = [rng.normal(size=(bb, ph, dof)).astype(np.float32) for _ in range(4)]
         assert np.array_equal(oracle.bspline_backward(*g, dt, gidx, imp, nk, degree), ref.bspline_backward(*g, dt, gidx, imp, nk, degree)), "B-spline VJP"
+        # Wolfe line search: random rounds with ties between candidates, flat costs and zero directions; every state array identical
+        lb, nls, lv = int(rng.integers(1, 40)), 4, int(rng.choice([7, 84, 96]))
+        z = np.zeros
+        mkst = lambda: dict(best_cost=np.full((lb,), 1e9, np.float32), best_action=z((lb, lv), np.float32), best_iteration=z((lb,), np.int16),  # noqa: E731
+                            current_iteration=z((lb,), np.int16), converged=z((lb,), np.uint8), exploration_cost=z((lb,), np.float32),
+                            exploration_action=z((lb, lv), np.float32), exploration_gradient=z((lb, lv), np.float32), cost=z((lb,), np.float32),
+                            action=z((lb, lv), np.float32), gradient=z((lb, lv), np.float32), exploration_idx=z((lb, nls), np.int32),
+                            selected_idx=z((lb, nls), np.int32))
+        sa, sb = mkst(), mkst()
+        strong, approx = bool(rng.random() < 0.4), bool(rng.random() < 0.4)
+        if strong:
+            approx = False
+        for rnd in range(3):
+            x, dd = rng.normal(size=(lb, nls, lv)).astype(np.float32), rng.normal(size=(lb, lv)).astype(np.float32)
+            c = (rng.random((lb, nls)) * np.array([1, 0.8, 1.2, 2.0])).astype(np.float32)
+            mode = int(rng.integers(0, 4))
+            if mode == 1:
+                c[:, 2] = c[:, 1]  # a tie between two candidates
+            if mode == 2:
+                c[rng.random(lb) < 0.5] = 0.5  # all candidates of a problem cost the same
+            if mode == 3:
+                dd[rng.random(lb) < 0.5] = 0  # zero direction
+            gx = (rng.normal(size=(lb, nls, lv)) * 0.3).astype(np.float32)
+            al = np.array([0.0, 0.25, 0.5, 1.0], np.float32)
+            for impl, st in ((oracle, sa), (ref, sb)):
+                impl.line_search(st, c, x, gx, dd, al, 1e-5, 0.9, strong, approx, 5, 0.0, 0.001)
+            for k in sa:
+                assert np.array_equal(sa[k], sb[k]), f"line search {k} (round {rnd}, mode {mode}, strong {strong}, approx {approx})"
     except AssertionError as e:
         bad += 1
         print(f"FAILED case {case}: {robot} n {n} scale {scale}: {str(e)[:400]}".replace("\n", " | "))
