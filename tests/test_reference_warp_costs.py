@@ -217,3 +217,17 @@ def test_hip_reproduces_the_reference_lm_tile_kernel(tag, device):
     d_ref = g[tag + "/joint_position_out"] - q
     np.testing.assert_allclose(q_out.cpu().numpy() - q, d_ref, rtol=2e-3, atol=5e-4 * np.abs(d_ref).max())
     np.testing.assert_allclose(pred.cpu().numpy(), g[tag + "/pred_reduction"], rtol=2e-3, atol=1e-4 * np.abs(g[tag + "/pred_reduction"]).max())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/curobo/_src/cost"), reason="the reference's Warp sources are not on this machine")
+@pytest.mark.parametrize("script,cases", [("sweep_reference_warp_tool_pose.py", "60"), ("sweep_reference_warp_scene.py", "40")])
+def test_randomised_sweep_against_the_reference_warp_kernels(script, cases):
+    """the oracle against the reference's Warp kernels (through tests/golden/warp_emulator) on random inputs:
+    tests/randomised/sweep_reference_warp_*.py at a small size"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", script), cases, "9"], capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
