@@ -122,3 +122,16 @@ def test_torch_twin_of_the_optimiser_stage_matches_the_reference_golden(name, go
     np.testing.assert_allclose(y.numpy(), gold[f"lbfgs_{name}_y"], atol=1e-6)
     np.testing.assert_allclose(s.numpy(), gold[f"lbfgs_{name}_s"], atol=1e-6)
     np.testing.assert_allclose(rho.numpy(), gold[f"lbfgs_{name}_rho"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/curobo/_src/optim"), reason="the reference's torch twins are not on this machine")
+def test_randomised_sweep_against_the_reference_torch_twins():
+    """tests/randomised/sweep_reference_torch_optim.py at a small size: the oracle's L-BFGS step and Wolfe line search against
+    the reference's own torch twins on random batch sizes, dimensions, history lengths and strategies"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", "sweep_reference_torch_optim.py"), "30", "9"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
