@@ -98,3 +98,16 @@ def test_rnea_external_force_enters_linearly_with_negative_sign(oracle):
         tp, _ = oracle.rnea_forward(q, qd, qdd, m, f_ext=fe + d)
         fd = ((tp - t1) * w).sum(1) / 1e-2
         np.testing.assert_allclose(gfe[:, k, 2], fd, rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/curobo/tests/_src/robot/dynamics/rnea_numpy_reference.py"),
+                    reason="the reference's NumPy RNEA is not on this machine")
+def test_randomised_sweep_against_the_reference_numpy_rnea():
+    """tests/randomised/sweep_reference_numpy_rnea.py at a small size: random configurations, velocity / acceleration scales, robots"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", "sweep_reference_numpy_rnea.py"), "40", "9"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
