@@ -220,7 +220,7 @@ def test_hip_reproduces_the_reference_lm_tile_kernel(tag, device):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/curobo/_src/cost"), reason="the reference's Warp sources are not on this machine")
-@pytest.mark.parametrize("script,cases", [("sweep_reference_warp_tool_pose.py", "60"), ("sweep_reference_warp_scene.py", "40"), ("sweep_reference_warp_cspace.py", "40")])
+@pytest.mark.parametrize("script,cases", [("sweep_reference_warp_tool_pose.py", "60"), ("sweep_reference_warp_scene.py", "40"), ("sweep_reference_warp_cspace.py", "40"), ("sweep_reference_warp_lm.py", "40")])
 def test_randomised_sweep_against_the_reference_warp_kernels(script, cases):
     """the oracle against the reference's Warp kernels (through tests/golden/warp_emulator) on random inputs:
     tests/randomised/sweep_reference_warp_*.py at a small size"""
