@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_ik.py", ["5", "5"], ", 0 failed"),
     ("fuzz_costs.py", ["16", "5"], ", 0 failed"),
     ("fuzz_lm.py", ["30", "5"], ", 0 failed"),
+    ("fuzz_mppi.py", ["30", "5"], ", 0 failed"),
     ("fuzz_opt.py", ["16", "5"], None),  # (its L-BFGS cases include ill-conditioned histories: the line-search half must be exact)
 ])
 def test_randomised_sweep(script, args, ok):

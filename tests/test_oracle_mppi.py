@@ -23,3 +23,15 @@ def test_mppi_update_matches_reference_torch(case):
     np.testing.assert_allclose(new_cov, k("new_cov"), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(new_tril, k("new_tril"), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(w.sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/curobo/_src/optim/particle"), reason="the reference's torch functions are not on this machine")
+def test_randomised_sweep_against_the_reference_torch_functions():
+    """tests/randomised/sweep_reference_torch_mppi.py at a small size: random shapes, temperatures, step sizes"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", "sweep_reference_torch_mppi.py"), "60", "9"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
