@@ -257,3 +257,15 @@ def test_basis_functions_match_scipy(degree, oracle):
             for der, k in enumerate(("position", "velocity", "acceleration", "jerk")):
                 want = basis[der, ti] @ ctrl / knot_dt ** der
                 np.testing.assert_allclose(out[k][0, h], want, atol=1e-5 * max(1.0, np.abs(want).max()) * 3.0 ** der)
+
+
+def test_randomised_sweep_of_the_host_utilities_against_the_reference():
+    """tests/randomised/sweep_reference_torch_util.py at a small size (skips itself where /root/reference is absent)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", "sweep_reference_torch_util.py"), "60", "9"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout or "0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
