@@ -55,3 +55,16 @@ def test_stomp_noise_is_smooth_and_pinned_at_the_ends():
     rough = np.abs(np.diff(x[:, 1:-2], n=2, axis=1)).mean()
     white = np.abs(np.diff(np.random.default_rng(0).normal(size=x[:, 1:-2].shape) * x.std(), n=2, axis=1)).mean()
     assert rough < 0.3 * white
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/curobo/_src/optim/particle"), reason="the reference's sample library is not on this machine")
+def test_randomised_sweep_against_the_reference_sample_library():
+    """tests/randomised/sweep_reference_torch_samples.py at a small size: random horizons, dimensions, seeds, counts, ratios, filters;
+    continuing streams (fixed_samples off) and the optimiser's pre-generated set"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "randomised", "sweep_reference_torch_samples.py"), "40", "9"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ", 0 failed" in out.stdout, (out.stdout + out.stderr)[-2000:]
