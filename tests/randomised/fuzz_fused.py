@@ -52,11 +52,19 @@ for case in range(n_cases):
     kw["use_speed_metric"] = kw["use_sweep"] and bool(rng.random() < 0.7)
     kw["use_scene_collision"] = n_obs > 0 and (not kw["use_self_collision"] or rng.random() < 0.9)
     voxel = bool(rng.random() < 0.2) and kw["use_scene_collision"]
-    desc = f"case {case}: {robot} seeds {seeds} degree {degree} knots {n_knots} x {interp} obstacles {n_obs} voxel {voxel} {kw}"
+    desc = f"case {case}: {robot} (multi-env worlds in a quarter of the cases) seeds {seeds} degree {degree} knots {n_knots} x {interp} obstacles {n_obs} voxel {voxel} {kw}"
     if not (kw["use_self_collision"] or kw["use_scene_collision"]):
         continue
     try:
-        _, _, knots, _, ro_ref, ro_fused = T._pair(dev, robot=robot, seeds=seeds, world=random_world(max(n_obs, 1)), voxel=voxel, **kw)
+        n_env = int(rng.choice([1, 1, 2, 3]))
+        world = [random_world(max(n_obs, 1))[0] for _ in range(n_env)]  # several environments: different obstacle sets (and counts)
+        if n_env > 1:
+            world = [w[: max(1, int(rng.integers(1, len(w) + 1)))] for w in world]
+        _, _, knots, _, ro_ref, ro_fused = T._pair(dev, robot=robot, seeds=seeds, world=world, voxel=voxel and n_env == 1, **kw)
+        if n_env > 1:
+            env = torch.as_tensor(rng.integers(0, n_env, size=seeds).astype(np.int32), device=dev)
+            ro_ref.update_env_query_idx(env)
+            ro_fused.update_env_query_idx(env)
         if not ro_fused.fused_available():
             continue
         knots = knots * float(rng.uniform(0.3, 1.2))
