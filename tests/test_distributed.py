@@ -259,3 +259,39 @@ def _problem_worker(rank, world, port):
 @pytest.mark.timeout(120)
 def test_problem_shard_exchange_world_size_2_gloo():
     mp.spawn(_problem_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_exchange_worker(rank, world, port, seed):
+    """random costs with many ties (quantised to a few values), uneven problem counts and payload widths: the arg-min and the
+    top-k over the ranks must be the stable-sort answer over the global seed set, on every rank"""
+    from curobo_amd.distributed import global_topk
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(seed)  # the same global problem on every rank
+    for _ in range(4):
+        P = int(torch.randint(1, 9, (1,), generator=g))
+        per = int(torch.randint(1, 7, (1,), generator=g))
+        total, V = per * world, int(torch.randint(1, 9, (1,), generator=g))
+        levels = int(torch.randint(2, 6, (1,), generator=g))
+        cost = torch.randint(0, levels, (P, total), generator=g).float() * 0.25  # a handful of distinct values: ties everywhere
+        payload = torch.rand(P, total, V, generator=g)
+        lo, hi = shard_range(total, rank, world)
+        c, i, p = global_argmin(cost[:, lo:hi].contiguous(), payload[:, lo:hi].contiguous(), lo)
+        ref = torch.sort(cost, dim=1, stable=True)
+        assert torch.equal(i, ref.indices[:, 0]) and torch.equal(c, ref.values[:, 0]), (rank, world, i, ref.indices[:, 0])
+        assert torch.equal(p, payload[torch.arange(P), ref.indices[:, 0]])
+        k = int(torch.randint(1, total + 1, (1,), generator=g))
+        c, i, p = global_topk(cost[:, lo:hi].contiguous(), payload[:, lo:hi].contiguous(), lo, k)
+        assert torch.equal(i, ref.indices[:, :k]) and torch.equal(c, ref.values[:, :k]), (rank, world, k)
+        assert torch.equal(p, payload[torch.arange(P).unsqueeze(1), ref.indices[:, :k]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [3, 4, 8])
+def test_random_exchanges_with_ties_world_sizes_3_4_8_gloo(world):
+    """the exchange of the path at the world sizes of BASELINE's configs (4 and 8 ranks; 3 for an uneven one), gloo on the CPU"""
+    mp.spawn(_random_exchange_worker, args=(world, _free_port(), 100 + world), nprocs=world, join=True)
