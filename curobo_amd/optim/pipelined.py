@@ -20,6 +20,7 @@ from typing import Callable, List, Optional, Tuple
 
 import torch
 
+from ..util.stream_scope import forked_stream
 from .lbfgs import LBFGSOpt, LBFGSOptCfg
 
 
@@ -55,7 +56,7 @@ class PipelinedLBFGS:
         cur = torch.cuda.current_stream(self.device)
         for opt, s in zip(self.opts, self.streams):
             s.wait_stream(cur)
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s), forked_stream():  # (a rollout with a side stream of its own keeps to the shard's stream)
                 fn(opt)
         for s in self.streams:
             cur.wait_stream(s)

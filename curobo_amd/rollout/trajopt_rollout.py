@@ -28,6 +28,7 @@ from ..backends import rollout as rollout_hip
 from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
 from ..scene.data import SceneData, validate_env_query_idx
+from ..util.stream_scope import inside_forked_stream
 
 
 @dataclass
@@ -285,7 +286,7 @@ class TrajOptRollout:
         # serial tree walks of RNEA occupy half a wavefront per SIMD (528 wavefronts for 33 792 elements) and leave the
         # chip to the collision kernels; one after the other they cost the sum (Unitree G1, C4 shapes: 1 428 us).
         side = None
-        if tq and c.overlap_dynamics and self.position.is_cuda:
+        if tq and c.overlap_dynamics and self.position.is_cuda and not inside_forked_stream():
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
             side = self._side_stream

@@ -396,3 +396,44 @@ def test_humanoid_rollout_side_stream_scratch_walks_equal_the_single_stream_sequ
         np.testing.assert_allclose(tau.cpu().numpy(), ref["tau"], rtol=1e-5, atol=1e-5 * np.abs(ref["tau"]).max())
         np.testing.assert_allclose(c.cpu().numpy(), ref["cost"], rtol=1e-5, atol=1e-6 * np.abs(ref["cost"]).max())
         np.testing.assert_allclose(g.cpu().numpy(), gk, rtol=5e-4, atol=5e-4 * np.abs(gk).max())
+
+
+def test_seed_shards_over_torque_limited_rollouts_capture_and_match_one_batch(device):
+    """PipelinedLBFGS (seed shards on their own streams, one hipGraph) over TrajOptRollouts with torque limits on the kernel
+    sequence.  Such a rollout forks a side stream for its joint-space chain; from inside a shard's stream that is a two-level
+    fork, which crashes hipStreamEndCapture on this ROCm (tools/r04/c4_shards.py) -- inside a shard the rollout therefore keeps
+    both chains on the shard's stream (curobo_amd/util/stream_scope.py).  The capture must run, and the shards must take the
+    iterates of the one batch (whose rollout does use its side stream: same kernels, same numbers)."""
+    from curobo_amd.optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()  # noqa: F841
+    cfg = TrajOptRolloutCfg(use_fused=False, use_torque_limits=True, effort_limit=[12.0, 25.0, 10.0, 10.0, 2.0, 1.5, 0.5])
+    seeds = 8
+    ocfg = LBFGSOptCfg(num_problems=seeds, inner_iters=4, num_iters=8)
+    nls = len(ocfg.line_search_scale)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+    rng = np.random.default_rng(3)
+    gpos = torch.as_tensor(rng.normal(size=(1, 1, 1, 3)).astype(np.float32) * 0.3 + np.array([0.4, 0.0, 0.4], np.float32), device=device)
+    gq = torch.as_tensor(np.array([[[[0.0, 1.0, 0.0, 0.0]]]], np.float32), device=device)
+
+    def make(batch):
+        ro = TrajOptRollout(kin, scene, batch, cfg)
+        ro.update_start_state(start)
+        ro.update_goals(gpos, gq, torch.zeros(batch, dtype=torch.int32, device=device))
+        return ro.cost_and_gradient
+
+    x0 = torch.as_tensor(seed_knots(model, seeds, cfg.n_knots, seed=4, spread=0.4), device=device)
+    one = LBFGSOpt(ocfg, make(seeds * nls), cfg.n_knots, kin.num_dof, bounds, device)
+    ref = one.optimize(x0).clone()
+    ref_cost = one.best_cost.clone()
+    pipe = PipelinedLBFGS(ocfg, make, cfg.n_knots, kin.num_dof, bounds, device, n_shards=2)
+    got = pipe.optimize(x0)  # (captures the two shards into one graph)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref_cost).all() and float(ref_cost.min()) < 1e9
+    # the staged (in-shard) and the scratch / side-stream RNEA launches differ in the last bits of the torques: costs to 1e-5
+    torch.testing.assert_close(pipe.best_cost, ref_cost, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
