@@ -303,69 +303,143 @@ struct MeshQueueArgs {
   uint2 *queue;       // workspace + 16 bytes: (sphere index, live slot mask)
 };
 
+#ifndef MESH_SELECT_STAGED
+#define MESH_SELECT_STAGED 1
+#endif
+#ifndef MESH_SELECT_CHUNKS
+#define MESH_SELECT_CHUNKS 4  // spheres per lane: 256 x 4 per workgroup (1 / 2 / 4 / 8 / 16: 47.6 / 44.5 / 39.6 / 48.4 / 68.2 us for 2.2 M spheres)
+#endif
 template <int SWEEP>
 __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueueArgs qa) {
-  __shared__ int wave_cnt[2][4];
+  constexpr int CH = MESH_SELECT_CHUNKS;
+  __shared__ int wave_cnt[2][CH * 4];  // live spheres of (class, chunk, wavefront); after the scan: their offset in the workgroup's run
   __shared__ uint32_t run_base[2];
+  // The obstacle slots the workgroup's spheres meet (pose, root box of the mesh), fetched ONCE per workgroup into LDS (read per
+  // sphere they are four dependent loads a slot: count / enable -> mesh id -> mesh record -> root box), and CH spheres a lane:
+  // their loads are in flight together, and the two queue counters take one atomic per 256 x CH spheres.
+  constexpr int kRecs = 128;
+  __shared__ float s_rec[kRecs][16];  // t[3] q[4] lo[3] hi[3] enabled
   const MeshCollArgs &a = qa.c;
-  const long total = (long)a.batch * a.horizon * a.nspheres;
+  const long total = (long)a.batch * a.horizon * a.nspheres;  // (< 2^31: the launcher checks)
   const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
-  const long sidx = (long)blockIdx.x * 256 + tid;
-  const int hs = a.horizon * a.nspheres;
-  const bool in = sidx < total;
-  const int b = in ? (int)(sidx / hs) : 0;
-  const int h = in ? (int)((sidx - (long)b * hs) / a.nspheres) : 0;
-  const int env = (in && a.use_multi_env) ? a.env_query_idx[b] : 0;
-  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
-  uint32_t live = 0u;
-  bool heavy = false;  // the centre lies inside the bounding box of a live slot's mesh: long walks (front of the queue)
-  if (in) {
-    const float4 s = sph[sidx];
-    if (s.w >= 0.0f) {
-      const f3 center = make_f3(s.x, s.y, s.z);
-      const float r_adj = s.w + a.eta[0];
-      float reach = 2e-6f;
-      if (SWEEP > 0) {
-        float half_w_prev = 0.0f, half_w_next = 0.0f;
-        if (h > 0) { const float4 ps = sph[sidx - a.nspheres]; const f3 dd = make_f3(ps.x, ps.y, ps.z) - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
-        if (h < a.horizon - 1) { const float4 ns = sph[sidx + a.nspheres]; const f3 dd = make_f3(ns.x, ns.y, ns.z) - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
-        reach = fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f;
+  const long base = (long)blockIdx.x * (256 * CH);
+  const uint32_t hs = (uint32_t)(a.horizon * a.nspheres);
+  const int first_b = (int)((uint32_t)base / hs);
+  const int last_b = (int)((uint32_t)min(base + (256 * CH - 1), total - 1) / hs);
+  const int n_rec = (a.use_multi_env ? last_b - first_b + 1 : 1) * a.nslots;
+  const bool staged = MESH_SELECT_STAGED && n_rec <= kRecs;
+  if (staged) {
+    for (int r = tid; r < n_rec; r += 256) {
+      const int bb = r / a.nslots, k = r - bb * a.nslots;
+      const MeshSlot slot = load_mesh_slot(a.set, a.use_multi_env ? a.env_query_idx[first_b + bb] : 0, a.slot0 + k);
+      float *rec = s_rec[r];
+      rec[0] = slot.t.x; rec[1] = slot.t.y; rec[2] = slot.t.z;
+      rec[3] = slot.qw; rec[4] = slot.qx; rec[5] = slot.qy; rec[6] = slot.qz;
+      if (slot.enabled) {
+        const float *rb = slot.m.node_box + 8;
+        rec[7] = rb[0]; rec[8] = rb[1]; rec[9] = rb[2]; rec[10] = rb[4]; rec[11] = rb[5]; rec[12] = rb[6];
       }
-      for (int k = 0; k < a.nslots; k++) {
-        const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
-        if (!slot.enabled) continue;
-        const f3 lc = mesh_to_local(slot, center);
-        if (!mesh_early_reject(slot, lc, r_adj, reach)) {
-          live |= 1u << k;
-          const float *rb = slot.m.node_box + 8;
-          if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]);
+      rec[13] = slot.enabled ? 1.0f : 0.0f;
+    }
+  }
+  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
+  const float eta = a.eta[0];
+  // ---- the lane's spheres and their neighbours, all loads first
+  float4 s[CH];
+  float reach[CH];  // half the longer step to a neighbour (+ rounding): how far a sweep sample can lie from the centre
+  int bb[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const long sidx = base + c * 256 + tid;
+    const bool in = sidx < total;
+    const uint32_t s32 = in ? (uint32_t)sidx : 0u;
+    bb[c] = (int)(s32 / hs);
+    const int h = (int)((s32 - (uint32_t)bb[c] * hs) / (uint32_t)a.nspheres);
+    s[c] = in ? sph[sidx] : make_float4(0.f, 0.f, 0.f, -1.0f);
+    reach[c] = 2e-6f;
+    if (SWEEP > 0) {
+      const float4 ps = (in && h > 0) ? sph[sidx - a.nspheres] : s[c], ns = (in && h < a.horizon - 1) ? sph[sidx + a.nspheres] : s[c];
+      const f3 center = make_f3(s[c].x, s[c].y, s[c].z);
+      const f3 dp = make_f3(ps.x, ps.y, ps.z) - center, dn = make_f3(ns.x, ns.y, ns.z) - center;
+      // (a missing neighbour stands in as the sphere itself: half step 0, as the walk kernel has it)
+      reach[c] = fmaxf(0.5f * sqrtf(dot(dp, dp)), 0.5f * sqrtf(dot(dn, dn))) * 1.0001f + 2e-6f;
+    }
+  }
+  if (staged) __syncthreads();
+  uint32_t live[CH];
+  unsigned heavy_bits = 0u;  // the centre lies inside the bounding box of a live slot's mesh: long walks (front of the queue)
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const long sidx = base + c * 256 + tid;
+    const bool in = sidx < total;
+    live[c] = 0u;
+    bool heavy = false;
+    if (in && s[c].w >= 0.0f) {
+      const f3 center = make_f3(s[c].x, s[c].y, s[c].z);
+      const float r_adj = s[c].w + eta;
+      if (staged) {
+        const float *recs = s_rec[a.use_multi_env ? (bb[c] - first_b) * a.nslots : 0];
+        const float thr = r_adj + reach[c];
+        for (int k = 0; k < a.nslots; k++) {
+          const float *rec = recs + k * 16;
+          if (rec[13] == 0.0f) continue;
+          const f3 lc = quat_rot(rec[3], rec[4], rec[5], rec[6], center) + make_f3(rec[0], rec[1], rec[2]);  // (mesh_to_local)
+          // (mesh_early_reject on the staged root box)
+          const float ex = fmaxf(fmaxf(rec[7] - lc.x, lc.x - rec[10]), 0.0f), ey = fmaxf(fmaxf(rec[8] - lc.y, lc.y - rec[11]), 0.0f),
+                      ez = fmaxf(fmaxf(rec[9] - lc.z, lc.z - rec[12]), 0.0f);
+          if (!(ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f)) {
+            live[c] |= 1u << k;
+            if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rec[7] || lc.y < rec[8] || lc.z < rec[9] || lc.x > rec[10] || lc.y > rec[11] || lc.z > rec[12]);
+          }
+        }
+      } else {
+        const int env = a.use_multi_env ? a.env_query_idx[bb[c]] : 0;
+        for (int k = 0; k < a.nslots; k++) {
+          const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
+          if (!slot.enabled) continue;
+          const f3 lc = mesh_to_local(slot, center);
+          if (!mesh_early_reject(slot, lc, r_adj, reach[c])) {
+            live[c] |= 1u << k;
+            const float *rb = slot.m.node_box + 8;
+            if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]);
+          }
         }
       }
     }
-    if (live == 0u && !a.accumulate) {
+    if (in && live[c] == 0u && !a.accumulate) {
       a.distance[sidx] = 0.0f;
       reinterpret_cast<float4 *>(a.gradient)[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (heavy) heavy_bits |= 1u << c;
   }
   // two classes: the heavy entries fill the queue from its head (counter word 0), the others from its tail backwards
   // (counter word 2): the walk takes the head first, so the launch's longest chains start when the launch does
-  const bool is_h = live != 0u && heavy, is_l = live != 0u && !heavy;
-  const unsigned long long ball_h = __ballot(is_h), ball_l = __ballot(is_l);
-  const unsigned long long ball = is_h ? ball_h : ball_l;
-  const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
-  if (lane64 == 0) { wave_cnt[0][wave] = __builtin_popcountll(ball_h); wave_cnt[1][wave] = __builtin_popcountll(ball_l); }
+  int before[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const bool is_h = live[c] != 0u && ((heavy_bits >> c) & 1u), is_l = live[c] != 0u && !((heavy_bits >> c) & 1u);
+    const unsigned long long ball_h = __ballot(is_h), ball_l = __ballot(is_l);
+    const unsigned long long ball = is_h ? ball_h : ball_l;
+    before[c] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ball >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ball, 0u));
+    if (lane64 == 0) { wave_cnt[0][c * 4 + wave] = __builtin_popcountll(ball_h); wave_cnt[1][c * 4 + wave] = __builtin_popcountll(ball_l); }
+  }
   __syncthreads();
-  if (tid < 2) {
-    const int n = wave_cnt[tid][0] + wave_cnt[tid][1] + wave_cnt[tid][2] + wave_cnt[tid][3];
+  if (tid < 2) {  // exclusive scan of the class's (chunk, wavefront) counts in place; one atomic for the workgroup's run
+    int v[CH * 4], n = 0;
+#pragma unroll
+    for (int i = 0; i < CH * 4; i++) v[i] = wave_cnt[tid][i];
+#pragma unroll
+    for (int i = 0; i < CH * 4; i++) { wave_cnt[tid][i] = n; n += v[i]; }
     run_base[tid] = n ? atomicAdd(qa.counter + 2 * tid, (uint32_t)n) : 0u;
   }
   __syncthreads();
-  if (live != 0u) {
-    const int cls = is_h ? 0 : 1;
-    int at = before;
-    for (int wv = 0; wv < wave; wv++) at += wave_cnt[cls][wv];
-    const uint32_t pos = run_base[cls] + (uint32_t)at;
-    qa.queue[is_h ? pos : (uint32_t)(total - 1) - pos] = make_uint2((uint32_t)sidx, live);
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    if (live[c] != 0u) {
+      const bool is_h = ((heavy_bits >> c) & 1u) != 0u;
+      const uint32_t pos = run_base[is_h ? 0 : 1] + (uint32_t)(wave_cnt[is_h ? 0 : 1][c * 4 + wave] + before[c]);
+      qa.queue[is_h ? pos : (uint32_t)(total - 1) - pos] = make_uint2((uint32_t)(base + c * 256 + tid), live[c]);
+    }
   }
 }
 
@@ -432,8 +506,8 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
     const uint2 e = qa.queue[qq < n_front ? qq : q_last - (qq - n_front)];
     if (live_group && (threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(6, 1);
     const long sidx = (long)e.x;
-    const int b = (int)(sidx / hs);
-    const int h = (int)((sidx - (long)b * hs) / a.nspheres);
+    const int b = (int)(e.x / (uint32_t)hs);  // (32-bit: the queued form holds sphere indices in 32 bits)
+    const int h = (int)((e.x - (uint32_t)b * (uint32_t)hs) / (uint32_t)a.nspheres);
     const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
     const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;
     const bool nb_prev = need_nb && h > 0, nb_next = need_nb && h < a.horizon - 1;
@@ -581,7 +655,7 @@ static int sphere_mesh_collision_impl(
   const long total = (long)batch_size * horizon * num_spheres;
   if (total == 0) return CUROBO_HIP_OK;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)ceil_div_l(total, 256)), block(256);
+  const dim3 grid((unsigned)ceil_div_l(total, 256)), block(256), select_grid((unsigned)ceil_div_l(total, 256 * MESH_SELECT_CHUNKS));
   if (meshes->max_n == 0) {  // no mesh slots: this kind's share is zero -- which an overwriting launch still has to write
     if (!accumulate) hipLaunchKernelGGL(mesh_zero_outputs_kernel, grid, block, 0, st, distance, reinterpret_cast<float4 *>(gradient), total);
     return check_launch(what, st);
@@ -609,10 +683,10 @@ static int sphere_mesh_collision_impl(
       // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
       const unsigned walk_blocks = (unsigned)std::min<long>(MESH_WALK_MAX_BLOCKS, ceil_div_l(total, MESH_WALK_THREADS / MESH_WALK_GROUP));
       if (sweep_steps > 0) {
-        hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), grid, block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), select_grid, block, 0, st, qa);
         hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
       } else {
-        hipLaunchKernelGGL((sphere_mesh_select_kernel<0>), grid, block, 0, st, qa);
+        hipLaunchKernelGGL((sphere_mesh_select_kernel<0>), select_grid, block, 0, st, qa);
         hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
       }
       continue;

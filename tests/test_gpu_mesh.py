@@ -163,6 +163,32 @@ def test_queued_mesh_launch_equals_the_one_kernel_launch(sweep, accumulate, orac
     assert bad.mean() < 2e-3, bad.mean()
 
 
+@pytest.mark.parametrize("h", [1, 2])
+def test_many_short_trajectories_per_select_workgroup_with_environments(h, oracle, device):
+    """few spheres per trajectory and an environment index per trajectory: a workgroup of the select kernel then meets more
+    (trajectory, slot) pairs than its LDS table of obstacle slots holds and reads the slots per sphere instead -- same results"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData
+
+    w0 = mesh_world()[0]
+    envs = [[w0[0], w0[1]], [dict(w0[2]), dict(w0[3]), dict(w0[1], name="ball_b", mesh_name="ball")], [dict(w0[3]), dict(w0[0])]]
+    sph = np.ascontiguousarray(_trajectory_spheres(oracle, 700, h)[:, :, 20:28])
+    b, _, S, _ = sph.shape
+    idx = (np.arange(b) % 3).astype(np.int32)
+    scene = SceneData.from_arrays(None, device, meshes=envs)
+    dist, grad = torch.full((b, h, S), 0.5, device=device), torch.full((b, h, S, 4), 0.5, device=device)
+    Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([2.0], device=device),
+                                 torch.tensor([0.02], device=device), torch.as_tensor(idx, device=device), b, h, S, True, 3 if h > 1 else 0, False, None)
+    torch.cuda.synchronize()
+    ref = oracle.scene_collision(sph, mesh_scene_arrays(envs), 2.0, 0.02, env_query_idx=idx, use_multi_env=True, sweep=h > 1)
+    assert all((ref["distance"][k::3] > 0).any() for k in range(3))
+    np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
+    bad = np.abs(grad.cpu().numpy() - ref["gradient"]).max(-1) > 1e-4 + 1e-3 * np.abs(ref["gradient"]).max(-1)
+    assert bad.mean() < 2e-3, bad.mean()
+
+
 def test_mesh_slots_per_environment_pose_updates_and_enable(oracle, device):
     """two environments with different mesh sets, ``env_query_idx`` per trajectory; then move a mesh and switch one off:
     the BVH stays, the store's pose / enable rows change (reference MeshData.update_pose / enable_obstacle)"""
