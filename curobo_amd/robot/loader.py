@@ -225,8 +225,11 @@ class _TreeBuilder:
         inertia6 = np.array([1e-2, 1e-2, 1e-2, 0.0, 0.0, 0.0]) * mass
         if link.mass is not None:
             mass = link.mass if link.mass > 0.0 else 0.01
-            # the CoM pose is rigidly attached, only its translation matters (:160-173)
-            com = (link.inertial_origin if link.inertial_origin is not None else np.eye(4))[:3, 3].copy()
+            # parser_urdf.py:157-170 composes the inertial origin AS A POSE (R, t) with the pose (I, t) and keeps the position of
+            # the product: com = R t + t (twice the URDF's offset when the inertial frame is not rotated).  Reproduced as it is:
+            # these are the numbers the reference's centre-of-mass output and its RNEA torques are computed from.
+            T = link.inertial_origin if link.inertial_origin is not None else np.eye(4)
+            com = T[:3, :3] @ T[:3, 3] + T[:3, 3]
             # NOTE: the reference computes an inertia array here but then stores the default
             # (`body_params["link_inertia"] = inertia`, parser_urdf.py:305); kept as is.
         if base:
@@ -472,6 +475,22 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
         pos_lim[:, j] = b.joint_limits
         vel_lim[:, j] = b.joint_velocity_limits
         eff_lim[j] = b.joint_effort_limit
+
+    # the cspace block's position clip shrinks the position range and its velocity scale the velocity range
+    # (kinematics_loader.py:1102-1124 _update_joint_limits; the scale is per cspace joint name, reindexed to the active joints by
+    # CSpaceParams.inplace_reindex, cspace_params.py:149-171; a clip given as a list is applied in the order it is written)
+    cs = cfg.get("cspace") or {}
+    clip = cs.get("position_limit_clip", 0.0)
+    clip = np.full(D, float(clip)) if isinstance(clip, (int, float)) else np.asarray(clip, np.float64).reshape(-1)
+    pos_lim[0] += clip
+    pos_lim[1] -= clip
+    vscale = cs.get("velocity_scale", 1.0)
+    if isinstance(vscale, (int, float)) or len(vscale) == 1:
+        vscale = np.full(D, float(vscale if isinstance(vscale, (int, float)) else vscale[0]))
+    else:
+        lut = dict(zip(cs["joint_names"], vscale))
+        vscale = np.asarray([float(lut[n]) for n in joint_names])
+    vel_lim = vel_lim * vscale[None]
 
     masses_com = np.stack([np.concatenate([b.com, [b.mass]]) for b in bodies]).astype(np.float32)
     inertias = np.zeros((L, 8), dtype=np.float32)

@@ -1,0 +1,72 @@
+"""curobo_amd.robot.loader against THE REFERENCE'S OWN loader (tests/golden/reference_robot_loader.py) on the reference's robot
+files: every kernel tensor of ``KinematicsParams``, the joint limits and the self-collision pair list.
+
+    python tests/golden/compare_robot_loader.py [robot ...]        (needs /root/reference; prints one line per robot)
+
+Integer tables and names must be identical; float tensors agree to 1e-6 (the links behind locked joints get their fixed
+transform from an FK evaluation in fp32 on the reference's side).  A robot without collision spheres: the reference keeps a
+[1, 1, 4] placeholder of zeros with ``total_spheres = 0``, this loader an empty [1, 0, 4] array."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reference_robot_loader as R  # noqa: E402  (puts /root/reference ahead of the repository on the path)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from curobo_amd.robot import load_robot_model  # noqa: E402
+
+CONTENT = os.path.join(R.REF, "curobo", "content")
+ROBOTS = ["franka", "ur10e", "dual_ur10e", "simple_mimic_robot", "unitree_g1_29dof_retarget", "unitree_g1"]
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def compare(name):
+    yml = os.path.join(CONTENT, "configs", "robot", f"{name}.yml")
+    kc, sc = R.reference_kinematics(yml)
+    m = load_robot_model(yml, os.path.join(CONTENT, "assets"))
+    bad = []
+    for what, a, b in (("link names", list(kc.link_name_to_idx_map.keys()), list(m.link_names)), ("joint names", list(kc.joint_names), list(m.joint_names)),
+                       ("tool frames", list(kc.tool_frames), list(m.tool_frames)), ("num_dof", int(kc.num_dof), int(m.num_dof))):
+        if a != b:
+            bad.append(f"{what}: {a} != {b}")
+    no_spheres = int(kc.total_spheres) == 0
+    for f in ("fixed_transforms", "link_map", "joint_map", "joint_map_type", "joint_offset_map", "tool_frame_map", "link_sphere_idx_map",
+              "link_chain_data", "link_chain_offsets", "joint_links_data", "joint_links_offsets", "joint_affects_endeffector", "link_spheres",
+              "link_masses_com", "link_inertias"):
+        a, b = npy(getattr(kc, f)), getattr(m, f)
+        if no_spheres and f in ("link_sphere_idx_map", "link_spheres"):
+            if b.size != 0 or np.abs(a).max() != 0:
+                bad.append(f"{f}: expected the reference's zero placeholder and an empty array")
+            continue
+        if a.size != b.size:
+            bad.append(f"{f}: shape {a.shape} != {b.shape}")
+            continue
+        a = a.reshape(b.shape)
+        if a.dtype.kind == "f":
+            if not np.allclose(a, b, rtol=0, atol=1e-6):
+                bad.append(f"{f}: max |diff| {np.abs(a.astype(np.float64) - b).max():.3e}")
+        elif not np.array_equal(a.astype(np.int64), b.astype(np.int64)):
+            bad.append(f"{f}: differs")
+    jl = kc.joint_limits
+    for f, a, b in (("position limits", npy(jl.position), m.joint_limits_position), ("velocity limits", npy(jl.velocity), m.joint_limits_velocity)):
+        if not np.allclose(a, b, rtol=0, atol=1e-6):
+            bad.append(f"{f}: max |diff| {np.abs(a - b).max():.3e}")
+    if sc is not None and not no_spheres:
+        if not np.array_equal(npy(sc.collision_pairs).astype(np.int64), m.collision_pairs.astype(np.int64)):
+            bad.append("self-collision pair list differs")
+        if not np.allclose(npy(sc.sphere_padding), m.sphere_padding, rtol=0, atol=1e-7):
+            bad.append("self-collision sphere padding differs")
+    print(f"{name}: {'ok' if not bad else 'DIFFERENT: ' + '; '.join(bad)}  ({m.num_dof} dof, {m.num_links} links, {m.num_spheres} spheres, "
+          f"{m.collision_pairs.shape[0]} pairs, {len(m.tool_frames)} tool frames)", flush=True)
+    return not bad
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ROBOTS
+    sys.exit(0 if all([compare(n) for n in names]) else 1)

@@ -250,6 +250,72 @@ def cw_div(a, b):
     return type(a)([x / y for x, y in zip(a.v, b.v)])
 
 
+class mat33(_Vec):  # row major; m[i, j] or m[i][j]
+    N = 9
+
+    def __init__(self, *a):
+        if len(a) == 3 and all(isinstance(x, _Vec) and x.N == 3 for x in a):  # from three column vectors (Warp's convention)
+            c0, c1, c2 = a
+            a = ([c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2]],)
+        _Vec.__init__(self, *a)
+
+    def __getitem__(self, i):
+        if isinstance(i, tuple):
+            return self.v[int(i[0]) * 3 + int(i[1])]
+        return vec3(self.v[3 * int(i):3 * int(i) + 3])
+
+    def __setitem__(self, i, x):
+        assert isinstance(i, tuple)
+        self.v[int(i[0]) * 3 + int(i[1])] = _F(x)
+
+    def __mul__(self, o):
+        if isinstance(o, mat33):
+            return mat33([sum((self[i, k] * o[k, j] for k in range(1, 3)), self[i, 0] * o[0, j]) for i in range(3) for j in range(3)])
+        if isinstance(o, _Vec) and o.N == 3:
+            return vec3([self[i, 0] * o[0] + self[i, 1] * o[1] + self[i, 2] * o[2] for i in range(3)])
+        return _Vec.__mul__(self, o)
+
+
+mat33f = mat33
+
+
+def quat_to_matrix(q):  # warp/native/quat.h: the columns are the rotated unit vectors
+    return mat33(quat_rotate(q, vec3(1.0, 0.0, 0.0)), quat_rotate(q, vec3(0.0, 1.0, 0.0)), quat_rotate(q, vec3(0.0, 0.0, 1.0)))
+
+
+def quat_from_matrix(m):  # warp/native/quat.h: trace form, else the largest diagonal element; normalised
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.v
+    tr = m00 + m11 + m22
+    half, one = _F(0.5), _F(1.0)
+    if tr >= _F(0.0):
+        h = _F(np.sqrt(tr + one))
+        w = half * h
+        h = half / h
+        x, y, z = (m21 - m12) * h, (m02 - m20) * h, (m10 - m01) * h
+    else:
+        d = 0
+        if m11 > m00:
+            d = 1
+        if m22 > (m00, m11)[d]:
+            d = 2
+        if d == 0:
+            h = _F(np.sqrt((m00 - (m11 + m22)) + one))
+            x = half * h
+            h = half / h
+            y, z, w = (m01 + m10) * h, (m20 + m02) * h, (m21 - m12) * h
+        elif d == 1:
+            h = _F(np.sqrt((m11 - (m22 + m00)) + one))
+            y = half * h
+            h = half / h
+            z, x, w = (m12 + m21) * h, (m01 + m10) * h, (m02 - m20) * h
+        else:
+            h = _F(np.sqrt((m22 - (m00 + m11)) + one))
+            z = half * h
+            h = half / h
+            x, y, w = (m20 + m02) * h, (m12 + m21) * h, (m10 - m01) * h
+    return normalize(quat(x, y, z, w))
+
+
 def quat_identity():
     return quat(0.0, 0.0, 0.0, 1.0)
 
