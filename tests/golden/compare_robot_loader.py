@@ -57,6 +57,12 @@ def compare(name):
     for f, a, b in (("position limits", npy(jl.position), m.joint_limits_position), ("velocity limits", npy(jl.velocity), m.joint_limits_velocity)):
         if not np.allclose(a, b, rtol=0, atol=1e-6):
             bad.append(f"{f}: max |diff| {np.abs(a - b).max():.3e}")
+    if getattr(jl, "effort", None) is not None and not np.allclose(npy(jl.effort)[1], m.joint_limits_effort, rtol=0, atol=1e-6):
+        bad.append(f"effort limits: max |diff| {np.abs(npy(jl.effort)[1] - m.joint_limits_effort).max():.3e}")
+    dq = kc.cspace.default_joint_position
+    if dq is not None and m.cspace.get("default_joint_position") is not None:
+        if not np.allclose(npy(dq), np.asarray(m.cspace["default_joint_position"], np.float32), rtol=0, atol=1e-6):
+            bad.append("cspace default joint position (reindexed to the active joints) differs")
     if sc is not None and not no_spheres:
         if not np.array_equal(npy(sc.collision_pairs).astype(np.int64), m.collision_pairs.astype(np.int64)):
             bad.append("self-collision pair list differs")

@@ -1,0 +1,61 @@
+"""The cuboid store a scene description becomes (dims, inverse poses, enable flags, counts: the obstacle input of the
+collision kernels) -- ``curobo_amd.scene.config.scene_arrays_from_config`` against THE REFERENCE'S OWN ``SceneCfg.create`` +
+``CuboidData.from_scene_cfg`` / ``from_batch_scene_cfg`` (geom/types.py, geom/data/data_cuboid.py:67-260) run on the CPU, on the
+scene files the reference ships and on random rotated cuboids in two environments.
+
+    python tests/golden/compare_scene_config.py        (needs /root/reference)
+
+The pad column of ``dims`` is not compared (the reference leaves its cache default 0.01 there; no kernel reads it)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reference_robot_loader as R  # noqa: E402,F401  (CPU DeviceCfg, the Warp stand-in, /root/reference on the path)
+import yaml  # noqa: E402
+from curobo._src.geom.data.data_cuboid import CuboidData  # noqa: E402
+from curobo._src.geom.types import SceneCfg  # noqa: E402
+from curobo._src.types.device_cfg import DeviceCfg  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from curobo_amd.scene.config import scene_arrays_from_config  # noqa: E402
+
+
+def compare(label, cfgs):
+    cfgs = [{"cuboid": c.get("cuboid") or {}} for c in cfgs]
+    scenes = [SceneCfg.create(c) for c in cfgs]
+    ref = CuboidData.from_batch_scene_cfg(scenes, DeviceCfg(device="cpu")) if len(scenes) > 1 else CuboidData.from_scene_cfg(scenes[0], DeviceCfg(device="cpu"))
+    ours = scene_arrays_from_config(cfgs if len(cfgs) > 1 else cfgs[0])
+    bad = []
+    if ref.count.tolist() != ours["cuboid_count"].tolist():
+        bad.append(f"count {ref.count.tolist()} != {ours['cuboid_count'].tolist()}")
+    for e, n in enumerate(ref.count.tolist()):
+        for rk, ok, cols in (("dims", "cuboid_dims", 3), ("inv_pose", "cuboid_inv_pose", 7), ("enable", "cuboid_enable", None)):
+            a, b = getattr(ref, rk).numpy()[e, :n], ours[ok][e, :n]
+            if cols is not None:
+                a, b = a[..., :cols], b[..., :cols]
+            if not np.allclose(a.astype(np.float64), b.astype(np.float64), rtol=0, atol=1e-6):
+                bad.append(f"env {e} {rk}: max |diff| {np.abs(a.astype(np.float64) - b).max():.3e}")
+    print(f"{label}: {'ok' if not bad else 'DIFFERENT: ' + '; '.join(bad)}  (cuboids per environment {ref.count.tolist()})", flush=True)
+    return not bad
+
+
+if __name__ == "__main__":
+    d = os.path.join(R.REF, "curobo", "content", "configs", "scene")
+    ok = True
+    for f in sorted(os.listdir(d)):
+        ok &= compare(f, [yaml.safe_load(open(os.path.join(d, f)))])
+    rng = np.random.default_rng(4)
+
+    def world(n):
+        out = {}
+        for i in range(n):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            out[f"box{i}"] = {"dims": [float(v) for v in rng.uniform(0.05, 1.0, 3)], "pose": [float(v) for v in rng.uniform(-1, 1, 3)] + [float(v) for v in q]}
+        return {"cuboid": out}
+
+    ok &= compare("random rotated cuboids, two environments (5 and 3)", [world(5), world(3)])
+    sys.exit(0 if ok else 1)

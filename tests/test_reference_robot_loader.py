@@ -54,3 +54,15 @@ def test_inertial_frame_and_cspace_limits_follow_the_reference():
     np.testing.assert_allclose(ur.link_masses_com[i], [-0.131, 0.0, 0.481, 12.93], atol=1e-6)
     # shoulder_pan: +-2 pi in the URDF, clipped by cspace.position_limit_clip = 0.1
     np.testing.assert_allclose(ur.joint_limits_position[:, 0], [-2 * np.pi + 0.1, 2 * np.pi - 0.1], atol=1e-6)
+
+
+@needs_reference
+def test_cuboid_store_of_a_scene_description_is_the_reference_cuboid_data():
+    """scene yaml / dictionary -> dims, inverse poses, enable flags, counts: the reference's ``SceneCfg.create`` +
+    ``CuboidData.from_scene_cfg`` / ``from_batch_scene_cfg`` run on the CPU, on its four scene files and on random rotated cuboids
+    in two environments"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_scene_config.py")], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert sum(": ok" in l for l in out.stdout.splitlines()) == 5, text[-3000:]
