@@ -53,6 +53,16 @@ def compare(name):
                 bad.append(f"{f}: max |diff| {np.abs(a.astype(np.float64) - b).max():.3e}")
         elif not np.array_equal(a.astype(np.int64), b.astype(np.int64)):
             bad.append(f"{f}: differs")
+    # the tree levels the RNEA kernels walk (kinematics_params.py:250-290), derived from the link map on both sides
+    import torch
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+
+    kp = KinematicsParams.from_model(m, torch.device("cpu"))
+    for f in ("link_level_data", "link_level_offsets"):
+        if not np.array_equal(npy(getattr(kc, f)).astype(np.int64), npy(getattr(kp, f)).astype(np.int64)):
+            bad.append(f"{f}: differs")
+    if int(kc.max_level_width) != int(kp.max_level_width) or int(kc.n_tree_levels) != int(kp.n_tree_levels):
+        bad.append("tree level width / count differs")
     jl = kc.joint_limits
     for f, a, b in (("position limits", npy(jl.position), m.joint_limits_position), ("velocity limits", npy(jl.velocity), m.joint_limits_velocity)):
         if not np.allclose(a, b, rtol=0, atol=1e-6):

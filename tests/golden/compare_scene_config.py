@@ -58,4 +58,38 @@ if __name__ == "__main__":
         return {"cuboid": out}
 
     ok &= compare("random rotated cuboids, two environments (5 and 3)", [world(5), world(3)])
+
+    # ---- voxel grids (fp16 ESDF): VoxelData.from_scene_cfg (geom/data/data_voxel.py:283-470) against voxel_arrays_from_config
+    import torch
+    from curobo._src.geom.data.data_voxel import VoxelData
+    from curobo._src.geom.types import VoxelGrid
+
+    from curobo_amd.scene.config import voxel_arrays_from_config
+
+    def grid(name, dims, vs):
+        n = [int(round(d / vs)) for d in dims]
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        f = rng.uniform(-0.2, 0.5, size=int(np.prod(n))).astype(np.float16)
+        return name, dict(dims=list(dims), voxel_size=vs, pose=[float(v) for v in rng.uniform(-1, 1, 3)] + [float(v) for v in q], feature_tensor=torch.as_tensor(f))
+
+    cfg = {"voxel": dict([grid("a", (0.5, 0.4, 0.3), 0.02), grid("b", (0.3, 0.3, 0.6), 0.05)])}
+    grids = [VoxelGrid(name=k, pose=v["pose"], dims=v["dims"], voxel_size=v["voxel_size"], feature_tensor=v["feature_tensor"].clone().view(-1, 1),
+                       feature_dtype=torch.float16) for k, v in cfg["voxel"].items()]
+    ref = VoxelData.from_scene_cfg(SceneCfg(voxel=grids), DeviceCfg(device="cpu"))
+    ours = voxel_arrays_from_config(cfg)
+    bad = []
+    # (the reference stores dims / voxel_size as computed in fp32, e.g. 15.000001 cells; its kernels truncate it to an integer)
+    if not np.array_equal(np.round(ref.params.numpy()[..., :3]), ours["voxel_params"][..., :3]) or not np.allclose(ref.params.numpy()[..., 3], ours["voxel_params"][..., 3]):
+        bad.append("params")
+    if not np.allclose(ref.inv_pose.numpy()[..., :7], ours["voxel_inv_pose"][..., :7], rtol=0, atol=1e-6):
+        bad.append("inv_pose")
+    if ref.enable.numpy().tolist() != ours["voxel_enable"].tolist() or ref.count.numpy().tolist() != ours["voxel_count"].tolist():
+        bad.append("enable / count")
+    for g, v in enumerate(cfg["voxel"].values()):
+        n = v["feature_tensor"].numel()
+        if not np.array_equal(ref.features.numpy()[0, g, :n, 0], ours["voxel_features"][0, g, :n]):
+            bad.append(f"features of grid {g}")
+    print(f"two voxel grids (25 x 20 x 15 at 2 cm, 6 x 6 x 12 at 5 cm, rotated): {'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)}", flush=True)
+    ok &= not bad
     sys.exit(0 if ok else 1)

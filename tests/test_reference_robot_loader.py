@@ -60,9 +60,9 @@ def test_inertial_frame_and_cspace_limits_follow_the_reference():
 def test_cuboid_store_of_a_scene_description_is_the_reference_cuboid_data():
     """scene yaml / dictionary -> dims, inverse poses, enable flags, counts: the reference's ``SceneCfg.create`` +
     ``CuboidData.from_scene_cfg`` / ``from_batch_scene_cfg`` run on the CPU, on its four scene files and on random rotated cuboids
-    in two environments"""
+    in two environments; and two rotated fp16 voxel grids against its ``VoxelData.from_scene_cfg``"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_scene_config.py")], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
-    assert sum(": ok" in l for l in out.stdout.splitlines()) == 5, text[-3000:]
+    assert sum(": ok" in l for l in out.stdout.splitlines()) == 6, text[-3000:]
