@@ -501,6 +501,15 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
     if "joint_names" in cspace and "default_joint_position" in cspace:
         lut = dict(zip(cspace["joint_names"], cspace["default_joint_position"]))
         cspace["default_joint_position"] = [float(lut.get(n, 0.0)) for n in joint_names]
+    # acceleration / jerk limits per ACTIVE joint (reference: JointLimits.acceleration / .jerk = -+ CSpaceParams.max_acceleration /
+    # max_jerk after inplace_reindex, kinematics_loader.py:1102-1112; scalars are broadcast, cspace_params.py:45-50, 84-110)
+    for key, default in (("max_acceleration", 10.0), ("max_jerk", 500.0)):
+        v = cspace.get(key, default)
+        if isinstance(v, (int, float)) or len(v) == 1:
+            cspace[key] = [float(v if isinstance(v, (int, float)) else v[0])] * D
+        else:
+            lut = dict(zip(cspace["joint_names"], v))
+            cspace[key] = [float(lut[n]) for n in joint_names]
 
     return RobotModel(
         fixed_transforms=fixed.astype(np.float32),

@@ -69,6 +69,9 @@ def compare(name):
             bad.append(f"{f}: max |diff| {np.abs(a - b).max():.3e}")
     if getattr(jl, "effort", None) is not None and not np.allclose(npy(jl.effort)[1], m.joint_limits_effort, rtol=0, atol=1e-6):
         bad.append(f"effort limits: max |diff| {np.abs(npy(jl.effort)[1] - m.joint_limits_effort).max():.3e}")
+    for f, key in (("acceleration", "max_acceleration"), ("jerk", "max_jerk")):
+        if not np.allclose(npy(getattr(jl, f))[1], np.asarray(m.cspace[key], np.float32), rtol=0, atol=1e-6):
+            bad.append(f"{f} limits (cspace {key}, per active joint) differ")
     dq = kc.cspace.default_joint_position
     if dq is not None and m.cspace.get("default_joint_position") is not None:
         if not np.allclose(npy(dq), np.asarray(m.cspace["default_joint_position"], np.float32), rtol=0, atol=1e-6):
