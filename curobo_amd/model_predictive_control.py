@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from .kinematics import Kinematics, KinematicsCfg, KinematicsState
-from .motion_planner import _load_kinematics
+from .motion_planner import _load_kinematics, apply_robot_limits
 from .scene import SceneData
 from .scene.config import scene_from_config
 from .solver.mpc import MPCSolver, MPCSolverCfg, MPCSolverResult
@@ -61,6 +61,7 @@ class ModelPredictiveControlCfg:
         if cold_start_optimization_num_iters is not None:
             s.cold_start_optimization_num_iters = int(cold_start_optimization_num_iters)
         s.rollout.scene_activation_distance = optimizer_collision_activation_distance
+        apply_robot_limits(s.rollout, kin)
         if not self_collision_check:
             s.rollout.self_collision_weight = 0.0
         return ModelPredictiveControlCfg(kinematics=kin, scene=scene_from_config(scene_model, device_cfg.device), device_cfg=device_cfg,

@@ -28,6 +28,7 @@ import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Union
 
+import numpy as np
 import torch
 
 from .kinematics import Kinematics, KinematicsCfg, KinematicsState
@@ -137,6 +138,28 @@ def _axis_offset_pose(axis: str, offset: float) -> Pose:
     return Pose.from_list([offset * (axis == a) for a in ("x", "y", "z")] + [1.0, 0.0, 0.0, 0.0])
 
 
+def robot_acceleration_jerk_limits(kinematics: Optional[KinematicsCfg]):
+    """(max_acceleration, max_jerk) of the robot file's cspace block (reference: JointLimits.acceleration / .jerk, which its
+    rollouts bound the trajectory by, kinematics_loader.py:1102-1112) -- when every active joint carries the same value, which
+    is what a rollout configuration holds (one scalar per limit); ``None`` for a limit that differs between joints (the G1)
+    or that the model does not carry: the configuration's default stays."""
+    cs = getattr(getattr(kinematics, "model", None), "cspace", None) or {}
+    out = []
+    for key in ("max_acceleration", "max_jerk"):
+        v = cs.get(key)
+        v = [] if v is None else [float(x) for x in np.atleast_1d(np.asarray(v, np.float64))]
+        out.append(v[0] if v and all(abs(x - v[0]) <= 1e-9 * max(1.0, abs(v[0])) for x in v) else None)
+    return tuple(out)
+
+
+def apply_robot_limits(rollout_cfg, kinematics: Optional[KinematicsCfg]) -> None:
+    acc, jerk = robot_acceleration_jerk_limits(kinematics)
+    if acc is not None:
+        rollout_cfg.max_acceleration = acc
+    if jerk is not None:
+        rollout_cfg.max_jerk = jerk
+
+
 @dataclass
 class TrajectoryOptimizerCfg:
     kinematics: KinematicsCfg = None
@@ -194,6 +217,7 @@ class TrajectoryOptimizerCfg:
                              maximum_trajectory_dt=self.maximum_trajectory_dt, num_goalset=self.max_goalset)
         c.rollout.n_knots, c.rollout.interpolation_steps = self.n_knots, self.interpolation_steps
         c.rollout.scene_activation_distance = self.optimizer_collision_activation_distance
+        apply_robot_limits(c.rollout, self.kinematics)  # (the UR10e file: 12 rad/s^2, not the Franka's 15)
         if not self.self_collision_check:
             c.rollout.self_collision_weight = 0.0
         c.ik = IKSolverCfg(num_seeds=self.num_ik_seeds, position_threshold=self.position_tolerance,

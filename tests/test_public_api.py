@@ -348,3 +348,28 @@ def test_kinematics_accessors_and_result_helpers():
         for n in names:
             assert hasattr(cls, n), (cls.__name__, n)
     assert hasattr(ModelPredictiveControlCfg, "create")
+
+
+def test_solver_configurations_take_the_robot_files_acceleration_and_jerk_limits():
+    """the trajectory optimiser and MPC front ends bound acceleration / jerk by the robot file's cspace values (reference:
+    JointLimits.acceleration / .jerk from CSpaceParams) when they are one value for all joints: UR10e 12 / 500, Franka 15 / 500;
+    the G1's per-joint lists do not fit the rollouts' scalar and leave the configuration's default"""
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.model_predictive_control import ModelPredictiveControlCfg
+    from curobo_amd.motion_planner import TrajectoryOptimizerCfg, robot_acceleration_jerk_limits
+    from curobo_amd.rollout.trajopt_rollout import TrajOptRolloutCfg
+
+    ur, fr, g1 = (KinematicsCfg.from_packaged(n, device="cpu") for n in ("ur10e", "franka", "unitree_g1"))
+    assert robot_acceleration_jerk_limits(ur) == (12.0, 500.0)
+    assert robot_acceleration_jerk_limits(fr) == (15.0, 500.0)
+    assert robot_acceleration_jerk_limits(None) == (None, None)
+    acc, jerk = robot_acceleration_jerk_limits(g1)
+    assert acc is None or isinstance(acc, float)
+    c = TrajectoryOptimizerCfg(kinematics=ur).solver_cfg()
+    assert (c.rollout.max_acceleration, c.rollout.max_jerk) == (12.0, 500.0)
+    c = TrajectoryOptimizerCfg(kinematics=fr).solver_cfg()
+    assert (c.rollout.max_acceleration, c.rollout.max_jerk) == (15.0, 500.0) == (TrajOptRolloutCfg().max_acceleration, TrajOptRolloutCfg().max_jerk)
+    from curobo_amd.types import DeviceCfg
+
+    m = ModelPredictiveControlCfg.create(ur, device_cfg=DeviceCfg(device="cpu"))
+    assert (m.solver.rollout.max_acceleration, m.solver.rollout.max_jerk) == (12.0, 500.0)
