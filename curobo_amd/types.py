@@ -266,3 +266,8 @@ class ToolPoseCriteria:
         free = [1.0 if axis == a else 0.0 for a in ("x", "y", "z")]
         return ToolPoseCriteria([1.0] * 6, [non_terminal_scale * (1.0 - f) for f in free] + [non_terminal_scale] * 3,
                                 project_distance_to_goal=project_distance_to_goal)
+
+    @staticmethod
+    def disabled() -> "ToolPoseCriteria":
+        """no pose cost on this tool frame (it stays part of the solver's frames): every factor zero (reference :201-215)"""
+        return ToolPoseCriteria([0.0] * 6, [0.0] * 6)

@@ -66,3 +66,12 @@ def test_cuboid_store_of_a_scene_description_is_the_reference_cuboid_data():
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
     assert sum(": ok" in l for l in out.stdout.splitlines()) == 6, text[-3000:]
+
+
+@needs_reference
+def test_tool_pose_criteria_factories_are_the_references():
+    """``ToolPoseCriteria.track_position / track_orientation / track_position_and_orientation / linear_motion / disabled``: axis
+    factors, tolerances and the projection flag against the reference's class (cost/tool_pose_criteria.py) run on the CPU"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_tool_pose_criteria.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "factory calls: ok" in out.stdout, (out.stdout + out.stderr)[-2000:]
