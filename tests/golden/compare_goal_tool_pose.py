@@ -1,0 +1,41 @@
+"""``GoalToolPose.from_poses`` (dictionary of per-frame poses -> the [batch, horizon, frames, goal set, 3 | 4] goal tensors the pose
+cost reads) against the reference's (types/tool_pose.py) on the CPU: frame order, goal-set layout, padding.
+
+    python tests/golden/compare_goal_tool_pose.py        (needs /root/reference)"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reference_robot_loader as R  # noqa: E402,F401
+import torch  # noqa: E402
+from curobo._src.types.pose import Pose as RefPose  # noqa: E402
+from curobo._src.types.tool_pose import GoalToolPose as Ref  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from curobo_amd.types import GoalToolPose as Ours  # noqa: E402
+from curobo_amd.types import Pose as OurPose  # noqa: E402
+
+rng = np.random.default_rng(8)
+ok = True
+for label, b, g, frames, order in (("one frame, batch 3", 3, 1, ["tool0"], ["tool0"]), ("two frames, given in the other order", 2, 1, ["tool1", "tool0"], ["tool0", "tool1"]),
+                                   ("goal set of 4, batch 2", 2, 4, ["hand"], ["hand"]), ("goal set of 3, two frames", 1, 3, ["a", "b"], ["b", "a"])):
+    data = {}
+    for f in frames:
+        p = rng.uniform(-1, 1, (b * g, 3)).astype(np.float32)
+        q = rng.normal(size=(b * g, 4)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        data[f] = (p, q)  # [batch * goal set, 3 | 4], goal-set members of a problem adjacent
+    try:
+        r = Ref.from_poses({f: RefPose(position=torch.as_tensor(p), quaternion=torch.as_tensor(q)) for f, (p, q) in data.items()}, ordered_tool_frames=order, num_goalset=g)
+        o = Ours.from_poses({f: OurPose(position=torch.as_tensor(p), quaternion=torch.as_tensor(q)) for f, (p, q) in data.items()}, ordered_tool_frames=order, num_goalset=g)
+        same = tuple(r.position.shape) == tuple(o.position.shape) and np.array_equal(r.position.numpy(), o.position.numpy()) and np.array_equal(r.quaternion.numpy(), o.quaternion.numpy()) \
+            and list(r.tool_frames) == list(o.tool_frames)
+        print(f"{label}: {'ok' if same else 'DIFFERENT'}  shape {tuple(r.position.shape)} / {tuple(o.position.shape)}  frames {list(r.tool_frames)} / {list(o.tool_frames)}")
+        ok &= same
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print(f"{label}: ERROR {type(e).__name__}: {str(e)[:300]}")
+sys.exit(0 if ok else 1)
