@@ -84,6 +84,14 @@ class KinematicsCfg:
         return KinematicsCfg(KinematicsParams.from_model(model, torch.device(device)), model)
 
     @staticmethod
+    def from_xrdf(xrdf_path: str, urdf_path: str, tool_frames: Optional[list] = None, device="cuda:0", num_envs: int = 1) -> "KinematicsCfg":
+        """an XRDF file next to its URDF (reference KinematicsCfg.from_robot_yaml_file with ``urdf_path`` for ``*.xrdf``,
+        robot/kinematics/kinematics_cfg.py:120-160 -> util/xrdf_util.py convert_xrdf_to_curobo)"""
+        from .robot.xrdf import convert_xrdf_to_config
+
+        return KinematicsCfg.from_data_dict(convert_xrdf_to_config(xrdf_path, urdf_path), tool_frames=tool_frames, device=device, num_envs=num_envs)
+
+    @staticmethod
     def from_basic_urdf(urdf_path: str, base_link: str, tool_frames: list, device="cuda:0") -> "KinematicsCfg":
         """reference KinematicsCfg.from_basic_urdf (:68-88): kinematics only (no collision spheres)."""
         return KinematicsCfg.from_data_dict({"urdf_path": urdf_path, "base_link": base_link, "tool_frames": list(tool_frames)},

@@ -90,6 +90,14 @@ def reference_kinematics(robot_yaml: str):
     return loader.kinematics_config, loader.self_collision_config
 
 
+def reference_kinematics_from_dict(kinematics_dict: dict):
+    """the same from the ``kinematics`` section of a robot configuration given as a dictionary"""
+    import copy
+
+    loader = CpuKinematicsLoader(KinematicsLoaderCfg(**copy.deepcopy(kinematics_dict), device_cfg=_DC.DeviceCfg(device="cpu")))
+    return loader.kinematics_config, loader.self_collision_config
+
+
 if __name__ == "__main__":
     kc, sc = reference_kinematics(os.path.join(REF, "curobo", "content", "configs", "robot", f"{sys.argv[1]}.yml"))
     print(kc.fixed_transforms.shape, kc.joint_names, kc.tool_frames)

@@ -86,6 +86,8 @@ class URDF:
         self.joint_map: Dict[str, Joint] = {j.name: j for j in joints}
         self.joint_names: List[str] = [j.name for j in joints]
         self.actuated_joint_names: List[str] = [j.name for j in joints if j.type != "fixed" and j.mimic is None]
+        children = {j.child for j in joints}
+        self.base_link: Optional[str] = next((l.name for l in links if l.name not in children), None)  # root of the tree
 
     @staticmethod
     def load(fname_or_file, load_meshes=False, build_scene_graph=False, filename_handler=None, **kwargs) -> "URDF":

@@ -90,3 +90,14 @@ def test_goal_tool_pose_from_poses_is_the_references():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_goal_tool_pose.py")], capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
     assert out.returncode == 0 and out.stdout.count(": ok") == 4, (out.stdout + out.stderr)[-2000:]
+
+
+@needs_reference
+def test_xrdf_conversion_is_the_references():
+    """``*.xrdf`` robot descriptions: the configuration dictionary against the reference's ``convert_xrdf_to_curobo`` (its ur10e.xrdf
+    as shipped, with an added frame, with a joint left out of the cspace) and the model built from it against its loader"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libcurobo_ref.so")):
+        pytest.skip("oracle/_ref is not built (python __graft_entry__.py)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_xrdf.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.count(": ok") == 4, (out.stdout + out.stderr)[-2000:]
