@@ -475,7 +475,22 @@ ORC_API void orc_self_collision(float *out_distance, float *out_gradient, float 
  *   Obstacle sums are accumulated in obstacle-index order (the reference uses float atomics
  *   whose order is undefined), cuboids first then voxel grids.
  * ---------------------------------------------------------------------------------------- */
-typedef struct { float p[3]; float q[4]; /* xyzw */ } orc_tf;
+typedef struct { float p[3]; float q[4]; /* xyzw */ float m[3][4]; /* mode 1 only: rows of [R | p] */ } orc_tf;
+
+/* Arithmetic of the world -> obstacle-frame transform of the sphere centres.
+ *   0 (default): the reference's -- Warp's quat_rotate + translation, as restated above.
+ *   1: the rotation-matrix form of the HIP path (curobo_amd/csrc/scene_device.hpp::load_rec_global + to_local: nine
+ *      entries from explicit fused multiply-adds, then a nest of three per coordinate).  Both round the same exact
+ *      transform; they differ in the last bit of a local coordinate.  The ONLY place of the algorithm where that bit is
+ *      a decision is the sweep's `jump >= half_dist` at jump = 0 (wp_sweep_collision_kernel.py:186-203): a sphere whose
+ *      world positions at h and h +- 1 differ by an ulp coincides with its neighbour in one arithmetic's obstacle frame
+ *      and not in the other's, and then gets one more copy of its centre sample.  Mode 1 lets a test feed the oracle
+ *      the device's own spheres and compare EVERY trajectory tightly; mode 0 against mode 1 on the same spheres isolates
+ *      exactly those resting spheres (tests/test_oracle_collision.py).  Gradients go back to the world frame with the
+ *      reference's quaternion form in both modes. */
+static int orc_frame_arithmetic = 0;
+ORC_API void orc_set_frame_arithmetic(int mode) { orc_frame_arithmetic = mode; }
+ORC_API int orc_get_frame_arithmetic(void) { return orc_frame_arithmetic; }
 
 static void orc_quat_rotate(const float *q, const float *v, float *o) {
   const float x = q[0], y = q[1], z = q[2], w = q[3];
@@ -491,9 +506,24 @@ static void orc_load_inv_tf(const float *inv_pose8, orc_tf *t) {
   /* helper_pose.py:28-90: [x y z qw qx qy qz pad] -> wp.transform(pos, quat(x,y,z,w)) */
   t->p[0] = inv_pose8[0]; t->p[1] = inv_pose8[1]; t->p[2] = inv_pose8[2];
   t->q[0] = inv_pose8[4]; t->q[1] = inv_pose8[5]; t->q[2] = inv_pose8[6]; t->q[3] = inv_pose8[3];
+  if (orc_frame_arithmetic == 1) {
+    const float x = t->q[0], y = t->q[1], z = t->q[2], w = t->q[3];
+    const float x2 = 2.0f * x, y2 = 2.0f * y, w2 = 2.0f * w;
+    const float k = __builtin_fmaf(w2, w, -1.0f);
+    const float wz = w2 * z, wy = w2 * y, wx = w2 * x;
+    t->m[0][0] = __builtin_fmaf(x2, x, k);   t->m[0][1] = __builtin_fmaf(x2, y, -wz); t->m[0][2] = __builtin_fmaf(x2, z, wy);
+    t->m[1][0] = __builtin_fmaf(x2, y, wz);  t->m[1][1] = __builtin_fmaf(y2, y, k);   t->m[1][2] = __builtin_fmaf(y2, z, -wx);
+    t->m[2][0] = __builtin_fmaf(x2, z, -wy); t->m[2][1] = __builtin_fmaf(y2, z, wx);  t->m[2][2] = __builtin_fmaf(2.0f * z, z, k);
+    t->m[0][3] = t->p[0]; t->m[1][3] = t->p[1]; t->m[2][3] = t->p[2];
+  }
 }
 
 static void orc_tf_point(const orc_tf *t, const float *v, float *o) {
+  if (orc_frame_arithmetic == 1) {
+    for (int r = 0; r < 3; r++)
+      o[r] = __builtin_fmaf(t->m[r][0], v[0], __builtin_fmaf(t->m[r][1], v[1], __builtin_fmaf(t->m[r][2], v[2], t->m[r][3])));
+    return;
+  }
   orc_quat_rotate(t->q, v, o);
   o[0] += t->p[0]; o[1] += t->p[1]; o[2] += t->p[2];
 }

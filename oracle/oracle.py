@@ -121,6 +121,7 @@ class Oracle:
     def __init__(self, path: Optional[str] = None):
         self.lib = C.CDLL(path or build_oracle())
         self.lib.orc_num_threads.restype = C.c_int
+        self.lib.orc_get_frame_arithmetic.restype = C.c_int
         for name in (
             "orc_kinematics_forward",
             "orc_kinematics_backward",
@@ -142,6 +143,7 @@ class Oracle:
             "orc_cspace_position_cost",
             "orc_cspace_state_cost",
             "orc_set_num_threads",
+            "orc_set_frame_arithmetic",
         ):
             getattr(self.lib, name).restype = None
 
@@ -151,6 +153,14 @@ class Oracle:
 
     def set_num_threads(self, n: int) -> None:
         self.lib.orc_set_num_threads(C.c_int(n))
+
+    def set_frame_arithmetic(self, mode: str) -> None:
+        """"reference" (Warp's quat_rotate, the default) or "device" (the rotation-matrix fma form of the HIP path) for the
+        world -> obstacle-frame transform of the scene-collision stage; see orc_set_frame_arithmetic in curobo_oracle.c."""
+        self.lib.orc_set_frame_arithmetic(C.c_int({"reference": 0, "device": 1}[mode]))
+
+    def frame_arithmetic(self) -> str:
+        return ("reference", "device")[int(self.lib.orc_get_frame_arithmetic())]
 
     # ------------------------------------------------------------------ FK
     def kinematics_forward(

@@ -157,7 +157,11 @@ def test_c3_ur10e_voxel_world_collision_checking_path(oracle, device):
     ref_w = oracle.scene_collision(sph, arrays, 1.0, 0.02)
     ref_s = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)
     assert (ref_w["distance"] > 0).mean() > 0.02, "the synthetic world must produce hits"
-    np.testing.assert_allclose(d_world.cpu().numpy(), ref_w["distance"], rtol=2e-4, atol=2e-5)
+    # (FK on the device vs FK of the oracle: the spheres differ by ~1e-6 m, the cost of the quadratic zone by that much;
+    # on IDENTICAL spheres the kernel is held to 1e-5 + 5e-6 m in test_gpu_kernels.py::test_scene_collision_voxels)
+    err = np.abs(d_world.cpu().numpy() - ref_w["distance"]) / (1e-5 * np.abs(ref_w["distance"]) + 1e-5)
+    print(f"\n[c3 checker] worst scene cost error {float(err.max()):.3f} of (1e-5 rel + 1e-5 m); FK-to-FK sphere difference included")
+    np.testing.assert_allclose(d_world.cpu().numpy(), ref_w["distance"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(d_self.cpu().numpy().reshape(-1), ref_s["distance"], rtol=1e-5, atol=1e-6)
     # bit-exact collision-hit indices (north_star): which spheres are in collision
     assert np.array_equal(d_world.cpu().numpy() > 0, ref_w["distance"] > 0)

@@ -6,9 +6,10 @@
   instantiation of the fused launch and ``scene_collision_packed_kernel`` of the kernel sequence.
 
 Protocol of ``test_gpu_fused.py::test_fused_swept_matches_oracle_at_c2_size`` part (1): the oracle's collision stages run
-on the spheres the launch itself materialises (identical inputs -> identical sweep branches), its VJP on FK of the
-launch's own joint positions; cost 1e-5, gradient 5e-4.  Trajectories that hold a sphere which is stationary up to
-rounding AND in collision are only held to the 3x band (the reference algorithm's own discontinuity).
+on the spheres the launch itself materialises, WITH THE DEVICE'S ARITHMETIC for the world -> obstacle-frame transform
+(``sweep_allowance.device_frame_arithmetic``), so that the sweep's `half_dist > 0` decision of a sphere that is stationary up
+to rounding is the device's: EVERY trajectory is held to cost 1e-5 / gradient 5e-4.  The per-sphere tests hold the kernels
+to the oracle in the REFERENCE's arithmetic with the whole-centre-term allowance per stationary sphere.
 """
 
 import numpy as np
@@ -20,13 +21,7 @@ from conftest import load_model
 pytestmark = pytest.mark.gpu
 
 
-def _rest_in_collision(spheres, scene_cost):
-    p = spheres[..., :3]
-    stepn = np.linalg.norm(np.diff(p, axis=1), axis=-1)
-    still = np.zeros(p.shape[:3], bool)
-    still[:, 1:] |= stepn < 1e-5
-    still[:, :-1] |= stepn < 1e-5
-    return (still & (scene_cost > 0)).any(axis=(1, 2))
+from sweep_allowance import device_frame_arithmetic, per_sphere_allowance, rest_in_collision as _rest_in_collision  # noqa: E402
 
 
 def _candidates(model, seeds, nls, n_knots, seed):
@@ -40,12 +35,10 @@ def _candidates(model, seeds, nls, n_knots, seed):
     return np.stack([base + a * step for a in alphas], axis=1).reshape(seeds * nls, n_knots, -1)
 
 
-def _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_idx, cost, grad, axis_aligned_world=False):
+def _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_idx, cost, grad, tag="fused"):
     """cost [B], grad [B, nk, D] of a fused launch (``fused_materialize``) vs the oracle's stages on the launch's own
-    spheres / joint positions.  Returns the mask of trajectories compared tightly.  ``axis_aligned_world``: every
-    obstacle frame is a pure translation of the world frame, so the transform into it is exact, two sphere positions
-    coincide there iff they coincide in the world, and the stationary-sphere discontinuity cannot split the two
-    implementations: every trajectory is compared tightly."""
+    spheres / joint positions, the oracle's obstacle-frame transform in the device's arithmetic: EVERY trajectory at
+    cost 1e-5 / gradient 5e-4, the ones with spheres that rest in collision too.  Returns (resting mask, self, scene)."""
     cfg = ro.cfg
     B, nk, D = knots.shape
     md, ph, S = model.as_dict(), cfg.padded_horizon, model.num_spheres
@@ -53,17 +46,18 @@ def _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_i
     pos = ro.position.cpu().numpy()
     multi = env_idx is not None
     sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, cfg.self_collision_weight)
-    wc = oracle.scene_collision(sph, arrays, cfg.scene_collision_weight, cfg.activation_distance, sweep=True,
-                                enable_speed_metric=True, speed_dt=cfg.traj_dt, env_query_idx=env_idx, use_multi_env=multi)
+    with device_frame_arithmetic(oracle):
+        wc = oracle.scene_collision(sph, arrays, cfg.scene_collision_weight, cfg.activation_distance, sweep=True,
+                                    enable_speed_metric=True, speed_dt=cfg.traj_dt, env_query_idx=env_idx, use_multi_env=multi)
     ref_cost = oracle.trajectory_cost_sum(sc["distance"].reshape(B, ph), wc["distance"])
     w = cfg.scene_collision_weight
     amb = _rest_in_collision(sph, wc["distance"])
-    if axis_aligned_world:
-        amb[:] = False
-    assert amb.mean() < 0.6, f"{amb.sum()} of {B} trajectories rest inside an obstacle"
-    np.testing.assert_allclose(cost[~amb], ref_cost[~amb], rtol=1e-5, atol=1e-7 * w)
-    band = (cost[amb] <= 3.001 * ref_cost[amb] + 1e-3 * w) & (ref_cost[amb] <= 3.001 * cost[amb] + 1e-3 * w)
-    assert band.all()
+    err = np.abs(cost - ref_cost) / (1e-5 * np.abs(ref_cost) + 1e-7 * w)
+    msg = (f"[{tag}] {int(amb.sum())} of {B} trajectories ({amb.mean():.3f}) hold a sphere that rests in collision; worst cost error "
+           f"{float(err.max()):.3f} of the bound (resting: {float(err[amb].max()) if amb.any() else 0.0:.3f}, "
+           f"moving: {float(err[~amb].max()) if (~amb).any() else 0.0:.3f}); beyond the bound: {int((err > 1).sum())}")
+    print("\n" + msg)
+    assert (err <= 1.0).all(), msg
     fk = oracle.kinematics_forward(pos.reshape(B * ph, D), md, horizon=ph)
     np.testing.assert_allclose(sph.reshape(B * ph, S, 4), fk["robot_spheres"], atol=1e-5)  # north_star: FK within 1e-5
     gs = sc["gradient"].reshape(B, ph, S, 4).copy()
@@ -72,8 +66,8 @@ def _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_i
     z = np.zeros((B, ph, D), np.float32)
     gk = oracle.bspline_backward(gq.reshape(B, ph, D), z, z, z, np.array([cfg.traj_dt], np.float32), np.zeros(B, np.int32),
                                  np.zeros(1, np.uint8), nk, cfg.bspline_degree)
-    np.testing.assert_allclose(grad[~amb], gk[~amb], rtol=5e-4, atol=5e-6 * np.abs(gk).max())
-    return ~amb, sc, wc
+    np.testing.assert_allclose(grad, gk, rtol=5e-4, atol=5e-6 * np.abs(gk).max(), err_msg=msg)
+    return amb, sc, wc
 
 
 def test_c5_bench_path_multi_env_cuboids_and_esdf_matches_oracle(oracle, device):
@@ -103,8 +97,8 @@ def test_c5_bench_path_multi_env_cuboids_and_esdf_matches_oracle(oracle, device)
     cost, grad = ro.cost_and_gradient(torch.as_tensor(knots, device=device).reshape(B, -1))
     torch.cuda.synchronize()
     cost, grad = cost.cpu().numpy(), grad.cpu().numpy().reshape(knots.shape)
-    tight, sc, wc = _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_idx, cost, grad)
-    assert tight.sum() >= 0.4 * B
+    resting, sc, wc = _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, env_idx, cost, grad, tag="c5 small")
+    assert resting.sum() >= 0.1 * B, "the case the device arithmetic exists for must be in the sample"
     # both obstacle kinds and both worlds take part: hits against the ESDF-only and the cuboid-only version of the worlds
     sph = ro.robot_spheres.cpu().numpy()
     only_vox = {k: v for k, v in arrays.items() if k.startswith("voxel")}
@@ -147,9 +141,8 @@ def test_c3_size_sweep_x_voxel_fused_and_packed_kernel_match_oracle(oracle, devi
     # (the benchmark's start configuration touches the ESDF's activation shell and a B-spline that starts from rest
     # repeats its first points: every trajectory holds stationary spheres in collision; the grid frame is a translation)
     assert np.allclose(arrays["voxel_inv_pose"][0, 0, 3:7], [1, 0, 0, 0])
-    tight, sc, wc = _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, None, cost, grad, axis_aligned_world=True)
-    assert tight.all() and (wc["distance"] > 0).sum() > 10000
-    assert _rest_in_collision(ro.robot_spheres.cpu().numpy(), wc["distance"]).all()
+    resting, sc, wc = _check_against_oracle_on_same_inputs(oracle, model, arrays, ro, knots, None, cost, grad, tag="c3")
+    assert resting.all() and (wc["distance"] > 0).sum() > 10000
     # (2) the kernel sequence's scene kernel on the SAME spheres, per sphere
     seq = CollisionRollout(kin, scene, B, CollisionRolloutCfg(use_fused=False))
     seq.update_start_state(start)
@@ -181,26 +174,6 @@ def test_c3_size_sweep_x_voxel_fused_and_packed_kernel_match_oracle(oracle, devi
     np.testing.assert_allclose(d.sum((1, 2)), wc["distance"].sum((1, 2)), rtol=1e-5, atol=1e-7 * w)
 
 
-def _per_obstacle_centre_terms(oracle, sph, arrays, w, eta, env_idx, speed_dt):
-    """Centre-sample cost / gradient of every sphere against every obstacle ALONE (sweep off, speed metric on: the map is
-    linear in (cost, gradient), so this is the term a duplicated centre sample adds): lists over the obstacles."""
-    out = []
-    n_c = arrays["cuboid_dims"].shape[1] if arrays.get("cuboid_dims") is not None else 0
-    n_v = arrays["voxel_params"].shape[1] if arrays.get("voxel_params") is not None else 0
-    for kind, n, key in (("cuboid", n_c, "cuboid_enable"), ("voxel", n_v, "voxel_enable")):
-        for o in range(n):
-            part = dict(arrays)
-            for k2 in ("cuboid_enable", "voxel_enable"):
-                if part.get(k2) is not None:
-                    part[k2] = np.zeros_like(arrays[k2])
-            part[key] = np.zeros_like(arrays[key])
-            part[key][:, o] = arrays[key][:, o]
-            r = oracle.scene_collision(sph, part, w, eta, sweep=False, enable_speed_metric=True, speed_dt=speed_dt,
-                                       env_query_idx=env_idx, use_multi_env=True)
-            out.append((r["distance"], r["gradient"][..., :3]))
-    return out
-
-
 @pytest.mark.parametrize("rotated", [False, True], ids=["bench_worlds", "rotated_cuboids"])
 def test_c5_bench_size_per_sphere_sweep_allowance(rotated, oracle, device):
     """C5 at the SIZE ``bench.py`` runs per GPU share (2 problems x 512 seeds x 4 candidates = 4096 trajectories x 65
@@ -216,8 +189,6 @@ def test_c5_bench_size_per_sphere_sweep_allowance(rotated, oracle, device):
     launches (axis-aligned obstacle frames: the transform into them is exact and no sphere needs the allowance --
     measured: 58 130 stationary colliding spheres, 0 whole-term corrections); ``rotated_cuboids`` turns the random cuboids
     so that the allowance is exercised at the same size."""
-    import itertools
-
     from curobo_amd.robot.kinematics_params import KinematicsParams
     from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
     from curobo_amd.scene import SceneData
@@ -256,68 +227,15 @@ def test_c5_bench_size_per_sphere_sweep_allowance(rotated, oracle, device):
                                 env_query_idx=env_idx, use_multi_env=True)
     sc = oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, cfg.self_collision_weight)
     d_ref, g_ref = wc["distance"], wc["gradient"][..., :3]
-    # stationary neighbours per sphere (world frame, up to rounding)
-    p = sph[..., :3]
-    stepn = np.linalg.norm(np.diff(p, axis=1), axis=-1)
-    n_still = np.zeros(p.shape[:3], np.int32)
-    n_still[:, 1:] += stepn < 1e-5
-    n_still[:, :-1] += stepn < 1e-5
-    amb = (n_still > 0) & ((d > 0) | (d_ref > 0))
-    frac_amb = float(amb.mean())
-    in_col = (d_ref > 0)
-    assert in_col.sum() > 100000, "the workload must collide"
-    assert np.array_equal((d > 0) & ~amb, in_col & ~amb), "which moving spheres collide must be identical"
-    tight = ~amb
-    e_d = np.abs(d[tight] - d_ref[tight])
-    # per sphere: 1e-5 relative + 5e-6 m of penetration (measured: 1.05e-6 m at most -- up to seven fp32 trilinear ESDF
-    # samples of fp16 data per sphere; the C3 test's bound for the same kernel is 2e-5 m)
-    tol_d = 1e-5 * np.abs(d_ref[tight]) + 5e-6 * w
-    e_g = np.abs(g[tight] - g_ref[tight])
-    tol_g = 1e-3 * np.abs(g_ref[tight]) + 2e-4 * w
-    print(f"\n[c5 per sphere] {B} trajectories, {int(in_col.sum())} colliding spheres, ambiguous (stationary and in collision) "
-          f"{int(amb.sum())} = {frac_amb:.2e} of all spheres; tight spheres: max cost error {float((e_d / tol_d).max()):.3f} of the "
-          f"bound ({float(e_d.max() / w):.2e} m), gradient {float((e_g / tol_g).max()):.3f} of the bound")
+    in_col = d_ref > 0
     # The sweep has a second discontinuity of the same kind: it stops when the accumulated jump reaches the half segment
     # (`if jump >= half_dist: break`, wp_sweep_collision_kernel.py:197-203), so a sphere whose jump lands within rounding of
     # its half segment takes one sample more or less.  In an axis-aligned obstacle frame both implementations compute the
     # same bits; in a rotated one (R as a matrix here, the quaternion form in the oracle) about one colliding sphere in 1e5
     # is split.  Such spheres are counted, bounded, and their trajectories left out of the per-trajectory comparison.
-    split = np.zeros(d.shape, bool)
-    split[tight] = e_d > tol_d
-    n_split = int(split.sum())
     max_split = 0 if not rotated else max(3, int(2e-5 * in_col.sum()))
-    assert n_split <= max_split, (f"tight spheres: {n_split} beyond the bound (allowed {max_split}); ambiguous fraction {frac_amb:.2e}")
-    if n_split:
-        print(f"[c5 per sphere] moving spheres whose sweep took one sample more / less than the oracle's: {n_split} of {int(in_col.sum())} "
-              f"colliding (allowed {max_split}); largest difference {float(e_d.max() / w):.2e} m")
-    ok_g = ~(split[tight])
-    assert (e_g[ok_g] > tol_g[ok_g]).mean() < 1e-5 and (e_g[ok_g] <= 30 * tol_g[ok_g]).all(), \
-        (int((e_g[ok_g] > tol_g[ok_g]).sum()), float((e_g[ok_g] / tol_g[ok_g]).max()))
-    # ambiguous spheres: the difference is a combination of whole centre-sample terms, |k_o| <= number of stationary neighbours
-    corr = np.zeros_like(d_ref, dtype=np.float64)  # what the HIP branches add to the oracle's per-sphere cost
-    if amb.any():
-        terms = _per_obstacle_centre_terms(oracle, sph, arrays, w, eta, env_idx, cfg.traj_dt)
-        ia = np.nonzero(amb)
-        diff = (d[ia] - d_ref[ia]).astype(np.float64)
-        c1 = np.stack([t[0][ia] for t in terms], axis=1).astype(np.float64)  # [n_amb, n_obs]
-        nmax = n_still[ia]
-        best = np.full(diff.shape, np.inf)
-        best_k = np.zeros_like(c1)
-        # (fewest whole terms first: an obstacle the sphere does not touch has c1 = 0 and must not collect a k)
-        for ks in sorted(itertools.product(range(-2, 3), repeat=c1.shape[1]), key=lambda k: sum(abs(v) for v in k)):
-            kv = np.asarray(ks, np.float64)
-            ok = (np.abs(kv)[None, :] <= nmax[:, None]).all(1)
-            r = np.where(ok, np.abs(diff - c1 @ kv), np.inf)
-            better = r < best - 1e-12
-            best = np.where(better, r, best)
-            best_k[better] = kv
-        tol_a = 1e-5 * (np.abs(d_ref[ia]) + np.abs(c1).sum(1)) + 5e-6 * w
-        assert (best <= tol_a).all(), (f"{int((best > tol_a).sum())} of {amb.sum()} ambiguous spheres differ from the oracle by more than "
-                                      f"whole centre-sample terms (ambiguous fraction {frac_amb:.2e})")
-        corr[ia] = (c1 * best_k).sum(1)
-        print(f"[c5 per sphere] ambiguous spheres: {int(amb.sum())}, of which the HIP kernel and the oracle took different sweep "
-              f"branches (a non-zero whole-term correction): {int((np.abs(c1 * best_k).sum(1) > 0).sum())}; largest residual "
-              f"{float((best / tol_a).max()):.3f} of the bound")
+    res = per_sphere_allowance(oracle, d, g, d_ref, g_ref, sph, arrays, w, eta, env_idx, cfg.traj_dt, max_split, "c5", min_colliding=100000)
+    corr, split, frac_amb = res["corr"], res["split"], res["frac_amb"]
     # (2) the fused launch, per trajectory: oracle per-sphere costs + exactly the allowed corrections + self collision
     want = d_ref.astype(np.float64).sum((1, 2)) + corr.sum((1, 2)) + sc["distance"].reshape(B, -1).astype(np.float64).sum(1)
     # (the criterion of _check_against_oracle_on_same_inputs: 1e-5 relative + 1e-7 m of penetration; in the rotated worlds

@@ -192,3 +192,49 @@ def test_self_collision_gradient_matches_finite_differences(oracle, franka):
         fd = (oracle.self_collision(p1, franka.sphere_padding, franka.collision_pairs, 1.0)["distance"][0]
               - oracle.self_collision(p0, franka.sphere_padding, franka.collision_pairs, 1.0)["distance"][0]) / (2 * eps)
         assert fd == pytest.approx(r["gradient"][0, i, a], abs=2e-3)
+
+
+def test_device_frame_arithmetic_differs_from_the_reference_only_on_resting_spheres(oracle, franka):
+    """orc_set_frame_arithmetic(1) (the HIP path's rotation-matrix fma form of the world -> obstacle-frame transform) against
+    the reference's quat_rotate form on the same spheres, swept: per sphere the two costs agree to rounding EXCEPT where the
+    sphere is stationary up to rounding (its obstacle-frame distance to a neighbour point is zero in one arithmetic and an
+    ulp in the other -> one more or one fewer copy of its centre sample, wp_sweep_collision_kernel.py:186-203).  The
+    difference there is a whole number of centre-sample costs.  Rotated cuboids, so that the transform rounds at all."""
+    from curobo_amd.workloads import seed_knots, start_configuration
+    from oracle.rollout_ref import rollout_cost_and_gradient
+
+    rng = np.random.default_rng(3)
+    world = []
+    for p in ([0.45, 0.0, 0.25], [0.3, 0.4, 0.5], [0.2, -0.4, 0.4], [0.55, 0.2, 0.7]):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        world.append({"dims": [0.35, 0.3, 0.3], "pose": [*p, *[float(v) for v in q]]})
+    arr = cuboid_scene_arrays([world])
+    knots = seed_knots(franka, 96, 12, seed=2)  # the seeds come to rest at their last knot: stationary spheres
+    ref = rollout_cost_and_gradient(oracle, franka.as_dict(), arr, knots, start_configuration(franka))
+    sph = ref["robot_spheres"]
+    eta, w = 0.02, 1.0
+    assert oracle.frame_arithmetic() == "reference"
+    a = oracle.scene_collision(sph, arr, w, eta, sweep=True)["distance"]
+    centre = oracle.scene_collision(sph, arr, w, eta, sweep=False)["distance"]
+    oracle.set_frame_arithmetic("device")
+    try:
+        b = oracle.scene_collision(sph, arr, w, eta, sweep=True)["distance"]
+        centre_b = oracle.scene_collision(sph, arr, w, eta, sweep=False)["distance"]
+    finally:
+        oracle.set_frame_arithmetic("reference")
+    np.testing.assert_allclose(centre_b, centre, rtol=2e-5, atol=1e-7)  # no decision in the discrete kernel
+    p = sph[..., :3]
+    stepn = np.linalg.norm(np.diff(p, axis=1), axis=-1)
+    still = np.zeros(p.shape[:3], bool)
+    still[:, 1:] |= stepn < 1e-5
+    still[:, :-1] |= stepn < 1e-5
+    # (a last bit of a local coordinate is ~6e-8 m; in the quadratic region of the activation a cost of 5e-3 moves by 1e-4 of itself)
+    differs = np.abs(a - b) > 5e-4 * np.maximum(np.abs(a), np.abs(b)) + 1e-7
+    assert (a > 0).sum() > 1000 and (still & (a > 0)).sum() > 100
+    assert not (differs & ~still).any(), "moving spheres see the same sweep in both arithmetics"
+    # where they differ: a whole number (1 or 2) of centre samples.  One obstacle in reach per resting sphere here would make
+    # this exact; with several, the centre cost is their sum and each may flip on its own: allow 0 .. 2 x the centre cost.
+    d = np.abs(a - b)[differs]
+    assert (d <= 2.0 * centre[differs] * (1 + 1e-4) + 1e-6).all()
+    assert differs.sum() > 0, "the case this mode exists for must occur in the sample"
