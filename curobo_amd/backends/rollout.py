@@ -251,3 +251,19 @@ def rollout_trajopt_fused_lds_bytes(padded_horizon: int, dof: int, num_links: in
     return int(load().curobo_hip_rollout_trajopt_fused_lds_bytes(
         padded_horizon, dof, num_links, num_spheres, num_collision_pairs, link_chain_len, num_obstacles,
         int(with_cspace_terms)))
+
+
+def fused_shape_id(padded_horizon: int, n_knots: int, dof: int, num_links: int, num_spheres: int, num_collision_pairs: int,
+                   link_chain_len: int, self_lane_len: int, max_cuboids: int, max_voxel_grids: int, bspline_degree: int = 3,
+                   sweep_steps: int = 3, kinds: int = 1, with_trajopt_terms: bool = False) -> int:
+    """Which compile-time shape (csrc/fused_shapes.hpp) a fused trajectory launch with these dimensions runs; 0 = the generic
+    kernel.  Host-side query, no GPU work."""
+    return int(load().curobo_hip_rollout_fused_shape_id(
+        int(padded_horizon), int(n_knots), int(dof), int(num_links), int(num_spheres), int(num_collision_pairs), int(link_chain_len),
+        int(self_lane_len), int(max_cuboids), int(max_voxel_grids), int(bspline_degree), int(sweep_steps), int(kinds),
+        1 if with_trajopt_terms else 0))
+
+
+def set_fused_shapes_enabled(enabled: bool) -> None:
+    """False: every fused trajectory launch takes the generic kernel (same results; A/B timing and the bit-equality tests)."""
+    check(load().curobo_hip_rollout_fused_set_shapes_enabled(1 if enabled else 0))

@@ -24,7 +24,7 @@ OBJ_DIR = os.path.join(_PKG, "build")
 ARCH = "gfx950"
 
 HEADERS = ["common.hpp", "cost_device.hpp", "scene_device.hpp", "fk_device.hpp", "self_device.hpp",
-           "bspline_device.hpp", "dynamics_device.hpp", "mesh_device.hpp"]
+           "bspline_device.hpp", "dynamics_device.hpp", "mesh_device.hpp", "fused_shapes.hpp"]
 
 SOURCES = [
     "runtime.cpp",
@@ -35,6 +35,22 @@ SOURCES = [
     "optimization.hip",
     "cost.hip", "rollout_fused.hip", "dynamics.hip", "linalg.hip", "mppi.hip", "seed_ik.hip", "mesh_bake.hip", "mesh_bvh.hip",
 ]
+
+
+def fused_shape_ids() -> List[int]:
+    """Compile-time shapes of the fused rollout launch (csrc/fused_shapes.hpp: CUROBO_FUSED_NUM_SHAPES)."""
+    import re
+
+    m = re.search(r"#define\s+CUROBO_FUSED_NUM_SHAPES\s+(\d+)", open(os.path.join(CSRC, "fused_shapes.hpp")).read())
+    return list(range(1, int(m.group(1)) + 1)) if m else []
+
+
+def compile_units() -> List[tuple]:
+    """(source, object stem, extra flags): every source once, plus rollout_fused.hip once more per compile-time shape
+    (-DCUROBO_FUSED_SHAPE_TU=k holds only that shape's instantiations and its launcher: the shapes compile in parallel)."""
+    units = [(s, s.rsplit(".", 1)[0], []) for s in SOURCES]
+    units += [("rollout_fused.hip", f"rollout_fused_shape{k}", [f"-DCUROBO_FUSED_SHAPE_TU={k}"]) for k in fused_shape_ids()]
+    return units
 
 
 def hipcc_path() -> str:
@@ -71,12 +87,13 @@ def _deps(src: str) -> List[str]:
                                                           if os.path.exists(os.path.join(CSRC, h))]
 
 
-def _compile(src_name: str, force: bool) -> str:
+def _compile(unit, force: bool) -> str:
+    src_name, stem, extra = unit if isinstance(unit, tuple) else (unit, unit.rsplit(".", 1)[0], [])
     src = os.path.join(CSRC, src_name)
-    obj = os.path.join(OBJ_DIR, src_name.rsplit(".", 1)[0] + ".o")
+    obj = os.path.join(OBJ_DIR, stem + ".o")
     if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(src)):
         return obj
-    cmd = [hipcc_path(), *_flags(), *NO_SLP, *PER_SOURCE_FLAGS.get(src_name, []), "-x", "hip", "-c", src, "-o", obj]
+    cmd = [hipcc_path(), *_flags(), *NO_SLP, *PER_SOURCE_FLAGS.get(src_name, []), *extra, "-x", "hip", "-c", src, "-o", obj]
     subprocess.check_call(cmd)
     return obj
 
@@ -96,8 +113,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    units = compile_units()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(units))) as ex:
+        objs = list(ex.map(lambda u: _compile(u, force), units))
     tmp = LIB_PATH + ".tmp"
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:

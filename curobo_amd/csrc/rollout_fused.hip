@@ -36,10 +36,17 @@
 
 #include "bspline_device.hpp"
 #include "cost_device.hpp"
+#include "fused_shapes.hpp"
 #include "dynamics_device.hpp"
 #include "fk_device.hpp"
 #include "scene_device.hpp"
 #include "self_device.hpp"
+
+// 0: the main translation unit (generic kernels + the C ABI); k > 0: ONLY the instantiations of compile-time shape k and their
+// launcher (fused_shapes.hpp; curobo_amd/build.py compiles this file once per shape, in parallel)
+#ifndef CUROBO_FUSED_SHAPE_TU
+#define CUROBO_FUSED_SHAPE_TU 0
+#endif
 
 namespace curobo_hip {
 
@@ -956,7 +963,7 @@ constexpr bool kStampTerms = false;
 
 // TERMS: the optional tool-pose / c-space STATE terms are compiled in (separate instantiation so the
 // collision-only kernel keeps its register budget: with them inlined it spilled 232 B per lane)
-template <int DEG, int SWEEP, int KINDS, bool TERMS>
+template <int DEG, int SWEEP, int KINDS, bool TERMS, class SH = FusedShapeDyn>
 __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const FusedTrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
@@ -969,6 +976,16 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int tid = threadIdx.x;
   const int wave_idx = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockDim.x;
+  if constexpr (SH::kStatic) {
+    // a compile-time shape (fused_shapes.hpp): the host launches this instantiation only when every one of these holds
+    __builtin_assume(H == SH::kH); __builtin_assume(a.bs.n_knots == SH::kNK); __builtin_assume(D == SH::kD); __builtin_assume(L == SH::kL);
+    __builtin_assume(S == SH::kS); __builtin_assume(P == SH::kP); __builtin_assume(a.chain_len == SH::kC);
+    __builtin_assume(a.lane_len0 == SH::kLen0); __builtin_assume(a.lane_len1 == SH::kLen1); __builtin_assume(nt == SH::kNT);
+    if constexpr (SH::kNCub >= 0) {
+      __builtin_assume(a.sc.max_cuboids == SH::kNCub); __builtin_assume(a.sc.max_voxel_grids == SH::kNVox);
+      __builtin_assume(n_rec == SH::kNCub + SH::kNVox);
+    }
+  }
   // trajectory of this workgroup: blockIdx.x itself, or the entry of the longest-first order that the
   // previous launches built from the measured workgroup durations (same results, shorter tail)
   const bool reorder = a.dispatch_ws != nullptr;
@@ -1583,11 +1600,54 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
   }
 }
 
+// ---- compile-time shapes (fused_shapes.hpp): one launcher per shape, each in its own translation unit.
+// Returns 1 when the shape holds an instantiation for exactly these arguments and it was launched (*err = what the attribute
+// call said), 0 otherwise (the caller runs the generic kernel).
+template <class SH>
+static bool fused_shape_matches(const FusedTrajArgs &a, int threads) {
+  return a.bs.padded_horizon == SH::kH && a.bs.n_knots == SH::kNK && a.bs.dof == SH::kD && a.nlinks == SH::kL && a.nspheres == SH::kS &&
+         a.npairs == SH::kP && a.chain_len == SH::kC && a.lane_lists != nullptr && a.lane_len0 == SH::kLen0 && a.lane_len1 == SH::kLen1 &&
+         threads == SH::kNT && (SH::kNCub < 0 || (a.sc.max_cuboids == SH::kNCub && a.sc.max_voxel_grids == SH::kNVox));
+}
+#define CUROBO_FUSED_SHAPE_LAUNCHER_PARAMS \
+  const FusedTrajArgs &a, int deg, int sweep, int kinds, bool terms, int batch, int threads, size_t lds, hipStream_t st, hipError_t *err
+#define CUROBO_FUSED_DECLARE_SHAPE(ID) int fused_shape_launch_##ID(CUROBO_FUSED_SHAPE_LAUNCHER_PARAMS);
+CUROBO_FUSED_FOR_EACH_SHAPE(CUROBO_FUSED_DECLARE_SHAPE)
+#undef CUROBO_FUSED_DECLARE_SHAPE
+
+#if CUROBO_FUSED_SHAPE_TU > 0
+#define CUROBO_FUSED_CAT2(a, b) a##b
+#define CUROBO_FUSED_CAT(a, b) CUROBO_FUSED_CAT2(a, b)
+#define CUROBO_FUSED_CAT3_(a, b, c) a##b##c
+#define CUROBO_FUSED_CAT3(a, b, c) CUROBO_FUSED_CAT3_(a, b, c)
+int CUROBO_FUSED_CAT(fused_shape_launch_, CUROBO_FUSED_SHAPE_TU)(CUROBO_FUSED_SHAPE_LAUNCHER_PARAMS) {
+  using SH = CUROBO_FUSED_CAT(CUROBO_FUSED_SHAPE_, CUROBO_FUSED_SHAPE_TU);
+  if (!fused_shape_matches<SH>(a, threads)) return 0;
+#define CUROBO_FUSED_SHAPE_KERNEL(DG, SW, KD, TM)                                                                      \
+  if (deg == DG && sweep == SW && kinds == KD && terms == TM) {                                                        \
+    auto kfn = rollout_trajectory_fused_kernel<DG, SW, KD, TM, SH>;                                                    \
+    if (batch <= 0) return 1; /* query only */                                                                         \
+    *err = lds > 64 * 1024 ? hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess; \
+    if (*err == hipSuccess) hipLaunchKernelGGL(kfn, dim3((unsigned)batch), dim3(threads), lds, st, a);                 \
+    return 1;                                                                                                          \
+  }
+  CUROBO_FUSED_CAT3(CUROBO_FUSED_SHAPE_, CUROBO_FUSED_SHAPE_TU, _KERNELS)(CUROBO_FUSED_SHAPE_KERNEL)
+#undef CUROBO_FUSED_SHAPE_KERNEL
+  return 0;
+}
+#endif
+
 }  // namespace curobo_hip
 
+#if CUROBO_FUSED_SHAPE_TU == 0  // ---- the C ABI and the generic instantiations: main translation unit only
 using namespace curobo_hip;
 
 static long long *g_fused_prof = nullptr;
+static bool g_fused_shapes_enabled = true;
+CUROBO_EXPORT int curobo_hip_rollout_fused_set_shapes_enabled(int enabled) {
+  g_fused_shapes_enabled = enabled != 0;
+  return CUROBO_HIP_OK;
+}
 
 // development hook (not part of the drop-in surface): device buffer [batch][8] of int64 that
 // receives 100 MHz wall-clock stamps at the phase boundaries of every fused launch; NULL = off
@@ -1630,6 +1690,53 @@ CUROBO_EXPORT int curobo_hip_rollout_trajectory_fused_lds_bytes(int padded_horiz
   const FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len,
                                                   num_collision_pairs, num_obstacles, 0, &threads, 2);
   return lay.total * (int)sizeof(float);
+}
+
+// layout and workgroup size of a launch; drops the lane form of the pair pass (a.lane_lists) where it would cost a workgroup slot
+static FusedLayout fused_resolve_layout(FusedTrajArgs &a, int n_rec, bool with_terms, int *threads_out) {
+  const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, C = a.chain_len, P = a.npairs;
+  const int n_dyn = a.use_cspace ? 4 * H * D : 0, rings = with_terms ? 1 : 2;
+  int threads;
+  FusedLayout lay = trajectory_launch_shape(H, D, L, S, C, P, n_rec, n_dyn, &threads, rings, a.lane_lists ? (a.lane_len0 + a.lane_len1) * 64 : 0);
+  if (a.lane_lists) {
+    // the lane form must not cost a workgroup slot: where its lists (64 words per entry, whatever the sphere count) push
+    // the trajectory over 160 KB, or over the 80 KB that let two workgroups share a CU, the pass walks pair_locations
+    int threads0;
+    const FusedLayout lay0 = trajectory_launch_shape(H, D, L, S, C, P, n_rec, n_dyn, &threads0, rings, 0);
+    const size_t l1 = (size_t)lay.total * sizeof(float), l0 = (size_t)lay0.total * sizeof(float);
+    if (l1 > 160 * 1024 || (l1 > 80 * 1024 && l0 <= 80 * 1024) || (a.use_torque && !fused_torque_fits(lay, H, D, L, S))) {
+      a.lane_lists = nullptr; a.lane_len0 = 0; a.lane_len1 = 0;
+      lay = lay0;
+      threads = threads0;
+    }
+  }
+  *threads_out = threads;
+  return lay;
+}
+
+CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, int num_links, int num_spheres,
+                                                    int num_collision_pairs, int link_chain_len, int self_lane_len, int max_cuboids,
+                                                    int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
+                                                    int with_trajopt_terms) {
+#ifdef CUROBO_FUSED_ONLY_C2
+  return 0;
+#else
+  FusedTrajArgs a{};
+  a.bs.padded_horizon = padded_horizon; a.bs.n_knots = n_knots; a.bs.dof = dof; a.nlinks = num_links; a.nspheres = num_spheres;
+  a.npairs = num_collision_pairs; a.chain_len = link_chain_len; a.sc.max_cuboids = max_cuboids; a.sc.max_voxel_grids = max_voxel_grids;
+  a.lane_len0 = self_lane_len & 0xffff; a.lane_len1 = (self_lane_len >> 16) & 0xffff;
+  static const uint32_t some_list = 0u;
+  a.lane_lists = self_lane_len ? &some_list : nullptr;
+  a.use_cspace = with_trajopt_terms ? 1 : 0;
+  int threads;
+  (void)fused_resolve_layout(a, max_cuboids + max_voxel_grids, with_trajopt_terms != 0, &threads);
+  hipError_t e = hipSuccess;
+#define CUROBO_FUSED_QUERY_SHAPE(ID) \
+  if (fused_shape_launch_##ID(a, bspline_degree, sweep_steps, kinds, with_trajopt_terms != 0, 0, threads, 0, nullptr, &e)) return ID;
+  CUROBO_FUSED_FOR_EACH_SHAPE(CUROBO_FUSED_QUERY_SHAPE)
+#undef CUROBO_FUSED_QUERY_SHAPE
+  return 0;
+#endif
 }
 
 static int rollout_trajectory_fused_impl(
@@ -1745,22 +1852,7 @@ static int rollout_trajectory_fused_impl(
   int threads;
   static const bool force_terms = getenv("CUROBO_HIP_FORCE_TERMS") != nullptr;
   const bool with_terms = a.use_pose || a.use_cspace || force_terms;  // the TERMS instantiation: one scene ring per wave
-  FusedLayout lay = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                            a.use_cspace ? 4 * padded_horizon * dof : 0, &threads, with_terms ? 1 : 2,
-                                            a.lane_lists ? (a.lane_len0 + a.lane_len1) * 64 : 0);
-  if (a.lane_lists) {
-    // the lane form must not cost a workgroup slot: where its lists (64 words per entry, whatever the sphere count) push
-    // the trajectory over 160 KB, or over the 80 KB that let two workgroups share a CU, the pass walks pair_locations
-    int threads0;
-    const FusedLayout lay0 = trajectory_launch_shape(padded_horizon, dof, num_links, num_spheres, link_chain_len, a.npairs, n_rec,
-                                                     a.use_cspace ? 4 * padded_horizon * dof : 0, &threads0, with_terms ? 1 : 2, 0);
-    const size_t l1 = (size_t)lay.total * sizeof(float), l0 = (size_t)lay0.total * sizeof(float);
-    if (l1 > 160 * 1024 || (l1 > 80 * 1024 && l0 <= 80 * 1024) || (a.use_torque && !fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres))) {
-      a.lane_lists = nullptr; a.lane_len0 = 0; a.lane_len1 = 0;
-      lay = lay0;
-      threads = threads0;
-    }
-  }
+  const FusedLayout lay = fused_resolve_layout(a, n_rec, with_terms, &threads);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CUROBO_REQUIRE(lds <= 160 * 1024, "%s: trajectory does not fit in LDS (%zu bytes); use the unfused kernels", what, lds);
   CUROBO_REQUIRE(!a.use_torque || fused_torque_fits(lay, padded_horizon, dof, num_links, num_spheres),
@@ -1769,10 +1861,15 @@ static int rollout_trajectory_fused_impl(
   // scenes with analytic primitives in the cuboid store run the one instantiation that tests the tag (KINDS = 7)
   const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
   hipStream_t st = (hipStream_t)stream;
+#ifdef CUROBO_FUSED_ONLY_C2
+#define CUROBO_FUSED_KERNEL_OF(DG, SW, KD) rollout_trajectory_fused_kernel<DG, SW, KD, false>
+#else
+#define CUROBO_FUSED_KERNEL_OF(DG, SW, KD) \
+  (with_terms ? rollout_trajectory_fused_kernel<DG, SW, KD, true> : rollout_trajectory_fused_kernel<DG, SW, KD, false>)
+#endif
 #define CUROBO_FUSED_LAUNCH(DG, SW, KD)                                                                        \
   do {                                                                                                         \
-    auto kfn = with_terms ? rollout_trajectory_fused_kernel<DG, SW, KD, true>                                 \
-                                            : rollout_trajectory_fused_kernel<DG, SW, KD, false>;                                                    \
+    auto kfn = CUROBO_FUSED_KERNEL_OF(DG, SW, KD);                                                             \
     if (lds > 64 * 1024) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(e)); \
@@ -1785,6 +1882,25 @@ static int rollout_trajectory_fused_impl(
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, dim3((unsigned)batch_size), dim3(threads), lds, st, a);                            \
   } while (0)
+#ifndef CUROBO_FUSED_ONLY_C2
+  {  // a compile-time shape that matches every dimension of this launch (fused_shapes.hpp), most specific first
+    static const bool env_off = getenv("CUROBO_HIP_FUSED_NO_SHAPES") != nullptr;  // development knob: always the generic kernel
+    const bool no_shapes = env_off || !g_fused_shapes_enabled;
+    hipError_t se = hipSuccess;
+#define CUROBO_FUSED_TRY_SHAPE(ID)                                                                                              \
+    if (!no_shapes && fused_shape_launch_##ID(a, bspline_degree, sweep_steps, kinds, with_terms, batch_size, threads, lds, st, &se)) { \
+      if (se != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(se));  \
+      return check_launch(what, st);                                                                                            \
+    }
+    CUROBO_FUSED_FOR_EACH_SHAPE(CUROBO_FUSED_TRY_SHAPE)
+#undef CUROBO_FUSED_TRY_SHAPE
+  }
+#endif
+#ifdef CUROBO_FUSED_ONLY_C2  // experiment builds (tools/r05/build_fused_variant.sh): one instantiation, seconds to compile
+  CUROBO_REQUIRE(bspline_degree == 3 && sweep_steps == 3 && kinds == 1 && !with_terms, "%s: this experiment build only holds the C2 instantiation", what);
+  CUROBO_FUSED_LAUNCH(3, 3, 1);
+  return check_launch(what, st);
+#else
 #define CUROBO_FUSED_KINDS(DG, SW)                         \
   do {                                                     \
     if (kinds == 2) CUROBO_FUSED_LAUNCH(DG, SW, 2);        \
@@ -1804,6 +1920,7 @@ static int rollout_trajectory_fused_impl(
 #undef CUROBO_FUSED_KINDS
 #undef CUROBO_FUSED_LAUNCH
   return check_launch(what, st);
+#endif
 }
 
 __global__ void dispatch_ws_init_kernel(int32_t *ws, int B) {
@@ -2026,10 +2143,15 @@ CUROBO_EXPORT int curobo_hip_rollout_ik_fused(
     }                                                                                                           \
     hipLaunchKernelGGL(kfn, grid, block, lds, st, ia);                                                          \
   } while (0)
+#ifdef CUROBO_FUSED_ONLY_C2
+  CUROBO_IK_LAUNCH(1);
+#else
   if (kinds == 2) CUROBO_IK_LAUNCH(2);
   else if (kinds == 3) CUROBO_IK_LAUNCH(3);
   else if (kinds == 7) CUROBO_IK_LAUNCH(7);
   else CUROBO_IK_LAUNCH(1);
+#endif
 #undef CUROBO_IK_LAUNCH
   return check_launch(what, st);
 }
+#endif  // CUROBO_FUSED_SHAPE_TU == 0

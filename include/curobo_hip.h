@@ -669,6 +669,20 @@ int curobo_hip_rollout_fused_set_profile_buffer(int64_t *device_buffer);
  * time the rollout launches inside the replayed graph (stamp 0 = workgroup start, 4 = end). */
 int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_buffer, int n_blocks, int block_rows);
 
+/* Compile-time shapes of the fused trajectory launches (csrc/fused_shapes.hpp): for the robots / horizons listed there the
+ * library holds instantiations whose every dimension is a compile-time constant (the reference compiles its kernels per
+ * robot with NVRTC templates: kinematics_forward_kernel.cuh:126 N_LINKS, cuda_core_backend/kernel_cache.py:161-235); a launch
+ * takes one only when ALL its dimensions match, otherwise the generic kernel -- same results, bit for bit.
+ * curobo_hip_rollout_fused_shape_id: host-side query (no GPU work), the id (>= 1) of the shape a launch with these arguments
+ * runs, 0 = the generic kernel.  self_lane_len = the value curobo_hip_self_lane_lists_host returned (0 = no lane lists);
+ * num_collision_pairs = 0 when the self-collision term is off; kinds = 1 cuboids | 2 voxel grids (7 = analytic primitives).
+ * curobo_hip_rollout_fused_set_shapes_enabled(0) makes every launch take the generic kernel (tests, A/B timing). */
+int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, int num_links, int num_spheres,
+                                      int num_collision_pairs, int link_chain_len, int self_lane_len, int max_cuboids,
+                                      int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
+                                      int with_trajopt_terms);
+int curobo_hip_rollout_fused_set_shapes_enabled(int enabled);
+
 /* ---------------------------------------------------------------- trajectory: B-spline
  * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142
  * kernels:   kernels/trajectory/bspline/bspline_kernel.cuh:81-151,332-380

@@ -1,0 +1,121 @@
+"""The compile-time shape table of the fused rollout launch (csrc/fused_shapes.hpp) against the packaged robots: a robot whose
+dimensions drift away from its row would silently lose the specialised kernel (the dispatch falls back to the generic one)."""
+
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model
+
+
+def _lane_len(model):
+    from curobo_amd.backends.rollout import attach_self_lane_lists
+
+    pairs = torch.as_tensor(np.asarray(model.collision_pairs)).to(torch.int16)
+    attach_self_lane_lists(pairs, model.num_spheres)
+    lists = getattr(pairs, "_self_lane_lists", None)  # (robots outside the lane form -- more than 128 spheres -- have none)
+    return int(lists[1]) if lists is not None else 0
+
+
+def _shape(model, padded_horizon, n_cub, n_vox, terms=False, kinds=None, **kw):
+    from curobo_amd.backends.rollout import fused_shape_id
+
+    d = model.as_dict()
+    args = dict(padded_horizon=padded_horizon, n_knots=12, dof=model.num_dof, num_links=model.num_links, num_spheres=model.num_spheres,
+                num_collision_pairs=len(model.collision_pairs), link_chain_len=len(d["link_chain_data"]), self_lane_len=_lane_len(model),
+                max_cuboids=n_cub, max_voxel_grids=n_vox, kinds=kinds if kinds is not None else ((1 if n_cub else 0) | (2 if n_vox else 0)),
+                with_trajopt_terms=terms)
+    args.update(kw)
+    return fused_shape_id(**args)
+
+
+def test_packaged_robots_take_their_compile_time_shapes():
+    franka, ur10e = load_model("franka"), load_model("ur10e")
+    assert _shape(franka, 33, 4, 0) == 1, "BASELINE C2: Franka, 12 knots x 2, the four cuboid slots of the C2 world"
+    assert _shape(franka, 33, 3, 0) == 2 and _shape(franka, 33, 7, 0) == 2, "Franka, any cuboid scene"
+    assert _shape(franka, 33, 4, 0, terms=True) == 2, "the full trajopt cost set"
+    assert _shape(franka, 33, 2, 1) == 2, "cuboids + ESDF"
+    assert _shape(franka, 65, 2, 1) == 3 and _shape(franka, 65, 5, 0) == 3, "BASELINE C5: horizon 64"
+    assert _shape(ur10e, 33, 0, 1) == 4 and _shape(ur10e, 33, 4, 0) == 4, "BASELINE C3: UR10e"
+
+
+def test_anything_else_runs_the_generic_kernel():
+    franka = load_model("franka")
+    assert _shape(franka, 33, 4, 0, n_knots=10) == 0
+    assert _shape(franka, 31, 4, 0) == 0
+    assert _shape(franka, 33, 4, 0, self_lane_len=0) == 0, "without lane lists the pair pass walks pair_locations: not in the table"
+    assert _shape(franka, 33, 4, 0, num_collision_pairs=0) == 0, "self collision off"
+    assert _shape(franka, 33, 4, 0, bspline_degree=4) == 0 and _shape(franka, 33, 4, 0, sweep_steps=0) == 0
+    assert _shape(franka, 33, 4, 0, kinds=7) == 0, "analytic primitives"
+    assert _shape(load_model("unitree_g1"), 33, 4, 0) == 0
+
+
+def test_table_rows_are_consistent_with_the_build():
+    import os
+
+    from curobo_amd.build import CSRC, compile_units, fused_shape_ids
+
+    text = open(os.path.join(CSRC, "fused_shapes.hpp")).read()
+    ids = [int(m) for m in re.findall(r"#define CUROBO_FUSED_SHAPE_(\d+) FusedShape<", text)]
+    assert ids == fused_shape_ids() == list(range(1, len(ids) + 1))
+    each = re.search(r"#define CUROBO_FUSED_FOR_EACH_SHAPE\(X\)(.*)", text).group(1)
+    assert [int(m) for m in re.findall(r"X\((\d+)\)", each)] == ids
+    for k in ids:
+        assert re.search(rf"#define CUROBO_FUSED_SHAPE_{k}_KERNELS\(K\)", text)
+        assert ("rollout_fused.hip", f"rollout_fused_shape{k}", [f"-DCUROBO_FUSED_SHAPE_TU={k}"]) in compile_units()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c2", "franka_3_cuboids", "franka_h65_mixed", "ur10e_esdf", "franka_terms"])
+def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device):
+    """the same launch through the compile-time shape and through the generic kernel: every output bit equal"""
+    from curobo_amd.backends.rollout import set_fused_shapes_enabled
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, c3_voxel_world, c5_mixed_worlds, seed_knots, start_configuration
+
+    robot = "ur10e" if case == "ur10e_esdf" else "franka"
+    model = load_model(robot)
+    kin = KinematicsParams.from_model(model, device)
+    interp = 4 if case == "franka_h65_mixed" else 2
+    if case == "franka_3_cuboids":
+        arrays = cuboid_scene_arrays([c2_world()[0][:3]])
+    elif case == "franka_h65_mixed":
+        arrays = c5_mixed_worlds(1, voxels=True)
+    elif case == "ur10e_esdf":
+        arrays = c3_voxel_world(64, 0.04)
+    else:
+        arrays = cuboid_scene_arrays(c2_world())
+    scene = SceneData.from_arrays(arrays, device)
+    B = 96
+    knots = torch.as_tensor(seed_knots(model, B, 12, seed=5), device=device).reshape(B, -1)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    if case == "franka_terms":  # the full cost set (pose + c-space + self + swept scene)
+        from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+
+        rng = np.random.default_rng(2)
+        ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(traj_dt=0.1))
+        ro.update_start_state(start)
+        gq = rng.normal(size=(3, 1, 1, 4)).astype(np.float32)
+        gq /= np.linalg.norm(gq, axis=-1, keepdims=True)
+        ro.update_goals(torch.as_tensor(rng.normal(size=(3, 1, 1, 3)).astype(np.float32) * 0.4, device=device), torch.as_tensor(gq, device=device),
+                        torch.as_tensor(rng.integers(0, 3, size=B).astype(np.int32), device=device))
+        assert ro.fused_available()
+    else:
+        ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(interpolation_steps=interp, fused_materialize=True))
+        ro.update_start_state(start)
+    outs = []
+    try:
+        for enabled in (True, False, True):
+            set_fused_shapes_enabled(enabled)
+            c, g = ro.cost_and_gradient_fused(knots) if case == "franka_terms" else ro.cost_and_gradient(knots)
+            torch.cuda.synchronize()
+            outs.append((c.clone(), g.clone()))
+    finally:
+        set_fused_shapes_enabled(True)
+    assert float(outs[0][0].abs().sum()) > 0
+    for c, g in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(g, outs[0][1])
