@@ -82,6 +82,142 @@ class RobotCollisionChecker:
         self._speed_dt = torch.tensor([0.02], device=d)
         self._shape = (b, h)
 
+    # ------------------------------------------------------------------ sphere-level entry points (reference :70-245, :418-495)
+    @property
+    def tool_frames(self):
+        return self.kinematics.tool_frames
+
+    def setup_batch_tensors(self, batch_size: int, horizon: int) -> None:
+        """reference :60-69: size the output buffers ahead of the first query (they are also sized on demand)"""
+        self._setup(batch_size, horizon)
+
+    def get_kinematics(self, joint_position: torch.Tensor):
+        """forward kinematics of joint positions [batch, horizon, dof] -> state with tool poses and collision spheres
+        (reference :71-92)"""
+        if joint_position.ndim != 3:
+            raise ValueError(f"joint_position must have shape [batch, horizon, dof], got {tuple(joint_position.shape)}")
+        return self.kinematics.compute_kinematics(joint_position)
+
+    def clear_scene_cache(self) -> None:
+        """reference :102-104.  The obstacle store here holds no cache beside its tensors: every obstacle is switched off
+        (an empty world of the same capacity), as the reference's ``SceneCollision.clear_cache`` leaves it."""
+        if self.scene is not None and hasattr(self.scene, "clear"):
+            self.scene.clear()
+
+    @staticmethod
+    def _spheres_of(x_sph) -> torch.Tensor:
+        sph = getattr(x_sph, "robot_spheres", x_sph)  # a kinematics state or the sphere tensor itself
+        if sph.ndim != 4 or sph.shape[-1] != 4:
+            raise ValueError(f"robot spheres must have shape [batch, horizon, num_spheres, 4], got {tuple(sph.shape)}")
+        return sph
+
+    def _scene_buffers(self, b: int, h: int, n: int) -> CollisionBuffer:
+        key = (b, h, n)
+        if getattr(self, "_sph_key", None) != key:
+            self._sph_buf = CollisionBuffer.create(b, h, n, self._eta.device)
+            self._sph_env = torch.zeros(b, dtype=torch.int32, device=self._eta.device)
+            self._sph_key = key
+        return self._sph_buf
+
+    def _scene_distance(self, x_sph, env_query_idx, eta: torch.Tensor) -> torch.Tensor:
+        sph = self._spheres_of(x_sph)
+        b, h, n, _ = sph.shape
+        if self.scene is None:
+            return torch.zeros(b, h, n, device=sph.device, dtype=sph.dtype)
+        buf = self._scene_buffers(b, h, n)
+        env = self._sph_env if env_query_idx is None else env_query_idx
+        return SphereObstacleCollision.apply(sph.contiguous(), buf, self.scene, self._w_scene, eta, self._max_d, env,
+                                             env_query_idx is not None, True)
+
+    def get_collision_distance(self, x_sph, env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """scene-collision COST of robot spheres [batch, horizon, num_spheres, 4] (or a kinematics state) -> [batch, horizon,
+        num_spheres]: the penetration into the activation shell (``collision_activation_distance``) through the reference's
+        activation (reference :106-134).  Differentiable in the spheres."""
+        return self._scene_distance(x_sph, env_query_idx, self._eta)
+
+    def get_collision_constraint(self, x_sph, env_query_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """the same with activation distance 0: positive only where a sphere actually penetrates (reference :136-166: its
+        ``collision_constraint`` is a second scene cost built with ``activation_distance = 0``,
+        collision_robot_scene_cfg.py:157-165)"""
+        if getattr(self, "_eta0", None) is None:
+            self._eta0 = torch.zeros(1, device=self._eta.device)
+        return self._scene_distance(x_sph, env_query_idx, self._eta0)
+
+    def get_collision_vector(self, x_sph, env_query_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(scene cost [batch, horizon, num_spheres], its gradient per sphere [batch, horizon, num_spheres, 4]); not
+        differentiable (reference :198-245: the cost's gradient buffer)"""
+        sph = self._spheres_of(x_sph).detach()
+        if self.scene is None:
+            return torch.zeros(sph.shape[:-1], device=sph.device, dtype=sph.dtype), torch.zeros_like(sph)
+        with torch.no_grad():
+            d = self._scene_distance(sph, env_query_idx, self._eta)
+        return d.detach(), self._sph_buf.gradient
+
+    def get_self_collision(self, x_sph: torch.Tensor) -> torch.Tensor:
+        """self-collision cost of robot spheres [batch, horizon, num_spheres, 4] -> [batch, horizon, 1] (reference :181-196);
+        differentiable in the spheres"""
+        sph = self._spheres_of(x_sph)
+        b, h, S, _ = sph.shape
+        sc = self.kinematics.kinematics_config.self_collision
+        if sc is None or sc.collision_pairs is None or sc.collision_pairs.numel() == 0:
+            return torch.zeros(b, h, 1, device=sph.device, dtype=sph.dtype)
+        self._setup(b, h)
+        return SelfCollisionDistance.apply(
+            sph.contiguous(), self._self_d, self._self_g, self._pd, self._sparse, self._w_self, sc.sphere_padding, sc.collision_pairs,
+            self._bbmv, self._bbmi, sc.num_blocks_per_batch, sc.max_threads_per_block, False, True)
+
+    def get_self_collision_distance(self, x_sph: torch.Tensor) -> torch.Tensor:
+        return self.get_self_collision(x_sph)  # reference :168-179
+
+    def pose_distance(self, x_des, x_current, resize: bool = False) -> torch.Tensor:
+        """distance between desired and current poses (``Pose`` objects: position [b, 3] or [b, h, 3], quaternion wxyz):
+        position error + geodesic rotation error, [b, h] ([b] with ``resize`` for 2-D inputs).  Reference :418-449 -- which
+        forwards to a ``pose_cost`` member its own configuration never creates (collision_robot_scene_cfg.py:207-218); the
+        quantity is the unweighted sum of the two distances its tool-pose cost reports (cost/wp_tool_pose.py:456-692)."""
+        from .backends import cost as cost_hip
+
+        cp, cq, gp, gq = x_current.position, x_current.quaternion, x_des.position, x_des.quaternion
+        squeeze = cp.ndim == 2
+        if squeeze:
+            cp, cq = cp.unsqueeze(1), cq.unsqueeze(1)
+        b, h = int(cp.shape[0]), int(cp.shape[1])
+        d = cp.device
+        f = lambda x: x.to(d, torch.float32).contiguous()  # noqa: E731
+        gp, gq = f(gp).reshape(-1, 3), f(gq).reshape(-1, 4)
+        if gp.shape[0] not in (1, b):
+            raise ValueError(f"x_des holds {gp.shape[0]} poses for a batch of {b}")
+        idx = torch.arange(b, device=d, dtype=torch.int32) if gp.shape[0] == b else torch.zeros(b, dtype=torch.int32, device=d)
+        n = gp.shape[0]
+        cost = torch.zeros(b, h, 1, 2, device=d)
+        pd, rd = torch.zeros(b, h, 1, device=d), torch.zeros(b, h, 1, device=d)
+        gpos, gquat = torch.zeros(b, h, 1, 3, device=d), torch.zeros(b, h, 1, 4, device=d)
+        gidx = torch.zeros(b, h, 1, dtype=torch.int32, device=d)
+        w6, tol, proj = torch.ones(6, device=d), torch.zeros(2, device=d), torch.zeros(1, dtype=torch.uint8, device=d)
+        cost_hip.tool_pose_distance(cost, pd, rd, gpos, gquat, gidx, f(cp).view(b, h, 1, 3), f(cq).view(b, h, 1, 4), gp.view(n, 1, 1, 3),
+                                    gq.view(n, 1, 1, 4), idx, torch.ones(2, device=d), w6, w6, tol, tol, proj, b, h, 1, 1, 0)
+        out = pd[..., 0] + rd[..., 0]
+        return out.squeeze(1) if (squeeze and resize) else out
+
+    def get_point_robot_distance(self, points: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+        """signed depth of points [n, 3] or [batch, n, 3] inside the robot at joint positions q [1, dof] (or [batch, dof]):
+        max over the robot's spheres of (radius - distance to the centre); positive = inside (reference :451-495)"""
+        if q.ndim == 1:
+            raise ValueError("q should be of shape [b, dof]")
+        sph = self.get_kinematics(q.view(q.shape[0], 1, -1) if q.ndim == 2 else q).robot_spheres
+        sph = sph.reshape(sph.shape[0], -1, 4)
+        squeeze = points.ndim == 2
+        pts = points.unsqueeze(0) if squeeze else points
+        if sph.shape[0] not in (1, pts.shape[0]):
+            raise ValueError(f"robot_spheres batch must be 1 or match points batch: got {sph.shape[0]} vs {pts.shape[0]}")
+        depth = sph[:, None, :, 3] - torch.linalg.norm(pts[:, :, None, :] - sph[:, None, :, :3], dim=-1)
+        depth = torch.where((sph[:, None, :, 3] >= 0).expand_as(depth), depth, torch.full_like(depth, -float("inf")))  # disabled spheres
+        out = depth.max(dim=-1).values
+        return out.view(-1) if squeeze else out
+
+    def get_active_js(self, full_js):
+        """the active joints of a full joint state, in the kinematics' order (reference :497-507)"""
+        return full_js.reorder(self.kinematics.joint_names)
+
     def get_scene_self_collision_distance_from_joints(
             self, q: torch.Tensor, env_query_idx: Optional[torch.Tensor] = None,
             sweep: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -625,7 +625,8 @@ __global__ void __launch_bounds__(256) ik_rank_kernel(const IkRankArgs a) {
       for (int j = 0; j < a.n_scene; j++) sc += a.scene_dist[e * a.n_scene + j];
       ok = ok && sc <= 0.0f;
     }
-    ok = ok && a.pos_dist[e * T] < a.pos_thr && a.rot_dist[e * T] < a.rot_thr;
+    // converged on EVERY tool frame (reference: torch.all over the per-link convergence list, solver_ik.py:463-476)
+    for (int t = 0; t < T; t++) ok = ok && a.pos_dist[e * T + t] < a.pos_thr && a.rot_dist[e * T + t] < a.rot_thr;
     const float c = a.cost[e] + 1e16f * (ok ? 0.0f : 1.0f);
     s_cost[i] = c == c ? c : __builtin_inff();
     s_ok[i] = ok ? 1 : 0;
@@ -636,11 +637,13 @@ __global__ void __launch_bounds__(256) ik_rank_kernel(const IkRankArgs a) {
     if (r < a.k) {
       const size_t e = (size_t)p * S + i, o = (size_t)p * a.k + r;
       a.out_success[o] = s_ok[i];
-      a.out_pos[o] = a.pos_dist[e * T];
-      a.out_rot[o] = a.rot_dist[e * T];
+      float pe = a.pos_dist[e * T], re = a.rot_dist[e * T];  // the largest error over the tool frames (solver_ik.py:549-550)
+      for (int t = 1; t < T; t++) { pe = fmaxf(pe, a.pos_dist[e * T + t]); re = fmaxf(re, a.rot_dist[e * T + t]); }
+      a.out_pos[o] = pe;
+      a.out_rot[o] = re;
       a.out_cost[o] = a.cost[e];
       a.out_seed[o] = a.seed_offset + i;
-      a.out_goalset[o] = a.goalset_idx ? (int64_t)a.goalset_idx[e * T] : 0;
+      for (int t = 0; t < T; t++) a.out_goalset[o * T + t] = a.goalset_idx ? (int64_t)a.goalset_idx[e * T + t] : 0;
       for (int d = 0; d < D; d++) a.out_solution[o * D + d] = a.q[e * D + d];
     }
   }

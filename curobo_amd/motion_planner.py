@@ -139,16 +139,24 @@ def _axis_offset_pose(axis: str, offset: float) -> Pose:
 
 
 def robot_acceleration_jerk_limits(kinematics: Optional[KinematicsCfg]):
-    """(max_acceleration, max_jerk) of the robot file's cspace block (reference: JointLimits.acceleration / .jerk, which its
-    rollouts bound the trajectory by, kinematics_loader.py:1102-1112) -- when every active joint carries the same value, which
-    is what a rollout configuration holds (one scalar per limit); ``None`` for a limit that differs between joints (the G1)
-    or that the model does not carry: the configuration's default stays."""
+    """(max_acceleration, max_jerk) of the robot file's cspace block, per ACTIVE joint as the loader carries them (reference:
+    JointLimits.acceleration / .jerk, which its rollouts bound the trajectory by per joint, kinematics_loader.py:1102-1124,
+    cost/wp_cspace_state.py:20-287): a float when every joint has the same value, else the list [dof]; ``None`` for a limit
+    the model does not carry (the configuration's default stays)."""
     cs = getattr(getattr(kinematics, "model", None), "cspace", None) or {}
+    dof = getattr(getattr(kinematics, "model", None), "num_dof", None)
     out = []
     for key in ("max_acceleration", "max_jerk"):
         v = cs.get(key)
         v = [] if v is None else [float(x) for x in np.atleast_1d(np.asarray(v, np.float64))]
-        out.append(v[0] if v and all(abs(x - v[0]) <= 1e-9 * max(1.0, abs(v[0])) for x in v) else None)
+        if not v:
+            out.append(None)
+        elif all(abs(x - v[0]) <= 1e-9 * max(1.0, abs(v[0])) for x in v):
+            out.append(v[0])
+        elif dof is not None and len(v) == int(dof):
+            out.append(v)
+        else:  # a list that is not per active joint cannot be applied joint by joint: the tightest value bounds every joint
+            out.append(min(v))
     return tuple(out)
 
 
@@ -398,7 +406,7 @@ class TrajectoryOptimizer:
         t0 = time.perf_counter()
         if num_seeds is not None and num_seeds != self.config.num_seeds:
             raise ValueError(f"num_seeds is fixed at construction ({self.config.num_seeds}); got {num_seeds}")
-        gp, gq = goal_tool_poses.static_goals()  # [batch, T, g, 3 | 4]
+        gp, gq = goal_tool_poses.static_goals(self.tool_frames)  # [batch, T, g, 3 | 4], the robot's frame order
         batch = int(gp.shape[0])
         if goal_tool_poses.num_goalset > self.config.max_goalset:
             raise ValueError(f"solve_pose: goal set of {goal_tool_poses.num_goalset} poses exceeds config.max_goalset="
@@ -573,21 +581,16 @@ class _PlannerBase:
         a goal set to ``max_goalset`` with its last pose"""
         c = self.config.trajopt_solver_config
         n, k, dev, G = c.max_batch_size, c.num_seeds, self.device_cfg.device, c.max_goalset
-        gp, gq = goal_tool_poses.static_goals()
-        if gp.shape[1] != 1:
-            # the reference hands every tool frame's goal to its IK solver (motion_planner.py:249); the IK stage here scores
-            # ONE frame, so seeds for a multi-frame goal would silently ignore the other frames' goals
-            raise ValueError(f"the planner's IK stage takes one tool frame, the goal has {gp.shape[1]}: plan multi-frame robots "
-                             "with TrajOptSolver.solve_pose and caller-provided seed configurations")
-        gp, gq = gp.to(dev, torch.float32)[:, 0], gq.to(dev, torch.float32)[:, 0]  # the tool frame: [batch, g, 3 | 4]
-        g = gp.shape[1]
+        # every tool frame's goal goes to the IK stage (reference motion_planner.py:249: the whole GoalToolPose), in the
+        # robot's frame order: [batch, T, g, 3 | 4]
+        gp, gq = goal_tool_poses.static_goals(self.tool_frames)
+        gp, gq = gp.to(dev, torch.float32), gq.to(dev, torch.float32)
+        T, g = int(gp.shape[1]), int(gp.shape[2])
         if g > G:
             raise ValueError(f"goal set of {g} poses exceeds max_goalset={G}")
         if g < G:
-            gp = torch.cat([gp, gp[:, -1:].expand(batch, G - g, 3)], 1)
-            gq = torch.cat([gq, gq[:, -1:].expand(batch, G - g, 4)], 1)
-        if G == 1:
-            gp, gq = gp[:, 0], gq[:, 0]
+            gp = torch.cat([gp, gp[:, :, -1:].expand(batch, T, G - g, 3)], 2)
+            gq = torch.cat([gq, gq[:, :, -1:].expand(batch, T, G - g, 4)], 2)
         pad = lambda x: x if batch == n else torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], 0)  # noqa: E731
         env = torch.arange(n, device=dev, dtype=torch.int32) if c.multi_env else None
         r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, exit_early=False, env_idx=env)

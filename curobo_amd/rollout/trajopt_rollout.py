@@ -15,7 +15,7 @@ from __future__ import annotations
 import contextlib
 
 from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -29,6 +29,18 @@ from ..backends import trajectory as trajectory_hip
 from ..robot.kinematics_params import KinematicsParams
 from ..scene.data import SceneData, validate_env_query_idx
 from ..util.stream_scope import inside_forked_stream
+
+
+def joint_limit_vector(value, dof: int, device, name: str = "limit") -> torch.Tensor:
+    """a scalar (every joint) or a per-joint list [dof] -> fp32 [dof] of positive limits"""
+    v = torch.as_tensor(value, dtype=torch.float32, device=device).reshape(-1)
+    if v.numel() == 1:
+        v = v.expand(dof)
+    if v.numel() != dof:
+        raise ValueError(f"{name}: one value or one per active joint ({dof}) expected, got {v.numel()}")
+    if bool((v <= 0).any()):
+        raise ValueError(f"{name} must be positive, got {v.tolist()}")
+    return v.contiguous().clone()
 
 
 @dataclass
@@ -57,8 +69,10 @@ class TrajOptRolloutCfg:
     cspace_regularization: List[float] = field(default_factory=lambda: [1000.0, 10000.0, 5.0, 0.0, 10000.0])
     retime_weights: bool = True
     retime_regularization_weights: bool = True
-    max_acceleration: float = 15.0  # content/configs/robot/franka.yml:48-49
-    max_jerk: float = 500.0
+    #: one value for every joint or one per active joint [dof] (reference JointLimits.acceleration / .jerk: per joint,
+    #: kinematics_loader.py:1102-1124, consumed per dof by cost/wp_cspace_state.py:20-287)
+    max_acceleration: Union[float, Sequence[float]] = 15.0  # content/configs/robot/franka.yml:48-49
+    max_jerk: Union[float, Sequence[float]] = 500.0
     #: joint-torque limits (reference: the c-space STATE cost's effort bound on inverse-dynamics torques,
     #: cost/wp_cspace_state.py + cuda_ops/dynamics.py RNEA; "motion generation with torque limits",
     #: docs/reference/benchmarks.rst:32-42): tau = RNEA(q, qd, qdd) per point, bound cost with
@@ -109,8 +123,9 @@ class TrajOptRollout:
         self._cs_w, self._cs_eta, self._cs_reg = f(c.cspace_weight), f(c.cspace_activation_distance), f(c.cspace_regularization)
         self._p_b, self._v_b = kin.joint_limits_position.contiguous(), kin.joint_limits_velocity.contiguous()
         ones = torch.ones(D, device=d)
-        self._a_b = torch.stack([-c.max_acceleration * ones, c.max_acceleration * ones])
-        self._j_b = torch.stack([-c.max_jerk * ones, c.max_jerk * ones])
+        amax, jmax = joint_limit_vector(c.max_acceleration, D, d, "max_acceleration"), joint_limit_vector(c.max_jerk, D, d, "max_jerk")
+        self._a_b = torch.stack([-amax, amax])
+        self._j_b = torch.stack([-jmax, jmax])
         self._effort_b = torch.stack([-1e9 * ones, 1e9 * ones])
         if c.use_torque_limits:
             lim = f(c.effort_limit) if c.effort_limit is not None else kin.joint_limits_effort

@@ -128,6 +128,18 @@ class SceneData:
             return int(self.meshes.num_envs)
         return 1
 
+    def clear(self) -> None:
+        """Switch every cuboid / voxel-grid / mesh slot off, in place (the kernels read the same enable tensors): an empty
+        world of the same capacity (reference SceneCollision.clear_cache, geom/collision/collision_scene.py: the stores'
+        ``clear`` zeroes their enable flags and counts)."""
+        for k in ("cuboid_enable", "voxel_enable"):
+            if self.tensors.get(k) is not None:
+                self.tensors[k].zero_()
+                if isinstance(self.arrays.get(k), np.ndarray):
+                    self.arrays[k][...] = 0
+        if self.meshes is not None and getattr(self.meshes, "enable", None) is not None:
+            self.meshes.enable.zero_()
+
     @staticmethod
     def from_arrays(arrays: Optional[Dict[str, np.ndarray]], device, coarse_culling: bool = True, meshes=None) -> "SceneData":
         """``coarse_culling``: also build the min-pooled ESDF the voxel kernels use to skip spheres that are far from

@@ -60,7 +60,7 @@ class IKResult:
     rotation_error: torch.Tensor  # [P]
     cost: torch.Tensor  # [P]
     seed_index: torch.Tensor  # [P] global seed index of the winner
-    goalset_index: Optional[torch.Tensor] = None  # [P] member of the goal set the solution reaches
+    goalset_index: Optional[torch.Tensor] = None  # [P, T] member of the goal set the solution reaches, per tool frame
 
 
 class IKSolver:
@@ -168,17 +168,18 @@ class IKSolver:
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
                    seeds: Optional[torch.Tensor] = None, return_seeds: int = 1,
                    exit_early: Optional[bool] = None, env_idx: Optional[torch.Tensor] = None) -> IKResult:
-        """goal_position [P,3], goal_quat [P,4] (wxyz) for the first tool frame -- or [P, G, 3] / [P, G, 4]
-        with ``cfg.num_goalset`` = G alternatives per problem (reference solve_pose with a goal set,
-        solver_ik.py:660-700; the result names the member reached).  ``return_seeds`` k > 1
-        returns the k best seeds per problem, best first (reference IKSolver.solve_pose
-        ``return_seeds``, solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result."""
+        """Goals of EVERY tool frame (reference IKSolver.solve_pose over a GoalToolPose, solver_ik.py:631-700): goal_position
+        [P, T, G, 3], goal_quat [P, T, G, 4] (wxyz) with T = the robot's tool frames (``kin.tool_frames`` order) and G =
+        ``cfg.num_goalset`` alternatives per problem (one member index per frame is chosen: the closest).  A robot with ONE
+        tool frame also takes [P, 3] / [P, 4] or [P, G, 3] / [P, G, 4].  A solution succeeds when every frame is within the
+        thresholds; the reported errors are the largest over the frames.  ``return_seeds`` k > 1 returns the k best seeds
+        per problem, best first (solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result."""
         P, S, D, T, G = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links, self.G
-        if goal_position.numel() != P * G * 3 or goal_quat.numel() != P * G * 4:
-            raise ValueError(f"solve_pose: expected {P} problems x {G} goal-set members, got position "
-                             f"{tuple(goal_position.shape)}, quaternion {tuple(goal_quat.shape)}")
-        gp = goal_position.to(self.device, torch.float32).view(P, 1, G, 3).expand(P, T, G, 3).contiguous()
-        gq = goal_quat.to(self.device, torch.float32).view(P, 1, G, 4).expand(P, T, G, 4).contiguous()
+        if goal_position.numel() != P * T * G * 3 or goal_quat.numel() != P * T * G * 4:
+            raise ValueError(f"solve_pose: expected goals for {P} problems x {T} tool frames {tuple(self.kin.tool_frames)} x {G} "
+                             f"goal-set members, got position {tuple(goal_position.shape)}, quaternion {tuple(goal_quat.shape)}")
+        gp = goal_position.to(self.device, torch.float32).reshape(P, T, G, 3).contiguous()
+        gq = goal_quat.to(self.device, torch.float32).reshape(P, T, G, 4).contiguous()
         self._set_envs(env_idx)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
         optimizer_goals_set = False
@@ -263,7 +264,7 @@ class IKSolver:
             ok_o = torch.empty(P, k, dtype=torch.uint8, device=dev)
             sol_o = torch.empty(P, k, D, device=dev)
             pe_o, re_o, c_o = (torch.empty(P, k, device=dev) for _ in range(3))
-            si_o, gi_o = (torch.empty(P, k, dtype=torch.int64, device=dev) for _ in range(2))
+            si_o, gi_o = torch.empty(P, k, dtype=torch.int64, device=dev), torch.empty(P, k, T, dtype=torch.int64, device=dev)
             linalg_hip.ik_rank(ok_o, sol_o, pe_o, re_o, c_o, si_o, gi_o, q.view(P * S, D), cost.view(P * S), m.pose_pos_dist.view(P * S, T),
                                m.pose_rot_dist.view(P * S, T), m.self_dist.view(P * S), m.cspace_cost.view(P * S, D),
                                m.scene_dist if self.scene is not None else None, m.goalset_idx.view(P * S, T),
@@ -271,22 +272,23 @@ class IKSolver:
             sq = (lambda x: x) if k > 1 else (lambda x: x[:, 0])  # noqa: E731
             return IKResult(success=sq(ok_o.bool()), solution=sq(sol_o), position_error=sq(pe_o), rotation_error=sq(re_o),
                             cost=sq(c_o), seed_index=sq(si_o), goalset_index=sq(gi_o))
-        pos_err = m.pose_pos_dist.view(P, S, T)[..., 0]
-        rot_err = m.pose_rot_dist.view(P, S, T)[..., 0]
+        pos_all, rot_all = m.pose_pos_dist.view(P, S, T), m.pose_rot_dist.view(P, S, T)
+        pos_err, rot_err = pos_all.max(-1).values, rot_all.max(-1).values  # the largest error over the tool frames
         feasible = (m.self_dist.view(P, S) <= 0.0) & (m.cspace_cost.view(P, S, D).sum(-1) <= 0.0)
         if self.scene is not None:
             feasible &= m.scene_dist.view(P, S, -1).sum(-1) <= 0.0
-        ok = feasible & (pos_err < self.cfg.position_threshold) & (rot_err < self.cfg.rotation_threshold)
+        # converged on every tool frame (reference: torch.all over the per-link convergence list, solver_ik.py:463-476)
+        ok = feasible & (pos_all < self.cfg.position_threshold).all(-1) & (rot_all < self.cfg.rotation_threshold).all(-1)
         ranked = cost.view(P, S) + 1e16 * (~ok).float()  # reference solver_ik.py:503-509
-        gidx = m.goalset_idx.view(P, S, T)[..., 0].float()
+        gidx = m.goalset_idx.view(P, S, T).float()
         payload = torch.cat([q.view(P, S, D), pos_err.unsqueeze(-1), rot_err.unsqueeze(-1), ok.float().unsqueeze(-1),
-                             cost.view(P, S, 1), gidx.unsqueeze(-1)], dim=-1)
+                             cost.view(P, S, 1), gidx], dim=-1)
         if return_seeds > 1:
             _, idx, win = global_topk(ranked, payload, self.seed_offset, return_seeds)
             return IKResult(success=win[..., D + 2] > 0.5, solution=win[..., :D], position_error=win[..., D],
                             rotation_error=win[..., D + 1], cost=win[..., D + 3], seed_index=idx,
-                            goalset_index=win[..., D + 4].long())
+                            goalset_index=win[..., D + 4:D + 4 + T].long())
         _, idx, win = global_argmin(ranked, payload, self.seed_offset)
         return IKResult(success=win[:, D + 2] > 0.5, solution=win[:, :D], position_error=win[:, D],
                         rotation_error=win[:, D + 1], cost=win[:, D + 3], seed_index=idx,
-                        goalset_index=win[:, D + 4].long())
+                        goalset_index=win[:, D + 4:D + 4 + T].long())

@@ -217,23 +217,22 @@ class InverseKinematics:
 
     def solve_pose(self, goal_tool_poses: GoalToolPose, seed_config: Optional[torch.Tensor] = None, return_seeds: int = 1,
                    **unused) -> InverseKinematicsResult:
-        """``goal_tool_poses``: GoalToolPose [batch, 1, T, num_goalset, 3 | 4] (first tool frame is the goal frame; a goal
-        set smaller than ``config.max_goalset`` is padded with its last pose, a larger one rebuilds the solvers);
-        ``seed_config`` [batch, num_seeds, dof] optional warm starts."""
+        """``goal_tool_poses``: GoalToolPose [batch, 1, T, num_goalset, 3 | 4] -- the goal of EVERY tool frame of the robot
+        (``tool_frames`` order), as the reference's solve_pose takes it (solver_ik.py:631-700); a goal set smaller than
+        ``config.max_goalset`` is padded with its last pose, a larger one rebuilds the solvers; ``seed_config``
+        [batch, num_seeds, dof] optional warm starts."""
         t0 = time.perf_counter()
-        gp, gq = goal_tool_poses.static_goals()
-        B, G = int(gp.shape[0]), int(gp.shape[2])
+        gp, gq = goal_tool_poses.static_goals(self.tool_frames)  # [batch, T, G, 3 | 4], the robot's frame order
+        B, T, G = int(gp.shape[0]), int(gp.shape[1]), int(gp.shape[2])
         if G > self.config.max_goalset:
             self.config.max_goalset = G
             self._solvers.clear()
         M = self.config.max_goalset
         slv = self._solver(B)
-        pos, quat = gp[:, 0].reshape(B, G, 3), gq[:, 0].reshape(B, G, 4)
+        pos, quat = gp.reshape(B, T, G, 3), gq.reshape(B, T, G, 4)
         if G < M:
-            pos = torch.cat([pos, pos[:, -1:].expand(B, M - G, 3)], 1)
-            quat = torch.cat([quat, quat[:, -1:].expand(B, M - G, 4)], 1)
-        if M == 1:
-            pos, quat = pos[:, 0], quat[:, 0]
+            pos = torch.cat([pos, pos[:, :, -1:].expand(B, T, M - G, 3)], 2)
+            quat = torch.cat([quat, quat[:, :, -1:].expand(B, T, M - G, 4)], 2)
         r = slv.solve_pose(pos, quat, seeds=seed_config, return_seeds=return_seeds, exit_early=self.config.exit_early)
         torch.cuda.synchronize(pos.device) if pos.is_cuda else None
         self.solve_time = time.perf_counter() - t0
@@ -242,5 +241,5 @@ class InverseKinematics:
         return InverseKinematicsResult(
             success=r.success.reshape(B, k), solution=sol, js_solution=JointState.from_position(sol, joint_names=self.joint_names),
             position_error=r.position_error.reshape(B, k), rotation_error=r.rotation_error.reshape(B, k),
-            goalset_index=None if r.goalset_index is None else r.goalset_index.reshape(B, k), solve_time=self.solve_time,
+            goalset_index=None if r.goalset_index is None else r.goalset_index.reshape(B, k, T), solve_time=self.solve_time,
             debug_info={"optimizer_ran": bool(getattr(slv, "optimizer_ran", True))})

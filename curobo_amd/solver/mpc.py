@@ -107,11 +107,8 @@ class MPCSolver:
 
     def update_goal_tool_poses(self, goal_tool_poses: GoalToolPose) -> None:
         """tracked tool poses [B, 1, T, 1, 3 | 4]; may change between control steps (reference :365-438)"""
-        gp, gq = goal_tool_poses.static_goals()
+        gp, gq = goal_tool_poses.static_goals(list(self.kin.tool_frames))  # every tool frame, the robot's frame order
         gp, gq = gp.to(self.device, torch.float32).contiguous(), gq.to(self.device, torch.float32).contiguous()
-        T = self.kin.num_pose_links
-        if gp.shape[1] != T:
-            gp, gq = gp[:, :1].expand(-1, T, -1, -1).contiguous(), gq[:, :1].expand(-1, T, -1, -1).contiguous()
         self.rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._rows)
         self.metrics_rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._mrows)
 

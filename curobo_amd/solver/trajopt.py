@@ -38,7 +38,7 @@ import torch
 from ..distributed import global_topk, shard_range
 from ..optim import LBFGSOpt, LBFGSOptCfg
 from ..robot.kinematics_params import KinematicsParams
-from ..rollout.trajopt_rollout import TrajOptRollout, TrajOptRolloutCfg
+from ..rollout.trajopt_rollout import TrajOptRollout, TrajOptRolloutCfg, joint_limit_vector
 from ..scene.data import SceneData
 from .ik import IKSolver, IKSolverCfg
 
@@ -257,9 +257,9 @@ class TrajOptSolver:
         from ..util.trajectory import calculate_dt_no_clamp
 
         rc, D = self.cfg.rollout, self.kin.num_dof
-        ones = torch.ones(D, device=self.device)
         vmax = self.kin.joint_limits_velocity[1].abs()
-        score = calculate_dt_no_clamp(velocity, acceleration, jerk, vmax, rc.max_acceleration * ones, rc.max_jerk * ones, epsilon)
+        amax, jmax = joint_limit_vector(rc.max_acceleration, D, self.device), joint_limit_vector(rc.max_jerk, D, self.device)  # per joint
+        score = calculate_dt_no_clamp(velocity, acceleration, jerk, vmax, amax, jmax, epsilon)
         base = dt if dt is not None else torch.full_like(score, rc.traj_dt)
         return torch.clamp(score * base, min=self.cfg.minimum_trajectory_dt, max=self.cfg.maximum_trajectory_dt)
 
@@ -636,6 +636,8 @@ class _InterpolatedCheck:
         ok &= ((pos >= lo - 1e-4) & (pos <= hi + 1e-4)).all(-1).all(-1)
         vmax = k.joint_limits_velocity[1].abs()
         ok &= (vel.abs() <= vmax * (1.0 + 1e-3) + 1e-4).all(-1).all(-1)
-        ok &= (acc.abs() <= rc.max_acceleration * (1.0 + 1e-3) + 1e-4).all(-1).all(-1)
-        ok &= (jerk.abs() <= rc.max_jerk * (1.0 + 1e-3) + 1e-4).all(-1).all(-1)
+        amax = joint_limit_vector(rc.max_acceleration, acc.shape[-1], acc.device)  # every joint against ITS OWN limit
+        jmax = joint_limit_vector(rc.max_jerk, jerk.shape[-1], jerk.device)
+        ok &= (acc.abs() <= amax * (1.0 + 1e-3) + 1e-4).all(-1).all(-1)
+        ok &= (jerk.abs() <= jmax * (1.0 + 1e-3) + 1e-4).all(-1).all(-1)
         return ok

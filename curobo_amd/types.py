@@ -164,9 +164,20 @@ class GoalToolPose:
     def device(self):
         return self.position.device
 
-    def static_goals(self):
-        """(position [batch, num_links, num_goalset, 3], quaternion [batch, num_links, num_goalset, 4]): what the solvers read"""
-        return self.position[:, -1], self.quaternion[:, -1]
+    def static_goals(self, ordered_tool_frames: Optional[List[str]] = None):
+        """(position [batch, num_links, num_goalset, 3], quaternion [batch, num_links, num_goalset, 4]): what the solvers read.
+        ``ordered_tool_frames`` = the robot's tool frames: the goal must name exactly those (any order) and is returned in
+        that order -- the kernels index goals by the robot's frame order (reference ToolPose.reorder_links,
+        tool_pose.py:147-163)."""
+        pos, quat = self.position[:, -1], self.quaternion[:, -1]
+        if ordered_tool_frames is None or list(ordered_tool_frames) == list(self.tool_frames):
+            return pos, quat
+        want = list(ordered_tool_frames)
+        if len(want) != len(self.tool_frames) or set(want) != set(self.tool_frames):
+            raise ValueError(f"the goal names the tool frames {list(self.tool_frames)}, the robot has {want}: every tool frame needs a goal "
+                             "(ToolPoseCriteria can switch a frame's axes off)")
+        idx = torch.as_tensor([self.tool_frames.index(n) for n in want], device=pos.device)
+        return pos.index_select(1, idx), quat.index_select(1, idx)
 
     @classmethod
     def from_poses(cls, pose_dict, ordered_tool_frames: Optional[List[str]] = None, num_goalset: int = 1) -> "GoalToolPose":

@@ -465,7 +465,9 @@ int curobo_hip_seed_ik_batch_status(const uint8_t *success, int num_problems, in
  * error (+ start_cspace_dist_weight |q - current_position|) + 1e10 for failures; the return_seeds best, best first.
  * curobo_hip_ik_rank: reference IKSolver._get_result (solver_ik.py:440-580): feasible = no self collision, no
  * joint-limit cost, no scene collision (scene_distance [P, S, num_scene_columns], NULL = no scene), success = feasible
- * and first tool frame within the thresholds, ranked by cost + 1e16 for failures.  num_seeds <= 1024. */
+ * and EVERY tool frame within the thresholds (position_distance / rotation_distance / goalset_idx [P, S, T]), ranked by
+ * cost + 1e16 for failures; out_position_error / out_rotation_error [P, k] = the largest error over the tool frames,
+ * out_goalset_index [P, k, T] (ABI 6: one column per tool frame, as the reference returns it).  num_seeds <= 1024. */
 int curobo_hip_seed_ik_select(
     uint8_t *out_success, float *out_solution, float *out_position_error, float *out_orientation_error,
     const float *joint_position, const float *position_error, const float *orientation_error, const float *limit_lower,

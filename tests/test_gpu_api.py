@@ -392,3 +392,96 @@ def test_jacobian_output_is_differentiable(robot, device):
     q3 = torch.as_tensor(qn, device=device).requires_grad_(True)
     (kin.compute_kinematics(q3).tool_poses.position * wp).sum().backward()
     torch.testing.assert_close(q2.grad, q.grad + q3.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()))
+
+
+def test_collision_checker_sphere_level_api(oracle, device):
+    """The sphere-level entry points of the reference's RobotSceneCollision (collision_robot_scene.py:70-245, :418-495), one by
+    one against the oracle: get_kinematics, get_collision_distance / _constraint / _vector, get_self_collision(_distance),
+    pose_distance, get_point_robot_distance, clear_scene_cache."""
+    from sweep_allowance import device_frame_arithmetic
+
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.types import Pose
+    from curobo_amd.workloads import c2_world
+
+    model = load_model("franka")
+    md = model.as_dict()
+    arrays = cuboid_scene_arrays(c2_world())
+    eta = 0.02
+    chk = RobotCollisionChecker(KinematicsCfg.from_packaged("franka", device=device), SceneData.from_arrays(arrays, device),
+                                activation_distance=eta)
+    B, H = 12, 4
+    q = sample_q(model, B * H, seed=4, scale=0.9).reshape(B, H, 7)
+    tq = torch.as_tensor(q, device=device)
+    # ---- get_kinematics
+    state = chk.get_kinematics(tq)
+    fk = oracle.kinematics_forward(q.reshape(-1, 7), md, horizon=H)
+    sph = fk["robot_spheres"].reshape(B, H, -1, 4)
+    np.testing.assert_allclose(state.robot_spheres.cpu().numpy(), sph, atol=1e-5)
+    with pytest.raises(ValueError, match="batch, horizon, dof"):
+        chk.get_kinematics(tq[:, 0])
+    # the collision entry points are checked on the ORACLE's spheres (identical inputs)
+    ts = torch.as_tensor(sph, device=device)
+    # ---- scene: cost (activation shell), constraint (eta = 0), vector
+    with device_frame_arithmetic(oracle):
+        ref = oracle.scene_collision(sph, arrays, 1.0, eta)
+        ref0 = oracle.scene_collision(sph, arrays, 1.0, 0.0)
+    d = chk.get_collision_distance(ts).detach().cpu().numpy()
+    assert d.shape == (B, H, model.num_spheres) and (ref["distance"] > 0).sum() > 50
+    assert np.array_equal(d > 0, ref["distance"] > 0)
+    np.testing.assert_allclose(d, ref["distance"], rtol=1e-5, atol=1e-6)
+    d_state = chk.get_collision_distance(state).detach().cpu().numpy()  # a kinematics state is accepted as well
+    np.testing.assert_allclose(d_state, d, rtol=1e-4, atol=1e-5)  # (device FK vs oracle FK: 1e-6 m apart)
+    c = chk.get_collision_constraint(ts).detach().cpu().numpy()
+    assert np.array_equal(c > 0, ref0["distance"] > 0) and (c > 0).sum() < (d > 0).sum()
+    np.testing.assert_allclose(c, ref0["distance"], rtol=1e-5, atol=1e-6)
+    dv, vec = chk.get_collision_vector(ts)
+    np.testing.assert_allclose(dv.cpu().numpy(), ref["distance"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(vec.cpu().numpy(), ref["gradient"], rtol=1e-3, atol=2e-4)
+    # differentiable in the spheres: the gradient of the summed cost is the vector
+    ts2 = ts.clone().requires_grad_(True)
+    chk.get_collision_distance(ts2).sum().backward()
+    np.testing.assert_allclose(ts2.grad.cpu().numpy(), ref["gradient"], rtol=1e-3, atol=2e-4)
+    # ---- self collision
+    # (configurations folded into themselves: joint angles scaled past the limits, FK does not mind)
+    sph_s = oracle.kinematics_forward(q.reshape(-1, 7) * 1.7, md, horizon=H)["robot_spheres"].reshape(B, H, -1, 4)
+    rs = oracle.self_collision(sph_s, model.sphere_padding, model.collision_pairs, 1.0)
+    ts_s = torch.as_tensor(sph_s, device=device)
+    ds = chk.get_self_collision(ts_s).detach().cpu().numpy()
+    assert ds.shape == (B, H, 1) and (rs["distance"] > 0).sum() >= 3
+    np.testing.assert_allclose(ds.reshape(-1), rs["distance"].reshape(-1), rtol=1e-5, atol=1e-7)
+    assert np.array_equal(chk.get_self_collision_distance(ts_s).detach().cpu().numpy(), ds)
+    # ---- pose distance: position error + geodesic rotation error
+    rng = np.random.default_rng(1)
+    p0, p1 = rng.normal(size=(B, 3)).astype(np.float32), rng.normal(size=(B, 3)).astype(np.float32)
+    q0, q1 = rng.normal(size=(B, 4)).astype(np.float32), rng.normal(size=(B, 4)).astype(np.float32)
+    q0 /= np.linalg.norm(q0, axis=-1, keepdims=True)
+    q1 /= np.linalg.norm(q1, axis=-1, keepdims=True)
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    pdist = chk.pose_distance(Pose(t(p0), t(q0)), Pose(t(p1), t(q1)), resize=True).cpu().numpy()
+    want = oracle.tool_pose_distance(p1.reshape(B, 1, 1, 3), q1.reshape(B, 1, 1, 4), p0.reshape(B, 1, 1, 3), q0.reshape(B, 1, 1, 4),
+                                     np.arange(B, dtype=np.int32), np.ones(2, np.float32), np.ones(6, np.float32), np.ones(6, np.float32),
+                                     np.zeros(2, np.float32), np.zeros(2, np.float32), np.zeros(1, np.uint8))
+    np.testing.assert_allclose(pdist, (want["position_distance"] + want["rotation_distance"]).reshape(B), rtol=1e-4, atol=1e-5)
+    same = chk.pose_distance(Pose(t(p0), t(q0)), Pose(t(p0), t(q0)), resize=True).cpu().numpy()
+    assert np.abs(same).max() < 1e-3
+    # ---- points against the robot: depth inside the union of its spheres
+    q1c = tq[:1, 0]
+    pts = rng.uniform(-0.6, 0.8, size=(500, 3)).astype(np.float32)
+    s1 = sph[0, 0]
+    live = s1[:, 3] >= 0
+    pts[:40] = s1[live][:40, :3] + rng.normal(size=(40, 3)).astype(np.float32) * 0.01  # some points inside the robot
+    got = chk.get_point_robot_distance(t(pts), q1c).cpu().numpy()
+    wantp = (s1[live, 3][None] - np.linalg.norm(pts[:, None] - s1[live, :3][None], axis=-1)).max(-1)
+    np.testing.assert_allclose(got, wantp, atol=1e-5)
+    assert (got > 0).any() and (got < 0).any()
+    gotb = chk.get_point_robot_distance(t(pts).view(2, 250, 3), q1c).cpu().numpy()
+    np.testing.assert_allclose(gotb.reshape(-1), wantp, atol=1e-5)
+    with pytest.raises(ValueError, match=r"\[b, dof\]"):
+        chk.get_point_robot_distance(t(pts), q1c[0])
+    # ---- clear_scene_cache: an empty world of the same capacity
+    assert chk.tool_frames == chk.kinematics.tool_frames
+    chk.clear_scene_cache()
+    assert float(chk.get_collision_distance(ts).abs().sum()) == 0.0

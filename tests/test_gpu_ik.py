@@ -242,7 +242,8 @@ def test_ik_solver_goalset(oracle, device):
     torch.cuda.synchronize()
     succ = res.success.cpu().numpy()
     assert succ.mean() >= 0.85, f"goal-set IK success rate {succ.mean():.2f}"
-    member = res.goalset_index.cpu().numpy()
+    assert res.goalset_index.shape == (P, 1), "one member index per tool frame"
+    member = res.goalset_index[:, 0].cpu().numpy()
     assert set(np.unique(member[succ])) <= {1, 2}
     qs = res.solution.cpu().numpy()[succ]
     chk = oracle.kinematics_forward(qs, md)
@@ -253,7 +254,7 @@ def test_ik_solver_goalset(oracle, device):
     assert (2 * np.arccos(np.clip(dotq, 0, 1)) < 0.05).all()
     # the top-k interface returns distinct ranked seeds per problem, best first
     top = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq), return_seeds=4)
-    assert top.solution.shape == (P, 4, kin.num_dof) and top.goalset_index.shape == (P, 4)
+    assert top.solution.shape == (P, 4, kin.num_dof) and top.goalset_index.shape == (P, 4, 1)
     c = top.cost.cpu().numpy() + 1e16 * (~top.success.cpu().numpy())
     assert (np.diff(c, axis=1) >= 0).all()
     assert top.success[:, 0].float().mean().item() >= 0.85  # (the seed sampler advances between solves: not the same seeds)

@@ -21,12 +21,15 @@ def _setup(device):
     return model, kin, arrays, SceneData.from_arrays(arrays, device)
 
 
-@pytest.mark.parametrize("fused,torque", [(False, False), (True, False), (False, True), (True, True)])
-def test_trajopt_rollout_matches_oracle_composition(fused, torque, oracle, device):
+@pytest.mark.parametrize("fused,torque,per_joint", [(False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                                    (False, False, True), (True, False, True)])
+def test_trajopt_rollout_matches_oracle_composition(fused, torque, per_joint, oracle, device):
     """non-swept scene term for the strict comparison (the sweep has the documented zero-motion
     discontinuity); every cost term of the reference trajopt task is active.  ``torque``: plus the
     joint-torque limits on the inverse-dynamics torques (RNEA forward, effort bound + regularisation in
-    the c-space STATE cost, RNEA VJP) -- the reference's torque-limited motion generation."""
+    the c-space STATE cost, RNEA VJP) -- the reference's torque-limited motion generation.  ``per_joint``: acceleration and
+    jerk limits as one value PER JOINT (reference JointLimits.acceleration / .jerk, kinematics_loader.py:1102-1124), tight
+    enough on some joints that their bound terms are active while the other joints' are not."""
     from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
     from curobo_amd.workloads import seed_knots, start_configuration
 
@@ -37,6 +40,9 @@ def test_trajopt_rollout_matches_oracle_composition(fused, torque, oracle, devic
         cfg.use_torque_limits, cfg.effort_limit = True, [12.0, 25.0, 10.0, 10.0, 2.0, 1.5, 0.5]
         cfg.cspace_weight = [10000.0, 10000.0, 100.0, 50.0, 30.0]
         cfg.cspace_regularization = [1000.0, 10000.0, 5.0, 0.02, 10000.0]
+    if per_joint:
+        cfg.max_acceleration = [200.0, 50.0, 200.0, 30.0, 200.0, 60.0, 200.0]
+        cfg.max_jerk = [1.0e4, 1.0e3, 1.0e4, 1.0e4, 5.0e2, 1.0e4, 2.0e3]
     B, nk, D, H = 10, cfg.n_knots, kin.num_dof, cfg.padded_horizon
     knots = seed_knots(model, B, nk, seed=4, spread=0.6)
     start = start_configuration(model)
@@ -64,8 +70,11 @@ def test_trajopt_rollout_matches_oracle_composition(fused, torque, oracle, devic
                                      np.full((T, 2), 1e-8, np.float32), np.full((T, 2), 1e-8, np.float32), np.zeros(T, np.uint8), 0)
     ones = np.ones(D, np.float32)
     lim = {"position": model.joint_limits_position.astype(np.float32), "velocity": model.joint_limits_velocity.astype(np.float32),
-           "acceleration": np.stack([-cfg.max_acceleration * ones, cfg.max_acceleration * ones]),
-           "jerk": np.stack([-cfg.max_jerk * ones, cfg.max_jerk * ones])}
+           "acceleration": np.stack([-np.asarray(cfg.max_acceleration, np.float32) * ones, np.asarray(cfg.max_acceleration, np.float32) * ones]),
+           "jerk": np.stack([-np.asarray(cfg.max_jerk, np.float32) * ones, np.asarray(cfg.max_jerk, np.float32) * ones])}
+    if per_joint:  # some joints are beyond their own limit somewhere, others never reach theirs: the bound is per joint
+        a_abs, a_lim = np.abs(s["acceleration"]).max((0, 1)), np.asarray(cfg.max_acceleration, np.float32)
+        assert (a_abs > a_lim).any() and (a_abs < a_lim).any(), (a_abs, a_lim)
     extra = {}
     if torque:
         grav = np.array(cfg.gravity, np.float32)

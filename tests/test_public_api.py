@@ -352,8 +352,8 @@ def test_kinematics_accessors_and_result_helpers():
 
 def test_solver_configurations_take_the_robot_files_acceleration_and_jerk_limits():
     """the trajectory optimiser and MPC front ends bound acceleration / jerk by the robot file's cspace values (reference:
-    JointLimits.acceleration / .jerk from CSpaceParams) when they are one value for all joints: UR10e 12 / 500, Franka 15 / 500;
-    the G1's per-joint lists do not fit the rollouts' scalar and leave the configuration's default"""
+    JointLimits.acceleration / .jerk from CSpaceParams): UR10e 12 / 500, Franka 15 / 500 (one value for all joints), and the
+    G1's PER-JOINT lists as lists -- the rollouts' bound tensors are [2, dof]"""
     from curobo_amd.kinematics import KinematicsCfg
     from curobo_amd.model_predictive_control import ModelPredictiveControlCfg
     from curobo_amd.motion_planner import TrajectoryOptimizerCfg, robot_acceleration_jerk_limits
@@ -363,8 +363,27 @@ def test_solver_configurations_take_the_robot_files_acceleration_and_jerk_limits
     assert robot_acceleration_jerk_limits(ur) == (12.0, 500.0)
     assert robot_acceleration_jerk_limits(fr) == (15.0, 500.0)
     assert robot_acceleration_jerk_limits(None) == (None, None)
+    assert robot_acceleration_jerk_limits(g1) == (10.0, 500.0)  # (the G1 file lists 49 equal values)
+    # a robot file with a different value per joint: the list goes through joint by joint
+    import copy
+    import dataclasses
+
+    want_a = [8.0 + 0.25 * i for i in range(g1.model.num_dof)]
+    model2 = dataclasses.replace(g1.model, cspace=dict(copy.deepcopy(g1.model.cspace), max_acceleration=want_a))
+    g1 = dataclasses.replace(g1, model=model2)
     acc, jerk = robot_acceleration_jerk_limits(g1)
-    assert acc is None or isinstance(acc, float)
+    assert acc == want_a and jerk == 500.0
+    c = TrajectoryOptimizerCfg(kinematics=g1).solver_cfg()
+    assert c.rollout.max_acceleration == want_a
+    from curobo_amd.rollout.trajopt_rollout import joint_limit_vector
+
+    v = joint_limit_vector(c.rollout.max_acceleration, g1.model.num_dof, "cpu")
+    assert v.shape == (g1.model.num_dof,) and np.allclose(v.numpy(), want_a)
+    assert joint_limit_vector(12.0, 6, "cpu").tolist() == [12.0] * 6
+    with pytest.raises(ValueError, match="one per active joint"):
+        joint_limit_vector([1.0, 2.0], 6, "cpu")
+    with pytest.raises(ValueError, match="positive"):
+        joint_limit_vector([1.0, 0.0, 1.0], 3, "cpu")
     c = TrajectoryOptimizerCfg(kinematics=ur).solver_cfg()
     assert (c.rollout.max_acceleration, c.rollout.max_jerk) == (12.0, 500.0)
     c = TrajectoryOptimizerCfg(kinematics=fr).solver_cfg()

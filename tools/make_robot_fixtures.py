@@ -49,7 +49,7 @@ def reference_pairs(model, cfg_yaml):
 def main():
     out_dir = os.path.join(ROOT, "curobo_amd", "content", "robot")
     os.makedirs(out_dir, exist_ok=True)
-    for name in ("franka", "ur10e", "unitree_g1"):
+    for name in ("franka", "ur10e", "dual_ur10e", "unitree_g1"):
         yml = os.path.join(CONTENT, "configs", "robot", f"{name}.yml")
         model = load_robot_model(yml, os.path.join(CONTENT, "assets"))
         if name != "unitree_g1":  # the O(S^2) python loop of the reference takes minutes on G1
