@@ -93,7 +93,10 @@ def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8) -> DeviceMesh:
     """vertices [V, 3] (mesh frame), faces [F, 3] -> the linear BVH on ``device``: Morton keys of the centroids (HIP), the
     sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level)"""
     import os
-    leaf_size = int(os.environ.get("CUROBO_MESH_LEAF_SIZE", leaf_size))  # development knob
+    try:  # development knob (a malformed value is ignored)
+        leaf_size = max(1, int(os.environ.get("CUROBO_MESH_LEAF_SIZE", leaf_size)))
+    except ValueError:
+        pass
     v = torch.as_tensor(np.ascontiguousarray(vertices, np.float32)).to(device).contiguous()
     f = torch.as_tensor(np.ascontiguousarray(faces, np.int32)).to(device).contiguous()
     if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3 or f.shape[0] == 0:
@@ -146,8 +149,12 @@ def sphere_mesh_collision(distance, gradient, spheres, mesh_set: MeshSet, weight
                           horizon: int, num_spheres: int, use_multi_env: bool, sweep_steps: int = 0, enable_speed_metric: bool = False,
                           speed_dt=None, accumulate: bool = True, workspace=None):
     """the mesh share of the scene-collision forward (``curobo_hip_sphere_mesh_collision_ws``: survivors of the bounding-box
-    reject queued launch-wide, see include/curobo_hip.h; ``workspace=False`` runs the one-kernel form).  The workspace is kept
-    per (device, size): launches on one stream are ordered, and a captured graph keeps its pointer alive through this cache."""
+    reject queued launch-wide, see include/curobo_hip.h; ``workspace=False`` runs the one-kernel form).  Without a caller-owned
+    ``workspace`` one is kept per OUTPUT BUFFER (device, size, address of ``distance``): the counter and queue of a launch
+    belong to the rollout that owns the output, so rollouts of equal size that run concurrently -- the seed shards of
+    ``PipelinedLBFGS`` on their own streams, the parallel branches of one captured graph -- never share them (a cache keyed
+    by size alone let one shard's select kernel clear or fill the queue another shard's walk kernel was reading); launches
+    into one output buffer are ordered by its owner's stream, and a captured graph keeps its pointer alive through the cache."""
     lib = load()
     if workspace is False:
         check(lib.curobo_hip_sphere_mesh_collision(
@@ -159,7 +166,7 @@ def sphere_mesh_collision(distance, gradient, spheres, mesh_set: MeshSet, weight
     check(lib.curobo_hip_sphere_mesh_collision_ws_bytes(batch_size, horizon, num_spheres, C.cast(C.pointer(nbytes), C.c_void_p)))
     need = int(nbytes.value)
     if workspace is None:
-        key = (distance.device, need)
+        key = (distance.device, need, int(distance.data_ptr()))
         workspace = _WORKSPACES.get(key)
         if workspace is None:
             workspace = _WORKSPACES[key] = torch.empty(need, dtype=torch.uint8, device=distance.device)

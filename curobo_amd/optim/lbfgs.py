@@ -73,6 +73,10 @@ class LBFGSOpt:
         # set by PipelinedLBFGS: this optimiser's launches run next to the rollouts of other seed shards, so its
         # iteration tail takes the form that does not wait for their LDS / registers (one wavefront per problem)
         self.overlapped = False
+        # set by a solver whose SEED axis is sharded over the ranks of torch.distributed (IKSolver / TrajOptSolver with
+        # global_num_seeds): only then is the convergence exit a collective -- ranks that solve independent problems must not
+        # meet in an all-reduce they enter a different number of times
+        self.rank_sharded = False
         if self.opt_dim >= 1024:  # reference lbfgs.py:177
             raise ValueError("opt_dim must be < 1024 for the fused L-BFGS step")
         if cfg.history > 31:
@@ -236,7 +240,7 @@ class LBFGSOpt:
         total = float(self.converged.numel())
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.rank_sharded and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from ..distributed import all_reduce_sum
 
             both = all_reduce_sum(torch.cat([n, torch.tensor([total], device=n.device)]))

@@ -110,10 +110,30 @@ class PipelinedLBFGS:
             self._forked(lambda o: o._opt_iters())
 
     def optimize(self, seed: torch.Tensor) -> torch.Tensor:
+        """``cfg.fixed_iters=False``: stop after the first block of ``inner_iters`` iterations at whose end more than
+        ``cfg.converged_ratio`` of ALL problems (over the shards) have converged (reference BestTracker.check_convergence,
+        optim/components/best_tracker.py:109-118; one device -> host read per block, as in ``LBFGSOpt.optimize``)."""
         self.reinitialize(seed)
+        self.iterations_run = 0
         for _ in range(max(1, self.cfg.num_iters // self.cfg.inner_iters)):
             self.run_inner()
+            self.iterations_run += self.cfg.inner_iters
+            if not self.cfg.fixed_iters and self._enough_converged():
+                break
         return self.best_action.view(self.cfg.num_problems, self.action_horizon, self.action_dim)
+
+    def _enough_converged(self) -> bool:
+        n = sum(torch.count_nonzero(o.converged).to(torch.float32) for o in self.opts).reshape(1)
+        total = float(sum(o.converged.numel() for o in self.opts))
+        if any(o.rank_sharded for o in self.opts):
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from ..distributed import all_reduce_sum
+
+                both = all_reduce_sum(torch.cat([n, torch.tensor([total], device=n.device)]))
+                n, total = both[:1], float(both[1])
+        return float(n.item()) > total * self.cfg.converged_ratio
 
     # ------------------------------------------------------------------ results (seed order of the input)
     @property

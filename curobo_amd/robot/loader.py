@@ -480,17 +480,32 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
     # (kinematics_loader.py:1102-1124 _update_joint_limits; the scale is per cspace joint name, reindexed to the active joints by
     # CSpaceParams.inplace_reindex, cspace_params.py:149-171; a clip given as a list is applied in the order it is written)
     cs = cfg.get("cspace") or {}
-    clip = cs.get("position_limit_clip", 0.0)
-    clip = np.full(D, float(clip)) if isinstance(clip, (int, float)) else np.asarray(clip, np.float64).reshape(-1)
+
+    def per_active_joint(key, value):
+        """a scalar / one-element list (every joint) or a list -> [D] in the order of the ACTIVE joints: a list as long as
+        cspace.joint_names is reindexed by name (CSpaceParams.inplace_reindex), a list of length D is taken as written"""
+        if isinstance(value, (int, float)):
+            return np.full(D, float(value))
+        v = [float(x) for x in np.asarray(value, np.float64).reshape(-1)]
+        if len(v) == 1:
+            return np.full(D, v[0])
+        names = cs.get("joint_names")
+        if names is not None and len(names) == len(v):
+            lut = dict(zip(names, v))
+            missing = [n for n in joint_names if n not in lut]
+            if missing:
+                raise ValueError(f"cspace.{key}: cspace.joint_names does not list the active joint(s) {missing}")
+            return np.asarray([lut[n] for n in joint_names])
+        if len(v) == D:
+            return np.asarray(v)
+        raise ValueError(f"cspace.{key} holds {len(v)} values: expected one, one per active joint ({D}: {list(joint_names)})"
+                         + (f" or one per cspace.joint_names entry ({len(names)})" if names is not None else
+                            " (or give cspace.joint_names to reindex a longer list by name)"))
+
+    clip = per_active_joint("position_limit_clip", cs.get("position_limit_clip", 0.0))
     pos_lim[0] += clip
     pos_lim[1] -= clip
-    vscale = cs.get("velocity_scale", 1.0)
-    if isinstance(vscale, (int, float)) or len(vscale) == 1:
-        vscale = np.full(D, float(vscale if isinstance(vscale, (int, float)) else vscale[0]))
-    else:
-        lut = dict(zip(cs["joint_names"], vscale))
-        vscale = np.asarray([float(lut[n]) for n in joint_names])
-    vel_lim = vel_lim * vscale[None]
+    vel_lim = vel_lim * per_active_joint("velocity_scale", cs.get("velocity_scale", 1.0))[None]
 
     masses_com = np.stack([np.concatenate([b.com, [b.mass]]) for b in bodies]).astype(np.float32)
     inertias = np.zeros((L, 8), dtype=np.float32)
@@ -498,18 +513,13 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
         inertias[i, :6] = b.inertia6
     cspace = dict(cfg.get("cspace") or {})
     # keep only the active joints of cspace lists (reference CSpaceParams.inplace_reindex)
-    if "joint_names" in cspace and "default_joint_position" in cspace:
+    if cspace.get("joint_names") is not None and cspace.get("default_joint_position") is not None:
         lut = dict(zip(cspace["joint_names"], cspace["default_joint_position"]))
         cspace["default_joint_position"] = [float(lut.get(n, 0.0)) for n in joint_names]
     # acceleration / jerk limits per ACTIVE joint (reference: JointLimits.acceleration / .jerk = -+ CSpaceParams.max_acceleration /
     # max_jerk after inplace_reindex, kinematics_loader.py:1102-1112; scalars are broadcast, cspace_params.py:45-50, 84-110)
     for key, default in (("max_acceleration", 10.0), ("max_jerk", 500.0)):
-        v = cspace.get(key, default)
-        if isinstance(v, (int, float)) or len(v) == 1:
-            cspace[key] = [float(v if isinstance(v, (int, float)) else v[0])] * D
-        else:
-            lut = dict(zip(cspace["joint_names"], v))
-            cspace[key] = [float(lut[n]) for n in joint_names]
+        cspace[key] = [float(x) for x in per_active_joint(key, cspace.get(key, default))]
 
     return RobotModel(
         fixed_transforms=fixed.astype(np.float32),

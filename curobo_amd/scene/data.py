@@ -160,8 +160,13 @@ class SceneData:
         if coarse_culling and t.get("voxel_features") is not None and t["voxel_features"].numel() > 0:
             block, dilate = 4, 3  # culls spheres whose sweep stays within 2 voxels of the centre's voxel
             import os
-            if os.environ.get("CUROBO_VOXEL_COARSE"):  # development knob: "block,dilate"
-                block, dilate = (int(v) for v in os.environ["CUROBO_VOXEL_COARSE"].split(","))
+            if os.environ.get("CUROBO_VOXEL_COARSE"):  # development knob: "block,dilate" (a malformed value is ignored)
+                try:
+                    b_, d_ = (int(v) for v in os.environ["CUROBO_VOXEL_COARSE"].split(","))
+                    if b_ >= 1 and d_ >= 0:
+                        block, dilate = b_, d_
+                except ValueError:
+                    pass
             coarse = t["voxel_coarse_min"] = build_voxel_coarse_min(t["voxel_features"], arrays["voxel_params"], block, dilate)
         struct = make_scene(
             t.get("cuboid_dims"), t.get("cuboid_inv_pose"), t.get("cuboid_enable"), t.get("cuboid_count"),

@@ -100,6 +100,8 @@ class IKSolver:
         else:
             self.optimizer = LBFGSOpt(ocfg, make_rollout(self.P * rows_per_problem), 1, kin.num_dof, bounds, self.device,
                                       use_cuda_graph=use_cuda_graph)
+        for o in getattr(self.optimizer, "opts", [self.optimizer]):
+            o.rank_sharded = self.S_global != self.S  # the seed axis is split over ranks: the convergence exit is a collective
         self.rollout = self.rollouts[0]
         self._row_goals = [(ro._first_problem + torch.arange(ro.batch_size, device=self.device) // rows_per_problem).to(torch.int32)
                            for ro in self.rollouts]

@@ -142,6 +142,7 @@ class TrajOptSolver:
         bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
         self.optimizer = LBFGSOpt(ocfg, self.rollout.cost_and_gradient, rc.n_knots, kin.num_dof, bounds, self.device,
                                   use_cuda_graph=use_cuda_graph)
+        self.optimizer.rank_sharded = self.S_global != self.S  # seeds split over ranks: the convergence exit is a collective
         self._check = _InterpolatedCheck(kin, scene, rc) if self.cfg.check_interpolated else None
 
     @classmethod

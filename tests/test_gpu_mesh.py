@@ -418,3 +418,49 @@ def test_collision_checker_from_a_scene_config_with_a_mesh_file(tmp_path, oracle
     d_scene, _ = chk.get_scene_self_collision_distance_from_joints(torch.as_tensor(q, device=device))
     torch.cuda.synchronize()
     np.testing.assert_allclose(d_scene.detach().cpu().numpy().reshape(256, -1), ref, atol=2e-5, rtol=1e-4)
+
+
+def test_seed_shards_over_a_mesh_scene_own_their_launch_workspaces(oracle, device):
+    """PipelinedLBFGS with two seed shards (two streams, the parallel branches of one captured graph) over rollouts of EQUAL
+    size in a mesh scene.  The queued mesh launch keeps a counter and a sphere queue per launch; cached by size alone they
+    were shared by the shards -- one shard's select kernel cleared or filled the queue the other's walk kernel was reading
+    (ADVICE round 4).  The workspace is now kept per output buffer: the shards must take the iterates of the one batch."""
+    from curobo_amd.backends import mesh as mesh_backend
+    from curobo_amd.optim import LBFGSOpt, LBFGSOptCfg, PipelinedLBFGS
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device, meshes=mesh_world())
+    cfg = CollisionRolloutCfg()
+    seeds = 16
+    ocfg = LBFGSOptCfg(num_problems=seeds, inner_iters=4, num_iters=8)
+    nls = len(ocfg.line_search_scale)
+    start = torch.as_tensor(start_configuration(model), device=device)
+    bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
+    made = []
+
+    def make(batch):
+        ro = CollisionRollout(kin, scene, batch, cfg)
+        assert not ro.fused_available()  # a mesh world runs the kernel sequence with the queued mesh launch
+        ro.update_start_state(start)
+        made.append(ro)
+        return ro.cost_and_gradient
+
+    x0 = torch.as_tensor(seed_knots(model, seeds, cfg.n_knots, seed=4, spread=0.4), device=device)
+    one = LBFGSOpt(ocfg, make(seeds * nls), cfg.n_knots, kin.num_dof, bounds, device)
+    ref = one.optimize(x0).clone()
+    ref_cost = one.best_cost.clone()
+    n_ws = len(mesh_backend._WORKSPACES)
+    pipe = PipelinedLBFGS(ocfg, make, cfg.n_knots, kin.num_dof, bounds, device, n_shards=2)
+    for _ in range(3):  # (replays of the captured graph: the race needed both shards in flight)
+        got = pipe.optimize(x0)
+    torch.cuda.synchronize()
+    assert len(made) == 3 and made[1].batch_size == made[2].batch_size, "two shards of equal size"
+    assert len(mesh_backend._WORKSPACES) >= n_ws + 2, "each shard's output buffer has its own launch workspace"
+    assert torch.isfinite(ref_cost).all() and float(ref_cost.max()) > 0
+    torch.testing.assert_close(pipe.best_cost, ref_cost, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)

@@ -89,3 +89,37 @@ def test_two_seed_shards_return_the_single_process_winners(device, tmp_path):
     ref_path = str(tmp_path / "single_process.npz")
     np.savez(ref_path, **ref)
     mp.spawn(_worker, args=(2, _free_port(), ref_path), nprocs=2, join=True)
+
+
+@pytest.mark.gpu
+def test_pipelined_lbfgs_takes_the_convergence_exit(device):
+    """LBFGSOptCfg.fixed_iters = False over seed shards (PipelinedLBFGS.optimize ignored it): a quadratic, 400
+    iterations allowed, stops after the first block at whose end more than converged_ratio of ALL problems carry the
+    line-search kernel's convergence flag -- same minimiser as the fixed-count run, far fewer iterations; and an optimiser
+    that is not a rank shard never enters a collective for it."""
+    import torch
+
+    from curobo_amd.optim import LBFGSOptCfg, PipelinedLBFGS
+
+    D, H, P = 7, 4, 8
+    target = torch.linspace(-0.5, 0.5, D * H, device=device)
+
+    def make(batch):
+        def cost_and_gradient(x):
+            d = x.view(batch, -1) - target
+            return (d * d).sum(-1), 2.0 * d
+        return cost_and_gradient
+
+    bounds = (-torch.ones(D, device=device) * 5, torch.ones(D, device=device) * 5)
+    torch.manual_seed(0)
+    x0 = torch.randn(P, H, D, device=device)
+    outs = {}
+    for fixed in (True, False):
+        cfg = LBFGSOptCfg(num_problems=P, num_iters=400, history=10, inner_iters=25, fixed_iters=fixed)
+        opt = PipelinedLBFGS(cfg, make, H, D, bounds, device, n_shards=2)
+        assert not any(o.rank_sharded for o in opt.opts)
+        outs[fixed] = (opt.optimize(x0.clone()).clone(), opt.iterations_run)
+    torch.cuda.synchronize()
+    assert outs[True][1] == 400 and 25 <= outs[False][1] < 400, outs[False][1]
+    for out, _ in outs.values():
+        assert float((out.view(P, -1) - target).abs().max()) < 1e-3

@@ -208,3 +208,41 @@ def test_kinematics_params_validate_shapes():
         dataclasses.replace(k, joint_links_offsets=k.joint_links_offsets[:-1]).validate_shapes()
     with pytest.raises(ValueError, match="joint_affects_endeffector"):
         dataclasses.replace(k, joint_affects_endeffector=k.joint_affects_endeffector.reshape(-1)[:-1]).validate_shapes()
+
+
+def test_cspace_lists_are_validated_with_descriptive_errors():
+    """cspace lists (velocity_scale, position_limit_clip, max_acceleration, max_jerk): one value, one per active joint, or one per
+    cspace.joint_names entry (reindexed by name); anything else is a ValueError that names the key (a bare
+    KeyError / a broadcast error)."""
+    import os
+
+    import yaml
+
+    from curobo_amd.robot.loader import build_robot_model
+    from curobo_amd.robot.urdf import load_urdf
+
+    ref = "/root/reference/curobo/content"
+    if not os.path.isdir(ref):
+        pytest.skip("needs the reference's robot files (this container)")
+    cfg = yaml.safe_load(open(os.path.join(ref, "configs", "robot", "ur10e.yml")))
+    cfg = cfg.get("robot_cfg", cfg)["kinematics"]
+    urdf = load_urdf(os.path.join(ref, "assets", cfg["urdf_path"]))
+    base = build_robot_model(dict(cfg), urdf)
+    D = base.num_dof
+
+    def with_cspace(**kw):
+        c = dict(cfg)
+        c["cspace"] = dict(cfg["cspace"], **kw)
+        return c
+
+    m = build_robot_model(with_cspace(max_acceleration=[float(i + 1) for i in range(D)], joint_names=None), urdf)
+    assert m.cspace["max_acceleration"] == [float(i + 1) for i in range(D)], "a list of length dof is taken as written"
+    names = list(cfg["cspace"]["joint_names"])
+    m = build_robot_model(with_cspace(max_jerk=[100.0 * (i + 1) for i in range(len(names))]), urdf)
+    assert m.cspace["max_jerk"] == [100.0 * (names.index(n) + 1) for n in base.joint_names], "reindexed by name"
+    with pytest.raises(ValueError, match="cspace.max_acceleration holds 3 values"):
+        build_robot_model(with_cspace(max_acceleration=[1.0, 2.0, 3.0]), urdf)
+    with pytest.raises(ValueError, match="cspace.position_limit_clip holds 2 values"):
+        build_robot_model(with_cspace(position_limit_clip=[0.1, 0.2]), urdf)
+    with pytest.raises(ValueError, match="does not list the active joint"):
+        build_robot_model(with_cspace(velocity_scale=[0.5] * len(names), joint_names=["nope"] * len(names)), urdf)
