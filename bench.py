@@ -1607,6 +1607,31 @@ def ik_benchmark(args, model, kin, device, torch):
     res_full, dt_full, _ = timed(False)  # every solve runs the 100 L-BFGS iterations
     res, dt, ran = timed(True)  # the reference's benchmark setting (ik_benchmark.py: config.exit_early = True)
     ocfg = solver.cfg.optimizer
+    extra = {}
+    try:  # the stage that does the work of such a solve: the Levenberg-Marquardt seed solver (iterate launches + ranking)
+        T, G = kin.num_pose_links, 1
+        gp4, gq4 = gp.to(device).view(P, T, G, 3).contiguous(), gq.to(device).view(P, T, G, 4).contiguous()
+        ss = solver.seed_solver
+        lm_us = time_kernel(lambda: ss.solve_batch(gp4, gq4, return_seeds=S), 5, torch, min_s=0.05)
+        n_rows, iters, D = P * ss.S, ss.cfg.max_iterations, kin.num_dof
+        R = 6 * T + D
+        # per (problem, seed) and iteration: J^T J (R x D x D multiply-adds on the matrix cores) + J^T e + the Cholesky solve
+        flops = n_rows * iters * (2.0 * R * D * D + 2.0 * R * D + D ** 3 / 3.0 + 2.0 * D * D)
+        extra["roofline"] = {"bound": "mfma", "kernel": "seed_ik_solve_kernel (FK + Jacobian + J^T J on v_mfma_f32_16x16x4_f32 + Cholesky + state update)",
+                             "achieved": round(flops / lm_us * 1e-6, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(flops / lm_us * 1e-6 / FP32_VECTOR_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_us": round(lm_us, 1),
+                             "algorithmic_flops_per_launch": int(flops), "lm_rows": n_rows, "lm_iterations": iters,
+                             "note": "13 x 7 x 7 contractions: the matrix pipe is all but idle, the solve is a chain of dependent "
+                                     "small steps (latency); fp32 MFMA issues at the vector rate on gfx950"}
+    except Exception as e:  # noqa: BLE001
+        extra["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_cpu_baseline:
+        try:
+            extra["cpu_baseline"] = cpu_ik_baseline(model, kin, gp, gq, solver, min(args.cpu_seconds, 8.0))
+            if "value" in extra["cpu_baseline"]:
+                extra["speedup_vs_cpu"] = round(P / dt / extra["cpu_baseline"]["value"], 1)
+        except Exception as e:  # noqa: BLE001
+            extra["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     stat = lambda r: {  # noqa: E731
         "success_rate": round(float(r.success.float().mean().item()), 4),
         "median_position_error_m": float(r.position_error[r.success].median().item()) if bool(r.success.any()) else None}
@@ -1617,7 +1642,7 @@ def ik_benchmark(args, model, kin, device, torch):
                            "lbfgs_iterations": ocfg.num_iters,
                            "rollout_rows_per_s": round(P * S * len(ocfg.line_search_scale) * (ocfg.num_iters + 1) / dt_full, 1),
                            **stat(res_full)},
-        "lm_seed_solver": bool(solver.cfg.use_lm_seed), "stream_shards": shards,
+        "lm_seed_solver": bool(solver.cfg.use_lm_seed), "stream_shards": shards, **extra,
         "reference_published": {"ms_per_batch": 2.726, "success_rate": 1.0, "hardware": "an NVIDIA GPU the page does not name",
                                 "source": "reference docs/reference/benchmarks.rst:62-72 (franka.yml, batch 100, collision-free IK)"},
         "workload": "C1: Franka 7-DoF, 64 seeds per problem (best 64 of 128 Levenberg-Marquardt seed-IK runs, as the "
@@ -1626,6 +1651,60 @@ def ik_benchmark(args, model, kin, device, torch):
                     "ik_benchmark.py (L-BFGS is skipped when the seed-IK solutions pass every check for all problems); "
                     "full_optimizer = the same solve with the 100 L-BFGS iterations (4 line-search candidates each) forced",
     }
+
+
+def cpu_ik_baseline(model, kin, gp, gq, solver, budget_s):
+    """The IK half of the metric on the host cores (BASELINE config 1 is the reference's CPU-runnable case; the reference has
+    no CPU path of its own, so this is the port): the work a GPU solve with exit_early does -- the Levenberg-Marquardt seed
+    solver of oracle/seed_ik_ref.py (the reference's seed-IK iteration restated on the oracle's FK / Jacobian / tool-pose /
+    LM-step functions, C with OpenMP underneath) over the same number of LM runs per problem, then the feasibility checks
+    (self + scene collision of the solutions' spheres, limits, pose thresholds) -- on a bounded sample of the problems."""
+    from oracle import load_native_oracle, load_oracle
+    from oracle.seed_ik_ref import SeedIKRefCfg, solve
+
+    try:
+        orc = load_native_oracle()
+    except Exception:  # noqa: BLE001
+        orc = load_oracle()
+    cores = usable_cores()
+    orc.set_num_threads(cores)
+    md = model.as_dict()
+    n_lm = int(solver.seed_solver.S)
+    T = int(kin.num_pose_links)
+    gp_h, gq_h = gp.cpu().numpy().reshape(-1, T, 1, 3), gq.cpu().numpy().reshape(-1, T, 1, 4)
+    lo, hi = np.asarray(md["joint_limits_position"], np.float32)
+    rng = np.random.default_rng(0)
+    cfg = SeedIKRefCfg(max_iterations=int(solver.seed_solver.cfg.max_iterations))
+    from curobo_amd.scene import cuboid_scene_arrays
+    from curobo_amd.workloads import c1_world
+
+    arrays = cuboid_scene_arrays(c1_world())
+
+    def one_pass(n_prob):
+        seeds = (lo + (hi - lo) * rng.random((n_prob * n_lm, lo.shape[0]), dtype=np.float32)).astype(np.float32)
+        idx = np.repeat(np.arange(n_prob, dtype=np.int32), n_lm)
+        st = solve(orc, md, cfg, seeds, gp_h[:n_prob], gq_h[:n_prob], idx)
+        q = st["joint_position"]
+        fk = orc.kinematics_forward(q, md)
+        sph = fk["robot_spheres"].reshape(len(q), 1, -1, 4)
+        free = (orc.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"].reshape(-1) == 0) & \
+            (orc.scene_collision(sph, arrays, 1.0, 0.0)["distance"].reshape(len(q), -1).sum(-1) == 0)
+        ok = (st["final_success"] & free).reshape(n_prob, n_lm)
+        return ok.any(1)
+
+    n_prob = min(4, gp_h.shape[0])
+    one_pass(n_prob)  # warm
+    t0, solved, done = time.perf_counter(), 0, 0
+    while True:
+        ok = one_pass(n_prob)
+        solved += int(ok.sum())
+        done += n_prob
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": done / el, "unit": "IK solves/s", "cores": int(orc.num_threads()), "kind": "port", "success_rate": round(solved / done, 4),
+            "sample": f"{done} problems ({n_prob} per pass) x {n_lm} Levenberg-Marquardt runs x {cfg.max_iterations} iterations + collision "
+                      f"checks in {el:.1f} s on {int(orc.num_threads())} threads (oracle/seed_ik_ref.py over the C oracle, OpenMP; NumPy glue included)"}
 
 
 def rollout_self(r):

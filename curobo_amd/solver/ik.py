@@ -127,6 +127,9 @@ class IKSolver:
             self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=lm_hi - lm_lo, use_cuda_graph=use_cuda_graph,
                                                                          sampler_seed=451 + self.cfg.seed),
                                             num_goalset=self.G, seed_offset=lm_lo, global_num_seeds=n_lm)
+            # one set of goal buffers for the metrics rollout and the seed stage ([P, T, G, 3 | 4] both): a solve uploads
+            # its goals once (shared BEFORE anything is captured: the graphs hold these addresses)
+            self.metrics_rollout.goal_position, self.metrics_rollout.goal_quat = self.seed_solver.goal_position, self.seed_solver.goal_quat
         self._gen = torch.Generator(device="cpu")
 
     @classmethod
@@ -195,7 +198,10 @@ class IKSolver:
         if seeds is None:
             if self.seed_solver is not None:
                 # the S_global best LM runs over all ranks, identical everywhere; this rank optimises its rows of them
-                seeds = self.seed_solver.solve_batch(gp, gq, return_seeds=self.S_global).solution
+                m = self.metrics_rollout  # (its goal buffers are the seed stage's: update_goals above filled them)
+                shared = self.seed_solver.goal_position is m.goal_position
+                seeds = self.seed_solver.solve_batch(m.goal_position if shared else gp, m.goal_quat if shared else gq,
+                                                     return_seeds=self.S_global).solution
                 if self.S_global != S:
                     seeds = seeds[:, self.seed_offset:self.seed_offset + S].contiguous()
             else:
@@ -204,7 +210,7 @@ class IKSolver:
         if self.cfg.exit_early if exit_early is None else exit_early:
             early = self._get_result(seeds.reshape(P * S, D).contiguous(), return_seeds)
             solved = early.success if return_seeds == 1 else early.success[:, 0]
-            if float(solved.float().mean()) >= self.cfg.exit_early_batch_success_threshold:
+            if int(torch.count_nonzero(solved)) >= self.cfg.exit_early_batch_success_threshold * solved.numel():
                 self.optimizer_ran = False
                 return early
         set_optimizer_goals()
@@ -241,13 +247,19 @@ class IKSolver:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._get_result_eager(q_static, return_seeds)
-            self._result_graphs[key] = (graph, q_static, out)
-        graph, q_static, out = self._result_graphs[key]
+            self._result_graphs[key] = (graph, q_static, out, getattr(self, "_rank_pack", None))
+        graph, q_static, out, pack = self._result_graphs[key]
         q_static.copy_(q)
         graph.replay()
-        return IKResult(**{f: (getattr(out, f).clone() if getattr(out, f) is not None else None)
-                           for f in ("success", "solution", "position_error", "rotation_error", "cost", "seed_index",
-                                     "goalset_index")})
+        fields = ("success", "solution", "position_error", "rotation_error", "cost", "seed_index", "goalset_index")
+        if pack is not None and getattr(out, "_packed", False):
+            # the seven outputs of the ranking launch are views of ONE buffer: one copy instead of seven
+            from .seed_ik import _unpack_like
+
+            views = _unpack_like(out._pack_views, pack.clone())
+            sq = (lambda x: x) if return_seeds > 1 else (lambda x: x[:, 0])  # noqa: E731
+            return IKResult(**{f: sq(v) for f, v in zip(fields, views)})
+        return IKResult(**{f: (getattr(out, f).clone() if getattr(out, f) is not None else None) for f in fields})
 
     def _get_result_eager(self, q: torch.Tensor, return_seeds: int) -> IKResult:
         """Metrics of P*S joint configurations, feasibility checks and the ranked winner(s) per problem
@@ -262,18 +274,23 @@ class IKSolver:
             # below is only needed across ranks)
             from ..backends import linalg as linalg_hip
 
+            from .seed_ik import _packed_outputs
+
             k, dev = return_seeds, self.device
-            ok_o = torch.empty(P, k, dtype=torch.uint8, device=dev)
-            sol_o = torch.empty(P, k, D, device=dev)
-            pe_o, re_o, c_o = (torch.empty(P, k, device=dev) for _ in range(3))
-            si_o, gi_o = torch.empty(P, k, dtype=torch.int64, device=dev), torch.empty(P, k, T, dtype=torch.int64, device=dev)
+            # (views of ONE buffer: a caller that wants copies -- _get_result over the replayed graph -- makes one)
+            self._rank_pack, (ok_o, sol_o, pe_o, re_o, c_o, si_o, gi_o) = _packed_outputs(
+                dev, [((P, k), torch.uint8), ((P, k, D), torch.float32), ((P, k), torch.float32), ((P, k), torch.float32),
+                      ((P, k), torch.float32), ((P, k), torch.int64), ((P, k, T), torch.int64)])
             linalg_hip.ik_rank(ok_o, sol_o, pe_o, re_o, c_o, si_o, gi_o, q.view(P * S, D), cost.view(P * S), m.pose_pos_dist.view(P * S, T),
                                m.pose_rot_dist.view(P * S, T), m.self_dist.view(P * S), m.cspace_cost.view(P * S, D),
                                m.scene_dist if self.scene is not None else None, m.goalset_idx.view(P * S, T),
                                self.cfg.position_threshold, self.cfg.rotation_threshold, P, S, k, self.seed_offset)
             sq = (lambda x: x) if k > 1 else (lambda x: x[:, 0])  # noqa: E731
-            return IKResult(success=sq(ok_o.bool()), solution=sq(sol_o), position_error=sq(pe_o), rotation_error=sq(re_o),
-                            cost=sq(c_o), seed_index=sq(si_o), goalset_index=sq(gi_o))
+            ok_b = ok_o.view(torch.bool)  # (the kernel writes 0 / 1 bytes)
+            res = IKResult(success=sq(ok_b), solution=sq(sol_o), position_error=sq(pe_o), rotation_error=sq(re_o),
+                           cost=sq(c_o), seed_index=sq(si_o), goalset_index=sq(gi_o))
+            res._packed, res._pack_views = True, [ok_b, sol_o, pe_o, re_o, c_o, si_o, gi_o]
+            return res
         pos_all, rot_all = m.pose_pos_dist.view(P, S, T), m.pose_rot_dist.view(P, S, T)
         pos_err, rot_err = pos_all.max(-1).values, rot_all.max(-1).values  # the largest error over the tool frames
         feasible = (m.self_dist.view(P, S) <= 0.0) & (m.cspace_cost.view(P, S, D).sum(-1) <= 0.0)

@@ -84,7 +84,43 @@ class SeedIKResult:  # the fields of IKSolverResult the seed solver fills (solve
     solution: torch.Tensor        # [P, return_seeds, D]
     position_error: torch.Tensor  # [P, return_seeds]
     rotation_error: torch.Tensor  # [P, return_seeds]
-    iterations: int
+    #: LM iterations that ran: an int, or (the one-graph solve) a device counter of the blocks of iterations that ran,
+    #: read -- one device -> host round trip -- only when somebody asks (``iterations``)
+    iterations_or_counter: object = 0
+    inner_iterations: int = 1
+
+    @property
+    def iterations(self) -> int:
+        v = self.iterations_or_counter
+        return int(v.item()) * self.inner_iterations if torch.is_tensor(v) else int(v)
+
+
+def _packed_outputs(device, specs):
+    """tensors of the given (shape, dtype) list as views of ONE byte buffer (16-byte aligned slices): (buffer, views)"""
+    import math as _m
+
+    sizes = [int(_m.prod(sh)) * torch.empty((), dtype=dt).element_size() for sh, dt in specs]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 15) & ~15
+    buf = torch.zeros(max(o, 16), dtype=torch.uint8, device=device)
+    return buf, _views_of(buf, specs, offs, sizes)
+
+
+def _views_of(buf, specs, offs, sizes):
+    return [buf[o:o + n].view(dt).view(*sh) for (sh, dt), o, n in zip(specs, offs, sizes)]
+
+
+def _unpack_like(views, buf_copy):
+    """the views of ``_packed_outputs`` (same shapes, dtypes, order) re-made over a copy of its buffer"""
+    specs = [(tuple(v.shape), v.dtype) for v in views]
+    sizes = [v.numel() * v.element_size() for v in views]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 15) & ~15
+    return _views_of(buf_copy, specs, offs, sizes)
 
 
 class HaltonSeeds:
@@ -110,6 +146,16 @@ class HaltonSeeds:
         idx = torch.randint(0, self.buffer.shape[0], (n,), generator=self._gen).to(self.buffer.device)
         s = self.buffer[idx]
         return s * self.range + self.low if bounded else s
+
+    def get_samples_host(self, n: int) -> torch.Tensor:
+        """the same n bounded samples as ``get_samples(n)`` (same index stream, the same two fp32 roundings), computed on
+        the host: a solve then uploads ONE small row instead of running an index / gather / multiply / add chain of
+        launches for it"""
+        if getattr(self, "_host", None) is None:
+            self._host = (self.buffer.cpu(), self.range.cpu(), self.low.cpu())
+        buf, rng, low = self._host
+        idx = torch.randint(0, buf.shape[0], (n,), generator=self._gen)
+        return buf[idx] * rng + low
 
 
 class SeedIKSolver:
@@ -287,6 +333,15 @@ class SeedIKSolver:
         seeds[:, -1, :] = self.default_joint_position.view(1, -1)
         return seeds[:, lo:lo + S].contiguous()
 
+    def _default_seed_row(self) -> torch.Tensor:
+        """the seed set of ONE problem when no seeds are given (``generate_seeds(None)`` repeats it for every problem): host
+        tensor [S_global, D], the same values from the same index stream"""
+        row = self.sampler.get_samples_host(self.S_global)
+        if getattr(self, "_default_host", None) is None:
+            self._default_host = self.default_joint_position.cpu()
+        row[-1] = self._default_host
+        return row
+
     def reset_seed(self) -> None:
         self.sampler.reset()
 
@@ -310,34 +365,55 @@ class SeedIKSolver:
                 self._vel_velocity.view(P, S, D).copy_(current_velocity.to(self.device, torch.float32).view(P, 1, D).expand(P, S, D))
             else:
                 self._vel_velocity.zero_()
-        self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, self.G, 3))
-        self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, self.G, 4))
+        if goal_position is not self.goal_position:  # (IKSolver shares its goal buffers with this solver: already in place)
+            self.goal_position.copy_(goal_position.to(self.device, torch.float32).view(P, T, self.G, 3))
+            self.goal_quat.copy_(goal_quat.to(self.device, torch.float32).view(P, T, self.G, 4))
         if seed_config is None and current_position is not None:
             seed_config = current_position.view(P, 1, D)
-        seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
         fused = self._fused_ok()
-        if fused and c.use_cuda_graph and not self._vel_active and current_position is None and not self._sharded():
+        one_graph = fused and c.use_cuda_graph and not self._vel_active and current_position is None and not self._sharded()
+        if one_graph and seed_config is None and getattr(self, "_seeds_static", None) is not None:
+            # the default seed set is one row of [S, D] repeated for every problem: built on the host (same values), one
+            # small upload and one broadcast copy into the graph's seed buffer instead of ~8 launches
+            lo = self.seed_offset
+            row = self._default_seed_row()[lo:lo + S].contiguous()
+            if getattr(self, "_seed_row_dev", None) is None:
+                self._seed_row_dev = torch.empty(S, D, device=self.device)
+                self._seed_row_pin = torch.empty(S, D).pin_memory() if self.device.type == "cuda" else torch.empty(S, D)
+            self._seed_row_pin.copy_(row)
+            self._seed_row_dev.copy_(self._seed_row_pin, non_blocking=True)
+            self._seeds_static.view(P, S, D).copy_(self._seed_row_dev.view(1, S, D).expand(P, S, D))
+            seeds = None
+        else:
+            seeds = self.generate_seeds(seed_config).reshape(self.n, D).contiguous()
+        if one_graph:
             # the whole solve after the seeds (initial evaluation, every block of iterations with the device-side exit
             # test, the ranking) replayed from ONE hipGraph: ~35 small submissions become one
             if return_seeds not in self._solve_graphs:
-                self._seeds_static = torch.empty_like(seeds)
-                self._seeds_static.copy_(seeds)
+                if getattr(self, "_seeds_static", None) is None:
+                    self._seeds_static = torch.empty_like(seeds)
+                if seeds is not None:  # (None: the broadcast above already filled the buffer)
+                    self._seeds_static.copy_(seeds)
                 self._solve_from_seeds(self._seeds_static, return_seeds, None)  # warm-up outside the capture
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self._solve_from_seeds(self._seeds_static, return_seeds, None)
-                self._solve_graphs[return_seeds] = (graph, out)
-            graph, out = self._solve_graphs[return_seeds]
-            self._seeds_static.copy_(seeds)
+                self._solve_graphs[return_seeds] = (graph, out, self._select_pack)
+            elif seeds is not None:
+                self._seeds_static.copy_(seeds)
+            graph, out, pack = self._solve_graphs[return_seeds]
             graph.replay()
-            ok_t, sol, pos_t, ori_t = (t.clone() for t in out)
-            it = 0
-        else:
-            ok_t, sol, pos_t, ori_t = self._solve_from_seeds(seeds, return_seeds, current_position)
-            it = self._last_outer
-        n_it = int(self._blocks_run.item()) * c.inner_iterations if fused else (it + 1) * c.inner_iterations
-        return SeedIKResult(success=ok_t, solution=sol, position_error=pos_t, rotation_error=ori_t, iterations=n_it)
+            # the four outputs live in ONE buffer (see _solve_from_seeds): one copy instead of four
+            ok_t, sol, pos_t, ori_t = _unpack_like(out, pack.clone())
+            return SeedIKResult(success=ok_t, solution=sol, position_error=pos_t, rotation_error=ori_t,
+                                iterations_or_counter=self._blocks_run, inner_iterations=c.inner_iterations)
+        ok_t, sol, pos_t, ori_t = self._solve_from_seeds(seeds, return_seeds, current_position)
+        if fused:
+            return SeedIKResult(success=ok_t, solution=sol, position_error=pos_t, rotation_error=ori_t,
+                                iterations_or_counter=self._blocks_run, inner_iterations=c.inner_iterations)
+        return SeedIKResult(success=ok_t, solution=sol, position_error=pos_t, rotation_error=ori_t,
+                            iterations_or_counter=(self._last_outer + 1) * c.inner_iterations)
 
     def _solve_from_seeds(self, seeds: torch.Tensor, return_seeds: int, current_position: Optional[torch.Tensor]):
         """initial evaluation -> blocks of LM iterations (exit test between blocks) -> ranked top ``return_seeds``"""
@@ -378,16 +454,17 @@ class SeedIKSolver:
             return self._rank_over_all_shards(return_seeds, current_position)
         if S <= 1024 and return_seeds <= S:  # one launch instead of ~20 torch kernels (masks, top-k, gathers)
             dev = self.device
-            ok_o = torch.empty(P, return_seeds, dtype=torch.uint8, device=dev)
-            sol_o = torch.empty(P, return_seeds, D, device=dev)
-            pos_o, ori_o = torch.empty(P, return_seeds, device=dev), torch.empty(P, return_seeds, device=dev)
+            # the four outputs are views of ONE buffer, so that a caller that wants copies makes one (_unpack_like)
+            self._select_pack, (ok_o, sol_o, pos_o, ori_o) = _packed_outputs(
+                dev, [((P, return_seeds), torch.uint8), ((P, return_seeds, D), torch.float32), ((P, return_seeds), torch.float32),
+                      ((P, return_seeds), torch.float32)])
             cur = None
             if c.start_cspace_dist_weight > 0 and current_position is not None:
                 cur = current_position.to(dev, torch.float32).reshape(P, D).contiguous()
             linalg_hip.seed_ik_select(ok_o, sol_o, pos_o, ori_o, self.q.view(P, S, D), self.position_error, self.orientation_error,
                                       self._limits[0], self._limits[1], cur, c.position_tolerance, c.orientation_tolerance,
                                       c.start_cspace_dist_weight, c.joint_limit_weight > 0, return_seeds)
-            return ok_o.bool(), sol_o, pos_o, ori_o
+            return ok_o.view(torch.bool), sol_o, pos_o, ori_o  # (the kernel writes 0 / 1 bytes)
         pos, ori = self.position_error.view(P, S), self.orientation_error.view(P, S)
         q = self.q.view(P, S, D)
         ok = (pos < c.position_tolerance) & (ori < c.orientation_tolerance)

@@ -350,19 +350,23 @@ def test_seed_selection_and_ik_ranking_kernels(device):
     # ---- IK ranking
     n_sc = 9
     cst = rng.choice([1.0, 2.0, 3.5], size=(P, S)).astype(np.float32)
+    # (per tool frame: a solution converges only when EVERY frame does, the reported error is the largest over the frames)
     pd = np.repeat(pos[..., None], T, -1).copy()
     rd = np.repeat(ori[..., None], T, -1).copy()
+    if T > 1:
+        pd[..., 1:] = rng.choice([0.001, 0.004, 0.02], p=[0.6, 0.3, 0.1], size=pd[..., 1:].shape).astype(np.float32)
+        rd[..., 1:] = rng.choice([0.01, 0.03, 0.2], p=[0.6, 0.3, 0.1], size=rd[..., 1:].shape).astype(np.float32)
     selfd = (rng.random((P, S)) < 0.1).astype(np.float32) * 0.3
     csp = (rng.random((P, S, D)) < 0.02).astype(np.float32)
     scd = (rng.random((P, S, n_sc)) < 0.01).astype(np.float32) * 0.1
     gidx = rng.integers(0, 3, size=(P, S, T)).astype(np.int32)
-    ok = (selfd <= 0) & (csp.sum(-1) <= 0) & (scd.sum(-1) <= 0) & (pos < 0.005) & (ori < 0.05)
+    ok = (selfd <= 0) & (csp.sum(-1) <= 0) & (scd.sum(-1) <= 0) & (pd < 0.005).all(-1) & (rd < 0.05).all(-1)
     ranked = cst + np.float32(1e16) * (~ok).astype(np.float32)
     order = np.argsort(ranked, axis=1, kind="stable")[:, :k]
     o_ok = torch.zeros(P, k, dtype=torch.uint8, device=device)
     o_sol = torch.zeros(P, k, D, device=device)
     o_pe, o_re, o_c = (torch.zeros(P, k, device=device) for _ in range(3))
-    o_si, o_gi = (torch.zeros(P, k, dtype=torch.int64, device=device) for _ in range(2))
+    o_si, o_gi = torch.zeros(P, k, dtype=torch.int64, device=device), torch.zeros(P, k, T, dtype=torch.int64, device=device)
     linalg.ik_rank(o_ok, o_sol, o_pe, o_re, o_c, o_si, o_gi, t(q).view(P * S, D), t(cst).view(-1), t(pd).view(P * S, T),
                    t(rd).view(P * S, T), t(selfd).view(-1), t(csp).view(P * S, D), t(scd), t(gidx).view(P * S, T), 0.005, 0.05,
                    P, S, k, 1000)
@@ -372,7 +376,9 @@ def test_seed_selection_and_ik_ranking_kernels(device):
     np.testing.assert_array_equal(o_ok.cpu().numpy().astype(bool), ok[ar, order])
     np.testing.assert_array_equal(o_sol.cpu().numpy(), q[ar, order])
     np.testing.assert_array_equal(o_c.cpu().numpy(), cst[ar, order])
-    np.testing.assert_array_equal(o_gi.cpu().numpy(), gidx[ar, order, 0])
+    np.testing.assert_array_equal(o_gi.cpu().numpy(), gidx[ar, order])  # one member index per tool frame
+    np.testing.assert_array_equal(o_pe.cpu().numpy(), pd.max(-1)[ar, order])
+    np.testing.assert_array_equal(o_re.cpu().numpy(), rd.max(-1)[ar, order])
     assert ok.any(1).mean() > 0.5 and (~ok).any()
 
 
