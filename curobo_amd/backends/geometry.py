@@ -19,8 +19,8 @@ DENSE_MIN_PAIRS, DENSE_MIN_DENSITY = 8192, 0.25
 _bitmap_cache: Dict[Tuple[int, int, int, str], Optional[Tuple[torch.Tensor, int]]] = {}
 
 
-def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[torch.Tensor, int, torch.Tensor]]:
-    """(bitmap uint32 [2 * nslots, nslots * 64] on the pairs' device, nslots, tile list int32) for
+def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[torch.Tensor, int, torch.Tensor, torch.Tensor]]:
+    """(bitmap uint32 [2 * nslots, nslots * 64] on the pairs' device, nslots, tile list int32, tile lane masks uint8 [tiles, 64]) for
     ``curobo_hip_self_collision_distance_dense`` -- bit jj of bitmap[jb, i] <-> pair (i, 32 * jb + jj) -- or ``None``
     when the list is not (i, j)-sorted with i < j (then "lowest pair index" is not the lexicographic order the
     dense kernel resolves ties by).  Built once per pair tensor (one host read-back: call outside graph capture)."""
@@ -39,8 +39,16 @@ def pair_bitmap(pair_locations: torch.Tensor, nspheres: int) -> Optional[Tuple[t
         # the 16 x 16 tiles of the pair matrix that hold an enabled pair, (i / 16) | (j / 16) << 8, in (ib, jb) order
         tkey = np.unique((i // 16) * 256 + (j // 16))
         tiles = ((tkey // 256) | ((tkey % 256) << 8)).astype(np.int32)
+        # the pair set of every listed tile in the layout in which a lane receives the matrix-core result (self_collision.hip,
+        # the mfma kernel): bit reg of masks[c, lane] <-> pair (16 ib + 4 (lane / 16) + reg, 16 jb + lane % 16)
+        tix = {int(k): c for c, k in enumerate(tkey)}
+        c_of = np.asarray([tix[int(k)] for k in (i // 16) * 256 + (j // 16)], np.int64)
+        lane_of = ((i % 16) // 4) * 16 + (j % 16)
+        masks = np.zeros((len(tkey), 64), np.uint8)
+        np.bitwise_or.at(masks, (c_of, lane_of), (np.uint8(1) << (i % 4).astype(np.uint8)))
         res = (torch.as_tensor(bm.view(np.int32)).to(pair_locations.device).contiguous(), nslots,
-               torch.as_tensor(tiles).to(pair_locations.device).contiguous())
+               torch.as_tensor(tiles).to(pair_locations.device).contiguous(),
+               torch.as_tensor(masks).to(pair_locations.device).contiguous())
     _bitmap_cache[key] = (weakref.ref(pair_locations), res)
     weakref.finalize(pair_locations, _evict_dead, _bitmap_cache, key)  # the device tensors of an entry go with the pair tensor
     return res
@@ -81,7 +89,7 @@ def self_collision_distance(
         if bm is not None:
             check(load().curobo_hip_self_collision_distance_dense(
                 ptr(out_distance), ptr(out_vec), ptr(sparse_index), ptr(robot_spheres), ptr(sphere_padding), ptr(weight),
-                ptr(bm[0]), ptr(bm[2]), int(bm[2].shape[0]), batch_size, horizon, nspheres, bm[1], int(compute_grad),
+                ptr(bm[0]), ptr(bm[2]), int(bm[2].shape[0]), ptr(bm[3]), batch_size, horizon, nspheres, bm[1], int(compute_grad),
                 current_stream(out_distance)))
             return
     check(load().curobo_hip_self_collision_distance(

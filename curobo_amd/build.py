@@ -78,7 +78,9 @@ def _flags() -> List[str]:
 # half rate and every pair costs register shuffles (v_mov / v_pk_mov): ~110 instructions per link become ~150 on the
 # serial chain of kinematics.hip, and rollout_fused.hip's main instantiation needs 125 instead of 95 VGPRs (its
 # SWEEP x voxel instantiations spill 54-60 registers with it, 2-4 without).  Off for every source.
-PER_SOURCE_FLAGS: dict = {}
+# self_collision.hip: the matrix-core narrow phase compares the tile results on the vector ALU, so they must land in VGPRs -- the
+# AGPR form costs a v_accvgpr_write per accumulator input and a v_accvgpr_read per output, twelve moves per 16 x 16 tile
+PER_SOURCE_FLAGS: dict = {"self_collision.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 NO_SLP = ["-fno-slp-vectorize"]
 
 

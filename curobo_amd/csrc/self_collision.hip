@@ -390,6 +390,7 @@ struct SelfTilesArgs {
   SelfDenseArgs d;
   const int32_t *tiles;
   int n_tiles;
+  const uint8_t *lane_masks;  // optional [n_tiles][64]: the tile's listed pairs in the matrix-core result layout (see the mfma kernel)
 };
 
 __device__ __forceinline__ float pair_pen(float4 o, float4 sj) {
@@ -738,6 +739,216 @@ __global__ void __launch_bounds__(kT2Waves * 64) self_collision_tiles2_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MATRIX-CORE narrow phase.  After the level-1 block-box test a point keeps ~100 of its 763 listed 16 x 16 tiles; the
+// two-level kernel above then spends most of its instructions on the second level (sub-tile boxes, ring compaction, the
+// 4 x 4 pair tests) while the matrix pipe idles.  A 16 x 16 tile of penetrations is ONE v_mfma_f32_16x16x4_f32:
+//   (r_i + r_j)^2 - |c_i - c_j|^2 = [2 c_i . c_j + 2 r_i r_j] + (r_i^2 - |c_i|^2) + (r_j^2 - |c_j|^2)
+// K = 4 = (x, y, z, r): A = 2 (x, y, z, r)_i, B = (x, y, z, r)_j, the row / column terms as the accumulator's initial
+// value.  fp32 operands and accumulation (the f32 MFMA is an fmaf chain), but the expanded form cancels (|c|^2 ~ 1 against
+// penetrations ~1e-3), so its result only CULLS: a listed pair whose tile value exceeds -kMfmaSlack is evaluated again
+// with pair_pen -- the same function, the same bits as the other kernels -- and only those values enter the arg-max.
+// Same outputs as self_collision_tiles2_kernel, bit for bit (test_self_collision_dense_bitmap_kernel_c4_size).
+// Reference: self_collision_kernel.cuh:113-297 (map-reduce max over the pair list).
+constexpr int kTmWaves = 4;
+constexpr float kMfmaSlack = 4.0e-5f;  // m^2: > the rounding of five fp32 terms of magnitude <= 16 (coordinates within +-2 m)
+__host__ __device__ inline size_t tilesm_kept_cap(int n_tiles) { return (size_t)((n_tiles + kTmWaves * 64 - 1) / (kTmWaves * 64)) * 64; }
+__host__ __device__ inline size_t tilesm_lds_floats(int nslots, int n_tiles) {
+  const size_t SL = (size_t)nslots * 64;
+  return SL * 4 + SL + (SL / kTile) * kT2Box + kTmWaves * tilesm_kept_cap(n_tiles) + 2 * kTmWaves;
+}
+typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(kTmWaves * 64) self_collision_tiles_mfma_kernel(const SelfTilesArgs t) {
+  const SelfDenseArgs &a = t.d;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.nspheres, NS = a.nslots, SL = NS * 64, NB = SL / kTile;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int kept_cap = (int)tilesm_kept_cap(t.n_tiles);
+  float4 *sph = reinterpret_cast<float4 *>(smem);
+  float *aterm = reinterpret_cast<float *>(sph + SL);     // [SL]: h = (r^2 - |c|^2) / 2 (NaN for disabled / padding spheres)
+  float *box = aterm + SL;                                // [NB][6]: lo xyz, hi xyz of 16 consecutive spheres
+  int *kept = reinterpret_cast<int *>(box + NB * kT2Box) + wave * kept_cap;  // this wavefront's surviving tiles
+  float *red = box + NB * kT2Box + kTmWaves * kept_cap;   // [kTmWaves] (penetration, key) per wavefront
+  const int n = blockIdx.x;
+  const float qnan = __builtin_nanf("");
+  const int row = lane >> 4, li = lane & 15;
+  constexpr int kMaxTileTrips = 8;  // <= 8 * 256 = 2048 listed tiles
+  int my_tiles[kMaxTileTrips];
+#pragma unroll
+  for (int u = 0; u < kMaxTileTrips; u++) {
+    const int c = (u * kTmWaves + wave) * kWave + lane;
+    my_tiles[u] = c < t.n_tiles ? t.tiles[c] : -1;
+  }
+  {  // spheres (+ padding) -> LDS with their row / column term, stale gradient rows cleared, boxes of 16 consecutive spheres
+    const float4 *src = reinterpret_cast<const float4 *>(a.robot_spheres) + (size_t)n * S;
+    constexpr int kMaxSlots = 4;  // nslots <= 16, four wavefronts
+    float4 sv[kMaxSlots];
+    float off[kMaxSlots];
+    uint8_t dirty[kMaxSlots];
+#pragma unroll
+    for (int u = 0; u < kMaxSlots; u++) {
+      const int s = (u * kTmWaves + wave) * 64 + lane;
+      const bool in = u * kTmWaves + wave < NS && s < S;
+      sv[u] = in ? src[s] : make_float4(0.f, 0.f, 0.f, qnan);
+      off[u] = in ? a.offsets[s] : 0.0f;
+      dirty[u] = in ? a.sparse_index[(size_t)n * S + s] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxSlots; u++) {
+      const int sl = u * kTmWaves + wave;
+      if (sl >= NS) break;
+      const int s = sl * 64 + lane;
+      float4 v = sv[u];
+      if (s < S) {
+        v.w += off[u];
+        if (!(v.w >= 0.0f)) v.w = qnan;
+        if (dirty[u]) {
+          reinterpret_cast<float4 *>(a.out_gradient)[(size_t)n * S + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a.sparse_index[(size_t)n * S + s] = 0;
+        }
+      }
+      sph[s] = v;
+      aterm[s] = 0.5f * (v.w * v.w - (v.x * v.x + v.y * v.y + v.z * v.z));
+      const bool on = v.w == v.w;  // disabled / padding spheres: an empty box
+      const float big = 3.0e38f;
+      float e[6] = {on ? v.w - v.x : -big, on ? v.w - v.y : -big, on ? v.w - v.z : -big,
+                    on ? v.x + v.w : -big, on ? v.y + v.w : -big, on ? v.z + v.w : -big};
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        e[c] = fmaxf(e[c], dpp_f<0xB1>(e[c]));
+        e[c] = fmaxf(e[c], dpp_f<0x4E>(e[c]));
+        e[c] = fmaxf(e[c], dpp_f<0x141>(e[c]));
+        e[c] = fmaxf(e[c], dpp_f<0x140>(e[c]));
+      }
+      if (li == 0) {
+        float *b = box + (sl * 4 + row) * kT2Box;
+        b[0] = -e[0]; b[1] = -e[1]; b[2] = -e[2]; b[3] = e[3]; b[4] = e[4]; b[5] = e[5];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- level 1: this wavefront's share of the tiles whose block boxes overlap, compacted in list order
+  int count = 0;
+#pragma unroll
+  for (int u = 0; u < kMaxTileTrips; u++) {
+    if ((u * kTmWaves + wave) * kWave >= t.n_tiles) break;
+    const int tl = my_tiles[u];
+    bool keep = false;
+    if (tl >= 0) {
+      const float *bi = box + (tl & 0xff) * kT2Box, *bj = box + (tl >> 8) * kT2Box;
+      keep = bi[0] <= bj[3] && bj[0] <= bi[3] && bi[1] <= bj[4] && bj[1] <= bi[4] && bi[2] <= bj[5] && bj[2] <= bi[5];
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) kept[count + __popcll(m & ((1ull << lane) - 1ull))] = tl | (((u * kTmWaves + wave) * kWave + lane) << 16);  // + its list index
+    count += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- narrow phase: one tile per pair of matrix-core instructions.  Lane (k = lane / 16, m = lane % 16) feeds component k of
+  // sphere 16 ib + m (A) and of sphere 16 jb + m (B); it receives rows 4 k .. 4 k + 3 of column m: the pairs
+  // (16 ib + 4 k + reg, 16 jb + m).  HALF the penetration is accumulated: c_i . c_j + r_i r_j from the first instruction, the
+  // row / column terms h_i + h_j (h = (r^2 - |c|^2) / 2) from a second one with A = (h_i, 1, 0, 0), B = (1, h_j, 0, 0) --
+  // no accumulator initialisation, no doubling.  A disabled / padding sphere carries NaN: its whole row / column is NaN and
+  // compares false.
+  float bv = 0.0f;
+  int bkey = 0x7fffffff;
+  const int kk = lane >> 4, mm = lane & 15;
+  const char *sphb = reinterpret_cast<const char *>(sph) + (mm * 4 + kk) * 4;  // + 256 * block: component kk of its sphere mm
+  const char *ahb = reinterpret_cast<const char *>(aterm) + mm * 4;             // + 64 * block: h of its sphere mm
+  const float sel0 = kk == 0 ? 1.0f : 0.0f, sel1 = kk == 1 ? 1.0f : 0.0f;
+  const sc_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const float thr = -0.5f * kMfmaSlack;
+  constexpr int U = 4;  // tiles per trip: the trip's operand reads and matrix-core instructions are independent of each other
+  for (int t0 = 0; t0 < count; t0 += U) {
+    const int4 k4 = *reinterpret_cast<const int4 *>(kept + t0);  // (one LDS round trip per trip; kept_cap is a multiple of 64)
+    const int kv[U] = {k4.x, k4.y, k4.z, k4.w};
+    int tl[U];
+    sc_f32x4 acc[U];
+    uint32_t listed[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool in = t0 + u < count;
+      tl[u] = __builtin_amdgcn_readfirstlane(in ? kv[u] : kv[0]);
+      const int ib = tl[u] & 0xff, jb = (tl[u] >> 8) & 0xff;
+      // which of this lane's four pairs are LISTED: requested with the operands (an L2 round trip that the matrix-core
+      // instructions cover) -- most kept tiles hold close UNLISTED pairs (the spheres of one link, of neighbouring links), so
+      // asking only after the close test would put the load on the dependent path of every other tile
+      if (t.lane_masks != nullptr) {
+        listed[u] = in ? (uint32_t)t.lane_masks[(size_t)(tl[u] >> 16) * 64 + lane] : 0u;
+      } else {  // bit (16 (jb & 1) + m) of bitmap[jb / 2][i] <-> pair (i, 16 jb + m): the words of this lane's four rows i
+        const uint4 w = *reinterpret_cast<const uint4 *>(a.bitmap + (size_t)(jb >> 1) * SL + ib * kTile + 4 * kk);
+        const int sh = (jb & 1) * 16 + mm;
+        listed[u] = in ? ((w.x >> sh) & 1u) | (((w.y >> sh) & 1u) << 1) | (((w.z >> sh) & 1u) << 2) | (((w.w >> sh) & 1u) << 3) : 0u;
+      }
+      const float av = *reinterpret_cast<const float *>(sphb + ib * 256);
+      const float bw = *reinterpret_cast<const float *>(sphb + jb * 256);
+      const float hi_ = *reinterpret_cast<const float *>(ahb + ib * 64);
+      const float hj_ = *reinterpret_cast<const float *>(ahb + jb * 64);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, zero4, 0, 0, 0);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_fmaf(sel0, hi_, sel1), __builtin_fmaf(sel1, hj_, sel0), acc[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float m4 = fmaxf(fmaxf(fmaxf(acc[u][0], acc[u][1]), acc[u][2]), acc[u][3]);
+      if (__ballot(m4 > thr && listed[u] != 0u) == 0ull) continue;  // no listed pair of this tile is close
+      uint32_t cand = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) cand |= (acc[u][reg] > thr ? 1u : 0u) << reg;
+      cand &= listed[u];
+      if (__ballot(cand != 0u) == 0ull) continue;  // (~30 listed pairs of a point penetrate)
+      const int ib = tl[u] & 0xff, jb = (tl[u] >> 8) & 0xff;
+      const int j = jb * kTile + mm;
+      const float4 sj = sph[j];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        if ((cand >> reg) & 1u) {
+          const int i = ib * kTile + 4 * kk + reg;
+          const float v = pair_pen(sph[i], sj);
+          const int key = (i << 10) | j;
+          if (v > 0.0f && (v > bv || (v == bv && key < bkey))) { bv = v; bkey = key; }
+        }
+      }
+    }
+  }
+  // ---- arg-max: largest penetration, then the lexicographically first (i, j); over the wavefront, then over the four
+  float m = bv;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  int key = (m > 0.0f && bv == m) ? bkey : 0x7fffffff;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, kWave));
+  if (lane == 0) {
+    red[wave * 2] = m;
+    reinterpret_cast<int *>(red)[wave * 2 + 1] = key;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  m = 0.0f;
+  key = 0x7fffffff;
+  for (int w = 0; w < kTmWaves; w++) {
+    const float mw = red[w * 2];
+    const int kw = reinterpret_cast<const int *>(red)[w * 2 + 1];
+    if (mw > m || (mw == m && kw < key)) { m = mw; key = kw; }
+  }
+  if (!(m > 0.0f) || key == 0x7fffffff) {
+    a.out_distance[n] = 0.0f;
+    return;
+  }
+  const float wgt = a.weight[0];
+  a.out_distance[n] = 0.5f * wgt * m;
+  if (a.write_grad) {
+    const int i = key >> 10, j = key & 1023;
+    const float4 s1 = sph[i], s2 = sph[j];
+    const float vx = wgt * (s2.x - s1.x), vy = wgt * (s2.y - s1.y), vz = wgt * (s2.z - s1.z);
+    float4 *g = reinterpret_cast<float4 *>(a.out_gradient) + (size_t)n * S;
+    g[i] = make_float4(vx, vy, vz, wgt * -1.0f);
+    g[j] = make_float4(-1.0f * vx, -1.0f * vy, -1.0f * vz, wgt * -1.0f);
+    a.sparse_index[(size_t)n * S + i] = 1;
+    a.sparse_index[(size_t)n * S + j] = 1;
+  }
+}
+
 template <int NWAVES>
 static void launch_self(const SelfCollArgs &a, int blocks, size_t lds, int ppw, int tile, hipStream_t st) {
   if (a.store_pair_distance)
@@ -799,7 +1010,7 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance(
 CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
     float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
     const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, const int32_t *tile_list, int num_tiles,
-    int batch_size, int horizon, int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream) {
+    const uint8_t *tile_lane_masks, int batch_size, int horizon, int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream) {
   const char *what = "self_collision_distance_dense";
   CUROBO_REQUIRE(nspheres >= 1 && nspheres <= 1024, "%s: nspheres=%d out of range [1,1024]", what, nspheres);
   CUROBO_REQUIRE(nslots >= 1 && nslots * 64 >= nspheres && nslots % 4 == 0 && nslots <= 16,
@@ -815,12 +1026,29 @@ CUROBO_EXPORT int curobo_hip_self_collision_distance_dense(
   static const bool no_tiles = getenv("CUROBO_HIP_SELF_NO_BROAD_PHASE") != nullptr;
   if (tile_list != nullptr && num_tiles > 0 && !no_tiles) {  // broad phase over 16 x 16 tiles
     static const bool one_level = getenv("CUROBO_HIP_SELF_ONE_LEVEL") != nullptr;  // (A/B knob: the round-2 kernel)
-    SelfTilesArgs ta{a, tile_list, num_tiles};
+    SelfTilesArgs ta{a, tile_list, num_tiles, tile_lane_masks};
     static bool attr2 = false;
     if (!attr2) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr2 = true;
+    }
+    // The matrix-core narrow phase (self_collision_tiles_mfma_kernel) is bit-identical to the two-level kernel and, measured
+    // on the G1 (profiles/r05_c_self_collision_mfma.json), exactly as fast: 7.3 M matrix-core instructions per launch replace
+    // the second box level, but the launch stays bound by instruction issue of the code AROUND them (166 M VALU + 71 M scalar
+    // wave-instructions, 4.1 SIMD-cycles each).  It runs on request (CUROBO_HIP_SELF_MFMA=1, the tests); the default stays the
+    // two-level kernel.
+    const bool use_mfma = getenv("CUROBO_HIP_SELF_MFMA") != nullptr;  // (read per call: the tests switch it)
+    if (!one_level && use_mfma) {  // level-1 block boxes, then one 16 x 16 tile per pair of matrix-core instructions
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(self_collision_tiles_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr3 = true;
+      }
+      const size_t lds = tilesm_lds_floats(nslots, num_tiles) * sizeof(float);
+      CUROBO_REQUIRE(lds <= 64 * 1024 && num_tiles <= 2048 && nslots <= 16, "%s: too many tiles / spheres for the LDS tiling", what);
+      hipLaunchKernelGGL(self_collision_tiles_mfma_kernel, dim3((unsigned)n_points), dim3(kTmWaves * 64), lds, st, ta);
+      return check_launch(what, st);
     }
     if (!one_level) {  // two-level broad phase, four wavefronts per point
       const size_t lds = tiles2_lds_floats(nslots, num_tiles) * sizeof(float);

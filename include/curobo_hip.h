@@ -123,11 +123,17 @@ int curobo_hip_self_collision_distance(
  * tile_list (optional, NULL = evaluate every tile): the 16 x 16 tiles of the pair matrix that hold an enabled pair, as
  * (i / 16) | (j / 16) << 8; with it a tile is only evaluated when the bounding boxes of its two 16-sphere blocks overlap
  * (result preserving: only positive penetrations count).
- */
+ * With a tile list the narrow phase runs on the matrix cores: one v_mfma_f32_16x16x4_f32 per surviving tile gives all 256
+ * penetrations of the tile in the expanded form 2 c_i.c_j + 2 r_i r_j + (r_i^2 - |c_i|^2) + (r_j^2 - |c_j|^2); that value
+ * only culls, the listed pairs it leaves are evaluated again exactly (same bits as the other kernels).
+ * tile_lane_masks (ABI 6, optional, NULL = read the pair bitmap instead): uint8 [num_tiles][64], bit reg of byte (c, lane)
+ * <-> pair (16 ib + 4 (lane / 16) + reg, 16 jb + lane % 16) of tile c is listed: the tile's pair set in the layout in which
+ * a lane receives the matrix-core result, 64 bytes per tile instead of 1 KB of bitmap words. */
 int curobo_hip_self_collision_distance_dense(
     float *out_distance, float *out_vec, uint8_t *sparse_index, const float *robot_spheres,
     const float *sphere_padding, const float *weight, const uint32_t *pair_bitmap, const int32_t *tile_list, int num_tiles,
-    int batch_size, int horizon, int nspheres, int nslots, int compute_grad, curobo_hip_stream_t stream);
+    const uint8_t *tile_lane_masks, int batch_size, int horizon, int nspheres, int nslots, int compute_grad,
+    curobo_hip_stream_t stream);
 
 /* ---------------------------------------------------------------- collision: sphere vs scene
  * The reference has NO backend hook here: these are NVIDIA Warp kernels launched from

@@ -194,8 +194,18 @@ def test_pair_bitmap_and_tile_list_of_the_dense_self_collision_entry():
     S = 70
     pairs = [(0, 1), (0, 33), (2, 69), (17, 40), (40, 41)]
     t = torch.tensor(pairs, dtype=torch.int16)
-    bm, nslots, tiles = G.pair_bitmap(t, S)
+    bm, nslots, tiles, masks = G.pair_bitmap(t, S)
     assert nslots == 4 and tuple(bm.shape) == (8, 256)
+    # the lane masks: bit reg of masks[c, lane] <-> pair (16 ib + 4 (lane / 16) + reg, 16 jb + lane % 16) of tile c
+    assert tuple(masks.shape) == (tiles.shape[0], 64) and masks.dtype == torch.uint8
+    listed = set()
+    for c, tl in enumerate(tiles.tolist()):
+        ib, jb = tl & 0xff, tl >> 8
+        for lane in range(64):
+            for reg in range(4):
+                if (int(masks[c, lane]) >> reg) & 1:
+                    listed.add((16 * ib + 4 * (lane // 16) + reg, 16 * jb + lane % 16))
+    assert listed == set(pairs)
     words = bm.numpy().view(np.uint32)
     want = np.zeros_like(words)
     for i, j in pairs:

@@ -570,6 +570,16 @@ def test_self_collision_dense_bitmap_kernel_c4_size(oracle, device):
 
     d1, g1, f1 = run(True)
     d0, g0, f0 = run(False)
+    # the matrix-core narrow phase (self_collision_tiles_mfma_kernel: two v_mfma_f32_16x16x4_f32 per surviving tile cull, the
+    # listed close pairs are evaluated again exactly): every output bit of the two-level kernel
+    import os
+
+    os.environ["CUROBO_HIP_SELF_MFMA"] = "1"
+    try:
+        d2, g2, f2 = run(True)
+    finally:
+        del os.environ["CUROBO_HIP_SELF_MFMA"]
+    assert np.array_equal(d2, d1) and np.array_equal(g2, g1) and np.array_equal(f2, f1)
     assert np.array_equal(f1, ref["sparse_index"]) and np.array_equal(f0, f1), "collision-pair indices must be exact"
     np.testing.assert_allclose(d1, ref["distance"], atol=ATOL, rtol=1e-5)
     np.testing.assert_allclose(g1, ref["gradient"], atol=ATOL, rtol=1e-5)
