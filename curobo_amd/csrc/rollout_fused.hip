@@ -1861,8 +1861,8 @@ static int rollout_trajectory_fused_impl(
   // scenes with analytic primitives in the cuboid store run the one instantiation that tests the tag (KINDS = 7)
   const int kinds = (a.sc.max_cuboids > 0 && a.sc.cuboid_has_primitives) ? 7 : ((a.sc.max_cuboids > 0 ? 1 : 0) | (a.sc.max_voxel_grids > 0 ? 2 : 0));
   hipStream_t st = (hipStream_t)stream;
-#ifdef CUROBO_FUSED_ONLY_C2
-#define CUROBO_FUSED_KERNEL_OF(DG, SW, KD) rollout_trajectory_fused_kernel<DG, SW, KD, false>
+#ifdef CUROBO_FUSED_ONLY_C2  // (experiment builds: the C2 instantiation with its compile-time shape, nothing else)
+#define CUROBO_FUSED_KERNEL_OF(DG, SW, KD) rollout_trajectory_fused_kernel<DG, SW, KD, false, CUROBO_FUSED_SHAPE_1>
 #else
 #define CUROBO_FUSED_KERNEL_OF(DG, SW, KD) \
   (with_terms ? rollout_trajectory_fused_kernel<DG, SW, KD, true> : rollout_trajectory_fused_kernel<DG, SW, KD, false>)
