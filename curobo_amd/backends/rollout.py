@@ -255,13 +255,14 @@ def rollout_trajopt_fused_lds_bytes(padded_horizon: int, dof: int, num_links: in
 
 def fused_shape_id(padded_horizon: int, n_knots: int, dof: int, num_links: int, num_spheres: int, num_collision_pairs: int,
                    link_chain_len: int, self_lane_len: int, max_cuboids: int, max_voxel_grids: int, bspline_degree: int = 3,
-                   sweep_steps: int = 3, kinds: int = 1, with_trajopt_terms: bool = False) -> int:
+                   sweep_steps: int = 3, kinds: int = 1, with_trajopt_terms: bool = False, plain_launch: bool = True) -> int:
     """Which compile-time shape (csrc/fused_shapes.hpp) a fused trajectory launch with these dimensions runs; 0 = the generic
-    kernel.  Host-side query, no GPU work."""
+    kernel.  ``plain_launch``: the launch form of an optimiser iteration (self + scene collision with the speed metric, one
+    environment, longest-first dispatch, nothing materialised).  Host-side query, no GPU work."""
     return int(load().curobo_hip_rollout_fused_shape_id(
         int(padded_horizon), int(n_knots), int(dof), int(num_links), int(num_spheres), int(num_collision_pairs), int(link_chain_len),
         int(self_lane_len), int(max_cuboids), int(max_voxel_grids), int(bspline_degree), int(sweep_steps), int(kinds),
-        1 if with_trajopt_terms else 0))
+        1 if with_trajopt_terms else 0, 1 if plain_launch else 0))
 
 
 def set_fused_shapes_enabled(enabled: bool) -> None:

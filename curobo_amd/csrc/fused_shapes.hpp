@@ -22,28 +22,39 @@ namespace curobo_hip {
 
 struct FusedShapeDyn { static constexpr bool kStatic = false; };
 
-template <int H_, int NK_, int D_, int L_, int S_, int P_, int C_, int LEN0_, int LEN1_, int NT_, int NCUB_, int NVOX_>
+template <int H_, int NK_, int D_, int L_, int S_, int P_, int C_, int LEN0_, int LEN1_, int NT_, int NCUB_, int NVOX_, int PLAIN_ = 0>
 struct FusedShape {
   static constexpr bool kStatic = true;
   static constexpr int kH = H_, kNK = NK_, kD = D_, kL = L_, kS = S_, kP = P_, kC = C_, kLen0 = LEN0_, kLen1 = LEN1_, kNT = NT_,
                        kNCub = NCUB_, kNVox = NVOX_;
+  // PLAIN: the launch form of an optimiser iteration is part of the shape too -- self + scene collision with the speed
+  // metric, one environment, longest-first dispatch, nothing materialised (no position / sphere outputs, no profile
+  // stamps): the branches on those arguments fold away (53.8 -> 51.0 us on the C2 workload).  Any other form of the same
+  // dimensions takes the next shape in the list, or the generic kernel.
+  static constexpr bool kPlain = PLAIN_ != 0;
 };
 
 }  // namespace curobo_hip
 
-//                                      H  NK  D   L   S    P   C  LEN0 LEN1  NT NCUB NVOX
-// 1: Franka, 12 knots x 2 (BASELINE C2: 256 seeds x 32-step horizon), a scene of four cuboid slots (the C2 world's)
-#define CUROBO_FUSED_SHAPE_1 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, 4, 0>
+//                                      H  NK  D   L   S    P   C  LEN0 LEN1  NT NCUB NVOX PLAIN
+// 1: Franka, 12 knots x 2 (BASELINE C2: 256 seeds x 32-step horizon), a scene of four cuboid slots (the C2 world's), plain launch
+#define CUROBO_FUSED_SHAPE_1 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, 4, 0, 1>
 #define CUROBO_FUSED_SHAPE_1_KERNELS(K) K(3, 3, 1, false)
-// 2: Franka, 12 knots x 2, any scene; with the optional trajopt terms (tool pose, c-space STATE)
-#define CUROBO_FUSED_SHAPE_2 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, -1, -1>
-#define CUROBO_FUSED_SHAPE_2_KERNELS(K) K(3, 3, 1, false) K(3, 3, 1, true) K(3, 3, 3, false)
-// 3: Franka, 12 knots x 4 (BASELINE C5: horizon 64), any scene
-#define CUROBO_FUSED_SHAPE_3 FusedShape<65, 12, 7, 13, 65, 818, 88, 13, 0, 1024, -1, -1>
-#define CUROBO_FUSED_SHAPE_3_KERNELS(K) K(3, 3, 1, false) K(3, 3, 3, false)
-// 4: UR10e, 12 knots x 2 (BASELINE C3: ESDF world), any scene
-#define CUROBO_FUSED_SHAPE_4 FusedShape<33, 12, 6, 10, 20, 83, 55, 5, 0, 512, -1, -1>
-#define CUROBO_FUSED_SHAPE_4_KERNELS(K) K(3, 3, 2, false) K(3, 3, 1, false)
-#define CUROBO_FUSED_NUM_SHAPES 4
+// 2: Franka, 12 knots x 2, any scene, plain launch
+#define CUROBO_FUSED_SHAPE_2 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, -1, -1, 1>
+#define CUROBO_FUSED_SHAPE_2_KERNELS(K) K(3, 3, 1, false) K(3, 3, 3, false)
+// 3: Franka, 12 knots x 2, any scene, any launch form; with the optional trajopt terms (tool pose, c-space STATE)
+#define CUROBO_FUSED_SHAPE_3 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, -1, -1, 0>
+#define CUROBO_FUSED_SHAPE_3_KERNELS(K) K(3, 3, 1, false) K(3, 3, 1, true) K(3, 3, 3, false)
+// 4: Franka, 12 knots x 4 (BASELINE C5: horizon 64, one world per problem), any scene, any launch form
+#define CUROBO_FUSED_SHAPE_4 FusedShape<65, 12, 7, 13, 65, 818, 88, 13, 0, 1024, -1, -1, 0>
+#define CUROBO_FUSED_SHAPE_4_KERNELS(K) K(3, 3, 1, false) K(3, 3, 3, false)
+// 5: UR10e, 12 knots x 2 (BASELINE C3: ESDF world), any scene, plain launch
+#define CUROBO_FUSED_SHAPE_5 FusedShape<33, 12, 6, 10, 20, 83, 55, 5, 0, 512, -1, -1, 1>
+#define CUROBO_FUSED_SHAPE_5_KERNELS(K) K(3, 3, 2, false) K(3, 3, 1, false)
+// 6: UR10e, 12 knots x 2, any scene, any launch form
+#define CUROBO_FUSED_SHAPE_6 FusedShape<33, 12, 6, 10, 20, 83, 55, 5, 0, 512, -1, -1, 0>
+#define CUROBO_FUSED_SHAPE_6_KERNELS(K) K(3, 3, 2, false) K(3, 3, 1, false)
+#define CUROBO_FUSED_NUM_SHAPES 6
 // (the list the main translation unit walks, most specific first)
-#define CUROBO_FUSED_FOR_EACH_SHAPE(X) X(1) X(2) X(3) X(4)
+#define CUROBO_FUSED_FOR_EACH_SHAPE(X) X(1) X(2) X(3) X(4) X(5) X(6)

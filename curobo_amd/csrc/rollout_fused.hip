@@ -985,6 +985,13 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       __builtin_assume(a.sc.max_cuboids == SH::kNCub); __builtin_assume(a.sc.max_voxel_grids == SH::kNVox);
       __builtin_assume(n_rec == SH::kNCub + SH::kNVox);
     }
+    __builtin_assume(a.lane_lists != nullptr);
+    if constexpr (SH::kPlain) {  // the launch form of an optimiser iteration (fused_plain_launch)
+      __builtin_assume(a.use_self == 1); __builtin_assume(a.use_scene == 1); __builtin_assume(a.enable_speed_metric == 1);
+      __builtin_assume(a.out_position == nullptr); __builtin_assume(a.out_spheres == nullptr); __builtin_assume(a.prof == nullptr);
+      __builtin_assume(a.use_multi_env == 0); __builtin_assume(a.num_envs == 1); __builtin_assume(a.scene_rows == 0);
+      __builtin_assume(a.dispatch_ws != nullptr); __builtin_assume(a.sphere_padding != nullptr);
+    }
   }
   // trajectory of this workgroup: blockIdx.x itself, or the entry of the longest-first order that the
   // previous launches built from the measured workgroup durations (same results, shorter tail)
@@ -1603,8 +1610,15 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
 // ---- compile-time shapes (fused_shapes.hpp): one launcher per shape, each in its own translation unit.
 // Returns 1 when the shape holds an instantiation for exactly these arguments and it was launched (*err = what the attribute
 // call said), 0 otherwise (the caller runs the generic kernel).
+// the launch form a PLAIN shape assumes (fused_shapes.hpp)
+static bool fused_plain_launch(const FusedTrajArgs &a) {
+  return a.use_self == 1 && a.use_scene == 1 && a.enable_speed_metric == 1 && a.out_position == nullptr && a.out_spheres == nullptr &&
+         a.prof == nullptr && a.use_multi_env == 0 && a.num_envs == 1 && a.scene_rows == 0 && a.dispatch_ws != nullptr &&
+         a.sphere_padding != nullptr;
+}
 template <class SH>
 static bool fused_shape_matches(const FusedTrajArgs &a, int threads) {
+  if (SH::kPlain && !fused_plain_launch(a)) return false;
   return a.bs.padded_horizon == SH::kH && a.bs.n_knots == SH::kNK && a.bs.dof == SH::kD && a.nlinks == SH::kL && a.nspheres == SH::kS &&
          a.npairs == SH::kP && a.chain_len == SH::kC && a.lane_lists != nullptr && a.lane_len0 == SH::kLen0 && a.lane_len1 == SH::kLen1 &&
          threads == SH::kNT && (SH::kNCub < 0 || (a.sc.max_cuboids == SH::kNCub && a.sc.max_voxel_grids == SH::kNVox));
@@ -1717,7 +1731,7 @@ static FusedLayout fused_resolve_layout(FusedTrajArgs &a, int n_rec, bool with_t
 CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, int num_links, int num_spheres,
                                                     int num_collision_pairs, int link_chain_len, int self_lane_len, int max_cuboids,
                                                     int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
-                                                    int with_trajopt_terms) {
+                                                    int with_trajopt_terms, int plain_launch) {
 #ifdef CUROBO_FUSED_ONLY_C2
   return 0;
 #else
@@ -1726,7 +1740,12 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_kn
   a.npairs = num_collision_pairs; a.chain_len = link_chain_len; a.sc.max_cuboids = max_cuboids; a.sc.max_voxel_grids = max_voxel_grids;
   a.lane_len0 = self_lane_len & 0xffff; a.lane_len1 = (self_lane_len >> 16) & 0xffff;
   static const uint32_t some_list = 0u;
+  static const float some_float = 0.0f;
+  static int32_t some_ws = 0;
   a.lane_lists = self_lane_len ? &some_list : nullptr;
+  if (plain_launch) {  // self + scene collision with the speed metric, one environment, longest-first dispatch, nothing materialised
+    a.use_self = 1; a.use_scene = 1; a.enable_speed_metric = 1; a.num_envs = 1; a.dispatch_ws = &some_ws; a.sphere_padding = &some_float;
+  }
   a.use_cspace = with_trajopt_terms ? 1 : 0;
   int threads;
   (void)fused_resolve_layout(a, max_cuboids + max_voxel_grids, with_trajopt_terms != 0, &threads);

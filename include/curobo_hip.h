@@ -684,11 +684,13 @@ int curobo_hip_rollout_fused_set_profile_sequence(int64_t *device_buffer, int n_
  * curobo_hip_rollout_fused_shape_id: host-side query (no GPU work), the id (>= 1) of the shape a launch with these arguments
  * runs, 0 = the generic kernel.  self_lane_len = the value curobo_hip_self_lane_lists_host returned (0 = no lane lists);
  * num_collision_pairs = 0 when the self-collision term is off; kinds = 1 cuboids | 2 voxel grids (7 = analytic primitives).
+ * plain_launch = 1: the launch form of an optimiser iteration -- self + scene collision with the speed metric, one environment,
+ * a dispatch workspace, no materialised outputs, no profile stamps -- which some shapes also hold as compile-time facts.
  * curobo_hip_rollout_fused_set_shapes_enabled(0) makes every launch take the generic kernel (tests, A/B timing). */
 int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, int num_links, int num_spheres,
                                       int num_collision_pairs, int link_chain_len, int self_lane_len, int max_cuboids,
                                       int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
-                                      int with_trajopt_terms);
+                                      int with_trajopt_terms, int plain_launch);
 int curobo_hip_rollout_fused_set_shapes_enabled(int enabled);
 
 /* ---------------------------------------------------------------- trajectory: B-spline

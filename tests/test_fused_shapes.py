@@ -19,26 +19,28 @@ def _lane_len(model):
     return int(lists[1]) if lists is not None else 0
 
 
-def _shape(model, padded_horizon, n_cub, n_vox, terms=False, kinds=None, **kw):
+def _shape(model, padded_horizon, n_cub, n_vox, terms=False, kinds=None, plain_launch=True, **kw):
     from curobo_amd.backends.rollout import fused_shape_id
 
     d = model.as_dict()
     args = dict(padded_horizon=padded_horizon, n_knots=12, dof=model.num_dof, num_links=model.num_links, num_spheres=model.num_spheres,
                 num_collision_pairs=len(model.collision_pairs), link_chain_len=len(d["link_chain_data"]), self_lane_len=_lane_len(model),
                 max_cuboids=n_cub, max_voxel_grids=n_vox, kinds=kinds if kinds is not None else ((1 if n_cub else 0) | (2 if n_vox else 0)),
-                with_trajopt_terms=terms)
+                with_trajopt_terms=terms, plain_launch=plain_launch)
     args.update(kw)
     return fused_shape_id(**args)
 
 
 def test_packaged_robots_take_their_compile_time_shapes():
     franka, ur10e = load_model("franka"), load_model("ur10e")
-    assert _shape(franka, 33, 4, 0) == 1, "BASELINE C2: Franka, 12 knots x 2, the four cuboid slots of the C2 world"
-    assert _shape(franka, 33, 3, 0) == 2 and _shape(franka, 33, 7, 0) == 2, "Franka, any cuboid scene"
-    assert _shape(franka, 33, 4, 0, terms=True) == 2, "the full trajopt cost set"
+    assert _shape(franka, 33, 4, 0) == 1, "BASELINE C2: Franka, 12 knots x 2, the four cuboid slots of the C2 world, plain launch"
+    assert _shape(franka, 33, 3, 0) == 2 and _shape(franka, 33, 7, 0) == 2, "Franka, any cuboid scene, plain launch"
     assert _shape(franka, 33, 2, 1) == 2, "cuboids + ESDF"
-    assert _shape(franka, 65, 2, 1) == 3 and _shape(franka, 65, 5, 0) == 3, "BASELINE C5: horizon 64"
-    assert _shape(ur10e, 33, 0, 1) == 4 and _shape(ur10e, 33, 4, 0) == 4, "BASELINE C3: UR10e"
+    assert _shape(franka, 33, 4, 0, plain_launch=False) == 3, "materialised outputs / several environments / profile stamps"
+    assert _shape(franka, 33, 4, 0, terms=True) == 3 and _shape(franka, 33, 4, 0, terms=True, plain_launch=False) == 3, "the full trajopt cost set"
+    assert _shape(franka, 65, 2, 1) == 4 and _shape(franka, 65, 5, 0, plain_launch=False) == 4, "BASELINE C5: horizon 64"
+    assert _shape(ur10e, 33, 0, 1) == 5 and _shape(ur10e, 33, 4, 0) == 5, "BASELINE C3: UR10e"
+    assert _shape(ur10e, 33, 0, 1, plain_launch=False) == 6
 
 
 def test_anything_else_runs_the_generic_kernel():
@@ -68,7 +70,8 @@ def test_table_rows_are_consistent_with_the_build():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["c2", "franka_3_cuboids", "franka_h65_mixed", "ur10e_esdf", "franka_terms"])
+@pytest.mark.parametrize("case", ["c2", "c2_materialized", "franka_3_cuboids", "franka_h65_mixed", "ur10e_esdf", "ur10e_esdf_materialized",
+                                  "franka_terms"])
 def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device):
     """the same launch through the compile-time shape and through the generic kernel: every output bit equal"""
     from curobo_amd.backends.rollout import set_fused_shapes_enabled
@@ -77,7 +80,8 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
     from curobo_amd.scene import SceneData, cuboid_scene_arrays
     from curobo_amd.workloads import c2_world, c3_voxel_world, c5_mixed_worlds, seed_knots, start_configuration
 
-    robot = "ur10e" if case == "ur10e_esdf" else "franka"
+    robot = "ur10e" if case.startswith("ur10e_esdf") else "franka"
+    materialize = case.endswith("_materialized")  # (a launch that writes positions / spheres is not the plain form: other shapes)
     model = load_model(robot)
     kin = KinematicsParams.from_model(model, device)
     interp = 4 if case == "franka_h65_mixed" else 2
@@ -85,7 +89,7 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
         arrays = cuboid_scene_arrays([c2_world()[0][:3]])
     elif case == "franka_h65_mixed":
         arrays = c5_mixed_worlds(1, voxels=True)
-    elif case == "ur10e_esdf":
+    elif case.startswith("ur10e_esdf"):
         arrays = c3_voxel_world(64, 0.04)
     else:
         arrays = cuboid_scene_arrays(c2_world())
@@ -105,7 +109,7 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
                         torch.as_tensor(rng.integers(0, 3, size=B).astype(np.int32), device=device))
         assert ro.fused_available()
     else:
-        ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(interpolation_steps=interp, fused_materialize=True))
+        ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(interpolation_steps=interp, fused_materialize=materialize))
         ro.update_start_state(start)
     outs = []
     try:
