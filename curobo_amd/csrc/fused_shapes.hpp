@@ -55,6 +55,14 @@ struct FusedShape {
 // 6: UR10e, 12 knots x 2, any scene, any launch form
 #define CUROBO_FUSED_SHAPE_6 FusedShape<33, 12, 6, 10, 20, 83, 55, 5, 0, 512, -1, -1, 0>
 #define CUROBO_FUSED_SHAPE_6_KERNELS(K) K(3, 3, 2, false) K(3, 3, 1, false)
+// 99: a shape compiled at RUN TIME for the robot / horizon at hand (curobo_amd/backends/fused_jit.py: hipcc on this file's
+// translation unit with the shape and its kernel list on the command line, the object loaded and registered with
+// curobo_hip_rollout_fused_register_shape) -- what the reference does for every kernel with NVRTC
+// (cuda_core_backend/kernel_cache.py:161-235)
+#ifdef CUROBO_FUSED_JIT_SHAPE
+#define CUROBO_FUSED_SHAPE_99 CUROBO_FUSED_JIT_SHAPE
+#define CUROBO_FUSED_SHAPE_99_KERNELS(K) CUROBO_FUSED_JIT_KERNELS(K)  // (-D'CUROBO_FUSED_JIT_KERNELS(K)=K(3, 3, 1, false) ...')
+#endif
 #define CUROBO_FUSED_NUM_SHAPES 6
 // (the list the main translation unit walks, most specific first)
 #define CUROBO_FUSED_FOR_EACH_SHAPE(X) X(1) X(2) X(3) X(4) X(5) X(6)

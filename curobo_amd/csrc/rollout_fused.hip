@@ -1649,6 +1649,20 @@ int CUROBO_FUSED_CAT(fused_shape_launch_, CUROBO_FUSED_SHAPE_TU)(CUROBO_FUSED_SH
 #undef CUROBO_FUSED_SHAPE_KERNEL
   return 0;
 }
+#ifdef CUROBO_FUSED_JIT_SHAPE
+// entry points of a run-time compiled shape object (loaded by curobo_amd/backends/fused_jit.py, handed to
+// curobo_hip_rollout_fused_register_shape): the launcher behind a C signature, and the size of the argument block so that an
+// object built from other sources than the library's is refused
+extern "C" __attribute__((visibility("default"))) int curobo_fused_jit_launch(const void *args, int deg, int sweep, int kinds, int terms,
+                                                                               int batch, int threads, size_t lds, void *stream, int *err) {
+  hipError_t e = hipSuccess;
+  const int r = CUROBO_FUSED_CAT(fused_shape_launch_, CUROBO_FUSED_SHAPE_TU)(*static_cast<const FusedTrajArgs *>(args), deg, sweep, kinds,
+                                                                             terms != 0, batch, threads, lds, (hipStream_t)stream, &e);
+  *err = (int)e;
+  return r;
+}
+extern "C" __attribute__((visibility("default"))) int curobo_fused_jit_args_bytes(void) { return (int)sizeof(FusedTrajArgs); }
+#endif
 #endif
 
 }  // namespace curobo_hip
@@ -1658,6 +1672,24 @@ using namespace curobo_hip;
 
 static long long *g_fused_prof = nullptr;
 static bool g_fused_shapes_enabled = true;
+// shapes compiled at run time (curobo_fused_jit_launch of their objects), tried before the built-in table
+typedef int (*fused_jit_launcher_t)(const void *, int, int, int, int, int, int, size_t, void *, int *);
+static std::vector<fused_jit_launcher_t> &fused_jit_shapes() {
+  static std::vector<fused_jit_launcher_t> v;
+  return v;
+}
+constexpr int kJitShapeIdBase = 100;
+CUROBO_EXPORT int curobo_hip_rollout_fused_register_shape(void *launcher, int args_bytes) {
+  CUROBO_REQUIRE(launcher != nullptr, "rollout_fused_register_shape: NULL launcher%s", "");
+  CUROBO_REQUIRE(args_bytes == (int)sizeof(FusedTrajArgs),
+                 "rollout_fused_register_shape: the shape object was built for an argument block of %d bytes, this library's is %d "
+                 "(compile it from this library's sources)", args_bytes, (int)sizeof(FusedTrajArgs));
+  auto &v = fused_jit_shapes();
+  for (size_t i = 0; i < v.size(); i++)
+    if ((void *)v[i] == launcher) return CUROBO_HIP_OK;
+  v.push_back(reinterpret_cast<fused_jit_launcher_t>(launcher));
+  return CUROBO_HIP_OK;
+}
 CUROBO_EXPORT int curobo_hip_rollout_fused_set_shapes_enabled(int enabled) {
   g_fused_shapes_enabled = enabled != 0;
   return CUROBO_HIP_OK;
@@ -1728,6 +1760,20 @@ static FusedLayout fused_resolve_layout(FusedTrajArgs &a, int n_rec, bool with_t
   return lay;
 }
 
+// workgroup size a launch with these dimensions uses (a compile-time shape holds it as a constant).  Returns the thread count.
+CUROBO_EXPORT int curobo_hip_rollout_fused_threads(int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
+                                                   int link_chain_len, int self_lane_len, int num_obstacles, int with_trajopt_terms) {
+  FusedTrajArgs a{};
+  a.bs.padded_horizon = padded_horizon; a.bs.dof = dof; a.nlinks = num_links; a.nspheres = num_spheres; a.npairs = num_collision_pairs;
+  a.chain_len = link_chain_len; a.lane_len0 = self_lane_len & 0xffff; a.lane_len1 = (self_lane_len >> 16) & 0xffff;
+  static const uint32_t some_list = 0u;
+  a.lane_lists = self_lane_len ? &some_list : nullptr;
+  a.use_cspace = with_trajopt_terms ? 1 : 0;
+  int threads = 0;
+  (void)fused_resolve_layout(a, num_obstacles, with_trajopt_terms != 0, &threads);
+  return threads;
+}
+
 CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, int num_links, int num_spheres,
                                                     int num_collision_pairs, int link_chain_len, int self_lane_len, int max_cuboids,
                                                     int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
@@ -1749,6 +1795,13 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_kn
   a.use_cspace = with_trajopt_terms ? 1 : 0;
   int threads;
   (void)fused_resolve_layout(a, max_cuboids + max_voxel_grids, with_trajopt_terms != 0, &threads);
+  {
+    const auto &v = fused_jit_shapes();
+    for (size_t i = 0; i < v.size(); i++) {
+      int e2 = 0;
+      if (v[i](&a, bspline_degree, sweep_steps, kinds, with_trajopt_terms != 0 ? 1 : 0, 0, threads, 0, nullptr, &e2)) return kJitShapeIdBase + (int)i;
+    }
+  }
   hipError_t e = hipSuccess;
 #define CUROBO_FUSED_QUERY_SHAPE(ID) \
   if (fused_shape_launch_##ID(a, bspline_degree, sweep_steps, kinds, with_trajopt_terms != 0, 0, threads, 0, nullptr, &e)) return ID;
@@ -1906,6 +1959,15 @@ static int rollout_trajectory_fused_impl(
     static const bool env_off = getenv("CUROBO_HIP_FUSED_NO_SHAPES") != nullptr;  // development knob: always the generic kernel
     const bool no_shapes = env_off || !g_fused_shapes_enabled;
     hipError_t se = hipSuccess;
+    if (!no_shapes) {  // shapes compiled at run time for this robot / horizon
+      for (fused_jit_launcher_t fn : fused_jit_shapes()) {
+        int e = 0;
+        if (fn(&a, bspline_degree, sweep_steps, kinds, with_terms ? 1 : 0, batch_size, threads, lds, (void *)st, &e)) {
+          if (e != 0) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString((hipError_t)e));
+          return check_launch(what, st);
+        }
+      }
+    }
 #define CUROBO_FUSED_TRY_SHAPE(ID)                                                                                              \
     if (!no_shapes && fused_shape_launch_##ID(a, bspline_degree, sweep_steps, kinds, with_terms, batch_size, threads, lds, st, &se)) { \
       if (se != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot raise LDS limit: %s", what, hipGetErrorString(se));  \

@@ -57,6 +57,10 @@ class CollisionRolloutCfg:
     longest_first_dispatch: bool = True
     #: fused path: also write position[B,H,D] and robot_spheres[B,H,S,4] to HBM
     fused_materialize: bool = False
+    #: compile a compile-time shape of the fused launch for THIS robot / horizon at first use when the library holds none
+    #: (``backends/fused_jit.py``: hipcc at run time, 5-10 s once, cached on disk -- the reference compiles its kernels per robot
+    #: with NVRTC); also switched on by CUROBO_HIP_JIT_SHAPES=1.  Same results, ~20 % faster launches.
+    jit_shape: bool = False
 
     @property
     def horizon(self) -> int:
@@ -286,6 +290,21 @@ class CollisionRollout:
             return False  # mesh obstacles are queried by their own launch (BVH): the kernel sequence runs
         return need <= rollout_hip.FUSED_LDS_LIMIT and k.num_links <= 128
 
+    def _maybe_jit_shape(self) -> None:
+        """cfg.jit_shape / CUROBO_HIP_JIT_SHAPES: a compile-time shape for this rollout's dimensions, built once when the library
+        has none (never inside a captured launch sequence: the first call of a rollout is an eager warm-up)"""
+        from ..backends import fused_jit
+
+        if not (self.cfg.jit_shape or fused_jit.enabled_by_env()) or not self.cfg.use_self_collision:
+            return
+        k, cfg = self.kin, self.cfg
+        lanes = getattr(k.self_collision.collision_pairs, "_self_lane_lists", None)
+        use_scene = cfg.use_scene_collision and self.scene is not None
+        n_obs = (self.scene.struct.max_cuboids + self.scene.struct.max_voxel_grids) if use_scene else 0
+        fused_jit.ensure_shape(cfg.padded_horizon, cfg.n_knots, self.action_dim, k.num_links, k.num_spheres,
+                               int(k.self_collision.collision_pairs.shape[0]), int(k.link_chain_data.shape[0]),
+                               int(lanes[1]) if lanes is not None else 0, n_obs, with_trajopt_terms=False)
+
     def _dispatch_order(self):
         """longest-first dispatch workspace of this rollout's fused launches (cfg.longest_first_dispatch)"""
         if not self.cfg.longest_first_dispatch:
@@ -320,6 +339,8 @@ class CollisionRollout:
         if self.cfg.use_fused:
             if self._fused_ok is None:
                 self._fused_ok = self.fused_available()
+                if self._fused_ok:
+                    self._maybe_jit_shape()
             if self._fused_ok:
                 cost, grad = self.cost_and_gradient_fused(act)
                 return cost, grad.view(self.batch_size, -1)

@@ -90,6 +90,9 @@ class TrajOptRolloutCfg:
     gravity: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 0.0, 0.0, 9.81])  # spatial base acceleration
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
+    #: compile a compile-time shape of the fused launch for this robot / horizon at first use when the library holds none
+    #: (``backends/fused_jit.py``; also CUROBO_HIP_JIT_SHAPES=1): see CollisionRolloutCfg.jit_shape
+    jit_shape: bool = False
     longest_first_dispatch: bool = True  # see CollisionRolloutCfg
 
     @property
@@ -405,6 +408,18 @@ class TrajOptRollout:
                 int(k.link_chain_data.shape[0]), n_obs)
         return ok
 
+    def _maybe_jit_shape(self) -> None:
+        from ..backends import fused_jit
+
+        if not (self.cfg.jit_shape or fused_jit.enabled_by_env()):
+            return
+        k, c = self.kin, self.cfg
+        lanes = getattr(k.self_collision.collision_pairs, "_self_lane_lists", None)
+        n_obs = (self.scene.struct.max_cuboids + self.scene.struct.max_voxel_grids) if self.scene is not None else 0
+        fused_jit.ensure_shape(c.padded_horizon, c.n_knots, k.num_dof, k.num_links, k.num_spheres,
+                               int(k.self_collision.collision_pairs.shape[0]), int(k.link_chain_data.shape[0]),
+                               int(lanes[1]) if lanes is not None else 0, n_obs, with_trajopt_terms=True)
+
     def _dispatch_order(self):
         if not self.cfg.longest_first_dispatch:
             return None
@@ -457,6 +472,8 @@ class TrajOptRollout:
                 c = self.cfg
                 too_big = c.use_torque_limits and c.overlap_dynamics and self.batch_size > c.fused_torque_max_batch
                 self._fused_ok = self.fused_available() and not too_big
+                if self._fused_ok:
+                    self._maybe_jit_shape()
             if self._fused_ok:
                 return self.cost_and_gradient_fused(act)
         cost = self.evaluate_action(act, with_gradient=True)

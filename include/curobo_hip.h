@@ -692,6 +692,15 @@ int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_knots, int dof, 
                                       int max_voxel_grids, int bspline_degree, int sweep_steps, int kinds,
                                       int with_trajopt_terms, int plain_launch);
 int curobo_hip_rollout_fused_set_shapes_enabled(int enabled);
+/* Shapes compiled at run time (curobo_amd/backends/fused_jit.py: hipcc on csrc/rollout_fused.hip with the shape on the command
+ * line, as the reference compiles its kernels per robot with NVRTC): `launcher` = the object's curobo_fused_jit_launch,
+ * args_bytes = its curobo_fused_jit_args_bytes() (an object built from other sources is refused).  Registered shapes are tried
+ * before the built-in table and report ids >= 100 from curobo_hip_rollout_fused_shape_id.
+ * curobo_hip_rollout_fused_threads returns the workgroup size a launch with these dimensions uses (a shape holds it as a
+ * constant); num_obstacles = max_cuboids + max_voxel_grids.  Host-side, no GPU work. */
+int curobo_hip_rollout_fused_register_shape(void *launcher, int args_bytes);
+int curobo_hip_rollout_fused_threads(int padded_horizon, int dof, int num_links, int num_spheres, int num_collision_pairs,
+                                     int link_chain_len, int self_lane_len, int num_obstacles, int with_trajopt_terms);
 
 /* ---------------------------------------------------------------- trajectory: B-spline
  * reference: cuda_core_backend/trajectory.py:28-204, pybind/trajectory_bindings.cpp:133-142

@@ -123,3 +123,72 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
     assert float(outs[0][0].abs().sum()) > 0
     for c, g in outs[1:]:
         assert torch.equal(c, outs[0][0]) and torch.equal(g, outs[0][1])
+
+
+def test_run_time_shape_compiles_loads_and_serves_its_dimensions(tmp_path, monkeypatch):
+    """backends/fused_jit: a shape the library does not ship (Franka with 10 knots: padded horizon 29) is compiled by hipcc,
+    loaded, registered, and the dispatch query then answers with a run-time id (>= 100); the object is cached on disk (the second
+    call does not compile); an object whose argument block has another size is refused.  hipcc cross-compiles without a GPU."""
+    from curobo_amd._lib import load
+    from curobo_amd.backends import fused_jit
+
+    monkeypatch.setenv("CUROBO_HIP_JIT_CACHE", str(tmp_path))
+    franka = load_model("franka")
+    lane = _lane_len(franka)
+    d = franka.as_dict()
+    dims = dict(padded_horizon=29, n_knots=10, dof=franka.num_dof, num_links=franka.num_links, num_spheres=franka.num_spheres,
+                num_collision_pairs=len(franka.collision_pairs), link_chain_len=len(d["link_chain_data"]), self_lane_len=lane)
+    assert _shape(franka, 29, 4, 0, n_knots=10) == 0
+    assert fused_jit.ensure_shape(**dims, num_obstacles=4, kernels=[(3, 3, 1, False)])
+    built = sorted(p.name for p in tmp_path.iterdir() if p.suffix == ".so")
+    assert len(built) == 2, "the plain form and the any-form shape"
+    assert _shape(franka, 29, 4, 0, n_knots=10) >= 100 and _shape(franka, 29, 4, 0, n_knots=10, plain_launch=False) >= 100
+    assert _shape(franka, 29, 4, 0, n_knots=10, kinds=2) == 0, "only the instantiations that were asked for"
+    assert _shape(franka, 33, 4, 0) == 1 and _shape(franka, 31, 4, 0) == 0, "other dimensions are untouched"
+    # cached: nothing is compiled again
+    import subprocess
+
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("compiled again")))
+    assert fused_jit.ensure_shape(**dims, num_obstacles=4, kernels=[(3, 3, 1, False)])
+    spec = fused_jit.shape_spec(**dims, threads=512, plain=True)
+    assert fused_jit.compile_shape(spec, [(3, 3, 1, False)]).endswith(built[0]) or fused_jit.compile_shape(spec, [(3, 3, 1, False)]).endswith(built[1])
+    # an object built for another argument block is refused
+    lib = load()
+    assert lib.curobo_hip_rollout_fused_register_shape(None, 1) != 0
+    import ctypes as C
+
+    fn = C.cast(lib.curobo_hip_abi_version, C.c_void_p)
+    assert lib.curobo_hip_rollout_fused_register_shape(fn, 12345) != 0 and b"argument block" in lib.curobo_hip_last_error()
+
+
+@pytest.mark.gpu
+def test_run_time_shape_is_bit_identical_to_the_generic_kernel(device, tmp_path, monkeypatch):
+    """CollisionRolloutCfg(jit_shape=True) on dimensions outside the shipped table (Franka, 10 knots x 2): the first call builds
+    and registers the shape, later launches run it -- same bits as the generic kernel."""
+    from curobo_amd.backends.rollout import set_fused_shapes_enabled
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    monkeypatch.setenv("CUROBO_HIP_JIT_CACHE", str(tmp_path))
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    B = 64
+    ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(n_knots=10, jit_shape=True))
+    assert ro.cfg.padded_horizon == 29
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+    x = torch.as_tensor(seed_knots(model, B, 10, seed=5), device=device).reshape(B, -1)
+    assert _shape(model, 29, 4, 0, n_knots=10) == 0
+    c1, g1 = [t.clone() for t in ro.cost_and_gradient(x)]  # (compiles here)
+    assert _shape(model, 29, 4, 0, n_knots=10) >= 100
+    c2, g2 = [t.clone() for t in ro.cost_and_gradient(x)]
+    set_fused_shapes_enabled(False)
+    try:
+        c0, g0 = [t.clone() for t in ro.cost_and_gradient(x)]
+    finally:
+        set_fused_shapes_enabled(True)
+    torch.cuda.synchronize()
+    assert float(c0.abs().sum()) > 0
+    assert torch.equal(c1, c0) and torch.equal(g1, g0) and torch.equal(c2, c0) and torch.equal(g2, g0)
