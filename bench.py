@@ -358,20 +358,32 @@ def main():
             k -= n
         return out
 
-    def run_steps(k):
-        """exactly k optimiser iterations"""
+    def local_exchange_stage():
+        """the local stage of the arg-min exchange: best seed of this rank -> one packed row (one launch + two concatenations
+        over the shards); captured behind the iterations of the LAST graph of a timed block, so a block is two graph
+        launches and the collective"""
+        linalg_hip.argmin_rows(row_buf, opt.best_cost.view(1, -1).contiguous(), opt.best_action.view(1, seeds, -1).contiguous(),
+                               rank * seeds)
+
+    def run_steps(k, with_exchange=False):
+        """exactly k optimiser iterations (with_exchange: + the local stage of the arg-min exchange behind the last one)"""
         one = opt.step if shards > 1 else opt._opt_step
         if args.no_graph:
             for _ in range(k):
                 one()
+            if with_exchange:
+                local_exchange_stage()
             return
-        for n in step_chunks(k):
-            if n == G:
+        chunks = step_chunks(k)
+        for ci, n in enumerate(chunks):
+            last = with_exchange and ci == len(chunks) - 1
+            if n == G and not last:
                 opt.run_inner()
                 continue
-            if n not in rem_graphs:  # its own (cached) graph, so any step count runs at replay speed
-                rem_graphs[n] = opt.make_graph(n)
-            rem_graphs[n].replay()
+            key = (n, last)
+            if key not in rem_graphs:  # its own (cached) graph, so any step count runs at replay speed
+                rem_graphs[key] = opt.make_graph(n, after=local_exchange_stage if last else None)
+            rem_graphs[key].replay()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -386,9 +398,7 @@ def main():
     row_buf = torch.empty(1, 2 + cfg.n_knots * kin.num_dof, device=device)
 
     def run_block():
-        run_steps(args.steps)
-        linalg_hip.argmin_rows(row_buf, opt.best_cost.view(1, -1).contiguous(), opt.best_action.view(1, seeds, -1).contiguous(),
-                               rank * seeds)
+        run_steps(args.steps, with_exchange=True)
         # the one real exchange of the path: arg-min over the seeds of all ranks (1 problem)
         return global_argmin_of_rows(row_buf)
 
