@@ -114,7 +114,8 @@ def ensure_shape(padded_horizon: int, n_knots: int, dof: int, num_links: int, nu
                  link_chain_len: int, self_lane_len: int, num_obstacles: int, with_trajopt_terms: bool = False,
                  kernels: Optional[Iterable[Tuple[int, int, int, bool]]] = None, verbose: bool = False) -> bool:
     """Make sure launches of these dimensions have a compile-time shape: nothing to do when the library (or an earlier call)
-    already holds one for them, else compile + register the PLAIN form (an optimiser iteration) and the any-form shape.
+    already holds one for them, else compile + register the PLAIN form (an optimiser iteration: collision-only, or with
+    ``with_trajopt_terms`` the full trajectory-optimisation cost set) and the any-form shape.
     ``self_lane_len`` = what ``curobo_hip_self_lane_lists_host`` returned for the robot (0: no lane lists -> no shapes: the
     shapes are built for the lane form of the pair pass).  Returns whether a shape now serves these dimensions; a build
     failure is reported once and leaves the generic kernel in place."""
@@ -126,14 +127,15 @@ def ensure_shape(padded_horizon: int, n_knots: int, dof: int, num_links: int, nu
     have = lambda plain: fused_shape_id(padded_horizon, n_knots, dof, num_links, num_spheres, num_collision_pairs, link_chain_len,  # noqa: E731
                                         self_lane_len, max(num_obstacles, 1), 0, with_trajopt_terms=with_trajopt_terms, plain_launch=plain)
     ok = True
-    for plain in ((False,) if with_trajopt_terms else (True, False)):
+    for plain in (True, False):
         if have(plain) != 0:
             continue
         threads = int(lib.curobo_hip_rollout_fused_threads(int(padded_horizon), int(dof), int(num_links), int(num_spheres), int(num_collision_pairs),
                                                            int(link_chain_len), int(self_lane_len), int(num_obstacles), 1 if with_trajopt_terms else 0))
         spec = shape_spec(padded_horizon, n_knots, dof, num_links, num_spheres, num_collision_pairs, link_chain_len, self_lane_len, threads,
                           -1, -1, plain)
-        ks = tuple(kernels) if kernels is not None else tuple(k for k in DEFAULT_KERNELS if not (plain and k[3]))
+        # a plain shape holds the instantiations of ITS launch form: collision-only rollouts or the full trajopt cost set
+        ks = tuple(kernels) if kernels is not None else tuple(k for k in DEFAULT_KERNELS if not plain or k[3] == bool(with_trajopt_terms))
         try:
             register_shape_object(compile_shape(spec, ks, verbose=verbose))
         except Exception as e:  # noqa: BLE001  (no compiler, a full disk ...: the generic kernel keeps serving the launch)

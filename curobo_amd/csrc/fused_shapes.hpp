@@ -40,9 +40,10 @@ struct FusedShape {
 // 1: Franka, 12 knots x 2 (BASELINE C2: 256 seeds x 32-step horizon), a scene of four cuboid slots (the C2 world's), plain launch
 #define CUROBO_FUSED_SHAPE_1 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, 4, 0, 1>
 #define CUROBO_FUSED_SHAPE_1_KERNELS(K) K(3, 3, 1, false)
-// 2: Franka, 12 knots x 2, any scene, plain launch
+// 2: Franka, 12 knots x 2, any scene, plain launch; K(.., true) = the plain form of the full trajectory-optimisation cost set
+//    (tool pose + c-space STATE on top of the collision terms, no torque limits, no per-term outputs: fused_plain_terms)
 #define CUROBO_FUSED_SHAPE_2 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, -1, -1, 1>
-#define CUROBO_FUSED_SHAPE_2_KERNELS(K) K(3, 3, 1, false) K(3, 3, 3, false)
+#define CUROBO_FUSED_SHAPE_2_KERNELS(K) K(3, 3, 1, false) K(3, 3, 3, false) K(3, 3, 1, true)
 // 3: Franka, 12 knots x 2, any scene, any launch form; with the optional trajopt terms (tool pose, c-space STATE)
 #define CUROBO_FUSED_SHAPE_3 FusedShape<33, 12, 7, 13, 65, 818, 88, 13, 0, 512, -1, -1, 0>
 #define CUROBO_FUSED_SHAPE_3_KERNELS(K) K(3, 3, 1, false) K(3, 3, 1, true) K(3, 3, 3, false)

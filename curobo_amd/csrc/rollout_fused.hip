@@ -900,18 +900,42 @@ __device__ __forceinline__ void fused_derive_tables(const FusedCtx &c) {
 // Optional terms of a point, each in its own loop over the row's points (the register sets of the
 // tool-pose distance, the c-space STATE term and the wrench gather then do not add up):
 // tool pose -> cost, wrench and gradient flag; c-space STATE -> cost and stream gradients.
-__device__ __forceinline__ void point_pose_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane, int lane64) {
+// The argument blocks of the optional terms (~90 scalar registers of pointers) are read WHERE THEY ARE USED, as a burst of scalar
+// loads from the kernel-argument segment that the optimiser cannot move: read through the by-value parameter they are loaded at
+// kernel entry and stay live across the collision pass, whose own scalars then spill to vector lanes (the TERMS instantiation
+// carried 219 spilled scalar registers, ~1100 v_readlane / v_writelane in its straight-line code, and ran collision-only work
+// 13 us per 1024 trajectories slower than the collision instantiation).  The struct is the kernel's only parameter: offset 0.
+template <class T>
+__device__ __forceinline__ T kernarg_block(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char *kernarg_ptr;
+  kernarg_ptr base = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(base));
+  return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + offset);
+#else
+  return T{};  // (host pass of the translation unit: never called)
+#endif
+}
+// NO_OUT: the launch form of an optimiser iteration writes no per-term outputs (fused_plain_terms)
+template <bool NO_OUT>
+__device__ __forceinline__ void point_pose_term(const FusedCtx &c, int b, int h, int lane, int lane64) {
   bool any_grad = c.flag[h] != 0;
   float cost2 = 0.0f;
-  point_tool_pose(c, a.tp, a.tool_frame_map, a.n_tool_frames, b, h, h, ((size_t)b * c.H + h) * a.n_tool_frames, nullptr, nullptr,
+  ToolPoseArgs tp = kernarg_block<ToolPoseArgs>(offsetof(FusedTrajArgs, tp));
+  if (NO_OUT) { tp.out_distance = nullptr; tp.out_position_distance = nullptr; tp.out_rotation_distance = nullptr; tp.out_goalset_idx = nullptr; }
+  const int16_t *tool_frame_map = kernarg_block<const int16_t *>(offsetof(FusedTrajArgs, tool_frame_map));
+  const int n_tool_frames = kernarg_block<int>(offsetof(FusedTrajArgs, n_tool_frames));
+  point_tool_pose(c, tp, tool_frame_map, n_tool_frames, b, h, h, ((size_t)b * c.H + h) * n_tool_frames, nullptr, nullptr,
                   lane, lane64, cost2, any_grad);
   cost2 = row16_sum(cost2);
   if (lane == 0) { c.cost[h] += cost2; c.flag[h] = any_grad ? 1 : 0; }
 }
-__device__ __forceinline__ void point_cspace_term(const FusedCtx &c, const FusedTrajArgs &a, int b, int h, int lane,
-                                                  const float *tau, float *gtau) {
+template <bool NO_OUT>
+__device__ __forceinline__ void point_cspace_term(const FusedCtx &c, int b, int h, int lane, const float *tau, float *gtau) {
   float cost2 = 0.0f;
-  point_cspace_state(c, a.cs, b, h, lane, cost2, tau, gtau);
+  CspaceStateArgs cs = kernarg_block<CspaceStateArgs>(offsetof(FusedTrajArgs, cs));
+  if (NO_OUT) cs.out_cost = nullptr;
+  point_cspace_state(c, cs, b, h, lane, cost2, tau, gtau);
   cost2 = row16_sum(cost2);
   if (lane == 0) c.cost[h] += cost2;
 }
@@ -961,6 +985,8 @@ constexpr bool kStampTerms = true;  // diagnostic builds only: the stamps cost t
 constexpr bool kStampTerms = false;
 #endif
 
+template <class SH> constexpr bool fused_shape_is_plain() { if constexpr (SH::kStatic) return SH::kPlain; else return false; }
+
 // TERMS: the optional tool-pose / c-space STATE terms are compiled in (separate instantiation so the
 // collision-only kernel keeps its register budget: with them inlined it spilled 232 B per lane)
 template <int DEG, int SWEEP, int KINDS, bool TERMS, class SH = FusedShapeDyn>
@@ -969,6 +995,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const int H = a.bs.padded_horizon, D = a.bs.dof, L = a.nlinks, S = a.nspheres, P = a.npairs;
   const int n_rec = a.sc.max_cuboids + a.sc.max_voxel_grids;
   const bool use_pose = TERMS && a.use_pose != 0, use_cspace = TERMS && a.use_cspace != 0;
+  constexpr bool kPlainTerms = TERMS && fused_shape_is_plain<SH>();
   constexpr int kRings = TERMS ? 1 : 2;  // the TERMS variant has no LDS to spare for the second ring (dense obstacle tests)
   const bool use_lanes = a.lane_lists != nullptr && a.use_self;
   const FusedLayout lay = fused_layout(H, D, L, S, a.chain_len, P, n_rec, use_cspace ? 4 * H * D : 0, (int)blockDim.x >> 6, kRings,
@@ -991,6 +1018,9 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
       __builtin_assume(a.out_position == nullptr); __builtin_assume(a.out_spheres == nullptr); __builtin_assume(a.prof == nullptr);
       __builtin_assume(a.use_multi_env == 0); __builtin_assume(a.num_envs == 1); __builtin_assume(a.scene_rows == 0);
       __builtin_assume(a.dispatch_ws != nullptr); __builtin_assume(a.sphere_padding != nullptr);
+      if constexpr (TERMS) {  // ... of a trajectory-optimisation iteration (fused_plain_terms): tool pose + c-space STATE, no torque limits
+        __builtin_assume(a.use_pose == 1); __builtin_assume(a.use_cspace == 1); __builtin_assume(a.use_torque == 0);
+      }
     }
   }
   // trajectory of this workgroup: blockIdx.x itself, or the entry of the longest-first order that the
@@ -1025,7 +1055,7 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   const float bs_dt = a.bs.traj_dt[bs_go];
   const bool bs_implicit = a.bs.use_implicit_goal[bs_go] != 0;
   fused_stage_tables(c, a, lay, rs, n_rec);
-  if (use_cspace) stage_cspace_tables(c, a.cs, b);
+  if (use_cspace) stage_cspace_tables(c, kernarg_block<CspaceStateArgs>(offsetof(FusedTrajArgs, cs)), b);
   for (int e = rotated_tid(nwaves / 2); e < H * D; e += nt) {
     const int h = e / D, d = e - h * D;
     float o4[4];
@@ -1395,11 +1425,11 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
     for (int h = grp; h < H; h += ngroups) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      point_pose_term(c, a, b, h, lane, lane64);
+      point_pose_term<kPlainTerms>(c, b, h, lane, lane64);
     }
   CUROBO_STAMP(13);
   if (TERMS && use_cspace)
-    for (int h = grp; h < H; h += ngroups) point_cspace_term(c, a, b, h, lane, use_torque ? tq_tau : nullptr, tq_gtau);
+    for (int h = grp; h < H; h += ngroups) point_cspace_term<kPlainTerms>(c, b, h, lane, use_torque ? tq_tau : nullptr, tq_gtau);
   CUROBO_STAMP(14);
   for (int h = grp; h < H; h += ngroups) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1616,6 +1646,11 @@ static bool fused_plain_launch(const FusedTrajArgs &a) {
          a.prof == nullptr && a.use_multi_env == 0 && a.num_envs == 1 && a.scene_rows == 0 && a.dispatch_ws != nullptr &&
          a.sphere_padding != nullptr;
 }
+// ... and of its TERMS instantiation: a trajectory-optimisation iteration (pose + c-space STATE, no torque limits, no cost outputs)
+static bool fused_plain_terms(const FusedTrajArgs &a) {
+  return a.use_pose == 1 && a.use_cspace == 1 && a.use_torque == 0 && a.tp.out_distance == nullptr && a.tp.out_position_distance == nullptr &&
+         a.tp.out_rotation_distance == nullptr && a.tp.out_goalset_idx == nullptr && a.cs.out_cost == nullptr;
+}
 template <class SH>
 static bool fused_shape_matches(const FusedTrajArgs &a, int threads) {
   if (SH::kPlain && !fused_plain_launch(a)) return false;
@@ -1638,7 +1673,7 @@ int CUROBO_FUSED_CAT(fused_shape_launch_, CUROBO_FUSED_SHAPE_TU)(CUROBO_FUSED_SH
   using SH = CUROBO_FUSED_CAT(CUROBO_FUSED_SHAPE_, CUROBO_FUSED_SHAPE_TU);
   if (!fused_shape_matches<SH>(a, threads)) return 0;
 #define CUROBO_FUSED_SHAPE_KERNEL(DG, SW, KD, TM)                                                                      \
-  if (deg == DG && sweep == SW && kinds == KD && terms == TM) {                                                        \
+  if (deg == DG && sweep == SW && kinds == KD && terms == TM && (!(TM) || !SH::kPlain || fused_plain_terms(a))) {      \
     auto kfn = rollout_trajectory_fused_kernel<DG, SW, KD, TM, SH>;                                                    \
     if (batch <= 0) return 1; /* query only */                                                                         \
     *err = lds > 64 * 1024 ? hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess; \
@@ -1793,6 +1828,7 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_kn
     a.use_self = 1; a.use_scene = 1; a.enable_speed_metric = 1; a.num_envs = 1; a.dispatch_ws = &some_ws; a.sphere_padding = &some_float;
   }
   a.use_cspace = with_trajopt_terms ? 1 : 0;
+  a.use_pose = (with_trajopt_terms && plain_launch) ? 1 : 0;  // (plain + terms = a trajectory-optimisation iteration: pose + c-space STATE)
   int threads;
   (void)fused_resolve_layout(a, max_cuboids + max_voxel_grids, with_trajopt_terms != 0, &threads);
   {

@@ -37,7 +37,8 @@ def test_packaged_robots_take_their_compile_time_shapes():
     assert _shape(franka, 33, 3, 0) == 2 and _shape(franka, 33, 7, 0) == 2, "Franka, any cuboid scene, plain launch"
     assert _shape(franka, 33, 2, 1) == 2, "cuboids + ESDF"
     assert _shape(franka, 33, 4, 0, plain_launch=False) == 3, "materialised outputs / several environments / profile stamps"
-    assert _shape(franka, 33, 4, 0, terms=True) == 3 and _shape(franka, 33, 4, 0, terms=True, plain_launch=False) == 3, "the full trajopt cost set"
+    assert _shape(franka, 33, 4, 0, terms=True) == 2, "the full trajopt cost set as an optimiser iteration (pose + c-space STATE, no cost outputs)"
+    assert _shape(franka, 33, 4, 0, terms=True, plain_launch=False) == 3, "... with metrics outputs / torque limits"
     assert _shape(franka, 65, 2, 1) == 4 and _shape(franka, 65, 5, 0, plain_launch=False) == 4, "BASELINE C5: horizon 64"
     assert _shape(ur10e, 33, 0, 1) == 5 and _shape(ur10e, 33, 4, 0) == 5, "BASELINE C3: UR10e"
     assert _shape(ur10e, 33, 0, 1, plain_launch=False) == 6
@@ -71,7 +72,7 @@ def test_table_rows_are_consistent_with_the_build():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["c2", "c2_materialized", "franka_3_cuboids", "franka_h65_mixed", "ur10e_esdf", "ur10e_esdf_materialized",
-                                  "franka_terms"])
+                                  "franka_terms", "franka_terms_metrics"])
 def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device):
     """the same launch through the compile-time shape and through the generic kernel: every output bit equal"""
     from curobo_amd.backends.rollout import set_fused_shapes_enabled
@@ -97,7 +98,7 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
     B = 96
     knots = torch.as_tensor(seed_knots(model, B, 12, seed=5), device=device).reshape(B, -1)
     start = torch.as_tensor(start_configuration(model), device=device)
-    if case == "franka_terms":  # the full cost set (pose + c-space + self + swept scene)
+    if case.startswith("franka_terms"):  # the full cost set (pose + c-space + self + swept scene); _metrics: with the per-term outputs
         from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
 
         rng = np.random.default_rng(2)
@@ -115,7 +116,10 @@ def test_specialised_launch_is_bit_identical_to_the_generic_kernel(case, device)
     try:
         for enabled in (True, False, True):
             set_fused_shapes_enabled(enabled)
-            c, g = ro.cost_and_gradient_fused(knots) if case == "franka_terms" else ro.cost_and_gradient(knots)
+            if case.startswith("franka_terms"):
+                c, g = ro.cost_and_gradient_fused(knots, with_metrics=case.endswith("_metrics"))
+            else:
+                c, g = ro.cost_and_gradient(knots)
             torch.cuda.synchronize()
             outs.append((c.clone(), g.clone()))
     finally:
@@ -192,3 +196,45 @@ def test_run_time_shape_is_bit_identical_to_the_generic_kernel(device, tmp_path,
     torch.cuda.synchronize()
     assert float(c0.abs().sum()) > 0
     assert torch.equal(c1, c0) and torch.equal(g1, g0) and torch.equal(c2, c0) and torch.equal(g2, g0)
+
+
+@pytest.mark.gpu
+def test_run_time_shape_of_the_full_trajopt_cost_set(device, tmp_path, monkeypatch):
+    """TrajOptRolloutCfg(jit_shape=True), Franka with 8 knots: the optimiser-iteration form (pose + c-space STATE + self + swept
+    scene, no cost outputs) and the metrics form each get their run-time shape; both give the generic kernel's bits."""
+    from curobo_amd.backends.rollout import set_fused_shapes_enabled
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    monkeypatch.setenv("CUROBO_HIP_JIT_CACHE", str(tmp_path))
+    model = load_model("franka")
+    kin = KinematicsParams.from_model(model, device)
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
+    B = 64
+    ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg(n_knots=8, traj_dt=0.1, jit_shape=True))
+    ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
+    rng = np.random.default_rng(4)
+    gq = rng.normal(size=(2, 1, 1, 4)).astype(np.float32)
+    gq /= np.linalg.norm(gq, axis=-1, keepdims=True)
+    ro.update_goals(torch.as_tensor(rng.normal(size=(2, 1, 1, 3)).astype(np.float32) * 0.4, device=device), torch.as_tensor(gq, device=device),
+                    torch.as_tensor(rng.integers(0, 2, size=B).astype(np.int32), device=device))
+    x = torch.as_tensor(seed_knots(model, B, 8, seed=5), device=device).reshape(B, -1)
+    assert ro.fused_available()
+    H = ro.cfg.padded_horizon
+    assert _shape(model, H, 4, 0, n_knots=8, terms=True) == 0
+    outs = {}
+    ro.cost_and_gradient(x)  # (the rollout's first call builds and registers both forms)
+    for metrics in (False, True):
+        c1, g1 = [t.clone() for t in ro.cost_and_gradient_fused(x.view(B, 8, -1), with_metrics=metrics)]
+        set_fused_shapes_enabled(False)
+        try:
+            c0, g0 = [t.clone() for t in ro.cost_and_gradient_fused(x.view(B, 8, -1), with_metrics=metrics)]
+        finally:
+            set_fused_shapes_enabled(True)
+        torch.cuda.synchronize()
+        assert float(c0.abs().sum()) > 0 and torch.equal(c1, c0) and torch.equal(g1, g0)
+        outs[metrics] = c0
+    assert _shape(model, H, 4, 0, n_knots=8, terms=True) >= 100 and _shape(model, H, 4, 0, n_knots=8, terms=True, plain_launch=False) >= 100
+    assert torch.equal(outs[False], outs[True]), "the outputs do not change the cost"
