@@ -1402,9 +1402,13 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   RneaArgs rn{};
   if (use_torque) {
     __syncthreads();  // row 0 has applied the leftover point's self-collision pair: pair list, spheres and rings are dead
-    rn.fixed_transforms = a.fixed_transform; rn.link_masses_com = a.link_masses_com; rn.link_inertias = a.link_inertias;
-    rn.joint_map_type = a.joint_map_type; rn.joint_map = a.joint_map; rn.link_map = a.link_map;
-    rn.joint_offset_map = a.joint_offset; rn.gravity = a.gravity; rn.level_links = a.level_links;
+#define CUROBO_KA(T, f) kernarg_block<T>(offsetof(FusedTrajArgs, f))
+    rn.fixed_transforms = CUROBO_KA(const float *, fixed_transform); rn.link_masses_com = CUROBO_KA(const float *, link_masses_com);
+    rn.link_inertias = CUROBO_KA(const float *, link_inertias); rn.joint_map_type = CUROBO_KA(const int8_t *, joint_map_type);
+    rn.joint_map = CUROBO_KA(const int16_t *, joint_map); rn.link_map = CUROBO_KA(const int16_t *, link_map);
+    rn.joint_offset_map = CUROBO_KA(const float *, joint_offset); rn.gravity = CUROBO_KA(const float *, gravity);
+    rn.level_links = CUROBO_KA(const int16_t *, level_links);
+#undef CUROBO_KA
     rn.num_links = L; rn.num_dof = D; rn.batch = H;
     rn.q = tq_q; rn.qd = tq_q + H * D; rn.qdd = tq_q + 2 * H * D; rn.tau = tq_tau; rn.cache = c.work;
     for (int e = tid; e < H * D; e += nt) {
@@ -1449,10 +1453,15 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   CUROBO_STAMP(3);
 
   // ---------------- P3: B-spline VJP + trajectory cost
+  // (its pointers come from the argument segment here, kernarg_block: read through `a` they are loaded at entry and stay in
+  // scalar registers across the collision pass)
   const int nk = a.bs.n_knots;
-  const int go = a.bs.goal_idx[b];
-  const float traj_dt = a.bs.traj_dt[go];
-  const bool use_goal = a.bs.use_implicit_goal[go] != 0;
+  constexpr size_t kBs = offsetof(FusedTrajArgs, bs);
+  const int go = kernarg_block<const int32_t *>(kBs + offsetof(BsFwdArgs, goal_idx))[b];
+  const float traj_dt = kernarg_block<const float *>(kBs + offsetof(BsFwdArgs, traj_dt))[go];
+  const bool use_goal = kernarg_block<const uint8_t *>(kBs + offsetof(BsFwdArgs, use_implicit_goal))[go] != 0;
+  float *const out_grad_knots = kernarg_block<float *>(offsetof(FusedTrajArgs, out_grad_knots));
+  float *const out_cost = kernarg_block<float *>(offsetof(FusedTrajArgs, out_cost));
   const float *gin[4] = {c.q, use_cspace ? c.dyn : nullptr, use_cspace ? c.dyn + H * D : nullptr,
                          use_cspace ? c.dyn + 2 * H * D : nullptr};
   // TERMS variant: the thread id is recomputed here (uniform wave index * 64 + mbcnt, opaque to CSE)
@@ -1465,20 +1474,22 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   }
   for (int e = tid3; e < nk * D; e += nt) {
     const int k = e / D, d = e - k * D;
-    a.out_grad_knots[(size_t)b * nk * D + e] = bspline_knot_grad<DEG>(gin, (size_t)d, D, k, nk, H, traj_dt, use_goal);
+    out_grad_knots[(size_t)b * nk * D + e] = bspline_knot_grad<DEG>(gin, (size_t)d, D, k, nk, H, traj_dt, use_goal);
   }
   if (tid3 == 0) {
     float acc = 0.0f;
     for (int h = 0; h < H; h++) acc += c.cost[h];
-    a.out_cost[b] = acc;
+    out_cost[b] = acc;
   }
   CUROBO_STAMP(4);
 #undef CUROBO_STAMP
   if (reorder) {
-    if (tid3 == 0) a.dispatch_ws[(size_t)(2 + a.dispatch_phase) * a.batch + b] = (int)(wall_clock64() - t_begin);
+    int32_t *const ws = kernarg_block<int32_t *>(offsetof(FusedTrajArgs, dispatch_ws));
+    const int phase = kernarg_block<int>(offsetof(FusedTrajArgs, dispatch_phase)), n_traj = kernarg_block<int>(offsetof(FusedTrajArgs, batch));
+    if (tid3 == 0) ws[(size_t)(2 + phase) * n_traj + b] = (int)(wall_clock64() - t_begin);
     if (blockIdx.x == (gridDim.x - 1) / 2) {
       __syncthreads();
-      rebuild_dispatch_order(a.dispatch_ws, a.batch, a.dispatch_phase, reinterpret_cast<int *>(smem), tid3, nt);
+      rebuild_dispatch_order(ws, n_traj, phase, reinterpret_cast<int *>(smem), tid3, nt);
     }
   }
 }
