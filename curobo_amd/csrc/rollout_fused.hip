@@ -627,7 +627,10 @@ __device__ __forceinline__ void point_sphere(const FusedCtx &c, const FusedTrajA
 // (n, hh, tool frame 0) in the optional metric outputs.
 __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPoseArgs &tp, const int16_t *tool_frame_map,
                                                 int T, int n, int hh, int h, size_t out_index0, float *out_link_pos,
-                                                float *out_link_quat, int lane, int lane64, float &cost_pt, bool &any_grad) {
+                                                float *out_link_quat, int lane, int lane64, float &cost_pt, bool &any_grad,
+                                                uint32_t *row_bits = nullptr) {
+  // (n, hh, h, out_index0 and lane may differ from lane to lane: point_pose_term_pair puts two points on one row; the lanes of
+  // the row that contributed a gradient are then reported in row_bits)
   const float *cumul = c.cumul + (size_t)h * c.L * 12;
   float *wr = c.wrench + (size_t)h * c.wl;
   int lane_o = lane;
@@ -661,6 +664,7 @@ __device__ __forceinline__ void point_tool_pose(const FusedCtx &c, const ToolPos
     // one contributing lane at a time (lane order): reproducible fp32 sums
     unsigned long long mk = __ballot(gp.x != 0.f || gp.y != 0.f || gp.z != 0.f || om.x != 0.f || om.y != 0.f || om.z != 0.f);
     any_grad = any_grad || ((mk >> (lane64 & 48)) & 0xffffull) != 0ull;
+    if (row_bits) *row_bits |= (uint32_t)((mk >> (lane64 & 48)) & 0xffffull);
     while (mk) {
       const int src = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
@@ -938,6 +942,49 @@ __device__ __forceinline__ void point_cspace_term(const FusedCtx &c, int b, int 
   point_cspace_state(c, cs, b, h, lane, cost2, tau, gtau);
   cost2 = row16_sum(cost2);
   if (lane == 0) c.cost[h] += cost2;
+}
+// The same two terms for TWO points on one 16-lane row.  With H = rows + 1 points (33 on 32 rows) the loops over the row's points
+// run a second time for the one leftover point while 31 rows wait, and these passes are latency (the pose pass: 1.8 us per
+// point, quaternion / atan2 / square roots on ONE lane per tool frame; the c-space pass: one lane per dof): the leftover point
+// rides on the idle lanes of row 0 instead -- tool frames on lanes T .. 2T-1 (2T <= 16), dofs on lanes 8 .. 8+D-1 (D <= 8).
+// Per lane the arithmetic is that of the single-point functions; each point's cost is summed from ITS lanes moved to the
+// positions the single-point pass has them in (same reduction tree, same bits); wrenches are added per point in lane order.
+template <bool NO_OUT>
+__device__ __forceinline__ void point_pose_term_pair(const FusedCtx &c, int b, int h, int h2, int lane, int lane64) {
+  ToolPoseArgs tp = kernarg_block<ToolPoseArgs>(offsetof(FusedTrajArgs, tp));
+  if (NO_OUT) { tp.out_distance = nullptr; tp.out_position_distance = nullptr; tp.out_rotation_distance = nullptr; tp.out_goalset_idx = nullptr; }
+  const int16_t *tool_frame_map = kernarg_block<const int16_t *>(offsetof(FusedTrajArgs, tool_frame_map));
+  const int T = kernarg_block<int>(offsetof(FusedTrajArgs, n_tool_frames));
+  const bool second = h2 >= 0 && lane >= T && lane < 2 * T;
+  const int hp = second ? h2 : h, lt = second ? lane - T : (lane < T ? lane : T);  // (lt = T: the lane has no tool frame)
+  const bool had = c.flag[h] != 0, had2 = h2 >= 0 && c.flag[h2] != 0;
+  bool any = false;
+  uint32_t bits = 0u;
+  float cost2 = 0.0f;
+  point_tool_pose(c, tp, tool_frame_map, T, b, hp, hp, ((size_t)b * c.H + hp) * T, nullptr, nullptr, lt, lane64, cost2, any, &bits);
+  const float moved = __shfl(cost2, (lane + T) & (kFkLanes - 1), kFkLanes);
+  const float ca = row16_sum(lane < T ? cost2 : 0.0f), cb = row16_sum(lane < T ? moved : 0.0f);
+  const uint32_t low = (1u << T) - 1u;
+  if (lane == 0) {
+    c.cost[h] += ca;
+    c.flag[h] = (had || (bits & low) != 0u) ? 1 : 0;
+    if (h2 >= 0) { c.cost[h2] += cb; c.flag[h2] = (had2 || ((bits >> T) & low) != 0u) ? 1 : 0; }
+  }
+}
+template <bool NO_OUT>
+__device__ __forceinline__ void point_cspace_term_pair(const FusedCtx &c, int b, int h, int h2, int lane, const float *tau, float *gtau) {
+  CspaceStateArgs cs = kernarg_block<CspaceStateArgs>(offsetof(FusedTrajArgs, cs));
+  if (NO_OUT) cs.out_cost = nullptr;
+  const bool second = lane >= 8;
+  const int hp = second ? (h2 >= 0 ? h2 : h) : h, ld = (second && h2 < 0) ? c.D : (lane & 7);  // (ld >= D: nothing to do)
+  float cost2 = 0.0f;
+  point_cspace_state(c, cs, b, hp, ld, cost2, tau, gtau);
+  const float moved = __shfl(cost2, lane ^ 8, kFkLanes);
+  const float ca = row16_sum(second ? 0.0f : cost2), cb = row16_sum(second ? 0.0f : moved);
+  if (lane == 0) {
+    c.cost[h] += ca;
+    if (h2 >= 0) c.cost[h2] += cb;
+  }
 }
 
 // Longest-first dispatch of the trajectory workgroups.  A launch is two rounds of workgroups on the
@@ -1425,15 +1472,27 @@ __global__ void __launch_bounds__(1024, 4) rollout_trajectory_fused_kernel(const
   // allocation of the collision pass above is not shared with the optional terms, and so that those
   // are instantiated once): tool pose, c-space STATE, then the VJP gather
   CUROBO_STAMP(12);
-  if (TERMS && use_pose)
-    for (int h = grp; h < H; h += ngroups) {
+  const bool pair_left = H == ngroups + 1;  // one leftover point: it shares row 0 with point 0 in the two passes below
+  if (TERMS && use_pose) {
+    if (pair_left && 2 * a.n_tool_frames <= kFkLanes) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      point_pose_term<kPlainTerms>(c, b, h, lane, lane64);
+      point_pose_term_pair<kPlainTerms>(c, b, grp, grp == 0 ? H - 1 : -1, lane, lane64);
+    } else {
+      for (int h = grp; h < H; h += ngroups) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        point_pose_term<kPlainTerms>(c, b, h, lane, lane64);
+      }
     }
+  }
   CUROBO_STAMP(13);
-  if (TERMS && use_cspace)
-    for (int h = grp; h < H; h += ngroups) point_cspace_term<kPlainTerms>(c, b, h, lane, use_torque ? tq_tau : nullptr, tq_gtau);
+  if (TERMS && use_cspace) {
+    if (pair_left && D <= 8)
+      point_cspace_term_pair<kPlainTerms>(c, b, grp, grp == 0 ? H - 1 : -1, lane, use_torque ? tq_tau : nullptr, tq_gtau);
+    else
+      for (int h = grp; h < H; h += ngroups) point_cspace_term<kPlainTerms>(c, b, h, lane, use_torque ? tq_tau : nullptr, tq_gtau);
+  }
   CUROBO_STAMP(14);
   for (int h = grp; h < H; h += ngroups) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
