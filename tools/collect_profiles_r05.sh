@@ -11,7 +11,7 @@
 set -u
 TAG=${1:-r05}
 shift || true
-CFGS=${*:-c2 c3 c4 c5 mesh}
+CFGS=${*:-c2 c3 c4 c5 mesh trajopt}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT/summary"

@@ -142,8 +142,27 @@ def mesh():
                                              ro.env_query_idx, B, cfg.padded_horizon, kin.num_spheres, False, 3, True, ro._speed_dt))
 
 
+def trajopt():
+    """the fused launch with the FULL trajectory-optimisation cost set (tool pose + c-space STATE + self + swept scene), C2 shapes:
+    1024 trajectories (the bench's `full_trajopt_rollout`) and 32 (one problem x 8 seeds x 4 candidates: a planner's iteration)"""
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.workloads import c2_world, seed_knots, start_configuration
+
+    kcfg = KinematicsCfg.from_packaged("franka", device=dev)
+    model, kin = kcfg.model, kcfg.kinematics_config
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), dev)
+    for B in (1024, 32):
+        ro = TrajOptRollout(kin, scene, B, TrajOptRolloutCfg())
+        ro.update_start_state(torch.as_tensor(start_configuration(model), device=dev))
+        x = torch.as_tensor(seed_knots(model, B, 12, seed=2), device=dev).reshape(B, -1)
+        run(lambda: ro.cost_and_gradient(x))
+
+
 if __name__ == "__main__":
-    want = [a for a in sys.argv[1:] if a in ("c2", "c3", "c4", "c5", "mesh")] or ["c2", "c3", "c4", "c5", "mesh"]
+    known = ("c2", "c3", "c4", "c5", "mesh", "trajopt")
+    want = [a for a in sys.argv[1:] if a in known] or list(known)
     for w in want:
         globals()[w]()
     print("ran", want)
