@@ -1583,8 +1583,9 @@ def trajopt_solve_benchmark(model, kin, scene, device, torch):
         res[f"{P}_problems_x_{S}_seeds"]["with_convergence_exit"] = {
             "ms_per_batch": round((time.perf_counter() - t0) / reps * 1e3, 2), "success_rate": round(float(r2.success.float().mean()), 3),
             "iterations_of_the_last_pass": its}
-    res["workload"] = ("Franka, C2 world, 32-step horizon, pose goal; IK (64 seeds, 100 iterations) + trajopt (100 iterations, "
-                       "pose + c-space state + self + swept scene collision) + metrics; context only: the reference "
+    res["workload"] = ("Franka, C2 world, 32-step horizon, pose goal; IK (64 seeds: Levenberg-Marquardt seed stage, its L-BFGS stage only "
+                       "when the seed stage leaves a problem unsolved, exit_early as the reference's planner) + trajopt (100 iterations, "
+                       "pose + c-space state + self + swept scene collision) + finetune pass + metrics; context only: the reference "
                        "publishes 31 ms mean solve time for its full motion planner on an RTX 6000 Ada")
     return res
 

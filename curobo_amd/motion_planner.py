@@ -593,7 +593,7 @@ class _PlannerBase:
             gq = torch.cat([gq, gq[:, :, -1:].expand(batch, T, G - g, 4)], 2)
         pad = lambda x: x if batch == n else torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], 0)  # noqa: E731
         env = torch.arange(n, device=dev, dtype=torch.int32) if c.multi_env else None
-        r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, exit_early=False, env_idx=env)
+        r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, env_idx=env)  # (the configured exit_early: reference motion_planner.py:249-253)
         return r.success.reshape(n, k)[:batch], r.solution.reshape(n, k, -1)[:batch]
 
 

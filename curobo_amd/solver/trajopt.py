@@ -298,11 +298,13 @@ class TrajOptSolver:
         start = start_position.to(self.device, torch.float32).reshape(-1, D)
         ik_ok = None
         if seed_config is None and seed_traj is None:
-            # the L-BFGS stage of the IK always runs here: the goal configurations should be converged, not just inside the
-            # IK tolerances (the reference's motion planner switches exit_early off as well, motion_planner.py:143-144)
+            # the IK stage with the IK solver's own configuration (exit_early = True by default): when the Levenberg-Marquardt
+            # seed stage already solves every problem its L-BFGS stage is skipped, as in the reference's planner
+            # (motion_planner.py:249-253 calls ik_solver.solve_pose with the configured exit_early; it is switched off only
+            # for the warm-up, :143-144 and :179, so that the optimiser's graph gets captured)
             K = self.K
             gp_ik, gq_ik = self._goal_sets(goal_position, goal_quat)
-            ikr = self.ik.solve_pose(gp_ik[:, 0], gq_ik[:, 0], return_seeds=K, exit_early=False, env_idx=env_idx)
+            ikr = self.ik.solve_pose(gp_ik[:, 0], gq_ik[:, 0], return_seeds=K, env_idx=env_idx)
             ik_ok = ikr.success.view(P, K)
             ik_q = ikr.solution.reshape(P, K, D).contiguous()
             choice = self.seed_goal_choice(ik_ok)  # [P, S_global]
