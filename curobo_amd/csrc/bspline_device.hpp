@@ -37,6 +37,13 @@ static __device__ __constant__ float kFix5[4][6] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0
                                              {1.75f, 0.25f, -0.25f, 0.25f, 1.75f, 4.25f},
                                              {-0.833333f, 0.083333f, 0.0f, -0.083333f, 0.833333f, 3.75f}};
 
+// a / b of two small integers as the reference computes it (IEEE fp32 division, nvcc's default; interpolate_bspline_kernel's
+// t_mod, bspline_kernel.cuh:118).  This library is compiled without correctly rounded fp32 division, and where a compile-time
+// shape of the fused launch knows both operands the compiler folds the quotient exactly: the two were one ulp apart for step
+// counts that are not powers of two (found by tests/randomised/fuzz_fused.py with run-time shapes).  Through fp64 the quotient
+// rounds to fp32 once, correctly, in every instantiation.
+__device__ __forceinline__ float exact_ratio(int a, int b) { return (float)((double)a / (double)b); }
+
 template <int DEG>
 __device__ __forceinline__ float bcoef(int i, int j) {
   if (DEG == 3) return kB3[i][j];
@@ -135,7 +142,7 @@ __device__ __forceinline__ float bspline_sample_pre(const BsFwdArgs &a, int b, i
   }
   const bool req_start = knot_idx < SUP;
   const bool req_goal = implicit_goal ? (knot_idx > a.n_knots - 1) : (knot_idx > a.n_knots);
-  float t_mod = interp > 0 ? ((float)h / (float)interp) - (float)(int)(h / interp) : 0.0f;
+  float t_mod = interp > 0 ? exact_ratio(h, interp) - (float)(int)(h / interp) : 0.0f;
   if (past_end) t_mod = 1.0f;
   const float dt2 = knot_dt * knot_dt, dt3 = knot_dt * knot_dt * knot_dt;
   if (req_start || req_goal) {
@@ -242,7 +249,7 @@ __device__ __forceinline__ float bspline_knot_grad(const float *const *gin, size
       }
     }
     const int h_idx = (k + DEG) * interp + ii;
-    const float t_mod = ((float)h_idx / (float)interp) - (float)(int)(h_idx / interp);
+    const float t_mod = exact_ratio(h_idx, interp) - (float)(int)(h_idx / interp);
     float bs[SUP];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     basis<DEG, 0>(t_mod, bs);

@@ -166,9 +166,12 @@ def test_run_time_shape_compiles_loads_and_serves_its_dimensions(tmp_path, monke
 
 
 @pytest.mark.gpu
-def test_run_time_shape_is_bit_identical_to_the_generic_kernel(device, tmp_path, monkeypatch):
-    """CollisionRolloutCfg(jit_shape=True) on dimensions outside the shipped table (Franka, 10 knots x 2): the first call builds
-    and registers the shape, later launches run it -- same bits as the generic kernel."""
+@pytest.mark.parametrize("n_knots,steps", [(10, 2), (11, 3)])
+def test_run_time_shape_is_bit_identical_to_the_generic_kernel(n_knots, steps, device, tmp_path, monkeypatch):
+    """CollisionRolloutCfg(jit_shape=True) on dimensions outside the shipped table (Franka, 10 knots x 2; 11 knots x 3): the first
+    call builds and registers the shape, later launches run it -- same bits as the generic kernel.  Three interpolation steps: the
+    sample parameter h / 3 is where a shape (quotient folded at compile time) and the generic kernel (run-time division, this
+    library is built without correctly rounded fp32 division) were one ulp apart until bspline_device.hpp::exact_ratio."""
     from curobo_amd.backends.rollout import set_fused_shapes_enabled
     from curobo_amd.robot.kinematics_params import KinematicsParams
     from curobo_amd.rollout import CollisionRollout, CollisionRolloutCfg
@@ -180,13 +183,14 @@ def test_run_time_shape_is_bit_identical_to_the_generic_kernel(device, tmp_path,
     kin = KinematicsParams.from_model(model, device)
     scene = SceneData.from_arrays(cuboid_scene_arrays(c2_world()), device)
     B = 64
-    ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(n_knots=10, jit_shape=True))
-    assert ro.cfg.padded_horizon == 29
+    ro = CollisionRollout(kin, scene, B, CollisionRolloutCfg(n_knots=n_knots, interpolation_steps=steps, jit_shape=True))
+    H = ro.cfg.padded_horizon
+    assert H == (n_knots + 4) * steps + 1
     ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
-    x = torch.as_tensor(seed_knots(model, B, 10, seed=5), device=device).reshape(B, -1)
-    assert _shape(model, 29, 4, 0, n_knots=10) == 0
+    x = torch.as_tensor(seed_knots(model, B, n_knots, seed=5), device=device).reshape(B, -1)
+    assert _shape(model, H, 4, 0, n_knots=n_knots) == 0
     c1, g1 = [t.clone() for t in ro.cost_and_gradient(x)]  # (compiles here)
-    assert _shape(model, 29, 4, 0, n_knots=10) >= 100
+    assert _shape(model, H, 4, 0, n_knots=n_knots) >= 100
     c2, g2 = [t.clone() for t in ro.cost_and_gradient(x)]
     set_fused_shapes_enabled(False)
     try:
