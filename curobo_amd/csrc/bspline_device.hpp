@@ -37,11 +37,12 @@ static __device__ __constant__ float kFix5[4][6] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0
                                              {1.75f, 0.25f, -0.25f, 0.25f, 1.75f, 4.25f},
                                              {-0.833333f, 0.083333f, 0.0f, -0.083333f, 0.833333f, 3.75f}};
 
-// a / b of two small integers as the reference computes it (IEEE fp32 division, nvcc's default; interpolate_bspline_kernel's
-// t_mod, bspline_kernel.cuh:118).  This library is compiled without correctly rounded fp32 division, and where a compile-time
-// shape of the fused launch knows both operands the compiler folds the quotient exactly: the two were one ulp apart for step
-// counts that are not powers of two (found by tests/randomised/fuzz_fused.py with run-time shapes).  Through fp64 the quotient
-// rounds to fp32 once, correctly, in every instantiation.
+// a / b of two small integers, correctly rounded (interpolate_bspline_kernel's t_mod = h / steps, bspline_kernel.cuh:118).  The
+// reference builds its kernels with --prec-div=false and this library without correctly rounded fp32 division either, so the
+// run-time quotient is an approximation on both -- but where a compile-time shape of the fused launch knows both operands the
+// compiler folds it exactly, and shape and generic kernel were one ulp apart for step counts that are not powers of two (found
+// by tests/randomised/fuzz_fused.py under run-time shapes).  Through fp64 the quotient rounds to fp32 once, the same in every
+// instantiation, and equal to the oracle's IEEE division.
 __device__ __forceinline__ float exact_ratio(int a, int b) { return (float)((double)a / (double)b); }
 
 template <int DEG>
