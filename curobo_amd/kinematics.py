@@ -194,6 +194,70 @@ class Kinematics:
         return JointState(cat(p, lp), cat(active_js.velocity, z), cat(active_js.acceleration, z), cat(active_js.jerk, z),
                           list(active_js.joint_names or self.joint_names) + list(lock.joint_names), active_js.dt)
 
+    # ---- more of the reference's members (robot/kinematics/kinematics.py:75-100, 278-366, 443-497)
+    @property
+    def robot_spheres(self) -> torch.Tensor:
+        """the collision spheres in their link frames (sphere set 0), [num_spheres, 4]"""
+        return self.kinematics_config.link_spheres[0]
+
+    def update_batch_size(self, batch: int, horizon: int, force_update: bool = False, reset_buffers: bool = False) -> None:
+        """allocate the output buffers of ``compute_kinematics`` for [batch, horizon, dof] inputs ahead of the first call"""
+        if batch <= 0 or horizon <= 0:
+            raise ValueError("batch and horizon must be > 0")
+        if reset_buffers:
+            self._shape = None
+        self._setup(int(batch), int(horizon))
+
+    def get_link_poses(self, joint_position: torch.Tensor, query_link_names: List[str]):
+        """poses of tool frames at joint configurations [batch, dof] -> ``Pose`` [batch, len(query_link_names), 3 | 4]
+        (``query_link_names`` must be tool frames, as in the reference)"""
+        from .types import Pose
+
+        missing = [n for n in query_link_names if n not in self.tool_frames]
+        if missing:
+            raise ValueError(f"{missing} are not tool frames of this model ({self.tool_frames})")
+        q = joint_position if joint_position.ndim == 2 else joint_position.reshape(-1, self.dof)
+        tp = self.compute_kinematics(q).tool_poses
+        idx = [self.tool_frames.index(n) for n in query_link_names]
+        return Pose(tp.position[:, 0][:, idx].contiguous(), tp.quaternion[:, 0][:, idx].contiguous())
+
+    def _link_index(self, link_name: str) -> int:
+        names = self.kinematics_config.link_names
+        if names is None or link_name not in names:
+            raise ValueError(f"link {link_name} is not part of the kinematic model")
+        return list(names).index(link_name)
+
+    def get_link_transform(self, link_name: str):
+        """fixed offset of a link from its parent joint as a ``Pose`` (the model's ``fixed_transforms`` row)"""
+        from .types import Pose
+
+        return Pose.from_matrix(self._fixed_4x4(self.kinematics_config.fixed_transforms[self._link_index(link_name)].unsqueeze(0)))
+
+    def get_all_link_transforms(self):
+        from .types import Pose
+
+        return Pose.from_matrix(self._fixed_4x4(self.kinematics_config.fixed_transforms))
+
+    @staticmethod
+    def _fixed_4x4(m34: torch.Tensor) -> torch.Tensor:
+        m = torch.zeros(m34.shape[0], 4, 4, device=m34.device, dtype=m34.dtype)
+        m[:, :3, :4] = m34.reshape(-1, 3, 4)
+        m[:, 3, 3] = 1.0
+        return m
+
+    def update_kinematics_config(self, new_kin_config) -> None:
+        """copy the tensors of another ``KinematicsParams`` of the SAME dimensions into this model's, in place (captured
+        graphs and rollouts that hold the tensors see the new values): locked-joint offsets, attached-object spheres ..."""
+        import dataclasses
+
+        cur = self.kinematics_config
+        for f in dataclasses.fields(cur):
+            a, b = getattr(cur, f.name), getattr(new_kin_config, f.name)
+            if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+                if a.shape != b.shape:
+                    raise ValueError(f"update_kinematics_config: {f.name} changes shape {tuple(a.shape)} -> {tuple(b.shape)}; build a new Kinematics")
+                a.copy_(b)
+
     def get_robot_as_spheres(self, q: torch.Tensor, filter_valid: bool = True):
         """per configuration the robot's collision spheres as ``curobo.scene.Sphere`` objects (reference ``get_robot_as_spheres``);
         ``filter_valid`` drops the disabled ones (radius <= 0)"""

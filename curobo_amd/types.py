@@ -105,6 +105,27 @@ class Pose:
         t = torch.as_tensor([float(x) for x in pose], dtype=torch.float32, device=dev)
         return Pose(t[:3].view(1, 3).clone(), t[3:7].view(1, 4).clone())
 
+    @staticmethod
+    def from_matrix(matrix: torch.Tensor) -> "Pose":
+        """homogeneous transforms [..., 4, 4] (or [..., 3, 4]) -> Pose, quaternion wxyz with w >= 0 (reference Pose.from_matrix;
+        the rotation through the largest of the four squared components, the usual branch-stable conversion)"""
+        m = matrix.reshape(-1, matrix.shape[-2], matrix.shape[-1]).to(torch.float32)
+        R, t = m[:, :3, :3], m[:, :3, 3]
+        m00, m11, m22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+        four = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1).clamp_min(0.0)
+        k = four.argmax(-1)
+        h = 0.5 * torch.sqrt(four.gather(-1, k.unsqueeze(-1)).squeeze(-1)).clamp_min(1e-12)
+        q4 = 0.25 / h
+        cand = torch.stack([
+            torch.stack([h, (R[:, 2, 1] - R[:, 1, 2]) * q4, (R[:, 0, 2] - R[:, 2, 0]) * q4, (R[:, 1, 0] - R[:, 0, 1]) * q4], -1),
+            torch.stack([(R[:, 2, 1] - R[:, 1, 2]) * q4, h, (R[:, 0, 1] + R[:, 1, 0]) * q4, (R[:, 0, 2] + R[:, 2, 0]) * q4], -1),
+            torch.stack([(R[:, 0, 2] - R[:, 2, 0]) * q4, (R[:, 0, 1] + R[:, 1, 0]) * q4, h, (R[:, 1, 2] + R[:, 2, 1]) * q4], -1),
+            torch.stack([(R[:, 1, 0] - R[:, 0, 1]) * q4, (R[:, 0, 2] + R[:, 2, 0]) * q4, (R[:, 1, 2] + R[:, 2, 1]) * q4, h], -1)], 1)
+        q = cand[torch.arange(m.shape[0], device=m.device), k]
+        q = torch.where(q[:, :1] < 0, -q, q)
+        lead = matrix.shape[:-2]
+        return Pose(t.reshape(*lead, 3).contiguous(), q.reshape(*lead, 4).contiguous())
+
     def to(self, device) -> "Pose":
         return Pose(self.position.to(device), self.quaternion.to(device), self.name)
 

@@ -1,4 +1,4 @@
-"""``curobo_amd.types.Pose.multiply / inverse`` against the reference's ``Pose`` (types/pose.py; its Warp kernels run through the
+"""``curobo_amd.types.Pose.multiply / inverse / from_matrix`` against the reference's ``Pose`` (types/pose.py; its Warp kernels run through the
 stand-in) on random poses.   python tests/golden/compare_pose_ops.py        (needs /root/reference)"""
 import os
 import sys
@@ -37,4 +37,16 @@ for what, r, o in (("multiply", ra.multiply(rb), oa.multiply(ob)), ("inverse", r
     good = dp < 5e-6 and same_rotation(r.quaternion, o.quaternion)
     ok &= good
     print(f"{what}: {'ok' if good else 'DIFFERENT'} (max |dp| {dp:.2e})")
+# Pose.from_matrix (reference: Warp's quat_from_matrix through the stand-in): rotations incl. half turns about the axes
+from scipy.spatial.transform import Rotation  # noqa: E402
+
+mats = np.tile(np.eye(4, dtype=np.float32), (n + 3, 1, 1))
+mats[:n, :3, :3] = Rotation.from_quat(q1[:, [1, 2, 3, 0]]).as_matrix()
+mats[n:, :3, :3] = Rotation.from_rotvec(np.pi * np.eye(3)).as_matrix()
+mats[:n, :3, 3] = p1
+r, o = Ref.from_matrix(t(mats)), Ours.from_matrix(t(mats))
+dp = float(np.abs(r.position.detach().cpu().numpy().reshape(-1, 3) - o.position.detach().cpu().numpy().reshape(-1, 3)).max())
+good = dp < 1e-6 and same_rotation(r.quaternion, o.quaternion)
+ok &= good
+print(f"from_matrix: {'ok' if good else 'DIFFERENT'} (max |dp| {dp:.2e})")
 sys.exit(0 if ok else 1)

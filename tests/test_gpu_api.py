@@ -30,6 +30,13 @@ def test_kinematics_api_matches_oracle(oracle, device):
     np.testing.assert_allclose(st.robot_spheres.cpu().numpy().reshape(12, 65, 4), ref["robot_spheres"], atol=1e-5)
     np.testing.assert_allclose(st.tool_jacobians.cpu().numpy().reshape(12, 1, 6, 7), ref["jacobian"], atol=1e-5)
     assert st.tool_poses.tool_frames == ["panda_hand"]
+    # get_link_poses / update_batch_size (reference kinematics.py:75-100, 278-311)
+    kin.update_batch_size(12, 1)
+    lp = kin.get_link_poses(torch.as_tensor(q.reshape(12, 7), device=device), ["panda_hand"])
+    np.testing.assert_allclose(lp.position.cpu().numpy().reshape(12, 1, 3), ref["link_pos"], atol=1e-5)
+    np.testing.assert_allclose(lp.quaternion.cpu().numpy().reshape(12, 1, 4), ref["link_quat"], atol=1e-5)
+    with pytest.raises(ValueError, match="not tool frames"):
+        kin.get_link_poses(torch.zeros(1, 7, device=device), ["panda_link3"])
 
 
 def test_autograd_through_kinematics_matches_oracle_vjp(oracle, device):

@@ -333,6 +333,33 @@ def test_kinematics_accessors_and_result_helpers():
     with pytest.raises(ValueError, match="lacks the active joints"):
         k.get_active_js(JointState.from_position(torch.zeros(1, 2), joint_names=["a", "b"]))
     assert k.get_self_collision_config().collision_pairs.shape[0] == 818
+    # link offsets, the sphere set, in-place configuration updates (reference kinematics.py:345-366, 443-455, 476-478)
+    assert k.robot_spheres.shape == (65, 4) and k.robot_spheres.data_ptr() == k.kinematics_config.link_spheres.data_ptr()
+    kc = k.kinematics_config
+    i3 = list(kc.link_names).index("panda_link3")
+    t3 = k.get_link_transform("panda_link3")
+    np.testing.assert_allclose(t3.position.numpy().reshape(3), kc.fixed_transforms[i3].reshape(3, 4)[:, 3].numpy(), atol=1e-7)
+    all_t = k.get_all_link_transforms()
+    assert all_t.position.shape == (kc.fixed_transforms.shape[0], 3) and all_t.quaternion.shape == (kc.fixed_transforms.shape[0], 4)
+    R3 = kc.fixed_transforms[i3].reshape(3, 4)[:, :3].numpy()
+    w, x, y, z = all_t.quaternion[i3].tolist()
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    np.testing.assert_allclose(Rq, R3, atol=1e-6)
+    with pytest.raises(ValueError, match="not part of the kinematic model"):
+        k.get_link_transform("no_such_link")
+    import copy
+
+    other = copy.deepcopy(kc)
+    other.link_spheres[0, 3, 3] = 0.123
+    ptr = kc.link_spheres.data_ptr()
+    k.update_kinematics_config(other)
+    assert kc.link_spheres.data_ptr() == ptr and kc.link_spheres[0, 3, 3].item() == pytest.approx(0.123)
+    other.link_spheres = other.link_spheres[:, :-1]
+    with pytest.raises(ValueError, match="changes shape"):
+        k.update_kinematics_config(other)
+    with pytest.raises(ValueError, match="must be > 0"):
+        k.update_batch_size(0, 1)
 
     sol = torch.tensor([[[0.10, 0.2], [0.101, 0.2], [0.5, 0.5], [0.9, 0.9]]])
     res = InverseKinematicsResult(success=torch.tensor([[True, True, True, False]]), solution=sol, js_solution=None,
