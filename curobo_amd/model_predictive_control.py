@@ -25,6 +25,7 @@ from .scene import SceneData
 from .scene.config import scene_from_config
 from .solver.mpc import MPCSolver, MPCSolverCfg, MPCSolverResult
 from .types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPoseCriteria
+from .solver.tracking import ToolPoseTrackingMixin
 
 ModelPredictiveControlResult = MPCSolverResult
 
@@ -68,8 +69,11 @@ class ModelPredictiveControlCfg:
                                          max_batch_size=max_batch_size, solver=s)
 
 
-class ModelPredictiveControl:
+class ModelPredictiveControl(ToolPoseTrackingMixin):
     """the reference's ``MPCSolver`` call surface for ``max_batch_size`` robots"""
+
+    _tracking_non_terminal_factor = 1.0  # (a controller tracks the pose along the whole horizon: solver/mpc.py's non_terminal_pose_factor)
+
 
     def __init__(self, config: ModelPredictiveControlCfg):
         self.config = config

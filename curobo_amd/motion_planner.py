@@ -37,6 +37,7 @@ from .scene.config import scene_from_config
 from .solver.ik import IKSolver, IKSolverCfg
 from .solver.trajopt import TrajOptResult, TrajOptSolver, TrajOptSolverCfg
 from .types import DeviceCfg, GoalToolPose, JointState, Pose, ToolPoseCriteria
+from .solver.tracking import ToolPoseTrackingMixin
 
 
 def _load_kinematics(robot, device, assets_root: str = "", num_envs: int = 1) -> KinematicsCfg:
@@ -234,7 +235,7 @@ class TrajectoryOptimizerCfg:
         return c
 
 
-class TrajectoryOptimizer:
+class TrajectoryOptimizer(ToolPoseTrackingMixin):
     """the reference's ``TrajOptSolver`` call surface: ``solve_pose(goal_tool_poses, current_state, ...)`` and
     ``solve_cspace(goal_state, current_state, ...)`` on ``max_batch_size`` problems (smaller batches are padded with
     their first problem, as the reference does, :759-775)"""
@@ -481,7 +482,7 @@ class MotionPlannerCfg:
         return MotionPlannerCfg(trajopt_solver_config=to, num_ik_seeds=num_ik_seeds, device_cfg=device_cfg)
 
 
-class _PlannerBase:
+class _PlannerBase(ToolPoseTrackingMixin):
     def __init__(self, config: MotionPlannerCfg):
         self.config = config
         self.device_cfg = config.device_cfg

@@ -18,6 +18,7 @@ from ..scene import SceneData
 from ..scene.config import scene_from_config
 from ..types import DeviceCfg, GoalToolPose, JointState
 from .ik import IKSolver, IKSolverCfg
+from .tracking import ToolPoseTrackingMixin
 
 
 @dataclass
@@ -94,7 +95,7 @@ class InverseKinematicsCfg:
             max_batch_size=max_batch_size, max_goalset=max_goalset)
 
 
-class InverseKinematics:
+class InverseKinematics(ToolPoseTrackingMixin):
     def __init__(self, config: InverseKinematicsCfg):
         self.config = config
         self.kinematics = Kinematics(config.kinematics, compute_spheres=True)

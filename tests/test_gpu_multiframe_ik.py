@@ -109,6 +109,21 @@ def test_front_ends_take_every_frame_in_any_order(oracle, device):
     assert (pe[ok] < 5e-3).all() and (re[ok] < 0.05).all()
     with pytest.raises(ValueError, match="every tool frame"):
         ik.solve_pose(GoalToolPose.from_poses({frames[0]: poses[frames[0]]}))
+    # disable_tool_pose_tracking (reference solver_core.py:392-401): the second arm's goal 3 m away no longer counts ...
+    far = gp.copy()
+    far[:, 1] += np.array([3.0, 0.0, 0.0], np.float32)
+    far_goal = GoalToolPose.from_poses({frames[i]: Pose(t(far[:, i]), t(gq[:, i])) for i in range(2)})
+    assert not bool(ik.solve_pose(far_goal).success.any())
+    ik.disable_tool_pose_tracking([frames[1]])
+    r1 = ik.solve_pose(far_goal)
+    ok1 = r1.success[:, 0].cpu().numpy()
+    assert ok1.mean() >= 0.75
+    pe1, _ = _frame_errors(oracle, model, r1.solution[:, 0].cpu().numpy(), far, gq)
+    assert (pe1[ok1, 0] < 5e-3).all() and (pe1[ok1, 1] > 1.0).all(), "frame 0 reached, frame 1 ignored"
+    # ... and enable_tool_pose_tracking brings it back
+    ik.enable_tool_pose_tracking()
+    assert not bool(ik.solve_pose(far_goal).success.any())
+    assert ik.solve_pose(goal).success[:, 0].float().mean() >= 0.75
     # ---- the planner: IK over both frames -> trajectory optimisation over both frames
     planner = MotionPlanner(MotionPlannerCfg.create(robot="dual_ur10e.yml", scene_model=None, num_ik_seeds=32, num_trajopt_seeds=4))
     cur = JointState.from_position(planner.default_joint_state.position.view(1, -1).clone(), planner.joint_names)

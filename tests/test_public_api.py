@@ -375,6 +375,32 @@ def test_kinematics_accessors_and_result_helpers():
         for n in names:
             assert hasattr(cls, n), (cls.__name__, n)
     assert hasattr(ModelPredictiveControlCfg, "create")
+    # enable / disable_tool_pose_tracking (reference solver_core.py:370-401) on every front end, through update_tool_pose_criteria
+    from curobo import BatchMotionPlanner, MotionPlanner
+    from curobo.types import ToolPoseCriteria
+    from curobo_amd.solver.tracking import ToolPoseTrackingMixin
+
+    for cls in (InverseKinematics, TrajectoryOptimizer, ModelPredictiveControl, MotionPlanner, BatchMotionPlanner):
+        assert issubclass(cls, ToolPoseTrackingMixin)
+
+    class Stub(ToolPoseTrackingMixin):
+        tool_frames = ["left", "right"]
+
+        def __init__(self):
+            self._criteria = {}
+
+        def update_tool_pose_criteria(self, c):
+            self._criteria = dict(c)
+
+    st = Stub()
+    st.disable_tool_pose_tracking(["right"])
+    assert list(st._criteria) == ["right"] and st._criteria["right"].terminal_pose_axes_weight_factor == [0.0] * 6
+    st.enable_tool_pose_tracking(non_terminal_weight_factor=0.5)
+    assert set(st._criteria) == {"left", "right"} and st._criteria["right"].terminal_pose_axes_weight_factor == [1.0] * 6
+    assert st._criteria["left"].non_terminal_pose_axes_weight_factor == [0.5] * 6
+    st.disable_tool_pose_tracking()
+    assert all(c.terminal_pose_axes_weight_factor == ToolPoseCriteria.disabled().terminal_pose_axes_weight_factor for c in st._criteria.values())
+    assert ModelPredictiveControl._tracking_non_terminal_factor == 1.0 and InverseKinematics._tracking_non_terminal_factor == 0.0
 
 
 def test_solver_configurations_take_the_robot_files_acceleration_and_jerk_limits():
