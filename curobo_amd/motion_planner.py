@@ -565,6 +565,9 @@ class _PlannerBase(ToolPoseTrackingMixin):
             self._ik.update_tool_pose_criteria(tool_pose_criteria)
         self.trajopt_solver.update_tool_pose_criteria(tool_pose_criteria)
 
+    def sample_configs(self, num_samples: int, rejection_ratio: int = 10) -> torch.Tensor:
+        return self.trajopt_solver.sample_configs(num_samples, rejection_ratio)
+
     def destroy(self) -> None:
         self._ik = None
         self.trajopt_solver._solver = None

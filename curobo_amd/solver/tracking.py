@@ -1,4 +1,5 @@
-"""``enable_tool_pose_tracking`` / ``disable_tool_pose_tracking`` of the reference's solvers (solver/solver_core.py:370-401; the
+"""Members every solver front end of the reference has through its solver core: ``sample_configs`` (solver_core.py:447-480) and
+``enable_tool_pose_tracking`` / ``disable_tool_pose_tracking`` of the reference's solvers (solver/solver_core.py:370-401; the
 MPC front end forwards its configured non-terminal factor, solver_mpc.py:190-197): switch the pose cost of some (or all) tool
 frames on with the standard position + orientation criteria, or off, through ``update_tool_pose_criteria``.  A class that mixes
 this in has ``tool_frames`` and ``update_tool_pose_criteria``; criteria of the frames that are not named stay as they are."""
@@ -28,3 +29,19 @@ class ToolPoseTrackingMixin:
     def disable_tool_pose_tracking(self, tool_frames: Optional[List[str]] = None) -> None:
         frames = list(self.tool_frames) if tool_frames is None else list(tool_frames)
         self.update_tool_pose_criteria(self._merged_criteria({k: ToolPoseCriteria.disabled() for k in frames}))
+
+    def sample_configs(self, num_samples: int, rejection_ratio: int = 10) -> "torch.Tensor":  # noqa: F821
+        """collision-free joint configurations [<= num_samples, dof] inside the joint limits (reference sample_configs): rejection
+        sampling through a ``RobotCollisionChecker`` over the front end's robot and CURRENT scene"""
+        from ..collision_checking import RobotCollisionChecker
+
+        if num_samples <= 0:
+            raise ValueError("num_samples must be positive")
+        scene = getattr(self.config, "scene", None)
+        cached = getattr(self, "_sample_checker", None)
+        if cached is None or cached[0] is not scene:
+            cached = (scene, RobotCollisionChecker(self.config.kinematics, scene))
+            self._sample_checker = cached
+        chk = cached[1]
+        chk.rejection_ratio = rejection_ratio
+        return chk.sample(num_samples, mask_valid=True)

@@ -492,3 +492,28 @@ def test_collision_checker_sphere_level_api(oracle, device):
     assert chk.tool_frames == chk.kinematics.tool_frames
     chk.clear_scene_cache()
     assert float(chk.get_collision_distance(ts).abs().sum()) == 0.0
+
+
+def test_front_ends_sample_collision_free_configurations(oracle, device):
+    """``sample_configs`` (reference solver_core.py:447-480) on the trajectory optimiser, the planner and the controller: inside the
+    limits, free of self and scene collision by the oracle"""
+    from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg
+    from curobo_amd.motion_planner import MotionPlanner, MotionPlannerCfg
+    from curobo_amd.scene.types import Cuboid
+    from curobo_amd.scene.types import SceneCfg as Scene
+
+    scene = Scene(cuboid=[Cuboid(name="table", dims=[0.6, 1.0, 0.1], pose=[0.7, 0.0, 0.2, 1, 0, 0, 0])])
+    planner = MotionPlanner(MotionPlannerCfg.create(robot="franka.yml", scene_model=scene))
+    mpc = ModelPredictiveControl(ModelPredictiveControlCfg.create(robot="franka.yml", scene_model=scene))
+    model = planner.kinematics.config.model
+    for fe in (planner, planner.trajopt_solver, mpc):
+        q = fe.sample_configs(20, rejection_ratio=20)
+        assert q.ndim == 2 and q.shape[1] == 7 and 1 <= q.shape[0] <= 20
+        qn = q.cpu().numpy()
+        lo, hi = model.joint_limits_position
+        assert (qn >= lo - 1e-6).all() and (qn <= hi + 1e-6).all()
+        fk = oracle.kinematics_forward(qn, model.as_dict())
+        sph = fk["robot_spheres"].reshape(len(qn), 1, -1, 4)
+        assert (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"].reshape(-1) == 0).all()
+    with pytest.raises(ValueError, match="positive"):
+        mpc.sample_configs(0)
