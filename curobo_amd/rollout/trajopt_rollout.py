@@ -81,6 +81,12 @@ class TrajOptRolloutCfg:
     cspace_weight: List[float] = field(default_factory=lambda: [10000.0, 10000.0, 100.0, 50.0, 100.0])
     cspace_activation_distance: List[float] = field(default_factory=lambda: [0.01] * 5)
     cspace_regularization: List[float] = field(default_factory=lambda: [1000.0, 10000.0, 5.0, 0.0, 10000.0])
+    #: joint-position tracking of the c-space STATE cost (wp_cspace_state.py:205-225): weight of |q - target|^2 at the last point,
+    #: times ``cspace_non_terminal_weight_factor`` at the points before it.  0 = off (the trajopt task, lbfgs_bspline_trajopt.yml:72);
+    #: the MPC task tracks an IK solution of its pose goal with 1000 / 0.05 (lbfgs_mpc.yml:28-29).  The target itself comes through
+    #: ``TrajOptRollout.update_cspace_target``; ``enable_cspace_target`` / ``disable_cspace_target`` switch the term at run time.
+    cspace_target_weight: float = 0.0
+    cspace_non_terminal_weight_factor: float = 1.0
     retime_weights: bool = True
     retime_regularization_weights: bool = True
     #: one value for every joint or one per active joint [dof] (reference JointLimits.acceleration / .jerk: per joint,
@@ -151,6 +157,9 @@ class TrajOptRollout:
             self._effort_b = torch.stack([-lim.abs(), lim.abs()]).contiguous()
             self._gravity = f(c.gravity)
         self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
+        # joint-position tracking target: rows of _cs_target picked per trajectory by _cs_target_idx; weight 0 = term off
+        self._cs_target, self._cs_tw = torch.zeros(1, D, device=d), torch.zeros(1, device=d)  # (off until enable_cspace_target)
+        self._cs_nt, self._cs_dofw = f([c.cspace_non_terminal_weight_factor]), torch.ones(D, device=d)
         self.batch_size = 0
         self._fused_ok: Optional[bool] = None
         self._dispatch = None
@@ -182,6 +191,7 @@ class TrajOptRollout:
         self.point_cost, self.cost = z(B, H, 1), z(B)
         self.grad_q, self.grad_knots = z(B, H, D), z(B, c.n_knots, D)
         self.idxs_goal, self._idx0 = z(B, dt=torch.int32), z(B, dt=torch.int32)
+        self._cs_target_idx = z(B, dt=torch.int32)
         self.goal_position, self.goal_quat = z(1, T, 1, 3), z(1, T, 1, 4)
         self.goal_quat[..., 0] = 1.0
 
@@ -290,6 +300,35 @@ class TrajOptRollout:
             self._terms = None
         self.idxs_goal.copy_(idxs_goal.to(torch.int32))
 
+    def update_cspace_target(self, target_position: torch.Tensor, idxs_target: Optional[torch.Tensor] = None,
+                             dof_weight: Optional[torch.Tensor] = None) -> None:
+        """joint-position tracking target of the c-space STATE cost: ``target_position`` [G, D], trajectory b tracks row
+        ``idxs_target[b]`` (default: its pose goal's row, ``idxs_goal``); ``dof_weight`` [D] scales the joints.  Same shapes are
+        written in place (captured graphs see them); the term counts once ``enable_cspace_target`` gave it a weight"""
+        t = target_position.to(self.device, torch.float32).reshape(-1, self.action_dim)
+        if t.shape == self._cs_target.shape:
+            self._cs_target.copy_(t)
+        else:
+            self._cs_target = t.contiguous().clone()
+            self._terms = None
+        self._cs_target_idx.copy_((self.idxs_goal if idxs_target is None else idxs_target).to(self.device, torch.int32).reshape(-1))
+        if int(self._cs_target_idx.max()) >= self._cs_target.shape[0] or int(self._cs_target_idx.min()) < 0:
+            raise ValueError(f"idxs_target outside the {self._cs_target.shape[0]} target rows")
+        if dof_weight is not None:
+            self._cs_dofw.copy_(dof_weight.to(self.device, torch.float32).reshape(-1))
+
+    def enable_cspace_target(self, weight: Optional[float] = None, non_terminal_weight_factor: Optional[float] = None) -> None:
+        """switch joint-position tracking on (reference CSpaceCost.enable_cspace_target): the configured weight / factor, or these"""
+        c = self.cfg
+        w = c.cspace_target_weight if weight is None else float(weight)
+        if w <= 0.0:
+            raise ValueError("enable_cspace_target needs a positive weight (cfg.cspace_target_weight or the argument)")
+        self._cs_tw.fill_(w)
+        self._cs_nt.fill_(c.cspace_non_terminal_weight_factor if non_terminal_weight_factor is None else float(non_terminal_weight_factor))
+
+    def disable_cspace_target(self) -> None:
+        self._cs_tw.zero_()
+
     def update_tool_pose_criteria(self, criteria) -> None:
         """``{tool frame: ToolPoseCriteria}`` -> the per-frame factor / tolerance / projection rows the pose cost reads
         (reference ToolPoseCost.update_tool_pose_criteria); written in place, so captured graphs see the new values"""
@@ -346,9 +385,9 @@ class TrajOptRollout:
                                                  scratch=self._rnea_scratch)
             cost_hip.cspace_state_cost(
                 self.cspace_cost, self.cs_gp, self.cs_gv, self.cs_ga, self.cs_gj, self._cs_gtau if tq else None, self.position,
-                self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._zeroD,
-                self._idx0, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
-                self._zero1, self._zero1, self._onesD, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
+                self.velocity, self.acceleration, self.jerk, self._tau.view(B, H, D) if tq else None, self.state_dt, self._cs_target,
+                self._cs_target_idx, self._p_b, self._v_b, self._a_b, self._j_b, self._effort_b, self._cs_w, self._cs_eta, self._cs_reg,
+                self._cs_tw, self._cs_nt, self._cs_dofw, True, B, H, D, c.retime_weights, c.retime_regularization_weights)
             if tq and with_gradient:  # d cost / d tau back to (q, qd, qdd): RNEA VJP, added to the c-space gradients
                 if self._rnea_scratch is not None:  # straight into the c-space gradients (no separate buffers, no adds)
                     dynamics_hip.launch_rnea_backward(self.cs_gp.view(n, D), self.cs_gv.view(n, D), self.cs_ga.view(n, D),
@@ -458,11 +497,11 @@ class TrajOptRollout:
             non_terminal_pose_convergence_tolerance=self._tol0, project_distance_to_goal=self._project,
             tool_frame_map=k.tool_frame_map, n_tool_frames=k.num_pose_links, num_goalset=int(self.goal_position.shape[2]),
             rotation_method=c.rotation_method, out_cspace_cost=self.cspace_cost if m else None, state_dt=self.state_dt,
-            target_joint_position=self._zeroD, idxs_target_joint_position=self._idx0, p_b=self._p_b, v_b=self._v_b,
+            target_joint_position=self._cs_target, idxs_target_joint_position=self._cs_target_idx, p_b=self._p_b, v_b=self._v_b,
             a_b=self._a_b, j_b=self._j_b, effort_b=self._effort_b, cspace_weight=self._cs_w,
             cspace_activation_distance=self._cs_eta, squared_l2_regularization_weights=self._cs_reg,
-            cspace_target_weight=self._zero1, cspace_non_terminal_weight_factor=self._zero1,
-            cspace_target_dof_weight=self._onesD, retime_weights=c.retime_weights,
+            cspace_target_weight=self._cs_tw, cspace_non_terminal_weight_factor=self._cs_nt,
+            cspace_target_dof_weight=self._cs_dofw, retime_weights=c.retime_weights,
             retime_regularization_weights=c.retime_regularization_weights,
             **(dict(link_masses_com=k.link_masses_com, link_inertias=k.link_inertias, gravity=self._gravity,
                     level_links=self._level_links, use_torque_limits=1)

@@ -446,3 +446,68 @@ def test_seed_shards_over_torque_limited_rollouts_capture_and_match_one_batch(de
     # the staged (in-shard) and the scratch / side-stream RNEA launches differ in the last bits of the torques: costs to 1e-5
     torch.testing.assert_close(pipe.best_cost, ref_cost, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_joint_position_tracking_term_matches_oracle(fused, oracle, device):
+    """``update_cspace_target`` + ``enable_cspace_target`` (reference wp_cspace_state.py:205-225, the MPC task's cspace_target_weight 1000 /
+    non-terminal factor 0.05): the c-space STATE cost gains w |q - target|^2 per dof, the full weight at the last point, times the
+    factor before it; two targets picked per trajectory, per-joint weights.  The DIFFERENCE of the rollout's cost and gradient with the term
+    on and off is held to the oracle's difference (everything else cancels), and disable restores the old numbers bit for bit."""
+    from curobo_amd.rollout import TrajOptRollout, TrajOptRolloutCfg
+    from curobo_amd.workloads import seed_knots, start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()
+    cfg = TrajOptRolloutCfg(use_sweep=False, use_speed_metric=False, use_fused=fused, cspace_target_weight=1000.0,
+                            cspace_non_terminal_weight_factor=0.05)
+    B, nk, D, H = 8, cfg.n_knots, kin.num_dof, cfg.padded_horizon
+    knots = seed_knots(model, B, nk, seed=9, spread=0.5)
+    start = start_configuration(model)
+    goals = oracle.kinematics_forward(sample_q(model, 2, seed=6, scale=0.7), md)
+    idx = np.arange(B, dtype=np.int32) % 2
+    ro = TrajOptRollout(kin, scene, B, cfg)
+    ro.update_start_state(torch.as_tensor(start, device=device))
+    ro.update_goals(torch.as_tensor(goals["link_pos"].reshape(2, 1, 1, 3)), torch.as_tensor(goals["link_quat"].reshape(2, 1, 1, 4)),
+                    torch.as_tensor(idx, device=device))
+    x = torch.as_tensor(knots, device=device).reshape(B, -1)
+    c0, g0 = [t.clone() for t in ro.cost_and_gradient(x)]
+    target = sample_q(model, 2, seed=12, scale=0.6).astype(np.float32)
+    dofw = np.array([1.0, 0.5, 2.0, 1.0, 0.0, 1.5, 1.0], np.float32)
+    ro.update_cspace_target(torch.as_tensor(target), dof_weight=torch.as_tensor(dofw))  # rows follow the pose goal's index
+    c_off, g_off = [t.clone() for t in ro.cost_and_gradient(x)]
+    assert torch.equal(c_off, c0) and torch.equal(g_off, g0), "a target alone changes nothing: the term is off until it is enabled"
+    ro.enable_cspace_target()
+    c1, g1 = [t.clone() for t in ro.cost_and_gradient(x)]
+    ro.disable_cspace_target()
+    c2, g2 = [t.clone() for t in ro.cost_and_gradient(x)]
+    torch.cuda.synchronize()
+    assert torch.equal(c2, c0) and torch.equal(g2, g0)
+    # ---- the oracle's difference
+    zeros = np.zeros((1, D), np.float32)
+    st = {"position": start.reshape(1, D).astype(np.float32), "velocity": zeros, "acceleration": zeros, "jerk": zeros}
+    gl = {k: zeros for k in st}
+    i0 = np.zeros(B, np.int32)
+    dt = np.array([cfg.traj_dt], np.float32)
+    s = oracle.bspline_forward(knots, st, gl, i0, i0, dt, np.zeros(1, np.uint8), H, cfg.bspline_degree)
+    ones = np.ones(D, np.float32)
+    lim = {"position": model.joint_limits_position.astype(np.float32), "velocity": model.joint_limits_velocity.astype(np.float32),
+           "acceleration": np.stack([-cfg.max_acceleration * ones, cfg.max_acceleration * ones]),
+           "jerk": np.stack([-cfg.max_jerk * ones, cfg.max_jerk * ones])}
+    common = dict(retime_weights=True, retime_regularization_weights=True)
+    a = (s["position"], s["velocity"], s["acceleration"], s["jerk"], np.full(B, cfg.traj_dt, np.float32), lim, cfg.cspace_weight,
+         cfg.cspace_activation_distance, cfg.cspace_regularization)
+    off = oracle.cspace_state_cost(*a, **common)
+    on = oracle.cspace_state_cost(*a, target=target, idxs_target=idx, target_weight=1000.0, non_terminal_factor=0.05, target_dof_weight=dofw,
+                                  **common)
+    d_cost = (on["cost"] - off["cost"]).sum((1, 2))
+    assert (d_cost > 1.0).all()
+    got = (c1 - c0).cpu().numpy()
+    np.testing.assert_allclose(got, d_cost, rtol=2e-4, atol=2e-4 * float(np.abs(c0.cpu().numpy()).max()))
+    # gradient difference: d/d knots of the added term = B-spline VJP of its position gradient
+    gp = on["grad_position"] - off["grad_position"]
+    z = np.zeros_like(gp)
+    want_g = oracle.bspline_backward(gp, z, z, z, dt, i0, np.zeros(1, np.uint8), nk, cfg.bspline_degree)
+    dg = (g1 - g0).cpu().numpy().reshape(B, nk, D)
+    # (g1 - g0 is a difference of two fp32 gradients of the whole cost: its rounding is relative to THEIR size)
+    np.testing.assert_allclose(dg, want_g, rtol=2e-3, atol=2e-4 * float(np.abs(want_g).max()) + 2e-6 * float(g0.abs().max()))
