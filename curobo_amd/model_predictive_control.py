@@ -9,8 +9,10 @@ Reference: ``curobo/model_predictive_control.py`` (``MPCSolver`` / ``MPCSolverCf
     mpc.update_goal_tool_poses(goal_tool_poses)
     result = mpc.optimize_next_action(current_state)      # or optimize_action_sequence
 
-The controller tracks tool poses (``run_ik`` / joint-position tracking of the reference's ``update_goal_tool_poses`` are not
-mirrored: the flags are accepted and the Cartesian goal is what is tracked)."""
+``update_goal_tool_poses`` has the reference's defaults (``run_ik=True, use_ik_goal=True``): a collision-free IK solution of the
+goal, close to the current configuration, becomes the goal configuration of the joint-position tracking term beside the pose
+tracking; ``run_ik=False`` tracks the poses alone.  ``update_goal_state`` + ``enable_joint_position_tracking`` (+
+``disable_tool_pose_tracking``) give joint-space control."""
 
 from __future__ import annotations
 
@@ -155,7 +157,7 @@ class ModelPredictiveControl(ToolPoseTrackingMixin):
         self.update_goal_tool_poses(self.compute_kinematics(JointState.from_position(self._batch(current_state).position)).tool_poses.as_goal())
 
     def update_goal_tool_poses(self, goal_tool_poses: Union[GoalToolPose, Dict[str, Pose]], robot_ids: Optional[torch.Tensor] = None,
-                               run_ik: bool = False, use_ik_goal: bool = False, use_best_effort_ik: bool = False) -> bool:
+                               run_ik: bool = True, use_ik_goal: bool = True, use_best_effort_ik: bool = False) -> bool:
         """reference ``update_goal_tool_poses`` (:365-438): the whole goal, or with ``robot_ids`` the rows of those robots.  A
         dictionary ``{tool frame: Pose}`` is taken as one goal per robot."""
         if isinstance(goal_tool_poses, dict):
@@ -164,15 +166,31 @@ class ModelPredictiveControl(ToolPoseTrackingMixin):
         if robot_ids is not None:
             if self._goal is None:
                 raise ValueError("goal_tool_poses not set, call update_goal_tool_poses without robot_ids first")
-            ids = robot_ids.to(self._goal.position.device).long()
+            candidate = self._goal.clone()
+            ids = robot_ids.to(candidate.position.device).long()
             for i, name in enumerate(goal_tool_poses.tool_frames):
-                j = self._goal.tool_frames.index(name)
-                self._goal.position[ids, :, j] = goal_tool_poses.position[ids, :, i].to(self._goal.position.device)
-                self._goal.quaternion[ids, :, j] = goal_tool_poses.quaternion[ids, :, i].to(self._goal.position.device)
+                j = candidate.tool_frames.index(name)
+                candidate.position[ids, :, j] = goal_tool_poses.position[ids, :, i].to(candidate.position.device)
+                candidate.quaternion[ids, :, j] = goal_tool_poses.quaternion[ids, :, i].to(candidate.position.device)
         else:
-            self._goal = goal_tool_poses.clone()
-        self.solver.update_goal_tool_poses(self._goal)
+            candidate = goal_tool_poses.clone()
+        # (run_ik: the goal's IK solution becomes the tracked goal configuration; a failed IK leaves the previous goal in place)
+        if not self.solver.update_goal_tool_poses(candidate, run_ik=run_ik, use_ik_goal=use_ik_goal, use_best_effort_ik=use_best_effort_ik):
+            return False
+        self._goal = candidate
         return True
+
+    def update_goal_state(self, goal_state: JointState, robot_ids: Optional[torch.Tensor] = None) -> None:
+        """goal configuration of the joint-position tracking (reference :458-474; ``robot_ids`` is not supported there either)"""
+        if robot_ids is not None:
+            raise ValueError("robot_ids not supported for update_goal_state")
+        self.solver.update_goal_state(self._batch(goal_state))
+
+    def enable_joint_position_tracking(self) -> None:
+        self.solver.enable_joint_position_tracking()
+
+    def disable_joint_position_tracking(self) -> None:
+        self.solver.disable_joint_position_tracking()
 
     def update_current_state(self, current_state: JointState) -> None:
         self.solver.update_current_state(self._batch(current_state))

@@ -172,13 +172,16 @@ class IKSolver:
 
     def solve_pose(self, goal_position: torch.Tensor, goal_quat: torch.Tensor,
                    seeds: Optional[torch.Tensor] = None, return_seeds: int = 1,
-                   exit_early: Optional[bool] = None, env_idx: Optional[torch.Tensor] = None) -> IKResult:
+                   exit_early: Optional[bool] = None, env_idx: Optional[torch.Tensor] = None,
+                   current_position: Optional[torch.Tensor] = None) -> IKResult:
         """Goals of EVERY tool frame (reference IKSolver.solve_pose over a GoalToolPose, solver_ik.py:631-700): goal_position
         [P, T, G, 3], goal_quat [P, T, G, 4] (wxyz) with T = the robot's tool frames (``kin.tool_frames`` order) and G =
         ``cfg.num_goalset`` alternatives per problem (one member index per frame is chosen: the closest).  A robot with ONE
         tool frame also takes [P, 3] / [P, 4] or [P, G, 3] / [P, G, 4].  A solution succeeds when every frame is within the
         thresholds; the reported errors are the largest over the frames.  ``return_seeds`` k > 1 returns the k best seeds
-        per problem, best first (solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result."""
+        per problem, best first (solver_ik.py:503-530: top-k over the ranked cost), with a [P, k, ...] result.
+        ``current_position`` [P, D]: the robot's configuration -- the first seed of every problem, and the seed stage prefers
+        solutions close to it (reference: ``current_state`` / ``seed_config`` of solve_pose, as the MPC's goal IK passes them)."""
         P, S, D, T, G = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links, self.G
         if goal_position.numel() != P * T * G * 3 or goal_quat.numel() != P * T * G * 4:
             raise ValueError(f"solve_pose: expected goals for {P} problems x {T} tool frames {tuple(self.kin.tool_frames)} x {G} "
@@ -200,8 +203,9 @@ class IKSolver:
                 # the S_global best LM runs over all ranks, identical everywhere; this rank optimises its rows of them
                 m = self.metrics_rollout  # (its goal buffers are the seed stage's: update_goals above filled them)
                 shared = self.seed_solver.goal_position is m.goal_position
+                cur = None if current_position is None else current_position.to(self.device, torch.float32).reshape(P, D)
                 seeds = self.seed_solver.solve_batch(m.goal_position if shared else gp, m.goal_quat if shared else gq,
-                                                     return_seeds=self.S_global).solution
+                                                     return_seeds=self.S_global, current_position=cur).solution
                 if self.S_global != S:
                     seeds = seeds[:, self.seed_offset:self.seed_offset + S].contiguous()
             else:

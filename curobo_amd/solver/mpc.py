@@ -48,7 +48,12 @@ class MPCSolverCfg:
     #: that the velocity / acceleration bounds of the c-space STATE cost shape the motion at a 5 ms command step
     rollout: TrajOptRolloutCfg = field(default_factory=lambda: TrajOptRolloutCfg(
         non_terminal_pose_factor=1.0, pose_weight=[2000.0, 200.0], cspace_weight=[10000.0, 10000.0, 2000.0, 100.0, 100.0],
-        cspace_regularization=[10.0, 100.0, 1.0, 0.0, 10.0]))
+        cspace_regularization=[10.0, 100.0, 1.0, 0.0, 10.0],
+        # joint-position tracking (off until a goal configuration is given: update_goal_state / update_goal_tool_poses(run_ik=True)),
+        # the MPC task's values (lbfgs_mpc.yml:28-29)
+        cspace_target_weight=1000.0, cspace_non_terminal_weight_factor=0.05))
+    #: seeds of the goal IK (update_goal_tool_poses(run_ik=True)): the solution closest to the current configuration is tracked
+    goal_ik_seeds: int = 16
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=15, inner_iters=25))
     use_cuda_graph: bool = True
 
@@ -105,12 +110,54 @@ class MPCSolver:
         self._setup_done, self._warm = True, False
         self._knots = None
 
-    def update_goal_tool_poses(self, goal_tool_poses: GoalToolPose) -> None:
-        """tracked tool poses [B, 1, T, 1, 3 | 4]; may change between control steps (reference :365-438)"""
+    def update_goal_tool_poses(self, goal_tool_poses: GoalToolPose, run_ik: bool = False, use_ik_goal: bool = True,
+                               use_best_effort_ik: bool = False) -> bool:
+        """tracked tool poses [B, 1, T, 1, 3 | 4]; may change between control steps (reference :365-438).  ``run_ik``: a
+        collision-free IK solution of the goal (seeded with, and preferring solutions close to, the current configuration) becomes
+        the goal CONFIGURATION and, with ``use_ik_goal``, joint-position tracking is switched on beside the pose tracking; returns
+        False (and leaves the previous goal in place) when the IK fails for a robot, unless ``use_best_effort_ik``.  Without
+        ``run_ik`` joint-position tracking is switched off and only the poses are tracked."""
         gp, gq = goal_tool_poses.static_goals(list(self.kin.tool_frames))  # every tool frame, the robot's frame order
         gp, gq = gp.to(self.device, torch.float32).contiguous(), gq.to(self.device, torch.float32).contiguous()
+        if run_ik:
+            ok, q_goal = self._solve_goal_ik(gp[:, :, :1], gq[:, :, :1])
+            if not (use_best_effort_ik or bool(ok.all())):
+                return False
+            if use_ik_goal:
+                self.update_goal_state(JointState.from_position(q_goal, self.kin.joint_names))
+                self.enable_joint_position_tracking()
+        else:
+            self.disable_joint_position_tracking()
         self.rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._rows)
         self.metrics_rollout.update_goals(gp[:, :, :1], gq[:, :, :1], self._mrows)
+        return True
+
+    def _solve_goal_ik(self, gp: torch.Tensor, gq: torch.Tensor):
+        """(success [B], configuration [B, D]) of the pose goals (reference _solve_ik_for_goal, :439-456)"""
+        from .ik import IKSolver, IKSolverCfg
+
+        if getattr(self, "_ik", None) is None:
+            self._ik = IKSolver(self.kin, self.scene, self.B, IKSolverCfg(num_seeds=self.cfg.goal_ik_seeds))
+        cur = getattr(self, "_current", None)
+        r = self._ik.solve_pose(gp, gq, current_position=cur)
+        return r.success.reshape(self.B), r.solution.reshape(self.B, -1)
+
+    def update_goal_state(self, goal_state: JointState) -> None:
+        """goal configuration [B, D] of the joint-position tracking term (reference update_goal_state, :458-474); it counts once
+        ``enable_joint_position_tracking`` switched the term on"""
+        q = goal_state.position.to(self.device, torch.float32).reshape(self.B, self.kin.num_dof)
+        self.rollout.update_cspace_target(q, self._rows)
+        self.metrics_rollout.update_cspace_target(q, self._mrows)
+        self._goal_config = q.clone()
+
+    def enable_joint_position_tracking(self) -> None:
+        """reference solver_core.py:404-414"""
+        for ro in (self.rollout, self.metrics_rollout):
+            ro.enable_cspace_target()
+
+    def disable_joint_position_tracking(self) -> None:
+        for ro in (self.rollout, self.metrics_rollout):
+            ro.disable_cspace_target()
 
     def update_current_state(self, current_state: JointState) -> None:
         """the spline starts at the robot's current position / velocity / acceleration (reference :476-497)"""

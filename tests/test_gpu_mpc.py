@@ -97,6 +97,15 @@ def test_model_predictive_control_front_end(oracle, device):
     assert float((hold.next_action.position - q0).abs().max()) < 2e-3
     dq = torch.tensor([[0.4, 0.2, -0.3, 0.3, 0.2, -0.2, 0.3], [-0.4, 0.1, 0.3, 0.2, -0.3, 0.3, -0.2]], device=device)
     goal = mpc.compute_kinematics(JointState.from_position(q0 + dq)).tool_poses.as_goal()
+    assert mpc.update_goal_tool_poses(goal)  # (run_ik = True by default: the goal's IK solution is tracked in joint space as well)
+    sol = mpc.solver
+    assert float(sol.rollout._cs_tw) == 1000.0 and float(sol.metrics_rollout._cs_tw) == 1000.0
+    reached = mpc.compute_kinematics(JointState.from_position(sol._goal_config)).tool_poses.position[:, 0, 0]
+    assert float((reached - goal.position[:, 0, 0, 0]).norm(dim=-1).max()) < 5e-3, "the tracked configuration reaches the goal pose"
+    assert mpc.update_goal_tool_poses(goal, run_ik=False) and float(sol.rollout._cs_tw) == 0.0, "poses alone"
+    far = goal.clone()
+    far.position[..., 0] += 3.0  # unreachable: the IK fails, the previous goal stays
+    assert not mpc.update_goal_tool_poses(far) and float((mpc._goal.position - goal.position).abs().max()) == 0.0
     assert mpc.update_goal_tool_poses(goal)
 
     def run(steps):
@@ -127,3 +136,29 @@ def test_model_predictive_control_front_end(oracle, device):
     assert (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"] == 0).all()
     seq = mpc.optimize_action_sequence(state)
     assert seq.action_sequence.position.shape[0] == B and seq.action_sequence.position.shape[-1] == 7
+
+
+def test_mpc_joint_space_control(oracle, device):
+    """``update_goal_state`` + ``enable_joint_position_tracking`` with the pose tracking switched off (reference solver_mpc.py:458-474,
+    solver_core.py:392-414): the controller drives the robot to a goal CONFIGURATION"""
+    from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg
+    from curobo_amd.types import JointState
+
+    mpc = ModelPredictiveControl(ModelPredictiveControlCfg.create(robot="franka.yml", scene_model=None))
+    q0 = mpc.default_joint_state.position.view(1, -1).clone()
+    state = JointState(position=q0.clone(), velocity=torch.zeros_like(q0), acceleration=torch.zeros_like(q0), joint_names=mpc.joint_names)
+    mpc.setup(state)
+    q_goal = q0 + torch.tensor([[0.5, -0.3, 0.4, 0.3, -0.4, 0.3, 0.5]], device=q0.device)
+    mpc.disable_tool_pose_tracking()
+    mpc.update_goal_state(JointState.from_position(q_goal, mpc.joint_names))
+    mpc.enable_joint_position_tracking()
+    for _ in range(500):
+        r = mpc.optimize_next_action(state)
+        state = JointState(position=r.next_action.position.clone(), velocity=r.next_action.velocity.clone(),
+                           acceleration=r.next_action.acceleration.clone(), joint_names=mpc.joint_names)
+    err = (state.position - q_goal).abs().max()
+    assert float(err) < 0.02, f"joint-space goal missed by {float(err):.3f} rad"
+    lo, hi = mpc.kinematics.kinematics_config.joint_limits_position
+    assert bool(((state.position >= lo) & (state.position <= hi)).all())
+    with pytest.raises(ValueError, match="robot_ids"):
+        mpc.update_goal_state(JointState.from_position(q_goal, mpc.joint_names), robot_ids=torch.tensor([0]))
