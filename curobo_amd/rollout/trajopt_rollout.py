@@ -157,8 +157,8 @@ class TrajOptRollout:
             self._effort_b = torch.stack([-lim.abs(), lim.abs()]).contiguous()
             self._gravity = f(c.gravity)
         self._zero1, self._zeroD, self._onesD = torch.zeros(1, device=d), torch.zeros(1, D, device=d), ones
-        # joint-position tracking target: rows of _cs_target picked per trajectory by _cs_target_idx; weight 0 = term off
-        self._cs_target, self._cs_tw = torch.zeros(1, D, device=d), torch.zeros(1, device=d)  # (off until enable_cspace_target)
+        # joint-position tracking: _cs_target [B, D] holds every trajectory's target (allocated with the batch buffers); weight 0 = off
+        self._cs_tw = torch.zeros(1, device=d)  # (off until enable_cspace_target)
         self._cs_nt, self._cs_dofw = f([c.cspace_non_terminal_weight_factor]), torch.ones(D, device=d)
         self.batch_size = 0
         self._fused_ok: Optional[bool] = None
@@ -191,7 +191,8 @@ class TrajOptRollout:
         self.point_cost, self.cost = z(B, H, 1), z(B)
         self.grad_q, self.grad_knots = z(B, H, D), z(B, c.n_knots, D)
         self.idxs_goal, self._idx0 = z(B, dt=torch.int32), z(B, dt=torch.int32)
-        self._cs_target_idx = z(B, dt=torch.int32)
+        self._cs_target = z(B, D)  # the target of every trajectory (update_cspace_target gathers its rows here)
+        self._cs_target_idx = torch.arange(B, device=d, dtype=torch.int32)
         self.goal_position, self.goal_quat = z(1, T, 1, 3), z(1, T, 1, 4)
         self.goal_quat[..., 0] = 1.0
 
@@ -306,14 +307,12 @@ class TrajOptRollout:
         ``idxs_target[b]`` (default: its pose goal's row, ``idxs_goal``); ``dof_weight`` [D] scales the joints.  Same shapes are
         written in place (captured graphs see them); the term counts once ``enable_cspace_target`` gave it a weight"""
         t = target_position.to(self.device, torch.float32).reshape(-1, self.action_dim)
-        if t.shape == self._cs_target.shape:
-            self._cs_target.copy_(t)
-        else:
-            self._cs_target = t.contiguous().clone()
-            self._terms = None
-        self._cs_target_idx.copy_((self.idxs_goal if idxs_target is None else idxs_target).to(self.device, torch.int32).reshape(-1))
-        if int(self._cs_target_idx.max()) >= self._cs_target.shape[0] or int(self._cs_target_idx.min()) < 0:
-            raise ValueError(f"idxs_target outside the {self._cs_target.shape[0]} target rows")
+        idx = (self.idxs_goal if idxs_target is None else idxs_target).to(self.device, torch.int64).reshape(-1)
+        if int(idx.max()) >= t.shape[0] or int(idx.min()) < 0:
+            raise ValueError(f"idxs_target outside the {t.shape[0]} target rows")
+        # one row per trajectory, written in place: the buffer never moves, so launches captured in a hipGraph before the
+        # first target was given read the new values too
+        self._cs_target.copy_(t[idx])
         if dof_weight is not None:
             self._cs_dofw.copy_(dof_weight.to(self.device, torch.float32).reshape(-1))
 

@@ -139,8 +139,17 @@ class MPCSolver:
         if getattr(self, "_ik", None) is None:
             self._ik = IKSolver(self.kin, self.scene, self.B, IKSolverCfg(num_seeds=self.cfg.goal_ik_seeds))
         cur = getattr(self, "_current", None)
-        r = self._ik.solve_pose(gp, gq, current_position=cur)
-        return r.success.reshape(self.B), r.solution.reshape(self.B, -1)
+        S = self.cfg.goal_ik_seeds
+        r = self._ik.solve_pose(gp, gq, current_position=cur, return_seeds=S)
+        ok, sol = r.success.reshape(self.B, S), r.solution.reshape(self.B, S, -1)
+        if cur is None:
+            pick = torch.zeros(self.B, dtype=torch.long, device=self.device)  # (ranked best first)
+        else:
+            # of the solutions that pass every check, the one CLOSEST to the current configuration: the tracked goal must not
+            # send the arm through another branch of the kinematics (the ranking of the IK is by pose error, not by distance)
+            far = (sol - cur.view(self.B, 1, -1)).norm(dim=-1)
+            pick = torch.where(ok, far, torch.full_like(far, float("inf"))).argmin(dim=1)
+        return ok.any(dim=1), sol[torch.arange(self.B, device=self.device), pick]
 
     def update_goal_state(self, goal_state: JointState) -> None:
         """goal configuration [B, D] of the joint-position tracking term (reference update_goal_state, :458-474); it counts once
