@@ -91,6 +91,14 @@ class MPCSolver:
                                   use_cuda_graph=c.use_cuda_graph)
         self._rows = torch.arange(num_robots * self.nls, device=self.device, dtype=torch.int32) // self.nls
         self._mrows = torch.arange(num_robots, device=self.device, dtype=torch.int32)
+        # goal buffers in their final shape from the start ([B, T, 1, 3 | 4], identity rotations): every later goal update is then
+        # written in place, whatever was captured in a hipGraph in between (a re-allocated buffer would be invisible to it)
+        T = kin.num_pose_links
+        gp0 = torch.zeros(num_robots, T, 1, 3, device=self.device)
+        gq0 = torch.zeros(num_robots, T, 1, 4, device=self.device)
+        gq0[..., 0] = 1.0
+        self.rollout.update_goals(gp0, gq0, self._rows)
+        self.metrics_rollout.update_goals(gp0, gq0, self._mrows)
         self._knots: Optional[torch.Tensor] = None
         self._cmd = None       # (position, velocity, acceleration) [B, H, D] of the current plan
         self._cursor = 0
