@@ -200,6 +200,29 @@ class Kinematics:
         """the collision spheres in their link frames (sphere set 0), [num_spheres, 4]"""
         return self.kinematics_config.link_spheres[0]
 
+    @property
+    def all_articulated_joint_names(self) -> List[str]:
+        """the active joints followed by the locked ones (reference ``non_fixed_joint_names``, kinematics_loader.py:134)"""
+        return list(self.joint_names) + list(self.config.model.lock_joints.keys())
+
+    def get_mimic_js(self, joint_state):
+        """state of the mimic joints that follow the actuated joints of ``joint_state`` (reference get_mimic_js, :410-441):
+        position = multiplier x actuated + offset; None when the robot has none"""
+        from .types import JointState
+
+        mimic = self.config.model.mimic_joints
+        if not mimic:
+            return None
+        names, cols = [], []
+        for j, followers in mimic.items():
+            q = joint_state.position[..., list(joint_state.joint_names).index(j)]
+            for k in followers:
+                names.append(k["joint_name"])
+                cols.append(k["joint_offset"][0] * q + k["joint_offset"][1])
+        if not cols:
+            return None
+        return JointState.from_position(torch.stack(cols, dim=-1), joint_names=names)
+
     def update_batch_size(self, batch: int, horizon: int, force_update: bool = False, reset_buffers: bool = False) -> None:
         """allocate the output buffers of ``compute_kinematics`` for [batch, horizon, dof] inputs ahead of the first call"""
         if batch <= 0 or horizon <= 0:

@@ -102,6 +102,9 @@ class RobotModel:
     #: links in contact with a grasped object (robot yaml ``grasp_contact_link_names``; the grasp planner switches their
     #: collision spheres off for the final approach and the lift, reference motion_planner.py:437-440)
     grasp_contact_link_names: Optional[List[str]] = None
+    #: {actuated joint: [{"joint_name": mimic joint, "joint_offset": [multiplier, offset]}, ...]} (reference
+    #: KinematicsParams.mimic_joints, kinematics_loader.py:405-414); None for models saved before the field existed
+    mimic_joints: Optional[Dict[str, List[Dict]]] = None
 
     @property
     def num_links(self) -> int:
@@ -138,6 +141,10 @@ class RobotModel:
         )
         if self.grasp_contact_link_names is not None:
             meta["grasp_contact_link_names"] = np.array(list(self.grasp_contact_link_names), dtype=str)
+        if self.mimic_joints is not None:
+            import json
+
+            meta["mimic_joints_json"] = np.array(json.dumps(self.mimic_joints))
         np.savez_compressed(path, **self.as_dict(), **meta)
 
     @staticmethod
@@ -159,6 +166,7 @@ class RobotModel:
             ),
             base_link=str(z["base_link"]),
             grasp_contact_link_names=[str(x) for x in z["grasp_contact_link_names"]] if "grasp_contact_link_names" in z.files else None,
+            mimic_joints=__import__("json").loads(str(z["mimic_joints_json"])) if "mimic_joints_json" in z.files else None,
         )
 
 
@@ -521,6 +529,11 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
     for key, default in (("max_acceleration", 10.0), ("max_jerk", 500.0)):
         cspace[key] = [float(x) for x in per_active_joint(key, cspace.get(key, default))]
 
+    mimic: Dict[str, List[Dict]] = {}
+    for b in bodies[1:]:
+        if b.mimic_joint_name is not None:  # (followers of locked joints included: the reference fills the table before it locks them)
+            mimic.setdefault(b.joint_name, []).append({"joint_name": b.mimic_joint_name, "joint_offset": [float(b.joint_offset[0]), float(b.joint_offset[1])]})
+
     return RobotModel(
         fixed_transforms=fixed.astype(np.float32),
         link_map=link_map, joint_map=joint_map, joint_map_type=joint_map_type,
@@ -539,4 +552,5 @@ def build_robot_model(cfg: Dict, urdf: UrdfModel, num_envs: int = 1) -> RobotMod
         num_dof=D, joint_names=joint_names, link_names=list(chain_names),
         tool_frames=tool_frames, lock_joints=locked, cspace=cspace, base_link=base_link,
         grasp_contact_link_names=list(cfg["grasp_contact_link_names"]) if cfg.get("grasp_contact_link_names") else None,
+        mimic_joints=mimic,
     )

@@ -76,6 +76,13 @@ def compare(name):
     if dq is not None and m.cspace.get("default_joint_position") is not None:
         if not np.allclose(npy(dq), np.asarray(m.cspace["default_joint_position"], np.float32), rtol=0, atol=1e-6):
             bad.append("cspace default joint position (reindexed to the active joints) differs")
+    # mimic joints {actuated joint: [{joint_name, joint_offset}]} and the articulated joint names (active + locked)
+    ref_mimic = {k: [(d["joint_name"], [float(x) for x in d["joint_offset"]]) for d in v] for k, v in (kc.mimic_joints or {}).items()}
+    our_mimic = {k: [(d["joint_name"], [float(x) for x in d["joint_offset"]]) for d in v] for k, v in (m.mimic_joints or {}).items()}
+    if set(ref_mimic) != set(our_mimic) or any(sorted(ref_mimic[k]) != sorted(our_mimic[k]) for k in ref_mimic):
+        bad.append(f"mimic joints differ: {ref_mimic} vs {our_mimic}")
+    if list(kc.non_fixed_joint_names) != list(m.joint_names) + list(m.lock_joints.keys()):
+        bad.append(f"articulated joint names differ: {kc.non_fixed_joint_names} vs {list(m.joint_names) + list(m.lock_joints.keys())}")
     if sc is not None and not no_spheres:
         if not np.array_equal(npy(sc.collision_pairs).astype(np.int64), m.collision_pairs.astype(np.int64)):
             bad.append("self-collision pair list differs")

@@ -360,6 +360,14 @@ def test_kinematics_accessors_and_result_helpers():
         k.update_kinematics_config(other)
     with pytest.raises(ValueError, match="must be > 0"):
         k.update_batch_size(0, 1)
+    # articulated joints = active + locked; mimic joints follow their actuated joint (reference kinematics.py:313-315, 410-441)
+    assert k.all_articulated_joint_names == k.joint_names + ["panda_finger_joint1", "panda_finger_joint2"]
+    assert k.get_mimic_js(JointState.from_position(torch.zeros(1, 7), joint_names=k.joint_names)) is None
+    import dataclasses as dc
+
+    k.config.model = dc.replace(k.config.model, mimic_joints={k.joint_names[1]: [{"joint_name": "follower", "joint_offset": [-1.5, 0.5]}]})
+    mj = k.get_mimic_js(JointState.from_position(torch.tensor([[0.0, 0.2, 0, 0, 0, 0, 0], [0.0, -1.0, 0, 0, 0, 0, 0]]), joint_names=k.joint_names))
+    assert mj.joint_names == ["follower"] and mj.position.reshape(-1).tolist() == pytest.approx([0.2, 2.0])
 
     sol = torch.tensor([[[0.10, 0.2], [0.101, 0.2], [0.5, 0.5], [0.9, 0.9]]])
     res = InverseKinematicsResult(success=torch.tensor([[True, True, True, False]]), solution=sol, js_solution=None,
