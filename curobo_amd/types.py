@@ -126,7 +126,14 @@ class Pose:
         lead = matrix.shape[:-2]
         return Pose(t.reshape(*lead, 3).contiguous(), q.reshape(*lead, 4).contiguous())
 
-    def to(self, device) -> "Pose":
+    def to(self, device=None, device_cfg: Optional[DeviceCfg] = None) -> "Pose":
+        """a device, or (as the reference's first argument) a ``DeviceCfg``"""
+        if device_cfg is None and isinstance(device, DeviceCfg):
+            device_cfg, device = device, None
+        if device_cfg is not None:
+            device = device_cfg.device
+        if device is None:
+            raise ValueError("Pose.to() requires device_cfg or device")
         return Pose(self.position.to(device), self.quaternion.to(device), self.name)
 
     def clone(self) -> "Pose":
@@ -141,6 +148,208 @@ class Pose:
     def inverse(self) -> "Pose":
         qi = self.quaternion * self.quaternion.new_tensor([1.0, -1.0, -1.0, -1.0])
         return Pose(-_quat_rotate(qi, self.position), qi)
+
+    # ------------------------------------------------------------------ the reference's convenience members (types/pose.py:117-670),
+    # pure torch; held to the reference's class on random poses by tests/golden/compare_pose_ops.py
+    @property
+    def device(self):
+        return self.position.device
+
+    @property
+    def ndim(self) -> int:
+        return self.position.ndim
+
+    @property
+    def shape(self):
+        return self.position.shape
+
+    @property
+    def batch_size(self) -> int:
+        return int(self.position.shape[0]) if self.position.ndim > 1 else 1
+
+    batch = batch_size  # (deprecated name in the reference)
+
+    def __len__(self) -> int:
+        return self.batch_size
+
+    def __getitem__(self, idx) -> "Pose":
+        return Pose(self.position[idx], self.quaternion[idx])
+
+    def __setitem__(self, idx, value: "Pose") -> None:
+        self.position[idx] = value.position
+        self.quaternion[idx] = value.quaternion
+
+    def get_index(self, b: int, n: Optional[int] = None) -> "Pose":
+        return Pose(self.position[b, :], self.quaternion[b, :]) if n is None else Pose(self.position[b, n, :], self.quaternion[b, n, :])
+
+    def detach(self) -> "Pose":
+        self.position, self.quaternion = self.position.detach(), self.quaternion.detach()
+        return self
+
+    def requires_grad_(self, requires_grad: bool) -> None:
+        self.position.requires_grad_(requires_grad)
+        self.quaternion.requires_grad_(requires_grad)
+
+    def contiguous(self) -> "Pose":
+        return Pose(self.position.contiguous(), self.quaternion.contiguous(), self.name)
+
+    def copy_(self, pose: "Pose") -> None:
+        if pose.position.shape != self.position.shape or pose.quaternion.shape != self.quaternion.shape:
+            raise ValueError(f"Copy not possible due to shape mismatch: {tuple(pose.position.shape)} != {tuple(self.position.shape)}")
+        self.position.copy_(pose.position)
+        self.quaternion.copy_(pose.quaternion)
+
+    @staticmethod
+    def from_numpy(position, quaternion, device_cfg: Optional[DeviceCfg] = None) -> "Pose":
+        dev = device_cfg.device if device_cfg is not None else None
+        return Pose(torch.as_tensor(position, dtype=torch.float32, device=dev), torch.as_tensor(quaternion, dtype=torch.float32, device=dev))
+
+    @staticmethod
+    def from_batch_list(pose: Sequence[Sequence[float]], device_cfg: Optional[DeviceCfg] = None, q_xyzw: bool = False) -> "Pose":
+        dev = device_cfg.device if device_cfg is not None else None
+        m = torch.as_tensor(pose, dtype=torch.float32, device=dev)
+        q = m[..., 3:7]
+        if q_xyzw:
+            q = q[..., [3, 0, 1, 2]]
+        return Pose(m[..., :3].contiguous(), q.contiguous())
+
+    @staticmethod
+    def _euler_to_quaternion(euler_xyz: torch.Tensor, intrinsic: bool) -> torch.Tensor:
+        h = euler_xyz * 0.5
+        cx, cy, cz = torch.cos(h[..., 0:1]), torch.cos(h[..., 1:2]), torch.cos(h[..., 2:3])
+        sx, sy, sz = torch.sin(h[..., 0:1]), torch.sin(h[..., 1:2]), torch.sin(h[..., 2:3])
+        s = -1.0 if intrinsic else 1.0  # extrinsic XYZ: q = qz qy qx; intrinsic XYZ: q = qx qy qz
+        return torch.cat([cx * cy * cz + s * sx * sy * sz, sx * cy * cz - s * cx * sy * sz, cx * sy * cz + s * sx * cy * sz,
+                          cx * cy * sz - s * sx * sy * cz], dim=-1)
+
+    @classmethod
+    def _from_euler(cls, euler_xyz: torch.Tensor, position: Optional[torch.Tensor], intrinsic: bool) -> "Pose":
+        q = cls._euler_to_quaternion(euler_xyz, intrinsic)
+        if q.ndim == 1:
+            q = q.unsqueeze(0)
+        if position is None:
+            position = torch.zeros(q.shape[:-1] + (3,), device=euler_xyz.device, dtype=euler_xyz.dtype)
+        elif position.ndim == 1:
+            position = position.unsqueeze(0)
+        return cls(position, q)
+
+    @classmethod
+    def from_euler_xyz(cls, euler_xyz: torch.Tensor, position: Optional[torch.Tensor] = None) -> "Pose":
+        """rotations about the FIXED world axes X, then Y, then Z (reference from_euler_xyz)"""
+        return cls._from_euler(euler_xyz, position, False)
+
+    @classmethod
+    def from_euler_xyz_intrinsic(cls, euler_xyz: torch.Tensor, position: Optional[torch.Tensor] = None) -> "Pose":
+        """rotations about the BODY axes X, then Y, then Z, as a chain of revolute joints composes them"""
+        return cls._from_euler(euler_xyz, position, True)
+
+    def get_rotation(self) -> torch.Tensor:
+        """rotation matrices [..., 3, 3]"""
+        w, x, y, z = self.quaternion.unbind(-1)
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                            2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1).reshape(*self.quaternion.shape[:-1], 3, 3)
+
+    get_rotation_matrix = get_rotation
+
+    def get_affine_matrix(self, out_matrix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[..., 3, 4] = (R | t)"""
+        m = torch.cat([self.get_rotation(), self.position.unsqueeze(-1)], dim=-1)
+        if out_matrix is not None:
+            out_matrix.copy_(m)
+            return out_matrix
+        return m
+
+    def get_matrix(self, out_matrix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """homogeneous transforms [..., 4, 4]"""
+        m = torch.zeros(*self.position.shape[:-1], 4, 4, device=self.position.device, dtype=self.position.dtype)
+        m[..., :3, :4] = self.get_affine_matrix()
+        m[..., 3, 3] = 1.0
+        if out_matrix is not None:
+            out_matrix.copy_(m)
+            return out_matrix
+        return m
+
+    def get_numpy_matrix(self):
+        return self.get_matrix().cpu().numpy()
+
+    def get_numpy_affine_matrix(self):
+        return self.get_affine_matrix().cpu().numpy()
+
+    def get_pose_vector(self) -> torch.Tensor:
+        return torch.cat((self.position, self.quaternion), dim=-1)
+
+    def tolist(self, q_xyzw: bool = False) -> List[float]:
+        q = self.quaternion.cpu().squeeze().tolist()
+        return self.position.cpu().squeeze().tolist() + ([q[1], q[2], q[3], q[0]] if q_xyzw else q)
+
+    to_list = tolist
+
+    def stack(self, other_pose: "Pose") -> "Pose":
+        return Pose(torch.vstack((self.position, other_pose.position)), torch.vstack((self.quaternion, other_pose.quaternion)))
+
+    @staticmethod
+    def cat(pose_list: List["Pose"]) -> "Pose":
+        return Pose(torch.cat([p.position for p in pose_list]), torch.cat([p.quaternion for p in pose_list]))
+
+    def repeat(self, n: int) -> "Pose":
+        return self if n <= 1 else Pose(self.position.repeat(n, 1), self.quaternion.repeat(n, 1))
+
+    def repeat_seeds(self, num_seeds: int) -> "Pose":
+        if num_seeds <= 1:
+            return Pose(self.position, self.quaternion)
+        b = self.batch_size
+        return Pose(self.position.view(b, 1, 3).repeat(1, num_seeds, 1).reshape(b * num_seeds, 3),
+                    self.quaternion.view(b, 1, 4).repeat(1, num_seeds, 1).reshape(b * num_seeds, 4))
+
+    def unsqueeze(self, dim: int = -1) -> "Pose":
+        self.position, self.quaternion = self.position.unsqueeze(dim), self.quaternion.unsqueeze(dim)
+        return self
+
+    def squeeze(self, dim: int = -1) -> "Pose":
+        self.position, self.quaternion = self.position.squeeze(dim), self.quaternion.squeeze(dim)
+        return self
+
+    def apply_kernel(self, kernel_mat: torch.Tensor) -> "Pose":
+        return Pose(kernel_mat @ self.position, kernel_mat @ self.quaternion)
+
+    def linear_distance(self, other_pose: "Pose") -> torch.Tensor:
+        return torch.linalg.norm(self.position - other_pose.position, dim=-1)
+
+    def angular_distance(self, other_pose: "Pose", use_phi3: bool = False) -> torch.Tensor:
+        """angle of the relative rotation in radians, or with ``use_phi3`` Huynh's phi_3 in [0, 1] (reference geom/quaternion.py:75-135)"""
+        a = self.quaternion / self.quaternion.norm(dim=-1, keepdim=True)
+        b = other_pose.quaternion / other_pose.quaternion.norm(dim=-1, keepdim=True)
+        if use_phi3:
+            return torch.acos(torch.clamp((a * b).sum(-1).abs(), 0.0, 1.0)) / (torch.pi * 0.5)
+        rel = _quat_mul(a, b * b.new_tensor([1.0, -1.0, -1.0, -1.0]))
+        return 2.0 * torch.atan2(rel[..., 1:].norm(dim=-1), rel[..., 0].abs())
+
+    def distance(self, other_pose: "Pose", use_phi3: bool = False):
+        return self.linear_distance(other_pose), self.angular_distance(other_pose, use_phi3)
+
+    def transform_points(self, points: torch.Tensor, *unused) -> torch.Tensor:
+        """ONE pose applied to points [n, 3] (any leading shape is flattened) -> [n, 3]"""
+        pts = points.reshape(-1, 3)
+        return self.position.reshape(-1, 3)[:1] + _quat_rotate(self.quaternion.reshape(-1, 4)[:1].expand(pts.shape[0], 4), pts)
+
+    transform_point = transform_points  # (deprecated name in the reference)
+
+    def batch_transform_points(self, points: torch.Tensor, *unused) -> torch.Tensor:
+        """pose b applied to points [b, n, 3] -> [b, n, 3]"""
+        if points.ndim <= 2:
+            raise ValueError("batch_transform requires points to be b,n,3 shape")
+        p, q = self.position.reshape(-1, 1, 3), self.quaternion.reshape(-1, 1, 4)
+        return p + _quat_rotate(q.expand(points.shape[0], points.shape[1], 4), points)
+
+    def batch_transform_points_inverse(self, points: torch.Tensor, *unused) -> torch.Tensor:
+        return self.inverse().batch_transform_points(points)
+
+    def compute_offset_pose(self, offset: "Pose") -> "Pose":
+        return self.multiply(offset)
+
+    def compute_local_pose(self, world_pose: "Pose") -> "Pose":
+        return self.inverse().multiply(world_pose)
 
 
 @dataclass

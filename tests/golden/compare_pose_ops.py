@@ -49,4 +49,44 @@ dp = float(np.abs(r.position.detach().cpu().numpy().reshape(-1, 3) - o.position.
 good = dp < 1e-6 and same_rotation(r.quaternion, o.quaternion)
 ok &= good
 print(f"from_matrix: {'ok' if good else 'DIFFERENT'} (max |dp| {dp:.2e})")
+# the convenience members (types/pose.py:117-670): matrices, Euler constructors, distances, point transforms, shape helpers
+def close(a, b, tol=2e-6):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max()) < tol
+
+
+from curobo._src.types.device_cfg import DeviceCfg as RefDeviceCfg  # noqa: E402
+
+cpu_cfg = RefDeviceCfg(device=torch.device("cpu"))
+pts = t(rng.normal(size=(n, 7, 3)).astype(np.float32))
+eul = t(rng.uniform(-3, 3, (n, 3)).astype(np.float32))
+checks = {
+    "get_matrix": close(ra.get_matrix(), oa.get_matrix()),
+    "get_affine_matrix": close(ra.get_affine_matrix(), oa.get_affine_matrix()),
+    "get_rotation": close(ra.get_rotation(), oa.get_rotation()),
+    "get_pose_vector": close(ra.get_pose_vector(), oa.get_pose_vector()),
+    "linear_distance": close(ra.linear_distance(rb), oa.linear_distance(ob)),
+    # (the reference's axis-angle form returns [n, n] for n > 1 -- atan2 of a kept dimension against a dropped one broadcasts;
+    # its docstring says [...], which is its diagonal and what this package returns)
+    "angular_distance": close(torch.diagonal(ra.angular_distance(rb)), oa.angular_distance(ob), 5e-6)
+    and close(ra[2:3].angular_distance(rb[2:3]).reshape(-1), oa[2:3].angular_distance(ob[2:3]), 5e-6),
+    "angular_distance phi3": close(ra.angular_distance(rb, use_phi3=True), oa.angular_distance(ob, use_phi3=True), 5e-6),
+    "from_euler_xyz": same_rotation(Ref.from_euler_xyz(eul).quaternion, Ours.from_euler_xyz(eul).quaternion),
+    "from_euler_xyz_intrinsic": same_rotation(Ref.from_euler_xyz_intrinsic(eul).quaternion, Ours.from_euler_xyz_intrinsic(eul).quaternion),
+    "batch_transform_points": close(ra.batch_transform_points(pts), oa.batch_transform_points(pts), 5e-6),
+    "batch_transform_points_inverse": close(ra.batch_transform_points_inverse(pts), oa.batch_transform_points_inverse(pts), 5e-6),
+    "transform_points": close(ra[3:4].transform_points(pts[0]), oa[3:4].transform_points(pts[0]), 5e-6),
+    "compute_local_pose": close(ra.compute_local_pose(rb).position, oa.compute_local_pose(ob).position, 5e-6),
+    "compute_offset_pose": close(ra.compute_offset_pose(rb).position, oa.compute_offset_pose(ob).position, 5e-6),
+    "repeat_seeds": close(ra.repeat_seeds(3).position, oa.repeat_seeds(3).position) and ra.repeat_seeds(3).position.shape == oa.repeat_seeds(3).position.shape,
+    "repeat": ra.repeat(2).quaternion.shape == oa.repeat(2).quaternion.shape and close(ra.repeat(2).quaternion, oa.repeat(2).quaternion),
+    "stack / cat": close(ra.stack(rb).position, oa.stack(ob).position) and close(Ref.cat([ra, rb]).quaternion, Ours.cat([oa, ob]).quaternion),
+    "get_index / getitem / len": close(ra.get_index(2).position, oa.get_index(2).position) and close(ra[1:4].quaternion, oa[1:4].quaternion) and len(ra) == len(oa),
+    "tolist": np.allclose(ra[0:1].tolist(), oa[0:1].tolist(), atol=1e-6) and np.allclose(ra[0:1].tolist(q_xyzw=True), oa[0:1].tolist(q_xyzw=True), atol=1e-6),
+    "from_list / from_batch_list": close(Ref.from_list([1, 2, 3, 0, 1, 0, 0], device_cfg=cpu_cfg, q_xyzw=False).quaternion, Ours.from_list([1, 2, 3, 0, 1, 0, 0]).quaternion)
+    and same_rotation(Ref.from_batch_list([[1, 2, 3, 0, 0, 0.6, 0.8]], device_cfg=cpu_cfg, q_xyzw=True).quaternion, Ours.from_batch_list([[1, 2, 3, 0, 0, 0.6, 0.8]], q_xyzw=True).quaternion),
+    "shape / ndim / device": tuple(ra.shape) == tuple(oa.shape) and ra.ndim == oa.ndim and str(ra.device) == str(oa.device),
+}
+for k, v in checks.items():
+    print(f"member {k}: {'ok' if v else 'DIFFERENT'}")
+    ok &= bool(v)
 sys.exit(0 if ok else 1)

@@ -81,7 +81,7 @@ def test_tool_pose_criteria_factories_are_the_references():
 def test_pose_multiply_inverse_and_from_matrix_are_the_references():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_pose_ops.py")], capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
-    assert out.returncode == 0 and out.stdout.count(": ok") == 4, (out.stdout + out.stderr)[-2000:]
+    assert out.returncode == 0 and out.stdout.count(": ok") == 4 + 21 and "DIFFERENT" not in out.stdout, (out.stdout + out.stderr)[-2000:]
 
 
 @needs_reference
