@@ -42,13 +42,14 @@ class JointState:
     @staticmethod
     def from_position(position, joint_names: Optional[List[str]] = None) -> "JointState":
         p = position if torch.is_tensor(position) else torch.as_tensor(position, dtype=torch.float32)
-        return JointState(position=p, joint_names=list(joint_names) if joint_names is not None else None)
+        # (zero velocity / acceleration / jerk, as the reference's from_position: state_joint.py:133-140)
+        return JointState(p, p * 0.0, p * 0.0, p * 0.0, list(joint_names) if joint_names is not None else None)
 
     @staticmethod
     def zeros(shape: Sequence[int], device_cfg: Optional[DeviceCfg] = None, joint_names: Optional[List[str]] = None) -> "JointState":
         kw = (device_cfg or DeviceCfg()).as_torch_dict()
         z = lambda: torch.zeros(*shape, **kw)  # noqa: E731
-        return JointState(z(), z(), z(), z(), joint_names)
+        return JointState(z(), z(), z(), z(), joint_names, torch.ones(shape[0], **kw))  # (dt of ones per row: reference :159-169)
 
     @property
     def shape(self):
@@ -64,11 +65,269 @@ class JointState:
         return JointState(d(self.position), d(self.velocity), d(self.acceleration), d(self.jerk), self.joint_names, d(self.dt))
 
     def __getitem__(self, idx) -> "JointState":
+        if isinstance(idx, list):
+            idx = torch.as_tensor(idx, device=self.position.device, dtype=torch.long)
         g = lambda t: None if t is None else t[idx]  # noqa: E731
-        return JointState(g(self.position), g(self.velocity), g(self.acceleration), g(self.jerk), self.joint_names, self.dt)
+        dt = self.dt
+        if dt is not None and dt.ndim > 0 and dt.shape[0] > 1:  # a per-row dt follows the rows (kept 1-d for one row)
+            if isinstance(idx, int) or (torch.is_tensor(idx) and idx.numel() == 1):
+                i = int(idx)
+                dt = dt[i:i + 1]
+            elif isinstance(idx, slice) or torch.is_tensor(idx):
+                dt = dt[idx]
+        return JointState(g(self.position), g(self.velocity), g(self.acceleration), g(self.jerk), self.joint_names, dt)
 
     def __len__(self) -> int:
         return int(self.position.shape[0])
+
+    # ------------------------------------------------------------------ the reference's members (state/state_joint.py,
+    # state_joint_ops.py, state_joint_trajectory_ops.py), pure torch; held to the reference's class on random states by
+    # tests/golden/compare_joint_state.py
+    def _fields(self):
+        return (self.position, self.velocity, self.acceleration, self.jerk)
+
+    def _like(self, p, v, a, j, joint_names="same", dt="same") -> "JointState":
+        return JointState(p, v, a, j, self.joint_names if isinstance(joint_names, str) else joint_names, self.dt if isinstance(dt, str) else dt)
+
+    def _map(self, fn, dt="same") -> "JointState":
+        m = lambda t: None if t is None else fn(t)  # noqa: E731
+        return self._like(m(self.position), m(self.velocity), m(self.acceleration), m(self.jerk), dt=dt)
+
+    @property
+    def device(self) -> torch.device:
+        return self.position.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.position.dtype
+
+    @property
+    def ndim(self) -> int:
+        return self.position.ndim
+
+    def data_ptr(self) -> int:
+        return self.position.data_ptr()
+
+    @staticmethod
+    def from_numpy(joint_names: List[str], position, velocity=None, acceleration=None, jerk=None,
+                   device_cfg: Optional[DeviceCfg] = None) -> "JointState":
+        cfg = device_cfg or DeviceCfg()
+        pos = cfg.to_device(position)
+        f = lambda x: cfg.to_device(x) if x is not None else pos * 0.0  # noqa: E731
+        return JointState(pos, f(velocity), f(acceleration), f(jerk), list(joint_names) if joint_names is not None else None)
+
+    @staticmethod
+    def from_state_tensor(state_tensor: torch.Tensor, joint_names: Optional[List[str]] = None, dof: int = 7) -> "JointState":
+        c = lambda k: state_tensor[..., k * dof:(k + 1) * dof].contiguous()  # noqa: E731
+        return JointState(c(0), c(1), c(2), c(3), joint_names)
+
+    @staticmethod
+    def from_list(position, velocity, acceleration, device_cfg: Optional[DeviceCfg] = None) -> "JointState":
+        cfg = device_cfg or DeviceCfg()
+        return JointState(cfg.to_device(position), cfg.to_device(velocity), cfg.to_device(acceleration))
+
+    def to(self, device_cfg) -> "JointState":
+        """a ``DeviceCfg`` (the reference's argument) or a torch device"""
+        kw = device_cfg.as_torch_dict() if isinstance(device_cfg, DeviceCfg) else {"device": device_cfg}
+        return self._map(lambda t: t.to(**kw), dt=None if self.dt is None else self.dt.to(**kw))
+
+    def copy_reference(self, in_joint_state: "JointState") -> "JointState":
+        for f in ("position", "velocity", "acceleration", "jerk", "dt", "joint_names"):
+            setattr(self, f, getattr(in_joint_state, f))
+        return self
+
+    def _same_shape(self, other: "JointState") -> bool:
+        for mine, theirs in zip(self._fields()[:3], other._fields()[:3]):
+            if theirs is not None and (mine is None or mine.shape != theirs.shape):
+                return False
+        return True
+
+    def copy_(self, in_joint_state: "JointState", allow_clone: bool = True) -> "JointState":
+        """in place when the shapes agree; else (``allow_clone``) this state takes clones of the other's tensors"""
+        if in_joint_state.joint_names is not None:
+            self.joint_names = in_joint_state.joint_names
+        if self._same_shape(in_joint_state):
+            for f in ("position", "velocity", "acceleration", "jerk", "dt"):
+                mine, theirs = getattr(self, f), getattr(in_joint_state, f)
+                if mine is not None and theirs is not None:
+                    mine.copy_(theirs)
+            return self
+        if not allow_clone:
+            raise ValueError(f"current state has shape: {tuple(self.position.shape)} while new shape is {tuple(in_joint_state.position.shape)}")
+        return self.copy_reference(in_joint_state.clone())
+
+    def copy_data(self, in_joint_state: "JointState") -> "JointState":
+        return self.copy_(in_joint_state)
+
+    def unsqueeze(self, idx: int) -> "JointState":
+        return self._map(lambda t: t.unsqueeze(idx))
+
+    def squeeze(self, dim: Optional[int] = 0) -> "JointState":
+        return self._map(lambda t: torch.squeeze(t, dim))
+
+    def view(self, *shape) -> "JointState":
+        dt = self.dt.view(*shape[:2]) if len(shape) > 2 and self.dt is not None else self.dt
+        return self._map(lambda t: t.view(*shape), dt=dt)
+
+    def __setitem__(self, idx, value: "JointState") -> None:
+        for f in ("position", "velocity", "acceleration", "jerk"):
+            getattr(self, f)[idx] = getattr(value, f)
+        if self.dt is not None:
+            self.dt[idx] = value.dt
+
+    def get_state_tensor(self) -> torch.Tensor:
+        z = lambda t: self.position * 0.0 if t is None else t  # noqa: E731
+        return torch.cat((self.position, z(self.velocity), z(self.acceleration), z(self.jerk)), dim=-1)
+
+    def stack(self, new_state: "JointState") -> "JointState":
+        return JointState.from_state_tensor(torch.cat((self.get_state_tensor(), new_state.get_state_tensor()), dim=-2),
+                                            joint_names=self.joint_names, dof=self.position.shape[-1])
+
+    def cat(self, other_js: "JointState", dim: int) -> "JointState":
+        c = lambda a, b: torch.cat((a, b), dim=dim) if a is not None and b is not None else None  # noqa: E731
+        names = (self.joint_names + other_js.joint_names) if dim == -1 else self.joint_names
+        return JointState(*(c(a, b) for a, b in zip(self._fields(), other_js._fields())), names, self.dt)
+
+    def repeat(self, repeat_input: List[int]) -> "JointState":
+        return self._map(lambda t: t.repeat(repeat_input))
+
+    def repeat_seeds(self, num_seeds: int) -> "JointState":
+        r = lambda t: t.view(t.shape[0], 1, t.shape[-1]).repeat(1, num_seeds, 1).reshape(t.shape[0] * num_seeds, t.shape[-1])  # noqa: E731
+        return self._map(r, dt=None if self.dt is None else r(self.dt))
+
+    def apply_kernel(self, kernel_mat: torch.Tensor) -> "JointState":
+        return JointState(kernel_mat @ self.position, kernel_mat @ self.velocity, kernel_mat @ self.acceleration,
+                          kernel_mat @ self.jerk if self.jerk is not None else None, self.joint_names,
+                          kernel_mat @ self.dt if self.dt is not None else None)
+
+    def blend(self, coeff, new_state: "JointState") -> "JointState":
+        """in place: x <- c x_new + (1 - c) x with the coefficients coeff.position / .velocity / .acceleration / .jerk"""
+        for f in ("position", "velocity", "acceleration", "jerk"):
+            c = getattr(coeff, f)
+            getattr(self, f)[:] = c * getattr(new_state, f) + (1.0 - c) * getattr(self, f)
+        return self
+
+    def scale(self, dt) -> "JointState":
+        m = lambda t, k: None if t is None else t * (dt ** k)  # noqa: E731
+        return JointState(self.position, m(self.velocity, 1), m(self.acceleration, 2), m(self.jerk, 3), self.joint_names)
+
+    def scale_by_dt(self, dt: torch.Tensor, new_dt: torch.Tensor) -> "JointState":
+        s = dt / new_dt
+        if self.velocity is not None and self.velocity.ndim in (2, 3):
+            s = s.view(-1, *([1] * (self.velocity.ndim - 1)))
+        m = lambda t, k: None if t is None else t * (s ** k if k > 1 else s)  # noqa: E731
+        v = None if self.velocity is None else self.velocity * s
+        a = None if self.acceleration is None else self.acceleration * s * s
+        j = None if self.jerk is None else self.jerk * s * s * s
+        return JointState(self.position, v, a, j, self.joint_names, new_dt)
+
+    def scale_time(self, new_dt: torch.Tensor) -> "JointState":
+        return self.scale_by_dt(self.dt, new_dt)
+
+    def calculate_fd_from_position(self, dt: Optional[torch.Tensor] = None) -> "JointState":
+        """velocity, acceleration, jerk by forward differences along the horizon (each one sample shorter), in place"""
+        if self.dt is None and dt is None:
+            raise ValueError("dt is required")
+        dt = self.dt if dt is None else dt
+        fd = lambda p: ((torch.roll(p, -1, -2) - p) * (1 / dt).unsqueeze(-1))[..., :-1, :]  # noqa: E731
+        self.velocity = fd(self.position)
+        self.acceleration = fd(self.velocity)
+        self.jerk = fd(self.acceleration)
+        return self
+
+    def reindex(self, joint_names: List[str]) -> None:
+        """in place: the joints in the order of ``joint_names`` (a subset is allowed)"""
+        if self.joint_names is None:
+            raise ValueError("joint names are not specified in JointState")
+        idx = [self.joint_names.index(j) for j in joint_names]
+        self.joint_names = [self.joint_names[i] for i in idx]
+        sel = torch.as_tensor(idx, device=self.position.device, dtype=torch.long)
+        for f in ("position", "velocity", "acceleration", "jerk"):
+            t = getattr(self, f)
+            if t is not None:
+                setattr(self, f, torch.index_select(t, -1, sel))
+
+    def reorder(self, joint_names: List[str]) -> "JointState":
+        """a new state with the joints in the order of ``joint_names``"""
+        out = self.clone()
+        out.reindex(joint_names)
+        return out
+
+    def get_ordered_joint_state(self, ordered_joint_names: List[str]) -> "JointState":
+        return self.reorder(ordered_joint_names)
+
+    def get_augmented_joint_state(self, joint_names: List[str], lock_joints: Optional["JointState"] = None) -> "JointState":
+        if lock_joints is None:
+            return self.reorder(joint_names)
+        if joint_names is None or self.joint_names is None:
+            raise ValueError("joint_names can't be None")
+        if any(n in self.joint_names for n in lock_joints.joint_names):
+            raise ValueError("lock_joints is also listed in js.joint_names")
+        return self.clone().append_joints(lock_joints).reorder(joint_names)
+
+    def append_joints(self, joint_state: "JointState") -> "JointState":
+        """the joints of ``joint_state`` (one configuration, or one per row) behind this state's, zero derivatives for them"""
+        other = joint_state
+        if not other.joint_names:
+            raise ValueError("joint_names are required to append")
+        cur = self if self.position.ndim > 1 else self.unsqueeze(0)
+        lead = cur.position.shape[:-1]
+        op = other.position.reshape(-1, other.position.shape[-1])
+        if op.shape[0] not in (1, int(torch.tensor(lead).prod())):
+            raise ValueError("appending joints requires the new joints to have a shape matching current batch size or have a batch size of 1.")
+        extra = op.expand(int(torch.tensor(lead).prod()), -1).reshape(*lead, -1).to(cur.position.dtype)
+        z = torch.zeros_like(extra)
+        c = lambda t, e: None if t is None else torch.cat((t, e), dim=-1)  # noqa: E731
+        out = JointState(c(cur.position, extra), c(cur.velocity, z), c(cur.acceleration, z), c(cur.jerk, z),
+                         list(self.joint_names) + list(other.joint_names), other.dt if other.dt is not None else self.dt)
+        return out if self.position.ndim > 1 else out.squeeze(0)
+
+    def gather_by_seed_index(self, idx: torch.Tensor) -> "JointState":
+        """[batch, seeds, horizon, dof] state, idx [batch, k] -> the k chosen seeds of every problem [batch, k, horizon, dof]"""
+        if idx.ndim != 2 or idx.shape[0] != self.position.shape[0] or self.position.ndim != 4:
+            raise ValueError("gather_by_seed_index: idx [batch, k] against a [batch, seeds, horizon, dof] state")
+        B, S, H, D = self.position.shape
+        flat = (idx + torch.arange(B, device=idx.device).view(-1, 1) * S).view(-1)
+        g = lambda t: None if t is None else t.reshape(B * S, H, D)[flat].view(B, idx.shape[1], H, D)  # noqa: E731
+        dt = None if self.dt is None else self.dt.reshape(B * S, -1)[flat].view(B, idx.shape[1])
+        return JointState(g(self.position), g(self.velocity), g(self.acceleration), g(self.jerk), self.joint_names, dt)
+
+    def copy_only_index(self, in_joint_state: "JointState", idx) -> "JointState":
+        for f in ("position", "velocity", "acceleration", "jerk", "dt"):
+            if getattr(self, f) is not None:
+                getattr(self, f)[idx] = getattr(in_joint_state, f)[idx]
+        return self
+
+    def copy_at_index(self, in_joint_state: "JointState", idx) -> None:
+        top = idx if isinstance(idx, int) else (max(idx) if isinstance(idx, list) else int(torch.max(idx)))
+        if top >= self.position.shape[0]:
+            raise ValueError(f"{top} index out of range, current state is of length {self.position.shape[0]}")
+        for f in ("position", "velocity", "acceleration", "jerk"):
+            if getattr(self, f) is not None:
+                getattr(self, f)[idx] = getattr(in_joint_state, f)
+        if self.dt is not None and in_joint_state.dt is not None:
+            self.dt[idx] = in_joint_state.dt
+
+    def copy_at_batch_seed_indices(self, in_joint_state: "JointState", batch_idx: torch.Tensor, seed_idx: torch.Tensor) -> "JointState":
+        for f in ("position", "velocity", "acceleration", "jerk", "dt"):
+            if getattr(self, f) is not None and getattr(in_joint_state, f) is not None:
+                getattr(self, f)[batch_idx, seed_idx] = getattr(in_joint_state, f)[batch_idx, seed_idx]
+        return self
+
+    def get_trajectory_at_horizon_index(self, horizon_index: int) -> "JointState":
+        if self.position.ndim < 2:
+            raise ValueError("JointState does not have horizon")
+        return self._map(lambda t: t[..., horizon_index, :])
+
+    def trim_trajectory(self, start_idx: int, end_idx: Optional[int] = None) -> "JointState":
+        if self.position.ndim < 2:
+            raise ValueError("JointState does not have horizon")
+        end = self.position.shape[-2] if not end_idx else end_idx
+        return self._map(lambda t: t[..., start_idx:end, :])
+
+    def index_dof(self, idx: torch.Tensor) -> "JointState":
+        names = [self.joint_names[int(i)] for i in idx]
+        return JointState(*(None if t is None else torch.index_select(t, -1, idx) for t in self._fields()), names)
 
 
 def _quat_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -85,6 +85,15 @@ def test_pose_multiply_inverse_and_from_matrix_are_the_references():
 
 
 @needs_reference
+def test_joint_state_members_are_the_references():
+    """constructors, indexing, stack / cat / repeat, time scaling and finite differences, reorder / append / augment with
+    lock joints, seed gathers, trajectory trims and the copy family of ``JointState`` against the reference's class"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_joint_state.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.count(": ok") == 50 and "DIFFERENT" not in out.stdout, (out.stdout + out.stderr)[-2000:]
+
+
+@needs_reference
 def test_goal_tool_pose_from_poses_is_the_references():
     """frame order, goal-set layout [batch, 1, frames, goal set, 3 | 4] of the goals the pose cost reads"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_goal_tool_pose.py")], capture_output=True, text=True,
