@@ -67,7 +67,8 @@ class ModelPredictiveControlCfg:
         apply_robot_limits(s.rollout, kin)
         if not self_collision_check:
             s.rollout.self_collision_weight = 0.0
-        return ModelPredictiveControlCfg(kinematics=kin, scene=scene_from_config(scene_model, device_cfg.device), device_cfg=device_cfg,
+        return ModelPredictiveControlCfg(kinematics=kin, scene=scene_from_config(scene_model, device_cfg.device, cache=unused.get("collision_cache")),
+                                         device_cfg=device_cfg,
                                          max_batch_size=max_batch_size, solver=s)
 
 

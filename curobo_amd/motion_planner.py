@@ -209,7 +209,7 @@ class TrajectoryOptimizerCfg:
         and optimiser settings of ``content/configs/task/trajopt/lbfgs_bspline_trajopt.yml`` are built in."""
         device_cfg = device_cfg or DeviceCfg()
         dev = device_cfg.device
-        scene = scene_from_config(scene_model, dev)
+        scene = scene_from_config(scene_model, dev, cache=unused.get("collision_cache"))  # (slots reserved for add_obstacle)
         kin = _load_kinematics(robot, dev, assets_root)
         return TrajectoryOptimizerCfg(
             kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,
@@ -476,7 +476,8 @@ class MotionPlannerCfg:
             optimizer_collision_activation_distance=optimizer_collision_activation_distance, device_cfg=device_cfg,
             max_batch_size=max_batch_size, multi_env=multi_env, random_seed=random_seed, num_ik_seeds=num_ik_seeds,
             assets_root=assets_root, max_goalset=max_goalset, **{k: v for k, v in unused.items() if k in ("n_knots", "interpolation_steps", "interpolation_dt",
-                                                                                  "minimum_trajectory_dt", "maximum_trajectory_dt")})
+                                                                                  "minimum_trajectory_dt", "maximum_trajectory_dt",
+                                                                                  "collision_cache")})
         if multi_env and (to.scene is None or to.scene.num_envs < max_batch_size):
             raise ValueError(f"multi_env needs a list of {max_batch_size} scene models (one world per problem)")
         return MotionPlannerCfg(trajopt_solver_config=to, num_ik_seeds=num_ik_seeds, device_cfg=device_cfg)

@@ -98,7 +98,9 @@ def voxel_arrays_from_config(scene_model) -> Optional[Dict[str, np.ndarray]]:
             inv[e, g, :7] = inverse_pose7(c.get("pose") or [0, 0, 0, 1, 0, 0, 0])
             enable[e, g] = 1 if c.get("enable", True) else 0
             feats[e, g, : nx * ny * nz] = f.reshape(-1).astype(np.float16)
-    return {"voxel_params": params, "voxel_inv_pose": inv, "voxel_enable": enable, "voxel_count": count, "voxel_features": feats}
+    names = [[name for name, _ in grids] + [None] * (n - len(grids)) for grids in envs]
+    return {"voxel_params": params, "voxel_inv_pose": inv, "voxel_enable": enable, "voxel_count": count, "voxel_features": feats,
+            "voxel_names": names}
 
 
 def mesh_envs_from_config(scene_model) -> Optional[List[List[Dict]]]:
@@ -131,20 +133,36 @@ def load_scene_config(scene_model: Union[str, Dict, List, None]) -> Optional[Lis
     return [_one_env(scene_model)]
 
 
-def scene_arrays_from_config(scene_model) -> Optional[Dict[str, np.ndarray]]:
+def scene_arrays_from_config(scene_model, max_n: Optional[int] = None) -> Optional[Dict[str, np.ndarray]]:
     envs = load_scene_config(scene_model)
-    return None if envs is None else cuboid_scene_arrays(envs)
+    return None if envs is None else cuboid_scene_arrays(envs, max_n=max_n)
 
 
-def scene_from_config(scene_model, device, gradient_mode: int = 0):
+def _scene_cfgs(scene_model):
+    """the description as ``SceneCfg`` objects (one, or a list with one per environment); ``None`` when it is raw obstacle lists"""
+    from .types import SceneCfg
+
+    def one(m, d):
+        return m if isinstance(m, SceneCfg) else (SceneCfg.create(d) if isinstance(d, dict) else None)
+
+    dicts = _load_dicts(_plain(scene_model))
+    if isinstance(scene_model, (list, tuple)):
+        out = [one(m, d) for m, d in zip(scene_model, dicts)]
+        return None if any(o is None for o in out) else out
+    return one(scene_model, dicts[0])
+
+
+def scene_from_config(scene_model, device, gradient_mode: int = 0, cache: Optional[Dict[str, int]] = None):
     """scene description -> ``SceneData`` on ``device`` with every obstacle kind it names (cuboids and analytic primitives in the
     cuboid store, ``mesh`` entries behind their BVHs); ``None`` for no world.  What ``SceneCollision.from_config`` does with a
     ``SceneCfg`` in the reference (geom/collision/collision_scene.py)."""
     from .data import SceneData
     from .mesh import MeshStore
 
-    scene_model = _plain(scene_model)
-    arrays = scene_arrays_from_config(scene_model)
+    given, scene_model = scene_model, _plain(scene_model)
+    cache = cache or {}
+    # ``cache`` (reference SceneCollisionCfg.cache): slots to reserve per kind, so that ``add_obstacle`` has room later
+    arrays = scene_arrays_from_config(scene_model, max_n=cache.get("cuboid", cache.get("obb")))
     if arrays is None:
         return None
     voxels = voxel_arrays_from_config(scene_model)
@@ -152,4 +170,9 @@ def scene_from_config(scene_model, device, gradient_mode: int = 0):
         arrays = dict(arrays, **voxels)
     meshes = mesh_envs_from_config(scene_model)
     store = MeshStore(meshes, device, gradient_mode=gradient_mode) if meshes is not None else None
-    return SceneData.from_arrays(arrays, device, meshes=store)
+    data = SceneData.from_arrays(arrays, device, meshes=store)
+    try:
+        data.scene_model = _scene_cfgs(given)
+    except (TypeError, ValueError, OSError):  # (a description ``SceneCfg.create`` does not take: lookups by name stay with the stores)
+        data.scene_model = None
+    return data

@@ -52,6 +52,8 @@ def cuboid_scene_arrays(envs: List[List[Dict]], max_n: Optional[int] = None) -> 
     centred).  They live in the cuboid store with a tag in ``dims[..., 3]`` (see include/curobo_hip.h)."""
     E = len(envs)
     n = max_n or max(1, max(len(e) for e in envs))
+    if any(len(e) > n for e in envs):
+        raise ValueError(f"Cannot load {max(len(e) for e in envs)} cuboids, max cache size is {n}")
     dims = np.zeros((E, n, 4), np.float32)
     inv_pose = np.zeros((E, n, 8), np.float32)
     inv_pose[..., 3] = 1.0
@@ -79,7 +81,8 @@ def cuboid_scene_arrays(envs: List[List[Dict]], max_n: Optional[int] = None) -> 
                 raise ValueError(f"unknown obstacle type {kind!r}")
             inv_pose[e, i, :7] = inverse_pose7(pose)
             enable[e, i] = 1 if o.get("enable", True) else 0
-    return {"cuboid_dims": dims, "cuboid_inv_pose": inv_pose, "cuboid_enable": enable, "cuboid_count": count}
+    names = [[o.get("name") for o in obs] + [None] * (n - len(obs)) for obs in envs]  # (a list, not an array: stays on the host)
+    return {"cuboid_dims": dims, "cuboid_inv_pose": inv_pose, "cuboid_enable": enable, "cuboid_count": count, "cuboid_names": names}
 
 
 def voxel_grid_from_sdf(sdf_fn: Callable[[np.ndarray], np.ndarray], grid_shape: Sequence[int],
@@ -117,6 +120,9 @@ class SceneData:
     #: mesh obstacles (``scene.mesh.MeshStore``): queried through their BVHs by a launch of its own after the scene launch
     #: (``backends.collision.sphere_obstacle_collision`` runs it when ``struct.mesh_set`` is set)
     meshes: Optional["object"] = None
+    #: the description the stores were built from (``SceneCfg``, or a list with one per environment) when there was one:
+    #: what ``AttachmentManager.attach_from_scene`` looks obstacles up in (reference ``SceneCollision.scene_model``)
+    scene_model: Optional["object"] = None
 
     @property
     def num_envs(self) -> int:
@@ -127,6 +133,105 @@ class SceneData:
         if self.meshes is not None:  # a mesh-only scene: the mesh store carries the environment count
             return int(self.meshes.num_envs)
         return 1
+
+    # ------------------------------------------------------------------ obstacles by name (reference SceneData / SceneCollision:
+    # geom/data/data_scene.py:273-417, data_cuboid.py:259-428).  Every change is an in-place write into the tensors the kernels
+    # (and captured graphs) read; the host copies in ``arrays`` follow.
+    def _names(self, kind: str, env_idx: int) -> List[Optional[str]]:
+        if kind == "mesh":
+            return list(self.meshes.names[env_idx]) if self.meshes is not None else []
+        names = self.arrays.get(f"{kind}_names")
+        return names[env_idx] if names is not None else []
+
+    def _count(self, kind: str, env_idx: int) -> int:
+        c = self.arrays.get(f"{kind}_count")
+        return int(c[env_idx]) if c is not None else 0
+
+    def find_obstacle(self, name: str, env_idx: int = 0):
+        """(kind, slot) of a named obstacle: cuboid store (cuboids and analytic primitives), meshes, voxel grids, in the
+        reference's order of search; ``ValueError`` when no store of this environment holds the name"""
+        for kind in ("cuboid", "mesh", "voxel"):
+            names = self._names(kind, env_idx)
+            if name in names:
+                return kind, names.index(name)
+        raise ValueError(f"Obstacle '{name}' not found in environment {env_idx}")
+
+    def get_obstacle_names(self, env_idx: int = 0) -> List[str]:
+        out = list(self._names("cuboid", env_idx)[: self._count("cuboid", env_idx)])
+        out += [n for n in self._names("mesh", env_idx) if n is not None]
+        out += list(self._names("voxel", env_idx)[: self._count("voxel", env_idx)])
+        return out
+
+    def check_obstacle_exists(self, name: str, env_idx: int = 0) -> bool:
+        return name in self.get_obstacle_names(env_idx)
+
+    def _write(self, key: str, index, value) -> None:
+        import torch
+
+        t = self.tensors[key]
+        t[index] = torch.as_tensor(value, dtype=t.dtype, device=t.device)
+        if isinstance(self.arrays.get(key), np.ndarray):
+            self.arrays[key][index] = np.asarray(value.detach().cpu().numpy() if hasattr(value, "detach") else value, dtype=self.arrays[key].dtype)
+
+    def enable_obstacle(self, name: str, enable: bool = True, env_idx: int = 0) -> None:
+        kind, i = self.find_obstacle(name, env_idx)
+        if kind == "mesh":
+            self.meshes.set_enabled(name, enable, env_idx)
+        else:
+            self._write(f"{kind}_enable", (env_idx, i), int(bool(enable)))
+
+    @staticmethod
+    def _pose7(pose) -> List[float]:
+        if hasattr(pose, "position") and hasattr(pose, "quaternion"):  # a ``Pose``
+            return [float(v) for v in pose.position.reshape(-1)[:3].tolist() + pose.quaternion.reshape(-1)[:4].tolist()]
+        return [float(v) for v in pose]
+
+    def update_obstacle_pose(self, name: str, w_obj_pose, env_idx: int = 0) -> None:
+        """the obstacle's new pose in the world frame (a ``Pose`` or [x y z qw qx qy qz]); the stores hold its inverse"""
+        kind, i = self.find_obstacle(name, env_idx)
+        pose = self._pose7(w_obj_pose)
+        if kind == "mesh":
+            self.meshes.update_pose(name, pose, env_idx)
+            return
+        if kind == "cuboid" and float(self.arrays["cuboid_dims"][env_idx, i, 3]) == 2.0:
+            raise ValueError(f"'{name}' is a capsule: its stored frame is centred on its segment; re-load the scene to move it")
+        self._write(f"{kind}_inv_pose", (env_idx, i, slice(0, 7)), inverse_pose7(pose).astype(np.float32))
+
+    def update_obstacle_dims(self, name: str, dims, env_idx: int = 0) -> None:
+        """new full extents [x, y, z] of a cuboid (reference CuboidData.update_dims)"""
+        kind, i = self.find_obstacle(name, env_idx)
+        if kind != "cuboid" or float(self.arrays["cuboid_dims"][env_idx, i, 3]) != 0.0:
+            raise ValueError(f"'{name}' is not a cuboid")
+        self._write("cuboid_dims", (env_idx, i, slice(0, 3)), np.asarray(dims, np.float32))
+
+    def add_obstacle(self, obstacle, env_idx: int = 0) -> int:
+        """a cuboid / sphere / capsule / cylinder (``scene.types`` object or its dictionary with ``name``) into the next free
+        slot of the cuboid store of one environment; the store's capacity is what the scene was built with (``max_n`` of
+        ``cuboid_scene_arrays``, the reference's ``cache``): a full store or a name already there raises as the reference's does"""
+        if hasattr(obstacle, "get_mesh_data") or hasattr(obstacle, "get_grid_shape"):
+            raise ValueError("add_obstacle takes cuboids and analytic primitives; meshes and voxel grids are loaded with the scene")
+        if not isinstance(obstacle, dict):
+            from .types import SceneCfg
+
+            cfg = SceneCfg()
+            cfg.add_obstacle(obstacle)
+            from .config import _one_env
+
+            obstacle = _one_env(cfg.to_config())[0]
+        if "cuboid_dims" not in self.arrays:
+            raise ValueError("the scene has no cuboid store")
+        n, cap = self._count("cuboid", env_idx), int(self.arrays["cuboid_dims"].shape[1])
+        if n >= cap:
+            raise RuntimeError(f"Cannot add cuboid, cache is full ({cap} cuboids)")
+        if obstacle.get("name") in self._names("cuboid", env_idx)[:n]:
+            raise RuntimeError(f"Cuboid already exists with name: {obstacle.get('name')}")
+        one = cuboid_scene_arrays([[obstacle]], max_n=1)
+        self._write("cuboid_dims", (env_idx, n), one["cuboid_dims"][0, 0])
+        self._write("cuboid_inv_pose", (env_idx, n), one["cuboid_inv_pose"][0, 0])
+        self._write("cuboid_enable", (env_idx, n), one["cuboid_enable"][0, 0])
+        self._write("cuboid_count", (env_idx,), n + 1)
+        self.arrays.setdefault("cuboid_names", [[None] * cap for _ in range(self.num_envs)])[env_idx][n] = obstacle.get("name")
+        return n
 
     def clear(self) -> None:
         """Switch every cuboid / voxel-grid / mesh slot off, in place (the kernels read the same enable tensors): an empty

@@ -86,7 +86,7 @@ class InverseKinematicsCfg:
             kin = KinematicsCfg.from_robot_yaml_file(robot, assets_root or os.path.dirname(os.path.abspath(robot)), device=dev)
         else:
             kin = KinematicsCfg.from_packaged(str(robot).replace(".yml", "").replace(".yaml", ""), device=dev)
-        scene = scene_from_config(scene_model, dev)
+        scene = scene_from_config(scene_model, dev, cache=unused.get("collision_cache"))
         return InverseKinematicsCfg(
             kinematics=kin, scene=scene, device_cfg=device_cfg, num_seeds=num_seeds, position_tolerance=position_tolerance,
             orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,

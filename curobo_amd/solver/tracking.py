@@ -45,3 +45,18 @@ class ToolPoseTrackingMixin:
         chk = cached[1]
         chk.rejection_ratio = rejection_ratio
         return chk.sample(num_samples, mask_valid=True)
+
+    @property
+    def attachment_manager(self):
+        """attaching / detaching obstacles to a robot link (reference solver core :81-86; the planners hand out the trajectory
+        optimiser's, motion_planner.py:103-106): ONE manager per front end over its ``Kinematics`` -- whose ``link_spheres`` every
+        solver of the front end reads -- and its CURRENT scene"""
+        from ..attachment_manager import AttachmentManager
+
+        owner = getattr(self, "trajopt_solver", self)
+        scene = getattr(owner.config, "scene", None)
+        m = getattr(owner, "_attachment_manager", None)
+        if m is None:
+            m = owner._attachment_manager = AttachmentManager(owner.kinematics, scene)
+        m.update_world(scene)
+        return m

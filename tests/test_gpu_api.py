@@ -517,3 +517,73 @@ def test_front_ends_sample_collision_free_configurations(oracle, device):
         assert (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"].reshape(-1) == 0).all()
     with pytest.raises(ValueError, match="positive"):
         mpc.sample_configs(0)
+
+
+def test_attached_object_rides_the_tool_frame_and_collides(oracle, device):
+    """``AttachmentManager.update`` with the object's WORLD pose (reference attachment_manager.py:105-180): the spheres written into
+    the ``attached_object`` slots, carried through FK at the grasp configuration, are the object's spheres in the world; at any
+    other configuration they keep their place relative to the tool frame; a world cuboid at the object's place collides with the
+    robot only while the object is attached and the cuboid switched on; the planner hands out one manager over its own model"""
+    from curobo_amd.attachment_manager import AttachmentManager
+    from curobo_amd.collision_checking import RobotCollisionChecker
+    from curobo_amd.kinematics import Kinematics
+    from curobo_amd.motion_planner import MotionPlanner, MotionPlannerCfg
+    from curobo_amd.scene.config import scene_from_config
+    from curobo_amd.scene.types import Cuboid, Pose7
+    from curobo_amd.scene.types import SceneCfg as Scene
+    from curobo_amd.types import JointState, Pose
+
+    cfg = _cfg(device)
+    kin = Kinematics(cfg, compute_spheres=True)
+    kp = kin.kinematics_config
+    slots = kp.get_sphere_index_from_link_name("attached_object")
+    qg = torch.tensor([[0.0, -1.2, 0.0, -2.0, 0.0, 1.0, 0.0]], device=device)
+    hand = kin.get_link_poses(qg, ["panda_hand"])
+    hand7 = hand.position[0, 0].tolist() + hand.quaternion[0, 0].tolist()
+    # a box held 20 cm along the hand's z axis (clear of the fingers), turned against the hand
+    in_hand = Pose7([0.0, 0.0, 0.2, 0.924, 0.383, 0.0, 0.0])
+    H = Pose7(hand7)
+    box_t = H.transform(in_hand.t[None])[0]
+    Rw = H.R @ in_hand.R
+    from scipy.spatial.transform import Rotation
+
+    qx, qy, qz, qw = Rotation.from_matrix(Rw).as_quat()
+    box_pose = [*box_t.tolist(), float(qw), float(qx), float(qy), float(qz)]
+    local = torch.tensor([[0.0, 0.0, 0.0, 0.02], [0.03, 0.0, 0.0, 0.015], [-0.03, 0.01, 0.02, 0.015]], device=device)
+    world_pose = Pose(torch.tensor([box_pose[:3]], device=device), torch.tensor([box_pose[3:]], device=device))
+    scene = scene_from_config(Scene(cuboid=[Cuboid("held_box", box_pose, dims=[0.08, 0.04, 0.04])]), device)
+    m = AttachmentManager(kin, scene)
+    m.update(local, JointState.from_position(qg), world_objects_pose_offset=world_pose)
+    want = Pose7(box_pose).transform(local[:, :3].cpu().numpy())
+    sph = kin.compute_kinematics(qg).robot_spheres[0, 0, slots].cpu().numpy()
+    np.testing.assert_allclose(sph[:3, :3], want, atol=2e-6)
+    np.testing.assert_allclose(sph[:3, 3], local[:, 3].cpu().numpy(), atol=0)
+    assert (sph[3:, 3] < 0).all()
+    # another configuration: the same offsets from the hand, by the oracle's FK over the edited model
+    q2 = torch.as_tensor(sample_q(cfg.model, 3, seed=5), device=device)
+    got = kin.compute_kinematics(q2).robot_spheres[:, 0, slots[:3]].cpu().numpy()
+    hands = kin.get_link_poses(q2, ["panda_hand"])
+    for b in range(3):
+        Hb = Pose7(hands.position[b, 0].tolist() + hands.quaternion[b, 0].tolist())
+        np.testing.assert_allclose(got[b, :, :3], Hb.transform(in_hand.transform(local[:, :3].cpu().numpy())), atol=5e-6)
+    # the world's copy of the object: in collision with the attached spheres while it is on, clear when the manager switches it off
+    chk = RobotCollisionChecker(cfg, scene)
+    d_on = chk.get_scene_self_collision_distance_from_joints(qg)[0]
+    assert float(d_on.max()) > 0.0
+    m.detach()
+    assert float(chk.get_scene_self_collision_distance_from_joints(qg)[0].max()) == 0.0  # (the bare hand does not reach the box)
+    m.attach_from_scene(JointState.from_position(qg), ["held_box"], num_spheres=4, world_objects_pose_offset=Pose(
+        torch.zeros(1, 3, device=device), torch.tensor([[1.0, 0, 0, 0]], device=device)))  # (the fit is in the world frame already)
+    n = m._last_fit_result.num_spheres
+    sph = kin.compute_kinematics(qg).robot_spheres[0, 0, slots].cpu().numpy()
+    np.testing.assert_allclose(sph[:n], torch.cat([m._last_fit_result.centers, m._last_fit_result.radii[:, None]], 1).cpu().numpy(), atol=2e-6)
+    assert int(scene.tensors["cuboid_enable"][0, 0]) == 0
+    assert float(chk.get_scene_self_collision_distance_from_joints(qg)[0].max()) == 0.0
+    m.detach()
+    assert int(scene.tensors["cuboid_enable"][0, 0]) == 1
+    # front ends: one manager, over the tensors their solvers read
+    planner = MotionPlanner(MotionPlannerCfg.create(robot="franka.yml", scene_model=Scene(cuboid=[Cuboid("table", [0.7, 0, 0.2, 1, 0, 0, 0], dims=[0.6, 1.0, 0.1])]),
+                                                    collision_cache={"cuboid": 4}))
+    pm = planner.attachment_manager
+    assert pm is planner.trajopt_solver.attachment_manager and pm.kinematics_params is planner.kinematics.config.kinematics_config
+    assert pm._scene_collision is planner.trajopt_solver.config.scene and pm._scene_collision.tensors["cuboid_dims"].shape[1] == 4
