@@ -13,15 +13,37 @@ import torch
 from .hip_ops.kinematics import KinematicsFusedFunction
 from .robot import RobotModel, load_packaged_robot, load_robot_model
 from .robot.kinematics_params import KinematicsParams
+from .types import _FramePoseMembers
 
 
 @dataclass
-class ToolPose:
-    """positions [B,H,T,3] and quaternions [B,H,T,4] (wxyz) of the tool frames."""
+class ToolPose(_FramePoseMembers):
+    """positions [B,H,T,3] and quaternions [B,H,T,4] (wxyz) of the tool frames (reference ``ToolPose``, types/tool_pose.py:23-180;
+    ``get_link_pose`` / ``to_dict`` / ``reorder_links`` / indexing / copies come with ``_FramePoseMembers``)."""
 
     tool_frames: List[str]
     position: torch.Tensor
     quaternion: torch.Tensor
+
+    @property
+    def batch_size(self) -> int:
+        return int(self.position.shape[0])
+
+    @property
+    def horizon(self) -> int:
+        return int(self.position.shape[1])
+
+    @property
+    def num_links(self) -> int:
+        return int(self.position.shape[2])
+
+    @property
+    def shape(self):
+        return self.position.shape
+
+    @property
+    def device(self):
+        return self.position.device
 
     def as_goal(self, ordered_tool_frames: Optional[List[str]] = None):
         """the poses as goals for the solvers (reference ToolPose.as_goal, _src/types/tool_pose.py:165-179): a goal-set

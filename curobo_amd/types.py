@@ -611,8 +611,69 @@ class Pose:
         return self.inverse().multiply(world_pose)
 
 
+class _FramePoseMembers:
+    """what the reference's ``ToolPose`` [batch, horizon, links, 3 | 4] and ``GoalToolPose`` [batch, horizon, links, goal set, 3 | 4]
+    share (types/tool_pose.py:54-163, 214-357): the per-frame accessors and the tensor-wise copies, on ``tool_frames`` /
+    ``position`` / ``quaternion``"""
+
+    @property
+    def ndim(self) -> int:
+        return self.position.ndim
+
+    def get_link_pose(self, link_name: str, make_contiguous: bool = False) -> "Pose":
+        """one frame's poses flattened to [batch * horizon (* goal set), 3 | 4]"""
+        if link_name not in self.tool_frames:
+            raise ValueError(f"Link {link_name} not found in {self.tool_frames}")
+        li = self.tool_frames.index(link_name)
+        pos, quat = self.position[:, :, li].reshape(-1, 3), self.quaternion[:, :, li].reshape(-1, 4)
+        if make_contiguous:
+            pos, quat = pos.contiguous(), quat.contiguous()
+        return Pose(pos, quat, link_name)
+
+    def to_dict(self, make_contiguous: bool = True):
+        return {n: self.get_link_pose(n, make_contiguous) for n in self.tool_frames}
+
+    def copy_(self, other) -> None:
+        self.tool_frames = other.tool_frames
+        self.position.copy_(other.position)
+        self.quaternion.copy_(other.quaternion)
+
+    def requires_grad_(self, requires_grad: bool) -> None:
+        self.position.requires_grad_(requires_grad)
+        self.quaternion.requires_grad_(requires_grad)
+
+    def clone(self):
+        return type(self)(list(self.tool_frames), self.position.clone(), self.quaternion.clone())
+
+    def detach(self):
+        return type(self)(list(self.tool_frames), self.position.detach(), self.quaternion.detach())
+
+    def contiguous(self):
+        return type(self)(self.tool_frames, self.position.contiguous(), self.quaternion.contiguous())
+
+    def __len__(self) -> int:
+        return len(self.tool_frames)
+
+    def __getitem__(self, idx):
+        """a frame name -> its ``Pose``; an int -> that batch entry (batch axis kept); anything else indexes the batch axis"""
+        if isinstance(idx, str):
+            return self.get_link_pose(idx)
+        if isinstance(idx, int):
+            return type(self)(self.tool_frames, self.position[idx].unsqueeze(0), self.quaternion[idx].unsqueeze(0))
+        return type(self)(self.tool_frames, self.position[idx], self.quaternion[idx])
+
+    def reorder_links(self, ordered_tool_frames: List[str]):
+        """the frames in another order, or a subset of them"""
+        if not set(ordered_tool_frames).issubset(self.tool_frames):
+            raise ValueError(f"Ordered link names {ordered_tool_frames} not a subset of {self.tool_frames}")
+        if list(self.tool_frames) == list(ordered_tool_frames):
+            return self
+        idx = [self.tool_frames.index(n) for n in ordered_tool_frames]
+        return type(self)(list(ordered_tool_frames), self.position[:, :, idx].contiguous(), self.quaternion[:, :, idx].contiguous())
+
+
 @dataclass
-class GoalToolPose:
+class GoalToolPose(_FramePoseMembers):
     """goal poses per tool frame (reference GoalToolPose, _src/types/tool_pose.py:182-340): position [batch, horizon,
     num_links, num_goalset, 3], quaternion [batch, horizon, num_links, num_goalset, 4] (wxyz).  The solvers of this package
     take static goals: with horizon > 1 they read the last entry."""
@@ -682,28 +743,6 @@ class GoalToolPose:
         pos = torch.stack([pose_dict[f].position.reshape(batch, num_goalset, 3) for f in frames], dim=1)
         quat = torch.stack([pose_dict[f].quaternion.reshape(batch, num_goalset, 4) for f in frames], dim=1)
         return cls(frames, pos.unsqueeze(1), quat.unsqueeze(1))
-
-    def get_link_pose(self, link_name: str) -> Pose:
-        if link_name not in self.tool_frames:
-            raise ValueError(f"Link {link_name} not found in {self.tool_frames}")
-        li = self.tool_frames.index(link_name)
-        return Pose(self.position[:, :, li].reshape(-1, 3), self.quaternion[:, :, li].reshape(-1, 4), link_name)
-
-    def to_dict(self):
-        return {n: self.get_link_pose(n) for n in self.tool_frames}
-
-    def clone(self) -> "GoalToolPose":
-        return GoalToolPose(list(self.tool_frames), self.position.clone(), self.quaternion.clone())
-
-    def __len__(self) -> int:
-        return len(self.tool_frames)
-
-    def __getitem__(self, idx):
-        if isinstance(idx, str):
-            return self.get_link_pose(idx)
-        if isinstance(idx, int):
-            return GoalToolPose(self.tool_frames, self.position[idx].unsqueeze(0), self.quaternion[idx].unsqueeze(0))
-        return GoalToolPose(self.tool_frames, self.position[idx], self.quaternion[idx])
 
 
 @dataclass

@@ -38,4 +38,40 @@ for label, b, g, frames, order in (("one frame, batch 3", 3, 1, ["tool0"], ["too
     except Exception as e:  # noqa: BLE001
         ok = False
         print(f"{label}: ERROR {type(e).__name__}: {str(e)[:300]}")
+# the members ToolPose and GoalToolPose share (get_link_pose, to_dict, indexing, reorder_links, as_goal, copies): types/tool_pose.py:54-357
+from curobo._src.types.tool_pose import ToolPose as RefTool  # noqa: E402
+
+from curobo_amd.kinematics import ToolPose as OurTool  # noqa: E402
+
+frames = ["a", "b", "c"]
+for label, R_, O_, shape in (("ToolPose members", RefTool, OurTool, (4, 3, 3)), ("GoalToolPose members", Ref, Ours, (4, 3, 3, 2))):
+    p, q = torch.as_tensor(rng.normal(size=(*shape, 3)).astype(np.float32)), torch.as_tensor(rng.normal(size=(*shape, 4)).astype(np.float32))
+    r, o = R_(list(frames), p.clone(), q.clone()), O_(list(frames), p.clone(), q.clone())
+
+    def eq(a, b):
+        return tuple(a.position.shape) == tuple(b.position.shape) and torch.equal(a.position, b.position) and torch.equal(a.quaternion, b.quaternion) \
+            and list(getattr(a, "tool_frames", [])) == list(getattr(b, "tool_frames", []))
+
+    checks = [eq(r.get_link_pose("b"), o.get_link_pose("b")), eq(r["c"], o["c"]), eq(r[2], o[2]), eq(r[torch.tensor([0, 3])], o[torch.tensor([0, 3])]),
+              eq(r.reorder_links(["c", "a"]), o.reorder_links(["c", "a"])), r.reorder_links(frames) is r and o.reorder_links(frames) is o,
+              eq(r.clone(), o.clone()), eq(r.detach(), o.detach()), len(r) == len(o), r.ndim == o.ndim, tuple(r.shape) == tuple(o.shape),
+              (r.batch_size, r.horizon, r.num_links) == (o.batch_size, o.horizon, o.num_links),
+              all(eq(a, b) for a, b in zip(r.to_dict().values(), o.to_dict().values())) and list(r.to_dict()) == list(o.to_dict())]
+    if R_ is RefTool:
+        checks += [eq(r.as_goal(), o.as_goal()), eq(r.as_goal(["b", "a"]), o.as_goal(["b", "a"])), eq(r.contiguous(), o.contiguous())]
+    r2, o2 = R_(list(frames), p * 0, q * 0), O_(list(frames), p * 0, q * 0)
+    r2.copy_(r), o2.copy_(o)
+    checks.append(eq(r2, o2))
+    for bad in (lambda x: x.get_link_pose("zz"), lambda x: x.reorder_links(["a", "zz"])):
+        got = []
+        for x in (r, o):
+            try:
+                bad(x)
+                got.append(False)
+            except Exception:  # noqa: BLE001
+                got.append(True)
+        checks.append(all(got))
+    good = all(checks)
+    ok &= good
+    print(f"{label}: {'ok' if good else 'DIFFERENT ' + str(checks)}")
 sys.exit(0 if ok else 1)

@@ -98,7 +98,7 @@ def test_goal_tool_pose_from_poses_is_the_references():
     """frame order, goal-set layout [batch, 1, frames, goal set, 3 | 4] of the goals the pose cost reads"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_goal_tool_pose.py")], capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
-    assert out.returncode == 0 and out.stdout.count(": ok") == 4, (out.stdout + out.stderr)[-2000:]
+    assert out.returncode == 0 and out.stdout.count(": ok") == 4 + 2, (out.stdout + out.stderr)[-2000:]
 
 
 @needs_reference
