@@ -50,6 +50,9 @@ class IKSolverCfg:
     #: and the L-BFGS stage is skipped.  Costs one device->host read of the success count, as there.
     exit_early: bool = True
     exit_early_batch_success_threshold: float = 1.0
+    #: reference IKSolverCfg.override_iters_for_multi_link_ik (solver_ik_cfg.py:68, solver_ik.py:115-128): the L-BFGS iteration
+    #: count is raised to this when it is lower (its benchmark sets 240 for the Unitree G1)
+    override_iters_for_multi_link_ik: Optional[int] = None
 
 
 @dataclass
@@ -78,10 +81,18 @@ class IKSolver:
         self.S_global = int(global_num_seeds) if global_num_seeds is not None else self.S
         # private copy of the optimiser configuration: the caller's cfg may be shared by solvers of other sizes
         ocfg = dataclasses.replace(self.cfg.optimizer, num_problems=self.P * self.S)
+        if self.cfg.override_iters_for_multi_link_ik is not None and ocfg.num_iters < int(self.cfg.override_iters_for_multi_link_ik):
+            inner = max(int(ocfg.inner_iters), 1)
+            ocfg = dataclasses.replace(ocfg, num_iters=-(-int(self.cfg.override_iters_for_multi_link_ik) // inner) * inner)
         self.cfg = dataclasses.replace(self.cfg, optimizer=ocfg)
         self.nls = len(ocfg.line_search_scale)
         self.G = self.cfg.num_goalset
-        self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, self.cfg.rollout, num_goalset=self.G)
+        # the metrics rollout decides feasibility as the reference's does (content/configs/task/metrics_base.yml:8-19): joint limits
+        # and scene collision at ZERO activation distance -- a solution inside the optimiser's 0.01 rad / 2.5 mm activation shells
+        # is inside the limits and clear of the world (with 49 joints a quarter of the G1's solutions sit within 0.01 rad of a limit)
+        self.metrics_rollout = IKRollout(kin, scene, self.P * self.S, dataclasses.replace(
+            self.cfg.rollout, cspace_activation_distance=[0.0] * len(self.cfg.rollout.cspace_activation_distance),
+            scene_activation_distance=0.0), num_goalset=self.G)
         bounds = (kin.joint_limits_position[0], kin.joint_limits_position[1])
         K = self.cfg.stream_shards
         if K > 1 and self.P % K != 0:
@@ -112,7 +123,15 @@ class IKSolver:
             # W = 8 draw the same seeds): max(seed_solver_num_seeds, 2 x global seeds) LM runs per problem, this rank
             # takes a contiguous slice of them, all ranks rank them together and the optimiser seeds of this rank are
             # rows [seed_offset, seed_offset + num_seeds) of that ranking
-            n_lm = max(self.cfg.seed_solver_num_seeds, 2 * self.S_global)
+            # robots with several tool frames get more and longer LM runs, as the reference's IKSolver sets them
+            # (solver_ik.py:109-141: 128 runs x 20 iterations for two frames, 64 x 30 for more; 16 iterations otherwise)
+            n_frames = len(kin.tool_frames) if getattr(kin, "tool_frames", None) is not None else 1
+            lm_runs, lm_iters, lm_inner = self.cfg.seed_solver_num_seeds, 16, 4
+            if n_frames > 1:
+                lm_runs, lm_iters, lm_inner = 128, 20, 4
+            if n_frames > 2:
+                lm_runs, lm_iters, lm_inner = 64, 30, 5
+            n_lm = max(lm_runs, 2 * self.S_global)
             lm_lo, lm_hi = 0, n_lm
             if self.S_global != self.S:
                 import torch.distributed as dist
@@ -125,7 +144,8 @@ class IKSolver:
                                      f"contiguous shard {shard_range(self.S_global, rank, world)} (world size {world})")
                 lm_lo, lm_hi = shard_range(n_lm, rank, world)
             self.seed_solver = SeedIKSolver(kin, self.P, SeedIKSolverCfg(num_seeds=lm_hi - lm_lo, use_cuda_graph=use_cuda_graph,
-                                                                         sampler_seed=451 + self.cfg.seed),
+                                                                         sampler_seed=451 + self.cfg.seed, max_iterations=lm_iters,
+                                                                         inner_iterations=lm_inner, lambda_initial=1.0, rho_min=1e-5),
                                             num_goalset=self.G, seed_offset=lm_lo, global_num_seeds=n_lm)
             # one set of goal buffers for the metrics rollout and the seed stage ([P, T, G, 3 | 4] both): a solve uploads
             # its goals once (shared BEFORE anything is captured: the graphs hold these addresses)

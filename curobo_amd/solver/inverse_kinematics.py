@@ -64,14 +64,16 @@ class InverseKinematicsCfg:
     max_batch_size: int = 0
     max_goalset: int = 1
     stream_shards: int = 1
+    #: reference ``override_iters_for_multi_link_ik``: L-BFGS iterations raised to this when lower
+    override_iters_for_multi_link_ik: Optional[int] = None
 
     @staticmethod
     def create(robot: Union[str, Dict], scene_model: Union[str, Dict, List, None] = None, num_seeds: int = 32,
                position_tolerance: float = 0.005, orientation_tolerance: float = 0.05, use_cuda_graph: bool = True,
                self_collision_check: bool = True, optimizer_collision_activation_distance: float = 0.0025,
                device_cfg: Optional[DeviceCfg] = None, seed_solver_num_seeds: Optional[int] = None, max_batch_size: int = 0,
-               max_goalset: int = 1, use_lm_seed: bool = True, exit_early: bool = True, assets_root: str = "", **unused
-               ) -> "InverseKinematicsCfg":
+               max_goalset: int = 1, use_lm_seed: bool = True, exit_early: bool = True, assets_root: str = "",
+               override_iters_for_multi_link_ik: Optional[int] = None, **unused) -> "InverseKinematicsCfg":
         """``robot``: packaged name (``"franka.yml"``), a robot yaml path or its dictionary.  ``scene_model``: the
         reference's scene format (see ``curobo_amd.scene.config``).  Keyword arguments of the reference this backend has
         no use for (``optimizer_configs``, ``metrics_rollout``, ``transition_model``, ...) are accepted and ignored: the
@@ -92,7 +94,7 @@ class InverseKinematicsCfg:
             orientation_tolerance=orientation_tolerance, use_cuda_graph=use_cuda_graph, self_collision_check=self_collision_check,
             optimizer_collision_activation_distance=optimizer_collision_activation_distance, exit_early=exit_early,
             seed_solver_num_seeds=seed_solver_num_seeds or max(32, 2 * num_seeds), use_lm_seed=use_lm_seed,
-            max_batch_size=max_batch_size, max_goalset=max_goalset)
+            max_batch_size=max_batch_size, max_goalset=max_goalset, override_iters_for_multi_link_ik=override_iters_for_multi_link_ik)
 
 
 class InverseKinematics(ToolPoseTrackingMixin):
@@ -207,7 +209,8 @@ class InverseKinematics(ToolPoseTrackingMixin):
             c = self.config
             cfg = IKSolverCfg(num_seeds=c.num_seeds, position_threshold=c.position_tolerance, rotation_threshold=c.orientation_tolerance,
                               use_lm_seed=c.use_lm_seed, seed_solver_num_seeds=c.seed_solver_num_seeds, num_goalset=c.max_goalset,
-                              stream_shards=c.stream_shards if batch % max(c.stream_shards, 1) == 0 else 1)
+                              stream_shards=c.stream_shards if batch % max(c.stream_shards, 1) == 0 else 1,
+                              override_iters_for_multi_link_ik=c.override_iters_for_multi_link_ik)
             cfg.rollout.scene_activation_distance = c.optimizer_collision_activation_distance
             if not c.self_collision_check:
                 cfg.rollout.self_collision_weight = 0.0

@@ -123,10 +123,12 @@ class TrajOptSolver:
         self._ik: Optional[IKSolver] = None  # built on first use: callers that bring seed_config never need it
         self.rollout = TrajOptRollout(kin, scene, self.P * self.S * self.nls, rc)
         # the metrics rollout checks feasibility the way the reference's does (content/configs/task/metrics_base.yml:8-19):
-        # discrete scene collision at zero activation distance (a seed fails when a sphere penetrates, not when it enters
-        # the optimiser's 2.5 mm activation shell), kernel sequence (it materialises the per-point terms the checks read)
+        # discrete scene collision and the joint-state limits at zero activation distance (a seed fails when a sphere penetrates or a
+        # limit is crossed, not when it enters the optimiser's 2.5 mm / 0.01 activation shells), kernel sequence (it materialises the
+        # per-point terms the checks read)
         self.metrics_rollout = TrajOptRollout(kin, scene, self.P * self.S, dataclasses.replace(
-            rc, use_sweep=False, use_speed_metric=False, scene_activation_distance=0.0, use_fused=False))
+            rc, use_sweep=False, use_speed_metric=False, scene_activation_distance=0.0, use_fused=False,
+            cspace_activation_distance=[0.0] * len(rc.cspace_activation_distance)))
         self.K = max(1, min(self.cfg.num_ik_goals or self.S_global, self.S_global, self.cfg.ik.num_seeds))
         D, PS = kin.num_dof, self.P * self.S
         rows = torch.arange(PS * self.nls, device=self.device)

@@ -315,7 +315,10 @@ def test_ik_position_only_criteria(oracle, device, this_repos_curobo):  # noqa: 
     np.testing.assert_allclose(p, mixed.position[:, 0, 0, 0].cpu().numpy(), atol=5e-3)
     gq = mixed.quaternion[:, 0, 0, 0].cpu().numpy()
     off = np.minimum(np.linalg.norm(qn - gq, axis=1), np.linalg.norm(qn + gq, axis=1))
-    assert (off > 0.05).sum() >= n // 2, "the orientation was free"
+    # where the full pose cannot be reached the position-only solution leaves the goal's orientation (where it can, the seed stage's
+    # full-pose solution is a valid position-only solution too and may be returned as it is)
+    unreachable = ~full.success[:, 0].cpu().numpy()
+    assert unreachable.sum() >= 3 and (off[unreachable] > 0.02).all(), ("the orientation was free", unreachable, off)
     fk = oracle.kinematics_forward(sol, model.as_dict())
     sph = fk["robot_spheres"].reshape(n, 1, -1, 4)
     assert (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
