@@ -489,6 +489,7 @@ def main():
                 guarded("mesh_world", lambda: mesh_benchmark(model, kin, device, torch))
             if want("ik") and not args.no_ik:
                 guarded("ik", lambda: ik_benchmark(args, model, kin, device, torch))
+                guarded("ik_reference_protocol", lambda: ik_protocol_benchmark(torch))
                 guarded("full_trajopt_rollout", lambda: full_trajopt_benchmark(seeds, model, kin, scene, device, torch))
                 guarded("trajopt_solve", lambda: trajopt_solve_benchmark(model, kin, scene, device, torch))
             if not args.no_cpu_baseline:
@@ -589,6 +590,13 @@ def compact_line(out: dict) -> dict:
         for k in ("roofline", "cpu_baseline"):
             if isinstance(ik.get(k), dict):
                 line["ik"][k] = {a: b for a, b in ik[k].items() if not isinstance(b, (dict, list)) and (not isinstance(b, str) or len(b) <= 120)}
+    proto = out.get("ik_reference_protocol", {})
+    if ik and isinstance(proto.get("rows"), list):  # [IK ms, collision-free IK ms] per robot of the reference's published table
+        rows = [r for r in proto["rows"] if "ms" in r]
+        robots = sorted({r["robot"] for r in rows}, key=lambda n: ("franka", "dual_ur10e", "unitree_g1").index(n))
+        pick = lambda n, key: [next((r[key] for r in rows if r["robot"] == n and r["collision_free"] == c), None) for c in (False, True)]  # noqa: E731
+        line["ik"]["reference_protocol"] = {"ms": {n: pick(n, "ms") for n in robots}, "published_ms": {n: pick(n, "published_ms_nvidia") for n in robots},
+                                            "success_percent": {n: pick(n, "success_percent") for n in robots}}
     ss = out.get("strong_scaling", {})
     if ss:
         line["strong_scaling"] = {a: b for a, b in ss.items() if not isinstance(b, (dict, list)) and (not isinstance(b, str) or len(b) <= 80)}
@@ -1588,6 +1596,81 @@ def trajopt_solve_benchmark(model, kin, scene, device, torch):
                        "pose + c-space state + self + swept scene collision) + finetune pass + metrics; context only: the reference "
                        "publishes 31 ms mean solve time for its full motion planner on an RTX 6000 Ada")
     return res
+
+
+IK_PROTOCOL_PUBLISHED_MS = {"franka": (2.601, 2.726), "dual_ur10e": (6.058, 15.64), "unitree_g1": (31.39, 526.9)}
+IK_PROTOCOL_PUBLISHED_SUCCESS = {"franka": (100.0, 100.0), "dual_ur10e": (100.0, 99.2), "unitree_g1": (100.0, 98.4)}
+
+
+def ik_protocol_case(robot: str, collision_free: bool, torch, batch: int = 100) -> dict:
+    """One row of the reference's IK benchmark (benchmark/ik_benchmark.py:53-165; published: docs/reference/benchmarks.rst:62-72)
+    over this package's ``InverseKinematics`` front end: batch 100, goals = FK of collision-free samples, `IK` = no collision
+    terms with 2 seeds, `collision-free IK` = self collision + collision_table.yml with 8 (Franka) / 16 seeds, exit_early on, three
+    warm-up solves, then the mean over five goal sets of the wall time of ``solve_pose`` (host clock around a synchronised call).
+    Differences: the packaged robot models keep their locked joints and collision links in the `IK` case (the reference strips
+    both there); seed-solver seed counts and the G1's 240 L-BFGS iterations are the reference's."""
+    import numpy as np
+
+    from curobo_amd.solver.inverse_kinematics import InverseKinematics, InverseKinematicsCfg
+    from curobo_amd.types import JointState
+
+    g1 = robot == "unitree_g1"
+    seeds = (16 if robot in ("unitree_g1", "dual_ur10e") else 8) if collision_free else 2
+    ik = InverseKinematics(InverseKinematicsCfg.create(
+        robot=f"{robot}.yml", scene_model="collision_table.yml" if collision_free else None, num_seeds=seeds, position_tolerance=0.005,
+        optimizer_collision_activation_distance=0.0025, self_collision_check=collision_free, use_cuda_graph=True,
+        seed_solver_num_seeds=128 if g1 else max(32, 2 * seeds), max_batch_size=batch, override_iters_for_multi_link_ik=240 if g1 else None))
+    torch.manual_seed(2)
+    sets, ratio = [], 10
+    for _ in range(5):
+        q = ik.sample_configs(batch, rejection_ratio=ratio)
+        while q.shape[0] < batch:
+            ratio = int(1.2 * ratio) + 1
+            if ratio > 400:
+                raise RuntimeError("rejection ratio too high")
+            q = ik.sample_configs(batch, rejection_ratio=ratio)
+        sets.append(q[:batch].contiguous())
+    goal = lambda q: ik.compute_kinematics(JointState.from_position(q)).tool_poses.as_goal()  # noqa: E731
+    ik.config.exit_early = False
+    for _ in range(3):
+        ik.reset_seed()
+        ik.solve_pose(goal(sets[0]))
+    ik.config.exit_early = True
+    times, succ, perr, rerr = [], [], [], []
+    for q in sets:
+        ik.reset_seed()
+        g = goal(q)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = ik.solve_pose(g)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        ok = r.success.view(-1)
+        succ.append(100.0 * float(ok.float().mean()))
+        if bool(ok.any()):
+            perr.append(float(np.percentile(r.position_error.view(-1)[ok].cpu().numpy(), 90)))
+            rerr.append(float(np.percentile(r.rotation_error.view(-1)[ok].cpu().numpy(), 90)))
+    col = 1 if collision_free else 0
+    return {"robot": robot, "collision_free": collision_free, "batch": batch, "num_seeds": seeds, "tool_frames": len(ik.tool_frames), "dof": ik.dof,
+            "ms": round(1e3 * float(np.mean(times)), 3), "ms_each": [round(1e3 * t, 3) for t in times], "success_percent": round(float(np.mean(succ)), 2),
+            "position_error_p90_mm": round(1e3 * float(np.mean(perr)), 5) if perr else None,
+            "rotation_error_p90_deg": round(float(np.degrees(np.mean(rerr))), 5) if rerr else None,
+            "published_ms_nvidia": IK_PROTOCOL_PUBLISHED_MS[robot][col], "published_success_percent": IK_PROTOCOL_PUBLISHED_SUCCESS[robot][col],
+            "solves_per_s": round(batch / float(np.mean(times)), 1)}
+
+
+def ik_protocol_benchmark(torch) -> dict:
+    """the six rows of the reference's published IK table, each guarded on its own"""
+    rows = []
+    for robot in ("franka", "dual_ur10e", "unitree_g1"):
+        for cfree in (False, True):
+            try:
+                rows.append(ik_protocol_case(robot, cfree, torch))
+            except Exception as e:  # noqa: BLE001
+                rows.append({"robot": robot, "collision_free": cfree, "error": f"{type(e).__name__}: {str(e)[:300]}"})
+    return {"rows": rows, "protocol": "reference benchmark/ik_benchmark.py: batch 100, IK (2 seeds, no collision terms) / collision-free IK (8 or 16 "
+                                      "seeds, self collision + collision_table.yml), mean wall time of solve_pose over five goal sets",
+            "published": "docs/reference/benchmarks.rst:62-72 (NVIDIA GPU not named on the page)"}
 
 
 def ik_benchmark(args, model, kin, device, torch):

@@ -69,3 +69,21 @@ def test_compact_line_sheds_optional_objects_before_it_outgrows_the_limit():
     line = bench.compact_line(full)
     assert len(json.dumps(line)) <= bench.LINE_LIMIT
     assert "roofline" in line and "cpu_baseline" in line
+
+
+def test_ik_reference_protocol_rows_reach_the_line():
+    """the six rows of the reference's IK table travel in the line as [IK, collision-free IK] per robot, next to the published values"""
+    bench = _bench()
+    full = json.load(open(RECORDS[-1]))
+    rows = []
+    for i, robot in enumerate(("franka", "dual_ur10e", "unitree_g1")):
+        for cfree in (False, True):
+            rows.append({"robot": robot, "collision_free": cfree, "ms": 1.0 + i + 0.5 * cfree, "success_percent": 100.0 - cfree,
+                         "published_ms_nvidia": bench.IK_PROTOCOL_PUBLISHED_MS[robot][int(cfree)]})
+    rows[3] = {"robot": "dual_ur10e", "collision_free": True, "error": "RuntimeError: x"}  # a failed row leaves a gap, not a crash
+    full["ik_reference_protocol"] = {"rows": rows}
+    line = bench.compact_line(full)
+    proto = line["ik"]["reference_protocol"]
+    assert proto["ms"] == {"franka": [1.0, 1.5], "dual_ur10e": [2.0, None], "unitree_g1": [3.0, 3.5]}
+    assert proto["published_ms"]["unitree_g1"] == [31.39, 526.9] and proto["success_percent"]["franka"] == [100.0, 99.0]
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
