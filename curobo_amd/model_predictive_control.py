@@ -187,6 +187,14 @@ class ModelPredictiveControl(ToolPoseTrackingMixin):
             raise ValueError("robot_ids not supported for update_goal_state")
         self.solver.update_goal_state(self._batch(goal_state))
 
+    def update_seed_trajectory(self, seed_trajectory: torch.Tensor) -> None:
+        """knots [batch, action_horizon, action_dim] the next solve starts from (reference solver_mpc.py:498-514)"""
+        self.solver.update_seed_trajectory(seed_trajectory)
+
+    def update_seed_trajectory_from_goal_state(self, goal_joint_state: JointState) -> None:
+        """seed the next solve with the straight joint-space line from the current state to ``goal_joint_state`` (reference :516-531)"""
+        self.solver.update_seed_trajectory_from_goal_state(self._batch(goal_joint_state))
+
     def enable_joint_position_tracking(self) -> None:
         self.solver.enable_joint_position_tracking()
 

@@ -188,7 +188,40 @@ class MPCSolver:
 
     def reset_robot(self, current_state: JointState) -> None:
         self.update_current_state(current_state)
-        self._warm, self._knots = False, None
+        self._warm, self._knots, self._seed_override = False, None, None
+
+    # ------------------------------------------------------------------ seeds from outside
+    def update_seed_trajectory(self, seed_trajectory: torch.Tensor) -> None:
+        """the knots [batch, action_horizon, action_dim] the NEXT solve starts from instead of the hold-still seed (cold) or the
+        shifted previous plan (warm); the next ``optimize_next_action`` re-optimises (reference ``update_seed_trajectory``,
+        solver_mpc.py:498-514: the action buffer and the optimiser are re-initialised with the trajectory)"""
+        nk, D = self.rollout_cfg.n_knots, self.kin.num_dof
+        if seed_trajectory.ndim != 3:
+            raise ValueError(f"seed_trajectory must have 3 dimensions, got {seed_trajectory.ndim}")
+        if seed_trajectory.shape[0] != self.B:
+            raise ValueError(f"seed_trajectory must have {self.B} rows, got {seed_trajectory.shape[0]}")
+        if seed_trajectory.shape[2] != D:
+            raise ValueError(f"seed_trajectory must have {D} columns, got {seed_trajectory.shape[2]}")
+        if seed_trajectory.shape[1] != nk:
+            raise ValueError(f"seed_trajectory must have {nk} columns, got {seed_trajectory.shape[1]}")
+        lo, hi = self.kin.joint_limits_position[0], self.kin.joint_limits_position[1]
+        self._seed_override = torch.minimum(torch.maximum(seed_trajectory.to(self.device, torch.float32), lo), hi).contiguous().clone()
+        self._cursor = 1 << 30  # (a warm controller has 'used its commands up': the next call solves)
+
+    def update_seed_trajectory_from_goal_state(self, goal_joint_state: JointState) -> None:
+        """seed = the straight joint-space line from the current state to ``goal_joint_state`` [batch, dof] over the knots
+        (reference :516-531: ``prepare_trajectory_seeds`` with the goal as ``seed_config``)"""
+        if getattr(self, "_current", None) is None:
+            raise RuntimeError("Current state not available. Call setup first.")
+        nk, D = self.rollout_cfg.n_knots, self.kin.num_dof
+        goal = goal_joint_state.position.to(self.device, torch.float32).reshape(self.B, 1, D)
+        t = torch.linspace(0.0, 1.0, nk + 2, device=self.device)[1:-1].view(1, -1, 1)  # (the weights of TrajOptSolver.seed_knots)
+        self.update_seed_trajectory(self._current.view(self.B, 1, D) * (1 - t) + goal * t)
+
+    def _take_seed(self, default: torch.Tensor) -> torch.Tensor:
+        seed = getattr(self, "_seed_override", None)
+        self._seed_override = None
+        return default if seed is None else seed
 
     # ------------------------------------------------------------------ solves
     def _solve(self, seed_knots: torch.Tensor, iters: int) -> None:
@@ -216,7 +249,7 @@ class MPCSolver:
         """hold-still seed, ``cold_start_optimization_num_iters`` iterations (reference :626-642)"""
         self.update_current_state(current_state)
         seed = self._current.view(self.B, 1, -1).expand(-1, self.rollout_cfg.n_knots, -1).contiguous()
-        self._solve(seed, self.cfg.cold_start_optimization_num_iters)
+        self._solve(self._take_seed(seed), self.cfg.cold_start_optimization_num_iters)
 
     def warm_start_solve(self, current_state: JointState) -> None:
         """previous knots shifted by the executed intervals (last knot repeated), ``warm_start_optimization_num_iters`` iterations
@@ -227,7 +260,7 @@ class MPCSolver:
         start = 1 if self.cfg.continuous_commands else self.cfg.interpolation_steps
         n = max(1, min((self._cursor - start) // self.cfg.interpolation_steps, self._knots.shape[1] - 1))
         seed = torch.cat([self._knots[:, n:], self._knots[:, -1:].expand(-1, n, -1)], dim=1).contiguous()
-        self._solve(seed, self.cfg.warm_start_optimization_num_iters)
+        self._solve(self._take_seed(seed), self.cfg.warm_start_optimization_num_iters)
 
     def optimize_next_action(self, current_state: JointState) -> MPCSolverResult:
         if not self._setup_done:

@@ -162,3 +162,47 @@ def test_mpc_joint_space_control(oracle, device):
     assert bool(((state.position >= lo) & (state.position <= hi)).all())
     with pytest.raises(ValueError, match="robot_ids"):
         mpc.update_goal_state(JointState.from_position(q_goal, mpc.joint_names), robot_ids=torch.tensor([0]))
+
+
+def test_mpc_seed_trajectory_from_outside(oracle, device):
+    """``update_seed_trajectory`` / ``update_seed_trajectory_from_goal_state`` (reference solver_mpc.py:498-531): the next solve starts
+    from the given knots, a warm controller re-optimises at once, and a seed that
+    already leads to the goal's configuration converges in the first solve where the hold-still seed does not"""
+    from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg
+    from curobo_amd.types import JointState
+
+    mpc = ModelPredictiveControl(ModelPredictiveControlCfg.create(robot="franka.yml", scene_model=None))
+    q0 = mpc.default_joint_state.position.view(1, -1).clone()
+    state = JointState(position=q0.clone(), velocity=torch.zeros_like(q0), acceleration=torch.zeros_like(q0), joint_names=mpc.joint_names)
+    q_goal = q0 + torch.tensor([[0.4, -0.3, 0.3, 0.3, -0.3, 0.3, 0.4]], device=q0.device)
+    goal = mpc.compute_kinematics(JointState.from_position(q_goal, mpc.joint_names)).tool_poses.as_goal()
+    mpc.setup(state, goal)
+    s = mpc.solver
+    nk, D = s.rollout_cfg.n_knots, 7
+    # shapes are checked as the reference checks them
+    for bad in (torch.zeros(nk, D), torch.zeros(2, nk, D), torch.zeros(1, nk + 1, D), torch.zeros(1, nk, D + 1)):
+        with pytest.raises(ValueError, match="seed_trajectory"):
+            mpc.update_seed_trajectory(bad.to(device))
+    # the solve starts from the seed (limits applied), once
+    started_from, solve = [], s._solve
+    s._solve = lambda knots, iters: (started_from.append(knots.clone()), solve(knots, iters))[1]
+    seed = (q0.view(1, 1, D) + torch.linspace(0, 1, nk, device=device).view(1, nk, 1) * 0.2).contiguous()
+    mpc.update_seed_trajectory(seed)
+    r = mpc.optimize_next_action(state)
+    assert r.reoptimized and torch.equal(started_from[-1], seed) and s._seed_override is None
+    # a warm controller with commands left re-optimises on the next call once a seed is handed in
+    r = mpc.optimize_next_action(state)
+    assert not r.reoptimized
+    mpc.update_seed_trajectory_from_goal_state(JointState.from_position(q_goal, mpc.joint_names))
+    want = q0.view(1, 1, D) + torch.linspace(0, 1, nk + 2, device=device)[1:-1].view(1, nk, 1) * (q_goal - q0).view(1, 1, D)
+    assert torch.allclose(s._seed_override, want, atol=1e-6)
+    r = mpc.optimize_next_action(state)
+    assert r.reoptimized and s._seed_override is None and torch.allclose(started_from[-1], want, atol=1e-6)
+    # the line to the goal configuration as the first seed: the plan's last point is nearer the goal after ONE cold solve than from the hold-still seed
+    mpc.reset_robot(state)
+    mpc.update_seed_trajectory_from_goal_state(JointState.from_position(q_goal, mpc.joint_names))
+    r_seeded = mpc.optimize_action_sequence(state)
+    mpc.reset_robot(state)
+    r_plain = mpc.optimize_action_sequence(state)
+    assert float(r_seeded.position_error.max()) < 0.05, (r_seeded.position_error, r_plain.position_error)
+    assert float(r_seeded.position_error.max()) <= float(r_plain.position_error.max()) + 1e-4
