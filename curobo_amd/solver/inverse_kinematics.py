@@ -220,11 +220,12 @@ class InverseKinematics(ToolPoseTrackingMixin):
         return self._solvers[batch]
 
     def solve_pose(self, goal_tool_poses: GoalToolPose, seed_config: Optional[torch.Tensor] = None, return_seeds: int = 1,
-                   **unused) -> InverseKinematicsResult:
+                   current_state: Optional[JointState] = None, **unused) -> InverseKinematicsResult:
         """``goal_tool_poses``: GoalToolPose [batch, 1, T, num_goalset, 3 | 4] -- the goal of EVERY tool frame of the robot
         (``tool_frames`` order), as the reference's solve_pose takes it (solver_ik.py:631-700); a goal set smaller than
         ``config.max_goalset`` is padded with its last pose, a larger one rebuilds the solvers; ``seed_config``
-        [batch, num_seeds, dof] optional warm starts."""
+        [batch, num_seeds, dof] optional warm starts; ``current_state`` [batch, dof]: the robot's configuration -- first seed of
+        the seed stage, which then prefers solutions near it (reference ``solve_pose(current_state=)``, solver_ik.py:631-700)."""
         t0 = time.perf_counter()
         gp, gq = goal_tool_poses.static_goals(self.tool_frames)  # [batch, T, G, 3 | 4], the robot's frame order
         B, T, G = int(gp.shape[0]), int(gp.shape[1]), int(gp.shape[2])
@@ -237,7 +238,8 @@ class InverseKinematics(ToolPoseTrackingMixin):
         if G < M:
             pos = torch.cat([pos, pos[:, :, -1:].expand(B, T, M - G, 3)], 2)
             quat = torch.cat([quat, quat[:, :, -1:].expand(B, T, M - G, 4)], 2)
-        r = slv.solve_pose(pos, quat, seeds=seed_config, return_seeds=return_seeds, exit_early=self.config.exit_early)
+        cur = None if current_state is None else current_state.position.to(pos.device, torch.float32).reshape(-1, self.dof).expand(B, self.dof)
+        r = slv.solve_pose(pos, quat, seeds=seed_config, return_seeds=return_seeds, exit_early=self.config.exit_early, current_position=cur)
         torch.cuda.synchronize(pos.device) if pos.is_cuda else None
         self.solve_time = time.perf_counter() - t0
         k = return_seeds

@@ -368,3 +368,26 @@ def test_ik_fused_multi_env_equals_kernel_sequence(aligned, device):
     cz, _ = ro0.cost_and_gradient(q)
     torch.cuda.synchronize()
     assert float((cz - c0).abs().max()) > 1e-3
+
+
+def test_front_end_takes_the_robots_configuration(device):
+    """``InverseKinematics.solve_pose(current_state=)`` (reference solver_ik.py:631-700): the configuration is the first seed of the
+    seed stage and its ranking prefers solutions near it -- a goal the robot is already AT comes back as the configuration it is
+    in, where without it the solver returns whichever of the arm's solutions ranks first"""
+    from curobo_amd.solver.inverse_kinematics import InverseKinematics, InverseKinematicsCfg
+    from curobo_amd.types import JointState
+
+    n = 20
+    ik = InverseKinematics(InverseKinematicsCfg.create(robot="franka.yml", scene_model="collision_table.yml", num_seeds=8, max_batch_size=n))
+    q = ik.sample_configs(n, rejection_ratio=30)[:n].contiguous()
+    assert q.shape[0] == n
+    goal = ik.compute_kinematics(JointState.from_position(q)).tool_poses.as_goal()
+    ik.reset_seed()
+    near = ik.solve_pose(goal, current_state=JointState.from_position(q))
+    ik.reset_seed()
+    free = ik.solve_pose(goal)
+    assert bool(near.success.all()) and bool(free.success.all())
+    d_near = (near.solution[:, 0] - q).abs().max(-1).values
+    d_free = (free.solution[:, 0] - q).abs().max(-1).values
+    assert float(d_near.max()) < 2e-2, d_near
+    assert float(d_free.max()) > 0.1  # (some other branch of the arm's solutions is returned for at least one problem)
