@@ -599,12 +599,13 @@ class _PlannerBase(ToolPoseTrackingMixin):
             gq = torch.cat([gq, gq[:, :, -1:].expand(batch, T, G - g, 4)], 2)
         pad = lambda x: x if batch == n else torch.cat([x, x[:1].expand(n - batch, *x.shape[1:])], 0)  # noqa: E731
         env = torch.arange(n, device=dev, dtype=torch.int32) if c.multi_env else None
-        # (the configured exit_early: reference motion_planner.py:249-253.  The reference also hands the robot's configuration to its
-        #  IK call (``current_state=current_state``: first seed of the LM stage, which then prefers solutions near it); measured over
-        #  the random problems of tools/r05/planner_benchmark.py that changes neither the success rate nor the motion time beyond
-        #  noise (98 / 99 of 100, 2.04 / 2.02 s) and takes the LM stage off its single-graph path, so it is opt-in here)
+        # (the configured exit_early: reference motion_planner.py:249-253.  The robot's configuration goes with the goal as there
+        #  -- ``current_state=current_state`` --: it is the first seed of the LM stage, whose ranking then prefers solutions near it.
+        #  On arms whose joints turn more than a revolution (UR10e: +-2 pi) this is what keeps the goal configuration on the
+        #  robot's side of the revolution: without it a plan to the pose the robot is already AT travels up to 11 rad
+        #  (tools/r05/self_metric_diag.py); on the Franka it changes nothing measurable (tools/r05/planner_benchmark.py))
         cur = None
-        if current_state is not None and os.environ.get("CUROBO_PLANNER_IK_CURRENT", "0") != "0":
+        if current_state is not None and os.environ.get("CUROBO_PLANNER_IK_CURRENT", "1") != "0":
             cur = pad(current_state.position.to(dev, torch.float32).reshape(batch, -1))
         r = self.ik_solver.solve_pose(pad(gp), pad(gq), return_seeds=k, env_idx=env, current_position=cur)
         return r.success.reshape(n, k)[:batch], r.solution.reshape(n, k, -1)[:batch]

@@ -53,6 +53,10 @@ class IKSolverCfg:
     #: reference IKSolverCfg.override_iters_for_multi_link_ik (solver_ik_cfg.py:68, solver_ik.py:115-128): the L-BFGS iteration
     #: count is raised to this when it is lower (its benchmark sets 240 for the Unitree G1)
     override_iters_for_multi_link_ik: Optional[int] = None
+    #: with ``solve_pose(current_position=)``: the ranking cost of a solution grows by this x |q - current| (rad), so that among the
+    #: solutions that succeed the ones near the robot's configuration come first -- the reference ranks by pose error + its
+    #: ``start_cspace_dist`` convergence metric (solver_ik.py:486-500, metrics_base.yml:27-30).  Without a current position: no term.
+    start_cspace_dist_weight: float = 1.0
 
 
 @dataclass
@@ -151,6 +155,9 @@ class IKSolver:
             # its goals once (shared BEFORE anything is captured: the graphs hold these addresses)
             self.metrics_rollout.goal_position, self.metrics_rollout.goal_quat = self.seed_solver.goal_position, self.seed_solver.goal_quat
         self._gen = torch.Generator(device="cpu")
+        # the robot's configuration and the weight of its distance term in the ranking: fixed buffers (the ranking is a captured graph)
+        self._cur_buf = torch.zeros(self.P, kin.num_dof, device=self.device)
+        self._cur_w = torch.zeros(1, device=self.device)
 
     @classmethod
     def sharded(cls, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int, cfg: Optional[IKSolverCfg] = None,
@@ -210,6 +217,13 @@ class IKSolver:
         gq = goal_quat.to(self.device, torch.float32).reshape(P, T, G, 4).contiguous()
         self._set_envs(env_idx)
         self.metrics_rollout.update_goals(gp, gq, self._mrow_goal)
+        if current_position is not None:
+            self._cur_buf.copy_(current_position.to(self.device, torch.float32).reshape(P, D))
+            self._cur_w.fill_(float(self.cfg.start_cspace_dist_weight))
+            self._cur_on = True
+        elif getattr(self, "_cur_on", False):
+            self._cur_w.zero_()
+            self._cur_on = False
         optimizer_goals_set = False
 
         def set_optimizer_goals():  # (only when the L-BFGS stage runs: with exit_early the seed solutions usually suffice)
@@ -291,6 +305,8 @@ class IKSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         m = self.metrics_rollout
         cost = m.evaluate(q.view(P * S, 1, D), with_gradient=False)
+        # + weight x distance to the robot's configuration (weight 0 unless the caller gave one): ranks, does not decide success
+        cost = cost.view(P * S) + (self._cur_w * (q.view(P, S, D) - self._cur_buf.view(P, 1, D)).norm(dim=-1)).reshape(P * S)
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()) and S <= 1024 and return_seeds <= S:
