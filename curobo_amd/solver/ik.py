@@ -53,10 +53,11 @@ class IKSolverCfg:
     #: reference IKSolverCfg.override_iters_for_multi_link_ik (solver_ik_cfg.py:68, solver_ik.py:115-128): the L-BFGS iteration
     #: count is raised to this when it is lower (its benchmark sets 240 for the Unitree G1)
     override_iters_for_multi_link_ik: Optional[int] = None
-    #: with ``solve_pose(current_position=)``: the ranking cost of a solution grows by this x |q - current| (rad), so that among the
-    #: solutions that succeed the ones near the robot's configuration come first -- the reference ranks by pose error + its
-    #: ``start_cspace_dist`` convergence metric (solver_ik.py:486-500, metrics_base.yml:27-30).  Without a current position: no term.
-    start_cspace_dist_weight: float = 1.0
+    #: with ``solve_pose(current_position=)`` the solutions are ranked as the reference ranks them (solver_ik.py:463-500): by the sum
+    #: of the position [m] and rotation [rad] errors over the tool frames + this weight x 0.5 |q - current|^2 (its ``start_cspace_dist``
+    #: convergence metric, metrics_base.yml:27-30: weight 0.001), so that among the solutions that succeed the ones near the robot's
+    #: configuration come first unless they are millimetres less accurate.  Without a current position: the rollout's cost, as before.
+    start_cspace_dist_weight: float = 0.001
 
 
 @dataclass
@@ -158,6 +159,7 @@ class IKSolver:
         # the robot's configuration and the weight of its distance term in the ranking: fixed buffers (the ranking is a captured graph)
         self._cur_buf = torch.zeros(self.P, kin.num_dof, device=self.device)
         self._cur_w = torch.zeros(1, device=self.device)
+        self._cur_flag = torch.zeros(1, device=self.device)
 
     @classmethod
     def sharded(cls, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int, cfg: Optional[IKSolverCfg] = None,
@@ -220,9 +222,10 @@ class IKSolver:
         if current_position is not None:
             self._cur_buf.copy_(current_position.to(self.device, torch.float32).reshape(P, D))
             self._cur_w.fill_(float(self.cfg.start_cspace_dist_weight))
+            self._cur_flag.fill_(1.0)
             self._cur_on = True
         elif getattr(self, "_cur_on", False):
-            self._cur_w.zero_()
+            self._cur_flag.zero_()
             self._cur_on = False
         optimizer_goals_set = False
 
@@ -305,8 +308,11 @@ class IKSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         m = self.metrics_rollout
         cost = m.evaluate(q.view(P * S, 1, D), with_gradient=False)
-        # + weight x distance to the robot's configuration (weight 0 unless the caller gave one): ranks, does not decide success
-        cost = cost.view(P * S) + (self._cur_w * (q.view(P, S, D) - self._cur_buf.view(P, 1, D)).norm(dim=-1)).reshape(P * S)
+        # with the robot's configuration given (flag 1): ranked by pose errors + weight x 0.5 |q - current|^2 instead of the rollout's
+        # cost (flag 0).  Ranks, does not decide success; fixed buffers, so one captured graph serves both
+        near = (q.view(P, S, D) - self._cur_buf.view(P, 1, D)).square().sum(-1).reshape(P * S)
+        errs = m.pose_pos_dist.view(P * S, T).sum(-1) + m.pose_rot_dist.view(P * S, T).sum(-1)
+        cost = torch.lerp(cost.view(P * S), errs + 0.5 * self._cur_w * near, self._cur_flag)
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()) and S <= 1024 and return_seeds <= S:

@@ -306,7 +306,8 @@ class TrajOptSolver:
             # for the warm-up, :143-144 and :179, so that the optimiser's graph gets captured)
             K = self.K
             gp_ik, gq_ik = self._goal_sets(goal_position, goal_quat)
-            ikr = self.ik.solve_pose(gp_ik[:, 0], gq_ik[:, 0], return_seeds=K, env_idx=env_idx)
+            # (every tool frame's goal set; the start configuration goes along: goal configurations near it rank first)
+            ikr = self.ik.solve_pose(gp_ik, gq_ik, return_seeds=K, env_idx=env_idx, current_position=start.expand(P, D).contiguous())
             ik_ok = ikr.success.view(P, K)
             ik_q = ikr.solution.reshape(P, K, D).contiguous()
             choice = self.seed_goal_choice(ik_ok)  # [P, S_global]
