@@ -159,7 +159,6 @@ class IKSolver:
         # the robot's configuration and the weight of its distance term in the ranking: fixed buffers (the ranking is a captured graph)
         self._cur_buf = torch.zeros(self.P, kin.num_dof, device=self.device)
         self._cur_w = torch.zeros(1, device=self.device)
-        self._cur_flag = torch.zeros(1, device=self.device)
 
     @classmethod
     def sharded(cls, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int, cfg: Optional[IKSolverCfg] = None,
@@ -222,10 +221,8 @@ class IKSolver:
         if current_position is not None:
             self._cur_buf.copy_(current_position.to(self.device, torch.float32).reshape(P, D))
             self._cur_w.fill_(float(self.cfg.start_cspace_dist_weight))
-            self._cur_flag.fill_(1.0)
             self._cur_on = True
-        elif getattr(self, "_cur_on", False):
-            self._cur_flag.zero_()
+        else:
             self._cur_on = False
         optimizer_goals_set = False
 
@@ -279,7 +276,7 @@ class IKSolver:
 
         if not self._use_graph or (dist.is_available() and dist.is_initialized()):
             return self._get_result_eager(q, return_seeds)
-        key = (return_seeds, bool(getattr(self, "_env_mode", False)))
+        key = (return_seeds, bool(getattr(self, "_env_mode", False)), bool(getattr(self, "_cur_on", False)))
         if key not in self._result_graphs:
             q_static = torch.empty_like(q)
             q_static.copy_(q)
@@ -308,11 +305,11 @@ class IKSolver:
         P, S, D, T = self.P, self.S, self.kin.num_dof, self.kin.num_pose_links
         m = self.metrics_rollout
         cost = m.evaluate(q.view(P * S, 1, D), with_gradient=False)
-        # with the robot's configuration given (flag 1): ranked by pose errors + weight x 0.5 |q - current|^2 instead of the rollout's
-        # cost (flag 0).  Ranks, does not decide success; fixed buffers, so one captured graph serves both
-        near = (q.view(P, S, D) - self._cur_buf.view(P, 1, D)).square().sum(-1).reshape(P * S)
-        errs = m.pose_pos_dist.view(P * S, T).sum(-1) + m.pose_rot_dist.view(P * S, T).sum(-1)
-        cost = torch.lerp(cost.view(P * S), errs + 0.5 * self._cur_w * near, self._cur_flag)
+        # with the robot's configuration given: ranked by pose errors + weight x 0.5 |q - current|^2 instead of the rollout's cost.
+        # Ranks, does not decide success; the configuration lives in a fixed buffer the captured graph reads
+        if getattr(self, "_cur_on", False):  # (the captured ranking graphs are keyed by this flag: no extra launches without it)
+            near = (q.view(P, S, D) - self._cur_buf.view(P, 1, D)).square().sum(-1).reshape(P * S)
+            cost = m.pose_pos_dist.view(P * S, T).sum(-1) + m.pose_rot_dist.view(P * S, T).sum(-1) + 0.5 * self._cur_w * near
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()) and S <= 1024 and return_seeds <= S:
