@@ -130,10 +130,45 @@ class VoxelGrid(Obstacle):
     #: ESDF values, [nx * ny * nz] (x slowest) or [nx, ny, nz]
     feature_tensor: Optional[Any] = None
 
+    #: [n, 4] cell centres (x y z 0) as ``create_xyzr_tensor`` lays them out (x slowest): the order of ``feature_tensor``
+    xyzr_tensor: Optional[Any] = None
+
     def get_grid_shape(self) -> Tuple[List[int], List[float], List[float]]:
         shape = [int(round(float(x) / self.voxel_size)) for x in self.dims]
         half = [0.5 * float(x) for x in self.dims]
         return shape, [-h for h in half], half
+
+    def create_xyzr_tensor(self, transform_to_origin: bool = False, device_cfg=None):
+        """cell centres of the grid [nx * ny * nz, 4] (x slowest, r = 0) in the grid's frame, or in the world's with
+        ``transform_to_origin`` (reference ``VoxelGrid.create_xyzr_tensor``, geom/types.py:846-883: centre i of an axis of n cells
+        = (i + 1 - round(0.5 extent / voxel_size)) voxel_size - 0.5 voxel_size)"""
+        import torch
+
+        dev = device_cfg.device if device_cfg is not None else "cpu"
+        n, _, _ = self.get_grid_shape()
+        inv = 1.0 / self.voxel_size
+        axes = [(torch.linspace(1, n[a], n[a], device=dev) - round(0.5 * float(self.dims[a]) * inv)) * self.voxel_size - 0.5 * self.voxel_size
+                for a in range(3)]
+        xyz = torch.stack(torch.meshgrid(*axes, indexing="ij")).permute(1, 2, 3, 0).reshape(-1, 3)
+        if transform_to_origin:
+            xyz = torch.as_tensor(Pose7(self._need_pose()).transform(xyz.cpu().numpy()), dtype=xyz.dtype, device=xyz.device)
+        return torch.cat([xyz, torch.zeros_like(xyz[:, :1])], dim=1)
+
+    def get_occupied_voxels(self, feature_threshold: Optional[float] = None):
+        """[m, 4] centres + ESDF value of the cells whose value exceeds the threshold (default: half a voxel inside; reference :885-901)"""
+        if feature_threshold is None:
+            feature_threshold = -0.5 * self.voxel_size
+        if self.xyzr_tensor is None or self.feature_tensor is None:
+            raise ValueError("Feature tensor or xyzr tensor is empty")
+        xyzr = self.xyzr_tensor.clone()
+        xyzr[:, 3] = self.feature_tensor.reshape(-1).to(xyzr.dtype)
+        return xyzr[self.feature_tensor.reshape(-1) > feature_threshold]
+
+    def clone(self) -> "VoxelGrid":
+        c = lambda t: t.clone() if hasattr(t, "clone") else copy.deepcopy(t)  # noqa: E731
+        return VoxelGrid(name=self.name, pose=list(self.pose) if self.pose is not None else None, dims=list(self.dims), voxel_size=self.voxel_size,
+                         feature_tensor=None if self.feature_tensor is None else c(self.feature_tensor),
+                         xyzr_tensor=None if self.xyzr_tensor is None else c(self.xyzr_tensor), enable=self.enable)
 
 
 class Pose7:

@@ -92,4 +92,25 @@ if __name__ == "__main__":
             bad.append(f"features of grid {g}")
     print(f"two voxel grids (25 x 20 x 15 at 2 cm, 6 x 6 x 12 at 5 cm, rotated): {'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)}", flush=True)
     ok &= not bad
+    # the cell-centre layout the features are stored in, occupied cells, clone (geom/types.py:846-916)
+    from curobo_amd.scene.types import VoxelGrid as OurGrid
+
+    bad = []
+    for (name, v), rg in zip(cfg["voxel"].items(), grids):
+        og = OurGrid(name=name, pose=v["pose"], dims=v["dims"], voxel_size=v["voxel_size"], feature_tensor=v["feature_tensor"].clone())
+        for to_world in (False, True):
+            a, b = rg.create_xyzr_tensor(transform_to_origin=to_world, device_cfg=DeviceCfg(device="cpu")), og.create_xyzr_tensor(transform_to_origin=to_world)
+            if tuple(a.shape) != tuple(b.shape) or float((a - b).abs().max()) > 2e-6:
+                bad.append(f"{name}: cell centres (world frame: {to_world})")
+        rg.xyzr_tensor, og.xyzr_tensor = rg.create_xyzr_tensor(device_cfg=DeviceCfg(device="cpu")), og.create_xyzr_tensor()
+        rg.feature_tensor = rg.feature_tensor.view(-1)
+        for thr in (None, 0.1):
+            a, b = rg.get_occupied_voxels(thr), og.get_occupied_voxels(thr)
+            if tuple(a.shape) != tuple(b.shape) or a.shape[0] == 0 or float((a.float() - b.float()).abs().max()) > 2e-3:
+                bad.append(f"{name}: occupied cells (threshold {thr})")
+        c = og.clone()
+        if c.feature_tensor is og.feature_tensor or not torch.equal(c.feature_tensor, og.feature_tensor) or c.dims != list(og.dims):
+            bad.append(f"{name}: clone")
+    print(f"voxel grid cell centres / occupied cells / clone: {'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)}", flush=True)
+    ok &= not bad
     sys.exit(0 if ok else 1)

@@ -65,7 +65,7 @@ def test_cuboid_store_of_a_scene_description_is_the_reference_cuboid_data():
                          timeout=600, cwd=ROOT)
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
-    assert sum(": ok" in l for l in out.stdout.splitlines()) == 6, text[-3000:]
+    assert sum(": ok" in l for l in out.stdout.splitlines()) == 7, text[-3000:]
 
 
 @needs_reference
