@@ -34,6 +34,19 @@ class Obstacle:
             raise ValueError(f"{type(self).__name__} obstacle '{self.name}' requires a pose")
         return [float(x) for x in self.pose]
 
+    def get_transform_matrix(self) -> np.ndarray:
+        """the pose as a homogeneous 4 x 4 matrix (reference ``Obstacle.get_transform_matrix``, geom/types.py:160-170)"""
+        P = Pose7(self._need_pose())
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = P.R, P.t
+        return m
+
+    def get_sphere(self, n: int = 1) -> "Sphere":
+        """one sphere at the centre of the obstacle's bounding cuboid with radius = the cuboid's smallest edge, as the reference
+        builds it (``Obstacle.get_sphere``, geom/types.py:172-194: the radius is the edge, not half of it)"""
+        obb = self.get_cuboid()
+        return Sphere(name="m_sphere", pose=list(obb.pose), radius=float(min(obb.dims)))
+
 
 @dataclass
 class Cuboid(Obstacle):

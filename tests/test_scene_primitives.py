@@ -172,3 +172,20 @@ def test_primitive_world_costs_add_up(oracle):
                                     sweep=True) for k in range(4)]
     np.testing.assert_allclose(full["distance"], sum(p["distance"] for p in parts), rtol=1e-5, atol=1e-6)
     assert all((p["distance"] > 0).any() for p in parts)
+
+
+def test_obstacle_transform_matrix_and_bounding_sphere():
+    """``Obstacle.get_transform_matrix`` / ``get_sphere`` (reference geom/types.py:160-194)"""
+    from scipy.spatial.transform import Rotation
+
+    from curobo_amd.scene.types import Cuboid, Cylinder
+
+    pose = [0.1, 0.2, 0.3, 0.924, 0.0, 0.383, 0.0]
+    c = Cuboid("a", pose, dims=[0.3, 0.2, 0.1])
+    m = c.get_transform_matrix()
+    q = np.asarray(pose[3:]) / np.linalg.norm(pose[3:])
+    np.testing.assert_allclose(m[:3, :3], Rotation.from_quat(q[[1, 2, 3, 0]]).as_matrix(), atol=1e-12)
+    np.testing.assert_allclose(m[:, 3], [0.1, 0.2, 0.3, 1.0])
+    s = c.get_sphere()
+    assert s.radius == 0.1 and list(s.pose) == pose  # (the cuboid's smallest edge, as the reference takes it)
+    assert Cylinder("c", pose=[0, 0, 1, 1, 0, 0, 0], radius=0.1, height=0.5).get_sphere().radius == pytest.approx(0.2)
