@@ -188,4 +188,4 @@ def test_obstacle_transform_matrix_and_bounding_sphere():
     np.testing.assert_allclose(m[:, 3], [0.1, 0.2, 0.3, 1.0])
     s = c.get_sphere()
     assert s.radius == 0.1 and list(s.pose) == pose  # (the cuboid's smallest edge, as the reference takes it)
-    assert Cylinder("c", pose=[0, 0, 1, 1, 0, 0, 0], radius=0.1, height=0.5).get_sphere().radius == pytest.approx(0.2)
+    assert abs(Cylinder("c", pose=[0, 0, 1, 1, 0, 0, 0], radius=0.1, height=0.5).get_sphere().radius - 0.2) < 1e-12
