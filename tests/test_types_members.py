@@ -1,0 +1,119 @@
+"""Host types without the reference checkout: the members of ``JointState`` / ``ToolPose`` / ``GoalToolPose`` that the CPU harness holds to
+the reference's classes (tests/golden/compare_joint_state.py, compare_goal_tool_pose.py) checked here against their definitions, so that
+the suite covers them on a machine that has only this repository."""
+import pytest
+import torch
+
+from curobo_amd.kinematics import ToolPose
+from curobo_amd.types import DeviceCfg, GoalToolPose, JointState
+
+
+def _js(*shape, dt=None, names=True):
+    g = torch.Generator().manual_seed(sum(shape))
+    r = lambda: torch.randn(*shape, generator=g)  # noqa: E731
+    return JointState(r(), r(), r(), r(), [f"j{i}" for i in range(shape[-1])] if names else None, None if dt is None else torch.as_tensor(dt))
+
+
+def test_joint_state_constructors_and_state_tensor():
+    p = torch.randn(5, 6)
+    js = JointState.from_position(p, [f"j{i}" for i in range(6)])
+    assert torch.equal(js.position, p) and all(float(t.abs().max()) == 0 for t in (js.velocity, js.acceleration, js.jerk))
+    z = JointState.zeros((3, 6), DeviceCfg(device=torch.device("cpu")))
+    assert z.dt.shape == (3,) and float(z.dt.min()) == 1.0
+    st = torch.randn(4, 9, 24)
+    back = JointState.from_state_tensor(st, dof=6).get_state_tensor()
+    assert torch.equal(back, st)
+    a = _js(4, 9, 6)
+    assert a.stack(a).shape == (4, 18, 6) and a.cat(a, 0).shape == (8, 9, 6)
+    assert a.cat(a, -1).joint_names == a.joint_names * 2
+    assert (a.device, a.dtype, a.ndim, len(a)) == (a.position.device, torch.float32, 3, 4)
+
+
+def test_joint_state_indexing_follows_a_per_row_dt():
+    a = _js(4, 9, 6, dt=[0.1, 0.2, 0.3, 0.4])
+    assert a[2].position.shape == (9, 6) and a[2].dt.tolist() == pytest.approx([0.3])
+    assert a[torch.tensor([0, 3])].dt.tolist() == pytest.approx([0.1, 0.4])
+    assert a[1:3].dt.tolist() == pytest.approx([0.2, 0.3]) and a[[1, 2]].position.shape == (2, 9, 6)
+    b = a.clone()
+    b[torch.tensor([0, 2])] = a[torch.tensor([1, 3])]
+    assert torch.equal(b.position[0], a.position[1]) and b.dt.tolist() == pytest.approx([0.2, 0.2, 0.4, 0.4])
+
+
+def test_joint_state_time_scaling_and_finite_differences():
+    a = _js(9, 6, dt=[0.1])
+    s = a.scale_by_dt(a.dt, torch.tensor([0.2]))
+    assert torch.allclose(s.velocity, a.velocity * 0.5) and torch.allclose(s.acceleration, a.acceleration * 0.25)
+    assert torch.allclose(s.jerk, a.jerk * 0.125) and s.dt.tolist() == pytest.approx([0.2])
+    assert torch.allclose(a.scale(0.5).jerk, a.jerk * 0.125)
+    t = torch.linspace(0, 1, 11).view(1, 11, 1)
+    q = JointState.from_position(t ** 2 * torch.ones(1, 1, 3))
+    q.calculate_fd_from_position(torch.tensor([0.1]))
+    assert q.velocity.shape == (1, 10, 3) and q.acceleration.shape == (1, 9, 3) and q.jerk.shape == (1, 8, 3)
+    assert torch.allclose(q.acceleration, torch.full_like(q.acceleration, 2.0), atol=1e-3)  # d2/dt2 of t^2
+
+
+def test_joint_state_reorder_append_and_augment():
+    a = _js(4, 6)
+    order = ["j3", "j0", "j5", "j1", "j2", "j4"]
+    r = a.reorder(order)
+    assert r.joint_names == order and torch.equal(r.position[:, 0], a.position[:, 3]) and a.joint_names[0] == "j0"
+    assert a.reorder(order[:2]).position.shape == (4, 2)
+    lock = JointState.from_position(torch.tensor([0.01, 0.02]), ["gl", "gr"])
+    full = a.get_augmented_joint_state(["gr"] + order + ["gl"], lock)
+    assert full.position.shape == (4, 8) and torch.all(full.position[:, 0] == 0.02) and torch.all(full.position[:, -1] == 0.01)
+    assert float(full.velocity[:, 0].abs().max()) == 0.0
+    assert _js(3, 5, 6).append_joints(lock).position.shape == (3, 5, 8) and _js(6).append_joints(lock).position.shape == (8,)
+    with pytest.raises(ValueError):
+        a.get_augmented_joint_state(order, JointState.from_position(torch.zeros(1), ["j0"]))
+    with pytest.raises(ValueError):
+        a.reorder(["j0", "nope"])
+    assert a.index_dof(torch.tensor([4, 1])).joint_names == ["j4", "j1"]
+
+
+def test_joint_state_seed_gather_trims_and_copies():
+    a = _js(3, 5, 7, 6, dt=torch.rand(3, 5) + 0.01)
+    idx = torch.tensor([[4, 0], [1, 1], [2, 3]])
+    g = a.gather_by_seed_index(idx)
+    assert g.position.shape == (3, 2, 7, 6) and torch.equal(g.position[1, 0], a.position[1, 1]) and torch.equal(g.dt[2], a.dt[2, [2, 3]])
+    b = _js(4, 9, 6)
+    assert torch.equal(b.get_trajectory_at_horizon_index(-1).position, b.position[:, -1])
+    assert b.trim_trajectory(2, 7).position.shape == (4, 5, 6) and b.trim_trajectory(3).position.shape == (4, 6, 6)
+    src = _js(4, 9, 6)
+    c = b.clone()
+    ptr = c.position.data_ptr()
+    c.copy_(src)
+    assert c.position.data_ptr() == ptr and torch.equal(c.position, src.position)  # in place when the shapes agree
+    d = b.clone().copy_(_js(2, 6))
+    assert d.position.shape == (2, 6)
+    with pytest.raises(ValueError):
+        b.clone().copy_(_js(2, 6), allow_clone=False)
+    rs = _js(5, 6).repeat_seeds(3)
+    assert rs.position.shape == (15, 6) and torch.equal(rs.position[0], rs.position[2]) and not torch.equal(rs.position[0], rs.position[3])
+
+
+@pytest.mark.parametrize("cls,shape", [(ToolPose, (4, 3, 3)), (GoalToolPose, (4, 3, 3, 2))])
+def test_frame_pose_members(cls, shape):
+    frames = ["a", "b", "c"]
+    p, q = torch.randn(*shape, 3), torch.randn(*shape, 4)
+    x = cls(list(frames), p.clone(), q.clone())
+    n = 1
+    for s in shape[:2] + shape[3:]:
+        n *= s
+    assert x["b"].position.shape == (n, 3) and x.get_link_pose("c").name == "c" and list(x.to_dict()) == frames
+    assert x[2].position.shape == (1, *shape[1:], 3) and x[torch.tensor([0, 3])].position.shape == (2, *shape[1:], 3)
+    r = x.reorder_links(["c", "a"])
+    assert r.tool_frames == ["c", "a"] and torch.equal(r.position[:, :, 0], p[:, :, 2]) and x.reorder_links(frames) is x
+    assert len(x) == 3 and x.ndim == len(shape) + 1 and (x.batch_size, x.horizon, x.num_links) == (4, 3, 3)
+    c = x.clone()
+    c.position.zero_()
+    assert float(x.position.abs().max()) > 0 and x.detach().position.data_ptr() == x.position.data_ptr()
+    y = cls(list(frames), torch.zeros_like(p), torch.zeros_like(q))
+    y.copy_(x)
+    assert torch.equal(y.position, p) and torch.equal(y.quaternion, q)
+    with pytest.raises(ValueError):
+        x.get_link_pose("zz")
+    with pytest.raises(ValueError):
+        x.reorder_links(["a", "zz"])
+    if cls is ToolPose:
+        g = x.as_goal(["b", "a"])
+        assert isinstance(g, GoalToolPose) and g.position.shape == (4, 3, 2, 1, 3) and g.tool_frames == ["b", "a"]
