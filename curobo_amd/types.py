@@ -215,7 +215,6 @@ class JointState:
         s = dt / new_dt
         if self.velocity is not None and self.velocity.ndim in (2, 3):
             s = s.view(-1, *([1] * (self.velocity.ndim - 1)))
-        m = lambda t, k: None if t is None else t * (s ** k if k > 1 else s)  # noqa: E731
         v = None if self.velocity is None else self.velocity * s
         a = None if self.acceleration is None else self.acceleration * s * s
         j = None if self.jerk is None else self.jerk * s * s * s
