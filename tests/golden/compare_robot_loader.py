@@ -26,8 +26,24 @@ def npy(t):
     return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
 
 
+def with_attached_object_slots(name, n):
+    """the robot file with ``extra_collision_spheres: {attached_object: n}`` (what the reference's attachment tests load,
+    tests/_src/collision/test_attachment_manager.py:25-31), written next to nothing of the reference's: a temporary file"""
+    import tempfile
+
+    import yaml
+
+    with open(os.path.join(CONTENT, "configs", "robot", f"{name}.yml")) as fh:
+        d = yaml.safe_load(fh)
+    d["robot_cfg"]["kinematics"]["extra_collision_spheres"] = {"attached_object": n}
+    fd, path = tempfile.mkstemp(suffix=f"_{name}_attached_{n}.yml")
+    with os.fdopen(fd, "w") as fh:
+        yaml.safe_dump(d, fh)
+    return path
+
+
 def compare(name):
-    yml = os.path.join(CONTENT, "configs", "robot", f"{name}.yml")
+    yml = name if name.endswith(".yml") else os.path.join(CONTENT, "configs", "robot", f"{name}.yml")
     kc, sc = R.reference_kinematics(yml)
     m = load_robot_model(yml, os.path.join(CONTENT, "assets"))
     bad = []
@@ -95,4 +111,11 @@ def compare(name):
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ROBOTS
-    sys.exit(0 if all([compare(n) for n in names]) else 1)
+    results = [compare(n) for n in names]
+    if not sys.argv[1:]:  # the robot the reference's attachment tests load: Franka with 100 sphere slots on the attached-object link
+        tmp = with_attached_object_slots("franka", 100)
+        try:
+            results.append(compare(tmp))
+        finally:
+            os.remove(tmp)
+    sys.exit(0 if all(results) else 1)

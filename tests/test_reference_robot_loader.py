@@ -25,7 +25,7 @@ def test_loader_builds_the_tensors_the_reference_loader_builds():
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
     lines = [l for l in out.stdout.splitlines() if ": ok" in l]
-    assert len(lines) == 6, text[-3000:]
+    assert len(lines) == 6 + 1, text[-3000:]  # (+ the Franka with 100 attached-object sphere slots of the reference's attachment tests)
 
 
 @needs_reference
