@@ -198,8 +198,11 @@ class TrajOptSolver:
 
     def seed_knots(self, start: torch.Tensor, goal_config: torch.Tensor, choice: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[P, S_global, n_knots, D]: straight joint-space lines start -> the seed's goal configuration
-        (reference seed generation, solver_trajopt.py:390-420; linspace weights as
-        trajectory_seed_generator.py:150-170).  ``start`` [1 or P, D], ``goal_config`` [P, K, D] (or [P, D]), ``choice``
+        (reference seed generation, solver_trajopt.py:390-420).  Knot placement DIFFERS from the reference's generator
+        (util/trajectory_seed_generator.py:16-40: weights linspace(0, 1, n_knots) INCLUDING both ends, so its first free knot
+        repeats the start and its last the goal -- a line that leaves and arrives slowly); here the free knots are the interior
+        points of linspace(0, 1, n_knots + 2), evenly spaced between the boundary knots.  Both are the same straight line in joint
+        space; only seeds differ, not costs.  ``start`` [1 or P, D], ``goal_config`` [P, K, D] (or [P, D]), ``choice``
         [P, S_global] from ``seed_goal_choice``; a seed that repeats an earlier seed's goal adds a smooth
         mid-trajectory bump so that the seeds stay distinct.  Every rank builds the global set (host generator)."""
         rc, D, P, S = self.cfg.rollout, self.kin.num_dof, self.P, getattr(self, "S_global", self.S)
