@@ -49,6 +49,10 @@ class TrajOptSolverCfg:
     position_threshold: float = 0.005
     rotation_threshold: float = 0.05
     seed_bump: float = 0.15  # relative mid-trajectory perturbation of the seeds that repeat a goal configuration
+    #: where the free knots of a straight-line seed sit: "even" = interior points of linspace(0, 1, n_knots + 2) (this package's,
+    #: the default every measurement of this repository was taken with); "reference" = linspace(0, 1, n_knots) including both ends,
+    #: as util/trajectory_seed_generator.py:16-40 places them (first free knot on the start, last on the goal)
+    seed_knot_placement: str = "even"
     #: distinct IK solutions the seeds aim at (reference: every trajopt seed gets its own IK solution,
     #: solver_trajopt.py:390-420 / trajectory_seed_generator.py:122-170).  Seed s ends in solution
     #: s % num_ik_goals (the best one when that solution failed); 0 = num_seeds (the reference's
@@ -210,7 +214,12 @@ class TrajOptSolver:
         if choice is None:
             choice = torch.zeros(P, S, dtype=torch.int64, device=self.device)
         goal = torch.gather(goal_config, 1, choice.unsqueeze(-1).expand(P, S, D))  # [P, S, D]
-        t = torch.linspace(0.0, 1.0, rc.n_knots + 2, device=self.device)[1:-1].view(1, 1, -1, 1)
+        if self.cfg.seed_knot_placement == "reference":
+            t = torch.linspace(0.0, 1.0, rc.n_knots, device=self.device).view(1, 1, -1, 1)
+        elif self.cfg.seed_knot_placement == "even":
+            t = torch.linspace(0.0, 1.0, rc.n_knots + 2, device=self.device)[1:-1].view(1, 1, -1, 1)
+        else:
+            raise ValueError(f"seed_knot_placement must be 'even' or 'reference', got {self.cfg.seed_knot_placement!r}")
         line = start.reshape(-1, 1, 1, D) * (1 - t) + goal.view(P, S, 1, D) * t
         gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
         half = 0.5 * (self.kin.joint_limits_position[1] - self.kin.joint_limits_position[0])
