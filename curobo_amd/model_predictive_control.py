@@ -191,6 +191,11 @@ class ModelPredictiveControl(ToolPoseTrackingMixin):
         """knots [batch, action_horizon, action_dim] the next solve starts from (reference solver_mpc.py:498-514)"""
         self.solver.update_seed_trajectory(seed_trajectory)
 
+    def prepare_safe_deceleration_trajectory(self, current_state: JointState, failed_mask: Optional[torch.Tensor] = None,
+                                             deceleration_time: Optional[float] = None, deceleration_profile: Optional[str] = None) -> torch.Tensor:
+        """knots that bring the robots to rest from ``current_state`` (reference solver_mpc.py:701-762); see ``MPCSolver``"""
+        return self.solver.prepare_safe_deceleration_trajectory(self._batch(current_state), failed_mask, deceleration_time, deceleration_profile)
+
     def update_seed_trajectory_from_goal_state(self, goal_joint_state: JointState) -> None:
         """seed the next solve with the straight joint-space line from the current state to ``goal_joint_state`` (reference :516-531)"""
         self.solver.update_seed_trajectory_from_goal_state(self._batch(goal_joint_state))

@@ -34,6 +34,9 @@ from ..types import GoalToolPose, JointState
 @dataclass
 class MPCSolverCfg:
     optimization_dt: float = 0.02          # duration of one knot interval (reference default, solver_mpc_cfg.py:71)
+    #: ``prepare_safe_deceleration_trajectory`` (reference solver_mpc_cfg.py:81-90): deceleration seeds for a moving robot, or hold still
+    use_deceleration_on_failure: bool = True
+    deceleration_profile: str = "exponential"  # "linear" | "exponential" | "smooth"
     interpolation_steps: int = 4           # commands per knot interval: command_dt = optimization_dt / interpolation_steps
     n_knots: int = 16
     #: False (the reference): commands are the plan's SECOND knot interval and the plan is renewed every interval from the
@@ -217,6 +220,25 @@ class MPCSolver:
         goal = goal_joint_state.position.to(self.device, torch.float32).reshape(self.B, 1, D)
         t = torch.linspace(0.0, 1.0, nk + 2, device=self.device)[1:-1].view(1, -1, 1)  # (the weights of TrajOptSolver.seed_knots)
         self.update_seed_trajectory(self._current.view(self.B, 1, D) * (1 - t) + goal * t)
+
+    def prepare_safe_deceleration_trajectory(self, current_state: JointState, failed_mask: torch.Tensor,
+                                             deceleration_time: Optional[float] = None, deceleration_profile: Optional[str] = None) -> torch.Tensor:
+        """knots [batch, action_horizon, action_dim] that bring the robots to rest from ``current_state`` (position, velocity,
+        acceleration [batch, dof]): the reference's deceleration seeds (``util/deceleration.py``) when a robot moves and
+        ``cfg.use_deceleration_on_failure``, the hold-still line otherwise.  A utility, as in the reference (solver_mpc.py:701-762; its
+        control loop does not call it, :679); hand the result to ``update_seed_trajectory`` to start the next solve from it.
+        ``failed_mask`` [batch] and ``deceleration_time`` are accepted for the reference's signature: the trajectory is built for every
+        robot (the caller picks the rows), the profile always spans the action horizon."""
+        from ..util.deceleration import deceleration_knots
+
+        nk, D = self.rollout_cfg.n_knots, self.kin.num_dof
+        p = current_state.position.to(self.device, torch.float32).reshape(self.B, D)
+        v = None if current_state.velocity is None else current_state.velocity.to(self.device, torch.float32).reshape(self.B, D)
+        if not self.cfg.use_deceleration_on_failure or v is None or not bool((v.abs() > 1e-6).any()):
+            return p.view(self.B, 1, D).expand(self.B, nk, D).contiguous()
+        a = torch.zeros_like(p) if current_state.acceleration is None else current_state.acceleration.to(self.device, torch.float32).reshape(self.B, D)
+        profile = deceleration_profile or self.cfg.deceleration_profile
+        return deceleration_knots(p, v, a, float(self.cfg.optimization_dt), nk, profile)
 
     def _take_seed(self, default: torch.Tensor) -> torch.Tensor:
         seed = getattr(self, "_seed_override", None)

@@ -110,3 +110,12 @@ def test_xrdf_conversion_is_the_references():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_xrdf.py")], capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
     assert out.returncode == 0 and out.stdout.count(": ok") == 4, (out.stdout + out.stderr)[-2000:]
+
+
+@needs_reference
+def test_deceleration_seeds_are_the_references():
+    """``util/deceleration.py`` (knots that bring a moving robot to rest: the MPC's fallback seeds) against the reference's
+    ``TrajectorySeedGenerator.generate_deceleration_seeds`` on random states: three profiles + an unknown name, two time steps, resting joints"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "compare_deceleration_seeds.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.count(": ok") == 24 and "DIFFERENT" not in out.stdout, (out.stdout + out.stderr)[-2000:]

@@ -155,3 +155,34 @@ def test_seed_knot_placement_options():
         cfg.rollout.n_knots = nk
         TrajOptSolver.seed_knots(types.SimpleNamespace(cfg=cfg, kin=types.SimpleNamespace(num_dof=D, joint_limits_position=lim), P=P, S=S, S_global=S,
                                                        device=torch.device("cpu")), start, goal)
+
+
+def test_deceleration_knots_bring_the_robot_to_rest():
+    """``util/deceleration.py`` by its definition (the reference's generator is compared in tests/golden/compare_deceleration_seeds.py) and
+    ``MPCSolver.prepare_safe_deceleration_trajectory`` over a stand-in for the solver"""
+    import types
+
+    from curobo_amd.solver.mpc import MPCSolver, MPCSolverCfg
+    from curobo_amd.util.deceleration import deceleration_accelerations, deceleration_knots
+
+    p = torch.tensor([[0.0, 1.0, -1.0]])
+    v = torch.tensor([[1.0, -0.5, 0.0]])
+    a = torch.tensor([[2.0, 0.0, 3.0]])
+    for profile in ("linear", "exponential", "smooth"):
+        acc = deceleration_accelerations(v, a, 12, profile)
+        assert torch.equal(acc[0, 0], torch.tensor([2.0, 0.0, 0.0]))  # starts from the current acceleration; a resting joint gets none
+        assert bool((acc[0, 4:, 0] <= 0).all()) and bool((acc[0, 4:, 1] >= 0).all())  # then opposes the velocity
+        k = deceleration_knots(p, v, a, 0.05, 12, profile)
+        assert k.shape == (1, 12, 3) and torch.equal(k[:, 0], p) and torch.equal(k[0, :, 2], torch.full((12,), -1.0))
+        step = k[0, 1:] - k[0, :-1]
+        assert bool((step[:, 0] >= 0).all()) and bool((step[:, 1] <= 0).all())  # never reverses
+        assert float(step[-1].abs().max()) <= float(step[0].abs().max())  # slower at the end than at the start
+    cfg = MPCSolverCfg()
+    stub = types.SimpleNamespace(cfg=cfg, rollout_cfg=types.SimpleNamespace(n_knots=12), kin=types.SimpleNamespace(num_dof=3), B=1, device=torch.device("cpu"))
+    js = JointState(position=p, velocity=v, acceleration=a)
+    k = MPCSolver.prepare_safe_deceleration_trajectory(stub, js, torch.tensor([True]))
+    assert torch.equal(k, deceleration_knots(p, v, a, cfg.optimization_dt, 12, "exponential"))
+    still = MPCSolver.prepare_safe_deceleration_trajectory(stub, JointState(position=p, velocity=v * 0, acceleration=a), torch.tensor([True]))
+    assert torch.equal(still, p.view(1, 1, 3).expand(1, 12, 3))
+    cfg.use_deceleration_on_failure = False
+    assert torch.equal(MPCSolver.prepare_safe_deceleration_trajectory(stub, js, torch.tensor([True])), still)
