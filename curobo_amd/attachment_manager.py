@@ -9,8 +9,8 @@ the world obstacles back on).  Every write lands in tensors the kernels and capt
 
 Sphere fitting is NOT the reference's: its ``fit_spheres_to_mesh`` (MorphIt / voxel fits over a ``trimesh`` mesh,
 ``geom/sphere_fit/``) is an offline geometry tool outside the hot path and needs ``trimesh``; here cuboids, spheres, capsules
-and cylinders get a closed-form lattice of inscribed spheres (``fit_spheres_to_obstacle``), meshes and voxel grids the lattice of
-their bounding cuboid.  A caller with its own fit hands the [n, 4] tensor to ``update`` directly, as with the reference.
+and cylinders get a closed-form lattice of inscribed spheres (``fit_spheres_to_obstacle``; ``conservative=True``: of COVERING spheres),
+meshes and voxel grids the lattice of their bounding cuboid.  A caller with its own fit hands the [n, 4] tensor to ``update`` directly, as with the reference.
 """
 
 from __future__ import annotations
@@ -53,11 +53,28 @@ def _lattice(half: np.ndarray, radius: float, budget: Optional[int]) -> np.ndarr
     return np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3)
 
 
-def fit_spheres_to_obstacle(obstacle, num_spheres: Optional[int] = None, surface_radius: float = 0.002) -> np.ndarray:
+def _covering_lattice(half: np.ndarray, budget: Optional[int]):
+    """(centres, radius) of equal spheres whose UNION contains the box [-half, half]: the box is cut into nx x ny x nz equal cells
+    (as cubic as the budget allows; default: cells of about the smallest extent), one sphere per cell centre with the cell's half
+    diagonal as radius"""
+    ext = 2.0 * np.maximum(half, 1e-9)
+    budget = max(int(budget), 1) if budget is not None else 64
+    pitch = float(ext.min())
+    counts = lambda p: np.maximum(np.ceil(ext / p - 1e-9).astype(int), 1)  # noqa: E731
+    while int(np.prod(counts(pitch))) > budget:
+        pitch *= 1.1
+    n = counts(pitch)
+    cell = ext / n
+    axes = [(-half[a] + cell[a] * (np.arange(n[a]) + 0.5)) for a in range(3)]
+    return np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3), 0.5 * float(np.linalg.norm(cell))
+
+
+def fit_spheres_to_obstacle(obstacle, num_spheres: Optional[int] = None, surface_radius: float = 0.002, conservative: bool = False) -> np.ndarray:
     """[n, 4] spheres (x y z r) in the WORLD frame (the obstacle's pose applied, as the reference's combined mesh is built with
     ``transform_with_pose=True``) that lie inside the obstacle and touch its faces: a sphere is itself; a capsule a row of spheres of
     its radius; everything else a lattice of spheres of radius = the smallest half extent of its (bounding) cuboid, never less than
-    ``surface_radius``"""
+    ``surface_radius``.  ``conservative``: the spheres COVER the obstacle's (bounding) cuboid instead of lying inside it (they stick out by
+    less than their radius): for a grasped object that must not touch anything."""
     from .scene.types import Capsule, Pose7, Sphere
 
     if isinstance(obstacle, Sphere):
@@ -72,8 +89,11 @@ def fit_spheres_to_obstacle(obstacle, num_spheres: Optional[int] = None, surface
         local = np.concatenate([pts, np.full((n, 1), r)], axis=1)
     else:
         half = 0.5 * np.asarray(obstacle.get_cuboid().dims, np.float64)
-        r = max(float(half.min()), float(surface_radius))
-        c = _lattice(half, r, num_spheres)
+        if conservative:
+            c, r = _covering_lattice(half, num_spheres)
+        else:
+            r = max(float(half.min()), float(surface_radius))
+            c = _lattice(half, r, num_spheres)
         local = np.concatenate([c, np.full((c.shape[0], 1), r)], axis=1)
     pose = obstacle.pose if obstacle.pose is not None else [0, 0, 0, 1, 0, 0, 0]
     if not isinstance(obstacle, (Sphere, Capsule)):
@@ -107,15 +127,15 @@ class AttachmentManager:
 
     # ------------------------------------------------------------------ fit
     def fit_spheres(self, obstacles: List, num_spheres: Optional[int] = None, surface_radius: float = 0.002,
-                    sphere_fit_type=None) -> torch.Tensor:
+                    sphere_fit_type=None, conservative: bool = False) -> torch.Tensor:
         """[n, 4] spheres over all ``obstacles`` (``num_spheres`` shared between them by volume); ``sphere_fit_type`` is accepted
-        for the reference's signature and ignored (one closed-form fit here)"""
+        for the reference's signature and ignored (one closed-form fit here); ``conservative``: covering instead of inscribed spheres"""
         t0 = time.perf_counter()
         if not obstacles:
             raise ValueError("fit_spheres needs at least one obstacle")
         vol = np.array([max(float(np.prod(o.get_cuboid().dims)), 1e-12) for o in obstacles])
         share = [None] * len(obstacles) if num_spheres is None else [max(int(num_spheres * v / vol.sum()), 1) for v in vol]
-        sph = np.concatenate([fit_spheres_to_obstacle(o, n, surface_radius) for o, n in zip(obstacles, share)], axis=0)
+        sph = np.concatenate([fit_spheres_to_obstacle(o, n, surface_radius, conservative) for o, n in zip(obstacles, share)], axis=0)
         t = self._device_cfg.to_device(sph)
         self._last_fit_result = SphereFitResult(t[:, :3], t[:, 3], int(t.shape[0]), time.perf_counter() - t0)
         return t
@@ -160,9 +180,10 @@ class AttachmentManager:
 
     def attach(self, joint_states: JointState, obstacles: List, link_name: str = "attached_object", num_spheres: Optional[int] = None,
                surface_radius: float = 0.002, sphere_fit_type=None, world_objects_pose_offset: Optional[Pose] = None,
-               disable_obstacle_names: Optional[List[str]] = None) -> None:
+               disable_obstacle_names: Optional[List[str]] = None, conservative: bool = False) -> None:
         """``fit_spheres`` + ``update`` + the named world obstacles off in every environment"""
-        sph = self.fit_spheres(obstacles, num_spheres=num_spheres, surface_radius=surface_radius, sphere_fit_type=sphere_fit_type)
+        sph = self.fit_spheres(obstacles, num_spheres=num_spheres, surface_radius=surface_radius, sphere_fit_type=sphere_fit_type,
+                               conservative=conservative)
         self.update(sph, joint_states, link_name, world_objects_pose_offset)
         if disable_obstacle_names and self._scene_collision is not None:
             n = self._get_num_envs(joint_states)
@@ -174,7 +195,7 @@ class AttachmentManager:
 
     def attach_from_scene(self, joint_states: JointState, obstacle_names: List[str], link_name: str = "attached_object",
                           num_spheres: Optional[int] = None, surface_radius: float = 0.002, sphere_fit_type=None,
-                          world_objects_pose_offset: Optional[Pose] = None) -> None:
+                          world_objects_pose_offset: Optional[Pose] = None, conservative: bool = False) -> None:
         """obstacles looked up by name in the world's description (``scene_collision.scene_model``), attached and switched off"""
         if self._scene_collision is None:
             raise ValueError("attach_from_scene requires scene_collision to be set.")
@@ -190,7 +211,8 @@ class AttachmentManager:
                 raise ValueError(f"Obstacle '{name}' not found in scene_collision.scene_model.")
             obstacles.append(o)
         self.attach(joint_states, obstacles, link_name=link_name, num_spheres=num_spheres, surface_radius=surface_radius,
-                    sphere_fit_type=sphere_fit_type, world_objects_pose_offset=world_objects_pose_offset, disable_obstacle_names=obstacle_names)
+                    sphere_fit_type=sphere_fit_type, world_objects_pose_offset=world_objects_pose_offset, disable_obstacle_names=obstacle_names,
+                    conservative=conservative)
 
     def detach(self, link_name: Optional[str] = None, enable_obstacle_names: Optional[List[str]] = None) -> None:
         """the link's spheres as loaded, the obstacles the last ``attach`` switched off (or the named ones) back on"""

@@ -175,3 +175,22 @@ def test_scene_obstacles_by_name_are_in_place_edits_of_the_stores():
     assert {k: v.data_ptr() for k, v in scene.tensors.items()} == ptrs  # (captured graphs keep reading the same memory)
     with pytest.raises(ValueError):
         scene_from_config(SceneCfg(cuboid=[box, Cuboid("b2", box.pose, dims=box.dims)]), "cpu", cache={"cuboid": 1})
+
+
+def test_conservative_fit_covers_the_obstacle():
+    """``conservative=True``: every point of the (rotated) box lies in some sphere, within the budget; the default fit stays inside"""
+    from curobo_amd.scene.types import Pose7
+
+    rng = np.random.default_rng(3)
+    for dims, budget in (([0.3, 0.1, 0.02], 12), ([0.05, 0.05, 0.05], 4), ([0.2, 0.15, 0.1], None), ([0.4, 0.02, 0.02], 3)):
+        box = Cuboid("b", [0.1, -0.2, 0.3, 0.924, 0.0, 0.383, 0.0], dims=dims)
+        s = fit_spheres_to_obstacle(box, budget, conservative=True)
+        assert budget is None or s.shape[0] <= budget
+        P = Pose7(box.pose)
+        pts = P.transform(rng.uniform(-0.5, 0.5, (4000, 3)) * np.asarray(dims))
+        corners = P.transform(0.5 * np.asarray(dims) * np.array([[i, j, k] for i in (-1, 1) for j in (-1, 1) for k in (-1, 1)]))
+        for q in (pts, corners):
+            d = np.linalg.norm(q[:, None, :] - s[None, :, :3], axis=-1) - s[None, :, 3]
+            assert d.min(axis=1).max() <= 1e-6
+    m_in = fit_spheres_to_obstacle(Cuboid("b", [0, 0, 0, 1, 0, 0, 0], dims=[0.3, 0.1, 0.02]), 12)
+    assert (np.abs(m_in[:, :3]) + m_in[:, 3:4] <= 0.5 * np.array([0.3, 0.1, 0.02]) + 1e-6).all()
