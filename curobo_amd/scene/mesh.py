@@ -36,8 +36,44 @@ def load_obj(path: str):
     return np.asarray(v, np.float32), np.asarray(f, np.int32)
 
 
+def _weld(tri: np.ndarray):
+    """[F, 3, 3] triangle corners -> (vertices [V, 3], faces [F, 3]) with identical corners shared (STL stores every corner per triangle)"""
+    v, inverse = np.unique(tri.reshape(-1, 3), axis=0, return_inverse=True)
+    return v.astype(np.float32), inverse.reshape(-1, 3).astype(np.int32)
+
+
+def load_stl(path: str):
+    """(vertices [V, 3], faces [F, 3]) of an STL file, binary (80-byte header, uint32 count, 50-byte records) or ASCII (``vertex x y z``
+    lines); corners that coincide exactly are welded, degenerate triangles dropped"""
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    n = int(np.frombuffer(raw[80:84], "<u4")[0]) if len(raw) >= 84 else -1
+    if n >= 0 and len(raw) == 84 + 50 * n:  # the binary layout is decided by the size, not by a header that may start with "solid"
+        rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+        tri = rec["v"].astype(np.float32)
+    else:
+        pts = [[float(x) for x in line.split()[1:4]] for line in raw.decode("ascii", "ignore").splitlines() if line.strip().startswith("vertex")]
+        if not pts or len(pts) % 3:
+            raise ValueError(f"{path}: not an STL file this loader reads ({len(pts)} vertex records)")
+        tri = np.asarray(pts, np.float32).reshape(-1, 3, 3)
+    v, f = _weld(tri)
+    keep = (f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])
+    return v, f[keep]
+
+
+def load_mesh_file(path: str):
+    """(vertices, faces) of a mesh file by its extension: Wavefront OBJ or STL (the formats of the reference's robot and scene assets that
+    need no third-party reader; it reads everything through ``trimesh``)"""
+    ext = path.lower().rsplit(".", 1)[-1]
+    if ext == "obj":
+        return load_obj(path)
+    if ext == "stl":
+        return load_stl(path)
+    raise ValueError(f"{path}: mesh files are read as .obj or .stl (give ``vertices`` and ``faces`` for anything else)")
+
+
 class MeshStore:
-    """``envs[e]`` = list of ``{"name": str, "vertices": [V, 3], "faces": [F, 3] (or "file_path": *.obj), "pose": [x, y, z,
+    """``envs[e]`` = list of ``{"name": str, "vertices": [V, 3], "faces": [F, 3] (or "file_path": *.obj / *.stl), "pose": [x, y, z,
     qw, qx, qy, qz], "scale": [sx, sy, sz] (optional), "enable": bool}``; meshes that share a name share one BVH."""
 
     #: 0 = the local gradient as the reference's mesh query returns it (data_mesh.py:693-697: away from the surface for a centre
@@ -66,7 +102,7 @@ class MeshStore:
                     if "vertices" in o:
                         v, f = np.asarray(o["vertices"], np.float32), np.asarray(o["faces"], np.int32)
                     else:
-                        v, f = load_obj(o["file_path"])
+                        v, f = load_mesh_file(o["file_path"])
                     if o.get("scale") is not None:
                         v = v * np.asarray(o["scale"], np.float32).reshape(1, 3)
                     self.cache[key] = len(self.meshes)

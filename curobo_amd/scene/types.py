@@ -105,7 +105,7 @@ class Sphere(Obstacle):
 
 @dataclass
 class Mesh(Obstacle):
-    #: Wavefront OBJ file (``scene.mesh.load_obj``), or ``vertices`` [V, 3] + ``faces`` [F, 3]
+    #: Wavefront OBJ or STL file (``scene.mesh.load_mesh_file``), or ``vertices`` [V, 3] + ``faces`` [F, 3]
     file_path: Optional[str] = None
     vertices: Optional[Any] = None
     faces: Optional[Any] = None
@@ -118,9 +118,9 @@ class Mesh(Obstacle):
     def get_mesh_data(self) -> Tuple[np.ndarray, np.ndarray]:
         if self.vertices is not None:
             return np.asarray(self.vertices, np.float32), np.asarray(self.faces, np.int32).reshape(-1, 3)
-        from .mesh import load_obj
+        from .mesh import load_mesh_file
 
-        v, f = load_obj(self.file_path)
+        v, f = load_mesh_file(self.file_path)
         if self.scale is not None:
             v = v * np.ravel(np.asarray(self.scale, np.float32))
         return v, f

@@ -3,6 +3,7 @@ closed-form field of the same solid, primitives obey their defining properties, 
 reproduces the field within the grid's interpolation error through the oracle's voxel lookup."""
 
 import numpy as np
+from pytest import raises as pytest_raises
 
 from curobo_amd.scene import bake_esdf, box_mesh, capsule_sdf, cuboid_sdf, cylinder_sdf, mesh_sdf, sphere_sdf, union_sdf
 
@@ -189,3 +190,44 @@ def test_obstacle_transform_matrix_and_bounding_sphere():
     s = c.get_sphere()
     assert s.radius == 0.1 and list(s.pose) == pose  # (the cuboid's smallest edge, as the reference takes it)
     assert abs(Cylinder("c", pose=[0, 0, 1, 1, 0, 0, 0], radius=0.1, height=0.5).get_sphere().radius - 0.2) < 1e-12
+
+
+def test_stl_files_binary_and_ascii(tmp_path):
+    """``scene.mesh.load_stl`` / ``load_mesh_file``: a cube written as binary STL (with a header that starts with "solid") and as ASCII STL
+    reads back as 8 welded vertices and 12 faces with the volume of the cube; the reference's own STL assets load when they are here"""
+    import os
+    import struct
+
+    from curobo_amd.scene.mesh import load_mesh_file, load_stl
+    from curobo_amd.scene.types import Mesh
+
+    c = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32) * 0.2
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = np.array([t for q in quads for t in ([c[q[0]], c[q[1]], c[q[2]]], [c[q[0]], c[q[2]], c[q[3]]])], np.float32)
+    binary = tmp_path / "cube.stl"
+    with open(binary, "wb") as fh:
+        fh.write(b"solid binary files may begin like this".ljust(80, b" "))
+        fh.write(struct.pack("<I", len(tris)))
+        for t in tris:
+            fh.write(struct.pack("<12fH", 0, 0, 0, *t.reshape(-1), 0))
+    ascii_ = tmp_path / "cube_ascii.STL"
+    with open(ascii_, "w") as fh:
+        fh.write("solid cube\n")
+        for t in tris:
+            fh.write(" facet normal 0 0 0\n  outer loop\n" + "".join(f"   vertex {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}\n" for p in t) + "  endloop\n endfacet\n")
+        fh.write("endsolid cube\n")
+    for path in (binary, ascii_):
+        v, f = load_mesh_file(str(path))
+        assert v.shape == (8, 3) and f.shape == (12, 3)
+        a, b, d = v[f[:, 0]].astype(np.float64), v[f[:, 1]].astype(np.float64), v[f[:, 2]].astype(np.float64)
+        assert abs(abs(np.einsum("ij,ij->i", a, np.cross(b, d)).sum() / 6.0) - 0.2 ** 3) < 1e-9  # (divergence theorem: consistent winding)
+    mv, mf = Mesh(name="m", pose=[0, 0, 0, 1, 0, 0, 0], file_path=str(binary)).get_mesh_data()
+    assert len(mv) == 8 and len(mf) == 12
+    with pytest_raises(ValueError):
+        load_mesh_file(str(tmp_path / "thing.dae"))
+    ref = "/root/reference/curobo/content/assets/robot"
+    if os.path.isdir(ref):
+        found = [os.path.join(d, n) for d, _, names in os.walk(ref) for n in names if n.lower().endswith(".stl")][:5]
+        for p in found:
+            v, f = load_stl(p)
+            assert v.shape[0] >= 4 and f.shape[0] >= 4 and int(f.max()) < v.shape[0]
