@@ -33,6 +33,47 @@ class InverseKinematicsResult:
     goalset_index: Optional[torch.Tensor] = None
     solve_time: float = 0.0
     debug_info: Optional[dict] = None
+    total_time: float = 0.0
+    position_tolerance: float = 0.0
+    orientation_tolerance: float = 0.0
+    batch_size: int = 0
+    num_seeds: int = 0
+
+    _TENSORS = ("success", "solution", "position_error", "rotation_error", "goalset_index")
+
+    def clone(self) -> "InverseKinematicsResult":
+        """deep copy (reference BaseSolverResult.clone, solver_base_result.py:81-131)"""
+        import dataclasses
+
+        c = lambda t: None if t is None else t.clone()  # noqa: E731
+        dbg = None if self.debug_info is None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.debug_info.items()}
+        return dataclasses.replace(self, **{f: c(getattr(self, f)) for f in self._TENSORS}, js_solution=c(self.js_solution), debug_info=dbg)
+
+    def copy_successful_solutions(self, other: "InverseKinematicsResult") -> None:
+        """every (problem, seed) entry that succeeded in ``other`` replaces the entry here, in place (reference :133-210: merging the
+        results of several attempts)"""
+        if self.success is None or other.success is None:
+            raise ValueError("success is not set")
+        b, k = other.success.nonzero(as_tuple=True)
+        for f in self._TENSORS:
+            dst, src = getattr(self, f), getattr(other, f)
+            if dst is not None and src is not None:
+                dst[b, k] = src[b, k]
+        if self.js_solution is not None and other.js_solution is not None:
+            self.js_solution.copy_at_batch_seed_indices(other.js_solution, b, k)
+
+    def copy_at_batch_indices(self, other: "InverseKinematicsResult", mask: torch.Tensor) -> None:
+        """whole problems (all their seeds) selected by ``mask`` [batch] taken from ``other``, in place (reference :212-240:
+        first-success-wins merging in batched planning)"""
+        for f in self._TENSORS:
+            dst, src = getattr(self, f), getattr(other, f)
+            if dst is not None and src is not None and dst.shape == src.shape:
+                dst[mask] = src[mask]
+        if self.js_solution is not None and other.js_solution is not None:
+            for f in ("position", "velocity", "acceleration", "jerk"):
+                dst, src = getattr(self.js_solution, f), getattr(other.js_solution, f)
+                if dst is not None and src is not None and dst.shape == src.shape:
+                    dst[mask] = src[mask]
 
     def get_unique_solution(self, roundoff_decimals: int = 2) -> torch.Tensor:
         """the successful solutions, one representative per configuration after rounding to ``roundoff_decimals`` (reference
@@ -248,4 +289,6 @@ class InverseKinematics(ToolPoseTrackingMixin):
             success=r.success.reshape(B, k), solution=sol, js_solution=JointState.from_position(sol, joint_names=self.joint_names),
             position_error=r.position_error.reshape(B, k), rotation_error=r.rotation_error.reshape(B, k),
             goalset_index=None if r.goalset_index is None else r.goalset_index.reshape(B, k, T), solve_time=self.solve_time,
-            debug_info={"optimizer_ran": bool(getattr(slv, "optimizer_ran", True))})
+            debug_info={"optimizer_ran": bool(getattr(slv, "optimizer_ran", True))}, total_time=self.solve_time,
+            position_tolerance=self.config.position_tolerance, orientation_tolerance=self.config.orientation_tolerance, batch_size=B,
+            num_seeds=self.config.num_seeds)

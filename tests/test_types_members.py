@@ -186,3 +186,31 @@ def test_deceleration_knots_bring_the_robot_to_rest():
     assert torch.equal(still, p.view(1, 1, 3).expand(1, 12, 3))
     cfg.use_deceleration_on_failure = False
     assert torch.equal(MPCSolver.prepare_safe_deceleration_trajectory(stub, js, torch.tensor([True])), still)
+
+
+def test_ik_result_clone_and_merges():
+    """``InverseKinematicsResult.clone / copy_successful_solutions / copy_at_batch_indices`` (reference solver_base_result.py:81-240)"""
+    from curobo_amd.solver.inverse_kinematics import InverseKinematicsResult
+
+    def result(seed, success):
+        g = torch.Generator().manual_seed(seed)
+        sol = torch.randn(3, 2, 7, generator=g)
+        return InverseKinematicsResult(success=torch.tensor(success), solution=sol, js_solution=JointState.from_position(sol.clone()),
+                                       position_error=torch.rand(3, 2, generator=g), rotation_error=torch.rand(3, 2, generator=g),
+                                       goalset_index=torch.zeros(3, 2, 1, dtype=torch.long), debug_info={"t": torch.ones(1), "n": 3}, batch_size=3, num_seeds=2)
+
+    a = result(1, [[True, False], [False, False], [False, True]])
+    b = result(2, [[False, True], [True, False], [False, True]])
+    c = a.clone()
+    c.solution.zero_(), c.debug_info["t"].zero_()
+    assert float(a.solution.abs().max()) > 0 and float(a.debug_info["t"]) == 1.0 and c.batch_size == 3
+    m = a.clone()
+    m.copy_successful_solutions(b)
+    assert m.success.tolist() == [[True, True], [True, False], [False, True]]
+    assert torch.equal(m.solution[0, 1], b.solution[0, 1]) and torch.equal(m.solution[0, 0], a.solution[0, 0])
+    assert torch.equal(m.solution[2, 1], b.solution[2, 1]) and torch.equal(m.js_solution.position[1, 0], b.solution[1, 0])
+    assert float(m.position_error[1, 0]) == float(b.position_error[1, 0]) and float(m.position_error[1, 1]) == float(a.position_error[1, 1])
+    w = a.clone()
+    w.copy_at_batch_indices(b, torch.tensor([False, True, False]))
+    assert torch.equal(w.solution[1], b.solution[1]) and torch.equal(w.solution[0], a.solution[0]) and w.success[1].tolist() == [True, False]
+    assert torch.equal(w.js_solution.position[1], b.solution[1])
