@@ -34,9 +34,6 @@ from ..types import GoalToolPose, JointState
 @dataclass
 class MPCSolverCfg:
     optimization_dt: float = 0.02          # duration of one knot interval (reference default, solver_mpc_cfg.py:71)
-    #: ``prepare_safe_deceleration_trajectory`` (reference solver_mpc_cfg.py:81-90): deceleration seeds for a moving robot, or hold still
-    use_deceleration_on_failure: bool = True
-    deceleration_profile: str = "exponential"  # "linear" | "exponential" | "smooth"
     interpolation_steps: int = 4           # commands per knot interval: command_dt = optimization_dt / interpolation_steps
     n_knots: int = 16
     #: False (the reference): commands are the plan's SECOND knot interval and the plan is renewed every interval from the
@@ -59,6 +56,9 @@ class MPCSolverCfg:
     goal_ik_seeds: int = 16
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=15, inner_iters=25))
     use_cuda_graph: bool = True
+    #: ``prepare_safe_deceleration_trajectory`` (reference solver_mpc_cfg.py:81-90): deceleration seeds for a moving robot, or hold still
+    use_deceleration_on_failure: bool = True
+    deceleration_profile: str = "exponential"  # "linear" | "exponential" | "smooth"
 
 
 @dataclass

@@ -49,10 +49,6 @@ class TrajOptSolverCfg:
     position_threshold: float = 0.005
     rotation_threshold: float = 0.05
     seed_bump: float = 0.15  # relative mid-trajectory perturbation of the seeds that repeat a goal configuration
-    #: where the free knots of a straight-line seed sit: "even" = interior points of linspace(0, 1, n_knots + 2) (this package's,
-    #: the default every measurement of this repository was taken with); "reference" = linspace(0, 1, n_knots) including both ends,
-    #: as util/trajectory_seed_generator.py:16-40 places them (first free knot on the start, last on the goal)
-    seed_knot_placement: str = "even"
     #: distinct IK solutions the seeds aim at (reference: every trajopt seed gets its own IK solution,
     #: solver_trajopt.py:390-420 / trajectory_seed_generator.py:122-170).  Seed s ends in solution
     #: s % num_ik_goals (the best one when that solution failed); 0 = num_seeds (the reference's
@@ -77,6 +73,10 @@ class TrajOptSolverCfg:
     #: success also needs the trajectory re-sampled at ``interpolation_dt`` to stay inside the position / velocity /
     #: acceleration / jerk limits and free of self and scene collision (reference interpolated_rollout, :475-497)
     check_interpolated: bool = True
+    #: where the free knots of a straight-line seed sit: "even" = interior points of linspace(0, 1, n_knots + 2) (this package's,
+    #: the default every measurement of this repository was taken with); "reference" = linspace(0, 1, n_knots) including both ends,
+    #: as util/trajectory_seed_generator.py:16-40 places them (first free knot on the start, last on the goal)
+    seed_knot_placement: str = "even"
 
 
 @dataclass
