@@ -60,6 +60,23 @@ class MPCSolverCfg:
     use_deceleration_on_failure: bool = True
     deceleration_profile: str = "exponential"  # "linear" | "exponential" | "smooth"
 
+    @staticmethod
+    def reference_task(**overrides) -> "MPCSolverCfg":
+        """The cost weights and optimiser settings of the reference's MPC task file, content/configs/task/mpc/lbfgs_mpc.yml, instead of
+        this package's defaults above (which were tuned on this package's own closed-loop tests: lower pose weights, stronger joint-state
+        bounds, retimed weights, 15-deep history, 100 / 25 iterations).  The values are held to the file by
+        ``tests/test_types_members.py::test_mpc_reference_task_is_the_reference_file``; the closed-loop behaviour with them has not been
+        measured on the GPU."""
+        rollout = TrajOptRolloutCfg(
+            non_terminal_pose_factor=1.0, pose_weight=[5000.0, 200.0], pose_convergence_tolerance=[0.0, 0.0],
+            cspace_weight=[1000.0, 1000.0, 1000.0, 100.0, 0.0], cspace_activation_distance=[0.01] * 5,
+            cspace_regularization=[0.01, 10000.0, 10.0, 0.0, 0.0], retime_weights=False, retime_regularization_weights=True,
+            cspace_target_weight=1000.0, cspace_non_terminal_weight_factor=0.05,
+            scene_activation_distance=0.01, scene_collision_weight=10000.0, use_sweep=True, use_speed_metric=True, self_collision_weight=100000.0)
+        optimizer = LBFGSOptCfg(history=27, inner_iters=25, num_iters=50, cost_relative_threshold=1.0, line_search_c_1=1e-3, line_search_c_2=0.98,
+                                epsilon=0.01, step_scale=0.98, line_search_scale=[0.0, 0.1, 0.5, 1.0])
+        return MPCSolverCfg(**{**dict(rollout=rollout, optimizer=optimizer), **overrides})
+
 
 @dataclass
 class MPCSolverResult:

@@ -214,3 +214,40 @@ def test_ik_result_clone_and_merges():
     w.copy_at_batch_indices(b, torch.tensor([False, True, False]))
     assert torch.equal(w.solution[1], b.solution[1]) and torch.equal(w.solution[0], a.solution[0]) and w.success[1].tolist() == [True, False]
     assert torch.equal(w.js_solution.position[1], b.solution[1])
+
+
+def test_mpc_reference_task_is_the_reference_file():
+    """``MPCSolverCfg.reference_task()`` against content/configs/task/mpc/lbfgs_mpc.yml, value by value (this package's own MPC defaults differ
+    from that file on purpose; the option carries the file's)"""
+    import os
+
+    import yaml
+
+    from curobo_amd.solver.mpc import MPCSolverCfg
+
+    c = MPCSolverCfg.reference_task(goal_ik_seeds=8)
+    assert c.goal_ik_seeds == 8 and c.rollout.non_terminal_pose_factor == 1.0
+    path = "/root/reference/curobo/content/configs/task/mpc/lbfgs_mpc.yml"
+    if not os.path.exists(path):
+        pytest.skip("needs the reference checkout")
+    with open(path) as fh:
+        y = yaml.safe_load(fh)
+    cost, con, opt = y["rollout"]["cost_cfg"], y["rollout"]["constraint_cfg"], y["optimizer"]
+    r, o = c.rollout, c.optimizer
+    cs = cost["cspace_cfg"]
+    assert [float(v) for v in cs["weight"]] == r.cspace_weight and [float(v) for v in cs["activation_distance"]] == r.cspace_activation_distance
+    assert [float(v) for v in cs["squared_l2_regularization_weight"]] == r.cspace_regularization
+    assert (cs["retime_weights"], cs["retime_regularization_weights"]) == (r.retime_weights, r.retime_regularization_weights)
+    assert (float(cs["cspace_target_weight"]), float(cs["cspace_non_terminal_weight_factor"])) == (r.cspace_target_weight, r.cspace_non_terminal_weight_factor)
+    tp = cost["tool_pose_cfg"]
+    assert [float(v) for v in tp["weight"]] == r.pose_weight and [float(v) for v in tp["_terminal_pose_convergence_tolerance"]] == r.pose_convergence_tolerance
+    assert tp["use_lie_group"] is False and r.rotation_method == 0
+    sc = con["scene_collision_cfg"]
+    assert (float(sc["activation_distance"]), float(sc["weight"]), sc["use_sweep"], sc["use_speed_metric"]) == \
+        (r.scene_activation_distance, r.scene_collision_weight, r.use_sweep, r.use_speed_metric)
+    assert float(con["self_collision_cfg"]["weight"]) == r.self_collision_weight
+    assert (opt["history"], opt["inner_iters"], opt["num_iters"]) == (o.history, o.inner_iters, o.num_iters)
+    assert [float(v) for v in opt["line_search_scale"]] == o.line_search_scale and opt["line_search_type"] == o.line_search_type
+    assert (float(opt["line_search_wolfe_c_1"]), float(opt["line_search_wolfe_c_2"])) == (o.line_search_c_1, o.line_search_c_2)
+    assert (float(opt["cost_relative_threshold"]), float(opt["epsilon"]), float(opt["step_scale"]), opt["stable_mode"], opt["fixed_iters"]) == \
+        (o.cost_relative_threshold, o.epsilon, o.step_scale, o.stable_mode, o.fixed_iters)
