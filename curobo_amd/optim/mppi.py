@@ -51,6 +51,24 @@ class MPPICfg:
     fixed_samples: bool = True      # one noise set for every iteration (else num_iters sets, cycled)
     sample_per_problem: bool = True  # every problem its own particles (else one set repeated over the problems)
 
+    @staticmethod
+    def reference_task(task: str, **overrides) -> "MPPICfg":
+        """the optimiser block of the reference's particle stage files: ``task`` = "ik" (content/configs/task/ik/particle_ik.yml: 4
+        iterations of 25 Halton particles, BEST) or "trajopt" (task/trajopt/particle_trajopt.yml: 3 iterations of 25 STOMP particles,
+        BEST) -- the short particle stage the reference can put in front of its L-BFGS stage (``MultiStageOptimizer``).  Held to the
+        files by ``tests/test_types_members.py::test_mppi_reference_tasks_are_the_reference_files``."""
+        if task == "ik":
+            base = dict(gamma=1.0, init_cov=1.0, kappa=0.01, beta=1.0, step_size_cov=0.2, step_size_mean=0.9, num_iters=4, inner_iters=4,
+                        null_act_frac=0.0, num_particles=25, sample_mode="BEST", filter_coeffs=(0.0, 0.0, 1.0), fixed_samples=True,
+                        sample_ratio={"halton": 1.0}, sample_per_problem=True, seed=0, update_cov=True)
+        elif task == "trajopt":
+            base = dict(gamma=1.0, init_cov=0.5, kappa=0.001, beta=0.01, step_size_cov=0.1, step_size_mean=0.98, num_iters=3, inner_iters=3,
+                        null_act_frac=0.0, num_particles=25, sample_mode="BEST", filter_coeffs=(0.3, 0.3, 0.4), fixed_samples=True,
+                        sample_ratio={"stomp": 1.0}, sample_per_problem=True, seed=0, update_cov=True)
+        else:
+            raise ValueError(f"task must be 'ik' or 'trajopt', got {task!r}")
+        return MPPICfg(**{**base, **overrides})
+
 
 class MPPI:
     """``optimize(seed[num_problems, action_horizon, action_dim])`` -> action of the fitted distribution.

@@ -251,3 +251,31 @@ def test_mpc_reference_task_is_the_reference_file():
     assert (float(opt["line_search_wolfe_c_1"]), float(opt["line_search_wolfe_c_2"])) == (o.line_search_c_1, o.line_search_c_2)
     assert (float(opt["cost_relative_threshold"]), float(opt["epsilon"]), float(opt["step_scale"]), opt["stable_mode"], opt["fixed_iters"]) == \
         (o.cost_relative_threshold, o.epsilon, o.step_scale, o.stable_mode, o.fixed_iters)
+
+
+@pytest.mark.parametrize("task,path", [("ik", "ik/particle_ik.yml"), ("trajopt", "trajopt/particle_trajopt.yml")])
+def test_mppi_reference_tasks_are_the_reference_files(task, path):
+    """``MPPICfg.reference_task`` against the optimiser block of the reference's particle-stage task files, value by value"""
+    import os
+
+    import yaml
+
+    from curobo_amd.optim.mppi import MPPICfg
+
+    c = MPPICfg.reference_task(task, num_problems=3)
+    assert c.num_problems == 3
+    with pytest.raises(ValueError):
+        MPPICfg.reference_task("mpc")
+    full = os.path.join("/root/reference/curobo/content/configs/task", path)
+    if not os.path.exists(full):
+        pytest.skip("needs the reference checkout")
+    with open(full) as fh:
+        o = yaml.safe_load(fh)["optimizer"]
+    for k in ("gamma", "init_cov", "kappa", "beta", "step_size_cov", "step_size_mean", "null_act_frac"):
+        assert float(o[k]) == getattr(c, k), k
+    for k in ("num_iters", "inner_iters", "num_particles", "sample_per_problem", "seed", "update_cov"):
+        assert o[k] == getattr(c, k), k
+    assert o["sample_mode"] == c.sample_mode and o["solver_type"] == "mppi"
+    sp = o["sample_params"]
+    assert tuple(float(v) for v in sp["filter_coeffs"]) == c.filter_coeffs and sp["fixed_samples"] == c.fixed_samples
+    assert {k: float(v) for k, v in sp["sample_ratio"].items() if float(v) > 0} == c.sample_ratio
