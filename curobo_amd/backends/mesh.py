@@ -89,6 +89,34 @@ def feature_pseudonormals(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray
     return out
 
 
+#: how the sign of a mesh query is decided (``curobo_hip_mesh.sign_rule``)
+SIGN_CLOSEST_FEATURE, SIGN_WARP_RAYS = 0, 1
+
+
+def _weld_ids(vertices: np.ndarray) -> np.ndarray:
+    v = np.asarray(vertices, np.float64)
+    span = float(np.ptp(v, axis=0).max()) or 1.0
+    key = np.round((v - v.min(0)) / (span * 1e-7)).astype(np.int64)
+    _, weld = np.unique(key, axis=0, return_inverse=True)
+    return weld.reshape(-1)
+
+
+def mesh_is_closed_and_oriented(vertices: np.ndarray, faces: np.ndarray) -> bool:
+    """True when, over vertices welded by position, every directed edge occurs exactly once and its reverse exactly once: a closed
+    2-manifold whose faces all wind the same way.  On such a surface the reference's sign -- Warp's ``mesh_query_point``: rays along
+    +x, +y, +z, inside iff every ray's nearest hit is a back face (warp/native/mesh.h ``mesh_query_inside``) -- is the same function
+    of the query point as the closest-feature pseudonormal sign the kernels evaluate without a ray; on anything else (an open
+    scan, a flipped face, a T-junction) the two differ and the kernels cast Warp's three rays (``SIGN_WARP_RAYS``)."""
+    f = _weld_ids(vertices)[np.asarray(faces, np.int64)]
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    if (e[:, 0] == e[:, 1]).any():
+        return False
+    key = e[:, 0] * (int(f.max()) + 1) + e[:, 1]
+    rkey = e[:, 1] * (int(f.max()) + 1) + e[:, 0]
+    uk, cnt = np.unique(key, return_counts=True)
+    return bool((cnt == 1).all() and np.isin(rkey, uk).all())
+
+
 def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8) -> DeviceMesh:
     """vertices [V, 3] (mesh frame), faces [F, 3] -> the linear BVH on ``device``: Morton keys of the centroids (HIP), the
     sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level)"""

@@ -81,12 +81,6 @@ class TrajOptRolloutCfg:
     cspace_weight: List[float] = field(default_factory=lambda: [10000.0, 10000.0, 100.0, 50.0, 100.0])
     cspace_activation_distance: List[float] = field(default_factory=lambda: [0.01] * 5)
     cspace_regularization: List[float] = field(default_factory=lambda: [1000.0, 10000.0, 5.0, 0.0, 10000.0])
-    #: joint-position tracking of the c-space STATE cost (wp_cspace_state.py:205-225): weight of |q - target|^2 at the last point,
-    #: times ``cspace_non_terminal_weight_factor`` at the points before it.  0 = off (the trajopt task, lbfgs_bspline_trajopt.yml:72);
-    #: the MPC task tracks an IK solution of its pose goal with 1000 / 0.05 (lbfgs_mpc.yml:28-29).  The target itself comes through
-    #: ``TrajOptRollout.update_cspace_target``; ``enable_cspace_target`` / ``disable_cspace_target`` switch the term at run time.
-    cspace_target_weight: float = 0.0
-    cspace_non_terminal_weight_factor: float = 1.0
     retime_weights: bool = True
     retime_regularization_weights: bool = True
     #: one value for every joint or one per active joint [dof] (reference JointLimits.acceleration / .jerk: per joint,
@@ -110,10 +104,17 @@ class TrajOptRolloutCfg:
     gravity: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 0.0, 0.0, 9.81])  # spatial base acceleration
     #: one fused launch (csrc/rollout_fused.hip with the trajopt terms) when a trajectory fits in LDS
     use_fused: bool = True
+    longest_first_dispatch: bool = True  # see CollisionRolloutCfg
+    # (fields added after round 4 stay at the END: positional construction keeps its meaning)
     #: compile a compile-time shape of the fused launch for this robot / horizon at first use when the library holds none
     #: (``backends/fused_jit.py``; also CUROBO_HIP_JIT_SHAPES=1): see CollisionRolloutCfg.jit_shape
     jit_shape: bool = False
-    longest_first_dispatch: bool = True  # see CollisionRolloutCfg
+    #: joint-position tracking of the c-space STATE cost (wp_cspace_state.py:205-225): weight of |q - target|^2 at the last point,
+    #: times ``cspace_non_terminal_weight_factor`` at the points before it.  0 = off (the trajopt task, lbfgs_bspline_trajopt.yml:72);
+    #: the MPC task tracks an IK solution of its pose goal with 1000 / 0.05 (lbfgs_mpc.yml:28-29).  The target itself comes through
+    #: ``TrajOptRollout.update_cspace_target``; ``enable_cspace_target`` / ``disable_cspace_target`` switch the term at run time.
+    cspace_target_weight: float = 0.0
+    cspace_non_terminal_weight_factor: float = 1.0
 
     @property
     def horizon(self) -> int:

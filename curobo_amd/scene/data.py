@@ -233,17 +233,29 @@ class SceneData:
         self.arrays.setdefault("cuboid_names", [[None] * cap for _ in range(self.num_envs)])[env_idx][n] = obstacle.get("name")
         return n
 
-    def clear(self) -> None:
-        """Switch every cuboid / voxel-grid / mesh slot off, in place (the kernels read the same enable tensors): an empty
-        world of the same capacity (reference SceneCollision.clear_cache, geom/collision/collision_scene.py: the stores'
-        ``clear`` zeroes their enable flags and counts)."""
-        for k in ("cuboid_enable", "voxel_enable"):
-            if self.tensors.get(k) is not None:
-                self.tensors[k].zero_()
-                if isinstance(self.arrays.get(k), np.ndarray):
-                    self.arrays[k][...] = 0
+    def clear(self, env_idx: Optional[int] = None) -> None:
+        """Remove every cuboid / voxel-grid / mesh obstacle of one environment (``None``: of all), in place (the kernels and
+        captured graphs read the same enable / count tensors): an empty world of the same capacity.  As the reference's
+        stores do it (geom/data/data_cuboid.py:411-424, data_voxel.py:624-639, data_mesh.py:472-486): enable flags AND
+        counts to zero, the names forgotten -- so that a cleared obstacle is not found by name any more, cannot be
+        switched back on, and the same world can be added again into the freed slots."""
+        sel = slice(None) if env_idx is None else env_idx
+        envs = range(self.num_envs) if env_idx is None else [env_idx]
+        for kind in ("cuboid", "voxel"):
+            for key in (f"{kind}_enable", f"{kind}_count"):
+                if self.tensors.get(key) is not None:
+                    self.tensors[key][sel] = 0
+                if isinstance(self.arrays.get(key), np.ndarray):
+                    self.arrays[key][sel] = 0
+            names = self.arrays.get(f"{kind}_names")
+            if names is not None:
+                for e in envs:
+                    names[e] = [None] * len(names[e])
         if self.meshes is not None and getattr(self.meshes, "enable", None) is not None:
-            self.meshes.enable.zero_()
+            self.meshes.enable[sel] = 0
+            self.meshes.count[sel] = 0
+            for e in envs:
+                self.meshes.names[e] = [None] * len(self.meshes.names[e])
 
     @staticmethod
     def from_arrays(arrays: Optional[Dict[str, np.ndarray]], device, coarse_culling: bool = True, meshes=None) -> "SceneData":

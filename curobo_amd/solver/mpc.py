@@ -52,13 +52,13 @@ class MPCSolverCfg:
         # joint-position tracking (off until a goal configuration is given: update_goal_state / update_goal_tool_poses(run_ik=True)),
         # the MPC task's values (lbfgs_mpc.yml:28-29)
         cspace_target_weight=1000.0, cspace_non_terminal_weight_factor=0.05))
-    #: seeds of the goal IK (update_goal_tool_poses(run_ik=True)): the solution closest to the current configuration is tracked
-    goal_ik_seeds: int = 16
     optimizer: LBFGSOptCfg = field(default_factory=lambda: LBFGSOptCfg(history=15, inner_iters=25))
     use_cuda_graph: bool = True
     #: ``prepare_safe_deceleration_trajectory`` (reference solver_mpc_cfg.py:81-90): deceleration seeds for a moving robot, or hold still
     use_deceleration_on_failure: bool = True
     deceleration_profile: str = "exponential"  # "linear" | "exponential" | "smooth"
+    #: seeds of the goal IK (update_goal_tool_poses(run_ik=True)): the solution closest to the current configuration is tracked
+    goal_ik_seeds: int = 16
 
     @staticmethod
     def reference_task(**overrides) -> "MPCSolverCfg":

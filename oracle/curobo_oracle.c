@@ -644,9 +644,52 @@ typedef struct {
 } orc_scene;
 
 /* ---- triangle meshes: data_mesh.py:630-700 (compute_local_sdf_with_grad) with the closest point found by brute force
- * (Ericson, Real-Time Collision Detection 5.1.5) and the sign from the generalised winding number (van Oosterom-Strackee
- * solid angles summed in double precision): |w| > 0.5 = inside.  Warp's mesh_query_point is outside the reference tree;
- * this restates its contract for closed, consistently oriented meshes. */
+ * (Ericson, Real-Time Collision Detection 5.1.5).  The SIGN of the query is Warp's (wp.mesh_query_point, data_mesh.py:632,
+ * 682; warp-lang >= 0.10.0 is the reference's pin, pyproject.toml:37; the package is not in /root/reference and has no
+ * ROCm build, so its PUBLISHED algorithm is restated, warp/native/mesh.h):
+ *   rule 1, "rays" = mesh_query_point -> mesh_query_inside: three rays from the query point along +x, +y and +z; each ray's
+ *     NEAREST hit (mesh_query_ray, t > 0) reports on which side of the hit face the ray origin lies ("sign > 0 if the ray
+ *     hit in front of the face", i.e. dot(direction, ab x ac) < 0); the point is INSIDE iff all three rays hit and all three
+ *     nearest hits are back faces, else outside.  Restated in double precision over every triangle.
+ *   rule 0, "winding" (the default the oracle has had since round 3) = the generalised winding number (van Oosterom-
+ *     Strackee solid angles summed in double precision), |w| > 0.5 = inside.
+ * On a closed, consistently oriented surface the two rules and the closest-feature pseudonormal rule of the HIP path
+ * (Baerentzen & Aanaes) are the same function away from the surface; on open or inconsistently oriented meshes they are three
+ * different functions and only rule 1 is the reference's (tests/test_oracle_mesh_sign.py tabulates where they part). */
+static int orc_mesh_sign_rule = 0;
+ORC_API void orc_set_mesh_sign_rule(int rule) { orc_mesh_sign_rule = rule; }
+ORC_API int orc_get_mesh_sign_rule(void) { return orc_mesh_sign_rule; }
+
+/* mesh_query_inside (warp/native/mesh.h): 1 = inside.  Moeller-Trumbore in double precision; a ray that passes exactly
+ * through an edge or a vertex is a degenerate case of Warp's fp32 watertight test too -- the fixtures avoid them. */
+static int orc_mesh_inside_rays(const float *verts, const int32_t *faces, int n_faces, const float *lp) {
+  int votes = 0;
+  for (int axis = 0; axis < 3; axis++) {
+    double best_t = 1e300;
+    int best_back = 0, hit = 0;
+    for (int f = 0; f < n_faces; f++) {
+      const float *a = verts + (size_t)faces[f * 3] * 3, *b = verts + (size_t)faces[f * 3 + 1] * 3, *c = verts + (size_t)faces[f * 3 + 2] * 3;
+      double ab[3], ac[3], tv[3], d[3] = {0.0, 0.0, 0.0};
+      d[axis] = 1.0;
+      for (int i = 0; i < 3; i++) { ab[i] = (double)b[i] - a[i]; ac[i] = (double)c[i] - a[i]; tv[i] = (double)lp[i] - a[i]; }
+      const double pv[3] = {d[1] * ac[2] - d[2] * ac[1], d[2] * ac[0] - d[0] * ac[2], d[0] * ac[1] - d[1] * ac[0]};
+      const double det = ab[0] * pv[0] + ab[1] * pv[1] + ab[2] * pv[2];
+      if (det == 0.0) continue;
+      const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+      if (u < 0.0 || u > 1.0) continue;
+      const double qv[3] = {tv[1] * ab[2] - tv[2] * ab[1], tv[2] * ab[0] - tv[0] * ab[2], tv[0] * ab[1] - tv[1] * ab[0]};
+      const double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) / det;
+      if (v < 0.0 || u + v > 1.0) continue;
+      const double t = (ac[0] * qv[0] + ac[1] * qv[1] + ac[2] * qv[2]) / det;
+      if (t <= 0.0 || t >= best_t) continue;
+      /* the face normal ab x ac against the ray: d . n = det' -- with pv = d x ac, det = ab . (d x ac) = -d . (ab x ac) */
+      best_t = t; hit = 1; best_back = det < 0.0;  /* d . n > 0: the ray leaves through the back of the face */
+    }
+    if (hit && best_back) votes++;
+  }
+  return votes == 3;
+}
+
 static void orc_closest_on_triangle(const float *p, const float *a, const float *b, const float *c, float *out) {
   float ab[3], ac[3], ap[3];
   for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
@@ -709,7 +752,8 @@ static float orc_mesh_sdf_raw(const float *verts, const int32_t *faces, int n_fa
   if (!found) return max_distance;
   const float d = sqrtf(best2);
   if (d > 1e-6f) { g[0] = (lp[0] - cl[0]) / d; g[1] = (lp[1] - cl[1]) / d; g[2] = (lp[2] - cl[2]) / d; }
-  return fabs(solid) > 6.283185307179586 ? -d : d;
+  const int inside = orc_mesh_sign_rule == 1 ? orc_mesh_inside_rays(verts, faces, n_faces, lp) : fabs(solid) > 6.283185307179586;
+  return inside ? -d : d;
 }
 
 ORC_API void orc_mesh_query(float *out_sdf, float *out_grad, const float *points, const float *vertices, const int32_t *faces,

@@ -144,6 +144,7 @@ class Oracle:
             "orc_cspace_state_cost",
             "orc_set_num_threads",
             "orc_set_frame_arithmetic",
+            "orc_set_mesh_sign_rule",
         ):
             getattr(self.lib, name).restype = None
 
@@ -158,6 +159,16 @@ class Oracle:
         """"reference" (Warp's quat_rotate, the default) or "device" (the rotation-matrix fma form of the HIP path) for the
         world -> obstacle-frame transform of the scene-collision stage; see orc_set_frame_arithmetic in curobo_oracle.c."""
         self.lib.orc_set_frame_arithmetic(C.c_int({"reference": 0, "device": 1}[mode]))
+
+    MESH_SIGN_RULES = {"winding": 0, "rays": 1}
+
+    def set_mesh_sign_rule(self, rule: str) -> None:
+        """"winding" (generalised winding number, the default) or "rays" (Warp's mesh_query_point as published: +x / +y / +z
+        rays, inside iff every ray's nearest hit is a back face) for the sign of mesh queries; see curobo_oracle.c."""
+        self.lib.orc_set_mesh_sign_rule(C.c_int(self.MESH_SIGN_RULES[rule]))
+
+    def mesh_sign_rule(self) -> str:
+        return {v: k for k, v in self.MESH_SIGN_RULES.items()}[int(self.lib.orc_get_mesh_sign_rule())]
 
     def frame_arithmetic(self) -> str:
         return ("reference", "device")[int(self.lib.orc_get_frame_arithmetic())]

@@ -177,6 +177,42 @@ def test_scene_obstacles_by_name_are_in_place_edits_of_the_stores():
         scene_from_config(SceneCfg(cuboid=[box, Cuboid("b2", box.pose, dims=box.dims)]), "cpu", cache={"cuboid": 1})
 
 
+def test_clear_forgets_the_obstacles_and_frees_their_slots():
+    """``SceneData.clear`` as the reference's stores clear (data_cuboid.py:411-424): enable AND count to zero, names
+    forgotten -- the same world can be added again, a cleared obstacle cannot be switched back on."""
+    box = Cuboid("box", [0.5, 0, 0.5, 1, 0, 0, 0], dims=[0.1, 0.2, 0.3])
+    ball = Sphere("ball", pose=[1, 1, 1, 1, 0, 0, 0], radius=0.1)
+    scene = scene_with(box, ball, cache=2)
+    ptrs = {k: v.data_ptr() for k, v in scene.tensors.items()}
+    scene.clear()
+    assert scene.get_obstacle_names() == [] and not scene.check_obstacle_exists("box")
+    assert int(scene.tensors["cuboid_count"][0]) == 0 and scene.tensors["cuboid_enable"][0].tolist() == [0, 0]
+    assert int(scene.arrays["cuboid_count"][0]) == 0
+    with pytest.raises(ValueError):
+        scene.enable_obstacle("box", True)  # gone, not merely switched off
+    # the same world again: the full store has room, the names are free
+    assert scene.add_obstacle(box) == 0 and scene.add_obstacle(ball) == 1
+    assert scene.get_obstacle_names() == ["box", "ball"] and scene.tensors["cuboid_enable"][0].tolist() == [1, 1]
+    assert {k: v.data_ptr() for k, v in scene.tensors.items()} == ptrs
+    # one environment of two
+    cfg = SceneCfg()
+    cfg.add_obstacle(box)
+    two = scene_from_config([cfg, cfg], "cpu", cache={"cuboid": 2}) if _takes_env_list() else None
+    if two is not None:
+        two.clear(env_idx=1)
+        assert two.get_obstacle_names(0) == ["box"] and two.get_obstacle_names(1) == []
+        assert two.tensors["cuboid_count"].tolist() == [1, 0]
+
+
+def _takes_env_list():
+    try:
+        cfg = SceneCfg()
+        cfg.add_obstacle(Cuboid("b", [0, 0, 0, 1, 0, 0, 0], dims=[0.1, 0.1, 0.1]))
+        return scene_from_config([cfg, cfg], "cpu", cache={"cuboid": 2}).num_envs == 2
+    except Exception:
+        return False
+
+
 def test_conservative_fit_covers_the_obstacle():
     """``conservative=True``: every point of the (rotated) box lies in some sphere, within the budget; the default fit stays inside"""
     from curobo_amd.scene.types import Pose7
