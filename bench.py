@@ -1203,8 +1203,12 @@ def c2_world_as_meshes():
 
 def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, out, x, times, Cn, build_mesh_bvh, mesh_esdf_bake_bvh,
                          CollisionRollout, SceneData, cuboid_scene_arrays, start_configuration):
+    scene_cells = None
+    from curobo_amd.scene import MeshStore
+
     for key, scene in (("cuboid_kernel", SceneData.from_arrays(cuboid_scene_arrays(world), device)),
-                       ("mesh_launch", SceneData.from_arrays(None, device, meshes=meshes))):
+                       ("mesh_launch", SceneData.from_arrays(None, device, meshes=meshes)),
+                       ("mesh_launch_tree_walk", SceneData.from_arrays(None, device, meshes=MeshStore(meshes, device, cells=False)))):
         ro = CollisionRollout(kin, scene, B, cfg)
         ro.update_start_state(torch.as_tensor(start_configuration(model), device=device))
         ro.compute_kinematics(ro.compute_state_from_action(x.view(B, cfg.n_knots, -1)))
@@ -1218,12 +1222,20 @@ def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, ou
         g = graphed(scene_pass, 5, torch)
         times[key] = time_kernel(g.replay, 3, torch, min_s=0.05) / 5
         out[key] = {"us": round(times[key], 2), "cost_sum": float(ro.scene_dist.sum())}
+        if key == "mesh_launch":
+            scene_cells = scene
     alg = B * H * kin.num_spheres * 36
     out["mesh_launch"].update({"algorithmic_bytes": alg, "GBps": round(alg / times["mesh_launch"] * 1e-3, 1),
                                "hbm_frac": round(alg / times["mesh_launch"] * 1e-3 / HBM_PEAK_GBS, 4),
                                "cost_relative_to_cuboids": round(out["mesh_launch"]["cost_sum"] / max(out["cuboid_kernel"]["cost_sum"], 1e-9), 6),
                                "slowdown_vs_cuboid_kernel": round(times["mesh_launch"] / times["cuboid_kernel"], 2)})
-    out["mesh_launch"]["kernels"] = "curobo_hip_sphere_mesh_collision_ws: sphere_mesh_select_kernel<3> (bounding-box reject, queue) + sphere_mesh_walk_kernel<3>"
+    out["mesh_launch"]["kernels"] = ("curobo_hip_sphere_mesh_collision_ws: sphere_mesh_select_kernel<3> (bounding-box reject, queue) + "
+                                     "sphere_mesh_cells_kernel<3> (distance-sorted closest-triangle cell lists) + sphere_mesh_walk_kernel<3> (what the lists cannot answer)")
+    out["mesh_launch_tree_walk"]["note"] = "the same launch over meshes built without cell lists (round 4-5 form): select + tree walk"
+    out["mesh_launch"]["speedup_vs_tree_walk"] = round(times["mesh_launch_tree_walk"] / times["mesh_launch"], 2)
+    out["mesh_launch"]["cost_equals_tree_walk"] = bool(abs(out["mesh_launch"]["cost_sum"] - out["mesh_launch_tree_walk"]["cost_sum"])
+                                                       <= 1e-5 * abs(out["mesh_launch_tree_walk"]["cost_sum"]))
+    out["mesh_launch"]["cell_lists"] = [m.cells_info for m in scene_cells.meshes.meshes] if scene_cells is not None else None
     out["mesh_launch"]["kernel_counters"] = {
         k2: (lambda e: None if e is None else {"mean_us": e.get("mean_us"), "hbm_bytes": e.get("hbm_bytes"), "valu_issue_frac": e.get("valu_issue_frac"),
                                                "SQ_INSTS_VALU": e["counters"].get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": e["counters"].get("SQ_INSTS_SALU"),
@@ -1234,10 +1246,18 @@ def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, ou
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        bvh = build_mesh_bvh(v, f, device)
+        bvh = build_mesh_bvh(v, f, device, cells=False)
     torch.cuda.synchronize()
     out["bvh_build"] = {"triangles": int(len(f)), "ms": round((time.perf_counter() - t0) / 5 * 1e3, 3),
                         "note": "Morton keys + torch.sort + one launch per tree level; host-driven, per loaded mesh, once"}
+    from curobo_amd.backends.mesh import build_mesh_cells
+    t0 = time.perf_counter()
+    for _ in range(3):
+        build_mesh_cells(bvh)
+    torch.cuda.synchronize()
+    out["cell_lists_build"] = {"ms": round((time.perf_counter() - t0) / 3 * 1e3, 3), **(bvh.cells_info or {}),
+                               "note": "count launch + prefix sum + fill launch + torch.sort of the entries; per loaded mesh, once"}
+    bvh = build_mesh_bvh(v, f, device, cells=False)
     n = 96
     grid_a = torch.zeros(n ** 3, dtype=torch.float16, device=device)
     grid_b = torch.zeros_like(grid_a)

@@ -9,7 +9,9 @@ not in the reference tree, so what these functions follow is the contract of tha
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -22,7 +24,9 @@ class Mesh(C.Structure):
     """``curobo_hip_mesh``"""
 
     _fields_ = [("tri", C.c_void_p), ("node_box", C.c_void_p), ("tri_pn", C.c_void_p), ("n_tri", C.c_int32), ("n_leaves", C.c_int32),
-                ("leaf_size", C.c_int32), ("_pad", C.c_int32)]
+                ("leaf_size", C.c_int32), ("sign_rule", C.c_int32),
+                ("cell_start", C.c_void_p), ("cell_list", C.c_void_p), ("grid_lo", C.c_float * 3), ("grid_h", C.c_float),
+                ("grid_n", C.c_int32 * 3), ("grid_pad", C.c_float)]
 
 
 class MeshSet(C.Structure):
@@ -30,7 +34,10 @@ class MeshSet(C.Structure):
 
     _fields_ = [("meshes", C.c_void_p), ("mesh_id", C.c_void_p), ("dims", C.c_void_p), ("inv_pose", C.c_void_p),
                 ("enable", C.c_void_p), ("count", C.c_void_p), ("max_n", C.c_int32), ("gradient_mode", C.c_int32),
-                ("num_envs", C.c_int32), ("_pad", C.c_int32)]
+                ("num_envs", C.c_int32), ("flags", C.c_int32)]
+
+
+MESH_SET_HAS_CELLS = 1  # curobo_hip_mesh_set.flags
 
 
 @dataclass
@@ -43,6 +50,12 @@ class DeviceMesh:
     struct: Mesh
     bounds: np.ndarray  # [2, 3] lo / hi in the mesh frame
     n_tri: int
+    #: SIGN_CLOSEST_FEATURE (closed, consistently oriented) or SIGN_WARP_RAYS (anything else: the reference's three rays)
+    sign_rule: int = 0
+    #: the cell lists (``build_mesh_cells``): packed cell words, (triangle, distance) entries -- kept alive here -- and what was built
+    cell_start: Optional[torch.Tensor] = None
+    cell_list: Optional[torch.Tensor] = None
+    cells_info: Optional[dict] = None
 
     @property
     def dims(self) -> np.ndarray:
@@ -117,10 +130,12 @@ def mesh_is_closed_and_oriented(vertices: np.ndarray, faces: np.ndarray) -> bool
     return bool((cnt == 1).all() and np.isin(rkey, uk).all())
 
 
-def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8) -> DeviceMesh:
+def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8, sign_rule: Optional[int] = None, cells=None) -> DeviceMesh:
     """vertices [V, 3] (mesh frame), faces [F, 3] -> the linear BVH on ``device``: Morton keys of the centroids (HIP), the
-    sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level)"""
-    import os
+    sort (torch: plumbing), triangles in sorted order + node boxes (HIP, one launch per level).  ``sign_rule``: None = by the
+    mesh's topology (``mesh_is_closed_and_oriented``: closest feature on closed consistently oriented meshes, the reference's
+    three rays on anything else), or forced.  ``cells``: build the cell lists too (None: on unless CUROBO_MESH_CELLS=0; a dict =
+    the keyword arguments of ``build_mesh_cells``)."""
     try:  # development knob (a malformed value is ignored)
         leaf_size = max(1, int(os.environ.get("CUROBO_MESH_LEAF_SIZE", leaf_size)))
     except ValueError:
@@ -147,8 +162,69 @@ def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8) -> DeviceMesh:
     # pseudonormals of the triangle features, in the sorted order of the triangles (the low half of a key is the index)
     pn = torch.as_tensor(feature_pseudonormals(np.asarray(vertices, np.float32), np.asarray(faces, np.int64))).to(device)
     tri_pn = pn[(codes & 0xFFFFFFFF).long()].contiguous()
-    s = Mesh(ptr(tri), ptr(box), ptr(tri_pn), n, n_leaves, leaf_size, 0)
-    return DeviceMesh(tri, box, tri_pn, s, bounds, n)
+    rule = SIGN_CLOSEST_FEATURE if sign_rule is None and mesh_is_closed_and_oriented(vertices, faces) else \
+        (SIGN_WARP_RAYS if sign_rule is None else int(sign_rule))
+    s = Mesh(ptr(tri), ptr(box), ptr(tri_pn), n, n_leaves, leaf_size, rule)
+    mesh = DeviceMesh(tri, box, tri_pn, s, bounds, n, rule)
+    if cells is None:
+        cells = os.environ.get("CUROBO_MESH_CELLS", "1") != "0"
+    if cells:
+        build_mesh_cells(mesh, **(cells if isinstance(cells, dict) else {}))
+    return mesh
+
+
+def build_mesh_cells(mesh: DeviceMesh, cell_size: Optional[float] = None, pad: float = 0.2, max_cells: int = 1 << 18,
+                     gather_cap: int = 2048) -> DeviceMesh:
+    """The distance-sorted closest-triangle cell lists of ``mesh`` (``curobo_hip_mesh.cell_start / cell_list``; the query is
+    ``csrc/mesh_device.hpp::mesh_cells_sdf``), written into ``mesh.struct`` in place.
+
+    A uniform grid over the bounding box grown by ``pad`` (how far from the box a query can still be answered without a tree
+    walk: the largest sphere radius + activation distance + half a sweep step one expects; 0.2 m: measured on the bench's mesh
+    world, 0.1 m sends 2 % of the live spheres -- the fast-moving ones -- to the tree walk and 0.2 m none); cells of ``cell_size``
+    (default 2 cm), coarsened until the grid has at most ``max_cells`` cells.  Two launches around a prefix sum and a sort (torch:
+    plumbing): count -> offsets -> fill + keys -> sort -> gather.  ``gather_cap``: cells whose candidate ball holds more
+    triangles get no list (their queries walk the tree)."""
+    lib = load()
+    dev = mesh.tri.device
+    lo, hi = mesh.bounds[0].astype(np.float64) - pad, mesh.bounds[1].astype(np.float64) + pad
+    h = float(cell_size) if cell_size else float(os.environ.get("CUROBO_MESH_CELL_SIZE", 0.02))
+    ext = hi - lo
+    while np.prod(np.ceil(ext / h)) > max_cells:
+        h *= 1.1
+    n3 = np.maximum(np.ceil(ext / h).astype(np.int64), 1)
+    st = mesh.struct
+    st.cell_start, st.cell_list = None, None
+    for i in range(3):
+        st.grid_lo[i] = float(lo[i])
+        st.grid_n[i] = int(n3[i])
+    st.grid_h, st.grid_pad = h, float(pad)
+    n_cells = int(np.prod(n3))
+    count = torch.empty(n_cells, dtype=torch.int32, device=dev)
+    cover = torch.empty(n_cells, dtype=torch.float32, device=dev)
+    side = torch.empty(n_cells, dtype=torch.uint8, device=dev)
+    centre_dist = torch.empty(n_cells, dtype=torch.float32, device=dev)
+    stream = current_stream(count)
+    check(lib.curobo_hip_mesh_cells_count(ptr(count), ptr(cover), ptr(side), ptr(centre_dist), C.addressof(st), int(gather_cap), stream))
+    offsets = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(count, 0, out=offsets[1:])
+    total = int(offsets[-1])
+    if total >= 1 << 30:
+        raise RuntimeError(f"cell lists of {total} entries: raise cell_size or lower gather_cap")
+    keys = torch.empty(total, dtype=torch.int64, device=dev)
+    entries = torch.empty(total, 4, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(n_cells + 1, 2, dtype=torch.int32, device=dev)
+    check(lib.curobo_hip_mesh_cells_fill(ptr(keys), ptr(entries), ptr(cell_start), ptr(offsets), ptr(cover), ptr(side), ptr(centre_dist),
+                                         C.addressof(st), stream))
+    perm = torch.sort(keys).indices
+    mesh.cell_list = entries[perm].contiguous()
+    mesh.cell_start = cell_start
+    st.cell_start, st.cell_list = ptr(mesh.cell_start), ptr(mesh.cell_list)
+    listed = count > 1
+    mesh.cells_info = {"cell_size": h, "grid": [int(v) for v in n3], "pad": float(pad), "cells": n_cells, "entries": total,
+                       "bytes": int(total * 16 + (n_cells + 1) * 8), "cells_without_list": int((cover == 0).sum()),
+                       "mean_list": float(count[listed].float().mean() - 1) if bool(listed.any()) else 0.0,
+                       "max_list": int(count.max()) - 1}
+    return mesh
 
 
 def mesh_query(mesh: DeviceMesh, points: torch.Tensor, max_distance: float, want_grad: bool = True
@@ -182,7 +258,8 @@ def sphere_mesh_collision(distance, gradient, spheres, mesh_set: MeshSet, weight
     belong to the rollout that owns the output, so rollouts of equal size that run concurrently -- the seed shards of
     ``PipelinedLBFGS`` on their own streams, the parallel branches of one captured graph -- never share them (a cache keyed
     by size alone let one shard's select kernel clear or fill the queue another shard's walk kernel was reading); launches
-    into one output buffer are ordered by its owner's stream, and a captured graph keeps its pointer alive through the cache."""
+    into one output buffer are ordered by its owner's stream; the workspace is held BY the output tensor (an attribute of it, or
+    of its base for a view), so a captured graph's workspace lives as long as the buffer the graph writes."""
     lib = load()
     if workspace is False:
         check(lib.curobo_hip_sphere_mesh_collision(
@@ -194,14 +271,23 @@ def sphere_mesh_collision(distance, gradient, spheres, mesh_set: MeshSet, weight
     check(lib.curobo_hip_sphere_mesh_collision_ws_bytes(batch_size, horizon, num_spheres, C.cast(C.pointer(nbytes), C.c_void_p)))
     need = int(nbytes.value)
     if workspace is None:
+        # owned by the OUTPUT tensor (its base when a view is handed in): the workspace lives exactly as long as the buffer
+        # whose launches it serves -- nothing piles up when rollouts are rebuilt, and a freed address that comes back for
+        # another rollout's buffer never inherits a workspace an older captured graph may still point at
+        owner = distance._base if distance._base is not None else distance
+        held = getattr(owner, "_curobo_mesh_ws", None)
+        if held is None:
+            held = owner._curobo_mesh_ws = {}
         key = (distance.device, need, int(distance.data_ptr()))
-        workspace = _WORKSPACES.get(key)
+        workspace = held.get(key)
         if workspace is None:
-            workspace = _WORKSPACES[key] = torch.empty(need, dtype=torch.uint8, device=distance.device)
+            workspace = held[key] = torch.empty(need, dtype=torch.uint8, device=distance.device)
+            _WORKSPACES[key] = workspace
     check(lib.curobo_hip_sphere_mesh_collision_ws(
         ptr(distance), ptr(gradient), ptr(spheres), C.addressof(mesh_set), ptr(weight), ptr(activation_distance), ptr(env_query_idx),
         batch_size, horizon, num_spheres, int(use_multi_env), sweep_steps, int(enable_speed_metric), ptr(speed_dt), int(accumulate),
         ptr(workspace), int(workspace.numel()), current_stream(distance)))
 
 
-_WORKSPACES: dict = {}
+#: the live launch workspaces, for inspection only (weak: an entry goes when the output tensor that owns it does)
+_WORKSPACES = weakref.WeakValueDictionary()

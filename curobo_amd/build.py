@@ -84,9 +84,27 @@ PER_SOURCE_FLAGS: dict = {"self_collision.hip": ["-mllvm", "-amdgpu-mfma-vgpr-fo
 NO_SLP = ["-fno-slp-vectorize"]
 
 
+def _included(path: str, seen: set) -> None:
+    """the package headers a source reaches through its #include "..." lines (transitively)"""
+    import re
+
+    try:
+        text = open(path).read()
+    except OSError:
+        return
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for base in (CSRC, INCLUDE):
+            cand = os.path.join(base, name)
+            if os.path.exists(cand) and cand not in seen:
+                seen.add(cand)
+                _included(cand, seen)
+
+
 def _deps(src: str) -> List[str]:
-    return [src, os.path.join(INCLUDE, "curobo_hip.h")] + [os.path.join(CSRC, h) for h in HEADERS
-                                                          if os.path.exists(os.path.join(CSRC, h))]
+    """the source, the C header and the device headers it actually includes (a header edit rebuilds its users, not the library)"""
+    seen: set = set()
+    _included(src, seen)
+    return [src, os.path.join(INCLUDE, "curobo_hip.h"), *sorted(seen)]
 
 
 def _compile(unit, force: bool) -> str:

@@ -114,8 +114,121 @@ __global__ void __launch_bounds__(256) mesh_esdf_bake_bvh_kernel(const MeshBakeB
   int side;
   const bool found = mesh_closest_point(a.m, p, d2, cp, side);
   const float d = found ? sqrtf(d2) : a.max_distance;
-  const bool inside = (found && side != 0) ? side < 0 : mesh_inside(a.m, p);
+  const bool inside = mesh_point_inside(a.m, p, found ? side : 0);
   a.out[v] = __float2half(inside ? -d : d);
+}
+
+// ------------------------------------------------------------------------------------------------ cell lists (build)
+// One lane per cell of the grid (curobo_hip_mesh.cell_start / cell_list; the query is mesh_device.hpp::mesh_cells_sdf).
+// Pass 1: the distance dc of the cell's centre c from the surface (the tree walk) and the side c is on; the list has to hold
+// every triangle that can be the closest one of SOME point of the cell: for p in the cell, dist(p, t*) <= dist(p, t_c) <=
+// dc + hd (hd = half the cell's diagonal), so dist(c, t*) <= dc + 2 hd =: R -- the triangles within R of c are counted by a
+// pre-order walk pruned with R.  A cell that is outside the surface and farther from it than the grid's pad can never be
+// asked for more than "how far at least" (queries there reach no farther than the pad, or go to the tree walk): it lists
+// its nearest triangle only.  A cell whose ball holds more than `gather_cap` triangles (the middle of a blob: everything is
+// about equally far) gets no list: its queries walk the tree.  Pass 2 (after the caller's prefix sum): the same walk writes
+// (triangle, distance) and a sort key cell << 32 | distance bits; the caller sorts the keys (torch.sort: plumbing) and
+// gathers the entries: every list ascending in distance, its sentinel (-1, cover = R) last.
+struct MeshCellsArgs {
+  curobo_hip_mesh m;       // grid_lo / grid_h / grid_n / grid_pad set, cell pointers unused
+  int32_t *count;          // [n_cells]: entries of the cell's list including the sentinel
+  float *cover;            // [n_cells]: R of the cell (0: no list)
+  uint8_t *side;           // [n_cells]: 1 / 2 = the whole cell is outside / inside, 0 = it may straddle the surface
+  float *centre_dist;      // [n_cells]: distance of the cell's centre from the surface
+  const int64_t *offsets;  // pass 2: [n_cells + 1] exclusive prefix sum of count
+  int64_t *keys;           // pass 2: [offsets[n_cells]]
+  int32_t *entries;        // pass 2: [offsets[n_cells]][4] (CellEntry)
+  int n_cells, gather_cap;
+};
+
+__device__ __forceinline__ f3 mesh_cell_centre(const curobo_hip_mesh &m, int cell) {
+  const int iz = cell % m.grid_n[2], iy = (cell / m.grid_n[2]) % m.grid_n[1], ix = cell / (m.grid_n[2] * m.grid_n[1]);
+  return make_f3(m.grid_lo[0] + ((float)ix + 0.5f) * m.grid_h, m.grid_lo[1] + ((float)iy + 0.5f) * m.grid_h,
+                 m.grid_lo[2] + ((float)iz + 0.5f) * m.grid_h);
+}
+
+// every triangle within sqrt(r2) of c, in pre-order of the tree: f(triangle index, distance, c - its closest point)
+template <class F>
+__device__ __forceinline__ void mesh_ball_walk(const curobo_hip_mesh &m, f3 c, float r2, F f) {
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  unsigned node = 1u;
+  while (node != 0u) {
+    const bool hit = box_dist2(box[node * 2], box[node * 2 + 1], c) <= r2;  // (an empty padding box is infinitely far)
+    if (hit && node < (unsigned)m.n_leaves) { node = node * 2u; continue; }
+    if (hit) {
+      const int t0 = ((int)node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+      for (int t = t0; t < t1; t++) {
+        const TriRec r = tri[t];
+        int region;
+        const f3 q = closest_on_triangle(c, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+        const f3 d = c - q;
+        const float d2 = dot(d, d);
+        if (d2 <= r2) f(t, sqrtf(d2), d);
+      }
+    }
+    node >>= __builtin_ctz(~node);
+    node = node ? (node | 1u) : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256) mesh_cells_count_kernel(const MeshCellsArgs a) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= a.n_cells) return;
+  const curobo_hip_mesh &m = a.m;
+  const f3 c = mesh_cell_centre(m, cell);
+  const float hd = 0.8660254f * m.grid_h * 1.0001f;
+  float d2 = 3.0e38f;
+  f3 cp = c;
+  int fside = 0;
+  mesh_closest_point(m, c, d2, cp, fside);  // (a mesh has a triangle: always found)
+  const float dc = sqrtf(d2);
+  // the side of the whole cell: every point of it is within hd of c, so a centre farther than hd from the surface has the
+  // cell on its side (closed meshes; the reference's ray rule has no such continuity: sign_rule 1 keeps 0)
+  unsigned side = 0u;
+  if (m.sign_rule == 0 && dc > hd + 1e-6f) side = mesh_point_inside(m, c, fside) ? 2u : 1u;
+  const bool far_out = side == 1u && dc - hd > m.grid_pad;
+  // (the query's prefix ends at dc (1 + 1e-6) + 2 delta with delta <= hd + 2e-6: the cover has to reach past that for every
+  // point of the cell, corners included -- a list that ends a rounding short sends its sphere to the tree walk)
+  const float R = far_out ? dc * 1.000001f + 1e-7f : (dc + 2.0f * hd) * 1.00002f + 1e-5f;
+  int n = 0;
+  mesh_ball_walk(m, c, R * R, [&](int, float, f3) { n++; });
+  const bool listed = n <= a.gather_cap;
+  a.count[cell] = (listed ? n : 0) + 1;
+  a.cover[cell] = listed ? R : 0.0f;
+  a.side[cell] = (uint8_t)side;
+  a.centre_dist[cell] = dc;
+}
+
+__global__ void __launch_bounds__(256) mesh_cells_fill_kernel(const MeshCellsArgs a) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= a.n_cells) return;
+  const curobo_hip_mesh &m = a.m;
+  const int64_t base = a.offsets[cell];
+  const int n = (int)(a.offsets[cell + 1] - base) - 1;
+  const float R = a.cover[cell];
+  if (n > 0) {
+    int i = 0;
+    mesh_ball_walk(m, mesh_cell_centre(m, cell), R * R, [&](int t, float d, f3 v) {
+      if (i < n) {  // (the count pass walked the same nodes: i never reaches n)
+        float ox = 0.0f, oy = 0.0f;
+        if (d > 1e-6f) oct_encode((1.0f / d) * v, ox, oy);
+        reinterpret_cast<float4 *>(a.entries)[base + i] = make_float4(__int_as_float(t), d, ox, oy);
+        a.keys[base + i] = ((int64_t)cell << 32) | (int64_t)__float_as_int(d);
+      }
+      i++;
+    });
+  }
+  reinterpret_cast<float4 *>(a.entries)[base + n] = make_float4(__int_as_float(-1), R, 0.0f, 0.0f);
+  a.keys[base + n] = ((int64_t)cell << 32) | 0x7fffffffll;
+}
+
+__global__ void __launch_bounds__(256) mesh_cells_start_kernel(uint2 *cell_start, const int64_t *offsets, const uint8_t *side,
+                                                               const float *centre_dist, int n_cells) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell > n_cells) return;
+  cell_start[cell] = make_uint2((uint32_t)offsets[cell] | (cell < n_cells ? (uint32_t)side[cell] << 30 : 0u),
+                                cell < n_cells ? (uint32_t)__float_as_int(centre_dist[cell]) : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ sphere vs meshes
@@ -299,8 +412,10 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
 #endif
 struct MeshQueueArgs {
   MeshCollArgs c;
-  uint32_t *counter;  // workspace word 0
+  uint32_t *counter;  // workspace words 0 (entries from the head), 2 (entries from the tail), 1 (entries of queue2)
   uint2 *queue;       // workspace + 16 bytes: (sphere index, live slot mask)
+  uint2 *queue2;      // behind it: the spheres the cell-list kernel hands to the tree walk
+  int from_queue2;    // the walk kernel reads queue2 (filled from its head, counter word 1) instead of queue
 };
 
 #ifndef MESH_SELECT_STAGED
@@ -319,6 +434,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
   // their loads are in flight together, and the two queue counters take one atomic per 256 x CH spheres.
   constexpr int kRecs = 128;
   __shared__ float s_rec[kRecs][16];  // t[3] q[4] lo[3] hi[3] enabled
+  __shared__ MeshGridRec s_grid[kRecs];  // the slot's cell grid (mesh_cell_clear)
   const MeshCollArgs &a = qa.c;
   const long total = (long)a.batch * a.horizon * a.nspheres;  // (< 2^31: the launcher checks)
   const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
@@ -340,6 +456,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
         rec[7] = rb[0]; rec[8] = rb[1]; rec[9] = rb[2]; rec[10] = rb[4]; rec[11] = rb[5]; rec[12] = rb[6];
       }
       rec[13] = slot.enabled ? 1.0f : 0.0f;
+      s_grid[r] = load_grid_rec(slot.m, slot.enabled);
     }
   }
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
@@ -387,7 +504,8 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
           // (mesh_early_reject on the staged root box)
           const float ex = fmaxf(fmaxf(rec[7] - lc.x, lc.x - rec[10]), 0.0f), ey = fmaxf(fmaxf(rec[8] - lc.y, lc.y - rec[11]), 0.0f),
                       ez = fmaxf(fmaxf(rec[9] - lc.z, lc.z - rec[12]), 0.0f);
-          if (!(ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f)) {
+          if (!(ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f) &&
+              !mesh_cell_clear(s_grid[(a.use_multi_env ? (bb[c] - first_b) * a.nslots : 0) + k], lc, thr)) {
             live[c] |= 1u << k;
             if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rec[7] || lc.y < rec[8] || lc.z < rec[9] || lc.x > rec[10] || lc.y > rec[11] || lc.z > rec[12]);
           }
@@ -398,7 +516,7 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
           const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
           if (!slot.enabled) continue;
           const f3 lc = mesh_to_local(slot, center);
-          if (!mesh_early_reject(slot, lc, r_adj, reach[c])) {
+          if (!mesh_early_reject(slot, lc, r_adj, reach[c]) && !mesh_cell_clear(load_grid_rec(slot.m, true), lc, r_adj + reach[c])) {
             live[c] |= 1u << k;
             const float *rb = slot.m.node_box + 8;
             if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]);
@@ -490,7 +608,9 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
 template <int SWEEP>
 __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_walk_kernel(const MeshQueueArgs qa) {
   const MeshCollArgs &a = qa.c;
-  const uint32_t n_front = qa.counter[0], n = n_front + qa.counter[2];  // heavy entries from the head, the others from the tail
+  // heavy entries from the head, the others from the tail; queue2 (the cell-list kernel's leftovers) from its head only
+  const uint32_t n_front = qa.from_queue2 ? qa.counter[1] : qa.counter[0], n = qa.from_queue2 ? n_front : n_front + qa.counter[2];
+  const uint2 *queue = qa.from_queue2 ? qa.queue2 : qa.queue;
   const uint32_t q_last = (uint32_t)((long)a.batch * a.horizon * a.nspheres - 1);
   const int hs = a.horizon * a.nspheres;
   const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
@@ -503,7 +623,7 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
     // (a group beyond the end of the queue repeats the last entry so that ballots and shuffles stay whole; it writes nothing)
     const bool live_group = q < n;
     const uint32_t qq = live_group ? q : n - 1;
-    const uint2 e = qa.queue[qq < n_front ? qq : q_last - (qq - n_front)];
+    const uint2 e = queue[qq < n_front ? qq : q_last - (qq - n_front)];
     if (live_group && (threadIdx.x & (G - 1u)) == 0) CUROBO_MESH_COUNT(6, 1);
     const long sidx = (long)e.x;
     const int b = (int)(e.x / (uint32_t)hs);  // (32-bit: the queued form holds sphere indices in 32 bits)
@@ -543,6 +663,106 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
     }
     if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f) mesh_speed_metric(center, pp, np, a.speed_dt[0], dsum, gsum);
     if (!live_group || (threadIdx.x & (G - 1u)) != 0) continue;
+    float4 *grad = reinterpret_cast<float4 *>(a.gradient);
+    if (a.accumulate) {
+      if (dsum > 0.0f) {
+        a.distance[sidx] += dsum;
+        const float4 g0 = grad[sidx];
+        grad[sidx] = make_float4(g0.x + gsum.x, g0.y + gsum.y, g0.z + gsum.z, g0.w);
+      }
+    } else {
+      a.distance[sidx] = dsum;
+      grad[sidx] = make_float4(gsum.x, gsum.y, gsum.z, 0.0f);
+    }
+  }
+}
+
+// ---- the cell-list kernel: the walk kernel's job without a tree walk.  Eight lanes per live sphere again (a chunk of a
+// cell's list is eight triangles, one per lane); every query of the sphere goes through mesh_cells_sdf.  A sphere with a query
+// the lists cannot answer (outside the grid yet within reach, a cell without a list, a list that ends too early) is handed
+// whole to the walk kernel through queue2 and writes nothing here.
+#ifndef MESH_CELLS_GROUP
+#define MESH_CELLS_GROUP 8  // lanes per live sphere (4 / 8 / 16 / 32 measured: 8)
+#endif
+#ifndef MESH_CELLS_UNROLL
+#define MESH_CELLS_UNROLL 4  // list entries per lane and round (2 / 4 / 8 measured: 4)
+#endif
+#ifndef MESH_CELLS_HEAVY_GROUP
+#define MESH_CELLS_HEAVY_GROUP 0  // > 0: the head of the queue by a launch of its own with this many lanes per sphere
+#endif
+#ifndef MESH_CELLS_HEAVY_UNROLL
+#define MESH_CELLS_HEAVY_UNROLL 2
+#endif
+#ifndef MESH_CELLS_ATTR
+#define MESH_CELLS_ATTR
+#endif
+// PART 0: the whole queue; 1: the entries queued from its head (centre inside a live mesh's bounding box: the long lists of
+// cells inside a surface); 2: the entries queued from its tail.
+template <int SWEEP, int GROUP, int UNROLL, int PART>
+__global__ void __launch_bounds__(256) MESH_CELLS_ATTR sphere_mesh_cells_kernel(const MeshQueueArgs qa) {
+  const MeshCollArgs &a = qa.c;
+  const uint32_t n_front = qa.counter[0], n_all = n_front + qa.counter[2];
+  const uint32_t q_begin = PART == 2 ? n_front : 0u, n = PART == 1 ? n_front : n_all;
+  const uint32_t q_last = (uint32_t)((long)a.batch * a.horizon * a.nspheres - 1);
+  const int hs = a.horizon * a.nspheres;
+  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
+  const float w = a.weight[0], eta = a.eta[0];
+  constexpr unsigned G = GROUP, PER_WG = 256 / G;
+  __shared__ float s_state[PER_WG][MESH_ST_WORDS];  // the groups' LDS records (mesh_device.hpp MESH_ST_*)
+  float *st = s_state[threadIdx.x / G];
+  for (uint32_t q0 = q_begin + blockIdx.x * PER_WG; q0 < n; q0 += gridDim.x * PER_WG) {
+    const uint32_t q = q0 + threadIdx.x / G;
+    const bool live_group = q < n;
+    const uint32_t qq = live_group ? q : n - 1;
+    const uint2 e = qa.queue[qq < n_front ? qq : q_last - (qq - n_front)];
+    const long sidx = (long)e.x;
+    const int b = (int)(e.x / (uint32_t)hs);
+    const int h = (int)((e.x - (uint32_t)b * (uint32_t)hs) / (uint32_t)a.nspheres);
+    const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
+    const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;
+    const bool nb_prev = need_nb && h > 0, nb_next = need_nb && h < a.horizon - 1;
+    float r_adj, reach;
+    {
+      const float4 s = sph[sidx];
+      const float4 ps = nb_prev ? sph[sidx - a.nspheres] : s, ns = nb_next ? sph[sidx + a.nspheres] : s;
+      const f3 center = make_f3(s.x, s.y, s.z), pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
+      r_adj = s.w + eta;
+      float half_w_prev = 0.0f, half_w_next = 0.0f;
+      if (SWEEP > 0) {
+        if (nb_prev) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+        if (nb_next) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+      }
+      reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
+      st_store3(st, MESH_ST_CENTER, center); st_store3(st, MESH_ST_PREV, pp); st_store3(st, MESH_ST_NEXT, np);
+      st[MESH_ST_HALF_PREV] = half_w_prev; st[MESH_ST_HALF_NEXT] = half_w_next;
+      st[MESH_ST_DSUM] = 0.0f; st_store3(st, MESH_ST_GSUM, make_f3(0.f, 0.f, 0.f));
+    }
+    const unsigned flags = (SWEEP > 0 && nb_prev ? 1u : 0u) | (SWEEP > 0 && nb_next ? 2u : 0u);
+    uint32_t m = e.y;
+    bool answered = true;
+#pragma unroll 1
+    while (m && answered) {
+      const int k = __ffs((int)m) - 1;
+      m &= m - 1;
+      const MeshPoseSlot slot = load_mesh_pose_slot(a.set, env, a.slot0 + k, st);
+      st[MESH_ST_COST] = 0.0f; st_store3(st, MESH_ST_GRAD, make_f3(0.f, 0.f, 0.f));
+      answered = mesh_contribution_cells<SWEEP, (int)G, UNROLL>(slot, a.set.gradient_mode, st, flags, r_adj, eta, reach, q);
+      const float cost_sum = st[MESH_ST_COST];
+      if (cost_sum > 0.0f) {
+        const f3 gw = mesh_to_world_vector_st(st, st_load3(st, MESH_ST_GRAD));
+        st[MESH_ST_DSUM] += w * cost_sum;
+        st_store3(st, MESH_ST_GSUM, st_load3(st, MESH_ST_GSUM) + w * gw);
+      }
+    }
+    if (!live_group || (threadIdx.x & (G - 1u)) != 0) continue;
+    if (!answered) {  // to the tree walk, whole
+      qa.queue2[atomicAdd(qa.counter + 1, 1u)] = e;
+      continue;
+    }
+    float dsum = st[MESH_ST_DSUM];
+    f3 gsum = st_load3(st, MESH_ST_GSUM);
+    if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f)
+      mesh_speed_metric(st_load3(st, MESH_ST_CENTER), st_load3(st, MESH_ST_PREV), st_load3(st, MESH_ST_NEXT), a.speed_dt[0], dsum, gsum);
     float4 *grad = reinterpret_cast<float4 *>(a.gradient);
     if (a.accumulate) {
       if (dsum > 0.0f) {
@@ -614,6 +834,42 @@ static int check_mesh(const curobo_hip_mesh *m, const char *what) {
   return CUROBO_HIP_OK;
 }
 
+static int check_grid(const curobo_hip_mesh *m, const char *what) {
+  CUROBO_REQUIRE(m->grid_h > 0.0f && m->grid_n[0] > 0 && m->grid_n[1] > 0 && m->grid_n[2] > 0 && m->grid_pad >= 0.0f &&
+                     (long)m->grid_n[0] * m->grid_n[1] * m->grid_n[2] < (1l << 30),
+                 "%s: the mesh's grid fields (grid_lo / grid_h / grid_n / grid_pad) are not set", what);
+  return CUROBO_HIP_OK;
+}
+
+CUROBO_EXPORT int curobo_hip_mesh_cells_count(int32_t *out_count, float *out_cover, uint8_t *out_side, float *out_centre_dist,
+                                              const curobo_hip_mesh *mesh, int gather_cap, curobo_hip_stream_t stream) {
+  const char *what = "mesh_cells_count";
+  CUROBO_REQUIRE(out_count && out_cover && out_side && out_centre_dist && gather_cap >= 1, "%s: bad arguments", what);
+  if (int rc = check_mesh(mesh, what)) return rc;
+  if (int rc = check_grid(mesh, what)) return rc;
+  MeshCellsArgs a{};
+  a.m = *mesh; a.count = out_count; a.cover = out_cover; a.side = out_side; a.centre_dist = out_centre_dist; a.gather_cap = gather_cap;
+  a.n_cells = mesh->grid_n[0] * mesh->grid_n[1] * mesh->grid_n[2];
+  hipLaunchKernelGGL(mesh_cells_count_kernel, dim3((unsigned)ceil_div(a.n_cells, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch(what, (hipStream_t)stream);
+}
+
+CUROBO_EXPORT int curobo_hip_mesh_cells_fill(int64_t *out_keys, int32_t *out_entries, uint32_t *out_cell_start, const int64_t *offsets,
+                                             const float *cover, const uint8_t *side, const float *centre_dist,
+                                             const curobo_hip_mesh *mesh, curobo_hip_stream_t stream) {
+  const char *what = "mesh_cells_fill";
+  CUROBO_REQUIRE(out_keys && out_entries && out_cell_start && offsets && cover && side && centre_dist, "%s: NULL argument", what);
+  if (int rc = check_mesh(mesh, what)) return rc;
+  if (int rc = check_grid(mesh, what)) return rc;
+  MeshCellsArgs a{};
+  a.m = *mesh; a.cover = const_cast<float *>(cover); a.offsets = offsets; a.keys = out_keys; a.entries = out_entries;
+  a.n_cells = mesh->grid_n[0] * mesh->grid_n[1] * mesh->grid_n[2];
+  hipLaunchKernelGGL(mesh_cells_fill_kernel, dim3((unsigned)ceil_div(a.n_cells, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mesh_cells_start_kernel, dim3((unsigned)ceil_div(a.n_cells + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<uint2 *>(out_cell_start), offsets, side, centre_dist, a.n_cells);
+  return check_launch(what, (hipStream_t)stream);
+}
+
 CUROBO_EXPORT int curobo_hip_mesh_query(float *out_sdf, float *out_grad, const float *points, const curobo_hip_mesh *mesh,
                                         float max_distance, int n_points, curobo_hip_stream_t stream) {
   const char *what = "mesh_query";
@@ -667,9 +923,10 @@ static int sphere_mesh_collision_impl(
   const bool queued = workspace != nullptr;
   if (queued) {
     CUROBO_REQUIRE(total < (1l << 31), "%s: the queued form indexes spheres with 32 bits", what);
-    CUROBO_REQUIRE(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 16 + (size_t)total * sizeof(uint2),
+    CUROBO_REQUIRE(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= 16 + 2 * (size_t)total * sizeof(uint2),
                    "%s: workspace too small or misaligned (curobo_hip_sphere_mesh_collision_ws_bytes)", what);
   }
+  const bool with_cells = (meshes->flags & CUROBO_HIP_MESH_SET_HAS_CELLS) != 0;
   // 32 obstacle slots per launch (the live mask of a sphere); further groups add to the first one's output
   for (int slot0 = 0; slot0 < meshes->max_n; slot0 += kMeshSlotsPerLaunch) {
     a.slot0 = slot0;
@@ -679,15 +936,41 @@ static int sphere_mesh_collision_impl(
       MeshQueueArgs qa{};
       qa.c = a; qa.counter = reinterpret_cast<uint32_t *>(workspace);
       qa.queue = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(workspace) + 16);
+      qa.queue2 = qa.queue + total;
       if (hipMemsetAsync(workspace, 0, 16, st) != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot clear the queue counter", what);
       // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
       const unsigned walk_blocks = (unsigned)std::min<long>(MESH_WALK_MAX_BLOCKS, ceil_div_l(total, MESH_WALK_THREADS / MESH_WALK_GROUP));
+      // with cell lists: select -> cell-list kernel (every sphere it can answer) -> tree walk of the few it could not
+      const unsigned cells_blocks = (unsigned)std::min<long>(8192, ceil_div_l(total, 256 / MESH_CELLS_GROUP));
+      const unsigned rest_blocks = std::min(walk_blocks, 4096u);
       if (sweep_steps > 0) {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), select_grid, block, 0, st, qa);
-        hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        if (with_cells) {
+          if (MESH_CELLS_HEAVY_GROUP > 0) {
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<3, MESH_CELLS_HEAVY_GROUP ? MESH_CELLS_HEAVY_GROUP : 8, MESH_CELLS_HEAVY_UNROLL, 1>), dim3(cells_blocks), block, 0, st, qa);
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<3, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 2>), dim3(cells_blocks), block, 0, st, qa);
+          } else {
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<3, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 0>), dim3(cells_blocks), block, 0, st, qa);
+          }
+          qa.from_queue2 = 1;
+          hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(rest_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        } else {
+          hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        }
       } else {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<0>), select_grid, block, 0, st, qa);
-        hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        if (with_cells) {
+          if (MESH_CELLS_HEAVY_GROUP > 0) {
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<0, MESH_CELLS_HEAVY_GROUP ? MESH_CELLS_HEAVY_GROUP : 8, MESH_CELLS_HEAVY_UNROLL, 1>), dim3(cells_blocks), block, 0, st, qa);
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<0, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 2>), dim3(cells_blocks), block, 0, st, qa);
+          } else {
+            hipLaunchKernelGGL((sphere_mesh_cells_kernel<0, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 0>), dim3(cells_blocks), block, 0, st, qa);
+          }
+          qa.from_queue2 = 1;
+          hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(rest_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        } else {
+          hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
+        }
       }
       continue;
     }
@@ -709,7 +992,7 @@ CUROBO_EXPORT int curobo_hip_sphere_mesh_collision(
 
 CUROBO_EXPORT int curobo_hip_sphere_mesh_collision_ws_bytes(int batch_size, int horizon, int num_spheres, int64_t *out_bytes_host) {
   CUROBO_REQUIRE(out_bytes_host && batch_size >= 0 && horizon >= 0 && num_spheres >= 0, "sphere_mesh_collision_ws_bytes: bad arguments%s", "");
-  *out_bytes_host = 16 + (int64_t)batch_size * horizon * num_spheres * (int64_t)sizeof(uint2);
+  *out_bytes_host = 16 + 2 * (int64_t)batch_size * horizon * num_spheres * (int64_t)sizeof(uint2);  // counters, queue, queue2
   return CUROBO_HIP_OK;
 }
 

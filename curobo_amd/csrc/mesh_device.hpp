@@ -198,16 +198,17 @@ __device__ __forceinline__ bool mesh_closest_point(const curobo_hip_mesh &m, f3 
 // deep.  A leaf node here is any node >= n_leaves; the tree depth need not be a multiple of three (the last step is
 // narrower).
 template <int G>
-__device__ __forceinline__ float group_min(float v) {
+__device__ __forceinline__ float group_min(float v) {  // G = 4, 8, 16 or 32 aligned lanes
   v = fminf(v, dpp_f<0xB1>(v));
   v = fminf(v, dpp_f<0x4E>(v));
-  v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror: lane i <-> 7 - i of its group of eight
-  if (G == 16) v = fminf(v, dpp_f<0x140>(v));  // row_mirror: i <-> 15 - i
+  if (G >= 8) v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror: lane i <-> 7 - i of its group of eight
+  if (G >= 16) v = fminf(v, dpp_f<0x140>(v));  // row_mirror: i <-> 15 - i
+  if (G >= 32) v = fminf(v, __shfl_xor(v, 16, 64));
   return v;
 }
 template <int G>
 __device__ __forceinline__ unsigned group_ballot(bool pred) {
-  return (unsigned)(__ballot(pred) >> (threadIdx.x & (64u - G))) & ((1u << G) - 1u);
+  return (unsigned)(__ballot(pred) >> (threadIdx.x & (64u - G))) & (G >= 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 }
 // ``keys`` (mesh_contribution_group): the calling lane's column of a [MESH_GROUP_LEVELS][blockDim.x] float table in LDS (the
 // ordering key of this lane's descendant at every step level: siblings are revisited nearest first and re-judged against the
@@ -269,6 +270,65 @@ __device__ __forceinline__ bool mesh_inside(const curobo_hip_mesh &m, f3 p) {
   return (mesh_ray_crossings(m, p, make_f3(0.0331f, -0.0617f, -1.0f)) & 1) != 0;
 }
 
+// The reference's inside test as published (Warp's mesh_query_point -> mesh_query_inside, warp/native/mesh.h; the call is
+// data_mesh.py:632,682): three rays from p along +x, +y, +z; a ray's NEAREST hit tells whether it met the front or the back
+// of a face; inside iff all three rays hit and all three nearest hits are back faces.  On a closed, consistently oriented
+// surface that is the function mesh_feature_side evaluates without a ray; meshes that are not (curobo_hip_mesh.sign_rule =
+// 1) are signed with this walk: pre-order, pruned by the axis slab and the nearest hit so far.
+__device__ __forceinline__ bool mesh_inside_warp_rays(const curobo_hip_mesh &m, f3 p) {
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  int votes = 0;
+#pragma unroll 1
+  for (int axis = 0; axis < 3; axis++) {
+    const f3 d = make_f3(axis == 0 ? 1.0f : 0.0f, axis == 1 ? 1.0f : 0.0f, axis == 2 ? 1.0f : 0.0f);
+    float best_t = 3.0e38f;
+    bool back = false;
+    unsigned node = 1u;
+    while (node != 0u) {
+      const float4 lo = box[node * 2], hi = box[node * 2 + 1];
+      // the ray runs along one axis: inside the box's extent on the other two, and the box not behind the origin nor
+      // beyond the nearest hit (an empty padding box has lo > hi and fails the first test)
+      const bool in_x = p.x >= lo.x && p.x <= hi.x, in_y = p.y >= lo.y && p.y <= hi.y, in_z = p.z >= lo.z && p.z <= hi.z;
+      const float pa = axis == 0 ? p.x : axis == 1 ? p.y : p.z, la = axis == 0 ? lo.x : axis == 1 ? lo.y : lo.z,
+                  ha = axis == 0 ? hi.x : axis == 1 ? hi.y : hi.z;
+      const bool lateral = axis == 0 ? (in_y && in_z) : axis == 1 ? (in_x && in_z) : (in_x && in_y);
+      const bool hit = lateral && ha >= pa && (la - pa) <= best_t;
+      if (hit && node < (unsigned)m.n_leaves) { node = node * 2u; continue; }
+      if (hit) {
+        const int t0 = ((int)node - m.n_leaves) * m.leaf_size, t1 = min(t0 + m.leaf_size, m.n_tri);
+        for (int t = t0; t < t1; t++) {  // Moeller-Trumbore
+          const TriRec r = tri[t];
+          const f3 ab = make_f3(r.ab.x, r.ab.y, r.ab.z), ac = make_f3(r.ac.x, r.ac.y, r.ac.z);
+          const f3 pv = cross(d, ac);
+          const float det = dot(ab, pv);
+          if (det == 0.0f) continue;
+          const float idet = 1.0f / det;
+          const f3 tv = p - make_f3(r.a.x, r.a.y, r.a.z);
+          const float u = dot(tv, pv) * idet;
+          if (u < 0.0f || u > 1.0f) continue;
+          const f3 qv = cross(tv, ab);
+          const float v = dot(d, qv) * idet;
+          if (v < 0.0f || u + v > 1.0f) continue;
+          const float tt = dot(ac, qv) * idet;
+          // det = ab . (d x ac) = -d . (ab x ac): negative when the ray leaves through the back of the face
+          if (tt > 0.0f && tt < best_t) { best_t = tt; back = det < 0.0f; }
+        }
+      }
+      node >>= __builtin_ctz(~node);
+      node = node ? (node | 1u) : 0u;
+    }
+    if (best_t < 3.0e38f && back) votes++;
+  }
+  return votes == 3;
+}
+
+// inside / outside of a query whose closest feature gave the verdict `side` (0 = none), by the mesh's rule
+__device__ __forceinline__ bool mesh_point_inside(const curobo_hip_mesh &m, f3 p, int side) {
+  if (m.sign_rule == 1) return mesh_inside_warp_rays(m, p);
+  return side != 0 ? side < 0 : mesh_inside(m, p);
+}
+
 // The same signed distance, searched only as far as the caller can use it.  The cost of a sample needs the distance when
 // it is below r_adj; the sweep's step needs it when it is below r_adj + what is left of the half segment -- beyond that
 // the sample contributes nothing and the walk along the segment ends, whatever the exact value (result preserving).  So
@@ -301,7 +361,7 @@ __device__ __forceinline__ float mesh_sdf_within(const curobo_hip_mesh &m, f3 lp
   const f3 delta = lp - cp;
   if (d > 1e-6f) g = (1.0f / d) * delta;
   // the feature the closest point lies on says which side the point is on; without a verdict the crossings are counted
-  const bool inside = side != 0 ? side < 0 : mesh_inside(m, lp);
+  const bool inside = mesh_point_inside(m, lp, side);
   return inside ? -d : d;
 }
 
@@ -404,9 +464,10 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
       if (!(dir == 0 ? has_prev : has_next)) continue;
       // sweep culling (result preserving, as for cuboids: scene_device.hpp): every sample lies within the half segment
       // length of the centre and the signed distance is 1-Lipschitz, so a centre that is clear by more than that cannot
-      // have a penetrating sample.  (A centre that found no surface within its search radius is clear by more than any
+      // have a penetrating sample.  (Closed meshes only: under the reference's ray rule an open mesh's sign changes across
+      // the shadow lines of its rim, far from any surface -- sign_rule 1 culls nothing by continuity.)  (A centre that found no surface within its search radius is clear by more than any
       // half segment -- or beyond max_distance, where the samples find nothing either.)
-      if (-pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
+      if (s.m.sign_rule == 0 && -pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
       ln = mesh_to_local(s, dir == 0 ? prev_c : next_c);
       const f3 dd = ln - lc;
       half_dist = sqrtf(dot(dd, dd)) * 0.5f;
@@ -426,7 +487,7 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
     // the sample's distance matters below r_adj (cost) and below r_adj + the rest of the half segment (next step);
     // it lies within half_dist of the centre, so it can only be deep inside when the centre is inside
     q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
-    q_may_in = sdf_c < half_dist;
+    q_may_in = s.m.sign_rule != 0 || sdf_c < half_dist;
   }
 }
 
@@ -583,7 +644,7 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
       const int side = mesh_feature_side(m, qp, cp, dmin, __shfl(l_t, src, 64), __shfl(l_region, src, 64), tie);
       const float d = sqrtf(dmin);
       if (d > 1e-6f) gq = (1.0f / d) * (qp - cp);
-      const bool inside = side != 0 ? side < 0 : mesh_inside(m, qp);
+      const bool inside = mesh_point_inside(m, qp, side);
       sdf = inside ? -d : d;
       have_prev = true; prev_d = d; prev_qp = qp;
     }
@@ -611,7 +672,7 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
       dir++;
       if (dir >= 2) break;
       if (!(dir == 0 ? has_prev : has_next)) continue;
-      if (-pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
+      if (s.m.sign_rule == 0 && -pen_c > (dir == 0 ? half_w_prev : half_w_next) * 1.0001f + cull_slack) continue;
       ln = mesh_to_local(s, dir == 0 ? prev_c : next_c);
       const f3 dd = ln - lc;
       half_dist = sqrtf(dot(dd, dd)) * 0.5f;
@@ -628,10 +689,355 @@ __device__ __forceinline__ void mesh_contribution_group(const MeshSlot &s, int g
     const float tt = 1.0f - 0.5f * jump * inv_half;
     qp = tt * lc + (1.0f - tt) * ln;
     q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
-    q_may_in = sdf_c < half_dist;
+    q_may_in = s.m.sign_rule != 0 || sdf_c < half_dist;
     full = !(q_radius < max_distance);
     begin_query();
   }
+}
+
+// ---- distance-sorted closest-triangle cell lists (curobo_hip_mesh.cell_start / cell_list; built by mesh_bvh.hip).
+// The tree walk above is a chain of dependent box fetches -- 17 moves per sphere on the bench's mesh world, 129 in the worst
+// query, ~1.2 us a move -- and its divergent control flow is a third of its instruction stream.  A query through the cell
+// lists has no walk: one fetch for the cell, then the triangles listed for it, in order of their distance from the cell's
+// centre c, as far as any of them can matter: the closest triangle t* of a point p at delta = |p - c| satisfies
+// dist(c, t*) <= dist(p, t*) + delta <= dist(p, t_c) + delta <= dist(c, t_c) + 2 delta, where t_c is the first entry -- so the
+// prefix of the list up to dist(c, t_c) + 2 delta holds it, and once some triangle at distance best from p is known, the
+// prefix up to best + delta.  The G lanes of the group fetch U x G entries of that prefix at once, then their triangles at
+// once, and tighten it with what they found; the first round usually is the only one.  The closest point is the exact one -- the same minimum over the same fp32
+// point-triangle distances as the walk finds.  A list that ends before that prefix does (cells without a list, the single-entry
+// lists of cells far outside) and points outside the grid that the radius still reaches go to the walk.
+// what the select kernel needs of a mesh's cell grid to drop a sphere the bounding-box test let through: the packed cell words
+// carry the distance dc of every cell's centre from the surface and whether the whole cell is outside it
+struct MeshGridRec {
+  const uint2 *cell_start;  // nullptr: no cells (or a mesh signed by the reference's rays: no continuity to argue with)
+  float lx, ly, lz, h;
+  int nx, ny, nz;
+};
+__device__ __forceinline__ MeshGridRec load_grid_rec(const curobo_hip_mesh &m, bool enabled) {
+  MeshGridRec g;
+  g.cell_start = (enabled && m.sign_rule == 0) ? reinterpret_cast<const uint2 *>(m.cell_start) : nullptr;
+  g.lx = m.grid_lo[0]; g.ly = m.grid_lo[1]; g.lz = m.grid_lo[2]; g.h = m.grid_h;
+  g.nx = m.grid_n[0]; g.ny = m.grid_n[1]; g.nz = m.grid_n[2];
+  return g;
+}
+// true when a sphere whose centre is lc (mesh frame) cannot touch the surface within `thr` (= r_adj + the reach of its sweep)
+// anywhere along its sweep: its cell is wholly outside the (closed) surface and its centre farther than thr from it.  Result
+// preserving for the reasons of mesh_early_reject, with the exact distance of the cell's centre in place of the bounding box.
+__device__ __forceinline__ bool mesh_cell_clear(const MeshGridRec &g, f3 lc, float thr) {
+  if (g.cell_start == nullptr) return false;
+  const float inv_h = __frcp_rn(g.h);
+  const float fx = (lc.x - g.lx) * inv_h, fy = (lc.y - g.ly) * inv_h, fz = (lc.z - g.lz) * inv_h;
+  const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && ix < g.nx && iy < g.ny && iz < g.nz)) return false;
+  const uint2 rec = g.cell_start[(ix * g.ny + iy) * g.nz + iz];
+  if ((rec.x >> 30) != 1u) return false;
+  const f3 dv = lc - make_f3(g.lx + ((float)ix + 0.5f) * g.h, g.ly + ((float)iy + 0.5f) * g.h, g.lz + ((float)iz + 0.5f) * g.h);
+  const float delta = sqrtf(dot(dv, dv)) * 1.0001f + 2e-6f;
+  return __int_as_float((int)rec.y) - delta > thr * 1.0001f + 2e-6f;
+}
+
+struct CellEntry {  // 16 bytes
+  int32_t tri;   // sorted-order triangle index; -1: the sentinel
+  float dist;    // distance of the triangle from the cell's centre c (sentinel: the cover radius of the list)
+  float ox, oy;  // octahedral code of the unit vector n from the triangle's closest point q towards c.  The triangle lies
+                 // behind the plane through q with normal n, so for ANY p: dist(p, t) >= dist + (p - c) . n -- a bound that
+                 // knows in which direction p left the centre (the plain triangle inequality only knows how far)
+};
+__device__ __forceinline__ void oct_encode(f3 n, float &ox, float &oy) {  // n: unit
+  const float s = 1.0f / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+  float x = n.x * s, y = n.y * s;
+  if (n.z < 0.0f) {
+    const float tx = (1.0f - fabsf(y)) * (x >= 0.0f ? 1.0f : -1.0f), ty = (1.0f - fabsf(x)) * (y >= 0.0f ? 1.0f : -1.0f);
+    x = tx; y = ty;
+  }
+  ox = x; oy = y;
+}
+__device__ __forceinline__ f3 oct_decode(float ox, float oy) {
+  f3 n = make_f3(ox, oy, 1.0f - fabsf(ox) - fabsf(oy));
+  const float t = fmaxf(-n.z, 0.0f);
+  n.x += n.x >= 0.0f ? -t : t;
+  n.y += n.y >= 0.0f ? -t : t;
+  return __frsqrt_rn(dot(n, n)) * n;
+}
+
+// what a query needs of a mesh record, read once per (sphere, mesh) item.  (The lanes of a wavefront query different meshes: the
+// whole record by value is 22 vector registers, and reading a field where it is used puts a fetch in front of every query.)
+// The grid's numbers live in the group's LDS record (see MESH_ST_*): a query reads them once, at its start.
+struct MeshCellsView {
+  const curobo_hip_mesh *mp;
+  const uint2 *cell_start;
+  const CellEntry *list;
+  const TriRec *tri;
+  const float *st;  // the group's LDS record
+};
+// ---- the LDS record of a group of lanes working on one sphere (floats; written and read by every lane of the group with the
+// same values -- a wavefront's LDS operations execute in order, so no barrier is involved): what the sphere's program needs
+// only BETWEEN queries -- the sphere and its neighbours, the slot's pose, the centre sample's terms, the sums.  Measured (notebook,
+// round 6): it does NOT lower the kernel's register count -- the compiler forwards the record through registers (142 with it,
+// 147 without), and forcing the traffic with `volatile` raised it to 197; the count is set inside closest_on_triangle with a
+// round's four entries in flight.  Kept because the item program reads better against named slots than against fifteen arguments.
+enum : int {
+  MESH_ST_CENTER = 0, MESH_ST_PREV = 3, MESH_ST_NEXT = 6, MESH_ST_HALF_PREV = 9, MESH_ST_HALF_NEXT = 10,
+  MESH_ST_T = 11, MESH_ST_Q = 14 /* w x y z */, MESH_ST_GC = 18, MESH_ST_PEN_C = 21, MESH_ST_C_C = 22, MESH_ST_GS_C = 23,
+  MESH_ST_DSUM = 24, MESH_ST_GSUM = 25, MESH_ST_COST = 28, MESH_ST_GRAD = 29,
+  MESH_ST_GRID_LO = 32, MESH_ST_GRID_H = 35, MESH_ST_GRID_PAD = 36, MESH_ST_GRID_N = 37, MESH_ST_WORDS = 40
+};
+__device__ __forceinline__ f3 st_load3(const float *st, int i) { return make_f3(st[i], st[i + 1], st[i + 2]); }
+__device__ __forceinline__ void st_store3(float *st, int i, f3 v) { st[i] = v.x; st[i + 1] = v.y; st[i + 2] = v.z; }
+__device__ __forceinline__ MeshCellsView load_cells_view(const curobo_hip_mesh *mp, float *st) {
+  MeshCellsView v;
+  v.mp = mp;
+  v.cell_start = reinterpret_cast<const uint2 *>(mp->cell_start);
+  v.list = reinterpret_cast<const CellEntry *>(mp->cell_list);
+  v.tri = reinterpret_cast<const TriRec *>(mp->tri);
+  v.st = st;
+  st[MESH_ST_GRID_LO] = mp->grid_lo[0]; st[MESH_ST_GRID_LO + 1] = mp->grid_lo[1]; st[MESH_ST_GRID_LO + 2] = mp->grid_lo[2];
+  st[MESH_ST_GRID_H] = mp->grid_h; st[MESH_ST_GRID_PAD] = mp->grid_pad;
+  st[MESH_ST_GRID_N] = __int_as_float(mp->grid_n[0]); st[MESH_ST_GRID_N + 1] = __int_as_float(mp->grid_n[1]);
+  st[MESH_ST_GRID_N + 2] = __int_as_float(mp->grid_n[2]);
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ float group_bcast0(float v) {  // the value of lane 0 of the group
+  return __shfl(v, (int)(threadIdx.x & (64u - G)), 64);
+}
+
+// (p - closest point) . unit (pseudo)normal of the feature of triangle t the closest point lies on: positive outside
+__device__ __forceinline__ float mesh_side_term(const TriRec *tri, const float *tri_pn, int t, int region, f3 d) {
+  f3 n;
+  if (region == 0) {
+    const TriRec r = tri[t];
+    n = cross(make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z));
+  } else {
+    if (tri_pn == nullptr) return 0.0f;
+    const float4 n4 = reinterpret_cast<const float4 *>(tri_pn)[(size_t)t * 6 + (region - 1)];
+    n = make_f3(n4.x, n4.y, n4.z);
+  }
+  const float nn = dot(n, n);
+  return nn > 1e-30f ? dot(d, n) * __frsqrt_rn(nn) : 0.0f;
+}
+template <int G>
+__device__ __forceinline__ float group_sum_dpp(float v) {  // G = 4, 8, 16 or 32 aligned lanes; every lane gets the sum
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  if (G >= 8) v += dpp_f<0x141>(v);
+  if (G >= 16) v += dpp_f<0x140>(v);
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+// the signed distance of qp (mesh frame) and the reference's local gradient, by the G lanes of an aligned group that all hold
+// the same query.  Returns false when the cell lists cannot answer it (the caller walks the tree instead).  A surface
+// farther than `q_radius` from a point OUTSIDE it may be reported as "nothing within max_distance" (max_distance, 0), exactly
+// as mesh_sdf_within does -- the callers' results are the same either way (see mesh_sdf_within).
+template <int G, int U>
+__device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, float q_radius, float max_distance, float &sdf, f3 &grad,
+                                               unsigned stat_q = 0u) {
+  constexpr float FAR = 3.0e38f;
+  sdf = max_distance;
+  grad = make_f3(0.f, 0.f, 0.f);
+  if (mv.cell_start == nullptr) return false;
+  const int g = threadIdx.x & (G - 1), gbase = threadIdx.x & (64 - G);
+  const float lx = mv.st[MESH_ST_GRID_LO], ly = mv.st[MESH_ST_GRID_LO + 1], lz = mv.st[MESH_ST_GRID_LO + 2], h = mv.st[MESH_ST_GRID_H];
+  const int nx = __float_as_int(mv.st[MESH_ST_GRID_N]), ny = __float_as_int(mv.st[MESH_ST_GRID_N + 1]), nz = __float_as_int(mv.st[MESH_ST_GRID_N + 2]);
+  const float inv_h = __frcp_rn(h);
+  const float fx = (qp.x - lx) * inv_h, fy = (qp.y - ly) * inv_h, fz = (qp.z - lz) * inv_h;
+  const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && ix < nx && iy < ny && iz < nz)) {
+    // outside the grid = farther than grid_pad from the bounding box, hence from the surface, and outside it under either
+    // sign rule (the reference's rays all have to hit: the point would lie inside the box)
+    return q_radius <= mv.st[MESH_ST_GRID_PAD];
+  }
+  const int cell = (ix * ny + iy) * nz + iz;
+  const uint2 rec = mv.cell_start[cell];
+  const uint32_t w0 = rec.x, w1 = mv.cell_start[cell + 1].x;
+  const int n = (int)((w1 & 0x3fffffffu) - (w0 & 0x3fffffffu));  // >= 1: the sentinel
+  const unsigned cell_side = w0 >> 30;
+  const float dc = __int_as_float((int)rec.y);  // distance of the cell's centre from the surface
+  const CellEntry *list = mv.list + (w0 & 0x3fffffffu);
+  const f3 dv = qp - make_f3(lx + ((float)ix + 0.5f) * h, ly + ((float)iy + 0.5f) * h, lz + ((float)iz + 0.5f) * h);
+  const float delta = sqrtf(dot(dv, dv)) * 1.0001f + 2e-6f;  // |p - c|, rounded up past the fp32 error of the listed distances
+#ifdef CUROBO_MESH_STATS
+  if (g == 0) g_mesh_lane[0x20000u + (stat_q & 0x1ffffu)] += 1;  // queries of the queue entry
+#endif
+  if (g == 0) CUROBO_MESH_COUNT(0, 1);
+  // the surface is at least dc - delta away from p: outside and beyond the radius needs no triangle
+  if (cell_side == 1u && dc - delta > q_radius) { if (g == 0) CUROBO_MESH_COUNT(4, 1); return true; }
+  if (n <= 1) return false;  // a cell without a list
+  // the closest triangle of p is no farther than dc + 2 delta from the centre
+  float l_d2 = FAR, lim = dc * 1.000001f + 2.0f * delta, best_d2 = FAR;
+  f3 l_c = qp;
+  int l_t = 0, l_region = 0;
+  float l_tie_term = 0.0f;  // side terms of earlier triangles of this lane at the SAME distance as the kept one
+  bool complete = false;
+  const float4 *list4 = reinterpret_cast<const float4 *>(list);
+  const float dir_slack = delta * 2e-4f + 2e-6f;  // rounding of the decoded direction and of the listed distance
+#pragma unroll 1
+  for (int k = 0;; k += U * G) {
+#ifdef CUROBO_MESH_STATS
+    if (g == 0) g_mesh_lane[stat_q & 0x1ffffu] += 1;  // rounds of the queue entry
+#endif
+    if (g == 0) CUROBO_MESH_COUNT(1, 1);
+    // a round: U x G entries, fetched at once (16 bytes each); an entry needs its triangle only when neither its distance
+    // nor its directional bound clears it -- after the first few of the first round that is rare, so the rounds of a long
+    // prefix (a point deep inside a block: every face is about equally far) are scans
+    float4 e[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) e[u] = list4[min(k + u * G + g, n - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int t = __float_as_int(e[u].x);
+      const float dist = e[u].y;
+      // dist(p, t) >= dist + (p - c) . n (see CellEntry); a triangle the centre touches has no direction: the plain bound
+      const float lb = dist > 1e-6f ? dist + dot(dv, oct_decode(e[u].z, e[u].w)) - dir_slack : dist - delta;
+      if (t >= 0 && dist <= lim) CUROBO_MESH_COUNT(5, 1);
+      if (t >= 0 && dist <= lim && (lb <= 0.0f || lb * lb <= fminf(best_d2, l_d2))) {
+        CUROBO_MESH_COUNT(2, 1);
+        const TriRec r = mv.tri[t];
+        int region;
+        const f3 c = closest_on_triangle(qp, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+        const f3 d = qp - c;
+        const float d2 = dot(d, d);
+        if (d2 <= l_d2) {
+          // (an exact tie: the triangle kept so far stays in the verdict through its side term)
+          l_tie_term = d2 == l_d2 ? l_tie_term + mesh_side_term(mv.tri, mv.mp->tri_pn, l_t, l_region, qp - l_c) : 0.0f;
+          l_d2 = d2; l_c = c; l_t = t; l_region = region;
+        }
+      }
+      // what the group found so far clears later entries: no triangle whose bound exceeds it can be closer to p
+      if (u < 2 || u == U - 1) best_d2 = fminf(best_d2, group_min<G>(l_d2));
+    }
+    if (best_d2 < FAR) lim = fminf(lim, sqrtf(best_d2) * 1.000001f + delta);
+    // the last entry of the round (uniform over the group): past the prefix -> done; the sentinel -> the list is over, and it
+    // was complete only up to its cover
+    const int last_tri = __shfl(__float_as_int(e[U - 1].x), gbase | (G - 1), 64);
+    const float last_dist = __shfl(e[U - 1].y, gbase | (G - 1), 64);
+    if (last_tri < 0) { complete = last_dist >= lim; break; }
+    if (last_dist > lim) { complete = true; break; }
+  }
+  if (!complete) return false;
+  if (!(best_d2 <= max_distance * max_distance)) return true;  // nothing within max_distance: (max_distance, 0)
+  const float best_d = sqrtf(best_d2);
+  const bool winner = l_d2 == best_d2;
+  const unsigned win = group_ballot<G>(winner);
+  const int src = gbase | (__ffs((int)win) - 1);
+  const f3 cp = make_f3(__shfl(l_c.x, src, 64), __shfl(l_c.y, src, 64), __shfl(l_c.z, src, 64));
+  bool inside;
+  if (cell_side != 0u) inside = cell_side == 2u;  // (sign_rule 0 only: the build leaves 0 otherwise)
+  else {
+    // The side by the closest feature -- the face's normal, or the pseudonormal of the edge / vertex (Baerentzen & Aanaes) -- of
+    // EVERY triangle that attains the minimum: the sign of the sum of (p - closest point) . unit normal over them.  One
+    // triangle: mesh_feature_side's verdict.  A closest point on an edge that each of its two triangles files under "face" by a
+    // rounding: the sum of the two face normals IS the edge's pseudonormal.  A point on the bisector of two faces: both terms
+    // agree.  So no query of a closed mesh needs a ray here (the tree walk casts rays where mesh_feature_side gives no verdict:
+    // as a call from this kernel that cast cost a fifth of its registers, and handed to the walk kernel one such sphere costs
+    // the launch 100 us).  A mesh signed by the reference's rays (sign_rule 1) does go to the tree walk.
+    if (mv.mp->sign_rule != 0) return false;
+    float term = 0.0f;
+    if (winner && best_d2 > 1e-12f) term = l_tie_term + mesh_side_term(mv.tri, mv.mp->tri_pn, l_t, l_region, qp - l_c);
+    inside = group_sum_dpp<G>(term) < 0.0f;
+  }
+  if (best_d > 1e-6f) grad = (1.0f / best_d) * (qp - cp);
+  sdf = inside ? -best_d : best_d;
+  return true;
+}
+
+// one obstacle slot of a mesh set for the cell-list kernel: the mesh record stays in memory (see MeshCellsView), the pose goes
+// to the group's LDS record
+struct MeshPoseSlot {
+  const curobo_hip_mesh *mp;
+  float max_half_diag;
+  bool enabled;
+};
+__device__ __forceinline__ MeshPoseSlot load_mesh_pose_slot(const curobo_hip_mesh_set &ms, int env, int o, float *st) {
+  MeshPoseSlot s;
+  const int flat = env * ms.max_n + o;
+  s.enabled = o < ms.count[env] && ms.enable[flat] == 1;
+  s.mp = ms.meshes + (s.enabled ? ms.mesh_id[flat] : 0);
+  const float4 *ip = reinterpret_cast<const float4 *>(ms.inv_pose + (size_t)flat * 8);
+  const float4 p0 = ip[0], p1 = ip[1];
+  st[MESH_ST_T] = p0.x; st[MESH_ST_T + 1] = p0.y; st[MESH_ST_T + 2] = p0.z;
+  st[MESH_ST_Q] = p0.w; st[MESH_ST_Q + 1] = p1.x; st[MESH_ST_Q + 2] = p1.y; st[MESH_ST_Q + 3] = p1.z;
+  const float4 dm = *reinterpret_cast<const float4 *>(ms.dims + (size_t)flat * 4);
+  s.max_half_diag = 0.5f * sqrtf(dm.x * dm.x + dm.y * dm.y + dm.z * dm.z);
+  return s;
+}
+__device__ __forceinline__ f3 mesh_to_local_st(const float *st, f3 v) {
+  return quat_rot(st[MESH_ST_Q], st[MESH_ST_Q + 1], st[MESH_ST_Q + 2], st[MESH_ST_Q + 3], v) + st_load3(st, MESH_ST_T);
+}
+__device__ __forceinline__ f3 mesh_to_world_vector_st(const float *st, f3 v) {
+  return quat_rot(st[MESH_ST_Q], -st[MESH_ST_Q + 1], -st[MESH_ST_Q + 2], -st[MESH_ST_Q + 3], v);
+}
+
+// mesh_contribution with every query through the cell lists, by a group of G lanes; the item's cost and mesh-frame gradient are
+// ADDED to st[MESH_ST_COST] / st[MESH_ST_GRAD..].  The sphere (centre, neighbours, half steps) and the slot's pose are read from
+// the group's LDS record.  flags: bit 0 / 1 = the previous / next point exists.  Returns false when a query of the item could
+// not be answered by the lists: the caller then hands the sphere to the tree walk.
+template <int SWEEP, int G, int U>
+__device__ __forceinline__ bool mesh_contribution_cells(const MeshPoseSlot &s, int gradient_mode, float *st, unsigned flags,
+                                                        float r_adj, float eta, float reach, unsigned stat_q = 0u) {
+  const float max_distance = fmaxf(s.max_half_diag, r_adj);
+  const float cull_slack = 2e-6f + 1e-6f * max_distance;
+  const bool lipschitz = s.mp->sign_rule == 0;
+  const MeshCellsView mv = load_cells_view(s.mp, st);
+  const f3 lc = mesh_to_local_st(st, st_load3(st, MESH_ST_CENTER));
+  f3 ln = lc, qp = lc;
+  float half_dist = 0.0f, inv_half = 0.0f, jump = 0.0f;
+  float q_radius = (r_adj + reach + cull_slack) * 1.0001f + 1e-6f;
+  int dir = -1, k = 0;
+#pragma unroll 1
+  for (;;) {
+    f3 g;
+    float sdf;
+    if (!mesh_cells_sdf<G, U>(mv, qp, q_radius, max_distance, sdf, g, stat_q)) return false;
+    if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
+    const float pen = -sdf + r_adj;
+    float c = 0.0f, gs = 0.0f;
+    if (pen > 0.0f) {
+      activation_m(pen, eta, c, gs);
+      st[MESH_ST_COST] += c;
+      st_store3(st, MESH_ST_GRAD, st_load3(st, MESH_ST_GRAD) + gs * g);
+    }
+    if (dir < 0) { st[MESH_ST_PEN_C] = pen; st[MESH_ST_C_C] = c; st[MESH_ST_GS_C] = gs; st_store3(st, MESH_ST_GC, g); }
+    else {
+      if (pen > 0.0f) jump += pen;
+      else if (-pen >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen, r_adj);
+      k++;
+    }
+    if (SWEEP == 0) break;
+    bool have = false;
+#pragma unroll 1
+    while (!have) {
+      if (dir >= 0 && k < SWEEP && !(jump >= half_dist)) { have = true; break; }
+      dir++;
+      if (dir >= 2) break;
+      if (!((flags >> dir) & 1u)) continue;
+      const float pen_c = st[MESH_ST_PEN_C];
+      if (lipschitz && -pen_c > st[MESH_ST_HALF_PREV + dir] * 1.0001f + cull_slack) continue;
+      ln = mesh_to_local_st(st, st_load3(st, dir == 0 ? MESH_ST_PREV : MESH_ST_NEXT));
+      const f3 dd = ln - lc;
+      half_dist = sqrtf(dot(dd, dd)) * 0.5f;
+      inv_half = 1.0f / fmaxf(half_dist, 0.001f);
+      jump = 0.0f;
+      k = SWEEP;
+      if (jump >= half_dist) continue;
+      if (pen_c > 0.0f) {
+        st[MESH_ST_COST] += st[MESH_ST_C_C];
+        st_store3(st, MESH_ST_GRAD, st_load3(st, MESH_ST_GRAD) + st[MESH_ST_GS_C] * st_load3(st, MESH_ST_GC));
+        jump += pen_c;
+      }
+      else if (-pen_c >= 1000.0f) jump += r_adj;
+      else jump += fmaxf(-pen_c, r_adj);
+      k = 1;
+    }
+    if (!have) break;
+    const float tt = 1.0f - 0.5f * jump * inv_half;
+    qp = tt * lc + (1.0f - tt) * ln;
+    q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
+  }
+  return true;
 }
 
 __device__ __forceinline__ f3 mesh_to_world_vector(const MeshSlot &s, f3 v) {  // transform_vector(transform_inverse(inv_t), .)

@@ -1624,7 +1624,6 @@ __global__ void __launch_bounds__(256, 4) rollout_ik_fused_kernel(const FusedIkA
 
   // ---- costs + wrenches
   const float4 *sph = c.spheres(h);
-  const float *cumul = c.cumul + (size_t)h * L * 12;
   float *wr = c.wrench + (size_t)h * c.wl;
   float cost_pt = 0.0f;
   bool any_grad = false;

@@ -34,5 +34,5 @@ int check_launch(const char *what, hipStream_t stream) {
 }  // namespace curobo_hip
 
 CUROBO_EXPORT const char *curobo_hip_last_error(void) { return curobo_hip::g_err; }
-CUROBO_EXPORT int curobo_hip_abi_version(void) { return 6; }  // 6: curobo_hip_rollout_fused_shape_id / _set_shapes_enabled (compile-time shapes of the fused launch); 3: round-3 additions (mesh BVH, seed-IK LDS query); 4: RNEA launches with a transposition scratch; 5: curobo_hip_mesh_set.num_envs, the queued mesh launch
+CUROBO_EXPORT int curobo_hip_abi_version(void) { return 7; }  // 7: curobo_hip_mesh.sign_rule + cell lists, curobo_hip_mesh_set.flags, curobo_hip_mesh_cells_*; 6: curobo_hip_rollout_fused_shape_id / _set_shapes_enabled (compile-time shapes of the fused launch); 3: round-3 additions (mesh BVH, seed-IK LDS query); 4: RNEA launches with a transposition scratch; 5: curobo_hip_mesh_set.num_envs, the queued mesh launch
 CUROBO_EXPORT void curobo_hip_set_debug_sync(int enabled) { curobo_hip::g_debug_sync.store(enabled ? 1 : 0); }

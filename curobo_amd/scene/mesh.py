@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from ..backends.mesh import DeviceMesh, Mesh, MeshSet, build_mesh_bvh
+from ..backends.mesh import MESH_SET_HAS_CELLS, DeviceMesh, Mesh, MeshSet, build_mesh_bvh
 from .data import inverse_pose7
 
 
@@ -80,7 +80,8 @@ class MeshStore:
     #: outside it -- the opposite of what its cuboid and voxel queries return there); 1 = toward the obstacle on both sides
     REFERENCE_GRADIENT, CONSISTENT_GRADIENT = 0, 1
 
-    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 8, gradient_mode: int = 0):
+    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 8, gradient_mode: int = 0,
+                 cells=None, sign_rule: Optional[int] = None):
         self.device = torch.device(device)
         E = len(envs)
         n = max_n or max(1, max(len(e) for e in envs))
@@ -106,7 +107,7 @@ class MeshStore:
                     if o.get("scale") is not None:
                         v = v * np.asarray(o["scale"], np.float32).reshape(1, 3)
                     self.cache[key] = len(self.meshes)
-                    self.meshes.append(build_mesh_bvh(v, f, self.device, leaf_size))
+                    self.meshes.append(build_mesh_bvh(v, f, self.device, leaf_size, sign_rule=o.get("sign_rule", sign_rule), cells=cells))
                 mid = self.cache[key]
                 mesh_id[e, i] = mid
                 dims[e, i, :3] = self.meshes[mid].dims
@@ -119,7 +120,8 @@ class MeshStore:
         self._mesh_structs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device).contiguous()
         self.max_n, self.num_envs = n, E
         self.struct = MeshSet(self._mesh_structs.data_ptr(), self.mesh_id.data_ptr(), self.dims.data_ptr(), self.inv_pose.data_ptr(),
-                              self.enable.data_ptr(), self.count.data_ptr(), n, int(gradient_mode), E, 0)
+                              self.enable.data_ptr(), self.count.data_ptr(), n, int(gradient_mode), E,
+                              MESH_SET_HAS_CELLS if any(m.cell_start is not None for m in self.meshes) else 0)
         self.envs = envs
 
     def _slot(self, name: str, env_idx: int) -> int:

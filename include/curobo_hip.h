@@ -208,7 +208,32 @@ typedef struct curobo_hip_mesh {
    * Baerentzen & Aanaes 2005).  The sign of a query whose closest point lies on an edge or a vertex is the sign of
    * (point - closest) . pseudonormal; NULL = count ray crossings instead (three tree walks per such query). */
   const float *tri_pn;
-  int32_t n_tri, n_leaves, leaf_size, _pad;
+  int32_t n_tri, n_leaves, leaf_size;
+  /* ABI 7 (was padding = 0).  How inside / outside is decided:
+   *   0 = by the closest feature (face normal / pseudonormal; crossings counted when that gives no verdict): the same function
+   *       as the reference's rule on a closed, consistently oriented surface, without a ray;
+   *   1 = the reference's rule as published -- Warp's mesh_query_point -> mesh_query_inside (warp/native/mesh.h; called from
+   *       data_mesh.py:632,682): rays from the query point along +x, +y, +z, inside iff all three hit and every ray's NEAREST
+   *       hit is a back face.  The rule for meshes that are open or not consistently oriented, where the two differ. */
+  int32_t sign_rule;
+  /* ABI 7, optional: distance-sorted closest-triangle cell lists over a uniform grid in the mesh frame (NULL = every query
+   * walks the tree).  The grid covers the bounding box grown by grid_pad, cells of edge grid_h, cell (ix, iy, iz) has the
+   * index (ix * grid_n[1] + iy) * grid_n[2] + iz.  cell_start [n_cells + 1][2]: word 0: bits 0..29 = first entry of the cell's list in
+   * cell_list, bits 30..31 = 1 / 2 when every point of the cell is outside / inside the surface (sign_rule 0 only), else 0;
+   * word 1: the distance of the cell's centre from the surface (float bits).
+   * cell_list: 16-byte entries (int32 triangle index in sorted order, float distance of that triangle from the CELL CENTRE c,
+   * two floats = the octahedral code of the unit vector n from the triangle's closest point towards c), ascending in distance,
+   * closed by a sentinel (-1, cover, 0, 0): every triangle not listed is farther than `cover` from the centre.  A query point p
+   * at distance delta from its cell's centre goes through the list in order: an entry needs its triangle tested only when its
+   * bound distance + (p - c) . n (the triangle lies behind the plane through its closest point with normal n) does not exceed
+   * the best distance found; the query stops at the first entry whose distance - delta exceeds it (every later triangle is
+   * farther still: the result is the exact closest point); a list that ends before that (best > cover - delta) sends the query
+   * to the tree walk. */
+  const uint32_t *cell_start;
+  const int32_t *cell_list;
+  float grid_lo[3], grid_h;
+  int32_t grid_n[3];
+  float grid_pad;
 } curobo_hip_mesh;
 
 /* The mesh obstacles of a scene (layout of the reference's MeshData, data_mesh.py:60-120): meshes = DEVICE array of
@@ -217,6 +242,8 @@ typedef struct curobo_hip_mesh {
  * cuboids.  gradient_mode 0: the local gradient exactly as data_mesh.py:693-697 computes it, (p - closest) / |p - closest|
  * on either side of the surface; 1: that vector negated for centres outside the surface, i.e. minus the gradient of the
  * signed distance everywhere, which is what the cuboid (data_cuboid.py:596-626) and voxel kinds hand to the same kernel. */
+/* some mesh of the set carries cell lists: the queued launch answers what it can through them before it walks trees */
+#define CUROBO_HIP_MESH_SET_HAS_CELLS 1
 typedef struct curobo_hip_mesh_set {
   const curobo_hip_mesh *meshes;
   const int32_t *mesh_id;
@@ -225,7 +252,8 @@ typedef struct curobo_hip_mesh_set {
   const uint8_t *enable;
   const int32_t *count;
   int32_t max_n, gradient_mode;
-  int32_t num_envs, _pad;  /* leading dimension of mesh_id / dims / inv_pose / enable / count (ABI 5) */
+  int32_t num_envs;        /* leading dimension of mesh_id / dims / inv_pose / enable / count (ABI 5) */
+  int32_t flags;           /* ABI 7 (was padding = 0): CUROBO_HIP_MESH_SET_HAS_CELLS */
 } curobo_hip_mesh_set;
 
 /* Build: (1) Morton keys of the triangle centroids inside bounds_lo_hi_host (HOST pointer, 6 floats: the mesh's bounding
@@ -237,6 +265,21 @@ int curobo_hip_mesh_morton_codes(int64_t *out_codes, const float *vertices, cons
 int curobo_hip_mesh_bvh_build(float *out_tri, float *out_node_box, const float *vertices, const int32_t *faces,
                               const int64_t *sorted_codes, int n_faces, int n_leaves, int leaf_size,
                               curobo_hip_stream_t stream);
+
+/* The cell lists of a mesh (curobo_hip_mesh.cell_start / cell_list), in two launches around the caller's prefix sum and sort
+ * (plumbing, as for the Morton keys).  `mesh` (HOST pointer) carries the tree and the grid fields; its cell pointers are not
+ * read.  (1) count: per cell the length of its list including the sentinel -> out_count [n_cells], its cover radius ->
+ * out_cover [n_cells] (0 = the cell has no list: more than gather_cap triangles about equally far), the side of the whole
+ * cell -> out_side [n_cells] (1 outside / 2 inside / 0 may straddle), the distance of its centre from the surface ->
+ * out_centre_dist [n_cells].  (2) fill, given offsets [n_cells + 1] = the exclusive
+ * prefix sum of out_count as int64: out_entries [offsets[n_cells]][4] = (triangle, distance bits, direction code x, y), unsorted within a cell,
+ * out_keys [offsets[n_cells]] = cell << 32 | distance bits (sentinel: 0x7fffffff), out_cell_start [n_cells + 1][2] = the packed
+ * words of curobo_hip_mesh.cell_start.  The caller sorts the keys and gathers the entries with the permutation. */
+int curobo_hip_mesh_cells_count(int32_t *out_count, float *out_cover, uint8_t *out_side, float *out_centre_dist,
+                                const curobo_hip_mesh *mesh, int gather_cap, curobo_hip_stream_t stream);
+int curobo_hip_mesh_cells_fill(int64_t *out_keys, int32_t *out_entries, uint32_t *out_cell_start, const int64_t *offsets,
+                               const float *cover, const uint8_t *side, const float *centre_dist,
+                               const curobo_hip_mesh *mesh, curobo_hip_stream_t stream);
 
 /* compute_local_sdf_with_grad of data_mesh.py:630-700 for points [n, 3] in the mesh frame: out_sdf [n] = signed distance
  * (negative inside; max_distance when no surface lies within max_distance), out_grad [n, 3] (may be NULL) = (point -

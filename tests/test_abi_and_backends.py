@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), f"libcurobo_hip.so does not export {n}"
-    assert lib.curobo_hip_abi_version() == 6
+    assert lib.curobo_hip_abi_version() == 7
     assert isinstance(lib.curobo_hip_last_error(), bytes)
 
 

@@ -464,3 +464,127 @@ def test_seed_shards_over_a_mesh_scene_own_their_launch_workspaces(oracle, devic
     assert torch.isfinite(ref_cost).all() and float(ref_cost.max()) > 0
     torch.testing.assert_close(pipe.best_cost, ref_cost, rtol=1e-5, atol=1e-3)
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ cell lists (round 6)
+def _mesh_launch(device, world, sph, sweep, cells, **store_kw):
+    from curobo_amd.backends import mesh as M
+    from curobo_amd.scene import MeshStore
+
+    store = MeshStore(world, device, cells=cells, **store_kw)
+    b, h, S, _ = sph.shape
+    w, eta, dt = torch.tensor([3.0], device=device), torch.tensor([0.02], device=device), torch.tensor([0.05], device=device)
+    dist, grad = torch.full((b, h, S), 0.25, device=device), torch.full((b, h, S, 4), 0.5, device=device)
+    M.sphere_mesh_collision(dist, grad, sph, store.struct, w, eta, None, b, h, S, False, 3 if sweep else 0, sweep, dt, accumulate=False)
+    torch.cuda.synchronize()
+    owner = dist._base if dist._base is not None else dist
+    ws = next(iter(owner._curobo_mesh_ws.values()))
+    counters = ws[:16].view(torch.int32).cpu().numpy()  # [heavy, handed to the tree walk, light, -]
+    return dist.cpu().numpy(), grad.cpu().numpy(), counters, store
+
+
+@pytest.mark.parametrize("sweep", [False, True])
+@pytest.mark.parametrize("cell_size", [0.02, 0.05])
+def test_cell_list_launch_is_the_tree_walk_launch(sweep, cell_size, oracle, device):
+    """The queued mesh launch through the distance-sorted cell lists (select -> cell-list kernel -> tree walk of what the lists
+    cannot answer) against the same launch over meshes built WITHOUT lists (select -> tree walk): the closest point is the
+    same minimum over the same fp32 point-triangle distances, so costs are equal to the bit except where a sweep sample's
+    branch turns on a tie; and on these closed meshes (next to) no sphere is handed to the tree walk."""
+    world = mesh_world()
+    sph = torch.as_tensor(_trajectory_spheres(oracle, 96, 9, scale=0.5), device=device)  # (steps of a few centimetres)
+    d_c, g_c, cnt_c, store = _mesh_launch(device, world, sph, sweep, {"cell_size": cell_size})
+    d_w, g_w, cnt_w, _ = _mesh_launch(device, world, sph, sweep, False)
+    info = [m.cells_info for m in store.meshes]
+    assert all(i is not None and i["entries"] > i["cells"] for i in info)
+    live_c, live_w = int(cnt_c[0]) + int(cnt_c[2]), int(cnt_w[0]) + int(cnt_w[2])
+    # (the select kernel drops spheres whose cell is wholly outside and farther than their reach: fewer live spheres)
+    assert 100 < live_c <= live_w
+    # (a sphere that moves more than the grid's pad per step can still reach past it: at most a couple here)
+    assert cnt_w[1] == 0 and cnt_c[1] <= 2, (cnt_c, info)
+    assert 0.002 < (d_w > 0).mean() < 0.9
+    assert np.array_equal(d_c > 0, d_w > 0)
+    assert (d_c != d_w).mean() < 1e-4
+    np.testing.assert_allclose(d_c, d_w, rtol=2e-6, atol=1e-7)
+    bad = np.abs(g_c - g_w).max(-1) > 1e-5 + 1e-4 * np.abs(g_w).max(-1)
+    assert bad.mean() < 2e-3, bad.mean()   # (the medial axis: two triangles equally close)
+
+
+def test_cell_lists_fall_back_to_the_walk_beyond_the_grid_and_without_lists(oracle, device):
+    """a grid with no pad and a cap of one triangle per list: nearly every query is outside the grid or in a cell without a list, so
+    nearly every live sphere goes through queue2 to the tree walk -- and the results are still those of the walk launch.  Fast
+    trajectories (steps of decimetres: the sweep's reach exceeds any pad) do the same to the default grid."""
+    world = mesh_world()
+    sph = torch.as_tensor(_trajectory_spheres(oracle, 24, 9), device=device)
+    d_w, g_w, cnt_w, _ = _mesh_launch(device, world, sph, True, False)
+    for cells, least in (({"cell_size": 0.05, "pad": 0.0, "gather_cap": 1}, 0.5), ({}, 0.0)):
+        d_c, g_c, cnt_c, _ = _mesh_launch(device, world, sph, True, cells)
+        live = int(cnt_c[0]) + int(cnt_c[2])
+        assert cnt_c[1] >= least * live and (least == 0.0 or cnt_c[1] > 0)
+        np.testing.assert_allclose(d_c, d_w, rtol=2e-6, atol=1e-7)
+        bad = np.abs(g_c - g_w).max(-1) > 1e-5 + 1e-4 * np.abs(g_w).max(-1)
+        assert bad.mean() < 2e-3
+
+
+def _open_fixtures():
+    from test_oracle_mesh_sign import face_normals, plate, with_flipped, without_faces_facing
+
+    vb, fb = box_shape([0.3, 0.5, 0.2], 2)
+    n = face_normals(vb, fb)
+    return {
+        "open_box(+z missing)": without_faces_facing(vb, fb, [0, 0, 1]),
+        "open_box(-z missing)": without_faces_facing(vb, fb, [0, 0, -1]),
+        "single_sided_plate": plate(),
+        "box_one_flipped_face": with_flipped(vb, fb, [np.flatnonzero(n[:, 0] > 0.999)[3]]),
+    }
+
+
+@pytest.mark.parametrize("name", ["open_box(+z missing)", "open_box(-z missing)", "single_sided_plate", "box_one_flipped_face"])
+def test_open_and_flipped_meshes_take_the_reference_ray_sign(name, oracle, device):
+    """Meshes that are not closed or not consistently oriented are signed on the device by the reference's rule -- Warp's three
+    rays (+x, +y, +z; inside iff every ray's nearest hit is a back face), restated in the oracle in fp64 (``set_mesh_sign_rule("rays")``;
+    tests/test_oracle_mesh_sign.py) -- through both query paths: the point query (tree walk per lane) and the sphere launch (cell
+    lists).  On these fixtures the closest-feature rule would give another answer on up to half of the probes."""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.backends.mesh import SIGN_WARP_RAYS, build_mesh_bvh, mesh_query
+    from curobo_amd.scene import SceneData
+
+    v, f = _open_fixtures()[name]
+    mesh = build_mesh_bvh(v, f, device)
+    assert mesh.sign_rule == SIGN_WARP_RAYS and mesh.struct.sign_rule == 1
+    rng = np.random.default_rng(11)
+    p = rng.uniform(v.min(0) - 0.1, v.max(0) + 0.1, size=(4000, 3)).astype(np.float32)
+    oracle.set_mesh_sign_rule("rays")
+    try:
+        ref_sdf, _ = oracle.mesh_query(p, v, f, 10.0)
+        sdf, _ = mesh_query(mesh, torch.as_tensor(p, device=device), 10.0)
+        torch.cuda.synchronize()
+        sdf = sdf.cpu().numpy()
+        np.testing.assert_allclose(np.abs(sdf), np.abs(ref_sdf), atol=2e-6, rtol=1e-5)
+        # a probe whose ray passes within rounding of an edge or whose nearest hit is at rounding distance may differ: fp32 rays
+        # on the device against fp64 in the oracle -- a handful in thousands
+        off = np.abs(ref_sdf) > 1e-4
+        differ = ((sdf < 0) != (ref_sdf < 0)) & off
+        assert differ.mean() < 2e-3, differ.mean()
+        if name != "single_sided_plate":
+            assert (ref_sdf < 0).sum() >= (0 if name == "open_box(+z missing)" else 50)
+        # the sphere launch over the same mesh at a pose
+        pose = [0.05, -0.02, 0.3, 0.9659258, 0, 0.2588190, 0]
+        world = [[{"name": "m", "vertices": v, "faces": f, "pose": pose}]]
+        sph = np.concatenate([rng.uniform([-0.3, -0.4, 0.0], [0.4, 0.4, 0.6], size=(6000, 3)), rng.uniform(0.01, 0.05, size=(6000, 1))], 1)
+        sph = sph.astype(np.float32).reshape(8, 5, 150, 4)
+        for sweep in (False, True):
+            ref = oracle.scene_collision(sph, mesh_scene_arrays(world), 2.0, 0.02, sweep=sweep)
+            scene = SceneData.from_arrays(None, device, meshes=world)
+            assert scene.meshes.meshes[0].sign_rule == SIGN_WARP_RAYS
+            dist, grad = torch.zeros(8, 5, 150, device=device), torch.zeros(8, 5, 150, 4, device=device)
+            Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([2.0], device=device),
+                                         torch.tensor([0.02], device=device), None, 8, 5, 150, False, 3 if sweep else 0, False, None)
+            torch.cuda.synchronize()
+            d = dist.cpu().numpy()
+            bad = np.abs(d - ref["distance"]) > 2e-5 + 1e-4 * np.abs(ref["distance"])
+            assert (ref["distance"] > 0).mean() > 0.02
+            assert bad.mean() < (4e-3 if sweep else 2e-3), bad.mean()
+    finally:
+        oracle.set_mesh_sign_rule("winding")
