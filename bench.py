@@ -1627,8 +1627,9 @@ def ik_protocol_case(robot: str, collision_free: bool, torch, batch: int = 100) 
     over this package's ``InverseKinematics`` front end: batch 100, goals = FK of collision-free samples, `IK` = no collision
     terms with 2 seeds, `collision-free IK` = self collision + collision_table.yml with 8 (Franka) / 16 seeds, exit_early on, three
     warm-up solves, then the mean over five goal sets of the wall time of ``solve_pose`` (host clock around a synchronised call).
-    Differences: the packaged robot models keep their locked joints and collision links in the `IK` case (the reference strips
-    both there); seed-solver seed counts and the G1's 240 L-BFGS iterations are the reference's."""
+    The `IK` rows load the robot as the reference's benchmark does there (ik_benchmark.py:60-65: collision_link_names = None,
+    lock_joints = None -> the packaged ``<robot>_kinematics_only`` models: no spheres, only the joints on the chains to the tool
+    frames; goals from unrestricted joint samples); seed-solver seed counts and the G1's 240 L-BFGS iterations are the reference's."""
     import numpy as np
 
     from curobo_amd.solver.inverse_kinematics import InverseKinematics, InverseKinematicsCfg
@@ -1637,7 +1638,8 @@ def ik_protocol_case(robot: str, collision_free: bool, torch, batch: int = 100) 
     g1 = robot == "unitree_g1"
     seeds = (16 if robot in ("unitree_g1", "dual_ur10e") else 8) if collision_free else 2
     ik = InverseKinematics(InverseKinematicsCfg.create(
-        robot=f"{robot}.yml", scene_model="collision_table.yml" if collision_free else None, num_seeds=seeds, position_tolerance=0.005,
+        robot=f"{robot}.yml" if collision_free else f"{robot}_kinematics_only.yml", scene_model="collision_table.yml" if collision_free else None,
+        num_seeds=seeds, position_tolerance=0.005,
         optimizer_collision_activation_distance=0.0025, self_collision_check=collision_free, use_cuda_graph=True,
         seed_solver_num_seeds=128 if g1 else max(32, 2 * seeds), max_batch_size=batch, override_iters_for_multi_link_ik=240 if g1 else None))
     torch.manual_seed(2)
@@ -1672,6 +1674,7 @@ def ik_protocol_case(robot: str, collision_free: bool, torch, batch: int = 100) 
             rerr.append(float(np.percentile(r.rotation_error.view(-1)[ok].cpu().numpy(), 90)))
     col = 1 if collision_free else 0
     return {"robot": robot, "collision_free": collision_free, "batch": batch, "num_seeds": seeds, "tool_frames": len(ik.tool_frames), "dof": ik.dof,
+            "robot_model": f"{robot}.yml" if collision_free else f"{robot}_kinematics_only (collision links and locked joints stripped: ik_benchmark.py:60-65)",
             "ms": round(1e3 * float(np.mean(times)), 3), "ms_each": [round(1e3 * t, 3) for t in times], "success_percent": round(float(np.mean(succ)), 2),
             "position_error_p90_mm": round(1e3 * float(np.mean(perr)), 5) if perr else None,
             "rotation_error_p90_deg": round(float(np.degrees(np.mean(rerr))), 5) if rerr else None,

@@ -64,5 +64,41 @@ def main():
               f"({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def kinematics_only():
+    """The robot files as the reference's IK benchmark loads them for its `IK` rows (benchmark/ik_benchmark.py:60-65: collision_link_names
+    = None, lock_joints = None): no spheres, and only the joints on the chains to the tool frames -> <name>_kinematics_only.npz"""
+    import tempfile
+
+    import yaml
+
+    out_dir = os.path.join(ROOT, "curobo_amd", "content", "robot")
+    for name in ("franka", "dual_ur10e", "unitree_g1"):
+        yml = os.path.join(CONTENT, "configs", "robot", f"{name}.yml")
+        data = yaml.safe_load(open(yml))
+        k = data.get("robot_cfg", data)["kinematics"]
+        k["collision_link_names"], k["lock_joints"] = None, None
+        with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as f:
+            yaml.safe_dump(data, f)
+        model = load_robot_model(f.name, os.path.join(CONTENT, "assets"))
+        os.unlink(f.name)
+        if model.num_spheres == 0:
+            # one DISABLED sphere (negative radius, the convention of the attached-object placeholders) on the base link: the sphere
+            # buffers of every launch keep a non-empty shape, and no kernel counts a disabled sphere
+            import dataclasses
+
+            E = model.link_spheres.shape[0]
+            model = dataclasses.replace(
+                model, link_spheres=np.tile(np.array([[[0.0, 0.0, 0.0, -10.0]]], np.float32), (E, 1, 1)),
+                link_sphere_idx_map=np.zeros(1, model.link_sphere_idx_map.dtype), sphere_padding=np.zeros(1, np.float32),
+                collision_pairs=np.zeros((0, 2), model.collision_pairs.dtype))
+        path = os.path.join(out_dir, f"{name}_kinematics_only.npz")
+        model.save_npz(path)
+        print(f"{name}_kinematics_only: D={model.num_dof} L={model.num_links} S={model.num_spheres} T={len(model.tool_frames)} -> {path}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--kinematics-only" in sys.argv:
+        kinematics_only()
+    else:
+        main()
+        kinematics_only()

@@ -7,9 +7,13 @@ target of the rocprofv3 counter passes of tools/collect_profiles_r03.sh.  Worklo
   c4   Unitree G1, 256 x 4 x 33: FK, self_collision_tiles2_kernel, RNEA forward (staged kernels) / backward, c-space cost, FK VJP
   c5   Franka, 2 worlds (cuboids + 64^3 ESDF) x 512 x 4 x 65: the fused multi-env launch, the swept scene kernel
 
-  mesh bench.py's mesh world (the C2 cuboids as 12 288 triangles): sphere_mesh_select_kernel + sphere_mesh_walk_kernel
+  mesh bench.py's mesh world (the C2 cuboids as 12 288 triangles): sphere_mesh_select_kernel + sphere_mesh_cells_kernel (+ the
+       tree walk of what the cell lists cannot answer), and the same launch over meshes without lists (sphere_mesh_walk_kernel)
+  ik   C1 (the IK half of the metric): Franka, 100 problems x 64 seeds, 4-cuboid world: seed_ik_solve_kernel (128 Levenberg-
+       Marquardt runs per problem, 16 iterations), ik_rank_kernel, and the IK rollout rollout_ik_fused_kernel of one L-BFGS
+       iteration (100 x 64 x 4 line-search candidates)
 
-Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [mesh] [--reps N]
+Usage: python tools/run_kernels_once.py [c2] [c3] [c4] [c5] [mesh] [trajopt] [ik] [--reps N]
 """
 import os
 import sys
@@ -140,6 +144,33 @@ def mesh():
     ro.compute_kinematics(ro.compute_state_from_action(x.view(B, cfg.n_knots, -1)))
     run(lambda: Cn.sphere_obstacle_collision(ro.scene_dist, ro.scene_grad, ro.robot_spheres, scene.struct, ro._w_scene, ro._eta,
                                              ro.env_query_idx, B, cfg.padded_horizon, kin.num_spheres, False, 3, True, ro._speed_dt))
+    from curobo_amd.scene import MeshStore
+
+    walk = SceneData.from_arrays(None, dev, meshes=MeshStore(B_.c2_world_as_meshes(), dev, cells=False))
+    run(lambda: Cn.sphere_obstacle_collision(ro.scene_dist, ro.scene_grad, ro.robot_spheres, walk.struct, ro._w_scene, ro._eta,
+                                             ro.env_query_idx, B, cfg.padded_horizon, kin.num_spheres, False, 3, True, ro._speed_dt))
+
+
+def ik():
+    """C1 shapes: the Levenberg-Marquardt seed solver (seed_ik_solve_kernel + ik_rank_kernel) as bench.py's `ik` object times it,
+    and one evaluation of the IK rollout over 100 x 64 x 4 rows (rollout_ik_fused_kernel), plain launches"""
+    from curobo_amd.kinematics import KinematicsCfg
+    from curobo_amd.scene import SceneData, cuboid_scene_arrays
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+    from curobo_amd.workloads import c1_world, feasible_goals
+
+    kcfg = KinematicsCfg.from_packaged("franka", device=dev)
+    kin = kcfg.kinematics_config
+    scene = SceneData.from_arrays(cuboid_scene_arrays(c1_world()), dev)
+    P, S = 100, 64
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=S, stream_shards=1, use_cuda_graph=False)
+                      if "use_cuda_graph" in IKSolverCfg.__dataclass_fields__ else IKSolverCfg(num_seeds=S, stream_shards=1))
+    gp, gq = feasible_goals(kin, scene, P)
+    T = kin.num_pose_links
+    gp4, gq4 = gp.to(dev).view(P, T, 1, 3).contiguous(), gq.to(dev).view(P, T, 1, 4).contiguous()
+    ss = solver.seed_solver
+    run(lambda: ss.solve_batch(gp4, gq4, return_seeds=S))
+    run(lambda: solver.solve_pose(gp, gq, exit_early=False), 2)  # (every kernel of a full solve, the IK rollout among them)
 
 
 def trajopt():
@@ -161,7 +192,7 @@ def trajopt():
 
 
 if __name__ == "__main__":
-    known = ("c2", "c3", "c4", "c5", "mesh", "trajopt")
+    known = ("c2", "c3", "c4", "c5", "mesh", "trajopt", "ik")
     want = [a for a in sys.argv[1:] if a in known] or list(known)
     for w in want:
         globals()[w]()
