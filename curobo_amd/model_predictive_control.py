@@ -46,17 +46,21 @@ class ModelPredictiveControlCfg:
                optimizer_collision_activation_distance: float = 0.01, optimization_dt: float = 0.02, interpolation_steps: int = 4,
                num_control_points: Optional[int] = None, warm_start_optimization_num_iters: Optional[int] = None,
                cold_start_optimization_num_iters: Optional[int] = None, max_batch_size: int = 1, max_goalset: int = 1,
-               assets_root: str = "", continuous_commands: bool = False, **unused) -> "ModelPredictiveControlCfg":
+               assets_root: str = "", continuous_commands: bool = False, task: str = "package", **unused) -> "ModelPredictiveControlCfg":
         """Arguments of the reference's ``MPCSolverCfg.create`` (solver_mpc_cfg.py:126-165).  Task / optimiser yaml arguments are
         accepted and ignored (the cost set and optimiser of ``content/configs/task/mpc/`` are built in); the iteration counts
         default to this backend's (100 cold / 25 warm L-BFGS iterations: its line search evaluates four step sizes per
-        iteration).  ``continuous_commands``: see ``MPCSolverCfg`` (False = the reference's command indexing)."""
+        iteration).  ``continuous_commands``: see ``MPCSolverCfg`` (False = the reference's command indexing).
+        ``task``: "package" = this package's MPC task values, "reference" = ``MPCSolverCfg.reference_task()``."""
         if max_goalset != 1:
             raise ValueError("the MPC front end tracks one goal pose per tool frame (max_goalset must be 1)")
         device_cfg = device_cfg or DeviceCfg()
         kin = _load_kinematics(robot, device_cfg.device, assets_root)
-        s = MPCSolverCfg(optimization_dt=optimization_dt, interpolation_steps=interpolation_steps, use_cuda_graph=use_cuda_graph,
-                         continuous_commands=continuous_commands)
+        if task not in ("package", "reference"):
+            raise ValueError(f"task must be 'package' or 'reference', got {task!r}")
+        make = MPCSolverCfg.reference_task if task == "reference" else MPCSolverCfg  # (lbfgs_mpc.yml's values + 300 / 200 iterations)
+        s = make(optimization_dt=optimization_dt, interpolation_steps=interpolation_steps, use_cuda_graph=use_cuda_graph,
+                 continuous_commands=continuous_commands)
         if num_control_points is not None:
             s.n_knots = int(num_control_points)
         if warm_start_optimization_num_iters is not None:

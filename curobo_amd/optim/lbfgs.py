@@ -54,6 +54,18 @@ class LBFGSOptCfg:
     #: drop-in launches of the reference's iteration
     fused_tail: bool = True
 
+    def improvement_thresholds(self) -> Tuple[float, float]:
+        """(cost_delta_threshold, cost_relative_threshold) as the kernels get them.  Reference optim/gradient/gradient_descent.py:
+        68-75 (the base of its LBFGSOptCfg): with a fixed iteration count both are switched off -- they feed the line-search kernel's
+        `update_best = cost_delta > delta_threshold && cost_relative > relative_threshold` (line_search_helpers.cuh:33), so a task
+        file's `cost_relative_threshold: 1.0` (lbfgs_mpc.yml) would otherwise freeze the best iterate at the seed -- and a relative
+        threshold of 1 or more is an error.  (Evaluated at use, not at construction: `fixed_iters` is switched after the fact.)"""
+        if self.fixed_iters:
+            return 0.0, 0.0
+        if self.cost_relative_threshold >= 1.0:
+            raise ValueError("cost_relative_threshold must be less than 1.0")
+        return float(self.cost_delta_threshold), float(self.cost_relative_threshold)
+
 
 class LBFGSOpt:
     """``optimize(seed)`` runs ``num_iters`` iterations on ``num_problems`` independent problems.
@@ -141,7 +153,7 @@ class LBFGSOpt:
             self._evaluate_search_points()
             optimization_hip.launch_lbfgs_iteration_tail(
                 self.best_cost, self.best_action, self.best_iteration, self.current_iteration, self.converged,
-                cfg.convergence_iteration, cfg.cost_delta_threshold, cfg.cost_relative_threshold,
+                cfg.convergence_iteration, *cfg.improvement_thresholds(),
                 self.exploration_cost, self.exploration_action, self.exploration_gradient,
                 self.exploration_idx.view(-1), self.cost, self.action, self.gradient, self.selected_idx.view(-1),
                 self.search_cost, self.x_set, self.search_gradient, self.step_scaled, self._alphas,
@@ -156,7 +168,7 @@ class LBFGSOpt:
         self._evaluate_search_points()
         optimization_hip.launch_line_search(
             self.best_cost, self.best_action, self.best_iteration, self.current_iteration, self.converged,
-            cfg.convergence_iteration, cfg.cost_delta_threshold, cfg.cost_relative_threshold,
+            cfg.convergence_iteration, *cfg.improvement_thresholds(),
             self.exploration_cost, self.exploration_action, self.exploration_gradient,
             self.exploration_idx.view(-1), self.cost, self.action, self.gradient, self.selected_idx.view(-1),
             self.search_cost, self.x_set, self.search_gradient, self.step_scaled, self._alphas,

@@ -65,8 +65,8 @@ class MPCSolverCfg:
         """The cost weights and optimiser settings of the reference's MPC task file, content/configs/task/mpc/lbfgs_mpc.yml, instead of
         this package's defaults above (which were tuned on this package's own closed-loop tests: lower pose weights, stronger joint-state
         bounds, retimed weights, 15-deep history, 100 / 25 iterations).  The values are held to the file by
-        ``tests/test_types_members.py::test_mpc_reference_task_is_the_reference_file``; the closed-loop behaviour with them has not been
-        measured on the GPU."""
+        ``tests/test_types_members.py::test_mpc_reference_task_is_the_reference_file``; the closed-loop behaviour of both value sets is
+        measured by ``tools/r06/mpc_task_compare.py``."""
         rollout = TrajOptRolloutCfg(
             non_terminal_pose_factor=1.0, pose_weight=[5000.0, 200.0], pose_convergence_tolerance=[0.0, 0.0],
             cspace_weight=[1000.0, 1000.0, 1000.0, 100.0, 0.0], cspace_activation_distance=[0.01] * 5,
@@ -75,7 +75,11 @@ class MPCSolverCfg:
             scene_activation_distance=0.01, scene_collision_weight=10000.0, use_sweep=True, use_speed_metric=True, self_collision_weight=100000.0)
         optimizer = LBFGSOptCfg(history=27, inner_iters=25, num_iters=50, cost_relative_threshold=1.0, line_search_c_1=1e-3, line_search_c_2=0.98,
                                 epsilon=0.01, step_scale=0.98, line_search_scale=[0.0, 0.1, 0.5, 1.0])
-        return MPCSolverCfg(**{**dict(rollout=rollout, optimizer=optimizer), **overrides})
+        # the iteration counts of the reference's MPCSolverCfg itself (solver_mpc_cfg.py:75-78): 300 for the first solve, 200 for every
+        # warm-started one -- eight times this package's 25: with the file's acceleration regularisation (10 000) the short warm
+        # starts of the package defaults stall centimetres from the goal (profiles/r06_b_mpc_task_compare.json)
+        return MPCSolverCfg(**{**dict(rollout=rollout, optimizer=optimizer, cold_start_optimization_num_iters=300,
+                                      warm_start_optimization_num_iters=200), **overrides})
 
 
 @dataclass

@@ -30,6 +30,7 @@ with one all-gather (``curobo_amd.distributed``).
 from __future__ import annotations
 
 import dataclasses
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -41,6 +42,11 @@ from ..robot.kinematics_params import KinematicsParams
 from ..rollout.trajopt_rollout import TrajOptRollout, TrajOptRolloutCfg, joint_limit_vector
 from ..scene.data import SceneData
 from .ik import IKSolver, IKSolverCfg
+
+
+#: where the free knots of a straight-line seed sit when a configuration does not say (see TrajOptSolverCfg.seed_knot_placement);
+#: CUROBO_SEED_KNOT_PLACEMENT overrides it for A/B measurements
+DEFAULT_SEED_KNOT_PLACEMENT = "reference"
 
 
 @dataclass
@@ -73,10 +79,12 @@ class TrajOptSolverCfg:
     #: success also needs the trajectory re-sampled at ``interpolation_dt`` to stay inside the position / velocity /
     #: acceleration / jerk limits and free of self and scene collision (reference interpolated_rollout, :475-497)
     check_interpolated: bool = True
-    #: where the free knots of a straight-line seed sit: "even" = interior points of linspace(0, 1, n_knots + 2) (this package's,
-    #: the default every measurement of this repository was taken with); "reference" = linspace(0, 1, n_knots) including both ends,
-    #: as util/trajectory_seed_generator.py:16-40 places them (first free knot on the start, last on the goal)
-    seed_knot_placement: str = "even"
+    #: where the free knots of a straight-line seed sit: "reference" (the default since round 6) = linspace(0, 1, n_knots) including
+    #: both ends, as util/trajectory_seed_generator.py:16-40 places them (first free knot on the start, last on the goal); "even" =
+    #: interior points of linspace(0, 1, n_knots + 2) (this package's placement up to round 5).  Measured on 100 random Franka problems
+    #: in two worlds (profiles/r06_b_planner_benchmark_seed_knots_*.json): the same success (100 % / 97 %), the same motion times to
+    #: four digits, median plan time 10.0 / 10.9 ms against 10.3 / 10.9 ms -- the optimiser forgets the parametrisation of its seed.
+    seed_knot_placement: str = field(default_factory=lambda: os.environ.get("CUROBO_SEED_KNOT_PLACEMENT", DEFAULT_SEED_KNOT_PLACEMENT))
 
 
 @dataclass
@@ -202,10 +210,10 @@ class TrajOptSolver:
 
     def seed_knots(self, start: torch.Tensor, goal_config: torch.Tensor, choice: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[P, S_global, n_knots, D]: straight joint-space lines start -> the seed's goal configuration
-        (reference seed generation, solver_trajopt.py:390-420).  Knot placement DIFFERS from the reference's generator
-        (util/trajectory_seed_generator.py:16-40: weights linspace(0, 1, n_knots) INCLUDING both ends, so its first free knot
-        repeats the start and its last the goal -- a line that leaves and arrives slowly); here the free knots are the interior
-        points of linspace(0, 1, n_knots + 2), evenly spaced between the boundary knots.  Both are the same straight line in joint
+        (reference seed generation, solver_trajopt.py:390-420).  Knot placement as the reference's generator has it by default
+        (util/trajectory_seed_generator.py:16-40: weights linspace(0, 1, n_knots) INCLUDING both ends, so the first free knot
+        repeats the start and the last the goal -- a line that leaves and arrives slowly); ``seed_knot_placement = "even"`` puts
+        the free knots on the interior points of linspace(0, 1, n_knots + 2) instead.  Both are the same straight line in joint
         space; only seeds differ, not costs.  ``start`` [1 or P, D], ``goal_config`` [P, K, D] (or [P, D]), ``choice``
         [P, S_global] from ``seed_goal_choice``; a seed that repeats an earlier seed's goal adds a smooth
         mid-trajectory bump so that the seeds stay distinct.  Every rank builds the global set (host generator)."""

@@ -251,6 +251,19 @@ def test_mpc_reference_task_is_the_reference_file():
     assert (float(opt["line_search_wolfe_c_1"]), float(opt["line_search_wolfe_c_2"])) == (o.line_search_c_1, o.line_search_c_2)
     assert (float(opt["cost_relative_threshold"]), float(opt["epsilon"]), float(opt["step_scale"]), opt["stable_mode"], opt["fixed_iters"]) == \
         (o.cost_relative_threshold, o.epsilon, o.step_scale, o.stable_mode, o.fixed_iters)
+    # ... which reaches the kernels as the reference's optimiser hands it over: with fixed_iters both improvement thresholds are zero
+    # (optim/gradient/gradient_descent.py:68-75); the file's 1.0 taken literally freezes the best iterate at the seed
+    assert o.improvement_thresholds() == (0.0, 0.0)
+    import dataclasses
+    with pytest.raises(ValueError):
+        dataclasses.replace(o, fixed_iters=False).improvement_thresholds()
+    assert dataclasses.replace(o, fixed_iters=False, cost_relative_threshold=0.01).improvement_thresholds() == (0.0, 0.01)
+    # the iteration counts are those of the reference's MPCSolverCfg (solver_mpc_cfg.py:75-78)
+    import re
+    src = open("/root/reference/curobo/_src/solver/solver_mpc_cfg.py").read()
+    warm = int(re.search(r"warm_start_optimization_num_iters: int = (\d+)", src).group(1))
+    cold = int(re.search(r"cold_start_optimization_num_iters: int = (\d+)", src).group(1))
+    assert (c.cold_start_optimization_num_iters, c.warm_start_optimization_num_iters) == (cold, warm) == (300, 200)
 
 
 @pytest.mark.parametrize("task,path", [("ik", "ik/particle_ik.yml"), ("trajopt", "trajopt/particle_trajopt.yml")])

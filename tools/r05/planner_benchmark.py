@@ -7,8 +7,12 @@ import json
 import sys
 import time
 
+import os
+
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from curobo_amd.motion_planner import MotionPlanner, MotionPlannerCfg
 from curobo_amd.scene.types import Cuboid, SceneCfg
