@@ -410,6 +410,9 @@ __global__ void __launch_bounds__(256) sphere_mesh_collision_kernel(const MeshCo
 #ifndef MESH_HEAVY_FIRST
 #define MESH_HEAVY_FIRST 1
 #endif
+#ifndef MESH_LONG_LIST
+#define MESH_LONG_LIST 96  // entries in the list of the centre's cell from which a sphere counts as one of the launch's long chains
+#endif
 struct MeshQueueArgs {
   MeshCollArgs c;
   uint32_t *counter;  // workspace words 0 (entries from the head), 2 (entries from the tail), 1 (entries of queue2)
@@ -504,10 +507,15 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
           // (mesh_early_reject on the staged root box)
           const float ex = fmaxf(fmaxf(rec[7] - lc.x, lc.x - rec[10]), 0.0f), ey = fmaxf(fmaxf(rec[8] - lc.y, lc.y - rec[11]), 0.0f),
                       ez = fmaxf(fmaxf(rec[9] - lc.z, lc.z - rec[12]), 0.0f);
+          int list_len;
           if (!(ex * ex + ey * ey + ez * ez > thr * thr * 1.00001f) &&
-              !mesh_cell_clear(s_grid[(a.use_multi_env ? (bb[c] - first_b) * a.nslots : 0) + k], lc, thr)) {
+              !mesh_cell_clear(s_grid[(a.use_multi_env ? (bb[c] - first_b) * a.nslots : 0) + k], lc, thr, list_len)) {
             live[c] |= 1u << k;
-            if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rec[7] || lc.y < rec[8] || lc.z < rec[9] || lc.x > rec[10] || lc.y > rec[11] || lc.z > rec[12]);
+            // the long chains of the launch: with cell lists the spheres whose centre's cell has a long list (inside a block every
+            // face is about equally far), without them the spheres inside a mesh's bounding box
+            if (MESH_HEAVY_FIRST)
+              heavy = heavy || (list_len >= 0 ? list_len >= MESH_LONG_LIST
+                                              : !(lc.x < rec[7] || lc.y < rec[8] || lc.z < rec[9] || lc.x > rec[10] || lc.y > rec[11] || lc.z > rec[12]));
           }
         }
       } else {
@@ -516,10 +524,13 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
           const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
           if (!slot.enabled) continue;
           const f3 lc = mesh_to_local(slot, center);
-          if (!mesh_early_reject(slot, lc, r_adj, reach[c]) && !mesh_cell_clear(load_grid_rec(slot.m, true), lc, r_adj + reach[c])) {
+          int list_len;
+          if (!mesh_early_reject(slot, lc, r_adj, reach[c]) && !mesh_cell_clear(load_grid_rec(slot.m, true), lc, r_adj + reach[c], list_len)) {
             live[c] |= 1u << k;
             const float *rb = slot.m.node_box + 8;
-            if (MESH_HEAVY_FIRST) heavy = heavy || !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]);
+            if (MESH_HEAVY_FIRST)
+              heavy = heavy || (list_len >= 0 ? list_len >= MESH_LONG_LIST
+                                              : !(lc.x < rb[0] || lc.y < rb[1] || lc.z < rb[2] || lc.x > rb[4] || lc.y > rb[5] || lc.z > rb[6]));
           }
         }
       }
@@ -694,7 +705,7 @@ __global__ void __launch_bounds__(MESH_WALK_THREADS) MESH_WALK_ATTR sphere_mesh_
 #define MESH_CELLS_HEAVY_UNROLL 2
 #endif
 #ifndef MESH_CELLS_ATTR
-#define MESH_CELLS_ATTR
+#define MESH_CELLS_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // 128 registers (142 unconstrained: three wavefronts a SIMD): 179 -> 156 us
 #endif
 // PART 0: the whole queue; 1: the entries queued from its head (centre inside a live mesh's bounding box: the long lists of
 // cells inside a surface); 2: the entries queued from its tail.

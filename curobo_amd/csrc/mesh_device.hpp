@@ -723,13 +723,16 @@ __device__ __forceinline__ MeshGridRec load_grid_rec(const curobo_hip_mesh &m, b
 // true when a sphere whose centre is lc (mesh frame) cannot touch the surface within `thr` (= r_adj + the reach of its sweep)
 // anywhere along its sweep: its cell is wholly outside the (closed) surface and its centre farther than thr from it.  Result
 // preserving for the reasons of mesh_early_reject, with the exact distance of the cell's centre in place of the bounding box.
-__device__ __forceinline__ bool mesh_cell_clear(const MeshGridRec &g, f3 lc, float thr) {
+__device__ __forceinline__ bool mesh_cell_clear(const MeshGridRec &g, f3 lc, float thr, int &list_len) {
+  list_len = -1;  // unknown: no cells, or outside the grid
   if (g.cell_start == nullptr) return false;
   const float inv_h = __frcp_rn(g.h);
   const float fx = (lc.x - g.lx) * inv_h, fy = (lc.y - g.ly) * inv_h, fz = (lc.z - g.lz) * inv_h;
   const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
   if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && ix < g.nx && iy < g.ny && iz < g.nz)) return false;
-  const uint2 rec = g.cell_start[(ix * g.ny + iy) * g.nz + iz];
+  const int cell = (ix * g.ny + iy) * g.nz + iz;
+  const uint2 rec = g.cell_start[cell];
+  list_len = (int)((g.cell_start[cell + 1].x & 0x3fffffffu) - (rec.x & 0x3fffffffu)) - 1;
   if ((rec.x >> 30) != 1u) return false;
   const f3 dv = lc - make_f3(g.lx + ((float)ix + 0.5f) * g.h, g.ly + ((float)iy + 0.5f) * g.h, g.lz + ((float)iz + 0.5f) * g.h);
   const float delta = sqrtf(dot(dv, dv)) * 1.0001f + 2e-6f;
