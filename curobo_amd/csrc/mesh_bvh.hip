@@ -536,8 +536,13 @@ __global__ void __launch_bounds__(256) sphere_mesh_select_kernel(const MeshQueue
       }
     }
     if (in && live[c] == 0u && !a.accumulate) {
+#ifdef MESH_SELECT_PLAIN_STORES
       a.distance[sidx] = 0.0f;
       reinterpret_cast<float4 *>(a.gradient)[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else  // written once, read by a later launch: past the caches' allocate-on-write
+      __builtin_nontemporal_store(0.0f, a.distance + sidx);
+      store_float4_streaming(reinterpret_cast<float4 *>(a.gradient) + sidx, make_float4(0.f, 0.f, 0.f, 0.f));
+#endif
     }
     if (heavy) heavy_bits |= 1u << c;
   }

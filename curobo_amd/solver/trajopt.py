@@ -84,6 +84,8 @@ class TrajOptSolverCfg:
     #: interior points of linspace(0, 1, n_knots + 2) (this package's placement up to round 5).  Measured on 100 random Franka problems
     #: in two worlds (profiles/r06_b_planner_benchmark_seed_knots_*.json): the same success (100 % / 97 %), the same motion times to
     #: four digits, median plan time 10.0 / 10.9 ms against 10.3 / 10.9 ms -- the optimiser forgets the parametrisation of its seed.
+    #: the retime + metrics pass after every optimisation pass replayed from a hipGraph (``TrajOptSolver._metrics_pass``); False = eager
+    capture_metrics_pass: bool = field(default_factory=lambda: os.environ.get("CUROBO_CAPTURE_METRICS_PASS", "1") != "0")
     seed_knot_placement: str = field(default_factory=lambda: os.environ.get("CUROBO_SEED_KNOT_PLACEMENT", DEFAULT_SEED_KNOT_PLACEMENT))
 
 
@@ -158,6 +160,7 @@ class TrajOptSolver:
                                   use_cuda_graph=use_cuda_graph)
         self.optimizer.rank_sharded = self.S_global != self.S  # seeds split over ranks: the convergence exit is a collective
         self._check = _InterpolatedCheck(kin, scene, rc) if self.cfg.check_interpolated else None
+        self._pass_graphs: dict = {}  # captured metrics passes, per goal kind (_metrics_pass)
 
     @classmethod
     def sharded(cls, kin: KinematicsParams, scene: Optional[SceneData], num_problems: int,
@@ -449,10 +452,7 @@ class TrajOptSolver:
             passes += 1
             knots = opt.reshape(P * S, nk, D).contiguous()
             # retime every seed to the fastest dt its optimised trajectory allows, then the metrics at that dt
-            m.compute_state_from_action(knots)
-            new_dt = self.compute_trajectory_dt(m.velocity, m.acceleration, m.jerk, cur_dt)
-            self._set_dt(new_dt)
-            r = self._seed_metrics(knots, new_dt, start, seed_goal, use_implicit_goal)
+            new_dt, r = self._metrics_pass(knots, cur_dt, start, seed_goal, use_implicit_goal)
             self.last_pass_trace.append(dict(run_dt=cur_dt.view(P, S).clone(), retimed_dt=new_dt.view(P, S).clone(),
                                              success=r["success"].view(P, S).clone()))
             if best is None:
@@ -470,6 +470,46 @@ class TrajOptSolver:
         res.implicit_goal = bool(use_implicit_goal)
         return res
 
+    def _metrics_pass_eager(self, knots, cur_dt, start, seed_goal, use_implicit_goal, static_steps=None):
+        m = self.metrics_rollout
+        m.compute_state_from_action(knots)
+        new_dt = self.compute_trajectory_dt(m.velocity, m.acceleration, m.jerk, cur_dt)
+        self._set_dt(new_dt)
+        return new_dt, self._seed_metrics(knots, new_dt, start, seed_goal, use_implicit_goal, static_steps)
+
+    def _metrics_pass(self, knots, cur_dt, start, seed_goal, use_implicit_goal):
+        """State from the knots -> retimed dt -> metrics rollout -> per-seed success and rank cost (reference solver_trajopt.py:
+        469-484 + rollout/metrics.py:233-265).  Run eagerly the pass is ~360 small launches (torch element-wise kernels around the
+        metrics rollout's), ~2 ms of host time per pass at ~6 us each; it has no data-dependent shape once the interpolated check
+        samples for the LONGEST trajectory the dt range allows instead of reading the longest one back, so it is captured once
+        per (solver, goal kind) into a hipGraph and replayed.  Inputs are copied into the graph's buffers, outputs are cloned out
+        of them (the next pass overwrites them).  Not on a seed shard (``_set_dt`` is a collective there) and not without graphs."""
+        if not (self._use_graph and self.S_global == self.S and knots.is_cuda and self.cfg.capture_metrics_pass):
+            return self._metrics_pass_eager(knots, cur_dt, start, seed_goal, use_implicit_goal)
+        key = bool(use_implicit_goal)
+        g = self._pass_graphs.get(key)
+        if g is None:
+            rc, cfg = self.cfg.rollout, self.cfg
+            # samples of the longest trajectory: knot spacing maximum_trajectory_dt x interpolation_steps (calculate_traj_steps)
+            per = int((cfg.maximum_trajectory_dt * rc.interpolation_steps + cfg.interpolation_dt) / cfg.interpolation_dt)
+            static_steps = -(-((rc.n_knots + rc.bspline_degree + 1) * per + 1) // 32) * 32
+            buf = dict(knots=knots.clone(), cur_dt=cur_dt.clone(), start=start.clone(), seed_goal=seed_goal.clone())
+            run = lambda: self._metrics_pass_eager(buf["knots"], buf["cur_dt"], buf["start"], buf["seed_goal"], use_implicit_goal, static_steps)  # noqa: E731
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up off the capture (allocations, lazily built tables)
+                run()
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_dt, out = run()
+            g = self._pass_graphs[key] = dict(graph=graph, buf=buf, out_dt=out_dt, out=out)
+        b = g["buf"]
+        b["knots"].copy_(knots); b["cur_dt"].copy_(cur_dt); b["start"].copy_(start.expand_as(b["start"])); b["seed_goal"].copy_(seed_goal)
+        g["graph"].replay()
+        return g["out_dt"].clone(), {k: v.clone() for k, v in g["out"].items()}
+
     @staticmethod
     def _any(mask: torch.Tensor) -> bool:
         """``mask.any()`` over the seeds of ALL ranks (the host decisions of the finetune loop, reference :441-450, are taken
@@ -478,7 +518,7 @@ class TrajOptSolver:
 
         return bool(all_reduce_max(mask.any().to(torch.int32).view(1)).item())
 
-    def _seed_metrics(self, knots, dt, start, seed_goal, use_implicit_goal) -> dict:
+    def _seed_metrics(self, knots, dt, start, seed_goal, use_implicit_goal, static_steps=None) -> dict:
         """metrics rollout of P * S optimised seeds at their dt: success = feasible over the horizon (and on the
         interpolated trajectory) and converged at the last point (reference _process_metrics, solver_trajopt_result.py:
         143-238); rank cost of _jit_compute_rank (:271-300)"""
@@ -507,7 +547,7 @@ class TrajOptSolver:
         if self._check is not None:
             env = m.env_query_idx if m.use_multi_env else None
             feasible &= self._check.feasible(knots, dt, start.expand(P, D).contiguous(), self._mrow_problem, seed_goal.reshape(P * S, D),
-                                             use_implicit_goal, cfg.interpolation_dt, env)
+                                             use_implicit_goal, cfg.interpolation_dt, env, static_steps=static_steps)
         converged = (pos_err < cfg.position_threshold) & (rot_err < cfg.rotation_threshold)
         ok = feasible & converged
         H = q.shape[1]
@@ -622,7 +662,7 @@ class _InterpolatedCheck:
         self._env0 = z(B, dt=torch.int32)
         self._shape = (B, n)
 
-    def feasible(self, knots, dt, start, start_rows, goal, implicit, interpolation_dt, env_query_idx) -> torch.Tensor:
+    def feasible(self, knots, dt, start, start_rows, goal, implicit, interpolation_dt, env_query_idx, static_steps=None) -> torch.Tensor:
         from ..backends import collision as collision_hip
         from ..backends import geometry as geometry_hip
         from ..backends import kinematics as kinematics_hip
@@ -632,15 +672,19 @@ class _InterpolatedCheck:
         B, nk, D = knots.shape
         knot_dt = dt * rc.interpolation_steps
         total = nk + rc.bspline_degree + 1
-        _, steps_max = calculate_traj_steps(knot_dt, torch.full_like(knot_dt, float(interpolation_dt)), total + 1, nearest_int=True)
-        n = -(-int(steps_max) // 32) * 32  # (one device -> host read per pass; buffers grow in steps of 32 samples)
+        if static_steps is not None:  # (a captured pass: the longest trajectory the dt range allows, no read-back)
+            n = int(static_steps)
+        else:
+            _, steps_max = calculate_traj_steps(knot_dt, torch.full_like(knot_dt, float(interpolation_dt)), total + 1, nearest_int=True)
+            n = -(-int(steps_max) // 32) * 32  # (one device -> host read per pass; buffers grow in steps of 32 samples)
         zs = torch.zeros_like(start)
         st = tuple(t[start_rows.long()].contiguous() for t in (start, zs, zs, zs))
         zg = torch.zeros_like(goal)
         gl = (goal.contiguous(), zg, zg, zg)
         imp = torch.full((B,), 1 if implicit else 0, dtype=torch.uint8, device=dev)
         (pos, vel, acc, jerk), last = interpolate_bspline_knots(knots, knot_dt, interpolation_dt, st, gl if implicit else None,
-                                                                imp if implicit else None, rc.bspline_degree, out_steps=n)
+                                                                imp if implicit else None, rc.bspline_degree, out_steps=n,
+                                                                out_steps_is_bound=static_steps is not None)
         self._alloc(B, n)
         S = k.num_spheres
         env = self._env0 if env_query_idx is None else env_query_idx

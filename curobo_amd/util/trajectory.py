@@ -39,7 +39,7 @@ def calculate_traj_steps(opt_dt: torch.Tensor, interpolation_dt: torch.Tensor, h
 
 def interpolate_bspline_knots(knots: torch.Tensor, knot_dt: torch.Tensor, interpolation_dt: float, start_state,
                               goal_state=None, use_implicit_goal_state: Optional[torch.Tensor] = None,
-                              bspline_degree: int = 3, out_steps: Optional[int] = None):
+                              bspline_degree: int = 3, out_steps: Optional[int] = None, out_steps_is_bound: bool = False):
     """knots [B, n_knots, D] with knot spacing ``knot_dt`` [B] -> (position, velocity, acceleration,
     jerk) [B, steps_max, D] sampled every ``interpolation_dt`` and ``last_tstep`` [B] (samples beyond
     it repeat the final state).  ``start_state`` / ``goal_state`` = tuples of (position, velocity,
@@ -51,9 +51,15 @@ def interpolate_bspline_knots(knots: torch.Tensor, knot_dt: torch.Tensor, interp
     total = n_knots + bspline_degree + 1  # reference ControlSpace.spline_total_knots
     idt = torch.full((B,), float(interpolation_dt), device=dev)
     steps, steps_max = calculate_traj_steps(knot_dt.to(dev, torch.float32), idt, total + 1, nearest_int=True)
-    n_out = int(out_steps) if out_steps is not None else int(steps_max)
-    if n_out < int(steps_max):
-        raise ValueError(f"interpolation buffer ({n_out} steps) is smaller than the trajectory ({int(steps_max)} steps)")
+    if out_steps_is_bound:
+        # the caller's buffer holds the longest trajectory its dt range allows: nothing is read back (graph capture); a
+        # trajectory that claims more samples is cut at the buffer
+        n_out = int(out_steps)
+        steps = torch.clamp(steps, max=n_out)
+    else:
+        n_out = int(out_steps) if out_steps is not None else int(steps_max)
+        if n_out < int(steps_max):
+            raise ValueError(f"interpolation buffer ({n_out} steps) is smaller than the trajectory ({int(steps_max)} steps)")
     z = lambda: torch.zeros(B, n_out, D, device=dev)  # noqa: E731
     out = [z(), z(), z(), z()]
     out_dt = torch.zeros(B, device=dev)
