@@ -29,9 +29,11 @@
 // launches built from measured workgroup durations (rebuild_dispatch_order).  DESIGN.md section 4.1
 // has the measurements behind each of these choices.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "bspline_device.hpp"
@@ -1778,20 +1780,35 @@ static long long *g_fused_prof = nullptr;
 static bool g_fused_shapes_enabled = true;
 // shapes compiled at run time (curobo_fused_jit_launch of their objects), tried before the built-in table
 typedef int (*fused_jit_launcher_t)(const void *, int, int, int, int, int, int, size_t, void *, int *);
-static std::vector<fused_jit_launcher_t> &fused_jit_shapes() {
-  static std::vector<fused_jit_launcher_t> v;
-  return v;
-}
+// A fixed table with an atomic count: ctypes releases the GIL around the entry points, so one thread may register a shape
+// while another launches -- a launch reads the count once (acquire) and only the slots below it, a registration writes its slot
+// before it publishes the count (release) under a lock that serialises writers (the std::vector here could be
+// reallocated under a reader).
+constexpr int kMaxJitShapes = 64;
+static fused_jit_launcher_t g_jit_shapes[kMaxJitShapes];
+static std::atomic<int> g_jit_shape_count{0};
+static std::mutex g_jit_shape_lock;
+struct JitShapeView {
+  int n;
+  const fused_jit_launcher_t *begin() const { return g_jit_shapes; }
+  const fused_jit_launcher_t *end() const { return g_jit_shapes + n; }
+  size_t size() const { return (size_t)n; }
+  fused_jit_launcher_t operator[](size_t i) const { return g_jit_shapes[i]; }
+};
+static JitShapeView fused_jit_shapes() { return JitShapeView{g_jit_shape_count.load(std::memory_order_acquire)}; }
 constexpr int kJitShapeIdBase = 100;
 CUROBO_EXPORT int curobo_hip_rollout_fused_register_shape(void *launcher, int args_bytes) {
   CUROBO_REQUIRE(launcher != nullptr, "rollout_fused_register_shape: NULL launcher%s", "");
   CUROBO_REQUIRE(args_bytes == (int)sizeof(FusedTrajArgs),
                  "rollout_fused_register_shape: the shape object was built for an argument block of %d bytes, this library's is %d "
                  "(compile it from this library's sources)", args_bytes, (int)sizeof(FusedTrajArgs));
-  auto &v = fused_jit_shapes();
-  for (size_t i = 0; i < v.size(); i++)
-    if ((void *)v[i] == launcher) return CUROBO_HIP_OK;
-  v.push_back(reinterpret_cast<fused_jit_launcher_t>(launcher));
+  std::lock_guard<std::mutex> guard(g_jit_shape_lock);
+  const int n = g_jit_shape_count.load(std::memory_order_relaxed);
+  for (int i = 0; i < n; i++)
+    if ((void *)g_jit_shapes[i] == launcher) return CUROBO_HIP_OK;
+  CUROBO_REQUIRE(n < kMaxJitShapes, "rollout_fused_register_shape: more than %d run-time shapes", kMaxJitShapes);
+  g_jit_shapes[n] = reinterpret_cast<fused_jit_launcher_t>(launcher);
+  g_jit_shape_count.store(n + 1, std::memory_order_release);
   return CUROBO_HIP_OK;
 }
 CUROBO_EXPORT int curobo_hip_rollout_fused_set_shapes_enabled(int enabled) {
@@ -1901,7 +1918,7 @@ CUROBO_EXPORT int curobo_hip_rollout_fused_shape_id(int padded_horizon, int n_kn
   int threads;
   (void)fused_resolve_layout(a, max_cuboids + max_voxel_grids, with_trajopt_terms != 0, &threads);
   {
-    const auto &v = fused_jit_shapes();
+    const JitShapeView v = fused_jit_shapes();
     for (size_t i = 0; i < v.size(); i++) {
       int e2 = 0;
       if (v[i](&a, bspline_degree, sweep_steps, kinds, with_trajopt_terms != 0 ? 1 : 0, 0, threads, 0, nullptr, &e2)) return kJitShapeIdBase + (int)i;

@@ -159,7 +159,12 @@ class ModelPredictiveControl(ToolPoseTrackingMixin):
         self.solver.setup(state, self._goal)
 
     def set_default_goal_from_current_state(self, current_state: JointState) -> None:
-        self.update_goal_tool_poses(self.compute_kinematics(JointState.from_position(self._batch(current_state).position)).tool_poses.as_goal())
+        """hold the current tool pose.  No goal IK here: the goal IS the pose of the current configuration, and an IK that fails on
+        one robot must not leave every robot on its old goal without a word (``update_goal_tool_poses`` returns False then)"""
+        ok = self.update_goal_tool_poses(self.compute_kinematics(JointState.from_position(self._batch(current_state).position)).tool_poses.as_goal(),
+                                         run_ik=False)
+        if not ok:
+            raise RuntimeError("set_default_goal_from_current_state: the current tool pose was not accepted as a goal")
 
     def update_goal_tool_poses(self, goal_tool_poses: Union[GoalToolPose, Dict[str, Pose]], robot_ids: Optional[torch.Tensor] = None,
                                run_ik: bool = True, use_ik_goal: bool = True, use_best_effort_ik: bool = False) -> bool:

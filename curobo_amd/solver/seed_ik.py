@@ -380,8 +380,17 @@ class SeedIKSolver:
             if getattr(self, "_seed_row_dev", None) is None:
                 self._seed_row_dev = torch.empty(S, D, device=self.device)
                 self._seed_row_pin = torch.empty(S, D).pin_memory() if self.device.type == "cuda" else torch.empty(S, D)
+                self._seed_row_done = torch.cuda.Event() if self.device.type == "cuda" else None
+                self._seed_row_pending = False
+            # the upload of the previous solve may still be queued (solve_batch does not synchronise): the pinned buffer is
+            # rewritten only after the stream has read it, else that solve would run on this call's seed row
+            if self._seed_row_pending:
+                self._seed_row_done.synchronize()
             self._seed_row_pin.copy_(row)
             self._seed_row_dev.copy_(self._seed_row_pin, non_blocking=True)
+            if self._seed_row_done is not None:
+                self._seed_row_done.record()
+                self._seed_row_pending = True
             self._seeds_static.view(P, S, D).copy_(self._seed_row_dev.view(1, S, D).expand(P, S, D))
             seeds = None
         else:
