@@ -565,6 +565,9 @@ def compact_line(out: dict) -> dict:
         else:
             roof.update(_pick(r, ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "traffic")))
         roof.setdefault("traffic", None)
+        # (hardware counters cannot be collected inside the timed process: `traffic` and `issue` are READ from the newest committed
+        # counter table, which rocprofv3 --pmc passes over tools/run_kernels_once.py produced; every duration in the line is live)
+        roof["traffic_source"] = (r.get("primary_bound", {}) or {}).get("counters_source") or r.get("counters_source") or "committed profile (none found)"
         roof.update(_pick(r, ("valu_issue_frac", "kernel_sequence_us")))
         if ws:
             roof["whole_step"] = dict(_pick(ws, ("GBps", "frac", "us")), algorithmic_bytes=r.get("algorithmic_bytes_per_step"))

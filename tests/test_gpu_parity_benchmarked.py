@@ -162,7 +162,12 @@ def test_c3_size_sweep_x_voxel_fused_and_packed_kernel_match_oracle(oracle, devi
     # per sphere the tolerance is the one of the kernel tests (test_gpu_kernels.py::test_scene_collision_voxels: 2e-5 of
     # the weight, i.e. 2e-5 m of penetration): up to seven trilinear samples per sphere are summed and the speed metric
     # scales the sum; measured on this workload: 8 ulp-level differences of 1e-6 m at most (tools/diag_r03.py)
-    np.testing.assert_allclose(d[moving], wc["distance"][moving], rtol=1e-4, atol=2e-5 * w)
+    # held to 1e-5 relative + 1e-5 m of penetration per sphere (the kernel tests' bound is 1e-4 + 2e-5 m); measured on this
+    # workload: the worst sphere sits at 1.21 x (1e-5 relative + 5e-6 m) -- one fp16-grid trilinear term of seven (round 6)
+    err = np.abs(d[moving] - wc["distance"][moving])
+    worst = float((err / (1e-5 * np.abs(wc["distance"][moving]) + 5e-6 * w)).max())
+    print(f"[C3 per sphere] worst error in units of (1e-5 relative + 5e-6 m of penetration): {worst:.3f}")
+    assert worst < 2.0, worst
     gerr = np.abs(g[moving][:, :3] - wc["gradient"][moving][:, :3])
     gtol = 1e-3 * np.abs(wc["gradient"][moving][:, :3]) + 2e-4 * w
     # (the speed metric divides by the sphere's speed: a handful of slow spheres carry a few 1e-3 of relative error)
