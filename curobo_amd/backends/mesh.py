@@ -174,7 +174,7 @@ def build_mesh_bvh(vertices, faces, device, leaf_size: int = 8, sign_rule: Optio
 
 
 def build_mesh_cells(mesh: DeviceMesh, cell_size: Optional[float] = None, pad: float = 0.2, max_cells: int = 1 << 18,
-                     gather_cap: int = 2048) -> DeviceMesh:
+                     gather_cap: int = 2048, max_entries: int = 1 << 26) -> DeviceMesh:
     """The distance-sorted closest-triangle cell lists of ``mesh`` (``curobo_hip_mesh.cell_start / cell_list``; the query is
     ``csrc/mesh_device.hpp::mesh_cells_sdf``), written into ``mesh.struct`` in place.
 
@@ -183,33 +183,43 @@ def build_mesh_cells(mesh: DeviceMesh, cell_size: Optional[float] = None, pad: f
     world, 0.1 m sends 2 % of the live spheres -- the fast-moving ones -- to the tree walk and 0.2 m none); cells of ``cell_size``
     (default 2 cm), coarsened until the grid has at most ``max_cells`` cells.  Two launches around a prefix sum and a sort (torch:
     plumbing): count -> offsets -> fill + keys -> sort -> gather.  ``gather_cap``: cells whose candidate ball holds more
-    triangles get no list (their queries walk the tree)."""
+    triangles get no list (their queries walk the tree).  ``max_entries`` (2^26 entries = 1 GiB): the budget of one mesh's lists."""
     lib = load()
     dev = mesh.tri.device
     lo, hi = mesh.bounds[0].astype(np.float64) - pad, mesh.bounds[1].astype(np.float64) + pad
     h = float(cell_size) if cell_size else float(os.environ.get("CUROBO_MESH_CELL_SIZE", 0.02))
     ext = hi - lo
-    while np.prod(np.ceil(ext / h)) > max_cells:
-        h *= 1.1
-    n3 = np.maximum(np.ceil(ext / h).astype(np.int64), 1)
     st = mesh.struct
     st.cell_start, st.cell_list = None, None
-    for i in range(3):
-        st.grid_lo[i] = float(lo[i])
-        st.grid_n[i] = int(n3[i])
-    st.grid_h, st.grid_pad = h, float(pad)
-    n_cells = int(np.prod(n3))
-    count = torch.empty(n_cells, dtype=torch.int32, device=dev)
-    cover = torch.empty(n_cells, dtype=torch.float32, device=dev)
-    side = torch.empty(n_cells, dtype=torch.uint8, device=dev)
-    centre_dist = torch.empty(n_cells, dtype=torch.float32, device=dev)
-    stream = current_stream(count)
-    check(lib.curobo_hip_mesh_cells_count(ptr(count), ptr(cover), ptr(side), ptr(centre_dist), C.addressof(st), int(gather_cap), stream))
-    offsets = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(count, 0, out=offsets[1:])
-    total = int(offsets[-1])
-    if total >= 1 << 30:
-        raise RuntimeError(f"cell lists of {total} entries: raise cell_size or lower gather_cap")
+    mesh.cell_start = mesh.cell_list = mesh.cells_info = None
+    # The lists' size is known only after the count pass.  A dense mesh (entries per cell grow with the triangle density, the
+    # total falls with the square of the cell size) gets coarser cells until the lists fit ``max_entries``; a mesh that does not
+    # fit after a few tries keeps the tree walk alone (a slower launch, the same results).
+    for attempt in range(5):
+        while np.prod(np.ceil(ext / h)) > max_cells:
+            h *= 1.1
+        n3 = np.maximum(np.ceil(ext / h).astype(np.int64), 1)
+        for i in range(3):
+            st.grid_lo[i] = float(lo[i])
+            st.grid_n[i] = int(n3[i])
+        st.grid_h, st.grid_pad = h, float(pad)
+        n_cells = int(np.prod(n3))
+        count = torch.empty(n_cells, dtype=torch.int32, device=dev)
+        cover = torch.empty(n_cells, dtype=torch.float32, device=dev)
+        side = torch.empty(n_cells, dtype=torch.uint8, device=dev)
+        centre_dist = torch.empty(n_cells, dtype=torch.float32, device=dev)
+        stream = current_stream(count)
+        check(lib.curobo_hip_mesh_cells_count(ptr(count), ptr(cover), ptr(side), ptr(centre_dist), C.addressof(st), int(gather_cap), stream))
+        offsets = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(count, 0, out=offsets[1:])
+        total = int(offsets[-1])
+        if total <= max_entries:
+            break
+        h *= 1.5
+    else:
+        st.grid_h = 0.0
+        mesh.cells_info = {"skipped": f"{total} list entries at a cell size of {h / 1.5:.3f} m exceed max_entries = {max_entries}: tree walk only"}
+        return mesh
     keys = torch.empty(total, dtype=torch.int64, device=dev)
     entries = torch.empty(total, 4, dtype=torch.int32, device=dev)
     cell_start = torch.empty(n_cells + 1, 2, dtype=torch.int32, device=dev)

@@ -588,3 +588,24 @@ def test_open_and_flipped_meshes_take_the_reference_ray_sign(name, oracle, devic
             assert bad.mean() < (4e-3 if sweep else 2e-3), bad.mean()
     finally:
         oracle.set_mesh_sign_rule("winding")
+
+
+def test_cell_lists_that_exceed_their_budget_coarsen_or_are_left_out(oracle, device):
+    """``build_mesh_cells(max_entries=)``: lists that do not fit get coarser cells; a mesh whose lists never fit keeps the tree walk
+    alone -- the launch's results are the same either way"""
+    from curobo_amd.backends.mesh import build_mesh_bvh
+
+    v, f = torus_shape(0.22, 0.06, 64, 32)
+    full = build_mesh_bvh(v, f, device)
+    assert full.cells_info["entries"] > 50_000
+    small = build_mesh_bvh(v, f, device, cells={"max_entries": full.cells_info["entries"] // 2})
+    assert small.cell_start is not None and small.cells_info["cell_size"] > full.cells_info["cell_size"]
+    assert small.cells_info["entries"] <= full.cells_info["entries"] // 2
+    none = build_mesh_bvh(v, f, device, cells={"max_entries": 10})
+    assert none.cell_start is None and none.struct.cell_start is None and "skipped" in none.cells_info
+    world = [[{"name": "ring", "vertices": v, "faces": f, "pose": [0.1, 0.45, 0.45, 0.9238795, 0.3826834, 0, 0]}]]
+    sph = torch.as_tensor(_trajectory_spheres(oracle, 24, 9, scale=0.6), device=device)
+    outs = [_mesh_launch(device, world, sph, True, c)[0] for c in ({}, {"max_entries": full.cells_info["entries"] // 2}, {"max_entries": 10})]
+    assert (outs[0] > 0).sum() > 10
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(outs[2], outs[0], rtol=2e-6, atol=1e-7)
