@@ -609,3 +609,32 @@ def test_cell_lists_that_exceed_their_budget_coarsen_or_are_left_out(oracle, dev
     assert (outs[0] > 0).sum() > 10
     np.testing.assert_allclose(outs[1], outs[0], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(outs[2], outs[0], rtol=2e-6, atol=1e-7)
+
+
+def test_more_than_thirty_two_mesh_slots_run_as_slot_groups(oracle, device):
+    """a sphere's live slots are a 32-bit mask: 40 mesh obstacles (one shared BVH, 40 poses) run as two slot groups into the same
+    buffers, through the cell lists -- against the oracle's scene restatement"""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.backends import collision as Cn
+    from curobo_amd.scene import SceneData
+
+    v, f = box_shape([0.08, 0.08, 0.08], 1)
+    rng = np.random.default_rng(4)
+    world = [[{"name": f"cube{i}", "mesh_name": "cube", "vertices": v, "faces": f,
+               "pose": [float(x) for x in rng.uniform([-0.6, -0.6, 0.1], [0.6, 0.6, 0.9])] + [1, 0, 0, 0], "enable": i % 7 != 3}
+              for i in range(40)]]
+    sph = _trajectory_spheres(oracle, 16, 5, scale=0.5)
+    b, h, S, _ = sph.shape
+    scene = SceneData.from_arrays(None, device, meshes=world)
+    assert scene.meshes.max_n == 40 and len(scene.meshes.meshes) == 1 and scene.meshes.meshes[0].cell_start is not None
+    for sweep in (False, True):
+        ref = oracle.scene_collision(sph, mesh_scene_arrays(world), 2.0, 0.02, sweep=sweep)
+        dist, grad = torch.full((b, h, S), 3.0, device=device), torch.full((b, h, S, 4), 3.0, device=device)
+        Cn.sphere_obstacle_collision(dist, grad, torch.as_tensor(sph, device=device), scene.struct, torch.tensor([2.0], device=device),
+                                     torch.tensor([0.02], device=device), None, b, h, S, False, 3 if sweep else 0, False, None)
+        torch.cuda.synchronize()
+        assert (ref["distance"] > 0).mean() > 0.01
+        np.testing.assert_allclose(dist.cpu().numpy(), ref["distance"], atol=2e-5, rtol=1e-4)
+        bad = np.abs(grad.cpu().numpy() - ref["gradient"]).max(-1) > 1e-4 + 1e-3 * np.abs(ref["gradient"]).max(-1)
+        assert bad.mean() < 2e-3, bad.mean()
