@@ -145,7 +145,9 @@ def test_trajopt_seed_generation_host_logic():
     start = torch.rand(1, D, generator=g) - 0.5
     knots = slv.seed_knots(start, goals, choice)
     assert knots.shape == (P, S, nk, D)
-    t = torch.linspace(0, 1, nk + 2)[1:-1].view(1, 1, nk, 1)
+    # (the free knots sit where the configured placement puts them: the reference's -- both ends included -- by default)
+    assert slv.cfg.seed_knot_placement == "reference"
+    t = torch.linspace(0, 1, nk).view(1, 1, nk, 1)
     sel = torch.gather(goals, 1, choice.unsqueeze(-1).expand(P, S, D))
     line = start.view(1, 1, 1, D) * (1 - t) + sel.view(P, S, 1, D) * t
     first = torch.tensor([[1, 1, 1, 1, 0, 0], [1, 0, 1, 0, 0, 0], [1, 0, 0, 0, 0, 0]], dtype=torch.bool)
