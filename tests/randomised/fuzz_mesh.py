@@ -1,6 +1,11 @@
 """The mesh launch (select + group walk) against the oracle's brute force on random mesh worlds: boxes (thin slabs and pillars
 among them), spheres, tori, L prisms at random poses and sizes, disabled slots, discrete / swept / speed metric, random
-activation distance.   python tests/randomised/fuzz_mesh.py [cases] [seed]"""
+activation distance.   python tests/randomised/fuzz_mesh.py [cases] [seed] [--open]
+
+--open (round 6): a third of the meshes lose faces or get some flipped; the oracle signs EVERY mesh with the reference's rule
+(Warp's three axis rays, ``set_mesh_sign_rule("rays")``: on the closed meshes of the world that is the same function), the device
+picks its rule per mesh from the topology.  A sphere whose ray grazes an edge may differ (fp32 rays against fp64): a small
+allowance of whole spheres."""
 import os
 import sys
 
@@ -19,6 +24,10 @@ from oracle.oracle import Oracle, mesh_scene_arrays  # noqa: E402
 
 dev = torch.device("cuda:0")
 oracle = Oracle()
+OPEN = "--open" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--open"]
+if OPEN:
+    oracle.set_mesh_sign_rule("rays")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 model = load_model("franka")
@@ -43,6 +52,13 @@ def random_mesh(i):
         v, f = torus_shape(float(rng.uniform(0.15, 0.3)), float(rng.uniform(0.03, 0.08)), int(rng.choice([16, 48])), int(rng.choice([8, 24])))
     else:
         v, f = ell_shape(int(rng.integers(1, 3)))
+    if OPEN and rng.random() < 0.35:
+        f = np.asarray(f).copy()
+        if rng.random() < 0.5:  # an open mesh: a few faces missing
+            f = f[rng.random(len(f)) > float(rng.uniform(0.02, 0.3))]
+        else:                   # inconsistently oriented: a few faces wound the other way
+            flip = rng.random(len(f)) < float(rng.uniform(0.01, 0.2))
+            f[flip] = f[flip][:, [0, 2, 1]]
     o = {"name": f"m{i}", "vertices": v, "faces": f, "pose": [float(x) for x in rng.uniform([-0.6, -0.6, -0.1], [0.6, 0.6, 0.9])] + rq()}
     if rng.random() < 0.15:
         o["enable"] = False
@@ -77,10 +93,15 @@ for case in range(n_cases):
             ok[:, :-1] &= stepn >= 1e-5
         sc = 20.0 if speed else 1.0
         graze = np.abs(d - dr) < 3e-5 * sc
-        assert np.array_equal((d > 0)[ok & ~graze], (dr > 0)[ok & ~graze]), "hit set differs"
+        if OPEN:
+            assert ((d > 0) != (dr > 0))[ok & ~graze].sum() <= 2 + int(4e-3 * (dr > 0).sum()), "hit set differs"
+        else:
+            assert np.array_equal((d > 0)[ok & ~graze], (dr > 0)[ok & ~graze]), "hit set differs"
         e, tol = np.abs(d - dr)[ok], 3e-5 * sc + 2e-4 * np.abs(dr)[ok]
         n_off = int((e > tol).sum())
         allowed = (2 + int(2e-4 * (dr > 0).sum())) if sweep else 0
+        if OPEN:
+            allowed += 2 + int(4e-3 * (dr > 0).sum())  # (a ray through an edge: the sign of a whole sphere)
         assert n_off <= allowed, f"{n_off} spheres beyond the cost bound (allowed {allowed}), worst {float((e / tol).max()):.1f} x; colliding {int((dr > 0).sum())}"
         badg = np.abs(g - gr).max(-1)[ok] > (3e-4 * sc + 2e-3 * np.abs(gr).max(-1)[ok])
         assert badg.mean() < 3e-3, f"gradient: {float(badg.mean()):.2e} of the spheres off (closest-point ties aside)"

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_fk_bspline.py", ["16", "5"], "failed in total: 0"),
     ("fuzz_rnea.py", ["6", "5"], "failed in total: 0"),
     ("fuzz_mesh.py", ["10", "5"], ", 0 failed"),
+    ("fuzz_mesh.py", ["10", "6", "--open"], ", 0 failed"),  # open / flipped meshes against the reference's ray sign
     ("fuzz_planner.py", ["3", "5"], ", 0 failed"),
     ("fuzz_ik.py", ["5", "5"], ", 0 failed"),
     ("fuzz_costs.py", ["16", "5"], ", 0 failed"),
