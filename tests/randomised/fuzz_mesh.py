@@ -104,7 +104,7 @@ for case in range(n_cases):
             allowed += 2 + int(4e-3 * (dr > 0).sum())  # (a ray through an edge: the sign of a whole sphere)
         assert n_off <= allowed, f"{n_off} spheres beyond the cost bound (allowed {allowed}), worst {float((e / tol).max()):.1f} x; colliding {int((dr > 0).sum())}"
         badg = np.abs(g - gr).max(-1)[ok] > (3e-4 * sc + 2e-3 * np.abs(gr).max(-1)[ok])
-        assert badg.mean() < 3e-3, f"gradient: {float(badg.mean()):.2e} of the spheres off (closest-point ties aside)"
+        assert badg.size == 0 or badg.mean() < 3e-3, f"gradient: {float(badg.mean()):.2e} of the spheres off (closest-point ties aside)"
     except AssertionError as ex:
         bad += 1
         print(f"FAILED case {case}: meshes {[(m['name'], len(m['faces'])) for m in world[0]]} sweep {sweep} speed {speed} eta {eta} b {b} h {h}: {str(ex)[:300]}")
