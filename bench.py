@@ -1243,7 +1243,7 @@ def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, ou
         k2: (lambda e: None if e is None else {"mean_us": e.get("mean_us"), "hbm_bytes": e.get("hbm_bytes"), "valu_issue_frac": e.get("valu_issue_frac"),
                                                "SQ_INSTS_VALU": e["counters"].get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": e["counters"].get("SQ_INSTS_SALU"),
                                                "source": e["source"]})(committed_counters(k2))
-        for k2 in ("sphere_mesh_select_kernel", "sphere_mesh_walk_kernel")}
+        for k2 in ("sphere_mesh_select_kernel", "sphere_mesh_cells_kernel", "sphere_mesh_walk_kernel")}
     # BVH build and the two bakes of one mesh (torus-free: the table box, 3 072 triangles) into a 96^3 grid
     v, f = meshes[0][0]["vertices"], meshes[0][0]["faces"]
     torch.cuda.synchronize()
