@@ -493,7 +493,9 @@ class TrajOptSolver:
             # samples of the longest trajectory: knot spacing maximum_trajectory_dt x interpolation_steps (calculate_traj_steps)
             per = int((cfg.maximum_trajectory_dt * rc.interpolation_steps + cfg.interpolation_dt) / cfg.interpolation_dt)
             static_steps = -(-((rc.n_knots + rc.bspline_degree + 1) * per + 1) // 32) * 32
-            buf = dict(knots=knots.clone(), cur_dt=cur_dt.clone(), start=start.clone(), seed_goal=seed_goal.clone())
+            # (one start row per problem in the graph's buffer, whatever shape the first caller had: [1, D] and [P, D] both fit)
+            buf = dict(knots=knots.clone(), cur_dt=cur_dt.clone(), start=start.to(self.device).reshape(-1, self.kin.num_dof).expand(self.P, -1).clone(),
+                       seed_goal=seed_goal.clone())
             run = lambda: self._metrics_pass_eager(buf["knots"], buf["cur_dt"], buf["start"], buf["seed_goal"], use_implicit_goal, static_steps)  # noqa: E731
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -506,7 +508,8 @@ class TrajOptSolver:
                 out_dt, out = run()
             g = self._pass_graphs[key] = dict(graph=graph, buf=buf, out_dt=out_dt, out=out)
         b = g["buf"]
-        b["knots"].copy_(knots); b["cur_dt"].copy_(cur_dt); b["start"].copy_(start.expand_as(b["start"])); b["seed_goal"].copy_(seed_goal)
+        b["knots"].copy_(knots); b["cur_dt"].copy_(cur_dt); b["seed_goal"].copy_(seed_goal.reshape(b["seed_goal"].shape))
+        b["start"].copy_(start.to(self.device).reshape(-1, self.kin.num_dof).expand_as(b["start"]))
         g["graph"].replay()
         return g["out_dt"].clone(), {k: v.clone() for k, v in g["out"].items()}
 
