@@ -511,3 +511,42 @@ def test_joint_position_tracking_term_matches_oracle(fused, oracle, device):
     dg = (g1 - g0).cpu().numpy().reshape(B, nk, D)
     # (g1 - g0 is a difference of two fp32 gradients of the whole cost: its rounding is relative to THEIR size)
     np.testing.assert_allclose(dg, want_g, rtol=2e-3, atol=2e-4 * float(np.abs(want_g).max()) + 2e-6 * float(g0.abs().max()))
+
+
+def test_captured_metrics_pass_is_the_eager_pass(oracle, device):
+    """``TrajOptSolver._metrics_pass`` replayed from its hipGraph (round 6: the retime + metrics pass after every optimisation pass; the
+    interpolated check samples for the LONGEST trajectory the dt range allows instead of reading the longest one back) against the same
+    pass run eagerly: the same successes, dt, knots and errors, solve after solve (the graph's buffers are refilled in place), for a
+    start given per problem and a start given once."""
+    import dataclasses
+
+    from curobo_amd.solver import TrajOptSolver, TrajOptSolverCfg
+    from curobo_amd.workloads import start_configuration
+
+    model, kin, arrays, scene = _setup(device)
+    md = model.as_dict()
+    P = 4
+    cand = sample_q(model, 300, seed=21, scale=0.6)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(300, 1, -1, 4)
+    free = (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0) & \
+        (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0)
+    sel = np.nonzero(free)[0][:2 * P]
+    start = torch.as_tensor(start_configuration(model))
+    cfg = TrajOptSolverCfg(num_seeds=4)
+    captured = TrajOptSolver(kin, scene, P, dataclasses.replace(cfg, capture_metrics_pass=True))
+    eager = TrajOptSolver(kin, scene, P, dataclasses.replace(cfg, capture_metrics_pass=False))
+    for rnd, starts in enumerate((start, start.view(1, -1).repeat(P, 1))):
+        pick = sel[rnd * P:(rnd + 1) * P]
+        gp, gq = torch.as_tensor(fk["link_pos"][pick, 0]), torch.as_tensor(fk["link_quat"][pick, 0])
+        a, b = captured.solve_pose(starts, gp, gq), eager.solve_pose(starts, gp, gq)
+        torch.cuda.synchronize()
+        assert captured._pass_graphs and not eager._pass_graphs
+        assert torch.equal(a.success, b.success) and bool(a.success.any())
+        assert a.finetune_passes == b.finetune_passes
+        # (two solver objects: their optimisers agree to rounding -- a last-bit difference in a dt was seen -- not to the bit)
+        torch.testing.assert_close(a.traj_dt, b.traj_dt, rtol=1e-6, atol=0)
+        torch.testing.assert_close(a.knots, b.knots, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a.position_error, b.position_error, rtol=1e-3, atol=1e-7)
+        for key in ("success", "feasible_interpolated", "in_limits", "no_scene_collision"):
+            assert torch.equal(a.all_seeds[key], b.all_seeds[key]), key
