@@ -793,6 +793,13 @@ __global__ void __launch_bounds__(256) MESH_CELLS_ATTR sphere_mesh_cells_kernel(
   }
 }
 
+// the queue counters of a launch (workspace words 0-3) back to zero.  A kernel, not hipMemsetAsync: a captured memset node of
+// these 16 bytes replays correctly ONCE -- the second replay of the graph faults (tools/r06/mesh_graph_replay.py,
+// docs/NOTEBOOK.md round 6) -- and a solver replays its graphs for as long as it lives.
+__global__ void __launch_bounds__(64) mesh_queue_reset_kernel(uint32_t *counter) {
+  if (threadIdx.x < 4) counter[threadIdx.x] = 0u;
+}
+
 __global__ void __launch_bounds__(256) mesh_zero_outputs_kernel(float *distance, float4 *gradient, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) { distance[i] = 0.0f; gradient[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -953,7 +960,7 @@ static int sphere_mesh_collision_impl(
       qa.c = a; qa.counter = reinterpret_cast<uint32_t *>(workspace);
       qa.queue = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(workspace) + 16);
       qa.queue2 = qa.queue + total;
-      if (hipMemsetAsync(workspace, 0, 16, st) != hipSuccess) return set_error(CUROBO_HIP_ERR_LAUNCH, "%s: cannot clear the queue counter", what);
+      hipLaunchKernelGGL(mesh_queue_reset_kernel, dim3(1), dim3(64), 0, st, qa.counter);
       // the walk's grid covers the chip once (1024 workgroups of four wavefronts); the queue is usually much shorter
       const unsigned walk_blocks = (unsigned)std::min<long>(MESH_WALK_MAX_BLOCKS, ceil_div_l(total, MESH_WALK_THREADS / MESH_WALK_GROUP));
       // with cell lists: select -> cell-list kernel (every sphere it can answer) -> tree walk of the few it could not

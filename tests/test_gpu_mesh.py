@@ -466,6 +466,42 @@ def test_seed_shards_over_a_mesh_scene_own_their_launch_workspaces(oracle, devic
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("horizon", [1, 8])
+def test_captured_mesh_launch_replays_like_the_eager_launch(horizon, device):
+    """the queued launch inside a hipGraph, replayed as a solver replays it (IKSolver's ranking graph: horizon 1).  The
+    launch used to clear its queue counters with hipMemsetAsync; the captured 16-byte memset node replayed once and faulted
+    at the SECOND replay (tools/r06/mesh_graph_replay.py) -- the counters are now cleared by a kernel.  Every replay on moved
+    spheres gives the eager launch's numbers to the bit and leaves the launch's own counters."""
+    from curobo_amd.backends import mesh as M
+    from curobo_amd.scene import MeshStore
+
+    store = MeshStore(mesh_world(), device)
+    b, S = 32, 65
+    g = torch.Generator().manual_seed(3)
+    sph = torch.cat([torch.rand(b, horizon, S, 3, generator=g) * 1.6 - 0.8, torch.full((b, horizon, S, 1), 0.05)], -1).to(device)
+    w, eta = torch.tensor([1.0], device=device), torch.tensor([0.01], device=device)
+    out = [(torch.zeros(b, horizon, S, device=device), torch.zeros(b, horizon, S, 4, device=device)) for _ in range(2)]
+
+    def launch(k):
+        M.sphere_mesh_collision(out[k][0], out[k][1], sph, store.struct, w, eta, None, b, horizon, S, False, 0, False, None, accumulate=False)
+
+    launch(0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch(0)
+    ws = [next(iter(o[0]._curobo_mesh_ws.values())) if hasattr(o[0], "_curobo_mesh_ws") else None for o in out]
+    for rep in range(5):
+        sph[..., :3] += 0.02
+        graph.replay()
+        launch(1)
+        torch.cuda.synchronize()
+        assert float(out[1][0].sum()) > 0
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), rep
+        ws[1] = next(iter(out[1][0]._curobo_mesh_ws.values()))
+        assert torch.equal(ws[0][:16], ws[1][:16]), rep  # (the counters of this launch alone: cleared at its start)
+
+
 # ------------------------------------------------------------------------------------------------ cell lists (round 6)
 def _mesh_launch(device, world, sph, sweep, cells, **store_kw):
     from curobo_amd.backends import mesh as M

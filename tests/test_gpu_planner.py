@@ -217,6 +217,47 @@ def test_motion_planner_plan_pose_and_plan_cspace(oracle, device, this_repos_cur
     assert planner.plan_pose(far, cur, max_attempts=1) is None
 
 
+def test_motion_planner_in_a_mesh_world(oracle, device, this_repos_curobo):
+    """the same planner call with triangle-mesh obstacles in ``scene_model`` (reference SceneCfg ``mesh`` entries, geom/types.py):
+    the mesh launch (cell lists + BVH walk) runs inside the captured solver and metrics graphs next to the cuboid store; the
+    winner is free of collision against cuboids AND meshes by the oracle's brute force over every triangle"""
+    from curobo.motion_planner import MotionPlanner, MotionPlannerCfg
+    from curobo.types import JointState
+    from oracle.oracle import mesh_scene_arrays
+    from test_oracle_mesh import box_shape, sphere_shape
+
+    from curobo_amd.scene import cuboid_scene_arrays
+
+    vb, fb = box_shape([0.16, 0.16, 0.7], 2)
+    vs, fs = sphere_shape(0.12)
+    meshes = {"pillar": {"vertices": vb, "faces": fb, "pose": [0.5, 0.0, 0.35, 1, 0, 0, 0]},
+              "ball": {"vertices": vs, "faces": fs, "pose": [0.0, 0.55, 0.9, 0.9238795, 0, 0.3826834, 0]}}
+    table = {"dims": [2.0, 2.0, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}
+    config = MotionPlannerCfg.create(robot="franka.yml", scene_model={"cuboid": {"table": table}, "mesh": meshes},
+                                     num_ik_seeds=32, num_trajopt_seeds=4)
+    planner = MotionPlanner(config)
+    scene = config.trajopt_solver_config.scene
+    assert scene.meshes is not None and len(scene.meshes.meshes) == 2 and all(m.cell_start is not None for m in scene.meshes.meshes)
+    model = config.trajopt_solver_config.kinematics.model
+    arrays = {**cuboid_scene_arrays([[table]]), **mesh_scene_arrays([[dict(m, name=k) for k, m in meshes.items()]])}
+    q0 = torch.tensor([[-0.9, 0.3, 0.0, -1.9, 0.0, 2.2, 0.8]], device=planner.default_joint_state.position.device)
+    cur = JointState.from_position(q0, planner.joint_names)
+    goal_js = cur.clone()
+    goal_js.position[0, 0] = 0.9  # the straight joint-space line sweeps the outstretched arm through the pillar
+    H = 33
+    tt = np.linspace(0, 1, H, dtype=np.float32)[:, None]
+    line = cur.position[0].cpu().numpy()[None] * (1 - tt) + goal_js.position[0].cpu().numpy()[None] * tt
+    s_line = oracle.kinematics_forward(line, model.as_dict(), horizon=H)["robot_spheres"].reshape(1, H, -1, 4)
+    assert oracle.scene_collision(s_line, arrays, 1.0, 0.0)["distance"].sum() > 0
+    goal = planner.compute_kinematics(goal_js).tool_poses.as_goal()
+    res = planner.plan_pose(goal, cur, max_attempts=3)
+    assert res is not None and bool(res.success[0, 0]), res
+    assert float(res.position_error[0, 0]) < 0.005 and float(res.rotation_error[0, 0]) < 0.05
+    traj = res.js_solution.position[0].cpu().numpy()
+    _verify_with_oracle(oracle, model, arrays, traj, res.js_solution.dt[0].cpu().numpy(), cur.position[0].cpu().numpy(),
+                        config.trajopt_solver_config.solver_cfg().rollout)
+
+
 def test_batch_motion_planner_one_world_per_problem(oracle, device, this_repos_curobo):
     """BASELINE config 5 at planner level (reference motion_planner_batch.py with multi_env): a batch of problems, each with
     its own start state, goal and world; every winner is collision free in ITS world."""
