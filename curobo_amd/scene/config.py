@@ -152,12 +152,24 @@ def _scene_cfgs(scene_model):
     return one(scene_model, dicts[0])
 
 
-def scene_from_config(scene_model, device, gradient_mode: int = 0, cache: Optional[Dict[str, int]] = None):
+def scene_from_config(scene_model, device, gradient_mode: Optional[int] = None, cache: Optional[Dict[str, int]] = None):
     """scene description -> ``SceneData`` on ``device`` with every obstacle kind it names (cuboids and analytic primitives in the
     cuboid store, ``mesh`` entries behind their BVHs); ``None`` for no world.  What ``SceneCollision.from_config`` does with a
-    ``SceneCfg`` in the reference (geom/collision/collision_scene.py)."""
+    ``SceneCfg`` in the reference (geom/collision/collision_scene.py).
+
+    ``gradient_mode`` of the mesh store: ``None`` = ``MeshStore.CONSISTENT_GRADIENT`` (``CUROBO_MESH_GRADIENT=reference`` for
+    the other).  A STATED DEVIATION of the scenes the solvers build: the reference's mesh query (data_mesh.py:693-697) returns
+    (p - closest) / |p - closest| on both sides of the surface, which for a sphere centre OUTSIDE the mesh is the opposite of
+    what its cuboid and voxel queries hand to the same kernel -- the cost then pulls every sphere that touches a mesh inward
+    until its centre sits on the surface, and no optimiser leaves that state (tools/r06/mesh_vs_cuboid_plan.py: 0 of 12 seeds
+    around a pillar as a mesh against 5 of 12 as a cuboid; 5 of 12 with the consistent vector).  The launch itself keeps the
+    reference's vector as mode 0 (``MeshStore(...)`` default), which is what the parity tests hold against the oracle."""
     from .data import SceneData
     from .mesh import MeshStore
+
+    if gradient_mode is None:
+        gradient_mode = {"reference": MeshStore.REFERENCE_GRADIENT, "consistent": MeshStore.CONSISTENT_GRADIENT}[
+            os.environ.get("CUROBO_MESH_GRADIENT", "consistent")]
 
     given, scene_model = scene_model, _plain(scene_model)
     cache = cache or {}

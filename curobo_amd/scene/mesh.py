@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 
@@ -80,9 +82,13 @@ class MeshStore:
     #: outside it -- the opposite of what its cuboid and voxel queries return there); 1 = toward the obstacle on both sides
     REFERENCE_GRADIENT, CONSISTENT_GRADIENT = 0, 1
 
-    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 8, gradient_mode: int = 0,
-                 cells=None, sign_rule: Optional[int] = None):
+    def __init__(self, envs: List[List[Dict]], device, max_n: Optional[int] = None, leaf_size: int = 8,
+                 gradient_mode: Optional[int] = None, cells=None, sign_rule: Optional[int] = None):
         self.device = torch.device(device)
+        if gradient_mode is None:  # (``CUROBO_MESH_GRADIENT`` = reference | consistent: the default of stores that are not told)
+            gradient_mode = {"reference": self.REFERENCE_GRADIENT, "consistent": self.CONSISTENT_GRADIENT}[
+                os.environ.get("CUROBO_MESH_GRADIENT", "reference")]
+        self.gradient_mode = int(gradient_mode)
         E = len(envs)
         n = max_n or max(1, max(len(e) for e in envs))
         self.cache: Dict[str, int] = {}

@@ -220,7 +220,10 @@ def test_motion_planner_plan_pose_and_plan_cspace(oracle, device, this_repos_cur
 def test_motion_planner_in_a_mesh_world(oracle, device, this_repos_curobo):
     """the same planner call with triangle-mesh obstacles in ``scene_model`` (reference SceneCfg ``mesh`` entries, geom/types.py):
     the mesh launch (cell lists + BVH walk) runs inside the captured solver and metrics graphs next to the cuboid store; the
-    winner is free of collision against cuboids AND meshes by the oracle's brute force over every triangle"""
+    winner is free of collision against cuboids AND meshes by the oracle's brute force over every triangle.  The scenes the
+    solvers build use the sign-consistent mesh gradient (``scene_from_config``): with the vector the reference's mesh query
+    returns (data_mesh.py:693-697, kept as mode 0 of the launch) no seed of this problem leaves the pillar
+    (tools/r06/mesh_vs_cuboid_plan.py, docs/NOTEBOOK.md round 6)."""
     from curobo.motion_planner import MotionPlanner, MotionPlannerCfg
     from curobo.types import JointState
     from oracle.oracle import mesh_scene_arrays
@@ -238,6 +241,7 @@ def test_motion_planner_in_a_mesh_world(oracle, device, this_repos_curobo):
     planner = MotionPlanner(config)
     scene = config.trajopt_solver_config.scene
     assert scene.meshes is not None and len(scene.meshes.meshes) == 2 and all(m.cell_start is not None for m in scene.meshes.meshes)
+    assert scene.meshes.gradient_mode == scene.meshes.CONSISTENT_GRADIENT
     model = config.trajopt_solver_config.kinematics.model
     arrays = {**cuboid_scene_arrays([[table]]), **mesh_scene_arrays([[dict(m, name=k) for k, m in meshes.items()]])}
     q0 = torch.tensor([[-0.9, 0.3, 0.0, -1.9, 0.0, 2.2, 0.8]], device=planner.default_joint_state.position.device)
