@@ -162,7 +162,7 @@ def scene_from_config(scene_model, device, gradient_mode: Optional[int] = None, 
     (p - closest) / |p - closest| on both sides of the surface, which for a sphere centre OUTSIDE the mesh is the opposite of
     what its cuboid and voxel queries hand to the same kernel -- the cost then pulls every sphere that touches a mesh inward
     until its centre sits on the surface, and no optimiser leaves that state (tools/r06/mesh_vs_cuboid_plan.py: 0 of 12 seeds
-    around a pillar as a mesh against 5 of 12 as a cuboid; 5 of 12 with the consistent vector).  The launch itself keeps the
+    around a pillar as a mesh against 3 of 12 as a cuboid; the same 3 of 12 with the consistent vector).  The launch itself keeps the
     reference's vector as mode 0 (``MeshStore(...)`` default), which is what the parity tests hold against the oracle."""
     from .data import SceneData
     from .mesh import MeshStore
