@@ -502,6 +502,48 @@ def test_captured_mesh_launch_replays_like_the_eager_launch(horizon, device):
         assert torch.equal(ws[0][:16], ws[1][:16]), rep  # (the counters of this launch alone: cleared at its start)
 
 
+@pytest.mark.parametrize("exit_early", [False, True])
+def test_ik_solver_in_a_mesh_world(exit_early, oracle, device):
+    """IKSolver over a scene of meshes (the kernel sequence with the queued mesh launch inside the optimiser's and the ranking
+    graph), solved three times (graph replays): solutions reach their goals and are free of collision by the oracle's brute force
+    over every triangle.  Consistent mesh gradient, as the scenes the solvers build have it (scene/config.py)."""
+    from oracle.oracle import mesh_scene_arrays
+
+    from curobo_amd.robot.kinematics_params import KinematicsParams
+    from curobo_amd.scene import MeshStore, SceneData
+    from curobo_amd.solver import IKSolver, IKSolverCfg
+
+    model = load_model("franka")
+    md = model.as_dict()
+    kin = KinematicsParams.from_model(model, device)
+    world = mesh_world()
+    arrays = mesh_scene_arrays(world)
+    scene = SceneData.from_arrays(None, device, meshes=MeshStore(world, device, gradient_mode=MeshStore.CONSISTENT_GRADIENT))
+    P = 12
+    cand = sample_q(model, 600, seed=13, scale=0.8)
+    fk = oracle.kinematics_forward(cand, md)
+    sph = fk["robot_spheres"].reshape(600, 1, -1, 4)
+    free = (oracle.self_collision(sph, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0) & \
+        (oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0)
+    assert 0.1 < free.mean() < 0.9, "the meshes must rule out a good share of the samples"
+    sel = np.nonzero(free)[0][:P]
+    gp, gq = fk["link_pos"][sel, 0], fk["link_quat"][sel, 0]
+    solver = IKSolver(kin, scene, P, IKSolverCfg(num_seeds=32, exit_early=exit_early))
+    for rep in range(3):
+        res = solver.solve_pose(torch.as_tensor(gp), torch.as_tensor(gq))
+        torch.cuda.synchronize()
+        succ = res.success.cpu().numpy()
+        assert succ.mean() >= 0.8, f"IK success rate {succ.mean():.2f} (solve {rep})"
+        qs = res.solution.cpu().numpy()[succ]
+        chk = oracle.kinematics_forward(qs, md)
+        np.testing.assert_allclose(chk["link_pos"][:, 0], gp[succ], atol=5e-3)
+        s2 = chk["robot_spheres"].reshape(len(qs), 1, -1, 4)
+        assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all()
+        assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all()
+    if not exit_early:
+        assert solver.optimizer_ran
+
+
 # ------------------------------------------------------------------------------------------------ cell lists (round 6)
 def _mesh_launch(device, world, sph, sweep, cells, **store_kw):
     from curobo_amd.backends import mesh as M

@@ -206,3 +206,54 @@ def test_mpc_seed_trajectory_from_outside(oracle, device):
     r_plain = mpc.optimize_action_sequence(state)
     assert float(r_seeded.position_error.max()) < 0.05, (r_seeded.position_error, r_plain.position_error)
     assert float(r_seeded.position_error.max()) <= float(r_plain.position_error.max()) + 1e-4
+
+
+def test_mpc_around_a_mesh_obstacle(oracle, device):
+    """the front end over a scene description with a triangle mesh: a ball the hand's arc grazes (8 cm deep on the straight
+    joint-space line).  The loop re-optimises from captured graphs every knot interval -- hundreds of replays of graphs that hold
+    the queued mesh launch -- reaches the goal, and every executed state is clear of table and ball by the oracle's brute force."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from oracle.oracle import mesh_scene_arrays
+    from test_oracle_mesh import sphere_shape
+
+    from curobo_amd.model_predictive_control import ModelPredictiveControl, ModelPredictiveControlCfg
+    from curobo_amd.scene import cuboid_scene_arrays
+    from curobo_amd.types import JointState
+
+    vs, fs = sphere_shape(0.08)
+    table = {"dims": [2.0, 2.0, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}
+    ball = {"vertices": vs, "faces": fs, "pose": [0.6968, -0.1375, 0.3710, 1, 0, 0, 0]}
+    config = ModelPredictiveControlCfg.create(robot="franka.yml", scene_model={"cuboid": {"table": table}, "mesh": {"ball": ball}},
+                                              optimization_dt=0.02, interpolation_steps=4, max_batch_size=1)
+    mpc = ModelPredictiveControl(config)
+    assert config.scene.meshes is not None and config.scene.meshes.gradient_mode == config.scene.meshes.CONSISTENT_GRADIENT
+    model = config.kinematics.model
+    arrays = {**cuboid_scene_arrays([[table]]), **mesh_scene_arrays([[dict(ball, name="ball")]])}
+    q0 = torch.tensor([[-0.6, 0.3, 0.0, -1.9, 0.0, 2.2, 0.8]], device=device)
+    q1 = q0.clone()
+    q1[0, 0] = 0.4
+    # the straight line between the two is in collision with the ball, its ends are not
+    tt = np.linspace(0, 1, 41, dtype=np.float32)[:, None]
+    line = q0.cpu().numpy() * (1 - tt) + q1.cpu().numpy() * tt
+    pen = oracle.scene_collision(oracle.kinematics_forward(line, model.as_dict(), horizon=41)["robot_spheres"].reshape(1, 41, -1, 4),
+                                 arrays, 1.0, 0.0)["distance"][0].sum(-1)
+    assert pen[0] == 0 and pen[-1] == 0 and pen.max() > 0.05
+    state = JointState(position=q0.clone(), velocity=torch.zeros_like(q0), acceleration=torch.zeros_like(q0), joint_names=mpc.joint_names)
+    mpc.setup(state)
+    goal = mpc.compute_kinematics(JointState.from_position(q1)).tool_poses.as_goal()
+    assert mpc.update_goal_tool_poses(goal)
+    visited = []
+    for _ in range(700):
+        r = mpc.optimize_next_action(state)
+        state = JointState(position=r.next_action.position.clone(), velocity=r.next_action.velocity.clone(),
+                           acceleration=r.next_action.acceleration.clone(), joint_names=mpc.joint_names)
+        visited.append(state.position[0].cpu().numpy())
+    p = mpc.compute_kinematics(JointState.from_position(state.position)).tool_poses.position[:, 0, 0]
+    assert float((p - goal.position[:, 0, 0, 0]).norm(dim=-1).max()) < 0.015
+    v = np.stack(visited[::4])
+    sph = oracle.kinematics_forward(v, model.as_dict())["robot_spheres"].reshape(len(v), 1, -1, 4)
+    d = oracle.scene_collision(sph, arrays, 1.0, 0.0)["distance"].sum((1, 2))
+    assert (d == 0).all(), (int((d > 0).sum()), float(d.max()))
