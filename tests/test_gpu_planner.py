@@ -262,6 +262,49 @@ def test_motion_planner_in_a_mesh_world(oracle, device, this_repos_curobo):
                         config.trajopt_solver_config.solver_cfg().rollout)
 
 
+def test_motion_planner_in_a_voxel_world(oracle, device, this_repos_curobo):
+    """the same problem with the pillar as an ESDF voxel grid (reference ``VoxelGrid`` entry of a scene description: dims,
+    voxel_size, feature_tensor, pose): the planner's graphs run the voxel lookup next to the cuboid store; the winner is clear
+    of table and grid by the oracle's voxel restatement"""
+    from curobo.motion_planner import MotionPlanner, MotionPlannerCfg
+    from curobo.types import JointState
+
+    from curobo_amd.scene import cuboid_scene_arrays, voxel_grid_from_sdf
+    from curobo_amd.scene.config import voxel_arrays_from_config
+
+    centre, half = np.array([0.5, 0.0, 0.35]), np.array([0.08, 0.08, 0.35])
+
+    def pillar(p):
+        q = np.abs(p - centre) - half
+        return np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0)
+
+    pose = [0.5, 0.0, 0.45, 1, 0, 0, 0]
+    grid = voxel_grid_from_sdf(pillar, (32, 32, 48), 0.02, pose7=pose, max_distance=10.0)
+    table = {"dims": [2.0, 2.0, 0.2], "pose": [0.0, 0.0, -0.1, 1, 0, 0, 0]}
+    world = {"cuboid": {"table": table}, "voxel": {"pillar": {"dims": [0.64, 0.64, 0.96], "voxel_size": 0.02, "pose": pose,
+                                                              "feature_tensor": grid["voxel_features"].reshape(-1)}}}
+    config = MotionPlannerCfg.create(robot="franka.yml", scene_model=world, num_ik_seeds=32, num_trajopt_seeds=4)
+    planner = MotionPlanner(config)
+    model = config.trajopt_solver_config.kinematics.model
+    arrays = {**cuboid_scene_arrays([[table]]), **voxel_arrays_from_config(world)}
+    q0 = torch.tensor([[-0.9, 0.3, 0.0, -1.9, 0.0, 2.2, 0.8]], device=planner.default_joint_state.position.device)
+    cur = JointState.from_position(q0, planner.joint_names)
+    goal_js = cur.clone()
+    goal_js.position[0, 0] = 0.9
+    H = 33
+    tt = np.linspace(0, 1, H, dtype=np.float32)[:, None]
+    line = cur.position[0].cpu().numpy()[None] * (1 - tt) + goal_js.position[0].cpu().numpy()[None] * tt
+    s_line = oracle.kinematics_forward(line, model.as_dict(), horizon=H)["robot_spheres"].reshape(1, H, -1, 4)
+    assert oracle.scene_collision(s_line, arrays, 1.0, 0.0)["distance"].sum() > 0.5
+    goal = planner.compute_kinematics(goal_js).tool_poses.as_goal()
+    res = planner.plan_pose(goal, cur, max_attempts=3)
+    assert res is not None and bool(res.success[0, 0]), res
+    assert float(res.position_error[0, 0]) < 0.005 and float(res.rotation_error[0, 0]) < 0.05
+    traj = res.js_solution.position[0].cpu().numpy()
+    _verify_with_oracle(oracle, model, arrays, traj, res.js_solution.dt[0].cpu().numpy(), cur.position[0].cpu().numpy(),
+                        config.trajopt_solver_config.solver_cfg().rollout)
+
+
 def test_batch_motion_planner_one_world_per_problem(oracle, device, this_repos_curobo):
     """BASELINE config 5 at planner level (reference motion_planner_batch.py with multi_env): a batch of problems, each with
     its own start state, goal and world; every winner is collision free in ITS world."""
