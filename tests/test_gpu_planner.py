@@ -260,6 +260,17 @@ def test_motion_planner_in_a_mesh_world(oracle, device, this_repos_curobo):
     traj = res.js_solution.position[0].cpu().numpy()
     _verify_with_oracle(oracle, model, arrays, traj, res.js_solution.dt[0].cpu().numpy(), cur.position[0].cpu().numpy(),
                         config.trajopt_solver_config.solver_cfg().rollout)
+    # the pillar lifted out of the way IN PLACE (the captured graphs read the pose buffer): the next plan is shorter; put back,
+    # the plan goes around it again
+    around = float(res.motion_time[0, 0])
+    scene.update_obstacle_pose("pillar", [0.5, 0.0, 3.35, 1, 0, 0, 0])
+    res_free = planner.plan_pose(goal, cur, max_attempts=3)
+    assert res_free is not None and bool(res_free.success[0, 0]) and float(res_free.motion_time[0, 0]) < 0.85 * around
+    scene.update_obstacle_pose("pillar", [0.5, 0.0, 0.35, 1, 0, 0, 0])
+    res_back = planner.plan_pose(goal, cur, max_attempts=3)
+    assert res_back is not None and bool(res_back.success[0, 0])
+    _verify_with_oracle(oracle, model, arrays, res_back.js_solution.position[0].cpu().numpy(), res_back.js_solution.dt[0].cpu().numpy(),
+                        cur.position[0].cpu().numpy(), config.trajopt_solver_config.solver_cfg().rollout)
 
 
 def test_motion_planner_in_a_voxel_world(oracle, device, this_repos_curobo):
