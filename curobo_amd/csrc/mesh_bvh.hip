@@ -755,14 +755,14 @@ __global__ void __launch_bounds__(256) MESH_CELLS_ATTR sphere_mesh_cells_kernel(
     }
     const unsigned flags = (SWEEP > 0 && nb_prev ? 1u : 0u) | (SWEEP > 0 && nb_next ? 2u : 0u);
     uint32_t m = e.y;
-    bool answered = true;
+    int code = MESH_CELLS_OK;
 #pragma unroll 1
-    while (m && answered) {
+    while (m && code == MESH_CELLS_OK) {
       const int k = __ffs((int)m) - 1;
       m &= m - 1;
       const MeshPoseSlot slot = load_mesh_pose_slot(a.set, env, a.slot0 + k, st);
       st[MESH_ST_COST] = 0.0f; st_store3(st, MESH_ST_GRAD, make_f3(0.f, 0.f, 0.f));
-      answered = mesh_contribution_cells<SWEEP, (int)G, UNROLL>(slot, a.set.gradient_mode, st, flags, r_adj, eta, reach, q);
+      code = mesh_contribution_cells<SWEEP, (int)G, UNROLL>(slot, a.set.gradient_mode, st, flags, r_adj, eta, reach, q);
       const float cost_sum = st[MESH_ST_COST];
       if (cost_sum > 0.0f) {
         const f3 gw = mesh_to_world_vector_st(st, st_load3(st, MESH_ST_GRAD));
@@ -771,14 +771,85 @@ __global__ void __launch_bounds__(256) MESH_CELLS_ATTR sphere_mesh_cells_kernel(
       }
     }
     if (!live_group || (threadIdx.x & (G - 1u)) != 0) continue;
-    if (!answered) {  // to the tree walk, whole
-      qa.queue2[atomicAdd(qa.counter + 1, 1u)] = e;
+    if (code != MESH_CELLS_OK) {  // whole, to the tree walk (queue2 from its head) or to a workgroup of its own (from its tail)
+      if (code == MESH_CELLS_TO_WALK) qa.queue2[atomicAdd(qa.counter + 1, 1u)] = e;
+      else qa.queue2[q_last - atomicAdd(qa.counter + 3, 1u)] = e;
       continue;
     }
     float dsum = st[MESH_ST_DSUM];
     f3 gsum = st_load3(st, MESH_ST_GSUM);
     if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f)
       mesh_speed_metric(st_load3(st, MESH_ST_CENTER), st_load3(st, MESH_ST_PREV), st_load3(st, MESH_ST_NEXT), a.speed_dt[0], dsum, gsum);
+    float4 *grad = reinterpret_cast<float4 *>(a.gradient);
+    if (a.accumulate) {
+      if (dsum > 0.0f) {
+        a.distance[sidx] += dsum;
+        const float4 g0 = grad[sidx];
+        grad[sidx] = make_float4(g0.x + gsum.x, g0.y + gsum.y, g0.z + gsum.z, g0.w);
+      }
+    } else {
+      a.distance[sidx] = dsum;
+      grad[sidx] = make_float4(gsum.x, gsum.y, gsum.z, 0.0f);
+    }
+  }
+}
+
+// ---- one workgroup per sphere: what the cell-list kernel sent to the tail of queue2 (counter word 3) -- spheres with a query
+// about equally far from hundreds or thousands of triangles (the middle of a ball, the axis of a pipe).  Eight lanes walking a
+// tree that cannot prune, or scanning a list that is the whole mesh, held the launch for 430 us with FIVE such spheres in the
+// tests' mesh world (128 trajectories: 473 us, of which the walk kernel 406; docs/NOTEBOOK.md round 6); 256 lanes answer each
+// query by mesh_block_sdf.  Every thread of the workgroup carries the sphere's sweep state (the same values): the control flow
+// is uniform, the barriers inside the query are met by all.
+template <int SWEEP>
+__global__ void __launch_bounds__(256) sphere_mesh_wide_kernel(const MeshQueueArgs qa) {
+  const MeshCollArgs &a = qa.c;
+  const uint32_t n = qa.counter[3];
+  const uint32_t q_last = (uint32_t)((long)a.batch * a.horizon * a.nspheres - 1);
+  const int hs = a.horizon * a.nspheres;
+  const float4 *sph = reinterpret_cast<const float4 *>(a.spheres);
+  const float w = a.weight[0], eta = a.eta[0];
+  __shared__ MeshWideLds lds;
+  for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+    const uint2 e = qa.queue2[q_last - q];
+    const long sidx = (long)e.x;
+    const int b = (int)(e.x / (uint32_t)hs);
+    const int h = (int)((e.x - (uint32_t)b * (uint32_t)hs) / (uint32_t)a.nspheres);
+    const int env = a.use_multi_env ? a.env_query_idx[b] : 0;
+    const bool need_nb = SWEEP > 0 || a.enable_speed_metric != 0;
+    const bool nb_prev = need_nb && h > 0, nb_next = need_nb && h < a.horizon - 1;
+    const float4 s = sph[sidx];
+    const float4 ps = nb_prev ? sph[sidx - a.nspheres] : s, ns = nb_next ? sph[sidx + a.nspheres] : s;
+    const f3 center = make_f3(s.x, s.y, s.z), pp = make_f3(ps.x, ps.y, ps.z), np = make_f3(ns.x, ns.y, ns.z);
+    const bool hp = SWEEP > 0 && nb_prev, hn = SWEEP > 0 && nb_next;
+    const float r_adj = s.w + eta;
+    float half_w_prev = 0.0f, half_w_next = 0.0f;
+    if (SWEEP > 0) {
+      if (hp) { const f3 dd = pp - center; half_w_prev = 0.5f * sqrtf(dot(dd, dd)); }
+      if (hn) { const f3 dd = np - center; half_w_next = 0.5f * sqrtf(dot(dd, dd)); }
+    }
+    const float reach = SWEEP > 0 ? fmaxf(half_w_prev, half_w_next) * 1.0001f + 2e-6f : 2e-6f;
+    float dsum = 0.0f;
+    f3 gsum = make_f3(0.f, 0.f, 0.f);
+    uint32_t m = e.y;
+#pragma unroll 1
+    while (m) {
+      const int k = __ffs((int)m) - 1;
+      m &= m - 1;
+      const MeshSlot slot = load_mesh_slot(a.set, env, a.slot0 + k);
+      float cost_sum = 0.0f;
+      f3 grad_local = make_f3(0.f, 0.f, 0.f);
+      mesh_contribution_q<SWEEP>(slot, a.set.gradient_mode, mesh_to_local(slot, center), hp, hn, pp, np, r_adj, eta, half_w_prev, half_w_next,
+                                 reach, cost_sum, grad_local, [&](f3 qp, float, float max_distance, bool, f3 &g) {
+                                   return mesh_block_sdf(slot.m, qp, max_distance, g, lds);
+                                 });
+      if (cost_sum > 0.0f) {
+        const f3 gw = mesh_to_world_vector(slot, grad_local);
+        dsum += w * cost_sum;
+        gsum = gsum + w * gw;
+      }
+    }
+    if (a.enable_speed_metric && nb_prev && nb_next && dsum > 0.0f) mesh_speed_metric(center, pp, np, a.speed_dt[0], dsum, gsum);
+    if (threadIdx.x != 0) continue;
     float4 *grad = reinterpret_cast<float4 *>(a.gradient);
     if (a.accumulate) {
       if (dsum > 0.0f) {
@@ -966,6 +1037,7 @@ static int sphere_mesh_collision_impl(
       // with cell lists: select -> cell-list kernel (every sphere it can answer) -> tree walk of the few it could not
       const unsigned cells_blocks = (unsigned)std::min<long>(8192, ceil_div_l(total, 256 / MESH_CELLS_GROUP));
       const unsigned rest_blocks = std::min(walk_blocks, 4096u);
+      const unsigned wide_blocks = (unsigned)std::min<long>(2048, total);  // (a workgroup per sphere sent there: usually none)
       if (sweep_steps > 0) {
         hipLaunchKernelGGL((sphere_mesh_select_kernel<3>), select_grid, block, 0, st, qa);
         if (with_cells) {
@@ -976,6 +1048,7 @@ static int sphere_mesh_collision_impl(
             hipLaunchKernelGGL((sphere_mesh_cells_kernel<3, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 0>), dim3(cells_blocks), block, 0, st, qa);
           }
           qa.from_queue2 = 1;
+          hipLaunchKernelGGL((sphere_mesh_wide_kernel<3>), dim3(wide_blocks), dim3(256), 0, st, qa);
           hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(rest_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
         } else {
           hipLaunchKernelGGL((sphere_mesh_walk_kernel<3>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
@@ -990,6 +1063,7 @@ static int sphere_mesh_collision_impl(
             hipLaunchKernelGGL((sphere_mesh_cells_kernel<0, MESH_CELLS_GROUP, MESH_CELLS_UNROLL, 0>), dim3(cells_blocks), block, 0, st, qa);
           }
           qa.from_queue2 = 1;
+          hipLaunchKernelGGL((sphere_mesh_wide_kernel<0>), dim3(wide_blocks), dim3(256), 0, st, qa);
           hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(rest_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);
         } else {
           hipLaunchKernelGGL((sphere_mesh_walk_kernel<0>), dim3(walk_blocks), dim3(MESH_WALK_THREADS), 0, st, qa);

@@ -419,10 +419,12 @@ __device__ __forceinline__ bool mesh_early_reject(const MeshSlot &s, f3 lc, floa
 // Cost and mesh-frame gradient of ONE sphere against ONE mesh that passed the early reject: the centre sample plus the
 // sweep towards the previous / next point (wp_sweep_collision_kernel.py:176-254; the mesh twin of
 // scene_device.hpp::obstacle_contribution).  lc = centre in the mesh frame, reach as for mesh_early_reject.
-template <int SWEEP>
-__device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
-                                                  f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
-                                                  float reach, float &cost_sum, f3 &grad_local) {
+// (QUERY: sdf = query(point, radius that matters, max_distance, may be inside, gradient&) -- mesh_sdf_within for a lane on its own,
+// mesh_block_sdf for a workgroup that answers one sphere's queries together)
+template <int SWEEP, class QUERY>
+__device__ __forceinline__ void mesh_contribution_q(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
+                                                    f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
+                                                    float reach, float &cost_sum, f3 &grad_local, QUERY query) {
   // max_distance = max(half the bounding-box diagonal, the query distance) (data_mesh.py:660-668)
   const float max_distance = fmaxf(s.max_half_diag, r_adj);
   // how far the centre's distance matters: its cost below r_adj, the sweep culling below r_adj + the half segment
@@ -437,7 +439,7 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
 #pragma unroll 1
   for (;;) {
     f3 g;
-    const float sdf = mesh_sdf_within(s.m, qp, q_radius, max_distance, q_may_in, g);
+    const float sdf = query(qp, q_radius, max_distance, q_may_in, g);
     if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
     const float pen = -sdf + r_adj;
     float c = 0.0f, gs = 0.0f;
@@ -489,6 +491,16 @@ __device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradien
     q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
     q_may_in = s.m.sign_rule != 0 || sdf_c < half_dist;
   }
+}
+
+template <int SWEEP>
+__device__ __forceinline__ void mesh_contribution(const MeshSlot &s, int gradient_mode, f3 lc, bool has_prev, bool has_next, f3 prev_c,
+                                                  f3 next_c, float r_adj, float eta, float half_w_prev, float half_w_next,
+                                                  float reach, float &cost_sum, f3 &grad_local) {
+  mesh_contribution_q<SWEEP>(s, gradient_mode, lc, has_prev, has_next, prev_c, next_c, r_adj, eta, half_w_prev, half_w_next, reach, cost_sum,
+                             grad_local, [&](f3 qp, float q_radius, float max_distance, bool may_in, f3 &g) {
+                               return mesh_sdf_within(s.m, qp, q_radius, max_distance, may_in, g);
+                             });
 }
 
 // ---- the same contribution by a GROUP of G lanes (sphere_mesh_walk_kernel), every query of the item in ONE loop.
@@ -834,13 +846,22 @@ __device__ __forceinline__ float group_sum_dpp(float v) {  // G = 4, 8, 16 or 32
 // the same query.  Returns false when the cell lists cannot answer it (the caller walks the tree instead).  A surface
 // farther than `q_radius` from a point OUTSIDE it may be reported as "nothing within max_distance" (max_distance, 0), exactly
 // as mesh_sdf_within does -- the callers' results are the same either way (see mesh_sdf_within).
+// Answers: MESH_CELLS_OK; MESH_CELLS_TO_WALK -- the lists do not apply (no lists, a mesh signed by rays, a point outside the grid
+// that the radius still reaches: the tree walk prunes those well); MESH_CELLS_TO_WIDE -- the lists apply and this group of G lanes
+// is the wrong tool: a cell without a list (more candidates than the build gathers), a list that ends before the prefix does, or
+// a prefix still open after MESH_CELLS_MAX_ROUNDS rounds (a point about equally far from hundreds of triangles: the centre of a
+// ball) -- such a sphere is answered by a whole workgroup (sphere_mesh_wide_kernel), not by eight lanes while the launch waits.
+enum : int { MESH_CELLS_OK = 0, MESH_CELLS_TO_WALK = 1, MESH_CELLS_TO_WIDE = 2 };
+#ifndef MESH_CELLS_MAX_ROUNDS
+#define MESH_CELLS_MAX_ROUNDS 16
+#endif
 template <int G, int U>
-__device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, float q_radius, float max_distance, float &sdf, f3 &grad,
-                                               unsigned stat_q = 0u) {
+__device__ __forceinline__ int mesh_cells_sdf(const MeshCellsView &mv, f3 qp, float q_radius, float max_distance, float &sdf, f3 &grad,
+                                              unsigned stat_q = 0u) {
   constexpr float FAR = 3.0e38f;
   sdf = max_distance;
   grad = make_f3(0.f, 0.f, 0.f);
-  if (mv.cell_start == nullptr) return false;
+  if (mv.cell_start == nullptr) return MESH_CELLS_TO_WALK;
   const int g = threadIdx.x & (G - 1), gbase = threadIdx.x & (64 - G);
   const float lx = mv.st[MESH_ST_GRID_LO], ly = mv.st[MESH_ST_GRID_LO + 1], lz = mv.st[MESH_ST_GRID_LO + 2], h = mv.st[MESH_ST_GRID_H];
   const int nx = __float_as_int(mv.st[MESH_ST_GRID_N]), ny = __float_as_int(mv.st[MESH_ST_GRID_N + 1]), nz = __float_as_int(mv.st[MESH_ST_GRID_N + 2]);
@@ -850,7 +871,7 @@ __device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, f
   if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && ix < nx && iy < ny && iz < nz)) {
     // outside the grid = farther than grid_pad from the bounding box, hence from the surface, and outside it under either
     // sign rule (the reference's rays all have to hit: the point would lie inside the box)
-    return q_radius <= mv.st[MESH_ST_GRID_PAD];
+    return q_radius <= mv.st[MESH_ST_GRID_PAD] ? MESH_CELLS_OK : MESH_CELLS_TO_WALK;
   }
   const int cell = (ix * ny + iy) * nz + iz;
   const uint2 rec = mv.cell_start[cell];
@@ -866,8 +887,9 @@ __device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, f
 #endif
   if (g == 0) CUROBO_MESH_COUNT(0, 1);
   // the surface is at least dc - delta away from p: outside and beyond the radius needs no triangle
-  if (cell_side == 1u && dc - delta > q_radius) { if (g == 0) CUROBO_MESH_COUNT(4, 1); return true; }
-  if (n <= 1) return false;  // a cell without a list
+  if (cell_side == 1u && dc - delta > q_radius) { if (g == 0) CUROBO_MESH_COUNT(4, 1); return MESH_CELLS_OK; }
+  if (mv.mp->sign_rule != 0) return MESH_CELLS_TO_WALK;  // (a mesh signed by the reference's rays: see below)
+  if (n <= 1) return MESH_CELLS_TO_WIDE;  // a cell without a list
   // the closest triangle of p is no farther than dc + 2 delta from the centre
   float l_d2 = FAR, lim = dc * 1.000001f + 2.0f * delta, best_d2 = FAR;
   f3 l_c = qp;
@@ -918,9 +940,10 @@ __device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, f
     const float last_dist = __shfl(e[U - 1].y, gbase | (G - 1), 64);
     if (last_tri < 0) { complete = last_dist >= lim; break; }
     if (last_dist > lim) { complete = true; break; }
+    if (k + U * G >= MESH_CELLS_MAX_ROUNDS * U * G) break;  // (uniform over the group)
   }
-  if (!complete) return false;
-  if (!(best_d2 <= max_distance * max_distance)) return true;  // nothing within max_distance: (max_distance, 0)
+  if (!complete) return MESH_CELLS_TO_WIDE;
+  if (!(best_d2 <= max_distance * max_distance)) return MESH_CELLS_OK;  // nothing within max_distance: (max_distance, 0)
   const float best_d = sqrtf(best_d2);
   const bool winner = l_d2 == best_d2;
   const unsigned win = group_ballot<G>(winner);
@@ -936,14 +959,14 @@ __device__ __forceinline__ bool mesh_cells_sdf(const MeshCellsView &mv, f3 qp, f
     // agree.  So no query of a closed mesh needs a ray here (the tree walk casts rays where mesh_feature_side gives no verdict:
     // as a call from this kernel that cast cost a fifth of its registers, and handed to the walk kernel one such sphere costs
     // the launch 100 us).  A mesh signed by the reference's rays (sign_rule 1) does go to the tree walk.
-    if (mv.mp->sign_rule != 0) return false;
+    if (mv.mp->sign_rule != 0) return MESH_CELLS_TO_WALK;
     float term = 0.0f;
     if (winner && best_d2 > 1e-12f) term = l_tie_term + mesh_side_term(mv.tri, mv.mp->tri_pn, l_t, l_region, qp - l_c);
     inside = group_sum_dpp<G>(term) < 0.0f;
   }
   if (best_d > 1e-6f) grad = (1.0f / best_d) * (qp - cp);
   sdf = inside ? -best_d : best_d;
-  return true;
+  return MESH_CELLS_OK;
 }
 
 // one obstacle slot of a mesh set for the cell-list kernel: the mesh record stays in memory (see MeshCellsView), the pose goes
@@ -978,8 +1001,8 @@ __device__ __forceinline__ f3 mesh_to_world_vector_st(const float *st, f3 v) {
 // the group's LDS record.  flags: bit 0 / 1 = the previous / next point exists.  Returns false when a query of the item could
 // not be answered by the lists: the caller then hands the sphere to the tree walk.
 template <int SWEEP, int G, int U>
-__device__ __forceinline__ bool mesh_contribution_cells(const MeshPoseSlot &s, int gradient_mode, float *st, unsigned flags,
-                                                        float r_adj, float eta, float reach, unsigned stat_q = 0u) {
+__device__ __forceinline__ int mesh_contribution_cells(const MeshPoseSlot &s, int gradient_mode, float *st, unsigned flags,
+                                                       float r_adj, float eta, float reach, unsigned stat_q = 0u) {
   const float max_distance = fmaxf(s.max_half_diag, r_adj);
   const float cull_slack = 2e-6f + 1e-6f * max_distance;
   const bool lipschitz = s.mp->sign_rule == 0;
@@ -993,7 +1016,7 @@ __device__ __forceinline__ bool mesh_contribution_cells(const MeshPoseSlot &s, i
   for (;;) {
     f3 g;
     float sdf;
-    if (!mesh_cells_sdf<G, U>(mv, qp, q_radius, max_distance, sdf, g, stat_q)) return false;
+    if (const int code = mesh_cells_sdf<G, U>(mv, qp, q_radius, max_distance, sdf, g, stat_q)) return code;
     if (gradient_mode == 1 && sdf > 0.0f) g = -1.0f * g;
     const float pen = -sdf + r_adj;
     float c = 0.0f, gs = 0.0f;
@@ -1040,7 +1063,86 @@ __device__ __forceinline__ bool mesh_contribution_cells(const MeshPoseSlot &s, i
     qp = tt * lc + (1.0f - tt) * ln;
     q_radius = (r_adj + (half_dist - jump)) * 1.0001f + 1e-6f;
   }
-  return true;
+  return MESH_CELLS_OK;
+}
+
+// ---- one query answered by a WHOLE WORKGROUP (sphere_mesh_wide_kernel): every thread calls with the same arguments and gets the
+// same result.  The exact closest point over the leaves whose boxes lie within an a-priori bound -- the distance of the cell's
+// centre from the surface + the point's distance from that centre where the mesh has a cell grid, else max_distance -- thread i
+// taking leaves i, i + 256, ...: no tree, no list, no order to get wrong; for the points that are sent here (about equally far
+// from very many triangles) nothing prunes anyway and 256 lanes are 32 times the eight of the other kernels.  The sign as in
+// mesh_cells_sdf (the sum of the side terms of every triangle at the minimum; sign_rule 1: the reference's rays, every lane the
+// same walk).  Ties between triangles are settled by the lower triangle index (deterministic).
+struct MeshWideLds {
+  float w_d2[4], w_term[4], cp[3];
+  int w_t[4];
+};
+__device__ __forceinline__ float mesh_block_sdf(const curobo_hip_mesh &m, f3 qp, float max_distance, f3 &grad, MeshWideLds &L) {
+  constexpr float FAR = 3.0e38f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4 *box = reinterpret_cast<const float4 *>(m.node_box);
+  const TriRec *tri = reinterpret_cast<const TriRec *>(m.tri);
+  grad = make_f3(0.f, 0.f, 0.f);
+  float ub = max_distance * 1.000001f + 1e-6f;
+  if (m.cell_start != nullptr) {
+    const float inv_h = __frcp_rn(m.grid_h);
+    const float fx = (qp.x - m.grid_lo[0]) * inv_h, fy = (qp.y - m.grid_lo[1]) * inv_h, fz = (qp.z - m.grid_lo[2]) * inv_h;
+    const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
+    if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && ix < m.grid_n[0] && iy < m.grid_n[1] && iz < m.grid_n[2]) {
+      const uint2 rec = reinterpret_cast<const uint2 *>(m.cell_start)[(ix * m.grid_n[1] + iy) * m.grid_n[2] + iz];
+      const f3 dv = qp - make_f3(m.grid_lo[0] + ((float)ix + 0.5f) * m.grid_h, m.grid_lo[1] + ((float)iy + 0.5f) * m.grid_h,
+                                 m.grid_lo[2] + ((float)iz + 0.5f) * m.grid_h);
+      ub = fminf(ub, __int_as_float((int)rec.y) * 1.00001f + sqrtf(dot(dv, dv)) * 1.0001f + 4e-6f);
+    }
+  }
+  const float ub2 = ub * ub;
+  float l_d2 = FAR, l_tie_term = 0.0f;
+  f3 l_c = qp;
+  int l_t = 0x7fffffff, l_region = 0;
+  const int used = (m.n_tri + m.leaf_size - 1) / m.leaf_size;
+#pragma unroll 1
+  for (int leaf = tid; leaf < used; leaf += 256) {
+    if (box_dist2(box[(size_t)(m.n_leaves + leaf) * 2], box[(size_t)(m.n_leaves + leaf) * 2 + 1], qp) > ub2) continue;
+    const int t1 = min((leaf + 1) * m.leaf_size, m.n_tri);
+#pragma unroll 1
+    for (int t = leaf * m.leaf_size; t < t1; t++) {
+      const TriRec r = tri[t];
+      int region;
+      const f3 c = closest_on_triangle(qp, make_f3(r.a.x, r.a.y, r.a.z), make_f3(r.ab.x, r.ab.y, r.ab.z), make_f3(r.ac.x, r.ac.y, r.ac.z), region);
+      const f3 d = qp - c;
+      const float d2 = dot(d, d);
+      if (d2 <= l_d2) {  // (triangles come in ascending order within a lane: on a tie the lower index stays the kept one)
+        if (d2 == l_d2) l_tie_term += mesh_side_term(tri, m.tri_pn, t, region, d);
+        else { l_tie_term = 0.0f; l_d2 = d2; l_c = c; l_t = t; l_region = region; }
+      }
+    }
+  }
+  float wmin = l_d2;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+  __syncthreads();  // (the previous query's readers are done with L)
+  if (lane == 0) L.w_d2[wave] = wmin;
+  __syncthreads();
+  const float dmin = fminf(fminf(L.w_d2[0], L.w_d2[1]), fminf(L.w_d2[2], L.w_d2[3]));
+  if (!(dmin <= max_distance * max_distance)) return max_distance;  // (uniform) nothing within max_distance: (max_distance, 0)
+  const bool winner = l_d2 == dmin;
+  int wt = winner ? l_t : 0x7fffffff;
+  float term = (winner && dmin > 1e-12f) ? l_tie_term + mesh_side_term(tri, m.tri_pn, l_t, l_region, qp - l_c) : 0.0f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    wt = min(wt, __shfl_xor(wt, o, 64));
+    term += __shfl_xor(term, o, 64);
+  }
+  if (lane == 0) { L.w_t[wave] = wt; L.w_term[wave] = term; }
+  __syncthreads();
+  const int best_t = min(min(L.w_t[0], L.w_t[1]), min(L.w_t[2], L.w_t[3]));
+  if (winner && l_t == best_t) { L.cp[0] = l_c.x; L.cp[1] = l_c.y; L.cp[2] = l_c.z; }
+  __syncthreads();
+  const f3 cp = make_f3(L.cp[0], L.cp[1], L.cp[2]);
+  const bool inside = m.sign_rule == 0 ? (L.w_term[0] + L.w_term[1]) + (L.w_term[2] + L.w_term[3]) < 0.0f : mesh_inside_warp_rays(m, qp);
+  const float best_d = sqrtf(dmin);
+  if (best_d > 1e-6f) grad = (1.0f / best_d) * (qp - cp);
+  return inside ? -best_d : best_d;
 }
 
 __device__ __forceinline__ f3 mesh_to_world_vector(const MeshSlot &s, f3 v) {  // transform_vector(transform_inverse(inv_t), .)

@@ -331,10 +331,11 @@ def test_trajopt_rollout_in_a_mesh_world_against_the_oracle_composition(with_cub
     off (the fused launch does not walk meshes) and the kernel sequence runs with the mesh launch adding its share to the
     cuboid kernel's: cost and d cost / d knots against the oracle's composition of the stages with the mesh kind in its scene
     restatement, and replayed from a hipGraph.
-    (Measured and not kept: the fused launch for every other term + the meshes' share by its own chain on a side stream --
-    B-spline samples -> FK -> BVH walk -> FK VJP -> B-spline VJP, added to the fused result; equal to this sequence to 2e-7
-    and SLOWER, 575 us against 540 us per 1024 rollouts in the bench's mesh world: FK -> mesh walk (447 us) -> FK VJP is the
-    critical path of both, and the fused launch next to it only competes for the CUs.)"""
+    (Measured and not kept, twice: the fused launch for every other term + the meshes' share by its own chain on a side stream --
+    B-spline samples -> FK -> mesh launch -> FK VJP -> B-spline VJP, added to the fused result; equal to this sequence to 3e-7.
+    Round 4: SLOWER at 1024 rollouts, 575 us against 540 us in the bench's mesh world.  Round 6, at a planner's sizes: the same --
+    16 / 32 / 64 / 128 rollouts 116 / 135 / 143 / 554 us against the sequence's 115 / 137 / 149 / 569 us
+    (tools/r06/mesh_rollout_forms.py as it then was): FK -> mesh launch -> FK VJP is the critical path of both.)"""
     from oracle.oracle import mesh_scene_arrays
     from oracle_compose import trajopt_cost_and_gradient
 
@@ -557,7 +558,7 @@ def _mesh_launch(device, world, sph, sweep, cells, **store_kw):
     torch.cuda.synchronize()
     owner = dist._base if dist._base is not None else dist
     ws = next(iter(owner._curobo_mesh_ws.values()))
-    counters = ws[:16].view(torch.int32).cpu().numpy()  # [heavy, handed to the tree walk, light, -]
+    counters = ws[:16].view(torch.int32).cpu().numpy()  # [heavy, handed to the tree walk, light, handed to a workgroup of its own]
     return dist.cpu().numpy(), grad.cpu().numpy(), counters, store
 
 
@@ -594,13 +595,46 @@ def test_cell_lists_fall_back_to_the_walk_beyond_the_grid_and_without_lists(orac
     world = mesh_world()
     sph = torch.as_tensor(_trajectory_spheres(oracle, 24, 9), device=device)
     d_w, g_w, cnt_w, _ = _mesh_launch(device, world, sph, True, False)
-    for cells, least in (({"cell_size": 0.05, "pad": 0.0, "gather_cap": 1}, 0.5), ({}, 0.0)):
+    for cells, least in (({"cell_size": 0.05, "pad": 0.0, "gather_cap": 1}, 0.5), (None, 0.0)):
         d_c, g_c, cnt_c, _ = _mesh_launch(device, world, sph, True, cells)
         live = int(cnt_c[0]) + int(cnt_c[2])
-        assert cnt_c[1] >= least * live and (least == 0.0 or cnt_c[1] > 0)
+        # (outside the grid: to the tree walk, word 1; a cell without a list: to a workgroup of its own, word 3)
+        assert cnt_c[1] + cnt_c[3] >= least * live and (least == 0.0 or (cnt_c[1] > 0 and cnt_c[3] > 0))
         np.testing.assert_allclose(d_c, d_w, rtol=2e-6, atol=1e-7)
         bad = np.abs(g_c - g_w).max(-1) > 1e-5 + 1e-4 * np.abs(g_w).max(-1)
         assert bad.mean() < 2e-3
+
+
+@pytest.mark.parametrize("sweep", [False, True])
+def test_spheres_in_the_middle_of_a_ball_get_a_workgroup_each(sweep, oracle, device):
+    """Points about equally far from every triangle (the middle of a ball of 3 968 triangles, the axis of a torus' tube): the
+    cells there have no list (more candidates than the build gathers) or a prefix that is the whole list, and no tree prunes --
+    eight lanes held the launch for 430 us with FIVE such spheres (tools/r06/mesh_fallback_probe.py).  The cell-list kernel
+    hands them to ``sphere_mesh_wide_kernel`` (a workgroup per sphere, every leaf within the a-priori bound tested by 256
+    lanes): same distances as the tree walk launch, none of them sent to the walk, and as the oracle's brute force has them."""
+    from oracle.oracle import mesh_scene_arrays
+
+    vs, fs = sphere_shape(0.2, 32, 64)
+    world = [[{"name": "ball", "vertices": vs, "faces": fs, "pose": [0.1, -0.2, 0.3, 0.9238795, 0, 0.3826834, 0]}]]
+    rng = np.random.default_rng(5)
+    b, h, S = 6, 5, 16
+    c = np.array([0.1, -0.2, 0.3], np.float32)
+    sph = np.zeros((b, h, S, 4), np.float32)
+    sph[..., :3] = c + rng.normal(size=(b, 1, S, 3)).astype(np.float32) * np.array([0.004, 0.004, 0.06], np.float32)  # around the middle, and out along z
+    sph[..., :3] += (np.arange(h, dtype=np.float32)[None, :, None, None] - 2) * rng.normal(size=(b, 1, S, 3)).astype(np.float32) * 0.01
+    sph[..., 3] = 0.03
+    t = torch.as_tensor(sph, device=device)
+    d_c, g_c, cnt_c, store = _mesh_launch(device, world, t, sweep, None)
+    d_w, g_w, cnt_w, _ = _mesh_launch(device, world, t, sweep, False)
+    assert store.meshes[0].cells_info["max_list"] > 16 * 32 or store.meshes[0].cells_info["cells_without_list"] > 0
+    assert cnt_c[3] > 10 and cnt_c[1] == 0 and cnt_w[1] == 0, cnt_c
+    assert (d_w > 0).all()  # (every sphere is inside the ball)
+    np.testing.assert_allclose(d_c, d_w, rtol=2e-6, atol=1e-7)
+    assert (d_c != d_w).mean() < 0.02
+    bad = np.abs(g_c - g_w).max(-1) > 1e-5 + 1e-4 * np.abs(g_w).max(-1)
+    assert bad.mean() < 0.05, bad.mean()  # (near the middle the closest triangle is one of many within rounding of each other)
+    ref = oracle.scene_collision(sph, mesh_scene_arrays(world), 3.0, 0.02, sweep=sweep, enable_speed_metric=sweep, speed_dt=0.05)
+    np.testing.assert_allclose(d_c, ref["distance"], rtol=1e-4, atol=2e-5 * (20.0 if sweep else 1.0))
 
 
 def _open_fixtures():
