@@ -851,9 +851,16 @@ __device__ __forceinline__ float group_sum_dpp(float v) {  // G = 4, 8, 16 or 32
 // is the wrong tool: a cell without a list (more candidates than the build gathers), a list that ends before the prefix does, or
 // a prefix still open after MESH_CELLS_MAX_ROUNDS rounds (a point about equally far from hundreds of triangles: the centre of a
 // ball) -- such a sphere is answered by a whole workgroup (sphere_mesh_wide_kernel), not by eight lanes while the launch waits.
+// (Only for meshes of up to MESH_WIDE_MAX_LEAVES leaves = 32 k triangles: the workgroup's scan is over ALL leaves within its bound.
+// On a dense mesh a cell has no list because many SMALL triangles are near it, not because they are equally far: the tree prunes
+// those, and a scan of 20 k leaf boxes per query would not -- 159 k triangles, 23 k spheres sent there: 2.5 ms either way
+// (tools/r06/big_mesh_probe.py); such a mesh keeps the tree walk for what its lists cannot answer.)
 enum : int { MESH_CELLS_OK = 0, MESH_CELLS_TO_WALK = 1, MESH_CELLS_TO_WIDE = 2 };
 #ifndef MESH_CELLS_MAX_ROUNDS
 #define MESH_CELLS_MAX_ROUNDS 16
+#endif
+#ifndef MESH_WIDE_MAX_LEAVES
+#define MESH_WIDE_MAX_LEAVES 4096
 #endif
 template <int G, int U>
 __device__ __forceinline__ int mesh_cells_sdf(const MeshCellsView &mv, f3 qp, float q_radius, float max_distance, float &sdf, f3 &grad,
@@ -889,7 +896,8 @@ __device__ __forceinline__ int mesh_cells_sdf(const MeshCellsView &mv, f3 qp, fl
   // the surface is at least dc - delta away from p: outside and beyond the radius needs no triangle
   if (cell_side == 1u && dc - delta > q_radius) { if (g == 0) CUROBO_MESH_COUNT(4, 1); return MESH_CELLS_OK; }
   if (mv.mp->sign_rule != 0) return MESH_CELLS_TO_WALK;  // (a mesh signed by the reference's rays: see below)
-  if (n <= 1) return MESH_CELLS_TO_WIDE;  // a cell without a list
+  const int beyond = mv.mp->n_leaves <= MESH_WIDE_MAX_LEAVES ? MESH_CELLS_TO_WIDE : MESH_CELLS_TO_WALK;
+  if (n <= 1) return beyond;  // a cell without a list
   // the closest triangle of p is no farther than dc + 2 delta from the centre
   float l_d2 = FAR, lim = dc * 1.000001f + 2.0f * delta, best_d2 = FAR;
   f3 l_c = qp;
@@ -942,7 +950,7 @@ __device__ __forceinline__ int mesh_cells_sdf(const MeshCellsView &mv, f3 qp, fl
     if (last_dist > lim) { complete = true; break; }
     if (k + U * G >= MESH_CELLS_MAX_ROUNDS * U * G) break;  // (uniform over the group)
   }
-  if (!complete) return MESH_CELLS_TO_WIDE;
+  if (!complete) return beyond;
   if (!(best_d2 <= max_distance * max_distance)) return MESH_CELLS_OK;  // nothing within max_distance: (max_distance, 0)
   const float best_d = sqrtf(best_d2);
   const bool winner = l_d2 == best_d2;
