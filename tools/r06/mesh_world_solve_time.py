@@ -22,6 +22,8 @@ worlds = {"cuboid": {"cuboid": {"table": table, "pillar": {"dims": [0.16, 0.16, 
           "mesh": {"cuboid": {"table": table}, "mesh": {"pillar": {"vertices": vb, "faces": fb, "pose": pose}}}}
 for seeds in (4, 12):
     for name, world in worlds.items():
+        if os.environ.get("ONLY_MESH") and (name != "mesh" or seeds != 4):
+            continue
         config = MotionPlannerCfg.create(robot="franka.yml", scene_model=world, num_ik_seeds=32, num_trajopt_seeds=seeds)
         planner = MotionPlanner(config)
         q0 = torch.tensor([[-0.9, 0.3, 0.0, -1.9, 0.0, 2.2, 0.8]], device="cuda")
