@@ -26,8 +26,23 @@ def c2_scene():
     return SceneCfg(cuboid=[Cuboid(f"c{i}", list(o["pose"]), dims=list(o["dims"])) for i, o in enumerate(c2_world()[0])])
 
 
+def c2_mesh_scene():
+    """the C2 world with the table as a cuboid and the pillar and the blocks as triangle meshes (12 triangles each)"""
+    from curobo_amd.scene import box_mesh
+
+    obs = c2_world()[0]
+    meshes = {}
+    for i, o in enumerate(obs[1:]):
+        v, f = box_mesh(o["dims"])
+        meshes[f"m{i}"] = {"vertices": v.astype(np.float32), "faces": f.astype(np.int32), "pose": list(o["pose"])}
+    return {"cuboid": {"table": {"dims": list(obs[0]["dims"]), "pose": list(obs[0]["pose"])}}, "mesh": meshes}
+
+
 out = []
-for label, scene in (("collision_table.yml", "collision_table.yml"), ("C2 world (table, pillar, two blocks)", c2_scene())):
+cases = [("collision_table.yml", "collision_table.yml"), ("C2 world (table, pillar, two blocks)", c2_scene())]
+if os.environ.get("PLANNER_BENCH_MESH", "0") == "1":  # (round 6: the same world with meshes, same problems)
+    cases = [cases[1], ("C2 world, pillar and blocks as triangle meshes", c2_mesh_scene())]
+for label, scene in cases:
     planner = MotionPlanner(MotionPlannerCfg.create(robot="franka.yml", scene_model=scene))
     planner.warmup()
     torch.manual_seed(7)
