@@ -1233,7 +1233,9 @@ def _mesh_benchmark_body(model, kin, device, torch, world, meshes, B, H, cfg, ou
                                "cost_relative_to_cuboids": round(out["mesh_launch"]["cost_sum"] / max(out["cuboid_kernel"]["cost_sum"], 1e-9), 6),
                                "slowdown_vs_cuboid_kernel": round(times["mesh_launch"] / times["cuboid_kernel"], 2)})
     out["mesh_launch"]["kernels"] = ("curobo_hip_sphere_mesh_collision_ws: sphere_mesh_select_kernel<3> (bounding-box reject, queue) + "
-                                     "sphere_mesh_cells_kernel<3> (distance-sorted closest-triangle cell lists) + sphere_mesh_walk_kernel<3> (what the lists cannot answer)")
+                                     "sphere_mesh_cells_kernel<3> (distance-sorted closest-triangle cell lists) + sphere_mesh_wide_kernel<3> (a workgroup per sphere about "
+                                     "equally far from very many triangles) + sphere_mesh_walk_kernel<3> (what the lists do not apply to); the queue counters are "
+                                     "cleared by mesh_queue_reset_kernel")
     out["mesh_launch_tree_walk"]["note"] = "the same launch over meshes built without cell lists (round 4-5 form): select + tree walk"
     out["mesh_launch"]["speedup_vs_tree_walk"] = round(times["mesh_launch_tree_walk"] / times["mesh_launch"], 2)
     out["mesh_launch"]["cost_equals_tree_walk"] = bool(abs(out["mesh_launch"]["cost_sum"] - out["mesh_launch_tree_walk"]["cost_sum"])
