@@ -306,6 +306,20 @@ class SceneData:
         return SceneData(tensors=t, struct=struct, arrays=arrays, meshes=store)
 
 
+def warn_if_reference_mesh_gradient(scene: Optional["SceneData"], who: str) -> None:
+    """a solver over a scene whose mesh store hands out the reference's mesh gradient as written (``MeshStore`` mode 0): say once
+    what that does to an optimiser -- the scenes ``scene_from_config`` builds use the consistent vector"""
+    meshes = getattr(scene, "meshes", None) if scene is not None else None
+    if meshes is not None and getattr(meshes, "gradient_mode", 1) == 0 and not getattr(warn_if_reference_mesh_gradient, "_said", False):
+        import warnings
+
+        warn_if_reference_mesh_gradient._said = True
+        warnings.warn(f"{who}: the scene's mesh store returns the reference's mesh gradient as written (gradient_mode 0): for a sphere "
+                      "outside a mesh it points away from what the cuboid and voxel queries return, and optimisers are held inside meshes "
+                      "by it.  Build the store with MeshStore(..., gradient_mode=MeshStore.CONSISTENT_GRADIENT) (what scene_from_config "
+                      "does) unless reproducing data_mesh.py:693-697 is the point.", stacklevel=3)
+
+
 def validate_env_query_idx(env_query_idx, scene: Optional["SceneData"], kin_num_envs: int = 1) -> None:
     """Reject environment indices the kernels would read out of bounds: every entry must address one of
     the scene's environments and, when the robot carries per-environment collision spheres

@@ -79,6 +79,9 @@ class IKSolver:
         ``global_num_seeds`` when the seed axis is sharded over ranks (default: all of them; ``IKSolver.sharded``
         derives the shard of this rank from ``torch.distributed``)."""
         self.kin, self.scene, self.cfg = kin, scene, cfg or IKSolverCfg()
+        from ..scene.data import warn_if_reference_mesh_gradient
+
+        warn_if_reference_mesh_gradient(scene, "IKSolver")
         self._use_graph, self._result_graphs = use_cuda_graph, {}
         self.P, self.S = num_problems, self.cfg.num_seeds
         self.device = kin.device

@@ -100,6 +100,9 @@ class MPCSolverResult:
 class MPCSolver:
     def __init__(self, kin: KinematicsParams, scene: Optional[SceneData], num_robots: int = 1, cfg: Optional[MPCSolverCfg] = None):
         self.kin, self.scene, self.B = kin, scene, num_robots
+        from ..scene.data import warn_if_reference_mesh_gradient
+
+        warn_if_reference_mesh_gradient(scene, "MPCSolver")
         self.cfg = cfg or MPCSolverCfg()
         c = self.cfg
         self.device = kin.device

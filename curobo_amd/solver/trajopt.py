@@ -125,6 +125,9 @@ class TrajOptSolver:
         """``cfg.num_seeds`` seeds per problem run in this process: seeds ``[seed_offset, seed_offset + num_seeds)`` of
         ``global_num_seeds`` when the seed axis is sharded over ranks (``TrajOptSolver.sharded``)."""
         self.kin, self.scene, self.cfg = kin, scene, cfg or TrajOptSolverCfg()
+        from ..scene.data import warn_if_reference_mesh_gradient
+
+        warn_if_reference_mesh_gradient(scene, "TrajOptSolver")
         self.P, self.S, self.device = num_problems, self.cfg.num_seeds, kin.device
         self.seed_offset = int(seed_offset)
         self.S_global = int(global_num_seeds) if global_num_seeds is not None else self.S

@@ -292,3 +292,29 @@ def test_mppi_reference_tasks_are_the_reference_files(task, path):
     sp = o["sample_params"]
     assert tuple(float(v) for v in sp["filter_coeffs"]) == c.filter_coeffs and sp["fixed_samples"] == c.fixed_samples
     assert {k: float(v) for k, v in sp["sample_ratio"].items() if float(v) > 0} == c.sample_ratio
+
+
+def test_solvers_say_once_what_the_reference_mesh_gradient_does():
+    """a solver over a hand-built mesh store in the reference's gradient mode warns (once per process); a store in the consistent
+    mode -- what ``scene_from_config`` builds -- does not"""
+    import warnings
+
+    from curobo_amd.scene import data as D
+
+    class Store:
+        def __init__(self, mode):
+            self.gradient_mode = mode
+
+    class Scene:
+        def __init__(self, mode):
+            self.meshes = Store(mode)
+
+    D.warn_if_reference_mesh_gradient._said = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        D.warn_if_reference_mesh_gradient(None, "TrajOptSolver")
+        D.warn_if_reference_mesh_gradient(Scene(1), "TrajOptSolver")
+        assert len(w) == 0
+        D.warn_if_reference_mesh_gradient(Scene(0), "TrajOptSolver")
+        D.warn_if_reference_mesh_gradient(Scene(0), "IKSolver")
+        assert len(w) == 1 and "gradient_mode 0" in str(w[0].message) and "CONSISTENT_GRADIENT" in str(w[0].message)
