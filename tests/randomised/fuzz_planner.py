@@ -1,7 +1,11 @@
 """End to end on random worlds: TrajOptSolver.solve_pose (IK -> trajectory optimisation -> finetune -> retime) for feasible random
 goals; every reported SUCCESS is verified with the oracle (starts at the start, reaches the pose, inside the joint limits, free
 of self and scene collision over the horizon), no result may be non-finite, and the success rate is reported.
-    python tests/randomised/fuzz_planner.py [worlds] [seed]"""
+    python tests/randomised/fuzz_planner.py [worlds] [seed] [--mesh]
+
+--mesh (end of round 6): every obstacle but the table is given as a triangle mesh (a box of 12 x 4^k triangles, a ball, a torus) in
+a store with the sign-consistent gradient -- what ``scene_from_config`` builds -- and the successes are verified against the
+oracle's brute force over every triangle."""
 import os
 import sys
 
@@ -21,6 +25,8 @@ from oracle.oracle import Oracle  # noqa: E402
 
 dev = torch.device("cuda:0")
 oracle = Oracle()
+MESH = "--mesh" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--mesh"]
 n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 model = load_model("franka")
@@ -40,6 +46,24 @@ for wi in range(n_worlds):
                       "pose": [float(r * np.cos(a)), float(r * np.sin(a)), float(rng.uniform(0.1, 0.8))] + [float(v) for v in q]})
     arrays = cuboid_scene_arrays([world])
     scene = SceneData.from_arrays(arrays, dev)
+    if MESH:
+        from test_oracle_mesh import box_shape, sphere_shape, torus_shape
+
+        from curobo_amd.scene import MeshStore
+        from oracle.oracle import mesh_scene_arrays
+
+        meshes = []
+        for i, o in enumerate(world[1:]):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                v, f = box_shape(o["dims"], int(rng.integers(0, 3)))
+            elif kind == 1:
+                v, f = sphere_shape(0.5 * float(max(o["dims"])), 12, 24)
+            else:
+                v, f = torus_shape(0.5 * float(max(o["dims"])) + 0.05, 0.03, 24, 12)
+            meshes.append({"name": f"m{i}", "vertices": v, "faces": f, "pose": o["pose"]})
+        arrays = {**cuboid_scene_arrays([world[:1]]), **mesh_scene_arrays([meshes])}
+        scene = SceneData.from_arrays(cuboid_scene_arrays([world[:1]]), dev, meshes=MeshStore([meshes], dev, gradient_mode=MeshStore.CONSISTENT_GRADIENT))
     try:
         gp, gq = feasible_goals(kin, scene, P)
         solver = TrajOptSolver(kin, scene, P, TrajOptSolverCfg(num_seeds=4))
@@ -61,7 +85,7 @@ for wi in range(n_worlds):
             s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
             assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all(), "self collision on a success"
             assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all(), "scene collision on a success"
-        print(f"world {wi}: {len(world)} cuboids, IK success {float(res.ik_success.float().mean()):.2f}, trajopt success {succ.mean():.2f}, passes {res.finetune_passes}", flush=True)
+        print(f"world {wi}: {len(world)} {'obstacles (meshes but the table)' if MESH else 'cuboids'}, IK success {float(res.ik_success.float().mean()):.2f}, trajopt success {succ.mean():.2f}, passes {res.finetune_passes}", flush=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print(f"FAILED world {wi}: {type(e).__name__}: {str(e)[:400]}".replace("\n", " | "))
