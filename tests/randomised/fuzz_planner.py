@@ -85,7 +85,9 @@ for wi in range(n_worlds):
             s2 = chk["robot_spheres"].reshape(n, H, -1, 4)
             assert (oracle.self_collision(s2, model.sphere_padding, model.collision_pairs, 1.0)["distance"] == 0).all(), "self collision on a success"
             assert (oracle.scene_collision(s2, arrays, 1.0, 0.0)["distance"].sum((1, 2)) == 0).all(), "scene collision on a success"
-        print(f"world {wi}: {len(world)} {'obstacles (meshes but the table)' if MESH else 'cuboids'}, IK success {float(res.ik_success.float().mean()):.2f}, trajopt success {succ.mean():.2f}, passes {res.finetune_passes}", flush=True)
+        s0 = oracle.kinematics_forward(np.asarray(start, np.float32)[None], md)["robot_spheres"].reshape(1, 1, -1, 4)
+        start_pen = float(oracle.scene_collision(s0, arrays, 1.0, 0.0)["distance"].sum())
+        print(f"world {wi}: {len(world)} {'obstacles (meshes but the table)' if MESH else 'cuboids'}{', START IN COLLISION' if start_pen > 0 else ''}, IK success {float(res.ik_success.float().mean()):.2f}, trajopt success {succ.mean():.2f}, passes {res.finetune_passes}", flush=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print(f"FAILED world {wi}: {type(e).__name__}: {str(e)[:400]}".replace("\n", " | "))
