@@ -181,3 +181,44 @@ def _():
     arrays = {**cuboid_scene_arrays([[table]]), **mesh_scene_arrays([[{"name": "ball", "vertices": vs, "faces": fs, "pose": [0.6, 0.0, 0.5, 1, 0, 0, 0]}]])}
     print("   success", ok, "oracle collision", None if res is None else float(free(model, res.js_solution.position[0].cpu().numpy(), arrays)[0]))
     assert ok
+
+
+@scenario("mixed scenes per problem")
+def _():
+    from curobo_amd.scene import voxel_grid_from_sdf
+    from curobo_amd.scene.config import voxel_arrays_from_config
+
+    B = 4
+    centre, half = np.array([0.5, 0.0, 0.35]), np.array([0.08, 0.08, 0.35])
+
+    def pillar(p):
+        q = np.abs(p - centre) - half
+        return np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0)
+
+    gpose = [0.5, 0.0, 0.45, 1, 0, 0, 0]
+    grid = voxel_grid_from_sdf(pillar, (32, 32, 48), 0.02, pose7=gpose, max_distance=10.0)
+    vox = {"pillar": {"dims": [0.64, 0.64, 0.96], "voxel_size": 0.02, "pose": gpose, "feature_tensor": grid["voxel_features"].reshape(-1)}}
+    ball = {"ball": {"vertices": vs, "faces": fs, "pose": [0.0, 0.55, 0.9, 1, 0, 0, 0]}}
+    worlds = []
+    for i in range(B):  # pillar as a voxel grid (0, 2) or as a mesh (1, 3); a ball mesh above in every world
+        w = {"cuboid": {"table": table}, "mesh": dict(ball)}
+        if i % 2 == 0:
+            w["voxel"] = vox
+        else:
+            w["mesh"]["pillar"] = {"vertices": vb, "faces": fb, "pose": pillar_pose}
+        worlds.append(w)
+    config = MotionPlannerCfg.create(robot="franka.yml", scene_model=worlds, max_batch_size=B, multi_env=True, num_ik_seeds=32, num_trajopt_seeds=4)
+    planner = BatchMotionPlanner(config)
+    model = config.trajopt_solver_config.kinematics.model
+    cur, gjs, goal = start_goal(planner, B, 0.1)
+    res = planner.plan_pose(goal, cur, max_attempts=4)
+    succ = res.success[:, 0].cpu().numpy()
+    # oracle: every world on its own (the kinds differ per world)
+    d = []
+    for i in range(B):
+        arrays = {**cuboid_scene_arrays([[table]]), **mesh_scene_arrays([[dict(m, name=k) for k, m in worlds[i]["mesh"].items()]])}
+        if "voxel" in worlds[i]:
+            arrays.update(voxel_arrays_from_config(worlds[i]))
+        d.append(float(free(model, res.js_solution.position[i:i + 1, 0].cpu().numpy(), arrays)[0]))
+    print("   success", succ.tolist(), "oracle collision per problem in ITS world", d, "motion time", res.motion_time[:, 0].cpu().numpy().round(3).tolist())
+    assert succ.sum() >= 3 and all(x == 0.0 for x, ok in zip(d, succ) if ok)
