@@ -306,7 +306,10 @@ int curobo_hip_sphere_mesh_collision(
  * aligned, contents irrelevant; the size is written to the HOST pointer out_bytes_host): the spheres that survive the bounding-box reject of any mesh -- few, and clustered in the
  * batch -- are queued launch-wide and their tree walks run on a grid that covers the chip once, instead of inside the
  * workgroups that happen to hold them.  Same results (per sphere the slots are summed in ascending order in both forms);
- * two kernels + one 16-byte memset on `stream`, graph-capturable. */
+ * kernels only on `stream` (since the end of round 6 the queue counters -- the first 16 bytes: spheres queued from the head,
+ * handed to the tree walk, queued from the tail, handed to a workgroup of their own -- are cleared by a kernel: a captured
+ * 16-byte memset node faulted at the second replay of its graph), graph-capturable: counter reset, select, and with cell lists
+ * the cell-list kernel, the workgroup-per-sphere kernel and the tree walk of what is left. */
 int curobo_hip_sphere_mesh_collision_ws_bytes(int batch_size, int horizon, int num_spheres, int64_t *out_bytes_host);
 int curobo_hip_sphere_mesh_collision_ws(
     float *distance, float *gradient, const float *spheres, const curobo_hip_mesh_set *meshes, const float *weight,
